@@ -1,0 +1,75 @@
+// Shared device helpers for the espnet_amd HIP kernels (gfx950 / MI355X only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#define EAMD_OK 0
+#define EAMD_EINVAL (-1)
+#define EAMD_EUNSUPPORTED (-2)
+
+#define EAMD_WAVE 64
+
+#define EAMD_LAUNCH_CHECK()                      \
+  do {                                           \
+    hipError_t e__ = hipGetLastError();          \
+    if (e__ != hipSuccess) return (int)e__;      \
+  } while (0)
+
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+typedef __attribute__((ext_vector_type(8))) short bf16x8;
+typedef __attribute__((ext_vector_type(4))) short bf16x4;
+
+// activation ids shared by host and device
+enum { EAMD_ACT_NONE = 0, EAMD_ACT_RELU = 1, EAMD_ACT_SWISH = 2 };
+
+__device__ __forceinline__ float eamd_sigmoid(float x) { return 1.0f / (1.0f + __expf(-x)); }
+__device__ __forceinline__ float eamd_swish(float x) { return x * eamd_sigmoid(x); }
+// d/dx [x*sigmoid(x)] = s + x*s*(1-s)
+__device__ __forceinline__ float eamd_dswish(float x) {
+  float s = eamd_sigmoid(x);
+  return s * (1.0f + x * (1.0f - s));
+}
+__device__ __forceinline__ float eamd_act(float x, int act) {
+  if (act == EAMD_ACT_RELU) return x > 0.f ? x : 0.f;
+  if (act == EAMD_ACT_SWISH) return eamd_swish(x);
+  return x;
+}
+
+// fp32 -> bf16 round-to-nearest-even (plain cast keeps NaN a NaN on gfx950).
+__device__ __forceinline__ unsigned short eamd_f2bf(float f) {
+  __bf16 b = (__bf16)f;
+  return __builtin_bit_cast(unsigned short, b);
+}
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+  return v;
+}
+
+// Block-wide reductions for blockDim.x <= 1024 (multiple of 64). `red` is >= 16 floats of LDS.
+__device__ __forceinline__ float block_sum(float v, float* red) {
+  v = wave_sum(v);
+  const int w = threadIdx.x >> 6, l = threadIdx.x & 63, nw = (blockDim.x + 63) >> 6;
+  __syncthreads();
+  if (l == 0) red[w] = v;
+  __syncthreads();
+  float r = 0.f;
+  for (int i = 0; i < nw; ++i) r += red[i];
+  return r;
+}
+__device__ __forceinline__ float block_max(float v, float* red) {
+  v = wave_max(v);
+  const int w = threadIdx.x >> 6, l = threadIdx.x & 63, nw = (blockDim.x + 63) >> 6;
+  __syncthreads();
+  if (l == 0) red[w] = v;
+  __syncthreads();
+  float r = red[0];
+  for (int i = 1; i < nw; ++i) r = fmaxf(r, red[i]);
+  return r;
+}

@@ -1,0 +1,233 @@
+// CTC loss forward + gradient for gfx950.
+// Replaces warp-ctc (tools/installers/install_warp-ctc.sh; call sites ctc.py:40-43,62-63) and
+// torch.nn.CTCLoss(reduction="sum")/B (ctc.py:37-39,53-61; espnet2/asr/ctc.py:32-52): takes raw
+// activations, returns sum_b(-log p(y_b|x_b)) per utterance and d(loss)/d(activations).
+//
+// Four launches, no host synchronisation:
+//   prep       : compact padded labels (ignore_id removed) -> extended label table
+//   lse_gather : one 256-thread block per (t,b) row: log-sum-exp over V (the only pass that reads the
+//                whole 159 MB logits), then gathers the <=2L+1 label log-probs into a compact lattice
+//   alpha_beta : one block per (b, direction): wavefront scan over T in log space, states across
+//                lanes, previous column exchanged through LDS (double buffered, 1 barrier per frame)
+//   grad       : one block per (t,b): softmax row minus per-label occupancies accumulated in LDS
+#include "common.h"
+#include "../../include/espnet_amd.h"
+
+namespace {
+
+__device__ __forceinline__ float lse2(float a, float b) {
+  float m = fmaxf(a, b);
+  if (m == -INFINITY) return -INFINITY;
+  return m + logf(expf(a - m) + expf(b - m));
+}
+__device__ __forceinline__ float lse3(float a, float b, float c) {
+  float m = fmaxf(fmaxf(a, b), c);
+  if (m == -INFINITY) return -INFINITY;
+  return m + logf(expf(a - m) + expf(b - m) + expf(c - m));
+}
+
+__global__ void ctc_prep_kernel(const long long* __restrict__ ys, int Lmax, int ignore_id, int* __restrict__ lab,
+                                int* __restrict__ lablen, int B) {
+  const int b = blockIdx.x * blockDim.x + threadIdx.x;
+  if (b >= B) return;
+  int n = 0;
+  for (int i = 0; i < Lmax; ++i) {
+    long long y = ys[(long)b * Lmax + i];
+    if (y != ignore_id) lab[(long)b * Lmax + n++] = (int)y;
+  }
+  lablen[b] = n;
+}
+
+__global__ __launch_bounds__(256) void ctc_lse_gather_kernel(const float* __restrict__ x, long st, long sb,
+                                                             const int* __restrict__ ilen,
+                                                             const int* __restrict__ lab,
+                                                             const int* __restrict__ lablen, int Lmax,
+                                                             float* __restrict__ lse_out, float* __restrict__ lp,
+                                                             int T, int V, int Smax, int blank) {
+  __shared__ float red[16];
+  const int t = blockIdx.x, b = blockIdx.y;
+  if (t >= ilen[b]) return;
+  const float* xr = x + t * st + b * sb;
+  float mx = -INFINITY;
+  for (int v = threadIdx.x; v < V; v += blockDim.x) mx = fmaxf(mx, xr[v]);
+  mx = block_max(mx, red);
+  float se = 0.f;
+  for (int v = threadIdx.x; v < V; v += blockDim.x) se += expf(xr[v] - mx);
+  se = block_sum(se, red);
+  const float lse = mx + logf(se);
+  if (threadIdx.x == 0) lse_out[(long)b * T + t] = lse;
+  const int S = 2 * lablen[b] + 1;
+  float* lpr = lp + ((long)b * T + t) * Smax;
+  for (int s = threadIdx.x; s < S; s += blockDim.x) {
+    int l = (s & 1) ? lab[(long)b * Lmax + (s >> 1)] : blank;
+    lpr[s] = xr[l] - lse;
+  }
+}
+
+// blockIdx.y == 0: alpha (forward), == 1: beta (backward, includes the emission at t)
+__global__ __launch_bounds__(1024) void ctc_alpha_beta_kernel(const float* __restrict__ lp,
+                                                              const int* __restrict__ ilen,
+                                                              const int* __restrict__ lab,
+                                                              const int* __restrict__ lablen, int Lmax,
+                                                              float* __restrict__ alpha, float* __restrict__ beta,
+                                                              float* __restrict__ nll, int T, int Smax, int blank) {
+  extern __shared__ float sh[];  // [2][Smax + 4]
+  const int b = blockIdx.x;
+  const int dir = blockIdx.y;
+  const int s = threadIdx.x;
+  const int Tb = ilen[b];
+  const int L = lablen[b];
+  const int S = 2 * L + 1;
+  const int W = Smax + 4;
+  float* buf0 = sh;
+  float* buf1 = sh + W;
+  // pads: indices [0,1] and [S+2, S+3] hold -inf so s-1, s-2, s+1, s+2 never need bounds checks
+  for (int i = threadIdx.x; i < 2 * W; i += blockDim.x) sh[i] = -INFINITY;
+  __syncthreads();
+  if (Tb <= 0) {
+    if (dir == 0 && s == 0) nll[b] = (L == 0) ? 0.f : INFINITY;
+    return;
+  }
+  const bool active = s < S;
+  const int my = active ? ((s & 1) ? lab[(long)b * Lmax + (s >> 1)] : blank) : blank;
+  bool skip = false;  // may take the s-2 (alpha) / s+2 (beta) transition
+  if (active && (s & 1)) {
+    if (dir == 0) skip = (s >= 2) && (lab[(long)b * Lmax + ((s - 2) >> 1)] != my);
+    else          skip = (s + 2 < S) && (lab[(long)b * Lmax + ((s + 2) >> 1)] != my);
+  }
+  const float* lpb = lp + (long)b * T * Smax;
+  float* out = (dir == 0 ? alpha : beta) + (long)b * T * Smax;
+
+  if (dir == 0) {
+    float cur = -INFINITY;
+    if (active && s < 2) cur = lpb[s];
+    if (active) { buf0[s + 2] = cur; out[s] = cur; }
+    __syncthreads();
+    float* prev = buf0; float* next = buf1;
+    float e = (active && Tb > 1) ? lpb[(long)Smax + s] : 0.f;
+    for (int t = 1; t < Tb; ++t) {
+      float e_next = (active && t + 1 < Tb) ? lpb[(long)(t + 1) * Smax + s] : 0.f;
+      if (active) {
+        float a = lse3(prev[s + 2], prev[s + 1], skip ? prev[s] : -INFINITY) + e;
+        next[s + 2] = a;
+        out[(long)t * Smax + s] = a;
+      }
+      __syncthreads();
+      float* tmp = prev; prev = next; next = tmp;
+      e = e_next;
+    }
+    if (s == 0) {
+      float a1 = prev[S - 1 + 2];
+      float a2 = S >= 2 ? prev[S - 2 + 2] : -INFINITY;
+      nll[b] = -lse2(a1, a2);
+    }
+  } else {
+    float cur = -INFINITY;
+    if (active && s >= S - 2) cur = lpb[(long)(Tb - 1) * Smax + s];
+    if (active) { buf0[s + 2] = cur; out[(long)(Tb - 1) * Smax + s] = cur; }
+    __syncthreads();
+    float* prev = buf0; float* next = buf1;
+    float e = (active && Tb > 1) ? lpb[(long)(Tb - 2) * Smax + s] : 0.f;
+    for (int t = Tb - 2; t >= 0; --t) {
+      float e_next = (active && t - 1 >= 0) ? lpb[(long)(t - 1) * Smax + s] : 0.f;
+      if (active) {
+        float a = lse3(prev[s + 2], prev[s + 3], skip ? prev[s + 4] : -INFINITY) + e;
+        next[s + 2] = a;
+        out[(long)t * Smax + s] = a;
+      }
+      __syncthreads();
+      float* tmp = prev; prev = next; next = tmp;
+      e = e_next;
+    }
+  }
+}
+
+__global__ __launch_bounds__(256) void ctc_grad_kernel(const float* __restrict__ x, long st, long sb,
+                                                       const int* __restrict__ ilen, const int* __restrict__ lab,
+                                                       const int* __restrict__ lablen, int Lmax,
+                                                       const float* __restrict__ lse, const float* __restrict__ lp,
+                                                       const float* __restrict__ alpha,
+                                                       const float* __restrict__ beta, const float* __restrict__ nll,
+                                                       float* __restrict__ grad, long gst, long gsb, int T, int V,
+                                                       int Smax, int blank, float scale) {
+  extern __shared__ float occ[];  // [V]
+  const int t = blockIdx.x, b = blockIdx.y;
+  float* gr = grad + t * gst + b * gsb;
+  if (t >= ilen[b]) {
+    for (int v = threadIdx.x; v < V; v += blockDim.x) gr[v] = 0.f;
+    return;
+  }
+  for (int v = threadIdx.x; v < V; v += blockDim.x) occ[v] = 0.f;
+  __syncthreads();
+  const int S = 2 * lablen[b] + 1;
+  const long base = ((long)b * T + t) * Smax;
+  const float nl = nll[b];
+  for (int s = threadIdx.x; s < S; s += blockDim.x) {
+    int l = (s & 1) ? lab[(long)b * Lmax + (s >> 1)] : blank;
+    float g = expf(alpha[base + s] + beta[base + s] - lp[base + s] + nl);
+    atomicAdd(&occ[l], g);
+  }
+  __syncthreads();
+  const float* xr = x + t * st + b * sb;
+  const float ls = lse[(long)b * T + t];
+  for (int v = threadIdx.x; v < V; v += blockDim.x) gr[v] = (expf(xr[v] - ls) - occ[v]) * scale;
+}
+
+}  // namespace
+
+extern "C" {
+
+/* workspace bytes needed by eamd_ctc_loss */
+int64_t eamd_ctc_workspace_bytes(int B, int T, int Lmax) {
+  int64_t Smax = 2 * (int64_t)Lmax + 1;
+  int64_t n = (int64_t)B * Lmax * 4 + (int64_t)B * 4      /* lab, lablen */
+              + (int64_t)B * T * 4                          /* lse */
+              + 3 * (int64_t)B * T * Smax * 4;              /* lp, alpha, beta */
+  return n + 256;
+}
+
+/*
+ * acts  : [T,B,V] or [B,T,V] fp32 via element strides (stride_t, stride_b); V contiguous
+ * ys_pad: [B,Lmax] int64 padded with ignore_id; ilens: [B] int32 valid frames
+ * nll   : [B] fp32 out (-log p per utterance, +inf if no valid alignment)
+ * grad  : optional, same strides convention (gstride_t, gstride_b); = scale * d(sum_b nll_b)/d acts
+ */
+int eamd_ctc_loss(const float* acts, int64_t stride_t, int64_t stride_b, const int64_t* ys_pad,
+                  const int32_t* ilens, float* nll, float* grad, int64_t gstride_t, int64_t gstride_b,
+                  void* workspace, int B, int T, int V, int Lmax, int blank, int ignore_id, float grad_scale,
+                  void* stream) {
+  if (!acts || !ys_pad || !ilens || !nll || !workspace || B <= 0 || T <= 0 || V <= 0 || Lmax < 0) return EAMD_EINVAL;
+  const int Smax = 2 * Lmax + 1;
+  int threads = ((Smax + 63) / 64) * 64;
+  if (threads > 1024) return EAMD_EUNSUPPORTED;
+  if (grad && (size_t)V * 4 > 64 * 1024) return EAMD_EUNSUPPORTED;
+  hipStream_t s = (hipStream_t)stream;
+  char* w = (char*)workspace;
+  int Lm = Lmax > 0 ? Lmax : 1;
+  int* lab = (int*)w; w += (size_t)B * Lm * 4;
+  int* lablen = (int*)w; w += (size_t)B * 4;
+  w = (char*)(((uintptr_t)w + 15) & ~(uintptr_t)15);
+  float* lse = (float*)w; w += (size_t)B * T * 4;
+  float* lp = (float*)w; w += (size_t)B * T * Smax * 4;
+  float* alpha = (float*)w; w += (size_t)B * T * Smax * 4;
+  float* beta = (float*)w;
+
+  hipLaunchKernelGGL(ctc_prep_kernel, dim3((B + 63) / 64), dim3(64), 0, s, (const long long*)ys_pad, Lmax, ignore_id,
+                     lab, lablen, B);
+  EAMD_LAUNCH_CHECK();
+  hipLaunchKernelGGL(ctc_lse_gather_kernel, dim3(T, B), dim3(256), 0, s, acts, (long)stride_t, (long)stride_b, ilens,
+                     lab, lablen, Lm, lse, lp, T, V, Smax, blank);
+  EAMD_LAUNCH_CHECK();
+  hipLaunchKernelGGL(ctc_alpha_beta_kernel, dim3(B, 2), dim3(threads), 2 * (Smax + 4) * sizeof(float), s, lp, ilens,
+                     lab, lablen, Lm, alpha, beta, nll, T, Smax, blank);
+  EAMD_LAUNCH_CHECK();
+  if (grad) {
+    hipLaunchKernelGGL(ctc_grad_kernel, dim3(T, B), dim3(256), (size_t)V * sizeof(float), s, acts, (long)stride_t,
+                       (long)stride_b, ilens, lab, lablen, Lm, lse, lp, alpha, beta, nll, grad, (long)gstride_t,
+                       (long)gstride_b, T, V, Smax, blank, grad_scale);
+    EAMD_LAUNCH_CHECK();
+  }
+  return EAMD_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,299 @@
+// Element-wise / small reduction kernels (HBM-bound, float4-vectorised, grid-stride capped at
+// 2048 blocks): GLU, Swish, bias broadcasts, axpby, column sums, embedding + positional encoding,
+// weight-layout permutations for the implicit-GEMM convolutions, dropout.
+#include "common.h"
+#include "../../include/espnet_amd.h"
+
+namespace {
+
+inline int grid_for(long n_threads_needed) {
+  long b = (n_threads_needed + 255) / 256;
+  if (b < 1) b = 1;
+  if (b > 2048) b = 2048;
+  return (int)b;
+}
+
+// out = a*x + b*y (y optional)
+__global__ void axpby_kernel(const float* __restrict__ x, const float* __restrict__ y, float* __restrict__ out,
+                             long n, long n4, float a, float b) {
+  const long stride = (long)gridDim.x * blockDim.x;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += stride) {
+    float4 xv = reinterpret_cast<const float4*>(x)[i], o;
+    if (y) {
+      float4 yv = reinterpret_cast<const float4*>(y)[i];
+      o.x = a * xv.x + b * yv.x; o.y = a * xv.y + b * yv.y; o.z = a * xv.z + b * yv.z; o.w = a * xv.w + b * yv.w;
+    } else {
+      o.x = a * xv.x; o.y = a * xv.y; o.z = a * xv.z; o.w = a * xv.w;
+    }
+    reinterpret_cast<float4*>(out)[i] = o;
+  }
+  for (long i = n4 * 4 + (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride)
+    out[i] = a * x[i] + (y ? b * y[i] : 0.f);
+}
+
+// out = scale_dev[0] * x  (scale read from device memory: keeps upstream loss scaling sync-free)
+__global__ void scale_dev_kernel(const float* __restrict__ x, const float* __restrict__ scale_dev,
+                                 float* __restrict__ out, long n, float extra) {
+  const float s = scale_dev[0] * extra;
+  const long stride = (long)gridDim.x * blockDim.x;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) out[i] = s * x[i];
+}
+
+// Activation forward / backward on flat arrays.
+__global__ void act_fwd_kernel(const float* __restrict__ x, float* __restrict__ y, long n, int act) {
+  const long stride = (long)gridDim.x * blockDim.x;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) y[i] = eamd_act(x[i], act);
+}
+__global__ void act_bwd_kernel(const float* __restrict__ dy, const float* __restrict__ x, float* __restrict__ dx,
+                               long n, int act) {
+  const long stride = (long)gridDim.x * blockDim.x;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+    float g = dy[i];
+    if (act == EAMD_ACT_RELU) g = x[i] > 0.f ? g : 0.f;
+    else if (act == EAMD_ACT_SWISH) g *= eamd_dswish(x[i]);
+    dx[i] = g;
+  }
+}
+
+// GLU over the channel dim of a [rows, 2C] matrix: y[r,c] = x[r,c] * sigmoid(x[r,C+c]).
+// reference: conformer/convolution.py:72 (glu(dim=1) on (B,2C,T) == per-row halves in (B,T,2C)).
+__global__ void glu_fwd_kernel(const float* __restrict__ x, float* __restrict__ y, long rows, int C) {
+  const long n = rows * C;
+  const long stride = (long)gridDim.x * blockDim.x;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+    long r = i / C; int c = i % C;
+    float a = x[r * 2 * C + c], g = x[r * 2 * C + C + c];
+    y[i] = a * eamd_sigmoid(g);
+  }
+}
+__global__ void glu_bwd_kernel(const float* __restrict__ dy, const float* __restrict__ x, float* __restrict__ dx,
+                               long rows, int C) {
+  const long n = rows * C;
+  const long stride = (long)gridDim.x * blockDim.x;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+    long r = i / C; int c = i % C;
+    float a = x[r * 2 * C + c], g = x[r * 2 * C + C + c];
+    float s = eamd_sigmoid(g), d = dy[i];
+    dx[r * 2 * C + c] = d * s;
+    dx[r * 2 * C + C + c] = d * a * s * (1.f - s);
+  }
+}
+
+// qu = q + u, qv = q + v with u,v broadcast over rows ([D] each).
+// reference: transformer/attention.py:186-190 (q_with_bias_u / q_with_bias_v).
+__global__ void add_bias2_kernel(const float* __restrict__ q, const float* __restrict__ u,
+                                 const float* __restrict__ v, float* __restrict__ qu, float* __restrict__ qv,
+                                 long rows, int D) {
+  const long n = rows * D;
+  const long stride = (long)gridDim.x * blockDim.x;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+    int d = i % D;
+    float x = q[i];
+    qu[i] = x + u[d];
+    qv[i] = x + v[d];
+  }
+}
+
+// Column sums of a [rows, D] matrix, ADDED into out[D] (bias gradients).  Each block reduces a slab
+// of rows with threads along columns (coalesced) and issues one atomic per column.
+__global__ __launch_bounds__(256) void colsum_kernel(const float* __restrict__ x, long ld, float* __restrict__ out,
+                                                     long rows, int D, int rows_per_block, float scale) {
+  const long r0 = (long)blockIdx.y * rows_per_block;
+  const long r1 = min(rows, r0 + (long)rows_per_block);
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= D) return;
+  float s = 0.f;
+  for (long r = r0; r < r1; ++r) s += x[r * ld + c];
+  atomicAdd(&out[c], s * scale);
+}
+
+// Embedding lookup * scale + absolute positional encoding.
+// reference: decoder.py:251 (embed = Embedding + PositionalEncoding), embedding.py:80-91.
+__global__ void embed_pe_kernel(const long long* __restrict__ tok, const float* __restrict__ table,
+                                const float* __restrict__ pe, float* __restrict__ out, long rows, int U, int D,
+                                float scale, int pos_offset) {
+  const long n = rows * D;
+  const long stride = (long)gridDim.x * blockDim.x;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+    long r = i / D; int d = i % D;
+    long id = tok[r];
+    int pos = (int)(r % U) + pos_offset;
+    out[i] = table[id * D + d] * scale + pe[(long)pos * D + d];
+  }
+}
+__global__ void embed_bwd_kernel(const long long* __restrict__ tok, const float* __restrict__ dout,
+                                 float* __restrict__ dtable, long rows, int D, float scale) {
+  const long n = rows * D;
+  const long stride = (long)gridDim.x * blockDim.x;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+    long r = i / D; int d = i % D;
+    atomicAdd(&dtable[tok[r] * D + d], dout[i] * scale);
+  }
+}
+
+// x*scale + pe[t] for [B, T, D] (absolute positional encoding on float inputs).
+__global__ void posenc_kernel(const float* __restrict__ x, const float* __restrict__ pe, float* __restrict__ out,
+                              long rows, int T, int D, float scale) {
+  const long n = rows * D;
+  const long stride = (long)gridDim.x * blockDim.x;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+    long r = i / D; int d = i % D;
+    out[i] = x[i] * scale + pe[(r % T) * D + d];
+  }
+}
+
+// Generic 4-D permutation copy with optional accumulate: dst[perm(idx)] (+)= src[idx].
+// Used for conv weight layouts: Conv2d weight [Co][Ci][kh][kw] <-> tap-major GEMM operands.
+__global__ void permute4_kernel(const float* __restrict__ src, float* __restrict__ dst, int d0, int d1, int d2,
+                                int d3, long s0, long s1, long s2, long s3, int accumulate) {
+  const long n = (long)d0 * d1 * d2 * d3;
+  const long stride = (long)gridDim.x * blockDim.x;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+    int i3 = i % d3; long t = i / d3;
+    int i2 = t % d2; t /= d2;
+    int i1 = t % d1; int i0 = t / d1;
+    long o = i0 * s0 + i1 * s1 + i2 * s2 + i3 * s3;
+    if (accumulate) dst[o] += src[i]; else dst[o] = src[i];
+  }
+}
+
+// Counter-based dropout (one Philox-like hash per element).  Keeps y = x * keep / (1-p).
+// reference: torch.nn.Dropout call sites (encoder_layer.py:55, attention.py:38, embedding.py:56);
+// streams cannot match torch's generator, parity runs use p = 0 (SURVEY.md §7 "Dropout").
+__device__ __forceinline__ unsigned hash32(unsigned long long x) {
+  x ^= x >> 33; x *= 0xff51afd7ed558ccdULL; x ^= x >> 33; x *= 0xc4ceb9fe1a85ec53ULL; x ^= x >> 33;
+  return (unsigned)x;
+}
+__global__ void dropout_kernel(const float* __restrict__ x, float* __restrict__ y, long n, float p,
+                               unsigned long long seed) {
+  const float inv = 1.f / (1.f - p);
+  const unsigned thr = (unsigned)(p * 4294967296.0);
+  const long stride = (long)gridDim.x * blockDim.x;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+    unsigned h = hash32(seed * 0x9E3779B97F4A7C15ULL + (unsigned long long)i);
+    y[i] = h >= thr ? x[i] * inv : 0.f;
+  }
+}
+
+}  // namespace
+
+extern "C" {
+
+int eamd_axpby(const float* x, const float* y, float* out, int64_t n, float a, float b, void* stream) {
+  if (!x || !out || n < 0) return EAMD_EINVAL;
+  if (n == 0) return EAMD_OK;
+  const bool vec = ((((uintptr_t)x | (uintptr_t)out | (uintptr_t)y) & 15) == 0);
+  hipLaunchKernelGGL(axpby_kernel, dim3(grid_for(vec ? n / 4 + 1 : n)), dim3(256), 0, (hipStream_t)stream, x, y,
+                     out, (long)n, vec ? (long)(n / 4) : 0L, a, b);
+  EAMD_LAUNCH_CHECK();
+  return EAMD_OK;
+}
+
+int eamd_scale_dev(const float* x, const float* scale_dev, float* out, int64_t n, float extra, void* stream) {
+  if (!x || !out || !scale_dev || n < 0) return EAMD_EINVAL;
+  if (n == 0) return EAMD_OK;
+  hipLaunchKernelGGL(scale_dev_kernel, dim3(grid_for(n)), dim3(256), 0, (hipStream_t)stream, x, scale_dev, out,
+                     (long)n, extra);
+  EAMD_LAUNCH_CHECK();
+  return EAMD_OK;
+}
+
+int eamd_act_fwd(const float* x, float* y, int64_t n, int act, void* stream) {
+  if (!x || !y || n < 0) return EAMD_EINVAL;
+  if (n == 0) return EAMD_OK;
+  hipLaunchKernelGGL(act_fwd_kernel, dim3(grid_for(n)), dim3(256), 0, (hipStream_t)stream, x, y, (long)n, act);
+  EAMD_LAUNCH_CHECK();
+  return EAMD_OK;
+}
+
+int eamd_act_bwd(const float* dy, const float* x, float* dx, int64_t n, int act, void* stream) {
+  if (!dy || !x || !dx || n < 0) return EAMD_EINVAL;
+  if (n == 0) return EAMD_OK;
+  hipLaunchKernelGGL(act_bwd_kernel, dim3(grid_for(n)), dim3(256), 0, (hipStream_t)stream, dy, x, dx, (long)n, act);
+  EAMD_LAUNCH_CHECK();
+  return EAMD_OK;
+}
+
+int eamd_glu_fwd(const float* x, float* y, int64_t rows, int C, void* stream) {
+  if (!x || !y || rows <= 0 || C <= 0) return EAMD_EINVAL;
+  hipLaunchKernelGGL(glu_fwd_kernel, dim3(grid_for(rows * C)), dim3(256), 0, (hipStream_t)stream, x, y, (long)rows, C);
+  EAMD_LAUNCH_CHECK();
+  return EAMD_OK;
+}
+
+int eamd_glu_bwd(const float* dy, const float* x, float* dx, int64_t rows, int C, void* stream) {
+  if (!dy || !x || !dx || rows <= 0 || C <= 0) return EAMD_EINVAL;
+  hipLaunchKernelGGL(glu_bwd_kernel, dim3(grid_for(rows * C)), dim3(256), 0, (hipStream_t)stream, dy, x, dx,
+                     (long)rows, C);
+  EAMD_LAUNCH_CHECK();
+  return EAMD_OK;
+}
+
+int eamd_add_bias2(const float* q, const float* u, const float* v, float* qu, float* qv, int64_t rows, int D,
+                   void* stream) {
+  if (!q || !u || !v || !qu || !qv || rows <= 0 || D <= 0) return EAMD_EINVAL;
+  hipLaunchKernelGGL(add_bias2_kernel, dim3(grid_for(rows * D)), dim3(256), 0, (hipStream_t)stream, q, u, v, qu,
+                     qv, (long)rows, D);
+  EAMD_LAUNCH_CHECK();
+  return EAMD_OK;
+}
+
+int eamd_colsum(const float* x, int64_t ld, float* out, int64_t rows, int D, float scale, void* stream) {
+  if (!x || !out || rows <= 0 || D <= 0) return EAMD_EINVAL;
+  int gx = (D + 255) / 256;
+  long want = 1024 / gx; if (want < 1) want = 1;
+  long rpb = (rows + want - 1) / want; if (rpb < 32) rpb = 32;
+  int gy = (int)((rows + rpb - 1) / rpb);
+  hipLaunchKernelGGL(colsum_kernel, dim3(gx, gy), dim3(256), 0, (hipStream_t)stream, x, (long)ld, out, (long)rows,
+                     D, (int)rpb, scale);
+  EAMD_LAUNCH_CHECK();
+  return EAMD_OK;
+}
+
+int eamd_embed_pe(const int64_t* tok, const float* table, const float* pe, float* out, int64_t rows, int U,
+                  int D, float scale, int pos_offset, void* stream) {
+  if (!tok || !table || !pe || !out || rows <= 0 || U <= 0 || D <= 0) return EAMD_EINVAL;
+  hipLaunchKernelGGL(embed_pe_kernel, dim3(grid_for(rows * D)), dim3(256), 0, (hipStream_t)stream,
+                     (const long long*)tok, table, pe, out, (long)rows, U, D, scale, pos_offset);
+  EAMD_LAUNCH_CHECK();
+  return EAMD_OK;
+}
+
+int eamd_embed_bwd(const int64_t* tok, const float* dout, float* dtable, int64_t rows, int D, float scale,
+                   void* stream) {
+  if (!tok || !dout || !dtable || rows <= 0 || D <= 0) return EAMD_EINVAL;
+  hipLaunchKernelGGL(embed_bwd_kernel, dim3(grid_for(rows * D)), dim3(256), 0, (hipStream_t)stream,
+                     (const long long*)tok, dout, dtable, (long)rows, D, scale);
+  EAMD_LAUNCH_CHECK();
+  return EAMD_OK;
+}
+
+int eamd_posenc(const float* x, const float* pe, float* out, int64_t rows, int T, int D, float scale,
+                void* stream) {
+  if (!x || !pe || !out || rows <= 0 || T <= 0 || D <= 0) return EAMD_EINVAL;
+  hipLaunchKernelGGL(posenc_kernel, dim3(grid_for(rows * D)), dim3(256), 0, (hipStream_t)stream, x, pe, out,
+                     (long)rows, T, D, scale);
+  EAMD_LAUNCH_CHECK();
+  return EAMD_OK;
+}
+
+int eamd_permute4(const float* src, float* dst, int d0, int d1, int d2, int d3, int64_t s0, int64_t s1,
+                  int64_t s2, int64_t s3, int accumulate, void* stream) {
+  if (!src || !dst || d0 <= 0 || d1 <= 0 || d2 <= 0 || d3 <= 0) return EAMD_EINVAL;
+  long n = (long)d0 * d1 * d2 * d3;
+  hipLaunchKernelGGL(permute4_kernel, dim3(grid_for(n)), dim3(256), 0, (hipStream_t)stream, src, dst, d0, d1, d2,
+                     d3, (long)s0, (long)s1, (long)s2, (long)s3, accumulate);
+  EAMD_LAUNCH_CHECK();
+  return EAMD_OK;
+}
+
+int eamd_dropout(const float* x, float* y, int64_t n, float p, uint64_t seed, void* stream) {
+  if (!x || !y || n < 0 || p < 0.f || p >= 1.f) return EAMD_EINVAL;
+  if (n == 0) return EAMD_OK;
+  hipLaunchKernelGGL(dropout_kernel, dim3(grid_for(n)), dim3(256), 0, (hipStream_t)stream, x, y, (long)n, p,
+                     (unsigned long long)seed);
+  EAMD_LAUNCH_CHECK();
+  return EAMD_OK;
+}
+
+}  // extern "C"

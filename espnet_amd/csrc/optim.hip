@@ -1,0 +1,139 @@
+// Flat-buffer optimizer kernels: all parameters / gradients / Adam moments of the model live in
+// four contiguous fp32 arenas (sized for HBM3E, one launch per step instead of one per tensor).
+// reference: transformer/optimizer.py:12-75 (NoamOpt + Adam(betas=(0.9,0.98), eps=1e-9)),
+// espnet2/schedulers/warmup_lr.py:10-53, trainer.py:430-467 (clip_grad_norm_, non-finite => skip),
+// asr.py:228-240 (espnet1 clip + NaN guard).
+#include "common.h"
+#include "../../include/espnet_amd.h"
+
+namespace {
+
+__global__ __launch_bounds__(256) void sumsq_partial_kernel(const float* __restrict__ g, long n,
+                                                            float* __restrict__ part) {
+  __shared__ float red[16];
+  float s = 0.f;
+  const long stride = (long)gridDim.x * blockDim.x;
+  const long n4 = n / 4;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += stride) {
+    float4 v = reinterpret_cast<const float4*>(g)[i];
+    s += v.x * v.x + v.y * v.y + v.z * v.z + v.w * v.w;
+  }
+  for (long i = n4 * 4 + (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) s += g[i] * g[i];
+  s = block_sum(s, red);
+  if (threadIdx.x == 0) part[blockIdx.x] = s;
+}
+// out[0] = sqrt(sum(part)), fixed order => bitwise reproducible norm
+__global__ __launch_bounds__(1024) void sumsq_final_kernel(const float* __restrict__ part, int n, float* __restrict__ out) {
+  __shared__ float red[16];
+  float s = 0.f;
+  for (int i = threadIdx.x; i < n; i += blockDim.x) s += part[i];
+  s = block_sum(s, red);
+  if (threadIdx.x == 0) out[0] = sqrtf(s);
+}
+
+// state (device, 8 floats): [0]=step (float count), [1]=lr, [2]=bias_corr1, [3]=bias_corr2,
+//                           [4]=last grad norm, [5]=skipped-steps counter, [6]=clip coef
+// Noam / WarmupLR schedule evaluated on device so the whole training step stays capturable.
+//   mode 0: lr = base           (constant)
+//   mode 1: lr = factor * d^-0.5 * min(step^-0.5, step*warmup^-1.5)         (NoamOpt)
+//   mode 2: lr = base * warmup^0.5 * min(step^-0.5, step*warmup^-1.5)       (WarmupLR)
+__global__ void sched_kernel(float* __restrict__ st, const float* __restrict__ gnorm, int mode, float base,
+                             float factor, float dmodel, float warmup, float beta1, float beta2, float max_norm) {
+  if (threadIdx.x != 0 || blockIdx.x != 0) return;
+  float norm = gnorm ? gnorm[0] : 0.f;
+  st[4] = norm;
+  bool finite = isfinite(norm);
+  if (!finite) { st[5] += 1.f; st[6] = 0.f; return; }  // reference skips optimizer.step() entirely
+  float step = st[0] + 1.f;
+  st[0] = step;
+  float lr = base;
+  if (mode == 1) lr = factor * rsqrtf(dmodel) * fminf(rsqrtf(step), step * powf(warmup, -1.5f));
+  else if (mode == 2) lr = base * sqrtf(warmup) * fminf(rsqrtf(step), step * powf(warmup, -1.5f));
+  st[1] = lr;
+  st[2] = 1.f - powf(beta1, step);
+  st[3] = 1.f - powf(beta2, step);
+  float coef = 1.f;
+  if (max_norm > 0.f) { coef = max_norm / (norm + 1e-6f); if (coef > 1.f) coef = 1.f; }
+  st[6] = coef;
+}
+
+// torch.optim.Adam semantics (L2 weight decay added to the gradient), gradient pre-scaled by the
+// clip coefficient; a zero coefficient together with a non-finite norm means "skip this step".
+__global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, const float* __restrict__ g,
+                                                   float* __restrict__ m, float* __restrict__ v, long n,
+                                                   const float* __restrict__ st, float beta1, float beta2,
+                                                   float eps, float weight_decay) {
+  const float norm = st[4];
+  if (!isfinite(norm)) return;
+  const float lr = st[1], bc1 = st[2], bc2 = st[3], coef = st[6];
+  const float step_size = lr / bc1;
+  const float inv_sqrt_bc2 = rsqrtf(bc2);
+  const long stride = (long)gridDim.x * blockDim.x;
+  const long n4 = n / 4;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += stride) {
+    float4 pv = reinterpret_cast<float4*>(p)[i];
+    float4 gv = reinterpret_cast<const float4*>(g)[i];
+    float4 mv = reinterpret_cast<float4*>(m)[i];
+    float4 vv = reinterpret_cast<float4*>(v)[i];
+    float* pp = &pv.x; float* gp = &gv.x; float* mp = &mv.x; float* vp = &vv.x;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      float gg = gp[k] * coef + weight_decay * pp[k];
+      mp[k] = beta1 * mp[k] + (1.f - beta1) * gg;
+      vp[k] = beta2 * vp[k] + (1.f - beta2) * gg * gg;
+      float denom = sqrtf(vp[k]) * inv_sqrt_bc2 + eps;
+      pp[k] -= step_size * mp[k] / denom;
+    }
+    reinterpret_cast<float4*>(p)[i] = pv;
+    reinterpret_cast<float4*>(m)[i] = mv;
+    reinterpret_cast<float4*>(v)[i] = vv;
+  }
+  for (long i = n4 * 4 + (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+    float gg = g[i] * coef + weight_decay * p[i];
+    m[i] = beta1 * m[i] + (1.f - beta1) * gg;
+    v[i] = beta2 * v[i] + (1.f - beta2) * gg * gg;
+    float denom = sqrtf(v[i]) * inv_sqrt_bc2 + eps;
+    p[i] -= step_size * m[i] / denom;
+  }
+}
+
+}  // namespace
+
+extern "C" {
+
+/* gnorm_out[0] = ||g||_2 ; workspace >= 1024 floats */
+int eamd_grad_norm(const float* g, int64_t n, float* workspace, float* gnorm_out, void* stream) {
+  if (!g || !workspace || !gnorm_out || n <= 0) return EAMD_EINVAL;
+  if ((uintptr_t)g & 15) return EAMD_EINVAL;
+  long want = (n / 4 + 255) / 256;
+  int nblk = (int)(want < 1 ? 1 : (want > 1024 ? 1024 : want));
+  hipStream_t s = (hipStream_t)stream;
+  hipLaunchKernelGGL(sumsq_partial_kernel, dim3(nblk), dim3(256), 0, s, g, (long)n, workspace);
+  EAMD_LAUNCH_CHECK();
+  hipLaunchKernelGGL(sumsq_final_kernel, dim3(1), dim3(1024), 0, s, workspace, nblk, gnorm_out);
+  EAMD_LAUNCH_CHECK();
+  return EAMD_OK;
+}
+
+int eamd_sched_step(float* state, const float* gnorm, int mode, float base_lr, float factor, float dmodel,
+                    float warmup, float beta1, float beta2, float max_norm, void* stream) {
+  if (!state || mode < 0 || mode > 2) return EAMD_EINVAL;
+  hipLaunchKernelGGL(sched_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, state, gnorm, mode, base_lr, factor,
+                     dmodel, warmup, beta1, beta2, max_norm);
+  EAMD_LAUNCH_CHECK();
+  return EAMD_OK;
+}
+
+int eamd_adam_step(float* p, const float* g, float* m, float* v, int64_t n, const float* state, float beta1,
+                   float beta2, float eps, float weight_decay, void* stream) {
+  if (!p || !g || !m || !v || !state || n <= 0) return EAMD_EINVAL;
+  if (((uintptr_t)p | (uintptr_t)g | (uintptr_t)m | (uintptr_t)v) & 15) return EAMD_EINVAL;
+  long want = (n / 4 + 255) / 256;
+  int nblk = (int)(want < 1 ? 1 : (want > 2048 ? 2048 : want));
+  hipLaunchKernelGGL(adam_kernel, dim3(nblk), dim3(256), 0, (hipStream_t)stream, p, g, m, v, (long)n, state, beta1,
+                     beta2, eps, weight_decay);
+  EAMD_LAUNCH_CHECK();
+  return EAMD_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,422 @@
+// Row kernels (HBM-bound): LayerNorm fwd/bwd, masked softmax with the legacy rel-shift fused in,
+// label-smoothing KL loss (+gradient, +accuracy), row argmax.  One 64-lane wave owns one row
+// unless stated; rows are staged in registers / LDS so each element is read from HBM once.
+#include "common.h"
+#include "../../include/espnet_amd.h"
+
+namespace {
+
+// ---------------------------------------------------------------------------------------------
+// LayerNorm  (reference: transformer/layer_norm.py:12-38 = nn.LayerNorm(d, eps=1e-12))
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void layernorm_fwd_kernel(const float* __restrict__ x,
+                                                            const float* __restrict__ gamma,
+                                                            const float* __restrict__ beta,
+                                                            float* __restrict__ y, float* __restrict__ mean_out,
+                                                            float* __restrict__ rstd_out, int rows, int D,
+                                                            float eps) {
+  const int lane = threadIdx.x & 63;
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= rows) return;
+  const float* xr = x + (long)row * D;
+  float s = 0.f;
+  for (int i = lane; i < D; i += 64) s += xr[i];
+  const float mean = wave_sum(s) / D;
+  float v = 0.f;
+  for (int i = lane; i < D; i += 64) { float d = xr[i] - mean; v += d * d; }
+  const float rstd = rsqrtf(wave_sum(v) / D + eps);
+  float* yr = y + (long)row * D;
+  for (int i = lane; i < D; i += 64) yr[i] = (xr[i] - mean) * rstd * gamma[i] + beta[i];
+  if (lane == 0) { mean_out[row] = mean; rstd_out[row] = rstd; }
+}
+
+// D % 256 == 0, D <= 1024: each lane keeps its float4 slices in registers.
+template <int VEC>
+__global__ __launch_bounds__(256) void layernorm_fwd_vec_kernel(const float* __restrict__ x,
+                                                                const float* __restrict__ gamma,
+                                                                const float* __restrict__ beta,
+                                                                float* __restrict__ y,
+                                                                float* __restrict__ mean_out,
+                                                                float* __restrict__ rstd_out, int rows,
+                                                                float eps) {
+  constexpr int D = VEC * 256;
+  const int lane = threadIdx.x & 63;
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= rows) return;
+  const float4* xr = reinterpret_cast<const float4*>(x + (long)row * D);
+  float4 v[VEC];
+  float s = 0.f;
+#pragma unroll
+  for (int j = 0; j < VEC; ++j) { v[j] = xr[lane + 64 * j]; s += v[j].x + v[j].y + v[j].z + v[j].w; }
+  const float mean = wave_sum(s) / D;
+  float q = 0.f;
+#pragma unroll
+  for (int j = 0; j < VEC; ++j) {
+    float a = v[j].x - mean, b = v[j].y - mean, c = v[j].z - mean, d = v[j].w - mean;
+    q += a * a + b * b + c * c + d * d;
+  }
+  const float rstd = rsqrtf(wave_sum(q) / D + eps);
+  float4* yr = reinterpret_cast<float4*>(y + (long)row * D);
+  const float4* g4 = reinterpret_cast<const float4*>(gamma);
+  const float4* b4 = reinterpret_cast<const float4*>(beta);
+#pragma unroll
+  for (int j = 0; j < VEC; ++j) {
+    float4 g = g4[lane + 64 * j], b = b4[lane + 64 * j], o;
+    o.x = (v[j].x - mean) * rstd * g.x + b.x;
+    o.y = (v[j].y - mean) * rstd * g.y + b.y;
+    o.z = (v[j].z - mean) * rstd * g.z + b.z;
+    o.w = (v[j].w - mean) * rstd * g.w + b.w;
+    yr[lane + 64 * j] = o;
+  }
+  if (lane == 0) { mean_out[row] = mean; rstd_out[row] = rstd; }
+}
+
+// Backward: dx per row; dgamma/dbeta accumulated per lane-column over the block's rows, combined
+// across the 4 waves through LDS and added to global with one atomic per column per block.
+__global__ __launch_bounds__(256) void layernorm_bwd_kernel(
+    const float* __restrict__ dy, const float* __restrict__ x, const float* __restrict__ gamma,
+    const float* __restrict__ mean, const float* __restrict__ rstd, float* __restrict__ dx,
+    float* __restrict__ dgamma, float* __restrict__ dbeta, int rows, int D, int rows_per_block) {
+  extern __shared__ float lds[];  // [2][D]
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  for (int i = threadIdx.x; i < 2 * D; i += blockDim.x) lds[i] = 0.f;
+  __syncthreads();
+  const int r0 = blockIdx.x * rows_per_block;
+  const int r1 = min(rows, r0 + rows_per_block);
+  // columns owned by this lane: lane, lane+64, ... (at most 16 per lane kept in registers)
+  constexpr int MAXC = 16;
+  float ag[MAXC], ab[MAXC];
+#pragma unroll
+  for (int c = 0; c < MAXC; ++c) { ag[c] = 0.f; ab[c] = 0.f; }
+  for (int row = r0 + wave; row < r1; row += 4) {
+    const float* dyr = dy + (long)row * D;
+    const float* xr = x + (long)row * D;
+    const float mu = mean[row], rs = rstd[row];
+    float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+    for (int c = 0; c < MAXC; ++c) {
+      int i = lane + 64 * c;
+      if (i < D) {
+        float xh = (xr[i] - mu) * rs;
+        float dg = dyr[i] * gamma[i];
+        s1 += dg; s2 += dg * xh;
+        ag[c] += dyr[i] * xh; ab[c] += dyr[i];
+      }
+    }
+    s1 = wave_sum(s1) / D; s2 = wave_sum(s2) / D;
+    float* dxr = dx + (long)row * D;
+#pragma unroll
+    for (int c = 0; c < MAXC; ++c) {
+      int i = lane + 64 * c;
+      if (i < D) {
+        float xh = (xr[i] - mu) * rs;
+        dxr[i] = rs * (dyr[i] * gamma[i] - s1 - xh * s2);
+      }
+    }
+  }
+#pragma unroll
+  for (int c = 0; c < MAXC; ++c) {
+    int i = lane + 64 * c;
+    if (i < D) { atomicAdd(&lds[i], ag[c]); atomicAdd(&lds[D + i], ab[c]); }
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i < D; i += blockDim.x) {
+    atomicAdd(&dgamma[i], lds[i]);
+    atomicAdd(&dbeta[i], lds[D + i]);
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Masked softmax over attention scores with the legacy Transformer-XL rel-shift folded in.
+// reference: transformer/attention.py:63-90 (masked_fill(min) -> softmax -> masked_fill(0)),
+//            attention.py:141-162 (rel_shift), attention.py:200-204 ((ac + bd) / sqrt(d_k)).
+// scores layout: [nb][T1][ld] rows, nb = H*B blocks (block index z -> batch b = z % B).
+//   s[i,j] = scale * (ac[i,j] + (bd ? shift(bd)[i,j] : 0))
+//   shift(x)[i,j] = P_flat[T1 + i*T2 + j] with P = [0 | x] of shape (T1, T2+1)
+// mask: uint8, element (b,i,j) at mask[b*mb + i*mi + j] (mi = 0 broadcasts over queries); 0 = masked.
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ float shifted_bd(const float* __restrict__ bd, int T1, int T2, long ld, int i,
+                                            int j) {
+  int f = T1 + i * T2 + j;
+  int r = f / (T2 + 1), c = f % (T2 + 1);
+  return c == 0 ? 0.f : bd[(long)r * ld + (c - 1)];
+}
+
+__global__ __launch_bounds__(256) void softmax_fwd_kernel(const float* __restrict__ ac,
+                                                          const float* __restrict__ bd,
+                                                          const unsigned char* __restrict__ mask, long mb,
+                                                          long mi, float* __restrict__ P, int nb, int B,
+                                                          int T1, int T2, long ld, float scale) {
+  extern __shared__ float lds[];  // [4][T2]
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const long rowid = (long)blockIdx.x * 4 + wave;
+  if (rowid >= (long)nb * T1) return;
+  const int z = rowid / T1, i = rowid % T1;
+  const int b = z % B;
+  const float* acr = ac + ((long)z * T1 + i) * ld;
+  const float* bdz = bd ? bd + (long)z * T1 * ld : nullptr;
+  const unsigned char* mr = mask ? mask + b * mb + i * mi : nullptr;
+  float* buf = lds + wave * T2;
+  float mx = -INFINITY;
+  for (int j = lane; j < T2; j += 64) {
+    float v = acr[j];
+    if (bdz) v += shifted_bd(bdz, T1, T2, ld, i, j);
+    v *= scale;
+    if (mr && mr[j] == 0) v = -INFINITY;
+    buf[j] = v;
+    mx = fmaxf(mx, v);
+  }
+  mx = wave_max(mx);
+  float* pr = P + ((long)z * T1 + i) * ld;
+  if (mx == -INFINITY) {  // every key masked: softmax(min,...)=uniform, then masked_fill(0) -> zeros
+    for (int j = lane; j < ld; j += 64) pr[j] = 0.f;
+    return;
+  }
+  float s = 0.f;
+  for (int j = lane; j < T2; j += 64) { float e = __expf(buf[j] - mx); buf[j] = e; s += e; }
+  const float inv = 1.f / wave_sum(s);
+  for (int j = lane; j < ld; j += 64) pr[j] = j < T2 ? buf[j] * inv : 0.f;
+}
+
+// dS = P * (dP - sum_j dP*P) * scale, written over dP (d_ac); optional scatter of dS through the
+// inverse rel-shift into dbd (pre-zeroed by the caller).
+__global__ __launch_bounds__(256) void softmax_bwd_kernel(const float* __restrict__ P, float* __restrict__ dP,
+                                                          float* __restrict__ dbd, int nb, int T1, int T2,
+                                                          long ld, float scale) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const long rowid = (long)blockIdx.x * 4 + wave;
+  if (rowid >= (long)nb * T1) return;
+  const int z = rowid / T1, i = rowid % T1;
+  const float* pr = P + ((long)z * T1 + i) * ld;
+  float* dr = dP + ((long)z * T1 + i) * ld;
+  float s = 0.f;
+  for (int j = lane; j < T2; j += 64) s += pr[j] * dr[j];
+  s = wave_sum(s);
+  float* dbz = dbd ? dbd + (long)z * T1 * ld : nullptr;
+  for (int j = lane; j < T2; j += 64) {
+    float g = pr[j] * (dr[j] - s) * scale;
+    dr[j] = g;
+    if (dbz) {
+      int f = T1 + i * T2 + j;
+      int r = f / (T2 + 1), c = f % (T2 + 1);
+      if (c != 0) dbz[(long)r * ld + (c - 1)] = g;
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Label-smoothing KL loss + gradient + accuracy
+// reference: transformer/label_smoothing_loss.py:44-63, nets_utils.py:299-319 (th_accuracy)
+//   true_dist = eps/(V-1) everywhere, 1-eps at target; loss_row = sum_v td*(log td - logp_v)
+// One 256-thread block per row; grad (unscaled by upstream) = (softmax - td) * inv_denom.
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void lsm_loss_kernel(const float* __restrict__ x,
+                                                       const long long* __restrict__ target,
+                                                       float* __restrict__ loss_rows,
+                                                       float* __restrict__ correct_rows,
+                                                       float* __restrict__ grad, int V, int ignore_id,
+                                                       float smoothing, float inv_denom) {
+  __shared__ float red[16];
+  __shared__ int redi[16];
+  const int row = blockIdx.x;
+  const float* xr = x + (long)row * V;
+  float* gr = grad ? grad + (long)row * V : nullptr;
+  const long long tg = target[row];
+  if (tg == ignore_id) {
+    if (gr) for (int v = threadIdx.x; v < V; v += blockDim.x) gr[v] = 0.f;
+    if (threadIdx.x == 0) { loss_rows[row] = 0.f; correct_rows[row] = 0.f; }
+    return;
+  }
+  // max + first argmax
+  float mx = -INFINITY; int am = 0x7fffffff;
+  for (int v = threadIdx.x; v < V; v += blockDim.x) {
+    float a = xr[v];
+    if (a > mx) { mx = a; am = v; }
+  }
+  // wave reduce (value, index) with lowest-index tie-break (torch.argmax semantics)
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    float om = __shfl_xor(mx, o, 64); int oi = __shfl_xor(am, o, 64);
+    if (om > mx || (om == mx && oi < am)) { mx = om; am = oi; }
+  }
+  const int w = threadIdx.x >> 6, l = threadIdx.x & 63;
+  if (l == 0) { red[w] = mx; redi[w] = am; }
+  __syncthreads();
+  mx = red[0]; am = redi[0];
+  for (int k = 1; k < (blockDim.x >> 6); ++k)
+    if (red[k] > mx || (red[k] == mx && redi[k] < am)) { mx = red[k]; am = redi[k]; }
+  __syncthreads();
+  float se = 0.f, sx = 0.f;
+  for (int v = threadIdx.x; v < V; v += blockDim.x) { float a = xr[v]; se += __expf(a - mx); sx += a; }
+  se = block_sum(se, red);
+  sx = block_sum(sx, red);
+  const float lse = mx + __logf(se);
+  const float conf = 1.f - smoothing;
+  const float low = smoothing / (V - 1);
+  const float logp_t = xr[tg] - lse;
+  const float sum_logp = sx - V * lse;
+  float loss = -conf * logp_t - low * (sum_logp - logp_t);
+  if (conf > 0.f) loss += conf * __logf(conf);
+  if (low > 0.f) loss += (V - 1) * low * __logf(low);
+  if (threadIdx.x == 0) {
+    loss_rows[row] = loss;
+    correct_rows[row] = (am == (int)tg) ? 1.f : 0.f;
+  }
+  if (gr) {
+    for (int v = threadIdx.x; v < V; v += blockDim.x) {
+      float p = __expf(xr[v] - lse);
+      float td = (v == (int)tg) ? conf : low;
+      gr[v] = (p - td) * inv_denom;
+    }
+  }
+}
+
+// Row argmax (first maximal index), one block per row.  reference: ctc.py:144-151 (CTC.argmax),
+// e2e_asr_transformer.py:274-284 (greedy CTC decode).
+__global__ __launch_bounds__(256) void argmax_rows_kernel(const float* __restrict__ x, long ld,
+                                                          int* __restrict__ out, int V) {
+  __shared__ float red[16];
+  __shared__ int redi[16];
+  const float* xr = x + (long)blockIdx.x * ld;
+  float mx = -INFINITY; int am = 0x7fffffff;
+  for (int v = threadIdx.x; v < V; v += blockDim.x) {
+    float a = xr[v];
+    if (a > mx || (a == mx && v < am)) { mx = a; am = v; }
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    float om = __shfl_xor(mx, o, 64); int oi = __shfl_xor(am, o, 64);
+    if (om > mx || (om == mx && oi < am)) { mx = om; am = oi; }
+  }
+  const int w = threadIdx.x >> 6, l = threadIdx.x & 63;
+  if (l == 0) { red[w] = mx; redi[w] = am; }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    mx = red[0]; am = redi[0];
+    for (int k = 1; k < (blockDim.x >> 6); ++k)
+      if (red[k] > mx || (red[k] == mx && redi[k] < am)) { mx = red[k]; am = redi[k]; }
+    out[blockIdx.x] = am == 0x7fffffff ? 0 : am;
+  }
+}
+
+// Deterministic single-block sum: out[0] = scale * sum(in[0..n)).
+__global__ __launch_bounds__(1024) void reduce_sum_kernel(const float* __restrict__ in, long n,
+                                                          float* __restrict__ out, float scale) {
+  __shared__ float red[16];
+  float s = 0.f;
+  for (long i = threadIdx.x; i < n; i += blockDim.x) s += in[i];
+  s = block_sum(s, red);
+  if (threadIdx.x == 0) out[0] = s * scale;
+}
+
+// Row log-softmax (decoder scoring).  reference: decoder.py:318 (log_softmax in forward_one_step),
+// ctc.py:134-142 (CTC.log_softmax).
+__global__ __launch_bounds__(256) void log_softmax_rows_kernel(const float* __restrict__ x,
+                                                               float* __restrict__ y, int V) {
+  __shared__ float red[16];
+  const float* xr = x + (long)blockIdx.x * V;
+  float* yr = y + (long)blockIdx.x * V;
+  float mx = -INFINITY;
+  for (int v = threadIdx.x; v < V; v += blockDim.x) mx = fmaxf(mx, xr[v]);
+  mx = block_max(mx, red);
+  float se = 0.f;
+  for (int v = threadIdx.x; v < V; v += blockDim.x) se += __expf(xr[v] - mx);
+  se = block_sum(se, red);
+  const float lse = mx + __logf(se);
+  for (int v = threadIdx.x; v < V; v += blockDim.x) yr[v] = xr[v] - lse;
+}
+
+}  // namespace
+
+extern "C" {
+
+int eamd_layernorm_fwd(const float* x, const float* gamma, const float* beta, float* y, float* mean,
+                       float* rstd, int rows, int D, float eps, void* stream) {
+  if (!x || !gamma || !beta || !y || !mean || !rstd || rows <= 0 || D <= 0) return EAMD_EINVAL;
+  hipStream_t s = (hipStream_t)stream;
+  dim3 grid((rows + 3) / 4), block(256);
+  const bool al = ((uintptr_t)x % 16 == 0) && ((uintptr_t)y % 16 == 0) && ((uintptr_t)gamma % 16 == 0) &&
+                  ((uintptr_t)beta % 16 == 0);
+  if (al && D == 256) hipLaunchKernelGGL(layernorm_fwd_vec_kernel<1>, grid, block, 0, s, x, gamma, beta, y, mean, rstd, rows, eps);
+  else if (al && D == 512) hipLaunchKernelGGL(layernorm_fwd_vec_kernel<2>, grid, block, 0, s, x, gamma, beta, y, mean, rstd, rows, eps);
+  else hipLaunchKernelGGL(layernorm_fwd_kernel, grid, block, 0, s, x, gamma, beta, y, mean, rstd, rows, D, eps);
+  EAMD_LAUNCH_CHECK();
+  return EAMD_OK;
+}
+
+int eamd_layernorm_bwd(const float* dy, const float* x, const float* gamma, const float* mean,
+                       const float* rstd, float* dx, float* dgamma, float* dbeta, int rows, int D,
+                       void* stream) {
+  if (!dy || !x || !gamma || !mean || !rstd || !dx || !dgamma || !dbeta || rows <= 0 || D <= 0)
+    return EAMD_EINVAL;
+  if (D > 1024) return EAMD_EUNSUPPORTED;
+  int nblk = min(1024, (rows + 15) / 16);
+  int rpb = (rows + nblk - 1) / nblk;
+  nblk = (rows + rpb - 1) / rpb;
+  hipLaunchKernelGGL(layernorm_bwd_kernel, dim3(nblk), dim3(256), 2 * D * sizeof(float), (hipStream_t)stream,
+                     dy, x, gamma, mean, rstd, dx, dgamma, dbeta, rows, D, rpb);
+  EAMD_LAUNCH_CHECK();
+  return EAMD_OK;
+}
+
+int eamd_softmax_fwd(const float* ac, const float* bd, const unsigned char* mask, int64_t mask_bstride,
+                     int64_t mask_qstride, float* P, int nblocks, int B, int T1, int T2, int64_t ld,
+                     float scale, void* stream) {
+  if (!ac || !P || nblocks <= 0 || B <= 0 || T1 <= 0 || T2 <= 0 || ld < T2) return EAMD_EINVAL;
+  if ((size_t)T2 * 16 > 160 * 1024) return EAMD_EUNSUPPORTED;
+  long rows = (long)nblocks * T1;
+  size_t smem = (size_t)4 * T2 * sizeof(float);
+  if (smem > 64 * 1024) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&softmax_fwd_kernel),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+    if (e != hipSuccess) return (int)e;
+  }
+  hipLaunchKernelGGL(softmax_fwd_kernel, dim3((rows + 3) / 4), dim3(256), smem, (hipStream_t)stream, ac, bd,
+                     mask, (long)mask_bstride, (long)mask_qstride, P, nblocks, B, T1, T2, (long)ld, scale);
+  EAMD_LAUNCH_CHECK();
+  return EAMD_OK;
+}
+
+int eamd_softmax_bwd(const float* P, float* dP, float* dbd, int nblocks, int T1, int T2, int64_t ld,
+                     float scale, void* stream) {
+  if (!P || !dP || nblocks <= 0 || T1 <= 0 || T2 <= 0 || ld < T2) return EAMD_EINVAL;
+  long rows = (long)nblocks * T1;
+  hipLaunchKernelGGL(softmax_bwd_kernel, dim3((rows + 3) / 4), dim3(256), 0, (hipStream_t)stream, P, dP, dbd,
+                     nblocks, T1, T2, (long)ld, scale);
+  EAMD_LAUNCH_CHECK();
+  return EAMD_OK;
+}
+
+int eamd_lsm_loss(const float* logits, const int64_t* target, float* loss_rows, float* correct_rows,
+                  float* grad, int rows, int V, int ignore_id, float smoothing, float inv_denom,
+                  void* stream) {
+  if (!logits || !target || !loss_rows || !correct_rows || rows <= 0 || V <= 1) return EAMD_EINVAL;
+  hipLaunchKernelGGL(lsm_loss_kernel, dim3(rows), dim3(256), 0, (hipStream_t)stream, logits,
+                     (const long long*)target, loss_rows, correct_rows, grad, V, ignore_id, smoothing,
+                     inv_denom);
+  EAMD_LAUNCH_CHECK();
+  return EAMD_OK;
+}
+
+int eamd_argmax_rows(const float* x, int64_t ld, int32_t* out, int rows, int V, void* stream) {
+  if (!x || !out || rows <= 0 || V <= 0) return EAMD_EINVAL;
+  hipLaunchKernelGGL(argmax_rows_kernel, dim3(rows), dim3(256), 0, (hipStream_t)stream, x, (long)ld, out, V);
+  EAMD_LAUNCH_CHECK();
+  return EAMD_OK;
+}
+
+int eamd_reduce_sum(const float* in, int64_t n, float* out, float scale, void* stream) {
+  if (!in || !out || n < 0) return EAMD_EINVAL;
+  hipLaunchKernelGGL(reduce_sum_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, in, (long)n, out, scale);
+  EAMD_LAUNCH_CHECK();
+  return EAMD_OK;
+}
+
+int eamd_log_softmax_rows(const float* x, float* y, int rows, int V, void* stream) {
+  if (!x || !y || rows <= 0 || V <= 0) return EAMD_EINVAL;
+  hipLaunchKernelGGL(log_softmax_rows_kernel, dim3(rows), dim3(256), 0, (hipStream_t)stream, x, y, V);
+  EAMD_LAUNCH_CHECK();
+  return EAMD_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,198 @@
+/*
+ * espnet_amd C ABI — MI355X (gfx950) kernels for the hybrid CTC/attention ASR hot path.
+ *
+ * The reference (kan-bayashi/espnet v0.9.5) has no native interface for this path: it is pure
+ * Python over torch ops plus the third-party warp-ctc wheel.  The boundary below is therefore the
+ * one SURVEY.md §8b defines; every entry point cites the reference computation it replaces
+ * (paths relative to the reference root).
+ *
+ * Conventions
+ *  - every pointer is a DEVICE pointer to fp32 / int32 / int64 data owned by the caller; the
+ *    library never allocates, frees or retains memory and keeps no mutable global state;
+ *  - every call is asynchronous on `stream` (hipStream_t passed as void*), re-entrant, and
+ *    performs no host synchronisation (so it can be captured into a hipGraph);
+ *  - return 0 on success, <0 for a rejected argument (EAMD_EINVAL=-1, EAMD_EUNSUPPORTED=-2),
+ *    >0 = hipError_t from the launch.  Numerical failure (e.g. infeasible CTC alignment) is
+ *    reported in the data (+inf loss), never as an error code.
+ */
+#ifndef ESPNET_AMD_H_
+#define ESPNET_AMD_H_
+#include <stdint.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+int eamd_abi_version(void);
+
+/* ------------------------------------------------------------------------------------------
+ * GEMM family (MFMA).  Replaces every nn.Linear / torch.matmul / pointwise Conv1d / Conv2d on the
+ * path: transformer/attention.py:33-36,55-57,91,96,113,195,199; positionwise_feed_forward.py:25-32;
+ * subsampling.py:28-35; conformer/convolution.py:28-53; decoder.py:247; ctc.py:26,85.
+ *
+ *   acc[m,n] = sum_k opA(A)[m,k] * opB(B)[k,n]
+ *   v = acc + bias[n];  v = epilogue(v, aux[m,n]);  v = alpha*v + R[m,n] + beta*C_old[m,n]
+ *
+ * transA=0: A is [M,K] row-major (lda); transA=1: A is stored [K,M] (lda = stride of k).
+ * transB=0: B is stored [N,K] (nn.Linear weight, ldb = stride of n); transB=1: B is [K,N].
+ * a_act/b_act apply an activation to the operand while it is staged (EAMD_ACT_*).
+ * epilogue: 0 none, 1 relu, 2 swish, 3 multiply by (aux>0), 4 multiply by dswish(aux).
+ * splitk>1: partial sums are atomically ADDED to C (caller pre-initialises C; epilogue must be 0,
+ *           beta ignored, bias/R contributed by split 0).
+ * precision: 0 = fp32 MFMA (v_mfma_f32_16x16x4_f32, exact fp32 products),
+ *            1 = bf16 MFMA (operands rounded to bf16 while staged, fp32 accumulate).
+ * Two-level batch (batch1 x batch2) with independent element strides for A/B/C(aux,R share C's).
+ * Optional implicit-im2col view of A (`gather`) and strided row map for C (`cmap`) express the
+ * Conv2dSubsampling convolutions and their input-gradient without materialising columns.
+ * ------------------------------------------------------------------------------------------ */
+typedef struct {
+  int32_t enabled;
+  int32_t C;          /* channels per tap (contiguous in memory, NHWC) */
+  int32_t ntap;
+  int32_t Ho, Wo;     /* logical row = (b*Ho + i)*Wo + j */
+  int32_t Hin, Win;   /* source tensor is [B,Hin,Win,C] */
+  int32_t sh, sw;     /* source pixel = (i*sh + dh[tap], j*sw + dw[tap]); out of range -> 0 */
+  int32_t dh[9], dw[9];
+} eamd_gather_t;
+
+typedef struct {
+  int32_t enabled;
+  int32_t Ho, Wo;     /* logical row = (b*Ho + i)*Wo + j */
+  int32_t Hc, Wc;     /* physical row = (b*Hc + i*sh + oh)*Wc + j*sw + ow */
+  int32_t sh, oh, sw, ow;
+} eamd_rowmap_t;
+
+typedef struct {
+  const float* A; const float* B; float* C;
+  const float* bias; const float* aux; const float* R;
+  int32_t M, N, K;
+  int32_t transA, transB;
+  int64_t lda, ldb, ldc, ldaux, ldr;
+  int32_t batch1, batch2;
+  int64_t sA1, sA2, sB1, sB2, sC1, sC2;
+  float alpha, beta;
+  int32_t a_act, b_act, epilogue;
+  int32_t splitk;
+  int32_t precision;
+  int32_t tile;        /* 0 auto, 64 or 128 */
+  eamd_gather_t gather;
+  eamd_rowmap_t cmap;
+} eamd_gemm_t;
+
+int eamd_gemm(const eamd_gemm_t* p, void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Row kernels (HBM-bound).
+ * ------------------------------------------------------------------------------------------ */
+/* LayerNorm over the last dim.  reference: transformer/layer_norm.py:12-38 (eps = 1e-12). */
+int eamd_layernorm_fwd(const float* x, const float* gamma, const float* beta, float* y, float* mean,
+                       float* rstd, int rows, int D, float eps, void* stream);
+/* dgamma/dbeta are ACCUMULATED (+=) with f32 atomics; dx is overwritten. */
+int eamd_layernorm_bwd(const float* dy, const float* x, const float* gamma, const float* mean,
+                       const float* rstd, float* dx, float* dgamma, float* dbeta, int rows, int D,
+                       void* stream);
+
+/* Masked softmax of attention scores, legacy rel_shift of `bd` fused in.
+ * reference: transformer/attention.py:63-90 (mask fill / softmax / zero fill), :141-162 (rel_shift),
+ * :200-204 ((ac+bd)/sqrt(d_k)).  Scores are nblocks x [T1, ld] (ld >= T2, pad columns of P are
+ * zeroed); block z belongs to batch z % B.  mask (uint8, 0 = masked) element (b,i,j) at
+ * mask[b*mask_bstride + i*mask_qstride + j]; NULL = no mask. */
+int eamd_softmax_fwd(const float* ac, const float* bd, const unsigned char* mask, int64_t mask_bstride,
+                     int64_t mask_qstride, float* P, int nblocks, int B, int T1, int T2, int64_t ld,
+                     float scale, void* stream);
+/* dP is overwritten by d(ac); if dbd != NULL (pre-zeroed) the same values are scattered through the
+ * inverse rel_shift. */
+int eamd_softmax_bwd(const float* P, float* dP, float* dbd, int nblocks, int T1, int T2, int64_t ld,
+                     float scale, void* stream);
+
+/* Label-smoothing KL loss rows + argmax-correct flags + gradient (softmax - true_dist)*inv_denom.
+ * reference: transformer/label_smoothing_loss.py:44-63, nets_utils.py:299-319 (th_accuracy). */
+int eamd_lsm_loss(const float* logits, const int64_t* target, float* loss_rows, float* correct_rows,
+                  float* grad, int rows, int V, int ignore_id, float smoothing, float inv_denom,
+                  void* stream);
+/* First-max argmax per row (torch.argmax tie-break).  reference: ctc.py:144-151,
+ * e2e_asr_transformer.py:274-284 (greedy CTC). */
+int eamd_argmax_rows(const float* x, int64_t ld, int32_t* out, int rows, int V, void* stream);
+int eamd_reduce_sum(const float* in, int64_t n, float* out, float scale, void* stream);
+/* reference: decoder.py:318, ctc.py:134-142. */
+int eamd_log_softmax_rows(const float* x, float* y, int rows, int V, void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Element-wise helpers.
+ * ------------------------------------------------------------------------------------------ */
+int eamd_axpby(const float* x, const float* y, float* out, int64_t n, float a, float b, void* stream);
+int eamd_scale_dev(const float* x, const float* scale_dev, float* out, int64_t n, float extra, void* stream);
+int eamd_act_fwd(const float* x, float* y, int64_t n, int act, void* stream);
+int eamd_act_bwd(const float* dy, const float* x, float* dx, int64_t n, int act, void* stream);
+/* reference: conformer/convolution.py:72 (GLU). x is [rows, 2C], y/dy [rows, C]. */
+int eamd_glu_fwd(const float* x, float* y, int64_t rows, int C, void* stream);
+int eamd_glu_bwd(const float* dy, const float* x, float* dx, int64_t rows, int C, void* stream);
+/* reference: transformer/attention.py:186-190 (q + pos_bias_u, q + pos_bias_v). */
+int eamd_add_bias2(const float* q, const float* u, const float* v, float* qu, float* qv, int64_t rows, int D,
+                   void* stream);
+/* out[D] += scale * column sums of x[rows, D] (bias gradients). */
+int eamd_colsum(const float* x, int64_t ld, float* out, int64_t rows, int D, float scale, void* stream);
+/* reference: decoder.py:83-86,251 (Embedding + PositionalEncoding), embedding.py:80-91. */
+int eamd_embed_pe(const int64_t* tok, const float* table, const float* pe, float* out, int64_t rows, int U,
+                  int D, float scale, int pos_offset, void* stream);
+int eamd_embed_bwd(const int64_t* tok, const float* dout, float* dtable, int64_t rows, int D, float scale,
+                   void* stream);
+int eamd_posenc(const float* x, const float* pe, float* out, int64_t rows, int T, int D, float scale,
+                void* stream);
+int eamd_permute4(const float* src, float* dst, int d0, int d1, int d2, int d3, int64_t s0, int64_t s1,
+                  int64_t s2, int64_t s3, int accumulate, void* stream);
+int eamd_dropout(const float* x, float* y, int64_t n, float p, uint64_t seed, void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Conformer convolution module + first subsampling convolution (channels-last activations).
+ * reference: conformer/convolution.py:13-79, transformer/subsampling.py:28-33.
+ * ------------------------------------------------------------------------------------------ */
+int eamd_dwconv_fwd(const float* x, const float* w, const float* bias, float* y, int B, int T, int C, int K,
+                    void* stream);
+int eamd_dwconv_bwd_x(const float* dy, const float* w, float* dx, int B, int T, int C, int K, void* stream);
+/* dw[C,K], db[C] are ACCUMULATED. */
+int eamd_dwconv_bwd_w(const float* dy, const float* x, float* dw, float* db, int B, int T, int C, int K,
+                      void* stream);
+int eamd_bn_nslab(int64_t M, int C);
+/* BatchNorm1d training statistics over [M, C]; workspace 3*C*nslab floats; running stats updated in
+ * place (momentum, unbiased variance) when non-NULL. */
+int eamd_bn_stats(const float* x, float* workspace, float* mean, float* rstd, float* running_mean,
+                  float* running_var, int64_t M, int C, float eps, float momentum, void* stream);
+int eamd_bn_apply(const float* x, const float* mean, const float* rstd, const float* gamma, const float* beta,
+                  float* y, int64_t M, int C, int act, void* stream);
+/* workspace (2*nslab+2)*C floats; dgamma/dbeta ACCUMULATED. */
+int eamd_bn_bwd(const float* dy, const float* x, const float* mean, const float* rstd, const float* gamma,
+                const float* beta, float* workspace, float* dx, float* dgamma, float* dbeta, int64_t M, int C,
+                int act, int training, void* stream);
+/* Conv2d(1, C, 3, 2) + ReLU, x [B,T,F] -> y [B,H,W,C] (NHWC). */
+int eamd_conv1_fwd(const float* x, const float* w, const float* bias, float* y, int B, int T, int F, int C,
+                   void* stream);
+int eamd_conv1_bwd_w(const float* dy, const float* x, float* dw, float* db, int B, int T, int F, int C,
+                     void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * CTC loss (warp-ctc operator slot).  reference: ctc.py:30-47,53-66 (ctc_type warpctc|builtin),
+ * espnet2/asr/ctc.py:32-66.  acts are RAW activations (softmax fused), element strides select
+ * (T,B,V) or (B,T,V) layout.  nll[b] = -log p(y_b|x_b) (+inf if infeasible);
+ * grad = grad_scale * d(sum_b nll_b)/d(acts), zero for t >= ilens[b].
+ * ------------------------------------------------------------------------------------------ */
+int64_t eamd_ctc_workspace_bytes(int B, int T, int Lmax);
+int eamd_ctc_loss(const float* acts, int64_t stride_t, int64_t stride_b, const int64_t* ys_pad,
+                  const int32_t* ilens, float* nll, float* grad, int64_t gstride_t, int64_t gstride_b,
+                  void* workspace, int B, int T, int V, int Lmax, int blank, int ignore_id, float grad_scale,
+                  void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Optimizer on flat fp32 arenas.  reference: transformer/optimizer.py:12-75 (NoamOpt),
+ * espnet2/schedulers/warmup_lr.py:10-53, trainer.py:430-467 (clip + non-finite skip).
+ * state: 8 device floats [step, lr, bias_corr1, bias_corr2, grad_norm, skipped, clip_coef, -].
+ * ------------------------------------------------------------------------------------------ */
+int eamd_grad_norm(const float* g, int64_t n, float* workspace, float* gnorm_out, void* stream);
+int eamd_sched_step(float* state, const float* gnorm, int mode, float base_lr, float factor, float dmodel,
+                    float warmup, float beta1, float beta2, float max_norm, void* stream);
+int eamd_adam_step(float* p, const float* g, float* m, float* v, int64_t n, const float* state, float beta1,
+                   float beta2, float eps, float weight_decay, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* ESPNET_AMD_H_ */
