@@ -1,0 +1,99 @@
+"""ctypes binding of the espnet_amd C ABI (include/espnet_amd.h).
+
+The product path has no CPU fallback: if the HIP library is missing or a call is made with
+tensors that are not on a GPU, this module raises.  torch is used only for device memory and
+streams (tensor.data_ptr(), torch.cuda.current_stream()).
+"""
+import ctypes as C
+import os
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "csrc", "libespnet_amd_hip.so")
+
+
+class EamdError(RuntimeError):
+    pass
+
+
+class GatherT(C.Structure):
+    _fields_ = [("enabled", C.c_int32), ("C", C.c_int32), ("ntap", C.c_int32), ("Ho", C.c_int32),
+                ("Wo", C.c_int32), ("Hin", C.c_int32), ("Win", C.c_int32), ("sh", C.c_int32),
+                ("sw", C.c_int32), ("dh", C.c_int32 * 9), ("dw", C.c_int32 * 9)]
+
+
+class RowMapT(C.Structure):
+    _fields_ = [("enabled", C.c_int32), ("Ho", C.c_int32), ("Wo", C.c_int32), ("Hc", C.c_int32),
+                ("Wc", C.c_int32), ("sh", C.c_int32), ("oh", C.c_int32), ("sw", C.c_int32),
+                ("ow", C.c_int32)]
+
+
+class GemmT(C.Structure):
+    _fields_ = [("A", C.c_void_p), ("B", C.c_void_p), ("C", C.c_void_p), ("bias", C.c_void_p),
+                ("aux", C.c_void_p), ("R", C.c_void_p),
+                ("M", C.c_int32), ("N", C.c_int32), ("K", C.c_int32),
+                ("transA", C.c_int32), ("transB", C.c_int32),
+                ("lda", C.c_int64), ("ldb", C.c_int64), ("ldc", C.c_int64), ("ldaux", C.c_int64),
+                ("ldr", C.c_int64),
+                ("batch1", C.c_int32), ("batch2", C.c_int32),
+                ("sA1", C.c_int64), ("sA2", C.c_int64), ("sB1", C.c_int64), ("sB2", C.c_int64),
+                ("sC1", C.c_int64), ("sC2", C.c_int64),
+                ("alpha", C.c_float), ("beta", C.c_float),
+                ("a_act", C.c_int32), ("b_act", C.c_int32), ("epilogue", C.c_int32),
+                ("splitk", C.c_int32), ("precision", C.c_int32), ("tile", C.c_int32),
+                ("gather", GatherT), ("cmap", RowMapT)]
+
+
+_lib = None
+
+# every symbol include/espnet_amd.h declares (tests check they are all exported)
+SYMBOLS = [
+    "eamd_abi_version", "eamd_gemm", "eamd_layernorm_fwd", "eamd_layernorm_bwd", "eamd_softmax_fwd",
+    "eamd_softmax_bwd", "eamd_lsm_loss", "eamd_argmax_rows", "eamd_reduce_sum", "eamd_log_softmax_rows",
+    "eamd_axpby", "eamd_scale_dev", "eamd_act_fwd", "eamd_act_bwd", "eamd_glu_fwd", "eamd_glu_bwd",
+    "eamd_add_bias2", "eamd_colsum", "eamd_embed_pe", "eamd_embed_bwd", "eamd_posenc", "eamd_permute4",
+    "eamd_dropout", "eamd_dwconv_fwd", "eamd_dwconv_bwd_x", "eamd_dwconv_bwd_w", "eamd_bn_nslab",
+    "eamd_bn_stats", "eamd_bn_apply", "eamd_bn_bwd", "eamd_conv1_fwd", "eamd_conv1_bwd_w",
+    "eamd_conv2_weight_prep", "eamd_conv2_weight_grad", "eamd_add_sos_eos", "eamd_ctc_collapse",
+    "eamd_ctc_workspace_bytes", "eamd_ctc_loss", "eamd_grad_norm", "eamd_sched_step", "eamd_adam_step",
+]
+
+
+def lib():
+    """Load the HIP shared library (once).  Raises if it has not been built."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise EamdError(
+                f"{LIB_PATH} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+                "or `make -C espnet_amd/csrc` (there is no CPU fallback)")
+        _lib = C.CDLL(LIB_PATH)
+        _lib.eamd_ctc_workspace_bytes.restype = C.c_int64
+        for s in SYMBOLS:
+            getattr(_lib, s)  # AttributeError here = header/library mismatch
+    return _lib
+
+
+def stream_ptr():
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def check(rc, what):
+    if rc != 0:
+        raise EamdError(f"{what} failed with code {rc}")
+
+
+def ptr(t, offset=0):
+    """Device pointer of a tensor (+ element offset); None -> NULL."""
+    if t is None:
+        return None
+    if not t.is_cuda:
+        raise EamdError("espnet_amd kernels need GPU tensors (no CPU fallback in the product path)")
+    return C.c_void_p(t.data_ptr() + offset * t.element_size())
+
+
+def f32(t):
+    if t.dtype != torch.float32:
+        raise EamdError(f"expected float32 tensor, got {t.dtype}")
+    return t

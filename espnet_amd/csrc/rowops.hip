@@ -75,7 +75,7 @@ __global__ __launch_bounds__(256) void layernorm_fwd_vec_kernel(const float* __r
 // across the 4 waves through LDS and added to global with one atomic per column per block.
 __global__ __launch_bounds__(256) void layernorm_bwd_kernel(
     const float* __restrict__ dy, const float* __restrict__ x, const float* __restrict__ gamma,
-    const float* __restrict__ mean, const float* __restrict__ rstd, float* __restrict__ dx,
+    const float* __restrict__ mean, const float* __restrict__ rstd, const float* dres, float* dx,
     float* __restrict__ dgamma, float* __restrict__ dbeta, int rows, int D, int rows_per_block) {
   extern __shared__ float lds[];  // [2][D]
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -110,7 +110,9 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(
       int i = lane + 64 * c;
       if (i < D) {
         float xh = (xr[i] - mu) * rs;
-        dxr[i] = rs * (dyr[i] * gamma[i] - s1 - xh * s2);
+        float g = rs * (dyr[i] * gamma[i] - s1 - xh * s2);
+        if (dres) g += dres[(long)row * D + i];
+        dxr[i] = g;
       }
     }
   }
@@ -142,10 +144,10 @@ __device__ __forceinline__ float shifted_bd(const float* __restrict__ bd, int T1
   return c == 0 ? 0.f : bd[(long)r * ld + (c - 1)];
 }
 
-__global__ __launch_bounds__(256) void softmax_fwd_kernel(const float* __restrict__ ac,
+__global__ __launch_bounds__(256) void softmax_fwd_kernel(const float* ac,
                                                           const float* __restrict__ bd,
                                                           const unsigned char* __restrict__ mask, long mb,
-                                                          long mi, float* __restrict__ P, int nb, int B,
+                                                          long mi, float* P, int nb, int B,
                                                           int T1, int T2, long ld, float scale) {
   extern __shared__ float lds[];  // [4][T2]
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -345,8 +347,8 @@ int eamd_layernorm_fwd(const float* x, const float* gamma, const float* beta, fl
 }
 
 int eamd_layernorm_bwd(const float* dy, const float* x, const float* gamma, const float* mean,
-                       const float* rstd, float* dx, float* dgamma, float* dbeta, int rows, int D,
-                       void* stream) {
+                       const float* rstd, const float* dres, float* dx, float* dgamma, float* dbeta, int rows,
+                       int D, void* stream) {
   if (!dy || !x || !gamma || !mean || !rstd || !dx || !dgamma || !dbeta || rows <= 0 || D <= 0)
     return EAMD_EINVAL;
   if (D > 1024) return EAMD_EUNSUPPORTED;
@@ -354,7 +356,7 @@ int eamd_layernorm_bwd(const float* dy, const float* x, const float* gamma, cons
   int rpb = (rows + nblk - 1) / nblk;
   nblk = (rows + rpb - 1) / rpb;
   hipLaunchKernelGGL(layernorm_bwd_kernel, dim3(nblk), dim3(256), 2 * D * sizeof(float), (hipStream_t)stream,
-                     dy, x, gamma, mean, rstd, dx, dgamma, dbeta, rows, D, rpb);
+                     dy, x, gamma, mean, rstd, dres, dx, dgamma, dbeta, rows, D, rpb);
   EAMD_LAUNCH_CHECK();
   return EAMD_OK;
 }

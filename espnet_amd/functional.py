@@ -1,0 +1,504 @@
+"""Block-level autograd Functions: each Conformer / Transformer sub-block is one Function whose
+forward and backward are explicit kernel sequences over the C ABI (espnet_amd.ops).
+
+torch.autograd is only the tape between blocks.  Weight gradients are accumulated straight into
+the flat gradient arena (``param._eamd_grad`` installed by espnet_amd.train.FlatParams) when
+present, otherwise they are returned to autograd like any other Function would.
+"""
+import math
+
+import torch
+
+from . import ops
+from .ops import (ACT_NONE, ACT_RELU, ACT_SWISH, EPI_MUL_DSWISH, EPI_MUL_RELU_MASK, EPI_NONE, EPI_RELU)
+
+
+class GradSink:
+    """Where backward kernels accumulate parameter gradients."""
+
+    def __init__(self, params):
+        self.params = list(params)
+        self.ret = [None] * len(self.params)
+
+    def buf(self, i):
+        p = self.params[i]
+        g = getattr(p, "_eamd_grad", None)
+        if g is not None:
+            return g
+        if self.ret[i] is None:
+            self.ret[i] = torch.zeros_like(p)
+        return self.ret[i]
+
+    def results(self):
+        return tuple(self.ret)
+
+
+def _act_epi(act):
+    return {ACT_RELU: EPI_MUL_RELU_MASK, ACT_SWISH: EPI_MUL_DSWISH}[act]
+
+
+# =================================================================================================
+# LayerNorm  (reference: transformer/layer_norm.py:12-38)
+# =================================================================================================
+class LayerNormFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, weight, bias, eps):
+        shp = x.shape
+        x2 = x.reshape(-1, shp[-1]).contiguous()
+        y, mean, rstd = ops.layernorm_fwd(x2, weight, bias, eps)
+        ctx.save_for_backward(x2, mean, rstd)
+        ctx.pr = (weight, bias)
+        ctx.shp = shp
+        return y.view(shp)
+
+    @staticmethod
+    def backward(ctx, dy):
+        x2, mean, rstd = ctx.saved_tensors
+        w, b = ctx.pr
+        sink = GradSink([w, b])
+        dy2 = dy.reshape(x2.shape).contiguous()
+        dx = ops.layernorm_bwd(dy2, x2, w, mean, rstd, None, sink.buf(0), sink.buf(1))
+        return (dx.view(ctx.shp),) + sink.results() + (None,)
+
+
+# =================================================================================================
+# nn.Linear  (reference: torch.nn.Linear call sites; decoder.py:247 output_layer, ctc.py:26 ctc_lo)
+# =================================================================================================
+class LinearFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, weight, bias):
+        shp = x.shape
+        x2 = x.reshape(-1, shp[-1]).contiguous()
+        y = ops.linear_fwd(x2, weight, bias)
+        ctx.save_for_backward(x2)
+        ctx.pr = (weight, bias)
+        ctx.shp = shp
+        return y.view(*shp[:-1], weight.shape[0])
+
+    @staticmethod
+    def backward(ctx, dy):
+        (x2,) = ctx.saved_tensors
+        w, b = ctx.pr
+        sink = GradSink([w, b] if b is not None else [w])
+        dy2 = dy.reshape(x2.shape[0], w.shape[0]).contiguous()
+        dx = ops.linear_bwd_x(dy2, w) if ctx.needs_input_grad[0] else None
+        ops.linear_bwd_w(dy2, x2, sink.buf(0))
+        if b is not None:
+            ops.colsum(dy2, sink.buf(1))
+        res = sink.results()
+        return (dx.view(ctx.shp) if dx is not None else None, res[0], res[1] if b is not None else None)
+
+
+# =================================================================================================
+# Position-wise feed-forward block with pre-LayerNorm and scaled residual
+#   out = x + scale * (W2 act(W1 LN(x) + b1) + b2)
+# reference: positionwise_feed_forward.py:12-32, conformer/encoder_layer.py:97-103,141-146,
+#            transformer/encoder_layer.py / decoder_layer.py:123-128 (scale = 1, ReLU)
+# =================================================================================================
+class FFNBlockFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, ln_w, ln_b, w1, b1, w2, b2, scale, act, eps):
+        shp = x.shape
+        D = shp[-1]
+        x2 = x.reshape(-1, D).contiguous()
+        xn, mean, rstd = ops.layernorm_fwd(x2, ln_w, ln_b, eps)
+        z = ops.linear_fwd(xn, w1, b1)                                     # [M, F] pre-activation
+        out = ops.linear_fwd(z, w2, b2, R=x2, alpha=scale, a_act=act)      # act applied while staging z
+        ctx.save_for_backward(x2, mean, rstd, xn, z)
+        ctx.pr = (ln_w, ln_b, w1, b1, w2, b2)
+        ctx.cfg = (scale, act, shp)
+        return out.view(shp)
+
+    @staticmethod
+    def backward(ctx, dout):
+        x2, mean, rstd, xn, z = ctx.saved_tensors
+        ln_w, ln_b, w1, b1, w2, b2 = ctx.pr
+        scale, act, shp = ctx.cfg
+        sink = GradSink(ctx.pr)
+        do = dout.reshape(x2.shape).contiguous()
+        ops.linear_bwd_w(do, z, sink.buf(4), alpha=scale, b_act=act)       # dW2 += s * do^T act(z)
+        ops.colsum(do, sink.buf(5), scale)
+        dz = ops.linear_bwd_x(do, w2, epilogue=_act_epi(act), aux=z, alpha=scale)   # (do W2) * act'(z) * s
+        ops.linear_bwd_w(dz, xn, sink.buf(2))
+        ops.colsum(dz, sink.buf(3))
+        dxn = ops.linear_bwd_x(dz, w1)
+        dx = ops.layernorm_bwd(dxn, x2, ln_w, mean, rstd, do, sink.buf(0), sink.buf(1))
+        return (dx.view(shp),) + sink.results() + (None, None, None)
+
+
+# =================================================================================================
+# Attention core on projected q/k/v laid out [B, T, H, dk] (i.e. the Linear outputs, untransposed)
+# scores live in [H, B, T1, ldp] so that for one head the (b, i) rows are uniformly strided.
+# =================================================================================================
+def _ldp(T2):
+    return (T2 + 3) // 4 * 4
+
+
+def attn_scores_fwd(qu, qv, k, p, mask, B, T1, T2, H, dk):
+    D = H * dk
+    ldp = _ldp(T2)
+    ac = torch.empty(H * B * T1 * ldp, device=qu.device, dtype=torch.float32)
+    ops.gemm(qu, k, ac, T1, T2, dk, D, D, ldp, batch=(B, H), sA=(T1 * D, dk), sB=(T2 * D, dk),
+             sC=(T1 * ldp, B * T1 * ldp))
+    bd = None
+    if p is not None:
+        bd = torch.empty_like(ac)
+        ops.gemm(qv, p, bd, T1, T2, dk, D, D, ldp, batch=(B, H), sA=(T1 * D, dk), sB=(0, dk),
+                 sC=(T1 * ldp, B * T1 * ldp))
+    ops.softmax_fwd(ac, bd, mask, ac, H * B, B, T1, T2, ldp, 1.0 / math.sqrt(dk))
+    return ac  # now holds P
+
+
+def attn_context_fwd(P, v, B, T1, T2, H, dk):
+    D = H * dk
+    ldp = _ldp(T2)
+    ctxv = torch.empty(B * T1, D, device=v.device, dtype=torch.float32)
+    ops.gemm(P, v, ctxv, T1, dk, T2, ldp, D, D, transB=1, batch=(B, H), sA=(T1 * ldp, B * T1 * ldp),
+             sB=(T2 * D, dk), sC=(T1 * D, dk))
+    return ctxv
+
+
+def attn_core_bwd(dctx, P, qu, qv, k, v, p, B, T1, T2, H, dk):
+    """returns dqu, dqv (or None), dk, dv, dp (or None)"""
+    D = H * dk
+    ldp = _ldp(T2)
+    dev = dctx.device
+    sP = (T1 * ldp, B * T1 * ldp)
+    dP = torch.empty(H * B * T1 * ldp, device=dev, dtype=torch.float32)
+    # dP = dctx v^T
+    ops.gemm(dctx, v, dP, T1, T2, dk, D, D, ldp, batch=(B, H), sA=(T1 * D, dk), sB=(T2 * D, dk), sC=sP)
+    # dv = P^T dctx
+    dv = torch.empty(B * T2, D, device=dev, dtype=torch.float32)
+    ops.gemm(P, dctx, dv, T2, dk, T1, ldp, D, D, transA=1, transB=1, batch=(B, H), sA=sP, sB=(T1 * D, dk),
+             sC=(T2 * D, dk))
+    dbd = torch.zeros_like(dP) if p is not None else None
+    ops.softmax_bwd(P, dP, dbd, H * B, T1, T2, ldp, 1.0 / math.sqrt(dk))   # dP <- d(ac)
+    dS = dP
+    dqu = torch.empty(B * T1, D, device=dev, dtype=torch.float32)
+    ops.gemm(dS, k, dqu, T1, dk, T2, ldp, D, D, transB=1, batch=(B, H), sA=sP, sB=(T2 * D, dk), sC=(T1 * D, dk))
+    dkk = torch.empty(B * T2, D, device=dev, dtype=torch.float32)
+    ops.gemm(dS, qu, dkk, T2, dk, T1, ldp, D, D, transA=1, transB=1, batch=(B, H), sA=sP, sB=(T1 * D, dk),
+             sC=(T2 * D, dk))
+    dqv = dp = None
+    if p is not None:
+        dqv = torch.empty(B * T1, D, device=dev, dtype=torch.float32)
+        ops.gemm(dbd, p, dqv, T1, dk, T2, ldp, D, D, transB=1, batch=(B, H), sA=sP, sB=(0, dk), sC=(T1 * D, dk))
+        # dp[j, h, :] = sum_{b,i} dbd[h, b, i, j] * qv[b, i, h, :]   (reduction over B*T1 rows, split-K)
+        dp = torch.zeros(T2, D, device=dev, dtype=torch.float32)
+        ops.gemm(dbd, qv, dp, T2, dk, B * T1, ldp, D, D, transA=1, transB=1, batch=(1, H),
+                 sA=(0, B * T1 * ldp), sB=(0, dk), sC=(0, dk), splitk=max(2, ops.auto_splitk(T2, dk, B * T1) // H + 1))
+    return dqu, dqv, dkk, dv, dp
+
+
+class MHABlockFn(torch.autograd.Function):
+    """out = x + Wo . Attention(LN(x) [, memory]) with optional legacy relative positions.
+
+    reference: transformer/attention.py:16-114 (MultiHeadedAttention), :117-206
+    (RelPositionMultiHeadedAttention), conformer/encoder_layer.py:106-129,
+    transformer/decoder_layer.py:82-121 (self-attention and source attention with pre-norm).
+    params: ln_w, ln_b, wq, bq, wk, bk, wv, bv, wo, bo [, wpos, pos_u, pos_v]
+    """
+
+    @staticmethod
+    def forward(ctx, x, memory, pos_emb, mask, H, eps, last_query_only, *params):
+        ln_w, ln_b, wq, bq, wk, bk, wv, bv, wo, bo = params[:10]
+        rel = len(params) > 10
+        B, T1f, D = x.shape
+        dk = D // H
+        x2 = x.reshape(-1, D).contiguous()
+        xn, mean, rstd = ops.layernorm_fwd(x2, ln_w, ln_b, eps)
+        if memory is None:
+            kv_in, T2 = xn, T1f
+        else:
+            kv_in, T2 = memory.reshape(-1, D).contiguous(), memory.shape[1]
+        if last_query_only:   # cached decoding: only the newest position queries (decoder_layer.py:88-101)
+            xq = xn.view(B, T1f, D)[:, -1, :].contiguous()
+            res = x2.view(B, T1f, D)[:, -1, :].contiguous()
+            T1 = 1
+        else:
+            xq, res, T1 = xn, x2, T1f
+        q = ops.linear_fwd(xq, wq, bq)
+        k = ops.linear_fwd(kv_in, wk, bk)
+        v = ops.linear_fwd(kv_in, wv, bv)
+        if rel:
+            wpos, pu, pv = params[10:13]
+            p = ops.linear_fwd(pos_emb.reshape(-1, D).contiguous(), wpos, None)
+            qu, qv = ops.add_bias2(q, pu.reshape(-1), pv.reshape(-1))
+        else:
+            p, qu, qv = None, q, None
+        P = attn_scores_fwd(qu, qv, k, p, mask, B, T1, T2, H, dk)
+        cx = attn_context_fwd(P, v, B, T1, T2, H, dk)
+        out = ops.linear_fwd(cx, wo, bo, R=res)
+        ctx.save_for_backward(x2, mean, rstd, xn, kv_in if memory is not None else None, qu, qv, k, v, p, P, cx,
+                              pos_emb)
+        ctx.pr = params
+        ctx.cfg = (B, T1, T2, H, dk, D, rel, memory is not None, last_query_only)
+        return out.view(B, T1, D)
+
+    @staticmethod
+    def backward(ctx, dout):
+        x2, mean, rstd, xn, mem2, qu, qv, k, v, p, P, cx, pos_emb = ctx.saved_tensors
+        B, T1, T2, H, dk, D, rel, cross, last = ctx.cfg
+        assert not last, "cached decoding path is inference-only"
+        params = ctx.pr
+        ln_w, ln_b, wq, bq, wk, bk, wv, bv, wo, bo = params[:10]
+        sink = GradSink(params)
+        do = dout.reshape(-1, D).contiguous()
+        ops.linear_bwd_w(do, cx, sink.buf(8))
+        ops.colsum(do, sink.buf(9))
+        dctx = ops.linear_bwd_x(do, wo)
+        dqu, dqv, dkk, dv, dp = attn_core_bwd(dctx, P, qu, qv, k, v, p, B, T1, T2, H, dk)
+        if rel:
+            wpos = params[10]
+            ops.colsum(dqu, sink.buf(11).view(-1))
+            ops.colsum(dqv, sink.buf(12).view(-1))
+            dq = ops.axpby(dqu, dqv, 1.0, 1.0)
+            ops.linear_bwd_w(dp, pos_emb.reshape(-1, D).contiguous(), sink.buf(10))
+        else:
+            dq = dqu
+        kv_in = mem2 if cross else xn
+        ops.linear_bwd_w(dq, xn, sink.buf(2))
+        ops.colsum(dq, sink.buf(3))
+        ops.linear_bwd_w(dkk, kv_in, sink.buf(4))
+        ops.colsum(dkk, sink.buf(5))
+        ops.linear_bwd_w(dv, kv_in, sink.buf(6))
+        ops.colsum(dv, sink.buf(7))
+        dxn = ops.linear_bwd_x(dq, wq)
+        dmem = None
+        if cross:
+            dmem = ops.linear_bwd_x(dkk, wk)
+            ops.linear_bwd_x(dv, wv, out=dmem, beta=1.0)
+            dmem = dmem.view(B, T2, D)
+        else:
+            ops.linear_bwd_x(dkk, wk, out=dxn, beta=1.0)
+            ops.linear_bwd_x(dv, wv, out=dxn, beta=1.0)
+        dx = ops.layernorm_bwd(dxn, x2, ln_w, mean, rstd, do, sink.buf(0), sink.buf(1))
+        return (dx.view(B, T1, D), dmem, None, None, None, None, None) + sink.results()
+
+
+# =================================================================================================
+# Conformer convolution module with pre-LayerNorm and residual
+# reference: conformer/convolution.py:13-79, conformer/encoder_layer.py:132-138
+# params: ln_w, ln_b, pw1_w [2C,C,1], pw1_b, dw_w [C,1,K], dw_b, bn_w, bn_b, pw2_w [C,C,1], pw2_b
+# buffers: running_mean, running_var (updated in training mode)
+# =================================================================================================
+class ConvModuleBlockFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, running_mean, running_var, training, act, eps, bn_eps, bn_momentum, *params):
+        ln_w, ln_b, w1, b1, wd, bd_, g, be, w2, b2 = params
+        B, T, D = x.shape
+        Cc = w2.shape[0]
+        K = wd.shape[-1]
+        M = B * T
+        x2 = x.reshape(M, D).contiguous()
+        xn, mean, rstd = ops.layernorm_fwd(x2, ln_w, ln_b, eps)
+        a = ops.linear_fwd(xn, w1.view(2 * Cc, D), b1)               # pointwise conv 1  [M, 2C]
+        gl = ops.glu_fwd(a, Cc)                                      # [M, C]
+        d = ops.dwconv_fwd(gl, wd.view(Cc, K), bd_, B, T, Cc, K)     # depthwise conv over time
+        if training:
+            bmean, brstd = ops.bn_stats(d, M, Cc, bn_eps, bn_momentum, running_mean, running_var)
+        else:
+            bmean = running_mean
+            brstd = ops.axpby(running_var, None, 1.0, 0.0)
+            brstd = torch.rsqrt_(brstd.add_(bn_eps))  # tiny [C] host-issued op on eval path only
+        e = ops.bn_apply(d, bmean, brstd, g, be, M, Cc, act)
+        out = ops.linear_fwd(e, w2.view(Cc, Cc), b2, R=x2)
+        ctx.save_for_backward(x2, mean, rstd, xn, a, gl, d, bmean, brstd, e)
+        ctx.pr = params
+        ctx.cfg = (B, T, D, Cc, K, act, training)
+        return out.view(B, T, D)
+
+    @staticmethod
+    def backward(ctx, dout):
+        x2, mean, rstd, xn, a, gl, d, bmean, brstd, e = ctx.saved_tensors
+        ln_w, ln_b, w1, b1, wd, bd_, g, be, w2, b2 = ctx.pr
+        B, T, D, Cc, K, act, training = ctx.cfg
+        M = B * T
+        sink = GradSink(ctx.pr)
+        do = dout.reshape(M, D).contiguous()
+        ops.linear_bwd_w(do, e, sink.buf(8).view(Cc, Cc))
+        ops.colsum(do, sink.buf(9))
+        de = ops.linear_bwd_x(do, w2.view(Cc, Cc))
+        dd = ops.bn_bwd(de, d, bmean, brstd, g, be, sink.buf(6), sink.buf(7), M, Cc, act, training)
+        dgl = ops.dwconv_bwd_x(dd, wd.view(Cc, K), B, T, Cc, K)
+        ops.dwconv_bwd_w(dd, gl, sink.buf(4).view(Cc, K), sink.buf(5), B, T, Cc, K)
+        da = ops.glu_bwd(dgl, a, Cc)
+        ops.linear_bwd_w(da, xn, sink.buf(2).view(2 * Cc, D))
+        ops.colsum(da, sink.buf(3))
+        dxn = ops.linear_bwd_x(da, w1.view(2 * Cc, D))
+        dx = ops.layernorm_bwd(dxn, x2, ln_w, mean, rstd, do, sink.buf(0), sink.buf(1))
+        return (dx.view(B, T, D), None, None, None, None, None, None, None) + sink.results()
+
+
+# =================================================================================================
+# Conv2dSubsampling (1/4 length): conv3x3 s2 + ReLU, conv3x3 s2 + ReLU, Linear, x * sqrt(d)
+# reference: transformer/subsampling.py:14-59; embedding.py:80-91,143-161 (x * xscale)
+# params: c1_w [C,1,3,3], c1_b, c2_w [C,C,3,3], c2_b, lin_w [D, C*W2], lin_b
+# =================================================================================================
+_TAPS_FWD = [(kh, kw) for kh in range(3) for kw in range(3)]
+# stride-parity classes of the input gradient: (ph, pw) -> [(kh, kw)] in eamd_conv2_weight_prep order
+_CLASSES = [((0, 0), [(0, 0), (0, 2), (2, 0), (2, 2)]), ((0, 1), [(0, 1), (2, 1)]),
+            ((1, 0), [(1, 0), (1, 2)]), ((1, 1), [(1, 1)])]
+
+
+class Conv2dSubsamplingFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, xscale, c1_w, c1_b, c2_w, c2_b, lin_w, lin_b):
+        B, T, F = x.shape
+        Cc = c1_w.shape[0]
+        D = lin_w.shape[0]
+        H1, W1 = (T - 3) // 2 + 1, (F - 3) // 2 + 1
+        H2, W2 = (H1 - 3) // 2 + 1, (W1 - 3) // 2 + 1
+        assert lin_w.shape[1] == Cc * W2
+        x = x.contiguous()
+        y1 = ops.conv1_fwd(x, c1_w, c1_b, B, T, F, Cc)                       # [B,H1,W1,C] NHWC, ReLU'd
+        wf, wd = ops.conv2_weight_prep(c2_w)
+        g = ops.make_gather(Cc, _TAPS_FWD, H2, W2, H1, W1, 2, 2)
+        M2 = B * H2 * W2
+        y2 = torch.empty(M2, Cc, device=x.device, dtype=torch.float32)
+        ops.gemm(y1, wf, y2, M2, Cc, 9 * Cc, 9 * Cc, Cc, Cc, transB=1, bias=c2_b, epilogue=EPI_RELU, gather=g)
+        # Linear over (c, f) features: our rows are (f, c)-ordered, so permute the weight columns
+        wl = torch.empty(D, W2 * Cc, device=x.device, dtype=torch.float32)
+        ops.permute4(lin_w, wl, (D, Cc, W2, 1), (W2 * Cc, 1, Cc, 0))
+        out = ops.linear_fwd(y2.view(B * H2, W2 * Cc), wl, lin_b, alpha=xscale)
+        ctx.save_for_backward(x, y1, y2, wd, wl)
+        ctx.pr = (c1_w, c1_b, c2_w, c2_b, lin_w, lin_b)
+        ctx.cfg = (B, T, F, Cc, D, H1, W1, H2, W2, xscale)
+        return out.view(B, H2, D)
+
+    @staticmethod
+    def backward(ctx, dout):
+        x, y1, y2, wd, wl = ctx.saved_tensors
+        c1_w, c1_b, c2_w, c2_b, lin_w, lin_b = ctx.pr
+        B, T, F, Cc, D, H1, W1, H2, W2, xscale = ctx.cfg
+        sink = GradSink(ctx.pr)
+        dev = x.device
+        do = dout.reshape(B * H2, D).contiguous()
+        y2v = y2.view(B * H2, W2 * Cc)
+        # Linear: weight grad in permuted column order, then un-permute-accumulate
+        dwl = torch.zeros(D, W2 * Cc, device=dev, dtype=torch.float32)
+        ops.linear_bwd_w(do, y2v, dwl, alpha=xscale)
+        ops.permute4(dwl, sink.buf(4), (D, W2, Cc, 1), (W2 * Cc, 1, W2, 0), accumulate=True)
+        ops.colsum(do, sink.buf(5), xscale)
+        dy2 = ops.linear_bwd_x(do, wl, epilogue=EPI_MUL_RELU_MASK, aux=y2v, alpha=xscale)   # [B*H2, W2*C]
+        dy2 = dy2.view(B * H2 * W2, Cc)
+        M2 = B * H2 * W2
+        ops.colsum(dy2, sink.buf(3))
+        # conv2 weight gradient: dwf[(tap, ci), co] = sum_pos col[pos, (tap, ci)] * dy2[pos, co]
+        dwf = torch.zeros(9 * Cc, Cc, device=dev, dtype=torch.float32)
+        g = ops.make_gather(Cc, _TAPS_FWD, H2, W2, H1, W1, 2, 2)
+        tile = 128 if Cc % 128 == 0 else 64
+        ntile = (9 * Cc // tile) * ((Cc + tile - 1) // tile)
+        sk = max(2, min(64, (768 + ntile - 1) // ntile, max(1, M2 // 256)))
+        ops.gemm(y1, dy2, dwf, 9 * Cc, Cc, M2, 9 * Cc, Cc, Cc, transA=1, transB=1, gather=g, splitk=sk, tile=tile)
+        ops.conv2_weight_grad(dwf, sink.buf(2), Cc, Cc)
+        # conv2 input gradient, one implicit GEMM per stride-parity class, ReLU mask of conv1 fused
+        dy1 = torch.empty_like(y1)
+        q0 = 0
+        for (ph, pw), taps in _CLASSES:
+            Ho, Wo = (H1 - ph + 1) // 2, (W1 - pw + 1) // 2
+            if Ho > 0 and Wo > 0:
+                gt = ops.make_gather(Cc, [((ph - kh) // 2, (pw - kw) // 2) for kh, kw in taps], Ho, Wo, H2, W2, 1, 1)
+                cm = ops.make_rowmap(Ho, Wo, H1, W1, 2, ph, 2, pw)
+                nt = len(taps)
+                ops.gemm(dy2, wd, dy1, B * Ho * Wo, Cc, nt * Cc, nt * Cc, Cc, Cc, transB=1, b_off=q0 * Cc * Cc,
+                         gather=gt, cmap=cm, epilogue=EPI_MUL_RELU_MASK, aux=y1, ldaux=Cc)
+            q0 += len(taps)
+        ops.conv1_bwd_w(dy1, x, sink.buf(0), sink.buf(1), B, T, F, Cc)
+        return (None, None) + sink.results()
+
+
+# =================================================================================================
+# Embedding + absolute positional encoding (decoder input layer)
+# reference: decoder.py:83-86 (Embedding, PositionalEncoding), embedding.py:80-91
+# =================================================================================================
+class EmbedPEFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, tokens, table, pe, scale, pos_offset):
+        B, U = tokens.shape
+        tok = tokens.contiguous()
+        out = ops.embed_pe(tok, table, pe, U, scale, pos_offset)
+        ctx.save_for_backward(tok)
+        ctx.pr = (table,)
+        ctx.scale = scale
+        return out.view(B, U, table.shape[1])
+
+    @staticmethod
+    def backward(ctx, dout):
+        (tok,) = ctx.saved_tensors
+        sink = GradSink(ctx.pr)
+        ops.embed_bwd(tok, dout.reshape(-1, dout.shape[-1]).contiguous(), sink.buf(0), ctx.scale)
+        return (None,) + sink.results() + (None, None, None)
+
+
+class PosEncFn(torch.autograd.Function):
+    """x * scale + pe[:T]  (PositionalEncoding on float inputs, embedding.py:80-91)"""
+
+    @staticmethod
+    def forward(ctx, x, pe, scale):
+        B, T, D = x.shape
+        ctx.scale = scale
+        return ops.posenc(x.reshape(-1, D).contiguous(), pe, T, scale).view(B, T, D)
+
+    @staticmethod
+    def backward(ctx, dout):
+        return ops.axpby(dout.contiguous(), None, ctx.scale, 0.0), None, None
+
+
+# =================================================================================================
+# Losses: gradients are produced by the forward kernels; backward only rescales by the upstream
+# scalar, read on the device (no host synchronisation).
+# =================================================================================================
+class CTCLossFn(torch.autograd.Function):
+    """sum_b -log p(y_b | x_b) / B on raw activations [B, T, V].
+    reference: ctc.py:53-66,67-123 (loss_fn + forward), espnet2/asr/ctc.py:44-108."""
+
+    @staticmethod
+    def forward(ctx, acts, ys_pad, hlens, blank, ignore_id):
+        B = acts.shape[0]
+        nll, grad = ops.ctc_loss(acts.contiguous(), ys_pad, hlens, blank, ignore_id, 1.0 / B,
+                                 want_grad=acts.requires_grad)
+        ctx.save_for_backward(grad)
+        ctx.nll = nll
+        return ops.reduce_sum(nll, 1.0 / B)
+
+    @staticmethod
+    def backward(ctx, g):
+        (grad,) = ctx.saved_tensors
+        return ops.scale_dev(grad, g.contiguous(), 1.0, out=grad), None, None, None, None
+
+
+class LabelSmoothingLossFn(torch.autograd.Function):
+    """reference: transformer/label_smoothing_loss.py:44-63 (normalize_length=False => / batch)."""
+
+    @staticmethod
+    def forward(ctx, logits, target, smoothing, ignore_id, denom):
+        V = logits.shape[-1]
+        lg = logits.reshape(-1, V).contiguous()
+        tg = target.reshape(-1).contiguous()
+        loss_rows, correct, grad = ops.lsm_loss(lg, tg, smoothing, 1.0 / denom, ignore_id,
+                                                want_grad=logits.requires_grad)
+        ctx.save_for_backward(grad)
+        ctx.shp = logits.shape
+        ctx.mark_non_differentiable(correct)
+        return ops.reduce_sum(loss_rows, 1.0 / denom), correct
+
+    @staticmethod
+    def backward(ctx, g, _gc):
+        (grad,) = ctx.saved_tensors
+        return ops.scale_dev(grad, g.contiguous(), 1.0, out=grad).view(ctx.shp), None, None, None, None
+
+
+class WeightedSumFn(torch.autograd.Function):
+    """alpha * a + (1 - alpha) * b on 0-dim device scalars (e2e_asr_transformer.py:219-232)."""
+
+    @staticmethod
+    def forward(ctx, a, b, alpha):
+        ctx.alpha = alpha
+        return ops.axpby(a.reshape(1), b.reshape(1), alpha, 1.0 - alpha).reshape(())
+
+    @staticmethod
+    def backward(ctx, g):
+        g1 = g.reshape(1).contiguous()
+        return (ops.axpby(g1, None, ctx.alpha, 0.0).reshape(()),
+                ops.axpby(g1, None, 1.0 - ctx.alpha, 0.0).reshape(()), None)

@@ -1,0 +1,684 @@
+"""Host-side mirror of the reference's nn building blocks (same class names, constructor
+arguments, parameter names/shapes, so reference checkpoints load key-for-key) whose forward
+passes run on the espnet_amd HIP kernels.
+
+reference files mirrored (espnet/nets/pytorch_backend/...):
+  transformer/{layer_norm,embedding,subsampling,attention,positionwise_feed_forward,
+  encoder_layer,encoder,decoder_layer,decoder,label_smoothing_loss,mask,add_sos_eos}.py,
+  conformer/{convolution,encoder_layer,encoder,swish}.py, ctc.py, nets_utils.py
+torch.nn.Linear / Conv / BatchNorm objects below are parameter containers only (default init and
+state_dict layout identical to the reference); their torch forward is never called.
+"""
+import math
+
+import numpy as np
+import torch
+
+from .. import functional as F_
+from .. import ops
+
+_EPS_LN = 1e-12
+
+
+def _act_id(activation_type):
+    if activation_type in ("swish", None) or isinstance(activation_type, Swish):
+        return ops.ACT_SWISH
+    if activation_type == "relu" or isinstance(activation_type, torch.nn.ReLU):
+        return ops.ACT_RELU
+    raise NotImplementedError(f"activation {activation_type!r} has no HIP kernel (relu, swish supported)")
+
+
+def _no_dropout(module, p):
+    if module.training and p > 0.0:
+        raise NotImplementedError(
+            "dropout > 0 in training mode is not wired into the fused HIP blocks yet; "
+            "set dropout_rate=0.0 (parity and benchmark runs do)")
+
+
+class Swish(torch.nn.Module):
+    """reference: conformer/swish.py:13-18"""
+
+    def forward(self, x):
+        y = torch.empty_like(x)
+        ops._lib.check(ops._lib.lib().eamd_act_fwd(ops.ptr(x.contiguous()), ops.ptr(y), x.numel(), ops.ACT_SWISH,
+                                                   ops.stream_ptr()), "eamd_act_fwd")
+        return y
+
+
+def get_activation(act):
+    """reference: nets_utils.py:485-498"""
+    table = {"relu": torch.nn.ReLU, "swish": Swish}
+    if act not in table:
+        raise NotImplementedError(f"activation {act!r}: only relu and swish have HIP kernels")
+    return table[act]()
+
+
+class LayerNorm(torch.nn.LayerNorm):
+    """reference: transformer/layer_norm.py:12-38 (eps 1e-12, last dim)"""
+
+    def __init__(self, nout, dim=-1):
+        super().__init__(nout, eps=_EPS_LN)
+        assert dim == -1, "only last-dim LayerNorm is on the ASR path"
+
+    def forward(self, x):
+        return F_.LayerNormFn.apply(x, self.weight, self.bias, self.eps)
+
+
+# ---- masks / padding helpers (integer work, host side like the reference) ----------------------
+def make_pad_mask(lengths, maxlen=None):
+    """reference: nets_utils.py:64-176 (length_dim=-1, xs=None case). True at padded positions."""
+    if not isinstance(lengths, (list, tuple)):
+        lengths = [int(v) for v in lengths.tolist()]
+    maxlen = int(max(lengths)) if maxlen is None else maxlen
+    ar = np.arange(maxlen)[None, :]
+    return torch.from_numpy(ar >= np.asarray(lengths)[:, None])
+
+
+def make_non_pad_mask(lengths, maxlen=None):
+    """reference: nets_utils.py:179-265"""
+    return ~make_pad_mask(lengths, maxlen)
+
+
+def subsequent_mask(size, device="cpu", dtype=torch.bool):
+    """reference: transformer/mask.py:20-38"""
+    return torch.tril(torch.ones(size, size, device=device, dtype=dtype))
+
+
+def target_mask(ys_in_pad, ignore_id):
+    """reference: transformer/mask.py:41-51"""
+    ys_mask = ys_in_pad != ignore_id
+    m = subsequent_mask(ys_mask.size(-1), device=ys_mask.device).unsqueeze(0)
+    return ys_mask.unsqueeze(-2) & m
+
+
+def pad_list(xs, pad_value):
+    """reference: nets_utils.py:34-61"""
+    n = len(xs)
+    maxlen = max(x.size(0) for x in xs)
+    pad = xs[0].new_full((n, maxlen) + tuple(xs[0].shape[1:]), pad_value)
+    for i, x in enumerate(xs):
+        pad[i, : x.size(0)] = x
+    return pad
+
+
+def subsampled_lengths(ilens, tmax=None):
+    """valid frames after Conv2dSubsampling's mask[:, :, :-2:2][:, :, :-2:2] (subsampling.py:59)."""
+    out = []
+    for n in ilens:
+        n = int(n)
+        t = n if tmax is None else tmax
+        a = max(0, -(-min(n, t - 2) // 2))            # true entries of mask[:-2:2]
+        t1 = max(0, -(-(t - 2) // 2))
+        out.append(max(0, -(-min(a, t1 - 2) // 2)))
+    return out
+
+
+def _mask_u8(mask, device):
+    """bool/uint8 mask of shape (B,1,T2) or (B,T1,T2) -> contiguous uint8 on device (None passes)."""
+    if mask is None:
+        return None
+    m = mask.to(device=device, dtype=torch.uint8, non_blocking=True)
+    return m.contiguous()
+
+
+# ---- positional encodings -----------------------------------------------------------------------
+class PositionalEncoding(torch.nn.Module):
+    """reference: transformer/embedding.py:35-91.  Table is built on the host in fp32 exactly as the
+    reference does and cached on the device; x*sqrt(d)+pe runs in eamd_posenc."""
+
+    def __init__(self, d_model, dropout_rate, max_len=5000, reverse=False):
+        super().__init__()
+        self.d_model = d_model
+        self.reverse = reverse
+        self.xscale = math.sqrt(d_model)
+        self.dropout_rate = dropout_rate
+        self.pe = None
+        self.extend_pe(max_len, torch.device("cpu"))
+        self._register_load_state_dict_pre_hook(self._pre_hook)
+
+    @staticmethod
+    def _pre_hook(state_dict, prefix, *args):
+        state_dict.pop(prefix + "pe", None)   # embedding.py:14-32 (back-compat)
+
+    def extend_pe(self, length, device):
+        if self.pe is not None and self.pe.size(0) >= length:
+            if self.pe.device != device:
+                self.pe = self.pe.to(device)
+            return
+        pe = torch.zeros(length, self.d_model)
+        if self.reverse:
+            position = torch.arange(length - 1, -1, -1.0, dtype=torch.float32).unsqueeze(1)
+        else:
+            position = torch.arange(0, length, dtype=torch.float32).unsqueeze(1)
+        div_term = torch.exp(torch.arange(0, self.d_model, 2, dtype=torch.float32)
+                             * -(math.log(10000.0) / self.d_model))
+        pe[:, 0::2] = torch.sin(position * div_term)
+        pe[:, 1::2] = torch.cos(position * div_term)
+        self.pe = pe.to(device)
+
+    def forward(self, x):
+        _no_dropout(self, self.dropout_rate)
+        self.extend_pe(x.size(1), x.device)
+        return F_.PosEncFn.apply(x, self.pe, self.xscale)
+
+
+class RelPositionalEncoding(PositionalEncoding):
+    """reference: transformer/embedding.py:131-161 (legacy: reversed table of max_len, first T rows)."""
+
+    def __init__(self, d_model, dropout_rate, max_len=5000):
+        super().__init__(d_model, dropout_rate, max_len, reverse=True)
+
+    def pos_emb(self, T, device):
+        self.extend_pe(T, device)
+        return self.pe[:T]
+
+    def forward(self, x):
+        _no_dropout(self, self.dropout_rate)
+        y = ops.axpby(x.contiguous(), None, self.xscale, 0.0)
+        return y, self.pos_emb(x.size(1), x.device).unsqueeze(0)
+
+
+# ---- input layers -------------------------------------------------------------------------------
+class Conv2dSubsampling(torch.nn.Module):
+    """reference: transformer/subsampling.py:14-59"""
+
+    def __init__(self, idim, odim, dropout_rate, pos_enc=None):
+        super().__init__()
+        self.conv = torch.nn.Sequential(torch.nn.Conv2d(1, odim, 3, 2), torch.nn.ReLU(),
+                                        torch.nn.Conv2d(odim, odim, 3, 2), torch.nn.ReLU())
+        self.out = torch.nn.Sequential(
+            torch.nn.Linear(odim * (((idim - 1) // 2 - 1) // 2), odim),
+            pos_enc if pos_enc is not None else PositionalEncoding(odim, dropout_rate))
+        if odim % 64 != 0:
+            raise NotImplementedError("Conv2dSubsampling HIP path needs odim % 64 == 0 (implicit-GEMM tiles)")
+
+    def forward(self, x, x_mask):
+        pos = self.out[1]
+        _no_dropout(pos, pos.dropout_rate)
+        y = F_.Conv2dSubsamplingFn.apply(x, pos.xscale, self.conv[0].weight, self.conv[0].bias,
+                                         self.conv[2].weight, self.conv[2].bias, self.out[0].weight,
+                                         self.out[0].bias)
+        if isinstance(pos, RelPositionalEncoding):
+            y = (y, pos.pos_emb(y.size(1), y.device).unsqueeze(0))
+        else:
+            pos.extend_pe(y.size(1), y.device)
+            y = F_.PosEncFn.apply(y, pos.pe, 1.0)   # x*xscale already applied in the Linear epilogue
+        if x_mask is None:
+            return y, None
+        return y, x_mask[:, :, :-2:2][:, :, :-2:2]
+
+
+# ---- attention ---------------------------------------------------------------------------------
+class MultiHeadedAttention(torch.nn.Module):
+    """reference: transformer/attention.py:16-114.  Standalone forward = attention without the
+    surrounding LayerNorm/residual (used by external callers); encoder/decoder layers call the
+    fused block instead."""
+
+    def __init__(self, n_head, n_feat, dropout_rate):
+        super().__init__()
+        assert n_feat % n_head == 0
+        self.d_k = n_feat // n_head
+        self.h = n_head
+        self.linear_q = torch.nn.Linear(n_feat, n_feat)
+        self.linear_k = torch.nn.Linear(n_feat, n_feat)
+        self.linear_v = torch.nn.Linear(n_feat, n_feat)
+        self.linear_out = torch.nn.Linear(n_feat, n_feat)
+        self.attn = None
+        self.dropout_rate = dropout_rate
+
+    def block_params(self):
+        return (self.linear_q.weight, self.linear_q.bias, self.linear_k.weight, self.linear_k.bias,
+                self.linear_v.weight, self.linear_v.bias, self.linear_out.weight, self.linear_out.bias)
+
+
+class RelPositionMultiHeadedAttention(MultiHeadedAttention):
+    """reference: transformer/attention.py:117-206 (legacy rel_shift, zero_triu=False)"""
+
+    def __init__(self, n_head, n_feat, dropout_rate):
+        super().__init__(n_head, n_feat, dropout_rate)
+        self.linear_pos = torch.nn.Linear(n_feat, n_feat, bias=False)
+        self.pos_bias_u = torch.nn.Parameter(torch.Tensor(self.h, self.d_k))
+        self.pos_bias_v = torch.nn.Parameter(torch.Tensor(self.h, self.d_k))
+        torch.nn.init.xavier_uniform_(self.pos_bias_u)
+        torch.nn.init.xavier_uniform_(self.pos_bias_v)
+
+    def block_params(self):
+        return super().block_params() + (self.linear_pos.weight, self.pos_bias_u, self.pos_bias_v)
+
+
+def mha_block(norm, attn, x, memory, pos_emb, mask, last_query_only=False):
+    """x + attn(LN(x)[, memory]) through the fused HIP block."""
+    _no_dropout(attn, attn.dropout_rate)
+    return F_.MHABlockFn.apply(x.contiguous(), memory, pos_emb, _mask_u8(mask, x.device), attn.h, norm.eps,
+                               last_query_only, norm.weight, norm.bias, *attn.block_params())
+
+
+class PositionwiseFeedForward(torch.nn.Module):
+    """reference: transformer/positionwise_feed_forward.py:12-32"""
+
+    def __init__(self, idim, hidden_units, dropout_rate, activation=None):
+        super().__init__()
+        self.w_1 = torch.nn.Linear(idim, hidden_units)
+        self.w_2 = torch.nn.Linear(hidden_units, idim)
+        self.dropout_rate = dropout_rate
+        self.activation = activation if activation is not None else torch.nn.ReLU()
+        self.act_id = _act_id(self.activation)
+
+
+def ffn_block(norm, ff, x, scale):
+    _no_dropout(ff, ff.dropout_rate)
+    return F_.FFNBlockFn.apply(x.contiguous(), norm.weight, norm.bias, ff.w_1.weight, ff.w_1.bias, ff.w_2.weight,
+                               ff.w_2.bias, scale, ff.act_id, norm.eps)
+
+
+class ConvolutionModule(torch.nn.Module):
+    """reference: conformer/convolution.py:13-79"""
+
+    def __init__(self, channels, kernel_size, activation=None, bias=True):
+        super().__init__()
+        assert (kernel_size - 1) % 2 == 0
+        self.pointwise_conv1 = torch.nn.Conv1d(channels, 2 * channels, kernel_size=1, stride=1, padding=0, bias=bias)
+        self.depthwise_conv = torch.nn.Conv1d(channels, channels, kernel_size, stride=1,
+                                              padding=(kernel_size - 1) // 2, groups=channels, bias=bias)
+        self.norm = torch.nn.BatchNorm1d(channels)
+        self.pointwise_conv2 = torch.nn.Conv1d(channels, channels, kernel_size=1, stride=1, padding=0, bias=bias)
+        self.activation = activation if activation is not None else torch.nn.ReLU()
+        self.act_id = _act_id(self.activation)
+        assert bias, "bias=False variant is not on the path"
+
+
+def conv_block(norm, cm, x):
+    bn = cm.norm
+    if cm.training:
+        with torch.no_grad():
+            bn.num_batches_tracked += 1
+    return F_.ConvModuleBlockFn.apply(
+        x.contiguous(), bn.running_mean, bn.running_var, cm.training, cm.act_id, norm.eps, bn.eps, bn.momentum,
+        norm.weight, norm.bias, cm.pointwise_conv1.weight, cm.pointwise_conv1.bias, cm.depthwise_conv.weight,
+        cm.depthwise_conv.bias, bn.weight, bn.bias, cm.pointwise_conv2.weight, cm.pointwise_conv2.bias)
+
+
+# ---- encoder layers ----------------------------------------------------------------------------
+class ConformerEncoderLayer(torch.nn.Module):
+    """reference: conformer/encoder_layer.py:16-157 (normalize_before=True, concat_after=False)"""
+
+    def __init__(self, size, self_attn, feed_forward, feed_forward_macaron, conv_module, dropout_rate,
+                 normalize_before=True, concat_after=False):
+        super().__init__()
+        if not normalize_before or concat_after:
+            raise NotImplementedError("only pre-norm without concat_after is on the HIP path")
+        self.self_attn = self_attn
+        self.feed_forward = feed_forward
+        self.feed_forward_macaron = feed_forward_macaron
+        self.conv_module = conv_module
+        self.norm_ff = LayerNorm(size)
+        self.norm_mha = LayerNorm(size)
+        if feed_forward_macaron is not None:
+            self.norm_ff_macaron = LayerNorm(size)
+            self.ff_scale = 0.5
+        else:
+            self.ff_scale = 1.0
+        if self.conv_module is not None:
+            self.norm_conv = LayerNorm(size)
+            self.norm_final = LayerNorm(size)
+        self.dropout_rate = dropout_rate
+        self.size = size
+        self.normalize_before = normalize_before
+        self.concat_after = concat_after
+
+    def forward(self, x_input, mask, cache=None):
+        assert cache is None, "encoder-side cache is not used on the ASR path"
+        _no_dropout(self, self.dropout_rate)
+        if isinstance(x_input, tuple):
+            x, pos_emb = x_input
+        else:
+            x, pos_emb = x_input, None
+        if self.feed_forward_macaron is not None:
+            x = ffn_block(self.norm_ff_macaron, self.feed_forward_macaron, x, self.ff_scale)
+        x = mha_block(self.norm_mha, self.self_attn, x, None, pos_emb, mask)
+        if self.conv_module is not None:
+            x = conv_block(self.norm_conv, self.conv_module, x)
+        x = ffn_block(self.norm_ff, self.feed_forward, x, self.ff_scale)
+        if self.conv_module is not None:
+            x = self.norm_final(x)
+        if pos_emb is not None:
+            return (x, pos_emb), mask
+        return x, mask
+
+
+class TransformerEncoderLayer(torch.nn.Module):
+    """reference: transformer/encoder_layer.py (pre-norm, no concat)"""
+
+    def __init__(self, size, self_attn, feed_forward, dropout_rate, normalize_before=True, concat_after=False):
+        super().__init__()
+        if not normalize_before or concat_after:
+            raise NotImplementedError("only pre-norm without concat_after is on the HIP path")
+        self.self_attn = self_attn
+        self.feed_forward = feed_forward
+        self.norm1 = LayerNorm(size)
+        self.norm2 = LayerNorm(size)
+        self.dropout_rate = dropout_rate
+        self.size = size
+        self.normalize_before = normalize_before
+        self.concat_after = concat_after
+
+    def forward(self, x, mask, cache=None):
+        assert cache is None
+        _no_dropout(self, self.dropout_rate)
+        x = mha_block(self.norm1, self.self_attn, x, None, None, mask)
+        x = ffn_block(self.norm2, self.feed_forward, x, 1.0)
+        return x, mask
+
+
+class MultiSequential(torch.nn.ModuleList):
+    """reference: transformer/repeat.py:12-33 (state_dict keys `N.<name>` like nn.Sequential)"""
+
+    def forward(self, *args):
+        for m in self:
+            args = m(*args)
+        return args
+
+
+def repeat(N, fn):
+    return MultiSequential([fn(n) for n in range(N)])
+
+
+class ConformerEncoder(torch.nn.Module):
+    """reference: conformer/encoder.py:33-227"""
+
+    def __init__(self, idim, attention_dim=256, attention_heads=4, linear_units=2048, num_blocks=6,
+                 dropout_rate=0.1, positional_dropout_rate=0.1, attention_dropout_rate=0.0, input_layer="conv2d",
+                 normalize_before=True, concat_after=False, positionwise_layer_type="linear",
+                 positionwise_conv_kernel_size=1, macaron_style=False, pos_enc_layer_type="abs_pos",
+                 selfattention_layer_type="selfattn", activation_type="swish", use_cnn_module=False,
+                 cnn_module_kernel=31, padding_idx=-1):
+        super().__init__()
+        if pos_enc_layer_type == "abs_pos":
+            pos_enc_class = PositionalEncoding
+        elif pos_enc_layer_type == "rel_pos":
+            assert selfattention_layer_type == "rel_selfattn"
+            pos_enc_class = RelPositionalEncoding
+        else:
+            raise NotImplementedError("pos_enc_layer_type " + pos_enc_layer_type)
+        if input_layer != "conv2d":
+            raise NotImplementedError("input_layer=%r: only conv2d is on the HIP path" % (input_layer,))
+        if positionwise_layer_type != "linear":
+            raise NotImplementedError("positionwise_layer_type=%r (SURVEY.md §8f, next)" % positionwise_layer_type)
+        self.embed = Conv2dSubsampling(idim, attention_dim, dropout_rate,
+                                       pos_enc_class(attention_dim, positional_dropout_rate))
+        self.normalize_before = normalize_before
+        if selfattention_layer_type == "selfattn":
+            attn_class = MultiHeadedAttention
+        elif selfattention_layer_type == "rel_selfattn":
+            assert pos_enc_layer_type == "rel_pos"
+            attn_class = RelPositionMultiHeadedAttention
+        else:
+            raise NotImplementedError("selfattention_layer_type " + selfattention_layer_type)
+        self.encoders = repeat(
+            num_blocks,
+            lambda lnum: ConformerEncoderLayer(
+                attention_dim,
+                attn_class(attention_heads, attention_dim, attention_dropout_rate),
+                PositionwiseFeedForward(attention_dim, linear_units, dropout_rate, get_activation(activation_type)),
+                PositionwiseFeedForward(attention_dim, linear_units, dropout_rate, get_activation(activation_type))
+                if macaron_style else None,
+                ConvolutionModule(attention_dim, cnn_module_kernel, get_activation(activation_type))
+                if use_cnn_module else None,
+                dropout_rate, normalize_before, concat_after))
+        if self.normalize_before:
+            self.after_norm = LayerNorm(attention_dim)
+
+    def forward(self, xs, masks):
+        xs, masks = self.embed(xs, masks)
+        xs, masks = self.encoders(xs, masks)
+        if isinstance(xs, tuple):
+            xs = xs[0]
+        if self.normalize_before:
+            xs = self.after_norm(xs)
+        return xs, masks
+
+
+class TransformerEncoder(torch.nn.Module):
+    """reference: transformer/encoder.py:48-332 (selfattn + linear positionwise + conv2d input)"""
+
+    def __init__(self, idim, attention_dim=256, attention_heads=4, linear_units=2048, num_blocks=6,
+                 dropout_rate=0.1, positional_dropout_rate=0.1, attention_dropout_rate=0.0, input_layer="conv2d",
+                 pos_enc_class=PositionalEncoding, normalize_before=True, concat_after=False,
+                 positionwise_layer_type="linear", positionwise_conv_kernel_size=1, padding_idx=-1, **unused):
+        super().__init__()
+        if input_layer != "conv2d" or positionwise_layer_type != "linear":
+            raise NotImplementedError("only conv2d input + linear positionwise are on the HIP path")
+        self.embed = Conv2dSubsampling(idim, attention_dim, dropout_rate,
+                                       pos_enc_class(attention_dim, positional_dropout_rate))
+        self.normalize_before = normalize_before
+        self.encoders = repeat(
+            num_blocks,
+            lambda lnum: TransformerEncoderLayer(
+                attention_dim, MultiHeadedAttention(attention_heads, attention_dim, attention_dropout_rate),
+                PositionwiseFeedForward(attention_dim, linear_units, dropout_rate), dropout_rate,
+                normalize_before, concat_after))
+        if self.normalize_before:
+            self.after_norm = LayerNorm(attention_dim)
+
+    def forward(self, xs, masks):
+        xs, masks = self.embed(xs, masks)
+        xs, masks = self.encoders(xs, masks)
+        if self.normalize_before:
+            xs = self.after_norm(xs)
+        return xs, masks
+
+
+# ---- decoder ------------------------------------------------------------------------------------
+class DecoderLayer(torch.nn.Module):
+    """reference: transformer/decoder_layer.py:15-134"""
+
+    def __init__(self, size, self_attn, src_attn, feed_forward, dropout_rate, normalize_before=True,
+                 concat_after=False):
+        super().__init__()
+        if not normalize_before or concat_after:
+            raise NotImplementedError("only pre-norm without concat_after is on the HIP path")
+        self.size = size
+        self.self_attn = self_attn
+        self.src_attn = src_attn
+        self.feed_forward = feed_forward
+        self.norm1 = LayerNorm(size)
+        self.norm2 = LayerNorm(size)
+        self.norm3 = LayerNorm(size)
+        self.dropout_rate = dropout_rate
+        self.normalize_before = normalize_before
+        self.concat_after = concat_after
+
+    def forward(self, tgt, tgt_mask, memory, memory_mask, cache=None):
+        _no_dropout(self, self.dropout_rate)
+        if cache is None:
+            x = mha_block(self.norm1, self.self_attn, tgt, None, None, tgt_mask)
+        else:
+            assert cache.shape == (tgt.shape[0], tgt.shape[1] - 1, self.size)
+            q_mask = None if tgt_mask is None else tgt_mask[:, -1:, :]
+            x = mha_block(self.norm1, self.self_attn, tgt, None, None, q_mask, last_query_only=True)
+        x = mha_block(self.norm2, self.src_attn, x, memory, None, memory_mask)
+        x = ffn_block(self.norm3, self.feed_forward, x, 1.0)
+        if cache is not None:
+            x = torch.cat([cache, x], dim=1)
+        return x, tgt_mask, memory, memory_mask
+
+
+class Decoder(torch.nn.Module):
+    """reference: transformer/decoder.py:47-370 (embed input layer, selfattn layers)"""
+
+    def __init__(self, odim, selfattention_layer_type="selfattn", attention_dim=256, attention_heads=4,
+                 conv_wshare=4, conv_kernel_length=11, conv_usebias=False, linear_units=2048, num_blocks=6,
+                 dropout_rate=0.1, positional_dropout_rate=0.1, self_attention_dropout_rate=0.0,
+                 src_attention_dropout_rate=0.0, input_layer="embed", use_output_layer=True,
+                 pos_enc_class=PositionalEncoding, normalize_before=True, concat_after=False):
+        super().__init__()
+        if input_layer != "embed" or selfattention_layer_type != "selfattn":
+            raise NotImplementedError("only embed input + selfattn decoder layers are on the HIP path")
+        self._register_load_state_dict_pre_hook(self._pre_hook)
+        self.embed = torch.nn.Sequential(torch.nn.Embedding(odim, attention_dim),
+                                         pos_enc_class(attention_dim, positional_dropout_rate))
+        self.normalize_before = normalize_before
+        self.decoders = repeat(
+            num_blocks,
+            lambda lnum: DecoderLayer(
+                attention_dim, MultiHeadedAttention(attention_heads, attention_dim, self_attention_dropout_rate),
+                MultiHeadedAttention(attention_heads, attention_dim, src_attention_dropout_rate),
+                PositionwiseFeedForward(attention_dim, linear_units, dropout_rate), dropout_rate,
+                normalize_before, concat_after))
+        self.selfattention_layer_type = selfattention_layer_type
+        if self.normalize_before:
+            self.after_norm = LayerNorm(attention_dim)
+        self.output_layer = torch.nn.Linear(attention_dim, odim) if use_output_layer else None
+        self.odim = odim
+
+    @staticmethod
+    def _pre_hook(state_dict, prefix, *args):
+        # reference: decoder.py:34-44 (output_norm -> after_norm rename)
+        for k in list(state_dict):
+            if k.startswith(prefix + "output_norm."):
+                state_dict[k.replace("output_norm.", "after_norm.")] = state_dict.pop(k)
+
+    def _embed(self, tgt, pos_offset=0):
+        pos = self.embed[1]
+        _no_dropout(pos, pos.dropout_rate)
+        pos.extend_pe(tgt.size(1) + pos_offset, self.embed[0].weight.device)
+        return F_.EmbedPEFn.apply(tgt, self.embed[0].weight, pos.pe, pos.xscale, pos_offset)
+
+    def forward(self, tgt, tgt_mask, memory, memory_mask):
+        x = self._embed(tgt)
+        x, tgt_mask, memory, memory_mask = self.decoders(x, tgt_mask, memory, memory_mask)
+        if self.normalize_before:
+            x = self.after_norm(x)
+        if self.output_layer is not None:
+            x = F_.LinearFn.apply(x, self.output_layer.weight, self.output_layer.bias)
+        return x, tgt_mask
+
+    def forward_one_step(self, tgt, tgt_mask, memory, cache=None):
+        """reference: decoder.py:283-321"""
+        x = self._embed(tgt)
+        if cache is None:
+            cache = [None] * len(self.decoders)
+        new_cache = []
+        for c, decoder in zip(cache, self.decoders):
+            x, tgt_mask, memory, memory_mask = decoder(x, tgt_mask, memory, None, cache=c)
+            new_cache.append(x)
+        y = x[:, -1]
+        if self.normalize_before:
+            y = self.after_norm(y.contiguous())
+        if self.output_layer is not None:
+            y = F_.LinearFn.apply(y, self.output_layer.weight, self.output_layer.bias)
+            y = ops.log_softmax_rows(y.contiguous())
+        return y, new_cache
+
+    # ---- beam-search scorer API (reference: decoder.py:323-370, scorer_interface.py) ----
+    def init_state(self, x):
+        return None
+
+    def batch_init_state(self, x):
+        return None
+
+    def select_state(self, state, i, new_id=None):
+        return None if state is None else state[i]
+
+    def final_score(self, state):
+        return 0.0
+
+    def score(self, ys, state, x):
+        ys_mask = subsequent_mask(len(ys), device=x.device).unsqueeze(0)
+        logp, state = self.forward_one_step(ys.unsqueeze(0), ys_mask, x.unsqueeze(0), cache=state)
+        return logp.squeeze(0), state
+
+    def batch_score(self, ys, states, xs):
+        n_batch = len(ys)
+        n_layers = len(self.decoders)
+        if states[0] is None:
+            batch_state = None
+        else:
+            batch_state = [torch.stack([states[b][i] for b in range(n_batch)]) for i in range(n_layers)]
+        ys_mask = subsequent_mask(ys.size(-1), device=xs.device).unsqueeze(0)
+        logp, states = self.forward_one_step(ys, ys_mask, xs, cache=batch_state)
+        state_list = [[states[i][b] for i in range(n_layers)] for b in range(n_batch)]
+        return logp, state_list
+
+
+# ---- losses -------------------------------------------------------------------------------------
+class LabelSmoothingLoss(torch.nn.Module):
+    """reference: transformer/label_smoothing_loss.py:13-63.  forward returns the loss; the per-row
+    argmax-correct flags of the same pass are kept in `self.correct_rows` for th_accuracy."""
+
+    def __init__(self, size, padding_idx, smoothing, normalize_length=False, criterion=None):
+        super().__init__()
+        self.padding_idx = padding_idx
+        self.confidence = 1.0 - smoothing
+        self.smoothing = smoothing
+        self.size = size
+        self.normalize_length = normalize_length
+        self.correct_rows = None
+
+    def forward(self, x, target, n_tokens=None):
+        assert x.size(2) == self.size
+        batch_size = x.size(0)
+        if self.normalize_length:
+            if n_tokens is None:   # same host sync as label_smoothing_loss.py:58
+                n_tokens = int((target != self.padding_idx).sum().item())
+            denom = n_tokens
+        else:
+            denom = batch_size
+        loss, self.correct_rows = F_.LabelSmoothingLossFn.apply(x, target, self.smoothing, self.padding_idx,
+                                                                float(denom))
+        return loss
+
+
+class CTC(torch.nn.Module):
+    """reference: ctc.py:12-151 (espnet1) / espnet2/asr/ctc.py:6-111.
+    ctc_type is accepted for interface parity ("warpctc" and "builtin" compute the same quantity:
+    sum_b -log p / B); both run the espnet_amd HIP kernel."""
+
+    def __init__(self, odim, eprojs, dropout_rate, ctc_type="warpctc", reduce=True):
+        super().__init__()
+        self.dropout_rate = dropout_rate
+        self.loss = None
+        self.ctc_lo = torch.nn.Linear(eprojs, odim)
+        self.probs = None
+        if ctc_type not in ("builtin", "warpctc"):
+            raise ValueError('ctc_type must be "builtin" or "warpctc": {}'.format(ctc_type))
+        self.ctc_type = ctc_type
+        self.ignore_id = -1
+        self.reduce = reduce
+        if not reduce:
+            raise NotImplementedError("reduce=False is not on the path")
+
+    def logits(self, hs_pad):
+        if self.dropout_rate > 0.0:   # ctc.py:85 applies F.dropout even in eval mode
+            raise NotImplementedError("CTC dropout_rate > 0 not wired into the HIP path yet")
+        return F_.LinearFn.apply(hs_pad, self.ctc_lo.weight, self.ctc_lo.bias)
+
+    def forward(self, hs_pad, hlens, ys_pad):
+        """hs_pad (B,T,D); hlens list/tensor of valid frames; ys_pad (B,L) int64 padded with -1."""
+        ys_hat = self.logits(hs_pad)
+        if isinstance(hlens, torch.Tensor):
+            hl = hlens.to(device=hs_pad.device, dtype=torch.int32)
+        else:
+            hl = torch.tensor([int(v) for v in hlens], dtype=torch.int32).to(hs_pad.device, non_blocking=True)
+        self.loss = F_.CTCLossFn.apply(ys_hat, ys_pad.contiguous(), hl, 0, self.ignore_id)
+        return self.loss
+
+    def softmax(self, hs_pad):
+        lp = self.log_softmax(hs_pad)
+        self.probs = torch.exp(lp)
+        return self.probs
+
+    def log_softmax(self, hs_pad):
+        y = self.logits(hs_pad)
+        return ops.log_softmax_rows(y.reshape(-1, y.shape[-1]).contiguous()).view(y.shape)
+
+    def argmax(self, hs_pad):
+        y = self.logits(hs_pad)
+        return ops.argmax_rows(y.reshape(-1, y.shape[-1]).contiguous()).view(y.shape[:-1]).long()
+
+
+def th_accuracy(correct_rows, pad_targets, ignore_label):
+    """reference: nets_utils.py:299-319; numerator comes from the fused loss kernel."""
+    num = ops.reduce_sum(correct_rows)
+    den = (pad_targets != ignore_label).sum()
+    return num / den

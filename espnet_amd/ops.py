@@ -1,0 +1,444 @@
+"""Thin tensor-level wrappers over the C ABI (one Python function per kernel family).
+
+No arithmetic happens here: every function validates shapes on the host (a faulting kernel can
+take the whole GPU node down), fills the argument struct and launches on torch's current stream.
+"""
+import ctypes as C
+import math
+
+import torch
+
+from . import _lib
+from ._lib import GatherT, GemmT, RowMapT, check, ptr, stream_ptr
+
+ACT_NONE, ACT_RELU, ACT_SWISH = 0, 1, 2
+EPI_NONE, EPI_RELU, EPI_SWISH, EPI_MUL_RELU_MASK, EPI_MUL_DSWISH = 0, 1, 2, 3, 4
+
+_PRECISIONS = {"fp32": 0, "bf16": 1}
+_state = {"precision": 0}
+
+
+def set_precision(name):
+    """'fp32' -> v_mfma_f32_16x16x4_f32 (exact fp32 products, parity mode);
+    'bf16' -> v_mfma_f32_16x16x32_bf16 (operands rounded to bf16 on load, fp32 accumulate)."""
+    if name not in _PRECISIONS:
+        raise ValueError(f"precision must be one of {list(_PRECISIONS)}")
+    _state["precision"] = _PRECISIONS[name]
+
+
+def get_precision():
+    return [k for k, v in _PRECISIONS.items() if v == _state["precision"]][0]
+
+
+def _numel_from(t, off):
+    return t.numel() - off
+
+
+def _span(rows, ld, cols):
+    """elements touched by a [rows, cols] matrix with leading dimension ld"""
+    return (rows - 1) * ld + cols if rows > 0 else 0
+
+
+def gemm(A, B, Cm, M, N, K, lda, ldb, ldc, *, transA=0, transB=0, bias=None, aux=None, ldaux=0, R=None,
+         ldr=0, batch=(1, 1), sA=(0, 0), sB=(0, 0), sC=(0, 0), alpha=1.0, beta=0.0, a_act=0, b_act=0,
+         epilogue=0, splitk=1, tile=0, gather=None, cmap=None, a_off=0, b_off=0, c_off=0, precision=None):
+    for t in (A, B, Cm):
+        if t.dtype != torch.float32 or not t.is_cuda:
+            raise _lib.EamdError("gemm needs float32 GPU tensors")
+    b1, b2 = batch
+    # ---- host-side bounds checks -------------------------------------------------------------
+    if gather is None:
+        a_span = _span(K, lda, M) if transA else _span(M, lda, K)
+        a_need = a_off + (b1 - 1) * sA[0] + (b2 - 1) * sA[1] + a_span
+        if a_need > A.numel():
+            raise _lib.EamdError(f"gemm: A too small ({A.numel()} < {a_need})")
+    b_span = _span(K, ldb, N) if transB else _span(N, ldb, K)
+    b_need = b_off + (b1 - 1) * sB[0] + (b2 - 1) * sB[1] + b_span
+    if b_need > B.numel():
+        raise _lib.EamdError(f"gemm: B too small ({B.numel()} < {b_need})")
+    if cmap is None:
+        c_need = c_off + (b1 - 1) * sC[0] + (b2 - 1) * sC[1] + _span(M, ldc, N)
+        if c_need > Cm.numel():
+            raise _lib.EamdError(f"gemm: C too small ({Cm.numel()} < {c_need})")
+    if bias is not None and bias.numel() < N:
+        raise _lib.EamdError("gemm: bias too small")
+
+    p = GemmT()
+    p.A, p.B, p.C = ptr(A, a_off), ptr(B, b_off), ptr(Cm, c_off)
+    p.bias = ptr(bias)
+    p.aux = ptr(aux, c_off) if aux is not None else None
+    p.R = ptr(R, c_off) if R is not None else None
+    p.M, p.N, p.K = M, N, K
+    p.transA, p.transB = int(transA), int(transB)
+    p.lda, p.ldb, p.ldc, p.ldaux, p.ldr = lda, ldb, ldc, ldaux or ldc, ldr or ldc
+    p.batch1, p.batch2 = b1, b2
+    p.sA1, p.sA2 = sA
+    p.sB1, p.sB2 = sB
+    p.sC1, p.sC2 = sC
+    p.alpha, p.beta = alpha, beta
+    p.a_act, p.b_act, p.epilogue = a_act, b_act, epilogue
+    p.splitk = splitk
+    p.precision = _state["precision"] if precision is None else precision
+    p.tile = tile
+    if gather is not None:
+        p.gather = gather
+    if cmap is not None:
+        p.cmap = cmap
+    check(_lib.lib().eamd_gemm(C.byref(p), stream_ptr()), "eamd_gemm")
+
+
+def auto_splitk(m_out, n_out, k_red):
+    tiles = ((m_out + 63) // 64) * ((n_out + 63) // 64)
+    if tiles >= 512:
+        return 1
+    s = min((512 + tiles - 1) // tiles, max(1, k_red // 128))
+    return max(1, min(s, 64))
+
+
+# ---- nn.Linear pieces -------------------------------------------------------------------------
+def linear_fwd(x, W, b, out=None, *, act=EPI_NONE, R=None, alpha=1.0, a_act=ACT_NONE):
+    """out[M,N] = alpha * act(a_act(x)[M,K] @ W[N,K]^T + b) + R"""
+    M, K = x.shape
+    N = W.shape[0]
+    assert W.shape[1] == K and x.is_contiguous() and W.is_contiguous()
+    if out is None:
+        out = torch.empty(M, N, device=x.device, dtype=torch.float32)
+    gemm(x, W, out, M, N, K, K, K, N, bias=b, epilogue=act, R=R, ldr=N, alpha=alpha, a_act=a_act)
+    return out
+
+
+def linear_bwd_x(dy, W, out=None, *, beta=0.0, epilogue=EPI_NONE, aux=None, alpha=1.0):
+    """out[M,K] = alpha * epi(dy[M,N] @ W[N,K]) + beta*out"""
+    M, N = dy.shape
+    K = W.shape[1]
+    assert W.shape[0] == N and dy.is_contiguous()
+    if out is None:
+        assert beta == 0.0
+        out = torch.empty(M, K, device=dy.device, dtype=torch.float32)
+    gemm(dy, W, out, M, K, N, N, K, K, transB=1, beta=beta, epilogue=epilogue, aux=aux, ldaux=K, alpha=alpha)
+    return out
+
+
+def linear_bwd_w(dy, x, dW, *, alpha=1.0, b_act=ACT_NONE):
+    """dW[N,K] += alpha * dy[M,N]^T @ b_act(x)[M,K]   (split-K, f32 atomics)"""
+    M, N = dy.shape
+    K = x.shape[1]
+    assert x.shape[0] == M and dW.numel() == N * K
+    sk = auto_splitk(N, K, M)
+    gemm(dy, x, dW, N, K, M, N, K, K, transA=1, transB=1, alpha=alpha, b_act=b_act, splitk=sk,
+         beta=1.0 if sk == 1 else 0.0)
+
+
+def colsum(x, out, scale=1.0, rows=None, D=None, ld=None):
+    rows = x.shape[0] if rows is None else rows
+    D = x.shape[1] if D is None else D
+    ld = D if ld is None else ld
+    assert out.numel() >= D
+    check(_lib.lib().eamd_colsum(ptr(x), C.c_int64(ld), ptr(out), C.c_int64(rows), D, C.c_float(scale),
+                                 stream_ptr()), "eamd_colsum")
+
+
+# ---- row kernels -------------------------------------------------------------------------------
+def layernorm_fwd(x, gamma, beta, eps):
+    rows, D = x.shape
+    y = torch.empty_like(x)
+    mean = torch.empty(rows, device=x.device, dtype=torch.float32)
+    rstd = torch.empty(rows, device=x.device, dtype=torch.float32)
+    check(_lib.lib().eamd_layernorm_fwd(ptr(x), ptr(gamma), ptr(beta), ptr(y), ptr(mean), ptr(rstd), rows, D,
+                                        C.c_float(eps), stream_ptr()), "eamd_layernorm_fwd")
+    return y, mean, rstd
+
+
+def layernorm_bwd(dy, x, gamma, mean, rstd, dres, dgamma, dbeta):
+    rows, D = x.shape
+    assert dy.shape == x.shape and dgamma.numel() == D and dbeta.numel() == D
+    dx = torch.empty_like(x)
+    check(_lib.lib().eamd_layernorm_bwd(ptr(dy), ptr(x), ptr(gamma), ptr(mean), ptr(rstd), ptr(dres), ptr(dx),
+                                        ptr(dgamma), ptr(dbeta), rows, D, stream_ptr()), "eamd_layernorm_bwd")
+    return dx
+
+
+def softmax_fwd(ac, bd, mask, P, nblocks, B, T1, T2, ld, scale):
+    mb = mi = 0
+    if mask is not None:
+        assert mask.dtype == torch.uint8 and mask.is_contiguous() and mask.dim() == 3 and mask.shape[0] == B
+        assert mask.shape[2] == T2 and mask.shape[1] in (1, T1)
+        mb = mask.shape[1] * mask.shape[2]
+        mi = 0 if mask.shape[1] == 1 else T2
+    assert ac.numel() >= nblocks * T1 * ld and P.numel() >= nblocks * T1 * ld
+    check(_lib.lib().eamd_softmax_fwd(ptr(ac), ptr(bd), ptr(mask), C.c_int64(mb), C.c_int64(mi), ptr(P), nblocks,
+                                      B, T1, T2, C.c_int64(ld), C.c_float(scale), stream_ptr()),
+          "eamd_softmax_fwd")
+
+
+def softmax_bwd(P, dP, dbd, nblocks, T1, T2, ld, scale):
+    assert P.numel() >= nblocks * T1 * ld and dP.numel() >= nblocks * T1 * ld
+    check(_lib.lib().eamd_softmax_bwd(ptr(P), ptr(dP), ptr(dbd), nblocks, T1, T2, C.c_int64(ld), C.c_float(scale),
+                                      stream_ptr()), "eamd_softmax_bwd")
+
+
+def lsm_loss(logits, target, smoothing, inv_denom, ignore_id, want_grad=True):
+    rows, V = logits.shape
+    assert target.numel() == rows and target.dtype == torch.int64
+    loss_rows = torch.empty(rows, device=logits.device, dtype=torch.float32)
+    correct = torch.empty(rows, device=logits.device, dtype=torch.float32)
+    grad = torch.empty_like(logits) if want_grad else None
+    check(_lib.lib().eamd_lsm_loss(ptr(logits), ptr(target), ptr(loss_rows), ptr(correct), ptr(grad), rows, V,
+                                   ignore_id, C.c_float(smoothing), C.c_float(inv_denom), stream_ptr()),
+          "eamd_lsm_loss")
+    return loss_rows, correct, grad
+
+
+def argmax_rows(x):
+    rows, V = x.shape
+    out = torch.empty(rows, device=x.device, dtype=torch.int32)
+    check(_lib.lib().eamd_argmax_rows(ptr(x), C.c_int64(V), ptr(out), rows, V, stream_ptr()), "eamd_argmax_rows")
+    return out
+
+
+def reduce_sum(x, scale=1.0):
+    out = torch.empty((), device=x.device, dtype=torch.float32)
+    check(_lib.lib().eamd_reduce_sum(ptr(x), C.c_int64(x.numel()), ptr(out), C.c_float(scale), stream_ptr()),
+          "eamd_reduce_sum")
+    return out
+
+
+def log_softmax_rows(x):
+    rows, V = x.shape
+    y = torch.empty_like(x)
+    check(_lib.lib().eamd_log_softmax_rows(ptr(x), ptr(y), rows, V, stream_ptr()), "eamd_log_softmax_rows")
+    return y
+
+
+# ---- element-wise ------------------------------------------------------------------------------
+def axpby(x, y, a=1.0, b=1.0, out=None):
+    if out is None:
+        out = torch.empty_like(x)
+    assert y is None or y.numel() == x.numel()
+    check(_lib.lib().eamd_axpby(ptr(x), ptr(y), ptr(out), C.c_int64(x.numel()), C.c_float(a), C.c_float(b),
+                                stream_ptr()), "eamd_axpby")
+    return out
+
+
+def scale_dev(x, scale_t, extra=1.0, out=None):
+    if out is None:
+        out = torch.empty_like(x)
+    check(_lib.lib().eamd_scale_dev(ptr(x), ptr(scale_t), ptr(out), C.c_int64(x.numel()), C.c_float(extra),
+                                    stream_ptr()), "eamd_scale_dev")
+    return out
+
+
+def glu_fwd(a, Cc):
+    rows = a.shape[0]
+    y = torch.empty(rows, Cc, device=a.device, dtype=torch.float32)
+    check(_lib.lib().eamd_glu_fwd(ptr(a), ptr(y), C.c_int64(rows), Cc, stream_ptr()), "eamd_glu_fwd")
+    return y
+
+
+def glu_bwd(dy, a, Cc):
+    rows = a.shape[0]
+    dx = torch.empty_like(a)
+    check(_lib.lib().eamd_glu_bwd(ptr(dy), ptr(a), ptr(dx), C.c_int64(rows), Cc, stream_ptr()), "eamd_glu_bwd")
+    return dx
+
+
+def add_bias2(q, u, v):
+    rows, D = q.shape
+    assert u.numel() == D and v.numel() == D
+    qu, qv = torch.empty_like(q), torch.empty_like(q)
+    check(_lib.lib().eamd_add_bias2(ptr(q), ptr(u), ptr(v), ptr(qu), ptr(qv), C.c_int64(rows), D, stream_ptr()),
+          "eamd_add_bias2")
+    return qu, qv
+
+
+def embed_pe(tok, table, pe, U, scale, pos_offset=0):
+    rows = tok.numel()
+    D = table.shape[1]
+    assert pe.shape[0] >= U + pos_offset and pe.shape[1] == D and tok.dtype == torch.int64
+    out = torch.empty(rows, D, device=table.device, dtype=torch.float32)
+    check(_lib.lib().eamd_embed_pe(ptr(tok), ptr(table), ptr(pe), ptr(out), C.c_int64(rows), U, D,
+                                   C.c_float(scale), pos_offset, stream_ptr()), "eamd_embed_pe")
+    return out
+
+
+def embed_bwd(tok, dout, dtable, scale):
+    rows, D = dout.shape
+    check(_lib.lib().eamd_embed_bwd(ptr(tok), ptr(dout), ptr(dtable), C.c_int64(rows), D, C.c_float(scale),
+                                    stream_ptr()), "eamd_embed_bwd")
+
+
+def posenc(x, pe, T, scale):
+    rows, D = x.shape
+    assert pe.shape[0] >= T and pe.shape[1] == D
+    out = torch.empty_like(x)
+    check(_lib.lib().eamd_posenc(ptr(x), ptr(pe), ptr(out), C.c_int64(rows), T, D, C.c_float(scale), stream_ptr()),
+          "eamd_posenc")
+    return out
+
+
+def dropout(x, p, seed):
+    y = torch.empty_like(x)
+    check(_lib.lib().eamd_dropout(ptr(x), ptr(y), C.c_int64(x.numel()), C.c_float(p), C.c_uint64(seed),
+                                  stream_ptr()), "eamd_dropout")
+    return y
+
+
+# ---- convolution module --------------------------------------------------------------------------
+def dwconv_fwd(x, w, bias, B, T, Cc, K):
+    assert x.numel() == B * T * Cc and w.numel() == Cc * K
+    y = torch.empty_like(x)
+    check(_lib.lib().eamd_dwconv_fwd(ptr(x), ptr(w), ptr(bias), ptr(y), B, T, Cc, K, stream_ptr()),
+          "eamd_dwconv_fwd")
+    return y
+
+
+def dwconv_bwd_x(dy, w, B, T, Cc, K):
+    dx = torch.empty_like(dy)
+    check(_lib.lib().eamd_dwconv_bwd_x(ptr(dy), ptr(w), ptr(dx), B, T, Cc, K, stream_ptr()), "eamd_dwconv_bwd_x")
+    return dx
+
+
+def dwconv_bwd_w(dy, x, dw, db, B, T, Cc, K):
+    assert dw.numel() == Cc * K and (db is None or db.numel() == Cc)
+    check(_lib.lib().eamd_dwconv_bwd_w(ptr(dy), ptr(x), ptr(dw), ptr(db), B, T, Cc, K, stream_ptr()),
+          "eamd_dwconv_bwd_w")
+
+
+def bn_stats(x, M, Cc, eps, momentum, running_mean, running_var):
+    nslab = _lib.lib().eamd_bn_nslab(C.c_int64(M), Cc)
+    ws = torch.empty(3 * Cc * nslab, device=x.device, dtype=torch.float32)
+    mean = torch.empty(Cc, device=x.device, dtype=torch.float32)
+    rstd = torch.empty(Cc, device=x.device, dtype=torch.float32)
+    check(_lib.lib().eamd_bn_stats(ptr(x), ptr(ws), ptr(mean), ptr(rstd), ptr(running_mean), ptr(running_var),
+                                   C.c_int64(M), Cc, C.c_float(eps), C.c_float(momentum), stream_ptr()),
+          "eamd_bn_stats")
+    return mean, rstd
+
+
+def bn_apply(x, mean, rstd, gamma, beta, M, Cc, act):
+    y = torch.empty_like(x)
+    check(_lib.lib().eamd_bn_apply(ptr(x), ptr(mean), ptr(rstd), ptr(gamma), ptr(beta), ptr(y), C.c_int64(M), Cc,
+                                   act, stream_ptr()), "eamd_bn_apply")
+    return y
+
+
+def bn_bwd(dy, x, mean, rstd, gamma, beta, dgamma, dbeta, M, Cc, act, training):
+    nslab = _lib.lib().eamd_bn_nslab(C.c_int64(M), Cc)
+    ws = torch.empty((2 * nslab + 2) * Cc, device=x.device, dtype=torch.float32)
+    dx = torch.empty_like(x)
+    check(_lib.lib().eamd_bn_bwd(ptr(dy), ptr(x), ptr(mean), ptr(rstd), ptr(gamma), ptr(beta), ptr(ws), ptr(dx),
+                                 ptr(dgamma), ptr(dbeta), C.c_int64(M), Cc, act, int(training), stream_ptr()),
+          "eamd_bn_bwd")
+    return dx
+
+
+def conv1_fwd(x, w, bias, B, T, F, Cc):
+    H, W = (T - 3) // 2 + 1, (F - 3) // 2 + 1
+    assert x.numel() == B * T * F and w.numel() == Cc * 9
+    y = torch.empty(B, H, W, Cc, device=x.device, dtype=torch.float32)
+    check(_lib.lib().eamd_conv1_fwd(ptr(x), ptr(w), ptr(bias), ptr(y), B, T, F, Cc, stream_ptr()),
+          "eamd_conv1_fwd")
+    return y
+
+
+def conv1_bwd_w(dy, x, dw, db, B, T, F, Cc):
+    check(_lib.lib().eamd_conv1_bwd_w(ptr(dy), ptr(x), ptr(dw), ptr(db), B, T, F, Cc, stream_ptr()),
+          "eamd_conv1_bwd_w")
+
+
+def conv2_weight_prep(w):
+    Co, Ci = w.shape[0], w.shape[1]
+    wf = torch.empty(9, Ci, Co, device=w.device, dtype=torch.float32)
+    wd = torch.empty(9, Co, Ci, device=w.device, dtype=torch.float32)
+    check(_lib.lib().eamd_conv2_weight_prep(ptr(w), ptr(wf), ptr(wd), Co, Ci, stream_ptr()),
+          "eamd_conv2_weight_prep")
+    return wf, wd
+
+
+def conv2_weight_grad(dwf, dw, Co, Ci):
+    check(_lib.lib().eamd_conv2_weight_grad(ptr(dwf), ptr(dw), Co, Ci, stream_ptr()), "eamd_conv2_weight_grad")
+
+
+def permute4(src, dst, dims, dst_strides, accumulate=False):
+    d0, d1, d2, d3 = dims
+    s0, s1, s2, s3 = dst_strides
+    assert src.numel() == d0 * d1 * d2 * d3
+    assert (d0 - 1) * s0 + (d1 - 1) * s1 + (d2 - 1) * s2 + (d3 - 1) * s3 < dst.numel()
+    check(_lib.lib().eamd_permute4(ptr(src), ptr(dst), d0, d1, d2, d3, C.c_int64(s0), C.c_int64(s1), C.c_int64(s2),
+                                   C.c_int64(s3), int(accumulate), stream_ptr()), "eamd_permute4")
+
+
+# ---- integer helpers ----------------------------------------------------------------------------
+def add_sos_eos(ys_pad, sos, eos, ignore_id):
+    B, L = ys_pad.shape
+    assert ys_pad.dtype == torch.int64 and ys_pad.is_contiguous()
+    ys_in = torch.empty(B, L + 1, device=ys_pad.device, dtype=torch.int64)
+    ys_out = torch.empty(B, L + 1, device=ys_pad.device, dtype=torch.int64)
+    olen = torch.empty(B, device=ys_pad.device, dtype=torch.int32)
+    check(_lib.lib().eamd_add_sos_eos(ptr(ys_pad), ptr(ys_in), ptr(ys_out), ptr(olen), B, L, sos, eos, ignore_id,
+                                      stream_ptr()), "eamd_add_sos_eos")
+    return ys_in, ys_out, olen
+
+
+def ctc_collapse(ids, hlens, blank):
+    B, T = ids.shape
+    assert ids.dtype == torch.int32 and ids.is_contiguous()
+    out = torch.empty(B, T, device=ids.device, dtype=torch.int32)
+    outlen = torch.empty(B, device=ids.device, dtype=torch.int32)
+    check(_lib.lib().eamd_ctc_collapse(ptr(ids), ptr(hlens), ptr(out), ptr(outlen), B, T, blank, stream_ptr()),
+          "eamd_ctc_collapse")
+    return out, outlen
+
+
+# ---- CTC -----------------------------------------------------------------------------------------
+def ctc_loss(acts_btv, ys_pad, ilens, blank=0, ignore_id=-1, grad_scale=1.0, want_grad=True):
+    """acts [B,T,V] raw activations; ys_pad [B,L] int64; ilens [B] int32 -> nll [B], grad [B,T,V]"""
+    B, T, V = acts_btv.shape
+    L = ys_pad.shape[1]
+    assert acts_btv.is_contiguous() and ys_pad.is_contiguous() and ys_pad.dtype == torch.int64
+    assert ilens.dtype == torch.int32 and ilens.numel() == B and ys_pad.shape[0] == B
+    ws_bytes = _lib.lib().eamd_ctc_workspace_bytes(B, T, L)
+    ws = torch.empty(ws_bytes, device=acts_btv.device, dtype=torch.uint8)
+    nll = torch.empty(B, device=acts_btv.device, dtype=torch.float32)
+    grad = torch.empty_like(acts_btv) if want_grad else None
+    check(_lib.lib().eamd_ctc_loss(ptr(acts_btv), C.c_int64(V), C.c_int64(T * V), ptr(ys_pad), ptr(ilens), ptr(nll),
+                                   ptr(grad), C.c_int64(V), C.c_int64(T * V), ptr(ws), B, T, V, L, blank, ignore_id,
+                                   C.c_float(grad_scale), stream_ptr()), "eamd_ctc_loss")
+    return nll, grad
+
+
+# ---- optimizer -------------------------------------------------------------------------------------
+def grad_norm(g, ws, out):
+    check(_lib.lib().eamd_grad_norm(ptr(g), C.c_int64(g.numel()), ptr(ws), ptr(out), stream_ptr()),
+          "eamd_grad_norm")
+
+
+def sched_step(state, gnorm, mode, base_lr, factor, dmodel, warmup, beta1, beta2, max_norm):
+    check(_lib.lib().eamd_sched_step(ptr(state), ptr(gnorm), mode, C.c_float(base_lr), C.c_float(factor),
+                                     C.c_float(dmodel), C.c_float(warmup), C.c_float(beta1), C.c_float(beta2),
+                                     C.c_float(max_norm), stream_ptr()), "eamd_sched_step")
+
+
+def adam_step(p, g, m, v, state, beta1, beta2, eps, weight_decay):
+    n = p.numel()
+    assert g.numel() == n and m.numel() == n and v.numel() == n
+    check(_lib.lib().eamd_adam_step(ptr(p), ptr(g), ptr(m), ptr(v), C.c_int64(n), ptr(state), C.c_float(beta1),
+                                    C.c_float(beta2), C.c_float(eps), C.c_float(weight_decay), stream_ptr()),
+          "eamd_adam_step")
+
+
+def make_gather(Cc, taps, Ho, Wo, Hin, Win, sh, sw):
+    g = GatherT()
+    g.enabled = 1
+    g.C, g.ntap, g.Ho, g.Wo, g.Hin, g.Win, g.sh, g.sw = Cc, len(taps), Ho, Wo, Hin, Win, sh, sw
+    for i, (dh, dw) in enumerate(taps):
+        g.dh[i] = dh
+        g.dw[i] = dw
+    return g
+
+
+def make_rowmap(Ho, Wo, Hc, Wc, sh, oh, sw, ow):
+    m = RowMapT()
+    m.enabled = 1
+    m.Ho, m.Wo, m.Hc, m.Wc, m.sh, m.oh, m.sw, m.ow = Ho, Wo, Hc, Wc, sh, oh, sw, ow
+    return m

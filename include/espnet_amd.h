@@ -86,10 +86,11 @@ int eamd_gemm(const eamd_gemm_t* p, void* stream);
 /* LayerNorm over the last dim.  reference: transformer/layer_norm.py:12-38 (eps = 1e-12). */
 int eamd_layernorm_fwd(const float* x, const float* gamma, const float* beta, float* y, float* mean,
                        float* rstd, int rows, int D, float eps, void* stream);
-/* dgamma/dbeta are ACCUMULATED (+=) with f32 atomics; dx is overwritten. */
+/* dgamma/dbeta are ACCUMULATED (+=) with f32 atomics; dx = LN-backward(dy) + dres (dres optional,
+ * may alias dx: the residual branch's gradient is folded in). */
 int eamd_layernorm_bwd(const float* dy, const float* x, const float* gamma, const float* mean,
-                       const float* rstd, float* dx, float* dgamma, float* dbeta, int rows, int D,
-                       void* stream);
+                       const float* rstd, const float* dres, float* dx, float* dgamma, float* dbeta, int rows,
+                       int D, void* stream);
 
 /* Masked softmax of attention scores, legacy rel_shift of `bd` fused in.
  * reference: transformer/attention.py:63-90 (mask fill / softmax / zero fill), :141-162 (rel_shift),
@@ -191,6 +192,22 @@ int eamd_sched_step(float* state, const float* gnorm, int mode, float base_lr, f
                     float warmup, float beta1, float beta2, float max_norm, void* stream);
 int eamd_adam_step(float* p, const float* g, float* m, float* v, int64_t n, const float* state, float beta1,
                    float beta2, float eps, float weight_decay, void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Integer / layout helpers (bit-exact).
+ * ------------------------------------------------------------------------------------------ */
+/* reference: transformer/add_sos_eos.py:12-31.  ys_in/ys_out are [B, L+1]; olen[b] = #labels. */
+int eamd_add_sos_eos(const int64_t* ys_pad, int64_t* ys_in, int64_t* ys_out, int32_t* olen, int B, int L, int sos,
+                     int eos, int ignore_id, void* stream);
+/* reference: e2e_asr_transformer.py:274-284 (greedy CTC: groupby + drop blank). out padded with -1. */
+int eamd_ctc_collapse(const int32_t* ids, const int32_t* hlens, int32_t* out, int32_t* outlen, int B, int T,
+                      int blank, void* stream);
+/* Conv2d(C,C,3,2) weight [Co][Ci][3][3] -> wf [9][Ci][Co] (tap = kh*3+kw) and wd [9][Co][Ci] with
+ * taps in stride-parity class order (0,0)(0,2)(2,0)(2,2)|(0,1)(2,1)|(1,0)(1,2)|(1,1).
+ * reference: transformer/subsampling.py:31 (second Conv2d). */
+int eamd_conv2_weight_prep(const float* w, float* wf, float* wd, int Co, int Ci, void* stream);
+/* dw[Co][Ci][3][3] += dwf[9][Ci][Co] */
+int eamd_conv2_weight_grad(const float* dwf, float* dw, int Co, int Ci, void* stream);
 
 #ifdef __cplusplus
 }

@@ -1,0 +1,342 @@
+#!/usr/bin/env python3
+"""Generate tests/golden/*.npz by RUNNING THE REFERENCE (kan-bayashi/espnet v0.9.5, PyTorch CPU).
+
+Build-container only: needs /root/reference on disk; nothing here travels to the GPU box except the
+.npz data files it writes (inputs, seeded weights, reference outputs and gradients).  Missing
+third-party packages that the hot path never computes with are replaced by inert in-process stubs
+(SURVEY.md §8c).  Usage:  python oracle/gen_golden.py [--ref /root/reference] [--out tests/golden]
+"""
+import argparse
+import os
+import sys
+import types
+
+import numpy as np
+import torch
+
+
+def install_stubs():
+    class _Permissive(types.ModuleType):
+        """inert stand-in: any attribute is a do-nothing callable / base class"""
+
+        def __getattr__(self, item):
+            if item.startswith("__"):
+                raise AttributeError(item)
+            return type(item, (), {"__init__": lambda self, *a, **k: None, "__call__": lambda self, *a, **k: None})
+
+    def mod(name, **attrs):
+        m = _Permissive(name)
+        m.__dict__.update(attrs)
+        sys.modules[name] = m
+        return m
+
+    if "chainer" not in sys.modules:
+        class _Rep:
+            def report(self, *a, **k):
+                pass
+
+        class _Chain:
+            pass
+
+        ch = mod("chainer", Chain=_Chain)
+        ch.reporter = mod("chainer.reporter", report=lambda *a, **k: None, Reporter=_Rep)
+        ch.training = mod("chainer.training")
+        ch.training.extension = mod("chainer.training.extension", Extension=object)
+        ch.datasets = mod("chainer.datasets")
+    if "editdistance" not in sys.modules:
+        def _eval(a, b):
+            a, b = list(a), list(b)
+            d = list(range(len(b) + 1))
+            for i in range(1, len(a) + 1):
+                prev, d[0] = d[0], i
+                for j in range(1, len(b) + 1):
+                    cur = min(d[j] + 1, d[j - 1] + 1, prev + (a[i - 1] != b[j - 1]))
+                    prev, d[j] = d[j], cur
+            return d[-1]
+        mod("editdistance", eval=_eval)
+    for name in ("configargparse", "humanfriendly", "librosa", "torch_complex", "pytorch_wpe"):
+        if name not in sys.modules:
+            try:
+                __import__(name)
+            except Exception:  # noqa: BLE001
+                m = mod(name)
+                if name == "configargparse":
+                    m.ArgumentParser = argparse.ArgumentParser
+                    m.YAMLConfigFileParser = object
+                    m.ArgumentDefaultsHelpFormatter = argparse.ArgumentDefaultsHelpFormatter
+                if name == "torch_complex":
+                    m.tensor = mod("torch_complex.tensor", ComplexTensor=object)
+                    m.functional = mod("torch_complex.functional")
+    if "typeguard" not in sys.modules:
+        try:
+            import typeguard  # noqa: F401
+        except Exception:  # noqa: BLE001
+            mod("typeguard", check_argument_types=lambda *a, **k: True, check_return_type=lambda *a, **k: True,
+                typechecked=lambda f=None, **k: f if f else (lambda g: g))
+    if not hasattr(np, "int"):
+        np.int = int  # nets_utils.py:406 uses the alias removed in numpy 1.24
+    if not hasattr(np, "float"):
+        np.float = float
+    if not hasattr(np, "bool"):
+        np.bool = bool
+
+
+def sd_np(module, prefix=""):
+    return {prefix + k: v.detach().cpu().numpy().copy() for k, v in module.state_dict().items()}
+
+
+def grads_np(module, prefix="grad/"):
+    return {prefix + k: p.grad.detach().cpu().numpy() for k, p in module.named_parameters() if p.grad is not None}
+
+
+def save(path, **arrs):
+    np.savez_compressed(path, **{k: np.asarray(v) for k, v in arrs.items()})
+    print("wrote", path, "%.1f KB" % (os.path.getsize(path) / 1024))
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--ref", default="/root/reference")
+    ap.add_argument("--out", default=os.path.join(os.path.dirname(__file__), "..", "tests", "golden"))
+    a = ap.parse_args()
+    install_stubs()
+    sys.path.insert(0, a.ref)
+    os.makedirs(a.out, exist_ok=True)
+    out = lambda n: os.path.join(a.out, n)  # noqa: E731
+    torch.set_num_threads(4)
+
+    from espnet.nets.pytorch_backend.conformer.convolution import ConvolutionModule
+    from espnet.nets.pytorch_backend.conformer.encoder_layer import EncoderLayer as ConfLayer
+    from espnet.nets.pytorch_backend.conformer.swish import Swish
+    from espnet.nets.pytorch_backend.ctc import CTC
+    from espnet.nets.pytorch_backend.transformer.attention import (MultiHeadedAttention,
+                                                                    RelPositionMultiHeadedAttention)
+    from espnet.nets.pytorch_backend.transformer.decoder import Decoder
+    from espnet.nets.pytorch_backend.transformer.embedding import (PositionalEncoding, RelPositionalEncoding)
+    from espnet.nets.pytorch_backend.transformer.label_smoothing_loss import LabelSmoothingLoss
+    from espnet.nets.pytorch_backend.transformer.layer_norm import LayerNorm
+    from espnet.nets.pytorch_backend.transformer.mask import subsequent_mask
+    from espnet.nets.pytorch_backend.transformer.positionwise_feed_forward import PositionwiseFeedForward
+    from espnet.nets.pytorch_backend.transformer.subsampling import Conv2dSubsampling
+    from espnet.nets.pytorch_backend.nets_utils import th_accuracy
+
+    # ---- a10 LayerNorm ---------------------------------------------------------------------
+    torch.manual_seed(10)
+    ln = LayerNorm(64)
+    ln.weight.data.uniform_(0.5, 1.5)
+    ln.bias.data.uniform_(-0.5, 0.5)
+    x = torch.randn(3, 7, 64, requires_grad=True)
+    y = ln(x)
+    gy = torch.randn_like(y)
+    y.backward(gy)
+    save(out("layernorm.npz"), x=x.detach(), y=y.detach(), gy=gy, gx=x.grad, **sd_np(ln, "sd/"), **grads_np(ln))
+
+    # ---- a7 rel_shift on T1 != T2, and RelPositionMultiHeadedAttention --------------------
+    torch.manual_seed(7)
+    att = RelPositionMultiHeadedAttention(4, 64, 0.0)
+    xs = torch.randn(2, 3, 5, 9)
+    xs2 = torch.randn(1, 2, 6, 6)
+    save(out("rel_shift.npz"), x=xs, y=att.rel_shift(xs), x2=xs2, y2=att.rel_shift(xs2))
+    pe = RelPositionalEncoding(64, 0.0)
+    x = torch.randn(2, 11, 64, requires_grad=True)
+    _, pos = pe(x)
+    mask = torch.ones(2, 1, 11, dtype=torch.bool)
+    mask[1, 0, 8:] = False
+    y = att(x, x, x, pos, mask)
+    gy = torch.randn_like(y)
+    y.backward(gy)
+    save(out("rel_mha.npz"), x=x.detach(), pos=pos.detach(), mask=mask, y=y.detach(), gy=gy, gx=x.grad,
+         attn=att.attn.detach(), **sd_np(att, "sd/"), **grads_np(att))
+
+    # ---- a6 MultiHeadedAttention: self (causal mask) and source attention, fully masked row --
+    torch.manual_seed(6)
+    att = MultiHeadedAttention(4, 64, 0.0)
+    q = torch.randn(2, 5, 64, requires_grad=True)
+    mem = torch.randn(2, 9, 64, requires_grad=True)
+    mmask = torch.ones(2, 1, 9, dtype=torch.bool)
+    mmask[1, 0, 6:] = False
+    y = att(q, mem, mem, mmask)
+    gy = torch.randn_like(y)
+    y.backward(gy)
+    cm = subsequent_mask(5).unsqueeze(0).expand(2, 5, 5).clone()
+    cm[1, 2, :] = False   # a fully masked query row -> zeros after masked_fill(0)
+    y2 = att(q.detach(), q.detach(), q.detach(), cm)
+    save(out("mha.npz"), q=q.detach(), mem=mem.detach(), mmask=mmask, y=y.detach(), gy=gy, gq=q.grad, gmem=mem.grad,
+         cmask=cm, y_self=y2.detach(), **sd_np(att, "sd/"), **grads_np(att))
+
+    # ---- a8 FFN (swish and relu) -----------------------------------------------------------
+    torch.manual_seed(8)
+    for name, actm in (("swish", Swish()), ("relu", torch.nn.ReLU())):
+        ff = PositionwiseFeedForward(64, 96, 0.0, actm)
+        x = torch.randn(2, 6, 64, requires_grad=True)
+        y = ff(x)
+        gy = torch.randn_like(y)
+        y.backward(gy)
+        save(out("ffn_%s.npz" % name), x=x.detach(), y=y.detach(), gy=gy, gx=x.grad, **sd_np(ff, "sd/"),
+             **grads_np(ff))
+
+    # ---- a9 ConvolutionModule train + eval ---------------------------------------------------
+    torch.manual_seed(9)
+    cm_ = ConvolutionModule(64, 7, Swish())
+    cm_.norm.weight.data.uniform_(0.5, 1.5)
+    cm_.norm.bias.data.uniform_(-0.3, 0.3)
+    sd0 = sd_np(cm_, "sd/")
+    x = torch.randn(3, 13, 64, requires_grad=True)
+    cm_.train()
+    y = cm_(x)
+    gy = torch.randn_like(y)
+    y.backward(gy)
+    sd1 = sd_np(cm_, "sd_after/")
+    cm_.eval()
+    ye = cm_(x.detach())
+    save(out("conv_module.npz"), x=x.detach(), y=y.detach(), gy=gy, gx=x.grad, y_eval=ye.detach(), **sd0, **sd1,
+         **grads_np(cm_))
+
+    # ---- a3/a4 Conv2dSubsampling with abs and rel positional encoding -------------------------
+    torch.manual_seed(3)
+    for name, pcls in (("abs", PositionalEncoding), ("rel", RelPositionalEncoding)):
+        sub = Conv2dSubsampling(20, 64, 0.0, pcls(64, 0.0))
+        x = torch.randn(2, 37, 20)
+        m = torch.ones(2, 1, 37, dtype=torch.bool)
+        m[1, 0, 29:] = False
+        y, ym = sub(x, m)
+        pos = None
+        if isinstance(y, tuple):
+            y, pos = y
+        gy = torch.randn_like(y)
+        y.backward(gy)
+        extra = dict(pos=pos.detach()) if pos is not None else {}
+        save(out("subsampling_%s.npz" % name), x=x, mask=m, y=y.detach(), ymask=ym, gy=gy, **extra, **sd_np(sub, "sd/"),
+             **grads_np(sub))
+
+    # ---- a5 conformer encoder layer, the four variants of test_e2e_asr_conformer.py:69-88 ----
+    torch.manual_seed(5)
+    for macaron in (False, True):
+        for cnn in (False, True):
+            lay = ConfLayer(64, RelPositionMultiHeadedAttention(4, 64, 0.0),
+                            PositionwiseFeedForward(64, 96, 0.0, Swish()),
+                            PositionwiseFeedForward(64, 96, 0.0, Swish()) if macaron else None,
+                            ConvolutionModule(64, 7, Swish()) if cnn else None, 0.0, True, False)
+            sd0 = sd_np(lay, "sd/")
+            x = torch.randn(2, 12, 64, requires_grad=True)
+            _, pos = RelPositionalEncoding(64, 0.0)(x)
+            m = torch.ones(2, 1, 12, dtype=torch.bool)
+            m[0, 0, 9:] = False
+            (y, _), _ = lay((x, pos), m)
+            gy = torch.randn_like(y)
+            y.backward(gy)
+            save(out("conformer_layer_m%d_c%d.npz" % (macaron, cnn)), x=x.detach(), pos=pos.detach(), mask=m,
+                 y=y.detach(), gy=gy, gx=x.grad, **sd0, **grads_np(lay))
+
+    # ---- a14 LabelSmoothingLoss both normalisations + th_accuracy ----------------------------
+    torch.manual_seed(14)
+    x = torch.randn(3, 5, 17, requires_grad=True)
+    t = torch.randint(0, 17, (3, 5))
+    t[0, 3:] = -1
+    t[2, 4:] = -1
+    res = {}
+    for norm in (False, True):
+        x.grad = None
+        loss = LabelSmoothingLoss(17, -1, 0.1, norm)(x, t)
+        loss.backward()
+        res["loss_n%d" % norm] = loss.detach()
+        res["gx_n%d" % norm] = x.grad.clone()
+    x.grad = None
+    l0 = LabelSmoothingLoss(17, -1, 0.0, False)(x, t)
+    save(out("lsm_loss.npz"), x=x.detach(), t=t, acc=th_accuracy(x.detach().view(-1, 17), t, -1), loss_s0=l0.detach(),
+         **res)
+
+    # ---- a15 CTC: lengths of test/test_loss.py:18-20, repeated labels, infeasible ------------
+    torch.manual_seed(15)
+    ctc = CTC(6, 8, 0.0, ctc_type="builtin", reduce=True)
+    hs = torch.randn(3, 5, 8, requires_grad=True)
+    hlens = torch.tensor([5, 4, 5])
+    ys = torch.tensor([[1, 2, -1], [3, 3, 4], [2, -1, -1]])     # utt1: repeated label, T=4 >= 2+1+... feasible
+    loss = ctc(hs, hlens, ys)
+    loss.backward()
+    logits = ctc.ctc_lo(hs).detach()
+    # gradient wrt the raw activations (what warp-ctc returns) for direct kernel checks
+    lg = logits.clone().requires_grad_(True)
+    l2 = torch.nn.functional.ctc_loss(lg.transpose(0, 1).log_softmax(2), torch.tensor([1, 2, 3, 3, 4, 2], dtype=torch.int32),
+                                      torch.tensor([5, 4, 5], dtype=torch.int32), torch.tensor([2, 3, 1], dtype=torch.int32),
+                                      reduction="sum") / 3
+    l2.backward()
+    # infeasible: 3 labels with a repeat need T >= 4, give T = 3
+    linf = torch.nn.functional.ctc_loss(logits[:1, :3].transpose(0, 1).log_softmax(2), torch.tensor([3, 3, 4], dtype=torch.int32),
+                                        torch.tensor([3], dtype=torch.int32), torch.tensor([3], dtype=torch.int32),
+                                        reduction="sum")
+    # per-utterance nll
+    nll = torch.nn.functional.ctc_loss(logits.transpose(0, 1).log_softmax(2), torch.tensor([1, 2, 3, 3, 4, 2], dtype=torch.int32),
+                                       torch.tensor([5, 4, 5], dtype=torch.int32), torch.tensor([2, 3, 1], dtype=torch.int32),
+                                       reduction="none")
+    save(out("ctc.npz"), hs=hs.detach(), hlens=hlens, ys=ys, loss=loss.detach(), ghs=hs.grad, logits=logits,
+         glogits=lg.grad, loss_direct=l2.detach(), loss_infeasible=linf.detach(), nll=nll.detach(),
+         argmax=ctc.argmax(hs).detach(), log_softmax=ctc.log_softmax(hs).detach(), **sd_np(ctc, "sd/"), **grads_np(ctc))
+
+    # ---- a12 Decoder: full forward/backward + cached one-step --------------------------------
+    torch.manual_seed(12)
+    dec = Decoder(odim=23, attention_dim=64, attention_heads=4, linear_units=96, num_blocks=2, dropout_rate=0.0,
+                  positional_dropout_rate=0.0, self_attention_dropout_rate=0.0, src_attention_dropout_rate=0.0)
+    ys_in = torch.randint(1, 22, (2, 6))
+    mem = torch.randn(2, 9, 64, requires_grad=True)
+    mmask = torch.ones(2, 1, 9, dtype=torch.bool)
+    mmask[1, 0, 7:] = False
+    tmask = subsequent_mask(6).unsqueeze(0).expand(2, 6, 6)
+    y, _ = dec(ys_in, tmask, mem, mmask)
+    gy = torch.randn_like(y)
+    y.backward(gy)
+    dec.eval()
+    cache = None
+    steps = []
+    for i in range(1, 5):
+        lp, cache = dec.forward_one_step(ys_in[:1, :i], subsequent_mask(i).unsqueeze(0), mem[:1].detach(), cache=cache)
+        steps.append(lp.detach())
+    save(out("decoder.npz"), ys_in=ys_in, mem=mem.detach(), mmask=mmask, y=y.detach(), gy=gy, gmem=mem.grad,
+         step_logp=torch.stack(steps), **sd_np(dec, "sd/"), **grads_np(dec))
+
+    # ---- a1 end-to-end: small Conformer and small Transformer (BASELINE config 1) -------------
+    from espnet.nets.pytorch_backend.e2e_asr_conformer import E2E as ConfE2E
+    from espnet.nets.pytorch_backend.e2e_asr_transformer import E2E as TrfE2E
+
+    def e2e_case(name, cls, extra, seed):
+        torch.manual_seed(seed)
+        kw = dict(adim=64, aheads=4, elayers=2, eunits=128, dlayers=1, dunits=128, mtlalpha=0.3,
+                  lsm_weight=0.1, dropout_rate=0.0, transformer_attn_dropout_rate=0.0,
+                  transformer_length_normalized_loss=False, transformer_init="pytorch",
+                  transformer_input_layer="conv2d", ctc_type="builtin", report_cer=False,
+                  report_wer=False, char_list=None, sym_space="<space>", sym_blank="<blank>")
+        kw.update(extra)
+        ns = argparse.Namespace(**kw)
+        model = cls(20, 50, ns)
+        model.train()
+        sd0 = sd_np(model, "sd/")
+        g = torch.Generator().manual_seed(1)
+        xs = torch.randn(2, 100, 20, generator=g)
+        ilens = torch.tensor([100, 77])
+        ys = torch.randint(1, 49, (2, 9), generator=g)
+        ys[1, 6:] = -1
+        loss = model(xs, ilens, ys)
+        loss.backward()
+        rep = dict(loss=float(loss), acc=float(model.acc), hs=model.hs_pad.detach().clone(),
+                   pred=model.pred_pad.detach().clone(), loss_ctc=float(model.ctc.loss))
+        model.eval()
+        with torch.no_grad():
+            lz = model.ctc.argmax(model.encoder(xs[:1], None)[0])
+            from itertools import groupby
+            greedy = [v for v in (k[0] for k in groupby(lz[0].tolist())) if v != 0]
+            model(xs, ilens, ys)   # eval-mode loss (BatchNorm running stats)
+            eval_loss = float(model.loss)
+        save(out(name), xs=xs, ilens=ilens, ys=ys, hs_pad=rep["hs"], pred_pad=rep["pred"],
+             loss=rep["loss"], loss_ctc=rep["loss_ctc"], acc=rep["acc"], eval_loss=eval_loss, greedy=np.asarray(greedy, dtype=np.int64),
+             **sd0, **grads_np(model))
+        return model
+
+    e2e_case("e2e_conformer.npz", ConfE2E, dict(transformer_encoder_pos_enc_layer_type="rel_pos",
+                                                transformer_encoder_selfattn_layer_type="rel_selfattn",
+                                                transformer_encoder_activation_type="swish", macaron_style=True,
+                                                use_cnn_module=True, cnn_module_kernel=15), 21)
+    e2e_case("e2e_transformer.npz", TrfE2E, dict(eunits=256, dunits=256), 22)
+
+
+if __name__ == "__main__":
+    main()

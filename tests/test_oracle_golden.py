@@ -1,0 +1,224 @@
+"""Pins oracle/asr_oracle.py against vectors recorded from the reference (oracle/gen_golden.py)."""
+import math
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import load_golden, split_golden
+
+TOL = dict(rtol=2e-5, atol=2e-6)
+
+
+def close(a, b, **kw):
+    t = dict(TOL)
+    t.update(kw)
+    torch.testing.assert_close(a, b, **t)
+
+
+def run_grads(y, gy, sd):
+    params = [v for v in sd.values() if v.requires_grad]
+    y.backward(gy)
+
+
+def req(sd):
+    return {k: (v.clone().requires_grad_(True) if v.is_floating_point() else v) for k, v in sd.items()}
+
+
+def check_param_grads(sd, grads, **kw):
+    for k, g in grads.items():
+        assert sd[k].grad is not None, k
+        close(sd[k].grad, g, **kw)
+
+
+def test_layernorm(oracle):
+    p, sd, grads = split_golden(load_golden("layernorm.npz"))
+    sd = req(sd)
+    x = p["x"].clone().requires_grad_(True)
+    y = oracle.layer_norm(sd, "", x)
+    close(y, p["y"])
+    y.backward(p["gy"])
+    close(x.grad, p["gx"])
+    check_param_grads(sd, grads)
+
+
+def test_rel_shift(oracle):
+    p, _, _ = split_golden(load_golden("rel_shift.npz"))
+    assert torch.equal(oracle.rel_shift(p["x"]), p["y"])
+    assert torch.equal(oracle.rel_shift(p["x2"]), p["y2"])
+    # index formula of SURVEY.md §7: out[i,j] = P_flat[T1 + i*T2 + j], P = [0 | x]
+    x = p["x"][0, 0]
+    t1, t2 = x.shape
+    for i in range(t1):
+        for j in range(t2):
+            f = t1 + i * t2 + j
+            r, c = divmod(f, t2 + 1)
+            want = 0.0 if c == 0 else float(x[r, c - 1])
+            assert float(p["y"][0, 0, i, j]) == want
+
+
+def test_rel_mha(oracle):
+    p, sd, grads = split_golden(load_golden("rel_mha.npz"))
+    sd = req(sd)
+    x = p["x"].clone().requires_grad_(True)
+    y = oracle.rel_mha(sd, "", x, p["pos"], p["mask"], 4)
+    close(y, p["y"])
+    y.backward(p["gy"])
+    close(x.grad, p["gx"])
+    check_param_grads(sd, grads)
+
+
+def test_mha(oracle):
+    p, sd, grads = split_golden(load_golden("mha.npz"))
+    sd = req(sd)
+    q = p["q"].clone().requires_grad_(True)
+    mem = p["mem"].clone().requires_grad_(True)
+    y = oracle.mha(sd, "", q, mem, mem, p["mmask"], 4)
+    close(y, p["y"])
+    y.backward(p["gy"])
+    close(q.grad, p["gq"])
+    close(mem.grad, p["gmem"])
+    check_param_grads(sd, grads)
+    y2 = oracle.mha(sd, "", p["q"], p["q"], p["q"], p["cmask"], 4)
+    close(y2, p["y_self"])
+
+
+@pytest.mark.parametrize("name", ["swish", "relu"])
+def test_ffn(oracle, name):
+    p, sd, grads = split_golden(load_golden("ffn_%s.npz" % name))
+    sd = req(sd)
+    x = p["x"].clone().requires_grad_(True)
+    y = oracle.ffn(sd, "", x, oracle.activation(name))
+    close(y, p["y"])
+    y.backward(p["gy"])
+    close(x.grad, p["gx"])
+    check_param_grads(sd, grads)
+
+
+def test_conv_module(oracle):
+    p, sd, grads = split_golden(load_golden("conv_module.npz"))
+    sd = req(sd)
+    x = p["x"].clone().requires_grad_(True)
+    st = {}
+    y = oracle.conv_module(sd, "", x, oracle.swish, True, st)
+    close(y, p["y"], rtol=1e-4, atol=1e-5)
+    y.backward(p["gy"])
+    close(x.grad, p["gx"], rtol=1e-4, atol=1e-5)
+    check_param_grads(sd, grads, rtol=1e-4, atol=1e-5)
+    close(st["norm.running_mean"], p["sd_after/norm.running_mean"])
+    close(st["norm.running_var"], p["sd_after/norm.running_var"])
+    sd_eval = {k: v.detach() for k, v in sd.items()}
+    sd_eval["norm.running_mean"] = p["sd_after/norm.running_mean"]
+    sd_eval["norm.running_var"] = p["sd_after/norm.running_var"]
+    close(oracle.conv_module(sd_eval, "", p["x"], oracle.swish, False), p["y_eval"], rtol=1e-4, atol=1e-5)
+
+
+@pytest.mark.parametrize("name", ["abs", "rel"])
+def test_subsampling(oracle, name):
+    p, sd, grads = split_golden(load_golden("subsampling_%s.npz" % name))
+    sd = req(sd)
+    y, pos, m = oracle.conv2d_subsampling(sd, "", p["x"], p["mask"], name == "rel")
+    close(y, p["y"], rtol=1e-4, atol=1e-5)
+    assert torch.equal(m, p["ymask"])
+    if name == "rel":
+        close(pos, p["pos"])
+    y.backward(p["gy"])
+    check_param_grads(sd, grads, rtol=1e-4, atol=1e-4)
+
+
+@pytest.mark.parametrize("macaron", [0, 1])
+@pytest.mark.parametrize("cnn", [0, 1])
+def test_conformer_layer(oracle, macaron, cnn):
+    p, sd, grads = split_golden(load_golden("conformer_layer_m%d_c%d.npz" % (macaron, cnn)))
+    sd = req(sd)
+    x = p["x"].clone().requires_grad_(True)
+    y = oracle.conformer_layer(sd, "", x, p["pos"], p["mask"], dict(aheads=4), True)
+    close(y, p["y"], rtol=1e-4, atol=1e-5)
+    y.backward(p["gy"])
+    close(x.grad, p["gx"], rtol=1e-4, atol=1e-5)
+    check_param_grads(sd, grads, rtol=1e-4, atol=1e-5)
+
+
+def test_lsm_loss(oracle):
+    p, _, _ = split_golden(load_golden("lsm_loss.npz"))
+    for norm in (0, 1):
+        x = p["x"].clone().requires_grad_(True)
+        loss = oracle.label_smoothing_loss(x, p["t"], 0.1, -1, bool(norm))
+        close(loss, p["loss_n%d" % norm])
+        loss.backward()
+        close(x.grad, p["gx_n%d" % norm])
+    close(oracle.label_smoothing_loss(p["x"], p["t"], 0.0, -1, False), p["loss_s0"])
+    assert abs(oracle.accuracy(p["x"].view(-1, 17), p["t"], -1) - float(p["acc"])) < 1e-7
+
+
+def test_ctc(oracle):
+    p, sd, grads = split_golden(load_golden("ctc.npz"))
+    for builtin in (True, False):
+        lg = p["logits"].clone().requires_grad_(True)
+        loss = oracle.ctc_loss(lg, p["hlens"], p["ys"], -1, builtin)
+        close(loss, p["loss"])
+        close(loss, p["loss_direct"])
+        loss.backward()
+        close(lg.grad, p["glogits"], rtol=1e-4, atol=1e-6)
+    # per-utterance recursion and the infeasible case
+    logp = torch.log_softmax(p["logits"], 2)
+    ys = [[1, 2], [3, 3, 4], [2]]
+    for b in range(3):
+        close(oracle.ctc_alpha_nll(logp[b, : int(p["hlens"][b])], ys[b]), p["nll"][b])
+    assert math.isinf(float(p["loss_infeasible"]))
+    assert math.isinf(float(oracle.ctc_alpha_nll(logp[0, :3], [3, 3, 4])))
+    # whole module: ctc_lo + loss
+    sdr = req(sd)
+    hs = p["hs"].clone().requires_grad_(True)
+    loss = oracle.ctc_loss(oracle.linear(sdr, "ctc_lo.", hs), p["hlens"], p["ys"])
+    loss.backward()
+    close(hs.grad, p["ghs"], rtol=1e-4, atol=1e-6)
+    check_param_grads(sdr, grads, rtol=1e-4, atol=1e-6)
+    assert torch.equal(oracle.linear(sd, "ctc_lo.", p["hs"]).argmax(-1), p["argmax"])
+
+
+def test_decoder(oracle):
+    p, sd, grads = split_golden(load_golden("decoder.npz"))
+    sd = req(sd)
+    mem = p["mem"].clone().requires_grad_(True)
+    u = p["ys_in"].shape[1]
+    tmask = torch.tril(torch.ones(u, u, dtype=torch.bool)).unsqueeze(0)
+    y = oracle.decoder(sd, "", p["ys_in"], tmask, mem, p["mmask"], 4)
+    close(y, p["y"], rtol=1e-4, atol=1e-5)
+    y.backward(p["gy"])
+    close(mem.grad, p["gmem"], rtol=1e-4, atol=1e-5)
+    check_param_grads(sd, grads, rtol=1e-4, atol=2e-5)
+    # cached one-step == last row of the full causal forward (test_transformer_decode.py:13-79)
+    sdd = {k: v.detach() for k, v in sd.items()}
+    for i in range(1, 5):
+        tm = torch.tril(torch.ones(i, i, dtype=torch.bool)).unsqueeze(0)
+        lp = torch.log_softmax(oracle.decoder(sdd, "", p["ys_in"][:1, :i], tm, p["mem"][:1], None, 4)[:, -1], -1)
+        close(lp, p["step_logp"][i - 1], rtol=1e-4, atol=1e-5)
+
+
+@pytest.mark.parametrize("name,cfg", [
+    ("e2e_conformer.npz", dict(conformer=True, rel_pos=True, activation="swish")),
+    ("e2e_transformer.npz", dict(conformer=False, rel_pos=False)),
+])
+def test_e2e(oracle, name, cfg):
+    p, sd, grads = split_golden(load_golden(name))
+    sd = req(sd)
+    cfg = dict(cfg, aheads=4, mtlalpha=0.3, lsm_weight=0.1, odim=50)
+    out = oracle.e2e_forward(sd, p["xs"], p["ilens"].tolist(), p["ys"], cfg, training=True)
+    assert abs(float(out["loss"].detach()) - float(p["loss"])) <= 2e-5 * abs(float(p["loss"]))
+    assert abs(out["acc"] - float(p["acc"])) < 1e-6
+    close(out["hs_pad"], p["hs_pad"], rtol=1e-3, atol=1e-4)
+    out["loss"].backward()
+    worst = 0.0
+    for k, g in grads.items():
+        a = sd[k].grad
+        assert a is not None, k
+        if float(g.norm()) > 1e-3:   # e.g. linear_k.bias has an analytically zero gradient: cosine of noise
+            cos = float(torch.nn.functional.cosine_similarity(a.flatten().double(), g.flatten().double(), dim=0))
+            worst = max(worst, 1 - cos)
+        close(a, g, rtol=2e-3, atol=2e-4)
+    assert worst < 1e-5
+    if "greedy" in p:
+        hs, _ = oracle.encoder({k: v.detach() for k, v in sd.items()}, "encoder.", p["xs"][:1], None, cfg, training=False)
+        ids = oracle.greedy_ctc(oracle.linear(sd, "ctc.ctc_lo.", hs)[0])
+        assert ids == p["greedy"].tolist()
