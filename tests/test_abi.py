@@ -1,0 +1,76 @@
+"""CPU-side checks of the C-ABI boundary: the library builds, loads, and exports exactly the entry
+points include/espnet_amd.h declares (no kernels are launched here)."""
+import ctypes
+import os
+import re
+import subprocess
+
+import pytest
+
+from conftest import ROOT
+
+HDR = os.path.join(ROOT, "include", "espnet_amd.h")
+LIB = os.path.join(ROOT, "espnet_amd", "csrc", "libespnet_amd_hip.so")
+
+
+def declared_symbols():
+    src = open(HDR).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    return sorted(set(re.findall(r"\b(eamd_[a-z0-9_]+)\s*\(", src)))
+
+
+@pytest.fixture(scope="module")
+def lib():
+    if not os.path.exists(LIB):
+        subprocess.check_call(["make", "-C", os.path.dirname(LIB), "-j4"])
+    return ctypes.CDLL(LIB)
+
+
+def test_header_declares_entry_points():
+    syms = declared_symbols()
+    assert "eamd_gemm" in syms and "eamd_ctc_loss" in syms and len(syms) >= 35
+
+
+def test_library_exports_every_declared_symbol(lib):
+    missing = [s for s in declared_symbols() if not hasattr(lib, s)]
+    assert not missing, missing
+
+
+def test_python_binding_lists_every_symbol():
+    from espnet_amd import _lib
+    assert sorted(_lib.SYMBOLS) == declared_symbols()
+
+
+def test_abi_version(lib):
+    assert lib.eamd_abi_version() == 1
+
+
+def test_bad_arguments_are_rejected_without_a_gpu(lib):
+    # NULL operands must be refused on the host (negative code), never launched
+    assert lib.eamd_gemm(None, None) < 0
+    lib.eamd_ctc_workspace_bytes.restype = ctypes.c_int64
+    assert lib.eamd_ctc_workspace_bytes(2, 10, 3) > 0
+    assert lib.eamd_layernorm_fwd(None, None, None, None, None, None, 4, 8, ctypes.c_float(1e-12), None) < 0
+
+
+def test_struct_layout_matches_header():
+    from espnet_amd._lib import GatherT, GemmT, RowMapT
+    assert ctypes.sizeof(GatherT) == 4 * 27
+    assert ctypes.sizeof(RowMapT) == 4 * 9
+    # 6 pointers, 5 int32, 5 int64, 2 int32, 6 int64, 2 float, 6 int32, gather, rowmap (8-byte aligned)
+    assert ctypes.sizeof(GemmT) % 8 == 0 and ctypes.sizeof(GemmT) >= 48 + 20 + 40 + 8 + 48 + 8 + 24 + 108 + 36
+
+
+def test_product_path_has_no_cpu_fallback():
+    import torch
+    from espnet_amd import ops, _lib
+    x = torch.zeros(4, 8)
+    with pytest.raises(_lib.EamdError):
+        ops.layernorm_fwd(x, torch.ones(8), torch.zeros(8), 1e-12)
+
+
+def test_product_never_imports_oracle():
+    for dirpath, _, files in os.walk(os.path.join(ROOT, "espnet_amd")):
+        for f in files:
+            if f.endswith(".py"):
+                assert "oracle" not in open(os.path.join(dirpath, f)).read().replace("# oracle", ""), f

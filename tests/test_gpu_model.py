@@ -1,0 +1,249 @@
+"""GPU parity tests, module / model level: the reference-mirroring modules (HIP kernels behind the
+C ABI) against vectors recorded from the reference itself (tests/golden) and against the CPU oracle
+at larger sizes.  Tolerances: fp32-MFMA path 1e-4 relative on activations/gradients, loss within
+1e-5 relative (north_star bar: 1e-3); bf16-MFMA path must stay within the 1e-3 loss bar."""
+import argparse
+import math
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import load_golden, split_golden
+from test_gpu_ops import report
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+
+
+@pytest.fixture(autouse=True)
+def _fp32():
+    import espnet_amd
+    espnet_amd.set_precision("fp32")
+    yield
+    espnet_amd.set_precision("fp32")
+
+
+def load_sd(module, sd, prefix=""):
+    own = module.state_dict()
+    sub = {k[len(prefix):]: v for k, v in sd.items() if k.startswith(prefix)}
+    missing = set(own) - set(sub)
+    unexpected = set(sub) - set(own)
+    assert not missing and not unexpected, (missing, unexpected)   # reference checkpoints load key-for-key
+    module.load_state_dict(sub)
+    return module.to(DEV)
+
+
+def check_grads(module, grads, prefix="", tol=2e-4, skip_zero=True):
+    worst = 0.0
+    for k, p in module.named_parameters():
+        g = grads[prefix + k]
+        assert p.grad is not None, k
+        if skip_zero and float(g.norm()) < 1e-4:
+            assert float(p.grad.norm()) < 1e-3, k
+            continue
+        e = float((p.grad.double().cpu() - g.double()).norm() / g.double().norm())
+        worst = max(worst, e)
+        assert e <= tol, f"grad {k}: rel err {e}"
+    print(f"[parity] {type(module).__name__} worst param-grad rel err {worst:.3e}")
+
+
+def test_conv2d_subsampling_golden():
+    from espnet_amd.nets import modules as M
+    for name, pcls in (("abs", M.PositionalEncoding), ("rel", M.RelPositionalEncoding)):
+        p, sd, grads = split_golden(load_golden("subsampling_%s.npz" % name))
+        sub = load_sd(M.Conv2dSubsampling(20, 64, 0.0, pcls(64, 0.0)), sd)
+        y, ym = sub(p["x"].to(DEV), p["mask"])
+        if isinstance(y, tuple):
+            y, pos = y
+            report("subsampling pos_emb", pos, p["pos"], 1e-6)
+        report("subsampling_%s fwd" % name, y, p["y"], 1e-5)
+        assert torch.equal(ym.cpu(), p["ymask"])
+        y.backward(p["gy"].to(DEV))
+        check_grads(sub, grads)
+
+
+@pytest.mark.parametrize("macaron", [0, 1])
+@pytest.mark.parametrize("cnn", [0, 1])
+def test_conformer_layer_golden(macaron, cnn):
+    from espnet_amd.nets import modules as M
+    p, sd, grads = split_golden(load_golden("conformer_layer_m%d_c%d.npz" % (macaron, cnn)))
+    lay = M.ConformerEncoderLayer(
+        64, M.RelPositionMultiHeadedAttention(4, 64, 0.0), M.PositionwiseFeedForward(64, 96, 0.0, M.Swish()),
+        M.PositionwiseFeedForward(64, 96, 0.0, M.Swish()) if macaron else None,
+        M.ConvolutionModule(64, 7, M.Swish()) if cnn else None, 0.0, True, False)
+    lay = load_sd(lay, sd)
+    lay.train()
+    x = p["x"].to(DEV).requires_grad_(True)
+    (y, _), _ = lay((x, p["pos"].to(DEV)), p["mask"])
+    report("conformer_layer m%d c%d fwd" % (macaron, cnn), y, p["y"], 2e-5)
+    y.backward(p["gy"].to(DEV))
+    report("conformer_layer m%d c%d dx" % (macaron, cnn), x.grad, p["gx"], 1e-4)
+    check_grads(lay, grads)
+
+
+def test_decoder_golden():
+    from espnet_amd.nets import modules as M
+    p, sd, grads = split_golden(load_golden("decoder.npz"))
+    dec = load_sd(M.Decoder(odim=23, attention_dim=64, attention_heads=4, linear_units=96, num_blocks=2,
+                            dropout_rate=0.0, positional_dropout_rate=0.0), sd)
+    mem = p["mem"].to(DEV).requires_grad_(True)
+    tmask = M.subsequent_mask(6).unsqueeze(0).expand(2, 6, 6).contiguous()
+    y, _ = dec(p["ys_in"].to(DEV), tmask, mem, p["mmask"])
+    report("decoder fwd", y, p["y"], 2e-5)
+    y.backward(p["gy"].to(DEV))
+    report("decoder dmemory", mem.grad, p["gmem"], 1e-4)
+    check_grads(dec, grads)
+    # cached one-step decoding == reference forward_one_step (test_transformer_decode.py:13-79)
+    dec.eval()
+    cache = None
+    with torch.no_grad():
+        for i in range(1, 5):
+            lp, cache = dec.forward_one_step(p["ys_in"][:1, :i].to(DEV), M.subsequent_mask(i).unsqueeze(0),
+                                             p["mem"][:1].to(DEV), cache=cache)
+            report("decoder one-step %d" % i, lp, p["step_logp"][i - 1], 2e-5)
+
+
+def test_ctc_module_golden():
+    from espnet_amd.nets import modules as M
+    p, sd, grads = split_golden(load_golden("ctc.npz"))
+    ctc = load_sd(M.CTC(6, 8, 0.0, ctc_type="builtin"), sd)
+    hs = p["hs"].to(DEV).requires_grad_(True)
+    loss = ctc(hs, p["hlens"], p["ys"].to(DEV))
+    report("CTC module loss", loss, p["loss"], 2e-6)
+    loss.backward()
+    report("CTC module dhs", hs.grad, p["ghs"], 2e-5)
+    check_grads(ctc, grads)
+    assert torch.equal(ctc.argmax(p["hs"].to(DEV)).cpu(), p["argmax"])       # bit-exact token ids
+    report("CTC log_softmax", ctc.log_softmax(p["hs"].to(DEV)), p["log_softmax"], 1e-6)
+
+
+def _e2e(cls_name, extra):
+    from espnet_amd.nets import e2e_asr_conformer, e2e_asr_transformer
+    cls = {"conformer": e2e_asr_conformer.E2E, "transformer": e2e_asr_transformer.E2E}[cls_name]
+    ns = argparse.Namespace(adim=64, aheads=4, elayers=2, eunits=128, dlayers=1, dunits=128, mtlalpha=0.3,
+                            lsm_weight=0.1, dropout_rate=0.0, transformer_length_normalized_loss=False)
+    for k, v in extra.items():
+        setattr(ns, k, v)
+    return cls(20, 50, ns)
+
+
+CASES = [
+    ("e2e_conformer.npz", "conformer", dict(transformer_encoder_pos_enc_layer_type="rel_pos",
+                                            transformer_encoder_selfattn_layer_type="rel_selfattn",
+                                            macaron_style=True, use_cnn_module=True, cnn_module_kernel=15)),
+    ("e2e_transformer.npz", "transformer", dict(eunits=256, dunits=256)),
+]
+
+
+@pytest.mark.parametrize("name,kind,extra", CASES)
+def test_e2e_golden_fp32(name, kind, extra):
+    """BASELINE config 1 scale: loss, accuracy, encoder output, every parameter gradient, greedy ids."""
+    p, sd, grads = split_golden(load_golden(name))
+    model = load_sd(_e2e(kind, extra), sd)
+    model.train()
+    loss = model(p["xs"].to(DEV), p["ilens"], p["ys"].to(DEV))
+    ref = float(p["loss"])
+    rel = abs(float(loss) - ref) / abs(ref)
+    print(f"[parity] {name} loss hip={float(loss):.6f} ref={ref:.6f} rel={rel:.2e}; acc hip={model.acc} ref={float(p['acc'])}")
+    assert rel < 1e-5
+    assert abs(model.acc - float(p["acc"])) < 1e-6
+    assert abs(float(model.ctc.loss) - float(p["loss_ctc"])) <= 1e-5 * abs(float(p["loss_ctc"]))
+    report(name + " hs_pad", model.hs_pad, p["hs_pad"], 1e-4)
+    report(name + " pred_pad", model.pred_pad, p["pred_pad"], 1e-4)
+    loss.backward()
+    check_grads(model, grads, tol=1e-3)
+    # eval mode (BatchNorm running stats updated by the training step) + greedy CTC ids, bit-exact
+    model.eval()
+    with torch.no_grad():
+        model(p["xs"].to(DEV), p["ilens"], p["ys"].to(DEV))
+        assert abs(float(model.loss) - float(p["eval_loss"])) <= 2e-5 * abs(float(p["eval_loss"]))
+    ra = argparse.Namespace(ctc_weight=1.0, beam_size=1)
+    hyp = model.recognize(p["xs"][0].numpy(), ra)
+    assert hyp[0]["yseq"][1:] == p["greedy"].tolist()
+
+
+@pytest.mark.parametrize("name,kind,extra", CASES)
+def test_e2e_golden_bf16(name, kind, extra):
+    """bf16-MFMA path against the reference's fp32 numbers: north_star bar = loss within 1e-3 rel."""
+    import espnet_amd
+    p, sd, grads = split_golden(load_golden(name))
+    model = load_sd(_e2e(kind, extra), sd)
+    model.train()
+    espnet_amd.set_precision("bf16")
+    loss = model(p["xs"].to(DEV), p["ilens"], p["ys"].to(DEV))
+    loss.backward()
+    espnet_amd.set_precision("fp32")
+    ref = float(p["loss"])
+    rel = abs(float(loss) - ref) / abs(ref)
+    print(f"[parity] {name} bf16 loss hip={float(loss):.6f} ref={ref:.6f} rel={rel:.2e}")
+    assert rel < 1e-3
+    cos = []
+    for k, q in model.named_parameters():
+        g = grads[k]
+        if float(g.norm()) > 1e-3:
+            cos.append(float(torch.nn.functional.cosine_similarity(q.grad.flatten().double().cpu(),
+                                                                   g.flatten().double(), dim=0)))
+    print(f"[parity] {name} bf16 min grad cosine {min(cos):.6f}")
+    assert min(cos) > 0.99
+
+
+def test_state_dict_keys_match_reference():
+    for name, kind, extra in CASES:
+        _, sd, _ = split_golden(load_golden(name))
+        model = _e2e(kind, extra)
+        assert list(model.state_dict().keys()) == list(sd.keys())
+        for k, v in model.state_dict().items():
+            assert tuple(v.shape) == tuple(sd[k].shape), k
+
+
+def test_midsize_vs_oracle(oracle):
+    """Ragged batch at a size between config 1 and config 2 (B=4, T=323, d=128, 3 layers, V=300):
+    HIP fp32 path vs the CPU oracle on identical seeded inputs and weights."""
+    from espnet_amd.nets.e2e_asr_conformer import E2E
+    torch.manual_seed(0)
+    ns = argparse.Namespace(adim=128, aheads=4, elayers=3, eunits=256, dlayers=2, dunits=256, mtlalpha=0.3,
+                            lsm_weight=0.1, dropout_rate=0.0, transformer_length_normalized_loss=False,
+                            transformer_encoder_pos_enc_layer_type="rel_pos",
+                            transformer_encoder_selfattn_layer_type="rel_selfattn", macaron_style=True,
+                            use_cnn_module=True, cnn_module_kernel=31)
+    model = E2E(80, 300, ns)
+    sd = {k: v.clone() for k, v in model.state_dict().items()}
+    g = torch.Generator().manual_seed(1)
+    xs = torch.randn(4, 323, 80, generator=g)
+    ilens = [323, 290, 211, 194]
+    ys = torch.randint(1, 299, (4, 20), generator=g)
+    ys[1, 15:] = -1
+    ys[3, 10:] = -1
+    cfg = dict(conformer=True, rel_pos=True, activation="swish", aheads=4, mtlalpha=0.3, lsm_weight=0.1, odim=300)
+    sdr = {k: (v.clone().requires_grad_(True) if v.is_floating_point() else v) for k, v in sd.items()}
+    ref = oracle.e2e_forward(sdr, xs, ilens, ys, cfg, training=True)
+    ref["loss"].backward()
+    model = model.to(DEV)
+    model.train()
+    loss = model(xs.to(DEV), ilens, ys.to(DEV))
+    loss.backward()
+    rel = abs(float(loss) - float(ref["loss"])) / abs(float(ref["loss"]))
+    print(f"[parity] midsize loss hip={float(loss):.5f} oracle={float(ref['loss']):.5f} rel={rel:.2e}")
+    assert rel < 2e-5
+    report("midsize hs_pad", model.hs_pad, ref["hs_pad"].detach(), 2e-4)
+    worst = 0.0
+    for k, q in model.named_parameters():
+        gr = sdr[k].grad
+        if float(gr.norm()) < 1e-4:
+            continue
+        e = float((q.grad.double().cpu() - gr.double()).norm() / gr.double().norm())
+        worst = max(worst, e)
+        assert e < 2e-3, (k, e)
+    print(f"[parity] midsize worst param-grad rel err {worst:.3e}")
+    # greedy CTC token ids, batched, bit-exact vs oracle
+    model.eval()
+    ids, n = model.greedy_ctc_batch(xs.to(DEV), ilens)
+    sde = {k: v.detach() for k, v in model.state_dict().items()}
+    sde = {k: v.cpu() for k, v in sde.items()}
+    from espnet_amd.nets.modules import subsampled_lengths
+    hl = subsampled_lengths(ilens, 323)
+    hs, _ = oracle.encoder(sde, "encoder.", xs, oracle.non_pad_mask(ilens).unsqueeze(-2), cfg, training=False)
+    lg = oracle.linear(sde, "ctc.ctc_lo.", hs)
+    for b in range(4):
+        assert ids[b, : int(n[b])].tolist() == oracle.greedy_ctc(lg[b, : hl[b]])

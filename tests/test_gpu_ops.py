@@ -1,0 +1,442 @@
+"""GPU parity tests, kernel level: every HIP entry point against the CPU oracle / torch float64 on the
+same seeded inputs, and against the vectors recorded from the reference (tests/golden).
+Bar: integer work bit-exact; fp32 path rtol ~1e-4 (accumulation order differs from MKL);
+bf16-MFMA path within the bf16 input-rounding bound (stated per test)."""
+import math
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import load_golden, split_golden
+
+pytestmark = pytest.mark.gpu
+
+DEV = "cuda"
+
+
+@pytest.fixture(scope="module")
+def ops():
+    from espnet_amd import ops as o
+    o.set_precision("fp32")
+    return o
+
+
+def rel_err(a, b):
+    a, b = a.double().cpu(), b.double().cpu()
+    return float((a - b).norm() / (b.norm() + 1e-30))
+
+
+def report(name, a, b, tol):
+    e = rel_err(a, b)
+    mx = float((a.double().cpu() - b.double().cpu()).abs().max())
+    print(f"[parity] {name}: rel_l2={e:.3e} max_abs={mx:.3e} (tol {tol:g})")
+    assert e <= tol, f"{name}: rel err {e} > {tol}"
+
+
+# ---------------------------------------------------------------------------------------------
+# GEMM family
+# ---------------------------------------------------------------------------------------------
+GEMM_SHAPES = [(1, 1, 1), (5, 7, 3), (64, 64, 32), (65, 63, 33), (128, 128, 64), (257, 130, 100), (249, 249, 64),
+               (300, 5000, 256), (7968 // 8, 256, 2048)]
+
+
+@pytest.mark.parametrize("prec,tol", [("fp32", 2e-6), ("bf16", 6e-3)])
+@pytest.mark.parametrize("tile", [0, 64, 128])
+def test_gemm_nt_shapes(ops, prec, tol, tile):
+    g = torch.Generator().manual_seed(0)
+    for (M, N, K) in GEMM_SHAPES:
+        A = torch.randn(M, K, generator=g)
+        B = torch.randn(N, K, generator=g)
+        bias = torch.randn(N, generator=g)
+        C = torch.empty(M, N, device=DEV)
+        ops.gemm(A.to(DEV), B.to(DEV), C, M, N, K, K, K, N, bias=bias.to(DEV), tile=tile,
+                 precision=0 if prec == "fp32" else 1)
+        ref = A.double() @ B.double().t() + bias.double()
+        report(f"gemm_nt[{prec},tile{tile}] {M}x{N}x{K}", C, ref, tol)
+
+
+@pytest.mark.parametrize("prec,tol", [("fp32", 2e-6), ("bf16", 6e-3)])
+def test_gemm_layouts_batch_epilogues(ops, prec, tol):
+    pr = 0 if prec == "fp32" else 1
+    g = torch.Generator().manual_seed(1)
+    M, N, K = 77, 45, 53
+    A = torch.randn(M, K, generator=g)
+    Bm = torch.randn(K, N, generator=g)
+    # NN (B stored [K,N])
+    C = torch.empty(M, N, device=DEV)
+    ops.gemm(A.to(DEV), Bm.to(DEV), C, M, N, K, K, N, N, transB=1, precision=pr)
+    report("gemm_nn", C, A.double() @ Bm.double(), tol)
+    # TN (A stored [K,M]) + accumulate through beta
+    At = torch.randn(K, M, generator=g)
+    C0 = torch.randn(M, N, generator=g)
+    C = C0.clone().to(DEV)
+    ops.gemm(At.to(DEV), Bm.to(DEV), C, M, N, K, M, N, N, transA=1, transB=1, beta=1.0, alpha=0.5, precision=pr)
+    report("gemm_tn_beta", C, 0.5 * (At.double().t() @ Bm.double()) + C0.double(), tol)
+    # split-K atomics accumulate into C
+    C = C0.clone().to(DEV)
+    ops.gemm(At.to(DEV), Bm.to(DEV), C, M, N, K, M, N, N, transA=1, transB=1, splitk=3, precision=pr)
+    report("gemm_tn_splitk", C, At.double().t() @ Bm.double() + C0.double(), tol)
+    # epilogues: relu, swish, residual, prologue activation, masks
+    Bn = torch.randn(N, K, generator=g)
+    bias = torch.randn(N, generator=g)
+    R = torch.randn(M, N, generator=g)
+    aux = torch.randn(M, N, generator=g)
+    base = A.double() @ Bn.double().t() + bias.double()
+    for epi, fn in ((1, lambda v: v.clamp_min(0)), (2, lambda v: v * torch.sigmoid(v)),
+                    (3, lambda v: v * (aux.double() > 0)),
+                    (4, lambda v: v * (torch.sigmoid(aux.double()) * (1 + aux.double() * (1 - torch.sigmoid(aux.double())))))):
+        C = torch.empty(M, N, device=DEV)
+        ops.gemm(A.to(DEV), Bn.to(DEV), C, M, N, K, K, K, N, bias=bias.to(DEV), epilogue=epi, aux=aux.to(DEV),
+                 ldaux=N, R=R.to(DEV), ldr=N, alpha=0.7, precision=pr)
+        report(f"gemm_epilogue{epi}", C, 0.7 * fn(base) + R.double(), tol)
+    C = torch.empty(M, N, device=DEV)
+    ops.gemm(A.to(DEV), Bn.to(DEV), C, M, N, K, K, K, N, a_act=2, precision=pr)
+    sw = A.double() * torch.sigmoid(A.double())
+    report("gemm_a_act_swish", C, sw @ Bn.double().t(), tol)
+    # two-level strided batch (attention layout): q,k [B,T,H,dk] -> scores [H,B,T1,ldp]
+    Bb, T1, T2, H, dk = 3, 10, 13, 4, 16
+    D = H * dk
+    q = torch.randn(Bb, T1, D, generator=g)
+    k = torch.randn(Bb, T2, D, generator=g)
+    ldp = 16
+    sc = torch.zeros(H * Bb * T1 * ldp, device=DEV)
+    ops.gemm(q.to(DEV), k.to(DEV), sc, T1, T2, dk, D, D, ldp, batch=(Bb, H), sA=(T1 * D, dk), sB=(T2 * D, dk),
+             sC=(T1 * ldp, Bb * T1 * ldp), precision=pr)
+    ref = torch.einsum("bihd,bjhd->hbij", q.view(Bb, T1, H, dk).double(), k.view(Bb, T2, H, dk).double())
+    report("gemm_batched_scores", sc.view(H, Bb, T1, ldp)[..., :T2], ref, tol)
+
+
+@pytest.mark.parametrize("prec,tol", [("fp32", 3e-6), ("bf16", 6e-3)])
+def test_gemm_implicit_conv(ops, prec, tol):
+    """Conv2d(C,C,3,2) forward / weight-grad / input-grad as implicit GEMMs vs torch conv2d (float64)."""
+    pr = 0 if prec == "fp32" else 1
+    from espnet_amd import functional as F_
+    g = torch.Generator().manual_seed(2)
+    B, H1, W1, Cc = 2, 17, 9, 64
+    H2, W2 = (H1 - 3) // 2 + 1, (W1 - 3) // 2 + 1
+    y1 = torch.randn(B, H1, W1, Cc, generator=g)             # NHWC
+    w = torch.randn(Cc, Cc, 3, 3, generator=g) * 0.1
+    dy2 = torch.randn(B, H2, W2, Cc, generator=g)
+    y1d = y1.permute(0, 3, 1, 2).double().requires_grad_(True)
+    wd_ = w.double().requires_grad_(True)
+    ref = torch.nn.functional.conv2d(y1d, wd_, stride=2)
+    ref.backward(dy2.permute(0, 3, 1, 2).double())
+    wf, wdd = ops.conv2_weight_prep(w.to(DEV))
+    assert torch.equal(wf.cpu(), w.permute(2, 3, 1, 0).reshape(9, Cc, Cc))
+    gth = ops.make_gather(Cc, F_._TAPS_FWD, H2, W2, H1, W1, 2, 2)
+    M2 = B * H2 * W2
+    y2 = torch.empty(M2, Cc, device=DEV)
+    ops.gemm(y1.to(DEV), wf, y2, M2, Cc, 9 * Cc, 9 * Cc, Cc, Cc, transB=1, gather=gth, precision=pr)
+    report("conv2_fwd", y2.view(B, H2, W2, Cc), ref.permute(0, 2, 3, 1), tol)
+    dwf = torch.zeros(9 * Cc, Cc, device=DEV)
+    ops.gemm(y1.to(DEV), dy2.reshape(M2, Cc).to(DEV), dwf, 9 * Cc, Cc, M2, 9 * Cc, Cc, Cc, transA=1, transB=1,
+             gather=gth, splitk=2, tile=64, precision=pr)
+    dw = torch.zeros(Cc, Cc, 3, 3, device=DEV)
+    ops.conv2_weight_grad(dwf, dw, Cc, Cc)
+    report("conv2_bwd_w", dw, wd_.grad, tol)
+    dy1 = torch.full((B, H1, W1, Cc), float("nan"), device=DEV)
+    ones = torch.ones(B, H1, W1, Cc, device=DEV)
+    q0 = 0
+    for (ph, pw), taps in F_._CLASSES:
+        Ho, Wo = (H1 - ph + 1) // 2, (W1 - pw + 1) // 2
+        gt = ops.make_gather(Cc, [((ph - kh) // 2, (pw - kw) // 2) for kh, kw in taps], Ho, Wo, H2, W2, 1, 1)
+        cm = ops.make_rowmap(Ho, Wo, H1, W1, 2, ph, 2, pw)
+        nt = len(taps)
+        ops.gemm(dy2.reshape(M2, Cc).to(DEV), wdd, dy1, B * Ho * Wo, Cc, nt * Cc, nt * Cc, Cc, Cc, transB=1,
+                 b_off=q0 * Cc * Cc, gather=gt, cmap=cm, epilogue=3, aux=ones, ldaux=Cc, precision=pr)
+        q0 += nt
+    report("conv2_bwd_x", dy1, y1d.grad.permute(0, 2, 3, 1), tol)
+
+
+# ---------------------------------------------------------------------------------------------
+# row kernels
+# ---------------------------------------------------------------------------------------------
+def test_layernorm_golden(ops):
+    p, sd, grads = split_golden(load_golden("layernorm.npz"))
+    x = p["x"].reshape(-1, 64).to(DEV)
+    w, b = sd["weight"].to(DEV), sd["bias"].to(DEV)
+    y, mean, rstd = ops.layernorm_fwd(x, w, b, 1e-12)
+    report("layernorm_fwd", y, p["y"].reshape(-1, 64), 1e-6)
+    dg, db = torch.zeros(64, device=DEV), torch.zeros(64, device=DEV)
+    dx = ops.layernorm_bwd(p["gy"].reshape(-1, 64).to(DEV), x, w, mean, rstd, None, dg, db)
+    report("layernorm_bwd_x", dx, p["gx"].reshape(-1, 64), 1e-5)
+    report("layernorm_bwd_w", dg, grads["weight"], 1e-5)
+    report("layernorm_bwd_b", db, grads["bias"], 1e-5)
+    # d=256 vector path + residual-gradient fusion
+    g = torch.Generator().manual_seed(3)
+    x = torch.randn(1000, 256, generator=g)
+    gy = torch.randn(1000, 256, generator=g)
+    res = torch.randn(1000, 256, generator=g)
+    w = torch.rand(256, generator=g) + 0.5
+    b = torch.randn(256, generator=g)
+    xd = x.double().requires_grad_(True)
+    wd_, bd_ = w.double().requires_grad_(True), b.double().requires_grad_(True)
+    yr = torch.nn.functional.layer_norm(xd, (256,), wd_, bd_, 1e-12)
+    yr.backward(gy.double())
+    y, mean, rstd = ops.layernorm_fwd(x.to(DEV), w.to(DEV), b.to(DEV), 1e-12)
+    report("layernorm256_fwd", y, yr, 1e-6)
+    dg, db = torch.zeros(256, device=DEV), torch.zeros(256, device=DEV)
+    dx = ops.layernorm_bwd(gy.to(DEV), x.to(DEV), w.to(DEV), mean, rstd, res.to(DEV), dg, db)
+    report("layernorm256_bwd_x+res", dx, xd.grad + res.double(), 1e-5)
+    report("layernorm256_bwd_w", dg, wd_.grad, 1e-5)
+    report("layernorm256_bwd_b", db, bd_.grad, 1e-5)
+
+
+def test_softmax_relshift_golden(ops, oracle):
+    """rel_shift index map (bit-exact data movement) + masked softmax incl. a fully masked row."""
+    p, _, _ = split_golden(load_golden("rel_shift.npz"))
+    for key_x, key_y in (("x", "y"), ("x2", "y2")):
+        x, want = p[key_x], p[key_y]
+        b, h, t1, t2 = x.shape
+        ld = (t2 + 3) // 4 * 4
+        bd = torch.zeros(h * b * t1 * ld)
+        bd.view(h, b, t1, ld)[..., :t2] = x.permute(1, 0, 2, 3)
+        ac = torch.zeros_like(bd)
+        P = torch.empty(h * b * t1 * ld, device=DEV)
+        ops.softmax_fwd(ac.to(DEV), bd.to(DEV), None, P, h * b, b, t1, t2, ld, 1.0)
+        ref = torch.softmax(want.double(), -1).permute(1, 0, 2, 3)
+        report("softmax(rel_shift) " + key_x, P.view(h, b, t1, ld)[..., :t2], ref, 1e-6)
+        assert float(P.view(h, b, t1, ld)[..., t2:].abs().sum()) == 0.0
+    # masks + backward vs autograd (float64)
+    g = torch.Generator().manual_seed(4)
+    b, h, t1, t2 = 2, 3, 7, 7
+    ld = 8
+    ac = torch.randn(h, b, t1, ld, generator=g)
+    bdm = torch.randn(h, b, t1, ld, generator=g)
+    mask = torch.ones(b, t1, t2, dtype=torch.uint8)
+    mask[1, :, 5:] = 0
+    mask[0, 3, :] = 0     # fully masked query row
+    dP = torch.randn(h, b, t1, ld, generator=g)
+    acd = ac[..., :t2].double().requires_grad_(True)
+    bdd = bdm[..., :t2].double().requires_grad_(True)
+    sc = (acd + oracle.rel_shift(bdd.permute(1, 0, 2, 3)).permute(1, 0, 2, 3)) * 0.25
+    mm = mask.bool().unsqueeze(0).eq(0)
+    pr = torch.softmax(sc.masked_fill(mm, torch.finfo(torch.float64).min), -1).masked_fill(mm, 0.0)
+    pr.backward(dP[..., :t2].double())
+    P = torch.empty(h * b * t1 * ld, device=DEV)
+    ops.softmax_fwd(ac.reshape(-1).to(DEV), bdm.reshape(-1).to(DEV), mask.to(DEV), P, h * b, b, t1, t2, ld, 0.25)
+    report("masked_softmax_fwd", P.view(h, b, t1, ld)[..., :t2], pr, 1e-6)
+    dS = dP.reshape(-1).clone().to(DEV)
+    dbd = torch.zeros(h * b * t1 * ld, device=DEV)
+    ops.softmax_bwd(P, dS, dbd, h * b, t1, t2, ld, 0.25)
+    report("masked_softmax_bwd_ac", dS.view(h, b, t1, ld)[..., :t2], acd.grad, 1e-5)
+    report("masked_softmax_bwd_bd", dbd.view(h, b, t1, ld)[..., :t2], bdd.grad, 1e-5)
+
+
+def test_lsm_loss_golden(ops):
+    p, _, _ = split_golden(load_golden("lsm_loss.npz"))
+    x = p["x"].reshape(-1, 17).to(DEV)
+    t = p["t"].reshape(-1).to(DEV)
+    rows, correct, grad = ops.lsm_loss(x, t, 0.1, 1.0 / 3, -1)
+    report("lsm_loss", ops.reduce_sum(rows, 1.0 / 3), p["loss_n0"], 2e-6)
+    report("lsm_grad", grad.view(3, 5, 17), p["gx_n0"], 1e-5)
+    n = int((p["t"] != -1).sum())
+    rows, _, grad = ops.lsm_loss(x, t, 0.1, 1.0 / n, -1)
+    report("lsm_loss_lengthnorm", ops.reduce_sum(rows, 1.0 / n), p["loss_n1"], 2e-6)
+    report("lsm_grad_lengthnorm", grad.view(3, 5, 17), p["gx_n1"], 1e-5)
+    rows, _, _ = ops.lsm_loss(x, t, 0.0, 1.0 / 3, -1, want_grad=False)
+    report("lsm_loss_smoothing0", ops.reduce_sum(rows, 1.0 / 3), p["loss_s0"], 2e-6)
+    acc = float(correct.sum()) / n
+    assert abs(acc - float(p["acc"])) < 1e-7
+
+
+def test_argmax_and_collapse_bit_exact(ops, oracle):
+    g = torch.Generator().manual_seed(5)
+    x = torch.randn(300, 5000, generator=g)
+    x[7, 100] = x[7, 4000] = 50.0      # tie -> lowest index
+    got = ops.argmax_rows(x.to(DEV)).cpu()
+    assert torch.equal(got.long(), x.argmax(-1))
+    ids = torch.randint(0, 4, (5, 40), generator=g, dtype=torch.int32)
+    hl = torch.tensor([40, 33, 1, 0, 17], dtype=torch.int32)
+    out, n = ops.ctc_collapse(ids.to(DEV), hl.to(DEV), 0)
+    for b in range(5):
+        row = ids[b, : int(hl[b])]
+        want, prev = [], None
+        for v in row.tolist():
+            if v != prev:
+                if v != 0:
+                    want.append(v)
+                prev = v
+        assert out[b, : int(n[b])].tolist() == want
+        assert (out[b, int(n[b]):] == -1).all()
+
+
+def test_add_sos_eos_bit_exact(ops, oracle):
+    ys = torch.tensor([[3, 4, 5, -1], [7, -1, -1, -1], [1, 2, 3, 4], [-1, -1, -1, -1]])
+    a, b, n = ops.add_sos_eos(ys.to(DEV), 9, 9, -1)
+    ra, rb = oracle.add_sos_eos(ys, 9, 9, -1)
+    assert torch.equal(a.cpu(), ra) and torch.equal(b.cpu(), rb)
+    assert n.tolist() == [3, 1, 4, 0]
+
+
+def test_ctc_golden(ops):
+    p, _, _ = split_golden(load_golden("ctc.npz"))
+    lg = p["logits"].contiguous().to(DEV)
+    hl = p["hlens"].to(torch.int32).to(DEV)
+    nll, grad = ops.ctc_loss(lg, p["ys"].to(DEV), hl, 0, -1, 1.0 / 3)
+    report("ctc_nll", nll, p["nll"], 2e-6)
+    report("ctc_loss", ops.reduce_sum(nll, 1.0 / 3), p["loss"], 2e-6)
+    report("ctc_grad", grad, p["glogits"], 2e-5)
+    assert float(grad[1, 4].abs().sum()) == 0.0          # frames beyond hlens get zero gradient
+    # infeasible alignment -> +inf, never an error code
+    nll, _ = ops.ctc_loss(lg[:1, :3].contiguous(), torch.tensor([[3, 3, 4]]).to(DEV),
+                          torch.tensor([3], dtype=torch.int32).to(DEV), 0, -1, 1.0, want_grad=False)
+    assert math.isinf(float(nll[0])) and float(nll[0]) > 0
+
+
+def test_ctc_random_vs_oracle(ops, oracle):
+    """ragged lengths, repeated labels, empty label sequence; loss and gradient vs torch CPU"""
+    g = torch.Generator().manual_seed(6)
+    B, T, V, L = 6, 50, 40, 12
+    x = torch.randn(B, T, V, generator=g)
+    ys = torch.randint(1, V, (B, L), generator=g)
+    ys[0, :] = 5                      # all-repeated labels
+    ys[1, 3:] = -1
+    ys[2, :] = -1                     # empty
+    ys[3, 1:] = ys[3, 0:1]
+    hl = torch.tensor([50, 40, 10, 50, 25, 49], dtype=torch.int32)
+    xd = x.double().requires_grad_(True)
+    ref = oracle.ctc_loss(xd, hl, ys)
+    ref.backward()
+    nll, grad = ops.ctc_loss(x.to(DEV), ys.to(DEV), hl.to(DEV), 0, -1, 1.0 / B)
+    report("ctc_random_loss", ops.reduce_sum(nll, 1.0 / B), ref, 1e-5)
+    report("ctc_random_grad", grad, xd.grad, 1e-4)
+    # property: every valid frame's gradient row sums to zero (softmax minus occupancies)
+    rs = grad.sum(-1).abs().max()
+    assert float(rs) < 1e-5
+
+
+# ---------------------------------------------------------------------------------------------
+# element-wise / conv module pieces
+# ---------------------------------------------------------------------------------------------
+def test_elementwise(ops):
+    g = torch.Generator().manual_seed(7)
+    a = torch.randn(33, 2 * 48, generator=g)
+    dy = torch.randn(33, 48, generator=g)
+    ad = a.double().requires_grad_(True)
+    yr = torch.nn.functional.glu(ad, -1)
+    yr.backward(dy.double())
+    report("glu_fwd", ops.glu_fwd(a.to(DEV), 48), yr, 1e-6)
+    report("glu_bwd", ops.glu_bwd(dy.to(DEV), a.to(DEV), 48), ad.grad, 1e-6)
+    x = torch.randn(1001, generator=g)
+    y = torch.randn(1001, generator=g)
+    report("axpby", ops.axpby(x.to(DEV), y.to(DEV), 0.3, -1.5), 0.3 * x.double() - 1.5 * y.double(), 1e-6)
+    m = torch.randn(500, 70, generator=g)
+    out = torch.ones(70, device=DEV)
+    ops.colsum(m.to(DEV), out, 2.0)
+    report("colsum", out, 1 + 2 * m.double().sum(0), 1e-5)
+    tok = torch.randint(0, 11, (3, 5), generator=g)
+    table = torch.randn(11, 16, generator=g)
+    pe = torch.randn(9, 16, generator=g)
+    e = ops.embed_pe(tok.to(DEV), table.to(DEV), pe.to(DEV), 5, 4.0)
+    report("embed_pe", e.view(3, 5, 16), table[tok].double() * 4 + pe[:5].double(), 1e-6)
+    dt = torch.zeros(11, 16, device=DEV)
+    do = torch.randn(15, 16, generator=g)
+    ops.embed_bwd(tok.reshape(-1).to(DEV), do.to(DEV), dt, 4.0)
+    ref = torch.zeros(11, 16, dtype=torch.float64).index_add_(0, tok.reshape(-1), do.double() * 4)
+    report("embed_bwd", dt, ref, 1e-5)
+
+
+def test_dwconv_bn(ops):
+    g = torch.Generator().manual_seed(8)
+    B, T, Cc, K = 3, 29, 64, 15
+    x = torch.randn(B, T, Cc, generator=g)
+    w = torch.randn(Cc, 1, K, generator=g)
+    bias = torch.randn(Cc, generator=g)
+    dy = torch.randn(B, T, Cc, generator=g)
+    xd = x.double().requires_grad_(True)
+    wd_, bd_ = w.double().requires_grad_(True), bias.double().requires_grad_(True)
+    yr = torch.nn.functional.conv1d(xd.transpose(1, 2), wd_, bd_, padding=(K - 1) // 2, groups=Cc).transpose(1, 2)
+    yr.backward(dy.double())
+    y = ops.dwconv_fwd(x.to(DEV), w.view(Cc, K).to(DEV), bias.to(DEV), B, T, Cc, K)
+    report("dwconv_fwd", y, yr, 1e-6)
+    report("dwconv_bwd_x", ops.dwconv_bwd_x(dy.to(DEV), w.view(Cc, K).to(DEV), B, T, Cc, K), xd.grad, 1e-6)
+    dw, db = torch.zeros(Cc, K, device=DEV), torch.zeros(Cc, device=DEV)
+    ops.dwconv_bwd_w(dy.to(DEV), x.to(DEV), dw, db, B, T, Cc, K)
+    report("dwconv_bwd_w", dw, wd_.grad.view(Cc, K), 1e-5)
+    report("dwconv_bwd_b", db, bd_.grad, 1e-5)
+    # batch norm (train) + swish
+    M = B * T
+    xb = (torch.randn(M, Cc, generator=g) * 2 + 1)
+    gam, bet = torch.rand(Cc, generator=g) + 0.5, torch.randn(Cc, generator=g)
+    rm, rv = torch.zeros(Cc), torch.ones(Cc)
+    xbd = xb.double().requires_grad_(True)
+    gd, bd2 = gam.double().requires_grad_(True), bet.double().requires_grad_(True)
+    rmd, rvd = rm.double().clone(), rv.double().clone()
+    z = torch.nn.functional.batch_norm(xbd, rmd, rvd, gd, bd2, True, 0.1, 1e-5)
+    yr = z * torch.sigmoid(z)
+    dyb = torch.randn(M, Cc, generator=g)
+    yr.backward(dyb.double())
+    rmg, rvg = rm.to(DEV), rv.to(DEV)
+    mean, rstd = ops.bn_stats(xb.to(DEV), M, Cc, 1e-5, 0.1, rmg, rvg)
+    y = ops.bn_apply(xb.to(DEV), mean, rstd, gam.to(DEV), bet.to(DEV), M, Cc, 2)
+    report("bn_swish_fwd", y, yr, 2e-6)
+    report("bn_running_mean", rmg, rmd, 1e-6)
+    report("bn_running_var", rvg, rvd, 1e-6)
+    dg, dbt = torch.zeros(Cc, device=DEV), torch.zeros(Cc, device=DEV)
+    dx = ops.bn_bwd(dyb.to(DEV), xb.to(DEV), mean, rstd, gam.to(DEV), bet.to(DEV), dg, dbt, M, Cc, 2, True)
+    report("bn_swish_bwd_x", dx, xbd.grad, 2e-5)
+    report("bn_bwd_gamma", dg, gd.grad, 2e-5)
+    report("bn_bwd_beta", dbt, bd2.grad, 2e-5)
+
+
+def test_conv1(ops):
+    g = torch.Generator().manual_seed(9)
+    B, T, F, Cc = 2, 21, 20, 64
+    x = torch.randn(B, T, F, generator=g)
+    w = torch.randn(Cc, 1, 3, 3, generator=g)
+    b = torch.randn(Cc, generator=g)
+    wd_, bd_ = w.double().requires_grad_(True), b.double().requires_grad_(True)
+    pre = torch.nn.functional.conv2d(x.double().unsqueeze(1), wd_, bd_, stride=2)
+    yr = torch.relu(pre)
+    y = ops.conv1_fwd(x.to(DEV), w.to(DEV), b.to(DEV), B, T, F, Cc)
+    report("conv1_fwd", y, yr.permute(0, 2, 3, 1), 1e-6)
+    dy = torch.randn_like(yr)
+    yr.backward(dy)
+    dyn = (dy * (pre > 0)).permute(0, 2, 3, 1).contiguous().float()
+    dw, db = torch.zeros(Cc, 9, device=DEV), torch.zeros(Cc, device=DEV)
+    ops.conv1_bwd_w(dyn.to(DEV), x.to(DEV), dw, db, B, T, F, Cc)
+    report("conv1_bwd_w", dw, wd_.grad.view(Cc, 9), 1e-5)
+    report("conv1_bwd_b", db, bd_.grad, 1e-5)
+
+
+def test_optimizer(ops):
+    """Adam + Noam schedule + clipping vs torch.optim.Adam / clip_grad_norm_ (fp32 CPU)."""
+    g = torch.Generator().manual_seed(10)
+    n = 10007
+    p0 = torch.randn(n, generator=g)
+    pr = p0.clone().requires_grad_(True)
+    opt = torch.optim.Adam([pr], lr=0.0, betas=(0.9, 0.98), eps=1e-9)
+    pad = (4 - n % 4) % 4
+    p = torch.zeros(n + pad)
+    p[:n] = p0
+    p, m, v = p.to(DEV), torch.zeros(n + pad, device=DEV), torch.zeros(n + pad, device=DEV)
+    state = torch.zeros(8, device=DEV)
+    ws = torch.empty(1024, device=DEV)
+    gn = torch.empty(1, device=DEV)
+    factor, dmodel, warm = 1.0, 256.0, 25.0
+    for step in range(1, 6):
+        gr = torch.randn(n, generator=g) * (10.0 if step == 3 else 0.1)
+        pr.grad = gr.clone()
+        torch.nn.utils.clip_grad_norm_([pr], 5.0)
+        lr = factor * dmodel ** -0.5 * min(step ** -0.5, step * warm ** -1.5)
+        for grp in opt.param_groups:
+            grp["lr"] = lr
+        opt.step()
+        gfull = torch.zeros(n + pad)
+        gfull[:n] = gr
+        gd = gfull.to(DEV)
+        ops.grad_norm(gd, ws, gn)
+        ops.sched_step(state, gn, 1, 0.0, factor, dmodel, warm, 0.9, 0.98, 5.0)
+        ops.adam_step(p, gd, m, v, state, 0.9, 0.98, 1e-9, 0.0)
+        assert abs(float(gn) - float(gr.norm())) <= 1e-5 * float(gr.norm())
+        assert abs(float(state[1]) - lr) <= 1e-6 * lr
+    report("adam_5_steps", p[:n], pr.detach(), 1e-5)
+    # non-finite gradient -> step skipped, parameters untouched (trainer.py:439-455)
+    before = p.clone()
+    gd = torch.full((n + pad,), float("nan"), device=DEV)
+    ops.grad_norm(gd, ws, gn)
+    ops.sched_step(state, gn, 1, 0.0, factor, dmodel, warm, 0.9, 0.98, 5.0)
+    ops.adam_step(p, gd, m, v, state, 0.9, 0.98, 1e-9, 0.0)
+    assert torch.equal(p, before) and float(state[0]) == 5.0 and float(state[5]) == 1.0
