@@ -16,6 +16,8 @@ from .ops import (ACT_NONE, ACT_RELU, ACT_SWISH, EPI_MUL_DSWISH, EPI_MUL_RELU_MA
 class GradSink:
     """Where backward kernels accumulate parameter gradients."""
 
+    on_done = None   # optional callback(params): gradients of these parameters are final (DDP buckets)
+
     def __init__(self, params):
         self.params = list(params)
         self.ret = [None] * len(self.params)
@@ -30,6 +32,8 @@ class GradSink:
         return self.ret[i]
 
     def results(self):
+        if GradSink.on_done is not None:
+            GradSink.on_done(self.params)
         return tuple(self.ret)
 
 

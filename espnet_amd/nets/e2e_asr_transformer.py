@@ -157,30 +157,44 @@ class E2E(ASRInterface, torch.nn.Module):
                 m.reset_parameters()
 
     # ---- training forward ---------------------------------------------------------------------
-    def forward(self, xs_pad, ilens, ys_pad):
-        """reference: e2e_asr_transformer.py:159-241.  Returns the 0-dim loss tensor."""
+    def prepare(self, xs_pad, ilens, ys_pad):
+        """Host-side part of forward (lengths, masks, <sos>/<eos>): everything that needs Python lists
+        or H2D copies.  The returned dict feeds forward_core(), which only launches kernels and can be
+        captured into a hipGraph.  reference: e2e_asr_transformer.py:173-183,202."""
         il = [int(v) for v in (ilens.tolist() if isinstance(ilens, torch.Tensor) else ilens)]
         tmax = max(il)
-        xs_pad = xs_pad[:, :tmax]
-        src_mask = make_non_pad_mask(il).unsqueeze(-2)           # (B,1,T) bool, host
-        hs_pad, hs_mask = self.encoder(xs_pad, src_mask)
-        self.hs_pad = hs_pad
-        dev = hs_pad.device
-
-        loss_att = loss_ctc = None
-        self.acc = None
+        dev = next(self.parameters()).device
+        xs_pad = xs_pad[:, :tmax].to(dev).contiguous()
+        ys_pad = ys_pad.to(dev).contiguous()
+        src_mask = make_non_pad_mask(il).unsqueeze(-2).to(dev).to(torch.uint8)     # (B,1,T)
+        batch = dict(xs_pad=xs_pad, ys_pad=ys_pad, src_mask=src_mask, B=xs_pad.size(0))
         if self.decoder is not None:
-            ys_in_pad, ys_out_pad, _ = ops.add_sos_eos(ys_pad.contiguous(), self.sos, self.eos, self.ignore_id)
+            ys_in_pad, ys_out_pad, _ = ops.add_sos_eos(ys_pad, self.sos, self.eos, self.ignore_id)
             U = ys_in_pad.size(1)
-            ys_mask = subsequent_mask(U).unsqueeze(0).expand(xs_pad.size(0), U, U)   # ys_in has no -1
-            pred_pad, _ = self.decoder(ys_in_pad, ys_mask.contiguous(), hs_pad, hs_mask)
-            self.pred_pad = pred_pad
-            loss_att = self.criterion(pred_pad, ys_out_pad)
-            self._acc_t = th_accuracy(self.criterion.correct_rows, ys_out_pad, self.ignore_id)
+            # ys_in is padded with <eos>, never ignore_id, so target_mask() is the causal mask (mask.py:41-51)
+            ys_mask = subsequent_mask(U).unsqueeze(0).expand(xs_pad.size(0), U, U).to(torch.uint8).contiguous()
+            batch.update(ys_in_pad=ys_in_pad, ys_out_pad=ys_out_pad, ys_mask=ys_mask.to(dev),
+                         n_valid=(ys_out_pad != self.ignore_id).sum())
         if self.mtlalpha > 0.0:
-            hs_len = subsampled_lengths(il, tmax)
-            loss_ctc = self.ctc(hs_pad.view(xs_pad.size(0), -1, self.adim), hs_len, ys_pad)
+            batch["hs_len"] = torch.tensor(subsampled_lengths(il, tmax), dtype=torch.int32).to(dev)
+        return batch
 
+    def forward_core(self, batch):
+        """Kernel-only part of forward (reference: e2e_asr_transformer.py:175-232)."""
+        xs_pad = batch["xs_pad"]
+        hs_pad, hs_mask = self.encoder(xs_pad, batch["src_mask"])
+        self.hs_pad = hs_pad
+        if hs_mask is not None and not hs_mask.is_contiguous():
+            hs_mask = hs_mask.contiguous()
+        loss_att = loss_ctc = None
+        self._acc_t = None
+        if self.decoder is not None:
+            pred_pad, _ = self.decoder(batch["ys_in_pad"], batch["ys_mask"], hs_pad, hs_mask)
+            self.pred_pad = pred_pad
+            loss_att = self.criterion(pred_pad, batch["ys_out_pad"])
+            self._acc_t = ops.reduce_sum(self.criterion.correct_rows) / batch["n_valid"]
+        if self.mtlalpha > 0.0:
+            loss_ctc = self.ctc(hs_pad.view(batch["B"], -1, self.adim), batch["hs_len"], batch["ys_pad"])
         alpha = self.mtlalpha
         if alpha == 0:
             self.loss = loss_att
@@ -188,8 +202,13 @@ class E2E(ASRInterface, torch.nn.Module):
             self.loss = loss_ctc
         else:
             self.loss = F_.WeightedSumFn.apply(loss_ctc, loss_att, alpha)
-
         self._loss_ctc_t, self._loss_att_t = loss_ctc, loss_att
+        return self.loss
+
+    def forward(self, xs_pad, ilens, ys_pad):
+        """reference: e2e_asr_transformer.py:159-241.  Returns the 0-dim loss tensor."""
+        self.loss = self.forward_core(self.prepare(xs_pad, ilens, ys_pad))
+        self.acc = None
         if self.sync_report:
             self._report()
         return self.loss

@@ -205,7 +205,7 @@ class Conv2dSubsampling(torch.nn.Module):
             y = F_.PosEncFn.apply(y, pos.pe, 1.0)   # x*xscale already applied in the Linear epilogue
         if x_mask is None:
             return y, None
-        return y, x_mask[:, :, :-2:2][:, :, :-2:2]
+        return y, x_mask[:, :, :-2:2][:, :, :-2:2].contiguous()
 
 
 # ---- attention ---------------------------------------------------------------------------------

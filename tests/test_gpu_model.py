@@ -56,7 +56,8 @@ def test_conv2d_subsampling_golden():
         y, ym = sub(p["x"].to(DEV), p["mask"])
         if isinstance(y, tuple):
             y, pos = y
-            report("subsampling pos_emb", pos, p["pos"], 1e-6)
+            # table = host sin/cos of positions up to 4999 in fp32: libm differs across CPUs by ~1e-5 rel
+            report("subsampling pos_emb", pos, p["pos"], 1e-4)
         report("subsampling_%s fwd" % name, y, p["y"], 1e-5)
         assert torch.equal(ym.cpu(), p["ymask"])
         y.backward(p["gy"].to(DEV))
