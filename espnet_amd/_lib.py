@@ -31,7 +31,7 @@ class RowMapT(C.Structure):
 
 class GemmT(C.Structure):
     _fields_ = [("A", C.c_void_p), ("B", C.c_void_p), ("C", C.c_void_p), ("bias", C.c_void_p),
-                ("aux", C.c_void_p), ("R", C.c_void_p),
+                ("aux", C.c_void_p), ("R", C.c_void_p), ("colsum", C.c_void_p),
                 ("M", C.c_int32), ("N", C.c_int32), ("K", C.c_int32),
                 ("transA", C.c_int32), ("transB", C.c_int32),
                 ("lda", C.c_int64), ("ldb", C.c_int64), ("ldc", C.c_int64), ("ldaux", C.c_int64),

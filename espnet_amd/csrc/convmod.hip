@@ -12,25 +12,45 @@ constexpr int KMAX = 32;
 
 // y[b,t,c] = bias[c] + sum_k w[c,k] * x[b, t + k - pad, c]         (flip=0, forward)
 // y[b,t,c] =           sum_k w[c,k] * x[b, t - k + pad, c]         (flip=1, input gradient)
+// One thread = one channel x TT consecutive frames: the K taps stay in registers and the input
+// window (TT + K - 1 values) is read once, lanes along C (coalesced 256-B rows).
+constexpr int TT = 8;
 __global__ __launch_bounds__(256) void dwconv_kernel(const float* __restrict__ x, const float* __restrict__ w,
                                                      const float* __restrict__ bias, float* __restrict__ y,
                                                      int B, int T, int C, int K, int pad, int flip) {
-  const long n = (long)B * T * C;
-  const long stride = (long)gridDim.x * blockDim.x;
-  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
-    const int c = i % C;
-    const long bt = i / C;
-    const int t = bt % T;
-    const long b = bt / T;
-    const float* xb = x + b * T * C + c;
-    const float* wc = w + (long)c * K;
-    float acc = (bias && !flip) ? bias[c] : 0.f;
-    for (int k = 0; k < K; ++k) {
-      int ts = flip ? t - k + pad : t + k - pad;
-      if (ts >= 0 && ts < T) acc += wc[k] * xb[(long)ts * C];
-    }
-    y[i] = acc;
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= C) return;
+  const int nchunk = (T + TT - 1) / TT;
+  const int b = blockIdx.y / nchunk;
+  const int t0 = (blockIdx.y % nchunk) * TT;
+  float wr[KMAX];
+#pragma unroll
+  for (int k = 0; k < KMAX; ++k) {
+    int kk = flip ? K - 1 - k : k;          // flipped taps turn the gradient into the same correlation
+    wr[k] = (k < K) ? w[(long)c * K + kk] : 0.f;
   }
+  const float bv = (bias && !flip) ? bias[c] : 0.f;
+  float acc[TT];
+#pragma unroll
+  for (int i = 0; i < TT; ++i) acc[i] = bv;
+  const float* xb = x + (long)b * T * C + c;
+  // window position j covers frame t0 - pad + j, j in [0, TT + K - 1)
+#pragma unroll
+  for (int j = 0; j < TT + KMAX - 1; ++j) {
+    if (j < TT + K - 1) {
+      const int ts = t0 - pad + j;
+      const float xv = (ts >= 0 && ts < T) ? xb[(long)ts * C] : 0.f;
+#pragma unroll
+      for (int i = 0; i < TT; ++i) {
+        const int k = j - i;                 // tap index feeding output t0 + i
+        if (k >= 0 && k < KMAX) acc[i] += wr[k] * xv;
+      }
+    }
+  }
+  float* yb = y + (long)b * T * C + c;
+#pragma unroll
+  for (int i = 0; i < TT; ++i)
+    if (t0 + i < T) yb[(long)(t0 + i) * C] = acc[i];
 }
 
 // dw[c,k] += sum_{b,t} dy[b,t,c] * x[b,t+k-pad,c];  db[c] += sum dy.  One block = (row slab, 256 channels).
@@ -240,16 +260,18 @@ extern "C" {
 int eamd_dwconv_fwd(const float* x, const float* w, const float* bias, float* y, int B, int T, int C, int K,
                     void* stream) {
   if (!x || !w || !y || B <= 0 || T <= 0 || C <= 0 || K <= 0 || (K & 1) == 0) return EAMD_EINVAL;
-  hipLaunchKernelGGL(dwconv_kernel, dim3(grid_for((long)B * T * C)), dim3(256), 0, (hipStream_t)stream, x, w, bias,
-                     y, B, T, C, K, (K - 1) / 2, 0);
+  if (K > KMAX) return EAMD_EUNSUPPORTED;
+  hipLaunchKernelGGL(dwconv_kernel, dim3((C + 255) / 256, B * ((T + TT - 1) / TT)), dim3(256), 0, (hipStream_t)stream,
+                     x, w, bias, y, B, T, C, K, (K - 1) / 2, 0);
   EAMD_LAUNCH_CHECK();
   return EAMD_OK;
 }
 
 int eamd_dwconv_bwd_x(const float* dy, const float* w, float* dx, int B, int T, int C, int K, void* stream) {
   if (!dy || !w || !dx || B <= 0 || T <= 0 || C <= 0 || K <= 0 || (K & 1) == 0) return EAMD_EINVAL;
-  hipLaunchKernelGGL(dwconv_kernel, dim3(grid_for((long)B * T * C)), dim3(256), 0, (hipStream_t)stream, dy, w,
-                     (const float*)nullptr, dx, B, T, C, K, (K - 1) / 2, 1);
+  if (K > KMAX) return EAMD_EUNSUPPORTED;
+  hipLaunchKernelGGL(dwconv_kernel, dim3((C + 255) / 256, B * ((T + TT - 1) / TT)), dim3(256), 0, (hipStream_t)stream,
+                     dy, w, (const float*)nullptr, dx, B, T, C, K, (K - 1) / 2, 1);
   EAMD_LAUNCH_CHECK();
   return EAMD_OK;
 }
@@ -260,7 +282,7 @@ int eamd_dwconv_bwd_w(const float* dy, const float* x, float* dw, float* db, int
   if (K > KMAX) return EAMD_EUNSUPPORTED;
   long rows = (long)B * T;
   int gx = (C + 255) / 256;
-  long want = 1024 / gx; if (want < 1) want = 1;
+  long want = 192 / gx; if (want < 1) want = 1;
   long rpb = (rows + want - 1) / want; if (rpb < 8) rpb = 8;
   int gy = (int)((rows + rpb - 1) / rpb);
   hipLaunchKernelGGL(dwconv_bwd_w_kernel, dim3(gx, gy), dim3(256), 0, (hipStream_t)stream, dy, x, dw, db, B, T, C,
@@ -272,13 +294,13 @@ int eamd_dwconv_bwd_w(const float* dy, const float* x, float* dw, float* db, int
 /* workspace: 3*C*nslab floats where nslab = eamd_bn_nslab(M, C) */
 int eamd_bn_nslab(int64_t M, int C) {
   int gx = (C + 255) / 256;
-  long want = 512 / gx; if (want < 1) want = 1;
+  long want = 96 / gx; if (want < 1) want = 1;
   long rpb = (M + want - 1) / want; if (rpb < 16) rpb = 16;
   return (int)((M + rpb - 1) / rpb);
 }
 static long bn_rpb(long M, int C) {
   int gx = (C + 255) / 256;
-  long want = 512 / gx; if (want < 1) want = 1;
+  long want = 96 / gx; if (want < 1) want = 1;
   long rpb = (M + want - 1) / want; if (rpb < 16) rpb = 16;
   return rpb;
 }

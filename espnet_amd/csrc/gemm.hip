@@ -161,6 +161,9 @@ __global__ __launch_bounds__(NTHREADS) void gemm_kernel(const eamd_gemm_t p) {
   }
 
   float4 ra[NIA], rb[NIB];
+  // bias gradient fused into the weight-gradient GEMM: column sums of the transposed A operand
+  const bool do_colsum = p.colsum != nullptr && p.transA && !gat && blockIdx.y == 0;
+  float cs_acc = 0.f;
 
   // transposed gather: the 32 reduction rows of a K-tile are decomposed once per block into LDS
   auto fill_poff = [&](int kt, int slot) {
@@ -197,6 +200,7 @@ __global__ __launch_bounds__(NTHREADS) void gemm_kernel(const eamd_gemm_t p) {
         for (int i = 0; i < NIA; ++i) {
           const int m = m0 + a_row[i];
           ra[i] = load_kstrided(A + m, p.lda, m < p.M, k0 + a_kq[i], p.K);
+          if (do_colsum) cs_acc += (ra[i].x + ra[i].y) + (ra[i].z + ra[i].w);
         }
       } else {
         const int c = (m0 % p.gather.C) + a_row[0];
@@ -300,6 +304,11 @@ __global__ __launch_bounds__(NTHREADS) void gemm_kernel(const eamd_gemm_t p) {
 
     if (more) store_tile(buf ^ 1);
     __syncthreads();
+  }
+
+  if (do_colsum) {
+    const int m = m0 + a_row[0];
+    if (m < p.M) atomicAdd(p.colsum + (long)zb * p.M + m, cs_acc * p.alpha);
   }
 
   // ---- epilogue ------------------------------------------------------------------------------

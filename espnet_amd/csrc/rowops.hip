@@ -73,6 +73,8 @@ __global__ __launch_bounds__(256) void layernorm_fwd_vec_kernel(const float* __r
 
 // Backward: dx per row; dgamma/dbeta accumulated per lane-column over the block's rows, combined
 // across the 4 waves through LDS and added to global with one atomic per column per block.
+// Lane l owns columns {4l..4l+3} + 256j (float4 accesses) when D % 256 == 0, else {l + 64c}.
+template <int VEC>   // VEC = D/256 for the vector form, 0 = generic (D <= 1024)
 __global__ __launch_bounds__(256) void layernorm_bwd_kernel(
     const float* __restrict__ dy, const float* __restrict__ x, const float* __restrict__ gamma,
     const float* __restrict__ mean, const float* __restrict__ rstd, const float* dres, float* dx,
@@ -83,43 +85,90 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(
   __syncthreads();
   const int r0 = blockIdx.x * rows_per_block;
   const int r1 = min(rows, r0 + rows_per_block);
-  // columns owned by this lane: lane, lane+64, ... (at most 16 per lane kept in registers)
-  constexpr int MAXC = 16;
-  float ag[MAXC], ab[MAXC];
+  if constexpr (VEC > 0) {
+    float4 ag[VEC], ab[VEC], g4[VEC];
 #pragma unroll
-  for (int c = 0; c < MAXC; ++c) { ag[c] = 0.f; ab[c] = 0.f; }
-  for (int row = r0 + wave; row < r1; row += 4) {
-    const float* dyr = dy + (long)row * D;
-    const float* xr = x + (long)row * D;
-    const float mu = mean[row], rs = rstd[row];
-    float s1 = 0.f, s2 = 0.f;
+    for (int j = 0; j < VEC; ++j) {
+      ag[j] = make_float4(0.f, 0.f, 0.f, 0.f); ab[j] = ag[j];
+      g4[j] = reinterpret_cast<const float4*>(gamma)[lane + 64 * j];
+    }
+    for (int row = r0 + wave; row < r1; row += 4) {
+      const float4* dyr = reinterpret_cast<const float4*>(dy + (long)row * D);
+      const float4* xr = reinterpret_cast<const float4*>(x + (long)row * D);
+      const float mu = mean[row], rs = rstd[row];
+      float4 d4[VEC], h4[VEC];
+      float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+      for (int j = 0; j < VEC; ++j) {
+        d4[j] = dyr[lane + 64 * j];
+        float4 xv = xr[lane + 64 * j];
+        h4[j] = make_float4((xv.x - mu) * rs, (xv.y - mu) * rs, (xv.z - mu) * rs, (xv.w - mu) * rs);
+        float a = d4[j].x * g4[j].x, b = d4[j].y * g4[j].y, c = d4[j].z * g4[j].z, d = d4[j].w * g4[j].w;
+        s1 += (a + b) + (c + d);
+        s2 += (a * h4[j].x + b * h4[j].y) + (c * h4[j].z + d * h4[j].w);
+        ag[j].x += d4[j].x * h4[j].x; ag[j].y += d4[j].y * h4[j].y; ag[j].z += d4[j].z * h4[j].z; ag[j].w += d4[j].w * h4[j].w;
+        ab[j].x += d4[j].x; ab[j].y += d4[j].y; ab[j].z += d4[j].z; ab[j].w += d4[j].w;
+      }
+      s1 = wave_sum(s1) / D; s2 = wave_sum(s2) / D;
+      float4* dxr = reinterpret_cast<float4*>(dx + (long)row * D);
+      const float4* rr = dres ? reinterpret_cast<const float4*>(dres + (long)row * D) : nullptr;
+#pragma unroll
+      for (int j = 0; j < VEC; ++j) {
+        float4 o;
+        o.x = rs * (d4[j].x * g4[j].x - s1 - h4[j].x * s2);
+        o.y = rs * (d4[j].y * g4[j].y - s1 - h4[j].y * s2);
+        o.z = rs * (d4[j].z * g4[j].z - s1 - h4[j].z * s2);
+        o.w = rs * (d4[j].w * g4[j].w - s1 - h4[j].w * s2);
+        if (rr) { float4 r = rr[lane + 64 * j]; o.x += r.x; o.y += r.y; o.z += r.z; o.w += r.w; }
+        dxr[lane + 64 * j] = o;
+      }
+    }
+#pragma unroll
+    for (int j = 0; j < VEC; ++j) {
+      const int i = 4 * (lane + 64 * j);
+      atomicAdd(&lds[i + 0], ag[j].x); atomicAdd(&lds[i + 1], ag[j].y);
+      atomicAdd(&lds[i + 2], ag[j].z); atomicAdd(&lds[i + 3], ag[j].w);
+      atomicAdd(&lds[D + i + 0], ab[j].x); atomicAdd(&lds[D + i + 1], ab[j].y);
+      atomicAdd(&lds[D + i + 2], ab[j].z); atomicAdd(&lds[D + i + 3], ab[j].w);
+    }
+  } else {
+    constexpr int MAXC = 16;
+    float ag[MAXC], ab[MAXC];
+#pragma unroll
+    for (int c = 0; c < MAXC; ++c) { ag[c] = 0.f; ab[c] = 0.f; }
+    for (int row = r0 + wave; row < r1; row += 4) {
+      const float* dyr = dy + (long)row * D;
+      const float* xr = x + (long)row * D;
+      const float mu = mean[row], rs = rstd[row];
+      float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+      for (int c = 0; c < MAXC; ++c) {
+        int i = lane + 64 * c;
+        if (i < D) {
+          float xh = (xr[i] - mu) * rs;
+          float dg = dyr[i] * gamma[i];
+          s1 += dg; s2 += dg * xh;
+          ag[c] += dyr[i] * xh; ab[c] += dyr[i];
+        }
+      }
+      s1 = wave_sum(s1) / D; s2 = wave_sum(s2) / D;
+      float* dxr = dx + (long)row * D;
+#pragma unroll
+      for (int c = 0; c < MAXC; ++c) {
+        int i = lane + 64 * c;
+        if (i < D) {
+          float xh = (xr[i] - mu) * rs;
+          float g = rs * (dyr[i] * gamma[i] - s1 - xh * s2);
+          if (dres) g += dres[(long)row * D + i];
+          dxr[i] = g;
+        }
+      }
+    }
 #pragma unroll
     for (int c = 0; c < MAXC; ++c) {
       int i = lane + 64 * c;
-      if (i < D) {
-        float xh = (xr[i] - mu) * rs;
-        float dg = dyr[i] * gamma[i];
-        s1 += dg; s2 += dg * xh;
-        ag[c] += dyr[i] * xh; ab[c] += dyr[i];
-      }
+      if (i < D) { atomicAdd(&lds[i], ag[c]); atomicAdd(&lds[D + i], ab[c]); }
     }
-    s1 = wave_sum(s1) / D; s2 = wave_sum(s2) / D;
-    float* dxr = dx + (long)row * D;
-#pragma unroll
-    for (int c = 0; c < MAXC; ++c) {
-      int i = lane + 64 * c;
-      if (i < D) {
-        float xh = (xr[i] - mu) * rs;
-        float g = rs * (dyr[i] * gamma[i] - s1 - xh * s2);
-        if (dres) g += dres[(long)row * D + i];
-        dxr[i] = g;
-      }
-    }
-  }
-#pragma unroll
-  for (int c = 0; c < MAXC; ++c) {
-    int i = lane + 64 * c;
-    if (i < D) { atomicAdd(&lds[i], ag[c]); atomicAdd(&lds[D + i], ab[c]); }
   }
   __syncthreads();
   for (int i = threadIdx.x; i < D; i += blockDim.x) {
@@ -352,11 +401,21 @@ int eamd_layernorm_bwd(const float* dy, const float* x, const float* gamma, cons
   if (!dy || !x || !gamma || !mean || !rstd || !dx || !dgamma || !dbeta || rows <= 0 || D <= 0)
     return EAMD_EINVAL;
   if (D > 1024) return EAMD_EUNSUPPORTED;
-  int nblk = min(1024, (rows + 15) / 16);
+  int nblk = min(512, (rows + 15) / 16);
   int rpb = (rows + nblk - 1) / nblk;
   nblk = (rows + rpb - 1) / rpb;
-  hipLaunchKernelGGL(layernorm_bwd_kernel, dim3(nblk), dim3(256), 2 * D * sizeof(float), (hipStream_t)stream,
-                     dy, x, gamma, mean, rstd, dres, dx, dgamma, dbeta, rows, D, rpb);
+  const bool al = (((uintptr_t)dy | (uintptr_t)x | (uintptr_t)gamma | (uintptr_t)dx | (uintptr_t)dres) & 15) == 0;
+  hipStream_t s = (hipStream_t)stream;
+  size_t sm = 2 * D * sizeof(float);
+  if (al && D == 256)
+    hipLaunchKernelGGL(layernorm_bwd_kernel<1>, dim3(nblk), dim3(256), sm, s, dy, x, gamma, mean, rstd, dres, dx,
+                       dgamma, dbeta, rows, D, rpb);
+  else if (al && D == 512)
+    hipLaunchKernelGGL(layernorm_bwd_kernel<2>, dim3(nblk), dim3(256), sm, s, dy, x, gamma, mean, rstd, dres, dx,
+                       dgamma, dbeta, rows, D, rpb);
+  else
+    hipLaunchKernelGGL(layernorm_bwd_kernel<0>, dim3(nblk), dim3(256), sm, s, dy, x, gamma, mean, rstd, dres, dx,
+                       dgamma, dbeta, rows, D, rpb);
   EAMD_LAUNCH_CHECK();
   return EAMD_OK;
 }

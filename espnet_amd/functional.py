@@ -86,9 +86,7 @@ class LinearFn(torch.autograd.Function):
         sink = GradSink([w, b] if b is not None else [w])
         dy2 = dy.reshape(x2.shape[0], w.shape[0]).contiguous()
         dx = ops.linear_bwd_x(dy2, w) if ctx.needs_input_grad[0] else None
-        ops.linear_bwd_w(dy2, x2, sink.buf(0))
-        if b is not None:
-            ops.colsum(dy2, sink.buf(1))
+        ops.linear_bwd_w(dy2, x2, sink.buf(0), db=sink.buf(1) if b is not None else None)
         res = sink.results()
         return (dx.view(ctx.shp) if dx is not None else None, res[0], res[1] if b is not None else None)
 
@@ -120,11 +118,9 @@ class FFNBlockFn(torch.autograd.Function):
         scale, act, shp = ctx.cfg
         sink = GradSink(ctx.pr)
         do = dout.reshape(x2.shape).contiguous()
-        ops.linear_bwd_w(do, z, sink.buf(4), alpha=scale, b_act=act)       # dW2 += s * do^T act(z)
-        ops.colsum(do, sink.buf(5), scale)
+        ops.linear_bwd_w(do, z, sink.buf(4), alpha=scale, b_act=act, db=sink.buf(5))   # dW2 += s * do^T act(z)
         dz = ops.linear_bwd_x(do, w2, epilogue=_act_epi(act), aux=z, alpha=scale)   # (do W2) * act'(z) * s
-        ops.linear_bwd_w(dz, xn, sink.buf(2))
-        ops.colsum(dz, sink.buf(3))
+        ops.linear_bwd_w(dz, xn, sink.buf(2), db=sink.buf(3))
         dxn = ops.linear_bwd_x(dz, w1)
         dx = ops.layernorm_bwd(dxn, x2, ln_w, mean, rstd, do, sink.buf(0), sink.buf(1))
         return (dx.view(shp),) + sink.results() + (None, None, None)
@@ -248,8 +244,7 @@ class MHABlockFn(torch.autograd.Function):
         ln_w, ln_b, wq, bq, wk, bk, wv, bv, wo, bo = params[:10]
         sink = GradSink(params)
         do = dout.reshape(-1, D).contiguous()
-        ops.linear_bwd_w(do, cx, sink.buf(8))
-        ops.colsum(do, sink.buf(9))
+        ops.linear_bwd_w(do, cx, sink.buf(8), db=sink.buf(9))
         dctx = ops.linear_bwd_x(do, wo)
         dqu, dqv, dkk, dv, dp = attn_core_bwd(dctx, P, qu, qv, k, v, p, B, T1, T2, H, dk)
         if rel:
@@ -261,12 +256,9 @@ class MHABlockFn(torch.autograd.Function):
         else:
             dq = dqu
         kv_in = mem2 if cross else xn
-        ops.linear_bwd_w(dq, xn, sink.buf(2))
-        ops.colsum(dq, sink.buf(3))
-        ops.linear_bwd_w(dkk, kv_in, sink.buf(4))
-        ops.colsum(dkk, sink.buf(5))
-        ops.linear_bwd_w(dv, kv_in, sink.buf(6))
-        ops.colsum(dv, sink.buf(7))
+        ops.linear_bwd_w(dq, xn, sink.buf(2), db=sink.buf(3))
+        ops.linear_bwd_w(dkk, kv_in, sink.buf(4), db=sink.buf(5))
+        ops.linear_bwd_w(dv, kv_in, sink.buf(6), db=sink.buf(7))
         dxn = ops.linear_bwd_x(dq, wq)
         dmem = None
         if cross:
@@ -320,15 +312,13 @@ class ConvModuleBlockFn(torch.autograd.Function):
         M = B * T
         sink = GradSink(ctx.pr)
         do = dout.reshape(M, D).contiguous()
-        ops.linear_bwd_w(do, e, sink.buf(8).view(Cc, Cc))
-        ops.colsum(do, sink.buf(9))
+        ops.linear_bwd_w(do, e, sink.buf(8).view(Cc, Cc), db=sink.buf(9))
         de = ops.linear_bwd_x(do, w2.view(Cc, Cc))
         dd = ops.bn_bwd(de, d, bmean, brstd, g, be, sink.buf(6), sink.buf(7), M, Cc, act, training)
         dgl = ops.dwconv_bwd_x(dd, wd.view(Cc, K), B, T, Cc, K)
         ops.dwconv_bwd_w(dd, gl, sink.buf(4).view(Cc, K), sink.buf(5), B, T, Cc, K)
         da = ops.glu_bwd(dgl, a, Cc)
-        ops.linear_bwd_w(da, xn, sink.buf(2).view(2 * Cc, D))
-        ops.colsum(da, sink.buf(3))
+        ops.linear_bwd_w(da, xn, sink.buf(2).view(2 * Cc, D), db=sink.buf(3))
         dxn = ops.linear_bwd_x(da, w1.view(2 * Cc, D))
         dx = ops.layernorm_bwd(dxn, x2, ln_w, mean, rstd, do, sink.buf(0), sink.buf(1))
         return (dx.view(B, T, D), None, None, None, None, None, None, None) + sink.results()
@@ -381,9 +371,8 @@ class Conv2dSubsamplingFn(torch.autograd.Function):
         y2v = y2.view(B * H2, W2 * Cc)
         # Linear: weight grad in permuted column order, then un-permute-accumulate
         dwl = torch.zeros(D, W2 * Cc, device=dev, dtype=torch.float32)
-        ops.linear_bwd_w(do, y2v, dwl, alpha=xscale)
+        ops.linear_bwd_w(do, y2v, dwl, alpha=xscale, db=sink.buf(5))
         ops.permute4(dwl, sink.buf(4), (D, W2, Cc, 1), (W2 * Cc, 1, W2, 0), accumulate=True)
-        ops.colsum(do, sink.buf(5), xscale)
         dy2 = ops.linear_bwd_x(do, wl, epilogue=EPI_MUL_RELU_MASK, aux=y2v, alpha=xscale)   # [B*H2, W2*C]
         dy2 = dy2.view(B * H2 * W2, Cc)
         M2 = B * H2 * W2

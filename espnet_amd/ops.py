@@ -41,7 +41,8 @@ def _span(rows, ld, cols):
 
 def gemm(A, B, Cm, M, N, K, lda, ldb, ldc, *, transA=0, transB=0, bias=None, aux=None, ldaux=0, R=None,
          ldr=0, batch=(1, 1), sA=(0, 0), sB=(0, 0), sC=(0, 0), alpha=1.0, beta=0.0, a_act=0, b_act=0,
-         epilogue=0, splitk=1, tile=0, gather=None, cmap=None, a_off=0, b_off=0, c_off=0, precision=None):
+         epilogue=0, splitk=1, tile=0, gather=None, cmap=None, a_off=0, b_off=0, c_off=0, precision=None,
+         colsum=None):
     for t in (A, B, Cm):
         if t.dtype != torch.float32 or not t.is_cuda:
             raise _lib.EamdError("gemm needs float32 GPU tensors")
@@ -68,6 +69,10 @@ def gemm(A, B, Cm, M, N, K, lda, ldb, ldc, *, transA=0, transB=0, bias=None, aux
     p.bias = ptr(bias)
     p.aux = ptr(aux, c_off) if aux is not None else None
     p.R = ptr(R, c_off) if R is not None else None
+    if colsum is not None:
+        if not transA or gather is not None or colsum.numel() < M * b1 * b2:
+            raise _lib.EamdError("gemm: colsum needs transA, no gather and M outputs")
+        p.colsum = ptr(colsum)
     p.M, p.N, p.K = M, N, K
     p.transA, p.transB = int(transA), int(transB)
     p.lda, p.ldb, p.ldc, p.ldaux, p.ldr = lda, ldb, ldc, ldaux or ldc, ldr or ldc
@@ -119,14 +124,15 @@ def linear_bwd_x(dy, W, out=None, *, beta=0.0, epilogue=EPI_NONE, aux=None, alph
     return out
 
 
-def linear_bwd_w(dy, x, dW, *, alpha=1.0, b_act=ACT_NONE):
-    """dW[N,K] += alpha * dy[M,N]^T @ b_act(x)[M,K]   (split-K, f32 atomics)"""
+def linear_bwd_w(dy, x, dW, *, alpha=1.0, b_act=ACT_NONE, db=None):
+    """dW[N,K] += alpha * dy[M,N]^T @ b_act(x)[M,K]   (split-K, f32 atomics)
+    db[N] += alpha * column sums of dy (bias gradient, fused into the same launch)"""
     M, N = dy.shape
     K = x.shape[1]
     assert x.shape[0] == M and dW.numel() == N * K
     sk = auto_splitk(N, K, M)
     gemm(dy, x, dW, N, K, M, N, K, K, transA=1, transB=1, alpha=alpha, b_act=b_act, splitk=sk,
-         beta=1.0 if sk == 1 else 0.0)
+         beta=1.0 if sk == 1 else 0.0, colsum=db)
 
 
 def colsum(x, out, scale=1.0, rows=None, D=None, ld=None):

@@ -40,6 +40,8 @@ int eamd_abi_version(void);
  *           beta ignored, bias/R contributed by split 0).
  * precision: 0 = fp32 MFMA (v_mfma_f32_16x16x4_f32, exact fp32 products),
  *            1 = bf16 MFMA (operands rounded to bf16 while staged, fp32 accumulate).
+ * colsum (transA=1 only): the column sums of A are added there by the same launch, i.e. the bias
+ * gradient dB = sum_m dY[m,:] comes for free with dW = dY^T X.
  * Two-level batch (batch1 x batch2) with independent element strides for A/B/C(aux,R share C's).
  * Optional implicit-im2col view of A (`gather`) and strided row map for C (`cmap`) express the
  * Conv2dSubsampling convolutions and their input-gradient without materialising columns.
@@ -64,6 +66,7 @@ typedef struct {
 typedef struct {
   const float* A; const float* B; float* C;
   const float* bias; const float* aux; const float* R;
+  float* colsum;       /* optional, transA only: colsum[m] += alpha * sum_k A[k,m] (bias gradient) */
   int32_t M, N, K;
   int32_t transA, transB;
   int64_t lda, ldb, ldc, ldaux, ldr;
