@@ -42,7 +42,8 @@ class GemmT(C.Structure):
                 ("alpha", C.c_float), ("beta", C.c_float),
                 ("a_act", C.c_int32), ("b_act", C.c_int32), ("epilogue", C.c_int32),
                 ("splitk", C.c_int32), ("precision", C.c_int32), ("tile", C.c_int32),
-                ("gather", GatherT), ("cmap", RowMapT)]
+                ("gather", GatherT), ("cmap", RowMapT),
+                ("Cb", C.c_void_p), ("in_dtype", C.c_int32), ("aux_dtype", C.c_int32)]
 
 
 _lib = None
@@ -51,7 +52,7 @@ _lib = None
 SYMBOLS = [
     "eamd_abi_version", "eamd_gemm", "eamd_layernorm_fwd", "eamd_layernorm_bwd", "eamd_softmax_fwd",
     "eamd_softmax_bwd", "eamd_lsm_loss", "eamd_argmax_rows", "eamd_reduce_sum", "eamd_log_softmax_rows",
-    "eamd_axpby", "eamd_scale_dev", "eamd_act_fwd", "eamd_act_bwd", "eamd_glu_fwd", "eamd_glu_bwd",
+    "eamd_axpby", "eamd_cast_bf16", "eamd_scale_dev", "eamd_act_fwd", "eamd_act_bwd", "eamd_glu_fwd", "eamd_glu_bwd",
     "eamd_add_bias2", "eamd_colsum", "eamd_embed_pe", "eamd_embed_bwd", "eamd_posenc", "eamd_permute4",
     "eamd_dropout", "eamd_dwconv_fwd", "eamd_dwconv_bwd_x", "eamd_dwconv_bwd_w", "eamd_bn_nslab",
     "eamd_bn_stats", "eamd_bn_apply", "eamd_bn_bwd", "eamd_conv1_fwd", "eamd_conv1_bwd_w",

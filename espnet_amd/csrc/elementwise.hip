@@ -31,6 +31,21 @@ __global__ void axpby_kernel(const float* __restrict__ x, const float* __restric
     out[i] = a * x[i] + (y ? b * y[i] : 0.f);
 }
 
+// fp32 -> bf16 (round-to-nearest-even), 8 elements per thread
+__global__ void cast_bf16_kernel(const float* __restrict__ x, unsigned short* __restrict__ y, long n, long n8) {
+  const long stride = (long)gridDim.x * blockDim.x;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n8; i += stride) {
+    float4 a = reinterpret_cast<const float4*>(x)[2 * i], b = reinterpret_cast<const float4*>(x)[2 * i + 1];
+    uint4 o;
+    o.x = eamd_f2bf(a.x) | ((unsigned)eamd_f2bf(a.y) << 16);
+    o.y = eamd_f2bf(a.z) | ((unsigned)eamd_f2bf(a.w) << 16);
+    o.z = eamd_f2bf(b.x) | ((unsigned)eamd_f2bf(b.y) << 16);
+    o.w = eamd_f2bf(b.z) | ((unsigned)eamd_f2bf(b.w) << 16);
+    reinterpret_cast<uint4*>(y)[i] = o;
+  }
+  for (long i = n8 * 8 + (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) y[i] = eamd_f2bf(x[i]);
+}
+
 // out = scale_dev[0] * x  (scale read from device memory: keeps upstream loss scaling sync-free)
 __global__ void scale_dev_kernel(const float* __restrict__ x, const float* __restrict__ scale_dev,
                                  float* __restrict__ out, long n, float extra) {
@@ -185,6 +200,16 @@ int eamd_axpby(const float* x, const float* y, float* out, int64_t n, float a, f
   const bool vec = ((((uintptr_t)x | (uintptr_t)out | (uintptr_t)y) & 15) == 0);
   hipLaunchKernelGGL(axpby_kernel, dim3(grid_for(vec ? n / 4 + 1 : n)), dim3(256), 0, (hipStream_t)stream, x, y,
                      out, (long)n, vec ? (long)(n / 4) : 0L, a, b);
+  EAMD_LAUNCH_CHECK();
+  return EAMD_OK;
+}
+
+int eamd_cast_bf16(const float* x, void* y, int64_t n, void* stream) {
+  if (!x || !y || n < 0) return EAMD_EINVAL;
+  if (n == 0) return EAMD_OK;
+  const bool vec = ((((uintptr_t)x) & 15) == 0) && ((((uintptr_t)y) & 15) == 0);
+  hipLaunchKernelGGL(cast_bf16_kernel, dim3(grid_for(vec ? n / 8 + 1 : n)), dim3(256), 0, (hipStream_t)stream, x,
+                     (unsigned short*)y, (long)n, vec ? (long)(n / 8) : 0L);
   EAMD_LAUNCH_CHECK();
   return EAMD_OK;
 }

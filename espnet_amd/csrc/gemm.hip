@@ -56,9 +56,10 @@ __device__ __forceinline__ long gather_off(const eamd_gather_t& g, const RowStat
 }
 
 __device__ __forceinline__ float4 apply_act4(float4 v, int act) {
-  if (act != EAMD_ACT_NONE) {
-    v.x = eamd_act(v.x, act); v.y = eamd_act(v.y, act);
-    v.z = eamd_act(v.z, act); v.w = eamd_act(v.w, act);
+  if (act == EAMD_ACT_SWISH) {
+    v.x = eamd_swish(v.x); v.y = eamd_swish(v.y); v.z = eamd_swish(v.z); v.w = eamd_swish(v.w);
+  } else if (act == EAMD_ACT_RELU) {
+    v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f);
   }
   return v;
 }
@@ -370,11 +371,16 @@ int launch(const eamd_gemm_t& p, hipStream_t stream) {
 
 }  // namespace
 
+int eamd_gemm_bf16_dispatch(const eamd_gemm_t& p, int tile, hipStream_t stream);  // gemm_bf16.hip
+
 extern "C" int eamd_gemm(const eamd_gemm_t* pp, void* stream_) {
   if (!pp) return EAMD_EINVAL;
   eamd_gemm_t p = *pp;
   hipStream_t stream = (hipStream_t)stream_;
-  if (!p.A || !p.B || !p.C) return EAMD_EINVAL;
+  if (!p.A || !p.B || (!p.C && !p.Cb)) return EAMD_EINVAL;
+  if (p.in_dtype != 0 && p.in_dtype != 1) return EAMD_EINVAL;
+  if (p.in_dtype == 1 && p.precision != 1) return EAMD_EINVAL;
+  if (p.in_dtype == 0 && (p.Cb || p.aux_dtype || !p.C)) return EAMD_EUNSUPPORTED;
   if (p.M <= 0 || p.N <= 0 || p.K < 0) return EAMD_EINVAL;
   if (p.batch1 <= 0 || p.batch2 <= 0) return EAMD_EINVAL;
   if (p.splitk < 1) p.splitk = 1;
@@ -401,6 +407,7 @@ extern "C" int eamd_gemm(const eamd_gemm_t* pp, void* stream_) {
     }
   }
   if ((p.N + tile - 1) / tile > 65535) return EAMD_EUNSUPPORTED;
+  if (p.in_dtype == 1) return eamd_gemm_bf16_dispatch(p, tile, stream);
 
   if (tile == 128) {
     return p.precision ? launch<128, 128, 1>(p, stream) : launch<128, 128, 0>(p, stream);

@@ -42,10 +42,19 @@ def _span(rows, ld, cols):
 def gemm(A, B, Cm, M, N, K, lda, ldb, ldc, *, transA=0, transB=0, bias=None, aux=None, ldaux=0, R=None,
          ldr=0, batch=(1, 1), sA=(0, 0), sB=(0, 0), sC=(0, 0), alpha=1.0, beta=0.0, a_act=0, b_act=0,
          epilogue=0, splitk=1, tile=0, gather=None, cmap=None, a_off=0, b_off=0, c_off=0, precision=None,
-         colsum=None):
-    for t in (A, B, Cm):
-        if t.dtype != torch.float32 or not t.is_cuda:
-            raise _lib.EamdError("gemm needs float32 GPU tensors")
+         colsum=None, Cb=None):
+    """A, B: both float32 or both bfloat16 (bf16 operands select the fast MFMA kernel).
+    Cm: float32 result, or bfloat16 result (then no fp32 copy is written); Cb: extra bf16 copy."""
+    bf = A.dtype == torch.bfloat16
+    if A.dtype != B.dtype or A.dtype not in (torch.float32, torch.bfloat16) or not (A.is_cuda and B.is_cuda):
+        raise _lib.EamdError("gemm needs float32 or bfloat16 GPU operands of one dtype")
+    c32 = Cm if Cm.dtype == torch.float32 else None
+    c16 = Cb if Cb is not None else (Cm if Cm.dtype == torch.bfloat16 else None)
+    if c16 is not None and (c16.dtype != torch.bfloat16 or not bf):
+        raise _lib.EamdError("gemm: bf16 outputs need bf16 operands")
+    for tt in (R, bias, colsum):
+        if tt is not None and tt.dtype != torch.float32:
+            raise _lib.EamdError("gemm: bias / residual / colsum must be float32")
     b1, b2 = batch
     # ---- host-side bounds checks -------------------------------------------------------------
     if gather is None:
@@ -59,15 +68,19 @@ def gemm(A, B, Cm, M, N, K, lda, ldb, ldc, *, transA=0, transB=0, bias=None, aux
         raise _lib.EamdError(f"gemm: B too small ({B.numel()} < {b_need})")
     if cmap is None:
         c_need = c_off + (b1 - 1) * sC[0] + (b2 - 1) * sC[1] + _span(M, ldc, N)
-        if c_need > Cm.numel():
-            raise _lib.EamdError(f"gemm: C too small ({Cm.numel()} < {c_need})")
+        for ct in (c32, c16):
+            if ct is not None and c_need > ct.numel():
+                raise _lib.EamdError(f"gemm: C too small ({ct.numel()} < {c_need})")
     if bias is not None and bias.numel() < N:
         raise _lib.EamdError("gemm: bias too small")
 
     p = GemmT()
-    p.A, p.B, p.C = ptr(A, a_off), ptr(B, b_off), ptr(Cm, c_off)
+    p.A, p.B = ptr(A, a_off), ptr(B, b_off)
+    p.C = ptr(c32, c_off) if c32 is not None else None
+    p.Cb = ptr(c16, c_off) if c16 is not None else None
     p.bias = ptr(bias)
     p.aux = ptr(aux, c_off) if aux is not None else None
+    p.aux_dtype = 1 if (aux is not None and aux.dtype == torch.bfloat16) else 0
     p.R = ptr(R, c_off) if R is not None else None
     if colsum is not None:
         if not transA or gather is not None or colsum.numel() < M * b1 * b2:
@@ -83,13 +96,22 @@ def gemm(A, B, Cm, M, N, K, lda, ldb, ldc, *, transA=0, transB=0, bias=None, aux
     p.alpha, p.beta = alpha, beta
     p.a_act, p.b_act, p.epilogue = a_act, b_act, epilogue
     p.splitk = splitk
-    p.precision = _state["precision"] if precision is None else precision
+    p.in_dtype = 1 if bf else 0
+    p.precision = 1 if bf else (_state["precision"] if precision is None else precision)
     p.tile = tile
     if gather is not None:
         p.gather = gather
     if cmap is not None:
         p.cmap = cmap
     check(_lib.lib().eamd_gemm(C.byref(p), stream_ptr()), "eamd_gemm")
+
+
+def cast_bf16(x, out=None):
+    if out is None:
+        out = torch.empty(x.shape, device=x.device, dtype=torch.bfloat16)
+    assert x.dtype == torch.float32 and x.is_contiguous() and out.numel() == x.numel()
+    check(_lib.lib().eamd_cast_bf16(ptr(x), ptr(out), C.c_int64(x.numel()), stream_ptr()), "eamd_cast_bf16")
+    return out
 
 
 def auto_splitk(m_out, n_out, k_red):

@@ -39,7 +39,9 @@ int eamd_abi_version(void);
  * splitk>1: partial sums are atomically ADDED to C (caller pre-initialises C; epilogue must be 0,
  *           beta ignored, bias/R contributed by split 0).
  * precision: 0 = fp32 MFMA (v_mfma_f32_16x16x4_f32, exact fp32 products),
- *            1 = bf16 MFMA (operands rounded to bf16 while staged, fp32 accumulate).
+ *            1 = bf16 MFMA (fp32 accumulate); operands are either fp32 in memory and rounded while
+ *                staged (in_dtype 0) or already bf16 in memory (in_dtype 1, the fast path: 16-byte
+ *                staging, BK = 64, ds_read_b64_tr_b16 for the k-strided operand layouts).
  * colsum (transA=1 only): the column sums of A are added there by the same launch, i.e. the bias
  * gradient dB = sum_m dY[m,:] comes for free with dW = dY^T X.
  * Two-level batch (batch1 x batch2) with independent element strides for A/B/C(aux,R share C's).
@@ -79,6 +81,9 @@ typedef struct {
   int32_t tile;        /* 0 auto, 64 or 128 */
   eamd_gather_t gather;
   eamd_rowmap_t cmap;
+  void* Cb;            /* optional bf16 copy of the result (same layout as C); C may then be NULL */
+  int32_t in_dtype;    /* 0: A,B are fp32; 1: A,B are bf16 (precision must be 1) */
+  int32_t aux_dtype;   /* 0: aux is fp32; 1: aux is bf16 */
 } eamd_gemm_t;
 
 int eamd_gemm(const eamd_gemm_t* p, void* stream);
@@ -124,6 +129,8 @@ int eamd_log_softmax_rows(const float* x, float* y, int rows, int V, void* strea
  * Element-wise helpers.
  * ------------------------------------------------------------------------------------------ */
 int eamd_axpby(const float* x, const float* y, float* out, int64_t n, float a, float b, void* stream);
+/* fp32 -> bf16 (RNE) copy: bf16 shadows of weights / activations that feed the bf16-operand GEMM */
+int eamd_cast_bf16(const float* x, void* y_bf16, int64_t n, void* stream);
 int eamd_scale_dev(const float* x, const float* scale_dev, float* out, int64_t n, float extra, void* stream);
 int eamd_act_fwd(const float* x, float* y, int64_t n, int act, void* stream);
 int eamd_act_bwd(const float* dy, const float* x, float* dx, int64_t n, int act, void* stream);

@@ -440,3 +440,114 @@ def test_optimizer(ops):
     ops.sched_step(state, gn, 1, 0.0, factor, dmodel, warm, 0.9, 0.98, 5.0)
     ops.adam_step(p, gd, m, v, state, 0.9, 0.98, 1e-9, 0.0)
     assert torch.equal(p, before) and float(state[0]) == 5.0 and float(state[5]) == 1.0
+
+
+# ---------------------------------------------------------------------------------------------
+# bf16-operand fast GEMM (gemm_bf16.hip): inputs are rounded to bf16 on the host first, so the only
+# difference to the float64 reference is fp32 accumulation order -> tight tolerance, which pins the
+# ds_read_b64_tr_b16 fragment maps of the transposed layouts exactly (asymmetric random operands).
+# ---------------------------------------------------------------------------------------------
+def _bf(x):
+    return x.to(torch.bfloat16)
+
+
+@pytest.mark.parametrize("tile", [0, 64, 128])
+@pytest.mark.parametrize("ta,tb", [(0, 0), (0, 1), (1, 0), (1, 1)])
+def test_gemm_bf16_layouts(ops, tile, ta, tb):
+    g = torch.Generator().manual_seed(11)
+    for (M, N, K) in [(16, 16, 32), (64, 64, 64), (77, 45, 53), (130, 257, 100), (256, 2048, 996), (249, 64, 249),
+                      (128, 128, 8)]:
+        A = _bf(torch.randn(K, M, generator=g) if ta else torch.randn(M, K, generator=g))
+        B = _bf(torch.randn(K, N, generator=g) if tb else torch.randn(N, K, generator=g))
+        Ad = (A.double().t() if ta else A.double())
+        Bd = (B.double() if tb else B.double().t())
+        ref = Ad @ Bd
+        C = torch.empty(M, N, device=DEV)
+        Cb = torch.empty(M, N, device=DEV, dtype=torch.bfloat16)
+        ops.gemm(A.to(DEV), B.to(DEV), C, M, N, K, M if ta else K, N if tb else K, N, transA=ta, transB=tb,
+                 tile=tile, Cb=Cb)
+        report(f"gemm_bf16[ta{ta},tb{tb},tile{tile}] {M}x{N}x{K}", C, ref, 2e-6)
+        report(f"gemm_bf16 Cb copy", Cb.float(), ref, 4e-3)
+
+
+def test_gemm_bf16_epilogue_batch_gather(ops):
+    from espnet_amd import functional as F_
+    g = torch.Generator().manual_seed(12)
+    M, N, K = 90, 70, 130
+    A, Bn = _bf(torch.randn(M, K, generator=g)), _bf(torch.randn(N, K, generator=g))
+    bias, R = torch.randn(N, generator=g), torch.randn(M, N, generator=g)
+    aux = _bf(torch.randn(M, N, generator=g))
+    base = A.double() @ Bn.double().t() + bias.double()
+    sg = torch.sigmoid(aux.double())
+    for epi, fn in ((1, lambda v: v.clamp_min(0)), (2, lambda v: v * torch.sigmoid(v)),
+                    (3, lambda v: v * (aux.double() > 0)), (4, lambda v: v * (sg * (1 + aux.double() * (1 - sg))))):
+        C = torch.empty(M, N, device=DEV)
+        ops.gemm(A.to(DEV), Bn.to(DEV), C, M, N, K, K, K, N, bias=bias.to(DEV), epilogue=epi, aux=aux.to(DEV), ldaux=N,
+                 R=R.to(DEV), ldr=N, alpha=0.7)
+        report(f"gemm_bf16_epilogue{epi}", C, 0.7 * fn(base) + R.double(), 3e-6)
+    # prologue activation (rounded back to bf16 before the MFMA) + split-K + fused column sums
+    At = _bf(torch.randn(K, M, generator=g))
+    Bt = _bf(torch.randn(K, N, generator=g))
+    C0 = torch.randn(M, N, generator=g)
+    C = C0.clone().to(DEV)
+    cs = torch.ones(M, device=DEV)
+    ops.gemm(At.to(DEV), Bt.to(DEV), C, M, N, K, M, N, N, transA=1, transB=1, splitk=3, alpha=0.5, colsum=cs)
+    report("gemm_bf16_tn_splitk", C, 0.5 * (At.double().t() @ Bt.double()) + C0.double(), 3e-6)
+    report("gemm_bf16_colsum", cs, 1 + 0.5 * At.double().sum(0), 1e-5)
+    sw = _bf((Bt.float() * torch.sigmoid(Bt.float()))).double()
+    C = torch.empty(M, N, device=DEV)
+    ops.gemm(At.to(DEV), Bt.to(DEV), C, M, N, K, M, N, N, transA=1, transB=1, b_act=2)
+    report("gemm_bf16_b_act_swish", C, At.double().t() @ sw, 2e-3)
+    # attention layout, both products, through transposed reads
+    Bb, T1, T2, H, dk = 3, 10, 13, 4, 16
+    D = H * dk
+    q, k, v = (_bf(torch.randn(Bb, T, D, generator=g)) for T in (T1, T2, T2))
+    ldp = 16
+    sc = torch.zeros(H * Bb * T1 * ldp, device=DEV)
+    ops.gemm(q.to(DEV), k.to(DEV), sc, T1, T2, dk, D, D, ldp, batch=(Bb, H), sA=(T1 * D, dk), sB=(T2 * D, dk),
+             sC=(T1 * ldp, Bb * T1 * ldp))
+    ref = torch.einsum("bihd,bjhd->hbij", q.view(Bb, T1, H, dk).double(), k.view(Bb, T2, H, dk).double())
+    report("gemm_bf16_scores", sc.view(H, Bb, T1, ldp)[..., :T2], ref, 3e-6)
+    P = _bf(torch.randn(H, Bb, T1, ldp, generator=g))
+    P[..., T2:] = 0
+    cx = torch.empty(Bb * T1, D, device=DEV)
+    ops.gemm(P.to(DEV), v.to(DEV), cx, T1, dk, T2, ldp, D, D, transB=1, batch=(Bb, H), sA=(T1 * ldp, Bb * T1 * ldp),
+             sB=(T2 * D, dk), sC=(T1 * D, dk))
+    ref = torch.einsum("hbij,bjhd->bihd", P[..., :T2].double(), v.view(Bb, T2, H, dk).double()).reshape(Bb * T1, D)
+    report("gemm_bf16_context", cx, ref, 3e-6)
+    # implicit conv (forward / weight-grad / input-grad) with bf16 activations
+    B_, H1, W1, Cc = 2, 17, 9, 64
+    H2, W2 = (H1 - 3) // 2 + 1, (W1 - 3) // 2 + 1
+    y1 = _bf(torch.randn(B_, H1, W1, Cc, generator=g))
+    w = _bf(torch.randn(Cc, Cc, 3, 3, generator=g) * 0.1)
+    dy2 = _bf(torch.randn(B_, H2, W2, Cc, generator=g))
+    y1d = y1.permute(0, 3, 1, 2).double().requires_grad_(True)
+    wdd_ = w.double().requires_grad_(True)
+    ref = torch.nn.functional.conv2d(y1d, wdd_, stride=2)
+    ref.backward(dy2.permute(0, 3, 1, 2).double())
+    wf = w.permute(2, 3, 1, 0).reshape(9, Cc, Cc).contiguous().to(DEV)
+    order = [0, 2, 6, 8, 1, 7, 3, 5, 4]
+    wd = w.permute(2, 3, 0, 1).reshape(9, Cc, Cc)[order].contiguous().to(DEV)
+    gth = ops.make_gather(Cc, F_._TAPS_FWD, H2, W2, H1, W1, 2, 2)
+    M2 = B_ * H2 * W2
+    y2 = torch.empty(M2, Cc, device=DEV)
+    ops.gemm(y1.to(DEV), wf, y2, M2, Cc, 9 * Cc, 9 * Cc, Cc, Cc, transB=1, gather=gth)
+    report("conv2_bf16_fwd", y2.view(B_, H2, W2, Cc), ref.permute(0, 2, 3, 1), 3e-6)
+    dwf = torch.zeros(9 * Cc, Cc, device=DEV)
+    ops.gemm(y1.to(DEV), dy2.reshape(M2, Cc).to(DEV), dwf, 9 * Cc, Cc, M2, 9 * Cc, Cc, Cc, transA=1, transB=1,
+             gather=gth, splitk=2, tile=64)
+    dw = torch.zeros(Cc, Cc, 3, 3, device=DEV)
+    ops.conv2_weight_grad(dwf, dw, Cc, Cc)
+    report("conv2_bf16_bwd_w", dw, wdd_.grad, 3e-6)
+    dy1 = torch.full((B_, H1, W1, Cc), float("nan"), device=DEV)
+    ones = torch.ones(B_, H1, W1, Cc, device=DEV, dtype=torch.bfloat16)
+    q0 = 0
+    for (ph, pw), taps in F_._CLASSES:
+        Ho, Wo = (H1 - ph + 1) // 2, (W1 - pw + 1) // 2
+        gt = ops.make_gather(Cc, [((ph - kh) // 2, (pw - kw) // 2) for kh, kw in taps], Ho, Wo, H2, W2, 1, 1)
+        cm = ops.make_rowmap(Ho, Wo, H1, W1, 2, ph, 2, pw)
+        nt = len(taps)
+        ops.gemm(dy2.reshape(M2, Cc).to(DEV), wd, dy1, B_ * Ho * Wo, Cc, nt * Cc, nt * Cc, Cc, Cc, transB=1,
+                 b_off=q0 * Cc * Cc, gather=gt, cmap=cm, epilogue=3, aux=ones, ldaux=Cc)
+        q0 += nt
+    report("conv2_bf16_bwd_x", dy1, y1d.grad.permute(0, 2, 3, 1), 3e-6)
