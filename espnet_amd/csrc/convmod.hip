@@ -130,13 +130,16 @@ __global__ void bn_finalize_kernel(const float* __restrict__ part, int nslab, in
 // y = act((x - mean) * rstd * gamma + beta)
 __global__ void bn_apply_kernel(const float* __restrict__ x, const float* __restrict__ mean,
                                 const float* __restrict__ rstd, const float* __restrict__ gamma,
-                                const float* __restrict__ beta, float* __restrict__ y, long M, int C, int act) {
+                                const float* __restrict__ beta, float* __restrict__ y, long M, int C, int act,
+                                int bf16) {
   const long n = M * C;
   const long stride = (long)gridDim.x * blockDim.x;
+  unsigned short* y16 = reinterpret_cast<unsigned short*>(y);
   for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
     int c = i % C;
     float z = (x[i] - mean[c]) * rstd[c] * gamma[c] + beta[c];
-    y[i] = eamd_act(z, act);
+    z = eamd_act(z, act);
+    if (bf16) y16[i] = eamd_f2bf(z); else y[i] = z;
   }
 }
 // backward stage 1: dz = dy * act'(z); partial sums of dz and dz*xhat per (slab, channel)
@@ -199,7 +202,7 @@ __global__ void bn_bwd_apply_kernel(const float* __restrict__ dy, const float* _
 // x [B, T, F]; w [C, 1, 3, 3]; y [B, H, W, C] with H=(T-3)/2+1, W=(F-3)/2+1
 __global__ __launch_bounds__(256) void conv1_fwd_kernel(const float* __restrict__ x, const float* __restrict__ w,
                                                         const float* __restrict__ bias, float* __restrict__ y, int B,
-                                                        int T, int F, int H, int W, int C) {
+                                                        int T, int F, int H, int W, int C, int bf16) {
   const long n = (long)B * H * W * C;
   const long stride = (long)gridDim.x * blockDim.x;
   for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
@@ -214,13 +217,15 @@ __global__ __launch_bounds__(256) void conv1_fwd_kernel(const float* __restrict_
     for (int kh = 0; kh < 3; ++kh)
 #pragma unroll
       for (int kw = 0; kw < 3; ++kw) acc += wc[kh * 3 + kw] * xp[kh * F + kw];
-    y[i] = acc > 0.f ? acc : 0.f;
+    acc = acc > 0.f ? acc : 0.f;
+    if (bf16) reinterpret_cast<unsigned short*>(y)[i] = eamd_f2bf(acc); else y[i] = acc;
   }
 }
 // dW[c, kh, kw] += sum_pos dy[pos, c] * x[pos shifted]; db[c] += sum dy   (dy already ReLU-masked)
 __global__ __launch_bounds__(256) void conv1_bwd_w_kernel(const float* __restrict__ dy, const float* __restrict__ x,
                                                           float* __restrict__ dw, float* __restrict__ db, int B,
-                                                          int T, int F, int H, int W, int C, int pos_per_block) {
+                                                          int T, int F, int H, int W, int C, int pos_per_block,
+                                                          int bf16) {
   const int c = blockIdx.x * blockDim.x + threadIdx.x;
   if (c >= C) return;
   const long npos = (long)B * H * W;
@@ -233,7 +238,8 @@ __global__ __launch_bounds__(256) void conv1_bwd_w_kernel(const float* __restric
   for (long p = p0; p < p1; ++p) {
     const int ww = p % W; long q = p / W;
     const int hh = q % H; const long b = q / H;
-    const float g = dy[p * C + c];
+    const float g = bf16 ? __uint_as_float(((unsigned)reinterpret_cast<const unsigned short*>(dy)[p * C + c]) << 16)
+                         : dy[p * C + c];
     accb += g;
     const float* xp = x + (b * T + 2 * hh) * F + 2 * ww;
 #pragma unroll
@@ -321,10 +327,10 @@ int eamd_bn_stats(const float* x, float* workspace, float* mean, float* rstd, fl
 }
 
 int eamd_bn_apply(const float* x, const float* mean, const float* rstd, const float* gamma, const float* beta,
-                  float* y, int64_t M, int C, int act, void* stream) {
+                  void* y, int64_t M, int C, int act, int y_bf16, void* stream) {
   if (!x || !mean || !rstd || !gamma || !beta || !y || M <= 0 || C <= 0) return EAMD_EINVAL;
   hipLaunchKernelGGL(bn_apply_kernel, dim3(grid_for(M * C)), dim3(256), 0, (hipStream_t)stream, x, mean, rstd, gamma,
-                     beta, y, (long)M, C, act);
+                     beta, (float*)y, (long)M, C, act, y_bf16);
   EAMD_LAUNCH_CHECK();
   return EAMD_OK;
 }
@@ -351,18 +357,18 @@ int eamd_bn_bwd(const float* dy, const float* x, const float* mean, const float*
   return EAMD_OK;
 }
 
-int eamd_conv1_fwd(const float* x, const float* w, const float* bias, float* y, int B, int T, int F, int C,
-                   void* stream) {
+int eamd_conv1_fwd(const float* x, const float* w, const float* bias, void* y, int B, int T, int F, int C,
+                   int y_bf16, void* stream) {
   if (!x || !w || !bias || !y || B <= 0 || T < 3 || F < 3 || C <= 0) return EAMD_EINVAL;
   int H = (T - 3) / 2 + 1, W = (F - 3) / 2 + 1;
   hipLaunchKernelGGL(conv1_fwd_kernel, dim3(grid_for((long)B * H * W * C)), dim3(256), 0, (hipStream_t)stream, x, w,
-                     bias, y, B, T, F, H, W, C);
+                     bias, (float*)y, B, T, F, H, W, C, y_bf16);
   EAMD_LAUNCH_CHECK();
   return EAMD_OK;
 }
 
-int eamd_conv1_bwd_w(const float* dy, const float* x, float* dw, float* db, int B, int T, int F, int C,
-                     void* stream) {
+int eamd_conv1_bwd_w(const void* dy, const float* x, float* dw, float* db, int B, int T, int F, int C,
+                     int dy_bf16, void* stream) {
   if (!dy || !x || !dw || !db || B <= 0 || T < 3 || F < 3 || C <= 0) return EAMD_EINVAL;
   int H = (T - 3) / 2 + 1, W = (F - 3) / 2 + 1;
   long npos = (long)B * H * W;
@@ -370,8 +376,8 @@ int eamd_conv1_bwd_w(const float* dy, const float* x, float* dw, float* db, int 
   long want = 2048 / gx; if (want < 1) want = 1;
   long ppb = (npos + want - 1) / want; if (ppb < 16) ppb = 16;
   int gy = (int)((npos + ppb - 1) / ppb);
-  hipLaunchKernelGGL(conv1_bwd_w_kernel, dim3(gx, gy), dim3(256), 0, (hipStream_t)stream, dy, x, dw, db, B, T, F, H,
-                     W, C, (int)ppb);
+  hipLaunchKernelGGL(conv1_bwd_w_kernel, dim3(gx, gy), dim3(256), 0, (hipStream_t)stream, (const float*)dy, x, dw, db,
+                     B, T, F, H, W, C, (int)ppb, dy_bf16);
   EAMD_LAUNCH_CHECK();
   return EAMD_OK;
 }

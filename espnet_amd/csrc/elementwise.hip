@@ -82,15 +82,16 @@ __global__ void glu_fwd_kernel(const float* __restrict__ x, float* __restrict__ 
   }
 }
 __global__ void glu_bwd_kernel(const float* __restrict__ dy, const float* __restrict__ x, float* __restrict__ dx,
-                               long rows, int C) {
+                               unsigned short* __restrict__ dx16, long rows, int C) {
   const long n = rows * C;
   const long stride = (long)gridDim.x * blockDim.x;
   for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
     long r = i / C; int c = i % C;
     float a = x[r * 2 * C + c], g = x[r * 2 * C + C + c];
     float s = eamd_sigmoid(g), d = dy[i];
-    dx[r * 2 * C + c] = d * s;
-    dx[r * 2 * C + C + c] = d * a * s * (1.f - s);
+    const float g1 = d * s, g2 = d * a * s * (1.f - s);
+    if (dx16) { dx16[r * 2 * C + c] = eamd_f2bf(g1); dx16[r * 2 * C + C + c] = eamd_f2bf(g2); }
+    else { dx[r * 2 * C + c] = g1; dx[r * 2 * C + C + c] = g2; }
   }
 }
 
@@ -98,27 +99,48 @@ __global__ void glu_bwd_kernel(const float* __restrict__ dy, const float* __rest
 // reference: transformer/attention.py:186-190 (q_with_bias_u / q_with_bias_v).
 __global__ void add_bias2_kernel(const float* __restrict__ q, const float* __restrict__ u,
                                  const float* __restrict__ v, float* __restrict__ qu, float* __restrict__ qv,
-                                 long rows, int D) {
+                                 long rows, int D, int bf16) {
   const long n = rows * D;
   const long stride = (long)gridDim.x * blockDim.x;
+  const unsigned short* q16 = reinterpret_cast<const unsigned short*>(q);
+  unsigned short* qu16 = reinterpret_cast<unsigned short*>(qu);
+  unsigned short* qv16 = reinterpret_cast<unsigned short*>(qv);
   for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
     int d = i % D;
-    float x = q[i];
-    qu[i] = x + u[d];
-    qv[i] = x + v[d];
+    if (bf16) {
+      float x = __uint_as_float(((unsigned)q16[i]) << 16);
+      qu16[i] = eamd_f2bf(x + u[d]);
+      qv16[i] = eamd_f2bf(x + v[d]);
+    } else {
+      float x = q[i];
+      qu[i] = x + u[d];
+      qv[i] = x + v[d];
+    }
   }
+}
+
+// out_bf16 = a + b  (fp32 inputs): the query gradient dq = dq_u + dq_v feeding the bf16 GEMMs
+__global__ void add_cast_kernel(const float* __restrict__ a, const float* __restrict__ b, unsigned short* __restrict__ o,
+                                long n) {
+  const long stride = (long)gridDim.x * blockDim.x;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) o[i] = eamd_f2bf(a[i] + (b ? b[i] : 0.f));
 }
 
 // Column sums of a [rows, D] matrix, ADDED into out[D] (bias gradients).  Each block reduces a slab
 // of rows with threads along columns (coalesced) and issues one atomic per column.
 __global__ __launch_bounds__(256) void colsum_kernel(const float* __restrict__ x, long ld, float* __restrict__ out,
-                                                     long rows, int D, int rows_per_block, float scale) {
+                                                     long rows, int D, int rows_per_block, float scale, int bf16) {
   const long r0 = (long)blockIdx.y * rows_per_block;
   const long r1 = min(rows, r0 + (long)rows_per_block);
   const int c = blockIdx.x * blockDim.x + threadIdx.x;
   if (c >= D) return;
   float s = 0.f;
-  for (long r = r0; r < r1; ++r) s += x[r * ld + c];
+  if (bf16) {
+    const unsigned short* x16 = reinterpret_cast<const unsigned short*>(x);
+    for (long r = r0; r < r1; ++r) s += __uint_as_float(((unsigned)x16[r * ld + c]) << 16);
+  } else {
+    for (long r = r0; r < r1; ++r) s += x[r * ld + c];
+  }
   atomicAdd(&out[c], s * scale);
 }
 
@@ -246,31 +268,39 @@ int eamd_glu_fwd(const float* x, float* y, int64_t rows, int C, void* stream) {
   return EAMD_OK;
 }
 
-int eamd_glu_bwd(const float* dy, const float* x, float* dx, int64_t rows, int C, void* stream) {
-  if (!dy || !x || !dx || rows <= 0 || C <= 0) return EAMD_EINVAL;
+int eamd_glu_bwd(const float* dy, const float* x, float* dx, void* dx_bf16, int64_t rows, int C, void* stream) {
+  if (!dy || !x || (!dx && !dx_bf16) || rows <= 0 || C <= 0) return EAMD_EINVAL;
   hipLaunchKernelGGL(glu_bwd_kernel, dim3(grid_for(rows * C)), dim3(256), 0, (hipStream_t)stream, dy, x, dx,
-                     (long)rows, C);
+                     (unsigned short*)dx_bf16, (long)rows, C);
   EAMD_LAUNCH_CHECK();
   return EAMD_OK;
 }
 
-int eamd_add_bias2(const float* q, const float* u, const float* v, float* qu, float* qv, int64_t rows, int D,
-                   void* stream) {
+int eamd_add_cast_bf16(const float* a, const float* b, void* out_bf16, int64_t n, void* stream) {
+  if (!a || !out_bf16 || n <= 0) return EAMD_EINVAL;
+  hipLaunchKernelGGL(add_cast_kernel, dim3(grid_for(n)), dim3(256), 0, (hipStream_t)stream, a, b,
+                     (unsigned short*)out_bf16, (long)n);
+  EAMD_LAUNCH_CHECK();
+  return EAMD_OK;
+}
+
+int eamd_add_bias2(const void* q, const float* u, const float* v, void* qu, void* qv, int64_t rows, int D,
+                   int bf16, void* stream) {
   if (!q || !u || !v || !qu || !qv || rows <= 0 || D <= 0) return EAMD_EINVAL;
-  hipLaunchKernelGGL(add_bias2_kernel, dim3(grid_for(rows * D)), dim3(256), 0, (hipStream_t)stream, q, u, v, qu,
-                     qv, (long)rows, D);
+  hipLaunchKernelGGL(add_bias2_kernel, dim3(grid_for(rows * D)), dim3(256), 0, (hipStream_t)stream, (const float*)q, u,
+                     v, (float*)qu, (float*)qv, (long)rows, D, bf16);
   EAMD_LAUNCH_CHECK();
   return EAMD_OK;
 }
 
-int eamd_colsum(const float* x, int64_t ld, float* out, int64_t rows, int D, float scale, void* stream) {
+int eamd_colsum(const void* x, int64_t ld, float* out, int64_t rows, int D, float scale, int bf16, void* stream) {
   if (!x || !out || rows <= 0 || D <= 0) return EAMD_EINVAL;
   int gx = (D + 255) / 256;
   long want = 1024 / gx; if (want < 1) want = 1;
   long rpb = (rows + want - 1) / want; if (rpb < 32) rpb = 32;
   int gy = (int)((rows + rpb - 1) / rpb);
-  hipLaunchKernelGGL(colsum_kernel, dim3(gx, gy), dim3(256), 0, (hipStream_t)stream, x, (long)ld, out, (long)rows,
-                     D, (int)rpb, scale);
+  hipLaunchKernelGGL(colsum_kernel, dim3(gx, gy), dim3(256), 0, (hipStream_t)stream, (const float*)x, (long)ld, out,
+                     (long)rows, D, (int)rpb, scale, bf16);
   EAMD_LAUNCH_CHECK();
   return EAMD_OK;
 }

@@ -407,12 +407,26 @@ __global__ __launch_bounds__(NT_) void gemm_bf16_kernel(const eamd_gemm_t p) {
     }
   }
 
-  if (do_colsum) {
-#pragma unroll
-    for (int j = 0; j < 8; ++j) {
-      const int m = m0 + a_c[0] * 8 + j;
-      if (m < p.M) atomicAdd(p.colsum + (long)zb * p.M + m, cs[j] * p.alpha);
+  if (TA && p.colsum != nullptr && !gat) {   // wave-uniform: every thread of the block takes the same path
+    // bias gradient: combine the per-thread column sums in LDS (operand buffers are free now), then
+    // one global atomic per column per block
+    float* csl = reinterpret_cast<float*>(smem_raw);
+    if (do_colsum) {
+      for (int i = t; i < BM; i += NT_) csl[i] = 0.f;
     }
+    __syncthreads();
+    if (do_colsum) {
+#pragma unroll
+      for (int j = 0; j < 8; ++j) atomicAdd(&csl[a_c[0] * 8 + j], cs[j]);
+    }
+    __syncthreads();
+    if (do_colsum) {
+      for (int i = t; i < BM; i += NT_) {
+        const int m = m0 + i;
+        if (m < p.M) atomicAdd(p.colsum + (long)zb * p.M + m, csl[i] * p.alpha);
+      }
+    }
+    __syncthreads();
   }
 
   // ---- epilogue ------------------------------------------------------------------------------

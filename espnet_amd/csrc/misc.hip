@@ -50,18 +50,20 @@ __global__ void ctc_collapse_kernel(const int* __restrict__ ids, const int* __re
 // Class order q -> (kh,kw): (0,0)(0,2)(2,0)(2,2) | (0,1)(2,1) | (1,0)(1,2) | (1,1)
 __constant__ int kTapOrder[9] = {0, 2, 6, 8, 1, 7, 3, 5, 4};
 __global__ void conv2_weight_prep_kernel(const float* __restrict__ w, float* __restrict__ wf, float* __restrict__ wd,
-                                         int Co, int Ci) {
+                                         int Co, int Ci, int bf16) {
   const long n = (long)9 * Co * Ci;
   const long stride = (long)gridDim.x * blockDim.x;
   for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
     // i enumerates wf: [tap][ci][co]
     int co = i % Co; long t = i / Co; int ci = t % Ci; int tap = t / Ci;
-    wf[i] = w[((long)co * Ci + ci) * 9 + tap];
+    const float v = w[((long)co * Ci + ci) * 9 + tap];
+    if (bf16) reinterpret_cast<unsigned short*>(wf)[i] = eamd_f2bf(v); else wf[i] = v;
   }
   for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
     // i enumerates wd: [q][co][ci]
     int ci = i % Ci; long t = i / Ci; int co = t % Co; int q = t / Co;
-    wd[i] = w[((long)co * Ci + ci) * 9 + kTapOrder[q]];
+    const float v = w[((long)co * Ci + ci) * 9 + kTapOrder[q]];
+    if (bf16) reinterpret_cast<unsigned short*>(wd)[i] = eamd_f2bf(v); else wd[i] = v;
   }
 }
 // dw[Co][Ci][3][3] += dwf[tap][Ci][Co]
@@ -97,11 +99,12 @@ int eamd_ctc_collapse(const int32_t* ids, const int32_t* hlens, int32_t* out, in
   return EAMD_OK;
 }
 
-int eamd_conv2_weight_prep(const float* w, float* wf, float* wd, int Co, int Ci, void* stream) {
+int eamd_conv2_weight_prep(const float* w, void* wf, void* wd, int Co, int Ci, int out_bf16, void* stream) {
   if (!w || !wf || !wd || Co <= 0 || Ci <= 0) return EAMD_EINVAL;
   long n = (long)9 * Co * Ci;
   int g = (int)((n + 255) / 256); if (g > 2048) g = 2048;
-  hipLaunchKernelGGL(conv2_weight_prep_kernel, dim3(g), dim3(256), 0, (hipStream_t)stream, w, wf, wd, Co, Ci);
+  hipLaunchKernelGGL(conv2_weight_prep_kernel, dim3(g), dim3(256), 0, (hipStream_t)stream, w, (float*)wf, (float*)wd,
+                     Co, Ci, out_bf16);
   EAMD_LAUNCH_CHECK();
   return EAMD_OK;
 }

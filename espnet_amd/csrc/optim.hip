@@ -60,7 +60,8 @@ __global__ void sched_kernel(float* __restrict__ st, const float* __restrict__ g
 // torch.optim.Adam semantics (L2 weight decay added to the gradient), gradient pre-scaled by the
 // clip coefficient; a zero coefficient together with a non-finite norm means "skip this step".
 __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, const float* __restrict__ g,
-                                                   float* __restrict__ m, float* __restrict__ v, long n,
+                                                   float* __restrict__ m, float* __restrict__ v,
+                                                   unsigned short* __restrict__ p16, long n,
                                                    const float* __restrict__ st, float beta1, float beta2,
                                                    float eps, float weight_decay) {
   const float norm = st[4];
@@ -87,6 +88,12 @@ __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, const 
     reinterpret_cast<float4*>(p)[i] = pv;
     reinterpret_cast<float4*>(m)[i] = mv;
     reinterpret_cast<float4*>(v)[i] = vv;
+    if (p16) {   // bf16 shadow of the updated weights for the bf16-operand GEMMs (no extra read pass)
+      uint2 h;
+      h.x = eamd_f2bf(pv.x) | ((unsigned)eamd_f2bf(pv.y) << 16);
+      h.y = eamd_f2bf(pv.z) | ((unsigned)eamd_f2bf(pv.w) << 16);
+      reinterpret_cast<uint2*>(p16)[i] = h;
+    }
   }
   for (long i = n4 * 4 + (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
     float gg = g[i] * coef + weight_decay * p[i];
@@ -94,6 +101,7 @@ __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, const 
     v[i] = beta2 * v[i] + (1.f - beta2) * gg * gg;
     float denom = sqrtf(v[i]) * inv_sqrt_bc2 + eps;
     p[i] -= step_size * m[i] / denom;
+    if (p16) p16[i] = eamd_f2bf(p[i]);
   }
 }
 
@@ -124,14 +132,14 @@ int eamd_sched_step(float* state, const float* gnorm, int mode, float base_lr, f
   return EAMD_OK;
 }
 
-int eamd_adam_step(float* p, const float* g, float* m, float* v, int64_t n, const float* state, float beta1,
-                   float beta2, float eps, float weight_decay, void* stream) {
+int eamd_adam_step(float* p, const float* g, float* m, float* v, void* p_bf16, int64_t n, const float* state,
+                   float beta1, float beta2, float eps, float weight_decay, void* stream) {
   if (!p || !g || !m || !v || !state || n <= 0) return EAMD_EINVAL;
   if (((uintptr_t)p | (uintptr_t)g | (uintptr_t)m | (uintptr_t)v) & 15) return EAMD_EINVAL;
   long want = (n / 4 + 255) / 256;
   int nblk = (int)(want < 1 ? 1 : (want > 2048 ? 2048 : want));
-  hipLaunchKernelGGL(adam_kernel, dim3(nblk), dim3(256), 0, (hipStream_t)stream, p, g, m, v, (long)n, state, beta1,
-                     beta2, eps, weight_decay);
+  hipLaunchKernelGGL(adam_kernel, dim3(nblk), dim3(256), 0, (hipStream_t)stream, p, g, m, v, (unsigned short*)p_bf16,
+                     (long)n, state, beta1, beta2, eps, weight_decay);
   EAMD_LAUNCH_CHECK();
   return EAMD_OK;
 }

@@ -12,7 +12,8 @@ namespace {
 __global__ __launch_bounds__(256) void layernorm_fwd_kernel(const float* __restrict__ x,
                                                             const float* __restrict__ gamma,
                                                             const float* __restrict__ beta,
-                                                            float* __restrict__ y, float* __restrict__ mean_out,
+                                                            float* __restrict__ y, unsigned short* __restrict__ y16,
+                                                            float* __restrict__ mean_out,
                                                             float* __restrict__ rstd_out, int rows, int D,
                                                             float eps) {
   const int lane = threadIdx.x & 63;
@@ -25,8 +26,11 @@ __global__ __launch_bounds__(256) void layernorm_fwd_kernel(const float* __restr
   float v = 0.f;
   for (int i = lane; i < D; i += 64) { float d = xr[i] - mean; v += d * d; }
   const float rstd = rsqrtf(wave_sum(v) / D + eps);
-  float* yr = y + (long)row * D;
-  for (int i = lane; i < D; i += 64) yr[i] = (xr[i] - mean) * rstd * gamma[i] + beta[i];
+  for (int i = lane; i < D; i += 64) {
+    const float o = (xr[i] - mean) * rstd * gamma[i] + beta[i];
+    if (y) y[(long)row * D + i] = o;
+    if (y16) y16[(long)row * D + i] = eamd_f2bf(o);
+  }
   if (lane == 0) { mean_out[row] = mean; rstd_out[row] = rstd; }
 }
 
@@ -36,6 +40,7 @@ __global__ __launch_bounds__(256) void layernorm_fwd_vec_kernel(const float* __r
                                                                 const float* __restrict__ gamma,
                                                                 const float* __restrict__ beta,
                                                                 float* __restrict__ y,
+                                                                unsigned short* __restrict__ y16,
                                                                 float* __restrict__ mean_out,
                                                                 float* __restrict__ rstd_out, int rows,
                                                                 float eps) {
@@ -56,7 +61,8 @@ __global__ __launch_bounds__(256) void layernorm_fwd_vec_kernel(const float* __r
     q += a * a + b * b + c * c + d * d;
   }
   const float rstd = rsqrtf(wave_sum(q) / D + eps);
-  float4* yr = reinterpret_cast<float4*>(y + (long)row * D);
+  float4* yr = y ? reinterpret_cast<float4*>(y + (long)row * D) : nullptr;
+  uint2* yr16 = y16 ? reinterpret_cast<uint2*>(y16 + (long)row * D) : nullptr;
   const float4* g4 = reinterpret_cast<const float4*>(gamma);
   const float4* b4 = reinterpret_cast<const float4*>(beta);
 #pragma unroll
@@ -66,7 +72,13 @@ __global__ __launch_bounds__(256) void layernorm_fwd_vec_kernel(const float* __r
     o.y = (v[j].y - mean) * rstd * g.y + b.y;
     o.z = (v[j].z - mean) * rstd * g.z + b.z;
     o.w = (v[j].w - mean) * rstd * g.w + b.w;
-    yr[lane + 64 * j] = o;
+    if (yr) yr[lane + 64 * j] = o;
+    if (yr16) {
+      uint2 h;
+      h.x = eamd_f2bf(o.x) | ((unsigned)eamd_f2bf(o.y) << 16);
+      h.y = eamd_f2bf(o.z) | ((unsigned)eamd_f2bf(o.w) << 16);
+      yr16[lane + 64 * j] = h;
+    }
   }
   if (lane == 0) { mean_out[row] = mean; rstd_out[row] = rstd; }
 }
@@ -196,7 +208,7 @@ __device__ __forceinline__ float shifted_bd(const float* __restrict__ bd, int T1
 __global__ __launch_bounds__(256) void softmax_fwd_kernel(const float* ac,
                                                           const float* __restrict__ bd,
                                                           const unsigned char* __restrict__ mask, long mb,
-                                                          long mi, float* P, int nb, int B,
+                                                          long mi, float* P, unsigned short* P16, int nb, int B,
                                                           int T1, int T2, long ld, float scale) {
   extern __shared__ float lds[];  // [4][T2]
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -218,39 +230,52 @@ __global__ __launch_bounds__(256) void softmax_fwd_kernel(const float* ac,
     mx = fmaxf(mx, v);
   }
   mx = wave_max(mx);
-  float* pr = P + ((long)z * T1 + i) * ld;
+  const long ro = ((long)z * T1 + i) * ld;
   if (mx == -INFINITY) {  // every key masked: softmax(min,...)=uniform, then masked_fill(0) -> zeros
-    for (int j = lane; j < ld; j += 64) pr[j] = 0.f;
+    for (int j = lane; j < ld; j += 64) { if (P16) P16[ro + j] = 0; else P[ro + j] = 0.f; }
     return;
   }
   float s = 0.f;
   for (int j = lane; j < T2; j += 64) { float e = __expf(buf[j] - mx); buf[j] = e; s += e; }
   const float inv = 1.f / wave_sum(s);
-  for (int j = lane; j < ld; j += 64) pr[j] = j < T2 ? buf[j] * inv : 0.f;
+  for (int j = lane; j < ld; j += 64) {
+    const float o = j < T2 ? buf[j] * inv : 0.f;
+    if (P16) P16[ro + j] = eamd_f2bf(o); else P[ro + j] = o;
+  }
 }
 
 // dS = P * (dP - sum_j dP*P) * scale, written over dP (d_ac); optional scatter of dS through the
 // inverse rel-shift into dbd (pre-zeroed by the caller).
-__global__ __launch_bounds__(256) void softmax_bwd_kernel(const float* __restrict__ P, float* __restrict__ dP,
-                                                          float* __restrict__ dbd, int nb, int T1, int T2,
+__global__ __launch_bounds__(256) void softmax_bwd_kernel(const float* __restrict__ P,
+                                                          const unsigned short* __restrict__ P16, float* dP,
+                                                          float* __restrict__ dbd, unsigned short* __restrict__ dS16,
+                                                          unsigned short* __restrict__ dbd16, int nb, int T1, int T2,
                                                           long ld, float scale) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const long rowid = (long)blockIdx.x * 4 + wave;
   if (rowid >= (long)nb * T1) return;
   const int z = rowid / T1, i = rowid % T1;
-  const float* pr = P + ((long)z * T1 + i) * ld;
-  float* dr = dP + ((long)z * T1 + i) * ld;
+  const long ro = ((long)z * T1 + i) * ld;
+  float* dr = dP + ro;
   float s = 0.f;
-  for (int j = lane; j < T2; j += 64) s += pr[j] * dr[j];
-  s = wave_sum(s);
-  float* dbz = dbd ? dbd + (long)z * T1 * ld : nullptr;
   for (int j = lane; j < T2; j += 64) {
-    float g = pr[j] * (dr[j] - s) * scale;
-    dr[j] = g;
-    if (dbz) {
+    const float pv = P16 ? __uint_as_float(((unsigned)P16[ro + j]) << 16) : P[ro + j];
+    s += pv * dr[j];
+  }
+  s = wave_sum(s);
+  const long zo = (long)z * T1 * ld;
+  for (int j = lane; j < ld; j += 64) {
+    if (j >= T2) { if (dS16) dS16[ro + j] = 0; continue; }
+    const float pv = P16 ? __uint_as_float(((unsigned)P16[ro + j]) << 16) : P[ro + j];
+    float g = pv * (dr[j] - s) * scale;
+    if (dS16) dS16[ro + j] = eamd_f2bf(g); else dr[j] = g;
+    if (dbd || dbd16) {
       int f = T1 + i * T2 + j;
       int r = f / (T2 + 1), c = f % (T2 + 1);
-      if (c != 0) dbz[(long)r * ld + (c - 1)] = g;
+      if (c != 0) {
+        if (dbd16) dbd16[zo + (long)r * ld + (c - 1)] = eamd_f2bf(g);
+        else dbd[zo + (long)r * ld + (c - 1)] = g;
+      }
     }
   }
 }
@@ -381,16 +406,17 @@ __global__ __launch_bounds__(256) void log_softmax_rows_kernel(const float* __re
 
 extern "C" {
 
-int eamd_layernorm_fwd(const float* x, const float* gamma, const float* beta, float* y, float* mean,
+int eamd_layernorm_fwd(const float* x, const float* gamma, const float* beta, float* y, void* y_bf16, float* mean,
                        float* rstd, int rows, int D, float eps, void* stream) {
-  if (!x || !gamma || !beta || !y || !mean || !rstd || rows <= 0 || D <= 0) return EAMD_EINVAL;
+  if (!x || !gamma || !beta || (!y && !y_bf16) || !mean || !rstd || rows <= 0 || D <= 0) return EAMD_EINVAL;
+  unsigned short* y16 = (unsigned short*)y_bf16;
   hipStream_t s = (hipStream_t)stream;
   dim3 grid((rows + 3) / 4), block(256);
   const bool al = ((uintptr_t)x % 16 == 0) && ((uintptr_t)y % 16 == 0) && ((uintptr_t)gamma % 16 == 0) &&
-                  ((uintptr_t)beta % 16 == 0);
-  if (al && D == 256) hipLaunchKernelGGL(layernorm_fwd_vec_kernel<1>, grid, block, 0, s, x, gamma, beta, y, mean, rstd, rows, eps);
-  else if (al && D == 512) hipLaunchKernelGGL(layernorm_fwd_vec_kernel<2>, grid, block, 0, s, x, gamma, beta, y, mean, rstd, rows, eps);
-  else hipLaunchKernelGGL(layernorm_fwd_kernel, grid, block, 0, s, x, gamma, beta, y, mean, rstd, rows, D, eps);
+                  ((uintptr_t)beta % 16 == 0) && ((uintptr_t)y16 % 8 == 0);
+  if (al && D == 256) hipLaunchKernelGGL(layernorm_fwd_vec_kernel<1>, grid, block, 0, s, x, gamma, beta, y, y16, mean, rstd, rows, eps);
+  else if (al && D == 512) hipLaunchKernelGGL(layernorm_fwd_vec_kernel<2>, grid, block, 0, s, x, gamma, beta, y, y16, mean, rstd, rows, eps);
+  else hipLaunchKernelGGL(layernorm_fwd_kernel, grid, block, 0, s, x, gamma, beta, y, y16, mean, rstd, rows, D, eps);
   EAMD_LAUNCH_CHECK();
   return EAMD_OK;
 }
@@ -421,9 +447,9 @@ int eamd_layernorm_bwd(const float* dy, const float* x, const float* gamma, cons
 }
 
 int eamd_softmax_fwd(const float* ac, const float* bd, const unsigned char* mask, int64_t mask_bstride,
-                     int64_t mask_qstride, float* P, int nblocks, int B, int T1, int T2, int64_t ld,
+                     int64_t mask_qstride, float* P, void* P_bf16, int nblocks, int B, int T1, int T2, int64_t ld,
                      float scale, void* stream) {
-  if (!ac || !P || nblocks <= 0 || B <= 0 || T1 <= 0 || T2 <= 0 || ld < T2) return EAMD_EINVAL;
+  if (!ac || (!P && !P_bf16) || nblocks <= 0 || B <= 0 || T1 <= 0 || T2 <= 0 || ld < T2) return EAMD_EINVAL;
   if ((size_t)T2 * 16 > 160 * 1024) return EAMD_EUNSUPPORTED;
   long rows = (long)nblocks * T1;
   size_t smem = (size_t)4 * T2 * sizeof(float);
@@ -433,16 +459,18 @@ int eamd_softmax_fwd(const float* ac, const float* bd, const unsigned char* mask
     if (e != hipSuccess) return (int)e;
   }
   hipLaunchKernelGGL(softmax_fwd_kernel, dim3((rows + 3) / 4), dim3(256), smem, (hipStream_t)stream, ac, bd,
-                     mask, (long)mask_bstride, (long)mask_qstride, P, nblocks, B, T1, T2, (long)ld, scale);
+                     mask, (long)mask_bstride, (long)mask_qstride, P, (unsigned short*)P_bf16, nblocks, B, T1, T2,
+                     (long)ld, scale);
   EAMD_LAUNCH_CHECK();
   return EAMD_OK;
 }
 
-int eamd_softmax_bwd(const float* P, float* dP, float* dbd, int nblocks, int T1, int T2, int64_t ld,
-                     float scale, void* stream) {
-  if (!P || !dP || nblocks <= 0 || T1 <= 0 || T2 <= 0 || ld < T2) return EAMD_EINVAL;
+int eamd_softmax_bwd(const float* P, const void* P_bf16, float* dP, float* dbd, void* dS_bf16, void* dbd_bf16,
+                     int nblocks, int T1, int T2, int64_t ld, float scale, void* stream) {
+  if ((!P && !P_bf16) || !dP || nblocks <= 0 || T1 <= 0 || T2 <= 0 || ld < T2) return EAMD_EINVAL;
   long rows = (long)nblocks * T1;
-  hipLaunchKernelGGL(softmax_bwd_kernel, dim3((rows + 3) / 4), dim3(256), 0, (hipStream_t)stream, P, dP, dbd,
+  hipLaunchKernelGGL(softmax_bwd_kernel, dim3((rows + 3) / 4), dim3(256), 0, (hipStream_t)stream, P,
+                     (const unsigned short*)P_bf16, dP, dbd, (unsigned short*)dS_bf16, (unsigned short*)dbd_bf16,
                      nblocks, T1, T2, (long)ld, scale);
   EAMD_LAUNCH_CHECK();
   return EAMD_OK;

@@ -72,8 +72,8 @@ class LinearFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, weight, bias):
         shp = x.shape
-        x2 = x.reshape(-1, shp[-1]).contiguous()
-        y = ops.linear_fwd(x2, weight, bias)
+        x2 = ops.to_act(x.reshape(-1, shp[-1]).contiguous())
+        y = ops.linear_fwd(x2, ops.wshadow(weight), bias)
         ctx.save_for_backward(x2)
         ctx.pr = (weight, bias)
         ctx.shp = shp
@@ -84,8 +84,8 @@ class LinearFn(torch.autograd.Function):
         (x2,) = ctx.saved_tensors
         w, b = ctx.pr
         sink = GradSink([w, b] if b is not None else [w])
-        dy2 = dy.reshape(x2.shape[0], w.shape[0]).contiguous()
-        dx = ops.linear_bwd_x(dy2, w) if ctx.needs_input_grad[0] else None
+        dy2 = ops.to_act(dy.reshape(x2.shape[0], w.shape[0]).contiguous())
+        dx = ops.linear_bwd_x(dy2, ops.wshadow(w)) if ctx.needs_input_grad[0] else None
         ops.linear_bwd_w(dy2, x2, sink.buf(0), db=sink.buf(1) if b is not None else None)
         res = sink.results()
         return (dx.view(ctx.shp) if dx is not None else None, res[0], res[1] if b is not None else None)
@@ -102,10 +102,11 @@ class FFNBlockFn(torch.autograd.Function):
     def forward(ctx, x, ln_w, ln_b, w1, b1, w2, b2, scale, act, eps):
         shp = x.shape
         D = shp[-1]
+        adt = ops.act_dtype()
         x2 = x.reshape(-1, D).contiguous()
-        xn, mean, rstd = ops.layernorm_fwd(x2, ln_w, ln_b, eps)
-        z = ops.linear_fwd(xn, w1, b1)                                     # [M, F] pre-activation
-        out = ops.linear_fwd(z, w2, b2, R=x2, alpha=scale, a_act=act)      # act applied while staging z
+        xn, mean, rstd = ops.layernorm_fwd(x2, ln_w, ln_b, eps, adt)            # GEMM operand (bf16 in fast mode)
+        z = ops.linear_fwd(xn, ops.wshadow(w1), b1, out_dtype=adt)              # [M, F] pre-activation
+        out = ops.linear_fwd(z, ops.wshadow(w2), b2, R=x2, alpha=scale, a_act=act)   # act applied while staging z
         ctx.save_for_backward(x2, mean, rstd, xn, z)
         ctx.pr = (ln_w, ln_b, w1, b1, w2, b2)
         ctx.cfg = (scale, act, shp)
@@ -116,12 +117,14 @@ class FFNBlockFn(torch.autograd.Function):
         x2, mean, rstd, xn, z = ctx.saved_tensors
         ln_w, ln_b, w1, b1, w2, b2 = ctx.pr
         scale, act, shp = ctx.cfg
+        adt = ops.act_dtype()
         sink = GradSink(ctx.pr)
         do = dout.reshape(x2.shape).contiguous()
-        ops.linear_bwd_w(do, z, sink.buf(4), alpha=scale, b_act=act, db=sink.buf(5))   # dW2 += s * do^T act(z)
-        dz = ops.linear_bwd_x(do, w2, epilogue=_act_epi(act), aux=z, alpha=scale)   # (do W2) * act'(z) * s
+        dob = ops.to_act(do)
+        ops.linear_bwd_w(dob, z, sink.buf(4), alpha=scale, b_act=act, db=sink.buf(5))   # dW2 += s * do^T act(z)
+        dz = ops.linear_bwd_x(dob, ops.wshadow(w2), epilogue=_act_epi(act), aux=z, alpha=scale, out_dtype=adt)
         ops.linear_bwd_w(dz, xn, sink.buf(2), db=sink.buf(3))
-        dxn = ops.linear_bwd_x(dz, w1)
+        dxn = ops.linear_bwd_x(dz, ops.wshadow(w1))
         dx = ops.layernorm_bwd(dxn, x2, ln_w, mean, rstd, do, sink.buf(0), sink.buf(1))
         return (dx.view(shp),) + sink.results() + (None, None, None)
 
@@ -131,7 +134,7 @@ class FFNBlockFn(torch.autograd.Function):
 # scores live in [H, B, T1, ldp] so that for one head the (b, i) rows are uniformly strided.
 # =================================================================================================
 def _ldp(T2):
-    return (T2 + 3) // 4 * 4
+    return (T2 + 7) // 8 * 8
 
 
 def attn_scores_fwd(qu, qv, k, p, mask, B, T1, T2, H, dk):
@@ -145,38 +148,45 @@ def attn_scores_fwd(qu, qv, k, p, mask, B, T1, T2, H, dk):
         bd = torch.empty_like(ac)
         ops.gemm(qv, p, bd, T1, T2, dk, D, D, ldp, batch=(B, H), sA=(T1 * D, dk), sB=(0, dk),
                  sC=(T1 * ldp, B * T1 * ldp))
-    ops.softmax_fwd(ac, bd, mask, ac, H * B, B, T1, T2, ldp, 1.0 / math.sqrt(dk))
-    return ac  # now holds P
+    if ops.fast():
+        P = torch.empty(H * B * T1 * ldp, device=qu.device, dtype=torch.bfloat16)
+    else:
+        P = ac   # in place
+    ops.softmax_fwd(ac, bd, mask, P, H * B, B, T1, T2, ldp, 1.0 / math.sqrt(dk))
+    return P
 
 
 def attn_context_fwd(P, v, B, T1, T2, H, dk):
     D = H * dk
     ldp = _ldp(T2)
-    ctxv = torch.empty(B * T1, D, device=v.device, dtype=torch.float32)
+    ctxv = torch.empty(B * T1, D, device=v.device, dtype=ops.act_dtype())
     ops.gemm(P, v, ctxv, T1, dk, T2, ldp, D, D, transB=1, batch=(B, H), sA=(T1 * ldp, B * T1 * ldp),
              sB=(T2 * D, dk), sC=(T1 * D, dk))
     return ctxv
 
 
 def attn_core_bwd(dctx, P, qu, qv, k, v, p, B, T1, T2, H, dk):
-    """returns dqu, dqv (or None), dk, dv, dp (or None)"""
+    """returns dqu (fp32), dqv (fp32 or None), dk, dv (GEMM-operand dtype), dp (fp32 or None)"""
     D = H * dk
     ldp = _ldp(T2)
     dev = dctx.device
+    adt = ops.act_dtype()
     sP = (T1 * ldp, B * T1 * ldp)
     dP = torch.empty(H * B * T1 * ldp, device=dev, dtype=torch.float32)
-    # dP = dctx v^T
-    ops.gemm(dctx, v, dP, T1, T2, dk, D, D, ldp, batch=(B, H), sA=(T1 * D, dk), sB=(T2 * D, dk), sC=sP)
-    # dv = P^T dctx
-    dv = torch.empty(B * T2, D, device=dev, dtype=torch.float32)
+    ops.gemm(dctx, v, dP, T1, T2, dk, D, D, ldp, batch=(B, H), sA=(T1 * D, dk), sB=(T2 * D, dk), sC=sP)   # dctx v^T
+    dv = torch.empty(B * T2, D, device=dev, dtype=adt)
     ops.gemm(P, dctx, dv, T2, dk, T1, ldp, D, D, transA=1, transB=1, batch=(B, H), sA=sP, sB=(T1 * D, dk),
-             sC=(T2 * D, dk))
-    dbd = torch.zeros_like(dP) if p is not None else None
-    ops.softmax_bwd(P, dP, dbd, H * B, T1, T2, ldp, 1.0 / math.sqrt(dk))   # dP <- d(ac)
-    dS = dP
+             sC=(T2 * D, dk))                                                                             # P^T dctx
+    dbd = torch.zeros(H * B * T1 * ldp, device=dev, dtype=adt) if p is not None else None
+    if ops.fast():
+        dS = torch.empty(H * B * T1 * ldp, device=dev, dtype=torch.bfloat16)
+        ops.softmax_bwd(P, dP, dbd, H * B, T1, T2, ldp, 1.0 / math.sqrt(dk), dS16=dS)
+    else:
+        ops.softmax_bwd(P, dP, dbd, H * B, T1, T2, ldp, 1.0 / math.sqrt(dk))   # dP <- d(ac)
+        dS = dP
     dqu = torch.empty(B * T1, D, device=dev, dtype=torch.float32)
     ops.gemm(dS, k, dqu, T1, dk, T2, ldp, D, D, transB=1, batch=(B, H), sA=sP, sB=(T2 * D, dk), sC=(T1 * D, dk))
-    dkk = torch.empty(B * T2, D, device=dev, dtype=torch.float32)
+    dkk = torch.empty(B * T2, D, device=dev, dtype=adt)
     ops.gemm(dS, qu, dkk, T2, dk, T1, ldp, D, D, transA=1, transB=1, batch=(B, H), sA=sP, sB=(T1 * D, dk),
              sC=(T2 * D, dk))
     dqv = dp = None
@@ -205,69 +215,73 @@ class MHABlockFn(torch.autograd.Function):
         rel = len(params) > 10
         B, T1f, D = x.shape
         dk = D // H
+        adt = ops.act_dtype()
         x2 = x.reshape(-1, D).contiguous()
-        xn, mean, rstd = ops.layernorm_fwd(x2, ln_w, ln_b, eps)
+        xn, mean, rstd = ops.layernorm_fwd(x2, ln_w, ln_b, eps, adt)
         if memory is None:
             kv_in, T2 = xn, T1f
         else:
-            kv_in, T2 = memory.reshape(-1, D).contiguous(), memory.shape[1]
+            kv_in, T2 = ops.to_act(memory.reshape(-1, D).contiguous()), memory.shape[1]
         if last_query_only:   # cached decoding: only the newest position queries (decoder_layer.py:88-101)
             xq = xn.view(B, T1f, D)[:, -1, :].contiguous()
             res = x2.view(B, T1f, D)[:, -1, :].contiguous()
             T1 = 1
         else:
             xq, res, T1 = xn, x2, T1f
-        q = ops.linear_fwd(xq, wq, bq)
-        k = ops.linear_fwd(kv_in, wk, bk)
-        v = ops.linear_fwd(kv_in, wv, bv)
+        q = ops.linear_fwd(xq, ops.wshadow(wq), bq, out_dtype=adt)
+        k = ops.linear_fwd(kv_in, ops.wshadow(wk), bk, out_dtype=adt)
+        v = ops.linear_fwd(kv_in, ops.wshadow(wv), bv, out_dtype=adt)
+        pos2 = None
         if rel:
             wpos, pu, pv = params[10:13]
-            p = ops.linear_fwd(pos_emb.reshape(-1, D).contiguous(), wpos, None)
+            pos2 = ops.to_act(pos_emb.reshape(-1, D).contiguous())
+            p = ops.linear_fwd(pos2, ops.wshadow(wpos), None, out_dtype=adt)
             qu, qv = ops.add_bias2(q, pu.reshape(-1), pv.reshape(-1))
         else:
             p, qu, qv = None, q, None
         P = attn_scores_fwd(qu, qv, k, p, mask, B, T1, T2, H, dk)
         cx = attn_context_fwd(P, v, B, T1, T2, H, dk)
-        out = ops.linear_fwd(cx, wo, bo, R=res)
-        ctx.save_for_backward(x2, mean, rstd, xn, kv_in if memory is not None else None, qu, qv, k, v, p, P, cx,
-                              pos_emb)
+        out = ops.linear_fwd(cx, ops.wshadow(wo), bo, R=res)
+        ctx.save_for_backward(x2, mean, rstd, xn, kv_in if memory is not None else None, qu, qv, k, v, p, P, cx, pos2)
         ctx.pr = params
         ctx.cfg = (B, T1, T2, H, dk, D, rel, memory is not None, last_query_only)
         return out.view(B, T1, D)
 
     @staticmethod
     def backward(ctx, dout):
-        x2, mean, rstd, xn, mem2, qu, qv, k, v, p, P, cx, pos_emb = ctx.saved_tensors
+        x2, mean, rstd, xn, mem2, qu, qv, k, v, p, P, cx, pos2 = ctx.saved_tensors
         B, T1, T2, H, dk, D, rel, cross, last = ctx.cfg
         assert not last, "cached decoding path is inference-only"
         params = ctx.pr
         ln_w, ln_b, wq, bq, wk, bk, wv, bv, wo, bo = params[:10]
+        adt = ops.act_dtype()
         sink = GradSink(params)
         do = dout.reshape(-1, D).contiguous()
-        ops.linear_bwd_w(do, cx, sink.buf(8), db=sink.buf(9))
-        dctx = ops.linear_bwd_x(do, wo)
+        dob = ops.to_act(do)
+        ops.linear_bwd_w(dob, cx, sink.buf(8), db=sink.buf(9))
+        dctx = ops.linear_bwd_x(dob, ops.wshadow(wo), out_dtype=adt)
         dqu, dqv, dkk, dv, dp = attn_core_bwd(dctx, P, qu, qv, k, v, p, B, T1, T2, H, dk)
         if rel:
             wpos = params[10]
             ops.colsum(dqu, sink.buf(11).view(-1))
             ops.colsum(dqv, sink.buf(12).view(-1))
-            dq = ops.axpby(dqu, dqv, 1.0, 1.0)
-            ops.linear_bwd_w(dp, pos_emb.reshape(-1, D).contiguous(), sink.buf(10))
+            dq = ops.add_cast(dqu, dqv) if ops.fast() else ops.axpby(dqu, dqv, 1.0, 1.0)
+            ops.linear_bwd_w(ops.to_act(dp), pos2, sink.buf(10))
         else:
-            dq = dqu
+            dq = ops.to_act(dqu)
         kv_in = mem2 if cross else xn
         ops.linear_bwd_w(dq, xn, sink.buf(2), db=sink.buf(3))
         ops.linear_bwd_w(dkk, kv_in, sink.buf(4), db=sink.buf(5))
         ops.linear_bwd_w(dv, kv_in, sink.buf(6), db=sink.buf(7))
-        dxn = ops.linear_bwd_x(dq, wq)
+        dxn = ops.linear_bwd_x(dq, ops.wshadow(wq))
         dmem = None
         if cross:
-            dmem = ops.linear_bwd_x(dkk, wk)
-            ops.linear_bwd_x(dv, wv, out=dmem, beta=1.0)
+            dmem = ops.linear_bwd_x(dkk, ops.wshadow(wk))
+            ops.linear_bwd_x(dv, ops.wshadow(wv), out=dmem, beta=1.0)
             dmem = dmem.view(B, T2, D)
         else:
-            ops.linear_bwd_x(dkk, wk, out=dxn, beta=1.0)
-            ops.linear_bwd_x(dv, wv, out=dxn, beta=1.0)
+            ops.linear_bwd_x(dkk, ops.wshadow(wk), out=dxn, beta=1.0)
+            ops.linear_bwd_x(dv, ops.wshadow(wv), out=dxn, beta=1.0)
         dx = ops.layernorm_bwd(dxn, x2, ln_w, mean, rstd, do, sink.buf(0), sink.buf(1))
         return (dx.view(B, T1, D), dmem, None, None, None, None, None) + sink.results()
 
@@ -286,19 +300,20 @@ class ConvModuleBlockFn(torch.autograd.Function):
         Cc = w2.shape[0]
         K = wd.shape[-1]
         M = B * T
+        adt = ops.act_dtype()
         x2 = x.reshape(M, D).contiguous()
-        xn, mean, rstd = ops.layernorm_fwd(x2, ln_w, ln_b, eps)
-        a = ops.linear_fwd(xn, w1.view(2 * Cc, D), b1)               # pointwise conv 1  [M, 2C]
-        gl = ops.glu_fwd(a, Cc)                                      # [M, C]
-        d = ops.dwconv_fwd(gl, wd.view(Cc, K), bd_, B, T, Cc, K)     # depthwise conv over time
+        xn, mean, rstd = ops.layernorm_fwd(x2, ln_w, ln_b, eps, adt)
+        a = ops.linear_fwd(xn, ops.wshadow(w1).view(2 * Cc, D), b1)     # pointwise conv 1  [M, 2C] fp32
+        gl = ops.glu_fwd(a, Cc)                                          # [M, C]
+        d = ops.dwconv_fwd(gl, wd.view(Cc, K), bd_, B, T, Cc, K)         # depthwise conv over time
         if training:
             bmean, brstd = ops.bn_stats(d, M, Cc, bn_eps, bn_momentum, running_mean, running_var)
         else:
             bmean = running_mean
             brstd = ops.axpby(running_var, None, 1.0, 0.0)
             brstd = torch.rsqrt_(brstd.add_(bn_eps))  # tiny [C] host-issued op on eval path only
-        e = ops.bn_apply(d, bmean, brstd, g, be, M, Cc, act)
-        out = ops.linear_fwd(e, w2.view(Cc, Cc), b2, R=x2)
+        e = ops.bn_apply(d, bmean, brstd, g, be, M, Cc, act, adt)
+        out = ops.linear_fwd(e, ops.wshadow(w2).view(Cc, Cc), b2, R=x2)
         ctx.save_for_backward(x2, mean, rstd, xn, a, gl, d, bmean, brstd, e)
         ctx.pr = params
         ctx.cfg = (B, T, D, Cc, K, act, training)
@@ -310,16 +325,18 @@ class ConvModuleBlockFn(torch.autograd.Function):
         ln_w, ln_b, w1, b1, wd, bd_, g, be, w2, b2 = ctx.pr
         B, T, D, Cc, K, act, training = ctx.cfg
         M = B * T
+        adt = ops.act_dtype()
         sink = GradSink(ctx.pr)
         do = dout.reshape(M, D).contiguous()
-        ops.linear_bwd_w(do, e, sink.buf(8).view(Cc, Cc), db=sink.buf(9))
-        de = ops.linear_bwd_x(do, w2.view(Cc, Cc))
+        dob = ops.to_act(do)
+        ops.linear_bwd_w(dob, e, sink.buf(8).view(Cc, Cc), db=sink.buf(9))
+        de = ops.linear_bwd_x(dob, ops.wshadow(w2).view(Cc, Cc))
         dd = ops.bn_bwd(de, d, bmean, brstd, g, be, sink.buf(6), sink.buf(7), M, Cc, act, training)
         dgl = ops.dwconv_bwd_x(dd, wd.view(Cc, K), B, T, Cc, K)
         ops.dwconv_bwd_w(dd, gl, sink.buf(4).view(Cc, K), sink.buf(5), B, T, Cc, K)
-        da = ops.glu_bwd(dgl, a, Cc)
+        da = ops.glu_bwd(dgl, a, Cc, adt)
         ops.linear_bwd_w(da, xn, sink.buf(2).view(2 * Cc, D), db=sink.buf(3))
-        dxn = ops.linear_bwd_x(da, w1.view(2 * Cc, D))
+        dxn = ops.linear_bwd_x(da, ops.wshadow(w1).view(2 * Cc, D))
         dx = ops.layernorm_bwd(dxn, x2, ln_w, mean, rstd, do, sink.buf(0), sink.buf(1))
         return (dx.view(B, T, D), None, None, None, None, None, None, None) + sink.results()
 
@@ -344,16 +361,18 @@ class Conv2dSubsamplingFn(torch.autograd.Function):
         H1, W1 = (T - 3) // 2 + 1, (F - 3) // 2 + 1
         H2, W2 = (H1 - 3) // 2 + 1, (W1 - 3) // 2 + 1
         assert lin_w.shape[1] == Cc * W2
+        adt = ops.act_dtype()
         x = x.contiguous()
-        y1 = ops.conv1_fwd(x, c1_w, c1_b, B, T, F, Cc)                       # [B,H1,W1,C] NHWC, ReLU'd
-        wf, wd = ops.conv2_weight_prep(c2_w)
+        y1 = ops.conv1_fwd(x, c1_w, c1_b, B, T, F, Cc, adt)                  # [B,H1,W1,C] NHWC, ReLU'd
+        wf, wd = ops.conv2_weight_prep(c2_w, adt)
         g = ops.make_gather(Cc, _TAPS_FWD, H2, W2, H1, W1, 2, 2)
         M2 = B * H2 * W2
-        y2 = torch.empty(M2, Cc, device=x.device, dtype=torch.float32)
+        y2 = torch.empty(M2, Cc, device=x.device, dtype=adt)
         ops.gemm(y1, wf, y2, M2, Cc, 9 * Cc, 9 * Cc, Cc, Cc, transB=1, bias=c2_b, epilogue=EPI_RELU, gather=g)
         # Linear over (c, f) features: our rows are (f, c)-ordered, so permute the weight columns
         wl = torch.empty(D, W2 * Cc, device=x.device, dtype=torch.float32)
         ops.permute4(lin_w, wl, (D, Cc, W2, 1), (W2 * Cc, 1, Cc, 0))
+        wl = ops.to_act(wl)
         out = ops.linear_fwd(y2.view(B * H2, W2 * Cc), wl, lin_b, alpha=xscale)
         ctx.save_for_backward(x, y1, y2, wd, wl)
         ctx.pr = (c1_w, c1_b, c2_w, c2_b, lin_w, lin_b)
@@ -365,15 +384,16 @@ class Conv2dSubsamplingFn(torch.autograd.Function):
         x, y1, y2, wd, wl = ctx.saved_tensors
         c1_w, c1_b, c2_w, c2_b, lin_w, lin_b = ctx.pr
         B, T, F, Cc, D, H1, W1, H2, W2, xscale = ctx.cfg
+        adt = ops.act_dtype()
         sink = GradSink(ctx.pr)
         dev = x.device
-        do = dout.reshape(B * H2, D).contiguous()
+        dob = ops.to_act(dout.reshape(B * H2, D).contiguous())
         y2v = y2.view(B * H2, W2 * Cc)
         # Linear: weight grad in permuted column order, then un-permute-accumulate
         dwl = torch.zeros(D, W2 * Cc, device=dev, dtype=torch.float32)
-        ops.linear_bwd_w(do, y2v, dwl, alpha=xscale, db=sink.buf(5))
+        ops.linear_bwd_w(dob, y2v, dwl, alpha=xscale, db=sink.buf(5))
         ops.permute4(dwl, sink.buf(4), (D, W2, Cc, 1), (W2 * Cc, 1, W2, 0), accumulate=True)
-        dy2 = ops.linear_bwd_x(do, wl, epilogue=EPI_MUL_RELU_MASK, aux=y2v, alpha=xscale)   # [B*H2, W2*C]
+        dy2 = ops.linear_bwd_x(dob, wl, epilogue=EPI_MUL_RELU_MASK, aux=y2v, alpha=xscale, out_dtype=adt)
         dy2 = dy2.view(B * H2 * W2, Cc)
         M2 = B * H2 * W2
         ops.colsum(dy2, sink.buf(3))
@@ -386,7 +406,7 @@ class Conv2dSubsamplingFn(torch.autograd.Function):
         ops.gemm(y1, dy2, dwf, 9 * Cc, Cc, M2, 9 * Cc, Cc, Cc, transA=1, transB=1, gather=g, splitk=sk, tile=tile)
         ops.conv2_weight_grad(dwf, sink.buf(2), Cc, Cc)
         # conv2 input gradient, one implicit GEMM per stride-parity class, ReLU mask of conv1 fused
-        dy1 = torch.empty_like(y1)
+        dy1 = torch.empty(y1.shape, device=dev, dtype=adt)
         q0 = 0
         for (ph, pw), taps in _CLASSES:
             Ho, Wo = (H1 - ph + 1) // 2, (W1 - pw + 1) // 2

@@ -30,6 +30,39 @@ def get_precision():
     return [k for k, v in _PRECISIONS.items() if v == _state["precision"]][0]
 
 
+def fast():
+    """bf16 mode: GEMM operands (activations + weight shadows) live in HBM as bf16."""
+    return _state["precision"] == 1
+
+
+def act_dtype():
+    return torch.bfloat16 if fast() else torch.float32
+
+
+def wshadow(p):
+    """bf16 shadow of a parameter (fast mode) or the parameter itself (fp32 mode).
+    FlatParams keeps an arena shadow that the Adam kernel refreshes; otherwise (or after an external
+    in-place modification, detected through tensor._version) the shadow is re-cast on demand."""
+    if not fast():
+        return p
+    sh = getattr(p, "_eamd_bf16", None)
+    if sh is not None and getattr(p, "_eamd_bf16_ver", None) == p._version:
+        return sh
+    if sh is None:
+        sh = torch.empty(p.shape, device=p.device, dtype=torch.bfloat16)
+        p._eamd_bf16 = sh
+    cast_bf16(p.detach().contiguous(), sh)
+    p._eamd_bf16_ver = p._version
+    return sh
+
+
+def to_act(x):
+    """fp32 activation -> GEMM operand dtype of the current mode"""
+    if fast() and x.dtype == torch.float32:
+        return cast_bf16(x.contiguous())
+    return x
+
+
 def _numel_from(t, off):
     return t.numel() - off
 
@@ -123,25 +156,25 @@ def auto_splitk(m_out, n_out, k_red):
 
 
 # ---- nn.Linear pieces -------------------------------------------------------------------------
-def linear_fwd(x, W, b, out=None, *, act=EPI_NONE, R=None, alpha=1.0, a_act=ACT_NONE):
-    """out[M,N] = alpha * act(a_act(x)[M,K] @ W[N,K]^T + b) + R"""
+def linear_fwd(x, W, b, out=None, *, act=EPI_NONE, R=None, alpha=1.0, a_act=ACT_NONE, out_dtype=torch.float32):
+    """out[M,N] = alpha * act(a_act(x)[M,K] @ W[N,K]^T + b) + R      (x, W: both fp32 or both bf16)"""
     M, K = x.shape
     N = W.shape[0]
     assert W.shape[1] == K and x.is_contiguous() and W.is_contiguous()
     if out is None:
-        out = torch.empty(M, N, device=x.device, dtype=torch.float32)
+        out = torch.empty(M, N, device=x.device, dtype=out_dtype)
     gemm(x, W, out, M, N, K, K, K, N, bias=b, epilogue=act, R=R, ldr=N, alpha=alpha, a_act=a_act)
     return out
 
 
-def linear_bwd_x(dy, W, out=None, *, beta=0.0, epilogue=EPI_NONE, aux=None, alpha=1.0):
+def linear_bwd_x(dy, W, out=None, *, beta=0.0, epilogue=EPI_NONE, aux=None, alpha=1.0, out_dtype=torch.float32):
     """out[M,K] = alpha * epi(dy[M,N] @ W[N,K]) + beta*out"""
     M, N = dy.shape
     K = W.shape[1]
     assert W.shape[0] == N and dy.is_contiguous()
     if out is None:
         assert beta == 0.0
-        out = torch.empty(M, K, device=dy.device, dtype=torch.float32)
+        out = torch.empty(M, K, device=dy.device, dtype=out_dtype)
     gemm(dy, W, out, M, K, N, N, K, K, transB=1, beta=beta, epilogue=epilogue, aux=aux, ldaux=K, alpha=alpha)
     return out
 
@@ -151,7 +184,7 @@ def linear_bwd_w(dy, x, dW, *, alpha=1.0, b_act=ACT_NONE, db=None):
     db[N] += alpha * column sums of dy (bias gradient, fused into the same launch)"""
     M, N = dy.shape
     K = x.shape[1]
-    assert x.shape[0] == M and dW.numel() == N * K
+    assert x.shape[0] == M and dW.numel() == N * K and dW.dtype == torch.float32
     sk = auto_splitk(N, K, M)
     gemm(dy, x, dW, N, K, M, N, K, K, transA=1, transB=1, alpha=alpha, b_act=b_act, splitk=sk,
          beta=1.0 if sk == 1 else 0.0, colsum=db)
@@ -163,16 +196,17 @@ def colsum(x, out, scale=1.0, rows=None, D=None, ld=None):
     ld = D if ld is None else ld
     assert out.numel() >= D
     check(_lib.lib().eamd_colsum(ptr(x), C.c_int64(ld), ptr(out), C.c_int64(rows), D, C.c_float(scale),
-                                 stream_ptr()), "eamd_colsum")
+                                 1 if x.dtype == torch.bfloat16 else 0, stream_ptr()), "eamd_colsum")
 
 
 # ---- row kernels -------------------------------------------------------------------------------
-def layernorm_fwd(x, gamma, beta, eps):
+def layernorm_fwd(x, gamma, beta, eps, out_dtype=torch.float32):
     rows, D = x.shape
-    y = torch.empty_like(x)
+    y = torch.empty(rows, D, device=x.device, dtype=out_dtype)
     mean = torch.empty(rows, device=x.device, dtype=torch.float32)
     rstd = torch.empty(rows, device=x.device, dtype=torch.float32)
-    check(_lib.lib().eamd_layernorm_fwd(ptr(x), ptr(gamma), ptr(beta), ptr(y), ptr(mean), ptr(rstd), rows, D,
+    y32, y16 = (ptr(y), None) if out_dtype == torch.float32 else (None, ptr(y))
+    check(_lib.lib().eamd_layernorm_fwd(ptr(x), ptr(gamma), ptr(beta), y32, y16, ptr(mean), ptr(rstd), rows, D,
                                         C.c_float(eps), stream_ptr()), "eamd_layernorm_fwd")
     return y, mean, rstd
 
@@ -187,6 +221,7 @@ def layernorm_bwd(dy, x, gamma, mean, rstd, dres, dgamma, dbeta):
 
 
 def softmax_fwd(ac, bd, mask, P, nblocks, B, T1, T2, ld, scale):
+    """P may be fp32 (may alias ac) or bf16 (separate buffer)"""
     mb = mi = 0
     if mask is not None:
         assert mask.dtype == torch.uint8 and mask.is_contiguous() and mask.dim() == 3 and mask.shape[0] == B
@@ -194,15 +229,23 @@ def softmax_fwd(ac, bd, mask, P, nblocks, B, T1, T2, ld, scale):
         mb = mask.shape[1] * mask.shape[2]
         mi = 0 if mask.shape[1] == 1 else T2
     assert ac.numel() >= nblocks * T1 * ld and P.numel() >= nblocks * T1 * ld
-    check(_lib.lib().eamd_softmax_fwd(ptr(ac), ptr(bd), ptr(mask), C.c_int64(mb), C.c_int64(mi), ptr(P), nblocks,
+    p32, p16 = (ptr(P), None) if P.dtype == torch.float32 else (None, ptr(P))
+    check(_lib.lib().eamd_softmax_fwd(ptr(ac), ptr(bd), ptr(mask), C.c_int64(mb), C.c_int64(mi), p32, p16, nblocks,
                                       B, T1, T2, C.c_int64(ld), C.c_float(scale), stream_ptr()),
           "eamd_softmax_fwd")
 
 
-def softmax_bwd(P, dP, dbd, nblocks, T1, T2, ld, scale):
-    assert P.numel() >= nblocks * T1 * ld and dP.numel() >= nblocks * T1 * ld
-    check(_lib.lib().eamd_softmax_bwd(ptr(P), ptr(dP), ptr(dbd), nblocks, T1, T2, C.c_int64(ld), C.c_float(scale),
-                                      stream_ptr()), "eamd_softmax_bwd")
+def softmax_bwd(P, dP, dbd, nblocks, T1, T2, ld, scale, dS16=None):
+    """fp32: dP is overwritten with dS, dbd (fp32, pre-zeroed) receives the inverse rel-shift scatter.
+    bf16: P bf16, dP fp32 in, dS16 (bf16) out, dbd bf16 (pre-zeroed)."""
+    assert P.numel() >= nblocks * T1 * ld and dP.numel() >= nblocks * T1 * ld and dP.dtype == torch.float32
+    if P.dtype == torch.bfloat16:
+        assert dS16 is not None and dS16.dtype == torch.bfloat16 and (dbd is None or dbd.dtype == torch.bfloat16)
+        check(_lib.lib().eamd_softmax_bwd(None, ptr(P), ptr(dP), None, ptr(dS16), ptr(dbd), nblocks, T1, T2,
+                                          C.c_int64(ld), C.c_float(scale), stream_ptr()), "eamd_softmax_bwd")
+    else:
+        check(_lib.lib().eamd_softmax_bwd(ptr(P), None, ptr(dP), ptr(dbd), None, None, nblocks, T1, T2,
+                                          C.c_int64(ld), C.c_float(scale), stream_ptr()), "eamd_softmax_bwd")
 
 
 def lsm_loss(logits, target, smoothing, inv_denom, ignore_id, want_grad=True):
@@ -263,10 +306,11 @@ def glu_fwd(a, Cc):
     return y
 
 
-def glu_bwd(dy, a, Cc):
+def glu_bwd(dy, a, Cc, out_dtype=torch.float32):
     rows = a.shape[0]
-    dx = torch.empty_like(a)
-    check(_lib.lib().eamd_glu_bwd(ptr(dy), ptr(a), ptr(dx), C.c_int64(rows), Cc, stream_ptr()), "eamd_glu_bwd")
+    dx = torch.empty(a.shape, device=a.device, dtype=out_dtype)
+    d32, d16 = (ptr(dx), None) if out_dtype == torch.float32 else (None, ptr(dx))
+    check(_lib.lib().eamd_glu_bwd(ptr(dy), ptr(a), d32, d16, C.c_int64(rows), Cc, stream_ptr()), "eamd_glu_bwd")
     return dx
 
 
@@ -274,9 +318,17 @@ def add_bias2(q, u, v):
     rows, D = q.shape
     assert u.numel() == D and v.numel() == D
     qu, qv = torch.empty_like(q), torch.empty_like(q)
-    check(_lib.lib().eamd_add_bias2(ptr(q), ptr(u), ptr(v), ptr(qu), ptr(qv), C.c_int64(rows), D, stream_ptr()),
-          "eamd_add_bias2")
+    check(_lib.lib().eamd_add_bias2(ptr(q), ptr(u), ptr(v), ptr(qu), ptr(qv), C.c_int64(rows), D,
+                                    1 if q.dtype == torch.bfloat16 else 0, stream_ptr()), "eamd_add_bias2")
     return qu, qv
+
+
+def add_cast(a, b):
+    """bf16(a + b) from fp32 inputs (b optional)"""
+    out = torch.empty(a.shape, device=a.device, dtype=torch.bfloat16)
+    check(_lib.lib().eamd_add_cast_bf16(ptr(a), ptr(b), ptr(out), C.c_int64(a.numel()), stream_ptr()),
+          "eamd_add_cast_bf16")
+    return out
 
 
 def embed_pe(tok, table, pe, U, scale, pos_offset=0):
@@ -343,10 +395,10 @@ def bn_stats(x, M, Cc, eps, momentum, running_mean, running_var):
     return mean, rstd
 
 
-def bn_apply(x, mean, rstd, gamma, beta, M, Cc, act):
-    y = torch.empty_like(x)
+def bn_apply(x, mean, rstd, gamma, beta, M, Cc, act, out_dtype=torch.float32):
+    y = torch.empty(x.shape, device=x.device, dtype=out_dtype)
     check(_lib.lib().eamd_bn_apply(ptr(x), ptr(mean), ptr(rstd), ptr(gamma), ptr(beta), ptr(y), C.c_int64(M), Cc,
-                                   act, stream_ptr()), "eamd_bn_apply")
+                                   act, 1 if out_dtype == torch.bfloat16 else 0, stream_ptr()), "eamd_bn_apply")
     return y
 
 
@@ -360,25 +412,26 @@ def bn_bwd(dy, x, mean, rstd, gamma, beta, dgamma, dbeta, M, Cc, act, training):
     return dx
 
 
-def conv1_fwd(x, w, bias, B, T, F, Cc):
+def conv1_fwd(x, w, bias, B, T, F, Cc, out_dtype=torch.float32):
     H, W = (T - 3) // 2 + 1, (F - 3) // 2 + 1
     assert x.numel() == B * T * F and w.numel() == Cc * 9
-    y = torch.empty(B, H, W, Cc, device=x.device, dtype=torch.float32)
-    check(_lib.lib().eamd_conv1_fwd(ptr(x), ptr(w), ptr(bias), ptr(y), B, T, F, Cc, stream_ptr()),
-          "eamd_conv1_fwd")
+    y = torch.empty(B, H, W, Cc, device=x.device, dtype=out_dtype)
+    check(_lib.lib().eamd_conv1_fwd(ptr(x), ptr(w), ptr(bias), ptr(y), B, T, F, Cc,
+                                    1 if out_dtype == torch.bfloat16 else 0, stream_ptr()), "eamd_conv1_fwd")
     return y
 
 
 def conv1_bwd_w(dy, x, dw, db, B, T, F, Cc):
-    check(_lib.lib().eamd_conv1_bwd_w(ptr(dy), ptr(x), ptr(dw), ptr(db), B, T, F, Cc, stream_ptr()),
-          "eamd_conv1_bwd_w")
+    check(_lib.lib().eamd_conv1_bwd_w(ptr(dy), ptr(x), ptr(dw), ptr(db), B, T, F, Cc,
+                                      1 if dy.dtype == torch.bfloat16 else 0, stream_ptr()), "eamd_conv1_bwd_w")
 
 
-def conv2_weight_prep(w):
+def conv2_weight_prep(w, out_dtype=torch.float32):
     Co, Ci = w.shape[0], w.shape[1]
-    wf = torch.empty(9, Ci, Co, device=w.device, dtype=torch.float32)
-    wd = torch.empty(9, Co, Ci, device=w.device, dtype=torch.float32)
-    check(_lib.lib().eamd_conv2_weight_prep(ptr(w), ptr(wf), ptr(wd), Co, Ci, stream_ptr()),
+    wf = torch.empty(9, Ci, Co, device=w.device, dtype=out_dtype)
+    wd = torch.empty(9, Co, Ci, device=w.device, dtype=out_dtype)
+    check(_lib.lib().eamd_conv2_weight_prep(ptr(w), ptr(wf), ptr(wd), Co, Ci,
+                                            1 if out_dtype == torch.bfloat16 else 0, stream_ptr()),
           "eamd_conv2_weight_prep")
     return wf, wd
 
@@ -447,10 +500,10 @@ def sched_step(state, gnorm, mode, base_lr, factor, dmodel, warmup, beta1, beta2
                                      C.c_float(max_norm), stream_ptr()), "eamd_sched_step")
 
 
-def adam_step(p, g, m, v, state, beta1, beta2, eps, weight_decay):
+def adam_step(p, g, m, v, state, beta1, beta2, eps, weight_decay, p16=None):
     n = p.numel()
-    assert g.numel() == n and m.numel() == n and v.numel() == n
-    check(_lib.lib().eamd_adam_step(ptr(p), ptr(g), ptr(m), ptr(v), C.c_int64(n), ptr(state), C.c_float(beta1),
+    assert g.numel() == n and m.numel() == n and v.numel() == n and (p16 is None or p16.numel() == n)
+    check(_lib.lib().eamd_adam_step(ptr(p), ptr(g), ptr(m), ptr(v), ptr(p16), C.c_int64(n), ptr(state), C.c_float(beta1),
                                     C.c_float(beta2), C.c_float(eps), C.c_float(weight_decay), stream_ptr()),
           "eamd_adam_step")
 

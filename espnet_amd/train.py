@@ -30,19 +30,31 @@ class FlatParams:
         self.params = params
         offs, n = [], 0
         for p in params:
-            n = (n + 3) // 4 * 4          # keep every tensor 16-byte aligned for float4 kernels
+            n = (n + 7) // 8 * 8          # 32-byte (fp32) / 16-byte (bf16 shadow) aligned tensors
             offs.append(n)
             n += p.numel()
-        self.numel = (n + 3) // 4 * 4
+        self.numel = (n + 7) // 8 * 8
         self.offsets = offs
         self.data = torch.zeros(self.numel, device=dev, dtype=torch.float32)
         self.grad = torch.zeros(self.numel, device=dev, dtype=torch.float32)
+        # bf16 shadow of every weight for the bf16-operand GEMMs; kept current by the Adam kernel
+        self.shadow = torch.zeros(self.numel, device=dev, dtype=torch.bfloat16) if dev.type == "cuda" else None
         for p, o in zip(params, offs):
             view = self.data[o:o + p.numel()].view(p.shape)
             view.copy_(p.data)
             p.data = view
             p._eamd_grad = self.grad[o:o + p.numel()].view(p.shape)
         self.model = model
+        self.refresh_shadow()
+
+    def refresh_shadow(self):
+        """re-cast the whole arena (after construction / external weight changes)"""
+        if self.shadow is None:
+            return
+        ops.cast_bf16(self.data, self.shadow)
+        for p, o in zip(self.params, self.offsets):
+            p._eamd_bf16 = self.shadow[o:o + p.numel()].view(p.shape)
+            p._eamd_bf16_ver = p._version
 
     def zero_grad(self):
         self.grad.zero_()   # one memset node
@@ -76,7 +88,7 @@ class NoamAdam:
         ops.sched_step(self.state, self.gnorm, self.mode, self.base_lr, self.factor, self.model_size, self.warmup,
                        self.betas[0], self.betas[1], self.max_grad_norm)
         ops.adam_step(self.flat.data, self.flat.grad, self.m, self.v, self.state, self.betas[0], self.betas[1],
-                      self.eps, self.weight_decay)
+                      self.eps, self.weight_decay, p16=self.flat.shadow)
 
     def stats(self):
         s = self.state.tolist()

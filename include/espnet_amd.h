@@ -92,7 +92,8 @@ int eamd_gemm(const eamd_gemm_t* p, void* stream);
  * Row kernels (HBM-bound).
  * ------------------------------------------------------------------------------------------ */
 /* LayerNorm over the last dim.  reference: transformer/layer_norm.py:12-38 (eps = 1e-12). */
-int eamd_layernorm_fwd(const float* x, const float* gamma, const float* beta, float* y, float* mean,
+/* y (fp32) and/or y_bf16 (bf16 copy for the bf16-operand GEMM) are written; either may be NULL. */
+int eamd_layernorm_fwd(const float* x, const float* gamma, const float* beta, float* y, void* y_bf16, float* mean,
                        float* rstd, int rows, int D, float eps, void* stream);
 /* dgamma/dbeta are ACCUMULATED (+=) with f32 atomics; dx = LN-backward(dy) + dres (dres optional,
  * may alias dx: the residual branch's gradient is folded in). */
@@ -106,12 +107,13 @@ int eamd_layernorm_bwd(const float* dy, const float* x, const float* gamma, cons
  * zeroed); block z belongs to batch z % B.  mask (uint8, 0 = masked) element (b,i,j) at
  * mask[b*mask_bstride + i*mask_qstride + j]; NULL = no mask. */
 int eamd_softmax_fwd(const float* ac, const float* bd, const unsigned char* mask, int64_t mask_bstride,
-                     int64_t mask_qstride, float* P, int nblocks, int B, int T1, int T2, int64_t ld,
+                     int64_t mask_qstride, float* P, void* P_bf16, int nblocks, int B, int T1, int T2, int64_t ld,
                      float scale, void* stream);
 /* dP is overwritten by d(ac); if dbd != NULL (pre-zeroed) the same values are scattered through the
  * inverse rel_shift. */
-int eamd_softmax_bwd(const float* P, float* dP, float* dbd, int nblocks, int T1, int T2, int64_t ld,
-                     float scale, void* stream);
+/* bf16 variant: P_bf16 in; dS_bf16 (instead of overwriting dP) and dbd_bf16 out (pre-zeroed). */
+int eamd_softmax_bwd(const float* P, const void* P_bf16, float* dP, float* dbd, void* dS_bf16, void* dbd_bf16,
+                     int nblocks, int T1, int T2, int64_t ld, float scale, void* stream);
 
 /* Label-smoothing KL loss rows + argmax-correct flags + gradient (softmax - true_dist)*inv_denom.
  * reference: transformer/label_smoothing_loss.py:44-63, nets_utils.py:299-319 (th_accuracy). */
@@ -136,12 +138,16 @@ int eamd_act_fwd(const float* x, float* y, int64_t n, int act, void* stream);
 int eamd_act_bwd(const float* dy, const float* x, float* dx, int64_t n, int act, void* stream);
 /* reference: conformer/convolution.py:72 (GLU). x is [rows, 2C], y/dy [rows, C]. */
 int eamd_glu_fwd(const float* x, float* y, int64_t rows, int C, void* stream);
-int eamd_glu_bwd(const float* dy, const float* x, float* dx, int64_t rows, int C, void* stream);
+/* dx (fp32) or dx_bf16 (bf16, when non-NULL) receives the [rows, 2C] gradient */
+int eamd_glu_bwd(const float* dy, const float* x, float* dx, void* dx_bf16, int64_t rows, int C, void* stream);
 /* reference: transformer/attention.py:186-190 (q + pos_bias_u, q + pos_bias_v). */
-int eamd_add_bias2(const float* q, const float* u, const float* v, float* qu, float* qv, int64_t rows, int D,
-                   void* stream);
+/* bf16 = 1: q, qu, qv are bf16 */
+int eamd_add_bias2(const void* q, const float* u, const float* v, void* qu, void* qv, int64_t rows, int D,
+                   int bf16, void* stream);
+/* out_bf16 = a + b (b optional), fp32 inputs */
+int eamd_add_cast_bf16(const float* a, const float* b, void* out_bf16, int64_t n, void* stream);
 /* out[D] += scale * column sums of x[rows, D] (bias gradients). */
-int eamd_colsum(const float* x, int64_t ld, float* out, int64_t rows, int D, float scale, void* stream);
+int eamd_colsum(const void* x, int64_t ld, float* out, int64_t rows, int D, float scale, int x_bf16, void* stream);
 /* reference: decoder.py:83-86,251 (Embedding + PositionalEncoding), embedding.py:80-91. */
 int eamd_embed_pe(const int64_t* tok, const float* table, const float* pe, float* out, int64_t rows, int U,
                   int D, float scale, int pos_offset, void* stream);
@@ -169,16 +175,16 @@ int eamd_bn_nslab(int64_t M, int C);
 int eamd_bn_stats(const float* x, float* workspace, float* mean, float* rstd, float* running_mean,
                   float* running_var, int64_t M, int C, float eps, float momentum, void* stream);
 int eamd_bn_apply(const float* x, const float* mean, const float* rstd, const float* gamma, const float* beta,
-                  float* y, int64_t M, int C, int act, void* stream);
+                  void* y, int64_t M, int C, int act, int y_bf16, void* stream);
 /* workspace (2*nslab+2)*C floats; dgamma/dbeta ACCUMULATED. */
 int eamd_bn_bwd(const float* dy, const float* x, const float* mean, const float* rstd, const float* gamma,
                 const float* beta, float* workspace, float* dx, float* dgamma, float* dbeta, int64_t M, int C,
                 int act, int training, void* stream);
 /* Conv2d(1, C, 3, 2) + ReLU, x [B,T,F] -> y [B,H,W,C] (NHWC). */
-int eamd_conv1_fwd(const float* x, const float* w, const float* bias, float* y, int B, int T, int F, int C,
-                   void* stream);
-int eamd_conv1_bwd_w(const float* dy, const float* x, float* dw, float* db, int B, int T, int F, int C,
-                     void* stream);
+int eamd_conv1_fwd(const float* x, const float* w, const float* bias, void* y, int B, int T, int F, int C,
+                   int y_bf16, void* stream);
+int eamd_conv1_bwd_w(const void* dy, const float* x, float* dw, float* db, int B, int T, int F, int C,
+                     int dy_bf16, void* stream);
 
 /* ------------------------------------------------------------------------------------------
  * CTC loss (warp-ctc operator slot).  reference: ctc.py:30-47,53-66 (ctc_type warpctc|builtin),
@@ -200,8 +206,9 @@ int eamd_ctc_loss(const float* acts, int64_t stride_t, int64_t stride_b, const i
 int eamd_grad_norm(const float* g, int64_t n, float* workspace, float* gnorm_out, void* stream);
 int eamd_sched_step(float* state, const float* gnorm, int mode, float base_lr, float factor, float dmodel,
                     float warmup, float beta1, float beta2, float max_norm, void* stream);
-int eamd_adam_step(float* p, const float* g, float* m, float* v, int64_t n, const float* state, float beta1,
-                   float beta2, float eps, float weight_decay, void* stream);
+/* p_bf16 (optional): bf16 shadow of the updated parameters, written by the same pass */
+int eamd_adam_step(float* p, const float* g, float* m, float* v, void* p_bf16, int64_t n, const float* state,
+                   float beta1, float beta2, float eps, float weight_decay, void* stream);
 
 /* ------------------------------------------------------------------------------------------
  * Integer / layout helpers (bit-exact).
@@ -215,7 +222,7 @@ int eamd_ctc_collapse(const int32_t* ids, const int32_t* hlens, int32_t* out, in
 /* Conv2d(C,C,3,2) weight [Co][Ci][3][3] -> wf [9][Ci][Co] (tap = kh*3+kw) and wd [9][Co][Ci] with
  * taps in stride-parity class order (0,0)(0,2)(2,0)(2,2)|(0,1)(2,1)|(1,0)(1,2)|(1,1).
  * reference: transformer/subsampling.py:31 (second Conv2d). */
-int eamd_conv2_weight_prep(const float* w, float* wf, float* wd, int Co, int Ci, void* stream);
+int eamd_conv2_weight_prep(const float* w, void* wf, void* wd, int Co, int Ci, int out_bf16, void* stream);
 /* dw[Co][Ci][3][3] += dwf[9][Ci][Co] */
 int eamd_conv2_weight_grad(const float* dwf, float* dw, int Co, int Ci, void* stream);
 

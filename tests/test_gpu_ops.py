@@ -222,6 +222,15 @@ def test_softmax_relshift_golden(ops, oracle):
     ops.softmax_bwd(P, dS, dbd, h * b, t1, t2, ld, 0.25)
     report("masked_softmax_bwd_ac", dS.view(h, b, t1, ld)[..., :t2], acd.grad, 1e-5)
     report("masked_softmax_bwd_bd", dbd.view(h, b, t1, ld)[..., :t2], bdd.grad, 1e-5)
+    # bf16-storage variant of the same kernels (P, dS, dbd in bf16): bf16 rounding of outputs only
+    P16 = torch.empty(h * b * t1 * ld, device=DEV, dtype=torch.bfloat16)
+    ops.softmax_fwd(ac.reshape(-1).to(DEV), bdm.reshape(-1).to(DEV), mask.to(DEV), P16, h * b, b, t1, t2, ld, 0.25)
+    report("masked_softmax_fwd_bf16", P16.float().view(h, b, t1, ld)[..., :t2], pr, 4e-3)
+    dS16 = torch.empty_like(P16)
+    dbd16 = torch.zeros_like(P16)
+    ops.softmax_bwd(P16, dP.reshape(-1).clone().to(DEV), dbd16, h * b, t1, t2, ld, 0.25, dS16=dS16)
+    report("masked_softmax_bwd_ac_bf16", dS16.float().view(h, b, t1, ld)[..., :t2], acd.grad, 1e-2)
+    report("masked_softmax_bwd_bd_bf16", dbd16.float().view(h, b, t1, ld)[..., :t2], bdd.grad, 1e-2)
 
 
 def test_lsm_loss_golden(ops):
