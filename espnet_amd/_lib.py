@@ -57,7 +57,7 @@ SYMBOLS = [
     "eamd_dropout", "eamd_dwconv_fwd", "eamd_dwconv_bwd_x", "eamd_dwconv_bwd_w", "eamd_bn_nslab",
     "eamd_bn_stats", "eamd_bn_apply", "eamd_bn_bwd", "eamd_conv1_fwd", "eamd_conv1_bwd_w",
     "eamd_conv2_weight_prep", "eamd_conv2_weight_grad", "eamd_add_sos_eos", "eamd_ctc_collapse",
-    "eamd_ctc_workspace_bytes", "eamd_ctc_loss", "eamd_grad_norm", "eamd_sched_step", "eamd_adam_step",
+    "eamd_ctc_workspace_bytes", "eamd_ctc_loss", "eamd_ctc_prefix_score", "eamd_grad_norm", "eamd_sched_step", "eamd_adam_step",
 ]
 
 

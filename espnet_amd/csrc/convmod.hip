@@ -53,30 +53,41 @@ __global__ __launch_bounds__(256) void dwconv_kernel(const float* __restrict__ x
     if (t0 + i < T) yb[(long)(t0 + i) * C] = acc[i];
 }
 
-// dw[c,k] += sum_{b,t} dy[b,t,c] * x[b,t+k-pad,c];  db[c] += sum dy.  One block = (row slab, 256 channels).
+// dw[c,k] += sum_{b,t} dy[b,t,c] * x[b,t+k-pad,c];  db[c] += sum dy.
+// One thread = one channel; a block walks `chunks_per_block` chunks of TT frames.  Per chunk the
+// TT + K - 1 input window and the TT output gradients are loaded up front (independent loads, all
+// in flight together) and combined with fully unrolled FMAs into K register accumulators.
 __global__ __launch_bounds__(256) void dwconv_bwd_w_kernel(const float* __restrict__ dy, const float* __restrict__ x,
                                                            float* __restrict__ dw, float* __restrict__ db, int B,
-                                                           int T, int C, int K, int pad, int rows_per_block) {
+                                                           int T, int C, int K, int pad, int chunks_per_block) {
   const int c = blockIdx.x * blockDim.x + threadIdx.x;
   if (c >= C) return;
-  const long rows = (long)B * T;
-  const long r0 = (long)blockIdx.y * rows_per_block;
-  const long r1 = min(rows, r0 + (long)rows_per_block);
+  const int nchunk = (T + TT - 1) / TT;
+  const long total = (long)B * nchunk;
+  const long q0 = (long)blockIdx.y * chunks_per_block;
+  const long q1 = min(total, q0 + (long)chunks_per_block);
   float acc[KMAX];
 #pragma unroll
   for (int k = 0; k < KMAX; ++k) acc[k] = 0.f;
   float accb = 0.f;
-  for (long r = r0; r < r1; ++r) {
-    const int t = r % T;
-    const long b = r / T;
-    const float g = dy[r * C + c];
-    accb += g;
-    const float* xb = x + b * T * C + c;
+  for (long q = q0; q < q1; ++q) {
+    const int b = q / nchunk;
+    const int t0 = (int)(q % nchunk) * TT;
+    const float* xb = x + (long)b * T * C + c;
+    const float* gb = dy + (long)b * T * C + c;
+    float g[TT];
 #pragma unroll
-    for (int k = 0; k < KMAX; ++k) {
-      if (k < K) {
-        int ts = t + k - pad;
-        if (ts >= 0 && ts < T) acc[k] += g * xb[(long)ts * C];
+    for (int i = 0; i < TT; ++i) { g[i] = (t0 + i < T) ? gb[(long)(t0 + i) * C] : 0.f; accb += g[i]; }
+#pragma unroll
+    for (int j = 0; j < TT + KMAX - 1; ++j) {
+      if (j < TT + K - 1) {
+        const int ts = t0 - pad + j;
+        const float xv = (ts >= 0 && ts < T) ? xb[(long)ts * C] : 0.f;
+#pragma unroll
+        for (int i = 0; i < TT; ++i) {
+          const int k = j - i;
+          if (k >= 0 && k < KMAX) acc[k] += g[i] * xv;
+        }
       }
     }
   }
@@ -286,13 +297,13 @@ int eamd_dwconv_bwd_w(const float* dy, const float* x, float* dw, float* db, int
                       void* stream) {
   if (!dy || !x || !dw || B <= 0 || T <= 0 || C <= 0 || K <= 0 || (K & 1) == 0) return EAMD_EINVAL;
   if (K > KMAX) return EAMD_EUNSUPPORTED;
-  long rows = (long)B * T;
+  long total = (long)B * ((T + TT - 1) / TT);
   int gx = (C + 255) / 256;
-  long want = 192 / gx; if (want < 1) want = 1;
-  long rpb = (rows + want - 1) / want; if (rpb < 8) rpb = 8;
-  int gy = (int)((rows + rpb - 1) / rpb);
+  long want = 512 / gx; if (want < 1) want = 1;
+  long cpb = (total + want - 1) / want; if (cpb < 1) cpb = 1;
+  int gy = (int)((total + cpb - 1) / cpb);
   hipLaunchKernelGGL(dwconv_bwd_w_kernel, dim3(gx, gy), dim3(256), 0, (hipStream_t)stream, dy, x, dw, db, B, T, C,
-                     K, (K - 1) / 2, (int)rpb);
+                     K, (K - 1) / 2, (int)cpb);
   EAMD_LAUNCH_CHECK();
   return EAMD_OK;
 }

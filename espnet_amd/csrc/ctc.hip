@@ -231,3 +231,66 @@ int eamd_ctc_loss(const float* acts, int64_t stride_t, int64_t stride_b, const i
 }
 
 }  // extern "C"
+
+// ---------------------------------------------------------------------------------------------
+// CTC prefix scoring for joint CTC/attention beam search (Watanabe et al. 2017, Algorithm 2).
+// reference: espnet/nets/ctc_prefix_score.py:224-310 (CTCPrefixScore.__call__), :157-162 (the per-frame
+// loop of CTCPrefixScoreTH).  One thread = one (hypothesis, candidate token): sequential scan over the
+// T frames in log space; candidates of one hypothesis share the broadcast r_prev reads.
+//   logp   [T, V]                  frame log-posteriors (CTC.log_softmax)
+//   r_prev [nhyp, T, 2]            (r^n, r^b) of each hypothesis prefix
+//   cand   [nhyp, ncand] int32     tokens to score;  last[nhyp], olen[nhyp] = last token / prefix length-1
+//   psi    [nhyp, ncand]           log prefix probabilities;  r_new [nhyp, ncand, T, 2]
+// ---------------------------------------------------------------------------------------------
+namespace {
+constexpr float kLogZero = -10000000000.0f;
+__device__ __forceinline__ float lae(float a, float b) {   // numpy.logaddexp
+  float m = fmaxf(a, b);
+  return m + log1pf(expf(-fabsf(a - b)));
+}
+__global__ void ctc_prefix_kernel(const float* __restrict__ logp, const float* __restrict__ r_prev,
+                                  const int* __restrict__ cand, const int* __restrict__ last,
+                                  const int* __restrict__ olen, float* __restrict__ psi, float* __restrict__ r_new,
+                                  int T, int V, int ncand, int blank, int eos) {
+  const int j = blockIdx.x * blockDim.x + threadIdx.x;
+  const int h = blockIdx.y;
+  if (j >= ncand) return;
+  const int c = cand[(long)h * ncand + j];
+  const float* rp = r_prev + (long)h * T * 2;
+  float* rn = r_new + ((long)h * ncand + j) * T * 2;
+  const int ol = olen[h];
+  const bool same = ol > 0 && last[h] == c;
+  const int start = max(ol, 1);
+  // rows before start-1 are never read by later steps; keep them at log-zero like the reference's r
+  for (int t = 0; t < start - 1; ++t) { rn[2 * t] = kLogZero; rn[2 * t + 1] = kLogZero; }
+  float rn_n, rn_b;
+  if (ol == 0) { rn_n = logp[c]; rn_b = kLogZero; }
+  else { rn_n = kLogZero; rn_b = kLogZero; }
+  rn[2 * (start - 1)] = rn_n; rn[2 * (start - 1) + 1] = rn_b;
+  float lpsi = rn_n;
+  for (int t = start; t < T; ++t) {
+    const float pn = rp[2 * (t - 1)], pb = rp[2 * (t - 1) + 1];
+    const float phi = same ? pb : lae(pn, pb);
+    const float x = logp[(long)t * V + c];
+    const float nn = lae(rn_n, phi) + x;
+    const float nb = lae(rn_n, rn_b) + logp[(long)t * V + blank];
+    lpsi = lae(lpsi, phi + x);
+    rn_n = nn; rn_b = nb;
+    rn[2 * t] = nn; rn[2 * t + 1] = nb;
+  }
+  if (c == eos) lpsi = lae(rp[2 * (T - 1)], rp[2 * (T - 1) + 1]);
+  if (c == blank) lpsi = kLogZero;
+  psi[(long)h * ncand + j] = lpsi;
+}
+}  // namespace
+
+extern "C" int eamd_ctc_prefix_score(const float* logp, const float* r_prev, const int32_t* cand, const int32_t* last,
+                                     const int32_t* olen, float* psi, float* r_new, int nhyp, int ncand, int T, int V,
+                                     int blank, int eos, void* stream) {
+  if (!logp || !r_prev || !cand || !last || !olen || !psi || !r_new || nhyp <= 0 || ncand <= 0 || T <= 0 || V <= 0)
+    return EAMD_EINVAL;
+  hipLaunchKernelGGL(ctc_prefix_kernel, dim3((ncand + 63) / 64, nhyp), dim3(64), 0, (hipStream_t)stream, logp, r_prev,
+                     cand, last, olen, psi, r_new, T, V, ncand, blank, eos);
+  EAMD_LAUNCH_CHECK();
+  return EAMD_OK;
+}

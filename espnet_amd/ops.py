@@ -224,9 +224,9 @@ def softmax_fwd(ac, bd, mask, P, nblocks, B, T1, T2, ld, scale):
     """P may be fp32 (may alias ac) or bf16 (separate buffer)"""
     mb = mi = 0
     if mask is not None:
-        assert mask.dtype == torch.uint8 and mask.is_contiguous() and mask.dim() == 3 and mask.shape[0] == B
+        assert mask.dtype == torch.uint8 and mask.is_contiguous() and mask.dim() == 3 and mask.shape[0] in (1, B)
         assert mask.shape[2] == T2 and mask.shape[1] in (1, T1)
-        mb = mask.shape[1] * mask.shape[2]
+        mb = 0 if mask.shape[0] == 1 else mask.shape[1] * mask.shape[2]   # batch-broadcast masks
         mi = 0 if mask.shape[1] == 1 else T2
     assert ac.numel() >= nblocks * T1 * ld and P.numel() >= nblocks * T1 * ld
     p32, p16 = (ptr(P), None) if P.dtype == torch.float32 else (None, ptr(P))
@@ -486,6 +486,21 @@ def ctc_loss(acts_btv, ys_pad, ilens, blank=0, ignore_id=-1, grad_scale=1.0, wan
                                    ptr(grad), C.c_int64(V), C.c_int64(T * V), ptr(ws), B, T, V, L, blank, ignore_id,
                                    C.c_float(grad_scale), stream_ptr()), "eamd_ctc_loss")
     return nll, grad
+
+
+def ctc_prefix_score(logp, r_prev, cand, last, olen, blank, eos):
+    """logp [T,V] fp32; r_prev [nhyp,T,2]; cand [nhyp,ncand] int32; last, olen [nhyp] int32
+    -> psi [nhyp,ncand], r_new [nhyp,ncand,T,2]"""
+    T, V = logp.shape
+    nhyp, ncand = cand.shape
+    assert r_prev.shape == (nhyp, T, 2) and cand.dtype == torch.int32 and logp.is_contiguous()
+    assert int(cand.max()) < V and int(cand.min()) >= 0
+    psi = torch.empty(nhyp, ncand, device=logp.device, dtype=torch.float32)
+    r_new = torch.empty(nhyp, ncand, T, 2, device=logp.device, dtype=torch.float32)
+    check(_lib.lib().eamd_ctc_prefix_score(ptr(logp), ptr(r_prev.contiguous()), ptr(cand.contiguous()), ptr(last),
+                                           ptr(olen), ptr(psi), ptr(r_new), nhyp, ncand, T, V, blank, eos,
+                                           stream_ptr()), "eamd_ctc_prefix_score")
+    return psi, r_new
 
 
 # ---- optimizer -------------------------------------------------------------------------------------

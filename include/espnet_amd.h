@@ -198,6 +198,13 @@ int eamd_ctc_loss(const float* acts, int64_t stride_t, int64_t stride_b, const i
                   void* workspace, int B, int T, int V, int Lmax, int blank, int ignore_id, float grad_scale,
                   void* stream);
 
+/* CTC prefix scores of (hypothesis, candidate) pairs for joint CTC/attention beam search.
+ * reference: espnet/nets/ctc_prefix_score.py:224-310, scorers/ctc.py:11-127.
+ * logp [T,V]; r_prev [nhyp,T,2]; cand [nhyp,ncand]; last/olen [nhyp]; psi [nhyp,ncand]; r_new [nhyp,ncand,T,2]. */
+int eamd_ctc_prefix_score(const float* logp, const float* r_prev, const int32_t* cand, const int32_t* last,
+                          const int32_t* olen, float* psi, float* r_new, int nhyp, int ncand, int T, int V,
+                          int blank, int eos, void* stream);
+
 /* ------------------------------------------------------------------------------------------
  * Optimizer on flat fp32 arenas.  reference: transformer/optimizer.py:12-75 (NoamOpt),
  * espnet2/schedulers/warmup_lr.py:10-53, trainer.py:430-467 (clip + non-finite skip).

@@ -326,8 +326,24 @@ def main():
             greedy = [v for v in (k[0] for k in groupby(lz[0].tolist())) if v != 0]
             model(xs, ilens, ys)   # eval-mode loss (BatchNorm running stats)
             eval_loss = float(model.loss)
+            # a19: joint CTC/attention beam search n-best (reference BeamSearch, per-hypothesis scoring)
+            from espnet.nets.beam_search import BeamSearch
+            from espnet.nets.scorers.length_bonus import LengthBonus
+            enc = model.encode(xs[1, :77].numpy())
+            beam = {}
+            for cw in (0.0, 0.3, 1.0):
+                scorers = model.scorers()
+                scorers["length_bonus"] = LengthBonus(50)
+                bs = BeamSearch(beam_size=4, vocab_size=50, weights=dict(decoder=1.0 - cw, ctc=cw, length_bonus=0.2),
+                                scorers=scorers, sos=model.sos, eos=model.eos, token_list=None,
+                                pre_beam_score_key=None if cw == 1.0 else "full")
+                nb = bs(x=enc, maxlenratio=0.0, minlenratio=0.0)[:3]
+                tag = "beam_w%02d" % int(cw * 10)
+                beam[tag + "_scores"] = np.asarray([float(h.score) for h in nb], dtype=np.float64)
+                beam[tag + "_lens"] = np.asarray([len(h.yseq) for h in nb], dtype=np.int64)
+                beam[tag + "_yseq"] = np.asarray(sum([[int(t) for t in h.yseq] for h in nb], []), dtype=np.int64)
         save(out(name), xs=xs, ilens=ilens, ys=ys, hs_pad=rep["hs"], pred_pad=rep["pred"],
-             loss=rep["loss"], loss_ctc=rep["loss_ctc"], acc=rep["acc"], eval_loss=eval_loss, greedy=np.asarray(greedy, dtype=np.int64),
+             loss=rep["loss"], loss_ctc=rep["loss_ctc"], acc=rep["acc"], eval_loss=eval_loss, **beam, greedy=np.asarray(greedy, dtype=np.int64),
              **sd0, **grads_np(model))
         return model
 

@@ -248,3 +248,34 @@ def test_midsize_vs_oracle(oracle):
     lg = oracle.linear(sde, "ctc.ctc_lo.", hs)
     for b in range(4):
         assert ids[b, : int(n[b])].tolist() == oracle.greedy_ctc(lg[b, : hl[b]])
+
+
+@pytest.mark.parametrize("name,kind,extra", CASES)
+def test_beam_search_golden(name, kind, extra):
+    """Joint CTC/attention beam search (decoder batch_score + CTC prefix-score kernel) against the
+    reference BeamSearch n-best recorded in the fixtures: token ids bit-exact, scores to 1e-4."""
+    p, sd, _ = split_golden(load_golden(name))
+    model = load_sd(_e2e(kind, extra), sd)
+    # the recorded search ran after one training-mode forward (BatchNorm running stats updated once)
+    model.train()
+    model(p["xs"].to(DEV), p["ilens"], p["ys"].to(DEV))
+    model.eval()
+    x = p["xs"][1, :77].numpy()
+    for cw in (0.0, 0.3, 1.0):
+        tag = "beam_w%02d" % int(cw * 10)
+        ra = argparse.Namespace(ctc_weight=cw, beam_size=4, penalty=0.2, maxlenratio=0.0, minlenratio=0.0, nbest=3)
+        if cw == 1.0:
+            from espnet_amd.nets.beam_search import recognize_beam
+            got = recognize_beam(model, model.encode(x), ra)
+        else:
+            got = model.recognize(x, ra)
+        lens = p[tag + "_lens"].tolist()
+        flat = p[tag + "_yseq"].tolist()
+        want, o = [], 0
+        for n in lens:
+            want.append(flat[o:o + n])
+            o += n
+        print(f"[parity] {name} beam ctc_weight={cw}: hip {[round(g['score'], 4) for g in got]} ref {p[tag + '_scores'].tolist()}")
+        assert [g["yseq"] for g in got] == want
+        for g, s in zip(got, p[tag + "_scores"].tolist()):
+            assert abs(g["score"] - s) <= 1e-4 * max(1.0, abs(s))
