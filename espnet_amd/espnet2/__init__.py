@@ -1,0 +1,2 @@
+"""espnet2 model surface on the HIP kernels (reference: espnet2/asr/*)."""
+from .asr import CTC, ConformerEncoder, ESPnetASRModel, TransformerDecoder, TransformerEncoder, register_choices  # noqa: F401

@@ -347,6 +347,36 @@ def main():
              **sd0, **grads_np(model))
         return model
 
+    # ---- a2 espnet2 surface: ESPnetASRModel(ConformerEncoder, TransformerDecoder, CTC) ------------
+    from espnet2.asr.ctc import CTC as CTC2
+    from espnet2.asr.decoder.transformer_decoder import TransformerDecoder
+    from espnet2.asr.encoder.conformer_encoder import ConformerEncoder
+    from espnet2.asr.espnet_model import ESPnetASRModel
+    torch.manual_seed(23)
+    enc = ConformerEncoder(20, output_size=64, attention_heads=4, linear_units=96, num_blocks=2, dropout_rate=0.0,
+                           positional_dropout_rate=0.0, attention_dropout_rate=0.0, macaron_style=True,
+                           cnn_module_kernel=7)
+    dec = TransformerDecoder(30, 64, attention_heads=4, linear_units=96, num_blocks=1, dropout_rate=0.0,
+                             positional_dropout_rate=0.0, self_attention_dropout_rate=0.0,
+                             src_attention_dropout_rate=0.0)
+    m2 = ESPnetASRModel(vocab_size=30, token_list=["<blank>"] + [str(i) for i in range(1, 28)] + ["<space>", "<sos/eos>"], frontend=None, specaug=None,
+                        normalize=None, encoder=enc, decoder=dec, ctc=CTC2(30, 64, ctc_type="builtin"),
+                        rnnt_decoder=None, ctc_weight=0.3, lsm_weight=0.1, length_normalized_loss=False)
+    m2.train()
+    sd0 = sd_np(m2, "sd/")
+    g = torch.Generator().manual_seed(2)
+    speech = torch.randn(3, 61, 20, generator=g)
+    slen = torch.tensor([61, 50, 33])
+    text = torch.randint(1, 29, (3, 7), generator=g)
+    tlen = torch.tensor([7, 5, 3])
+    for i, n in enumerate(tlen.tolist()):
+        text[i, n:] = -1
+    loss, stats, weight = m2(speech, slen, text, tlen)
+    loss.backward()
+    save(out("espnet2_model.npz"), speech=speech, speech_lengths=slen, text=text, text_lengths=tlen,
+         loss=loss.detach(), loss_att=stats["loss_att"], loss_ctc=stats["loss_ctc"], acc=float(stats["acc"]),
+         weight=weight, **sd0, **grads_np(m2))
+
     e2e_case("e2e_conformer.npz", ConfE2E, dict(transformer_encoder_pos_enc_layer_type="rel_pos",
                                                 transformer_encoder_selfattn_layer_type="rel_selfattn",
                                                 transformer_encoder_activation_type="swish", macaron_style=True,

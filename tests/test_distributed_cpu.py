@@ -1,0 +1,78 @@
+"""Data-parallel control flow rehearsed on CPU with gloo (world_size 2): flat arenas, bucket
+construction, ready-notification order, overlapped all-reduce, batch sharding, env rendezvous.
+reference: espnet2/train/trainer.py:150-165,371-399 ; espnet2/tasks/abs_task.py:1445 ;
+test/espnet2/train/test_distributed_utils.py:183-310 (gloo, 2 ranks)."""
+import os
+import socket
+
+import pytest
+import torch
+import torch.multiprocessing as mp
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def _worker(rank, world, port, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
+                      LOCAL_RANK=str(rank))
+    from espnet_amd import train
+    r, lr, w = train.init_distributed()
+    assert (r, w) == (rank, world)
+    torch.manual_seed(0)
+    model = torch.nn.Sequential(torch.nn.Linear(7, 300), torch.nn.Linear(300, 300), torch.nn.Linear(300, 5))
+    flat = train.FlatParams(model)
+    # arena views alias the parameters
+    assert all(p.data_ptr() == flat.data[o:o + p.numel()].data_ptr() for p, o in zip(flat.params, flat.offsets))
+    red = train.GradReducer(flat, bucket_mb=0.2)       # several buckets
+    assert len(red.buckets) >= 2 and sum(b[3] for b in red.buckets) == len(flat.params)
+    covered = sorted((b[0], b[1]) for b in red.buckets)
+    assert covered[0][0] == 0 and covered[-1][1] == flat.numel and all(a[1] == b[0] for a, b in zip(covered, covered[1:]))
+    train.attach_reducer(red)
+    for step in range(2):
+        flat.zero_grad()
+        red.begin()
+        # "backward": parameters become ready last-to-first, each rank contributes rank+1
+        for p in reversed(flat.params):
+            p._eamd_grad.add_(float(rank + 1) * (step + 1))
+            from espnet_amd.functional import GradSink
+            GradSink([p]).results()
+        red.finish()
+        want = sum(range(1, world + 1)) * (step + 1)
+        for p in flat.params:
+            assert torch.all(p._eamd_grad == want), (rank, step)
+    # interleaved sharding of a global minibatch (abs_task.py:1445)
+    items = list(range(10))
+    assert train.shard_batch(items, rank, world) == items[rank::world]
+    train.attach_reducer(None)
+    torch.distributed.barrier()
+    torch.distributed.destroy_process_group()
+    q.put((rank, "ok"))
+
+
+def test_gloo_two_ranks():
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(timeout=120)
+    for p in procs:
+        assert p.exitcode == 0
+    got = sorted(q.get(timeout=5) for _ in range(2))
+    assert got == [(0, "ok"), (1, "ok")]
+
+
+def test_single_process_defaults(monkeypatch):
+    from espnet_amd import train
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK"):
+        monkeypatch.delenv(k, raising=False)
+    if torch.cuda.is_available():
+        pytest.skip("covers the CPU-only path")
+    assert train.init_distributed() == (0, 0, 1)
+    assert train.shard_batch([1, 2, 3], 0, 1) == [1, 2, 3]

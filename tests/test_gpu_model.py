@@ -279,3 +279,29 @@ def test_beam_search_golden(name, kind, extra):
         assert [g["yseq"] for g in got] == want
         for g, s in zip(got, p[tag + "_scores"].tolist()):
             assert abs(g["score"] - s) <= 1e-4 * max(1.0, abs(s))
+
+
+def test_espnet2_model_golden():
+    """espnet2 surface: ESPnetASRModel(ConformerEncoder, TransformerDecoder, CTC).forward ->
+    (loss, stats, weight) against the reference's own espnet2 model on the same weights and batch."""
+    from espnet_amd.espnet2 import CTC, ConformerEncoder, ESPnetASRModel, TransformerDecoder
+    p, sd, grads = split_golden(load_golden("espnet2_model.npz"))
+    enc = ConformerEncoder(20, output_size=64, attention_heads=4, linear_units=96, num_blocks=2, dropout_rate=0.0,
+                           positional_dropout_rate=0.0, attention_dropout_rate=0.0, macaron_style=True,
+                           cnn_module_kernel=7)
+    dec = TransformerDecoder(30, 64, attention_heads=4, linear_units=96, num_blocks=1, dropout_rate=0.0,
+                             positional_dropout_rate=0.0)
+    model = ESPnetASRModel(vocab_size=30, encoder=enc, decoder=dec, ctc=CTC(30, 64, ctc_type="builtin"),
+                           ctc_weight=0.3, lsm_weight=0.1)
+    assert list(model.state_dict().keys()) == list(sd.keys())
+    model = load_sd(model, sd)
+    model.train()
+    loss, stats, weight = model(p["speech"].to(DEV), p["speech_lengths"], p["text"].to(DEV), p["text_lengths"])
+    assert loss.shape == (1,) and weight.shape == (1,) and int(weight) == int(p["weight"])
+    for k in ("loss", "loss_att", "loss_ctc"):
+        rel = abs(float(stats[k]) - float(p[k])) / abs(float(p[k]))
+        print(f"[parity] espnet2 {k}: hip={float(stats[k]):.6f} ref={float(p[k]):.6f} rel={rel:.2e}")
+        assert rel < 1e-5
+    assert abs(float(stats["acc"]) - float(p["acc"])) < 1e-6
+    loss.backward()
+    check_grads(model, grads, tol=1e-3)
