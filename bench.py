@@ -77,7 +77,7 @@ def main():
     ap.add_argument("--frames", type=int, default=1000)
     ap.add_argument("--no-graph", action="store_true", help="eager launches instead of hipGraph replay")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-sample-batch", type=int, default=4)
+    ap.add_argument("--cpu-sample-batch", type=int, default=32)
     a = ap.parse_args()
 
     import espnet_amd
@@ -193,7 +193,8 @@ def main():
             "metric": "frames/sec, 12L Conformer hybrid CTC/attention training step (B=32 T=1000 d=256 per GPU)",
             "value": round(frames / dt, 1), "unit": "frames/s", "n_gpus": world, "steps": a.steps,
             "warmup": a.warmup, "ms_per_step": round(ms, 3), "higher_is_better": True, "scaling": "weak",
-            "vs_baseline": None, "dtype": "bf16-mfma/fp32-accum,fp32-storage" if a.precision == "bf16" else "f32",
+            "vs_baseline": None, "dtype": "bf16" if a.precision == "bf16" else "f32",
+            "dtype_detail": "bf16 GEMM operands + MFMA, fp32 accumulate / residual stream / master weights / optimizer" if a.precision == "bf16" else "fp32 everywhere (v_mfma_f32_16x16x4_f32)",
             "data": "synthetic", "utt_per_s": round(B * world * a.steps / dt, 2), "loss": round(loss_val, 4),
             "config": {"workload": "BASELINE configs[1]: 12L Conformer enc d=256 h=4 ff=2048 k=31 macaron+cnn rel_pos, "
                                    "6L Transformer dec, V=5000, fbank B=%d T=%d L=100, mtlalpha 0.3, lsm 0.1" % (B, T),

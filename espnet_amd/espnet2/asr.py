@@ -118,7 +118,9 @@ class TransformerDecoder(AbsDecoder):
                         use_output_layer=use_output_layer, pos_enc_class=pos_enc_class,
                         normalize_before=normalize_before, concat_after=concat_after)
         self._dec = [dec]   # not registered twice: the submodules below carry the parameters
-        self.embed, self.decoders, self.after_norm, self.output_layer = dec.embed, dec.decoders, dec.after_norm, dec.output_layer
+        # registration order of the reference (BaseTransformerDecoder first, then the subclass' layers)
+        self.embed, self.after_norm, self.output_layer = dec.embed, dec.after_norm, dec.output_layer
+        self.decoders = dec.decoders
         self.normalize_before = normalize_before
 
     def forward(self, hs_pad, hlens, ys_in_pad, ys_in_lens):
