@@ -392,7 +392,13 @@ extern "C" int eamd_gemm(const eamd_gemm_t* pp, void* stream_) {
   int tile = p.tile;
   if (tile == 0) {
     long t128 = (long)((p.M + 127) / 128) * ((p.N + 127) / 128) * p.batch1 * p.batch2 * p.splitk;
-    tile = (t128 >= 512 && p.M >= 128 && p.N >= 128) ? 128 : 64;
+    if (p.in_dtype == 1) {
+      // measured on MI355X (tools/gemm_probe2.py): the 64x64 tile wins on every skinny shape of the model
+      // (K or N = 256); 128x128 only pays for large square problems
+      tile = (t128 >= 1024 && p.K >= 2048 && p.M >= 2048 && p.N >= 2048) ? 128 : 64;
+    } else {
+      tile = (t128 >= 512 && p.M >= 128 && p.N >= 128) ? 128 : 64;
+    }
   }
   if (tile != 64 && tile != 128) return EAMD_EINVAL;
 

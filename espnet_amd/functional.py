@@ -400,9 +400,9 @@ class Conv2dSubsamplingFn(torch.autograd.Function):
         # conv2 weight gradient: dwf[(tap, ci), co] = sum_pos col[pos, (tap, ci)] * dy2[pos, co]
         dwf = torch.zeros(9 * Cc, Cc, device=dev, dtype=torch.float32)
         g = ops.make_gather(Cc, _TAPS_FWD, H2, W2, H1, W1, 2, 2)
-        tile = 128 if Cc % 128 == 0 else 64
+        tile = 64
         ntile = (9 * Cc // tile) * ((Cc + tile - 1) // tile)
-        sk = max(2, min(64, (768 + ntile - 1) // ntile, max(1, M2 // 256)))
+        sk = max(2, min(64, (1024 + ntile - 1) // ntile, max(1, M2 // 256)))
         ops.gemm(y1, dy2, dwf, 9 * Cc, Cc, M2, 9 * Cc, Cc, Cc, transA=1, transB=1, gather=g, splitk=sk, tile=tile)
         ops.conv2_weight_grad(dwf, sink.buf(2), Cc, Cc)
         # conv2 input gradient, one implicit GEMM per stride-parity class, ReLU mask of conv1 fused
