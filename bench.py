@@ -77,6 +77,8 @@ def main():
     ap.add_argument("--frames", type=int, default=1000)
     ap.add_argument("--no-graph", action="store_true", help="eager launches instead of hipGraph replay")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--wgrad-stream", action="store_true",
+                    help="issue weight-gradient GEMMs on a second stream (measured: no gain on MI355X, off by default)")
     ap.add_argument("--cpu-sample-batch", type=int, default=32)
     a = ap.parse_args()
 
@@ -102,6 +104,7 @@ def main():
         train.attach_reducer(reducer)
     xs, ilens, ys = synth_batch(B, T, L, V, seed=1 + rank)
     batch = model.prepare(xs, ilens, ys)
+    ops.enable_wgrad_stream(a.wgrad_stream)
 
     def step():
         return train.train_step(model, flat, opt, batch, reducer)
@@ -173,8 +176,15 @@ def main():
         flop_per_launch = STEP_FLOP * (B / 32.0) * (T / 1000.0) / n
         avg_ms = gemm_ms / n
         ach = flop_per_launch / (avg_ms * 1e-3) / 1e12
+        traffic = None
+        try:   # HBM bytes per GEMM launch from the last committed PMC passes (profiles/, FETCH_SIZE x2 + WRITE_SIZE)
+            with open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")) as fh:
+                traffic = round(json.load(fh)["gemm_family"]["hbm_bytes_per_launch"])
+        except Exception:  # noqa: BLE001
+            traffic = None
         roof = dict(bound="mfma", achieved=round(ach, 2), peak=PEAK_TFLOPS[a.precision], unit="TFLOP/s",
-                    frac=round(ach / PEAK_TFLOPS[a.precision], 4), traffic=None,
+                    frac=round(ach / PEAK_TFLOPS[a.precision], 4), traffic=traffic,
+                    traffic_note="HBM bytes per launch, rocprofv3 PMC (FETCH_SIZE doubled + WRITE_SIZE), profiles/r01_pmc*",
                     kernel="gemm_kernel<*> (all MFMA contractions)", launches_per_step=n,
                     avg_launch_us=round(avg_ms * 1e3, 2), gemm_ms_per_step=round(gemm_ms, 3))
 
@@ -199,7 +209,7 @@ def main():
             "config": {"workload": "BASELINE configs[1]: 12L Conformer enc d=256 h=4 ff=2048 k=31 macaron+cnn rel_pos, "
                                    "6L Transformer dec, V=5000, fbank B=%d T=%d L=100, mtlalpha 0.3, lsm 0.1" % (B, T),
                        "global_batch": B * world, "frames": T, "parallelism": "dp%d" % world,
-                       "dropout": 0.0, "optimizer": "adam+noam, clip 5.0", "launch": "hipGraph" if use_graph else "eager",
+                       "dropout": 0.0, "optimizer": "adam+noam, clip 5.0", "launch": "hipGraph" if use_graph else "eager", "wgrad_side_stream": a.wgrad_stream,
                        "optimizer_steps_done": st["step"], "grad_norm": round(st["grad_norm"], 4)},
             "roofline": roof, "cpu_baseline": cpu,
         }

@@ -427,7 +427,7 @@ int eamd_layernorm_bwd(const float* dy, const float* x, const float* gamma, cons
   if (!dy || !x || !gamma || !mean || !rstd || !dx || !dgamma || !dbeta || rows <= 0 || D <= 0)
     return EAMD_EINVAL;
   if (D > 1024) return EAMD_EUNSUPPORTED;
-  int nblk = min(512, (rows + 15) / 16);
+  int nblk = min(1024, (rows + 7) / 8);
   int rpb = (rows + nblk - 1) / nblk;
   nblk = (rows + rpb - 1) / rpb;
   const bool al = (((uintptr_t)dy | (uintptr_t)x | (uintptr_t)gamma | (uintptr_t)dx | (uintptr_t)dres) & 15) == 0;

@@ -33,6 +33,7 @@ class GradSink:
 
     def results(self):
         if GradSink.on_done is not None:
+            ops.wgrad_join()   # the all-reduce of these gradients must see the side-stream GEMMs
             GradSink.on_done(self.params)
         return tuple(self.ret)
 

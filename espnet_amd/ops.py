@@ -179,7 +179,40 @@ def linear_bwd_x(dy, W, out=None, *, beta=0.0, epilogue=EPI_NONE, aux=None, alph
     return out
 
 
+# ---- weight-gradient side stream ---------------------------------------------------------------
+# dW = dY^T X is needed only by the optimizer (and the gradient all-reduce), never by the rest of
+# backward.  When enabled, every weight-gradient GEMM is issued on a second HIP stream so that it
+# overlaps the dX chain; under hipGraph capture this becomes a parallel branch of the graph.
+_wgrad = {"stream": None, "used": False}
+
+
+def enable_wgrad_stream(enable=True):
+    _wgrad["stream"] = torch.cuda.Stream() if enable else None
+    _wgrad["used"] = False
+
+
+def wgrad_join():
+    """make the current stream wait for all weight-gradient work issued so far"""
+    st = _wgrad["stream"]
+    if st is not None and _wgrad["used"]:
+        torch.cuda.current_stream().wait_stream(st)
+        _wgrad["used"] = False
+
+
 def linear_bwd_w(dy, x, dW, *, alpha=1.0, b_act=ACT_NONE, db=None):
+    st = _wgrad["stream"]
+    if st is None:
+        return _linear_bwd_w(dy, x, dW, alpha=alpha, b_act=b_act, db=db)
+    cur = torch.cuda.current_stream()
+    st.wait_stream(cur)                 # operands were produced on the main stream
+    with torch.cuda.stream(st):
+        _linear_bwd_w(dy, x, dW, alpha=alpha, b_act=b_act, db=db)
+    dy.record_stream(st)                # keep the caching allocator from recycling them early
+    x.record_stream(st)
+    _wgrad["used"] = True
+
+
+def _linear_bwd_w(dy, x, dW, *, alpha=1.0, b_act=ACT_NONE, db=None):
     """dW[N,K] += alpha * dy[M,N]^T @ b_act(x)[M,K]   (split-K, f32 atomics)
     db[N] += alpha * column sums of dy (bias gradient, fused into the same launch)"""
     M, N = dy.shape

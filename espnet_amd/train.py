@@ -185,6 +185,7 @@ def train_step(model, flat, opt, batch, reducer=None, loss_scale=1.0):
     loss = model.forward_core(batch) if isinstance(batch, dict) else model(*batch)
     scale = loss_scale / (reducer.world if reducer is not None else 1)
     loss.backward(torch.full((), scale, device=loss.device, dtype=loss.dtype) if scale != 1.0 else None)
+    ops.wgrad_join()
     if reducer is not None:
         reducer.finish()
     opt.step()
