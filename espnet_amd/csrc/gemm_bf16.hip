@@ -135,15 +135,22 @@ __global__ __launch_bounds__(NT_) void gemm_bf16_kernel(const eamd_gemm_t p) {
   // L2), so give every XCD one contiguous run of row-major (m-tile, n-tile) pairs: the N-tiles that
   // re-read one A row panel then hit the same L2 instead of pulling the panel through the fabric 8x.
   const int tiles_n = (p.N + BN - 1) / BN;
-  const int ntile = gridDim.x;
-  int tile_id;
-  {
+  int tile_id, split;
+  if (p.splitk > 1) {
+    // split-K: the split index is the fastest-varying part of the workgroup id, so XCD i (ids = i mod 8)
+    // owns K-slice i (mod splitk) of EVERY tile: each XCD streams its slice of A and B once through its
+    // own L2 instead of all eight XCDs re-reading the whole reduction range
+    split = blockIdx.x % p.splitk;
+    tile_id = blockIdx.x / p.splitk;
+  } else {
+    split = 0;
+    const int ntile = gridDim.x;
     const int id = blockIdx.x, q = ntile >> 3, r = ntile & 7, xcd = id & 7, j = id >> 3;
     tile_id = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + j;
   }
   const int tile_m = tile_id / tiles_n, tile_n = tile_id % tiles_n;
   const int m0 = tile_m * BM, n0 = tile_n * BN;
-  const int zb = blockIdx.z / p.splitk, split = blockIdx.z % p.splitk;
+  const int zb = blockIdx.z;
   const int b1 = zb / p.batch2, b2 = zb % p.batch2;
   const bf16_t* __restrict__ A = reinterpret_cast<const bf16_t*>(p.A) + b1 * p.sA1 + b2 * p.sA2;
   const bf16_t* __restrict__ B = reinterpret_cast<const bf16_t*>(p.B) + b1 * p.sB1 + b2 * p.sB2;
@@ -178,14 +185,14 @@ __global__ __launch_bounds__(NT_) void gemm_bf16_kernel(const eamd_gemm_t p) {
   }
   // register ring of DEPTH tile sets: DEPTH-1 tiles of loads stay in flight across the MFMA phases
   // (skinny N=256 GEMMs have ~2 workgroups per CU, so bytes in flight per workgroup hide HBM latency)
-  constexpr int DEPTH = (BM == 64) ? 4 : 2;
+  constexpr int DEPTH = 2;
   uint4 ra[DEPTH][NCA], rb[DEPTH][NCB];
   const bool do_colsum = TA && p.colsum != nullptr && !gat && tile_n == 0;
   float cs[8];
 #pragma unroll
   for (int j = 0; j < 8; ++j) cs[j] = 0.f;
 
-  auto fill_poff = [&](int kt, int slot) {
+  auto fill_poff = [&](int kt, int slot) __attribute__((always_inline)) {
     if (t < BK) {
       const int tap = m0 / p.gather.C;
       RowStateB s = decompose_b(p.gather, kt * BK + t, p.K);
@@ -193,7 +200,7 @@ __global__ __launch_bounds__(NT_) void gemm_bf16_kernel(const eamd_gemm_t p) {
     }
   };
 
-  auto load_tile = [&](auto set_c, int kt) {
+  auto load_tile = [&](auto set_c, int kt) __attribute__((always_inline)) {
     constexpr int SET = decltype(set_c)::value;
     const int k0 = kt * BK;
     // ---- A ----
@@ -254,7 +261,7 @@ __global__ __launch_bounds__(NT_) void gemm_bf16_kernel(const eamd_gemm_t p) {
   };
 
   // validity (number of in-range elements) of staged chunk i of tile kt, recomputed at store time
-  auto nv_a = [&](int i, int kt) -> int {
+  auto nv_a = [&](int i, int kt) __attribute__((always_inline)) -> int {
     const int k0 = kt * BK;
     if constexpr (gat) {
       if constexpr (!TA) return gather_off_b(p.gather, a_rs[i], k0 / p.gather.C) >= 0 ? 8 : 0;
@@ -265,13 +272,13 @@ __global__ __launch_bounds__(NT_) void gemm_bf16_kernel(const eamd_gemm_t p) {
       return (k0 + a_r[i]) < p.K ? min(8, p.M - (m0 + a_c[i] * 8)) : 0;
     }
   };
-  auto nv_b = [&](int i, int kt) -> int {
+  auto nv_b = [&](int i, int kt) __attribute__((always_inline)) -> int {
     const int k0 = kt * BK;
     if constexpr (!TB) return (n0 + b_r[i]) < p.N ? min(8, p.K - (k0 + b_c[i] * 8)) : 0;
     else return (k0 + b_r[i]) < p.K ? min(8, p.N - (n0 + b_c[i] * 8)) : 0;
   };
 
-  auto store_tile = [&](auto set_c, int buf, int kt) {
+  auto store_tile = [&](auto set_c, int buf, int kt) __attribute__((always_inline)) {
     constexpr int SET = decltype(set_c)::value;
     if constexpr (FAST || gat) {
       // interior tiles (the vast majority) need no masking at all: one wave-uniform test per tile
@@ -348,13 +355,19 @@ __global__ __launch_bounds__(NT_) void gemm_bf16_kernel(const eamd_gemm_t p) {
   const int fr = lane & 15, fq = lane >> 4;
   // one K-tile: issue the loads of tile it+2 into the register set tile `it` came from, run the 32
   // (or 8) MFMAs of tile `it` from LDS, then move tile it+1 (loaded one phase ago) into the other LDS buffer
-  auto phase = [&](auto par_c, int it) {
+  auto phase = [&](auto par_c, auto guard_c, int it) __attribute__((always_inline)) {
     constexpr int PAR = decltype(par_c)::value;                       // it % DEPTH
+    constexpr bool GUARD = decltype(guard_c)::value;
     using load_t = std::integral_constant<int, (PAR + DEPTH - 1) % DEPTH>;   // set freed one phase ago
     using other_t = std::integral_constant<int, (PAR + 1) % DEPTH>;          // tile it+1
     const int buf = PAR & 1;
-    if (tgat && it + DEPTH < nkt) fill_poff(kt_begin + it + DEPTH, (kt_begin + it + DEPTH) % 8);
-    if (it + DEPTH - 1 < nkt) load_tile(load_t{}, kt_begin + it + DEPTH - 1);
+    if constexpr (GUARD) {
+      if (tgat && it + DEPTH < nkt) fill_poff(kt_begin + it + DEPTH, (kt_begin + it + DEPTH) % 8);
+      if (it + DEPTH - 1 < nkt) load_tile(load_t{}, kt_begin + it + DEPTH - 1);
+    } else {
+      if constexpr (tgat) fill_poff(kt_begin + it + DEPTH, (kt_begin + it + DEPTH) % 8);
+      load_tile(load_t{}, kt_begin + it + DEPTH - 1);
+    }
 #pragma unroll
     for (int ks = 0; ks < 2; ++ks) {
       bf16x8 af[MT], bfr[NTL];
@@ -390,20 +403,40 @@ __global__ __launch_bounds__(NT_) void gemm_bf16_kernel(const eamd_gemm_t p) {
         for (int j = 0; j < NTL; ++j)
           acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i], bfr[j], acc[i][j], 0, 0, 0);
     }
-    if (it + 1 < nkt) store_tile(other_t{}, buf ^ 1, kt_begin + it + 1);
+    if constexpr (GUARD) {
+      if (it + 1 < nkt) store_tile(other_t{}, buf ^ 1, kt_begin + it + 1);
+    } else {
+      store_tile(other_t{}, buf ^ 1, kt_begin + it + 1);
+    }
     __syncthreads();
   };
+  // steady state: groups of DEPTH phases with NO conditionals, so the compiler sees one straight-line
+  // body and can emit counted s_waitcnt vmcnt(N) that leave the newer tiles' loads in flight; the last
+  // (up to 2*DEPTH-2) tiles run through the guarded form.
+  using T_ = std::true_type;
+  using F_ = std::false_type;
+  int it = 0;
   if constexpr (DEPTH == 2) {
-    for (int it = 0; it < nkt; it += 2) {
-      phase(std::integral_constant<int, 0>{}, it);
-      if (it + 1 < nkt) phase(std::integral_constant<int, 1>{}, it + 1);
+    for (; it + 2 * DEPTH - 2 < nkt; it += 2) {
+      phase(std::integral_constant<int, 0>{}, F_{}, it);
+      phase(std::integral_constant<int, 1>{}, F_{}, it + 1);
+    }
+    for (; it < nkt; it += 2) {
+      phase(std::integral_constant<int, 0>{}, T_{}, it);
+      if (it + 1 < nkt) phase(std::integral_constant<int, 1>{}, T_{}, it + 1);
     }
   } else {
-    for (int it = 0; it < nkt; it += 4) {
-      phase(std::integral_constant<int, 0>{}, it);
-      if (it + 1 < nkt) phase(std::integral_constant<int, 1>{}, it + 1);
-      if (it + 2 < nkt) phase(std::integral_constant<int, 2>{}, it + 2);
-      if (it + 3 < nkt) phase(std::integral_constant<int, 3>{}, it + 3);
+    for (; it + 2 * DEPTH - 2 < nkt; it += 4) {
+      phase(std::integral_constant<int, 0>{}, F_{}, it);
+      phase(std::integral_constant<int, 1>{}, F_{}, it + 1);
+      phase(std::integral_constant<int, 2>{}, F_{}, it + 2);
+      phase(std::integral_constant<int, 3>{}, F_{}, it + 3);
+    }
+    for (; it < nkt; it += 4) {
+      phase(std::integral_constant<int, 0>{}, T_{}, it);
+      if (it + 1 < nkt) phase(std::integral_constant<int, 1>{}, T_{}, it + 1);
+      if (it + 2 < nkt) phase(std::integral_constant<int, 2>{}, T_{}, it + 2);
+      if (it + 3 < nkt) phase(std::integral_constant<int, 3>{}, T_{}, it + 3);
     }
   }
 
@@ -575,7 +608,7 @@ __global__ __launch_bounds__(NT_) void gemm_bf16_kernel(const eamd_gemm_t p) {
 
 template <int BM, int BN, bool TA, bool TB, bool FAST, bool GAT>
 int launch_b(const eamd_gemm_t& p, hipStream_t stream) {
-  dim3 grid(((p.M + BM - 1) / BM) * ((p.N + BN - 1) / BN), 1, p.batch1 * p.batch2 * p.splitk);
+  dim3 grid(((p.M + BM - 1) / BM) * ((p.N + BN - 1) / BN) * p.splitk, 1, p.batch1 * p.batch2);
   size_t smem = sizeof(SmemB<BM, BN, TA, TB>);
   if (smem > 64 * 1024) {
     static const hipError_t attr_err = hipFuncSetAttribute(

@@ -148,11 +148,16 @@ def cast_bf16(x, out=None):
 
 
 def auto_splitk(m_out, n_out, k_red):
+    """split count for reduction-heavy GEMMs: enough workgroups to fill 256 CUs, rounded to a multiple
+    of 8 so that every XCD owns whole K-slices (see gemm_bf16.hip: split index = workgroup id mod splitk)"""
     tiles = ((m_out + 63) // 64) * ((n_out + 63) // 64)
     if tiles >= 512:
         return 1
-    s = min((512 + tiles - 1) // tiles, max(1, k_red // 128))
-    return max(1, min(s, 64))
+    s = min((768 + tiles - 1) // tiles, max(1, k_red // 128))
+    s = max(1, min(s, 64))
+    if s >= 6:
+        s = min(64, (s + 7) // 8 * 8)
+    return s
 
 
 # ---- nn.Linear pieces -------------------------------------------------------------------------
