@@ -76,6 +76,7 @@ def main():
     ap.add_argument("--batch", type=int, default=32, help="utterances per GPU")
     ap.add_argument("--frames", type=int, default=1000)
     ap.add_argument("--no-graph", action="store_true", help="eager launches instead of hipGraph replay")
+    ap.add_argument("--dropout", type=float, default=0.1, help="dropout-rate of the recipe (yaml: 0.1)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--wgrad-stream", action="store_true",
                     help="issue weight-gradient GEMMs on a second stream (measured: no gain on MI355X, off by default)")
@@ -94,8 +95,9 @@ def main():
     B, T, L, V = a.batch, a.frames, 100, 5000
 
     torch.manual_seed(0)
-    model = E2E(80, V, c2_args()).to(dev).train()
+    model = E2E(80, V, c2_args(a.dropout)).to(dev).train()
     model.sync_report = False
+    ops.manual_seed(1234 + 1000003 * rank)
     flat = train.FlatParams(model)
     opt = train.NoamAdam(flat, mode="noam", factor=1.0, model_size=256, warmup=25000, max_grad_norm=5.0)
     reducer = None
@@ -209,7 +211,7 @@ def main():
             "config": {"workload": "BASELINE configs[1]: 12L Conformer enc d=256 h=4 ff=2048 k=31 macaron+cnn rel_pos, "
                                    "6L Transformer dec, V=5000, fbank B=%d T=%d L=100, mtlalpha 0.3, lsm 0.1" % (B, T),
                        "global_batch": B * world, "frames": T, "parallelism": "dp%d" % world,
-                       "dropout": 0.0, "optimizer": "adam+noam, clip 5.0", "launch": "hipGraph" if use_graph else "eager", "wgrad_side_stream": a.wgrad_stream,
+                       "dropout": a.dropout, "optimizer": "adam+noam, clip 5.0", "launch": "hipGraph" if use_graph else "eager", "wgrad_side_stream": a.wgrad_stream,
                        "optimizer_steps_done": st["step"], "grad_norm": round(st["grad_norm"], 4)},
             "roofline": roof, "cpu_baseline": cpu,
         }

@@ -194,22 +194,35 @@ __global__ void permute4_kernel(const float* __restrict__ src, float* __restrict
   }
 }
 
-// Counter-based dropout (one Philox-like hash per element).  Keeps y = x * keep / (1-p).
-// reference: torch.nn.Dropout call sites (encoder_layer.py:55, attention.py:38, embedding.py:56);
-// streams cannot match torch's generator, parity runs use p = 0 (SURVEY.md §7 "Dropout").
+// Counter-based dropout: keep(i) = hash(step_counter, salt, i) >= p * 2^32, y = x * keep / (1 - p).
+// The step counter lives in DEVICE memory (advanced once per training step by eamd_rng_advance), so a
+// captured hipGraph draws fresh masks on every replay; backward re-derives the same mask by calling the
+// same kernel on the gradient.  Optional fused activation (FFN inner dropout: drop(act(z))).
+// reference: torch.nn.Dropout call sites (conformer/encoder_layer.py:55, positionwise_feed_forward.py:27,
+// embedding.py:56, ctc.py:85); RNG streams cannot match torch's generator - parity runs use p = 0.
 __device__ __forceinline__ unsigned hash32(unsigned long long x) {
   x ^= x >> 33; x *= 0xff51afd7ed558ccdULL; x ^= x >> 33; x *= 0xc4ceb9fe1a85ec53ULL; x ^= x >> 33;
   return (unsigned)x;
 }
 __global__ void dropout_kernel(const float* __restrict__ x, float* __restrict__ y, long n, float p,
-                               unsigned long long seed) {
+                               const unsigned long long* __restrict__ step, unsigned long long salt, int act,
+                               int in_bf16, int out_bf16) {
   const float inv = 1.f / (1.f - p);
-  const unsigned thr = (unsigned)(p * 4294967296.0);
+  const unsigned thr = (unsigned)fminf(p * 4294967296.0f, 4294967040.0f);
+  const unsigned long long base = (step ? step[0] : 0ULL) * 0x9E3779B97F4A7C15ULL + salt * 0xD1B54A32D192ED03ULL;
   const long stride = (long)gridDim.x * blockDim.x;
+  const unsigned short* x16 = reinterpret_cast<const unsigned short*>(x);
+  unsigned short* y16 = reinterpret_cast<unsigned short*>(y);
   for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
-    unsigned h = hash32(seed * 0x9E3779B97F4A7C15ULL + (unsigned long long)i);
-    y[i] = h >= thr ? x[i] * inv : 0.f;
+    float v = in_bf16 ? __uint_as_float(((unsigned)x16[i]) << 16) : x[i];
+    v = eamd_act(v, act);
+    const unsigned h = hash32(base + (unsigned long long)i);
+    v = h >= thr ? v * inv : 0.f;
+    if (out_bf16) y16[i] = eamd_f2bf(v); else y[i] = v;
   }
+}
+__global__ void rng_advance_kernel(unsigned long long* step) {
+  if (threadIdx.x == 0 && blockIdx.x == 0) step[0] += 1ULL;
 }
 
 }  // namespace
@@ -342,11 +355,19 @@ int eamd_permute4(const float* src, float* dst, int d0, int d1, int d2, int d3, 
   return EAMD_OK;
 }
 
-int eamd_dropout(const float* x, float* y, int64_t n, float p, uint64_t seed, void* stream) {
+int eamd_dropout(const void* x, void* y, int64_t n, float p, const uint64_t* step_dev, uint64_t salt, int act,
+                 int in_bf16, int out_bf16, void* stream) {
   if (!x || !y || n < 0 || p < 0.f || p >= 1.f) return EAMD_EINVAL;
   if (n == 0) return EAMD_OK;
-  hipLaunchKernelGGL(dropout_kernel, dim3(grid_for(n)), dim3(256), 0, (hipStream_t)stream, x, y, (long)n, p,
-                     (unsigned long long)seed);
+  hipLaunchKernelGGL(dropout_kernel, dim3(grid_for(n)), dim3(256), 0, (hipStream_t)stream, (const float*)x, (float*)y,
+                     (long)n, p, (const unsigned long long*)step_dev, (unsigned long long)salt, act, in_bf16, out_bf16);
+  EAMD_LAUNCH_CHECK();
+  return EAMD_OK;
+}
+
+int eamd_rng_advance(uint64_t* step_dev, void* stream) {
+  if (!step_dev) return EAMD_EINVAL;
+  hipLaunchKernelGGL(rng_advance_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, (unsigned long long*)step_dev);
   EAMD_LAUNCH_CHECK();
   return EAMD_OK;
 }

@@ -43,6 +43,25 @@ def _act_epi(act):
 
 
 # =================================================================================================
+# Dropout (mask = hash(device step counter, salt, index); backward re-applies the same mask)
+# =================================================================================================
+class DropoutFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, p, salt):
+        ctx.cfg = (p, salt)
+        return ops.dropout(x.contiguous(), p, salt)
+
+    @staticmethod
+    def backward(ctx, dy):
+        p, salt = ctx.cfg
+        return ops.dropout(dy.contiguous(), p, salt), None, None
+
+
+def dropout(x, p, salt, training):
+    return DropoutFn.apply(x, p, salt) if (training and p > 0.0) else x
+
+
+# =================================================================================================
 # LayerNorm  (reference: transformer/layer_norm.py:12-38)
 # =================================================================================================
 class LayerNormFn(torch.autograd.Function):
@@ -99,35 +118,54 @@ class LinearFn(torch.autograd.Function):
 #            transformer/encoder_layer.py / decoder_layer.py:123-128 (scale = 1, ReLU)
 # =================================================================================================
 class FFNBlockFn(torch.autograd.Function):
+    """drop = (p_inner, salt_inner, p_out, salt_out): dropout after the activation
+    (positionwise_feed_forward.py:27) and on the block output before the residual add
+    (conformer/encoder_layer.py:101,144); p = 0 keeps the fully fused path."""
+
     @staticmethod
-    def forward(ctx, x, ln_w, ln_b, w1, b1, w2, b2, scale, act, eps):
+    def forward(ctx, x, ln_w, ln_b, w1, b1, w2, b2, scale, act, eps, drop=(0.0, 0, 0.0, 0)):
         shp = x.shape
         D = shp[-1]
         adt = ops.act_dtype()
+        p_in, s_in, p_out, s_out = drop
         x2 = x.reshape(-1, D).contiguous()
         xn, mean, rstd = ops.layernorm_fwd(x2, ln_w, ln_b, eps, adt)            # GEMM operand (bf16 in fast mode)
         z = ops.linear_fwd(xn, ops.wshadow(w1), b1, out_dtype=adt)              # [M, F] pre-activation
-        out = ops.linear_fwd(z, ops.wshadow(w2), b2, R=x2, alpha=scale, a_act=act)   # act applied while staging z
-        ctx.save_for_backward(x2, mean, rstd, xn, z)
+        h = None
+        if p_in > 0.0:
+            h = ops.dropout(z, p_in, s_in, act=act)                             # drop(act(z)), materialised
+        src, a_act = (h, ACT_NONE) if h is not None else (z, act)
+        if p_out > 0.0:
+            br = ops.linear_fwd(src, ops.wshadow(w2), b2, a_act=a_act)
+            out = ops.axpby(x2, ops.dropout(br, p_out, s_out), 1.0, scale)
+        else:
+            out = ops.linear_fwd(src, ops.wshadow(w2), b2, R=x2, alpha=scale, a_act=a_act)
+        ctx.save_for_backward(x2, mean, rstd, xn, z, h)
         ctx.pr = (ln_w, ln_b, w1, b1, w2, b2)
-        ctx.cfg = (scale, act, shp)
+        ctx.cfg = (scale, act, shp, drop)
         return out.view(shp)
 
     @staticmethod
     def backward(ctx, dout):
-        x2, mean, rstd, xn, z = ctx.saved_tensors
+        x2, mean, rstd, xn, z, h = ctx.saved_tensors
         ln_w, ln_b, w1, b1, w2, b2 = ctx.pr
-        scale, act, shp = ctx.cfg
+        scale, act, shp, (p_in, s_in, p_out, s_out) = ctx.cfg
         adt = ops.act_dtype()
         sink = GradSink(ctx.pr)
         do = dout.reshape(x2.shape).contiguous()
-        dob = ops.to_act(do)
-        ops.linear_bwd_w(dob, z, sink.buf(4), alpha=scale, b_act=act, db=sink.buf(5))   # dW2 += s * do^T act(z)
+        dbr = ops.dropout(do, p_out, s_out) if p_out > 0.0 else do              # gradient of the branch output
+        dob = ops.to_act(dbr)
+        if h is not None:
+            ops.linear_bwd_w(dob, h, sink.buf(4), alpha=scale, db=sink.buf(5))
+        else:
+            ops.linear_bwd_w(dob, z, sink.buf(4), alpha=scale, b_act=act, db=sink.buf(5))   # dW2 += s * do^T act(z)
         dz = ops.linear_bwd_x(dob, ops.wshadow(w2), epilogue=_act_epi(act), aux=z, alpha=scale, out_dtype=adt)
+        if h is not None:
+            dz = ops.dropout(dz, p_in, s_in)
         ops.linear_bwd_w(dz, xn, sink.buf(2), db=sink.buf(3))
         dxn = ops.linear_bwd_x(dz, ops.wshadow(w1))
         dx = ops.layernorm_bwd(dxn, x2, ln_w, mean, rstd, do, sink.buf(0), sink.buf(1))
-        return (dx.view(shp),) + sink.results() + (None, None, None)
+        return (dx.view(shp),) + sink.results() + (None, None, None, None)
 
 
 # =================================================================================================
@@ -166,8 +204,9 @@ def attn_context_fwd(P, v, B, T1, T2, H, dk):
     return ctxv
 
 
-def attn_core_bwd(dctx, P, qu, qv, k, v, p, B, T1, T2, H, dk):
-    """returns dqu (fp32), dqv (fp32 or None), dk, dv (GEMM-operand dtype), dp (fp32 or None)"""
+def attn_core_bwd(dctx, P, qu, qv, k, v, p, B, T1, T2, H, dk, Pd=None, attn_drop=(0.0, 0)):
+    """returns dqu (fp32), dqv (fp32 or None), dk, dv (GEMM-operand dtype), dp (fp32 or None)
+    Pd = dropped-out probabilities actually used for the context (None when attention dropout is off)."""
     D = H * dk
     ldp = _ldp(T2)
     dev = dctx.device
@@ -175,9 +214,11 @@ def attn_core_bwd(dctx, P, qu, qv, k, v, p, B, T1, T2, H, dk):
     sP = (T1 * ldp, B * T1 * ldp)
     dP = torch.empty(H * B * T1 * ldp, device=dev, dtype=torch.float32)
     ops.gemm(dctx, v, dP, T1, T2, dk, D, D, ldp, batch=(B, H), sA=(T1 * D, dk), sB=(T2 * D, dk), sC=sP)   # dctx v^T
+    if Pd is not None:
+        dP = ops.dropout(dP, attn_drop[0], attn_drop[1])      # same mask as the forward probabilities
     dv = torch.empty(B * T2, D, device=dev, dtype=adt)
-    ops.gemm(P, dctx, dv, T2, dk, T1, ldp, D, D, transA=1, transB=1, batch=(B, H), sA=sP, sB=(T1 * D, dk),
-             sC=(T2 * D, dk))                                                                             # P^T dctx
+    ops.gemm(Pd if Pd is not None else P, dctx, dv, T2, dk, T1, ldp, D, D, transA=1, transB=1, batch=(B, H), sA=sP,
+             sB=(T1 * D, dk), sC=(T2 * D, dk))                                                            # P^T dctx
     dbd = torch.zeros(H * B * T1 * ldp, device=dev, dtype=adt) if p is not None else None
     if ops.fast():
         dS = torch.empty(H * B * T1 * ldp, device=dev, dtype=torch.bfloat16)
@@ -211,7 +252,10 @@ class MHABlockFn(torch.autograd.Function):
     """
 
     @staticmethod
-    def forward(ctx, x, memory, pos_emb, mask, H, eps, last_query_only, *params):
+    def forward(ctx, x, memory, pos_emb, mask, H, eps, last_query_only, drop, *params):
+        # drop = (p_attn, salt_attn, p_out, salt_out): attention.py:91 (dropout on the probabilities) and the
+        # block-output dropout before the residual add (encoder_layer.py:126, decoder_layer.py:104,115)
+        p_att, s_att, p_out, s_out = drop
         ln_w, ln_b, wq, bq, wk, bk, wv, bv, wo, bo = params[:10]
         rel = len(params) > 10
         B, T1f, D = x.shape
@@ -241,27 +285,34 @@ class MHABlockFn(torch.autograd.Function):
         else:
             p, qu, qv = None, q, None
         P = attn_scores_fwd(qu, qv, k, p, mask, B, T1, T2, H, dk)
-        cx = attn_context_fwd(P, v, B, T1, T2, H, dk)
-        out = ops.linear_fwd(cx, ops.wshadow(wo), bo, R=res)
-        ctx.save_for_backward(x2, mean, rstd, xn, kv_in if memory is not None else None, qu, qv, k, v, p, P, cx, pos2)
+        Pd = ops.dropout(P, p_att, s_att) if p_att > 0.0 else P
+        cx = attn_context_fwd(Pd, v, B, T1, T2, H, dk)
+        if p_out > 0.0:
+            br = ops.linear_fwd(cx, ops.wshadow(wo), bo)
+            out = ops.axpby(res, ops.dropout(br, p_out, s_out), 1.0, 1.0)
+        else:
+            out = ops.linear_fwd(cx, ops.wshadow(wo), bo, R=res)
+        ctx.save_for_backward(x2, mean, rstd, xn, kv_in if memory is not None else None, qu, qv, k, v, p, P, cx, pos2,
+                              Pd if p_att > 0.0 else None)
         ctx.pr = params
-        ctx.cfg = (B, T1, T2, H, dk, D, rel, memory is not None, last_query_only)
+        ctx.cfg = (B, T1, T2, H, dk, D, rel, memory is not None, last_query_only, drop)
         return out.view(B, T1, D)
 
     @staticmethod
     def backward(ctx, dout):
-        x2, mean, rstd, xn, mem2, qu, qv, k, v, p, P, cx, pos2 = ctx.saved_tensors
-        B, T1, T2, H, dk, D, rel, cross, last = ctx.cfg
+        x2, mean, rstd, xn, mem2, qu, qv, k, v, p, P, cx, pos2, Pd = ctx.saved_tensors
+        B, T1, T2, H, dk, D, rel, cross, last, (p_att, s_att, p_out, s_out) = ctx.cfg
         assert not last, "cached decoding path is inference-only"
         params = ctx.pr
         ln_w, ln_b, wq, bq, wk, bk, wv, bv, wo, bo = params[:10]
         adt = ops.act_dtype()
         sink = GradSink(params)
         do = dout.reshape(-1, D).contiguous()
-        dob = ops.to_act(do)
+        dob = ops.to_act(ops.dropout(do, p_out, s_out) if p_out > 0.0 else do)
         ops.linear_bwd_w(dob, cx, sink.buf(8), db=sink.buf(9))
         dctx = ops.linear_bwd_x(dob, ops.wshadow(wo), out_dtype=adt)
-        dqu, dqv, dkk, dv, dp = attn_core_bwd(dctx, P, qu, qv, k, v, p, B, T1, T2, H, dk)
+        dqu, dqv, dkk, dv, dp = attn_core_bwd(dctx, P, qu, qv, k, v, p, B, T1, T2, H, dk,
+                                              Pd=Pd, attn_drop=(p_att, s_att))
         if rel:
             wpos = params[10]
             ops.colsum(dqu, sink.buf(11).view(-1))
@@ -284,7 +335,7 @@ class MHABlockFn(torch.autograd.Function):
             ops.linear_bwd_x(dkk, ops.wshadow(wk), out=dxn, beta=1.0)
             ops.linear_bwd_x(dv, ops.wshadow(wv), out=dxn, beta=1.0)
         dx = ops.layernorm_bwd(dxn, x2, ln_w, mean, rstd, do, sink.buf(0), sink.buf(1))
-        return (dx.view(B, T1, D), dmem, None, None, None, None, None) + sink.results()
+        return (dx.view(B, T1, D), dmem, None, None, None, None, None, None) + sink.results()
 
 
 # =================================================================================================
@@ -295,7 +346,8 @@ class MHABlockFn(torch.autograd.Function):
 # =================================================================================================
 class ConvModuleBlockFn(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x, running_mean, running_var, training, act, eps, bn_eps, bn_momentum, *params):
+    def forward(ctx, x, running_mean, running_var, training, act, eps, bn_eps, bn_momentum, drop, *params):
+        p_out, s_out = drop          # block-output dropout (conformer/encoder_layer.py:136)
         ln_w, ln_b, w1, b1, wd, bd_, g, be, w2, b2 = params
         B, T, D = x.shape
         Cc = w2.shape[0]
@@ -314,22 +366,26 @@ class ConvModuleBlockFn(torch.autograd.Function):
             brstd = ops.axpby(running_var, None, 1.0, 0.0)
             brstd = torch.rsqrt_(brstd.add_(bn_eps))  # tiny [C] host-issued op on eval path only
         e = ops.bn_apply(d, bmean, brstd, g, be, M, Cc, act, adt)
-        out = ops.linear_fwd(e, ops.wshadow(w2).view(Cc, Cc), b2, R=x2)
+        if p_out > 0.0:
+            br = ops.linear_fwd(e, ops.wshadow(w2).view(Cc, Cc), b2)
+            out = ops.axpby(x2, ops.dropout(br, p_out, s_out), 1.0, 1.0)
+        else:
+            out = ops.linear_fwd(e, ops.wshadow(w2).view(Cc, Cc), b2, R=x2)
         ctx.save_for_backward(x2, mean, rstd, xn, a, gl, d, bmean, brstd, e)
         ctx.pr = params
-        ctx.cfg = (B, T, D, Cc, K, act, training)
+        ctx.cfg = (B, T, D, Cc, K, act, training, drop)
         return out.view(B, T, D)
 
     @staticmethod
     def backward(ctx, dout):
         x2, mean, rstd, xn, a, gl, d, bmean, brstd, e = ctx.saved_tensors
         ln_w, ln_b, w1, b1, wd, bd_, g, be, w2, b2 = ctx.pr
-        B, T, D, Cc, K, act, training = ctx.cfg
+        B, T, D, Cc, K, act, training, (p_out, s_out) = ctx.cfg
         M = B * T
         adt = ops.act_dtype()
         sink = GradSink(ctx.pr)
         do = dout.reshape(M, D).contiguous()
-        dob = ops.to_act(do)
+        dob = ops.to_act(ops.dropout(do, p_out, s_out) if p_out > 0.0 else do)
         ops.linear_bwd_w(dob, e, sink.buf(8).view(Cc, Cc), db=sink.buf(9))
         de = ops.linear_bwd_x(dob, ops.wshadow(w2).view(Cc, Cc))
         dd = ops.bn_bwd(de, d, bmean, brstd, g, be, sink.buf(6), sink.buf(7), M, Cc, act, training)
@@ -339,7 +395,7 @@ class ConvModuleBlockFn(torch.autograd.Function):
         ops.linear_bwd_w(da, xn, sink.buf(2).view(2 * Cc, D), db=sink.buf(3))
         dxn = ops.linear_bwd_x(da, ops.wshadow(w1).view(2 * Cc, D))
         dx = ops.layernorm_bwd(dxn, x2, ln_w, mean, rstd, do, sink.buf(0), sink.buf(1))
-        return (dx.view(B, T, D), None, None, None, None, None, None, None) + sink.results()
+        return (dx.view(B, T, D), None, None, None, None, None, None, None, None) + sink.results()
 
 
 # =================================================================================================

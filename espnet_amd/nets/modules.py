@@ -28,11 +28,9 @@ def _act_id(activation_type):
     raise NotImplementedError(f"activation {activation_type!r} has no HIP kernel (relu, swish supported)")
 
 
-def _no_dropout(module, p):
-    if module.training and p > 0.0:
-        raise NotImplementedError(
-            "dropout > 0 in training mode is not wired into the fused HIP blocks yet; "
-            "set dropout_rate=0.0 (parity and benchmark runs do)")
+def _p(module, p):
+    """effective dropout probability of a module (0 in eval mode)"""
+    return float(p) if (module.training and p > 0.0) else 0.0
 
 
 class Swish(torch.nn.Module):
@@ -133,6 +131,7 @@ class PositionalEncoding(torch.nn.Module):
         self.xscale = math.sqrt(d_model)
         self.dropout_rate = dropout_rate
         self.pe = None
+        self.salt, self.salt2 = ops.new_salt(), ops.new_salt()
         self.extend_pe(max_len, torch.device("cpu"))
         self._register_load_state_dict_pre_hook(self._pre_hook)
 
@@ -157,9 +156,8 @@ class PositionalEncoding(torch.nn.Module):
         self.pe = pe.to(device)
 
     def forward(self, x):
-        _no_dropout(self, self.dropout_rate)
         self.extend_pe(x.size(1), x.device)
-        return F_.PosEncFn.apply(x, self.pe, self.xscale)
+        return F_.dropout(F_.PosEncFn.apply(x, self.pe, self.xscale), self.dropout_rate, self.salt, self.training)
 
 
 class RelPositionalEncoding(PositionalEncoding):
@@ -173,9 +171,10 @@ class RelPositionalEncoding(PositionalEncoding):
         return self.pe[:T]
 
     def forward(self, x):
-        _no_dropout(self, self.dropout_rate)
         y = ops.axpby(x.contiguous(), None, self.xscale, 0.0)
-        return y, self.pos_emb(x.size(1), x.device).unsqueeze(0)
+        pos = self.pos_emb(x.size(1), x.device).unsqueeze(0)
+        return (F_.dropout(y, self.dropout_rate, self.salt, self.training),
+                F_.dropout(pos, self.dropout_rate, self.salt2, self.training))
 
 
 # ---- input layers -------------------------------------------------------------------------------
@@ -194,15 +193,17 @@ class Conv2dSubsampling(torch.nn.Module):
 
     def forward(self, x, x_mask):
         pos = self.out[1]
-        _no_dropout(pos, pos.dropout_rate)
         y = F_.Conv2dSubsamplingFn.apply(x, pos.xscale, self.conv[0].weight, self.conv[0].bias,
                                          self.conv[2].weight, self.conv[2].bias, self.out[0].weight,
                                          self.out[0].bias)
         if isinstance(pos, RelPositionalEncoding):
-            y = (y, pos.pos_emb(y.size(1), y.device).unsqueeze(0))
+            pe = pos.pos_emb(y.size(1), y.device).unsqueeze(0)
+            y = (F_.dropout(y, pos.dropout_rate, pos.salt, pos.training),
+                 F_.dropout(pe, pos.dropout_rate, pos.salt2, pos.training))
         else:
             pos.extend_pe(y.size(1), y.device)
             y = F_.PosEncFn.apply(y, pos.pe, 1.0)   # x*xscale already applied in the Linear epilogue
+            y = F_.dropout(y, pos.dropout_rate, pos.salt, pos.training)
         if x_mask is None:
             return y, None
         return y, x_mask[:, :, :-2:2][:, :, :-2:2].contiguous()
@@ -225,6 +226,7 @@ class MultiHeadedAttention(torch.nn.Module):
         self.linear_out = torch.nn.Linear(n_feat, n_feat)
         self.attn = None
         self.dropout_rate = dropout_rate
+        self.salt_attn, self.salt_out = ops.new_salt(), ops.new_salt()
 
     def block_params(self):
         return (self.linear_q.weight, self.linear_q.bias, self.linear_k.weight, self.linear_k.bias,
@@ -246,11 +248,11 @@ class RelPositionMultiHeadedAttention(MultiHeadedAttention):
         return super().block_params() + (self.linear_pos.weight, self.pos_bias_u, self.pos_bias_v)
 
 
-def mha_block(norm, attn, x, memory, pos_emb, mask, last_query_only=False):
-    """x + attn(LN(x)[, memory]) through the fused HIP block."""
-    _no_dropout(attn, attn.dropout_rate)
+def mha_block(norm, attn, x, memory, pos_emb, mask, last_query_only=False, p_out=0.0):
+    """x + drop(attn(LN(x)[, memory])) through the fused HIP block (p_out = the layer's dropout rate)."""
+    drop = (_p(attn, attn.dropout_rate), attn.salt_attn, p_out if attn.training else 0.0, attn.salt_out)
     return F_.MHABlockFn.apply(x.contiguous(), memory, pos_emb, _mask_u8(mask, x.device), attn.h, norm.eps,
-                               last_query_only, norm.weight, norm.bias, *attn.block_params())
+                               last_query_only, drop, norm.weight, norm.bias, *attn.block_params())
 
 
 class PositionwiseFeedForward(torch.nn.Module):
@@ -263,12 +265,13 @@ class PositionwiseFeedForward(torch.nn.Module):
         self.dropout_rate = dropout_rate
         self.activation = activation if activation is not None else torch.nn.ReLU()
         self.act_id = _act_id(self.activation)
+        self.salt_in, self.salt_out = ops.new_salt(), ops.new_salt()
 
 
-def ffn_block(norm, ff, x, scale):
-    _no_dropout(ff, ff.dropout_rate)
+def ffn_block(norm, ff, x, scale, p_out=0.0):
+    drop = (_p(ff, ff.dropout_rate), ff.salt_in, p_out if ff.training else 0.0, ff.salt_out)
     return F_.FFNBlockFn.apply(x.contiguous(), norm.weight, norm.bias, ff.w_1.weight, ff.w_1.bias, ff.w_2.weight,
-                               ff.w_2.bias, scale, ff.act_id, norm.eps)
+                               ff.w_2.bias, scale, ff.act_id, norm.eps, drop)
 
 
 class ConvolutionModule(torch.nn.Module):
@@ -284,17 +287,18 @@ class ConvolutionModule(torch.nn.Module):
         self.pointwise_conv2 = torch.nn.Conv1d(channels, channels, kernel_size=1, stride=1, padding=0, bias=bias)
         self.activation = activation if activation is not None else torch.nn.ReLU()
         self.act_id = _act_id(self.activation)
+        self.salt_out = ops.new_salt()
         assert bias, "bias=False variant is not on the path"
 
 
-def conv_block(norm, cm, x):
+def conv_block(norm, cm, x, p_out=0.0):
     bn = cm.norm
     if cm.training:
         with torch.no_grad():
             bn.num_batches_tracked += 1
     return F_.ConvModuleBlockFn.apply(
         x.contiguous(), bn.running_mean, bn.running_var, cm.training, cm.act_id, norm.eps, bn.eps, bn.momentum,
-        norm.weight, norm.bias, cm.pointwise_conv1.weight, cm.pointwise_conv1.bias, cm.depthwise_conv.weight,
+        (p_out if cm.training else 0.0, cm.salt_out), norm.weight, norm.bias, cm.pointwise_conv1.weight, cm.pointwise_conv1.bias, cm.depthwise_conv.weight,
         cm.depthwise_conv.bias, bn.weight, bn.bias, cm.pointwise_conv2.weight, cm.pointwise_conv2.bias)
 
 
@@ -328,17 +332,17 @@ class ConformerEncoderLayer(torch.nn.Module):
 
     def forward(self, x_input, mask, cache=None):
         assert cache is None, "encoder-side cache is not used on the ASR path"
-        _no_dropout(self, self.dropout_rate)
+        p = self.dropout_rate
         if isinstance(x_input, tuple):
             x, pos_emb = x_input
         else:
             x, pos_emb = x_input, None
         if self.feed_forward_macaron is not None:
-            x = ffn_block(self.norm_ff_macaron, self.feed_forward_macaron, x, self.ff_scale)
-        x = mha_block(self.norm_mha, self.self_attn, x, None, pos_emb, mask)
+            x = ffn_block(self.norm_ff_macaron, self.feed_forward_macaron, x, self.ff_scale, p)
+        x = mha_block(self.norm_mha, self.self_attn, x, None, pos_emb, mask, p_out=p)
         if self.conv_module is not None:
-            x = conv_block(self.norm_conv, self.conv_module, x)
-        x = ffn_block(self.norm_ff, self.feed_forward, x, self.ff_scale)
+            x = conv_block(self.norm_conv, self.conv_module, x, p)
+        x = ffn_block(self.norm_ff, self.feed_forward, x, self.ff_scale, p)
         if self.conv_module is not None:
             x = self.norm_final(x)
         if pos_emb is not None:
@@ -364,9 +368,9 @@ class TransformerEncoderLayer(torch.nn.Module):
 
     def forward(self, x, mask, cache=None):
         assert cache is None
-        _no_dropout(self, self.dropout_rate)
-        x = mha_block(self.norm1, self.self_attn, x, None, None, mask)
-        x = ffn_block(self.norm2, self.feed_forward, x, 1.0)
+        p = self.dropout_rate
+        x = mha_block(self.norm1, self.self_attn, x, None, None, mask, p_out=p)
+        x = ffn_block(self.norm2, self.feed_forward, x, 1.0, p)
         return x, mask
 
 
@@ -489,15 +493,15 @@ class DecoderLayer(torch.nn.Module):
         self.concat_after = concat_after
 
     def forward(self, tgt, tgt_mask, memory, memory_mask, cache=None):
-        _no_dropout(self, self.dropout_rate)
+        p = self.dropout_rate
         if cache is None:
-            x = mha_block(self.norm1, self.self_attn, tgt, None, None, tgt_mask)
+            x = mha_block(self.norm1, self.self_attn, tgt, None, None, tgt_mask, p_out=p)
         else:
             assert cache.shape == (tgt.shape[0], tgt.shape[1] - 1, self.size)
             q_mask = None if tgt_mask is None else tgt_mask[:, -1:, :]
-            x = mha_block(self.norm1, self.self_attn, tgt, None, None, q_mask, last_query_only=True)
-        x = mha_block(self.norm2, self.src_attn, x, memory, None, memory_mask)
-        x = ffn_block(self.norm3, self.feed_forward, x, 1.0)
+            x = mha_block(self.norm1, self.self_attn, tgt, None, None, q_mask, last_query_only=True, p_out=p)
+        x = mha_block(self.norm2, self.src_attn, x, memory, None, memory_mask, p_out=p)
+        x = ffn_block(self.norm3, self.feed_forward, x, 1.0, p)
         if cache is not None:
             x = torch.cat([cache, x], dim=1)
         return x, tgt_mask, memory, memory_mask
@@ -540,9 +544,9 @@ class Decoder(torch.nn.Module):
 
     def _embed(self, tgt, pos_offset=0):
         pos = self.embed[1]
-        _no_dropout(pos, pos.dropout_rate)
         pos.extend_pe(tgt.size(1) + pos_offset, self.embed[0].weight.device)
-        return F_.EmbedPEFn.apply(tgt, self.embed[0].weight, pos.pe, pos.xscale, pos_offset)
+        y = F_.EmbedPEFn.apply(tgt, self.embed[0].weight, pos.pe, pos.xscale, pos_offset)
+        return F_.dropout(y, pos.dropout_rate, pos.salt, pos.training)
 
     def forward(self, tgt, tgt_mask, memory, memory_mask):
         x = self._embed(tgt)
@@ -645,17 +649,18 @@ class CTC(torch.nn.Module):
         self.ctc_type = ctc_type
         self.ignore_id = -1
         self.reduce = reduce
+        self.salt = ops.new_salt()
         if not reduce:
             raise NotImplementedError("reduce=False is not on the path")
 
-    def logits(self, hs_pad):
-        if self.dropout_rate > 0.0:   # ctc.py:85 applies F.dropout even in eval mode
-            raise NotImplementedError("CTC dropout_rate > 0 not wired into the HIP path yet")
+    def logits(self, hs_pad, loss_path=False):
+        if loss_path:   # ctc.py:85: F.dropout(hs_pad, p) without `training=` => active in eval mode too
+            hs_pad = F_.dropout(hs_pad, self.dropout_rate, self.salt, True)
         return F_.LinearFn.apply(hs_pad, self.ctc_lo.weight, self.ctc_lo.bias)
 
     def forward(self, hs_pad, hlens, ys_pad):
         """hs_pad (B,T,D); hlens list/tensor of valid frames; ys_pad (B,L) int64 padded with -1."""
-        ys_hat = self.logits(hs_pad)
+        ys_hat = self.logits(hs_pad, loss_path=True)
         if isinstance(hlens, torch.Tensor):
             hl = hlens.to(device=hs_pad.device, dtype=torch.int32)
         else:

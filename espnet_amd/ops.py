@@ -394,10 +394,40 @@ def posenc(x, pe, T, scale):
     return out
 
 
-def dropout(x, p, seed):
-    y = torch.empty_like(x)
-    check(_lib.lib().eamd_dropout(ptr(x), ptr(y), C.c_int64(x.numel()), C.c_float(p), C.c_uint64(seed),
-                                  stream_ptr()), "eamd_dropout")
+_rng = {"step": None, "salt": 0}
+
+
+def rng_state(device):
+    """device-resident step counter that seeds every dropout mask of the current training step"""
+    st = _rng["step"]
+    if st is None or st.device != torch.device(device):
+        st = torch.zeros(1, device=device, dtype=torch.int64)
+        _rng["step"] = st
+    return st
+
+
+def rng_advance(device):
+    check(_lib.lib().eamd_rng_advance(ptr(rng_state(device)), stream_ptr()), "eamd_rng_advance")
+
+
+def manual_seed(seed, device="cuda"):
+    rng_state(device).fill_(int(seed))
+
+
+def new_salt():
+    """unique id for a dropout site (module instance x use); masks of different sites are independent"""
+    _rng["salt"] += 1
+    return _rng["salt"]
+
+
+def dropout(x, p, salt, act=ACT_NONE, out_dtype=None):
+    """y = act(x) * mask / (1-p); calling it again with the same salt in the same step re-applies the
+    same mask (that is the backward pass).  x fp32 or bf16."""
+    out_dtype = x.dtype if out_dtype is None else out_dtype
+    y = torch.empty(x.shape, device=x.device, dtype=out_dtype)
+    check(_lib.lib().eamd_dropout(ptr(x), ptr(y), C.c_int64(x.numel()), C.c_float(p), ptr(rng_state(x.device)),
+                                  C.c_uint64(salt), act, 1 if x.dtype == torch.bfloat16 else 0,
+                                  1 if out_dtype == torch.bfloat16 else 0, stream_ptr()), "eamd_dropout")
     return y
 
 

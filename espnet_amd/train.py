@@ -180,6 +180,7 @@ def train_step(model, flat, opt, batch, reducer=None, loss_scale=1.0):
     """One optimizer step: zero grads, forward, backward (+ overlapped all-reduce), clip, Adam.
     `batch` = (xs_pad, ilens, ys_pad) or a dict prepared by model.prepare()."""
     flat.zero_grad()
+    ops.rng_advance(flat.data.device)      # new dropout masks for this step (device counter: graph-replay safe)
     if reducer is not None:
         reducer.begin()
     loss = model.forward_core(batch) if isinstance(batch, dict) else model(*batch)

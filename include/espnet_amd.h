@@ -157,7 +157,12 @@ int eamd_posenc(const float* x, const float* pe, float* out, int64_t rows, int T
                 void* stream);
 int eamd_permute4(const float* src, float* dst, int d0, int d1, int d2, int d3, int64_t s0, int64_t s1,
                   int64_t s2, int64_t s3, int accumulate, void* stream);
-int eamd_dropout(const float* x, float* y, int64_t n, float p, uint64_t seed, void* stream);
+/* y = act(x) * keep / (1-p), keep(i) = hash(step_dev[0], salt, i) >= p; the same call on a gradient applies the
+ * same mask (backward).  step_dev: device counter advanced once per training step (graph-replay safe).
+ * reference: nn.Dropout call sites (conformer/encoder_layer.py:55, positionwise_feed_forward.py:27, ctc.py:85). */
+int eamd_dropout(const void* x, void* y, int64_t n, float p, const uint64_t* step_dev, uint64_t salt, int act,
+                 int in_bf16, int out_bf16, void* stream);
+int eamd_rng_advance(uint64_t* step_dev, void* stream);
 
 /* ------------------------------------------------------------------------------------------
  * Conformer convolution module + first subsampling convolution (channels-last activations).

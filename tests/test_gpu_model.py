@@ -305,3 +305,85 @@ def test_espnet2_model_golden():
     assert abs(float(stats["acc"]) - float(p["acc"])) < 1e-6
     loss.backward()
     check_grads(model, grads, tol=1e-3)
+
+
+# ---------------------------------------------------------------------------------------------
+# dropout: RNG streams cannot match torch's generator, so the checks are (i) mask statistics and
+# determinism, (ii) forward/backward consistency of the fused blocks against a float64 torch graph that
+# uses the masks extracted from our own kernel, (iii) a dropout-0.1 training run that learns.
+# ---------------------------------------------------------------------------------------------
+def _mask(shape, p, salt, dtype=torch.float32):
+    from espnet_amd import ops
+    return ops.dropout(torch.ones(shape, device=DEV, dtype=dtype), p, salt).double().cpu()   # = keep / (1-p)
+
+
+def test_dropout_mask_statistics():
+    from espnet_amd import ops
+    ops.manual_seed(7)
+    x = torch.ones(1 << 20, device=DEV)
+    y = ops.dropout(x, 0.1, 11)
+    keep = float((y != 0).float().mean())
+    assert abs(keep - 0.9) < 2e-3, keep
+    assert torch.allclose(y[y != 0], torch.full_like(y[y != 0], 1 / 0.9))
+    assert torch.equal(y, ops.dropout(x, 0.1, 11))                 # same step + salt => same mask (backward)
+    assert not torch.equal(y, ops.dropout(x, 0.1, 12))             # other site => other mask
+    ops.rng_advance(DEV)
+    assert not torch.equal(y, ops.dropout(x, 0.1, 11))             # next training step => new mask
+    yb = ops.dropout(x.to(torch.bfloat16), 0.5, 3)
+    assert yb.dtype == torch.bfloat16 and abs(float((yb != 0).float().mean()) - 0.5) < 3e-3
+
+
+def test_ffn_block_dropout_consistency():
+    from espnet_amd import ops
+    from espnet_amd.nets import modules as M
+    ops.manual_seed(3)
+    torch.manual_seed(0)
+    ff = M.PositionwiseFeedForward(64, 96, 0.3, M.Swish()).to(DEV).train()
+    norm = M.LayerNorm(64).to(DEV)
+    x = torch.randn(2, 9, 64, device=DEV, requires_grad=True)
+    y = M.ffn_block(norm, ff, x, 0.5, p_out=0.2)
+    gy = torch.randn_like(y)
+    y.backward(gy)
+    m_in, m_out = _mask((18, 96), 0.3, ff.salt_in), _mask((18, 64), 0.2, ff.salt_out)
+    xd = x.detach().double().cpu().requires_grad_(True)
+    pr = {k: v.detach().double().cpu().requires_grad_(True) for k, v in
+          dict(ff.named_parameters(), **{"ln." + k: v for k, v in norm.named_parameters()}).items()}
+    xn = torch.nn.functional.layer_norm(xd, (64,), pr["ln.weight"], pr["ln.bias"], 1e-12).reshape(18, 64)
+    z = xn @ pr["w_1.weight"].t() + pr["w_1.bias"]
+    h = z * torch.sigmoid(z) * m_in
+    br = (h @ pr["w_2.weight"].t() + pr["w_2.bias"]) * m_out
+    yr = xd + 0.5 * br.reshape(2, 9, 64)
+    report("ffn dropout fwd", y, yr, 2e-6)
+    yr.backward(gy.double().cpu())
+    report("ffn dropout dx", x.grad, xd.grad, 2e-5)
+    for k, v in ff.named_parameters():
+        report("ffn dropout d" + k, v.grad, pr[k].grad, 2e-5)
+
+
+def test_training_with_dropout_learns():
+    """12 steps of the real training loop (flat arenas, Adam/Noam, dropout 0.1): loss decreases, stays finite."""
+    import espnet_amd
+    from espnet_amd import ops, train
+    from espnet_amd.nets.e2e_asr_conformer import E2E
+    for prec in ("fp32", "bf16"):
+        espnet_amd.set_precision(prec)
+        torch.manual_seed(0)
+        ops.manual_seed(5)
+        ns = argparse.Namespace(adim=64, aheads=4, elayers=2, eunits=128, dlayers=1, dunits=128, mtlalpha=0.3,
+                                lsm_weight=0.1, dropout_rate=0.1, transformer_length_normalized_loss=False,
+                                transformer_encoder_pos_enc_layer_type="rel_pos",
+                                transformer_encoder_selfattn_layer_type="rel_selfattn", macaron_style=True,
+                                use_cnn_module=True, cnn_module_kernel=15)
+        model = E2E(40, 30, ns).to(DEV).train()
+        model.sync_report = False
+        flat = train.FlatParams(model)
+        opt = train.NoamAdam(flat, mode="const", base_lr=2e-3, max_grad_norm=5.0)
+        g = torch.Generator().manual_seed(1)
+        xs, ilens = torch.randn(4, 80, 40, generator=g), [80, 70, 66, 50]
+        ys = torch.randint(1, 29, (4, 6), generator=g)
+        batch = model.prepare(xs, ilens, ys)
+        losses = [float(train.train_step(model, flat, opt, batch)) for _ in range(12)]
+        print(f"[parity] dropout-0.1 training ({prec}): loss {losses[0]:.3f} -> {losses[-1]:.3f}, skipped={opt.stats()['skipped']}")
+        assert all(math.isfinite(v) for v in losses) and losses[-1] < 0.8 * losses[0]
+        assert opt.stats()["step"] == 12 and opt.stats()["skipped"] == 0
+    espnet_amd.set_precision("fp32")
