@@ -162,6 +162,16 @@ def main():
             e1.record()
             ev.append((e0, e1))
 
+        # stream-event bracket overhead (record + timestamp granularity), measured on empty brackets and
+        # subtracted from every GEMM bracket so that the average agrees with the rocprofv3 kernel trace
+        cal = []
+        for _ in range(200):
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            e1.record()
+            cal.append((e0, e1))
+        torch.cuda.synchronize()
+        empty = sorted(e0.elapsed_time(e1) for e0, e1 in cal)[len(cal) // 2]
         ops.gemm = timed_gemm
         rd, train_red = reducer, None
         try:
@@ -173,7 +183,7 @@ def main():
             ops.gemm = orig
             if rd is not None:
                 train.attach_reducer(rd)
-        gemm_ms = sum(e0.elapsed_time(e1) for e0, e1 in ev)
+        gemm_ms = sum(max(0.0, e0.elapsed_time(e1) - empty) for e0, e1 in ev)
         n = len(ev)
         flop_per_launch = STEP_FLOP * (B / 32.0) * (T / 1000.0) / n
         avg_ms = gemm_ms / n
@@ -188,7 +198,8 @@ def main():
                     frac=round(ach / PEAK_TFLOPS[a.precision], 4), traffic=traffic,
                     traffic_note="HBM bytes per launch, rocprofv3 PMC (FETCH_SIZE doubled + WRITE_SIZE), profiles/r01_pmc*",
                     kernel="gemm_kernel<*> (all MFMA contractions)", launches_per_step=n,
-                    avg_launch_us=round(avg_ms * 1e3, 2), gemm_ms_per_step=round(gemm_ms, 3))
+                    avg_launch_us=round(avg_ms * 1e3, 2), gemm_ms_per_step=round(gemm_ms, 3),
+                    event_overhead_us=round(empty * 1e3, 2))
 
     cpu = None
     if rank == 0 and world == 1 and not a.no_cpu_baseline:

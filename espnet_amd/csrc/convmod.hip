@@ -14,11 +14,18 @@ constexpr int KMAX = 32;
 // y[b,t,c] =           sum_k w[c,k] * x[b, t - k + pad, c]         (flip=1, input gradient)
 // One thread = one channel x TT consecutive frames: the K taps stay in registers and the input
 // window (TT + K - 1 values) is read once, lanes along C (coalesced 256-B rows).
-constexpr int TT = 8;
+// The block's 256 x K taps are fetched with coalesced loads and handed out through LDS (a direct
+// w[c*K + k] read is a 64-way scattered access per tap).
+constexpr int TT = 16;
 __global__ __launch_bounds__(256) void dwconv_kernel(const float* __restrict__ x, const float* __restrict__ w,
                                                      const float* __restrict__ bias, float* __restrict__ y,
                                                      int B, int T, int C, int K, int pad, int flip) {
-  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  __shared__ float wl[256 * KMAX];
+  const int c0 = blockIdx.x * blockDim.x;
+  const int c = c0 + threadIdx.x;
+  const int nw = min(256, C - c0) * K;
+  for (int i = threadIdx.x; i < nw; i += blockDim.x) wl[i] = w[(long)c0 * K + i];
+  __syncthreads();
   if (c >= C) return;
   const int nchunk = (T + TT - 1) / TT;
   const int b = blockIdx.y / nchunk;
@@ -27,7 +34,7 @@ __global__ __launch_bounds__(256) void dwconv_kernel(const float* __restrict__ x
 #pragma unroll
   for (int k = 0; k < KMAX; ++k) {
     int kk = flip ? K - 1 - k : k;          // flipped taps turn the gradient into the same correlation
-    wr[k] = (k < K) ? w[(long)c * K + kk] : 0.f;
+    wr[k] = (k < K) ? wl[threadIdx.x * K + kk] : 0.f;
   }
   const float bv = (bias && !flip) ? bias[c] : 0.f;
   float acc[TT];
@@ -108,44 +115,117 @@ __global__ __launch_bounds__(256) void dwconv_bwd_w_kernel(const float* __restri
 }
 
 // ---- BatchNorm1d over [M, C] -----------------------------------------------------------------
-// stage 1: per (slab, channel) count / mean / M2 (two passes over the slab, cache resident)
-__global__ __launch_bounds__(256) void bn_partial_kernel(const float* __restrict__ x, float* __restrict__ part,
-                                                         long M, int C, int rows_per_block) {
-  const int c = blockIdx.x * blockDim.x + threadIdx.x;
-  if (c >= C) return;
-  const long r0 = (long)blockIdx.y * rows_per_block;
-  const long r1 = min(M, r0 + (long)rows_per_block);
-  float s = 0.f;
-  for (long r = r0; r < r1; ++r) s += x[r * C + c];
-  const float n = (float)(r1 - r0);
-  const float mean = s / n;
-  float m2 = 0.f;
-  for (long r = r0; r < r1; ++r) { float d = x[r * C + c] - mean; m2 += d * d; }
-  float* p = part + ((long)blockIdx.y * 3) * C;
-  p[c] = n; p[C + c] = mean; p[2 * C + c] = m2;
+// Statistics are reduced in two launches sized for latency, not for a serial sweep: a slab is
+// BN_R * (256 / (C/4)) rows; every thread pulls its BN_R rows of one float4 channel group into
+// registers with all loads in flight, forms (n, mean, M2) there (exact two-pass, no re-read), and the
+// row-subgroups of the block are merged with Chan's update through LDS.  The finalize block merges the
+// slab partials the same way (fixed order => bitwise reproducible).
+constexpr int BN_R = 16;
+struct BnGeom { int cq, rs, slab_rows; };
+__host__ __device__ inline BnGeom bn_geom(int C) {
+  BnGeom g;
+  g.cq = C / 4;                          // float4 channel groups (C % 4 == 0, C <= 1024)
+  g.rs = 256 / g.cq;                     // row-subgroups per 256-thread block
+  g.slab_rows = BN_R * g.rs;
+  return g;
 }
-// stage 2: Chan combination in slab order (deterministic); writes mean, rstd, updates running stats
-__global__ void bn_finalize_kernel(const float* __restrict__ part, int nslab, int C, float eps, float momentum,
-                                   float* __restrict__ mean_out, float* __restrict__ rstd_out,
-                                   float* __restrict__ running_mean, float* __restrict__ running_var) {
-  const int c = blockIdx.x * blockDim.x + threadIdx.x;
-  if (c >= C) return;
-  float n = 0.f, mean = 0.f, m2 = 0.f;
-  for (int s = 0; s < nslab; ++s) {
-    const float* p = part + (long)s * 3 * C;
-    float nb = p[c], mb = p[C + c], m2b = p[2 * C + c];
-    float nt = n + nb;
-    float d = mb - mean;
-    mean += d * nb / nt;
-    m2 += m2b + d * d * n * nb / nt;
-    n = nt;
+__device__ __forceinline__ void chan_merge(float& n, float& mean, float& m2, float nb, float mb, float m2b) {
+  const float nt = n + nb;
+  if (nt > 0.f) {
+    const float d = mb - mean;
+    const float f = nb / nt;
+    mean += d * f;
+    m2 += m2b + d * d * n * f;
   }
-  const float var = m2 / n;
-  mean_out[c] = mean;
-  rstd_out[c] = rsqrtf(var + eps);
-  if (running_mean) {
-    running_mean[c] = (1.f - momentum) * running_mean[c] + momentum * mean;
-    running_var[c] = (1.f - momentum) * running_var[c] + momentum * (n > 1.f ? m2 / (n - 1.f) : var);
+  n = nt;
+}
+
+__global__ __launch_bounds__(256) void bn_partial_kernel(const float* __restrict__ x, float* __restrict__ part,
+                                                         long M, int C) {
+  __shared__ float4 sh_mean[256], sh_m2[256];
+  __shared__ float sh_n[256];
+  const BnGeom g = bn_geom(C);
+  const int t = threadIdx.x;
+  const int q = t % g.cq, sub = t / g.cq;
+  const bool live = sub < g.rs;
+  const long r0 = (long)blockIdx.x * g.slab_rows + sub;
+  float4 v[BN_R];
+  float n = 0.f;
+  float4 sum = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+  for (int i = 0; i < BN_R; ++i) {
+    const long r = r0 + (long)i * g.rs;
+    const bool ok = live && r < M;
+    v[i] = ok ? reinterpret_cast<const float4*>(x + r * C)[q] : make_float4(0.f, 0.f, 0.f, 0.f);
+    n += ok ? 1.f : 0.f;
+    sum.x += v[i].x; sum.y += v[i].y; sum.z += v[i].z; sum.w += v[i].w;
+  }
+  const float inv = n > 0.f ? 1.f / n : 0.f;
+  float4 mean = make_float4(sum.x * inv, sum.y * inv, sum.z * inv, sum.w * inv);
+  float4 m2 = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+  for (int i = 0; i < BN_R; ++i) {
+    const bool ok = live && (r0 + (long)i * g.rs) < M;
+    if (ok) {
+      float a = v[i].x - mean.x, b = v[i].y - mean.y, c = v[i].z - mean.z, d = v[i].w - mean.w;
+      m2.x += a * a; m2.y += b * b; m2.z += c * c; m2.w += d * d;
+    }
+  }
+  sh_n[t] = n; sh_mean[t] = mean; sh_m2[t] = m2;
+  __syncthreads();
+  if (sub == 0) {
+    for (int s2 = 1; s2 < g.rs; ++s2) {
+      const int o = s2 * g.cq + q;
+      const float nb = sh_n[o];
+      const float4 mb = sh_mean[o], qb = sh_m2[o];
+      float n0 = n, n1 = n, n2 = n, n3 = n;
+      chan_merge(n0, mean.x, m2.x, nb, mb.x, qb.x);
+      chan_merge(n1, mean.y, m2.y, nb, mb.y, qb.y);
+      chan_merge(n2, mean.z, m2.z, nb, mb.z, qb.z);
+      chan_merge(n3, mean.w, m2.w, nb, mb.w, qb.w);
+      n = n0;
+    }
+    float* p = part + (long)blockIdx.x * 3 * C;
+    reinterpret_cast<float4*>(p)[q] = make_float4(n, n, n, n);
+    reinterpret_cast<float4*>(p + C)[q] = mean;
+    reinterpret_cast<float4*>(p + 2 * C)[q] = m2;
+  }
+}
+// stage 2 (one block of 1024 threads): thread (group gi, channel c) merges slabs gi, gi+G, ... in order,
+// then the G group results are merged in group order; writes mean, rstd, updates running stats
+__global__ __launch_bounds__(1024) void bn_finalize_kernel(const float* __restrict__ part, int nslab, int C,
+                                                           float eps, float momentum, float* __restrict__ mean_out,
+                                                           float* __restrict__ rstd_out,
+                                                           float* __restrict__ running_mean,
+                                                           float* __restrict__ running_var) {
+  __shared__ float sh[3][1024];
+  const int t = threadIdx.x;
+  const int G = 1024 / C > 0 ? 1024 / C : 1;
+  for (int c0 = 0; c0 < C; c0 += 1024) {
+    const int c = c0 + t % (C < 1024 ? C : 1024), gi = t / (C < 1024 ? C : 1024);
+    float n = 0.f, mean = 0.f, m2 = 0.f;
+    if (c < C && gi < G) {
+      for (int s = gi; s < nslab; s += G) {
+        const float* p = part + (long)s * 3 * C;
+        chan_merge(n, mean, m2, p[c], p[C + c], p[2 * C + c]);
+      }
+    }
+    sh[0][t] = n; sh[1][t] = mean; sh[2][t] = m2;
+    __syncthreads();
+    if (gi == 0 && c < C) {
+      for (int g2 = 1; g2 < G; ++g2) {
+        const int o = g2 * C + (c - c0);
+        chan_merge(n, mean, m2, sh[0][o], sh[1][o], sh[2][o]);
+      }
+      const float var = m2 / n;
+      mean_out[c] = mean;
+      rstd_out[c] = rsqrtf(var + eps);
+      if (running_mean) {
+        running_mean[c] = (1.f - momentum) * running_mean[c] + momentum * mean;
+        running_var[c] = (1.f - momentum) * running_var[c] + momentum * (n > 1.f ? m2 / (n - 1.f) : var);
+      }
+    }
+    __syncthreads();
   }
 }
 // y = act((x - mean) * rstd * gamma + beta)
@@ -163,39 +243,86 @@ __global__ void bn_apply_kernel(const float* __restrict__ x, const float* __rest
     if (bf16) y16[i] = eamd_f2bf(z); else y[i] = z;
   }
 }
-// backward stage 1: dz = dy * act'(z); partial sums of dz and dz*xhat per (slab, channel)
+// backward stage 1: dz = dy * act'(z); partial sums of dz and dz*xhat per (slab, channel); same slab
+// geometry as the forward statistics
 __global__ __launch_bounds__(256) void bn_bwd_partial_kernel(const float* __restrict__ dy, const float* __restrict__ x,
                                                              const float* __restrict__ mean,
                                                              const float* __restrict__ rstd,
                                                              const float* __restrict__ gamma,
                                                              const float* __restrict__ beta, float* __restrict__ part,
-                                                             long M, int C, int rows_per_block, int act) {
-  const int c = blockIdx.x * blockDim.x + threadIdx.x;
-  if (c >= C) return;
-  const long r0 = (long)blockIdx.y * rows_per_block;
-  const long r1 = min(M, r0 + (long)rows_per_block);
-  const float mu = mean[c], rs = rstd[c], g = gamma[c], be = beta[c];
-  float s1 = 0.f, s2 = 0.f;
-  for (long r = r0; r < r1; ++r) {
-    float xh = (x[r * C + c] - mu) * rs;
-    float z = xh * g + be;
-    float d = dy[r * C + c];
-    if (act == EAMD_ACT_SWISH) d *= eamd_dswish(z);
-    else if (act == EAMD_ACT_RELU) d = z > 0.f ? d : 0.f;
-    s1 += d; s2 += d * xh;
+                                                             long M, int C, int act) {
+  __shared__ float4 sh1[256], sh2[256];
+  const BnGeom g = bn_geom(C);
+  const int t = threadIdx.x;
+  const int q = t % g.cq, sub = t / g.cq;
+  const bool live = sub < g.rs;
+  const long r0 = (long)blockIdx.x * g.slab_rows + sub;
+  float4 mu = make_float4(0.f, 0.f, 0.f, 0.f), rs = mu, gm = mu, be = mu;
+  if (live) {
+    mu = reinterpret_cast<const float4*>(mean)[q]; rs = reinterpret_cast<const float4*>(rstd)[q];
+    gm = reinterpret_cast<const float4*>(gamma)[q]; be = reinterpret_cast<const float4*>(beta)[q];
   }
-  float* p = part + (long)blockIdx.y * 2 * C;
-  p[c] = s1; p[C + c] = s2;
+  float4 xv[BN_R], dv[BN_R];
+#pragma unroll
+  for (int i = 0; i < BN_R; ++i) {
+    const long r = r0 + (long)i * g.rs;
+    const bool ok = live && r < M;
+    xv[i] = ok ? reinterpret_cast<const float4*>(x + r * C)[q] : make_float4(0.f, 0.f, 0.f, 0.f);
+    dv[i] = ok ? reinterpret_cast<const float4*>(dy + r * C)[q] : make_float4(0.f, 0.f, 0.f, 0.f);
+  }
+  float4 s1 = make_float4(0.f, 0.f, 0.f, 0.f), s2 = s1;
+#pragma unroll
+  for (int i = 0; i < BN_R; ++i) {
+    const float* xp = &xv[i].x; const float* dp = &dv[i].x;
+    const float* mp = &mu.x; const float* rp = &rs.x; const float* gp = &gm.x; const float* bp = &be.x;
+    float* a1 = &s1.x; float* a2 = &s2.x;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const float xh = (xp[e] - mp[e]) * rp[e];
+      const float z = xh * gp[e] + bp[e];
+      float d = dp[e];   // rows past M hold dy = 0 => contribute nothing
+      if (act == EAMD_ACT_SWISH) d *= eamd_dswish(z);
+      else if (act == EAMD_ACT_RELU) d = z > 0.f ? d : 0.f;
+      a1[e] += d; a2[e] += d * xh;
+    }
+  }
+  sh1[t] = s1; sh2[t] = s2;
+  __syncthreads();
+  if (sub == 0) {
+    for (int k = 1; k < g.rs; ++k) {
+      const float4 a = sh1[k * g.cq + q], b = sh2[k * g.cq + q];
+      s1.x += a.x; s1.y += a.y; s1.z += a.z; s1.w += a.w;
+      s2.x += b.x; s2.y += b.y; s2.z += b.z; s2.w += b.w;
+    }
+    float* p = part + (long)blockIdx.x * 2 * C;
+    reinterpret_cast<float4*>(p)[q] = s1;
+    reinterpret_cast<float4*>(p + C)[q] = s2;
+  }
 }
-// backward stage 2: reduce partials in slab order -> sums[2][C]; accumulate dgamma/dbeta
-__global__ void bn_bwd_finalize_kernel(const float* __restrict__ part, int nslab, int C, float* __restrict__ sums,
-                                       float* __restrict__ dgamma, float* __restrict__ dbeta) {
-  const int c = blockIdx.x * blockDim.x + threadIdx.x;
-  if (c >= C) return;
-  float s1 = 0.f, s2 = 0.f;
-  for (int s = 0; s < nslab; ++s) { s1 += part[(long)s * 2 * C + c]; s2 += part[(long)s * 2 * C + C + c]; }
-  sums[c] = s1; sums[C + c] = s2;
-  dbeta[c] += s1; dgamma[c] += s2;
+// backward stage 2 (one block of 1024 threads): reduce partials in a fixed order -> sums[2][C];
+// accumulate dgamma/dbeta
+__global__ __launch_bounds__(1024) void bn_bwd_finalize_kernel(const float* __restrict__ part, int nslab, int C,
+                                                               float* __restrict__ sums, float* __restrict__ dgamma,
+                                                               float* __restrict__ dbeta) {
+  __shared__ float sh[2][1024];
+  const int t = threadIdx.x;
+  const int W = C < 1024 ? C : 1024;
+  const int G = 1024 / W;
+  for (int c0 = 0; c0 < C; c0 += 1024) {
+    const int c = c0 + t % W, gi = t / W;
+    float s1 = 0.f, s2 = 0.f;
+    if (c < C && gi < G) {
+      for (int s = gi; s < nslab; s += G) { s1 += part[(long)s * 2 * C + c]; s2 += part[(long)s * 2 * C + C + c]; }
+    }
+    sh[0][t] = s1; sh[1][t] = s2;
+    __syncthreads();
+    if (gi == 0 && c < C) {
+      for (int g2 = 1; g2 < G; ++g2) { s1 += sh[0][g2 * W + (c - c0)]; s2 += sh[1][g2 * W + (c - c0)]; }
+      sums[c] = s1; sums[C + c] = s2;
+      dbeta[c] += s1; dgamma[c] += s2;
+    }
+    __syncthreads();
+  }
 }
 // backward stage 3: dx = gamma*rstd*(dz - s1/M - xhat*s2/M)   (training-mode statistics)
 __global__ void bn_bwd_apply_kernel(const float* __restrict__ dy, const float* __restrict__ x,
@@ -325,29 +452,23 @@ int eamd_dwconv_bwd_w(const float* dy, const float* x, float* dw, float* db, int
 }
 
 /* workspace: 3*C*nslab floats where nslab = eamd_bn_nslab(M, C) */
+static bool bn_shape_ok(int C) { return C >= 4 && C <= 1024 && C % 4 == 0; }
 int eamd_bn_nslab(int64_t M, int C) {
-  int gx = (C + 255) / 256;
-  long want = 96 / gx; if (want < 1) want = 1;
-  long rpb = (M + want - 1) / want; if (rpb < 16) rpb = 16;
-  return (int)((M + rpb - 1) / rpb);
-}
-static long bn_rpb(long M, int C) {
-  int gx = (C + 255) / 256;
-  long want = 96 / gx; if (want < 1) want = 1;
-  long rpb = (M + want - 1) / want; if (rpb < 16) rpb = 16;
-  return rpb;
+  if (!bn_shape_ok(C) || M <= 0) return 0;
+  const BnGeom g = bn_geom(C);
+  return (int)((M + g.slab_rows - 1) / g.slab_rows);
 }
 
 int eamd_bn_stats(const float* x, float* workspace, float* mean, float* rstd, float* running_mean,
                   float* running_var, int64_t M, int C, float eps, float momentum, void* stream) {
   if (!x || !workspace || !mean || !rstd || M <= 0 || C <= 0) return EAMD_EINVAL;
+  if (!bn_shape_ok(C)) return EAMD_EUNSUPPORTED;   // channel counts 4..1024, multiples of 4
+  if ((uintptr_t)x & 15) return EAMD_EINVAL;
   hipStream_t s = (hipStream_t)stream;
-  int gx = (C + 255) / 256;
-  long rpb = bn_rpb(M, C);
-  int nslab = (int)((M + rpb - 1) / rpb);
-  hipLaunchKernelGGL(bn_partial_kernel, dim3(gx, nslab), dim3(256), 0, s, x, workspace, (long)M, C, (int)rpb);
+  const int nslab = eamd_bn_nslab(M, C);
+  hipLaunchKernelGGL(bn_partial_kernel, dim3(nslab), dim3(256), 0, s, x, workspace, (long)M, C);
   EAMD_LAUNCH_CHECK();
-  hipLaunchKernelGGL(bn_finalize_kernel, dim3(gx), dim3(256), 0, s, workspace, nslab, C, eps, momentum, mean, rstd,
+  hipLaunchKernelGGL(bn_finalize_kernel, dim3(1), dim3(1024), 0, s, workspace, nslab, C, eps, momentum, mean, rstd,
                      running_mean, running_var);
   EAMD_LAUNCH_CHECK();
   return EAMD_OK;
@@ -368,15 +489,16 @@ int eamd_bn_bwd(const float* dy, const float* x, const float* mean, const float*
                 int act, int training, void* stream) {
   if (!dy || !x || !mean || !rstd || !gamma || !beta || !workspace || !dx || !dgamma || !dbeta || M <= 0 || C <= 0)
     return EAMD_EINVAL;
+  if (!bn_shape_ok(C)) return EAMD_EUNSUPPORTED;
+  if (((uintptr_t)x | (uintptr_t)dy | (uintptr_t)mean | (uintptr_t)rstd | (uintptr_t)gamma | (uintptr_t)beta) & 15)
+    return EAMD_EINVAL;
   hipStream_t s = (hipStream_t)stream;
-  int gx = (C + 255) / 256;
-  long rpb = bn_rpb(M, C);
-  int nslab = (int)((M + rpb - 1) / rpb);
+  const int nslab = eamd_bn_nslab(M, C);
   float* sums = workspace + (long)nslab * 2 * C;
-  hipLaunchKernelGGL(bn_bwd_partial_kernel, dim3(gx, nslab), dim3(256), 0, s, dy, x, mean, rstd, gamma, beta,
-                     workspace, (long)M, C, (int)rpb, act);
+  hipLaunchKernelGGL(bn_bwd_partial_kernel, dim3(nslab), dim3(256), 0, s, dy, x, mean, rstd, gamma, beta,
+                     workspace, (long)M, C, act);
   EAMD_LAUNCH_CHECK();
-  hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(gx), dim3(256), 0, s, workspace, nslab, C, sums, dgamma, dbeta);
+  hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(1), dim3(1024), 0, s, workspace, nslab, C, sums, dgamma, dbeta);
   EAMD_LAUNCH_CHECK();
   hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(grid_for(M * C)), dim3(256), 0, s, dy, x, mean, rstd, gamma, beta,
                      sums, dx, (long)M, C, act, training);

@@ -117,7 +117,9 @@ __device__ __forceinline__ unsigned relu2(unsigned w) {
 __device__ __forceinline__ uint4 swish8(uint4 v) { return make_uint4(swish2(v.x), swish2(v.y), swish2(v.z), swish2(v.w)); }
 __device__ __forceinline__ uint4 relu8(uint4 v) { return make_uint4(relu2(v.x), relu2(v.y), relu2(v.z), relu2(v.w)); }
 
-template <int BM, int BN, bool TA, bool TB, bool FAST, bool GAT>
+// ACT: prologue activations (a_act / b_act) compiled in; the hot instantiations leave them out so the
+// steady-state loop carries no transcendental code and no branches around it.
+template <int BM, int BN, bool TA, bool TB, bool FAST, bool GAT, bool ACT>
 __global__ __launch_bounds__(NT_) void gemm_bf16_kernel(const eamd_gemm_t p) {
   constexpr int WM = BM / 2, WN = BN / 2;
   constexpr int MT = WM / 16, NTL = WN / 16;
@@ -178,6 +180,24 @@ __global__ __launch_bounds__(NT_) void gemm_bf16_kernel(const eamd_gemm_t p) {
     if constexpr (TB) { b_r[i] = t / CPR_B + RPP_B * i; b_c[i] = t % CPR_B; }
     else              { b_r[i] = t / 8 + 32 * i;        b_c[i] = t % 8; }
   }
+  // FAST staging reads through clamped coordinates: rows / column chunks past the M or N edge re-read
+  // the last valid one.  Whatever they hold only reaches output rows / columns that the epilogue never
+  // stores, so full K-tiles need no masking at all; only the ragged last K-tile is masked (to zero).
+  long a_off[NCA], b_off[NCB];
+  if constexpr (FAST && !gat) {
+#pragma unroll
+    for (int i = 0; i < NCA; ++i) {
+      if constexpr (!TA) a_off[i] = (long)min(m0 + a_r[i], p.M - 1) * p.lda + a_c[i] * 8;
+      else a_off[i] = (long)a_r[i] * p.lda + min(m0 + a_c[i] * 8, (p.M - 1) & ~7);
+    }
+  }
+  if constexpr (FAST) {
+#pragma unroll
+    for (int i = 0; i < NCB; ++i) {
+      if constexpr (!TB) b_off[i] = (long)min(n0 + b_r[i], p.N - 1) * p.ldb + b_c[i] * 8;
+      else b_off[i] = (long)b_r[i] * p.ldb + min(n0 + b_c[i] * 8, (p.N - 1) & ~7);
+    }
+  }
   RowStateB a_rs[NCA];
   if constexpr (gat && !TA) {
 #pragma unroll
@@ -185,7 +205,8 @@ __global__ __launch_bounds__(NT_) void gemm_bf16_kernel(const eamd_gemm_t p) {
   }
   // register ring of DEPTH tile sets: DEPTH-1 tiles of loads stay in flight across the MFMA phases
   // (skinny N=256 GEMMs have ~2 workgroups per CU, so bytes in flight per workgroup hide HBM latency)
-  constexpr int DEPTH = 2;
+  constexpr int DEPTH = BM >= 128 ? 3 : 4;
+  constexpr int UNROLL = DEPTH % 2 ? 2 * DEPTH : DEPTH;   // phases per steady-state iteration (set and LDS buffer both static)
   uint4 ra[DEPTH][NCA], rb[DEPTH][NCB];
   const bool do_colsum = TA && p.colsum != nullptr && !gat && tile_n == 0;
   float cs[8];
@@ -200,8 +221,11 @@ __global__ __launch_bounds__(NT_) void gemm_bf16_kernel(const eamd_gemm_t p) {
     }
   };
 
-  auto load_tile = [&](auto set_c, int kt) __attribute__((always_inline)) {
+  // GUARD = the tile may be the ragged last one (k0 + BK > K): out-of-range chunk starts are redirected
+  // to the start of the row / to row 0 and zeroed at store time.
+  auto load_tile = [&](auto set_c, auto guard_c, int kt) __attribute__((always_inline)) {
     constexpr int SET = decltype(set_c)::value;
+    constexpr bool GUARD = decltype(guard_c)::value;
     const int k0 = kt * BK;
     // ---- A ----
     if constexpr (!TA) {
@@ -209,9 +233,13 @@ __global__ __launch_bounds__(NT_) void gemm_bf16_kernel(const eamd_gemm_t p) {
 #pragma unroll
         for (int i = 0; i < NCA; ++i) {
           const int m = m0 + a_r[i], k = k0 + a_c[i] * 8;
-          const int nv = m < p.M ? min(8, p.K - k) : 0;
-          if constexpr (FAST) ra[SET][i] = load8_fast(A, (long)m * p.lda + k, nv);
-          else ra[SET][i] = load8(A, (long)m * p.lda + k, nv, a_vec);
+          if constexpr (FAST) {
+            const int kk = (GUARD && k >= p.K) ? -a_c[i] * 8 : k0;
+            ra[SET][i] = *reinterpret_cast<const uint4*>(A + a_off[i] + kk);
+          } else {
+            const int nv = m < p.M ? min(8, p.K - k) : 0;
+            ra[SET][i] = load8(A, (long)m * p.lda + k, nv, a_vec);
+          }
         }
       } else {
         const int tap = k0 / p.gather.C, c0 = k0 % p.gather.C;
@@ -226,9 +254,13 @@ __global__ __launch_bounds__(NT_) void gemm_bf16_kernel(const eamd_gemm_t p) {
 #pragma unroll
         for (int i = 0; i < NCA; ++i) {
           const int k = k0 + a_r[i], m = m0 + a_c[i] * 8;
-          const int nv = k < p.K ? min(8, p.M - m) : 0;
-          if constexpr (FAST) ra[SET][i] = load8_fast(A, (long)k * p.lda + m, nv);
-          else ra[SET][i] = load8(A, (long)k * p.lda + m, nv, a_vec);
+          if constexpr (FAST) {
+            const int kk = (GUARD && k >= p.K) ? -a_r[i] : k0;
+            ra[SET][i] = *reinterpret_cast<const uint4*>(A + a_off[i] + (long)kk * p.lda);
+          } else {
+            const int nv = k < p.K ? min(8, p.M - m) : 0;
+            ra[SET][i] = load8(A, (long)k * p.lda + m, nv, a_vec);
+          }
         }
       } else {
         const int c = (m0 % p.gather.C) + a_c[0] * 8;
@@ -245,17 +277,25 @@ __global__ __launch_bounds__(NT_) void gemm_bf16_kernel(const eamd_gemm_t p) {
 #pragma unroll
       for (int i = 0; i < NCB; ++i) {
         const int n = n0 + b_r[i], k = k0 + b_c[i] * 8;
-        const int nv = n < p.N ? min(8, p.K - k) : 0;
-        if constexpr (FAST) rb[SET][i] = load8_fast(B, (long)n * p.ldb + k, nv);
-        else rb[SET][i] = load8(B, (long)n * p.ldb + k, nv, b_vec);
+        if constexpr (FAST) {
+          const int kk = (GUARD && k >= p.K) ? -b_c[i] * 8 : k0;
+          rb[SET][i] = *reinterpret_cast<const uint4*>(B + b_off[i] + kk);
+        } else {
+          const int nv = n < p.N ? min(8, p.K - k) : 0;
+          rb[SET][i] = load8(B, (long)n * p.ldb + k, nv, b_vec);
+        }
       }
     } else {
 #pragma unroll
       for (int i = 0; i < NCB; ++i) {
         const int k = k0 + b_r[i], n = n0 + b_c[i] * 8;
-        const int nv = k < p.K ? min(8, p.N - n) : 0;
-        if constexpr (FAST) rb[SET][i] = load8_fast(B, (long)k * p.ldb + n, nv);
-        else rb[SET][i] = load8(B, (long)k * p.ldb + n, nv, b_vec);
+        if constexpr (FAST) {
+          const int kk = (GUARD && k >= p.K) ? -b_r[i] : k0;
+          rb[SET][i] = *reinterpret_cast<const uint4*>(B + b_off[i] + (long)kk * p.ldb);
+        } else {
+          const int nv = k < p.K ? min(8, p.N - n) : 0;
+          rb[SET][i] = load8(B, (long)k * p.ldb + n, nv, b_vec);
+        }
       }
     }
   };
@@ -267,35 +307,34 @@ __global__ __launch_bounds__(NT_) void gemm_bf16_kernel(const eamd_gemm_t p) {
       if constexpr (!TA) return gather_off_b(p.gather, a_rs[i], k0 / p.gather.C) >= 0 ? 8 : 0;
       else return sm.poff[kt % 8][a_r[i]] >= 0 ? 8 : 0;
     } else if constexpr (!TA) {
-      return (m0 + a_r[i]) < p.M ? min(8, p.K - (k0 + a_c[i] * 8)) : 0;
+      return min(8, p.K - (k0 + a_c[i] * 8));       // K edge only (M edge: clamped rows, never stored)
     } else {
-      return (k0 + a_r[i]) < p.K ? min(8, p.M - (m0 + a_c[i] * 8)) : 0;
+      return (k0 + a_r[i]) < p.K ? 8 : 0;
     }
   };
   auto nv_b = [&](int i, int kt) __attribute__((always_inline)) -> int {
     const int k0 = kt * BK;
-    if constexpr (!TB) return (n0 + b_r[i]) < p.N ? min(8, p.K - (k0 + b_c[i] * 8)) : 0;
-    else return (k0 + b_r[i]) < p.K ? min(8, p.N - (n0 + b_c[i] * 8)) : 0;
+    if constexpr (!TB) return min(8, p.K - (k0 + b_c[i] * 8));
+    else return (k0 + b_r[i]) < p.K ? 8 : 0;
   };
 
-  auto store_tile = [&](auto set_c, int buf, int kt) __attribute__((always_inline)) {
+  auto store_tile = [&](auto set_c, auto guard_c, int buf, int kt) __attribute__((always_inline)) {
     constexpr int SET = decltype(set_c)::value;
-    if constexpr (FAST || gat) {
-      // interior tiles (the vast majority) need no masking at all: one wave-uniform test per tile
-      const int k0 = kt * BK;
-      const bool k_in = k0 + BK <= p.K;
-      if constexpr (gat) {   // gathered rows are either fully valid or fully zero (padding taps / row tail)
+    constexpr bool GUARD = decltype(guard_c)::value;
+    if constexpr (gat) {   // gathered rows are either fully valid or fully zero (padding taps / row tail)
 #pragma unroll
-        for (int i = 0; i < NCA; ++i) {
-          const bool ok = nv_a(i, kt) > 0;
-          ra[SET][i] = make_uint4(ok ? ra[SET][i].x : 0u, ok ? ra[SET][i].y : 0u, ok ? ra[SET][i].z : 0u,
-                                  ok ? ra[SET][i].w : 0u);
-        }
-      } else if (!(k_in && m0 + BM <= p.M)) {
-#pragma unroll
-        for (int i = 0; i < NCA; ++i) ra[SET][i] = mask8(ra[SET][i], nv_a(i, kt));
+      for (int i = 0; i < NCA; ++i) {
+        const bool ok = nv_a(i, kt) > 0;
+        ra[SET][i] = make_uint4(ok ? ra[SET][i].x : 0u, ok ? ra[SET][i].y : 0u, ok ? ra[SET][i].z : 0u,
+                                ok ? ra[SET][i].w : 0u);
       }
-      if (!(k_in && n0 + BN <= p.N)) {
+    }
+    if constexpr (FAST && GUARD) {
+      if (kt * BK + BK > p.K) {      // ragged last K-tile: zero the out-of-range reduction elements
+        if constexpr (!gat) {
+#pragma unroll
+          for (int i = 0; i < NCA; ++i) ra[SET][i] = mask8(ra[SET][i], nv_a(i, kt));
+        }
 #pragma unroll
         for (int i = 0; i < NCB; ++i) rb[SET][i] = mask8(rb[SET][i], nv_b(i, kt));
       }
@@ -309,19 +348,21 @@ __global__ __launch_bounds__(NT_) void gemm_bf16_kernel(const eamd_gemm_t p) {
         cs[6] += bf2f(ra[SET][i].w & 0xffff); cs[7] += bf2f(ra[SET][i].w >> 16);
       }
     }
-    if (p.a_act == EAMD_ACT_SWISH) {
+    if constexpr (ACT) {
+      if (p.a_act == EAMD_ACT_SWISH) {
 #pragma unroll
-      for (int i = 0; i < NCA; ++i) ra[SET][i] = swish8(ra[SET][i]);
-    } else if (p.a_act == EAMD_ACT_RELU) {
+        for (int i = 0; i < NCA; ++i) ra[SET][i] = swish8(ra[SET][i]);
+      } else if (p.a_act == EAMD_ACT_RELU) {
 #pragma unroll
-      for (int i = 0; i < NCA; ++i) ra[SET][i] = relu8(ra[SET][i]);
-    }
-    if (p.b_act == EAMD_ACT_SWISH) {
+        for (int i = 0; i < NCA; ++i) ra[SET][i] = relu8(ra[SET][i]);
+      }
+      if (p.b_act == EAMD_ACT_SWISH) {
 #pragma unroll
-      for (int i = 0; i < NCB; ++i) rb[SET][i] = swish8(rb[SET][i]);
-    } else if (p.b_act == EAMD_ACT_RELU) {
+        for (int i = 0; i < NCB; ++i) rb[SET][i] = swish8(rb[SET][i]);
+      } else if (p.b_act == EAMD_ACT_RELU) {
 #pragma unroll
-      for (int i = 0; i < NCB; ++i) rb[SET][i] = relu8(rb[SET][i]);
+        for (int i = 0; i < NCB; ++i) rb[SET][i] = relu8(rb[SET][i]);
+      }
     }
 #pragma unroll
     for (int i = 0; i < NCA; ++i)
@@ -343,30 +384,32 @@ __global__ __launch_bounds__(NT_) void gemm_bf16_kernel(const eamd_gemm_t p) {
       for (int q = 0; q < DEPTH && q < nkt; ++q) fill_poff(kt_begin + q, (kt_begin + q) % 8);
       __syncthreads();
     }
-    load_tile(std::integral_constant<int, 0>{}, kt_begin);
-    if (nkt > 1) load_tile(std::integral_constant<int, 1>{}, kt_begin + 1);
+    load_tile(std::integral_constant<int, 0>{}, std::true_type{}, kt_begin);
+    if (nkt > 1) load_tile(std::integral_constant<int, 1>{}, std::true_type{}, kt_begin + 1);
     if constexpr (DEPTH == 4) {
-      if (nkt > 2) load_tile(std::integral_constant<int, 2>{}, kt_begin + 2);
+      if (nkt > 2) load_tile(std::integral_constant<int, 2>{}, std::true_type{}, kt_begin + 2);
     }
-    store_tile(std::integral_constant<int, 0>{}, 0, kt_begin);
+    store_tile(std::integral_constant<int, 0>{}, std::true_type{}, 0, kt_begin);
     __syncthreads();
   }
 
   const int fr = lane & 15, fq = lane >> 4;
-  // one K-tile: issue the loads of tile it+2 into the register set tile `it` came from, run the 32
-  // (or 8) MFMAs of tile `it` from LDS, then move tile it+1 (loaded one phase ago) into the other LDS buffer
-  auto phase = [&](auto par_c, auto guard_c, int it) __attribute__((always_inline)) {
-    constexpr int PAR = decltype(par_c)::value;                       // it % DEPTH
+  // one K-tile: issue the loads of tile it+DEPTH-1 into the register set freed one phase ago, run the
+  // 32 (or 8) MFMAs of tile `it` from LDS, then move tile it+1 (loaded DEPTH-2 phases ago) into the other
+  // LDS buffer: DEPTH-2 whole tiles of loads stay in flight behind a counted s_waitcnt.
+  auto phase = [&](auto idx_c, auto guard_c, int it) __attribute__((always_inline)) {
+    constexpr int IDX = decltype(idx_c)::value;                       // it % UNROLL
+    constexpr int PAR = IDX % DEPTH;
     constexpr bool GUARD = decltype(guard_c)::value;
     using load_t = std::integral_constant<int, (PAR + DEPTH - 1) % DEPTH>;   // set freed one phase ago
     using other_t = std::integral_constant<int, (PAR + 1) % DEPTH>;          // tile it+1
-    const int buf = PAR & 1;
+    constexpr int buf = IDX & 1;
     if constexpr (GUARD) {
       if (tgat && it + DEPTH < nkt) fill_poff(kt_begin + it + DEPTH, (kt_begin + it + DEPTH) % 8);
-      if (it + DEPTH - 1 < nkt) load_tile(load_t{}, kt_begin + it + DEPTH - 1);
+      if (it + DEPTH - 1 < nkt) load_tile(load_t{}, guard_c, kt_begin + it + DEPTH - 1);
     } else {
       if constexpr (tgat) fill_poff(kt_begin + it + DEPTH, (kt_begin + it + DEPTH) % 8);
-      load_tile(load_t{}, kt_begin + it + DEPTH - 1);
+      load_tile(load_t{}, guard_c, kt_begin + it + DEPTH - 1);
     }
 #pragma unroll
     for (int ks = 0; ks < 2; ++ks) {
@@ -404,9 +447,9 @@ __global__ __launch_bounds__(NT_) void gemm_bf16_kernel(const eamd_gemm_t p) {
           acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i], bfr[j], acc[i][j], 0, 0, 0);
     }
     if constexpr (GUARD) {
-      if (it + 1 < nkt) store_tile(other_t{}, buf ^ 1, kt_begin + it + 1);
+      if (it + 1 < nkt) store_tile(other_t{}, guard_c, buf ^ 1, kt_begin + it + 1);
     } else {
-      store_tile(other_t{}, buf ^ 1, kt_begin + it + 1);
+      store_tile(other_t{}, guard_c, buf ^ 1, kt_begin + it + 1);
     }
     __syncthreads();
   };
@@ -416,27 +459,26 @@ __global__ __launch_bounds__(NT_) void gemm_bf16_kernel(const eamd_gemm_t p) {
   using T_ = std::true_type;
   using F_ = std::false_type;
   int it = 0;
-  if constexpr (DEPTH == 2) {
-    for (; it + 2 * DEPTH - 2 < nkt; it += 2) {
-      phase(std::integral_constant<int, 0>{}, F_{}, it);
-      phase(std::integral_constant<int, 1>{}, F_{}, it + 1);
+  // unguarded group: its last phase loads tile it + UNROLL + DEPTH - 2, which must not be the (possibly
+  // ragged) last tile
+  for (; it + UNROLL + DEPTH - 1 < nkt; it += UNROLL) {
+    phase(std::integral_constant<int, 0>{}, F_{}, it);
+    phase(std::integral_constant<int, 1>{}, F_{}, it + 1);
+    phase(std::integral_constant<int, 2>{}, F_{}, it + 2);
+    phase(std::integral_constant<int, 3>{}, F_{}, it + 3);
+    if constexpr (UNROLL == 6) {
+      phase(std::integral_constant<int, 4>{}, F_{}, it + 4);
+      phase(std::integral_constant<int, 5>{}, F_{}, it + 5);
     }
-    for (; it < nkt; it += 2) {
-      phase(std::integral_constant<int, 0>{}, T_{}, it);
-      if (it + 1 < nkt) phase(std::integral_constant<int, 1>{}, T_{}, it + 1);
-    }
-  } else {
-    for (; it + 2 * DEPTH - 2 < nkt; it += 4) {
-      phase(std::integral_constant<int, 0>{}, F_{}, it);
-      phase(std::integral_constant<int, 1>{}, F_{}, it + 1);
-      phase(std::integral_constant<int, 2>{}, F_{}, it + 2);
-      phase(std::integral_constant<int, 3>{}, F_{}, it + 3);
-    }
-    for (; it < nkt; it += 4) {
-      phase(std::integral_constant<int, 0>{}, T_{}, it);
-      if (it + 1 < nkt) phase(std::integral_constant<int, 1>{}, T_{}, it + 1);
-      if (it + 2 < nkt) phase(std::integral_constant<int, 2>{}, T_{}, it + 2);
-      if (it + 3 < nkt) phase(std::integral_constant<int, 3>{}, T_{}, it + 3);
+  }
+  for (; it < nkt; it += UNROLL) {
+    phase(std::integral_constant<int, 0>{}, T_{}, it);
+    if (it + 1 < nkt) phase(std::integral_constant<int, 1>{}, T_{}, it + 1);
+    if (it + 2 < nkt) phase(std::integral_constant<int, 2>{}, T_{}, it + 2);
+    if (it + 3 < nkt) phase(std::integral_constant<int, 3>{}, T_{}, it + 3);
+    if constexpr (UNROLL == 6) {
+      if (it + 4 < nkt) phase(std::integral_constant<int, 4>{}, T_{}, it + 4);
+      if (it + 5 < nkt) phase(std::integral_constant<int, 5>{}, T_{}, it + 5);
     }
   }
 
@@ -606,19 +648,26 @@ __global__ __launch_bounds__(NT_) void gemm_bf16_kernel(const eamd_gemm_t p) {
   }
 }
 
-template <int BM, int BN, bool TA, bool TB, bool FAST, bool GAT>
-int launch_b(const eamd_gemm_t& p, hipStream_t stream) {
+template <int BM, int BN, bool TA, bool TB, bool FAST, bool GAT, bool ACT>
+int launch_b2(const eamd_gemm_t& p, hipStream_t stream) {
   dim3 grid(((p.M + BM - 1) / BM) * ((p.N + BN - 1) / BN) * p.splitk, 1, p.batch1 * p.batch2);
   size_t smem = sizeof(SmemB<BM, BN, TA, TB>);
   if (smem > 64 * 1024) {
     static const hipError_t attr_err = hipFuncSetAttribute(
-        reinterpret_cast<const void*>(&gemm_bf16_kernel<BM, BN, TA, TB, FAST, GAT>),
+        reinterpret_cast<const void*>(&gemm_bf16_kernel<BM, BN, TA, TB, FAST, GAT, ACT>),
         hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(SmemB<BM, BN, TA, TB>));
     if (attr_err != hipSuccess) return (int)attr_err;
   }
-  hipLaunchKernelGGL((gemm_bf16_kernel<BM, BN, TA, TB, FAST, GAT>), grid, dim3(NT_), smem, stream, p);
+  hipLaunchKernelGGL((gemm_bf16_kernel<BM, BN, TA, TB, FAST, GAT, ACT>), grid, dim3(NT_), smem, stream, p);
   EAMD_LAUNCH_CHECK();
   return EAMD_OK;
+}
+
+template <int BM, int BN, bool TA, bool TB, bool FAST, bool GAT>
+int launch_b(const eamd_gemm_t& p, hipStream_t stream) {
+  if constexpr (GAT) return launch_b2<BM, BN, TA, TB, FAST, GAT, false>(p, stream);
+  else if (p.a_act != EAMD_ACT_NONE || p.b_act != EAMD_ACT_NONE) return launch_b2<BM, BN, TA, TB, FAST, GAT, true>(p, stream);
+  return launch_b2<BM, BN, TA, TB, FAST, GAT, false>(p, stream);
 }
 
 template <int T, bool FAST>
@@ -643,6 +692,7 @@ int eamd_gemm_bf16_dispatch(const eamd_gemm_t& p, int tile, hipStream_t stream) 
     // implicit-conv operands: A gathered ([rows][(tap, C)] view of an NHWC tensor), B = tap-major weights [K][N]
     const eamd_gather_t& g = p.gather;
     if (g.C % BK != 0 || !p.transB || !aligned16(p.A) || !b_ok) return EAMD_EINVAL;
+    if (p.a_act != EAMD_ACT_NONE || p.b_act != EAMD_ACT_NONE) return EAMD_EINVAL;
     if (p.transA && g.C % tile != 0) return EAMD_EINVAL;
     if (tile == 128)
       return p.transA ? launch_b<128, 128, true, true, true, true>(p, stream)

@@ -90,7 +90,8 @@ template <int VEC>   // VEC = D/256 for the vector form, 0 = generic (D <= 1024)
 __global__ __launch_bounds__(256) void layernorm_bwd_kernel(
     const float* __restrict__ dy, const float* __restrict__ x, const float* __restrict__ gamma,
     const float* __restrict__ mean, const float* __restrict__ rstd, const float* dres, float* dx,
-    float* __restrict__ dgamma, float* __restrict__ dbeta, int rows, int D, int rows_per_block) {
+    float* __restrict__ dgamma, float* __restrict__ dbeta, float* __restrict__ ws, int rows, int D,
+    int rows_per_block) {
   extern __shared__ float lds[];  // [2][D]
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   for (int i = threadIdx.x; i < 2 * D; i += blockDim.x) lds[i] = 0.f;
@@ -183,9 +184,42 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(
     }
   }
   __syncthreads();
+  if (ws) {   // per-block partial sums, combined by layernorm_bwd_reduce_kernel (no same-address atomic storm)
+    float* w = ws + (long)blockIdx.x * 2 * D;
+    for (int i = threadIdx.x; i < 2 * D; i += blockDim.x) w[i] = lds[i];
+    return;
+  }
   for (int i = threadIdx.x; i < D; i += blockDim.x) {
     atomicAdd(&dgamma[i], lds[i]);
     atomicAdd(&dbeta[i], lds[D + i]);
+  }
+}
+
+// ws[nblk][2D] -> dgamma[D] += , dbeta[D] +=.  grid (ceil(2D/64), row slices): each block sums its slice of
+// partial rows for 64 columns (4 row-subgroups x 64 lanes, combined in LDS) and issues one atomic per column.
+__global__ __launch_bounds__(256) void layernorm_bwd_reduce_kernel(const float* __restrict__ ws, int nblk, int D,
+                                                                   float* __restrict__ dgamma,
+                                                                   float* __restrict__ dbeta) {
+  __shared__ float red[4][64];
+  const int lane = threadIdx.x & 63, sub = threadIdx.x >> 6;
+  const int col = blockIdx.x * 64 + lane;
+  const int per = (nblk + gridDim.y - 1) / gridDim.y;
+  const int r0 = blockIdx.y * per, r1 = min(nblk, r0 + per);
+  float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+  if (col < 2 * D) {
+    int r = r0 + sub;
+    for (; r + 12 < r1; r += 16) {
+      s0 += ws[(long)r * 2 * D + col];        s1 += ws[(long)(r + 4) * 2 * D + col];
+      s2 += ws[(long)(r + 8) * 2 * D + col];  s3 += ws[(long)(r + 12) * 2 * D + col];
+    }
+    for (; r < r1; r += 4) s0 += ws[(long)r * 2 * D + col];
+  }
+  red[sub][lane] = (s0 + s1) + (s2 + s3);
+  __syncthreads();
+  if (sub == 0 && col < 2 * D) {
+    const float v = (red[0][lane] + red[1][lane]) + (red[2][lane] + red[3][lane]);
+    if (col < D) atomicAdd(&dgamma[col], v);
+    else atomicAdd(&dbeta[col - D], v);
   }
 }
 
@@ -421,28 +455,46 @@ int eamd_layernorm_fwd(const float* x, const float* gamma, const float* beta, fl
   return EAMD_OK;
 }
 
+static void ln_bwd_grid(int rows, int* nblk, int* rpb) {
+  int n = min(1024, (rows + 7) / 8);
+  *rpb = (rows + n - 1) / n;
+  *nblk = (rows + *rpb - 1) / *rpb;
+}
+
+int64_t eamd_layernorm_bwd_workspace(int rows, int D) {
+  if (rows <= 0 || D <= 0) return 0;
+  int nblk, rpb;
+  ln_bwd_grid(rows, &nblk, &rpb);
+  return (int64_t)nblk * 2 * D;
+}
+
 int eamd_layernorm_bwd(const float* dy, const float* x, const float* gamma, const float* mean,
-                       const float* rstd, const float* dres, float* dx, float* dgamma, float* dbeta, int rows,
-                       int D, void* stream) {
+                       const float* rstd, const float* dres, float* dx, float* dgamma, float* dbeta,
+                       float* workspace, int rows, int D, void* stream) {
   if (!dy || !x || !gamma || !mean || !rstd || !dx || !dgamma || !dbeta || rows <= 0 || D <= 0)
     return EAMD_EINVAL;
   if (D > 1024) return EAMD_EUNSUPPORTED;
-  int nblk = min(1024, (rows + 7) / 8);
-  int rpb = (rows + nblk - 1) / nblk;
-  nblk = (rows + rpb - 1) / rpb;
+  int nblk, rpb;
+  ln_bwd_grid(rows, &nblk, &rpb);
+  float* ws = nblk >= 32 ? workspace : nullptr;   // few blocks: direct atomics are cheaper than a second launch
   const bool al = (((uintptr_t)dy | (uintptr_t)x | (uintptr_t)gamma | (uintptr_t)dx | (uintptr_t)dres) & 15) == 0;
   hipStream_t s = (hipStream_t)stream;
   size_t sm = 2 * D * sizeof(float);
   if (al && D == 256)
     hipLaunchKernelGGL(layernorm_bwd_kernel<1>, dim3(nblk), dim3(256), sm, s, dy, x, gamma, mean, rstd, dres, dx,
-                       dgamma, dbeta, rows, D, rpb);
+                       dgamma, dbeta, ws, rows, D, rpb);
   else if (al && D == 512)
     hipLaunchKernelGGL(layernorm_bwd_kernel<2>, dim3(nblk), dim3(256), sm, s, dy, x, gamma, mean, rstd, dres, dx,
-                       dgamma, dbeta, rows, D, rpb);
+                       dgamma, dbeta, ws, rows, D, rpb);
   else
     hipLaunchKernelGGL(layernorm_bwd_kernel<0>, dim3(nblk), dim3(256), sm, s, dy, x, gamma, mean, rstd, dres, dx,
-                       dgamma, dbeta, rows, D, rpb);
+                       dgamma, dbeta, ws, rows, D, rpb);
   EAMD_LAUNCH_CHECK();
+  if (ws) {
+    hipLaunchKernelGGL(layernorm_bwd_reduce_kernel, dim3((2 * D + 63) / 64, min(16, (nblk + 31) / 32)), dim3(256), 0,
+                       s, ws, nblk, D, dgamma, dbeta);
+    EAMD_LAUNCH_CHECK();
+  }
   return EAMD_OK;
 }
 

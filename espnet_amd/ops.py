@@ -148,16 +148,18 @@ def cast_bf16(x, out=None):
 
 
 def auto_splitk(m_out, n_out, k_red):
-    """split count for reduction-heavy GEMMs: enough workgroups to fill 256 CUs, rounded to a multiple
-    of 8 so that every XCD owns whole K-slices (see gemm_bf16.hip: split index = workgroup id mod splitk)"""
+    """split count for reduction-heavy GEMMs (dW = dY^T X).  Measured on MI355X (tools/gemm_probe2.py,
+    K = 7968): 128 output tiles -> 4, 32 tiles -> 8, 16 tiles -> 16 are the fastest; more splits lose to
+    the f32 atomics, fewer leave CUs idle.  Powers of two >= 8 keep whole K-slices per XCD (gemm_bf16.hip:
+    split index = workgroup id mod splitk)."""
     tiles = ((m_out + 63) // 64) * ((n_out + 63) // 64)
     if tiles >= 512:
         return 1
-    s = min((768 + tiles - 1) // tiles, max(1, k_red // 128))
-    s = max(1, min(s, 64))
-    if s >= 6:
-        s = min(64, (s + 7) // 8 * 8)
-    return s
+    want = 4.0 * (128.0 / tiles) ** 0.5
+    s = 1
+    while s < want:
+        s *= 2
+    return max(1, min(s, 64, max(1, k_red // 128)))
 
 
 # ---- nn.Linear pieces -------------------------------------------------------------------------
@@ -253,8 +255,10 @@ def layernorm_bwd(dy, x, gamma, mean, rstd, dres, dgamma, dbeta):
     rows, D = x.shape
     assert dy.shape == x.shape and dgamma.numel() == D and dbeta.numel() == D
     dx = torch.empty_like(x)
-    check(_lib.lib().eamd_layernorm_bwd(ptr(dy), ptr(x), ptr(gamma), ptr(mean), ptr(rstd), ptr(dres), ptr(dx),
-                                        ptr(dgamma), ptr(dbeta), rows, D, stream_ptr()), "eamd_layernorm_bwd")
+    L = _lib.lib()
+    ws = torch.empty(int(L.eamd_layernorm_bwd_workspace(rows, D)), device=x.device, dtype=torch.float32)
+    check(L.eamd_layernorm_bwd(ptr(dy), ptr(x), ptr(gamma), ptr(mean), ptr(rstd), ptr(dres), ptr(dx),
+                               ptr(dgamma), ptr(dbeta), ptr(ws), rows, D, stream_ptr()), "eamd_layernorm_bwd")
     return dx
 
 

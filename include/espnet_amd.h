@@ -95,11 +95,13 @@ int eamd_gemm(const eamd_gemm_t* p, void* stream);
 /* y (fp32) and/or y_bf16 (bf16 copy for the bf16-operand GEMM) are written; either may be NULL. */
 int eamd_layernorm_fwd(const float* x, const float* gamma, const float* beta, float* y, void* y_bf16, float* mean,
                        float* rstd, int rows, int D, float eps, void* stream);
-/* dgamma/dbeta are ACCUMULATED (+=) with f32 atomics; dx = LN-backward(dy) + dres (dres optional,
- * may alias dx: the residual branch's gradient is folded in). */
+/* dgamma/dbeta are ACCUMULATED (+=); dx = LN-backward(dy) + dres (dres optional, may alias dx: the
+ * residual branch's gradient is folded in).  workspace: eamd_layernorm_bwd_workspace(rows, D) floats of
+ * scratch for the two-stage column reduction (NULL => one f32 atomic per column per block instead). */
+int64_t eamd_layernorm_bwd_workspace(int rows, int D);
 int eamd_layernorm_bwd(const float* dy, const float* x, const float* gamma, const float* mean,
-                       const float* rstd, const float* dres, float* dx, float* dgamma, float* dbeta, int rows,
-                       int D, void* stream);
+                       const float* rstd, const float* dres, float* dx, float* dgamma, float* dbeta,
+                       float* workspace, int rows, int D, void* stream);
 
 /* Masked softmax of attention scores, legacy rel_shift of `bd` fused in.
  * reference: transformer/attention.py:63-90 (mask fill / softmax / zero fill), :141-162 (rel_shift),

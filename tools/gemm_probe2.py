@@ -18,18 +18,22 @@ def run(name, m, n, k, ta, tb, tile, sk, out_bf16=False, aux=False, colsum=False
     print(f"{name:28s} {m}x{n}x{k} ta{ta} tb{tb} tile={tile} sk={sk} bf16out={out_bf16} aux={aux} cs={colsum}: {t:7.1f} us {2.0*m*n*k/t/1e6:7.1f} TF/s")
 
 M = 7968
-for tile, sk in ((64, 4), (64, 8), (128, 8), (128, 16), (128, 32)):
-    run("dW1 TN", 2048, 256, M, 1, 1, tile, sk)
-run("dW1 TN +colsum", 2048, 256, M, 1, 1, 64, 4, colsum=True)
-run("dW1 TN +colsum", 2048, 256, M, 1, 1, 128, 16, colsum=True)
-for tile, sk in ((64, 4), (128, 8), (128, 16)):
-    run("dW2 TN", 256, 2048, M, 1, 1, tile, sk)
-for tile, sk in ((64, 32), (64, 16), (128, 32), (128, 64)):
-    run("dWproj TN", 256, 256, M, 1, 1, tile, sk)
+for sk in (2, 4, 8, 16):
+    run("dW1 TN +colsum", 2048, 256, M, 1, 1, 64, sk, colsum=True)
+for sk in (2, 4, 8, 16):
+    run("dW2 TN +colsum", 256, 2048, M, 1, 1, 64, sk, colsum=True)
+for sk in (4, 8, 16, 24, 32, 48):
+    run("dWproj TN +colsum", 256, 256, M, 1, 1, 64, sk, colsum=True)
+for sk in (4, 8, 16, 32):
+    run("dWpw1 TN +colsum", 512, 256, M, 1, 1, 64, sk, colsum=True)
 for tile in (64, 128):
     run("dz NN bf16out+aux", M, 2048, 256, 0, 1, tile, 1, True, True)
+    run("dz NN bf16out", M, 2048, 256, 0, 1, tile, 1, True, False)
     run("ffn_w1 NT bf16out", M, 2048, 256, 0, 0, tile, 1, True)
     run("ffn_w2 NT", M, 256, 2048, 0, 0, tile, 1)
     run("dxn NN", M, 256, 2048, 0, 1, tile, 1)
+    run("proj NT", M, 256, 256, 0, 0, tile, 1)
+    run("dproj NN", M, 256, 256, 0, 1, tile, 1)
+    run("pw1 NT", M, 512, 256, 0, 0, tile, 1)
     run("ctc_lo NT", M, 5000, 256, 0, 0, tile, 1)
     run("dlogits NN", M, 256, 5000, 0, 1, tile, 1)
