@@ -58,6 +58,8 @@ SYMBOLS = [
     "eamd_bn_stats", "eamd_bn_apply", "eamd_bn_bwd", "eamd_conv1_fwd", "eamd_conv1_bwd_w",
     "eamd_conv2_weight_prep", "eamd_conv2_weight_grad", "eamd_add_sos_eos", "eamd_ctc_collapse",
     "eamd_ctc_workspace_bytes", "eamd_ctc_loss", "eamd_ctc_prefix_score", "eamd_grad_norm", "eamd_sched_step", "eamd_adam_step",
+    "eamd_lstm_cell_fwd", "eamd_lstm_cell_bwd", "eamd_maxpool2x2_fwd", "eamd_maxpool2x2_bwd",
+    "eamd_joint_fwd", "eamd_joint_bwd", "eamd_rnnt_workspace", "eamd_rnnt_loss",
 ]
 
 
@@ -72,6 +74,7 @@ def lib():
         _lib = C.CDLL(LIB_PATH)
         _lib.eamd_ctc_workspace_bytes.restype = C.c_int64
         _lib.eamd_layernorm_bwd_workspace.restype = C.c_int64
+        _lib.eamd_rnnt_workspace.restype = C.c_int64
         for s in SYMBOLS:
             getattr(_lib, s)  # AttributeError here = header/library mismatch
     return _lib

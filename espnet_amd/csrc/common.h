@@ -20,7 +20,7 @@ typedef __attribute__((ext_vector_type(8))) short bf16x8;
 typedef __attribute__((ext_vector_type(4))) short bf16x4;
 
 // activation ids shared by host and device
-enum { EAMD_ACT_NONE = 0, EAMD_ACT_RELU = 1, EAMD_ACT_SWISH = 2 };
+enum { EAMD_ACT_NONE = 0, EAMD_ACT_RELU = 1, EAMD_ACT_SWISH = 2, EAMD_ACT_TANH = 3 };
 
 __device__ __forceinline__ float eamd_sigmoid(float x) { return 1.0f / (1.0f + __expf(-x)); }
 __device__ __forceinline__ float eamd_swish(float x) { return x * eamd_sigmoid(x); }
@@ -32,7 +32,15 @@ __device__ __forceinline__ float eamd_dswish(float x) {
 __device__ __forceinline__ float eamd_act(float x, int act) {
   if (act == EAMD_ACT_RELU) return x > 0.f ? x : 0.f;
   if (act == EAMD_ACT_SWISH) return eamd_swish(x);
+  if (act == EAMD_ACT_TANH) return tanhf(x);
   return x;
+}
+// derivative of eamd_act at pre-activation x
+__device__ __forceinline__ float eamd_dact(float x, int act) {
+  if (act == EAMD_ACT_RELU) return x > 0.f ? 1.f : 0.f;
+  if (act == EAMD_ACT_SWISH) return eamd_dswish(x);
+  if (act == EAMD_ACT_TANH) { float t = tanhf(x); return 1.f - t * t; }
+  return 1.f;
 }
 
 // fp32 -> bf16 round-to-nearest-even (plain cast keeps NaN a NaN on gfx950).

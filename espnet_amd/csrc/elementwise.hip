@@ -63,10 +63,7 @@ __global__ void act_bwd_kernel(const float* __restrict__ dy, const float* __rest
                                long n, int act) {
   const long stride = (long)gridDim.x * blockDim.x;
   for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
-    float g = dy[i];
-    if (act == EAMD_ACT_RELU) g = x[i] > 0.f ? g : 0.f;
-    else if (act == EAMD_ACT_SWISH) g *= eamd_dswish(x[i]);
-    dx[i] = g;
+    dx[i] = dy[i] * eamd_dact(x[i], act);
   }
 }
 
@@ -155,15 +152,16 @@ __global__ void embed_pe_kernel(const long long* __restrict__ tok, const float* 
     long r = i / D; int d = i % D;
     long id = tok[r];
     int pos = (int)(r % U) + pos_offset;
-    out[i] = table[id * D + d] * scale + pe[(long)pos * D + d];
+    out[i] = table[id * D + d] * scale + (pe ? pe[(long)pos * D + d] : 0.f);
   }
 }
 __global__ void embed_bwd_kernel(const long long* __restrict__ tok, const float* __restrict__ dout,
-                                 float* __restrict__ dtable, long rows, int D, float scale) {
+                                 float* __restrict__ dtable, long rows, int D, float scale, long pad_idx) {
   const long n = rows * D;
   const long stride = (long)gridDim.x * blockDim.x;
   for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
     long r = i / D; int d = i % D;
+    if (tok[r] == pad_idx) continue;      // nn.Embedding(padding_idx): that row never receives gradient
     atomicAdd(&dtable[tok[r] * D + d], dout[i] * scale);
   }
 }
@@ -320,7 +318,7 @@ int eamd_colsum(const void* x, int64_t ld, float* out, int64_t rows, int D, floa
 
 int eamd_embed_pe(const int64_t* tok, const float* table, const float* pe, float* out, int64_t rows, int U,
                   int D, float scale, int pos_offset, void* stream) {
-  if (!tok || !table || !pe || !out || rows <= 0 || U <= 0 || D <= 0) return EAMD_EINVAL;
+  if (!tok || !table || !out || rows <= 0 || U <= 0 || D <= 0) return EAMD_EINVAL;
   hipLaunchKernelGGL(embed_pe_kernel, dim3(grid_for(rows * D)), dim3(256), 0, (hipStream_t)stream,
                      (const long long*)tok, table, pe, out, (long)rows, U, D, scale, pos_offset);
   EAMD_LAUNCH_CHECK();
@@ -328,10 +326,10 @@ int eamd_embed_pe(const int64_t* tok, const float* table, const float* pe, float
 }
 
 int eamd_embed_bwd(const int64_t* tok, const float* dout, float* dtable, int64_t rows, int D, float scale,
-                   void* stream) {
+                   int64_t pad_idx, void* stream) {
   if (!tok || !dout || !dtable || rows <= 0 || D <= 0) return EAMD_EINVAL;
   hipLaunchKernelGGL(embed_bwd_kernel, dim3(grid_for(rows * D)), dim3(256), 0, (hipStream_t)stream,
-                     (const long long*)tok, dout, dtable, (long)rows, D, scale);
+                     (const long long*)tok, dout, dtable, (long)rows, D, scale, (long)pad_idx);
   EAMD_LAUNCH_CHECK();
   return EAMD_OK;
 }

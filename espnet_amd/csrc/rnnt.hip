@@ -1,0 +1,246 @@
+// RNN-Transducer: joint network pointwise parts and the transducer loss (Graves 2012) on the
+// (T, U+1) lattice.  reference: transducer/joint_network.py:34-48 (lin_out(act(lin_enc(h_enc) +
+// lin_dec(h_dec)))), transducer/loss.py:8-79 (warp-transducer RNNTLoss(blank), raw logits in,
+// log-softmax inside, mean over the batch), transducer/utils.py:9-53 (targets / lengths).
+// The three Linear layers run through eamd_gemm; the kernels here are
+//   joint_fwd / joint_bwd_* : broadcast add + activation over [B,T,U,J] and its two reductions,
+//   rnnt_lse_gather         : per lattice node log-sum-exp over V and the two log-probs the lattice uses,
+//   rnnt_alpha_beta         : forward/backward variables, one workgroup per (utterance, direction),
+//                             anti-diagonal wavefront with the previous diagonal held in LDS,
+//   rnnt_grad               : d loss / d logits written in place over the logits.
+#include "common.h"
+#include "../../include/espnet_amd.h"
+
+namespace {
+
+inline int grid_for(long n) {
+  long g = (n + 255) / 256;
+  return (int)(g < 1 ? 1 : (g > 65535 ? 65535 : g));
+}
+
+__global__ void joint_fwd_kernel(const float* __restrict__ e, const float* __restrict__ d, float* __restrict__ out,
+                                 unsigned short* __restrict__ out16, int B, int T, int U, int J, int act) {
+  const long n = (long)B * T * U * J;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+    const int j = i % J; long p = i / J;
+    const int u = p % U; p /= U;
+    const int t = p % T; const int b = p / T;
+    const float v = eamd_act(e[((long)b * T + t) * J + j] + d[((long)b * U + u) * J + j], act);
+    if (out) out[i] = v;
+    if (out16) out16[i] = eamd_f2bf(v);
+  }
+}
+
+// d_enc[b,t,j] = sum_u dh[b,t,u,j] * act'(e[b,t,j] + d[b,u,j])      grid (B*T), threads over j
+__global__ __launch_bounds__(256) void joint_bwd_enc_kernel(const float* __restrict__ dh, const float* __restrict__ e,
+                                                            const float* __restrict__ d, float* __restrict__ de,
+                                                            int B, int T, int U, int J, int act) {
+  const long bt = blockIdx.x;
+  const int b = bt / T;
+  for (int j = threadIdx.x; j < J; j += blockDim.x) {
+    const float ev = e[bt * J + j];
+    float s = 0.f;
+    for (int u = 0; u < U; ++u)
+      s += dh[(bt * U + u) * J + j] * eamd_dact(ev + d[((long)b * U + u) * J + j], act);
+    de[bt * J + j] = s;
+  }
+}
+// d_dec[b,u,j] = sum_t dh[b,t,u,j] * act'(e[b,t,j] + d[b,u,j])      grid (B*U)
+__global__ __launch_bounds__(256) void joint_bwd_dec_kernel(const float* __restrict__ dh, const float* __restrict__ e,
+                                                            const float* __restrict__ d, float* __restrict__ dd,
+                                                            int B, int T, int U, int J, int act) {
+  const long bu = blockIdx.x;
+  const int b = bu / U, u = bu % U;
+  for (int j = threadIdx.x; j < J; j += blockDim.x) {
+    const float dv = d[bu * J + j];
+    float s = 0.f;
+    for (int t = 0; t < T; ++t)
+      s += dh[(((long)b * T + t) * U + u) * J + j] * eamd_dact(e[((long)b * T + t) * J + j] + dv, act);
+    dd[bu * J + j] = s;
+  }
+}
+
+// one workgroup per lattice node (b,t,u): lse over V; log p(blank), log p(next label)
+__global__ __launch_bounds__(256) void rnnt_lse_gather_kernel(const float* __restrict__ z, const int* __restrict__ labels,
+                                                              float* __restrict__ lse, float* __restrict__ lpb,
+                                                              float* __restrict__ lpl, int T, int U, int V,
+                                                              int blank) {
+  __shared__ float red[16];
+  const long row = blockIdx.x;
+  const float* zr = z + row * V;
+  float m = -INFINITY;
+  for (int v = threadIdx.x; v < V; v += blockDim.x) m = fmaxf(m, zr[v]);
+  m = block_max(m, red);
+  float s = 0.f;
+  for (int v = threadIdx.x; v < V; v += blockDim.x) s += expf(zr[v] - m);
+  s = block_sum(s, red);
+  if (threadIdx.x == 0) {
+    const float l = m + logf(s);
+    const int u = row % U;
+    const long b = row / ((long)T * U);
+    lse[row] = l;
+    lpb[row] = zr[blank] - l;
+    lpl[row] = (u < U - 1) ? zr[labels[b * (U - 1) + u]] - l : -INFINITY;
+  }
+}
+
+__device__ __forceinline__ float lae(float a, float b) {   // log(exp(a) + exp(b)), -inf safe
+  const float m = fmaxf(a, b);
+  if (m == -INFINITY) return -INFINITY;
+  return m + log1pf(expf(fminf(a, b) - m));
+}
+
+// blocks [0,B): alpha ; blocks [B,2B): beta.  alpha/beta [B,T,U]; nodes outside (t < tlen, u <= ulen) = -inf.
+// loss[b] = -beta(0,0)
+__global__ __launch_bounds__(256) void rnnt_alpha_beta_kernel(const float* __restrict__ lpb,
+                                                              const float* __restrict__ lpl,
+                                                              const int* __restrict__ tlens,
+                                                              const int* __restrict__ ulens, float* __restrict__ alpha,
+                                                              float* __restrict__ beta, float* __restrict__ loss,
+                                                              int B, int T, int U) {
+  extern __shared__ float sh[];   // [2][U]
+  const bool is_beta = blockIdx.x >= B;
+  const int b = is_beta ? blockIdx.x - B : blockIdx.x;
+  const int Tb = tlens[b], Ub = ulens[b] + 1;   // lattice of this utterance: Tb x Ub
+  const long base = (long)b * T * U;
+  float* out = (is_beta ? beta : alpha) + base;
+  const float* pb = lpb + base;
+  const float* pl = lpl + base;
+  for (int i = threadIdx.x; i < T * U; i += blockDim.x) out[i] = -INFINITY;
+  if (Tb <= 0 || Tb > T || Ub <= 0 || Ub > U) { if (is_beta && threadIdx.x == 0) loss[b] = INFINITY; return; }
+  float* prev = sh;
+  float* cur = sh + U;
+  __syncthreads();
+  const int ndiag = Tb + Ub - 1;
+  if (!is_beta) {
+    for (int dg = 0; dg < ndiag; ++dg) {
+      const int u0 = max(0, dg - (Tb - 1)), u1 = min(dg, Ub - 1);
+      for (int u = u0 + threadIdx.x; u <= u1; u += blockDim.x) {
+        const int t = dg - u;
+        float a;
+        if (dg == 0) a = 0.f;
+        else {
+          const float from_t = t > 0 ? prev[u] + pb[(long)(t - 1) * U + u] : -INFINITY;       // blank: (t-1,u)->(t,u)
+          const float from_u = u > 0 ? prev[u - 1] + pl[(long)t * U + (u - 1)] : -INFINITY;   // label: (t,u-1)->(t,u)
+          a = lae(from_t, from_u);
+        }
+        cur[u] = a;
+        out[(long)t * U + u] = a;
+      }
+      __syncthreads();
+      float* tmp = prev; prev = cur; cur = tmp;
+    }
+  } else {
+    for (int dg = ndiag - 1; dg >= 0; --dg) {
+      const int u0 = max(0, dg - (Tb - 1)), u1 = min(dg, Ub - 1);
+      for (int u = u0 + threadIdx.x; u <= u1; u += blockDim.x) {
+        const int t = dg - u;
+        float v;
+        if (t == Tb - 1 && u == Ub - 1) v = pb[(long)t * U + u];
+        else {
+          const float to_t = t < Tb - 1 ? prev[u] + pb[(long)t * U + u] : -INFINITY;          // (t,u)->(t+1,u)
+          const float to_u = u < Ub - 1 ? prev[u + 1] + pl[(long)t * U + u] : -INFINITY;      // (t,u)->(t,u+1)
+          v = lae(to_t, to_u);
+        }
+        cur[u] = v;
+        out[(long)t * U + u] = v;
+      }
+      __syncthreads();
+      float* tmp = prev; prev = cur; cur = tmp;
+    }
+    if (threadIdx.x == 0) loss[b] = -prev[0];
+  }
+}
+
+// in place: z[row, v] <- scale * d(-log P(y|x)) / d z[row, v]
+__global__ __launch_bounds__(256) void rnnt_grad_kernel(float* __restrict__ z, const int* __restrict__ labels,
+                                                        const float* __restrict__ lse, const float* __restrict__ lpb,
+                                                        const float* __restrict__ lpl, const float* __restrict__ alpha,
+                                                        const float* __restrict__ beta, const int* __restrict__ tlens,
+                                                        const int* __restrict__ ulens, const float* __restrict__ gscale,
+                                                        float scale, int T, int U, int V, int blank) {
+  const long row = blockIdx.x;
+  const int u = row % U;
+  const int t = (row / U) % T;
+  const long b = row / ((long)T * U);
+  float* zr = z + row * V;
+  const int Tb = tlens[b], Ub = ulens[b] + 1;
+  const float logZ = beta[b * (long)T * U];
+  const float a = alpha[row];
+  const bool valid = t < Tb && u < Ub && a > -INFINITY && beta[row] > -INFINITY && isfinite(logZ);
+  if (!valid) {
+    for (int v = threadIdx.x; v < V; v += blockDim.x) zr[v] = 0.f;
+    return;
+  }
+  const float sc = scale * (gscale ? gscale[0] : 1.f);
+  const float tot = a + beta[row] - logZ - lse[row];       // log of (node occupancy / softmax normaliser)
+  float gb, gl = 0.f;
+  if (t < Tb - 1) gb = expf(a + lpb[row] + beta[row + U] - logZ);
+  else gb = (u == Ub - 1) ? expf(a + lpb[row] - logZ) : 0.f;
+  int lab = -1;
+  if (u < Ub - 1) { lab = labels[b * (U - 1) + u]; gl = expf(a + lpl[row] + beta[row + 1] - logZ); }
+  for (int v = threadIdx.x; v < V; v += blockDim.x) {
+    float g = expf(zr[v] + tot);
+    if (v == blank) g -= gb;
+    if (v == lab) g -= gl;
+    zr[v] = sc * g;
+  }
+}
+
+}  // namespace
+
+extern "C" {
+
+int eamd_joint_fwd(const float* enc, const float* dec, float* out, void* out_bf16, int B, int T, int U, int J, int act,
+                   void* stream) {
+  if (!enc || !dec || (!out && !out_bf16) || B <= 0 || T <= 0 || U <= 0 || J <= 0) return EAMD_EINVAL;
+  hipLaunchKernelGGL(joint_fwd_kernel, dim3(grid_for((long)B * T * U * J)), dim3(256), 0, (hipStream_t)stream, enc, dec,
+                     out, (unsigned short*)out_bf16, B, T, U, J, act);
+  EAMD_LAUNCH_CHECK();
+  return EAMD_OK;
+}
+
+int eamd_joint_bwd(const float* dh, const float* enc, const float* dec, float* d_enc, float* d_dec, int B, int T, int U,
+                   int J, int act, void* stream) {
+  if (!dh || !enc || !dec || !d_enc || !d_dec || B <= 0 || T <= 0 || U <= 0 || J <= 0) return EAMD_EINVAL;
+  hipStream_t s = (hipStream_t)stream;
+  hipLaunchKernelGGL(joint_bwd_enc_kernel, dim3(B * T), dim3(256), 0, s, dh, enc, dec, d_enc, B, T, U, J, act);
+  EAMD_LAUNCH_CHECK();
+  hipLaunchKernelGGL(joint_bwd_dec_kernel, dim3(B * U), dim3(256), 0, s, dh, enc, dec, d_dec, B, T, U, J, act);
+  EAMD_LAUNCH_CHECK();
+  return EAMD_OK;
+}
+
+/* workspace floats: 5 * B*T*U  (lse, lp_blank, lp_label, alpha, beta) */
+int64_t eamd_rnnt_workspace(int B, int T, int U) { return (B <= 0 || T <= 0 || U <= 0) ? 0 : (int64_t)5 * B * T * U; }
+
+int eamd_rnnt_loss(float* logits, const int32_t* labels, const int32_t* tlens, const int32_t* ulens, float* workspace,
+                   float* loss, int B, int T, int U, int V, int blank, int compute_grad, const float* gscale_dev,
+                   float scale, void* stream) {
+  if (!logits || !labels || !tlens || !ulens || !workspace || !loss || B <= 0 || T <= 0 || U <= 0 || V <= 1)
+    return EAMD_EINVAL;
+  if (blank < 0 || blank >= V) return EAMD_EINVAL;
+  if ((size_t)2 * U * sizeof(float) > 64 * 1024) return EAMD_EUNSUPPORTED;
+  if ((long)B * T * U > 2147483647L) return EAMD_EUNSUPPORTED;
+  hipStream_t s = (hipStream_t)stream;
+  const long n = (long)B * T * U;
+  float* lse = workspace;
+  float* lpb = lse + n;
+  float* lpl = lpb + n;
+  float* alpha = lpl + n;
+  float* beta = alpha + n;
+  hipLaunchKernelGGL(rnnt_lse_gather_kernel, dim3((unsigned)n), dim3(256), 0, s, logits, labels, lse, lpb, lpl, T, U, V,
+                     blank);
+  EAMD_LAUNCH_CHECK();
+  hipLaunchKernelGGL(rnnt_alpha_beta_kernel, dim3(2 * B), dim3(256), 2 * U * sizeof(float), s, lpb, lpl, tlens, ulens,
+                     alpha, beta, loss, B, T, U);
+  EAMD_LAUNCH_CHECK();
+  if (compute_grad) {
+    hipLaunchKernelGGL(rnnt_grad_kernel, dim3((unsigned)n), dim3(256), 0, s, logits, labels, lse, lpb, lpl, alpha, beta,
+                       tlens, ulens, gscale_dev, scale, T, U, V, blank);
+    EAMD_LAUNCH_CHECK();
+  }
+  return EAMD_OK;
+}
+
+}  // extern "C"

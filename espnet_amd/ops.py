@@ -374,19 +374,21 @@ def add_cast(a, b):
 
 
 def embed_pe(tok, table, pe, U, scale, pos_offset=0):
+    """out[r] = table[tok[r]] * scale + pe[r % U + pos_offset]   (pe None: plain embedding lookup)"""
     rows = tok.numel()
     D = table.shape[1]
-    assert pe.shape[0] >= U + pos_offset and pe.shape[1] == D and tok.dtype == torch.int64
+    assert tok.dtype == torch.int64 and tok.is_contiguous()
+    assert pe is None or (pe.shape[0] >= U + pos_offset and pe.shape[1] == D)
     out = torch.empty(rows, D, device=table.device, dtype=torch.float32)
     check(_lib.lib().eamd_embed_pe(ptr(tok), ptr(table), ptr(pe), ptr(out), C.c_int64(rows), U, D,
                                    C.c_float(scale), pos_offset, stream_ptr()), "eamd_embed_pe")
     return out
 
 
-def embed_bwd(tok, dout, dtable, scale):
+def embed_bwd(tok, dout, dtable, scale, pad_idx=-1):
     rows, D = dout.shape
     check(_lib.lib().eamd_embed_bwd(ptr(tok), ptr(dout), ptr(dtable), C.c_int64(rows), D, C.c_float(scale),
-                                    stream_ptr()), "eamd_embed_bwd")
+                                    C.c_int64(pad_idx), stream_ptr()), "eamd_embed_bwd")
 
 
 def posenc(x, pe, T, scale):

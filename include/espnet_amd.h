@@ -150,11 +150,13 @@ int eamd_add_bias2(const void* q, const float* u, const float* v, void* qu, void
 int eamd_add_cast_bf16(const float* a, const float* b, void* out_bf16, int64_t n, void* stream);
 /* out[D] += scale * column sums of x[rows, D] (bias gradients). */
 int eamd_colsum(const void* x, int64_t ld, float* out, int64_t rows, int D, float scale, int x_bf16, void* stream);
-/* reference: decoder.py:83-86,251 (Embedding + PositionalEncoding), embedding.py:80-91. */
+/* reference: decoder.py:83-86,251 (Embedding + PositionalEncoding), embedding.py:80-91.
+ * pe may be NULL (plain nn.Embedding lookup: rnn/decoders.py:88, transducer/rnn_decoder.py:44);
+ * pad_idx >= 0 in the backward = nn.Embedding(padding_idx): that row gets no gradient (-1: none). */
 int eamd_embed_pe(const int64_t* tok, const float* table, const float* pe, float* out, int64_t rows, int U,
                   int D, float scale, int pos_offset, void* stream);
 int eamd_embed_bwd(const int64_t* tok, const float* dout, float* dtable, int64_t rows, int D, float scale,
-                   void* stream);
+                   int64_t pad_idx, void* stream);
 int eamd_posenc(const float* x, const float* pe, float* out, int64_t rows, int T, int D, float scale,
                 void* stream);
 int eamd_permute4(const float* src, float* dst, int d0, int d1, int d2, int d3, int64_t s0, int64_t s1,
@@ -211,6 +213,46 @@ int eamd_ctc_loss(const float* acts, int64_t stride_t, int64_t stride_b, const i
 int eamd_ctc_prefix_score(const float* logp, const float* r_prev, const int32_t* cand, const int32_t* last,
                           const int32_t* olen, float* psi, float* r_new, int nhyp, int ncand, int T, int V,
                           int blank, int eos, void* stream);
+
+/* ---- recurrent layers (RNN paths) ------------------------------
+ * One LSTM step on gate pre-activations gates[B,4H] = x W_ih^T + b_ih + h W_hh^T + b_hh (the products are
+ * eamd_gemm calls), gate order i,f,g,o as torch.nn.LSTM / LSTMCell.
+ * reference: rnn/encoders.py:15-162 (torch.nn.LSTM on packed sequences), rnn/decoders.py:88-101,120-134,
+ * transducer/rnn_decoder.py:47-57,106-138 (LSTMCell stacks).
+ * live[B] (optional, uint8): 0 = this sequence has ended (pack_padded_sequence semantics): the state is
+ * carried through unchanged (needs h_prev) and the output row y is 0.  acts[B,4H] keeps the activated
+ * gates for the backward. */
+int eamd_lstm_cell_fwd(const float* gates, const float* c_prev, const float* h_prev, const uint8_t* live, float* h,
+                       float* c, float* y, float* acts, int B, int H, void* stream);
+/* dh = total gradient wrt h (output path + recurrent path), dc = gradient wrt c (NULL = 0).
+ * dgates[B,4H]: pre-activation gradients; dh_pass: share of dh that flows unchanged to h_prev (rows with
+ * live == 0), required when live is given. */
+int eamd_lstm_cell_bwd(const float* dh, const float* dc, const float* acts, const float* c_prev, const float* c,
+                       const uint8_t* live, float* dgates, float* dc_prev, float* dh_pass, int B, int H,
+                       void* stream);
+/* F.max_pool2d(x, 2, stride=2, ceil_mode=True) on NHWC activations (VGG2L, rnn/encoders.py:205,208).
+ * idx[B,Ho,Wo,C] keeps the position (0..3) of the maximum inside its window. */
+int eamd_maxpool2x2_fwd(const float* x, float* y, uint8_t* idx, int B, int H, int W, int C, void* stream);
+int eamd_maxpool2x2_bwd(const float* dy, const uint8_t* idx, float* dx, int B, int H, int W, int C, void* stream);
+
+/* ---- RNN-Transducer ----------------------------------------------------------------------------
+ * Joint network pointwise part: out[b,t,u,:] = act(enc[b,t,:] + dec[b,u,:]) (fp32 and/or bf16 copy for
+ * the lin_out GEMM).  reference: transducer/joint_network.py:34-48, rnn_decoder.py:155-162.
+ * Backward: d_enc[b,t,:] = sum_u dh * act'(pre), d_dec[b,u,:] = sum_t dh * act'(pre) (pre recomputed). */
+int eamd_joint_fwd(const float* enc, const float* dec, float* out, void* out_bf16, int B, int T, int U, int J, int act,
+                   void* stream);
+int eamd_joint_bwd(const float* dh, const float* enc, const float* dec, float* d_enc, float* d_dec, int B, int T, int U,
+                   int J, int act, void* stream);
+/* Transducer loss on raw joint logits[B,T,U,V] (U = max label length + 1), log-softmax inside.
+ * reference: transducer/loss.py:8-79 (warp-transducer RNNTLoss(blank) semantics), utils.py:9-53
+ * (labels[B,U-1] int32 padded with blank, tlens[B] encoder lengths, ulens[B] label lengths).
+ * loss[b] = -log P(y_b | x_b).  compute_grad != 0: logits are OVERWRITTEN with
+ * scale * gscale_dev[0] * d loss[b] / d logits (gscale_dev may be NULL = 1).
+ * workspace: eamd_rnnt_workspace(B,T,U) floats. */
+int64_t eamd_rnnt_workspace(int B, int T, int U);
+int eamd_rnnt_loss(float* logits, const int32_t* labels, const int32_t* tlens, const int32_t* ulens, float* workspace,
+                   float* loss, int B, int T, int U, int V, int blank, int compute_grad, const float* gscale_dev,
+                   float scale, void* stream);
 
 /* ------------------------------------------------------------------------------------------
  * Optimizer on flat fp32 arenas.  reference: transformer/optimizer.py:12-75 (NoamOpt),

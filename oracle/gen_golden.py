@@ -377,6 +377,93 @@ def main():
          loss=loss.detach(), loss_att=stats["loss_att"], loss_ctc=stats["loss_ctc"], acc=float(stats["acc"]),
          weight=weight, **sd0, **grads_np(m2))
 
+    # ---- a20: RNN path (VGG-BLSTMP encoder, location-aware attention LSTM decoder, CTC) -----------
+    from espnet.nets.pytorch_backend.e2e_asr import E2E as RnnE2E
+
+    def rnn_args(**kw):
+        d = dict(elayers=2, subsample="1_2_1", etype="vggblstmp", eunits=12, eprojs=10, dtype="lstm", dlayers=2,
+                 dunits=14, atype="location", aheads=1, awin=3, aconv_chans=3, aconv_filts=2, mtlalpha=0.5,
+                 lsm_type="", lsm_weight=0.0, sampling_probability=0.0, adim=9, dropout_rate=0.0,
+                 dropout_rate_decoder=0.0, nbest=1, beam_size=1, penalty=0.0, maxlenratio=0.0, minlenratio=0.0,
+                 ctc_weight=0.0, ctc_window_margin=0, lm_weight=0.0, rnnlm=None, verbose=0,
+                 char_list=["<blank>", "a", "b", "c", "d", "e", "<eos>"], outdir=None, ctc_type="builtin",
+                 report_cer=False, report_wer=False, sym_space="<space>", sym_blank="<blank>", sortagrad=0,
+                 grad_noise=False, context_residual=False, use_frontend=False, replace_sos=False, tgt_lang=False)
+        d.update(kw)
+        return argparse.Namespace(**d)
+
+    torch.manual_seed(31)
+    m = RnnE2E(12, 7, rnn_args())
+    m.train()
+    sd0 = sd_np(m, "sd/")
+    g = torch.Generator().manual_seed(3)
+    xs = torch.randn(3, 41, 12, generator=g)
+    ilens = torch.tensor([41, 33, 20])
+    ys = torch.randint(1, 6, (3, 6), generator=g)
+    ys[1, 4:] = -1
+    ys[2, 3:] = -1
+    xs = xs * (torch.arange(41).view(1, -1, 1) < ilens.view(-1, 1, 1))
+    hs, hlens, _ = m.enc(xs, ilens)
+    loss = m(xs, ilens, ys)
+    loss.backward()
+    save(out("e2e_rnn.npz"), xs=xs, ilens=ilens, ys=ys, hs_pad=hs.detach(), hlens=np.asarray(hlens, dtype=np.int64),
+         loss=float(loss), loss_att=float(m.loss_att), loss_ctc=float(m.loss_ctc), acc=float(m.acc), **sd0,
+         **grads_np(m))
+
+    # ---- a21: transducer.  The loss package (warprnnt_pytorch) is absent here: TransLoss is given the
+    # oracle's float64 restatement of the published recursion (asr_oracle.rnnt_loss, mean over the batch),
+    # everything else (encoder, predictor, joint network, input preparation) is the reference's own code.
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    import asr_oracle
+
+    class _RNNTLoss:
+        def __init__(self, blank=0, **kw):
+            self.blank = blank
+
+        def __call__(self, acts, labels, act_lens, label_lens):
+            return asr_oracle.rnnt_loss(acts, labels, act_lens, label_lens, self.blank).to(acts.dtype)
+
+    wp = types.ModuleType("warprnnt_pytorch")
+    wp.RNNTLoss = _RNNTLoss
+    sys.modules["warprnnt_pytorch"] = wp
+    from espnet.nets.pytorch_backend.e2e_asr_transducer import E2E as TrnE2E
+
+    def trn_case(name, seed, **kw):
+        d = dict(etype="vggblstmp", elayers=1, subsample="1_1", eunits=10, eprojs=8, dtype="lstm", dlayers=2,
+                 dunits=12, dec_embed_dim=6, atype="location", adim=4, aheads=2, awin=2, aconv_chans=2,
+                 aconv_filts=5, dropout_rate=0.0, dropout_rate_decoder=0.0, dropout_rate_embed_decoder=0.0,
+                 joint_dim=7, joint_activation_type="tanh", mtlalpha=1.0, rnnt_mode="rnnt", use_frontend=False,
+                 trans_type="warp-transducer", char_list=["a", "b", "c", "d"], sym_space="<space>",
+                 sym_blank="<blank>", report_cer=False, report_wer=False, score_norm_transducer=True, beam_size=1,
+                 nbest=1, verbose=0, outdir=None, rnnlm=None, transformer_init="pytorch")
+        d.update(kw)
+        torch.manual_seed(seed)
+        m = TrnE2E(12, 6, argparse.Namespace(**d))
+        m.train()
+        sd0 = sd_np(m, "sd/")
+        g = torch.Generator().manual_seed(seed + 100)
+        xs = torch.randn(3, 37, 12, generator=g)
+        ilens = torch.tensor([37, 30, 21])
+        ys = torch.randint(1, 6, (3, 5), generator=g)
+        ys[1, 3:] = -1
+        ys[2, 4:] = -1
+        xs = xs * (torch.arange(37).view(1, -1, 1) < ilens.view(-1, 1, 1))
+        loss = m(xs, ilens, ys)
+        loss.backward()
+        save(out(name), xs=xs, ilens=ilens, ys=ys, hs_pad=m.hs_pad.detach(), pred_pad=m.pred_pad.detach(),
+             loss=float(loss), **sd0, **grads_np(m))
+
+    trn_case("transducer_rnn.npz", 41)
+    conf_arch = [dict(type="conformer", d_hidden=32, d_ff=48, heads=4, macaron_style=True, use_conv_mod=True,
+                      conv_mod_kernel=7)]
+    conf_arch[0]["dropout-rate"] = 0.0
+    conf_arch[0]["pos-dropout-rate"] = 0.0
+    conf_arch[0]["att-dropout-rate"] = 0.0
+    trn_case("transducer_conformer.npz", 42, etype="transformer", enc_block_arch=conf_arch, enc_block_repeat=2,
+             transformer_enc_input_layer="conv2d", transformer_enc_self_attn_type="rel_self_attn",
+             transformer_enc_positional_encoding_type="rel_pos", transformer_enc_pw_activation_type="swish",
+             transformer_enc_conv_mod_activation_type="swish", dlayers=1, joint_activation_type="tanh")
+
     e2e_case("e2e_conformer.npz", ConfE2E, dict(transformer_encoder_pos_enc_layer_type="rel_pos",
                                                 transformer_encoder_selfattn_layer_type="rel_selfattn",
                                                 transformer_encoder_activation_type="swish", macaron_style=True,

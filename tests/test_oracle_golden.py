@@ -222,3 +222,73 @@ def test_e2e(oracle, name, cfg):
         hs, _ = oracle.encoder({k: v.detach() for k, v in sd.items()}, "encoder.", p["xs"][:1], None, cfg, training=False)
         ids = oracle.greedy_ctc(oracle.linear(sd, "ctc.ctc_lo.", hs)[0])
         assert ids == p["greedy"].tolist()
+
+
+# ---- RNN paths (rows a20 / a21) -------------------------------------------------------------------
+def _grad_check(sd, grads, rtol=2e-3, atol=2e-5):
+    for k, g in grads.items():
+        a = sd[k].grad
+        if a is None:
+            assert float(g.abs().max()) == 0.0, k
+            continue
+        close(a, g, rtol=rtol, atol=atol)
+
+
+def test_e2e_rnn(oracle):
+    """VGG-BLSTMP encoder + AttLoc LSTM decoder + CTC against the reference E2E (e2e_asr.py:205-338)"""
+    p, sd, grads = split_golden(load_golden("e2e_rnn.npz"))
+    sd = req(sd)
+    hs, hlens = oracle.rnn_encoder(sd, "enc.", p["xs"], p["ilens"].tolist(), 2, [1, 1, 1])   # vgg*: no RNNP subsampling (nets_utils.py:415-424)
+    assert hlens == p["hlens"].tolist()
+    close(hs, p["hs_pad"], rtol=1e-4, atol=1e-5)
+    loss_ctc = oracle.ctc_loss(oracle.linear(sd, "ctc.ctc_lo.", hs), torch.tensor(hlens), p["ys"])
+    loss_att, acc, _ = oracle.rnn_att_decoder(sd, "dec.", hs, hlens, p["ys"], 6, 6, 2, "att.0.")
+    close(loss_ctc.detach(), p["loss_ctc"], rtol=1e-4, atol=1e-5)
+    close(loss_att.detach(), p["loss_att"], rtol=1e-4, atol=1e-5)
+    assert abs(acc - float(p["acc"])) < 1e-6
+    loss = 0.5 * loss_ctc + 0.5 * loss_att
+    close(loss.detach(), p["loss"], rtol=1e-4, atol=1e-5)
+    loss.backward()
+    _grad_check(sd, grads)
+
+
+def test_rnnt_loss_brute_force(oracle):
+    """the lattice recursion equals the explicit sum over all alignments (Graves 2012, eq. 1-3)"""
+    g = torch.Generator().manual_seed(7)
+    for T, U, V in ((1, 1, 3), (3, 1, 4), (1, 3, 4), (4, 3, 5), (3, 4, 6)):
+        z = torch.randn(1, T, U, V, generator=g, dtype=torch.float64)
+        y = torch.randint(1, V, (1, max(U - 1, 1)), generator=g)
+        want = oracle.rnnt_brute_force(z[0], y[0][: U - 1])
+        got = oracle.rnnt_loss(z, y, [T], [U - 1], reduction="none")[0]
+        assert abs(float(got) - float(want)) < 1e-12
+    # padded batch entries do not leak into shorter utterances
+    z = torch.randn(2, 5, 4, 6, generator=g, dtype=torch.float64)
+    y = torch.randint(1, 6, (2, 3), generator=g)
+    both = oracle.rnnt_loss(z, y, [5, 3], [3, 2], reduction="none")
+    solo = oracle.rnnt_loss(z[1:, :3, :3], y[1:, :2], [3], [2], reduction="none")
+    assert abs(float(both[1]) - float(solo[0])) < 1e-12
+
+
+@pytest.mark.parametrize("name", ["transducer_rnn.npz", "transducer_conformer.npz"])
+def test_transducer(oracle, name):
+    """encoder -> DecoderRNNT -> JointNetwork against the reference modules (e2e_asr_transducer.py:510-563);
+    the loss value in the fixture comes from oracle.rnnt_loss itself (warprnnt_pytorch is absent)."""
+    p, sd, grads = split_golden(load_golden(name))
+    sd = req(sd)
+    if "rnn" in name:
+        hs, hlens = oracle.rnn_encoder(sd, "enc.", p["xs"], p["ilens"].tolist(), 1, [1, 1])
+        dl = 2
+    else:
+        cfg = dict(conformer=True, rel_pos=True, activation="swish", aheads=4)
+        mask = oracle.non_pad_mask(p["ilens"]).unsqueeze(-2)
+        hs, hmask = oracle.encoder(sd, "encoder.", p["xs"], mask, cfg, training=True)
+        hlens = hmask.squeeze(1).sum(1).tolist()
+        dl = 1
+    close(hs, p["hs_pad"], rtol=1e-4, atol=1e-5)
+    ys_in, target, ulens = oracle.rnnt_prepare(p["ys"])
+    z = oracle.rnnt_decoder(sd, "dec.", hs, ys_in, dl)
+    close(z, p["pred_pad"], rtol=1e-4, atol=1e-5)
+    loss = oracle.rnnt_loss(z, target, hlens, ulens)
+    assert abs(float(loss) - float(p["loss"])) < 1e-5 * abs(float(p["loss"]))
+    loss.backward()
+    _grad_check(sd, grads)
