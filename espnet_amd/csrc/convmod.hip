@@ -350,7 +350,8 @@ __global__ void bn_bwd_apply_kernel(const float* __restrict__ dy, const float* _
 // x [B, T, F]; w [C, 1, 3, 3]; y [B, H, W, C] with H=(T-3)/2+1, W=(F-3)/2+1
 __global__ __launch_bounds__(256) void conv1_fwd_kernel(const float* __restrict__ x, const float* __restrict__ w,
                                                         const float* __restrict__ bias, float* __restrict__ y, int B,
-                                                        int T, int F, int H, int W, int C, int bf16) {
+                                                        int T, int F, int H, int W, int C, int bf16, int st,
+                                                        int pad) {
   const long n = (long)B * H * W * C;
   const long stride = (long)gridDim.x * blockDim.x;
   for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
@@ -358,13 +359,17 @@ __global__ __launch_bounds__(256) void conv1_fwd_kernel(const float* __restrict_
     long p = i / C;
     const int ww = p % W; p /= W;
     const int hh = p % H; const long b = p / H;
-    const float* xp = x + (b * T + 2 * hh) * F + 2 * ww;
+    const int t0 = st * hh - pad, f0 = st * ww - pad;
+    const float* xb = x + b * T * F;
     const float* wc = w + (long)c * 9;
     float acc = bias[c];
 #pragma unroll
     for (int kh = 0; kh < 3; ++kh)
 #pragma unroll
-      for (int kw = 0; kw < 3; ++kw) acc += wc[kh * 3 + kw] * xp[kh * F + kw];
+      for (int kw = 0; kw < 3; ++kw) {
+        const int tt = t0 + kh, ff = f0 + kw;
+        if (tt >= 0 && tt < T && ff >= 0 && ff < F) acc += wc[kh * 3 + kw] * xb[(long)tt * F + ff];
+      }
     acc = acc > 0.f ? acc : 0.f;
     if (bf16) reinterpret_cast<unsigned short*>(y)[i] = eamd_f2bf(acc); else y[i] = acc;
   }
@@ -373,7 +378,7 @@ __global__ __launch_bounds__(256) void conv1_fwd_kernel(const float* __restrict_
 __global__ __launch_bounds__(256) void conv1_bwd_w_kernel(const float* __restrict__ dy, const float* __restrict__ x,
                                                           float* __restrict__ dw, float* __restrict__ db, int B,
                                                           int T, int F, int H, int W, int C, int pos_per_block,
-                                                          int bf16) {
+                                                          int bf16, int st, int pad) {
   const int c_raw = blockIdx.x * blockDim.x + threadIdx.x;
   const bool live = c_raw < C;
   const int c = live ? c_raw : C - 1;
@@ -390,11 +395,15 @@ __global__ __launch_bounds__(256) void conv1_bwd_w_kernel(const float* __restric
     const float g = bf16 ? __uint_as_float(((unsigned)reinterpret_cast<const unsigned short*>(dy)[p * C + c]) << 16)
                          : dy[p * C + c];
     accb += g;
-    const float* xp = x + (b * T + 2 * hh) * F + 2 * ww;
+    const int t0 = st * hh - pad, f0 = st * ww - pad;
+    const float* xb = x + b * T * F;
 #pragma unroll
     for (int kh = 0; kh < 3; ++kh)
 #pragma unroll
-      for (int kw = 0; kw < 3; ++kw) acc[kh * 3 + kw] += g * xp[kh * F + kw];
+      for (int kw = 0; kw < 3; ++kw) {
+        const int tt = t0 + kh, ff = f0 + kw;
+        if (tt >= 0 && tt < T && ff >= 0 && ff < F) acc[kh * 3 + kw] += g * xb[(long)tt * F + ff];
+      }
   }
   __shared__ float tr9[256 * 10];
 #pragma unroll
@@ -506,29 +515,45 @@ int eamd_bn_bwd(const float* dy, const float* x, const float* mean, const float*
   return EAMD_OK;
 }
 
-int eamd_conv1_fwd(const float* x, const float* w, const float* bias, void* y, int B, int T, int F, int C,
-                   int y_bf16, void* stream) {
-  if (!x || !w || !bias || !y || B <= 0 || T < 3 || F < 3 || C <= 0) return EAMD_EINVAL;
-  int H = (T - 3) / 2 + 1, W = (F - 3) / 2 + 1;
+static int conv_c1_fwd(const float* x, const float* w, const float* bias, void* y, int B, int T, int F, int C,
+                       int y_bf16, int st, int pad, void* stream) {
+  if (!x || !w || !bias || !y || B <= 0 || T + 2 * pad < 3 || F + 2 * pad < 3 || C <= 0) return EAMD_EINVAL;
+  int H = (T + 2 * pad - 3) / st + 1, W = (F + 2 * pad - 3) / st + 1;
   hipLaunchKernelGGL(conv1_fwd_kernel, dim3(grid_for((long)B * H * W * C)), dim3(256), 0, (hipStream_t)stream, x, w,
-                     bias, (float*)y, B, T, F, H, W, C, y_bf16);
+                     bias, (float*)y, B, T, F, H, W, C, y_bf16, st, pad);
   EAMD_LAUNCH_CHECK();
   return EAMD_OK;
 }
+int eamd_conv1_fwd(const float* x, const float* w, const float* bias, void* y, int B, int T, int F, int C,
+                   int y_bf16, void* stream) {
+  return conv_c1_fwd(x, w, bias, y, B, T, F, C, y_bf16, 2, 0, stream);
+}
+int eamd_conv3x3_c1_fwd(const float* x, const float* w, const float* bias, void* y, int B, int T, int F, int C,
+                        int y_bf16, void* stream) {
+  return conv_c1_fwd(x, w, bias, y, B, T, F, C, y_bf16, 1, 1, stream);
+}
 
-int eamd_conv1_bwd_w(const void* dy, const float* x, float* dw, float* db, int B, int T, int F, int C,
-                     int dy_bf16, void* stream) {
-  if (!dy || !x || !dw || !db || B <= 0 || T < 3 || F < 3 || C <= 0) return EAMD_EINVAL;
-  int H = (T - 3) / 2 + 1, W = (F - 3) / 2 + 1;
+static int conv_c1_bwd_w(const void* dy, const float* x, float* dw, float* db, int B, int T, int F, int C,
+                         int dy_bf16, int st, int pad, void* stream) {
+  if (!dy || !x || !dw || !db || B <= 0 || T + 2 * pad < 3 || F + 2 * pad < 3 || C <= 0) return EAMD_EINVAL;
+  int H = (T + 2 * pad - 3) / st + 1, W = (F + 2 * pad - 3) / st + 1;
   long npos = (long)B * H * W;
   int gx = (C + 255) / 256;
   long want = 2048 / gx; if (want < 1) want = 1;
   long ppb = (npos + want - 1) / want; if (ppb < 16) ppb = 16;
   int gy = (int)((npos + ppb - 1) / ppb);
   hipLaunchKernelGGL(conv1_bwd_w_kernel, dim3(gx, gy), dim3(256), 0, (hipStream_t)stream, (const float*)dy, x, dw, db,
-                     B, T, F, H, W, C, (int)ppb, dy_bf16);
+                     B, T, F, H, W, C, (int)ppb, dy_bf16, st, pad);
   EAMD_LAUNCH_CHECK();
   return EAMD_OK;
+}
+int eamd_conv1_bwd_w(const void* dy, const float* x, float* dw, float* db, int B, int T, int F, int C,
+                     int dy_bf16, void* stream) {
+  return conv_c1_bwd_w(dy, x, dw, db, B, T, F, C, dy_bf16, 2, 0, stream);
+}
+int eamd_conv3x3_c1_bwd_w(const void* dy, const float* x, float* dw, float* db, int B, int T, int F, int C,
+                          int dy_bf16, void* stream) {
+  return conv_c1_bwd_w(dy, x, dw, db, B, T, F, C, dy_bf16, 1, 1, stream);
 }
 
 }  // extern "C"

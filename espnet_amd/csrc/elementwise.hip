@@ -67,6 +67,14 @@ __global__ void act_bwd_kernel(const float* __restrict__ dy, const float* __rest
   }
 }
 
+// y[r, :] = keep[r] ? x[r, :] : 0   (masked_fill of padded frames, rnn/encoders.py:323-325)
+__global__ void mask_rows_kernel(const float* __restrict__ x, const unsigned char* __restrict__ keep,
+                                 float* __restrict__ y, long rows, int D) {
+  const long n = rows * D;
+  const long stride = (long)gridDim.x * blockDim.x;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) y[i] = keep[i / D] ? x[i] : 0.f;
+}
+
 // GLU over the channel dim of a [rows, 2C] matrix: y[r,c] = x[r,c] * sigmoid(x[r,C+c]).
 // reference: conformer/convolution.py:72 (glu(dim=1) on (B,2C,T) == per-row halves in (B,T,2C)).
 __global__ void glu_fwd_kernel(const float* __restrict__ x, float* __restrict__ y, long rows, int C) {
@@ -268,6 +276,14 @@ int eamd_act_bwd(const float* dy, const float* x, float* dx, int64_t n, int act,
   if (!dy || !x || !dx || n < 0) return EAMD_EINVAL;
   if (n == 0) return EAMD_OK;
   hipLaunchKernelGGL(act_bwd_kernel, dim3(grid_for(n)), dim3(256), 0, (hipStream_t)stream, dy, x, dx, (long)n, act);
+  EAMD_LAUNCH_CHECK();
+  return EAMD_OK;
+}
+
+int eamd_mask_rows(const float* x, const uint8_t* keep, float* y, int64_t rows, int D, void* stream) {
+  if (!x || !keep || !y || rows <= 0 || D <= 0) return EAMD_EINVAL;
+  hipLaunchKernelGGL(mask_rows_kernel, dim3(grid_for(rows * D)), dim3(256), 0, (hipStream_t)stream, x, keep, y,
+                     (long)rows, D);
   EAMD_LAUNCH_CHECK();
   return EAMD_OK;
 }

@@ -36,10 +36,11 @@ __global__ __launch_bounds__(256) void lstm_fwd_kernel(const float* __restrict__
   }
 }
 
-// dh: gradient wrt h (sum of the output-path and the recurrent-path gradients), dc: gradient wrt c.
-// Outputs dgates [B,4H] (pre-activation gradients), dc_prev, and dh_pass = the part of dh that goes
-// straight to h_prev (masked rows only; 0 elsewhere).
-__global__ __launch_bounds__(256) void lstm_bwd_kernel(const float* __restrict__ dh, const float* __restrict__ dc,
+// dy: gradient wrt the step output y, dh: gradient wrt h arriving from the next step (recurrent path),
+// dc: gradient wrt c (each may be NULL = 0).  Outputs dgates [B,4H] (pre-activation gradients), dc_prev,
+// and dh_pass = the part that goes straight to h_prev (masked rows only; 0 elsewhere).
+__global__ __launch_bounds__(256) void lstm_bwd_kernel(const float* __restrict__ dy, const float* __restrict__ dh,
+                                                       const float* __restrict__ dc,
                                                        const float* __restrict__ acts,
                                                        const float* __restrict__ c_prev, const float* __restrict__ c,
                                                        const unsigned char* __restrict__ live,
@@ -49,13 +50,14 @@ __global__ __launch_bounds__(256) void lstm_bwd_kernel(const float* __restrict__
   for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < n; idx += (long)gridDim.x * blockDim.x) {
     const int b = idx / H, j = idx % H;
     float* db = dgates + (long)b * 4 * H;
-    const float dhv = dh[idx], dcv = dc ? dc[idx] : 0.f;
-    if (live && !live[b]) {
+    const float dhr = dh ? dh[idx] : 0.f, dcv = dc ? dc[idx] : 0.f;
+    if (live && !live[b]) {      // y was 0 there: only the recurrent-path gradient passes through
       db[j] = 0.f; db[H + j] = 0.f; db[2 * H + j] = 0.f; db[3 * H + j] = 0.f;
       dc_prev[idx] = dcv;
-      if (dh_pass) dh_pass[idx] = dhv;
+      if (dh_pass) dh_pass[idx] = dhr;
       continue;
     }
+    const float dhv = dhr + (dy ? dy[idx] : 0.f);
     const float* ab = acts + (long)b * 4 * H;
     const float i = ab[j], f = ab[H + j], gg = ab[2 * H + j], o = ab[3 * H + j];
     const float tc = tanhf(c[idx]);
@@ -103,6 +105,176 @@ __global__ void maxpool_bwd_kernel(const float* __restrict__ dy, const unsigned 
   }
 }
 
+// ---- location-aware attention (AttLoc), one decoder step -----------------------------------------
+// reference: rnn/attentions.py:300-380
+//   conv[b,t,c]  = sum_k conv_w[c,k] * att_prev[b, t + k - F]                 (Conv2d(1,C,(1,2F+1)), no bias)
+//   e[b,t]       = gvec . tanh(W_att conv[b,t] + pre_enc[b,t] + dec_proj[b]) + gb ; -inf for t >= len_b
+//   w[b,:]       = softmax(scaling * e[b,:]) ;  ctx[b,:] = sum_t w[b,t] * enc_h[b,t,:]
+// one workgroup per (b,t); the C location features live in LDS, threads run along the attention dim
+__global__ __launch_bounds__(128) void attloc_energy_fwd_kernel(
+    const float* __restrict__ att_prev, const float* __restrict__ conv_w, const float* __restrict__ w_att,
+    const float* __restrict__ pre_enc, const float* __restrict__ dec_proj, const float* __restrict__ gvec,
+    const float* __restrict__ gb, const int* __restrict__ lens, float* __restrict__ e, float* __restrict__ th,
+    float* __restrict__ conv, int T, int A, int C, int K) {
+  __shared__ float convl[64];
+  __shared__ float red[16];
+  const int bt = blockIdx.x, b = bt / T, t = bt % T;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
+  const int F = (K - 1) / 2;
+  const float* pv = att_prev + (long)b * T;
+  for (int c = wave; c < C; c += nw) {
+    float sacc = 0.f;
+    for (int k = lane; k < K; k += 64) {
+      const int ts = t + k - F;
+      if (ts >= 0 && ts < T) sacc += conv_w[c * K + k] * pv[ts];
+    }
+    sacc = wave_sum(sacc);
+    if (lane == 0) { convl[c] = sacc; conv[(long)bt * C + c] = sacc; }
+  }
+  __syncthreads();
+  float acc = 0.f;
+  for (int a = threadIdx.x; a < A; a += blockDim.x) {
+    float f = pre_enc[(long)bt * A + a] + dec_proj[(long)b * A + a];
+    for (int c = 0; c < C; ++c) f += w_att[a * C + c] * convl[c];
+    const float v = tanhf(f);
+    th[(long)bt * A + a] = v;
+    acc += gvec[a] * v;
+  }
+  acc = block_sum(acc, red);
+  if (threadIdx.x == 0) e[bt] = t < lens[b] ? acc + gb[0] : -INFINITY;
+}
+
+// grid (B, ceil(E/64)); 256 threads = 4 frame-subgroups x 64 feature lanes; dynamic LDS: T floats
+__global__ __launch_bounds__(256) void attloc_ctx_fwd_kernel(const float* __restrict__ e,
+                                                             const float* __restrict__ enc_h, float scaling,
+                                                             float* __restrict__ w, float* __restrict__ ctx, int T,
+                                                             int E) {
+  extern __shared__ float wl[];
+  __shared__ float red[16];
+  __shared__ float part[4][64];
+  const int b = blockIdx.x;
+  const float* eb = e + (long)b * T;
+  float m = -INFINITY;
+  for (int t = threadIdx.x; t < T; t += blockDim.x) m = fmaxf(m, scaling * eb[t]);
+  m = block_max(m, red);
+  float sum = 0.f;
+  for (int t = threadIdx.x; t < T; t += blockDim.x) {
+    const float v = expf(scaling * eb[t] - m);
+    wl[t] = v; sum += v;
+  }
+  sum = block_sum(sum, red);     // (barriers inside also publish wl)
+  const float inv = 1.f / sum;
+  for (int t = threadIdx.x; t < T; t += blockDim.x) {
+    const float v = wl[t] * inv;
+    wl[t] = v;
+    if (blockIdx.y == 0) w[(long)b * T + t] = v;
+  }
+  __syncthreads();
+  const int lane = threadIdx.x & 63, sub = threadIdx.x >> 6;
+  const int col = blockIdx.y * 64 + lane;
+  float acc = 0.f;
+  if (col < E)
+    for (int t = sub; t < T; t += 4) acc += wl[t] * enc_h[((long)b * T + t) * E + col];
+  part[sub][lane] = acc;
+  __syncthreads();
+  if (sub == 0 && col < E) ctx[(long)b * E + col] = (part[0][lane] + part[1][lane]) + (part[2][lane] + part[3][lane]);
+}
+
+// backward of softmax + context: de[b,t] = scaling * w * (dw - sum_t w dw), dw = dw_ext + enc_h . dctx;
+// d_enc_h[b,t,:] = w[b,t] * dctx[b,:]; dgb += sum_t de.   grid B, dynamic LDS T floats
+__global__ __launch_bounds__(256) void attloc_ctx_bwd_kernel(const float* __restrict__ dctx,
+                                                             const float* __restrict__ dw_ext,
+                                                             const float* __restrict__ w,
+                                                             const float* __restrict__ enc_h, float scaling,
+                                                             float* __restrict__ de, float* __restrict__ d_enc_h,
+                                                             float* __restrict__ dgb, int T, int E) {
+  extern __shared__ float dwl[];
+  __shared__ float red[16];
+  const int b = blockIdx.x;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const float* dc = dctx + (long)b * E;
+  for (int t = wave; t < T; t += 4) {
+    const float* h = enc_h + ((long)b * T + t) * E;
+    float d = 0.f;
+    for (int x = lane; x < E; x += 64) d += dc[x] * h[x];
+    d = wave_sum(d);
+    if (lane == 0) dwl[t] = d + (dw_ext ? dw_ext[(long)b * T + t] : 0.f);
+  }
+  __syncthreads();
+  float s = 0.f;
+  for (int t = threadIdx.x; t < T; t += blockDim.x) s += w[(long)b * T + t] * dwl[t];
+  s = block_sum(s, red);
+  float tot = 0.f;
+  for (int t = threadIdx.x; t < T; t += blockDim.x) {
+    const float v = scaling * w[(long)b * T + t] * (dwl[t] - s);
+    de[(long)b * T + t] = v;
+    tot += v;
+  }
+  tot = block_sum(tot, red);
+  if (threadIdx.x == 0) atomicAdd(dgb, tot);
+  const long n = (long)T * E;
+  for (long i = threadIdx.x; i < n; i += blockDim.x)
+    d_enc_h[(long)b * n + i] = w[(long)b * T + i / E] * dc[i % E];
+}
+
+// df[b,t,a] = de[b,t] * gvec[a] * (1 - th^2); dgvec[a] += sum de*th; d_dec_proj[b,a] += sum_t df
+// grid (B, ceil(T/TCH)), threads along a
+constexpr int ATT_TCH = 8;
+__global__ __launch_bounds__(256) void attloc_energy_bwd_kernel(const float* __restrict__ de,
+                                                                const float* __restrict__ th,
+                                                                const float* __restrict__ gvec, float* __restrict__ df,
+                                                                float* __restrict__ dgvec, float* __restrict__ ddec,
+                                                                int T, int A) {
+  const int b = blockIdx.x;
+  const int t0 = blockIdx.y * ATT_TCH, t1 = min(T, t0 + ATT_TCH);
+  for (int a = threadIdx.x; a < A; a += blockDim.x) {
+    const float g = gvec[a];
+    float pg = 0.f, pd = 0.f;
+    for (int t = t0; t < t1; ++t) {
+      const long i = ((long)b * T + t) * A + a;
+      const float d = de[(long)b * T + t], v = th[i];
+      const float f = d * g * (1.f - v * v);
+      df[i] = f;
+      pg += d * v; pd += f;
+    }
+    atomicAdd(&dgvec[a], pg);
+    atomicAdd(&ddec[(long)b * A + a], pd);
+  }
+}
+
+// d_prev[b,s] = sum_{c,k} dconv[b, s - k + F, c] * conv_w[c,k]          grid (B, ceil(T/256))
+__global__ __launch_bounds__(256) void attloc_conv_bwd_prev_kernel(const float* __restrict__ dconv,
+                                                                   const float* __restrict__ conv_w,
+                                                                   float* __restrict__ d_prev, int T, int C, int K) {
+  const int b = blockIdx.x;
+  const int s = blockIdx.y * blockDim.x + threadIdx.x;
+  if (s >= T) return;
+  const int F = (K - 1) / 2;
+  float acc = 0.f;
+  for (int k = 0; k < K; ++k) {
+    const int t = s - k + F;
+    if (t < 0 || t >= T) continue;
+    const float* dcv = dconv + ((long)b * T + t) * C;
+    for (int c = 0; c < C; ++c) acc += dcv[c] * conv_w[c * K + k];
+  }
+  d_prev[(long)b * T + s] = acc;
+}
+// dconv_w[c,k] += sum_{b,t} dconv[b,t,c] * att_prev[b, t + k - F]       grid (C, B), threads along k
+__global__ __launch_bounds__(256) void attloc_conv_bwd_w_kernel(const float* __restrict__ dconv,
+                                                                const float* __restrict__ att_prev,
+                                                                float* __restrict__ dconv_w, int T, int C, int K) {
+  const int c = blockIdx.x, b = blockIdx.y;
+  const int F = (K - 1) / 2;
+  for (int k = threadIdx.x; k < K; k += blockDim.x) {
+    float acc = 0.f;
+    for (int t = 0; t < T; ++t) {
+      const int ts = t + k - F;
+      if (ts >= 0 && ts < T) acc += dconv[((long)b * T + t) * C + c] * att_prev[(long)b * T + ts];
+    }
+    atomicAdd(&dconv_w[c * K + k], acc);
+  }
+}
+
 inline int grid_for(long n) {
   long g = (n + 255) / 256;
   return (int)(g < 1 ? 1 : (g > 65535 ? 65535 : g));
@@ -122,12 +294,12 @@ int eamd_lstm_cell_fwd(const float* gates, const float* c_prev, const float* h_p
   return EAMD_OK;
 }
 
-int eamd_lstm_cell_bwd(const float* dh, const float* dc, const float* acts, const float* c_prev, const float* c,
-                       const uint8_t* live, float* dgates, float* dc_prev, float* dh_pass, int B, int H,
+int eamd_lstm_cell_bwd(const float* dy, const float* dh, const float* dc, const float* acts, const float* c_prev,
+                       const float* c, const uint8_t* live, float* dgates, float* dc_prev, float* dh_pass, int B, int H,
                        void* stream) {
-  if (!dh || !acts || !c_prev || !c || !dgates || !dc_prev || B <= 0 || H <= 0) return EAMD_EINVAL;
+  if ((!dy && !dh && !dc) || !acts || !c_prev || !c || !dgates || !dc_prev || B <= 0 || H <= 0) return EAMD_EINVAL;
   if (live && !dh_pass) return EAMD_EINVAL;
-  hipLaunchKernelGGL(lstm_bwd_kernel, dim3(grid_for((long)B * H)), dim3(256), 0, (hipStream_t)stream, dh, dc, acts,
+  hipLaunchKernelGGL(lstm_bwd_kernel, dim3(grid_for((long)B * H)), dim3(256), 0, (hipStream_t)stream, dy, dh, dc, acts,
                      c_prev, c, live, dgates, dc_prev, dh_pass, B, H);
   EAMD_LAUNCH_CHECK();
   return EAMD_OK;
@@ -147,6 +319,55 @@ int eamd_maxpool2x2_bwd(const float* dy, const uint8_t* idx, float* dx, int B, i
   const int Ho = (H + 1) / 2, Wo = (W + 1) / 2;
   hipLaunchKernelGGL(maxpool_bwd_kernel, dim3(grid_for((long)B * H * W * C)), dim3(256), 0, (hipStream_t)stream, dy, idx,
                      dx, B, H, W, C, Ho, Wo);
+  EAMD_LAUNCH_CHECK();
+  return EAMD_OK;
+}
+
+int eamd_attloc_fwd(const float* att_prev, const float* conv_w, const float* w_att, const float* pre_enc,
+                    const float* dec_proj, const float* gvec, const float* gb, const int32_t* lens, const float* enc_h,
+                    float scaling, float* e, float* th, float* conv, float* w, float* ctx, int B, int T, int A, int C,
+                    int K, int E, void* stream) {
+  if (!att_prev || !conv_w || !w_att || !pre_enc || !dec_proj || !gvec || !gb || !lens || !enc_h || !e || !th ||
+      !conv || !w || !ctx || B <= 0 || T <= 0 || A <= 0 || C <= 0 || K <= 0 || E <= 0)
+    return EAMD_EINVAL;
+  if (C > 64 || (K & 1) == 0 || (size_t)T * sizeof(float) > 60 * 1024) return EAMD_EUNSUPPORTED;
+  hipStream_t s = (hipStream_t)stream;
+  hipLaunchKernelGGL(attloc_energy_fwd_kernel, dim3(B * T), dim3(128), 0, s, att_prev, conv_w, w_att, pre_enc, dec_proj,
+                     gvec, gb, lens, e, th, conv, T, A, C, K);
+  EAMD_LAUNCH_CHECK();
+  hipLaunchKernelGGL(attloc_ctx_fwd_kernel, dim3(B, (E + 63) / 64), dim3(256), T * sizeof(float), s, e, enc_h, scaling,
+                     w, ctx, T, E);
+  EAMD_LAUNCH_CHECK();
+  return EAMD_OK;
+}
+
+/* stage 1 of the backward: de, d_enc_h, dgb, then df / dgvec / d_dec_proj (d_dec_proj, dgvec, dgb accumulate) */
+int eamd_attloc_bwd_energy(const float* dctx, const float* dw_ext, const float* w, const float* enc_h, const float* th,
+                           const float* gvec, float scaling, float* de, float* d_enc_h, float* df, float* dgvec,
+                           float* dgb, float* d_dec_proj, int B, int T, int A, int E, void* stream) {
+  if (!dctx || !w || !enc_h || !th || !gvec || !de || !d_enc_h || !df || !dgvec || !dgb || !d_dec_proj || B <= 0 ||
+      T <= 0 || A <= 0 || E <= 0)
+    return EAMD_EINVAL;
+  if ((size_t)T * sizeof(float) > 60 * 1024) return EAMD_EUNSUPPORTED;
+  hipStream_t s = (hipStream_t)stream;
+  hipLaunchKernelGGL(attloc_ctx_bwd_kernel, dim3(B), dim3(256), T * sizeof(float), s, dctx, dw_ext, w, enc_h, scaling, de,
+                     d_enc_h, dgb, T, E);
+  EAMD_LAUNCH_CHECK();
+  hipLaunchKernelGGL(attloc_energy_bwd_kernel, dim3(B, (T + ATT_TCH - 1) / ATT_TCH), dim3(256), 0, s, de, th, gvec, df,
+                     dgvec, d_dec_proj, T, A);
+  EAMD_LAUNCH_CHECK();
+  return EAMD_OK;
+}
+
+/* stage 2 (after dconv = df @ W_att has been formed by eamd_gemm): gradients of the location convolution */
+int eamd_attloc_bwd_conv(const float* dconv, const float* conv_w, const float* att_prev, float* d_prev, float* dconv_w,
+                         int B, int T, int C, int K, void* stream) {
+  if (!dconv || !conv_w || !att_prev || !d_prev || !dconv_w || B <= 0 || T <= 0 || C <= 0 || K <= 0 || (K & 1) == 0)
+    return EAMD_EINVAL;
+  hipStream_t s = (hipStream_t)stream;
+  hipLaunchKernelGGL(attloc_conv_bwd_prev_kernel, dim3(B, (T + 255) / 256), dim3(256), 0, s, dconv, conv_w, d_prev, T, C, K);
+  EAMD_LAUNCH_CHECK();
+  hipLaunchKernelGGL(attloc_conv_bwd_w_kernel, dim3(C, B), dim3(256), 0, s, dconv, att_prev, dconv_w, T, C, K);
   EAMD_LAUNCH_CHECK();
   return EAMD_OK;
 }

@@ -152,8 +152,8 @@ __global__ __launch_bounds__(256) void rnnt_alpha_beta_kernel(const float* __res
   }
 }
 
-// in place: z[row, v] <- scale * d(-log P(y|x)) / d z[row, v]
-__global__ __launch_bounds__(256) void rnnt_grad_kernel(float* __restrict__ z, const int* __restrict__ labels,
+// g[row, v] <- scale * d(-log P(y|x)) / d z[row, v]   (g may alias z: every element is read before it is written)
+__global__ __launch_bounds__(256) void rnnt_grad_kernel(const float* z, float* g_out, const int* __restrict__ labels,
                                                         const float* __restrict__ lse, const float* __restrict__ lpb,
                                                         const float* __restrict__ lpl, const float* __restrict__ alpha,
                                                         const float* __restrict__ beta, const int* __restrict__ tlens,
@@ -163,13 +163,14 @@ __global__ __launch_bounds__(256) void rnnt_grad_kernel(float* __restrict__ z, c
   const int u = row % U;
   const int t = (row / U) % T;
   const long b = row / ((long)T * U);
-  float* zr = z + row * V;
+  const float* zr = z + row * V;
+  float* gr = g_out + row * V;
   const int Tb = tlens[b], Ub = ulens[b] + 1;
   const float logZ = beta[b * (long)T * U];
   const float a = alpha[row];
   const bool valid = t < Tb && u < Ub && a > -INFINITY && beta[row] > -INFINITY && isfinite(logZ);
   if (!valid) {
-    for (int v = threadIdx.x; v < V; v += blockDim.x) zr[v] = 0.f;
+    for (int v = threadIdx.x; v < V; v += blockDim.x) gr[v] = 0.f;
     return;
   }
   const float sc = scale * (gscale ? gscale[0] : 1.f);
@@ -183,7 +184,7 @@ __global__ __launch_bounds__(256) void rnnt_grad_kernel(float* __restrict__ z, c
     float g = expf(zr[v] + tot);
     if (v == blank) g -= gb;
     if (v == lab) g -= gl;
-    zr[v] = sc * g;
+    gr[v] = sc * g;
   }
 }
 
@@ -214,9 +215,9 @@ int eamd_joint_bwd(const float* dh, const float* enc, const float* dec, float* d
 /* workspace floats: 5 * B*T*U  (lse, lp_blank, lp_label, alpha, beta) */
 int64_t eamd_rnnt_workspace(int B, int T, int U) { return (B <= 0 || T <= 0 || U <= 0) ? 0 : (int64_t)5 * B * T * U; }
 
-int eamd_rnnt_loss(float* logits, const int32_t* labels, const int32_t* tlens, const int32_t* ulens, float* workspace,
-                   float* loss, int B, int T, int U, int V, int blank, int compute_grad, const float* gscale_dev,
-                   float scale, void* stream) {
+int eamd_rnnt_loss(const float* logits, const int32_t* labels, const int32_t* tlens, const int32_t* ulens,
+                   float* workspace, float* loss, float* grad, int B, int T, int U, int V, int blank,
+                   const float* gscale_dev, float scale, void* stream) {
   if (!logits || !labels || !tlens || !ulens || !workspace || !loss || B <= 0 || T <= 0 || U <= 0 || V <= 1)
     return EAMD_EINVAL;
   if (blank < 0 || blank >= V) return EAMD_EINVAL;
@@ -235,8 +236,8 @@ int eamd_rnnt_loss(float* logits, const int32_t* labels, const int32_t* tlens, c
   hipLaunchKernelGGL(rnnt_alpha_beta_kernel, dim3(2 * B), dim3(256), 2 * U * sizeof(float), s, lpb, lpl, tlens, ulens,
                      alpha, beta, loss, B, T, U);
   EAMD_LAUNCH_CHECK();
-  if (compute_grad) {
-    hipLaunchKernelGGL(rnnt_grad_kernel, dim3((unsigned)n), dim3(256), 0, s, logits, labels, lse, lpb, lpl, alpha, beta,
+  if (grad) {
+    hipLaunchKernelGGL(rnnt_grad_kernel, dim3((unsigned)n), dim3(256), 0, s, logits, grad, labels, lse, lpb, lpl, alpha, beta,
                        tlens, ulens, gscale_dev, scale, T, U, V, blank);
     EAMD_LAUNCH_CHECK();
   }

@@ -61,6 +61,21 @@ def dropout(x, p, salt, training):
     return DropoutFn.apply(x, p, salt) if (training and p > 0.0) else x
 
 
+class MaskRowsFn(torch.autograd.Function):
+    """x.masked_fill(~keep, 0) over the frames of a padded batch (rnn/encoders.py:323-325); keep: bool [B,T,1]"""
+
+    @staticmethod
+    def forward(ctx, x, keep):
+        k8 = keep.reshape(-1).to(torch.uint8).contiguous()
+        ctx.save_for_backward(k8)
+        return ops.mask_rows(x.reshape(-1, x.shape[-1]).contiguous(), k8).view(x.shape)
+
+    @staticmethod
+    def backward(ctx, dy):
+        (k8,) = ctx.saved_tensors
+        return ops.mask_rows(dy.reshape(-1, dy.shape[-1]).contiguous(), k8).view(dy.shape), None
+
+
 # =================================================================================================
 # LayerNorm  (reference: transformer/layer_norm.py:12-38)
 # =================================================================================================
@@ -557,6 +572,19 @@ class LabelSmoothingLossFn(torch.autograd.Function):
     def backward(ctx, g, _gc):
         (grad,) = ctx.saved_tensors
         return ops.scale_dev(grad, g.contiguous(), 1.0, out=grad).view(ctx.shp), None, None, None, None
+
+
+class ScaleFn(torch.autograd.Function):
+    """a * x for a host constant a (rnn/decoders.py:272: loss *= mean(len(ys_in)) - 1)"""
+
+    @staticmethod
+    def forward(ctx, x, a):
+        ctx.a = a
+        return ops.axpby(x.reshape(-1).contiguous(), None, a, 0.0).view(x.shape)
+
+    @staticmethod
+    def backward(ctx, g):
+        return ops.axpby(g.reshape(-1).contiguous(), None, ctx.a, 0.0).view(g.shape), None
 
 
 class WeightedSumFn(torch.autograd.Function):

@@ -1,0 +1,117 @@
+"""espnet1 transducer model surface on the espnet_amd HIP kernels.
+
+Plug-in slot: ``--model-module espnet_amd.nets.e2e_asr_transducer:E2E``
+(reference: espnet/nets/pytorch_backend/e2e_asr_transducer.py:41-675; BASELINE config 5:
+custom Conformer encoder + LSTM prediction network + joint network + transducer loss).
+"""
+from collections import Counter
+
+import torch
+
+from .asr_interface import ASRInterface
+from .e2e_asr import get_subsample, lecun_normal_init_parameters, set_forget_bias_to_one
+from .modules import make_non_pad_mask
+from .rnn.encoders import encoder_for
+from .transducer.loss import TransLoss
+from .transducer.rnn_decoder import DecoderRNNT
+from .transducer.transformer_encoder import Encoder
+from .transducer.utils import prepare_loss_inputs
+
+
+def _initialize_transformer(model, init_type):
+    """reference: transformer/initializer.py:13-42"""
+    if init_type == "pytorch":
+        return
+    for p in model.parameters():
+        if p.dim() > 1:
+            if init_type == "xavier_uniform":
+                torch.nn.init.xavier_uniform_(p.data)
+            elif init_type == "xavier_normal":
+                torch.nn.init.xavier_normal_(p.data)
+            elif init_type == "kaiming_uniform":
+                torch.nn.init.kaiming_uniform_(p.data, nonlinearity="relu")
+            elif init_type == "kaiming_normal":
+                torch.nn.init.kaiming_normal_(p.data, nonlinearity="relu")
+            else:
+                raise ValueError("Unknown initialization: " + init_type)
+    for p in model.parameters():
+        if p.dim() == 1:
+            p.data.zero_()
+    for m in model.modules():
+        if isinstance(m, (torch.nn.Embedding, torch.nn.LayerNorm)):
+            m.reset_parameters()
+
+
+class E2E(ASRInterface, torch.nn.Module):
+    """reference: e2e_asr_transducer.py:356-563 (rnnt mode, lstm prediction network)"""
+
+    def __init__(self, idim, odim, args, ignore_id=-1, blank_id=0):
+        torch.nn.Module.__init__(self)
+        if "transformer" in args.etype:
+            if getattr(args, "enc_block_arch", None) is None:
+                raise ValueError("Transformer-based blocks in transducer mode should be defined individually "
+                                 "in the YAML file. See egs/vivos/asr1/conf/transducer/* for more info.")
+            self.subsample = get_subsample(args, mode="asr", arch="transformer")
+            self.encoder = Encoder(
+                idim, args.enc_block_arch, input_layer=args.transformer_enc_input_layer,
+                repeat_block=args.enc_block_repeat, self_attn_type=args.transformer_enc_self_attn_type,
+                positional_encoding_type=args.transformer_enc_positional_encoding_type,
+                positionwise_activation_type=args.transformer_enc_pw_activation_type,
+                conv_mod_activation_type=args.transformer_enc_conv_mod_activation_type)
+            encoder_out = self.encoder.enc_out
+            args.eprojs = self.encoder.enc_out
+            self.most_dom_list = args.enc_block_arch[:]
+        else:
+            self.subsample = get_subsample(args, mode="asr", arch="rnn-t")
+            self.enc = encoder_for(args, idim, self.subsample)
+            encoder_out = args.eprojs
+        if "transformer" in args.dtype:
+            raise NotImplementedError("transformer-transducer decoder is outside the hot-path scope (SURVEY.md 8f)")
+        if getattr(args, "rnnt_mode", "rnnt") != "rnnt":
+            raise NotImplementedError("rnnt-att mode is outside the hot-path scope (SURVEY.md 8f)")
+        self.dec = DecoderRNNT(encoder_out, odim, args.dtype, args.dlayers, args.dunits, blank_id,
+                               args.dec_embed_dim, args.joint_dim, args.joint_activation_type,
+                               args.dropout_rate_decoder, args.dropout_rate_embed_decoder)
+        if hasattr(self, "most_dom_list"):
+            self.most_dom_dim = sorted(Counter(d["d_hidden"] for d in self.most_dom_list if "d_hidden" in d)
+                                       .most_common(), key=lambda x: x[0], reverse=True)[0][0]
+        self.etype, self.dtype, self.rnnt_mode = args.etype, args.dtype, getattr(args, "rnnt_mode", "rnnt")
+        self.sos = odim - 1
+        self.eos = odim - 1
+        self.blank_id = blank_id
+        self.ignore_id = ignore_id
+        self.space = args.sym_space
+        self.blank = args.sym_blank
+        self.odim = odim
+        self.criterion = TransLoss(args.trans_type, self.blank_id)
+        self.default_parameters(args)
+        self.error_calculator = None
+        self.loss = None
+        self.rnnlm = None
+
+    def default_parameters(self, args):
+        """reference: transducer/initializer.py:12-36"""
+        if "transformer" in args.etype:
+            _initialize_transformer(self.encoder, args.transformer_init)
+            lecun_normal_init_parameters(self.dec)
+        else:
+            lecun_normal_init_parameters(self)
+        self.dec.embed.weight.data.normal_(0, 1)
+        for i in range(len(self.dec.decoder)):
+            set_forget_bias_to_one(self.dec.decoder[i].bias_ih)
+
+    def forward(self, xs_pad, ilens, ys_pad):
+        """xs_pad (B,Tmax,idim), ilens (B), ys_pad (B,Lmax) -> transducer loss (e2e_asr_transducer.py:510-563)"""
+        il = [int(v) for v in (ilens.tolist() if torch.is_tensor(ilens) else ilens)]
+        xs_pad = xs_pad[:, : max(il)]
+        if "transformer" in self.etype:
+            src_mask = make_non_pad_mask(il).to(xs_pad.device).unsqueeze(-2)
+            hs_pad, hs_mask = self.encoder(xs_pad, src_mask)
+        else:
+            hs_pad, hs_mask, _ = self.enc(xs_pad, il)
+        self.hs_pad = hs_pad
+        ys_in_pad, target, pred_len, target_len = prepare_loss_inputs(ys_pad, hs_mask)
+        pred_pad = self.dec(hs_pad, ys_in_pad)
+        self.pred_pad = pred_pad
+        self.loss = self.criterion(pred_pad, target, pred_len, target_len)
+        return self.loss

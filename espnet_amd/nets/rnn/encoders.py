@@ -1,0 +1,183 @@
+"""VGG / (B)LSTM(P) encoders.  reference: espnet/nets/pytorch_backend/rnn/encoders.py (same class names,
+constructor arguments and parameter names; torch.nn.LSTM containers are replaced by `LSTM` below, whose
+parameters carry torch.nn.LSTM's names so reference checkpoints load key-for-key).  GRU variants have no
+HIP kernel yet and raise NotImplementedError."""
+import math
+
+import numpy as np
+import torch
+
+from ... import functional as F_
+from ... import ops
+from ... import rnn_functional as R_
+from ..modules import make_pad_mask
+
+
+class LSTM(torch.nn.Module):
+    """single-layer (bi)directional LSTM, batch_first, on padded batches + lengths (what
+    pack_padded_sequence -> torch.nn.LSTM -> pad_packed_sequence computes, encoders.py:62-71)."""
+
+    def __init__(self, input_size, hidden_size, bidirectional=False):
+        super().__init__()
+        self.input_size, self.hidden_size, self.bidirectional = input_size, hidden_size, bidirectional
+        k = 1.0 / math.sqrt(hidden_size)
+        for sfx in ([""] + (["_reverse"] if bidirectional else [])):
+            for name, shape in (("weight_ih_l0", (4 * hidden_size, input_size)),
+                                ("weight_hh_l0", (4 * hidden_size, hidden_size)),
+                                ("bias_ih_l0", (4 * hidden_size,)), ("bias_hh_l0", (4 * hidden_size,))):
+                self.register_parameter(name + sfx, torch.nn.Parameter(torch.empty(shape).uniform_(-k, k)))
+
+    def flatten_parameters(self):
+        pass
+
+    def forward(self, xs_pad, ilens):
+        """xs_pad (B,T,I), ilens list[int] -> (B, max(ilens), H or 2H), zeros after each length"""
+        B = xs_pad.shape[0]
+        T = int(max(ilens))
+        x_tm = xs_pad[:, :T].transpose(0, 1).contiguous()                   # time-major for per-frame views
+        live = torch.from_numpy((np.arange(T)[:, None] < np.asarray(ilens)[None, :]).astype(np.uint8))
+        live = live.to(xs_pad.device, non_blocking=True) if min(ilens) < T else None
+        outs = []
+        for sfx, rev in (("", False),) + ((("_reverse", True),) if self.bidirectional else ()):
+            gx = F_.LinearFn.apply(x_tm, getattr(self, "weight_ih_l0" + sfx), getattr(self, "bias_ih_l0" + sfx))
+            outs.append(R_.LSTMSeqFn.apply(gx, getattr(self, "weight_hh_l0" + sfx), getattr(self, "bias_hh_l0" + sfx),
+                                           live, rev))
+        y = outs[0] if len(outs) == 1 else torch.cat(outs, dim=-1)
+        return y.transpose(0, 1).contiguous()
+
+
+def _lstm_or_raise(typ):
+    if "lstm" not in typ:
+        raise NotImplementedError("etype %r: only (b)lstm(p) encoders have HIP kernels (GRU: SURVEY.md 8f)" % typ)
+
+
+class RNNP(torch.nn.Module):
+    """reference: rnn/encoders.py:15-100"""
+
+    def __init__(self, idim, elayers, cdim, hdim, subsample, dropout, typ="blstm"):
+        super().__init__()
+        _lstm_or_raise(typ)
+        bidir = typ[0] == "b"
+        for i in range(elayers):
+            inputdim = idim if i == 0 else hdim
+            setattr(self, "%s%d" % ("birnn" if bidir else "rnn", i), LSTM(inputdim, cdim, bidirectional=bidir))
+            setattr(self, "bt%d" % i, torch.nn.Linear(2 * cdim if bidir else cdim, hdim))
+        self.elayers, self.cdim, self.subsample, self.typ, self.bidir, self.dropout = \
+            elayers, cdim, subsample, typ, bidir, dropout
+        self.salts = [ops.new_salt() for _ in range(elayers)]
+
+    def forward(self, xs_pad, ilens, prev_state=None):
+        assert prev_state is None, "streaming states are not on the training path"
+        ilens = [int(v) for v in ilens]
+        for layer in range(self.elayers):
+            rnn = getattr(self, ("birnn" if self.bidir else "rnn") + str(layer))
+            ys_pad = rnn(xs_pad, ilens)
+            sub = int(self.subsample[layer + 1])
+            if sub > 1:
+                ys_pad = ys_pad[:, ::sub].contiguous()
+                ilens = [(i + 1) // sub for i in ilens]
+            bt = getattr(self, "bt%d" % layer)
+            xs_pad = F_.LinearFn.apply(ys_pad, bt.weight, bt.bias)
+            if layer < self.elayers - 1:
+                # encoders.py:98: tanh(F.dropout(x, p)) - functional dropout, active in eval mode too
+                xs_pad = R_.ActFn.apply(F_.dropout(xs_pad, self.dropout, self.salts[layer], True), ops.ACT_TANH)
+        return xs_pad, ilens, None
+
+
+class RNN(torch.nn.Module):
+    """reference: rnn/encoders.py:103-162 (stacked (B)LSTM + tanh(Linear)); parameters keep
+    torch.nn.LSTM's `nbrnn.weight_ih_l{k}[_reverse]` names."""
+
+    def __init__(self, idim, elayers, cdim, hdim, dropout, typ="blstm"):
+        super().__init__()
+        _lstm_or_raise(typ)
+        bidir = typ[0] == "b"
+        self.nbrnn = torch.nn.LSTM(idim, cdim, elayers, batch_first=True, dropout=dropout, bidirectional=bidir)
+        self.l_last = torch.nn.Linear(cdim * 2 if bidir else cdim, hdim)
+        self.typ, self.bidir, self.elayers, self.dropout = typ, bidir, elayers, dropout
+        self.salts = [ops.new_salt() for _ in range(elayers)]
+
+    def forward(self, xs_pad, ilens, prev_state=None):
+        assert prev_state is None
+        ilens = [int(v) for v in ilens]
+        B = xs_pad.shape[0]
+        T = int(max(ilens))
+        x = xs_pad[:, :T].transpose(0, 1).contiguous()
+        live = torch.from_numpy((np.arange(T)[:, None] < np.asarray(ilens)[None, :]).astype(np.uint8))
+        live = live.to(xs_pad.device, non_blocking=True) if min(ilens) < T else None
+        for k in range(self.elayers):
+            outs = []
+            for sfx, rev in (("", False),) + ((("_reverse", True),) if self.bidir else ()):
+                p = lambda n: getattr(self.nbrnn, "%s_l%d%s" % (n, k, sfx))   # noqa: E731
+                gx = F_.LinearFn.apply(x, p("weight_ih"), p("bias_ih"))
+                outs.append(R_.LSTMSeqFn.apply(gx, p("weight_hh"), p("bias_hh"), live, rev))
+            x = outs[0] if len(outs) == 1 else torch.cat(outs, dim=-1)
+            if k < self.elayers - 1:   # torch.nn.LSTM(dropout=p): between layers, training mode only
+                x = F_.dropout(x, self.dropout, self.salts[k], self.training)
+        ys = x.transpose(0, 1).contiguous()
+        proj = R_.ActFn.apply(F_.LinearFn.apply(ys, self.l_last.weight, self.l_last.bias), ops.ACT_TANH)
+        return proj, ilens, None
+
+
+class VGG2L(torch.nn.Module):
+    """reference: rnn/encoders.py:178-237"""
+
+    def __init__(self, in_channel=1):
+        super().__init__()
+        if in_channel != 1:
+            raise NotImplementedError("VGG2L HIP path: in_channel = 1")
+        self.conv1_1 = torch.nn.Conv2d(in_channel, 64, 3, stride=1, padding=1)
+        self.conv1_2 = torch.nn.Conv2d(64, 64, 3, stride=1, padding=1)
+        self.conv2_1 = torch.nn.Conv2d(64, 128, 3, stride=1, padding=1)
+        self.conv2_2 = torch.nn.Conv2d(128, 128, 3, stride=1, padding=1)
+        self.in_channel = in_channel
+
+    def forward(self, xs_pad, ilens, **kwargs):
+        y = R_.VGG2LFn.apply(xs_pad, self.conv1_1.weight, self.conv1_1.bias, self.conv1_2.weight, self.conv1_2.bias,
+                             self.conv2_1.weight, self.conv2_1.bias, self.conv2_2.weight, self.conv2_2.bias)
+        ilens = [int(math.ceil(math.ceil(int(v) / 2) / 2)) for v in ilens]
+        return y, ilens, None
+
+
+def get_vgg2l_odim(idim, in_channel=3, out_channel=128):
+    """reference: espnet/nets/e2e_asr_common.py:238-249"""
+    idim = idim / in_channel
+    idim = np.ceil(np.array(idim, dtype=np.float32) / 2)
+    idim = np.ceil(np.array(idim, dtype=np.float32) / 2)
+    return int(idim) * out_channel
+
+
+class Encoder(torch.nn.Module):
+    """reference: rnn/encoders.py:240-326"""
+
+    def __init__(self, etype, idim, elayers, eunits, eprojs, subsample, dropout, in_channel=1):
+        super().__init__()
+        typ = etype.lstrip("vgg").rstrip("p")
+        if typ not in ["lstm", "gru", "blstm", "bgru"]:
+            raise ValueError("Error: need to specify an appropriate encoder architecture")
+        mods = []
+        if etype.startswith("vgg"):
+            mods.append(VGG2L(in_channel))
+            idim = get_vgg2l_odim(idim, in_channel=in_channel)
+        if etype[-1] == "p":
+            mods.append(RNNP(idim, elayers, eunits, eprojs, subsample, dropout, typ=typ))
+        else:
+            mods.append(RNN(idim, elayers, eunits, eprojs, dropout, typ=typ))
+        self.enc = torch.nn.ModuleList(mods)
+
+    def forward(self, xs_pad, ilens, prev_states=None):
+        assert prev_states is None
+        ilens = [int(v) for v in (ilens.tolist() if torch.is_tensor(ilens) else ilens)]
+        for module in self.enc:
+            xs_pad, ilens, _ = module(xs_pad, ilens)
+        # encoders.py:323-325: zero the padded frames (projection biases leak into them otherwise)
+        keep = (~make_pad_mask(ilens, xs_pad.shape[1])).to(xs_pad.device).unsqueeze(-1)
+        return F_.MaskRowsFn.apply(xs_pad, keep), ilens, None
+
+
+def encoder_for(args, idim, subsample):
+    """reference: rnn/encoders.py:329-372 (single encoder)"""
+    num_encs = getattr(args, "num_encs", 1)
+    if num_encs != 1:
+        raise NotImplementedError("multi-encoder mode is out of the hot-path scope")
+    return Encoder(args.etype, idim, args.elayers, args.eunits, args.eprojs, subsample, args.dropout_rate)

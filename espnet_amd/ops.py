@@ -612,3 +612,152 @@ def make_rowmap(Ho, Wo, Hc, Wc, sh, oh, sw, ow):
     m.enabled = 1
     m.Ho, m.Wo, m.Hc, m.Wc, m.sh, m.oh, m.sw, m.ow = Ho, Wo, Hc, Wc, sh, oh, sw, ow
     return m
+
+
+# ---- recurrent layers / RNN-Transducer (rows a20, a21) -------------------------------------------
+ACT_TANH = 3
+
+
+def act_fwd_any(x, act):
+    y = torch.empty_like(x)
+    check(_lib.lib().eamd_act_fwd(ptr(x), ptr(y), C.c_int64(x.numel()), act, stream_ptr()), "eamd_act_fwd")
+    return y
+
+
+def act_bwd_any(dy, x, act):
+    dx = torch.empty_like(x)
+    check(_lib.lib().eamd_act_bwd(ptr(dy), ptr(x), ptr(dx), C.c_int64(x.numel()), act, stream_ptr()), "eamd_act_bwd")
+    return dx
+
+
+def lstm_cell_fwd(gates, c_prev, h_prev, live, h, c, y, acts):
+    B, H4 = gates.shape
+    H = H4 // 4
+    assert c_prev.numel() == B * H and h.numel() == B * H and c.numel() == B * H and acts.numel() == B * H4
+    assert live is None or (live.dtype == torch.uint8 and live.numel() == B and h_prev is not None)
+    check(_lib.lib().eamd_lstm_cell_fwd(ptr(gates), ptr(c_prev), ptr(h_prev), ptr(live), ptr(h), ptr(c), ptr(y),
+                                        ptr(acts), B, H, stream_ptr()), "eamd_lstm_cell_fwd")
+
+
+def lstm_cell_bwd(dy, dh, dc, acts, c_prev, c, live, dgates, dc_prev, dh_pass):
+    B, H4 = acts.shape
+    H = H4 // 4
+    assert dgates.numel() == B * H4 and dc_prev.numel() == B * H
+    check(_lib.lib().eamd_lstm_cell_bwd(ptr(dy), ptr(dh), ptr(dc), ptr(acts), ptr(c_prev), ptr(c), ptr(live),
+                                        ptr(dgates), ptr(dc_prev), ptr(dh_pass), B, H, stream_ptr()),
+          "eamd_lstm_cell_bwd")
+
+
+def maxpool2x2_fwd(x):
+    B, H, W, Cc = x.shape
+    y = torch.empty(B, (H + 1) // 2, (W + 1) // 2, Cc, device=x.device, dtype=torch.float32)
+    idx = torch.empty(y.shape, device=x.device, dtype=torch.uint8)
+    check(_lib.lib().eamd_maxpool2x2_fwd(ptr(x), ptr(y), ptr(idx), B, H, W, Cc, stream_ptr()), "eamd_maxpool2x2_fwd")
+    return y, idx
+
+
+def maxpool2x2_bwd(dy, idx, shape):
+    B, H, W, Cc = shape
+    dx = torch.empty(B, H, W, Cc, device=dy.device, dtype=torch.float32)
+    check(_lib.lib().eamd_maxpool2x2_bwd(ptr(dy), ptr(idx), ptr(dx), B, H, W, Cc, stream_ptr()), "eamd_maxpool2x2_bwd")
+    return dx
+
+
+def conv3x3_c1_fwd(x, w, bias, B, T, F, Cc, out_dtype=torch.float32):
+    assert x.numel() == B * T * F and w.numel() == Cc * 9
+    y = torch.empty(B, T, F, Cc, device=x.device, dtype=out_dtype)
+    check(_lib.lib().eamd_conv3x3_c1_fwd(ptr(x), ptr(w), ptr(bias), ptr(y), B, T, F, Cc,
+                                         1 if out_dtype == torch.bfloat16 else 0, stream_ptr()), "eamd_conv3x3_c1_fwd")
+    return y
+
+
+def conv3x3_c1_bwd_w(dy, x, dw, db, B, T, F, Cc):
+    check(_lib.lib().eamd_conv3x3_c1_bwd_w(ptr(dy), ptr(x), ptr(dw), ptr(db), B, T, F, Cc,
+                                           1 if dy.dtype == torch.bfloat16 else 0, stream_ptr()),
+          "eamd_conv3x3_c1_bwd_w")
+
+
+def joint_fwd(enc, dec, act, out_dtype=torch.float32):
+    B, T, J = enc.shape
+    U = dec.shape[1]
+    assert dec.shape[0] == B and dec.shape[2] == J and enc.is_contiguous() and dec.is_contiguous()
+    out = torch.empty(B, T, U, J, device=enc.device, dtype=out_dtype)
+    o32, o16 = (ptr(out), None) if out_dtype == torch.float32 else (None, ptr(out))
+    check(_lib.lib().eamd_joint_fwd(ptr(enc), ptr(dec), o32, o16, B, T, U, J, act, stream_ptr()), "eamd_joint_fwd")
+    return out
+
+
+def joint_bwd(dh, enc, dec, act):
+    B, T, J = enc.shape
+    U = dec.shape[1]
+    assert dh.numel() == B * T * U * J and dh.dtype == torch.float32
+    d_enc = torch.empty_like(enc)
+    d_dec = torch.empty_like(dec)
+    check(_lib.lib().eamd_joint_bwd(ptr(dh), ptr(enc), ptr(dec), ptr(d_enc), ptr(d_dec), B, T, U, J, act,
+                                    stream_ptr()), "eamd_joint_bwd")
+    return d_enc, d_dec
+
+
+def rnnt_loss(logits, labels, tlens, ulens, blank, grad=None, gscale=None, scale=1.0):
+    """logits [B,T,U,V] fp32; labels [B,U-1] int32; tlens/ulens [B] int32 -> per-utterance loss [B]"""
+    B, T, U, V = logits.shape
+    assert logits.dtype == torch.float32 and logits.is_contiguous()
+    assert labels.dtype == torch.int32 and labels.is_contiguous() and labels.numel() == B * max(U - 1, 0)
+    assert tlens.dtype == torch.int32 and ulens.dtype == torch.int32 and tlens.numel() == B and ulens.numel() == B
+    assert grad is None or (grad.numel() == logits.numel() and grad.dtype == torch.float32)
+    ws = torch.empty(int(_lib.lib().eamd_rnnt_workspace(B, T, U)), device=logits.device, dtype=torch.float32)
+    loss = torch.empty(B, device=logits.device, dtype=torch.float32)
+    lab = labels if labels.numel() > 0 else torch.zeros(1, device=logits.device, dtype=torch.int32)
+    check(_lib.lib().eamd_rnnt_loss(ptr(logits), ptr(lab), ptr(tlens), ptr(ulens), ptr(ws), ptr(loss), ptr(grad),
+                                    B, T, U, V, blank, ptr(gscale), C.c_float(scale), stream_ptr()), "eamd_rnnt_loss")
+    return loss
+
+
+def attloc_fwd(att_prev, conv_w, w_att, pre_enc, dec_proj, gvec, gb, lens, enc_h, scaling):
+    B, T, A = pre_enc.shape
+    Cc, K = conv_w.shape[0], conv_w.shape[-1]
+    E = enc_h.shape[2]
+    dev = enc_h.device
+    assert att_prev.shape == (B, T) and dec_proj.shape == (B, A) and w_att.shape == (A, Cc) and gvec.numel() == A
+    assert lens.dtype == torch.int32 and lens.numel() == B and conv_w.numel() == Cc * K
+    e = torch.empty(B, T, device=dev, dtype=torch.float32)
+    th = torch.empty(B, T, A, device=dev, dtype=torch.float32)
+    conv = torch.empty(B, T, Cc, device=dev, dtype=torch.float32)
+    w = torch.empty(B, T, device=dev, dtype=torch.float32)
+    ctx = torch.empty(B, E, device=dev, dtype=torch.float32)
+    check(_lib.lib().eamd_attloc_fwd(ptr(att_prev), ptr(conv_w), ptr(w_att), ptr(pre_enc), ptr(dec_proj), ptr(gvec),
+                                     ptr(gb), ptr(lens), ptr(enc_h), C.c_float(scaling), ptr(e), ptr(th), ptr(conv),
+                                     ptr(w), ptr(ctx), B, T, A, Cc, K, E, stream_ptr()), "eamd_attloc_fwd")
+    return ctx, w, th, conv
+
+
+def attloc_bwd_energy(dctx, dw_ext, w, enc_h, th, gvec, scaling, dgvec, dgb):
+    B, T, A = th.shape
+    E = enc_h.shape[2]
+    dev = enc_h.device
+    de = torch.empty(B, T, device=dev, dtype=torch.float32)
+    d_enc_h = torch.empty(B, T, E, device=dev, dtype=torch.float32)
+    df = torch.empty(B, T, A, device=dev, dtype=torch.float32)
+    d_dec = torch.zeros(B, A, device=dev, dtype=torch.float32)
+    check(_lib.lib().eamd_attloc_bwd_energy(ptr(dctx), ptr(dw_ext), ptr(w), ptr(enc_h), ptr(th), ptr(gvec),
+                                            C.c_float(scaling), ptr(de), ptr(d_enc_h), ptr(df), ptr(dgvec), ptr(dgb),
+                                            ptr(d_dec), B, T, A, E, stream_ptr()), "eamd_attloc_bwd_energy")
+    return d_enc_h, df, d_dec
+
+
+def attloc_bwd_conv(dconv, conv_w, att_prev, dconv_w):
+    B, T, Cc = dconv.shape
+    K = conv_w.shape[-1]
+    d_prev = torch.empty(B, T, device=dconv.device, dtype=torch.float32)
+    check(_lib.lib().eamd_attloc_bwd_conv(ptr(dconv), ptr(conv_w), ptr(att_prev), ptr(d_prev), ptr(dconv_w), B, T, Cc,
+                                          K, stream_ptr()), "eamd_attloc_bwd_conv")
+    return d_prev
+
+
+def mask_rows(x, keep):
+    """x [rows, D] fp32, keep [rows] uint8 -> rows with keep == 0 zeroed"""
+    rows, D = x.shape
+    assert keep.dtype == torch.uint8 and keep.numel() == rows and x.dtype == torch.float32
+    y = torch.empty_like(x)
+    check(_lib.lib().eamd_mask_rows(ptr(x), ptr(keep), ptr(y), C.c_int64(rows), D, stream_ptr()), "eamd_mask_rows")
+    return y

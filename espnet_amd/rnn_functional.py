@@ -1,0 +1,306 @@
+"""autograd Functions of the RNN paths (VGG-BLSTMP encoder, location-aware attention decoder,
+RNN-Transducer predictor / joint network / loss): explicit HIP kernel sequences over the C ABI, same
+conventions as espnet_amd.functional (weight gradients go to the flat gradient arena when present).
+
+reference: rnn/encoders.py, rnn/attentions.py:250-380, rnn/decoders.py:142-311,
+transducer/rnn_decoder.py, transducer/joint_network.py, transducer/loss.py.
+"""
+import torch
+
+from . import ops
+from .functional import GradSink
+from .ops import ACT_RELU, EPI_MUL_RELU_MASK, EPI_RELU
+
+
+class ActFn(torch.autograd.Function):
+    """elementwise activation (tanh between RNNP layers, encoders.py:98)"""
+
+    @staticmethod
+    def forward(ctx, x, act):
+        x = x.contiguous()
+        ctx.save_for_backward(x)
+        ctx.act = act
+        return ops.act_fwd_any(x, act)
+
+    @staticmethod
+    def backward(ctx, dy):
+        (x,) = ctx.saved_tensors
+        return ops.act_bwd_any(dy.contiguous(), x, ctx.act), None
+
+
+class PlainEmbedFn(torch.autograd.Function):
+    """torch.nn.Embedding lookup; pad_idx >= 0 = Embedding(padding_idx): no gradient for that row
+    (rnn/decoders.py:88, transducer/rnn_decoder.py:44)."""
+
+    @staticmethod
+    def forward(ctx, tokens, table, pad_idx):
+        tok = tokens.contiguous()
+        out = ops.embed_pe(tok.view(-1), table, None, 1, 1.0)
+        ctx.save_for_backward(tok)
+        ctx.pr = (table,)
+        ctx.pad = pad_idx
+        return out.view(*tokens.shape, table.shape[1])
+
+    @staticmethod
+    def backward(ctx, dout):
+        (tok,) = ctx.saved_tensors
+        sink = GradSink(ctx.pr)
+        ops.embed_bwd(tok.view(-1), dout.reshape(-1, dout.shape[-1]).contiguous(), sink.buf(0), 1.0, ctx.pad)
+        return (None,) + sink.results() + (None,)
+
+
+# =================================================================================================
+# LSTM over a whole sequence whose input projections are known up front (encoder layers, transducer
+# predictor): gx[T,B,4H] = x W_ih^T + b_ih for all frames is ONE GEMM done by the caller; this Function
+# runs the recurrence (one small GEMM + one pointwise kernel per frame) and, in backward, gathers the
+# recurrent weight gradient of all frames into a single GEMM.
+# live[T,B] uint8 reproduces pack_padded_sequence: finished sequences keep their state, emit zeros.
+# =================================================================================================
+class LSTMSeqFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, gx, w_hh, b_hh, live, reverse):
+        T, B, H4 = gx.shape
+        H = H4 // 4
+        dev = gx.device
+        gx = gx.contiguous()
+        h_out = torch.empty(T, B, H, device=dev, dtype=torch.float32)
+        c_out = torch.empty(T, B, H, device=dev, dtype=torch.float32)
+        acts = torch.empty(T, B, H4, device=dev, dtype=torch.float32)
+        y = torch.empty(T, B, H, device=dev, dtype=torch.float32)
+        zero = torch.zeros(B, H, device=dev, dtype=torch.float32)
+        gates = torch.empty(B, H4, device=dev, dtype=torch.float32)
+        hp, cp = zero, zero
+        for t in (range(T - 1, -1, -1) if reverse else range(T)):
+            ops.gemm(hp, w_hh, gates, B, H4, H, H, H, H4, bias=b_hh, R=gx[t], ldr=H4)
+            ops.lstm_cell_fwd(gates, cp, hp, None if live is None else live[t], h_out[t], c_out[t], y[t], acts[t])
+            hp, cp = h_out[t], c_out[t]
+        ctx.save_for_backward(h_out, c_out, acts, zero, live if live is not None else zero)
+        ctx.pr = (w_hh, b_hh)
+        ctx.cfg = (reverse, live is not None)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        h_out, c_out, acts, zero, live = ctx.saved_tensors
+        w_hh, b_hh = ctx.pr
+        reverse, has_live = ctx.cfg
+        T, B, H4 = acts.shape
+        H = H4 // 4
+        dev = acts.device
+        dy = dy.contiguous()
+        sink = GradSink(ctx.pr)
+        dgates = torch.empty(T, B, H4, device=dev, dtype=torch.float32)
+        dh, dc = None, None
+        for t in (range(T) if reverse else range(T - 1, -1, -1)):
+            pt = t + 1 if reverse else t - 1            # frame whose state fed this step
+            has_prev = 0 <= pt < T
+            cprev = c_out[pt] if has_prev else zero
+            dc_new = torch.empty(B, H, device=dev, dtype=torch.float32)
+            dh_pass = torch.empty(B, H, device=dev, dtype=torch.float32) if has_live else None
+            ops.lstm_cell_bwd(dy[t], dh, dc, acts[t], cprev, c_out[t], live[t] if has_live else None, dgates[t],
+                              dc_new, dh_pass)
+            if has_prev:
+                dh = torch.empty(B, H, device=dev, dtype=torch.float32)
+                ops.gemm(dgates[t], w_hh, dh, B, H, H4, H4, H, H, transB=1, R=dh_pass, ldr=H)
+            dc = dc_new
+        if T > 1:
+            dg, hp = (dgates[:-1], h_out[1:]) if reverse else (dgates[1:], h_out[:-1])
+            ops.linear_bwd_w(dg.reshape(-1, H4), hp.reshape(-1, H), sink.buf(0))
+        ops.colsum(dgates.view(-1, H4), sink.buf(1))
+        return (dgates,) + sink.results() + (None, None)
+
+
+class LSTMCellFn(torch.autograd.Function):
+    """one LSTMCell step whose input depends on the previous step (attention decoder, decoders.py:120-134):
+    gates = gx (= x W_ih^T + b_ih, a LinearFn product) + h W_hh^T + b_hh."""
+
+    @staticmethod
+    def forward(ctx, gx, h_prev, c_prev, w_hh, b_hh):
+        B, H4 = gx.shape
+        H = H4 // 4
+        dev = gx.device
+        gx, h_prev, c_prev = gx.contiguous(), h_prev.contiguous(), c_prev.contiguous()
+        gates = torch.empty(B, H4, device=dev, dtype=torch.float32)
+        ops.gemm(h_prev, w_hh, gates, B, H4, H, H, H, H4, bias=b_hh, R=gx, ldr=H4)
+        h = torch.empty(B, H, device=dev, dtype=torch.float32)
+        c = torch.empty(B, H, device=dev, dtype=torch.float32)
+        acts = gates                                       # activated gates overwrite the pre-activations
+        ops.lstm_cell_fwd(gates, c_prev, None, None, h, c, None, acts)
+        ctx.save_for_backward(acts, h_prev, c_prev, c)
+        ctx.pr = (w_hh, b_hh)
+        return h, c
+
+    @staticmethod
+    def backward(ctx, dh, dc):
+        acts, h_prev, c_prev, c = ctx.saved_tensors
+        w_hh, b_hh = ctx.pr
+        B, H4 = acts.shape
+        H = H4 // 4
+        dev = acts.device
+        sink = GradSink(ctx.pr)
+        dgates = torch.empty(B, H4, device=dev, dtype=torch.float32)
+        dc_prev = torch.empty(B, H, device=dev, dtype=torch.float32)
+        ops.lstm_cell_bwd(None, dh.contiguous() if dh is not None else None, dc.contiguous() if dc is not None else None,
+                          acts, c_prev, c, None, dgates, dc_prev, None)
+        dh_prev = torch.empty(B, H, device=dev, dtype=torch.float32)
+        ops.gemm(dgates, w_hh, dh_prev, B, H, H4, H4, H, H, transB=1)
+        ops.linear_bwd_w(dgates, h_prev, sink.buf(0), db=sink.buf(1))
+        return (dgates, dh_prev, dc_prev) + sink.results()
+
+
+# =================================================================================================
+# VGG2L front-end: 2 x (conv3x3-ReLU, conv3x3-ReLU, maxpool 2x2 ceil) on NHWC activations.
+# reference: rnn/encoders.py:178-237.  conv1_1 (C_in = 1) is a direct kernel, the other three are
+# implicit GEMMs over the gather descriptor (zero padding = out-of-range taps), ReLU fused in the
+# epilogue; the ReLU masks of the backward are fused into the input-gradient GEMMs.
+# =================================================================================================
+_TAPS = [(kh, kw) for kh in range(3) for kw in range(3)]
+# tap order of the input-gradient weight image built by eamd_conv2_weight_prep (misc.hip: kTapOrder)
+_TAPS_DX = [(0, 0), (0, 2), (2, 0), (2, 2), (0, 1), (2, 1), (1, 0), (1, 2), (1, 1)]
+
+
+def _conv3x3_fwd(x, w, b, B, H, W):
+    """x NHWC [B,H,W,Ci] -> relu(conv3x3 pad 1) [B,H,W,Co]"""
+    Co, Ci = w.shape[0], w.shape[1]
+    wf, wd = ops.conv2_weight_prep(w, x.dtype)
+    g = ops.make_gather(Ci, [(kh - 1, kw - 1) for kh, kw in _TAPS], H, W, H, W, 1, 1)
+    M = B * H * W
+    y = torch.empty(M, Co, device=x.device, dtype=x.dtype)
+    ops.gemm(x, wf, y, M, Co, 9 * Ci, 9 * Ci, Co, Co, transB=1, bias=b, epilogue=EPI_RELU, gather=g)
+    return y.view(B, H, W, Co), wd
+
+
+def _conv3x3_bwd(dy, x, wd, dw_buf, db_buf, B, H, W, Co, Ci, relu_aux):
+    """dy [B*H*W, Co] (already masked by this conv's ReLU); accumulates dW, db; returns dX
+    (masked by relu_aux > 0 when given = ReLU of the producing layer)"""
+    M = B * H * W
+    dev = dy.device
+    ops.colsum(dy, db_buf)
+    dwf = torch.zeros(9 * Ci, Co, device=dev, dtype=torch.float32)
+    g = ops.make_gather(Ci, [(kh - 1, kw - 1) for kh, kw in _TAPS], H, W, H, W, 1, 1)
+    ntile = (9 * Ci // 64) * ((Co + 63) // 64)
+    sk = max(1, min(64, (1024 + ntile - 1) // ntile, max(1, M // 256)))
+    ops.gemm(x, dy, dwf, 9 * Ci, Co, M, 9 * Ci, Co, Co, transA=1, transB=1, gather=g, splitk=sk, tile=64)
+    ops.conv2_weight_grad(dwf, dw_buf, Co, Ci)
+    gt = ops.make_gather(Co, [(1 - kh, 1 - kw) for kh, kw in _TAPS_DX], H, W, H, W, 1, 1)
+    dx = torch.empty(M, Ci, device=dev, dtype=dy.dtype)
+    if relu_aux is not None:
+        ops.gemm(dy, wd, dx, M, Ci, 9 * Co, 9 * Co, Ci, Ci, transB=1, gather=gt, epilogue=EPI_MUL_RELU_MASK,
+                 aux=relu_aux, ldaux=Ci)
+    else:
+        ops.gemm(dy, wd, dx, M, Ci, 9 * Co, 9 * Co, Ci, Ci, transB=1, gather=gt)
+    return dx
+
+
+class VGG2LFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, w11, b11, w12, b12, w21, b21, w22, b22):
+        B, T, F = x.shape
+        x = x.contiguous()
+        C1, C2 = w11.shape[0], w21.shape[0]
+        y1 = ops.conv3x3_c1_fwd(x, w11, b11, B, T, F, C1)                     # [B,T,F,64]
+        y2, wd12 = _conv3x3_fwd(y1, w12, b12, B, T, F)
+        p1, i1 = ops.maxpool2x2_fwd(y2)
+        T2, F2 = p1.shape[1], p1.shape[2]
+        y3, wd21 = _conv3x3_fwd(p1, w21, b21, B, T2, F2)
+        y4, wd22 = _conv3x3_fwd(y3, w22, b22, B, T2, F2)
+        p2, i2 = ops.maxpool2x2_fwd(y4)
+        T4, F4 = p2.shape[1], p2.shape[2]
+        out = torch.empty(B, T4, C2, F4, device=x.device, dtype=torch.float32)   # (c, f) feature order
+        ops.permute4(p2, out, (B * T4, F4, C2, 1), (C2 * F4, 1, F4, 0))
+        ctx.save_for_backward(x, y1, y2, i1, p1, y3, y4, i2, wd12, wd21, wd22)
+        ctx.pr = (w11, b11, w12, b12, w21, b21, w22, b22)
+        ctx.cfg = (B, T, F, T2, F2, T4, F4, C1, C2)
+        return out.view(B, T4, C2 * F4)
+
+    @staticmethod
+    def backward(ctx, dout):
+        x, y1, y2, i1, p1, y3, y4, i2, wd12, wd21, wd22 = ctx.saved_tensors
+        B, T, F, T2, F2, T4, F4, C1, C2 = ctx.cfg
+        sink = GradSink(ctx.pr)
+        dev = x.device
+        dp2 = torch.empty(B, T4, F4, C2, device=dev, dtype=torch.float32)
+        ops.permute4(dout.contiguous(), dp2, (B * T4, C2, F4, 1), (F4 * C2, 1, C2, 0))
+        dy4 = ops.maxpool2x2_bwd(dp2, i2, (B, T2, F2, C2))
+        dy4 = ops.act_bwd_any(dy4, y4, ACT_RELU)                               # y4 > 0 <=> pre-activation > 0
+        dy3 = _conv3x3_bwd(dy4.view(-1, C2), y3, wd22, sink.buf(6), sink.buf(7), B, T2, F2, C2, C2, y3.view(-1, C2))
+        dp1 = _conv3x3_bwd(dy3, p1, wd21, sink.buf(4), sink.buf(5), B, T2, F2, C2, C1, None)
+        dy2 = ops.maxpool2x2_bwd(dp1.view(B, T2, F2, C1), i1, (B, T, F, C1))
+        dy2 = ops.act_bwd_any(dy2, y2, ACT_RELU)
+        dy1 = _conv3x3_bwd(dy2.view(-1, C1), y1, wd12, sink.buf(2), sink.buf(3), B, T, F, C1, C1, y1.view(-1, C1))
+        ops.conv3x3_c1_bwd_w(dy1, x, sink.buf(0), sink.buf(1), B, T, F, C1)
+        return (None,) + sink.results()
+
+
+# =================================================================================================
+# Location-aware attention, one decoder step (AttLoc.forward, attentions.py:300-380)
+# inputs: enc_h [B,T,E], pre_enc = mlp_enc(enc_h) [B,T,A], dec_proj = mlp_dec(z) [B,A], att_prev [B,T]
+# params: loc_conv.weight [C,1,1,K], mlp_att.weight [A,C], gvec.weight [1,A], gvec.bias [1]
+# =================================================================================================
+class AttLocStepFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, enc_h, pre_enc, dec_proj, att_prev, lens, scaling, conv_w, w_att, gvec_w, gvec_b):
+        enc_h, pre_enc, dec_proj, att_prev = (t.contiguous() for t in (enc_h, pre_enc, dec_proj, att_prev))
+        c, w, th, conv = ops.attloc_fwd(att_prev, conv_w, w_att, pre_enc, dec_proj, gvec_w, gvec_b, lens, enc_h,
+                                        scaling)
+        ctx.save_for_backward(enc_h, att_prev, w, th, conv)
+        ctx.pr = (conv_w, w_att, gvec_w, gvec_b)
+        ctx.scaling = scaling
+        return c, w
+
+    @staticmethod
+    def backward(ctx, dc, dw):
+        enc_h, att_prev, w, th, conv = ctx.saved_tensors
+        conv_w, w_att, gvec_w, gvec_b = ctx.pr
+        sink = GradSink(ctx.pr)
+        B, T, A = th.shape
+        Cc = conv.shape[2]
+        d_enc_h, df, d_dec = ops.attloc_bwd_energy(dc.contiguous(), dw.contiguous() if dw is not None else None, w,
+                                                   enc_h, th, gvec_w, ctx.scaling, sink.buf(2), sink.buf(3))
+        df2 = df.view(B * T, A)
+        dconv = torch.empty(B * T, Cc, device=df.device, dtype=torch.float32)
+        ops.gemm(df2, w_att, dconv, B * T, Cc, A, A, Cc, Cc, transB=1)              # dconv = df @ W_att
+        ops.linear_bwd_w(df2, conv.view(B * T, Cc), sink.buf(1))                     # dW_att += df^T conv
+        d_prev = ops.attloc_bwd_conv(dconv.view(B, T, Cc), conv_w, att_prev, sink.buf(0))
+        return (d_enc_h, df, d_dec, d_prev, None, None) + sink.results()
+
+
+# =================================================================================================
+# Transducer joint network pointwise part and loss
+# =================================================================================================
+class JointFn(torch.autograd.Function):
+    """h[b,t,u,:] = act(enc_proj[b,t,:] + dec_proj[b,u,:])   (joint_network.py:45)"""
+
+    @staticmethod
+    def forward(ctx, enc_proj, dec_proj, act):
+        enc_proj, dec_proj = enc_proj.contiguous(), dec_proj.contiguous()
+        ctx.save_for_backward(enc_proj, dec_proj)
+        ctx.act = act
+        return ops.joint_fwd(enc_proj, dec_proj, act)
+
+    @staticmethod
+    def backward(ctx, dh):
+        enc_proj, dec_proj = ctx.saved_tensors
+        d_enc, d_dec = ops.joint_bwd(dh.contiguous(), enc_proj, dec_proj, ctx.act)
+        return d_enc, d_dec, None
+
+
+class RNNTLossFn(torch.autograd.Function):
+    """mean_b -log P(y_b | x_b) on raw joint logits [B,T,U,V] (transducer/loss.py:74-76: warp-transducer
+    RNNTLoss(blank), default reduction = mean over the batch).  The gradient is produced by the same
+    launch sequence as the loss and only rescaled by the upstream scalar in backward."""
+
+    @staticmethod
+    def forward(ctx, logits, labels, tlens, ulens, blank):
+        B = logits.shape[0]
+        logits = logits.contiguous()
+        grad = torch.empty_like(logits) if logits.requires_grad else None
+        nll = ops.rnnt_loss(logits, labels, tlens, ulens, blank, grad=grad, scale=1.0 / B)
+        ctx.save_for_backward(grad)
+        ctx.nll = nll
+        return ops.reduce_sum(nll, 1.0 / B)
+
+    @staticmethod
+    def backward(ctx, g):
+        (grad,) = ctx.saved_tensors
+        return ops.scale_dev(grad, g.contiguous(), 1.0, out=grad), None, None, None, None

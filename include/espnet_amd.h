@@ -224,16 +224,42 @@ int eamd_ctc_prefix_score(const float* logp, const float* r_prev, const int32_t*
  * gates for the backward. */
 int eamd_lstm_cell_fwd(const float* gates, const float* c_prev, const float* h_prev, const uint8_t* live, float* h,
                        float* c, float* y, float* acts, int B, int H, void* stream);
-/* dh = total gradient wrt h (output path + recurrent path), dc = gradient wrt c (NULL = 0).
- * dgates[B,4H]: pre-activation gradients; dh_pass: share of dh that flows unchanged to h_prev (rows with
- * live == 0), required when live is given. */
-int eamd_lstm_cell_bwd(const float* dh, const float* dc, const float* acts, const float* c_prev, const float* c,
-                       const uint8_t* live, float* dgates, float* dc_prev, float* dh_pass, int B, int H,
+/* dy = gradient wrt the step output y, dh = gradient wrt h from the next step, dc = gradient wrt c
+ * (each may be NULL = 0).  dgates[B,4H]: pre-activation gradients; dh_pass: share of dh that flows
+ * unchanged to h_prev (rows with live == 0), required when live is given. */
+int eamd_lstm_cell_bwd(const float* dy, const float* dh, const float* dc, const float* acts, const float* c_prev,
+                       const float* c, const uint8_t* live, float* dgates, float* dc_prev, float* dh_pass, int B, int H,
                        void* stream);
 /* F.max_pool2d(x, 2, stride=2, ceil_mode=True) on NHWC activations (VGG2L, rnn/encoders.py:205,208).
  * idx[B,Ho,Wo,C] keeps the position (0..3) of the maximum inside its window. */
 int eamd_maxpool2x2_fwd(const float* x, float* y, uint8_t* idx, int B, int H, int W, int C, void* stream);
 int eamd_maxpool2x2_bwd(const float* dy, const uint8_t* idx, float* dx, int B, int H, int W, int C, void* stream);
+/* y[r,:] = keep[r] ? x[r,:] : 0  (zeroing of padded encoder frames, rnn/encoders.py:323-325; x may alias y) */
+int eamd_mask_rows(const float* x, const uint8_t* keep, float* y, int64_t rows, int D, void* stream);
+/* VGG2L first convolution (1 -> C channels, 3x3, stride 1, padding 1) + ReLU on [B,T,F] -> NHWC [B,T,F,C], and
+ * its weight gradient (dy already ReLU-masked).  reference: rnn/encoders.py:184,203. */
+int eamd_conv3x3_c1_fwd(const float* x, const float* w, const float* bias, void* y, int B, int T, int F, int C,
+                        int y_bf16, void* stream);
+int eamd_conv3x3_c1_bwd_w(const void* dy, const float* x, float* dw, float* db, int B, int T, int F, int C,
+                          int dy_bf16, void* stream);
+/* Location-aware attention, one decoder step.  reference: rnn/attentions.py:300-380 (AttLoc.forward).
+ *   conv = Conv2d(1,C,(1,K))(att_prev) (K = 2*aconv_filts+1, no bias); e = gvec . tanh(W_att conv + pre_enc +
+ *   dec_proj) + gb, -inf for t >= lens[b]; w = softmax(scaling * e); ctx = sum_t w * enc_h.
+ * pre_enc = mlp_enc(enc_h) [B,T,A] and dec_proj = mlp_dec(dec_z) [B,A] are eamd_gemm products.
+ * th [B,T,A] (tanh output) and conv [B,T,C] are kept for the backward. */
+int eamd_attloc_fwd(const float* att_prev, const float* conv_w, const float* w_att, const float* pre_enc,
+                    const float* dec_proj, const float* gvec, const float* gb, const int32_t* lens, const float* enc_h,
+                    float scaling, float* e, float* th, float* conv, float* w, float* ctx, int B, int T, int A, int C,
+                    int K, int E, void* stream);
+/* backward stage 1: from d ctx [B,E] and the gradient arriving at w from the next step (dw_ext, may be NULL):
+ * de [B,T], d_enc_h [B,T,E] (= w * dctx), df [B,T,A] (gradient at the tanh input = d pre_enc);
+ * dgvec [A], dgb [1], d_dec_proj [B,A] are ACCUMULATED. */
+int eamd_attloc_bwd_energy(const float* dctx, const float* dw_ext, const float* w, const float* enc_h, const float* th,
+                           const float* gvec, float scaling, float* de, float* d_enc_h, float* df, float* dgvec,
+                           float* dgb, float* d_dec_proj, int B, int T, int A, int E, void* stream);
+/* backward stage 2, given dconv = df @ W_att [B,T,C]: d att_prev [B,T] and dconv_w [C,K] (accumulated). */
+int eamd_attloc_bwd_conv(const float* dconv, const float* conv_w, const float* att_prev, float* d_prev, float* dconv_w,
+                         int B, int T, int C, int K, void* stream);
 
 /* ---- RNN-Transducer ----------------------------------------------------------------------------
  * Joint network pointwise part: out[b,t,u,:] = act(enc[b,t,:] + dec[b,u,:]) (fp32 and/or bf16 copy for
@@ -246,13 +272,13 @@ int eamd_joint_bwd(const float* dh, const float* enc, const float* dec, float* d
 /* Transducer loss on raw joint logits[B,T,U,V] (U = max label length + 1), log-softmax inside.
  * reference: transducer/loss.py:8-79 (warp-transducer RNNTLoss(blank) semantics), utils.py:9-53
  * (labels[B,U-1] int32 padded with blank, tlens[B] encoder lengths, ulens[B] label lengths).
- * loss[b] = -log P(y_b | x_b).  compute_grad != 0: logits are OVERWRITTEN with
+ * loss[b] = -log P(y_b | x_b).  grad (optional, may alias logits) receives
  * scale * gscale_dev[0] * d loss[b] / d logits (gscale_dev may be NULL = 1).
  * workspace: eamd_rnnt_workspace(B,T,U) floats. */
 int64_t eamd_rnnt_workspace(int B, int T, int U);
-int eamd_rnnt_loss(float* logits, const int32_t* labels, const int32_t* tlens, const int32_t* ulens, float* workspace,
-                   float* loss, int B, int T, int U, int V, int blank, int compute_grad, const float* gscale_dev,
-                   float scale, void* stream);
+int eamd_rnnt_loss(const float* logits, const int32_t* labels, const int32_t* tlens, const int32_t* ulens,
+                   float* workspace, float* loss, float* grad, int B, int T, int U, int V, int blank,
+                   const float* gscale_dev, float scale, void* stream);
 
 /* ------------------------------------------------------------------------------------------
  * Optimizer on flat fp32 arenas.  reference: transformer/optimizer.py:12-75 (NoamOpt),

@@ -454,7 +454,7 @@ def main():
              loss=float(loss), **sd0, **grads_np(m))
 
     trn_case("transducer_rnn.npz", 41)
-    conf_arch = [dict(type="conformer", d_hidden=32, d_ff=48, heads=4, macaron_style=True, use_conv_mod=True,
+    conf_arch = [dict(type="conformer", d_hidden=64, d_ff=96, heads=4, macaron_style=True, use_conv_mod=True,
                       conv_mod_kernel=7)]
     conf_arch[0]["dropout-rate"] = 0.0
     conf_arch[0]["pos-dropout-rate"] = 0.0

@@ -1,0 +1,248 @@
+"""GPU parity tests of the RNN paths: HIP kernels behind the C ABI
+against the CPU oracle on seeded inputs and against vectors recorded from the reference (tests/golden).
+fp32 tolerances are written at each check; integer work (lengths, pooling indices) is exact."""
+import argparse
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import load_golden, split_golden
+from test_gpu_model import check_grads, load_sd
+from test_gpu_ops import report
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+
+
+@pytest.fixture(autouse=True)
+def _fp32():
+    import espnet_amd
+    espnet_amd.set_precision("fp32")
+    yield
+    espnet_amd.set_precision("fp32")
+
+
+# ---- kernels ---------------------------------------------------------------------------------------
+def test_maxpool_ceil_mode():
+    from espnet_amd import ops
+    g = torch.Generator().manual_seed(0)
+    for (B, H, W, C) in ((2, 7, 5, 3), (1, 8, 6, 64), (3, 1, 9, 5)):
+        x = torch.randn(B, H, W, C, generator=g)
+        want = torch.nn.functional.max_pool2d(x.permute(0, 3, 1, 2), 2, stride=2, ceil_mode=True).permute(0, 2, 3, 1)
+        y, idx = ops.maxpool2x2_fwd(x.to(DEV))
+        assert torch.equal(y.cpu(), want)                              # selection: bit-exact
+        gy = torch.randn(want.shape, generator=g)
+        xr = x.clone().requires_grad_(True)
+        torch.nn.functional.max_pool2d(xr.permute(0, 3, 1, 2), 2, stride=2, ceil_mode=True).permute(0, 2, 3, 1) \
+            .backward(gy)
+        dx = ops.maxpool2x2_bwd(gy.to(DEV), idx, (B, H, W, C))
+        assert torch.equal(dx.cpu(), xr.grad)
+
+
+@pytest.mark.parametrize("reverse", [False, True])
+def test_lstm_sequence_vs_oracle(oracle, reverse):
+    from espnet_amd import rnn_functional as R
+    g = torch.Generator().manual_seed(3)
+    T, B, I, H = 9, 4, 6, 5
+    lens = [9, 7, 4, 1]
+    sd = {"weight_ih_l0": torch.randn(4 * H, I, generator=g) * 0.4, "weight_hh_l0": torch.randn(4 * H, H, generator=g) * 0.4,
+          "bias_ih_l0": torch.randn(4 * H, generator=g) * 0.2, "bias_hh_l0": torch.randn(4 * H, generator=g) * 0.2}
+    x = torch.randn(B, T, I, generator=g)
+    sdr = {k: v.clone().requires_grad_(True) for k, v in sd.items()}
+    xr = x.clone().requires_grad_(True)
+    want = oracle.lstm_layer(sdr, "", xr, lens, reverse=reverse)
+    gy = torch.randn(want.shape, generator=g)
+    want.backward(gy)
+
+    w_ih, w_hh, b_ih, b_hh = (sd[k].to(DEV).requires_grad_(True) for k in
+                              ("weight_ih_l0", "weight_hh_l0", "bias_ih_l0", "bias_hh_l0"))
+    xd = x.to(DEV).requires_grad_(True)
+    from espnet_amd import functional as F_
+    gx = F_.LinearFn.apply(xd.transpose(0, 1).contiguous(), w_ih, b_ih)
+    live = torch.from_numpy((np.arange(T)[:, None] < np.asarray(lens)[None, :]).astype(np.uint8)).to(DEV)
+    y = R.LSTMSeqFn.apply(gx, w_hh, b_hh, live, reverse).transpose(0, 1)
+    report("lstm seq fwd rev=%d" % reverse, y, want.detach(), 1e-5)
+    y.backward(gy.to(DEV))
+    report("lstm seq dx", xd.grad, xr.grad, 1e-4)
+    report("lstm seq dW_hh", w_hh.grad, sdr["weight_hh_l0"].grad, 1e-4)
+    report("lstm seq db_hh", b_hh.grad, sdr["bias_hh_l0"].grad, 1e-4)
+    report("lstm seq dW_ih", w_ih.grad, sdr["weight_ih_l0"].grad, 1e-4)
+
+
+def test_lstm_cell_vs_oracle(oracle):
+    from espnet_amd.nets.rnn.decoders import LSTMCell
+    g = torch.Generator().manual_seed(4)
+    B, I, H = 5, 7, 6
+    cell = LSTMCell(I, H)
+    sd = {k: v.detach().clone() for k, v in cell.state_dict().items()}
+    cell = cell.to(DEV)
+    x, h, c = torch.randn(B, I, generator=g), torch.randn(B, H, generator=g), torch.randn(B, H, generator=g)
+    sdr = {k: v.clone().requires_grad_(True) for k, v in sd.items()}
+    xr, hr, cr = (t.clone().requires_grad_(True) for t in (x, h, c))
+    h2w, c2w = oracle.lstm_cell(sdr, "", xr, hr, cr)
+    gh, gc = torch.randn(B, H, generator=g), torch.randn(B, H, generator=g)
+    (h2w * gh).sum().add((c2w * gc).sum()).backward()
+    xd, hd, cd = (t.to(DEV).requires_grad_(True) for t in (x, h, c))
+    h2, c2 = cell(xd, (hd, cd))
+    report("lstm cell h", h2, h2w.detach(), 1e-5)
+    report("lstm cell c", c2, c2w.detach(), 1e-5)
+    torch.autograd.backward([h2, c2], [gh.to(DEV), gc.to(DEV)])
+    report("lstm cell dx", xd.grad, xr.grad, 1e-4)
+    report("lstm cell dh", hd.grad, hr.grad, 1e-4)
+    report("lstm cell dc", cd.grad, cr.grad, 1e-4)
+    for k, p in cell.named_parameters():
+        report("lstm cell d" + k, p.grad, sdr[k].grad, 1e-4)
+
+
+def test_attloc_step_vs_oracle(oracle):
+    """two chained AttLoc steps (the second consumes the first's weights) against rnn/attentions.py:300-380"""
+    from espnet_amd.nets.rnn.attentions import AttLoc
+    g = torch.Generator().manual_seed(5)
+    B, T, E, D, A, C, F = 3, 11, 6, 5, 7, 4, 2
+    att = AttLoc(E, D, A, C, F)
+    sd = {k: v.detach().clone() for k, v in att.state_dict().items()}
+    att = att.to(DEV)
+    lens = [11, 8, 5]
+    enc = torch.randn(B, T, E, generator=g)
+    z1, z2 = torch.randn(B, D, generator=g), torch.randn(B, D, generator=g)
+    sdr = {k: v.clone().requires_grad_(True) for k, v in sd.items()}
+    encr, z1r, z2r = (t.clone().requires_grad_(True) for t in (enc, z1, z2))
+    pre = oracle.linear(sdr, "mlp_enc.", encr)
+    c1w, w1w = oracle.att_loc(sdr, "", encr, pre, lens, z1r, None)
+    c2w, w2w = oracle.att_loc(sdr, "", encr, pre, lens, z2r, w1w)
+    g1, g2, gw = torch.randn(B, E, generator=g), torch.randn(B, E, generator=g), torch.randn(B, T, generator=g)
+    ((c1w * g1).sum() + (c2w * g2).sum() + (w2w * gw).sum()).backward()
+
+    encd, z1d, z2d = (t.to(DEV).requires_grad_(True) for t in (enc, z1, z2))
+    att.reset()
+    c1, w1 = att(encd, lens, z1d, None)
+    c2, w2 = att(encd, lens, z2d, w1)
+    report("attloc ctx1", c1, c1w.detach(), 1e-5)
+    report("attloc w1", w1, w1w.detach(), 1e-5)
+    report("attloc ctx2", c2, c2w.detach(), 1e-5)
+    assert float(w2[1, 8:].abs().max()) == 0.0 and float(w2[2, 5:].abs().max()) == 0.0   # masked frames: exactly 0
+    torch.autograd.backward([c1, c2, w2], [g1.to(DEV), g2.to(DEV), gw.to(DEV)])
+    report("attloc d enc_h", encd.grad, encr.grad, 1e-4)
+    report("attloc d z1", z1d.grad, z1r.grad, 1e-4)
+    report("attloc d z2", z2d.grad, z2r.grad, 1e-4)
+    for k, p in att.named_parameters():
+        if k == "gvec.bias":     # softmax is shift invariant: the exact gradient is 0, both sides hold rounding noise
+            assert float(p.grad.abs().max()) < 1e-5
+            continue
+        report("attloc d" + k, p.grad, sdr[k].grad, 2e-4)
+
+
+@pytest.mark.parametrize("shape", [(2, 6, 4, 7), (3, 17, 9, 33), (1, 1, 1, 5), (2, 5, 1, 4), (2, 1, 4, 6)])
+def test_rnnt_loss_vs_oracle(oracle, shape):
+    from espnet_amd import rnn_functional as R
+    B, T, U, V = shape
+    g = torch.Generator().manual_seed(B * 100 + T)
+    z = torch.randn(B, T, U, V, generator=g) * 2.0
+    y = torch.randint(1, V, (B, max(U - 1, 1)), generator=g)[:, : U - 1].int()
+    tl = torch.tensor([T] + [max(1, T - 1 - i) for i in range(B - 1)], dtype=torch.int32)
+    ul = torch.tensor([U - 1] + [max(0, U - 2 - i) for i in range(B - 1)], dtype=torch.int32)
+    zr = z.clone().requires_grad_(True)
+    want = oracle.rnnt_loss(zr, y, tl.tolist(), ul.tolist())
+    want.backward()
+    zd = z.to(DEV).requires_grad_(True)
+    got = R.RNNTLossFn.apply(zd, y.to(DEV).contiguous(), tl.to(DEV), ul.to(DEV), 0)
+    rel = abs(float(got) - float(want)) / abs(float(want))
+    print("[parity] rnnt loss %s: hip %.6f oracle %.6f rel %.2e" % (shape, float(got), float(want), rel))
+    assert rel < 1e-5
+    got.backward()
+    report("rnnt dlogits %s" % (shape,), zd.grad, zr.grad.float(), 2e-4)
+    # rows outside each utterance's lattice receive exactly zero gradient
+    for b in range(B):
+        assert float(zd.grad[b, int(tl[b]):].abs().max() if int(tl[b]) < T else 0.0) == 0.0
+        assert float(zd.grad[b, :, int(ul[b]) + 1:].abs().max() if int(ul[b]) + 1 < U else 0.0) == 0.0
+
+
+def test_joint_network_vs_oracle(oracle):
+    from espnet_amd.nets.transducer.joint_network import JointNetwork
+    g = torch.Generator().manual_seed(8)
+    for act in ("tanh", "relu", "swish"):
+        jn = JointNetwork(9, 6, 5, 7, act)
+        sd = {"joint_network." + k: v.detach().clone().requires_grad_(True) for k, v in jn.state_dict().items()}
+        jn = jn.to(DEV)
+        he, hd = torch.randn(2, 5, 6, generator=g), torch.randn(2, 4, 5, generator=g)
+        her, hdr = he.clone().requires_grad_(True), hd.clone().requires_grad_(True)
+        j = "joint_network."
+        pre = oracle.linear(sd, j + "lin_enc.", her).unsqueeze(2) + \
+            torch.nn.functional.linear(hdr, sd[j + "lin_dec.weight"]).unsqueeze(1)
+        want = oracle.linear(sd, j + "lin_out.", oracle.activation(act)(pre))
+        gz = torch.randn(want.shape, generator=g)
+        want.backward(gz)
+        hed, hdd = he.to(DEV).requires_grad_(True), hd.to(DEV).requires_grad_(True)
+        z = jn(hed.unsqueeze(2), hdd.unsqueeze(1))
+        report("joint %s fwd" % act, z, want.detach(), 1e-5)
+        z.backward(gz.to(DEV))
+        report("joint %s d h_enc" % act, hed.grad, her.grad, 1e-4)
+        report("joint %s d h_dec" % act, hdd.grad, hdr.grad, 1e-4)
+        for k, p in jn.named_parameters():
+            report("joint %s d%s" % (act, k), p.grad, sd[j + k].grad, 1e-4)
+
+
+# ---- models against the reference fixtures --------------------------------------------------------------
+def _rnn_args(**kw):
+    d = dict(elayers=2, subsample="1_2_1", etype="vggblstmp", eunits=12, eprojs=10, dtype="lstm", dlayers=2, dunits=14,
+             atype="location", aheads=1, awin=3, aconv_chans=3, aconv_filts=2, mtlalpha=0.5, lsm_type="", lsm_weight=0.0,
+             sampling_probability=0.0, adim=9, dropout_rate=0.0, dropout_rate_decoder=0.0, verbose=0,
+             char_list=["<blank>", "a", "b", "c", "d", "e", "<eos>"], outdir=None, ctc_type="builtin",
+             sym_space="<space>", sym_blank="<blank>", context_residual=False, use_frontend=False, replace_sos=False)
+    d.update(kw)
+    return argparse.Namespace(**d)
+
+
+def test_e2e_rnn_golden():
+    """VGG-BLSTMP + AttLoc LSTM decoder + CTC == reference E2E (e2e_asr.py:205-338) on its own weights"""
+    from espnet_amd.nets.e2e_asr import E2E
+    p, sd, grads = split_golden(load_golden("e2e_rnn.npz"))
+    m = load_sd(E2E(12, 7, _rnn_args()), sd)
+    m.train()
+    loss = m(p["xs"].to(DEV), p["ilens"], p["ys"].to(DEV))
+    assert m.hlens == p["hlens"].tolist()
+    report("e2e_rnn hs_pad", m.hs_pad, p["hs_pad"], 1e-4)
+    for name, got, want in (("loss", loss, p["loss"]), ("loss_att", m.loss_att, p["loss_att"]),
+                            ("loss_ctc", m.loss_ctc, p["loss_ctc"])):
+        rel = abs(float(got) - float(want)) / abs(float(want))
+        print("[parity] e2e_rnn %s hip %.6f ref %.6f rel %.2e" % (name, float(got), float(want), rel))
+        assert rel < 1e-5
+    assert abs(float(m.acc) - float(p["acc"])) < 1e-6
+    loss.backward()
+    check_grads(m, grads, tol=5e-4)
+
+
+def _trn_args(**kw):
+    d = dict(etype="vggblstmp", elayers=1, subsample="1_1", eunits=10, eprojs=8, dtype="lstm", dlayers=2, dunits=12,
+             dec_embed_dim=6, dropout_rate=0.0, dropout_rate_decoder=0.0, dropout_rate_embed_decoder=0.0, joint_dim=7,
+             joint_activation_type="tanh", rnnt_mode="rnnt", trans_type="warp-transducer", sym_space="<space>",
+             sym_blank="<blank>", transformer_init="pytorch")
+    d.update(kw)
+    return argparse.Namespace(**d)
+
+
+@pytest.mark.parametrize("name", ["transducer_rnn.npz", "transducer_conformer.npz"])
+def test_transducer_golden(name):
+    """encoder -> DecoderRNNT -> JointNetwork == reference modules; loss == float64 transducer recursion"""
+    from espnet_amd.nets.e2e_asr_transducer import E2E
+    p, sd, grads = split_golden(load_golden(name))
+    if "rnn" in name:
+        args = _trn_args()
+    else:
+        arch = [dict(type="conformer", d_hidden=64, d_ff=96, heads=4, macaron_style=True, use_conv_mod=True,
+                     conv_mod_kernel=7)]
+        args = _trn_args(etype="transformer", enc_block_arch=arch, enc_block_repeat=2,
+                         transformer_enc_input_layer="conv2d", transformer_enc_self_attn_type="rel_self_attn",
+                         transformer_enc_positional_encoding_type="rel_pos", transformer_enc_pw_activation_type="swish",
+                         transformer_enc_conv_mod_activation_type="swish", dlayers=1)
+    m = load_sd(E2E(12, 6, args), sd)
+    m.train()
+    loss = m(p["xs"].to(DEV), p["ilens"], p["ys"].to(DEV))
+    report(name + " hs_pad", m.hs_pad, p["hs_pad"], 1e-4)
+    report(name + " joint logits", m.pred_pad, p["pred_pad"], 1e-4)
+    rel = abs(float(loss) - float(p["loss"])) / abs(float(p["loss"]))
+    print("[parity] %s loss hip %.6f ref %.6f rel %.2e" % (name, float(loss), float(p["loss"]), rel))
+    assert rel < 1e-5
+    loss.backward()
+    check_grads(m, grads, tol=5e-4)

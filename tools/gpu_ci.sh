@@ -18,6 +18,7 @@ for t in "$@"; do
   case $t in
     ops)   run test_ops python -m pytest tests/test_gpu_ops.py -m gpu -q -s --tb=short -p no:cacheprovider ;;
     model) run test_model python -m pytest tests/test_gpu_model.py -m gpu -q -s --tb=short -p no:cacheprovider ;;
+    rnn)   run test_rnn python -m pytest tests/test_gpu_rnn.py -m gpu -q -s --tb=short -p no:cacheprovider ;;
     smoke) run smoke python -c "import __graft_entry__ as g; g.smoke()" ;;
     bench) run bench python bench.py --steps 5 --warmup 2 ;;
     *) echo "unknown tier $t"; exit 2 ;;
