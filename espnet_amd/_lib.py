@@ -43,7 +43,9 @@ class GemmT(C.Structure):
                 ("a_act", C.c_int32), ("b_act", C.c_int32), ("epilogue", C.c_int32),
                 ("splitk", C.c_int32), ("precision", C.c_int32), ("tile", C.c_int32),
                 ("gather", GatherT), ("cmap", RowMapT),
-                ("Cb", C.c_void_p), ("in_dtype", C.c_int32), ("aux_dtype", C.c_int32)]
+                ("Cb", C.c_void_p), ("in_dtype", C.c_int32), ("aux_dtype", C.c_int32),
+                ("drop_p", C.c_float), ("drop_salt", C.c_uint64), ("drop_step", C.c_void_p), ("Hb", C.c_void_p),
+                ("h_act", C.c_int32)]
 
 
 _lib = None

@@ -61,8 +61,9 @@ __global__ __launch_bounds__(256) void dwconv_kernel(const float* __restrict__ x
 }
 
 // dw[c,k] += sum_{b,t} dy[b,t,c] * x[b,t+k-pad,c];  db[c] += sum dy.
-// One thread = one channel; a block walks `chunks_per_block` chunks of TT frames.  Per chunk the
-// TT + K - 1 input window and the TT output gradients are loaded up front (independent loads, all
+constexpr int TTW = 8;   // frames per chunk of the weight-gradient kernel
+// One thread = one channel; a block walks `chunks_per_block` chunks of TTW frames.  Per chunk the
+// TTW + K - 1 input window and the TTW output gradients are loaded up front (independent loads, all
 // in flight together) and combined with fully unrolled FMAs into K register accumulators.
 __global__ __launch_bounds__(256) void dwconv_bwd_w_kernel(const float* __restrict__ dy, const float* __restrict__ x,
                                                            float* __restrict__ dw, float* __restrict__ db, int B,
@@ -70,7 +71,7 @@ __global__ __launch_bounds__(256) void dwconv_bwd_w_kernel(const float* __restri
   const int c_raw = blockIdx.x * blockDim.x + threadIdx.x;
   const bool live = c_raw < C;
   const int c = live ? c_raw : C - 1;        // dead lanes shadow a valid channel and contribute nothing
-  const int nchunk = (T + TT - 1) / TT;
+  const int nchunk = (T + TTW - 1) / TTW;
   const long total = (long)B * nchunk;
   const long q0 = (long)blockIdx.y * chunks_per_block;
   const long q1 = live ? min(total, q0 + (long)chunks_per_block) : q0;
@@ -80,19 +81,19 @@ __global__ __launch_bounds__(256) void dwconv_bwd_w_kernel(const float* __restri
   float accb = 0.f;
   for (long q = q0; q < q1; ++q) {
     const int b = q / nchunk;
-    const int t0 = (int)(q % nchunk) * TT;
+    const int t0 = (int)(q % nchunk) * TTW;
     const float* xb = x + (long)b * T * C + c;
     const float* gb = dy + (long)b * T * C + c;
-    float g[TT];
+    float g[TTW];
 #pragma unroll
-    for (int i = 0; i < TT; ++i) { g[i] = (t0 + i < T) ? gb[(long)(t0 + i) * C] : 0.f; accb += g[i]; }
+    for (int i = 0; i < TTW; ++i) { g[i] = (t0 + i < T) ? gb[(long)(t0 + i) * C] : 0.f; accb += g[i]; }
 #pragma unroll
-    for (int j = 0; j < TT + KMAX - 1; ++j) {
-      if (j < TT + K - 1) {
+    for (int j = 0; j < TTW + KMAX - 1; ++j) {
+      if (j < TTW + K - 1) {
         const int ts = t0 - pad + j;
         const float xv = (ts >= 0 && ts < T) ? xb[(long)ts * C] : 0.f;
 #pragma unroll
-        for (int i = 0; i < TT; ++i) {
+        for (int i = 0; i < TTW; ++i) {
           const int k = j - i;
           if (k >= 0 && k < KMAX) acc[k] += g[i] * xv;
         }
@@ -449,7 +450,7 @@ int eamd_dwconv_bwd_w(const float* dy, const float* x, float* dw, float* db, int
                       void* stream) {
   if (!dy || !x || !dw || B <= 0 || T <= 0 || C <= 0 || K <= 0 || (K & 1) == 0) return EAMD_EINVAL;
   if (K > KMAX) return EAMD_EUNSUPPORTED;
-  long total = (long)B * ((T + TT - 1) / TT);
+  long total = (long)B * ((T + TTW - 1) / TTW);
   int gx = (C + 255) / 256;
   long want = 512 / gx; if (want < 1) want = 1;
   long cpb = (total + want - 1) / want; if (cpb < 1) cpb = 1;

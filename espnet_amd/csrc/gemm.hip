@@ -413,6 +413,7 @@ extern "C" int eamd_gemm(const eamd_gemm_t* pp, void* stream_) {
     }
   }
   if ((p.N + tile - 1) / tile > 65535) return EAMD_EUNSUPPORTED;
+  if (p.in_dtype != 1 && (p.drop_p != 0.f || p.Hb)) return EAMD_EUNSUPPORTED;   // fused dropout: bf16-operand kernel only
   if (p.in_dtype == 1) return eamd_gemm_bf16_dispatch(p, tile, stream);
 
   if (tile == 128) {

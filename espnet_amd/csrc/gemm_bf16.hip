@@ -42,6 +42,12 @@ __device__ __forceinline__ int lds_chunk_off(int r, int c16) {
   }
 }
 
+// same counter-based generator as dropout_kernel (elementwise.hip)
+__device__ __forceinline__ unsigned drop_hash(unsigned long long x) {
+  x ^= x >> 33; x *= 0xff51afd7ed558ccdULL; x ^= x >> 33; x *= 0xc4ceb9fe1a85ec53ULL; x ^= x >> 33;
+  return (unsigned)x;
+}
+
 template <int BM, int BN, bool TA, bool TB>
 struct SmemB {
   static constexpr int LDA = TA ? BM : BK;
@@ -560,8 +566,13 @@ __global__ __launch_bounds__(NT_) void gemm_bf16_kernel(const eamd_gemm_t p) {
   const bool cvec = (p.ldc % 4 == 0) && (coff % 4 == 0) &&
                     (!p.C || (reinterpret_cast<uintptr_t>(p.C) & 15) == 0) &&
                     (!Cb || (reinterpret_cast<uintptr_t>(Cb) & 7) == 0) &&
+                    (!p.Hb || (reinterpret_cast<uintptr_t>(p.Hb) & 7) == 0) &&
                     (!p.R || ((p.ldr % 4 == 0) && (reinterpret_cast<uintptr_t>(p.R) & 15) == 0)) &&
                     (!p.aux || (p.ldaux % 4 == 0 && (reinterpret_cast<uintptr_t>(p.aux) & 15) == 0));
+  bf16_t* __restrict__ Hb = reinterpret_cast<bf16_t*>(p.Hb);
+  const unsigned long long drop_base =
+      p.drop_p > 0.f ? (p.drop_step ? p.drop_step[0] : 0ULL) * 0x9E3779B97F4A7C15ULL + p.drop_salt * 0xD1B54A32D192ED03ULL
+                     : 0ULL;
   float bv[4] = {0.f, 0.f, 0.f, 0.f};
   if (p.bias) {
 #pragma unroll
@@ -626,6 +637,32 @@ __global__ __launch_bounds__(NT_) void gemm_bf16_kernel(const eamd_gemm_t p) {
 #pragma unroll
       for (int e = 0; e < 4; ++e) v[e] *= eamd_dswish(ax[e]);
     }
+    if (p.drop_p > 0.f) {
+      // wave-uniform branch; mask index = element index of the contiguous [M, N] result
+      const float inv = 1.f / (1.f - p.drop_p);
+      const unsigned thr = (unsigned)fminf(p.drop_p * 4294967296.0f, 4294967040.0f);
+      const unsigned long long base = drop_base + (unsigned long long)ci;
+      if (Hb) {
+        float h[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const float a = eamd_act(v[e], p.h_act);
+          h[e] = drop_hash(base + e) >= thr ? a * inv : 0.f;
+        }
+        if (full) {
+          uint2 o;
+          o.x = eamd_f2bf(h[0]) | ((unsigned)eamd_f2bf(h[1]) << 16);
+          o.y = eamd_f2bf(h[2]) | ((unsigned)eamd_f2bf(h[3]) << 16);
+          *reinterpret_cast<uint2*>(Hb + ci) = o;
+        } else {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) if (n + e < p.N) Hb[ci + e] = eamd_f2bf(h[e]);
+        }
+      } else {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] = drop_hash(base + e) >= thr ? v[e] * inv : 0.f;
+      }
+    }
 #pragma unroll
     for (int e = 0; e < 4; ++e) v[e] = v[e] * p.alpha + rv[e] + p.beta * cold[e];
     if (full) {
@@ -682,7 +719,9 @@ bool aligned16(const void* q) { return (reinterpret_cast<uintptr_t>(q) & 15) == 
 
 // called by eamd_gemm (gemm.hip) after argument validation when in_dtype == 1
 int eamd_gemm_bf16_dispatch(const eamd_gemm_t& p, int tile, hipStream_t stream) {
-  if (p.splitk > 1 && (!p.C || p.Cb)) return EAMD_EINVAL;
+  if (p.splitk > 1 && (!p.C || p.Cb || p.drop_p > 0.f)) return EAMD_EINVAL;
+  if (p.drop_p < 0.f || p.drop_p >= 1.f || (p.Hb && p.drop_p <= 0.f)) return EAMD_EINVAL;
+  if (p.drop_p > 0.f && (p.cmap.enabled || p.batch1 * p.batch2 != 1 || p.ldc != p.N)) return EAMD_EINVAL;   // mask index = row*N+col
   // branch-free staging needs 16-byte aligned chunk starts that stay inside the operand
   const bool a_ok = aligned16(p.A) && p.lda % 8 == 0 && p.sA1 % 8 == 0 && p.sA2 % 8 == 0 &&
                     p.lda >= (p.transA ? (p.M + 7) / 8 * 8 : (p.K + 7) / 8 * 8);

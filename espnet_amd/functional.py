@@ -145,12 +145,19 @@ class FFNBlockFn(torch.autograd.Function):
         p_in, s_in, p_out, s_out = drop
         x2 = x.reshape(-1, D).contiguous()
         xn, mean, rstd = ops.layernorm_fwd(x2, ln_w, ln_b, eps, adt)            # GEMM operand (bf16 in fast mode)
-        z = ops.linear_fwd(xn, ops.wshadow(w1), b1, out_dtype=adt)              # [M, F] pre-activation
+        fused = ops.fast()      # bf16-operand GEMMs carry the dropout masks in their epilogues
         h = None
-        if p_in > 0.0:
-            h = ops.dropout(z, p_in, s_in, act=act)                             # drop(act(z)), materialised
+        if p_in > 0.0 and fused:
+            h = torch.empty(x2.shape[0], w1.shape[0], device=x2.device, dtype=adt)
+            z = ops.linear_fwd(xn, ops.wshadow(w1), b1, out_dtype=adt, drop=(p_in, s_in), Hb=h, h_act=act)
+        else:
+            z = ops.linear_fwd(xn, ops.wshadow(w1), b1, out_dtype=adt)          # [M, F] pre-activation
+            if p_in > 0.0:
+                h = ops.dropout(z, p_in, s_in, act=act)                         # drop(act(z)), materialised
         src, a_act = (h, ACT_NONE) if h is not None else (z, act)
-        if p_out > 0.0:
+        if p_out > 0.0 and fused:
+            out = ops.linear_fwd(src, ops.wshadow(w2), b2, R=x2, alpha=scale, a_act=a_act, drop=(p_out, s_out))
+        elif p_out > 0.0:
             br = ops.linear_fwd(src, ops.wshadow(w2), b2, a_act=a_act)
             out = ops.axpby(x2, ops.dropout(br, p_out, s_out), 1.0, scale)
         else:
@@ -168,15 +175,19 @@ class FFNBlockFn(torch.autograd.Function):
         adt = ops.act_dtype()
         sink = GradSink(ctx.pr)
         do = dout.reshape(x2.shape).contiguous()
-        dbr = ops.dropout(do, p_out, s_out) if p_out > 0.0 else do              # gradient of the branch output
-        dob = ops.to_act(dbr)
+        # gradient of the branch output (dropout mask re-derived, cast to the GEMM operand dtype in the same pass)
+        dob = ops.dropout(do, p_out, s_out, out_dtype=adt) if p_out > 0.0 else ops.to_act(do)
         if h is not None:
             ops.linear_bwd_w(dob, h, sink.buf(4), alpha=scale, db=sink.buf(5))
         else:
             ops.linear_bwd_w(dob, z, sink.buf(4), alpha=scale, b_act=act, db=sink.buf(5))   # dW2 += s * do^T act(z)
-        dz = ops.linear_bwd_x(dob, ops.wshadow(w2), epilogue=_act_epi(act), aux=z, alpha=scale, out_dtype=adt)
-        if h is not None:
-            dz = ops.dropout(dz, p_in, s_in)
+        if h is not None and ops.fast():
+            dz = ops.linear_bwd_x(dob, ops.wshadow(w2), epilogue=_act_epi(act), aux=z, alpha=scale, out_dtype=adt,
+                                  drop=(p_in, s_in))
+        else:
+            dz = ops.linear_bwd_x(dob, ops.wshadow(w2), epilogue=_act_epi(act), aux=z, alpha=scale, out_dtype=adt)
+            if h is not None:
+                dz = ops.dropout(dz, p_in, s_in)
         ops.linear_bwd_w(dz, xn, sink.buf(2), db=sink.buf(3))
         dxn = ops.linear_bwd_x(dz, ops.wshadow(w1))
         dx = ops.layernorm_bwd(dxn, x2, ln_w, mean, rstd, do, sink.buf(0), sink.buf(1))
@@ -302,7 +313,9 @@ class MHABlockFn(torch.autograd.Function):
         P = attn_scores_fwd(qu, qv, k, p, mask, B, T1, T2, H, dk)
         Pd = ops.dropout(P, p_att, s_att) if p_att > 0.0 else P
         cx = attn_context_fwd(Pd, v, B, T1, T2, H, dk)
-        if p_out > 0.0:
+        if p_out > 0.0 and ops.fast():
+            out = ops.linear_fwd(cx, ops.wshadow(wo), bo, R=res, drop=(p_out, s_out))
+        elif p_out > 0.0:
             br = ops.linear_fwd(cx, ops.wshadow(wo), bo)
             out = ops.axpby(res, ops.dropout(br, p_out, s_out), 1.0, 1.0)
         else:
@@ -323,7 +336,7 @@ class MHABlockFn(torch.autograd.Function):
         adt = ops.act_dtype()
         sink = GradSink(params)
         do = dout.reshape(-1, D).contiguous()
-        dob = ops.to_act(ops.dropout(do, p_out, s_out) if p_out > 0.0 else do)
+        dob = ops.dropout(do, p_out, s_out, out_dtype=ops.act_dtype()) if p_out > 0.0 else ops.to_act(do)
         ops.linear_bwd_w(dob, cx, sink.buf(8), db=sink.buf(9))
         dctx = ops.linear_bwd_x(dob, ops.wshadow(wo), out_dtype=adt)
         dqu, dqv, dkk, dv, dp = attn_core_bwd(dctx, P, qu, qv, k, v, p, B, T1, T2, H, dk,
@@ -381,7 +394,9 @@ class ConvModuleBlockFn(torch.autograd.Function):
             brstd = ops.axpby(running_var, None, 1.0, 0.0)
             brstd = torch.rsqrt_(brstd.add_(bn_eps))  # tiny [C] host-issued op on eval path only
         e = ops.bn_apply(d, bmean, brstd, g, be, M, Cc, act, adt)
-        if p_out > 0.0:
+        if p_out > 0.0 and ops.fast():
+            out = ops.linear_fwd(e, ops.wshadow(w2).view(Cc, Cc), b2, R=x2, drop=(p_out, s_out))
+        elif p_out > 0.0:
             br = ops.linear_fwd(e, ops.wshadow(w2).view(Cc, Cc), b2)
             out = ops.axpby(x2, ops.dropout(br, p_out, s_out), 1.0, 1.0)
         else:
@@ -400,7 +415,7 @@ class ConvModuleBlockFn(torch.autograd.Function):
         adt = ops.act_dtype()
         sink = GradSink(ctx.pr)
         do = dout.reshape(M, D).contiguous()
-        dob = ops.to_act(ops.dropout(do, p_out, s_out) if p_out > 0.0 else do)
+        dob = ops.dropout(do, p_out, s_out, out_dtype=ops.act_dtype()) if p_out > 0.0 else ops.to_act(do)
         ops.linear_bwd_w(dob, e, sink.buf(8).view(Cc, Cc), db=sink.buf(9))
         de = ops.linear_bwd_x(dob, ops.wshadow(w2).view(Cc, Cc))
         dd = ops.bn_bwd(de, d, bmean, brstd, g, be, sink.buf(6), sink.buf(7), M, Cc, act, training)

@@ -75,7 +75,7 @@ def _span(rows, ld, cols):
 def gemm(A, B, Cm, M, N, K, lda, ldb, ldc, *, transA=0, transB=0, bias=None, aux=None, ldaux=0, R=None,
          ldr=0, batch=(1, 1), sA=(0, 0), sB=(0, 0), sC=(0, 0), alpha=1.0, beta=0.0, a_act=0, b_act=0,
          epilogue=0, splitk=1, tile=0, gather=None, cmap=None, a_off=0, b_off=0, c_off=0, precision=None,
-         colsum=None, Cb=None):
+         colsum=None, Cb=None, drop=None, Hb=None, h_act=0):
     """A, B: both float32 or both bfloat16 (bf16 operands select the fast MFMA kernel).
     Cm: float32 result, or bfloat16 result (then no fp32 copy is written); Cb: extra bf16 copy."""
     bf = A.dtype == torch.bfloat16
@@ -136,6 +136,15 @@ def gemm(A, B, Cm, M, N, K, lda, ldb, ldc, *, transA=0, transB=0, bias=None, aux
         p.gather = gather
     if cmap is not None:
         p.cmap = cmap
+    if drop is not None and drop[0] > 0.0:      # (p, salt): fused dropout, see include/espnet_amd.h
+        if not bf or ldc != N or c_off != 0:
+            raise _lib.EamdError("gemm: fused dropout needs bf16 operands and a contiguous [M, N] result")
+        p.drop_p, p.drop_salt = float(drop[0]), int(drop[1])
+        p.drop_step = ptr(rng_state(A.device))
+        if Hb is not None:
+            if Hb.dtype != torch.bfloat16 or Hb.numel() < M * N:
+                raise _lib.EamdError("gemm: Hb must be a bf16 [M, N] buffer")
+            p.Hb, p.h_act = ptr(Hb), h_act
     check(_lib.lib().eamd_gemm(C.byref(p), stream_ptr()), "eamd_gemm")
 
 
@@ -163,26 +172,32 @@ def auto_splitk(m_out, n_out, k_red):
 
 
 # ---- nn.Linear pieces -------------------------------------------------------------------------
-def linear_fwd(x, W, b, out=None, *, act=EPI_NONE, R=None, alpha=1.0, a_act=ACT_NONE, out_dtype=torch.float32):
-    """out[M,N] = alpha * act(a_act(x)[M,K] @ W[N,K]^T + b) + R      (x, W: both fp32 or both bf16)"""
+def linear_fwd(x, W, b, out=None, *, act=EPI_NONE, R=None, alpha=1.0, a_act=ACT_NONE, out_dtype=torch.float32,
+               drop=None, Hb=None, h_act=ACT_NONE):
+    """out[M,N] = alpha * drop(act(a_act(x)[M,K] @ W[N,K]^T + b)) + R      (x, W: both fp32 or both bf16)
+    drop = (p, salt): dropout fused in the epilogue (bf16 operands); with Hb the value itself is left
+    alone and Hb <- dropout(h_act(value)) is written as a second bf16 output."""
     M, K = x.shape
     N = W.shape[0]
     assert W.shape[1] == K and x.is_contiguous() and W.is_contiguous()
     if out is None:
         out = torch.empty(M, N, device=x.device, dtype=out_dtype)
-    gemm(x, W, out, M, N, K, K, K, N, bias=b, epilogue=act, R=R, ldr=N, alpha=alpha, a_act=a_act)
+    gemm(x, W, out, M, N, K, K, K, N, bias=b, epilogue=act, R=R, ldr=N, alpha=alpha, a_act=a_act, drop=drop, Hb=Hb,
+         h_act=h_act)
     return out
 
 
-def linear_bwd_x(dy, W, out=None, *, beta=0.0, epilogue=EPI_NONE, aux=None, alpha=1.0, out_dtype=torch.float32):
-    """out[M,K] = alpha * epi(dy[M,N] @ W[N,K]) + beta*out"""
+def linear_bwd_x(dy, W, out=None, *, beta=0.0, epilogue=EPI_NONE, aux=None, alpha=1.0, out_dtype=torch.float32,
+                 drop=None):
+    """out[M,K] = alpha * drop(epi(dy[M,N] @ W[N,K])) + beta*out"""
     M, N = dy.shape
     K = W.shape[1]
     assert W.shape[0] == N and dy.is_contiguous()
     if out is None:
         assert beta == 0.0
         out = torch.empty(M, K, device=dy.device, dtype=out_dtype)
-    gemm(dy, W, out, M, K, N, N, K, K, transB=1, beta=beta, epilogue=epilogue, aux=aux, ldaux=K, alpha=alpha)
+    gemm(dy, W, out, M, K, N, N, K, K, transB=1, beta=beta, epilogue=epilogue, aux=aux, ldaux=K, alpha=alpha,
+         drop=drop)
     return out
 
 

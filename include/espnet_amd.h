@@ -84,6 +84,17 @@ typedef struct {
   void* Cb;            /* optional bf16 copy of the result (same layout as C); C may then be NULL */
   int32_t in_dtype;    /* 0: A,B are fp32; 1: A,B are bf16 (precision must be 1) */
   int32_t aux_dtype;   /* 0: aux is fp32; 1: aux is bf16 */
+  /* fused dropout (bf16-operand kernel, splitk == 1): keep(i) = hash(drop_step[0], drop_salt, i) >= p * 2^32 with
+   * i = row * ldc + col, the same mask eamd_dropout draws for a contiguous [M, N] tensor.
+   *   Hb == NULL: v <- keep ? v / (1 - p) : 0 on the epilogue value (after bias / activation / aux factor,
+   *               before alpha, residual and beta), e.g. out = x + scale * dropout(W2 h + b2);
+   *   Hb != NULL: second bf16 output Hb = dropout(h_act(v)) while C / Cb keep v itself (FFN: z and
+   *               h = dropout(act(z)) from one launch, positionwise_feed_forward.py:27). */
+  float drop_p;
+  uint64_t drop_salt;
+  const uint64_t* drop_step;
+  void* Hb;
+  int32_t h_act;
 } eamd_gemm_t;
 
 int eamd_gemm(const eamd_gemm_t* p, void* stream);

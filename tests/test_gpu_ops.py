@@ -560,3 +560,59 @@ def test_gemm_bf16_epilogue_batch_gather(ops):
                  b_off=q0 * Cc * Cc, gather=gt, cmap=cm, epilogue=3, aux=ones, ldaux=Cc)
         q0 += nt
     report("conv2_bf16_bwd_x", dy1, y1d.grad.permute(0, 2, 3, 1), 3e-6)
+
+
+def test_gemm_fused_dropout_matches_dropout_kernel(ops):
+    """GEMM epilogue dropout draws the very mask eamd_dropout draws for the same (step, salt, index)"""
+    import espnet_amd
+    espnet_amd.set_precision("bf16")
+    try:
+        g = torch.Generator().manual_seed(11)
+        M, N, K = 300, 192, 128
+        x = torch.randn(M, K, generator=g).to(DEV).to(torch.bfloat16)
+        W = torch.randn(N, K, generator=g).to(DEV).to(torch.bfloat16)
+        b = torch.randn(N, generator=g).to(DEV)
+        R = torch.randn(M, N, generator=g).to(DEV)
+        p, salt = 0.3, 77
+        plain = ops.linear_fwd(x, W, b)
+        fused = ops.linear_fwd(x, W, b, R=R, alpha=0.5, drop=(p, salt))
+        want = R + 0.5 * ops.dropout(plain, p, salt)
+        assert torch.equal(fused == R, want == R)                      # identical keep pattern
+        report("gemm fused dropout", fused, want, 1e-6)
+        kept = float((fused != R).float().mean())
+        assert abs(kept - (1 - p)) < 0.02
+        # dual output: z untouched, h = dropout(swish(z))
+        z = torch.empty(M, N, device=DEV, dtype=torch.bfloat16)
+        h = torch.empty(M, N, device=DEV, dtype=torch.bfloat16)
+        ops.linear_fwd(x, W, b, out=z, drop=(p, salt), Hb=h, h_act=ops.ACT_SWISH)
+        report("gemm dual z", z.float(), plain, 4e-3)
+        hw = ops.dropout(plain, p, salt, act=ops.ACT_SWISH)
+        assert torch.equal(h.float() == 0, hw == 0) or float(((h.float() == 0) != (hw == 0)).float().mean()) < 1e-4
+        report("gemm dual h", h.float(), hw, 4e-3)
+        # same masks on the backward side: dz = drop(dswish(z) * (dy W))
+        dy = torch.randn(M, K, generator=g).to(DEV).to(torch.bfloat16)
+        Wt = torch.randn(K, N, generator=g).to(DEV).to(torch.bfloat16)
+        a = ops.linear_bwd_x(dy, Wt, drop=(p, salt))
+        bb = ops.dropout(ops.linear_bwd_x(dy, Wt), p, salt)
+        report("gemm bwd_x fused dropout", a, bb, 1e-6)
+    finally:
+        espnet_amd.set_precision("fp32")
+
+
+@pytest.mark.parametrize("shape", [(4, 80, 128, 31), (2, 33, 300, 29), (3, 17, 64, 3), (1, 5, 32, 1)])
+def test_dwconv_kernel_sizes(ops, shape):
+    """depthwise conv fwd / input grad / weight grad at the recipe's kernel size 31 and at ragged channel counts"""
+    B, T, Cc, K = shape
+    g = torch.Generator().manual_seed(K)
+    x, w = torch.randn(B, T, Cc, generator=g), torch.randn(Cc, 1, K, generator=g)
+    bias, dy = torch.randn(Cc, generator=g), torch.randn(B, T, Cc, generator=g)
+    xd, wd_, bd_ = x.double().requires_grad_(True), w.double().requires_grad_(True), bias.double().requires_grad_(True)
+    yr = torch.nn.functional.conv1d(xd.transpose(1, 2), wd_, bd_, padding=(K - 1) // 2, groups=Cc).transpose(1, 2)
+    yr.backward(dy.double())
+    wk = w.view(Cc, K).to(DEV)
+    report("dwconv_fwd %s" % (shape,), ops.dwconv_fwd(x.to(DEV), wk, bias.to(DEV), B, T, Cc, K), yr, 1e-6)
+    report("dwconv_bwd_x %s" % (shape,), ops.dwconv_bwd_x(dy.to(DEV), wk, B, T, Cc, K), xd.grad, 1e-6)
+    dw, db = torch.zeros(Cc, K, device=DEV), torch.zeros(Cc, device=DEV)
+    ops.dwconv_bwd_w(dy.to(DEV), x.to(DEV), dw, db, B, T, Cc, K)
+    report("dwconv_bwd_w %s" % (shape,), dw, wd_.grad.view(Cc, K), 1e-5)
+    report("dwconv_bwd_b %s" % (shape,), db, bd_.grad, 1e-5)
