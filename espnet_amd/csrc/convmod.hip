@@ -3,6 +3,7 @@
 // statistics over all B*T positions, padded frames included - reference behaviour) fused with the
 // following activation, and the first Conv2dSubsampling convolution (C_in = 1) as a direct kernel.
 // reference: conformer/convolution.py:13-79, transformer/subsampling.py:28-33.
+#include <stdlib.h>
 #include "common.h"
 #include "../../include/espnet_amd.h"
 
@@ -16,7 +17,7 @@ constexpr int KMAX = 32;
 // window (TT + K - 1 values) is read once, lanes along C (coalesced 256-B rows).
 // The block's 256 x K taps are fetched with coalesced loads and handed out through LDS (a direct
 // w[c*K + k] read is a 64-way scattered access per tap).
-constexpr int TT = 16;
+template <int TT>
 __global__ __launch_bounds__(256) void dwconv_kernel(const float* __restrict__ x, const float* __restrict__ w,
                                                      const float* __restrict__ bias, float* __restrict__ y,
                                                      int B, int T, int C, int K, int pad, int flip) {
@@ -206,9 +207,16 @@ __global__ __launch_bounds__(1024) void bn_finalize_kernel(const float* __restri
     const int c = c0 + t % (C < 1024 ? C : 1024), gi = t / (C < 1024 ? C : 1024);
     float n = 0.f, mean = 0.f, m2 = 0.f;
     if (c < C && gi < G) {
-      for (int s = gi; s < nslab; s += G) {
-        const float* p = part + (long)s * 3 * C;
-        chan_merge(n, mean, m2, p[c], p[C + c], p[2 * C + c]);
+      for (int s0 = gi; s0 < nslab; s0 += 8 * G) {      // 8 slabs per trip, all 24 loads in flight together
+        float pn[8], pm[8], pq[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+          const int s = s0 + u * G;
+          const float* p = part + (long)(s < nslab ? s : s0) * 3 * C;
+          pn[u] = s < nslab ? p[c] : 0.f; pm[u] = p[C + c]; pq[u] = s < nslab ? p[2 * C + c] : 0.f;
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) chan_merge(n, mean, m2, pn[u], pm[u], pq[u]);
       }
     }
     sh[0][t] = n; sh[1][t] = mean; sh[2][t] = m2;
@@ -313,7 +321,18 @@ __global__ __launch_bounds__(1024) void bn_bwd_finalize_kernel(const float* __re
     const int c = c0 + t % W, gi = t / W;
     float s1 = 0.f, s2 = 0.f;
     if (c < C && gi < G) {
-      for (int s = gi; s < nslab; s += G) { s1 += part[(long)s * 2 * C + c]; s2 += part[(long)s * 2 * C + C + c]; }
+      for (int s0 = gi; s0 < nslab; s0 += 8 * G) {
+        float a1[8], a2[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+          const int s = s0 + u * G;
+          const bool ok = s < nslab;
+          a1[u] = ok ? part[(long)s * 2 * C + c] : 0.f;
+          a2[u] = ok ? part[(long)s * 2 * C + C + c] : 0.f;
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) { s1 += a1[u]; s2 += a2[u]; }
+      }
     }
     sh[0][t] = s1; sh[1][t] = s2;
     __syncthreads();
@@ -347,68 +366,101 @@ __global__ void bn_bwd_apply_kernel(const float* __restrict__ dy, const float* _
   }
 }
 
-// ---- Conv2dSubsampling first convolution: 1 -> C channels, 3x3, stride 2, + ReLU, NHWC output ----
-// x [B, T, F]; w [C, 1, 3, 3]; y [B, H, W, C] with H=(T-3)/2+1, W=(F-3)/2+1
+// ---- first convolution of the front-ends: 1 -> C channels, 3x3, + ReLU, NHWC output ----------------
+// x [B, T, F]; w [C, 1, 3, 3]; y [B, H, W, C], H = (T + 2 pad - 3)/st + 1, W = (F + 2 pad - 3)/st + 1
+// (st 2 / pad 0: Conv2dSubsampling, subsampling.py:28-33; st 1 / pad 1: VGG2L, rnn/encoders.py:184).
+// One workgroup per output row (b, hh): the three input rows it needs sit in LDS with a zeroed halo, a
+// thread owns one output channel (its 9 taps in registers) and walks the W positions, so every store is
+// a full 2*C / 4*C-byte row segment and the inner loop has neither index divisions nor bounds tests.
+constexpr int C1_MAXF = 512;     // input feature dim + 2*pad must fit
 __global__ __launch_bounds__(256) void conv1_fwd_kernel(const float* __restrict__ x, const float* __restrict__ w,
                                                         const float* __restrict__ bias, float* __restrict__ y, int B,
                                                         int T, int F, int H, int W, int C, int bf16, int st,
                                                         int pad) {
-  const long n = (long)B * H * W * C;
-  const long stride = (long)gridDim.x * blockDim.x;
-  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
-    const int c = i % C;
-    long p = i / C;
-    const int ww = p % W; p /= W;
-    const int hh = p % H; const long b = p / H;
-    const int t0 = st * hh - pad, f0 = st * ww - pad;
-    const float* xb = x + b * T * F;
-    const float* wc = w + (long)c * 9;
-    float acc = bias[c];
+  __shared__ float xs[3][C1_MAXF];
+  const int row = blockIdx.x;                 // b * H + hh
+  const int b = row / H, hh = row % H;
+  const int FP = F + 2 * pad;
+  for (int i = threadIdx.x; i < 3 * FP; i += blockDim.x) {
+    const int kh = i / FP, f = i % FP - pad;
+    const int tt = st * hh - pad + kh;
+    xs[kh][i % FP] = (tt >= 0 && tt < T && f >= 0 && f < F) ? x[((long)b * T + tt) * F + f] : 0.f;
+  }
+  __syncthreads();
+  unsigned short* y16 = reinterpret_cast<unsigned short*>(y);
+  for (int c = threadIdx.x; c < C; c += blockDim.x) {
+    float wr[9];
 #pragma unroll
-    for (int kh = 0; kh < 3; ++kh)
+    for (int k = 0; k < 9; ++k) wr[k] = w[(long)c * 9 + k];
+    const float bv = bias[c];
+    long o = (long)row * W * C + c;
+    for (int ww = 0; ww < W; ++ww, o += C) {
+      const int f0 = st * ww;
+      float acc = bv;
 #pragma unroll
-      for (int kw = 0; kw < 3; ++kw) {
-        const int tt = t0 + kh, ff = f0 + kw;
-        if (tt >= 0 && tt < T && ff >= 0 && ff < F) acc += wc[kh * 3 + kw] * xb[(long)tt * F + ff];
-      }
-    acc = acc > 0.f ? acc : 0.f;
-    if (bf16) reinterpret_cast<unsigned short*>(y)[i] = eamd_f2bf(acc); else y[i] = acc;
+      for (int kh = 0; kh < 3; ++kh)
+#pragma unroll
+        for (int kw = 0; kw < 3; ++kw) acc += wr[kh * 3 + kw] * xs[kh][f0 + kw];
+      acc = acc > 0.f ? acc : 0.f;
+      if (bf16) y16[o] = eamd_f2bf(acc); else y[o] = acc;
+    }
   }
 }
 // dW[c, kh, kw] += sum_pos dy[pos, c] * x[pos shifted]; db[c] += sum dy   (dy already ReLU-masked)
+// grid (ceil(C/256), row groups): a workgroup walks `rows_per_block` output rows, staging the three input
+// rows of each in LDS; thread = channel, 9 + 1 register accumulators, LDS-transposed coalesced atomics at the end.
 __global__ __launch_bounds__(256) void conv1_bwd_w_kernel(const float* __restrict__ dy, const float* __restrict__ x,
                                                           float* __restrict__ dw, float* __restrict__ db, int B,
-                                                          int T, int F, int H, int W, int C, int pos_per_block,
+                                                          int T, int F, int H, int W, int C, int rows_per_block,
                                                           int bf16, int st, int pad) {
+  __shared__ float xs[3][C1_MAXF];
+  __shared__ float tr9[256 * 10];
   const int c_raw = blockIdx.x * blockDim.x + threadIdx.x;
   const bool live = c_raw < C;
   const int c = live ? c_raw : C - 1;
-  const long npos = (long)B * H * W;
-  const long p0 = (long)blockIdx.y * pos_per_block;
-  const long p1 = live ? min(npos, p0 + (long)pos_per_block) : p0;
+  const int FP = F + 2 * pad;
+  const long nrow = (long)B * H;
+  const long r0 = (long)blockIdx.y * rows_per_block;
+  const long r1 = min(nrow, r0 + (long)rows_per_block);
+  const unsigned short* dy16 = reinterpret_cast<const unsigned short*>(dy);
   float acc[9];
 #pragma unroll
   for (int k = 0; k < 9; ++k) acc[k] = 0.f;
   float accb = 0.f;
-  for (long p = p0; p < p1; ++p) {
-    const int ww = p % W; long q = p / W;
-    const int hh = q % H; const long b = q / H;
-    const float g = bf16 ? __uint_as_float(((unsigned)reinterpret_cast<const unsigned short*>(dy)[p * C + c]) << 16)
-                         : dy[p * C + c];
-    accb += g;
-    const int t0 = st * hh - pad, f0 = st * ww - pad;
-    const float* xb = x + b * T * F;
+  for (long row = r0; row < r1; ++row) {
+    const int b = row / H, hh = row % H;
+    __syncthreads();
+    for (int i = threadIdx.x; i < 3 * FP; i += blockDim.x) {
+      const int kh = i / FP, f = i % FP - pad;
+      const int tt = st * hh - pad + kh;
+      xs[kh][i % FP] = (tt >= 0 && tt < T && f >= 0 && f < F) ? x[((long)b * T + tt) * F + f] : 0.f;
+    }
+    __syncthreads();
+    if (live) {
+      const long o = row * W * C + c;
+      for (int w0 = 0; w0 < W; w0 += 8) {        // 8 positions per trip: their loads are issued together
+        float g[8];
 #pragma unroll
-    for (int kh = 0; kh < 3; ++kh)
+        for (int u = 0; u < 8; ++u) {
+          const int ww = w0 + u;
+          const long oi = o + (long)(ww < W ? ww : w0) * C;
+          const float v = bf16 ? __uint_as_float(((unsigned)dy16[oi]) << 16) : dy[oi];
+          g[u] = ww < W ? v : 0.f;
+        }
 #pragma unroll
-      for (int kw = 0; kw < 3; ++kw) {
-        const int tt = t0 + kh, ff = f0 + kw;
-        if (tt >= 0 && tt < T && ff >= 0 && ff < F) acc[kh * 3 + kw] += g * xb[(long)tt * F + ff];
+        for (int u = 0; u < 8; ++u) {
+          accb += g[u];
+          const int f0 = st * min(w0 + u, W - 1);
+#pragma unroll
+          for (int kh = 0; kh < 3; ++kh)
+#pragma unroll
+            for (int kw = 0; kw < 3; ++kw) acc[kh * 3 + kw] += g[u] * xs[kh][f0 + kw];
+        }
       }
+    }
   }
-  __shared__ float tr9[256 * 10];
 #pragma unroll
-  for (int k = 0; k < 9; ++k) tr9[threadIdx.x * 10 + k] = acc[k];
+  for (int k = 0; k < 9; ++k) tr9[threadIdx.x * 10 + k] = live ? acc[k] : 0.f;
   __syncthreads();
   const int c0 = blockIdx.x * blockDim.x;
   const int nch = min(256, C - c0);
@@ -423,6 +475,21 @@ inline int grid_for(long n) {
   return (int)b;
 }
 
+// frames per thread of the depthwise convolution: fewer frames = more workgroups in flight (the kernel is
+// latency-bound at B*T ~ 8k frames), more frames = less re-reading of the K-1 halo.  EAMD_DWCONV_TT overrides.
+inline void dwconv_launch(const float* x, const float* w, const float* bias, float* y, int B, int T, int C, int K,
+                          int flip, hipStream_t s) {
+  static const int tt_env = [] { const char* e = getenv("EAMD_DWCONV_TT"); return e ? atoi(e) : 0; }();
+  const int tt = tt_env ? tt_env : 8;
+  const int gx = (C + 255) / 256, pad = (K - 1) / 2;
+  if (tt == 4)
+    hipLaunchKernelGGL(dwconv_kernel<4>, dim3(gx, B * ((T + 3) / 4)), dim3(256), 0, s, x, w, bias, y, B, T, C, K, pad, flip);
+  else if (tt == 16)
+    hipLaunchKernelGGL(dwconv_kernel<16>, dim3(gx, B * ((T + 15) / 16)), dim3(256), 0, s, x, w, bias, y, B, T, C, K, pad, flip);
+  else
+    hipLaunchKernelGGL(dwconv_kernel<8>, dim3(gx, B * ((T + 7) / 8)), dim3(256), 0, s, x, w, bias, y, B, T, C, K, pad, flip);
+}
+
 }  // namespace
 
 extern "C" {
@@ -431,8 +498,7 @@ int eamd_dwconv_fwd(const float* x, const float* w, const float* bias, float* y,
                     void* stream) {
   if (!x || !w || !y || B <= 0 || T <= 0 || C <= 0 || K <= 0 || (K & 1) == 0) return EAMD_EINVAL;
   if (K > KMAX) return EAMD_EUNSUPPORTED;
-  hipLaunchKernelGGL(dwconv_kernel, dim3((C + 255) / 256, B * ((T + TT - 1) / TT)), dim3(256), 0, (hipStream_t)stream,
-                     x, w, bias, y, B, T, C, K, (K - 1) / 2, 0);
+  dwconv_launch(x, w, bias, y, B, T, C, K, 0, (hipStream_t)stream);
   EAMD_LAUNCH_CHECK();
   return EAMD_OK;
 }
@@ -440,8 +506,7 @@ int eamd_dwconv_fwd(const float* x, const float* w, const float* bias, float* y,
 int eamd_dwconv_bwd_x(const float* dy, const float* w, float* dx, int B, int T, int C, int K, void* stream) {
   if (!dy || !w || !dx || B <= 0 || T <= 0 || C <= 0 || K <= 0 || (K & 1) == 0) return EAMD_EINVAL;
   if (K > KMAX) return EAMD_EUNSUPPORTED;
-  hipLaunchKernelGGL(dwconv_kernel, dim3((C + 255) / 256, B * ((T + TT - 1) / TT)), dim3(256), 0, (hipStream_t)stream,
-                     dy, w, (const float*)nullptr, dx, B, T, C, K, (K - 1) / 2, 1);
+  dwconv_launch(dy, w, (const float*)nullptr, dx, B, T, C, K, 1, (hipStream_t)stream);
   EAMD_LAUNCH_CHECK();
   return EAMD_OK;
 }
@@ -519,9 +584,10 @@ int eamd_bn_bwd(const float* dy, const float* x, const float* mean, const float*
 static int conv_c1_fwd(const float* x, const float* w, const float* bias, void* y, int B, int T, int F, int C,
                        int y_bf16, int st, int pad, void* stream) {
   if (!x || !w || !bias || !y || B <= 0 || T + 2 * pad < 3 || F + 2 * pad < 3 || C <= 0) return EAMD_EINVAL;
+  if (F + 2 * pad > C1_MAXF) return EAMD_EUNSUPPORTED;
   int H = (T + 2 * pad - 3) / st + 1, W = (F + 2 * pad - 3) / st + 1;
-  hipLaunchKernelGGL(conv1_fwd_kernel, dim3(grid_for((long)B * H * W * C)), dim3(256), 0, (hipStream_t)stream, x, w,
-                     bias, (float*)y, B, T, F, H, W, C, y_bf16, st, pad);
+  hipLaunchKernelGGL(conv1_fwd_kernel, dim3(B * H), dim3(256), 0, (hipStream_t)stream, x, w, bias, (float*)y, B, T, F, H,
+                     W, C, y_bf16, st, pad);
   EAMD_LAUNCH_CHECK();
   return EAMD_OK;
 }
@@ -537,14 +603,15 @@ int eamd_conv3x3_c1_fwd(const float* x, const float* w, const float* bias, void*
 static int conv_c1_bwd_w(const void* dy, const float* x, float* dw, float* db, int B, int T, int F, int C,
                          int dy_bf16, int st, int pad, void* stream) {
   if (!dy || !x || !dw || !db || B <= 0 || T + 2 * pad < 3 || F + 2 * pad < 3 || C <= 0) return EAMD_EINVAL;
+  if (F + 2 * pad > C1_MAXF) return EAMD_EUNSUPPORTED;
   int H = (T + 2 * pad - 3) / st + 1, W = (F + 2 * pad - 3) / st + 1;
-  long npos = (long)B * H * W;
+  long nrow = (long)B * H;
   int gx = (C + 255) / 256;
   long want = 2048 / gx; if (want < 1) want = 1;
-  long ppb = (npos + want - 1) / want; if (ppb < 16) ppb = 16;
-  int gy = (int)((npos + ppb - 1) / ppb);
-  hipLaunchKernelGGL(conv1_bwd_w_kernel, dim3(gx, gy), dim3(256), 0, (hipStream_t)stream, (const float*)dy, x, dw, db,
-                     B, T, F, H, W, C, (int)ppb, dy_bf16, st, pad);
+  long rpb = (nrow + want - 1) / want; if (rpb < 1) rpb = 1;
+  int gy = (int)((nrow + rpb - 1) / rpb);
+  hipLaunchKernelGGL(conv1_bwd_w_kernel, dim3(gx, gy), dim3(256), 0, (hipStream_t)stream, (const float*)dy, x, dw, db, B,
+                     T, F, H, W, C, (int)rpb, dy_bf16, st, pad);
   EAMD_LAUNCH_CHECK();
   return EAMD_OK;
 }

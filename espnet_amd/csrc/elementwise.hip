@@ -1,6 +1,7 @@
 // Element-wise / small reduction kernels (HBM-bound, float4-vectorised, grid-stride capped at
 // 2048 blocks): GLU, Swish, bias broadcasts, axpby, column sums, embedding + positional encoding,
 // weight-layout permutations for the implicit-GEMM convolutions, dropout.
+#include <stdlib.h>
 #include "common.h"
 #include "../../include/espnet_amd.h"
 
@@ -139,12 +140,28 @@ __global__ __launch_bounds__(256) void colsum_kernel(const float* __restrict__ x
   const long r1 = min(rows, r0 + (long)rows_per_block);
   const int c = blockIdx.x * blockDim.x + threadIdx.x;
   if (c >= D) return;
+  // 8 rows per trip, loads issued together (a serial row walk is latency-bound: one HBM round trip per row)
   float s = 0.f;
   if (bf16) {
     const unsigned short* x16 = reinterpret_cast<const unsigned short*>(x);
-    for (long r = r0; r < r1; ++r) s += __uint_as_float(((unsigned)x16[r * ld + c]) << 16);
+    long r = r0;
+    for (; r + 8 <= r1; r += 8) {
+      unsigned short v[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) v[u] = x16[(r + u) * ld + c];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) s += __uint_as_float(((unsigned)v[u]) << 16);
+    }
+    for (; r < r1; ++r) s += __uint_as_float(((unsigned)x16[r * ld + c]) << 16);
   } else {
-    for (long r = r0; r < r1; ++r) s += x[r * ld + c];
+    long r = r0;
+    for (; r + 8 <= r1; r += 8) {
+      float v[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) v[u] = x[(r + u) * ld + c];
+      s += ((v[0] + v[1]) + (v[2] + v[3])) + ((v[4] + v[5]) + (v[6] + v[7]));
+    }
+    for (; r < r1; ++r) s += x[r * ld + c];
   }
   atomicAdd(&out[c], s * scale);
 }
@@ -323,8 +340,9 @@ int eamd_add_bias2(const void* q, const float* u, const float* v, void* qu, void
 int eamd_colsum(const void* x, int64_t ld, float* out, int64_t rows, int D, float scale, int bf16, void* stream) {
   if (!x || !out || rows <= 0 || D <= 0) return EAMD_EINVAL;
   int gx = (D + 255) / 256;
+  static const int min_rpb = [] { const char* e = getenv("EAMD_COLSUM_RPB"); return e ? atoi(e) : 128; }();
   long want = 1024 / gx; if (want < 1) want = 1;
-  long rpb = (rows + want - 1) / want; if (rpb < 32) rpb = 32;
+  long rpb = (rows + want - 1) / want; if (rpb < min_rpb) rpb = min_rpb;
   int gy = (int)((rows + rpb - 1) / rpb);
   hipLaunchKernelGGL(colsum_kernel, dim3(gx, gy), dim3(256), 0, (hipStream_t)stream, (const float*)x, (long)ld, out,
                      (long)rows, D, (int)rpb, scale, bf16);

@@ -1,6 +1,7 @@
 // Row kernels (HBM-bound): LayerNorm fwd/bwd, masked softmax with the legacy rel-shift fused in,
 // label-smoothing KL loss (+gradient, +accuracy), row argmax.  One 64-lane wave owns one row
 // unless stated; rows are staged in registers / LDS so each element is read from HBM once.
+#include <stdlib.h>
 #include "common.h"
 #include "../../include/espnet_amd.h"
 
@@ -456,7 +457,8 @@ int eamd_layernorm_fwd(const float* x, const float* gamma, const float* beta, fl
 }
 
 static void ln_bwd_grid(int rows, int* nblk, int* rpb) {
-  int n = min(1024, (rows + 7) / 8);
+  static const int per = [] { const char* e = getenv("EAMD_LNB_RPB"); return e ? atoi(e) : 16; }();
+  int n = min(4096, (rows + per - 1) / per);
   *rpb = (rows + n - 1) / n;
   *nblk = (rows + *rpb - 1) / *rpb;
 }
