@@ -57,12 +57,12 @@ SYMBOLS = [
     "eamd_axpby", "eamd_cast_bf16", "eamd_scale_dev", "eamd_act_fwd", "eamd_act_bwd", "eamd_glu_fwd", "eamd_glu_bwd",
     "eamd_add_bias2", "eamd_add_cast_bf16", "eamd_colsum", "eamd_embed_pe", "eamd_embed_bwd", "eamd_posenc", "eamd_permute4",
     "eamd_dropout", "eamd_rng_advance", "eamd_dwconv_fwd", "eamd_dwconv_bwd_x", "eamd_dwconv_bwd_w", "eamd_bn_nslab",
-    "eamd_bn_stats", "eamd_bn_apply", "eamd_bn_bwd", "eamd_conv1_fwd", "eamd_conv1_bwd_w",
+    "eamd_bn_stats", "eamd_bn_apply", "eamd_bn_bwd", "eamd_conv1_fwd", "eamd_conv1_bwd_w_workspace", "eamd_conv1_bwd_w",
     "eamd_conv2_weight_prep", "eamd_conv2_weight_grad", "eamd_add_sos_eos", "eamd_ctc_collapse",
     "eamd_ctc_workspace_bytes", "eamd_ctc_loss", "eamd_ctc_prefix_score", "eamd_grad_norm", "eamd_sched_step", "eamd_adam_step",
     "eamd_lstm_cell_fwd", "eamd_lstm_cell_bwd", "eamd_maxpool2x2_fwd", "eamd_maxpool2x2_bwd", "eamd_mask_rows",
     "eamd_joint_fwd", "eamd_joint_bwd", "eamd_rnnt_workspace", "eamd_rnnt_loss",
-    "eamd_conv3x3_c1_fwd", "eamd_conv3x3_c1_bwd_w", "eamd_attloc_fwd", "eamd_attloc_bwd_energy", "eamd_attloc_bwd_conv",
+    "eamd_conv3x3_c1_fwd", "eamd_conv3x3_c1_bwd_w_workspace", "eamd_conv3x3_c1_bwd_w", "eamd_attloc_fwd", "eamd_attloc_bwd_energy", "eamd_attloc_bwd_conv",
 ]
 
 
@@ -78,6 +78,8 @@ def lib():
         _lib.eamd_ctc_workspace_bytes.restype = C.c_int64
         _lib.eamd_layernorm_bwd_workspace.restype = C.c_int64
         _lib.eamd_rnnt_workspace.restype = C.c_int64
+        _lib.eamd_conv1_bwd_w_workspace.restype = C.c_int64
+        _lib.eamd_conv3x3_c1_bwd_w_workspace.restype = C.c_int64
         for s in SYMBOLS:
             getattr(_lib, s)  # AttributeError here = header/library mismatch
     return _lib

@@ -410,9 +410,9 @@ __global__ __launch_bounds__(256) void conv1_fwd_kernel(const float* __restrict_
 // grid (ceil(C/256), row groups): a workgroup walks `rows_per_block` output rows, staging the three input
 // rows of each in LDS; thread = channel, 9 + 1 register accumulators, LDS-transposed coalesced atomics at the end.
 __global__ __launch_bounds__(256) void conv1_bwd_w_kernel(const float* __restrict__ dy, const float* __restrict__ x,
-                                                          float* __restrict__ dw, float* __restrict__ db, int B,
-                                                          int T, int F, int H, int W, int C, int rows_per_block,
-                                                          int bf16, int st, int pad) {
+                                                          float* __restrict__ dw, float* __restrict__ db,
+                                                          float* __restrict__ part, int B, int T, int F, int H, int W,
+                                                          int C, int rows_per_block, int bf16, int st, int pad) {
   __shared__ float xs[3][C1_MAXF];
   __shared__ float tr9[256 * 10];
   const int c_raw = blockIdx.x * blockDim.x + threadIdx.x;
@@ -459,6 +459,15 @@ __global__ __launch_bounds__(256) void conv1_bwd_w_kernel(const float* __restric
       }
     }
   }
+  if (part) {   // per-block partial sums [gridDim.y][10][C] (k-major: coalesced), reduced by conv1_bwd_w_reduce_kernel
+    if (live) {
+      float* pp = part + (long)blockIdx.y * 10 * C + c;
+#pragma unroll
+      for (int k = 0; k < 9; ++k) pp[(long)k * C] = acc[k];
+      pp[(long)9 * C] = accb;
+    }
+    return;
+  }
 #pragma unroll
   for (int k = 0; k < 9; ++k) tr9[threadIdx.x * 10 + k] = live ? acc[k] : 0.f;
   __syncthreads();
@@ -466,6 +475,31 @@ __global__ __launch_bounds__(256) void conv1_bwd_w_kernel(const float* __restric
   const int nch = min(256, C - c0);
   for (int i = threadIdx.x; i < nch * 9; i += blockDim.x) atomicAdd(&dw[(long)c0 * 9 + i], tr9[(i / 9) * 10 + (i % 9)]);
   if (live) atomicAdd(&db[c], accb);
+}
+// part[nblk][10][C] -> dw[C][9] +=, db[C] +=.  grid (ceil(10*C/64), slices): 4 row-subgroups x 64 columns per block
+__global__ __launch_bounds__(256) void conv1_bwd_w_reduce_kernel(const float* __restrict__ part, int nblk, int C,
+                                                                 float* __restrict__ dw, float* __restrict__ db) {
+  __shared__ float red[4][64];
+  const int lane = threadIdx.x & 63, sub = threadIdx.x >> 6;
+  const int col = blockIdx.x * 64 + lane;         // index into [10][C]
+  const int per = (nblk + gridDim.y - 1) / gridDim.y;
+  const int r0 = blockIdx.y * per, r1 = min(nblk, r0 + per);
+  float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+  if (col < 10 * C) {
+    int r = r0 + sub;
+    for (; r + 12 < r1; r += 16) {
+      s0 += part[(long)r * 10 * C + col];        s1 += part[(long)(r + 4) * 10 * C + col];
+      s2 += part[(long)(r + 8) * 10 * C + col];  s3 += part[(long)(r + 12) * 10 * C + col];
+    }
+    for (; r < r1; r += 4) s0 += part[(long)r * 10 * C + col];
+  }
+  red[sub][lane] = (s0 + s1) + (s2 + s3);
+  __syncthreads();
+  if (sub == 0 && col < 10 * C) {
+    const float v = (red[0][lane] + red[1][lane]) + (red[2][lane] + red[3][lane]);
+    const int k = col / C, c = col % C;
+    if (k < 9) atomicAdd(&dw[(long)c * 9 + k], v); else atomicAdd(&db[c], v);
+  }
 }
 
 inline int grid_for(long n) {
@@ -600,28 +634,49 @@ int eamd_conv3x3_c1_fwd(const float* x, const float* w, const float* bias, void*
   return conv_c1_fwd(x, w, bias, y, B, T, F, C, y_bf16, 1, 1, stream);
 }
 
-static int conv_c1_bwd_w(const void* dy, const float* x, float* dw, float* db, int B, int T, int F, int C,
-                         int dy_bf16, int st, int pad, void* stream) {
+static void conv_c1_bwd_w_grid(int B, int H, int C, int* gx, int* gy, long* rpb) {
+  long nrow = (long)B * H;
+  *gx = (C + 255) / 256;
+  long want = 2048 / *gx; if (want < 1) want = 1;
+  *rpb = (nrow + want - 1) / want; if (*rpb < 1) *rpb = 1;
+  *gy = (int)((nrow + *rpb - 1) / *rpb);
+}
+static int conv_c1_bwd_w(const void* dy, const float* x, float* dw, float* db, float* workspace, int B, int T, int F,
+                         int C, int dy_bf16, int st, int pad, void* stream) {
   if (!dy || !x || !dw || !db || B <= 0 || T + 2 * pad < 3 || F + 2 * pad < 3 || C <= 0) return EAMD_EINVAL;
   if (F + 2 * pad > C1_MAXF) return EAMD_EUNSUPPORTED;
   int H = (T + 2 * pad - 3) / st + 1, W = (F + 2 * pad - 3) / st + 1;
-  long nrow = (long)B * H;
-  int gx = (C + 255) / 256;
-  long want = 2048 / gx; if (want < 1) want = 1;
-  long rpb = (nrow + want - 1) / want; if (rpb < 1) rpb = 1;
-  int gy = (int)((nrow + rpb - 1) / rpb);
-  hipLaunchKernelGGL(conv1_bwd_w_kernel, dim3(gx, gy), dim3(256), 0, (hipStream_t)stream, (const float*)dy, x, dw, db, B,
-                     T, F, H, W, C, (int)rpb, dy_bf16, st, pad);
+  int gx, gy; long rpb;
+  conv_c1_bwd_w_grid(B, H, C, &gx, &gy, &rpb);
+  float* part = gy >= 64 ? workspace : nullptr;     // few blocks: direct atomics beat a second launch
+  hipStream_t s = (hipStream_t)stream;
+  hipLaunchKernelGGL(conv1_bwd_w_kernel, dim3(gx, gy), dim3(256), 0, s, (const float*)dy, x, dw, db, part, B, T, F, H, W,
+                     C, (int)rpb, dy_bf16, st, pad);
   EAMD_LAUNCH_CHECK();
+  if (part) {
+    hipLaunchKernelGGL(conv1_bwd_w_reduce_kernel, dim3((10 * C + 63) / 64, min(16, (gy + 31) / 32)), dim3(256), 0, s, part,
+                       gy, C, dw, db);
+    EAMD_LAUNCH_CHECK();
+  }
   return EAMD_OK;
 }
-int eamd_conv1_bwd_w(const void* dy, const float* x, float* dw, float* db, int B, int T, int F, int C,
-                     int dy_bf16, void* stream) {
-  return conv_c1_bwd_w(dy, x, dw, db, B, T, F, C, dy_bf16, 2, 0, stream);
+/* floats of scratch for eamd_conv1_bwd_w / eamd_conv3x3_c1_bwd_w (stride/pad as in the forward) */
+static int64_t conv_c1_ws(int B, int T, int C, int st, int pad) {
+  if (B <= 0 || T + 2 * pad < 3 || C <= 0) return 0;
+  int H = (T + 2 * pad - 3) / st + 1;
+  int gx, gy; long rpb;
+  conv_c1_bwd_w_grid(B, H, C, &gx, &gy, &rpb);
+  return (int64_t)gy * 10 * C;
 }
-int eamd_conv3x3_c1_bwd_w(const void* dy, const float* x, float* dw, float* db, int B, int T, int F, int C,
-                          int dy_bf16, void* stream) {
-  return conv_c1_bwd_w(dy, x, dw, db, B, T, F, C, dy_bf16, 1, 1, stream);
+int64_t eamd_conv1_bwd_w_workspace(int B, int T, int C) { return conv_c1_ws(B, T, C, 2, 0); }
+int64_t eamd_conv3x3_c1_bwd_w_workspace(int B, int T, int C) { return conv_c1_ws(B, T, C, 1, 1); }
+int eamd_conv1_bwd_w(const void* dy, const float* x, float* dw, float* db, float* workspace, int B, int T, int F,
+                     int C, int dy_bf16, void* stream) {
+  return conv_c1_bwd_w(dy, x, dw, db, workspace, B, T, F, C, dy_bf16, 2, 0, stream);
+}
+int eamd_conv3x3_c1_bwd_w(const void* dy, const float* x, float* dw, float* db, float* workspace, int B, int T, int F,
+                          int C, int dy_bf16, void* stream) {
+  return conv_c1_bwd_w(dy, x, dw, db, workspace, B, T, F, C, dy_bf16, 1, 1, stream);
 }
 
 }  // extern "C"

@@ -511,8 +511,10 @@ def conv1_fwd(x, w, bias, B, T, F, Cc, out_dtype=torch.float32):
 
 
 def conv1_bwd_w(dy, x, dw, db, B, T, F, Cc):
-    check(_lib.lib().eamd_conv1_bwd_w(ptr(dy), ptr(x), ptr(dw), ptr(db), B, T, F, Cc,
-                                      1 if dy.dtype == torch.bfloat16 else 0, stream_ptr()), "eamd_conv1_bwd_w")
+    L = _lib.lib()
+    ws = torch.empty(int(L.eamd_conv1_bwd_w_workspace(B, T, Cc)), device=x.device, dtype=torch.float32)
+    check(L.eamd_conv1_bwd_w(ptr(dy), ptr(x), ptr(dw), ptr(db), ptr(ws), B, T, F, Cc,
+                             1 if dy.dtype == torch.bfloat16 else 0, stream_ptr()), "eamd_conv1_bwd_w")
 
 
 def conv2_weight_prep(w, out_dtype=torch.float32):
@@ -687,9 +689,10 @@ def conv3x3_c1_fwd(x, w, bias, B, T, F, Cc, out_dtype=torch.float32):
 
 
 def conv3x3_c1_bwd_w(dy, x, dw, db, B, T, F, Cc):
-    check(_lib.lib().eamd_conv3x3_c1_bwd_w(ptr(dy), ptr(x), ptr(dw), ptr(db), B, T, F, Cc,
-                                           1 if dy.dtype == torch.bfloat16 else 0, stream_ptr()),
-          "eamd_conv3x3_c1_bwd_w")
+    L = _lib.lib()
+    ws = torch.empty(int(L.eamd_conv3x3_c1_bwd_w_workspace(B, T, Cc)), device=x.device, dtype=torch.float32)
+    check(L.eamd_conv3x3_c1_bwd_w(ptr(dy), ptr(x), ptr(dw), ptr(db), ptr(ws), B, T, F, Cc,
+                                  1 if dy.dtype == torch.bfloat16 else 0, stream_ptr()), "eamd_conv3x3_c1_bwd_w")
 
 
 def joint_fwd(enc, dec, act, out_dtype=torch.float32):

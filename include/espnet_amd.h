@@ -203,8 +203,11 @@ int eamd_bn_bwd(const float* dy, const float* x, const float* mean, const float*
 /* Conv2d(1, C, 3, 2) + ReLU, x [B,T,F] -> y [B,H,W,C] (NHWC). */
 int eamd_conv1_fwd(const float* x, const float* w, const float* bias, void* y, int B, int T, int F, int C,
                    int y_bf16, void* stream);
-int eamd_conv1_bwd_w(const void* dy, const float* x, float* dw, float* db, int B, int T, int F, int C,
-                     int dy_bf16, void* stream);
+/* weight / bias gradient (accumulated; dy already ReLU-masked).  workspace: eamd_conv1_bwd_w_workspace(B,T,C) floats
+ * of scratch for the two-stage reduction (NULL => f32 atomics straight into dw / db). */
+int64_t eamd_conv1_bwd_w_workspace(int B, int T, int C);
+int eamd_conv1_bwd_w(const void* dy, const float* x, float* dw, float* db, float* workspace, int B, int T, int F,
+                     int C, int dy_bf16, void* stream);
 
 /* ------------------------------------------------------------------------------------------
  * CTC loss (warp-ctc operator slot).  reference: ctc.py:30-47,53-66 (ctc_type warpctc|builtin),
@@ -251,8 +254,9 @@ int eamd_mask_rows(const float* x, const uint8_t* keep, float* y, int64_t rows, 
  * its weight gradient (dy already ReLU-masked).  reference: rnn/encoders.py:184,203. */
 int eamd_conv3x3_c1_fwd(const float* x, const float* w, const float* bias, void* y, int B, int T, int F, int C,
                         int y_bf16, void* stream);
-int eamd_conv3x3_c1_bwd_w(const void* dy, const float* x, float* dw, float* db, int B, int T, int F, int C,
-                          int dy_bf16, void* stream);
+int64_t eamd_conv3x3_c1_bwd_w_workspace(int B, int T, int C);
+int eamd_conv3x3_c1_bwd_w(const void* dy, const float* x, float* dw, float* db, float* workspace, int B, int T, int F,
+                          int C, int dy_bf16, void* stream);
 /* Location-aware attention, one decoder step.  reference: rnn/attentions.py:300-380 (AttLoc.forward).
  *   conv = Conv2d(1,C,(1,K))(att_prev) (K = 2*aconv_filts+1, no bias); e = gvec . tanh(W_att conv + pre_enc +
  *   dec_proj) + gb, -inf for t >= lens[b]; w = softmax(scaling * e); ctx = sum_t w * enc_h.
