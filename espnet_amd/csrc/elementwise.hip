@@ -105,7 +105,7 @@ __global__ void glu_bwd_kernel(const float* __restrict__ dy, const float* __rest
 // reference: transformer/attention.py:186-190 (q_with_bias_u / q_with_bias_v).
 __global__ void add_bias2_kernel(const float* __restrict__ q, const float* __restrict__ u,
                                  const float* __restrict__ v, float* __restrict__ qu, float* __restrict__ qv,
-                                 long rows, int D, int bf16) {
+                                 long rows, int D, int bf16, long ldq) {
   const long n = rows * D;
   const long stride = (long)gridDim.x * blockDim.x;
   const unsigned short* q16 = reinterpret_cast<const unsigned short*>(q);
@@ -113,12 +113,13 @@ __global__ void add_bias2_kernel(const float* __restrict__ q, const float* __res
   unsigned short* qv16 = reinterpret_cast<unsigned short*>(qv);
   for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
     int d = i % D;
+    const long qi = (i / D) * ldq + d;        // q may be a column block of a wider matrix (fused QKV projection)
     if (bf16) {
-      float x = __uint_as_float(((unsigned)q16[i]) << 16);
+      float x = __uint_as_float(((unsigned)q16[qi]) << 16);
       qu16[i] = eamd_f2bf(x + u[d]);
       qv16[i] = eamd_f2bf(x + v[d]);
     } else {
-      float x = q[i];
+      float x = q[qi];
       qu[i] = x + u[d];
       qv[i] = x + v[d];
     }
@@ -127,9 +128,10 @@ __global__ void add_bias2_kernel(const float* __restrict__ q, const float* __res
 
 // out_bf16 = a + b  (fp32 inputs): the query gradient dq = dq_u + dq_v feeding the bf16 GEMMs
 __global__ void add_cast_kernel(const float* __restrict__ a, const float* __restrict__ b, unsigned short* __restrict__ o,
-                                long n) {
+                                long n, int cols, long ld_out) {
   const long stride = (long)gridDim.x * blockDim.x;
-  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) o[i] = eamd_f2bf(a[i] + (b ? b[i] : 0.f));
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride)
+    o[(i / cols) * ld_out + i % cols] = eamd_f2bf(a[i] + (b ? b[i] : 0.f));
 }
 
 // Column sums of a [rows, D] matrix, ADDED into out[D] (bias gradients).  Each block reduces a slab
@@ -320,19 +322,21 @@ int eamd_glu_bwd(const float* dy, const float* x, float* dx, void* dx_bf16, int6
   return EAMD_OK;
 }
 
-int eamd_add_cast_bf16(const float* a, const float* b, void* out_bf16, int64_t n, void* stream) {
-  if (!a || !out_bf16 || n <= 0) return EAMD_EINVAL;
+int eamd_add_cast_bf16(const float* a, const float* b, void* out_bf16, int64_t rows, int cols, int64_t ld_out,
+                       void* stream) {
+  if (!a || !out_bf16 || rows <= 0 || cols <= 0 || ld_out < cols) return EAMD_EINVAL;
+  const long n = (long)rows * cols;
   hipLaunchKernelGGL(add_cast_kernel, dim3(grid_for(n)), dim3(256), 0, (hipStream_t)stream, a, b,
-                     (unsigned short*)out_bf16, (long)n);
+                     (unsigned short*)out_bf16, n, cols, (long)ld_out);
   EAMD_LAUNCH_CHECK();
   return EAMD_OK;
 }
 
-int eamd_add_bias2(const void* q, const float* u, const float* v, void* qu, void* qv, int64_t rows, int D,
+int eamd_add_bias2(const void* q, int64_t ldq, const float* u, const float* v, void* qu, void* qv, int64_t rows, int D,
                    int bf16, void* stream) {
-  if (!q || !u || !v || !qu || !qv || rows <= 0 || D <= 0) return EAMD_EINVAL;
+  if (!q || !u || !v || !qu || !qv || rows <= 0 || D <= 0 || ldq < D) return EAMD_EINVAL;
   hipLaunchKernelGGL(add_bias2_kernel, dim3(grid_for(rows * D)), dim3(256), 0, (hipStream_t)stream, (const float*)q, u,
-                     v, (float*)qu, (float*)qv, (long)rows, D, bf16);
+                     v, (float*)qu, (float*)qv, (long)rows, D, bf16, (long)ldq);
   EAMD_LAUNCH_CHECK();
   return EAMD_OK;
 }

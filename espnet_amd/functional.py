@@ -202,19 +202,33 @@ def _ldp(T2):
     return (T2 + 7) // 8 * 8
 
 
+class _MV:
+    """[rows, D] matrix stored as a column block of a wider row-major tensor: element (r, c) at off + r*ld + c"""
+
+    __slots__ = ("t", "off", "ld")
+
+    def __init__(self, t, off=0, ld=None):
+        self.t, self.off, self.ld = t, off, (t.shape[-1] if ld is None else ld)
+
+
+def _mv(x):
+    return x if isinstance(x, _MV) else _MV(x)
+
+
 def attn_scores_fwd(qu, qv, k, p, mask, B, T1, T2, H, dk):
     D = H * dk
     ldp = _ldp(T2)
-    ac = torch.empty(H * B * T1 * ldp, device=qu.device, dtype=torch.float32)
-    ops.gemm(qu, k, ac, T1, T2, dk, D, D, ldp, batch=(B, H), sA=(T1 * D, dk), sB=(T2 * D, dk),
-             sC=(T1 * ldp, B * T1 * ldp))
+    qu, k = _mv(qu), _mv(k)
+    ac = torch.empty(H * B * T1 * ldp, device=qu.t.device, dtype=torch.float32)
+    ops.gemm(qu.t, k.t, ac, T1, T2, dk, qu.ld, k.ld, ldp, batch=(B, H), sA=(T1 * qu.ld, dk), sB=(T2 * k.ld, dk),
+             sC=(T1 * ldp, B * T1 * ldp), a_off=qu.off, b_off=k.off)
     bd = None
     if p is not None:
         bd = torch.empty_like(ac)
         ops.gemm(qv, p, bd, T1, T2, dk, D, D, ldp, batch=(B, H), sA=(T1 * D, dk), sB=(0, dk),
                  sC=(T1 * ldp, B * T1 * ldp))
     if ops.fast():
-        P = torch.empty(H * B * T1 * ldp, device=qu.device, dtype=torch.bfloat16)
+        P = torch.empty(H * B * T1 * ldp, device=ac.device, dtype=torch.bfloat16)
     else:
         P = ac   # in place
     ops.softmax_fwd(ac, bd, mask, P, H * B, B, T1, T2, ldp, 1.0 / math.sqrt(dk))
@@ -224,27 +238,37 @@ def attn_scores_fwd(qu, qv, k, p, mask, B, T1, T2, H, dk):
 def attn_context_fwd(P, v, B, T1, T2, H, dk):
     D = H * dk
     ldp = _ldp(T2)
-    ctxv = torch.empty(B * T1, D, device=v.device, dtype=ops.act_dtype())
-    ops.gemm(P, v, ctxv, T1, dk, T2, ldp, D, D, transB=1, batch=(B, H), sA=(T1 * ldp, B * T1 * ldp),
-             sB=(T2 * D, dk), sC=(T1 * D, dk))
+    v = _mv(v)
+    ctxv = torch.empty(B * T1, D, device=P.device, dtype=ops.act_dtype())
+    ops.gemm(P, v.t, ctxv, T1, dk, T2, ldp, v.ld, D, transB=1, batch=(B, H), sA=(T1 * ldp, B * T1 * ldp),
+             sB=(T2 * v.ld, dk), sC=(T1 * D, dk), b_off=v.off)
     return ctxv
 
 
-def attn_core_bwd(dctx, P, qu, qv, k, v, p, B, T1, T2, H, dk, Pd=None, attn_drop=(0.0, 0)):
+def attn_core_bwd(dctx, P, qu, qv, k, v, p, B, T1, T2, H, dk, Pd=None, attn_drop=(0.0, 0), dqkv=None):
     """returns dqu (fp32), dqv (fp32 or None), dk, dv (GEMM-operand dtype), dp (fp32 or None)
-    Pd = dropped-out probabilities actually used for the context (None when attention dropout is off)."""
+    Pd = dropped-out probabilities actually used for the context (None when attention dropout is off).
+    dqkv (fused QKV projection, self-attention): a [B*T, 3D] operand-dtype buffer; dk / dv are written into its
+    column blocks 1 / 2, and without relative positions dq goes straight into block 0 (dqu is then None)."""
     D = H * dk
     ldp = _ldp(T2)
     dev = dctx.device
     adt = ops.act_dtype()
+    qu, k, v = _mv(qu), _mv(k), _mv(v)
     sP = (T1 * ldp, B * T1 * ldp)
     dP = torch.empty(H * B * T1 * ldp, device=dev, dtype=torch.float32)
-    ops.gemm(dctx, v, dP, T1, T2, dk, D, D, ldp, batch=(B, H), sA=(T1 * D, dk), sB=(T2 * D, dk), sC=sP)   # dctx v^T
+    ops.gemm(dctx, v.t, dP, T1, T2, dk, D, v.ld, ldp, batch=(B, H), sA=(T1 * D, dk), sB=(T2 * v.ld, dk), sC=sP,
+             b_off=v.off)                                                                                 # dctx v^T
     if Pd is not None:
         dP = ops.dropout(dP, attn_drop[0], attn_drop[1])      # same mask as the forward probabilities
-    dv = torch.empty(B * T2, D, device=dev, dtype=adt)
-    ops.gemm(Pd if Pd is not None else P, dctx, dv, T2, dk, T1, ldp, D, D, transA=1, transB=1, batch=(B, H), sA=sP,
-             sB=(T1 * D, dk), sC=(T2 * D, dk))                                                            # P^T dctx
+    if dqkv is None:
+        dv, dv_off, ldo = torch.empty(B * T2, D, device=dev, dtype=adt), 0, D
+        dkk, dk_off = torch.empty(B * T2, D, device=dev, dtype=adt), 0
+    else:
+        ldo = 3 * D
+        dv, dv_off, dkk, dk_off = dqkv, 2 * D, dqkv, D
+    ops.gemm(Pd if Pd is not None else P, dctx, dv, T2, dk, T1, ldp, D, ldo, transA=1, transB=1, batch=(B, H), sA=sP,
+             sB=(T1 * D, dk), sC=(T2 * ldo, dk), c_off=dv_off)                                            # P^T dctx
     dbd = torch.zeros(H * B * T1 * ldp, device=dev, dtype=adt) if p is not None else None
     if ops.fast():
         dS = torch.empty(H * B * T1 * ldp, device=dev, dtype=torch.bfloat16)
@@ -252,11 +276,16 @@ def attn_core_bwd(dctx, P, qu, qv, k, v, p, B, T1, T2, H, dk, Pd=None, attn_drop
     else:
         ops.softmax_bwd(P, dP, dbd, H * B, T1, T2, ldp, 1.0 / math.sqrt(dk))   # dP <- d(ac)
         dS = dP
-    dqu = torch.empty(B * T1, D, device=dev, dtype=torch.float32)
-    ops.gemm(dS, k, dqu, T1, dk, T2, ldp, D, D, transB=1, batch=(B, H), sA=sP, sB=(T2 * D, dk), sC=(T1 * D, dk))
-    dkk = torch.empty(B * T2, D, device=dev, dtype=adt)
-    ops.gemm(dS, qu, dkk, T2, dk, T1, ldp, D, D, transA=1, transB=1, batch=(B, H), sA=sP, sB=(T1 * D, dk),
-             sC=(T2 * D, dk))
+    if dqkv is not None and p is None:
+        dqu = None      # no relative positions: dq is needed only as a GEMM operand
+        ops.gemm(dS, k.t, dqkv, T1, dk, T2, ldp, k.ld, ldo, transB=1, batch=(B, H), sA=sP, sB=(T2 * k.ld, dk),
+                 sC=(T1 * ldo, dk), b_off=k.off)
+    else:
+        dqu = torch.empty(B * T1, D, device=dev, dtype=torch.float32)
+        ops.gemm(dS, k.t, dqu, T1, dk, T2, ldp, k.ld, D, transB=1, batch=(B, H), sA=sP, sB=(T2 * k.ld, dk),
+                 sC=(T1 * D, dk), b_off=k.off)
+    ops.gemm(dS, qu.t, dkk, T2, dk, T1, ldp, qu.ld, ldo, transA=1, transB=1, batch=(B, H), sA=sP, sB=(T1 * qu.ld, dk),
+             sC=(T2 * ldo, dk), b_off=qu.off, c_off=dk_off)
     dqv = dp = None
     if p is not None:
         dqv = torch.empty(B * T1, D, device=dev, dtype=torch.float32)
@@ -266,6 +295,33 @@ def attn_core_bwd(dctx, P, qu, qv, k, v, p, B, T1, T2, H, dk, Pd=None, attn_drop
         ops.gemm(dbd, qv, dp, T2, dk, B * T1, ldp, D, D, transA=1, transB=1, batch=(1, H),
                  sA=(0, B * T1 * ldp), sB=(0, dk), sC=(0, dk), splitk=max(2, ops.auto_splitk(T2, dk, B * T1) // H + 1))
     return dqu, dqv, dkk, dv, dp
+
+
+FUSE_QKV = True   # tests flip this to compare against the three-GEMM path
+
+
+def _adjacent3(a, b, c):
+    n = a.numel() * a.element_size()
+    return (a.is_contiguous() and b.is_contiguous() and c.is_contiguous() and a.numel() == b.numel() == c.numel()
+            and b.data_ptr() == a.data_ptr() + n and c.data_ptr() == b.data_ptr() + n)
+
+
+def _qkv_adjacent(wq, wk, wv, bq, bk, bv):
+    """True when the q/k/v projection weights (fp32 masters, bf16 shadows, gradient buffers) and biases lie back
+    to back in their arenas (espnet_amd.train.FlatParams arranges that), so that the three Linear layers can run
+    as one GEMM over a [3D, D] view.  The state_dict keeps the reference's separate linear_q / linear_k / linear_v."""
+    if not FUSE_QKV or bq is None or not (_adjacent3(wq, wk, wv) and _adjacent3(bq, bk, bv)):
+        return False
+    gw = [getattr(t, "_eamd_grad", None) for t in (wq, wk, wv, bq, bk, bv)]
+    if any(g is None for g in gw) or not (_adjacent3(*gw[:3]) and _adjacent3(*gw[3:])):
+        return False
+    return _adjacent3(ops.wshadow(wq), ops.wshadow(wk), ops.wshadow(wv))
+
+
+def _span3(first, shape):
+    """view over three adjacent equally sized tensors, starting at `first`"""
+    stride = (shape[1], 1) if len(shape) == 2 else (1,)
+    return first.detach().as_strided(shape, stride)
 
 
 class MHABlockFn(torch.autograd.Function):
@@ -299,15 +355,26 @@ class MHABlockFn(torch.autograd.Function):
             T1 = 1
         else:
             xq, res, T1 = xn, x2, T1f
-        q = ops.linear_fwd(xq, ops.wshadow(wq), bq, out_dtype=adt)
-        k = ops.linear_fwd(kv_in, ops.wshadow(wk), bk, out_dtype=adt)
-        v = ops.linear_fwd(kv_in, ops.wshadow(wv), bv, out_dtype=adt)
+        fused = memory is None and not last_query_only and ops.fast() and _qkv_adjacent(wq, wk, wv, bq, bk, bv)
+        if fused:
+            # q, k, v weights sit back to back in the arenas (FlatParams): one [M, D] x [3D, D]^T projection
+            w3, b3 = _span3(ops.wshadow(wq), (3 * D, D)), _span3(bq, (3 * D,))
+            qkv = ops.linear_fwd(xq, w3, b3, out_dtype=adt)
+            q, k, v = _MV(qkv, 0, 3 * D), _MV(qkv, D, 3 * D), _MV(qkv, 2 * D, 3 * D)
+        else:
+            qkv = None
+            q = ops.linear_fwd(xq, ops.wshadow(wq), bq, out_dtype=adt)
+            k = ops.linear_fwd(kv_in, ops.wshadow(wk), bk, out_dtype=adt)
+            v = ops.linear_fwd(kv_in, ops.wshadow(wv), bv, out_dtype=adt)
         pos2 = None
         if rel:
             wpos, pu, pv = params[10:13]
             pos2 = ops.to_act(pos_emb.reshape(-1, D).contiguous())
             p = ops.linear_fwd(pos2, ops.wshadow(wpos), None, out_dtype=adt)
-            qu, qv = ops.add_bias2(q, pu.reshape(-1), pv.reshape(-1))
+            if fused:
+                qu, qv = ops.add_bias2(qkv, pu.reshape(-1), pv.reshape(-1), rows=B * T1, D=D, ldq=3 * D, q_off=0)
+            else:
+                qu, qv = ops.add_bias2(q, pu.reshape(-1), pv.reshape(-1))
         else:
             p, qu, qv = None, q, None
         P = attn_scores_fwd(qu, qv, k, p, mask, B, T1, T2, H, dk)
@@ -320,9 +387,14 @@ class MHABlockFn(torch.autograd.Function):
             out = ops.axpby(res, ops.dropout(br, p_out, s_out), 1.0, 1.0)
         else:
             out = ops.linear_fwd(cx, ops.wshadow(wo), bo, R=res)
-        ctx.save_for_backward(x2, mean, rstd, xn, kv_in if memory is not None else None, qu, qv, k, v, p, P, cx, pos2,
-                              Pd if p_att > 0.0 else None)
+        if fused:   # k, v (and q without relative positions) are column blocks of qkv
+            ctx.save_for_backward(x2, mean, rstd, xn, None, qu if rel else None, qv, qkv, None, p, P, cx, pos2,
+                                  Pd if p_att > 0.0 else None)
+        else:
+            ctx.save_for_backward(x2, mean, rstd, xn, kv_in if memory is not None else None, qu, qv, k, v, p, P, cx,
+                                  pos2, Pd if p_att > 0.0 else None)
         ctx.pr = params
+        ctx.fused = fused
         ctx.cfg = (B, T1, T2, H, dk, D, rel, memory is not None, last_query_only, drop)
         return out.view(B, T1, D)
 
@@ -339,6 +411,22 @@ class MHABlockFn(torch.autograd.Function):
         dob = ops.dropout(do, p_out, s_out, out_dtype=ops.act_dtype()) if p_out > 0.0 else ops.to_act(do)
         ops.linear_bwd_w(dob, cx, sink.buf(8), db=sink.buf(9))
         dctx = ops.linear_bwd_x(dob, ops.wshadow(wo), out_dtype=adt)
+        if ctx.fused:
+            qkv = k
+            dqkv = torch.empty(B * T1, 3 * D, device=do.device, dtype=adt)
+            quv = qu if rel else _MV(qkv, 0, 3 * D)
+            dqu, dqv, _, _, dp = attn_core_bwd(dctx, P, quv, qv, _MV(qkv, D, 3 * D), _MV(qkv, 2 * D, 3 * D), p, B, T1,
+                                               T2, H, dk, Pd=Pd, attn_drop=(p_att, s_att), dqkv=dqkv)
+            if rel:
+                wpos = params[10]
+                ops.colsum(dqu, sink.buf(11).view(-1))
+                ops.colsum(dqv, sink.buf(12).view(-1))
+                ops.add_cast(dqu, dqv, out=dqkv, out_off=0, ld_out=3 * D)
+                ops.linear_bwd_w(ops.to_act(dp), pos2, sink.buf(10))
+            ops.linear_bwd_w(dqkv, xn, _span3(sink.buf(2), (3 * D, D)), db=_span3(sink.buf(3), (3 * D,)))
+            dxn = ops.linear_bwd_x(dqkv, _span3(ops.wshadow(wq), (3 * D, D)))
+            dx = ops.layernorm_bwd(dxn, x2, ln_w, mean, rstd, do, sink.buf(0), sink.buf(1))
+            return (dx.view(B, T1, D), None, None, None, None, None, None, None) + sink.results()
         dqu, dqv, dkk, dv, dp = attn_core_bwd(dctx, P, qu, qv, k, v, p, B, T1, T2, H, dk,
                                               Pd=Pd, attn_drop=(p_att, s_att))
         if rel:

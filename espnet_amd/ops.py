@@ -371,20 +371,28 @@ def glu_bwd(dy, a, Cc, out_dtype=torch.float32):
     return dx
 
 
-def add_bias2(q, u, v):
-    rows, D = q.shape
-    assert u.numel() == D and v.numel() == D
-    qu, qv = torch.empty_like(q), torch.empty_like(q)
-    check(_lib.lib().eamd_add_bias2(ptr(q), ptr(u), ptr(v), ptr(qu), ptr(qv), C.c_int64(rows), D,
+def add_bias2(q, u, v, rows=None, D=None, ldq=None, q_off=0):
+    """qu = q + u, qv = q + v (dense [rows, D] outputs); q may be a column block (q_off, ldq) of a wider matrix"""
+    if rows is None:
+        rows, D = q.shape
+    ldq = D if ldq is None else ldq
+    assert u.numel() == D and v.numel() == D and q.numel() >= q_off + (rows - 1) * ldq + D
+    qu = torch.empty(rows, D, device=q.device, dtype=q.dtype)
+    qv = torch.empty(rows, D, device=q.device, dtype=q.dtype)
+    check(_lib.lib().eamd_add_bias2(ptr(q, q_off), C.c_int64(ldq), ptr(u), ptr(v), ptr(qu), ptr(qv), C.c_int64(rows), D,
                                     1 if q.dtype == torch.bfloat16 else 0, stream_ptr()), "eamd_add_bias2")
     return qu, qv
 
 
-def add_cast(a, b):
-    """bf16(a + b) from fp32 inputs (b optional)"""
-    out = torch.empty(a.shape, device=a.device, dtype=torch.bfloat16)
-    check(_lib.lib().eamd_add_cast_bf16(ptr(a), ptr(b), ptr(out), C.c_int64(a.numel()), stream_ptr()),
-          "eamd_add_cast_bf16")
+def add_cast(a, b, out=None, out_off=0, ld_out=None):
+    """bf16(a + b) from dense fp32 [rows, cols] inputs (b optional); optionally into a column block of `out`"""
+    rows, cols = a.shape
+    if out is None:
+        out = torch.empty(a.shape, device=a.device, dtype=torch.bfloat16)
+        ld_out = cols
+    assert out.dtype == torch.bfloat16 and out.numel() >= out_off + (rows - 1) * ld_out + cols
+    check(_lib.lib().eamd_add_cast_bf16(ptr(a), ptr(b), ptr(out, out_off), C.c_int64(rows), cols, C.c_int64(ld_out),
+                                        stream_ptr()), "eamd_add_cast_bf16")
     return out
 
 

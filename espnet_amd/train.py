@@ -23,7 +23,7 @@ from . import ops
 
 class FlatParams:
     def __init__(self, model):
-        params = [p for p in model.parameters()]
+        params = self._layout_order(model)
         if not params:
             raise ValueError("model has no parameters")
         dev = params[0].device
@@ -46,6 +46,30 @@ class FlatParams:
             p._eamd_grad = self.grad[o:o + p.numel()].view(p.shape)
         self.model = model
         self.refresh_shadow()
+
+    @staticmethod
+    def _layout_order(model):
+        """registration order, except that the q / k / v projections of every attention module are placed back to
+        back (weights, then biases): MHABlockFn then runs them as ONE [3D, D] GEMM.  Only the arena layout
+        changes; parameter names / state_dict are the reference's."""
+        named = list(model.named_parameters())
+        by_name = dict(named)
+        seen, order = set(), []
+        for name, p in named:
+            if id(p) in seen:
+                continue
+            if name.endswith("linear_q.weight"):
+                base = name[: -len("linear_q.weight")]
+                grp = [base + n for n in ("linear_q.weight", "linear_k.weight", "linear_v.weight", "linear_q.bias",
+                                          "linear_k.bias", "linear_v.bias")]
+                if all(g in by_name and id(by_name[g]) not in seen for g in grp):
+                    for g in grp:
+                        order.append(by_name[g])
+                        seen.add(id(by_name[g]))
+                    continue
+            order.append(p)
+            seen.add(id(p))
+        return order
 
     def refresh_shadow(self):
         """re-cast the whole arena (after construction / external weight changes)"""

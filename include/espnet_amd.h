@@ -154,11 +154,12 @@ int eamd_glu_fwd(const float* x, float* y, int64_t rows, int C, void* stream);
 /* dx (fp32) or dx_bf16 (bf16, when non-NULL) receives the [rows, 2C] gradient */
 int eamd_glu_bwd(const float* dy, const float* x, float* dx, void* dx_bf16, int64_t rows, int C, void* stream);
 /* reference: transformer/attention.py:186-190 (q + pos_bias_u, q + pos_bias_v). */
-/* bf16 = 1: q, qu, qv are bf16 */
-int eamd_add_bias2(const void* q, const float* u, const float* v, void* qu, void* qv, int64_t rows, int D,
+/* bf16 = 1: q, qu, qv are bf16.  q has row stride ldq (a column block of the fused QKV projection); qu, qv dense */
+int eamd_add_bias2(const void* q, int64_t ldq, const float* u, const float* v, void* qu, void* qv, int64_t rows, int D,
                    int bf16, void* stream);
-/* out_bf16 = a + b (b optional), fp32 inputs */
-int eamd_add_cast_bf16(const float* a, const float* b, void* out_bf16, int64_t n, void* stream);
+/* out_bf16[r * ld_out + c] = a[r, c] + b[r, c] (b optional), dense fp32 [rows, cols] inputs */
+int eamd_add_cast_bf16(const float* a, const float* b, void* out_bf16, int64_t rows, int cols, int64_t ld_out,
+                       void* stream);
 /* out[D] += scale * column sums of x[rows, D] (bias gradients). */
 int eamd_colsum(const void* x, int64_t ld, float* out, int64_t rows, int D, float scale, int x_bf16, void* stream);
 /* reference: decoder.py:83-86,251 (Embedding + PositionalEncoding), embedding.py:80-91.

@@ -387,3 +387,44 @@ def test_training_with_dropout_learns():
         assert all(math.isfinite(v) for v in losses) and losses[-1] < 0.8 * losses[0]
         assert opt.stats()["step"] == 12 and opt.stats()["skipped"] == 0
     espnet_amd.set_precision("fp32")
+
+
+def test_fused_qkv_projection_matches_separate_linears():
+    """With the flat arenas the q/k/v Linear layers of self-attention run as one [3D, D] GEMM (bf16 mode);
+    loss and every parameter gradient must match the three-GEMM path on the same weights and batch."""
+    import espnet_amd
+    from espnet_amd import functional as F_
+    from espnet_amd import train
+    from espnet_amd.nets.e2e_asr_conformer import E2E
+    espnet_amd.set_precision("bf16")
+    try:
+        torch.manual_seed(3)
+        ns = argparse.Namespace(adim=64, aheads=4, elayers=2, eunits=128, dlayers=2, dunits=128, mtlalpha=0.3,
+                                lsm_weight=0.1, dropout_rate=0.0, transformer_length_normalized_loss=False,
+                                transformer_encoder_pos_enc_layer_type="rel_pos",
+                                transformer_encoder_selfattn_layer_type="rel_selfattn", macaron_style=True,
+                                use_cnn_module=True, cnn_module_kernel=7)
+        model = E2E(40, 30, ns).to(DEV).train()
+        flat = train.FlatParams(model)
+        g = torch.Generator().manual_seed(2)
+        xs, ilens = torch.randn(3, 90, 40, generator=g), [90, 71, 64]
+        ys = torch.randint(1, 29, (3, 7), generator=g)
+        ys[2, 4:] = -1
+        batch = model.prepare(xs, ilens, ys)
+        out = {}
+        for fuse in (False, True):
+            F_.FUSE_QKV = fuse
+            flat.zero_grad()
+            loss = model.forward_core(batch)
+            loss.backward()
+            out[fuse] = (float(loss), flat.grad.clone())
+        q = dict(model.named_parameters())["encoder.encoders.0.self_attn.linear_q.weight"]
+        k = dict(model.named_parameters())["encoder.encoders.0.self_attn.linear_k.weight"]
+        assert k.data_ptr() == q.data_ptr() + q.numel() * 4          # the arena layout that enables the fusion
+        rel = abs(out[True][0] - out[False][0]) / abs(out[False][0])
+        print(f"[parity] fused-qkv loss {out[True][0]:.5f} vs {out[False][0]:.5f} rel {rel:.2e}")
+        assert rel < 1e-4
+        report("fused-qkv gradient arena", out[True][1], out[False][1], 5e-3)
+    finally:
+        F_.FUSE_QKV = True
+        espnet_amd.set_precision("fp32")
