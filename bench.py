@@ -10,6 +10,7 @@ measured live with stream events) and `cpu_baseline` (the CPU oracle timed on th
 a bounded sample).
 """
 import argparse
+import ctypes
 import json
 import os
 import sys
@@ -150,56 +151,67 @@ def main():
     st = opt.stats()
 
     # ---- roofline of the dominant kernel family (MFMA GEMM), measured live with stream events ----
+    # Every eamd_gemm descriptor of one training step is recorded (operands kept alive), then the whole family is
+    # replayed back to back as ONE hipGraph on the current stream and bracketed by a single pair of stream
+    # events: device time of the kernels themselves, no host gaps, no per-launch event overhead - the quantity
+    # the rocprofv3 kernel trace of the same command reports as the family's total duration.
     roof = None
     if rank == 0:
-        ev = []
-        orig = ops.gemm
-
-        def timed_gemm(*args, **kw):
-            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            e0.record()
-            orig(*args, **kw)
-            e1.record()
-            ev.append((e0, e1))
-
-        # stream-event bracket overhead (record + timestamp granularity), measured on empty brackets and
-        # subtracted from every GEMM bracket so that the average agrees with the rocprofv3 kernel trace
-        cal = []
-        for _ in range(200):
-            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            e0.record()
-            e1.record()
-            cal.append((e0, e1))
-        torch.cuda.synchronize()
-        empty = sorted(e0.elapsed_time(e1) for e0, e1 in cal)[len(cal) // 2]
-        ops.gemm = timed_gemm
-        rd, train_red = reducer, None
+        from espnet_amd import _lib as L_
+        rec = []
+        rd = reducer
         try:
             if reducer is not None:
                 train.attach_reducer(None)
+            ops._gemm_record = rec
             train.train_step(model, flat, opt, batch, None)
             torch.cuda.synchronize()
         finally:
-            ops.gemm = orig
+            ops._gemm_record = None
             if rd is not None:
                 train.attach_reducer(rd)
-        gemm_ms = sum(max(0.0, e0.elapsed_time(e1) - empty) for e0, e1 in ev)
-        n = len(ev)
+        n = len(rec)
+        lib = L_.lib()
+
+        def replay_all():
+            sp = ops.stream_ptr()
+            for p, _keep in rec:
+                L_.check(lib.eamd_gemm(ctypes.byref(p), sp), "eamd_gemm")
+
+        gg = torch.cuda.CUDAGraph()
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            replay_all()
+            torch.cuda.synchronize()
+            with torch.cuda.graph(gg, stream=side):
+                replay_all()
+        torch.cuda.synchronize()
+        gg.replay()
+        torch.cuda.synchronize()
+        reps = 5
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(reps):
+            gg.replay()
+        e1.record()
+        torch.cuda.synchronize()
+        gemm_ms = e0.elapsed_time(e1) / reps
         flop_per_launch = STEP_FLOP * (B / 32.0) * (T / 1000.0) / n
         avg_ms = gemm_ms / n
         ach = flop_per_launch / (avg_ms * 1e-3) / 1e12
         traffic = None
         try:   # HBM bytes per GEMM launch from the last committed PMC passes (profiles/, FETCH_SIZE x2 + WRITE_SIZE)
-            with open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")) as fh:
+            with open(os.path.join(ROOT, "profiles", "r01_h_pmc_traffic.json")) as fh:
                 traffic = round(json.load(fh)["gemm_family"]["hbm_bytes_per_launch"])
         except Exception:  # noqa: BLE001
             traffic = None
         roof = dict(bound="mfma", achieved=round(ach, 2), peak=PEAK_TFLOPS[a.precision], unit="TFLOP/s",
                     frac=round(ach / PEAK_TFLOPS[a.precision], 4), traffic=traffic,
-                    traffic_note="HBM bytes per launch, rocprofv3 PMC (FETCH_SIZE doubled + WRITE_SIZE), profiles/r01_pmc*",
+                    traffic_note="HBM bytes per launch, rocprofv3 PMC (FETCH_SIZE doubled + WRITE_SIZE), profiles/r01_h_pmc*",
                     kernel="gemm_kernel<*> (all MFMA contractions)", launches_per_step=n,
                     avg_launch_us=round(avg_ms * 1e3, 2), gemm_ms_per_step=round(gemm_ms, 3),
-                    event_overhead_us=round(empty * 1e3, 2))
+                    timing="all eamd_gemm launches of one step replayed as one hipGraph between two stream events")
 
     cpu = None
     if rank == 0 and world == 1 and not a.no_cpu_baseline:

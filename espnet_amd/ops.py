@@ -72,6 +72,12 @@ def _span(rows, ld, cols):
     return (rows - 1) * ld + cols if rows > 0 else 0
 
 
+_gemm_record = None   # bench.py: list collecting (descriptor, operand references) of every launch of one step
+
+
+_gemm_record = None   # bench.py: list collecting (descriptor, operand references) of every launch of one step
+
+
 def gemm(A, B, Cm, M, N, K, lda, ldb, ldc, *, transA=0, transB=0, bias=None, aux=None, ldaux=0, R=None,
          ldr=0, batch=(1, 1), sA=(0, 0), sB=(0, 0), sC=(0, 0), alpha=1.0, beta=0.0, a_act=0, b_act=0,
          epilogue=0, splitk=1, tile=0, gather=None, cmap=None, a_off=0, b_off=0, c_off=0, precision=None,
@@ -145,6 +151,8 @@ def gemm(A, B, Cm, M, N, K, lda, ldb, ldc, *, transA=0, transB=0, bias=None, aux
             if Hb.dtype != torch.bfloat16 or Hb.numel() < M * N:
                 raise _lib.EamdError("gemm: Hb must be a bf16 [M, N] buffer")
             p.Hb, p.h_act = ptr(Hb), h_act
+    if _gemm_record is not None:
+        _gemm_record.append((p, (A, B, Cm, bias, aux, R, colsum, Cb, Hb)))
     check(_lib.lib().eamd_gemm(C.byref(p), stream_ptr()), "eamd_gemm")
 
 
