@@ -43,6 +43,21 @@ __device__ __forceinline__ float eamd_dact(float x, int act) {
   return 1.f;
 }
 
+// Counter-based dropout bits shared by eamd_dropout and the fused GEMM epilogues: a per-launch 32-bit seed from
+// (device step counter, site salt) and a 32-bit avalanche (lowbias32) of the element index.  The 64-bit
+// mix runs once per thread, the per-element cost is ~10 VALU instructions (a 64-bit splitmix per element made the
+// FFN up-projection epilogue ALU-bound).
+__device__ __forceinline__ unsigned eamd_drop_seed(const unsigned long long* step, unsigned long long salt) {
+  unsigned long long x = (step ? step[0] : 0ULL) * 0x9E3779B97F4A7C15ULL + salt * 0xD1B54A32D192ED03ULL;
+  x ^= x >> 33; x *= 0xff51afd7ed558ccdULL; x ^= x >> 33; x *= 0xc4ceb9fe1a85ec53ULL; x ^= x >> 33;
+  return (unsigned)x ^ (unsigned)(x >> 32);
+}
+__device__ __forceinline__ unsigned eamd_drop_bits(unsigned seed, unsigned long long idx) {
+  unsigned h = ((unsigned)idx ^ seed) + (unsigned)(idx >> 32) * 0x9E3779B1u;
+  h ^= h >> 16; h *= 0x7feb352du; h ^= h >> 15; h *= 0x846ca68bu; h ^= h >> 16;
+  return h;
+}
+
 // fp32 -> bf16 round-to-nearest-even (plain cast keeps NaN a NaN on gfx950).
 __device__ __forceinline__ unsigned short eamd_f2bf(float f) {
   __bf16 b = (__bf16)f;

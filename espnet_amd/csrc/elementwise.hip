@@ -225,23 +225,19 @@ __global__ void permute4_kernel(const float* __restrict__ src, float* __restrict
 // same kernel on the gradient.  Optional fused activation (FFN inner dropout: drop(act(z))).
 // reference: torch.nn.Dropout call sites (conformer/encoder_layer.py:55, positionwise_feed_forward.py:27,
 // embedding.py:56, ctc.py:85); RNG streams cannot match torch's generator - parity runs use p = 0.
-__device__ __forceinline__ unsigned hash32(unsigned long long x) {
-  x ^= x >> 33; x *= 0xff51afd7ed558ccdULL; x ^= x >> 33; x *= 0xc4ceb9fe1a85ec53ULL; x ^= x >> 33;
-  return (unsigned)x;
-}
 __global__ void dropout_kernel(const float* __restrict__ x, float* __restrict__ y, long n, float p,
                                const unsigned long long* __restrict__ step, unsigned long long salt, int act,
                                int in_bf16, int out_bf16) {
   const float inv = 1.f / (1.f - p);
   const unsigned thr = (unsigned)fminf(p * 4294967296.0f, 4294967040.0f);
-  const unsigned long long base = (step ? step[0] : 0ULL) * 0x9E3779B97F4A7C15ULL + salt * 0xD1B54A32D192ED03ULL;
+  const unsigned seed = eamd_drop_seed(step, salt);
   const long stride = (long)gridDim.x * blockDim.x;
   const unsigned short* x16 = reinterpret_cast<const unsigned short*>(x);
   unsigned short* y16 = reinterpret_cast<unsigned short*>(y);
   for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
     float v = in_bf16 ? __uint_as_float(((unsigned)x16[i]) << 16) : x[i];
     v = eamd_act(v, act);
-    const unsigned h = hash32(base + (unsigned long long)i);
+    const unsigned h = eamd_drop_bits(seed, (unsigned long long)i);
     v = h >= thr ? v * inv : 0.f;
     if (out_bf16) y16[i] = eamd_f2bf(v); else y[i] = v;
   }

@@ -616,3 +616,42 @@ def test_dwconv_kernel_sizes(ops, shape):
     ops.dwconv_bwd_w(dy.to(DEV), x.to(DEV), dw, db, B, T, Cc, K)
     report("dwconv_bwd_w %s" % (shape,), dw, wd_.grad.view(Cc, K), 1e-5)
     report("dwconv_bwd_b %s" % (shape,), db, bd_.grad, 1e-5)
+
+
+@pytest.mark.parametrize("shape", [(4100, 1500, 256), (3000, 2200, 512), (7968, 2048, 256)])
+def test_gemm_persistent_tiles(ops, shape):
+    """launches with >= 1536 tiles and K % 256 == 0 take the persistent kernel (gemm_persist.hip): all four
+    operand layouts and the fused epilogues against a float64 product of the same bf16 operands"""
+    import espnet_amd
+    espnet_amd.set_precision("bf16")
+    try:
+        M, N, K = shape
+        g = torch.Generator().manual_seed(M + N)
+        bf = lambda *s: (torch.randn(*s, generator=g) * 0.5).to(torch.bfloat16)
+        A, At, B, Bt = bf(M, K), bf(K, M), bf(N, K), bf(K, N)
+        bias, R = torch.randn(N, generator=g), torch.randn(M, N, generator=g)
+        for ta, tb in ((0, 0), (0, 1), (1, 0), (1, 1)):
+            a, b = (At if ta else A), (Bt if tb else B)
+            want = (a.double().t() if ta else a.double()) @ (b.double() if tb else b.double().t())
+            C = torch.empty(M, N, device=DEV)
+            ops.gemm(a.to(DEV), b.to(DEV), C, M, N, K, M if ta else K, N if tb else K, N, transA=ta, transB=tb,
+                     bias=bias.to(DEV), R=R.to(DEV), ldr=N, alpha=0.5)
+            report("persistent gemm ta%d tb%d %s" % (ta, tb, shape), C, 0.5 * (want + bias.double()) + R.double(), 2e-6)
+        # bf16 output + Swish-derivative mask of a bf16 aux operand + fused dropout (the FFN backward epilogue)
+        aux = bf(M, N)
+        Cb = torch.empty(M, N, device=DEV, dtype=torch.bfloat16)
+        ops.gemm(A.to(DEV), Bt.to(DEV), Cb, M, N, K, K, N, N, transB=1, epilogue=4, aux=aux.to(DEV), ldaux=N,
+                 drop=(0.2, 9))
+        plain = torch.empty(M, N, device=DEV)
+        ops.gemm(A.to(DEV), Bt.to(DEV), plain, M, N, K, K, N, N, transB=1, epilogue=4, aux=aux.to(DEV), ldaux=N)
+        want = ops.dropout(plain, 0.2, 9)
+        report("persistent gemm dswish+dropout bf16 out", Cb.float(), want, 4e-3)
+        # dual output
+        z = torch.empty(M, N, device=DEV, dtype=torch.bfloat16)
+        h = torch.empty(M, N, device=DEV, dtype=torch.bfloat16)
+        ops.linear_fwd(A.to(DEV), B.to(DEV), bias.to(DEV), out=z, drop=(0.1, 3), Hb=h, h_act=ops.ACT_SWISH)
+        ref = ops.linear_fwd(A.to(DEV), B.to(DEV), bias.to(DEV))
+        report("persistent gemm dual z", z.float(), ref, 4e-3)
+        report("persistent gemm dual h", h.float(), ops.dropout(ref, 0.1, 3, act=ops.ACT_SWISH), 4e-3)
+    finally:
+        espnet_amd.set_precision("fp32")
