@@ -217,6 +217,62 @@ def train_step(model, flat, opt, batch, reducer=None, loss_scale=1.0):
     return loss
 
 
+class GraphedDataParallelStep:
+    """hipGraph replay of a data-parallel training step without capturing any collective:
+      graph A = zero the gradient arena, advance the dropout counter, forward, backward (loss pre-scaled by
+                1/world, as the reference's DDP averaging);
+      eager   = RCCL all-reduce (SUM) of the flat gradient arena, bucket by bucket, asynchronously on the
+                communicator's stream (torch.distributed orders it after graph A and before graph B);
+      graph B = gradient norm, clipping, Noam schedule, Adam, bf16 shadow refresh.
+    Compared with the eager step + backward-overlapped buckets (train_step with a GradReducer) this gives up the
+    overlap (about 1 ms of all-reduce for 187 MB over xGMI) and wins back the launch overhead of ~1500 kernels.
+    reference: espnet2/train/trainer.py:381-467 (forward, backward, clip, step under DistributedDataParallel)."""
+
+    def __init__(self, model, flat, opt, batch, world=1, group=None, bucket_mb=48.0, warmup=2):
+        import torch.distributed as dist
+        self.dist, self.group, self.world = dist, group, world
+        self.model, self.flat, self.opt, self.batch = model, flat, opt, batch
+        cap = max(1, int(bucket_mb * 1024 * 1024 // 4))
+        self.buckets = [(s, min(flat.numel, s + cap)) for s in range(0, flat.numel, cap)]
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            for _ in range(max(1, warmup)):
+                self._fwd_bwd()
+                self._reduce()
+                opt.step()
+        torch.cuda.current_stream().wait_stream(side)
+        torch.cuda.synchronize()
+        self.graph_a = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(self.graph_a):
+            self.loss = self._fwd_bwd()
+        self.graph_b = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(self.graph_b):
+            opt.step()
+
+    def _fwd_bwd(self):
+        self.flat.zero_grad()
+        ops.rng_advance(self.flat.data.device)
+        loss = self.model.forward_core(self.batch)
+        scale = 1.0 / self.world
+        loss.backward(torch.full((), scale, device=loss.device, dtype=loss.dtype) if scale != 1.0 else None)
+        ops.wgrad_join()
+        return loss
+
+    def _reduce(self):
+        if self.dist.is_initialized():
+            works = [self.dist.all_reduce(self.flat.grad[s:e], op=self.dist.ReduceOp.SUM, group=self.group, async_op=True)
+                     for s, e in self.buckets]
+            for w in works:
+                w.wait()      # stream-level wait: the current stream continues after the collective, no host block
+
+    def __call__(self):
+        self.graph_a.replay()
+        self._reduce()
+        self.graph_b.replay()
+        return self.loss
+
+
 def init_distributed():
     """reference: espnet2/train/distributed_utils.py:28-107 (env:// rendezvous, one process per GPU)."""
     import torch.distributed as dist

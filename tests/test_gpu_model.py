@@ -428,3 +428,49 @@ def test_fused_qkv_projection_matches_separate_linears():
     finally:
         F_.FUSE_QKV = True
         espnet_amd.set_precision("fp32")
+
+
+def test_graphed_data_parallel_step_matches_eager_step():
+    """The N>1 bench path (hipGraph fwd+bwd | all-reduce of the arena | hipGraph optimizer) on a one-rank RCCL group
+    produces the same parameters as the plain eager training step."""
+    import torch.distributed as dist
+    import espnet_amd
+    from espnet_amd import ops, train
+    from espnet_amd.nets.e2e_asr_conformer import E2E
+    espnet_amd.set_precision("bf16")
+    created = False
+    try:
+        if not dist.is_initialized():
+            dist.init_process_group("nccl", init_method="tcp://127.0.0.1:29633", rank=0, world_size=1)
+            created = True
+        ns = argparse.Namespace(adim=64, aheads=4, elayers=2, eunits=128, dlayers=1, dunits=128, mtlalpha=0.3,
+                                lsm_weight=0.1, dropout_rate=0.0, transformer_length_normalized_loss=False,
+                                transformer_encoder_pos_enc_layer_type="rel_pos",
+                                transformer_encoder_selfattn_layer_type="rel_selfattn", macaron_style=True,
+                                use_cnn_module=True, cnn_module_kernel=7)
+        g = torch.Generator().manual_seed(4)
+        xs, ilens = torch.randn(3, 70, 40, generator=g), [70, 61, 50]
+        ys = torch.randint(1, 29, (3, 6), generator=g)
+        results = []
+        for mode in ("eager", "graph"):
+            torch.manual_seed(11)
+            model = E2E(40, 30, ns).to(DEV).train()
+            model.sync_report = False
+            flat = train.FlatParams(model)
+            opt = train.NoamAdam(flat, mode="const", base_lr=1e-3, max_grad_norm=5.0)
+            batch = model.prepare(xs, ilens, ys)
+            if mode == "eager":
+                for _ in range(4):
+                    train.train_step(model, flat, opt, batch)
+            else:
+                step = train.GraphedDataParallelStep(model, flat, opt, batch, world=1, warmup=1)   # 1 warm-up step
+                for _ in range(3):
+                    step()
+            torch.cuda.synchronize()
+            results.append((flat.data.clone(), opt.stats()["step"]))
+        assert results[0][1] == results[1][1] == 4
+        report("graphed DP step parameters after 4 steps", results[1][0], results[0][0], 2e-3)
+    finally:
+        if created:
+            dist.destroy_process_group()
+        espnet_amd.set_precision("fp32")
