@@ -327,10 +327,11 @@ int eamd_attloc_fwd(const float* att_prev, const float* conv_w, const float* w_a
                     const float* dec_proj, const float* gvec, const float* gb, const int32_t* lens, const float* enc_h,
                     float scaling, float* e, float* th, float* conv, float* w, float* ctx, int B, int T, int A, int C,
                     int K, int E, void* stream) {
-  if (!att_prev || !conv_w || !w_att || !pre_enc || !dec_proj || !gvec || !gb || !lens || !enc_h || !e || !th ||
-      !conv || !w || !ctx || B <= 0 || T <= 0 || A <= 0 || C <= 0 || K <= 0 || E <= 0)
+  if (!pre_enc || !dec_proj || !gvec || !gb || !lens || !enc_h || !e || !th || !w || !ctx || B <= 0 || T <= 0 ||
+      A <= 0 || C < 0 || E <= 0)
     return EAMD_EINVAL;
-  if (C > 64 || (K & 1) == 0 || (size_t)T * sizeof(float) > 60 * 1024) return EAMD_EUNSUPPORTED;
+  if (C > 0 && (!att_prev || !conv_w || !w_att || !conv || K <= 0)) return EAMD_EINVAL;   // C = 0: additive attention
+  if (C > 64 || (C > 0 && (K & 1) == 0) || (size_t)T * sizeof(float) > 60 * 1024) return EAMD_EUNSUPPORTED;
   hipStream_t s = (hipStream_t)stream;
   hipLaunchKernelGGL(attloc_energy_fwd_kernel, dim3(B * T), dim3(128), 0, s, att_prev, conv_w, w_att, pre_enc, dec_proj,
                      gvec, gb, lens, e, th, conv, T, A, C, K);

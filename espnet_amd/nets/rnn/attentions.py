@@ -1,6 +1,8 @@
 """Decoder-side attention of the RNN path.  reference: espnet/nets/pytorch_backend/rnn/attentions.py.
 AttLoc (location-aware attention, :250-380) runs on the espnet_amd HIP kernels; the other attention
 types listed by `initial_att` (:1722-1771) have no kernel yet and raise NotImplementedError."""
+import math
+
 import numpy as np
 import torch
 
@@ -57,11 +59,159 @@ class AttLoc(torch.nn.Module):
         return c, w
 
 
+class AttAdd(torch.nn.Module):
+    """additive attention.  reference: rnn/attentions.py:167-247 (e = gvec . tanh(mlp_enc(h) + mlp_dec(z)),
+    softmax(2.0 * e)): the location-aware kernels with the location term switched off."""
+
+    def __init__(self, eprojs, dunits, att_dim, han_mode=False):
+        super().__init__()
+        self.mlp_enc = torch.nn.Linear(eprojs, att_dim)
+        self.mlp_dec = torch.nn.Linear(dunits, att_dim, bias=False)
+        self.gvec = torch.nn.Linear(att_dim, 1)
+        self.dunits, self.eprojs, self.att_dim, self.han_mode = dunits, eprojs, att_dim, han_mode
+        self.reset()
+
+    def reset(self):
+        self.h_length = None
+        self.enc_h = None
+        self.pre_compute_enc_h = None
+        self.mask = None
+        self._lens = None
+
+    def forward(self, enc_hs_pad, enc_hs_len, dec_z, att_prev, scaling=2.0):
+        batch = enc_hs_pad.shape[0]
+        if self.pre_compute_enc_h is None or self.han_mode:
+            self.enc_h = enc_hs_pad.contiguous()
+            self.h_length = self.enc_h.size(1)
+            self.pre_compute_enc_h = F_.LinearFn.apply(self.enc_h, self.mlp_enc.weight, self.mlp_enc.bias)
+            self._lens = torch.tensor([int(v) for v in enc_hs_len], dtype=torch.int32).to(enc_hs_pad.device,
+                                                                                          non_blocking=True)
+        dec_z = enc_hs_pad.new_zeros(batch, self.dunits) if dec_z is None else dec_z.view(batch, self.dunits)
+        dec_proj = F_.LinearFn.apply(dec_z, self.mlp_dec.weight, None)
+        return R_.AttLocStepFn.apply(self.enc_h, self.pre_compute_enc_h, dec_proj, None, self._lens, float(scaling),
+                                     None, None, self.gvec.weight, self.gvec.bias)
+
+
+class _MultiHeadBase(torch.nn.Module):
+    """shared part of the multi-head attentions (rnn/attentions.py:845-1385): per head k = mlp_k(h) (no bias),
+    v = mlp_v(h) (no bias), q = mlp_q(z) (bias); the H context vectors are concatenated and mixed by mlp_o."""
+
+    def __init__(self, eprojs, dunits, aheads, att_dim_k, att_dim_v, han_mode=False):
+        super().__init__()
+        self.mlp_q = torch.nn.ModuleList([torch.nn.Linear(dunits, att_dim_k) for _ in range(aheads)])
+        self.mlp_k = torch.nn.ModuleList([torch.nn.Linear(eprojs, att_dim_k, bias=False) for _ in range(aheads)])
+        self.mlp_v = torch.nn.ModuleList([torch.nn.Linear(eprojs, att_dim_v, bias=False) for _ in range(aheads)])
+        self.gvec = torch.nn.ModuleList([torch.nn.Linear(att_dim_k, 1) for _ in range(aheads)])
+        self.mlp_o = torch.nn.Linear(aheads * att_dim_v, eprojs, bias=False)
+        self.dunits, self.eprojs, self.aheads = dunits, eprojs, aheads
+        self.att_dim_k, self.att_dim_v = att_dim_k, att_dim_v
+        self.scaling = 1.0 / math.sqrt(att_dim_k)
+        self.han_mode = han_mode
+        self.reset()
+
+    def reset(self):
+        self.h_length = None
+        self.enc_h = None
+        self.pre_compute_k = None
+        self.pre_compute_v = None
+        self.mask = None
+        self._lens = None
+
+    def _precompute(self, enc_hs_pad, enc_hs_len):
+        if self.pre_compute_k is None or self.han_mode:
+            self.enc_h = enc_hs_pad.contiguous()
+            self.h_length = self.enc_h.size(1)
+            self.pre_compute_k = [F_.LinearFn.apply(self.enc_h, self.mlp_k[h].weight, None) for h in range(self.aheads)]
+            self.pre_compute_v = [F_.LinearFn.apply(self.enc_h, self.mlp_v[h].weight, None) for h in range(self.aheads)]
+            lens = np.asarray([int(v) for v in enc_hs_len], dtype=np.int32)
+            self._lens_host = lens
+            self._lens = torch.from_numpy(lens).to(enc_hs_pad.device, non_blocking=True)
+
+    def _uniform(self, dev):
+        keep = (np.arange(self.h_length)[None, :] < self._lens_host[:, None]).astype(np.float32)
+        return torch.from_numpy(keep / self._lens_host[:, None].astype(np.float32)).to(dev, non_blocking=True)
+
+    def _head(self, h, dec_z, att_prev_h, scaling):
+        raise NotImplementedError
+
+    def _forward(self, enc_hs_pad, enc_hs_len, dec_z, att_prev, scaling, needs_prev):
+        batch = enc_hs_pad.shape[0]
+        self._precompute(enc_hs_pad, enc_hs_len)
+        dec_z = enc_hs_pad.new_zeros(batch, self.dunits) if dec_z is None else dec_z.view(batch, self.dunits)
+        if needs_prev and att_prev is None:
+            u = self._uniform(enc_hs_pad.device)
+            att_prev = [u for _ in range(self.aheads)]
+        c, w = [], []
+        for h in range(self.aheads):
+            q = F_.LinearFn.apply(dec_z, self.mlp_q[h].weight, self.mlp_q[h].bias)
+            ch, wh = self._head(h, q, att_prev[h] if needs_prev else None, scaling)
+            c.append(ch)
+            w.append(wh)
+        c = F_.LinearFn.apply(torch.cat(c, dim=1), self.mlp_o.weight, None)
+        return c, w
+
+
+class AttMultiHeadAdd(_MultiHeadBase):
+    """reference: rnn/attentions.py:993-1107 (per head: gvec . tanh(k + q), softmax(e / sqrt(d_k)))"""
+
+    def _head(self, h, q, att_prev_h, scaling):
+        return R_.AttLocStepFn.apply(self.pre_compute_v[h], self.pre_compute_k[h], q, None, self._lens, scaling, None,
+                                     None, self.gvec[h].weight, self.gvec[h].bias)
+
+    def forward(self, enc_hs_pad, enc_hs_len, dec_z, att_prev):
+        return self._forward(enc_hs_pad, enc_hs_len, dec_z, att_prev, self.scaling, False)
+
+
+class AttMultiHeadLoc(_MultiHeadBase):
+    """reference: rnn/attentions.py:1110-1258 (per head location-aware energies, softmax(scaling * e), scaling 2.0)"""
+
+    def __init__(self, eprojs, dunits, aheads, att_dim_k, att_dim_v, aconv_chans, aconv_filts, han_mode=False):
+        super().__init__(eprojs, dunits, aheads, att_dim_k, att_dim_v, han_mode)
+        self.loc_conv = torch.nn.ModuleList([
+            torch.nn.Conv2d(1, aconv_chans, (1, 2 * aconv_filts + 1), padding=(0, aconv_filts), bias=False)
+            for _ in range(aheads)])
+        self.mlp_att = torch.nn.ModuleList([torch.nn.Linear(aconv_chans, att_dim_k, bias=False) for _ in range(aheads)])
+
+    def _head(self, h, q, att_prev_h, scaling):
+        return R_.AttLocStepFn.apply(self.pre_compute_v[h], self.pre_compute_k[h], q, att_prev_h, self._lens, scaling,
+                                     self.loc_conv[h].weight, self.mlp_att[h].weight, self.gvec[h].weight,
+                                     self.gvec[h].bias)
+
+    def forward(self, enc_hs_pad, enc_hs_len, dec_z, att_prev, scaling=2.0):
+        return self._forward(enc_hs_pad, enc_hs_len, dec_z, att_prev, float(scaling), True)
+
+
+class AttMultiHeadMultiResLoc(AttMultiHeadLoc):
+    """reference: rnn/attentions.py:1261-1385: head h uses filter half-width aconv_filts * (h + 1) // aheads,
+    softmax(e / sqrt(d_k))"""
+
+    def __init__(self, eprojs, dunits, aheads, att_dim_k, att_dim_v, aconv_chans, aconv_filts, han_mode=False):
+        _MultiHeadBase.__init__(self, eprojs, dunits, aheads, att_dim_k, att_dim_v, han_mode)
+        self.loc_conv = torch.nn.ModuleList()
+        self.mlp_att = torch.nn.ModuleList()
+        for h in range(aheads):
+            afilts = aconv_filts * (h + 1) // aheads
+            self.loc_conv += [torch.nn.Conv2d(1, aconv_chans, (1, 2 * afilts + 1), padding=(0, afilts), bias=False)]
+            self.mlp_att += [torch.nn.Linear(aconv_chans, att_dim_k, bias=False)]
+
+    def forward(self, enc_hs_pad, enc_hs_len, dec_z, att_prev):
+        return self._forward(enc_hs_pad, enc_hs_len, dec_z, att_prev, self.scaling, True)
+
+
 def initial_att(atype, eprojs, dunits, aheads, adim, awin, aconv_chans, aconv_filts, han_mode=False):
     """reference: rnn/attentions.py:1722-1771"""
     if atype == "location":
         return AttLoc(eprojs, dunits, adim, aconv_chans, aconv_filts, han_mode)
-    raise NotImplementedError("atype %r: only 'location' has HIP kernels (SURVEY.md 8f lists the rest as next)" % atype)
+    if atype == "add":
+        return AttAdd(eprojs, dunits, adim, han_mode)
+    if atype == "multi_head_add":
+        return AttMultiHeadAdd(eprojs, dunits, aheads, adim, adim, han_mode)
+    if atype == "multi_head_loc":
+        return AttMultiHeadLoc(eprojs, dunits, aheads, adim, adim, aconv_chans, aconv_filts, han_mode)
+    if atype == "multi_head_multi_res_loc":
+        return AttMultiHeadMultiResLoc(eprojs, dunits, aheads, adim, adim, aconv_chans, aconv_filts, han_mode)
+    raise NotImplementedError("atype %r has no HIP kernels yet (on the HIP path: location, add, multi_head_add, "
+                              "multi_head_loc, multi_head_multi_res_loc)" % atype)
 
 
 def att_for(args, num_att=1, han_mode=False):

@@ -749,14 +749,14 @@ def rnnt_loss(logits, labels, tlens, ulens, blank, grad=None, gscale=None, scale
 
 def attloc_fwd(att_prev, conv_w, w_att, pre_enc, dec_proj, gvec, gb, lens, enc_h, scaling):
     B, T, A = pre_enc.shape
-    Cc, K = conv_w.shape[0], conv_w.shape[-1]
+    Cc, K = (conv_w.shape[0], conv_w.shape[-1]) if conv_w is not None else (0, 0)   # no conv: additive attention
     E = enc_h.shape[2]
     dev = enc_h.device
-    assert att_prev.shape == (B, T) and dec_proj.shape == (B, A) and w_att.shape == (A, Cc) and gvec.numel() == A
-    assert lens.dtype == torch.int32 and lens.numel() == B and conv_w.numel() == Cc * K
+    assert dec_proj.shape == (B, A) and gvec.numel() == A and lens.dtype == torch.int32 and lens.numel() == B
+    assert conv_w is None or (att_prev.shape == (B, T) and w_att.shape == (A, Cc) and conv_w.numel() == Cc * K)
     e = torch.empty(B, T, device=dev, dtype=torch.float32)
     th = torch.empty(B, T, A, device=dev, dtype=torch.float32)
-    conv = torch.empty(B, T, Cc, device=dev, dtype=torch.float32)
+    conv = torch.empty(B, T, Cc, device=dev, dtype=torch.float32) if Cc else None
     w = torch.empty(B, T, device=dev, dtype=torch.float32)
     ctx = torch.empty(B, E, device=dev, dtype=torch.float32)
     check(_lib.lib().eamd_attloc_fwd(ptr(att_prev), ptr(conv_w), ptr(w_att), ptr(pre_enc), ptr(dec_proj), ptr(gvec),

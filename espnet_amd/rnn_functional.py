@@ -240,20 +240,27 @@ class VGG2LFn(torch.autograd.Function):
 class AttLocStepFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, enc_h, pre_enc, dec_proj, att_prev, lens, scaling, conv_w, w_att, gvec_w, gvec_b):
-        enc_h, pre_enc, dec_proj, att_prev = (t.contiguous() for t in (enc_h, pre_enc, dec_proj, att_prev))
+        enc_h, pre_enc, dec_proj = (t.contiguous() for t in (enc_h, pre_enc, dec_proj))
+        att_prev = att_prev.contiguous() if conv_w is not None else None       # conv_w None: additive attention
         c, w, th, conv = ops.attloc_fwd(att_prev, conv_w, w_att, pre_enc, dec_proj, gvec_w, gvec_b, lens, enc_h,
                                         scaling)
         ctx.save_for_backward(enc_h, att_prev, w, th, conv)
-        ctx.pr = (conv_w, w_att, gvec_w, gvec_b)
+        ctx.pr = (conv_w, w_att, gvec_w, gvec_b) if conv_w is not None else (gvec_w, gvec_b)
+        ctx.has_conv = conv_w is not None
         ctx.scaling = scaling
         return c, w
 
     @staticmethod
     def backward(ctx, dc, dw):
         enc_h, att_prev, w, th, conv = ctx.saved_tensors
-        conv_w, w_att, gvec_w, gvec_b = ctx.pr
         sink = GradSink(ctx.pr)
         B, T, A = th.shape
+        if not ctx.has_conv:
+            gvec_w, gvec_b = ctx.pr
+            d_enc_h, df, d_dec = ops.attloc_bwd_energy(dc.contiguous(), dw.contiguous() if dw is not None else None,
+                                                       w, enc_h, th, gvec_w, ctx.scaling, sink.buf(0), sink.buf(1))
+            return (d_enc_h, df, d_dec, None, None, None, None, None) + sink.results()
+        conv_w, w_att, gvec_w, gvec_b = ctx.pr
         Cc = conv.shape[2]
         d_enc_h, df, d_dec = ops.attloc_bwd_energy(dc.contiguous(), dw.contiguous() if dw is not None else None, w,
                                                    enc_h, th, gvec_w, ctx.scaling, sink.buf(2), sink.buf(3))

@@ -262,7 +262,9 @@ int eamd_conv3x3_c1_bwd_w(const void* dy, const float* x, float* dw, float* db, 
  *   conv = Conv2d(1,C,(1,K))(att_prev) (K = 2*aconv_filts+1, no bias); e = gvec . tanh(W_att conv + pre_enc +
  *   dec_proj) + gb, -inf for t >= lens[b]; w = softmax(scaling * e); ctx = sum_t w * enc_h.
  * pre_enc = mlp_enc(enc_h) [B,T,A] and dec_proj = mlp_dec(dec_z) [B,A] are eamd_gemm products.
- * th [B,T,A] (tanh output) and conv [B,T,C] are kept for the backward. */
+ * th [B,T,A] (tanh output) and conv [B,T,C] are kept for the backward.
+ * C = 0 (att_prev, conv_w, w_att, conv NULL): no location term = additive attention (AttAdd, attentions.py:167-247,
+ * and the per-head energies of AttMultiHeadAdd :993-1107). */
 int eamd_attloc_fwd(const float* att_prev, const float* conv_w, const float* w_att, const float* pre_enc,
                     const float* dec_proj, const float* gvec, const float* gb, const int32_t* lens, const float* enc_h,
                     float scaling, float* e, float* th, float* conv, float* w, float* ctx, int B, int T, int A, int C,

@@ -410,6 +410,27 @@ def main():
          loss=float(loss), loss_att=float(m.loss_att), loss_ctc=float(m.loss_ctc), acc=float(m.acc), **sd0,
          **grads_np(m))
 
+    # a20: the other attention types on the HIP path, on a small BLSTMP (subsampling 1_2) model each
+    for atype in ("add", "multi_head_add", "multi_head_loc", "multi_head_multi_res_loc"):
+        torch.manual_seed(32)
+        m = RnnE2E(9, 7, rnn_args(etype="blstmp", elayers=2, subsample="1_2_1", eunits=8, eprojs=8, dlayers=1, dunits=10,
+                                  atype=atype, adim=6, aheads=2, aconv_chans=3, aconv_filts=4))
+        m.train()
+        sd0 = sd_np(m, "sd/")
+        g = torch.Generator().manual_seed(5)
+        xs = torch.randn(3, 26, 9, generator=g)
+        ilens = torch.tensor([26, 21, 14])
+        ys = torch.randint(1, 6, (3, 5), generator=g)
+        ys[1, 3:] = -1
+        ys[2, 4:] = -1
+        xs = xs * (torch.arange(26).view(1, -1, 1) < ilens.view(-1, 1, 1))
+        hs, hlens, _ = m.enc(xs, ilens)
+        loss = m(xs, ilens, ys)
+        loss.backward()
+        save(out("e2e_rnn_%s.npz" % atype), xs=xs, ilens=ilens, ys=ys, hs_pad=hs.detach(),
+             hlens=np.asarray(hlens, dtype=np.int64), loss=float(loss), loss_att=float(m.loss_att),
+             loss_ctc=float(m.loss_ctc), acc=float(m.acc), **sd0, **grads_np(m))
+
     # ---- a21: transducer.  The loss package (warprnnt_pytorch) is absent here: TransLoss is given the
     # oracle's float64 restatement of the published recursion (asr_oracle.rnnt_loss, mean over the batch),
     # everything else (encoder, predictor, joint network, input preparation) is the reference's own code.

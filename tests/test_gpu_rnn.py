@@ -213,6 +213,25 @@ def test_e2e_rnn_golden():
     check_grads(m, grads, tol=5e-4)
 
 
+@pytest.mark.parametrize("atype", ["add", "multi_head_add", "multi_head_loc", "multi_head_multi_res_loc"])
+def test_e2e_rnn_attention_types_golden(atype):
+    """BLSTMP (frame subsampling 1_2) + additive / multi-head attentions == reference E2E on its own weights"""
+    from espnet_amd.nets.e2e_asr import E2E
+    p, sd, grads = split_golden(load_golden("e2e_rnn_%s.npz" % atype))
+    m = load_sd(E2E(9, 7, _rnn_args(etype="blstmp", elayers=2, subsample="1_2_1", eunits=8, eprojs=8, dlayers=1, dunits=10,
+                                     atype=atype, adim=6, aheads=2, aconv_chans=3, aconv_filts=4)), sd)
+    m.train()
+    loss = m(p["xs"].to(DEV), p["ilens"], p["ys"].to(DEV))
+    assert m.hlens == p["hlens"].tolist()
+    report("e2e_rnn %s hs_pad" % atype, m.hs_pad, p["hs_pad"], 1e-4)
+    for name, got, want in (("loss", loss, p["loss"]), ("loss_att", m.loss_att, p["loss_att"])):
+        rel = abs(float(got) - float(want)) / abs(float(want))
+        print("[parity] e2e_rnn %s %s hip %.6f ref %.6f rel %.2e" % (atype, name, float(got), float(want), rel))
+        assert rel < 1e-5
+    loss.backward()
+    check_grads(m, grads, tol=5e-4)
+
+
 def _trn_args(**kw):
     d = dict(etype="vggblstmp", elayers=1, subsample="1_1", eunits=10, eprojs=8, dtype="lstm", dlayers=2, dunits=12,
              dec_embed_dim=6, dropout_rate=0.0, dropout_rate_decoder=0.0, dropout_rate_embed_decoder=0.0, joint_dim=7,

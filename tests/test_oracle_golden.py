@@ -252,6 +252,23 @@ def test_e2e_rnn(oracle):
     _grad_check(sd, grads)
 
 
+@pytest.mark.parametrize("atype", ["add", "multi_head_add", "multi_head_loc", "multi_head_multi_res_loc"])
+def test_e2e_rnn_attention_types(oracle, atype):
+    """BLSTMP (subsample 1_2) + the other attention types on the HIP path against the reference E2E"""
+    p, sd, grads = split_golden(load_golden("e2e_rnn_%s.npz" % atype))
+    sd = req(sd)
+    hs, hlens = oracle.rnn_encoder(sd, "enc.", p["xs"], p["ilens"].tolist(), 2, [1, 2, 1], vgg=False)
+    assert hlens == p["hlens"].tolist()
+    close(hs, p["hs_pad"], rtol=1e-4, atol=1e-5)
+    loss_ctc = oracle.ctc_loss(oracle.linear(sd, "ctc.ctc_lo.", hs), torch.tensor(hlens), p["ys"])
+    loss_att, acc, _ = oracle.rnn_att_decoder(sd, "dec.", hs, hlens, p["ys"], 6, 6, 1, "att.0.", atype=atype, aheads=2)
+    close(loss_att.detach(), p["loss_att"], rtol=1e-4, atol=1e-5)
+    loss = 0.5 * loss_ctc + 0.5 * loss_att
+    close(loss.detach(), p["loss"], rtol=1e-4, atol=1e-5)
+    loss.backward()
+    _grad_check(sd, grads)
+
+
 def test_rnnt_loss_brute_force(oracle):
     """the lattice recursion equals the explicit sum over all alignments (Graves 2012, eq. 1-3)"""
     g = torch.Generator().manual_seed(7)
