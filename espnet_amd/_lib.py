@@ -63,6 +63,7 @@ SYMBOLS = [
     "eamd_lstm_cell_fwd", "eamd_lstm_cell_bwd", "eamd_maxpool2x2_fwd", "eamd_maxpool2x2_bwd", "eamd_mask_rows",
     "eamd_joint_fwd", "eamd_joint_bwd", "eamd_rnnt_workspace", "eamd_rnnt_loss",
     "eamd_conv3x3_c1_fwd", "eamd_conv3x3_c1_bwd_w_workspace", "eamd_conv3x3_c1_bwd_w", "eamd_attloc_fwd", "eamd_attloc_bwd_energy", "eamd_attloc_bwd_conv",
+    "eamd_att_dot_energy_fwd", "eamd_att_dot_energy_bwd", "eamd_att_ctx_fwd", "eamd_att_ctx_bwd",
 ]
 
 

@@ -275,6 +275,36 @@ __global__ __launch_bounds__(256) void attloc_conv_bwd_w_kernel(const float* __r
   }
 }
 
+// ---- dot-product attention energies (AttDot :91-164, AttMultiHeadDot :845-990) ---------------------------
+// e[b,t] = sum_a k[b,t,a] * q[b,a]  (k = tanh(mlp_k h), q = tanh(mlp_q z), both already activated); -inf for t >= len
+__global__ __launch_bounds__(64) void att_dot_energy_fwd_kernel(const float* __restrict__ k, const float* __restrict__ q,
+                                                               const int* __restrict__ lens, float* __restrict__ e,
+                                                               int T, int A) {
+  const int bt = blockIdx.x, b = bt / T, t = bt % T;
+  float acc = 0.f;
+  for (int a = threadIdx.x; a < A; a += 64) acc += k[(long)bt * A + a] * q[(long)b * A + a];
+  acc = wave_sum(acc);
+  if (threadIdx.x == 0) e[bt] = t < lens[b] ? acc : -INFINITY;
+}
+// dk[b,t,a] = de[b,t] * q[b,a];  dq[b,a] = sum_t de[b,t] * k[b,t,a]      grid (B, ceil(T/TCH)), threads along a
+__global__ __launch_bounds__(256) void att_dot_energy_bwd_kernel(const float* __restrict__ de, const float* __restrict__ k,
+                                                                 const float* __restrict__ q, float* __restrict__ dk,
+                                                                 float* __restrict__ dq, int T, int A) {
+  const int b = blockIdx.x;
+  const int t0 = blockIdx.y * ATT_TCH, t1 = min(T, t0 + ATT_TCH);
+  for (int a = threadIdx.x; a < A; a += blockDim.x) {
+    const float qv = q[(long)b * A + a];
+    float acc = 0.f;
+    for (int t = t0; t < t1; ++t) {
+      const long i = ((long)b * T + t) * A + a;
+      const float d = de[(long)b * T + t];
+      dk[i] = d * qv;
+      acc += d * k[i];
+    }
+    atomicAdd(&dq[(long)b * A + a], acc);
+  }
+}
+
 inline int grid_for(long n) {
   long g = (n + 255) / 256;
   return (int)(g < 1 ? 1 : (g > 65535 ? 65535 : g));
@@ -369,6 +399,42 @@ int eamd_attloc_bwd_conv(const float* dconv, const float* conv_w, const float* a
   hipLaunchKernelGGL(attloc_conv_bwd_prev_kernel, dim3(B, (T + 255) / 256), dim3(256), 0, s, dconv, conv_w, d_prev, T, C, K);
   EAMD_LAUNCH_CHECK();
   hipLaunchKernelGGL(attloc_conv_bwd_w_kernel, dim3(C, B), dim3(256), 0, s, dconv, att_prev, dconv_w, T, C, K);
+  EAMD_LAUNCH_CHECK();
+  return EAMD_OK;
+}
+
+/* softmax(scaling * e) over the frames + context vector, for energies produced elsewhere (dot-product attention) */
+int eamd_att_ctx_fwd(const float* e, const float* v, float scaling, float* w, float* ctx, int B, int T, int E,
+                     void* stream) {
+  if (!e || !v || !w || !ctx || B <= 0 || T <= 0 || E <= 0) return EAMD_EINVAL;
+  if ((size_t)T * sizeof(float) > 60 * 1024) return EAMD_EUNSUPPORTED;
+  hipLaunchKernelGGL(attloc_ctx_fwd_kernel, dim3(B, (E + 63) / 64), dim3(256), T * sizeof(float), (hipStream_t)stream, e, v,
+                     scaling, w, ctx, T, E);
+  EAMD_LAUNCH_CHECK();
+  return EAMD_OK;
+}
+int eamd_att_ctx_bwd(const float* dctx, const float* dw_ext, const float* w, const float* v, float scaling, float* de,
+                     float* d_v, float* dsum, int B, int T, int E, void* stream) {
+  if (!dctx || !w || !v || !de || !d_v || !dsum || B <= 0 || T <= 0 || E <= 0) return EAMD_EINVAL;
+  if ((size_t)T * sizeof(float) > 60 * 1024) return EAMD_EUNSUPPORTED;
+  hipLaunchKernelGGL(attloc_ctx_bwd_kernel, dim3(B), dim3(256), T * sizeof(float), (hipStream_t)stream, dctx, dw_ext, w, v,
+                     scaling, de, d_v, dsum, T, E);
+  EAMD_LAUNCH_CHECK();
+  return EAMD_OK;
+}
+int eamd_att_dot_energy_fwd(const float* k, const float* q, const int32_t* lens, float* e, int B, int T, int A,
+                            void* stream) {
+  if (!k || !q || !lens || !e || B <= 0 || T <= 0 || A <= 0) return EAMD_EINVAL;
+  hipLaunchKernelGGL(att_dot_energy_fwd_kernel, dim3(B * T), dim3(64), 0, (hipStream_t)stream, k, q, lens, e, T, A);
+  EAMD_LAUNCH_CHECK();
+  return EAMD_OK;
+}
+/* dk [B,T,A] written, dq [B,A] ACCUMULATED */
+int eamd_att_dot_energy_bwd(const float* de, const float* k, const float* q, float* dk, float* dq, int B, int T, int A,
+                            void* stream) {
+  if (!de || !k || !q || !dk || !dq || B <= 0 || T <= 0 || A <= 0) return EAMD_EINVAL;
+  hipLaunchKernelGGL(att_dot_energy_bwd_kernel, dim3(B, (T + ATT_TCH - 1) / ATT_TCH), dim3(256), 0, (hipStream_t)stream, de,
+                     k, q, dk, dq, T, A);
   EAMD_LAUNCH_CHECK();
   return EAMD_OK;
 }

@@ -7,6 +7,7 @@ import numpy as np
 import torch
 
 from ... import functional as F_
+from ... import ops
 from ... import rnn_functional as R_
 
 
@@ -92,6 +93,37 @@ class AttAdd(torch.nn.Module):
                                      None, None, self.gvec.weight, self.gvec.bias)
 
 
+class AttDot(torch.nn.Module):
+    """dot-product attention.  reference: rnn/attentions.py:91-164"""
+
+    def __init__(self, eprojs, dunits, att_dim, han_mode=False):
+        super().__init__()
+        self.mlp_enc = torch.nn.Linear(eprojs, att_dim)
+        self.mlp_dec = torch.nn.Linear(dunits, att_dim)
+        self.dunits, self.eprojs, self.att_dim, self.han_mode = dunits, eprojs, att_dim, han_mode
+        self.reset()
+
+    def reset(self):
+        self.h_length = None
+        self.enc_h = None
+        self.pre_compute_enc_h = None
+        self.mask = None
+        self._lens = None
+
+    def forward(self, enc_hs_pad, enc_hs_len, dec_z, att_prev, scaling=2.0):
+        batch = enc_hs_pad.shape[0]
+        if self.pre_compute_enc_h is None or self.han_mode:
+            self.enc_h = enc_hs_pad.contiguous()
+            self.h_length = self.enc_h.size(1)
+            self.pre_compute_enc_h = R_.ActFn.apply(
+                F_.LinearFn.apply(self.enc_h, self.mlp_enc.weight, self.mlp_enc.bias), ops.ACT_TANH)
+            self._lens = torch.tensor([int(v) for v in enc_hs_len], dtype=torch.int32).to(enc_hs_pad.device,
+                                                                                          non_blocking=True)
+        dec_z = enc_hs_pad.new_zeros(batch, self.dunits) if dec_z is None else dec_z.view(batch, self.dunits)
+        q = R_.ActFn.apply(F_.LinearFn.apply(dec_z, self.mlp_dec.weight, self.mlp_dec.bias), ops.ACT_TANH)
+        return R_.AttDotStepFn.apply(self.pre_compute_enc_h, q, self.enc_h, self._lens, float(scaling))
+
+
 class _MultiHeadBase(torch.nn.Module):
     """shared part of the multi-head attentions (rnn/attentions.py:845-1385): per head k = mlp_k(h) (no bias),
     v = mlp_v(h) (no bias), q = mlp_q(z) (bias); the H context vectors are concatenated and mixed by mlp_o."""
@@ -151,6 +183,28 @@ class _MultiHeadBase(torch.nn.Module):
         return c, w
 
 
+class AttMultiHeadDot(_MultiHeadBase):
+    """reference: rnn/attentions.py:845-990 (k = tanh(mlp_k h), q = tanh(mlp_q z), e = k . q, softmax(e / sqrt(d_k)));
+    this variant has no gvec parameters"""
+
+    def __init__(self, eprojs, dunits, aheads, att_dim_k, att_dim_v, han_mode=False):
+        super().__init__(eprojs, dunits, aheads, att_dim_k, att_dim_v, han_mode)
+        del self.gvec
+
+    def _precompute(self, enc_hs_pad, enc_hs_len):
+        fresh = self.pre_compute_k is None or self.han_mode
+        super()._precompute(enc_hs_pad, enc_hs_len)
+        if fresh:
+            self.pre_compute_k = [R_.ActFn.apply(k, ops.ACT_TANH) for k in self.pre_compute_k]
+
+    def _head(self, h, q, att_prev_h, scaling):
+        return R_.AttDotStepFn.apply(self.pre_compute_k[h], R_.ActFn.apply(q, ops.ACT_TANH), self.pre_compute_v[h],
+                                     self._lens, scaling)
+
+    def forward(self, enc_hs_pad, enc_hs_len, dec_z, att_prev):
+        return self._forward(enc_hs_pad, enc_hs_len, dec_z, att_prev, self.scaling, False)
+
+
 class AttMultiHeadAdd(_MultiHeadBase):
     """reference: rnn/attentions.py:993-1107 (per head: gvec . tanh(k + q), softmax(e / sqrt(d_k)))"""
 
@@ -202,16 +256,20 @@ def initial_att(atype, eprojs, dunits, aheads, adim, awin, aconv_chans, aconv_fi
     """reference: rnn/attentions.py:1722-1771"""
     if atype == "location":
         return AttLoc(eprojs, dunits, adim, aconv_chans, aconv_filts, han_mode)
+    if atype == "dot":
+        return AttDot(eprojs, dunits, adim, han_mode)
     if atype == "add":
         return AttAdd(eprojs, dunits, adim, han_mode)
+    if atype == "multi_head_dot":
+        return AttMultiHeadDot(eprojs, dunits, aheads, adim, adim, han_mode)
     if atype == "multi_head_add":
         return AttMultiHeadAdd(eprojs, dunits, aheads, adim, adim, han_mode)
     if atype == "multi_head_loc":
         return AttMultiHeadLoc(eprojs, dunits, aheads, adim, adim, aconv_chans, aconv_filts, han_mode)
     if atype == "multi_head_multi_res_loc":
         return AttMultiHeadMultiResLoc(eprojs, dunits, aheads, adim, adim, aconv_chans, aconv_filts, han_mode)
-    raise NotImplementedError("atype %r has no HIP kernels yet (on the HIP path: location, add, multi_head_add, "
-                              "multi_head_loc, multi_head_multi_res_loc)" % atype)
+    raise NotImplementedError("atype %r has no HIP kernels yet (on the HIP path: location, dot, add, multi_head_dot, "
+                              "multi_head_add, multi_head_loc, multi_head_multi_res_loc)" % atype)
 
 
 def att_for(args, num_att=1, han_mode=False):

@@ -795,3 +795,35 @@ def mask_rows(x, keep):
     y = torch.empty_like(x)
     check(_lib.lib().eamd_mask_rows(ptr(x), ptr(keep), ptr(y), C.c_int64(rows), D, stream_ptr()), "eamd_mask_rows")
     return y
+
+
+def att_dot_fwd(k, q, v, lens, scaling):
+    """dot-product attention step: k [B,T,A], q [B,A] (both tanh-activated), v [B,T,E] -> ctx [B,E], w [B,T]"""
+    B, T, A = k.shape
+    E = v.shape[2]
+    dev = k.device
+    e = torch.empty(B, T, device=dev, dtype=torch.float32)
+    w = torch.empty(B, T, device=dev, dtype=torch.float32)
+    ctx = torch.empty(B, E, device=dev, dtype=torch.float32)
+    L = _lib.lib()
+    check(L.eamd_att_dot_energy_fwd(ptr(k), ptr(q), ptr(lens), ptr(e), B, T, A, stream_ptr()), "eamd_att_dot_energy_fwd")
+    check(L.eamd_att_ctx_fwd(ptr(e), ptr(v), C.c_float(scaling), ptr(w), ptr(ctx), B, T, E, stream_ptr()),
+          "eamd_att_ctx_fwd")
+    return ctx, w
+
+
+def att_dot_bwd(dctx, dw_ext, w, k, q, v, scaling):
+    B, T, A = k.shape
+    E = v.shape[2]
+    dev = k.device
+    de = torch.empty(B, T, device=dev, dtype=torch.float32)
+    d_v = torch.empty(B, T, E, device=dev, dtype=torch.float32)
+    dk = torch.empty(B, T, A, device=dev, dtype=torch.float32)
+    dq = torch.zeros(B, A, device=dev, dtype=torch.float32)
+    dsum = torch.zeros(1, device=dev, dtype=torch.float32)
+    L = _lib.lib()
+    check(L.eamd_att_ctx_bwd(ptr(dctx), ptr(dw_ext), ptr(w), ptr(v), C.c_float(scaling), ptr(de), ptr(d_v), ptr(dsum),
+                             B, T, E, stream_ptr()), "eamd_att_ctx_bwd")
+    check(L.eamd_att_dot_energy_bwd(ptr(de), ptr(k), ptr(q), ptr(dk), ptr(dq), B, T, A, stream_ptr()),
+          "eamd_att_dot_energy_bwd")
+    return d_v, dk, dq

@@ -272,6 +272,26 @@ class AttLocStepFn(torch.autograd.Function):
         return (d_enc_h, df, d_dec, d_prev, None, None) + sink.results()
 
 
+class AttDotStepFn(torch.autograd.Function):
+    """dot-product attention step on activated keys / query (AttDot, AttMultiHeadDot heads):
+    e = k . q, w = softmax(scaling * e) over the valid frames, ctx = sum_t w * v"""
+
+    @staticmethod
+    def forward(ctx, k, q, v, lens, scaling):
+        k, q, v = k.contiguous(), q.contiguous(), v.contiguous()
+        c, w = ops.att_dot_fwd(k, q, v, lens, scaling)
+        ctx.save_for_backward(k, q, v, w)
+        ctx.scaling = scaling
+        return c, w
+
+    @staticmethod
+    def backward(ctx, dc, dw):
+        k, q, v, w = ctx.saved_tensors
+        d_v, dk, dq = ops.att_dot_bwd(dc.contiguous(), dw.contiguous() if dw is not None else None, w, k, q, v,
+                                      ctx.scaling)
+        return dk, dq, d_v, None, None
+
+
 # =================================================================================================
 # Transducer joint network pointwise part and loss
 # =================================================================================================

@@ -275,6 +275,19 @@ int eamd_attloc_fwd(const float* att_prev, const float* conv_w, const float* w_a
 int eamd_attloc_bwd_energy(const float* dctx, const float* dw_ext, const float* w, const float* enc_h, const float* th,
                            const float* gvec, float scaling, float* de, float* d_enc_h, float* df, float* dgvec,
                            float* dgb, float* d_dec_proj, int B, int T, int A, int E, void* stream);
+/* Dot-product attention (AttDot rnn/attentions.py:91-164, per head of AttMultiHeadDot :845-990):
+ * e[b,t] = k[b,t,:] . q[b,:] on already tanh-activated k = tanh(mlp_k h), q = tanh(mlp_q z); -inf for t >= lens[b];
+ * then w = softmax(scaling * e), ctx = sum_t w * v (eamd_att_ctx_*: the softmax / context half of eamd_attloc_*).
+ * eamd_att_ctx_bwd: de [B,T], d_v [B,T,E] written, dsum[0] += sum de (= 0 analytically);
+ * eamd_att_dot_energy_bwd: dk [B,T,A] written, dq [B,A] accumulated. */
+int eamd_att_dot_energy_fwd(const float* k, const float* q, const int32_t* lens, float* e, int B, int T, int A,
+                            void* stream);
+int eamd_att_dot_energy_bwd(const float* de, const float* k, const float* q, float* dk, float* dq, int B, int T, int A,
+                            void* stream);
+int eamd_att_ctx_fwd(const float* e, const float* v, float scaling, float* w, float* ctx, int B, int T, int E,
+                     void* stream);
+int eamd_att_ctx_bwd(const float* dctx, const float* dw_ext, const float* w, const float* v, float scaling, float* de,
+                     float* d_v, float* dsum, int B, int T, int E, void* stream);
 /* backward stage 2, given dconv = df @ W_att [B,T,C]: d att_prev [B,T] and dconv_w [C,K] (accumulated). */
 int eamd_attloc_bwd_conv(const float* dconv, const float* conv_w, const float* att_prev, float* d_prev, float* dconv_w,
                          int B, int T, int C, int K, void* stream);

@@ -213,7 +213,7 @@ def test_e2e_rnn_golden():
     check_grads(m, grads, tol=5e-4)
 
 
-@pytest.mark.parametrize("atype", ["add", "multi_head_add", "multi_head_loc", "multi_head_multi_res_loc"])
+@pytest.mark.parametrize("atype", ["dot", "add", "multi_head_dot", "multi_head_add", "multi_head_loc", "multi_head_multi_res_loc"])
 def test_e2e_rnn_attention_types_golden(atype):
     """BLSTMP (frame subsampling 1_2) + additive / multi-head attentions == reference E2E on its own weights"""
     from espnet_amd.nets.e2e_asr import E2E
