@@ -180,41 +180,47 @@ __global__ __launch_bounds__(256) void attloc_ctx_fwd_kernel(const float* __rest
   if (sub == 0 && col < E) ctx[(long)b * E + col] = (part[0][lane] + part[1][lane]) + (part[2][lane] + part[3][lane]);
 }
 
-// backward of softmax + context: de[b,t] = scaling * w * (dw - sum_t w dw), dw = dw_ext + enc_h . dctx;
-// d_enc_h[b,t,:] = w[b,t] * dctx[b,:]; dgb += sum_t de.   grid B, dynamic LDS T floats
-__global__ __launch_bounds__(256) void attloc_ctx_bwd_kernel(const float* __restrict__ dctx,
-                                                             const float* __restrict__ dw_ext,
-                                                             const float* __restrict__ w,
-                                                             const float* __restrict__ enc_h, float scaling,
-                                                             float* __restrict__ de, float* __restrict__ d_enc_h,
-                                                             float* __restrict__ dgb, int T, int E) {
-  extern __shared__ float dwl[];
+// backward of softmax + context, two launches sized for the machine (one workgroup per utterance starved it):
+//  (1) one wave per frame (b,t): dw[b,t] = dw_ext[b,t] + enc_h[b,t,:] . dctx[b,:]  and  d_enc_h[b,t,:] = w[b,t] * dctx[b,:]
+//  (2) one workgroup per utterance: de[b,t] = scaling * w * (dw - sum_t w dw) in place over dw; dgb += sum_t de
+__global__ __launch_bounds__(256) void attloc_ctx_bwd_rows_kernel(const float* __restrict__ dctx,
+                                                                  const float* __restrict__ dw_ext,
+                                                                  const float* __restrict__ w,
+                                                                  const float* __restrict__ enc_h,
+                                                                  float* __restrict__ dwv, float* __restrict__ d_enc_h,
+                                                                  int BT, int T, int E) {
+  const int lane = threadIdx.x & 63;
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= BT) return;
+  const int b = row / T;
+  const float* dc = dctx + (long)b * E;
+  const float* h = enc_h + (long)row * E;
+  float* o = d_enc_h + (long)row * E;
+  const float wv = w[row];
+  float d = 0.f;
+  for (int x = lane; x < E; x += 64) {
+    const float c = dc[x];
+    d += c * h[x];
+    o[x] = wv * c;
+  }
+  d = wave_sum(d);
+  if (lane == 0) dwv[row] = d + (dw_ext ? dw_ext[row] : 0.f);
+}
+__global__ __launch_bounds__(256) void attloc_softmax_bwd_kernel(const float* __restrict__ w, float scaling,
+                                                                 float* __restrict__ de, float* __restrict__ dgb, int T) {
   __shared__ float red[16];
   const int b = blockIdx.x;
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const float* dc = dctx + (long)b * E;
-  for (int t = wave; t < T; t += 4) {
-    const float* h = enc_h + ((long)b * T + t) * E;
-    float d = 0.f;
-    for (int x = lane; x < E; x += 64) d += dc[x] * h[x];
-    d = wave_sum(d);
-    if (lane == 0) dwl[t] = d + (dw_ext ? dw_ext[(long)b * T + t] : 0.f);
-  }
-  __syncthreads();
   float s = 0.f;
-  for (int t = threadIdx.x; t < T; t += blockDim.x) s += w[(long)b * T + t] * dwl[t];
+  for (int t = threadIdx.x; t < T; t += blockDim.x) s += w[(long)b * T + t] * de[(long)b * T + t];
   s = block_sum(s, red);
   float tot = 0.f;
   for (int t = threadIdx.x; t < T; t += blockDim.x) {
-    const float v = scaling * w[(long)b * T + t] * (dwl[t] - s);
+    const float v = scaling * w[(long)b * T + t] * (de[(long)b * T + t] - s);
     de[(long)b * T + t] = v;
     tot += v;
   }
   tot = block_sum(tot, red);
   if (threadIdx.x == 0) atomicAdd(dgb, tot);
-  const long n = (long)T * E;
-  for (long i = threadIdx.x; i < n; i += blockDim.x)
-    d_enc_h[(long)b * n + i] = w[(long)b * T + i / E] * dc[i % E];
 }
 
 // df[b,t,a] = de[b,t] * gvec[a] * (1 - th^2); dgvec[a] += sum de*th; d_dec_proj[b,a] += sum_t df
@@ -242,22 +248,25 @@ __global__ __launch_bounds__(256) void attloc_energy_bwd_kernel(const float* __r
   }
 }
 
-// d_prev[b,s] = sum_{c,k} dconv[b, s - k + F, c] * conv_w[c,k]          grid (B, ceil(T/256))
+// d_prev[b,s] = sum_{c,k} dconv[b, s - k + F, c] * conv_w[c,k]          one wave per output frame (b,s): lanes over k
 __global__ __launch_bounds__(256) void attloc_conv_bwd_prev_kernel(const float* __restrict__ dconv,
                                                                    const float* __restrict__ conv_w,
-                                                                   float* __restrict__ d_prev, int T, int C, int K) {
-  const int b = blockIdx.x;
-  const int s = blockIdx.y * blockDim.x + threadIdx.x;
-  if (s >= T) return;
+                                                                   float* __restrict__ d_prev, int BT, int T, int C,
+                                                                   int K) {
+  const int lane = threadIdx.x & 63;
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= BT) return;
+  const int b = row / T, s = row % T;
   const int F = (K - 1) / 2;
   float acc = 0.f;
-  for (int k = 0; k < K; ++k) {
+  for (int k = lane; k < K; k += 64) {
     const int t = s - k + F;
     if (t < 0 || t >= T) continue;
     const float* dcv = dconv + ((long)b * T + t) * C;
     for (int c = 0; c < C; ++c) acc += dcv[c] * conv_w[c * K + k];
   }
-  d_prev[(long)b * T + s] = acc;
+  acc = wave_sum(acc);
+  if (lane == 0) d_prev[row] = acc;
 }
 // dconv_w[c,k] += sum_{b,t} dconv[b,t,c] * att_prev[b, t + k - F]       grid (C, B), threads along k
 __global__ __launch_bounds__(256) void attloc_conv_bwd_w_kernel(const float* __restrict__ dconv,
@@ -381,8 +390,10 @@ int eamd_attloc_bwd_energy(const float* dctx, const float* dw_ext, const float* 
     return EAMD_EINVAL;
   if ((size_t)T * sizeof(float) > 60 * 1024) return EAMD_EUNSUPPORTED;
   hipStream_t s = (hipStream_t)stream;
-  hipLaunchKernelGGL(attloc_ctx_bwd_kernel, dim3(B), dim3(256), T * sizeof(float), s, dctx, dw_ext, w, enc_h, scaling, de,
-                     d_enc_h, dgb, T, E);
+  hipLaunchKernelGGL(attloc_ctx_bwd_rows_kernel, dim3((B * T + 3) / 4), dim3(256), 0, s, dctx, dw_ext, w, enc_h, de, d_enc_h,
+                     B * T, T, E);
+  EAMD_LAUNCH_CHECK();
+  hipLaunchKernelGGL(attloc_softmax_bwd_kernel, dim3(B), dim3(256), 0, s, w, scaling, de, dgb, T);
   EAMD_LAUNCH_CHECK();
   hipLaunchKernelGGL(attloc_energy_bwd_kernel, dim3(B, (T + ATT_TCH - 1) / ATT_TCH), dim3(256), 0, s, de, th, gvec, df,
                      dgvec, d_dec_proj, T, A);
@@ -396,7 +407,7 @@ int eamd_attloc_bwd_conv(const float* dconv, const float* conv_w, const float* a
   if (!dconv || !conv_w || !att_prev || !d_prev || !dconv_w || B <= 0 || T <= 0 || C <= 0 || K <= 0 || (K & 1) == 0)
     return EAMD_EINVAL;
   hipStream_t s = (hipStream_t)stream;
-  hipLaunchKernelGGL(attloc_conv_bwd_prev_kernel, dim3(B, (T + 255) / 256), dim3(256), 0, s, dconv, conv_w, d_prev, T, C, K);
+  hipLaunchKernelGGL(attloc_conv_bwd_prev_kernel, dim3((B * T + 3) / 4), dim3(256), 0, s, dconv, conv_w, d_prev, B * T, T, C, K);
   EAMD_LAUNCH_CHECK();
   hipLaunchKernelGGL(attloc_conv_bwd_w_kernel, dim3(C, B), dim3(256), 0, s, dconv, att_prev, dconv_w, T, C, K);
   EAMD_LAUNCH_CHECK();
@@ -417,8 +428,10 @@ int eamd_att_ctx_bwd(const float* dctx, const float* dw_ext, const float* w, con
                      float* d_v, float* dsum, int B, int T, int E, void* stream) {
   if (!dctx || !w || !v || !de || !d_v || !dsum || B <= 0 || T <= 0 || E <= 0) return EAMD_EINVAL;
   if ((size_t)T * sizeof(float) > 60 * 1024) return EAMD_EUNSUPPORTED;
-  hipLaunchKernelGGL(attloc_ctx_bwd_kernel, dim3(B), dim3(256), T * sizeof(float), (hipStream_t)stream, dctx, dw_ext, w, v,
-                     scaling, de, d_v, dsum, T, E);
+  hipLaunchKernelGGL(attloc_ctx_bwd_rows_kernel, dim3((B * T + 3) / 4), dim3(256), 0, (hipStream_t)stream, dctx, dw_ext, w, v,
+                     de, d_v, B * T, T, E);
+  EAMD_LAUNCH_CHECK();
+  hipLaunchKernelGGL(attloc_softmax_bwd_kernel, dim3(B), dim3(256), 0, (hipStream_t)stream, w, scaling, de, dsum, T);
   EAMD_LAUNCH_CHECK();
   return EAMD_OK;
 }

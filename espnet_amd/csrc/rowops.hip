@@ -106,35 +106,53 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(
       ag[j] = make_float4(0.f, 0.f, 0.f, 0.f); ab[j] = ag[j];
       g4[j] = reinterpret_cast<const float4*>(gamma)[lane + 64 * j];
     }
-    for (int row = r0 + wave; row < r1; row += 4) {
-      const float4* dyr = reinterpret_cast<const float4*>(dy + (long)row * D);
-      const float4* xr = reinterpret_cast<const float4*>(x + (long)row * D);
-      const float mu = mean[row], rs = rstd[row];
-      float4 d4[VEC], h4[VEC];
-      float s1 = 0.f, s2 = 0.f;
+    // two rows per trip, every operand of both rows (dy, x, residual gradient) requested before the first use:
+    // one memory round trip per pair instead of two dependent ones per row
+    for (int row = r0 + wave; row < r1; row += 8) {
+      const int row2 = row + 4;
+      const bool two = row2 < r1;
+      const int rb = two ? row2 : row;          // second row falls back to the first (results discarded)
+      float4 d4[2][VEC], xv[2][VEC], rv[2][VEC];
 #pragma unroll
       for (int j = 0; j < VEC; ++j) {
-        d4[j] = dyr[lane + 64 * j];
-        float4 xv = xr[lane + 64 * j];
-        h4[j] = make_float4((xv.x - mu) * rs, (xv.y - mu) * rs, (xv.z - mu) * rs, (xv.w - mu) * rs);
-        float a = d4[j].x * g4[j].x, b = d4[j].y * g4[j].y, c = d4[j].z * g4[j].z, d = d4[j].w * g4[j].w;
-        s1 += (a + b) + (c + d);
-        s2 += (a * h4[j].x + b * h4[j].y) + (c * h4[j].z + d * h4[j].w);
-        ag[j].x += d4[j].x * h4[j].x; ag[j].y += d4[j].y * h4[j].y; ag[j].z += d4[j].z * h4[j].z; ag[j].w += d4[j].w * h4[j].w;
-        ab[j].x += d4[j].x; ab[j].y += d4[j].y; ab[j].z += d4[j].z; ab[j].w += d4[j].w;
+        d4[0][j] = reinterpret_cast<const float4*>(dy + (long)row * D)[lane + 64 * j];
+        xv[0][j] = reinterpret_cast<const float4*>(x + (long)row * D)[lane + 64 * j];
+        d4[1][j] = reinterpret_cast<const float4*>(dy + (long)rb * D)[lane + 64 * j];
+        xv[1][j] = reinterpret_cast<const float4*>(x + (long)rb * D)[lane + 64 * j];
+        if (dres) {
+          rv[0][j] = reinterpret_cast<const float4*>(dres + (long)row * D)[lane + 64 * j];
+          rv[1][j] = reinterpret_cast<const float4*>(dres + (long)rb * D)[lane + 64 * j];
+        }
       }
-      s1 = wave_sum(s1) / D; s2 = wave_sum(s2) / D;
-      float4* dxr = reinterpret_cast<float4*>(dx + (long)row * D);
-      const float4* rr = dres ? reinterpret_cast<const float4*>(dres + (long)row * D) : nullptr;
+      const float mu[2] = {mean[row], mean[rb]}, rs[2] = {rstd[row], rstd[rb]};
 #pragma unroll
-      for (int j = 0; j < VEC; ++j) {
-        float4 o;
-        o.x = rs * (d4[j].x * g4[j].x - s1 - h4[j].x * s2);
-        o.y = rs * (d4[j].y * g4[j].y - s1 - h4[j].y * s2);
-        o.z = rs * (d4[j].z * g4[j].z - s1 - h4[j].z * s2);
-        o.w = rs * (d4[j].w * g4[j].w - s1 - h4[j].w * s2);
-        if (rr) { float4 r = rr[lane + 64 * j]; o.x += r.x; o.y += r.y; o.z += r.z; o.w += r.w; }
-        dxr[lane + 64 * j] = o;
+      for (int q = 0; q < 2; ++q) {
+        if (q == 1 && !two) break;
+        float4 h4[VEC];
+        float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+        for (int j = 0; j < VEC; ++j) {
+          const float4 xq = xv[q][j], dq = d4[q][j];
+          h4[j] = make_float4((xq.x - mu[q]) * rs[q], (xq.y - mu[q]) * rs[q], (xq.z - mu[q]) * rs[q], (xq.w - mu[q]) * rs[q]);
+          float a = dq.x * g4[j].x, b = dq.y * g4[j].y, c = dq.z * g4[j].z, d = dq.w * g4[j].w;
+          s1 += (a + b) + (c + d);
+          s2 += (a * h4[j].x + b * h4[j].y) + (c * h4[j].z + d * h4[j].w);
+          ag[j].x += dq.x * h4[j].x; ag[j].y += dq.y * h4[j].y; ag[j].z += dq.z * h4[j].z; ag[j].w += dq.w * h4[j].w;
+          ab[j].x += dq.x; ab[j].y += dq.y; ab[j].z += dq.z; ab[j].w += dq.w;
+        }
+        s1 = wave_sum(s1) / D; s2 = wave_sum(s2) / D;
+        float4* dxr = reinterpret_cast<float4*>(dx + (long)(q ? row2 : row) * D);
+#pragma unroll
+        for (int j = 0; j < VEC; ++j) {
+          const float4 dq = d4[q][j];
+          float4 o;
+          o.x = rs[q] * (dq.x * g4[j].x - s1 - h4[j].x * s2);
+          o.y = rs[q] * (dq.y * g4[j].y - s1 - h4[j].y * s2);
+          o.z = rs[q] * (dq.z * g4[j].z - s1 - h4[j].z * s2);
+          o.w = rs[q] * (dq.w * g4[j].w - s1 - h4[j].w * s2);
+          if (dres) { o.x += rv[q][j].x; o.y += rv[q][j].y; o.z += rv[q][j].z; o.w += rv[q][j].w; }
+          dxr[lane + 64 * j] = o;
+        }
       }
     }
 #pragma unroll
@@ -478,7 +496,8 @@ int eamd_layernorm_bwd(const float* dy, const float* x, const float* gamma, cons
   if (D > 1024) return EAMD_EUNSUPPORTED;
   int nblk, rpb;
   ln_bwd_grid(rows, &nblk, &rpb);
-  float* ws = nblk >= 32 ? workspace : nullptr;   // few blocks: direct atomics are cheaper than a second launch
+  static const int ws_min = [] { const char* e = getenv("EAMD_LNB_WS_MIN"); return e ? atoi(e) : 32; }();
+  float* ws = nblk >= ws_min ? workspace : nullptr;   // few blocks: direct atomics are cheaper than a second launch
   const bool al = (((uintptr_t)dy | (uintptr_t)x | (uintptr_t)gamma | (uintptr_t)dx | (uintptr_t)dres) & 15) == 0;
   hipStream_t s = (hipStream_t)stream;
   size_t sm = 2 * D * sizeof(float);

@@ -10,7 +10,8 @@ import torch
 
 from .asr_interface import ASRInterface
 from .e2e_asr import get_subsample, lecun_normal_init_parameters, set_forget_bias_to_one
-from .modules import make_non_pad_mask
+from .. import ops
+from .modules import make_non_pad_mask, subsampled_lengths
 from .rnn.encoders import encoder_for
 from .transducer.loss import TransLoss
 from .transducer.rnn_decoder import DecoderRNNT
@@ -105,12 +106,15 @@ class E2E(ASRInterface, torch.nn.Module):
         il = [int(v) for v in (ilens.tolist() if torch.is_tensor(ilens) else ilens)]
         xs_pad = xs_pad[:, : max(il)]
         if "transformer" in self.etype:
-            src_mask = make_non_pad_mask(il).to(xs_pad.device).unsqueeze(-2)
+            src_mask = ops.h2d_cached("src_mask", make_non_pad_mask(il).numpy(), xs_pad.device).unsqueeze(-2)
             hs_pad, hs_mask = self.encoder(xs_pad, src_mask)
+            # valid encoder frames: host arithmetic on the input lengths (two 3x3 / stride-2 convolutions,
+            # subsampling.py:52-59) instead of reading the device mask back
+            hs_mask = subsampled_lengths(il, xs_pad.shape[1])
         else:
             hs_pad, hs_mask, _ = self.enc(xs_pad, il)
         self.hs_pad = hs_pad
-        ys_in_pad, target, pred_len, target_len = prepare_loss_inputs(ys_pad, hs_mask)
+        ys_in_pad, target, pred_len, target_len = prepare_loss_inputs(ys_pad, hs_mask, device=xs_pad.device)
         pred_pad = self.dec(hs_pad, ys_in_pad)
         self.pred_pad = pred_pad
         self.loss = self.criterion(pred_pad, target, pred_len, target_len)

@@ -664,7 +664,9 @@ class CTC(torch.nn.Module):
         if isinstance(hlens, torch.Tensor):
             hl = hlens.to(device=hs_pad.device, dtype=torch.int32)
         else:
-            hl = torch.tensor([int(v) for v in hlens], dtype=torch.int32).to(hs_pad.device, non_blocking=True)
+            hl = ops.h2d_cached("ctclens", np.asarray([int(v) for v in hlens], dtype=np.int32), hs_pad.device)
+        if not ys_pad.is_cuda:     # host labels (kept on the host for the decoder's label parsing): cached upload
+            ys_pad = ops.h2d_cached("ctc_ys", ys_pad.numpy(), hs_pad.device)
         self.loss = F_.CTCLossFn.apply(ys_hat, ys_pad.contiguous(), hl, 0, self.ignore_id)
         return self.loss
 

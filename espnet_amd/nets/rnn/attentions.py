@@ -45,7 +45,7 @@ class AttLoc(torch.nn.Module):
             self.pre_compute_enc_h = F_.LinearFn.apply(self.enc_h, self.mlp_enc.weight, self.mlp_enc.bias)
             lens = np.asarray([int(v) for v in enc_hs_len], dtype=np.int32)
             self._lens_host = lens
-            self._lens = torch.from_numpy(lens).to(dev, non_blocking=True)
+            self._lens = ops.h2d_cached("attlens", lens, dev)
         if dec_z is None:
             dec_z = enc_hs_pad.new_zeros(batch, self.dunits)
         else:
@@ -53,7 +53,7 @@ class AttLoc(torch.nn.Module):
         if att_prev is None:
             # uniform over the valid frames (attentions.py:331-337); a constant, built on the host
             keep = (np.arange(self.h_length)[None, :] < self._lens_host[:, None]).astype(np.float32)
-            att_prev = torch.from_numpy(keep / self._lens_host[:, None].astype(np.float32)).to(dev, non_blocking=True)
+            att_prev = ops.h2d_cached("attuniform", keep / self._lens_host[:, None].astype(np.float32), dev)
         dec_proj = F_.LinearFn.apply(dec_z, self.mlp_dec.weight, None)
         c, w = R_.AttLocStepFn.apply(self.enc_h, self.pre_compute_enc_h, dec_proj, att_prev, self._lens, float(scaling),
                                      self.loc_conv.weight, self.mlp_att.weight, self.gvec.weight, self.gvec.bias)
@@ -85,8 +85,8 @@ class AttAdd(torch.nn.Module):
             self.enc_h = enc_hs_pad.contiguous()
             self.h_length = self.enc_h.size(1)
             self.pre_compute_enc_h = F_.LinearFn.apply(self.enc_h, self.mlp_enc.weight, self.mlp_enc.bias)
-            self._lens = torch.tensor([int(v) for v in enc_hs_len], dtype=torch.int32).to(enc_hs_pad.device,
-                                                                                          non_blocking=True)
+            self._lens = ops.h2d_cached("attlens", np.asarray([int(v) for v in enc_hs_len], dtype=np.int32),
+                                        enc_hs_pad.device)
         dec_z = enc_hs_pad.new_zeros(batch, self.dunits) if dec_z is None else dec_z.view(batch, self.dunits)
         dec_proj = F_.LinearFn.apply(dec_z, self.mlp_dec.weight, None)
         return R_.AttLocStepFn.apply(self.enc_h, self.pre_compute_enc_h, dec_proj, None, self._lens, float(scaling),
@@ -117,8 +117,8 @@ class AttDot(torch.nn.Module):
             self.h_length = self.enc_h.size(1)
             self.pre_compute_enc_h = R_.ActFn.apply(
                 F_.LinearFn.apply(self.enc_h, self.mlp_enc.weight, self.mlp_enc.bias), ops.ACT_TANH)
-            self._lens = torch.tensor([int(v) for v in enc_hs_len], dtype=torch.int32).to(enc_hs_pad.device,
-                                                                                          non_blocking=True)
+            self._lens = ops.h2d_cached("attlens", np.asarray([int(v) for v in enc_hs_len], dtype=np.int32),
+                                        enc_hs_pad.device)
         dec_z = enc_hs_pad.new_zeros(batch, self.dunits) if dec_z is None else dec_z.view(batch, self.dunits)
         q = R_.ActFn.apply(F_.LinearFn.apply(dec_z, self.mlp_dec.weight, self.mlp_dec.bias), ops.ACT_TANH)
         return R_.AttDotStepFn.apply(self.pre_compute_enc_h, q, self.enc_h, self._lens, float(scaling))
@@ -157,11 +157,11 @@ class _MultiHeadBase(torch.nn.Module):
             self.pre_compute_v = [F_.LinearFn.apply(self.enc_h, self.mlp_v[h].weight, None) for h in range(self.aheads)]
             lens = np.asarray([int(v) for v in enc_hs_len], dtype=np.int32)
             self._lens_host = lens
-            self._lens = torch.from_numpy(lens).to(enc_hs_pad.device, non_blocking=True)
+            self._lens = ops.h2d_cached("attlens", lens, enc_hs_pad.device)
 
     def _uniform(self, dev):
         keep = (np.arange(self.h_length)[None, :] < self._lens_host[:, None]).astype(np.float32)
-        return torch.from_numpy(keep / self._lens_host[:, None].astype(np.float32)).to(dev, non_blocking=True)
+        return ops.h2d_cached("attuniform", keep / self._lens_host[:, None].astype(np.float32), dev)
 
     def _head(self, h, dec_z, att_prev_h, scaling):
         raise NotImplementedError

@@ -75,14 +75,15 @@ class Decoder(torch.nn.Module):
     def forward(self, hs_pad, hlens, ys_pad, strm_idx=0, lang_ids=None):
         """hs_pad (B,T,D), hlens list[int], ys_pad (B,Lmax) padded with -1 -> (loss, acc, ppl)"""
         hlens = [int(v) for v in hlens]
-        ys = [y[y != self.ignore_id] for y in ys_pad.cpu()]       # host-side label parsing (decoders.py:167)
+        ys = [y[y != self.ignore_id] for y in ys_pad.cpu()]       # host-side label parsing (decoders.py:167);
+        # pass ys_pad as a CPU tensor to keep this free of a device->host sync (needed under hipGraph capture)
         eos = ys[0].new([self.eos])
         sos = ys[0].new([self.sos])
         ys_in = [torch.cat([sos, y], dim=0) for y in ys]
         ys_out = [torch.cat([y, eos], dim=0) for y in ys]
         dev = hs_pad.device
-        ys_in_pad = pad_list(ys_in, self.eos).to(dev, non_blocking=True)
-        ys_out_pad = pad_list(ys_out, self.ignore_id).to(dev, non_blocking=True)
+        ys_in_pad = ops.h2d_cached("ys_in", pad_list(ys_in, self.eos).numpy(), dev)
+        ys_out_pad = ops.h2d_cached("ys_out", pad_list(ys_out, self.ignore_id).numpy(), dev)
         batch, olength = ys_out_pad.size(0), ys_out_pad.size(1)
         c_list = [self.zero_state(hs_pad) for _ in range(self.dlayers)]
         z_list = [self.zero_state(hs_pad) for _ in range(self.dlayers)]

@@ -35,8 +35,10 @@ class LSTM(torch.nn.Module):
         B = xs_pad.shape[0]
         T = int(max(ilens))
         x_tm = xs_pad[:, :T].transpose(0, 1).contiguous()                   # time-major for per-frame views
-        live = torch.from_numpy((np.arange(T)[:, None] < np.asarray(ilens)[None, :]).astype(np.uint8))
-        live = live.to(xs_pad.device, non_blocking=True) if min(ilens) < T else None
+        live = None
+        if min(ilens) < T:
+            live = ops.h2d_cached("live", (np.arange(T)[:, None] < np.asarray(ilens)[None, :]).astype(np.uint8),
+                                  xs_pad.device)
         outs = []
         for sfx, rev in (("", False),) + ((("_reverse", True),) if self.bidirectional else ()):
             gx = F_.LinearFn.apply(x_tm, getattr(self, "weight_ih_l0" + sfx), getattr(self, "bias_ih_l0" + sfx))
@@ -103,8 +105,10 @@ class RNN(torch.nn.Module):
         B = xs_pad.shape[0]
         T = int(max(ilens))
         x = xs_pad[:, :T].transpose(0, 1).contiguous()
-        live = torch.from_numpy((np.arange(T)[:, None] < np.asarray(ilens)[None, :]).astype(np.uint8))
-        live = live.to(xs_pad.device, non_blocking=True) if min(ilens) < T else None
+        live = None
+        if min(ilens) < T:
+            live = ops.h2d_cached("live", (np.arange(T)[:, None] < np.asarray(ilens)[None, :]).astype(np.uint8),
+                                  xs_pad.device)
         for k in range(self.elayers):
             outs = []
             for sfx, rev in (("", False),) + ((("_reverse", True),) if self.bidir else ()):
@@ -171,7 +175,7 @@ class Encoder(torch.nn.Module):
         for module in self.enc:
             xs_pad, ilens, _ = module(xs_pad, ilens)
         # encoders.py:323-325: zero the padded frames (projection biases leak into them otherwise)
-        keep = (~make_pad_mask(ilens, xs_pad.shape[1])).to(xs_pad.device).unsqueeze(-1)
+        keep = ops.h2d_cached("keep", ~make_pad_mask(ilens, xs_pad.shape[1]).numpy(), xs_pad.device).unsqueeze(-1)
         return F_.MaskRowsFn.apply(xs_pad, keep), ilens, None
 
 

@@ -4,11 +4,11 @@ import torch
 from ..modules import pad_list
 
 
-def prepare_loss_inputs(ys_pad, hlens, blank_id=0, ignore_id=-1):
+def prepare_loss_inputs(ys_pad, hlens, blank_id=0, ignore_id=-1, device=None):
     """-> ys_in_pad (B,Lmax+1) int64 blank-prefixed, target (B,Lmax) int32, pred_len (B) int32, target_len (B) int32.
     Integer / host work exactly as in the reference (per-utterance Python loops, utils.py:28-51);
     hlens: lengths (list / 1-D tensor) or a (B,1,Tmax) mask."""
-    device = ys_pad.device
+    device = ys_pad.device if device is None else torch.device(device)
     ys_cpu = ys_pad.cpu()
     ys = [y[y != ignore_id] for y in ys_cpu]
     blank = ys[0].new([blank_id])
@@ -24,5 +24,8 @@ def prepare_loss_inputs(ys_pad, hlens, blank_id=0, ignore_id=-1):
     else:
         hlens = [int(v) for v in hlens]
     pred_len = torch.IntTensor(hlens)
-    return (ys_in_pad.to(device, non_blocking=True), target.to(device, non_blocking=True),
-            pred_len.to(device, non_blocking=True), target_len.to(device, non_blocking=True))
+    if device.type != "cuda":
+        return ys_in_pad, target, pred_len, target_len
+    from ... import ops
+    return (ops.h2d_cached("rnnt_ys_in", ys_in_pad.numpy(), device), ops.h2d_cached("rnnt_target", target.numpy(), device),
+            ops.h2d_cached("rnnt_tlen", pred_len.numpy(), device), ops.h2d_cached("rnnt_ulen", target_len.numpy(), device))

@@ -56,6 +56,19 @@ class PlainEmbedFn(torch.autograd.Function):
 # recurrent weight gradient of all frames into a single GEMM.
 # live[T,B] uint8 reproduces pack_padded_sequence: finished sequences keep their state, emit zeros.
 # =================================================================================================
+def _rec_gemm(a, w, out, M, N, K, lda, ldb, ldc, *, transB=0, bias=None, R=None, ldr=0):
+    """recurrent-step product with a handful of rows (M = batch): one row of 64-wide tiles leaves most CUs idle and
+    each tile walks the whole reduction alone, so the reduction is split across workgroups (f32 atomics into the
+    zeroed result; bias / R are added by the leading split)"""
+    tiles = ((M + 63) // 64) * ((N + 63) // 64)
+    sk = 1
+    while tiles * sk < 512 and K // (sk * 2) >= 128:
+        sk *= 2
+    if sk > 1:
+        out.zero_()
+    ops.gemm(a, w, out, M, N, K, lda, ldb, ldc, transB=transB, bias=bias, R=R, ldr=ldr, splitk=sk)
+
+
 class LSTMSeqFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, gx, w_hh, b_hh, live, reverse):
@@ -71,7 +84,7 @@ class LSTMSeqFn(torch.autograd.Function):
         gates = torch.empty(B, H4, device=dev, dtype=torch.float32)
         hp, cp = zero, zero
         for t in (range(T - 1, -1, -1) if reverse else range(T)):
-            ops.gemm(hp, w_hh, gates, B, H4, H, H, H, H4, bias=b_hh, R=gx[t], ldr=H4)
+            _rec_gemm(hp, w_hh, gates, B, H4, H, H, H, H4, bias=b_hh, R=gx[t], ldr=H4)
             ops.lstm_cell_fwd(gates, cp, hp, None if live is None else live[t], h_out[t], c_out[t], y[t], acts[t])
             hp, cp = h_out[t], c_out[t]
         ctx.save_for_backward(h_out, c_out, acts, zero, live if live is not None else zero)
@@ -101,7 +114,7 @@ class LSTMSeqFn(torch.autograd.Function):
                               dc_new, dh_pass)
             if has_prev:
                 dh = torch.empty(B, H, device=dev, dtype=torch.float32)
-                ops.gemm(dgates[t], w_hh, dh, B, H, H4, H4, H, H, transB=1, R=dh_pass, ldr=H)
+                _rec_gemm(dgates[t], w_hh, dh, B, H, H4, H4, H, H, transB=1, R=dh_pass, ldr=H)
             dc = dc_new
         if T > 1:
             dg, hp = (dgates[:-1], h_out[1:]) if reverse else (dgates[1:], h_out[:-1])
@@ -121,7 +134,7 @@ class LSTMCellFn(torch.autograd.Function):
         dev = gx.device
         gx, h_prev, c_prev = gx.contiguous(), h_prev.contiguous(), c_prev.contiguous()
         gates = torch.empty(B, H4, device=dev, dtype=torch.float32)
-        ops.gemm(h_prev, w_hh, gates, B, H4, H, H, H, H4, bias=b_hh, R=gx, ldr=H4)
+        _rec_gemm(h_prev, w_hh, gates, B, H4, H, H, H, H4, bias=b_hh, R=gx, ldr=H4)
         h = torch.empty(B, H, device=dev, dtype=torch.float32)
         c = torch.empty(B, H, device=dev, dtype=torch.float32)
         acts = gates                                       # activated gates overwrite the pre-activations
@@ -143,7 +156,7 @@ class LSTMCellFn(torch.autograd.Function):
         ops.lstm_cell_bwd(None, dh.contiguous() if dh is not None else None, dc.contiguous() if dc is not None else None,
                           acts, c_prev, c, None, dgates, dc_prev, None)
         dh_prev = torch.empty(B, H, device=dev, dtype=torch.float32)
-        ops.gemm(dgates, w_hh, dh_prev, B, H, H4, H4, H, H, transB=1)
+        _rec_gemm(dgates, w_hh, dh_prev, B, H, H4, H4, H, H, transB=1)
         ops.linear_bwd_w(dgates, h_prev, sink.buf(0), db=sink.buf(1))
         return (dgates, dh_prev, dc_prev) + sink.results()
 

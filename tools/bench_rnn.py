@@ -16,19 +16,45 @@ import espnet_amd  # noqa: E402
 DEV = "cuda"
 
 
-def run(name, model, xs, ilens, ys, steps=3):
+def run(name, model, xs, ilens, ys, steps=3, graph=True):
+    from espnet_amd import train
     model = model.to(DEV).train()
     nparam = sum(p.numel() for p in model.parameters())
+    flat = train.FlatParams(model)          # gradients accumulate into the flat arena (one memset per step)
+    ys = ys.cpu()                           # labels are parsed on the host (as in the reference): no device sync
     times = []
-    for i in range(steps):
-        for p in model.parameters():
-            p.grad = None
-        torch.cuda.synchronize()
-        t0 = time.perf_counter()
+
+    def step():
+        flat.zero_grad()
         loss = model(xs, ilens, ys)
         loss.backward()
+        return loss
+
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        for i in range(2):
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            loss = step()
+            torch.cuda.synchronize()
+            times.append(time.perf_counter() - t0)
+    torch.cuda.current_stream().wait_stream(side)
+    eager = min(times)
+    if graph:
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g):
+            loss = step()
         torch.cuda.synchronize()
-        times.append(time.perf_counter() - t0)
+        times = []
+        for i in range(steps):
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            g.replay()
+            torch.cuda.synchronize()
+            times.append(time.perf_counter() - t0)
+    flat.expose_grads()
+    name = name + (" [hipGraph replay; eager %.1f ms]" % (eager * 1e3) if graph else " [eager]")
     gn = math.sqrt(sum(float((p.grad.double() ** 2).sum()) for p in model.parameters() if p.grad is not None))
     frames = int(sum(ilens))
     print("%s: params %.1fM loss %.4f gradnorm %.4f step %.1f ms (best of %d) -> %.0f frames/s, peak mem %.1f GB" %
