@@ -244,4 +244,24 @@ int eamd_rnnt_loss(const float* logits, const int32_t* labels, const int32_t* tl
   return EAMD_OK;
 }
 
+/* gradient pass alone, from the workspace a previous eamd_rnnt_loss call on the same logits filled (lets the caller
+ * fold the upstream scalar, read from device memory, into this pass instead of rescaling 4*B*T*U*V bytes later) */
+int eamd_rnnt_grad(const float* logits, const int32_t* labels, const int32_t* tlens, const int32_t* ulens,
+                   const float* workspace, float* grad, int B, int T, int U, int V, int blank, const float* gscale_dev,
+                   float scale, void* stream) {
+  if (!logits || !labels || !tlens || !ulens || !workspace || !grad || B <= 0 || T <= 0 || U <= 0 || V <= 1)
+    return EAMD_EINVAL;
+  if (blank < 0 || blank >= V || (long)B * T * U > 2147483647L) return EAMD_EINVAL;
+  const long n = (long)B * T * U;
+  const float* lse = workspace;
+  const float* lpb = lse + n;
+  const float* lpl = lpb + n;
+  const float* alpha = lpl + n;
+  const float* beta = alpha + n;
+  hipLaunchKernelGGL(rnnt_grad_kernel, dim3((unsigned)n), dim3(256), 0, (hipStream_t)stream, logits, grad, labels, lse, lpb,
+                     lpl, alpha, beta, tlens, ulens, gscale_dev, scale, T, U, V, blank);
+  EAMD_LAUNCH_CHECK();
+  return EAMD_OK;
+}
+
 }  // extern "C"

@@ -732,7 +732,18 @@ def joint_bwd(dh, enc, dec, act):
     return d_enc, d_dec
 
 
-def rnnt_loss(logits, labels, tlens, ulens, blank, grad=None, gscale=None, scale=1.0):
+def rnnt_grad(logits, labels, tlens, ulens, blank, ws, gscale, scale, grad=None):
+    """d loss / d logits from the lattice workspace `ws` of a previous rnnt_loss(..., return_ws=True) call;
+    gscale: 0-dim / 1-element device tensor multiplied in (the upstream gradient of the scalar loss)"""
+    B, T, U, V = logits.shape
+    grad = torch.empty_like(logits) if grad is None else grad
+    lab = labels if labels.numel() > 0 else torch.zeros(1, device=logits.device, dtype=torch.int32)
+    check(_lib.lib().eamd_rnnt_grad(ptr(logits), ptr(lab), ptr(tlens), ptr(ulens), ptr(ws), ptr(grad), B, T, U, V, blank,
+                                    ptr(gscale), C.c_float(scale), stream_ptr()), "eamd_rnnt_grad")
+    return grad
+
+
+def rnnt_loss(logits, labels, tlens, ulens, blank, grad=None, gscale=None, scale=1.0, return_ws=False):
     """logits [B,T,U,V] fp32; labels [B,U-1] int32; tlens/ulens [B] int32 -> per-utterance loss [B]"""
     B, T, U, V = logits.shape
     assert logits.dtype == torch.float32 and logits.is_contiguous()
@@ -744,7 +755,7 @@ def rnnt_loss(logits, labels, tlens, ulens, blank, grad=None, gscale=None, scale
     lab = labels if labels.numel() > 0 else torch.zeros(1, device=logits.device, dtype=torch.int32)
     check(_lib.lib().eamd_rnnt_loss(ptr(logits), ptr(lab), ptr(tlens), ptr(ulens), ptr(ws), ptr(loss), ptr(grad),
                                     B, T, U, V, blank, ptr(gscale), C.c_float(scale), stream_ptr()), "eamd_rnnt_loss")
-    return loss
+    return (loss, ws) if return_ws else loss
 
 
 def attloc_fwd(att_prev, conv_w, w_att, pre_enc, dec_proj, gvec, gb, lens, enc_h, scaling):

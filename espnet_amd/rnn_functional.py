@@ -327,20 +327,23 @@ class JointFn(torch.autograd.Function):
 
 class RNNTLossFn(torch.autograd.Function):
     """mean_b -log P(y_b | x_b) on raw joint logits [B,T,U,V] (transducer/loss.py:74-76: warp-transducer
-    RNNTLoss(blank), default reduction = mean over the batch).  The gradient is produced by the same
-    launch sequence as the loss and only rescaled by the upstream scalar in backward."""
+    RNNTLoss(blank), default reduction = mean over the batch).  Forward fills the lattice workspace (lse, the two
+    log-probabilities per node, alpha, beta); backward is ONE pass over the logits that writes the gradient with
+    the upstream scalar (read on the device) already folded in."""
 
     @staticmethod
     def forward(ctx, logits, labels, tlens, ulens, blank):
         B = logits.shape[0]
         logits = logits.contiguous()
-        grad = torch.empty_like(logits) if logits.requires_grad else None
-        nll = ops.rnnt_loss(logits, labels, tlens, ulens, blank, grad=grad, scale=1.0 / B)
-        ctx.save_for_backward(grad)
+        nll, ws = ops.rnnt_loss(logits, labels, tlens, ulens, blank, return_ws=True)
+        ctx.save_for_backward(logits, labels, tlens, ulens, ws)
+        ctx.blank = blank
         ctx.nll = nll
         return ops.reduce_sum(nll, 1.0 / B)
 
     @staticmethod
     def backward(ctx, g):
-        (grad,) = ctx.saved_tensors
-        return ops.scale_dev(grad, g.contiguous(), 1.0, out=grad), None, None, None, None
+        logits, labels, tlens, ulens, ws = ctx.saved_tensors
+        B = logits.shape[0]
+        grad = ops.rnnt_grad(logits, labels, tlens, ulens, ctx.blank, ws, g.reshape(1).contiguous(), 1.0 / B)
+        return grad, None, None, None, None

@@ -310,6 +310,10 @@ int64_t eamd_rnnt_workspace(int B, int T, int U);
 int eamd_rnnt_loss(const float* logits, const int32_t* labels, const int32_t* tlens, const int32_t* ulens,
                    float* workspace, float* loss, float* grad, int B, int T, int U, int V, int blank,
                    const float* gscale_dev, float scale, void* stream);
+/* the gradient pass alone, reusing the workspace an eamd_rnnt_loss call (grad = NULL) filled for the same logits */
+int eamd_rnnt_grad(const float* logits, const int32_t* labels, const int32_t* tlens, const int32_t* ulens,
+                   const float* workspace, float* grad, int B, int T, int U, int V, int blank, const float* gscale_dev,
+                   float scale, void* stream);
 
 /* ------------------------------------------------------------------------------------------
  * Optimizer on flat fp32 arenas.  reference: transformer/optimizer.py:12-75 (NoamOpt),
