@@ -243,11 +243,12 @@ class GraphedDataParallelStep:
                 opt.step()
         torch.cuda.current_stream().wait_stream(side)
         torch.cuda.synchronize()
+        # thread_local: the communicator's watchdog thread may query its events while we capture
         self.graph_a = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(self.graph_a):
+        with torch.cuda.graph(self.graph_a, capture_error_mode="thread_local"):
             self.loss = self._fwd_bwd()
         self.graph_b = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(self.graph_b):
+        with torch.cuda.graph(self.graph_b, capture_error_mode="thread_local"):
             opt.step()
 
     def _fwd_bwd(self):
