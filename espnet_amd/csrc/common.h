@@ -64,14 +64,29 @@ __device__ __forceinline__ unsigned short eamd_f2bf(float f) {
   return __builtin_bit_cast(unsigned short, b);
 }
 
+// Wave-wide reductions (result in every lane).  The four steps inside a 16-lane row are DPP modifiers on the
+// VALU operand (quad_perm, row_half_mirror, row_mirror: no LDS crossbar trip), only the two cross-row steps go
+// through ds_bpermute; the plain six-step __shfl_xor butterfly spends ~6 dependent LDS round trips per reduction.
+template <int CTRL>
+__device__ __forceinline__ float eamd_dpp(float v) {
+  return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xf, 0xf, true));
+}
 __device__ __forceinline__ float wave_sum(float v) {
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  v += eamd_dpp<0xB1>(v);      // quad_perm [1,0,3,2]
+  v += eamd_dpp<0x4E>(v);      // quad_perm [2,3,0,1]
+  v += eamd_dpp<0x141>(v);     // row_half_mirror
+  v += eamd_dpp<0x140>(v);     // row_mirror  -> every lane holds its 16-lane row sum
+  v += __shfl_xor(v, 16, 64);
+  v += __shfl_xor(v, 32, 64);
   return v;
 }
 __device__ __forceinline__ float wave_max(float v) {
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+  v = fmaxf(v, eamd_dpp<0xB1>(v));
+  v = fmaxf(v, eamd_dpp<0x4E>(v));
+  v = fmaxf(v, eamd_dpp<0x141>(v));
+  v = fmaxf(v, eamd_dpp<0x140>(v));
+  v = fmaxf(v, __shfl_xor(v, 16, 64));
+  v = fmaxf(v, __shfl_xor(v, 32, 64));
   return v;
 }
 

@@ -88,7 +88,7 @@ __global__ __launch_bounds__(256) void layernorm_fwd_vec_kernel(const float* __r
 // across the 4 waves through LDS and added to global with one atomic per column per block.
 // Lane l owns columns {4l..4l+3} + 256j (float4 accesses) when D % 256 == 0, else {l + 64c}.
 template <int VEC>   // VEC = D/256 for the vector form, 0 = generic (D <= 1024)
-__global__ __launch_bounds__(256) void layernorm_bwd_kernel(
+__global__ __launch_bounds__(1024) void layernorm_bwd_kernel(
     const float* __restrict__ dy, const float* __restrict__ x, const float* __restrict__ gamma,
     const float* __restrict__ mean, const float* __restrict__ rstd, const float* dres, float* dx,
     float* __restrict__ dgamma, float* __restrict__ dbeta, float* __restrict__ ws, int rows, int D,
@@ -108,8 +108,9 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(
     }
     // two rows per trip, every operand of both rows (dy, x, residual gradient) requested before the first use:
     // one memory round trip per pair instead of two dependent ones per row
-    for (int row = r0 + wave; row < r1; row += 8) {
-      const int row2 = row + 4;
+    const int nw = blockDim.x >> 6;
+    for (int row = r0 + wave; row < r1; row += 2 * nw) {
+      const int row2 = row + nw;
       const bool two = row2 < r1;
       const int rb = two ? row2 : row;          // second row falls back to the first (results discarded)
       float4 d4[2][VEC], xv[2][VEC], rv[2][VEC];
@@ -168,7 +169,7 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(
     float ag[MAXC], ab[MAXC];
 #pragma unroll
     for (int c = 0; c < MAXC; ++c) { ag[c] = 0.f; ab[c] = 0.f; }
-    for (int row = r0 + wave; row < r1; row += 4) {
+    for (int row = r0 + wave; row < r1; row += (int)(blockDim.x >> 6)) {
       const float* dyr = dy + (long)row * D;
       const float* xr = x + (long)row * D;
       const float mu = mean[row], rs = rstd[row];
@@ -498,17 +499,18 @@ int eamd_layernorm_bwd(const float* dy, const float* x, const float* gamma, cons
   ln_bwd_grid(rows, &nblk, &rpb);
   static const int ws_min = [] { const char* e = getenv("EAMD_LNB_WS_MIN"); return e ? atoi(e) : 32; }();
   float* ws = nblk >= ws_min ? workspace : nullptr;   // few blocks: direct atomics are cheaper than a second launch
+  static const int nthr = [] { const char* e = getenv("EAMD_LNB_THREADS"); return e ? atoi(e) : 256; }();
   const bool al = (((uintptr_t)dy | (uintptr_t)x | (uintptr_t)gamma | (uintptr_t)dx | (uintptr_t)dres) & 15) == 0;
   hipStream_t s = (hipStream_t)stream;
   size_t sm = 2 * D * sizeof(float);
   if (al && D == 256)
-    hipLaunchKernelGGL(layernorm_bwd_kernel<1>, dim3(nblk), dim3(256), sm, s, dy, x, gamma, mean, rstd, dres, dx,
+    hipLaunchKernelGGL(layernorm_bwd_kernel<1>, dim3(nblk), dim3(nthr), sm, s, dy, x, gamma, mean, rstd, dres, dx,
                        dgamma, dbeta, ws, rows, D, rpb);
   else if (al && D == 512)
-    hipLaunchKernelGGL(layernorm_bwd_kernel<2>, dim3(nblk), dim3(256), sm, s, dy, x, gamma, mean, rstd, dres, dx,
+    hipLaunchKernelGGL(layernorm_bwd_kernel<2>, dim3(nblk), dim3(nthr), sm, s, dy, x, gamma, mean, rstd, dres, dx,
                        dgamma, dbeta, ws, rows, D, rpb);
   else
-    hipLaunchKernelGGL(layernorm_bwd_kernel<0>, dim3(nblk), dim3(256), sm, s, dy, x, gamma, mean, rstd, dres, dx,
+    hipLaunchKernelGGL(layernorm_bwd_kernel<0>, dim3(nblk), dim3(nthr), sm, s, dy, x, gamma, mean, rstd, dres, dx,
                        dgamma, dbeta, ws, rows, D, rpb);
   EAMD_LAUNCH_CHECK();
   if (ws) {
