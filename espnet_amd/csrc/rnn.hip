@@ -71,6 +71,62 @@ __global__ __launch_bounds__(256) void lstm_bwd_kernel(const float* __restrict__
   }
 }
 
+// ---- GRU step (torch.nn.GRU / GRUCell, gate order r, z, n) ------------------------------------------------
+// gx = x W_ih^T + b_ih [B,3H], gh = h W_hh^T + b_hh [B,3H]:
+//   r = sig(gx_r + gh_r), z = sig(gx_z + gh_z), n = tanh(gx_n + r * gh_n), h' = (1 - z) * n + z * h
+// acts [B,4H] keeps r, z, n, gh_n for the backward.  live as in the LSTM step.
+__global__ __launch_bounds__(256) void gru_fwd_kernel(const float* __restrict__ gx, const float* __restrict__ gh,
+                                                      const float* __restrict__ h_prev,
+                                                      const unsigned char* __restrict__ live, float* __restrict__ h,
+                                                      float* __restrict__ y, float* __restrict__ acts, int B, int H) {
+  const long n_ = (long)B * H;
+  for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < n_; idx += (long)gridDim.x * blockDim.x) {
+    const int b = idx / H, j = idx % H;
+    const float* xb = gx + (long)b * 3 * H;
+    const float* hb = gh + (long)b * 3 * H;
+    const float r = sigm(xb[j] + hb[j]), z = sigm(xb[H + j] + hb[H + j]);
+    const float ghn = hb[2 * H + j];
+    const float nn = tanhf(xb[2 * H + j] + r * ghn);
+    const float hp = h_prev[idx];
+    float hn = (1.f - z) * nn + z * hp;
+    float yo = hn;
+    if (live && !live[b]) { hn = hp; yo = 0.f; }
+    h[idx] = hn;
+    if (y) y[idx] = yo;
+    float* ab = acts + (long)b * 4 * H;
+    ab[j] = r; ab[H + j] = z; ab[2 * H + j] = nn; ab[3 * H + j] = ghn;
+  }
+}
+// dy / dh as in lstm_bwd_kernel.  dgx, dgh [B,3H]; dh_direct [B,H] = share of the gradient that reaches h_prev
+// without passing through W_hh (z * dh', or everything for a masked row)
+__global__ __launch_bounds__(256) void gru_bwd_kernel(const float* __restrict__ dy, const float* __restrict__ dh,
+                                                      const float* __restrict__ acts, const float* __restrict__ h_prev,
+                                                      const unsigned char* __restrict__ live, float* __restrict__ dgx,
+                                                      float* __restrict__ dgh, float* __restrict__ dh_direct, int B,
+                                                      int H) {
+  const long n_ = (long)B * H;
+  for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < n_; idx += (long)gridDim.x * blockDim.x) {
+    const int b = idx / H, j = idx % H;
+    float* xb = dgx + (long)b * 3 * H;
+    float* hb = dgh + (long)b * 3 * H;
+    const float dhr = dh ? dh[idx] : 0.f;
+    if (live && !live[b]) {
+      xb[j] = 0.f; xb[H + j] = 0.f; xb[2 * H + j] = 0.f; hb[j] = 0.f; hb[H + j] = 0.f; hb[2 * H + j] = 0.f;
+      dh_direct[idx] = dhr;
+      continue;
+    }
+    const float d = dhr + (dy ? dy[idx] : 0.f);
+    const float* ab = acts + (long)b * 4 * H;
+    const float r = ab[j], z = ab[H + j], nn = ab[2 * H + j], ghn = ab[3 * H + j];
+    const float dn_pre = d * (1.f - z) * (1.f - nn * nn);
+    const float dz_pre = d * (h_prev[idx] - nn) * z * (1.f - z);
+    const float dr_pre = dn_pre * ghn * r * (1.f - r);
+    xb[j] = dr_pre; xb[H + j] = dz_pre; xb[2 * H + j] = dn_pre;
+    hb[j] = dr_pre; hb[H + j] = dz_pre; hb[2 * H + j] = dn_pre * r;
+    dh_direct[idx] = d * z;
+  }
+}
+
 // ---- 2x2 / stride-2 max pooling with ceil_mode on NHWC activations (VGG2L, encoders.py:205,208) ----
 // x [B, H, W, C] -> y [B, ceil(H/2), ceil(W/2), C]; idx keeps the winning input offset (0..3) for backward
 __global__ void maxpool_fwd_kernel(const float* __restrict__ x, float* __restrict__ y, unsigned char* __restrict__ idx,
@@ -340,6 +396,24 @@ int eamd_lstm_cell_bwd(const float* dy, const float* dh, const float* dc, const 
   if (live && !dh_pass) return EAMD_EINVAL;
   hipLaunchKernelGGL(lstm_bwd_kernel, dim3(grid_for((long)B * H)), dim3(256), 0, (hipStream_t)stream, dy, dh, dc, acts,
                      c_prev, c, live, dgates, dc_prev, dh_pass, B, H);
+  EAMD_LAUNCH_CHECK();
+  return EAMD_OK;
+}
+
+int eamd_gru_cell_fwd(const float* gx, const float* gh, const float* h_prev, const uint8_t* live, float* h, float* y,
+                      float* acts, int B, int H, void* stream) {
+  if (!gx || !gh || !h_prev || !h || !acts || B <= 0 || H <= 0) return EAMD_EINVAL;
+  hipLaunchKernelGGL(gru_fwd_kernel, dim3(grid_for((long)B * H)), dim3(256), 0, (hipStream_t)stream, gx, gh, h_prev, live, h,
+                     y, acts, B, H);
+  EAMD_LAUNCH_CHECK();
+  return EAMD_OK;
+}
+
+int eamd_gru_cell_bwd(const float* dy, const float* dh, const float* acts, const float* h_prev, const uint8_t* live,
+                      float* dgx, float* dgh, float* dh_direct, int B, int H, void* stream) {
+  if ((!dy && !dh) || !acts || !h_prev || !dgx || !dgh || !dh_direct || B <= 0 || H <= 0) return EAMD_EINVAL;
+  hipLaunchKernelGGL(gru_bwd_kernel, dim3(grid_for((long)B * H)), dim3(256), 0, (hipStream_t)stream, dy, dh, acts, h_prev,
+                     live, dgx, dgh, dh_direct, B, H);
   EAMD_LAUNCH_CHECK();
   return EAMD_OK;
 }

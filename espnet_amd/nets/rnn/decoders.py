@@ -29,6 +29,23 @@ class LSTMCell(torch.nn.Module):
         return R_.LSTMCellFn.apply(gx, h, c, self.weight_hh, self.bias_hh)
 
 
+class GRUCell(torch.nn.Module):
+    """parameter container with torch.nn.GRUCell's names; forward(x, h) -> h'"""
+
+    def __init__(self, input_size, hidden_size):
+        super().__init__()
+        k = 1.0 / math.sqrt(hidden_size)
+        self.input_size, self.hidden_size = input_size, hidden_size
+        self.weight_ih = torch.nn.Parameter(torch.empty(3 * hidden_size, input_size).uniform_(-k, k))
+        self.weight_hh = torch.nn.Parameter(torch.empty(3 * hidden_size, hidden_size).uniform_(-k, k))
+        self.bias_ih = torch.nn.Parameter(torch.empty(3 * hidden_size).uniform_(-k, k))
+        self.bias_hh = torch.nn.Parameter(torch.empty(3 * hidden_size).uniform_(-k, k))
+
+    def forward(self, x, h):
+        gx = F_.LinearFn.apply(x, self.weight_ih, self.bias_ih)
+        return R_.GRUCellFn.apply(gx, h, self.weight_hh, self.bias_hh)
+
+
 class Decoder(torch.nn.Module):
     """reference: rnn/decoders.py:28-311"""
 
@@ -36,15 +53,15 @@ class Decoder(torch.nn.Module):
                  labeldist=None, lsm_weight=0.0, sampling_probability=0.0, dropout=0.0, context_residual=False,
                  replace_sos=False, num_encs=1):
         super().__init__()
-        if dtype != "lstm":
-            raise NotImplementedError("dtype %r: only lstm decoders have HIP kernels" % dtype)
+        if dtype not in ("lstm", "gru"):
+            raise NotImplementedError("dtype %r: lstm and gru decoders have HIP kernels" % dtype)
         if num_encs != 1 or replace_sos or labeldist is not None or sampling_probability > 0.0:
             raise NotImplementedError("multi-encoder / replace_sos / label-dist smoothing / scheduled sampling "
                                       "are outside the hot-path scope")
         self.dtype, self.dunits, self.dlayers, self.context_residual = dtype, dunits, dlayers, context_residual
         self.embed = torch.nn.Embedding(odim, dunits)
-        self.decoder = torch.nn.ModuleList([LSTMCell(dunits + eprojs, dunits)] +
-                                           [LSTMCell(dunits, dunits) for _ in range(1, dlayers)])
+        cell = LSTMCell if dtype == "lstm" else GRUCell
+        self.decoder = torch.nn.ModuleList([cell(dunits + eprojs, dunits)] + [cell(dunits, dunits) for _ in range(1, dlayers)])
         self.ignore_id = -1
         self.output = torch.nn.Linear(dunits + eprojs if context_residual else dunits, odim)
         self.loss = None
@@ -67,9 +84,14 @@ class Decoder(torch.nn.Module):
         return F_.dropout(x, self.dropout, self.salts[k] + 131 * (step + 1), self.training)
 
     def rnn_forward(self, ey, z_list, c_list, z_prev, c_prev, step=0):
-        z_list[0], c_list[0] = self.decoder[0](ey, (z_prev[0], c_prev[0]))
-        for i in range(1, self.dlayers):
-            z_list[i], c_list[i] = self.decoder[i](self._drop(i - 1, z_list[i - 1], step), (z_prev[i], c_prev[i]))
+        if self.dtype == "lstm":
+            z_list[0], c_list[0] = self.decoder[0](ey, (z_prev[0], c_prev[0]))
+            for i in range(1, self.dlayers):
+                z_list[i], c_list[i] = self.decoder[i](self._drop(i - 1, z_list[i - 1], step), (z_prev[i], c_prev[i]))
+        else:
+            z_list[0] = self.decoder[0](ey, z_prev[0])
+            for i in range(1, self.dlayers):
+                z_list[i] = self.decoder[i](self._drop(i - 1, z_list[i - 1], step), z_prev[i])
         return z_list, c_list
 
     def forward(self, hs_pad, hlens, ys_pad, strm_idx=0, lang_ids=None):

@@ -14,17 +14,21 @@ from ..modules import make_pad_mask
 
 
 class LSTM(torch.nn.Module):
-    """single-layer (bi)directional LSTM, batch_first, on padded batches + lengths (what
-    pack_padded_sequence -> torch.nn.LSTM -> pad_packed_sequence computes, encoders.py:62-71)."""
+    """single-layer (bi)directional LSTM (gates = 4) or GRU (gates = 3), batch_first, on padded batches + lengths
+    (what pack_padded_sequence -> torch.nn.LSTM / GRU -> pad_packed_sequence computes, encoders.py:62-71)."""
+
+    gates = 4
+    seq_fn = R_.LSTMSeqFn
 
     def __init__(self, input_size, hidden_size, bidirectional=False):
         super().__init__()
         self.input_size, self.hidden_size, self.bidirectional = input_size, hidden_size, bidirectional
         k = 1.0 / math.sqrt(hidden_size)
+        g = self.gates
         for sfx in ([""] + (["_reverse"] if bidirectional else [])):
-            for name, shape in (("weight_ih_l0", (4 * hidden_size, input_size)),
-                                ("weight_hh_l0", (4 * hidden_size, hidden_size)),
-                                ("bias_ih_l0", (4 * hidden_size,)), ("bias_hh_l0", (4 * hidden_size,))):
+            for name, shape in (("weight_ih_l0", (g * hidden_size, input_size)),
+                                ("weight_hh_l0", (g * hidden_size, hidden_size)),
+                                ("bias_ih_l0", (g * hidden_size,)), ("bias_hh_l0", (g * hidden_size,))):
                 self.register_parameter(name + sfx, torch.nn.Parameter(torch.empty(shape).uniform_(-k, k)))
 
     def flatten_parameters(self):
@@ -42,15 +46,22 @@ class LSTM(torch.nn.Module):
         outs = []
         for sfx, rev in (("", False),) + ((("_reverse", True),) if self.bidirectional else ()):
             gx = F_.LinearFn.apply(x_tm, getattr(self, "weight_ih_l0" + sfx), getattr(self, "bias_ih_l0" + sfx))
-            outs.append(R_.LSTMSeqFn.apply(gx, getattr(self, "weight_hh_l0" + sfx), getattr(self, "bias_hh_l0" + sfx),
-                                           live, rev))
+            outs.append(self.seq_fn.apply(gx, getattr(self, "weight_hh_l0" + sfx), getattr(self, "bias_hh_l0" + sfx),
+                                          live, rev))
         y = outs[0] if len(outs) == 1 else torch.cat(outs, dim=-1)
         return y.transpose(0, 1).contiguous()
 
 
+class GRU(LSTM):
+    """torch.nn.GRU counterpart (gate order r, z, n)"""
+
+    gates = 3
+    seq_fn = R_.GRUSeqFn
+
+
 def _lstm_or_raise(typ):
-    if "lstm" not in typ:
-        raise NotImplementedError("etype %r: only (b)lstm(p) encoders have HIP kernels (GRU: SURVEY.md 8f)" % typ)
+    if "lstm" not in typ and "gru" not in typ:
+        raise NotImplementedError("etype %r: lstm / gru recurrent layers are on the HIP path" % typ)
 
 
 class RNNP(torch.nn.Module):
@@ -62,7 +73,8 @@ class RNNP(torch.nn.Module):
         bidir = typ[0] == "b"
         for i in range(elayers):
             inputdim = idim if i == 0 else hdim
-            setattr(self, "%s%d" % ("birnn" if bidir else "rnn", i), LSTM(inputdim, cdim, bidirectional=bidir))
+            cls = LSTM if "lstm" in typ else GRU
+            setattr(self, "%s%d" % ("birnn" if bidir else "rnn", i), cls(inputdim, cdim, bidirectional=bidir))
             setattr(self, "bt%d" % i, torch.nn.Linear(2 * cdim if bidir else cdim, hdim))
         self.elayers, self.cdim, self.subsample, self.typ, self.bidir, self.dropout = \
             elayers, cdim, subsample, typ, bidir, dropout
@@ -94,7 +106,9 @@ class RNN(torch.nn.Module):
         super().__init__()
         _lstm_or_raise(typ)
         bidir = typ[0] == "b"
-        self.nbrnn = torch.nn.LSTM(idim, cdim, elayers, batch_first=True, dropout=dropout, bidirectional=bidir)
+        rnn_cls = torch.nn.LSTM if "lstm" in typ else torch.nn.GRU          # parameter container only
+        self.seq_fn = R_.LSTMSeqFn if "lstm" in typ else R_.GRUSeqFn
+        self.nbrnn = rnn_cls(idim, cdim, elayers, batch_first=True, dropout=dropout, bidirectional=bidir)
         self.l_last = torch.nn.Linear(cdim * 2 if bidir else cdim, hdim)
         self.typ, self.bidir, self.elayers, self.dropout = typ, bidir, elayers, dropout
         self.salts = [ops.new_salt() for _ in range(elayers)]
@@ -114,7 +128,7 @@ class RNN(torch.nn.Module):
             for sfx, rev in (("", False),) + ((("_reverse", True),) if self.bidir else ()):
                 p = lambda n: getattr(self.nbrnn, "%s_l%d%s" % (n, k, sfx))   # noqa: E731
                 gx = F_.LinearFn.apply(x, p("weight_ih"), p("bias_ih"))
-                outs.append(R_.LSTMSeqFn.apply(gx, p("weight_hh"), p("bias_hh"), live, rev))
+                outs.append(self.seq_fn.apply(gx, p("weight_hh"), p("bias_hh"), live, rev))
             x = outs[0] if len(outs) == 1 else torch.cat(outs, dim=-1)
             if k < self.elayers - 1:   # torch.nn.LSTM(dropout=p): between layers, training mode only
                 x = F_.dropout(x, self.dropout, self.salts[k], self.training)

@@ -4,7 +4,7 @@ import torch
 from ... import functional as F_
 from ... import ops
 from ... import rnn_functional as R_
-from ..rnn.decoders import LSTMCell
+from ..rnn.decoders import GRUCell, LSTMCell
 from .joint_network import JointNetwork
 
 
@@ -16,11 +16,11 @@ class DecoderRNNT(torch.nn.Module):
     def __init__(self, eprojs, odim, dtype, dlayers, dunits, blank, embed_dim, joint_dim,
                  joint_activation_type="tanh", dropout=0.0, dropout_embed=0.0):
         super().__init__()
-        if dtype != "lstm":
-            raise NotImplementedError("dtype %r: only lstm prediction networks have HIP kernels" % dtype)
+        if dtype not in ("lstm", "gru"):
+            raise NotImplementedError("dtype %r: lstm and gru prediction networks have HIP kernels" % dtype)
         self.embed = torch.nn.Embedding(odim, embed_dim, padding_idx=blank)
-        self.decoder = torch.nn.ModuleList([LSTMCell(embed_dim, dunits)] +
-                                           [LSTMCell(dunits, dunits) for _ in range(1, dlayers)])
+        cell = LSTMCell if dtype == "lstm" else GRUCell
+        self.decoder = torch.nn.ModuleList([cell(embed_dim, dunits)] + [cell(dunits, dunits) for _ in range(1, dlayers)])
         self.joint_network = JointNetwork(odim, eprojs, dunits, joint_dim, joint_activation_type)
         self.dlayers, self.dunits, self.dtype = dlayers, dunits, dtype
         self.embed_dim, self.joint_dim, self.odim = embed_dim, joint_dim, odim
@@ -39,10 +39,16 @@ class DecoderRNNT(torch.nn.Module):
         """single step (decoding): ey (B, emb) -> (y (B, dunits), new state)   (rnn_decoder.py:106-138)"""
         z_prev, c_prev = state
         z_list, c_list = self.init_state(ey)
-        z_list[0], c_list[0] = self.decoder[0](ey, (z_prev[0], c_prev[0]))
+        if self.dtype == "lstm":
+            z_list[0], c_list[0] = self.decoder[0](ey, (z_prev[0], c_prev[0]))
+        else:
+            z_list[0] = self.decoder[0](ey, z_prev[0])
         for i in range(1, self.dlayers):
             x = F_.dropout(z_list[i - 1], self.dropout, self.salts[i - 1], self.training)
-            z_list[i], c_list[i] = self.decoder[i](x, (z_prev[i], c_prev[i]))
+            if self.dtype == "lstm":
+                z_list[i], c_list[i] = self.decoder[i](x, (z_prev[i], c_prev[i]))
+            else:
+                z_list[i] = self.decoder[i](x, z_prev[i])
         y = F_.dropout(z_list[-1], self.dropout, self.salts[-1], self.training)
         return y, (z_list, c_list)
 
@@ -53,7 +59,7 @@ class DecoderRNNT(torch.nn.Module):
         x = eys.transpose(0, 1).contiguous()                              # (U,B,emb) time-major
         for i, cell in enumerate(self.decoder):
             gx = F_.LinearFn.apply(x, cell.weight_ih, cell.bias_ih)
-            x = R_.LSTMSeqFn.apply(gx, cell.weight_hh, cell.bias_hh, None, False)
+            x = (R_.LSTMSeqFn if self.dtype == "lstm" else R_.GRUSeqFn).apply(gx, cell.weight_hh, cell.bias_hh, None, False)
             x = F_.dropout(x, self.dropout, self.salts[i], self.training)
         h_dec = x.transpose(0, 1).contiguous()                            # (B,U,dunits)
         return self.joint_network(hs_pad, h_dec)

@@ -860,3 +860,19 @@ def h2d_cached(tag, array, device):
         t = torch.from_numpy(a.copy()).to(device)
         _h2d_cache[key] = t
     return t
+
+
+def gru_cell_fwd(gx, gh, h_prev, live, h, y, acts):
+    B, H3 = gx.shape
+    H = H3 // 3
+    assert gh.numel() == B * H3 and h_prev.numel() == B * H and h.numel() == B * H and acts.numel() == B * 4 * H
+    check(_lib.lib().eamd_gru_cell_fwd(ptr(gx), ptr(gh), ptr(h_prev), ptr(live), ptr(h), ptr(y), ptr(acts), B, H,
+                                       stream_ptr()), "eamd_gru_cell_fwd")
+
+
+def gru_cell_bwd(dy, dh, acts, h_prev, live, dgx, dgh, dh_direct):
+    B, H4 = acts.shape
+    H = H4 // 4
+    assert dgx.numel() == B * 3 * H and dgh.numel() == B * 3 * H and dh_direct.numel() == B * H
+    check(_lib.lib().eamd_gru_cell_bwd(ptr(dy), ptr(dh), ptr(acts), ptr(h_prev), ptr(live), ptr(dgx), ptr(dgh),
+                                       ptr(dh_direct), B, H, stream_ptr()), "eamd_gru_cell_bwd")

@@ -162,6 +162,97 @@ class LSTMCellFn(torch.autograd.Function):
 
 
 # =================================================================================================
+# GRU: same structure as the LSTM Functions; the recurrent product keeps its own [B,3H] buffer because the
+# candidate gate needs r * (h W_hn^T + b_hn), not a plain sum with the input projection.
+# =================================================================================================
+class GRUSeqFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, gx, w_hh, b_hh, live, reverse):
+        T, B, H3 = gx.shape
+        H = H3 // 3
+        dev = gx.device
+        gx = gx.contiguous()
+        h_out = torch.empty(T, B, H, device=dev, dtype=torch.float32)
+        acts = torch.empty(T, B, 4 * H, device=dev, dtype=torch.float32)
+        y = torch.empty(T, B, H, device=dev, dtype=torch.float32)
+        zero = torch.zeros(B, H, device=dev, dtype=torch.float32)
+        gh = torch.empty(B, H3, device=dev, dtype=torch.float32)
+        hp = zero
+        for t in (range(T - 1, -1, -1) if reverse else range(T)):
+            _rec_gemm(hp, w_hh, gh, B, H3, H, H, H, H3, bias=b_hh)
+            ops.gru_cell_fwd(gx[t], gh, hp, None if live is None else live[t], h_out[t], y[t], acts[t])
+            hp = h_out[t]
+        ctx.save_for_backward(h_out, acts, zero, live if live is not None else zero)
+        ctx.pr = (w_hh, b_hh)
+        ctx.cfg = (reverse, live is not None)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        h_out, acts, zero, live = ctx.saved_tensors
+        w_hh, b_hh = ctx.pr
+        reverse, has_live = ctx.cfg
+        T, B, H4 = acts.shape
+        H = H4 // 4
+        dev = acts.device
+        dy = dy.contiguous()
+        sink = GradSink(ctx.pr)
+        dgx = torch.empty(T, B, 3 * H, device=dev, dtype=torch.float32)
+        dgh = torch.empty(T, B, 3 * H, device=dev, dtype=torch.float32)
+        dh = None
+        for t in (range(T) if reverse else range(T - 1, -1, -1)):
+            pt = t + 1 if reverse else t - 1
+            has_prev = 0 <= pt < T
+            hprev = h_out[pt] if has_prev else zero
+            direct = torch.empty(B, H, device=dev, dtype=torch.float32)
+            ops.gru_cell_bwd(dy[t], dh, acts[t], hprev, live[t] if has_live else None, dgx[t], dgh[t], direct)
+            if has_prev:
+                dh = torch.empty(B, H, device=dev, dtype=torch.float32)
+                _rec_gemm(dgh[t], w_hh, dh, B, H, 3 * H, 3 * H, H, H, transB=1, R=direct, ldr=H)
+        if T > 1:
+            dg, hp = (dgh[:-1], h_out[1:]) if reverse else (dgh[1:], h_out[:-1])
+            ops.linear_bwd_w(dg.reshape(-1, 3 * H), hp.reshape(-1, H), sink.buf(0))
+        ops.colsum(dgh.view(-1, 3 * H), sink.buf(1))
+        return (dgx,) + sink.results() + (None, None)
+
+
+class GRUCellFn(torch.autograd.Function):
+    """one GRUCell step (decoders whose input depends on the previous step); gx = x W_ih^T + b_ih"""
+
+    @staticmethod
+    def forward(ctx, gx, h_prev, w_hh, b_hh):
+        B, H3 = gx.shape
+        H = H3 // 3
+        dev = gx.device
+        gx, h_prev = gx.contiguous(), h_prev.contiguous()
+        gh = torch.empty(B, H3, device=dev, dtype=torch.float32)
+        _rec_gemm(h_prev, w_hh, gh, B, H3, H, H, H, H3, bias=b_hh)
+        h = torch.empty(B, H, device=dev, dtype=torch.float32)
+        acts = torch.empty(B, 4 * H, device=dev, dtype=torch.float32)
+        ops.gru_cell_fwd(gx, gh, h_prev, None, h, None, acts)
+        ctx.save_for_backward(acts, h_prev)
+        ctx.pr = (w_hh, b_hh)
+        return h
+
+    @staticmethod
+    def backward(ctx, dh):
+        acts, h_prev = ctx.saved_tensors
+        w_hh, b_hh = ctx.pr
+        B, H4 = acts.shape
+        H = H4 // 4
+        dev = acts.device
+        sink = GradSink(ctx.pr)
+        dgx = torch.empty(B, 3 * H, device=dev, dtype=torch.float32)
+        dgh = torch.empty(B, 3 * H, device=dev, dtype=torch.float32)
+        direct = torch.empty(B, H, device=dev, dtype=torch.float32)
+        ops.gru_cell_bwd(None, dh.contiguous(), acts, h_prev, None, dgx, dgh, direct)
+        dh_prev = torch.empty(B, H, device=dev, dtype=torch.float32)
+        _rec_gemm(dgh, w_hh, dh_prev, B, H, 3 * H, 3 * H, H, H, transB=1, R=direct, ldr=H)
+        ops.linear_bwd_w(dgh, h_prev, sink.buf(0), db=sink.buf(1))
+        return (dgx, dh_prev) + sink.results()
+
+
+# =================================================================================================
 # VGG2L front-end: 2 x (conv3x3-ReLU, conv3x3-ReLU, maxpool 2x2 ceil) on NHWC activations.
 # reference: rnn/encoders.py:178-237.  conv1_1 (C_in = 1) is a direct kernel, the other three are
 # implicit GEMMs over the gather descriptor (zero padding = out-of-range taps), ReLU fused in the

@@ -245,6 +245,14 @@ int eamd_lstm_cell_fwd(const float* gates, const float* c_prev, const float* h_p
 int eamd_lstm_cell_bwd(const float* dy, const float* dh, const float* dc, const float* acts, const float* c_prev,
                        const float* c, const uint8_t* live, float* dgates, float* dc_prev, float* dh_pass, int B, int H,
                        void* stream);
+/* One GRU step (torch.nn.GRU / GRUCell, gate order r,z,n; rnn/encoders.py:31-33,110-119, rnn/decoders.py:96,105,
+ * transducer/rnn_decoder.py:50) on gx = x W_ih^T + b_ih and gh = h W_hh^T + b_hh (both [B,3H], eamd_gemm products).
+ * acts [B,4H] = r, z, n, gh_n.  Backward: dgx, dgh [B,3H] and dh_direct [B,H] (the part of the gradient that reaches
+ * h_prev directly: z * dh', or all of it on rows with live == 0). */
+int eamd_gru_cell_fwd(const float* gx, const float* gh, const float* h_prev, const uint8_t* live, float* h, float* y,
+                      float* acts, int B, int H, void* stream);
+int eamd_gru_cell_bwd(const float* dy, const float* dh, const float* acts, const float* h_prev, const uint8_t* live,
+                      float* dgx, float* dgh, float* dh_direct, int B, int H, void* stream);
 /* F.max_pool2d(x, 2, stride=2, ceil_mode=True) on NHWC activations (VGG2L, rnn/encoders.py:205,208).
  * idx[B,Ho,Wo,C] keeps the position (0..3) of the maximum inside its window. */
 int eamd_maxpool2x2_fwd(const float* x, float* y, uint8_t* idx, int B, int H, int W, int C, void* stream);

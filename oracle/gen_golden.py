@@ -431,6 +431,24 @@ def main():
              hlens=np.asarray(hlens, dtype=np.int64), loss=float(loss), loss_att=float(m.loss_att),
              loss_ctc=float(m.loss_ctc), acc=float(m.acc), **sd0, **grads_np(m))
 
+    # a20: GRU cells (bidirectional GRU-P encoder, 2-layer GRU decoder)
+    torch.manual_seed(33)
+    m = RnnE2E(9, 7, rnn_args(etype="bgrup", elayers=2, subsample="1_2_1", eunits=8, eprojs=8, dtype="gru", dlayers=2,
+                              dunits=10, atype="location", adim=6, aconv_chans=3, aconv_filts=4))
+    m.train()
+    sd0 = sd_np(m, "sd/")
+    g = torch.Generator().manual_seed(6)
+    xs = torch.randn(3, 26, 9, generator=g)
+    ilens = torch.tensor([26, 21, 14])
+    ys = torch.randint(1, 6, (3, 5), generator=g)
+    ys[1, 3:] = -1
+    xs = xs * (torch.arange(26).view(1, -1, 1) < ilens.view(-1, 1, 1))
+    hs, hlens, _ = m.enc(xs, ilens)
+    loss = m(xs, ilens, ys)
+    loss.backward()
+    save(out("e2e_rnn_gru.npz"), xs=xs, ilens=ilens, ys=ys, hs_pad=hs.detach(), hlens=np.asarray(hlens, dtype=np.int64),
+         loss=float(loss), loss_att=float(m.loss_att), loss_ctc=float(m.loss_ctc), acc=float(m.acc), **sd0, **grads_np(m))
+
     # ---- a21: transducer.  The loss package (warprnnt_pytorch) is absent here: TransLoss is given the
     # oracle's float64 restatement of the published recursion (asr_oracle.rnnt_loss, mean over the batch),
     # everything else (encoder, predictor, joint network, input preparation) is the reference's own code.
@@ -475,6 +493,7 @@ def main():
              loss=float(loss), **sd0, **grads_np(m))
 
     trn_case("transducer_rnn.npz", 41)
+    trn_case("transducer_gru.npz", 43, etype="bgru", elayers=2, dtype="gru", dlayers=2)   # stacked nn.GRU + l_last
     conf_arch = [dict(type="conformer", d_hidden=64, d_ff=96, heads=4, macaron_style=True, use_conv_mod=True,
                       conv_mod_kernel=7)]
     conf_arch[0]["dropout-rate"] = 0.0

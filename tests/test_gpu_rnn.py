@@ -232,6 +232,23 @@ def test_e2e_rnn_attention_types_golden(atype):
     check_grads(m, grads, tol=5e-4)
 
 
+def test_e2e_rnn_gru_golden():
+    """bidirectional GRU-P encoder + 2-layer GRU attention decoder == reference E2E on its own weights"""
+    from espnet_amd.nets.e2e_asr import E2E
+    p, sd, grads = split_golden(load_golden("e2e_rnn_gru.npz"))
+    m = load_sd(E2E(9, 7, _rnn_args(etype="bgrup", elayers=2, subsample="1_2_1", eunits=8, eprojs=8, dtype="gru", dlayers=2,
+                                     dunits=10, atype="location", adim=6, aconv_chans=3, aconv_filts=4)), sd)
+    m.train()
+    loss = m(p["xs"].to(DEV), p["ilens"], p["ys"].to(DEV))
+    assert m.hlens == p["hlens"].tolist()
+    report("e2e_rnn gru hs_pad", m.hs_pad, p["hs_pad"], 1e-4)
+    rel = abs(float(loss) - float(p["loss"])) / abs(float(p["loss"]))
+    print("[parity] e2e_rnn gru loss hip %.6f ref %.6f rel %.2e" % (float(loss), float(p["loss"]), rel))
+    assert rel < 1e-5
+    loss.backward()
+    check_grads(m, grads, tol=5e-4)
+
+
 def _trn_args(**kw):
     d = dict(etype="vggblstmp", elayers=1, subsample="1_1", eunits=10, eprojs=8, dtype="lstm", dlayers=2, dunits=12,
              dec_embed_dim=6, dropout_rate=0.0, dropout_rate_decoder=0.0, dropout_rate_embed_decoder=0.0, joint_dim=7,
@@ -241,13 +258,15 @@ def _trn_args(**kw):
     return argparse.Namespace(**d)
 
 
-@pytest.mark.parametrize("name", ["transducer_rnn.npz", "transducer_conformer.npz"])
+@pytest.mark.parametrize("name", ["transducer_rnn.npz", "transducer_gru.npz", "transducer_conformer.npz"])
 def test_transducer_golden(name):
     """encoder -> DecoderRNNT -> JointNetwork == reference modules; loss == float64 transducer recursion"""
     from espnet_amd.nets.e2e_asr_transducer import E2E
     p, sd, grads = split_golden(load_golden(name))
     if "rnn" in name:
         args = _trn_args()
+    elif "gru" in name:
+        args = _trn_args(etype="bgru", elayers=2, dtype="gru", dlayers=2)
     else:
         arch = [dict(type="conformer", d_hidden=64, d_ff=96, heads=4, macaron_style=True, use_conv_mod=True,
                      conv_mod_kernel=7)]

@@ -269,6 +269,21 @@ def test_e2e_rnn_attention_types(oracle, atype):
     _grad_check(sd, grads)
 
 
+def test_e2e_rnn_gru(oracle):
+    """bidirectional GRU-P encoder + 2-layer GRU attention decoder against the reference E2E"""
+    p, sd, grads = split_golden(load_golden("e2e_rnn_gru.npz"))
+    sd = req(sd)
+    hs, hlens = oracle.rnn_encoder(sd, "enc.", p["xs"], p["ilens"].tolist(), 2, [1, 2, 1], vgg=False, gru=True)
+    assert hlens == p["hlens"].tolist()
+    close(hs, p["hs_pad"], rtol=1e-4, atol=1e-5)
+    loss_ctc = oracle.ctc_loss(oracle.linear(sd, "ctc.ctc_lo.", hs), torch.tensor(hlens), p["ys"])
+    loss_att, acc, _ = oracle.rnn_att_decoder(sd, "dec.", hs, hlens, p["ys"], 6, 6, 2, "att.0.", gru=True)
+    loss = 0.5 * loss_ctc + 0.5 * loss_att
+    close(loss.detach(), p["loss"], rtol=1e-4, atol=1e-5)
+    loss.backward()
+    _grad_check(sd, grads)
+
+
 def test_rnnt_loss_brute_force(oracle):
     """the lattice recursion equals the explicit sum over all alignments (Graves 2012, eq. 1-3)"""
     g = torch.Generator().manual_seed(7)
@@ -286,14 +301,19 @@ def test_rnnt_loss_brute_force(oracle):
     assert abs(float(both[1]) - float(solo[0])) < 1e-12
 
 
-@pytest.mark.parametrize("name", ["transducer_rnn.npz", "transducer_conformer.npz"])
+@pytest.mark.parametrize("name", ["transducer_rnn.npz", "transducer_gru.npz", "transducer_conformer.npz"])
 def test_transducer(oracle, name):
     """encoder -> DecoderRNNT -> JointNetwork against the reference modules (e2e_asr_transducer.py:510-563);
     the loss value in the fixture comes from oracle.rnnt_loss itself (warprnnt_pytorch is absent)."""
     p, sd, grads = split_golden(load_golden(name))
     sd = req(sd)
+    gru = "gru" in name
     if "rnn" in name:
         hs, hlens = oracle.rnn_encoder(sd, "enc.", p["xs"], p["ilens"].tolist(), 1, [1, 1])
+        dl = 2
+    elif gru:
+        hs, hlens = oracle.rnn_encoder(sd, "enc.", p["xs"], p["ilens"].tolist(), 2, [1, 1, 1], vgg=False, gru=True,
+                                       proj=False)
         dl = 2
     else:
         cfg = dict(conformer=True, rel_pos=True, activation="swish", aheads=4)
@@ -303,7 +323,7 @@ def test_transducer(oracle, name):
         dl = 1
     close(hs, p["hs_pad"], rtol=1e-4, atol=1e-5)
     ys_in, target, ulens = oracle.rnnt_prepare(p["ys"])
-    z = oracle.rnnt_decoder(sd, "dec.", hs, ys_in, dl)
+    z = oracle.rnnt_decoder(sd, "dec.", hs, ys_in, dl, gru=gru)
     close(z, p["pred_pad"], rtol=1e-4, atol=1e-5)
     loss = oracle.rnnt_loss(z, target, hlens, ulens)
     assert abs(float(loss) - float(p["loss"])) < 1e-5 * abs(float(p["loss"]))
