@@ -79,5 +79,8 @@ def test_unsupported_variants_fail_loudly():
     from espnet_amd.nets.rnn.encoders import Encoder
     with pytest.raises(NotImplementedError):
         initial_att("coverage", 8, 8, 2, 4, 3, 2, 1)
+    with pytest.raises(ValueError):
+        Encoder("brnnp", 10, 1, 4, 4, np.ones(2, dtype=np.int64), 0.0)
+    from espnet_amd.nets.rnn.decoders import Decoder
     with pytest.raises(NotImplementedError):
-        Encoder("bgrup", 10, 1, 4, 4, np.ones(2, dtype=np.int64), 0.0)
+        Decoder(4, 5, "lstm", 1, 4, 4, 4, None, sampling_probability=0.5)
