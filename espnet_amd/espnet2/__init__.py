@@ -1,2 +1,3 @@
 """espnet2 model surface on the HIP kernels (reference: espnet2/asr/*)."""
 from .asr import CTC, ConformerEncoder, ESPnetASRModel, TransformerDecoder, TransformerEncoder, register_choices  # noqa: F401
+from .layers import GlobalMVN, MaskAlongAxis, SpecAug, TimeWarp, UtteranceMVN  # noqa: F401,E402

@@ -175,8 +175,8 @@ class CTC(torch.nn.Module):
 
 
 class ESPnetASRModel(AbsESPnetModel):
-    """reference: espnet2/asr/espnet_model.py:35-290 (frontend / specaug / normalize = None: the metric
-    feeds fbank features directly; those layers are the next row of the scope table)."""
+    """reference: espnet2/asr/espnet_model.py:35-290.  frontend = None (fbank features are the input); specaug and
+    normalize take the espnet_amd.espnet2.layers modules (SpecAug, GlobalMVN, UtteranceMVN)."""
 
     def __init__(self, vocab_size, token_list=None, frontend=None, specaug=None, normalize=None, encoder=None,
                  decoder=None, ctc=None, rnnt_decoder=None, ctc_weight=0.5, ignore_id=-1, lsm_weight=0.0,
@@ -184,8 +184,8 @@ class ESPnetASRModel(AbsESPnetModel):
                  sym_blank="<blank>"):
         assert 0.0 <= ctc_weight <= 1.0, ctc_weight
         assert rnnt_decoder is None, "Not implemented"
-        if frontend is not None or specaug is not None or normalize is not None:
-            raise NotImplementedError("frontend / specaug / normalize are the next scope rows (SURVEY.md §8f)")
+        if frontend is not None:
+            raise NotImplementedError("waveform frontends are a later scope row (SURVEY.md §8f rank 4)")
         super().__init__()
         self.sos = vocab_size - 1
         self.eos = vocab_size - 1
@@ -193,7 +193,7 @@ class ESPnetASRModel(AbsESPnetModel):
         self.ignore_id = ignore_id
         self.ctc_weight = ctc_weight
         self.token_list = list(token_list) if token_list is not None else None
-        self.frontend, self.specaug, self.normalize = None, None, None
+        self.frontend, self.specaug, self.normalize = None, specaug, normalize
         self.encoder = encoder
         self.decoder = decoder
         self.ctc = None if ctc_weight == 0.0 else ctc
@@ -203,8 +203,14 @@ class ESPnetASRModel(AbsESPnetModel):
         self.error_calculator = None
 
     def encode(self, speech, speech_lengths):
-        """reference: espnet_model.py:178-213 (features = speech when frontend is None)"""
-        encoder_out, encoder_out_lens, _ = self.encoder(speech, speech_lengths)
+        """reference: espnet_model.py:178-213 (features = speech when frontend is None; SpecAug in training mode
+        only, then the normalisation layer, :192-197)"""
+        feats, feats_lengths = speech, speech_lengths
+        if self.specaug is not None and self.training:
+            feats, feats_lengths = self.specaug(feats, feats_lengths)
+        if self.normalize is not None:
+            feats, feats_lengths = self.normalize(feats, feats_lengths)
+        encoder_out, encoder_out_lens, _ = self.encoder(feats, feats_lengths)
         assert encoder_out.size(0) == speech.size(0)
         return encoder_out, encoder_out_lens
 

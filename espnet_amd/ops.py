@@ -876,3 +876,32 @@ def gru_cell_bwd(dy, dh, acts, h_prev, live, dgx, dgh, dh_direct):
     assert dgx.numel() == B * 3 * H and dgh.numel() == B * 3 * H and dh_direct.numel() == B * H
     check(_lib.lib().eamd_gru_cell_bwd(ptr(dy), ptr(dh), ptr(acts), ptr(h_prev), ptr(live), ptr(dgx), ptr(dgh),
                                        ptr(dh_direct), B, H, stream_ptr()), "eamd_gru_cell_bwd")
+
+
+# ---- feature-side layers --------------------------------------------------------------------------
+def specaug(x, lens=None, center=None, warped=None, fpos=None, flen=None, tpos=None, tlen=None):
+    """x [B,T,F] fp32 -> augmented copy; all parameter arrays are int32 device tensors (see include/espnet_amd.h)"""
+    B, T, F = x.shape
+    assert x.dtype == torch.float32 and x.is_contiguous()
+    y = torch.empty_like(x)
+    nf = fpos.shape[1] if fpos is not None else 0
+    nt = tpos.shape[1] if tpos is not None else 0
+    check(_lib.lib().eamd_specaug(ptr(x), ptr(y), ptr(lens), ptr(center), ptr(warped), ptr(fpos), ptr(flen), nf, ptr(tpos),
+                                  ptr(tlen), nt, B, T, F, stream_ptr()), "eamd_specaug")
+    return y
+
+
+def global_mvn(x, lens, mean, std):
+    B, T, F = x.shape
+    y = torch.empty_like(x)
+    check(_lib.lib().eamd_global_mvn(ptr(x), ptr(y), ptr(lens), ptr(mean), ptr(std), B, T, F, stream_ptr()), "eamd_global_mvn")
+    return y
+
+
+def utterance_mvn(x, lens, norm_means, norm_vars, eps):
+    B, T, F = x.shape
+    y = torch.empty_like(x)
+    ws = torch.empty(2 * B * F, device=x.device, dtype=torch.float32)
+    check(_lib.lib().eamd_utterance_mvn(ptr(x), ptr(y), ptr(lens), ptr(ws), int(norm_means), int(norm_vars), C.c_float(eps),
+                                        B, T, F, stream_ptr()), "eamd_utterance_mvn")
+    return y

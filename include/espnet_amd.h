@@ -229,6 +229,25 @@ int eamd_ctc_prefix_score(const float* logp, const float* r_prev, const int32_t*
                           const int32_t* olen, float* psi, float* r_new, int nhyp, int ncand, int T, int V,
                           int blank, int eos, void* stream);
 
+/* ---- feature-side layers ----------------------------------------------
+ * SpecAugment on a [B,T,F] batch (x != y).  reference: espnet2/asr/specaug/specaug.py:19-84,
+ * espnet2/layers/time_warp.py:15-94 (bicubic F.interpolate along time, align_corners=False, of the segments left and
+ * right of `center` to lengths `warped` and len - warped), espnet2/layers/mask_along_axis.py:7-62 (zero fill).
+ * lens[B] (NULL = T): frames >= lens[b] become 0 (pad_list of the per-utterance warp path);
+ * center/warped[B] (NULL or center < 0 = no warp); fpos/flen [B,nf], tpos/tlen [B,nt]: mask pos <= i < pos + len. */
+int eamd_specaug(const float* x, float* y, const int32_t* lens, const int32_t* center, const int32_t* warped,
+                 const int32_t* fpos, const int32_t* flen, int nf, const int32_t* tpos, const int32_t* tlen, int nt, int B,
+                 int T, int F, void* stream);
+/* GlobalMVN: y = ((x - mean[f]) with padded frames zeroed) / std[f]; mean / std / lens each optional.
+ * reference: espnet2/layers/global_mvn.py:62-98 */
+int eamd_global_mvn(const float* x, float* y, const int32_t* lens, const float* mean, const float* stdv, int B, int T,
+                    int F, void* stream);
+/* UtteranceMVN, statistics over the valid frames of each utterance; follows utterance_mvn.py:62-88 literally
+ * (norm_means leaves -mean in the padding; with both flags the divisor is sqrt(clamp(sqrt(var), eps))).
+ * workspace: 2*B*F floats. */
+int eamd_utterance_mvn(const float* x, float* y, const int32_t* lens, float* workspace, int norm_means, int norm_vars,
+                       float eps, int B, int T, int F, void* stream);
+
 /* ---- recurrent layers (RNN paths) ------------------------------
  * One LSTM step on gate pre-activations gates[B,4H] = x W_ih^T + b_ih + h W_hh^T + b_hh (the products are
  * eamd_gemm calls), gate order i,f,g,o as torch.nn.LSTM / LSTMCell.

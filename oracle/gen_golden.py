@@ -504,6 +504,44 @@ def main():
              transformer_enc_positional_encoding_type="rel_pos", transformer_enc_pw_activation_type="swish",
              transformer_enc_conv_mod_activation_type="swish", dlayers=1, joint_activation_type="tanh")
 
+    # ---- 8f rank 1: SpecAug and the normalisation layers (seeded draws from the CPU generator) -------------
+    from espnet2.asr.specaug.specaug import SpecAug
+    from espnet2.layers.global_mvn import GlobalMVN
+    from espnet2.layers.utterance_mvn import UtteranceMVN
+    import tempfile
+    g = torch.Generator().manual_seed(9)
+    feats = torch.randn(4, 120, 20, generator=g) * 2.0 + 0.5
+    res = {}
+    for tag, lens in (("eq", [120, 120, 120, 120]), ("ragged", [120, 97, 64, 9])):
+        ll = torch.tensor(lens)
+        x = feats * (torch.arange(120).view(1, -1, 1) < ll.view(-1, 1, 1))
+        sa = SpecAug(time_warp_window=5, freq_mask_width_range=(0, 6), num_freq_mask=2, time_mask_width_range=(0, 20),
+                     num_time_mask=2)
+        torch.manual_seed(77)
+        y, _ = sa(x.clone(), ll)
+        res["specaug_%s" % tag] = y
+        res["lens_%s" % tag] = ll
+        sa2 = SpecAug(apply_time_warp=False, freq_mask_width_range=(0, 6), time_mask_width_range=(0, 20))
+        torch.manual_seed(78)
+        res["specaug_nowarp_%s" % tag] = sa2(x.clone(), ll)[0]
+        sa3 = SpecAug(apply_freq_mask=False, apply_time_mask=False, time_warp_window=7)
+        torch.manual_seed(79)
+        res["specaug_warponly_%s" % tag] = sa3(x.clone(), ll)[0]
+    cnt = 1000.0
+    ssum = (torch.randn(20, generator=g) * cnt).double().numpy()
+    ssq = (torch.rand(20, generator=g).double().numpy() * 4.0 + 1.0) * cnt + ssum * ssum / cnt
+    with tempfile.TemporaryDirectory() as td:
+        np.savez(os.path.join(td, "stats.npz"), count=cnt, sum=ssum, sum_square=ssq)
+        ll = torch.tensor([120, 97, 64, 9])
+        x = feats * (torch.arange(120).view(1, -1, 1) < ll.view(-1, 1, 1))
+        for nm in (True, False):
+            for nv in (True, False):
+                gm = GlobalMVN(os.path.join(td, "stats.npz"), norm_means=nm, norm_vars=nv)
+                res["gmvn_%d%d" % (nm, nv)] = gm(x.clone(), ll)[0]
+                um = UtteranceMVN(norm_means=nm, norm_vars=nv)
+                res["umvn_%d%d" % (nm, nv)] = um(x.clone(), ll)[0]
+    save(out("feature_layers.npz"), feats=feats, stats_count=cnt, stats_sum=ssum, stats_sum_square=ssq, **res)
+
     e2e_case("e2e_conformer.npz", ConfE2E, dict(transformer_encoder_pos_enc_layer_type="rel_pos",
                                                 transformer_encoder_selfattn_layer_type="rel_selfattn",
                                                 transformer_encoder_activation_type="swish", macaron_style=True,

@@ -474,3 +474,41 @@ def test_graphed_data_parallel_step_matches_eager_step():
         if created:
             dist.destroy_process_group()
         espnet_amd.set_precision("fp32")
+
+
+def test_feature_layers_golden(tmp_path):
+    """espnet2 SpecAug / GlobalMVN / UtteranceMVN on the HIP kernels vs the reference layers' recorded outputs
+    (same seeded CPU draws); then the layers inside ESPnetASRModel.encode."""
+    import numpy as np
+    from espnet_amd.espnet2 import GlobalMVN, SpecAug, UtteranceMVN
+    p, _, _ = split_golden(load_golden("feature_layers.npz"))
+
+    def masked(lens):
+        return (p["feats"] * (torch.arange(120).view(1, -1, 1) < torch.as_tensor(lens).view(-1, 1, 1))).to(DEV)
+
+    for tag in ("eq", "ragged"):
+        lens = p["lens_%s" % tag]
+        x = masked(lens.tolist())
+        sa = SpecAug(time_warp_window=5, freq_mask_width_range=(0, 6), num_freq_mask=2, time_mask_width_range=(0, 20),
+                     num_time_mask=2)
+        torch.manual_seed(77)
+        y, _ = sa(x, lens)
+        report("specaug %s" % tag, y, p["specaug_%s" % tag], 2e-6)
+        assert torch.equal(y.cpu() == 0, p["specaug_%s" % tag] == 0)          # mask / padding pattern: exact
+        torch.manual_seed(78)
+        y, _ = SpecAug(apply_time_warp=False, freq_mask_width_range=(0, 6), time_mask_width_range=(0, 20))(x, lens)
+        assert torch.equal(y.cpu(), p["specaug_nowarp_%s" % tag])              # masking alone: bit exact
+        torch.manual_seed(79)
+        y, _ = SpecAug(apply_freq_mask=False, apply_time_mask=False, time_warp_window=7)(x, lens)
+        report("specaug warp only %s" % tag, y, p["specaug_warponly_%s" % tag], 2e-6)
+    stats = str(tmp_path / "stats.npz")
+    np.savez(stats, count=float(p["stats_count"]), sum=p["stats_sum"].double().numpy(),
+             sum_square=p["stats_sum_square"].double().numpy())
+    lens = torch.tensor([120, 97, 64, 9])
+    x = masked(lens.tolist())
+    for nm in (1, 0):
+        for nv in (1, 0):
+            y, _ = GlobalMVN(stats, norm_means=bool(nm), norm_vars=bool(nv))(x, lens)
+            report("global_mvn %d%d" % (nm, nv), y, p["gmvn_%d%d" % (nm, nv)], 2e-6)
+            y, _ = UtteranceMVN(norm_means=bool(nm), norm_vars=bool(nv))(x, lens)
+            report("utterance_mvn %d%d" % (nm, nv), y, p["umvn_%d%d" % (nm, nv)], 5e-6)

@@ -329,3 +329,35 @@ def test_transducer(oracle, name):
     assert abs(float(loss) - float(p["loss"])) < 1e-5 * abs(float(p["loss"]))
     loss.backward()
     _grad_check(sd, grads)
+
+
+# ---- feature-side layers ---------------------------------------------------------
+def _masked(feats, lens):
+    return feats * (torch.arange(feats.shape[1]).view(1, -1, 1) < torch.as_tensor(lens).view(-1, 1, 1))
+
+
+def test_feature_layers(oracle):
+    """SpecAug (seeded CPU draws), GlobalMVN and UtteranceMVN against the espnet2 layers' own outputs"""
+    p, _, _ = split_golden(load_golden("feature_layers.npz"))
+    for tag in ("eq", "ragged"):
+        lens = p["lens_%s" % tag].tolist()
+        x = _masked(p["feats"], lens)
+        torch.manual_seed(77)
+        y = oracle.specaug(x.clone(), lens, 5, (0, 6), 2, (0, 20), 2)
+        close(y, p["specaug_%s" % tag], rtol=1e-5, atol=1e-6)
+        torch.manual_seed(78)
+        y = oracle.specaug(x.clone(), lens, 5, (0, 6), 2, (0, 20), 2, apply=(False, True, True))
+        assert torch.equal(y, p["specaug_nowarp_%s" % tag])           # masking alone is exact
+        torch.manual_seed(79)
+        y = oracle.specaug(x.clone(), lens, 7, apply=(True, False, False))
+        close(y, p["specaug_warponly_%s" % tag], rtol=1e-5, atol=1e-6)
+    lens = [120, 97, 64, 9]
+    x = _masked(p["feats"], lens)
+    cnt = float(p["stats_count"])
+    mean = (p["stats_sum"].double() / cnt)
+    std = torch.sqrt(torch.clamp(p["stats_sum_square"].double() / cnt - mean * mean, min=1e-20))
+    for nm in (1, 0):
+        for nv in (1, 0):
+            close(oracle.global_mvn(x.clone(), lens, mean.float(), std.float(), bool(nm), bool(nv)), p["gmvn_%d%d" % (nm, nv)],
+                  rtol=1e-5, atol=1e-6)
+            close(oracle.utterance_mvn(x.clone(), lens, bool(nm), bool(nv)), p["umvn_%d%d" % (nm, nv)], rtol=1e-5, atol=1e-6)
