@@ -119,3 +119,33 @@ class E2E(ASRInterface, torch.nn.Module):
         self.pred_pad = pred_pad
         self.loss = self.criterion(pred_pad, target, pred_len, target_len)
         return self.loss
+
+    def encode_transformer(self, x):
+        """x ndarray (T, D) -> encoder states (T', d)   (e2e_asr_transducer.py:565-580)"""
+        self.eval()
+        p = next(self.parameters())
+        h = torch.as_tensor(x, device=p.device, dtype=p.dtype).unsqueeze(0)
+        with torch.no_grad():
+            enc_output, _ = self.encoder(h, None)
+        return enc_output.squeeze(0)
+
+    def encode_rnn(self, x):
+        """e2e_asr_transducer.py:582-602"""
+        self.eval()
+        ilens = [x.shape[0]]
+        x = x[:: int(self.subsample[0]), :]
+        p = next(self.parameters())
+        h = torch.as_tensor(x, device=p.device, dtype=p.dtype).contiguous().unsqueeze(0)
+        with torch.no_grad():
+            hs, _, _ = self.enc(h, ilens)
+        return hs.squeeze(0)
+
+    def recognize(self, x, beam_search):
+        """x ndarray (T, D), beam_search: espnet_amd.nets.beam_search_transducer.BeamSearchTransducer
+        -> n-best list of dicts (e2e_asr_transducer.py:604-625)"""
+        from dataclasses import asdict
+        h = self.encode_transformer(x) if "transformer" in self.etype else self.encode_rnn(x)
+        nbest_hyps = beam_search(h)
+        if isinstance(nbest_hyps, list):
+            return [asdict(n) for n in nbest_hyps]
+        return asdict(nbest_hyps)

@@ -20,8 +20,21 @@ class JointNetwork(torch.nn.Module):
             raise NotImplementedError("joint activation %r has no HIP kernel" % joint_activation_type)
         self.act_id = _ACTS[joint_activation_type]
 
+    def project_enc(self, h):
+        """lin_enc over all frames of one utterance, h (T, D_enc) -> (T, J)   (decoding: hoisted out of the search loop)"""
+        return F_.LinearFn.apply(h.contiguous(), self.lin_enc.weight, self.lin_enc.bias)
+
+    def joint_step(self, enc_proj_t, y):
+        """joint output for one frame and one prediction-network output: enc_proj_t (J,), y (D_dec,) -> (V,)
+        == lin_out(act(lin_enc(h_t) + lin_dec(y)))  (joint_network.py:45-46 on 1-D inputs)"""
+        d = F_.LinearFn.apply(y.reshape(1, -1).contiguous(), self.lin_dec.weight, None)
+        z = R_.JointFn.apply(enc_proj_t.reshape(1, 1, -1).contiguous(), d.reshape(1, 1, -1), self.act_id)
+        return F_.LinearFn.apply(z.reshape(1, -1), self.lin_out.weight, self.lin_out.bias).reshape(-1)
+
     def forward(self, h_enc, h_dec):
         """h_enc (B,T,1,D_enc) or (B,T,D_enc); h_dec (B,1,U,D_dec) or (B,U,D_dec)"""
+        if h_enc.dim() == 1 and h_dec.dim() == 1:      # decoding: one frame, one prediction-network output
+            return self.joint_step(self.project_enc(h_enc.reshape(1, -1))[0], h_dec)
         if h_enc.dim() == 4:
             h_enc = h_enc.squeeze(2)
         if h_dec.dim() == 4:

@@ -52,6 +52,32 @@ class DecoderRNNT(torch.nn.Module):
         y = F_.dropout(z_list[-1], self.dropout, self.salts[-1], self.training)
         return y, (z_list, c_list)
 
+    def score(self, hyp, cache, init_tensor=None):
+        """one prediction-network step for a hypothesis, cached by its label prefix (rnn_decoder.py:168-193)
+        -> (y (1, dunits), state, last token (1,))"""
+        dev = self.embed.weight.device
+        vy = torch.full((1, 1), hyp.yseq[-1], dtype=torch.long, device=dev)
+        str_yseq = "".join([str(x) for x in hyp.yseq])
+        if str_yseq in cache:
+            y, state = cache[str_yseq]
+        else:
+            ey = R_.PlainEmbedFn.apply(vy, self.embed.weight, self.blank)
+            y, state = self.rnn_forward(ey[0], hyp.dec_state)
+            cache[str_yseq] = (y, state)
+        return y, state, vy[0]
+
+    def select_state(self, batch_states, idx):
+        """rnn_decoder.py:251-266"""
+        return ([batch_states[0][layer][idx] for layer in range(self.dlayers)],
+                [batch_states[1][layer][idx] for layer in range(self.dlayers)])
+
+    def create_batch_states(self, batch_states, l_states, l_tokens=None):
+        """rnn_decoder.py:268-288"""
+        for layer in range(self.dlayers):
+            batch_states[0][layer] = torch.stack([s[0][layer] for s in l_states])
+            batch_states[1][layer] = torch.stack([s[1][layer] for s in l_states])
+        return batch_states
+
     def forward(self, hs_pad, ys_in_pad, hlens=None):
         """hs_pad (B,Tmax,D), ys_in_pad (B,Lmax+1) -> joint logits (B,T,U,odim)   (rnn_decoder.py:140-166)"""
         eys = R_.PlainEmbedFn.apply(ys_in_pad, self.embed.weight, self.blank)

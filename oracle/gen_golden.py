@@ -489,8 +489,23 @@ def main():
         xs = xs * (torch.arange(37).view(1, -1, 1) < ilens.view(-1, 1, 1))
         loss = m(xs, ilens, ys)
         loss.backward()
-        save(out(name), xs=xs, ilens=ilens, ys=ys, hs_pad=m.hs_pad.detach(), pred_pad=m.pred_pad.detach(),
-             loss=float(loss), **sd0, **grads_np(m))
+        # decoding (beam_search_transducer.py:130-237): greedy and default beam search on the first utterance
+        from espnet.nets.beam_search_transducer import BeamSearchTransducer
+        hs_train, pred_train = m.hs_pad.detach().clone(), m.pred_pad.detach().clone()
+        dec = {}
+        m.eval()
+        with torch.no_grad():
+            xin = xs[0, : int(ilens[0])].numpy()
+            for tag, kw2 in (("greedy", dict(beam_size=1)), ("beam3", dict(beam_size=3, search_type="default")),
+                             ("beam3_nonorm", dict(beam_size=3, search_type="default", score_norm=False))):
+                bs = BeamSearchTransducer(decoder=m.dec, lm=None, lm_weight=0.0, **kw2)
+                nb = m.recognize(xin, bs)
+                nb = nb if isinstance(nb, list) else [nb]
+                dec["dec_%s_scores" % tag] = np.asarray([float(h["score"]) for h in nb], dtype=np.float64)
+                dec["dec_%s_lens" % tag] = np.asarray([len(h["yseq"]) for h in nb], dtype=np.int64)
+                dec["dec_%s_yseq" % tag] = np.asarray(sum([[int(t) for t in h["yseq"]] for h in nb], []), dtype=np.int64)
+        save(out(name), xs=xs, ilens=ilens, ys=ys, hs_pad=hs_train, pred_pad=pred_train,
+             loss=float(loss), **dec, **sd0, **grads_np(m))
 
     trn_case("transducer_rnn.npz", 41)
     trn_case("transducer_gru.npz", 43, etype="bgru", elayers=2, dtype="gru", dlayers=2)   # stacked nn.GRU + l_last

@@ -284,3 +284,43 @@ def test_transducer_golden(name):
     assert rel < 1e-5
     loss.backward()
     check_grads(m, grads, tol=5e-4)
+
+
+@pytest.mark.parametrize("name", ["transducer_rnn.npz", "transducer_gru.npz", "transducer_conformer.npz"])
+def test_transducer_decoding_golden(name):
+    """greedy and default beam search (beam_search_transducer.py:130-237) reproduce the reference's hypotheses:
+    token sequences exactly, scores to 1e-4, in the reference's n-best order"""
+    from espnet_amd.nets.beam_search_transducer import BeamSearchTransducer
+    from espnet_amd.nets.e2e_asr_transducer import E2E
+    p, sd, _ = split_golden(load_golden(name))
+    if "rnn" in name:
+        args = _trn_args()
+    elif "gru" in name:
+        args = _trn_args(etype="bgru", elayers=2, dtype="gru", dlayers=2)
+    else:
+        arch = [dict(type="conformer", d_hidden=64, d_ff=96, heads=4, macaron_style=True, use_conv_mod=True,
+                     conv_mod_kernel=7)]
+        args = _trn_args(etype="transformer", enc_block_arch=arch, enc_block_repeat=2,
+                         transformer_enc_input_layer="conv2d", transformer_enc_self_attn_type="rel_self_attn",
+                         transformer_enc_positional_encoding_type="rel_pos", transformer_enc_pw_activation_type="swish",
+                         transformer_enc_conv_mod_activation_type="swish", dlayers=1)
+    m = load_sd(E2E(12, 6, args), sd)
+    m.train()
+    m(p["xs"].to(DEV), p["ilens"], p["ys"].to(DEV))      # as in the fixture: BatchNorm running stats see one training batch
+    m.eval()
+    x = p["xs"][0, : int(p["ilens"][0])].numpy()
+    for tag, kw in (("greedy", dict(beam_size=1)), ("beam3", dict(beam_size=3, search_type="default")),
+                    ("beam3_nonorm", dict(beam_size=3, search_type="default", score_norm=False))):
+        nb = m.recognize(x, BeamSearchTransducer(decoder=m.dec, **kw))
+        nb = nb if isinstance(nb, list) else [nb]
+        lens = p["dec_%s_lens" % tag].tolist()
+        want_scores = p["dec_%s_scores" % tag].tolist()
+        flat = p["dec_%s_yseq" % tag].tolist()
+        assert len(nb) == len(lens), (tag, len(nb), len(lens))
+        o = 0
+        for h, n, sc in zip(nb, lens, want_scores):
+            assert h["yseq"] == flat[o:o + n], (tag, h["yseq"], flat[o:o + n])      # token ids: bit exact
+            assert abs(h["score"] - sc) <= 1e-4 * max(1.0, abs(sc)), (tag, h["score"], sc)
+            o += n
+        print("[parity] %s %s: %d hypotheses identical, best score %.5f (ref %.5f)" % (name, tag, len(nb), nb[0]["score"],
+                                                                                         want_scores[0]))
