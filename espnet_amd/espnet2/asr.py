@@ -13,6 +13,7 @@ import torch
 from .. import functional as F_
 from .. import ops
 from ..nets import modules as M
+from ..nets.scorer_interface import BatchScorerInterface
 
 try:  # pragma: no cover - only when the reference package is importable
     from espnet2.asr.decoder.abs_decoder import AbsDecoder  # type: ignore
@@ -102,7 +103,7 @@ class TransformerEncoder(AbsEncoder):
         return xs_pad, olens, None
 
 
-class TransformerDecoder(AbsDecoder):
+class TransformerDecoder(AbsDecoder, BatchScorerInterface):
     """reference: espnet2/asr/decoder/transformer_decoder.py:31-275 (BaseTransformerDecoder + TransformerDecoder)"""
 
     def __init__(self, vocab_size, encoder_output_size, attention_heads=4, linear_units=2048, num_blocks=6,

@@ -1,29 +1,39 @@
-"""Joint CTC/attention beam search for one utterance (hypotheses batched through the HIP kernels).
+"""Joint CTC/attention(/LM) beam search for one utterance, every beam step batched through the HIP kernels.
 
-reference semantics: espnet/nets/beam_search.py:36-458 (BeamSearch: full scorers, pre-beam of
-int(1.5*beam) on the full score, partial (CTC prefix) scorer on the pre-beam, weighted sum, top-`beam`
-over all expansions, <eos> handling in post_process), espnet/nets/e2e_asr_common.py:21-51 (end_detect),
-legacy E2E.recognize options (e2e_asr_transformer.py:259-477: ctc_weight, penalty, maxlenratio,
-minlenratio, nbest).  Utterances are independent: decode many by running one search per utterance on
-separate streams / GPUs (SURVEY.md §8e "replicas only").
+reference: espnet/nets/beam_search.py:36-458 (BeamSearch: constructor, scorer dictionaries, pre-beam on the
+full score, partial scorers on the pre-beam only, top-`beam` over all expansions, <eos> handling and
+final_score in post_process, end detection), espnet/nets/e2e_asr_common.py:21-51 (end_detect), legacy
+E2E.recognize options (e2e_asr_transformer.py:259-477: ctc_weight, lm_weight, penalty, maxlenratio,
+minlenratio, nbest).
+
+Same constructor and `forward(x, maxlenratio, minlenratio) -> List[Hypothesis]` as the reference.  Where the
+reference's BeamSearch scores hypothesis by hypothesis (`score` / `score_partial`), one step here is: one
+`batch_score` per full scorer over all running hypotheses, one top-k for the pre-beam, one CTC prefix-score
+launch, one flat top-k, and one device->host copy of the selected (hypothesis, token, scores) rows.
+Utterances are independent: decode many by running one search per utterance on separate streams / GPUs
+(SURVEY.md §8e "replicas only").
 """
 import math
+from itertools import chain
+from typing import Any, Dict, NamedTuple
 
-import numpy as np
 import torch
 
-from .ctc_prefix_score import CTCPrefixScorer
-from .modules import subsequent_mask
+from .ctc_prefix_score import CTCPrefixScorer, LengthBonus
+from .scorer_interface import PartialScorerInterface, ScorerInterface
 
 
-class Hypothesis:
-    __slots__ = ("yseq", "score", "scores", "dec_state", "ctc_state")
+class Hypothesis(NamedTuple):
+    """reference: beam_search.py:20-33 (yseq is an int64 tensor that starts with <sos>)"""
 
-    def __init__(self, yseq, score, scores, dec_state, ctc_state):
-        self.yseq, self.score, self.scores, self.dec_state, self.ctc_state = yseq, score, scores, dec_state, ctc_state
+    yseq: torch.Tensor
+    score: Any = 0.0
+    scores: Dict[str, Any] = dict()
+    states: Dict[str, Any] = dict()
 
     def asdict(self):
-        return {"yseq": list(self.yseq), "score": float(self.score), "scores": dict(self.scores)}
+        return self._replace(yseq=self.yseq.tolist(), score=float(self.score),
+                             scores={k: float(v) for k, v in self.scores.items()})._asdict()
 
 
 def end_detect(ended_hyps, i, M=3, D_end=math.log(1 * math.exp(-10))):
@@ -39,112 +49,178 @@ def end_detect(ended_hyps, i, M=3, D_end=math.log(1 * math.exp(-10))):
     return count == M
 
 
-class BeamSearch:
-    def __init__(self, decoder, ctc_scorer, weights, beam_size, vocab_size, sos, eos, pre_beam_ratio=1.5):
-        self.decoder = decoder if weights.get("decoder", 0) != 0 else None
-        self.ctc = ctc_scorer if (ctc_scorer is not None and weights.get("ctc", 0) != 0) else None
-        self.weights = weights
-        self.beam_size, self.n_vocab, self.sos, self.eos = beam_size, vocab_size, sos, eos
-        self.pre_beam_size = int(pre_beam_ratio * beam_size)
-        # pre-beam on the full (attention) score, as asr_inference / recog_v2 configure it
-        self.do_pre_beam = self.decoder is not None and self.ctc is not None and self.pre_beam_size < vocab_size
+class BeamSearch(torch.nn.Module):
+    # how partial scorers report: "ids" = scores of the pre-beam ids only, everything else is dropped
+    # (beam_search.py:226-262); "full" = (n, V) matrices (batch_beam_search.py:221-231)
+    partial_mode = "ids"
+    apply_final_score = True
 
-    def _expand(self, hyps, x):
-        n, V, dev = len(hyps), self.n_vocab, x.device
-        w = self.weights
+    def __init__(self, scorers, weights, beam_size, vocab_size, sos, eos, token_list=None, pre_beam_ratio=1.5,
+                 pre_beam_score_key=None):
+        super().__init__()
+        self.weights = weights
+        self.scorers, self.full_scorers, self.part_scorers = dict(), dict(), dict()
+        self.nn_dict = torch.nn.ModuleDict()          # so that .to() / .eval() reach the scorer modules
+        for k, v in scorers.items():
+            if weights.get(k, 0) == 0 or v is None:
+                continue
+            assert isinstance(v, ScorerInterface), f"{k} ({type(v)}) does not implement ScorerInterface"
+            self.scorers[k] = v
+            (self.part_scorers if isinstance(v, PartialScorerInterface) else self.full_scorers)[k] = v
+            if isinstance(v, torch.nn.Module):
+                self.nn_dict[k] = v
+        self.sos, self.eos, self.token_list = sos, eos, token_list
+        self.pre_beam_size = int(pre_beam_ratio * beam_size)
+        self.beam_size, self.n_vocab = beam_size, vocab_size
+        if (pre_beam_score_key is not None and pre_beam_score_key != "full"
+                and pre_beam_score_key not in self.full_scorers):
+            raise KeyError(f"{pre_beam_score_key} is not found in {self.full_scorers}")
+        self.pre_beam_score_key = pre_beam_score_key
+        self.do_pre_beam = (pre_beam_score_key is not None and self.pre_beam_size < vocab_size
+                            and len(self.part_scorers) > 0)
+
+    # ---- hypothesis bookkeeping (host side, as in the reference) -------------------------------------
+    def init_hyp(self, x):
+        states = {k: d.batch_init_state(x) if hasattr(d, "batch_init_state") else d.init_state(x)
+                  for k, d in self.scorers.items()}
+        return [Hypothesis(yseq=torch.tensor([self.sos], dtype=torch.int64), score=0.0,
+                           scores={k: 0.0 for k in self.scorers}, states=states)]
+
+    @staticmethod
+    def append_token(xs, x):
+        return torch.cat((xs, torch.tensor([int(x)], dtype=xs.dtype)))
+
+    # ---- one step ------------------------------------------------------------------------------------
+    def search(self, running_hyps, x):
+        """running hypotheses (all of one length) -> the `beam_size` best one-token extensions, best first"""
+        n, V, dev = len(running_hyps), self.n_vocab, x.device
+        ys = torch.stack([h.yseq for h in running_hyps]).to(dev)
+        xs = x.unsqueeze(0).expand(n, *x.shape)
         weighted = torch.zeros(n, V, device=dev, dtype=torch.float32)
-        dec_logp = new_dec_states = None
-        if self.decoder is not None:
-            ys = torch.tensor([h.yseq for h in hyps], dtype=torch.int64).to(dev)
-            dec_logp, new_dec_states = self.decoder.batch_score(ys, [h.dec_state for h in hyps],
-                                                                x.unsqueeze(0).expand(n, *x.shape).contiguous())
-            weighted += w["decoder"] * dec_logp
-        if w.get("length_bonus", 0) != 0:
-            weighted += w["length_bonus"]
-        cand = psi = r_new = ctc_delta = None
-        if self.ctc is not None:
-            if self.do_pre_beam:
-                cand = torch.topk(weighted, self.pre_beam_size, dim=1)[1].to(torch.int32)
+        scores, states = {}, {}
+        for k, d in self.full_scorers.items():
+            scores[k], states[k] = d.batch_score(ys, [h.states[k] for h in running_hyps], xs)
+            weighted += self.weights[k] * scores[k]
+        part_ids = None
+        if self.do_pre_beam:
+            pre = weighted if self.pre_beam_score_key == "full" else scores[self.pre_beam_score_key]
+            part_ids = torch.topk(pre, self.pre_beam_size, dim=-1)[1]
+        part_scores, part_states = {}, {}
+        if self.part_scorers:
+            if self.partial_mode == "full":
+                for k, d in self.part_scorers.items():
+                    part_scores[k], part_states[k] = d.batch_score_partial(
+                        ys, part_ids, [h.states[k] for h in running_hyps], x)
+                    weighted += self.weights[k] * part_scores[k]
             else:
-                cand = torch.arange(V, device=dev, dtype=torch.int32).unsqueeze(0).expand(n, V).contiguous()
-            ctc_delta, (psi, r_new) = self.ctc.batch_score_partial([h.yseq for h in hyps], cand,
-                                                                   [h.ctc_state for h in hyps])
-            if self.do_pre_beam:   # tokens outside the pre-beam are dropped (reference: beam())
-                masked = torch.full_like(weighted, -float("inf"))
-                masked.scatter_(1, cand.long(), torch.gather(weighted, 1, cand.long()) + w["ctc"] * ctc_delta)
-                weighted = masked
+                ids = part_ids if part_ids is not None else torch.arange(V, device=dev).unsqueeze(0).expand(n, V)
+                local = torch.zeros(n, ids.shape[1], device=dev, dtype=torch.float32)
+                for k, d in self.part_scorers.items():
+                    part_scores[k], part_states[k] = d.score_partial_batch(
+                        ys, ids, [h.states[k] for h in running_hyps], x)
+                    local += self.weights[k] * part_scores[k]
+                if part_ids is not None:   # tokens outside the pre-beam are dropped (beam_search.py:252-262)
+                    kept = torch.full_like(weighted, -float("inf"))
+                    kept.scatter_(1, ids, torch.gather(weighted, 1, ids) + local)
+                    weighted = kept
+                else:
+                    weighted += local
+        weighted += torch.tensor([float(h.score) for h in running_hyps], dtype=torch.float32).to(dev)[:, None]
+
+        # global top-`beam` over all (hypothesis, token) expansions; everything the host needs in one copy
+        k_sel = min(self.beam_size, n * V)
+        top_s, top_i = weighted.view(-1).topk(k_sel)
+        hyp_i, tok_i = top_i // V, top_i % V
+        cols = [top_s, hyp_i.float(), tok_i.float()]
+        names = list(scores.keys())
+        for k in names:
+            cols.append(scores[k][hyp_i, tok_i])
+        pos = None
+        for k in part_scores:
+            if self.partial_mode == "full":
+                cols.append(part_scores[k][hyp_i, tok_i])
             else:
-                weighted += w["ctc"] * ctc_delta
-        weighted += torch.tensor([h.score for h in hyps], dtype=torch.float32).to(dev)[:, None]
-        # host side: pick the global top-`beam` expansions (hypothesis bookkeeping is Python in the reference too)
-        k = min(self.beam_size, V)
-        top_s, top_i = torch.topk(weighted, k, dim=1)
-        top_s, top_i = top_s.cpu().numpy(), top_i.cpu().numpy()
-        flat = [(float(top_s[a, b]), a, int(top_i[a, b])) for a in range(n) for b in range(k)
-                if np.isfinite(top_s[a, b])]
-        flat.sort(key=lambda t: -t[0])
-        flat = flat[: self.beam_size]
-        dec_np = dec_logp.cpu().numpy() if dec_logp is not None else None
-        cand_np = cand.cpu().numpy() if cand is not None else None
-        delta_np = ctc_delta.cpu().numpy() if ctc_delta is not None else None
-        psi_np = psi.cpu().numpy() if psi is not None else None
+                if pos is None:
+                    pos = (ids[hyp_i] == tok_i[:, None]).float().argmax(-1) if part_ids is not None else tok_i
+                cols.append(part_scores[k][hyp_i, pos])
+        if pos is not None:
+            cols.append(pos.float())
+        host = torch.stack(cols, dim=1).cpu()
         out = []
-        for score, a, tok in flat:
-            h = hyps[a]
-            scores = dict(h.scores)
-            if dec_np is not None:
-                scores["decoder"] = scores.get("decoder", 0.0) + float(dec_np[a, tok])
-            if w.get("length_bonus", 0) != 0:
-                scores["length_bonus"] = scores.get("length_bonus", 0.0) + 1.0
-            ctc_state = None
-            if cand_np is not None:
-                j = int(np.nonzero(cand_np[a] == tok)[0][0])
-                scores["ctc"] = scores.get("ctc", 0.0) + float(delta_np[a, j])
-                ctc_state = (float(psi_np[a, j]), r_new[a, j])
-            out.append(Hypothesis(h.yseq + [tok], score, scores,
-                                  new_dec_states[a] if new_dec_states is not None else None, ctc_state))
+        for row in host.tolist():
+            if not math.isfinite(row[0]):
+                continue
+            a, tok = int(row[1]), int(row[2])
+            prev = running_hyps[a]
+            new_scores = dict(prev.scores)
+            c = 3
+            for k in names:
+                new_scores[k] = float(prev.scores[k]) + row[c]
+                c += 1
+            for k in part_scores:
+                new_scores[k] = float(prev.scores[k]) + row[c]
+                c += 1
+            new_states = {k: self.full_scorers[k].select_state(states[k], a) for k in names}
+            for k in part_scores:
+                if self.partial_mode == "full":
+                    new_states[k] = self.part_scorers[k].select_state(part_states[k], a, tok)
+                else:
+                    new_states[k] = self.part_scorers[k].select_state(part_states[k], (a, int(row[-1])))
+            out.append(Hypothesis(yseq=self.append_token(prev.yseq, tok), score=row[0], scores=new_scores,
+                                  states=new_states))
         return out
 
-    def __call__(self, x, maxlenratio=0.0, minlenratio=0.0):
+    def post_process(self, i, maxlen, maxlenratio, running_hyps, ended_hyps):
+        """reference: beam_search.py:407-458"""
+        if i == maxlen - 1:      # force <eos> at the last position so that something ends
+            running_hyps = [h._replace(yseq=self.append_token(h.yseq, self.eos)) for h in running_hyps]
+        remained = []
+        for hyp in running_hyps:
+            if int(hyp.yseq[-1]) == self.eos:
+                if self.apply_final_score:     # e.g. a word LM adds its final <eos> score
+                    for k, d in chain(self.full_scorers.items(), self.part_scorers.items()):
+                        s = d.final_score(hyp.states[k])
+                        hyp.scores[k] += s
+                        hyp = hyp._replace(score=hyp.score + self.weights[k] * s)
+                ended_hyps.append(hyp)
+            else:
+                remained.append(hyp)
+        return remained
+
+    def forward(self, x, maxlenratio=0.0, minlenratio=0.0):
         """x: (T, D) encoder output.  Returns the ended hypotheses, best first."""
         T = x.shape[0]
         maxlen = T if maxlenratio == 0 else max(1, int(maxlenratio * T))
-        minlen = int(minlenratio * T)
-        init_scores = {}
-        ctc_state = self.ctc.init_state(x) if self.ctc is not None else None
-        running = [Hypothesis([self.sos], 0.0, init_scores, None, ctc_state)]
-        ended = []
         with torch.no_grad():
+            running = self.init_hyp(x)
+            ended = []
             for i in range(maxlen):
-                best = self._expand(running, x)
-                if i == maxlen - 1:      # force <eos> at the last position (beam_search.py:436-441)
-                    for h in best:
-                        h.yseq = h.yseq + [self.eos]
-                running = []
-                for h in best:
-                    if h.yseq[-1] == self.eos:     # v0.9.5 post_process applies no minlen filter
-                        ended.append(h)
-                    else:
-                        running.append(h)
+                best = self.search(running, x)
+                running = self.post_process(i, maxlen, maxlenratio, best, ended)
                 if maxlenratio == 0.0 and end_detect([h.asdict() for h in ended], i):
                     break
-                if not running:
+                if len(running) == 0:
                     break
-        ended.sort(key=lambda h: -h.score)
-        return ended
+        nbest = sorted(ended, key=lambda h: float(h.score), reverse=True)
+        if len(nbest) == 0:      # beam_search.py:375-384
+            return [] if minlenratio < 0.1 else self.forward(x, maxlenratio, max(0.0, minlenratio - 0.1))
+        return nbest
 
 
 def recognize_beam(model, enc_output, recog_args, char_list=None, rnnlm=None):
-    """E2E.recognize for ctc_weight < 1 (reference: e2e_asr_transformer.py:286-477 / recog_v2).
+    """E2E.recognize for ctc_weight < 1 (reference: e2e_asr_transformer.py:286-477 / asr/pytorch_backend/recog.py).
+    rnnlm: any BatchScorerInterface language model, fused with weight recog_args.lm_weight.
     Returns [{"score": float, "yseq": [int]}] n-best, yseq starts with <sos> and ends with <eos>."""
-    if rnnlm is not None:
-        raise NotImplementedError("LM fusion is the next row of the scope table (SURVEY.md §8f)")
     ctc_weight = float(getattr(recog_args, "ctc_weight", 0.0))
     if model.ctc is None:
         ctc_weight = 0.0
-    weights = dict(decoder=1.0 - ctc_weight, ctc=ctc_weight, length_bonus=float(getattr(recog_args, "penalty", 0.0)))
-    scorer = CTCPrefixScorer(model.ctc, model.eos) if ctc_weight > 0 else None
-    bs = BeamSearch(model.decoder, scorer, weights, int(recog_args.beam_size), model.odim, model.sos, model.eos)
+    lm_weight = float(getattr(recog_args, "lm_weight", 0.0)) if rnnlm is not None else 0.0
+    weights = dict(decoder=1.0 - ctc_weight, ctc=ctc_weight, lm=lm_weight,
+                   length_bonus=float(getattr(recog_args, "penalty", 0.0)))
+    scorers = dict(decoder=model.decoder, ctc=CTCPrefixScorer(model.ctc, model.eos) if ctc_weight > 0 else None,
+                   lm=rnnlm, length_bonus=LengthBonus(model.odim))
+    bs = BeamSearch(scorers, weights, int(recog_args.beam_size), model.odim, model.sos, model.eos,
+                    pre_beam_score_key=None if ctc_weight == 1.0 else "full")
     hyps = bs(enc_output, float(getattr(recog_args, "maxlenratio", 0.0)), float(getattr(recog_args, "minlenratio", 0.0)))
     nbest = int(getattr(recog_args, "nbest", 1))
     return [{"score": float(h.score), "yseq": [int(t) for t in h.yseq], "scores": h.scores} for h in hyps[:nbest]]

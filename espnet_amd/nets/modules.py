@@ -16,6 +16,8 @@ import torch
 
 from .. import functional as F_
 from .. import ops
+from .. import rnn_functional as R_
+from .scorer_interface import BatchScorerInterface
 
 _EPS_LN = 1e-12
 
@@ -367,10 +369,16 @@ class TransformerEncoderLayer(torch.nn.Module):
         self.concat_after = concat_after
 
     def forward(self, x, mask, cache=None):
-        assert cache is None
         p = self.dropout_rate
-        x = mha_block(self.norm1, self.self_attn, x, None, None, mask, p_out=p)
+        if cache is None:
+            x = mha_block(self.norm1, self.self_attn, x, None, None, mask, p_out=p)
+        else:   # incremental scoring: only the newest position queries (encoder_layer.py:70-77)
+            assert cache.shape == (x.shape[0], x.shape[1] - 1, self.size)
+            mask = None if mask is None else mask[:, -1:, :]
+            x = mha_block(self.norm1, self.self_attn, x, None, None, mask, last_query_only=True, p_out=p)
         x = ffn_block(self.norm2, self.feed_forward, x, 1.0, p)
+        if cache is not None:
+            x = torch.cat([cache, x], dim=1)
         return x, mask
 
 
@@ -442,18 +450,53 @@ class ConformerEncoder(torch.nn.Module):
         return xs, masks
 
 
+class _LinearInput(torch.nn.Sequential):
+    """input_layer="linear": Linear -> LayerNorm -> Dropout -> ReLU -> pos_enc (encoder.py:95-102); the
+    children keep the reference's indices so the state_dict keys are embed.0.* / embed.1.*"""
+
+    def __init__(self, idim, odim, dropout_rate, pos_enc):
+        super().__init__(torch.nn.Linear(idim, odim), LayerNorm(odim), torch.nn.Dropout(dropout_rate),
+                         torch.nn.ReLU(), pos_enc)
+        self.salt = ops.new_salt()
+
+    def forward(self, x):
+        y = F_.LinearFn.apply(x, self[0].weight, self[0].bias)
+        y = F_.dropout(self[1](y), self[2].p, self.salt, self.training)
+        y = R_.ActFn.apply(y, ops.ACT_RELU)
+        return self[4](y)
+
+
+class _EmbedInput(torch.nn.Sequential):
+    """input_layer="embed": Embedding -> pos_enc (encoder.py:123-127)"""
+
+    def __init__(self, idim, odim, padding_idx, pos_enc):
+        super().__init__(torch.nn.Embedding(idim, odim, padding_idx=padding_idx), pos_enc)
+
+    def forward(self, tokens):
+        pad = self[0].padding_idx
+        return self[1](R_.PlainEmbedFn.apply(tokens, self[0].weight, -1 if pad is None else pad))
+
+
 class TransformerEncoder(torch.nn.Module):
-    """reference: transformer/encoder.py:48-332 (selfattn + linear positionwise + conv2d input)"""
+    """reference: transformer/encoder.py:48-332 (selfattn + linear positionwise; conv2d / linear / embed
+    input layers; `forward_one_step` with per-layer caches for language-model scoring)"""
 
     def __init__(self, idim, attention_dim=256, attention_heads=4, linear_units=2048, num_blocks=6,
                  dropout_rate=0.1, positional_dropout_rate=0.1, attention_dropout_rate=0.0, input_layer="conv2d",
                  pos_enc_class=PositionalEncoding, normalize_before=True, concat_after=False,
                  positionwise_layer_type="linear", positionwise_conv_kernel_size=1, padding_idx=-1, **unused):
         super().__init__()
-        if input_layer != "conv2d" or positionwise_layer_type != "linear":
-            raise NotImplementedError("only conv2d input + linear positionwise are on the HIP path")
-        self.embed = Conv2dSubsampling(idim, attention_dim, dropout_rate,
-                                       pos_enc_class(attention_dim, positional_dropout_rate))
+        if positionwise_layer_type != "linear":
+            raise NotImplementedError("only the linear positionwise layer is on the HIP path")
+        pos = pos_enc_class(attention_dim, positional_dropout_rate)
+        if input_layer == "conv2d":
+            self.embed = Conv2dSubsampling(idim, attention_dim, dropout_rate, pos)
+        elif input_layer == "linear":
+            self.embed = _LinearInput(idim, attention_dim, dropout_rate, pos)
+        elif input_layer == "embed":
+            self.embed = _EmbedInput(idim, attention_dim, padding_idx, pos)
+        else:
+            raise NotImplementedError("input_layer %r: conv2d / linear / embed are on the HIP path" % (input_layer,))
         self.normalize_before = normalize_before
         self.encoders = repeat(
             num_blocks,
@@ -464,12 +507,30 @@ class TransformerEncoder(torch.nn.Module):
         if self.normalize_before:
             self.after_norm = LayerNorm(attention_dim)
 
+    def _embed(self, xs, masks):
+        if isinstance(self.embed, Conv2dSubsampling):
+            return self.embed(xs, masks)
+        return self.embed(xs), masks
+
     def forward(self, xs, masks):
-        xs, masks = self.embed(xs, masks)
+        xs, masks = self._embed(xs, masks)
         xs, masks = self.encoders(xs, masks)
         if self.normalize_before:
             xs = self.after_norm(xs)
         return xs, masks
+
+    def forward_one_step(self, xs, masks, cache=None):
+        """reference: encoder.py:306-332 -> (ys [B, L, D], masks, new per-layer caches)"""
+        xs, masks = self._embed(xs, masks)
+        if cache is None:
+            cache = [None] * len(self.encoders)
+        new_cache = []
+        for c, e in zip(cache, self.encoders):
+            xs, masks = e(xs, masks, cache=c)
+            new_cache.append(xs)
+        if self.normalize_before:
+            xs = self.after_norm(xs.contiguous())
+        return xs, masks, new_cache
 
 
 # ---- decoder ------------------------------------------------------------------------------------
@@ -507,7 +568,7 @@ class DecoderLayer(torch.nn.Module):
         return x, tgt_mask, memory, memory_mask
 
 
-class Decoder(torch.nn.Module):
+class Decoder(torch.nn.Module, BatchScorerInterface):
     """reference: transformer/decoder.py:47-370 (embed input layer, selfattn layers)"""
 
     def __init__(self, odim, selfattention_layer_type="selfattn", attention_dim=256, attention_heads=4,

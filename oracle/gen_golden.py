@@ -377,6 +377,51 @@ def main():
          loss=loss.detach(), loss_att=stats["loss_att"], loss_ctc=stats["loss_ctc"], acc=float(stats["acc"]),
          weight=weight, **sd0, **grads_np(m2))
 
+    # ---- a19 / f2: BatchBeamSearch, and LM shallow fusion (TransformerLM, SequentialRNNLM) ----------
+    from espnet.nets.batch_beam_search import BatchBeamSearch
+    from espnet.nets.beam_search import BeamSearch as RefBeamSearch
+    from espnet.nets.scorers.ctc import CTCPrefixScorer as RefCTCScorer
+    from espnet.nets.scorers.length_bonus import LengthBonus as RefLengthBonus
+    from espnet2.lm.seq_rnn_lm import SequentialRNNLM
+    from espnet2.lm.transformer_lm import TransformerLM
+    torch.manual_seed(29)
+    tlm = TransformerLM(30, pos_enc=None, embed_unit=16, att_unit=32, head=2, unit=48, layer=2, dropout_rate=0.0)
+    tlm_pe = TransformerLM(30, pos_enc="sinusoidal", embed_unit=16, att_unit=32, head=2, unit=48, layer=1,
+                           dropout_rate=0.0)
+    rlm = SequentialRNNLM(30, unit=24, nlayers=2, rnn_type="lstm")
+    glm = SequentialRNNLM(30, unit=24, nhid=20, nlayers=1, rnn_type="gru")
+    m2.eval()
+    for lm_ in (tlm, tlm_pe, rlm, glm):
+        lm_.eval()
+    fus = {}
+    with torch.no_grad():
+        toks = torch.randint(1, 29, (2, 6), generator=g)
+        toks[1, 4:] = 0
+        for nm, lm_ in (("tlm", tlm), ("tlm_pe", tlm_pe), ("rlm", rlm), ("glm", glm)):
+            fus["lm_" + nm + "_logits"] = lm_(toks, None)[0]
+        enc_out, _ = m2.encode(speech[:1], slen[:1])
+        for tag, cls, lm_, cw, lw in (("bbeam_w00", BatchBeamSearch, None, 0.0, 0.0),
+                                      ("bbeam_w03", BatchBeamSearch, None, 0.3, 0.0),
+                                      ("bbeam_w10", BatchBeamSearch, None, 1.0, 0.0),
+                                      ("bbeam_tlm", BatchBeamSearch, tlm, 0.3, 0.6),
+                                      ("bbeam_tlm_pe", BatchBeamSearch, tlm_pe, 0.3, 0.6),
+                                      ("bbeam_rlm", BatchBeamSearch, rlm, 0.3, 0.6),
+                                      ("bbeam_glm", BatchBeamSearch, glm, 0.5, 0.4),
+                                      ("beam_tlm", RefBeamSearch, tlm, 0.3, 0.6),
+                                      ("beam_rlm", RefBeamSearch, rlm, 0.3, 0.6)):
+            scorers = dict(decoder=m2.decoder, ctc=RefCTCScorer(ctc=m2.ctc, eos=m2.eos),
+                           length_bonus=RefLengthBonus(30), lm=lm_)
+            bs = cls(beam_size=4, vocab_size=30, weights=dict(decoder=1.0 - cw, ctc=cw, lm=lw, length_bonus=0.1),
+                     scorers=scorers, sos=m2.sos, eos=m2.eos, token_list=None,
+                     pre_beam_score_key=None if cw == 1.0 else "full")
+            nb = bs(x=enc_out[0], maxlenratio=0.0, minlenratio=0.0)[:3]
+            fus[tag + "_scores"] = np.asarray([float(h.score) for h in nb], dtype=np.float64)
+            fus[tag + "_lens"] = np.asarray([len(h.yseq) for h in nb], dtype=np.int64)
+            fus[tag + "_yseq"] = np.asarray(sum([[int(t) for t in h.yseq] for h in nb], []), dtype=np.int64)
+            print(tag, fus[tag + "_scores"], [h.yseq.tolist() for h in nb][:1])
+    save(out("decode_fusion.npz"), speech=speech[0], lm_tokens=toks, enc_out=enc_out[0], **fus, **sd_np(m2, "sd/"),
+         **sd_np(tlm, "tlm/"), **sd_np(tlm_pe, "tlm_pe/"), **sd_np(rlm, "rlm/"), **sd_np(glm, "glm/"))
+
     # ---- a20: RNN path (VGG-BLSTMP encoder, location-aware attention LSTM decoder, CTC) -----------
     from espnet.nets.pytorch_backend.e2e_asr import E2E as RnnE2E
 

@@ -512,3 +512,97 @@ def test_feature_layers_golden(tmp_path):
             report("global_mvn %d%d" % (nm, nv), y, p["gmvn_%d%d" % (nm, nv)], 2e-6)
             y, _ = UtteranceMVN(norm_means=bool(nm), norm_vars=bool(nv))(x, lens)
             report("utterance_mvn %d%d" % (nm, nv), y, p["umvn_%d%d" % (nm, nv)], 5e-6)
+
+
+def _nbest_from(p, tag):
+    lens, flat = p[tag + "_lens"].tolist(), p[tag + "_yseq"].tolist()
+    want, o = [], 0
+    for n in lens:
+        want.append(flat[o:o + n])
+        o += n
+    return want, p[tag + "_scores"].tolist()
+
+
+def _fusion_models():
+    from espnet_amd.espnet2 import (CTC, ConformerEncoder, ESPnetASRModel, SequentialRNNLM, TransformerDecoder,
+                                    TransformerLM)
+    g = load_golden("decode_fusion.npz")
+    p, sd, _ = split_golden(g)
+    enc = ConformerEncoder(20, output_size=64, attention_heads=4, linear_units=96, num_blocks=2, dropout_rate=0.0,
+                           positional_dropout_rate=0.0, attention_dropout_rate=0.0, macaron_style=True,
+                           cnn_module_kernel=7)
+    dec = TransformerDecoder(30, 64, attention_heads=4, linear_units=96, num_blocks=1, dropout_rate=0.0,
+                             positional_dropout_rate=0.0)
+    model = ESPnetASRModel(vocab_size=30, encoder=enc, decoder=dec, ctc=CTC(30, 64, ctc_type="builtin"),
+                           ctc_weight=0.3, lsm_weight=0.1)
+    model = load_sd(model, sd).eval()
+    lms = dict(tlm=TransformerLM(30, pos_enc=None, embed_unit=16, att_unit=32, head=2, unit=48, layer=2,
+                                 dropout_rate=0.0),
+               tlm_pe=TransformerLM(30, pos_enc="sinusoidal", embed_unit=16, att_unit=32, head=2, unit=48, layer=1,
+                                    dropout_rate=0.0),
+               rlm=SequentialRNNLM(30, unit=24, nlayers=2, rnn_type="lstm"),
+               glm=SequentialRNNLM(30, unit=24, nhid=20, nlayers=1, rnn_type="gru"))
+    for k in lms:
+        sub = {n[len(k) + 1:]: torch.from_numpy(np.asarray(v)) for n, v in g.items() if n.startswith(k + "/")}
+        assert list(lms[k].state_dict().keys()) == list(sub.keys()), k    # reference LM checkpoints load key-for-key
+        lms[k].load_state_dict(sub)
+        lms[k].to(DEV).eval()
+    return p, model, lms
+
+
+def test_lm_forward_golden():
+    """TransformerLM / SequentialRNNLM logits on a padded token batch against the reference's own modules."""
+    p, _, lms = _fusion_models()
+    toks = p["lm_tokens"].to(DEV)
+    with torch.no_grad():
+        for k, lm in lms.items():
+            y, _ = lm(toks, None)
+            report("lm %s logits" % k, y, p["lm_%s_logits" % k], 2e-5)
+
+
+@pytest.mark.parametrize("tag,batch,lm,cw,lw", [
+    ("bbeam_w00", True, None, 0.0, 0.0), ("bbeam_w03", True, None, 0.3, 0.0), ("bbeam_w10", True, None, 1.0, 0.0),
+    ("bbeam_tlm", True, "tlm", 0.3, 0.6), ("bbeam_tlm_pe", True, "tlm_pe", 0.3, 0.6),
+    ("bbeam_rlm", True, "rlm", 0.3, 0.6), ("bbeam_glm", True, "glm", 0.5, 0.4),
+    ("beam_tlm", False, "tlm", 0.3, 0.6), ("beam_rlm", False, "rlm", 0.3, 0.6)])
+def test_decode_fusion_golden(tag, batch, lm, cw, lw):
+    """a19 + §8f rank 2: BatchBeamSearch / BeamSearch with CTC prefix scores, length bonus and LM shallow fusion
+    against the n-best the reference's own search produced on the same weights: ids exact, scores to 1e-4."""
+    from espnet_amd.nets.batch_beam_search import BatchBeamSearch
+    from espnet_amd.nets.beam_search import BeamSearch
+    from espnet_amd.nets.ctc_prefix_score import CTCPrefixScorer, LengthBonus
+    p, model, lms = _fusion_models()
+    with torch.no_grad():
+        enc, _ = model.encode(p["speech"].unsqueeze(0).to(DEV), torch.tensor([p["speech"].shape[0]]))
+    report("fusion enc_out", enc[0], p["enc_out"], 5e-5)
+    scorers = dict(decoder=model.decoder, ctc=CTCPrefixScorer(model.ctc, model.eos), length_bonus=LengthBonus(30),
+                   lm=lms[lm] if lm else None)
+    cls = BatchBeamSearch if batch else BeamSearch
+    bs = cls(scorers, dict(decoder=1.0 - cw, ctc=cw, lm=lw, length_bonus=0.1), 4, 30, model.sos, model.eos,
+             pre_beam_score_key=None if cw == 1.0 else "full")
+    got = bs(enc[0])[:3]
+    want, scores = _nbest_from(p, tag)
+    print(f"[parity] {tag}: hip {[round(float(h.score), 4) for h in got]} ref {[round(s, 4) for s in scores]}")
+    assert [h.yseq.tolist() for h in got] == want
+    for h, s in zip(got, scores):
+        assert abs(float(h.score) - s) <= 1e-4 * max(1.0, abs(s))
+        assert abs(sum(bs.weights[k] * float(v) for k, v in h.scores.items()) - float(h.score)) < 1e-3
+
+
+def test_speech2text():
+    """espnet2 inference surface: Speech2Text(model, lm) -> [(text, token, token_int, hyp)], BatchBeamSearch selected
+    as in asr_inference.py:108-118; same n-best as the reference's search with these weights."""
+    from espnet_amd.espnet2 import Speech2Text
+    from espnet_amd.espnet2.asr_inference import CharTokenizer
+    from espnet_amd.nets.batch_beam_search import BatchBeamSearch
+    p, model, lms = _fusion_models()
+    token_list = ["<blank>"] + [str(i) for i in range(1, 28)] + ["<space>", "<sos/eos>"]
+    s2t = Speech2Text(model, lm=lms["rlm"], token_list=token_list, tokenizer=CharTokenizer(), device=DEV, beam_size=4,
+                      ctc_weight=0.3, lm_weight=0.6, penalty=0.1, nbest=3)
+    assert isinstance(s2t.beam_search, BatchBeamSearch)
+    res = s2t(p["speech"].numpy())
+    want, scores = _nbest_from(p, "bbeam_rlm")
+    assert [r[3].yseq.tolist() for r in res] == want
+    text, token, token_int, hyp = res[0]
+    assert token_int == [t for t in want[0][1:-1] if t != 0] and token == [token_list[t] for t in token_int]
+    assert text == "".join(" " if t == "<space>" else t for t in token)
