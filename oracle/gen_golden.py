@@ -390,8 +390,14 @@ def main():
                            dropout_rate=0.0)
     rlm = SequentialRNNLM(30, unit=24, nlayers=2, rnn_type="lstm")
     glm = SequentialRNNLM(30, unit=24, nhid=20, nlayers=1, rnn_type="gru")
+    from espnet.nets.pytorch_backend.lm.default import DefaultRNNLM
+    from espnet.nets.pytorch_backend.lm.transformer import TransformerLM as TransformerLM1
+    dlm = DefaultRNNLM(30, argparse.Namespace(layer=2, unit=24, type="lstm", dropout_rate=0.0, embed_unit=None))
+    dgm = DefaultRNNLM(30, argparse.Namespace(layer=1, unit=20, type="gru", dropout_rate=0.0, embed_unit=12))
+    tlm1 = TransformerLM1(30, argparse.Namespace(layer=1, unit=40, att_unit=32, embed_unit=16, head=4,
+                                                  dropout_rate=0.0, pos_enc="sinusoidal"))
     m2.eval()
-    for lm_ in (tlm, tlm_pe, rlm, glm):
+    for lm_ in (tlm, tlm_pe, rlm, glm, dlm, dgm, tlm1):
         lm_.eval()
     fus = {}
     with torch.no_grad():
@@ -399,6 +405,9 @@ def main():
         toks[1, 4:] = 0
         for nm, lm_ in (("tlm", tlm), ("tlm_pe", tlm_pe), ("rlm", rlm), ("glm", glm)):
             fus["lm_" + nm + "_logits"] = lm_(toks, None)[0]
+        tgt = torch.cat([toks[:, 1:], torch.zeros(2, 1, dtype=toks.dtype)], dim=1)
+        for nm, lm_ in (("dlm", dlm), ("dgm", dgm), ("tlm1", tlm1)):
+            fus["lm_" + nm + "_loss"] = np.asarray([float(v) for v in lm_(toks, tgt)], dtype=np.float64)
         enc_out, _ = m2.encode(speech[:1], slen[:1])
         for tag, cls, lm_, cw, lw in (("bbeam_w00", BatchBeamSearch, None, 0.0, 0.0),
                                       ("bbeam_w03", BatchBeamSearch, None, 0.3, 0.0),
@@ -407,6 +416,9 @@ def main():
                                       ("bbeam_tlm_pe", BatchBeamSearch, tlm_pe, 0.3, 0.6),
                                       ("bbeam_rlm", BatchBeamSearch, rlm, 0.3, 0.6),
                                       ("bbeam_glm", BatchBeamSearch, glm, 0.5, 0.4),
+                                      ("bbeam_dlm", BatchBeamSearch, dlm, 0.3, 0.6),
+                                      ("beam_dgm", RefBeamSearch, dgm, 0.3, 0.6),
+                                      ("bbeam_tlm1", BatchBeamSearch, tlm1, 0.3, 0.6),
                                       ("beam_tlm", RefBeamSearch, tlm, 0.3, 0.6),
                                       ("beam_rlm", RefBeamSearch, rlm, 0.3, 0.6)):
             scorers = dict(decoder=m2.decoder, ctc=RefCTCScorer(ctc=m2.ctc, eos=m2.eos),
@@ -420,7 +432,8 @@ def main():
             fus[tag + "_yseq"] = np.asarray(sum([[int(t) for t in h.yseq] for h in nb], []), dtype=np.int64)
             print(tag, fus[tag + "_scores"], [h.yseq.tolist() for h in nb][:1])
     save(out("decode_fusion.npz"), speech=speech[0], lm_tokens=toks, enc_out=enc_out[0], **fus, **sd_np(m2, "sd/"),
-         **sd_np(tlm, "tlm/"), **sd_np(tlm_pe, "tlm_pe/"), **sd_np(rlm, "rlm/"), **sd_np(glm, "glm/"))
+         **sd_np(tlm, "tlm/"), **sd_np(tlm_pe, "tlm_pe/"), **sd_np(rlm, "rlm/"), **sd_np(glm, "glm/"),
+         **sd_np(dlm, "dlm/"), **sd_np(dgm, "dgm/"), **sd_np(tlm1, "tlm1/"))
 
     # ---- a20: RNN path (VGG-BLSTMP encoder, location-aware attention LSTM decoder, CTC) -----------
     from espnet.nets.pytorch_backend.e2e_asr import E2E as RnnE2E

@@ -542,6 +542,12 @@ def _fusion_models():
                                     dropout_rate=0.0),
                rlm=SequentialRNNLM(30, unit=24, nlayers=2, rnn_type="lstm"),
                glm=SequentialRNNLM(30, unit=24, nhid=20, nlayers=1, rnn_type="gru"))
+    import argparse as ap
+    from espnet_amd.nets.lm import DefaultRNNLM, TransformerLM as TransformerLM1
+    lms.update(dlm=DefaultRNNLM(30, ap.Namespace(layer=2, unit=24, type="lstm", dropout_rate=0.0, embed_unit=None)),
+               dgm=DefaultRNNLM(30, ap.Namespace(layer=1, unit=20, type="gru", dropout_rate=0.0, embed_unit=12)),
+               tlm1=TransformerLM1(30, ap.Namespace(layer=1, unit=40, att_unit=32, embed_unit=16, head=4,
+                                                    dropout_rate=0.0, pos_enc="sinusoidal")))
     for k in lms:
         sub = {n[len(k) + 1:]: torch.from_numpy(np.asarray(v)) for n, v in g.items() if n.startswith(k + "/")}
         assert list(lms[k].state_dict().keys()) == list(sub.keys()), k    # reference LM checkpoints load key-for-key
@@ -556,15 +562,23 @@ def test_lm_forward_golden():
     toks = p["lm_tokens"].to(DEV)
     with torch.no_grad():
         for k, lm in lms.items():
-            y, _ = lm(toks, None)
-            report("lm %s logits" % k, y, p["lm_%s_logits" % k], 2e-5)
+            if "lm_%s_logits" % k in p:
+                y, _ = lm(toks, None)
+                report("lm %s logits" % k, y, p["lm_%s_logits" % k], 2e-5)
+            else:     # espnet1 interface: forward(x, t) -> (loss, nll, count)
+                tgt = torch.cat([toks[:, 1:], torch.zeros(2, 1, dtype=toks.dtype, device=DEV)], dim=1)
+                got = [float(v) for v in lm(toks, tgt)]
+                want = p["lm_%s_loss" % k].tolist()
+                print(f"[parity] lm {k} (loss, nll, count): hip {got} ref {want}")
+                assert all(abs(a - b) <= 2e-5 * max(1.0, abs(b)) for a, b in zip(got, want))
 
 
 @pytest.mark.parametrize("tag,batch,lm,cw,lw", [
     ("bbeam_w00", True, None, 0.0, 0.0), ("bbeam_w03", True, None, 0.3, 0.0), ("bbeam_w10", True, None, 1.0, 0.0),
     ("bbeam_tlm", True, "tlm", 0.3, 0.6), ("bbeam_tlm_pe", True, "tlm_pe", 0.3, 0.6),
     ("bbeam_rlm", True, "rlm", 0.3, 0.6), ("bbeam_glm", True, "glm", 0.5, 0.4),
-    ("beam_tlm", False, "tlm", 0.3, 0.6), ("beam_rlm", False, "rlm", 0.3, 0.6)])
+    ("beam_tlm", False, "tlm", 0.3, 0.6), ("beam_rlm", False, "rlm", 0.3, 0.6),
+    ("bbeam_dlm", True, "dlm", 0.3, 0.6), ("beam_dgm", False, "dgm", 0.3, 0.6), ("bbeam_tlm1", True, "tlm1", 0.3, 0.6)])
 def test_decode_fusion_golden(tag, batch, lm, cw, lw):
     """a19 + §8f rank 2: BatchBeamSearch / BeamSearch with CTC prefix scores, length bonus and LM shallow fusion
     against the n-best the reference's own search produced on the same weights: ids exact, scores to 1e-4."""
