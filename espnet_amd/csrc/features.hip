@@ -126,6 +126,60 @@ __global__ void utt_apply_kernel(const float* __restrict__ x, float* __restrict_
   }
 }
 
+// ---- log-mel frontend ---------------------------------------------------------------------------------
+// torch.stft(center=True, pad_mode="reflect") pads the [B, L] batch by n_fft/2 reflected samples on both sides
+// (stft.py:82-91).  y rows have stride ldy (a multiple of the hop, so that frame t of utterance b is the GEMM
+// operand row b*ldy/hop + t with leading dimension hop); the tail [L + 2 pad, ldy) is zero.
+__global__ void reflect_pad_kernel(const float* __restrict__ x, long ldx, float* __restrict__ y, long ldy, int B, int L,
+                                   int pad) {
+  const long n = (long)B * ldy;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+    const long b = i / ldy; const long j = i % ldy;
+    float v = 0.f;
+    if (j < L + 2L * pad) {
+      long s = j - pad;
+      if (s < 0) s = -s;
+      if (s >= L) s = 2L * (L - 1) - s;
+      v = x[b * ldx + s];
+    }
+    y[i] = v;
+  }
+}
+
+// One wave per frame: |X|^2 of the F = n_fft/2+1 interleaved (re, im) bins into LDS, then lane m sums its mel
+// filter's bin range [lo[m], hi[m]) (Slaney triangles are short), clamp 1e-10, log; frames >= flens[b] -> 0.
+// reference: frontend/default.py:121-124 (power spectrum), log_mel.py:55-75
+__global__ __launch_bounds__(256) void logmel_kernel(const float* __restrict__ spec, long ld, long rows_per_utt,
+                                                     const float* __restrict__ melmat, const int* __restrict__ lo,
+                                                     const int* __restrict__ hi, const int* __restrict__ flens,
+                                                     float* __restrict__ out, int B, int T, int F, int M,
+                                                     float log_scale, int power_input) {
+  extern __shared__ float pw[];   // [4][F]
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const long fr = (long)blockIdx.x * 4 + wave;
+  if (fr >= (long)B * T) return;
+  const int b = fr / T, t = fr % T;
+  float* o = out + fr * M;
+  if (flens && t >= flens[b]) {
+    for (int m = lane; m < M; m += 64) o[m] = 0.f;
+    return;
+  }
+  const float* row1 = spec + ((long)b * rows_per_utt + t) * ld;
+  const float2* row = reinterpret_cast<const float2*>(row1);
+  float* p = pw + wave * F;
+  if (power_input) {
+    for (int f = lane; f < F; f += 64) p[f] = row1[f];
+  } else {
+    for (int f = lane; f < F; f += 64) { const float2 c = row[f]; p[f] = c.x * c.x + c.y * c.y; }
+  }
+  __builtin_amdgcn_wave_barrier();
+  for (int m = lane; m < M; m += 64) {
+    float acc = 0.f;
+    for (int f = lo[m]; f < hi[m]; ++f) acc += p[f] * melmat[(long)f * M + m];
+    o[m] = logf(fmaxf(acc, 1e-10f)) * log_scale;
+  }
+}
+
 }  // namespace
 
 extern "C" {
@@ -161,6 +215,27 @@ int eamd_utterance_mvn(const float* x, float* y, const int32_t* lens, float* wor
   EAMD_LAUNCH_CHECK();
   hipLaunchKernelGGL(utt_apply_kernel, dim3(grid_for((long)B * T * F)), dim3(256), 0, s, x, y, lens, mean, var, norm_means,
                      norm_vars, eps, B, T, F);
+  EAMD_LAUNCH_CHECK();
+  return EAMD_OK;
+}
+
+int eamd_reflect_pad(const float* x, int64_t ldx, float* y, int64_t ldy, int B, int L, int pad, void* stream) {
+  if (!x || !y || B <= 0 || L <= 1 || pad < 0 || pad >= L || ldx < L || ldy < L + 2L * pad) return EAMD_EINVAL;
+  hipLaunchKernelGGL(reflect_pad_kernel, dim3(grid_for((long)B * ldy)), dim3(256), 0, (hipStream_t)stream, x, (long)ldx, y,
+                     (long)ldy, B, L, pad);
+  EAMD_LAUNCH_CHECK();
+  return EAMD_OK;
+}
+
+int eamd_logmel(const float* spec, int64_t ld, int64_t rows_per_utt, const float* melmat, const int32_t* lo,
+                const int32_t* hi, const int32_t* flens, float* out, int B, int T, int F, int M, float log_scale,
+                int power_input, void* stream) {
+  if (!spec || !melmat || !lo || !hi || !out || B <= 0 || T <= 0 || F <= 0 || M <= 0 || rows_per_utt < T) return EAMD_EINVAL;
+  if (power_input ? ld < F : (ld < 2L * F || (ld & 1) || ((uintptr_t)spec & 7))) return EAMD_EINVAL;
+  const size_t sm = (size_t)4 * F * sizeof(float);
+  if (sm > 64 * 1024) return EAMD_EUNSUPPORTED;
+  hipLaunchKernelGGL(logmel_kernel, dim3((unsigned)(((long)B * T + 3) / 4)), dim3(256), sm, (hipStream_t)stream, spec,
+                     (long)ld, (long)rows_per_utt, melmat, lo, hi, flens, out, B, T, F, M, log_scale, power_input);
   EAMD_LAUNCH_CHECK();
   return EAMD_OK;
 }

@@ -3,3 +3,4 @@ from .asr import CTC, ConformerEncoder, ESPnetASRModel, TransformerDecoder, Tran
 from .layers import GlobalMVN, MaskAlongAxis, SpecAug, TimeWarp, UtteranceMVN  # noqa: F401,E402
 from .lm import SequentialRNNLM, TransformerLM  # noqa: F401,E402
 from .asr_inference import Speech2Text  # noqa: F401,E402
+from .frontend import DefaultFrontend, LogMel, Stft  # noqa: F401,E402

@@ -176,8 +176,9 @@ class CTC(torch.nn.Module):
 
 
 class ESPnetASRModel(AbsESPnetModel):
-    """reference: espnet2/asr/espnet_model.py:35-290.  frontend = None (fbank features are the input); specaug and
-    normalize take the espnet_amd.espnet2.layers modules (SpecAug, GlobalMVN, UtteranceMVN)."""
+    """reference: espnet2/asr/espnet_model.py:35-290.  frontend = None (fbank features are the input) or
+    espnet_amd.espnet2.DefaultFrontend (waveform input); specaug and normalize take the espnet_amd.espnet2.layers
+    modules (SpecAug, GlobalMVN, UtteranceMVN)."""
 
     def __init__(self, vocab_size, token_list=None, frontend=None, specaug=None, normalize=None, encoder=None,
                  decoder=None, ctc=None, rnnt_decoder=None, ctc_weight=0.5, ignore_id=-1, lsm_weight=0.0,
@@ -185,8 +186,6 @@ class ESPnetASRModel(AbsESPnetModel):
                  sym_blank="<blank>"):
         assert 0.0 <= ctc_weight <= 1.0, ctc_weight
         assert rnnt_decoder is None, "Not implemented"
-        if frontend is not None:
-            raise NotImplementedError("waveform frontends are a later scope row (SURVEY.md §8f rank 4)")
         super().__init__()
         self.sos = vocab_size - 1
         self.eos = vocab_size - 1
@@ -194,7 +193,7 @@ class ESPnetASRModel(AbsESPnetModel):
         self.ignore_id = ignore_id
         self.ctc_weight = ctc_weight
         self.token_list = list(token_list) if token_list is not None else None
-        self.frontend, self.specaug, self.normalize = None, specaug, normalize
+        self.frontend, self.specaug, self.normalize = frontend, specaug, normalize
         self.encoder = encoder
         self.decoder = decoder
         self.ctc = None if ctc_weight == 0.0 else ctc
@@ -206,7 +205,7 @@ class ESPnetASRModel(AbsESPnetModel):
     def encode(self, speech, speech_lengths):
         """reference: espnet_model.py:178-213 (features = speech when frontend is None; SpecAug in training mode
         only, then the normalisation layer, :192-197)"""
-        feats, feats_lengths = speech, speech_lengths
+        feats, feats_lengths = self._extract_feats(speech, speech_lengths)
         if self.specaug is not None and self.training:
             feats, feats_lengths = self.specaug(feats, feats_lengths)
         if self.normalize is not None:
@@ -215,8 +214,16 @@ class ESPnetASRModel(AbsESPnetModel):
         assert encoder_out.size(0) == speech.size(0)
         return encoder_out, encoder_out_lens
 
+    def _extract_feats(self, speech, speech_lengths):
+        """reference: espnet_model.py:214-233"""
+        speech = speech[:, : int(max(_lens(speech_lengths)))]
+        if self.frontend is not None:
+            return self.frontend(speech.contiguous(), speech_lengths)
+        return speech, speech_lengths
+
     def collect_feats(self, speech, speech_lengths, text, text_lengths):
-        return {"feats": speech, "feats_lengths": speech_lengths}
+        feats, feats_lengths = self._extract_feats(speech, speech_lengths)
+        return {"feats": feats, "feats_lengths": feats_lengths}
 
     def forward(self, speech, speech_lengths, text, text_lengths):
         assert text_lengths.dim() == 1, text_lengths.shape

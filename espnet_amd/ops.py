@@ -905,3 +905,28 @@ def utterance_mvn(x, lens, norm_means, norm_vars, eps):
     check(_lib.lib().eamd_utterance_mvn(ptr(x), ptr(y), ptr(lens), ptr(ws), int(norm_means), int(norm_vars), C.c_float(eps),
                                         B, T, F, stream_ptr()), "eamd_utterance_mvn")
     return y
+
+
+def reflect_pad(x, pad, ldy, tail):
+    """x [B, L] fp32 -> flat buffer of B rows of stride ldy (+ `tail` zero floats): reflect padding by `pad` on both
+    sides of every row (torch.stft center=True), zeros up to ldy"""
+    B, L = x.shape
+    assert x.dtype == torch.float32 and x.is_contiguous() and ldy >= L + 2 * pad
+    y = torch.zeros(B * ldy + tail, device=x.device, dtype=torch.float32)
+    check(_lib.lib().eamd_reflect_pad(ptr(x), C.c_int64(L), ptr(y), C.c_int64(ldy), B, L, pad, stream_ptr()),
+          "eamd_reflect_pad")
+    return y
+
+
+def logmel(spec, ld, rows_per_utt, melmat, lo, hi, flens, B, T, F, log_scale=1.0, power_input=False):
+    """-> [B, T, M] log-mel features (see include/espnet_amd.h: eamd_logmel)"""
+    M = melmat.shape[1]
+    assert melmat.shape[0] == F and melmat.is_contiguous() and lo.dtype == torch.int32 and hi.dtype == torch.int32
+    need = ((B - 1) * rows_per_utt + T - 1) * ld + (F if power_input else 2 * F)
+    if spec.numel() < need:
+        raise _lib.EamdError(f"logmel: spectrum buffer too small ({spec.numel()} < {need})")
+    out = torch.empty(B, T, M, device=spec.device, dtype=torch.float32)
+    check(_lib.lib().eamd_logmel(ptr(spec), C.c_int64(ld), C.c_int64(rows_per_utt), ptr(melmat), ptr(lo), ptr(hi),
+                                 ptr(flens) if flens is not None else None, ptr(out), B, T, F, M, C.c_float(log_scale),
+                                 int(power_input), stream_ptr()), "eamd_logmel")
+    return out

@@ -248,6 +248,21 @@ int eamd_global_mvn(const float* x, float* y, const int32_t* lens, const float* 
 int eamd_utterance_mvn(const float* x, float* y, const int32_t* lens, float* workspace, int norm_means, int norm_vars,
                        float eps, int B, int T, int F, void* stream);
 
+/* ---- log-mel frontend ------------------------------------------------
+ * reference: espnet2/layers/stft.py:62-111 (torch.stft: hann window, center=True -> reflect padding of the padded
+ * batch by n_fft/2, hop_length, onesided), espnet2/asr/frontend/default.py:93-133 (power spectrum),
+ * espnet2/layers/log_mel.py:20-75 (librosa mel matrix, clamp 1e-10, log, padded frames zeroed).
+ * The DFT itself is an eamd_gemm call in fp32: A = the padded waveform read as overlapping rows (lda = hop),
+ * B = the windowed DFT basis [2F, n_fft] with interleaved (cos, -sin) rows.
+ * eamd_reflect_pad: y[b, j] = x[b, reflect(j - pad)] for j < L + 2 pad, 0 for the rest of the row (ldy >= L + 2 pad). */
+int eamd_reflect_pad(const float* x, int64_t ldx, float* y, int64_t ldy, int B, int L, int pad, void* stream);
+/* spec: frame t of utterance b = row b*rows_per_utt + t, F interleaved (re, im) pairs, row stride ld (even) -
+ * or, with power_input != 0, F power values per row (LogMel on its own); melmat [F, M]; lo/hi [M] = non-zero bin range of each mel filter; flens [B] (NULL = T) valid frames;
+ * out[b,t,m] = log(max(sum_f |spec|^2 melmat[f,m], 1e-10)) * log_scale, 0 for t >= flens[b]. */
+int eamd_logmel(const float* spec, int64_t ld, int64_t rows_per_utt, const float* melmat, const int32_t* lo,
+                const int32_t* hi, const int32_t* flens, float* out, int B, int T, int F, int M, float log_scale,
+                int power_input, void* stream);
+
 /* ---- recurrent layers (RNN paths) ------------------------------
  * One LSTM step on gate pre-activations gates[B,4H] = x W_ih^T + b_ih + h W_hh^T + b_hh (the products are
  * eamd_gemm calls), gate order i,f,g,o as torch.nn.LSTM / LSTMCell.

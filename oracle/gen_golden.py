@@ -615,6 +615,41 @@ def main():
                 res["umvn_%d%d" % (nm, nv)] = um(x.clone(), ll)[0]
     save(out("feature_layers.npz"), feats=feats, stats_count=cnt, stats_sum=ssum, stats_sum_square=ssq, **res)
 
+    # ---- 8f rank 4: log-mel frontend.  The reference's Stft calls torch.stft without `return_complex`, which the
+    # installed torch requires; the call below is the same one with that flag (and view_as_real for the (..., 2)
+    # layout stft.py:92-95 expects).  librosa is absent: LogMel's `librosa.filters.mel` resolves to the oracle's
+    # restatement of that function (a stub module, like warprnnt_pytorch above).
+    import asr_oracle as _orc
+    lib = types.ModuleType("librosa")
+    lib.filters = types.ModuleType("librosa.filters")
+    lib.filters.mel = lambda sr, n_fft, n_mels=128, fmin=0.0, fmax=None, htk=False: _orc.mel_filterbank(
+        sr, n_fft, n_mels, fmin, fmax, htk)
+    sys.modules["librosa"], sys.modules["librosa.filters"] = lib, lib.filters
+    from espnet2.layers.log_mel import LogMel
+    from espnet2.layers.stft import Stft
+    _stft = torch.stft
+    torch.stft = lambda *a, **k: torch.view_as_real(_stft(*a, return_complex=True, **k))
+    try:
+        g = torch.Generator().manual_seed(13)
+        wav = torch.randn(3, 4000, generator=g) * torch.linspace(0.05, 1.0, 4000)
+        wav = wav + 0.3 * torch.sin(torch.arange(4000) * 0.05)
+        wlens = torch.tensor([4000, 3301, 1500])
+        wav = wav * (torch.arange(4000)[None, :] < wlens[:, None])
+        fr = {}
+        for tag, kw_s, kw_m in (("default", dict(), dict()),
+                                ("win400", dict(n_fft=512, win_length=400, hop_length=160), dict(n_mels=40, htk=True)),
+                                ("n256", dict(n_fft=256, hop_length=64), dict(n_fft=256, n_mels=23, fmin=80, fmax=7600))):
+            st = Stft(**kw_s)
+            spec, flens = st(wav, wlens)
+            power = spec[..., 0] ** 2 + spec[..., 1] ** 2          # frontend/default.py:121-124
+            feats, _ = LogMel(**kw_m)(power, flens)
+            fr[tag + "_stft"], fr[tag + "_flens"], fr[tag + "_feats"] = spec, flens, feats
+        wav2 = torch.stack([wav, wav.flip(0)], dim=-1)             # (B, L, C): channel 0 is used in eval mode
+        fr["mc_stft"] = Stft()(wav2, wlens)[0]
+    finally:
+        torch.stft = _stft
+    save(out("frontend.npz"), wav=wav, wlens=wlens, **fr)
+
     e2e_case("e2e_conformer.npz", ConfE2E, dict(transformer_encoder_pos_enc_layer_type="rel_pos",
                                                 transformer_encoder_selfattn_layer_type="rel_selfattn",
                                                 transformer_encoder_activation_type="swish", macaron_style=True,

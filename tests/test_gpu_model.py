@@ -620,3 +620,49 @@ def test_speech2text():
     text, token, token_int, hyp = res[0]
     assert token_int == [t for t in want[0][1:-1] if t != 0] and token == [token_list[t] for t in token_int]
     assert text == "".join(" " if t == "<space>" else t for t in token)
+
+
+def test_frontend_golden():
+    """8f rank 4: DefaultFrontend (reflect pad -> fp32 DFT GEMM over overlapping rows -> fused power / mel / log
+    kernel), Stft and LogMel against the outputs recorded from the reference's Stft (torch.stft) and LogMel.
+    Tolerances: STFT 2e-5 of the largest magnitude; log-mel 1e-3 absolute (fp32 power spectrum over a 100 dB range)."""
+    from espnet_amd.espnet2 import DefaultFrontend, ESPnetASRModel, LogMel, Stft  # noqa: F401
+    p, _, _ = split_golden(load_golden("frontend.npz"))
+    wav, wlens = p["wav"].to(DEV), p["wlens"]
+    for tag, kw_s, kw_m in (("default", dict(), dict()),
+                            ("win400", dict(n_fft=512, win_length=400, hop_length=160), dict(n_mels=40, htk=True)),
+                            ("n256", dict(n_fft=256, hop_length=64), dict(n_fft=256, n_mels=23, fmin=80, fmax=7600))):
+        fe = DefaultFrontend(**kw_s, **{k: v for k, v in kw_m.items() if k != "n_fft"}).to(DEV)
+        feats, flens = fe(wav, wlens)
+        assert flens.tolist() == p[tag + "_flens"].tolist() and fe.output_size() == feats.shape[-1]
+        ref = p[tag + "_feats"]
+        err = float((feats.cpu() - ref).abs().max())
+        print(f"[parity] frontend {tag}: log-mel max abs err {err:.2e} (range {float(ref.min()):.1f}..{float(ref.max()):.1f})")
+        assert feats.shape == ref.shape and err < 1e-3
+        assert torch.equal(feats.cpu() == 0, ref == 0)                      # padded frames: exactly zero
+        spec, olens = Stft(**kw_s)(wav, wlens)
+        sr = p[tag + "_stft"]
+        assert spec.shape == sr.shape and olens.tolist() == p[tag + "_flens"].tolist()
+        e2 = float((spec.cpu() - sr).abs().max() / sr.abs().max())
+        print(f"[parity] stft {tag}: max err / max |X| = {e2:.2e}")
+        assert e2 < 2e-5
+        power = (sr[..., 0] ** 2 + sr[..., 1] ** 2).to(DEV)
+        lm, _ = LogMel(**kw_m).to(DEV)(power, p[tag + "_flens"])
+        assert float((lm.cpu() - ref).abs().max()) < 1e-4
+    wav2 = torch.stack([p["wav"], p["wav"].flip(0)], dim=-1).to(DEV)
+    mc, _ = Stft()(wav2, wlens)
+    assert mc.shape == p["mc_stft"].shape
+    assert float((mc.cpu() - p["mc_stft"]).abs().max() / p["mc_stft"].abs().max()) < 2e-5
+    f0, _ = DefaultFrontend().to(DEV).eval()(wav2, wlens)
+    assert float((f0.cpu() - p["default_feats"]).abs().max()) < 1e-3
+    # inside the model: waveform in, frontend -> normalisation -> encoder (espnet_model.py:178-233)
+    from espnet_amd.espnet2 import UtteranceMVN
+    _, model, _ = _fusion_models()
+    fe = DefaultFrontend(n_mels=20).to(DEV)
+    model.frontend, model.normalize = fe, UtteranceMVN()
+    with torch.no_grad():
+        got, glens = model.encode(wav, wlens)
+        feats, flens = fe(wav, wlens)
+        model.frontend = None
+        want, wl = model.encode(feats, flens)
+    assert torch.equal(got, want) and glens.tolist() == wl.tolist()

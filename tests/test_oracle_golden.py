@@ -361,3 +361,35 @@ def test_feature_layers(oracle):
             close(oracle.global_mvn(x.clone(), lens, mean.float(), std.float(), bool(nm), bool(nv)), p["gmvn_%d%d" % (nm, nv)],
                   rtol=1e-5, atol=1e-6)
             close(oracle.utterance_mvn(x.clone(), lens, bool(nm), bool(nv)), p["umvn_%d%d" % (nm, nv)], rtol=1e-5, atol=1e-6)
+
+
+def test_frontend(oracle):
+    """8f rank 4: the numpy restatement of Stft -> power -> LogMel against the reference layers' recorded outputs
+    (torch.stft), the mel matrix against the two values printed in librosa.filters.mel's docstring (the only
+    known answers available without librosa), and the product's own mel matrix against the oracle's."""
+    import numpy as np
+    from espnet_amd.espnet2.frontend import mel_filterbank
+    g = load_golden("frontend.npz")
+    wav, wlens = np.asarray(g["wav"]), np.asarray(g["wlens"])
+    for tag, kw in (("default", dict()), ("win400", dict(n_fft=512, win_length=400, hop=160, n_mels=40, htk=True)),
+                    ("n256", dict(n_fft=256, hop=64, n_mels=23, fmin=80, fmax=7600))):
+        feat, olens = oracle.logmel_frontend(wav, wlens, **kw)
+        assert olens.tolist() == np.asarray(g[tag + "_flens"]).tolist()
+        ref = np.asarray(g[tag + "_feats"])
+        assert feat.shape == ref.shape
+        err = np.abs(feat - ref).max()
+        print(f"[oracle] frontend {tag}: max abs err {err:.2e} (range {ref.min():.1f}..{ref.max():.1f})")
+        assert err < 2e-3
+        s = oracle.stft(wav, kw.get("n_fft", 512), kw.get("hop", 128), kw.get("win_length"))
+        sr = np.asarray(g[tag + "_stft"])
+        T = s.shape[1]
+        keep = (np.arange(T)[None, :] < olens[:, None])[..., None]
+        assert np.abs(s.real * keep - sr[..., 0]).max() < 2e-4 * np.abs(sr).max()
+        assert np.abs(s.imag * keep - sr[..., 1]).max() < 2e-4 * np.abs(sr).max()
+    m = oracle.mel_filterbank(22050, 2048)
+    assert m.shape == (128, 1025) and m[0, 0] == 0 and round(float(m[0, 1]), 3) == 0.016 and m[-1, -1] == 0
+    assert round(float(oracle.mel_filterbank(22050, 2048, fmax=8000)[0, 1]), 2) == 0.02
+    for kw in (dict(sr=16000, n_fft=512, n_mels=80), dict(sr=16000, n_fft=512, n_mels=40, htk=True),
+               dict(sr=8000, n_fft=256, n_mels=23, fmin=80, fmax=3800)):
+        a, b = oracle.mel_filterbank(**kw), mel_filterbank(**kw)
+        assert np.abs(a - b).max() < 1e-7 * np.abs(a).max() + 1e-9
