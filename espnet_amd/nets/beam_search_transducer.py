@@ -42,9 +42,9 @@ class BeamSearchTransducer:
             self.search_algorithm = self.default_beam_search
         else:
             raise NotImplementedError("search_type %r: greedy and 'default' are on the HIP path" % search_type)
-        if lm is not None:
-            raise NotImplementedError("LM fusion is a later scope row (SURVEY.md 8f rank 2)")
-        self.lm, self.lm_weight = None, lm_weight
+        # lm: a ClassifierWithState (espnet_amd.nets.lm, as espnet/asr/pytorch_backend/asr.py passes it) whose
+        # predict(state, tokens) -> (state, log-probs (1, V)); fused with lm_weight in the default search
+        self.lm, self.lm_weight = lm, lm_weight
         self.max_sym_exp, self.u_max, self.nstep, self.prefix_alpha = max_sym_exp, u_max, nstep, prefix_alpha
         self.score_norm = score_norm
 
@@ -93,10 +93,13 @@ class BeamSearchTransducer:
             while True:
                 max_hyp = max(hyps, key=lambda x: x.score)
                 hyps.remove(max_hyp)
-                y, state, _ = self.decoder.score(max_hyp, cache, init_tensor)
+                y, state, lm_tokens = self.decoder.score(max_hyp, cache, init_tensor)
                 ytu = _log_softmax(self.decoder.joint_network.joint_step(enc_proj[t], y[0]))
                 top_v, top_i = ytu[1:].topk(beam_k, dim=-1)
                 cand = list(zip(top_v.tolist(), (top_i + 1).tolist())) + [(float(ytu[0]), self.blank)]
+                if self.lm:
+                    lm_state, lm_scores = self.lm.predict(max_hyp.lm_state, lm_tokens)
+                    lm_host = lm_scores[0].tolist()
                 for logp, k in cand:
                     new_hyp = Hypothesis(score=(max_hyp.score + float(logp)), yseq=max_hyp.yseq[:],
                                          dec_state=max_hyp.dec_state, lm_state=max_hyp.lm_state)
@@ -105,6 +108,9 @@ class BeamSearchTransducer:
                     else:
                         new_hyp.dec_state = state
                         new_hyp.yseq.append(int(k))
+                        if self.lm:
+                            new_hyp.lm_state = lm_state
+                            new_hyp.score += self.lm_weight * lm_host[k]
                         hyps.append(new_hyp)
                 hyps_max = float(max(hyps, key=lambda x: x.score).score)
                 kept_most_prob = sorted([hyp for hyp in kept_hyps if hyp.score > hyps_max], key=lambda x: x.score)

@@ -562,6 +562,16 @@ def main():
                 dec["dec_%s_scores" % tag] = np.asarray([float(h["score"]) for h in nb], dtype=np.float64)
                 dec["dec_%s_lens" % tag] = np.asarray([len(h["yseq"]) for h in nb], dtype=np.int64)
                 dec["dec_%s_yseq" % tag] = np.asarray(sum([[int(t) for t in h["yseq"]] for h in nb], []), dtype=np.int64)
+            # LM shallow fusion in the default search (beam_search_transducer.py:204-224): an espnet1 RNNLM
+            from espnet.nets.pytorch_backend.lm.default import ClassifierWithState, RNNLM
+            torch.manual_seed(seed + 7)
+            lm = ClassifierWithState(RNNLM(6, 1, 8, None, "lstm", 0.0)).eval()
+            bs = BeamSearchTransducer(decoder=m.dec, lm=lm, lm_weight=0.5, beam_size=3, search_type="default")
+            nb = m.recognize(xin, bs)
+            dec["dec_beam3_lm_scores"] = np.asarray([float(h["score"]) for h in nb], dtype=np.float64)
+            dec["dec_beam3_lm_lens"] = np.asarray([len(h["yseq"]) for h in nb], dtype=np.int64)
+            dec["dec_beam3_lm_yseq"] = np.asarray(sum([[int(t) for t in h["yseq"]] for h in nb], []), dtype=np.int64)
+            dec.update(sd_np(lm, "lm/"))
         save(out(name), xs=xs, ilens=ilens, ys=ys, hs_pad=hs_train, pred_pad=pred_train,
              loss=float(loss), **dec, **sd0, **grads_np(m))
 

@@ -309,8 +309,13 @@ def test_transducer_decoding_golden(name):
     m(p["xs"].to(DEV), p["ilens"], p["ys"].to(DEV))      # as in the fixture: BatchNorm running stats see one training batch
     m.eval()
     x = p["xs"][0, : int(p["ilens"][0])].numpy()
+    from espnet_amd.nets.lm import ClassifierWithState, RNNLM
+    lm = ClassifierWithState(RNNLM(6, 1, 8, None, "lstm", 0.0))
+    lm.load_state_dict({k[3:]: v for k, v in p.items() if k.startswith("lm/")})      # the reference LM's own keys
+    lm.to(DEV).eval()
     for tag, kw in (("greedy", dict(beam_size=1)), ("beam3", dict(beam_size=3, search_type="default")),
-                    ("beam3_nonorm", dict(beam_size=3, search_type="default", score_norm=False))):
+                    ("beam3_nonorm", dict(beam_size=3, search_type="default", score_norm=False)),
+                    ("beam3_lm", dict(beam_size=3, search_type="default", lm=lm, lm_weight=0.5))):
         nb = m.recognize(x, BeamSearchTransducer(decoder=m.dec, **kw))
         nb = nb if isinstance(nb, list) else [nb]
         lens = p["dec_%s_lens" % tag].tolist()
