@@ -23,36 +23,49 @@ __global__ __launch_bounds__(256) void dwconv_kernel(const float* __restrict__ x
                                                      int B, int T, int C, int K, int pad, int flip) {
   __shared__ float wl[256 * KMAX];
   const int c0 = blockIdx.x * blockDim.x;
-  const int c = c0 + threadIdx.x;
-  const int nw = min(256, C - c0) * K;
-  for (int i = threadIdx.x; i < nw; i += blockDim.x) wl[i] = w[(long)c0 * K + i];
-  __syncthreads();
-  if (c >= C) return;
+  const int c_raw = c0 + threadIdx.x;
+  const int c = min(c_raw, C - 1);          // dead lanes shadow a valid channel (no divergent exit before the barrier)
   const int nchunk = (T + TT - 1) / TT;
   const int b = blockIdx.y / nchunk;
   const int t0 = (blockIdx.y % nchunk) * TT;
+  // the whole input window first, branch-free (clamped rows, zeroed afterwards): TT + K - 1 independent loads in
+  // flight together instead of one round trip per tap; window position j covers frame t0 - pad + j
+  // the block's taps likewise: KMAX independent coalesced loads per thread (a runtime-bounded copy loop waits for
+  // every load before issuing the next: K serialized round trips)
+  const int nw = min(256, C - c0) * K;
+  float tw[KMAX];
+#pragma unroll
+  for (int q = 0; q < KMAX; ++q) tw[q] = w[(long)c0 * K + min((int)threadIdx.x + q * 256, nw - 1)];
+  const float* xb = x + (long)b * T * C + c;
+  float xv[TT + KMAX - 1];
+#pragma unroll
+  for (int j = 0; j < TT + KMAX - 1; ++j) {
+    const int ts = min(max(t0 - pad + j, 0), T - 1);
+    xv[j] = xb[(long)ts * C];
+  }
+#pragma unroll
+  for (int q = 0; q < KMAX; ++q)
+    if ((int)threadIdx.x + q * 256 < nw) wl[threadIdx.x + q * 256] = tw[q];
+  __syncthreads();
+  if (c_raw >= C) return;
   float wr[KMAX];
 #pragma unroll
   for (int k = 0; k < KMAX; ++k) {
     int kk = flip ? K - 1 - k : k;          // flipped taps turn the gradient into the same correlation
-    wr[k] = (k < K) ? wl[threadIdx.x * K + kk] : 0.f;
+    wr[k] = (k < K) ? wl[threadIdx.x * K + min(max(kk, 0), K - 1)] : 0.f;
   }
   const float bv = (bias && !flip) ? bias[c] : 0.f;
   float acc[TT];
 #pragma unroll
   for (int i = 0; i < TT; ++i) acc[i] = bv;
-  const float* xb = x + (long)b * T * C + c;
-  // window position j covers frame t0 - pad + j, j in [0, TT + K - 1)
 #pragma unroll
   for (int j = 0; j < TT + KMAX - 1; ++j) {
-    if (j < TT + K - 1) {
-      const int ts = t0 - pad + j;
-      const float xv = (ts >= 0 && ts < T) ? xb[(long)ts * C] : 0.f;
+    const int ts = t0 - pad + j;
+    const float v = (ts >= 0 && ts < T && j < TT + K - 1) ? xv[j] : 0.f;
 #pragma unroll
-      for (int i = 0; i < TT; ++i) {
-        const int k = j - i;                 // tap index feeding output t0 + i
-        if (k >= 0 && k < KMAX) acc[i] += wr[k] * xv;
-      }
+    for (int i = 0; i < TT; ++i) {
+      const int k = j - i;                 // tap index feeding output t0 + i
+      if (k >= 0 && k < KMAX) acc[i] += wr[k] * v;
     }
   }
   float* yb = y + (long)b * T * C + c;
@@ -61,59 +74,162 @@ __global__ __launch_bounds__(256) void dwconv_kernel(const float* __restrict__ x
     if (t0 + i < T) yb[(long)(t0 + i) * C] = acc[i];
 }
 
+// LDS-tiled form of the same correlation (the default): a block owns 64 channels x NWV*8 frames.  The NWV*8 + K - 1
+// input rows are fetched ONCE per block (coalesced 256-byte rows, all loads of a thread in flight together) into LDS,
+// as are the 64 x K taps; wave w then produces frames [8w, 8w+8) from LDS.  L2 -> CU traffic per output drops from
+// (8 + K - 1) / 8 input rows + a 256 x K tap block per 8 frames to (NWV*8 + K - 1) / (NWV*8) rows + a 64 x K tap block
+// per NWV*8 frames (K = 31, NWV = 8: 8.8x -> 1.6x the output bytes).
+template <int NWV>
+__global__ __launch_bounds__(NWV * 64) void dwconv_lds_kernel(const float* __restrict__ x, const float* __restrict__ w,
+                                                              const float* __restrict__ bias, float* __restrict__ y,
+                                                              int B, int T, int C, int K, int pad, int flip) {
+  constexpr int TB = NWV * 8;                       // frames per block
+  constexpr int NR = (TB + KMAX - 1 + NWV - 1) / NWV;   // input rows per wave (upper bound)
+  constexpr int NWL = (64 * KMAX + NWV * 64 - 1) / (NWV * 64);
+  __shared__ float xs[(TB + KMAX - 1) * 64];
+  __shared__ float wl[64 * KMAX];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int c0 = blockIdx.x * 64;
+  const int c = min(c0 + lane, C - 1);
+  const int nblk = (T + TB - 1) / TB;
+  const int b = blockIdx.y / nblk;
+  const int tb0 = (blockIdx.y % nblk) * TB;
+  const int rows = TB + K - 1;
+  const int nw = min(64, C - c0) * K;
+  const float* xb = x + (long)b * T * C + c;
+  float xr[NR], tw[NWL];
+#pragma unroll
+  for (int i = 0; i < NR; ++i) {
+    const int ts = min(max(tb0 - pad + wave + i * NWV, 0), T - 1);
+    xr[i] = xb[(long)ts * C];
+  }
+#pragma unroll
+  for (int q = 0; q < NWL; ++q) tw[q] = w[(long)c0 * K + min((int)threadIdx.x + q * NWV * 64, nw - 1)];
+#pragma unroll
+  for (int i = 0; i < NR; ++i) {
+    const int r = wave + i * NWV, ts = tb0 - pad + r;
+    if (r < rows) xs[r * 64 + lane] = (ts >= 0 && ts < T) ? xr[i] : 0.f;
+  }
+#pragma unroll
+  for (int q = 0; q < NWL; ++q)
+    if ((int)threadIdx.x + q * NWV * 64 < nw) wl[threadIdx.x + q * NWV * 64] = tw[q];
+  __syncthreads();
+  const int t0 = tb0 + wave * 8;
+  if (c0 + lane >= C || t0 >= T) return;
+  float wr[KMAX];
+#pragma unroll
+  for (int k = 0; k < KMAX; ++k) {
+    const int kk = flip ? K - 1 - k : k;
+    wr[k] = (k < K) ? wl[lane * K + min(max(kk, 0), K - 1)] : 0.f;
+  }
+  const float bv = (bias && !flip) ? bias[c] : 0.f;
+  float acc[8];
+#pragma unroll
+  for (int i = 0; i < 8; ++i) acc[i] = bv;
+#pragma unroll
+  for (int j = 0; j < 8 + KMAX - 1; ++j) {
+    const float v = (j < 8 + K - 1) ? xs[(wave * 8 + min(j, 8 + K - 2)) * 64 + lane] : 0.f;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      const int k = j - i;
+      if (k >= 0 && k < KMAX) acc[i] += wr[k] * v;
+    }
+  }
+  float* yb = y + (long)b * T * C + c;
+#pragma unroll
+  for (int i = 0; i < 8; ++i)
+    if (t0 + i < T) yb[(long)(t0 + i) * C] = acc[i];
+}
+
 // dw[c,k] += sum_{b,t} dy[b,t,c] * x[b,t+k-pad,c];  db[c] += sum dy.
-constexpr int TTW = 8;   // frames per chunk of the weight-gradient kernel
-// One thread = one channel; a block walks `chunks_per_block` chunks of TTW frames.  Per chunk the
-// TTW + K - 1 input window and the TTW output gradients are loaded up front (independent loads, all
-// in flight together) and combined with fully unrolled FMAs into K register accumulators.
-__global__ __launch_bounds__(256) void dwconv_bwd_w_kernel(const float* __restrict__ dy, const float* __restrict__ x,
-                                                           float* __restrict__ dw, float* __restrict__ db, int B,
-                                                           int T, int C, int K, int pad, int chunks_per_block) {
-  const int c_raw = blockIdx.x * blockDim.x + threadIdx.x;
-  const bool live = c_raw < C;
-  const int c = live ? c_raw : C - 1;        // dead lanes shadow a valid channel and contribute nothing
-  const int nchunk = (T + TTW - 1) / TTW;
-  const long total = (long)B * nchunk;
-  const long q0 = (long)blockIdx.y * chunks_per_block;
-  const long q1 = live ? min(total, q0 + (long)chunks_per_block) : q0;
+// Block = NWV waves on 64 channels, walking `tiles_per_block` tiles of NWV*8 frames: per tile the NWV*8 + K - 1 input
+// rows and the NWV*8 gradient rows go through LDS once (coalesced, all of a thread's loads in flight together), wave
+// w combines frames [8w, 8w+8) into K register accumulators with fully unrolled FMAs.  The waves' accumulators are
+// summed through per-wave LDS slots and the block adds its [64, K] result to global memory with lanes along the
+// contiguous (c, k) index (uncoalesced f32 atomics run ~17x slower on gfx950).
+constexpr int WNWV = 8;
+__global__ __launch_bounds__(WNWV * 64) void dwconv_bwd_w_kernel(const float* __restrict__ dy,
+                                                                 const float* __restrict__ x, float* __restrict__ dw,
+                                                                 float* __restrict__ db, int B, int T, int C, int K,
+                                                                 int pad, int tiles_per_block) {
+  constexpr int NWV = WNWV, TB = NWV * 8;
+  constexpr int NR = (TB + KMAX - 1 + NWV - 1) / NWV;
+  // one buffer, two lives: the (x, dy) tile while accumulating, then one [64][K+1] slot per wave for the block sum
+  // (LDS float atomics measured ~40 us here; plain stores + a strided read cost nothing)
+  __shared__ float smem[NWV * 64 * (KMAX + 1)];
+  static_assert((TB + KMAX - 1) * 64 + TB * 64 <= NWV * 64 * (KMAX + 1), "tile must fit in the reduction buffer");
+  float* xs = smem;
+  float* gs = smem + (TB + KMAX - 1) * 64;
+  __shared__ float redb[NWV * 64];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int c0 = blockIdx.x * 64;
+  const bool live = c0 + lane < C;
+  const int c = live ? c0 + lane : C - 1;    // dead lanes shadow a valid channel and contribute nothing
+  const int nblk = (T + TB - 1) / TB;
+  const long total = (long)B * nblk;
+  const int rows = TB + K - 1;
   float acc[KMAX];
 #pragma unroll
   for (int k = 0; k < KMAX; ++k) acc[k] = 0.f;
   float accb = 0.f;
-  for (long q = q0; q < q1; ++q) {
-    const int b = q / nchunk;
-    const int t0 = (int)(q % nchunk) * TTW;
+  for (int r = 0; r < tiles_per_block; ++r) {
+    const long q = (long)blockIdx.y * tiles_per_block + r;
+    if (q >= total) break;
+    const int b = q / nblk;
+    const int tb0 = (int)(q % nblk) * TB;
     const float* xb = x + (long)b * T * C + c;
     const float* gb = dy + (long)b * T * C + c;
-    float g[TTW];
+    float xr[NR], gr[8];
 #pragma unroll
-    for (int i = 0; i < TTW; ++i) { g[i] = (t0 + i < T) ? gb[(long)(t0 + i) * C] : 0.f; accb += g[i]; }
+    for (int i = 0; i < NR; ++i) xr[i] = xb[(long)min(max(tb0 - pad + wave + i * NWV, 0), T - 1) * C];
 #pragma unroll
-    for (int j = 0; j < TTW + KMAX - 1; ++j) {
-      if (j < TTW + K - 1) {
-        const int ts = t0 - pad + j;
-        const float xv = (ts >= 0 && ts < T) ? xb[(long)ts * C] : 0.f;
+    for (int i = 0; i < 8; ++i) gr[i] = gb[(long)min(tb0 + wave + i * NWV, T - 1) * C];
+    __syncthreads();                       // previous tile fully consumed (also orders the zero-fill of red)
 #pragma unroll
-        for (int i = 0; i < TTW; ++i) {
-          const int k = j - i;
-          if (k >= 0 && k < KMAX) acc[k] += g[i] * xv;
-        }
+    for (int i = 0; i < NR; ++i) {
+      const int rr = wave + i * NWV, ts = tb0 - pad + rr;
+      if (rr < rows) xs[rr * 64 + lane] = (ts >= 0 && ts < T) ? xr[i] : 0.f;
+    }
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      const int rr = wave + i * NWV;
+      gs[rr * 64 + lane] = (tb0 + rr < T) ? gr[i] : 0.f;
+    }
+    __syncthreads();
+    float g[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) { g[i] = gs[(wave * 8 + i) * 64 + lane]; accb += g[i]; }
+#pragma unroll
+    for (int j = 0; j < 8 + KMAX - 1; ++j) {
+      const float xv = (j < 8 + K - 1) ? xs[(wave * 8 + min(j, 8 + K - 2)) * 64 + lane] : 0.f;
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        const int k = j - i;
+        if (k >= 0 && k < KMAX) acc[k] += g[i] * xv;
       }
     }
   }
-  // transpose through LDS so that a wave's atomics hit 256 contiguous bytes (lanes along k within a channel
-  // row), not 64 addresses K floats apart (uncoalesced f32 atomics run ~17x slower on gfx950)
-  __shared__ float tr[256 * (KMAX + 1)];
-#pragma unroll
-  for (int k = 0; k < KMAX; ++k) tr[threadIdx.x * (KMAX + 1) + k] = acc[k];
   __syncthreads();
-  const int c0 = blockIdx.x * blockDim.x;
-  const int nch = min(256, C - c0);
+  float* slot = smem + wave * 64 * (KMAX + 1);
+#pragma unroll
+  for (int k = 0; k < KMAX; ++k)
+    if (k < K) slot[lane * (KMAX + 1) + k] = live ? acc[k] : 0.f;
+  redb[wave * 64 + lane] = live ? accb : 0.f;
+  __syncthreads();
+  const int nch = min(64, C - c0);
   for (int i = threadIdx.x; i < nch * K; i += blockDim.x) {
     const int cc = i / K, k = i % K;
-    atomicAdd(&dw[(long)c0 * K + i], tr[cc * (KMAX + 1) + k]);
+    float t = 0.f;
+#pragma unroll
+    for (int wv = 0; wv < NWV; ++wv) t += smem[wv * 64 * (KMAX + 1) + cc * (KMAX + 1) + k];
+    atomicAdd(&dw[(long)c0 * K + i], t);
   }
-  if (db && live) atomicAdd(&db[c], accb);
+  if (db && threadIdx.x < nch) {
+    float t = 0.f;
+#pragma unroll
+    for (int wv = 0; wv < NWV; ++wv) t += redb[wv * 64 + threadIdx.x];
+    atomicAdd(&db[c0 + threadIdx.x], t);
+  }
 }
 
 // ---- BatchNorm1d over [M, C] -----------------------------------------------------------------
@@ -514,8 +630,14 @@ inline int grid_for(long n) {
 inline void dwconv_launch(const float* x, const float* w, const float* bias, float* y, int B, int T, int C, int K,
                           int flip, hipStream_t s) {
   static const int tt_env = [] { const char* e = getenv("EAMD_DWCONV_TT"); return e ? atoi(e) : 0; }();
-  const int tt = tt_env ? tt_env : 8;
-  const int gx = (C + 255) / 256, pad = (K - 1) / 2;
+  const int pad = (K - 1) / 2;
+  if (tt_env == 0) {      // LDS-tiled default: 64 channels x 64 frames per block
+    hipLaunchKernelGGL(dwconv_lds_kernel<8>, dim3((C + 63) / 64, B * ((T + 63) / 64)), dim3(512), 0, s, x, w, bias, y, B, T, C,
+                       K, pad, flip);
+    return;
+  }
+  const int tt = tt_env;
+  const int gx = (C + 255) / 256;
   if (tt == 4)
     hipLaunchKernelGGL(dwconv_kernel<4>, dim3(gx, B * ((T + 3) / 4)), dim3(256), 0, s, x, w, bias, y, B, T, C, K, pad, flip);
   else if (tt == 16)
@@ -549,13 +671,17 @@ int eamd_dwconv_bwd_w(const float* dy, const float* x, float* dw, float* db, int
                       void* stream) {
   if (!dy || !x || !dw || B <= 0 || T <= 0 || C <= 0 || K <= 0 || (K & 1) == 0) return EAMD_EINVAL;
   if (K > KMAX) return EAMD_EUNSUPPORTED;
-  long total = (long)B * ((T + TTW - 1) / TTW);
-  int gx = (C + 255) / 256;
-  long want = 512 / gx; if (want < 1) want = 1;
-  long cpb = (total + want - 1) / want; if (cpb < 1) cpb = 1;
-  int gy = (int)((total + cpb - 1) / cpb);
-  hipLaunchKernelGGL(dwconv_bwd_w_kernel, dim3(gx, gy), dim3(256), 0, (hipStream_t)stream, dy, x, dw, db, B, T, C,
-                     K, (K - 1) / 2, (int)cpb);
+  const long total = (long)B * ((T + WNWV * 8 - 1) / (WNWV * 8));      // tiles of 64 frames
+  const int gx = (C + 63) / 64;
+  // about two 8-wave blocks per CU; more tiles per block = fewer global atomics, fewer blocks in flight
+  long gy = (512 + gx - 1) / gx;
+  if (gy > total) gy = total;
+  if (gy < 1) gy = 1;
+  static const int tpb_env = [] { const char* e = getenv("EAMD_DWW_TPB"); return e ? atoi(e) : 0; }();
+  const long tpb = tpb_env ? tpb_env : (total + gy - 1) / gy;
+  gy = (total + tpb - 1) / tpb;
+  hipLaunchKernelGGL(dwconv_bwd_w_kernel, dim3(gx, (unsigned)gy), dim3(WNWV * 64), 0, (hipStream_t)stream, dy, x, dw, db, B,
+                     T, C, K, (K - 1) / 2, (int)tpb);
   EAMD_LAUNCH_CHECK();
   return EAMD_OK;
 }

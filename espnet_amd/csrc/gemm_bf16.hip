@@ -390,20 +390,23 @@ __global__ __launch_bounds__(NT_) void gemm_bf16_kernel(const eamd_gemm_t p) {
   if (TA && p.colsum != nullptr && !gat) {   // wave-uniform: every thread of the block takes the same path
     // bias gradient: combine the per-thread column sums in LDS (operand buffers are free now), then
     // one global atomic per column per block
+    // (one LDS row per k-row group of the staging layout, plain stores: ds_add_f32 is slow on gfx950)
     float* csl = reinterpret_cast<float*>(smem_raw);
-    if (do_colsum) {
-      for (int i = t; i < BM; i += NT_) csl[i] = 0.f;
-    }
+    constexpr int NSLOT = NT_ / CPR_A;
+    static_assert(sizeof(float) * NSLOT * BM <= sizeof(S), "column-sum slots must fit in the operand buffers");
     __syncthreads();
     if (do_colsum) {
 #pragma unroll
-      for (int j = 0; j < 8; ++j) atomicAdd(&csl[a_c[0] * 8 + j], cs[j]);
+      for (int j = 0; j < 8; ++j) csl[(t / CPR_A) * BM + a_c[0] * 8 + j] = cs[j];
     }
     __syncthreads();
     if (do_colsum) {
       for (int i = t; i < BM; i += NT_) {
         const int m = m0 + i;
-        if (m < p.M) atomicAdd(p.colsum + (long)zb * p.M + m, csl[i] * p.alpha);
+        float v = 0.f;
+#pragma unroll 8
+        for (int sl = 0; sl < NSLOT; ++sl) v += csl[sl * BM + i];
+        if (m < p.M) atomicAdd(p.colsum + (long)zb * p.M + m, v * p.alpha);
       }
     }
     __syncthreads();

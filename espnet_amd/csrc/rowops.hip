@@ -93,10 +93,10 @@ __global__ __launch_bounds__(1024) void layernorm_bwd_kernel(
     const float* __restrict__ mean, const float* __restrict__ rstd, const float* dres, float* dx,
     float* __restrict__ dgamma, float* __restrict__ dbeta, float* __restrict__ ws, int rows, int D,
     int rows_per_block) {
-  extern __shared__ float lds[];  // [2][D]
+  extern __shared__ float lds[];  // [waves][2][D]: one slot per wave, summed after the barrier (plain stores:
+                                  // ds_add_f32 runs at a fraction of a lane per clock on gfx950)
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  for (int i = threadIdx.x; i < 2 * D; i += blockDim.x) lds[i] = 0.f;
-  __syncthreads();
+  float* slot = lds + (long)wave * 2 * D;
   const int r0 = blockIdx.x * rows_per_block;
   const int r1 = min(rows, r0 + rows_per_block);
   if constexpr (VEC > 0) {
@@ -159,10 +159,8 @@ __global__ __launch_bounds__(1024) void layernorm_bwd_kernel(
 #pragma unroll
     for (int j = 0; j < VEC; ++j) {
       const int i = 4 * (lane + 64 * j);
-      atomicAdd(&lds[i + 0], ag[j].x); atomicAdd(&lds[i + 1], ag[j].y);
-      atomicAdd(&lds[i + 2], ag[j].z); atomicAdd(&lds[i + 3], ag[j].w);
-      atomicAdd(&lds[D + i + 0], ab[j].x); atomicAdd(&lds[D + i + 1], ab[j].y);
-      atomicAdd(&lds[D + i + 2], ab[j].z); atomicAdd(&lds[D + i + 3], ab[j].w);
+      *reinterpret_cast<float4*>(slot + i) = ag[j];
+      *reinterpret_cast<float4*>(slot + D + i) = ab[j];
     }
   } else {
     constexpr int MAXC = 16;
@@ -200,18 +198,17 @@ __global__ __launch_bounds__(1024) void layernorm_bwd_kernel(
 #pragma unroll
     for (int c = 0; c < MAXC; ++c) {
       int i = lane + 64 * c;
-      if (i < D) { atomicAdd(&lds[i], ag[c]); atomicAdd(&lds[D + i], ab[c]); }
+      if (i < D) { slot[i] = ag[c]; slot[D + i] = ab[c]; }
     }
   }
   __syncthreads();
-  if (ws) {   // per-block partial sums, combined by layernorm_bwd_reduce_kernel (no same-address atomic storm)
-    float* w = ws + (long)blockIdx.x * 2 * D;
-    for (int i = threadIdx.x; i < 2 * D; i += blockDim.x) w[i] = lds[i];
-    return;
-  }
-  for (int i = threadIdx.x; i < D; i += blockDim.x) {
-    atomicAdd(&dgamma[i], lds[i]);
-    atomicAdd(&dbeta[i], lds[D + i]);
+  const int nwv = blockDim.x >> 6;
+  for (int i = threadIdx.x; i < 2 * D; i += blockDim.x) {
+    float t = 0.f;
+    for (int wv = 0; wv < nwv; ++wv) t += lds[(long)wv * 2 * D + i];
+    if (ws) ws[(long)blockIdx.x * 2 * D + i] = t;   // per-block partials, combined by layernorm_bwd_reduce_kernel
+    else if (i < D) atomicAdd(&dgamma[i], t);
+    else atomicAdd(&dbeta[i - D], t);
   }
 }
 
@@ -502,7 +499,7 @@ int eamd_layernorm_bwd(const float* dy, const float* x, const float* gamma, cons
   static const int nthr = [] { const char* e = getenv("EAMD_LNB_THREADS"); return e ? atoi(e) : 256; }();
   const bool al = (((uintptr_t)dy | (uintptr_t)x | (uintptr_t)gamma | (uintptr_t)dx | (uintptr_t)dres) & 15) == 0;
   hipStream_t s = (hipStream_t)stream;
-  size_t sm = 2 * D * sizeof(float);
+  size_t sm = (size_t)(nthr / 64) * 2 * D * sizeof(float);
   if (al && D == 256)
     hipLaunchKernelGGL(layernorm_bwd_kernel<1>, dim3(nblk), dim3(nthr), sm, s, dy, x, gamma, mean, rstd, dres, dx,
                        dgamma, dbeta, ws, rows, D, rpb);
