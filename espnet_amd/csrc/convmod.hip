@@ -489,108 +489,185 @@ __global__ void bn_bwd_apply_kernel(const float* __restrict__ dy, const float* _
 // thread owns one output channel (its 9 taps in registers) and walks the W positions, so every store is
 // a full 2*C / 4*C-byte row segment and the inner loop has neither index divisions nor bounds tests.
 constexpr int C1_MAXF = 512;     // input feature dim + 2*pad must fit
+// Eight positions per trip: their wave-uniform input window (ST*7+3 floats per kernel row) is read as float4
+// broadcasts, 15 LDS instructions instead of 72 scalar ones (the scalar form was LDS-issue bound); a thread owns
+// NC = 2 adjacent channels when the output is bf16 (one packed 4-byte store per position) or 1 channel otherwise.
+template <int ST, int NC>
 __global__ __launch_bounds__(256) void conv1_fwd_kernel(const float* __restrict__ x, const float* __restrict__ w,
                                                         const float* __restrict__ bias, float* __restrict__ y, int B,
-                                                        int T, int F, int H, int W, int C, int bf16, int st,
-                                                        int pad) {
-  __shared__ float xs[3][C1_MAXF];
+                                                        int T, int F, int H, int W, int C, int bf16, int pad) {
+  constexpr int XLD = C1_MAXF + 32;
+  constexpr int NV = (ST * 7 + 3 + 3) / 4;
+  __shared__ __attribute__((aligned(16))) float xs[3 * XLD];
   const int row = blockIdx.x;                 // b * H + hh
   const int b = row / H, hh = row % H;
   const int FP = F + 2 * pad;
-  for (int i = threadIdx.x; i < 3 * FP; i += blockDim.x) {
-    const int kh = i / FP, f = i % FP - pad;
-    const int tt = st * hh - pad + kh;
-    xs[kh][i % FP] = (tt >= 0 && tt < T && f >= 0 && f < F) ? x[((long)b * T + tt) * F + f] : 0.f;
+  for (int i = threadIdx.x; i < 3 * XLD; i += blockDim.x) {
+    const int kh = i / XLD, j = i % XLD, f = j - pad;
+    const int tt = ST * hh - pad + kh;
+    const bool ok = j < FP && tt >= 0 && tt < T && f >= 0 && f < F;
+    const float v = x[((long)b * T + min(max(tt, 0), T - 1)) * F + min(max(f, 0), F - 1)];
+    xs[i] = ok ? v : 0.f;
   }
   __syncthreads();
   unsigned short* y16 = reinterpret_cast<unsigned short*>(y);
-  for (int c = threadIdx.x; c < C; c += blockDim.x) {
-    float wr[9];
+  unsigned int* y32 = reinterpret_cast<unsigned int*>(y);
+  for (int c = threadIdx.x * NC; c < C; c += blockDim.x * NC) {
+    float wr[NC][9], bv[NC];
 #pragma unroll
-    for (int k = 0; k < 9; ++k) wr[k] = w[(long)c * 9 + k];
-    const float bv = bias[c];
-    long o = (long)row * W * C + c;
-    for (int ww = 0; ww < W; ++ww, o += C) {
-      const int f0 = st * ww;
-      float acc = bv;
+    for (int e = 0; e < NC; ++e) {
+#pragma unroll
+      for (int k = 0; k < 9; ++k) wr[e][k] = w[(long)(c + e) * 9 + k];
+      bv[e] = bias[c + e];
+    }
+    const long o = (long)row * W * C + c;
+    for (int w0 = 0; w0 < W; w0 += 8) {
+      float xr[3][NV * 4];
 #pragma unroll
       for (int kh = 0; kh < 3; ++kh)
 #pragma unroll
-        for (int kw = 0; kw < 3; ++kw) acc += wr[kh * 3 + kw] * xs[kh][f0 + kw];
-      acc = acc > 0.f ? acc : 0.f;
-      if (bf16) y16[o] = eamd_f2bf(acc); else y[o] = acc;
+        for (int q = 0; q < NV; ++q) {
+          const float4 v = *reinterpret_cast<const float4*>(&xs[kh * XLD + ST * w0 + 4 * q]);
+          xr[kh][4 * q] = v.x; xr[kh][4 * q + 1] = v.y; xr[kh][4 * q + 2] = v.z; xr[kh][4 * q + 3] = v.w;
+        }
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        float acc[NC];
+#pragma unroll
+        for (int e = 0; e < NC; ++e) {
+          acc[e] = bv[e];
+#pragma unroll
+          for (int kh = 0; kh < 3; ++kh)
+#pragma unroll
+            for (int kw = 0; kw < 3; ++kw) acc[e] += wr[e][kh * 3 + kw] * xr[kh][ST * u + kw];
+          acc[e] = acc[e] > 0.f ? acc[e] : 0.f;
+        }
+        if (w0 + u < W) {
+          const long oi = o + (long)(w0 + u) * C;
+          if (NC == 2) y32[oi >> 1] = (unsigned)eamd_f2bf(acc[0]) | ((unsigned)eamd_f2bf(acc[NC - 1]) << 16);
+          else if (bf16) y16[oi] = eamd_f2bf(acc[0]);
+          else y[oi] = acc[0];
+        }
+      }
     }
   }
 }
 // dW[c, kh, kw] += sum_pos dy[pos, c] * x[pos shifted]; db[c] += sum dy   (dy already ReLU-masked)
 // grid (ceil(C/256), row groups): a workgroup walks `rows_per_block` output rows, staging the three input
-// rows of each in LDS; thread = channel, 9 + 1 register accumulators, LDS-transposed coalesced atomics at the end.
+// rows of each in LDS; thread = channel, 9 + 1 register accumulators.  Per output row the (up to 40) gradient values of
+// the thread's channel are requested BEFORE the input rows are staged (one memory round trip per row, not one per
+// eight positions), and the wave-uniform input window of eight positions is read as float4 broadcasts
+// (ST*7+3 floats per kernel row: 15 LDS instructions per eight positions instead of 72 scalar ones - the scalar form
+// was LDS-issue bound).
+// NC = 2 (bf16 gradients): a thread owns two adjacent channels and reads them as one dword - sub-dword loads
+// (global_load_ushort) run this kernel at 0.9 TB/s where the dword form reaches > 4 TB/s.
+template <int ST, int NC>
 __global__ __launch_bounds__(256) void conv1_bwd_w_kernel(const float* __restrict__ dy, const float* __restrict__ x,
                                                           float* __restrict__ dw, float* __restrict__ db,
                                                           float* __restrict__ part, int B, int T, int F, int H, int W,
-                                                          int C, int rows_per_block, int bf16, int st, int pad) {
-  __shared__ float xs[3][C1_MAXF];
-  __shared__ float tr9[256 * 10];
-  const int c_raw = blockIdx.x * blockDim.x + threadIdx.x;
+                                                          int C, int rows_per_block, int bf16, int pad) {
+  constexpr int XLD = C1_MAXF + 32;          // row stride of the staged input (floats, multiple of 4)
+  constexpr int NV = (ST * 7 + 3 + 3) / 4;   // float4 reads covering eight positions of one kernel row
+  constexpr int NPOS = NC == 2 ? 24 : 40;    // gradient values requested ahead per output row
+  __shared__ __attribute__((aligned(16))) float xs[3 * XLD];
+  __shared__ float tr9[256 * 10 * NC];
+  const int c_raw = (blockIdx.x * blockDim.x + threadIdx.x) * NC;
   const bool live = c_raw < C;
-  const int c = live ? c_raw : C - 1;
+  const int c = live ? c_raw : C - NC;
   const int FP = F + 2 * pad;
   const long nrow = (long)B * H;
   const long r0 = (long)blockIdx.y * rows_per_block;
   const long r1 = min(nrow, r0 + (long)rows_per_block);
   const unsigned short* dy16 = reinterpret_cast<const unsigned short*>(dy);
-  float acc[9];
+  const unsigned int* dy32 = reinterpret_cast<const unsigned int*>(dy);
+  for (int i = threadIdx.x; i < 3 * XLD; i += blockDim.x) xs[i] = 0.f;   // the tail past FP stays zero (read, never NaN)
+  float acc[NC][9], accb[NC];
 #pragma unroll
-  for (int k = 0; k < 9; ++k) acc[k] = 0.f;
-  float accb = 0.f;
+  for (int e = 0; e < NC; ++e) {
+    accb[e] = 0.f;
+#pragma unroll
+    for (int k = 0; k < 9; ++k) acc[e][k] = 0.f;
+  }
   for (long row = r0; row < r1; ++row) {
     const int b = row / H, hh = row % H;
-    __syncthreads();
-    for (int i = threadIdx.x; i < 3 * FP; i += blockDim.x) {
-      const int kh = i / FP, f = i % FP - pad;
-      const int tt = st * hh - pad + kh;
-      xs[kh][i % FP] = (tt >= 0 && tt < T && f >= 0 && f < F) ? x[((long)b * T + tt) * F + f] : 0.f;
-    }
-    __syncthreads();
-    if (live) {
-      const long o = row * W * C + c;
-      for (int w0 = 0; w0 < W; w0 += 8) {        // 8 positions per trip: their loads are issued together
-        float g[8];
+    const long o = row * W * C + c;
+    for (int w00 = 0; w00 < W; w00 += NPOS) {
+      float g[NPOS / 8][8][NC];
+#pragma unroll
+      for (int tq = 0; tq < NPOS / 8; ++tq)
 #pragma unroll
         for (int u = 0; u < 8; ++u) {
-          const int ww = w0 + u;
-          const long oi = o + (long)(ww < W ? ww : w0) * C;
-          const float v = bf16 ? __uint_as_float(((unsigned)dy16[oi]) << 16) : dy[oi];
-          g[u] = ww < W ? v : 0.f;
+          const int ww = w00 + tq * 8 + u;
+          const long oi = o + (long)min(ww, W - 1) * C;
+          if (NC == 2) {
+            const unsigned v = dy32[oi >> 1];
+            g[tq][u][0] = __uint_as_float(v << 16); g[tq][u][NC - 1] = __uint_as_float(v & 0xffff0000u);
+          } else {
+            g[tq][u][0] = bf16 ? __uint_as_float(((unsigned)dy16[oi]) << 16) : dy[oi];
+          }
         }
+      if (w00 == 0) {
+        __syncthreads();
+        for (int i = threadIdx.x; i < 3 * FP; i += blockDim.x) {
+          const int kh = i / FP, f = i % FP - pad;
+          const int tt = ST * hh - pad + kh;
+          const bool ok = tt >= 0 && tt < T && f >= 0 && f < F;
+          const float v = x[((long)b * T + min(max(tt, 0), T - 1)) * F + min(max(f, 0), F - 1)];
+          xs[kh * XLD + i % FP] = ok ? v : 0.f;
+        }
+        __syncthreads();
+      }
 #pragma unroll
-        for (int u = 0; u < 8; ++u) {
-          accb += g[u];
-          const int f0 = st * min(w0 + u, W - 1);
+      for (int tq = 0; tq < NPOS / 8; ++tq) {
+        const int w0 = w00 + tq * 8;
+        if (w0 < W) {                          // block-uniform
+          float xr[3][NV * 4];
 #pragma unroll
           for (int kh = 0; kh < 3; ++kh)
 #pragma unroll
-            for (int kw = 0; kw < 3; ++kw) acc[kh * 3 + kw] += g[u] * xs[kh][f0 + kw];
+            for (int q = 0; q < NV; ++q) {
+              const float4 v = *reinterpret_cast<const float4*>(&xs[kh * XLD + ST * w0 + 4 * q]);
+              xr[kh][4 * q] = v.x; xr[kh][4 * q + 1] = v.y; xr[kh][4 * q + 2] = v.z; xr[kh][4 * q + 3] = v.w;
+            }
+#pragma unroll
+          for (int u = 0; u < 8; ++u) {
+#pragma unroll
+            for (int e = 0; e < NC; ++e) {
+              const float gv = (w0 + u < W) ? g[tq][u][e] : 0.f;
+              accb[e] += gv;
+#pragma unroll
+              for (int kh = 0; kh < 3; ++kh)
+#pragma unroll
+                for (int kw = 0; kw < 3; ++kw) acc[e][kh * 3 + kw] += gv * xr[kh][ST * u + kw];
+            }
+          }
         }
       }
     }
   }
   if (part) {   // per-block partial sums [gridDim.y][10][C] (k-major: coalesced), reduced by conv1_bwd_w_reduce_kernel
     if (live) {
-      float* pp = part + (long)blockIdx.y * 10 * C + c;
 #pragma unroll
-      for (int k = 0; k < 9; ++k) pp[(long)k * C] = acc[k];
-      pp[(long)9 * C] = accb;
+      for (int e = 0; e < NC; ++e) {
+        float* pp = part + (long)blockIdx.y * 10 * C + c + e;
+#pragma unroll
+        for (int k = 0; k < 9; ++k) pp[(long)k * C] = acc[e][k];
+        pp[(long)9 * C] = accb[e];
+      }
     }
     return;
   }
 #pragma unroll
-  for (int k = 0; k < 9; ++k) tr9[threadIdx.x * 10 + k] = live ? acc[k] : 0.f;
+  for (int e = 0; e < NC; ++e)
+#pragma unroll
+    for (int k = 0; k < 9; ++k) tr9[(threadIdx.x * NC + e) * 10 + k] = live ? acc[e][k] : 0.f;
   __syncthreads();
-  const int c0 = blockIdx.x * blockDim.x;
-  const int nch = min(256, C - c0);
+  const int c0 = blockIdx.x * blockDim.x * NC;
+  const int nch = min((int)blockDim.x * NC, C - c0);
   for (int i = threadIdx.x; i < nch * 9; i += blockDim.x) atomicAdd(&dw[(long)c0 * 9 + i], tr9[(i / 9) * 10 + (i % 9)]);
-  if (live) atomicAdd(&db[c], accb);
+  if (live)
+#pragma unroll
+    for (int e = 0; e < NC; ++e) atomicAdd(&db[c + e], accb[e]);
 }
 // part[nblk][10][C] -> dw[C][9] +=, db[C] +=.  grid (ceil(10*C/64), slices): 4 row-subgroups x 64 columns per block
 __global__ __launch_bounds__(256) void conv1_bwd_w_reduce_kernel(const float* __restrict__ part, int nblk, int C,
@@ -746,8 +823,14 @@ static int conv_c1_fwd(const float* x, const float* w, const float* bias, void* 
   if (!x || !w || !bias || !y || B <= 0 || T + 2 * pad < 3 || F + 2 * pad < 3 || C <= 0) return EAMD_EINVAL;
   if (F + 2 * pad > C1_MAXF) return EAMD_EUNSUPPORTED;
   int H = (T + 2 * pad - 3) / st + 1, W = (F + 2 * pad - 3) / st + 1;
-  hipLaunchKernelGGL(conv1_fwd_kernel, dim3(B * H), dim3(256), 0, (hipStream_t)stream, x, w, bias, (float*)y, B, T, F, H,
-                     W, C, y_bf16, st, pad);
+  hipStream_t s = (hipStream_t)stream;
+  const bool pair = y_bf16 && (C % 2 == 0) && (((uintptr_t)y & 3) == 0);
+  const int nthr = pair ? ((C / 2 + 63) / 64) * 64 : 256;
+#define EAMD_C1F(ST_, NC_) hipLaunchKernelGGL((conv1_fwd_kernel<ST_, NC_>), dim3(B * H), dim3(min(nthr, 256)), 0, s, x, w, \
+                                              bias, (float*)y, B, T, F, H, W, C, y_bf16, pad)
+  if (st == 2) { if (pair) EAMD_C1F(2, 2); else EAMD_C1F(2, 1); }
+  else         { if (pair) EAMD_C1F(1, 2); else EAMD_C1F(1, 1); }
+#undef EAMD_C1F
   EAMD_LAUNCH_CHECK();
   return EAMD_OK;
 }
@@ -763,7 +846,8 @@ int eamd_conv3x3_c1_fwd(const float* x, const float* w, const float* bias, void*
 static void conv_c1_bwd_w_grid(int B, int H, int C, int* gx, int* gy, long* rpb) {
   long nrow = (long)B * H;
   *gx = (C + 255) / 256;
-  long want = 2048 / *gx; if (want < 1) want = 1;
+  static const int want_env = [] { const char* e = getenv("EAMD_C1W_BLOCKS"); return e ? atoi(e) : 2048; }();
+  long want = want_env / *gx; if (want < 1) want = 1;
   *rpb = (nrow + want - 1) / want; if (*rpb < 1) *rpb = 1;
   *gy = (int)((nrow + *rpb - 1) / *rpb);
 }
@@ -776,8 +860,14 @@ static int conv_c1_bwd_w(const void* dy, const float* x, float* dw, float* db, f
   conv_c1_bwd_w_grid(B, H, C, &gx, &gy, &rpb);
   float* part = gy >= 64 ? workspace : nullptr;     // few blocks: direct atomics beat a second launch
   hipStream_t s = (hipStream_t)stream;
-  hipLaunchKernelGGL(conv1_bwd_w_kernel, dim3(gx, gy), dim3(256), 0, s, (const float*)dy, x, dw, db, part, B, T, F, H, W,
-                     C, (int)rpb, dy_bf16, st, pad);
+  const bool pair = dy_bf16 && (C % 2 == 0) && (((uintptr_t)dy & 3) == 0);
+  const int nthr = pair ? min(256, ((C / 2 + 63) / 64) * 64) : 256;
+  if (pair) gx = (C / 2 + nthr - 1) / nthr;
+#define EAMD_C1W(ST_, NC_) hipLaunchKernelGGL((conv1_bwd_w_kernel<ST_, NC_>), dim3(gx, gy), dim3(nthr), 0, s, \
+                                              (const float*)dy, x, dw, db, part, B, T, F, H, W, C, (int)rpb, dy_bf16, pad)
+  if (st == 2) { if (pair) EAMD_C1W(2, 2); else EAMD_C1W(2, 1); }
+  else         { if (pair) EAMD_C1W(1, 2); else EAMD_C1W(1, 1); }
+#undef EAMD_C1W
   EAMD_LAUNCH_CHECK();
   if (part) {
     hipLaunchKernelGGL(conv1_bwd_w_reduce_kernel, dim3((10 * C + 63) / 64, min(16, (gy + 31) / 32)), dim3(256), 0, s, part,

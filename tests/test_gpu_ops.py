@@ -408,6 +408,25 @@ def test_conv1(ops):
     ops.conv1_bwd_w(dyn.to(DEV), x.to(DEV), dw, db, B, T, F, Cc)
     report("conv1_bwd_w", dw, wd_.grad.view(Cc, 9), 1e-5)
     report("conv1_bwd_b", db, bd_.grad, 1e-5)
+    # bf16 activations (two channels per thread, packed stores; bf16 gradient input) and a ragged width (W = 41 > 40)
+    for (B2, T2, F2, C2) in ((2, 21, 20, 64), (3, 17, 84, 128)):
+        x2 = torch.randn(B2, T2, F2, generator=g)
+        w2 = torch.randn(C2, 1, 3, 3, generator=g)
+        b2 = torch.randn(C2, generator=g)
+        ref = torch.relu(torch.nn.functional.conv2d(x2.double().unsqueeze(1), w2.double(), b2.double(), stride=2))
+        ref = ref.permute(0, 2, 3, 1)
+        y32 = ops.conv1_fwd(x2.to(DEV), w2.to(DEV), b2.to(DEV), B2, T2, F2, C2)
+        report("conv1_fwd %dx%d" % (F2, C2), y32, ref, 1e-6)
+        y16 = ops.conv1_fwd(x2.to(DEV), w2.to(DEV), b2.to(DEV), B2, T2, F2, C2, torch.bfloat16)
+        assert torch.equal(y16, y32.to(torch.bfloat16))                 # same values, rounded once
+        dy2 = torch.randn(ref.shape, generator=g).to(torch.bfloat16)
+        dwr = torch.einsum("bhwc,bhwk->ck", dy2.double(),
+                           torch.nn.functional.unfold(x2.double().unsqueeze(1), 3, stride=2)
+                           .transpose(1, 2).reshape(B2, ref.shape[1], ref.shape[2], 9))
+        dw2, db2 = torch.zeros(C2, 9, device=DEV), torch.zeros(C2, device=DEV)
+        ops.conv1_bwd_w(dy2.to(DEV), x2.to(DEV), dw2, db2, B2, T2, F2, C2)
+        report("conv1_bwd_w bf16 %dx%d" % (F2, C2), dw2, dwr, 1e-5)
+        report("conv1_bwd_b bf16 %dx%d" % (F2, C2), db2, dy2.double().sum((0, 1, 2)), 1e-5)
 
 
 def test_optimizer(ops):

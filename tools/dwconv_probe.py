@@ -23,14 +23,18 @@ def graph_time(f, n=100):
     return (time.perf_counter() - t0) / 3 / n * 1e6
 
 
-B, T, C, K = 32, 249, 256, 31
-x = torch.randn(B, T, C, device=DEV)
-dy = torch.randn(B, T, C, device=DEV)
-w = torch.randn(C, K, device=DEV)
-b = torch.randn(C, device=DEV)
-dw = torch.zeros(C, K, device=DEV)
-db = torch.zeros(C, device=DEV)
-print("fwd   %6.1f us" % graph_time(lambda: ops.dwconv_fwd(x, w, b, B, T, C, K)))
-print("bwd_x %6.1f us" % graph_time(lambda: ops.dwconv_bwd_x(dy, w, B, T, C, K)))
-print("bwd_w %6.1f us  (EAMD_DWW_TPB=%s EAMD_DWW_MODE=%s)" % (graph_time(lambda: ops.dwconv_bwd_w(dy, x, dw, db, B, T, C, K)),
-                                                            os.environ.get("EAMD_DWW_TPB"), os.environ.get("EAMD_DWW_MODE")))
+def main():
+    x = torch.randn(B, T, C, device=DEV)
+    dy = torch.randn(B, T, C, device=DEV)
+    w = torch.randn(C, K, device=DEV)
+    b = torch.randn(C, device=DEV)
+    dw = torch.zeros(C, K, device=DEV)
+    db = torch.zeros(C, device=DEV)
+    print("fwd   %6.1f us" % graph_time(lambda: ops.dwconv_fwd(x, w, b, B, T, C, K)))
+    print("bwd_x %6.1f us" % graph_time(lambda: ops.dwconv_bwd_x(dy, w, B, T, C, K)))
+    print("bwd_w %6.1f us  (EAMD_DWW_TPB=%s EAMD_DWW_MODE=%s)" % (graph_time(lambda: ops.dwconv_bwd_w(dy, x, dw, db, B, T, C, K)),
+                                                                os.environ.get("EAMD_DWW_TPB"), os.environ.get("EAMD_DWW_MODE")))
+
+
+if __name__ == "__main__":
+    main()
