@@ -246,6 +246,38 @@ __global__ void rng_advance_kernel(unsigned long long* step) {
   if (threadIdx.x == 0 && blockIdx.x == 0) step[0] += 1ULL;
 }
 
+// ---- conv1d positionwise layers: im2col along time ------------------------------------------------------------
+// col[(b,t), kk*C + c] = x[b, t + kk - p, c] (0 outside the sequence), p = (k-1)/2; 4-byte words, so bf16 rows are
+// copied as channel pairs (C even) and fp32 rows as they are.  reference: transformer/multi_layer_conv.py:13-105
+// (torch.nn.Conv1d(padding=(k-1)//2) over the padded batch).
+__global__ void unfold1d_kernel(const unsigned int* __restrict__ x, unsigned int* __restrict__ col, int B, int T, int CW,
+                                int k) {
+  const int p = (k - 1) / 2;
+  const long n = (long)B * T * k * CW;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+    const int c = i % CW; long r = i / CW;
+    const int kk = r % k; r /= k;
+    const int t = r % T; const int b = r / T;
+    const int ts = t + kk - p;
+    col[i] = (ts >= 0 && ts < T) ? x[((long)b * T + ts) * CW + c] : 0u;
+  }
+}
+// dx[b,t,c] = sum_kk dcol[(b, t - kk + p), kk*C + c] over the rows inside the sequence
+__global__ void fold1d_kernel(const float* __restrict__ dcol, float* __restrict__ dx, int B, int T, int C, int k) {
+  const int p = (k - 1) / 2;
+  const long n = (long)B * T * C;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+    const int c = i % C; long r = i / C;
+    const int t = r % T; const int b = r / T;
+    float acc = 0.f;
+    for (int kk = 0; kk < k; ++kk) {
+      const int ts = t - kk + p;
+      if (ts >= 0 && ts < T) acc += dcol[(((long)b * T + ts) * k + kk) * C + c];
+    }
+    dx[i] = acc;
+  }
+}
+
 }  // namespace
 
 extern "C" {
@@ -299,6 +331,24 @@ int eamd_mask_rows(const float* x, const uint8_t* keep, float* y, int64_t rows, 
   if (!x || !keep || !y || rows <= 0 || D <= 0) return EAMD_EINVAL;
   hipLaunchKernelGGL(mask_rows_kernel, dim3(grid_for(rows * D)), dim3(256), 0, (hipStream_t)stream, x, keep, y,
                      (long)rows, D);
+  EAMD_LAUNCH_CHECK();
+  return EAMD_OK;
+}
+
+int eamd_unfold1d(const void* x, void* col, int B, int T, int C, int k, int bf16, void* stream) {
+  if (!x || !col || x == col || B <= 0 || T <= 0 || C <= 0 || k <= 0 || (k & 1) == 0) return EAMD_EINVAL;
+  if (bf16 && (C & 1)) return EAMD_EUNSUPPORTED;
+  if (((uintptr_t)x | (uintptr_t)col) & 3) return EAMD_EINVAL;
+  const int CW = bf16 ? C / 2 : C;
+  hipLaunchKernelGGL(unfold1d_kernel, dim3(grid_for((long)B * T * k * CW)), dim3(256), 0, (hipStream_t)stream,
+                     (const unsigned int*)x, (unsigned int*)col, B, T, CW, k);
+  EAMD_LAUNCH_CHECK();
+  return EAMD_OK;
+}
+
+int eamd_fold1d(const float* dcol, float* dx, int B, int T, int C, int k, void* stream) {
+  if (!dcol || !dx || dcol == dx || B <= 0 || T <= 0 || C <= 0 || k <= 0 || (k & 1) == 0) return EAMD_EINVAL;
+  hipLaunchKernelGGL(fold1d_kernel, dim3(grid_for((long)B * T * C)), dim3(256), 0, (hipStream_t)stream, dcol, dx, B, T, C, k);
   EAMD_LAUNCH_CHECK();
   return EAMD_OK;
 }

@@ -194,6 +194,74 @@ class FFNBlockFn(torch.autograd.Function):
         return (dx.view(shp),) + sink.results() + (None, None, None, None)
 
 
+class Conv1dFFNBlockFn(torch.autograd.Function):
+    """x + scale * drop(W2 (*) drop(relu(W1 (*) LN(x)))) with (*) a conv1d along time, the positionwise variants
+    MultiLayeredConv1d (both layers conv1d, k2 = k) and Conv1dLinear (second layer linear, k2 = 1).
+    reference: transformer/multi_layer_conv.py:13-105 (always ReLU), encoder_layer / conformer block wiring as
+    FFNBlockFn.  Each conv1d is im2col along time (eamd_unfold1d) + one GEMM against the tap-major [N, k*C] weight;
+    drop = (p_inner, salt_inner, p_out, salt_out)."""
+
+    @staticmethod
+    def forward(ctx, x, ln_w, ln_b, w1, b1, w2, b2, scale, eps, drop=(0.0, 0, 0.0, 0)):
+        B, T, D = x.shape
+        H, k1 = w1.shape[0], w1.shape[2]
+        k2 = w2.shape[2] if w2.dim() == 3 else 1
+        adt = ops.act_dtype()
+        p_in, s_in, p_out, s_out = drop
+        x2 = x.reshape(-1, D).contiguous()
+        xn, mean, rstd = ops.layernorm_fwd(x2, ln_w, ln_b, eps, adt)
+        w1k = torch.empty(H, k1 * D, device=x.device, dtype=torch.float32)
+        ops.permute4(w1.contiguous(), w1k, (H, D, k1, 1), (k1 * D, 1, D, 0))                 # [H, C, k] -> [H, k, C]
+        w1k = ops.to_act(w1k)
+        col1 = ops.unfold1d(xn, B, T, D, k1) if k1 > 1 else xn
+        z = ops.linear_fwd(col1, w1k, b1)                                                     # fp32 pre-activation
+        h = ops.dropout(z, p_in, s_in, act=ACT_RELU, out_dtype=adt)                           # p = 0: relu + cast
+        if k2 > 1:
+            w2k = torch.empty(D, k2 * H, device=x.device, dtype=torch.float32)
+            ops.permute4(w2.contiguous(), w2k, (D, H, k2, 1), (k2 * H, 1, H, 0))
+            w2k = ops.to_act(w2k)
+            col2 = ops.unfold1d(h, B, T, H, k2)
+        else:
+            w2k, col2 = ops.wshadow(w2), h
+        if p_out > 0.0:
+            br = ops.linear_fwd(col2, w2k, b2)
+            out = ops.axpby(x2, ops.dropout(br, p_out, s_out), 1.0, scale)
+        else:
+            out = ops.linear_fwd(col2, w2k, b2, R=x2, alpha=scale)
+        ctx.save_for_backward(x2, mean, rstd, col1, z, col2, w1k, w2k)
+        ctx.pr = (ln_w, ln_b, w1, b1, w2, b2)
+        ctx.cfg = (scale, (B, T, D, H, k1, k2), drop)
+        return out.view(B, T, D)
+
+    @staticmethod
+    def backward(ctx, dout):
+        x2, mean, rstd, col1, z, col2, w1k, w2k = ctx.saved_tensors
+        ln_w, ln_b, w1, b1, w2, b2 = ctx.pr
+        scale, (B, T, D, H, k1, k2), (p_in, s_in, p_out, s_out) = ctx.cfg
+        adt = ops.act_dtype()
+        sink = GradSink(ctx.pr)
+        do = dout.reshape(x2.shape).contiguous()
+        dob = ops.dropout(do, p_out, s_out, out_dtype=adt) if p_out > 0.0 else ops.to_act(do)
+        if k2 > 1:      # tap-major weight gradient, then back to the [D, H, k] parameter layout
+            dw2k = torch.zeros(D, k2 * H, device=do.device, dtype=torch.float32)
+            ops.linear_bwd_w(dob, col2, dw2k, alpha=scale, db=sink.buf(5))
+            ops.permute4(dw2k, sink.buf(4), (D, k2, H, 1), (H * k2, 1, k2, 0), accumulate=True)
+            dh = ops.fold1d(ops.linear_bwd_x(dob, w2k, alpha=scale), B, T, H, k2)
+        else:
+            ops.linear_bwd_w(dob, col2, sink.buf(4), alpha=scale, db=sink.buf(5))
+            dh = ops.linear_bwd_x(dob, w2k, alpha=scale)
+        if p_in > 0.0:
+            dh = ops.dropout(dh, p_in, s_in)
+        dz = ops.to_act(ops.act_bwd_any(dh, z, ACT_RELU))
+        dw1k = torch.zeros(H, k1 * D, device=do.device, dtype=torch.float32)
+        ops.linear_bwd_w(dz, col1, dw1k, db=sink.buf(3))
+        ops.permute4(dw1k, sink.buf(2), (H, k1, D, 1), (D * k1, 1, k1, 0), accumulate=True)
+        dcol = ops.linear_bwd_x(dz, w1k)
+        dxn = ops.fold1d(dcol, B, T, D, k1) if k1 > 1 else dcol
+        dx = ops.layernorm_bwd(dxn, x2, ln_w, mean, rstd, do, sink.buf(0), sink.buf(1))
+        return (dx.view(B, T, D),) + sink.results() + (None, None, None)
+
+
 # =================================================================================================
 # Attention core on projected q/k/v laid out [B, T, H, dk] (i.e. the Linear outputs, untransposed)
 # scores live in [H, B, T1, ldp] so that for one head the (b, i) rows are uniformly strided.

@@ -270,8 +270,48 @@ class PositionwiseFeedForward(torch.nn.Module):
         self.salt_in, self.salt_out = ops.new_salt(), ops.new_salt()
 
 
+class MultiLayeredConv1d(torch.nn.Module):
+    """reference: transformer/multi_layer_conv.py:13-58 (Conv1d -> ReLU -> dropout -> Conv1d along time)"""
+
+    def __init__(self, in_chans, hidden_chans, kernel_size, dropout_rate):
+        super().__init__()
+        self.w_1 = torch.nn.Conv1d(in_chans, hidden_chans, kernel_size, stride=1, padding=(kernel_size - 1) // 2)
+        self.w_2 = torch.nn.Conv1d(hidden_chans, in_chans, kernel_size, stride=1, padding=(kernel_size - 1) // 2)
+        self.dropout_rate = dropout_rate
+        self.salt_in, self.salt_out = ops.new_salt(), ops.new_salt()
+        if kernel_size % 2 == 0:
+            raise NotImplementedError("even conv1d kernels change the sequence length; odd kernels are on the HIP path")
+
+
+class Conv1dLinear(torch.nn.Module):
+    """reference: transformer/multi_layer_conv.py:61-105 (Conv1d -> ReLU -> dropout -> Linear)"""
+
+    def __init__(self, in_chans, hidden_chans, kernel_size, dropout_rate):
+        super().__init__()
+        self.w_1 = torch.nn.Conv1d(in_chans, hidden_chans, kernel_size, stride=1, padding=(kernel_size - 1) // 2)
+        self.w_2 = torch.nn.Linear(hidden_chans, in_chans)
+        self.dropout_rate = dropout_rate
+        self.salt_in, self.salt_out = ops.new_salt(), ops.new_salt()
+        if kernel_size % 2 == 0:
+            raise NotImplementedError("even conv1d kernels change the sequence length; odd kernels are on the HIP path")
+
+
+def positionwise_layer(layer_type, attention_dim, linear_units, dropout_rate, conv_kernel_size=1, activation=None):
+    """reference: encoder.py:258-285 (get_positionwise_layer); the conv1d variants take no activation argument"""
+    if layer_type == "linear":
+        return PositionwiseFeedForward(attention_dim, linear_units, dropout_rate, activation)
+    if layer_type == "conv1d":
+        return MultiLayeredConv1d(attention_dim, linear_units, conv_kernel_size, dropout_rate)
+    if layer_type == "conv1d-linear":
+        return Conv1dLinear(attention_dim, linear_units, conv_kernel_size, dropout_rate)
+    raise NotImplementedError("Support only linear or conv1d.")
+
+
 def ffn_block(norm, ff, x, scale, p_out=0.0):
     drop = (_p(ff, ff.dropout_rate), ff.salt_in, p_out if ff.training else 0.0, ff.salt_out)
+    if not isinstance(ff, PositionwiseFeedForward):
+        return F_.Conv1dFFNBlockFn.apply(x.contiguous(), norm.weight, norm.bias, ff.w_1.weight, ff.w_1.bias,
+                                         ff.w_2.weight, ff.w_2.bias, scale, norm.eps, drop)
     return F_.FFNBlockFn.apply(x.contiguous(), norm.weight, norm.bias, ff.w_1.weight, ff.w_1.bias, ff.w_2.weight,
                                ff.w_2.bias, scale, ff.act_id, norm.eps, drop)
 
@@ -414,10 +454,12 @@ class ConformerEncoder(torch.nn.Module):
             raise NotImplementedError("pos_enc_layer_type " + pos_enc_layer_type)
         if input_layer != "conv2d":
             raise NotImplementedError("input_layer=%r: only conv2d is on the HIP path" % (input_layer,))
-        if positionwise_layer_type != "linear":
-            raise NotImplementedError("positionwise_layer_type=%r (SURVEY.md §8f, next)" % positionwise_layer_type)
         self.embed = Conv2dSubsampling(idim, attention_dim, dropout_rate,
                                        pos_enc_class(attention_dim, positional_dropout_rate))
+
+        def pw():
+            return positionwise_layer(positionwise_layer_type, attention_dim, linear_units, dropout_rate,
+                                      positionwise_conv_kernel_size, get_activation(activation_type))
         self.normalize_before = normalize_before
         if selfattention_layer_type == "selfattn":
             attn_class = MultiHeadedAttention
@@ -431,8 +473,8 @@ class ConformerEncoder(torch.nn.Module):
             lambda lnum: ConformerEncoderLayer(
                 attention_dim,
                 attn_class(attention_heads, attention_dim, attention_dropout_rate),
-                PositionwiseFeedForward(attention_dim, linear_units, dropout_rate, get_activation(activation_type)),
-                PositionwiseFeedForward(attention_dim, linear_units, dropout_rate, get_activation(activation_type))
+                pw(),
+                pw()
                 if macaron_style else None,
                 ConvolutionModule(attention_dim, cnn_module_kernel, get_activation(activation_type))
                 if use_cnn_module else None,
@@ -486,8 +528,6 @@ class TransformerEncoder(torch.nn.Module):
                  pos_enc_class=PositionalEncoding, normalize_before=True, concat_after=False,
                  positionwise_layer_type="linear", positionwise_conv_kernel_size=1, padding_idx=-1, **unused):
         super().__init__()
-        if positionwise_layer_type != "linear":
-            raise NotImplementedError("only the linear positionwise layer is on the HIP path")
         pos = pos_enc_class(attention_dim, positional_dropout_rate)
         if input_layer == "conv2d":
             self.embed = Conv2dSubsampling(idim, attention_dim, dropout_rate, pos)
@@ -502,7 +542,8 @@ class TransformerEncoder(torch.nn.Module):
             num_blocks,
             lambda lnum: TransformerEncoderLayer(
                 attention_dim, MultiHeadedAttention(attention_heads, attention_dim, attention_dropout_rate),
-                PositionwiseFeedForward(attention_dim, linear_units, dropout_rate), dropout_rate,
+                positionwise_layer(positionwise_layer_type, attention_dim, linear_units, dropout_rate,
+                                   positionwise_conv_kernel_size), dropout_rate,
                 normalize_before, concat_after))
         if self.normalize_before:
             self.after_norm = LayerNorm(attention_dim)

@@ -930,3 +930,20 @@ def logmel(spec, ld, rows_per_utt, melmat, lo, hi, flens, B, T, F, log_scale=1.0
                                  ptr(flens) if flens is not None else None, ptr(out), B, T, F, M, C.c_float(log_scale),
                                  int(power_input), stream_ptr()), "eamd_logmel")
     return out
+
+
+def unfold1d(x, B, T, Cc, k):
+    """x [B*T, C] (fp32 / bf16) -> col [B*T, k*C]: rows t-(k-1)/2 .. t+(k-1)/2 of the same sequence side by side"""
+    assert x.numel() == B * T * Cc and x.is_contiguous() and x.dtype in (torch.float32, torch.bfloat16)
+    col = torch.empty(B * T, k * Cc, device=x.device, dtype=x.dtype)
+    check(_lib.lib().eamd_unfold1d(ptr(x), ptr(col), B, T, Cc, k, 1 if x.dtype == torch.bfloat16 else 0, stream_ptr()),
+          "eamd_unfold1d")
+    return col
+
+
+def fold1d(dcol, B, T, Cc, k):
+    """adjoint of unfold1d on fp32: dcol [B*T, k*C] -> dx [B*T, C]"""
+    assert dcol.numel() == B * T * k * Cc and dcol.dtype == torch.float32 and dcol.is_contiguous()
+    dx = torch.empty(B * T, Cc, device=dcol.device, dtype=torch.float32)
+    check(_lib.lib().eamd_fold1d(ptr(dcol), ptr(dx), B, T, Cc, k, stream_ptr()), "eamd_fold1d")
+    return dx

@@ -293,6 +293,12 @@ int eamd_maxpool2x2_fwd(const float* x, float* y, uint8_t* idx, int B, int H, in
 int eamd_maxpool2x2_bwd(const float* dy, const uint8_t* idx, float* dx, int B, int H, int W, int C, void* stream);
 /* y[r,:] = keep[r] ? x[r,:] : 0  (zeroing of padded encoder frames, rnn/encoders.py:323-325; x may alias y) */
 int eamd_mask_rows(const float* x, const uint8_t* keep, float* y, int64_t rows, int D, void* stream);
+/* conv1d positionwise layers (MultiLayeredConv1d / Conv1dLinear, transformer/multi_layer_conv.py:13-105): im2col along
+ * time so that Conv1d(C, N, k, padding=(k-1)/2) over [B,T,C] is one eamd_gemm against the [N, k*C] tap-major weight.
+ * col[(b,t), kk*C + c] = x[b, t+kk-(k-1)/2, c] (zero outside 0 <= . < T); x / col fp32 or both bf16 (C even);
+ * eamd_fold1d is the adjoint on fp32: dx[b,t,c] = sum_kk dcol[(b, t-kk+(k-1)/2), kk*C + c]. */
+int eamd_unfold1d(const void* x, void* col, int B, int T, int C, int k, int bf16, void* stream);
+int eamd_fold1d(const float* dcol, float* dx, int B, int T, int C, int k, void* stream);
 /* VGG2L first convolution (1 -> C channels, 3x3, stride 1, padding 1) + ReLU on [B,T,F] -> NHWC [B,T,F,C], and
  * its weight gradient (dy already ReLU-masked).  reference: rnn/encoders.py:184,203. */
 int eamd_conv3x3_c1_fwd(const float* x, const float* w, const float* bias, void* y, int B, int T, int F, int C,

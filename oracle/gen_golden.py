@@ -377,6 +377,28 @@ def main():
          loss=loss.detach(), loss_att=stats["loss_att"], loss_ctc=stats["loss_ctc"], acc=float(stats["acc"]),
          weight=weight, **sd0, **grads_np(m2))
 
+    # ---- 8f rank 4: conv1d positionwise layers (MultiLayeredConv1d / Conv1dLinear) inside the espnet2 encoders ----
+    from espnet2.asr.encoder.transformer_encoder import TransformerEncoder as TrfEncoder2
+    for tag, cls, kw in (("conf_conv1d", ConformerEncoder, dict(positionwise_layer_type="conv1d", macaron_style=True,
+                                                               cnn_module_kernel=7)),
+                         ("conf_conv1dlin", ConformerEncoder, dict(positionwise_layer_type="conv1d-linear",
+                                                                  positionwise_conv_kernel_size=5, use_cnn_module=False)),
+                         ("trf_conv1d", TrfEncoder2, dict(positionwise_layer_type="conv1d",
+                                                          positionwise_conv_kernel_size=3))):
+        torch.manual_seed(31)
+        enc_pw = cls(20, output_size=64, attention_heads=4, linear_units=96, num_blocks=2, dropout_rate=0.0,
+                     positional_dropout_rate=0.0, attention_dropout_rate=0.0, **kw)
+        enc_pw.train()
+        sd_pw = sd_np(enc_pw, "sd/")
+        gp = torch.Generator().manual_seed(5)
+        xs_pw = torch.randn(2, 61, 20, generator=gp)
+        il_pw = torch.tensor([61, 44])
+        y_pw, ol_pw, _ = enc_pw(xs_pw, il_pw)
+        gy_pw = torch.randn(y_pw.shape, generator=gp)
+        (y_pw * gy_pw).sum().backward()
+        save(out("pw_%s.npz" % tag), xs=xs_pw, ilens=il_pw, y=y_pw.detach(), olens=ol_pw, gy=gy_pw, **sd_pw,
+             **grads_np(enc_pw))
+
     # ---- a19 / f2: BatchBeamSearch, and LM shallow fusion (TransformerLM, SequentialRNNLM) ----------
     from espnet.nets.batch_beam_search import BatchBeamSearch
     from espnet.nets.beam_search import BeamSearch as RefBeamSearch

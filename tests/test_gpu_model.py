@@ -666,3 +666,37 @@ def test_frontend_golden():
         model.frontend = None
         want, wl = model.encode(feats, flens)
     assert torch.equal(got, want) and glens.tolist() == wl.tolist()
+
+
+@pytest.mark.parametrize("tag,kind,kw", [
+    ("conf_conv1d", "conformer", dict(positionwise_layer_type="conv1d", macaron_style=True, cnn_module_kernel=7)),
+    ("conf_conv1dlin", "conformer", dict(positionwise_layer_type="conv1d-linear", positionwise_conv_kernel_size=5,
+                                         use_cnn_module=False)),
+    ("trf_conv1d", "transformer", dict(positionwise_layer_type="conv1d", positionwise_conv_kernel_size=3))])
+def test_positionwise_conv1d_golden(tag, kind, kw):
+    """8f rank 4: MultiLayeredConv1d / Conv1dLinear positionwise layers (im2col along time + GEMM) inside the espnet2
+    encoders, outputs and every parameter gradient against the reference's own encoders."""
+    from espnet_amd.espnet2 import ConformerEncoder, TransformerEncoder
+    p, sd, grads = split_golden(load_golden("pw_%s.npz" % tag))
+    cls = ConformerEncoder if kind == "conformer" else TransformerEncoder
+    enc = cls(20, output_size=64, attention_heads=4, linear_units=96, num_blocks=2, dropout_rate=0.0,
+              positional_dropout_rate=0.0, attention_dropout_rate=0.0, **kw)
+    assert list(enc.state_dict().keys()) == list(sd.keys())
+    enc = load_sd(enc, sd)
+    enc.train()
+    y, olens, _ = enc(p["xs"].to(DEV), p["ilens"])
+    assert olens.tolist() == p["olens"].tolist()
+    report("pw %s fwd" % tag, y, p["y"], 5e-5)
+    y.backward(p["gy"].to(DEV))
+    check_grads(enc, grads, tol=5e-4)
+    # bf16-operand mode (bf16 im2col rows): same module, outputs within bf16 rounding of the fp32 result
+    import espnet_amd
+    espnet_amd.set_precision("bf16")
+    try:
+        with torch.no_grad():
+            yb, _, _ = enc(p["xs"].to(DEV), p["ilens"])
+    finally:
+        espnet_amd.set_precision("fp32")
+    rel = float((yb.cpu() - p["y"]).norm() / p["y"].norm())
+    print(f"[parity] pw {tag} bf16-mode rel_l2 {rel:.2e}")
+    assert rel < 3e-2
