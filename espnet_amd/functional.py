@@ -595,72 +595,103 @@ _CLASSES = [((0, 0), [(0, 0), (0, 2), (2, 0), (2, 2)]), ((0, 1), [(0, 1), (2, 1)
             ((1, 0), [(1, 0), (1, 2)]), ((1, 1), [(1, 1)])]
 
 
+def _conv3s2_fwd(y_in, w, b, B, Hi, Wi, Cc, adt):
+    """3x3 stride-2 convolution + ReLU on an NHWC activation [B*Hi*Wi, Cc] as one implicit GEMM (rows gathered tap by
+    tap) -> (y [B*Ho*Wo, Cc], input-gradient weight image wd, Ho, Wo)"""
+    Ho, Wo = (Hi - 3) // 2 + 1, (Wi - 3) // 2 + 1
+    wf, wd = ops.conv2_weight_prep(w, adt)
+    g = ops.make_gather(Cc, _TAPS_FWD, Ho, Wo, Hi, Wi, 2, 2)
+    M = B * Ho * Wo
+    y = torch.empty(M, Cc, device=y_in.device, dtype=adt)
+    ops.gemm(y_in, wf, y, M, Cc, 9 * Cc, 9 * Cc, Cc, Cc, transB=1, bias=b, epilogue=EPI_RELU, gather=g)
+    return y, wd, Ho, Wo
+
+
+def _conv3s2_bwd(dy, y_in, wd, dw_buf, db_buf, B, Hi, Wi, Ho, Wo, Cc, adt):
+    """dy [B*Ho*Wo, Cc] (already multiplied by this stage's ReLU mask) -> gradient w.r.t. y_in, multiplied by the ReLU
+    mask of y_in in the epilogue; weight / bias gradients are accumulated into dw_buf / db_buf"""
+    dev = dy.device
+    M = B * Ho * Wo
+    ops.colsum(dy, db_buf)
+    # weight gradient: dwf[(tap, ci), co] = sum_pos col[pos, (tap, ci)] * dy[pos, co]
+    dwf = torch.zeros(9 * Cc, Cc, device=dev, dtype=torch.float32)
+    g = ops.make_gather(Cc, _TAPS_FWD, Ho, Wo, Hi, Wi, 2, 2)
+    tile = 64
+    ntile = (9 * Cc // tile) * ((Cc + tile - 1) // tile)
+    sk = max(2, min(64, (1024 + ntile - 1) // ntile, max(1, M // 256)))
+    ops.gemm(y_in, dy, dwf, 9 * Cc, Cc, M, 9 * Cc, Cc, Cc, transA=1, transB=1, gather=g, splitk=sk, tile=tile)
+    ops.conv2_weight_grad(dwf, dw_buf, Cc, Cc)
+    # input gradient, one implicit GEMM per stride-parity class
+    dy_in = torch.empty(y_in.shape, device=dev, dtype=adt)
+    q0 = 0
+    for (ph, pw), taps in _CLASSES:
+        Hc, Wc = (Hi - ph + 1) // 2, (Wi - pw + 1) // 2
+        if Hc > 0 and Wc > 0:
+            gt = ops.make_gather(Cc, [((ph - kh) // 2, (pw - kw) // 2) for kh, kw in taps], Hc, Wc, Ho, Wo, 1, 1)
+            cm = ops.make_rowmap(Hc, Wc, Hi, Wi, 2, ph, 2, pw)
+            nt = len(taps)
+            ops.gemm(dy, wd, dy_in, B * Hc * Wc, Cc, nt * Cc, nt * Cc, Cc, Cc, transB=1, b_off=q0 * Cc * Cc,
+                     gather=gt, cmap=cm, epilogue=EPI_MUL_RELU_MASK, aux=y_in, ldaux=Cc)
+        q0 += len(taps)
+    return dy_in
+
+
 class Conv2dSubsamplingFn(torch.autograd.Function):
+    """Conv2d(1, C, 3, 2) -> ReLU -> n x [Conv2d(C, C, 3, 2) -> ReLU] -> Linear(C * W', D) * xscale.
+    n = 1: Conv2dSubsampling (subsampling.py:17-66); n = 2: Conv2dSubsampling8 (:123-168).
+    convs = (w, b) pairs of the C -> C stages."""
+
     @staticmethod
-    def forward(ctx, x, xscale, c1_w, c1_b, c2_w, c2_b, lin_w, lin_b):
+    def forward(ctx, x, xscale, c1_w, c1_b, lin_w, lin_b, *convs):
         B, T, F = x.shape
         Cc = c1_w.shape[0]
         D = lin_w.shape[0]
         H1, W1 = (T - 3) // 2 + 1, (F - 3) // 2 + 1
-        H2, W2 = (H1 - 3) // 2 + 1, (W1 - 3) // 2 + 1
-        assert lin_w.shape[1] == Cc * W2
         adt = ops.act_dtype()
         x = x.contiguous()
-        y1 = ops.conv1_fwd(x, c1_w, c1_b, B, T, F, Cc, adt)                  # [B,H1,W1,C] NHWC, ReLU'd
-        wf, wd = ops.conv2_weight_prep(c2_w, adt)
-        g = ops.make_gather(Cc, _TAPS_FWD, H2, W2, H1, W1, 2, 2)
-        M2 = B * H2 * W2
-        y2 = torch.empty(M2, Cc, device=x.device, dtype=adt)
-        ops.gemm(y1, wf, y2, M2, Cc, 9 * Cc, 9 * Cc, Cc, Cc, transB=1, bias=c2_b, epilogue=EPI_RELU, gather=g)
+        ys = [ops.conv1_fwd(x, c1_w, c1_b, B, T, F, Cc, adt)]               # [B,H1,W1,C] NHWC, ReLU'd
+        dims, wds = [(H1, W1)], []
+        for i in range(0, len(convs), 2):
+            y, wd, Ho, Wo = _conv3s2_fwd(ys[-1].view(-1, Cc), convs[i], convs[i + 1], B, dims[-1][0], dims[-1][1], Cc, adt)
+            ys.append(y)
+            wds.append(wd)
+            dims.append((Ho, Wo))
+        Hl, Wl = dims[-1]
+        assert lin_w.shape[1] == Cc * Wl
         # Linear over (c, f) features: our rows are (f, c)-ordered, so permute the weight columns
-        wl = torch.empty(D, W2 * Cc, device=x.device, dtype=torch.float32)
-        ops.permute4(lin_w, wl, (D, Cc, W2, 1), (W2 * Cc, 1, Cc, 0))
+        wl = torch.empty(D, Wl * Cc, device=x.device, dtype=torch.float32)
+        ops.permute4(lin_w, wl, (D, Cc, Wl, 1), (Wl * Cc, 1, Cc, 0))
         wl = ops.to_act(wl)
-        out = ops.linear_fwd(y2.view(B * H2, W2 * Cc), wl, lin_b, alpha=xscale)
-        ctx.save_for_backward(x, y1, y2, wd, wl)
-        ctx.pr = (c1_w, c1_b, c2_w, c2_b, lin_w, lin_b)
-        ctx.cfg = (B, T, F, Cc, D, H1, W1, H2, W2, xscale)
-        return out.view(B, H2, D)
+        out = ops.linear_fwd(ys[-1].view(B * Hl, Wl * Cc), wl, lin_b, alpha=xscale)
+        ctx.save_for_backward(x, wl, *ys, *wds)
+        ctx.pr = (c1_w, c1_b, lin_w, lin_b) + tuple(convs)
+        ctx.cfg = (B, T, F, Cc, D, dims, xscale)
+        return out.view(B, Hl, D)
 
     @staticmethod
     def backward(ctx, dout):
-        x, y1, y2, wd, wl = ctx.saved_tensors
-        c1_w, c1_b, c2_w, c2_b, lin_w, lin_b = ctx.pr
-        B, T, F, Cc, D, H1, W1, H2, W2, xscale = ctx.cfg
+        B, T, F, Cc, D, dims, xscale = ctx.cfg
+        n = len(dims) - 1
+        x, wl = ctx.saved_tensors[:2]
+        ys = ctx.saved_tensors[2:3 + n]
+        wds = ctx.saved_tensors[3 + n:]
         adt = ops.act_dtype()
         sink = GradSink(ctx.pr)
         dev = x.device
-        dob = ops.to_act(dout.reshape(B * H2, D).contiguous())
-        y2v = y2.view(B * H2, W2 * Cc)
+        Hl, Wl = dims[-1]
+        dob = ops.to_act(dout.reshape(B * Hl, D).contiguous())
+        ylv = ys[-1].view(B * Hl, Wl * Cc)
         # Linear: weight grad in permuted column order, then un-permute-accumulate
-        dwl = torch.zeros(D, W2 * Cc, device=dev, dtype=torch.float32)
-        ops.linear_bwd_w(dob, y2v, dwl, alpha=xscale, db=sink.buf(5))
-        ops.permute4(dwl, sink.buf(4), (D, W2, Cc, 1), (W2 * Cc, 1, W2, 0), accumulate=True)
-        dy2 = ops.linear_bwd_x(dob, wl, epilogue=EPI_MUL_RELU_MASK, aux=y2v, alpha=xscale, out_dtype=adt)
-        dy2 = dy2.view(B * H2 * W2, Cc)
-        M2 = B * H2 * W2
-        ops.colsum(dy2, sink.buf(3))
-        # conv2 weight gradient: dwf[(tap, ci), co] = sum_pos col[pos, (tap, ci)] * dy2[pos, co]
-        dwf = torch.zeros(9 * Cc, Cc, device=dev, dtype=torch.float32)
-        g = ops.make_gather(Cc, _TAPS_FWD, H2, W2, H1, W1, 2, 2)
-        tile = 64
-        ntile = (9 * Cc // tile) * ((Cc + tile - 1) // tile)
-        sk = max(2, min(64, (1024 + ntile - 1) // ntile, max(1, M2 // 256)))
-        ops.gemm(y1, dy2, dwf, 9 * Cc, Cc, M2, 9 * Cc, Cc, Cc, transA=1, transB=1, gather=g, splitk=sk, tile=tile)
-        ops.conv2_weight_grad(dwf, sink.buf(2), Cc, Cc)
-        # conv2 input gradient, one implicit GEMM per stride-parity class, ReLU mask of conv1 fused
-        dy1 = torch.empty(y1.shape, device=dev, dtype=adt)
-        q0 = 0
-        for (ph, pw), taps in _CLASSES:
-            Ho, Wo = (H1 - ph + 1) // 2, (W1 - pw + 1) // 2
-            if Ho > 0 and Wo > 0:
-                gt = ops.make_gather(Cc, [((ph - kh) // 2, (pw - kw) // 2) for kh, kw in taps], Ho, Wo, H2, W2, 1, 1)
-                cm = ops.make_rowmap(Ho, Wo, H1, W1, 2, ph, 2, pw)
-                nt = len(taps)
-                ops.gemm(dy2, wd, dy1, B * Ho * Wo, Cc, nt * Cc, nt * Cc, Cc, Cc, transB=1, b_off=q0 * Cc * Cc,
-                         gather=gt, cmap=cm, epilogue=EPI_MUL_RELU_MASK, aux=y1, ldaux=Cc)
-            q0 += len(taps)
-        ops.conv1_bwd_w(dy1, x, sink.buf(0), sink.buf(1), B, T, F, Cc)
+        dwl = torch.zeros(D, Wl * Cc, device=dev, dtype=torch.float32)
+        ops.linear_bwd_w(dob, ylv, dwl, alpha=xscale, db=sink.buf(3))
+        ops.permute4(dwl, sink.buf(2), (D, Wl, Cc, 1), (Wl * Cc, 1, Wl, 0), accumulate=True)
+        dy = ops.linear_bwd_x(dob, wl, epilogue=EPI_MUL_RELU_MASK, aux=ylv, alpha=xscale, out_dtype=adt)
+        dy = dy.view(B * Hl * Wl, Cc)
+        for i in range(n - 1, -1, -1):
+            (Hi, Wi), (Ho, Wo) = dims[i], dims[i + 1]
+            dy = _conv3s2_bwd(dy, ys[i].view(-1, Cc), wds[i], sink.buf(4 + 2 * i), sink.buf(5 + 2 * i), B, Hi, Wi, Ho, Wo,
+                              Cc, adt)
+        ops.conv1_bwd_w(dy, x, sink.buf(0), sink.buf(1), B, T, F, Cc)
         return (None, None) + sink.results()
 
 

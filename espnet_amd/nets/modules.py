@@ -101,15 +101,17 @@ def pad_list(xs, pad_value):
     return pad
 
 
-def subsampled_lengths(ilens, tmax=None):
-    """valid frames after Conv2dSubsampling's mask[:, :, :-2:2][:, :, :-2:2] (subsampling.py:59)."""
+def subsampled_lengths(ilens, tmax=None, stages=2):
+    """valid frames after `stages` applications of mask[:, :, :-2:2] (subsampling.py:59 for Conv2dSubsampling: two;
+    :166 for Conv2dSubsampling8: three)."""
     out = []
     for n in ilens:
         n = int(n)
         t = n if tmax is None else tmax
-        a = max(0, -(-min(n, t - 2) // 2))            # true entries of mask[:-2:2]
-        t1 = max(0, -(-(t - 2) // 2))
-        out.append(max(0, -(-min(a, t1 - 2) // 2)))
+        for _ in range(stages):
+            n = max(0, -(-min(n, t - 2) // 2))        # true entries of mask[:-2:2]
+            t = max(0, -(-(t - 2) // 2))
+        out.append(n)
     return out
 
 
@@ -195,9 +197,9 @@ class Conv2dSubsampling(torch.nn.Module):
 
     def forward(self, x, x_mask):
         pos = self.out[1]
-        y = F_.Conv2dSubsamplingFn.apply(x, pos.xscale, self.conv[0].weight, self.conv[0].bias,
-                                         self.conv[2].weight, self.conv[2].bias, self.out[0].weight,
-                                         self.out[0].bias)
+        stages = [t for i in range(2, len(self.conv), 2) for t in (self.conv[i].weight, self.conv[i].bias)]
+        y = F_.Conv2dSubsamplingFn.apply(x, pos.xscale, self.conv[0].weight, self.conv[0].bias, self.out[0].weight,
+                                         self.out[0].bias, *stages)
         if isinstance(pos, RelPositionalEncoding):
             pe = pos.pos_emb(y.size(1), y.device).unsqueeze(0)
             y = (F_.dropout(y, pos.dropout_rate, pos.salt, pos.training),
@@ -209,6 +211,27 @@ class Conv2dSubsampling(torch.nn.Module):
         if x_mask is None:
             return y, None
         return y, x_mask[:, :, :-2:2][:, :, :-2:2].contiguous()
+
+
+class Conv2dSubsampling8(Conv2dSubsampling):
+    """reference: transformer/subsampling.py:123-168 (three 3x3 stride-2 convolutions, 1/8 length)"""
+
+    def __init__(self, idim, odim, dropout_rate, pos_enc=None):
+        torch.nn.Module.__init__(self)
+        self.conv = torch.nn.Sequential(torch.nn.Conv2d(1, odim, 3, 2), torch.nn.ReLU(),
+                                        torch.nn.Conv2d(odim, odim, 3, 2), torch.nn.ReLU(),
+                                        torch.nn.Conv2d(odim, odim, 3, 2), torch.nn.ReLU())
+        self.out = torch.nn.Sequential(
+            torch.nn.Linear(odim * ((((idim - 1) // 2 - 1) // 2 - 1) // 2), odim),
+            pos_enc if pos_enc is not None else PositionalEncoding(odim, dropout_rate))
+        if odim % 64 != 0:
+            raise NotImplementedError("Conv2dSubsampling HIP path needs odim % 64 == 0 (implicit-GEMM tiles)")
+
+    def forward(self, x, x_mask):
+        y, m = super().forward(x, None if x_mask is None else x_mask)
+        if x_mask is None:
+            return y, None
+        return y, x_mask[:, :, :-2:2][:, :, :-2:2][:, :, :-2:2].contiguous()
 
 
 # ---- attention ---------------------------------------------------------------------------------
@@ -452,10 +475,10 @@ class ConformerEncoder(torch.nn.Module):
             pos_enc_class = RelPositionalEncoding
         else:
             raise NotImplementedError("pos_enc_layer_type " + pos_enc_layer_type)
-        if input_layer != "conv2d":
-            raise NotImplementedError("input_layer=%r: only conv2d is on the HIP path" % (input_layer,))
-        self.embed = Conv2dSubsampling(idim, attention_dim, dropout_rate,
-                                       pos_enc_class(attention_dim, positional_dropout_rate))
+        if input_layer not in ("conv2d", "conv2d8"):
+            raise NotImplementedError("input_layer=%r: conv2d / conv2d8 are on the HIP path" % (input_layer,))
+        self.embed = (Conv2dSubsampling if input_layer == "conv2d" else Conv2dSubsampling8)(
+            idim, attention_dim, dropout_rate, pos_enc_class(attention_dim, positional_dropout_rate))
 
         def pw():
             return positionwise_layer(positionwise_layer_type, attention_dim, linear_units, dropout_rate,
@@ -531,12 +554,14 @@ class TransformerEncoder(torch.nn.Module):
         pos = pos_enc_class(attention_dim, positional_dropout_rate)
         if input_layer == "conv2d":
             self.embed = Conv2dSubsampling(idim, attention_dim, dropout_rate, pos)
+        elif input_layer == "conv2d8":
+            self.embed = Conv2dSubsampling8(idim, attention_dim, dropout_rate, pos)
         elif input_layer == "linear":
             self.embed = _LinearInput(idim, attention_dim, dropout_rate, pos)
         elif input_layer == "embed":
             self.embed = _EmbedInput(idim, attention_dim, padding_idx, pos)
         else:
-            raise NotImplementedError("input_layer %r: conv2d / linear / embed are on the HIP path" % (input_layer,))
+            raise NotImplementedError("input_layer %r: conv2d / conv2d8 / linear / embed are on the HIP path" % (input_layer,))
         self.normalize_before = normalize_before
         self.encoders = repeat(
             num_blocks,

@@ -672,10 +672,13 @@ def test_frontend_golden():
     ("conf_conv1d", "conformer", dict(positionwise_layer_type="conv1d", macaron_style=True, cnn_module_kernel=7)),
     ("conf_conv1dlin", "conformer", dict(positionwise_layer_type="conv1d-linear", positionwise_conv_kernel_size=5,
                                          use_cnn_module=False)),
-    ("trf_conv1d", "transformer", dict(positionwise_layer_type="conv1d", positionwise_conv_kernel_size=3))])
+    ("trf_conv1d", "transformer", dict(positionwise_layer_type="conv1d", positionwise_conv_kernel_size=3)),
+    ("conf_conv2d8", "conformer", dict(input_layer="conv2d8", use_cnn_module=False)),
+    ("trf_conv2d8", "transformer", dict(input_layer="conv2d8"))])
 def test_positionwise_conv1d_golden(tag, kind, kw):
-    """8f rank 4: MultiLayeredConv1d / Conv1dLinear positionwise layers (im2col along time + GEMM) inside the espnet2
-    encoders, outputs and every parameter gradient against the reference's own encoders."""
+    """8f rank 4: MultiLayeredConv1d / Conv1dLinear positionwise layers (im2col along time + GEMM) and the
+    Conv2dSubsampling8 input layer (three implicit-GEMM 3x3 stride-2 stages) inside the espnet2 encoders, outputs,
+    lengths and every parameter gradient against the reference's own encoders."""
     from espnet_amd.espnet2 import ConformerEncoder, TransformerEncoder
     p, sd, grads = split_golden(load_golden("pw_%s.npz" % tag))
     cls = ConformerEncoder if kind == "conformer" else TransformerEncoder
