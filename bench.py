@@ -215,15 +215,18 @@ def main():
         flop_per_launch = STEP_FLOP * (B / 32.0) * (T / 1000.0) / n
         avg_ms = gemm_ms / n
         ach = flop_per_launch / (avg_ms * 1e-3) / 1e12
-        traffic = None
+        traffic, traffic_src = None, None
         try:   # HBM bytes per GEMM launch from the last committed PMC passes (profiles/, FETCH_SIZE x2 + WRITE_SIZE)
-            with open(os.path.join(ROOT, "profiles", "r01_h_pmc_traffic.json")) as fh:
+            import glob
+            traffic_src = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc_traffic.json")))[-1]
+            with open(traffic_src) as fh:
                 traffic = round(json.load(fh)["gemm_family"]["hbm_bytes_per_launch"])
+            traffic_src = os.path.basename(traffic_src)
         except Exception:  # noqa: BLE001
             traffic = None
         roof = dict(bound="mfma", achieved=round(ach, 2), peak=PEAK_TFLOPS[a.precision], unit="TFLOP/s",
                     frac=round(ach / PEAK_TFLOPS[a.precision], 4), traffic=traffic,
-                    traffic_note="HBM bytes per launch, rocprofv3 PMC (FETCH_SIZE doubled + WRITE_SIZE), profiles/r01_h_pmc*",
+                    traffic_note="HBM bytes per launch, rocprofv3 PMC (FETCH_SIZE doubled + WRITE_SIZE), profiles/%s" % traffic_src,
                     kernel="gemm_kernel<*> (all MFMA contractions)", launches_per_step=n,
                     avg_launch_us=round(avg_ms * 1e3, 2), gemm_ms_per_step=round(gemm_ms, 3),
                     timing="all eamd_gemm launches of one step replayed as one hipGraph between two stream events")
