@@ -128,3 +128,9 @@ class E2E(ASRInterface, torch.nn.Module):
         with torch.no_grad():
             hs, _, _ = self.enc(h, [x.shape[0]])
         return hs.squeeze(0)
+
+    def recognize(self, x, recog_args, char_list=None, rnnlm=None):
+        """x ndarray (T, D) -> n-best list of {"score", "yseq"} (e2e_asr.py:372-392)"""
+        hs = self.encode(x).unsqueeze(0)
+        lpz = self.ctc.log_softmax(hs)[0] if recog_args.ctc_weight > 0.0 else None
+        return self.dec.recognize_beam(hs[0], lpz, recog_args, char_list, rnnlm)

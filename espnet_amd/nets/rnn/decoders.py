@@ -133,6 +133,119 @@ class Decoder(torch.nn.Module):
         return self.loss, acc, ppl
 
 
+def _recognize_beam(self, h, lpz, recog_args, char_list=None, rnnlm=None, strm_idx=0):
+    """reference: rnn/decoders.py:313-605 (single encoder).  h (T, eprojs) encoder states, lpz (T, odim) CTC
+    log-posteriors or None -> n-best list of {"score", "yseq"} dicts.  Hypotheses are expanded one by one as in the
+    reference (attention state, decoder cells and the pre-beam are per hypothesis); the CTC prefix scores of a
+    hypothesis' pre-beam come from one eamd_ctc_prefix_score launch instead of the numpy CTCPrefixScore."""
+    from argparse import Namespace
+
+    from ..beam_search import end_detect
+    from ..ctc_prefix_score import CTCPrefixScorer
+    CTC_SCORING_RATIO = 1.5
+    dev = h.device
+    att = self.att[min(strm_idx, len(self.att) - 1)]
+    hx = h.unsqueeze(0)
+    c_list = [self.zero_state(hx) for _ in range(self.dlayers)]
+    z_list = [self.zero_state(hx) for _ in range(self.dlayers)]
+    att.reset()
+    beam, penalty = recog_args.beam_size, recog_args.penalty
+    ctc_weight = getattr(recog_args, "ctc_weight", False)
+    lm_weight = getattr(recog_args, "lm_weight", 0.0)
+    y = self.sos
+    maxlen = h.size(0)
+    if recog_args.maxlenratio != 0:
+        maxlen = max(1, int(recog_args.maxlenratio * maxlen))
+    minlen = int(recog_args.minlenratio * maxlen)
+    hyp = {"score": 0.0, "yseq": [y], "c_prev": c_list, "z_prev": z_list, "a_prev": None}
+    if rnnlm:
+        hyp["rnnlm_prev"] = None
+    scorer = None
+    if lpz is not None:
+        scorer = CTCPrefixScorer(None, self.eos)
+        scorer.logp = lpz.detach().contiguous()
+        r0 = torch.full((lpz.size(0), 2), self.logzero, device=dev)
+        r0[:, 1] = torch.cumsum(scorer.logp[:, 0], 0)
+        hyp["ctc_state_prev"] = r0
+        hyp["ctc_score_prev"] = 0.0
+        ctc_beam = min(lpz.shape[-1], int(beam * CTC_SCORING_RATIO)) if ctc_weight != 1.0 else lpz.shape[-1]
+    hyps, ended_hyps = [hyp], []
+    with torch.no_grad():
+        for i in range(maxlen):
+            hyps_best_kept = []
+            for hyp in hyps:
+                vy = torch.full((1,), hyp["yseq"][i], dtype=torch.long, device=dev)
+                ey = R_.PlainEmbedFn.apply(vy, self.embed.weight, -1)
+                att_c, att_w = att(hx, [h.size(0)], hyp["z_prev"][0], hyp["a_prev"])
+                ey = torch.cat((ey, att_c), dim=1)
+                z_list, c_list = self.rnn_forward(ey, [None] * self.dlayers, [None] * self.dlayers, hyp["z_prev"],
+                                                  hyp["c_prev"])
+                top = torch.cat((z_list[-1], att_c), dim=-1) if self.context_residual else z_list[-1]
+                logits = F_.LinearFn.apply(top, self.output.weight, self.output.bias)
+                local_att_scores = ops.log_softmax_rows(logits.contiguous())
+                if rnnlm:
+                    rnnlm_state, local_lm_scores = rnnlm.predict(hyp["rnnlm_prev"], vy)
+                    local_scores = local_att_scores + lm_weight * local_lm_scores
+                else:
+                    local_scores = local_att_scores
+                if scorer is not None:
+                    _, local_best_ids = torch.topk(local_att_scores, ctc_beam, dim=1)
+                    ids = local_best_ids.to(torch.int32)
+                    last = torch.tensor([hyp["yseq"][-1]], dtype=torch.int32, device=dev)
+                    olen = torch.tensor([len(hyp["yseq"]) - 1], dtype=torch.int32, device=dev)
+                    psi, r_new = ops.ctc_prefix_score(scorer.logp, hyp["ctc_state_prev"].unsqueeze(0), ids, last, olen,
+                                                      0, self.eos)
+                    local_scores = (1.0 - ctc_weight) * local_att_scores[:, local_best_ids[0]] \
+                        + ctc_weight * (psi - hyp["ctc_score_prev"])
+                    if rnnlm:
+                        local_scores = local_scores + lm_weight * local_lm_scores[:, local_best_ids[0]]
+                    local_best_scores, joint_best_ids = torch.topk(local_scores, beam, dim=1)
+                    local_best_ids = local_best_ids[:, joint_best_ids[0]]
+                    joint = joint_best_ids[0].tolist()
+                    psi_host = psi[0].tolist()
+                else:
+                    local_best_scores, local_best_ids = torch.topk(local_scores, beam, dim=1)
+                best_scores, best_ids = local_best_scores[0].tolist(), local_best_ids[0].tolist()
+                for j in range(beam):
+                    new_hyp = {"z_prev": z_list[:], "c_prev": c_list[:], "a_prev": att_w,
+                               "score": hyp["score"] + best_scores[j], "yseq": hyp["yseq"] + [int(best_ids[j])]}
+                    if rnnlm:
+                        new_hyp["rnnlm_prev"] = rnnlm_state
+                    if scorer is not None:
+                        new_hyp["ctc_state_prev"] = r_new[0, joint[j]]
+                        new_hyp["ctc_score_prev"] = psi_host[joint[j]]
+                    hyps_best_kept.append(new_hyp)
+                hyps_best_kept = sorted(hyps_best_kept, key=lambda x: x["score"], reverse=True)[:beam]
+            hyps = hyps_best_kept
+            if i == maxlen - 1:      # force <eos> so that something ends (decoders.py:561-564)
+                for hyp in hyps:
+                    hyp["yseq"].append(self.eos)
+            remained_hyps = []
+            for hyp in hyps:
+                if hyp["yseq"][-1] == self.eos:
+                    if len(hyp["yseq"]) > minlen:       # shorter ones are dropped (decoders.py:569-580)
+                        hyp["score"] += (i + 1) * penalty
+                        if rnnlm:
+                            hyp["score"] += lm_weight * rnnlm.final(hyp["rnnlm_prev"])
+                        ended_hyps.append(hyp)
+                else:
+                    remained_hyps.append(hyp)
+            if end_detect(ended_hyps, i) and recog_args.maxlenratio == 0.0:
+                break
+            hyps = remained_hyps
+            if len(hyps) == 0:
+                break
+    nbest_hyps = sorted(ended_hyps, key=lambda x: x["score"], reverse=True)[: min(len(ended_hyps), recog_args.nbest)]
+    if len(nbest_hyps) == 0:     # decoders.py:607-619: retry with a smaller minimum length
+        recog_args = Namespace(**vars(recog_args))
+        recog_args.minlenratio = max(0.0, recog_args.minlenratio - 0.1)
+        return self.recognize_beam(h, lpz, recog_args, char_list, rnnlm)
+    return nbest_hyps
+
+
+Decoder.recognize_beam = _recognize_beam
+
+
 def decoder_for(args, odim, sos, eos, att, labeldist):
     """reference: rnn/decoders.py:1199-1218"""
     return Decoder(args.eprojs, odim, args.dtype, args.dlayers, args.dunits, sos, eos, att, args.verbose,

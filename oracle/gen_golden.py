@@ -474,6 +474,28 @@ def main():
         d.update(kw)
         return argparse.Namespace(**d)
 
+    def rnn_decode(model, x, seed):
+        """a20 decode: E2E.recognize -> Decoder.recognize_beam (rnn/decoders.py:313-605) with and without CTC / LM"""
+        from espnet.nets.pytorch_backend.lm.default import ClassifierWithState, RNNLM
+        torch.manual_seed(seed)
+        lm = ClassifierWithState(RNNLM(7, 1, 8, None, "lstm", 0.0)).eval()
+        res = dict(sd_np(lm, "rlm/"))
+        was = model.training
+        model.eval()
+        with torch.no_grad():
+            for tag, kw, use_lm in (("b3", dict(beam_size=3, ctc_weight=0.0, penalty=0.0), False),
+                                    ("b3ctc", dict(beam_size=3, ctc_weight=0.5, penalty=0.1), False),
+                                    ("b2lm", dict(beam_size=2, ctc_weight=0.3, penalty=0.0, lm_weight=0.4), True),
+                                    ("b3ctc1", dict(beam_size=3, ctc_weight=1.0, penalty=0.2, maxlenratio=0.5), False)):
+                ra = argparse.Namespace(**dict(dict(nbest=3, maxlenratio=0.0, minlenratio=0.0, lm_weight=0.0), **kw))
+                nb = model.recognize(x, ra, model.char_list if hasattr(model, "char_list") else rnn_args().char_list,
+                                     lm if use_lm else None)
+                res["rb_%s_scores" % tag] = np.asarray([float(h["score"]) for h in nb], dtype=np.float64)
+                res["rb_%s_lens" % tag] = np.asarray([len(h["yseq"]) for h in nb], dtype=np.int64)
+                res["rb_%s_yseq" % tag] = np.asarray(sum([[int(t) for t in h["yseq"]] for h in nb], []), dtype=np.int64)
+        model.train(was)
+        return res
+
     torch.manual_seed(31)
     m = RnnE2E(12, 7, rnn_args())
     m.train()
@@ -490,7 +512,7 @@ def main():
     loss.backward()
     save(out("e2e_rnn.npz"), xs=xs, ilens=ilens, ys=ys, hs_pad=hs.detach(), hlens=np.asarray(hlens, dtype=np.int64),
          loss=float(loss), loss_att=float(m.loss_att), loss_ctc=float(m.loss_ctc), acc=float(m.acc), **sd0,
-         **grads_np(m))
+         **grads_np(m), **rnn_decode(m, xs[0].numpy(), 131))
 
     # a20: the other attention types on the HIP path, on a small BLSTMP (subsampling 1_2) model each
     for atype in ("dot", "add", "multi_head_dot", "multi_head_add", "multi_head_loc", "multi_head_multi_res_loc"):
@@ -511,7 +533,7 @@ def main():
         loss.backward()
         save(out("e2e_rnn_%s.npz" % atype), xs=xs, ilens=ilens, ys=ys, hs_pad=hs.detach(),
              hlens=np.asarray(hlens, dtype=np.int64), loss=float(loss), loss_att=float(m.loss_att),
-             loss_ctc=float(m.loss_ctc), acc=float(m.acc), **sd0, **grads_np(m))
+             loss_ctc=float(m.loss_ctc), acc=float(m.acc), **sd0, **grads_np(m), **rnn_decode(m, xs[0].numpy(), 132))
 
     # a20: GRU cells (bidirectional GRU-P encoder, 2-layer GRU decoder)
     torch.manual_seed(33)
@@ -529,7 +551,8 @@ def main():
     loss = m(xs, ilens, ys)
     loss.backward()
     save(out("e2e_rnn_gru.npz"), xs=xs, ilens=ilens, ys=ys, hs_pad=hs.detach(), hlens=np.asarray(hlens, dtype=np.int64),
-         loss=float(loss), loss_att=float(m.loss_att), loss_ctc=float(m.loss_ctc), acc=float(m.acc), **sd0, **grads_np(m))
+         loss=float(loss), loss_att=float(m.loss_att), loss_ctc=float(m.loss_ctc), acc=float(m.acc), **sd0, **grads_np(m),
+         **rnn_decode(m, xs[0].numpy(), 133))
 
     # ---- a21: transducer.  The loss package (warprnnt_pytorch) is absent here: TransLoss is given the
     # oracle's float64 restatement of the published recursion (asr_oracle.rnnt_loss, mean over the batch),

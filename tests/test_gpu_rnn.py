@@ -329,3 +329,45 @@ def test_transducer_decoding_golden(name):
             o += n
         print("[parity] %s %s: %d hypotheses identical, best score %.5f (ref %.5f)" % (name, tag, len(nb), nb[0]["score"],
                                                                                          want_scores[0]))
+
+
+_SMALL = dict(etype="blstmp", elayers=2, subsample="1_2_1", eunits=8, eprojs=8, dlayers=1, dunits=10, adim=6, aheads=2,
+              aconv_chans=3, aconv_filts=4)
+
+
+@pytest.mark.parametrize("name,idim,kw", [
+    ("e2e_rnn.npz", 12, dict()),
+    ("e2e_rnn_dot.npz", 9, dict(_SMALL, atype="dot")), ("e2e_rnn_add.npz", 9, dict(_SMALL, atype="add")),
+    ("e2e_rnn_multi_head_dot.npz", 9, dict(_SMALL, atype="multi_head_dot")),
+    ("e2e_rnn_multi_head_add.npz", 9, dict(_SMALL, atype="multi_head_add")),
+    ("e2e_rnn_multi_head_loc.npz", 9, dict(_SMALL, atype="multi_head_loc")),
+    ("e2e_rnn_multi_head_multi_res_loc.npz", 9, dict(_SMALL, atype="multi_head_multi_res_loc")),
+    ("e2e_rnn_gru.npz", 9, dict(etype="bgrup", elayers=2, subsample="1_2_1", eunits=8, eprojs=8, dtype="gru", dlayers=2,
+                                dunits=10, atype="location", adim=6, aconv_chans=3, aconv_filts=4))])
+def test_rnn_decoding_golden(name, idim, kw):
+    """a20 decode: E2E.recognize -> Decoder.recognize_beam (rnn/decoders.py:313-605) - attention-only, joint CTC
+    (prefix scores from the HIP kernel), LM fusion and CTC-only with a length cap - reproduces the reference's n-best:
+    token sequences exactly, scores to 1e-4."""
+    from espnet_amd.nets.e2e_asr import E2E
+    from espnet_amd.nets.lm import ClassifierWithState, RNNLM
+    p, sd, _ = split_golden(load_golden(name))
+    m = load_sd(E2E(idim, 7, _rnn_args(**kw)), sd).eval()
+    lm = ClassifierWithState(RNNLM(7, 1, 8, None, "lstm", 0.0))
+    lm.load_state_dict({k[4:]: v for k, v in p.items() if k.startswith("rlm/")})
+    lm.to(DEV).eval()
+    x = p["xs"][0].numpy()
+    for tag, rkw, use_lm in (("b3", dict(beam_size=3, ctc_weight=0.0, penalty=0.0), False),
+                             ("b3ctc", dict(beam_size=3, ctc_weight=0.5, penalty=0.1), False),
+                             ("b2lm", dict(beam_size=2, ctc_weight=0.3, penalty=0.0, lm_weight=0.4), True),
+                             ("b3ctc1", dict(beam_size=3, ctc_weight=1.0, penalty=0.2, maxlenratio=0.5), False)):
+        ra = argparse.Namespace(**dict(dict(nbest=3, maxlenratio=0.0, minlenratio=0.0, lm_weight=0.0), **rkw))
+        nb = m.recognize(x, ra, _rnn_args().char_list, lm if use_lm else None)
+        lens, flat, scores = p["rb_%s_lens" % tag].tolist(), p["rb_%s_yseq" % tag].tolist(), p["rb_%s_scores" % tag].tolist()
+        assert len(nb) == len(lens), (tag, len(nb), len(lens))
+        o = 0
+        for h, n, sc in zip(nb, lens, scores):
+            assert h["yseq"] == flat[o:o + n], (tag, h["yseq"], flat[o:o + n])
+            assert abs(float(h["score"]) - sc) <= 1e-4 * max(1.0, abs(sc)), (tag, float(h["score"]), sc)
+            o += n
+        print("[parity] %s %s: %d hypotheses identical, best %.5f (ref %.5f)" % (name, tag, len(nb), float(nb[0]["score"]),
+                                                                               scores[0]))
