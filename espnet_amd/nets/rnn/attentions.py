@@ -1,6 +1,6 @@
 """Decoder-side attention of the RNN path.  reference: espnet/nets/pytorch_backend/rnn/attentions.py.
-AttLoc (location-aware attention, :250-380) runs on the espnet_amd HIP kernels; the other attention
-types listed by `initial_att` (:1722-1771) have no kernel yet and raise NotImplementedError."""
+Ten of the twelve attention types listed by `initial_att` (:1722-1771) run on the espnet_amd HIP kernels; location2d
+and location_recurrent have no kernel yet and raise NotImplementedError."""
 import math
 
 import numpy as np
@@ -252,8 +252,130 @@ class AttMultiHeadMultiResLoc(AttMultiHeadLoc):
         return self._forward(enc_hs_pad, enc_hs_len, dec_z, att_prev, self.scaling, True)
 
 
+class NoAtt(torch.nn.Module):
+    """reference: rnn/attentions.py:46-91: the context is the mean of the valid encoder frames, computed once.
+    Runs the dot-attention kernels on zero keys (softmax of zeros over the valid frames = the uniform weights)."""
+
+    def __init__(self):
+        super().__init__()
+        self.reset()
+
+    def reset(self):
+        self.h_length = None
+        self.enc_h = None
+        self.pre_compute_enc_h = None
+        self.c = None
+
+    def forward(self, enc_hs_pad, enc_hs_len, dec_z, att_prev):
+        batch = enc_hs_pad.shape[0]
+        if self.pre_compute_enc_h is None:
+            self.enc_h = enc_hs_pad.contiguous()
+            self.h_length = self.enc_h.size(1)
+        if att_prev is None:
+            dev = enc_hs_pad.device
+            lens = ops.h2d_cached("attlens", np.asarray([int(v) for v in enc_hs_len], dtype=np.int32), dev)
+            zk = torch.zeros(batch, self.h_length, 1, device=dev)
+            self.c, att_prev = R_.AttDotStepFn.apply(zk, torch.zeros(batch, 1, device=dev), self.enc_h, lens, 1.0)
+            att_prev = att_prev.detach()
+        return self.c, att_prev
+
+
+class _Coverage(list):
+    """att_prev_list of the coverage attentions with its running sum kept alongside (the reference re-adds the whole
+    list at every step, attentions.py:433)"""
+
+    total = None
+
+
+class AttCov(torch.nn.Module):
+    """coverage attention.  reference: rnn/attentions.py:383-482: e = gvec . tanh(wvec(sum of previous weights) +
+    mlp_enc(h) + mlp_dec(z)).  Maps onto the location-aware kernels: a 1-channel, 1-tap unit "convolution" of the
+    coverage vector, wvec.weight as the channel projection and wvec.bias folded into the decoder projection."""
+
+    def __init__(self, eprojs, dunits, att_dim, han_mode=False):
+        super().__init__()
+        self.mlp_enc = torch.nn.Linear(eprojs, att_dim)
+        self.mlp_dec = torch.nn.Linear(dunits, att_dim, bias=False)
+        self.wvec = torch.nn.Linear(1, att_dim)
+        self.gvec = torch.nn.Linear(att_dim, 1)
+        self.dunits, self.eprojs, self.att_dim, self.han_mode = dunits, eprojs, att_dim, han_mode
+        self.reset()
+
+    def reset(self):
+        self.h_length = None
+        self.enc_h = None
+        self.pre_compute_enc_h = None
+        self.mask = None
+        self._lens = None
+
+    def _prepare(self, enc_hs_pad, enc_hs_len, dec_z, att_prev_list):
+        batch = enc_hs_pad.shape[0]
+        dev = enc_hs_pad.device
+        if self.pre_compute_enc_h is None or self.han_mode:
+            self.enc_h = enc_hs_pad.contiguous()
+            self.h_length = self.enc_h.size(1)
+            self.pre_compute_enc_h = F_.LinearFn.apply(self.enc_h, self.mlp_enc.weight, self.mlp_enc.bias)
+            self._lens_host = np.asarray([int(v) for v in enc_hs_len], dtype=np.int32)
+            self._lens = ops.h2d_cached("attlens", self._lens_host, dev)
+        dec_z = enc_hs_pad.new_zeros(batch, self.dunits) if dec_z is None else dec_z.view(batch, self.dunits)
+        if att_prev_list is None:
+            keep = (np.arange(self.h_length)[None, :] < self._lens_host[:, None]).astype(np.float32)
+            att_prev_list = _Coverage([ops.h2d_cached("attuniform", keep / self._lens_host[:, None].astype(np.float32), dev)])
+            att_prev_list.total = att_prev_list[0]
+        elif getattr(att_prev_list, "total", None) is None:      # a plain list handed in by an external caller
+            tot = att_prev_list[0]
+            for w in att_prev_list[1:]:
+                tot = R_.AddFn.apply(tot, w)
+            att_prev_list = _Coverage(att_prev_list)
+            att_prev_list.total = tot
+        return dec_z, att_prev_list
+
+    @staticmethod
+    def _extend(att_prev_list, w):
+        out = _Coverage(list(att_prev_list) + [w])      # a new list: beam search keeps the old one for sibling hypotheses
+        out.total = R_.AddFn.apply(att_prev_list.total, w)
+        return out
+
+    def forward(self, enc_hs_pad, enc_hs_len, dec_z, att_prev_list, scaling=2.0):
+        dec_z, att_prev_list = self._prepare(enc_hs_pad, enc_hs_len, dec_z, att_prev_list)
+        dec_proj = F_.LinearFn.apply(dec_z, self.mlp_dec.weight, self.wvec.bias)
+        one = ops.h2d_cached("attone", np.ones((1, 1, 1, 1), dtype=np.float32), enc_hs_pad.device)
+        c, w = R_.AttLocStepFn.apply(self.enc_h, self.pre_compute_enc_h, dec_proj, att_prev_list.total, self._lens,
+                                     float(scaling), one, self.wvec.weight, self.gvec.weight, self.gvec.bias)
+        return c, self._extend(att_prev_list, w)
+
+
+class AttCovLoc(AttCov):
+    """coverage + location attention.  reference: rnn/attentions.py:729-842 (the location convolution is applied to
+    the coverage vector instead of the previous weights)"""
+
+    def __init__(self, eprojs, dunits, att_dim, aconv_chans, aconv_filts, han_mode=False):
+        torch.nn.Module.__init__(self)
+        self.mlp_enc = torch.nn.Linear(eprojs, att_dim)
+        self.mlp_dec = torch.nn.Linear(dunits, att_dim, bias=False)
+        self.mlp_att = torch.nn.Linear(aconv_chans, att_dim, bias=False)
+        self.loc_conv = torch.nn.Conv2d(1, aconv_chans, (1, 2 * aconv_filts + 1), padding=(0, aconv_filts), bias=False)
+        self.gvec = torch.nn.Linear(att_dim, 1)
+        self.dunits, self.eprojs, self.att_dim, self.aconv_chans, self.han_mode = dunits, eprojs, att_dim, aconv_chans, han_mode
+        self.reset()
+
+    def forward(self, enc_hs_pad, enc_hs_len, dec_z, att_prev_list, scaling=2.0):
+        dec_z, att_prev_list = self._prepare(enc_hs_pad, enc_hs_len, dec_z, att_prev_list)
+        dec_proj = F_.LinearFn.apply(dec_z, self.mlp_dec.weight, None)
+        c, w = R_.AttLocStepFn.apply(self.enc_h, self.pre_compute_enc_h, dec_proj, att_prev_list.total, self._lens,
+                                     float(scaling), self.loc_conv.weight, self.mlp_att.weight, self.gvec.weight,
+                                     self.gvec.bias)
+        return c, self._extend(att_prev_list, w)
+
+
 def initial_att(atype, eprojs, dunits, aheads, adim, awin, aconv_chans, aconv_filts, han_mode=False):
     """reference: rnn/attentions.py:1722-1771"""
+    if atype == "noatt":
+        return NoAtt()
+    if atype == "coverage":
+        return AttCov(eprojs, dunits, adim, han_mode)
+    if atype == "coverage_location":
+        return AttCovLoc(eprojs, dunits, adim, aconv_chans, aconv_filts, han_mode)
     if atype == "location":
         return AttLoc(eprojs, dunits, adim, aconv_chans, aconv_filts, han_mode)
     if atype == "dot":
@@ -268,8 +390,9 @@ def initial_att(atype, eprojs, dunits, aheads, adim, awin, aconv_chans, aconv_fi
         return AttMultiHeadLoc(eprojs, dunits, aheads, adim, adim, aconv_chans, aconv_filts, han_mode)
     if atype == "multi_head_multi_res_loc":
         return AttMultiHeadMultiResLoc(eprojs, dunits, aheads, adim, adim, aconv_chans, aconv_filts, han_mode)
-    raise NotImplementedError("atype %r has no HIP kernels yet (on the HIP path: location, dot, add, multi_head_dot, "
-                              "multi_head_add, multi_head_loc, multi_head_multi_res_loc)" % atype)
+    raise NotImplementedError("atype %r has no HIP kernels yet (on the HIP path: noatt, location, dot, add, coverage, "
+                              "coverage_location, multi_head_dot, multi_head_add, multi_head_loc, "
+                              "multi_head_multi_res_loc)" % atype)
 
 
 def att_for(args, num_att=1, han_mode=False):

@@ -396,6 +396,18 @@ class AttDotStepFn(torch.autograd.Function):
         return dk, dq, d_v, None, None
 
 
+class AddFn(torch.autograd.Function):
+    """a + b (running coverage vector of AttCov / AttCovLoc, attentions.py:433,795)"""
+
+    @staticmethod
+    def forward(ctx, a, b):
+        return ops.axpby(a.contiguous(), b.contiguous(), 1.0, 1.0)
+
+    @staticmethod
+    def backward(ctx, g):
+        return g, g
+
+
 # =================================================================================================
 # Transducer joint network pointwise part and loss
 # =================================================================================================

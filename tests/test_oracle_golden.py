@@ -252,7 +252,8 @@ def test_e2e_rnn(oracle):
     _grad_check(sd, grads)
 
 
-@pytest.mark.parametrize("atype", ["dot", "add", "multi_head_dot", "multi_head_add", "multi_head_loc", "multi_head_multi_res_loc"])
+@pytest.mark.parametrize("atype", ["dot", "add", "multi_head_dot", "multi_head_add", "multi_head_loc", "multi_head_multi_res_loc",
+                                   "noatt", "coverage", "coverage_location"])
 def test_e2e_rnn_attention_types(oracle, atype):
     """BLSTMP (subsample 1_2) + the other attention types on the HIP path against the reference E2E"""
     p, sd, grads = split_golden(load_golden("e2e_rnn_%s.npz" % atype))
