@@ -78,7 +78,7 @@ def test_unsupported_variants_fail_loudly():
     from espnet_amd.nets.rnn.attentions import initial_att
     from espnet_amd.nets.rnn.encoders import Encoder
     with pytest.raises(NotImplementedError):
-        initial_att("coverage", 8, 8, 2, 4, 3, 2, 1)
+        initial_att("location2d", 8, 8, 2, 4, 3, 2, 1)
     with pytest.raises(ValueError):
         Encoder("brnnp", 10, 1, 4, 4, np.ones(2, dtype=np.int64), 0.0)
     from espnet_amd.nets.rnn.decoders import Decoder
