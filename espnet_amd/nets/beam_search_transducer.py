@@ -1,9 +1,10 @@
-"""Transducer decoding: greedy search and the default beam search.
-reference: espnet/nets/beam_search_transducer.py:23-237 (Hypothesis, BeamSearchTransducer.__init__/__call__/
-sort_nbest/greedy_search/default_beam_search).  The control flow (hypothesis lists, expansion order, the prediction
+"""Transducer decoding: greedy search, the default beam search, time-synchronous (tsd) and alignment-length
+synchronous (alsd) decoding, with optional RNNLM shallow fusion.
+reference: espnet/nets/beam_search_transducer.py:23-462 (Hypothesis, BeamSearchTransducer.__init__/__call__/
+sort_nbest/greedy_search/default_beam_search/time_sync_decoding/align_length_sync_decoding).  The control flow (hypothesis lists, expansion order, the prediction
 network cache keyed by the label prefix) is host Python exactly as in the reference; every arithmetic step
-(embedding, LSTM / GRU step, joint network, log-softmax) runs on the espnet_amd kernels.  The tsd / alsd / nsc
-variants and LM fusion are not on the HIP path yet and raise."""
+(embedding, LSTM / GRU step, joint network, log-softmax) runs on the espnet_amd kernels - batched over the beam in the
+tsd / alsd searches.  The nsc variant is not on the HIP path yet and raises."""
 from dataclasses import dataclass
 from typing import Any, Dict, List, Union
 
@@ -40,8 +41,12 @@ class BeamSearchTransducer:
             self.search_algorithm = self.greedy_search
         elif search_type == "default":
             self.search_algorithm = self.default_beam_search
+        elif search_type == "tsd":
+            self.search_algorithm = self.time_sync_decoding
+        elif search_type == "alsd":
+            self.search_algorithm = self.align_length_sync_decoding
         else:
-            raise NotImplementedError("search_type %r: greedy and 'default' are on the HIP path" % search_type)
+            raise NotImplementedError("search_type %r: greedy, 'default', 'tsd' and 'alsd' are on the HIP path" % search_type)
         # lm: a ClassifierWithState (espnet_amd.nets.lm, as espnet/asr/pytorch_backend/asr.py passes it) whose
         # predict(state, tokens) -> (state, log-probs (1, V)); fused with lm_weight in the default search
         self.lm, self.lm_weight = lm, lm_weight
@@ -118,3 +123,140 @@ class BeamSearchTransducer:
                     kept_hyps = kept_most_prob
                     break
         return self.sort_nbest(kept_hyps)
+
+    # ---- LM state plumbing of the batched searches (transducer/utils.py:96-178; RNNLM states {c, h} per layer) --------
+    def _lm_init(self):
+        lm_model = self.lm.predictor
+        p = next(lm_model.parameters())
+        state = {"h": [torch.zeros(lm_model.n_units, device=p.device, dtype=p.dtype) for _ in range(len(lm_model.rnn))]}
+        if lm_model.typ == "lstm":
+            state["c"] = [torch.zeros(lm_model.n_units, device=p.device, dtype=p.dtype) for _ in range(len(lm_model.rnn))]
+        return state
+
+    @staticmethod
+    def _lm_batch(states):
+        return {k: [torch.stack([s[k][layer] for s in states]) for layer in range(len(states[0][k]))] for k in states[0]}
+
+    @staticmethod
+    def _lm_select(states, idx):
+        return {k: [v[layer][idx] for layer in range(len(v))] for k, v in states.items()}
+
+    def _joint_logp(self, h_enc, beam_y):
+        """h_enc (n, D_enc) or (1, D_enc), beam_y (n, D_dec) -> log-softmax of the joint outputs (n, V): the n
+        (frame, hypothesis) pairs as one batch through lin_enc / lin_dec / the joint kernel / lin_out"""
+        from .. import functional as F_
+        from .. import rnn_functional as R_
+        jn = self.decoder.joint_network
+        n = beam_y.shape[0]
+        enc = jn.project_enc(h_enc)
+        if enc.shape[0] != n:
+            enc = enc.expand(n, -1).contiguous()
+        d = F_.LinearFn.apply(beam_y.contiguous(), jn.lin_dec.weight, None)
+        z = R_.JointFn.apply(enc.view(n, 1, -1).contiguous(), d.view(n, 1, -1), jn.act_id)
+        logits = F_.LinearFn.apply(z.reshape(n, -1), jn.lin_out.weight, jn.lin_out.bias)
+        return ops.log_softmax_rows(logits.contiguous())
+
+    def time_sync_decoding(self, h):
+        """reference: beam_search_transducer.py:238-350 (https://ieeexplore.ieee.org/document/9053040)"""
+        import numpy as np
+        beam = min(self.beam_size, self.vocab_size)
+        init_tensor = h.unsqueeze(0)
+        beam_state = self.decoder.init_state(torch.zeros((beam, self.hidden_size), device=h.device))
+        B = [Hypothesis(yseq=[self.blank], score=0.0, dec_state=self.decoder.select_state(beam_state, 0))]
+        if self.lm:
+            B[0].lm_state = self._lm_init()
+        cache = {}
+        for t in range(h.shape[0]):
+            A = []
+            C = B
+            h_enc = h[t].unsqueeze(0)
+            for v in range(self.max_sym_exp):
+                D = []
+                beam_y, beam_state, beam_lm_tokens = self.decoder.batch_score(C, beam_state, cache, init_tensor)
+                beam_logp = self._joint_logp(h_enc, beam_y)
+                top_v, top_i = beam_logp[:, 1:].topk(beam, dim=-1)
+                blank_lp, top_v, top_i = beam_logp[:, 0].tolist(), top_v.tolist(), (top_i + 1).tolist()
+                seq_A = [hy.yseq for hy in A]
+                for i, hyp in enumerate(C):
+                    if hyp.yseq not in seq_A:
+                        A.append(Hypothesis(score=(hyp.score + blank_lp[i]), yseq=hyp.yseq[:], dec_state=hyp.dec_state,
+                                            lm_state=hyp.lm_state))
+                    else:
+                        pos = seq_A.index(hyp.yseq)
+                        A[pos].score = np.logaddexp(A[pos].score, (hyp.score + blank_lp[i]))
+                if v < self.max_sym_exp:
+                    if self.lm:
+                        beam_lm_states, beam_lm_scores = self.lm.buff_predict(
+                            self._lm_batch([c.lm_state for c in C]), beam_lm_tokens, len(C))
+                        lm_host = beam_lm_scores.tolist()
+                    for i, hyp in enumerate(C):
+                        for logp, k in zip(top_v[i], top_i[i]):
+                            new_hyp = Hypothesis(score=(hyp.score + float(logp)), yseq=(hyp.yseq + [int(k)]),
+                                                 dec_state=self.decoder.select_state(beam_state, i), lm_state=hyp.lm_state)
+                            if self.lm:
+                                new_hyp.score += self.lm_weight * lm_host[i][k]
+                                new_hyp.lm_state = self._lm_select(beam_lm_states, i)
+                            D.append(new_hyp)
+                C = sorted(D, key=lambda x: x.score, reverse=True)[:beam]
+            B = sorted(A, key=lambda x: x.score, reverse=True)[:beam]
+        return self.sort_nbest(B)
+
+    def align_length_sync_decoding(self, h):
+        """reference: beam_search_transducer.py:352-462 (https://ieeexplore.ieee.org/document/9053040)"""
+        import numpy as np
+        beam = min(self.beam_size, self.vocab_size)
+        h_length = int(h.size(0))
+        u_max = min(self.u_max, (h_length - 1))
+        init_tensor = h.unsqueeze(0)
+        beam_state = self.decoder.init_state(torch.zeros((beam, self.hidden_size), device=h.device))
+        B = [Hypothesis(yseq=[self.blank], score=0.0, dec_state=self.decoder.select_state(beam_state, 0))]
+        final = []
+        if self.lm:
+            B[0].lm_state = self._lm_init()
+        cache = {}
+        for i in range(h_length + u_max):
+            A, B_, h_states = [], [], []
+            for hyp in B:
+                u = len(hyp.yseq) - 1
+                t = i - u + 1
+                if t > (h_length - 1):
+                    continue
+                B_.append(hyp)
+                h_states.append((t, h[t]))
+            if B_:
+                beam_y, beam_state, beam_lm_tokens = self.decoder.batch_score(B_, beam_state, cache, init_tensor)
+                h_enc = torch.stack([hs[1] for hs in h_states])
+                beam_logp = self._joint_logp(h_enc, beam_y)
+                top_v, top_i = beam_logp[:, 1:].topk(beam, dim=-1)
+                blank_lp, top_v, top_i = beam_logp[:, 0].tolist(), top_v.tolist(), (top_i + 1).tolist()
+                if self.lm:
+                    beam_lm_states, beam_lm_scores = self.lm.buff_predict(
+                        self._lm_batch([b.lm_state for b in B_]), beam_lm_tokens, len(B_))
+                    lm_host = beam_lm_scores.tolist()
+                for j, hyp in enumerate(B_):
+                    new_hyp = Hypothesis(score=(hyp.score + blank_lp[j]), yseq=hyp.yseq[:], dec_state=hyp.dec_state,
+                                         lm_state=hyp.lm_state)
+                    A.append(new_hyp)
+                    if h_states[j][0] == (h_length - 1):
+                        final.append(new_hyp)
+                    for logp, k in zip(top_v[j], top_i[j]):
+                        new_hyp = Hypothesis(score=(hyp.score + float(logp)), yseq=(hyp.yseq[:] + [int(k)]),
+                                             dec_state=self.decoder.select_state(beam_state, j), lm_state=hyp.lm_state)
+                        if self.lm:
+                            new_hyp.score += self.lm_weight * lm_host[j][k]
+                            new_hyp.lm_state = self._lm_select(beam_lm_states, j)
+                        A.append(new_hyp)
+                B = sorted(A, key=lambda x: x.score, reverse=True)[:beam]
+                # recombine_hyps (transducer/utils.py:181-203): scores of equal sequences are merged into the first one,
+                # the list itself is returned unchanged
+                firsts = []
+                for hyp in B:
+                    seqs = [f.yseq for f in firsts if f.yseq]
+                    if hyp.yseq in seqs:
+                        f = firsts[seqs.index(hyp.yseq)]
+                        f.score = np.logaddexp(f.score, hyp.score)
+                    else:
+                        firsts.append(hyp)
+        if final:
+            return self.sort_nbest(final)
+        return B

@@ -79,6 +79,10 @@ class ClassifierWithState(torch.nn.Module):
         state, z = self.predictor(state, x)
         return state, ops.log_softmax_rows(z.contiguous())
 
+    def buff_predict(self, state, x, n):
+        """reference: default.py:245-259 (an RNNLM predictor scores the whole batch at once)"""
+        return self.predict(state, x)
+
     def final(self, state, index=None):
         return 0.0
 

@@ -66,6 +66,39 @@ class DecoderRNNT(torch.nn.Module):
             cache[str_yseq] = (y, state)
         return y, state, vy[0]
 
+    def batch_score(self, hyps, batch_states, cache, init_tensor=None):
+        """one prediction-network step for all hypotheses that are not cached yet, as ONE batch through the cell
+        kernels (rnn_decoder.py:197-257) -> (batch_y (n, dunits), batch_states, last tokens (n,))"""
+        dev = self.embed.weight.device
+        final_batch = len(hyps)
+        tokens, process = [], []
+        done = [None] * final_batch
+        for i, hyp in enumerate(hyps):
+            str_yseq = "".join([str(x) for x in hyp.yseq])
+            if str_yseq in cache:
+                done[i] = cache[str_yseq]
+            else:
+                tokens.append(hyp.yseq[-1])
+                process.append((str_yseq, hyp.dec_state))
+        if process:
+            batch = len(process)
+            tok = torch.tensor(tokens, dtype=torch.long).to(dev).view(batch)
+            dec_state = self.init_state(torch.zeros((batch, self.dunits), device=dev))
+            dec_state = self.create_batch_states(dec_state, [p[1] for p in process])
+            ey = R_.PlainEmbedFn.apply(tok, self.embed.weight, self.blank)
+            y, dec_state = self.rnn_forward(ey, dec_state)
+        j = 0
+        for i in range(final_batch):
+            if done[i] is None:
+                new_state = self.select_state(dec_state, j)
+                done[i] = (y[j], new_state)
+                cache[process[j][0]] = (y[j], new_state)
+                j += 1
+        batch_states = self.create_batch_states(batch_states, [d[1] for d in done])
+        batch_y = torch.stack([d[0] for d in done])
+        lm_tokens = torch.tensor([h.yseq[-1] for h in hyps], dtype=torch.long).to(dev).view(final_batch)
+        return batch_y, batch_states, lm_tokens
+
     def select_state(self, batch_states, idx):
         """rnn_decoder.py:251-266"""
         return ([batch_states[0][layer][idx] for layer in range(self.dlayers)],

@@ -603,7 +603,11 @@ def main():
         with torch.no_grad():
             xin = xs[0, : int(ilens[0])].numpy()
             for tag, kw2 in (("greedy", dict(beam_size=1)), ("beam3", dict(beam_size=3, search_type="default")),
-                             ("beam3_nonorm", dict(beam_size=3, search_type="default", score_norm=False))):
+                             ("beam3_nonorm", dict(beam_size=3, search_type="default", score_norm=False)),
+                             ("tsd3", dict(beam_size=3, search_type="tsd", max_sym_exp=2)),
+                             ("tsd2", dict(beam_size=2, search_type="tsd", max_sym_exp=3, score_norm=False)),
+                             ("alsd3", dict(beam_size=3, search_type="alsd", u_max=10)),
+                             ("alsd2", dict(beam_size=2, search_type="alsd", u_max=4, score_norm=False))):
                 bs = BeamSearchTransducer(decoder=m.dec, lm=None, lm_weight=0.0, **kw2)
                 nb = m.recognize(xin, bs)
                 nb = nb if isinstance(nb, list) else [nb]
@@ -614,11 +618,12 @@ def main():
             from espnet.nets.pytorch_backend.lm.default import ClassifierWithState, RNNLM
             torch.manual_seed(seed + 7)
             lm = ClassifierWithState(RNNLM(6, 1, 8, None, "lstm", 0.0)).eval()
-            bs = BeamSearchTransducer(decoder=m.dec, lm=lm, lm_weight=0.5, beam_size=3, search_type="default")
-            nb = m.recognize(xin, bs)
-            dec["dec_beam3_lm_scores"] = np.asarray([float(h["score"]) for h in nb], dtype=np.float64)
-            dec["dec_beam3_lm_lens"] = np.asarray([len(h["yseq"]) for h in nb], dtype=np.int64)
-            dec["dec_beam3_lm_yseq"] = np.asarray(sum([[int(t) for t in h["yseq"]] for h in nb], []), dtype=np.int64)
+            for tag, st in (("beam3_lm", "default"), ("tsd3_lm", "tsd"), ("alsd3_lm", "alsd")):
+                bs = BeamSearchTransducer(decoder=m.dec, lm=lm, lm_weight=0.5, beam_size=3, search_type=st)
+                nb = m.recognize(xin, bs)
+                dec["dec_%s_scores" % tag] = np.asarray([float(h["score"]) for h in nb], dtype=np.float64)
+                dec["dec_%s_lens" % tag] = np.asarray([len(h["yseq"]) for h in nb], dtype=np.int64)
+                dec["dec_%s_yseq" % tag] = np.asarray(sum([[int(t) for t in h["yseq"]] for h in nb], []), dtype=np.int64)
             dec.update(sd_np(lm, "lm/"))
         save(out(name), xs=xs, ilens=ilens, ys=ys, hs_pad=hs_train, pred_pad=pred_train,
              loss=float(loss), **dec, **sd0, **grads_np(m))

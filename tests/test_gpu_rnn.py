@@ -289,7 +289,8 @@ def test_transducer_golden(name):
 
 @pytest.mark.parametrize("name", ["transducer_rnn.npz", "transducer_gru.npz", "transducer_conformer.npz"])
 def test_transducer_decoding_golden(name):
-    """greedy and default beam search (beam_search_transducer.py:130-237) reproduce the reference's hypotheses:
+    """greedy, default, time-synchronous and alignment-length synchronous searches, with and without RNNLM fusion
+    (beam_search_transducer.py:130-462) reproduce the reference's hypotheses:
     token sequences exactly, scores to 1e-4, in the reference's n-best order"""
     from espnet_amd.nets.beam_search_transducer import BeamSearchTransducer
     from espnet_amd.nets.e2e_asr_transducer import E2E
@@ -316,7 +317,13 @@ def test_transducer_decoding_golden(name):
     lm.to(DEV).eval()
     for tag, kw in (("greedy", dict(beam_size=1)), ("beam3", dict(beam_size=3, search_type="default")),
                     ("beam3_nonorm", dict(beam_size=3, search_type="default", score_norm=False)),
-                    ("beam3_lm", dict(beam_size=3, search_type="default", lm=lm, lm_weight=0.5))):
+                    ("beam3_lm", dict(beam_size=3, search_type="default", lm=lm, lm_weight=0.5)),
+                    ("tsd3", dict(beam_size=3, search_type="tsd", max_sym_exp=2)),
+                    ("tsd2", dict(beam_size=2, search_type="tsd", max_sym_exp=3, score_norm=False)),
+                    ("alsd3", dict(beam_size=3, search_type="alsd", u_max=10)),
+                    ("alsd2", dict(beam_size=2, search_type="alsd", u_max=4, score_norm=False)),
+                    ("tsd3_lm", dict(beam_size=3, search_type="tsd", lm=lm, lm_weight=0.5)),
+                    ("alsd3_lm", dict(beam_size=3, search_type="alsd", lm=lm, lm_weight=0.5))):
         nb = m.recognize(x, BeamSearchTransducer(decoder=m.dec, **kw))
         nb = nb if isinstance(nb, list) else [nb]
         lens = p["dec_%s_lens" % tag].tolist()
