@@ -1,10 +1,10 @@
 """Transducer decoding: greedy search, the default beam search, time-synchronous (tsd) and alignment-length
-synchronous (alsd) decoding, with optional RNNLM shallow fusion.
+synchronous (alsd) decoding and the N-step constrained search (nsc), with optional RNNLM shallow fusion.
 reference: espnet/nets/beam_search_transducer.py:23-462 (Hypothesis, BeamSearchTransducer.__init__/__call__/
-sort_nbest/greedy_search/default_beam_search/time_sync_decoding/align_length_sync_decoding).  The control flow (hypothesis lists, expansion order, the prediction
+sort_nbest/greedy_search/default_beam_search/time_sync_decoding/align_length_sync_decoding/nsc_beam_search, :23-662).  The control flow (hypothesis lists, expansion order, the prediction
 network cache keyed by the label prefix) is host Python exactly as in the reference; every arithmetic step
 (embedding, LSTM / GRU step, joint network, log-softmax) runs on the espnet_amd kernels - batched over the beam in the
-tsd / alsd searches.  The nsc variant is not on the HIP path yet and raises."""
+tsd / alsd / nsc searches."""
 from dataclasses import dataclass
 from typing import Any, Dict, List, Union
 
@@ -45,8 +45,10 @@ class BeamSearchTransducer:
             self.search_algorithm = self.time_sync_decoding
         elif search_type == "alsd":
             self.search_algorithm = self.align_length_sync_decoding
+        elif search_type == "nsc":
+            self.search_algorithm = self.nsc_beam_search
         else:
-            raise NotImplementedError("search_type %r: greedy, 'default', 'tsd' and 'alsd' are on the HIP path" % search_type)
+            raise NotImplementedError("search_type %r: greedy, default, tsd, alsd, nsc" % search_type)
         # lm: a ClassifierWithState (espnet_amd.nets.lm, as espnet/asr/pytorch_backend/asr.py passes it) whose
         # predict(state, tokens) -> (state, log-probs (1, V)); fused with lm_weight in the default search
         self.lm, self.lm_weight = lm, lm_weight
@@ -260,3 +262,90 @@ class BeamSearchTransducer:
         if final:
             return self.sort_nbest(final)
         return B
+
+    def nsc_beam_search(self, h):
+        """N-step constrained beam search.  reference: beam_search_transducer.py:464-662
+        (https://arxiv.org/pdf/2002.03577.pdf as modified there)"""
+        import numpy as np
+        beam = min(self.beam_size, self.vocab_size)
+        beam_k = min(beam, (self.vocab_size - 1))
+        jn = self.decoder.joint_network
+        init_tensor = h.unsqueeze(0)
+        beam_state = self.decoder.init_state(torch.zeros((beam, self.hidden_size), device=h.device))
+        init_tokens = [Hypothesis(yseq=[self.blank], score=0.0, dec_state=self.decoder.select_state(beam_state, 0))]
+        cache = {}
+        beam_y, beam_state, beam_lm_tokens = self.decoder.batch_score(init_tokens, beam_state, cache, init_tensor)
+        state = self.decoder.select_state(beam_state, 0)
+        lm_state = lm_scores = None
+        if self.lm:
+            beam_lm_states, beam_lm_scores = self.lm.buff_predict(None, beam_lm_tokens, 1)
+            lm_state = self._lm_select(beam_lm_states, 0)
+            lm_scores = beam_lm_scores[0]
+        kept_hyps = [Hypothesis(yseq=[self.blank], score=0.0, dec_state=state, y=[beam_y[0]], lm_state=lm_state,
+                                lm_scores=lm_scores)]
+        enc_proj = jn.project_enc(h)
+
+        def is_prefix(x, pref):
+            return len(pref) < len(x) and all(pref[i] == x[i] for i in range(len(pref)))
+
+        for t in range(h.shape[0]):
+            hyps = sorted(kept_hyps, key=lambda x: len(x.yseq), reverse=True)
+            kept_hyps = []
+            h_enc = h[t].unsqueeze(0)
+            for j in range(len(hyps) - 1):       # prefix search: a longer hypothesis also collects its prefixes' mass
+                for i in range((j + 1), len(hyps)):
+                    if is_prefix(hyps[j].yseq, hyps[i].yseq) and \
+                            (len(hyps[j].yseq) - len(hyps[i].yseq)) <= self.prefix_alpha:
+                        next_id = len(hyps[i].yseq)
+                        ytu = _log_softmax(jn.joint_step(enc_proj[t], hyps[i].y[-1]))
+                        curr_score = hyps[i].score + float(ytu[hyps[j].yseq[next_id]])
+                        for k in range(next_id, (len(hyps[j].yseq) - 1)):
+                            ytu = _log_softmax(jn.joint_step(enc_proj[t], hyps[j].y[k]))
+                            curr_score += float(ytu[hyps[j].yseq[k + 1]])
+                        hyps[j].score = np.logaddexp(hyps[j].score, curr_score)
+            S, V = [], []
+            for n in range(self.nstep):
+                beam_y = torch.stack([hyp.y[-1] for hyp in hyps])
+                beam_logp = self._joint_logp(h_enc, beam_y)
+                top_v, top_i = beam_logp[:, 1:].topk(beam_k, dim=-1)
+                blank_lp, top_v, top_i = beam_logp[:, 0].tolist(), top_v.tolist(), (top_i + 1).tolist()
+                if self.lm:
+                    lm_host = torch.stack([hyp.lm_scores for hyp in hyps]).tolist()
+                for i, hyp in enumerate(hyps):
+                    for logp, k in list(zip(top_v[i], top_i[i])) + [(blank_lp[i], self.blank)]:
+                        new_hyp = Hypothesis(yseq=hyp.yseq[:], score=(hyp.score + float(logp)), y=hyp.y[:],
+                                             dec_state=hyp.dec_state, lm_state=hyp.lm_state, lm_scores=hyp.lm_scores)
+                        if k == self.blank:
+                            S.append(new_hyp)
+                        else:
+                            new_hyp.yseq.append(int(k))
+                            if self.lm:
+                                new_hyp.score += self.lm_weight * float(lm_host[i][k])
+                        V.append(new_hyp)       # blank extensions too: `substract` drops them again (same yseq as a parent)
+                V = sorted(V, key=lambda x: x.score, reverse=True)
+                V = [v for v in V if not any(v.yseq == hy.yseq for hy in hyps)][:beam]
+                beam_state = self.decoder.create_batch_states(beam_state, [v.dec_state for v in V], [v.yseq for v in V])
+                beam_y, beam_state, beam_lm_tokens = self.decoder.batch_score(V, beam_state, cache, init_tensor)
+                if self.lm:
+                    beam_lm_states, beam_lm_scores = self.lm.buff_predict(self._lm_batch([v.lm_state for v in V]),
+                                                                           beam_lm_tokens, len(V))
+                if n < (self.nstep - 1):
+                    for i, v in enumerate(V):
+                        v.y.append(beam_y[i])
+                        v.dec_state = self.decoder.select_state(beam_state, i)
+                        if self.lm:
+                            v.lm_state = self._lm_select(beam_lm_states, i)
+                            v.lm_scores = beam_lm_scores[i]
+                    hyps = V[:]
+                else:
+                    last_blank = self._joint_logp(h_enc, beam_y)[:, 0].tolist()
+                    for i, v in enumerate(V):
+                        if self.nstep != 1:
+                            v.score += float(last_blank[i])
+                        v.y.append(beam_y[i])
+                        v.dec_state = self.decoder.select_state(beam_state, i)
+                        if self.lm:
+                            v.lm_state = self._lm_select(beam_lm_states, i)
+                            v.lm_scores = beam_lm_scores[i]
+            kept_hyps = sorted((S + V), key=lambda x: x.score, reverse=True)[:beam]
+        return self.sort_nbest(kept_hyps)

@@ -607,7 +607,10 @@ def main():
                              ("tsd3", dict(beam_size=3, search_type="tsd", max_sym_exp=2)),
                              ("tsd2", dict(beam_size=2, search_type="tsd", max_sym_exp=3, score_norm=False)),
                              ("alsd3", dict(beam_size=3, search_type="alsd", u_max=10)),
-                             ("alsd2", dict(beam_size=2, search_type="alsd", u_max=4, score_norm=False))):
+                             ("alsd2", dict(beam_size=2, search_type="alsd", u_max=4, score_norm=False)),
+                             ("nsc3", dict(beam_size=3, search_type="nsc", nstep=1, prefix_alpha=1)),
+                             ("nsc3n2", dict(beam_size=3, search_type="nsc", nstep=2, prefix_alpha=2)),
+                             ("nsc2n3", dict(beam_size=2, search_type="nsc", nstep=3, prefix_alpha=1, score_norm=False))):
                 bs = BeamSearchTransducer(decoder=m.dec, lm=None, lm_weight=0.0, **kw2)
                 nb = m.recognize(xin, bs)
                 nb = nb if isinstance(nb, list) else [nb]
@@ -618,8 +621,8 @@ def main():
             from espnet.nets.pytorch_backend.lm.default import ClassifierWithState, RNNLM
             torch.manual_seed(seed + 7)
             lm = ClassifierWithState(RNNLM(6, 1, 8, None, "lstm", 0.0)).eval()
-            for tag, st in (("beam3_lm", "default"), ("tsd3_lm", "tsd"), ("alsd3_lm", "alsd")):
-                bs = BeamSearchTransducer(decoder=m.dec, lm=lm, lm_weight=0.5, beam_size=3, search_type=st)
+            for tag, st in (("beam3_lm", "default"), ("tsd3_lm", "tsd"), ("alsd3_lm", "alsd"), ("nsc3_lm", "nsc")):
+                bs = BeamSearchTransducer(decoder=m.dec, lm=lm, lm_weight=0.5, beam_size=3, search_type=st, nstep=2)
                 nb = m.recognize(xin, bs)
                 dec["dec_%s_scores" % tag] = np.asarray([float(h["score"]) for h in nb], dtype=np.float64)
                 dec["dec_%s_lens" % tag] = np.asarray([len(h["yseq"]) for h in nb], dtype=np.int64)

@@ -317,13 +317,17 @@ def test_transducer_decoding_golden(name):
     lm.to(DEV).eval()
     for tag, kw in (("greedy", dict(beam_size=1)), ("beam3", dict(beam_size=3, search_type="default")),
                     ("beam3_nonorm", dict(beam_size=3, search_type="default", score_norm=False)),
-                    ("beam3_lm", dict(beam_size=3, search_type="default", lm=lm, lm_weight=0.5)),
+                    ("beam3_lm", dict(beam_size=3, search_type="default", lm=lm, lm_weight=0.5, nstep=2)),
                     ("tsd3", dict(beam_size=3, search_type="tsd", max_sym_exp=2)),
                     ("tsd2", dict(beam_size=2, search_type="tsd", max_sym_exp=3, score_norm=False)),
                     ("alsd3", dict(beam_size=3, search_type="alsd", u_max=10)),
                     ("alsd2", dict(beam_size=2, search_type="alsd", u_max=4, score_norm=False)),
-                    ("tsd3_lm", dict(beam_size=3, search_type="tsd", lm=lm, lm_weight=0.5)),
-                    ("alsd3_lm", dict(beam_size=3, search_type="alsd", lm=lm, lm_weight=0.5))):
+                    ("nsc3", dict(beam_size=3, search_type="nsc", nstep=1, prefix_alpha=1)),
+                    ("nsc3n2", dict(beam_size=3, search_type="nsc", nstep=2, prefix_alpha=2)),
+                    ("nsc2n3", dict(beam_size=2, search_type="nsc", nstep=3, prefix_alpha=1, score_norm=False)),
+                    ("tsd3_lm", dict(beam_size=3, search_type="tsd", lm=lm, lm_weight=0.5, nstep=2)),
+                    ("alsd3_lm", dict(beam_size=3, search_type="alsd", lm=lm, lm_weight=0.5, nstep=2)),
+                    ("nsc3_lm", dict(beam_size=3, search_type="nsc", lm=lm, lm_weight=0.5, nstep=2))):
         nb = m.recognize(x, BeamSearchTransducer(decoder=m.dec, **kw))
         nb = nb if isinstance(nb, list) else [nb]
         lens = p["dec_%s_lens" % tag].tolist()
