@@ -183,8 +183,8 @@ int launch_persist(const eamd_gemm_t& p, int ntiles, hipStream_t stream) {
   // one workgroup per resident slot: CUs x occupancy (registers / 49 KB of LDS decide; queried once)
   static const int grid = [] {
     int dev = 0, cus = 256, occ = 2;
-    hipGetDevice(&dev);
-    hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+    if (hipGetDevice(&dev) != hipSuccess) dev = 0;
+    if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus < 1) cus = 256;
     if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, reinterpret_cast<const void*>(&gemm_bf16_persist_kernel<TA, TB>),
                                                      NT_, sizeof(SmemP<TA, TB>)) != hipSuccess || occ < 1)
       occ = 2;

@@ -75,9 +75,6 @@ def _span(rows, ld, cols):
 _gemm_record = None   # bench.py: list collecting (descriptor, operand references) of every launch of one step
 
 
-_gemm_record = None   # bench.py: list collecting (descriptor, operand references) of every launch of one step
-
-
 def gemm(A, B, Cm, M, N, K, lda, ldb, ldc, *, transA=0, transB=0, bias=None, aux=None, ldaux=0, R=None,
          ldr=0, batch=(1, 1), sA=(0, 0), sB=(0, 0), sC=(0, 0), alpha=1.0, beta=0.0, a_act=0, b_act=0,
          epilogue=0, splitk=1, tile=0, gather=None, cmap=None, a_off=0, b_off=0, c_off=0, precision=None,
