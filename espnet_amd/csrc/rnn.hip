@@ -171,18 +171,19 @@ __global__ __launch_bounds__(128) void attloc_energy_fwd_kernel(
     const float* __restrict__ att_prev, const float* __restrict__ conv_w, const float* __restrict__ w_att,
     const float* __restrict__ pre_enc, const float* __restrict__ dec_proj, const float* __restrict__ gvec,
     const float* __restrict__ gb, const int* __restrict__ lens, float* __restrict__ e, float* __restrict__ th,
-    float* __restrict__ conv, int T, int A, int C, int K) {
+    float* __restrict__ conv, int T, int A, int C, int K, int R) {
   __shared__ float convl[64];
   __shared__ float red[16];
   const int bt = blockIdx.x, b = bt / T, t = bt % T;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
   const int F = (K - 1) / 2;
-  const float* pv = att_prev + (long)b * T;
+  const float* pv = att_prev + (long)b * R * T;      // R rows of history (AttLoc2D window), R = 1: the previous weights
   for (int c = wave; c < C; c += nw) {
     float sacc = 0.f;
-    for (int k = lane; k < K; k += 64) {
+    for (int q = lane; q < R * K; q += 64) {
+      const int r = q / K, k = q % K;
       const int ts = t + k - F;
-      if (ts >= 0 && ts < T) sacc += conv_w[c * K + k] * pv[ts];
+      if (ts >= 0 && ts < T) sacc += conv_w[((long)c * R + r) * K + k] * pv[(long)r * T + ts];
     }
     sacc = wave_sum(sacc);
     if (lane == 0) { convl[c] = sacc; conv[(long)bt * C + c] = sacc; }
@@ -304,39 +305,87 @@ __global__ __launch_bounds__(256) void attloc_energy_bwd_kernel(const float* __r
   }
 }
 
-// d_prev[b,s] = sum_{c,k} dconv[b, s - k + F, c] * conv_w[c,k]          one wave per output frame (b,s): lanes over k
+// d_prev[b,r,s] = sum_{c,k} dconv[b, s - k + F, c] * conv_w[c,r,k]      one wave per output (b,r,s): lanes over k
 __global__ __launch_bounds__(256) void attloc_conv_bwd_prev_kernel(const float* __restrict__ dconv,
                                                                    const float* __restrict__ conv_w,
-                                                                   float* __restrict__ d_prev, int BT, int T, int C,
-                                                                   int K) {
+                                                                   float* __restrict__ d_prev, int BRT, int T, int C,
+                                                                   int K, int R) {
   const int lane = threadIdx.x & 63;
   const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
-  if (row >= BT) return;
-  const int b = row / T, s = row % T;
+  if (row >= BRT) return;
+  const int s = row % T, r = (row / T) % R, b = row / (T * R);
   const int F = (K - 1) / 2;
   float acc = 0.f;
   for (int k = lane; k < K; k += 64) {
     const int t = s - k + F;
     if (t < 0 || t >= T) continue;
     const float* dcv = dconv + ((long)b * T + t) * C;
-    for (int c = 0; c < C; ++c) acc += dcv[c] * conv_w[c * K + k];
+    for (int c = 0; c < C; ++c) acc += dcv[c] * conv_w[((long)c * R + r) * K + k];
   }
   acc = wave_sum(acc);
   if (lane == 0) d_prev[row] = acc;
 }
-// dconv_w[c,k] += sum_{b,t} dconv[b,t,c] * att_prev[b, t + k - F]       grid (C, B), threads along k
+// dconv_w[c,r,k] += sum_{b,t} dconv[b,t,c] * att_prev[b, r, t + k - F]       grid (C, B), threads along (r, k)
 __global__ __launch_bounds__(256) void attloc_conv_bwd_w_kernel(const float* __restrict__ dconv,
                                                                 const float* __restrict__ att_prev,
-                                                                float* __restrict__ dconv_w, int T, int C, int K) {
+                                                                float* __restrict__ dconv_w, int T, int C, int K, int R) {
   const int c = blockIdx.x, b = blockIdx.y;
   const int F = (K - 1) / 2;
-  for (int k = threadIdx.x; k < K; k += blockDim.x) {
+  for (int q = threadIdx.x; q < R * K; q += blockDim.x) {
+    const int r = q / K, k = q % K;
     float acc = 0.f;
     for (int t = 0; t < T; ++t) {
       const int ts = t + k - F;
-      if (ts >= 0 && ts < T) acc += dconv[((long)b * T + t) * C + c] * att_prev[(long)b * T + ts];
+      if (ts >= 0 && ts < T) acc += dconv[((long)b * T + t) * C + c] * att_prev[((long)b * R + r) * T + ts];
     }
-    atomicAdd(&dconv_w[c * K + k], acc);
+    atomicAdd(&dconv_w[((long)c * R + r) * K + k], acc);
+  }
+}
+
+// ---- AttLocRec front end (attentions.py:690-696): pooled[b,c] = max_t relu(conv(att_prev)[b,c,t]), idx = its frame
+// one wave per (b,c): lanes over frames, the K-tap window per frame read from global (att_prev rows are tiny)
+__global__ __launch_bounds__(256) void attloc_convmax_fwd_kernel(const float* __restrict__ att_prev,
+                                                                 const float* __restrict__ conv_w,
+                                                                 float* __restrict__ pooled, int* __restrict__ idx, int BC,
+                                                                 int T, int C, int K) {
+  const int lane = threadIdx.x & 63;
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= BC) return;
+  const int b = row / C, c = row % C;
+  const int F = (K - 1) / 2;
+  const float* pv = att_prev + (long)b * T;
+  float best = -INFINITY; int bi = 0;
+  for (int t = lane; t < T; t += 64) {
+    float acc = 0.f;
+    for (int k = 0; k < K; ++k) {
+      const int ts = t + k - F;
+      if (ts >= 0 && ts < T) acc += conv_w[c * K + k] * pv[ts];
+    }
+    if (acc > best) { best = acc; bi = t; }
+  }
+  // wave arg-max, ties to the earliest frame (what max_pool2d's backward picks)
+  for (int off = 32; off > 0; off >>= 1) {
+    const float ob = __shfl_xor(best, off); const int oi = __shfl_xor(bi, off);
+    if (ob > best || (ob == best && oi < bi)) { best = ob; bi = oi; }
+  }
+  if (lane == 0) { pooled[row] = fmaxf(best, 0.f); idx[row] = bi; }
+}
+// backward: only the arg-max frame of each (b,c) carries gradient, and only where the ReLU was active
+// d_prev[b, idx+k-F] += dpool[b,c] * conv_w[c,k] ; dconv_w[c,k] += dpool[b,c] * att_prev[b, idx+k-F]   thread = (b,c,k)
+__global__ void attloc_convmax_bwd_kernel(const float* __restrict__ dpool, const float* __restrict__ pooled,
+                                          const int* __restrict__ idx, const float* __restrict__ att_prev,
+                                          const float* __restrict__ conv_w, float* __restrict__ d_prev,
+                                          float* __restrict__ dconv_w, int B, int T, int C, int K) {
+  const long n = (long)B * C * K;
+  const int F = (K - 1) / 2;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+    const int k = i % K; const long bc = i / K; const int c = bc % C; const int b = bc / C;
+    if (pooled[bc] <= 0.f) continue;
+    const int ts = idx[bc] + k - F;
+    if (ts < 0 || ts >= T) continue;
+    const float g = dpool[bc];
+    atomicAdd(&d_prev[(long)b * T + ts], g * conv_w[c * K + k]);
+    atomicAdd(&dconv_w[c * K + k], g * att_prev[(long)b * T + ts]);
   }
 }
 
@@ -439,15 +488,15 @@ int eamd_maxpool2x2_bwd(const float* dy, const uint8_t* idx, float* dx, int B, i
 int eamd_attloc_fwd(const float* att_prev, const float* conv_w, const float* w_att, const float* pre_enc,
                     const float* dec_proj, const float* gvec, const float* gb, const int32_t* lens, const float* enc_h,
                     float scaling, float* e, float* th, float* conv, float* w, float* ctx, int B, int T, int A, int C,
-                    int K, int E, void* stream) {
+                    int K, int R, int E, void* stream) {
   if (!pre_enc || !dec_proj || !gvec || !gb || !lens || !enc_h || !e || !th || !w || !ctx || B <= 0 || T <= 0 ||
       A <= 0 || C < 0 || E <= 0)
     return EAMD_EINVAL;
-  if (C > 0 && (!att_prev || !conv_w || !w_att || !conv || K <= 0)) return EAMD_EINVAL;   // C = 0: additive attention
+  if (C > 0 && (!att_prev || !conv_w || !w_att || !conv || K <= 0 || R <= 0)) return EAMD_EINVAL;   // C = 0: additive attention
   if (C > 64 || (C > 0 && (K & 1) == 0) || (size_t)T * sizeof(float) > 60 * 1024) return EAMD_EUNSUPPORTED;
   hipStream_t s = (hipStream_t)stream;
   hipLaunchKernelGGL(attloc_energy_fwd_kernel, dim3(B * T), dim3(128), 0, s, att_prev, conv_w, w_att, pre_enc, dec_proj,
-                     gvec, gb, lens, e, th, conv, T, A, C, K);
+                     gvec, gb, lens, e, th, conv, T, A, C, K, C > 0 ? R : 1);
   EAMD_LAUNCH_CHECK();
   hipLaunchKernelGGL(attloc_ctx_fwd_kernel, dim3(B, (E + 63) / 64), dim3(256), T * sizeof(float), s, e, enc_h, scaling,
                      w, ctx, T, E);
@@ -477,13 +526,36 @@ int eamd_attloc_bwd_energy(const float* dctx, const float* dw_ext, const float* 
 
 /* stage 2 (after dconv = df @ W_att has been formed by eamd_gemm): gradients of the location convolution */
 int eamd_attloc_bwd_conv(const float* dconv, const float* conv_w, const float* att_prev, float* d_prev, float* dconv_w,
-                         int B, int T, int C, int K, void* stream) {
-  if (!dconv || !conv_w || !att_prev || !d_prev || !dconv_w || B <= 0 || T <= 0 || C <= 0 || K <= 0 || (K & 1) == 0)
+                         int B, int T, int C, int K, int R, void* stream) {
+  if (!dconv || !conv_w || !att_prev || !d_prev || !dconv_w || B <= 0 || T <= 0 || C <= 0 || K <= 0 || (K & 1) == 0 ||
+      R <= 0)
     return EAMD_EINVAL;
   hipStream_t s = (hipStream_t)stream;
-  hipLaunchKernelGGL(attloc_conv_bwd_prev_kernel, dim3((B * T + 3) / 4), dim3(256), 0, s, dconv, conv_w, d_prev, B * T, T, C, K);
+  hipLaunchKernelGGL(attloc_conv_bwd_prev_kernel, dim3((B * R * T + 3) / 4), dim3(256), 0, s, dconv, conv_w, d_prev,
+                     B * R * T, T, C, K, R);
   EAMD_LAUNCH_CHECK();
-  hipLaunchKernelGGL(attloc_conv_bwd_w_kernel, dim3(C, B), dim3(256), 0, s, dconv, att_prev, dconv_w, T, C, K);
+  hipLaunchKernelGGL(attloc_conv_bwd_w_kernel, dim3(C, B), dim3(256), 0, s, dconv, att_prev, dconv_w, T, C, K, R);
+  EAMD_LAUNCH_CHECK();
+  return EAMD_OK;
+}
+
+int eamd_attloc_convmax_fwd(const float* att_prev, const float* conv_w, float* pooled, int32_t* idx, int B, int T, int C,
+                            int K, void* stream) {
+  if (!att_prev || !conv_w || !pooled || !idx || B <= 0 || T <= 0 || C <= 0 || K <= 0 || (K & 1) == 0) return EAMD_EINVAL;
+  hipLaunchKernelGGL(attloc_convmax_fwd_kernel, dim3((B * C + 3) / 4), dim3(256), 0, (hipStream_t)stream, att_prev, conv_w,
+                     pooled, idx, B * C, T, C, K);
+  EAMD_LAUNCH_CHECK();
+  return EAMD_OK;
+}
+
+/* d_prev [B,T] and dconv_w [C,K] are ACCUMULATED (zero d_prev first) */
+int eamd_attloc_convmax_bwd(const float* dpool, const float* pooled, const int32_t* idx, const float* att_prev,
+                            const float* conv_w, float* d_prev, float* dconv_w, int B, int T, int C, int K, void* stream) {
+  if (!dpool || !pooled || !idx || !att_prev || !conv_w || !d_prev || !dconv_w || B <= 0 || T <= 0 || C <= 0 || K <= 0 ||
+      (K & 1) == 0)
+    return EAMD_EINVAL;
+  hipLaunchKernelGGL(attloc_convmax_bwd_kernel, dim3(grid_for((long)B * C * K)), dim3(256), 0, (hipStream_t)stream, dpool,
+                     pooled, idx, att_prev, conv_w, d_prev, dconv_w, B, T, C, K);
   EAMD_LAUNCH_CHECK();
   return EAMD_OK;
 }

@@ -1,6 +1,5 @@
 """Decoder-side attention of the RNN path.  reference: espnet/nets/pytorch_backend/rnn/attentions.py.
-Ten of the twelve attention types listed by `initial_att` (:1722-1771) run on the espnet_amd HIP kernels; location2d
-and location_recurrent have no kernel yet and raise NotImplementedError."""
+All twelve attention types listed by `initial_att` (:1722-1771) run on the espnet_amd HIP kernels."""
 import math
 
 import numpy as np
@@ -368,8 +367,98 @@ class AttCovLoc(AttCov):
         return c, self._extend(att_prev_list, w)
 
 
+class AttLoc2D(AttLoc):
+    """location-aware attention over a window of the last att_win weight vectors.  reference: rnn/attentions.py:485-603
+    (Conv2d(1, C, (att_win, 2F+1)) spanning the whole window = the location kernels with att_win history rows)"""
+
+    def __init__(self, eprojs, dunits, att_dim, att_win, aconv_chans, aconv_filts, han_mode=False):
+        torch.nn.Module.__init__(self)
+        self.mlp_enc = torch.nn.Linear(eprojs, att_dim)
+        self.mlp_dec = torch.nn.Linear(dunits, att_dim, bias=False)
+        self.mlp_att = torch.nn.Linear(aconv_chans, att_dim, bias=False)
+        self.loc_conv = torch.nn.Conv2d(1, aconv_chans, (att_win, 2 * aconv_filts + 1), padding=(0, aconv_filts),
+                                        bias=False)
+        self.gvec = torch.nn.Linear(att_dim, 1)
+        self.dunits, self.eprojs, self.att_dim, self.aconv_chans, self.att_win = dunits, eprojs, att_dim, aconv_chans, att_win
+        self.han_mode = han_mode
+        self.reset()
+
+    def forward(self, enc_hs_pad, enc_hs_len, dec_z, att_prev, scaling=2.0):
+        first = att_prev is None      # the window starts as att_win copies of the uniform weights (:560-566)
+        batch = enc_hs_pad.shape[0]
+        dev = enc_hs_pad.device
+        if self.pre_compute_enc_h is None or self.han_mode:
+            self.enc_h = enc_hs_pad.contiguous()
+            self.h_length = self.enc_h.size(1)
+            self.pre_compute_enc_h = F_.LinearFn.apply(self.enc_h, self.mlp_enc.weight, self.mlp_enc.bias)
+            self._lens_host = np.asarray([int(v) for v in enc_hs_len], dtype=np.int32)
+            self._lens = ops.h2d_cached("attlens", self._lens_host, dev)
+        dec_z = enc_hs_pad.new_zeros(batch, self.dunits) if dec_z is None else dec_z.view(batch, self.dunits)
+        if first:
+            keep = (np.arange(self.h_length)[None, :] < self._lens_host[:, None]).astype(np.float32)
+            uni = keep / self._lens_host[:, None].astype(np.float32)
+            att_prev = ops.h2d_cached("attuniform2d", np.repeat(uni[:, None, :], self.att_win, axis=1), dev)
+        dec_proj = F_.LinearFn.apply(dec_z, self.mlp_dec.weight, None)
+        c, w = R_.AttLocStepFn.apply(self.enc_h, self.pre_compute_enc_h, dec_proj, att_prev, self._lens, float(scaling),
+                                     self.loc_conv.weight, self.mlp_att.weight, self.gvec.weight, self.gvec.bias)
+        # slide the window: drop the oldest row, append the new weights (attentions.py:598-601; data movement only)
+        att_prev = torch.cat([att_prev[:, 1:], w.unsqueeze(1)], dim=1)
+        return c, att_prev
+
+
+class AttLocRec(torch.nn.Module):
+    """location-aware recurrent attention.  reference: rnn/attentions.py:606-726: the location features are max-pooled
+    over time and fed to an LSTMCell whose output replaces the per-frame location term; the energy is then the additive
+    one with the decoder projection shifted by that output."""
+
+    def __init__(self, eprojs, dunits, att_dim, aconv_chans, aconv_filts, han_mode=False):
+        super().__init__()
+        self.mlp_enc = torch.nn.Linear(eprojs, att_dim)
+        self.mlp_dec = torch.nn.Linear(dunits, att_dim, bias=False)
+        self.loc_conv = torch.nn.Conv2d(1, aconv_chans, (1, 2 * aconv_filts + 1), padding=(0, aconv_filts), bias=False)
+        self.att_lstm = torch.nn.LSTMCell(aconv_chans, att_dim, bias=False)      # parameter container only
+        self.gvec = torch.nn.Linear(att_dim, 1)
+        self.dunits, self.eprojs, self.att_dim, self.han_mode = dunits, eprojs, att_dim, han_mode
+        self.reset()
+
+    def reset(self):
+        self.h_length = None
+        self.enc_h = None
+        self.pre_compute_enc_h = None
+        self.mask = None
+        self._lens = None
+
+    def forward(self, enc_hs_pad, enc_hs_len, dec_z, att_prev_states, scaling=2.0):
+        batch = enc_hs_pad.shape[0]
+        dev = enc_hs_pad.device
+        if self.pre_compute_enc_h is None or self.han_mode:
+            self.enc_h = enc_hs_pad.contiguous()
+            self.h_length = self.enc_h.size(1)
+            self.pre_compute_enc_h = F_.LinearFn.apply(self.enc_h, self.mlp_enc.weight, self.mlp_enc.bias)
+            self._lens_host = np.asarray([int(v) for v in enc_hs_len], dtype=np.int32)
+            self._lens = ops.h2d_cached("attlens", self._lens_host, dev)
+        dec_z = enc_hs_pad.new_zeros(batch, self.dunits) if dec_z is None else dec_z.view(batch, self.dunits)
+        if att_prev_states is None:
+            keep = (np.arange(self.h_length)[None, :] < self._lens_host[:, None]).astype(np.float32)
+            att_prev = ops.h2d_cached("attuniform", keep / self._lens_host[:, None].astype(np.float32), dev)
+            att_states = (enc_hs_pad.new_zeros(batch, self.att_dim), enc_hs_pad.new_zeros(batch, self.att_dim))
+        else:
+            att_prev, att_states = att_prev_states
+        pooled = R_.ConvMaxFn.apply(att_prev, self.loc_conv.weight)
+        gx = F_.LinearFn.apply(pooled, self.att_lstm.weight_ih, None)
+        att_h, att_c = R_.LSTMCellFn.apply(gx, att_states[0], att_states[1], self.att_lstm.weight_hh, None)
+        dec_proj = R_.AddFn.apply(F_.LinearFn.apply(dec_z, self.mlp_dec.weight, None), att_h)
+        c, w = R_.AttLocStepFn.apply(self.enc_h, self.pre_compute_enc_h, dec_proj, None, self._lens, float(scaling),
+                                     None, None, self.gvec.weight, self.gvec.bias)
+        return c, (w, (att_h, att_c))
+
+
 def initial_att(atype, eprojs, dunits, aheads, adim, awin, aconv_chans, aconv_filts, han_mode=False):
     """reference: rnn/attentions.py:1722-1771"""
+    if atype == "location2d":
+        return AttLoc2D(eprojs, dunits, adim, awin, aconv_chans, aconv_filts, han_mode)
+    if atype == "location_recurrent":
+        return AttLocRec(eprojs, dunits, adim, aconv_chans, aconv_filts, han_mode)
     if atype == "noatt":
         return NoAtt()
     if atype == "coverage":
@@ -390,9 +479,7 @@ def initial_att(atype, eprojs, dunits, aheads, adim, awin, aconv_chans, aconv_fi
         return AttMultiHeadLoc(eprojs, dunits, aheads, adim, adim, aconv_chans, aconv_filts, han_mode)
     if atype == "multi_head_multi_res_loc":
         return AttMultiHeadMultiResLoc(eprojs, dunits, aheads, adim, adim, aconv_chans, aconv_filts, han_mode)
-    raise NotImplementedError("atype %r has no HIP kernels yet (on the HIP path: noatt, location, dot, add, coverage, "
-                              "coverage_location, multi_head_dot, multi_head_add, multi_head_loc, "
-                              "multi_head_multi_res_loc)" % atype)
+    raise ValueError("unknown attention type %r" % atype)
 
 
 def att_for(args, num_att=1, han_mode=False):

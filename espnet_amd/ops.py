@@ -758,10 +758,11 @@ def rnnt_loss(logits, labels, tlens, ulens, blank, grad=None, gscale=None, scale
 def attloc_fwd(att_prev, conv_w, w_att, pre_enc, dec_proj, gvec, gb, lens, enc_h, scaling):
     B, T, A = pre_enc.shape
     Cc, K = (conv_w.shape[0], conv_w.shape[-1]) if conv_w is not None else (0, 0)   # no conv: additive attention
+    R = conv_w.shape[2] if (conv_w is not None and conv_w.dim() == 4) else 1          # rows of attention history
     E = enc_h.shape[2]
     dev = enc_h.device
     assert dec_proj.shape == (B, A) and gvec.numel() == A and lens.dtype == torch.int32 and lens.numel() == B
-    assert conv_w is None or (att_prev.shape == (B, T) and w_att.shape == (A, Cc) and conv_w.numel() == Cc * K)
+    assert conv_w is None or (att_prev.numel() == B * R * T and w_att.shape == (A, Cc) and conv_w.numel() == Cc * R * K)
     e = torch.empty(B, T, device=dev, dtype=torch.float32)
     th = torch.empty(B, T, A, device=dev, dtype=torch.float32)
     conv = torch.empty(B, T, Cc, device=dev, dtype=torch.float32) if Cc else None
@@ -769,7 +770,7 @@ def attloc_fwd(att_prev, conv_w, w_att, pre_enc, dec_proj, gvec, gb, lens, enc_h
     ctx = torch.empty(B, E, device=dev, dtype=torch.float32)
     check(_lib.lib().eamd_attloc_fwd(ptr(att_prev), ptr(conv_w), ptr(w_att), ptr(pre_enc), ptr(dec_proj), ptr(gvec),
                                      ptr(gb), ptr(lens), ptr(enc_h), C.c_float(scaling), ptr(e), ptr(th), ptr(conv),
-                                     ptr(w), ptr(ctx), B, T, A, Cc, K, E, stream_ptr()), "eamd_attloc_fwd")
+                                     ptr(w), ptr(ctx), B, T, A, Cc, K, R, E, stream_ptr()), "eamd_attloc_fwd")
     return ctx, w, th, conv
 
 
@@ -790,9 +791,30 @@ def attloc_bwd_energy(dctx, dw_ext, w, enc_h, th, gvec, scaling, dgvec, dgb):
 def attloc_bwd_conv(dconv, conv_w, att_prev, dconv_w):
     B, T, Cc = dconv.shape
     K = conv_w.shape[-1]
-    d_prev = torch.empty(B, T, device=dconv.device, dtype=torch.float32)
+    R = conv_w.shape[2] if conv_w.dim() == 4 else 1
+    d_prev = torch.empty(att_prev.shape, device=dconv.device, dtype=torch.float32)
     check(_lib.lib().eamd_attloc_bwd_conv(ptr(dconv), ptr(conv_w), ptr(att_prev), ptr(d_prev), ptr(dconv_w), B, T, Cc,
-                                          K, stream_ptr()), "eamd_attloc_bwd_conv")
+                                          K, R, stream_ptr()), "eamd_attloc_bwd_conv")
+    return d_prev
+
+
+def attloc_convmax_fwd(att_prev, conv_w):
+    """att_prev [B,T], conv_w [C,1,1,K] -> pooled [B,C] = max_t relu(conv), idx [B,C] int32 (AttLocRec front end)"""
+    B, T = att_prev.shape
+    Cc, K = conv_w.shape[0], conv_w.shape[-1]
+    pooled = torch.empty(B, Cc, device=att_prev.device, dtype=torch.float32)
+    idx = torch.empty(B, Cc, device=att_prev.device, dtype=torch.int32)
+    check(_lib.lib().eamd_attloc_convmax_fwd(ptr(att_prev), ptr(conv_w), ptr(pooled), ptr(idx), B, T, Cc, K, stream_ptr()),
+          "eamd_attloc_convmax_fwd")
+    return pooled, idx
+
+
+def attloc_convmax_bwd(dpool, pooled, idx, att_prev, conv_w, dconv_w):
+    B, T = att_prev.shape
+    Cc, K = conv_w.shape[0], conv_w.shape[-1]
+    d_prev = torch.zeros(B, T, device=att_prev.device, dtype=torch.float32)
+    check(_lib.lib().eamd_attloc_convmax_bwd(ptr(dpool), ptr(pooled), ptr(idx), ptr(att_prev), ptr(conv_w), ptr(d_prev),
+                                             ptr(dconv_w), B, T, Cc, K, stream_ptr()), "eamd_attloc_convmax_bwd")
     return d_prev
 
 

@@ -140,13 +140,13 @@ class LSTMCellFn(torch.autograd.Function):
         acts = gates                                       # activated gates overwrite the pre-activations
         ops.lstm_cell_fwd(gates, c_prev, None, None, h, c, None, acts)
         ctx.save_for_backward(acts, h_prev, c_prev, c)
-        ctx.pr = (w_hh, b_hh)
+        ctx.pr = (w_hh, b_hh) if b_hh is not None else (w_hh,)      # LSTMCell(bias=False): AttLocRec's att_lstm
         return h, c
 
     @staticmethod
     def backward(ctx, dh, dc):
         acts, h_prev, c_prev, c = ctx.saved_tensors
-        w_hh, b_hh = ctx.pr
+        w_hh = ctx.pr[0]
         B, H4 = acts.shape
         H = H4 // 4
         dev = acts.device
@@ -157,8 +157,9 @@ class LSTMCellFn(torch.autograd.Function):
                           acts, c_prev, c, None, dgates, dc_prev, None)
         dh_prev = torch.empty(B, H, device=dev, dtype=torch.float32)
         _rec_gemm(dgates, w_hh, dh_prev, B, H, H4, H4, H, H, transB=1)
-        ops.linear_bwd_w(dgates, h_prev, sink.buf(0), db=sink.buf(1))
-        return (dgates, dh_prev, dc_prev) + sink.results()
+        has_b = len(ctx.pr) > 1
+        ops.linear_bwd_w(dgates, h_prev, sink.buf(0), db=sink.buf(1) if has_b else None)
+        return (dgates, dh_prev, dc_prev) + sink.results() + (() if has_b else (None,))
 
 
 # =================================================================================================
@@ -394,6 +395,25 @@ class AttDotStepFn(torch.autograd.Function):
         d_v, dk, dq = ops.att_dot_bwd(dc.contiguous(), dw.contiguous() if dw is not None else None, w, k, q, v,
                                       ctx.scaling)
         return dk, dq, d_v, None, None
+
+
+class ConvMaxFn(torch.autograd.Function):
+    """max over frames of relu(Conv2d(1, C, (1, K))(att_prev)) (AttLocRec, attentions.py:690-696) -> [B, C]"""
+
+    @staticmethod
+    def forward(ctx, att_prev, conv_w):
+        att_prev = att_prev.contiguous()
+        pooled, idx = ops.attloc_convmax_fwd(att_prev, conv_w)
+        ctx.save_for_backward(att_prev, pooled, idx)
+        ctx.pr = (conv_w,)
+        return pooled
+
+    @staticmethod
+    def backward(ctx, dpool):
+        att_prev, pooled, idx = ctx.saved_tensors
+        sink = GradSink(ctx.pr)
+        d_prev = ops.attloc_convmax_bwd(dpool.contiguous(), pooled, idx, att_prev, ctx.pr[0], sink.buf(0))
+        return (d_prev,) + sink.results()
 
 
 class AddFn(torch.autograd.Function):

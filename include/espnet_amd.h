@@ -312,11 +312,13 @@ int eamd_conv3x3_c1_bwd_w(const void* dy, const float* x, float* dw, float* db, 
  * pre_enc = mlp_enc(enc_h) [B,T,A] and dec_proj = mlp_dec(dec_z) [B,A] are eamd_gemm products.
  * th [B,T,A] (tanh output) and conv [B,T,C] are kept for the backward.
  * C = 0 (att_prev, conv_w, w_att, conv NULL): no location term = additive attention (AttAdd, attentions.py:167-247,
- * and the per-head energies of AttMultiHeadAdd :993-1107). */
+ * and the per-head energies of AttMultiHeadAdd :993-1107).
+ * R = rows of attention history the convolution spans: 1 for AttLoc; att_win for AttLoc2D (attentions.py:485-603),
+ * where att_prev is [B,R,T] and conv_w [C,1,R,K]. */
 int eamd_attloc_fwd(const float* att_prev, const float* conv_w, const float* w_att, const float* pre_enc,
                     const float* dec_proj, const float* gvec, const float* gb, const int32_t* lens, const float* enc_h,
                     float scaling, float* e, float* th, float* conv, float* w, float* ctx, int B, int T, int A, int C,
-                    int K, int E, void* stream);
+                    int K, int R, int E, void* stream);
 /* backward stage 1: from d ctx [B,E] and the gradient arriving at w from the next step (dw_ext, may be NULL):
  * de [B,T], d_enc_h [B,T,E] (= w * dctx), df [B,T,A] (gradient at the tanh input = d pre_enc);
  * dgvec [A], dgb [1], d_dec_proj [B,A] are ACCUMULATED. */
@@ -336,9 +338,15 @@ int eamd_att_ctx_fwd(const float* e, const float* v, float scaling, float* w, fl
                      void* stream);
 int eamd_att_ctx_bwd(const float* dctx, const float* dw_ext, const float* w, const float* v, float scaling, float* de,
                      float* d_v, float* dsum, int B, int T, int E, void* stream);
-/* backward stage 2, given dconv = df @ W_att [B,T,C]: d att_prev [B,T] and dconv_w [C,K] (accumulated). */
+/* backward stage 2, given dconv = df @ W_att [B,T,C]: d att_prev [B,R,T] and dconv_w [C,R,K] (accumulated). */
 int eamd_attloc_bwd_conv(const float* dconv, const float* conv_w, const float* att_prev, float* d_prev, float* dconv_w,
-                         int B, int T, int C, int K, void* stream);
+                         int B, int T, int C, int K, int R, void* stream);
+/* AttLocRec front end (attentions.py:690-696): pooled[b,c] = max_t relu(Conv2d(1,C,(1,K))(att_prev)[b,c,t]) and the
+ * frame idx[b,c] of that maximum; backward: d_prev [B,T] and dconv_w [C,K] are ACCUMULATED (zero d_prev first). */
+int eamd_attloc_convmax_fwd(const float* att_prev, const float* conv_w, float* pooled, int32_t* idx, int B, int T, int C,
+                            int K, void* stream);
+int eamd_attloc_convmax_bwd(const float* dpool, const float* pooled, const int32_t* idx, const float* att_prev,
+                            const float* conv_w, float* d_prev, float* dconv_w, int B, int T, int C, int K, void* stream);
 
 /* ---- RNN-Transducer ----------------------------------------------------------------------------
  * Joint network pointwise part: out[b,t,u,:] = act(enc[b,t,:] + dec[b,u,:]) (fp32 and/or bf16 copy for

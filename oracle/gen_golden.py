@@ -516,7 +516,7 @@ def main():
 
     # a20: the other attention types on the HIP path, on a small BLSTMP (subsampling 1_2) model each
     for atype in ("dot", "add", "multi_head_dot", "multi_head_add", "multi_head_loc", "multi_head_multi_res_loc", "noatt",
-                  "coverage", "coverage_location"):
+                  "coverage", "coverage_location", "location2d", "location_recurrent"):
         torch.manual_seed(32)
         m = RnnE2E(9, 7, rnn_args(etype="blstmp", elayers=2, subsample="1_2_1", eunits=8, eprojs=8, dlayers=1, dunits=10,
                                   atype=atype, adim=6, aheads=2, aconv_chans=3, aconv_filts=4))

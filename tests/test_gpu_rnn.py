@@ -214,7 +214,7 @@ def test_e2e_rnn_golden():
 
 
 @pytest.mark.parametrize("atype", ["dot", "add", "multi_head_dot", "multi_head_add", "multi_head_loc", "multi_head_multi_res_loc",
-                                   "noatt", "coverage", "coverage_location"])
+                                   "noatt", "coverage", "coverage_location", "location2d", "location_recurrent"])
 def test_e2e_rnn_attention_types_golden(atype):
     """BLSTMP (frame subsampling 1_2) + additive / multi-head attentions == reference E2E on its own weights"""
     from espnet_amd.nets.e2e_asr import E2E
@@ -356,6 +356,8 @@ _SMALL = dict(etype="blstmp", elayers=2, subsample="1_2_1", eunits=8, eprojs=8, 
     ("e2e_rnn_multi_head_multi_res_loc.npz", 9, dict(_SMALL, atype="multi_head_multi_res_loc")),
     ("e2e_rnn_noatt.npz", 9, dict(_SMALL, atype="noatt")), ("e2e_rnn_coverage.npz", 9, dict(_SMALL, atype="coverage")),
     ("e2e_rnn_coverage_location.npz", 9, dict(_SMALL, atype="coverage_location")),
+    ("e2e_rnn_location2d.npz", 9, dict(_SMALL, atype="location2d")),
+    ("e2e_rnn_location_recurrent.npz", 9, dict(_SMALL, atype="location_recurrent")),
     ("e2e_rnn_gru.npz", 9, dict(etype="bgrup", elayers=2, subsample="1_2_1", eunits=8, eprojs=8, dtype="gru", dlayers=2,
                                 dunits=10, atype="location", adim=6, aconv_chans=3, aconv_filts=4))])
 def test_rnn_decoding_golden(name, idim, kw):

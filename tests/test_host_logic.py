@@ -77,8 +77,8 @@ def test_flat_arena_groups_qkv_projections():
 def test_unsupported_variants_fail_loudly():
     from espnet_amd.nets.rnn.attentions import initial_att
     from espnet_amd.nets.rnn.encoders import Encoder
-    with pytest.raises(NotImplementedError):
-        initial_att("location2d", 8, 8, 2, 4, 3, 2, 1)
+    with pytest.raises(ValueError):
+        initial_att("no_such_attention", 8, 8, 2, 4, 3, 2, 1)
     with pytest.raises(ValueError):
         Encoder("brnnp", 10, 1, 4, 4, np.ones(2, dtype=np.int64), 0.0)
     from espnet_amd.nets.rnn.decoders import Decoder

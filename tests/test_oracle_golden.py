@@ -253,7 +253,7 @@ def test_e2e_rnn(oracle):
 
 
 @pytest.mark.parametrize("atype", ["dot", "add", "multi_head_dot", "multi_head_add", "multi_head_loc", "multi_head_multi_res_loc",
-                                   "noatt", "coverage", "coverage_location"])
+                                   "noatt", "coverage", "coverage_location", "location2d", "location_recurrent"])
 def test_e2e_rnn_attention_types(oracle, atype):
     """BLSTMP (subsample 1_2) + the other attention types on the HIP path against the reference E2E"""
     p, sd, grads = split_golden(load_golden("e2e_rnn_%s.npz" % atype))
