@@ -259,8 +259,15 @@ class ESPnetASRModel(AbsESPnetModel):
 
 
 def register_choices(asr_task_module):
-    """Add the HIP classes to the reference's ClassChoices registries (espnet2/tasks/asr.py:77-101) so
-    `--encoder conformer_mi355x --decoder transformer_mi355x` selects them."""
+    """Add the HIP classes to the reference's ClassChoices registries (espnet2/tasks/asr.py:53-101) so
+    `--frontend default_mi355x --specaug specaug_mi355x --normalize global_mvn_mi355x --encoder conformer_mi355x
+    --decoder transformer_mi355x` selects them."""
     asr_task_module.encoder_choices.classes["conformer_mi355x"] = ConformerEncoder
     asr_task_module.encoder_choices.classes["transformer_mi355x"] = TransformerEncoder
     asr_task_module.decoder_choices.classes["transformer_mi355x"] = TransformerDecoder
+    from .frontend import DefaultFrontend
+    from .layers import GlobalMVN, SpecAug, UtteranceMVN
+    asr_task_module.frontend_choices.classes["default_mi355x"] = DefaultFrontend
+    asr_task_module.specaug_choices.classes["specaug_mi355x"] = SpecAug
+    asr_task_module.normalize_choices.classes["global_mvn_mi355x"] = GlobalMVN
+    asr_task_module.normalize_choices.classes["utterance_mvn_mi355x"] = UtteranceMVN

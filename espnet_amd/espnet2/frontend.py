@@ -21,6 +21,11 @@ import torch
 from .. import ops
 from ..nets.modules import make_pad_mask
 
+try:  # pragma: no cover - only when the reference package is importable
+    from espnet2.asr.frontend.abs_frontend import AbsFrontend  # type: ignore
+except Exception:  # noqa: BLE001
+    AbsFrontend = torch.nn.Module
+
 
 def _hz_to_mel(f, htk):
     f = np.asarray(f, dtype=np.float64)
@@ -185,7 +190,7 @@ class LogMel(torch.nn.Module):
         return out, ilens
 
 
-class DefaultFrontend(torch.nn.Module):
+class DefaultFrontend(AbsFrontend):
     """Stft -> power spectrum -> LogMel.  frontend_conf (WPE / MVDR beamformer of espnet/nets/pytorch_backend/frontends)
     is speech enhancement, outside this path: only its switched-off default is accepted."""
 

@@ -23,6 +23,13 @@ def _dev_i32(a, device):
     return torch.as_tensor(np.ascontiguousarray(a, dtype=np.int32)).to(device, non_blocking=True)
 
 
+try:  # pragma: no cover - only when the reference package is importable: its registries type-check these bases
+    from espnet2.asr.specaug.abs_specaug import AbsSpecAug  # type: ignore
+    from espnet2.layers.abs_normalize import AbsNormalize  # type: ignore
+except Exception:  # noqa: BLE001
+    AbsSpecAug = AbsNormalize = torch.nn.Module
+
+
 class TimeWarp(torch.nn.Module):
     """reference: espnet2/layers/time_warp.py:56-94 (draws only; the interpolation runs inside SpecAug's kernel)"""
 
@@ -108,7 +115,7 @@ class MaskAlongAxis(torch.nn.Module):
         return ops.specaug(spec.contiguous(), **kw), spec_lengths
 
 
-class SpecAug(torch.nn.Module):
+class SpecAug(AbsSpecAug):
     """reference: espnet2/asr/specaug/specaug.py:19-84.  time warp -> frequency masks -> time masks, fused into ONE
     kernel launch (the draws are made in the reference's order first)."""
 
@@ -144,7 +151,7 @@ class SpecAug(torch.nn.Module):
         return ops.specaug(xin.contiguous(), **kw), x_lengths
 
 
-class GlobalMVN(torch.nn.Module):
+class GlobalMVN(AbsNormalize):
     """reference: espnet2/layers/global_mvn.py:14-121 (stats from a Kaldi-style .npy or a count/sum/sum_square .npz)"""
 
     def __init__(self, stats_file, norm_means=True, norm_vars=True, eps=1.0e-20):
@@ -180,7 +187,7 @@ class GlobalMVN(torch.nn.Module):
         return y, ilens
 
 
-class UtteranceMVN(torch.nn.Module):
+class UtteranceMVN(AbsNormalize):
     """reference: espnet2/layers/utterance_mvn.py:9-88"""
 
     def __init__(self, norm_means=True, norm_vars=False, eps=1.0e-20):

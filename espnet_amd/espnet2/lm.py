@@ -14,11 +14,22 @@ from ..nets.modules import PositionalEncoding, TransformerEncoder, subsequent_ma
 from ..nets.scorer_interface import BatchScorerInterface
 
 
-class AbsLM(torch.nn.Module, BatchScorerInterface):
-    """reference: espnet2/lm/abs_model.py:11-32"""
+try:  # pragma: no cover - only when the reference package is importable
+    from espnet2.lm.abs_model import AbsLM  # type: ignore
+except Exception:  # noqa: BLE001
 
-    def forward(self, input, hidden):
-        raise NotImplementedError
+    class AbsLM(torch.nn.Module, BatchScorerInterface):
+        """reference: espnet2/lm/abs_model.py:11-32"""
+
+        def forward(self, input, hidden):
+            raise NotImplementedError
+
+
+def register_lm_choices(lm_task_module):
+    """Add the HIP language models to the reference's registry (espnet2/tasks/lm.py:31-39):
+    `--lm transformer_mi355x` / `--lm seq_rnn_mi355x`."""
+    lm_task_module.lm_choices.classes["transformer_mi355x"] = TransformerLM
+    lm_task_module.lm_choices.classes["seq_rnn_mi355x"] = SequentialRNNLM
 
 
 class _NoPosEnc(torch.nn.Sequential):
