@@ -280,8 +280,12 @@ def init_distributed():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    # rehearsal knobs (a multi-rank run on a one-GPU box): EAMD_FORCE_DEVICE pins every rank to one device,
+    # EAMD_DIST_BACKEND=gloo replaces RCCL, which refuses two ranks on the same GPU
+    if os.environ.get("EAMD_FORCE_DEVICE") is not None:
+        local_rank = int(os.environ["EAMD_FORCE_DEVICE"])
     if world > 1 and not dist.is_initialized():
-        backend = "nccl" if torch.cuda.is_available() else "gloo"
+        backend = os.environ.get("EAMD_DIST_BACKEND") or ("nccl" if torch.cuda.is_available() else "gloo")
         if torch.cuda.is_available():
             torch.cuda.set_device(local_rank)
         dist.init_process_group(backend=backend, init_method="env://", rank=rank, world_size=world)
