@@ -636,10 +636,74 @@ def _conv3s2_bwd(dy, y_in, wd, dw_buf, db_buf, B, Hi, Wi, Ho, Wo, Cc, adt):
     return dy_in
 
 
+def _taps(k):
+    return [(kh, kw) for kh in range(k) for kw in range(k)]
+
+
+def _conv_ks_fwd(y_in, w, b, B, Hi, Wi, Cc, adt, k, st):
+    """general k x k stride-st convolution + ReLU on an NHWC activation (Conv2dSubsampling6's 5x5 stride 3): the gather
+    descriptor holds 9 taps, so the k*k taps run as ceil(k*k/9) implicit GEMMs accumulating into an fp32 buffer."""
+    Ho, Wo = (Hi - k) // st + 1, (Wi - k) // st + 1
+    KK = k * k
+    wf = torch.empty(KK, Cc, Cc, device=y_in.device, dtype=torch.float32)          # [tap][ci][co]
+    ops.permute4(w.contiguous(), wf, (Cc, Cc, KK, 1), (1, Cc, Cc * Cc, 0))
+    wd = torch.empty(KK, Cc, Cc, device=y_in.device, dtype=torch.float32)          # [tap][co][ci]
+    ops.permute4(w.contiguous(), wd, (Cc, Cc, KK, 1), (Cc, 1, Cc * Cc, 0))
+    wf, wd = ops.to_act(wf), ops.to_act(wd)
+    M = B * Ho * Wo
+    y32 = torch.empty(M, Cc, device=y_in.device, dtype=torch.float32)
+    taps = _taps(k)
+    for t0 in range(0, KK, 9):
+        ch = taps[t0:t0 + 9]
+        g = ops.make_gather(Cc, ch, Ho, Wo, Hi, Wi, st, st)
+        ops.gemm(y_in, wf, y32, M, Cc, len(ch) * Cc, len(ch) * Cc, Cc, Cc, transB=1, bias=b if t0 == 0 else None,
+                 beta=0.0 if t0 == 0 else 1.0, gather=g, b_off=t0 * Cc * Cc)
+    y = ops.dropout(y32, 0.0, 0, act=ACT_RELU, out_dtype=adt)                       # p = 0: ReLU + cast
+    return y, wd, Ho, Wo
+
+
+def _conv_ks_bwd(dy, y_in, wd, dw_buf, db_buf, B, Hi, Wi, Ho, Wo, Cc, adt, k, st):
+    dev = dy.device
+    M = B * Ho * Wo
+    KK = k * k
+    taps = _taps(k)
+    ops.colsum(dy, db_buf)
+    dwf = torch.zeros(KK * Cc, Cc, device=dev, dtype=torch.float32)                 # [(tap, ci), co]
+    for t0 in range(0, KK, 9):
+        ch = taps[t0:t0 + 9]
+        g = ops.make_gather(Cc, ch, Ho, Wo, Hi, Wi, st, st)
+        ntile = (len(ch) * Cc // 64) * ((Cc + 63) // 64)
+        sk = max(2, min(64, (1024 + ntile - 1) // ntile, max(1, M // 256)))
+        ops.gemm(y_in, dy, dwf, len(ch) * Cc, Cc, M, len(ch) * Cc, Cc, Cc, transA=1, transB=1, gather=g, splitk=sk, tile=64,
+                 c_off=t0 * Cc * Cc)
+    ops.permute4(dwf, dw_buf, (KK, Cc, Cc, 1), (1, KK, Cc * KK, 0), accumulate=True)      # -> dw[co][ci][tap]
+    # input gradient: one implicit GEMM per stride-parity class (ph, pw); its taps are kh = ph (mod st), kw = pw (mod st)
+    dy_in = torch.empty(y_in.shape, device=dev, dtype=adt)
+    order, classes = [], []
+    for ph in range(st):
+        for pw in range(st):
+            ct = [(kh, kw) for kh in range(ph, k, st) for kw in range(pw, k, st)]
+            classes.append(((ph, pw), ct))
+            order += [kh * k + kw for kh, kw in ct]
+    wd_cls = wd.index_select(0, torch.tensor(order, device=dev)).contiguous()          # class-ordered taps (data movement)
+    q0 = 0
+    for (ph, pw), ct in classes:
+        Hc, Wc = (Hi - ph + st - 1) // st, (Wi - pw + st - 1) // st
+        if Hc > 0 and Wc > 0 and ct:
+            gt = ops.make_gather(Cc, [((ph - kh) // st, (pw - kw) // st) for kh, kw in ct], Hc, Wc, Ho, Wo, 1, 1)
+            cm = ops.make_rowmap(Hc, Wc, Hi, Wi, st, ph, st, pw)
+            nt = len(ct)
+            ops.gemm(dy, wd_cls, dy_in, B * Hc * Wc, Cc, nt * Cc, nt * Cc, Cc, Cc, transB=1, b_off=q0 * Cc * Cc,
+                     gather=gt, cmap=cm, epilogue=EPI_MUL_RELU_MASK, aux=y_in, ldaux=Cc)
+        q0 += len(ct)
+    return dy_in
+
+
 class Conv2dSubsamplingFn(torch.autograd.Function):
     """Conv2d(1, C, 3, 2) -> ReLU -> n x [Conv2d(C, C, 3, 2) -> ReLU] -> Linear(C * W', D) * xscale.
-    n = 1: Conv2dSubsampling (subsampling.py:17-66); n = 2: Conv2dSubsampling8 (:123-168).
-    convs = (w, b) pairs of the C -> C stages."""
+    n = 1: Conv2dSubsampling (subsampling.py:17-66); n = 2: Conv2dSubsampling8 (:123-168); a 5x5 stride-3 second stage:
+    Conv2dSubsampling6 (:69-120).  convs = (w, b) pairs of the C -> C stages; the stride of a stage follows from its
+    kernel size (3 -> 2, 5 -> 3) as in the reference's three layouts."""
 
     @staticmethod
     def forward(ctx, x, xscale, c1_w, c1_b, lin_w, lin_b, *convs):
@@ -652,7 +716,12 @@ class Conv2dSubsamplingFn(torch.autograd.Function):
         ys = [ops.conv1_fwd(x, c1_w, c1_b, B, T, F, Cc, adt)]               # [B,H1,W1,C] NHWC, ReLU'd
         dims, wds = [(H1, W1)], []
         for i in range(0, len(convs), 2):
-            y, wd, Ho, Wo = _conv3s2_fwd(ys[-1].view(-1, Cc), convs[i], convs[i + 1], B, dims[-1][0], dims[-1][1], Cc, adt)
+            k = convs[i].shape[-1]
+            if k == 3:
+                y, wd, Ho, Wo = _conv3s2_fwd(ys[-1].view(-1, Cc), convs[i], convs[i + 1], B, dims[-1][0], dims[-1][1], Cc, adt)
+            else:
+                y, wd, Ho, Wo = _conv_ks_fwd(ys[-1].view(-1, Cc), convs[i], convs[i + 1], B, dims[-1][0], dims[-1][1], Cc,
+                                             adt, k, (k + 1) // 2)
             ys.append(y)
             wds.append(wd)
             dims.append((Ho, Wo))
@@ -666,6 +735,7 @@ class Conv2dSubsamplingFn(torch.autograd.Function):
         ctx.save_for_backward(x, wl, *ys, *wds)
         ctx.pr = (c1_w, c1_b, lin_w, lin_b) + tuple(convs)
         ctx.cfg = (B, T, F, Cc, D, dims, xscale)
+        ctx.ks = [convs[i].shape[-1] for i in range(0, len(convs), 2)]
         return out.view(B, Hl, D)
 
     @staticmethod
@@ -689,8 +759,12 @@ class Conv2dSubsamplingFn(torch.autograd.Function):
         dy = dy.view(B * Hl * Wl, Cc)
         for i in range(n - 1, -1, -1):
             (Hi, Wi), (Ho, Wo) = dims[i], dims[i + 1]
-            dy = _conv3s2_bwd(dy, ys[i].view(-1, Cc), wds[i], sink.buf(4 + 2 * i), sink.buf(5 + 2 * i), B, Hi, Wi, Ho, Wo,
-                              Cc, adt)
+            if ctx.ks[i] == 3:
+                dy = _conv3s2_bwd(dy, ys[i].view(-1, Cc), wds[i], sink.buf(4 + 2 * i), sink.buf(5 + 2 * i), B, Hi, Wi, Ho,
+                                  Wo, Cc, adt)
+            else:
+                dy = _conv_ks_bwd(dy, ys[i].view(-1, Cc), wds[i], sink.buf(4 + 2 * i), sink.buf(5 + 2 * i), B, Hi, Wi, Ho,
+                                  Wo, Cc, adt, ctx.ks[i], (ctx.ks[i] + 1) // 2)
         ops.conv1_bwd_w(dy, x, sink.buf(0), sink.buf(1), B, T, F, Cc)
         return (None, None) + sink.results()
 

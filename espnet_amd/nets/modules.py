@@ -102,15 +102,17 @@ def pad_list(xs, pad_value):
 
 
 def subsampled_lengths(ilens, tmax=None, stages=2):
-    """valid frames after `stages` applications of mask[:, :, :-2:2] (subsampling.py:59 for Conv2dSubsampling: two;
-    :166 for Conv2dSubsampling8: three)."""
+    """valid frames after the mask slicing of the conv2d input layers: `stages` = 2 -> [:-2:2] twice (subsampling.py:59,
+    Conv2dSubsampling), 3 -> three times (:166, Conv2dSubsampling8), or an explicit list of (cut, step) slices, e.g.
+    [(2, 2), (4, 3)] for Conv2dSubsampling6's [:-2:2][:-4:3] (:118)."""
+    slices = [(2, 2)] * stages if isinstance(stages, int) else list(stages)
     out = []
     for n in ilens:
         n = int(n)
         t = n if tmax is None else tmax
-        for _ in range(stages):
-            n = max(0, -(-min(n, t - 2) // 2))        # true entries of mask[:-2:2]
-            t = max(0, -(-(t - 2) // 2))
+        for cut, step in slices:
+            n = max(0, -(-min(n, t - cut) // step))   # true entries of mask[:-cut:step]
+            t = max(0, -(-(t - cut) // step))
         out.append(n)
     return out
 
@@ -232,6 +234,26 @@ class Conv2dSubsampling8(Conv2dSubsampling):
         if x_mask is None:
             return y, None
         return y, x_mask[:, :, :-2:2][:, :, :-2:2][:, :, :-2:2].contiguous()
+
+
+class Conv2dSubsampling6(Conv2dSubsampling):
+    """reference: transformer/subsampling.py:69-120 (3x3 stride 2, then 5x5 stride 3: 1/6 length)"""
+
+    def __init__(self, idim, odim, dropout_rate, pos_enc=None):
+        torch.nn.Module.__init__(self)
+        self.conv = torch.nn.Sequential(torch.nn.Conv2d(1, odim, 3, 2), torch.nn.ReLU(),
+                                        torch.nn.Conv2d(odim, odim, 5, 3), torch.nn.ReLU())
+        self.out = torch.nn.Sequential(
+            torch.nn.Linear(odim * (((idim - 1) // 2 - 2) // 3), odim),
+            pos_enc if pos_enc is not None else PositionalEncoding(odim, dropout_rate))
+        if odim % 64 != 0:
+            raise NotImplementedError("Conv2dSubsampling HIP path needs odim % 64 == 0 (implicit-GEMM tiles)")
+
+    def forward(self, x, x_mask):
+        y, _ = super().forward(x, None)
+        if x_mask is None:
+            return y, None
+        return y, x_mask[:, :, :-2:2][:, :, :-4:3].contiguous()
 
 
 # ---- attention ---------------------------------------------------------------------------------
@@ -475,9 +497,9 @@ class ConformerEncoder(torch.nn.Module):
             pos_enc_class = RelPositionalEncoding
         else:
             raise NotImplementedError("pos_enc_layer_type " + pos_enc_layer_type)
-        if input_layer not in ("conv2d", "conv2d8"):
-            raise NotImplementedError("input_layer=%r: conv2d / conv2d8 are on the HIP path" % (input_layer,))
-        self.embed = (Conv2dSubsampling if input_layer == "conv2d" else Conv2dSubsampling8)(
+        if input_layer not in ("conv2d", "conv2d6", "conv2d8"):
+            raise NotImplementedError("input_layer=%r: conv2d / conv2d6 / conv2d8 are on the HIP path" % (input_layer,))
+        self.embed = {"conv2d": Conv2dSubsampling, "conv2d6": Conv2dSubsampling6, "conv2d8": Conv2dSubsampling8}[input_layer](
             idim, attention_dim, dropout_rate, pos_enc_class(attention_dim, positional_dropout_rate))
 
         def pw():
@@ -556,12 +578,14 @@ class TransformerEncoder(torch.nn.Module):
             self.embed = Conv2dSubsampling(idim, attention_dim, dropout_rate, pos)
         elif input_layer == "conv2d8":
             self.embed = Conv2dSubsampling8(idim, attention_dim, dropout_rate, pos)
+        elif input_layer == "conv2d6":
+            self.embed = Conv2dSubsampling6(idim, attention_dim, dropout_rate, pos)
         elif input_layer == "linear":
             self.embed = _LinearInput(idim, attention_dim, dropout_rate, pos)
         elif input_layer == "embed":
             self.embed = _EmbedInput(idim, attention_dim, padding_idx, pos)
         else:
-            raise NotImplementedError("input_layer %r: conv2d / conv2d8 / linear / embed are on the HIP path" % (input_layer,))
+            raise NotImplementedError("input_layer %r: conv2d / conv2d6 / conv2d8 / linear / embed are on the HIP path" % (input_layer,))
         self.normalize_before = normalize_before
         self.encoders = repeat(
             num_blocks,

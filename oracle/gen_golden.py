@@ -386,7 +386,9 @@ def main():
                          ("trf_conv1d", TrfEncoder2, dict(positionwise_layer_type="conv1d",
                                                           positionwise_conv_kernel_size=3)),
                          ("conf_conv2d8", ConformerEncoder, dict(input_layer="conv2d8", use_cnn_module=False)),
-                         ("trf_conv2d8", TrfEncoder2, dict(input_layer="conv2d8"))):
+                         ("trf_conv2d8", TrfEncoder2, dict(input_layer="conv2d8")),
+                         ("conf_conv2d6", ConformerEncoder, dict(input_layer="conv2d6", use_cnn_module=False)),
+                         ("trf_conv2d6", TrfEncoder2, dict(input_layer="conv2d6"))):
         torch.manual_seed(31)
         enc_pw = cls(20, output_size=64, attention_heads=4, linear_units=96, num_blocks=2, dropout_rate=0.0,
                      positional_dropout_rate=0.0, attention_dropout_rate=0.0, **kw)

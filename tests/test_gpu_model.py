@@ -674,7 +674,9 @@ def test_frontend_golden():
                                          use_cnn_module=False)),
     ("trf_conv1d", "transformer", dict(positionwise_layer_type="conv1d", positionwise_conv_kernel_size=3)),
     ("conf_conv2d8", "conformer", dict(input_layer="conv2d8", use_cnn_module=False)),
-    ("trf_conv2d8", "transformer", dict(input_layer="conv2d8"))])
+    ("trf_conv2d8", "transformer", dict(input_layer="conv2d8")),
+    ("conf_conv2d6", "conformer", dict(input_layer="conv2d6", use_cnn_module=False)),
+    ("trf_conv2d6", "transformer", dict(input_layer="conv2d6"))])
 def test_positionwise_conv1d_golden(tag, kind, kw):
     """8f rank 4: MultiLayeredConv1d / Conv1dLinear positionwise layers (im2col along time + GEMM) and the
     Conv2dSubsampling8 input layer (three implicit-GEMM 3x3 stride-2 stages) inside the espnet2 encoders, outputs,
