@@ -11,7 +11,7 @@ import torch
 from .asr_interface import ASRInterface
 from .e2e_asr import get_subsample, lecun_normal_init_parameters, set_forget_bias_to_one
 from .. import ops
-from .modules import make_non_pad_mask, subsampled_lengths
+from .modules import make_non_pad_mask, subsampled_lengths, target_mask
 from .rnn.encoders import encoder_for
 from .transducer.loss import TransLoss
 from .transducer.rnn_decoder import DecoderRNNT
@@ -67,12 +67,22 @@ class E2E(ASRInterface, torch.nn.Module):
             self.enc = encoder_for(args, idim, self.subsample)
             encoder_out = args.eprojs
         if "transformer" in args.dtype:
-            raise NotImplementedError("transformer-transducer decoder is outside the hot-path scope (SURVEY.md 8f)")
-        if getattr(args, "rnnt_mode", "rnnt") != "rnnt":
-            raise NotImplementedError("rnnt-att mode is outside the hot-path scope (SURVEY.md 8f)")
-        self.dec = DecoderRNNT(encoder_out, odim, args.dtype, args.dlayers, args.dunits, blank_id,
-                               args.dec_embed_dim, args.joint_dim, args.joint_activation_type,
-                               args.dropout_rate_decoder, args.dropout_rate_embed_decoder)
+            if args.dec_block_arch is None:
+                raise ValueError("Transformer-based blocks in transducer mode should be defined individually in the "
+                                 "YAML file.")
+            from .transducer.transformer_decoder import DecoderTT
+            self.decoder = DecoderTT(odim, encoder_out, args.joint_dim, args.dec_block_arch,
+                                     input_layer=args.transformer_dec_input_layer, repeat_block=args.dec_block_repeat,
+                                     joint_activation_type=args.joint_activation_type,
+                                     positionwise_activation_type=args.transformer_dec_pw_activation_type,
+                                     dropout_rate_embed=args.dropout_rate_embed_decoder)
+            self.most_dom_list = (self.most_dom_list if hasattr(self, "most_dom_list") else []) + args.dec_block_arch[:]
+        else:
+            if getattr(args, "rnnt_mode", "rnnt") != "rnnt":
+                raise NotImplementedError("rnnt-att mode is outside the hot-path scope (SURVEY.md 8f)")
+            self.dec = DecoderRNNT(encoder_out, odim, args.dtype, args.dlayers, args.dunits, blank_id,
+                                   args.dec_embed_dim, args.joint_dim, args.joint_activation_type,
+                                   args.dropout_rate_decoder, args.dropout_rate_embed_decoder)
         if hasattr(self, "most_dom_list"):
             self.most_dom_dim = sorted(Counter(d["d_hidden"] for d in self.most_dom_list if "d_hidden" in d)
                                        .most_common(), key=lambda x: x[0], reverse=True)[0][0]
@@ -92,6 +102,13 @@ class E2E(ASRInterface, torch.nn.Module):
 
     def default_parameters(self, args):
         """reference: transducer/initializer.py:12-36"""
+        if "transformer" in args.dtype:
+            if "transformer" in args.etype:
+                _initialize_transformer(self, args.transformer_init)
+            else:
+                lecun_normal_init_parameters(self.enc)
+                _initialize_transformer(self.decoder, args.transformer_init)
+            return
         if "transformer" in args.etype:
             _initialize_transformer(self.encoder, args.transformer_init)
             lecun_normal_init_parameters(self.dec)
@@ -115,7 +132,11 @@ class E2E(ASRInterface, torch.nn.Module):
             hs_pad, hs_mask, _ = self.enc(xs_pad, il)
         self.hs_pad = hs_pad
         ys_in_pad, target, pred_len, target_len = prepare_loss_inputs(ys_pad, hs_mask, device=xs_pad.device)
-        pred_pad = self.dec(hs_pad, ys_in_pad)
+        if "transformer" in self.dtype:
+            ys_mask = target_mask(ys_in_pad, self.blank_id)          # blank keys hidden + causal (e2e_asr_transducer.py:537)
+            pred_pad, _ = self.decoder(ys_in_pad, ys_mask, hs_pad)
+        else:
+            pred_pad = self.dec(hs_pad, ys_in_pad)
         self.pred_pad = pred_pad
         self.loss = self.criterion(pred_pad, target, pred_len, target_len)
         return self.loss

@@ -2,7 +2,8 @@
 espnet/nets/pytorch_backend/transducer/blocks.py:39-552 (check_and_prepare, get_pos_enc_and_att_class,
 build_input_layer, build_transformer_block, build_conformer_block, build_blocks).
 Block types on the HIP path: "transformer" and "conformer" encoder blocks behind a conv2d input layer
-(the configuration BASELINE config 5 names); tdnn / causal-conv1d / vgg2l / embed inputs raise."""
+(the configuration BASELINE config 5 names) and "transformer" decoder blocks behind an embed input layer
+(transformer-transducer); tdnn / causal-conv1d / vgg2l inputs raise."""
 from collections import Counter
 
 from ..modules import (ConformerEncoderLayer, Conv2dSubsampling, ConvolutionModule, MultiHeadedAttention,
@@ -17,8 +18,6 @@ def _most_common_max(blocks_arch, key):
 
 def check_and_prepare(net_part, blocks_arch, input_layer):
     """reference: blocks.py:39-222"""
-    if net_part != "encoder":
-        raise NotImplementedError("transformer-transducer decoder blocks are outside the hot-path scope")
     if blocks_arch[0]["type"] in ("tdnn", "causal-conv1d"):
         raise NotImplementedError("tdnn / causal-conv1d blocks have no HIP kernels")
     input_layer_odim = blocks_arch[0]["d_hidden"]
@@ -77,7 +76,10 @@ def build_input_layer(input_layer, idim, odim, pos_enc_class, dropout_rate_embed
         return Conv2dSubsampling(idim, odim, dropout_rate)
     if input_layer == "conformer-conv2d":
         return Conv2dSubsampling(idim, odim, dropout_rate, pos_enc_class(odim, pos_dropout_rate))
-    raise NotImplementedError("input layer %r: conv2d is the one on the HIP path" % (input_layer,))
+    if input_layer == "embed":      # decoder side (blocks.py:290-294)
+        from ..modules import _EmbedInput
+        return _EmbedInput(idim, odim, padding_idx, pos_enc_class(odim, pos_dropout_rate))
+    raise NotImplementedError("input layer %r: conv2d (encoder) and embed (decoder) are on the HIP path" % (input_layer,))
 
 
 def _rates(block_arch):

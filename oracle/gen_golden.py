@@ -613,7 +613,7 @@ def main():
                              ("nsc3", dict(beam_size=3, search_type="nsc", nstep=1, prefix_alpha=1)),
                              ("nsc3n2", dict(beam_size=3, search_type="nsc", nstep=2, prefix_alpha=2)),
                              ("nsc2n3", dict(beam_size=2, search_type="nsc", nstep=3, prefix_alpha=1, score_norm=False))):
-                bs = BeamSearchTransducer(decoder=m.dec, lm=None, lm_weight=0.0, **kw2)
+                bs = BeamSearchTransducer(decoder=m.decoder if hasattr(m, "decoder") else m.dec, lm=None, lm_weight=0.0, **kw2)
                 nb = m.recognize(xin, bs)
                 nb = nb if isinstance(nb, list) else [nb]
                 dec["dec_%s_scores" % tag] = np.asarray([float(h["score"]) for h in nb], dtype=np.float64)
@@ -624,7 +624,8 @@ def main():
             torch.manual_seed(seed + 7)
             lm = ClassifierWithState(RNNLM(6, 1, 8, None, "lstm", 0.0)).eval()
             for tag, st in (("beam3_lm", "default"), ("tsd3_lm", "tsd"), ("alsd3_lm", "alsd"), ("nsc3_lm", "nsc")):
-                bs = BeamSearchTransducer(decoder=m.dec, lm=lm, lm_weight=0.5, beam_size=3, search_type=st, nstep=2)
+                bs = BeamSearchTransducer(decoder=m.decoder if hasattr(m, "decoder") else m.dec, lm=lm, lm_weight=0.5, beam_size=3,
+                                          search_type=st, nstep=2)
                 nb = m.recognize(xin, bs)
                 dec["dec_%s_scores" % tag] = np.asarray([float(h["score"]) for h in nb], dtype=np.float64)
                 dec["dec_%s_lens" % tag] = np.asarray([len(h["yseq"]) for h in nb], dtype=np.int64)
@@ -640,6 +641,16 @@ def main():
     conf_arch[0]["dropout-rate"] = 0.0
     conf_arch[0]["pos-dropout-rate"] = 0.0
     conf_arch[0]["att-dropout-rate"] = 0.0
+    # transformer-transducer: transformer prediction network (DecoderTT) behind a transformer encoder (the reference's
+    # initializer breaks on an RNN encoder + transformer decoder: transducer/initializer.py:34 reads model.encoder)
+    tt_dec = [dict(type="transformer", d_hidden=16, d_ff=24, heads=2)]
+    tt_kw = dict(dtype="transformer", dec_block_arch=tt_dec, dec_block_repeat=2, transformer_dec_input_layer="embed",
+                 transformer_dec_pw_activation_type="relu")
+    trn_case("transducer_tt.npz", 45, etype="transformer",
+             enc_block_arch=[dict(type="transformer", d_hidden=64, d_ff=96, heads=4)], enc_block_repeat=2,
+             transformer_enc_input_layer="conv2d", transformer_enc_self_attn_type="self_attn",
+             transformer_enc_positional_encoding_type="abs_pos", transformer_enc_pw_activation_type="relu",
+             transformer_enc_conv_mod_activation_type="relu", **tt_kw)
     trn_case("transducer_conformer.npz", 42, etype="transformer", enc_block_arch=conf_arch, enc_block_repeat=2,
              transformer_enc_input_layer="conv2d", transformer_enc_self_attn_type="rel_self_attn",
              transformer_enc_positional_encoding_type="rel_pos", transformer_enc_pw_activation_type="swish",

@@ -259,23 +259,35 @@ def _trn_args(**kw):
     return argparse.Namespace(**d)
 
 
-@pytest.mark.parametrize("name", ["transducer_rnn.npz", "transducer_gru.npz", "transducer_conformer.npz"])
+_TT = dict(dtype="transformer", dec_block_arch=[dict(type="transformer", d_hidden=16, d_ff=24, heads=2)], dec_block_repeat=2,
+           transformer_dec_input_layer="embed", transformer_dec_pw_activation_type="relu")
+_TRN_CASES = ["transducer_rnn.npz", "transducer_gru.npz", "transducer_conformer.npz", "transducer_tt.npz"]
+
+
+def _trn_case_args(name):
+    if name == "transducer_rnn.npz":
+        return _trn_args()
+    if name == "transducer_gru.npz":
+        return _trn_args(etype="bgru", elayers=2, dtype="gru", dlayers=2)
+    if name == "transducer_tt.npz":
+        return _trn_args(etype="transformer", enc_block_arch=[dict(type="transformer", d_hidden=64, d_ff=96, heads=4)],
+                         enc_block_repeat=2, transformer_enc_input_layer="conv2d",
+                         transformer_enc_self_attn_type="self_attn", transformer_enc_positional_encoding_type="abs_pos",
+                         transformer_enc_pw_activation_type="relu", transformer_enc_conv_mod_activation_type="relu", **_TT)
+    arch = [dict(type="conformer", d_hidden=64, d_ff=96, heads=4, macaron_style=True, use_conv_mod=True,
+                 conv_mod_kernel=7)]
+    return _trn_args(etype="transformer", enc_block_arch=arch, enc_block_repeat=2,
+                     transformer_enc_input_layer="conv2d", transformer_enc_self_attn_type="rel_self_attn",
+                     transformer_enc_positional_encoding_type="rel_pos", transformer_enc_pw_activation_type="swish",
+                     transformer_enc_conv_mod_activation_type="swish", dlayers=1)
+
+
+@pytest.mark.parametrize("name", _TRN_CASES)
 def test_transducer_golden(name):
     """encoder -> DecoderRNNT -> JointNetwork == reference modules; loss == float64 transducer recursion"""
     from espnet_amd.nets.e2e_asr_transducer import E2E
     p, sd, grads = split_golden(load_golden(name))
-    if "rnn" in name:
-        args = _trn_args()
-    elif "gru" in name:
-        args = _trn_args(etype="bgru", elayers=2, dtype="gru", dlayers=2)
-    else:
-        arch = [dict(type="conformer", d_hidden=64, d_ff=96, heads=4, macaron_style=True, use_conv_mod=True,
-                     conv_mod_kernel=7)]
-        args = _trn_args(etype="transformer", enc_block_arch=arch, enc_block_repeat=2,
-                         transformer_enc_input_layer="conv2d", transformer_enc_self_attn_type="rel_self_attn",
-                         transformer_enc_positional_encoding_type="rel_pos", transformer_enc_pw_activation_type="swish",
-                         transformer_enc_conv_mod_activation_type="swish", dlayers=1)
-    m = load_sd(E2E(12, 6, args), sd)
+    m = load_sd(E2E(12, 6, _trn_case_args(name)), sd)
     m.train()
     loss = m(p["xs"].to(DEV), p["ilens"], p["ys"].to(DEV))
     report(name + " hs_pad", m.hs_pad, p["hs_pad"], 1e-4)
@@ -287,7 +299,7 @@ def test_transducer_golden(name):
     check_grads(m, grads, tol=5e-4)
 
 
-@pytest.mark.parametrize("name", ["transducer_rnn.npz", "transducer_gru.npz", "transducer_conformer.npz"])
+@pytest.mark.parametrize("name", _TRN_CASES)
 def test_transducer_decoding_golden(name):
     """greedy, default, time-synchronous and alignment-length synchronous searches, with and without RNNLM fusion
     (beam_search_transducer.py:130-462) reproduce the reference's hypotheses:
@@ -295,17 +307,7 @@ def test_transducer_decoding_golden(name):
     from espnet_amd.nets.beam_search_transducer import BeamSearchTransducer
     from espnet_amd.nets.e2e_asr_transducer import E2E
     p, sd, _ = split_golden(load_golden(name))
-    if "rnn" in name:
-        args = _trn_args()
-    elif "gru" in name:
-        args = _trn_args(etype="bgru", elayers=2, dtype="gru", dlayers=2)
-    else:
-        arch = [dict(type="conformer", d_hidden=64, d_ff=96, heads=4, macaron_style=True, use_conv_mod=True,
-                     conv_mod_kernel=7)]
-        args = _trn_args(etype="transformer", enc_block_arch=arch, enc_block_repeat=2,
-                         transformer_enc_input_layer="conv2d", transformer_enc_self_attn_type="rel_self_attn",
-                         transformer_enc_positional_encoding_type="rel_pos", transformer_enc_pw_activation_type="swish",
-                         transformer_enc_conv_mod_activation_type="swish", dlayers=1)
+    args = _trn_case_args(name)
     m = load_sd(E2E(12, 6, args), sd)
     m.train()
     m(p["xs"].to(DEV), p["ilens"], p["ys"].to(DEV))      # as in the fixture: BatchNorm running stats see one training batch
@@ -328,7 +330,7 @@ def test_transducer_decoding_golden(name):
                     ("tsd3_lm", dict(beam_size=3, search_type="tsd", lm=lm, lm_weight=0.5, nstep=2)),
                     ("alsd3_lm", dict(beam_size=3, search_type="alsd", lm=lm, lm_weight=0.5, nstep=2)),
                     ("nsc3_lm", dict(beam_size=3, search_type="nsc", lm=lm, lm_weight=0.5, nstep=2))):
-        nb = m.recognize(x, BeamSearchTransducer(decoder=m.dec, **kw))
+        nb = m.recognize(x, BeamSearchTransducer(decoder=m.decoder if hasattr(m, "decoder") else m.dec, **kw))
         nb = nb if isinstance(nb, list) else [nb]
         lens = p["dec_%s_lens" % tag].tolist()
         want_scores = p["dec_%s_scores" % tag].tolist()
