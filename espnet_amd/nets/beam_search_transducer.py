@@ -57,6 +57,8 @@ class BeamSearchTransducer:
 
     def __call__(self, h):
         """h: encoded speech features (T_max, D_enc) -> 1-best Hypothesis (greedy) or sorted n-best list"""
+        if hasattr(self.decoder, "att"):          # rnnt-att: forget the previous utterance's encoder projections (:105-109)
+            self.decoder.att[0].reset()
         with torch.no_grad():
             return self.search_algorithm(h)
 

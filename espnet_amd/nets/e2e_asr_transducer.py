@@ -78,11 +78,17 @@ class E2E(ASRInterface, torch.nn.Module):
                                      dropout_rate_embed=args.dropout_rate_embed_decoder)
             self.most_dom_list = (self.most_dom_list if hasattr(self, "most_dom_list") else []) + args.dec_block_arch[:]
         else:
-            if getattr(args, "rnnt_mode", "rnnt") != "rnnt":
-                raise NotImplementedError("rnnt-att mode is outside the hot-path scope (SURVEY.md 8f)")
-            self.dec = DecoderRNNT(encoder_out, odim, args.dtype, args.dlayers, args.dunits, blank_id,
-                                   args.dec_embed_dim, args.joint_dim, args.joint_activation_type,
-                                   args.dropout_rate_decoder, args.dropout_rate_embed_decoder)
+            if getattr(args, "rnnt_mode", "rnnt") == "rnnt-att":
+                from .rnn.attentions import att_for
+                from .transducer.rnn_att_decoder import DecoderRNNTAtt
+                self.att = att_for(args)
+                self.dec = DecoderRNNTAtt(args.eprojs, odim, args.dtype, args.dlayers, args.dunits, blank_id, self.att,
+                                          args.dec_embed_dim, args.joint_dim, args.joint_activation_type,
+                                          args.dropout_rate_decoder, args.dropout_rate_embed_decoder)
+            else:
+                self.dec = DecoderRNNT(encoder_out, odim, args.dtype, args.dlayers, args.dunits, blank_id,
+                                       args.dec_embed_dim, args.joint_dim, args.joint_activation_type,
+                                       args.dropout_rate_decoder, args.dropout_rate_embed_decoder)
         if hasattr(self, "most_dom_list"):
             self.most_dom_dim = sorted(Counter(d["d_hidden"] for d in self.most_dom_list if "d_hidden" in d)
                                        .most_common(), key=lambda x: x[0], reverse=True)[0][0]
@@ -135,8 +141,10 @@ class E2E(ASRInterface, torch.nn.Module):
         if "transformer" in self.dtype:
             ys_mask = target_mask(ys_in_pad, self.blank_id)          # blank keys hidden + causal (e2e_asr_transducer.py:537)
             pred_pad, _ = self.decoder(ys_in_pad, ys_mask, hs_pad)
-        else:
+        elif self.rnnt_mode == "rnnt":
             pred_pad = self.dec(hs_pad, ys_in_pad)
+        else:
+            pred_pad = self.dec(hs_pad, ys_in_pad, hs_mask)      # host-side encoder lengths (pred_len on the device)
         self.pred_pad = pred_pad
         self.loss = self.criterion(pred_pad, target, pred_len, target_len)
         return self.loss

@@ -1,0 +1,109 @@
+"""RNN-Transducer prediction network with attention over the encoder states (`--rnnt-mode rnnt-att`).
+
+reference: espnet/nets/pytorch_backend/transducer/rnn_att_decoder.py:11-381 (DecoderRNNTAtt): at every label step an
+attention module (any of espnet_amd.nets.rnn.attentions) summarises the encoder states, the context is concatenated to
+the label embedding and fed to the LSTM / GRU cell stack; joint network as in DecoderRNNT.
+"""
+import torch
+
+from ... import functional as F_
+from ... import ops
+from ... import rnn_functional as R_
+from ..rnn.decoders import GRUCell, LSTMCell
+from .joint_network import JointNetwork
+
+
+class DecoderRNNTAtt(torch.nn.Module):
+    def __init__(self, eprojs, odim, dtype, dlayers, dunits, blank, att, embed_dim, joint_dim,
+                 joint_activation_type="tanh", dropout=0.0, dropout_embed=0.0):
+        super().__init__()
+        if dtype not in ("lstm", "gru"):
+            raise NotImplementedError("dtype %r: lstm and gru prediction networks have HIP kernels" % dtype)
+        self.embed = torch.nn.Embedding(odim, embed_dim, padding_idx=blank)
+        cell = LSTMCell if dtype == "lstm" else GRUCell
+        self.decoder = torch.nn.ModuleList([cell(embed_dim + eprojs, dunits)] + [cell(dunits, dunits) for _ in range(1, dlayers)])
+        self.joint_network = JointNetwork(odim, eprojs, dunits, joint_dim, joint_activation_type)
+        self.att = att
+        self.dtype, self.dlayers, self.dunits = dtype, dlayers, dunits
+        self.embed_dim, self.joint_dim, self.odim = embed_dim, joint_dim, odim
+        self.dropout, self.dropout_embed_rate = dropout, dropout_embed
+        self.ignore_id = -1
+        self.blank = blank
+        self.salt_emb = ops.new_salt()
+        self.salts = [ops.new_salt() for _ in range(dlayers + 1)]
+
+    def init_state(self, init_tensor):
+        z = [init_tensor.new_zeros(init_tensor.size(0), self.dunits) for _ in range(self.dlayers)]
+        c = [init_tensor.new_zeros(init_tensor.size(0), self.dunits) for _ in range(self.dlayers)]
+        return ((z, c), None)
+
+    def _drop(self, k, x, step):
+        return F_.dropout(x, self.dropout, self.salts[k] + 131 * (step + 1), self.training)
+
+    def rnn_forward(self, ey, state, step=0):
+        """rnn_att_decoder.py:95-130"""
+        z_prev, c_prev = state
+        (z_list, c_list), _ = self.init_state(ey)
+        if self.dtype == "lstm":
+            z_list[0], c_list[0] = self.decoder[0](ey, (z_prev[0], c_prev[0]))
+        else:
+            z_list[0] = self.decoder[0](ey, z_prev[0])
+        for i in range(1, self.dlayers):
+            x = self._drop(i - 1, z_list[i - 1], step)
+            if self.dtype == "lstm":
+                z_list[i], c_list[i] = self.decoder[i](x, (z_prev[i], c_prev[i]))
+            else:
+                z_list[i] = self.decoder[i](x, z_prev[i])
+        return self._drop(self.dlayers - 1, z_list[-1], step), (z_list, c_list)
+
+    def forward(self, hs_pad, ys_in_pad, hlens=None):
+        """hs_pad (B,Tmax,D), ys_in_pad (B,Lmax+1), hlens -> joint logits (B,T,U,odim)   (rnn_att_decoder.py:132-171)"""
+        olength = ys_in_pad.size(1)
+        hlens = [int(v) for v in hlens]
+        self.att[0].reset()
+        state, att_w = self.init_state(hs_pad)
+        eys = F_.dropout(R_.PlainEmbedFn.apply(ys_in_pad, self.embed.weight, self.blank), self.dropout_embed_rate,
+                         self.salt_emb, self.training)
+        z_all = []
+        for i in range(olength):
+            att_c, att_w = self.att[0](hs_pad, hlens, self._drop(self.dlayers, state[0][0], i), att_w)
+            ey = torch.cat((eys[:, i, :], att_c), dim=1)
+            y, state = self.rnn_forward(ey, state, step=i)
+            z_all.append(y)
+        return self.joint_network(hs_pad, torch.stack(z_all, dim=1))
+
+    def score(self, hyp, cache, init_tensor):
+        """one step for one hypothesis, cached by its label prefix (rnn_att_decoder.py:173-211);
+        state = ((z_list, c_list), attention state)"""
+        dev = self.embed.weight.device
+        vy = torch.full((1, 1), hyp.yseq[-1], dtype=torch.long, device=dev)
+        str_yseq = "".join([str(x) for x in hyp.yseq])
+        if str_yseq in cache:
+            y, state = cache[str_yseq]
+        else:
+            ey = R_.PlainEmbedFn.apply(vy, self.embed.weight, self.blank)
+            att_c, att_w = self.att[0](init_tensor, [init_tensor.size(1)], hyp.dec_state[0][0][0], hyp.dec_state[1])
+            ey = torch.cat((ey[0], att_c), dim=1)
+            y, dec_state = self.rnn_forward(ey, hyp.dec_state[0])
+            state = (dec_state, att_w)
+            cache[str_yseq] = (y, state)
+        return y, state, vy[0]
+
+    def batch_score(self, hyps, batch_states, cache, init_tensor):
+        raise NotImplementedError("rnnt-att: the batched searches (tsd / alsd / nsc) are not on the HIP path; the reference's "
+                                  "own batch_score feeds the attention a fresh zero state (rnn_att_decoder.py:252-262)")
+
+    def select_state(self, batch_states, idx):
+        """rnn_att_decoder.py:283-306"""
+        z_list = [batch_states[0][0][layer][idx] for layer in range(self.dlayers)]
+        c_list = [batch_states[0][1][layer][idx] for layer in range(self.dlayers)]
+        att_state = batch_states[1][idx] if batch_states[1] is not None else batch_states[1]
+        return ((z_list, c_list), att_state)
+
+    def create_batch_states(self, batch_states, l_states, l_tokens=None):
+        """rnn_att_decoder.py:308-336"""
+        for layer in range(self.dlayers):
+            batch_states[0][0][layer] = torch.stack([s[0][0][layer] for s in l_states])
+            batch_states[0][1][layer] = torch.stack([s[0][1][layer] for s in l_states])
+        att_states = torch.stack([s[1] for s in l_states]) if l_states[0][1] is not None else None
+        return (batch_states[0], att_states)

@@ -613,6 +613,8 @@ def main():
                              ("nsc3", dict(beam_size=3, search_type="nsc", nstep=1, prefix_alpha=1)),
                              ("nsc3n2", dict(beam_size=3, search_type="nsc", nstep=2, prefix_alpha=2)),
                              ("nsc2n3", dict(beam_size=2, search_type="nsc", nstep=3, prefix_alpha=1, score_norm=False))):
+                if d["rnnt_mode"] == "rnnt-att" and kw2.get("search_type", "default") != "default":
+                    continue      # the batched searches are not usable with the attention decoder's batch_score
                 bs = BeamSearchTransducer(decoder=m.decoder if hasattr(m, "decoder") else m.dec, lm=None, lm_weight=0.0, **kw2)
                 nb = m.recognize(xin, bs)
                 nb = nb if isinstance(nb, list) else [nb]
@@ -624,6 +626,8 @@ def main():
             torch.manual_seed(seed + 7)
             lm = ClassifierWithState(RNNLM(6, 1, 8, None, "lstm", 0.0)).eval()
             for tag, st in (("beam3_lm", "default"), ("tsd3_lm", "tsd"), ("alsd3_lm", "alsd"), ("nsc3_lm", "nsc")):
+                if d["rnnt_mode"] == "rnnt-att" and st != "default":
+                    continue
                 bs = BeamSearchTransducer(decoder=m.decoder if hasattr(m, "decoder") else m.dec, lm=lm, lm_weight=0.5, beam_size=3,
                                           search_type=st, nstep=2)
                 nb = m.recognize(xin, bs)
@@ -651,6 +655,9 @@ def main():
              transformer_enc_input_layer="conv2d", transformer_enc_self_attn_type="self_attn",
              transformer_enc_positional_encoding_type="abs_pos", transformer_enc_pw_activation_type="relu",
              transformer_enc_conv_mod_activation_type="relu", **tt_kw)
+    trn_case("transducer_att.npz", 46, rnnt_mode="rnnt-att", etype="blstmp", elayers=1, subsample="1_1", atype="location")
+    trn_case("transducer_att_gru.npz", 47, rnnt_mode="rnnt-att", etype="blstmp", elayers=1, subsample="1_1", dtype="gru",
+             dlayers=1, atype="multi_head_add")
     trn_case("transducer_conformer.npz", 42, etype="transformer", enc_block_arch=conf_arch, enc_block_repeat=2,
              transformer_enc_input_layer="conv2d", transformer_enc_self_attn_type="rel_self_attn",
              transformer_enc_positional_encoding_type="rel_pos", transformer_enc_pw_activation_type="swish",
