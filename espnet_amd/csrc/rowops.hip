@@ -295,6 +295,117 @@ __global__ __launch_bounds__(256) void softmax_fwd_kernel(const float* ac,
   }
 }
 
+// Vector form of the forward for bf16 probabilities and rows of at most 4 * 256 columns (ld % 4 == 0, 16-byte aligned
+// rows): a lane owns 4 adjacent columns per 256-column chunk, the whole row lives in registers (no LDS pass), the
+// scores are read as float4 and the probabilities leave as one 8-byte store per chunk - 2-byte stores run at a
+// fraction of the dword rate on gfx950.
+template <int NCH>
+__global__ __launch_bounds__(256) void softmax_fwd_vec_kernel(const float* __restrict__ ac, const float* __restrict__ bd,
+                                                              const unsigned char* __restrict__ mask, long mb, long mi,
+                                                              unsigned short* __restrict__ P16, int nb, int B, int T1,
+                                                              int T2, long ld, float scale) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const long rowid = (long)blockIdx.x * 4 + wave;
+  if (rowid >= (long)nb * T1) return;
+  const int z = rowid / T1, i = rowid % T1;
+  const int b = z % B;
+  const long ro = ((long)z * T1 + i) * ld;
+  const float* bdz = bd ? bd + (long)z * T1 * ld : nullptr;
+  const unsigned char* mr = mask ? mask + b * mb + i * mi : nullptr;
+  float v[NCH][4];
+  float mx = -INFINITY;
+#pragma unroll
+  for (int k = 0; k < NCH; ++k) {
+    const int j0 = 4 * lane + 256 * k;
+    float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (j0 < ld) a = *reinterpret_cast<const float4*>(ac + ro + j0);
+    const float av[4] = {a.x, a.y, a.z, a.w};
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const int j = j0 + e;
+      float x = -INFINITY;
+      if (j < T2) {
+        x = av[e];
+        if (bdz) x += shifted_bd(bdz, T1, T2, ld, i, j);
+        x *= scale;
+        if (mr && mr[j] == 0) x = -INFINITY;
+      }
+      v[k][e] = x;
+      mx = fmaxf(mx, x);
+    }
+  }
+  mx = wave_max(mx);
+  const bool dead = mx == -INFINITY;      // every key masked: softmax(min,...) = uniform, then masked_fill(0) -> zeros
+  float s = 0.f;
+#pragma unroll
+  for (int k = 0; k < NCH; ++k)
+#pragma unroll
+    for (int e = 0; e < 4; ++e) { const float ex = dead ? 0.f : __expf(v[k][e] - mx); v[k][e] = ex; s += ex; }
+  const float inv = dead ? 0.f : 1.f / wave_sum(s);
+#pragma unroll
+  for (int k = 0; k < NCH; ++k) {
+    const int j0 = 4 * lane + 256 * k;
+    if (j0 < ld) {
+      uint2 o;
+      o.x = (unsigned)eamd_f2bf(v[k][0] * inv) | ((unsigned)eamd_f2bf(v[k][1] * inv) << 16);
+      o.y = (unsigned)eamd_f2bf(v[k][2] * inv) | ((unsigned)eamd_f2bf(v[k][3] * inv) << 16);
+      *reinterpret_cast<uint2*>(P16 + ro + j0) = o;
+    }
+  }
+}
+
+// Vector form of the backward (bf16 P in, bf16 dS out): 8-byte P loads, float4 gradient loads, 8-byte dS stores; the
+// inverse rel-shift scatter into dbd keeps its 2-byte stores (its destination is shifted by one element per row).
+template <int NCH>
+__global__ __launch_bounds__(256) void softmax_bwd_vec_kernel(const unsigned short* __restrict__ P16,
+                                                              const float* __restrict__ dP,
+                                                              unsigned short* __restrict__ dS16,
+                                                              unsigned short* __restrict__ dbd16, int nb, int T1, int T2,
+                                                              long ld, float scale) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const long rowid = (long)blockIdx.x * 4 + wave;
+  if (rowid >= (long)nb * T1) return;
+  const int z = rowid / T1, i = rowid % T1;
+  const long ro = ((long)z * T1 + i) * ld;
+  const long zo = (long)z * T1 * ld;
+  float pv[NCH][4], dv[NCH][4];
+  float s = 0.f;
+#pragma unroll
+  for (int k = 0; k < NCH; ++k) {
+    const int j0 = 4 * lane + 256 * k;
+    uint2 pr = make_uint2(0u, 0u);
+    float4 d = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (j0 < ld) { pr = *reinterpret_cast<const uint2*>(P16 + ro + j0); d = *reinterpret_cast<const float4*>(dP + ro + j0); }
+    pv[k][0] = __uint_as_float(pr.x << 16); pv[k][1] = __uint_as_float(pr.x & 0xffff0000u);
+    pv[k][2] = __uint_as_float(pr.y << 16); pv[k][3] = __uint_as_float(pr.y & 0xffff0000u);
+    dv[k][0] = d.x; dv[k][1] = d.y; dv[k][2] = d.z; dv[k][3] = d.w;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) if (j0 + e < T2) s += pv[k][e] * dv[k][e];
+  }
+  s = wave_sum(s);
+#pragma unroll
+  for (int k = 0; k < NCH; ++k) {
+    const int j0 = 4 * lane + 256 * k;
+    if (j0 >= ld) continue;
+    unsigned short g16[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const int j = j0 + e;
+      const float g = j < T2 ? pv[k][e] * (dv[k][e] - s) * scale : 0.f;
+      g16[e] = eamd_f2bf(g);
+      if (dbd16 && j < T2) {
+        const int f = T1 + i * T2 + j;
+        const int r = f / (T2 + 1), c = f % (T2 + 1);
+        if (c != 0) dbd16[zo + (long)r * ld + (c - 1)] = g16[e];
+      }
+    }
+    uint2 o;
+    o.x = (unsigned)g16[0] | ((unsigned)g16[1] << 16);
+    o.y = (unsigned)g16[2] | ((unsigned)g16[3] << 16);
+    *reinterpret_cast<uint2*>(dS16 + ro + j0) = o;
+  }
+}
+
 // dS = P * (dP - sum_j dP*P) * scale, written over dP (d_ac); optional scatter of dS through the
 // inverse rel-shift into dbd (pre-zeroed by the caller).
 __global__ __launch_bounds__(256) void softmax_bwd_kernel(const float* __restrict__ P,
@@ -530,6 +641,19 @@ int eamd_softmax_fwd(const float* ac, const float* bd, const unsigned char* mask
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
     if (e != hipSuccess) return (int)e;
   }
+  // bf16 probabilities in their own buffer, rows of <= 1024 columns: register-resident vector form
+  const bool vec = P_bf16 && !P && ld % 4 == 0 && ld <= 1024 && (((uintptr_t)ac | (uintptr_t)P_bf16) & 15) == 0;
+  if (vec) {
+    const dim3 g((rows + 3) / 4), blk(256);
+    hipStream_t s = (hipStream_t)stream;
+    unsigned short* p16 = (unsigned short*)P_bf16;
+    const long mbs = (long)mask_bstride, mqs = (long)mask_qstride, l = (long)ld;
+    if (ld <= 256) hipLaunchKernelGGL(softmax_fwd_vec_kernel<1>, g, blk, 0, s, ac, bd, mask, mbs, mqs, p16, nblocks, B, T1, T2, l, scale);
+    else if (ld <= 512) hipLaunchKernelGGL(softmax_fwd_vec_kernel<2>, g, blk, 0, s, ac, bd, mask, mbs, mqs, p16, nblocks, B, T1, T2, l, scale);
+    else hipLaunchKernelGGL(softmax_fwd_vec_kernel<4>, g, blk, 0, s, ac, bd, mask, mbs, mqs, p16, nblocks, B, T1, T2, l, scale);
+    EAMD_LAUNCH_CHECK();
+    return EAMD_OK;
+  }
   hipLaunchKernelGGL(softmax_fwd_kernel, dim3((rows + 3) / 4), dim3(256), smem, (hipStream_t)stream, ac, bd,
                      mask, (long)mask_bstride, (long)mask_qstride, P, (unsigned short*)P_bf16, nblocks, B, T1, T2,
                      (long)ld, scale);
@@ -541,6 +665,20 @@ int eamd_softmax_bwd(const float* P, const void* P_bf16, float* dP, float* dbd, 
                      int nblocks, int T1, int T2, int64_t ld, float scale, void* stream) {
   if ((!P && !P_bf16) || !dP || nblocks <= 0 || T1 <= 0 || T2 <= 0 || ld < T2) return EAMD_EINVAL;
   long rows = (long)nblocks * T1;
+  const bool vec = P_bf16 && !P && dS_bf16 && !dbd && ld % 4 == 0 && ld <= 1024 &&
+                   (((uintptr_t)dP | (uintptr_t)P_bf16 | (uintptr_t)dS_bf16) & 15) == 0;
+  if (vec) {
+    const dim3 g((rows + 3) / 4), blk(256);
+    hipStream_t s = (hipStream_t)stream;
+    const unsigned short* p16 = (const unsigned short*)P_bf16;
+    unsigned short* ds = (unsigned short*)dS_bf16; unsigned short* db = (unsigned short*)dbd_bf16;
+    const long l = (long)ld;
+    if (ld <= 256) hipLaunchKernelGGL(softmax_bwd_vec_kernel<1>, g, blk, 0, s, p16, dP, ds, db, nblocks, T1, T2, l, scale);
+    else if (ld <= 512) hipLaunchKernelGGL(softmax_bwd_vec_kernel<2>, g, blk, 0, s, p16, dP, ds, db, nblocks, T1, T2, l, scale);
+    else hipLaunchKernelGGL(softmax_bwd_vec_kernel<4>, g, blk, 0, s, p16, dP, ds, db, nblocks, T1, T2, l, scale);
+    EAMD_LAUNCH_CHECK();
+    return EAMD_OK;
+  }
   hipLaunchKernelGGL(softmax_bwd_kernel, dim3((rows + 3) / 4), dim3(256), 0, (hipStream_t)stream, P,
                      (const unsigned short*)P_bf16, dP, dbd, (unsigned short*)dS_bf16, (unsigned short*)dbd_bf16,
                      nblocks, T1, T2, (long)ld, scale);

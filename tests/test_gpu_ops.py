@@ -231,6 +231,31 @@ def test_softmax_relshift_golden(ops, oracle):
     ops.softmax_bwd(P16, dP.reshape(-1).clone().to(DEV), dbd16, h * b, t1, t2, ld, 0.25, dS16=dS16)
     report("masked_softmax_bwd_ac_bf16", dS16.float().view(h, b, t1, ld)[..., :t2], acd.grad, 1e-2)
     report("masked_softmax_bwd_bd_bf16", dbd16.float().view(h, b, t1, ld)[..., :t2], bdd.grad, 1e-2)
+    # register-resident vector form (bf16 storage, 1 / 2 / 4 chunks of 256 columns) against the fp32 kernels
+    for (t1, t2, ld) in ((249, 249, 256), (300, 300, 304), (130, 600, 600)):
+        b, h = 2, 2
+        ac = torch.randn(h * b * t1 * ld, generator=g).to(DEV)
+        bdm = torch.randn(h * b * t1 * ld, generator=g).to(DEV) if t1 == t2 else None
+        mask = (torch.rand(b, 1, t2, generator=g) > 0.1).to(torch.uint8)
+        mask[0, 0, :] = 1
+        dP = torch.randn(h * b * t1 * ld, generator=g).to(DEV)
+        P32 = torch.empty(h * b * t1 * ld, device=DEV)
+        ops.softmax_fwd(ac, bdm, mask.to(DEV), P32, h * b, b, t1, t2, ld, 0.125)
+        P16 = torch.empty(h * b * t1 * ld, device=DEV, dtype=torch.bfloat16)
+        ops.softmax_fwd(ac, bdm, mask.to(DEV), P16, h * b, b, t1, t2, ld, 0.125)
+        # same values up to the summation order of the row sum, rounded once: 1 bf16 ulp
+        report("softmax_fwd vec %dx%d" % (t1, t2), P16.float(), P32, 3e-3)
+        assert torch.equal(P16 == 0, P32.to(torch.bfloat16) == 0) or float(((P16 == 0) != (P32.to(torch.bfloat16) == 0)).sum()) < 8
+        dS32, dbd32 = dP.clone(), torch.zeros(h * b * t1 * ld, device=DEV)
+        ops.softmax_bwd(P16.float(), dS32, dbd32 if bdm is not None else None, h * b, t1, t2, ld, 0.125)
+        dS16 = torch.empty_like(P16)
+        dbd16 = torch.zeros_like(P16) if bdm is not None else None
+        ops.softmax_bwd(P16, dP.clone(), dbd16, h * b, t1, t2, ld, 0.125, dS16=dS16)
+        v = lambda x: x.float().view(h * b, t1, ld)[..., :t2]                          # noqa: E731
+        report("softmax_bwd vec %dx%d" % (t1, t2), v(dS16), v(dS32), 4e-3)
+        assert float(dS16.float().view(h * b, t1, ld)[..., t2:].abs().sum()) == 0.0
+        if bdm is not None:
+            report("softmax_bwd vec dbd %dx%d" % (t1, t2), dbd16.float(), dbd32, 4e-3)
 
 
 def test_lsm_loss_golden(ops):
