@@ -134,6 +134,52 @@ __global__ void add_cast_kernel(const float* __restrict__ a, const float* __rest
     o[(i / cols) * ld_out + i % cols] = eamd_f2bf(a[i] + (b ? b[i] : 0.f));
 }
 
+// ---- two adjacent columns per thread for the bf16-storage variants (dword stores; all widths even) ----------------
+__device__ __forceinline__ unsigned eamd_pack2(float a, float b) {
+  return (unsigned)eamd_f2bf(a) | ((unsigned)eamd_f2bf(b) << 16);
+}
+__global__ void glu_bwd_x2_kernel(const float* __restrict__ dy, const float* __restrict__ x, unsigned int* __restrict__ dx32,
+                                  long rows, int C) {
+  const int CW = C / 2;
+  const long n = rows * CW;
+  const long stride = (long)gridDim.x * blockDim.x;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+    const long r = i / CW; const int c = 2 * (int)(i % CW);
+    const float2 a = *reinterpret_cast<const float2*>(x + r * 2 * C + c);
+    const float2 g = *reinterpret_cast<const float2*>(x + r * 2 * C + C + c);
+    const float2 d = *reinterpret_cast<const float2*>(dy + r * C + c);
+    const float s0 = eamd_sigmoid(g.x), s1 = eamd_sigmoid(g.y);
+    dx32[(r * 2 * C + c) >> 1] = eamd_pack2(d.x * s0, d.y * s1);
+    dx32[(r * 2 * C + C + c) >> 1] = eamd_pack2(d.x * a.x * s0 * (1.f - s0), d.y * a.y * s1 * (1.f - s1));
+  }
+}
+__global__ void add_bias2_x2_kernel(const unsigned int* __restrict__ q32, const float* __restrict__ u,
+                                    const float* __restrict__ v, unsigned int* __restrict__ qu32,
+                                    unsigned int* __restrict__ qv32, long rows, int D, long ldq) {
+  const int DW = D / 2;
+  const long n = rows * DW;
+  const long stride = (long)gridDim.x * blockDim.x;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+    const int d = 2 * (int)(i % DW);
+    const unsigned w = q32[((i / DW) * ldq + d) >> 1];
+    const float x0 = __uint_as_float(w << 16), x1 = __uint_as_float(w & 0xffff0000u);
+    qu32[i] = eamd_pack2(x0 + u[d], x1 + u[d + 1]);
+    qv32[i] = eamd_pack2(x0 + v[d], x1 + v[d + 1]);
+  }
+}
+__global__ void add_cast_x2_kernel(const float* __restrict__ a, const float* __restrict__ b, unsigned int* __restrict__ o32,
+                                   long n2, int cols, long ld_out) {
+  const int CW = cols / 2;
+  const long stride = (long)gridDim.x * blockDim.x;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n2; i += stride) {
+    const long r = i / CW; const int c = 2 * (int)(i % CW);
+    const float2 av = *reinterpret_cast<const float2*>(a + r * cols + c);
+    float2 bv = make_float2(0.f, 0.f);
+    if (b) bv = *reinterpret_cast<const float2*>(b + r * cols + c);
+    o32[(r * ld_out + c) >> 1] = eamd_pack2(av.x + bv.x, av.y + bv.y);
+  }
+}
+
 // Column sums of a [rows, D] matrix, ADDED into out[D] (bias gradients).  Each block reduces a slab
 // of rows with threads along columns (coalesced) and issues one atomic per column.
 __global__ __launch_bounds__(256) void colsum_kernel(const float* __restrict__ x, long ld, float* __restrict__ out,
@@ -166,6 +212,28 @@ __global__ __launch_bounds__(256) void colsum_kernel(const float* __restrict__ x
     for (; r < r1; ++r) s += x[r * ld + c];
   }
   atomicAdd(&out[c], s * scale);
+}
+
+// bf16 input, two adjacent columns per thread read as one dword (D, ld even; 4-byte aligned base)
+__global__ __launch_bounds__(256) void colsum_bf16x2_kernel(const unsigned int* __restrict__ x, long ldw,
+                                                            float* __restrict__ out, long rows, int D,
+                                                            int rows_per_block, float scale) {
+  const long r0 = (long)blockIdx.y * rows_per_block;
+  const long r1 = min(rows, r0 + (long)rows_per_block);
+  const int cw = blockIdx.x * blockDim.x + threadIdx.x;       // column pair
+  if (2 * cw >= D) return;
+  float s0 = 0.f, s1 = 0.f;
+  long r = r0;
+  for (; r + 8 <= r1; r += 8) {
+    unsigned v[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) v[u] = x[(r + u) * ldw + cw];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) { s0 += __uint_as_float(v[u] << 16); s1 += __uint_as_float(v[u] & 0xffff0000u); }
+  }
+  for (; r < r1; ++r) { const unsigned v = x[r * ldw + cw]; s0 += __uint_as_float(v << 16); s1 += __uint_as_float(v & 0xffff0000u); }
+  atomicAdd(&out[2 * cw], s0 * scale);
+  atomicAdd(&out[2 * cw + 1], s1 * scale);
 }
 
 // Embedding lookup * scale + absolute positional encoding.
@@ -240,6 +308,41 @@ __global__ void dropout_kernel(const float* __restrict__ x, float* __restrict__ 
     const unsigned h = eamd_drop_bits(seed, (unsigned long long)i);
     v = h >= thr ? v * inv : 0.f;
     if (out_bf16) y16[i] = eamd_f2bf(v); else y[i] = v;
+  }
+}
+// four elements per thread: float4 / 8-byte bf16 accesses (2-byte loads and stores run at a fraction of the dword
+// rate on gfx950); the mask of element i is the same hash as in the scalar kernel
+__global__ void dropout_vec4_kernel(const float* __restrict__ x, float* __restrict__ y, long n4, float p,
+                                    const unsigned long long* __restrict__ step, unsigned long long salt, int act,
+                                    int in_bf16, int out_bf16) {
+  const float inv = 1.f / (1.f - p);
+  const unsigned thr = (unsigned)fminf(p * 4294967296.0f, 4294967040.0f);
+  const unsigned seed = eamd_drop_seed(step, salt);
+  const long stride = (long)gridDim.x * blockDim.x;
+  for (long q = (long)blockIdx.x * blockDim.x + threadIdx.x; q < n4; q += stride) {
+    float v[4];
+    if (in_bf16) {
+      const uint2 r = reinterpret_cast<const uint2*>(x)[q];
+      v[0] = __uint_as_float(r.x << 16); v[1] = __uint_as_float(r.x & 0xffff0000u);
+      v[2] = __uint_as_float(r.y << 16); v[3] = __uint_as_float(r.y & 0xffff0000u);
+    } else {
+      const float4 r = reinterpret_cast<const float4*>(x)[q];
+      v[0] = r.x; v[1] = r.y; v[2] = r.z; v[3] = r.w;
+    }
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const float a = eamd_act(v[e], act);
+      const unsigned h = eamd_drop_bits(seed, (unsigned long long)(4 * q + e));
+      v[e] = h >= thr ? a * inv : 0.f;
+    }
+    if (out_bf16) {
+      uint2 o;
+      o.x = (unsigned)eamd_f2bf(v[0]) | ((unsigned)eamd_f2bf(v[1]) << 16);
+      o.y = (unsigned)eamd_f2bf(v[2]) | ((unsigned)eamd_f2bf(v[3]) << 16);
+      reinterpret_cast<uint2*>(y)[q] = o;
+    } else {
+      reinterpret_cast<float4*>(y)[q] = make_float4(v[0], v[1], v[2], v[3]);
+    }
   }
 }
 __global__ void rng_advance_kernel(unsigned long long* step) {
@@ -362,6 +465,12 @@ int eamd_glu_fwd(const float* x, float* y, int64_t rows, int C, void* stream) {
 
 int eamd_glu_bwd(const float* dy, const float* x, float* dx, void* dx_bf16, int64_t rows, int C, void* stream) {
   if (!dy || !x || (!dx && !dx_bf16) || rows <= 0 || C <= 0) return EAMD_EINVAL;
+  if (dx_bf16 && C % 2 == 0 && (((uintptr_t)dy | (uintptr_t)x) & 7) == 0 && ((uintptr_t)dx_bf16 & 3) == 0) {
+    hipLaunchKernelGGL(glu_bwd_x2_kernel, dim3(grid_for(rows * C / 2)), dim3(256), 0, (hipStream_t)stream, dy, x,
+                       (unsigned int*)dx_bf16, (long)rows, C);
+    EAMD_LAUNCH_CHECK();
+    return EAMD_OK;
+  }
   hipLaunchKernelGGL(glu_bwd_kernel, dim3(grid_for(rows * C)), dim3(256), 0, (hipStream_t)stream, dy, x, dx,
                      (unsigned short*)dx_bf16, (long)rows, C);
   EAMD_LAUNCH_CHECK();
@@ -372,6 +481,12 @@ int eamd_add_cast_bf16(const float* a, const float* b, void* out_bf16, int64_t r
                        void* stream) {
   if (!a || !out_bf16 || rows <= 0 || cols <= 0 || ld_out < cols) return EAMD_EINVAL;
   const long n = (long)rows * cols;
+  if (cols % 2 == 0 && ld_out % 2 == 0 && (((uintptr_t)a | (uintptr_t)b) & 7) == 0 && ((uintptr_t)out_bf16 & 3) == 0) {
+    hipLaunchKernelGGL(add_cast_x2_kernel, dim3(grid_for(n / 2)), dim3(256), 0, (hipStream_t)stream, a, b,
+                       (unsigned int*)out_bf16, n / 2, cols, (long)ld_out);
+    EAMD_LAUNCH_CHECK();
+    return EAMD_OK;
+  }
   hipLaunchKernelGGL(add_cast_kernel, dim3(grid_for(n)), dim3(256), 0, (hipStream_t)stream, a, b,
                      (unsigned short*)out_bf16, n, cols, (long)ld_out);
   EAMD_LAUNCH_CHECK();
@@ -381,6 +496,12 @@ int eamd_add_cast_bf16(const float* a, const float* b, void* out_bf16, int64_t r
 int eamd_add_bias2(const void* q, int64_t ldq, const float* u, const float* v, void* qu, void* qv, int64_t rows, int D,
                    int bf16, void* stream) {
   if (!q || !u || !v || !qu || !qv || rows <= 0 || D <= 0 || ldq < D) return EAMD_EINVAL;
+  if (bf16 && D % 2 == 0 && ldq % 2 == 0 && (((uintptr_t)q | (uintptr_t)qu | (uintptr_t)qv) & 3) == 0) {
+    hipLaunchKernelGGL(add_bias2_x2_kernel, dim3(grid_for(rows * D / 2)), dim3(256), 0, (hipStream_t)stream,
+                       (const unsigned int*)q, u, v, (unsigned int*)qu, (unsigned int*)qv, (long)rows, D, (long)ldq);
+    EAMD_LAUNCH_CHECK();
+    return EAMD_OK;
+  }
   hipLaunchKernelGGL(add_bias2_kernel, dim3(grid_for(rows * D)), dim3(256), 0, (hipStream_t)stream, (const float*)q, u,
                      v, (float*)qu, (float*)qv, (long)rows, D, bf16, (long)ldq);
   EAMD_LAUNCH_CHECK();
@@ -389,12 +510,24 @@ int eamd_add_bias2(const void* q, int64_t ldq, const float* u, const float* v, v
 
 int eamd_colsum(const void* x, int64_t ld, float* out, int64_t rows, int D, float scale, int bf16, void* stream) {
   if (!x || !out || rows <= 0 || D <= 0) return EAMD_EINVAL;
-  int gx = (D + 255) / 256;
+  const bool pair = bf16 && D % 2 == 0 && ld % 2 == 0 && ((uintptr_t)x & 3) == 0;
+  const int ncol = pair ? D / 2 : D;                      // threads needed along the columns
+  const int nthr = 256;
+  const int gx = (ncol + nthr - 1) / nthr;
   static const int min_rpb = [] { const char* e = getenv("EAMD_COLSUM_RPB"); return e ? atoi(e) : 128; }();
+  // ~1024 workgroups: more of them only lengthen the same-address atomic chains (measured: 2048 blocks on a
+  // [151k, 256] bf16 matrix take 109 us, 1024 take 61 us)
   long want = 1024 / gx; if (want < 1) want = 1;
-  long rpb = (rows + want - 1) / want; if (rpb < min_rpb) rpb = min_rpb;
-  int gy = (int)((rows + rpb - 1) / rpb);
-  hipLaunchKernelGGL(colsum_kernel, dim3(gx, gy), dim3(256), 0, (hipStream_t)stream, (const float*)x, (long)ld, out,
+  long rpb = (rows + want - 1) / want; if (rpb < (pair ? min_rpb / 2 : min_rpb)) rpb = pair ? min_rpb / 2 : min_rpb;
+  if (rpb < 8) rpb = 8;
+  const int gy = (int)((rows + rpb - 1) / rpb);
+  if (pair) {
+    hipLaunchKernelGGL(colsum_bf16x2_kernel, dim3(gx, gy), dim3(nthr), 0, (hipStream_t)stream, (const unsigned int*)x,
+                       (long)(ld / 2), out, (long)rows, D, (int)rpb, scale);
+    EAMD_LAUNCH_CHECK();
+    return EAMD_OK;
+  }
+  hipLaunchKernelGGL(colsum_kernel, dim3(gx, gy), dim3(nthr), 0, (hipStream_t)stream, (const float*)x, (long)ld, out,
                      (long)rows, D, (int)rpb, scale, bf16);
   EAMD_LAUNCH_CHECK();
   return EAMD_OK;
@@ -441,6 +574,13 @@ int eamd_dropout(const void* x, void* y, int64_t n, float p, const uint64_t* ste
                  int in_bf16, int out_bf16, void* stream) {
   if (!x || !y || n < 0 || p < 0.f || p >= 1.f) return EAMD_EINVAL;
   if (n == 0) return EAMD_OK;
+  if (n % 4 == 0 && (((uintptr_t)x | (uintptr_t)y) & 15) == 0) {
+    hipLaunchKernelGGL(dropout_vec4_kernel, dim3(grid_for(n / 4)), dim3(256), 0, (hipStream_t)stream, (const float*)x,
+                       (float*)y, (long)(n / 4), p, (const unsigned long long*)step_dev, (unsigned long long)salt, act,
+                       in_bf16, out_bf16);
+    EAMD_LAUNCH_CHECK();
+    return EAMD_OK;
+  }
   hipLaunchKernelGGL(dropout_kernel, dim3(grid_for(n)), dim3(256), 0, (hipStream_t)stream, (const float*)x, (float*)y,
                      (long)n, p, (const unsigned long long*)step_dev, (unsigned long long)salt, act, in_bf16, out_bf16);
   EAMD_LAUNCH_CHECK();

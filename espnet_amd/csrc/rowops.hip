@@ -320,16 +320,20 @@ __global__ __launch_bounds__(256) void softmax_fwd_vec_kernel(const float* __res
     float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
     if (j0 < ld) a = *reinterpret_cast<const float4*>(ac + ro + j0);
     const float av[4] = {a.x, a.y, a.z, a.w};
+    // rel-shift source of column j0 (one division per chunk; the next columns step through the (T2+1)-wide rows)
+    int sr = 0, sc = 0;
+    if (bdz) { const int f = T1 + i * T2 + j0; sr = f / (T2 + 1); sc = f % (T2 + 1); }
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
       const int j = j0 + e;
       float x = -INFINITY;
       if (j < T2) {
         x = av[e];
-        if (bdz) x += shifted_bd(bdz, T1, T2, ld, i, j);
+        if (bdz && sc != 0) x += bdz[(long)sr * ld + (sc - 1)];
         x *= scale;
         if (mr && mr[j] == 0) x = -INFINITY;
       }
+      if (++sc > T2) { sc = 0; ++sr; }
       v[k][e] = x;
       mx = fmaxf(mx, x);
     }
