@@ -1,7 +1,7 @@
 """VGG / (B)LSTM(P) encoders.  reference: espnet/nets/pytorch_backend/rnn/encoders.py (same class names,
 constructor arguments and parameter names; torch.nn.LSTM containers are replaced by `LSTM` below, whose
-parameters carry torch.nn.LSTM's names so reference checkpoints load key-for-key).  GRU variants have no
-HIP kernel yet and raise NotImplementedError."""
+parameters carry torch.nn.LSTM's names so reference checkpoints load key-for-key).  LSTM and GRU cells, with
+and without projection layers and frame subsampling, are on the HIP path."""
 import math
 
 import numpy as np
