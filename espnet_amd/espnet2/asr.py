@@ -267,6 +267,9 @@ def register_choices(asr_task_module):
     asr_task_module.encoder_choices.classes["conformer_mi355x"] = ConformerEncoder
     asr_task_module.encoder_choices.classes["transformer_mi355x"] = TransformerEncoder
     asr_task_module.decoder_choices.classes["transformer_mi355x"] = TransformerDecoder
+    from .rnn import RNNEncoder, VGGRNNEncoder
+    asr_task_module.encoder_choices.classes["rnn_mi355x"] = RNNEncoder
+    asr_task_module.encoder_choices.classes["vgg_rnn_mi355x"] = VGGRNNEncoder
     from .frontend import DefaultFrontend
     from .layers import GlobalMVN, SpecAug, UtteranceMVN
     asr_task_module.frontend_choices.classes["default_mi355x"] = DefaultFrontend

@@ -403,6 +403,27 @@ def main():
         save(out("pw_%s.npz" % tag), xs=xs_pw, ilens=il_pw, y=y_pw.detach(), olens=ol_pw, gy=gy_pw, **sd_pw,
              **grads_np(enc_pw))
 
+    # ---- espnet2 RNN encoders (RNNEncoder, VGGRNNEncoder) ----------------------------------------------------------------
+    from espnet2.asr.encoder.rnn_encoder import RNNEncoder
+    from espnet2.asr.encoder.vgg_rnn_encoder import VGGRNNEncoder
+    for tag, cls, kw in (("rnnp", RNNEncoder, dict(num_layers=3, hidden_size=12, output_size=10, subsample=(2, 1))),
+                         ("gru", RNNEncoder, dict(rnn_type="gru", bidirectional=False, use_projection=False, num_layers=2,
+                                                  hidden_size=12, output_size=10, subsample=None)),
+                         ("vgg", VGGRNNEncoder, dict(num_layers=1, hidden_size=12, output_size=10))):
+        torch.manual_seed(37)
+        enc_r = cls(20, **kw)
+        enc_r.train()
+        sd_r = sd_np(enc_r, "sd/")
+        gp = torch.Generator().manual_seed(6)
+        xs_r = torch.randn(3, 41, 20, generator=gp)
+        il_r = torch.tensor([41, 30, 17])
+        xs_r = xs_r * (torch.arange(41).view(1, -1, 1) < il_r.view(-1, 1, 1))
+        y_r, ol_r, _ = enc_r(xs_r, il_r)
+        gy_r = torch.randn(y_r.shape, generator=gp)
+        (y_r * gy_r).sum().backward()
+        save(out("enc2_%s.npz" % tag), xs=xs_r, ilens=il_r, y=y_r.detach(), olens=torch.as_tensor(ol_r), gy=gy_r, **sd_r,
+             **grads_np(enc_r))
+
     # ---- a19 / f2: BatchBeamSearch, and LM shallow fusion (TransformerLM, SequentialRNNLM) ----------
     from espnet.nets.batch_beam_search import BatchBeamSearch
     from espnet.nets.beam_search import BeamSearch as RefBeamSearch

@@ -398,3 +398,24 @@ def test_rnn_decoding_golden(name, idim, kw):
             o += n
         print("[parity] %s %s: %d hypotheses identical, best %.5f (ref %.5f)" % (name, tag, len(nb), float(nb[0]["score"]),
                                                                                scores[0]))
+
+
+@pytest.mark.parametrize("tag,cls,kw", [
+    ("rnnp", "RNNEncoder", dict(num_layers=3, hidden_size=12, output_size=10, subsample=(2, 1))),
+    ("gru", "RNNEncoder", dict(rnn_type="gru", bidirectional=False, use_projection=False, num_layers=2, hidden_size=12,
+                               output_size=10, subsample=None)),
+    ("vgg", "VGGRNNEncoder", dict(num_layers=1, hidden_size=12, output_size=10))])
+def test_espnet2_rnn_encoders_golden(tag, cls, kw):
+    """espnet2 RNNEncoder / VGGRNNEncoder (the espnet1 stacks behind AbsEncoder): outputs, lengths and all parameter
+    gradients against the reference's own encoders"""
+    import espnet_amd.espnet2 as e2
+    p, sd, grads = split_golden(load_golden("enc2_%s.npz" % tag))
+    enc = getattr(e2, cls)(20, **kw)
+    assert list(enc.state_dict().keys()) == list(sd.keys())
+    enc = load_sd(enc, sd)
+    enc.train()
+    y, olens, _ = enc(p["xs"].to(DEV), p["ilens"])
+    assert olens.tolist() == p["olens"].tolist() and enc.output_size() == 10
+    report("espnet2 %s fwd" % tag, y, p["y"], 2e-5)
+    y.backward(p["gy"].to(DEV))
+    check_grads(enc, grads, tol=5e-4)
