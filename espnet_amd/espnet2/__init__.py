@@ -4,4 +4,4 @@ from .layers import GlobalMVN, MaskAlongAxis, SpecAug, TimeWarp, UtteranceMVN  #
 from .lm import SequentialRNNLM, TransformerLM, register_lm_choices  # noqa: F401,E402
 from .asr_inference import Speech2Text  # noqa: F401,E402
 from .frontend import DefaultFrontend, LogMel, Stft  # noqa: F401,E402
-from .rnn import RNNEncoder, VGGRNNEncoder  # noqa: F401,E402
+from .rnn import RNNDecoder, RNNEncoder, VGGRNNEncoder  # noqa: F401,E402

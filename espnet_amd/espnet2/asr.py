@@ -267,7 +267,8 @@ def register_choices(asr_task_module):
     asr_task_module.encoder_choices.classes["conformer_mi355x"] = ConformerEncoder
     asr_task_module.encoder_choices.classes["transformer_mi355x"] = TransformerEncoder
     asr_task_module.decoder_choices.classes["transformer_mi355x"] = TransformerDecoder
-    from .rnn import RNNEncoder, VGGRNNEncoder
+    from .rnn import RNNDecoder, RNNEncoder, VGGRNNEncoder
+    asr_task_module.decoder_choices.classes["rnn_mi355x"] = RNNDecoder
     asr_task_module.encoder_choices.classes["rnn_mi355x"] = RNNEncoder
     asr_task_module.encoder_choices.classes["vgg_rnn_mi355x"] = VGGRNNEncoder
     from .frontend import DefaultFrontend

@@ -99,7 +99,11 @@ class BeamSearch(torch.nn.Module):
         weighted = torch.zeros(n, V, device=dev, dtype=torch.float32)
         scores, states = {}, {}
         for k, d in self.full_scorers.items():
-            scores[k], states[k] = d.batch_score(ys, [h.states[k] for h in running_hyps], xs)
+            if hasattr(d, "batch_score"):
+                scores[k], states[k] = d.batch_score(ys, [h.states[k] for h in running_hyps], xs)
+            else:      # a plain ScorerInterface (e.g. the attention RNN decoder): hypothesis by hypothesis
+                sc, st = zip(*[d.score(ys[i], running_hyps[i].states[k], x) for i in range(n)])
+                scores[k], states[k] = torch.stack(sc), list(st)
             weighted += self.weights[k] * scores[k]
         part_ids = None
         if self.do_pre_beam:

@@ -424,6 +424,43 @@ def main():
         save(out("enc2_%s.npz" % tag), xs=xs_r, ilens=il_r, y=y_r.detach(), olens=torch.as_tensor(ol_r), gy=gy_r, **sd_r,
              **grads_np(enc_r))
 
+    # ---- espnet2 RNN model: RNNEncoder + attention RNNDecoder + CTC inside ESPnetASRModel, loss and BeamSearch n-best ------
+    from espnet2.asr.decoder.rnn_decoder import RNNDecoder
+    from espnet.nets.beam_search import BeamSearch as RefBeamSearch
+    from espnet.nets.scorers.ctc import CTCPrefixScorer as RefCTCScorer
+    from espnet.nets.scorers.length_bonus import LengthBonus as RefLengthBonus
+    for tag, dkw in (("loc", dict(rnn_type="lstm", num_layers=2, att_conf=dict(atype="location", adim=8, aconv_chans=3,
+                                                                              aconv_filts=4))),
+                     ("mh", dict(rnn_type="gru", num_layers=1, context_residual=True,
+                                 att_conf=dict(atype="multi_head_add", adim=8, aheads=2)))):
+        torch.manual_seed(39)
+        enc_m = RNNEncoder(20, num_layers=2, hidden_size=12, output_size=10, subsample=(2, 1))
+        dec_m = RNNDecoder(30, 10, hidden_size=12, **dkw)
+        m3 = ESPnetASRModel(vocab_size=30, token_list=["<blank>"] + [str(i) for i in range(1, 28)] + ["<space>", "<sos/eos>"],
+                            frontend=None, specaug=None, normalize=None, encoder=enc_m, decoder=dec_m,
+                            ctc=CTC2(30, 10, ctc_type="builtin"), rnnt_decoder=None, ctc_weight=0.3, lsm_weight=0.1,
+                            length_normalized_loss=False)
+        m3.train()
+        sd3 = sd_np(m3, "sd/")
+        loss3, stats3, w3 = m3(speech, slen, text, tlen)
+        loss3.backward()
+        m3.eval()
+        res3 = {}
+        with torch.no_grad():
+            enc3, _ = m3.encode(speech[:1], slen[:1])
+            for btag, cw in (("w00", 0.0), ("w03", 0.3)):
+                scorers = dict(decoder=m3.decoder, ctc=RefCTCScorer(ctc=m3.ctc, eos=m3.eos), length_bonus=RefLengthBonus(30))
+                bs = RefBeamSearch(beam_size=3, vocab_size=30, weights=dict(decoder=1.0 - cw, ctc=cw, length_bonus=0.1),
+                                   scorers=scorers, sos=m3.sos, eos=m3.eos, token_list=None,
+                                   pre_beam_score_key=None if cw == 1.0 else "full")
+                nb = bs(x=enc3[0], maxlenratio=0.0, minlenratio=0.0)[:3]
+                res3["beam_%s_scores" % btag] = np.asarray([float(h.score) for h in nb], dtype=np.float64)
+                res3["beam_%s_lens" % btag] = np.asarray([len(h.yseq) for h in nb], dtype=np.int64)
+                res3["beam_%s_yseq" % btag] = np.asarray(sum([[int(t) for t in h.yseq] for h in nb], []), dtype=np.int64)
+        save(out("espnet2_rnn_%s.npz" % tag), speech=speech, speech_lengths=slen, text=text, text_lengths=tlen,
+             loss=loss3.detach(), loss_att=stats3["loss_att"], loss_ctc=stats3["loss_ctc"], acc=float(stats3["acc"]), **res3,
+             **sd3, **grads_np(m3))
+
     # ---- a19 / f2: BatchBeamSearch, and LM shallow fusion (TransformerLM, SequentialRNNLM) ----------
     from espnet.nets.batch_beam_search import BatchBeamSearch
     from espnet.nets.beam_search import BeamSearch as RefBeamSearch

@@ -419,3 +419,47 @@ def test_espnet2_rnn_encoders_golden(tag, cls, kw):
     report("espnet2 %s fwd" % tag, y, p["y"], 2e-5)
     y.backward(p["gy"].to(DEV))
     check_grads(enc, grads, tol=5e-4)
+
+
+@pytest.mark.parametrize("tag,dkw", [
+    ("loc", dict(rnn_type="lstm", num_layers=2, att_conf=dict(atype="location", adim=8, aconv_chans=3, aconv_filts=4))),
+    ("mh", dict(rnn_type="gru", num_layers=1, context_residual=True, att_conf=dict(atype="multi_head_add", adim=8, aheads=2)))])
+def test_espnet2_rnn_model_golden(tag, dkw):
+    """ESPnetASRModel(RNNEncoder, attention RNNDecoder, CTC): loss, stats, all parameter gradients and the BeamSearch n-best
+    (the decoder is a plain ScorerInterface: scored hypothesis by hypothesis) against the reference's own espnet2 model"""
+    from espnet_amd.espnet2 import CTC, ESPnetASRModel, RNNDecoder, RNNEncoder
+    from espnet_amd.nets.beam_search import BeamSearch
+    from espnet_amd.nets.ctc_prefix_score import CTCPrefixScorer, LengthBonus
+    p, sd, grads = split_golden(load_golden("espnet2_rnn_%s.npz" % tag))
+    model = ESPnetASRModel(vocab_size=30, encoder=RNNEncoder(20, num_layers=2, hidden_size=12, output_size=10, subsample=(2, 1)),
+                           decoder=RNNDecoder(30, 10, hidden_size=12, **dkw), ctc=CTC(30, 10, ctc_type="builtin"),
+                           ctc_weight=0.3, lsm_weight=0.1)
+    assert list(model.state_dict().keys()) == list(sd.keys())
+    model = load_sd(model, sd)
+    model.train()
+    loss, stats, weight = model(p["speech"].to(DEV), p["speech_lengths"], p["text"].to(DEV), p["text_lengths"])
+    for k in ("loss", "loss_att", "loss_ctc"):
+        got, want = float(stats[k]), float(p[k])
+        print("[parity] espnet2 rnn %s %s hip %.6f ref %.6f" % (tag, k, got, want))
+        assert abs(got - want) <= 1e-5 * abs(want)
+    assert abs(float(stats["acc"]) - float(p["acc"])) < 1e-6
+    loss.backward()
+    check_grads(model, grads, tol=5e-4)
+    model.eval()
+    with torch.no_grad():
+        enc, _ = model.encode(p["speech"][:1].to(DEV), p["speech_lengths"][:1])
+    for btag, cw in (("w00", 0.0), ("w03", 0.3)):
+        scorers = dict(decoder=model.decoder, ctc=CTCPrefixScorer(model.ctc, model.eos), length_bonus=LengthBonus(30))
+        bs = BeamSearch(scorers, dict(decoder=1.0 - cw, ctc=cw, length_bonus=0.1), 3, 30, model.sos, model.eos,
+                        pre_beam_score_key="full")
+        got = bs(enc[0])[:3]
+        lens, flat, scores = p["beam_%s_lens" % btag].tolist(), p["beam_%s_yseq" % btag].tolist(), p["beam_%s_scores" % btag].tolist()
+        want, o = [], 0
+        for n in lens:
+            want.append(flat[o:o + n])
+            o += n
+        print("[parity] espnet2 rnn %s beam %s: hip %s ref %s" % (tag, btag, [round(float(h.score), 4) for h in got],
+                                                                 [round(s, 4) for s in scores]))
+        assert [h.yseq.tolist() for h in got] == want
+        for h, s in zip(got, scores):
+            assert abs(float(h.score) - s) <= 1e-4 * max(1.0, abs(s))
