@@ -92,7 +92,11 @@ __global__ __launch_bounds__(1024) void layernorm_bwd_kernel(
     const float* __restrict__ dy, const float* __restrict__ x, const float* __restrict__ gamma,
     const float* __restrict__ mean, const float* __restrict__ rstd, const float* dres, float* dx,
     float* __restrict__ dgamma, float* __restrict__ dbeta, float* __restrict__ ws, int rows, int D,
-    int rows_per_block) {
+    int rows_per_block, unsigned short* __restrict__ drop16, float drop_p, const unsigned long long* drop_step,
+    unsigned long long drop_salt) {
+  // drop16 (vector form only): a second, bf16 output dropout(dx; p, salt) with the mask eamd_dropout would draw for
+  // the contiguous [rows, D] tensor - the incoming-gradient dropout + cast of the PREVIOUS block, fused into this
+  // kernel's store instead of a separate pass over dx
   extern __shared__ float lds[];  // [waves][2][D]: one slot per wave, summed after the barrier (plain stores:
                                   // ds_add_f32 runs at a fraction of a lane per clock on gfx950)
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -100,6 +104,9 @@ __global__ __launch_bounds__(1024) void layernorm_bwd_kernel(
   const int r0 = blockIdx.x * rows_per_block;
   const int r1 = min(rows, r0 + rows_per_block);
   if constexpr (VEC > 0) {
+    const float drop_inv = 1.f / (1.f - drop_p);
+    const unsigned drop_thr = (unsigned)fminf(drop_p * 4294967296.0f, 4294967040.0f);
+    const unsigned drop_seed = drop16 ? eamd_drop_seed(drop_step, drop_salt) : 0u;
     float4 ag[VEC], ab[VEC], g4[VEC];
 #pragma unroll
     for (int j = 0; j < VEC; ++j) {
@@ -153,6 +160,18 @@ __global__ __launch_bounds__(1024) void layernorm_bwd_kernel(
           o.w = rs[q] * (dq.w * g4[j].w - s1 - h4[j].w * s2);
           if (dres) { o.x += rv[q][j].x; o.y += rv[q][j].y; o.z += rv[q][j].z; o.w += rv[q][j].w; }
           dxr[lane + 64 * j] = o;
+          if (drop16) {
+            const long e0 = (long)(q ? row2 : row) * D + 4 * (lane + 64 * j);
+            const float ov[4] = {o.x, o.y, o.z, o.w};
+            unsigned short h16[4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+              h16[e] = eamd_f2bf(eamd_drop_bits(drop_seed, (unsigned long long)(e0 + e)) >= drop_thr ? ov[e] * drop_inv : 0.f);
+            uint2 pk;
+            pk.x = (unsigned)h16[0] | ((unsigned)h16[1] << 16);
+            pk.y = (unsigned)h16[2] | ((unsigned)h16[3] << 16);
+            *reinterpret_cast<uint2*>(drop16 + e0) = pk;
+          }
         }
       }
     }
@@ -601,12 +620,13 @@ int64_t eamd_layernorm_bwd_workspace(int rows, int D) {
   return (int64_t)nblk * 2 * D;
 }
 
-int eamd_layernorm_bwd(const float* dy, const float* x, const float* gamma, const float* mean,
-                       const float* rstd, const float* dres, float* dx, float* dgamma, float* dbeta,
-                       float* workspace, int rows, int D, void* stream) {
+static int layernorm_bwd_impl(const float* dy, const float* x, const float* gamma, const float* mean, const float* rstd,
+                              const float* dres, float* dx, float* dgamma, float* dbeta, float* workspace, int rows, int D,
+                              void* drop16, float drop_p, const uint64_t* drop_step, uint64_t drop_salt, void* stream) {
   if (!dy || !x || !gamma || !mean || !rstd || !dx || !dgamma || !dbeta || rows <= 0 || D <= 0)
     return EAMD_EINVAL;
   if (D > 1024) return EAMD_EUNSUPPORTED;
+  if (drop16 && (drop_p < 0.f || drop_p >= 1.f || !drop_step || ((uintptr_t)drop16 & 7))) return EAMD_EINVAL;
   int nblk, rpb;
   ln_bwd_grid(rows, &nblk, &rpb);
   static const int ws_min = [] { const char* e = getenv("EAMD_LNB_WS_MIN"); return e ? atoi(e) : 32; }();
@@ -615,15 +635,19 @@ int eamd_layernorm_bwd(const float* dy, const float* x, const float* gamma, cons
   const bool al = (((uintptr_t)dy | (uintptr_t)x | (uintptr_t)gamma | (uintptr_t)dx | (uintptr_t)dres) & 15) == 0;
   hipStream_t s = (hipStream_t)stream;
   size_t sm = (size_t)(nthr / 64) * 2 * D * sizeof(float);
+  unsigned short* d16 = (unsigned short*)drop16;
+  const unsigned long long* dst = (const unsigned long long*)drop_step;
   if (al && D == 256)
     hipLaunchKernelGGL(layernorm_bwd_kernel<1>, dim3(nblk), dim3(nthr), sm, s, dy, x, gamma, mean, rstd, dres, dx,
-                       dgamma, dbeta, ws, rows, D, rpb);
+                       dgamma, dbeta, ws, rows, D, rpb, d16, drop_p, dst, (unsigned long long)drop_salt);
   else if (al && D == 512)
     hipLaunchKernelGGL(layernorm_bwd_kernel<2>, dim3(nblk), dim3(nthr), sm, s, dy, x, gamma, mean, rstd, dres, dx,
-                       dgamma, dbeta, ws, rows, D, rpb);
-  else
+                       dgamma, dbeta, ws, rows, D, rpb, d16, drop_p, dst, (unsigned long long)drop_salt);
+  else {
+    if (drop16) return EAMD_EUNSUPPORTED;       // the fused dropout output exists in the vector form only
     hipLaunchKernelGGL(layernorm_bwd_kernel<0>, dim3(nblk), dim3(nthr), sm, s, dy, x, gamma, mean, rstd, dres, dx,
-                       dgamma, dbeta, ws, rows, D, rpb);
+                       dgamma, dbeta, ws, rows, D, rpb, d16, drop_p, dst, (unsigned long long)drop_salt);
+  }
   EAMD_LAUNCH_CHECK();
   if (ws) {
     hipLaunchKernelGGL(layernorm_bwd_reduce_kernel, dim3((2 * D + 63) / 64, min(16, (nblk + 31) / 32)), dim3(256), 0,
@@ -631,6 +655,21 @@ int eamd_layernorm_bwd(const float* dy, const float* x, const float* gamma, cons
     EAMD_LAUNCH_CHECK();
   }
   return EAMD_OK;
+}
+
+int eamd_layernorm_bwd(const float* dy, const float* x, const float* gamma, const float* mean,
+                       const float* rstd, const float* dres, float* dx, float* dgamma, float* dbeta,
+                       float* workspace, int rows, int D, void* stream) {
+  return layernorm_bwd_impl(dy, x, gamma, mean, rstd, dres, dx, dgamma, dbeta, workspace, rows, D, nullptr, 0.f, nullptr, 0,
+                            stream);
+}
+
+int eamd_layernorm_bwd_drop(const float* dy, const float* x, const float* gamma, const float* mean, const float* rstd,
+                            const float* dres, float* dx, void* dx_drop_bf16, float drop_p, const uint64_t* step_dev,
+                            uint64_t salt, float* dgamma, float* dbeta, float* workspace, int rows, int D, void* stream) {
+  if (!dx_drop_bf16) return EAMD_EINVAL;
+  return layernorm_bwd_impl(dy, x, gamma, mean, rstd, dres, dx, dgamma, dbeta, workspace, rows, D, dx_drop_bf16, drop_p,
+                            step_dev, salt, stream);
 }
 
 int eamd_softmax_fwd(const float* ac, const float* bd, const unsigned char* mask, int64_t mask_bstride,

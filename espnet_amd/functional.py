@@ -38,6 +38,43 @@ class GradSink:
         return tuple(self.ret)
 
 
+# ---- incoming-gradient dropout fused into the producer -------------------------------------------------------------
+# In backward every block first applies its output dropout to the incoming gradient and casts it for the GEMMs:
+# one more pass over a [rows, D] tensor.  That gradient is produced by the LayerNorm backward of the NEXT block, so the
+# forward tags each block output with its (p, salt) and the next block's LayerNorm backward writes the dropped bf16
+# copy alongside dx (eamd_layernorm_bwd_drop); the copy travels as an attribute of the gradient tensor.  Anything that
+# breaks the chain (gradient accumulation from several consumers, another dtype / width) falls back to the plain pass.
+FUSE_GRAD_DROP = True
+
+
+def _tag_out(out, p_out, s_out):
+    if FUSE_GRAD_DROP and p_out > 0.0 and ops.fast():
+        out._eamd_out_drop = (float(p_out), int(s_out))
+    return out
+
+
+def _prev_drop(x):
+    return getattr(x, "_eamd_out_drop", None) if (FUSE_GRAD_DROP and ops.fast()) else None
+
+
+def _grad_in(dout, do, p_out, s_out):
+    """bf16 GEMM operand of the incoming gradient: the fused copy if the producer made one for this (p, salt)"""
+    pre = getattr(dout, "_eamd_dropped", None)
+    if pre is not None and pre[1] == (float(p_out), int(s_out)) and pre[0].numel() == do.numel():
+        return pre[0].view(do.shape)
+    return ops.dropout(do, p_out, s_out, out_dtype=ops.act_dtype()) if p_out > 0.0 else ops.to_act(do)
+
+
+def _ln_bwd_out(dxn, x2, ln_w, mean, rstd, do, gbuf, bbuf, prev, shp):
+    """LayerNorm backward of a block + residual; with `prev` = the previous block's (p, salt) also its dropped bf16 copy"""
+    if prev is not None and x2.shape[1] in (256, 512):
+        dx, dx16 = ops.layernorm_bwd(dxn, x2, ln_w, mean, rstd, do, gbuf, bbuf, drop=prev)
+        out = dx.view(shp)
+        out._eamd_dropped = (dx16, prev)
+        return out
+    return ops.layernorm_bwd(dxn, x2, ln_w, mean, rstd, do, gbuf, bbuf).view(shp)
+
+
 def _act_epi(act):
     return {ACT_RELU: EPI_MUL_RELU_MASK, ACT_SWISH: EPI_MUL_DSWISH}[act]
 
@@ -88,6 +125,7 @@ class LayerNormFn(torch.autograd.Function):
         ctx.save_for_backward(x2, mean, rstd)
         ctx.pr = (weight, bias)
         ctx.shp = shp
+        ctx.prev = _prev_drop(x)       # the block in front of a layer's final norm: its gradient dropout rides along
         return y.view(shp)
 
     @staticmethod
@@ -96,8 +134,8 @@ class LayerNormFn(torch.autograd.Function):
         w, b = ctx.pr
         sink = GradSink([w, b])
         dy2 = dy.reshape(x2.shape).contiguous()
-        dx = ops.layernorm_bwd(dy2, x2, w, mean, rstd, None, sink.buf(0), sink.buf(1))
-        return (dx.view(ctx.shp),) + sink.results() + (None,)
+        dx = _ln_bwd_out(dy2, x2, w, mean, rstd, None, sink.buf(0), sink.buf(1), ctx.prev, ctx.shp)
+        return (dx,) + sink.results() + (None,)
 
 
 # =================================================================================================
@@ -165,7 +203,8 @@ class FFNBlockFn(torch.autograd.Function):
         ctx.save_for_backward(x2, mean, rstd, xn, z, h)
         ctx.pr = (ln_w, ln_b, w1, b1, w2, b2)
         ctx.cfg = (scale, act, shp, drop)
-        return out.view(shp)
+        ctx.prev = _prev_drop(x)
+        return _tag_out(out.view(shp), p_out, s_out)
 
     @staticmethod
     def backward(ctx, dout):
@@ -176,7 +215,7 @@ class FFNBlockFn(torch.autograd.Function):
         sink = GradSink(ctx.pr)
         do = dout.reshape(x2.shape).contiguous()
         # gradient of the branch output (dropout mask re-derived, cast to the GEMM operand dtype in the same pass)
-        dob = ops.dropout(do, p_out, s_out, out_dtype=adt) if p_out > 0.0 else ops.to_act(do)
+        dob = _grad_in(dout, do, p_out, s_out)
         if h is not None:
             ops.linear_bwd_w(dob, h, sink.buf(4), alpha=scale, db=sink.buf(5))
         else:
@@ -190,8 +229,8 @@ class FFNBlockFn(torch.autograd.Function):
                 dz = ops.dropout(dz, p_in, s_in)
         ops.linear_bwd_w(dz, xn, sink.buf(2), db=sink.buf(3))
         dxn = ops.linear_bwd_x(dz, ops.wshadow(w1))
-        dx = ops.layernorm_bwd(dxn, x2, ln_w, mean, rstd, do, sink.buf(0), sink.buf(1))
-        return (dx.view(shp),) + sink.results() + (None, None, None, None)
+        dx = _ln_bwd_out(dxn, x2, ln_w, mean, rstd, do, sink.buf(0), sink.buf(1), ctx.prev, shp)
+        return (dx,) + sink.results() + (None, None, None, None)
 
 
 class Conv1dFFNBlockFn(torch.autograd.Function):
@@ -464,7 +503,8 @@ class MHABlockFn(torch.autograd.Function):
         ctx.pr = params
         ctx.fused = fused
         ctx.cfg = (B, T1, T2, H, dk, D, rel, memory is not None, last_query_only, drop)
-        return out.view(B, T1, D)
+        ctx.prev = _prev_drop(x)
+        return _tag_out(out.view(B, T1, D), p_out, s_out)
 
     @staticmethod
     def backward(ctx, dout):
@@ -476,7 +516,7 @@ class MHABlockFn(torch.autograd.Function):
         adt = ops.act_dtype()
         sink = GradSink(params)
         do = dout.reshape(-1, D).contiguous()
-        dob = ops.dropout(do, p_out, s_out, out_dtype=ops.act_dtype()) if p_out > 0.0 else ops.to_act(do)
+        dob = _grad_in(dout, do, p_out, s_out)
         ops.linear_bwd_w(dob, cx, sink.buf(8), db=sink.buf(9))
         dctx = ops.linear_bwd_x(dob, ops.wshadow(wo), out_dtype=adt)
         if ctx.fused:
@@ -493,8 +533,8 @@ class MHABlockFn(torch.autograd.Function):
                 ops.linear_bwd_w(ops.to_act(dp), pos2, sink.buf(10))
             ops.linear_bwd_w(dqkv, xn, _span3(sink.buf(2), (3 * D, D)), db=_span3(sink.buf(3), (3 * D,)))
             dxn = ops.linear_bwd_x(dqkv, _span3(ops.wshadow(wq), (3 * D, D)))
-            dx = ops.layernorm_bwd(dxn, x2, ln_w, mean, rstd, do, sink.buf(0), sink.buf(1))
-            return (dx.view(B, T1, D), None, None, None, None, None, None, None) + sink.results()
+            dx = _ln_bwd_out(dxn, x2, ln_w, mean, rstd, do, sink.buf(0), sink.buf(1), ctx.prev, (B, T1, D))
+            return (dx, None, None, None, None, None, None, None) + sink.results()
         dqu, dqv, dkk, dv, dp = attn_core_bwd(dctx, P, qu, qv, k, v, p, B, T1, T2, H, dk,
                                               Pd=Pd, attn_drop=(p_att, s_att))
         if rel:
@@ -518,8 +558,8 @@ class MHABlockFn(torch.autograd.Function):
         else:
             ops.linear_bwd_x(dkk, ops.wshadow(wk), out=dxn, beta=1.0)
             ops.linear_bwd_x(dv, ops.wshadow(wv), out=dxn, beta=1.0)
-        dx = ops.layernorm_bwd(dxn, x2, ln_w, mean, rstd, do, sink.buf(0), sink.buf(1))
-        return (dx.view(B, T1, D), dmem, None, None, None, None, None, None) + sink.results()
+        dx = _ln_bwd_out(dxn, x2, ln_w, mean, rstd, do, sink.buf(0), sink.buf(1), ctx.prev, (B, T1, D))
+        return (dx, dmem, None, None, None, None, None, None) + sink.results()
 
 
 # =================================================================================================
@@ -560,7 +600,8 @@ class ConvModuleBlockFn(torch.autograd.Function):
         ctx.save_for_backward(x2, mean, rstd, xn, a, gl, d, bmean, brstd, e)
         ctx.pr = params
         ctx.cfg = (B, T, D, Cc, K, act, training, drop)
-        return out.view(B, T, D)
+        ctx.prev = _prev_drop(x)
+        return _tag_out(out.view(B, T, D), p_out, s_out)
 
     @staticmethod
     def backward(ctx, dout):
@@ -571,7 +612,7 @@ class ConvModuleBlockFn(torch.autograd.Function):
         adt = ops.act_dtype()
         sink = GradSink(ctx.pr)
         do = dout.reshape(M, D).contiguous()
-        dob = ops.dropout(do, p_out, s_out, out_dtype=ops.act_dtype()) if p_out > 0.0 else ops.to_act(do)
+        dob = _grad_in(dout, do, p_out, s_out)
         ops.linear_bwd_w(dob, e, sink.buf(8).view(Cc, Cc), db=sink.buf(9))
         de = ops.linear_bwd_x(dob, ops.wshadow(w2).view(Cc, Cc))
         dd = ops.bn_bwd(de, d, bmean, brstd, g, be, sink.buf(6), sink.buf(7), M, Cc, act, training)
@@ -580,8 +621,8 @@ class ConvModuleBlockFn(torch.autograd.Function):
         da = ops.glu_bwd(dgl, a, Cc, adt)
         ops.linear_bwd_w(da, xn, sink.buf(2).view(2 * Cc, D), db=sink.buf(3))
         dxn = ops.linear_bwd_x(da, ops.wshadow(w1).view(2 * Cc, D))
-        dx = ops.layernorm_bwd(dxn, x2, ln_w, mean, rstd, do, sink.buf(0), sink.buf(1))
-        return (dx.view(B, T, D), None, None, None, None, None, None, None, None) + sink.results()
+        dx = _ln_bwd_out(dxn, x2, ln_w, mean, rstd, do, sink.buf(0), sink.buf(1), ctx.prev, (B, T, D))
+        return (dx, None, None, None, None, None, None, None, None) + sink.results()
 
 
 # =================================================================================================

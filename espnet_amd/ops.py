@@ -271,12 +271,20 @@ def layernorm_fwd(x, gamma, beta, eps, out_dtype=torch.float32):
     return y, mean, rstd
 
 
-def layernorm_bwd(dy, x, gamma, mean, rstd, dres, dgamma, dbeta):
+def layernorm_bwd(dy, x, gamma, mean, rstd, dres, dgamma, dbeta, drop=None):
+    """drop = (p, salt): also return bf16(dropout(dx; p, salt)) written by the same kernel (D = 256 / 512 only) ->
+    (dx, dx_dropped); otherwise -> dx"""
     rows, D = x.shape
     assert dy.shape == x.shape and dgamma.numel() == D and dbeta.numel() == D
     dx = torch.empty_like(x)
     L = _lib.lib()
     ws = torch.empty(int(L.eamd_layernorm_bwd_workspace(rows, D)), device=x.device, dtype=torch.float32)
+    if drop is not None:
+        dx16 = torch.empty(rows, D, device=x.device, dtype=torch.bfloat16)
+        check(L.eamd_layernorm_bwd_drop(ptr(dy), ptr(x), ptr(gamma), ptr(mean), ptr(rstd), ptr(dres), ptr(dx), ptr(dx16),
+                                        C.c_float(drop[0]), ptr(rng_state(x.device)), C.c_uint64(drop[1]), ptr(dgamma),
+                                        ptr(dbeta), ptr(ws), rows, D, stream_ptr()), "eamd_layernorm_bwd_drop")
+        return dx, dx16
     check(L.eamd_layernorm_bwd(ptr(dy), ptr(x), ptr(gamma), ptr(mean), ptr(rstd), ptr(dres), ptr(dx),
                                ptr(dgamma), ptr(dbeta), ptr(ws), rows, D, stream_ptr()), "eamd_layernorm_bwd")
     return dx

@@ -113,6 +113,13 @@ int64_t eamd_layernorm_bwd_workspace(int rows, int D);
 int eamd_layernorm_bwd(const float* dy, const float* x, const float* gamma, const float* mean,
                        const float* rstd, const float* dres, float* dx, float* dgamma, float* dbeta,
                        float* workspace, int rows, int D, void* stream);
+/* Same, with a second output dx_drop_bf16 = bf16(dropout(dx; p, salt)) drawn with the mask eamd_dropout uses for a
+ * contiguous [rows, D] tensor: the incoming-gradient dropout + cast of the block BEFORE this LayerNorm (whose output
+ * dropout the forward applied with (p, salt)), fused into this kernel's store.  D = 256 or 512, 16-byte aligned
+ * operands; otherwise EAMD_EUNSUPPORTED (run eamd_layernorm_bwd and eamd_dropout instead). */
+int eamd_layernorm_bwd_drop(const float* dy, const float* x, const float* gamma, const float* mean, const float* rstd,
+                            const float* dres, float* dx, void* dx_drop_bf16, float drop_p, const uint64_t* step_dev,
+                            uint64_t salt, float* dgamma, float* dbeta, float* workspace, int rows, int D, void* stream);
 
 /* Masked softmax of attention scores, legacy rel_shift of `bd` fused in.
  * reference: transformer/attention.py:63-90 (mask fill / softmax / zero fill), :141-162 (rel_shift),

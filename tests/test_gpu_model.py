@@ -705,3 +705,36 @@ def test_positionwise_conv1d_golden(tag, kind, kw):
     rel = float((yb.cpu() - p["y"]).norm() / p["y"].norm())
     print(f"[parity] pw {tag} bf16-mode rel_l2 {rel:.2e}")
     assert rel < 3e-2
+
+
+def test_fused_gradient_dropout_matches_separate_pass():
+    """bf16 mode, dropout on: the incoming-gradient dropout written by the next block's LayerNorm backward
+    (eamd_layernorm_bwd_drop) must reproduce the separate dropout pass - same masks, same rounding: the parameter gradients
+    of a small Conformer E2E with the fusion on and off differ by no more than two runs of the same configuration do
+    (split-K f32 atomics make the step itself non-deterministic in the last bits)."""
+    import espnet_amd
+    from espnet_amd import functional as F_
+    from espnet_amd import ops
+    p, sd, _ = split_golden(load_golden("e2e_conformer.npz"))
+    extra = dict(CASES[0][2], dropout_rate=0.1, transformer_attn_dropout_rate=0.1, adim=256, aheads=4, eunits=64, dunits=64)
+    espnet_amd.set_precision("bf16")
+    try:
+        grads = {}
+        torch.manual_seed(5)
+        model = _e2e("conformer", extra).to(DEV).train()        # one instance: the dropout salts belong to the modules
+        for fuse in (True, False, None):       # None: the separate pass once more = the run-to-run noise of the f32 atomics
+            F_.FUSE_GRAD_DROP = bool(fuse)
+            model.zero_grad(set_to_none=True)
+            ops.manual_seed(77)
+            loss = model(p["xs"].to(DEV), p["ilens"], p["ys"].to(DEV))
+            loss.backward()
+            grads[fuse] = {k: q.grad.clone() for k, q in model.named_parameters()}
+            grads[fuse]["__loss__"] = loss.detach().clone()
+        def worst(a, b):
+            return max(float((a[k].double() - b[k].double()).norm() / (b[k].double().norm() + 1e-30)) for k in a)
+        noise, diff = worst(grads[None], grads[False]), worst(grads[True], grads[False])
+        print("[parity] fused gradient dropout: worst rel diff vs separate pass %.2e (run-to-run noise %.2e)" % (diff, noise))
+        assert diff <= max(4.0 * noise, 1e-6)
+    finally:
+        F_.FUSE_GRAD_DROP = True
+        espnet_amd.set_precision("fp32")
