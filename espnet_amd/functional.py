@@ -455,7 +455,7 @@ class MHABlockFn(torch.autograd.Function):
         if memory is None:
             kv_in, T2 = xn, T1f
         else:
-            kv_in, T2 = ops.to_act(memory.reshape(-1, D).contiguous()), memory.shape[1]
+            kv_in, T2 = ops.to_act_shared(memory).reshape(-1, D), memory.shape[1]
         if last_query_only:   # cached decoding: only the newest position queries (decoder_layer.py:88-101)
             xq = xn.view(B, T1f, D)[:, -1, :].contiguous()
             res = x2.view(B, T1f, D)[:, -1, :].contiguous()
@@ -476,7 +476,7 @@ class MHABlockFn(torch.autograd.Function):
         pos2 = None
         if rel:
             wpos, pu, pv = params[10:13]
-            pos2 = ops.to_act(pos_emb.reshape(-1, D).contiguous())
+            pos2 = ops.to_act_shared(pos_emb).reshape(-1, D)
             p = ops.linear_fwd(pos2, ops.wshadow(wpos), None, out_dtype=adt)
             if fused:
                 qu, qv = ops.add_bias2(qkv, pu.reshape(-1), pv.reshape(-1), rows=B * T1, D=D, ldq=3 * D, q_off=0)

@@ -63,6 +63,19 @@ def to_act(x):
     return x
 
 
+def to_act_shared(x):
+    """to_act for a tensor that several consumers cast within one step (the encoder memory read by every decoder
+    layer, the positional embedding read by every encoder layer): the bf16 copy rides on the tensor object"""
+    if not (fast() and x.dtype == torch.float32):
+        return x
+    c = getattr(x, "_eamd_act", None)
+    if c is not None and c[1] == x._version and c[0].shape == x.shape:
+        return c[0]
+    y = cast_bf16(x.contiguous())
+    x._eamd_act = (y, x._version)
+    return y
+
+
 def _numel_from(t, off):
     return t.numel() - off
 
