@@ -406,6 +406,14 @@ __global__ __launch_bounds__(256) void softmax_bwd_vec_kernel(const unsigned sho
     for (int e = 0; e < 4; ++e) if (j0 + e < T2) s += pv[k][e] * dv[k][e];
   }
   s = wave_sum(s);
+  if (dbd16) {      // dbd is fully defined here: pad columns of this row, and (row 0) the head the scatter never reaches
+    for (int j = T2 + lane; j < ld; j += 64) dbd16[ro + j] = 0;
+    if (i == 0)
+      for (int f = 1 + lane; f < T1; f += 64) {
+        const int r = f / (T2 + 1), c = f % (T2 + 1);
+        if (c != 0) dbd16[zo + (long)r * ld + (c - 1)] = 0;
+      }
+  }
 #pragma unroll
   for (int k = 0; k < NCH; ++k) {
     const int j0 = 4 * lane + 256 * k;
@@ -430,7 +438,7 @@ __global__ __launch_bounds__(256) void softmax_bwd_vec_kernel(const unsigned sho
 }
 
 // dS = P * (dP - sum_j dP*P) * scale, written over dP (d_ac); optional scatter of dS through the
-// inverse rel-shift into dbd (pre-zeroed by the caller).
+// inverse rel-shift into dbd (every element of dbd is written: no pre-zeroing needed).
 __global__ __launch_bounds__(256) void softmax_bwd_kernel(const float* __restrict__ P,
                                                           const unsigned short* __restrict__ P16, float* dP,
                                                           float* __restrict__ dbd, unsigned short* __restrict__ dS16,
@@ -449,6 +457,17 @@ __global__ __launch_bounds__(256) void softmax_bwd_kernel(const float* __restric
   }
   s = wave_sum(s);
   const long zo = (long)z * T1 * ld;
+  // dbd is fully defined here (no pre-zeroing by the caller): the scatter below covers every (r, c-1) whose padded
+  // index r*(T2+1)+c lies in [T1, T1*(T2+1)); the wave of row 0 zeroes the head [1, T1) it never reaches, and every
+  // wave zeroes the pad columns [T2, ld) of its own row
+  if (dbd || dbd16) {
+    for (int j = T2 + lane; j < ld; j += 64) { if (dbd16) dbd16[ro + j] = 0; else dbd[ro + j] = 0.f; }
+    if (i == 0)
+      for (int f = 1 + lane; f < T1; f += 64) {
+        const int r = f / (T2 + 1), c = f % (T2 + 1);
+        if (c != 0) { if (dbd16) dbd16[zo + (long)r * ld + (c - 1)] = 0; else dbd[zo + (long)r * ld + (c - 1)] = 0.f; }
+      }
+  }
   for (int j = lane; j < ld; j += 64) {
     if (j >= T2) { if (dS16) dS16[ro + j] = 0; continue; }
     const float pv = P16 ? __uint_as_float(((unsigned)P16[ro + j]) << 16) : P[ro + j];

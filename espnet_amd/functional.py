@@ -376,7 +376,7 @@ def attn_core_bwd(dctx, P, qu, qv, k, v, p, B, T1, T2, H, dk, Pd=None, attn_drop
         dv, dv_off, dkk, dk_off = dqkv, 2 * D, dqkv, D
     ops.gemm(Pd if Pd is not None else P, dctx, dv, T2, dk, T1, ldp, D, ldo, transA=1, transB=1, batch=(B, H), sA=sP,
              sB=(T1 * D, dk), sC=(T2 * ldo, dk), c_off=dv_off)                                            # P^T dctx
-    dbd = torch.zeros(H * B * T1 * ldp, device=dev, dtype=adt) if p is not None else None
+    dbd = torch.empty(H * B * T1 * ldp, device=dev, dtype=adt) if p is not None else None   # fully written by softmax_bwd
     if ops.fast():
         dS = torch.empty(H * B * T1 * ldp, device=dev, dtype=torch.bfloat16)
         ops.softmax_bwd(P, dP, dbd, H * B, T1, T2, ldp, 1.0 / math.sqrt(dk), dS16=dS)

@@ -319,8 +319,8 @@ def softmax_fwd(ac, bd, mask, P, nblocks, B, T1, T2, ld, scale):
 
 
 def softmax_bwd(P, dP, dbd, nblocks, T1, T2, ld, scale, dS16=None):
-    """fp32: dP is overwritten with dS, dbd (fp32, pre-zeroed) receives the inverse rel-shift scatter.
-    bf16: P bf16, dP fp32 in, dS16 (bf16) out, dbd bf16 (pre-zeroed)."""
+    """fp32: dP is overwritten with dS, dbd (fp32) receives the inverse rel-shift scatter.
+    bf16: P bf16, dP fp32 in, dS16 (bf16) out, dbd bf16.  dbd is fully written by the kernel (no pre-zeroing)."""
     assert P.numel() >= nblocks * T1 * ld and dP.numel() >= nblocks * T1 * ld and dP.dtype == torch.float32
     if P.dtype == torch.bfloat16:
         assert dS16 is not None and dS16.dtype == torch.bfloat16 and (dbd is None or dbd.dtype == torch.bfloat16)

@@ -129,9 +129,10 @@ int eamd_layernorm_bwd_drop(const float* dy, const float* x, const float* gamma,
 int eamd_softmax_fwd(const float* ac, const float* bd, const unsigned char* mask, int64_t mask_bstride,
                      int64_t mask_qstride, float* P, void* P_bf16, int nblocks, int B, int T1, int T2, int64_t ld,
                      float scale, void* stream);
-/* dP is overwritten by d(ac); if dbd != NULL (pre-zeroed) the same values are scattered through the
+/* dP is overwritten by d(ac); if dbd != NULL the same values are scattered through the
  * inverse rel_shift. */
-/* bf16 variant: P_bf16 in; dS_bf16 (instead of overwriting dP) and dbd_bf16 out (pre-zeroed). */
+/* bf16 variant: P_bf16 in; dS_bf16 (instead of overwriting dP) and dbd_bf16 out.  Every element of dbd is
+ * written (scattered value, or zero where the shift never lands and in the pad columns): no pre-zeroing. */
 int eamd_softmax_bwd(const float* P, const void* P_bf16, float* dP, float* dbd, void* dS_bf16, void* dbd_bf16,
                      int nblocks, int T1, int T2, int64_t ld, float scale, void* stream);
 

@@ -218,7 +218,7 @@ def test_softmax_relshift_golden(ops, oracle):
     ops.softmax_fwd(ac.reshape(-1).to(DEV), bdm.reshape(-1).to(DEV), mask.to(DEV), P, h * b, b, t1, t2, ld, 0.25)
     report("masked_softmax_fwd", P.view(h, b, t1, ld)[..., :t2], pr, 1e-6)
     dS = dP.reshape(-1).clone().to(DEV)
-    dbd = torch.zeros(h * b * t1 * ld, device=DEV)
+    dbd = torch.full((h * b * t1 * ld,), float("nan"), device=DEV)      # the kernel defines every element itself
     ops.softmax_bwd(P, dS, dbd, h * b, t1, t2, ld, 0.25)
     report("masked_softmax_bwd_ac", dS.view(h, b, t1, ld)[..., :t2], acd.grad, 1e-5)
     report("masked_softmax_bwd_bd", dbd.view(h, b, t1, ld)[..., :t2], bdd.grad, 1e-5)
@@ -227,7 +227,7 @@ def test_softmax_relshift_golden(ops, oracle):
     ops.softmax_fwd(ac.reshape(-1).to(DEV), bdm.reshape(-1).to(DEV), mask.to(DEV), P16, h * b, b, t1, t2, ld, 0.25)
     report("masked_softmax_fwd_bf16", P16.float().view(h, b, t1, ld)[..., :t2], pr, 4e-3)
     dS16 = torch.empty_like(P16)
-    dbd16 = torch.zeros_like(P16)
+    dbd16 = torch.full_like(P16, float("nan"))
     ops.softmax_bwd(P16, dP.reshape(-1).clone().to(DEV), dbd16, h * b, t1, t2, ld, 0.25, dS16=dS16)
     report("masked_softmax_bwd_ac_bf16", dS16.float().view(h, b, t1, ld)[..., :t2], acd.grad, 1e-2)
     report("masked_softmax_bwd_bd_bf16", dbd16.float().view(h, b, t1, ld)[..., :t2], bdd.grad, 1e-2)
@@ -246,10 +246,10 @@ def test_softmax_relshift_golden(ops, oracle):
         # same values up to the summation order of the row sum, rounded once: 1 bf16 ulp
         report("softmax_fwd vec %dx%d" % (t1, t2), P16.float(), P32, 3e-3)
         assert torch.equal(P16 == 0, P32.to(torch.bfloat16) == 0) or float(((P16 == 0) != (P32.to(torch.bfloat16) == 0)).sum()) < 8
-        dS32, dbd32 = dP.clone(), torch.zeros(h * b * t1 * ld, device=DEV)
+        dS32, dbd32 = dP.clone(), torch.full((h * b * t1 * ld,), float("nan"), device=DEV)
         ops.softmax_bwd(P16.float(), dS32, dbd32 if bdm is not None else None, h * b, t1, t2, ld, 0.125)
         dS16 = torch.empty_like(P16)
-        dbd16 = torch.zeros_like(P16) if bdm is not None else None
+        dbd16 = torch.full_like(P16, float("nan")) if bdm is not None else None
         ops.softmax_bwd(P16, dP.clone(), dbd16, h * b, t1, t2, ld, 0.125, dS16=dS16)
         v = lambda x: x.float().view(h * b, t1, ld)[..., :t2]                          # noqa: E731
         report("softmax_bwd vec %dx%d" % (t1, t2), v(dS16), v(dS32), 4e-3)
