@@ -65,9 +65,7 @@ class ConformerEncoder(AbsEncoder):
             xs_pad = xs_pad[0]
         if self.normalize_before:
             xs_pad = self.after_norm(xs_pad)
-        stages = 3 if isinstance(self.embed, M.Conv2dSubsampling8) else \
-            ([(2, 2), (4, 3)] if isinstance(self.embed, M.Conv2dSubsampling6) else 2)
-        olens = torch.tensor(M.subsampled_lengths(il, self._tin, stages), dtype=torch.int64).to(xs_pad.device)
+        olens = torch.tensor(M.embed_output_lengths(self.embed, il, self._tin), dtype=torch.int64).to(xs_pad.device)
         return xs_pad, olens, None
 
 
@@ -101,9 +99,7 @@ class TransformerEncoder(AbsEncoder):
         xs_pad, masks = self.encoders(xs_pad, masks)
         if self.normalize_before:
             xs_pad = self.after_norm(xs_pad)
-        stages = 3 if isinstance(self.embed, M.Conv2dSubsampling8) else \
-            ([(2, 2), (4, 3)] if isinstance(self.embed, M.Conv2dSubsampling6) else 2)
-        olens = torch.tensor(M.subsampled_lengths(il, self._tin, stages), dtype=torch.int64).to(xs_pad.device)
+        olens = torch.tensor(M.embed_output_lengths(self.embed, il, self._tin), dtype=torch.int64).to(xs_pad.device)
         return xs_pad, olens, None
 
 

@@ -15,7 +15,7 @@ from .. import functional as F_
 from .. import ops
 from .asr_interface import ASRInterface
 from .modules import (CTC, Decoder, LabelSmoothingLoss, TransformerEncoder, make_non_pad_mask,
-                      subsampled_lengths, subsequent_mask, th_accuracy)
+                      embed_output_lengths, subsampled_lengths, subsequent_mask, th_accuracy)
 
 CTC_LOSS_THRESHOLD = 10000  # reference: e2e_asr.py:43
 
@@ -176,7 +176,7 @@ class E2E(ASRInterface, torch.nn.Module):
             batch.update(ys_in_pad=ys_in_pad, ys_out_pad=ys_out_pad, ys_mask=ys_mask.to(dev),
                          n_valid=(ys_out_pad != self.ignore_id).sum())
         if self.mtlalpha > 0.0:
-            batch["hs_len"] = torch.tensor(subsampled_lengths(il, tmax), dtype=torch.int32).to(dev)
+            batch["hs_len"] = torch.tensor(embed_output_lengths(self.encoder.embed, il, tmax), dtype=torch.int32).to(dev)
         return batch
 
     def forward_core(self, batch):
@@ -262,7 +262,7 @@ class E2E(ASRInterface, torch.nn.Module):
         with torch.no_grad():
             hs, _ = self.encoder(xs_pad[:, :tmax], make_non_pad_mask(il).unsqueeze(-2))
             ids = self.ctc.argmax(hs).to(torch.int32).contiguous()
-            hl = torch.tensor(subsampled_lengths(il, tmax), dtype=torch.int32).to(ids.device)
+            hl = torch.tensor(embed_output_lengths(self.encoder.embed, il, tmax), dtype=torch.int32).to(ids.device)
             return ops.ctc_collapse(ids, hl, self.blank)
 
     def calculate_all_ctc_probs(self, xs_pad, ilens, ys_pad):

@@ -117,6 +117,17 @@ def subsampled_lengths(ilens, tmax=None, stages=2):
     return out
 
 
+def embed_output_lengths(embed, ilens, tmax=None):
+    """valid frames behind an encoder input layer: the conv2d family subsamples the mask, linear / embed keep it"""
+    if isinstance(embed, Conv2dSubsampling8):
+        return subsampled_lengths(ilens, tmax, 3)
+    if isinstance(embed, Conv2dSubsampling6):
+        return subsampled_lengths(ilens, tmax, [(2, 2), (4, 3)])
+    if isinstance(embed, Conv2dSubsampling):
+        return subsampled_lengths(ilens, tmax, 2)
+    return [int(n) for n in ilens]
+
+
 def _mask_u8(mask, device):
     """bool/uint8 mask of shape (B,1,T2) or (B,T1,T2) -> contiguous uint8 on device (None passes)."""
     if mask is None:
