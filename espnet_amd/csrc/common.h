@@ -22,7 +22,9 @@ typedef __attribute__((ext_vector_type(4))) short bf16x4;
 // activation ids shared by host and device
 enum { EAMD_ACT_NONE = 0, EAMD_ACT_RELU = 1, EAMD_ACT_SWISH = 2, EAMD_ACT_TANH = 3 };
 
-__device__ __forceinline__ float eamd_sigmoid(float x) { return 1.0f / (1.0f + __expf(-x)); }
+// v_exp_f32 + v_rcp_f32 (1 ulp each); an IEEE division here costs ten more VALU instructions per element, which the
+// GEMM epilogues (Swish / its derivative on every FFN hidden unit) cannot hide
+__device__ __forceinline__ float eamd_sigmoid(float x) { return __builtin_amdgcn_rcpf(1.0f + __expf(-x)); }
 __device__ __forceinline__ float eamd_swish(float x) { return x * eamd_sigmoid(x); }
 // d/dx [x*sigmoid(x)] = s + x*s*(1-s)
 __device__ __forceinline__ float eamd_dswish(float x) {
@@ -43,19 +45,36 @@ __device__ __forceinline__ float eamd_dact(float x, int act) {
   return 1.f;
 }
 
-// Counter-based dropout bits shared by eamd_dropout and the fused GEMM epilogues: a per-launch 32-bit seed from
-// (device step counter, site salt) and a 32-bit avalanche (lowbias32) of the element index.  The 64-bit
-// mix runs once per thread, the per-element cost is ~10 VALU instructions (a 64-bit splitmix per element made the
-// FFN up-projection epilogue ALU-bound).
+// Counter-based dropout bits shared by eamd_dropout and the fused GEMM / LayerNorm epilogues: a per-launch 32-bit
+// seed from (device step counter, site salt) and a 32-bit avalanche (lowbias32) of the element-PAIR index; element
+// 2q takes the low 16 bits, element 2q+1 the high 16 bits, keep <=> bits >= round(p * 2^16).  One hash (two
+// quarter-rate v_mul_lo_u32) serves two elements: a hash per element made the FFN epilogues VALU-bound.  The
+// survivors are scaled by 2^16 / (2^16 - threshold), the exact inverse of the keep probability drawn.
 __device__ __forceinline__ unsigned eamd_drop_seed(const unsigned long long* step, unsigned long long salt) {
   unsigned long long x = (step ? step[0] : 0ULL) * 0x9E3779B97F4A7C15ULL + salt * 0xD1B54A32D192ED03ULL;
   x ^= x >> 33; x *= 0xff51afd7ed558ccdULL; x ^= x >> 33; x *= 0xc4ceb9fe1a85ec53ULL; x ^= x >> 33;
   return (unsigned)x ^ (unsigned)(x >> 32);
 }
-__device__ __forceinline__ unsigned eamd_drop_bits(unsigned seed, unsigned long long idx) {
-  unsigned h = ((unsigned)idx ^ seed) + (unsigned)(idx >> 32) * 0x9E3779B1u;
+__device__ __forceinline__ unsigned eamd_drop_thr16(float p) {
+  return p >= 1.f ? 65536u : (unsigned)fminf(fmaxf(p, 0.f) * 65536.0f + 0.5f, 65535.0f);
+}
+__device__ __forceinline__ float eamd_drop_inv(unsigned thr16) {
+  return thr16 >= 65536u ? 0.f : 65536.0f / (float)(65536u - thr16);
+}
+__device__ __forceinline__ unsigned eamd_drop_pair(unsigned seed, unsigned long long pair_idx) {
+  unsigned h = ((unsigned)pair_idx ^ seed) + (unsigned)(pair_idx >> 32) * 0x9E3779B1u;
   h ^= h >> 16; h *= 0x7feb352du; h ^= h >> 15; h *= 0x846ca68bu; h ^= h >> 16;
   return h;
+}
+__device__ __forceinline__ bool eamd_drop_keep(unsigned seed, unsigned long long idx, unsigned thr16) {
+  const unsigned h = eamd_drop_pair(seed, idx >> 1);
+  return ((idx & 1ULL) ? (h >> 16) : (h & 0xffffu)) >= thr16;
+}
+// four consecutive elements starting at an EVEN index: two hashes
+__device__ __forceinline__ void eamd_drop_keep4(unsigned seed, unsigned long long base, unsigned thr16, bool (&k)[4]) {
+  const unsigned h0 = eamd_drop_pair(seed, base >> 1), h1 = eamd_drop_pair(seed, (base >> 1) + 1ULL);
+  k[0] = (h0 & 0xffffu) >= thr16; k[1] = (h0 >> 16) >= thr16;
+  k[2] = (h1 & 0xffffu) >= thr16; k[3] = (h1 >> 16) >= thr16;
 }
 
 // fp32 -> bf16 round-to-nearest-even (plain cast keeps NaN a NaN on gfx950).

@@ -287,7 +287,7 @@ __global__ void permute4_kernel(const float* __restrict__ src, float* __restrict
   }
 }
 
-// Counter-based dropout: keep(i) = hash(step_counter, salt, i) >= p * 2^32, y = x * keep / (1 - p).
+// Counter-based dropout: keep(i) = 16 hash bits of (step_counter, salt, i) >= p * 2^16, y = x * keep / P(keep).
 // The step counter lives in DEVICE memory (advanced once per training step by eamd_rng_advance), so a
 // captured hipGraph draws fresh masks on every replay; backward re-derives the same mask by calling the
 // same kernel on the gradient.  Optional fused activation (FFN inner dropout: drop(act(z))).
@@ -296,8 +296,8 @@ __global__ void permute4_kernel(const float* __restrict__ src, float* __restrict
 __global__ void dropout_kernel(const float* __restrict__ x, float* __restrict__ y, long n, float p,
                                const unsigned long long* __restrict__ step, unsigned long long salt, int act,
                                int in_bf16, int out_bf16) {
-  const float inv = 1.f / (1.f - p);
-  const unsigned thr = (unsigned)fminf(p * 4294967296.0f, 4294967040.0f);
+  const unsigned thr = eamd_drop_thr16(p);
+  const float inv = eamd_drop_inv(thr);
   const unsigned seed = eamd_drop_seed(step, salt);
   const long stride = (long)gridDim.x * blockDim.x;
   const unsigned short* x16 = reinterpret_cast<const unsigned short*>(x);
@@ -305,8 +305,7 @@ __global__ void dropout_kernel(const float* __restrict__ x, float* __restrict__ 
   for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
     float v = in_bf16 ? __uint_as_float(((unsigned)x16[i]) << 16) : x[i];
     v = eamd_act(v, act);
-    const unsigned h = eamd_drop_bits(seed, (unsigned long long)i);
-    v = h >= thr ? v * inv : 0.f;
+    v = eamd_drop_keep(seed, (unsigned long long)i, thr) ? v * inv : 0.f;
     if (out_bf16) y16[i] = eamd_f2bf(v); else y[i] = v;
   }
 }
@@ -315,8 +314,8 @@ __global__ void dropout_kernel(const float* __restrict__ x, float* __restrict__ 
 __global__ void dropout_vec4_kernel(const float* __restrict__ x, float* __restrict__ y, long n4, float p,
                                     const unsigned long long* __restrict__ step, unsigned long long salt, int act,
                                     int in_bf16, int out_bf16) {
-  const float inv = 1.f / (1.f - p);
-  const unsigned thr = (unsigned)fminf(p * 4294967296.0f, 4294967040.0f);
+  const unsigned thr = eamd_drop_thr16(p);
+  const float inv = eamd_drop_inv(thr);
   const unsigned seed = eamd_drop_seed(step, salt);
   const long stride = (long)gridDim.x * blockDim.x;
   for (long q = (long)blockIdx.x * blockDim.x + threadIdx.x; q < n4; q += stride) {
@@ -329,12 +328,10 @@ __global__ void dropout_vec4_kernel(const float* __restrict__ x, float* __restri
       const float4 r = reinterpret_cast<const float4*>(x)[q];
       v[0] = r.x; v[1] = r.y; v[2] = r.z; v[3] = r.w;
     }
+    bool keep[4];
+    eamd_drop_keep4(seed, (unsigned long long)(4 * q), thr, keep);
 #pragma unroll
-    for (int e = 0; e < 4; ++e) {
-      const float a = eamd_act(v[e], act);
-      const unsigned h = eamd_drop_bits(seed, (unsigned long long)(4 * q + e));
-      v[e] = h >= thr ? a * inv : 0.f;
-    }
+    for (int e = 0; e < 4; ++e) v[e] = keep[e] ? eamd_act(v[e], act) * inv : 0.f;
     if (out_bf16) {
       uint2 o;
       o.x = (unsigned)eamd_f2bf(v[0]) | ((unsigned)eamd_f2bf(v[1]) << 16);

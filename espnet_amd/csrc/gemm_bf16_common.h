@@ -171,15 +171,22 @@ __device__ __forceinline__ void store_c_tile(const eamd_gemm_t& p, f32x4 (&acc)[
     }
     if (p.drop_p > 0.f) {
       // wave-uniform branch; mask index = element index of the contiguous [M, N] result
-      const float inv = 1.f / (1.f - p.drop_p);
-      const unsigned thr = (unsigned)fminf(p.drop_p * 4294967296.0f, 4294967040.0f);
+      const unsigned thr = eamd_drop_thr16(p.drop_p);
+      const float inv = eamd_drop_inv(thr);
       const unsigned long long base = (unsigned long long)ci;
+      bool keep[4];
+      if (full) {          // ci is a multiple of 4 on the vector path
+        eamd_drop_keep4(drop_seed, base, thr, keep);
+      } else {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) keep[e] = eamd_drop_keep(drop_seed, base + e, thr);
+      }
       if (Hb) {
         float h[4];
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
           const float a = eamd_act(v[e], p.h_act);
-          h[e] = eamd_drop_bits(drop_seed, base + e) >= thr ? a * inv : 0.f;
+          h[e] = keep[e] ? a * inv : 0.f;
         }
         if (full) {
           uint2 o;
@@ -192,7 +199,7 @@ __device__ __forceinline__ void store_c_tile(const eamd_gemm_t& p, f32x4 (&acc)[
         }
       } else {
 #pragma unroll
-        for (int e = 0; e < 4; ++e) v[e] = eamd_drop_bits(drop_seed, base + e) >= thr ? v[e] * inv : 0.f;
+        for (int e = 0; e < 4; ++e) v[e] = keep[e] ? v[e] * inv : 0.f;
       }
     }
 #pragma unroll

@@ -104,8 +104,8 @@ __global__ __launch_bounds__(1024) void layernorm_bwd_kernel(
   const int r0 = blockIdx.x * rows_per_block;
   const int r1 = min(rows, r0 + rows_per_block);
   if constexpr (VEC > 0) {
-    const float drop_inv = 1.f / (1.f - drop_p);
-    const unsigned drop_thr = (unsigned)fminf(drop_p * 4294967296.0f, 4294967040.0f);
+    const unsigned drop_thr = eamd_drop_thr16(drop_p);
+    const float drop_inv = eamd_drop_inv(drop_thr);
     const unsigned drop_seed = drop16 ? eamd_drop_seed(drop_step, drop_salt) : 0u;
     float4 ag[VEC], ab[VEC], g4[VEC];
 #pragma unroll
@@ -164,9 +164,10 @@ __global__ __launch_bounds__(1024) void layernorm_bwd_kernel(
             const long e0 = (long)(q ? row2 : row) * D + 4 * (lane + 64 * j);
             const float ov[4] = {o.x, o.y, o.z, o.w};
             unsigned short h16[4];
+            bool keep[4];
+            eamd_drop_keep4(drop_seed, (unsigned long long)e0, drop_thr, keep);     // e0 is a multiple of 4
 #pragma unroll
-            for (int e = 0; e < 4; ++e)
-              h16[e] = eamd_f2bf(eamd_drop_bits(drop_seed, (unsigned long long)(e0 + e)) >= drop_thr ? ov[e] * drop_inv : 0.f);
+            for (int e = 0; e < 4; ++e) h16[e] = eamd_f2bf(keep[e] ? ov[e] * drop_inv : 0.f);
             uint2 pk;
             pk.x = (unsigned)h16[0] | ((unsigned)h16[1] << 16);
             pk.y = (unsigned)h16[2] | ((unsigned)h16[3] << 16);
@@ -256,6 +257,36 @@ __global__ __launch_bounds__(256) void layernorm_bwd_reduce_kernel(const float* 
     const float v = (red[0][lane] + red[1][lane]) + (red[2][lane] + red[3][lane]);
     if (col < D) atomicAdd(&dgamma[col], v);
     else atomicAdd(&dbeta[col - D], v);
+  }
+}
+
+// Deferred second stage: the partials of up to LN_JOBS LayerNorm backward passes (job table in the kernel argument
+// segment) are summed by ONE launch at the end of backward instead of one launch per LayerNorm (80 per training
+// step of the 12-layer Conformer).  grid (ceil(2D/64), njobs); one block owns 64 columns of one job.
+constexpr int LN_JOBS = 64;
+struct LnJobTable { eamd_ln_reduce_job_t j[LN_JOBS]; };
+__global__ __launch_bounds__(256) void layernorm_bwd_reduce_batched_kernel(const LnJobTable tab) {
+  __shared__ float red[4][64];
+  const eamd_ln_reduce_job_t jb = tab.j[blockIdx.y];
+  const int lane = threadIdx.x & 63, sub = threadIdx.x >> 6;
+  const int col = blockIdx.x * 64 + lane;
+  const int D2 = 2 * jb.D;
+  float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+  if (col < D2) {
+    const float* __restrict__ ws = jb.ws;
+    int r = sub;
+    for (; r + 12 < jb.nblk; r += 16) {
+      s0 += ws[(long)r * D2 + col];        s1 += ws[(long)(r + 4) * D2 + col];
+      s2 += ws[(long)(r + 8) * D2 + col];  s3 += ws[(long)(r + 12) * D2 + col];
+    }
+    for (; r < jb.nblk; r += 4) s0 += ws[(long)r * D2 + col];
+  }
+  red[sub][lane] = (s0 + s1) + (s2 + s3);
+  __syncthreads();
+  if (sub == 0 && col < D2) {
+    const float v = (red[0][lane] + red[1][lane]) + (red[2][lane] + red[3][lane]);
+    if (col < jb.D) atomicAdd(&jb.dgamma[col], v);
+    else atomicAdd(&jb.dbeta[col - jb.D], v);
   }
 }
 
@@ -642,14 +673,15 @@ int64_t eamd_layernorm_bwd_workspace(int rows, int D) {
 static int layernorm_bwd_impl(const float* dy, const float* x, const float* gamma, const float* mean, const float* rstd,
                               const float* dres, float* dx, float* dgamma, float* dbeta, float* workspace, int rows, int D,
                               void* drop16, float drop_p, const uint64_t* drop_step, uint64_t drop_salt, void* stream) {
-  if (!dy || !x || !gamma || !mean || !rstd || !dx || !dgamma || !dbeta || rows <= 0 || D <= 0)
+  const bool deferred = !dgamma && !dbeta && workspace;      // partials stay in `workspace` (eamd_layernorm_bwd_reduce)
+  if (!dy || !x || !gamma || !mean || !rstd || !dx || (!deferred && (!dgamma || !dbeta)) || rows <= 0 || D <= 0)
     return EAMD_EINVAL;
   if (D > 1024) return EAMD_EUNSUPPORTED;
   if (drop16 && (drop_p < 0.f || drop_p >= 1.f || !drop_step || ((uintptr_t)drop16 & 7))) return EAMD_EINVAL;
   int nblk, rpb;
   ln_bwd_grid(rows, &nblk, &rpb);
   static const int ws_min = [] { const char* e = getenv("EAMD_LNB_WS_MIN"); return e ? atoi(e) : 32; }();
-  float* ws = nblk >= ws_min ? workspace : nullptr;   // few blocks: direct atomics are cheaper than a second launch
+  float* ws = (deferred || nblk >= ws_min) ? workspace : nullptr;   // few blocks: direct atomics are cheaper than a second launch
   static const int nthr = [] { const char* e = getenv("EAMD_LNB_THREADS"); return e ? atoi(e) : 256; }();
   const bool al = (((uintptr_t)dy | (uintptr_t)x | (uintptr_t)gamma | (uintptr_t)dx | (uintptr_t)dres) & 15) == 0;
   hipStream_t s = (hipStream_t)stream;
@@ -668,7 +700,7 @@ static int layernorm_bwd_impl(const float* dy, const float* x, const float* gamm
                        dgamma, dbeta, ws, rows, D, rpb, d16, drop_p, dst, (unsigned long long)drop_salt);
   }
   EAMD_LAUNCH_CHECK();
-  if (ws) {
+  if (ws && !deferred) {
     hipLaunchKernelGGL(layernorm_bwd_reduce_kernel, dim3((2 * D + 63) / 64, min(16, (nblk + 31) / 32)), dim3(256), 0,
                        s, ws, nblk, D, dgamma, dbeta);
     EAMD_LAUNCH_CHECK();
@@ -681,6 +713,26 @@ int eamd_layernorm_bwd(const float* dy, const float* x, const float* gamma, cons
                        float* workspace, int rows, int D, void* stream) {
   return layernorm_bwd_impl(dy, x, gamma, mean, rstd, dres, dx, dgamma, dbeta, workspace, rows, D, nullptr, 0.f, nullptr, 0,
                             stream);
+}
+
+int eamd_layernorm_bwd_reduce(const eamd_ln_reduce_job_t* jobs, int njobs, void* stream) {
+  if (njobs < 0 || (njobs > 0 && !jobs)) return EAMD_EINVAL;
+  for (int i = 0; i < njobs; ++i)
+    if (!jobs[i].ws || !jobs[i].dgamma || !jobs[i].dbeta || jobs[i].nblk <= 0 || jobs[i].D <= 0 || jobs[i].D > 1024)
+      return EAMD_EINVAL;
+  for (int j0 = 0; j0 < njobs; j0 += LN_JOBS) {
+    const int n = min(LN_JOBS, njobs - j0);
+    LnJobTable tab;
+    int dmax = 0;
+    for (int i = 0; i < LN_JOBS; ++i) {
+      tab.j[i] = jobs[j0 + (i < n ? i : 0)];
+      if (i < n) dmax = max(dmax, tab.j[i].D);
+    }
+    hipLaunchKernelGGL(layernorm_bwd_reduce_batched_kernel, dim3((2 * dmax + 63) / 64, n), dim3(256), 0,
+                       (hipStream_t)stream, tab);
+    EAMD_LAUNCH_CHECK();
+  }
+  return EAMD_OK;
 }
 
 int eamd_layernorm_bwd_drop(const float* dy, const float* x, const float* gamma, const float* mean, const float* rstd,

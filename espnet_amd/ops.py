@@ -284,6 +284,49 @@ def layernorm_fwd(x, gamma, beta, eps, out_dtype=torch.float32):
     return y, mean, rstd
 
 
+class _LnReduceJob(C.Structure):
+    _fields_ = [("ws", C.c_void_p), ("dgamma", C.c_void_p), ("dbeta", C.c_void_p), ("nblk", C.c_int32), ("D", C.c_int32)]
+
+
+# Deferred gamma / beta reduction: inside a backward pass every LayerNorm backward leaves its per-block partial sums
+# in its workspace and ONE launch at the end of the pass (autograd's final callback, the hook DistributedDataParallel
+# uses) adds them all into the gradients - 80 launches per config-2 training step become one.  Only for gradients
+# that live in the flat arena of train.FlatParams (persistent memory); switched off while a
+# GradReducer overlaps bucket all-reduces with backward (the gradients must be final when a block reports them).
+defer_ln_reduce = True
+_ln_pending = []
+_ln_task = -1        # autograd graph-task id the pending partials belong to
+
+
+def flush_ln_reduce():
+    """add the pending LayerNorm gamma / beta partials into their gradients (one launch per 64 LayerNorms)"""
+    global _ln_pending, _ln_task
+    jobs, _ln_pending, _ln_task = _ln_pending, [], -1
+    if not jobs:
+        return
+    tab = (_LnReduceJob * len(jobs))()
+    for i, (ws, dg, db, nblk, D) in enumerate(jobs):
+        tab[i].ws, tab[i].dgamma, tab[i].dbeta, tab[i].nblk, tab[i].D = ws.data_ptr(), dg.data_ptr(), db.data_ptr(), nblk, D
+    with torch.cuda.device(jobs[0][0].device):
+        check(_lib.lib().eamd_layernorm_bwd_reduce(tab, len(jobs), stream_ptr()), "eamd_layernorm_bwd_reduce")
+
+
+def _defer_ln(ws, dgamma, dbeta, nblk, D):
+    """True if the reduction of this pass was queued behind the running backward pass"""
+    global _ln_pending, _ln_task
+    if not defer_ln_reduce or not (getattr(dgamma, "_eamd_arena", False) and getattr(dbeta, "_eamd_arena", False)):
+        return False      # gradients handed back to autograd by value must be complete when backward returns them
+    task = torch._C._current_graph_task_id()
+    if task < 0:                  # not inside a backward pass (direct call): reduce right away
+        return False
+    if task != _ln_task:          # first LayerNorm of this pass (partials of a pass that died are dropped)
+        _ln_pending = []
+        torch.autograd.Variable._execution_engine.queue_callback(flush_ln_reduce)
+        _ln_task = task
+    _ln_pending.append((ws, dgamma, dbeta, nblk, D))
+    return True
+
+
 def layernorm_bwd(dy, x, gamma, mean, rstd, dres, dgamma, dbeta, drop=None):
     """drop = (p, salt): also return bf16(dropout(dx; p, salt)) written by the same kernel (D = 256 / 512 only) ->
     (dx, dx_dropped); otherwise -> dx"""
@@ -291,15 +334,19 @@ def layernorm_bwd(dy, x, gamma, mean, rstd, dres, dgamma, dbeta, drop=None):
     assert dy.shape == x.shape and dgamma.numel() == D and dbeta.numel() == D
     dx = torch.empty_like(x)
     L = _lib.lib()
-    ws = torch.empty(int(L.eamd_layernorm_bwd_workspace(rows, D)), device=x.device, dtype=torch.float32)
+    nws = int(L.eamd_layernorm_bwd_workspace(rows, D))
+    ws = torch.empty(nws, device=x.device, dtype=torch.float32)
+    pg, pb = ptr(dgamma), ptr(dbeta)
+    if _defer_ln(ws, dgamma, dbeta, nws // (2 * D), D):
+        pg = pb = None
     if drop is not None:
         dx16 = torch.empty(rows, D, device=x.device, dtype=torch.bfloat16)
         check(L.eamd_layernorm_bwd_drop(ptr(dy), ptr(x), ptr(gamma), ptr(mean), ptr(rstd), ptr(dres), ptr(dx), ptr(dx16),
-                                        C.c_float(drop[0]), ptr(rng_state(x.device)), C.c_uint64(drop[1]), ptr(dgamma),
-                                        ptr(dbeta), ptr(ws), rows, D, stream_ptr()), "eamd_layernorm_bwd_drop")
+                                        C.c_float(drop[0]), ptr(rng_state(x.device)), C.c_uint64(drop[1]), pg,
+                                        pb, ptr(ws), rows, D, stream_ptr()), "eamd_layernorm_bwd_drop")
         return dx, dx16
     check(L.eamd_layernorm_bwd(ptr(dy), ptr(x), ptr(gamma), ptr(mean), ptr(rstd), ptr(dres), ptr(dx),
-                               ptr(dgamma), ptr(dbeta), ptr(ws), rows, D, stream_ptr()), "eamd_layernorm_bwd")
+                               pg, pb, ptr(ws), rows, D, stream_ptr()), "eamd_layernorm_bwd")
     return dx
 
 

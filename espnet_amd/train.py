@@ -44,6 +44,7 @@ class FlatParams:
             view.copy_(p.data)
             p.data = view
             p._eamd_grad = self.grad[o:o + p.numel()].view(p.shape)
+            p._eamd_grad._eamd_arena = True      # persistent: kernels may still add to it after the block's backward returned
         self.model = model
         self.refresh_shadow()
 
@@ -198,6 +199,7 @@ class GradReducer:
 
 def attach_reducer(reducer):
     F_.GradSink.on_done = reducer.notify if reducer is not None else None
+    ops.defer_ln_reduce = reducer is None     # overlapped buckets need every block's gradients final when it reports
 
 
 def train_step(model, flat, opt, batch, reducer=None, loss_scale=1.0):

@@ -110,6 +110,16 @@ int eamd_layernorm_fwd(const float* x, const float* gamma, const float* beta, fl
  * residual branch's gradient is folded in).  workspace: eamd_layernorm_bwd_workspace(rows, D) floats of
  * scratch for the two-stage column reduction (NULL => one f32 atomic per column per block instead). */
 int64_t eamd_layernorm_bwd_workspace(int rows, int D);
+/* Deferred second stage: with dgamma == dbeta == NULL (workspace required) eamd_layernorm_bwd / _bwd_drop leave the
+ * per-block partial sums in `workspace` = [nblk][2D] floats, nblk = eamd_layernorm_bwd_workspace(rows, D) / (2D);
+ * eamd_layernorm_bwd_reduce then ACCUMULATES the partials of any number of such passes into their dgamma / dbeta
+ * with one launch per 64 jobs (the table is read on the host during the call; the workspaces must stay alive until
+ * the launch has run).  The reference leaves this sum to autograd (nn.LayerNorm backward, layer_norm.py:12-38). */
+typedef struct {
+  const float* ws; float* dgamma; float* dbeta;
+  int32_t nblk, D;
+} eamd_ln_reduce_job_t;
+int eamd_layernorm_bwd_reduce(const eamd_ln_reduce_job_t* jobs, int njobs, void* stream);
 int eamd_layernorm_bwd(const float* dy, const float* x, const float* gamma, const float* mean,
                        const float* rstd, const float* dres, float* dx, float* dgamma, float* dbeta,
                        float* workspace, int rows, int D, void* stream);

@@ -738,3 +738,46 @@ def test_fused_gradient_dropout_matches_separate_pass():
     finally:
         F_.FUSE_GRAD_DROP = True
         espnet_amd.set_precision("fp32")
+
+
+def test_deferred_layernorm_reduction_matches_immediate():
+    """With the flat gradient arena (train.FlatParams) the gamma / beta partial sums of all LayerNorm backward passes
+    are added by one launch at the end of backward (autograd final callback); the gradients must equal those of the
+    per-LayerNorm second stage, and a direct call outside a backward pass must still reduce on the spot."""
+    from espnet_amd import ops, train
+    p, sd, _ = split_golden(load_golden("e2e_conformer.npz"))
+    torch.manual_seed(5)
+    model = _e2e("conformer", CASES[0][2]).to(DEV).train()
+    flat = train.FlatParams(model)
+    grads, seen = {}, {}
+    orig = ops.flush_ln_reduce
+    try:
+        for defer in (True, False):
+            ops.defer_ln_reduce = defer
+            flat.zero_grad()
+            loss = model(p["xs"].to(DEV), p["ilens"], p["ys"].to(DEV))
+            loss.backward()
+            seen[defer] = ops._ln_task
+            assert not ops._ln_pending and ops._ln_task == -1
+            grads[defer] = {k: q._eamd_grad.clone() for k, q in model.named_parameters()}
+    finally:
+        ops.defer_ln_reduce = True
+    n_ln = 0
+    for k in grads[True]:
+        a, b = grads[True][k].double(), grads[False][k].double()
+        assert float((a - b).norm()) <= 1e-5 * float(b.norm()) + 1e-5, k      # linear_k.bias has a zero gradient: noise only
+        if "norm" in k:
+            n_ln += 1
+            assert float(b.norm()) > 0
+    assert n_ln > 0
+    # direct call (no graph task): reduced immediately
+    x = torch.randn(700, 256, device=DEV)
+    dy = torch.randn_like(x)
+    g = torch.randn(256, device=DEV)
+    mean, var = x.mean(1), x.var(1, unbiased=False)
+    rstd = (var + 1e-12).rsqrt()
+    dg, db = torch.zeros(256, device=DEV), torch.zeros(256, device=DEV)
+    dg._eamd_arena = db._eamd_arena = True
+    ops.layernorm_bwd(dy, x, g, mean, rstd, None, dg, db)
+    assert torch.allclose(db, dy.sum(0), rtol=1e-4, atol=1e-3)
+    assert torch.allclose(dg, (dy * (x - mean[:, None]) * rstd[:, None]).sum(0), rtol=1e-4, atol=1e-3)

@@ -1,0 +1,81 @@
+#!/usr/bin/env python3
+"""Where the GEMM family's time goes: every eamd_gemm descriptor of one config-2 training step, grouped by shape /
+layout / epilogue, each group timed by graph replay of its own launches (device time, no host gaps)."""
+import collections
+import ctypes
+import os
+import sys
+import time
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import bench  # noqa: E402
+import espnet_amd  # noqa: E402
+from espnet_amd import _lib as L_, ops, train  # noqa: E402
+from espnet_amd.nets.e2e_asr_conformer import E2E  # noqa: E402
+
+
+def main():
+    dev = torch.device("cuda", 0)
+    espnet_amd.set_precision("bf16")
+    B, T, L, V = 32, 1000, 100, 5000
+    torch.manual_seed(0)
+    model = E2E(80, V, bench.c2_args(0.1)).to(dev).train()
+    model.sync_report = False
+    ops.manual_seed(1234)
+    flat = train.FlatParams(model)
+    opt = train.NoamAdam(flat, mode="noam", factor=1.0, model_size=256, warmup=25000, max_grad_norm=5.0)
+    xs, ilens, ys = bench.synth_batch(B, T, L, V)
+    batch = model.prepare(xs, ilens, ys)
+    for _ in range(2):
+        train.train_step(model, flat, opt, batch, None)
+    torch.cuda.synchronize()
+    rec = []
+    ops._gemm_record = rec
+    train.train_step(model, flat, opt, batch, None)
+    torch.cuda.synchronize()
+    ops._gemm_record = None
+    lib = L_.lib()
+    groups = collections.OrderedDict()
+    for p, keep in rec:
+        key = (p.M, p.N, p.K, p.transA, p.transB, p.batch1 * p.batch2, p.splitk, p.epilogue, int(p.gather.enabled),
+               int(bool(p.C)), int(bool(p.Cb)), int(bool(p.Hb)), int(bool(p.R)), int(bool(p.aux)), int(bool(p.colsum)),
+               int(p.drop_p > 0), p.in_dtype)
+        groups.setdefault(key, []).append(p)
+    rows = []
+    for key, ps in groups.items():
+        def f():
+            sp = ops.stream_ptr()
+            for p in ps:
+                L_.check(lib.eamd_gemm(ctypes.byref(p), sp), "eamd_gemm")
+        g = torch.cuda.CUDAGraph()
+        s = torch.cuda.Stream()
+        s.wait_stream(torch.cuda.current_stream())
+        reps = max(1, 40 // len(ps))
+        with torch.cuda.stream(s):
+            f()
+            torch.cuda.synchronize()
+            with torch.cuda.graph(g, stream=s):
+                for _ in range(reps):
+                    f()
+        torch.cuda.synchronize()
+        g.replay()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(5):
+            g.replay()
+        torch.cuda.synchronize()
+        us = (time.perf_counter() - t0) / 5 / reps / len(ps) * 1e6
+        fl = 2.0 * key[0] * key[1] * key[2] * key[5]
+        rows.append((us * len(ps), len(ps), us, fl / us / 1e6, key))
+    rows.sort(reverse=True)
+    tot = sum(r[0] for r in rows)
+    print("total %.1f us over %d launches" % (tot, len(rec)))
+    print("%9s %4s %8s %7s | M N K tA tB batch splitk epi gather C Cb Hb R aux colsum drop bf16in" % ("sum us", "n", "us each", "TF/s"))
+    for r in rows:
+        print("%9.1f %4d %8.1f %7.1f | %s" % (r[0], r[1], r[2], r[3], " ".join(str(k) for k in r[4])))
+
+
+if __name__ == "__main__":
+    main()
