@@ -483,6 +483,7 @@ bool aligned16(const void* q) { return (reinterpret_cast<uintptr_t>(q) & 15) == 
 }  // namespace
 
 int eamd_gemm_bf16_persist(const eamd_gemm_t& p, int ntiles, hipStream_t stream);   // gemm_persist.hip
+int eamd_gemm_bf16_direct(const eamd_gemm_t& p, hipStream_t stream);                // gemm_direct.hip
 
 // called by eamd_gemm (gemm.hip) after argument validation when in_dtype == 1
 int eamd_gemm_bf16_dispatch(const eamd_gemm_t& p, int tile, hipStream_t stream) {
@@ -505,6 +506,12 @@ int eamd_gemm_bf16_dispatch(const eamd_gemm_t& p, int tile, hipStream_t stream) 
                       : launch_b<128, 128, false, true, true, true>(p, stream);
     return p.transA ? launch_b<64, 64, true, true, true, true>(p, stream)
                     : launch_b<64, 64, false, true, true, true>(p, stream);
+  }
+  if (a_ok && b_ok && tile == 64 && !p.transA && !p.transB && (p.K == 64 || p.K == 128) && p.splitk == 1 && p.C && !p.Cb &&
+      !p.Hb && !p.bias && !p.aux && !p.R && !p.colsum && p.epilogue == 0 && p.beta == 0.f && p.drop_p <= 0.f &&
+      p.a_act == EAMD_ACT_NONE && p.b_act == EAMD_ACT_NONE && !p.cmap.enabled) {
+    static const int direct_on = [] { const char* e = getenv("EAMD_GEMM_DIRECT"); return e ? atoi(e) : 1; }();
+    if (direct_on) return eamd_gemm_bf16_direct(p, stream);      // attention score products: one or two K-tiles
   }
   if (a_ok && b_ok && tile == 64) {
     static const int persist_min = [] { const char* e = getenv("EAMD_GEMM_PERSIST_MIN"); return e ? atoi(e) : 1536; }();

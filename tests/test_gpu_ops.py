@@ -699,3 +699,27 @@ def test_gemm_persistent_tiles(ops, shape):
         report("persistent gemm dual h", h.float(), ops.dropout(ref, 0.1, 3, act=ops.ACT_SWISH), 4e-3)
     finally:
         espnet_amd.set_precision("fp32")
+
+
+@pytest.mark.parametrize("dims", [(32, 249, 249, 4, 64), (3, 101, 249, 4, 64), (5, 7, 300, 2, 64), (9, 130, 65, 2, 128)])
+def test_gemm_direct_short_k(ops, dims):
+    """k-contiguous bf16 products with K = 64 / 128 and a plain fp32 result take the register-direct kernel
+    (gemm_direct.hip): attention-score layout [B,T,H,dk] x [B,T,H,dk] -> [H,B,T1,ldp], ragged edges, batch counts
+    that are not multiples of the 8 XCDs, alpha; pad columns of the result stay untouched"""
+    Bb, T1, T2, H, dk = dims
+    D = H * dk
+    g = torch.Generator().manual_seed(T1 + T2)
+    q, k = ((torch.randn(Bb, T, D, generator=g)).to(torch.bfloat16) for T in (T1, T2))
+    ldp = (T2 + 7) // 8 * 8
+    sc = torch.full((H * Bb * T1 * ldp,), -7.0, device=DEV)
+    ops.gemm(q.to(DEV), k.to(DEV), sc, T1, T2, dk, D, D, ldp, batch=(Bb, H), sA=(T1 * D, dk), sB=(T2 * D, dk),
+             sC=(T1 * ldp, Bb * T1 * ldp), alpha=0.25)
+    ref = 0.25 * torch.einsum("bihd,bjhd->hbij", q.view(Bb, T1, H, dk).double(), k.view(Bb, T2, H, dk).double())
+    got = sc.view(H, Bb, T1, ldp)
+    report("gemm_direct %s" % (dims,), got[..., :T2], ref, 3e-6)
+    assert bool((got[..., T2:] == -7.0).all())
+    # unbatched, M and N below one wave tile
+    a, b = (torch.randn(n, 64, generator=g).to(torch.bfloat16) for n in (5, 19))
+    C = torch.empty(5, 19, device=DEV)
+    ops.gemm(a.to(DEV), b.to(DEV), C, 5, 19, 64, 64, 64, 19)
+    report("gemm_direct tiny", C, a.double() @ b.double().t(), 3e-6)
