@@ -1,0 +1,264 @@
+// Fused attention forward for bf16 activations, d_k = 64, up to 256 keys: scores (+ relative-position term with the
+// legacy rel_shift), mask, softmax and the context product in ONE kernel; the fp32 scores never reach HBM.
+// reference: transformer/attention.py:63-114 (forward_attention / MultiHeadedAttention.forward),
+//            attention.py:141-206 (RelPositionMultiHeadedAttention: rel_shift, (ac + bd) / sqrt(d_k)).
+//
+// One workgroup = one (batch, head) pair x 64 queries; wave w owns 16 queries and ALL keys, so a softmax row never
+// leaves its wave.  Everything is computed in the transposed orientation S^T = K Q^T:
+//   * the 16x16x32 MFMA operand layout of a k-contiguous matrix is 16 bytes of global memory per lane, so the K, q,
+//     positional and (q+v) fragments are loaded straight into registers (no operand staging, no barriers);
+//   * the accumulator of tile t then holds, for query `lane & 15`, the keys 16 t + 4 (lane >> 4) + {0..3}: four
+//     ADJACENT probabilities per lane - an 8-byte bf16 store into P, and exactly the pairing the context product
+//     needs: with the (arbitrary) contraction order "keys 32 s + 4 q + {0..3}, then 32 s + 16 + 4 q + {0..3}" the
+//     probabilities of tiles 2s, 2s+1 ARE the MFMA operand, no layout change through LDS.  The V fragments of
+//     the same order come from ds_read_b64_tr_b16 on a V panel staged once per workgroup;
+//   * the context is accumulated as C^T = V^T P^T, which leaves four adjacent channels per lane (8-byte stores).
+// The legacy rel_shift is a flat re-indexing of bd = (q+v) p^T padded with a zero column: shifted[i][j] =
+// pad_flat[T1 + i T2 + j] over rows of T2 + 1.  Each wave writes the 17 rows of bd its 16 queries touch (T1 == T2)
+// into a private LDS image with exactly that padding and reads the shifted values back with one add per element.
+// After the softmax the pad images are dead and the V panel is staged over them.
+#include "gemm_bf16_common.h"
+
+namespace {
+
+constexpr int ATT_DK = 64;
+constexpr int ATT_MAXK = 256;                 // keys per row (16 accumulator tiles of 16)
+
+struct AttnArgs {
+  const bf16_t* qu; const bf16_t* qv; const bf16_t* k; const bf16_t* v; const bf16_t* pos;
+  const unsigned char* mask;
+  bf16_t* P; bf16_t* ctx;
+  long ldq, ldqv, ldk, ldv, ldpos, ldc, ldp, mb, mi;
+  int B, H, T1, T2, nqb;
+  float scale;
+};
+
+__device__ __forceinline__ float xor_max16_32(float v) {
+  v = fmaxf(v, __shfl_xor(v, 16));
+  return fmaxf(v, __shfl_xor(v, 32));
+}
+__device__ __forceinline__ float xor_sum16_32(float v) {
+  v += __shfl_xor(v, 16);
+  return v + __shfl_xor(v, 32);
+}
+
+// NKT = key tiles of 16 the instantiation covers (T2 <= 16 NKT).  Every loop over tiles is fully unrolled and free of
+// branches: rows past T2 are clamped re-reads whose scores are masked, so that all fragment loads of a phase are in
+// flight together (a uniform `if (tile < T2)` per tile made each load wait for the previous tile's MFMAs).
+template <bool REL, int NKT>
+__global__ __launch_bounds__(256) void attn_fwd_kernel(const AttnArgs a) {
+  extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+  const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+  const int fr = lane & 15, fq = lane >> 4;
+  // (batch, head) pairs are dealt to the XCDs in contiguous runs: the query blocks of one pair share an L2
+  const int xcd = blockIdx.x & 7, jb = blockIdx.x >> 3;
+  const int z = (jb / a.nqb) * 8 + xcd;            // z = h * B + b, as the score tensors are laid out
+  const bool live = z < a.B * a.H;                 // whole workgroup; dead ones only keep the barriers company
+  const int zz = live ? z : 0;
+  const int h = zz / a.B, b = zz % a.B;
+  const int r0 = (jb % a.nqb) * 64 + wave * 16;    // first query of this wave
+  const bool active = live && r0 < a.T1;
+  const int T1 = a.T1, T2 = a.T2;
+  const int qi = min(r0 + fr, T1 - 1);             // this lane's query (clamped lanes are never stored)
+
+  f32x4 S[NKT];
+#pragma unroll
+  for (int kt = 0; kt < NKT; ++kt) S[kt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+  float* pad = reinterpret_cast<float*>(smem_raw) + (long)wave * 17 * (T2 + 1);
+  if (REL && active) {
+    // ---- bd^T tiles: rows = positions m, columns = queries r0 .. r0+31 (only r0 .. r0+16 are kept) ----
+    uint4 qf[2][2];
+#pragma unroll
+    for (int g = 0; g < 2; ++g) {
+      const bf16_t* qr = a.qv + ((long)b * T1 + min(r0 + 16 * g + fr, T1 - 1)) * a.ldqv + h * ATT_DK + fq * 8;
+      qf[g][0] = *reinterpret_cast<const uint4*>(qr);
+      qf[g][1] = *reinterpret_cast<const uint4*>(qr + 32);
+    }
+    if (fq == 0) pad[fr * (T2 + 1)] = 0.f;                  // the zero column of rows 0 .. 15
+    if (lane == 0) pad[16 * (T2 + 1)] = 0.f;                // ... and of row 16
+#pragma unroll
+    for (int mt = 0; mt < NKT; ++mt) {
+      const bf16_t* pr = a.pos + (long)min(mt * 16 + fr, T2 - 1) * a.ldpos + h * ATT_DK + fq * 8;
+      const uint4 p0 = *reinterpret_cast<const uint4*>(pr), p1 = *reinterpret_cast<const uint4*>(pr + 32);
+      f32x4 c0 = (f32x4){0.f, 0.f, 0.f, 0.f}, c1 = c0;
+      c0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, p0), __builtin_bit_cast(bf16x8, qf[0][0]), c0, 0, 0, 0);
+      c0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, p1), __builtin_bit_cast(bf16x8, qf[0][1]), c0, 0, 0, 0);
+      c1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, p0), __builtin_bit_cast(bf16x8, qf[1][0]), c1, 0, 0, 0);
+      c1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, p1), __builtin_bit_cast(bf16x8, qf[1][1]), c1, 0, 0, 0);
+      // c[r] = bd[query r0 + 16 g + fr][m = 16 mt + 4 fq + r]  ->  pad row (16 g + fr), column 1 + m
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int m = mt * 16 + fq * 4 + r;
+        if (m < T2) {
+          pad[fr * (T2 + 1) + 1 + m] = c0[r];
+          if (fr == 0) pad[16 * (T2 + 1) + 1 + m] = c1[r];
+        }
+      }
+    }
+  }
+  if (active) {
+    // ---- ac^T tiles: rows = keys, columns = this wave's 16 queries ----
+    const bf16_t* qr = a.qu + ((long)b * T1 + qi) * a.ldq + h * ATT_DK + fq * 8;
+    const uint4 q0 = *reinterpret_cast<const uint4*>(qr), q1 = *reinterpret_cast<const uint4*>(qr + 32);
+#pragma unroll
+    for (int kt = 0; kt < NKT; ++kt) {
+      const bf16_t* kr = a.k + ((long)b * T2 + min(kt * 16 + fr, T2 - 1)) * a.ldk + h * ATT_DK + fq * 8;
+      const uint4 k0 = *reinterpret_cast<const uint4*>(kr), k1 = *reinterpret_cast<const uint4*>(kr + 32);
+      S[kt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, k0), __builtin_bit_cast(bf16x8, q0), S[kt], 0, 0, 0);
+      S[kt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, k1), __builtin_bit_cast(bf16x8, q1), S[kt], 0, 0, 0);
+    }
+  }
+  // ---- scale, rel-shift term, mask, softmax over the keys of query (r0 + fr) ----
+  uint2 Pk[NKT];                                    // four bf16 probabilities per tile
+  if (active) {
+    // pad index of (query fr, key j): T1 + (r0 + fr) T2 + j - r0 (T2 + 1); rows past T1 are clamped into the image
+    const int pmax = 17 * (T2 + 1) - 1;
+    const int pbase = T1 + (r0 + fr) * T2 - r0 * (T2 + 1);
+    // mask bytes of this lane's keys: unconditional clamped loads (a load behind a lane-dependent guard is waited
+    // for on the spot), all of them in flight together; keys past T2 are masked by index below
+    unsigned mk[NKT];
+    if (a.mask) {
+      const unsigned char* mr = a.mask + (long)b * a.mb + (long)qi * a.mi;
+#pragma unroll
+      for (int kt = 0; kt < NKT; ++kt) {
+        const int j0 = kt * 16 + fq * 4;
+        const unsigned m0 = mr[min(j0, T2 - 1)], m1 = mr[min(j0 + 1, T2 - 1)], m2 = mr[min(j0 + 2, T2 - 1)],
+                       m3 = mr[min(j0 + 3, T2 - 1)];
+        mk[kt] = m0 | (m1 << 8) | (m2 << 16) | (m3 << 24);
+      }
+    } else {
+#pragma unroll
+      for (int kt = 0; kt < NKT; ++kt) mk[kt] = 0x01010101u;
+    }
+    float mx = -INFINITY;
+#pragma unroll
+    for (int kt = 0; kt < NKT; ++kt) {
+      const int j0 = kt * 16 + fq * 4;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int j = j0 + r;
+        float x = S[kt][r];
+        if (REL) x += pad[min(pbase + j, pmax)];
+        x *= a.scale;
+        if (j >= T2 || ((mk[kt] >> (8 * r)) & 0xffu) == 0u) x = -INFINITY;
+        S[kt][r] = x;
+        mx = fmaxf(mx, x);
+      }
+    }
+    mx = xor_max16_32(mx);
+    const bool dead = mx == -INFINITY;              // every key masked: softmax(min, ...) = uniform, then masked_fill(0)
+    float sum = 0.f;
+#pragma unroll
+    for (int kt = 0; kt < NKT; ++kt)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const float e = dead ? 0.f : __expf(S[kt][r] - mx);
+        S[kt][r] = e;
+        sum += e;
+      }
+    sum = xor_sum16_32(sum);
+    const float inv = dead ? 0.f : 1.f / sum;
+    const bool qok = r0 + fr < T1;
+    bf16_t* prow = a.P + ((long)zz * T1 + qi) * a.ldp;
+#pragma unroll
+    for (int kt = 0; kt < NKT; ++kt) {
+      Pk[kt].x = (unsigned)eamd_f2bf(S[kt][0] * inv) | ((unsigned)eamd_f2bf(S[kt][1] * inv) << 16);
+      Pk[kt].y = (unsigned)eamd_f2bf(S[kt][2] * inv) | ((unsigned)eamd_f2bf(S[kt][3] * inv) << 16);
+      const int j0 = kt * 16 + fq * 4;
+      if (qok && j0 < a.ldp) *reinterpret_cast<uint2*>(prow + j0) = Pk[kt];     // pad columns receive zeros
+    }
+  } else {
+#pragma unroll
+    for (int kt = 0; kt < NKT; ++kt) Pk[kt] = make_uint2(0u, 0u);
+  }
+  __syncthreads();                                  // every wave is done with its pad image
+  // ---- V panel [256 keys][64 channels] -> LDS (k-strided image, rows past T2 are zero) ----
+  bf16_t* Vs = reinterpret_cast<bf16_t*>(smem_raw);
+#pragma unroll
+  for (int q = 0; q < NKT / 2; ++q) {
+    const int c = t + 256 * q, row = c >> 3, c16 = c & 7;
+    uint4 v = *reinterpret_cast<const uint4*>(a.v + ((long)b * T2 + min(row, T2 - 1)) * a.ldv + h * ATT_DK + c16 * 8);
+    if (row >= T2) v = make_uint4(0u, 0u, 0u, 0u);
+    *reinterpret_cast<uint4*>(&Vs[lds_chunk_off<true, 64>(row, c16)]) = v;
+  }
+  __syncthreads();
+  if (!active) return;
+  // ---- context^T = V^T P^T: rows = channels, columns = queries ----
+  f32x4 C[4];
+#pragma unroll
+  for (int dt = 0; dt < 4; ++dt) C[dt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int ks = 0; ks < NKT / 2; ++ks) {
+    {
+      const uint4 pw = make_uint4(Pk[2 * ks].x, Pk[2 * ks].y, Pk[2 * ks + 1].x, Pk[2 * ks + 1].y);
+      const bf16x8 pf = __builtin_bit_cast(bf16x8, pw);
+      const int rlo = ks * 32 + 4 * fq + (fr >> 2), rhi = rlo + 16;
+#pragma unroll
+      for (int dt = 0; dt < 4; ++dt) {
+        const int cc = dt * 16 + 4 * (fr & 3);
+        const bf16_t* q0 = &Vs[lds_chunk_off<true, 64>(rlo, cc >> 3) + (cc & 7)];
+        const bf16_t* q1 = &Vs[lds_chunk_off<true, 64>(rhi, cc >> 3) + (cc & 7)];
+        s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4 __attribute__((address_space(3)))*)q0);
+        s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4 __attribute__((address_space(3)))*)q1);
+        const bf16x8 vf = (bf16x8){lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+        C[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf, pf, C[dt], 0, 0, 0);
+      }
+    }
+  }
+  if (r0 + fr < T1) {
+    bf16_t* crow = a.ctx + ((long)b * T1 + r0 + fr) * a.ldc + h * ATT_DK;
+#pragma unroll
+    for (int dt = 0; dt < 4; ++dt) {
+      uint2 o;
+      o.x = (unsigned)eamd_f2bf(C[dt][0]) | ((unsigned)eamd_f2bf(C[dt][1]) << 16);
+      o.y = (unsigned)eamd_f2bf(C[dt][2]) | ((unsigned)eamd_f2bf(C[dt][3]) << 16);
+      *reinterpret_cast<uint2*>(crow + dt * 16 + fq * 4) = o;
+    }
+  }
+}
+
+template <bool REL, int NKT>
+int launch_attn(const AttnArgs& a, size_t smem, hipStream_t stream) {
+  static const hipError_t attr_err = hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_fwd_kernel<REL, NKT>),
+                                                         hipFuncAttributeMaxDynamicSharedMemorySize, 72 * 1024);
+  if (attr_err != hipSuccess) return (int)attr_err;
+  const int nz = (a.B * a.H + 7) / 8 * 8;
+  hipLaunchKernelGGL((attn_fwd_kernel<REL, NKT>), dim3((unsigned)(a.nqb * nz)), dim3(256), smem, stream, a);
+  EAMD_LAUNCH_CHECK();
+  return EAMD_OK;
+}
+
+bool al16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
+
+}  // namespace
+
+extern "C" int eamd_attn_fwd(const void* qu, int64_t ldq, const void* qv, int64_t ldqv, const void* k, int64_t ldk,
+                             const void* v, int64_t ldv, const void* pos, int64_t ldpos, const unsigned char* mask,
+                             int64_t mask_bstride, int64_t mask_qstride, void* P_bf16, int64_t ldp, void* ctx_bf16,
+                             int64_t ldc, int B, int H, int T1, int T2, int dk, float scale, void* stream) {
+  if (!qu || !k || !v || !P_bf16 || !ctx_bf16 || B <= 0 || H <= 0 || T1 <= 0 || T2 <= 0) return EAMD_EINVAL;
+  if ((pos == nullptr) != (qv == nullptr)) return EAMD_EINVAL;
+  if (dk != ATT_DK || T2 > ATT_MAXK || (pos && T1 != T2)) return EAMD_EUNSUPPORTED;
+  if (ldq % 8 || ldk % 8 || ldv % 8 || ldc % 4 || ldp % 8 || ldp < T2 || (pos && (ldqv % 8 || ldpos % 8)))
+    return EAMD_EUNSUPPORTED;
+  if (!al16(qu) || !al16(k) || !al16(v) || !al16(P_bf16) || (reinterpret_cast<uintptr_t>(ctx_bf16) & 7) ||
+      (pos && (!al16(qv) || !al16(pos))))
+    return EAMD_EUNSUPPORTED;
+  if ((long)B * H * ((T1 + 63) / 64) >= (1L << 28)) return EAMD_EUNSUPPORTED;
+  AttnArgs a;
+  a.qu = (const bf16_t*)qu; a.qv = (const bf16_t*)qv; a.k = (const bf16_t*)k; a.v = (const bf16_t*)v;
+  a.pos = (const bf16_t*)pos; a.mask = mask; a.P = (bf16_t*)P_bf16; a.ctx = (bf16_t*)ctx_bf16;
+  a.ldq = ldq; a.ldqv = ldqv; a.ldk = ldk; a.ldv = ldv; a.ldpos = ldpos; a.ldc = ldc; a.ldp = ldp;
+  a.mb = mask_bstride; a.mi = mask_qstride;
+  a.B = B; a.H = H; a.T1 = T1; a.T2 = T2; a.nqb = (T1 + 63) / 64; a.scale = scale;
+  const bool half = T2 <= 128;                                       // 8 key tiles instead of 16
+  const size_t vbytes = (size_t)(half ? 128 : ATT_MAXK) * ATT_DK * sizeof(bf16_t);
+  hipStream_t s = (hipStream_t)stream;
+  if (pos) {
+    const size_t pbytes = (size_t)4 * 17 * (T2 + 1) * sizeof(float);
+    const size_t smem = pbytes > vbytes ? pbytes : vbytes;
+    return half ? launch_attn<true, 8>(a, smem, s) : launch_attn<true, 16>(a, smem, s);
+  }
+  return half ? launch_attn<false, 8>(a, vbytes, s) : launch_attn<false, 16>(a, vbytes, s);
+}

@@ -342,6 +342,20 @@ def attn_scores_fwd(qu, qv, k, p, mask, B, T1, T2, H, dk):
     return P
 
 
+FUSE_ATTN = True   # tests flip this to compare against the GEMM / softmax / GEMM path
+
+
+def attn_fwd_fused(qu, qv, k, v, p, mask, B, T1, T2, H, dk):
+    """(P, ctx) from eamd_attn_fwd, or None when the library declines the operands"""
+    qu, k, v = _mv(qu), _mv(k), _mv(v)
+    qv3 = None
+    if p is not None:
+        qvm = _mv(qv)
+        qv3 = (qvm.t, qvm.off, qvm.ld)
+    return ops.attn_fwd((qu.t, qu.off, qu.ld), qv3, (k.t, k.off, k.ld), (v.t, v.off, v.ld), p, mask, B, T1, T2, H, dk,
+                        _ldp(T2), 1.0 / math.sqrt(dk))
+
+
 def attn_context_fwd(P, v, B, T1, T2, H, dk):
     D = H * dk
     ldp = _ldp(T2)
@@ -484,9 +498,16 @@ class MHABlockFn(torch.autograd.Function):
                 qu, qv = ops.add_bias2(q, pu.reshape(-1), pv.reshape(-1))
         else:
             p, qu, qv = None, q, None
-        P = attn_scores_fwd(qu, qv, k, p, mask, B, T1, T2, H, dk)
-        Pd = ops.dropout(P, p_att, s_att) if p_att > 0.0 else P
-        cx = attn_context_fwd(Pd, v, B, T1, T2, H, dk)
+        fwd = None
+        if FUSE_ATTN and p_att <= 0.0 and ops.attn_fwd_supported(T1, T2, dk, rel):
+            fwd = attn_fwd_fused(qu, qv, k, v, p, mask, B, T1, T2, H, dk)      # scores, softmax and context in one launch
+        if fwd is not None:
+            P, cx = fwd
+            Pd = P
+        else:
+            P = attn_scores_fwd(qu, qv, k, p, mask, B, T1, T2, H, dk)
+            Pd = ops.dropout(P, p_att, s_att) if p_att > 0.0 else P
+            cx = attn_context_fwd(Pd, v, B, T1, T2, H, dk)
         if p_out > 0.0 and ops.fast():
             out = ops.linear_fwd(cx, ops.wshadow(wo), bo, R=res, drop=(p_out, s_out))
         elif p_out > 0.0:

@@ -350,6 +350,38 @@ def layernorm_bwd(dy, x, gamma, mean, rstd, dres, dgamma, dbeta, drop=None):
     return dx
 
 
+def attn_fwd_supported(T1, T2, dk, rel):
+    """shapes the fused attention forward (eamd_attn_fwd) covers; alignment is checked by the library"""
+    return fast() and dk == 64 and T2 <= 256 and (not rel or T1 == T2)
+
+
+def attn_fwd(qu, qv, k, v, pos, mask, B, T1, T2, H, dk, ldp, scale):
+    """qu / qv / k / v: (tensor, element offset, row stride) views of bf16 [rows, *] matrices, heads side by side;
+    pos: bf16 [T2, H*dk] or None.  Returns (P bf16 [H*B*T1*ldp], ctx bf16 [B*T1, H*dk]) or None if the library
+    declines the operands (EAMD_EUNSUPPORTED)."""
+    dev = qu[0].device
+    D = H * dk
+    mb = mi = 0
+    if mask is not None:
+        assert mask.dtype == torch.uint8 and mask.is_contiguous() and mask.dim() == 3 and mask.shape[0] in (1, B)
+        assert mask.shape[2] == T2 and mask.shape[1] in (1, T1)
+        mb = 0 if mask.shape[0] == 1 else mask.shape[1] * mask.shape[2]
+        mi = 0 if mask.shape[1] == 1 else T2
+    for t_, _, _ in (qu, k, v) + ((qv,) if qv is not None else ()):
+        assert t_.dtype == torch.bfloat16 and t_.is_cuda
+    P = torch.empty(H * B * T1 * ldp, device=dev, dtype=torch.bfloat16)
+    cx = torch.empty(B * T1, D, device=dev, dtype=torch.bfloat16)
+    i64 = C.c_int64
+    rc = _lib.lib().eamd_attn_fwd(
+        ptr(qu[0], qu[1]), i64(qu[2]), ptr(qv[0], qv[1]) if qv is not None else None, i64(qv[2] if qv is not None else 0),
+        ptr(k[0], k[1]), i64(k[2]), ptr(v[0], v[1]), i64(v[2]), ptr(pos), i64(D if pos is not None else 0),
+        ptr(mask), i64(mb), i64(mi), ptr(P), i64(ldp), ptr(cx), i64(D), B, H, T1, T2, dk, C.c_float(scale), stream_ptr())
+    if rc == _lib.EAMD_EUNSUPPORTED:
+        return None
+    check(rc, "eamd_attn_fwd")
+    return P, cx
+
+
 def softmax_fwd(ac, bd, mask, P, nblocks, B, T1, T2, ld, scale):
     """P may be fp32 (may alias ac) or bf16 (separate buffer)"""
     mb = mi = 0

@@ -146,6 +146,19 @@ int eamd_softmax_fwd(const float* ac, const float* bd, const unsigned char* mask
 int eamd_softmax_bwd(const float* P, const void* P_bf16, float* dP, float* dbd, void* dS_bf16, void* dbd_bf16,
                      int nblocks, int T1, int T2, int64_t ld, float scale, void* stream);
 
+/* Fused attention forward (bf16 activations, d_k = 64, T2 <= 256): P = softmax(mask(scale * (qu k^T + rel_shift(qv pos^T))))
+ * and ctx = P v in one launch; the fp32 scores stay on chip.  reference: transformer/attention.py:63-114 (forward_attention,
+ * MultiHeadedAttention.forward), :141-206 (RelPositionMultiHeadedAttention).  All operands are bf16 with heads side by side:
+ * element (b, t, h, d) of qu at qu[(b*T1 + t)*ldq + h*64 + d] (k, v: T2 rows per batch; pos: (m, h, d) at pos[m*ldpos + h*64 + d],
+ * shared by the batch).  qv / pos are both NULL (no relative positions) or both set (then T1 == T2).  mask as in
+ * eamd_softmax_fwd.  Outputs: P_bf16 [H][B][T1][ldp] (pad columns zeroed; kept for the backward pass) and
+ * ctx_bf16 (b, t, h, d) at ctx[(b*T1 + t)*ldc + h*64 + d].  EAMD_EUNSUPPORTED for other d_k / longer rows / unaligned
+ * operands: callers then run the score GEMMs, eamd_softmax_fwd and the context GEMM instead. */
+int eamd_attn_fwd(const void* qu, int64_t ldq, const void* qv, int64_t ldqv, const void* k, int64_t ldk, const void* v,
+                  int64_t ldv, const void* pos, int64_t ldpos, const unsigned char* mask, int64_t mask_bstride,
+                  int64_t mask_qstride, void* P_bf16, int64_t ldp, void* ctx_bf16, int64_t ldc, int B, int H, int T1,
+                  int T2, int dk, float scale, void* stream);
+
 /* Label-smoothing KL loss rows + argmax-correct flags + gradient (softmax - true_dist)*inv_denom.
  * reference: transformer/label_smoothing_loss.py:44-63, nets_utils.py:299-319 (th_accuracy). */
 int eamd_lsm_loss(const float* logits, const int64_t* target, float* loss_rows, float* correct_rows,

@@ -723,3 +723,57 @@ def test_gemm_direct_short_k(ops, dims):
     C = torch.empty(5, 19, device=DEV)
     ops.gemm(a.to(DEV), b.to(DEV), C, 5, 19, 64, 64, 64, 19)
     report("gemm_direct tiny", C, a.double() @ b.double().t(), 3e-6)
+
+
+@pytest.mark.parametrize("case", [
+    dict(B=3, T1=249, T2=249, rel=True, mask="len"), dict(B=2, T1=256, T2=256, rel=True, mask=None),
+    dict(B=9, T1=30, T2=30, rel=True, mask="len"), dict(B=2, T1=65, T2=65, rel=True, mask="len"),
+    dict(B=2, T1=101, T2=249, rel=False, mask="len"), dict(B=3, T1=101, T2=101, rel=False, mask="causal"),
+    dict(B=2, T1=1, T2=77, rel=False, mask="len"), dict(B=2, T1=64, T2=16, rel=False, mask="dead")])
+def test_attention_forward_fused_matches_unfused(ops, case):
+    """eamd_attn_fwd (scores + rel-shift + mask + softmax + context in one launch) against the score GEMMs,
+    eamd_softmax_fwd and the context GEMM on the same bf16 operands: probabilities and context agree to bf16 rounding,
+    fully masked rows give zeros, pad columns of P are zero; q / k / v are column blocks of one fused [B*T, 3D] buffer
+    where the layout allows it (self-attention), as in the model"""
+    import espnet_amd
+    from espnet_amd import functional as F_
+    espnet_amd.set_precision("bf16")
+    try:
+        B, T1, T2, rel, mk = case["B"], case["T1"], case["T2"], case["rel"], case["mask"]
+        H, dk = 4, 64
+        D = H * dk
+        g = torch.Generator().manual_seed(T1 * 7 + T2)
+        bf = lambda *s: torch.randn(*s, generator=g).to(torch.bfloat16).to(DEV)
+        if T1 == T2:
+            qkv = bf(B * T1, 3 * D)
+            k, v = F_._MV(qkv, D, 3 * D), F_._MV(qkv, 2 * D, 3 * D)
+            qu = bf(B * T1, D) if rel else F_._MV(qkv, 0, 3 * D)
+        else:
+            qu, k, v = bf(B * T1, D), bf(B * T2, D), bf(B * T2, D)
+        qv = bf(B * T1, D) if rel else None
+        p = bf(T2, D) if rel else None
+        mask = None
+        if mk == "len":
+            lens = torch.linspace(T2, max(1, T2 // 2), B).long()
+            mask = (torch.arange(T2)[None, :] < lens[:, None]).to(torch.uint8).view(B, 1, T2).contiguous().to(DEV)
+        elif mk == "causal":
+            mask = torch.tril(torch.ones(T1, T2)).to(torch.uint8).expand(B, T1, T2).contiguous().to(DEV)
+        elif mk == "dead":
+            mask = torch.ones(B, 1, T2, dtype=torch.uint8)
+            mask[1] = 0
+            mask = mask.to(DEV)
+        fused = F_.attn_fwd_fused(qu, qv, k, v, p, mask, B, T1, T2, H, dk)
+        assert fused is not None
+        P1, c1 = fused
+        P0 = F_.attn_scores_fwd(qu, qv, k, p, mask, B, T1, T2, H, dk)
+        c0 = F_.attn_context_fwd(P0, v, B, T1, T2, H, dk)
+        ldp = F_._ldp(T2)
+        P0v, P1v = P0.view(H, B, T1, ldp).float(), P1.view(H, B, T1, ldp).float()
+        report("fused attention P %s" % (case,), P1v, P0v, 3e-3)
+        report("fused attention ctx %s" % (case,), c1.float(), c0.float(), 6e-3)
+        assert float((P1v - P0v).abs().max()) <= 2e-2
+        assert bool((P1v[..., T2:] == 0).all())
+        if mk == "dead":
+            assert bool((P1v[:, 1] == 0).all()) and bool((c1.view(B, T1, D)[1] == 0).all())
+    finally:
+        espnet_amd.set_precision("fp32")
