@@ -218,6 +218,155 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const AttnArgs a) {
   }
 }
 
+// ---- backward, query side: dP = dctx V^T, dS = scale * P (dP - rowsum(P dP)), dq = dS K in one launch ----
+// Same orientation and lane layout as the forward: dP^T tiles from register-direct V / dctx fragments, P re-read with
+// the 8-byte accesses the forward stored it with, the row sum inside the wave, dS (bf16) stored for the key-side
+// GEMMs (dK = dS^T q, and with relative positions dqv / dpos from the inverse rel_shift scatter dbd, written here
+// element by element exactly as eamd_softmax_bwd does) and dq^T = K^T dS^T from the K panel in LDS - the context
+// product of the forward with K in place of V.  reference: autograd of attention.py:63-114, :141-206.
+struct AttnBwdArgs {
+  const bf16_t* dctx; const bf16_t* k; const bf16_t* v; const bf16_t* P;
+  bf16_t* dS; bf16_t* dbd; void* dq;
+  long ldd, ldk, ldv, ldp, ldo;
+  int B, H, T1, T2, nqb, dq_bf16;
+  float scale;
+};
+
+template <int NKT>
+__global__ __launch_bounds__(256, 2) void attn_bwd_q_kernel(const AttnBwdArgs a) {
+  extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+  const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+  const int fr = lane & 15, fq = lane >> 4;
+  const int xcd = blockIdx.x & 7, jb = blockIdx.x >> 3;
+  const int z = (jb / a.nqb) * 8 + xcd;
+  const bool live = z < a.B * a.H;
+  const int zz = live ? z : 0;
+  const int h = zz / a.B, b = zz % a.B;
+  const int r0 = (jb % a.nqb) * 64 + wave * 16;
+  const bool active = live && r0 < a.T1;
+  const int T1 = a.T1, T2 = a.T2;
+  const int qi = min(r0 + fr, T1 - 1);
+  const bool qok = r0 + fr < T1;
+
+  // K panel [16 NKT keys][64 channels] -> LDS first: its latency hides behind the score-gradient phase
+  bf16_t* Ks = reinterpret_cast<bf16_t*>(smem_raw);
+#pragma unroll
+  for (int q = 0; q < NKT / 2; ++q) {
+    const int c = t + 256 * q, row = c >> 3, c16 = c & 7;
+    uint4 kv = *reinterpret_cast<const uint4*>(a.k + ((long)b * T2 + min(row, T2 - 1)) * a.ldk + h * ATT_DK + c16 * 8);
+    if (row >= T2) kv = make_uint4(0u, 0u, 0u, 0u);
+    *reinterpret_cast<uint4*>(&Ks[lds_chunk_off<true, 64>(row, c16)]) = kv;
+  }
+  uint2 Gk[NKT];                                    // four bf16 score gradients per tile
+#pragma unroll
+  for (int kt = 0; kt < NKT; ++kt) Gk[kt] = make_uint2(0u, 0u);
+  if (active) {
+    f32x4 S[NKT];
+    const bf16_t* dr = a.dctx + ((long)b * T1 + qi) * a.ldd + h * ATT_DK + fq * 8;
+    const uint4 d0 = *reinterpret_cast<const uint4*>(dr), d1 = *reinterpret_cast<const uint4*>(dr + 32);
+    const bf16_t* prow = a.P + ((long)zz * T1 + qi) * a.ldp;
+    uint2 Pr[NKT];
+#pragma unroll
+    for (int kt = 0; kt < NKT; ++kt) {
+      const int j0 = kt * 16 + fq * 4;
+      Pr[kt] = *reinterpret_cast<const uint2*>(prow + min(j0, (int)a.ldp - 4));
+    }
+#pragma unroll
+    for (int kt = 0; kt < NKT; ++kt) {
+      const bf16_t* vr = a.v + ((long)b * T2 + min(kt * 16 + fr, T2 - 1)) * a.ldv + h * ATT_DK + fq * 8;
+      const uint4 v0 = *reinterpret_cast<const uint4*>(vr), v1 = *reinterpret_cast<const uint4*>(vr + 32);
+      S[kt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+      S[kt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, v0), __builtin_bit_cast(bf16x8, d0), S[kt], 0, 0, 0);
+      S[kt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, v1), __builtin_bit_cast(bf16x8, d1), S[kt], 0, 0, 0);
+    }
+    // P is unpacked from its packed registers in both passes (a second fp32 copy costs 64 VGPRs and a wave per SIMD)
+    auto unpack = [&](int kt, int r) __attribute__((always_inline)) -> float {
+      const unsigned w = r < 2 ? Pr[kt].x : Pr[kt].y;
+      const float f = __uint_as_float((r & 1) ? (w & 0xffff0000u) : (w << 16));
+      return kt * 16 + fq * 4 < (int)a.ldp ? f : 0.f;   // pad columns of P hold zeros, columns past ldp do not exist
+    };
+    float s = 0.f;
+#pragma unroll
+    for (int kt = 0; kt < NKT; ++kt)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) if (kt * 16 + fq * 4 + r < T2) s += unpack(kt, r) * S[kt][r];
+    s = xor_sum16_32(s);
+    const long zo = (long)zz * T1 * a.ldp;
+    bf16_t* srow = a.dS + zo + (long)qi * a.ldp;
+    const int i = r0 + fr;
+#pragma unroll
+    for (int kt = 0; kt < NKT; ++kt) {
+      const int j0 = kt * 16 + fq * 4;
+      unsigned short g16[4];
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int j = j0 + r;
+        g16[r] = eamd_f2bf(j < T2 ? unpack(kt, r) * (S[kt][r] - s) * a.scale : 0.f);
+        if (a.dbd && qok) {
+          // inverse rel_shift for T1 == T2 = T: padded index T + i T + j lands in row i (j <= i) or row i + 1
+          if (j < T2) {
+            const int R = j <= i ? i : i + 1, c = j <= i ? T2 + j - i : j - i - 1;
+            if (c != 0) a.dbd[zo + (long)R * a.ldp + (c - 1)] = g16[r];
+          } else if (j < (int)a.ldp) {
+            a.dbd[zo + (long)i * a.ldp + j] = 0;      // pad columns of this row
+          }
+        }
+      }
+      Gk[kt].x = (unsigned)g16[0] | ((unsigned)g16[1] << 16);
+      Gk[kt].y = (unsigned)g16[2] | ((unsigned)g16[3] << 16);
+      if (qok && j0 < (int)a.ldp) *reinterpret_cast<uint2*>(srow + j0) = Gk[kt];
+    }
+    if (a.dbd && r0 == 0)                            // the head of row 0 the scatter never reaches
+      for (int f = 1 + lane; f < T1; f += 64) a.dbd[zo + (f - 1)] = 0;
+  }
+  __syncthreads();
+  if (!active) return;
+  // ---- dq^T = K^T dS^T: rows = channels, columns = queries ----
+  f32x4 C[4];
+#pragma unroll
+  for (int dt = 0; dt < 4; ++dt) C[dt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int ks = 0; ks < NKT / 2; ++ks) {
+    const uint4 gw = make_uint4(Gk[2 * ks].x, Gk[2 * ks].y, Gk[2 * ks + 1].x, Gk[2 * ks + 1].y);
+    const bf16x8 gf = __builtin_bit_cast(bf16x8, gw);
+    const int rlo = ks * 32 + 4 * fq + (fr >> 2), rhi = rlo + 16;
+#pragma unroll
+    for (int dt = 0; dt < 4; ++dt) {
+      const int cc = dt * 16 + 4 * (fr & 3);
+      const bf16_t* q0 = &Ks[lds_chunk_off<true, 64>(rlo, cc >> 3) + (cc & 7)];
+      const bf16_t* q1 = &Ks[lds_chunk_off<true, 64>(rhi, cc >> 3) + (cc & 7)];
+      s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4 __attribute__((address_space(3)))*)q0);
+      s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4 __attribute__((address_space(3)))*)q1);
+      const bf16x8 kf = (bf16x8){lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+      C[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf, gf, C[dt], 0, 0, 0);
+    }
+  }
+  if (qok) {
+    const long ro = ((long)b * T1 + r0 + fr) * a.ldo + h * ATT_DK;
+#pragma unroll
+    for (int dt = 0; dt < 4; ++dt) {
+      if (a.dq_bf16) {
+        uint2 o;
+        o.x = (unsigned)eamd_f2bf(C[dt][0]) | ((unsigned)eamd_f2bf(C[dt][1]) << 16);
+        o.y = (unsigned)eamd_f2bf(C[dt][2]) | ((unsigned)eamd_f2bf(C[dt][3]) << 16);
+        *reinterpret_cast<uint2*>(reinterpret_cast<bf16_t*>(a.dq) + ro + dt * 16 + fq * 4) = o;
+      } else {
+        *reinterpret_cast<float4*>(reinterpret_cast<float*>(a.dq) + ro + dt * 16 + fq * 4) =
+            make_float4(C[dt][0], C[dt][1], C[dt][2], C[dt][3]);
+      }
+    }
+  }
+}
+
+template <int NKT>
+int launch_attn_bwd(const AttnBwdArgs& a, hipStream_t stream) {
+  const int nz = (a.B * a.H + 7) / 8 * 8;
+  hipLaunchKernelGGL((attn_bwd_q_kernel<NKT>), dim3((unsigned)(a.nqb * nz)), dim3(256), (size_t)NKT * 16 * ATT_DK * sizeof(bf16_t),
+                     stream, a);
+  EAMD_LAUNCH_CHECK();
+  return EAMD_OK;
+}
+
 template <bool REL, int NKT>
 int launch_attn(const AttnArgs& a, size_t smem, hipStream_t stream) {
   static const hipError_t attr_err = hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_fwd_kernel<REL, NKT>),
@@ -261,4 +410,22 @@ extern "C" int eamd_attn_fwd(const void* qu, int64_t ldq, const void* qv, int64_
     return half ? launch_attn<true, 8>(a, smem, s) : launch_attn<true, 16>(a, smem, s);
   }
   return half ? launch_attn<false, 8>(a, vbytes, s) : launch_attn<false, 16>(a, vbytes, s);
+}
+
+extern "C" int eamd_attn_bwd_q(const void* dctx, int64_t ldd, const void* k, int64_t ldk, const void* v, int64_t ldv,
+                               const void* P_bf16, int64_t ldp, void* dS_bf16, void* dbd_bf16, void* dq, int64_t ldo,
+                               int dq_is_bf16, int B, int H, int T1, int T2, int dk, float scale, void* stream) {
+  if (!dctx || !k || !v || !P_bf16 || !dS_bf16 || !dq || B <= 0 || H <= 0 || T1 <= 0 || T2 <= 0) return EAMD_EINVAL;
+  if (dk != ATT_DK || T2 > ATT_MAXK || (dbd_bf16 && T1 != T2)) return EAMD_EUNSUPPORTED;
+  if (ldd % 8 || ldk % 8 || ldv % 8 || ldp % 8 || ldp < T2 || ldo % 4) return EAMD_EUNSUPPORTED;
+  if (!al16(dctx) || !al16(k) || !al16(v) || !al16(P_bf16) || !al16(dS_bf16) ||
+      (reinterpret_cast<uintptr_t>(dq) & (dq_is_bf16 ? 7 : 15)))
+    return EAMD_EUNSUPPORTED;
+  if ((long)B * H * ((T1 + 63) / 64) >= (1L << 28)) return EAMD_EUNSUPPORTED;
+  AttnBwdArgs a;
+  a.dctx = (const bf16_t*)dctx; a.k = (const bf16_t*)k; a.v = (const bf16_t*)v; a.P = (const bf16_t*)P_bf16;
+  a.dS = (bf16_t*)dS_bf16; a.dbd = (bf16_t*)dbd_bf16; a.dq = dq;
+  a.ldd = ldd; a.ldk = ldk; a.ldv = ldv; a.ldp = ldp; a.ldo = ldo;
+  a.B = B; a.H = H; a.T1 = T1; a.T2 = T2; a.nqb = (T1 + 63) / 64; a.dq_bf16 = dq_is_bf16; a.scale = scale;
+  return T2 <= 128 ? launch_attn_bwd<8>(a, (hipStream_t)stream) : launch_attn_bwd<16>(a, (hipStream_t)stream);
 }

@@ -377,11 +377,6 @@ def attn_core_bwd(dctx, P, qu, qv, k, v, p, B, T1, T2, H, dk, Pd=None, attn_drop
     adt = ops.act_dtype()
     qu, k, v = _mv(qu), _mv(k), _mv(v)
     sP = (T1 * ldp, B * T1 * ldp)
-    dP = torch.empty(H * B * T1 * ldp, device=dev, dtype=torch.float32)
-    ops.gemm(dctx, v.t, dP, T1, T2, dk, D, v.ld, ldp, batch=(B, H), sA=(T1 * D, dk), sB=(T2 * v.ld, dk), sC=sP,
-             b_off=v.off)                                                                                 # dctx v^T
-    if Pd is not None:
-        dP = ops.dropout(dP, attn_drop[0], attn_drop[1])      # same mask as the forward probabilities
     if dqkv is None:
         dv, dv_off, ldo = torch.empty(B * T2, D, device=dev, dtype=adt), 0, D
         dkk, dk_off = torch.empty(B * T2, D, device=dev, dtype=adt), 0
@@ -390,21 +385,38 @@ def attn_core_bwd(dctx, P, qu, qv, k, v, p, B, T1, T2, H, dk, Pd=None, attn_drop
         dv, dv_off, dkk, dk_off = dqkv, 2 * D, dqkv, D
     ops.gemm(Pd if Pd is not None else P, dctx, dv, T2, dk, T1, ldp, D, ldo, transA=1, transB=1, batch=(B, H), sA=sP,
              sB=(T1 * D, dk), sC=(T2 * ldo, dk), c_off=dv_off)                                            # P^T dctx
-    dbd = torch.empty(H * B * T1 * ldp, device=dev, dtype=adt) if p is not None else None   # fully written by softmax_bwd
-    if ops.fast():
+    dq_in_qkv = dqkv is not None and p is None     # no relative positions: dq is needed only as a GEMM operand
+    dS = dbd = dqu = None
+    if FUSE_ATTN and Pd is None and P.dtype == torch.bfloat16 and ops.attn_fwd_supported(T1, T2, dk, p is not None):
+        # dP, softmax backward (+ inverse rel-shift scatter) and dq in one launch
         dS = torch.empty(H * B * T1 * ldp, device=dev, dtype=torch.bfloat16)
-        ops.softmax_bwd(P, dP, dbd, H * B, T1, T2, ldp, 1.0 / math.sqrt(dk), dS16=dS)
-    else:
-        ops.softmax_bwd(P, dP, dbd, H * B, T1, T2, ldp, 1.0 / math.sqrt(dk))   # dP <- d(ac)
-        dS = dP
-    if dqkv is not None and p is None:
-        dqu = None      # no relative positions: dq is needed only as a GEMM operand
-        ops.gemm(dS, k.t, dqkv, T1, dk, T2, ldp, k.ld, ldo, transB=1, batch=(B, H), sA=sP, sB=(T2 * k.ld, dk),
-                 sC=(T1 * ldo, dk), b_off=k.off)
-    else:
-        dqu = torch.empty(B * T1, D, device=dev, dtype=torch.float32)
-        ops.gemm(dS, k.t, dqu, T1, dk, T2, ldp, k.ld, D, transB=1, batch=(B, H), sA=sP, sB=(T2 * k.ld, dk),
-                 sC=(T1 * D, dk), b_off=k.off)
+        dbd = torch.empty(H * B * T1 * ldp, device=dev, dtype=adt) if p is not None else None
+        dqu = None if dq_in_qkv else torch.empty(B * T1, D, device=dev, dtype=torch.float32)
+        dq_view = (dqkv, 0, ldo) if dq_in_qkv else (dqu, 0, D)
+        if not ops.attn_bwd_q((dctx, 0, D), (k.t, k.off, k.ld), (v.t, v.off, v.ld), P, dS, dbd, dq_view, B, T1, T2, H, dk,
+                              ldp, 1.0 / math.sqrt(dk)):
+            dS = None
+    if dS is None:
+        dP = torch.empty(H * B * T1 * ldp, device=dev, dtype=torch.float32)
+        ops.gemm(dctx, v.t, dP, T1, T2, dk, D, v.ld, ldp, batch=(B, H), sA=(T1 * D, dk), sB=(T2 * v.ld, dk), sC=sP,
+                 b_off=v.off)                                                                             # dctx v^T
+        if Pd is not None:
+            dP = ops.dropout(dP, attn_drop[0], attn_drop[1])      # same mask as the forward probabilities
+        dbd = torch.empty(H * B * T1 * ldp, device=dev, dtype=adt) if p is not None else None   # fully written by softmax_bwd
+        if ops.fast():
+            dS = torch.empty(H * B * T1 * ldp, device=dev, dtype=torch.bfloat16)
+            ops.softmax_bwd(P, dP, dbd, H * B, T1, T2, ldp, 1.0 / math.sqrt(dk), dS16=dS)
+        else:
+            ops.softmax_bwd(P, dP, dbd, H * B, T1, T2, ldp, 1.0 / math.sqrt(dk))   # dP <- d(ac)
+            dS = dP
+        if dq_in_qkv:
+            dqu = None
+            ops.gemm(dS, k.t, dqkv, T1, dk, T2, ldp, k.ld, ldo, transB=1, batch=(B, H), sA=sP, sB=(T2 * k.ld, dk),
+                     sC=(T1 * ldo, dk), b_off=k.off)
+        else:
+            dqu = torch.empty(B * T1, D, device=dev, dtype=torch.float32)
+            ops.gemm(dS, k.t, dqu, T1, dk, T2, ldp, k.ld, D, transB=1, batch=(B, H), sA=sP, sB=(T2 * k.ld, dk),
+                     sC=(T1 * D, dk), b_off=k.off)
     ops.gemm(dS, qu.t, dkk, T2, dk, T1, ldp, qu.ld, ldo, transA=1, transB=1, batch=(B, H), sA=sP, sB=(T1 * qu.ld, dk),
              sC=(T2 * ldo, dk), b_off=qu.off, c_off=dk_off)
     dqv = dp = None

@@ -382,6 +382,20 @@ def attn_fwd(qu, qv, k, v, pos, mask, B, T1, T2, H, dk, ldp, scale):
     return P, cx
 
 
+def attn_bwd_q(dctx, k, v, P, dS, dbd, dq, B, T1, T2, H, dk, ldp, scale):
+    """dctx / k / v / dq: (tensor, element offset, row stride) views; P, dS (and dbd or None): bf16 [H*B*T1*ldp].
+    dS, dbd and dq are written.  Returns False if the library declines the operands (EAMD_EUNSUPPORTED)."""
+    i64 = C.c_int64
+    rc = _lib.lib().eamd_attn_bwd_q(
+        ptr(dctx[0], dctx[1]), i64(dctx[2]), ptr(k[0], k[1]), i64(k[2]), ptr(v[0], v[1]), i64(v[2]), ptr(P), i64(ldp),
+        ptr(dS), ptr(dbd), ptr(dq[0], dq[1]), i64(dq[2]), int(dq[0].dtype == torch.bfloat16), B, H, T1, T2, dk,
+        C.c_float(scale), stream_ptr())
+    if rc == _lib.EAMD_EUNSUPPORTED:
+        return False
+    check(rc, "eamd_attn_bwd_q")
+    return True
+
+
 def softmax_fwd(ac, bd, mask, P, nblocks, B, T1, T2, ld, scale):
     """P may be fp32 (may alias ac) or bf16 (separate buffer)"""
     mb = mi = 0

@@ -159,6 +159,16 @@ int eamd_attn_fwd(const void* qu, int64_t ldq, const void* qv, int64_t ldqv, con
                   int64_t mask_qstride, void* P_bf16, int64_t ldp, void* ctx_bf16, int64_t ldc, int B, int H, int T1,
                   int T2, int dk, float scale, void* stream);
 
+/* Query side of the attention backward in one launch (same operand layouts and limits as eamd_attn_fwd):
+ * dP = dctx v^T, dS = scale * P (dP - rowsum(P dP)) -> dS_bf16 [H][B][T1][ldp] (pad columns zeroed), its inverse
+ * rel_shift scatter -> dbd_bf16 (same shape, every element written; NULL without relative positions, else T1 == T2)
+ * and dq = dS k -> dq (fp32 or bf16, element (b, t, h, d) at dq[(b*T1 + t)*ldo + h*64 + d]).  Replaces a score-
+ * gradient GEMM, eamd_softmax_bwd and the dq GEMM; the key-side products (dv = P^T dctx, dk = dS^T q, dqv / dpos
+ * from dbd) remain GEMMs over P / dS / dbd. */
+int eamd_attn_bwd_q(const void* dctx, int64_t ldd, const void* k, int64_t ldk, const void* v, int64_t ldv,
+                    const void* P_bf16, int64_t ldp, void* dS_bf16, void* dbd_bf16, void* dq, int64_t ldo, int dq_is_bf16,
+                    int B, int H, int T1, int T2, int dk, float scale, void* stream);
+
 /* Label-smoothing KL loss rows + argmax-correct flags + gradient (softmax - true_dist)*inv_denom.
  * reference: transformer/label_smoothing_loss.py:44-63, nets_utils.py:299-319 (th_accuracy). */
 int eamd_lsm_loss(const float* logits, const int64_t* target, float* loss_rows, float* correct_rows,

@@ -777,3 +777,48 @@ def test_attention_forward_fused_matches_unfused(ops, case):
             assert bool((P1v[:, 1] == 0).all()) and bool((c1.view(B, T1, D)[1] == 0).all())
     finally:
         espnet_amd.set_precision("fp32")
+
+
+@pytest.mark.parametrize("case", [
+    dict(B=3, T1=249, T2=249, rel=True, qkv=True), dict(B=2, T1=256, T2=256, rel=True, qkv=False),
+    dict(B=9, T1=30, T2=30, rel=True, qkv=True), dict(B=2, T1=65, T2=65, rel=False, qkv=True),
+    dict(B=2, T1=101, T2=249, rel=False, qkv=False), dict(B=3, T1=101, T2=101, rel=False, qkv=False)])
+def test_attention_backward_fused_matches_unfused(ops, case):
+    """eamd_attn_bwd_q (score gradient + softmax backward + inverse rel-shift scatter + dq in one launch) inside
+    attn_core_bwd against the GEMM / eamd_softmax_bwd / GEMM path: every returned gradient (dq, dqv, dk, dv, dpos)
+    agrees to bf16 rounding, with q / k / v gradients written into the fused [B*T, 3D] buffer where the model does so"""
+    import espnet_amd
+    from espnet_amd import functional as F_
+    espnet_amd.set_precision("bf16")
+    try:
+        B, T1, T2, rel, use_qkv = case["B"], case["T1"], case["T2"], case["rel"], case["qkv"]
+        H, dk = 4, 64
+        D = H * dk
+        g = torch.Generator().manual_seed(T1 * 5 + T2)
+        bf = lambda *s: torch.randn(*s, generator=g).to(torch.bfloat16).to(DEV)
+        if use_qkv:
+            qkv = bf(B * T1, 3 * D)
+            k, v = F_._MV(qkv, D, 3 * D), F_._MV(qkv, 2 * D, 3 * D)
+            qu = bf(B * T1, D) if rel else F_._MV(qkv, 0, 3 * D)
+        else:
+            qu, k, v = bf(B * T1, D), bf(B * T2, D), bf(B * T2, D)
+        qv = bf(B * T1, D) if rel else None
+        p = bf(T2, D) if rel else None
+        lens = torch.linspace(T2, max(1, T2 // 2), B).long()
+        mask = (torch.arange(T2)[None, :] < lens[:, None]).to(torch.uint8).view(B, 1, T2).contiguous().to(DEV)
+        P = F_.attn_scores_fwd(qu, qv, k, p, mask, B, T1, T2, H, dk)
+        dctx = bf(B * T1, D)
+        outs = {}
+        for fuse in (True, False):
+            F_.FUSE_ATTN = fuse
+            dqkv = torch.zeros(B * T1, 3 * D, device=DEV, dtype=torch.bfloat16) if use_qkv else None
+            r = F_.attn_core_bwd(dctx, P, qu, qv, k, v, p, B, T1, T2, H, dk, dqkv=dqkv)
+            outs[fuse] = [None if x is None else x.float().clone() for x in r] + [None if dqkv is None else dqkv.float().clone()]
+        names = ("dqu", "dqv", "dk", "dv", "dpos", "dqkv")
+        for n, a, b in zip(names, outs[True], outs[False]):
+            assert (a is None) == (b is None), n
+            if a is not None:
+                report("fused attention bwd %s %s" % (n, case), a, b, 6e-3)
+    finally:
+        F_.FUSE_ATTN = True
+        espnet_amd.set_precision("fp32")
