@@ -166,7 +166,8 @@ def main():
     st = opt.stats()
 
     # ---- roofline of the dominant kernel family (MFMA GEMM), measured live with stream events ----
-    # Every eamd_gemm descriptor of one training step is recorded (operands kept alive), then the whole family is
+    # Every MFMA-contraction launch of one training step (eamd_gemm descriptors, the fused attention kernels
+    # eamd_attn_fwd / eamd_attn_bwd_q) is recorded (operands kept alive), then the whole family is
     # replayed back to back as ONE hipGraph on the current stream and bracketed by a single pair of stream
     # events: device time of the kernels themselves, no host gaps, no per-launch event overhead - the quantity
     # the rocprofv3 kernel trace of the same command reports as the family's total duration.
@@ -190,8 +191,8 @@ def main():
 
         def replay_all():
             sp = ops.stream_ptr()
-            for p, _keep in rec:
-                L_.check(lib.eamd_gemm(ctypes.byref(p), sp), "eamd_gemm")
+            for _p, _keep, replay in rec:
+                replay(sp)
 
         gg = torch.cuda.CUDAGraph()
         side = torch.cuda.Stream()
@@ -227,9 +228,9 @@ def main():
         roof = dict(bound="mfma", achieved=round(ach, 2), peak=PEAK_TFLOPS[a.precision], unit="TFLOP/s",
                     frac=round(ach / PEAK_TFLOPS[a.precision], 4), traffic=traffic,
                     traffic_note="HBM bytes per launch, rocprofv3 PMC (FETCH_SIZE doubled + WRITE_SIZE), profiles/%s" % traffic_src,
-                    kernel="gemm_kernel<*> (all MFMA contractions)", launches_per_step=n,
+                    kernel="gemm_*_kernel<*> + attn_{fwd,bwd_q}_kernel (all MFMA contractions)", launches_per_step=n,
                     avg_launch_us=round(avg_ms * 1e3, 2), gemm_ms_per_step=round(gemm_ms, 3),
-                    timing="all eamd_gemm launches of one step replayed as one hipGraph between two stream events")
+                    timing="all MFMA-contraction launches of one step replayed as one hipGraph between two stream events")
 
     cpu = None
     if rank == 0 and world == 1 and not a.no_cpu_baseline:

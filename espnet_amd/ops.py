@@ -85,7 +85,9 @@ def _span(rows, ld, cols):
     return (rows - 1) * ld + cols if rows > 0 else 0
 
 
-_gemm_record = None   # bench.py: list collecting (descriptor, operand references) of every launch of one step
+# bench.py: list collecting every MFMA-contraction launch of one step as (descriptor or None, operand references,
+# replay(stream_ptr)) - eamd_gemm descriptors and the fused attention kernels (descriptor None)
+_gemm_record = None
 
 
 def gemm(A, B, Cm, M, N, K, lda, ldb, ldc, *, transA=0, transB=0, bias=None, aux=None, ldaux=0, R=None,
@@ -162,7 +164,8 @@ def gemm(A, B, Cm, M, N, K, lda, ldb, ldc, *, transA=0, transB=0, bias=None, aux
                 raise _lib.EamdError("gemm: Hb must be a bf16 [M, N] buffer")
             p.Hb, p.h_act = ptr(Hb), h_act
     if _gemm_record is not None:
-        _gemm_record.append((p, (A, B, Cm, bias, aux, R, colsum, Cb, Hb)))
+        _gemm_record.append((p, (A, B, Cm, bias, aux, R, colsum, Cb, Hb),
+                             lambda sp, p=p: check(_lib.lib().eamd_gemm(C.byref(p), sp), "eamd_gemm")))
     check(_lib.lib().eamd_gemm(C.byref(p), stream_ptr()), "eamd_gemm")
 
 
@@ -372,13 +375,16 @@ def attn_fwd(qu, qv, k, v, pos, mask, B, T1, T2, H, dk, ldp, scale):
     P = torch.empty(H * B * T1 * ldp, device=dev, dtype=torch.bfloat16)
     cx = torch.empty(B * T1, D, device=dev, dtype=torch.bfloat16)
     i64 = C.c_int64
-    rc = _lib.lib().eamd_attn_fwd(
-        ptr(qu[0], qu[1]), i64(qu[2]), ptr(qv[0], qv[1]) if qv is not None else None, i64(qv[2] if qv is not None else 0),
-        ptr(k[0], k[1]), i64(k[2]), ptr(v[0], v[1]), i64(v[2]), ptr(pos), i64(D if pos is not None else 0),
-        ptr(mask), i64(mb), i64(mi), ptr(P), i64(ldp), ptr(cx), i64(D), B, H, T1, T2, dk, C.c_float(scale), stream_ptr())
+    args = (ptr(qu[0], qu[1]), i64(qu[2]), ptr(qv[0], qv[1]) if qv is not None else None, i64(qv[2] if qv is not None else 0),
+            ptr(k[0], k[1]), i64(k[2]), ptr(v[0], v[1]), i64(v[2]), ptr(pos), i64(D if pos is not None else 0),
+            ptr(mask), i64(mb), i64(mi), ptr(P), i64(ldp), ptr(cx), i64(D), B, H, T1, T2, dk, C.c_float(scale))
+    rc = _lib.lib().eamd_attn_fwd(*args, stream_ptr())
     if rc == _lib.EAMD_EUNSUPPORTED:
         return None
     check(rc, "eamd_attn_fwd")
+    if _gemm_record is not None:
+        _gemm_record.append((None, (qu, qv, k, v, pos, mask, P, cx),
+                             lambda sp, args=args: check(_lib.lib().eamd_attn_fwd(*args, sp), "eamd_attn_fwd")))
     return P, cx
 
 
@@ -386,13 +392,16 @@ def attn_bwd_q(dctx, k, v, P, dS, dbd, dq, B, T1, T2, H, dk, ldp, scale):
     """dctx / k / v / dq: (tensor, element offset, row stride) views; P, dS (and dbd or None): bf16 [H*B*T1*ldp].
     dS, dbd and dq are written.  Returns False if the library declines the operands (EAMD_EUNSUPPORTED)."""
     i64 = C.c_int64
-    rc = _lib.lib().eamd_attn_bwd_q(
-        ptr(dctx[0], dctx[1]), i64(dctx[2]), ptr(k[0], k[1]), i64(k[2]), ptr(v[0], v[1]), i64(v[2]), ptr(P), i64(ldp),
-        ptr(dS), ptr(dbd), ptr(dq[0], dq[1]), i64(dq[2]), int(dq[0].dtype == torch.bfloat16), B, H, T1, T2, dk,
-        C.c_float(scale), stream_ptr())
+    args = (ptr(dctx[0], dctx[1]), i64(dctx[2]), ptr(k[0], k[1]), i64(k[2]), ptr(v[0], v[1]), i64(v[2]), ptr(P), i64(ldp),
+            ptr(dS), ptr(dbd), ptr(dq[0], dq[1]), i64(dq[2]), int(dq[0].dtype == torch.bfloat16), B, H, T1, T2, dk,
+            C.c_float(scale))
+    rc = _lib.lib().eamd_attn_bwd_q(*args, stream_ptr())
     if rc == _lib.EAMD_EUNSUPPORTED:
         return False
     check(rc, "eamd_attn_bwd_q")
+    if _gemm_record is not None:
+        _gemm_record.append((None, (dctx, k, v, P, dS, dbd, dq),
+                             lambda sp, args=args: check(_lib.lib().eamd_attn_bwd_q(*args, sp), "eamd_attn_bwd_q")))
     return True
 
 

@@ -30,3 +30,12 @@ for (B, T1, T2, rel, mk) in ((32, 249, 249, True, "len"), (32, 249, 249, False, 
         F_.attn_context_fwd(P, v, B, T1, T2, H, dk)
     tu = graph_time(unf, n=50)
     print("B=%d T1=%d T2=%d rel=%d: fused %6.1f us   unfused %6.1f us" % (B, T1, T2, rel, tf, tu))
+    # backward: whole attn_core_bwd with the query side fused / unfused
+    P = F_.attn_scores_fwd(qu, qv, k, p, mask, B, T1, T2, H, dk)
+    dctx = bf(B * T1, D)
+    ts = []
+    for fuse in (True, False):
+        F_.FUSE_ATTN = fuse
+        ts.append(graph_time(lambda: F_.attn_core_bwd(dctx, P, qu, qv, k, v, p, B, T1, T2, H, dk), n=30))
+    F_.FUSE_ATTN = True
+    print("      backward (all products): query side fused %6.1f us   unfused %6.1f us" % (ts[0], ts[1]))
