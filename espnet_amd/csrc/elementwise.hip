@@ -474,6 +474,54 @@ int eamd_glu_bwd(const float* dy, const float* x, float* dx, void* dx_bf16, int6
   return EAMD_OK;
 }
 
+// out = bf16(a + b) together with the column sums of a and of b (ADDED into suma / sumb): the relative-position
+// attention backward needs dq = dqu + dqv as a GEMM operand and the column sums of both terms as the gradients of
+// pos_bias_u / pos_bias_v - one pass over the two [rows, D] tensors instead of three.  Thread = (column pair, row
+// group); a block owns `rpb` rows, sums in registers, combines its row groups in LDS, one atomic per column.
+__global__ __launch_bounds__(256) void add_cast_colsum2_kernel(const float* __restrict__ a, const float* __restrict__ b,
+                                                               unsigned int* __restrict__ o32, long ld_out,
+                                                               float* __restrict__ suma, float* __restrict__ sumb,
+                                                               long rows, int D, int rpb) {
+  __shared__ float red[256][4];
+  const int CW = D / 2, ngrp = 256 / CW;
+  const int cp = threadIdx.x % CW, grp = threadIdx.x / CW;
+  const long r0 = (long)blockIdx.x * rpb, r1 = min(rows, r0 + (long)rpb);
+  float2 sa = make_float2(0.f, 0.f), sb = sa;
+  if (grp < ngrp) {
+    long r = r0 + grp;
+    for (; r + 3L * ngrp < r1; r += 4L * ngrp) {       // four rows per trip, loads issued together
+      float2 av[4], bv[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        av[u] = *reinterpret_cast<const float2*>(a + (r + (long)u * ngrp) * D + 2 * cp);
+        bv[u] = *reinterpret_cast<const float2*>(b + (r + (long)u * ngrp) * D + 2 * cp);
+      }
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        sa.x += av[u].x; sa.y += av[u].y; sb.x += bv[u].x; sb.y += bv[u].y;
+        o32[((r + (long)u * ngrp) * ld_out + 2 * cp) >> 1] = eamd_pack2(av[u].x + bv[u].x, av[u].y + bv[u].y);
+      }
+    }
+    for (; r < r1; r += ngrp) {
+      const float2 av = *reinterpret_cast<const float2*>(a + r * D + 2 * cp);
+      const float2 bv = *reinterpret_cast<const float2*>(b + r * D + 2 * cp);
+      sa.x += av.x; sa.y += av.y; sb.x += bv.x; sb.y += bv.y;
+      o32[(r * ld_out + 2 * cp) >> 1] = eamd_pack2(av.x + bv.x, av.y + bv.y);
+    }
+  }
+  red[threadIdx.x][0] = sa.x; red[threadIdx.x][1] = sa.y; red[threadIdx.x][2] = sb.x; red[threadIdx.x][3] = sb.y;
+  __syncthreads();
+  if (threadIdx.x < CW) {
+    float t0 = 0.f, t1 = 0.f, t2 = 0.f, t3 = 0.f;
+    for (int g = 0; g < ngrp; ++g) {
+      const float* q = red[g * CW + threadIdx.x];
+      t0 += q[0]; t1 += q[1]; t2 += q[2]; t3 += q[3];
+    }
+    atomicAdd(&suma[2 * cp], t0); atomicAdd(&suma[2 * cp + 1], t1);
+    atomicAdd(&sumb[2 * cp], t2); atomicAdd(&sumb[2 * cp + 1], t3);
+  }
+}
+
 int eamd_add_cast_bf16(const float* a, const float* b, void* out_bf16, int64_t rows, int cols, int64_t ld_out,
                        void* stream) {
   if (!a || !out_bf16 || rows <= 0 || cols <= 0 || ld_out < cols) return EAMD_EINVAL;
@@ -486,6 +534,17 @@ int eamd_add_cast_bf16(const float* a, const float* b, void* out_bf16, int64_t r
   }
   hipLaunchKernelGGL(add_cast_kernel, dim3(grid_for(n)), dim3(256), 0, (hipStream_t)stream, a, b,
                      (unsigned short*)out_bf16, n, cols, (long)ld_out);
+  EAMD_LAUNCH_CHECK();
+  return EAMD_OK;
+}
+
+int eamd_add_cast_colsum2(const float* a, const float* b, void* out_bf16, int64_t ld_out, float* suma, float* sumb,
+                            int64_t rows, int D, void* stream) {
+  if (!a || !b || !out_bf16 || !suma || !sumb || rows <= 0 || D <= 0 || ld_out < D) return EAMD_EINVAL;
+  if (D % 2 || D > 512 || ld_out % 2 || (((uintptr_t)a | (uintptr_t)b) & 7) || ((uintptr_t)out_bf16 & 3)) return EAMD_EUNSUPPORTED;
+  const int rpb = 64;
+  hipLaunchKernelGGL(add_cast_colsum2_kernel, dim3((unsigned)((rows + rpb - 1) / rpb)), dim3(256), 0, (hipStream_t)stream, a, b,
+                     (unsigned int*)out_bf16, (long)ld_out, suma, sumb, (long)rows, D, rpb);
   EAMD_LAUNCH_CHECK();
   return EAMD_OK;
 }

@@ -560,9 +560,13 @@ class MHABlockFn(torch.autograd.Function):
                                                T2, H, dk, Pd=Pd, attn_drop=(p_att, s_att), dqkv=dqkv)
             if rel:
                 wpos = params[10]
-                ops.colsum(dqu, sink.buf(11).view(-1))
-                ops.colsum(dqv, sink.buf(12).view(-1))
-                ops.add_cast(dqu, dqv, out=dqkv, out_off=0, ld_out=3 * D)
+                if ops.fast():      # dq = dqu + dqv (bf16, into the fused buffer) + both bias gradients in one pass
+                    ops.add_cast_colsum2(dqu, dqv, sink.buf(11).view(-1), sink.buf(12).view(-1), out=dqkv, out_off=0,
+                                         ld_out=3 * D)
+                else:
+                    ops.colsum(dqu, sink.buf(11).view(-1))
+                    ops.colsum(dqv, sink.buf(12).view(-1))
+                    ops.add_cast(dqu, dqv, out=dqkv, out_off=0, ld_out=3 * D)
                 ops.linear_bwd_w(ops.to_act(dp), pos2, sink.buf(10))
             ops.linear_bwd_w(dqkv, xn, _span3(sink.buf(2), (3 * D, D)), db=_span3(sink.buf(3), (3 * D,)))
             dxn = ops.linear_bwd_x(dqkv, _span3(ops.wshadow(wq), (3 * D, D)))
@@ -572,9 +576,12 @@ class MHABlockFn(torch.autograd.Function):
                                               Pd=Pd, attn_drop=(p_att, s_att))
         if rel:
             wpos = params[10]
-            ops.colsum(dqu, sink.buf(11).view(-1))
-            ops.colsum(dqv, sink.buf(12).view(-1))
-            dq = ops.add_cast(dqu, dqv) if ops.fast() else ops.axpby(dqu, dqv, 1.0, 1.0)
+            if ops.fast():
+                dq = ops.add_cast_colsum2(dqu, dqv, sink.buf(11).view(-1), sink.buf(12).view(-1))
+            else:
+                ops.colsum(dqu, sink.buf(11).view(-1))
+                ops.colsum(dqv, sink.buf(12).view(-1))
+                dq = ops.axpby(dqu, dqv, 1.0, 1.0)
             ops.linear_bwd_w(ops.to_act(dp), pos2, sink.buf(10))
         else:
             dq = ops.to_act(dqu)

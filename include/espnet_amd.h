@@ -201,6 +201,11 @@ int eamd_add_bias2(const void* q, int64_t ldq, const float* u, const float* v, v
 /* out_bf16[r * ld_out + c] = a[r, c] + b[r, c] (b optional), dense fp32 [rows, cols] inputs */
 int eamd_add_cast_bf16(const float* a, const float* b, void* out_bf16, int64_t rows, int cols, int64_t ld_out,
                        void* stream);
+/* out_bf16[r * ld_out + c] = a[r, c] + b[r, c] and, from the same pass, suma[c] += sum_r a[r, c], sumb[c] += sum_r b[r, c]
+ * (dense fp32 [rows, D] inputs, D even and <= 512, else EAMD_EUNSUPPORTED): dq = dqu + dqv and the gradients of
+ * pos_bias_u / pos_bias_v in the backward of attention.py:186-190. */
+int eamd_add_cast_colsum2(const float* a, const float* b, void* out_bf16, int64_t ld_out, float* suma, float* sumb,
+                          int64_t rows, int D, void* stream);
 /* out[D] += scale * column sums of x[rows, D] (bias gradients). */
 int eamd_colsum(const void* x, int64_t ld, float* out, int64_t rows, int D, float scale, int x_bf16, void* stream);
 /* reference: decoder.py:83-86,251 (Embedding + PositionalEncoding), embedding.py:80-91.

@@ -822,3 +822,20 @@ def test_attention_backward_fused_matches_unfused(ops, case):
     finally:
         F_.FUSE_ATTN = True
         espnet_amd.set_precision("fp32")
+
+
+@pytest.mark.parametrize("shape", [(7968, 256, 768), (333, 64, 64), (70, 320, 320), (5, 512, 1024)])
+def test_add_cast_colsum2(ops, shape):
+    """one pass: out = bf16(a + b) into a column block, both column sums accumulated"""
+    rows, D, ld = shape
+    g = torch.Generator().manual_seed(rows)
+    a, b = torch.randn(rows, D, generator=g).to(DEV), torch.randn(rows, D, generator=g).to(DEV)
+    sa, sb = torch.ones(D, device=DEV), torch.full((D,), -2.0, device=DEV)
+    out = torch.zeros(rows, ld, device=DEV, dtype=torch.bfloat16)
+    off = ld - D
+    ops.add_cast_colsum2(a, b, sa, sb, out=out, out_off=off, ld_out=ld)
+    want = (a + b).to(torch.bfloat16)
+    assert torch.equal(out[:, off:], want)
+    assert off == 0 or bool((out[:, :off] == 0).all())
+    report("add_cast_colsum2 suma", sa, 1 + a.double().sum(0), 1e-5)
+    report("add_cast_colsum2 sumb", sb, -2 + b.double().sum(0), 1e-5)
