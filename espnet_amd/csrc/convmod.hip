@@ -309,8 +309,10 @@ __global__ __launch_bounds__(256) void bn_partial_kernel(const float* __restrict
     reinterpret_cast<float4*>(p + 2 * C)[q] = m2;
   }
 }
-// stage 2 (one block of 1024 threads): thread (group gi, channel c) merges slabs gi, gi+G, ... in order,
-// then the G group results are merged in group order; writes mean, rstd, updates running stats
+// stage 2: one block of 1024 threads per 32 channels; thread (group gi of 32, channel c) merges slabs gi, gi+32, ...
+// in order, then the 32 group results are merged in group order; writes mean, rstd, updates running stats.
+// (One block for all channels walked nslab / 4 dependent Chan merges per thread: 10 us for 249 slabs.)
+constexpr int BN_CPB = 32, BN_G = 1024 / BN_CPB;
 __global__ __launch_bounds__(1024) void bn_finalize_kernel(const float* __restrict__ part, int nslab, int C,
                                                            float eps, float momentum, float* __restrict__ mean_out,
                                                            float* __restrict__ rstd_out,
@@ -318,39 +320,36 @@ __global__ __launch_bounds__(1024) void bn_finalize_kernel(const float* __restri
                                                            float* __restrict__ running_var) {
   __shared__ float sh[3][1024];
   const int t = threadIdx.x;
-  const int G = 1024 / C > 0 ? 1024 / C : 1;
-  for (int c0 = 0; c0 < C; c0 += 1024) {
-    const int c = c0 + t % (C < 1024 ? C : 1024), gi = t / (C < 1024 ? C : 1024);
-    float n = 0.f, mean = 0.f, m2 = 0.f;
-    if (c < C && gi < G) {
-      for (int s0 = gi; s0 < nslab; s0 += 8 * G) {      // 8 slabs per trip, all 24 loads in flight together
-        float pn[8], pm[8], pq[8];
+  const int cl = t % BN_CPB, gi = t / BN_CPB;
+  const int c = blockIdx.x * BN_CPB + cl;
+  float n = 0.f, mean = 0.f, m2 = 0.f;
+  if (c < C) {
+    for (int s0 = gi; s0 < nslab; s0 += 8 * BN_G) {      // 8 slabs per trip, all 24 loads in flight together
+      float pn[8], pm[8], pq[8];
 #pragma unroll
-        for (int u = 0; u < 8; ++u) {
-          const int s = s0 + u * G;
-          const float* p = part + (long)(s < nslab ? s : s0) * 3 * C;
-          pn[u] = s < nslab ? p[c] : 0.f; pm[u] = p[C + c]; pq[u] = s < nslab ? p[2 * C + c] : 0.f;
-        }
+      for (int u = 0; u < 8; ++u) {
+        const int s = s0 + u * BN_G;
+        const float* p = part + (long)(s < nslab ? s : s0) * 3 * C;
+        pn[u] = s < nslab ? p[c] : 0.f; pm[u] = p[C + c]; pq[u] = s < nslab ? p[2 * C + c] : 0.f;
+      }
 #pragma unroll
-        for (int u = 0; u < 8; ++u) chan_merge(n, mean, m2, pn[u], pm[u], pq[u]);
-      }
+      for (int u = 0; u < 8; ++u) chan_merge(n, mean, m2, pn[u], pm[u], pq[u]);
     }
-    sh[0][t] = n; sh[1][t] = mean; sh[2][t] = m2;
-    __syncthreads();
-    if (gi == 0 && c < C) {
-      for (int g2 = 1; g2 < G; ++g2) {
-        const int o = g2 * C + (c - c0);
-        chan_merge(n, mean, m2, sh[0][o], sh[1][o], sh[2][o]);
-      }
-      const float var = m2 / n;
-      mean_out[c] = mean;
-      rstd_out[c] = rsqrtf(var + eps);
-      if (running_mean) {
-        running_mean[c] = (1.f - momentum) * running_mean[c] + momentum * mean;
-        running_var[c] = (1.f - momentum) * running_var[c] + momentum * (n > 1.f ? m2 / (n - 1.f) : var);
-      }
+  }
+  sh[0][t] = n; sh[1][t] = mean; sh[2][t] = m2;
+  __syncthreads();
+  if (gi == 0 && c < C) {
+    for (int g2 = 1; g2 < BN_G; ++g2) {
+      const int o = g2 * BN_CPB + cl;
+      chan_merge(n, mean, m2, sh[0][o], sh[1][o], sh[2][o]);
     }
-    __syncthreads();
+    const float var = m2 / n;
+    mean_out[c] = mean;
+    rstd_out[c] = rsqrtf(var + eps);
+    if (running_mean) {
+      running_mean[c] = (1.f - momentum) * running_mean[c] + momentum * mean;
+      running_var[c] = (1.f - momentum) * running_var[c] + momentum * (n > 1.f ? m2 / (n - 1.f) : var);
+    }
   }
 }
 // y = act((x - mean) * rstd * gamma + beta)
@@ -424,40 +423,38 @@ __global__ __launch_bounds__(256) void bn_bwd_partial_kernel(const float* __rest
     reinterpret_cast<float4*>(p + C)[q] = s2;
   }
 }
-// backward stage 2 (one block of 1024 threads): reduce partials in a fixed order -> sums[2][C];
+// backward stage 2 (one block of 1024 threads per 32 channels): reduce partials in a fixed order -> sums[2][C];
 // accumulate dgamma/dbeta
 __global__ __launch_bounds__(1024) void bn_bwd_finalize_kernel(const float* __restrict__ part, int nslab, int C,
                                                                float* __restrict__ sums, float* __restrict__ dgamma,
                                                                float* __restrict__ dbeta) {
   __shared__ float sh[2][1024];
   const int t = threadIdx.x;
-  const int W = C < 1024 ? C : 1024;
-  const int G = 1024 / W;
-  for (int c0 = 0; c0 < C; c0 += 1024) {
-    const int c = c0 + t % W, gi = t / W;
-    float s1 = 0.f, s2 = 0.f;
-    if (c < C && gi < G) {
-      for (int s0 = gi; s0 < nslab; s0 += 8 * G) {
-        float a1[8], a2[8];
+  const int cl = t % BN_CPB, gi = t / BN_CPB;
+  const int c = blockIdx.x * BN_CPB + cl;
+  float s1 = 0.f, s2 = 0.f;
+  if (c < C) {
+    for (int s0 = gi; s0 < nslab; s0 += 8 * BN_G) {
+      float a1[8], a2[8];
 #pragma unroll
-        for (int u = 0; u < 8; ++u) {
-          const int s = s0 + u * G;
-          const bool ok = s < nslab;
-          a1[u] = ok ? part[(long)s * 2 * C + c] : 0.f;
-          a2[u] = ok ? part[(long)s * 2 * C + C + c] : 0.f;
-        }
-#pragma unroll
-        for (int u = 0; u < 8; ++u) { s1 += a1[u]; s2 += a2[u]; }
+      for (int u = 0; u < 8; ++u) {
+        const int s = s0 + u * BN_G;
+        const bool ok = s < nslab;
+        const float* q = part + (long)(ok ? s : s0) * 2 * C;       // unconditional (clamped) loads, selected afterwards
+        const float v1 = q[c], v2 = q[C + c];
+        a1[u] = ok ? v1 : 0.f;
+        a2[u] = ok ? v2 : 0.f;
       }
+#pragma unroll
+      for (int u = 0; u < 8; ++u) { s1 += a1[u]; s2 += a2[u]; }
     }
-    sh[0][t] = s1; sh[1][t] = s2;
-    __syncthreads();
-    if (gi == 0 && c < C) {
-      for (int g2 = 1; g2 < G; ++g2) { s1 += sh[0][g2 * W + (c - c0)]; s2 += sh[1][g2 * W + (c - c0)]; }
-      sums[c] = s1; sums[C + c] = s2;
-      dbeta[c] += s1; dgamma[c] += s2;
-    }
-    __syncthreads();
+  }
+  sh[0][t] = s1; sh[1][t] = s2;
+  __syncthreads();
+  if (gi == 0 && c < C) {
+    for (int g2 = 1; g2 < BN_G; ++g2) { s1 += sh[0][g2 * BN_CPB + cl]; s2 += sh[1][g2 * BN_CPB + cl]; }
+    sums[c] = s1; sums[C + c] = s2;
+    dbeta[c] += s1; dgamma[c] += s2;
   }
 }
 // backward stage 3: dx = gamma*rstd*(dz - s1/M - xhat*s2/M)   (training-mode statistics)
@@ -780,7 +777,7 @@ int eamd_bn_stats(const float* x, float* workspace, float* mean, float* rstd, fl
   const int nslab = eamd_bn_nslab(M, C);
   hipLaunchKernelGGL(bn_partial_kernel, dim3(nslab), dim3(256), 0, s, x, workspace, (long)M, C);
   EAMD_LAUNCH_CHECK();
-  hipLaunchKernelGGL(bn_finalize_kernel, dim3(1), dim3(1024), 0, s, workspace, nslab, C, eps, momentum, mean, rstd,
+  hipLaunchKernelGGL(bn_finalize_kernel, dim3((C + BN_CPB - 1) / BN_CPB), dim3(1024), 0, s, workspace, nslab, C, eps, momentum, mean, rstd,
                      running_mean, running_var);
   EAMD_LAUNCH_CHECK();
   return EAMD_OK;
@@ -810,7 +807,7 @@ int eamd_bn_bwd(const float* dy, const float* x, const float* mean, const float*
   hipLaunchKernelGGL(bn_bwd_partial_kernel, dim3(nslab), dim3(256), 0, s, dy, x, mean, rstd, gamma, beta,
                      workspace, (long)M, C, act);
   EAMD_LAUNCH_CHECK();
-  hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(1), dim3(1024), 0, s, workspace, nslab, C, sums, dgamma, dbeta);
+  hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((C + BN_CPB - 1) / BN_CPB), dim3(1024), 0, s, workspace, nslab, C, sums, dgamma, dbeta);
   EAMD_LAUNCH_CHECK();
   hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(grid_for(M * C)), dim3(256), 0, s, dy, x, mean, rstd, gamma, beta,
                      sums, dx, (long)M, C, act, training);
