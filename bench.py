@@ -82,10 +82,12 @@ def main():
     ap.add_argument("--wgrad-stream", action="store_true",
                     help="issue weight-gradient GEMMs on a second stream (measured: no gain on MI355X, off by default)")
     ap.add_argument("--cpu-sample-batch", type=int, default=32)
-    ap.add_argument("--dp-mode", default="graph", choices=["graph", "overlap"],
-                    help="N>1: 'graph' = hipGraph replay of forward/backward and of the optimizer with the RCCL "
-                         "all-reduce of the gradient arena between them; 'overlap' = eager launches with "
-                         "backward-overlapped bucket all-reduces")
+    ap.add_argument("--dp-mode", default="graph", choices=["graph", "graph1", "overlap"],
+                    help="N>1: 'graph' = hipGraph replay of forward + backward in three phases (decoder/CTC | upper | "
+                         "lower encoder layers), each phase's range of the gradient arena all-reduced over RCCL under "
+                         "the next phase, then the optimizer graph; 'graph1' = one forward/backward graph, the whole "
+                         "arena all-reduced behind it; 'overlap' = eager launches with backward-overlapped bucket "
+                         "all-reduces")
     ap.add_argument("--rehearse-dp", action="store_true",
                     help="N=1 only: run the N>1 'graph' code path on a one-rank RCCL group (exercises the path "
                          "the multi-GPU runs take)")
@@ -111,7 +113,7 @@ def main():
     reducer = None
     if a.rehearse_dp and world == 1 and not torch.distributed.is_initialized():
         torch.distributed.init_process_group("nccl", init_method="tcp://127.0.0.1:29611", rank=0, world_size=1)
-    dp_graph = (world > 1 or a.rehearse_dp) and a.dp_mode == "graph" and not a.no_graph
+    dp_graph = (world > 1 or a.rehearse_dp) and a.dp_mode in ("graph", "graph1") and not a.no_graph
     if world > 1 and not dp_graph:
         reducer = train.GradReducer(flat, bucket_mb=48.0)
         train.attach_reducer(reducer)
@@ -125,7 +127,7 @@ def main():
     use_graph = (not a.no_graph) and world == 1 and not dp_graph
     dp_step = None
     if dp_graph:
-        dp_step = train.GraphedDataParallelStep(model, flat, opt, batch, world=world)
+        dp_step = train.GraphedDataParallelStep(model, flat, opt, batch, world=world, phases=(a.dp_mode == "graph"))
     side = torch.cuda.Stream()
     side.wait_stream(torch.cuda.current_stream())
     with torch.cuda.stream(side):
@@ -253,7 +255,7 @@ def main():
             "config": {"workload": "BASELINE configs[1]: 12L Conformer enc d=256 h=4 ff=2048 k=31 macaron+cnn rel_pos, "
                                    "6L Transformer dec, V=5000, fbank B=%d T=%d L=100, mtlalpha 0.3, lsm 0.1" % (B, T),
                        "global_batch": B * world, "frames": T, "parallelism": "dp%d" % world,
-                       "dropout": a.dropout, "optimizer": "adam+noam, clip 5.0", "launch": ("hipGraph fwd+bwd | RCCL all-reduce | hipGraph optimizer" if dp_step is not None else "hipGraph" if use_graph else "eager"), "wgrad_side_stream": a.wgrad_stream,
+                       "dropout": a.dropout, "optimizer": "adam+noam, clip 5.0", "launch": (("hipGraph fwd+bwd in %d phases, RCCL all-reduce of each phase's arena range under the next | hipGraph optimizer" % len(dp_step.ranges)) if dp_step is not None else "hipGraph" if use_graph else "eager"), "wgrad_side_stream": a.wgrad_stream,
                        "optimizer_steps_done": st["step"], "grad_norm": round(st["grad_norm"], 4)},
             "roofline": roof, "cpu_baseline": cpu,
         }

@@ -15,7 +15,7 @@ from .. import functional as F_
 from .. import ops
 from .asr_interface import ASRInterface
 from .modules import (CTC, Decoder, LabelSmoothingLoss, TransformerEncoder, make_non_pad_mask,
-                      embed_output_lengths, subsampled_lengths, subsequent_mask, th_accuracy)
+                      embed_output_lengths, grad_cut, subsampled_lengths, subsequent_mask, th_accuracy)
 
 CTC_LOSS_THRESHOLD = 10000  # reference: e2e_asr.py:43
 
@@ -183,6 +183,7 @@ class E2E(ASRInterface, torch.nn.Module):
         """Kernel-only part of forward (reference: e2e_asr_transformer.py:175-232)."""
         xs_pad = batch["xs_pad"]
         hs_pad, hs_mask = self.encoder(xs_pad, batch["src_mask"])
+        hs_pad = grad_cut(hs_pad)        # no-op unless a phased backward is being set up (modules.GradCuts)
         self.hs_pad = hs_pad
         if hs_mask is not None and not hs_mask.is_contiguous():
             hs_mask = hs_mask.contiguous()

@@ -478,11 +478,39 @@ class TransformerEncoderLayer(torch.nn.Module):
         return x, mask
 
 
+class GradCuts:
+    """Phased backward for data-parallel training (train.GraphedDataParallelStep): while `active` is a list, every cut
+    point replaces the activation by a detached leaf and records (upstream tensor, leaf).  loss.backward() then stops
+    at the last cut; upstream.backward(leaf.grad) continues segment by segment, so that the gradients of the layers
+    already finished can be all-reduced while the rest of backward runs.  Values are unchanged."""
+
+    active = None
+
+
+def grad_cut(x):
+    """x: tensor, or the (x, pos_emb) pair the relative-position layers pass along"""
+    if GradCuts.active is None:
+        return x
+    t = x[0] if isinstance(x, tuple) else x
+    if not (torch.is_tensor(t) and t.requires_grad):
+        return x
+    leaf = t.detach().requires_grad_(True)
+    tag = getattr(t, "_eamd_out_drop", None)      # the next block's LayerNorm backward may fuse this block's dropout
+    if tag is not None:
+        leaf._eamd_out_drop = tag
+    GradCuts.active.append((t, leaf))
+    return (leaf,) + tuple(x[1:]) if isinstance(x, tuple) else leaf
+
+
 class MultiSequential(torch.nn.ModuleList):
     """reference: transformer/repeat.py:12-33 (state_dict keys `N.<name>` like nn.Sequential)"""
 
+    cut_before = ()      # layer indices in front of which a gradient cut is placed while GradCuts.active
+
     def forward(self, *args):
-        for m in self:
+        for i, m in enumerate(self):
+            if GradCuts.active is not None and i in self.cut_before:
+                args = (grad_cut(args[0]),) + tuple(args[1:])
             args = m(*args)
         return args
 

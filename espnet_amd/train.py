@@ -222,56 +222,144 @@ def train_step(model, flat, opt, batch, reducer=None, loss_scale=1.0):
 class GraphedDataParallelStep:
     """hipGraph replay of a data-parallel training step without capturing any collective:
       graph A = zero the gradient arena, advance the dropout counter, forward, backward (loss pre-scaled by
-                1/world, as the reference's DDP averaging);
-      eager   = RCCL all-reduce (SUM) of the flat gradient arena, bucket by bucket, asynchronously on the
-                communicator's stream (torch.distributed orders it after graph A and before graph B);
+                1/world, as the reference's DDP averaging) - split by gradient cuts into phases A1 | A2 | A3 whose
+                arena ranges are contiguous (see __init__);
+      eager   = RCCL all-reduce (SUM) of each phase's range of the flat gradient arena, bucket by bucket,
+                asynchronously on the communicator's stream, issued right behind the phase's graph so that it
+                overlaps the next phase (torch.distributed orders it after that graph; graph B waits for all);
       graph B = gradient norm, clipping, Noam schedule, Adam, bf16 shadow refresh.
     Compared with the eager step + backward-overlapped buckets (train_step with a GradReducer) this gives up the
     overlap (about 1 ms of all-reduce for 187 MB over xGMI) and wins back the launch overhead of ~1500 kernels.
     reference: espnet2/train/trainer.py:381-467 (forward, backward, clip, step under DistributedDataParallel)."""
 
-    def __init__(self, model, flat, opt, batch, world=1, group=None, bucket_mb=48.0, warmup=2):
+    def __init__(self, model, flat, opt, batch, world=1, group=None, bucket_mb=48.0, warmup=2, phases=True):
         import torch.distributed as dist
         self.dist, self.group, self.world = dist, group, world
         self.model, self.flat, self.opt, self.batch = model, flat, opt, batch
-        cap = max(1, int(bucket_mb * 1024 * 1024 // 4))
-        self.buckets = [(s, min(flat.numel, s + cap)) for s in range(0, flat.numel, cap)]
+        self.cap = max(1, int(bucket_mb * 1024 * 1024 // 4))
+        # Phased backward (phases=True, models with an `encoder.encoders` layer stack): gradient cuts behind the
+        # encoder and in the middle of its layer stack split graph A into A1 (forward + backward of decoder / CTC),
+        # A2 (upper encoder layers) and A3 (lower layers + input layer).  The arena keeps registration order, so each
+        # phase owns one contiguous range of the gradient arena; its all-reduce is issued as soon as the phase's
+        # graph has been enqueued and runs on the communicator's stream under the next phase.  Only the last
+        # range (about 40 % of the bytes at config 2) is exposed.
+        self.ranges = [(0, flat.numel)]
+        self.cuts = []
+        self._stack = None
+        if phases:
+            self._plan_phases()
         side = torch.cuda.Stream()
         side.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(side):
             for _ in range(max(1, warmup)):
-                self._fwd_bwd()
-                self._reduce()
+                loss = self._phase(0)
+                works = self._reduce(0)
+                for k in range(1, len(self.ranges)):
+                    self._phase(k)
+                    works += self._reduce(k)
+                self._wait(works)
                 opt.step()
         torch.cuda.current_stream().wait_stream(side)
         torch.cuda.synchronize()
         # thread_local: the communicator's watchdog thread may query its events while we capture
-        self.graph_a = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(self.graph_a, capture_error_mode="thread_local"):
-            self.loss = self._fwd_bwd()
+        self.graphs = []
+        for k in range(len(self.ranges)):
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g, capture_error_mode="thread_local"):
+                out = self._phase(k)
+            if k == 0:
+                self.loss = out
+            self.graphs.append(g)
+        self.graph_a = self.graphs[0]
         self.graph_b = torch.cuda.CUDAGraph()
         with torch.cuda.graph(self.graph_b, capture_error_mode="thread_local"):
             opt.step()
 
-    def _fwd_bwd(self):
-        self.flat.zero_grad()
-        ops.rng_advance(self.flat.data.device)
-        loss = self.model.forward_core(self.batch)
-        scale = 1.0 / self.world
-        loss.backward(torch.full((), scale, device=loss.device, dtype=loss.dtype) if scale != 1.0 else None)
-        ops.wgrad_join()
-        return loss
+    def _plan_phases(self):
+        """cut points + the arena range each backward phase completes; leaves the single-phase plan in place when the
+        model has no layer stack to cut or the ranges would not be contiguous"""
+        from .nets.modules import MultiSequential
+        enc = getattr(self.model, "encoder", None)
+        stack = getattr(enc, "encoders", None)
+        if not isinstance(stack, MultiSequential) or len(stack) < 2 or not hasattr(self.model, "forward_core"):
+            return
+        mid = len(stack) // 2
+        phase_of = {}
+        for name, p in self.model.named_parameters():
+            if not name.startswith("encoder."):
+                ph = 0                                              # decoder, CTC, anything behind the encoder
+            elif name.startswith("encoder.encoders."):
+                ph = 1 if int(name.split(".")[2]) >= mid else 2
+            elif name.startswith("encoder.after_norm."):
+                ph = 1
+            else:
+                ph = 2                                              # input layer
+            phase_of[id(p)] = ph
+        spans = {}
+        for p, o in zip(self.flat.params, self.flat.offsets):
+            ph = phase_of.get(id(p))
+            if ph is None:
+                return
+            lo, hi = spans.get(ph, (o, o))
+            spans[ph] = (min(lo, o), max(hi, o + p.numel()))
+        if sorted(spans) != [0, 1, 2]:
+            return
+        order = sorted(spans.values())
+        if any(a[1] > b[0] for a, b in zip(order, order[1:])):      # interleaved in the arena: keep one phase
+            return
+        bounds = [order[0][0], order[1][0], order[2][0], self.flat.numel]
+        bounds[0] = 0
+        rng = {}
+        for ph, sp in spans.items():
+            i = order.index(sp)
+            rng[ph] = (bounds[i], bounds[i + 1])
+        self.ranges = [rng[0], rng[1], rng[2]]
+        self._stack, self._mid = stack, mid
 
-    def _reduce(self):
-        if self.dist.is_initialized():
-            works = [self.dist.all_reduce(self.flat.grad[s:e], op=self.dist.ReduceOp.SUM, group=self.group, async_op=True)
-                     for s, e in self.buckets]
-            for w in works:
-                w.wait()      # stream-level wait: the current stream continues after the collective, no host block
+    def _phase(self, k):
+        from .nets.modules import GradCuts
+        if k == 0:
+            self.flat.zero_grad()
+            ops.rng_advance(self.flat.data.device)
+            if self._stack is not None:
+                self._stack.cut_before = (self._mid,)
+                GradCuts.active = []
+            try:
+                loss = self.model.forward_core(self.batch)
+                self.cuts = GradCuts.active or []
+            finally:
+                GradCuts.active = None
+                if self._stack is not None:
+                    self._stack.cut_before = ()
+            if self._stack is not None and len(self.cuts) != 2:
+                raise RuntimeError("phased backward expects two gradient cuts, found %d" % len(self.cuts))
+            scale = 1.0 / self.world
+            loss.backward(torch.full((), scale, device=loss.device, dtype=loss.dtype) if scale != 1.0 else None)
+            ops.wgrad_join()
+            return loss
+        upstream, leaf = self.cuts[len(self.cuts) - k]       # phase 1 resumes behind the encoder, phase 2 mid-stack
+        upstream.backward(leaf.grad)
+        ops.wgrad_join()
+        return None
+
+    def _reduce(self, k):
+        if not self.dist.is_initialized():
+            return []
+        lo, hi = self.ranges[k]
+        return [self.dist.all_reduce(self.flat.grad[s:min(hi, s + self.cap)], op=self.dist.ReduceOp.SUM, group=self.group,
+                                     async_op=True) for s in range(lo, hi, self.cap)]
+
+    @staticmethod
+    def _wait(works):
+        for w in works:
+            w.wait()      # stream-level wait: the current stream continues after the collective, no host block
 
     def __call__(self):
-        self.graph_a.replay()
-        self._reduce()
+        works = []
+        for k, g in enumerate(self.graphs):
+            g.replay()
+            works += self._reduce(k)      # runs on the communicator's stream under the next phase's graph
+        self._wait(works)
         self.graph_b.replay()
         return self.loss
 

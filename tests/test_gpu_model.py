@@ -452,7 +452,7 @@ def test_graphed_data_parallel_step_matches_eager_step():
         xs, ilens = torch.randn(3, 70, 40, generator=g), [70, 61, 50]
         ys = torch.randint(1, 29, (3, 6), generator=g)
         results = []
-        for mode in ("eager", "graph"):
+        for mode in ("eager", "graph", "graph1"):
             torch.manual_seed(11)
             model = E2E(40, 30, ns).to(DEV).train()
             model.sync_report = False
@@ -463,13 +463,20 @@ def test_graphed_data_parallel_step_matches_eager_step():
                 for _ in range(4):
                     train.train_step(model, flat, opt, batch)
             else:
-                step = train.GraphedDataParallelStep(model, flat, opt, batch, world=1, warmup=1)   # 1 warm-up step
+                step = train.GraphedDataParallelStep(model, flat, opt, batch, world=1, warmup=1,   # 1 warm-up step
+                                                     phases=(mode == "graph"))
+                # phased: backward of decoder + CTC | upper encoder layers | lower layers + input layer, one contiguous
+                # arena range each, together the whole arena
+                assert len(step.ranges) == (3 if mode == "graph" else 1)
+                assert sorted(step.ranges)[0][0] == 0 and sorted(step.ranges)[-1][1] == flat.numel
+                assert all(a[1] == b[0] for a, b in zip(sorted(step.ranges), sorted(step.ranges)[1:]))
                 for _ in range(3):
                     step()
             torch.cuda.synchronize()
             results.append((flat.data.clone(), opt.stats()["step"]))
-        assert results[0][1] == results[1][1] == 4
-        report("graphed DP step parameters after 4 steps", results[1][0], results[0][0], 2e-3)
+        assert results[0][1] == results[1][1] == results[2][1] == 4
+        report("graphed DP step (phased backward) parameters after 4 steps", results[1][0], results[0][0], 2e-3)
+        report("graphed DP step (single phase) parameters after 4 steps", results[2][0], results[0][0], 2e-3)
     finally:
         if created:
             dist.destroy_process_group()
