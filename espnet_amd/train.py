@@ -232,7 +232,7 @@ class GraphedDataParallelStep:
     overlap (about 1 ms of all-reduce for 187 MB over xGMI) and wins back the launch overhead of ~1500 kernels.
     reference: espnet2/train/trainer.py:381-467 (forward, backward, clip, step under DistributedDataParallel)."""
 
-    def __init__(self, model, flat, opt, batch, world=1, group=None, bucket_mb=48.0, warmup=2, phases=True):
+    def __init__(self, model, flat, opt, batch, world=1, group=None, bucket_mb=128.0, warmup=2, phases=True):
         import torch.distributed as dist
         self.dist, self.group, self.world = dist, group, world
         self.model, self.flat, self.opt, self.batch = model, flat, opt, batch
@@ -241,8 +241,9 @@ class GraphedDataParallelStep:
         # encoder and in the middle of its layer stack split graph A into A1 (forward + backward of decoder / CTC),
         # A2 (upper encoder layers) and A3 (lower layers + input layer).  The arena keeps registration order, so each
         # phase owns one contiguous range of the gradient arena; its all-reduce is issued as soon as the phase's
-        # graph has been enqueued and runs on the communicator's stream under the next phase.  Only the last
-        # range (about 40 % of the bytes at config 2) is exposed.
+        # graph has been enqueued and runs on the communicator's stream under the next phase (one collective per
+        # range up to bucket_mb: few, large messages).  Only the last range (about 25 % of the bytes at config 2)
+        # is exposed.
         self.ranges = [(0, flat.numel)]
         self.cuts = []
         self._stack = None
@@ -283,7 +284,9 @@ class GraphedDataParallelStep:
         stack = getattr(enc, "encoders", None)
         if not isinstance(stack, MultiSequential) or len(stack) < 2 or not hasattr(self.model, "forward_core"):
             return
-        mid = len(stack) // 2
+        # the cut sits a third of the way up: the exposed range (input layer + lowest third) is the smallest, and the
+        # larger middle range still has the whole last phase to hide under
+        mid = max(1, len(stack) // 3)
         phase_of = {}
         for name, p in self.model.named_parameters():
             if not name.startswith("encoder."):
