@@ -284,19 +284,21 @@ class GraphedDataParallelStep:
         stack = getattr(enc, "encoders", None)
         if not isinstance(stack, MultiSequential) or len(stack) < 2 or not hasattr(self.model, "forward_core"):
             return
-        # the cut sits a third of the way up: the exposed range (input layer + lowest third) is the smallest, and the
-        # larger middle range still has the whole last phase to hide under
-        mid = max(1, len(stack) // 3)
+        # cuts low in the stack keep the exposed last range small (input layer + the lowest sixth of the layers:
+        # 16 % of the bytes at config 2) while every other range has a whole phase of backward to hide under
+        n = len(stack)
+        cuts = sorted({max(1, n // 6), max(1, (7 * n) // 12)})
+        nph = len(cuts) + 2
         phase_of = {}
         for name, p in self.model.named_parameters():
             if not name.startswith("encoder."):
                 ph = 0                                              # decoder, CTC, anything behind the encoder
             elif name.startswith("encoder.encoders."):
-                ph = 1 if int(name.split(".")[2]) >= mid else 2
+                ph = 1 + sum(1 for c in cuts if int(name.split(".")[2]) < c)
             elif name.startswith("encoder.after_norm."):
                 ph = 1
             else:
-                ph = 2                                              # input layer
+                ph = nph - 1                                        # input layer
             phase_of[id(p)] = ph
         spans = {}
         for p, o in zip(self.flat.params, self.flat.offsets):
@@ -305,19 +307,14 @@ class GraphedDataParallelStep:
                 return
             lo, hi = spans.get(ph, (o, o))
             spans[ph] = (min(lo, o), max(hi, o + p.numel()))
-        if sorted(spans) != [0, 1, 2]:
+        if sorted(spans) != list(range(nph)):
             return
         order = sorted(spans.values())
         if any(a[1] > b[0] for a, b in zip(order, order[1:])):      # interleaved in the arena: keep one phase
             return
-        bounds = [order[0][0], order[1][0], order[2][0], self.flat.numel]
-        bounds[0] = 0
-        rng = {}
-        for ph, sp in spans.items():
-            i = order.index(sp)
-            rng[ph] = (bounds[i], bounds[i + 1])
-        self.ranges = [rng[0], rng[1], rng[2]]
-        self._stack, self._mid = stack, mid
+        bounds = [0] + [sp[0] for sp in order[1:]] + [self.flat.numel]
+        self.ranges = [(bounds[order.index(spans[ph])], bounds[order.index(spans[ph]) + 1]) for ph in range(nph)]
+        self._stack, self._cut_layers = stack, tuple(cuts)
 
     def _phase(self, k):
         from .nets.modules import GradCuts
@@ -325,7 +322,7 @@ class GraphedDataParallelStep:
             self.flat.zero_grad()
             ops.rng_advance(self.flat.data.device)
             if self._stack is not None:
-                self._stack.cut_before = (self._mid,)
+                self._stack.cut_before = self._cut_layers
                 GradCuts.active = []
             try:
                 loss = self.model.forward_core(self.batch)
@@ -334,13 +331,13 @@ class GraphedDataParallelStep:
                 GradCuts.active = None
                 if self._stack is not None:
                     self._stack.cut_before = ()
-            if self._stack is not None and len(self.cuts) != 2:
-                raise RuntimeError("phased backward expects two gradient cuts, found %d" % len(self.cuts))
+            if self._stack is not None and len(self.cuts) != len(self.ranges) - 1:
+                raise RuntimeError("phased backward expects %d gradient cuts, found %d" % (len(self.ranges) - 1, len(self.cuts)))
             scale = 1.0 / self.world
             loss.backward(torch.full((), scale, device=loss.device, dtype=loss.dtype) if scale != 1.0 else None)
             ops.wgrad_join()
             return loss
-        upstream, leaf = self.cuts[len(self.cuts) - k]       # phase 1 resumes behind the encoder, phase 2 mid-stack
+        upstream, leaf = self.cuts[len(self.cuts) - k]       # phase 1 resumes behind the encoder, the next ones lower in the stack
         upstream.backward(leaf.grad)
         ops.wgrad_join()
         return None

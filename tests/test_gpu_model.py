@@ -465,7 +465,7 @@ def test_graphed_data_parallel_step_matches_eager_step():
             else:
                 step = train.GraphedDataParallelStep(model, flat, opt, batch, world=1, warmup=1,   # 1 warm-up step
                                                      phases=(mode == "graph"))
-                # phased: backward of decoder + CTC | upper encoder layers | lower layers + input layer, one contiguous
+                # phased: backward of decoder + CTC | upper encoder layer(s) | lowest layer(s) + input layer, one contiguous
                 # arena range each, together the whole arena
                 assert len(step.ranges) == (3 if mode == "graph" else 1)
                 assert sorted(step.ranges)[0][0] == 0 and sorted(step.ranges)[-1][1] == flat.numel
