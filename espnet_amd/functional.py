@@ -343,6 +343,7 @@ def attn_scores_fwd(qu, qv, k, p, mask, B, T1, T2, H, dk):
 
 
 FUSE_ATTN = True   # tests flip this to compare against the GEMM / softmax / GEMM path
+ATTN_TAP = None    # a list while E2E.calculate_all_attentions runs: every attention block appends its probabilities
 
 
 def attn_fwd_fused(qu, qv, k, v, p, mask, B, T1, T2, H, dk):
@@ -520,6 +521,8 @@ class MHABlockFn(torch.autograd.Function):
             P = attn_scores_fwd(qu, qv, k, p, mask, B, T1, T2, H, dk)
             Pd = ops.dropout(P, p_att, s_att) if p_att > 0.0 else P
             cx = attn_context_fwd(Pd, v, B, T1, T2, H, dk)
+        if ATTN_TAP is not None:      # calculate_all_attentions: the probabilities in the reference's (B, H, T1, T2) layout
+            ATTN_TAP.append(Pd.view(H, B, T1, _ldp(T2))[..., :T2].permute(1, 0, 2, 3).float())
         if p_out > 0.0 and ops.fast():
             out = ops.linear_fwd(cx, ops.wshadow(wo), bo, R=res, drop=(p_out, s_out))
         elif p_out > 0.0:

@@ -266,6 +266,24 @@ class E2E(ASRInterface, torch.nn.Module):
             hl = torch.tensor(embed_output_lengths(self.encoder.embed, il, tmax), dtype=torch.int32).to(ids.device)
             return ops.ctc_collapse(ids, hl, self.blank)
 
+    def calculate_all_attentions(self, xs_pad, ilens, ys_pad):
+        """reference: e2e_asr_transformer.py:479-503.  {module name: (B, H, T1, T2) float ndarray} for every attention
+        module (encoder self-attention, decoder self- and source-attention) from one eval-mode forward pass."""
+        from .modules import MultiHeadedAttention
+        self.eval()
+        F_.ATTN_TAP = []
+        try:
+            with torch.no_grad():
+                self.forward(xs_pad, ilens, ys_pad)
+        finally:
+            F_.ATTN_TAP = None
+        ret = dict()
+        for name, m in self.named_modules():
+            if isinstance(m, MultiHeadedAttention) and m.attn is not None:
+                ret[name] = m.attn.cpu().numpy()
+        self.train()       # the reference leaves the model in training mode (e2e_asr_transformer.py:502)
+        return ret
+
     def calculate_all_ctc_probs(self, xs_pad, ilens, ys_pad):
         """reference: e2e_asr_transformer.py:503-525"""
         if self.mtlalpha == 0:

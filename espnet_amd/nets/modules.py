@@ -309,8 +309,12 @@ class RelPositionMultiHeadedAttention(MultiHeadedAttention):
 def mha_block(norm, attn, x, memory, pos_emb, mask, last_query_only=False, p_out=0.0):
     """x + drop(attn(LN(x)[, memory])) through the fused HIP block (p_out = the layer's dropout rate)."""
     drop = (_p(attn, attn.dropout_rate), attn.salt_attn, p_out if attn.training else 0.0, attn.salt_out)
-    return F_.MHABlockFn.apply(x.contiguous(), memory, pos_emb, _mask_u8(mask, x.device), attn.h, norm.eps,
-                               last_query_only, drop, norm.weight, norm.bias, *attn.block_params())
+    n_tap = len(F_.ATTN_TAP) if F_.ATTN_TAP is not None else 0
+    out = F_.MHABlockFn.apply(x.contiguous(), memory, pos_emb, _mask_u8(mask, x.device), attn.h, norm.eps,
+                              last_query_only, drop, norm.weight, norm.bias, *attn.block_params())
+    if F_.ATTN_TAP is not None and len(F_.ATTN_TAP) > n_tap:
+        attn.attn = F_.ATTN_TAP[-1]        # attention.py:90 (self.attn, kept for calculate_all_attentions / plotting)
+    return out
 
 
 class PositionwiseFeedForward(torch.nn.Module):

@@ -788,3 +788,45 @@ def test_deferred_layernorm_reduction_matches_immediate():
     ops.layernorm_bwd(dy, x, g, mean, rstd, None, dg, db)
     assert torch.allclose(db, dy.sum(0), rtol=1e-4, atol=1e-3)
     assert torch.allclose(dg, (dy * (x - mean[:, None]) * rstd[:, None]).sum(0), rtol=1e-4, atol=1e-3)
+
+
+def test_calculate_all_attentions():
+    """E2E.calculate_all_attentions (e2e_asr_transformer.py:479-503): one (B, H, T1, T2) array per attention module; rows
+    are distributions over the valid keys, padded keys get zero weight, decoder self-attention is causal; the fused
+    bf16 kernels and the fp32 GEMM + softmax path agree"""
+    import espnet_amd
+    p, sd, _ = split_golden(load_golden("e2e_conformer.npz"))
+    torch.manual_seed(3)
+    model = _e2e("conformer", CASES[0][2]).to(DEV)
+    xs, ilens, ys = p["xs"].to(DEV), p["ilens"], p["ys"].to(DEV)
+    att = {}
+    for prec in ("fp32", "bf16"):
+        espnet_amd.set_precision(prec)
+        try:
+            att[prec] = model.calculate_all_attentions(xs, ilens, ys)
+        finally:
+            espnet_amd.set_precision("fp32")
+    assert model.training
+    a = att["fp32"]
+    names = set(a)
+    assert {"encoder.encoders.0.self_attn", "decoder.decoders.0.self_attn", "decoder.decoders.0.src_attn"} <= names
+    B = xs.shape[0]
+    hl = None
+    for name, w in a.items():
+        assert w.ndim == 4 and w.shape[0] == B and w.dtype == np.float32, name
+        s = w.sum(-1)
+        assert np.all((np.abs(s - 1) < 1e-4) | (np.abs(s) < 1e-6)), name
+        if name.startswith("encoder."):
+            hl = w.shape[-1]
+            assert w.shape[2] == w.shape[3]
+        if name.endswith("decoders.0.self_attn"):
+            assert np.allclose(np.triu(w[0, 0], 1), 0.0)          # causal
+    from espnet_amd.nets.modules import subsampled_lengths
+    lens = subsampled_lengths([int(n) for n in ilens], int(max(ilens)))
+    enc = a["encoder.encoders.0.self_attn"]
+    for b, n in enumerate(lens):
+        assert np.all(enc[b, :, :, n:] == 0.0) and hl >= n
+    for name in a:
+        d = float(np.abs(a[name] - att["bf16"][name]).max())
+        print(f"[parity] attention weights {name}: fp32 vs bf16 max abs diff {d:.2e}")
+        assert d < 3e-2, name
