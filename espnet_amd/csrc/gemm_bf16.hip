@@ -514,7 +514,7 @@ int eamd_gemm_bf16_dispatch(const eamd_gemm_t& p, int tile, hipStream_t stream) 
     if (direct_on) return eamd_gemm_bf16_direct(p, stream);      // attention score products: one or two K-tiles
   }
   if (a_ok && b_ok && tile == 64) {
-    static const int persist_min = [] { const char* e = getenv("EAMD_GEMM_PERSIST_MIN"); return e ? atoi(e) : 1536; }();
+    static const int persist_min = [] { const char* e = getenv("EAMD_GEMM_PERSIST_MIN"); return e ? atoi(e) : 512; }();
     const long ntiles = (long)((p.M + 63) / 64) * ((p.N + 63) / 64);
     if (persist_min > 0 && ntiles >= persist_min && ntiles < (1L << 30) && p.K % 256 == 0 && p.splitk == 1 &&
         p.batch1 * p.batch2 == 1 && !p.colsum && p.a_act == EAMD_ACT_NONE && p.b_act == EAMD_ACT_NONE && !p.cmap.enabled &&
