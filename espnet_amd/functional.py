@@ -16,7 +16,16 @@ from .ops import (ACT_NONE, ACT_RELU, ACT_SWISH, EPI_MUL_DSWISH, EPI_MUL_RELU_MA
 class GradSink:
     """Where backward kernels accumulate parameter gradients."""
 
-    on_done = None   # optional callback(params): gradients of these parameters are final (DDP buckets)
+    on_done = None   # optional callback(params): one use of these parameters has written its gradients (DDP buckets)
+    on_use = None    # optional callback(params): a forward pass recorded one more use of these parameters
+
+    @staticmethod
+    def use(params):
+        """every block forward passes its parameters through here: a parameter that several blocks (or several
+        time steps of one recurrent cell) use is final only when EACH use has reported from backward"""
+        if GradSink.on_use is not None and torch.is_grad_enabled():
+            GradSink.on_use(params)
+        return params
 
     def __init__(self, params):
         self.params = list(params)
@@ -123,7 +132,7 @@ class LayerNormFn(torch.autograd.Function):
         x2 = x.reshape(-1, shp[-1]).contiguous()
         y, mean, rstd = ops.layernorm_fwd(x2, weight, bias, eps)
         ctx.save_for_backward(x2, mean, rstd)
-        ctx.pr = (weight, bias)
+        ctx.pr = GradSink.use((weight, bias))
         ctx.shp = shp
         ctx.prev = _prev_drop(x)       # the block in front of a layer's final norm: its gradient dropout rides along
         return y.view(shp)
@@ -148,7 +157,7 @@ class LinearFn(torch.autograd.Function):
         x2 = ops.to_act(x.reshape(-1, shp[-1]).contiguous())
         y = ops.linear_fwd(x2, ops.wshadow(weight), bias)
         ctx.save_for_backward(x2)
-        ctx.pr = (weight, bias)
+        ctx.pr = GradSink.use((weight, bias))
         ctx.shp = shp
         return y.view(*shp[:-1], weight.shape[0])
 
@@ -201,7 +210,7 @@ class FFNBlockFn(torch.autograd.Function):
         else:
             out = ops.linear_fwd(src, ops.wshadow(w2), b2, R=x2, alpha=scale, a_act=a_act)
         ctx.save_for_backward(x2, mean, rstd, xn, z, h)
-        ctx.pr = (ln_w, ln_b, w1, b1, w2, b2)
+        ctx.pr = GradSink.use((ln_w, ln_b, w1, b1, w2, b2))
         ctx.cfg = (scale, act, shp, drop)
         ctx.prev = _prev_drop(x)
         return _tag_out(out.view(shp), p_out, s_out)
@@ -268,7 +277,7 @@ class Conv1dFFNBlockFn(torch.autograd.Function):
         else:
             out = ops.linear_fwd(col2, w2k, b2, R=x2, alpha=scale)
         ctx.save_for_backward(x2, mean, rstd, col1, z, col2, w1k, w2k)
-        ctx.pr = (ln_w, ln_b, w1, b1, w2, b2)
+        ctx.pr = GradSink.use((ln_w, ln_b, w1, b1, w2, b2))
         ctx.cfg = (scale, (B, T, D, H, k1, k2), drop)
         return out.view(B, T, D)
 
@@ -536,7 +545,7 @@ class MHABlockFn(torch.autograd.Function):
         else:
             ctx.save_for_backward(x2, mean, rstd, xn, kv_in if memory is not None else None, qu, qv, k, v, p, P, cx,
                                   pos2, Pd if p_att > 0.0 else None)
-        ctx.pr = params
+        ctx.pr = GradSink.use(params)
         ctx.fused = fused
         ctx.cfg = (B, T1, T2, H, dk, D, rel, memory is not None, last_query_only, drop)
         ctx.prev = _prev_drop(x)
@@ -641,7 +650,7 @@ class ConvModuleBlockFn(torch.autograd.Function):
         else:
             out = ops.linear_fwd(e, ops.wshadow(w2).view(Cc, Cc), b2, R=x2)
         ctx.save_for_backward(x2, mean, rstd, xn, a, gl, d, bmean, brstd, e)
-        ctx.pr = params
+        ctx.pr = GradSink.use(params)
         ctx.cfg = (B, T, D, Cc, K, act, training, drop)
         ctx.prev = _prev_drop(x)
         return _tag_out(out.view(B, T, D), p_out, s_out)
@@ -817,7 +826,7 @@ class Conv2dSubsamplingFn(torch.autograd.Function):
         wl = ops.to_act(wl)
         out = ops.linear_fwd(ys[-1].view(B * Hl, Wl * Cc), wl, lin_b, alpha=xscale)
         ctx.save_for_backward(x, wl, *ys, *wds)
-        ctx.pr = (c1_w, c1_b, lin_w, lin_b) + tuple(convs)
+        ctx.pr = GradSink.use((c1_w, c1_b, lin_w, lin_b) + tuple(convs))
         ctx.cfg = (B, T, F, Cc, D, dims, xscale)
         ctx.ks = [convs[i].shape[-1] for i in range(0, len(convs), 2)]
         return out.view(B, Hl, D)
@@ -864,7 +873,7 @@ class EmbedPEFn(torch.autograd.Function):
         tok = tokens.contiguous()
         out = ops.embed_pe(tok, table, pe, U, scale, pos_offset)
         ctx.save_for_backward(tok)
-        ctx.pr = (table,)
+        ctx.pr = GradSink.use((table,))
         ctx.scale = scale
         return out.view(B, U, table.shape[1])
 

@@ -37,7 +37,7 @@ class PlainEmbedFn(torch.autograd.Function):
         tok = tokens.contiguous()
         out = ops.embed_pe(tok.view(-1), table, None, 1, 1.0)
         ctx.save_for_backward(tok)
-        ctx.pr = (table,)
+        ctx.pr = GradSink.use((table,))
         ctx.pad = pad_idx
         return out.view(*tokens.shape, table.shape[1])
 
@@ -88,7 +88,7 @@ class LSTMSeqFn(torch.autograd.Function):
             ops.lstm_cell_fwd(gates, cp, hp, None if live is None else live[t], h_out[t], c_out[t], y[t], acts[t])
             hp, cp = h_out[t], c_out[t]
         ctx.save_for_backward(h_out, c_out, acts, zero, live if live is not None else zero)
-        ctx.pr = (w_hh, b_hh)
+        ctx.pr = GradSink.use((w_hh, b_hh))
         ctx.cfg = (reverse, live is not None)
         return y
 
@@ -140,7 +140,7 @@ class LSTMCellFn(torch.autograd.Function):
         acts = gates                                       # activated gates overwrite the pre-activations
         ops.lstm_cell_fwd(gates, c_prev, None, None, h, c, None, acts)
         ctx.save_for_backward(acts, h_prev, c_prev, c)
-        ctx.pr = (w_hh, b_hh) if b_hh is not None else (w_hh,)      # LSTMCell(bias=False): AttLocRec's att_lstm
+        ctx.pr = GradSink.use((w_hh, b_hh) if b_hh is not None else (w_hh,))      # LSTMCell(bias=False): AttLocRec's att_lstm
         return h, c
 
     @staticmethod
@@ -184,7 +184,7 @@ class GRUSeqFn(torch.autograd.Function):
             ops.gru_cell_fwd(gx[t], gh, hp, None if live is None else live[t], h_out[t], y[t], acts[t])
             hp = h_out[t]
         ctx.save_for_backward(h_out, acts, zero, live if live is not None else zero)
-        ctx.pr = (w_hh, b_hh)
+        ctx.pr = GradSink.use((w_hh, b_hh))
         ctx.cfg = (reverse, live is not None)
         return y
 
@@ -232,7 +232,7 @@ class GRUCellFn(torch.autograd.Function):
         acts = torch.empty(B, 4 * H, device=dev, dtype=torch.float32)
         ops.gru_cell_fwd(gx, gh, h_prev, None, h, None, acts)
         ctx.save_for_backward(acts, h_prev)
-        ctx.pr = (w_hh, b_hh)
+        ctx.pr = GradSink.use((w_hh, b_hh))
         return h
 
     @staticmethod
@@ -314,7 +314,7 @@ class VGG2LFn(torch.autograd.Function):
         out = torch.empty(B, T4, C2, F4, device=x.device, dtype=torch.float32)   # (c, f) feature order
         ops.permute4(p2, out, (B * T4, F4, C2, 1), (C2 * F4, 1, F4, 0))
         ctx.save_for_backward(x, y1, y2, i1, p1, y3, y4, i2, wd12, wd21, wd22)
-        ctx.pr = (w11, b11, w12, b12, w21, b21, w22, b22)
+        ctx.pr = GradSink.use((w11, b11, w12, b12, w21, b21, w22, b22))
         ctx.cfg = (B, T, F, T2, F2, T4, F4, C1, C2)
         return out.view(B, T4, C2 * F4)
 
@@ -350,7 +350,7 @@ class AttLocStepFn(torch.autograd.Function):
         c, w, th, conv = ops.attloc_fwd(att_prev, conv_w, w_att, pre_enc, dec_proj, gvec_w, gvec_b, lens, enc_h,
                                         scaling)
         ctx.save_for_backward(enc_h, att_prev, w, th, conv)
-        ctx.pr = (conv_w, w_att, gvec_w, gvec_b) if conv_w is not None else (gvec_w, gvec_b)
+        ctx.pr = GradSink.use((conv_w, w_att, gvec_w, gvec_b) if conv_w is not None else (gvec_w, gvec_b))
         ctx.has_conv = conv_w is not None
         ctx.scaling = scaling
         return c, w
@@ -405,7 +405,7 @@ class ConvMaxFn(torch.autograd.Function):
         att_prev = att_prev.contiguous()
         pooled, idx = ops.attloc_convmax_fwd(att_prev, conv_w)
         ctx.save_for_backward(att_prev, pooled, idx)
-        ctx.pr = (conv_w,)
+        ctx.pr = GradSink.use((conv_w,))
         return pooled
 
     @staticmethod

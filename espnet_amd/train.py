@@ -7,7 +7,7 @@
                  non-finite-step skip, all evaluated on the device (no host sync, graph-capturable).
 * GradReducer  - data-parallel gradient all-reduce over RCCL: fixed-size buckets of the arena, each
                  launched as soon as its last gradient is final, overlapping the rest of backward.
-* train_step / DataParallelTrainer - espnet2 Trainer.train_one_epoch semantics for one step.
+* train_step / GraphedDataParallelStep - espnet2 Trainer.train_one_epoch semantics for one step.
 
 reference: espnet2/train/trainer.py:118-322,325-495 (DDP wrap, per-step collectives, clip, finite
 check, optimizer/scheduler step), espnet2/torch_utils/recursive_op.py:14-53, transformer/optimizer.py,
@@ -161,20 +161,36 @@ class GradReducer:
                     self.bucket_of[id(p)] = i
                     break
         self.works = []
+        self.uses = {}
         self.enabled = self.world > 1
 
     def begin(self):
         for b in self.buckets:
             b[2] = b[3]
         self.works = []
+        self.uses = {}      # id(param) -> uses recorded by this step's forward that have not reported from backward yet
 
-    def notify(self, params):
-        """called by block backward functions when these parameters' gradients are final"""
+    def use(self, params):
+        """called by block forward functions (GradSink.use): one more consumer of these parameters"""
         if not self.enabled:
             return
         for p in params:
-            i = self.bucket_of.get(id(p))
+            if p is not None and id(p) in self.bucket_of:
+                self.uses[id(p)] = self.uses.get(id(p), 0) + 1
+
+    def notify(self, params):
+        """called by block backward functions: ONE use of these parameters has accumulated its gradients.  A
+        parameter is final when its last recorded use reports (shared parameters, recurrent cells applied once per
+        time step); a bucket starts its all-reduce when all of its parameters are final."""
+        if not self.enabled:
+            return
+        for p in params:
+            i = self.bucket_of.get(id(p)) if p is not None else None
             if i is None:
+                continue
+            left = self.uses.get(id(p), 1) - 1      # a use nobody recorded (direct GradSink call): treat as the only one
+            self.uses[id(p)] = left
+            if left != 0:
                 continue
             b = self.buckets[i]
             b[2] -= 1
@@ -199,6 +215,7 @@ class GradReducer:
 
 def attach_reducer(reducer):
     F_.GradSink.on_done = reducer.notify if reducer is not None else None
+    F_.GradSink.on_use = reducer.use if reducer is not None else None
     ops.defer_ln_reduce = reducer is None     # overlapped buckets need every block's gradients final when it reports
 
 

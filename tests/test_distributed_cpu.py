@@ -44,6 +44,31 @@ def _worker(rank, world, port, q):
         want = sum(range(1, world + 1)) * (step + 1)
         for p in flat.params:
             assert torch.all(p._eamd_grad == want), (rank, step)
+    # a parameter used several times per step (shared weights, a recurrent cell applied once per time step): its
+    # bucket may only start once EVERY use recorded in forward has reported from backward
+    from espnet_amd.functional import GradSink
+    launched = []
+    orig = red._launch
+    red._launch = lambda b: (launched.append((b[0], b[1])), orig(b))[1]
+    shared = flat.params[-1]
+    flat.zero_grad()
+    red.begin()
+    for p in flat.params:
+        GradSink.use((p,))
+    GradSink.use((shared, None))                     # second consumer of the last-registered parameter
+    for p in reversed(flat.params):                  # every parameter reports once: `shared` still has one use open
+        p._eamd_grad.add_(float(rank + 1))
+        GradSink([p]).results()
+    assert all(hi != flat.numel for _lo, hi in launched), "bucket started before the shared parameter's second use reported"
+    shared._eamd_grad.add_(float(rank + 1))
+    GradSink([shared]).results()
+    assert launched[-1][1] == flat.numel
+    red.finish()
+    tot = sum(range(1, world + 1))
+    for p in flat.params:
+        assert torch.all(p._eamd_grad == (2 * tot if p is shared else tot)), rank
+    assert all(v == 0 for v in red.uses.values())
+    red._launch = orig
     # interleaved sharding of a global minibatch (abs_task.py:1445)
     items = list(range(10))
     assert train.shard_batch(items, rank, world) == items[rank::world]
