@@ -2,6 +2,7 @@
 // 2048 blocks): GLU, Swish, bias broadcasts, axpby, column sums, embedding + positional encoding,
 // weight-layout permutations for the implicit-GEMM convolutions, dropout.
 #include <stdlib.h>
+#include <algorithm>
 #include "common.h"
 #include "../../include/espnet_amd.h"
 
@@ -270,6 +271,37 @@ __global__ void posenc_kernel(const float* __restrict__ x, const float* __restri
     long r = i / D; int d = i % D;
     out[i] = x[i] * scale + pe[(r % T) * D + d];
   }
+}
+
+// ScaledPositionalEncoding (embedding.py:95-128): out = x * scale + alpha[0] * pe[t]; alpha is read on the device.
+__global__ void posenc_scaled_kernel(const float* __restrict__ x, const float* __restrict__ pe,
+                                     const float* __restrict__ alpha, float* __restrict__ out, long rows, int T, int D,
+                                     float scale) {
+  const long n = rows * D;
+  const long stride = (long)gridDim.x * blockDim.x;
+  const float a = alpha[0];
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+    long r = i / D; int d = i % D;
+    out[i] = x[i] * scale + a * pe[(r % T) * D + d];
+  }
+}
+// dalpha += sum_i dout[i] * pe[t(i), d(i)]: per-thread partial sums, wave shuffle, one LDS slot per wave, one atomic
+// per workgroup.
+__global__ __launch_bounds__(256) void posenc_scaled_bwd_kernel(const float* __restrict__ dout, const float* __restrict__ pe,
+                                                                float* __restrict__ dalpha, long rows, int T, int D) {
+  __shared__ float red[4];
+  const long n = rows * D;
+  const long stride = (long)gridDim.x * blockDim.x;
+  float s = 0.f;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+    long r = i / D; int d = i % D;
+    s += dout[i] * pe[(r % T) * D + d];
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) s += __shfl_down(s, o, 64);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+  __syncthreads();
+  if (threadIdx.x == 0) atomicAdd(dalpha, red[0] + red[1] + red[2] + red[3]);
 }
 
 // Generic 4-D permutation copy with optional accumulate: dst[perm(idx)] (+)= src[idx].
@@ -612,6 +644,26 @@ int eamd_posenc(const float* x, const float* pe, float* out, int64_t rows, int T
   if (!x || !pe || !out || rows <= 0 || T <= 0 || D <= 0) return EAMD_EINVAL;
   hipLaunchKernelGGL(posenc_kernel, dim3(grid_for(rows * D)), dim3(256), 0, (hipStream_t)stream, x, pe, out,
                      (long)rows, T, D, scale);
+  EAMD_LAUNCH_CHECK();
+  return EAMD_OK;
+}
+
+int eamd_posenc_scaled(const float* x, const float* pe, const float* alpha, float* out, int64_t rows, int T, int D,
+                       float scale, void* stream) {
+  if (!x || !pe || !alpha || !out || rows <= 0 || T <= 0 || D <= 0) return EAMD_EINVAL;
+  hipLaunchKernelGGL(posenc_scaled_kernel, dim3(grid_for(rows * D)), dim3(256), 0, (hipStream_t)stream, x, pe, alpha,
+                     out, (long)rows, T, D, scale);
+  EAMD_LAUNCH_CHECK();
+  return EAMD_OK;
+}
+
+int eamd_posenc_scaled_bwd(const float* dout, const float* pe, float* dalpha, int64_t rows, int T, int D,
+                           void* stream) {
+  if (!dout || !pe || !dalpha || rows <= 0 || T <= 0 || D <= 0) return EAMD_EINVAL;
+  const long n = (long)rows * D;
+  const int blocks = (int)std::min<long>(512, (n + 256 * 8 - 1) / (256 * 8));
+  hipLaunchKernelGGL(posenc_scaled_bwd_kernel, dim3(std::max(1, blocks)), dim3(256), 0, (hipStream_t)stream, dout, pe,
+                     dalpha, (long)rows, T, D);
   EAMD_LAUNCH_CHECK();
   return EAMD_OK;
 }

@@ -33,6 +33,8 @@ class GradSink:
 
     def buf(self, i):
         p = self.params[i]
+        if p is None:        # bare modules have no LayerNorm in front
+            return None
         g = getattr(p, "_eamd_grad", None)
         if g is not None:
             return g
@@ -74,8 +76,18 @@ def _grad_in(dout, do, p_out, s_out):
     return ops.dropout(do, p_out, s_out, out_dtype=ops.act_dtype()) if p_out > 0.0 else ops.to_act(do)
 
 
+def _ln_fwd_in(x2, ln_w, ln_b, eps, adt):
+    """pre-norm of a block; eps None = bare module (the reference's standalone MultiHeadedAttention /
+    PositionwiseFeedForward / ConvolutionModule forward: no LayerNorm in front, no residual behind)"""
+    if eps is None:
+        return ops.to_act(x2), None, None
+    return ops.layernorm_fwd(x2, ln_w, ln_b, eps, adt)
+
+
 def _ln_bwd_out(dxn, x2, ln_w, mean, rstd, do, gbuf, bbuf, prev, shp):
     """LayerNorm backward of a block + residual; with `prev` = the previous block's (p, salt) also its dropped bf16 copy"""
+    if mean is None:       # bare module: the gradient of the branch input is the block's input gradient
+        return dxn.float().view(shp) if dxn.dtype != torch.float32 else dxn.view(shp)
     if prev is not None and x2.shape[1] in (256, 512):
         dx, dx16 = ops.layernorm_bwd(dxn, x2, ln_w, mean, rstd, do, gbuf, bbuf, drop=prev)
         out = dx.view(shp)
@@ -191,7 +203,8 @@ class FFNBlockFn(torch.autograd.Function):
         adt = ops.act_dtype()
         p_in, s_in, p_out, s_out = drop
         x2 = x.reshape(-1, D).contiguous()
-        xn, mean, rstd = ops.layernorm_fwd(x2, ln_w, ln_b, eps, adt)            # GEMM operand (bf16 in fast mode)
+        xn, mean, rstd = _ln_fwd_in(x2, ln_w, ln_b, eps, adt)                   # GEMM operand (bf16 in fast mode)
+        assert eps is not None or p_out <= 0.0
         fused = ops.fast()      # bf16-operand GEMMs carry the dropout masks in their epilogues
         h = None
         if p_in > 0.0 and fused:
@@ -208,7 +221,7 @@ class FFNBlockFn(torch.autograd.Function):
             br = ops.linear_fwd(src, ops.wshadow(w2), b2, a_act=a_act)
             out = ops.axpby(x2, ops.dropout(br, p_out, s_out), 1.0, scale)
         else:
-            out = ops.linear_fwd(src, ops.wshadow(w2), b2, R=x2, alpha=scale, a_act=a_act)
+            out = ops.linear_fwd(src, ops.wshadow(w2), b2, R=x2 if eps is not None else None, alpha=scale, a_act=a_act)
         ctx.save_for_backward(x2, mean, rstd, xn, z, h)
         ctx.pr = GradSink.use((ln_w, ln_b, w1, b1, w2, b2))
         ctx.cfg = (scale, act, shp, drop)
@@ -487,7 +500,8 @@ class MHABlockFn(torch.autograd.Function):
         dk = D // H
         adt = ops.act_dtype()
         x2 = x.reshape(-1, D).contiguous()
-        xn, mean, rstd = ops.layernorm_fwd(x2, ln_w, ln_b, eps, adt)
+        xn, mean, rstd = _ln_fwd_in(x2, ln_w, ln_b, eps, adt)
+        assert eps is not None or (p_out <= 0.0 and not last_query_only)
         if memory is None:
             kv_in, T2 = xn, T1f
         else:
@@ -497,7 +511,7 @@ class MHABlockFn(torch.autograd.Function):
             res = x2.view(B, T1f, D)[:, -1, :].contiguous()
             T1 = 1
         else:
-            xq, res, T1 = xn, x2, T1f
+            xq, res, T1 = xn, (x2 if eps is not None else None), T1f
         fused = memory is None and not last_query_only and ops.fast() and _qkv_adjacent(wq, wk, wv, bq, bk, bv)
         if fused:
             # q, k, v weights sit back to back in the arenas (FlatParams): one [M, D] x [3D, D]^T projection
@@ -631,7 +645,8 @@ class ConvModuleBlockFn(torch.autograd.Function):
         M = B * T
         adt = ops.act_dtype()
         x2 = x.reshape(M, D).contiguous()
-        xn, mean, rstd = ops.layernorm_fwd(x2, ln_w, ln_b, eps, adt)
+        xn, mean, rstd = _ln_fwd_in(x2, ln_w, ln_b, eps, adt)
+        assert eps is not None or p_out <= 0.0
         a = ops.linear_fwd(xn, ops.wshadow(w1).view(2 * Cc, D), b1)     # pointwise conv 1  [M, 2C] fp32
         gl = ops.glu_fwd(a, Cc)                                          # [M, C]
         d = ops.dwconv_fwd(gl, wd.view(Cc, K), bd_, B, T, Cc, K)         # depthwise conv over time
@@ -648,7 +663,7 @@ class ConvModuleBlockFn(torch.autograd.Function):
             br = ops.linear_fwd(e, ops.wshadow(w2).view(Cc, Cc), b2)
             out = ops.axpby(x2, ops.dropout(br, p_out, s_out), 1.0, 1.0)
         else:
-            out = ops.linear_fwd(e, ops.wshadow(w2).view(Cc, Cc), b2, R=x2)
+            out = ops.linear_fwd(e, ops.wshadow(w2).view(Cc, Cc), b2, R=x2 if eps is not None else None)
         ctx.save_for_backward(x2, mean, rstd, xn, a, gl, d, bmean, brstd, e)
         ctx.pr = GradSink.use(params)
         ctx.cfg = (B, T, D, Cc, K, act, training, drop)
@@ -897,6 +912,29 @@ class PosEncFn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, dout):
         return ops.axpby(dout.contiguous(), None, ctx.scale, 0.0), None, None
+
+
+class ScaledPosEncFn(torch.autograd.Function):
+    """x * scale + alpha * pe[:T]  (ScaledPositionalEncoding, embedding.py:95-128; scale = 1 there)"""
+
+    @staticmethod
+    def forward(ctx, x, pe, alpha, scale):
+        B, T, D = x.shape
+        ctx.save_for_backward(pe)
+        ctx.pr = GradSink.use((alpha,))
+        ctx.cfg = (T, scale)
+        return ops.posenc_scaled(x.reshape(-1, D).contiguous(), pe, alpha.reshape(1), T, scale).view(B, T, D)
+
+    @staticmethod
+    def backward(ctx, dout):
+        (pe,) = ctx.saved_tensors
+        T, scale = ctx.cfg
+        sink = GradSink(ctx.pr)
+        do = dout.contiguous()
+        ops.posenc_scaled_bwd(do.view(-1, do.shape[-1]), pe, sink.buf(0).view(1), T)
+        dx = do if scale == 1.0 else ops.axpby(do, None, scale, 0.0)
+        res = sink.results()
+        return dx, None, res[0], None
 
 
 # =================================================================================================

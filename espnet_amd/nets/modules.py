@@ -177,6 +177,24 @@ class PositionalEncoding(torch.nn.Module):
         return F_.dropout(F_.PosEncFn.apply(x, self.pe, self.xscale), self.dropout_rate, self.salt, self.training)
 
 
+class ScaledPositionalEncoding(PositionalEncoding):
+    """reference: transformer/embedding.py:95-128: x + alpha * pe[:T] with a learnable scalar alpha (state_dict key
+    `...alpha`); the input is NOT multiplied by sqrt(d) - xscale is 1 here, which is also what the subsampling
+    Linear's epilogue applies when this class sits behind it."""
+
+    def __init__(self, d_model, dropout_rate, max_len=5000):
+        super().__init__(d_model, dropout_rate, max_len)
+        self.xscale = 1.0
+        self.alpha = torch.nn.Parameter(torch.tensor(1.0))
+
+    def reset_parameters(self):
+        self.alpha.data = torch.tensor(1.0, device=self.alpha.device)
+
+    def forward(self, x):
+        self.extend_pe(x.size(1), x.device)
+        return F_.dropout(F_.ScaledPosEncFn.apply(x, self.pe, self.alpha, 1.0), self.dropout_rate, self.salt, self.training)
+
+
 class RelPositionalEncoding(PositionalEncoding):
     """reference: transformer/embedding.py:131-161 (legacy: reversed table of max_len, first T rows)."""
 
@@ -219,7 +237,10 @@ class Conv2dSubsampling(torch.nn.Module):
                  F_.dropout(pe, pos.dropout_rate, pos.salt2, pos.training))
         else:
             pos.extend_pe(y.size(1), y.device)
-            y = F_.PosEncFn.apply(y, pos.pe, 1.0)   # x*xscale already applied in the Linear epilogue
+            if isinstance(pos, ScaledPositionalEncoding):
+                y = F_.ScaledPosEncFn.apply(y, pos.pe, pos.alpha, 1.0)
+            else:
+                y = F_.PosEncFn.apply(y, pos.pe, 1.0)   # x*xscale already applied in the Linear epilogue
             y = F_.dropout(y, pos.dropout_rate, pos.salt, pos.training)
         if x_mask is None:
             return y, None
@@ -290,6 +311,23 @@ class MultiHeadedAttention(torch.nn.Module):
         return (self.linear_q.weight, self.linear_q.bias, self.linear_k.weight, self.linear_k.bias,
                 self.linear_v.weight, self.linear_v.bias, self.linear_out.weight, self.linear_out.bias)
 
+    def _bare(self, query, key, value, pos_emb, mask):
+        """the module on its own (attention.py:94-114 / :164-206): same kernels as the fused block, without the
+        LayerNorm in front and the residual behind (eps = None)"""
+        assert key is value or (key.shape == value.shape and key.data_ptr() == value.data_ptr()), \
+            "key and value must be the same tensor (as at every call site of the reference)"
+        memory = None if (key is query or key.data_ptr() == query.data_ptr()) else key.contiguous()
+        drop = (_p(self, self.dropout_rate), self.salt_attn, 0.0, self.salt_out)
+        n_tap = len(F_.ATTN_TAP) if F_.ATTN_TAP is not None else 0
+        out = F_.MHABlockFn.apply(query.contiguous(), memory, pos_emb, _mask_u8(mask, query.device), self.h, None,
+                                  False, drop, None, None, *self.block_params())
+        if F_.ATTN_TAP is not None and len(F_.ATTN_TAP) > n_tap:
+            self.attn = F_.ATTN_TAP[-1]
+        return out
+
+    def forward(self, query, key, value, mask):
+        return self._bare(query, key, value, None, mask)
+
 
 class RelPositionMultiHeadedAttention(MultiHeadedAttention):
     """reference: transformer/attention.py:117-206 (legacy rel_shift, zero_triu=False)"""
@@ -304,6 +342,9 @@ class RelPositionMultiHeadedAttention(MultiHeadedAttention):
 
     def block_params(self):
         return super().block_params() + (self.linear_pos.weight, self.pos_bias_u, self.pos_bias_v)
+
+    def forward(self, query, key, value, pos_emb, mask):
+        return self._bare(query, key, value, pos_emb, mask)
 
 
 def mha_block(norm, attn, x, memory, pos_emb, mask, last_query_only=False, p_out=0.0):
@@ -328,6 +369,12 @@ class PositionwiseFeedForward(torch.nn.Module):
         self.activation = activation if activation is not None else torch.nn.ReLU()
         self.act_id = _act_id(self.activation)
         self.salt_in, self.salt_out = ops.new_salt(), ops.new_salt()
+
+    def forward(self, x):
+        """the module on its own (positionwise_feed_forward.py:30-32): no LayerNorm in front, no residual behind"""
+        drop = (_p(self, self.dropout_rate), self.salt_in, 0.0, self.salt_out)
+        return F_.FFNBlockFn.apply(x.contiguous(), None, None, self.w_1.weight, self.w_1.bias, self.w_2.weight,
+                                   self.w_2.bias, 1.0, self.act_id, None, drop)
 
 
 class MultiLayeredConv1d(torch.nn.Module):
@@ -391,6 +438,18 @@ class ConvolutionModule(torch.nn.Module):
         self.act_id = _act_id(self.activation)
         self.salt_out = ops.new_salt()
         assert bias, "bias=False variant is not on the path"
+
+    def forward(self, x):
+        """the module on its own (convolution.py:53-79): no LayerNorm in front, no residual behind"""
+        bn = self.norm
+        if self.training:
+            with torch.no_grad():
+                bn.num_batches_tracked += 1
+        return F_.ConvModuleBlockFn.apply(
+            x.contiguous(), bn.running_mean, bn.running_var, self.training, self.act_id, None, bn.eps, bn.momentum,
+            (0.0, self.salt_out), None, None, self.pointwise_conv1.weight, self.pointwise_conv1.bias,
+            self.depthwise_conv.weight, self.depthwise_conv.bias, bn.weight, bn.bias, self.pointwise_conv2.weight,
+            self.pointwise_conv2.bias)
 
 
 def conv_block(norm, cm, x, p_out=0.0):
@@ -535,6 +594,8 @@ class ConformerEncoder(torch.nn.Module):
         super().__init__()
         if pos_enc_layer_type == "abs_pos":
             pos_enc_class = PositionalEncoding
+        elif pos_enc_layer_type == "scaled_abs_pos":       # conformer/encoder.py:98-99
+            pos_enc_class = ScaledPositionalEncoding
         elif pos_enc_layer_type == "rel_pos":
             assert selfattention_layer_type == "rel_selfattn"
             pos_enc_class = RelPositionalEncoding

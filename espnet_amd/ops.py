@@ -570,6 +570,21 @@ def posenc(x, pe, T, scale):
     return out
 
 
+def posenc_scaled(x, pe, alpha, T, scale=1.0):
+    rows, D = x.shape
+    assert pe.shape[0] >= T and pe.shape[1] == D and alpha.numel() == 1
+    out = torch.empty_like(x)
+    check(_lib.lib().eamd_posenc_scaled(ptr(x), ptr(pe), ptr(alpha), ptr(out), C.c_int64(rows), T, D, C.c_float(scale),
+                                        stream_ptr()), "eamd_posenc_scaled")
+    return out
+
+
+def posenc_scaled_bwd(dout, pe, dalpha, T):
+    rows, D = dout.shape
+    check(_lib.lib().eamd_posenc_scaled_bwd(ptr(dout), ptr(pe), ptr(dalpha), C.c_int64(rows), T, D, stream_ptr()),
+          "eamd_posenc_scaled_bwd")
+
+
 _rng = {"step": None, "salt": 0}
 
 

@@ -217,6 +217,13 @@ int eamd_embed_bwd(const int64_t* tok, const float* dout, float* dtable, int64_t
                    int64_t pad_idx, void* stream);
 int eamd_posenc(const float* x, const float* pe, float* out, int64_t rows, int T, int D, float scale,
                 void* stream);
+/* ScaledPositionalEncoding (transformer/embedding.py:95-128): out = x * scale + alpha[0] * pe[t] with the learnable
+ * scalar alpha read on the device (no host sync); the backward entry accumulates dalpha += sum(dout * pe[t]) (dx is
+ * dout * scale, an eamd_axpby). */
+int eamd_posenc_scaled(const float* x, const float* pe, const float* alpha, float* out, int64_t rows, int T, int D,
+                       float scale, void* stream);
+int eamd_posenc_scaled_bwd(const float* dout, const float* pe, float* dalpha, int64_t rows, int T, int D,
+                           void* stream);
 int eamd_permute4(const float* src, float* dst, int d0, int d1, int d2, int d3, int64_t s0, int64_t s1,
                   int64_t s2, int64_t s3, int accumulate, void* stream);
 /* y = act(x) * keep / (1-p), keep(i) = hash(step_dev[0], salt, i) >= p; the same call on a gradient applies the

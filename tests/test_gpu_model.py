@@ -250,6 +250,295 @@ def test_midsize_vs_oracle(oracle):
         assert ids[b, : int(n[b])].tolist() == oracle.greedy_ctc(lg[b, : hl[b]])
 
 
+def test_config2_fullsize_vs_oracle(oracle):
+    """BASELINE config 2 at FULL size (12-layer Conformer d=256 h=4 ff=2048 k=31, 6-layer decoder, V=5000, B=32, T=1000,
+    L=100; ragged: ilens = linspace(T, 0.6T), label lengths linspace(L, 0.5L); dropout 0) - exactly the
+    kernels and shapes bench.py times - against the CPU oracle on the same weights and batch:
+      * fp32 mode: total / CTC / attention loss rel <= 1e-5 (bar 1e-3), accuracy equal, min gradient cosine >= 0.9999,
+        greedy-CTC argmax bit-exact on every frame whose oracle top-2 logit gap exceeds fp32 accumulation noise
+        (1e-4 of the logit scale), collapsed ids bit-exact for every utterance without such a near-tie frame;
+      * bf16 mode (the fused attention / persistent GEMM dispatch): the three losses rel <= 1e-3, min gradient
+        cosine >= 0.999."""
+    import espnet_amd
+    import bench
+    from espnet_amd import train
+    from espnet_amd.nets.e2e_asr_conformer import E2E
+    from espnet_amd.nets.modules import subsampled_lengths
+    B, T, L, V = 32, 1000, 100, 5000
+    torch.manual_seed(0)
+    model = E2E(80, V, bench.c2_args(0.0))
+    sd = {k: v.clone() for k, v in model.state_dict().items()}
+    g = torch.Generator().manual_seed(1)
+    xs = torch.randn(B, T, 80, generator=g)
+    ilens = [int(round(v)) for v in torch.linspace(T, 0.6 * T, B).tolist()]
+    ys = torch.randint(1, V - 1, (B, L), generator=g)
+    for b, n in enumerate(int(round(v)) for v in torch.linspace(L, 0.5 * L, B).tolist()):
+        ys[b, n:] = -1
+    cfg = dict(conformer=True, rel_pos=True, activation="swish", aheads=4, mtlalpha=0.3, lsm_weight=0.1, odim=V)
+    torch.set_num_threads(min(64, len(__import__("os").sched_getaffinity(0))))
+    # ---- oracle: eval-mode CTC logits (greedy), then one training-mode forward + backward ----
+    with torch.no_grad():
+        hs_e, _ = oracle.encoder(sd, "encoder.", xs, oracle.non_pad_mask(ilens).unsqueeze(-2), cfg, training=False)
+        lg = oracle.linear(sd, "ctc.ctc_lo.", hs_e)                                  # (B, T', V)
+    sdr = {k: (v.clone().requires_grad_(True) if v.is_floating_point() and "running" not in k else v.clone())
+           for k, v in sd.items()}
+    ref = oracle.e2e_forward(sdr, xs, ilens, ys, cfg, training=True)
+    ref["loss"].backward()
+    ref_l = {k: float(ref[k]) for k in ("loss", "loss_ctc", "loss_att")}
+    # ---- HIP ----
+    model = model.to(DEV)
+    flat = train.FlatParams(model)
+    flat.expose_grads()
+    hl = subsampled_lengths(ilens, T)
+    model.eval()
+    with torch.no_grad():
+        hs, _ = model.encoder(xs.to(DEV), oracle.non_pad_mask(ilens).unsqueeze(-2))
+        am = model.ctc.argmax(hs).cpu()
+        ids, n = model.greedy_ctc_batch(xs.to(DEV), ilens)
+    top2 = lg.topk(2, dim=-1)
+    gap = (top2.values[..., 0] - top2.values[..., 1]) / lg.abs().amax(dim=-1).clamp_min(1e-20)
+    near_tie, frames, mism = 0, 0, 0
+    for b in range(B):
+        clear = gap[b, : hl[b]] > 1e-4
+        frames += int(hl[b])
+        near_tie += int((~clear).sum())
+        same = am[b, : hl[b]] == top2.indices[b, : hl[b], 0]
+        mism += int((~same).sum())
+        assert bool(same[clear].all()), "greedy CTC argmax differs on a frame without a near-tie (utt %d)" % b
+        if bool(clear.all()):
+            assert ids[b, : int(n[b])].tolist() == oracle.greedy_ctc(lg[b, : hl[b]]), b
+    print(f"[parity] config2 full size: greedy argmax equal on {frames - mism}/{frames} frames ({near_tie} near-tie frames)")
+    model.train()
+    for prec, ltol, ctol in (("fp32", 1e-5, 0.9999), ("bf16", 1e-3, 0.999)):
+        espnet_amd.set_precision(prec)
+        flat.refresh_shadow()
+        flat.zero_grad()
+        loss = model(xs.to(DEV), ilens, ys.to(DEV))
+        loss.backward()
+        got = dict(loss=float(loss), loss_ctc=float(model._loss_ctc_t), loss_att=float(model._loss_att_t))
+        for k in ("loss", "loss_ctc", "loss_att"):
+            rel = abs(got[k] - ref_l[k]) / abs(ref_l[k])
+            print(f"[parity] config2 full size [{prec}] {k}: hip={got[k]:.6f} oracle={ref_l[k]:.6f} rel={rel:.2e}")
+            assert rel <= ltol, (prec, k, rel)
+        if prec == "fp32":
+            assert abs(model.acc - float(ref["acc"])) < 1e-6
+        cos = []
+        for k, q in model.named_parameters():
+            gr = sdr[k].grad
+            if gr is None or float(gr.norm()) < 1e-6:
+                continue
+            if k.endswith("conv_module.depthwise_conv.bias"):
+                # a bias in front of training-mode BatchNorm: its gradient is zero mathematically, rounding noise in
+                # both implementations - only its size can be compared
+                wn = float(sdr[k.replace(".bias", ".weight")].grad.norm())
+                assert float(q.grad.norm()) <= 1e-3 * wn and float(gr.norm()) <= 1e-3 * wn, k
+                continue
+            cos.append((float(torch.nn.functional.cosine_similarity(q.grad.flatten().double().cpu(), gr.flatten().double(), dim=0)), k))
+        print(f"[parity] config2 full size [{prec}] min gradient cosine {min(cos)[0]:.6f} ({min(cos)[1]}) over {len(cos)} tensors")
+        assert min(cos)[0] >= ctol, min(cos)
+    espnet_amd.set_precision("fp32")
+
+
+# ---- round 2: reference vectors at the width whose kernels bench.py dispatches (d = 256, h = 4, d_k = 64) ----------
+def _seeded(module, salt):
+    from conftest import seeded_weights
+    return seeded_weights().fill_parameters(module, salt=salt).to(DEV)
+
+
+def _check_seeded(module, fixture, tol, prefix="", loose=()):
+    from conftest import seeded_weights
+    SW = seeded_weights()
+    fx = {(k.replace("/", "/" + "", 1)): v for k, v in fixture.items()}
+    if prefix:
+        fx = {k[len(prefix):]: v for k, v in fixture.items() if k.startswith(prefix)}
+    worst, bad = 0.0, []
+    names = [k for k, _ in module.named_parameters() if any(t + k in fx for t in ("grad/", "gprobe_r/"))]
+    top = max(SW.ref_norm(k, fx) for k in names)
+    for k, q in module.named_parameters():
+        if k not in names:
+            continue
+        assert q.grad is not None, k
+        if SW.ref_norm(k, fx) < 1e-5 * top:
+            # mathematically zero in the reference (e.g. linear_k.bias: the softmax is invariant to a key bias), its
+            # recorded value is rounding noise - only the size can be compared
+            assert float(q.grad.norm()) <= 2e-3 * top, (k, float(q.grad.norm()), top)
+            continue
+        kind, e = SW.grad_check(k, q.grad, fx)
+        worst = max(worst, e)
+        if e > 0.5 * tol:
+            print(f"[parity]   {k} ({kind}): {e:.3e}")
+        lim = max([tol] + [t for frag, t in loose if frag in k])
+        bad = bad + [(k, kind, e)] if e > lim else bad
+    assert not bad, bad
+    print(f"[parity] {type(module).__name__} worst param-grad err vs reference {worst:.3e} (tol {tol:g})")
+
+
+DK64_TOL = {"fp32": dict(y=5e-5, g=3e-4), "bf16": dict(y=1e-2, g=3e-2)}
+
+
+@pytest.mark.parametrize("flat", [False, True])
+@pytest.mark.parametrize("prec", ["fp32", "bf16"])
+def test_rel_mha_dk64_golden(prec, flat):
+    """RelPositionMultiHeadedAttention(4, 256) on its own against the reference's output / gradients at T = 249 with a
+    ragged and a fully masked utterance.  bf16 mode runs eamd_attn_fwd / eamd_attn_bwd_q (the kernels of the bench);
+    flat=True places q/k/v back to back (FlatParams) so the fused [3D, D] projection path of the model runs."""
+    import espnet_amd
+    from espnet_amd import train
+    from espnet_amd import functional as F_
+    from espnet_amd.nets import modules as M
+    g = load_golden("rel_mha_dk64.npz")
+    att = _seeded(M.RelPositionMultiHeadedAttention(4, 256, 0.0), 71)
+    att.train()
+    if flat:
+        train.FlatParams(att).expose_grads()
+    espnet_amd.set_precision(prec)
+    tol = DK64_TOL[prec]
+    x = torch.from_numpy(g["x"]).to(DEV).requires_grad_(True)
+    F_.ATTN_TAP = []
+    try:
+        y = att(x, x, x, torch.from_numpy(g["pos"]).to(DEV), torch.from_numpy(g["mask"]))
+        attn = att.attn
+    finally:
+        F_.ATTN_TAP = None
+    report("rel_mha_dk64[%s] y" % prec, y, torch.from_numpy(g["y"]), tol["y"])
+    report("rel_mha_dk64[%s] attn rows" % prec, attn[:, :, ::31, :], torch.from_numpy(g["attn_sample"]), tol["y"])
+    assert bool((attn[2] == 0).all())                      # fully masked utterance: attention.py:84-88
+    y.backward(torch.from_numpy(g["gy"]).to(DEV))
+    report("rel_mha_dk64[%s] dx" % prec, x.grad, torch.from_numpy(g["gx"]), tol["g"])
+    _check_seeded(att, g, tol["g"])
+
+
+@pytest.mark.parametrize("prec", ["fp32", "bf16"])
+def test_mha_dk64_golden(prec):
+    """MultiHeadedAttention(4, 256): source attention 101 x 249 over a ragged memory and causal self-attention (T = 101)
+    against the reference; bf16 mode = the fused kernels without relative positions"""
+    import espnet_amd
+    from espnet_amd.nets import modules as M
+    g = load_golden("mha_dk64.npz")
+    att = _seeded(M.MultiHeadedAttention(4, 256, 0.0), 61)
+    att.train()
+    espnet_amd.set_precision(prec)
+    tol = DK64_TOL[prec]
+    q = torch.from_numpy(g["q"]).to(DEV).requires_grad_(True)
+    mem = torch.from_numpy(g["mem"]).to(DEV).requires_grad_(True)
+    y = att(q, mem, mem, torch.from_numpy(g["mmask"]))
+    report("mha_dk64[%s] y" % prec, y, torch.from_numpy(g["y"]), tol["y"])
+    y.backward(torch.from_numpy(g["gy"]).to(DEV))
+    report("mha_dk64[%s] dq" % prec, q.grad, torch.from_numpy(g["gq"]), tol["g"])
+    report("mha_dk64[%s] dmem" % prec, mem.grad, torch.from_numpy(g["gmem"]), tol["g"])
+    _check_seeded(att, g, tol["g"])
+    att.zero_grad()
+    q2 = torch.from_numpy(g["q"]).to(DEV).requires_grad_(True)
+    y2 = att(q2, q2, q2, torch.from_numpy(g["cmask"]))
+    report("mha_dk64[%s] causal y" % prec, y2, torch.from_numpy(g["y_self"]), tol["y"])
+    y2.backward(torch.from_numpy(g["gy"]).to(DEV))
+    report("mha_dk64[%s] causal dq" % prec, q2.grad, torch.from_numpy(g["gq_self"]), tol["g"])
+    _check_seeded(att, g, tol["g"], prefix="self_")
+
+
+@pytest.mark.parametrize("prec", ["fp32", "bf16"])
+def test_e2e_conformer_dk64_golden(prec):
+    """espnet1 Conformer E2E at adim 256 / aheads 4 against the reference: loss, CTC loss, accuracy, encoder output,
+    every parameter gradient, greedy ids.  In bf16 mode this is the dispatch of the bench (FlatParams, fused q/k/v
+    projection, eamd_attn_fwd / eamd_attn_bwd_q, LayerNorm-backward gradient dropout fusion at D = 256)."""
+    import espnet_amd
+    from espnet_amd import ops, train
+    from conftest import e2e_dk64_model
+    g = load_golden("e2e_conformer_dk64.npz")
+    model, _cfg = e2e_dk64_model()
+    model = model.to(DEV).train()
+    flat = train.FlatParams(model)
+    flat.expose_grads()
+    espnet_amd.set_precision(prec)
+    assert prec == "fp32" or ops.attn_fwd_supported(74, 74, 64, True)
+    xs, ilens, ys = torch.from_numpy(g["xs"]).to(DEV), torch.from_numpy(g["ilens"]), torch.from_numpy(g["ys"]).to(DEV)
+    loss = model(xs, ilens, ys)
+    loss.backward()
+    ref = float(g["loss"])
+    rel = abs(float(loss) - ref) / abs(ref)
+    relc = abs(float(model.ctc.loss) - float(g["loss_ctc"])) / abs(float(g["loss_ctc"]))
+    print(f"[parity] e2e_conformer_dk64[{prec}] loss hip={float(loss):.6f} ref={ref:.6f} rel={rel:.2e}; ctc rel={relc:.2e}; "
+          f"acc hip={model.acc} ref={float(g['acc'])}")
+    assert rel < (1e-5 if prec == "fp32" else 1e-3) and relc < (1e-5 if prec == "fp32" else 1e-3)
+    report("e2e_conformer_dk64[%s] hs_pad" % prec, model.hs_pad, torch.from_numpy(g["hs_pad"]), 1e-4 if prec == "fp32" else 2e-2)
+    if prec == "fp32":
+        assert abs(model.acc - float(g["acc"])) < 1e-6
+    # bf16 + ReLU (decoder FFN): operand rounding flips the sign of pre-activations within ~0.3 % of zero, i.e. the
+    # gradient mask of ~0.25 % of the hidden units, each a full-size error in dz: sqrt(0.0025 / 0.5) = 7 % relative
+    # on dz and what is reduced from it over only 39 token rows (w_1, its bias, the norm in front); Swish is smooth.
+    _check_seeded(model, g, 1e-3 if prec == "fp32" else 5e-2,
+                  loose=() if prec == "fp32" else (("decoders.0.feed_forward.w_1", 0.2), ("decoders.0.norm3", 0.1)))
+    if prec == "fp32":      # greedy CTC ids, bit-exact, every utterance at its own length
+        model.eval()
+        ra = argparse.Namespace(ctc_weight=1.0, beam_size=1)
+        off = 0
+        for b, n in enumerate(g["greedy_lens"].tolist()):
+            hyp = model.recognize(g["xs"][b, : int(g["ilens"][b])], ra)
+            assert hyp[0]["yseq"][1:] == g["greedy"][off:off + n].tolist(), b
+            off += n
+
+
+def test_edge_fixtures_on_hip():
+    """the standalone-module fixtures of rows a6 / a8 / a9 / a4 on the HIP path (they used to be consumed by the CPU
+    oracle tests only): mha.npz (source attention, causal self-attention with a fully masked QUERY row), rel_mha.npz,
+    ffn_{swish,relu}.npz, conv_module.npz (training step, running statistics, eval-mode BatchNorm), scaled_posenc.npz"""
+    from espnet_amd.nets import modules as M
+    p, sd, grads = split_golden(load_golden("mha.npz"))
+    att = load_sd(M.MultiHeadedAttention(4, 64, 0.0), sd).train()
+    q, mem = p["q"].to(DEV).requires_grad_(True), p["mem"].to(DEV).requires_grad_(True)
+    y = att(q, mem, mem, p["mmask"])
+    report("mha.npz y", y, p["y"], 2e-5)
+    y.backward(p["gy"].to(DEV))
+    report("mha.npz dq", q.grad, p["gq"], 1e-4)
+    report("mha.npz dmem", mem.grad, p["gmem"], 1e-4)
+    check_grads(att, grads)
+    with torch.no_grad():
+        qd = p["q"].to(DEV)
+        report("mha.npz self, fully masked row", att(qd, qd, qd, p["cmask"]), p["y_self"], 2e-5)
+    p, sd, grads = split_golden(load_golden("rel_mha.npz"))
+    att = load_sd(M.RelPositionMultiHeadedAttention(4, 64, 0.0), sd).train()
+    x = p["x"].to(DEV).requires_grad_(True)
+    y = att(x, x, x, p["pos"].to(DEV), p["mask"])
+    report("rel_mha.npz y", y, p["y"], 2e-5)
+    y.backward(p["gy"].to(DEV))
+    report("rel_mha.npz dx", x.grad, p["gx"], 1e-4)
+    check_grads(att, grads)
+    for name, actm in (("swish", M.Swish()), ("relu", torch.nn.ReLU())):
+        p, sd, grads = split_golden(load_golden("ffn_%s.npz" % name))
+        ff = load_sd(M.PositionwiseFeedForward(64, 96, 0.0, actm), sd).train()
+        x = p["x"].to(DEV).requires_grad_(True)
+        y = ff(x)
+        report("ffn_%s.npz y" % name, y, p["y"], 2e-5)
+        y.backward(p["gy"].to(DEV))
+        report("ffn_%s.npz dx" % name, x.grad, p["gx"], 1e-4)
+        check_grads(ff, grads)
+    p, sd, grads = split_golden(load_golden("conv_module.npz"))
+    cm = load_sd(M.ConvolutionModule(64, 7, M.Swish()), sd).train()
+    x = p["x"].to(DEV).requires_grad_(True)
+    y = cm(x)
+    report("conv_module.npz y (train)", y, p["y"], 2e-5)
+    y.backward(p["gy"].to(DEV))
+    report("conv_module.npz dx", x.grad, p["gx"], 1e-4)
+    check_grads(cm, grads)
+    for k, v in cm.state_dict().items():
+        if "running" in k:
+            report("conv_module.npz " + k, v, p["sd_after/" + k], 1e-5)
+    cm.eval()
+    with torch.no_grad():
+        report("conv_module.npz y (eval BatchNorm)", cm(p["x"].to(DEV)), p["y_eval"], 2e-5)
+    g = load_golden("scaled_posenc.npz")
+    pe = M.ScaledPositionalEncoding(64, 0.0).to(DEV)
+    with torch.no_grad():
+        pe.alpha.fill_(float(g["alpha"]))
+    x = torch.from_numpy(g["x"]).to(DEV).requires_grad_(True)
+    y = pe(x)
+    report("scaled_posenc y", y, torch.from_numpy(g["y"]), 2e-6)
+    y.backward(torch.from_numpy(g["gy"]).to(DEV))
+    report("scaled_posenc dx", x.grad, torch.from_numpy(g["gx"]), 1e-6)
+    report("scaled_posenc dalpha", pe.alpha.grad, torch.from_numpy(g["galpha"]), 1e-5)
+    assert "alpha" in pe.state_dict() and list(pe.state_dict()) == ["alpha"]
+
+
 @pytest.mark.parametrize("name,kind,extra", CASES)
 def test_beam_search_golden(name, kind, extra):
     """Joint CTC/attention beam search (decoder batch_score + CTC prefix-score kernel) against the

@@ -824,6 +824,91 @@ def test_attention_backward_fused_matches_unfused(ops, case):
         espnet_amd.set_precision("fp32")
 
 
+def _oracle_attention(oracle, qu, qv, k, v, p, mask, dctx, B, T1, T2, H, dk):
+    """float64 restatement of the reference's attention core on the SAME bf16-rounded operands, built from the
+    oracle's pieces: scores (+ oracle.rel_shift of the position term, attention.py:141-162,195-203), the mask ->
+    finfo.min -> softmax -> zero-fill sequence of forward_attention (attention.py:63-92) and its autograd gradients."""
+    f64 = lambda t, T: t.detach().cpu().double().view(-1, T, H, dk).requires_grad_(True)
+    Q, K, V = f64(qu, T1), f64(k, T2), f64(v, T2)
+    QV = f64(qv, T1) if qv is not None else None
+    Pm = p.detach().cpu().double().view(1, T2, H, dk).requires_grad_(True) if p is not None else None
+    sc = torch.einsum("bihd,bjhd->bhij", Q, K)
+    if p is not None:
+        sc = sc + oracle.rel_shift(torch.einsum("bihd,xjhd->bhij", QV, Pm))
+    sc = sc / math.sqrt(dk)
+    if mask is not None:
+        m = mask.cpu().bool().unsqueeze(1).eq(0)                     # (B, 1, 1|T1, T2)
+        attn = torch.softmax(sc.masked_fill(m, torch.finfo(torch.float32).min), dim=-1).masked_fill(m, 0.0)
+    else:
+        attn = torch.softmax(sc, dim=-1)
+    ctx = torch.einsum("bhij,bjhd->bihd", attn, V).reshape(B * T1, H * dk)
+    ctx.backward(dctx.detach().cpu().double())
+    g = lambda t: None if t is None else t.grad
+    return attn.detach(), ctx.detach(), g(Q), g(QV), g(K), g(V), g(Pm)
+
+
+@pytest.mark.parametrize("case", [
+    dict(B=3, T1=249, T2=249, rel=True, mask="len"), dict(B=2, T1=101, T2=101, rel=False, mask="causal"),
+    dict(B=2, T1=101, T2=249, rel=False, mask="len"), dict(B=2, T1=1, T2=77, rel=False, mask="len"),
+    dict(B=3, T1=64, T2=64, rel=True, mask="dead"), dict(B=2, T1=30, T2=30, rel=True, mask=None),
+    dict(B=2, T1=64, T2=16, rel=False, mask="dead")])
+def test_attention_fused_vs_oracle(ops, oracle, case):
+    """The kernels bench.py dispatches at config 2 (eamd_attn_fwd / eamd_attn_bwd_q: H = 4, d_k = 64, T2 <= 256)
+    against the ORACLE in float64 on the same bf16 operands - not against our own unfused path: probabilities,
+    context and every gradient (dq+u, dq+v, dk, dv, dpos), ragged key lengths, a causal mask, a single query and a
+    fully masked utterance (reference: zeros, attention.py:84-88).  Error budget: P and dS are rounded to bf16
+    inside the kernels (2^-9 relative), so rel-L2 <= 4e-3 on P / ctx and <= 8e-3 on the gradients."""
+    import espnet_amd
+    from espnet_amd import functional as F_
+    espnet_amd.set_precision("bf16")
+    try:
+        B, T1, T2, rel, mk = case["B"], case["T1"], case["T2"], case["rel"], case["mask"]
+        H, dk = 4, 64
+        D = H * dk
+        g = torch.Generator().manual_seed(T1 * 11 + T2)
+        bf = lambda *s: (0.5 * torch.randn(*s, generator=g)).to(torch.bfloat16).to(DEV)
+        qu, k, v = bf(B * T1, D), bf(B * T2, D), bf(B * T2, D)
+        qv = bf(B * T1, D) if rel else None
+        p = bf(T2, D) if rel else None
+        mask = None
+        if mk == "len":
+            lens = torch.linspace(T2, max(1, T2 // 2), B).long()
+            mask = (torch.arange(T2)[None, :] < lens[:, None]).to(torch.uint8).view(B, 1, T2).contiguous().to(DEV)
+        elif mk == "causal":
+            mask = torch.tril(torch.ones(T1, T2)).to(torch.uint8).expand(B, T1, T2).contiguous().to(DEV)
+        elif mk == "dead":
+            mask = torch.ones(B, 1, T2, dtype=torch.uint8)
+            mask[1] = 0
+            mask[0, 0, T2 // 2:] = 0
+            mask = mask.to(DEV)
+        assert ops.attn_fwd_supported(T1, T2, dk, rel)
+        fused = F_.attn_fwd_fused(qu, qv, k, v, p, mask, B, T1, T2, H, dk)
+        assert fused is not None, "eamd_attn_fwd declined the config-2 operand layout"
+        P1, c1 = fused
+        dctx = bf(B * T1, D)
+        F_.FUSE_ATTN = True
+        dqu, dqv, dkk, dvv, dpos = F_.attn_core_bwd(dctx, P1, qu, qv, k, v, p, B, T1, T2, H, dk)
+        attn, ctx, gq, gqv, gk, gv, gp = _oracle_attention(oracle, qu, qv, k, v, p, mask, dctx, B, T1, T2, H, dk)
+        ldp = F_._ldp(T2)
+        Pv = P1.view(H, B, T1, ldp).float().permute(1, 0, 2, 3)
+        report("attn_fwd P vs oracle %s" % (case,), Pv[..., :T2], attn, 4e-3)
+        assert bool((Pv[..., T2:] == 0).all())
+        report("attn_fwd ctx vs oracle %s" % (case,), c1.float(), ctx, 4e-3)
+        if mk == "dead":
+            assert bool((Pv[1] == 0).all()) and bool((c1.view(B, T1, D)[1] == 0).all())
+            assert bool((Pv[0, ..., T2 // 2:] == 0).all())
+        r2 = lambda t, T: t.reshape(B * T, D)
+        report("attn_bwd dq(u) vs oracle %s" % (case,), dqu.float(), r2(gq, T1), 8e-3)
+        report("attn_bwd dk vs oracle %s" % (case,), dkk.float(), r2(gk, T2), 8e-3)
+        report("attn_bwd dv vs oracle %s" % (case,), dvv.float(), r2(gv, T2), 8e-3)
+        if rel:
+            report("attn_bwd dq(v) vs oracle %s" % (case,), dqv.float(), r2(gqv, T1), 8e-3)
+            report("attn_bwd dpos vs oracle %s" % (case,), dpos.float().view(T2, D), gp.reshape(T2, D), 8e-3)
+    finally:
+        F_.FUSE_ATTN = True
+        espnet_amd.set_precision("fp32")
+
+
 @pytest.mark.parametrize("shape", [(7968, 256, 768), (333, 64, 64), (70, 320, 320), (5, 512, 1024)])
 def test_add_cast_colsum2(ops, shape):
     """one pass: out = bf16(a + b) into a column block, both column sums accumulated"""

@@ -394,3 +394,89 @@ def test_frontend(oracle):
                dict(sr=8000, n_fft=256, n_mels=23, fmin=80, fmax=3800)):
         a, b = oracle.mel_filterbank(**kw), mel_filterbank(**kw)
         assert np.abs(a - b).max() < 1e-7 * np.abs(a).max() + 1e-9
+
+
+# ---- round 2: the width at which bf16 mode dispatches the fused attention kernels (d = 256, h = 4, d_k = 64) ----
+def _seeded_sd(shapes, salt, oracle_dir=None):
+    import os, sys
+    from conftest import ROOT
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import seeded_weights as SW
+    return SW, {k: SW.seeded_value(k, shp, salt).requires_grad_(True) for k, shp in shapes.items()}
+
+
+def _mha_shapes(d, rel):
+    sh = {}
+    for n in ("q", "k", "v", "out"):
+        sh["linear_%s.weight" % n] = (d, d)
+        sh["linear_%s.bias" % n] = (d,)
+    if rel:
+        sh["linear_pos.weight"] = (d, d)
+        sh["pos_bias_u"] = (4, d // 4)
+        sh["pos_bias_v"] = (4, d // 4)
+    return sh
+
+
+def _check_seeded_grads(SW, sd, fixture, tol, prefix=""):
+    worst = 0.0
+    for k, v in sd.items():
+        if not (torch.is_tensor(v) and v.requires_grad):
+            continue
+        fx = {kk[len(prefix):] if prefix and kk.startswith(prefix) else kk: vv for kk, vv in fixture.items()} if prefix else fixture
+        if not any(t + k in fx for t in ("grad/", "gprobe_r/")):
+            continue
+        assert v.grad is not None, k
+        kind, e = SW.grad_check(k, v.grad, fx)
+        worst = max(worst, e)
+        assert e <= tol, (k, kind, e)
+    return worst
+
+
+def test_rel_mha_dk64(oracle):
+    g = load_golden("rel_mha_dk64.npz")
+    SW, sd = _seeded_sd(_mha_shapes(256, True), 71)
+    x = torch.from_numpy(g["x"]).requires_grad_(True)
+    y = oracle.rel_mha(sd, "", x, torch.from_numpy(g["pos"]), torch.from_numpy(g["mask"]), 4)
+    close(y, torch.from_numpy(g["y"]), rtol=1e-4, atol=2e-5)
+    assert bool((y[2] == sd["linear_out.bias"]).all())        # the fully masked utterance: zeros through linear_out
+    y.backward(torch.from_numpy(g["gy"]))
+    close(x.grad, torch.from_numpy(g["gx"]), rtol=1e-4, atol=2e-5)
+    assert _check_seeded_grads(SW, sd, g, 1e-4) < 1e-4
+
+
+def test_mha_dk64(oracle):
+    g = load_golden("mha_dk64.npz")
+    SW, sd = _seeded_sd(_mha_shapes(256, False), 61)
+    q = torch.from_numpy(g["q"]).requires_grad_(True)
+    mem = torch.from_numpy(g["mem"]).requires_grad_(True)
+    y = oracle.mha(sd, "", q, mem, mem, torch.from_numpy(g["mmask"]), 4)
+    close(y, torch.from_numpy(g["y"]), rtol=1e-4, atol=2e-5)
+    y.backward(torch.from_numpy(g["gy"]))
+    close(q.grad, torch.from_numpy(g["gq"]), rtol=1e-4, atol=2e-5)
+    close(mem.grad, torch.from_numpy(g["gmem"]), rtol=1e-4, atol=2e-5)
+    assert _check_seeded_grads(SW, sd, g, 1e-4) < 1e-4
+    q2 = torch.from_numpy(g["q"]).requires_grad_(True)
+    y2 = oracle.mha(sd, "", q2, q2, q2, torch.from_numpy(g["cmask"]), 4)
+    close(y2, torch.from_numpy(g["y_self"]), rtol=1e-4, atol=2e-5)
+
+
+def test_e2e_conformer_dk64(oracle):
+    """the oracle end to end at adim 256 / aheads 4 against the reference's loss, encoder output, gradients and
+    greedy ids (weights from oracle/seeded_weights.py on both sides)"""
+    import os, sys
+    from conftest import ROOT
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import seeded_weights as SW
+    from conftest import e2e_dk64_model
+    g = load_golden("e2e_conformer_dk64.npz")
+    model, cfg = e2e_dk64_model()
+    sd = {k: (v.clone().requires_grad_(True) if v.is_floating_point() and "running" not in k else v.clone())
+          for k, v in model.state_dict().items()}
+    xs, ilens, ys = torch.from_numpy(g["xs"]), g["ilens"].tolist(), torch.from_numpy(g["ys"])
+    out = oracle.e2e_forward(sd, xs, ilens, ys, cfg, training=True)
+    assert abs(float(out["loss"]) - float(g["loss"])) <= 2e-5 * abs(float(g["loss"]))
+    assert abs(float(out["loss_ctc"]) - float(g["loss_ctc"])) <= 2e-5 * abs(float(g["loss_ctc"]))
+    assert abs(float(out["acc"]) - float(g["acc"])) < 1e-6
+    close(out["hs_pad"], torch.from_numpy(g["hs_pad"]), rtol=2e-4, atol=2e-5)
+    out["loss"].backward()
+    assert _check_seeded_grads(SW, sd, g, 2e-4) < 2e-4
