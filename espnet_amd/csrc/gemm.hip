@@ -372,6 +372,7 @@ int launch(const eamd_gemm_t& p, hipStream_t stream) {
 }  // namespace
 
 int eamd_gemm_bf16_dispatch(const eamd_gemm_t& p, int tile, hipStream_t stream);  // gemm_bf16.hip
+int eamd_gemm_f32_dispatch(const eamd_gemm_t& p, int tile, hipStream_t stream);   // gemm_f32.hip
 
 extern "C" int eamd_gemm(const eamd_gemm_t* pp, void* stream_) {
   if (!pp) return EAMD_EINVAL;
@@ -416,6 +417,10 @@ extern "C" int eamd_gemm(const eamd_gemm_t* pp, void* stream_) {
   if (p.in_dtype != 1 && (p.drop_p != 0.f || p.Hb)) return EAMD_EUNSUPPORTED;   // fused dropout: bf16-operand kernel only
   if (p.in_dtype == 1) return eamd_gemm_bf16_dispatch(p, tile, stream);
 
+  if (p.precision == 0) {     // reference precision: the pipelined fp32-MFMA kernel wherever its staging conditions hold
+    const int rc = eamd_gemm_f32_dispatch(p, tile, stream);
+    if (rc != EAMD_EUNSUPPORTED) return rc;
+  }
   if (tile == 128) {
     return p.precision ? launch<128, 128, 1>(p, stream) : launch<128, 128, 0>(p, stream);
   }

@@ -1,0 +1,460 @@
+// fp32-operand MFMA GEMM for gfx950: the reference-precision path of eamd_gemm (in_dtype = 0, precision = 0).
+//
+// Arithmetic: v_mfma_f32_16x16x4_f32 - fp32 operands, fp32 products, fp32 accumulation (bitwise an fmaf chain):
+// the reference's own number format.  Its matrix rate is 64 FLOP/clk/SIMD = 157 TFLOP/s for the chip, 1/16 of the
+// bf16 rate, so unlike the bf16 kernels this one is bound by the matrix pipe, and the whole job of the code around
+// the MFMAs is to never make them wait:
+//   * operand tiles go global -> VGPR (16-byte chunks) -> LDS through a register ring; a tile's loads are issued
+//     one or two MFMA phases (1024 - 4096 cycles each) before their first use and NOTHING touches the loaded
+//     registers in between, so hipcc emits one counted s_waitcnt in front of the LDS stores instead of draining
+//     vmcnt before the MFMAs (the generic kernel in gemm.hip guards every load with a branch and waits for each
+//     on the spot: 30-50 TFLOP/s on every shape of the model);
+//   * loads are branch-free: rows / column chunks past the M or N edge are clamped to the last valid one (they only
+//     reach output rows / columns the epilogue never stores), only the ragged last K-tile is masked to zero;
+//   * k-contiguous operands ([rows][K]) sit in LDS as [row][32 + 4] and are read as ds_read_b128 (4 k-steps per
+//     read); k-strided operands ([K][cols]: dX = dY W, dW = dY^T X) sit as [k][cols + 4] and are read as
+//     ds_read_b32, conflict-free for the 16x16x4 operand layout (lane = (row, k group)); no transposed copy of an
+//     activation or weight is ever made;
+//   * implicit-GEMM convolution (gathered A rows / gathered reduction rows), split-K with f32 atomics, fused
+//     bias-gradient column sums, operand activations and the LDS-staged 16-byte epilogue (bias, ReLU / Swish and
+//     their derivative masks, alpha, residual, beta, row maps) are the same features as the bf16 kernel's.
+// 256 threads = 4 waves (2 x 2); block tile 128x128 (wave tile 64x64 = 16 accumulators) or 64x64; BK = 32.
+#include <stdlib.h>
+#include <type_traits>
+#include "common.h"
+#include "../../include/espnet_amd.h"
+
+#include "gemm_bf16_common.h"      // store_c_tile (result epilogue), gather helpers
+
+namespace {
+
+constexpr int FBK = 32;
+
+template <int BM, int BN, bool TA, bool TB>
+struct SmemF {
+  static constexpr int LDA = TA ? BM + 4 : FBK + 4;     // floats per image row
+  static constexpr int RA = TA ? FBK : BM;
+  static constexpr int LDB = TB ? BN + 4 : FBK + 4;
+  static constexpr int RB = TB ? FBK : BN;
+  static constexpr int OPS = 2 * (RA * LDA + RB * LDB);
+  static constexpr int CT = BM * (BN + 4);
+  float ab[OPS > CT ? OPS : CT];                         // operand buffers, re-used as the result staging tile
+  int poff[8][FBK];
+  __device__ float* a(int buf) { return ab + buf * RA * LDA; }
+  __device__ float* b(int buf) { return ab + 2 * RA * LDA + buf * RB * LDB; }
+};
+
+__device__ __forceinline__ float4 act4(float4 v, int act) {
+  if (act == EAMD_ACT_SWISH) return make_float4(eamd_swish(v.x), eamd_swish(v.y), eamd_swish(v.z), eamd_swish(v.w));
+  return make_float4(fmaxf(v.x, 0.f), fmaxf(v.y, 0.f), fmaxf(v.z, 0.f), fmaxf(v.w, 0.f));
+}
+__device__ __forceinline__ float4 mask4(float4 v, int nv) {
+  return make_float4(nv > 0 ? v.x : 0.f, nv > 1 ? v.y : 0.f, nv > 2 ? v.z : 0.f, nv > 3 ? v.w : 0.f);
+}
+
+template <int BM, int BN, bool TA, bool TB, bool GAT, bool ACT>
+__global__ __launch_bounds__(NT_) void gemm_f32_kernel(const eamd_gemm_t p) {
+  constexpr int WM = BM / 2, WN = BN / 2;
+  constexpr int MT = WM / 16, NTL = WN / 16;
+  constexpr int NCA = BM / 32, NCB = BN / 32;           // 16-byte chunks per thread per tile
+  constexpr int CPR_A = BM / 4, RPP_A = NT_ / CPR_A;    // k-strided image: chunks per k-row, k-rows per pass
+  constexpr int CPR_B = BN / 4, RPP_B = NT_ / CPR_B;
+  using S = SmemF<BM, BN, TA, TB>;
+  extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+  S& sm = *reinterpret_cast<S*>(smem_raw);
+
+  const int t = threadIdx.x;
+  const int lane = t & 63, wave = t >> 6;
+  const int wm = wave >> 1, wn = wave & 1;
+  // XCD-aware tile order (see gemm_bf16.hip): every XCD gets one contiguous run of row-major tiles; with split-K
+  // the split index is the fastest-varying part of the workgroup id
+  const int tiles_n = (p.N + BN - 1) / BN;
+  int tile_id, split;
+  if (p.splitk > 1) {
+    split = blockIdx.x % p.splitk;
+    tile_id = blockIdx.x / p.splitk;
+  } else {
+    split = 0;
+    const int ntile = gridDim.x;
+    const int id = blockIdx.x, q = ntile >> 3, r = ntile & 7, xcd = id & 7, j = id >> 3;
+    tile_id = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + j;
+  }
+  const int tile_m = tile_id / tiles_n, tile_n = tile_id % tiles_n;
+  const int m0 = tile_m * BM, n0 = tile_n * BN;
+  const int zb = blockIdx.z;
+  const int b1 = zb / p.batch2, b2 = zb % p.batch2;
+  const float* __restrict__ A = p.A + b1 * p.sA1 + b2 * p.sA2;
+  const float* __restrict__ B = p.B + b1 * p.sB1 + b2 * p.sB2;
+  const long coff = b1 * p.sC1 + b2 * p.sC2;
+
+  const int nkt_total = (p.K + FBK - 1) / FBK;
+  const int per = (nkt_total + p.splitk - 1) / p.splitk;
+  const int kt_begin = split * per;
+  const int kt_end = min(nkt_total, kt_begin + per);
+  const int nkt = kt_end - kt_begin;
+
+  // ---- staging coordinates: LDS image (row, 16-byte chunk) of every staged chunk ----
+  int a_r[NCA], a_c[NCA], b_r[NCB], b_c[NCB];
+#pragma unroll
+  for (int i = 0; i < NCA; ++i) {
+    if constexpr (TA) { a_r[i] = t / CPR_A + RPP_A * i; a_c[i] = t % CPR_A; }
+    else              { a_r[i] = t / 8 + 32 * i;        a_c[i] = t % 8; }
+  }
+#pragma unroll
+  for (int i = 0; i < NCB; ++i) {
+    if constexpr (TB) { b_r[i] = t / CPR_B + RPP_B * i; b_c[i] = t % CPR_B; }
+    else              { b_r[i] = t / 8 + 32 * i;        b_c[i] = t % 8; }
+  }
+  long a_off[NCA], b_off[NCB];
+  if constexpr (!GAT) {
+#pragma unroll
+    for (int i = 0; i < NCA; ++i) {
+      if constexpr (!TA) a_off[i] = (long)min(m0 + a_r[i], p.M - 1) * p.lda + a_c[i] * 4;
+      else a_off[i] = (long)a_r[i] * p.lda + min(m0 + a_c[i] * 4, (p.M - 1) & ~3);
+    }
+  }
+#pragma unroll
+  for (int i = 0; i < NCB; ++i) {
+    if constexpr (!TB) b_off[i] = (long)min(n0 + b_r[i], p.N - 1) * p.ldb + b_c[i] * 4;
+    else b_off[i] = (long)b_r[i] * p.ldb + min(n0 + b_c[i] * 4, (p.N - 1) & ~3);
+  }
+  RowStateB a_rs[NCA];
+  if constexpr (GAT && !TA) {
+#pragma unroll
+    for (int i = 0; i < NCA; ++i) a_rs[i] = decompose_b(p.gather, m0 + a_r[i], p.M);
+  }
+  // register ring: DEPTH-1 tiles of loads in flight across the MFMA phases.  A 128x128 phase is 4096 MFMA cycles
+  // per wave (longer than an HBM round trip): one tile ahead is enough; 64x64 phases are 1024 cycles: two ahead.
+  constexpr int DEPTH = BM >= 128 ? 2 : 3;
+  constexpr int UNROLL = DEPTH % 2 ? 2 * DEPTH : DEPTH;
+  float4 ra[DEPTH][NCA], rb[DEPTH][NCB];
+  const bool do_colsum = TA && p.colsum != nullptr && !GAT && tile_n == 0;
+  float cs[4] = {0.f, 0.f, 0.f, 0.f};
+
+  auto fill_poff = [&](int kt, int slot) __attribute__((always_inline)) {
+    if (t < FBK) {
+      const int tap = m0 / p.gather.C;
+      RowStateB s = decompose_b(p.gather, kt * FBK + t, p.K);
+      sm.poff[slot][t] = (int)gather_off_b(p.gather, s, tap);
+    }
+  };
+
+  // GUARD = the tile may be the ragged last one (k0 + FBK > K): out-of-range chunk starts are redirected to the
+  // start of the row / to reduction row 0 and zeroed at store time
+  auto load_tile = [&](auto set_c, auto guard_c, int kt) __attribute__((always_inline)) {
+    constexpr int SET = decltype(set_c)::value;
+    constexpr bool GUARD = decltype(guard_c)::value;
+    const int k0 = kt * FBK;
+    if constexpr (!TA) {
+      if constexpr (!GAT) {
+#pragma unroll
+        for (int i = 0; i < NCA; ++i) {
+          const int kk = (GUARD && k0 + a_c[i] * 4 >= p.K) ? -a_c[i] * 4 : k0;
+          ra[SET][i] = *reinterpret_cast<const float4*>(A + a_off[i] + kk);
+        }
+      } else {
+        const int tap = k0 / p.gather.C, c0 = k0 % p.gather.C;
+#pragma unroll
+        for (int i = 0; i < NCA; ++i) {
+          const long off = gather_off_b(p.gather, a_rs[i], tap);
+          ra[SET][i] = *reinterpret_cast<const float4*>(A + (off >= 0 ? off + c0 + a_c[i] * 4 : 0L));
+        }
+      }
+    } else {
+      if constexpr (!GAT) {
+#pragma unroll
+        for (int i = 0; i < NCA; ++i) {
+          const int kk = (GUARD && k0 + a_r[i] >= p.K) ? -a_r[i] : k0;
+          ra[SET][i] = *reinterpret_cast<const float4*>(A + a_off[i] + (long)kk * p.lda);
+        }
+      } else {
+        const int c = (m0 % p.gather.C) + a_c[0] * 4;
+        const int slot = kt % 8;
+#pragma unroll
+        for (int i = 0; i < NCA; ++i) {
+          const int off = sm.poff[slot][a_r[i]];
+          ra[SET][i] = *reinterpret_cast<const float4*>(A + (off >= 0 ? (long)off + c : 0L));
+        }
+      }
+    }
+    if constexpr (!TB) {
+#pragma unroll
+      for (int i = 0; i < NCB; ++i) {
+        const int kk = (GUARD && k0 + b_c[i] * 4 >= p.K) ? -b_c[i] * 4 : k0;
+        rb[SET][i] = *reinterpret_cast<const float4*>(B + b_off[i] + kk);
+      }
+    } else {
+#pragma unroll
+      for (int i = 0; i < NCB; ++i) {
+        const int kk = (GUARD && k0 + b_r[i] >= p.K) ? -b_r[i] : k0;
+        rb[SET][i] = *reinterpret_cast<const float4*>(B + b_off[i] + (long)kk * p.ldb);
+      }
+    }
+  };
+
+  auto store_tile = [&](auto set_c, auto guard_c, int buf, int kt) __attribute__((always_inline)) {
+    constexpr int SET = decltype(set_c)::value;
+    constexpr bool GUARD = decltype(guard_c)::value;
+    const int k0 = kt * FBK;
+    if constexpr (GAT) {   // gathered rows are either fully valid or fully zero (padding taps / row tail)
+#pragma unroll
+      for (int i = 0; i < NCA; ++i) {
+        bool ok;
+        if constexpr (!TA) ok = gather_off_b(p.gather, a_rs[i], k0 / p.gather.C) >= 0;
+        else ok = sm.poff[kt % 8][a_r[i]] >= 0;
+        ra[SET][i] = mask4(ra[SET][i], ok ? 4 : 0);
+      }
+    }
+    if constexpr (GUARD) {
+      if (k0 + FBK > p.K) {      // ragged last K-tile: zero the out-of-range reduction elements
+        if constexpr (!GAT) {
+#pragma unroll
+          for (int i = 0; i < NCA; ++i)
+            ra[SET][i] = mask4(ra[SET][i], TA ? ((k0 + a_r[i]) < p.K ? 4 : 0) : p.K - (k0 + a_c[i] * 4));
+        }
+#pragma unroll
+        for (int i = 0; i < NCB; ++i)
+          rb[SET][i] = mask4(rb[SET][i], TB ? ((k0 + b_r[i]) < p.K ? 4 : 0) : p.K - (k0 + b_c[i] * 4));
+      }
+    }
+    if (do_colsum) {
+#pragma unroll
+      for (int i = 0; i < NCA; ++i) {
+        cs[0] += ra[SET][i].x; cs[1] += ra[SET][i].y; cs[2] += ra[SET][i].z; cs[3] += ra[SET][i].w;
+      }
+    }
+    if constexpr (ACT) {
+      if (p.a_act != EAMD_ACT_NONE) {
+#pragma unroll
+        for (int i = 0; i < NCA; ++i) ra[SET][i] = act4(ra[SET][i], p.a_act);
+      }
+      if (p.b_act != EAMD_ACT_NONE) {
+#pragma unroll
+        for (int i = 0; i < NCB; ++i) rb[SET][i] = act4(rb[SET][i], p.b_act);
+      }
+    }
+    float* la = sm.a(buf);
+    float* lb = sm.b(buf);
+#pragma unroll
+    for (int i = 0; i < NCA; ++i) *reinterpret_cast<float4*>(&la[a_r[i] * S::LDA + a_c[i] * 4]) = ra[SET][i];
+#pragma unroll
+    for (int i = 0; i < NCB; ++i) *reinterpret_cast<float4*>(&lb[b_r[i] * S::LDB + b_c[i] * 4]) = rb[SET][i];
+  };
+
+  f32x4 acc[MT][NTL];
+#pragma unroll
+  for (int i = 0; i < MT; ++i)
+#pragma unroll
+    for (int j = 0; j < NTL; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+  constexpr bool tgat = GAT && TA;
+  if (nkt > 0) {
+    if (tgat) {
+      for (int q = 0; q < DEPTH && q < nkt; ++q) fill_poff(kt_begin + q, (kt_begin + q) % 8);
+      __syncthreads();
+    }
+    load_tile(std::integral_constant<int, 0>{}, std::true_type{}, kt_begin);
+    if constexpr (DEPTH == 3) {
+      if (nkt > 1) load_tile(std::integral_constant<int, 1>{}, std::true_type{}, kt_begin + 1);
+    }
+    store_tile(std::integral_constant<int, 0>{}, std::true_type{}, 0, kt_begin);
+    __syncthreads();
+  }
+
+  const int fr = lane & 15, fq = lane >> 4;
+  // one K-tile: issue the loads of tile it+DEPTH-1, run the 8 k-steps (x MT x NTL MFMAs) of tile `it` from LDS,
+  // then move tile it+1 into the other LDS buffer.  MFMA e of half kk contracts k = kk*16 + 4*fq + e.
+  auto phase = [&](auto idx_c, auto guard_c, int it) __attribute__((always_inline)) {
+    constexpr int IDX = decltype(idx_c)::value;
+    constexpr int PAR = IDX % DEPTH;
+    constexpr bool GUARD = decltype(guard_c)::value;
+    using load_t = std::integral_constant<int, (PAR + DEPTH - 1) % DEPTH>;
+    using other_t = std::integral_constant<int, (PAR + 1) % DEPTH>;
+    constexpr int buf = IDX & 1;
+    if constexpr (GUARD) {
+      if (tgat && it + DEPTH < nkt) fill_poff(kt_begin + it + DEPTH, (kt_begin + it + DEPTH) % 8);
+      if (it + DEPTH - 1 < nkt) load_tile(load_t{}, guard_c, kt_begin + it + DEPTH - 1);
+    } else {
+      if constexpr (tgat) fill_poff(kt_begin + it + DEPTH, (kt_begin + it + DEPTH) % 8);
+      load_tile(load_t{}, guard_c, kt_begin + it + DEPTH - 1);
+    }
+    // the machine scheduler otherwise sinks the loads below the MFMAs, next to the LDS stores that consume them
+    __builtin_amdgcn_sched_barrier(0);
+    const float* la = sm.a(buf);
+    const float* lb = sm.b(buf);
+#pragma unroll
+    for (int kk = 0; kk < 2; ++kk) {
+      float af[MT][4], bfr[NTL][4];
+#pragma unroll
+      for (int i = 0; i < MT; ++i) {
+        if constexpr (!TA) {
+          const float4 v = *reinterpret_cast<const float4*>(&la[(wm * WM + i * 16 + fr) * S::LDA + kk * 16 + fq * 4]);
+          af[i][0] = v.x; af[i][1] = v.y; af[i][2] = v.z; af[i][3] = v.w;
+        } else {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) af[i][e] = la[(kk * 16 + fq * 4 + e) * S::LDA + wm * WM + i * 16 + fr];
+        }
+      }
+#pragma unroll
+      for (int j = 0; j < NTL; ++j) {
+        if constexpr (!TB) {
+          const float4 v = *reinterpret_cast<const float4*>(&lb[(wn * WN + j * 16 + fr) * S::LDB + kk * 16 + fq * 4]);
+          bfr[j][0] = v.x; bfr[j][1] = v.y; bfr[j][2] = v.z; bfr[j][3] = v.w;
+        } else {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) bfr[j][e] = lb[(kk * 16 + fq * 4 + e) * S::LDB + wn * WN + j * 16 + fr];
+        }
+      }
+#pragma unroll
+      for (int e = 0; e < 4; ++e)
+#pragma unroll
+        for (int i = 0; i < MT; ++i)
+#pragma unroll
+          for (int j = 0; j < NTL; ++j)
+            acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[i][e], bfr[j][e], acc[i][j], 0, 0, 0);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    if constexpr (GUARD) {
+      if (it + 1 < nkt) store_tile(other_t{}, guard_c, buf ^ 1, kt_begin + it + 1);
+    } else {
+      store_tile(other_t{}, guard_c, buf ^ 1, kt_begin + it + 1);
+    }
+    __syncthreads();
+  };
+  using T_ = std::true_type;
+  using F_ = std::false_type;
+  int it = 0;
+  // unguarded groups: the last phase of a group loads tile it + UNROLL + DEPTH - 2, which must not be the (possibly
+  // ragged) last tile
+  for (; it + UNROLL + DEPTH - 1 < nkt; it += UNROLL) {
+    phase(std::integral_constant<int, 0>{}, F_{}, it);
+    phase(std::integral_constant<int, 1>{}, F_{}, it + 1);
+    if constexpr (UNROLL == 6) {
+      phase(std::integral_constant<int, 2>{}, F_{}, it + 2);
+      phase(std::integral_constant<int, 3>{}, F_{}, it + 3);
+      phase(std::integral_constant<int, 4>{}, F_{}, it + 4);
+      phase(std::integral_constant<int, 5>{}, F_{}, it + 5);
+    }
+  }
+  for (; it < nkt; it += UNROLL) {
+    phase(std::integral_constant<int, 0>{}, T_{}, it);
+    if (it + 1 < nkt) phase(std::integral_constant<int, 1>{}, T_{}, it + 1);
+    if constexpr (UNROLL == 6) {
+      if (it + 2 < nkt) phase(std::integral_constant<int, 2>{}, T_{}, it + 2);
+      if (it + 3 < nkt) phase(std::integral_constant<int, 3>{}, T_{}, it + 3);
+      if (it + 4 < nkt) phase(std::integral_constant<int, 4>{}, T_{}, it + 4);
+      if (it + 5 < nkt) phase(std::integral_constant<int, 5>{}, T_{}, it + 5);
+    }
+  }
+
+  if (TA && p.colsum != nullptr && !GAT) {   // block-uniform
+    // bias gradient: per-thread column sums -> one LDS row per k-row group of the staging layout -> one global
+    // atomic per column per block (plain LDS stores: ds_add_f32 is slow on gfx950)
+    float* csl = sm.ab;
+    constexpr int NSLOT = NT_ / CPR_A;
+    static_assert(NSLOT * BM <= S::OPS, "column-sum slots must fit in the operand buffers");
+    __syncthreads();
+    if (do_colsum) {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) csl[(t / CPR_A) * BM + a_c[0] * 4 + j] = cs[j];
+    }
+    __syncthreads();
+    if (do_colsum) {
+      for (int i = t; i < BM; i += NT_) {
+        const int m = m0 + i;
+        float v = 0.f;
+#pragma unroll 8
+        for (int sl = 0; sl < NSLOT; ++sl) v += csl[sl * BM + i];
+        if (m < p.M) atomicAdd(p.colsum + (long)zb * p.M + m, v * p.alpha);
+      }
+    }
+    __syncthreads();
+  }
+
+  // ---- epilogue ----
+  if (p.splitk > 1) {
+    const bool lead = split == 0;
+#pragma unroll
+    for (int i = 0; i < MT; ++i) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int m = m0 + wm * WM + i * 16 + fq * 4 + r;
+        if (m >= p.M) continue;
+        long prow = m;
+        if (p.cmap.enabled) {
+          const eamd_rowmap_t& c = p.cmap;
+          int jj = m % c.Wo; int tt = m / c.Wo; int ii = tt % c.Ho; int bb = tt / c.Ho;
+          prow = ((long)bb * c.Hc + ii * c.sh + c.oh) * c.Wc + jj * c.sw + c.ow;
+        }
+#pragma unroll
+        for (int j = 0; j < NTL; ++j) {
+          const int n = n0 + wn * WN + j * 16 + fr;
+          if (n >= p.N) continue;
+          float v = acc[i][j][r];
+          if (lead && p.bias) v += p.bias[n];
+          v *= p.alpha;
+          if (lead && p.R) v += p.R[coff + prow * p.ldr + n];
+          atomicAdd(p.C + coff + prow * p.ldc + n, v);
+        }
+      }
+    }
+    return;
+  }
+  store_c_tile<BM, BN, true>(p, acc, sm.ab, m0, n0, coff);      // operand buffers are free now (last phase ended in a barrier)
+}
+
+template <int BM, int BN, bool TA, bool TB, bool GAT, bool ACT>
+int launch_f2(const eamd_gemm_t& p, hipStream_t stream) {
+  dim3 grid(((p.M + BM - 1) / BM) * ((p.N + BN - 1) / BN) * p.splitk, 1, p.batch1 * p.batch2);
+  constexpr size_t smem = sizeof(SmemF<BM, BN, TA, TB>);
+  if (smem > 64 * 1024) {
+    static const hipError_t attr_err = hipFuncSetAttribute(
+        reinterpret_cast<const void*>(&gemm_f32_kernel<BM, BN, TA, TB, GAT, ACT>),
+        hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+    if (attr_err != hipSuccess) return (int)attr_err;
+  }
+  hipLaunchKernelGGL((gemm_f32_kernel<BM, BN, TA, TB, GAT, ACT>), grid, dim3(NT_), smem, stream, p);
+  EAMD_LAUNCH_CHECK();
+  return EAMD_OK;
+}
+
+template <int BM, int BN, bool TA, bool TB, bool GAT>
+int launch_f(const eamd_gemm_t& p, hipStream_t stream) {
+  if constexpr (GAT) return launch_f2<BM, BN, TA, TB, GAT, false>(p, stream);
+  else if (p.a_act != EAMD_ACT_NONE || p.b_act != EAMD_ACT_NONE) return launch_f2<BM, BN, TA, TB, GAT, true>(p, stream);
+  return launch_f2<BM, BN, TA, TB, GAT, false>(p, stream);
+}
+
+template <int T>
+int dispatch_layout_f(const eamd_gemm_t& p, hipStream_t s) {
+  if (p.transA) return p.transB ? launch_f<T, T, true, true, false>(p, s) : launch_f<T, T, true, false, false>(p, s);
+  return p.transB ? launch_f<T, T, false, true, false>(p, s) : launch_f<T, T, false, false, false>(p, s);
+}
+
+bool aligned16f(const void* q) { return (reinterpret_cast<uintptr_t>(q) & 15) == 0; }
+
+}  // namespace
+
+// Called by eamd_gemm (gemm.hip) for in_dtype = 0, precision = 0 after argument validation.
+// Returns EAMD_EUNSUPPORTED when the operands do not meet the branch-free staging conditions (16-byte aligned chunk
+// starts that stay inside the operand); the caller then takes the generic kernel.
+int eamd_gemm_f32_dispatch(const eamd_gemm_t& p, int tile, hipStream_t stream) {
+  static const int on = [] { const char* e = getenv("EAMD_GEMM_F32_FAST"); return e ? atoi(e) : 1; }();
+  if (!on) return EAMD_EUNSUPPORTED;
+  if (p.Cb || p.Hb || p.aux_dtype || p.drop_p != 0.f || !p.C) return EAMD_EUNSUPPORTED;
+  const bool a_ok = aligned16f(p.A) && p.lda % 4 == 0 && p.sA1 % 4 == 0 && p.sA2 % 4 == 0 &&
+                    p.lda >= (p.transA ? (p.M + 3) / 4 * 4 : (p.K + 3) / 4 * 4);
+  const bool b_ok = aligned16f(p.B) && p.ldb % 4 == 0 && p.sB1 % 4 == 0 && p.sB2 % 4 == 0 &&
+                    p.ldb >= (p.transB ? (p.N + 3) / 4 * 4 : (p.K + 3) / 4 * 4);
+  if (p.gather.enabled) {
+    const eamd_gather_t& g = p.gather;
+    if (g.C % FBK != 0 || !p.transB || !aligned16f(p.A) || !b_ok) return EAMD_EUNSUPPORTED;
+    if (p.a_act != EAMD_ACT_NONE || p.b_act != EAMD_ACT_NONE) return EAMD_EUNSUPPORTED;
+    if (p.transA && g.C % tile != 0) return EAMD_EUNSUPPORTED;
+    if (tile == 128)
+      return p.transA ? launch_f<128, 128, true, true, true>(p, stream) : launch_f<128, 128, false, true, true>(p, stream);
+    return p.transA ? launch_f<64, 64, true, true, true>(p, stream) : launch_f<64, 64, false, true, true>(p, stream);
+  }
+  if (!a_ok || !b_ok) return EAMD_EUNSUPPORTED;
+  return tile == 128 ? dispatch_layout_f<128>(p, stream) : dispatch_layout_f<64>(p, stream);
+}

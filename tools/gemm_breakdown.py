@@ -18,7 +18,7 @@ from espnet_amd.nets.e2e_asr_conformer import E2E  # noqa: E402
 
 def main():
     dev = torch.device("cuda", 0)
-    espnet_amd.set_precision("bf16")
+    espnet_amd.set_precision(sys.argv[1] if len(sys.argv) > 1 else "bf16")
     B, T, L, V = 32, 1000, 100, 5000
     torch.manual_seed(0)
     model = E2E(80, V, bench.c2_args(0.1)).to(dev).train()
