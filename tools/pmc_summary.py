@@ -3,7 +3,7 @@
 HBM-traffic figure bench.py reports as roofline.traffic.
 
 FETCH_SIZE / WRITE_SIZE are in KiB; on gfx950 FETCH_SIZE counts 128-B requests as 64 B, so it is doubled
-(MI355X_MICROARCH.md, section HBM).  usage: pmc_summary.py <gpurun_out dir> <profiles dir> <tag> <gemm launches/step>
+(MI355X_MICROARCH.md, section HBM).  usage: pmc_summary.py <gpurun_out dir> <profiles dir> <tag> <gemm launches/step> [precision]
 """
 import csv
 import glob
@@ -13,6 +13,7 @@ import sys
 from collections import defaultdict
 
 src, dst, tag, lps = sys.argv[1], sys.argv[2], sys.argv[3], float(sys.argv[4])
+prec = sys.argv[5] if len(sys.argv) > 5 else None
 os.makedirs(os.path.join(dst, tag + "_pmc"), exist_ok=True)
 tot = {}
 for d in sorted(glob.glob(os.path.join(src, "pmc_*"))):
@@ -55,6 +56,6 @@ if "FETCH_SIZE" in tot and "WRITE_SIZE" in tot:
     for c, t in tot.items():
         if c not in ("FETCH_SIZE", "WRITE_SIZE"):
             out.setdefault("sq_counters_gemm_family_sum", {})[c] = t["gemm"][1]
-    with open(os.path.join(dst, tag + "_pmc_traffic.json"), "w") as f:
+    with open(os.path.join(dst, tag + "_pmc_traffic" + ("_" + prec if prec else "") + ".json"), "w") as f:
         json.dump(out, f, indent=1)
     print(json.dumps(out, indent=1))
