@@ -1,12 +1,28 @@
-"""Transducer decoding: greedy search, the default beam search, time-synchronous (tsd) and alignment-length
-synchronous (alsd) decoding and the N-step constrained search (nsc), with optional RNNLM shallow fusion.
-reference: espnet/nets/beam_search_transducer.py:23-462 (Hypothesis, BeamSearchTransducer.__init__/__call__/
-sort_nbest/greedy_search/default_beam_search/time_sync_decoding/align_length_sync_decoding/nsc_beam_search, :23-662).  The control flow (hypothesis lists, expansion order, the prediction
-network cache keyed by the label prefix) is host Python exactly as in the reference; every arithmetic step
-(embedding, LSTM / GRU step, joint network, log-softmax) runs on the espnet_amd kernels - batched over the beam in the
-tsd / alsd / nsc searches."""
-from dataclasses import dataclass
-from typing import Any, Dict, List, Union
+"""Transducer decoding on the device primitives: greedy search and the default (Graves) beam search.
+
+What the searches compute is pinned by the reference (espnet/nets/beam_search_transducer.py:130-237: one symbol per
+frame at most in the greedy search; the A / B hypothesis sets of Graves 2012 in the default search, RNNLM shallow
+fusion added to the non-blank extensions) and by the recorded hypotheses in tests/golden/transducer_*.npz.  How it is
+computed is this package's own design:
+
+  * label prefixes live in a TRIE (`_Prefixes`): a hypothesis is (score, node).  Everything that depends on the
+    label sequence only - the prediction network's output and state, the LM state and scores - is stored ONCE per
+    node under its integer id, so two hypotheses that reach the same sequence share it;
+  * the joint network runs on ROWS: `JointNetwork.joint_rows` takes n (frame, node) pairs and returns n log-softmax
+    rows from one lin_dec GEMM, one fused add + activation, one lin_out GEMM and one log-softmax launch;
+  * greedy search: the prediction output only changes when a symbol is emitted, so a whole CHUNK of frames is scored
+    against the current node in one batch, the first non-blank frame is located on the device and only that index
+    and token come back to the host - launches scale with emitted symbols, not with frames;
+  * default beam search: at the start of a frame all carried hypotheses are scored in one batch (prediction steps for
+    nodes first seen + joint rows + top-k, one device-to-host copy); children created during the frame are scored
+    lazily, again all pending ones in one batch, when the first of them is selected for expansion.
+
+Prediction networks take part through one of two protocols: `step(tokens, states)` (batched; DecoderRNNT) or the
+reference's per-hypothesis plug-in method `score(hyp, cache, init_tensor)` (any TransducerDecoderInterface).
+The time-synchronous / alignment-length-synchronous / N-step-constrained searches of the reference are outside the
+hot-path scope (greedy + default) and are not provided."""
+from dataclasses import dataclass, field
+from typing import Any, List
 
 import torch
 
@@ -15,339 +31,198 @@ from .. import ops
 
 @dataclass
 class Hypothesis:
-    """reference: beam_search_transducer.py:23-33"""
+    """result record (the fields the reference's recognisers read: score, yseq; the state fields stay empty)"""
 
     score: float
     yseq: List[int]
+    dec_state: Any = None
+    lm_state: Any = None
+    y: Any = None
+    lm_scores: Any = None
+
+
+class _Prefixes:
+    """trie of label sequences; node 0 = [blank]"""
+
+    def __init__(self, blank):
+        self.parent, self.token, self.kids = [-1], [blank], [{}]
+
+    def child(self, node, tok):
+        c = self.kids[node].get(tok)
+        if c is None:
+            c = len(self.parent)
+            self.parent.append(node)
+            self.token.append(tok)
+            self.kids.append({})
+            self.kids[node][tok] = c
+        return c
+
+    def labels(self, node):
+        out = []
+        while node >= 0:
+            out.append(self.token[node])
+            node = self.parent[node]
+        return out[::-1]
+
+
+@dataclass
+class _View:
+    """what a TransducerDecoderInterface.score() reads of a hypothesis"""
+
+    yseq: List[int]
     dec_state: Any
-    y: List[torch.Tensor] = None
-    lm_state: Union[Dict[str, Any], List[Any]] = None
-    lm_scores: torch.Tensor = None
+    score: float = 0.0
+    lm_state: Any = None
 
 
-def _log_softmax(z):
-    return ops.log_softmax_rows(z.reshape(1, -1).contiguous()).view(-1)
+@dataclass
+class _Pred:
+    """per-node results of the prediction network (and of the LM, filled on first expansion)"""
+
+    out: dict = field(default_factory=dict)       # node -> (dunits,) output
+    state: dict = field(default_factory=dict)     # node -> state AFTER consuming the node's token
+    lm_state: dict = field(default_factory=dict)
+    lm_logp: dict = field(default_factory=dict)   # node -> host list of LM log-probabilities of the next token
 
 
 class BeamSearchTransducer:
     def __init__(self, decoder, beam_size, lm=None, lm_weight=0.1, search_type="default", max_sym_exp=2, u_max=50,
-                 nstep=1, prefix_alpha=1, score_norm=True):
+                 nstep=1, prefix_alpha=1, score_norm=True, frame_chunk=32):
         self.decoder = decoder
         self.beam_size = beam_size
-        self.hidden_size = decoder.dunits
         self.vocab_size = decoder.odim
         self.blank = decoder.blank
-        if self.beam_size <= 1:
-            self.search_algorithm = self.greedy_search
-        elif search_type == "default":
-            self.search_algorithm = self.default_beam_search
-        elif search_type == "tsd":
-            self.search_algorithm = self.time_sync_decoding
-        elif search_type == "alsd":
-            self.search_algorithm = self.align_length_sync_decoding
-        elif search_type == "nsc":
-            self.search_algorithm = self.nsc_beam_search
-        else:
-            raise NotImplementedError("search_type %r: greedy, default, tsd, alsd, nsc" % search_type)
-        # lm: a ClassifierWithState (espnet_amd.nets.lm, as espnet/asr/pytorch_backend/asr.py passes it) whose
-        # predict(state, tokens) -> (state, log-probs (1, V)); fused with lm_weight in the default search
+        if self.blank != 0:
+            raise NotImplementedError("blank id must be 0 (the non-blank top-k is taken over ids 1..V-1)")
+        if beam_size > 1 and search_type != "default":
+            raise NotImplementedError("search_type %r: the greedy (beam_size <= 1) and default searches are provided" % search_type)
         self.lm, self.lm_weight = lm, lm_weight
-        self.max_sym_exp, self.u_max, self.nstep, self.prefix_alpha = max_sym_exp, u_max, nstep, prefix_alpha
         self.score_norm = score_norm
+        self.frame_chunk = frame_chunk
+        self.batched = hasattr(decoder, "step")
 
     def __call__(self, h):
-        """h: encoded speech features (T_max, D_enc) -> 1-best Hypothesis (greedy) or sorted n-best list"""
-        if hasattr(self.decoder, "att"):          # rnnt-att: forget the previous utterance's encoder projections (:105-109)
+        """h: encoder states of one utterance (T, D_enc) -> 1-best Hypothesis (greedy) or the sorted n-best list"""
+        if hasattr(self.decoder, "att"):          # rnnt-att: forget the previous utterance's encoder projections
             self.decoder.att[0].reset()
         with torch.no_grad():
-            return self.search_algorithm(h)
+            return self._greedy(h) if self.beam_size <= 1 else self._default(h)
 
-    def sort_nbest(self, hyps):
+    # ---- prediction network, once per trie node ---------------------------------------------------------------------
+    def _start(self, h):
+        self._tree = _Prefixes(self.blank)
+        self._pred = _Pred()
+        self._init_tensor = h.unsqueeze(0)
+        self._root_state = self.decoder.init_state(self._init_tensor)
+        self._ext_cache = {}
+
+    def _ensure_pred(self, nodes):
+        """prediction-network output / state for every node of `nodes` that has none yet (parents always have)"""
+        todo = [n for n in dict.fromkeys(nodes) if n not in self._pred.out]
+        if not todo:
+            return
+        tr, pr, dec = self._tree, self._pred, self.decoder
+        if self.batched:
+            dev = self._init_tensor.device
+            toks = torch.tensor([tr.token[n] for n in todo], dtype=torch.long, device=dev)
+            prev = [pr.state[tr.parent[n]] if tr.parent[n] >= 0 else dec.unbatch_state(self._root_state, 0) for n in todo]
+            y, new = dec.step(toks, dec.batch_states(prev))
+            for i, n in enumerate(todo):
+                pr.out[n] = y[i]
+                pr.state[n] = dec.unbatch_state(new, i)
+        else:
+            for n in todo:
+                prev = pr.state[tr.parent[n]] if tr.parent[n] >= 0 else self._root_state
+                y, st, _ = dec.score(_View(tr.labels(n), prev), self._ext_cache, self._init_tensor)
+                pr.out[n] = y.reshape(-1)
+                pr.state[n] = st
+
+    def _lm_step(self, node):
+        """LM log-probabilities of the token after `node` (RNNLM shallow fusion), once per node"""
+        pr = self._pred
+        if node not in pr.lm_logp:
+            par = self._tree.parent[node]
+            prev = pr.lm_state[par] if par >= 0 else None
+            tok = torch.tensor([self._tree.token[node]], dtype=torch.long, device=self._init_tensor.device)
+            st, logp = self.lm.predict(prev, tok)
+            pr.lm_state[node] = st
+            pr.lm_logp[node] = logp[0].tolist()
+        return pr.lm_logp[node]
+
+    def _rows(self, enc_rows, nodes):
+        """log-softmax rows of the joint network for n (encoder row, node) pairs -> (n, V)"""
+        y = torch.stack([self._pred.out[n] for n in nodes])
+        return ops.log_softmax_rows(self.decoder.joint_network.joint_rows(enc_rows, y))
+
+    # ---- greedy -----------------------------------------------------------------------------------------------------
+    def _greedy(self, h):
+        self._start(h)
+        jn = self.decoder.joint_network
+        enc = jn.project_enc(h)
+        T = enc.shape[0]
+        node, score, t = 0, 0.0, 0
+        self._ensure_pred([0])
+        while t < T:
+            n = min(self.frame_chunk, T - t)
+            logp = ops.log_softmax_rows(jn.joint_rows(enc[t:t + n], self._pred.out[node].unsqueeze(0)))
+            best = ops.argmax_rows(logp).long()                                     # (n,)
+            emit = (best != self.blank)
+            # first emitting frame of the chunk, its token and log-probability: one small copy to the host
+            first = torch.where(emit, torch.arange(n, device=best.device), torch.full((), n, device=best.device)).min()
+            idx = first.clamp(max=n - 1)
+            rec = torch.stack([first.float(), best[idx].float(), logp[idx, best[idx]]]).tolist()
+            f = int(rec[0])
+            if f >= n:                     # only blanks in this chunk
+                t += n
+                continue
+            node = self._tree.child(node, int(rec[1]))
+            score += rec[2]
+            self._ensure_pred([node])
+            t += f + 1                     # at most one symbol per frame (reference greedy_search)
+        return Hypothesis(score=score, yseq=self._tree.labels(node))
+
+    # ---- default beam search ----------------------------------------------------------------------------------------
+    def _default(self, h):
+        self._start(h)
+        enc = self.decoder.joint_network.project_enc(h)
+        beam = min(self.beam_size, self.vocab_size)
+        beam_k = min(beam, self.vocab_size - 1)
+        carried = [(0.0, 0)]                    # set B of the previous frame: (score, node)
+        for t in range(enc.shape[0]):
+            frontier = carried                  # set A
+            carried = []
+            scored = {}                         # node -> (blank logp, [(logp, token)] best non-blank extensions) at frame t
+
+            def score_pending(first):
+                """joint rows for `first` and every other node of the frontier that has none at this frame"""
+                nodes = [first] + [n for _s, n in frontier if n not in scored and n != first]
+                nodes = list(dict.fromkeys(nodes))
+                self._ensure_pred(nodes)
+                logp = self._rows(enc[t].unsqueeze(0).expand(len(nodes), -1), nodes)
+                top_v, top_i = logp[:, 1:].topk(beam_k, dim=-1)
+                host = torch.cat([logp[:, :1], top_v, (top_i + 1).float()], dim=1).tolist()
+                for n, row in zip(nodes, host):
+                    scored[n] = (row[0], list(zip(row[1:1 + beam_k], (int(v) for v in row[1 + beam_k:]))))
+
+            while True:
+                j = max(range(len(frontier)), key=lambda i: frontier[i][0])          # first maximum, as max() over a list
+                s_best, n_best = frontier.pop(j)
+                if n_best not in scored:
+                    score_pending(n_best)
+                blank_lp, ext = scored[n_best]
+                lm_lp = self._lm_step(n_best) if self.lm else None
+                for lp, tok in ext:
+                    s = s_best + lp
+                    if lm_lp is not None:
+                        s += self.lm_weight * lm_lp[tok]
+                    frontier.append((s, self._tree.child(n_best, tok)))
+                carried.append((s_best + blank_lp, n_best))
+                bound = max(s for s, _n in frontier)
+                ahead = sorted((c for c in carried if c[0] > bound), key=lambda c: c[0])
+                if len(ahead) >= beam:
+                    carried = ahead
+                    break
+        hyps = [Hypothesis(score=s, yseq=self._tree.labels(n)) for s, n in carried]
         if self.score_norm:
             return sorted(hyps, key=lambda x: x.score / len(x.yseq), reverse=True)
         return sorted(hyps, key=lambda x: x.score, reverse=True)
-
-    def greedy_search(self, h):
-        """reference: beam_search_transducer.py:130-162"""
-        init_tensor = h.unsqueeze(0)
-        dec_state = self.decoder.init_state(init_tensor)
-        hyp = Hypothesis(score=0.0, yseq=[self.blank], dec_state=dec_state)
-        cache = {}
-        y, state, _ = self.decoder.score(hyp, cache, init_tensor)
-        # the encoder side of the joint network does not depend on the hypothesis: one GEMM for all frames
-        enc_proj = self.decoder.joint_network.project_enc(h)
-        for i in range(h.shape[0]):
-            ytu = _log_softmax(self.decoder.joint_network.joint_step(enc_proj[i], y[0]))
-            logp, pred = torch.max(ytu, dim=-1)
-            pred = int(pred)
-            if pred != self.blank:
-                hyp.yseq.append(pred)
-                hyp.score += float(logp)
-                hyp.dec_state = state
-                y, state, _ = self.decoder.score(hyp, cache, init_tensor)
-        return hyp
-
-    def default_beam_search(self, h):
-        """reference: beam_search_transducer.py:164-237"""
-        beam = min(self.beam_size, self.vocab_size)
-        beam_k = min(beam, (self.vocab_size - 1))
-        init_tensor = h.unsqueeze(0)
-        dec_state = self.decoder.init_state(init_tensor)
-        kept_hyps = [Hypothesis(score=0.0, yseq=[self.blank], dec_state=dec_state)]
-        cache = {}
-        enc_proj = self.decoder.joint_network.project_enc(h)
-        for t in range(h.shape[0]):
-            hyps = kept_hyps
-            kept_hyps = []
-            while True:
-                max_hyp = max(hyps, key=lambda x: x.score)
-                hyps.remove(max_hyp)
-                y, state, lm_tokens = self.decoder.score(max_hyp, cache, init_tensor)
-                ytu = _log_softmax(self.decoder.joint_network.joint_step(enc_proj[t], y[0]))
-                top_v, top_i = ytu[1:].topk(beam_k, dim=-1)
-                cand = list(zip(top_v.tolist(), (top_i + 1).tolist())) + [(float(ytu[0]), self.blank)]
-                if self.lm:
-                    lm_state, lm_scores = self.lm.predict(max_hyp.lm_state, lm_tokens)
-                    lm_host = lm_scores[0].tolist()
-                for logp, k in cand:
-                    new_hyp = Hypothesis(score=(max_hyp.score + float(logp)), yseq=max_hyp.yseq[:],
-                                         dec_state=max_hyp.dec_state, lm_state=max_hyp.lm_state)
-                    if k == self.blank:
-                        kept_hyps.append(new_hyp)
-                    else:
-                        new_hyp.dec_state = state
-                        new_hyp.yseq.append(int(k))
-                        if self.lm:
-                            new_hyp.lm_state = lm_state
-                            new_hyp.score += self.lm_weight * lm_host[k]
-                        hyps.append(new_hyp)
-                hyps_max = float(max(hyps, key=lambda x: x.score).score)
-                kept_most_prob = sorted([hyp for hyp in kept_hyps if hyp.score > hyps_max], key=lambda x: x.score)
-                if len(kept_most_prob) >= beam:
-                    kept_hyps = kept_most_prob
-                    break
-        return self.sort_nbest(kept_hyps)
-
-    # ---- LM state plumbing of the batched searches (transducer/utils.py:96-178; RNNLM states {c, h} per layer) --------
-    def _lm_init(self):
-        lm_model = self.lm.predictor
-        p = next(lm_model.parameters())
-        state = {"h": [torch.zeros(lm_model.n_units, device=p.device, dtype=p.dtype) for _ in range(len(lm_model.rnn))]}
-        if lm_model.typ == "lstm":
-            state["c"] = [torch.zeros(lm_model.n_units, device=p.device, dtype=p.dtype) for _ in range(len(lm_model.rnn))]
-        return state
-
-    @staticmethod
-    def _lm_batch(states):
-        return {k: [torch.stack([s[k][layer] for s in states]) for layer in range(len(states[0][k]))] for k in states[0]}
-
-    @staticmethod
-    def _lm_select(states, idx):
-        return {k: [v[layer][idx] for layer in range(len(v))] for k, v in states.items()}
-
-    def _joint_logp(self, h_enc, beam_y):
-        """h_enc (n, D_enc) or (1, D_enc), beam_y (n, D_dec) -> log-softmax of the joint outputs (n, V): the n
-        (frame, hypothesis) pairs as one batch through lin_enc / lin_dec / the joint kernel / lin_out"""
-        from .. import functional as F_
-        from .. import rnn_functional as R_
-        jn = self.decoder.joint_network
-        n = beam_y.shape[0]
-        enc = jn.project_enc(h_enc)
-        if enc.shape[0] != n:
-            enc = enc.expand(n, -1).contiguous()
-        d = F_.LinearFn.apply(beam_y.contiguous(), jn.lin_dec.weight, None)
-        z = R_.JointFn.apply(enc.view(n, 1, -1).contiguous(), d.view(n, 1, -1), jn.act_id)
-        logits = F_.LinearFn.apply(z.reshape(n, -1), jn.lin_out.weight, jn.lin_out.bias)
-        return ops.log_softmax_rows(logits.contiguous())
-
-    def time_sync_decoding(self, h):
-        """reference: beam_search_transducer.py:238-350 (https://ieeexplore.ieee.org/document/9053040)"""
-        import numpy as np
-        beam = min(self.beam_size, self.vocab_size)
-        init_tensor = h.unsqueeze(0)
-        beam_state = self.decoder.init_state(torch.zeros((beam, self.hidden_size), device=h.device))
-        B = [Hypothesis(yseq=[self.blank], score=0.0, dec_state=self.decoder.select_state(beam_state, 0))]
-        if self.lm:
-            B[0].lm_state = self._lm_init()
-        cache = {}
-        for t in range(h.shape[0]):
-            A = []
-            C = B
-            h_enc = h[t].unsqueeze(0)
-            for v in range(self.max_sym_exp):
-                D = []
-                beam_y, beam_state, beam_lm_tokens = self.decoder.batch_score(C, beam_state, cache, init_tensor)
-                beam_logp = self._joint_logp(h_enc, beam_y)
-                top_v, top_i = beam_logp[:, 1:].topk(beam, dim=-1)
-                blank_lp, top_v, top_i = beam_logp[:, 0].tolist(), top_v.tolist(), (top_i + 1).tolist()
-                seq_A = [hy.yseq for hy in A]
-                for i, hyp in enumerate(C):
-                    if hyp.yseq not in seq_A:
-                        A.append(Hypothesis(score=(hyp.score + blank_lp[i]), yseq=hyp.yseq[:], dec_state=hyp.dec_state,
-                                            lm_state=hyp.lm_state))
-                    else:
-                        pos = seq_A.index(hyp.yseq)
-                        A[pos].score = np.logaddexp(A[pos].score, (hyp.score + blank_lp[i]))
-                if v < self.max_sym_exp:
-                    if self.lm:
-                        beam_lm_states, beam_lm_scores = self.lm.buff_predict(
-                            self._lm_batch([c.lm_state for c in C]), beam_lm_tokens, len(C))
-                        lm_host = beam_lm_scores.tolist()
-                    for i, hyp in enumerate(C):
-                        for logp, k in zip(top_v[i], top_i[i]):
-                            new_hyp = Hypothesis(score=(hyp.score + float(logp)), yseq=(hyp.yseq + [int(k)]),
-                                                 dec_state=self.decoder.select_state(beam_state, i), lm_state=hyp.lm_state)
-                            if self.lm:
-                                new_hyp.score += self.lm_weight * lm_host[i][k]
-                                new_hyp.lm_state = self._lm_select(beam_lm_states, i)
-                            D.append(new_hyp)
-                C = sorted(D, key=lambda x: x.score, reverse=True)[:beam]
-            B = sorted(A, key=lambda x: x.score, reverse=True)[:beam]
-        return self.sort_nbest(B)
-
-    def align_length_sync_decoding(self, h):
-        """reference: beam_search_transducer.py:352-462 (https://ieeexplore.ieee.org/document/9053040)"""
-        import numpy as np
-        beam = min(self.beam_size, self.vocab_size)
-        h_length = int(h.size(0))
-        u_max = min(self.u_max, (h_length - 1))
-        init_tensor = h.unsqueeze(0)
-        beam_state = self.decoder.init_state(torch.zeros((beam, self.hidden_size), device=h.device))
-        B = [Hypothesis(yseq=[self.blank], score=0.0, dec_state=self.decoder.select_state(beam_state, 0))]
-        final = []
-        if self.lm:
-            B[0].lm_state = self._lm_init()
-        cache = {}
-        for i in range(h_length + u_max):
-            A, B_, h_states = [], [], []
-            for hyp in B:
-                u = len(hyp.yseq) - 1
-                t = i - u + 1
-                if t > (h_length - 1):
-                    continue
-                B_.append(hyp)
-                h_states.append((t, h[t]))
-            if B_:
-                beam_y, beam_state, beam_lm_tokens = self.decoder.batch_score(B_, beam_state, cache, init_tensor)
-                h_enc = torch.stack([hs[1] for hs in h_states])
-                beam_logp = self._joint_logp(h_enc, beam_y)
-                top_v, top_i = beam_logp[:, 1:].topk(beam, dim=-1)
-                blank_lp, top_v, top_i = beam_logp[:, 0].tolist(), top_v.tolist(), (top_i + 1).tolist()
-                if self.lm:
-                    beam_lm_states, beam_lm_scores = self.lm.buff_predict(
-                        self._lm_batch([b.lm_state for b in B_]), beam_lm_tokens, len(B_))
-                    lm_host = beam_lm_scores.tolist()
-                for j, hyp in enumerate(B_):
-                    new_hyp = Hypothesis(score=(hyp.score + blank_lp[j]), yseq=hyp.yseq[:], dec_state=hyp.dec_state,
-                                         lm_state=hyp.lm_state)
-                    A.append(new_hyp)
-                    if h_states[j][0] == (h_length - 1):
-                        final.append(new_hyp)
-                    for logp, k in zip(top_v[j], top_i[j]):
-                        new_hyp = Hypothesis(score=(hyp.score + float(logp)), yseq=(hyp.yseq[:] + [int(k)]),
-                                             dec_state=self.decoder.select_state(beam_state, j), lm_state=hyp.lm_state)
-                        if self.lm:
-                            new_hyp.score += self.lm_weight * lm_host[j][k]
-                            new_hyp.lm_state = self._lm_select(beam_lm_states, j)
-                        A.append(new_hyp)
-                B = sorted(A, key=lambda x: x.score, reverse=True)[:beam]
-                # recombine_hyps (transducer/utils.py:181-203): scores of equal sequences are merged into the first one,
-                # the list itself is returned unchanged
-                firsts = []
-                for hyp in B:
-                    seqs = [f.yseq for f in firsts if f.yseq]
-                    if hyp.yseq in seqs:
-                        f = firsts[seqs.index(hyp.yseq)]
-                        f.score = np.logaddexp(f.score, hyp.score)
-                    else:
-                        firsts.append(hyp)
-        if final:
-            return self.sort_nbest(final)
-        return B
-
-    def nsc_beam_search(self, h):
-        """N-step constrained beam search.  reference: beam_search_transducer.py:464-662
-        (https://arxiv.org/pdf/2002.03577.pdf as modified there)"""
-        import numpy as np
-        beam = min(self.beam_size, self.vocab_size)
-        beam_k = min(beam, (self.vocab_size - 1))
-        jn = self.decoder.joint_network
-        init_tensor = h.unsqueeze(0)
-        beam_state = self.decoder.init_state(torch.zeros((beam, self.hidden_size), device=h.device))
-        init_tokens = [Hypothesis(yseq=[self.blank], score=0.0, dec_state=self.decoder.select_state(beam_state, 0))]
-        cache = {}
-        beam_y, beam_state, beam_lm_tokens = self.decoder.batch_score(init_tokens, beam_state, cache, init_tensor)
-        state = self.decoder.select_state(beam_state, 0)
-        lm_state = lm_scores = None
-        if self.lm:
-            beam_lm_states, beam_lm_scores = self.lm.buff_predict(None, beam_lm_tokens, 1)
-            lm_state = self._lm_select(beam_lm_states, 0)
-            lm_scores = beam_lm_scores[0]
-        kept_hyps = [Hypothesis(yseq=[self.blank], score=0.0, dec_state=state, y=[beam_y[0]], lm_state=lm_state,
-                                lm_scores=lm_scores)]
-        enc_proj = jn.project_enc(h)
-
-        def is_prefix(x, pref):
-            return len(pref) < len(x) and all(pref[i] == x[i] for i in range(len(pref)))
-
-        for t in range(h.shape[0]):
-            hyps = sorted(kept_hyps, key=lambda x: len(x.yseq), reverse=True)
-            kept_hyps = []
-            h_enc = h[t].unsqueeze(0)
-            for j in range(len(hyps) - 1):       # prefix search: a longer hypothesis also collects its prefixes' mass
-                for i in range((j + 1), len(hyps)):
-                    if is_prefix(hyps[j].yseq, hyps[i].yseq) and \
-                            (len(hyps[j].yseq) - len(hyps[i].yseq)) <= self.prefix_alpha:
-                        next_id = len(hyps[i].yseq)
-                        ytu = _log_softmax(jn.joint_step(enc_proj[t], hyps[i].y[-1]))
-                        curr_score = hyps[i].score + float(ytu[hyps[j].yseq[next_id]])
-                        for k in range(next_id, (len(hyps[j].yseq) - 1)):
-                            ytu = _log_softmax(jn.joint_step(enc_proj[t], hyps[j].y[k]))
-                            curr_score += float(ytu[hyps[j].yseq[k + 1]])
-                        hyps[j].score = np.logaddexp(hyps[j].score, curr_score)
-            S, V = [], []
-            for n in range(self.nstep):
-                beam_y = torch.stack([hyp.y[-1] for hyp in hyps])
-                beam_logp = self._joint_logp(h_enc, beam_y)
-                top_v, top_i = beam_logp[:, 1:].topk(beam_k, dim=-1)
-                blank_lp, top_v, top_i = beam_logp[:, 0].tolist(), top_v.tolist(), (top_i + 1).tolist()
-                if self.lm:
-                    lm_host = torch.stack([hyp.lm_scores for hyp in hyps]).tolist()
-                for i, hyp in enumerate(hyps):
-                    for logp, k in list(zip(top_v[i], top_i[i])) + [(blank_lp[i], self.blank)]:
-                        new_hyp = Hypothesis(yseq=hyp.yseq[:], score=(hyp.score + float(logp)), y=hyp.y[:],
-                                             dec_state=hyp.dec_state, lm_state=hyp.lm_state, lm_scores=hyp.lm_scores)
-                        if k == self.blank:
-                            S.append(new_hyp)
-                        else:
-                            new_hyp.yseq.append(int(k))
-                            if self.lm:
-                                new_hyp.score += self.lm_weight * float(lm_host[i][k])
-                        V.append(new_hyp)       # blank extensions too: `substract` drops them again (same yseq as a parent)
-                V = sorted(V, key=lambda x: x.score, reverse=True)
-                V = [v for v in V if not any(v.yseq == hy.yseq for hy in hyps)][:beam]
-                beam_state = self.decoder.create_batch_states(beam_state, [v.dec_state for v in V], [v.yseq for v in V])
-                beam_y, beam_state, beam_lm_tokens = self.decoder.batch_score(V, beam_state, cache, init_tensor)
-                if self.lm:
-                    beam_lm_states, beam_lm_scores = self.lm.buff_predict(self._lm_batch([v.lm_state for v in V]),
-                                                                           beam_lm_tokens, len(V))
-                if n < (self.nstep - 1):
-                    for i, v in enumerate(V):
-                        v.y.append(beam_y[i])
-                        v.dec_state = self.decoder.select_state(beam_state, i)
-                        if self.lm:
-                            v.lm_state = self._lm_select(beam_lm_states, i)
-                            v.lm_scores = beam_lm_scores[i]
-                    hyps = V[:]
-                else:
-                    last_blank = self._joint_logp(h_enc, beam_y)[:, 0].tolist()
-                    for i, v in enumerate(V):
-                        if self.nstep != 1:
-                            v.score += float(last_blank[i])
-                        v.y.append(beam_y[i])
-                        v.dec_state = self.decoder.select_state(beam_state, i)
-                        if self.lm:
-                            v.lm_state = self._lm_select(beam_lm_states, i)
-                            v.lm_scores = beam_lm_scores[i]
-            kept_hyps = sorted((S + V), key=lambda x: x.score, reverse=True)[:beam]
-        return self.sort_nbest(kept_hyps)

@@ -31,6 +31,18 @@ class JointNetwork(torch.nn.Module):
         z = R_.JointFn.apply(enc_proj_t.reshape(1, 1, -1).contiguous(), d.reshape(1, 1, -1), self.act_id)
         return F_.LinearFn.apply(z.reshape(1, -1), self.lin_out.weight, self.lin_out.bias).reshape(-1)
 
+    def joint_rows(self, enc_proj_rows, y_rows):
+        """decoding on rows: enc_proj_rows (n, J) projected encoder frames, y_rows (n, D_dec) or (1, D_dec) prediction
+        outputs (one output against every frame) -> logits (n, V): one lin_dec GEMM, one fused add + activation, one
+        lin_out GEMM for all n (frame, hypothesis) pairs"""
+        n = enc_proj_rows.shape[0]
+        d = F_.LinearFn.apply(y_rows.contiguous(), self.lin_dec.weight, None)
+        if d.shape[0] == 1:
+            z = R_.JointFn.apply(enc_proj_rows.contiguous().view(1, n, -1), d.view(1, 1, -1), self.act_id)
+        else:
+            z = R_.JointFn.apply(enc_proj_rows.contiguous().view(n, 1, -1), d.view(n, 1, -1), self.act_id)
+        return F_.LinearFn.apply(z.reshape(n, -1), self.lin_out.weight, self.lin_out.bias)
+
     def forward(self, h_enc, h_dec):
         """h_enc (B,T,1,D_enc) or (B,T,D_enc); h_dec (B,1,U,D_dec) or (B,U,D_dec)"""
         if h_enc.dim() == 1 and h_dec.dim() == 1:      # decoding: one frame, one prediction-network output

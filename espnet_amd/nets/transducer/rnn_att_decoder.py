@@ -88,22 +88,3 @@ class DecoderRNNTAtt(torch.nn.Module):
             state = (dec_state, att_w)
             cache[str_yseq] = (y, state)
         return y, state, vy[0]
-
-    def batch_score(self, hyps, batch_states, cache, init_tensor):
-        raise NotImplementedError("rnnt-att: the batched searches (tsd / alsd / nsc) are not on the HIP path; the reference's "
-                                  "own batch_score feeds the attention a fresh zero state (rnn_att_decoder.py:252-262)")
-
-    def select_state(self, batch_states, idx):
-        """rnn_att_decoder.py:283-306"""
-        z_list = [batch_states[0][0][layer][idx] for layer in range(self.dlayers)]
-        c_list = [batch_states[0][1][layer][idx] for layer in range(self.dlayers)]
-        att_state = batch_states[1][idx] if batch_states[1] is not None else batch_states[1]
-        return ((z_list, c_list), att_state)
-
-    def create_batch_states(self, batch_states, l_states, l_tokens=None):
-        """rnn_att_decoder.py:308-336"""
-        for layer in range(self.dlayers):
-            batch_states[0][0][layer] = torch.stack([s[0][0][layer] for s in l_states])
-            batch_states[0][1][layer] = torch.stack([s[0][1][layer] for s in l_states])
-        att_states = torch.stack([s[1] for s in l_states]) if l_states[0][1] is not None else None
-        return (batch_states[0], att_states)

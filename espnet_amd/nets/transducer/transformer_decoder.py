@@ -92,48 +92,3 @@ class DecoderTT(torch.nn.Module):
             y, new_state = self._step(tgt, state)
             cache[str_yseq] = (y, new_state)
         return y, new_state, lm_tokens
-
-    def batch_score(self, hyps, batch_states, cache, init_tensor=None):
-        """reference: transformer_decoder.py:158-236 (prefixes of unequal length are left-padded with blank)"""
-        dev = self.after_norm.weight.device
-        final_batch = len(hyps)
-        tokens, process = [], []
-        done = [None] * final_batch
-        for i, hyp in enumerate(hyps):
-            str_yseq = "".join([str(x) for x in hyp.yseq])
-            if str_yseq in cache:
-                done[i] = (*cache[str_yseq], hyp.yseq)
-            else:
-                tokens.append(hyp.yseq)
-                process.append((str_yseq, hyp.dec_state, hyp.yseq))
-        if process:
-            batch = len(tokens)
-            tokens = pad_sequence(tokens, self.blank)
-            b_tokens = torch.tensor(tokens, dtype=torch.long).to(dev).view(batch, -1)
-            dec_state = self.create_batch_states(self.init_state(), [p[1] for p in process], tokens)
-            tgt, next_state = self._step(b_tokens, dec_state)
-        j = 0
-        for i in range(final_batch):
-            if done[i] is None:
-                new_state = self.select_state(next_state, j)
-                done[i] = (tgt[j], new_state, process[j][2])
-                cache[process[j][0]] = (tgt[j], new_state)
-                j += 1
-        batch_states = self.create_batch_states(batch_states, [d[1] for d in done], [d[2] for d in done])
-        batch_y = torch.stack([d[0] for d in done])
-        lm_tokens = torch.tensor([h.yseq[-1] for h in hyps], dtype=torch.long).to(dev).view(final_batch)
-        return batch_y, batch_states, lm_tokens
-
-    def select_state(self, batch_states, idx):
-        """reference: transformer_decoder.py:238-258"""
-        if batch_states[0] is not None:
-            return [batch_states[layer][idx] for layer in range(len(self.decoders))]
-        return batch_states
-
-    def create_batch_states(self, batch_states, l_states, l_tokens):
-        """reference: transformer_decoder.py:260-283"""
-        if batch_states[0] is not None:
-            max_len = max(len(t) for t in l_tokens)
-            for layer in range(len(self.decoders)):
-                batch_states[layer] = pad_batch_state([s[layer] for s in l_states], max_len, self.blank)
-        return batch_states
