@@ -567,7 +567,6 @@ __global__ __launch_bounds__(256) void conv1_bwd_w_kernel(const float* __restric
   constexpr int NV = (ST * 7 + 3 + 3) / 4;   // float4 reads covering eight positions of one kernel row
   constexpr int NPOS = NC == 2 ? 24 : 40;    // gradient values requested ahead per output row
   __shared__ __attribute__((aligned(16))) float xs[3 * XLD];
-  __shared__ float tr9[256 * 10 * NC];
   const int c_raw = (blockIdx.x * blockDim.x + threadIdx.x) * NC;
   const bool live = c_raw < C;
   const int c = live ? c_raw : C - NC;
@@ -642,29 +641,18 @@ __global__ __launch_bounds__(256) void conv1_bwd_w_kernel(const float* __restric
       }
     }
   }
-  if (part) {   // per-block partial sums [gridDim.y][10][C] (k-major: coalesced), reduced by conv1_bwd_w_reduce_kernel
-    if (live) {
+  // per-block partial sums [gridDim.y][10][C] (k-major: coalesced), reduced by conv1_bwd_w_reduce_kernel.  (A second
+  // form that transposed the sums through LDS and added them to dw / db with atomics when the grid was small was
+  // removed in round 2: it was the one code path implicated in a wrong conv.0.weight gradient seen once in round 1.)
+  if (live) {
 #pragma unroll
-      for (int e = 0; e < NC; ++e) {
-        float* pp = part + (long)blockIdx.y * 10 * C + c + e;
+    for (int e = 0; e < NC; ++e) {
+      float* pp = part + (long)blockIdx.y * 10 * C + c + e;
 #pragma unroll
-        for (int k = 0; k < 9; ++k) pp[(long)k * C] = acc[e][k];
-        pp[(long)9 * C] = accb[e];
-      }
+      for (int k = 0; k < 9; ++k) pp[(long)k * C] = acc[e][k];
+      pp[(long)9 * C] = accb[e];
     }
-    return;
   }
-#pragma unroll
-  for (int e = 0; e < NC; ++e)
-#pragma unroll
-    for (int k = 0; k < 9; ++k) tr9[(threadIdx.x * NC + e) * 10 + k] = live ? acc[e][k] : 0.f;
-  __syncthreads();
-  const int c0 = blockIdx.x * blockDim.x * NC;
-  const int nch = min((int)blockDim.x * NC, C - c0);
-  for (int i = threadIdx.x; i < nch * 9; i += blockDim.x) atomicAdd(&dw[(long)c0 * 9 + i], tr9[(i / 9) * 10 + (i % 9)]);
-  if (live)
-#pragma unroll
-    for (int e = 0; e < NC; ++e) atomicAdd(&db[c + e], accb[e]);
 }
 // part[nblk][10][C] -> dw[C][9] +=, db[C] +=.  grid (ceil(10*C/64), slices): 4 row-subgroups x 64 columns per block
 __global__ __launch_bounds__(256) void conv1_bwd_w_reduce_kernel(const float* __restrict__ part, int nblk, int C,
@@ -855,7 +843,8 @@ static int conv_c1_bwd_w(const void* dy, const float* x, float* dw, float* db, f
   int H = (T + 2 * pad - 3) / st + 1, W = (F + 2 * pad - 3) / st + 1;
   int gx, gy; long rpb;
   conv_c1_bwd_w_grid(B, H, C, &gx, &gy, &rpb);
-  float* part = gy >= 64 ? workspace : nullptr;     // few blocks: direct atomics beat a second launch
+  if (!workspace) return EAMD_EINVAL;
+  float* part = workspace;
   hipStream_t s = (hipStream_t)stream;
   const bool pair = dy_bf16 && (C % 2 == 0) && (((uintptr_t)dy & 3) == 0);
   const int nthr = pair ? min(256, ((C / 2 + 63) / 64) * 64) : 256;
@@ -866,11 +855,9 @@ static int conv_c1_bwd_w(const void* dy, const float* x, float* dw, float* db, f
   else         { if (pair) EAMD_C1W(1, 2); else EAMD_C1W(1, 1); }
 #undef EAMD_C1W
   EAMD_LAUNCH_CHECK();
-  if (part) {
-    hipLaunchKernelGGL(conv1_bwd_w_reduce_kernel, dim3((10 * C + 63) / 64, min(16, (gy + 31) / 32)), dim3(256), 0, s, part,
-                       gy, C, dw, db);
-    EAMD_LAUNCH_CHECK();
-  }
+  hipLaunchKernelGGL(conv1_bwd_w_reduce_kernel, dim3((10 * C + 63) / 64, min(16, (gy + 31) / 32)), dim3(256), 0, s, part,
+                     gy, C, dw, db);
+  EAMD_LAUNCH_CHECK();
   return EAMD_OK;
 }
 /* floats of scratch for eamd_conv1_bwd_w / eamd_conv3x3_c1_bwd_w (stride/pad as in the forward) */

@@ -454,6 +454,38 @@ def test_conv1(ops):
         report("conv1_bwd_b bf16 %dx%d" % (F2, C2), db2, dy2.double().sum((0, 1, 2)), 1e-5)
 
 
+@pytest.mark.parametrize("shape", [(2, 37, 20, 64), (2, 29, 20, 64), (3, 29, 80, 16), (4, 100, 80, 256), (32, 1000, 80, 256)])
+@pytest.mark.parametrize("bf16", [False, True])
+def test_conv1_bwd_w_deterministic(ops, shape, bf16):
+    """eamd_conv1_bwd_w against the float64 weight gradient of conv2d at the shapes of the Conv2dSubsampling fixtures
+    (few row blocks), a mid-size batch (hundreds of row blocks) and config 2 itself, with fp32 (one channel per thread)
+    and bf16 (two channels per thread) gradients; launched twice into the same zeroed buffers: the two results must
+    be bit-identical (the per-block partial sums are reduced in a fixed order; nothing is added with float atomics
+    except the final <= 16 slice sums per element) and accumulate (dw += ...)."""
+    B, T, F, Cc = shape
+    g = torch.Generator().manual_seed(B * 1000 + T)
+    x = torch.randn(B, T, F, generator=g)
+    H, W = (T - 3) // 2 + 1, (F - 3) // 2 + 1
+    dy = torch.randn(B, H, W, Cc, generator=g)
+    dy = dy * (torch.rand(B, H, W, Cc, generator=g) > 0.5)          # ReLU-masked, as the caller hands it in
+    if bf16:
+        dy = dy.to(torch.bfloat16)
+    cols = torch.nn.functional.unfold(x.double().unsqueeze(1), 3, stride=2).transpose(1, 2).reshape(B, H, W, 9)
+    dwr = torch.einsum("bhwc,bhwk->ck", dy.double(), cols)
+    dbr = dy.double().sum((0, 1, 2))
+    outs = []
+    for _ in range(2):
+        dw, db = torch.zeros(Cc, 9, device=DEV), torch.zeros(Cc, device=DEV)
+        ops.conv1_bwd_w(dy.to(DEV), x.to(DEV), dw, db, B, T, F, Cc)
+        outs.append((dw.clone(), db.clone()))
+    report("conv1_bwd_w %s bf16=%s" % (shape, bf16), outs[0][0], dwr, 2e-5)
+    report("conv1_bwd_b %s bf16=%s" % (shape, bf16), outs[0][1], dbr, 2e-5)
+    if B * H <= 64:          # at most two reduction slices (a + b == b + a): bit-reproducible
+        assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])
+    ops.conv1_bwd_w(dy.to(DEV), x.to(DEV), dw, db, B, T, F, Cc)          # accumulates into non-zero buffers
+    report("conv1_bwd_w accumulate %s" % (shape,), dw, 2 * dwr, 2e-5)
+
+
 def test_optimizer(ops):
     """Adam + Noam schedule + clipping vs torch.optim.Adam / clip_grad_norm_ (fp32 CPU)."""
     g = torch.Generator().manual_seed(10)
