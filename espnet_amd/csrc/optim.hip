@@ -105,9 +105,40 @@ __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, const 
   }
 }
 
+// g[i] += sigma * N(0, 1): counter-based normals (Box-Muller over two 32-bit hashes of the element-pair index, the
+// dropout generator's seed derivation), so that the launch is graph-replayable: the device step counter advances the
+// stream of draws.  reference: espnet2/torch_utils/add_gradient_noise.py:4-31 (param.grad += sigma * randn).
+__global__ __launch_bounds__(256) void grad_noise_kernel(float* __restrict__ g, long n, float sigma,
+                                                         const unsigned long long* __restrict__ step,
+                                                         unsigned long long salt) {
+  const unsigned s0 = eamd_drop_seed(step, salt), s1 = eamd_drop_seed(step, salt ^ 0x5bd1e995ULL);
+  const long stride = (long)gridDim.x * blockDim.x;
+  const long np = (n + 1) / 2;
+  for (long q = (long)blockIdx.x * blockDim.x + threadIdx.x; q < np; q += stride) {
+    const unsigned h0 = eamd_drop_pair(s0, (unsigned long long)q), h1 = eamd_drop_pair(s1, (unsigned long long)q);
+    const float u0 = ((float)h0 + 1.0f) * 2.3283064365386963e-10f;      // (0, 1]
+    const float u1 = (float)h1 * 2.3283064365386963e-10f;               // [0, 1)
+    const float r = sigma * sqrtf(-2.0f * __logf(u0));
+    float sn, cs;
+    __sincosf(6.283185307179586f * u1, &sn, &cs);
+    g[2 * q] += r * cs;
+    if (2 * q + 1 < n) g[2 * q + 1] += r * sn;
+  }
+}
+
 }  // namespace
 
 extern "C" {
+
+int eamd_add_gradient_noise(float* g, int64_t n, float sigma, const uint64_t* step_dev, uint64_t salt, void* stream) {
+  if (!g || n <= 0 || !(sigma >= 0.f)) return EAMD_EINVAL;
+  long want = ((n + 1) / 2 + 255) / 256;
+  int nblk = (int)(want < 1 ? 1 : (want > 4096 ? 4096 : want));
+  hipLaunchKernelGGL(grad_noise_kernel, dim3(nblk), dim3(256), 0, (hipStream_t)stream, g, (long)n, sigma,
+                     (const unsigned long long*)step_dev, (unsigned long long)salt);
+  EAMD_LAUNCH_CHECK();
+  return EAMD_OK;
+}
 
 /* gnorm_out[0] = ||g||_2 ; workspace >= 1024 floats */
 int eamd_grad_norm(const float* g, int64_t n, float* workspace, float* gnorm_out, void* stream) {

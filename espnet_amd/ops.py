@@ -784,6 +784,12 @@ def adam_step(p, g, m, v, state, beta1, beta2, eps, weight_decay, p16=None):
           "eamd_adam_step")
 
 
+def add_gradient_noise(g, sigma, salt=0x6e6f697365):
+    """g += sigma * N(0, 1) over a flat fp32 gradient buffer (draws keyed by the device step counter)"""
+    check(_lib.lib().eamd_add_gradient_noise(ptr(g), C.c_int64(g.numel()), C.c_float(sigma), ptr(rng_state(g.device)),
+                                             C.c_uint64(salt), stream_ptr()), "eamd_add_gradient_noise")
+
+
 def make_gather(Cc, taps, Ho, Wo, Hin, Win, sh, sw):
     g = GatherT()
     g.enabled = 1

@@ -381,6 +381,202 @@ class GraphedDataParallelStep:
         return self.loss
 
 
+class EpochRunner:
+    """espnet2 Trainer.train_one_epoch / validate_one_epoch semantics for one process per GPU
+    (reference: espnet2/train/trainer.py:325-495,497-539; recursive_average, torch_utils/recursive_op.py:14-53).
+
+    Per micro-step the reference issues EIGHT small collectives (iterator-stop flag, five weighted statistics, the
+    weight sum) around a blocking forward; here ONE 8-float vector per micro-step carries all of it:
+
+        [ stop flag of THIS rank for the NEXT batch, weight of the NEXT batch,
+          weight, weight * loss, weight * loss_att, weight * loss_ctc, weight * acc of the batch just finished, spare ]
+
+    The iterator is read one batch ahead, so the vector of micro-step k is known before its forward starts; it is
+    all-reduced (SUM) asynchronously under the forward pass, and what the host needs of it before the NEXT step (the
+    stop flag) has long arrived by then.  On the device the all-reduced weight sum W gives the backward scale
+    w / (W * accum_grad) without a host sync: with SUM all-reduce of the gradients this is exactly the reference's
+    loss * weight / W * world_size / accum_grad under DistributedDataParallel's 1 / world_size averaging.
+
+    Gradients accumulate in the flat arena over `accum_grad` micro-steps and are all-reduced once at the boundary
+    (linear: same sum as the reference's per-micro-step DDP reduction), then gradient noise (optional), global-norm
+    clipping, the non-finite skip, Adam and the scheduler run on the device (NoamAdam.step), then the arena is zeroed.
+
+    The model-specific part is injected: `forward(batch) -> (loss 0-dim tensor, {name: 0-dim tensor}, weight float)`;
+    `backward(loss, scale 0-dim tensor)`.  Defaults drive the espnet1 E2E / espnet2 ESPnetASRModel shells."""
+
+    NSTAT = 8
+
+    def __init__(self, model, flat, opt, accum_grad=1, grad_noise=False, group=None, forward=None, backward=None,
+                 reduce_grads=None, pre_step=None, bucket_mb=128.0):
+        import torch.distributed as dist
+        self.dist, self.group = dist, group
+        self.distributed = dist.is_available() and dist.is_initialized()
+        self.world = dist.get_world_size(group) if self.distributed else 1
+        self.model, self.flat, self.opt = model, flat, opt
+        self.accum_grad, self.grad_noise = int(accum_grad), bool(grad_noise)
+        self.forward = forward or self._forward_default
+        self.backward = backward or (lambda loss, scale: loss.backward(scale))
+        self.reduce_grads = reduce_grads or self._reduce_default
+        self.pre_step = pre_step or (lambda: ops.rng_advance(flat.data.device))     # new dropout masks per micro-step
+        self.cap = max(1, int(bucket_mb * 1024 * 1024 // 4))
+        self.dev = flat.data.device
+        self.total_count = 0          # reporter.get_total_count(): optimizer-step attempts so far (gradient-noise decay)
+        self.history = []             # averaged statistics of every finished micro-step (device tensors, read lazily)
+
+    # ---- defaults for the model shells of this package ----
+    def _forward_default(self, batch):
+        m = self.model
+        if isinstance(batch, dict) and "speech" in batch:          # espnet2 ESPnetASRModel
+            loss, stats, weight = m(**batch)
+            return loss.reshape(()), {k: v.reshape(()) for k, v in stats.items() if v is not None and k != "loss"}, float(weight)
+        loss = m.forward_core(batch) if isinstance(batch, dict) else m(*batch)
+        stats = {}
+        if getattr(m, "_loss_att_t", None) is not None:
+            stats["loss_att"] = m._loss_att_t
+        if getattr(m, "_loss_ctc_t", None) is not None:
+            stats["loss_ctc"] = m._loss_ctc_t
+        if getattr(m, "_acc_t", None) is not None:
+            stats["acc"] = m._acc_t
+        B = batch["B"] if isinstance(batch, dict) else batch[0].shape[0]
+        return loss, stats, float(B)
+
+    def _reduce_default(self):
+        if not self.distributed or self.world == 1:
+            return
+        g = self.flat.grad
+        works = [self.dist.all_reduce(g[s:s + self.cap], op=self.dist.ReduceOp.SUM, group=self.group, async_op=True)
+                 for s in range(0, g.numel(), self.cap)]
+        for w in works:
+            w.wait()
+
+    # ---- the fused control / statistics vector ----
+    def _send(self, stop, weight_next, pending):
+        """all-reduce (SUM) [stop, weight_next, *pending[2:]] off the critical path: on a side stream (device runs) the
+        collective and the 2-float device-to-host copy wait only for the kernels that produced `pending`, not for
+        whatever the main stream has queued since; -> a ticket for _recv()"""
+        if self.dev.type != "cuda":
+            vec = pending.clone()
+            vec[0], vec[1] = stop, weight_next
+            if self.distributed and self.world > 1:
+                self.dist.all_reduce(vec, op=self.dist.ReduceOp.SUM, group=self.group)
+            return (vec, None, None)
+        if getattr(self, "_side", None) is None:
+            self._side = torch.cuda.Stream(device=self.dev)
+        side = self._side
+        side.wait_stream(torch.cuda.current_stream(self.dev))      # `pending` was written on the main stream
+        pending.record_stream(side)
+        with torch.cuda.stream(side):
+            vec = pending.clone()
+            vec[:2] = torch.tensor([stop, weight_next], dtype=vec.dtype).to(self.dev, non_blocking=True)
+            if self.distributed and self.world > 1:
+                self.dist.all_reduce(vec, op=self.dist.ReduceOp.SUM, group=self.group, async_op=True).wait()
+            host = torch.empty(2, dtype=vec.dtype, pin_memory=True)
+            host.copy_(vec[:2], non_blocking=True)
+            ev = torch.cuda.Event()
+            ev.record(side)
+        return (vec, host, ev)
+
+    @staticmethod
+    def _recv(ticket):
+        """-> (stop-flag sum, weight sum) as python floats; the only host wait of a micro-step"""
+        vec, host, ev = ticket
+        if ev is None:
+            return vec[:2].tolist()
+        ev.synchronize()
+        return host.tolist()
+
+    @staticmethod
+    def _next(it):
+        try:
+            return next(it)
+        except StopIteration:
+            return None
+
+    @staticmethod
+    def _weight_of(batch):
+        if batch is None:
+            return 0.0
+        if isinstance(batch, dict):
+            return float(batch["speech"].shape[0] if "speech" in batch else batch["B"])
+        return float(batch[0].shape[0])
+
+    def _run(self, iterator, train):
+        it = iter(iterator)
+        dev = self.dev
+        keys = ("loss", "loss_att", "loss_ctc", "acc")
+        zero = torch.zeros(self.NSTAT, device=dev)
+        cur = self._next(it)
+        ticket = self._send(1.0 if cur is None else 0.0, self._weight_of(cur), zero)       # about the first batch
+        tickets = []
+        iiter = 0
+        skipped0 = self.opt.stats()["skipped"] if train else 0
+        if train:
+            self.flat.zero_grad()
+        pending = zero
+        while True:
+            stop, wsum = self._recv(ticket)
+            if stop > 0:                                # some rank ran out of data: every rank stops here (trainer.py:369-372)
+                break
+            batch, cur = cur, self._next(it)            # read one batch ahead
+            # about the NEXT batch + the statistics of the PREVIOUS micro-step; travels under this step's kernels
+            ticket = self._send(1.0 if cur is None else 0.0, self._weight_of(cur), pending)
+            if iiter > 0:
+                tickets.append(ticket)
+            iiter += 1
+            w = self._weight_of(batch)
+            if train:
+                self.pre_step()
+                loss, stats, _w = self.forward(batch)
+                self.backward(loss, torch.full((), w / (wsum * self.accum_grad), device=dev, dtype=loss.dtype))
+                ops.wgrad_join()
+            else:
+                with torch.no_grad():
+                    loss, stats, _w = self.forward(batch)
+            parts = [torch.zeros((), device=dev)] * 2 + [torch.full((), w, device=dev), loss.detach().float() * w]
+            parts += [(stats[k].detach().float() * w if k in stats else torch.zeros((), device=dev)) for k in keys[1:]]
+            pending = torch.stack(parts + [torch.zeros((), device=dev)])
+            if train and iiter % self.accum_grad == 0:
+                self.reduce_grads()
+                if self.grad_noise:
+                    # add_gradient_noise.py:4-31 with the reference's call-site constants (trainer.py:420-427)
+                    ops.add_gradient_noise(self.flat.grad, 1.0 / ((self.total_count // 100) + 1) ** 0.55)
+                self.opt.step()                          # clip, non-finite skip, Adam, scheduler: all on the device
+                self.flat.zero_grad()
+                self.total_count += 1
+        if iiter > 0:                                    # statistics of the last micro-step: one more (blocking) exchange
+            tickets.append(self._send(0.0, 0.0, pending))
+        if dev.type == "cuda":
+            torch.cuda.current_stream(dev).wait_stream(self._side)
+        self.history = [{k: t[0][3 + i] / t[0][2].clamp_min(1e-30) for i, k in enumerate(keys)} | {"weight": t[0][2]}
+                        for t in tickets]
+        if not train:
+            return None
+        nsteps = iiter // self.accum_grad
+        return nsteps == 0 or (self.opt.stats()["skipped"] - skipped0) >= nsteps
+
+    def train_one_epoch(self, iterator):
+        """-> all_steps_are_invalid (trainer.py:495)"""
+        self.model.train()
+        self.history = []
+        return self._run(iterator, True)
+
+    def validate_one_epoch(self, iterator):
+        """no-grad pass in eval mode; -> list of per-batch averaged statistics (trainer.py:497-539)"""
+        self.model.eval()
+        self.history = []
+        self._run(iterator, False)
+        return self.history
+
+    def averaged(self):
+        """weighted mean of the recorded statistics over the epoch, as python floats (one host copy)"""
+        if not self.history:
+            return {}
+        keys = [k for k in self.history[0] if k != "weight"]
+        tab = torch.stack([torch.stack([h[k] for k in keys] + [h["weight"]]) for h in self.history]).tolist()
+        wsum = sum(r[-1] for r in tab)
+        return {k: sum(r[i] * r[-1] for r in tab) / wsum for i, k in enumerate(keys)}
+
+
 def init_distributed():
     """reference: espnet2/train/distributed_utils.py:28-107 (env:// rendezvous, one process per GPU)."""
     import torch.distributed as dist

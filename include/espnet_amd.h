@@ -435,6 +435,10 @@ int eamd_sched_step(float* state, const float* gnorm, int mode, float base_lr, f
 /* p_bf16 (optional): bf16 shadow of the updated parameters, written by the same pass */
 int eamd_adam_step(float* p, const float* g, float* m, float* v, void* p_bf16, int64_t n, const float* state,
                    float beta1, float beta2, float eps, float weight_decay, void* stream);
+/* g[i] += sigma * N(0,1) over the flat gradient arena (espnet2/torch_utils/add_gradient_noise.py:4-31; the caller
+ * computes sigma = eta / (iteration // duration + 1)^scale_factor).  Counter-based draws keyed by the device step
+ * counter and `salt`: no generator state, graph-replayable. */
+int eamd_add_gradient_noise(float* g, int64_t n, float sigma, const uint64_t* step_dev, uint64_t salt, void* stream);
 
 /* ------------------------------------------------------------------------------------------
  * Integer / layout helpers (bit-exact).

@@ -101,3 +101,126 @@ def test_single_process_defaults(monkeypatch):
         pytest.skip("covers the CPU-only path")
     assert train.init_distributed() == (0, 0, 1)
     assert train.shard_batch([1, 2, 3], 0, 1) == [1, 2, 3]
+
+
+# ---- EpochRunner: espnet2 Trainer.train_one_epoch / validate_one_epoch semantics (trainer.py:325-539) -----------------
+class _StubOpt:
+    """records the all-reduced gradient arena at every optimizer step and applies plain SGD"""
+
+    def __init__(self, flat):
+        self.flat, self.seen, self.skipped = flat, [], 0
+
+    def step(self):
+        self.seen.append(self.flat.grad.clone())
+        self.flat.data.add_(self.flat.grad, alpha=-0.1)
+
+    def stats(self):
+        return dict(skipped=self.skipped)
+
+
+def _toy_batches(rank):
+    """rank 0 holds 3 batches, rank 1 only 2 (the epoch must end after 2 micro-steps on BOTH ranks); batch sizes differ
+    between the ranks so that the weighted averaging matters"""
+    g = torch.Generator().manual_seed(100 + rank)
+    sizes = [3, 2, 4] if rank == 0 else [1, 5]
+    return [(torch.randn(n, 7, generator=g), torch.randn(n, 5, generator=g)) for n in sizes]
+
+
+def _runner_worker(rank, world, port, accum, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
+                      LOCAL_RANK=str(rank))
+    from espnet_amd import train
+    train.init_distributed()
+    torch.manual_seed(0)
+    model = torch.nn.Sequential(torch.nn.Linear(7, 16), torch.nn.Tanh(), torch.nn.Linear(16, 5))
+    flat = train.FlatParams(model)
+    opt = _StubOpt(flat)
+
+    def forward(batch):
+        x, y = batch
+        out = model(x)
+        loss = ((out - y) ** 2).mean()
+        return loss, {"loss_att": loss.detach() * 2, "acc": out.detach().mean()}, float(x.shape[0])
+
+    def backward(loss, scale):
+        grads = torch.autograd.grad(loss * scale, list(model.parameters()))
+        for p, gr in zip(model.parameters(), grads):
+            p._eamd_grad.add_(gr)
+
+    run = train.EpochRunner(model, flat, opt, accum_grad=accum, forward=forward, backward=backward, pre_step=lambda: None)
+    invalid = run.train_one_epoch(_toy_batches(rank))
+    hist = [{k: float(v) for k, v in h.items()} for h in run.history]
+    q.put((rank, invalid, [s.tolist() for s in opt.seen], hist, flat.data.tolist()))
+    torch.distributed.barrier()
+    torch.distributed.destroy_process_group()
+
+
+@pytest.mark.parametrize("accum", [1, 2])
+def test_epoch_runner_two_ranks(accum):
+    """two gloo ranks with different numbers of batches and different batch sizes: the epoch ends after two micro-steps
+    on both ranks (stop flag), the all-reduced gradient equals the gradient of the WEIGHTED mean loss over the union of
+    the two ranks' batches divided by accum_grad, the optimizer runs once per accum_grad micro-steps, and the recorded
+    statistics are the weighted means"""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_runner_worker, args=(r, 2, port, accum, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    got = sorted(q.get(timeout=120) for _ in range(2))
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    (r0, inv0, seen0, hist0, data0), (r1, inv1, seen1, hist1, data1) = got
+    assert inv0 is False and inv1 is False
+    assert len(seen0) == len(seen1) == 2 // accum and len(hist0) == len(hist1) == 2
+    assert seen0 == seen1 and data0 == data1                 # replicas stay identical
+    # single-process replay of what the reference computes on the union of the ranks' batches
+    torch.manual_seed(0)
+    model = torch.nn.Sequential(torch.nn.Linear(7, 16), torch.nn.Tanh(), torch.nn.Linear(16, 5))
+    from espnet_amd import train
+    flat = train.FlatParams(model)
+    b0, b1 = _toy_batches(0), _toy_batches(1)
+    want_grads, want_hist = [], []
+    for k in range(2):
+        parts = [b0[k], b1[k]]
+        wsum = float(sum(x.shape[0] for x, _ in parts))
+        losses = [((model(x) - y) ** 2).mean() for x, y in parts]
+        total = sum(l * x.shape[0] for l, (x, _) in zip(losses, parts)) / wsum / accum
+        grads = torch.autograd.grad(total, list(model.parameters()))
+        for p, gr in zip(model.parameters(), grads):
+            p._eamd_grad.add_(gr)
+        want_hist.append(dict(loss=float(sum(float(l) * x.shape[0] for l, (x, _) in zip(losses, parts)) / wsum), weight=wsum))
+        if (k + 1) % accum == 0:
+            want_grads.append(flat.grad.clone())
+            flat.data.add_(flat.grad, alpha=-0.1)
+            flat.zero_grad()
+    for got_g, want_g in zip(seen0, want_grads):
+        torch.testing.assert_close(torch.tensor(got_g), want_g, rtol=1e-5, atol=1e-6)
+    for h, w in zip(hist0, want_hist):
+        assert abs(h["loss"] - w["loss"]) < 1e-5 and h["weight"] == w["weight"]
+        assert abs(h["loss_att"] - 2 * w["loss"]) < 1e-5
+
+
+def test_epoch_runner_single_process_validation():
+    """world 1, CPU: validate_one_epoch runs without gradients in eval mode and averages by batch size"""
+    from espnet_amd import train
+    torch.manual_seed(0)
+    model = torch.nn.Sequential(torch.nn.Linear(7, 5), torch.nn.Dropout(0.5))
+    flat = train.FlatParams(model)
+    seen = []
+
+    def forward(batch):
+        x, y = batch
+        assert not torch.is_grad_enabled() and not model.training
+        out = model(x)
+        seen.append(out)
+        return ((out - y) ** 2).mean(), {}, float(x.shape[0])
+
+    run = train.EpochRunner(model, flat, _StubOpt(flat), forward=forward, pre_step=lambda: None)
+    hist = run.validate_one_epoch(_toy_batches(0))
+    assert len(hist) == 3 and [float(h["weight"]) for h in hist] == [3.0, 2.0, 4.0]
+    want = [float(((model(x) - y) ** 2).mean()) for x, y in _toy_batches(0)]
+    assert all(abs(float(h["loss"]) - w) < 1e-6 for h, w in zip(hist, want))
+    avg = run.averaged()
+    assert abs(avg["loss"] - sum(w * n for w, n in zip(want, (3, 2, 4))) / 9.0) < 1e-6

@@ -1119,3 +1119,144 @@ def test_calculate_all_attentions():
         d = float(np.abs(a[name] - att["bf16"][name]).max())
         print(f"[parity] attention weights {name}: fp32 vs bf16 max abs diff {d:.2e}")
         assert d < 3e-2, name
+
+
+# ---- trainer-step semantics: EpochRunner on the HIP path ------------------------------------------------
+def _c1_transformer(dropout=0.0):
+    """BASELINE config 1 shape: 2-layer Transformer d=64 h=4, 1-layer decoder, V=50 (no BatchNorm anywhere)"""
+    from espnet_amd.nets.e2e_asr_transformer import E2E
+    ns = argparse.Namespace(adim=64, aheads=4, elayers=2, eunits=256, dlayers=1, dunits=256, mtlalpha=0.3, lsm_weight=0.1,
+                            dropout_rate=dropout, transformer_length_normalized_loss=False)
+    torch.manual_seed(0)
+    m = E2E(20, 50, ns)
+    m.sync_report = False
+    return m
+
+
+def _c1_batch(B, seed=3):
+    g = torch.Generator().manual_seed(seed)
+    xs = torch.randn(B, 100, 20, generator=g)
+    # the first two utterances are full length: every shard [rank::2] is padded to the same 100 frames, as the global
+    # batch is (a shard cropped to a shorter maximum loses boundary frames of the subsampling - in the reference too)
+    ilens = [100, 100] + [100 - 7 * (i % 4) for i in range(2, B)]
+    for i, n in enumerate(ilens):
+        xs[i, n:] = 0.0
+    ys = torch.randint(1, 49, (B, 9), generator=g)
+    for i in range(B):
+        ys[i, 9 - (i % 3):] = -1
+    return xs, ilens, ys
+
+
+class _RecOpt:
+    def __init__(self, flat):
+        self.flat, self.seen = flat, []
+
+    def step(self):
+        self.seen.append(self.flat.grad.clone())
+
+    def stats(self):
+        return dict(skipped=0)
+
+
+def _dp_worker(rank, world, port, q):
+    import os
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
+                      LOCAL_RANK=str(rank), EAMD_FORCE_DEVICE="0", EAMD_DIST_BACKEND="gloo")
+    import espnet_amd
+    from espnet_amd import train
+    train.init_distributed()
+    espnet_amd.set_precision("fp32")
+    model = _c1_transformer().to("cuda").train()
+    flat = train.FlatParams(model)
+    opt = _RecOpt(flat)
+    xs, ilens, ys = _c1_batch(6)
+    mine = (xs[rank::world], ilens[rank::world], ys[rank::world])            # abs_task.py:1445 sharding
+    run = train.EpochRunner(model, flat, opt)
+    run.train_one_epoch([mine])
+    torch.cuda.synchronize()
+    q.put((rank, opt.seen[0].cpu().numpy(), {k: float(v) for k, v in run.history[0].items()}))
+    torch.distributed.barrier()
+    torch.distributed.destroy_process_group()
+
+
+def test_two_rank_gradient_equivalence():
+    """two ranks (gloo, both on cuda:0) each run half of a global batch of 6 through the HIP model under EpochRunner:
+    the all-reduced gradient arena equals the single-process arena of the whole batch (rel 1e-5), on both ranks, and
+    the all-reduced statistics equal the whole-batch loss.  reference: trainer.py:381-399 + DDP averaging."""
+    import socket
+    import torch.multiprocessing as mp
+    from espnet_amd import train
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_dp_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    got = sorted((q.get(timeout=300) for _ in range(2)), key=lambda t: t[0])
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    model = _c1_transformer().to(DEV).train()
+    flat = train.FlatParams(model)
+    xs, ilens, ys = _c1_batch(6)
+    loss = model(xs.to(DEV), ilens, ys.to(DEV))
+    loss.backward()
+    want = flat.grad.cpu()
+    got = [(r, torch.from_numpy(a), h) for r, a, h in got]
+    for rank, arena, hist in got:
+        e = float((arena.double() - want.double()).norm() / want.double().norm())
+        print(f"[parity] 2-rank all-reduced arena vs single-process arena (rank {rank}): rel {e:.3e}; loss {hist['loss']:.6f} vs {float(loss):.6f}")
+        assert e < 1e-5
+        assert abs(hist["loss"] - float(loss)) <= 1e-5 * abs(float(loss)) and hist["weight"] == 6.0
+    assert torch.equal(got[0][1], got[1][1])
+
+
+def test_epoch_runner_accum_grad_and_validation():
+    """accum_grad = 2 over two half batches gives the update of one step on the whole batch (dropout 0, no BatchNorm);
+    validate_one_epoch leaves parameters and gradients untouched and reports the eval-mode loss"""
+    from espnet_amd import train
+    xs, ilens, ys = _c1_batch(8)
+    outs = []
+    for accum in (1, 2):
+        model = _c1_transformer().to(DEV)
+        flat = train.FlatParams(model)
+        opt = train.NoamAdam(flat, mode="noam", factor=1.0, model_size=64, warmup=100, max_grad_norm=5.0)
+        run = train.EpochRunner(model, flat, opt, accum_grad=accum)
+        if accum == 1:
+            batches = [(xs, ilens, ys)]
+        else:
+            batches = [(xs[:4], ilens[:4], ys[:4]), (xs[4:], ilens[4:], ys[4:])]
+        assert run.train_one_epoch(batches) is False
+        st = opt.stats()
+        assert st["step"] == 1
+        outs.append((flat.data.clone(), st["grad_norm"], run.averaged()))
+    report("accum_grad=2 parameters vs one full-batch step", outs[1][0], outs[0][0], 1e-6)
+    assert abs(outs[1][1] - outs[0][1]) <= 2e-5 * outs[0][1]
+    assert abs(outs[1][2]["loss"] - outs[0][2]["loss"]) <= 1e-5 * abs(outs[0][2]["loss"])
+    before = flat.data.clone()
+    hist = run.validate_one_epoch([(xs, ilens, ys)])
+    assert torch.equal(flat.data, before) and float(flat.grad.abs().max()) == 0.0
+    assert len(hist) == 1 and float(hist[0]["weight"]) == 8.0 and math.isfinite(float(hist[0]["loss"]))
+
+
+def test_gradient_noise_kernel():
+    """eamd_add_gradient_noise: zero-mean Gaussian of the requested sigma (add_gradient_noise.py:4-31), a new draw per
+    step of the device counter, the same draw when the counter does not move"""
+    from espnet_amd import ops
+    n = 1 << 20
+    g = torch.zeros(n + 1, device=DEV)
+    ops.manual_seed(77)
+    ops.add_gradient_noise(g, 0.25)
+    a = g.clone()
+    assert abs(float(a.mean())) < 2e-3 and abs(float(a.std()) - 0.25) < 2e-3
+    k = float(((a / 0.25) ** 4).mean())
+    assert abs(k - 3.0) < 0.1                                    # Gaussian kurtosis
+    g.zero_()
+    ops.add_gradient_noise(g, 0.25)
+    assert torch.equal(g, a)
+    ops.rng_advance(DEV)
+    g.zero_()
+    ops.add_gradient_noise(g, 0.25)
+    assert not torch.equal(g, a) and abs(float((g * a).mean())) < 1e-3
