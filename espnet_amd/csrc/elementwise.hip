@@ -304,6 +304,16 @@ __global__ __launch_bounds__(256) void posenc_scaled_bwd_kernel(const float* __r
   if (threadIdx.x == 0) atomicAdd(dalpha, red[0] + red[1] + red[2] + red[3]);
 }
 
+// out[r * ld + c] = a[r, c] (+ b[r, c]): fp32 twin of add_cast (a column block of a wider fp32 matrix as destination)
+__global__ void add_block_f32_kernel(const float* __restrict__ a, const float* __restrict__ b, float* __restrict__ out,
+                                     long n, int cols, long ld) {
+  const long stride = (long)gridDim.x * blockDim.x;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+    const long r = i / cols; const int c = i % cols;
+    out[r * ld + c] = a[i] + (b ? b[i] : 0.f);
+  }
+}
+
 // Generic 4-D permutation copy with optional accumulate: dst[perm(idx)] (+)= src[idx].
 // Used for conv weight layouts: Conv2d weight [Co][Ci][kh][kw] <-> tap-major GEMM operands.
 __global__ void permute4_kernel(const float* __restrict__ src, float* __restrict__ dst, int d0, int d1, int d2,
@@ -552,6 +562,15 @@ __global__ __launch_bounds__(256) void add_cast_colsum2_kernel(const float* __re
     atomicAdd(&suma[2 * cp], t0); atomicAdd(&suma[2 * cp + 1], t1);
     atomicAdd(&sumb[2 * cp], t2); atomicAdd(&sumb[2 * cp + 1], t3);
   }
+}
+
+int eamd_add_block_f32(const float* a, const float* b, float* out, int64_t rows, int cols, int64_t ld_out, void* stream) {
+  if (!a || !out || rows <= 0 || cols <= 0 || ld_out < cols) return EAMD_EINVAL;
+  const long n = (long)rows * cols;
+  hipLaunchKernelGGL(add_block_f32_kernel, dim3(grid_for(n)), dim3(256), 0, (hipStream_t)stream, a, b, out, n, cols,
+                     (long)ld_out);
+  EAMD_LAUNCH_CHECK();
+  return EAMD_OK;
 }
 
 int eamd_add_cast_bf16(const float* a, const float* b, void* out_bf16, int64_t rows, int cols, int64_t ld_out,

@@ -398,7 +398,9 @@ extern "C" int eamd_gemm(const eamd_gemm_t* pp, void* stream_) {
       // (K or N = 256); 128x128 only pays for large square problems
       tile = (t128 >= 1024 && p.K >= 2048 && p.M >= 2048 && p.N >= 2048) ? 128 : 64;
     } else {
-      tile = (t128 >= 512 && p.M >= 128 && p.N >= 128) ? 128 : 64;
+      // measured on MI355X (tools/gemm_f32_probe.py): from ~1 tile per CU on the 128x128 tile wins (4x fewer LDS
+      // stores and barriers per MFMA), below that the 64x64 tile's 4x as many workgroups do
+      tile = (t128 >= 240 && p.M >= 128 && p.N >= 128) ? 128 : 64;
     }
   }
   if (tile != 64 && tile != 128) return EAMD_EINVAL;
@@ -414,12 +416,15 @@ extern "C" int eamd_gemm(const eamd_gemm_t* pp, void* stream_) {
     }
   }
   if ((p.N + tile - 1) / tile > 65535) return EAMD_EUNSUPPORTED;
-  if (p.in_dtype != 1 && (p.drop_p != 0.f || p.Hb)) return EAMD_EUNSUPPORTED;   // fused dropout: bf16-operand kernel only
+  // fused dropout: the bf16-operand kernels (incl. the dual bf16 output Hb) and, for a plain dropped result, the
+  // pipelined fp32 kernel (same epilogue code)
+  if (p.in_dtype != 1 && (p.Hb || (p.drop_p != 0.f && p.precision != 0))) return EAMD_EUNSUPPORTED;
   if (p.in_dtype == 1) return eamd_gemm_bf16_dispatch(p, tile, stream);
 
   if (p.precision == 0) {     // reference precision: the pipelined fp32-MFMA kernel wherever its staging conditions hold
     const int rc = eamd_gemm_f32_dispatch(p, tile, stream);
     if (rc != EAMD_EUNSUPPORTED) return rc;
+    if (p.drop_p != 0.f) return EAMD_EUNSUPPORTED;      // the generic kernel has no dropout epilogue
   }
   if (tile == 128) {
     return p.precision ? launch<128, 128, 1>(p, stream) : launch<128, 128, 0>(p, stream);

@@ -53,7 +53,7 @@ __device__ __forceinline__ float4 mask4(float4 v, int nv) {
 }
 
 template <int BM, int BN, bool TA, bool TB, bool GAT, bool ACT>
-__global__ __launch_bounds__(NT_) void gemm_f32_kernel(const eamd_gemm_t p) {
+__global__ __launch_bounds__(NT_, 2) void gemm_f32_kernel(const eamd_gemm_t p) {
   constexpr int WM = BM / 2, WN = BN / 2;
   constexpr int MT = WM / 16, NTL = WN / 16;
   constexpr int NCA = BM / 32, NCB = BN / 32;           // 16-byte chunks per thread per tile
@@ -262,8 +262,66 @@ __global__ __launch_bounds__(NT_) void gemm_f32_kernel(const eamd_gemm_t p) {
   }
 
   const int fr = lane & 15, fq = lane >> 4;
-  // one K-tile: issue the loads of tile it+DEPTH-1, run the 8 k-steps (x MT x NTL MFMAs) of tile `it` from LDS,
-  // then move tile it+1 into the other LDS buffer.  MFMA e of half kk contracts k = kk*16 + 4*fq + e.
+  // A K-tile is consumed in NS fragment sets of QD reduction steps each (64x64: 2 x 16 via ds_read_b128; 128x128:
+  // 4 x 8 via ds_read_b64 - half the fragment registers, which is what keeps two 128x128 workgroups per CU).
+  // MFMA e of set q contracts k = q*QD + EQ*fq + e.
+  constexpr int QD = BM >= 128 ? 8 : 16;
+  constexpr int NS = FBK / QD, EQ = QD / 4;
+  auto read_frags = [&](int buf, int q, float (&af)[MT][EQ], float (&bfr)[NTL][EQ]) __attribute__((always_inline)) {
+    const float* la = sm.a(buf);
+    const float* lb = sm.b(buf);
+#pragma unroll
+    for (int i = 0; i < MT; ++i) {
+      if constexpr (!TA) {
+        const float* src = &la[(wm * WM + i * 16 + fr) * S::LDA + q * QD + fq * EQ];
+        if constexpr (EQ == 4) {
+          const float4 v = *reinterpret_cast<const float4*>(src);
+          af[i][0] = v.x; af[i][1] = v.y; af[i][2] = v.z; af[i][3] = v.w;
+        } else {
+          const float2 v = *reinterpret_cast<const float2*>(src);
+          af[i][0] = v.x; af[i][1] = v.y;
+        }
+      } else {
+#pragma unroll
+        for (int e = 0; e < EQ; ++e) af[i][e] = la[(q * QD + fq * EQ + e) * S::LDA + wm * WM + i * 16 + fr];
+      }
+    }
+#pragma unroll
+    for (int j = 0; j < NTL; ++j) {
+      if constexpr (!TB) {
+        const float* src = &lb[(wn * WN + j * 16 + fr) * S::LDB + q * QD + fq * EQ];
+        if constexpr (EQ == 4) {
+          const float4 v = *reinterpret_cast<const float4*>(src);
+          bfr[j][0] = v.x; bfr[j][1] = v.y; bfr[j][2] = v.z; bfr[j][3] = v.w;
+        } else {
+          const float2 v = *reinterpret_cast<const float2*>(src);
+          bfr[j][0] = v.x; bfr[j][1] = v.y;
+        }
+      } else {
+#pragma unroll
+        for (int e = 0; e < EQ; ++e) bfr[j][e] = lb[(q * QD + fq * EQ + e) * S::LDB + wn * WN + j * 16 + fr];
+      }
+    }
+  };
+  auto mfma_set = [&](const float (&af)[MT][EQ], const float (&bfr)[NTL][EQ]) __attribute__((always_inline)) {
+#pragma unroll
+    for (int e = 0; e < EQ; ++e)
+#pragma unroll
+      for (int i = 0; i < MT; ++i)
+#pragma unroll
+        for (int j = 0; j < NTL; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[i][e], bfr[j][e], acc[i][j], 0, 0, 0);
+  };
+  // Software pipeline of one K-tile (fragment sets double-buffered in registers; set 0 of a tile is read at the END of
+  // the previous phase, behind the barrier but in front of that phase's last MFMA group, so no MFMA waits on a cold
+  // LDS read; the LDS stores of the next tile go in front of the second-to-last MFMA group - their buffer has had no
+  // readers since the previous barrier - and drain under it):
+  //     global loads (tile it+DEPTH-1) | read set 1 | MFMA set 0 | ... | read set NS-1 | LDS stores (tile it+1) |
+  //     MFMA set NS-2 | barrier | read set 0 of tile it+1 | MFMA set NS-1
+  // A 64x64 workgroup keeps a ring of 3 register tiles (tile it+1 landed a phase ago: its stores open the phase); a
+  // 128x128 one a ring of 2 (loads issued at the top of the phase, stored 2048 MFMA cycles later).
+  float fa[2][MT][EQ], fb[2][NTL][EQ];
+  if (nkt > 0) read_frags(0, 0, fa[0], fb[0]);
   auto phase = [&](auto idx_c, auto guard_c, int it) __attribute__((always_inline)) {
     constexpr int IDX = decltype(idx_c)::value;
     constexpr int PAR = IDX % DEPTH;
@@ -278,48 +336,41 @@ __global__ __launch_bounds__(NT_) void gemm_f32_kernel(const eamd_gemm_t p) {
       if constexpr (tgat) fill_poff(kt_begin + it + DEPTH, (kt_begin + it + DEPTH) % 8);
       load_tile(load_t{}, guard_c, kt_begin + it + DEPTH - 1);
     }
-    // the machine scheduler otherwise sinks the loads below the MFMAs, next to the LDS stores that consume them
-    __builtin_amdgcn_sched_barrier(0);
-    const float* la = sm.a(buf);
-    const float* lb = sm.b(buf);
 #pragma unroll
-    for (int kk = 0; kk < 2; ++kk) {
-      float af[MT][4], bfr[NTL][4];
-#pragma unroll
-      for (int i = 0; i < MT; ++i) {
-        if constexpr (!TA) {
-          const float4 v = *reinterpret_cast<const float4*>(&la[(wm * WM + i * 16 + fr) * S::LDA + kk * 16 + fq * 4]);
-          af[i][0] = v.x; af[i][1] = v.y; af[i][2] = v.z; af[i][3] = v.w;
+    for (int q = 0; q < NS; ++q) {
+      if (q + 1 < NS) {
+        read_frags(buf, q + 1, fa[(q + 1) & 1], fb[(q + 1) & 1]);
+      } else {
+        __builtin_amdgcn_sched_barrier(0);
+        __syncthreads();
+        if constexpr (GUARD) {
+          if (it + 1 < nkt) read_frags(buf ^ 1, 0, fa[0], fb[0]);
         } else {
+          read_frags(buf ^ 1, 0, fa[0], fb[0]);
+        }
+        // MFMAs are pure register operations: instruction selection is free to hoist the last set above the barrier
+        // (it did), which puts the barrier and the cold reads of the next tile back on the critical path.  Passing
+        // the set's fragments through an empty volatile asm orders its MFMAs behind the barrier.
 #pragma unroll
-          for (int e = 0; e < 4; ++e) af[i][e] = la[(kk * 16 + fq * 4 + e) * S::LDA + wm * WM + i * 16 + fr];
+        for (int e = 0; e < EQ; ++e) {
+#pragma unroll
+          for (int i = 0; i < MT; ++i) asm volatile("" : "+v"(fa[q & 1][i][e]));
+#pragma unroll
+          for (int j = 0; j < NTL; ++j) asm volatile("" : "+v"(fb[q & 1][j][e]));
         }
       }
-#pragma unroll
-      for (int j = 0; j < NTL; ++j) {
-        if constexpr (!TB) {
-          const float4 v = *reinterpret_cast<const float4*>(&lb[(wn * WN + j * 16 + fr) * S::LDB + kk * 16 + fq * 4]);
-          bfr[j][0] = v.x; bfr[j][1] = v.y; bfr[j][2] = v.z; bfr[j][3] = v.w;
+      // the machine scheduler otherwise moves the global loads / LDS traffic next to their consumers: pin the order
+      __builtin_amdgcn_sched_barrier(0);
+      if (q == NS - 2) {
+        if constexpr (GUARD) {
+          if (it + 1 < nkt) store_tile(other_t{}, guard_c, buf ^ 1, kt_begin + it + 1);
         } else {
-#pragma unroll
-          for (int e = 0; e < 4; ++e) bfr[j][e] = lb[(kk * 16 + fq * 4 + e) * S::LDB + wn * WN + j * 16 + fr];
+          store_tile(other_t{}, guard_c, buf ^ 1, kt_begin + it + 1);
         }
+        __builtin_amdgcn_sched_barrier(0);
       }
-#pragma unroll
-      for (int e = 0; e < 4; ++e)
-#pragma unroll
-        for (int i = 0; i < MT; ++i)
-#pragma unroll
-          for (int j = 0; j < NTL; ++j)
-            acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[i][e], bfr[j][e], acc[i][j], 0, 0, 0);
+      mfma_set(fa[q & 1], fb[q & 1]);
     }
-    __builtin_amdgcn_sched_barrier(0);
-    if constexpr (GUARD) {
-      if (it + 1 < nkt) store_tile(other_t{}, guard_c, buf ^ 1, kt_begin + it + 1);
-    } else {
-      store_tile(other_t{}, guard_c, buf ^ 1, kt_begin + it + 1);
-    }
-    __syncthreads();
   };
   using T_ = std::true_type;
   using F_ = std::false_type;
@@ -347,6 +398,7 @@ __global__ __launch_bounds__(NT_) void gemm_f32_kernel(const eamd_gemm_t p) {
     }
   }
 
+  __syncthreads();      // the last phase's trailing MFMAs ran behind its barrier: nothing reads the operand buffers now
   if (TA && p.colsum != nullptr && !GAT) {   // block-uniform
     // bias gradient: per-thread column sums -> one LDS row per k-row group of the staging layout -> one global
     // atomic per column per block (plain LDS stores: ds_add_f32 is slow on gfx950)
@@ -441,7 +493,10 @@ bool aligned16f(const void* q) { return (reinterpret_cast<uintptr_t>(q) & 15) ==
 int eamd_gemm_f32_dispatch(const eamd_gemm_t& p, int tile, hipStream_t stream) {
   static const int on = [] { const char* e = getenv("EAMD_GEMM_F32_FAST"); return e ? atoi(e) : 1; }();
   if (!on) return EAMD_EUNSUPPORTED;
-  if (p.Cb || p.Hb || p.aux_dtype || p.drop_p != 0.f || !p.C) return EAMD_EUNSUPPORTED;
+  if (p.Cb || p.Hb || p.aux_dtype || !p.C) return EAMD_EUNSUPPORTED;
+  if (p.drop_p < 0.f || p.drop_p >= 1.f) return EAMD_EINVAL;
+  // fused result dropout: mask index = row * N + col of a contiguous [M, N] result, as eamd_dropout draws it
+  if (p.drop_p > 0.f && (p.cmap.enabled || p.batch1 * p.batch2 != 1 || p.ldc != p.N || p.splitk > 1)) return EAMD_EINVAL;
   const bool a_ok = aligned16f(p.A) && p.lda % 4 == 0 && p.sA1 % 4 == 0 && p.sA2 % 4 == 0 &&
                     p.lda >= (p.transA ? (p.M + 3) / 4 * 4 : (p.K + 3) / 4 * 4);
   const bool b_ok = aligned16f(p.B) && p.ldb % 4 == 0 && p.sB1 % 4 == 0 && p.sB2 % 4 == 0 &&

@@ -215,7 +215,7 @@ class FFNBlockFn(torch.autograd.Function):
             if p_in > 0.0:
                 h = ops.dropout(z, p_in, s_in, act=act)                         # drop(act(z)), materialised
         src, a_act = (h, ACT_NONE) if h is not None else (z, act)
-        if p_out > 0.0 and fused:
+        if p_out > 0.0 and (fused or ops.f32_epilogue_drop()):
             out = ops.linear_fwd(src, ops.wshadow(w2), b2, R=x2, alpha=scale, a_act=a_act, drop=(p_out, s_out))
         elif p_out > 0.0:
             br = ops.linear_fwd(src, ops.wshadow(w2), b2, a_act=a_act)
@@ -512,7 +512,7 @@ class MHABlockFn(torch.autograd.Function):
             T1 = 1
         else:
             xq, res, T1 = xn, (x2 if eps is not None else None), T1f
-        fused = memory is None and not last_query_only and ops.fast() and _qkv_adjacent(wq, wk, wv, bq, bk, bv)
+        fused = memory is None and not last_query_only and _qkv_adjacent(wq, wk, wv, bq, bk, bv)
         if fused:
             # q, k, v weights sit back to back in the arenas (FlatParams): one [M, D] x [3D, D]^T projection
             w3, b3 = _span3(ops.wshadow(wq), (3 * D, D)), _span3(bq, (3 * D,))
@@ -546,7 +546,7 @@ class MHABlockFn(torch.autograd.Function):
             cx = attn_context_fwd(Pd, v, B, T1, T2, H, dk)
         if ATTN_TAP is not None:      # calculate_all_attentions: the probabilities in the reference's (B, H, T1, T2) layout
             ATTN_TAP.append(Pd.view(H, B, T1, _ldp(T2))[..., :T2].permute(1, 0, 2, 3).float())
-        if p_out > 0.0 and ops.fast():
+        if p_out > 0.0 and (ops.fast() or ops.f32_epilogue_drop()):
             out = ops.linear_fwd(cx, ops.wshadow(wo), bo, R=res, drop=(p_out, s_out))
         elif p_out > 0.0:
             br = ops.linear_fwd(cx, ops.wshadow(wo), bo)
@@ -657,7 +657,7 @@ class ConvModuleBlockFn(torch.autograd.Function):
             brstd = ops.axpby(running_var, None, 1.0, 0.0)
             brstd = torch.rsqrt_(brstd.add_(bn_eps))  # tiny [C] host-issued op on eval path only
         e = ops.bn_apply(d, bmean, brstd, g, be, M, Cc, act, adt)
-        if p_out > 0.0 and ops.fast():
+        if p_out > 0.0 and (ops.fast() or ops.f32_epilogue_drop()):
             out = ops.linear_fwd(e, ops.wshadow(w2).view(Cc, Cc), b2, R=x2, drop=(p_out, s_out))
         elif p_out > 0.0:
             br = ops.linear_fwd(e, ops.wshadow(w2).view(Cc, Cc), b2)

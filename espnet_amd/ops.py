@@ -35,6 +35,15 @@ def fast():
     return _state["precision"] == 1
 
 
+def f32_epilogue_drop():
+    """fp32 mode: block-output dropout + residual ride in the epilogue of the pipelined fp32 GEMM (gemm_f32.hip); the
+    operands of every block GEMM are 16-byte aligned with K % 4 == 0, which is all that kernel asks for"""
+    return _state["precision"] == 0 and F32_EPILOGUE_DROP
+
+
+F32_EPILOGUE_DROP = True     # tests flip this to compare against the stand-alone dropout kernel
+
+
 def act_dtype():
     return torch.bfloat16 if fast() else torch.float32
 
@@ -155,8 +164,8 @@ def gemm(A, B, Cm, M, N, K, lda, ldb, ldc, *, transA=0, transB=0, bias=None, aux
     if cmap is not None:
         p.cmap = cmap
     if drop is not None and drop[0] > 0.0:      # (p, salt): fused dropout, see include/espnet_amd.h
-        if not bf or ldc != N or c_off != 0:
-            raise _lib.EamdError("gemm: fused dropout needs bf16 operands and a contiguous [M, N] result")
+        if ldc != N or c_off != 0 or (not bf and (p.precision != 0 or Hb is not None)):
+            raise _lib.EamdError("gemm: fused dropout needs a contiguous [M, N] result and bf16 or fp32-MFMA operands")
         p.drop_p, p.drop_salt = float(drop[0]), int(drop[1])
         p.drop_step = ptr(rng_state(A.device))
         if Hb is not None:
@@ -513,11 +522,17 @@ def add_bias2(q, u, v, rows=None, D=None, ldq=None, q_off=0):
 
 
 def add_cast(a, b, out=None, out_off=0, ld_out=None):
-    """bf16(a + b) from dense fp32 [rows, cols] inputs (b optional); optionally into a column block of `out`"""
+    """bf16(a + b) from dense fp32 [rows, cols] inputs (b optional); optionally into a column block of `out`
+    (an fp32 `out` takes the sum as it is)"""
     rows, cols = a.shape
     if out is None:
         out = torch.empty(a.shape, device=a.device, dtype=torch.bfloat16)
         ld_out = cols
+    if out.dtype == torch.float32:
+        assert out.numel() >= out_off + (rows - 1) * ld_out + cols
+        check(_lib.lib().eamd_add_block_f32(ptr(a), ptr(b), ptr(out, out_off), C.c_int64(rows), cols, C.c_int64(ld_out),
+                                            stream_ptr()), "eamd_add_block_f32")
+        return out
     assert out.dtype == torch.bfloat16 and out.numel() >= out_off + (rows - 1) * ld_out + cols
     check(_lib.lib().eamd_add_cast_bf16(ptr(a), ptr(b), ptr(out, out_off), C.c_int64(rows), cols, C.c_int64(ld_out),
                                         stream_ptr()), "eamd_add_cast_bf16")

@@ -201,6 +201,9 @@ int eamd_add_bias2(const void* q, int64_t ldq, const float* u, const float* v, v
 /* out_bf16[r * ld_out + c] = a[r, c] + b[r, c] (b optional), dense fp32 [rows, cols] inputs */
 int eamd_add_cast_bf16(const float* a, const float* b, void* out_bf16, int64_t rows, int cols, int64_t ld_out,
                        void* stream);
+/* fp32 twin: out[r * ld_out + c] = a[r, c] + b[r, c] (b may be NULL) into a column block of a wider fp32 matrix
+ * (dq = dqu + dqv into the fused [rows, 3D] q/k/v gradient in fp32 mode). */
+int eamd_add_block_f32(const float* a, const float* b, float* out, int64_t rows, int cols, int64_t ld_out, void* stream);
 /* out_bf16[r * ld_out + c] = a[r, c] + b[r, c] and, from the same pass, suma[c] += sum_r a[r, c], sumb[c] += sum_r b[r, c]
  * (dense fp32 [rows, D] inputs, D even and <= 512, else EAMD_EUNSUPPORTED): dq = dqu + dqv and the gradients of
  * pos_bias_u / pos_bias_v in the backward of attention.py:186-190. */

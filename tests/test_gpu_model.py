@@ -1260,3 +1260,34 @@ def test_gradient_noise_kernel():
     g.zero_()
     ops.add_gradient_noise(g, 0.25)
     assert not torch.equal(g, a) and abs(float((g * a).mean())) < 1e-3
+
+
+def test_fp32_fused_paths_match_separate_paths():
+    """fp32 mode: (i) the block-output dropout + residual in the GEMM epilogue against the stand-alone dropout kernel +
+    add, (ii) the q/k/v projections as ONE [3D, D] GEMM over the flat arena against three GEMMs: same loss, same
+    gradients (dropout 0.1, same device step counter -> same masks)"""
+    from espnet_amd import functional as F_
+    from espnet_amd import ops, train
+    from conftest import e2e_dk64_model
+    g = load_golden("e2e_conformer_dk64.npz")
+    xs, ilens, ys = torch.from_numpy(g["xs"]).to(DEV), torch.from_numpy(g["ilens"]), torch.from_numpy(g["ys"]).to(DEV)
+    res = []
+    model, _cfg = e2e_dk64_model(dropout=0.1)          # one model: the dropout salts of its modules are the same in both runs
+    model = model.to(DEV).train()
+    flat = train.FlatParams(model)
+    try:
+        for fuse in (True, False):
+            ops.F32_EPILOGUE_DROP = fuse
+            F_.FUSE_QKV = fuse
+            flat.zero_grad()
+            ops.manual_seed(31)
+            loss = model(xs, ilens, ys)
+            loss.backward()
+            res.append((float(loss), flat.grad.clone()))
+    finally:
+        ops.F32_EPILOGUE_DROP = True
+        F_.FUSE_QKV = True
+    rel = abs(res[0][0] - res[1][0]) / abs(res[1][0])
+    print(f"[parity] fp32 fused vs separate paths: loss {res[0][0]:.6f} vs {res[1][0]:.6f} (rel {rel:.2e})")
+    assert rel < 1e-6
+    report("fp32 fused vs separate paths: gradient arena", res[0][1], res[1][1], 2e-5)

@@ -675,6 +675,24 @@ def test_gemm_fused_dropout_matches_dropout_kernel(ops):
         espnet_amd.set_precision("fp32")
 
 
+@pytest.mark.parametrize("shape", [(300, 192, 128), (7968, 256, 2048), (7968, 256, 256)])
+def test_gemm_f32_fused_dropout_matches_dropout_kernel(ops, shape):
+    """fp32 mode: the dropout epilogue of the pipelined fp32 GEMM draws the very mask eamd_dropout draws for the same
+    (step, salt, element index), for both tile sizes, with bias, alpha and the residual behind it"""
+    M, N, K = shape
+    g = torch.Generator().manual_seed(M + K)
+    x, W = torch.randn(M, K, generator=g).to(DEV), torch.randn(N, K, generator=g).to(DEV)
+    b, R = torch.randn(N, generator=g).to(DEV), torch.randn(M, N, generator=g).to(DEV)
+    p, salt = 0.1, 4242
+    plain = ops.linear_fwd(x, W, b)
+    fused = ops.linear_fwd(x, W, b, R=R, alpha=0.5, drop=(p, salt))
+    want = R + 0.5 * ops.dropout(plain, p, salt)
+    assert torch.equal(fused == R, want == R)                          # identical keep pattern
+    report("fp32 gemm fused dropout %s" % (shape,), fused, want, 1e-6)
+    assert abs(float((fused != R).float().mean()) - (1 - p)) < 0.01
+    report("fp32 gemm vs float64 %s" % (shape,), plain, x.double().cpu() @ W.double().cpu().t() + b.double().cpu(), 2e-6)
+
+
 @pytest.mark.parametrize("shape", [(4, 80, 128, 31), (2, 33, 300, 29), (3, 17, 64, 3), (1, 5, 32, 1)])
 def test_dwconv_kernel_sizes(ops, shape):
     """depthwise conv fwd / input grad / weight grad at the recipe's kernel size 31 and at ragged channel counts"""
