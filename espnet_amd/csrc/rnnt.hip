@@ -64,10 +64,11 @@ __global__ __launch_bounds__(256) void joint_bwd_dec_kernel(const float* __restr
 __global__ __launch_bounds__(256) void rnnt_lse_gather_kernel(const float* __restrict__ z, const int* __restrict__ labels,
                                                               float* __restrict__ lse, float* __restrict__ lpb,
                                                               float* __restrict__ lpl, int T, int U, int V,
-                                                              int blank) {
+                                                              int blank, long node0) {
   __shared__ float red[16];
-  const long row = blockIdx.x;
-  const float* zr = z + row * V;
+  // z holds the rows of the lattice nodes node0, node0+1, ... (the whole [B,T,U] lattice when node0 = 0)
+  const long row = node0 + blockIdx.x;
+  const float* zr = z + (long)blockIdx.x * V;
   float m = -INFINITY;
   for (int v = threadIdx.x; v < V; v += blockDim.x) m = fmaxf(m, zr[v]);
   m = block_max(m, red);
@@ -158,19 +159,24 @@ __global__ __launch_bounds__(256) void rnnt_grad_kernel(const float* z, float* g
                                                         const float* __restrict__ lpl, const float* __restrict__ alpha,
                                                         const float* __restrict__ beta, const int* __restrict__ tlens,
                                                         const int* __restrict__ ulens, const float* __restrict__ gscale,
-                                                        float scale, int T, int U, int V, int blank) {
-  const long row = blockIdx.x;
+                                                        float scale, int T, int U, int V, int blank, long node0,
+                                                        unsigned short* g16) {
+  const long row = node0 + blockIdx.x;            // lattice node; z / g_out hold rows node0.. only
   const int u = row % U;
   const int t = (row / U) % T;
   const long b = row / ((long)T * U);
-  const float* zr = z + row * V;
-  float* gr = g_out + row * V;
+  const float* zr = z + (long)blockIdx.x * V;
+  float* gr = g_out ? g_out + (long)blockIdx.x * V : nullptr;
+  unsigned short* gr16 = g16 ? g16 + (long)blockIdx.x * V : nullptr;
   const int Tb = tlens[b], Ub = ulens[b] + 1;
   const float logZ = beta[b * (long)T * U];
   const float a = alpha[row];
   const bool valid = t < Tb && u < Ub && a > -INFINITY && beta[row] > -INFINITY && isfinite(logZ);
   if (!valid) {
-    for (int v = threadIdx.x; v < V; v += blockDim.x) gr[v] = 0.f;
+    for (int v = threadIdx.x; v < V; v += blockDim.x) {
+      if (gr) gr[v] = 0.f;
+      if (gr16) gr16[v] = 0;
+    }
     return;
   }
   const float sc = scale * (gscale ? gscale[0] : 1.f);
@@ -184,7 +190,8 @@ __global__ __launch_bounds__(256) void rnnt_grad_kernel(const float* z, float* g
     float g = expf(zr[v] + tot);
     if (v == blank) g -= gb;
     if (v == lab) g -= gl;
-    gr[v] = sc * g;
+    if (gr) gr[v] = sc * g;
+    if (gr16) gr16[v] = eamd_f2bf(sc * g);
   }
 }
 
@@ -231,14 +238,14 @@ int eamd_rnnt_loss(const float* logits, const int32_t* labels, const int32_t* tl
   float* alpha = lpl + n;
   float* beta = alpha + n;
   hipLaunchKernelGGL(rnnt_lse_gather_kernel, dim3((unsigned)n), dim3(256), 0, s, logits, labels, lse, lpb, lpl, T, U, V,
-                     blank);
+                     blank, 0L);
   EAMD_LAUNCH_CHECK();
   hipLaunchKernelGGL(rnnt_alpha_beta_kernel, dim3(2 * B), dim3(256), 2 * U * sizeof(float), s, lpb, lpl, tlens, ulens,
                      alpha, beta, loss, B, T, U);
   EAMD_LAUNCH_CHECK();
   if (grad) {
     hipLaunchKernelGGL(rnnt_grad_kernel, dim3((unsigned)n), dim3(256), 0, s, logits, grad, labels, lse, lpb, lpl, alpha, beta,
-                       tlens, ulens, gscale_dev, scale, T, U, V, blank);
+                       tlens, ulens, gscale_dev, scale, T, U, V, blank, 0L, (unsigned short*)nullptr);
     EAMD_LAUNCH_CHECK();
   }
   return EAMD_OK;
@@ -259,7 +266,52 @@ int eamd_rnnt_grad(const float* logits, const int32_t* labels, const int32_t* tl
   const float* alpha = lpl + n;
   const float* beta = alpha + n;
   hipLaunchKernelGGL(rnnt_grad_kernel, dim3((unsigned)n), dim3(256), 0, (hipStream_t)stream, logits, grad, labels, lse, lpb,
-                     lpl, alpha, beta, tlens, ulens, gscale_dev, scale, T, U, V, blank);
+                     lpl, alpha, beta, tlens, ulens, gscale_dev, scale, T, U, V, blank, 0L, (unsigned short*)nullptr);
+  EAMD_LAUNCH_CHECK();
+  return EAMD_OK;
+}
+
+/* ---- the same loss on lattice ROWS: the caller streams the joint logits through a buffer of `nrows` consecutive lattice
+ * nodes at a time (node = (b*T + t)*U + u, rows node0 .. node0+nrows-1) instead of materialising [B,T,U,V];
+ * `workspace` is the 5*B*T*U-float lattice workspace of eamd_rnnt_workspace.
+ *   eamd_rnnt_node_stats : lse / log p(blank) / log p(label) of the rows into the workspace
+ *   eamd_rnnt_alpha_beta : forward / backward variables and loss[b] from the workspace (all rows must be in)
+ *   eamd_rnnt_node_grad  : d loss / d logits of the rows (fp32 and / or bf16 output; may alias the logits) */
+int eamd_rnnt_node_stats(const float* logits_rows, const int32_t* labels, float* workspace, int64_t node0, int64_t nrows,
+                         int B, int T, int U, int V, int blank, void* stream) {
+  const long n = (long)B * T * U;
+  if (!logits_rows || !labels || !workspace || node0 < 0 || nrows <= 0 || node0 + nrows > n || V <= 1 || blank < 0 ||
+      blank >= V || nrows > 2147483647L)
+    return EAMD_EINVAL;
+  float* lse = workspace;
+  hipLaunchKernelGGL(rnnt_lse_gather_kernel, dim3((unsigned)nrows), dim3(256), 0, (hipStream_t)stream, logits_rows, labels,
+                     lse, lse + n, lse + 2 * n, T, U, V, blank, (long)node0);
+  EAMD_LAUNCH_CHECK();
+  return EAMD_OK;
+}
+
+int eamd_rnnt_alpha_beta(float* workspace, const int32_t* tlens, const int32_t* ulens, float* loss, int B, int T, int U,
+                         void* stream) {
+  if (!workspace || !tlens || !ulens || !loss || B <= 0 || T <= 0 || U <= 0) return EAMD_EINVAL;
+  if ((size_t)2 * U * sizeof(float) > 64 * 1024) return EAMD_EUNSUPPORTED;
+  const long n = (long)B * T * U;
+  hipLaunchKernelGGL(rnnt_alpha_beta_kernel, dim3(2 * B), dim3(256), 2 * U * sizeof(float), (hipStream_t)stream,
+                     workspace + n, workspace + 2 * n, tlens, ulens, workspace + 3 * n, workspace + 4 * n, loss, B, T, U);
+  EAMD_LAUNCH_CHECK();
+  return EAMD_OK;
+}
+
+int eamd_rnnt_node_grad(const float* logits_rows, float* grad_rows, void* grad_rows_bf16, const int32_t* labels,
+                        const int32_t* tlens, const int32_t* ulens, const float* workspace, int64_t node0, int64_t nrows,
+                        int B, int T, int U, int V, int blank, const float* gscale_dev, float scale, void* stream) {
+  const long n = (long)B * T * U;
+  if (!logits_rows || (!grad_rows && !grad_rows_bf16) || !labels || !tlens || !ulens || !workspace || node0 < 0 ||
+      nrows <= 0 || node0 + nrows > n || V <= 1 || blank < 0 || blank >= V || nrows > 2147483647L)
+    return EAMD_EINVAL;
+  const float* lse = workspace;
+  hipLaunchKernelGGL(rnnt_grad_kernel, dim3((unsigned)nrows), dim3(256), 0, (hipStream_t)stream, logits_rows, grad_rows, labels,
+                     lse, lse + n, lse + 2 * n, lse + 3 * n, lse + 4 * n, tlens, ulens, gscale_dev, scale, T, U, V, blank,
+                     (long)node0, (unsigned short*)grad_rows_bf16);
   EAMD_LAUNCH_CHECK();
   return EAMD_OK;
 }

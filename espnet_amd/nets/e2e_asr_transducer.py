@@ -124,6 +124,17 @@ class E2E(ASRInterface, torch.nn.Module):
         for i in range(len(self.dec.decoder)):
             set_forget_bias_to_one(self.dec.decoder[i].bias_ih)
 
+    # joint logits above this many bytes are streamed through JointRNNTLossFn instead of being materialised
+    # (fused_loss = True / False forces either path; the small fixtures keep exercising both)
+    fused_loss = "auto"
+    fused_loss_min_bytes = 1 << 30
+
+    def _fuse_loss(self, hs_pad, ys_in_pad):
+        if self.fused_loss in (True, False):
+            return self.fused_loss
+        B, T = hs_pad.shape[:2]
+        return B * T * ys_in_pad.shape[1] * self.odim * 4 >= self.fused_loss_min_bytes
+
     def forward(self, xs_pad, ilens, ys_pad):
         """xs_pad (B,Tmax,idim), ilens (B), ys_pad (B,Lmax) -> transducer loss (e2e_asr_transducer.py:510-563)"""
         il = [int(v) for v in (ilens.tolist() if torch.is_tensor(ilens) else ilens)]
@@ -141,6 +152,13 @@ class E2E(ASRInterface, torch.nn.Module):
         if "transformer" in self.dtype:
             ys_mask = target_mask(ys_in_pad, self.blank_id)          # blank keys hidden + causal (e2e_asr_transducer.py:537)
             pred_pad, _ = self.decoder(ys_in_pad, ys_mask, hs_pad)
+        elif self.rnnt_mode == "rnnt" and self._fuse_loss(hs_pad, ys_in_pad):
+            # joint network + loss streamed over lattice rows: the (B,T,U,V) logits never exist (JointRNNTLossFn)
+            self.pred_pad = None
+            self.loss = self.dec.joint_network.loss(hs_pad, self.dec.hidden(ys_in_pad), target, pred_len, target_len,
+                                                    hs_mask if isinstance(hs_mask, (list, tuple)) else pred_len.tolist(),
+                                                    self.blank_id)
+            return self.loss
         elif self.rnnt_mode == "rnnt":
             pred_pad = self.dec(hs_pad, ys_in_pad)
         else:

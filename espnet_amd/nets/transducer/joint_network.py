@@ -43,6 +43,14 @@ class JointNetwork(torch.nn.Module):
             z = R_.JointFn.apply(enc_proj_rows.contiguous().view(n, 1, -1), d.view(n, 1, -1), self.act_id)
         return F_.LinearFn.apply(z.reshape(n, -1), self.lin_out.weight, self.lin_out.bias)
 
+    def loss(self, h_enc, h_dec, target, pred_len, target_len, pred_len_host, blank, chunk_rows=1 << 15):
+        """transducer loss from encoder states (B,T,D_enc) and prediction-network states (B,U,D_dec) without the
+        (B,T,U,V) logits (rnn_functional.JointRNNTLossFn): mean over the batch of -log P(y | x)"""
+        e = F_.LinearFn.apply(h_enc, self.lin_enc.weight, self.lin_enc.bias)
+        d = F_.LinearFn.apply(h_dec, self.lin_dec.weight, None)
+        return R_.JointRNNTLossFn.apply(e, d, self.lin_out.weight, self.lin_out.bias, target.contiguous(), pred_len.contiguous(),
+                                        target_len.contiguous(), blank, self.act_id, [int(v) for v in pred_len_host], chunk_rows)
+
     def forward(self, h_enc, h_dec):
         """h_enc (B,T,1,D_enc) or (B,T,D_enc); h_dec (B,1,U,D_dec) or (B,U,D_dec)"""
         if h_enc.dim() == 1 and h_dec.dim() == 1:      # decoding: one frame, one prediction-network output

@@ -82,6 +82,10 @@ class DecoderRNNT(torch.nn.Module):
 
     def forward(self, hs_pad, ys_in_pad, hlens=None):
         """hs_pad (B,Tmax,D), ys_in_pad (B,Lmax+1) -> joint logits (B,T,U,odim)   (rnn_decoder.py:140-166)"""
+        return self.joint_network(hs_pad, self.hidden(ys_in_pad))
+
+    def hidden(self, ys_in_pad):
+        """prediction network over the whole label history: ys_in_pad (B,Lmax+1) -> h_dec (B,U,dunits)"""
         eys = R_.PlainEmbedFn.apply(ys_in_pad, self.embed.weight, self.blank)
         eys = F_.dropout(eys, self.dropout_embed_rate, self.salt_emb, self.training)
         x = eys.transpose(0, 1).contiguous()                              # (U,B,emb) time-major
@@ -89,5 +93,4 @@ class DecoderRNNT(torch.nn.Module):
             gx = F_.LinearFn.apply(x, cell.weight_ih, cell.bias_ih)
             x = (R_.LSTMSeqFn if self.dtype == "lstm" else R_.GRUSeqFn).apply(gx, cell.weight_hh, cell.bias_hh, None, False)
             x = F_.dropout(x, self.dropout, self.salts[i], self.training)
-        h_dec = x.transpose(0, 1).contiguous()                            # (B,U,dunits)
-        return self.joint_network(hs_pad, h_dec)
+        return x.transpose(0, 1).contiguous()                             # (B,U,dunits)

@@ -933,6 +933,39 @@ def rnnt_loss(logits, labels, tlens, ulens, blank, grad=None, gscale=None, scale
     return (loss, ws) if return_ws else loss
 
 
+def rnnt_workspace(B, T, U, device):
+    return torch.empty(int(_lib.lib().eamd_rnnt_workspace(B, T, U)), device=device, dtype=torch.float32)
+
+
+def rnnt_node_stats(z_rows, labels, ws, node0, B, T, U, blank):
+    """lse / log p(blank) / log p(label) of the lattice rows node0.. (z_rows [nrows, V] fp32) into the workspace"""
+    nrows, V = z_rows.shape
+    assert z_rows.dtype == torch.float32 and z_rows.is_contiguous() and labels.dtype == torch.int32
+    check(_lib.lib().eamd_rnnt_node_stats(ptr(z_rows), ptr(labels), ptr(ws), C.c_int64(node0), C.c_int64(nrows), B, T, U, V,
+                                          blank, stream_ptr()), "eamd_rnnt_node_stats")
+
+
+def rnnt_alpha_beta(ws, tlens, ulens, B, T, U):
+    loss = torch.empty(B, device=ws.device, dtype=torch.float32)
+    check(_lib.lib().eamd_rnnt_alpha_beta(ptr(ws), ptr(tlens), ptr(ulens), ptr(loss), B, T, U, stream_ptr()),
+          "eamd_rnnt_alpha_beta")
+    return loss
+
+
+def rnnt_node_grad(z_rows, labels, tlens, ulens, ws, node0, B, T, U, blank, gscale, scale, out_dtype=torch.float32):
+    """d loss / d logits of the lattice rows node0.. -> [nrows, V] in out_dtype (fp32: written over z_rows)"""
+    nrows, V = z_rows.shape
+    if out_dtype == torch.float32:
+        g32, g16, out = ptr(z_rows), None, z_rows
+    else:
+        out = torch.empty(nrows, V, device=z_rows.device, dtype=torch.bfloat16)
+        g32, g16 = None, ptr(out)
+    check(_lib.lib().eamd_rnnt_node_grad(ptr(z_rows), g32, g16, ptr(labels), ptr(tlens), ptr(ulens), ptr(ws), C.c_int64(node0),
+                                         C.c_int64(nrows), B, T, U, V, blank, ptr(gscale), C.c_float(scale), stream_ptr()),
+          "eamd_rnnt_node_grad")
+    return out
+
+
 def attloc_fwd(att_prev, conv_w, w_att, pre_enc, dec_proj, gvec, gb, lens, enc_h, scaling):
     B, T, A = pre_enc.shape
     Cc, K = (conv_w.shape[0], conv_w.shape[-1]) if conv_w is not None else (0, 0)   # no conv: additive attention

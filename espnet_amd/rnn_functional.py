@@ -470,3 +470,64 @@ class RNNTLossFn(torch.autograd.Function):
         B = logits.shape[0]
         grad = ops.rnnt_grad(logits, labels, tlens, ulens, ctx.blank, ws, g.reshape(1).contiguous(), 1.0 / B)
         return grad, None, None, None, None
+
+
+class JointRNNTLossFn(torch.autograd.Function):
+    """mean_b -log P(y_b | x_b) straight from the joint network's two projections, WITHOUT the (B, T, U, V) logits:
+        z[b,t,u,:] = lin_out(act(e[b,t,:] + d[b,u,:]))      e = lin_enc(h_enc) (B,T,J), d = lin_dec(h_dec) (B,U,J)
+    reference: transducer/joint_network.py:34-48 + transducer/rnn_decoder.py:160-165 + transducer/loss.py:74-76, which
+    materialise z (12 GB at B=16, T'=374, U=101, V=5000) and hand it to warp-transducer.
+
+    Here the lattice is streamed in row chunks of one utterance's frames [t0, t1) x all U (at most `chunk_rows` nodes):
+      forward : H = act(e + d) for the chunk -> Z = H W_out^T + b (one GEMM) -> per-node lse and the two log-probabilities
+                the lattice needs (eamd_rnnt_node_stats) -> Z is dropped; then alpha / beta on the (B,T,U) lattices;
+      backward: H and Z of the chunk are recomputed, eamd_rnnt_node_grad turns Z into dZ in place (upstream scalar read
+                on the device), dH = dZ W_out, dW_out += dZ^T H, db_out += colsum(dZ), and the joint add's two
+                reductions give de rows and the utterance's dd.
+    Frames past an utterance's length are never touched.  Live memory: one chunk of logits (chunk_rows x V) + the
+    lattice workspace, instead of logits + their gradient + the (B,T,U,J) joint activations and their gradient."""
+
+    @staticmethod
+    def forward(ctx, e, d, w_out, b_out, labels, tlens, ulens, blank, act, tlens_host, chunk_rows):
+        B, T, J = e.shape
+        U = d.shape[1]
+        e, d = e.contiguous(), d.contiguous()
+        ws = ops.rnnt_workspace(B, T, U, e.device)
+        adt = ops.act_dtype()
+        nt_max = max(1, int(chunk_rows) // U)
+        plan = [(b, t0, min(nt_max, int(tlens_host[b]) - t0)) for b in range(B) for t0 in range(0, int(tlens_host[b]), nt_max)]
+        for b, t0, nt in plan:
+            H = ops.joint_fwd(e[b:b + 1, t0:t0 + nt], d[b:b + 1], act, out_dtype=adt)             # (1, nt, U, J)
+            Z = ops.linear_fwd(H.view(nt * U, J), ops.wshadow(w_out), b_out)
+            ops.rnnt_node_stats(Z, labels, ws, (b * T + t0) * U, B, T, U, blank)
+        nll = ops.rnnt_alpha_beta(ws, tlens, ulens, B, T, U)
+        ctx.save_for_backward(e, d, labels, tlens, ulens, ws)
+        ctx.pr = GradSink.use((w_out, b_out))
+        ctx.cfg = (blank, act, plan)
+        ctx.nll = nll
+        return ops.reduce_sum(nll, 1.0 / B)
+
+    @staticmethod
+    def backward(ctx, g):
+        e, d, labels, tlens, ulens, ws = ctx.saved_tensors
+        w_out, b_out = ctx.pr
+        blank, act, plan = ctx.cfg
+        B, T, J = e.shape
+        U = d.shape[1]
+        adt = ops.act_dtype()
+        sink = GradSink(ctx.pr)
+        gs = g.reshape(1).contiguous()
+        de = torch.zeros_like(e)
+        dd = torch.zeros_like(d)
+        for b, t0, nt in plan:
+            eb, db_ = e[b:b + 1, t0:t0 + nt], d[b:b + 1]
+            H = ops.joint_fwd(eb, db_, act, out_dtype=adt)
+            H2 = H.view(nt * U, J)
+            Z = ops.linear_fwd(H2, ops.wshadow(w_out), b_out)
+            dZ = ops.rnnt_node_grad(Z, labels, tlens, ulens, ws, (b * T + t0) * U, B, T, U, blank, gs, 1.0 / B, out_dtype=adt)
+            ops.linear_bwd_w(dZ, H2, sink.buf(0), db=sink.buf(1))
+            dH = ops.linear_bwd_x(dZ, ops.wshadow(w_out))
+            de_c, dd_c = ops.joint_bwd(dH.view(1, nt, U, J), eb.contiguous(), db_, act)
+            de[b, t0:t0 + nt].copy_(de_c[0])
+            ops.axpby(dd[b], dd_c[0], 1.0, 1.0, out=dd[b])
+        return (de, dd) + sink.results() + (None,) * 7

@@ -426,6 +426,17 @@ int eamd_rnnt_loss(const float* logits, const int32_t* labels, const int32_t* tl
 int eamd_rnnt_grad(const float* logits, const int32_t* labels, const int32_t* tlens, const int32_t* ulens,
                    const float* workspace, float* grad, int B, int T, int U, int V, int blank, const float* gscale_dev,
                    float scale, void* stream);
+/* The same loss without the [B,T,U,V] tensor: the caller streams the joint logits through a buffer of `nrows`
+ * consecutive lattice nodes (node = (b*T + t)*U + u) at a time - lin_out(act(lin_enc(h_enc) + lin_dec(h_dec))) of those
+ * rows, recomputed in backward - and the three entry points below fill / consume the 5*B*T*U-float lattice workspace.
+ * reference: transducer/rnn_decoder.py:160-165 + transducer/loss.py:74-76 (which materialise the logits). */
+int eamd_rnnt_node_stats(const float* logits_rows, const int32_t* labels, float* workspace, int64_t node0, int64_t nrows,
+                         int B, int T, int U, int V, int blank, void* stream);
+int eamd_rnnt_alpha_beta(float* workspace, const int32_t* tlens, const int32_t* ulens, float* loss, int B, int T, int U,
+                         void* stream);
+int eamd_rnnt_node_grad(const float* logits_rows, float* grad_rows, void* grad_rows_bf16, const int32_t* labels,
+                        const int32_t* tlens, const int32_t* ulens, const float* workspace, int64_t node0, int64_t nrows,
+                        int B, int T, int U, int V, int blank, const float* gscale_dev, float scale, void* stream);
 
 /* ------------------------------------------------------------------------------------------
  * Optimizer on flat fp32 arenas.  reference: transformer/optimizer.py:12-75 (NoamOpt),

@@ -306,6 +306,72 @@ def test_transducer_golden(name):
     check_grads(m, grads, tol=5e-4)
 
 
+@pytest.mark.parametrize("chunk_rows", [1 << 15, 7])
+@pytest.mark.parametrize("name", [n for n in _TRN_CASES if "att" not in n and "tt" not in n])
+def test_transducer_fused_joint_loss_golden(name, chunk_rows):
+    """JointRNNTLossFn (joint network + transducer loss streamed over lattice rows, the (B,T,U,V) logits never
+    materialised) against the reference fixtures: same loss, same parameter gradients as the materialised path is held
+    to; chunk_rows = 7 forces several frame chunks per utterance (accumulation of the prediction-side gradient)"""
+    from espnet_amd.nets.e2e_asr_transducer import E2E
+    from espnet_amd.nets.transducer.joint_network import JointNetwork
+    p, sd, grads = split_golden(load_golden(name))
+    m = load_sd(E2E(12, 6, _trn_case_args(name)), sd)
+    m.train()
+    m.fused_loss = True
+    orig = JointNetwork.loss
+    JointNetwork.loss = lambda self, *a, **k: orig(self, *a, **dict(k, chunk_rows=chunk_rows))
+    try:
+        loss = m(p["xs"].to(DEV), p["ilens"], p["ys"].to(DEV))
+        assert m.pred_pad is None
+        rel = abs(float(loss) - float(p["loss"])) / abs(float(p["loss"]))
+        print("[parity] %s fused joint+loss (chunk_rows %d): hip %.6f ref %.6f rel %.2e" % (name, chunk_rows, float(loss), float(p["loss"]), rel))
+        assert rel < 1e-5
+        loss.backward()
+        check_grads(m, grads, tol=5e-4)
+    finally:
+        JointNetwork.loss = orig
+
+
+@pytest.mark.parametrize("prec", ["fp32", "bf16"])
+def test_fused_joint_loss_config5_shape_vs_materialised(prec):
+    """the width of BASELINE config 5 (J = 320, V = 5000, U = 101) on a short ragged batch: JointRNNTLossFn against the
+    materialised JointFn -> Linear -> RNNTLossFn path on the same operands: loss and all five gradients (fp32: 1e-5 /
+    2e-4; bf16 operands: the two paths round identically up to the dZ cast, 2e-2)"""
+    import espnet_amd
+    from espnet_amd import rnn_functional as R
+    from espnet_amd.nets.transducer.joint_network import JointNetwork
+    espnet_amd.set_precision(prec)
+    try:
+        torch.manual_seed(5)
+        B, T, U, De, Dd, J, V = 3, 41, 101, 256, 320, 320, 5000
+        jn = JointNetwork(V, De, Dd, J, "tanh").to(DEV)
+        g = torch.Generator().manual_seed(55)
+        he, hd = torch.randn(B, T, De, generator=g).to(DEV), torch.randn(B, U, Dd, generator=g).to(DEV)
+        y = torch.randint(1, V, (B, U - 1), generator=g).int().to(DEV)
+        tl_host = [41, 33, 20]
+        tl, ul = torch.tensor(tl_host, dtype=torch.int32).to(DEV), torch.tensor([100, 77, 51], dtype=torch.int32).to(DEV)
+        res = []
+        for fused in (True, False):
+            jn.zero_grad()
+            a, b = he.clone().requires_grad_(True), hd.clone().requires_grad_(True)
+            if fused:
+                loss = jn.loss(a, b, y, tl, ul, tl_host, 0, chunk_rows=1500)
+            else:
+                loss = R.RNNTLossFn.apply(jn(a, b).float(), y, tl, ul, 0)
+            loss.backward()
+            res.append((float(loss), a.grad, b.grad, [q.grad.clone() for q in jn.parameters()]))
+        rel = abs(res[0][0] - res[1][0]) / abs(res[1][0])
+        tol = 2e-4 if prec == "fp32" else 2e-2
+        print("[parity] fused joint+loss [%s] J=320 V=5000: %.6f vs materialised %.6f (rel %.2e)" % (prec, res[0][0], res[1][0], rel))
+        assert rel < (1e-5 if prec == "fp32" else 1e-4)
+        report("fused joint+loss [%s] d h_enc" % prec, res[0][1], res[1][1], tol)
+        report("fused joint+loss [%s] d h_dec" % prec, res[0][2], res[1][2], tol)
+        for (n_, _q), ga, gb in zip(jn.named_parameters(), res[0][3], res[1][3]):
+            report("fused joint+loss [%s] d %s" % (prec, n_), ga, gb, tol)
+    finally:
+        espnet_amd.set_precision("fp32")
+
+
 @pytest.mark.parametrize("name", _TRN_CASES)
 def test_transducer_decoding_golden(name):
     """greedy and default beam search (beam_search_transducer.py:130-237), with and without RNNLM fusion, reproduce the

@@ -187,6 +187,70 @@ void run_p(const float* in, float* out, int blocks) {
   printf("variant %d, %4d workgroups: %.3f ms  %.1f TFLOP/s\n", V, blocks, best, flop / (best * 1e-3) / 1e12);
 }
 
+//   8: LDS-DMA staging (global_load_lds_dwordx4 into the other LDS buffer at the top of the phase, no VGPR hop, no
+//      ds_write), unpadded [row][32] image (bank conflicts not swizzled away here), __syncthreads at the end
+template <int V>
+__global__ __launch_bounds__(256, 2) void loop_d(const float* __restrict__ in, float* out, int phases) {
+  __shared__ __attribute__((aligned(16))) float lds[2][2][64 * 32];
+  const int t = threadIdx.x, lane = t & 63, wave = t >> 6, wm = wave >> 1, wn = wave & 1, fr = lane & 15, fq = lane >> 4;
+  for (int i = t; i < 2 * 2 * 64 * 32; i += 256) (&lds[0][0][0])[i] = in[i & 4095];
+  __syncthreads();
+  f32x4 acc[2][2];
+  for (int i = 0; i < 2; ++i) for (int j = 0; j < 2; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  const float* gp = in + (blockIdx.x % 64) * 8192 + t * 4;
+  auto body = [&](auto bufc, int ph) __attribute__((always_inline)) {
+    constexpr int buf = decltype(bufc)::value;
+    // each wave fills 2 x 1 KiB of A and 2 x 1 KiB of B of the OTHER buffer: wave w covers rows 16w..16w+15
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      __builtin_amdgcn_global_load_lds(gp + ((ph * 2 + i) & 7) * 1024, (__attribute__((address_space(3))) void*)&lds[buf ^ 1][0][(wave * 16 + i * 8) * 32], 16, 0, 0);
+      __builtin_amdgcn_global_load_lds(gp + ((ph * 2 + i + 4) & 7) * 1024, (__attribute__((address_space(3))) void*)&lds[buf ^ 1][1][(wave * 16 + i * 8) * 32], 16, 0, 0);
+    }
+#pragma unroll
+    for (int kk = 0; kk < 2; ++kk) {
+      float af[2][4], bf[2][4];
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        const int ra_ = wm * 32 + i * 16 + fr, rb_ = wn * 32 + i * 16 + fr;
+        const int ca = ((kk * 4 + fq) ^ ((ra_ >> 1) & 7)) * 4, cb = ((kk * 4 + fq) ^ ((rb_ >> 1) & 7)) * 4;
+        const float4 v = *reinterpret_cast<const float4*>(&lds[buf][0][ra_ * 32 + ca]);
+        const float4 w = *reinterpret_cast<const float4*>(&lds[buf][1][rb_ * 32 + cb]);
+        af[i][0] = v.x; af[i][1] = v.y; af[i][2] = v.z; af[i][3] = v.w;
+        bf[i][0] = w.x; bf[i][1] = w.y; bf[i][2] = w.z; bf[i][3] = w.w;
+      }
+#pragma unroll
+      for (int e = 0; e < 4; ++e)
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+          for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[i][e], bf[j][e], acc[i][j], 0, 0, 0);
+    }
+    __syncthreads();
+  };
+  for (int ph = 0; ph < phases; ph += 2) {
+    body(std::integral_constant<int, 0>{}, ph);
+    body(std::integral_constant<int, 1>{}, ph + 1);
+  }
+  float s = 0.f;
+  for (int i = 0; i < 2; ++i) for (int j = 0; j < 2; ++j) s += acc[i][j][0] + acc[i][j][1] + acc[i][j][2] + acc[i][j][3];
+  out[blockIdx.x * 256 + t] = s;
+}
+template <int V>
+void run_d(const float* in, float* out, int blocks) {
+  hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
+  const int phases = 2000;
+  float best = 1e9, ms;
+  for (int rep = 0; rep < 5; ++rep) {
+    hipEventRecord(e0);
+    hipLaunchKernelGGL(loop_d<V>, dim3(blocks), dim3(256), 0, 0, in, out, phases);
+    hipEventRecord(e1); hipEventSynchronize(e1);
+    hipEventElapsedTime(&ms, e0, e1);
+    if (ms < best) best = ms;
+  }
+  double flop = (double)blocks * 4 * phases * 32 * 2048.0;
+  printf("variant %d, %4d workgroups: %.3f ms  %.1f TFLOP/s\n", V, blocks, best, flop / (best * 1e-3) / 1e12);
+}
+
 int main() {
   float *in, *out;
   hipMalloc(&in, 64 * 8192 * 4 + 65536); hipMalloc(&out, 2048 * 256 * 4);
@@ -195,7 +259,7 @@ int main() {
   hipMemcpy(in, h.data(), h.size() * 4, hipMemcpyHostToDevice);
   for (int blocks : {512, 768}) {
     run<0>(in, out, blocks); run<2>(in, out, blocks); run<3>(in, out, blocks); run<4>(in, out, blocks);
-    run_p<5>(in, out, blocks); run_p<6>(in, out, blocks); run_p<7>(in, out, blocks);
+    run_p<5>(in, out, blocks); run_p<6>(in, out, blocks); run_p<7>(in, out, blocks); run_d<8>(in, out, blocks);
   }
   return 0;
 }
