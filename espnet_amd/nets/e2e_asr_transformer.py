@@ -157,16 +157,27 @@ class E2E(ASRInterface, torch.nn.Module):
                 m.reset_parameters()
 
     # ---- training forward ---------------------------------------------------------------------
-    def prepare(self, xs_pad, ilens, ys_pad):
+    def prepare(self, xs_pad, ilens, ys_pad, pad_to=None):
         """Host-side part of forward (lengths, masks, <sos>/<eos>): everything that needs Python lists
         or H2D copies.  The returned dict feeds forward_core(), which only launches kernels and can be
-        captured into a hipGraph.  reference: e2e_asr_transformer.py:173-183,202."""
+        captured into a hipGraph.  reference: e2e_asr_transformer.py:173-183,202.
+        pad_to = (T, L): instead of cropping to the longest utterance, pad frames (zeros) and labels (ignore_id) up to
+        these sizes - the batch then has the shapes of its bucket (train.BucketedGraphStep)."""
         il = [int(v) for v in (ilens.tolist() if isinstance(ilens, torch.Tensor) else ilens)]
         tmax = max(il)
         dev = next(self.parameters()).device
+        if pad_to is not None:
+            Tb, Lb = pad_to
+            assert Tb >= tmax
+            xp = xs_pad.new_zeros(xs_pad.shape[0], Tb, xs_pad.shape[2])
+            xp[:, :tmax] = xs_pad[:, :tmax]
+            yp = ys_pad.new_full((ys_pad.shape[0], Lb), self.ignore_id)
+            n = min(Lb, ys_pad.shape[1])
+            yp[:, :n] = ys_pad[:, :n]
+            xs_pad, ys_pad, tmax = xp, yp, Tb
         xs_pad = xs_pad[:, :tmax].to(dev).contiguous()
         ys_pad = ys_pad.to(dev).contiguous()
-        src_mask = make_non_pad_mask(il).unsqueeze(-2).to(dev).to(torch.uint8)     # (B,1,T)
+        src_mask = make_non_pad_mask(il, tmax).unsqueeze(-2).to(dev).to(torch.uint8)     # (B,1,T)
         batch = dict(xs_pad=xs_pad, ys_pad=ys_pad, src_mask=src_mask, B=xs_pad.size(0))
         if self.decoder is not None:
             ys_in_pad, ys_out_pad, _ = ops.add_sos_eos(ys_pad, self.sos, self.eos, self.ignore_id)

@@ -381,6 +381,73 @@ class GraphedDataParallelStep:
         return self.loss
 
 
+class BucketedGraphStep:
+    """hipGraph replay for batches whose shapes vary (real recipes batch by `batch_bins`: B, T and L all move).
+    A batch is padded up to its BUCKET - (B, T rounded up to `t_edge` frames, L rounded up to `l_edge` labels) - and
+    each bucket owns one captured graph of the whole training step (zero grads, forward, backward, clip, Adam,
+    schedule); a least-recently-used cache keeps `max_graphs` of them, all captured into one shared memory pool
+    (they never replay concurrently).  First sight of a bucket runs the step eagerly (that IS the warm-up the capture
+    needs, and it is a real training step, so the trajectory does not depend on the cache); the second sight captures
+    and replays; later ones copy the new batch into the graph's static inputs and replay.
+
+    Padding semantics: frames are padded with zeros and masked exactly as a longer utterance in the same batch would
+    mask them, labels with ignore_id; the result equals the eager step on the same padded batch (tested).  It is not
+    bit-equal to the step on the cropped batch: the reference's own results depend on a batch's longest utterance the
+    same way (subsampled mask lengths, and BatchNorm statistics that include padded frames, conformer/convolution.py)."""
+
+    def __init__(self, model, flat, opt, t_edge=64, l_edge=8, max_graphs=8):
+        from collections import OrderedDict
+        self.model, self.flat, self.opt = model, flat, opt
+        self.t_edge, self.l_edge, self.max_graphs = int(t_edge), int(l_edge), int(max_graphs)
+        self.cache = OrderedDict()          # bucket -> dict(graph, static, loss)
+        self.seen = {}                      # bucket -> number of eager runs so far
+        self.pool = None
+        self.hits = self.misses = self.captures = self.evictions = 0
+
+    def bucket(self, xs_pad, ilens, ys_pad):
+        il = [int(v) for v in (ilens.tolist() if torch.is_tensor(ilens) else ilens)]
+        T = max(il)
+        L = int((ys_pad != self.model.ignore_id).sum(1).max())
+        up = lambda v, e: (v + e - 1) // e * e  # noqa: E731
+        return (int(xs_pad.shape[0]), up(T, self.t_edge), up(max(L, 1), self.l_edge))
+
+    def __call__(self, xs_pad, ilens, ys_pad):
+        key = self.bucket(xs_pad, ilens, ys_pad)
+        batch = self.model.prepare(xs_pad, ilens, ys_pad, pad_to=key[1:])
+        entry = self.cache.get(key)
+        if entry is not None:
+            self.cache.move_to_end(key)
+            for k, v in batch.items():
+                if torch.is_tensor(v):
+                    entry["static"][k].copy_(v, non_blocking=True)
+            entry["graph"].replay()
+            self.hits += 1
+            return entry["loss"]
+        self.misses += 1
+        if self.seen.get(key, 0) == 0:          # first sight: eager step (doubles as the capture's warm-up)
+            self.seen[key] = 1
+            return train_step(self.model, self.flat, self.opt, batch)
+        # second sight: capture the step on this batch's tensors (they become the graph's static inputs), then replay
+        torch.cuda.synchronize()
+        g = torch.cuda.CUDAGraph()
+        if self.pool is None:
+            self.pool = torch.cuda.graph_pool_handle()
+        with torch.cuda.graph(g, pool=self.pool):
+            loss = train_step(self.model, self.flat, self.opt, batch)
+        g.replay()
+        self.captures += 1
+        self.cache[key] = dict(graph=g, static=batch, loss=loss)
+        if len(self.cache) > self.max_graphs:
+            self.cache.popitem(last=False)
+            self.evictions += 1
+        return loss
+
+    def stats(self):
+        n = self.hits + self.misses
+        return dict(steps=n, hits=self.hits, hit_rate=(self.hits / n if n else 0.0), captures=self.captures,
+                    evictions=self.evictions, graphs=len(self.cache))
+
+
 class EpochRunner:
     """espnet2 Trainer.train_one_epoch / validate_one_epoch semantics for one process per GPU
     (reference: espnet2/train/trainer.py:325-495,497-539; recursive_average, torch_utils/recursive_op.py:14-53).

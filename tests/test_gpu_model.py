@@ -1291,3 +1291,43 @@ def test_fp32_fused_paths_match_separate_paths():
     print(f"[parity] fp32 fused vs separate paths: loss {res[0][0]:.6f} vs {res[1][0]:.6f} (rel {rel:.2e})")
     assert rel < 1e-6
     report("fp32 fused vs separate paths: gradient arena", res[0][1], res[1][1], 2e-5)
+
+
+def test_bucketed_graph_step_matches_eager():
+    """a stream of batches of two different shapes through train.BucketedGraphStep (eager on first sight, capture on
+    the second, replay afterwards) against plain eager steps on the same padded batches with an identical second model:
+    same loss at every step, same parameters at the end (dropout 0: two model instances draw different dropout salts);
+    cache statistics as designed"""
+    from espnet_amd import ops, train
+    models = []
+    for _ in range(2):
+        m = _c1_transformer(dropout=0.0).to(DEV).train()
+        flat = train.FlatParams(m)
+        opt = train.NoamAdam(flat, mode="noam", factor=1.0, model_size=64, warmup=100, max_grad_norm=5.0)
+        models.append((m, flat, opt))
+    g = torch.Generator().manual_seed(9)
+
+    def batch(B, T, L):
+        xs = torch.randn(B, T, 20, generator=g)
+        ilens = [T - 5 * i for i in range(B)]
+        for i, n in enumerate(ilens):
+            xs[i, n:] = 0.0
+        ys = torch.randint(1, 49, (B, L), generator=g)
+        ys[-1, L - 2:] = -1
+        return xs, ilens, ys
+
+    stream = [batch(4, 150, 11), batch(3, 90, 6), batch(4, 141, 10), batch(3, 70, 7), batch(4, 133, 12), batch(3, 100, 5),
+              batch(4, 160, 9)]
+    bstep = train.BucketedGraphStep(models[0][0], models[0][1], models[0][2], t_edge=64, l_edge=8, max_graphs=4)
+    assert bstep.bucket(*stream[0]) == (4, 192, 16) == bstep.bucket(*stream[2]) and bstep.bucket(*stream[1]) == (3, 128, 8)
+    for i, (xs, ilens, ys) in enumerate(stream):
+        ops.manual_seed(1000 + i)
+        la = float(bstep(xs, ilens, ys))
+        ops.manual_seed(1000 + i)
+        m, flat, opt = models[1]
+        lb = float(train.train_step(m, flat, opt, m.prepare(xs, ilens, ys, pad_to=bstep.bucket(xs, ilens, ys)[1:])))
+        print(f"[parity] bucketed graph step {i} {bstep.bucket(xs, ilens, ys)}: loss {la:.6f} eager {lb:.6f}")
+        assert abs(la - lb) <= 1e-5 * abs(lb), i
+    report("bucketed graph: parameters after 7 steps (split-K atomics differ in order between runs)", models[0][1].data, models[1][1].data, 1e-4)
+    st = bstep.stats()
+    assert st["captures"] == 2 and st["hits"] == 3 and st["steps"] == 7 and st["graphs"] == 2, st
