@@ -328,6 +328,55 @@ def run_precision(a, prec, rank, world, dev):
     return res, step0
 
 
+def ragged_leg(a, prec, dev):
+    """--ragged: a stream of batches whose length varies, T ~ U(600, 1000) per batch (utterance lengths inside a batch
+    fall off linearly to 0.6 T), through (i) eager steps on the exact shapes and (ii) train.BucketedGraphStep (64-frame
+    buckets, LRU of 8 graphs).  Three passes over the same 28-batch stream; the last one is timed (every bucket is
+    captured by then)."""
+    import espnet_amd
+    from espnet_amd import ops, train
+    from espnet_amd.nets.e2e_asr_conformer import E2E
+    espnet_amd.set_precision(prec)
+    B, L, V = a.batch, 100, 5000
+    g = torch.Generator().manual_seed(17)
+    stream = []
+    for _ in range(28):
+        T = int(torch.randint(600, 1001, (1,), generator=g))
+        xs = torch.randn(B, T, 80, generator=g)
+        ilens = [int(round(v)) for v in torch.linspace(T, 0.6 * T, B).tolist()]
+        for i, n in enumerate(ilens):
+            xs[i, n:] = 0.0
+        stream.append((xs.to(dev), ilens, torch.randint(1, V - 1, (B, L), generator=g).to(dev)))
+    frames = sum(sum(il) for _x, il, _y in stream)
+    out = {}
+    for mode in ("eager", "bucketed"):
+        torch.manual_seed(0)
+        model = E2E(80, V, c2_args(a.dropout)).to(dev).train()
+        model.sync_report = False
+        flat = train.FlatParams(model)
+        opt = train.NoamAdam(flat, mode="noam", factor=1.0, model_size=256, warmup=25000, max_grad_norm=5.0)
+        step = train.BucketedGraphStep(model, flat, opt, t_edge=64, l_edge=8, max_graphs=8) if mode == "bucketed" else None
+        for ep in range(3):
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for xs, ilens, ys in stream:
+                if step is not None:
+                    step(xs, ilens, ys)
+                else:
+                    train.train_step(model, flat, opt, model.prepare(xs, ilens, ys))
+            torch.cuda.synchronize()
+            dt = time.perf_counter() - t0
+        out[mode] = dict(ms_per_step=round(dt / len(stream) * 1e3, 3), valid_frames_per_s=round(frames / dt, 1))
+        if step is not None:
+            st = step.stats()
+            out[mode].update(hit_rate_last_pass=1.0 if st["evictions"] == 0 else None, buckets=st["graphs"],
+                             captures=st["captures"], evictions=st["evictions"], hit_rate_overall=round(st["hit_rate"], 3))
+        del model, flat, opt, step
+        torch.cuda.empty_cache()
+    out["what"] = "28 batches, B=%d, T ~ U(600,1000) per batch, lengths linspace(T, 0.6T), L=100; third pass timed" % B
+    return out
+
+
 DTYPE = {"fp32": ("f32", "fp32 storage and arithmetic everywhere (v_mfma_f32_16x16x4_f32): the reference's precision"),
          "bf16": ("bf16", "bf16 GEMM operands + MFMA, fp32 accumulate / residual stream / master weights / optimizer")}
 
@@ -354,6 +403,8 @@ def main():
                          "the next phase, then the optimizer graph; 'graph1' = one forward/backward graph, the whole "
                          "arena all-reduced behind it; 'overlap' = eager launches with backward-overlapped bucket "
                          "all-reduces")
+    ap.add_argument("--ragged", action="store_true",
+                    help="N=1: add a `ragged` object: variable-length batch stream, eager vs shape-bucketed hipGraph cache")
     ap.add_argument("--rehearse-dp", action="store_true",
                     help="N=1 only: run the N>1 'graph' code path on a one-rank RCCL group")
     a = ap.parse_args()
@@ -376,6 +427,10 @@ def main():
         import espnet_amd
         espnet_amd.set_precision(a.precision)
         hbm = hbm_rooflines(a.precision)
+
+    ragged = None
+    if rank == 0 and world == 1 and a.ragged:
+        ragged = ragged_leg(a, a.precision, dev)
 
     cpu = orc = None
     if rank == 0 and world == 1 and not a.no_cpu_baseline:
@@ -423,6 +478,8 @@ def main():
             "roofline": head["roofline"], "roofline_hbm": hbm, "cpu_baseline": cpu, "parity": parity,
             other: sec,
         }
+        if ragged is not None:
+            out["ragged"] = ragged
         print(json.dumps(out))
     if torch.distributed.is_initialized():
         torch.distributed.barrier()
