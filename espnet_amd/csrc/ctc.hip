@@ -10,6 +10,7 @@
 //   alpha_beta : one block per (b, direction): wavefront scan over T in log space, states across
 //                lanes, previous column exchanged through LDS (double buffered, 1 barrier per frame)
 //   grad       : one block per (t,b): softmax row minus per-label occupancies accumulated in LDS
+#include <stdlib.h>
 #include "common.h"
 #include "../../include/espnet_amd.h"
 
@@ -20,22 +21,29 @@ __device__ __forceinline__ float lse2(float a, float b) {
   if (m == -INFINITY) return -INFINITY;
   return m + logf(expf(a - m) + expf(b - m));
 }
+// the scan's critical path: hardware exp2 / log2 forms (v_exp_f32 / v_log_f32; arguments are <= 0 resp. in [1, 3]),
+// the libm-accurate chains tripled the per-frame latency of the serial T-frame recursion
 __device__ __forceinline__ float lse3(float a, float b, float c) {
   float m = fmaxf(fmaxf(a, b), c);
   if (m == -INFINITY) return -INFINITY;
-  return m + logf(expf(a - m) + expf(b - m) + expf(c - m));
+  return m + __logf(__expf(a - m) + __expf(b - m) + __expf(c - m));
 }
 
-__global__ void ctc_prep_kernel(const long long* __restrict__ ys, int Lmax, int ignore_id, int* __restrict__ lab,
-                                int* __restrict__ lablen, int B) {
-  const int b = blockIdx.x * blockDim.x + threadIdx.x;
-  if (b >= B) return;
+// one wave per utterance: 64 labels per step, kept ones compacted by ballot / popcount (a thread per utterance walked the
+// Lmax labels through 100 dependent loads: 25 us at config 2)
+__global__ __launch_bounds__(64) void ctc_prep_kernel(const long long* __restrict__ ys, int Lmax, int ignore_id,
+                                                      int* __restrict__ lab, int* __restrict__ lablen, int B) {
+  const int b = blockIdx.x, lane = threadIdx.x;
   int n = 0;
-  for (int i = 0; i < Lmax; ++i) {
-    long long y = ys[(long)b * Lmax + i];
-    if (y != ignore_id) lab[(long)b * Lmax + n++] = (int)y;
+  for (int i0 = 0; i0 < Lmax; i0 += 64) {
+    const int i = i0 + lane;
+    const long long y = i < Lmax ? ys[(long)b * Lmax + i] : (long long)ignore_id;
+    const bool keep = i < Lmax && y != ignore_id;
+    const unsigned long long m = __ballot(keep);
+    if (keep) lab[(long)b * Lmax + n + __popcll(m & ((1ULL << lane) - 1ULL))] = (int)y;
+    n += __popcll(m);
   }
-  lablen[b] = n;
+  if (lane == 0) lablen[b] = n;
 }
 
 __global__ __launch_bounds__(256) void ctc_lse_gather_kernel(const float* __restrict__ x, long st, long sb,
@@ -48,12 +56,26 @@ __global__ __launch_bounds__(256) void ctc_lse_gather_kernel(const float* __rest
   const int t = blockIdx.x, b = blockIdx.y;
   if (t >= ilen[b]) return;
   const float* xr = x + t * st + b * sb;
-  float mx = -INFINITY;
-  for (int v = threadIdx.x; v < V; v += blockDim.x) mx = fmaxf(mx, xr[v]);
+  // one pass over the row: running maximum and rescaled sum per thread (16-byte loads where the row allows)
+  float mx = -INFINITY, se = 0.f;
+  if (((reinterpret_cast<uintptr_t>(xr) & 15) == 0) && (V % 4 == 0)) {
+    const float4* x4 = reinterpret_cast<const float4*>(xr);
+    for (int q = threadIdx.x; q < V / 4; q += blockDim.x) {
+      const float4 v = x4[q];
+      const float m4 = fmaxf(fmaxf(v.x, v.y), fmaxf(v.z, v.w));
+      if (m4 > mx) { se *= expf(mx - m4); mx = m4; }
+      se += (expf(v.x - mx) + expf(v.y - mx)) + (expf(v.z - mx) + expf(v.w - mx));
+    }
+  } else {
+    for (int v = threadIdx.x; v < V; v += blockDim.x) {
+      const float xv = xr[v];
+      if (xv > mx) { se *= expf(mx - xv); mx = xv; }
+      se += expf(xv - mx);
+    }
+  }
+  const float mt = mx;
   mx = block_max(mx, red);
-  float se = 0.f;
-  for (int v = threadIdx.x; v < V; v += blockDim.x) se += expf(xr[v] - mx);
-  se = block_sum(se, red);
+  se = block_sum(mt == -INFINITY ? 0.f : se * expf(mt - mx), red);
   const float lse = mx + logf(se);
   if (threadIdx.x == 0) lse_out[(long)b * T + t] = lse;
   const int S = 2 * lablen[b] + 1;
@@ -72,6 +94,7 @@ __global__ __launch_bounds__(1024) void ctc_alpha_beta_kernel(const float* __res
                                                               float* __restrict__ alpha, float* __restrict__ beta,
                                                               float* __restrict__ nll, int T, int Smax, int blank) {
   extern __shared__ float sh[];  // [2][Smax + 4]
+  constexpr int PF = 8;
   const int b = blockIdx.x;
   const int dir = blockIdx.y;
   const int s = threadIdx.x;
@@ -104,17 +127,30 @@ __global__ __launch_bounds__(1024) void ctc_alpha_beta_kernel(const float* __res
     if (active) { buf0[s + 2] = cur; out[s] = cur; }
     __syncthreads();
     float* prev = buf0; float* next = buf1;
-    float e = (active && Tb > 1) ? lpb[(long)Smax + s] : 0.f;
-    for (int t = 1; t < Tb; ++t) {
-      float e_next = (active && t + 1 < Tb) ? lpb[(long)(t + 1) * Smax + s] : 0.f;
-      if (active) {
-        float a = lse3(prev[s + 2], prev[s + 1], skip ? prev[s] : -INFINITY) + e;
-        next[s + 2] = a;
-        out[(long)t * Smax + s] = a;
+    // emissions are fetched PF frames ahead (a frame's own compute + barrier is ~0.1 us, an L2 / HBM round trip
+    // several times that: with one frame of look-ahead every step of the scan waited for its load)
+    float er[PF];
+#pragma unroll
+    for (int i = 0; i < PF; ++i) er[i] = (active && 1 + i < Tb) ? lpb[(long)(1 + i) * Smax + s] : 0.f;
+    for (int t0 = 1; t0 < Tb; t0 += PF) {
+      float en[PF];
+#pragma unroll
+      for (int i = 0; i < PF; ++i) en[i] = (active && t0 + PF + i < Tb) ? lpb[(long)(t0 + PF + i) * Smax + s] : 0.f;
+#pragma unroll
+      for (int i = 0; i < PF; ++i) {
+        const int t = t0 + i;
+        if (t < Tb) {                                 // block-uniform
+          if (active) {
+            float a = lse3(prev[s + 2], prev[s + 1], skip ? prev[s] : -INFINITY) + er[i];
+            next[s + 2] = a;
+            out[(long)t * Smax + s] = a;
+          }
+          __syncthreads();
+          float* tmp = prev; prev = next; next = tmp;
+        }
       }
-      __syncthreads();
-      float* tmp = prev; prev = next; next = tmp;
-      e = e_next;
+#pragma unroll
+      for (int i = 0; i < PF; ++i) er[i] = en[i];
     }
     if (s == 0) {
       float a1 = prev[S - 1 + 2];
@@ -127,17 +163,28 @@ __global__ __launch_bounds__(1024) void ctc_alpha_beta_kernel(const float* __res
     if (active) { buf0[s + 2] = cur; out[(long)(Tb - 1) * Smax + s] = cur; }
     __syncthreads();
     float* prev = buf0; float* next = buf1;
-    float e = (active && Tb > 1) ? lpb[(long)(Tb - 2) * Smax + s] : 0.f;
-    for (int t = Tb - 2; t >= 0; --t) {
-      float e_next = (active && t - 1 >= 0) ? lpb[(long)(t - 1) * Smax + s] : 0.f;
-      if (active) {
-        float a = lse3(prev[s + 2], prev[s + 3], skip ? prev[s + 4] : -INFINITY) + e;
-        next[s + 2] = a;
-        out[(long)t * Smax + s] = a;
+    float er[PF];
+#pragma unroll
+    for (int i = 0; i < PF; ++i) er[i] = (active && Tb - 2 - i >= 0) ? lpb[(long)(Tb - 2 - i) * Smax + s] : 0.f;
+    for (int t0 = Tb - 2; t0 >= 0; t0 -= PF) {
+      float en[PF];
+#pragma unroll
+      for (int i = 0; i < PF; ++i) en[i] = (active && t0 - PF - i >= 0) ? lpb[(long)(t0 - PF - i) * Smax + s] : 0.f;
+#pragma unroll
+      for (int i = 0; i < PF; ++i) {
+        const int t = t0 - i;
+        if (t >= 0) {                                 // block-uniform
+          if (active) {
+            float a = lse3(prev[s + 2], prev[s + 3], skip ? prev[s + 4] : -INFINITY) + er[i];
+            next[s + 2] = a;
+            out[(long)t * Smax + s] = a;
+          }
+          __syncthreads();
+          float* tmp = prev; prev = next; next = tmp;
+        }
       }
-      __syncthreads();
-      float* tmp = prev; prev = next; next = tmp;
-      e = e_next;
+#pragma unroll
+      for (int i = 0; i < PF; ++i) er[i] = en[i];
     }
   }
 }
@@ -212,8 +259,7 @@ int eamd_ctc_loss(const float* acts, int64_t stride_t, int64_t stride_b, const i
   float* alpha = (float*)w; w += (size_t)B * T * Smax * 4;
   float* beta = (float*)w;
 
-  hipLaunchKernelGGL(ctc_prep_kernel, dim3((B + 63) / 64), dim3(64), 0, s, (const long long*)ys_pad, Lmax, ignore_id,
-                     lab, lablen, B);
+  hipLaunchKernelGGL(ctc_prep_kernel, dim3(B), dim3(64), 0, s, (const long long*)ys_pad, Lmax, ignore_id, lab, lablen, B);
   EAMD_LAUNCH_CHECK();
   hipLaunchKernelGGL(ctc_lse_gather_kernel, dim3(T, B), dim3(256), 0, s, acts, (long)stride_t, (long)stride_b, ilens,
                      lab, lablen, Lm, lse, lp, T, V, Smax, blank);
