@@ -521,6 +521,92 @@ __global__ __launch_bounds__(256) void softmax_bwd_kernel(const float* __restric
 //   true_dist = eps/(V-1) everywhere, 1-eps at target; loss_row = sum_v td*(log td - logp_v)
 // One 256-thread block per row; grad (unscaled by upstream) = (softmax - td) * inv_denom.
 // ---------------------------------------------------------------------------------------------
+// Register-resident form for rows of up to 8192 logits (V % 4 == 0, 16-byte aligned rows): the row is read ONCE as
+// float4s (<= 8 per thread), max / argmax, sum-exp, sum and the gradient all come from registers, the gradient leaves
+// as float4 stores - the three-pass form below re-reads the row twice through L1 with scalar loads.
+template <int NV>
+__global__ __launch_bounds__(256) void lsm_loss_reg_kernel(const float* __restrict__ x, const long long* __restrict__ target,
+                                                           float* __restrict__ loss_rows, float* __restrict__ correct_rows,
+                                                           float* __restrict__ grad, int V, int ignore_id, float smoothing,
+                                                           float inv_denom) {
+  __shared__ float red[16];
+  __shared__ int redi[16];
+  const int row = blockIdx.x;
+  const float4* xr = reinterpret_cast<const float4*>(x + (long)row * V);
+  float4* gr = grad ? reinterpret_cast<float4*>(grad + (long)row * V) : nullptr;
+  const long long tg = target[row];
+  const int nq = V >> 2;
+  if (tg == ignore_id) {
+    if (gr) for (int q = threadIdx.x; q < nq; q += 256) gr[q] = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (threadIdx.x == 0) { loss_rows[row] = 0.f; correct_rows[row] = 0.f; }
+    return;
+  }
+  float4 v[NV];
+#pragma unroll
+  for (int i = 0; i < NV; ++i) {
+    const int q = threadIdx.x + 256 * i;
+    v[i] = q < nq ? xr[q] : make_float4(-INFINITY, -INFINITY, -INFINITY, -INFINITY);
+  }
+  float mx = -INFINITY; int am = 0x7fffffff;
+#pragma unroll
+  for (int i = 0; i < NV; ++i) {          // ascending index order within the thread: first maximum wins
+    const int base = (threadIdx.x + 256 * i) * 4;
+    if (v[i].x > mx) { mx = v[i].x; am = base; }
+    if (v[i].y > mx) { mx = v[i].y; am = base + 1; }
+    if (v[i].z > mx) { mx = v[i].z; am = base + 2; }
+    if (v[i].w > mx) { mx = v[i].w; am = base + 3; }
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    float om = __shfl_xor(mx, o, 64); int oi = __shfl_xor(am, o, 64);
+    if (om > mx || (om == mx && oi < am)) { mx = om; am = oi; }
+  }
+  const int w = threadIdx.x >> 6, l = threadIdx.x & 63;
+  if (l == 0) { red[w] = mx; redi[w] = am; }
+  __syncthreads();
+  mx = red[0]; am = redi[0];
+  for (int k = 1; k < 4; ++k)
+    if (red[k] > mx || (red[k] == mx && redi[k] < am)) { mx = red[k]; am = redi[k]; }
+  __syncthreads();
+  float se = 0.f, sx = 0.f;
+#pragma unroll
+  for (int i = 0; i < NV; ++i) {
+    if (threadIdx.x + 256 * i < nq) {
+      se += (__expf(v[i].x - mx) + __expf(v[i].y - mx)) + (__expf(v[i].z - mx) + __expf(v[i].w - mx));
+      sx += (v[i].x + v[i].y) + (v[i].z + v[i].w);
+    }
+  }
+  se = block_sum(se, red);
+  sx = block_sum(sx, red);
+  const float lse = mx + __logf(se);
+  const float conf = 1.f - smoothing;
+  const float low = smoothing / (V - 1);
+  const float logp_t = x[(long)row * V + tg] - lse;
+  const float sum_logp = sx - V * lse;
+  float loss = -conf * logp_t - low * (sum_logp - logp_t);
+  if (conf > 0.f) loss += conf * __logf(conf);
+  if (low > 0.f) loss += (V - 1) * low * __logf(low);
+  if (threadIdx.x == 0) {
+    loss_rows[row] = loss;
+    correct_rows[row] = (am == (int)tg) ? 1.f : 0.f;
+  }
+  if (gr) {
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+      const int q = threadIdx.x + 256 * i;
+      if (q < nq) {
+        const int base = q * 4;
+        float4 g;
+        g.x = (__expf(v[i].x - lse) - ((base == (int)tg) ? conf : low)) * inv_denom;
+        g.y = (__expf(v[i].y - lse) - ((base + 1 == (int)tg) ? conf : low)) * inv_denom;
+        g.z = (__expf(v[i].z - lse) - ((base + 2 == (int)tg) ? conf : low)) * inv_denom;
+        g.w = (__expf(v[i].w - lse) - ((base + 3 == (int)tg) ? conf : low)) * inv_denom;
+        gr[q] = g;
+      }
+    }
+  }
+}
+
 __global__ __launch_bounds__(256) void lsm_loss_kernel(const float* __restrict__ x,
                                                        const long long* __restrict__ target,
                                                        float* __restrict__ loss_rows,
@@ -804,9 +890,17 @@ int eamd_lsm_loss(const float* logits, const int64_t* target, float* loss_rows, 
                   float* grad, int rows, int V, int ignore_id, float smoothing, float inv_denom,
                   void* stream) {
   if (!logits || !target || !loss_rows || !correct_rows || rows <= 0 || V <= 1) return EAMD_EINVAL;
-  hipLaunchKernelGGL(lsm_loss_kernel, dim3(rows), dim3(256), 0, (hipStream_t)stream, logits,
-                     (const long long*)target, loss_rows, correct_rows, grad, V, ignore_id, smoothing,
-                     inv_denom);
+  const bool vec = V % 4 == 0 && V <= 8192 && (((uintptr_t)logits | (uintptr_t)grad) & 15) == 0;
+  if (vec && V <= 5120)
+    hipLaunchKernelGGL(lsm_loss_reg_kernel<5>, dim3(rows), dim3(256), 0, (hipStream_t)stream, logits,
+                       (const long long*)target, loss_rows, correct_rows, grad, V, ignore_id, smoothing, inv_denom);
+  else if (vec)
+    hipLaunchKernelGGL(lsm_loss_reg_kernel<8>, dim3(rows), dim3(256), 0, (hipStream_t)stream, logits,
+                       (const long long*)target, loss_rows, correct_rows, grad, V, ignore_id, smoothing, inv_denom);
+  else
+    hipLaunchKernelGGL(lsm_loss_kernel, dim3(rows), dim3(256), 0, (hipStream_t)stream, logits,
+                       (const long long*)target, loss_rows, correct_rows, grad, V, ignore_id, smoothing,
+                       inv_denom);
   EAMD_LAUNCH_CHECK();
   return EAMD_OK;
 }
