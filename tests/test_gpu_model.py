@@ -1331,3 +1331,26 @@ def test_bucketed_graph_step_matches_eager():
     report("bucketed graph: parameters after 7 steps (split-K atomics differ in order between runs)", models[0][1].data, models[1][1].data, 1e-4)
     st = bstep.stats()
     assert st["captures"] == 2 and st["hits"] == 3 and st["steps"] == 7 and st["graphs"] == 2, st
+
+
+def test_warpctc_slot_calling_convention():
+    """the warp-ctc operator slot exactly as the reference binds it (ctc.py:62-63,78-88): activations (T,B,V) on the
+    device, labels concatenated int32 on the CPU, both length vectors int32 on the CPU, size_average=True -> sum / B;
+    value and d/d acts against the ctc.npz fixture recorded from the reference's builtin path (same definition)"""
+    from espnet_amd.nets import modules as M
+    from espnet_amd.nets.warpctc import CTCLoss
+    p, sd, grads = split_golden(load_golden("ctc.npz"))
+    ctc = load_sd(M.CTC(6, 8, 0.0, ctc_type="warpctc"), sd)
+    hs = p["hs"].to(DEV).requires_grad_(True)
+    ys = [y[y != -1] for y in p["ys"]]
+    acts = ctc.logits(hs).transpose(0, 1)                                      # (T, B, V), as ctc.py:100 hands it over
+    labels = torch.cat(ys).cpu().int()
+    olens = torch.tensor([len(y) for y in ys], dtype=torch.int32)
+    hlens = torch.as_tensor(np.asarray(p["hlens"]), dtype=torch.int32)
+    loss = CTCLoss(size_average=True)(acts, labels, hlens, olens)
+    assert tuple(loss.shape) == (1,)
+    report("warp-ctc slot loss", loss[0], p["loss"], 2e-6)
+    loss.backward()
+    report("warp-ctc slot d hs", hs.grad, p["ghs"], 2e-5)
+    total = CTCLoss(size_average=False)(acts.detach(), labels, hlens, olens)
+    report("warp-ctc slot, size_average=False", total[0], p["loss"] * acts.shape[1], 2e-6)
