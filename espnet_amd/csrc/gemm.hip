@@ -400,7 +400,8 @@ extern "C" int eamd_gemm(const eamd_gemm_t* pp, void* stream_) {
     } else {
       // measured on MI355X (tools/gemm_f32_probe.py): from ~1 tile per CU on the 128x128 tile wins (4x fewer LDS
       // stores and barriers per MFMA), below that the 64x64 tile's 4x as many workgroups do
-      tile = (t128 >= 240 && p.M >= 128 && p.N >= 128) ? 128 : 64;
+      // (the generic kernel, which still serves fp32 operands with bf16 MFMA, keeps its old threshold)
+      tile = (t128 >= (p.precision == 0 ? 240 : 512) && p.M >= 128 && p.N >= 128) ? 128 : 64;
     }
   }
   if (tile != 64 && tile != 128) return EAMD_EINVAL;

@@ -424,6 +424,177 @@ inline int grid_for(long n) {
   return (int)(g < 1 ? 1 : (g > 65535 ? 65535 : g));
 }
 
+
+// ---- one LSTM time step as ONE launch --------------------------------------------------------------------------------------
+// gates = gx_t + b_hh + h_prev W_hh^T and the cell update, for all B utterances.  A workgroup owns U = 4 hidden units = the
+// 16 gate rows (i, f, g, o of each): a full 16-column MFMA tile.  Its 4 waves split the reduction over the H inputs; both
+// operands are read straight from global memory / L2 as 16-byte fragments (v_mfma_f32_16x16x4_f32: lane (row = lane % 16,
+// quad = lane / 16) holds 4 consecutive k of its row; MFMA e of a quad-step contracts k = k0 + 4*quad + e on both sides),
+// the four partial tiles are summed through LDS and 32 x 4 threads finish the cell.  Compared with the split-K GEMM
+// (zero fill + 256 atomically accumulated tiles) + cell kernel it replaces: no atomics, no [B,4H] round trip, 1 launch
+// instead of 3; the kernel boundary is the only inter-step synchronisation (a persistent kernel would pay a grid
+// barrier of several microseconds per step for the same all-to-all exchange of h).
+// reference: torch.nn.LSTM / LSTMCell steps inside rnn/encoders.py:36-117, rnn/decoders.py:120-134.
+constexpr int LS_U = 4;           // hidden units per workgroup in the forward step
+template <int MT>                 // batch tiles of 16 rows (B <= 16 * MT)
+__global__ __launch_bounds__(1024) void lstm_step_fwd_kernel(const float* __restrict__ gx, const float* __restrict__ w_hh,
+                                                            const float* __restrict__ b_hh, const float* __restrict__ h_prev,
+                                                            const float* __restrict__ c_prev,
+                                                            const unsigned char* __restrict__ live, float* __restrict__ h,
+                                                            float* __restrict__ c, float* __restrict__ y,
+                                                            float* __restrict__ acts, int B, int H) {
+  // the reduction is split over the workgroup's NW waves (up to 16: the step is latency-bound, what counts is how
+  // many 16-byte loads the CU has in flight); part[NW][MT*16][17]
+  extern __shared__ float part_raw[];
+  float (*part)[MT * 16][17] = reinterpret_cast<float (*)[MT * 16][17]>(part_raw);
+  const int t = threadIdx.x, lane = t & 63, wave = t >> 6, fr = lane & 15, fq = lane >> 4;
+  const int NW = blockDim.x >> 6;
+  const int u0 = blockIdx.x * LS_U;
+  // B-operand row n = gate (n / 4) of unit u0 + n % 4
+  const float* wrow = w_hh + ((long)(fr >> 2) * H + u0 + (fr & 3)) * H;
+  const int kw = H / NW, k_begin = wave * kw;
+  f32x4 acc[MT];
+#pragma unroll
+  for (int i = 0; i < MT; ++i) acc[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  const float* arow[MT];
+#pragma unroll
+  for (int i = 0; i < MT; ++i) arow[i] = h_prev + (long)min(i * 16 + fr, B - 1) * H;
+  for (int k0 = k_begin; k0 < k_begin + kw; k0 += 64) {       // 4 quad-steps of 16 k in flight
+    float4 bv[4], av[MT][4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int k = min(k0 + q * 16, k_begin + kw - 16) + fq * 4;
+      bv[q] = *reinterpret_cast<const float4*>(wrow + k);
+#pragma unroll
+      for (int i = 0; i < MT; ++i) av[i][q] = *reinterpret_cast<const float4*>(arow[i] + k);
+    }
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      if (k0 + q * 16 < k_begin + kw) {        // wave-uniform (the clamped tail steps re-read the last valid one)
+        const float b4[4] = {bv[q].x, bv[q].y, bv[q].z, bv[q].w};
+#pragma unroll
+        for (int i = 0; i < MT; ++i) {
+          const float a4[4] = {av[i][q].x, av[i][q].y, av[i][q].z, av[i][q].w};
+#pragma unroll
+          for (int e = 0; e < 4; ++e) acc[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(a4[e], b4[e], acc[i], 0, 0, 0);
+        }
+      }
+    }
+  }
+  // accumulator layout: lane (fr = column n, fq) holds rows 4*fq + r of the tile
+#pragma unroll
+  for (int i = 0; i < MT; ++i)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) part[wave][i * 16 + fq * 4 + r][fr] = acc[i][r];
+  __syncthreads();
+  for (int p = t; p < B * LS_U; p += blockDim.x) {
+    const int b = p / LS_U, j = p % LS_U, u = u0 + j;
+    float g4[4];
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      const int n = g * 4 + j;
+      float sacc = 0.f;
+      for (int w = 0; w < NW; ++w) sacc += part[w][b][n];
+      g4[g] = sacc + gx[(long)b * 4 * H + g * H + u] + (b_hh ? b_hh[g * H + u] : 0.f);
+    }
+    const float ig = sigm(g4[0]), fg = sigm(g4[1]), gg = tanhf(g4[2]), og = sigm(g4[3]);
+    const long idx = (long)b * H + u;
+    const float cp = c_prev[idx];
+    float cn = fg * cp + ig * gg;
+    float hn = og * tanhf(cn);
+    float yo = hn;
+    if (live && !live[b]) { cn = cp; hn = h_prev[idx]; yo = 0.f; }
+    c[idx] = cn; h[idx] = hn;
+    if (y) y[idx] = yo;
+    float* ab = acts + (long)b * 4 * H;
+    ab[u] = ig; ab[H + u] = fg; ab[2 * H + u] = gg; ab[3 * H + u] = og;
+  }
+}
+
+// Backward twin.  A workgroup owns U = 16 hidden units (a full MFMA tile of the recurrent input gradient):
+//   dh[b, u] = dh_pass[b, u] + sum_r dgates_next[b, r] * W_hh[r, u]      (r over the 4H gate rows; w_t = W_hh^T [H, 4H])
+// with the reduction split over its 4 waves, then the cell backward of its units writes dgates[b, {i,f,g,o}, u], dc_prev
+// and the masked pass-through.  dgates_next == NULL: the first backward step (no recurrent gradient yet).
+constexpr int LB_U = 16;
+template <int MT>
+__global__ __launch_bounds__(1024) void lstm_step_bwd_kernel(const float* __restrict__ dy, const float* __restrict__ dgates_next,
+                                                            const float* __restrict__ w_t, const float* __restrict__ dh_pass_in,
+                                                            const float* __restrict__ dc, const float* __restrict__ acts,
+                                                            const float* __restrict__ c_prev, const float* __restrict__ c,
+                                                            const unsigned char* __restrict__ live,
+                                                            float* __restrict__ dgates, float* __restrict__ dc_prev,
+                                                            float* __restrict__ dh_pass, int B, int H) {
+  extern __shared__ float part_raw[];
+  float (*part)[MT * 16][17] = reinterpret_cast<float (*)[MT * 16][17]>(part_raw);
+  const int t = threadIdx.x, lane = t & 63, wave = t >> 6, fr = lane & 15, fq = lane >> 4;
+  const int NW = blockDim.x >> 6;
+  const int u0 = blockIdx.x * LB_U;
+  const int K = 4 * H;
+  if (dgates_next) {
+    const float* wrow = w_t + (long)(u0 + fr) * K;
+    const int kw = K / NW, k_begin = wave * kw;
+    f32x4 acc[MT];
+#pragma unroll
+    for (int i = 0; i < MT; ++i) acc[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    const float* arow[MT];
+#pragma unroll
+    for (int i = 0; i < MT; ++i) arow[i] = dgates_next + (long)min(i * 16 + fr, B - 1) * K;
+    for (int k0 = k_begin; k0 < k_begin + kw; k0 += 64) {
+      float4 bv[4], av[MT][4];
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const int k = min(k0 + q * 16, k_begin + kw - 16) + fq * 4;
+        bv[q] = *reinterpret_cast<const float4*>(wrow + k);
+#pragma unroll
+        for (int i = 0; i < MT; ++i) av[i][q] = *reinterpret_cast<const float4*>(arow[i] + k);
+      }
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        if (k0 + q * 16 < k_begin + kw) {
+          const float b4[4] = {bv[q].x, bv[q].y, bv[q].z, bv[q].w};
+#pragma unroll
+          for (int i = 0; i < MT; ++i) {
+            const float a4[4] = {av[i][q].x, av[i][q].y, av[i][q].z, av[i][q].w};
+#pragma unroll
+            for (int e = 0; e < 4; ++e) acc[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(a4[e], b4[e], acc[i], 0, 0, 0);
+          }
+        }
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < MT; ++i)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) part[wave][i * 16 + fq * 4 + r][fr] = acc[i][r];
+  }
+  __syncthreads();
+  for (int p = t; p < B * LB_U; p += blockDim.x) {
+    const int b = p / LB_U, j = p % LB_U, u = u0 + j;
+    const long idx = (long)b * H + u;
+    float dhr = dh_pass_in ? dh_pass_in[idx] : 0.f;
+    if (dgates_next)
+      for (int w = 0; w < NW; ++w) dhr += part[w][b][j];
+    const float dcv = dc ? dc[idx] : 0.f;
+    float* db = dgates + (long)b * 4 * H;
+    if (live && !live[b]) {      // y was 0 there: only the recurrent-path gradient passes through
+      db[u] = 0.f; db[H + u] = 0.f; db[2 * H + u] = 0.f; db[3 * H + u] = 0.f;
+      dc_prev[idx] = dcv;
+      dh_pass[idx] = dhr;
+      continue;
+    }
+    const float dhv = dhr + (dy ? dy[idx] : 0.f);
+    const float* ab = acts + (long)b * 4 * H;
+    const float ig = ab[u], fg = ab[H + u], gg = ab[2 * H + u], og = ab[3 * H + u];
+    const float tc = tanhf(c[idx]);
+    const float dct = dcv + dhv * og * (1.f - tc * tc);
+    db[u] = dct * gg * ig * (1.f - ig);
+    db[H + u] = dct * c_prev[idx] * fg * (1.f - fg);
+    db[2 * H + u] = dct * ig * (1.f - gg * gg);
+    db[3 * H + u] = dhv * tc * og * (1.f - og);
+    dc_prev[idx] = dct * fg;
+    dh_pass[idx] = 0.f;
+  }
+}
+
 }  // namespace
 
 extern "C" {
@@ -445,6 +616,51 @@ int eamd_lstm_cell_bwd(const float* dy, const float* dh, const float* dc, const 
   if (live && !dh_pass) return EAMD_EINVAL;
   hipLaunchKernelGGL(lstm_bwd_kernel, dim3(grid_for((long)B * H)), dim3(256), 0, (hipStream_t)stream, dy, dh, dc, acts,
                      c_prev, c, live, dgates, dc_prev, dh_pass, B, H);
+  EAMD_LAUNCH_CHECK();
+  return EAMD_OK;
+}
+
+/* waves per workgroup of the step kernels: the largest count <= 16 that leaves every wave a multiple of 16 reduction steps */
+static int lstm_step_waves(int K) {
+  const int q = K / 16;
+  for (int d = 16; d > 1; --d)
+    if (q % d == 0) return d;
+  return 1;
+}
+
+/* one whole LSTM time step in one launch (recurrent product + cell); shapes it takes: H % 64 == 0, B <= 64, 16-byte
+ * aligned operands - EAMD_EUNSUPPORTED otherwise (the caller then runs eamd_gemm + eamd_lstm_cell_fwd) */
+int eamd_lstm_step_fwd(const float* gx, const float* w_hh, const float* b_hh, const float* h_prev, const float* c_prev,
+                       const uint8_t* live, float* h, float* c, float* y, float* acts, int B, int H, void* stream) {
+  if (!gx || !w_hh || !h_prev || !c_prev || !h || !c || !acts || B <= 0 || H <= 0) return EAMD_EINVAL;
+  if (H % 64 != 0 || B > 64 || (((uintptr_t)gx | (uintptr_t)w_hh | (uintptr_t)h_prev) & 15)) return EAMD_EUNSUPPORTED;
+  const int nw = lstm_step_waves(H);
+  const int mt = (B + 15) / 16;
+  const dim3 grid(H / LS_U), block(64 * nw);
+  const size_t lds = (size_t)nw * mt * 16 * 17 * sizeof(float);
+  hipStream_t s = (hipStream_t)stream;
+#define EAMD_LSF(MT_) hipLaunchKernelGGL(lstm_step_fwd_kernel<MT_>, grid, block, lds, s, gx, w_hh, b_hh, h_prev, c_prev, live, h, c, y, acts, B, H)
+  if (B <= 16) EAMD_LSF(1); else if (B <= 32) EAMD_LSF(2); else if (B <= 48) EAMD_LSF(3); else EAMD_LSF(4);
+#undef EAMD_LSF
+  EAMD_LAUNCH_CHECK();
+  return EAMD_OK;
+}
+
+/* one backward step: dh = dh_pass_in + dgates_next W_hh (w_t = W_hh^T [H, 4H]; dgates_next / dh_pass_in / dc may be NULL
+ * on the first step), then the cell backward -> dgates [B,4H], dc_prev [B,H], dh_pass [B,H] (masked rows' pass-through) */
+int eamd_lstm_step_bwd(const float* dy, const float* dgates_next, const float* w_t, const float* dh_pass_in, const float* dc,
+                       const float* acts, const float* c_prev, const float* c, const uint8_t* live, float* dgates,
+                       float* dc_prev, float* dh_pass, int B, int H, void* stream) {
+  if (!acts || !c_prev || !c || !dgates || !dc_prev || !dh_pass || B <= 0 || H <= 0 || (dgates_next && !w_t)) return EAMD_EINVAL;
+  if (H % 64 != 0 || B > 64 || (((uintptr_t)dgates_next | (uintptr_t)w_t) & 15)) return EAMD_EUNSUPPORTED;
+  const int nw = lstm_step_waves(4 * H);
+  const int mt = (B + 15) / 16;
+  const dim3 grid(H / LB_U), block(64 * nw);
+  const size_t lds = (size_t)nw * mt * 16 * 17 * sizeof(float);
+  hipStream_t s = (hipStream_t)stream;
+#define EAMD_LSB(MT_) hipLaunchKernelGGL(lstm_step_bwd_kernel<MT_>, grid, block, lds, s, dy, dgates_next, w_t, dh_pass_in, dc, acts, c_prev, c, live, dgates, dc_prev, dh_pass, B, H)
+  if (B <= 16) EAMD_LSB(1); else if (B <= 32) EAMD_LSB(2); else if (B <= 48) EAMD_LSB(3); else EAMD_LSB(4);
+#undef EAMD_LSB
   EAMD_LAUNCH_CHECK();
   return EAMD_OK;
 }

@@ -856,6 +856,29 @@ def lstm_cell_bwd(dy, dh, dc, acts, c_prev, c, live, dgates, dc_prev, dh_pass):
           "eamd_lstm_cell_bwd")
 
 
+def lstm_step_ok(B, H):
+    """shapes the one-launch LSTM step kernels take"""
+    return LSTM_FUSED_STEP and H % 64 == 0 and B <= 64
+
+
+LSTM_FUSED_STEP = True      # tests flip this to compare against the GEMM + cell-kernel steps
+
+
+def lstm_step_fwd(gx_t, w_hh, b_hh, h_prev, c_prev, live_t, h, c, y, acts):
+    B, H4 = gx_t.shape
+    H = H4 // 4
+    check(_lib.lib().eamd_lstm_step_fwd(ptr(gx_t), ptr(w_hh), ptr(b_hh), ptr(h_prev), ptr(c_prev), ptr(live_t), ptr(h), ptr(c),
+                                        ptr(y), ptr(acts), B, H, stream_ptr()), "eamd_lstm_step_fwd")
+
+
+def lstm_step_bwd(dy_t, dgates_next, w_t, dh_pass_in, dc, acts, c_prev, c, live_t, dgates, dc_prev, dh_pass):
+    B, H4 = acts.shape
+    H = H4 // 4
+    check(_lib.lib().eamd_lstm_step_bwd(ptr(dy_t), ptr(dgates_next), ptr(w_t), ptr(dh_pass_in), ptr(dc), ptr(acts), ptr(c_prev),
+                                        ptr(c), ptr(live_t), ptr(dgates), ptr(dc_prev), ptr(dh_pass), B, H, stream_ptr()),
+          "eamd_lstm_step_bwd")
+
+
 def maxpool2x2_fwd(x):
     B, H, W, Cc = x.shape
     y = torch.empty(B, (H + 1) // 2, (W + 1) // 2, Cc, device=x.device, dtype=torch.float32)

@@ -83,9 +83,13 @@ class LSTMSeqFn(torch.autograd.Function):
         zero = torch.zeros(B, H, device=dev, dtype=torch.float32)
         gates = torch.empty(B, H4, device=dev, dtype=torch.float32)
         hp, cp = zero, zero
+        fused = ops.lstm_step_ok(B, H)       # recurrent product + cell update of a step as ONE launch
         for t in (range(T - 1, -1, -1) if reverse else range(T)):
-            _rec_gemm(hp, w_hh, gates, B, H4, H, H, H, H4, bias=b_hh, R=gx[t], ldr=H4)
-            ops.lstm_cell_fwd(gates, cp, hp, None if live is None else live[t], h_out[t], c_out[t], y[t], acts[t])
+            if fused:
+                ops.lstm_step_fwd(gx[t], w_hh, b_hh, hp, cp, None if live is None else live[t], h_out[t], c_out[t], y[t], acts[t])
+            else:
+                _rec_gemm(hp, w_hh, gates, B, H4, H, H, H, H4, bias=b_hh, R=gx[t], ldr=H4)
+                ops.lstm_cell_fwd(gates, cp, hp, None if live is None else live[t], h_out[t], c_out[t], y[t], acts[t])
             hp, cp = h_out[t], c_out[t]
         ctx.save_for_backward(h_out, c_out, acts, zero, live if live is not None else zero)
         ctx.pr = GradSink.use((w_hh, b_hh))
@@ -104,6 +108,24 @@ class LSTMSeqFn(torch.autograd.Function):
         sink = GradSink(ctx.pr)
         dgates = torch.empty(T, B, H4, device=dev, dtype=torch.float32)
         dh, dc = None, None
+        if ops.lstm_step_ok(B, H):
+            # one launch per step: dh = dgates_next W_hh (+ the masked pass-through) and the cell backward; W_hh^T is made
+            # once per sequence so that the product's reduction runs along contiguous memory
+            w_t = w_hh.detach().t().contiguous()
+            dg_next = dpass = None
+            for t in (range(T) if reverse else range(T - 1, -1, -1)):
+                pt = t + 1 if reverse else t - 1
+                cprev = c_out[pt] if 0 <= pt < T else zero
+                dc_new = torch.empty(B, H, device=dev, dtype=torch.float32)
+                dpass_new = torch.empty(B, H, device=dev, dtype=torch.float32)
+                ops.lstm_step_bwd(dy[t], dg_next, w_t, dpass, dc, acts[t], cprev, c_out[t], live[t] if has_live else None,
+                                  dgates[t], dc_new, dpass_new)
+                dg_next, dpass, dc = dgates[t], dpass_new, dc_new
+            if T > 1:
+                dg, hp = (dgates[:-1], h_out[1:]) if reverse else (dgates[1:], h_out[:-1])
+                ops.linear_bwd_w(dg.reshape(-1, H4), hp.reshape(-1, H), sink.buf(0))
+            ops.colsum(dgates.view(-1, H4), sink.buf(1))
+            return (dgates,) + sink.results() + (None, None)
         for t in (range(T) if reverse else range(T - 1, -1, -1)):
             pt = t + 1 if reverse else t - 1            # frame whose state fed this step
             has_prev = 0 <= pt < T
@@ -134,11 +156,14 @@ class LSTMCellFn(torch.autograd.Function):
         dev = gx.device
         gx, h_prev, c_prev = gx.contiguous(), h_prev.contiguous(), c_prev.contiguous()
         gates = torch.empty(B, H4, device=dev, dtype=torch.float32)
-        _rec_gemm(h_prev, w_hh, gates, B, H4, H, H, H, H4, bias=b_hh, R=gx, ldr=H4)
         h = torch.empty(B, H, device=dev, dtype=torch.float32)
         c = torch.empty(B, H, device=dev, dtype=torch.float32)
         acts = gates                                       # activated gates overwrite the pre-activations
-        ops.lstm_cell_fwd(gates, c_prev, None, None, h, c, None, acts)
+        if ops.lstm_step_ok(B, H):
+            ops.lstm_step_fwd(gx, w_hh, b_hh, h_prev, c_prev, None, h, c, None, acts)
+        else:
+            _rec_gemm(h_prev, w_hh, gates, B, H4, H, H, H, H4, bias=b_hh, R=gx, ldr=H4)
+            ops.lstm_cell_fwd(gates, c_prev, None, None, h, c, None, acts)
         ctx.save_for_backward(acts, h_prev, c_prev, c)
         ctx.pr = GradSink.use((w_hh, b_hh) if b_hh is not None else (w_hh,))      # LSTMCell(bias=False): AttLocRec's att_lstm
         return h, c

@@ -335,6 +335,15 @@ int eamd_lstm_cell_fwd(const float* gates, const float* c_prev, const float* h_p
 int eamd_lstm_cell_bwd(const float* dy, const float* dh, const float* dc, const float* acts, const float* c_prev,
                        const float* c, const uint8_t* live, float* dgates, float* dc_prev, float* dh_pass, int B, int H,
                        void* stream);
+/* One LSTM time step as ONE launch: recurrent product h_prev W_hh^T (fp32 MFMA, both operands read as fragments from
+ * L2) + gx_t + b_hh + cell update; the backward twin computes dh = dh_pass_in + dgates_next W_hh (w_t = W_hh^T) and the
+ * cell backward.  H % 64 == 0 and B <= 64, else EAMD_EUNSUPPORTED (use eamd_gemm + eamd_lstm_cell_*).
+ * reference: torch.nn.LSTM / LSTMCell steps, rnn/encoders.py:36-117, rnn/decoders.py:120-134. */
+int eamd_lstm_step_fwd(const float* gx, const float* w_hh, const float* b_hh, const float* h_prev, const float* c_prev,
+                       const uint8_t* live, float* h, float* c, float* y, float* acts, int B, int H, void* stream);
+int eamd_lstm_step_bwd(const float* dy, const float* dgates_next, const float* w_t, const float* dh_pass_in, const float* dc,
+                       const float* acts, const float* c_prev, const float* c, const uint8_t* live, float* dgates,
+                       float* dc_prev, float* dh_pass, int B, int H, void* stream);
 /* One GRU step (torch.nn.GRU / GRUCell, gate order r,z,n; rnn/encoders.py:31-33,110-119, rnn/decoders.py:96,105,
  * transducer/rnn_decoder.py:50) on gx = x W_ih^T + b_ih and gh = h W_hh^T + b_hh (both [B,3H], eamd_gemm products).
  * acts [B,4H] = r, z, n, gh_n.  Backward: dgx, dgh [B,3H] and dh_direct [B,H] (the part of the gradient that reaches

@@ -519,3 +519,54 @@ def test_espnet2_rnn_model_golden(tag, dkw):
         assert [h.yseq.tolist() for h in got] == want
         for h, s in zip(got, scores):
             assert abs(float(h.score) - s) <= 1e-4 * max(1.0, abs(s))
+
+
+@pytest.mark.parametrize("shape", [(32, 1024, 9, True), (16, 320, 7, False), (5, 64, 11, True), (48, 128, 5, True)])
+def test_lstm_fused_step_kernels(shape):
+    """the one-launch LSTM step kernels (eamd_lstm_step_fwd / _bwd: fp32-MFMA recurrent product + cell in one launch)
+    inside LSTMSeqFn against torch.nn.LSTM in float64 (outputs, d input projections, d W_hh, d b_hh), forward and reversed
+    direction, with and without packed-sequence masking, and against the GEMM + cell-kernel steps they replace"""
+    from espnet_amd import ops
+    from espnet_amd import rnn_functional as R
+    B, H, T, masked = shape
+    g = torch.Generator().manual_seed(B + H)
+    ref = torch.nn.LSTM(H, H, 1).double()
+    w_hh, b_hh = ref.weight_hh_l0.detach().float().to(DEV), ref.bias_hh_l0.detach().float().to(DEV)
+    x = torch.randn(T, B, H, generator=g).double()
+    lens = sorted([max(1, T - (i * T) // (2 * B)) for i in range(B)], reverse=True) if masked else [T] * B
+    live = (torch.arange(T)[:, None] < torch.tensor(lens)[None, :]).to(torch.uint8).to(DEV).contiguous() if masked else None
+    gy = torch.randn(T, B, H, generator=g)
+    for t in range(T):
+        for b in range(B):
+            if t >= lens[b]:
+                gy[t, b] = 0.0
+    # float64 reference through pack_padded_sequence (what `live` reproduces)
+    xr = x.clone().requires_grad_(True)
+    packed = torch.nn.utils.rnn.pack_padded_sequence(xr, torch.tensor(lens), enforce_sorted=True)
+    yr, _ = torch.nn.utils.rnn.pad_packed_sequence(ref(packed)[0], total_length=T)
+    yr.backward(gy.double())
+    gx_ref = (xr.detach() @ ref.weight_ih_l0.detach().t() + ref.bias_ih_l0.detach()).float().to(DEV)
+    res = {}
+    for fused in (True, False):
+        ops.LSTM_FUSED_STEP = fused
+        try:
+            gx = gx_ref.clone().requires_grad_(True)
+            wh, bh = w_hh.clone().requires_grad_(True), b_hh.clone().requires_grad_(True)
+            y = R.LSTMSeqFn.apply(gx, wh, bh, live, False)
+            y.backward(gy.to(DEV))
+            res[fused] = (y.detach(), gx.grad, wh.grad, bh.grad)
+        finally:
+            ops.LSTM_FUSED_STEP = True
+    assert ops.lstm_step_ok(B, H)
+    report("lstm fused step y %s" % (shape,), res[True][0], yr.detach(), 2e-6)
+    report("lstm fused step dW_hh %s" % (shape,), res[True][2], ref.weight_hh_l0.grad, 2e-5)
+    report("lstm fused step db_hh %s" % (shape,), res[True][3], ref.bias_hh_l0.grad, 2e-5)
+    # d gx = d gates: against the unfused HIP path and, through W_ih, against the float64 input gradient
+    report("lstm fused step dgates vs GEMM + cell path %s" % (shape,), res[True][1], res[False][1], 2e-5)
+    report("lstm fused step dx %s" % (shape,), res[True][1].double().cpu() @ ref.weight_ih_l0.detach(), xr.grad, 2e-5)
+    # reversed direction: equals the forward direction on the time-reversed sequence when nothing is masked
+    if not masked:
+        gx = gx_ref.clone()
+        yb = R.LSTMSeqFn.apply(gx, w_hh, b_hh, None, True)
+        yf = R.LSTMSeqFn.apply(gx.flip(0).contiguous(), w_hh, b_hh, None, False)
+        report("lstm fused step reverse %s" % (shape,), yb, yf.flip(0), 1e-6)
