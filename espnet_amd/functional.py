@@ -242,7 +242,7 @@ class FFNBlockFn(torch.autograd.Function):
             ops.linear_bwd_w(dob, h, sink.buf(4), alpha=scale, db=sink.buf(5))
         else:
             ops.linear_bwd_w(dob, z, sink.buf(4), alpha=scale, b_act=act, db=sink.buf(5))   # dW2 += s * do^T act(z)
-        if h is not None and ops.fast():
+        if h is not None and (ops.fast() or ops.f32_epilogue_drop()):
             dz = ops.linear_bwd_x(dob, ops.wshadow(w2), epilogue=_act_epi(act), aux=z, alpha=scale, out_dtype=adt,
                                   drop=(p_in, s_in))
         else:
