@@ -14,7 +14,8 @@ from collections import defaultdict
 
 src, dst, tag, lps = sys.argv[1], sys.argv[2], sys.argv[3], float(sys.argv[4])
 prec = sys.argv[5] if len(sys.argv) > 5 else None
-os.makedirs(os.path.join(dst, tag + "_pmc"), exist_ok=True)
+pmcdir = tag + "_pmc" + ("_" + prec if prec else "")
+os.makedirs(os.path.join(dst, pmcdir), exist_ok=True)
 tot = {}
 for d in sorted(glob.glob(os.path.join(src, "pmc_*"))):
     if not os.path.isdir(d):
@@ -29,7 +30,7 @@ for d in sorted(glob.glob(os.path.join(src, "pmc_*"))):
             a[0] += 1
             a[1] += float(r["Counter_Value"])
     name = os.path.basename(d)[4:]
-    with open(os.path.join(dst, tag + "_pmc", name + "_summary.csv"), "w") as f:
+    with open(os.path.join(dst, pmcdir, name + "_summary.csv"), "w") as f:
         f.write("kernel,counter,dispatches,sum,mean\n")
         for (k, c), (n, s) in sorted(agg.items(), key=lambda kv: -kv[1][1]):
             f.write('"%s",%s,%d,%r,%r\n' % (k, c, n, s, s / n))
