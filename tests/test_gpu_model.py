@@ -1354,3 +1354,59 @@ def test_warpctc_slot_calling_convention():
     report("warp-ctc slot d hs", hs.grad, p["ghs"], 2e-5)
     total = CTCLoss(size_average=False)(acts.detach(), labels, hlens, olens)
     report("warp-ctc slot, size_average=False", total[0], p["loss"] * acts.shape[1], 2e-6)
+
+
+def _gdp_worker(rank, world, port, q):
+    import os
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
+                      LOCAL_RANK=str(rank), EAMD_FORCE_DEVICE="0", EAMD_DIST_BACKEND="gloo")
+    import espnet_amd
+    from espnet_amd import train
+    train.init_distributed()
+    espnet_amd.set_precision("fp32")
+    model = _c1_transformer().to("cuda").train()
+    flat = train.FlatParams(model)
+    opt = train.NoamAdam(flat, mode="noam", factor=1.0, model_size=64, warmup=100, max_grad_norm=5.0)
+    xs, ilens, ys = _c1_batch(8)
+    batch = model.prepare(xs[rank::world], ilens[rank::world], ys[rank::world])
+    dp = train.GraphedDataParallelStep(model, flat, opt, batch, world=world, phases=True, warmup=2)     # 2 real steps inside
+    nph = len(dp.ranges)
+    for _ in range(2):
+        dp()
+    torch.cuda.synchronize()
+    q.put((rank, nph, flat.data.cpu().numpy(), opt.stats()["step"]))
+    torch.distributed.barrier()
+    torch.distributed.destroy_process_group()
+
+
+def test_graphed_data_parallel_step_two_ranks():
+    """the driver of `bench.py --gpus N` (hipGraph phases + all-reduce of each phase's arena range under the next phase)
+    with two gloo ranks on cuda:0, each holding half of a batch of 8: after 2 warm-up + 2 replayed steps both replicas
+    hold the parameters a single process reaches in 4 eager steps on the whole batch (config-1 Transformer, no BatchNorm)"""
+    import socket
+    import torch.multiprocessing as mp
+    from espnet_amd import train
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_gdp_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    got = sorted((q.get(timeout=300) for _ in range(2)), key=lambda t: t[0])
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    model = _c1_transformer().to(DEV).train()
+    flat = train.FlatParams(model)
+    opt = train.NoamAdam(flat, mode="noam", factor=1.0, model_size=64, warmup=100, max_grad_norm=5.0)
+    xs, ilens, ys = _c1_batch(8)
+    batch = model.prepare(xs, ilens, ys)
+    for _ in range(4):
+        train.train_step(model, flat, opt, batch)
+    want = flat.data.cpu()
+    for rank, nph, data, steps in got:
+        assert nph == 3 and steps == 4, (nph, steps)
+        report("graphed DP step, 2 ranks (rank %d) vs single process" % rank, torch.from_numpy(data), want, 2e-5)
+    assert np.array_equal(got[0][2], got[1][2])
