@@ -1,0 +1,415 @@
+// Fused attention for fp32 activations (the reference's precision), d_k = 64, up to 256 keys, on the fp32 matrix
+// cores (v_mfma_f32_16x16x4_f32): scores (+ relative-position term with the legacy rel_shift), mask, softmax and the
+// context product in ONE kernel, and the query side of the backward in a second one; fp32 twins of attn_fused.hip.
+// reference: transformer/attention.py:63-114 (forward_attention / MultiHeadedAttention.forward),
+//            attention.py:141-206 (RelPositionMultiHeadedAttention: rel_shift, (ac + bd) / sqrt(d_k)).
+//
+// One workgroup = one (batch, head) pair x 64 queries; wave w owns 16 queries and ALL keys, so a softmax row never
+// leaves its wave.  Everything is computed in the transposed orientation S^T = K Q^T:
+//   * a 16x16x4 MFMA takes ONE float per lane per operand: lane (fr = lane & 15, fq = lane >> 4) supplies element
+//     (row fr, reduction index fq).  The order of the 64-channel contraction is free, so lane (fr, fq) takes the four
+//     16-byte chunks {4 j + fq} of row fr - four global loads of which each covers whole 64-byte segments - and MFMA
+//     (j, e) contracts channels 16 j + 4 fq + e.  K, q, positional and (q+v) fragments go straight from global memory
+//     into MFMA operands: no operand staging, no barriers in the score phase;
+//   * the accumulator of key tile t then holds, for query fr, the keys 16 t + 4 fq + {0..3}: four ADJACENT
+//     probabilities per lane (16-byte stores into P), and each of them IS the operand of the context product
+//     C^T = V^T P^T for the contraction step "keys 16 t + 4 fq + r, fq = 0..3".  V comes from a panel staged once per
+//     workgroup ([key][68] floats: the four fq groups of a ds_read_b32 fall into disjoint banks);
+//   * C^T leaves four adjacent channels per lane (16-byte stores).
+// The legacy rel_shift is a flat re-indexing of bd = (q+v) p^T padded with a zero column: shifted[i][j] =
+// pad_flat[T1 + i T2 + j] over rows of T2 + 1, i.e. query i reads rows i and i + 1 of bd.  The workgroup builds the
+// image of its 65 rows in LDS: each wave the 16 rows of its queries on the matrix cores, row 64 (first query of the
+// next workgroup) as 64-term dot products on the VALU - an MFMA tile for one row would double the bd work.  After the
+// softmax the image is dead and the V panel is staged over it.
+#include "common.h"
+
+namespace {
+
+constexpr int ATT_DK = 64;
+constexpr int ATT_MAXK = 256;                 // keys per row (16 accumulator tiles of 16)
+constexpr int PLD = 68;                       // row stride (floats) of the V / K panel in LDS
+
+struct AttnF32Args {
+  const float* qu; const float* qv; const float* k; const float* v; const float* pos;
+  const unsigned char* mask;
+  float* P; float* ctx;
+  long ldq, ldqv, ldk, ldv, ldpos, ldc, ldp, mb, mi;
+  int B, H, T1, T2, nqb;
+  float scale;
+};
+
+__device__ __forceinline__ float xmax16_32(float v) {
+  v = fmaxf(v, __shfl_xor(v, 16));
+  return fmaxf(v, __shfl_xor(v, 32));
+}
+__device__ __forceinline__ float xsum16_32(float v) {
+  v += __shfl_xor(v, 16);
+  return v + __shfl_xor(v, 32);
+}
+
+// this lane's share of a 64-channel row: chunks 4 j + fq
+__device__ __forceinline__ void load_frag(const float* row, int fq, float4 (&f)[4]) {
+#pragma unroll
+  for (int j = 0; j < 4; ++j) f[j] = *reinterpret_cast<const float4*>(row + 16 * j + 4 * fq);
+}
+// c += A B^T over the 64 channels, A rows / B rows held as load_frag leaves them
+__device__ __forceinline__ f32x4 dot_tile(const float4 (&x)[4], const float4 (&y)[4], f32x4 c) {
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    c = __builtin_amdgcn_mfma_f32_16x16x4f32(x[j].x, y[j].x, c, 0, 0, 0);
+    c = __builtin_amdgcn_mfma_f32_16x16x4f32(x[j].y, y[j].y, c, 0, 0, 0);
+    c = __builtin_amdgcn_mfma_f32_16x16x4f32(x[j].z, y[j].z, c, 0, 0, 0);
+    c = __builtin_amdgcn_mfma_f32_16x16x4f32(x[j].w, y[j].w, c, 0, 0, 0);
+  }
+  return c;
+}
+
+// panel [16 NKT rows][64 channels] of one (batch, head) -> LDS, rows past `rows` zeroed
+template <int NKT>
+__device__ __forceinline__ void stage_panel(const float* src, long ld, int rows, float* dst, int t) {
+  float4 r[NKT];
+#pragma unroll
+  for (int q = 0; q < NKT; ++q) {
+    const int c = t + 256 * q, row = c >> 4, c4 = c & 15;
+    r[q] = *reinterpret_cast<const float4*>(src + (long)min(row, rows - 1) * ld + c4 * 4);
+    if (row >= rows) r[q] = make_float4(0.f, 0.f, 0.f, 0.f);
+  }
+#pragma unroll
+  for (int q = 0; q < NKT; ++q) {
+    const int c = t + 256 * q, row = c >> 4, c4 = c & 15;
+    *reinterpret_cast<float4*>(&dst[row * PLD + c4 * 4]) = r[q];
+  }
+}
+
+// out^T[channel][query] += panel^T[channel][key] G^T[key][query] with G in the score-accumulator layout
+template <int NKT>
+__device__ __forceinline__ void panel_product(const float* panel, const f32x4 (&G)[NKT], int fr, int fq, f32x4 (&C)[4]) {
+#pragma unroll
+  for (int kt = 0; kt < NKT; ++kt)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const float* row = &panel[(kt * 16 + 4 * fq + r) * PLD + fr];
+#pragma unroll
+      for (int dt = 0; dt < 4; ++dt) C[dt] = __builtin_amdgcn_mfma_f32_16x16x4f32(row[dt * 16], G[kt][r], C[dt], 0, 0, 0);
+    }
+}
+
+// NKT = key tiles of 16 the instantiation covers (T2 <= 16 NKT).  Loops over tiles are fully unrolled and free of
+// branches: rows past T2 are clamped re-reads whose scores are masked, so the fragment loads of a phase overlap.
+template <bool REL, int NKT>
+__global__ __launch_bounds__(256, 2) void attn_f32_fwd_kernel(const AttnF32Args a) {
+  extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+  const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+  const int fr = lane & 15, fq = lane >> 4;
+  // (batch, head) pairs are dealt to the XCDs in contiguous runs: the query blocks of one pair share an L2
+  const int xcd = blockIdx.x & 7, jb = blockIdx.x >> 3;
+  const int z = (jb / a.nqb) * 8 + xcd;            // z = h * B + b, as the score tensors are laid out
+  const bool live = z < a.B * a.H;                 // whole workgroup; dead ones only keep the barriers company
+  const int zz = live ? z : 0;
+  const int h = zz / a.B, b = zz % a.B;
+  const int r0w = (jb % a.nqb) * 64;               // first query of the workgroup
+  const int r0 = r0w + wave * 16;                  // ... of this wave
+  const bool active = live && r0 < a.T1;
+  const int T1 = a.T1, T2 = a.T2;
+  const int qi = min(r0 + fr, T1 - 1);             // this lane's query (clamped lanes are never stored)
+  const int W = T2 + 1;
+
+  float* pad = reinterpret_cast<float*>(smem_raw);  // rows r0w .. r0w + 64 of [bd | zero column in front]
+  if (REL) {
+    if (active) {
+      float4 qf[4];
+      load_frag(a.qv + ((long)b * T1 + qi) * a.ldqv + h * ATT_DK, fq, qf);
+      float* prow = pad + (wave * 16 + fr) * W;
+      if (fq == 0) prow[0] = 0.f;
+#pragma unroll
+      for (int mt = 0; mt < NKT; ++mt) {
+        float4 pf[4];
+        load_frag(a.pos + (long)min(mt * 16 + fr, T2 - 1) * a.ldpos + h * ATT_DK, fq, pf);
+        const f32x4 c = dot_tile(pf, qf, (f32x4){0.f, 0.f, 0.f, 0.f});
+        // c[r] = bd[query r0 + fr][m = 16 mt + 4 fq + r]
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int m = mt * 16 + fq * 4 + r;
+          if (m < T2) prow[1 + m] = c[r];
+        }
+      }
+    }
+    if (live && r0w + 64 < T1 && t < T2) {          // row 64: one position per thread
+      const float4* qr = reinterpret_cast<const float4*>(a.qv + ((long)b * T1 + r0w + 64) * a.ldqv + h * ATT_DK);
+      const float4* pr = reinterpret_cast<const float4*>(a.pos + (long)t * a.ldpos + h * ATT_DK);
+      float s = 0.f;
+#pragma unroll
+      for (int j = 0; j < 16; ++j) {
+        const float4 x = qr[j], y = pr[j];
+        s += x.x * y.x + x.y * y.y + x.z * y.z + x.w * y.w;
+      }
+      pad[64 * W + 1 + t] = s;
+      if (t == 0) pad[64 * W] = 0.f;
+    }
+  }
+  f32x4 S[NKT];
+#pragma unroll
+  for (int kt = 0; kt < NKT; ++kt) S[kt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  if (active) {
+    // ---- ac^T tiles: rows = keys, columns = this wave's 16 queries ----
+    float4 qf[4];
+    load_frag(a.qu + ((long)b * T1 + qi) * a.ldq + h * ATT_DK, fq, qf);
+#pragma unroll
+    for (int kt = 0; kt < NKT; ++kt) {
+      float4 kf[4];
+      load_frag(a.k + ((long)b * T2 + min(kt * 16 + fr, T2 - 1)) * a.ldk + h * ATT_DK, fq, kf);
+      S[kt] = dot_tile(kf, qf, S[kt]);
+    }
+  }
+  if (REL) __syncthreads();                         // the image is complete (row r0 + 16 belongs to the next wave)
+  // ---- scale, rel-shift term, mask, softmax over the keys of query (r0 + fr) ----
+  if (active) {
+    // image index of (query i, key j): T1 + i T2 + j - r0w (T2 + 1); lanes past T1 are clamped into the image
+    const int pmax = 65 * W - 1;
+    const int pbase = T1 + (r0 + fr) * T2 - r0w * W;
+    // mask bytes of this lane's keys: unconditional clamped loads, all in flight together; keys past T2 are masked
+    // by index below
+    unsigned mk[NKT];
+    if (a.mask) {
+      const unsigned char* mr = a.mask + (long)b * a.mb + (long)qi * a.mi;
+#pragma unroll
+      for (int kt = 0; kt < NKT; ++kt) {
+        const int j0 = kt * 16 + fq * 4;
+        const unsigned m0 = mr[min(j0, T2 - 1)], m1 = mr[min(j0 + 1, T2 - 1)], m2 = mr[min(j0 + 2, T2 - 1)],
+                       m3 = mr[min(j0 + 3, T2 - 1)];
+        mk[kt] = m0 | (m1 << 8) | (m2 << 16) | (m3 << 24);
+      }
+    } else {
+#pragma unroll
+      for (int kt = 0; kt < NKT; ++kt) mk[kt] = 0x01010101u;
+    }
+    float mx = -INFINITY;
+#pragma unroll
+    for (int kt = 0; kt < NKT; ++kt) {
+      const int j0 = kt * 16 + fq * 4;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int j = j0 + r;
+        float x = S[kt][r];
+        if (REL) x += pad[min(pbase + j, pmax)];
+        x *= a.scale;
+        if (j >= T2 || ((mk[kt] >> (8 * r)) & 0xffu) == 0u) x = -INFINITY;
+        S[kt][r] = x;
+        mx = fmaxf(mx, x);
+      }
+    }
+    mx = xmax16_32(mx);
+    const bool dead = mx == -INFINITY;              // every key masked: softmax(min, ...) = uniform, then masked_fill(0)
+    float sum = 0.f;
+#pragma unroll
+    for (int kt = 0; kt < NKT; ++kt)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const float e = dead ? 0.f : __expf(S[kt][r] - mx);
+        S[kt][r] = e;
+        sum += e;
+      }
+    sum = xsum16_32(sum);
+    const float inv = dead ? 0.f : 1.f / sum;
+    const bool qok = r0 + fr < T1;
+    float* prow = a.P + ((long)zz * T1 + qi) * a.ldp;
+#pragma unroll
+    for (int kt = 0; kt < NKT; ++kt) {
+      S[kt] *= inv;
+      const int j0 = kt * 16 + fq * 4;
+      if (qok && j0 < a.ldp)                         // pad columns receive zeros
+        *reinterpret_cast<float4*>(prow + j0) = make_float4(S[kt][0], S[kt][1], S[kt][2], S[kt][3]);
+    }
+  }
+  __syncthreads();                                  // every wave is done with the image
+  float* Vs = reinterpret_cast<float*>(smem_raw);
+  stage_panel<NKT>(a.v + (long)b * T2 * a.ldv + h * ATT_DK, a.ldv, live ? T2 : 1, Vs, t);
+  __syncthreads();
+  if (!active) return;
+  // ---- context^T = V^T P^T: rows = channels, columns = queries ----
+  f32x4 C[4];
+#pragma unroll
+  for (int dt = 0; dt < 4; ++dt) C[dt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  panel_product<NKT>(Vs, S, fr, fq, C);
+  if (r0 + fr < T1) {
+    float* crow = a.ctx + ((long)b * T1 + r0 + fr) * a.ldc + h * ATT_DK;
+#pragma unroll
+    for (int dt = 0; dt < 4; ++dt)
+      *reinterpret_cast<float4*>(crow + dt * 16 + fq * 4) = make_float4(C[dt][0], C[dt][1], C[dt][2], C[dt][3]);
+  }
+}
+
+// ---- backward, query side: dP = dctx V^T, dS = scale * P (dP - rowsum(P dP)), dq = dS K in one launch ----
+// Same orientation and lane layout as the forward: dP^T tiles from register-direct V / dctx fragments, P re-read with
+// the 16-byte accesses the forward stored it with, the row sum inside the wave, dS stored for the key-side GEMMs
+// (dK = dS^T q, and with relative positions dqv / dpos from the inverse rel_shift scatter dbd, written here element by
+// element exactly as eamd_softmax_bwd does) and dq^T = K^T dS^T from the K panel in LDS - the context product of the
+// forward with K in place of V.  reference: autograd of attention.py:63-114, :141-206.
+struct AttnF32BwdArgs {
+  const float* dctx; const float* k; const float* v; const float* P;
+  float* dS; float* dbd; float* dq;
+  long ldd, ldk, ldv, ldp, ldo;
+  int B, H, T1, T2, nqb;
+  float scale;
+};
+
+template <int NKT>
+__global__ __launch_bounds__(256, 2) void attn_f32_bwd_q_kernel(const AttnF32BwdArgs a) {
+  extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+  const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+  const int fr = lane & 15, fq = lane >> 4;
+  const int xcd = blockIdx.x & 7, jb = blockIdx.x >> 3;
+  const int z = (jb / a.nqb) * 8 + xcd;
+  const bool live = z < a.B * a.H;
+  const int zz = live ? z : 0;
+  const int h = zz / a.B, b = zz % a.B;
+  const int r0 = (jb % a.nqb) * 64 + wave * 16;
+  const bool active = live && r0 < a.T1;
+  const int T1 = a.T1, T2 = a.T2;
+  const int qi = min(r0 + fr, T1 - 1);
+  const bool qok = r0 + fr < T1;
+
+  // K panel -> LDS first: nothing reads it before the barrier behind the score-gradient phase
+  float* Ks = reinterpret_cast<float*>(smem_raw);
+  stage_panel<NKT>(a.k + (long)b * T2 * a.ldk + h * ATT_DK, a.ldk, live ? T2 : 1, Ks, t);
+
+  f32x4 S[NKT];                                     // dP^T, then dS^T
+#pragma unroll
+  for (int kt = 0; kt < NKT; ++kt) S[kt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  if (active) {
+    float4 df[4];
+    load_frag(a.dctx + ((long)b * T1 + qi) * a.ldd + h * ATT_DK, fq, df);
+    const float* prow = a.P + ((long)zz * T1 + qi) * a.ldp;
+    float4 Pr[NKT];
+#pragma unroll
+    for (int kt = 0; kt < NKT; ++kt) {
+      const int j0 = kt * 16 + fq * 4;
+      Pr[kt] = *reinterpret_cast<const float4*>(prow + min(j0, (int)a.ldp - 4));
+      if (j0 >= (int)a.ldp) Pr[kt] = make_float4(0.f, 0.f, 0.f, 0.f);   // columns past ldp do not exist
+    }
+#pragma unroll
+    for (int kt = 0; kt < NKT; ++kt) {
+      float4 vf[4];
+      load_frag(a.v + ((long)b * T2 + min(kt * 16 + fr, T2 - 1)) * a.ldv + h * ATT_DK, fq, vf);
+      S[kt] = dot_tile(vf, df, S[kt]);
+    }
+    float s = 0.f;
+#pragma unroll
+    for (int kt = 0; kt < NKT; ++kt) {
+      const int j0 = kt * 16 + fq * 4;
+      const float pr[4] = {Pr[kt].x, Pr[kt].y, Pr[kt].z, Pr[kt].w};
+#pragma unroll
+      for (int r = 0; r < 4; ++r) if (j0 + r < T2) s += pr[r] * S[kt][r];
+    }
+    s = xsum16_32(s);
+    const long zo = (long)zz * T1 * a.ldp;
+    float* srow = a.dS + zo + (long)qi * a.ldp;
+    const int i = r0 + fr;
+#pragma unroll
+    for (int kt = 0; kt < NKT; ++kt) {
+      const int j0 = kt * 16 + fq * 4;
+      const float pr[4] = {Pr[kt].x, Pr[kt].y, Pr[kt].z, Pr[kt].w};
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int j = j0 + r;
+        const float g = j < T2 ? pr[r] * (S[kt][r] - s) * a.scale : 0.f;
+        S[kt][r] = g;
+        if (a.dbd && qok) {
+          // inverse rel_shift for T1 == T2 = T: padded index T + i T + j lands in row i (j <= i) or row i + 1
+          if (j < T2) {
+            const int R = j <= i ? i : i + 1, c = j <= i ? T2 + j - i : j - i - 1;
+            if (c != 0) a.dbd[zo + (long)R * a.ldp + (c - 1)] = g;
+          } else if (j < (int)a.ldp) {
+            a.dbd[zo + (long)i * a.ldp + j] = 0.f;    // pad columns of this row
+          }
+        }
+      }
+      if (qok && j0 < (int)a.ldp) *reinterpret_cast<float4*>(srow + j0) = make_float4(S[kt][0], S[kt][1], S[kt][2], S[kt][3]);
+    }
+    if (a.dbd && r0 == 0)                            // the head of row 0 the scatter never reaches
+      for (int f = 1 + lane; f < T1; f += 64) a.dbd[zo + (f - 1)] = 0.f;
+  }
+  __syncthreads();
+  if (!active) return;
+  // ---- dq^T = K^T dS^T: rows = channels, columns = queries ----
+  f32x4 C[4];
+#pragma unroll
+  for (int dt = 0; dt < 4; ++dt) C[dt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  panel_product<NKT>(Ks, S, fr, fq, C);
+  if (qok) {
+    float* orow = a.dq + ((long)b * T1 + r0 + fr) * a.ldo + h * ATT_DK;
+#pragma unroll
+    for (int dt = 0; dt < 4; ++dt)
+      *reinterpret_cast<float4*>(orow + dt * 16 + fq * 4) = make_float4(C[dt][0], C[dt][1], C[dt][2], C[dt][3]);
+  }
+}
+
+template <bool REL, int NKT>
+int launch_fwd(const AttnF32Args& a, size_t smem, hipStream_t stream) {
+  static const hipError_t attr_err = hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_f32_fwd_kernel<REL, NKT>),
+                                                         hipFuncAttributeMaxDynamicSharedMemorySize, 72 * 1024);
+  if (attr_err != hipSuccess) return (int)attr_err;
+  const int nz = (a.B * a.H + 7) / 8 * 8;
+  hipLaunchKernelGGL((attn_f32_fwd_kernel<REL, NKT>), dim3((unsigned)(a.nqb * nz)), dim3(256), smem, stream, a);
+  EAMD_LAUNCH_CHECK();
+  return EAMD_OK;
+}
+
+template <int NKT>
+int launch_bwd(const AttnF32BwdArgs& a, hipStream_t stream) {
+  static const hipError_t attr_err = hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_f32_bwd_q_kernel<NKT>),
+                                                         hipFuncAttributeMaxDynamicSharedMemorySize, 72 * 1024);
+  if (attr_err != hipSuccess) return (int)attr_err;
+  const int nz = (a.B * a.H + 7) / 8 * 8;
+  hipLaunchKernelGGL((attn_f32_bwd_q_kernel<NKT>), dim3((unsigned)(a.nqb * nz)), dim3(256),
+                     (size_t)NKT * 16 * PLD * sizeof(float), stream, a);
+  EAMD_LAUNCH_CHECK();
+  return EAMD_OK;
+}
+
+bool al16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
+
+}  // namespace
+
+extern "C" int eamd_attn_fwd_f32(const float* qu, int64_t ldq, const float* qv, int64_t ldqv, const float* k, int64_t ldk,
+                                 const float* v, int64_t ldv, const float* pos, int64_t ldpos, const unsigned char* mask,
+                                 int64_t mask_bstride, int64_t mask_qstride, float* P, int64_t ldp, float* ctx,
+                                 int64_t ldc, int B, int H, int T1, int T2, int dk, float scale, void* stream) {
+  if (!qu || !k || !v || !P || !ctx || B <= 0 || H <= 0 || T1 <= 0 || T2 <= 0) return EAMD_EINVAL;
+  if ((pos == nullptr) != (qv == nullptr)) return EAMD_EINVAL;
+  if (dk != ATT_DK || T2 > ATT_MAXK || (pos && T1 != T2)) return EAMD_EUNSUPPORTED;
+  if (ldq % 4 || ldk % 4 || ldv % 4 || ldc % 4 || ldp % 4 || ldp < T2 || (pos && (ldqv % 4 || ldpos % 4)))
+    return EAMD_EUNSUPPORTED;
+  if (!al16(qu) || !al16(k) || !al16(v) || !al16(P) || !al16(ctx) || (pos && (!al16(qv) || !al16(pos))))
+    return EAMD_EUNSUPPORTED;
+  if ((long)B * H * ((T1 + 63) / 64) >= (1L << 28)) return EAMD_EUNSUPPORTED;
+  AttnF32Args a;
+  a.qu = qu; a.qv = qv; a.k = k; a.v = v; a.pos = pos; a.mask = mask; a.P = P; a.ctx = ctx;
+  a.ldq = ldq; a.ldqv = ldqv; a.ldk = ldk; a.ldv = ldv; a.ldpos = ldpos; a.ldc = ldc; a.ldp = ldp;
+  a.mb = mask_bstride; a.mi = mask_qstride;
+  a.B = B; a.H = H; a.T1 = T1; a.T2 = T2; a.nqb = (T1 + 63) / 64; a.scale = scale;
+  const bool half = T2 <= 128;                                       // 8 key tiles instead of 16
+  const size_t vbytes = (size_t)(half ? 128 : ATT_MAXK) * PLD * sizeof(float);
+  hipStream_t s = (hipStream_t)stream;
+  if (pos) {
+    const size_t pbytes = (size_t)65 * (T2 + 1) * sizeof(float);
+    const size_t smem = pbytes > vbytes ? pbytes : vbytes;
+    return half ? launch_fwd<true, 8>(a, smem, s) : launch_fwd<true, 16>(a, smem, s);
+  }
+  return half ? launch_fwd<false, 8>(a, vbytes, s) : launch_fwd<false, 16>(a, vbytes, s);
+}
+
+extern "C" int eamd_attn_bwd_q_f32(const float* dctx, int64_t ldd, const float* k, int64_t ldk, const float* v, int64_t ldv,
+                                   const float* P, int64_t ldp, float* dS, float* dbd, float* dq, int64_t ldo, int B, int H,
+                                   int T1, int T2, int dk, float scale, void* stream) {
+  if (!dctx || !k || !v || !P || !dS || !dq || B <= 0 || H <= 0 || T1 <= 0 || T2 <= 0) return EAMD_EINVAL;
+  if (dk != ATT_DK || T2 > ATT_MAXK || (dbd && T1 != T2)) return EAMD_EUNSUPPORTED;
+  if (ldd % 4 || ldk % 4 || ldv % 4 || ldp % 4 || ldp < T2 || ldo % 4) return EAMD_EUNSUPPORTED;
+  if (!al16(dctx) || !al16(k) || !al16(v) || !al16(P) || !al16(dS) || !al16(dq)) return EAMD_EUNSUPPORTED;
+  if ((long)B * H * ((T1 + 63) / 64) >= (1L << 28)) return EAMD_EUNSUPPORTED;
+  AttnF32BwdArgs a;
+  a.dctx = dctx; a.k = k; a.v = v; a.P = P; a.dS = dS; a.dbd = dbd; a.dq = dq;
+  a.ldd = ldd; a.ldk = ldk; a.ldv = ldv; a.ldp = ldp; a.ldo = ldo;
+  a.B = B; a.H = H; a.T1 = T1; a.T2 = T2; a.nqb = (T1 + 63) / 64; a.scale = scale;
+  return T2 <= 128 ? launch_bwd<8>(a, (hipStream_t)stream) : launch_bwd<16>(a, (hipStream_t)stream);
+}

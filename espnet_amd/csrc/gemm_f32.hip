@@ -128,6 +128,9 @@ __global__ __launch_bounds__(NT_, 2) void gemm_f32_kernel(const eamd_gemm_t p) {
   constexpr int DEPTH = BM >= 128 ? 2 : 3;
   constexpr int UNROLL = DEPTH % 2 ? 2 * DEPTH : DEPTH;
   float4 ra[DEPTH][NCA], rb[DEPTH][NCB];
+  // operand-side dropout (ACT instantiations only): seeds once, one hash pair per staged 4-element chunk
+  const unsigned a_dseed = (ACT && p.a_drop_p > 0.f) ? eamd_drop_seed((const unsigned long long*)p.drop_step, p.a_drop_salt) : 0u;
+  const unsigned b_dseed = (ACT && p.b_drop_p > 0.f) ? eamd_drop_seed((const unsigned long long*)p.drop_step, p.b_drop_salt) : 0u;
   const bool do_colsum = TA && p.colsum != nullptr && !GAT && tile_n == 0;
   float cs[4] = {0.f, 0.f, 0.f, 0.f};
 
@@ -217,28 +220,56 @@ __global__ __launch_bounds__(NT_, 2) void gemm_f32_kernel(const eamd_gemm_t p) {
           rb[SET][i] = mask4(rb[SET][i], TB ? ((k0 + b_r[i]) < p.K ? 4 : 0) : p.K - (k0 + b_c[i] * 4));
       }
     }
-    if (do_colsum) {
-#pragma unroll
-      for (int i = 0; i < NCA; ++i) {
-        cs[0] += ra[SET][i].x; cs[1] += ra[SET][i].y; cs[2] += ra[SET][i].z; cs[3] += ra[SET][i].w;
-      }
-    }
-    if constexpr (ACT) {
-      if (p.a_act != EAMD_ACT_NONE) {
-#pragma unroll
-        for (int i = 0; i < NCA; ++i) ra[SET][i] = act4(ra[SET][i], p.a_act);
-      }
-      if (p.b_act != EAMD_ACT_NONE) {
-#pragma unroll
-        for (int i = 0; i < NCB; ++i) rb[SET][i] = act4(rb[SET][i], p.b_act);
-      }
-    }
     float* la = sm.a(buf);
     float* lb = sm.b(buf);
+    if constexpr (ACT) {
+      // activation / dropout of the staged operands, ONE chunk at a time (act -> mask -> bias-gradient sum -> LDS store,
+      // then a scheduling fence): interleaving the hashes of all chunks cost 30+ VGPRs and spilled the 128x128 variant.
+      // Mask index = element index in the operand's own [rows, ld] matrix = the chunk's load offset (chunks that were
+      // clamped in only feed rows / columns that are never stored); operands are < 2^32 elements (checked on the host).
+      const unsigned a_thr = eamd_drop_thr16(p.a_drop_p), b_thr = eamd_drop_thr16(p.b_drop_p);
+      const float a_inv = eamd_drop_inv(a_thr), b_inv = eamd_drop_inv(b_thr);
+      const unsigned a_k = TA ? (unsigned)k0 * (unsigned)p.lda : (unsigned)k0;
+      const unsigned b_k = TB ? (unsigned)k0 * (unsigned)p.ldb : (unsigned)k0;
 #pragma unroll
-    for (int i = 0; i < NCA; ++i) *reinterpret_cast<float4*>(&la[a_r[i] * S::LDA + a_c[i] * 4]) = ra[SET][i];
+      for (int i = 0; i < NCA; ++i) {
+        float4 v = ra[SET][i];
+        if (p.a_act != EAMD_ACT_NONE) v = act4(v, p.a_act);
+        if (p.a_drop_p > 0.f) {
+          bool kp[4];
+          eamd_drop_keep4(a_dseed, (unsigned long long)((unsigned)a_off[i] + a_k), a_thr, kp);
+          v = make_float4(kp[0] ? v.x * a_inv : 0.f, kp[1] ? v.y * a_inv : 0.f, kp[2] ? v.z * a_inv : 0.f,
+                          kp[3] ? v.w * a_inv : 0.f);
+        }
+        if (do_colsum) { cs[0] += v.x; cs[1] += v.y; cs[2] += v.z; cs[3] += v.w; }
+        *reinterpret_cast<float4*>(&la[a_r[i] * S::LDA + a_c[i] * 4]) = v;
+        __builtin_amdgcn_sched_barrier(0);
+      }
 #pragma unroll
-    for (int i = 0; i < NCB; ++i) *reinterpret_cast<float4*>(&lb[b_r[i] * S::LDB + b_c[i] * 4]) = rb[SET][i];
+      for (int i = 0; i < NCB; ++i) {
+        float4 v = rb[SET][i];
+        if (p.b_act != EAMD_ACT_NONE) v = act4(v, p.b_act);
+        if (p.b_drop_p > 0.f) {
+          bool kp[4];
+          eamd_drop_keep4(b_dseed, (unsigned long long)((unsigned)b_off[i] + b_k), b_thr, kp);
+          v = make_float4(kp[0] ? v.x * b_inv : 0.f, kp[1] ? v.y * b_inv : 0.f, kp[2] ? v.z * b_inv : 0.f,
+                          kp[3] ? v.w * b_inv : 0.f);
+        }
+        *reinterpret_cast<float4*>(&lb[b_r[i] * S::LDB + b_c[i] * 4]) = v;
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    } else {
+      if (do_colsum) {        // bias gradient of the transposed A operand
+#pragma unroll
+        for (int i = 0; i < NCA; ++i) {
+          cs[0] += ra[SET][i].x; cs[1] += ra[SET][i].y; cs[2] += ra[SET][i].z; cs[3] += ra[SET][i].w;
+        }
+      }
+#pragma unroll
+      for (int i = 0; i < NCA; ++i) *reinterpret_cast<float4*>(&la[a_r[i] * S::LDA + a_c[i] * 4]) = ra[SET][i];
+#pragma unroll
+      for (int i = 0; i < NCB; ++i) *reinterpret_cast<float4*>(&lb[b_r[i] * S::LDB + b_c[i] * 4]) = rb[SET][i];
+    }
   };
 
   f32x4 acc[MT][NTL];
@@ -473,7 +504,8 @@ int launch_f2(const eamd_gemm_t& p, hipStream_t stream) {
 template <int BM, int BN, bool TA, bool TB, bool GAT>
 int launch_f(const eamd_gemm_t& p, hipStream_t stream) {
   if constexpr (GAT) return launch_f2<BM, BN, TA, TB, GAT, false>(p, stream);
-  else if (p.a_act != EAMD_ACT_NONE || p.b_act != EAMD_ACT_NONE) return launch_f2<BM, BN, TA, TB, GAT, true>(p, stream);
+  else if (p.a_act != EAMD_ACT_NONE || p.b_act != EAMD_ACT_NONE || p.a_drop_p > 0.f || p.b_drop_p > 0.f)
+    return launch_f2<BM, BN, TA, TB, GAT, true>(p, stream);
   return launch_f2<BM, BN, TA, TB, GAT, false>(p, stream);
 }
 
@@ -495,6 +527,10 @@ int eamd_gemm_f32_dispatch(const eamd_gemm_t& p, int tile, hipStream_t stream) {
   if (!on) return EAMD_EUNSUPPORTED;
   if (p.Cb || p.Hb || p.aux_dtype || !p.C) return EAMD_EUNSUPPORTED;
   if (p.drop_p < 0.f || p.drop_p >= 1.f) return EAMD_EINVAL;
+  if (p.a_drop_p < 0.f || p.a_drop_p >= 1.f || p.b_drop_p < 0.f || p.b_drop_p >= 1.f) return EAMD_EINVAL;
+  if ((p.a_drop_p > 0.f || p.b_drop_p > 0.f) && (p.gather.enabled || p.batch1 * p.batch2 != 1 || !p.drop_step)) return EAMD_EINVAL;
+  if (p.a_drop_p > 0.f && (int64_t)(p.transA ? p.K : p.M) * p.lda >= (1LL << 32)) return EAMD_EUNSUPPORTED;   // 32-bit mask index
+  if (p.b_drop_p > 0.f && (int64_t)(p.transB ? p.K : p.N) * p.ldb >= (1LL << 32)) return EAMD_EUNSUPPORTED;
   // fused result dropout: mask index = row * N + col of a contiguous [M, N] result, as eamd_dropout draws it
   if (p.drop_p > 0.f && (p.cmap.enabled || p.batch1 * p.batch2 != 1 || p.ldc != p.N || p.splitk > 1)) return EAMD_EINVAL;
   const bool a_ok = aligned16f(p.A) && p.lda % 4 == 0 && p.sA1 % 4 == 0 && p.sA2 % 4 == 0 &&

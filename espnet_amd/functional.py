@@ -76,6 +76,14 @@ def _grad_in(dout, do, p_out, s_out):
     return ops.dropout(do, p_out, s_out, out_dtype=ops.act_dtype()) if p_out > 0.0 else ops.to_act(do)
 
 
+def _grad_operand(dout, do, p_out, s_out):
+    """-> (operand, a_drop) for the GEMMs that consume a block's incoming gradient: in fp32 mode the block-output dropout
+    of the gradient is applied while those GEMMs stage the operand (no dropped copy is written)"""
+    if p_out > 0.0 and ops.f32_operand_drop():
+        return do, (float(p_out), int(s_out))
+    return _grad_in(dout, do, p_out, s_out), None
+
+
 def _ln_fwd_in(x2, ln_w, ln_b, eps, adt):
     """pre-norm of a block; eps None = bare module (the reference's standalone MultiHeadedAttention /
     PositionwiseFeedForward / ConvolutionModule forward: no LayerNorm in front, no residual behind)"""
@@ -212,19 +220,23 @@ class FFNBlockFn(torch.autograd.Function):
             z = ops.linear_fwd(xn, ops.wshadow(w1), b1, out_dtype=adt, drop=(p_in, s_in), Hb=h, h_act=act)
         else:
             z = ops.linear_fwd(xn, ops.wshadow(w1), b1, out_dtype=adt)          # [M, F] pre-activation
-            if p_in > 0.0:
+            if p_in > 0.0 and not ops.f32_operand_drop():
                 h = ops.dropout(z, p_in, s_in, act=act)                         # drop(act(z)), materialised
         src, a_act = (h, ACT_NONE) if h is not None else (z, act)
+        # fp32 mode: h = drop(act(z)) is never written - the W2 product applies activation + mask while staging z
+        a_drop = (p_in, s_in) if (h is None and p_in > 0.0) else None
         if p_out > 0.0 and (fused or ops.f32_epilogue_drop()):
-            out = ops.linear_fwd(src, ops.wshadow(w2), b2, R=x2, alpha=scale, a_act=a_act, drop=(p_out, s_out))
+            out = ops.linear_fwd(src, ops.wshadow(w2), b2, R=x2, alpha=scale, a_act=a_act, drop=(p_out, s_out), a_drop=a_drop)
         elif p_out > 0.0:
-            br = ops.linear_fwd(src, ops.wshadow(w2), b2, a_act=a_act)
+            br = ops.linear_fwd(src, ops.wshadow(w2), b2, a_act=a_act, a_drop=a_drop)
             out = ops.axpby(x2, ops.dropout(br, p_out, s_out), 1.0, scale)
         else:
-            out = ops.linear_fwd(src, ops.wshadow(w2), b2, R=x2 if eps is not None else None, alpha=scale, a_act=a_act)
+            out = ops.linear_fwd(src, ops.wshadow(w2), b2, R=x2 if eps is not None else None, alpha=scale, a_act=a_act,
+                                 a_drop=a_drop)
         ctx.save_for_backward(x2, mean, rstd, xn, z, h)
         ctx.pr = GradSink.use((ln_w, ln_b, w1, b1, w2, b2))
         ctx.cfg = (scale, act, shp, drop)
+        ctx.in_opd = a_drop is not None
         ctx.prev = _prev_drop(x)
         return _tag_out(out.view(shp), p_out, s_out)
 
@@ -236,18 +248,20 @@ class FFNBlockFn(torch.autograd.Function):
         adt = ops.act_dtype()
         sink = GradSink(ctx.pr)
         do = dout.reshape(x2.shape).contiguous()
-        # gradient of the branch output (dropout mask re-derived, cast to the GEMM operand dtype in the same pass)
-        dob = _grad_in(dout, do, p_out, s_out)
+        # gradient of the branch output (dropout mask re-derived: as a bf16 copy, or - fp32 mode - inside the consuming GEMMs)
+        dob, g_drop = _grad_operand(dout, do, p_out, s_out)
+        inner = h is not None or ctx.in_opd          # the forward applied the inner dropout
         if h is not None:
-            ops.linear_bwd_w(dob, h, sink.buf(4), alpha=scale, db=sink.buf(5))
-        else:
-            ops.linear_bwd_w(dob, z, sink.buf(4), alpha=scale, b_act=act, db=sink.buf(5))   # dW2 += s * do^T act(z)
-        if h is not None and (ops.fast() or ops.f32_epilogue_drop()):
+            ops.linear_bwd_w(dob, h, sink.buf(4), alpha=scale, db=sink.buf(5), a_drop=g_drop)
+        else:                                         # dW2 += s * drop(do)^T drop(act(z))
+            ops.linear_bwd_w(dob, z, sink.buf(4), alpha=scale, b_act=act, db=sink.buf(5), a_drop=g_drop,
+                             b_drop=(p_in, s_in) if ctx.in_opd else None)
+        if inner and (ops.fast() or ops.f32_epilogue_drop()):
             dz = ops.linear_bwd_x(dob, ops.wshadow(w2), epilogue=_act_epi(act), aux=z, alpha=scale, out_dtype=adt,
-                                  drop=(p_in, s_in))
+                                  drop=(p_in, s_in), a_drop=g_drop)
         else:
-            dz = ops.linear_bwd_x(dob, ops.wshadow(w2), epilogue=_act_epi(act), aux=z, alpha=scale, out_dtype=adt)
-            if h is not None:
+            dz = ops.linear_bwd_x(dob, ops.wshadow(w2), epilogue=_act_epi(act), aux=z, alpha=scale, out_dtype=adt, a_drop=g_drop)
+            if inner:
                 dz = ops.dropout(dz, p_in, s_in)
         ops.linear_bwd_w(dz, xn, sink.buf(2), db=sink.buf(3))
         dxn = ops.linear_bwd_x(dz, ops.wshadow(w1))
@@ -410,9 +424,9 @@ def attn_core_bwd(dctx, P, qu, qv, k, v, p, B, T1, T2, H, dk, Pd=None, attn_drop
              sB=(T1 * D, dk), sC=(T2 * ldo, dk), c_off=dv_off)                                            # P^T dctx
     dq_in_qkv = dqkv is not None and p is None     # no relative positions: dq is needed only as a GEMM operand
     dS = dbd = dqu = None
-    if FUSE_ATTN and Pd is None and P.dtype == torch.bfloat16 and ops.attn_fwd_supported(T1, T2, dk, p is not None):
+    if FUSE_ATTN and Pd is None and P.dtype == adt and ops.attn_fwd_supported(T1, T2, dk, p is not None):
         # dP, softmax backward (+ inverse rel-shift scatter) and dq in one launch
-        dS = torch.empty(H * B * T1 * ldp, device=dev, dtype=torch.bfloat16)
+        dS = torch.empty(H * B * T1 * ldp, device=dev, dtype=adt)
         dbd = torch.empty(H * B * T1 * ldp, device=dev, dtype=adt) if p is not None else None
         dqu = None if dq_in_qkv else torch.empty(B * T1, D, device=dev, dtype=torch.float32)
         dq_view = (dqkv, 0, ldo) if dq_in_qkv else (dqu, 0, D)
@@ -575,9 +589,9 @@ class MHABlockFn(torch.autograd.Function):
         adt = ops.act_dtype()
         sink = GradSink(params)
         do = dout.reshape(-1, D).contiguous()
-        dob = _grad_in(dout, do, p_out, s_out)
-        ops.linear_bwd_w(dob, cx, sink.buf(8), db=sink.buf(9))
-        dctx = ops.linear_bwd_x(dob, ops.wshadow(wo), out_dtype=adt)
+        dob, g_drop = _grad_operand(dout, do, p_out, s_out)
+        ops.linear_bwd_w(dob, cx, sink.buf(8), db=sink.buf(9), a_drop=g_drop)
+        dctx = ops.linear_bwd_x(dob, ops.wshadow(wo), out_dtype=adt, a_drop=g_drop)
         if ctx.fused:
             qkv = k
             dqkv = torch.empty(B * T1, 3 * D, device=do.device, dtype=adt)
@@ -679,9 +693,9 @@ class ConvModuleBlockFn(torch.autograd.Function):
         adt = ops.act_dtype()
         sink = GradSink(ctx.pr)
         do = dout.reshape(M, D).contiguous()
-        dob = _grad_in(dout, do, p_out, s_out)
-        ops.linear_bwd_w(dob, e, sink.buf(8).view(Cc, Cc), db=sink.buf(9))
-        de = ops.linear_bwd_x(dob, ops.wshadow(w2).view(Cc, Cc))
+        dob, g_drop = _grad_operand(dout, do, p_out, s_out)
+        ops.linear_bwd_w(dob, e, sink.buf(8).view(Cc, Cc), db=sink.buf(9), a_drop=g_drop)
+        de = ops.linear_bwd_x(dob, ops.wshadow(w2).view(Cc, Cc), a_drop=g_drop)
         dd = ops.bn_bwd(de, d, bmean, brstd, g, be, sink.buf(6), sink.buf(7), M, Cc, act, training)
         dgl = ops.dwconv_bwd_x(dd, wd.view(Cc, K), B, T, Cc, K)
         ops.dwconv_bwd_w(dd, gl, sink.buf(4).view(Cc, K), sink.buf(5), B, T, Cc, K)

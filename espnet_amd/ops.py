@@ -44,6 +44,18 @@ def f32_epilogue_drop():
 F32_EPILOGUE_DROP = True     # tests flip this to compare against the stand-alone dropout kernel
 
 
+# Off by default: measured on configs[1] the staging-side hash + activation pushes the 128x128 instantiations over the
+# 256-VGPR budget (scratch) and the 64x64 ones from 3 to 2 waves per SIMD - the GEMMs lose 2.3 ms per step where the
+# stand-alone dropout passes they replace cost 1.1 ms.  Kept (and tested) as an operator feature.
+F32_OPERAND_DROP = False
+
+
+def f32_operand_drop():
+    """fp32 mode: dropout of a GEMM operand (FFN inner dropout, every block's incoming-gradient dropout) applied while
+    the operand is staged, instead of a pass that materialises the dropped tensor"""
+    return _state["precision"] == 0 and F32_OPERAND_DROP
+
+
 def act_dtype():
     return torch.bfloat16 if fast() else torch.float32
 
@@ -102,7 +114,7 @@ _gemm_record = None
 def gemm(A, B, Cm, M, N, K, lda, ldb, ldc, *, transA=0, transB=0, bias=None, aux=None, ldaux=0, R=None,
          ldr=0, batch=(1, 1), sA=(0, 0), sB=(0, 0), sC=(0, 0), alpha=1.0, beta=0.0, a_act=0, b_act=0,
          epilogue=0, splitk=1, tile=0, gather=None, cmap=None, a_off=0, b_off=0, c_off=0, precision=None,
-         colsum=None, Cb=None, drop=None, Hb=None, h_act=0):
+         colsum=None, Cb=None, drop=None, Hb=None, h_act=0, a_drop=None, b_drop=None):
     """A, B: both float32 or both bfloat16 (bf16 operands select the fast MFMA kernel).
     Cm: float32 result, or bfloat16 result (then no fp32 copy is written); Cb: extra bf16 copy."""
     bf = A.dtype == torch.bfloat16
@@ -172,6 +184,13 @@ def gemm(A, B, Cm, M, N, K, lda, ldb, ldc, *, transA=0, transB=0, bias=None, aux
             if Hb.dtype != torch.bfloat16 or Hb.numel() < M * N:
                 raise _lib.EamdError("gemm: Hb must be a bf16 [M, N] buffer")
             p.Hb, p.h_act = ptr(Hb), h_act
+    for which, d, ld_, off_, cols in (("a", a_drop, lda, a_off, (M if transA else K)), ("b", b_drop, ldb, b_off, (N if transB else K))):
+        if d is not None and d[0] > 0.0:    # operand-side dropout: the operand must BE the contiguous tensor the mask was drawn for
+            if bf or p.precision != 0 or ld_ != cols or off_ != 0 or b1 * b2 != 1 or gather is not None:
+                raise _lib.EamdError("gemm: operand dropout needs an fp32-MFMA launch on a dense, unbatched operand")
+            setattr(p, which + "_drop_p", float(d[0]))
+            setattr(p, which + "_drop_salt", int(d[1]))
+            p.drop_step = ptr(rng_state(A.device))
     if _gemm_record is not None:
         _gemm_record.append((p, (A, B, Cm, bias, aux, R, colsum, Cb, Hb),
                              lambda sp, p=p: check(_lib.lib().eamd_gemm(C.byref(p), sp), "eamd_gemm")))
@@ -203,7 +222,7 @@ def auto_splitk(m_out, n_out, k_red):
 
 # ---- nn.Linear pieces -------------------------------------------------------------------------
 def linear_fwd(x, W, b, out=None, *, act=EPI_NONE, R=None, alpha=1.0, a_act=ACT_NONE, out_dtype=torch.float32,
-               drop=None, Hb=None, h_act=ACT_NONE):
+               drop=None, Hb=None, h_act=ACT_NONE, a_drop=None):
     """out[M,N] = alpha * drop(act(a_act(x)[M,K] @ W[N,K]^T + b)) + R      (x, W: both fp32 or both bf16)
     drop = (p, salt): dropout fused in the epilogue (bf16 operands); with Hb the value itself is left
     alone and Hb <- dropout(h_act(value)) is written as a second bf16 output."""
@@ -213,12 +232,12 @@ def linear_fwd(x, W, b, out=None, *, act=EPI_NONE, R=None, alpha=1.0, a_act=ACT_
     if out is None:
         out = torch.empty(M, N, device=x.device, dtype=out_dtype)
     gemm(x, W, out, M, N, K, K, K, N, bias=b, epilogue=act, R=R, ldr=N, alpha=alpha, a_act=a_act, drop=drop, Hb=Hb,
-         h_act=h_act)
+         h_act=h_act, a_drop=a_drop)
     return out
 
 
 def linear_bwd_x(dy, W, out=None, *, beta=0.0, epilogue=EPI_NONE, aux=None, alpha=1.0, out_dtype=torch.float32,
-                 drop=None):
+                 drop=None, a_drop=None):
     """out[M,K] = alpha * drop(epi(dy[M,N] @ W[N,K])) + beta*out"""
     M, N = dy.shape
     K = W.shape[1]
@@ -227,7 +246,7 @@ def linear_bwd_x(dy, W, out=None, *, beta=0.0, epilogue=EPI_NONE, aux=None, alph
         assert beta == 0.0
         out = torch.empty(M, K, device=dy.device, dtype=out_dtype)
     gemm(dy, W, out, M, K, N, N, K, K, transB=1, beta=beta, epilogue=epilogue, aux=aux, ldaux=K, alpha=alpha,
-         drop=drop)
+         drop=drop, a_drop=a_drop)
     return out
 
 
@@ -251,28 +270,29 @@ def wgrad_join():
         _wgrad["used"] = False
 
 
-def linear_bwd_w(dy, x, dW, *, alpha=1.0, b_act=ACT_NONE, db=None):
+def linear_bwd_w(dy, x, dW, *, alpha=1.0, b_act=ACT_NONE, db=None, a_drop=None, b_drop=None):
     st = _wgrad["stream"]
     if st is None:
-        return _linear_bwd_w(dy, x, dW, alpha=alpha, b_act=b_act, db=db)
+        return _linear_bwd_w(dy, x, dW, alpha=alpha, b_act=b_act, db=db, a_drop=a_drop, b_drop=b_drop)
     cur = torch.cuda.current_stream()
     st.wait_stream(cur)                 # operands were produced on the main stream
     with torch.cuda.stream(st):
-        _linear_bwd_w(dy, x, dW, alpha=alpha, b_act=b_act, db=db)
+        _linear_bwd_w(dy, x, dW, alpha=alpha, b_act=b_act, db=db, a_drop=a_drop, b_drop=b_drop)
     dy.record_stream(st)                # keep the caching allocator from recycling them early
     x.record_stream(st)
     _wgrad["used"] = True
 
 
-def _linear_bwd_w(dy, x, dW, *, alpha=1.0, b_act=ACT_NONE, db=None):
-    """dW[N,K] += alpha * dy[M,N]^T @ b_act(x)[M,K]   (split-K, f32 atomics)
-    db[N] += alpha * column sums of dy (bias gradient, fused into the same launch)"""
+def _linear_bwd_w(dy, x, dW, *, alpha=1.0, b_act=ACT_NONE, db=None, a_drop=None, b_drop=None):
+    """dW[N,K] += alpha * drop_a(dy)[M,N]^T @ drop_b(b_act(x))[M,K]   (split-K, f32 atomics)
+    db[N] += alpha * column sums of drop_a(dy) (bias gradient, fused into the same launch);
+    a_drop / b_drop = (p, salt): fp32 mode only, the operand is dropped while it is staged (eamd_gemm_t.a_drop_p)"""
     M, N = dy.shape
     K = x.shape[1]
     assert x.shape[0] == M and dW.numel() == N * K and dW.dtype == torch.float32
     sk = auto_splitk(N, K, M)
     gemm(dy, x, dW, N, K, M, N, K, K, transA=1, transB=1, alpha=alpha, b_act=b_act, splitk=sk,
-         beta=1.0 if sk == 1 else 0.0, colsum=db)
+         beta=1.0 if sk == 1 else 0.0, colsum=db, a_drop=a_drop, b_drop=b_drop)
 
 
 def colsum(x, out, scale=1.0, rows=None, D=None, ld=None):
@@ -362,16 +382,21 @@ def layernorm_bwd(dy, x, gamma, mean, rstd, dres, dgamma, dbeta, drop=None):
     return dx
 
 
+F32_FUSED_ATTN = True   # fp32 mode: eamd_attn_fwd_f32 / eamd_attn_bwd_q_f32 (tests flip it to reach the GEMM / softmax path)
+
+
 def attn_fwd_supported(T1, T2, dk, rel):
     """shapes the fused attention forward (eamd_attn_fwd) covers; alignment is checked by the library"""
-    return fast() and dk == 64 and T2 <= 256 and (not rel or T1 == T2)
+    return (fast() or F32_FUSED_ATTN) and dk == 64 and T2 <= 256 and (not rel or T1 == T2)
 
 
 def attn_fwd(qu, qv, k, v, pos, mask, B, T1, T2, H, dk, ldp, scale):
-    """qu / qv / k / v: (tensor, element offset, row stride) views of bf16 [rows, *] matrices, heads side by side;
-    pos: bf16 [T2, H*dk] or None.  Returns (P bf16 [H*B*T1*ldp], ctx bf16 [B*T1, H*dk]) or None if the library
-    declines the operands (EAMD_EUNSUPPORTED)."""
+    """qu / qv / k / v: (tensor, element offset, row stride) views of [rows, *] matrices, heads side by side, all bf16
+    (eamd_attn_fwd) or all fp32 (eamd_attn_fwd_f32); pos: [T2, H*dk] of the same dtype or None.
+    Returns (P [H*B*T1*ldp], ctx [B*T1, H*dk]) in that dtype, or None if the library declines the operands
+    (EAMD_EUNSUPPORTED)."""
     dev = qu[0].device
+    dt = qu[0].dtype
     D = H * dk
     mb = mi = 0
     if mask is not None:
@@ -379,38 +404,50 @@ def attn_fwd(qu, qv, k, v, pos, mask, B, T1, T2, H, dk, ldp, scale):
         assert mask.shape[2] == T2 and mask.shape[1] in (1, T1)
         mb = 0 if mask.shape[0] == 1 else mask.shape[1] * mask.shape[2]
         mi = 0 if mask.shape[1] == 1 else T2
+    assert dt in (torch.bfloat16, torch.float32)
     for t_, _, _ in (qu, k, v) + ((qv,) if qv is not None else ()):
-        assert t_.dtype == torch.bfloat16 and t_.is_cuda
-    P = torch.empty(H * B * T1 * ldp, device=dev, dtype=torch.bfloat16)
-    cx = torch.empty(B * T1, D, device=dev, dtype=torch.bfloat16)
+        assert t_.dtype == dt and t_.is_cuda
+    assert pos is None or pos.dtype == dt
+    P = torch.empty(H * B * T1 * ldp, device=dev, dtype=dt)
+    cx = torch.empty(B * T1, D, device=dev, dtype=dt)
     i64 = C.c_int64
     args = (ptr(qu[0], qu[1]), i64(qu[2]), ptr(qv[0], qv[1]) if qv is not None else None, i64(qv[2] if qv is not None else 0),
             ptr(k[0], k[1]), i64(k[2]), ptr(v[0], v[1]), i64(v[2]), ptr(pos), i64(D if pos is not None else 0),
             ptr(mask), i64(mb), i64(mi), ptr(P), i64(ldp), ptr(cx), i64(D), B, H, T1, T2, dk, C.c_float(scale))
-    rc = _lib.lib().eamd_attn_fwd(*args, stream_ptr())
+    name = "eamd_attn_fwd" if dt == torch.bfloat16 else "eamd_attn_fwd_f32"
+    fn = getattr(_lib.lib(), name)
+    rc = fn(*args, stream_ptr())
     if rc == _lib.EAMD_EUNSUPPORTED:
         return None
-    check(rc, "eamd_attn_fwd")
+    check(rc, name)
     if _gemm_record is not None:
-        _gemm_record.append((None, (qu, qv, k, v, pos, mask, P, cx),
-                             lambda sp, args=args: check(_lib.lib().eamd_attn_fwd(*args, sp), "eamd_attn_fwd")))
+        _gemm_record.append((None, (qu, qv, k, v, pos, mask, P, cx), lambda sp, args=args: check(fn(*args, sp), name)))
     return P, cx
 
 
 def attn_bwd_q(dctx, k, v, P, dS, dbd, dq, B, T1, T2, H, dk, ldp, scale):
-    """dctx / k / v / dq: (tensor, element offset, row stride) views; P, dS (and dbd or None): bf16 [H*B*T1*ldp].
+    """dctx / k / v / dq: (tensor, element offset, row stride) views; P, dS (and dbd or None): [H*B*T1*ldp], bf16
+    (eamd_attn_bwd_q; dq fp32 or bf16) or everything fp32 (eamd_attn_bwd_q_f32).
     dS, dbd and dq are written.  Returns False if the library declines the operands (EAMD_EUNSUPPORTED)."""
     i64 = C.c_int64
-    args = (ptr(dctx[0], dctx[1]), i64(dctx[2]), ptr(k[0], k[1]), i64(k[2]), ptr(v[0], v[1]), i64(v[2]), ptr(P), i64(ldp),
-            ptr(dS), ptr(dbd), ptr(dq[0], dq[1]), i64(dq[2]), int(dq[0].dtype == torch.bfloat16), B, H, T1, T2, dk,
-            C.c_float(scale))
-    rc = _lib.lib().eamd_attn_bwd_q(*args, stream_ptr())
+    if P.dtype == torch.bfloat16:
+        name = "eamd_attn_bwd_q"
+        args = (ptr(dctx[0], dctx[1]), i64(dctx[2]), ptr(k[0], k[1]), i64(k[2]), ptr(v[0], v[1]), i64(v[2]), ptr(P), i64(ldp),
+                ptr(dS), ptr(dbd), ptr(dq[0], dq[1]), i64(dq[2]), int(dq[0].dtype == torch.bfloat16), B, H, T1, T2, dk,
+                C.c_float(scale))
+    else:
+        name = "eamd_attn_bwd_q_f32"
+        for t_ in (dctx[0], k[0], v[0], P, dS, dq[0]) + ((dbd,) if dbd is not None else ()):
+            assert t_.dtype == torch.float32
+        args = (ptr(dctx[0], dctx[1]), i64(dctx[2]), ptr(k[0], k[1]), i64(k[2]), ptr(v[0], v[1]), i64(v[2]), ptr(P), i64(ldp),
+                ptr(dS), ptr(dbd), ptr(dq[0], dq[1]), i64(dq[2]), B, H, T1, T2, dk, C.c_float(scale))
+    fn = getattr(_lib.lib(), name)
+    rc = fn(*args, stream_ptr())
     if rc == _lib.EAMD_EUNSUPPORTED:
         return False
-    check(rc, "eamd_attn_bwd_q")
+    check(rc, name)
     if _gemm_record is not None:
-        _gemm_record.append((None, (dctx, k, v, P, dS, dbd, dq),
-                             lambda sp, args=args: check(_lib.lib().eamd_attn_bwd_q(*args, sp), "eamd_attn_bwd_q")))
+        _gemm_record.append((None, (dctx, k, v, P, dS, dbd, dq), lambda sp, args=args: check(fn(*args, sp), name)))
     return True
 
 

@@ -95,6 +95,13 @@ typedef struct {
   const uint64_t* drop_step;
   void* Hb;
   int32_t h_act;
+  /* operand-side dropout (fp32-MFMA kernel, in_dtype 0 / precision 0): while an operand is staged, element i of its
+   * contiguous [rows, ld] matrix becomes keep(i) ? a_act(x) / (1 - p) : 0 with the mask eamd_dropout draws for
+   * (drop_step, salt, i) - a consumer reads dropout(act(z)) or dropout(dY) without that tensor ever being written:
+   *   W2 (drop(act(z))) in the FFN forward, dW2 += dY^T drop(act(z)), every block's incoming-gradient dropout in
+   *   backward (positionwise_feed_forward.py:27, encoder_layer.py:101-144).  Needs an unbatched, un-gathered operand. */
+  float a_drop_p, b_drop_p;
+  uint64_t a_drop_salt, b_drop_salt;
 } eamd_gemm_t;
 
 int eamd_gemm(const eamd_gemm_t* p, void* stream);
@@ -168,6 +175,18 @@ int eamd_attn_fwd(const void* qu, int64_t ldq, const void* qv, int64_t ldqv, con
 int eamd_attn_bwd_q(const void* dctx, int64_t ldd, const void* k, int64_t ldk, const void* v, int64_t ldv,
                     const void* P_bf16, int64_t ldp, void* dS_bf16, void* dbd_bf16, void* dq, int64_t ldo, int dq_is_bf16,
                     int B, int H, int T1, int T2, int dk, float scale, void* stream);
+
+/* fp32 twins of eamd_attn_fwd / eamd_attn_bwd_q (the reference's precision; v_mfma_f32_16x16x4_f32): same operand
+ * layouts, limits (d_k = 64, T2 <= 256, T1 == T2 with relative positions) and results, every tensor fp32: P, dS, dbd
+ * [H][B][T1][ldp] (ldp % 4 == 0, pad columns zeroed), ctx / dq (b, t, h, d).  Row strides are multiples of 4 floats and
+ * base pointers 16-byte aligned, else EAMD_EUNSUPPORTED (callers then run the GEMM / eamd_softmax_* path). */
+int eamd_attn_fwd_f32(const float* qu, int64_t ldq, const float* qv, int64_t ldqv, const float* k, int64_t ldk,
+                      const float* v, int64_t ldv, const float* pos, int64_t ldpos, const unsigned char* mask,
+                      int64_t mask_bstride, int64_t mask_qstride, float* P, int64_t ldp, float* ctx, int64_t ldc, int B,
+                      int H, int T1, int T2, int dk, float scale, void* stream);
+int eamd_attn_bwd_q_f32(const float* dctx, int64_t ldd, const float* k, int64_t ldk, const float* v, int64_t ldv,
+                        const float* P, int64_t ldp, float* dS, float* dbd, float* dq, int64_t ldo, int B, int H, int T1,
+                        int T2, int dk, float scale, void* stream);
 
 /* Label-smoothing KL loss rows + argmax-correct flags + gradient (softmax - true_dist)*inv_denom.
  * reference: transformer/label_smoothing_loss.py:44-63, nets_utils.py:299-319 (th_accuracy). */

@@ -1276,8 +1276,9 @@ def test_fp32_fused_paths_match_separate_paths():
     model = model.to(DEV).train()
     flat = train.FlatParams(model)
     try:
-        for fuse in (True, False):
+        for fuse, opd in ((True, True), (True, False), (False, False)):
             ops.F32_EPILOGUE_DROP = fuse
+            ops.F32_OPERAND_DROP = opd          # dropout of GEMM operands while they are staged (FFN inner, incoming gradients)
             F_.FUSE_QKV = fuse
             flat.zero_grad()
             ops.manual_seed(31)
@@ -1286,11 +1287,13 @@ def test_fp32_fused_paths_match_separate_paths():
             res.append((float(loss), flat.grad.clone()))
     finally:
         ops.F32_EPILOGUE_DROP = True
+        ops.F32_OPERAND_DROP = False
         F_.FUSE_QKV = True
-    rel = abs(res[0][0] - res[1][0]) / abs(res[1][0])
-    print(f"[parity] fp32 fused vs separate paths: loss {res[0][0]:.6f} vs {res[1][0]:.6f} (rel {rel:.2e})")
-    assert rel < 1e-6
-    report("fp32 fused vs separate paths: gradient arena", res[0][1], res[1][1], 2e-5)
+    for i, what in ((0, "epilogue + operand dropout"), (1, "epilogue dropout")):
+        rel = abs(res[i][0] - res[2][0]) / abs(res[2][0])
+        print(f"[parity] fp32 {what} vs separate paths: loss {res[i][0]:.6f} vs {res[2][0]:.6f} (rel {rel:.2e})")
+        assert rel < 1e-6
+        report("fp32 %s vs separate paths: gradient arena" % what, res[i][1], res[2][1], 2e-5)
 
 
 def test_bucketed_graph_step_matches_eager():

@@ -693,6 +693,35 @@ def test_gemm_f32_fused_dropout_matches_dropout_kernel(ops, shape):
     report("fp32 gemm vs float64 %s" % (shape,), plain, x.double().cpu() @ W.double().cpu().t() + b.double().cpu(), 2e-6)
 
 
+@pytest.mark.parametrize("shape", [(300, 192, 128), (7968, 256, 2048), (1000, 2048, 256)])
+def test_gemm_f32_operand_dropout_matches_dropout_kernel(ops, shape):
+    """fp32 mode: dropout applied to a GEMM operand while it is staged (eamd_gemm_t.a_drop_p / b_drop_p) gives what
+    the product of the materialised eamd_dropout result gives - forward (A = drop(act(z))), input gradient
+    (A = drop(dy)) and weight gradient (A = drop(dy), B = drop(act(z)), bias gradient = column sums of drop(dy))"""
+    from espnet_amd.ops import ACT_SWISH, ACT_NONE
+    M, N, K = shape
+    g = torch.Generator().manual_seed(M + 3 * K)
+    z, W = torch.randn(M, K, generator=g).to(DEV), (torch.randn(N, K, generator=g) / K ** 0.5).to(DEV)
+    b, dy = torch.randn(N, generator=g).to(DEV), torch.randn(M, N, generator=g).to(DEV)
+    p_in, s_in, p_out, s_out = 0.1, 777, 0.2, 991
+    h = ops.dropout(z, p_in, s_in, act=ACT_SWISH)
+    report("operand drop fwd %s" % (shape,), ops.linear_fwd(z, W, b, a_act=ACT_SWISH, a_drop=(p_in, s_in)),
+           ops.linear_fwd(h, W, b), 2e-6)
+    dyd = ops.dropout(dy, p_out, s_out)
+    report("operand drop bwd_x %s" % (shape,), ops.linear_bwd_x(dy, W, a_drop=(p_out, s_out)), ops.linear_bwd_x(dyd, W), 2e-6)
+    # with the epilogue dropout behind it (the FFN's dz)
+    report("operand drop bwd_x + epilogue drop %s" % (shape,),
+           ops.linear_bwd_x(dy, W, a_drop=(p_out, s_out), drop=(p_in, s_in)),
+           ops.dropout(ops.linear_bwd_x(dyd, W), p_in, s_in), 2e-6)
+    dW1, db1 = torch.zeros(N, K, device=DEV), torch.zeros(N, device=DEV)
+    dW2, db2 = torch.zeros(N, K, device=DEV), torch.zeros(N, device=DEV)
+    ops.linear_bwd_w(dy, z, dW1, alpha=0.5, b_act=ACT_SWISH, db=db1, a_drop=(p_out, s_out), b_drop=(p_in, s_in))
+    ops.linear_bwd_w(dyd, h, dW2, alpha=0.5, b_act=ACT_NONE, db=db2)
+    torch.cuda.synchronize()
+    report("operand drop bwd_w %s" % (shape,), dW1, dW2, 2e-5)
+    report("operand drop bias grad %s" % (shape,), db1, db2, 2e-5)
+
+
 @pytest.mark.parametrize("shape", [(4, 80, 128, 31), (2, 33, 300, 29), (3, 17, 64, 3), (1, 5, 32, 1)])
 def test_dwconv_kernel_sizes(ops, shape):
     """depthwise conv fwd / input grad / weight grad at the recipe's kernel size 31 and at ragged channel counts"""
@@ -780,20 +809,23 @@ def test_gemm_direct_short_k(ops, dims):
     dict(B=9, T1=30, T2=30, rel=True, mask="len"), dict(B=2, T1=65, T2=65, rel=True, mask="len"),
     dict(B=2, T1=101, T2=249, rel=False, mask="len"), dict(B=3, T1=101, T2=101, rel=False, mask="causal"),
     dict(B=2, T1=1, T2=77, rel=False, mask="len"), dict(B=2, T1=64, T2=16, rel=False, mask="dead")])
-def test_attention_forward_fused_matches_unfused(ops, case):
+@pytest.mark.parametrize("prec", ["bf16", "fp32"])
+def test_attention_forward_fused_matches_unfused(ops, case, prec):
     """eamd_attn_fwd (scores + rel-shift + mask + softmax + context in one launch) against the score GEMMs,
     eamd_softmax_fwd and the context GEMM on the same bf16 operands: probabilities and context agree to bf16 rounding,
     fully masked rows give zeros, pad columns of P are zero; q / k / v are column blocks of one fused [B*T, 3D] buffer
-    where the layout allows it (self-attention), as in the model"""
+    where the layout allows it (self-attention), as in the model.  fp32 mode: eamd_attn_fwd_f32 against the same path in
+    fp32 (agreement to fp32 rounding)"""
     import espnet_amd
     from espnet_amd import functional as F_
-    espnet_amd.set_precision("bf16")
+    espnet_amd.set_precision(prec)
+    tol_p, tol_c, tol_abs = (3e-3, 6e-3, 2e-2) if prec == "bf16" else (3e-6, 3e-6, 2e-6)
     try:
         B, T1, T2, rel, mk = case["B"], case["T1"], case["T2"], case["rel"], case["mask"]
         H, dk = 4, 64
         D = H * dk
         g = torch.Generator().manual_seed(T1 * 7 + T2)
-        bf = lambda *s: torch.randn(*s, generator=g).to(torch.bfloat16).to(DEV)
+        bf = lambda *s: torch.randn(*s, generator=g).to(torch.bfloat16).to(ops.act_dtype()).to(DEV)
         if T1 == T2:
             qkv = bf(B * T1, 3 * D)
             k, v = F_._MV(qkv, D, 3 * D), F_._MV(qkv, 2 * D, 3 * D)
@@ -819,9 +851,9 @@ def test_attention_forward_fused_matches_unfused(ops, case):
         c0 = F_.attn_context_fwd(P0, v, B, T1, T2, H, dk)
         ldp = F_._ldp(T2)
         P0v, P1v = P0.view(H, B, T1, ldp).float(), P1.view(H, B, T1, ldp).float()
-        report("fused attention P %s" % (case,), P1v, P0v, 3e-3)
-        report("fused attention ctx %s" % (case,), c1.float(), c0.float(), 6e-3)
-        assert float((P1v - P0v).abs().max()) <= 2e-2
+        report("fused attention P %s %s" % (prec, case), P1v, P0v, tol_p)
+        report("fused attention ctx %s %s" % (prec, case), c1.float(), c0.float(), tol_c)
+        assert float((P1v - P0v).abs().max()) <= tol_abs
         assert bool((P1v[..., T2:] == 0).all())
         if mk == "dead":
             assert bool((P1v[:, 1] == 0).all()) and bool((c1.view(B, T1, D)[1] == 0).all())
@@ -833,19 +865,22 @@ def test_attention_forward_fused_matches_unfused(ops, case):
     dict(B=3, T1=249, T2=249, rel=True, qkv=True), dict(B=2, T1=256, T2=256, rel=True, qkv=False),
     dict(B=9, T1=30, T2=30, rel=True, qkv=True), dict(B=2, T1=65, T2=65, rel=False, qkv=True),
     dict(B=2, T1=101, T2=249, rel=False, qkv=False), dict(B=3, T1=101, T2=101, rel=False, qkv=False)])
-def test_attention_backward_fused_matches_unfused(ops, case):
+@pytest.mark.parametrize("prec", ["bf16", "fp32"])
+def test_attention_backward_fused_matches_unfused(ops, case, prec):
     """eamd_attn_bwd_q (score gradient + softmax backward + inverse rel-shift scatter + dq in one launch) inside
     attn_core_bwd against the GEMM / eamd_softmax_bwd / GEMM path: every returned gradient (dq, dqv, dk, dv, dpos)
-    agrees to bf16 rounding, with q / k / v gradients written into the fused [B*T, 3D] buffer where the model does so"""
+    agrees to bf16 rounding, with q / k / v gradients written into the fused [B*T, 3D] buffer where the model does so.
+    fp32 mode: eamd_attn_bwd_q_f32, agreement to fp32 rounding"""
     import espnet_amd
     from espnet_amd import functional as F_
-    espnet_amd.set_precision("bf16")
+    espnet_amd.set_precision(prec)
+    tol = 6e-3 if prec == "bf16" else 1e-5
     try:
         B, T1, T2, rel, use_qkv = case["B"], case["T1"], case["T2"], case["rel"], case["qkv"]
         H, dk = 4, 64
         D = H * dk
         g = torch.Generator().manual_seed(T1 * 5 + T2)
-        bf = lambda *s: torch.randn(*s, generator=g).to(torch.bfloat16).to(DEV)
+        bf = lambda *s: torch.randn(*s, generator=g).to(torch.bfloat16).to(ops.act_dtype()).to(DEV)
         if use_qkv:
             qkv = bf(B * T1, 3 * D)
             k, v = F_._MV(qkv, D, 3 * D), F_._MV(qkv, 2 * D, 3 * D)
@@ -861,14 +896,14 @@ def test_attention_backward_fused_matches_unfused(ops, case):
         outs = {}
         for fuse in (True, False):
             F_.FUSE_ATTN = fuse
-            dqkv = torch.zeros(B * T1, 3 * D, device=DEV, dtype=torch.bfloat16) if use_qkv else None
-            r = F_.attn_core_bwd(dctx, P, qu, qv, k, v, p, B, T1, T2, H, dk, dqkv=dqkv)
+            dqkv = torch.zeros(B * T1, 3 * D, device=DEV, dtype=ops.act_dtype()) if use_qkv else None
+            r = F_.attn_core_bwd(dctx, P.clone(), qu, qv, k, v, p, B, T1, T2, H, dk, dqkv=dqkv)
             outs[fuse] = [None if x is None else x.float().clone() for x in r] + [None if dqkv is None else dqkv.float().clone()]
         names = ("dqu", "dqv", "dk", "dv", "dpos", "dqkv")
         for n, a, b in zip(names, outs[True], outs[False]):
             assert (a is None) == (b is None), n
             if a is not None:
-                report("fused attention bwd %s %s" % (n, case), a, b, 6e-3)
+                report("fused attention bwd %s %s %s" % (n, prec, case), a, b, tol)
     finally:
         F_.FUSE_ATTN = True
         espnet_amd.set_precision("fp32")
@@ -902,21 +937,25 @@ def _oracle_attention(oracle, qu, qv, k, v, p, mask, dctx, B, T1, T2, H, dk):
     dict(B=2, T1=101, T2=249, rel=False, mask="len"), dict(B=2, T1=1, T2=77, rel=False, mask="len"),
     dict(B=3, T1=64, T2=64, rel=True, mask="dead"), dict(B=2, T1=30, T2=30, rel=True, mask=None),
     dict(B=2, T1=64, T2=16, rel=False, mask="dead")])
-def test_attention_fused_vs_oracle(ops, oracle, case):
+@pytest.mark.parametrize("prec", ["bf16", "fp32"])
+def test_attention_fused_vs_oracle(ops, oracle, case, prec):
     """The kernels bench.py dispatches at config 2 (eamd_attn_fwd / eamd_attn_bwd_q: H = 4, d_k = 64, T2 <= 256)
     against the ORACLE in float64 on the same bf16 operands - not against our own unfused path: probabilities,
     context and every gradient (dq+u, dq+v, dk, dv, dpos), ragged key lengths, a causal mask, a single query and a
     fully masked utterance (reference: zeros, attention.py:84-88).  Error budget: P and dS are rounded to bf16
-    inside the kernels (2^-9 relative), so rel-L2 <= 4e-3 on P / ctx and <= 8e-3 on the gradients."""
+    inside the kernels (2^-9 relative), so rel-L2 <= 4e-3 on P / ctx and <= 8e-3 on the gradients.
+    fp32 mode (the bench headline): eamd_attn_fwd_f32 / eamd_attn_bwd_q_f32 on the same operand values held in fp32;
+    everything stays fp32 (fp32 MFMA, v_exp_f32 at 1 ulp), so rel-L2 <= 2e-6 on P / ctx and <= 1e-5 on the gradients."""
     import espnet_amd
     from espnet_amd import functional as F_
-    espnet_amd.set_precision("bf16")
+    espnet_amd.set_precision(prec)
+    tol_f, tol_g = (4e-3, 8e-3) if prec == "bf16" else (2e-6, 1e-5)
     try:
         B, T1, T2, rel, mk = case["B"], case["T1"], case["T2"], case["rel"], case["mask"]
         H, dk = 4, 64
         D = H * dk
         g = torch.Generator().manual_seed(T1 * 11 + T2)
-        bf = lambda *s: (0.5 * torch.randn(*s, generator=g)).to(torch.bfloat16).to(DEV)
+        bf = lambda *s: (0.5 * torch.randn(*s, generator=g)).to(torch.bfloat16).to(ops.act_dtype()).to(DEV)
         qu, k, v = bf(B * T1, D), bf(B * T2, D), bf(B * T2, D)
         qv = bf(B * T1, D) if rel else None
         p = bf(T2, D) if rel else None
@@ -935,25 +974,26 @@ def test_attention_fused_vs_oracle(ops, oracle, case):
         fused = F_.attn_fwd_fused(qu, qv, k, v, p, mask, B, T1, T2, H, dk)
         assert fused is not None, "eamd_attn_fwd declined the config-2 operand layout"
         P1, c1 = fused
+        assert P1.dtype == c1.dtype == ops.act_dtype()
         dctx = bf(B * T1, D)
         F_.FUSE_ATTN = True
         dqu, dqv, dkk, dvv, dpos = F_.attn_core_bwd(dctx, P1, qu, qv, k, v, p, B, T1, T2, H, dk)
         attn, ctx, gq, gqv, gk, gv, gp = _oracle_attention(oracle, qu, qv, k, v, p, mask, dctx, B, T1, T2, H, dk)
         ldp = F_._ldp(T2)
         Pv = P1.view(H, B, T1, ldp).float().permute(1, 0, 2, 3)
-        report("attn_fwd P vs oracle %s" % (case,), Pv[..., :T2], attn, 4e-3)
+        report("attn_fwd P vs oracle %s %s" % (prec, case), Pv[..., :T2], attn, tol_f)
         assert bool((Pv[..., T2:] == 0).all())
-        report("attn_fwd ctx vs oracle %s" % (case,), c1.float(), ctx, 4e-3)
+        report("attn_fwd ctx vs oracle %s %s" % (prec, case), c1.float(), ctx, tol_f)
         if mk == "dead":
             assert bool((Pv[1] == 0).all()) and bool((c1.view(B, T1, D)[1] == 0).all())
             assert bool((Pv[0, ..., T2 // 2:] == 0).all())
         r2 = lambda t, T: t.reshape(B * T, D)
-        report("attn_bwd dq(u) vs oracle %s" % (case,), dqu.float(), r2(gq, T1), 8e-3)
-        report("attn_bwd dk vs oracle %s" % (case,), dkk.float(), r2(gk, T2), 8e-3)
-        report("attn_bwd dv vs oracle %s" % (case,), dvv.float(), r2(gv, T2), 8e-3)
+        report("attn_bwd dq(u) vs oracle %s %s" % (prec, case), dqu.float(), r2(gq, T1), tol_g)
+        report("attn_bwd dk vs oracle %s %s" % (prec, case), dkk.float(), r2(gk, T2), tol_g)
+        report("attn_bwd dv vs oracle %s %s" % (prec, case), dvv.float(), r2(gv, T2), tol_g)
         if rel:
-            report("attn_bwd dq(v) vs oracle %s" % (case,), dqv.float(), r2(gqv, T1), 8e-3)
-            report("attn_bwd dpos vs oracle %s" % (case,), dpos.float().view(T2, D), gp.reshape(T2, D), 8e-3)
+            report("attn_bwd dq(v) vs oracle %s %s" % (prec, case), dqv.float(), r2(gqv, T1), tol_g)
+            report("attn_bwd dpos vs oracle %s %s" % (prec, case), dpos.float().view(T2, D), gp.reshape(T2, D), tol_g)
     finally:
         F_.FUSE_ATTN = True
         espnet_amd.set_precision("fp32")
