@@ -367,9 +367,10 @@ def attn_scores_fwd(qu, qv, k, p, mask, B, T1, T2, H, dk):
              sC=(T1 * ldp, B * T1 * ldp), a_off=qu.off, b_off=k.off)
     bd = None
     if p is not None:
+        pm = _mv(p)
         bd = torch.empty_like(ac)
-        ops.gemm(qv, p, bd, T1, T2, dk, D, D, ldp, batch=(B, H), sA=(T1 * D, dk), sB=(0, dk),
-                 sC=(T1 * ldp, B * T1 * ldp))
+        ops.gemm(qv, pm.t, bd, T1, T2, dk, D, pm.ld, ldp, batch=(B, H), sA=(T1 * D, dk), sB=(0, dk),
+                 sC=(T1 * ldp, B * T1 * ldp), b_off=pm.off)
     if ops.fast():
         P = torch.empty(H * B * T1 * ldp, device=ac.device, dtype=torch.bfloat16)
     else:
@@ -385,11 +386,11 @@ ATTN_TAP = None    # a list while E2E.calculate_all_attentions runs: every atten
 def attn_fwd_fused(qu, qv, k, v, p, mask, B, T1, T2, H, dk):
     """(P, ctx) from eamd_attn_fwd, or None when the library declines the operands"""
     qu, k, v = _mv(qu), _mv(k), _mv(v)
-    qv3 = None
+    qv3 = p3 = None
     if p is not None:
-        qvm = _mv(qv)
-        qv3 = (qvm.t, qvm.off, qvm.ld)
-    return ops.attn_fwd((qu.t, qu.off, qu.ld), qv3, (k.t, k.off, k.ld), (v.t, v.off, v.ld), p, mask, B, T1, T2, H, dk,
+        qvm, pm = _mv(qv), _mv(p)
+        qv3, p3 = (qvm.t, qvm.off, qvm.ld), (pm.t, pm.off, pm.ld)
+    return ops.attn_fwd((qu.t, qu.off, qu.ld), qv3, (k.t, k.off, k.ld), (v.t, v.off, v.ld), p3, mask, B, T1, T2, H, dk,
                         _ldp(T2), 1.0 / math.sqrt(dk))
 
 
@@ -403,18 +404,26 @@ def attn_context_fwd(P, v, B, T1, T2, H, dk):
     return ctxv
 
 
-def attn_core_bwd(dctx, P, qu, qv, k, v, p, B, T1, T2, H, dk, Pd=None, attn_drop=(0.0, 0), dqkv=None):
+def attn_core_bwd(dctx, P, qu, qv, k, v, p, B, T1, T2, H, dk, Pd=None, attn_drop=(0.0, 0), dqkv=None, dkv_out=None,
+                  dp_out=None):
     """returns dqu (fp32), dqv (fp32 or None), dk, dv (GEMM-operand dtype), dp (fp32 or None)
     Pd = dropped-out probabilities actually used for the context (None when attention dropout is off).
     dqkv (fused QKV projection, self-attention): a [B*T, 3D] operand-dtype buffer; dk / dv are written into its
-    column blocks 1 / 2, and without relative positions dq goes straight into block 0 (dqu is then None)."""
+    column blocks 1 / 2, and without relative positions dq goes straight into block 0 (dqu is then None).
+    dkv_out (shared cross-attention projection): _MV of a [B*T2, *] operand-dtype buffer; dk / dv are written into
+    its columns off .. off + D and off + D .. off + 2D.  dp_out (shared positional projection): _MV of a zeroed fp32
+    [T2, *] buffer that receives dp (dp is then returned as None)."""
     D = H * dk
     ldp = _ldp(T2)
     dev = dctx.device
     adt = ops.act_dtype()
     qu, k, v = _mv(qu), _mv(k), _mv(v)
     sP = (T1 * ldp, B * T1 * ldp)
-    if dqkv is None:
+    if dkv_out is not None:
+        assert dqkv is None
+        ldo = dkv_out.ld
+        dkk, dk_off, dv, dv_off = dkv_out.t, dkv_out.off, dkv_out.t, dkv_out.off + D
+    elif dqkv is None:
         dv, dv_off, ldo = torch.empty(B * T2, D, device=dev, dtype=adt), 0, D
         dkk, dk_off = torch.empty(B * T2, D, device=dev, dtype=adt), 0
     else:
@@ -458,12 +467,19 @@ def attn_core_bwd(dctx, P, qu, qv, k, v, p, B, T1, T2, H, dk, Pd=None, attn_drop
              sC=(T2 * ldo, dk), b_off=qu.off, c_off=dk_off)
     dqv = dp = None
     if p is not None:
+        pm = _mv(p)
         dqv = torch.empty(B * T1, D, device=dev, dtype=torch.float32)
-        ops.gemm(dbd, p, dqv, T1, dk, T2, ldp, D, D, transB=1, batch=(B, H), sA=sP, sB=(0, dk), sC=(T1 * D, dk))
+        ops.gemm(dbd, pm.t, dqv, T1, dk, T2, ldp, pm.ld, D, transB=1, batch=(B, H), sA=sP, sB=(0, dk), sC=(T1 * D, dk),
+                 b_off=pm.off)
         # dp[j, h, :] = sum_{b,i} dbd[h, b, i, j] * qv[b, i, h, :]   (reduction over B*T1 rows, split-K)
-        dp = torch.zeros(T2, D, device=dev, dtype=torch.float32)
-        ops.gemm(dbd, qv, dp, T2, dk, B * T1, ldp, D, D, transA=1, transB=1, batch=(1, H),
-                 sA=(0, B * T1 * ldp), sB=(0, dk), sC=(0, dk), splitk=max(2, ops.auto_splitk(T2, dk, B * T1) // H + 1))
+        if dp_out is None:
+            dp = torch.zeros(T2, D, device=dev, dtype=torch.float32)
+            dpt, dp_off, ldd = dp, 0, D
+        else:
+            dpt, dp_off, ldd = dp_out.t, dp_out.off, dp_out.ld
+        ops.gemm(dbd, qv, dpt, T2, dk, B * T1, ldp, D, ldd, transA=1, transB=1, batch=(1, H),
+                 sA=(0, B * T1 * ldp), sB=(0, dk), sC=(0, dk), c_off=dp_off,
+                 splitk=max(2, ops.auto_splitk(T2, dk, B * T1) // H + 1))
     return dqu, dqv, dkk, dv, dp
 
 
@@ -494,6 +510,112 @@ def _span3(first, shape):
     return first.detach().as_strided(shape, stride)
 
 
+SHARE_PROJ = True   # tests flip this to reach the per-layer projections
+
+
+def _adjacent_run(ts):
+    """tensors lie back to back (equal sizes not required)"""
+    return all(a.is_contiguous() and b.is_contiguous() and b.data_ptr() == a.data_ptr() + a.numel() * a.element_size()
+               for a, b in zip(ts, ts[1:]))
+
+
+def shared_proj_ok(weights, biases=None):
+    """True when `weights` (and `biases`) - fp32 masters, operand shadows and gradient buffers - each form one run in
+    their arenas (espnet_amd.train.FlatParams arranges that for the cross-attention k / v projections of a decoder
+    stack and the linear_pos projections of an encoder stack): the projections then run as ONE GEMM (SharedProjFn)"""
+    if not SHARE_PROJ or len(weights) < 2:
+        return False
+    for grp in (weights, biases):
+        if grp is None:
+            continue
+        gr = [getattr(t, "_eamd_grad", None) for t in grp]
+        if any(g is None for g in gr) or not (_adjacent_run(list(grp)) and _adjacent_run(gr)):
+            return False
+        if not _adjacent_run([ops.wshadow(t) for t in grp]):
+            return False
+    return True
+
+
+class SharedProj:
+    """Output of ONE projection GEMM whose column blocks feed several attention blocks, and the buffer that collects
+    the blocks' gradients.  Block i = columns i * width .. (i + 1) * width."""
+
+    def __init__(self, out, nblk, zero_grad, grad_dtype):
+        self.out, self.n = out, nblk
+        self.ld = out.shape[1]
+        self.width = self.ld // nblk
+        self.dout, self.pending, self.done = None, [], 0
+        self.zero_grad, self.grad_dtype = zero_grad, grad_dtype
+
+    def block(self, i, sub=0):
+        return _MV(self.out, i * self.width + sub, self.ld)
+
+    def grad_block(self, i):
+        """column block i of the gradient buffer (allocated by the first block that reports in a backward pass)"""
+        if self.dout is None:
+            mk = torch.zeros if self.zero_grad else torch.empty
+            self.dout = mk(self.out.shape, device=self.out.device, dtype=self.grad_dtype)
+        self.pending.append(i)
+        return _MV(self.dout, i * self.width, self.ld)
+
+
+class SharedProjFn(torch.autograd.Function):
+    """token = SharedProjFn(inp, box, zero_grad, nblk, n_w, *weights [, *biases]): out = inp W_all^T + b_all for the
+    row-stacked weights of `nblk` consumers in one GEMM.  The result travels in a SharedProj appended to `box`, not
+    through autograd: consumers read their column block, write their block of the gradient buffer in backward and
+    take `token` as an input they return no gradient for - autograd then runs this backward once every consumer of
+    the backward pass under way has reported (one pass, or one per phase of a phased data-parallel backward: only the
+    blocks that reported are processed).  Weight / bias gradients go straight to the arena.
+    reference: transformer/attention.py:94-114 (linear_k / linear_v), :164-206 (linear_pos) - per layer there."""
+
+    @staticmethod
+    def forward(ctx, inp, box, zero_grad, nblk, n_w, *params):
+        ctx.set_materialize_grads(False)
+        ws, bs = params[:n_w], params[n_w:]
+        Din = ws[0].shape[1]
+        rows_w = sum(w.shape[0] for w in ws)
+        adt = ops.act_dtype()
+        inp2 = ops.to_act_shared(inp).reshape(-1, Din)
+        W = ops.wshadow(ws[0]).detach().as_strided((rows_w, Din), (Din, 1))
+        b = bs[0].detach().as_strided((rows_w,), (1,)) if bs else None
+        out = ops.linear_fwd(inp2, W, b, out_dtype=adt)
+        sp = SharedProj(out, nblk, zero_grad, torch.float32 if zero_grad else adt)
+        box.append(sp)
+        ctx.sp, ctx.inp2, ctx.W, ctx.shape = sp, inp2, W, inp.shape      # plain attributes: survive a phased backward
+        ctx.pr = GradSink.use(params)
+        ctx.n_w = n_w
+        return torch.zeros((), device=inp.device)
+
+    @staticmethod
+    def backward(ctx, _dtoken):
+        sp, inp2, W = ctx.sp, ctx.inp2, ctx.W
+        params = ctx.pr
+        ws, bs = params[:ctx.n_w], params[ctx.n_w:]
+        blocks = sorted(sp.pending)
+        sp.pending = []
+        dinp = None
+        if blocks:
+            assert blocks == list(range(blocks[0], blocks[-1] + 1)), "consumers of one backward pass are consecutive blocks"
+            lo, hi = blocks[0] * sp.width, (blocks[-1] + 1) * sp.width
+            M, Din, n = inp2.shape[0], inp2.shape[1], hi - lo
+            dy = sp.dout if sp.dout.dtype == inp2.dtype else ops.to_act(sp.dout)
+            rows_w = W.shape[0]
+            dW = ws[0]._eamd_grad.as_strided((rows_w, Din), (Din, 1))[lo:hi]
+            db = bs[0]._eamd_grad.as_strided((rows_w,), (1,))[lo:hi] if bs else None
+            sk = ops.auto_splitk(n, Din, M)
+            ops.gemm(dy, inp2, dW, n, Din, M, sp.ld, Din, Din, transA=1, transB=1, splitk=sk,
+                     beta=1.0 if sk == 1 else 0.0, colsum=db, a_off=lo)            # dW += dY^T X, db += column sums
+            if ctx.needs_input_grad[0]:
+                dinp = torch.empty(M, Din, device=inp2.device, dtype=torch.float32)
+                ops.gemm(dy, W, dinp, M, Din, n, sp.ld, Din, Din, transB=1, a_off=lo, b_off=lo * Din)   # dX = dY W
+                dinp = dinp.view(ctx.shape)
+            sp.done += len(blocks)
+        if sp.done >= sp.n and GradSink.on_done is not None:
+            ops.wgrad_join()
+            GradSink.on_done(params)
+        return (dinp, None, None, None, None) + (None,) * len(params)
+
+
 class MHABlockFn(torch.autograd.Function):
     """out = x + Wo . Attention(LN(x) [, memory]) with optional legacy relative positions.
 
@@ -504,10 +626,14 @@ class MHABlockFn(torch.autograd.Function):
     """
 
     @staticmethod
-    def forward(ctx, x, memory, pos_emb, mask, H, eps, last_query_only, drop, *params):
+    def forward(ctx, x, memory, pos_emb, mask, H, eps, last_query_only, drop, pre, token, *params):
         # drop = (p_attn, salt_attn, p_out, salt_out): attention.py:91 (dropout on the probabilities) and the
         # block-output dropout before the residual add (encoder_layer.py:126, decoder_layer.py:104,115)
+        # pre = (kind, SharedProj, block index) with `token` from SharedProjFn: kind "kv" - k / v of the memory come
+        # from the decoder stack's shared projection; kind "pos" - the projected positions from the encoder stack's
         p_att, s_att, p_out, s_out = drop
+        pre_kv = pre if (pre is not None and pre[0] == "kv") else None
+        pre_pos = pre if (pre is not None and pre[0] == "pos") else None
         ln_w, ln_b, wq, bq, wk, bk, wv, bv, wo, bo = params[:10]
         rel = len(params) > 10
         B, T1f, D = x.shape
@@ -535,13 +661,20 @@ class MHABlockFn(torch.autograd.Function):
         else:
             qkv = None
             q = ops.linear_fwd(xq, ops.wshadow(wq), bq, out_dtype=adt)
-            k = ops.linear_fwd(kv_in, ops.wshadow(wk), bk, out_dtype=adt)
-            v = ops.linear_fwd(kv_in, ops.wshadow(wv), bv, out_dtype=adt)
+            if pre_kv is not None:
+                assert memory is not None
+                k, v = pre_kv[1].block(pre_kv[2], 0), pre_kv[1].block(pre_kv[2], D)
+            else:
+                k = ops.linear_fwd(kv_in, ops.wshadow(wk), bk, out_dtype=adt)
+                v = ops.linear_fwd(kv_in, ops.wshadow(wv), bv, out_dtype=adt)
         pos2 = None
         if rel:
             wpos, pu, pv = params[10:13]
-            pos2 = ops.to_act_shared(pos_emb).reshape(-1, D)
-            p = ops.linear_fwd(pos2, ops.wshadow(wpos), None, out_dtype=adt)
+            if pre_pos is not None:
+                p = pre_pos[1].block(pre_pos[2])
+            else:
+                pos2 = ops.to_act_shared(pos_emb).reshape(-1, D)
+                p = ops.linear_fwd(pos2, ops.wshadow(wpos), None, out_dtype=adt)
             if fused:
                 qu, qv = ops.add_bias2(qkv, pu.reshape(-1), pv.reshape(-1), rows=B * T1, D=D, ldq=3 * D, q_off=0)
             else:
@@ -567,12 +700,21 @@ class MHABlockFn(torch.autograd.Function):
             out = ops.axpby(res, ops.dropout(br, p_out, s_out), 1.0, 1.0)
         else:
             out = ops.linear_fwd(cx, ops.wshadow(wo), bo, R=res)
+        # tensors that live in a SharedProj stay out of save_for_backward (they are no outputs of this Function)
+        p_sv = None if pre_pos is not None else p
         if fused:   # k, v (and q without relative positions) are column blocks of qkv
-            ctx.save_for_backward(x2, mean, rstd, xn, None, qu if rel else None, qv, qkv, None, p, P, cx, pos2,
+            ctx.save_for_backward(x2, mean, rstd, xn, None, qu if rel else None, qv, qkv, None, p_sv, P, cx, pos2,
+                                  Pd if p_att > 0.0 else None)
+        elif pre_kv is not None:
+            ctx.save_for_backward(x2, mean, rstd, xn, None, qu, qv, None, None, p_sv, P, cx, pos2,
                                   Pd if p_att > 0.0 else None)
         else:
-            ctx.save_for_backward(x2, mean, rstd, xn, kv_in if memory is not None else None, qu, qv, k, v, p, P, cx,
+            ctx.save_for_backward(x2, mean, rstd, xn, kv_in if memory is not None else None, qu, qv, k, v, p_sv, P, cx,
                                   pos2, Pd if p_att > 0.0 else None)
+        ctx.pre = pre
+        if pre is not None:      # the shared projection owns these parameters' gradients
+            skip = (4, 5, 6, 7) if pre_kv is not None else (10,)
+            params = tuple(None if i in skip else q_ for i, q_ in enumerate(params))
         ctx.pr = GradSink.use(params)
         ctx.fused = fused
         ctx.cfg = (B, T1, T2, H, dk, D, rel, memory is not None, last_query_only, drop)
@@ -588,6 +730,11 @@ class MHABlockFn(torch.autograd.Function):
         ln_w, ln_b, wq, bq, wk, bk, wv, bv, wo, bo = params[:10]
         adt = ops.act_dtype()
         sink = GradSink(params)
+        pre = ctx.pre
+        pre_kv = pre if (pre is not None and pre[0] == "kv") else None
+        dp_out = None
+        if pre is not None and pre[0] == "pos":
+            p, dp_out = pre[1].block(pre[2]), pre[1].grad_block(pre[2])
         do = dout.reshape(-1, D).contiguous()
         dob, g_drop = _grad_operand(dout, do, p_out, s_out)
         ops.linear_bwd_w(dob, cx, sink.buf(8), db=sink.buf(9), a_drop=g_drop)
@@ -597,7 +744,7 @@ class MHABlockFn(torch.autograd.Function):
             dqkv = torch.empty(B * T1, 3 * D, device=do.device, dtype=adt)
             quv = qu if rel else _MV(qkv, 0, 3 * D)
             dqu, dqv, _, _, dp = attn_core_bwd(dctx, P, quv, qv, _MV(qkv, D, 3 * D), _MV(qkv, 2 * D, 3 * D), p, B, T1,
-                                               T2, H, dk, Pd=Pd, attn_drop=(p_att, s_att), dqkv=dqkv)
+                                               T2, H, dk, Pd=Pd, attn_drop=(p_att, s_att), dqkv=dqkv, dp_out=dp_out)
             if rel:
                 wpos = params[10]
                 if ops.fast():      # dq = dqu + dqv (bf16, into the fused buffer) + both bias gradients in one pass
@@ -607,13 +754,18 @@ class MHABlockFn(torch.autograd.Function):
                     ops.colsum(dqu, sink.buf(11).view(-1))
                     ops.colsum(dqv, sink.buf(12).view(-1))
                     ops.add_cast(dqu, dqv, out=dqkv, out_off=0, ld_out=3 * D)
-                ops.linear_bwd_w(ops.to_act(dp), pos2, sink.buf(10))
+                if dp_out is None:
+                    ops.linear_bwd_w(ops.to_act(dp), pos2, sink.buf(10))
             ops.linear_bwd_w(dqkv, xn, _span3(sink.buf(2), (3 * D, D)), db=_span3(sink.buf(3), (3 * D,)))
             dxn = ops.linear_bwd_x(dqkv, _span3(ops.wshadow(wq), (3 * D, D)))
             dx = _ln_bwd_out(dxn, x2, ln_w, mean, rstd, do, sink.buf(0), sink.buf(1), ctx.prev, (B, T1, D))
-            return (dx, None, None, None, None, None, None, None) + sink.results()
+            return (dx, None, None, None, None, None, None, None, None, None) + sink.results()
+        dkv_out = None
+        if pre_kv is not None:
+            k, v = pre_kv[1].block(pre_kv[2], 0), pre_kv[1].block(pre_kv[2], D)
+            dkv_out = pre_kv[1].grad_block(pre_kv[2])
         dqu, dqv, dkk, dv, dp = attn_core_bwd(dctx, P, qu, qv, k, v, p, B, T1, T2, H, dk,
-                                              Pd=Pd, attn_drop=(p_att, s_att))
+                                              Pd=Pd, attn_drop=(p_att, s_att), dkv_out=dkv_out, dp_out=dp_out)
         if rel:
             wpos = params[10]
             if ops.fast():
@@ -622,15 +774,19 @@ class MHABlockFn(torch.autograd.Function):
                 ops.colsum(dqu, sink.buf(11).view(-1))
                 ops.colsum(dqv, sink.buf(12).view(-1))
                 dq = ops.axpby(dqu, dqv, 1.0, 1.0)
-            ops.linear_bwd_w(ops.to_act(dp), pos2, sink.buf(10))
+            if dp_out is None:
+                ops.linear_bwd_w(ops.to_act(dp), pos2, sink.buf(10))
         else:
             dq = ops.to_act(dqu)
         kv_in = mem2 if cross else xn
         ops.linear_bwd_w(dq, xn, sink.buf(2), db=sink.buf(3))
-        ops.linear_bwd_w(dkk, kv_in, sink.buf(4), db=sink.buf(5))
-        ops.linear_bwd_w(dv, kv_in, sink.buf(6), db=sink.buf(7))
         dxn = ops.linear_bwd_x(dq, ops.wshadow(wq))
         dmem = None
+        if pre_kv is not None:     # dWk / dWv / dmemory: one GEMM each for the whole decoder stack (SharedProjFn.backward)
+            dx = _ln_bwd_out(dxn, x2, ln_w, mean, rstd, do, sink.buf(0), sink.buf(1), ctx.prev, (B, T1, D))
+            return (dx, None, None, None, None, None, None, None, None, None) + sink.results()
+        ops.linear_bwd_w(dkk, kv_in, sink.buf(4), db=sink.buf(5))
+        ops.linear_bwd_w(dv, kv_in, sink.buf(6), db=sink.buf(7))
         if cross:
             dmem = ops.linear_bwd_x(dkk, ops.wshadow(wk))
             ops.linear_bwd_x(dv, ops.wshadow(wv), out=dmem, beta=1.0)
@@ -639,7 +795,7 @@ class MHABlockFn(torch.autograd.Function):
             ops.linear_bwd_x(dkk, ops.wshadow(wk), out=dxn, beta=1.0)
             ops.linear_bwd_x(dv, ops.wshadow(wv), out=dxn, beta=1.0)
         dx = _ln_bwd_out(dxn, x2, ln_w, mean, rstd, do, sink.buf(0), sink.buf(1), ctx.prev, (B, T1, D))
-        return (dx, dmem, None, None, None, None, None, None) + sink.results()
+        return (dx, dmem, None, None, None, None, None, None, None, None) + sink.results()
 
 
 # =================================================================================================

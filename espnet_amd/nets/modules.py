@@ -320,7 +320,7 @@ class MultiHeadedAttention(torch.nn.Module):
         drop = (_p(self, self.dropout_rate), self.salt_attn, 0.0, self.salt_out)
         n_tap = len(F_.ATTN_TAP) if F_.ATTN_TAP is not None else 0
         out = F_.MHABlockFn.apply(query.contiguous(), memory, pos_emb, _mask_u8(mask, query.device), self.h, None,
-                                  False, drop, None, None, *self.block_params())
+                                  False, drop, None, None, None, None, *self.block_params())
         if F_.ATTN_TAP is not None and len(F_.ATTN_TAP) > n_tap:
             self.attn = F_.ATTN_TAP[-1]
         return out
@@ -347,12 +347,36 @@ class RelPositionMultiHeadedAttention(MultiHeadedAttention):
         return self._bare(query, key, value, pos_emb, mask)
 
 
-def mha_block(norm, attn, x, memory, pos_emb, mask, last_query_only=False, p_out=0.0):
-    """x + drop(attn(LN(x)[, memory])) through the fused HIP block (p_out = the layer's dropout rate)."""
+def shared_stack_proj(kind, layers, attn_of, inp):
+    """One projection GEMM for a whole layer stack (F_.SharedProjFn): kind "kv" = linear_k / linear_v of every
+    decoder layer's source attention applied to the encoder memory, kind "pos" = linear_pos of every encoder layer's
+    self-attention applied to the positional embedding.  Hands every layer its (kind, SharedProj, block, token) in
+    `layer._pre`; returns False (nothing set) when the parameters do not form one run in the arenas."""
+    atts = [attn_of(m) for m in layers]
+    if kind == "kv":
+        ws = [w for a in atts for w in (a.linear_k.weight, a.linear_v.weight)]
+        bs = [b for a in atts for b in (a.linear_k.bias, a.linear_v.bias)]
+    else:
+        if not all(hasattr(a, "linear_pos") for a in atts):
+            return False
+        ws, bs = [a.linear_pos.weight for a in atts], None
+    if not inp.is_cuda or not F_.shared_proj_ok(ws, bs):
+        return False
+    box = []
+    token = F_.SharedProjFn.apply(inp, box, kind == "pos", len(atts), len(ws), *(ws + (bs or [])))
+    for i, m in enumerate(layers):
+        m._pre = (kind, box[0], i, token)
+    return True
+
+
+def mha_block(norm, attn, x, memory, pos_emb, mask, last_query_only=False, p_out=0.0, pre=None):
+    """x + drop(attn(LN(x)[, memory])) through the fused HIP block (p_out = the layer's dropout rate).
+    pre = (kind, SharedProj, block, token): this layer's share of a projection the whole stack ran as one GEMM."""
     drop = (_p(attn, attn.dropout_rate), attn.salt_attn, p_out if attn.training else 0.0, attn.salt_out)
     n_tap = len(F_.ATTN_TAP) if F_.ATTN_TAP is not None else 0
     out = F_.MHABlockFn.apply(x.contiguous(), memory, pos_emb, _mask_u8(mask, x.device), attn.h, norm.eps,
-                              last_query_only, drop, norm.weight, norm.bias, *attn.block_params())
+                              last_query_only, drop, pre[:3] if pre is not None else None,
+                              pre[3] if pre is not None else None, norm.weight, norm.bias, *attn.block_params())
     if F_.ATTN_TAP is not None and len(F_.ATTN_TAP) > n_tap:
         attn.attn = F_.ATTN_TAP[-1]        # attention.py:90 (self.attn, kept for calculate_all_attentions / plotting)
     return out
@@ -491,6 +515,8 @@ class ConformerEncoderLayer(torch.nn.Module):
         self.normalize_before = normalize_before
         self.concat_after = concat_after
 
+    _pre = None      # set by ConformerEncoder.forward for the duration of one pass (shared linear_pos of the stack)
+
     def forward(self, x_input, mask, cache=None):
         assert cache is None, "encoder-side cache is not used on the ASR path"
         p = self.dropout_rate
@@ -500,7 +526,7 @@ class ConformerEncoderLayer(torch.nn.Module):
             x, pos_emb = x_input, None
         if self.feed_forward_macaron is not None:
             x = ffn_block(self.norm_ff_macaron, self.feed_forward_macaron, x, self.ff_scale, p)
-        x = mha_block(self.norm_mha, self.self_attn, x, None, pos_emb, mask, p_out=p)
+        x = mha_block(self.norm_mha, self.self_attn, x, None, pos_emb, mask, p_out=p, pre=self._pre)
         if self.conv_module is not None:
             x = conv_block(self.norm_conv, self.conv_module, x, p)
         x = ffn_block(self.norm_ff, self.feed_forward, x, self.ff_scale, p)
@@ -633,7 +659,14 @@ class ConformerEncoder(torch.nn.Module):
 
     def forward(self, xs, masks):
         xs, masks = self.embed(xs, masks)
-        xs, masks = self.encoders(xs, masks)
+        # relative positions: linear_pos of all layers on the one positional embedding as one [T, D*layers] GEMM
+        shared = isinstance(xs, tuple) and shared_stack_proj("pos", list(self.encoders), lambda m: m.self_attn, xs[1])
+        try:
+            xs, masks = self.encoders(xs, masks)
+        finally:
+            if shared:
+                for m in self.encoders:
+                    m._pre = None
         if isinstance(xs, tuple):
             xs = xs[0]
         if self.normalize_before:
@@ -747,6 +780,8 @@ class DecoderLayer(torch.nn.Module):
         self.normalize_before = normalize_before
         self.concat_after = concat_after
 
+    _pre = None      # set by Decoder.forward for the duration of one pass (shared k / v projection of the stack)
+
     def forward(self, tgt, tgt_mask, memory, memory_mask, cache=None):
         p = self.dropout_rate
         if cache is None:
@@ -755,7 +790,8 @@ class DecoderLayer(torch.nn.Module):
             assert cache.shape == (tgt.shape[0], tgt.shape[1] - 1, self.size)
             q_mask = None if tgt_mask is None else tgt_mask[:, -1:, :]
             x = mha_block(self.norm1, self.self_attn, tgt, None, None, q_mask, last_query_only=True, p_out=p)
-        x = mha_block(self.norm2, self.src_attn, x, memory, None, memory_mask, p_out=p)
+        x = mha_block(self.norm2, self.src_attn, x, memory, None, memory_mask, p_out=p,
+                      pre=self._pre if cache is None else None)
         x = ffn_block(self.norm3, self.feed_forward, x, 1.0, p)
         if cache is not None:
             x = torch.cat([cache, x], dim=1)
@@ -805,7 +841,14 @@ class Decoder(torch.nn.Module, BatchScorerInterface):
 
     def forward(self, tgt, tgt_mask, memory, memory_mask):
         x = self._embed(tgt)
-        x, tgt_mask, memory, memory_mask = self.decoders(x, tgt_mask, memory, memory_mask)
+        # linear_k / linear_v of all layers' source attention on the memory: one [B*T, 2*D*layers] GEMM
+        shared = shared_stack_proj("kv", list(self.decoders), lambda m: m.src_attn, memory)
+        try:
+            x, tgt_mask, memory, memory_mask = self.decoders(x, tgt_mask, memory, memory_mask)
+        finally:
+            if shared:
+                for m in self.decoders:
+                    m._pre = None
         if self.normalize_before:
             x = self.after_norm(x)
         if self.output_layer is not None:

@@ -392,7 +392,7 @@ def attn_fwd_supported(T1, T2, dk, rel):
 
 def attn_fwd(qu, qv, k, v, pos, mask, B, T1, T2, H, dk, ldp, scale):
     """qu / qv / k / v: (tensor, element offset, row stride) views of [rows, *] matrices, heads side by side, all bf16
-    (eamd_attn_fwd) or all fp32 (eamd_attn_fwd_f32); pos: [T2, H*dk] of the same dtype or None.
+    (eamd_attn_fwd) or all fp32 (eamd_attn_fwd_f32); pos: such a view of the [T2, H*dk] projected positions, or None.
     Returns (P [H*B*T1*ldp], ctx [B*T1, H*dk]) in that dtype, or None if the library declines the operands
     (EAMD_EUNSUPPORTED)."""
     dev = qu[0].device
@@ -407,12 +407,13 @@ def attn_fwd(qu, qv, k, v, pos, mask, B, T1, T2, H, dk, ldp, scale):
     assert dt in (torch.bfloat16, torch.float32)
     for t_, _, _ in (qu, k, v) + ((qv,) if qv is not None else ()):
         assert t_.dtype == dt and t_.is_cuda
-    assert pos is None or pos.dtype == dt
+    assert pos is None or (pos[0].dtype == dt and pos[2] >= D)
     P = torch.empty(H * B * T1 * ldp, device=dev, dtype=dt)
     cx = torch.empty(B * T1, D, device=dev, dtype=dt)
     i64 = C.c_int64
     args = (ptr(qu[0], qu[1]), i64(qu[2]), ptr(qv[0], qv[1]) if qv is not None else None, i64(qv[2] if qv is not None else 0),
-            ptr(k[0], k[1]), i64(k[2]), ptr(v[0], v[1]), i64(v[2]), ptr(pos), i64(D if pos is not None else 0),
+            ptr(k[0], k[1]), i64(k[2]), ptr(v[0], v[1]), i64(v[2]), ptr(pos[0], pos[1]) if pos is not None else None,
+            i64(pos[2] if pos is not None else 0),
             ptr(mask), i64(mb), i64(mi), ptr(P), i64(ldp), ptr(cx), i64(D), B, H, T1, T2, dk, C.c_float(scale))
     name = "eamd_attn_fwd" if dt == torch.bfloat16 else "eamd_attn_fwd_f32"
     fn = getattr(_lib.lib(), name)

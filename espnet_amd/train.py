@@ -50,20 +50,51 @@ class FlatParams:
 
     @staticmethod
     def _layout_order(model):
-        """registration order, except that the q / k / v projections of every attention module are placed back to
-        back (weights, then biases): MHABlockFn then runs them as ONE [3D, D] GEMM.  Only the arena layout
-        changes; parameter names / state_dict are the reference's."""
+        """registration order, except that parameters which one GEMM can serve are placed back to back (weights, then
+        biases): the q / k / v projections of every self-attention module (MHABlockFn runs them as ONE [3D, D] GEMM),
+        linear_k / linear_v of ALL source-attention modules of a decoder stack (one [2 D layers, D] GEMM on the encoder
+        memory) and linear_pos of ALL self-attention modules of an encoder stack (F_.SharedProjFn).  Only the arena
+        layout changes; parameter names / state_dict are the reference's."""
+        import re
         named = list(model.named_parameters())
         by_name = dict(named)
+        # stack-wide groups: stack prefix -> ordered member names
+        stacks = {}
+        for name, _p in named:
+            m = re.match(r"(.*)\.(\d+)\.src_attn\.linear_k\.weight$", name)
+            if m:
+                stacks.setdefault(("kv", m.group(1)), []).append(int(m.group(2)))
+            m = re.match(r"(.*)\.(\d+)\.self_attn\.linear_pos\.weight$", name)
+            if m:
+                stacks.setdefault(("pos", m.group(1)), []).append(int(m.group(2)))
+        group_of = {}
+        for (kind, base), idx in stacks.items():
+            idx = sorted(idx)
+            if len(idx) < 2:
+                continue
+            if kind == "kv":
+                names = ["%s.%d.src_attn.linear_%s.weight" % (base, i, kv) for i in idx for kv in "kv"]
+                names += ["%s.%d.src_attn.linear_%s.bias" % (base, i, kv) for i in idx for kv in "kv"]
+            else:
+                names = ["%s.%d.self_attn.linear_pos.weight" % (base, i) for i in idx]
+            if all(n in by_name for n in names) and len({id(by_name[n]) for n in names}) == len(names):
+                for n in names:
+                    group_of[n] = names
+                    by_name[n]._eamd_stack_group = kind
         seen, order = set(), []
         for name, p in named:
             if id(p) in seen:
+                continue
+            if name in group_of:
+                for g in group_of[name]:
+                    order.append(by_name[g])
+                    seen.add(id(by_name[g]))
                 continue
             if name.endswith("linear_q.weight"):
                 base = name[: -len("linear_q.weight")]
                 grp = [base + n for n in ("linear_q.weight", "linear_k.weight", "linear_v.weight", "linear_q.bias",
                                           "linear_k.bias", "linear_v.bias")]
-                if all(g in by_name and id(by_name[g]) not in seen for g in grp):
+                if all(g in by_name and id(by_name[g]) not in seen and g not in group_of for g in grp):
                     for g in grp:
                         order.append(by_name[g])
                         seen.add(id(by_name[g]))
@@ -310,6 +341,8 @@ class GraphedDataParallelStep:
         for name, p in self.model.named_parameters():
             if not name.startswith("encoder."):
                 ph = 0                                              # decoder, CTC, anything behind the encoder
+            elif getattr(p, "_eamd_stack_group", None) == "pos":
+                ph = nph - 1        # linear_pos of every layer lives (and is finished) with the lowest layers: F_.SharedProjFn
             elif name.startswith("encoder.encoders."):
                 ph = 1 + sum(1 for c in cuts if int(name.split(".")[2]) < c)
             elif name.startswith("encoder.after_norm."):

@@ -1296,6 +1296,46 @@ def test_fp32_fused_paths_match_separate_paths():
         report("fp32 %s vs separate paths: gradient arena" % what, res[i][1], res[2][1], 2e-5)
 
 
+@pytest.mark.parametrize("prec", ["fp32", "bf16"])
+def test_shared_stack_projections_match_per_layer(prec):
+    """linear_k / linear_v of all decoder layers' source attention as ONE GEMM on the encoder memory and linear_pos of
+    all encoder layers as ONE GEMM on the positional embedding (F_.SharedProjFn; weight / bias / memory gradients one
+    GEMM each) against the per-layer projections: same loss, same gradient arena (dropout 0.1, same masks)"""
+    import espnet_amd
+    from espnet_amd import functional as F_
+    from espnet_amd import ops, train
+    from conftest import e2e_dk64_model
+    g = load_golden("e2e_conformer_dk64.npz")
+    xs, ilens, ys = torch.from_numpy(g["xs"]).to(DEV), torch.from_numpy(g["ilens"]), torch.from_numpy(g["ys"]).to(DEV)
+    espnet_amd.set_precision(prec)
+    res, seen = [], []
+    try:
+        model, _cfg = e2e_dk64_model(dropout=0.1)
+        model = model.to(DEV).train()
+        flat = train.FlatParams(model)
+        for share in (True, False):
+            F_.SHARE_PROJ = share
+            flat.zero_grad()
+            ops.manual_seed(77)
+            rec = []
+            ops._gemm_record = rec
+            loss = model(xs, ilens, ys)
+            loss.backward()
+            ops._gemm_record = None
+            res.append((float(loss), flat.grad.clone()))
+            seen.append(len(rec))
+    finally:
+        ops._gemm_record = None
+        F_.SHARE_PROJ = True
+        espnet_amd.set_precision("fp32")
+    print(f"[launches] MFMA-contraction launches per step: shared {seen[0]}, per layer {seen[1]}")
+    assert seen[0] < seen[1]          # the shared path really ran (fewer GEMM launches)
+    rel = abs(res[0][0] - res[1][0]) / abs(res[1][0])
+    print(f"[parity] {prec} shared vs per-layer projections: loss {res[0][0]:.6f} vs {res[1][0]:.6f} (rel {rel:.2e})")
+    assert rel < (1e-6 if prec == "fp32" else 2e-3)
+    report("shared vs per-layer projections (%s): gradient arena" % prec, res[0][1], res[1][1], 2e-5 if prec == "fp32" else 2e-2)
+
+
 def test_bucketed_graph_step_matches_eager():
     """a stream of batches of two different shapes through train.BucketedGraphStep (eager on first sight, capture on
     the second, replay afterwards) against plain eager steps on the same padded batches with an identical second model:
