@@ -24,8 +24,10 @@ namespace {
 
 // ACT: prologue activations (a_act / b_act) compiled in; the hot instantiations leave them out so the
 // steady-state loop carries no transcendental code and no branches around it.
+// One workgroup's share of a problem: `bid` of `nblk` workgroups (tile x split-K slice), batch index `zb`.
+// gemm_bf16_kernel runs it on a launch of its own; gemm_bf16_group_kernel looks the problem up in a device table.
 template <int BM, int BN, bool TA, bool TB, bool FAST, bool GAT, bool ACT>
-__global__ __launch_bounds__(NT_) void gemm_bf16_kernel(const eamd_gemm_t p) {
+__device__ __forceinline__ void gemm_bf16_body(const eamd_gemm_t& p, const int bid, const int nblk, const int zb) {
   constexpr int WM = BM / 2, WN = BN / 2;
   constexpr int MT = WM / 16, NTL = WN / 16;
   constexpr int NCA = BM / 32, NCB = BN / 32;          // 16-byte chunks per thread per tile
@@ -47,17 +49,16 @@ __global__ __launch_bounds__(NT_) void gemm_bf16_kernel(const eamd_gemm_t p) {
     // split-K: the split index is the fastest-varying part of the workgroup id, so XCD i (ids = i mod 8)
     // owns K-slice i (mod splitk) of EVERY tile: each XCD streams its slice of A and B once through its
     // own L2 instead of all eight XCDs re-reading the whole reduction range
-    split = blockIdx.x % p.splitk;
-    tile_id = blockIdx.x / p.splitk;
+    split = bid % p.splitk;
+    tile_id = bid / p.splitk;
   } else {
     split = 0;
-    const int ntile = gridDim.x;
-    const int id = blockIdx.x, q = ntile >> 3, r = ntile & 7, xcd = id & 7, j = id >> 3;
+    const int ntile = nblk;
+    const int id = bid, q = ntile >> 3, r = ntile & 7, xcd = id & 7, j = id >> 3;
     tile_id = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + j;
   }
   const int tile_m = tile_id / tiles_n, tile_n = tile_id % tiles_n;
   const int m0 = tile_m * BM, n0 = tile_n * BN;
-  const int zb = blockIdx.z;
   const int b1 = zb / p.batch2, b2 = zb % p.batch2;
   const bf16_t* __restrict__ A = reinterpret_cast<const bf16_t*>(p.A) + b1 * p.sA1 + b2 * p.sA2;
   const bf16_t* __restrict__ B = reinterpret_cast<const bf16_t*>(p.B) + b1 * p.sB1 + b2 * p.sB2;
@@ -451,6 +452,25 @@ __global__ __launch_bounds__(NT_) void gemm_bf16_kernel(const eamd_gemm_t p) {
 }
 
 template <int BM, int BN, bool TA, bool TB, bool FAST, bool GAT, bool ACT>
+__global__ __launch_bounds__(NT_) void gemm_bf16_kernel(const eamd_gemm_t p) {
+  gemm_bf16_body<BM, BN, TA, TB, FAST, GAT, ACT>(p, blockIdx.x, gridDim.x, blockIdx.z);
+}
+
+// Grouped launch: workgroups first[i] .. first[i + 1] - 1 work on problem i of a device-resident descriptor table
+// (independent weight-gradient GEMMs dW_i += dY_i^T X_i of one backward pass, each too small to fill the chip).
+template <int BM, int BN, bool TA, bool TB>
+__global__ __launch_bounds__(NT_) void gemm_bf16_group_kernel(const eamd_gemm_t* __restrict__ tab,
+                                                              const int* __restrict__ first, const int n) {
+  int lo = 0, hi = n;                    // largest i with first[i] <= blockIdx.x
+  while (hi - lo > 1) {
+    const int mid = (lo + hi) >> 1;
+    if (first[mid] <= (int)blockIdx.x) lo = mid; else hi = mid;
+  }
+  const eamd_gemm_t p = tab[lo];         // wave-uniform: scalar loads
+  gemm_bf16_body<BM, BN, TA, TB, true, false, false>(p, (int)blockIdx.x - first[lo], first[lo + 1] - first[lo], 0);
+}
+
+template <int BM, int BN, bool TA, bool TB, bool FAST, bool GAT, bool ACT>
 int launch_b2(const eamd_gemm_t& p, hipStream_t stream) {
   dim3 grid(((p.M + BM - 1) / BM) * ((p.N + BN - 1) / BN) * p.splitk, 1, p.batch1 * p.batch2);
   size_t smem = sizeof(SmemB<BM, BN, TA, TB>);
@@ -524,4 +544,32 @@ int eamd_gemm_bf16_dispatch(const eamd_gemm_t& p, int tile, hipStream_t stream) 
   }
   if (a_ok && b_ok) return tile == 128 ? dispatch_layout<128, true>(p, stream) : dispatch_layout<64, true>(p, stream);
   return tile == 128 ? dispatch_layout<128, false>(p, stream) : dispatch_layout<64, false>(p, stream);
+}
+
+// ---- grouped weight-gradient launch (bf16 operands): see gemm_f32.hip ----
+int eamd_gemm_bf16_group_count(const eamd_gemm_t& p) {
+  if (p.in_dtype != 1 || !p.transA || !p.transB || !p.C || p.Cb || p.Hb || p.aux || p.R || p.bias) return EAMD_EUNSUPPORTED;
+  if (p.gather.enabled || p.cmap.enabled || p.epilogue || p.a_act || p.b_act || p.drop_p > 0.f || p.a_drop_p > 0.f ||
+      p.b_drop_p > 0.f || p.batch1 * p.batch2 != 1 || p.splitk < 1)
+    return EAMD_EUNSUPPORTED;
+  if (p.splitk == 1 && p.beta != 1.f) return EAMD_EUNSUPPORTED;          // accumulate into the gradient buffer
+  const bool a_ok = aligned16(p.A) && p.lda % 8 == 0 && p.lda >= (p.M + 7) / 8 * 8;
+  const bool b_ok = aligned16(p.B) && p.ldb % 8 == 0 && p.ldb >= (p.N + 7) / 8 * 8;
+  if (!a_ok || !b_ok) return EAMD_EUNSUPPORTED;
+  const long n = (long)((p.M + 63) / 64) * ((p.N + 63) / 64) * p.splitk;
+  return n < (1L << 24) ? (int)n : EAMD_EUNSUPPORTED;
+}
+
+int eamd_gemm_bf16_group_launch(const eamd_gemm_t* tab_dev, const int* first_dev, int n, int total, hipStream_t stream) {
+  const size_t smem = sizeof(SmemB<64, 64, true, true>);
+  if (smem > 64 * 1024) {
+    static const hipError_t attr_err = hipFuncSetAttribute(
+        reinterpret_cast<const void*>(&gemm_bf16_group_kernel<64, 64, true, true>),
+        hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+    if (attr_err != hipSuccess) return (int)attr_err;
+  }
+  hipLaunchKernelGGL((gemm_bf16_group_kernel<64, 64, true, true>), dim3((unsigned)total), dim3(NT_), smem, stream, tab_dev,
+                     first_dev, n);
+  EAMD_LAUNCH_CHECK();
+  return EAMD_OK;
 }

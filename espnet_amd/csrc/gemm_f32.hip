@@ -52,8 +52,10 @@ __device__ __forceinline__ float4 mask4(float4 v, int nv) {
   return make_float4(nv > 0 ? v.x : 0.f, nv > 1 ? v.y : 0.f, nv > 2 ? v.z : 0.f, nv > 3 ? v.w : 0.f);
 }
 
+// One workgroup's share of a problem: `bid` of `nblk` workgroups (tile x split-K slice), batch index `zb`.
+// gemm_f32_kernel runs it on a launch of its own; gemm_f32_group_kernel looks the problem up in a device table.
 template <int BM, int BN, bool TA, bool TB, bool GAT, bool ACT>
-__global__ __launch_bounds__(NT_, 2) void gemm_f32_kernel(const eamd_gemm_t p) {
+__device__ __forceinline__ void gemm_f32_body(const eamd_gemm_t& p, const int bid, const int nblk, const int zb) {
   constexpr int WM = BM / 2, WN = BN / 2;
   constexpr int MT = WM / 16, NTL = WN / 16;
   constexpr int NCA = BM / 32, NCB = BN / 32;           // 16-byte chunks per thread per tile
@@ -71,17 +73,16 @@ __global__ __launch_bounds__(NT_, 2) void gemm_f32_kernel(const eamd_gemm_t p) {
   const int tiles_n = (p.N + BN - 1) / BN;
   int tile_id, split;
   if (p.splitk > 1) {
-    split = blockIdx.x % p.splitk;
-    tile_id = blockIdx.x / p.splitk;
+    split = bid % p.splitk;
+    tile_id = bid / p.splitk;
   } else {
     split = 0;
-    const int ntile = gridDim.x;
-    const int id = blockIdx.x, q = ntile >> 3, r = ntile & 7, xcd = id & 7, j = id >> 3;
+    const int ntile = nblk;
+    const int id = bid, q = ntile >> 3, r = ntile & 7, xcd = id & 7, j = id >> 3;
     tile_id = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + j;
   }
   const int tile_m = tile_id / tiles_n, tile_n = tile_id % tiles_n;
   const int m0 = tile_m * BM, n0 = tile_n * BN;
-  const int zb = blockIdx.z;
   const int b1 = zb / p.batch2, b2 = zb % p.batch2;
   const float* __restrict__ A = p.A + b1 * p.sA1 + b2 * p.sA2;
   const float* __restrict__ B = p.B + b1 * p.sB1 + b2 * p.sB2;
@@ -487,6 +488,25 @@ __global__ __launch_bounds__(NT_, 2) void gemm_f32_kernel(const eamd_gemm_t p) {
 }
 
 template <int BM, int BN, bool TA, bool TB, bool GAT, bool ACT>
+__global__ __launch_bounds__(NT_, 2) void gemm_f32_kernel(const eamd_gemm_t p) {
+  gemm_f32_body<BM, BN, TA, TB, GAT, ACT>(p, blockIdx.x, gridDim.x, blockIdx.z);
+}
+
+// Grouped launch: workgroups first[i] .. first[i + 1] - 1 work on problem i of a device-resident descriptor table
+// (independent weight-gradient GEMMs dW_i += dY_i^T X_i of one backward pass, each too small to fill the chip).
+template <int BM, int BN, bool TA, bool TB>
+__global__ __launch_bounds__(NT_, 2) void gemm_f32_group_kernel(const eamd_gemm_t* __restrict__ tab,
+                                                                const int* __restrict__ first, const int n) {
+  int lo = 0, hi = n;                    // largest i with first[i] <= blockIdx.x
+  while (hi - lo > 1) {
+    const int mid = (lo + hi) >> 1;
+    if (first[mid] <= (int)blockIdx.x) lo = mid; else hi = mid;
+  }
+  const eamd_gemm_t p = tab[lo];         // wave-uniform: scalar loads
+  gemm_f32_body<BM, BN, TA, TB, false, false>(p, (int)blockIdx.x - first[lo], first[lo + 1] - first[lo], 0);
+}
+
+template <int BM, int BN, bool TA, bool TB, bool GAT, bool ACT>
 int launch_f2(const eamd_gemm_t& p, hipStream_t stream) {
   dim3 grid(((p.M + BM - 1) / BM) * ((p.N + BN - 1) / BN) * p.splitk, 1, p.batch1 * p.batch2);
   constexpr size_t smem = sizeof(SmemF<BM, BN, TA, TB>);
@@ -548,4 +568,36 @@ int eamd_gemm_f32_dispatch(const eamd_gemm_t& p, int tile, hipStream_t stream) {
   }
   if (!a_ok || !b_ok) return EAMD_EUNSUPPORTED;
   return tile == 128 ? dispatch_layout_f<128>(p, stream) : dispatch_layout_f<64>(p, stream);
+}
+
+// ---- grouped weight-gradient launch (fp32 operands) ----
+// plan: validates problem i for the grouped kernel (C += alpha A^T B with split-K atomics or beta = 1: transA, transB, no
+// epilogue / bias / residual / gather / row map / dropout, batch 1, operands meeting the staging conditions above) and
+// returns its workgroup count, or EAMD_EUNSUPPORTED.
+int eamd_gemm_f32_group_count(const eamd_gemm_t& p) {
+  if (p.in_dtype != 0 || p.precision != 0 || !p.transA || !p.transB || !p.C || p.Cb || p.Hb || p.aux || p.R || p.bias)
+    return EAMD_EUNSUPPORTED;
+  if (p.gather.enabled || p.cmap.enabled || p.epilogue || p.a_act || p.b_act || p.drop_p > 0.f || p.a_drop_p > 0.f ||
+      p.b_drop_p > 0.f || p.batch1 * p.batch2 != 1 || p.splitk < 1)
+    return EAMD_EUNSUPPORTED;
+  if (p.splitk == 1 && p.beta != 1.f) return EAMD_EUNSUPPORTED;          // accumulate into the gradient buffer
+  const bool a_ok = aligned16f(p.A) && p.lda % 4 == 0 && p.lda >= (p.M + 3) / 4 * 4;
+  const bool b_ok = aligned16f(p.B) && p.ldb % 4 == 0 && p.ldb >= (p.N + 3) / 4 * 4;
+  if (!a_ok || !b_ok) return EAMD_EUNSUPPORTED;
+  const long n = (long)((p.M + 63) / 64) * ((p.N + 63) / 64) * p.splitk;
+  return n < (1L << 24) ? (int)n : EAMD_EUNSUPPORTED;
+}
+
+int eamd_gemm_f32_group_launch(const eamd_gemm_t* tab_dev, const int* first_dev, int n, int total, hipStream_t stream) {
+  constexpr size_t smem = sizeof(SmemF<64, 64, true, true>);
+  if (smem > 64 * 1024) {
+    static const hipError_t attr_err = hipFuncSetAttribute(
+        reinterpret_cast<const void*>(&gemm_f32_group_kernel<64, 64, true, true>),
+        hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+    if (attr_err != hipSuccess) return (int)attr_err;
+  }
+  hipLaunchKernelGGL((gemm_f32_group_kernel<64, 64, true, true>), dim3((unsigned)total), dim3(NT_), smem, stream, tab_dev,
+                     first_dev, n);
+  EAMD_LAUNCH_CHECK();
+  return EAMD_OK;
 }

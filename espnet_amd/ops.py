@@ -4,6 +4,7 @@ No arithmetic happens here: every function validates shapes on the host (a fault
 take the whole GPU node down), fills the argument struct and launches on torch's current stream.
 """
 import ctypes as C
+import os
 import math
 
 import torch
@@ -114,9 +115,11 @@ _gemm_record = None
 def gemm(A, B, Cm, M, N, K, lda, ldb, ldc, *, transA=0, transB=0, bias=None, aux=None, ldaux=0, R=None,
          ldr=0, batch=(1, 1), sA=(0, 0), sB=(0, 0), sC=(0, 0), alpha=1.0, beta=0.0, a_act=0, b_act=0,
          epilogue=0, splitk=1, tile=0, gather=None, cmap=None, a_off=0, b_off=0, c_off=0, precision=None,
-         colsum=None, Cb=None, drop=None, Hb=None, h_act=0, a_drop=None, b_drop=None):
+         colsum=None, Cb=None, drop=None, Hb=None, h_act=0, a_drop=None, b_drop=None, group=False):
     """A, B: both float32 or both bfloat16 (bf16 operands select the fast MFMA kernel).
-    Cm: float32 result, or bfloat16 result (then no fp32 copy is written); Cb: extra bf16 copy."""
+    Cm: float32 result, or bfloat16 result (then no fp32 copy is written); Cb: extra bf16 copy.
+    group=True (weight gradients): while wgrad_group_begin() is in effect the launch is queued and leaves with all other
+    queued ones as ONE grouped launch at wgrad_join() (eamd_gemm_group_*), if the library accepts it for that."""
     bf = A.dtype == torch.bfloat16
     if A.dtype != B.dtype or A.dtype not in (torch.float32, torch.bfloat16) or not (A.is_cuda and B.is_cuda):
         raise _lib.EamdError("gemm needs float32 or bfloat16 GPU operands of one dtype")
@@ -191,10 +194,101 @@ def gemm(A, B, Cm, M, N, K, lda, ldb, ldc, *, transA=0, transB=0, bias=None, aux
             setattr(p, which + "_drop_p", float(d[0]))
             setattr(p, which + "_drop_salt", int(d[1]))
             p.drop_step = ptr(rng_state(A.device))
+    if group and _wgroup["on"] and Cm.untyped_storage().data_ptr() in _wgroup["arenas"] and _wgroup_accepts(p):
+        _wgroup["items"].append((p, (A, B, Cm, colsum)))
+        return
     if _gemm_record is not None:
         _gemm_record.append((p, (A, B, Cm, bias, aux, R, colsum, Cb, Hb),
                              lambda sp, p=p: check(_lib.lib().eamd_gemm(C.byref(p), sp), "eamd_gemm")))
     check(_lib.lib().eamd_gemm(C.byref(p), stream_ptr()), "eamd_gemm")
+
+
+# ---- grouped weight-gradient launches ------------------------------------------------------------
+# dW = dY^T X of a small layer (256 x 256 ... 768 x 256 outputs) is 16-48 tiles: even with split-K such a launch runs
+# at a quarter of what the chip can do and costs a launch slot.  Nothing in backward reads dW, so between
+# wgrad_group_begin() and wgrad_join() every eligible one is queued (operands kept alive) and all of them leave as ONE
+# launch whose workgroups look their problem up in a device table (eamd_gemm_group_plan / eamd_gemm_group_launch).
+GROUP_WGRAD = True            # tests flip this to reach the one-launch-per-GEMM path
+GROUP_WGRAD_MAX_TILES = int(os.environ.get("EAMD_GROUP_MAX_TILES", "384"))    # 64x64 output tiles: larger weight gradients fill the chip on their own
+# measured at config 2 (tools/group_sweep.sh): grouping everything up to 384 output tiles (all but the vocabulary-sized
+# gradients) with half the stand-alone split count is best in both precisions - 34.09 ms fp32 / 14.20 ms bf16 against
+# 35.0 / 15.04 ungrouped; the queue supplies the parallelism the extra splits (and their atomics) bought before
+GROUP_WGRAD_SK_DIV = int(os.environ.get("EAMD_GROUP_SK_DIV", "2"))
+_wgroup = {"on": False, "items": [], "pinned": [], "reserve": [], "arenas": set()}
+
+
+def register_grad_arena(t):
+    """only GEMMs that accumulate into a registered gradient arena (espnet_amd.train.FlatParams.grad) are queued: a
+    temporary result (tap-major weight gradients that are permuted into the arena next, gradients handed back to
+    autograd) is read by its consumer long before the grouped launch runs"""
+    _wgroup["arenas"].add(t.untyped_storage().data_ptr())
+
+
+def wgrad_group_begin():
+    _wgroup["on"] = GROUP_WGRAD
+
+
+def _wgroup_accepts(p):
+    if ((p.M + 63) // 64) * ((p.N + 63) // 64) > GROUP_WGRAD_MAX_TILES:
+        return False
+    first = (C.c_int32 * 2)()
+    return _lib.lib().eamd_gemm_group_plan(C.byref(p), 1, first) > 0
+
+
+def _wgroup_staging(nbytes):
+    """pinned host buffer for one descriptor table.  A captured graph copies from its buffer again at every replay, so
+    a capture takes a buffer for good out of a small reserve that eager flushes (every capture is preceded by eager
+    warm-up steps) keep topped up - pinned memory cannot be allocated while a stream is capturing."""
+    if torch.cuda.is_current_stream_capturing():
+        for i, h in enumerate(_wgroup["reserve"]):
+            if h.numel() >= nbytes:
+                _wgroup["pinned"].append(_wgroup["reserve"].pop(i))
+                return _wgroup["pinned"][-1][:nbytes]
+        return None
+    want = (nbytes + 4095) // 4096 * 4096 * 2
+    _wgroup["reserve"] = [h for h in _wgroup["reserve"] if h.numel() >= want]
+    while len(_wgroup["reserve"]) < 8:
+        _wgroup["reserve"].append(torch.empty(want, dtype=torch.uint8, pin_memory=True))
+    return torch.empty(nbytes, dtype=torch.uint8, pin_memory=True)
+
+
+def wgrad_group_flush():
+    """launch everything queued so far (one grouped launch; a single queued GEMM goes out on its own)"""
+    items = _wgroup["items"]
+    if not items:
+        return
+    _wgroup["items"] = []
+    L = _lib.lib()
+    if len(items) == 1:
+        p = items[0][0]
+        if _gemm_record is not None:
+            _gemm_record.append((p, items[0][1], lambda sp, p=p: check(L.eamd_gemm(C.byref(p), sp), "eamd_gemm")))
+        check(L.eamd_gemm(C.byref(p), stream_ptr()), "eamd_gemm")
+        return
+    n = len(items)
+    dev = items[0][1][0].device
+    arr = (GemmT * n)(*[it[0] for it in items])
+    first = (C.c_int32 * (n + 1))()
+    total = L.eamd_gemm_group_plan(arr, n, first)
+    check(min(total, 0), "eamd_gemm_group_plan")
+    nb_desc, nb_first = C.sizeof(arr), C.sizeof(first)
+    host = _wgroup_staging(nb_desc + nb_first)
+    if host is None:          # capturing with no staging buffer in reserve: one launch per GEMM
+        for p, keep in items:
+            if _gemm_record is not None:
+                _gemm_record.append((p, keep, lambda sp, p=p: check(L.eamd_gemm(C.byref(p), sp), "eamd_gemm")))
+            check(L.eamd_gemm(C.byref(p), stream_ptr()), "eamd_gemm")
+        return
+    C.memmove(host.data_ptr(), arr, nb_desc)
+    C.memmove(host.data_ptr() + nb_desc, first, nb_first)
+    tab = torch.empty(nb_desc + nb_first, dtype=torch.uint8, device=dev)
+    tab.copy_(host, non_blocking=True)
+    in_dtype = int(arr[0].in_dtype)
+    args = (ptr(tab), ptr(tab, nb_desc), n, total, in_dtype)
+    check(L.eamd_gemm_group_launch(*args, stream_ptr()), "eamd_gemm_group_launch")
+    if _gemm_record is not None:
+        _gemm_record.append((None, (tab, [it[1] for it in items]),
+                             lambda sp, args=args: check(L.eamd_gemm_group_launch(*args, sp), "eamd_gemm_group_launch")))
 
 
 def cast_bf16(x, out=None):
@@ -262,8 +356,14 @@ def enable_wgrad_stream(enable=True):
     _wgrad["used"] = False
 
 
+def wgrad_group_end():
+    wgrad_group_flush()
+    _wgroup["on"] = False
+
+
 def wgrad_join():
-    """make the current stream wait for all weight-gradient work issued so far"""
+    """launch the queued weight-gradient GEMMs and make the current stream wait for all weight-gradient work issued so far"""
+    wgrad_group_flush()
     st = _wgrad["stream"]
     if st is not None and _wgrad["used"]:
         torch.cuda.current_stream().wait_stream(st)
@@ -291,8 +391,10 @@ def _linear_bwd_w(dy, x, dW, *, alpha=1.0, b_act=ACT_NONE, db=None, a_drop=None,
     K = x.shape[1]
     assert x.shape[0] == M and dW.numel() == N * K and dW.dtype == torch.float32
     sk = auto_splitk(N, K, M)
+    if _wgroup["on"] and _wgrad["stream"] is None and ((N + 63) // 64) * ((K + 63) // 64) <= GROUP_WGRAD_MAX_TILES:
+        sk = max(1, sk // GROUP_WGRAD_SK_DIV)
     gemm(dy, x, dW, N, K, M, N, K, K, transA=1, transB=1, alpha=alpha, b_act=b_act, splitk=sk,
-         beta=1.0 if sk == 1 else 0.0, colsum=db, a_drop=a_drop, b_drop=b_drop)
+         beta=1.0 if sk == 1 else 0.0, colsum=db, a_drop=a_drop, b_drop=b_drop, group=_wgrad["stream"] is None)
 
 
 def colsum(x, out, scale=1.0, rows=None, D=None, ld=None):

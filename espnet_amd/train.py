@@ -37,6 +37,8 @@ class FlatParams:
         self.offsets = offs
         self.data = torch.zeros(self.numel, device=dev, dtype=torch.float32)
         self.grad = torch.zeros(self.numel, device=dev, dtype=torch.float32)
+        if dev.type == "cuda":
+            ops.register_grad_arena(self.grad)      # weight-gradient GEMMs into this arena may be grouped (ops.wgrad_group_begin)
         # bf16 shadow of every weight for the bf16-operand GEMMs; kept current by the Adam kernel
         self.shadow = torch.zeros(self.numel, device=dev, dtype=torch.bfloat16) if dev.type == "cuda" else None
         for p, o in zip(params, offs):
@@ -259,7 +261,11 @@ def train_step(model, flat, opt, batch, reducer=None, loss_scale=1.0):
         reducer.begin()
     loss = model.forward_core(batch) if isinstance(batch, dict) else model(*batch)
     scale = loss_scale / (reducer.world if reducer is not None else 1)
-    loss.backward(torch.full((), scale, device=loss.device, dtype=loss.dtype) if scale != 1.0 else None)
+    ops.wgrad_group_begin()      # small weight-gradient GEMMs of this backward pass leave as one grouped launch
+    try:
+        loss.backward(torch.full((), scale, device=loss.device, dtype=loss.dtype) if scale != 1.0 else None)
+    finally:
+        ops.wgrad_group_end()
     ops.wgrad_join()
     if reducer is not None:
         reducer.finish()
@@ -384,11 +390,19 @@ class GraphedDataParallelStep:
             if self._stack is not None and len(self.cuts) != len(self.ranges) - 1:
                 raise RuntimeError("phased backward expects %d gradient cuts, found %d" % (len(self.ranges) - 1, len(self.cuts)))
             scale = 1.0 / self.world
-            loss.backward(torch.full((), scale, device=loss.device, dtype=loss.dtype) if scale != 1.0 else None)
+            ops.wgrad_group_begin()      # one grouped launch of the small weight-gradient GEMMs per phase
+            try:
+                loss.backward(torch.full((), scale, device=loss.device, dtype=loss.dtype) if scale != 1.0 else None)
+            finally:
+                ops.wgrad_group_end()
             ops.wgrad_join()
             return loss
         upstream, leaf = self.cuts[len(self.cuts) - k]       # phase 1 resumes behind the encoder, the next ones lower in the stack
-        upstream.backward(leaf.grad)
+        ops.wgrad_group_begin()
+        try:
+            upstream.backward(leaf.grad)
+        finally:
+            ops.wgrad_group_end()
         ops.wgrad_join()
         return None
 
@@ -627,7 +641,11 @@ class EpochRunner:
             if train:
                 self.pre_step()
                 loss, stats, _w = self.forward(batch)
-                self.backward(loss, torch.full((), w / (wsum * self.accum_grad), device=dev, dtype=loss.dtype))
+                ops.wgrad_group_begin()
+                try:
+                    self.backward(loss, torch.full((), w / (wsum * self.accum_grad), device=dev, dtype=loss.dtype))
+                finally:
+                    ops.wgrad_group_end()
                 ops.wgrad_join()
             else:
                 with torch.no_grad():

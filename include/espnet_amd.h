@@ -106,6 +106,17 @@ typedef struct {
 
 int eamd_gemm(const eamd_gemm_t* p, void* stream);
 
+/* Grouped launch of independent weight-gradient GEMMs (the dW_i += alpha dY_i^T X_i of one backward pass - reference:
+ * the autograd of every nn.Linear on the path, e.g. transformer/attention.py:30-33 - each too small to fill the chip on
+ * its own): ONE kernel whose workgroups look their problem up in a device-resident table.
+ * eamd_gemm_group_plan validates n HOST descriptors (all of one in_dtype / precision; transA = transB = 1, batch 1, no
+ * bias / residual / aux / epilogue / gather / row map / dropout; split-K accumulating with atomics, or splitk = 1 with
+ * beta = 1; colsum allowed; operands meeting the 16-byte staging conditions of eamd_gemm's fast kernels), writes the
+ * first workgroup of every problem into first[0..n] and returns the total workgroup count, or EAMD_EUNSUPPORTED / EAMD_EINVAL.
+ * The caller copies the descriptors and `first` to the device (stream-ordered) and calls eamd_gemm_group_launch. */
+int eamd_gemm_group_plan(const eamd_gemm_t* descs, int n, int32_t* first);
+int eamd_gemm_group_launch(const eamd_gemm_t* descs_dev, const int32_t* first_dev, int n, int total, int in_dtype, void* stream);
+
 /* ------------------------------------------------------------------------------------------
  * Row kernels (HBM-bound).
  * ------------------------------------------------------------------------------------------ */

@@ -1336,6 +1336,60 @@ def test_shared_stack_projections_match_per_layer(prec):
     report("shared vs per-layer projections (%s): gradient arena" % prec, res[0][1], res[1][1], 2e-5 if prec == "fp32" else 2e-2)
 
 
+@pytest.mark.parametrize("prec", ["fp32", "bf16"])
+def test_grouped_weight_gradients_match_separate_launches(prec):
+    """train_step queues the small weight-gradient GEMMs of backward and launches them as ONE grouped kernel
+    (eamd_gemm_group_plan / eamd_gemm_group_launch: workgroups look their problem up in a device table) - against one
+    launch per GEMM: same loss, same gradient arena, same parameters after the optimizer step; eager and under
+    hipGraph capture + two replays (the table copy is part of the graph)"""
+    import espnet_amd
+    from espnet_amd import ops, train
+    from conftest import e2e_dk64_model
+    g = load_golden("e2e_conformer_dk64.npz")
+    xs, ilens, ys = torch.from_numpy(g["xs"]).to(DEV), torch.from_numpy(g["ilens"]), torch.from_numpy(g["ys"]).to(DEV)
+    espnet_amd.set_precision(prec)
+    out = {}
+    try:
+        for grouped in (True, False):
+            ops.GROUP_WGRAD = grouped
+            model, _cfg = e2e_dk64_model(dropout=0.0)
+            model = model.to(DEV).train()
+            flat = train.FlatParams(model)
+            opt = train.NoamAdam(flat, mode="noam", factor=1.0, model_size=256, warmup=100, max_grad_norm=5.0)
+            batch = model.prepare(xs, ilens, ys)
+            rec = []
+            ops._gemm_record = rec
+            loss = train.train_step(model, flat, opt, batch)
+            ops._gemm_record = None
+            res = dict(loss=float(loss), grad=flat.grad.clone(), launches=len(rec),
+                       grouped=sum(1 for r in rec if r[0] is None and isinstance(r[1][1], list)))
+            train.train_step(model, flat, opt, batch)                      # warm-up for the capture
+            torch.cuda.synchronize()
+            gr = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(gr):
+                lg = train.train_step(model, flat, opt, batch)
+            gr.replay()
+            gr.replay()
+            torch.cuda.synchronize()
+            res["loss_graph"], res["data"] = float(lg), flat.data.clone()
+            out[grouped] = res
+    finally:
+        ops._gemm_record = None
+        ops.GROUP_WGRAD = True
+        espnet_amd.set_precision("fp32")
+    a, b = out[True], out[False]
+    print(f"[launches] contraction launches per step: grouped {a['launches']} (grouped launches: {a['grouped']}), separate {b['launches']}")
+    assert a["grouped"] >= 1 and b["grouped"] == 0 and a["launches"] < b["launches"]
+    tol = 1e-6 if prec == "fp32" else 1e-3
+    assert abs(a["loss"] - b["loss"]) <= tol * abs(b["loss"])
+    assert abs(a["loss_graph"] - b["loss_graph"]) <= tol * abs(b["loss_graph"])
+    report("grouped vs separate weight gradients (%s): gradient arena" % prec, a["grad"], b["grad"], 2e-5 if prec == "fp32" else 5e-3)
+    # parameters: the depthwise-conv biases in front of a training-mode BatchNorm have a mathematically zero gradient;
+    # what is left is summation-order noise (1e-7), which Adam normalises into +-lr steps - hence 2e-4, not 1e-6
+    report("grouped vs separate (%s): parameters after 4 steps (2 eager + graph replays)" % prec, a["data"], b["data"],
+           2e-4 if prec == "fp32" else 1e-3)
+
+
 def test_bucketed_graph_step_matches_eager():
     """a stream of batches of two different shapes through train.BucketedGraphStep (eager on first sight, capture on
     the second, replay afterwards) against plain eager steps on the same padded batches with an identical second model:
