@@ -25,9 +25,14 @@ def run(name, model, xs, ilens, ys, steps=3, graph=True):
     times = []
 
     def step():
+        from espnet_amd import ops
         flat.zero_grad()
         loss = model(xs, ilens, ys)
-        loss.backward()
+        ops.wgrad_group_begin()         # small weight-gradient GEMMs (one per LSTM time step ...) leave as one grouped launch
+        try:
+            loss.backward()
+        finally:
+            ops.wgrad_group_end()
         return loss
 
     side = torch.cuda.Stream()
