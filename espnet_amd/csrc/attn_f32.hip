@@ -4,23 +4,28 @@
 // reference: transformer/attention.py:63-114 (forward_attention / MultiHeadedAttention.forward),
 //            attention.py:141-206 (RelPositionMultiHeadedAttention: rel_shift, (ac + bd) / sqrt(d_k)).
 //
-// One workgroup = one (batch, head) pair x 64 queries; wave w owns 16 queries and ALL keys, so a softmax row never
-// leaves its wave.  Everything is computed in the transposed orientation S^T = K Q^T:
-//   * a 16x16x4 MFMA takes ONE float per lane per operand: lane (fr = lane & 15, fq = lane >> 4) supplies element
-//     (row fr, reduction index fq).  The order of the 64-channel contraction is free, so lane (fr, fq) takes the four
-//     16-byte chunks {4 j + fq} of row fr - four global loads of which each covers whole 64-byte segments - and MFMA
-//     (j, e) contracts channels 16 j + 4 fq + e.  K, q, positional and (q+v) fragments go straight from global memory
-//     into MFMA operands: no operand staging, no barriers in the score phase;
-//   * the accumulator of key tile t then holds, for query fr, the keys 16 t + 4 fq + {0..3}: four ADJACENT
-//     probabilities per lane (16-byte stores into P), and each of them IS the operand of the context product
-//     C^T = V^T P^T for the contraction step "keys 16 t + 4 fq + r, fq = 0..3".  V comes from a panel staged once per
-//     workgroup ([key][68] floats: the four fq groups of a ds_read_b32 fall into disjoint banks);
-//   * C^T leaves four adjacent channels per lane (16-byte stores).
-// The legacy rel_shift is a flat re-indexing of bd = (q+v) p^T padded with a zero column: shifted[i][j] =
-// pad_flat[T1 + i T2 + j] over rows of T2 + 1, i.e. query i reads rows i and i + 1 of bd.  The workgroup builds the
-// image of its 65 rows in LDS: each wave the 16 rows of its queries on the matrix cores, row 64 (first query of the
-// next workgroup) as 64-term dot products on the VALU - an MFMA tile for one row would double the bd work.  After the
-// softmax the image is dead and the V panel is staged over it.
+// One workgroup = one (batch, head) pair x 64 queries, four waves.  Two work splits are used:
+//   * SCORE phases (ac = q k^T, bd = (q+v) p^T; dP = dctx v^T in the backward) - wave w takes a quarter of the KEYS
+//     (positions) and ALL 64 queries.  A 16x16x4 MFMA takes ONE float per lane per operand and the order of the
+//     64-channel contraction is free, so lane (fr = lane & 15, fq = lane >> 4) takes the four 16-byte chunks
+//     {4 j + fq} of row fr straight from global memory into MFMA operands: no operand staging.  Such row-strided
+//     fragment loads are the slow part of the kernel (16 cache lines per instruction), which is why the split is by
+//     keys: every K / position row is fetched by exactly one wave of the workgroup, the 64 query rows once per wave
+//     (measured: 63 -> see DESIGN for the variant in which every wave fetched all keys for its own 16 queries).
+//     The tiles S^T[key][query] land in an LDS score matrix X[query][key] (16-byte stores: an accumulator holds four
+//     adjacent keys of one query);
+//   * the legacy rel_shift is a flat re-indexing of bd padded with a zero column: shifted[i][j] = bd[i][T-1-i+j] for
+//     j <= i, 0 for j = i+1, bd[i+1][j-i-2] above.  It is one-to-one, so the bd tiles are STORED into X at their
+//     shifted place first (plain 4-byte LDS stores, one owner per element; as ds_add_f32 atomics on top of the ac
+//     tiles the same scatter cost 29 us of a 76 us kernel) and the ac tiles are then added by read-modify-write of
+//     16-byte rows behind a barrier.  bd row r0 + 64 (first query of the next workgroup) feeds query r0 + 63:
+//     64-term dot products on the VALU, one position per thread;
+//   * SOFTMAX and the products with P - wave w owns queries 16 w .. 16 w + 15 and all keys, so a softmax row never
+//     leaves its wave: it reads its X rows back in the accumulator layout (lane = query fr, keys 16 t + 4 fq + {0..3}),
+//     and each probability IS the operand of the context product C^T = V^T P^T for the contraction step
+//     "keys 16 t + 4 fq + r, fq = 0..3".  V comes from a panel staged over X once the scores are in registers
+//     ([key][68] floats: the four fq groups of a ds_read_b32 fall into disjoint banks; its global loads are issued
+//     before the softmax).  C^T leaves four adjacent channels per lane (16-byte stores).
 #include "common.h"
 
 namespace {
@@ -64,16 +69,19 @@ __device__ __forceinline__ f32x4 dot_tile(const float4 (&x)[4], const float4 (&y
   return c;
 }
 
-// panel [16 NKT rows][64 channels] of one (batch, head) -> LDS, rows past `rows` zeroed
+// panel [16 NKT rows][64 channels] of one (batch, head): global -> registers (rows past `rows` zeroed) ...
 template <int NKT>
-__device__ __forceinline__ void stage_panel(const float* src, long ld, int rows, float* dst, int t) {
-  float4 r[NKT];
+__device__ __forceinline__ void panel_load(const float* src, long ld, int rows, int t, float4 (&r)[NKT]) {
 #pragma unroll
   for (int q = 0; q < NKT; ++q) {
     const int c = t + 256 * q, row = c >> 4, c4 = c & 15;
     r[q] = *reinterpret_cast<const float4*>(src + (long)min(row, rows - 1) * ld + c4 * 4);
     if (row >= rows) r[q] = make_float4(0.f, 0.f, 0.f, 0.f);
   }
+}
+// ... -> LDS
+template <int NKT>
+__device__ __forceinline__ void panel_store(const float4 (&r)[NKT], float* dst, int t) {
 #pragma unroll
   for (int q = 0; q < NKT; ++q) {
     const int c = t + 256 * q, row = c >> 4, c4 = c & 15;
@@ -94,11 +102,41 @@ __device__ __forceinline__ void panel_product(const float* panel, const f32x4 (&
     }
 }
 
+// X[query][key] = (rows of `keys`) . (rows of `qs`)^T for this wave's quarter of the key tiles and all 64 queries.
+// keys: first key row of the (batch, head), T2 rows; qs: first query row of the workgroup, rows clamped to nq - 1.
+template <int NKT, bool ACC>
+__device__ __forceinline__ void score_tiles(const float* keys, long ldk, int T2, const float* qs, long ldq, int nq,
+                                            float* X, int XLD, int wave, int fr, int fq) {
+  constexpr int TPW = NKT / 4;
+  float4 qf[4][4];
+#pragma unroll
+  for (int qt = 0; qt < 4; ++qt) load_frag(qs + (long)min(qt * 16 + fr, nq - 1) * ldq, fq, qf[qt]);
+#pragma unroll
+  for (int u = 0; u < TPW; ++u) {
+    const int kt = wave * TPW + u;
+    float4 kf[4];
+    load_frag(keys + (long)min(kt * 16 + fr, T2 - 1) * ldk, fq, kf);
+#pragma unroll
+    for (int qt = 0; qt < 4; ++qt) {
+      f32x4 c = (f32x4){0.f, 0.f, 0.f, 0.f};
+      float4* xp = reinterpret_cast<float4*>(&X[(qt * 16 + fr) * XLD + kt * 16 + 4 * fq]);
+      if (ACC) {                      // on top of what is there (one owner per element: plain read-modify-write)
+        const float4 o = *xp;
+        c = (f32x4){o.x, o.y, o.z, o.w};
+      }
+      c = dot_tile(kf, qf[qt], c);    // c[r]: key 16 kt + 4 fq + r, query 16 qt + fr
+      *xp = make_float4(c[0], c[1], c[2], c[3]);
+    }
+  }
+}
+
 // NKT = key tiles of 16 the instantiation covers (T2 <= 16 NKT).  Loops over tiles are fully unrolled and free of
-// branches: rows past T2 are clamped re-reads whose scores are masked, so the fragment loads of a phase overlap.
+// branches: rows past T2 / T1 are clamped re-reads whose scores are masked / never stored.
 template <bool REL, int NKT>
 __global__ __launch_bounds__(256, 2) void attn_f32_fwd_kernel(const AttnF32Args a) {
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+  constexpr int XLD = NKT * 16 + 4;
+  constexpr int TPW = NKT / 4;
   const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
   const int fr = lane & 15, fq = lane >> 4;
   // (batch, head) pairs are dealt to the XCDs in contiguous runs: the query blocks of one pair share an L2
@@ -107,35 +145,44 @@ __global__ __launch_bounds__(256, 2) void attn_f32_fwd_kernel(const AttnF32Args 
   const bool live = z < a.B * a.H;                 // whole workgroup; dead ones only keep the barriers company
   const int zz = live ? z : 0;
   const int h = zz / a.B, b = zz % a.B;
-  const int r0w = (jb % a.nqb) * 64;               // first query of the workgroup
-  const int r0 = r0w + wave * 16;                  // ... of this wave
-  const bool active = live && r0 < a.T1;
   const int T1 = a.T1, T2 = a.T2;
+  const int r0w = min((jb % a.nqb) * 64, T1 - 1);  // first query of the workgroup
+  const int nq = T1 - r0w;                         // its queries (up to 64)
+  const int r0 = r0w + wave * 16;                  // first query this wave owns in the softmax / context phases
+  const bool active = live && r0 < T1;
   const int qi = min(r0 + fr, T1 - 1);             // this lane's query (clamped lanes are never stored)
-  const int W = T2 + 1;
 
-  float* pad = reinterpret_cast<float*>(smem_raw);  // rows r0w .. r0w + 64 of [bd | zero column in front]
+  float* X = reinterpret_cast<float*>(smem_raw);
   if (REL) {
-    if (active) {
-      float4 qf[4];
-      load_frag(a.qv + ((long)b * T1 + qi) * a.ldqv + h * ATT_DK, fq, qf);
-      float* prow = pad + (wave * 16 + fr) * W;
-      if (fq == 0) prow[0] = 0.f;
+    // ---- bd, stored at its rel-shifted place: bd[i][m] -> (i, m - (T-1-i)) if m >= T-1-i, else (i - 1, m + i + 1).
+    // The map is one-to-one; the only elements of a row it never reaches are (i, i + 1) - zeroed here - and, for the
+    // last query of the workgroup, the part fed by bd row r0w + 64 (the dot products below) ----
+    float4 qf[4][4];
+    const float* qs = a.qv + ((long)b * T1 + r0w) * a.ldqv + h * ATT_DK;
 #pragma unroll
-      for (int mt = 0; mt < NKT; ++mt) {
-        float4 pf[4];
-        load_frag(a.pos + (long)min(mt * 16 + fr, T2 - 1) * a.ldpos + h * ATT_DK, fq, pf);
-        const f32x4 c = dot_tile(pf, qf, (f32x4){0.f, 0.f, 0.f, 0.f});
-        // c[r] = bd[query r0 + fr][m = 16 mt + 4 fq + r]
+    for (int qt = 0; qt < 4; ++qt) load_frag(qs + (long)min(qt * 16 + fr, nq - 1) * a.ldqv, fq, qf[qt]);
+    if (t < 64 && r0w + t + 1 < T2) X[t * XLD + r0w + t + 1] = 0.f;
+#pragma unroll
+    for (int u = 0; u < TPW; ++u) {
+      const int mt = wave * TPW + u;
+      float4 pf[4];
+      load_frag(a.pos + (long)min(mt * 16 + fr, T2 - 1) * a.ldpos + h * ATT_DK, fq, pf);
+#pragma unroll
+      for (int qt = 0; qt < 4; ++qt) {
+        const f32x4 c = dot_tile(pf, qf[qt], (f32x4){0.f, 0.f, 0.f, 0.f});   // c[r] = bd[query 16 qt + fr][m = 16 mt + 4 fq + r]
+        const int ql = qt * 16 + fr, i = r0w + ql;
+        const int lim = T2 - 1 - i;
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-          const int m = mt * 16 + fq * 4 + r;
-          if (m < T2) prow[1 + m] = c[r];
+          const int m = mt * 16 + 4 * fq + r;
+          const int row = m >= lim ? ql : ql - 1, j = m >= lim ? m - lim : m + i + 1;
+          if (m < T2 && ql < nq && row >= 0) X[row * XLD + j] = c[r];
         }
       }
     }
-    if (live && r0w + 64 < T1 && t < T2) {          // row 64: one position per thread
-      const float4* qr = reinterpret_cast<const float4*>(a.qv + ((long)b * T1 + r0w + 64) * a.ldqv + h * ATT_DK);
+    const int i64 = r0w + 64;                        // first query of the next workgroup: its low positions feed query r0w + 63
+    if (live && i64 < T1 && t <= T2 - 2 - i64) {
+      const float4* qr = reinterpret_cast<const float4*>(a.qv + ((long)b * T1 + i64) * a.ldqv + h * ATT_DK);
       const float4* pr = reinterpret_cast<const float4*>(a.pos + (long)t * a.ldpos + h * ATT_DK);
       float s = 0.f;
 #pragma unroll
@@ -143,30 +190,20 @@ __global__ __launch_bounds__(256, 2) void attn_f32_fwd_kernel(const AttnF32Args 
         const float4 x = qr[j], y = pr[j];
         s += x.x * y.x + x.y * y.y + x.z * y.z + x.w * y.w;
       }
-      pad[64 * W + 1 + t] = s;
-      if (t == 0) pad[64 * W] = 0.f;
+      X[63 * XLD + t + i64 + 1] = s;
     }
+    __syncthreads();
   }
+  // ---- ac: X[q][j] (+)= qu_q . k_j ----
+  score_tiles<NKT, REL>(a.k + (long)b * T2 * a.ldk + h * ATT_DK, a.ldk, T2, a.qu + ((long)b * T1 + r0w) * a.ldq + h * ATT_DK,
+                        a.ldq, nq, X, XLD, wave, fr, fq);
+  // V panel: global loads now, LDS stores once the scores have left X
+  float4 vreg[NKT];
+  panel_load<NKT>(a.v + (long)b * T2 * a.ldv + h * ATT_DK, a.ldv, live ? T2 : 1, t, vreg);
+  __syncthreads();                                  // X is complete
+  // ---- scale, mask, softmax over the keys of query (r0 + fr) ----
   f32x4 S[NKT];
-#pragma unroll
-  for (int kt = 0; kt < NKT; ++kt) S[kt] = (f32x4){0.f, 0.f, 0.f, 0.f};
   if (active) {
-    // ---- ac^T tiles: rows = keys, columns = this wave's 16 queries ----
-    float4 qf[4];
-    load_frag(a.qu + ((long)b * T1 + qi) * a.ldq + h * ATT_DK, fq, qf);
-#pragma unroll
-    for (int kt = 0; kt < NKT; ++kt) {
-      float4 kf[4];
-      load_frag(a.k + ((long)b * T2 + min(kt * 16 + fr, T2 - 1)) * a.ldk + h * ATT_DK, fq, kf);
-      S[kt] = dot_tile(kf, qf, S[kt]);
-    }
-  }
-  if (REL) __syncthreads();                         // the image is complete (row r0 + 16 belongs to the next wave)
-  // ---- scale, rel-shift term, mask, softmax over the keys of query (r0 + fr) ----
-  if (active) {
-    // image index of (query i, key j): T1 + i T2 + j - r0w (T2 + 1); lanes past T1 are clamped into the image
-    const int pmax = 65 * W - 1;
-    const int pbase = T1 + (r0 + fr) * T2 - r0w * W;
     // mask bytes of this lane's keys: unconditional clamped loads, all in flight together; keys past T2 are masked
     // by index below
     unsigned mk[NKT];
@@ -183,17 +220,17 @@ __global__ __launch_bounds__(256, 2) void attn_f32_fwd_kernel(const AttnF32Args 
 #pragma unroll
       for (int kt = 0; kt < NKT; ++kt) mk[kt] = 0x01010101u;
     }
+    const float* xrow = &X[(wave * 16 + fr) * XLD + 4 * fq];
     float mx = -INFINITY;
 #pragma unroll
     for (int kt = 0; kt < NKT; ++kt) {
       const int j0 = kt * 16 + fq * 4;
+      const float4 xv = *reinterpret_cast<const float4*>(xrow + kt * 16);
+      const float xs[4] = {xv.x, xv.y, xv.z, xv.w};
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
-        const int j = j0 + r;
-        float x = S[kt][r];
-        if (REL) x += pad[min(pbase + j, pmax)];
-        x *= a.scale;
-        if (j >= T2 || ((mk[kt] >> (8 * r)) & 0xffu) == 0u) x = -INFINITY;
+        float x = xs[r] * a.scale;
+        if (j0 + r >= T2 || ((mk[kt] >> (8 * r)) & 0xffu) == 0u) x = -INFINITY;
         S[kt][r] = x;
         mx = fmaxf(mx, x);
       }
@@ -220,10 +257,13 @@ __global__ __launch_bounds__(256, 2) void attn_f32_fwd_kernel(const AttnF32Args 
       if (qok && j0 < a.ldp)                         // pad columns receive zeros
         *reinterpret_cast<float4*>(prow + j0) = make_float4(S[kt][0], S[kt][1], S[kt][2], S[kt][3]);
     }
+  } else {
+#pragma unroll
+    for (int kt = 0; kt < NKT; ++kt) S[kt] = (f32x4){0.f, 0.f, 0.f, 0.f};
   }
-  __syncthreads();                                  // every wave is done with the image
+  __syncthreads();                                  // every wave has its scores in registers
   float* Vs = reinterpret_cast<float*>(smem_raw);
-  stage_panel<NKT>(a.v + (long)b * T2 * a.ldv + h * ATT_DK, a.ldv, live ? T2 : 1, Vs, t);
+  panel_store<NKT>(vreg, Vs, t);
   __syncthreads();
   if (!active) return;
   // ---- context^T = V^T P^T: rows = channels, columns = queries ----
@@ -240,11 +280,11 @@ __global__ __launch_bounds__(256, 2) void attn_f32_fwd_kernel(const AttnF32Args 
 }
 
 // ---- backward, query side: dP = dctx V^T, dS = scale * P (dP - rowsum(P dP)), dq = dS K in one launch ----
-// Same orientation and lane layout as the forward: dP^T tiles from register-direct V / dctx fragments, P re-read with
-// the 16-byte accesses the forward stored it with, the row sum inside the wave, dS stored for the key-side GEMMs
-// (dK = dS^T q, and with relative positions dqv / dpos from the inverse rel_shift scatter dbd, written here element by
-// element exactly as eamd_softmax_bwd does) and dq^T = K^T dS^T from the K panel in LDS - the context product of the
-// forward with K in place of V.  reference: autograd of attention.py:63-114, :141-206.
+// Same two work splits as the forward: dP^T tiles by key quarter into the LDS matrix X, then each wave takes its 16
+// queries: P re-read with the 16-byte accesses the forward stored it with, the row sum inside the wave, dS stored for
+// the key-side GEMMs (dK = dS^T q, and with relative positions dqv / dpos from the inverse rel_shift scatter dbd,
+// written here element by element exactly as eamd_softmax_bwd does) and dq^T = K^T dS^T from a K panel staged over X -
+// the context product of the forward with K in place of V.  reference: autograd of attention.py:63-114, :141-206.
 struct AttnF32BwdArgs {
   const float* dctx; const float* k; const float* v; const float* P;
   float* dS; float* dbd; float* dq;
@@ -256,6 +296,7 @@ struct AttnF32BwdArgs {
 template <int NKT>
 __global__ __launch_bounds__(256, 2) void attn_f32_bwd_q_kernel(const AttnF32BwdArgs a) {
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+  constexpr int XLD = NKT * 16 + 4;
   const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
   const int fr = lane & 15, fq = lane >> 4;
   const int xcd = blockIdx.x & 7, jb = blockIdx.x >> 3;
@@ -263,40 +304,37 @@ __global__ __launch_bounds__(256, 2) void attn_f32_bwd_q_kernel(const AttnF32Bwd
   const bool live = z < a.B * a.H;
   const int zz = live ? z : 0;
   const int h = zz / a.B, b = zz % a.B;
-  const int r0 = (jb % a.nqb) * 64 + wave * 16;
-  const bool active = live && r0 < a.T1;
   const int T1 = a.T1, T2 = a.T2;
+  const int r0w = min((jb % a.nqb) * 64, T1 - 1);
+  const int nq = T1 - r0w;
+  const int r0 = r0w + wave * 16;
+  const bool active = live && r0 < T1;
   const int qi = min(r0 + fr, T1 - 1);
   const bool qok = r0 + fr < T1;
 
-  // K panel -> LDS first: nothing reads it before the barrier behind the score-gradient phase
-  float* Ks = reinterpret_cast<float*>(smem_raw);
-  stage_panel<NKT>(a.k + (long)b * T2 * a.ldk + h * ATT_DK, a.ldk, live ? T2 : 1, Ks, t);
-
+  float* X = reinterpret_cast<float*>(smem_raw);
+  // ---- dP: X[q][j] = dctx_q . v_j ----
+  score_tiles<NKT, false>(a.v + (long)b * T2 * a.ldv + h * ATT_DK, a.ldv, T2,
+                          a.dctx + ((long)b * T1 + r0w) * a.ldd + h * ATT_DK, a.ldd, nq, X, XLD, wave, fr, fq);
+  // this lane's probabilities: in flight across the barrier
+  const float* prow = a.P + ((long)zz * T1 + qi) * a.ldp;
+  float4 Pr[NKT];
+#pragma unroll
+  for (int kt = 0; kt < NKT; ++kt) {
+    const int j0 = kt * 16 + fq * 4;
+    Pr[kt] = *reinterpret_cast<const float4*>(prow + min(j0, (int)a.ldp - 4));
+    if (j0 >= (int)a.ldp) Pr[kt] = make_float4(0.f, 0.f, 0.f, 0.f);   // columns past ldp do not exist
+  }
+  __syncthreads();
   f32x4 S[NKT];                                     // dP^T, then dS^T
-#pragma unroll
-  for (int kt = 0; kt < NKT; ++kt) S[kt] = (f32x4){0.f, 0.f, 0.f, 0.f};
   if (active) {
-    float4 df[4];
-    load_frag(a.dctx + ((long)b * T1 + qi) * a.ldd + h * ATT_DK, fq, df);
-    const float* prow = a.P + ((long)zz * T1 + qi) * a.ldp;
-    float4 Pr[NKT];
-#pragma unroll
-    for (int kt = 0; kt < NKT; ++kt) {
-      const int j0 = kt * 16 + fq * 4;
-      Pr[kt] = *reinterpret_cast<const float4*>(prow + min(j0, (int)a.ldp - 4));
-      if (j0 >= (int)a.ldp) Pr[kt] = make_float4(0.f, 0.f, 0.f, 0.f);   // columns past ldp do not exist
-    }
-#pragma unroll
-    for (int kt = 0; kt < NKT; ++kt) {
-      float4 vf[4];
-      load_frag(a.v + ((long)b * T2 + min(kt * 16 + fr, T2 - 1)) * a.ldv + h * ATT_DK, fq, vf);
-      S[kt] = dot_tile(vf, df, S[kt]);
-    }
+    const float* xrow = &X[(wave * 16 + fr) * XLD + 4 * fq];
     float s = 0.f;
 #pragma unroll
     for (int kt = 0; kt < NKT; ++kt) {
       const int j0 = kt * 16 + fq * 4;
+      const float4 xv = *reinterpret_cast<const float4*>(xrow + kt * 16);
+      S[kt] = (f32x4){xv.x, xv.y, xv.z, xv.w};
       const float pr[4] = {Pr[kt].x, Pr[kt].y, Pr[kt].z, Pr[kt].w};
 #pragma unroll
       for (int r = 0; r < 4; ++r) if (j0 + r < T2) s += pr[r] * S[kt][r];
@@ -328,7 +366,15 @@ __global__ __launch_bounds__(256, 2) void attn_f32_bwd_q_kernel(const AttnF32Bwd
     }
     if (a.dbd && r0 == 0)                            // the head of row 0 the scatter never reaches
       for (int f = 1 + lane; f < T1; f += 64) a.dbd[zo + (f - 1)] = 0.f;
+  } else {
+#pragma unroll
+    for (int kt = 0; kt < NKT; ++kt) S[kt] = (f32x4){0.f, 0.f, 0.f, 0.f};
   }
+  float4 kreg[NKT];                                 // K panel: loads in flight across the barrier (the probabilities are dead)
+  panel_load<NKT>(a.k + (long)b * T2 * a.ldk + h * ATT_DK, a.ldk, live ? T2 : 1, t, kreg);
+  __syncthreads();                                  // every wave has its dP rows in registers
+  float* Ks = reinterpret_cast<float*>(smem_raw);
+  panel_store<NKT>(kreg, Ks, t);
   __syncthreads();
   if (!active) return;
   // ---- dq^T = K^T dS^T: rows = channels, columns = queries ----
@@ -389,14 +435,10 @@ extern "C" int eamd_attn_fwd_f32(const float* qu, int64_t ldq, const float* qv, 
   a.mb = mask_bstride; a.mi = mask_qstride;
   a.B = B; a.H = H; a.T1 = T1; a.T2 = T2; a.nqb = (T1 + 63) / 64; a.scale = scale;
   const bool half = T2 <= 128;                                       // 8 key tiles instead of 16
-  const size_t vbytes = (size_t)(half ? 128 : ATT_MAXK) * PLD * sizeof(float);
+  const size_t smem = (size_t)(half ? 128 : ATT_MAXK) * PLD * sizeof(float);      // V panel (the score matrix X is smaller)
   hipStream_t s = (hipStream_t)stream;
-  if (pos) {
-    const size_t pbytes = (size_t)65 * (T2 + 1) * sizeof(float);
-    const size_t smem = pbytes > vbytes ? pbytes : vbytes;
-    return half ? launch_fwd<true, 8>(a, smem, s) : launch_fwd<true, 16>(a, smem, s);
-  }
-  return half ? launch_fwd<false, 8>(a, vbytes, s) : launch_fwd<false, 16>(a, vbytes, s);
+  if (pos) return half ? launch_fwd<true, 8>(a, smem, s) : launch_fwd<true, 16>(a, smem, s);
+  return half ? launch_fwd<false, 8>(a, smem, s) : launch_fwd<false, 16>(a, smem, s);
 }
 
 extern "C" int eamd_attn_bwd_q_f32(const float* dctx, int64_t ldd, const float* k, int64_t ldk, const float* v, int64_t ldv,

@@ -7,11 +7,11 @@ import espnet_amd  # noqa: E402
 from espnet_amd import functional as F_  # noqa: E402
 from tools.gemm_probe4 import graph_time  # noqa: E402
 DEV = "cuda"
-espnet_amd.set_precision("bf16")
+espnet_amd.set_precision(sys.argv[1] if len(sys.argv) > 1 else "bf16")
 H, dk = 4, 64
 D = H * dk
 for (B, T1, T2, rel, mk) in ((32, 249, 249, True, "len"), (32, 249, 249, False, "len"), (32, 101, 249, False, "len"), (32, 101, 101, False, "causal")):
-    bf = lambda *s: torch.randn(*s, device=DEV).to(torch.bfloat16)
+    bf = lambda *s: torch.randn(*s, device=DEV).to(torch.bfloat16).to(espnet_amd.ops.act_dtype())
     if T1 == T2:
         qkv = bf(B * T1, 3 * D)
         k, v = F_._MV(qkv, D, 3 * D), F_._MV(qkv, 2 * D, 3 * D)
