@@ -46,7 +46,8 @@ class GemmT(C.Structure):
                 ("Cb", C.c_void_p), ("in_dtype", C.c_int32), ("aux_dtype", C.c_int32),
                 ("drop_p", C.c_float), ("drop_salt", C.c_uint64), ("drop_step", C.c_void_p), ("Hb", C.c_void_p),
                 ("h_act", C.c_int32),
-                ("a_drop_p", C.c_float), ("b_drop_p", C.c_float), ("a_drop_salt", C.c_uint64), ("b_drop_salt", C.c_uint64)]
+                ("a_drop_p", C.c_float), ("b_drop_p", C.c_float), ("a_drop_salt", C.c_uint64), ("b_drop_salt", C.c_uint64),
+                ("h_dtype", C.c_int32)]
 
 
 _lib = None

@@ -419,14 +419,17 @@ extern "C" int eamd_gemm(const eamd_gemm_t* pp, void* stream_) {
   if ((p.N + tile - 1) / tile > 65535) return EAMD_EUNSUPPORTED;
   // fused dropout: the bf16-operand kernels (incl. the dual bf16 output Hb) and, for a plain dropped result, the
   // pipelined fp32 kernel (same epilogue code)
-  if (p.in_dtype != 1 && (p.Hb || (p.drop_p != 0.f && p.precision != 0))) return EAMD_EUNSUPPORTED;
+  if (p.h_dtype != 0 && p.h_dtype != 1) return EAMD_EINVAL;
+  if (p.in_dtype == 1 && p.h_dtype != 0) return EAMD_EUNSUPPORTED;            // bf16 operands: bf16 second output
+  if (p.in_dtype != 1 && ((p.Hb && !(p.h_dtype == 1 && p.precision == 0)) || (p.drop_p != 0.f && p.precision != 0)))
+    return EAMD_EUNSUPPORTED;
   if ((p.a_drop_p != 0.f || p.b_drop_p != 0.f) && (p.in_dtype != 0 || p.precision != 0)) return EAMD_EUNSUPPORTED;
   if (p.in_dtype == 1) return eamd_gemm_bf16_dispatch(p, tile, stream);
 
   if (p.precision == 0) {     // reference precision: the pipelined fp32-MFMA kernel wherever its staging conditions hold
     const int rc = eamd_gemm_f32_dispatch(p, tile, stream);
     if (rc != EAMD_EUNSUPPORTED) return rc;
-    if (p.drop_p != 0.f || p.a_drop_p != 0.f || p.b_drop_p != 0.f) return EAMD_EUNSUPPORTED;   // generic kernel: no dropout
+    if (p.drop_p != 0.f || p.a_drop_p != 0.f || p.b_drop_p != 0.f || p.Hb) return EAMD_EUNSUPPORTED;   // generic kernel: no dropout
   }
   if (tile == 128) {
     return p.precision ? launch<128, 128, 1>(p, stream) : launch<128, 128, 0>(p, stream);

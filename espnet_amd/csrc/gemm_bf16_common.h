@@ -141,7 +141,7 @@ __device__ __forceinline__ void store_c_tile(const eamd_gemm_t& p, f32x4 (&acc)[
   const bool cvec = (p.ldc % 4 == 0) && (coff % 4 == 0) &&
                     (!p.C || (reinterpret_cast<uintptr_t>(p.C) & 15) == 0) &&
                     (!Cb || (reinterpret_cast<uintptr_t>(Cb) & 7) == 0) &&
-                    (!p.Hb || (reinterpret_cast<uintptr_t>(p.Hb) & 7) == 0) &&
+                    (!p.Hb || (reinterpret_cast<uintptr_t>(p.Hb) & (p.h_dtype ? 15 : 7)) == 0) &&
                     (!p.R || ((p.ldr % 4 == 0) && (reinterpret_cast<uintptr_t>(p.R) & 15) == 0)) &&
                     (!p.aux || (p.ldaux % 4 == 0 && (reinterpret_cast<uintptr_t>(p.aux) & 15) == 0));
   bf16_t* __restrict__ Hb = reinterpret_cast<bf16_t*>(p.Hb);
@@ -188,7 +188,15 @@ __device__ __forceinline__ void store_c_tile(const eamd_gemm_t& p, f32x4 (&acc)[
           const float a = eamd_act(v[e], p.h_act);
           h[e] = keep[e] ? a * inv : 0.f;
         }
-        if (full) {
+        if (p.h_dtype) {       // fp32 second output (reference-precision mode)
+          float* Hf = reinterpret_cast<float*>(p.Hb);
+          if (full) {
+            *reinterpret_cast<float4*>(Hf + ci) = make_float4(h[0], h[1], h[2], h[3]);
+          } else {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) if (nn + e < p.N) Hf[ci + e] = h[e];
+          }
+        } else if (full) {
           uint2 o;
           o.x = eamd_f2bf(h[0]) | ((unsigned)eamd_f2bf(h[1]) << 16);
           o.y = eamd_f2bf(h[2]) | ((unsigned)eamd_f2bf(h[3]) << 16);

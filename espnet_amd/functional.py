@@ -215,7 +215,8 @@ class FFNBlockFn(torch.autograd.Function):
         assert eps is not None or p_out <= 0.0
         fused = ops.fast()      # bf16-operand GEMMs carry the dropout masks in their epilogues
         h = None
-        if p_in > 0.0 and fused:
+        if p_in > 0.0 and (fused or (ops.f32_epilogue_drop() and not ops.f32_operand_drop())):
+            # z and h = dropout(act(z)) from one launch (second output of the epilogue), in the operand dtype
             h = torch.empty(x2.shape[0], w1.shape[0], device=x2.device, dtype=adt)
             z = ops.linear_fwd(xn, ops.wshadow(w1), b1, out_dtype=adt, drop=(p_in, s_in), Hb=h, h_act=act)
         else:

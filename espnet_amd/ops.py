@@ -179,14 +179,14 @@ def gemm(A, B, Cm, M, N, K, lda, ldb, ldc, *, transA=0, transB=0, bias=None, aux
     if cmap is not None:
         p.cmap = cmap
     if drop is not None and drop[0] > 0.0:      # (p, salt): fused dropout, see include/espnet_amd.h
-        if ldc != N or c_off != 0 or (not bf and (p.precision != 0 or Hb is not None)):
+        if ldc != N or c_off != 0 or (not bf and p.precision != 0):
             raise _lib.EamdError("gemm: fused dropout needs a contiguous [M, N] result and bf16 or fp32-MFMA operands")
         p.drop_p, p.drop_salt = float(drop[0]), int(drop[1])
         p.drop_step = ptr(rng_state(A.device))
         if Hb is not None:
-            if Hb.dtype != torch.bfloat16 or Hb.numel() < M * N:
-                raise _lib.EamdError("gemm: Hb must be a bf16 [M, N] buffer")
-            p.Hb, p.h_act = ptr(Hb), h_act
+            if Hb.dtype != (torch.bfloat16 if bf else torch.float32) or Hb.numel() < M * N:
+                raise _lib.EamdError("gemm: Hb must be an [M, N] buffer of the operand dtype")
+            p.Hb, p.h_act, p.h_dtype = ptr(Hb), h_act, 0 if bf else 1
     for which, d, ld_, off_, cols in (("a", a_drop, lda, a_off, (M if transA else K)), ("b", b_drop, ldb, b_off, (N if transB else K))):
         if d is not None and d[0] > 0.0:    # operand-side dropout: the operand must BE the contiguous tensor the mask was drawn for
             if bf or p.precision != 0 or ld_ != cols or off_ != 0 or b1 * b2 != 1 or gather is not None:

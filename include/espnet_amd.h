@@ -102,6 +102,7 @@ typedef struct {
    *   backward (positionwise_feed_forward.py:27, encoder_layer.py:101-144).  Needs an unbatched, un-gathered operand. */
   float a_drop_p, b_drop_p;
   uint64_t a_drop_salt, b_drop_salt;
+  int32_t h_dtype;     /* dtype of the second output Hb: 0 bf16, 1 fp32 (fp32-MFMA kernel: z and h = dropout(act(z)) in fp32) */
 } eamd_gemm_t;
 
 int eamd_gemm(const eamd_gemm_t* p, void* stream);

@@ -691,6 +691,12 @@ def test_gemm_f32_fused_dropout_matches_dropout_kernel(ops, shape):
     report("fp32 gemm fused dropout %s" % (shape,), fused, want, 1e-6)
     assert abs(float((fused != R).float().mean()) - (1 - p)) < 0.01
     report("fp32 gemm vs float64 %s" % (shape,), plain, x.double().cpu() @ W.double().cpu().t() + b.double().cpu(), 2e-6)
+    # second fp32 output (h_dtype 1): z untouched, h = dropout(swish(z)) from the same launch (FFN up-projection)
+    from espnet_amd.ops import ACT_SWISH
+    h = torch.empty(M, N, device=DEV)
+    z = ops.linear_fwd(x, W, b, drop=(p, salt), Hb=h, h_act=ACT_SWISH)
+    assert torch.equal(z, plain)
+    report("fp32 gemm dual output h %s" % (shape,), h, ops.dropout(plain, p, salt, act=ACT_SWISH), 1e-6)
 
 
 @pytest.mark.parametrize("shape", [(300, 192, 128), (7968, 256, 2048), (1000, 2048, 256)])
