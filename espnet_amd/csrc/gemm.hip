@@ -438,9 +438,9 @@ extern "C" int eamd_gemm(const eamd_gemm_t* pp, void* stream_) {
 }
 
 int eamd_gemm_f32_group_count(const eamd_gemm_t& p);                                            // gemm_f32.hip
-int eamd_gemm_f32_group_launch(const eamd_gemm_t* tab, const int* first, int n, int total, hipStream_t s);
+int eamd_gemm_f32_group_launch(const eamd_gemm_t* tab, const int* first, int n, int total, int tile, hipStream_t s);
 int eamd_gemm_bf16_group_count(const eamd_gemm_t& p);                                           // gemm_bf16.hip
-int eamd_gemm_bf16_group_launch(const eamd_gemm_t* tab, const int* first, int n, int total, hipStream_t s);
+int eamd_gemm_bf16_group_launch(const eamd_gemm_t* tab, const int* first, int n, int total, int tile, hipStream_t s);
 
 extern "C" int eamd_gemm_group_plan(const eamd_gemm_t* descs, int n, int32_t* first) {
   if (!descs || !first || n <= 0) return EAMD_EINVAL;
@@ -449,6 +449,7 @@ extern "C" int eamd_gemm_group_plan(const eamd_gemm_t* descs, int n, int32_t* fi
     const eamd_gemm_t& p = descs[i];
     if (!p.A || !p.B || !p.C || p.M <= 0 || p.N <= 0 || p.K <= 0) return EAMD_EINVAL;
     if (p.in_dtype != descs[0].in_dtype || p.precision != descs[0].precision) return EAMD_EINVAL;
+    if ((p.tile == 128) != (descs[0].tile == 128)) return EAMD_EINVAL;          // one tile size per launch
     const int c = p.in_dtype == 1 ? eamd_gemm_bf16_group_count(p) : eamd_gemm_f32_group_count(p);
     if (c < 0) return c;
     first[i] = (int32_t)total;
@@ -460,10 +461,10 @@ extern "C" int eamd_gemm_group_plan(const eamd_gemm_t* descs, int n, int32_t* fi
 }
 
 extern "C" int eamd_gemm_group_launch(const eamd_gemm_t* descs_dev, const int32_t* first_dev, int n, int total, int in_dtype,
-                                      void* stream) {
-  if (!descs_dev || !first_dev || n <= 0 || total <= 0) return EAMD_EINVAL;
-  return in_dtype == 1 ? eamd_gemm_bf16_group_launch(descs_dev, first_dev, n, total, (hipStream_t)stream)
-                       : eamd_gemm_f32_group_launch(descs_dev, first_dev, n, total, (hipStream_t)stream);
+                                      int tile, void* stream) {
+  if (!descs_dev || !first_dev || n <= 0 || total <= 0 || (tile != 64 && tile != 128)) return EAMD_EINVAL;
+  return in_dtype == 1 ? eamd_gemm_bf16_group_launch(descs_dev, first_dev, n, total, tile, (hipStream_t)stream)
+                       : eamd_gemm_f32_group_launch(descs_dev, first_dev, n, total, tile, (hipStream_t)stream);
 }
 
 extern "C" int eamd_abi_version(void) { return 1; }

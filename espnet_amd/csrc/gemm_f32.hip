@@ -72,7 +72,18 @@ __device__ __forceinline__ void gemm_f32_body(const eamd_gemm_t& p, const int bi
   // the split index is the fastest-varying part of the workgroup id
   const int tiles_n = (p.N + BN - 1) / BN;
   int tile_id, split;
-  if (p.splitk > 1) {
+  if (nblk < 0) {
+    // grouped launch: -nblk workgroups (a multiple of 8, so bid & 7 is the XCD) serve tiles x splits in split-major
+    // order, every XCD one contiguous run of it: an XCD works on one K-slice (or part of one) of neighbouring tiles,
+    // so the operand panels they share are fetched from HBM once into that XCD's L2 (dealt round-robin, the same
+    // launch fetched 3.8x its operand bytes)
+    const int ntile = ((p.M + BM - 1) / BM) * tiles_n;
+    const int per = (-nblk) >> 3;
+    const int v = (bid & 7) * per + (bid >> 3);
+    if (v >= ntile * p.splitk) return;       // padding workgroup
+    split = v / ntile;
+    tile_id = v - split * ntile;
+  } else if (p.splitk > 1) {
     split = bid % p.splitk;
     tile_id = bid / p.splitk;
   } else {
@@ -503,7 +514,7 @@ __global__ __launch_bounds__(NT_, 2) void gemm_f32_group_kernel(const eamd_gemm_
     if (first[mid] <= (int)blockIdx.x) lo = mid; else hi = mid;
   }
   const eamd_gemm_t p = tab[lo];         // wave-uniform: scalar loads
-  gemm_f32_body<BM, BN, TA, TB, false, false>(p, (int)blockIdx.x - first[lo], first[lo + 1] - first[lo], 0);
+  gemm_f32_body<BM, BN, TA, TB, false, false>(p, (int)blockIdx.x - first[lo], -(first[lo + 1] - first[lo]), 0);
 }
 
 template <int BM, int BN, bool TA, bool TB, bool GAT, bool ACT>
@@ -585,20 +596,27 @@ int eamd_gemm_f32_group_count(const eamd_gemm_t& p) {
   const bool a_ok = aligned16f(p.A) && p.lda % 4 == 0 && p.lda >= (p.M + 3) / 4 * 4;
   const bool b_ok = aligned16f(p.B) && p.ldb % 4 == 0 && p.ldb >= (p.N + 3) / 4 * 4;
   if (!a_ok || !b_ok) return EAMD_EUNSUPPORTED;
-  const long n = (long)((p.M + 63) / 64) * ((p.N + 63) / 64) * p.splitk;
+  const int T = p.tile == 128 ? 128 : 64;
+  const long n = ((long)((p.M + T - 1) / T) * ((p.N + T - 1) / T) * p.splitk + 7) / 8 * 8;   // whole rounds of the 8 XCDs
   return n < (1L << 24) ? (int)n : EAMD_EUNSUPPORTED;
 }
 
-int eamd_gemm_f32_group_launch(const eamd_gemm_t* tab_dev, const int* first_dev, int n, int total, hipStream_t stream) {
-  constexpr size_t smem = sizeof(SmemF<64, 64, true, true>);
+template <int T>
+static int group_launch_t(const eamd_gemm_t* tab_dev, const int* first_dev, int n, int total, hipStream_t stream) {
+  constexpr size_t smem = sizeof(SmemF<T, T, true, true>);
   if (smem > 64 * 1024) {
     static const hipError_t attr_err = hipFuncSetAttribute(
-        reinterpret_cast<const void*>(&gemm_f32_group_kernel<64, 64, true, true>),
+        reinterpret_cast<const void*>(&gemm_f32_group_kernel<T, T, true, true>),
         hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
     if (attr_err != hipSuccess) return (int)attr_err;
   }
-  hipLaunchKernelGGL((gemm_f32_group_kernel<64, 64, true, true>), dim3((unsigned)total), dim3(NT_), smem, stream, tab_dev,
+  hipLaunchKernelGGL((gemm_f32_group_kernel<T, T, true, true>), dim3((unsigned)total), dim3(NT_), smem, stream, tab_dev,
                      first_dev, n);
   EAMD_LAUNCH_CHECK();
   return EAMD_OK;
+}
+
+int eamd_gemm_f32_group_launch(const eamd_gemm_t* tab_dev, const int* first_dev, int n, int total, int tile, hipStream_t stream) {
+  return tile == 128 ? group_launch_t<128>(tab_dev, first_dev, n, total, stream)
+                     : group_launch_t<64>(tab_dev, first_dev, n, total, stream);
 }

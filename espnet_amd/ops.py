@@ -214,6 +214,11 @@ GROUP_WGRAD_MAX_TILES = int(os.environ.get("EAMD_GROUP_MAX_TILES", "384"))    # 
 # gradients) with half the stand-alone split count is best in both precisions - 34.09 ms fp32 / 14.20 ms bf16 against
 # 35.0 / 15.04 ungrouped; the queue supplies the parallelism the extra splits (and their atomics) bought before
 GROUP_WGRAD_SK_DIV = int(os.environ.get("EAMD_GROUP_SK_DIV", "2"))
+# fp32 operands only (measured: 33.45 -> 32.80 ms; with bf16 operands the 128x128 tile loses, 14.17 -> 14.3+ ms): problems
+# of at least this many 64x64 tiles - the FFN weights - take 128x128 tiles in a second grouped launch, with about
+# GROUP_WGRAD_T128_WGS workgroups (tiles x K-splits) each
+GROUP_WGRAD_TILE128_MIN = int(os.environ.get("EAMD_GROUP_T128_MIN", "100"))
+GROUP_WGRAD_T128_WGS = int(os.environ.get("EAMD_GROUP_T128_WGS", "96"))
 _wgroup = {"on": False, "items": [], "pinned": [], "reserve": [], "arenas": set()}
 
 
@@ -253,18 +258,28 @@ def _wgroup_staging(nbytes):
 
 
 def wgrad_group_flush():
-    """launch everything queued so far (one grouped launch; a single queued GEMM goes out on its own)"""
+    """launch everything queued so far: one grouped launch per tile size (a single queued GEMM goes out on its own)"""
     items = _wgroup["items"]
     if not items:
         return
     _wgroup["items"] = []
+    for tile in (64, 128):
+        part = [it for it in items if (128 if it[0].tile == 128 else 64) == tile]
+        if part:
+            _wgroup_launch(part, tile)
+
+
+def _wgroup_launch(items, tile):
     L = _lib.lib()
+
+    def separately():
+        for p, keep in items:
+            if _gemm_record is not None:
+                _gemm_record.append((p, keep, lambda sp, p=p: check(L.eamd_gemm(C.byref(p), sp), "eamd_gemm")))
+            check(L.eamd_gemm(C.byref(p), stream_ptr()), "eamd_gemm")
+
     if len(items) == 1:
-        p = items[0][0]
-        if _gemm_record is not None:
-            _gemm_record.append((p, items[0][1], lambda sp, p=p: check(L.eamd_gemm(C.byref(p), sp), "eamd_gemm")))
-        check(L.eamd_gemm(C.byref(p), stream_ptr()), "eamd_gemm")
-        return
+        return separately()
     n = len(items)
     dev = items[0][1][0].device
     arr = (GemmT * n)(*[it[0] for it in items])
@@ -274,17 +289,13 @@ def wgrad_group_flush():
     nb_desc, nb_first = C.sizeof(arr), C.sizeof(first)
     host = _wgroup_staging(nb_desc + nb_first)
     if host is None:          # capturing with no staging buffer in reserve: one launch per GEMM
-        for p, keep in items:
-            if _gemm_record is not None:
-                _gemm_record.append((p, keep, lambda sp, p=p: check(L.eamd_gemm(C.byref(p), sp), "eamd_gemm")))
-            check(L.eamd_gemm(C.byref(p), stream_ptr()), "eamd_gemm")
-        return
+        return separately()
     C.memmove(host.data_ptr(), arr, nb_desc)
     C.memmove(host.data_ptr() + nb_desc, first, nb_first)
     tab = torch.empty(nb_desc + nb_first, dtype=torch.uint8, device=dev)
     tab.copy_(host, non_blocking=True)
     in_dtype = int(arr[0].in_dtype)
-    args = (ptr(tab), ptr(tab, nb_desc), n, total, in_dtype)
+    args = (ptr(tab), ptr(tab, nb_desc), n, total, in_dtype, tile)
     check(L.eamd_gemm_group_launch(*args, stream_ptr()), "eamd_gemm_group_launch")
     if _gemm_record is not None:
         _gemm_record.append((None, (tab, [it[1] for it in items]),
@@ -391,9 +402,18 @@ def _linear_bwd_w(dy, x, dW, *, alpha=1.0, b_act=ACT_NONE, db=None, a_drop=None,
     K = x.shape[1]
     assert x.shape[0] == M and dW.numel() == N * K and dW.dtype == torch.float32
     sk = auto_splitk(N, K, M)
-    if _wgroup["on"] and _wgrad["stream"] is None and ((N + 63) // 64) * ((K + 63) // 64) <= GROUP_WGRAD_MAX_TILES:
-        sk = max(1, sk // GROUP_WGRAD_SK_DIV)
-    gemm(dy, x, dW, N, K, M, N, K, K, transA=1, transB=1, alpha=alpha, b_act=b_act, splitk=sk,
+    tile = 0
+    t64 = ((N + 63) // 64) * ((K + 63) // 64)
+    if (_wgroup["on"] and _wgrad["stream"] is None and t64 <= GROUP_WGRAD_MAX_TILES
+            and dW.untyped_storage().data_ptr() in _wgroup["arenas"]):
+        if t64 >= GROUP_WGRAD_TILE128_MIN and N >= 128 and K >= 128 and dy.dtype == torch.float32 and _state["precision"] == 0:
+            # big outputs (the FFN weights) go to the 128x128 grouped launch: a quarter of the operand re-reads
+            tile = 128
+            sk = max(1, min(GROUP_WGRAD_T128_WGS // (((N + 127) // 128) * ((K + 127) // 128)), M // 256))
+        else:
+            tile = 64
+            sk = max(1, sk // GROUP_WGRAD_SK_DIV)
+    gemm(dy, x, dW, N, K, M, N, K, K, transA=1, transB=1, alpha=alpha, b_act=b_act, splitk=sk, tile=tile,
          beta=1.0 if sk == 1 else 0.0, colsum=db, a_drop=a_drop, b_drop=b_drop, group=_wgrad["stream"] is None)
 
 

@@ -114,9 +114,12 @@ int eamd_gemm(const eamd_gemm_t* p, void* stream);
  * bias / residual / aux / epilogue / gather / row map / dropout; split-K accumulating with atomics, or splitk = 1 with
  * beta = 1; colsum allowed; operands meeting the 16-byte staging conditions of eamd_gemm's fast kernels), writes the
  * first workgroup of every problem into first[0..n] and returns the total workgroup count, or EAMD_EUNSUPPORTED / EAMD_EINVAL.
+ * All descriptors of one launch name the same tile (64, or 128 for outputs of at least 128 x 128: p.tile); workgroup counts are
+ * padded to multiples of 8 so that every XCD works on a contiguous run of one problem's tiles x K-slices.
  * The caller copies the descriptors and `first` to the device (stream-ordered) and calls eamd_gemm_group_launch. */
 int eamd_gemm_group_plan(const eamd_gemm_t* descs, int n, int32_t* first);
-int eamd_gemm_group_launch(const eamd_gemm_t* descs_dev, const int32_t* first_dev, int n, int total, int in_dtype, void* stream);
+int eamd_gemm_group_launch(const eamd_gemm_t* descs_dev, const int32_t* first_dev, int n, int total, int in_dtype, int tile,
+                           void* stream);
 
 /* ------------------------------------------------------------------------------------------
  * Row kernels (HBM-bound).
