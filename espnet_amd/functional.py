@@ -897,7 +897,9 @@ def _conv3s2_bwd(dy, y_in, wd, dw_buf, db_buf, B, Hi, Wi, Ho, Wo, Cc, adt):
     g = ops.make_gather(Cc, _TAPS_FWD, Ho, Wo, Hi, Wi, 2, 2)
     tile = 64
     ntile = (9 * Cc // tile) * ((Cc + tile - 1) // tile)
-    sk = max(2, min(64, (1024 + ntile - 1) // ntile, max(1, M // 256)))
+    # workgroups wanted: 1024 with bf16 operands; the fp32-MFMA kernel (lower occupancy, 16x the MFMA time per tile) is
+    # best from about 2300 (split-K 16 at config 2: 1.94 -> 1.7 ms)
+    sk = max(2, min(64, ((1024 if ops.fast() else 2304) + ntile - 1) // ntile, max(1, M // 256)))
     ops.gemm(y_in, dy, dwf, 9 * Cc, Cc, M, 9 * Cc, Cc, Cc, transA=1, transB=1, gather=g, splitk=sk, tile=tile)
     ops.conv2_weight_grad(dwf, dw_buf, Cc, Cc)
     # input gradient, one implicit GEMM per stride-parity class
