@@ -41,6 +41,8 @@ struct AttnF32Args {
   long ldq, ldqv, ldk, ldv, ldpos, ldc, ldp, mb, mi;
   int B, H, T1, T2, nqb;
   float scale;
+  // attention dropout (attention.py:91): Pd = dropout(P) feeds the context; mask index = element index in P
+  float* Pd; float drop_p; const unsigned long long* drop_step; unsigned long long drop_salt;
 };
 
 __device__ __forceinline__ float xmax16_32(float v) {
@@ -249,13 +251,28 @@ __global__ __launch_bounds__(256, 2) void attn_f32_fwd_kernel(const AttnF32Args 
     sum = xsum16_32(sum);
     const float inv = dead ? 0.f : 1.f / sum;
     const bool qok = r0 + fr < T1;
-    float* prow = a.P + ((long)zz * T1 + qi) * a.ldp;
+    const long pro = ((long)zz * T1 + qi) * a.ldp;
+    float* prow = a.P + pro;
 #pragma unroll
     for (int kt = 0; kt < NKT; ++kt) {
       S[kt] *= inv;
       const int j0 = kt * 16 + fq * 4;
       if (qok && j0 < a.ldp)                         // pad columns receive zeros
         *reinterpret_cast<float4*>(prow + j0) = make_float4(S[kt][0], S[kt][1], S[kt][2], S[kt][3]);
+    }
+    if (a.drop_p > 0.f) {                            // wave-uniform: the dropped probabilities go on to the context product
+      const unsigned seed = eamd_drop_seed(a.drop_step, a.drop_salt), thr = eamd_drop_thr16(a.drop_p);
+      const float dinv = eamd_drop_inv(thr);
+#pragma unroll
+      for (int kt = 0; kt < NKT; ++kt) {
+        const int j0 = kt * 16 + fq * 4;
+        bool kp[4];
+        eamd_drop_keep4(seed, (unsigned long long)(pro + min(j0, (int)a.ldp - 4)), thr, kp);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) S[kt][r] = kp[r] ? S[kt][r] * dinv : 0.f;
+        if (qok && j0 < a.ldp)
+          *reinterpret_cast<float4*>(a.Pd + pro + j0) = make_float4(S[kt][0], S[kt][1], S[kt][2], S[kt][3]);
+      }
     }
   } else {
 #pragma unroll
@@ -291,6 +308,7 @@ struct AttnF32BwdArgs {
   long ldd, ldk, ldv, ldp, ldo;
   int B, H, T1, T2, nqb;
   float scale;
+  float drop_p; const unsigned long long* drop_step; unsigned long long drop_salt;   // the forward's attention dropout
 };
 
 template <int NKT>
@@ -329,12 +347,22 @@ __global__ __launch_bounds__(256, 2) void attn_f32_bwd_q_kernel(const AttnF32Bwd
   f32x4 S[NKT];                                     // dP^T, then dS^T
   if (active) {
     const float* xrow = &X[(wave * 16 + fr) * XLD + 4 * fq];
+    const bool drop = a.drop_p > 0.f;                // wave-uniform
+    const unsigned seed = drop ? eamd_drop_seed(a.drop_step, a.drop_salt) : 0u, thr = eamd_drop_thr16(a.drop_p);
+    const float dinv = eamd_drop_inv(thr);
+    const long pro = ((long)zz * T1 + qi) * a.ldp;
     float s = 0.f;
 #pragma unroll
     for (int kt = 0; kt < NKT; ++kt) {
       const int j0 = kt * 16 + fq * 4;
       const float4 xv = *reinterpret_cast<const float4*>(xrow + kt * 16);
       S[kt] = (f32x4){xv.x, xv.y, xv.z, xv.w};
+      if (drop) {                                    // gradient of the dropped probabilities -> gradient of P
+        bool kp[4];
+        eamd_drop_keep4(seed, (unsigned long long)(pro + min(j0, (int)a.ldp - 4)), thr, kp);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) S[kt][r] = kp[r] ? S[kt][r] * dinv : 0.f;
+      }
       const float pr[4] = {Pr[kt].x, Pr[kt].y, Pr[kt].z, Pr[kt].w};
 #pragma unroll
       for (int r = 0; r < 4; ++r) if (j0 + r < T2) s += pr[r] * S[kt][r];
@@ -420,8 +448,10 @@ bool al16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
 extern "C" int eamd_attn_fwd_f32(const float* qu, int64_t ldq, const float* qv, int64_t ldqv, const float* k, int64_t ldk,
                                  const float* v, int64_t ldv, const float* pos, int64_t ldpos, const unsigned char* mask,
                                  int64_t mask_bstride, int64_t mask_qstride, float* P, int64_t ldp, float* ctx,
-                                 int64_t ldc, int B, int H, int T1, int T2, int dk, float scale, void* stream) {
+                                 int64_t ldc, int B, int H, int T1, int T2, int dk, float scale, float* Pd, float drop_p,
+                                 const uint64_t* drop_step, uint64_t drop_salt, void* stream) {
   if (!qu || !k || !v || !P || !ctx || B <= 0 || H <= 0 || T1 <= 0 || T2 <= 0) return EAMD_EINVAL;
+  if (drop_p < 0.f || drop_p >= 1.f || (drop_p > 0.f && (!Pd || !drop_step || !al16(Pd)))) return EAMD_EINVAL;
   if ((pos == nullptr) != (qv == nullptr)) return EAMD_EINVAL;
   if (dk != ATT_DK || T2 > ATT_MAXK || (pos && T1 != T2)) return EAMD_EUNSUPPORTED;
   if (ldq % 4 || ldk % 4 || ldv % 4 || ldc % 4 || ldp % 4 || ldp < T2 || (pos && (ldqv % 4 || ldpos % 4)))
@@ -434,6 +464,7 @@ extern "C" int eamd_attn_fwd_f32(const float* qu, int64_t ldq, const float* qv, 
   a.ldq = ldq; a.ldqv = ldqv; a.ldk = ldk; a.ldv = ldv; a.ldpos = ldpos; a.ldc = ldc; a.ldp = ldp;
   a.mb = mask_bstride; a.mi = mask_qstride;
   a.B = B; a.H = H; a.T1 = T1; a.T2 = T2; a.nqb = (T1 + 63) / 64; a.scale = scale;
+  a.Pd = Pd; a.drop_p = drop_p; a.drop_step = (const unsigned long long*)drop_step; a.drop_salt = drop_salt;
   const bool half = T2 <= 128;                                       // 8 key tiles instead of 16
   const size_t smem = (size_t)(half ? 128 : ATT_MAXK) * PLD * sizeof(float);      // V panel (the score matrix X is smaller)
   hipStream_t s = (hipStream_t)stream;
@@ -443,8 +474,10 @@ extern "C" int eamd_attn_fwd_f32(const float* qu, int64_t ldq, const float* qv, 
 
 extern "C" int eamd_attn_bwd_q_f32(const float* dctx, int64_t ldd, const float* k, int64_t ldk, const float* v, int64_t ldv,
                                    const float* P, int64_t ldp, float* dS, float* dbd, float* dq, int64_t ldo, int B, int H,
-                                   int T1, int T2, int dk, float scale, void* stream) {
+                                   int T1, int T2, int dk, float scale, float drop_p, const uint64_t* drop_step,
+                                   uint64_t drop_salt, void* stream) {
   if (!dctx || !k || !v || !P || !dS || !dq || B <= 0 || H <= 0 || T1 <= 0 || T2 <= 0) return EAMD_EINVAL;
+  if (drop_p < 0.f || drop_p >= 1.f || (drop_p > 0.f && !drop_step)) return EAMD_EINVAL;
   if (dk != ATT_DK || T2 > ATT_MAXK || (dbd && T1 != T2)) return EAMD_EUNSUPPORTED;
   if (ldd % 4 || ldk % 4 || ldv % 4 || ldp % 4 || ldp < T2 || ldo % 4) return EAMD_EUNSUPPORTED;
   if (!al16(dctx) || !al16(k) || !al16(v) || !al16(P) || !al16(dS) || !al16(dq)) return EAMD_EUNSUPPORTED;
@@ -453,5 +486,6 @@ extern "C" int eamd_attn_bwd_q_f32(const float* dctx, int64_t ldd, const float* 
   a.dctx = dctx; a.k = k; a.v = v; a.P = P; a.dS = dS; a.dbd = dbd; a.dq = dq;
   a.ldd = ldd; a.ldk = ldk; a.ldv = ldv; a.ldp = ldp; a.ldo = ldo;
   a.B = B; a.H = H; a.T1 = T1; a.T2 = T2; a.nqb = (T1 + 63) / 64; a.scale = scale;
+  a.drop_p = drop_p; a.drop_step = (const unsigned long long*)drop_step; a.drop_salt = drop_salt;
   return T2 <= 128 ? launch_bwd<8>(a, (hipStream_t)stream) : launch_bwd<16>(a, (hipStream_t)stream);
 }

@@ -31,6 +31,8 @@ struct AttnArgs {
   long ldq, ldqv, ldk, ldv, ldpos, ldc, ldp, mb, mi;
   int B, H, T1, T2, nqb;
   float scale;
+  // attention dropout (attention.py:91): Pd = dropout(P) feeds the context; mask index = element index in P
+  bf16_t* Pd; float drop_p; const unsigned long long* drop_step; unsigned long long drop_salt;
 };
 
 __device__ __forceinline__ float xor_max16_32(float v) {
@@ -160,13 +162,27 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const AttnArgs a) {
     sum = xor_sum16_32(sum);
     const float inv = dead ? 0.f : 1.f / sum;
     const bool qok = r0 + fr < T1;
-    bf16_t* prow = a.P + ((long)zz * T1 + qi) * a.ldp;
+    const long pro = ((long)zz * T1 + qi) * a.ldp;
+    bf16_t* prow = a.P + pro;
 #pragma unroll
     for (int kt = 0; kt < NKT; ++kt) {
       Pk[kt].x = (unsigned)eamd_f2bf(S[kt][0] * inv) | ((unsigned)eamd_f2bf(S[kt][1] * inv) << 16);
       Pk[kt].y = (unsigned)eamd_f2bf(S[kt][2] * inv) | ((unsigned)eamd_f2bf(S[kt][3] * inv) << 16);
       const int j0 = kt * 16 + fq * 4;
       if (qok && j0 < a.ldp) *reinterpret_cast<uint2*>(prow + j0) = Pk[kt];     // pad columns receive zeros
+    }
+    if (a.drop_p > 0.f) {                            // wave-uniform: the dropped probabilities go on to the context product
+      const unsigned seed = eamd_drop_seed(a.drop_step, a.drop_salt), thr = eamd_drop_thr16(a.drop_p);
+      const float dinv = eamd_drop_inv(thr) * inv;
+#pragma unroll
+      for (int kt = 0; kt < NKT; ++kt) {
+        const int j0 = kt * 16 + fq * 4;
+        bool kp[4];
+        eamd_drop_keep4(seed, (unsigned long long)(pro + min(j0, (int)a.ldp - 4)), thr, kp);
+        Pk[kt].x = (unsigned)eamd_f2bf(kp[0] ? S[kt][0] * dinv : 0.f) | ((unsigned)eamd_f2bf(kp[1] ? S[kt][1] * dinv : 0.f) << 16);
+        Pk[kt].y = (unsigned)eamd_f2bf(kp[2] ? S[kt][2] * dinv : 0.f) | ((unsigned)eamd_f2bf(kp[3] ? S[kt][3] * dinv : 0.f) << 16);
+        if (qok && j0 < a.ldp) *reinterpret_cast<uint2*>(a.Pd + pro + j0) = Pk[kt];
+      }
     }
   } else {
 #pragma unroll
@@ -230,6 +246,7 @@ struct AttnBwdArgs {
   long ldd, ldk, ldv, ldp, ldo;
   int B, H, T1, T2, nqb, dq_bf16;
   float scale;
+  float drop_p; const unsigned long long* drop_step; unsigned long long drop_salt;   // the forward's attention dropout
 };
 
 template <int NKT>
@@ -285,6 +302,18 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_q_kernel(const AttnBwdArgs a)
       const float f = __uint_as_float((r & 1) ? (w & 0xffff0000u) : (w << 16));
       return kt * 16 + fq * 4 < (int)a.ldp ? f : 0.f;   // pad columns of P hold zeros, columns past ldp do not exist
     };
+    if (a.drop_p > 0.f) {                            // wave-uniform: gradient of the dropped probabilities -> gradient of P
+      const unsigned seed = eamd_drop_seed(a.drop_step, a.drop_salt), thr = eamd_drop_thr16(a.drop_p);
+      const float dinv = eamd_drop_inv(thr);
+      const long pro = ((long)zz * T1 + qi) * a.ldp;
+#pragma unroll
+      for (int kt = 0; kt < NKT; ++kt) {
+        bool kp[4];
+        eamd_drop_keep4(seed, (unsigned long long)(pro + min(kt * 16 + fq * 4, (int)a.ldp - 4)), thr, kp);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) S[kt][r] = kp[r] ? S[kt][r] * dinv : 0.f;
+      }
+    }
     float s = 0.f;
 #pragma unroll
     for (int kt = 0; kt < NKT; ++kt)
@@ -385,8 +414,10 @@ bool al16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
 extern "C" int eamd_attn_fwd(const void* qu, int64_t ldq, const void* qv, int64_t ldqv, const void* k, int64_t ldk,
                              const void* v, int64_t ldv, const void* pos, int64_t ldpos, const unsigned char* mask,
                              int64_t mask_bstride, int64_t mask_qstride, void* P_bf16, int64_t ldp, void* ctx_bf16,
-                             int64_t ldc, int B, int H, int T1, int T2, int dk, float scale, void* stream) {
+                             int64_t ldc, int B, int H, int T1, int T2, int dk, float scale, void* Pd_bf16, float drop_p,
+                             const uint64_t* drop_step, uint64_t drop_salt, void* stream) {
   if (!qu || !k || !v || !P_bf16 || !ctx_bf16 || B <= 0 || H <= 0 || T1 <= 0 || T2 <= 0) return EAMD_EINVAL;
+  if (drop_p < 0.f || drop_p >= 1.f || (drop_p > 0.f && (!Pd_bf16 || !drop_step || !al16(Pd_bf16)))) return EAMD_EINVAL;
   if ((pos == nullptr) != (qv == nullptr)) return EAMD_EINVAL;
   if (dk != ATT_DK || T2 > ATT_MAXK || (pos && T1 != T2)) return EAMD_EUNSUPPORTED;
   if (ldq % 8 || ldk % 8 || ldv % 8 || ldc % 4 || ldp % 8 || ldp < T2 || (pos && (ldqv % 8 || ldpos % 8)))
@@ -401,6 +432,7 @@ extern "C" int eamd_attn_fwd(const void* qu, int64_t ldq, const void* qv, int64_
   a.ldq = ldq; a.ldqv = ldqv; a.ldk = ldk; a.ldv = ldv; a.ldpos = ldpos; a.ldc = ldc; a.ldp = ldp;
   a.mb = mask_bstride; a.mi = mask_qstride;
   a.B = B; a.H = H; a.T1 = T1; a.T2 = T2; a.nqb = (T1 + 63) / 64; a.scale = scale;
+  a.Pd = (bf16_t*)Pd_bf16; a.drop_p = drop_p; a.drop_step = (const unsigned long long*)drop_step; a.drop_salt = drop_salt;
   const bool half = T2 <= 128;                                       // 8 key tiles instead of 16
   const size_t vbytes = (size_t)(half ? 128 : ATT_MAXK) * ATT_DK * sizeof(bf16_t);
   hipStream_t s = (hipStream_t)stream;
@@ -414,8 +446,10 @@ extern "C" int eamd_attn_fwd(const void* qu, int64_t ldq, const void* qv, int64_
 
 extern "C" int eamd_attn_bwd_q(const void* dctx, int64_t ldd, const void* k, int64_t ldk, const void* v, int64_t ldv,
                                const void* P_bf16, int64_t ldp, void* dS_bf16, void* dbd_bf16, void* dq, int64_t ldo,
-                               int dq_is_bf16, int B, int H, int T1, int T2, int dk, float scale, void* stream) {
+                               int dq_is_bf16, int B, int H, int T1, int T2, int dk, float scale, float drop_p,
+                               const uint64_t* drop_step, uint64_t drop_salt, void* stream) {
   if (!dctx || !k || !v || !P_bf16 || !dS_bf16 || !dq || B <= 0 || H <= 0 || T1 <= 0 || T2 <= 0) return EAMD_EINVAL;
+  if (drop_p < 0.f || drop_p >= 1.f || (drop_p > 0.f && !drop_step)) return EAMD_EINVAL;
   if (dk != ATT_DK || T2 > ATT_MAXK || (dbd_bf16 && T1 != T2)) return EAMD_EUNSUPPORTED;
   if (ldd % 8 || ldk % 8 || ldv % 8 || ldp % 8 || ldp < T2 || ldo % 4) return EAMD_EUNSUPPORTED;
   if (!al16(dctx) || !al16(k) || !al16(v) || !al16(P_bf16) || !al16(dS_bf16) ||
@@ -427,5 +461,6 @@ extern "C" int eamd_attn_bwd_q(const void* dctx, int64_t ldd, const void* k, int
   a.dS = (bf16_t*)dS_bf16; a.dbd = (bf16_t*)dbd_bf16; a.dq = dq;
   a.ldd = ldd; a.ldk = ldk; a.ldv = ldv; a.ldp = ldp; a.ldo = ldo;
   a.B = B; a.H = H; a.T1 = T1; a.T2 = T2; a.nqb = (T1 + 63) / 64; a.dq_bf16 = dq_is_bf16; a.scale = scale;
+  a.drop_p = drop_p; a.drop_step = (const unsigned long long*)drop_step; a.drop_salt = drop_salt;
   return T2 <= 128 ? launch_attn_bwd<8>(a, (hipStream_t)stream) : launch_attn_bwd<16>(a, (hipStream_t)stream);
 }

@@ -384,15 +384,16 @@ FUSE_ATTN = True   # tests flip this to compare against the GEMM / softmax / GEM
 ATTN_TAP = None    # a list while E2E.calculate_all_attentions runs: every attention block appends its probabilities
 
 
-def attn_fwd_fused(qu, qv, k, v, p, mask, B, T1, T2, H, dk):
-    """(P, ctx) from eamd_attn_fwd, or None when the library declines the operands"""
+def attn_fwd_fused(qu, qv, k, v, p, mask, B, T1, T2, H, dk, drop=None):
+    """(P, Pd, ctx) from eamd_attn_fwd, or None when the library declines the operands; drop = (p, salt): attention
+    dropout inside the kernel (Pd = dropout(P) is what the context is built from; Pd is P without dropout)"""
     qu, k, v = _mv(qu), _mv(k), _mv(v)
     qv3 = p3 = None
     if p is not None:
         qvm, pm = _mv(qv), _mv(p)
         qv3, p3 = (qvm.t, qvm.off, qvm.ld), (pm.t, pm.off, pm.ld)
     return ops.attn_fwd((qu.t, qu.off, qu.ld), qv3, (k.t, k.off, k.ld), (v.t, v.off, v.ld), p3, mask, B, T1, T2, H, dk,
-                        _ldp(T2), 1.0 / math.sqrt(dk))
+                        _ldp(T2), 1.0 / math.sqrt(dk), drop=drop)
 
 
 def attn_context_fwd(P, v, B, T1, T2, H, dk):
@@ -434,14 +435,14 @@ def attn_core_bwd(dctx, P, qu, qv, k, v, p, B, T1, T2, H, dk, Pd=None, attn_drop
              sB=(T1 * D, dk), sC=(T2 * ldo, dk), c_off=dv_off)                                            # P^T dctx
     dq_in_qkv = dqkv is not None and p is None     # no relative positions: dq is needed only as a GEMM operand
     dS = dbd = dqu = None
-    if FUSE_ATTN and Pd is None and P.dtype == adt and ops.attn_fwd_supported(T1, T2, dk, p is not None):
+    if FUSE_ATTN and P.dtype == adt and ops.attn_fwd_supported(T1, T2, dk, p is not None):
         # dP, softmax backward (+ inverse rel-shift scatter) and dq in one launch
         dS = torch.empty(H * B * T1 * ldp, device=dev, dtype=adt)
         dbd = torch.empty(H * B * T1 * ldp, device=dev, dtype=adt) if p is not None else None
         dqu = None if dq_in_qkv else torch.empty(B * T1, D, device=dev, dtype=torch.float32)
         dq_view = (dqkv, 0, ldo) if dq_in_qkv else (dqu, 0, D)
         if not ops.attn_bwd_q((dctx, 0, D), (k.t, k.off, k.ld), (v.t, v.off, v.ld), P, dS, dbd, dq_view, B, T1, T2, H, dk,
-                              ldp, 1.0 / math.sqrt(dk)):
+                              ldp, 1.0 / math.sqrt(dk), drop=attn_drop if Pd is not None else None):
             dS = None
     if dS is None:
         dP = torch.empty(H * B * T1 * ldp, device=dev, dtype=torch.float32)
@@ -683,11 +684,11 @@ class MHABlockFn(torch.autograd.Function):
         else:
             p, qu, qv = None, q, None
         fwd = None
-        if FUSE_ATTN and p_att <= 0.0 and ops.attn_fwd_supported(T1, T2, dk, rel):
-            fwd = attn_fwd_fused(qu, qv, k, v, p, mask, B, T1, T2, H, dk)      # scores, softmax and context in one launch
+        if FUSE_ATTN and ops.attn_fwd_supported(T1, T2, dk, rel):
+            # scores, softmax, attention dropout and context in one launch
+            fwd = attn_fwd_fused(qu, qv, k, v, p, mask, B, T1, T2, H, dk, drop=(p_att, s_att) if p_att > 0.0 else None)
         if fwd is not None:
-            P, cx = fwd
-            Pd = P
+            P, Pd, cx = fwd
         else:
             P = attn_scores_fwd(qu, qv, k, p, mask, B, T1, T2, H, dk)
             Pd = ops.dropout(P, p_att, s_att) if p_att > 0.0 else P

@@ -512,11 +512,12 @@ def attn_fwd_supported(T1, T2, dk, rel):
     return (fast() or F32_FUSED_ATTN) and dk == 64 and T2 <= 256 and (not rel or T1 == T2)
 
 
-def attn_fwd(qu, qv, k, v, pos, mask, B, T1, T2, H, dk, ldp, scale):
+def attn_fwd(qu, qv, k, v, pos, mask, B, T1, T2, H, dk, ldp, scale, drop=None):
     """qu / qv / k / v: (tensor, element offset, row stride) views of [rows, *] matrices, heads side by side, all bf16
     (eamd_attn_fwd) or all fp32 (eamd_attn_fwd_f32); pos: such a view of the [T2, H*dk] projected positions, or None.
-    Returns (P [H*B*T1*ldp], ctx [B*T1, H*dk]) in that dtype, or None if the library declines the operands
-    (EAMD_EUNSUPPORTED)."""
+    Returns (P [H*B*T1*ldp], Pd, ctx [B*T1, H*dk]) in that dtype, or None if the library declines the operands
+    (EAMD_EUNSUPPORTED).  drop = (p, salt): attention dropout - ctx is built from Pd = dropout(P) (same mask as
+    ops.dropout(P, p, salt)), which is returned beside the undropped P; without dropout Pd is P."""
     dev = qu[0].device
     dt = qu[0].dtype
     D = H * dk
@@ -532,11 +533,15 @@ def attn_fwd(qu, qv, k, v, pos, mask, B, T1, T2, H, dk, ldp, scale):
     assert pos is None or (pos[0].dtype == dt and pos[2] >= D)
     P = torch.empty(H * B * T1 * ldp, device=dev, dtype=dt)
     cx = torch.empty(B * T1, D, device=dev, dtype=dt)
+    dropping = drop is not None and drop[0] > 0.0
+    Pd = torch.empty_like(P) if dropping else P
+    dargs = ((ptr(Pd), C.c_float(drop[0]), ptr(rng_state(dev)), C.c_uint64(drop[1])) if dropping
+             else (None, C.c_float(0.0), None, C.c_uint64(0)))
     i64 = C.c_int64
     args = (ptr(qu[0], qu[1]), i64(qu[2]), ptr(qv[0], qv[1]) if qv is not None else None, i64(qv[2] if qv is not None else 0),
             ptr(k[0], k[1]), i64(k[2]), ptr(v[0], v[1]), i64(v[2]), ptr(pos[0], pos[1]) if pos is not None else None,
             i64(pos[2] if pos is not None else 0),
-            ptr(mask), i64(mb), i64(mi), ptr(P), i64(ldp), ptr(cx), i64(D), B, H, T1, T2, dk, C.c_float(scale))
+            ptr(mask), i64(mb), i64(mi), ptr(P), i64(ldp), ptr(cx), i64(D), B, H, T1, T2, dk, C.c_float(scale)) + dargs
     name = "eamd_attn_fwd" if dt == torch.bfloat16 else "eamd_attn_fwd_f32"
     fn = getattr(_lib.lib(), name)
     rc = fn(*args, stream_ptr())
@@ -544,26 +549,29 @@ def attn_fwd(qu, qv, k, v, pos, mask, B, T1, T2, H, dk, ldp, scale):
         return None
     check(rc, name)
     if _gemm_record is not None:
-        _gemm_record.append((None, (qu, qv, k, v, pos, mask, P, cx), lambda sp, args=args: check(fn(*args, sp), name)))
-    return P, cx
+        _gemm_record.append((None, (qu, qv, k, v, pos, mask, P, Pd, cx), lambda sp, args=args: check(fn(*args, sp), name)))
+    return P, Pd, cx
 
 
-def attn_bwd_q(dctx, k, v, P, dS, dbd, dq, B, T1, T2, H, dk, ldp, scale):
+def attn_bwd_q(dctx, k, v, P, dS, dbd, dq, B, T1, T2, H, dk, ldp, scale, drop=None):
     """dctx / k / v / dq: (tensor, element offset, row stride) views; P, dS (and dbd or None): [H*B*T1*ldp], bf16
     (eamd_attn_bwd_q; dq fp32 or bf16) or everything fp32 (eamd_attn_bwd_q_f32).
     dS, dbd and dq are written.  Returns False if the library declines the operands (EAMD_EUNSUPPORTED)."""
     i64 = C.c_int64
+    dropping = drop is not None and drop[0] > 0.0      # the forward's attention dropout: dP <- mask * dP / (1 - p)
+    dargs = ((C.c_float(drop[0]), ptr(rng_state(P.device)), C.c_uint64(drop[1])) if dropping
+             else (C.c_float(0.0), None, C.c_uint64(0)))
     if P.dtype == torch.bfloat16:
         name = "eamd_attn_bwd_q"
         args = (ptr(dctx[0], dctx[1]), i64(dctx[2]), ptr(k[0], k[1]), i64(k[2]), ptr(v[0], v[1]), i64(v[2]), ptr(P), i64(ldp),
                 ptr(dS), ptr(dbd), ptr(dq[0], dq[1]), i64(dq[2]), int(dq[0].dtype == torch.bfloat16), B, H, T1, T2, dk,
-                C.c_float(scale))
+                C.c_float(scale)) + dargs
     else:
         name = "eamd_attn_bwd_q_f32"
         for t_ in (dctx[0], k[0], v[0], P, dS, dq[0]) + ((dbd,) if dbd is not None else ()):
             assert t_.dtype == torch.float32
         args = (ptr(dctx[0], dctx[1]), i64(dctx[2]), ptr(k[0], k[1]), i64(k[2]), ptr(v[0], v[1]), i64(v[2]), ptr(P), i64(ldp),
-                ptr(dS), ptr(dbd), ptr(dq[0], dq[1]), i64(dq[2]), B, H, T1, T2, dk, C.c_float(scale))
+                ptr(dS), ptr(dbd), ptr(dq[0], dq[1]), i64(dq[2]), B, H, T1, T2, dk, C.c_float(scale)) + dargs
     fn = getattr(_lib.lib(), name)
     rc = fn(*args, stream_ptr())
     if rc == _lib.EAMD_EUNSUPPORTED:

@@ -175,11 +175,15 @@ int eamd_softmax_bwd(const float* P, const void* P_bf16, float* dP, float* dbd, 
  * shared by the batch).  qv / pos are both NULL (no relative positions) or both set (then T1 == T2).  mask as in
  * eamd_softmax_fwd.  Outputs: P_bf16 [H][B][T1][ldp] (pad columns zeroed; kept for the backward pass) and
  * ctx_bf16 (b, t, h, d) at ctx[(b*T1 + t)*ldc + h*64 + d].  EAMD_EUNSUPPORTED for other d_k / longer rows / unaligned
- * operands: callers then run the score GEMMs, eamd_softmax_fwd and the context GEMM instead. */
+ * operands: callers then run the score GEMMs, eamd_softmax_fwd and the context GEMM instead.
+ * Attention dropout (attention.py:91; drop_p > 0): ctx = dropout(P) v with the mask eamd_dropout draws for
+ * (drop_step, drop_salt) on the elements of P; P stays undropped (the softmax backward needs it) and the dropped
+ * probabilities are written to Pd_bf16 (same shape: the operand of dv = Pd^T dctx). */
 int eamd_attn_fwd(const void* qu, int64_t ldq, const void* qv, int64_t ldqv, const void* k, int64_t ldk, const void* v,
                   int64_t ldv, const void* pos, int64_t ldpos, const unsigned char* mask, int64_t mask_bstride,
                   int64_t mask_qstride, void* P_bf16, int64_t ldp, void* ctx_bf16, int64_t ldc, int B, int H, int T1,
-                  int T2, int dk, float scale, void* stream);
+                  int T2, int dk, float scale, void* Pd_bf16, float drop_p, const uint64_t* drop_step, uint64_t drop_salt,
+                  void* stream);
 
 /* Query side of the attention backward in one launch (same operand layouts and limits as eamd_attn_fwd):
  * dP = dctx v^T, dS = scale * P (dP - rowsum(P dP)) -> dS_bf16 [H][B][T1][ldp] (pad columns zeroed), its inverse
@@ -189,7 +193,8 @@ int eamd_attn_fwd(const void* qu, int64_t ldq, const void* qv, int64_t ldqv, con
  * from dbd) remain GEMMs over P / dS / dbd. */
 int eamd_attn_bwd_q(const void* dctx, int64_t ldd, const void* k, int64_t ldk, const void* v, int64_t ldv,
                     const void* P_bf16, int64_t ldp, void* dS_bf16, void* dbd_bf16, void* dq, int64_t ldo, int dq_is_bf16,
-                    int B, int H, int T1, int T2, int dk, float scale, void* stream);
+                    int B, int H, int T1, int T2, int dk, float scale, float drop_p, const uint64_t* drop_step,
+                    uint64_t drop_salt, void* stream);   /* drop_*: the forward's attention dropout (dP <- mask * dP / (1 - p)) */
 
 /* fp32 twins of eamd_attn_fwd / eamd_attn_bwd_q (the reference's precision; v_mfma_f32_16x16x4_f32): same operand
  * layouts, limits (d_k = 64, T2 <= 256, T1 == T2 with relative positions) and results, every tensor fp32: P, dS, dbd
@@ -198,10 +203,12 @@ int eamd_attn_bwd_q(const void* dctx, int64_t ldd, const void* k, int64_t ldk, c
 int eamd_attn_fwd_f32(const float* qu, int64_t ldq, const float* qv, int64_t ldqv, const float* k, int64_t ldk,
                       const float* v, int64_t ldv, const float* pos, int64_t ldpos, const unsigned char* mask,
                       int64_t mask_bstride, int64_t mask_qstride, float* P, int64_t ldp, float* ctx, int64_t ldc, int B,
-                      int H, int T1, int T2, int dk, float scale, void* stream);
+                      int H, int T1, int T2, int dk, float scale, float* Pd, float drop_p, const uint64_t* drop_step,
+                      uint64_t drop_salt, void* stream);
 int eamd_attn_bwd_q_f32(const float* dctx, int64_t ldd, const float* k, int64_t ldk, const float* v, int64_t ldv,
                         const float* P, int64_t ldp, float* dS, float* dbd, float* dq, int64_t ldo, int B, int H, int T1,
-                        int T2, int dk, float scale, void* stream);
+                        int T2, int dk, float scale, float drop_p, const uint64_t* drop_step, uint64_t drop_salt,
+                        void* stream);
 
 /* Label-smoothing KL loss rows + argmax-correct flags + gradient (softmax - true_dist)*inv_denom.
  * reference: transformer/label_smoothing_loss.py:44-63, nets_utils.py:299-319 (th_accuracy). */

@@ -1390,6 +1390,46 @@ def test_grouped_weight_gradients_match_separate_launches(prec):
            2e-4 if prec == "fp32" else 1e-3)
 
 
+@pytest.mark.parametrize("prec", ["fp32", "bf16"])
+def test_attention_dropout_in_model_fused_vs_unfused(prec):
+    """transformer-attn-dropout-rate > 0 (attention.py:91) through the whole model: the fused attention kernels apply the
+    dropout themselves (no fall-back to the GEMM / softmax / dropout / GEMM path any more) - same loss and gradient arena
+    as that path with the same masks"""
+    import espnet_amd
+    from espnet_amd import functional as F_
+    from espnet_amd import ops, train
+    from espnet_amd.nets.modules import MultiHeadedAttention
+    from conftest import e2e_dk64_model
+    g = load_golden("e2e_conformer_dk64.npz")
+    xs, ilens, ys = torch.from_numpy(g["xs"]).to(DEV), torch.from_numpy(g["ilens"]), torch.from_numpy(g["ys"]).to(DEV)
+    espnet_amd.set_precision(prec)
+    res = []
+    try:
+        model, _cfg = e2e_dk64_model(dropout=0.1)
+        n_att = 0
+        for m in model.modules():
+            if isinstance(m, MultiHeadedAttention):
+                m.dropout_rate = 0.15
+                n_att += 1
+        assert n_att >= 4
+        model = model.to(DEV).train()
+        flat = train.FlatParams(model)
+        for fuse in (True, False):
+            F_.FUSE_ATTN = fuse
+            flat.zero_grad()
+            ops.manual_seed(404)
+            loss = model(xs, ilens, ys)
+            loss.backward()
+            res.append((float(loss), flat.grad.clone()))
+    finally:
+        F_.FUSE_ATTN = True
+        espnet_amd.set_precision("fp32")
+    rel = abs(res[0][0] - res[1][0]) / abs(res[1][0])
+    print(f"[parity] {prec} attention dropout, fused vs unfused attention: loss {res[0][0]:.6f} vs {res[1][0]:.6f} (rel {rel:.2e})")
+    assert rel < (1e-6 if prec == "fp32" else 3e-3)
+    report("attention dropout fused vs unfused (%s): gradient arena" % prec, res[0][1], res[1][1], 3e-5 if prec == "fp32" else 3e-2)
+
+
 def test_bucketed_graph_step_matches_eager():
     """a stream of batches of two different shapes through train.BucketedGraphStep (eager on first sight, capture on
     the second, replay afterwards) against plain eager steps on the same padded batches with an identical second model:

@@ -852,7 +852,7 @@ def test_attention_forward_fused_matches_unfused(ops, case, prec):
             mask = mask.to(DEV)
         fused = F_.attn_fwd_fused(qu, qv, k, v, p, mask, B, T1, T2, H, dk)
         assert fused is not None
-        P1, c1 = fused
+        P1, _Pd, c1 = fused
         P0 = F_.attn_scores_fwd(qu, qv, k, p, mask, B, T1, T2, H, dk)
         c0 = F_.attn_context_fwd(P0, v, B, T1, T2, H, dk)
         ldp = F_._ldp(T2)
@@ -910,6 +910,59 @@ def test_attention_backward_fused_matches_unfused(ops, case, prec):
             assert (a is None) == (b is None), n
             if a is not None:
                 report("fused attention bwd %s %s %s" % (n, prec, case), a, b, tol)
+    finally:
+        F_.FUSE_ATTN = True
+        espnet_amd.set_precision("fp32")
+
+
+@pytest.mark.parametrize("case", [dict(B=3, T1=249, T2=249, rel=True), dict(B=2, T1=101, T2=249, rel=False),
+                                  dict(B=2, T1=65, T2=65, rel=True), dict(B=3, T1=101, T2=101, rel=False)])
+@pytest.mark.parametrize("prec", ["bf16", "fp32"])
+def test_attention_dropout_fused_matches_unfused(ops, case, prec):
+    """attention dropout (attention.py:91) INSIDE the fused kernels: the forward builds the context from
+    Pd = dropout(P) with the very mask eamd_dropout draws on P (same keep pattern as ops.dropout(P)), keeps P undropped
+    for the softmax backward, and eamd_attn_bwd_q masks dP the same way - against the GEMM / softmax / dropout / GEMM
+    path: context and every gradient agree to the mode's rounding"""
+    import espnet_amd
+    from espnet_amd import functional as F_
+    espnet_amd.set_precision(prec)
+    tol_f, tol_g = (6e-3, 8e-3) if prec == "bf16" else (3e-6, 1e-5)
+    try:
+        B, T1, T2, rel = case["B"], case["T1"], case["T2"], case["rel"]
+        H, dk = 4, 64
+        D = H * dk
+        g = torch.Generator().manual_seed(T1 * 13 + T2)
+        bf = lambda *s: (0.5 * torch.randn(*s, generator=g)).to(torch.bfloat16).to(ops.act_dtype()).to(DEV)
+        qu, k, v = bf(B * T1, D), bf(B * T2, D), bf(B * T2, D)
+        qv = bf(B * T1, D) if rel else None
+        p = bf(T2, D) if rel else None
+        lens = torch.linspace(T2, max(1, T2 // 2), B).long()
+        mask = (torch.arange(T2)[None, :] < lens[:, None]).to(torch.uint8).view(B, 1, T2).contiguous().to(DEV)
+        drop = (0.2, 90210)
+        ops.manual_seed(5)
+        P1, Pd1, c1 = F_.attn_fwd_fused(qu, qv, k, v, p, mask, B, T1, T2, H, dk, drop=drop)
+        P0 = F_.attn_scores_fwd(qu, qv, k, p, mask, B, T1, T2, H, dk)
+        Pd0 = ops.dropout(P0, *drop)
+        c0 = F_.attn_context_fwd(Pd0, v, B, T1, T2, H, dk)
+        ldp = F_._ldp(T2)
+        view = lambda t: t.view(H, B, T1, ldp)[..., :T2].float()
+        report("attention dropout: P %s %s" % (prec, case), view(P1), view(P0), tol_f)
+        nz = view(P0) > 1e-4            # where the probability itself is not (near) zero the keep pattern must be identical
+        assert torch.equal((view(Pd1) != 0)[nz], (view(Pd0) != 0)[nz])
+        kept = float((view(Pd1) != 0)[nz].float().mean())
+        assert abs(kept - 0.8) < 0.02, kept
+        report("attention dropout: Pd %s %s" % (prec, case), view(Pd1), view(Pd0), tol_f)
+        report("attention dropout: ctx %s %s" % (prec, case), c1.float(), c0.float(), tol_f)
+        dctx = bf(B * T1, D)
+        outs = {}
+        for fuse in (True, False):
+            F_.FUSE_ATTN = fuse
+            r = F_.attn_core_bwd(dctx, P0.clone(), qu, qv, k, v, p, B, T1, T2, H, dk, Pd=Pd0, attn_drop=drop)
+            outs[fuse] = [None if x is None else x.float().clone() for x in r]
+        for n, a, b in zip(("dqu", "dqv", "dk", "dv", "dpos"), outs[True], outs[False]):
+            assert (a is None) == (b is None), n
+            if a is not None:
+                report("attention dropout bwd %s %s %s" % (n, prec, case), a, b, tol_g)
     finally:
         F_.FUSE_ATTN = True
         espnet_amd.set_precision("fp32")
@@ -979,7 +1032,7 @@ def test_attention_fused_vs_oracle(ops, oracle, case, prec):
         assert ops.attn_fwd_supported(T1, T2, dk, rel)
         fused = F_.attn_fwd_fused(qu, qv, k, v, p, mask, B, T1, T2, H, dk)
         assert fused is not None, "eamd_attn_fwd declined the config-2 operand layout"
-        P1, c1 = fused
+        P1, _Pd, c1 = fused
         assert P1.dtype == c1.dtype == ops.act_dtype()
         dctx = bf(B * T1, D)
         F_.FUSE_ATTN = True
