@@ -31,7 +31,7 @@
 namespace {
 
 constexpr int ATT_DK = 64;
-constexpr int ATT_MAXK = 256;                 // keys per row (16 accumulator tiles of 16)
+constexpr int ATT_MAXK = 512;                 // keys per row: 8 / 16 key tiles of 16 at two workgroups per CU, 32 at one (LDS)
 constexpr int PLD = 68;                       // row stride (floats) of the V / K panel in LDS
 
 struct AttnF32Args {
@@ -135,7 +135,7 @@ __device__ __forceinline__ void score_tiles(const float* keys, long ldk, int T2,
 // NKT = key tiles of 16 the instantiation covers (T2 <= 16 NKT).  Loops over tiles are fully unrolled and free of
 // branches: rows past T2 / T1 are clamped re-reads whose scores are masked / never stored.
 template <bool REL, int NKT>
-__global__ __launch_bounds__(256, 2) void attn_f32_fwd_kernel(const AttnF32Args a) {
+__global__ __launch_bounds__(256, NKT > 16 ? 1 : 2) void attn_f32_fwd_kernel(const AttnF32Args a) {
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
   constexpr int XLD = NKT * 16 + 4;
   constexpr int TPW = NKT / 4;
@@ -183,16 +183,18 @@ __global__ __launch_bounds__(256, 2) void attn_f32_fwd_kernel(const AttnF32Args 
       }
     }
     const int i64 = r0w + 64;                        // first query of the next workgroup: its low positions feed query r0w + 63
-    if (live && i64 < T1 && t <= T2 - 2 - i64) {
+    if (live && i64 < T1) {
       const float4* qr = reinterpret_cast<const float4*>(a.qv + ((long)b * T1 + i64) * a.ldqv + h * ATT_DK);
-      const float4* pr = reinterpret_cast<const float4*>(a.pos + (long)t * a.ldpos + h * ATT_DK);
-      float s = 0.f;
+      for (int m = t; m <= T2 - 2 - i64; m += 256) {
+        const float4* pr = reinterpret_cast<const float4*>(a.pos + (long)m * a.ldpos + h * ATT_DK);
+        float s = 0.f;
 #pragma unroll
-      for (int j = 0; j < 16; ++j) {
-        const float4 x = qr[j], y = pr[j];
-        s += x.x * y.x + x.y * y.y + x.z * y.z + x.w * y.w;
+        for (int j = 0; j < 16; ++j) {
+          const float4 x = qr[j], y = pr[j];
+          s += x.x * y.x + x.y * y.y + x.z * y.z + x.w * y.w;
+        }
+        X[63 * XLD + m + i64 + 1] = s;
       }
-      X[63 * XLD + t + i64 + 1] = s;
     }
     __syncthreads();
   }
@@ -312,7 +314,7 @@ struct AttnF32BwdArgs {
 };
 
 template <int NKT>
-__global__ __launch_bounds__(256, 2) void attn_f32_bwd_q_kernel(const AttnF32BwdArgs a) {
+__global__ __launch_bounds__(256, NKT > 16 ? 1 : 2) void attn_f32_bwd_q_kernel(const AttnF32BwdArgs a) {
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
   constexpr int XLD = NKT * 16 + 4;
   const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
@@ -421,7 +423,7 @@ __global__ __launch_bounds__(256, 2) void attn_f32_bwd_q_kernel(const AttnF32Bwd
 template <bool REL, int NKT>
 int launch_fwd(const AttnF32Args& a, size_t smem, hipStream_t stream) {
   static const hipError_t attr_err = hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_f32_fwd_kernel<REL, NKT>),
-                                                         hipFuncAttributeMaxDynamicSharedMemorySize, 72 * 1024);
+                                                         hipFuncAttributeMaxDynamicSharedMemorySize, NKT * 16 * PLD * 4);
   if (attr_err != hipSuccess) return (int)attr_err;
   const int nz = (a.B * a.H + 7) / 8 * 8;
   hipLaunchKernelGGL((attn_f32_fwd_kernel<REL, NKT>), dim3((unsigned)(a.nqb * nz)), dim3(256), smem, stream, a);
@@ -432,7 +434,7 @@ int launch_fwd(const AttnF32Args& a, size_t smem, hipStream_t stream) {
 template <int NKT>
 int launch_bwd(const AttnF32BwdArgs& a, hipStream_t stream) {
   static const hipError_t attr_err = hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_f32_bwd_q_kernel<NKT>),
-                                                         hipFuncAttributeMaxDynamicSharedMemorySize, 72 * 1024);
+                                                         hipFuncAttributeMaxDynamicSharedMemorySize, NKT * 16 * PLD * 4);
   if (attr_err != hipSuccess) return (int)attr_err;
   const int nz = (a.B * a.H + 7) / 8 * 8;
   hipLaunchKernelGGL((attn_f32_bwd_q_kernel<NKT>), dim3((unsigned)(a.nqb * nz)), dim3(256),
@@ -465,11 +467,11 @@ extern "C" int eamd_attn_fwd_f32(const float* qu, int64_t ldq, const float* qv, 
   a.mb = mask_bstride; a.mi = mask_qstride;
   a.B = B; a.H = H; a.T1 = T1; a.T2 = T2; a.nqb = (T1 + 63) / 64; a.scale = scale;
   a.Pd = Pd; a.drop_p = drop_p; a.drop_step = (const unsigned long long*)drop_step; a.drop_salt = drop_salt;
-  const bool half = T2 <= 128;                                       // 8 key tiles instead of 16
-  const size_t smem = (size_t)(half ? 128 : ATT_MAXK) * PLD * sizeof(float);      // V panel (the score matrix X is smaller)
+  const int nkt = T2 <= 128 ? 8 : T2 <= 256 ? 16 : 32;               // key tiles of 16 the instantiation covers
+  const size_t smem = (size_t)nkt * 16 * PLD * sizeof(float);        // V panel (the score matrix X is smaller)
   hipStream_t s = (hipStream_t)stream;
-  if (pos) return half ? launch_fwd<true, 8>(a, smem, s) : launch_fwd<true, 16>(a, smem, s);
-  return half ? launch_fwd<false, 8>(a, smem, s) : launch_fwd<false, 16>(a, smem, s);
+  if (pos) return nkt == 8 ? launch_fwd<true, 8>(a, smem, s) : nkt == 16 ? launch_fwd<true, 16>(a, smem, s) : launch_fwd<true, 32>(a, smem, s);
+  return nkt == 8 ? launch_fwd<false, 8>(a, smem, s) : nkt == 16 ? launch_fwd<false, 16>(a, smem, s) : launch_fwd<false, 32>(a, smem, s);
 }
 
 extern "C" int eamd_attn_bwd_q_f32(const float* dctx, int64_t ldd, const float* k, int64_t ldk, const float* v, int64_t ldv,
@@ -487,5 +489,6 @@ extern "C" int eamd_attn_bwd_q_f32(const float* dctx, int64_t ldd, const float* 
   a.ldd = ldd; a.ldk = ldk; a.ldv = ldv; a.ldp = ldp; a.ldo = ldo;
   a.B = B; a.H = H; a.T1 = T1; a.T2 = T2; a.nqb = (T1 + 63) / 64; a.scale = scale;
   a.drop_p = drop_p; a.drop_step = (const unsigned long long*)drop_step; a.drop_salt = drop_salt;
-  return T2 <= 128 ? launch_bwd<8>(a, (hipStream_t)stream) : launch_bwd<16>(a, (hipStream_t)stream);
+  return T2 <= 128 ? launch_bwd<8>(a, (hipStream_t)stream) : T2 <= 256 ? launch_bwd<16>(a, (hipStream_t)stream)
+                                                                         : launch_bwd<32>(a, (hipStream_t)stream);
 }

@@ -22,7 +22,7 @@
 namespace {
 
 constexpr int ATT_DK = 64;
-constexpr int ATT_MAXK = 256;                 // keys per row (16 accumulator tiles of 16)
+constexpr int ATT_MAXK = 512;                 // keys per row: 8 / 16 / 32 accumulator tiles of 16 (32: one workgroup per CU)
 
 struct AttnArgs {
   const bf16_t* qu; const bf16_t* qv; const bf16_t* k; const bf16_t* v; const bf16_t* pos;
@@ -250,7 +250,7 @@ struct AttnBwdArgs {
 };
 
 template <int NKT>
-__global__ __launch_bounds__(256, 2) void attn_bwd_q_kernel(const AttnBwdArgs a) {
+__global__ __launch_bounds__(256, NKT > 16 ? 1 : 2) void attn_bwd_q_kernel(const AttnBwdArgs a) {
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
   const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
   const int fr = lane & 15, fq = lane >> 4;
@@ -399,7 +399,7 @@ int launch_attn_bwd(const AttnBwdArgs& a, hipStream_t stream) {
 template <bool REL, int NKT>
 int launch_attn(const AttnArgs& a, size_t smem, hipStream_t stream) {
   static const hipError_t attr_err = hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_fwd_kernel<REL, NKT>),
-                                                         hipFuncAttributeMaxDynamicSharedMemorySize, 72 * 1024);
+                                                         hipFuncAttributeMaxDynamicSharedMemorySize, NKT > 16 ? 144 * 1024 : 72 * 1024);
   if (attr_err != hipSuccess) return (int)attr_err;
   const int nz = (a.B * a.H + 7) / 8 * 8;
   hipLaunchKernelGGL((attn_fwd_kernel<REL, NKT>), dim3((unsigned)(a.nqb * nz)), dim3(256), smem, stream, a);
@@ -433,15 +433,16 @@ extern "C" int eamd_attn_fwd(const void* qu, int64_t ldq, const void* qv, int64_
   a.mb = mask_bstride; a.mi = mask_qstride;
   a.B = B; a.H = H; a.T1 = T1; a.T2 = T2; a.nqb = (T1 + 63) / 64; a.scale = scale;
   a.Pd = (bf16_t*)Pd_bf16; a.drop_p = drop_p; a.drop_step = (const unsigned long long*)drop_step; a.drop_salt = drop_salt;
-  const bool half = T2 <= 128;                                       // 8 key tiles instead of 16
-  const size_t vbytes = (size_t)(half ? 128 : ATT_MAXK) * ATT_DK * sizeof(bf16_t);
+  const int nkt = T2 <= 128 ? 8 : T2 <= 256 ? 16 : 32;               // key tiles of 16 the instantiation covers
+  const size_t vbytes = (size_t)nkt * 16 * ATT_DK * sizeof(bf16_t);
   hipStream_t s = (hipStream_t)stream;
   if (pos) {
     const size_t pbytes = (size_t)4 * 17 * (T2 + 1) * sizeof(float);
     const size_t smem = pbytes > vbytes ? pbytes : vbytes;
-    return half ? launch_attn<true, 8>(a, smem, s) : launch_attn<true, 16>(a, smem, s);
+    return nkt == 8 ? launch_attn<true, 8>(a, smem, s) : nkt == 16 ? launch_attn<true, 16>(a, smem, s) : launch_attn<true, 32>(a, smem, s);
   }
-  return half ? launch_attn<false, 8>(a, vbytes, s) : launch_attn<false, 16>(a, vbytes, s);
+  return nkt == 8 ? launch_attn<false, 8>(a, vbytes, s) : nkt == 16 ? launch_attn<false, 16>(a, vbytes, s)
+                                                                     : launch_attn<false, 32>(a, vbytes, s);
 }
 
 extern "C" int eamd_attn_bwd_q(const void* dctx, int64_t ldd, const void* k, int64_t ldk, const void* v, int64_t ldv,
@@ -462,5 +463,6 @@ extern "C" int eamd_attn_bwd_q(const void* dctx, int64_t ldd, const void* k, int
   a.ldd = ldd; a.ldk = ldk; a.ldv = ldv; a.ldp = ldp; a.ldo = ldo;
   a.B = B; a.H = H; a.T1 = T1; a.T2 = T2; a.nqb = (T1 + 63) / 64; a.dq_bf16 = dq_is_bf16; a.scale = scale;
   a.drop_p = drop_p; a.drop_step = (const unsigned long long*)drop_step; a.drop_salt = drop_salt;
-  return T2 <= 128 ? launch_attn_bwd<8>(a, (hipStream_t)stream) : launch_attn_bwd<16>(a, (hipStream_t)stream);
+  return T2 <= 128 ? launch_attn_bwd<8>(a, (hipStream_t)stream) : T2 <= 256 ? launch_attn_bwd<16>(a, (hipStream_t)stream)
+                                                                             : launch_attn_bwd<32>(a, (hipStream_t)stream);
 }

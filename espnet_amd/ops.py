@@ -509,7 +509,7 @@ F32_FUSED_ATTN = True   # fp32 mode: eamd_attn_fwd_f32 / eamd_attn_bwd_q_f32 (te
 
 def attn_fwd_supported(T1, T2, dk, rel):
     """shapes the fused attention forward (eamd_attn_fwd) covers; alignment is checked by the library"""
-    return (fast() or F32_FUSED_ATTN) and dk == 64 and T2 <= 256 and (not rel or T1 == T2)
+    return (fast() or F32_FUSED_ATTN) and dk == 64 and T2 <= 512 and (not rel or T1 == T2)
 
 
 def attn_fwd(qu, qv, k, v, pos, mask, B, T1, T2, H, dk, ldp, scale, drop=None):

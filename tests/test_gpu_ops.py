@@ -995,7 +995,9 @@ def _oracle_attention(oracle, qu, qv, k, v, p, mask, dctx, B, T1, T2, H, dk):
     dict(B=3, T1=249, T2=249, rel=True, mask="len"), dict(B=2, T1=101, T2=101, rel=False, mask="causal"),
     dict(B=2, T1=101, T2=249, rel=False, mask="len"), dict(B=2, T1=1, T2=77, rel=False, mask="len"),
     dict(B=3, T1=64, T2=64, rel=True, mask="dead"), dict(B=2, T1=30, T2=30, rel=True, mask=None),
-    dict(B=2, T1=64, T2=16, rel=False, mask="dead")])
+    dict(B=2, T1=64, T2=16, rel=False, mask="dead"),
+    dict(B=2, T1=374, T2=374, rel=True, mask="len"), dict(B=1, T1=512, T2=512, rel=True, mask=None),     # 32 key tiles (config 5: T' = 374)
+    dict(B=2, T1=101, T2=500, rel=False, mask="len")])
 @pytest.mark.parametrize("prec", ["bf16", "fp32"])
 def test_attention_fused_vs_oracle(ops, oracle, case, prec):
     """The kernels bench.py dispatches at config 2 (eamd_attn_fwd / eamd_attn_bwd_q: H = 4, d_k = 64, T2 <= 256)
