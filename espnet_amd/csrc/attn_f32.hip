@@ -492,3 +492,143 @@ extern "C" int eamd_attn_bwd_q_f32(const float* dctx, int64_t ldd, const float* 
   return T2 <= 128 ? launch_bwd<8>(a, (hipStream_t)stream) : T2 <= 256 ? launch_bwd<16>(a, (hipStream_t)stream)
                                                                          : launch_bwd<32>(a, (hipStream_t)stream);
 }
+
+// ---- backward, key side: dV = Pd^T dctx, dK = dS^T qu and (relative positions) dpos += dbd^T qv in one launch ----
+// One workgroup = one (batch, head) pair x 64 keys; wave w owns keys 16 w .. 16 w + 15 and all 64 channels, and the
+// workgroup walks the queries in blocks of 64.  Both operands of a product come from row-major global tensors whose
+// rows are the CONTRACTED index (queries): a [64 queries][64 keys] tile of Pd / dS / dbd and a [64 queries][64 channels]
+// tile of dctx / qu / qv are staged in LDS with coalesced 16-byte loads and read back as MFMA operands along the
+// query axis (ds_read_b32: lane (fr, fq) takes element [4 kk + fq][.. + fr]; row stride 80 floats keeps the four fq
+// groups on disjoint banks).  The result is accumulated transposed, out^T[channel][key], so that a lane ends up with
+// four adjacent channels of one key (16-byte stores).  The next pair of tiles is prefetched into registers while the
+// current one feeds the matrix cores.  Replaces three batched GEMMs per layer (two without relative positions).
+// reference: autograd of attention.py:63-114 (dv, dk), :141-206 (the positional term).
+namespace {
+
+constexpr int KLD = 80;
+
+struct AttnF32KvArgs {
+  const float* Pd; const float* dS; const float* dbd;
+  const float* dctx; const float* qu; const float* qv;
+  float* dv; float* dk; float* dpos;
+  long ldp, ldd, ldq, ldqv, ldo, ldpos;
+  int B, H, T1, T2, nkb;
+};
+
+// rows i0 .. i0 + 63 of a [T1][ld] matrix, 64 columns from column c0 on: global -> registers; rows past T1 and
+// column chunks past `ncol` (the row length that exists) are zero
+__device__ __forceinline__ void kv_tile_load(const float* src, long ld, int i0, int T1, int c0, int ncol, int t, float4 (&r)[4]) {
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    const int c = t + 256 * q, row = c >> 4, c4 = c & 15;
+    const bool ok = i0 + row < T1 && c0 + c4 * 4 < ncol;
+    r[q] = *reinterpret_cast<const float4*>(src + (long)min(i0 + row, T1 - 1) * ld + (ok ? c0 + c4 * 4 : 0));
+    if (!ok) r[q] = make_float4(0.f, 0.f, 0.f, 0.f);
+  }
+}
+__device__ __forceinline__ void kv_tile_store(const float4 (&r)[4], float* dst, int t) {
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    const int c = t + 256 * q, row = c >> 4, c4 = c & 15;
+    *reinterpret_cast<float4*>(&dst[row * KLD + c4 * 4]) = r[q];
+  }
+}
+// acc^T[channel tile ct][key tile of this wave] += X[query][channel]^T  W[query][key]
+__device__ __forceinline__ void kv_product(const float* Xc, const float* Wk, int wave, int fr, int fq, f32x4 (&acc)[4]) {
+#pragma unroll
+  for (int kk = 0; kk < 16; ++kk) {
+    const int i = 4 * kk + fq;
+    const float b = Wk[i * KLD + wave * 16 + fr];
+#pragma unroll
+    for (int ct = 0; ct < 4; ++ct)
+      acc[ct] = __builtin_amdgcn_mfma_f32_16x16x4f32(Xc[i * KLD + ct * 16 + fr], b, acc[ct], 0, 0, 0);
+  }
+}
+
+template <bool REL>
+__global__ __launch_bounds__(256, 2) void attn_f32_bwd_kv_kernel(const AttnF32KvArgs a) {
+  __shared__ __attribute__((aligned(16))) float sW[64 * KLD];     // [query][key] tile
+  __shared__ __attribute__((aligned(16))) float sX[64 * KLD];     // [query][channel] tile
+  const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+  const int fr = lane & 15, fq = lane >> 4;
+  const int xcd = blockIdx.x & 7, jb = blockIdx.x >> 3;
+  const int z = (jb / a.nkb) * 8 + xcd;            // z = h * B + b
+  if (z >= a.B * a.H) return;                      // whole workgroup
+  const int h = z / a.B, b = z % a.B;
+  const int T1 = a.T1, T2 = a.T2;
+  const int j0 = (jb % a.nkb) * 64;                // first key of the workgroup
+  const long zo = (long)z * T1 * a.ldp;
+  const float* Wsrc[3] = {a.Pd + zo, a.dS + zo, REL ? a.dbd + zo : nullptr};
+  const float* Xsrc[3] = {a.dctx + (long)b * T1 * a.ldd + h * ATT_DK, a.qu + (long)b * T1 * a.ldq + h * ATT_DK,
+                          REL ? a.qv + (long)b * T1 * a.ldqv + h * ATT_DK : nullptr};
+  const long Xld[3] = {a.ldd, a.ldq, a.ldqv};
+  constexpr int NP = REL ? 3 : 2;
+  f32x4 acc[NP][4];
+#pragma unroll
+  for (int p = 0; p < NP; ++p)
+#pragma unroll
+    for (int ct = 0; ct < 4; ++ct) acc[p][ct] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  const int nstage = ((T1 + 63) / 64) * NP;
+  float4 rw[4], rx[4];
+  kv_tile_load(Wsrc[0], a.ldp, 0, T1, j0, (int)a.ldp, t, rw);
+  kv_tile_load(Xsrc[0], Xld[0], 0, T1, 0, 64, t, rx);
+  for (int s = 0; s < nstage; ++s) {
+    const int p = s % NP;
+    __syncthreads();                               // the previous stage's reads are done
+    kv_tile_store(rw, sW, t);
+    kv_tile_store(rx, sX, t);
+    __syncthreads();
+    if (s + 1 < nstage) {                          // next pair of tiles: in flight under the MFMAs
+      const int pn = (s + 1) % NP, i0 = (s + 1) / NP * 64;
+      if (pn == 0) { kv_tile_load(Wsrc[0], a.ldp, i0, T1, j0, (int)a.ldp, t, rw); kv_tile_load(Xsrc[0], Xld[0], i0, T1, 0, 64, t, rx); }
+      else if (pn == 1) { kv_tile_load(Wsrc[1], a.ldp, i0, T1, j0, (int)a.ldp, t, rw); kv_tile_load(Xsrc[1], Xld[1], i0, T1, 0, 64, t, rx); }
+      else if (REL) { kv_tile_load(Wsrc[2], a.ldp, i0, T1, j0, (int)a.ldp, t, rw); kv_tile_load(Xsrc[2], Xld[2], i0, T1, 0, 64, t, rx); }
+    }
+    if (p == 0) kv_product(sX, sW, wave, fr, fq, acc[0]);
+    else if (p == 1) kv_product(sX, sW, wave, fr, fq, acc[1]);
+    else if (REL) kv_product(sX, sW, wave, fr, fq, acc[NP - 1]);
+  }
+  const int j = j0 + wave * 16 + fr;               // this lane's key; acc[.][ct][r] = channel 16 ct + 4 fq + r
+  if (j < T2) {
+    float* vrow = a.dv + ((long)b * T2 + j) * a.ldo + h * ATT_DK + 4 * fq;
+    float* krow = a.dk + ((long)b * T2 + j) * a.ldo + h * ATT_DK + 4 * fq;
+#pragma unroll
+    for (int ct = 0; ct < 4; ++ct) {
+      *reinterpret_cast<float4*>(vrow + ct * 16) = make_float4(acc[0][ct][0], acc[0][ct][1], acc[0][ct][2], acc[0][ct][3]);
+      *reinterpret_cast<float4*>(krow + ct * 16) = make_float4(acc[1][ct][0], acc[1][ct][1], acc[1][ct][2], acc[1][ct][3]);
+    }
+    if (REL) {                                     // positions are shared by the batch: accumulate
+      float* prow = a.dpos + (long)j * a.ldpos + h * ATT_DK + 4 * fq;
+#pragma unroll
+      for (int ct = 0; ct < 4; ++ct)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) atomicAdd(prow + ct * 16 + r, acc[NP - 1][ct][r]);
+    }
+  }
+}
+
+}  // namespace
+
+extern "C" int eamd_attn_bwd_kv_f32(const float* Pd, const float* dS, const float* dbd, int64_t ldp, const float* dctx,
+                                    int64_t ldd, const float* qu, int64_t ldq, const float* qv, int64_t ldqv, float* dv,
+                                    float* dk_out, int64_t ldo, float* dpos, int64_t ldpos, int B, int H, int T1, int T2, int dk,
+                                    void* stream) {
+  if (!Pd || !dS || !dctx || !qu || !dv || !dk_out || B <= 0 || H <= 0 || T1 <= 0 || T2 <= 0) return EAMD_EINVAL;
+  if ((dbd == nullptr) != (qv == nullptr) || (dbd == nullptr) != (dpos == nullptr)) return EAMD_EINVAL;
+  if (dk != ATT_DK || (dbd && T1 != T2)) return EAMD_EUNSUPPORTED;
+  if (ldp % 4 || ldp < T2 || ldd % 4 || ldq % 4 || ldo % 4 || (dbd && (ldqv % 4 || ldpos % 4))) return EAMD_EUNSUPPORTED;
+  if (!al16(Pd) || !al16(dS) || !al16(dctx) || !al16(qu) || !al16(dv) || !al16(dk_out) ||
+      (dbd && (!al16(dbd) || !al16(qv) || !al16(dpos))))
+    return EAMD_EUNSUPPORTED;
+  AttnF32KvArgs a;
+  a.Pd = Pd; a.dS = dS; a.dbd = dbd; a.dctx = dctx; a.qu = qu; a.qv = qv; a.dv = dv; a.dk = dk_out; a.dpos = dpos;
+  a.ldp = ldp; a.ldd = ldd; a.ldq = ldq; a.ldqv = ldqv; a.ldo = ldo; a.ldpos = ldpos;
+  a.B = B; a.H = H; a.T1 = T1; a.T2 = T2; a.nkb = (T2 + 63) / 64;
+  if ((long)B * H * a.nkb >= (1L << 28)) return EAMD_EUNSUPPORTED;
+  const int nz = (B * H + 7) / 8 * 8;
+  hipStream_t s = (hipStream_t)stream;
+  if (dbd) hipLaunchKernelGGL((attn_f32_bwd_kv_kernel<true>), dim3((unsigned)(a.nkb * nz)), dim3(256), 0, s, a);
+  else hipLaunchKernelGGL((attn_f32_bwd_kv_kernel<false>), dim3((unsigned)(a.nkb * nz)), dim3(256), 0, s, a);
+  EAMD_LAUNCH_CHECK();
+  return EAMD_OK;
+}

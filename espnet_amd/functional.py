@@ -431,8 +431,12 @@ def attn_core_bwd(dctx, P, qu, qv, k, v, p, B, T1, T2, H, dk, Pd=None, attn_drop
     else:
         ldo = 3 * D
         dv, dv_off, dkk, dk_off = dqkv, 2 * D, dqkv, D
-    ops.gemm(Pd if Pd is not None else P, dctx, dv, T2, dk, T1, ldp, D, ldo, transA=1, transB=1, batch=(B, H), sA=sP,
-             sB=(T1 * D, dk), sC=(T2 * ldo, dk), c_off=dv_off)                                            # P^T dctx
+    # fp32 mode: the key-side products (dv, dk, dpos) are ONE launch behind the query side (eamd_attn_bwd_kv_f32)
+    kv_try = kv_fused = FUSE_ATTN and ops.F32_FUSED_ATTN_KV and adt == torch.float32 and P.dtype == torch.float32 \
+        and dk == 64 and dctx.dtype == torch.float32
+    if not kv_fused:
+        ops.gemm(Pd if Pd is not None else P, dctx, dv, T2, dk, T1, ldp, D, ldo, transA=1, transB=1, batch=(B, H), sA=sP,
+                 sB=(T1 * D, dk), sC=(T2 * ldo, dk), c_off=dv_off)                                        # P^T dctx
     dq_in_qkv = dqkv is not None and p is None     # no relative positions: dq is needed only as a GEMM operand
     dS = dbd = dqu = None
     if FUSE_ATTN and P.dtype == adt and ops.attn_fwd_supported(T1, T2, dk, p is not None):
@@ -465,20 +469,31 @@ def attn_core_bwd(dctx, P, qu, qv, k, v, p, B, T1, T2, H, dk, Pd=None, attn_drop
             dqu = torch.empty(B * T1, D, device=dev, dtype=torch.float32)
             ops.gemm(dS, k.t, dqu, T1, dk, T2, ldp, k.ld, D, transB=1, batch=(B, H), sA=sP, sB=(T2 * k.ld, dk),
                      sC=(T1 * D, dk), b_off=k.off)
-    ops.gemm(dS, qu.t, dkk, T2, dk, T1, ldp, qu.ld, ldo, transA=1, transB=1, batch=(B, H), sA=sP, sB=(T1 * qu.ld, dk),
-             sC=(T2 * ldo, dk), b_off=qu.off, c_off=dk_off)
-    dqv = dp = None
+    dqv = dp = dpt = None
     if p is not None:
         pm = _mv(p)
         dqv = torch.empty(B * T1, D, device=dev, dtype=torch.float32)
         ops.gemm(dbd, pm.t, dqv, T1, dk, T2, ldp, pm.ld, D, transB=1, batch=(B, H), sA=sP, sB=(0, dk), sC=(T1 * D, dk),
                  b_off=pm.off)
-        # dp[j, h, :] = sum_{b,i} dbd[h, b, i, j] * qv[b, i, h, :]   (reduction over B*T1 rows, split-K)
         if dp_out is None:
             dp = torch.zeros(T2, D, device=dev, dtype=torch.float32)
             dpt, dp_off, ldd = dp, 0, D
         else:
             dpt, dp_off, ldd = dp_out.t, dp_out.off, dp_out.ld
+    if kv_fused:
+        # dv and dk in one launch.  (The kernel can also accumulate dpos += dbd^T qv - eamd_attn_bwd_kv_f32 with dbd / qv /
+        # dpos set - but that product reduces over the BATCH too: 32-way contended atomics made it slower than the
+        # split-K GEMM below, measured 133.6 vs 133.2 us for the whole backward; it is left to the GEMM.)
+        kv_fused = ops.attn_bwd_kv(Pd if Pd is not None else P, dS, None, (dctx, 0, D), (qu.t, qu.off, qu.ld), None,
+                                   (dv, dv_off, ldo), (dkk, dk_off, ldo), None, B, T1, T2, H, dk, ldp)
+    if not kv_fused:
+        if kv_try:       # the library declined the operands: dv was skipped above
+            ops.gemm(Pd if Pd is not None else P, dctx, dv, T2, dk, T1, ldp, D, ldo, transA=1, transB=1, batch=(B, H), sA=sP,
+                     sB=(T1 * D, dk), sC=(T2 * ldo, dk), c_off=dv_off)
+        ops.gemm(dS, qu.t, dkk, T2, dk, T1, ldp, qu.ld, ldo, transA=1, transB=1, batch=(B, H), sA=sP, sB=(T1 * qu.ld, dk),
+                 sC=(T2 * ldo, dk), b_off=qu.off, c_off=dk_off)
+    if p is not None:
+        # dp[j, h, :] = sum_{b,i} dbd[h, b, i, j] * qv[b, i, h, :]   (reduction over B*T1 rows, split-K)
         ops.gemm(dbd, qv, dpt, T2, dk, B * T1, ldp, D, ldd, transA=1, transB=1, batch=(1, H),
                  sA=(0, B * T1 * ldp), sB=(0, dk), sC=(0, dk), c_off=dp_off,
                  splitk=max(2, ops.auto_splitk(T2, dk, B * T1) // H + 1))

@@ -210,6 +210,16 @@ int eamd_attn_bwd_q_f32(const float* dctx, int64_t ldd, const float* k, int64_t 
                         int T2, int dk, float scale, float drop_p, const uint64_t* drop_step, uint64_t drop_salt,
                         void* stream);
 
+/* Key side of the attention backward in one launch (fp32 tensors, d_k = 64; any T1 / T2): dv = Pd^T dctx, dk = dS^T qu and,
+ * with relative positions (dbd, qv, dpos all set; T1 == T2), dpos += dbd^T qv summed over the batch (dpos is ACCUMULATED
+ * into: positions are shared by the batch; zero it first).  Pd / dS / dbd: [H][B][T1][ldp] as eamd_attn_fwd_f32 /
+ * eamd_attn_bwd_q_f32 leave them (Pd = the probabilities the context was built from); dctx / qu / qv: (b, t, h, d) at
+ * [(b*T1 + t)*ld + h*64 + d]; dv / dk: (b, j, h, d) at [(b*T2 + j)*ldo + h*64 + d]; dpos: (m, h, d) at [m*ldpos + h*64 + d].
+ * Replaces the three batched GEMMs over P / dS / dbd.  reference: autograd of transformer/attention.py:63-114, :141-206. */
+int eamd_attn_bwd_kv_f32(const float* Pd, const float* dS, const float* dbd, int64_t ldp, const float* dctx, int64_t ldd,
+                         const float* qu, int64_t ldq, const float* qv, int64_t ldqv, float* dv, float* dk_out, int64_t ldo,
+                         float* dpos, int64_t ldpos, int B, int H, int T1, int T2, int dk, void* stream);
+
 /* Label-smoothing KL loss rows + argmax-correct flags + gradient (softmax - true_dist)*inv_denom.
  * reference: transformer/label_smoothing_loss.py:44-63, nets_utils.py:299-319 (th_accuracy). */
 int eamd_lsm_loss(const float* logits, const int64_t* target, float* loss_rows, float* correct_rows,
