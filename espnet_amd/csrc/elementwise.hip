@@ -517,9 +517,13 @@ int eamd_glu_bwd(const float* dy, const float* x, float* dx, void* dx_bf16, int6
 }
 
 // out = bf16(a + b) together with the column sums of a and of b (ADDED into suma / sumb): the relative-position
+}  // extern "C"
+
 // attention backward needs dq = dqu + dqv as a GEMM operand and the column sums of both terms as the gradients of
 // pos_bias_u / pos_bias_v - one pass over the two [rows, D] tensors instead of three.  Thread = (column pair, row
 // group); a block owns `rpb` rows, sums in registers, combines its row groups in LDS, one atomic per column.
+// F32OUT: the sum is stored as fp32 (reference-precision mode) instead of a bf16 pair.
+template <bool F32OUT>
 __global__ __launch_bounds__(256) void add_cast_colsum2_kernel(const float* __restrict__ a, const float* __restrict__ b,
                                                                unsigned int* __restrict__ o32, long ld_out,
                                                                float* __restrict__ suma, float* __restrict__ sumb,
@@ -541,14 +545,17 @@ __global__ __launch_bounds__(256) void add_cast_colsum2_kernel(const float* __re
 #pragma unroll
       for (int u = 0; u < 4; ++u) {
         sa.x += av[u].x; sa.y += av[u].y; sb.x += bv[u].x; sb.y += bv[u].y;
-        o32[((r + (long)u * ngrp) * ld_out + 2 * cp) >> 1] = eamd_pack2(av[u].x + bv[u].x, av[u].y + bv[u].y);
+        if (F32OUT) *reinterpret_cast<float2*>(reinterpret_cast<float*>(o32) + (r + (long)u * ngrp) * ld_out + 2 * cp) =
+            make_float2(av[u].x + bv[u].x, av[u].y + bv[u].y);
+        else o32[((r + (long)u * ngrp) * ld_out + 2 * cp) >> 1] = eamd_pack2(av[u].x + bv[u].x, av[u].y + bv[u].y);
       }
     }
     for (; r < r1; r += ngrp) {
       const float2 av = *reinterpret_cast<const float2*>(a + r * D + 2 * cp);
       const float2 bv = *reinterpret_cast<const float2*>(b + r * D + 2 * cp);
       sa.x += av.x; sa.y += av.y; sb.x += bv.x; sb.y += bv.y;
-      o32[(r * ld_out + 2 * cp) >> 1] = eamd_pack2(av.x + bv.x, av.y + bv.y);
+      if (F32OUT) *reinterpret_cast<float2*>(reinterpret_cast<float*>(o32) + r * ld_out + 2 * cp) = make_float2(av.x + bv.x, av.y + bv.y);
+      else o32[(r * ld_out + 2 * cp) >> 1] = eamd_pack2(av.x + bv.x, av.y + bv.y);
     }
   }
   red[threadIdx.x][0] = sa.x; red[threadIdx.x][1] = sa.y; red[threadIdx.x][2] = sb.x; red[threadIdx.x][3] = sb.y;
@@ -563,6 +570,8 @@ __global__ __launch_bounds__(256) void add_cast_colsum2_kernel(const float* __re
     atomicAdd(&sumb[2 * cp], t2); atomicAdd(&sumb[2 * cp + 1], t3);
   }
 }
+
+extern "C" {
 
 int eamd_add_block_f32(const float* a, const float* b, float* out, int64_t rows, int cols, int64_t ld_out, void* stream) {
   if (!a || !out || rows <= 0 || cols <= 0 || ld_out < cols) return EAMD_EINVAL;
@@ -594,8 +603,19 @@ int eamd_add_cast_colsum2(const float* a, const float* b, void* out_bf16, int64_
   if (!a || !b || !out_bf16 || !suma || !sumb || rows <= 0 || D <= 0 || ld_out < D) return EAMD_EINVAL;
   if (D % 2 || D > 512 || ld_out % 2 || (((uintptr_t)a | (uintptr_t)b) & 7) || ((uintptr_t)out_bf16 & 3)) return EAMD_EUNSUPPORTED;
   const int rpb = 64;
-  hipLaunchKernelGGL(add_cast_colsum2_kernel, dim3((unsigned)((rows + rpb - 1) / rpb)), dim3(256), 0, (hipStream_t)stream, a, b,
+  hipLaunchKernelGGL(add_cast_colsum2_kernel<false>, dim3((unsigned)((rows + rpb - 1) / rpb)), dim3(256), 0, (hipStream_t)stream, a, b,
                      (unsigned int*)out_bf16, (long)ld_out, suma, sumb, (long)rows, D, rpb);
+  EAMD_LAUNCH_CHECK();
+  return EAMD_OK;
+}
+
+int eamd_add_colsum2_f32(const float* a, const float* b, float* out, int64_t ld_out, float* suma, float* sumb, int64_t rows,
+                         int D, void* stream) {
+  if (!a || !b || !out || !suma || !sumb || rows <= 0 || D <= 0 || ld_out < D) return EAMD_EINVAL;
+  if (D % 2 || D > 512 || ld_out % 2 || (((uintptr_t)a | (uintptr_t)b | (uintptr_t)out) & 7)) return EAMD_EUNSUPPORTED;
+  const int rpb = 64;
+  hipLaunchKernelGGL(add_cast_colsum2_kernel<true>, dim3((unsigned)((rows + rpb - 1) / rpb)), dim3(256), 0, (hipStream_t)stream, a, b,
+                     (unsigned int*)out, (long)ld_out, suma, sumb, (long)rows, D, rpb);
   EAMD_LAUNCH_CHECK();
   return EAMD_OK;
 }

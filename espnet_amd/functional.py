@@ -764,13 +764,9 @@ class MHABlockFn(torch.autograd.Function):
                                                T2, H, dk, Pd=Pd, attn_drop=(p_att, s_att), dqkv=dqkv, dp_out=dp_out)
             if rel:
                 wpos = params[10]
-                if ops.fast():      # dq = dqu + dqv (bf16, into the fused buffer) + both bias gradients in one pass
-                    ops.add_cast_colsum2(dqu, dqv, sink.buf(11).view(-1), sink.buf(12).view(-1), out=dqkv, out_off=0,
-                                         ld_out=3 * D)
-                else:
-                    ops.colsum(dqu, sink.buf(11).view(-1))
-                    ops.colsum(dqv, sink.buf(12).view(-1))
-                    ops.add_cast(dqu, dqv, out=dqkv, out_off=0, ld_out=3 * D)
+                # dq = dqu + dqv (operand dtype, into the fused buffer) + both bias gradients in one pass
+                ops.add_cast_colsum2(dqu, dqv, sink.buf(11).view(-1), sink.buf(12).view(-1), out=dqkv, out_off=0,
+                                     ld_out=3 * D)
                 if dp_out is None:
                     ops.linear_bwd_w(ops.to_act(dp), pos2, sink.buf(10))
             ops.linear_bwd_w(dqkv, xn, _span3(sink.buf(2), (3 * D, D)), db=_span3(sink.buf(3), (3 * D,)))
@@ -785,12 +781,7 @@ class MHABlockFn(torch.autograd.Function):
                                               Pd=Pd, attn_drop=(p_att, s_att), dkv_out=dkv_out, dp_out=dp_out)
         if rel:
             wpos = params[10]
-            if ops.fast():
-                dq = ops.add_cast_colsum2(dqu, dqv, sink.buf(11).view(-1), sink.buf(12).view(-1))
-            else:
-                ops.colsum(dqu, sink.buf(11).view(-1))
-                ops.colsum(dqv, sink.buf(12).view(-1))
-                dq = ops.axpby(dqu, dqv, 1.0, 1.0)
+            dq = ops.add_cast_colsum2(dqu, dqv, sink.buf(11).view(-1), sink.buf(12).view(-1))
             if dp_out is None:
                 ops.linear_bwd_w(ops.to_act(dp), pos2, sink.buf(10))
         else:

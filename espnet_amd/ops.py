@@ -734,21 +734,24 @@ def add_cast(a, b, out=None, out_off=0, ld_out=None):
 
 
 def add_cast_colsum2(a, b, suma, sumb, out=None, out_off=0, ld_out=None):
-    """bf16(a + b) (optionally into a column block of `out`) and suma += column sums of a, sumb += column sums of b
-    in one pass; falls back to add_cast + two colsum launches for widths the fused kernel does not take"""
+    """a + b in the operand dtype (bf16 in fast mode, fp32 otherwise; optionally into a column block of `out`) and
+    suma += column sums of a, sumb += column sums of b in one pass; falls back to add_cast + two colsum launches for
+    widths the fused kernel does not take"""
     rows, cols = a.shape
     if out is None:
-        out = torch.empty(a.shape, device=a.device, dtype=torch.bfloat16)
+        out = torch.empty(a.shape, device=a.device, dtype=act_dtype())
         ld_out = cols
-    assert out.dtype == torch.bfloat16 and out.numel() >= out_off + (rows - 1) * ld_out + cols
+    assert out.dtype in (torch.bfloat16, torch.float32) and out.numel() >= out_off + (rows - 1) * ld_out + cols
     assert a.is_contiguous() and b.is_contiguous() and suma.numel() == cols and sumb.numel() == cols
-    rc = _lib.lib().eamd_add_cast_colsum2(ptr(a), ptr(b), ptr(out, out_off), C.c_int64(ld_out), ptr(suma), ptr(sumb),
-                                          C.c_int64(rows), cols, stream_ptr())
+    L = _lib.lib()
+    fn, name = ((L.eamd_add_cast_colsum2, "eamd_add_cast_colsum2") if out.dtype == torch.bfloat16
+                else (L.eamd_add_colsum2_f32, "eamd_add_colsum2_f32"))
+    rc = fn(ptr(a), ptr(b), ptr(out, out_off), C.c_int64(ld_out), ptr(suma), ptr(sumb), C.c_int64(rows), cols, stream_ptr())
     if rc == _lib.EAMD_EUNSUPPORTED:
         colsum(a, suma)
         colsum(b, sumb)
         return add_cast(a, b, out=out, out_off=out_off, ld_out=ld_out)
-    check(rc, "eamd_add_cast_colsum2")
+    check(rc, name)
     return out
 
 

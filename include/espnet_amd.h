@@ -260,6 +260,9 @@ int eamd_add_block_f32(const float* a, const float* b, float* out, int64_t rows,
  * pos_bias_u / pos_bias_v in the backward of attention.py:186-190. */
 int eamd_add_cast_colsum2(const float* a, const float* b, void* out_bf16, int64_t ld_out, float* suma, float* sumb,
                           int64_t rows, int D, void* stream);
+/* fp32 twin (reference-precision mode): out[r*ld_out + c] = a + b as fp32, same column sums. */
+int eamd_add_colsum2_f32(const float* a, const float* b, float* out, int64_t ld_out, float* suma, float* sumb, int64_t rows,
+                         int D, void* stream);
 /* out[D] += scale * column sums of x[rows, D] (bias gradients). */
 int eamd_colsum(const void* x, int64_t ld, float* out, int64_t rows, int D, float scale, int x_bf16, void* stream);
 /* reference: decoder.py:83-86,251 (Embedding + PositionalEncoding), embedding.py:80-91.

@@ -1075,3 +1075,11 @@ def test_add_cast_colsum2(ops, shape):
     assert off == 0 or bool((out[:, :off] == 0).all())
     report("add_cast_colsum2 suma", sa, 1 + a.double().sum(0), 1e-5)
     report("add_cast_colsum2 sumb", sb, -2 + b.double().sum(0), 1e-5)
+    # fp32 twin (eamd_add_colsum2_f32): exact sum, same column sums
+    sa, sb = torch.ones(D, device=DEV), torch.full((D,), -2.0, device=DEV)
+    out = torch.zeros(rows, ld, device=DEV)
+    ops.add_cast_colsum2(a, b, sa, sb, out=out, out_off=off, ld_out=ld)
+    assert torch.equal(out[:, off:], a + b)
+    assert off == 0 or bool((out[:, :off] == 0).all())
+    report("add_colsum2_f32 suma", sa, 1 + a.double().sum(0), 1e-5)
+    report("add_colsum2_f32 sumb", sb, -2 + b.double().sum(0), 1e-5)
