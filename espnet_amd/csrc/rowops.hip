@@ -93,7 +93,7 @@ __global__ __launch_bounds__(1024) void layernorm_bwd_kernel(
     const float* __restrict__ mean, const float* __restrict__ rstd, const float* dres, float* dx,
     float* __restrict__ dgamma, float* __restrict__ dbeta, float* __restrict__ ws, int rows, int D,
     int rows_per_block, unsigned short* __restrict__ drop16, float drop_p, const unsigned long long* drop_step,
-    unsigned long long drop_salt) {
+    unsigned long long drop_salt, int drop_f32) {
   // drop16 (vector form only): a second, bf16 output dropout(dx; p, salt) with the mask eamd_dropout would draw for
   // the contiguous [rows, D] tensor - the incoming-gradient dropout + cast of the PREVIOUS block, fused into this
   // kernel's store instead of a separate pass over dx
@@ -163,15 +163,21 @@ __global__ __launch_bounds__(1024) void layernorm_bwd_kernel(
           if (drop16) {
             const long e0 = (long)(q ? row2 : row) * D + 4 * (lane + 64 * j);
             const float ov[4] = {o.x, o.y, o.z, o.w};
-            unsigned short h16[4];
             bool keep[4];
             eamd_drop_keep4(drop_seed, (unsigned long long)e0, drop_thr, keep);     // e0 is a multiple of 4
+            if (drop_f32) {          // fp32 copy (reference-precision mode); wave-uniform
+              *reinterpret_cast<float4*>(reinterpret_cast<float*>(drop16) + e0) =
+                  make_float4(keep[0] ? ov[0] * drop_inv : 0.f, keep[1] ? ov[1] * drop_inv : 0.f,
+                              keep[2] ? ov[2] * drop_inv : 0.f, keep[3] ? ov[3] * drop_inv : 0.f);
+            } else {
+              unsigned short h16[4];
 #pragma unroll
-            for (int e = 0; e < 4; ++e) h16[e] = eamd_f2bf(keep[e] ? ov[e] * drop_inv : 0.f);
-            uint2 pk;
-            pk.x = (unsigned)h16[0] | ((unsigned)h16[1] << 16);
-            pk.y = (unsigned)h16[2] | ((unsigned)h16[3] << 16);
-            *reinterpret_cast<uint2*>(drop16 + e0) = pk;
+              for (int e = 0; e < 4; ++e) h16[e] = eamd_f2bf(keep[e] ? ov[e] * drop_inv : 0.f);
+              uint2 pk;
+              pk.x = (unsigned)h16[0] | ((unsigned)h16[1] << 16);
+              pk.y = (unsigned)h16[2] | ((unsigned)h16[3] << 16);
+              *reinterpret_cast<uint2*>(drop16 + e0) = pk;
+            }
           }
         }
       }
@@ -758,12 +764,13 @@ int64_t eamd_layernorm_bwd_workspace(int rows, int D) {
 
 static int layernorm_bwd_impl(const float* dy, const float* x, const float* gamma, const float* mean, const float* rstd,
                               const float* dres, float* dx, float* dgamma, float* dbeta, float* workspace, int rows, int D,
-                              void* drop16, float drop_p, const uint64_t* drop_step, uint64_t drop_salt, void* stream) {
+                              void* drop16, float drop_p, const uint64_t* drop_step, uint64_t drop_salt, void* stream,
+                              int drop_f32 = 0) {
   const bool deferred = !dgamma && !dbeta && workspace;      // partials stay in `workspace` (eamd_layernorm_bwd_reduce)
   if (!dy || !x || !gamma || !mean || !rstd || !dx || (!deferred && (!dgamma || !dbeta)) || rows <= 0 || D <= 0)
     return EAMD_EINVAL;
   if (D > 1024) return EAMD_EUNSUPPORTED;
-  if (drop16 && (drop_p < 0.f || drop_p >= 1.f || !drop_step || ((uintptr_t)drop16 & 7))) return EAMD_EINVAL;
+  if (drop16 && (drop_p < 0.f || drop_p >= 1.f || !drop_step || ((uintptr_t)drop16 & (drop_f32 ? 15 : 7)))) return EAMD_EINVAL;
   int nblk, rpb;
   ln_bwd_grid(rows, &nblk, &rpb);
   static const int ws_min = [] { const char* e = getenv("EAMD_LNB_WS_MIN"); return e ? atoi(e) : 32; }();
@@ -776,14 +783,14 @@ static int layernorm_bwd_impl(const float* dy, const float* x, const float* gamm
   const unsigned long long* dst = (const unsigned long long*)drop_step;
   if (al && D == 256)
     hipLaunchKernelGGL(layernorm_bwd_kernel<1>, dim3(nblk), dim3(nthr), sm, s, dy, x, gamma, mean, rstd, dres, dx,
-                       dgamma, dbeta, ws, rows, D, rpb, d16, drop_p, dst, (unsigned long long)drop_salt);
+                       dgamma, dbeta, ws, rows, D, rpb, d16, drop_p, dst, (unsigned long long)drop_salt, drop_f32);
   else if (al && D == 512)
     hipLaunchKernelGGL(layernorm_bwd_kernel<2>, dim3(nblk), dim3(nthr), sm, s, dy, x, gamma, mean, rstd, dres, dx,
-                       dgamma, dbeta, ws, rows, D, rpb, d16, drop_p, dst, (unsigned long long)drop_salt);
+                       dgamma, dbeta, ws, rows, D, rpb, d16, drop_p, dst, (unsigned long long)drop_salt, drop_f32);
   else {
     if (drop16) return EAMD_EUNSUPPORTED;       // the fused dropout output exists in the vector form only
     hipLaunchKernelGGL(layernorm_bwd_kernel<0>, dim3(nblk), dim3(nthr), sm, s, dy, x, gamma, mean, rstd, dres, dx,
-                       dgamma, dbeta, ws, rows, D, rpb, d16, drop_p, dst, (unsigned long long)drop_salt);
+                       dgamma, dbeta, ws, rows, D, rpb, d16, drop_p, dst, (unsigned long long)drop_salt, drop_f32);
   }
   EAMD_LAUNCH_CHECK();
   if (ws && !deferred) {
@@ -827,6 +834,14 @@ int eamd_layernorm_bwd_drop(const float* dy, const float* x, const float* gamma,
   if (!dx_drop_bf16) return EAMD_EINVAL;
   return layernorm_bwd_impl(dy, x, gamma, mean, rstd, dres, dx, dgamma, dbeta, workspace, rows, D, dx_drop_bf16, drop_p,
                             step_dev, salt, stream);
+}
+
+int eamd_layernorm_bwd_drop_f32(const float* dy, const float* x, const float* gamma, const float* mean, const float* rstd,
+                                const float* dres, float* dx, float* dx_drop, float drop_p, const uint64_t* step_dev,
+                                uint64_t salt, float* dgamma, float* dbeta, float* workspace, int rows, int D, void* stream) {
+  if (!dx_drop) return EAMD_EINVAL;
+  return layernorm_bwd_impl(dy, x, gamma, mean, rstd, dres, dx, dgamma, dbeta, workspace, rows, D, dx_drop, drop_p,
+                            step_dev, salt, stream, 1);
 }
 
 int eamd_softmax_fwd(const float* ac, const float* bd, const unsigned char* mask, int64_t mask_bstride,

@@ -59,13 +59,13 @@ FUSE_GRAD_DROP = True
 
 
 def _tag_out(out, p_out, s_out):
-    if FUSE_GRAD_DROP and p_out > 0.0 and ops.fast():
+    if FUSE_GRAD_DROP and p_out > 0.0:
         out._eamd_out_drop = (float(p_out), int(s_out))
     return out
 
 
 def _prev_drop(x):
-    return getattr(x, "_eamd_out_drop", None) if (FUSE_GRAD_DROP and ops.fast()) else None
+    return getattr(x, "_eamd_out_drop", None) if FUSE_GRAD_DROP else None
 
 
 def _grad_in(dout, do, p_out, s_out):

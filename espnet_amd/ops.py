@@ -494,10 +494,12 @@ def layernorm_bwd(dy, x, gamma, mean, rstd, dres, dgamma, dbeta, drop=None):
     if _defer_ln(ws, dgamma, dbeta, nws // (2 * D), D):
         pg = pb = None
     if drop is not None:
-        dx16 = torch.empty(rows, D, device=x.device, dtype=torch.bfloat16)
-        check(L.eamd_layernorm_bwd_drop(ptr(dy), ptr(x), ptr(gamma), ptr(mean), ptr(rstd), ptr(dres), ptr(dx), ptr(dx16),
-                                        C.c_float(drop[0]), ptr(rng_state(x.device)), C.c_uint64(drop[1]), pg,
-                                        pb, ptr(ws), rows, D, stream_ptr()), "eamd_layernorm_bwd_drop")
+        dx16 = torch.empty(rows, D, device=x.device, dtype=act_dtype())        # dropped copy in the GEMM-operand dtype
+        fn, name = ((L.eamd_layernorm_bwd_drop, "eamd_layernorm_bwd_drop") if fast()
+                    else (L.eamd_layernorm_bwd_drop_f32, "eamd_layernorm_bwd_drop_f32"))
+        check(fn(ptr(dy), ptr(x), ptr(gamma), ptr(mean), ptr(rstd), ptr(dres), ptr(dx), ptr(dx16),
+                 C.c_float(drop[0]), ptr(rng_state(x.device)), C.c_uint64(drop[1]), pg,
+                 pb, ptr(ws), rows, D, stream_ptr()), name)
         return dx, dx16
     check(L.eamd_layernorm_bwd(ptr(dy), ptr(x), ptr(gamma), ptr(mean), ptr(rstd), ptr(dres), ptr(dx),
                                pg, pb, ptr(ws), rows, D, stream_ptr()), "eamd_layernorm_bwd")

@@ -152,6 +152,10 @@ int eamd_layernorm_bwd(const float* dy, const float* x, const float* gamma, cons
 int eamd_layernorm_bwd_drop(const float* dy, const float* x, const float* gamma, const float* mean, const float* rstd,
                             const float* dres, float* dx, void* dx_drop_bf16, float drop_p, const uint64_t* step_dev,
                             uint64_t salt, float* dgamma, float* dbeta, float* workspace, int rows, int D, void* stream);
+/* fp32 twin: the dropped copy is fp32 (reference-precision mode: the previous block's GEMMs consume fp32 operands). */
+int eamd_layernorm_bwd_drop_f32(const float* dy, const float* x, const float* gamma, const float* mean, const float* rstd,
+                                const float* dres, float* dx, float* dx_drop, float drop_p, const uint64_t* step_dev,
+                                uint64_t salt, float* dgamma, float* dbeta, float* workspace, int rows, int D, void* stream);
 
 /* Masked softmax of attention scores, legacy rel_shift of `bd` fused in.
  * reference: transformer/attention.py:63-90 (mask fill / softmax / zero fill), :141-162 (rel_shift),

@@ -1003,9 +1003,10 @@ def test_positionwise_conv1d_golden(tag, kind, kw):
     assert rel < 3e-2
 
 
-def test_fused_gradient_dropout_matches_separate_pass():
-    """bf16 mode, dropout on: the incoming-gradient dropout written by the next block's LayerNorm backward
-    (eamd_layernorm_bwd_drop) must reproduce the separate dropout pass - same masks, same rounding: the parameter gradients
+@pytest.mark.parametrize("prec", ["bf16", "fp32"])
+def test_fused_gradient_dropout_matches_separate_pass(prec):
+    """dropout on: the incoming-gradient dropout written by the next block's LayerNorm backward
+    (eamd_layernorm_bwd_drop, in fp32 mode eamd_layernorm_bwd_drop_f32) must reproduce the separate dropout pass - same masks, same rounding: the parameter gradients
     of a small Conformer E2E with the fusion on and off differ by no more than two runs of the same configuration do
     (split-K f32 atomics make the step itself non-deterministic in the last bits)."""
     import espnet_amd
@@ -1013,7 +1014,7 @@ def test_fused_gradient_dropout_matches_separate_pass():
     from espnet_amd import ops
     p, sd, _ = split_golden(load_golden("e2e_conformer.npz"))
     extra = dict(CASES[0][2], dropout_rate=0.1, transformer_attn_dropout_rate=0.1, adim=256, aheads=4, eunits=64, dunits=64)
-    espnet_amd.set_precision("bf16")
+    espnet_amd.set_precision(prec)
     try:
         grads = {}
         torch.manual_seed(5)
@@ -1029,7 +1030,7 @@ def test_fused_gradient_dropout_matches_separate_pass():
         def worst(a, b):
             return max(float((a[k].double() - b[k].double()).norm() / (b[k].double().norm() + 1e-30)) for k in a)
         noise, diff = worst(grads[None], grads[False]), worst(grads[True], grads[False])
-        print("[parity] fused gradient dropout: worst rel diff vs separate pass %.2e (run-to-run noise %.2e)" % (diff, noise))
+        print("[parity] fused gradient dropout (%s): worst rel diff vs separate pass %.2e (run-to-run noise %.2e)" % (prec, diff, noise))
         assert diff <= max(4.0 * noise, 1e-6)
     finally:
         F_.FUSE_GRAD_DROP = True
