@@ -361,7 +361,7 @@ def ragged_leg(a, prec, dev):
             t0 = time.perf_counter()
             for xs, ilens, ys in stream:
                 if step is not None:
-                    step(xs, ilens, ys)
+                    step(xs, ilens, ys, olens=[L] * B)       # label lengths from the host, as a data loader has them
                 else:
                     train.train_step(model, flat, opt, model.prepare(xs, ilens, ys))
             torch.cuda.synchronize()

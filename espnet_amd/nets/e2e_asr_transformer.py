@@ -175,19 +175,21 @@ class E2E(ASRInterface, torch.nn.Module):
             n = min(Lb, ys_pad.shape[1])
             yp[:, :n] = ys_pad[:, :n]
             xs_pad, ys_pad, tmax = xp, yp, Tb
-        xs_pad = xs_pad[:, :tmax].to(dev).contiguous()
-        ys_pad = ys_pad.to(dev).contiguous()
-        src_mask = make_non_pad_mask(il, tmax).unsqueeze(-2).to(dev).to(torch.uint8)     # (B,1,T)
+        # host-built tensors go to the device through pinned staging copies (ops.h2d_async): the host never waits for the
+        # stream here, so the next batch is prepared while the previous step still runs
+        xs_pad = ops.h2d_async(xs_pad[:, :tmax], dev).contiguous()
+        ys_pad = ops.h2d_async(ys_pad, dev).contiguous()
+        src_mask = ops.h2d_async(make_non_pad_mask(il, tmax).unsqueeze(-2).to(torch.uint8), dev)     # (B,1,T)
         batch = dict(xs_pad=xs_pad, ys_pad=ys_pad, src_mask=src_mask, B=xs_pad.size(0))
         if self.decoder is not None:
             ys_in_pad, ys_out_pad, _ = ops.add_sos_eos(ys_pad, self.sos, self.eos, self.ignore_id)
             U = ys_in_pad.size(1)
             # ys_in is padded with <eos>, never ignore_id, so target_mask() is the causal mask (mask.py:41-51)
             ys_mask = subsequent_mask(U).unsqueeze(0).expand(xs_pad.size(0), U, U).to(torch.uint8).contiguous()
-            batch.update(ys_in_pad=ys_in_pad, ys_out_pad=ys_out_pad, ys_mask=ys_mask.to(dev),
+            batch.update(ys_in_pad=ys_in_pad, ys_out_pad=ys_out_pad, ys_mask=ops.h2d_async(ys_mask, dev),
                          n_valid=(ys_out_pad != self.ignore_id).sum())
         if self.mtlalpha > 0.0:
-            batch["hs_len"] = torch.tensor(embed_output_lengths(self.encoder.embed, il, tmax), dtype=torch.int32).to(dev)
+            batch["hs_len"] = ops.h2d_async(torch.tensor(embed_output_lengths(self.encoder.embed, il, tmax), dtype=torch.int32), dev)
         return batch
 
     def forward_core(self, batch):

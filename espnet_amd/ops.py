@@ -194,7 +194,7 @@ def gemm(A, B, Cm, M, N, K, lda, ldb, ldc, *, transA=0, transB=0, bias=None, aux
             setattr(p, which + "_drop_p", float(d[0]))
             setattr(p, which + "_drop_salt", int(d[1]))
             p.drop_step = ptr(rng_state(A.device))
-    if group and _wgroup["on"] and Cm.untyped_storage().data_ptr() in _wgroup["arenas"] and _wgroup_accepts(p):
+    if group and _wgroup["on"] and _in_grad_arena(Cm) and _wgroup_accepts(p):
         _wgroup["items"].append((p, (A, B, Cm, colsum)))
         return
     if _gemm_record is not None:
@@ -219,14 +219,30 @@ GROUP_WGRAD_SK_DIV = int(os.environ.get("EAMD_GROUP_SK_DIV", "2"))
 # GROUP_WGRAD_T128_WGS workgroups (tiles x K-splits) each
 GROUP_WGRAD_TILE128_MIN = int(os.environ.get("EAMD_GROUP_T128_MIN", "100"))
 GROUP_WGRAD_T128_WGS = int(os.environ.get("EAMD_GROUP_T128_WGS", "96"))
-_wgroup = {"on": False, "items": [], "pinned": [], "reserve": [], "arenas": set()}
+_wgroup = {"on": False, "items": [], "pinned": [], "reserve": [], "arenas": {}}
 
 
 def register_grad_arena(t):
     """only GEMMs that accumulate into a registered gradient arena (espnet_amd.train.FlatParams.grad) are queued: a
     temporary result (tap-major weight gradients that are permuted into the arena next, gradients handed back to
     autograd) is read by its consumer long before the grouped launch runs"""
-    _wgroup["arenas"].add(t.untyped_storage().data_ptr())
+    import weakref
+    key = t.untyped_storage().data_ptr()
+    _wgroup["arenas"][key] = weakref.ref(t)
+
+
+def _in_grad_arena(t):
+    """True if `t` lives in a registered gradient arena that is still alive (a freed arena's address may be handed to
+    any later allocation)"""
+    key = t.untyped_storage().data_ptr()
+    ref = _wgroup["arenas"].get(key)
+    if ref is None:
+        return False
+    a = ref()
+    if a is None or a.untyped_storage().data_ptr() != key:
+        del _wgroup["arenas"][key]
+        return False
+    return True
 
 
 def wgrad_group_begin():
@@ -252,7 +268,7 @@ def _wgroup_staging(nbytes):
         return None
     want = (nbytes + 4095) // 4096 * 4096 * 2
     _wgroup["reserve"] = [h for h in _wgroup["reserve"] if h.numel() >= want]
-    while len(_wgroup["reserve"]) < 8:
+    while len(_wgroup["reserve"]) < 16:
         _wgroup["reserve"].append(torch.empty(want, dtype=torch.uint8, pin_memory=True))
     return torch.empty(nbytes, dtype=torch.uint8, pin_memory=True)
 
@@ -405,7 +421,7 @@ def _linear_bwd_w(dy, x, dW, *, alpha=1.0, b_act=ACT_NONE, db=None, a_drop=None,
     tile = 0
     t64 = ((N + 63) // 64) * ((K + 63) // 64)
     if (_wgroup["on"] and _wgrad["stream"] is None and t64 <= GROUP_WGRAD_MAX_TILES
-            and dW.untyped_storage().data_ptr() in _wgroup["arenas"]):
+            and _in_grad_arena(dW)):
         if t64 >= GROUP_WGRAD_TILE128_MIN and N >= 128 and K >= 128 and dy.dtype == torch.float32 and _state["precision"] == 0:
             # big outputs (the FFN weights) go to the 128x128 grouped launch: a quarter of the operand re-reads
             tile = 128
@@ -1312,6 +1328,15 @@ def h2d_cached(tag, array, device):
         t = torch.from_numpy(a.copy()).to(device)
         _h2d_cache[key] = t
     return t
+
+
+def h2d_async(t_cpu, device):
+    """small host tensor -> device without making the host wait for the stream: a copy from PAGEABLE memory blocks the
+    host until everything queued before it has run (a whole training step behind a graph replay); from a pinned
+    staging copy it is just enqueued (the caching host allocator keeps the staging block until the copy has run)"""
+    if not t_cpu.is_cuda and torch.device(device).type == "cuda":
+        return t_cpu.contiguous().pin_memory().to(device, non_blocking=True)
+    return t_cpu.to(device)
 
 
 def gru_cell_fwd(gx, gh, h_prev, live, h, y, acts):

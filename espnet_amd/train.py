@@ -451,15 +451,18 @@ class BucketedGraphStep:
         self.pool = None
         self.hits = self.misses = self.captures = self.evictions = 0
 
-    def bucket(self, xs_pad, ilens, ys_pad):
+    def bucket(self, xs_pad, ilens, ys_pad, olens=None):
         il = [int(v) for v in (ilens.tolist() if torch.is_tensor(ilens) else ilens)]
         T = max(il)
-        L = int((ys_pad != self.model.ignore_id).sum(1).max())
+        if olens is not None:      # label lengths known on the host (a data loader has them): no device round trip
+            L = max(int(v) for v in (olens.tolist() if torch.is_tensor(olens) else olens))
+        else:                      # device labels: this waits for the GPU (the previous step) before the host can go on
+            L = int((ys_pad != self.model.ignore_id).sum(1).max())
         up = lambda v, e: (v + e - 1) // e * e  # noqa: E731
         return (int(xs_pad.shape[0]), up(T, self.t_edge), up(max(L, 1), self.l_edge))
 
-    def __call__(self, xs_pad, ilens, ys_pad):
-        key = self.bucket(xs_pad, ilens, ys_pad)
+    def __call__(self, xs_pad, ilens, ys_pad, olens=None):
+        key = self.bucket(xs_pad, ilens, ys_pad, olens)
         batch = self.model.prepare(xs_pad, ilens, ys_pad, pad_to=key[1:])
         entry = self.cache.get(key)
         if entry is not None:
