@@ -244,7 +244,7 @@ def run_precision(a, prec, rank, world, dev):
         torch.distributed.all_reduce(tt, op=torch.distributed.ReduceOp.MAX)
         dt = float(tt)
     ms = dt / a.steps * 1e3
-    loss_val = float(model.loss)
+    loss_val = float(model.loss.detach())
     st = opt.stats()
 
     # ---- roofline of the dominant kernel family (MFMA contractions), measured live with stream events ----

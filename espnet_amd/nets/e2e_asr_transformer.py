@@ -229,10 +229,10 @@ class E2E(ASRInterface, torch.nn.Module):
 
     def _report(self):
         """Host copies of the scalars (reference does float(loss) x3 inside forward)."""
-        lc = float(self._loss_ctc_t) if self._loss_ctc_t is not None else None
-        la = float(self._loss_att_t) if self._loss_att_t is not None else None
+        lc = float(self._loss_ctc_t.detach()) if self._loss_ctc_t is not None else None
+        la = float(self._loss_att_t.detach()) if self._loss_att_t is not None else None
         self.acc = float(self._acc_t) if self.decoder is not None else None
-        loss_data = float(self.loss)
+        loss_data = float(self.loss.detach())
         if loss_data < CTC_LOSS_THRESHOLD and not math.isnan(loss_data):
             self.reporter.report(lc, la, self.acc, None, None, None, loss_data)
         return loss_data

@@ -23,7 +23,7 @@ def ops():
 
 
 def rel_err(a, b):
-    a, b = a.double().cpu(), b.double().cpu()
+    a, b = a.detach().double().cpu(), b.detach().double().cpu()
     return float((a - b).norm() / (b.norm() + 1e-30))
 
 
