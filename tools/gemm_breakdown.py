@@ -72,6 +72,16 @@ def main():
         us = (time.perf_counter() - t0) / 5 / reps / len(ps) * 1e6
         fl = 0.0 if key[0] == "attention" else 2.0 * key[0] * key[1] * key[2] * key[5]
         rows.append((us * len(ps), len(ps), us, fl / us / 1e6, key))
+    # algorithmic HBM bytes of the descriptor launches: every operand and result once (A, B, C, residual, aux, second output)
+    esz = 2 if sys.argv[1:2] != ["fp32"] else 4
+    alg = 0
+    for p, keep, replay in rec:
+        if p is None:
+            continue
+        nb = p.batch1 * p.batch2
+        alg += nb * (p.M * p.K + p.N * p.K) * esz + nb * p.M * p.N * (4 if p.C else 0)
+        alg += nb * p.M * p.N * ((2 if p.Cb else 0) + (4 if p.R else 0) + ((2 if p.aux_dtype else 4) if p.aux else 0) + (esz if p.Hb else 0))
+    print("algorithmic operand + result bytes of the %d descriptor launches: %.2f GB per step" % (sum(1 for r in rec if r[0] is not None), alg / 1e9))
     rows.sort(key=lambda r: -r[0])
     tot = sum(r[0] for r in rows)
     print("total %.1f us over %d launches" % (tot, len(rec)))
