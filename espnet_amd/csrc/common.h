@@ -37,6 +37,23 @@ __device__ __forceinline__ float eamd_act(float x, int act) {
   if (act == EAMD_ACT_TANH) return tanhf(x);
   return x;
 }
+// activation and its derivative from ONE sigmoid / tanh (the FFN forward's factor epilogue needs both per element)
+__device__ __forceinline__ void eamd_act_dact(float x, int act, float& a, float& d) {
+  if (act == EAMD_ACT_SWISH) {
+    const float s = eamd_sigmoid(x);
+    a = x * s;
+    d = s * (1.0f + x * (1.0f - s));
+  } else if (act == EAMD_ACT_RELU) {
+    a = x > 0.f ? x : 0.f;
+    d = x > 0.f ? 1.f : 0.f;
+  } else if (act == EAMD_ACT_TANH) {
+    a = tanhf(x);
+    d = 1.f - a * a;
+  } else {
+    a = x;
+    d = 1.f;
+  }
+}
 // derivative of eamd_act at pre-activation x
 __device__ __forceinline__ float eamd_dact(float x, int act) {
   if (act == EAMD_ACT_RELU) return x > 0.f ? 1.f : 0.f;

@@ -342,6 +342,7 @@ __global__ __launch_bounds__(NTHREADS) void gemm_kernel(const eamd_gemm_t p) {
           else if (p.epilogue == 2) v = eamd_swish(v);
           else if (p.epilogue == 3) v = p.aux[coff + prow * p.ldaux + n] > 0.f ? v : 0.f;
           else if (p.epilogue == 4) v *= eamd_dswish(p.aux[coff + prow * p.ldaux + n]);
+          else if (p.epilogue == 5) v *= p.aux[coff + prow * p.ldaux + n];
           v *= p.alpha;
           if (p.R) v += p.R[coff + prow * p.ldr + n];
           float* cp = p.C + coff + prow * p.ldc + n;
@@ -386,7 +387,9 @@ extern "C" int eamd_gemm(const eamd_gemm_t* pp, void* stream_) {
   if (p.batch1 <= 0 || p.batch2 <= 0) return EAMD_EINVAL;
   if (p.splitk < 1) p.splitk = 1;
   if (p.splitk > 1 && p.epilogue != 0) return EAMD_EINVAL;
-  if ((p.epilogue == 3 || p.epilogue == 4) && !p.aux) return EAMD_EINVAL;
+  if (p.epilogue < 0 || p.epilogue > 6) return EAMD_EINVAL;
+  if (p.epilogue >= 3 && p.epilogue <= 5 && !p.aux) return EAMD_EINVAL;
+  if (p.epilogue == 6 && (!p.Hb || p.drop_p <= 0.f)) return EAMD_EINVAL;      // only with the dual-output dropout epilogue
   if (p.precision != 0 && p.precision != 1) return EAMD_EINVAL;
   if ((long)p.batch1 * p.batch2 * p.splitk > 65535) return EAMD_EUNSUPPORTED;
 

@@ -168,6 +168,9 @@ __device__ __forceinline__ void store_c_tile(const eamd_gemm_t& p, f32x4 (&acc)[
     } else if (p.epilogue == 4) {
 #pragma unroll
       for (int e = 0; e < 4; ++e) v[e] *= eamd_dswish(ax[e]);
+    } else if (p.epilogue == 5) {
+#pragma unroll
+      for (int e = 0; e < 4; ++e) v[e] *= ax[e];
     }
     if (p.drop_p > 0.f) {
       // wave-uniform branch; mask index = element index of the contiguous [M, N] result
@@ -183,10 +186,21 @@ __device__ __forceinline__ void store_c_tile(const eamd_gemm_t& p, f32x4 (&acc)[
       }
       if (Hb) {
         float h[4];
+        if (p.epilogue == 6) {
+          // the first output becomes the BACKWARD factor d h / d v = mask / (1 - p) * act'(v) instead of v
 #pragma unroll
-        for (int e = 0; e < 4; ++e) {
-          const float a = eamd_act(v[e], p.h_act);
-          h[e] = keep[e] ? a * inv : 0.f;
+          for (int e = 0; e < 4; ++e) {
+            float a, d;
+            eamd_act_dact(v[e], p.h_act, a, d);
+            h[e] = keep[e] ? a * inv : 0.f;
+            v[e] = keep[e] ? d * inv : 0.f;
+          }
+        } else {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            const float a = eamd_act(v[e], p.h_act);
+            h[e] = keep[e] ? a * inv : 0.f;
+          }
         }
         if (p.h_dtype) {       // fp32 second output (reference-precision mode)
           float* Hf = reinterpret_cast<float*>(p.Hb);
@@ -231,7 +245,7 @@ __device__ __forceinline__ void store_c_tile(const eamd_gemm_t& p, f32x4 (&acc)[
     }
   };
 
-  const bool want_aux = p.epilogue >= 3, want_r = p.R != nullptr, want_c = p.C && p.beta != 0.f;
+  const bool want_aux = p.epilogue >= 3 && p.epilogue <= 5, want_r = p.R != nullptr, want_c = p.C && p.beta != 0.f;
   if (PREFETCH && !want_c && cvec && !p.cmap.enabled && n + 3 < p.N) {
     // fast path (aligned rows, tile column inside N): the aux / residual / beta operands of GRP row passes are
     // requested together BEFORE they are consumed, so a tile pays one memory round trip per group instead of

@@ -10,7 +10,8 @@ import math
 import torch
 
 from . import ops
-from .ops import (ACT_NONE, ACT_RELU, ACT_SWISH, EPI_MUL_DSWISH, EPI_MUL_RELU_MASK, EPI_NONE, EPI_RELU)
+from .ops import (ACT_NONE, ACT_RELU, ACT_SWISH, EPI_DACT_FACTOR, EPI_MUL_AUX, EPI_MUL_DSWISH, EPI_MUL_RELU_MASK, EPI_NONE,
+                  EPI_RELU)
 
 
 class GradSink:
@@ -199,6 +200,10 @@ class LinearFn(torch.autograd.Function):
 # reference: positionwise_feed_forward.py:12-32, conformer/encoder_layer.py:97-103,141-146,
 #            transformer/encoder_layer.py / decoder_layer.py:123-128 (scale = 1, ReLU)
 # =================================================================================================
+import os as _os
+FFN_FACTOR = _os.environ.get("EAMD_FFN_FACTOR", "1") != "0"   # tests flip this to keep the pre-activation and re-derive mask / activation derivative in backward
+
+
 class FFNBlockFn(torch.autograd.Function):
     """drop = (p_inner, salt_inner, p_out, salt_out): dropout after the activation
     (positionwise_feed_forward.py:27) and on the block output before the residual add
@@ -214,11 +219,15 @@ class FFNBlockFn(torch.autograd.Function):
         xn, mean, rstd = _ln_fwd_in(x2, ln_w, ln_b, eps, adt)                   # GEMM operand (bf16 in fast mode)
         assert eps is not None or p_out <= 0.0
         fused = ops.fast()      # bf16-operand GEMMs carry the dropout masks in their epilogues
-        h = None
+        h, zf = None, False
         if p_in > 0.0 and (fused or (ops.f32_epilogue_drop() and not ops.f32_operand_drop())):
             # z and h = dropout(act(z)) from one launch (second output of the epilogue), in the operand dtype
+            # ... and what is kept for backward is not z but the ready factor f = mask / (1 - p) * act'(z): the input-gradient
+            # GEMM multiplies by it (EPI_MUL_AUX) instead of re-deriving the mask and the activation derivative per element
             h = torch.empty(x2.shape[0], w1.shape[0], device=x2.device, dtype=adt)
-            z = ops.linear_fwd(xn, ops.wshadow(w1), b1, out_dtype=adt, drop=(p_in, s_in), Hb=h, h_act=act)
+            z = ops.linear_fwd(xn, ops.wshadow(w1), b1, out_dtype=adt, drop=(p_in, s_in), Hb=h, h_act=act,
+                               act=EPI_DACT_FACTOR if FFN_FACTOR else EPI_NONE)
+            zf = FFN_FACTOR
         else:
             z = ops.linear_fwd(xn, ops.wshadow(w1), b1, out_dtype=adt)          # [M, F] pre-activation
             if p_in > 0.0 and not ops.f32_operand_drop():
@@ -238,6 +247,7 @@ class FFNBlockFn(torch.autograd.Function):
         ctx.pr = GradSink.use((ln_w, ln_b, w1, b1, w2, b2))
         ctx.cfg = (scale, act, shp, drop)
         ctx.in_opd = a_drop is not None
+        ctx.zf = zf
         ctx.prev = _prev_drop(x)
         return _tag_out(out.view(shp), p_out, s_out)
 
@@ -257,7 +267,9 @@ class FFNBlockFn(torch.autograd.Function):
         else:                                         # dW2 += s * drop(do)^T drop(act(z))
             ops.linear_bwd_w(dob, z, sink.buf(4), alpha=scale, b_act=act, db=sink.buf(5), a_drop=g_drop,
                              b_drop=(p_in, s_in) if ctx.in_opd else None)
-        if inner and (ops.fast() or ops.f32_epilogue_drop()):
+        if ctx.zf:       # z holds mask / (1 - p) * act'(z) already
+            dz = ops.linear_bwd_x(dob, ops.wshadow(w2), epilogue=EPI_MUL_AUX, aux=z, alpha=scale, out_dtype=adt, a_drop=g_drop)
+        elif inner and (ops.fast() or ops.f32_epilogue_drop()):
             dz = ops.linear_bwd_x(dob, ops.wshadow(w2), epilogue=_act_epi(act), aux=z, alpha=scale, out_dtype=adt,
                                   drop=(p_in, s_in), a_drop=g_drop)
         else:

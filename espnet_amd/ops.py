@@ -13,7 +13,7 @@ from . import _lib
 from ._lib import GatherT, GemmT, RowMapT, check, ptr, stream_ptr
 
 ACT_NONE, ACT_RELU, ACT_SWISH = 0, 1, 2
-EPI_NONE, EPI_RELU, EPI_SWISH, EPI_MUL_RELU_MASK, EPI_MUL_DSWISH = 0, 1, 2, 3, 4
+EPI_NONE, EPI_RELU, EPI_SWISH, EPI_MUL_RELU_MASK, EPI_MUL_DSWISH, EPI_MUL_AUX, EPI_DACT_FACTOR = 0, 1, 2, 3, 4, 5, 6
 
 _PRECISIONS = {"fp32": 0, "bf16": 1}
 _state = {"precision": 0}

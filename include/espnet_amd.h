@@ -35,7 +35,9 @@ int eamd_abi_version(void);
  * transA=0: A is [M,K] row-major (lda); transA=1: A is stored [K,M] (lda = stride of k).
  * transB=0: B is stored [N,K] (nn.Linear weight, ldb = stride of n); transB=1: B is [K,N].
  * a_act/b_act apply an activation to the operand while it is staged (EAMD_ACT_*).
- * epilogue: 0 none, 1 relu, 2 swish, 3 multiply by (aux>0), 4 multiply by dswish(aux).
+ * epilogue: 0 none, 1 relu, 2 swish, 3 multiply by (aux>0), 4 multiply by dswish(aux), 5 multiply by aux,
+ *   6 (only with Hb + dropout, below): C receives the factor d Hb / d v = mask / (1 - p) * h_act'(v) instead of v - the
+ *   FFN forward then hands its backward a ready factor (epilogue 5 there) instead of the pre-activation.
  * splitk>1: partial sums are atomically ADDED to C (caller pre-initialises C; epilogue must be 0,
  *           beta ignored, bias/R contributed by split 0).
  * precision: 0 = fp32 MFMA (v_mfma_f32_16x16x4_f32, exact fp32 products),

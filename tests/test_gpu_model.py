@@ -1431,6 +1431,37 @@ def test_attention_dropout_in_model_fused_vs_unfused(prec):
     report("attention dropout fused vs unfused (%s): gradient arena" % prec, res[0][1], res[1][1], 3e-5 if prec == "fp32" else 3e-2)
 
 
+@pytest.mark.parametrize("prec", ["fp32", "bf16"])
+def test_ffn_backward_factor_matches_rederivation(prec):
+    """FFN up-projection with epilogue 6: backward receives f = mask / (1 - p) * act'(z) ready-made and the input-gradient
+    GEMM multiplies by it (epilogue 5) - against keeping z and re-deriving mask and activation derivative in that GEMM's
+    epilogue: same loss, same gradient arena (Swish encoder FFNs and ReLU decoder FFNs, dropout 0.1)"""
+    import espnet_amd
+    from espnet_amd import functional as F_
+    from espnet_amd import ops, train
+    from conftest import e2e_dk64_model
+    g = load_golden("e2e_conformer_dk64.npz")
+    xs, ilens, ys = torch.from_numpy(g["xs"]).to(DEV), torch.from_numpy(g["ilens"]), torch.from_numpy(g["ys"]).to(DEV)
+    espnet_amd.set_precision(prec)
+    res = []
+    try:
+        model, _cfg = e2e_dk64_model(dropout=0.1)
+        model = model.to(DEV).train()
+        flat = train.FlatParams(model)
+        for factor in (True, False):
+            F_.FFN_FACTOR = factor
+            flat.zero_grad()
+            ops.manual_seed(808)
+            loss = model(xs, ilens, ys)
+            loss.backward()
+            res.append((float(loss.detach()), flat.grad.clone()))
+    finally:
+        F_.FFN_FACTOR = True
+        espnet_amd.set_precision("fp32")
+    assert abs(res[0][0] - res[1][0]) <= (1e-6 if prec == "fp32" else 1e-3) * abs(res[1][0])
+    report("FFN backward factor vs re-derivation (%s): gradient arena" % prec, res[0][1], res[1][1], 2e-5 if prec == "fp32" else 2e-2)
+
+
 def test_bucketed_graph_step_matches_eager():
     """a stream of batches of two different shapes through train.BucketedGraphStep (eager on first sight, capture on
     the second, replay afterwards) against plain eager steps on the same padded batches with an identical second model:
