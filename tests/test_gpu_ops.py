@@ -728,6 +728,61 @@ def test_gemm_f32_operand_dropout_matches_dropout_kernel(ops, shape):
     report("operand drop bias grad %s" % (shape,), db1, db2, 2e-5)
 
 
+@pytest.mark.parametrize("prec", ["fp32", "bf16"])
+def test_grouped_weight_gradient_launch_vs_float64(ops, prec):
+    """eamd_gemm_group_plan / eamd_gemm_group_launch through ops.linear_bwd_w's queue: a mix of weight-gradient problems
+    (square, skinny, ragged edges in every dimension, with and without bias-gradient column sums, alpha != 1, split-K 1
+    and > 1; in fp32 mode large ones on the 128x128 grouped launch) accumulated ON TOP of existing arena contents -
+    against float64; and a queue of one falls back to a plain launch"""
+    import espnet_amd
+    espnet_amd.set_precision(prec)
+    try:
+        g = torch.Generator().manual_seed(3)
+        adt = ops.act_dtype()
+        shapes = [(7968, 256, 256, True, 1.0), (3000, 768, 256, True, 0.5), (1000, 50, 256, True, 1.0), (517, 130, 70, False, 1.0),
+                  (7968, 2048, 256, True, 1.0), (4000, 256, 2048, False, 2.0), (96, 64, 64, True, 1.0)]
+        for sel in (shapes, shapes[:1]):
+            up8 = lambda v: (v + 7) // 8 * 8  # noqa: E731
+            total = sum(up8(n * k) + up8(n) for _m, n, k, _b, _a in sel)
+            arena = torch.randn(total, generator=g).to(DEV)
+            before = arena.clone()
+            ops.register_grad_arena(arena)
+            ops_in, off = [], 0
+            rec = []
+            ops._gemm_record = rec
+            ops.wgrad_group_begin()
+            for m, n, k, has_b, alpha in sel:
+                dy = (0.1 * torch.randn(m, n, generator=g)).to(torch.bfloat16).to(adt).to(DEV)
+                x = torch.randn(m, k, generator=g).to(torch.bfloat16).to(adt).to(DEV)
+                dW = arena[off:off + n * k].view(n, k)
+                boff = off + up8(n * k)
+                db = arena[boff:boff + n] if has_b else None
+                ops.linear_bwd_w(dy, x, dW, alpha=alpha, db=db)
+                ops_in.append((dy, x, off, boff, n, k, has_b, alpha))
+                off = boff + up8(n)
+            # (the [130 x 70] problem has rows of 70 floats: it misses the 16-byte staging conditions of the grouped kernel
+            # and leaves at once, through the generic kernel - the others wait in the queue)
+            if len(sel) == 1:
+                assert torch.equal(arena, before), "a queued launch must not have run yet"
+            ops.wgrad_group_end()
+            ops._gemm_record = None
+            torch.cuda.synchronize()
+            ngroup = sum(1 for r in rec if r[0] is None)
+            assert ngroup == (0 if len(sel) == 1 else (2 if prec == "fp32" else 1)), ngroup
+            for dy, x, off, boff, n, k, has_b, alpha in ops_in:
+                want = before[off:off + n * k].view(n, k).double().cpu() + alpha * dy.double().cpu().t() @ x.double().cpu()
+                report("grouped dW [%d x %d], %d rows (%s)" % (n, k, dy.shape[0], prec), arena[off:off + n * k].view(n, k), want, 2e-5)
+                if has_b:
+                    wb = before[boff:boff + n].double().cpu() + alpha * dy.double().cpu().sum(0)
+                    report("grouped db [%d] (%s)" % (n, prec), arena[boff:boff + n], wb, 2e-5)
+                else:
+                    assert torch.equal(arena[boff:boff + n], before[boff:boff + n])
+    finally:
+        ops._gemm_record = None
+        ops.wgrad_group_end()
+        espnet_amd.set_precision("fp32")
+
+
 @pytest.mark.parametrize("shape", [(4, 80, 128, 31), (2, 33, 300, 29), (3, 17, 64, 3), (1, 5, 32, 1)])
 def test_dwconv_kernel_sizes(ops, shape):
     """depthwise conv fwd / input grad / weight grad at the recipe's kernel size 31 and at ragged channel counts"""
