@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""debug: replay cost of train.BucketedGraphStep - one repeated shape, then alternating shapes"""
+"""Replay cost of train.BucketedGraphStep - one repeated shape, then alternating shapes"""
 import os, sys, time
 import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
