@@ -3,20 +3,18 @@
 // reference: transformer/attention.py:63-114 (forward_attention / MultiHeadedAttention.forward),
 //            attention.py:141-206 (RelPositionMultiHeadedAttention: rel_shift, (ac + bd) / sqrt(d_k)).
 //
-// One workgroup = one (batch, head) pair x 64 queries; wave w owns 16 queries and ALL keys, so a softmax row never
-// leaves its wave.  Everything is computed in the transposed orientation S^T = K Q^T:
+// One workgroup = one (batch, head) pair x 64 queries, four waves; everything is computed in the transposed
+// orientation S^T = K Q^T:
 //   * the 16x16x32 MFMA operand layout of a k-contiguous matrix is 16 bytes of global memory per lane, so the K, q,
-//     positional and (q+v) fragments are loaded straight into registers (no operand staging, no barriers);
-//   * the accumulator of tile t then holds, for query `lane & 15`, the keys 16 t + 4 (lane >> 4) + {0..3}: four
-//     ADJACENT probabilities per lane - an 8-byte bf16 store into P, and exactly the pairing the context product
-//     needs: with the (arbitrary) contraction order "keys 32 s + 4 q + {0..3}, then 32 s + 16 + 4 q + {0..3}" the
-//     probabilities of tiles 2s, 2s+1 ARE the MFMA operand, no layout change through LDS.  The V fragments of
-//     the same order come from ds_read_b64_tr_b16 on a V panel staged once per workgroup;
+//     positional and (q+v) fragments are loaded straight into registers (no operand staging);
+//   * SCORE phases split the KEYS over the waves (all 64 queries each: every K / position row is fetched by one wave
+//     only) and leave their tiles in an fp32 LDS score matrix X[query][key], the legacy rel_shift applied while the bd
+//     tiles are stored (see attn_fwd_kernel); for SOFTMAX and the products with P wave w owns queries 16 w .. 16 w + 15:
+//     it reads its X rows back in the accumulator layout - four ADJACENT keys per lane = an 8-byte bf16 store into P,
+//     and exactly the pairing the context product needs: with the (arbitrary) contraction order "keys 32 s + 4 q +
+//     {0..3}, then 32 s + 16 + 4 q + {0..3}" the probabilities of tiles 2s, 2s+1 ARE the MFMA operand.  The V fragments
+//     of the same order come from ds_read_b64_tr_b16 on a V panel staged over X once the scores are in registers;
 //   * the context is accumulated as C^T = V^T P^T, which leaves four adjacent channels per lane (8-byte stores).
-// The legacy rel_shift is a flat re-indexing of bd = (q+v) p^T padded with a zero column: shifted[i][j] =
-// pad_flat[T1 + i T2 + j] over rows of T2 + 1.  Each wave writes the 17 rows of bd its 16 queries touch (T1 == T2)
-// into a private LDS image with exactly that padding and reads the shifted values back with one add per element.
-// After the softmax the pad images are dead and the V panel is staged over them.
 #include "gemm_bf16_common.h"
 
 namespace {
@@ -45,11 +43,60 @@ __device__ __forceinline__ float xor_sum16_32(float v) {
 }
 
 // NKT = key tiles of 16 the instantiation covers (T2 <= 16 NKT).  Every loop over tiles is fully unrolled and free of
-// branches: rows past T2 are clamped re-reads whose scores are masked, so that all fragment loads of a phase are in
-// flight together (a uniform `if (tile < T2)` per tile made each load wait for the previous tile's MFMAs).
+// branches: rows past T2 / T1 are clamped re-reads whose scores are masked / never stored.
+// Score phases (bd, ac): wave w takes a quarter of the KEY tiles and all 64 queries of the workgroup, so every K /
+// position row is fetched by one wave only (round 1 had every wave fetch all keys for its own 16 queries, and computed
+// the bd tiles of 32 queries to get 17 rows); the tiles S^T[key][query] go to an fp32 LDS score matrix X[query][key]
+// (16-byte stores: an accumulator holds four adjacent keys of one query).  The legacy rel_shift is one-to-one -
+// shifted[i][j] = bd[i][T-1-i+j] for j <= i, 0 for j = i + 1, bd[i+1][j-i-2] above - so the bd tiles are STORED at their
+// shifted place and the ac tiles added by read-modify-write of 16-byte rows behind a barrier; bd row r0w + 64 (first query
+// of the next workgroup) feeds query r0w + 63: 64-term dot products on the VALU, one position per thread.
+template <int NKT>
+__device__ __forceinline__ void score_tiles_bf16(const bf16_t* keys, long ldk, int T2, const bf16_t* qs, long ldq, int nq,
+                                                 float* X, int XLD, int wave, int fr, int fq, bool acc) {
+  constexpr int TPW = NKT / 4;
+  uint4 qf[4][2];
+#pragma unroll
+  for (int qt = 0; qt < 4; ++qt) {
+    const bf16_t* qr = qs + (long)min(qt * 16 + fr, nq - 1) * ldq + fq * 8;
+    qf[qt][0] = *reinterpret_cast<const uint4*>(qr);
+    qf[qt][1] = *reinterpret_cast<const uint4*>(qr + 32);
+  }
+#pragma unroll
+  for (int u = 0; u < TPW; ++u) {
+    const int kt = wave * TPW + u;
+    const bf16_t* kr = keys + (long)min(kt * 16 + fr, T2 - 1) * ldk + fq * 8;
+    const uint4 k0 = *reinterpret_cast<const uint4*>(kr), k1 = *reinterpret_cast<const uint4*>(kr + 32);
+#pragma unroll
+    for (int qt = 0; qt < 4; ++qt) {
+      f32x4 c = (f32x4){0.f, 0.f, 0.f, 0.f};
+      float4* xp = reinterpret_cast<float4*>(&X[(qt * 16 + fr) * XLD + kt * 16 + 4 * fq]);
+      if (acc) {                      // on top of the shifted bd values (one owner per element: plain read-modify-write)
+        const float4 o = *xp;
+        c = (f32x4){o.x, o.y, o.z, o.w};
+      }
+      c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, k0), __builtin_bit_cast(bf16x8, qf[qt][0]), c, 0, 0, 0);
+      c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, k1), __builtin_bit_cast(bf16x8, qf[qt][1]), c, 0, 0, 0);
+      *xp = make_float4(c[0], c[1], c[2], c[3]);      // c[r]: key 16 kt + 4 fq + r, query 16 qt + fr
+    }
+  }
+}
+
+__device__ __forceinline__ float dot8_bf16(uint4 x, uint4 y) {
+  const unsigned xs[4] = {x.x, x.y, x.z, x.w}, ys[4] = {y.x, y.y, y.z, y.w};
+  float s = 0.f;
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+    s += __uint_as_float(xs[i] << 16) * __uint_as_float(ys[i] << 16) +
+         __uint_as_float(xs[i] & 0xffff0000u) * __uint_as_float(ys[i] & 0xffff0000u);
+  return s;
+}
+
 template <bool REL, int NKT>
-__global__ __launch_bounds__(256) void attn_fwd_kernel(const AttnArgs a) {
+__global__ __launch_bounds__(256, NKT > 16 ? 1 : 2) void attn_fwd_kernel(const AttnArgs a) {
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+  constexpr int XLD = NKT * 16 + 4;
+  constexpr int TPW = NKT / 4;
   const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
   const int fr = lane & 15, fq = lane >> 4;
   // (batch, head) pairs are dealt to the XCDs in contiguous runs: the query blocks of one pair share an L2
@@ -58,65 +105,74 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const AttnArgs a) {
   const bool live = z < a.B * a.H;                 // whole workgroup; dead ones only keep the barriers company
   const int zz = live ? z : 0;
   const int h = zz / a.B, b = zz % a.B;
-  const int r0 = (jb % a.nqb) * 64 + wave * 16;    // first query of this wave
-  const bool active = live && r0 < a.T1;
   const int T1 = a.T1, T2 = a.T2;
+  const int r0w = min((jb % a.nqb) * 64, T1 - 1);  // first query of the workgroup
+  const int nq = T1 - r0w;                         // its queries (up to 64)
+  const int r0 = r0w + wave * 16;                  // first query this wave owns in the softmax / context phases
+  const bool active = live && r0 < T1;
   const int qi = min(r0 + fr, T1 - 1);             // this lane's query (clamped lanes are never stored)
 
-  f32x4 S[NKT];
+  float* X = reinterpret_cast<float*>(smem_raw);
+  if (REL) {
+    // ---- bd, stored at its rel-shifted place: bd[i][m] -> (i, m - (T-1-i)) if m >= T-1-i, else (i - 1, m + i + 1) ----
+    uint4 qf[4][2];
+    const bf16_t* qs = a.qv + ((long)b * T1 + r0w) * a.ldqv + h * ATT_DK;
 #pragma unroll
-  for (int kt = 0; kt < NKT; ++kt) S[kt] = (f32x4){0.f, 0.f, 0.f, 0.f};
-
-  float* pad = reinterpret_cast<float*>(smem_raw) + (long)wave * 17 * (T2 + 1);
-  if (REL && active) {
-    // ---- bd^T tiles: rows = positions m, columns = queries r0 .. r0+31 (only r0 .. r0+16 are kept) ----
-    uint4 qf[2][2];
-#pragma unroll
-    for (int g = 0; g < 2; ++g) {
-      const bf16_t* qr = a.qv + ((long)b * T1 + min(r0 + 16 * g + fr, T1 - 1)) * a.ldqv + h * ATT_DK + fq * 8;
-      qf[g][0] = *reinterpret_cast<const uint4*>(qr);
-      qf[g][1] = *reinterpret_cast<const uint4*>(qr + 32);
+    for (int qt = 0; qt < 4; ++qt) {
+      const bf16_t* qr = qs + (long)min(qt * 16 + fr, nq - 1) * a.ldqv + fq * 8;
+      qf[qt][0] = *reinterpret_cast<const uint4*>(qr);
+      qf[qt][1] = *reinterpret_cast<const uint4*>(qr + 32);
     }
-    if (fq == 0) pad[fr * (T2 + 1)] = 0.f;                  // the zero column of rows 0 .. 15
-    if (lane == 0) pad[16 * (T2 + 1)] = 0.f;                // ... and of row 16
+    if (t < 64 && r0w + t + 1 < T2) X[t * XLD + r0w + t + 1] = 0.f;      // (i, i + 1): the zero column of the padding
 #pragma unroll
-    for (int mt = 0; mt < NKT; ++mt) {
+    for (int u = 0; u < TPW; ++u) {
+      const int mt = wave * TPW + u;
       const bf16_t* pr = a.pos + (long)min(mt * 16 + fr, T2 - 1) * a.ldpos + h * ATT_DK + fq * 8;
       const uint4 p0 = *reinterpret_cast<const uint4*>(pr), p1 = *reinterpret_cast<const uint4*>(pr + 32);
-      f32x4 c0 = (f32x4){0.f, 0.f, 0.f, 0.f}, c1 = c0;
-      c0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, p0), __builtin_bit_cast(bf16x8, qf[0][0]), c0, 0, 0, 0);
-      c0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, p1), __builtin_bit_cast(bf16x8, qf[0][1]), c0, 0, 0, 0);
-      c1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, p0), __builtin_bit_cast(bf16x8, qf[1][0]), c1, 0, 0, 0);
-      c1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, p1), __builtin_bit_cast(bf16x8, qf[1][1]), c1, 0, 0, 0);
-      // c[r] = bd[query r0 + 16 g + fr][m = 16 mt + 4 fq + r]  ->  pad row (16 g + fr), column 1 + m
 #pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const int m = mt * 16 + fq * 4 + r;
-        if (m < T2) {
-          pad[fr * (T2 + 1) + 1 + m] = c0[r];
-          if (fr == 0) pad[16 * (T2 + 1) + 1 + m] = c1[r];
+      for (int qt = 0; qt < 4; ++qt) {
+        f32x4 c = (f32x4){0.f, 0.f, 0.f, 0.f};
+        c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, p0), __builtin_bit_cast(bf16x8, qf[qt][0]), c, 0, 0, 0);
+        c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, p1), __builtin_bit_cast(bf16x8, qf[qt][1]), c, 0, 0, 0);
+        const int ql = qt * 16 + fr, i = r0w + ql;       // c[r] = bd[query i][m = 16 mt + 4 fq + r]
+        const int lim = T2 - 1 - i;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int m = mt * 16 + 4 * fq + r;
+          const int row = m >= lim ? ql : ql - 1, j = m >= lim ? m - lim : m + i + 1;
+          if (m < T2 && ql < nq && row >= 0) X[row * XLD + j] = c[r];
         }
       }
     }
-  }
-  if (active) {
-    // ---- ac^T tiles: rows = keys, columns = this wave's 16 queries ----
-    const bf16_t* qr = a.qu + ((long)b * T1 + qi) * a.ldq + h * ATT_DK + fq * 8;
-    const uint4 q0 = *reinterpret_cast<const uint4*>(qr), q1 = *reinterpret_cast<const uint4*>(qr + 32);
+    const int i64 = r0w + 64;                        // first query of the next workgroup: its low positions feed query r0w + 63
+    if (live && i64 < T1) {
+      const uint4* qr = reinterpret_cast<const uint4*>(a.qv + ((long)b * T1 + i64) * a.ldqv + h * ATT_DK);
+      for (int m = t; m <= T2 - 2 - i64; m += 256) {
+        const uint4* pr = reinterpret_cast<const uint4*>(a.pos + (long)m * a.ldpos + h * ATT_DK);
+        float s = 0.f;
 #pragma unroll
-    for (int kt = 0; kt < NKT; ++kt) {
-      const bf16_t* kr = a.k + ((long)b * T2 + min(kt * 16 + fr, T2 - 1)) * a.ldk + h * ATT_DK + fq * 8;
-      const uint4 k0 = *reinterpret_cast<const uint4*>(kr), k1 = *reinterpret_cast<const uint4*>(kr + 32);
-      S[kt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, k0), __builtin_bit_cast(bf16x8, q0), S[kt], 0, 0, 0);
-      S[kt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, k1), __builtin_bit_cast(bf16x8, q1), S[kt], 0, 0, 0);
+        for (int j = 0; j < 8; ++j) s += dot8_bf16(qr[j], pr[j]);
+        X[63 * XLD + m + i64 + 1] = s;
+      }
     }
+    __syncthreads();
   }
+  // ---- ac: X[q][j] (+)= qu_q . k_j ----
+  score_tiles_bf16<NKT>(a.k + (long)b * T2 * a.ldk + h * ATT_DK, a.ldk, T2, a.qu + ((long)b * T1 + r0w) * a.ldq + h * ATT_DK,
+                        a.ldq, nq, X, XLD, wave, fr, fq, REL);
+  // V panel [16 NKT keys][64 channels]: global loads now, LDS stores once the scores have left X
+  uint4 vreg[NKT / 2];
+#pragma unroll
+  for (int q = 0; q < NKT / 2; ++q) {
+    const int c = t + 256 * q, row = c >> 3, c16 = c & 7;
+    vreg[q] = *reinterpret_cast<const uint4*>(a.v + ((long)b * T2 + min(row, T2 - 1)) * a.ldv + h * ATT_DK + c16 * 8);
+    if (row >= T2) vreg[q] = make_uint4(0u, 0u, 0u, 0u);
+  }
+  __syncthreads();                                  // X is complete
   // ---- scale, rel-shift term, mask, softmax over the keys of query (r0 + fr) ----
   uint2 Pk[NKT];                                    // four bf16 probabilities per tile
   if (active) {
-    // pad index of (query fr, key j): T1 + (r0 + fr) T2 + j - r0 (T2 + 1); rows past T1 are clamped into the image
-    const int pmax = 17 * (T2 + 1) - 1;
-    const int pbase = T1 + (r0 + fr) * T2 - r0 * (T2 + 1);
+    f32x4 S[NKT];
     // mask bytes of this lane's keys: unconditional clamped loads (a load behind a lane-dependent guard is waited
     // for on the spot), all of them in flight together; keys past T2 are masked by index below
     unsigned mk[NKT];
@@ -133,17 +189,17 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const AttnArgs a) {
 #pragma unroll
       for (int kt = 0; kt < NKT; ++kt) mk[kt] = 0x01010101u;
     }
+    const float* xrow = &X[(wave * 16 + fr) * XLD + 4 * fq];
     float mx = -INFINITY;
 #pragma unroll
     for (int kt = 0; kt < NKT; ++kt) {
       const int j0 = kt * 16 + fq * 4;
+      const float4 xv = *reinterpret_cast<const float4*>(xrow + kt * 16);
+      const float xs[4] = {xv.x, xv.y, xv.z, xv.w};
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
-        const int j = j0 + r;
-        float x = S[kt][r];
-        if (REL) x += pad[min(pbase + j, pmax)];
-        x *= a.scale;
-        if (j >= T2 || ((mk[kt] >> (8 * r)) & 0xffu) == 0u) x = -INFINITY;
+        float x = xs[r] * a.scale;
+        if (j0 + r >= T2 || ((mk[kt] >> (8 * r)) & 0xffu) == 0u) x = -INFINITY;
         S[kt][r] = x;
         mx = fmaxf(mx, x);
       }
@@ -188,15 +244,13 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const AttnArgs a) {
 #pragma unroll
     for (int kt = 0; kt < NKT; ++kt) Pk[kt] = make_uint2(0u, 0u);
   }
-  __syncthreads();                                  // every wave is done with its pad image
-  // ---- V panel [256 keys][64 channels] -> LDS (k-strided image, rows past T2 are zero) ----
+  __syncthreads();                                  // every wave has its scores in registers
+  // ---- V panel -> LDS (k-strided image, rows past T2 are zero) ----
   bf16_t* Vs = reinterpret_cast<bf16_t*>(smem_raw);
 #pragma unroll
   for (int q = 0; q < NKT / 2; ++q) {
     const int c = t + 256 * q, row = c >> 3, c16 = c & 7;
-    uint4 v = *reinterpret_cast<const uint4*>(a.v + ((long)b * T2 + min(row, T2 - 1)) * a.ldv + h * ATT_DK + c16 * 8);
-    if (row >= T2) v = make_uint4(0u, 0u, 0u, 0u);
-    *reinterpret_cast<uint4*>(&Vs[lds_chunk_off<true, 64>(row, c16)]) = v;
+    *reinterpret_cast<uint4*>(&Vs[lds_chunk_off<true, 64>(row, c16)]) = vreg[q];
   }
   __syncthreads();
   if (!active) return;
@@ -235,7 +289,7 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const AttnArgs a) {
 }
 
 // ---- backward, query side: dP = dctx V^T, dS = scale * P (dP - rowsum(P dP)), dq = dS K in one launch ----
-// Same orientation and lane layout as the forward: dP^T tiles from register-direct V / dctx fragments, P re-read with
+// Same orientation and work splits as the forward: dP^T tiles by key quarter into the LDS matrix X, P re-read with
 // the 8-byte accesses the forward stored it with, the row sum inside the wave, dS (bf16) stored for the key-side
 // GEMMs (dK = dS^T q, and with relative positions dqv / dpos from the inverse rel_shift scatter dbd, written here
 // element by element exactly as eamd_softmax_bwd does) and dq^T = K^T dS^T from the K panel in LDS - the context
@@ -259,42 +313,38 @@ __global__ __launch_bounds__(256, NKT > 16 ? 1 : 2) void attn_bwd_q_kernel(const
   const bool live = z < a.B * a.H;
   const int zz = live ? z : 0;
   const int h = zz / a.B, b = zz % a.B;
-  const int r0 = (jb % a.nqb) * 64 + wave * 16;
-  const bool active = live && r0 < a.T1;
+  constexpr int XLD = NKT * 16 + 4;
   const int T1 = a.T1, T2 = a.T2;
+  const int r0w = min((jb % a.nqb) * 64, T1 - 1);
+  const int nq = T1 - r0w;
+  const int r0 = r0w + wave * 16;
+  const bool active = live && r0 < T1;
   const int qi = min(r0 + fr, T1 - 1);
   const bool qok = r0 + fr < T1;
 
-  // K panel [16 NKT keys][64 channels] -> LDS first: its latency hides behind the score-gradient phase
-  bf16_t* Ks = reinterpret_cast<bf16_t*>(smem_raw);
+  // ---- dP: X[q][j] = dctx_q . v_j, the key tiles split over the waves (see attn_fwd_kernel) ----
+  float* X = reinterpret_cast<float*>(smem_raw);
+  score_tiles_bf16<NKT>(a.v + (long)b * T2 * a.ldv + h * ATT_DK, a.ldv, T2, a.dctx + ((long)b * T1 + r0w) * a.ldd + h * ATT_DK,
+                        a.ldd, nq, X, XLD, wave, fr, fq, false);
+  // this lane's probabilities: in flight across the barrier
+  const bf16_t* prow = a.P + ((long)zz * T1 + qi) * a.ldp;
+  uint2 Pr[NKT];
 #pragma unroll
-  for (int q = 0; q < NKT / 2; ++q) {
-    const int c = t + 256 * q, row = c >> 3, c16 = c & 7;
-    uint4 kv = *reinterpret_cast<const uint4*>(a.k + ((long)b * T2 + min(row, T2 - 1)) * a.ldk + h * ATT_DK + c16 * 8);
-    if (row >= T2) kv = make_uint4(0u, 0u, 0u, 0u);
-    *reinterpret_cast<uint4*>(&Ks[lds_chunk_off<true, 64>(row, c16)]) = kv;
+  for (int kt = 0; kt < NKT; ++kt) {
+    const int j0 = kt * 16 + fq * 4;
+    Pr[kt] = *reinterpret_cast<const uint2*>(prow + min(j0, (int)a.ldp - 4));
   }
+  __syncthreads();
   uint2 Gk[NKT];                                    // four bf16 score gradients per tile
 #pragma unroll
   for (int kt = 0; kt < NKT; ++kt) Gk[kt] = make_uint2(0u, 0u);
   if (active) {
     f32x4 S[NKT];
-    const bf16_t* dr = a.dctx + ((long)b * T1 + qi) * a.ldd + h * ATT_DK + fq * 8;
-    const uint4 d0 = *reinterpret_cast<const uint4*>(dr), d1 = *reinterpret_cast<const uint4*>(dr + 32);
-    const bf16_t* prow = a.P + ((long)zz * T1 + qi) * a.ldp;
-    uint2 Pr[NKT];
+    const float* xrow = &X[(wave * 16 + fr) * XLD + 4 * fq];
 #pragma unroll
     for (int kt = 0; kt < NKT; ++kt) {
-      const int j0 = kt * 16 + fq * 4;
-      Pr[kt] = *reinterpret_cast<const uint2*>(prow + min(j0, (int)a.ldp - 4));
-    }
-#pragma unroll
-    for (int kt = 0; kt < NKT; ++kt) {
-      const bf16_t* vr = a.v + ((long)b * T2 + min(kt * 16 + fr, T2 - 1)) * a.ldv + h * ATT_DK + fq * 8;
-      const uint4 v0 = *reinterpret_cast<const uint4*>(vr), v1 = *reinterpret_cast<const uint4*>(vr + 32);
-      S[kt] = (f32x4){0.f, 0.f, 0.f, 0.f};
-      S[kt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, v0), __builtin_bit_cast(bf16x8, d0), S[kt], 0, 0, 0);
-      S[kt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, v1), __builtin_bit_cast(bf16x8, d1), S[kt], 0, 0, 0);
+      const float4 xv = *reinterpret_cast<const float4*>(xrow + kt * 16);
+      S[kt] = (f32x4){xv.x, xv.y, xv.z, xv.w};
     }
     // P is unpacked from its packed registers in both passes (a second fp32 copy costs 64 VGPRs and a wave per SIMD)
     auto unpack = [&](int kt, int r) __attribute__((always_inline)) -> float {
@@ -348,6 +398,21 @@ __global__ __launch_bounds__(256, NKT > 16 ? 1 : 2) void attn_bwd_q_kernel(const
     if (a.dbd && r0 == 0)                            // the head of row 0 the scatter never reaches
       for (int f = 1 + lane; f < T1; f += 64) a.dbd[zo + (f - 1)] = 0;
   }
+  // K panel [16 NKT keys][64 channels]: loads in flight across the barrier, staged over X once every wave has its rows
+  uint4 kreg[NKT / 2];
+#pragma unroll
+  for (int q = 0; q < NKT / 2; ++q) {
+    const int c = t + 256 * q, row = c >> 3, c16 = c & 7;
+    kreg[q] = *reinterpret_cast<const uint4*>(a.k + ((long)b * T2 + min(row, T2 - 1)) * a.ldk + h * ATT_DK + c16 * 8);
+    if (row >= T2) kreg[q] = make_uint4(0u, 0u, 0u, 0u);
+  }
+  __syncthreads();
+  bf16_t* Ks = reinterpret_cast<bf16_t*>(smem_raw);
+#pragma unroll
+  for (int q = 0; q < NKT / 2; ++q) {
+    const int c = t + 256 * q, row = c >> 3, c16 = c & 7;
+    *reinterpret_cast<uint4*>(&Ks[lds_chunk_off<true, 64>(row, c16)]) = kreg[q];
+  }
   __syncthreads();
   if (!active) return;
   // ---- dq^T = K^T dS^T: rows = channels, columns = queries ----
@@ -390,7 +455,10 @@ __global__ __launch_bounds__(256, NKT > 16 ? 1 : 2) void attn_bwd_q_kernel(const
 template <int NKT>
 int launch_attn_bwd(const AttnBwdArgs& a, hipStream_t stream) {
   const int nz = (a.B * a.H + 7) / 8 * 8;
-  hipLaunchKernelGGL((attn_bwd_q_kernel<NKT>), dim3((unsigned)(a.nqb * nz)), dim3(256), (size_t)NKT * 16 * ATT_DK * sizeof(bf16_t),
+  static const hipError_t attr_err = hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_bwd_q_kernel<NKT>),
+                                                         hipFuncAttributeMaxDynamicSharedMemorySize, NKT > 16 ? 144 * 1024 : 72 * 1024);
+  if (attr_err != hipSuccess) return (int)attr_err;
+  hipLaunchKernelGGL((attn_bwd_q_kernel<NKT>), dim3((unsigned)(a.nqb * nz)), dim3(256), (size_t)64 * (NKT * 16 + 4) * sizeof(float),
                      stream, a);
   EAMD_LAUNCH_CHECK();
   return EAMD_OK;
@@ -434,15 +502,12 @@ extern "C" int eamd_attn_fwd(const void* qu, int64_t ldq, const void* qv, int64_
   a.B = B; a.H = H; a.T1 = T1; a.T2 = T2; a.nqb = (T1 + 63) / 64; a.scale = scale;
   a.Pd = (bf16_t*)Pd_bf16; a.drop_p = drop_p; a.drop_step = (const unsigned long long*)drop_step; a.drop_salt = drop_salt;
   const int nkt = T2 <= 128 ? 8 : T2 <= 256 ? 16 : 32;               // key tiles of 16 the instantiation covers
-  const size_t vbytes = (size_t)nkt * 16 * ATT_DK * sizeof(bf16_t);
+  const size_t smem = (size_t)64 * (nkt * 16 + 4) * sizeof(float);   // score matrix X (the V panel staged over it is smaller)
   hipStream_t s = (hipStream_t)stream;
-  if (pos) {
-    const size_t pbytes = (size_t)4 * 17 * (T2 + 1) * sizeof(float);
-    const size_t smem = pbytes > vbytes ? pbytes : vbytes;
+  if (pos)
     return nkt == 8 ? launch_attn<true, 8>(a, smem, s) : nkt == 16 ? launch_attn<true, 16>(a, smem, s) : launch_attn<true, 32>(a, smem, s);
-  }
-  return nkt == 8 ? launch_attn<false, 8>(a, vbytes, s) : nkt == 16 ? launch_attn<false, 16>(a, vbytes, s)
-                                                                     : launch_attn<false, 32>(a, vbytes, s);
+  return nkt == 8 ? launch_attn<false, 8>(a, smem, s) : nkt == 16 ? launch_attn<false, 16>(a, smem, s)
+                                                                   : launch_attn<false, 32>(a, smem, s);
 }
 
 extern "C" int eamd_attn_bwd_q(const void* dctx, int64_t ldd, const void* k, int64_t ldk, const void* v, int64_t ldv,
