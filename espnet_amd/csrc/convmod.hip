@@ -317,8 +317,10 @@ __global__ __launch_bounds__(1024) void bn_finalize_kernel(const float* __restri
                                                            float eps, float momentum, float* __restrict__ mean_out,
                                                            float* __restrict__ rstd_out,
                                                            float* __restrict__ running_mean,
-                                                           float* __restrict__ running_var) {
+                                                           float* __restrict__ running_var,
+                                                           long long* __restrict__ num_batches_tracked) {
   __shared__ float sh[3][1024];
+  if (num_batches_tracked && blockIdx.x == 0 && threadIdx.x == 0) num_batches_tracked[0] += 1;   // batchnorm.py: += 1 per training forward
   const int t = threadIdx.x;
   const int cl = t % BN_CPB, gi = t / BN_CPB;
   const int c = blockIdx.x * BN_CPB + cl;
@@ -757,7 +759,7 @@ int eamd_bn_nslab(int64_t M, int C) {
 }
 
 int eamd_bn_stats(const float* x, float* workspace, float* mean, float* rstd, float* running_mean,
-                  float* running_var, int64_t M, int C, float eps, float momentum, void* stream) {
+                  float* running_var, int64_t* num_batches_tracked, int64_t M, int C, float eps, float momentum, void* stream) {
   if (!x || !workspace || !mean || !rstd || M <= 0 || C <= 0) return EAMD_EINVAL;
   if (!bn_shape_ok(C)) return EAMD_EUNSUPPORTED;   // channel counts 4..1024, multiples of 4
   if ((uintptr_t)x & 15) return EAMD_EINVAL;
@@ -766,7 +768,7 @@ int eamd_bn_stats(const float* x, float* workspace, float* mean, float* rstd, fl
   hipLaunchKernelGGL(bn_partial_kernel, dim3(nslab), dim3(256), 0, s, x, workspace, (long)M, C);
   EAMD_LAUNCH_CHECK();
   hipLaunchKernelGGL(bn_finalize_kernel, dim3((C + BN_CPB - 1) / BN_CPB), dim3(1024), 0, s, workspace, nslab, C, eps, momentum, mean, rstd,
-                     running_mean, running_var);
+                     running_mean, running_var, (long long*)num_batches_tracked);
   EAMD_LAUNCH_CHECK();
   return EAMD_OK;
 }

@@ -841,7 +841,10 @@ class ConvModuleBlockFn(torch.autograd.Function):
         gl = ops.glu_fwd(a, Cc)                                          # [M, C]
         d = ops.dwconv_fwd(gl, wd.view(Cc, K), bd_, B, T, Cc, K)         # depthwise conv over time
         if training:
-            bmean, brstd = ops.bn_stats(d, M, Cc, bn_eps, bn_momentum, running_mean, running_var)
+            # the BatchNorm's num_batches_tracked buffer rides on running_mean (ConvolutionModule sets it): += 1 in the
+            # same launch as the running-statistics update instead of a 1-element add kernel per layer
+            bmean, brstd = ops.bn_stats(d, M, Cc, bn_eps, bn_momentum, running_mean, running_var,
+                                        getattr(running_mean, "_eamd_nbt", None))
         else:
             bmean = running_mean
             brstd = ops.axpby(running_var, None, 1.0, 0.0)

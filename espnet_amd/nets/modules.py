@@ -466,9 +466,7 @@ class ConvolutionModule(torch.nn.Module):
     def forward(self, x):
         """the module on its own (convolution.py:53-79): no LayerNorm in front, no residual behind"""
         bn = self.norm
-        if self.training:
-            with torch.no_grad():
-                bn.num_batches_tracked += 1
+        bn.running_mean._eamd_nbt = bn.num_batches_tracked      # incremented by the statistics kernel in training mode
         return F_.ConvModuleBlockFn.apply(
             x.contiguous(), bn.running_mean, bn.running_var, self.training, self.act_id, None, bn.eps, bn.momentum,
             (0.0, self.salt_out), None, None, self.pointwise_conv1.weight, self.pointwise_conv1.bias,
@@ -478,9 +476,7 @@ class ConvolutionModule(torch.nn.Module):
 
 def conv_block(norm, cm, x, p_out=0.0):
     bn = cm.norm
-    if cm.training:
-        with torch.no_grad():
-            bn.num_batches_tracked += 1
+    bn.running_mean._eamd_nbt = bn.num_batches_tracked          # incremented by the statistics kernel in training mode
     return F_.ConvModuleBlockFn.apply(
         x.contiguous(), bn.running_mean, bn.running_var, cm.training, cm.act_id, norm.eps, bn.eps, bn.momentum,
         (p_out if cm.training else 0.0, cm.salt_out), norm.weight, norm.bias, cm.pointwise_conv1.weight, cm.pointwise_conv1.bias, cm.depthwise_conv.weight,

@@ -873,13 +873,14 @@ def dwconv_bwd_w(dy, x, dw, db, B, T, Cc, K):
           "eamd_dwconv_bwd_w")
 
 
-def bn_stats(x, M, Cc, eps, momentum, running_mean, running_var):
+def bn_stats(x, M, Cc, eps, momentum, running_mean, running_var, num_batches_tracked=None):
     nslab = _lib.lib().eamd_bn_nslab(C.c_int64(M), Cc)
     ws = torch.empty(3 * Cc * nslab, device=x.device, dtype=torch.float32)
     mean = torch.empty(Cc, device=x.device, dtype=torch.float32)
     rstd = torch.empty(Cc, device=x.device, dtype=torch.float32)
+    assert num_batches_tracked is None or (num_batches_tracked.dtype == torch.int64 and num_batches_tracked.is_cuda)
     check(_lib.lib().eamd_bn_stats(ptr(x), ptr(ws), ptr(mean), ptr(rstd), ptr(running_mean), ptr(running_var),
-                                   C.c_int64(M), Cc, C.c_float(eps), C.c_float(momentum), stream_ptr()),
+                                   ptr(num_batches_tracked), C.c_int64(M), Cc, C.c_float(eps), C.c_float(momentum), stream_ptr()),
           "eamd_bn_stats")
     return mean, rstd
 

@@ -308,9 +308,9 @@ int eamd_dwconv_bwd_w(const float* dy, const float* x, float* dw, float* db, int
                       void* stream);
 int eamd_bn_nslab(int64_t M, int C);
 /* BatchNorm1d training statistics over [M, C]; workspace 3*C*nslab floats; running stats updated in
- * place (momentum, unbiased variance) when non-NULL. */
+ * place (momentum, unbiased variance) and num_batches_tracked[0] += 1 when non-NULL (torch.nn.BatchNorm1d's buffers). */
 int eamd_bn_stats(const float* x, float* workspace, float* mean, float* rstd, float* running_mean,
-                  float* running_var, int64_t M, int C, float eps, float momentum, void* stream);
+                  float* running_var, int64_t* num_batches_tracked, int64_t M, int C, float eps, float momentum, void* stream);
 int eamd_bn_apply(const float* x, const float* mean, const float* rstd, const float* gamma, const float* beta,
                   void* y, int64_t M, int C, int act, int y_bf16, void* stream);
 /* workspace (2*nslab+2)*C floats; dgamma/dbeta ACCUMULATED. */

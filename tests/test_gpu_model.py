@@ -523,6 +523,8 @@ def test_edge_fixtures_on_hip():
     for k, v in cm.state_dict().items():
         if "running" in k:
             report("conv_module.npz " + k, v, p["sd_after/" + k], 1e-5)
+        if "num_batches_tracked" in k:      # incremented by the statistics kernel (eamd_bn_stats)
+            assert int(v) == int(p["sd_after/" + k]), (k, int(v), int(p["sd_after/" + k]))
     cm.eval()
     with torch.no_grad():
         report("conv_module.npz y (eval BatchNorm)", cm(p["x"].to(DEV)), p["y_eval"], 2e-5)

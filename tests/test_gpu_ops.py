@@ -403,7 +403,9 @@ def test_dwconv_bn(ops):
     dyb = torch.randn(M, Cc, generator=g)
     yr.backward(dyb.double())
     rmg, rvg = rm.to(DEV), rv.to(DEV)
-    mean, rstd = ops.bn_stats(xb.to(DEV), M, Cc, 1e-5, 0.1, rmg, rvg)
+    nbt = torch.full((), 7, dtype=torch.int64, device=DEV)
+    mean, rstd = ops.bn_stats(xb.to(DEV), M, Cc, 1e-5, 0.1, rmg, rvg, nbt)
+    assert int(nbt) == 8          # num_batches_tracked += 1 in the statistics launch
     y = ops.bn_apply(xb.to(DEV), mean, rstd, gam.to(DEV), bet.to(DEV), M, Cc, 2)
     report("bn_swish_fwd", y, yr, 2e-6)
     report("bn_running_mean", rmg, rmd, 1e-6)
