@@ -79,10 +79,16 @@ __global__ __launch_bounds__(256) void dwconv_kernel(const float* __restrict__ x
 // as are the 64 x K taps; wave w then produces frames [8w, 8w+8) from LDS.  L2 -> CU traffic per output drops from
 // (8 + K - 1) / 8 input rows + a 256 x K tap block per 8 frames to (NWV*8 + K - 1) / (NWV*8) rows + a 64 x K tap block
 // per NWV*8 frames (K = 31, NWV = 8: 8.8x -> 1.6x the output bytes).
-template <int NWV>
+// MODE 1 (forward of the Conformer convolution module): the input is GLU(a) of the pointwise-conv output a [B, T, 2C]
+// (value columns 0..C-1, gate columns C..2C-1), formed while the rows are loaded - the [B, T, C] GLU result is never
+// written.  MODE 2 (its input gradient, flip = 1): the result dgl is turned into da = GLU'(a) . dgl in the store -
+// da[.., c] = dgl * sigmoid(g), da[.., C + c] = dgl * v * sigmoid(g) (1 - sigmoid(g)) - fp32 or bf16 [B, T, 2C].
+// reference: conformer/convolution.py:53-79 (glu after pointwise_conv1, depthwise_conv), torch.nn.functional.glu.
+template <int NWV, int MODE>
 __global__ __launch_bounds__(NWV * 64) void dwconv_lds_kernel(const float* __restrict__ x, const float* __restrict__ w,
                                                               const float* __restrict__ bias, float* __restrict__ y,
-                                                              int B, int T, int C, int K, int pad, int flip) {
+                                                              int B, int T, int C, int K, int pad, int flip,
+                                                              const float* __restrict__ aglu, int y_bf16) {
   constexpr int TB = NWV * 8;                       // frames per block
   constexpr int NR = (TB + KMAX - 1 + NWV - 1) / NWV;   // input rows per wave (upper bound)
   constexpr int NWL = (64 * KMAX + NWV * 64 - 1) / (NWV * 64);
@@ -96,12 +102,24 @@ __global__ __launch_bounds__(NWV * 64) void dwconv_lds_kernel(const float* __res
   const int tb0 = (blockIdx.y % nblk) * TB;
   const int rows = TB + K - 1;
   const int nw = min(64, C - c0) * K;
-  const float* xb = x + (long)b * T * C + c;
+  const float* xb = x + (long)b * T * (MODE == 1 ? 2 * C : C) + c;
   float xr[NR], tw[NWL];
+  if constexpr (MODE == 1) {
+    float gr[NR];
 #pragma unroll
-  for (int i = 0; i < NR; ++i) {
-    const int ts = min(max(tb0 - pad + wave + i * NWV, 0), T - 1);
-    xr[i] = xb[(long)ts * C];
+    for (int i = 0; i < NR; ++i) {
+      const int ts = min(max(tb0 - pad + wave + i * NWV, 0), T - 1);
+      xr[i] = xb[(long)ts * 2 * C];
+      gr[i] = xb[(long)ts * 2 * C + C];
+    }
+#pragma unroll
+    for (int i = 0; i < NR; ++i) xr[i] *= eamd_sigmoid(gr[i]);
+  } else {
+#pragma unroll
+    for (int i = 0; i < NR; ++i) {
+      const int ts = min(max(tb0 - pad + wave + i * NWV, 0), T - 1);
+      xr[i] = xb[(long)ts * C];
+    }
   }
 #pragma unroll
   for (int q = 0; q < NWL; ++q) tw[q] = w[(long)c0 * K + min((int)threadIdx.x + q * NWV * 64, nw - 1)];
@@ -135,6 +153,27 @@ __global__ __launch_bounds__(NWV * 64) void dwconv_lds_kernel(const float* __res
       if (k >= 0 && k < KMAX) acc[i] += wr[k] * v;
     }
   }
+  if constexpr (MODE == 2) {
+    const float* ab = aglu + (long)b * T * 2 * C + c;
+    float av[8], gv[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      const long r = (long)min(t0 + i, T - 1) * 2 * C;
+      av[i] = ab[r]; gv[i] = ab[r + C];
+    }
+    unsigned short* y16 = reinterpret_cast<unsigned short*>(y) + (long)b * T * 2 * C + c;
+    float* y32 = y + (long)b * T * 2 * C + c;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      if (t0 + i >= T) continue;
+      const float sg = eamd_sigmoid(gv[i]);
+      const float g1 = acc[i] * sg, g2 = acc[i] * av[i] * sg * (1.f - sg);
+      const long r = (long)(t0 + i) * 2 * C;
+      if (y_bf16) { y16[r] = eamd_f2bf(g1); y16[r + C] = eamd_f2bf(g2); }
+      else { y32[r] = g1; y32[r + C] = g2; }
+    }
+    return;
+  }
   float* yb = y + (long)b * T * C + c;
 #pragma unroll
   for (int i = 0; i < 8; ++i)
@@ -151,7 +190,8 @@ constexpr int WNWV = 8;
 __global__ __launch_bounds__(WNWV * 64) void dwconv_bwd_w_kernel(const float* __restrict__ dy,
                                                                  const float* __restrict__ x, float* __restrict__ dw,
                                                                  float* __restrict__ db, int B, int T, int C, int K,
-                                                                 int pad, int tiles_per_block) {
+                                                                 int pad, int tiles_per_block, int glu) {
+  // glu: x is the pointwise-conv output a [B, T, 2C] and the convolution input is GLU(a), formed on load
   constexpr int NWV = WNWV, TB = NWV * 8;
   constexpr int NR = (TB + KMAX - 1 + NWV - 1) / NWV;
   // one buffer, two lives: the (x, dy) tile while accumulating, then one [64][K+1] slot per wave for the block sum
@@ -177,11 +217,19 @@ __global__ __launch_bounds__(WNWV * 64) void dwconv_bwd_w_kernel(const float* __
     if (q >= total) break;
     const int b = q / nblk;
     const int tb0 = (int)(q % nblk) * TB;
-    const float* xb = x + (long)b * T * C + c;
+    const int xld = glu ? 2 * C : C;
+    const float* xb = x + (long)b * T * xld + c;
     const float* gb = dy + (long)b * T * C + c;
     float xr[NR], gr[8];
 #pragma unroll
-    for (int i = 0; i < NR; ++i) xr[i] = xb[(long)min(max(tb0 - pad + wave + i * NWV, 0), T - 1) * C];
+    for (int i = 0; i < NR; ++i) xr[i] = xb[(long)min(max(tb0 - pad + wave + i * NWV, 0), T - 1) * xld];
+    if (glu) {                               // wave-uniform
+      float gg[NR];
+#pragma unroll
+      for (int i = 0; i < NR; ++i) gg[i] = xb[(long)min(max(tb0 - pad + wave + i * NWV, 0), T - 1) * xld + C];
+#pragma unroll
+      for (int i = 0; i < NR; ++i) xr[i] *= eamd_sigmoid(gg[i]);
+    }
 #pragma unroll
     for (int i = 0; i < 8; ++i) gr[i] = gb[(long)min(tb0 + wave + i * NWV, T - 1) * C];
     __syncthreads();                       // previous tile fully consumed (also orders the zero-fill of red)
@@ -696,8 +744,8 @@ inline void dwconv_launch(const float* x, const float* w, const float* bias, flo
   static const int tt_env = [] { const char* e = getenv("EAMD_DWCONV_TT"); return e ? atoi(e) : 0; }();
   const int pad = (K - 1) / 2;
   if (tt_env == 0) {      // LDS-tiled default: 64 channels x 64 frames per block
-    hipLaunchKernelGGL(dwconv_lds_kernel<8>, dim3((C + 63) / 64, B * ((T + 63) / 64)), dim3(512), 0, s, x, w, bias, y, B, T, C,
-                       K, pad, flip);
+    hipLaunchKernelGGL((dwconv_lds_kernel<8, 0>), dim3((C + 63) / 64, B * ((T + 63) / 64)), dim3(512), 0, s, x, w, bias, y, B, T, C,
+                       K, pad, flip, (const float*)nullptr, 0);
     return;
   }
   const int tt = tt_env;
@@ -745,7 +793,43 @@ int eamd_dwconv_bwd_w(const float* dy, const float* x, float* dw, float* db, int
   const long tpb = tpb_env ? tpb_env : (total + gy - 1) / gy;
   gy = (total + tpb - 1) / tpb;
   hipLaunchKernelGGL(dwconv_bwd_w_kernel, dim3(gx, (unsigned)gy), dim3(WNWV * 64), 0, (hipStream_t)stream, dy, x, dw, db, B,
-                     T, C, K, (K - 1) / 2, (int)tpb);
+                     T, C, K, (K - 1) / 2, (int)tpb, 0);
+  EAMD_LAUNCH_CHECK();
+  return EAMD_OK;
+}
+
+/* GLU-fused twins for the Conformer convolution module: `a` is the pointwise-conv output [B, T, 2C] (value | gate). */
+int eamd_dwconv_glu_fwd(const float* a, const float* w, const float* bias, float* y, int B, int T, int C, int K, void* stream) {
+  if (!a || !w || !y || B <= 0 || T <= 0 || C <= 0 || K <= 0 || (K & 1) == 0) return EAMD_EINVAL;
+  if (K > KMAX) return EAMD_EUNSUPPORTED;
+  hipLaunchKernelGGL((dwconv_lds_kernel<8, 1>), dim3((C + 63) / 64, B * ((T + 63) / 64)), dim3(512), 0, (hipStream_t)stream, a, w,
+                     bias, y, B, T, C, K, (K - 1) / 2, 0, (const float*)nullptr, 0);
+  EAMD_LAUNCH_CHECK();
+  return EAMD_OK;
+}
+
+int eamd_dwconv_glu_bwd_x(const float* dy, const float* w, const float* a, void* da, int da_bf16, int B, int T, int C, int K,
+                          void* stream) {
+  if (!dy || !w || !a || !da || B <= 0 || T <= 0 || C <= 0 || K <= 0 || (K & 1) == 0) return EAMD_EINVAL;
+  if (K > KMAX) return EAMD_EUNSUPPORTED;
+  hipLaunchKernelGGL((dwconv_lds_kernel<8, 2>), dim3((C + 63) / 64, B * ((T + 63) / 64)), dim3(512), 0, (hipStream_t)stream, dy, w,
+                     (const float*)nullptr, (float*)da, B, T, C, K, (K - 1) / 2, 1, a, da_bf16);
+  EAMD_LAUNCH_CHECK();
+  return EAMD_OK;
+}
+
+int eamd_dwconv_glu_bwd_w(const float* dy, const float* a, float* dw, float* db, int B, int T, int C, int K, void* stream) {
+  if (!dy || !a || !dw || B <= 0 || T <= 0 || C <= 0 || K <= 0 || (K & 1) == 0) return EAMD_EINVAL;
+  if (K > KMAX) return EAMD_EUNSUPPORTED;
+  const long total = (long)B * ((T + WNWV * 8 - 1) / (WNWV * 8));
+  const int gx = (C + 63) / 64;
+  long gy = (512 + gx - 1) / gx;
+  if (gy > total) gy = total;
+  if (gy < 1) gy = 1;
+  const long tpb = (total + gy - 1) / gy;
+  gy = (total + tpb - 1) / tpb;
+  hipLaunchKernelGGL(dwconv_bwd_w_kernel, dim3(gx, (unsigned)gy), dim3(WNWV * 64), 0, (hipStream_t)stream, dy, a, dw, db, B,
+                     T, C, K, (K - 1) / 2, (int)tpb, 1);
   EAMD_LAUNCH_CHECK();
   return EAMD_OK;
 }

@@ -824,6 +824,9 @@ class MHABlockFn(torch.autograd.Function):
 # params: ln_w, ln_b, pw1_w [2C,C,1], pw1_b, dw_w [C,1,K], dw_b, bn_w, bn_b, pw2_w [C,C,1], pw2_b
 # buffers: running_mean, running_var (updated in training mode)
 # =================================================================================================
+FUSE_GLU_DWCONV = True   # tests flip this to reach the stand-alone GLU kernels
+
+
 class ConvModuleBlockFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, running_mean, running_var, training, act, eps, bn_eps, bn_momentum, drop, *params):
@@ -838,8 +841,12 @@ class ConvModuleBlockFn(torch.autograd.Function):
         xn, mean, rstd = _ln_fwd_in(x2, ln_w, ln_b, eps, adt)
         assert eps is not None or p_out <= 0.0
         a = ops.linear_fwd(xn, ops.wshadow(w1).view(2 * Cc, D), b1)     # pointwise conv 1  [M, 2C] fp32
-        gl = ops.glu_fwd(a, Cc)                                          # [M, C]
-        d = ops.dwconv_fwd(gl, wd.view(Cc, K), bd_, B, T, Cc, K)         # depthwise conv over time
+        # GLU + depthwise conv over time in one launch (GLU(a) formed while the conv loads its rows, never written)
+        gl = None
+        d = ops.dwconv_glu_fwd(a, wd.view(Cc, K), bd_, B, T, Cc, K) if FUSE_GLU_DWCONV else None
+        if d is None:
+            gl = ops.glu_fwd(a, Cc)                                      # [M, C]
+            d = ops.dwconv_fwd(gl, wd.view(Cc, K), bd_, B, T, Cc, K)
         if training:
             # the BatchNorm's num_batches_tracked buffer rides on running_mean (ConvolutionModule sets it): += 1 in the
             # same launch as the running-statistics update instead of a 1-element add kernel per layer
@@ -876,9 +883,13 @@ class ConvModuleBlockFn(torch.autograd.Function):
         ops.linear_bwd_w(dob, e, sink.buf(8).view(Cc, Cc), db=sink.buf(9), a_drop=g_drop)
         de = ops.linear_bwd_x(dob, ops.wshadow(w2).view(Cc, Cc), a_drop=g_drop)
         dd = ops.bn_bwd(de, d, bmean, brstd, g, be, sink.buf(6), sink.buf(7), M, Cc, act, training)
-        dgl = ops.dwconv_bwd_x(dd, wd.view(Cc, K), B, T, Cc, K)
-        ops.dwconv_bwd_w(dd, gl, sink.buf(4).view(Cc, K), sink.buf(5), B, T, Cc, K)
-        da = ops.glu_bwd(dgl, a, Cc, adt)
+        if gl is None:       # GLU fused into the depthwise kernels: its derivative in the input-gradient store, GLU(a) on load
+            da = ops.dwconv_glu_bwd_x(dd, wd.view(Cc, K), a, B, T, Cc, K, adt)
+            ops.dwconv_glu_bwd_w(dd, a, sink.buf(4).view(Cc, K), sink.buf(5), B, T, Cc, K)
+        else:
+            dgl = ops.dwconv_bwd_x(dd, wd.view(Cc, K), B, T, Cc, K)
+            ops.dwconv_bwd_w(dd, gl, sink.buf(4).view(Cc, K), sink.buf(5), B, T, Cc, K)
+            da = ops.glu_bwd(dgl, a, Cc, adt)
         ops.linear_bwd_w(da, xn, sink.buf(2).view(2 * Cc, D), db=sink.buf(3))
         dxn = ops.linear_bwd_x(da, ops.wshadow(w1).view(2 * Cc, D))
         dx = _ln_bwd_out(dxn, x2, ln_w, mean, rstd, do, sink.buf(0), sink.buf(1), ctx.prev, (B, T, D))

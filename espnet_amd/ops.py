@@ -873,6 +873,32 @@ def dwconv_bwd_w(dy, x, dw, db, B, T, Cc, K):
           "eamd_dwconv_bwd_w")
 
 
+def dwconv_glu_fwd(a, w, bias, B, T, Cc, K):
+    """y [B*T, Cc] = dwconv(GLU(a)) for a [B*T, 2*Cc] (value | gate columns): GLU(a) is formed on load, never written.
+    Returns None when the library declines (kernel size beyond the LDS-tiled kernel)."""
+    assert a.numel() == B * T * 2 * Cc and w.numel() == Cc * K and a.dtype == torch.float32
+    y = torch.empty(B * T, Cc, device=a.device, dtype=torch.float32)
+    rc = _lib.lib().eamd_dwconv_glu_fwd(ptr(a), ptr(w), ptr(bias), ptr(y), B, T, Cc, K, stream_ptr())
+    if rc == _lib.EAMD_EUNSUPPORTED:
+        return None
+    check(rc, "eamd_dwconv_glu_fwd")
+    return y
+
+
+def dwconv_glu_bwd_x(dy, w, a, B, T, Cc, K, out_dtype=torch.float32):
+    """da [B*T, 2*Cc] = GLU'(a) . dwconv_bwd_x(dy): the gradient of the GLU output is never written"""
+    da = torch.empty(a.shape, device=a.device, dtype=out_dtype)
+    check(_lib.lib().eamd_dwconv_glu_bwd_x(ptr(dy), ptr(w), ptr(a), ptr(da), int(out_dtype == torch.bfloat16), B, T, Cc, K,
+                                           stream_ptr()), "eamd_dwconv_glu_bwd_x")
+    return da
+
+
+def dwconv_glu_bwd_w(dy, a, dw, db, B, T, Cc, K):
+    assert dw.numel() == Cc * K and (db is None or db.numel() == Cc)
+    check(_lib.lib().eamd_dwconv_glu_bwd_w(ptr(dy), ptr(a), ptr(dw), ptr(db), B, T, Cc, K, stream_ptr()),
+          "eamd_dwconv_glu_bwd_w")
+
+
 def bn_stats(x, M, Cc, eps, momentum, running_mean, running_var, num_batches_tracked=None):
     nslab = _lib.lib().eamd_bn_nslab(C.c_int64(M), Cc)
     ws = torch.empty(3 * Cc * nslab, device=x.device, dtype=torch.float32)

@@ -306,6 +306,14 @@ int eamd_dwconv_bwd_x(const float* dy, const float* w, float* dx, int B, int T, 
 /* dw[C,K], db[C] are ACCUMULATED. */
 int eamd_dwconv_bwd_w(const float* dy, const float* x, float* dw, float* db, int B, int T, int C, int K,
                       void* stream);
+/* GLU-fused twins for the Conformer convolution module (conformer/convolution.py:53-79): `a` = pointwise_conv1 output
+ * [B, T, 2C] (value columns | gate columns).  eamd_dwconv_glu_fwd: y = dwconv(GLU(a)) without writing GLU(a);
+ * eamd_dwconv_glu_bwd_w: dw / db += as eamd_dwconv_bwd_w with x = GLU(a) formed on load; eamd_dwconv_glu_bwd_x:
+ * da [B, T, 2C] (fp32, or bf16 when da_bf16) = GLU'(a) . dwconv_bwd_x(dy) - the depthwise input gradient never written. */
+int eamd_dwconv_glu_fwd(const float* a, const float* w, const float* bias, float* y, int B, int T, int C, int K, void* stream);
+int eamd_dwconv_glu_bwd_x(const float* dy, const float* w, const float* a, void* da, int da_bf16, int B, int T, int C, int K,
+                          void* stream);
+int eamd_dwconv_glu_bwd_w(const float* dy, const float* a, float* dw, float* db, int B, int T, int C, int K, void* stream);
 int eamd_bn_nslab(int64_t M, int C);
 /* BatchNorm1d training statistics over [M, C]; workspace 3*C*nslab floats; running stats updated in
  * place (momentum, unbiased variance) and num_batches_tracked[0] += 1 when non-NULL (torch.nn.BatchNorm1d's buffers). */

@@ -785,6 +785,33 @@ def test_grouped_weight_gradient_launch_vs_float64(ops, prec):
         espnet_amd.set_precision("fp32")
 
 
+@pytest.mark.parametrize("shape", [(32, 249, 256, 31), (3, 70, 96, 15), (2, 33, 300, 7), (1, 5, 32, 3)])
+def test_dwconv_glu_fused_vs_float64(ops, shape):
+    """eamd_dwconv_glu_fwd / _bwd_x / _bwd_w (GLU formed on load, its derivative applied in the input-gradient store)
+    against torch float64: glu -> depthwise conv1d forward, and the gradients w.r.t. the pointwise-conv output a, the
+    depthwise weight and bias; fp32 and bf16 da"""
+    B, T, Cc, K = shape
+    g = torch.Generator().manual_seed(T + K)
+    a = torch.randn(B, T, 2 * Cc, generator=g)
+    w, bias, dy = 0.3 * torch.randn(Cc, 1, K, generator=g), torch.randn(Cc, generator=g), torch.randn(B, T, Cc, generator=g)
+    ad, wd_, bd_ = a.double().requires_grad_(True), w.double().requires_grad_(True), bias.double().requires_grad_(True)
+    gl = torch.nn.functional.glu(ad, dim=-1)
+    yr = torch.nn.functional.conv1d(gl.transpose(1, 2), wd_, bd_, padding=(K - 1) // 2, groups=Cc).transpose(1, 2)
+    yr.backward(dy.double())
+    a2, wk = a.view(B * T, 2 * Cc).to(DEV), w.view(Cc, K).to(DEV)
+    y = ops.dwconv_glu_fwd(a2, wk, bias.to(DEV), B, T, Cc, K)
+    report("dwconv_glu_fwd %s" % (shape,), y.view(B, T, Cc), yr, 2e-6)
+    dyd = dy.view(B * T, Cc).to(DEV)
+    da = ops.dwconv_glu_bwd_x(dyd, wk, a2, B, T, Cc, K)
+    report("dwconv_glu_bwd_x %s" % (shape,), da.view(B, T, 2 * Cc), ad.grad, 2e-6)
+    da16 = ops.dwconv_glu_bwd_x(dyd, wk, a2, B, T, Cc, K, torch.bfloat16)
+    report("dwconv_glu_bwd_x bf16 %s" % (shape,), da16.float().view(B, T, 2 * Cc), ad.grad, 4e-3)
+    dw, db = torch.zeros(Cc, K, device=DEV), torch.zeros(Cc, device=DEV)
+    ops.dwconv_glu_bwd_w(dyd, a2, dw, db, B, T, Cc, K)
+    report("dwconv_glu_bwd_w %s" % (shape,), dw, wd_.grad.view(Cc, K), 1e-5)
+    report("dwconv_glu_bwd_w bias %s" % (shape,), db, bd_.grad, 1e-5)
+
+
 @pytest.mark.parametrize("shape", [(4, 80, 128, 31), (2, 33, 300, 29), (3, 17, 64, 3), (1, 5, 32, 1)])
 def test_dwconv_kernel_sizes(ops, shape):
     """depthwise conv fwd / input grad / weight grad at the recipe's kernel size 31 and at ragged channel counts"""
