@@ -74,6 +74,8 @@ __global__ __launch_bounds__(256) void dwconv_kernel(const float* __restrict__ x
     if (t0 + i < T) yb[(long)(t0 + i) * C] = acc[i];
 }
 
+__device__ __forceinline__ void chan_merge(float& n, float& mean, float& m2, float nb, float mb, float m2b);
+
 // LDS-tiled form of the same correlation (the default): a block owns 64 channels x NWV*8 frames.  The NWV*8 + K - 1
 // input rows are fetched ONCE per block (coalesced 256-byte rows, all loads of a thread in flight together) into LDS,
 // as are the 64 x K taps; wave w then produces frames [8w, 8w+8) from LDS.  L2 -> CU traffic per output drops from
@@ -88,7 +90,11 @@ template <int NWV, int MODE>
 __global__ __launch_bounds__(NWV * 64) void dwconv_lds_kernel(const float* __restrict__ x, const float* __restrict__ w,
                                                               const float* __restrict__ bias, float* __restrict__ y,
                                                               int B, int T, int C, int K, int pad, int flip,
-                                                              const float* __restrict__ aglu, int y_bf16) {
+                                                              const float* __restrict__ aglu, int y_bf16,
+                                                              float* __restrict__ bn_part) {
+  // bn_part (MODE 1): the block also leaves the BatchNorm partial statistics (count, mean, M2 per channel) of its
+  // 64-frame x 64-channel output tile in slab blockIdx.y of the workspace eamd_bn_finalize merges - bn_partial's job
+  // without re-reading the output
   constexpr int TB = NWV * 8;                       // frames per block
   constexpr int NR = (TB + KMAX - 1 + NWV - 1) / NWV;   // input rows per wave (upper bound)
   constexpr int NWL = (64 * KMAX + NWV * 64 - 1) / (NWV * 64);
@@ -133,7 +139,7 @@ __global__ __launch_bounds__(NWV * 64) void dwconv_lds_kernel(const float* __res
     if ((int)threadIdx.x + q * NWV * 64 < nw) wl[threadIdx.x + q * NWV * 64] = tw[q];
   __syncthreads();
   const int t0 = tb0 + wave * 8;
-  if (c0 + lane >= C || t0 >= T) return;
+  if ((MODE != 1 || !bn_part) && (c0 + lane >= C || t0 >= T)) return;
   float wr[KMAX];
 #pragma unroll
   for (int k = 0; k < KMAX; ++k) {
@@ -175,9 +181,28 @@ __global__ __launch_bounds__(NWV * 64) void dwconv_lds_kernel(const float* __res
     return;
   }
   float* yb = y + (long)b * T * C + c;
+  const bool clive = c0 + lane < C;
 #pragma unroll
   for (int i = 0; i < 8; ++i)
-    if (t0 + i < T) yb[(long)(t0 + i) * C] = acc[i];
+    if (clive && t0 + i < T) yb[(long)(t0 + i) * C] = acc[i];
+  if constexpr (MODE == 1) {
+    if (bn_part) {
+      __shared__ float bsh[NWV][3][64];
+      float n = 0.f, sum = 0.f;
+#pragma unroll
+      for (int i = 0; i < 8; ++i) if (t0 + i < T) { n += 1.f; sum += acc[i]; }
+      float mean = n > 0.f ? sum / n : 0.f, m2 = 0.f;
+#pragma unroll
+      for (int i = 0; i < 8; ++i) if (t0 + i < T) { const float d = acc[i] - mean; m2 += d * d; }
+      bsh[wave][0][lane] = n; bsh[wave][1][lane] = mean; bsh[wave][2][lane] = m2;
+      __syncthreads();
+      if (wave == 0 && clive) {            // fixed merge order: bitwise reproducible
+        for (int w2 = 1; w2 < NWV; ++w2) chan_merge(n, mean, m2, bsh[w2][0][lane], bsh[w2][1][lane], bsh[w2][2][lane]);
+        float* pp = bn_part + (long)blockIdx.y * 3 * C + c0 + lane;
+        pp[0] = n; pp[C] = mean; pp[2 * C] = m2;
+      }
+    }
+  }
 }
 
 // dw[c,k] += sum_{b,t} dy[b,t,c] * x[b,t+k-pad,c];  db[c] += sum dy.
@@ -745,7 +770,7 @@ inline void dwconv_launch(const float* x, const float* w, const float* bias, flo
   const int pad = (K - 1) / 2;
   if (tt_env == 0) {      // LDS-tiled default: 64 channels x 64 frames per block
     hipLaunchKernelGGL((dwconv_lds_kernel<8, 0>), dim3((C + 63) / 64, B * ((T + 63) / 64)), dim3(512), 0, s, x, w, bias, y, B, T, C,
-                       K, pad, flip, (const float*)nullptr, 0);
+                       K, pad, flip, (const float*)nullptr, 0, (float*)nullptr);
     return;
   }
   const int tt = tt_env;
@@ -799,11 +824,12 @@ int eamd_dwconv_bwd_w(const float* dy, const float* x, float* dw, float* db, int
 }
 
 /* GLU-fused twins for the Conformer convolution module: `a` is the pointwise-conv output [B, T, 2C] (value | gate). */
-int eamd_dwconv_glu_fwd(const float* a, const float* w, const float* bias, float* y, int B, int T, int C, int K, void* stream) {
+int eamd_dwconv_glu_fwd(const float* a, const float* w, const float* bias, float* y, float* bn_part, int B, int T, int C, int K,
+                        void* stream) {
   if (!a || !w || !y || B <= 0 || T <= 0 || C <= 0 || K <= 0 || (K & 1) == 0) return EAMD_EINVAL;
   if (K > KMAX) return EAMD_EUNSUPPORTED;
   hipLaunchKernelGGL((dwconv_lds_kernel<8, 1>), dim3((C + 63) / 64, B * ((T + 63) / 64)), dim3(512), 0, (hipStream_t)stream, a, w,
-                     bias, y, B, T, C, K, (K - 1) / 2, 0, (const float*)nullptr, 0);
+                     bias, y, B, T, C, K, (K - 1) / 2, 0, (const float*)nullptr, 0, bn_part);
   EAMD_LAUNCH_CHECK();
   return EAMD_OK;
 }
@@ -813,7 +839,7 @@ int eamd_dwconv_glu_bwd_x(const float* dy, const float* w, const float* a, void*
   if (!dy || !w || !a || !da || B <= 0 || T <= 0 || C <= 0 || K <= 0 || (K & 1) == 0) return EAMD_EINVAL;
   if (K > KMAX) return EAMD_EUNSUPPORTED;
   hipLaunchKernelGGL((dwconv_lds_kernel<8, 2>), dim3((C + 63) / 64, B * ((T + 63) / 64)), dim3(512), 0, (hipStream_t)stream, dy, w,
-                     (const float*)nullptr, (float*)da, B, T, C, K, (K - 1) / 2, 1, a, da_bf16);
+                     (const float*)nullptr, (float*)da, B, T, C, K, (K - 1) / 2, 1, a, da_bf16, (float*)nullptr);
   EAMD_LAUNCH_CHECK();
   return EAMD_OK;
 }
@@ -853,6 +879,17 @@ int eamd_bn_stats(const float* x, float* workspace, float* mean, float* rstd, fl
   EAMD_LAUNCH_CHECK();
   hipLaunchKernelGGL(bn_finalize_kernel, dim3((C + BN_CPB - 1) / BN_CPB), dim3(1024), 0, s, workspace, nslab, C, eps, momentum, mean, rstd,
                      running_mean, running_var, (long long*)num_batches_tracked);
+  EAMD_LAUNCH_CHECK();
+  return EAMD_OK;
+}
+
+/* second stage of eamd_bn_stats alone, for partial statistics a producer kernel left behind (eamd_dwconv_glu_fwd's bn_part:
+ * nslab = B * ceil(T / 64) slabs of [count | mean | M2] x C) */
+int eamd_bn_finalize(const float* part, int nslab, float* mean, float* rstd, float* running_mean, float* running_var,
+                     int64_t* num_batches_tracked, int C, float eps, float momentum, void* stream) {
+  if (!part || !mean || !rstd || nslab <= 0 || C <= 0) return EAMD_EINVAL;
+  hipLaunchKernelGGL(bn_finalize_kernel, dim3((C + BN_CPB - 1) / BN_CPB), dim3(1024), 0, (hipStream_t)stream, part, nslab, C, eps,
+                     momentum, mean, rstd, running_mean, running_var, (long long*)num_batches_tracked);
   EAMD_LAUNCH_CHECK();
   return EAMD_OK;
 }

@@ -842,16 +842,22 @@ class ConvModuleBlockFn(torch.autograd.Function):
         assert eps is not None or p_out <= 0.0
         a = ops.linear_fwd(xn, ops.wshadow(w1).view(2 * Cc, D), b1)     # pointwise conv 1  [M, 2C] fp32
         # GLU + depthwise conv over time in one launch (GLU(a) formed while the conv loads its rows, never written)
-        gl = None
-        d = ops.dwconv_glu_fwd(a, wd.view(Cc, K), bd_, B, T, Cc, K) if FUSE_GLU_DWCONV else None
+        # (in training mode the same launch leaves the BatchNorm partial statistics of its output tiles behind).
+        # The BatchNorm's num_batches_tracked buffer rides on running_mean (ConvolutionModule sets it): += 1 in the
+        # same launch as the running-statistics update instead of a 1-element add kernel per layer
+        gl = d = bmean = None
+        nbt = getattr(running_mean, "_eamd_nbt", None)
+        if FUSE_GLU_DWCONV:
+            d = ops.dwconv_glu_fwd(a, wd.view(Cc, K), bd_, B, T, Cc, K,
+                                   bn=(bn_eps, bn_momentum, running_mean, running_var, nbt) if training else None)
+            if d is not None and training:
+                d, bmean, brstd = d
         if d is None:
             gl = ops.glu_fwd(a, Cc)                                      # [M, C]
             d = ops.dwconv_fwd(gl, wd.view(Cc, K), bd_, B, T, Cc, K)
         if training:
-            # the BatchNorm's num_batches_tracked buffer rides on running_mean (ConvolutionModule sets it): += 1 in the
-            # same launch as the running-statistics update instead of a 1-element add kernel per layer
-            bmean, brstd = ops.bn_stats(d, M, Cc, bn_eps, bn_momentum, running_mean, running_var,
-                                        getattr(running_mean, "_eamd_nbt", None))
+            if bmean is None:
+                bmean, brstd = ops.bn_stats(d, M, Cc, bn_eps, bn_momentum, running_mean, running_var, nbt)
         else:
             bmean = running_mean
             brstd = ops.axpby(running_var, None, 1.0, 0.0)

@@ -873,16 +873,27 @@ def dwconv_bwd_w(dy, x, dw, db, B, T, Cc, K):
           "eamd_dwconv_bwd_w")
 
 
-def dwconv_glu_fwd(a, w, bias, B, T, Cc, K):
+def dwconv_glu_fwd(a, w, bias, B, T, Cc, K, bn=None):
     """y [B*T, Cc] = dwconv(GLU(a)) for a [B*T, 2*Cc] (value | gate columns): GLU(a) is formed on load, never written.
+    bn = (eps, momentum, running_mean, running_var, num_batches_tracked): training-mode BatchNorm statistics of y from
+    the same launch (partials in its epilogue + eamd_bn_finalize) -> (y, mean, rstd).
     Returns None when the library declines (kernel size beyond the LDS-tiled kernel)."""
     assert a.numel() == B * T * 2 * Cc and w.numel() == Cc * K and a.dtype == torch.float32
     y = torch.empty(B * T, Cc, device=a.device, dtype=torch.float32)
-    rc = _lib.lib().eamd_dwconv_glu_fwd(ptr(a), ptr(w), ptr(bias), ptr(y), B, T, Cc, K, stream_ptr())
+    nslab = B * ((T + 63) // 64)
+    part = torch.empty(3 * Cc * nslab, device=a.device, dtype=torch.float32) if bn is not None else None
+    rc = _lib.lib().eamd_dwconv_glu_fwd(ptr(a), ptr(w), ptr(bias), ptr(y), ptr(part), B, T, Cc, K, stream_ptr())
     if rc == _lib.EAMD_EUNSUPPORTED:
         return None
     check(rc, "eamd_dwconv_glu_fwd")
-    return y
+    if bn is None:
+        return y
+    eps, momentum, running_mean, running_var, nbt = bn
+    mean = torch.empty(Cc, device=a.device, dtype=torch.float32)
+    rstd = torch.empty(Cc, device=a.device, dtype=torch.float32)
+    check(_lib.lib().eamd_bn_finalize(ptr(part), nslab, ptr(mean), ptr(rstd), ptr(running_mean), ptr(running_var), ptr(nbt), Cc,
+                                      C.c_float(eps), C.c_float(momentum), stream_ptr()), "eamd_bn_finalize")
+    return y, mean, rstd
 
 
 def dwconv_glu_bwd_x(dy, w, a, B, T, Cc, K, out_dtype=torch.float32):

@@ -310,7 +310,8 @@ int eamd_dwconv_bwd_w(const float* dy, const float* x, float* dw, float* db, int
  * [B, T, 2C] (value columns | gate columns).  eamd_dwconv_glu_fwd: y = dwconv(GLU(a)) without writing GLU(a);
  * eamd_dwconv_glu_bwd_w: dw / db += as eamd_dwconv_bwd_w with x = GLU(a) formed on load; eamd_dwconv_glu_bwd_x:
  * da [B, T, 2C] (fp32, or bf16 when da_bf16) = GLU'(a) . dwconv_bwd_x(dy) - the depthwise input gradient never written. */
-int eamd_dwconv_glu_fwd(const float* a, const float* w, const float* bias, float* y, int B, int T, int C, int K, void* stream);
+int eamd_dwconv_glu_fwd(const float* a, const float* w, const float* bias, float* y, float* bn_part, int B, int T, int C, int K,
+                        void* stream);   /* bn_part (optional): 3*C*B*ceil(T/64) floats of BatchNorm partial statistics of y */
 int eamd_dwconv_glu_bwd_x(const float* dy, const float* w, const float* a, void* da, int da_bf16, int B, int T, int C, int K,
                           void* stream);
 int eamd_dwconv_glu_bwd_w(const float* dy, const float* a, float* dw, float* db, int B, int T, int C, int K, void* stream);
@@ -319,6 +320,10 @@ int eamd_bn_nslab(int64_t M, int C);
  * place (momentum, unbiased variance) and num_batches_tracked[0] += 1 when non-NULL (torch.nn.BatchNorm1d's buffers). */
 int eamd_bn_stats(const float* x, float* workspace, float* mean, float* rstd, float* running_mean,
                   float* running_var, int64_t* num_batches_tracked, int64_t M, int C, float eps, float momentum, void* stream);
+/* Second stage alone: merges nslab slabs of [count | mean | M2] x C (eamd_dwconv_glu_fwd's bn_part) into mean / rstd and
+ * updates the running statistics and the batch counter as eamd_bn_stats does. */
+int eamd_bn_finalize(const float* part, int nslab, float* mean, float* rstd, float* running_mean, float* running_var,
+                     int64_t* num_batches_tracked, int C, float eps, float momentum, void* stream);
 int eamd_bn_apply(const float* x, const float* mean, const float* rstd, const float* gamma, const float* beta,
                   void* y, int64_t M, int C, int act, int y_bf16, void* stream);
 /* workspace (2*nslab+2)*C floats; dgamma/dbeta ACCUMULATED. */

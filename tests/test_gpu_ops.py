@@ -801,6 +801,15 @@ def test_dwconv_glu_fused_vs_float64(ops, shape):
     a2, wk = a.view(B * T, 2 * Cc).to(DEV), w.view(Cc, K).to(DEV)
     y = ops.dwconv_glu_fwd(a2, wk, bias.to(DEV), B, T, Cc, K)
     report("dwconv_glu_fwd %s" % (shape,), y.view(B, T, Cc), yr, 2e-6)
+    # with the BatchNorm statistics of the output from the same launch (partials in the epilogue + eamd_bn_finalize)
+    rm, rv = torch.zeros(Cc, device=DEV), torch.ones(Cc, device=DEV)
+    nbt = torch.zeros((), dtype=torch.int64, device=DEV)
+    y2, mean, rstd = ops.dwconv_glu_fwd(a2, wk, bias.to(DEV), B, T, Cc, K, bn=(1e-5, 0.1, rm, rv, nbt))
+    assert torch.equal(y2, y) and int(nbt) == 1
+    yd = yr.detach().reshape(-1, Cc)
+    report("dwconv_glu_fwd bn mean %s" % (shape,), mean, yd.mean(0), 1e-5)
+    report("dwconv_glu_fwd bn rstd %s" % (shape,), rstd, (yd.var(0, unbiased=False) + 1e-5).rsqrt(), 1e-5)
+    report("dwconv_glu_fwd bn running_var %s" % (shape,), rv, 0.9 + 0.1 * yd.var(0, unbiased=True), 1e-5)
     dyd = dy.view(B * T, Cc).to(DEV)
     da = ops.dwconv_glu_bwd_x(dyd, wk, a2, B, T, Cc, K)
     report("dwconv_glu_bwd_x %s" % (shape,), da.view(B, T, 2 * Cc), ad.grad, 2e-6)
