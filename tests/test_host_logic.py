@@ -74,6 +74,60 @@ def test_flat_arena_groups_qkv_projections():
     assert sorted(flat.offsets) == flat.offsets                  # params list is in layout order (bucket builder relies on it)
 
 
+def test_flat_arena_groups_stack_wide_projections():
+    """FlatParams lays linear_k / linear_v of ALL source-attention modules of the decoder stack and linear_pos of ALL
+    encoder layers back to back (one GEMM each, functional.SharedProjFn); self-attention q / k / v stay grouped per module;
+    state_dict names and values are untouched; the phased data-parallel plan still gets contiguous arena ranges"""
+    import argparse
+    from espnet_amd import train
+    from espnet_amd.nets.e2e_asr_conformer import E2E
+    ns = argparse.Namespace(
+        adim=64, aheads=2, elayers=4, eunits=48, dlayers=3, dunits=48, mtlalpha=0.3, lsm_weight=0.1, dropout_rate=0.0,
+        transformer_length_normalized_loss=False, transformer_encoder_pos_enc_layer_type="rel_pos",
+        transformer_encoder_selfattn_layer_type="rel_selfattn", macaron_style=True, use_cnn_module=True, cnn_module_kernel=7)
+    torch.manual_seed(1)
+    model = E2E(20, 30, ns)
+    before = {k: v.detach().clone() for k, v in model.state_dict().items()}
+    flat = train.FlatParams(model)
+    assert list(model.state_dict().keys()) == list(before.keys())
+    for k, v in model.state_dict().items():
+        assert torch.equal(v, before[k])
+    def run(ts):
+        return all(b.data_ptr() == a.data_ptr() + a.numel() * 4 for a, b in zip(ts, ts[1:]))
+    dec = model.decoder.decoders
+    kv_w = [w for m in dec for w in (m.src_attn.linear_k.weight, m.src_attn.linear_v.weight)]
+    kv_b = [w for m in dec for w in (m.src_attn.linear_k.bias, m.src_attn.linear_v.bias)]
+    assert run(kv_w) and run(kv_b) and run([w._eamd_grad for w in kv_w]) and run([w._eamd_grad for w in kv_b])
+    pos = [m.self_attn.linear_pos.weight for m in model.encoder.encoders]
+    assert run(pos) and run([w._eamd_grad for w in pos])
+    for m in list(model.encoder.encoders) + [d.self_attn for d in dec]:
+        att = m.self_attn if hasattr(m, "self_attn") else m
+        assert run([att.linear_q.weight, att.linear_k.weight, att.linear_v.weight])
+    assert sorted(flat.offsets) == flat.offsets and len(set(map(id, flat.params))) == len(list(model.parameters()))
+    # arena ranges of the phased backward (decoder / upper encoder layers / ... / input layer + lowest layers + linear_pos group)
+    step = train.GraphedDataParallelStep.__new__(train.GraphedDataParallelStep)
+    step.model, step.flat, step.ranges, step._stack = model, flat, [(0, flat.numel)], None
+    step._plan_phases()
+    assert len(step.ranges) >= 3 and step.ranges[0][0] == 0 or min(r[0] for r in step.ranges) == 0
+    cover = sorted(step.ranges)
+    assert cover[0][0] == 0 and cover[-1][1] == flat.numel and all(a[1] == b[0] for a, b in zip(cover, cover[1:]))
+
+
+def test_bucketed_graph_step_bucket_key_from_host_lengths():
+    """BucketedGraphStep.bucket rounds (T, L) up to the bucket edges and takes the label lengths from the host when given"""
+    from espnet_amd import train
+    class M:  # noqa: D401
+        ignore_id = -1
+    st = train.BucketedGraphStep.__new__(train.BucketedGraphStep)
+    st.model, st.t_edge, st.l_edge = M(), 64, 8
+    xs = torch.zeros(3, 700, 4)
+    ys = torch.full((3, 20), -1, dtype=torch.long)
+    ys[0, :13] = 5
+    assert st.bucket(xs, [700, 650, 600], ys) == (3, 704, 16)
+    assert st.bucket(xs, torch.tensor([640, 600, 500]), ys, olens=[13, 4, 2]) == (3, 640, 16)
+    assert st.bucket(xs, [65, 3, 2], ys, olens=torch.tensor([17, 1, 1])) == (3, 128, 24)
+
+
 def test_unsupported_variants_fail_loudly():
     from espnet_amd.nets.rnn.attentions import initial_att
     from espnet_amd.nets.rnn.encoders import Encoder
