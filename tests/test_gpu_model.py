@@ -314,8 +314,19 @@ def test_config2_fullsize_vs_oracle(oracle):
         flat.refresh_shadow()
         flat.zero_grad()
         loss = model(xs.to(DEV), ilens, ys.to(DEV))
-        loss.backward()
-        got = dict(loss=float(loss), loss_ctc=float(model._loss_ctc_t), loss_att=float(model._loss_att_t))
+        from espnet_amd import ops
+        rec = []
+        ops._gemm_record = rec
+        ops.wgrad_group_begin()              # as train.train_step does: the weight gradients leave as grouped launches
+        try:
+            loss.backward()
+        finally:
+            ops.wgrad_group_end()
+            ops._gemm_record = None
+        ngroup = sum(1 for r in rec if r[0] is None and isinstance(r[1][1], list))
+        assert ngroup == (2 if prec == "fp32" else 1), ngroup          # the path bench.py times
+        del rec
+        got = dict(loss=float(loss.detach()), loss_ctc=float(model._loss_ctc_t.detach()), loss_att=float(model._loss_att_t.detach()))
         for k in ("loss", "loss_ctc", "loss_att"):
             rel = abs(got[k] - ref_l[k]) / abs(ref_l[k])
             print(f"[parity] config2 full size [{prec}] {k}: hip={got[k]:.6f} oracle={ref_l[k]:.6f} rel={rel:.2e}")
