@@ -43,11 +43,7 @@ class LSTM(torch.nn.Module):
         if min(ilens) < T:
             live = ops.h2d_cached("live", (np.arange(T)[:, None] < np.asarray(ilens)[None, :]).astype(np.uint8),
                                   xs_pad.device)
-        outs = []
-        for sfx, rev in (("", False),) + ((("_reverse", True),) if self.bidirectional else ()):
-            gx = F_.LinearFn.apply(x_tm, getattr(self, "weight_ih_l0" + sfx), getattr(self, "bias_ih_l0" + sfx))
-            outs.append(self.seq_fn.apply(gx, getattr(self, "weight_hh_l0" + sfx), getattr(self, "bias_hh_l0" + sfx),
-                                          live, rev))
+        outs = _directions(self.seq_fn, x_tm, live, self.bidirectional, lambda n, sfx: getattr(self, n + "_l0" + sfx))
         y = outs[0] if len(outs) == 1 else torch.cat(outs, dim=-1)
         return y.transpose(0, 1).contiguous()
 
@@ -57,6 +53,29 @@ class GRU(LSTM):
 
     gates = 3
     seq_fn = R_.GRUSeqFn
+
+
+def _directions(seq_fn, x_tm, live, bidir, param):
+    """input projection + recurrence of one layer for the forward (and reverse) direction -> [y_fwd (, y_rev)].
+    The two directions are independent chains of hundreds of small step launches (each far from filling the chip): the
+    reverse one runs on a second stream (a parallel branch of a captured graph); autograd runs its backward there too."""
+    def one(sfx, rev):
+        gx = F_.LinearFn.apply(x_tm, param("weight_ih", sfx), param("bias_ih", sfx))
+        return seq_fn.apply(gx, param("weight_hh", sfx), param("bias_hh", sfx), live, rev)
+    if not bidir:
+        return [one("", False)]
+    if not (ops.TWO_STREAM_BIRNN and x_tm.is_cuda):
+        return [one("", False), one("_reverse", True)]
+    cur = torch.cuda.current_stream(x_tm.device)
+    side = ops.side_stream(x_tm.device)
+    side.wait_stream(cur)                       # the layer input is ready
+    with torch.cuda.stream(side):
+        y_rev = one("_reverse", True)
+    y_fwd = one("", False)
+    cur.wait_stream(side)
+    y_rev.record_stream(cur)                    # consumed (concatenated) on the main stream
+    x_tm.record_stream(side)
+    return [y_fwd, y_rev]
 
 
 def _lstm_or_raise(typ):
@@ -124,11 +143,8 @@ class RNN(torch.nn.Module):
             live = ops.h2d_cached("live", (np.arange(T)[:, None] < np.asarray(ilens)[None, :]).astype(np.uint8),
                                   xs_pad.device)
         for k in range(self.elayers):
-            outs = []
-            for sfx, rev in (("", False),) + ((("_reverse", True),) if self.bidir else ()):
-                p = lambda n: getattr(self.nbrnn, "%s_l%d%s" % (n, k, sfx))   # noqa: E731
-                gx = F_.LinearFn.apply(x, p("weight_ih"), p("bias_ih"))
-                outs.append(self.seq_fn.apply(gx, p("weight_hh"), p("bias_hh"), live, rev))
+            outs = _directions(self.seq_fn, x, live, self.bidir,
+                               lambda n, sfx, k=k: getattr(self.nbrnn, "%s_l%d%s" % (n, k, sfx)))
             x = outs[0] if len(outs) == 1 else torch.cat(outs, dim=-1)
             if k < self.elayers - 1:   # torch.nn.LSTM(dropout=p): between layers, training mode only
                 x = F_.dropout(x, self.dropout, self.salts[k], self.training)

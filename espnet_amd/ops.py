@@ -1368,6 +1368,20 @@ def h2d_cached(tag, array, device):
     return t
 
 
+_side_streams = {}
+TWO_STREAM_BIRNN = True     # the two directions of a bidirectional recurrent layer on two streams (tests flip it)
+
+
+def side_stream(device, i=0):
+    """a cached second stream per device (independent branches of a step: the reverse direction of a BLSTM layer)"""
+    key = (str(device), i)
+    st = _side_streams.get(key)
+    if st is None:
+        st = torch.cuda.Stream(device=device)
+        _side_streams[key] = st
+    return st
+
+
 def h2d_async(t_cpu, device):
     """small host tensor -> device without making the host wait for the stream: a copy from PAGEABLE memory blocks the
     host until everything queued before it has run (a whole training step behind a graph replay); from a pinned
