@@ -304,8 +304,8 @@ def run_precision(a, prec, rank, world, dev):
             traffic_src = os.path.basename(traffic_src)
         except Exception:  # noqa: BLE001
             traffic = None
-        kern = ("gemm_f32_kernel<*> (+ gemm_kernel<*> for unaligned operands) + attn_f32_{fwd,bwd_q}_kernel: every MFMA contraction, v_mfma_f32_16x16x4_f32"
-                if prec == "fp32" else "gemm_bf16_*_kernel<*> + attn_{fwd,bwd_q}_kernel: every MFMA contraction, v_mfma_f32_16x16x32_bf16")
+        kern = ("gemm_f32_kernel<*> (+ gemm_kernel<*> for unaligned operands) + attn_f32_{fwd,bwd_q,bwd_kv}_kernel: every MFMA contraction, v_mfma_f32_16x16x4_f32"
+                if prec == "fp32" else "gemm_bf16_*_kernel<*> + attn_{fwd,bwd_q,bwd_kv}_kernel: every MFMA contraction, v_mfma_f32_16x16x32_bf16")
         roof = dict(bound="mfma", achieved=round(ach, 2), peak=PEAK_TFLOPS[prec], unit="TFLOP/s",
                     frac=round(ach / PEAK_TFLOPS[prec], 4), traffic=traffic,
                     traffic_note=("HBM bytes per launch, rocprofv3 PMC (FETCH_SIZE doubled + WRITE_SIZE), profiles/%s" % traffic_src) if traffic else "no PMC pass committed for this build",

@@ -452,6 +452,108 @@ __global__ __launch_bounds__(256, NKT > 16 ? 1 : 2) void attn_bwd_q_kernel(const
   }
 }
 
+// Key side of the backward in one launch (bf16 operands): dv = Pd^T dctx and dk = dS^T qu for one (batch, head) and a
+// block of 64 keys.  Both operands of each product are read TRANSPOSED (the contraction runs over the queries, the
+// leading index of both tiles), so each 64-query stage goes through LDS in the k-strided image and the fragments come
+// out of ds_read_tr16_b64, exactly as the V panel does in the forward; the next stage's tiles are in registers under
+// the MFMAs.  Wave w owns keys 16w .. 16w+15 and all 64 channels: out^T[channel][key], fp32 accumulation.
+// reference: autograd of attention.py:63-114 (dv, dk of softmax(QK^T)V), :141-206 (with q + pos_bias_u for dk).
+struct AttnKvArgs {
+  const bf16_t* Pd; const bf16_t* dS; const bf16_t* dctx; const bf16_t* qu;
+  bf16_t* dv; bf16_t* dk;
+  long ldp, ldd, ldq, ldo;
+  int B, H, T1, T2, nkb;
+};
+
+__device__ __forceinline__ void kv16_load(const bf16_t* src, long ld, int i0, int T1, int c0, int ncol, int t, uint4 (&r)[2]) {
+#pragma unroll
+  for (int q = 0; q < 2; ++q) {
+    const int c = t + 256 * q, row = c >> 3, c16 = c & 7;
+    const bool ok = i0 + row < T1 && c0 + c16 * 8 < ncol;
+    r[q] = *reinterpret_cast<const uint4*>(src + (long)min(i0 + row, T1 - 1) * ld + (ok ? c0 + c16 * 8 : 0));
+    if (!ok) r[q] = make_uint4(0u, 0u, 0u, 0u);
+  }
+}
+__device__ __forceinline__ void kv16_store(const uint4 (&r)[2], bf16_t* dst, int t) {
+#pragma unroll
+  for (int q = 0; q < 2; ++q) {
+    const int c = t + 256 * q, row = c >> 3, c16 = c & 7;
+    *reinterpret_cast<uint4*>(&dst[lds_chunk_off<true, 64>(row, c16)]) = r[q];
+  }
+}
+__device__ __forceinline__ bf16x8 kv16_frag(const bf16_t* tile, int ks, int col0, int fr, int fq) {
+  const int rlo = ks * 32 + 4 * fq + (fr >> 2), rhi = rlo + 16, cc = col0 + 4 * (fr & 3);
+  const bf16_t* q0 = &tile[lds_chunk_off<true, 64>(rlo, cc >> 3) + (cc & 7)];
+  const bf16_t* q1 = &tile[lds_chunk_off<true, 64>(rhi, cc >> 3) + (cc & 7)];
+  s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4 __attribute__((address_space(3)))*)q0);
+  s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((s16x4 __attribute__((address_space(3)))*)q1);
+  return (bf16x8){lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+}
+// acc^T[channel tile ct][key tile of this wave] += X[query][channel]^T  W[query][key]
+__device__ __forceinline__ void kv16_product(const bf16_t* Xc, const bf16_t* Wk, int wave, int fr, int fq, f32x4 (&acc)[4]) {
+#pragma unroll
+  for (int ks = 0; ks < 2; ++ks) {
+    const bf16x8 wf = kv16_frag(Wk, ks, wave * 16, fr, fq);
+#pragma unroll
+    for (int ct = 0; ct < 4; ++ct)
+      acc[ct] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kv16_frag(Xc, ks, ct * 16, fr, fq), wf, acc[ct], 0, 0, 0);
+  }
+}
+
+__global__ __launch_bounds__(256, 2) void attn_bwd_kv_kernel(const AttnKvArgs a) {
+  __shared__ __attribute__((aligned(16))) bf16_t sW[64 * 64];     // [query][key] tile, k-strided image
+  __shared__ __attribute__((aligned(16))) bf16_t sX[64 * 64];     // [query][channel] tile
+  const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+  const int fr = lane & 15, fq = lane >> 4;
+  const int xcd = blockIdx.x & 7, jb = blockIdx.x >> 3;
+  const int z = (jb / a.nkb) * 8 + xcd;            // z = h * B + b
+  if (z >= a.B * a.H) return;                      // whole workgroup
+  const int h = z / a.B, b = z % a.B;
+  const int T1 = a.T1, T2 = a.T2;
+  const int j0 = (jb % a.nkb) * 64;                // first key of the workgroup
+  const long zo = (long)z * T1 * a.ldp;
+  const bf16_t* W0 = a.Pd + zo;
+  const bf16_t* W1 = a.dS + zo;
+  const bf16_t* X0 = a.dctx + (long)b * T1 * a.ldd + h * ATT_DK;
+  const bf16_t* X1 = a.qu + (long)b * T1 * a.ldq + h * ATT_DK;
+  f32x4 acc[2][4];
+#pragma unroll
+  for (int p = 0; p < 2; ++p)
+#pragma unroll
+    for (int ct = 0; ct < 4; ++ct) acc[p][ct] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  const int nstage = ((T1 + 63) / 64) * 2;
+  uint4 rw[2], rx[2];
+  kv16_load(W0, a.ldp, 0, T1, j0, (int)a.ldp, t, rw);
+  kv16_load(X0, a.ldd, 0, T1, 0, 64, t, rx);
+  for (int s = 0; s < nstage; ++s) {
+    __syncthreads();                               // the previous stage's reads are done
+    kv16_store(rw, sW, t);
+    kv16_store(rx, sX, t);
+    __syncthreads();
+    if (s + 1 < nstage) {                          // next pair of tiles: in flight under the MFMAs
+      const int i0 = (s + 1) / 2 * 64;
+      if ((s + 1) & 1) { kv16_load(W1, a.ldp, i0, T1, j0, (int)a.ldp, t, rw); kv16_load(X1, a.ldq, i0, T1, 0, 64, t, rx); }
+      else { kv16_load(W0, a.ldp, i0, T1, j0, (int)a.ldp, t, rw); kv16_load(X0, a.ldd, i0, T1, 0, 64, t, rx); }
+    }
+    if (s & 1) kv16_product(sX, sW, wave, fr, fq, acc[1]);
+    else kv16_product(sX, sW, wave, fr, fq, acc[0]);
+  }
+  const int j = j0 + wave * 16 + fr;               // this lane's key; acc[.][ct][r] = channel 16 ct + 4 fq + r
+  if (j < T2) {
+    const long ro = ((long)b * T2 + j) * a.ldo + h * ATT_DK + 4 * fq;
+#pragma unroll
+    for (int ct = 0; ct < 4; ++ct) {
+      uint2 o;
+      o.x = (unsigned)eamd_f2bf(acc[0][ct][0]) | ((unsigned)eamd_f2bf(acc[0][ct][1]) << 16);
+      o.y = (unsigned)eamd_f2bf(acc[0][ct][2]) | ((unsigned)eamd_f2bf(acc[0][ct][3]) << 16);
+      *reinterpret_cast<uint2*>(a.dv + ro + ct * 16) = o;
+      o.x = (unsigned)eamd_f2bf(acc[1][ct][0]) | ((unsigned)eamd_f2bf(acc[1][ct][1]) << 16);
+      o.y = (unsigned)eamd_f2bf(acc[1][ct][2]) | ((unsigned)eamd_f2bf(acc[1][ct][3]) << 16);
+      *reinterpret_cast<uint2*>(a.dk + ro + ct * 16) = o;
+    }
+  }
+}
+
 template <int NKT>
 int launch_attn_bwd(const AttnBwdArgs& a, hipStream_t stream) {
   const int nz = (a.B * a.H + 7) / 8 * 8;
@@ -530,4 +632,25 @@ extern "C" int eamd_attn_bwd_q(const void* dctx, int64_t ldd, const void* k, int
   a.drop_p = drop_p; a.drop_step = (const unsigned long long*)drop_step; a.drop_salt = drop_salt;
   return T2 <= 128 ? launch_attn_bwd<8>(a, (hipStream_t)stream) : T2 <= 256 ? launch_attn_bwd<16>(a, (hipStream_t)stream)
                                                                              : launch_attn_bwd<32>(a, (hipStream_t)stream);
+}
+
+extern "C" int eamd_attn_bwd_kv(const void* Pd_bf16, const void* dS_bf16, int64_t ldp, const void* dctx, int64_t ldd,
+                                const void* qu, int64_t ldq, void* dv, void* dk_out, int64_t ldo, int B, int H, int T1,
+                                int T2, int dk, void* stream) {
+  if (!Pd_bf16 || !dS_bf16 || !dctx || !qu || !dv || !dk_out || B <= 0 || H <= 0 || T1 <= 0 || T2 <= 0) return EAMD_EINVAL;
+  if (dk != ATT_DK) return EAMD_EUNSUPPORTED;
+  if (ldp % 8 || ldp < T2 || ldd % 8 || ldq % 8 || ldo % 4) return EAMD_EUNSUPPORTED;
+  if (!al16(Pd_bf16) || !al16(dS_bf16) || !al16(dctx) || !al16(qu) || (reinterpret_cast<uintptr_t>(dv) & 7) ||
+      (reinterpret_cast<uintptr_t>(dk_out) & 7))
+    return EAMD_EUNSUPPORTED;
+  AttnKvArgs a;
+  a.Pd = (const bf16_t*)Pd_bf16; a.dS = (const bf16_t*)dS_bf16; a.dctx = (const bf16_t*)dctx; a.qu = (const bf16_t*)qu;
+  a.dv = (bf16_t*)dv; a.dk = (bf16_t*)dk_out;
+  a.ldp = ldp; a.ldd = ldd; a.ldq = ldq; a.ldo = ldo;
+  a.B = B; a.H = H; a.T1 = T1; a.T2 = T2; a.nkb = (T2 + 63) / 64;
+  if ((long)B * H * a.nkb >= (1L << 28)) return EAMD_EUNSUPPORTED;
+  const int nz = (B * H + 7) / 8 * 8;
+  hipLaunchKernelGGL(attn_bwd_kv_kernel, dim3((unsigned)(a.nkb * nz)), dim3(256), 0, (hipStream_t)stream, a);
+  EAMD_LAUNCH_CHECK();
+  return EAMD_OK;
 }

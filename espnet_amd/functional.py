@@ -443,9 +443,9 @@ def attn_core_bwd(dctx, P, qu, qv, k, v, p, B, T1, T2, H, dk, Pd=None, attn_drop
     else:
         ldo = 3 * D
         dv, dv_off, dkk, dk_off = dqkv, 2 * D, dqkv, D
-    # fp32 mode: the key-side products (dv, dk, dpos) are ONE launch behind the query side (eamd_attn_bwd_kv_f32)
-    kv_try = kv_fused = FUSE_ATTN and ops.F32_FUSED_ATTN_KV and adt == torch.float32 and P.dtype == torch.float32 \
-        and dk == 64 and dctx.dtype == torch.float32
+    # the key-side products (dv, dk) are ONE launch behind the query side (eamd_attn_bwd_kv_f32 / eamd_attn_bwd_kv)
+    kv_try = kv_fused = FUSE_ATTN and ops.FUSED_ATTN_KV and P.dtype == adt and dk == 64 and dctx.dtype == adt \
+        and qu.t.dtype == adt
     if not kv_fused:
         ops.gemm(Pd if Pd is not None else P, dctx, dv, T2, dk, T1, ldp, D, ldo, transA=1, transB=1, batch=(B, H), sA=sP,
                  sB=(T1 * D, dk), sC=(T2 * ldo, dk), c_off=dv_off)                                        # P^T dctx

@@ -600,29 +600,39 @@ def attn_bwd_q(dctx, k, v, P, dS, dbd, dq, B, T1, T2, H, dk, ldp, scale, drop=No
     return True
 
 
-F32_FUSED_ATTN_KV = True   # fp32 mode: eamd_attn_bwd_kv_f32 (tests flip it to reach the batched GEMMs)
+FUSED_ATTN_KV = True   # fp32 mode: eamd_attn_bwd_kv_f32 (tests flip it to reach the batched GEMMs)
 
 
 def attn_bwd_kv(Pd, dS, dbd, dctx, qu, qv, dv, dk_, dpos, B, T1, T2, H, dk, ldp):
-    """dv = Pd^T dctx, dk = dS^T qu (and dpos += dbd^T qv) in one launch (fp32).  dctx / qu / qv / dv / dk_ / dpos:
-    (tensor, element offset, row stride) views; dv and dk_ share their row stride.  Returns False if the library
-    declines the operands (EAMD_EUNSUPPORTED)."""
+    """dv = Pd^T dctx, dk = dS^T qu (and, fp32 only, dpos += dbd^T qv) in one launch.  All tensors fp32
+    (eamd_attn_bwd_kv_f32) or all bf16 (eamd_attn_bwd_kv).  dctx / qu / qv / dv / dk_ / dpos: (tensor, element offset,
+    row stride) views; dv and dk_ share their row stride.  Returns False if the library declines the operands
+    (EAMD_EUNSUPPORTED)."""
     i64 = C.c_int64
+    dt = Pd.dtype
+    assert dt in (torch.float32, torch.bfloat16)
     for t_ in (Pd, dS, dctx[0], qu[0], dv[0], dk_[0]):
-        assert t_.dtype == torch.float32 and t_.is_cuda
+        assert t_.dtype == dt and t_.is_cuda
     assert dv[2] == dk_[2]
     rel = dbd is not None
-    args = (ptr(Pd), ptr(dS), ptr(dbd) if rel else None, i64(ldp), ptr(dctx[0], dctx[1]), i64(dctx[2]), ptr(qu[0], qu[1]), i64(qu[2]),
-            ptr(qv[0], qv[1]) if rel else None, i64(qv[2] if rel else 0), ptr(dv[0], dv[1]), ptr(dk_[0], dk_[1]), i64(dv[2]),
-            ptr(dpos[0], dpos[1]) if rel else None, i64(dpos[2] if rel else 0), B, H, T1, T2, dk)
-    fn = _lib.lib().eamd_attn_bwd_kv_f32
+    if dt == torch.float32:
+        args = (ptr(Pd), ptr(dS), ptr(dbd) if rel else None, i64(ldp), ptr(dctx[0], dctx[1]), i64(dctx[2]), ptr(qu[0], qu[1]),
+                i64(qu[2]), ptr(qv[0], qv[1]) if rel else None, i64(qv[2] if rel else 0), ptr(dv[0], dv[1]), ptr(dk_[0], dk_[1]),
+                i64(dv[2]), ptr(dpos[0], dpos[1]) if rel else None, i64(dpos[2] if rel else 0), B, H, T1, T2, dk)
+        name = "eamd_attn_bwd_kv_f32"
+    else:
+        assert not rel, "the bf16 key-side launch leaves the positional product to the GEMM"
+        args = (ptr(Pd), ptr(dS), i64(ldp), ptr(dctx[0], dctx[1]), i64(dctx[2]), ptr(qu[0], qu[1]), i64(qu[2]),
+                ptr(dv[0], dv[1]), ptr(dk_[0], dk_[1]), i64(dv[2]), B, H, T1, T2, dk)
+        name = "eamd_attn_bwd_kv"
+    fn = getattr(_lib.lib(), name)
     rc = fn(*args, stream_ptr())
     if rc == _lib.EAMD_EUNSUPPORTED:
         return False
-    check(rc, "eamd_attn_bwd_kv_f32")
+    check(rc, name)
     if _gemm_record is not None:
         _gemm_record.append((None, (Pd, dS, dbd, dctx, qu, qv, dv, dk_, dpos),
-                             lambda sp, args=args: check(fn(*args, sp), "eamd_attn_bwd_kv_f32")))
+                             lambda sp, args=args: check(fn(*args, sp), name)))
     return True
 
 

@@ -226,6 +226,13 @@ int eamd_attn_bwd_kv_f32(const float* Pd, const float* dS, const float* dbd, int
                          const float* qu, int64_t ldq, const float* qv, int64_t ldqv, float* dv, float* dk_out, int64_t ldo,
                          float* dpos, int64_t ldpos, int B, int H, int T1, int T2, int dk, void* stream);
 
+/* The bf16 twin of the key-side launch (dv and dk only; the positional product stays a split-K GEMM): Pd / dS bf16
+ * [H][B][T1][ldp] as eamd_attn_fwd / eamd_attn_bwd_q leave them, dctx / qu bf16 (b, t, h, d), dv / dk bf16 (b, j, h, d)
+ * sharing the row stride ldo; fp32 accumulation.  ldp / ldd / ldq multiples of 8, ldo a multiple of 4.
+ * reference: autograd of transformer/attention.py:63-114, :141-206. */
+int eamd_attn_bwd_kv(const void* Pd_bf16, const void* dS_bf16, int64_t ldp, const void* dctx, int64_t ldd, const void* qu,
+                     int64_t ldq, void* dv, void* dk_out, int64_t ldo, int B, int H, int T1, int T2, int dk, void* stream);
+
 /* Label-smoothing KL loss rows + argmax-correct flags + gradient (softmax - true_dist)*inv_denom.
  * reference: transformer/label_smoothing_loss.py:44-63, nets_utils.py:299-319 (th_accuracy). */
 int eamd_lsm_loss(const float* logits, const int64_t* target, float* loss_rows, float* correct_rows,

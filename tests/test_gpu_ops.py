@@ -963,7 +963,8 @@ def test_attention_forward_fused_matches_unfused(ops, case, prec):
 @pytest.mark.parametrize("case", [
     dict(B=3, T1=249, T2=249, rel=True, qkv=True), dict(B=2, T1=256, T2=256, rel=True, qkv=False),
     dict(B=9, T1=30, T2=30, rel=True, qkv=True), dict(B=2, T1=65, T2=65, rel=False, qkv=True),
-    dict(B=2, T1=101, T2=249, rel=False, qkv=False), dict(B=3, T1=101, T2=101, rel=False, qkv=False)])
+    dict(B=2, T1=101, T2=249, rel=False, qkv=False), dict(B=3, T1=101, T2=101, rel=False, qkv=False),
+    dict(B=2, T1=300, T2=300, rel=True, qkv=True), dict(B=2, T1=70, T2=333, rel=False, qkv=False)])
 @pytest.mark.parametrize("prec", ["bf16", "fp32"])
 def test_attention_backward_fused_matches_unfused(ops, case, prec):
     """eamd_attn_bwd_q (score gradient + softmax backward + inverse rel-shift scatter + dq in one launch) inside

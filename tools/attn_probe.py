@@ -38,4 +38,7 @@ for (B, T1, T2, rel, mk) in ((32, 249, 249, True, "len"), (32, 249, 249, False, 
         F_.FUSE_ATTN = fuse
         ts.append(graph_time(lambda: F_.attn_core_bwd(dctx, P, qu, qv, k, v, p, B, T1, T2, H, dk), n=30))
     F_.FUSE_ATTN = True
-    print("      backward (all products): query side fused %6.1f us   unfused %6.1f us" % (ts[0], ts[1]))
+    espnet_amd.ops.FUSED_ATTN_KV = False
+    tk = graph_time(lambda: F_.attn_core_bwd(dctx, P, qu, qv, k, v, p, B, T1, T2, H, dk), n=30)
+    espnet_amd.ops.FUSED_ATTN_KV = True
+    print("      backward (all products): fused %6.1f us   key side as GEMMs %6.1f us   unfused %6.1f us" % (ts[0], tk, ts[1]))
