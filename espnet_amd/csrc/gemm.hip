@@ -9,6 +9,7 @@
 // buffers, one barrier per K-tile).  precision=1 rounds operands to bf16 in the staging pass and
 // uses v_mfma_f32_16x16x32_bf16; precision=0 keeps fp32 and uses v_mfma_f32_16x16x4_f32.
 // 256 threads = 4 waves (64 lanes) in a 2x2 arrangement; block tile 128x128 or 64x64, BK = 32.
+#include <stdlib.h>
 #include "common.h"
 #include "../../include/espnet_amd.h"
 
@@ -397,9 +398,13 @@ extern "C" int eamd_gemm(const eamd_gemm_t* pp, void* stream_) {
   if (tile == 0) {
     long t128 = (long)((p.M + 127) / 128) * ((p.N + 127) / 128) * p.batch1 * p.batch2 * p.splitk;
     if (p.in_dtype == 1) {
-      // measured on MI355X (tools/gemm_probe2.py): the 64x64 tile wins on every skinny shape of the model
-      // (K or N = 256); 128x128 only pays for large square problems
-      tile = (t128 >= 1024 && p.K >= 2048 && p.M >= 2048 && p.N >= 2048) ? 128 : 64;
+      // measured on MI355X (tools/gemm_breakdown.py bf16, tools/gemm_kslope.py): the 64x64 tile (and its persistent
+      // form) wins at K = 256; from K = 512 on the 128x128 tile, two workgroups per CU since its register cap, is ahead
+      // once there are two full rounds of tiles - the implicit-conv GEMMs of the subsampling front end
+      // (151392 x 256 x 2304: 461 -> 335 us, 160000 x 256 x 1024: 276 -> 220 us)
+      static const int kmin = [] { const char* e = getenv("EAMD_BF16_T128_KMIN"); return e ? atoi(e) : 512; }();
+      static const int nmin = [] { const char* e = getenv("EAMD_BF16_T128_NMIN"); return e ? atoi(e) : 256; }();
+      tile = (t128 >= 1024 && p.K >= kmin && p.M >= 2048 && p.N >= nmin) ? 128 : 64;
     } else {
       // measured on MI355X (tools/gemm_f32_probe.py): from ~1 tile per CU on the 128x128 tile wins (4x fewer LDS
       // stores and barriers per MFMA), below that the 64x64 tile's 4x as many workgroups do

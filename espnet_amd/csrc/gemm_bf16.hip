@@ -463,7 +463,7 @@ __device__ __forceinline__ void gemm_bf16_body(const eamd_gemm_t& p, const int b
 }
 
 template <int BM, int BN, bool TA, bool TB, bool FAST, bool GAT, bool ACT>
-__global__ __launch_bounds__(NT_) void gemm_bf16_kernel(const eamd_gemm_t p) {
+__global__ __launch_bounds__(NT_, 2) void gemm_bf16_kernel(const eamd_gemm_t p) {
   gemm_bf16_body<BM, BN, TA, TB, FAST, GAT, ACT>(p, blockIdx.x, gridDim.x, blockIdx.z);
 }
 
