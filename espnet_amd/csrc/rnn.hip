@@ -305,6 +305,149 @@ __global__ __launch_bounds__(256) void attloc_energy_bwd_kernel(const float* __r
   }
 }
 
+// The energy backward with the two products over W_att folded in (location-aware attention, one decoder step):
+//   df[b,t,a] = de[b,t] * gvec[a] * (1 - th^2)            dconv[b,t,c] = sum_a df[b,t,a] * W_att[a,c]
+//   dW_att[a,c] += sum_{b,t} df[b,t,a] * conv[b,t,c]      dgvec[a] += sum de * th      d_dec_proj[b,a] += sum_t df
+// As GEMMs the two products have N = C = 10 columns (56 + 63 us per step at config 4, each re-reading the 33 MB df);
+// here a workgroup owns (b, 32 frames), a thread 4 adjacent a: df is formed once, every reduction over (b, t) is kept
+// in registers and leaves as a per-workgroup partial that attloc_bwd_reduce_kernel sums (no atomics), the reduction
+// over a for dconv goes through the waves and LDS.  reference: autograd of rnn/attentions.py:329-365 (AttLoc.forward).
+constexpr int ATTF_TCH = 32, ATTF_MAXC = 16;
+__device__ __forceinline__ float row16_sum(float v) {     // sum over the 16 lanes of a DPP row (no LDS crossbar trip)
+  v += eamd_dpp<0xB1>(v);
+  v += eamd_dpp<0x4E>(v);
+  v += eamd_dpp<0x141>(v);
+  v += eamd_dpp<0x140>(v);
+  return v;
+}
+template <int CT>       // channels the code is unrolled for: C <= CT, the excess ones carry zeros
+__global__ __launch_bounds__(256) void attloc_energy_bwd_fused_kernel(const float* __restrict__ de,
+                                                                      const float* __restrict__ th,
+                                                                      const float* __restrict__ gvec,
+                                                                      const float* __restrict__ conv,
+                                                                      const float* __restrict__ w_att,
+                                                                      float* __restrict__ df, float* __restrict__ dconv,
+                                                                      float* __restrict__ part, int T, int A, int C) {
+  __shared__ float red[ATTF_TCH][16][ATTF_MAXC];         // [frame][16-lane row of the workgroup][channel]
+  const int b = blockIdx.x, ch = blockIdx.y;
+  const int t0 = ch * ATTF_TCH, t1 = min(T, t0 + ATTF_TCH);
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int a = 4 * tid;
+  const bool live = a < A;                               // A % 4 == 0, A <= 1024 (host-checked)
+  const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
+  const float4 g = live ? *reinterpret_cast<const float4*>(gvec + a) : z4;
+  float W[CT][4], acc[CT][4];
+#pragma unroll
+  for (int c = 0; c < CT; ++c)
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      W[c][k] = (live && c < C) ? w_att[(long)(a + k) * C + min(c, C - 1)] : 0.f;
+      acc[c][k] = 0.f;
+    }
+  float4 pg = z4, pd = z4;
+  // frames in groups of four, the next group's loads in flight under the arithmetic of this one (one wave per SIMD:
+  // nothing else hides the HBM round trip)
+  float4 vb[4];
+  float db[4];
+  auto load_group = [&](int tg) __attribute__((always_inline)) {
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int t = tg + u;
+      const long row = (long)b * T + min(t, t1 - 1);
+      db[u] = t < t1 ? de[row] : 0.f;
+      vb[u] = live ? *reinterpret_cast<const float4*>(th + row * A + a) : z4;
+    }
+  };
+  load_group(t0);
+  for (int tg = t0; tg < t1; tg += 4) {
+    float4 vc[4];
+    float dc[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) { vc[u] = vb[u]; dc[u] = db[u]; }
+    if (tg + 4 < t1) load_group(tg + 4);
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int t = min(tg + u, t1 - 1);                   // a frame past the chunk repeats the last one with d = 0
+      const long row = (long)b * T + t;
+      const float d = dc[u];
+      const float4 v = vc[u];
+      const float* cvr = conv + row * C;                   // workgroup-uniform: scalar loads, all CT requested together
+      float cv[CT];
+#pragma unroll
+      for (int c = 0; c < CT; ++c) cv[c] = cvr[CT == ATTF_MAXC ? min(c, C - 1) : c];
+      float4 f;
+      f.x = d * g.x * (1.f - v.x * v.x); f.y = d * g.y * (1.f - v.y * v.y);
+      f.z = d * g.z * (1.f - v.z * v.z); f.w = d * g.w * (1.f - v.w * v.w);
+      if (live && tg + u < t1) *reinterpret_cast<float4*>(df + row * A + a) = f;
+      pg.x += d * v.x; pg.y += d * v.y; pg.z += d * v.z; pg.w += d * v.w;
+      pd.x += f.x; pd.y += f.y; pd.z += f.z; pd.w += f.w;
+      float sc[CT];
+#pragma unroll
+      for (int c = 0; c < CT; ++c) {
+        acc[c][0] += f.x * cv[c]; acc[c][1] += f.y * cv[c]; acc[c][2] += f.z * cv[c]; acc[c][3] += f.w * cv[c];
+        sc[c] = row16_sum(f.x * W[c][0] + f.y * W[c][1] + f.z * W[c][2] + f.w * W[c][3]);
+      }
+      if ((lane & 15) == 0 && tg + u < t1) {
+#pragma unroll
+        for (int c = 0; c < CT; ++c) red[t - t0][tid >> 4][c] = sc[c];
+      }
+    }
+  }
+  __syncthreads();
+  for (int q = tid; q < (t1 - t0) * C; q += 256) {
+    const int tl = q / C, c = q - tl * C;
+    float s = 0.f;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) s += red[tl][r][c];
+    dconv[((long)b * T + t0 + tl) * C + c] = s;
+  }
+  if (live) {
+    float* ps = part + ((long)b * gridDim.y + ch) * A * (C + 2);
+#pragma unroll
+    for (int c = 0; c < CT; ++c)
+      if (c < C) {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) ps[(long)(a + k) * C + c] = acc[c][k];
+      }
+    *reinterpret_cast<float4*>(ps + (long)A * C + a) = pg;
+    *reinterpret_cast<float4*>(ps + (long)A * (C + 1) + a) = pd;
+  }
+}
+// dW_att / dgvec += the sum of the workgroup partials over all (b, chunk); d_dec_proj[b,:] += the sum over b's chunks.
+// A workgroup owns 64 adjacent outputs; its four waves split the slabs (eight loads in flight each) and meet in LDS.
+__global__ __launch_bounds__(256) void attloc_bwd_reduce_kernel(const float* __restrict__ part, float* __restrict__ dw_att,
+                                                                float* __restrict__ dgvec, float* __restrict__ ddec, int B,
+                                                                int NCH, int A, int C) {
+  __shared__ float red[4][64];
+  const long stride = (long)A * (C + 2);
+  const long n1 = (long)A * (C + 1), n2 = (long)B * A;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const long i = (long)blockIdx.x * 64 + lane;
+  float s = 0.f;
+  if (i < n1) {
+    const int ns = B * NCH;
+    float s8[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    int sl = wave;
+    for (; sl + 28 < ns; sl += 32) {
+#pragma unroll
+      for (int u = 0; u < 8; ++u) s8[u] += part[(long)(sl + 4 * u) * stride + i];
+    }
+    for (; sl < ns; sl += 4) s8[0] += part[(long)sl * stride + i];
+    s = ((s8[0] + s8[1]) + (s8[2] + s8[3])) + ((s8[4] + s8[5]) + (s8[6] + s8[7]));
+  } else if (i < n1 + n2) {
+    const long j = i - n1;
+    const int b = (int)(j / A), a = (int)(j - (long)b * A);
+    for (int chn = wave; chn < NCH; chn += 4) s += part[((long)b * NCH + chn) * stride + n1 + a];
+  }
+  red[wave][lane] = s;
+  __syncthreads();
+  if (wave == 0) {
+    s = (red[0][lane] + red[1][lane]) + (red[2][lane] + red[3][lane]);
+    if (i < (long)A * C) dw_att[i] += s;
+    else if (i < n1) dgvec[i - (long)A * C] += s;
+    else if (i < n1 + n2) ddec[i - n1] += s;
+  }
+}
 // d_prev[b,r,s] = sum_{c,k} dconv[b, s - k + F, c] * conv_w[c,r,k]      one wave per output (b,r,s): lanes over k
 __global__ __launch_bounds__(256) void attloc_conv_bwd_prev_kernel(const float* __restrict__ dconv,
                                                                    const float* __restrict__ conv_w,
@@ -736,6 +879,47 @@ int eamd_attloc_bwd_energy(const float* dctx, const float* dw_ext, const float* 
   EAMD_LAUNCH_CHECK();
   hipLaunchKernelGGL(attloc_energy_bwd_kernel, dim3(B, (T + ATT_TCH - 1) / ATT_TCH), dim3(256), 0, s, de, th, gvec, df,
                      dgvec, d_dec_proj, T, A);
+  EAMD_LAUNCH_CHECK();
+  return EAMD_OK;
+}
+
+/* stage 1 with the W_att products folded in (see attloc_energy_bwd_fused_kernel): additionally dconv [B,T,C] = df @ W_att is
+ * written and dw_att [A,C] += df^T conv accumulated.  workspace: eamd_attloc_bwd_workspace(B, T, A, C) bytes. */
+int64_t eamd_attloc_bwd_workspace(int B, int T, int A, int C) {
+  return (int64_t)B * ((T + ATTF_TCH - 1) / ATTF_TCH) * A * (C + 2) * (int64_t)sizeof(float);
+}
+int eamd_attloc_bwd_energy_conv(const float* dctx, const float* dw_ext, const float* w, const float* enc_h, const float* th,
+                                const float* gvec, float scaling, const float* conv, const float* w_att, float* de,
+                                float* d_enc_h, float* df, float* dconv, float* dgvec, float* dgb, float* d_dec_proj,
+                                float* dw_att, float* workspace, int B, int T, int A, int C, int E, void* stream) {
+  if (!dctx || !w || !enc_h || !th || !gvec || !conv || !w_att || !de || !d_enc_h || !df || !dconv || !dgvec || !dgb ||
+      !d_dec_proj || !dw_att || !workspace || B <= 0 || T <= 0 || A <= 0 || C <= 0 || E <= 0)
+    return EAMD_EINVAL;
+  if ((size_t)T * sizeof(float) > 60 * 1024 || C > ATTF_MAXC || A % 4 || A > 1024) return EAMD_EUNSUPPORTED;
+  if ((reinterpret_cast<uintptr_t>(th) | reinterpret_cast<uintptr_t>(df) | reinterpret_cast<uintptr_t>(gvec) |
+       reinterpret_cast<uintptr_t>(workspace)) & 15)
+    return EAMD_EUNSUPPORTED;
+  hipStream_t s = (hipStream_t)stream;
+  const int nch = (T + ATTF_TCH - 1) / ATTF_TCH;
+  hipLaunchKernelGGL(attloc_ctx_bwd_rows_kernel, dim3((B * T + 3) / 4), dim3(256), 0, s, dctx, dw_ext, w, enc_h, de, d_enc_h,
+                     B * T, T, E);
+  EAMD_LAUNCH_CHECK();
+  hipLaunchKernelGGL(attloc_softmax_bwd_kernel, dim3(B), dim3(256), 0, s, w, scaling, de, dgb, T);
+  EAMD_LAUNCH_CHECK();
+  // exact unrolls for the usual channel counts (aconv_chans = 10 in the recipes), the padded 16-channel form otherwise
+  if (C == 10)
+    hipLaunchKernelGGL(attloc_energy_bwd_fused_kernel<10>, dim3(B, nch), dim3(256), 0, s, de, th, gvec, conv, w_att, df, dconv,
+                       workspace, T, A, C);
+  else if (C == 4)
+    hipLaunchKernelGGL(attloc_energy_bwd_fused_kernel<4>, dim3(B, nch), dim3(256), 0, s, de, th, gvec, conv, w_att, df, dconv,
+                       workspace, T, A, C);
+  else
+    hipLaunchKernelGGL(attloc_energy_bwd_fused_kernel<ATTF_MAXC>, dim3(B, nch), dim3(256), 0, s, de, th, gvec, conv, w_att, df,
+                       dconv, workspace, T, A, C);
+  EAMD_LAUNCH_CHECK();
+  const long n = (long)A * (C + 1) + (long)B * A;
+  hipLaunchKernelGGL(attloc_bwd_reduce_kernel, dim3((unsigned)((n + 63) / 64)), dim3(256), 0, s, workspace, dw_att, dgvec,
+                     d_dec_proj, B, nch, A, C);
   EAMD_LAUNCH_CHECK();
   return EAMD_OK;
 }

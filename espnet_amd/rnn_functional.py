@@ -392,12 +392,18 @@ class AttLocStepFn(torch.autograd.Function):
             return (d_enc_h, df, d_dec, None, None, None, None, None) + sink.results()
         conv_w, w_att, gvec_w, gvec_b = ctx.pr
         Cc = conv.shape[2]
-        d_enc_h, df, d_dec = ops.attloc_bwd_energy(dc.contiguous(), dw.contiguous() if dw is not None else None, w,
-                                                   enc_h, th, gvec_w, ctx.scaling, sink.buf(2), sink.buf(3))
-        df2 = df.view(B * T, A)
-        dconv = torch.empty(B * T, Cc, device=df.device, dtype=torch.float32)
-        ops.gemm(df2, w_att, dconv, B * T, Cc, A, A, Cc, Cc, transB=1)              # dconv = df @ W_att
-        ops.linear_bwd_w(df2, conv.view(B * T, Cc), sink.buf(1))                     # dW_att += df^T conv
+        dcc, dwc = dc.contiguous(), dw.contiguous() if dw is not None else None
+        # one pass over th forms df, dconv = df @ W_att and dW_att += df^T conv (two N = C GEMMs otherwise)
+        r = ops.attloc_bwd_energy_conv(dcc, dwc, w, enc_h, th, gvec_w, ctx.scaling, conv, w_att, sink.buf(2), sink.buf(3),
+                                       sink.buf(1))
+        if r is not None:
+            d_enc_h, df, d_dec, dconv = r
+        else:
+            d_enc_h, df, d_dec = ops.attloc_bwd_energy(dcc, dwc, w, enc_h, th, gvec_w, ctx.scaling, sink.buf(2), sink.buf(3))
+            df2 = df.view(B * T, A)
+            dconv = torch.empty(B * T, Cc, device=df.device, dtype=torch.float32)
+            ops.gemm(df2, w_att, dconv, B * T, Cc, A, A, Cc, Cc, transB=1)              # dconv = df @ W_att
+            ops.linear_bwd_w(df2, conv.view(B * T, Cc), sink.buf(1))                     # dW_att += df^T conv
         d_prev = ops.attloc_bwd_conv(dconv.view(B, T, Cc), conv_w, att_prev, sink.buf(0))
         return (d_enc_h, df, d_dec, d_prev, None, None) + sink.results()
 

@@ -95,15 +95,18 @@ def test_lstm_cell_vs_oracle(oracle):
         report("lstm cell d" + k, p.grad, sdr[k].grad, 1e-4)
 
 
-def test_attloc_step_vs_oracle(oracle):
-    """two chained AttLoc steps (the second consumes the first's weights) against rnn/attentions.py:300-380"""
+@pytest.mark.parametrize("dims", [(3, 11, 6, 5, 7, 4, 2, [11, 8, 5]), (3, 45, 6, 5, 40, 10, 3, [45, 8, 5]),
+                                  (2, 70, 12, 9, 1024, 10, 20, [70, 33]), (3, 45, 6, 5, 40, 4, 3, [45, 30, 5]),
+                                  (2, 20, 5, 4, 16, 6, 2, [20, 7])])
+def test_attloc_step_vs_oracle(oracle, dims):
+    """two chained AttLoc steps (the second consumes the first's weights) against rnn/attentions.py:300-380.
+    A = 7: the GEMM form of the backward products over mlp_att's weight; A = 40 / 1024: eamd_attloc_bwd_energy_conv"""
     from espnet_amd.nets.rnn.attentions import AttLoc
     g = torch.Generator().manual_seed(5)
-    B, T, E, D, A, C, F = 3, 11, 6, 5, 7, 4, 2
+    B, T, E, D, A, C, F, lens = dims
     att = AttLoc(E, D, A, C, F)
     sd = {k: v.detach().clone() for k, v in att.state_dict().items()}
     att = att.to(DEV)
-    lens = [11, 8, 5]
     enc = torch.randn(B, T, E, generator=g)
     z1, z2 = torch.randn(B, D, generator=g), torch.randn(B, D, generator=g)
     sdr = {k: v.clone().requires_grad_(True) for k, v in sd.items()}
@@ -121,7 +124,7 @@ def test_attloc_step_vs_oracle(oracle):
     report("attloc ctx1", c1, c1w.detach(), 1e-5)
     report("attloc w1", w1, w1w.detach(), 1e-5)
     report("attloc ctx2", c2, c2w.detach(), 1e-5)
-    assert float(w2[1, 8:].abs().max()) == 0.0 and float(w2[2, 5:].abs().max()) == 0.0   # masked frames: exactly 0
+    assert float(w2[1, lens[1]:].abs().max()) == 0.0 and float(w2[B - 1, lens[-1]:].abs().max()) == 0.0   # masked frames: exactly 0
     torch.autograd.backward([c1, c2, w2], [g1.to(DEV), g2.to(DEV), gw.to(DEV)])
     report("attloc d enc_h", encd.grad, encr.grad, 1e-4)
     report("attloc d z1", z1d.grad, z1r.grad, 1e-4)
@@ -131,6 +134,39 @@ def test_attloc_step_vs_oracle(oracle):
             assert float(p.grad.abs().max()) < 1e-5
             continue
         report("attloc d" + k, p.grad, sdr[k].grad, 2e-4)
+
+
+def test_attloc_fused_backward_matches_gemm_form():
+    """eamd_attloc_bwd_energy_conv (df, dconv = df @ W_att, dW_att += df^T conv, dgvec, d dec from one pass over th, partial
+    sums reduced without atomics) against the energy-backward kernel + two GEMMs, at config 4's attention size"""
+    from espnet_amd import ops
+    from espnet_amd.nets.rnn.attentions import AttLoc
+    g = torch.Generator().manual_seed(11)
+    B, T, E, D, A, C, F = 4, 250, 64, 48, 1024, 10, 100
+    att = AttLoc(E, D, A, C, F).to(DEV)
+    lens = [250, 201, 133, 64]
+    enc = torch.randn(B, T, E, generator=g).to(DEV)
+    z1, z2 = torch.randn(B, D, generator=g).to(DEV), torch.randn(B, D, generator=g).to(DEV)
+    g1, g2, gw = (torch.randn(B, E, generator=g).to(DEV), torch.randn(B, E, generator=g).to(DEV),
+                  torch.randn(B, T, generator=g).to(DEV))
+    res = {}
+    try:
+        for fused in (True, False):
+            ops.ATTLOC_FUSED_BWD = fused
+            encd, z1d, z2d = (t.clone().requires_grad_(True) for t in (enc, z1, z2))
+            att.zero_grad()
+            att.reset()
+            c1, w1 = att(encd, lens, z1d, None)
+            c2, w2 = att(encd, lens, z2d, w1)
+            torch.autograd.backward([c1, c2, w2], [g1, g2, gw])
+            res[fused] = dict(enc=encd.grad.clone(), z1=z1d.grad.clone(), z2=z2d.grad.clone(),
+                              **{k: p.grad.clone() for k, p in att.named_parameters()})
+    finally:
+        ops.ATTLOC_FUSED_BWD = True
+    for k in res[True]:
+        if k == "gvec.bias":
+            continue
+        report("attloc fused bwd " + k, res[True][k], res[False][k], 2e-4)
 
 
 @pytest.mark.parametrize("shape", [(2, 6, 4, 7), (3, 17, 9, 33), (1, 1, 1, 5), (2, 5, 1, 4), (2, 1, 4, 6)])

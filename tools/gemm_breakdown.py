@@ -21,19 +21,48 @@ def main():
     espnet_amd.set_precision(sys.argv[1] if len(sys.argv) > 1 else "bf16")
     B, T, L, V = 32, 1000, 100, 5000
     torch.manual_seed(0)
-    model = E2E(80, V, bench.c2_args(0.1)).to(dev).train()
-    model.sync_report = False
-    ops.manual_seed(1234)
-    flat = train.FlatParams(model)
-    opt = train.NoamAdam(flat, mode="noam", factor=1.0, model_size=256, warmup=25000, max_grad_norm=5.0)
-    xs, ilens, ys = bench.synth_batch(B, T, L, V)
-    batch = model.prepare(xs, ilens, ys)
+    if "--config4" in sys.argv:
+        # BASELINE config 4 (VGG-BLSTM + location attention): the recurrent / decoder-step GEMMs
+        import argparse
+        from espnet_amd.nets.e2e_asr import E2E as E2ERnn
+        ns = argparse.Namespace(elayers=3, subsample="1_1_1_1", etype="vggblstm", eunits=1024, eprojs=1024, dtype="lstm",
+                                dlayers=1, dunits=1024, atype="location", aheads=4, awin=5, aconv_chans=10, aconv_filts=100,
+                                mtlalpha=0.5, lsm_type="", lsm_weight=0.0, sampling_probability=0.0, adim=1024,
+                                dropout_rate=0.0, dropout_rate_decoder=0.0, verbose=0, char_list=None, outdir=None,
+                                ctc_type="builtin", sym_space="<space>", sym_blank="<blank>", context_residual=False,
+                                use_frontend=False, replace_sos=False)
+        g = torch.Generator().manual_seed(0)
+        xs = torch.randn(B, T, 80, generator=g).to(dev)
+        ilens = [T - 7 * i for i in range(B)]
+        ys = torch.randint(1, V - 1, (B, L), generator=g)
+        model = E2ERnn(80, V, ns).to(dev).train()
+        flat = train.FlatParams(model)
+
+        def one_step():
+            flat.zero_grad()
+            loss = model(xs, ilens, ys)
+            ops.wgrad_group_begin()
+            try:
+                loss.backward()
+            finally:
+                ops.wgrad_group_end()
+    else:
+        model = E2E(80, V, bench.c2_args(0.1)).to(dev).train()
+        model.sync_report = False
+        ops.manual_seed(1234)
+        flat = train.FlatParams(model)
+        opt = train.NoamAdam(flat, mode="noam", factor=1.0, model_size=256, warmup=25000, max_grad_norm=5.0)
+        xs, ilens, ys = bench.synth_batch(B, T, L, V)
+        batch = model.prepare(xs, ilens, ys)
+
+        def one_step():
+            train.train_step(model, flat, opt, batch, None)
     for _ in range(2):
-        train.train_step(model, flat, opt, batch, None)
+        one_step()
     torch.cuda.synchronize()
     rec = []
     ops._gemm_record = rec
-    train.train_step(model, flat, opt, batch, None)
+    one_step()
     torch.cuda.synchronize()
     ops._gemm_record = None
     lib = L_.lib()
@@ -45,6 +74,8 @@ def main():
         key = (p.M, p.N, p.K, p.transA, p.transB, p.batch1 * p.batch2, p.splitk, p.epilogue, int(p.gather.enabled),
                int(bool(p.C)), int(bool(p.Cb)), int(bool(p.Hb)), int(bool(p.R)), int(bool(p.aux)), int(bool(p.colsum)),
                int(p.drop_p > 0), p.in_dtype)
+        if "--config4" in sys.argv:
+            key = key + (p.precision,)
         groups.setdefault(key, []).append(replay)
     rows = []
     for key, ps in groups.items():
