@@ -161,6 +161,14 @@ __global__ void maxpool_bwd_kernel(const float* __restrict__ dy, const unsigned 
   }
 }
 
+__device__ __forceinline__ float row16_sum(float v) {     // sum over the 16 lanes of a DPP row (no LDS crossbar trip)
+  v += eamd_dpp<0xB1>(v);
+  v += eamd_dpp<0x4E>(v);
+  v += eamd_dpp<0x141>(v);
+  v += eamd_dpp<0x140>(v);
+  return v;
+}
+
 // ---- location-aware attention (AttLoc), one decoder step -----------------------------------------
 // reference: rnn/attentions.py:300-380
 //   conv[b,t,c]  = sum_k conv_w[c,k] * att_prev[b, t + k - F]                 (Conv2d(1,C,(1,2F+1)), no bias)
@@ -199,6 +207,81 @@ __global__ __launch_bounds__(128) void attloc_energy_fwd_kernel(
   }
   acc = block_sum(acc, red);
   if (threadIdx.x == 0) e[bt] = t < lens[b] ? acc + gb[0] : -INFINITY;
+}
+
+// The same for A <= 1024, A % 4 == 0, C <= 16, one row of history (R = 1), K <= 255 taps: a workgroup owns eight frames of one utterance and a thread four adjacent
+// attention units, so mlp_att's weight rows, dec_proj and gvec are read once per eight frames into registers (the
+// per-frame kernel above re-reads the [A,C] weight with a 4C-byte lane stride for every frame: 53 us per step at
+// config 4, against 16 us for its 65 MB of pre_enc / th traffic).
+constexpr int ATTE_TCH = 8, ATTE_MAXK = 255;
+template <int CT>
+__global__ __launch_bounds__(256) void attloc_energy_fwd8_kernel(
+    const float* __restrict__ att_prev, const float* __restrict__ conv_w, const float* __restrict__ w_att,
+    const float* __restrict__ pre_enc, const float* __restrict__ dec_proj, const float* __restrict__ gvec,
+    const float* __restrict__ gb, const int* __restrict__ lens, float* __restrict__ e, float* __restrict__ th,
+    float* __restrict__ conv, int T, int A, int C, int K, int R) {
+  __shared__ float convl[ATTE_TCH][CT];
+  __shared__ float red[ATTE_TCH][16];
+  __shared__ float wl[CT * ATTE_MAXK];
+  __shared__ float win[ATTE_TCH + ATTE_MAXK];
+  const int b = blockIdx.x, t0 = blockIdx.y * ATTE_TCH, nt = min(ATTE_TCH, T - t0);
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int F = (K - 1) / 2;
+  // location features of the eight frames (R = 1): filter bank and the window of previous weights through LDS, one thread
+  // per (frame, channel) - as one wave per output the 80 short reductions of a workgroup ran back to back (30 us)
+  const float* pv = att_prev + (long)b * T;
+  for (int i = tid; i < C * K; i += 256) wl[i] = conv_w[i];
+  for (int i = tid; i < nt + K - 1; i += 256) {
+    const int ts = t0 - F + i;
+    win[i] = (ts >= 0 && ts < T) ? pv[ts] : 0.f;
+  }
+  __syncthreads();
+  if (tid < nt * CT) {
+    const int tl = tid / CT, c = tid - tl * CT;
+    float sacc = 0.f;
+    if (c < C) {
+      const float* wr = wl + c * K;
+      const float* xr = win + tl;
+      for (int k = 0; k < K; ++k) sacc += wr[k] * xr[k];
+      conv[((long)b * T + t0 + tl) * C + c] = sacc;
+    }
+    convl[tl][c] = sacc;
+  }
+  const int a = 4 * tid;
+  const bool live = a < A;
+  const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
+  float W[CT][4];
+#pragma unroll
+  for (int c = 0; c < CT; ++c)
+#pragma unroll
+    for (int k = 0; k < 4; ++k) W[c][k] = (live && c < C) ? w_att[(long)(a + k) * C + min(c, C - 1)] : 0.f;
+  const float4 dp = live ? *reinterpret_cast<const float4*>(dec_proj + (long)b * A + a) : z4;
+  const float4 g = live ? *reinterpret_cast<const float4*>(gvec + a) : z4;
+  float4 pe[ATTE_TCH];
+#pragma unroll
+  for (int u = 0; u < ATTE_TCH; ++u)
+    pe[u] = (live && u < nt) ? *reinterpret_cast<const float4*>(pre_enc + ((long)b * T + t0 + u) * A + a) : z4;
+  __syncthreads();
+#pragma unroll
+  for (int u = 0; u < ATTE_TCH; ++u) {
+    float4 f = make_float4(pe[u].x + dp.x, pe[u].y + dp.y, pe[u].z + dp.z, pe[u].w + dp.w);
+#pragma unroll
+    for (int c = 0; c < CT; ++c) {
+      const float cv = convl[u < nt ? u : 0][c];
+      f.x += W[c][0] * cv; f.y += W[c][1] * cv; f.z += W[c][2] * cv; f.w += W[c][3] * cv;
+    }
+    const float4 v = make_float4(tanhf(f.x), tanhf(f.y), tanhf(f.z), tanhf(f.w));
+    if (live && u < nt) *reinterpret_cast<float4*>(th + ((long)b * T + t0 + u) * A + a) = v;
+    const float s = row16_sum(live ? g.x * v.x + g.y * v.y + g.z * v.z + g.w * v.w : 0.f);
+    if ((lane & 15) == 0) red[u][tid >> 4] = s;
+  }
+  __syncthreads();
+  if (tid < nt) {
+    float s = 0.f;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) s += red[tid][r];
+    e[(long)b * T + t0 + tid] = (t0 + tid) < lens[b] ? s + gb[0] : -INFINITY;
+  }
 }
 
 // grid (B, ceil(E/64)); 256 threads = 4 frame-subgroups x 64 feature lanes; dynamic LDS: T floats
@@ -313,13 +396,6 @@ __global__ __launch_bounds__(256) void attloc_energy_bwd_kernel(const float* __r
 // in registers and leaves as a per-workgroup partial that attloc_bwd_reduce_kernel sums (no atomics), the reduction
 // over a for dconv goes through the waves and LDS.  reference: autograd of rnn/attentions.py:329-365 (AttLoc.forward).
 constexpr int ATTF_TCH = 32, ATTF_MAXC = 16;
-__device__ __forceinline__ float row16_sum(float v) {     // sum over the 16 lanes of a DPP row (no LDS crossbar trip)
-  v += eamd_dpp<0xB1>(v);
-  v += eamd_dpp<0x4E>(v);
-  v += eamd_dpp<0x141>(v);
-  v += eamd_dpp<0x140>(v);
-  return v;
-}
 template <int CT>       // channels the code is unrolled for: C <= CT, the excess ones carry zeros
 __global__ __launch_bounds__(256) void attloc_energy_bwd_fused_kernel(const float* __restrict__ de,
                                                                       const float* __restrict__ th,
@@ -476,11 +552,18 @@ __global__ __launch_bounds__(256) void attloc_conv_bwd_w_kernel(const float* __r
   const int F = (K - 1) / 2;
   for (int q = threadIdx.x; q < R * K; q += blockDim.x) {
     const int r = q / K, k = q % K;
-    float acc = 0.f;
-    for (int t = 0; t < T; ++t) {
-      const int ts = t + k - F;
-      if (ts >= 0 && ts < T) acc += dconv[((long)b * T + t) * C + c] * att_prev[((long)b * R + r) * T + ts];
+    // frames t with 0 <= t + k - F < T, eight independent products per trip (the loop is a chain of L2 round trips otherwise)
+    const int ta = max(0, F - k), tb = min(T, T + F - k);
+    const float* dcv = dconv + (long)b * T * C + c;
+    const float* pv = att_prev + ((long)b * R + r) * T + (k - F);
+    float a8[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    int t = ta;
+    for (; t + 8 <= tb; t += 8) {
+#pragma unroll
+      for (int u = 0; u < 8; ++u) a8[u] += dcv[(long)(t + u) * C] * pv[t + u];
     }
+    for (; t < tb; ++t) a8[0] += dcv[(long)t * C] * pv[t];
+    const float acc = ((a8[0] + a8[1]) + (a8[2] + a8[3])) + ((a8[4] + a8[5]) + (a8[6] + a8[7]));
     atomicAdd(&dconv_w[((long)c * R + r) * K + k], acc);
   }
 }
@@ -854,8 +937,19 @@ int eamd_attloc_fwd(const float* att_prev, const float* conv_w, const float* w_a
   if (C > 0 && (!att_prev || !conv_w || !w_att || !conv || K <= 0 || R <= 0)) return EAMD_EINVAL;   // C = 0: additive attention
   if (C > 64 || (C > 0 && (K & 1) == 0) || (size_t)T * sizeof(float) > 60 * 1024) return EAMD_EUNSUPPORTED;
   hipStream_t s = (hipStream_t)stream;
-  hipLaunchKernelGGL(attloc_energy_fwd_kernel, dim3(B * T), dim3(128), 0, s, att_prev, conv_w, w_att, pre_enc, dec_proj,
-                     gvec, gb, lens, e, th, conv, T, A, C, K, C > 0 ? R : 1);
+  const bool al = (((uintptr_t)pre_enc | (uintptr_t)th | (uintptr_t)dec_proj | (uintptr_t)gvec) & 15) == 0;
+  if (C > 0 && C <= 16 && R == 1 && K <= ATTE_MAXK && A % 4 == 0 && A <= 1024 && al) {
+    const dim3 grid(B, (T + ATTE_TCH - 1) / ATTE_TCH);
+    if (C == 10)
+      hipLaunchKernelGGL(attloc_energy_fwd8_kernel<10>, grid, dim3(256), 0, s, att_prev, conv_w, w_att, pre_enc, dec_proj, gvec,
+                         gb, lens, e, th, conv, T, A, C, K, R);
+    else
+      hipLaunchKernelGGL(attloc_energy_fwd8_kernel<16>, grid, dim3(256), 0, s, att_prev, conv_w, w_att, pre_enc, dec_proj, gvec,
+                         gb, lens, e, th, conv, T, A, C, K, R);
+  } else {
+    hipLaunchKernelGGL(attloc_energy_fwd_kernel, dim3(B * T), dim3(128), 0, s, att_prev, conv_w, w_att, pre_enc, dec_proj,
+                       gvec, gb, lens, e, th, conv, T, A, C, K, C > 0 ? R : 1);
+  }
   EAMD_LAUNCH_CHECK();
   hipLaunchKernelGGL(attloc_ctx_fwd_kernel, dim3(B, (E + 63) / 64), dim3(256), T * sizeof(float), s, e, enc_h, scaling,
                      w, ctx, T, E);
