@@ -209,6 +209,7 @@ def gemm(A, B, Cm, M, N, K, lda, ldb, ldc, *, transA=0, transB=0, bias=None, aux
 # wgrad_group_begin() and wgrad_join() every eligible one is queued (operands kept alive) and all of them leave as ONE
 # launch whose workgroups look their problem up in a device table (eamd_gemm_group_plan / eamd_gemm_group_launch).
 GROUP_WGRAD = True            # tests flip this to reach the one-launch-per-GEMM path
+STACK_WGRAD_MAX_ROWS = 64     # weight gradients of at most this many rows are stacked along the reduction until the flush (0: off)
 GROUP_WGRAD_MAX_TILES = int(os.environ.get("EAMD_GROUP_MAX_TILES", "384"))    # 64x64 output tiles: larger weight gradients fill the chip on their own
 # measured at config 2 (tools/group_sweep.sh): grouping everything up to 384 output tiles (all but the vocabulary-sized
 # gradients) with half the stand-alone split count is best in both precisions - 34.09 ms fp32 / 14.20 ms bf16 against
@@ -219,7 +220,7 @@ GROUP_WGRAD_SK_DIV = int(os.environ.get("EAMD_GROUP_SK_DIV", "2"))
 # GROUP_WGRAD_T128_WGS workgroups (tiles x K-splits) each
 GROUP_WGRAD_TILE128_MIN = int(os.environ.get("EAMD_GROUP_T128_MIN", "100"))
 GROUP_WGRAD_T128_WGS = int(os.environ.get("EAMD_GROUP_T128_WGS", "96"))
-_wgroup = {"on": False, "items": [], "pinned": [], "reserve": [], "arenas": {}}
+_wgroup = {"on": False, "items": [], "stack": {}, "pinned": [], "reserve": [], "arenas": {}}
 
 
 def register_grad_arena(t):
@@ -275,6 +276,18 @@ def _wgroup_staging(nbytes):
 
 def wgrad_group_flush():
     """launch everything queued so far: one grouped launch per tile size (a single queued GEMM goes out on its own)"""
+    stack, _wgroup["stack"] = _wgroup["stack"], {}
+    for dW, db, dys, xs in stack.values():          # stacked small-M weight gradients: one product per weight
+        if len(dys) == 1:
+            dyc, xc = dys[0], xs[0]
+        else:
+            dyc, xc = torch.cat(dys, 0), torch.cat(xs, 0)
+        if dyc.shape[0] <= STACK_WGRAD_MAX_ROWS:    # still a handful of rows: straight to the GEMM
+            sk = auto_splitk(dyc.shape[1], xc.shape[1], dyc.shape[0])
+            gemm(dyc, xc, dW, dyc.shape[1], xc.shape[1], dyc.shape[0], dyc.shape[1], xc.shape[1], xc.shape[1], transA=1,
+                 transB=1, splitk=sk, beta=1.0 if sk == 1 else 0.0, colsum=db, group=True)
+        else:
+            _linear_bwd_w(dyc, xc, dW, db=db)
     items = _wgroup["items"]
     if not items:
         return
@@ -368,7 +381,7 @@ def _skinny_splitk(M, N, K):
     64 workgroups, each walking the whole reduction alone while the weight matrix streams through a fraction of the
     chip: split the reduction until ~256 workgroups share it (f32 atomics into the zeroed result; config 4's decoder
     steps: 20 -> 9 us for the 32 x 2048 x 4096 input gradient)"""
-    if M > 64:
+    if M > 64 or N * K < 512 * 512:       # small weights: nothing to stream, keep the single-pass summation order
         return 1
     tiles = (M + 63) // 64 * ((N + 63) // 64)
     sk = 1
@@ -444,6 +457,17 @@ def _linear_bwd_w(dy, x, dW, *, alpha=1.0, b_act=ACT_NONE, db=None, a_drop=None,
     M, N = dy.shape
     K = x.shape[1]
     assert x.shape[0] == M and dW.numel() == N * K and dW.dtype == torch.float32
+    if (_wgroup["on"] and _wgrad["stream"] is None and M <= STACK_WGRAD_MAX_ROWS and alpha == 1.0 and b_act == ACT_NONE
+            and a_drop is None and b_drop is None and dy.is_contiguous() and x.is_contiguous() and _in_grad_arena(dW)):
+        # one decoder step's weight gradient (M = batch rows) reads and writes the whole dW for a reduction of M: the
+        # steps of a backward pass are stacked along the reduction instead and leave as ONE product at the flush
+        # (config 4: 101 x (22 + 12 us) of 32 MB / 16 MB read-modify-writes -> two GEMMs with K = 3232)
+        key = (dW.data_ptr(), db.data_ptr() if db is not None else 0, dy.dtype, x.dtype, N, K)
+        _wgroup["stack"].setdefault(key, (dW, db, [], []))
+        ent = _wgroup["stack"][key]
+        ent[2].append(dy)
+        ent[3].append(x)
+        return
     sk = auto_splitk(N, K, M)
     tile = 0
     t64 = ((N + 63) // 64) * ((K + 63) // 64)

@@ -249,6 +249,30 @@ def test_e2e_rnn_golden():
     check_grads(m, grads, tol=5e-4)
 
 
+def test_e2e_rnn_golden_stacked_step_weight_gradients():
+    """the same fixture with the gradients in a flat arena and backward inside wgrad_group_begin / end: the weight
+    gradients of the per-step products (decoder LSTM cells, attention projections: M = batch rows) are stacked along
+    the reduction and leave as one product per weight at the flush - same gradients as the reference"""
+    from espnet_amd import ops, train
+    from espnet_amd.nets.e2e_asr import E2E
+    p, sd, grads = split_golden(load_golden("e2e_rnn.npz"))
+    m = load_sd(E2E(12, 7, _rnn_args()), sd).to(DEV)
+    m.train()
+    flat = train.FlatParams(m)
+    flat.zero_grad()
+    loss = m(p["xs"].to(DEV), p["ilens"], p["ys"].to(DEV))
+    ops.wgrad_group_begin()
+    try:
+        loss.backward()
+        assert len(ops._wgroup["stack"]) > 0, "no per-step weight gradient was stacked"
+        nstacked = max(len(e[2]) for e in ops._wgroup["stack"].values())
+    finally:
+        ops.wgrad_group_end()
+    assert nstacked > 1 and not ops._wgroup["stack"]
+    flat.expose_grads()
+    check_grads(m, grads, tol=5e-4)
+
+
 @pytest.mark.parametrize("atype", ["dot", "add", "multi_head_dot", "multi_head_add", "multi_head_loc", "multi_head_multi_res_loc",
                                    "noatt", "coverage", "coverage_location", "location2d", "location_recurrent"])
 def test_e2e_rnn_attention_types_golden(atype):
