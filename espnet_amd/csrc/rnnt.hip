@@ -39,24 +39,40 @@ __global__ __launch_bounds__(256) void joint_bwd_enc_kernel(const float* __restr
   const int b = bt / T;
   for (int j = threadIdx.x; j < J; j += blockDim.x) {
     const float ev = e[bt * J + j];
-    float s = 0.f;
-    for (int u = 0; u < U; ++u)
-      s += dh[(bt * U + u) * J + j] * eamd_dact(ev + d[((long)b * U + u) * J + j], act);
-    de[bt * J + j] = s;
+    const float* dhp = dh + bt * U * J + j;
+    const float* dp = d + (long)b * U * J + j;
+    float s8[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};     // eight label positions in flight (a chain of L2 trips otherwise)
+    int u = 0;
+    for (; u + 8 <= U; u += 8) {
+#pragma unroll
+      for (int k = 0; k < 8; ++k) s8[k] += dhp[(long)(u + k) * J] * eamd_dact(ev + dp[(long)(u + k) * J], act);
+    }
+    for (; u < U; ++u) s8[0] += dhp[(long)u * J] * eamd_dact(ev + dp[(long)u * J], act);
+    de[bt * J + j] = ((s8[0] + s8[1]) + (s8[2] + s8[3])) + ((s8[4] + s8[5]) + (s8[6] + s8[7]));
   }
 }
-// d_dec[b,u,j] = sum_t dh[b,t,u,j] * act'(e[b,t,j] + d[b,u,j])      grid (B*U)
+// d_dec[b,u,j] = sum_t dh[b,t,u,j] * act'(e[b,t,j] + d[b,u,j])      grid (B*U, frame slices); slices > 1: atomics into zeroed dd
 __global__ __launch_bounds__(256) void joint_bwd_dec_kernel(const float* __restrict__ dh, const float* __restrict__ e,
                                                             const float* __restrict__ d, float* __restrict__ dd,
                                                             int B, int T, int U, int J, int act) {
   const long bu = blockIdx.x;
   const int b = bu / U, u = bu % U;
+  const int per = (T + gridDim.y - 1) / gridDim.y;
+  const int ta = blockIdx.y * per, tb = min(T, ta + per);
   for (int j = threadIdx.x; j < J; j += blockDim.x) {
     const float dv = d[bu * J + j];
-    float s = 0.f;
-    for (int t = 0; t < T; ++t)
-      s += dh[(((long)b * T + t) * U + u) * J + j] * eamd_dact(e[((long)b * T + t) * J + j] + dv, act);
-    dd[bu * J + j] = s;
+    const float* dhp = dh + ((long)b * T * U + u) * J + j;
+    const float* ep = e + (long)b * T * J + j;
+    float s8[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    int t = ta;
+    for (; t + 8 <= tb; t += 8) {
+#pragma unroll
+      for (int k = 0; k < 8; ++k) s8[k] += dhp[(long)(t + k) * U * J] * eamd_dact(ep[(long)(t + k) * J] + dv, act);
+    }
+    for (; t < tb; ++t) s8[0] += dhp[(long)t * U * J] * eamd_dact(ep[(long)t * J] + dv, act);
+    const float s = ((s8[0] + s8[1]) + (s8[2] + s8[3])) + ((s8[4] + s8[5]) + (s8[6] + s8[7]));
+    if (gridDim.y > 1) atomicAdd(&dd[bu * J + j], s);
+    else dd[bu * J + j] = s;
   }
 }
 
@@ -289,7 +305,11 @@ int eamd_joint_bwd(const float* dh, const float* enc, const float* dec, float* d
   hipStream_t s = (hipStream_t)stream;
   hipLaunchKernelGGL(joint_bwd_enc_kernel, dim3(B * T), dim3(256), 0, s, dh, enc, dec, d_enc, B, T, U, J, act);
   EAMD_LAUNCH_CHECK();
-  hipLaunchKernelGGL(joint_bwd_dec_kernel, dim3(B * U), dim3(256), 0, s, dh, enc, dec, d_dec, B, T, U, J, act);
+  // few (b, u) rows (one utterance's chunk): the frames are cut into slices so that ~512 workgroups share the pass
+  int slices = 1;
+  while ((long)B * U * slices < 512 && T / (slices * 2) >= 16) slices *= 2;
+  if (slices > 1 && hipMemsetAsync(d_dec, 0, (size_t)B * U * J * sizeof(float), s) != hipSuccess) return EAMD_EINVAL;
+  hipLaunchKernelGGL(joint_bwd_dec_kernel, dim3(B * U, slices), dim3(256), 0, s, dh, enc, dec, d_dec, B, T, U, J, act);
   EAMD_LAUNCH_CHECK();
   return EAMD_OK;
 }
