@@ -434,6 +434,17 @@ extern "C" int eamd_gemm(const eamd_gemm_t* pp, void* stream_) {
   if ((p.a_drop_p != 0.f || p.b_drop_p != 0.f) && (p.in_dtype != 0 || p.precision != 0)) return EAMD_EUNSUPPORTED;
   if (p.in_dtype == 1) return eamd_gemm_bf16_dispatch(p, tile, stream);
 
+  // fp32 operands asked to go through the bf16 matrix cores (precision 1, bf16 mode's leftovers: activations a producer
+  // keeps in fp32): the generic kernel converts while staging behind guarded loads (30-65 TFLOP/s on skinny shapes);
+  // the implicit-conv weight gradients among them (EAMD_P1_F32=0: off) go (gather + transA: tiny output, K in the millions,
+  // bound by the operand stream) through the pipelined fp32 kernel instead - exact fp32 arithmetic, i.e. no less accurate
+  // (config 4, bf16 mode: 92.5 -> 91.1 ms)
+  static const int p1_f32 = [] { const char* e = getenv("EAMD_P1_F32"); return e ? atoi(e) : 1; }();
+  if (p.precision == 1 && p1_f32 && p.gather.enabled && p.transA && !p.Hb && p.drop_p == 0.f && p.a_drop_p == 0.f &&
+      p.b_drop_p == 0.f) {
+    const int rc = eamd_gemm_f32_dispatch(p, tile, stream);
+    if (rc != EAMD_EUNSUPPORTED) return rc;
+  }
   if (p.precision == 0) {     // reference precision: the pipelined fp32-MFMA kernel wherever its staging conditions hold
     const int rc = eamd_gemm_f32_dispatch(p, tile, stream);
     if (rc != EAMD_EUNSUPPORTED) return rc;
