@@ -328,7 +328,7 @@ __global__ __launch_bounds__(256) void attloc_ctx_bwd_rows_kernel(const float* _
                                                                   const float* __restrict__ w,
                                                                   const float* __restrict__ enc_h,
                                                                   float* __restrict__ dwv, float* __restrict__ d_enc_h,
-                                                                  int BT, int T, int E) {
+                                                                  int BT, int T, int E, int accum = 0) {
   const int lane = threadIdx.x & 63;
   const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (row >= BT) return;
@@ -341,7 +341,7 @@ __global__ __launch_bounds__(256) void attloc_ctx_bwd_rows_kernel(const float* _
   for (int x = lane; x < E; x += 64) {
     const float c = dc[x];
     d += c * h[x];
-    o[x] = wv * c;
+    o[x] = accum ? o[x] + wv * c : wv * c;       // accum: the running sum over the decoder steps (see eamd_attloc_bwd_energy_conv)
   }
   d = wave_sum(d);
   if (lane == 0) dwv[row] = d + (dw_ext ? dw_ext[row] : 0.f);
@@ -403,7 +403,7 @@ __global__ __launch_bounds__(256) void attloc_energy_bwd_fused_kernel(const floa
                                                                       const float* __restrict__ conv,
                                                                       const float* __restrict__ w_att,
                                                                       float* __restrict__ df, float* __restrict__ dconv,
-                                                                      float* __restrict__ part, int T, int A, int C) {
+                                                                      float* __restrict__ part, int T, int A, int C, int accum) {
   __shared__ float red[ATTF_TCH][16][ATTF_MAXC];         // [frame][16-lane row of the workgroup][channel]
   const int b = blockIdx.x, ch = blockIdx.y;
   const int t0 = ch * ATTF_TCH, t1 = min(T, t0 + ATTF_TCH);
@@ -454,7 +454,11 @@ __global__ __launch_bounds__(256) void attloc_energy_bwd_fused_kernel(const floa
       float4 f;
       f.x = d * g.x * (1.f - v.x * v.x); f.y = d * g.y * (1.f - v.y * v.y);
       f.z = d * g.z * (1.f - v.z * v.z); f.w = d * g.w * (1.f - v.w * v.w);
-      if (live && tg + u < t1) *reinterpret_cast<float4*>(df + row * A + a) = f;
+      if (live && tg + u < t1) {
+        float4* dst = reinterpret_cast<float4*>(df + row * A + a);
+        if (accum) { const float4 o = *dst; *dst = make_float4(o.x + f.x, o.y + f.y, o.z + f.z, o.w + f.w); }
+        else *dst = f;
+      }
       pg.x += d * v.x; pg.y += d * v.y; pg.z += d * v.z; pg.w += d * v.w;
       pd.x += f.x; pd.y += f.y; pd.z += f.z; pd.w += f.w;
       float sc[CT];
@@ -985,7 +989,8 @@ int64_t eamd_attloc_bwd_workspace(int B, int T, int A, int C) {
 int eamd_attloc_bwd_energy_conv(const float* dctx, const float* dw_ext, const float* w, const float* enc_h, const float* th,
                                 const float* gvec, float scaling, const float* conv, const float* w_att, float* de,
                                 float* d_enc_h, float* df, float* dconv, float* dgvec, float* dgb, float* d_dec_proj,
-                                float* dw_att, float* workspace, int B, int T, int A, int C, int E, void* stream) {
+                                float* dw_att, float* workspace, int accumulate, int B, int T, int A, int C, int E,
+                                void* stream) {
   if (!dctx || !w || !enc_h || !th || !gvec || !conv || !w_att || !de || !d_enc_h || !df || !dconv || !dgvec || !dgb ||
       !d_dec_proj || !dw_att || !workspace || B <= 0 || T <= 0 || A <= 0 || C <= 0 || E <= 0)
     return EAMD_EINVAL;
@@ -996,20 +1001,20 @@ int eamd_attloc_bwd_energy_conv(const float* dctx, const float* dw_ext, const fl
   hipStream_t s = (hipStream_t)stream;
   const int nch = (T + ATTF_TCH - 1) / ATTF_TCH;
   hipLaunchKernelGGL(attloc_ctx_bwd_rows_kernel, dim3((B * T + 3) / 4), dim3(256), 0, s, dctx, dw_ext, w, enc_h, de, d_enc_h,
-                     B * T, T, E);
+                     B * T, T, E, accumulate);
   EAMD_LAUNCH_CHECK();
   hipLaunchKernelGGL(attloc_softmax_bwd_kernel, dim3(B), dim3(256), 0, s, w, scaling, de, dgb, T);
   EAMD_LAUNCH_CHECK();
   // exact unrolls for the usual channel counts (aconv_chans = 10 in the recipes), the padded 16-channel form otherwise
   if (C == 10)
     hipLaunchKernelGGL(attloc_energy_bwd_fused_kernel<10>, dim3(B, nch), dim3(256), 0, s, de, th, gvec, conv, w_att, df, dconv,
-                       workspace, T, A, C);
+                       workspace, T, A, C, accumulate);
   else if (C == 4)
     hipLaunchKernelGGL(attloc_energy_bwd_fused_kernel<4>, dim3(B, nch), dim3(256), 0, s, de, th, gvec, conv, w_att, df, dconv,
-                       workspace, T, A, C);
+                       workspace, T, A, C, accumulate);
   else
     hipLaunchKernelGGL(attloc_energy_bwd_fused_kernel<ATTF_MAXC>, dim3(B, nch), dim3(256), 0, s, de, th, gvec, conv, w_att, df,
-                       dconv, workspace, T, A, C);
+                       dconv, workspace, T, A, C, accumulate);
   EAMD_LAUNCH_CHECK();
   const long n = (long)A * (C + 1) + (long)B * A;
   hipLaunchKernelGGL(attloc_bwd_reduce_kernel, dim3((unsigned)((n + 63) / 64)), dim3(256), 0, s, workspace, dw_att, dgvec,

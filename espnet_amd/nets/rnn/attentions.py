@@ -31,6 +31,7 @@ class AttLoc(torch.nn.Module):
         self.pre_compute_enc_h = None
         self.mask = None
         self._lens = None
+        self._acc = None
 
     def forward(self, enc_hs_pad, enc_hs_len, dec_z, att_prev, scaling=2.0, last_attended_idx=None,
                 backward_window=1, forward_window=3):
@@ -38,6 +39,7 @@ class AttLoc(torch.nn.Module):
             raise NotImplementedError("attention constraint (TTS) is not on the ASR path")
         batch = enc_hs_pad.shape[0]
         dev = enc_hs_pad.device
+        first = False
         if self.pre_compute_enc_h is None or self.han_mode:
             self.enc_h = enc_hs_pad.contiguous()
             self.h_length = self.enc_h.size(1)
@@ -45,6 +47,10 @@ class AttLoc(torch.nn.Module):
             lens = np.asarray([int(v) for v in enc_hs_len], dtype=np.int32)
             self._lens_host = lens
             self._lens = ops.h2d_cached("attlens", lens, dev)
+            # the first step of a sequence that starts from no attention history: every later step depends on it, so its
+            # backward runs last and the steps can keep the gradients of enc_h / pre_compute_enc_h as one running sum
+            first = att_prev is None and not self.han_mode
+            self._acc = {} if first else None
         if dec_z is None:
             dec_z = enc_hs_pad.new_zeros(batch, self.dunits)
         else:
@@ -55,7 +61,8 @@ class AttLoc(torch.nn.Module):
             att_prev = ops.h2d_cached("attuniform", keep / self._lens_host[:, None].astype(np.float32), dev)
         dec_proj = F_.LinearFn.apply(dec_z, self.mlp_dec.weight, None)
         c, w = R_.AttLocStepFn.apply(self.enc_h, self.pre_compute_enc_h, dec_proj, att_prev, self._lens, float(scaling),
-                                     self.loc_conv.weight, self.mlp_att.weight, self.gvec.weight, self.gvec.bias)
+                                     self.loc_conv.weight, self.mlp_att.weight, self.gvec.weight, self.gvec.bias,
+                                     self._acc, first)
         return c, w
 
 

@@ -1339,9 +1339,11 @@ def attloc_bwd_energy(dctx, dw_ext, w, enc_h, th, gvec, scaling, dgvec, dgb):
 ATTLOC_FUSED_BWD = True     # tests flip this to reach the GEMM form of the two products over mlp_att's weight
 
 
-def attloc_bwd_energy_conv(dctx, dw_ext, w, enc_h, th, gvec, scaling, conv, w_att, dgvec, dgb, dw_att):
+def attloc_bwd_energy_conv(dctx, dw_ext, w, enc_h, th, gvec, scaling, conv, w_att, dgvec, dgb, dw_att, acc=None):
     """attloc_bwd_energy plus dconv = df @ W_att and dw_att += df^T conv from the same pass over th
-    (eamd_attloc_bwd_energy_conv).  Returns (d_enc_h, df, d_dec, dconv), or None if the library declines the shape."""
+    (eamd_attloc_bwd_energy_conv).  Returns (d_enc_h, df, d_dec, dconv), or None if the library declines the shape.
+    acc: a dict shared by the decoder steps of one utterance batch - d_enc_h and df (gradients of step-invariant tensors)
+    are then kept as ONE running sum in it (created by the first call, added to by the later ones) and returned as such."""
     B, T, A = th.shape
     E, Cc = enc_h.shape[2], conv.shape[2]
     if not ATTLOC_FUSED_BWD or Cc > 16 or A % 4 or A > 1024:
@@ -1351,16 +1353,23 @@ def attloc_bwd_energy_conv(dctx, dw_ext, w, enc_h, th, gvec, scaling, conv, w_at
     nws = int(lib.eamd_attloc_bwd_workspace(B, T, A, Cc)) // 4
     ws = torch.empty(nws, device=dev, dtype=torch.float32)
     de = torch.empty(B, T, device=dev, dtype=torch.float32)
-    d_enc_h = torch.empty(B, T, E, device=dev, dtype=torch.float32)
-    df = torch.empty(B, T, A, device=dev, dtype=torch.float32)
+    accumulate = acc is not None and "df" in acc
+    if accumulate:
+        d_enc_h, df = acc["deh"], acc["df"]
+    else:
+        d_enc_h = torch.empty(B, T, E, device=dev, dtype=torch.float32)
+        df = torch.empty(B, T, A, device=dev, dtype=torch.float32)
     dconv = torch.empty(B, T, Cc, device=dev, dtype=torch.float32)
     d_dec = torch.zeros(B, A, device=dev, dtype=torch.float32)
     rc = lib.eamd_attloc_bwd_energy_conv(ptr(dctx), ptr(dw_ext), ptr(w), ptr(enc_h), ptr(th), ptr(gvec), C.c_float(scaling),
                                          ptr(conv), ptr(w_att), ptr(de), ptr(d_enc_h), ptr(df), ptr(dconv), ptr(dgvec),
-                                         ptr(dgb), ptr(d_dec), ptr(dw_att), ptr(ws), B, T, A, Cc, E, stream_ptr())
+                                         ptr(dgb), ptr(d_dec), ptr(dw_att), ptr(ws), int(accumulate), B, T, A, Cc, E,
+                                         stream_ptr())
     if rc == _lib.EAMD_EUNSUPPORTED:
         return None
     check(rc, "eamd_attloc_bwd_energy_conv")
+    if acc is not None and not accumulate:
+        acc["deh"], acc["df"] = d_enc_h, df
     return d_enc_h, df, d_dec, dconv
 
 

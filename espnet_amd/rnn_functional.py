@@ -369,7 +369,13 @@ class VGG2LFn(torch.autograd.Function):
 # =================================================================================================
 class AttLocStepFn(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, enc_h, pre_enc, dec_proj, att_prev, lens, scaling, conv_w, w_att, gvec_w, gvec_b):
+    def forward(ctx, enc_h, pre_enc, dec_proj, att_prev, lens, scaling, conv_w, w_att, gvec_w, gvec_b, acc=None,
+                first=False):
+        # acc / first (AttLoc): enc_h and pre_enc are the same tensors at every decoder step, so their gradients are one
+        # running sum kept in `acc` by the step kernels; only the FIRST step - whose backward runs last: every later
+        # step hangs on it through the attention weights and the decoder state - hands that sum to autograd, the others
+        # return None (101 fresh 33 MB tensors each and autograd's adds otherwise: 4 ms per step at config 4)
+        ctx.acc, ctx.first = acc, first
         enc_h, pre_enc, dec_proj = (t.contiguous() for t in (enc_h, pre_enc, dec_proj))
         att_prev = att_prev.contiguous() if conv_w is not None else None       # conv_w None: additive attention
         c, w, th, conv = ops.attloc_fwd(att_prev, conv_w, w_att, pre_enc, dec_proj, gvec_w, gvec_b, lens, enc_h,
@@ -389,15 +395,21 @@ class AttLocStepFn(torch.autograd.Function):
             gvec_w, gvec_b = ctx.pr
             d_enc_h, df, d_dec = ops.attloc_bwd_energy(dc.contiguous(), dw.contiguous() if dw is not None else None,
                                                        w, enc_h, th, gvec_w, ctx.scaling, sink.buf(0), sink.buf(1))
-            return (d_enc_h, df, d_dec, None, None, None, None, None) + sink.results()
+            return (d_enc_h, df, d_dec, None, None, None, None, None) + sink.results() + (None, None)
         conv_w, w_att, gvec_w, gvec_b = ctx.pr
         Cc = conv.shape[2]
         dcc, dwc = dc.contiguous(), dw.contiguous() if dw is not None else None
         # one pass over th forms df, dconv = df @ W_att and dW_att += df^T conv (two N = C GEMMs otherwise)
+        acc = ctx.acc
         r = ops.attloc_bwd_energy_conv(dcc, dwc, w, enc_h, th, gvec_w, ctx.scaling, conv, w_att, sink.buf(2), sink.buf(3),
-                                       sink.buf(1))
+                                       sink.buf(1), acc=acc)
         if r is not None:
             d_enc_h, df, d_dec, dconv = r
+            if acc is not None:
+                if ctx.first:          # the last backward of the sequence: the sums go to autograd
+                    acc.clear()
+                else:
+                    d_enc_h = df = None
         else:
             d_enc_h, df, d_dec = ops.attloc_bwd_energy(dcc, dwc, w, enc_h, th, gvec_w, ctx.scaling, sink.buf(2), sink.buf(3))
             df2 = df.view(B * T, A)
@@ -405,7 +417,7 @@ class AttLocStepFn(torch.autograd.Function):
             ops.gemm(df2, w_att, dconv, B * T, Cc, A, A, Cc, Cc, transB=1)              # dconv = df @ W_att
             ops.linear_bwd_w(df2, conv.view(B * T, Cc), sink.buf(1))                     # dW_att += df^T conv
         d_prev = ops.attloc_bwd_conv(dconv.view(B, T, Cc), conv_w, att_prev, sink.buf(0))
-        return (d_enc_h, df, d_dec, d_prev, None, None) + sink.results()
+        return (d_enc_h, df, d_dec, d_prev, None, None) + sink.results() + (None, None)
 
 
 class AttDotStepFn(torch.autograd.Function):

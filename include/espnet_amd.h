@@ -474,12 +474,15 @@ int eamd_attloc_bwd_energy(const float* dctx, const float* dw_ext, const float* 
  * A <= 1024, A % 4 == 0): everything eamd_attloc_bwd_energy does, plus dconv [B,T,C] = df @ W_att (written) and
  * dw_att [A,C] += df^T conv (ACCUMULATED), with conv [B,T,C] as eamd_attloc_fwd left it and w_att [A,C] = mlp_att.weight.
  * workspace: eamd_attloc_bwd_workspace(B, T, A, C) bytes of device memory, 16-byte aligned (per-workgroup partial sums).
+ * accumulate != 0: d_enc_h and df are ADDED to (the caller keeps one running sum over the decoder steps of an utterance
+ * batch - both are gradients of step-invariant tensors - instead of 101 fresh 33 MB tensors for autograd to add up).
  * Replaces the two N = C GEMMs of the step.  reference: autograd of rnn/attentions.py:329-365. */
 int64_t eamd_attloc_bwd_workspace(int B, int T, int A, int C);
 int eamd_attloc_bwd_energy_conv(const float* dctx, const float* dw_ext, const float* w, const float* enc_h, const float* th,
                                 const float* gvec, float scaling, const float* conv, const float* w_att, float* de,
                                 float* d_enc_h, float* df, float* dconv, float* dgvec, float* dgb, float* d_dec_proj,
-                                float* dw_att, float* workspace, int B, int T, int A, int C, int E, void* stream);
+                                float* dw_att, float* workspace, int accumulate, int B, int T, int A, int C, int E,
+                                void* stream);
 /* Dot-product attention (AttDot rnn/attentions.py:91-164, per head of AttMultiHeadDot :845-990):
  * e[b,t] = k[b,t,:] . q[b,:] on already tanh-activated k = tanh(mlp_k h), q = tanh(mlp_q z); -inf for t >= lens[b];
  * then w = softmax(scaling * e), ctx = sum_t w * v (eamd_att_ctx_*: the softmax / context half of eamd_attloc_*).
