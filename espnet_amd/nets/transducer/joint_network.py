@@ -1,4 +1,5 @@
 """reference: espnet/nets/pytorch_backend/transducer/joint_network.py:8-48"""
+import os
 import torch
 
 from ... import functional as F_
@@ -43,9 +44,11 @@ class JointNetwork(torch.nn.Module):
             z = R_.JointFn.apply(enc_proj_rows.contiguous().view(n, 1, -1), d.view(n, 1, -1), self.act_id)
         return F_.LinearFn.apply(z.reshape(n, -1), self.lin_out.weight, self.lin_out.bias)
 
-    def loss(self, h_enc, h_dec, target, pred_len, target_len, pred_len_host, blank, chunk_rows=1 << 15):
+    def loss(self, h_enc, h_dec, target, pred_len, target_len, pred_len_host, blank, chunk_rows=None):
         """transducer loss from encoder states (B,T,D_enc) and prediction-network states (B,U,D_dec) without the
         (B,T,U,V) logits (rnn_functional.JointRNNTLossFn): mean over the batch of -log P(y | x)"""
+        if chunk_rows is None:
+            chunk_rows = int(os.environ.get("EAMD_RNNT_CHUNK_ROWS", str(1 << 16)))
         e = F_.LinearFn.apply(h_enc, self.lin_enc.weight, self.lin_enc.bias)
         d = F_.LinearFn.apply(h_dec, self.lin_dec.weight, None)
         return R_.JointRNNTLossFn.apply(e, d, self.lin_out.weight, self.lin_out.bias, target.contiguous(), pred_len.contiguous(),
