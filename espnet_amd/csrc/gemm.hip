@@ -399,10 +399,11 @@ extern "C" int eamd_gemm(const eamd_gemm_t* pp, void* stream_) {
     long t128 = (long)((p.M + 127) / 128) * ((p.N + 127) / 128) * p.batch1 * p.batch2 * p.splitk;
     if (p.in_dtype == 1) {
       // measured on MI355X (tools/gemm_breakdown.py bf16, tools/gemm_kslope.py): the 64x64 tile (and its persistent
-      // form) wins at K = 256; from K = 512 on the 128x128 tile, two workgroups per CU since its register cap, is ahead
+      // form) wins at K = 256; from K = 320 on the 128x128 tile, two workgroups per CU since its register cap, is ahead
       // once there are two full rounds of tiles - the implicit-conv GEMMs of the subsampling front end
-      // (151392 x 256 x 2304: 461 -> 335 us, 160000 x 256 x 1024: 276 -> 220 us)
-      static const int kmin = [] { const char* e = getenv("EAMD_BF16_T128_KMIN"); return e ? atoi(e) : 512; }();
+      // (151392 x 256 x 2304: 461 -> 335 us, 160000 x 256 x 1024: 276 -> 220 us) and the transducer's logits products
+      // (37774 x 5000 x 320: config 5 46.9 -> 44.4 ms)
+      static const int kmin = [] { const char* e = getenv("EAMD_BF16_T128_KMIN"); return e ? atoi(e) : 320; }();
       static const int nmin = [] { const char* e = getenv("EAMD_BF16_T128_NMIN"); return e ? atoi(e) : 256; }();
       tile = (t128 >= 1024 && p.K >= kmin && p.M >= 2048 && p.N >= nmin) ? 128 : 64;
     } else {
