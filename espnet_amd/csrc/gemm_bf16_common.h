@@ -106,6 +106,27 @@ __device__ __forceinline__ unsigned relu2(unsigned w) {
 __device__ __forceinline__ uint4 swish8(uint4 v) { return make_uint4(swish2(v.x), swish2(v.y), swish2(v.z), swish2(v.w)); }
 __device__ __forceinline__ uint4 relu8(uint4 v) { return make_uint4(relu2(v.x), relu2(v.y), relu2(v.z), relu2(v.w)); }
 
+// max / sum over the G = 16 or 32 adjacent lanes that hold one row of a staged result tile (DPP row operations; one
+// LDS-crossbar step joins the two 16-lane rows of a 32-lane group); every lane of the group gets the result
+template <int G>
+__device__ __forceinline__ float rowgroup_max(float v) {
+  v = fmaxf(v, eamd_dpp<0xB1>(v));
+  v = fmaxf(v, eamd_dpp<0x4E>(v));
+  v = fmaxf(v, eamd_dpp<0x141>(v));
+  v = fmaxf(v, eamd_dpp<0x140>(v));
+  if constexpr (G == 32) v = fmaxf(v, __shfl_xor(v, 16, 64));
+  return v;
+}
+template <int G>
+__device__ __forceinline__ float rowgroup_sum(float v) {
+  v += eamd_dpp<0xB1>(v);
+  v += eamd_dpp<0x4E>(v);
+  v += eamd_dpp<0x141>(v);
+  v += eamd_dpp<0x140>(v);
+  if constexpr (G == 32) v += __shfl_xor(v, 16, 64);
+  return v;
+}
+
 // Result tile -> global memory.  The accumulators go through an LDS staging area so that every lane stores 16
 // contiguous bytes of one output row (1 KiB per wave-instruction instead of four 64-byte segments); the residual /
 // aux operands are read the same way.  Fused here: bias, activation, aux-derivative masks, dropout / dual output,
@@ -150,6 +171,35 @@ __device__ __forceinline__ void store_c_tile(const eamd_gemm_t& p, f32x4 (&acc)[
   if (p.bias) {
 #pragma unroll
     for (int e = 0; e < 4; ++e) if (n + e < p.N) bv[e] = p.bias[n + e];
+  }
+  if (p.epilogue == 7) {
+    // row statistics instead of the result (see eamd_gemm_t.stats): the V4_PER_ROW lanes of a row reduce their four
+    // columns each to the tile's (max, sum exp) for that row; the two gathered columns leave from whichever lane holds them
+    static_assert(V4_PER_ROW == 16 || V4_PER_ROW == 32, "a staged row is one or two DPP rows of lanes");
+    const int tiles_n = (p.N + BN - 1) / BN, tile_n = n0 / BN;
+    for (int rr = t / V4_PER_ROW; rr < BM; rr += ROWS_PER_PASS) {      // same trip count for every lane: no early exits
+      const int m = m0 + rr;
+      const float4 a4 = *reinterpret_cast<const float4*>(&cl[rr * LDC + c4 * 4]);
+      const float v[4] = {a4.x + bv[0], a4.y + bv[1], a4.z + bv[2], a4.w + bv[3]};
+      float mx = -INFINITY;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) if (n + e < p.N) mx = fmaxf(mx, v[e]);
+      mx = rowgroup_max<V4_PER_ROW>(mx);
+      float sm = 0.f;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) if (n + e < p.N) sm += expf(v[e] - mx);
+      sm = rowgroup_sum<V4_PER_ROW>(sm);
+      if (m < p.M) {
+        if (c4 == 0) {
+          float* pp = p.stats.part + ((long)m * tiles_n + tile_n) * 2;
+          pp[0] = mx; pp[1] = sm;
+        }
+        const int lc = p.stats.col ? p.stats.col[m] : -1;
+        if (lc >= n && lc < n + 4 && lc < p.N) p.stats.zcol[m] = v[lc - n];
+        if (p.stats.fix >= n && p.stats.fix < n + 4 && p.stats.fix < p.N) p.stats.zfix[m] = v[p.stats.fix - n];
+      }
+    }
+    return;
   }
   // per-pass arithmetic + stores on values already in registers
   auto emit = [&](long ci, int nn, bool full, float (&v)[4], const float (&ax)[4], const float (&rv)[4],

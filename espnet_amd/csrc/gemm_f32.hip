@@ -556,7 +556,7 @@ bool aligned16f(const void* q) { return (reinterpret_cast<uintptr_t>(q) & 15) ==
 int eamd_gemm_f32_dispatch(const eamd_gemm_t& p, int tile, hipStream_t stream) {
   static const int on = [] { const char* e = getenv("EAMD_GEMM_F32_FAST"); return e ? atoi(e) : 1; }();
   if (!on) return EAMD_EUNSUPPORTED;
-  if (p.Cb || (p.Hb && !p.h_dtype) || p.aux_dtype || !p.C) return EAMD_EUNSUPPORTED;
+  if (p.Cb || (p.Hb && !p.h_dtype) || p.aux_dtype || (!p.C && p.epilogue != 7)) return EAMD_EUNSUPPORTED;
   if (p.Hb && p.drop_p <= 0.f) return EAMD_EINVAL;
   if (p.drop_p < 0.f || p.drop_p >= 1.f) return EAMD_EINVAL;
   if (p.a_drop_p < 0.f || p.a_drop_p >= 1.f || p.b_drop_p < 0.f || p.b_drop_p >= 1.f) return EAMD_EINVAL;

@@ -143,6 +143,26 @@ __global__ __launch_bounds__(256) void rnnt_lse_gather_wave_kernel(const float* 
     lpl[row] = (u < U - 1) ? zr[labels[b * (U - 1) + u]] - l : -INFINITY;
   }
 }
+// lse / log p(blank) / log p(label) of lattice nodes from the per-column-tile (max, sum exp) partials and the two gathered
+// logits that the logits GEMM's row-statistics epilogue left behind (eamd_gemm_t.stats): the logits are never stored
+__global__ __launch_bounds__(256) void rnnt_stats_combine_kernel(const float* __restrict__ part, const float* __restrict__ zlab,
+                                                                 const float* __restrict__ zblank, float* __restrict__ lse,
+                                                                 float* __restrict__ lpb, float* __restrict__ lpl,
+                                                                 int tiles_n, int U, long node0, long nrows) {
+  const long r = (long)blockIdx.x * 256 + threadIdx.x;
+  if (r >= nrows) return;
+  const float2* pp = reinterpret_cast<const float2*>(part) + r * tiles_n;
+  float m = -INFINITY;
+  for (int j = 0; j < tiles_n; ++j) m = fmaxf(m, pp[j].x);
+  float sm = 0.f;
+  for (int j = 0; j < tiles_n; ++j) sm += pp[j].y * expf(pp[j].x - m);
+  const float l = m + logf(sm);
+  const long row = node0 + r;
+  const int u = (int)(row % U);
+  lse[row] = l;
+  lpb[row] = zblank[r] - l;
+  lpl[row] = (u < U - 1) ? zlab[r] - l : -INFINITY;
+}
 static void launch_lse_gather(const float* z, const int* labels, float* lse, float* lpb, float* lpl, int T, int U, int V,
                               int blank, long node0, long nrows, hipStream_t s) {
   if (V % 4 == 0 && V <= RNNT_LSE_MAXP * 256 && (reinterpret_cast<uintptr_t>(z) & 15) == 0)
@@ -379,6 +399,23 @@ int eamd_rnnt_node_stats(const float* logits_rows, const int32_t* labels, float*
     return EAMD_EINVAL;
   float* lse = workspace;
   launch_lse_gather(logits_rows, labels, lse, lse + n, lse + 2 * n, T, U, V, blank, (long)node0, (long)nrows, (hipStream_t)stream);
+  EAMD_LAUNCH_CHECK();
+  return EAMD_OK;
+}
+
+/* eamd_rnnt_node_stats for logits that were never stored: part / zlab / zblank are what eamd_gemm's row-statistics epilogue
+ * (epilogue 7, eamd_gemm_t.stats with col = the node's next label or -1, fix = blank) wrote for the nrows nodes
+ * node0 .. node0 + nrows - 1; tiles_n = ceil(V / tile) of that launch */
+int eamd_rnnt_node_stats_part(const float* part, const float* zlab, const float* zblank, float* workspace, int64_t node0,
+                              int64_t nrows, int tiles_n, int B, int T, int U, void* stream) {
+  if (!part || !zlab || !zblank || !workspace || B <= 0 || T <= 0 || U <= 0 || tiles_n <= 0 || node0 < 0 || nrows <= 0)
+    return EAMD_EINVAL;
+  const long n = (long)B * T * U;
+  if (node0 + nrows > n) return EAMD_EINVAL;
+  if (reinterpret_cast<uintptr_t>(part) & 7) return EAMD_EUNSUPPORTED;
+  float* lse = workspace;
+  hipLaunchKernelGGL(rnnt_stats_combine_kernel, dim3((unsigned)((nrows + 255) / 256)), dim3(256), 0, (hipStream_t)stream, part,
+                     zlab, zblank, lse, lse + n, lse + 2 * n, tiles_n, U, (long)node0, (long)nrows);
   EAMD_LAUNCH_CHECK();
   return EAMD_OK;
 }

@@ -13,7 +13,7 @@ from . import _lib
 from ._lib import GatherT, GemmT, RowMapT, check, ptr, stream_ptr
 
 ACT_NONE, ACT_RELU, ACT_SWISH = 0, 1, 2
-EPI_NONE, EPI_RELU, EPI_SWISH, EPI_MUL_RELU_MASK, EPI_MUL_DSWISH, EPI_MUL_AUX, EPI_DACT_FACTOR = 0, 1, 2, 3, 4, 5, 6
+EPI_NONE, EPI_RELU, EPI_SWISH, EPI_MUL_RELU_MASK, EPI_MUL_DSWISH, EPI_MUL_AUX, EPI_DACT_FACTOR, EPI_ROW_STATS = 0, 1, 2, 3, 4, 5, 6, 7
 
 _PRECISIONS = {"fp32": 0, "bf16": 1}
 _state = {"precision": 0}
@@ -115,7 +115,7 @@ _gemm_record = None
 def gemm(A, B, Cm, M, N, K, lda, ldb, ldc, *, transA=0, transB=0, bias=None, aux=None, ldaux=0, R=None,
          ldr=0, batch=(1, 1), sA=(0, 0), sB=(0, 0), sC=(0, 0), alpha=1.0, beta=0.0, a_act=0, b_act=0,
          epilogue=0, splitk=1, tile=0, gather=None, cmap=None, a_off=0, b_off=0, c_off=0, precision=None,
-         colsum=None, Cb=None, drop=None, Hb=None, h_act=0, a_drop=None, b_drop=None, group=False):
+         colsum=None, Cb=None, drop=None, Hb=None, h_act=0, a_drop=None, b_drop=None, group=False, stats=None):
     """A, B: both float32 or both bfloat16 (bf16 operands select the fast MFMA kernel).
     Cm: float32 result, or bfloat16 result (then no fp32 copy is written); Cb: extra bf16 copy.
     group=True (weight gradients): while wgrad_group_begin() is in effect the launch is queued and leaves with all other
@@ -123,8 +123,10 @@ def gemm(A, B, Cm, M, N, K, lda, ldb, ldc, *, transA=0, transB=0, bias=None, aux
     bf = A.dtype == torch.bfloat16
     if A.dtype != B.dtype or A.dtype not in (torch.float32, torch.bfloat16) or not (A.is_cuda and B.is_cuda):
         raise _lib.EamdError("gemm needs float32 or bfloat16 GPU operands of one dtype")
-    c32 = Cm if Cm.dtype == torch.float32 else None
-    c16 = Cb if Cb is not None else (Cm if Cm.dtype == torch.bfloat16 else None)
+    if stats is not None:      # row statistics instead of a result (EPI_ROW_STATS): (part, col, zcol, zfix, fix), Cm = None
+        assert Cm is None and Cb is None and epilogue == EPI_ROW_STATS and tile in (64, 128) and splitk == 1
+    c32 = Cm if (Cm is not None and Cm.dtype == torch.float32) else None
+    c16 = Cb if Cb is not None else (Cm if (Cm is not None and Cm.dtype == torch.bfloat16) else None)
     if c16 is not None and (c16.dtype != torch.bfloat16 or not bf):
         raise _lib.EamdError("gemm: bf16 outputs need bf16 operands")
     for tt in (R, bias, colsum):
@@ -174,6 +176,13 @@ def gemm(A, B, Cm, M, N, K, lda, ldb, ldc, *, transA=0, transB=0, bias=None, aux
     p.in_dtype = 1 if bf else 0
     p.precision = 1 if bf else (_state["precision"] if precision is None else precision)
     p.tile = tile
+    if stats is not None:
+        part, col, zcol, zfix, fix = stats
+        tn = (N + tile - 1) // tile
+        if part.dtype != torch.float32 or part.numel() < M * tn * 2 or zfix.numel() < M or not (0 <= fix < N) or \
+                (col is not None and (col.dtype != torch.int32 or col.numel() < M or zcol is None or zcol.numel() < M)):
+            raise _lib.EamdError("gemm: row-statistics buffers too small or of the wrong dtype")
+        p.stats.part, p.stats.col, p.stats.zcol, p.stats.zfix, p.stats.fix = ptr(part), ptr(col), ptr(zcol), ptr(zfix), int(fix)
     if gather is not None:
         p.gather = gather
     if cmap is not None:
@@ -198,7 +207,7 @@ def gemm(A, B, Cm, M, N, K, lda, ldb, ldc, *, transA=0, transB=0, bias=None, aux
         _wgroup["items"].append((p, (A, B, Cm, colsum)))
         return
     if _gemm_record is not None:
-        _gemm_record.append((p, (A, B, Cm, bias, aux, R, colsum, Cb, Hb),
+        _gemm_record.append((p, (A, B, Cm, bias, aux, R, colsum, Cb, Hb, stats),
                              lambda sp, p=p: check(_lib.lib().eamd_gemm(C.byref(p), sp), "eamd_gemm")))
     check(_lib.lib().eamd_gemm(C.byref(p), stream_ptr()), "eamd_gemm")
 
@@ -1280,6 +1289,36 @@ def rnnt_node_stats(z_rows, labels, ws, node0, B, T, U, blank):
     assert z_rows.dtype == torch.float32 and z_rows.is_contiguous() and labels.dtype == torch.int32
     check(_lib.lib().eamd_rnnt_node_stats(ptr(z_rows), ptr(labels), ptr(ws), C.c_int64(node0), C.c_int64(nrows), B, T, U, V,
                                           blank, stream_ptr()), "eamd_rnnt_node_stats")
+
+
+RNNT_FUSED_STATS = True     # tests flip this to reach the stored-logits form (linear_fwd + eamd_rnnt_node_stats)
+
+
+def rnnt_node_stats_fused(H2, W, b_out, col, ws, node0, B, T, U, blank):
+    """the node statistics of the lattice rows node0.. straight from the joint activations H2 [nrows, J] (operand dtype) and
+    the output projection W [V, J] / b_out: the logits GEMM runs with the row-statistics epilogue (no logits written) and
+    eamd_rnnt_node_stats_part combines its partials.  col [nrows] int32: each node's next label or -1.
+    Returns False if the library declines (the caller then stores the logits)."""
+    if not RNNT_FUSED_STATS:
+        return False
+    nrows, J = H2.shape
+    V = W.shape[0]
+    tile = 128 if nrows >= 2048 else 64
+    tn = (V + tile - 1) // tile
+    dev = H2.device
+    part = torch.empty(nrows * tn * 2, device=dev, dtype=torch.float32)
+    zcol = torch.empty(nrows, device=dev, dtype=torch.float32)
+    zfix = torch.empty(nrows, device=dev, dtype=torch.float32)
+    try:
+        gemm(H2, W, None, nrows, V, J, J, J, V, bias=b_out, epilogue=EPI_ROW_STATS, tile=tile,
+             stats=(part, col, zcol, zfix, blank))
+    except _lib.EamdError as e:
+        if ("code %d" % _lib.EAMD_EUNSUPPORTED) in str(e):
+            return False
+        raise
+    check(_lib.lib().eamd_rnnt_node_stats_part(ptr(part), ptr(zcol), ptr(zfix), ptr(ws), C.c_int64(node0), C.c_int64(nrows), tn,
+                                               B, T, U, stream_ptr()), "eamd_rnnt_node_stats_part")
+    return True
 
 
 def rnnt_alpha_beta(ws, tlens, ulens, B, T, U):

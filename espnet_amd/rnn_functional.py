@@ -539,10 +539,16 @@ class JointRNNTLossFn(torch.autograd.Function):
         adt = ops.act_dtype()
         nt_max = max(1, int(chunk_rows) // U)
         plan = [(b, t0, min(nt_max, int(tlens_host[b]) - t0)) for b in range(B) for t0 in range(0, int(tlens_host[b]), nt_max)]
+        lab_u = torch.cat([labels.view(B, U - 1), labels.new_full((B, 1), -1)], 1) if U > 1 else labels.new_full((B, 1), -1)
         for b, t0, nt in plan:
             H = ops.joint_fwd(e[b:b + 1, t0:t0 + nt], d[b:b + 1], act, out_dtype=adt)             # (1, nt, U, J)
-            Z = ops.linear_fwd(H.view(nt * U, J), ops.wshadow(w_out), b_out)
-            ops.rnnt_node_stats(Z, labels, ws, (b * T + t0) * U, B, T, U, blank)
+            # the logits GEMM leaves per-tile softmax partials and the two logits a node needs instead of the chunk of
+            # logits (378-756 MB written and read back per chunk at config 5); declined shapes store the logits
+            col = lab_u[b].repeat(nt).contiguous()           # next label of node (t, u), -1 in the last column
+            if not ops.rnnt_node_stats_fused(H.view(nt * U, J), ops.wshadow(w_out), b_out, col, ws, (b * T + t0) * U, B, T, U,
+                                             blank):
+                Z = ops.linear_fwd(H.view(nt * U, J), ops.wshadow(w_out), b_out)
+                ops.rnnt_node_stats(Z, labels, ws, (b * T + t0) * U, B, T, U, blank)
         nll = ops.rnnt_alpha_beta(ws, tlens, ulens, B, T, U)
         ctx.save_for_backward(e, d, labels, tlens, ulens, ws)
         ctx.pr = GradSink.use((w_out, b_out))

@@ -105,6 +105,14 @@ typedef struct {
   float a_drop_p, b_drop_p;
   uint64_t a_drop_salt, b_drop_salt;
   int32_t h_dtype;     /* dtype of the second output Hb: 0 bf16, 1 fp32 (fp32-MFMA kernel: z and h = dropout(act(z)) in fp32) */
+  /* epilogue 7 (row statistics; splitk 1, tile given as 64 or 128, no batch / row map): the result v = A B + bias is NOT
+   * stored (C, Cb may be NULL); every workgroup leaves, for each row m of its tile and its column tile j,
+   *   part[(m * ceil(N / tile) + j) * 2 + {0, 1}] = (max_n v[m,n], sum_n exp(v[m,n] - max)) over the tile's columns,
+   * and the values of two columns per row: zcol[m] = v[m, col[m]] (col may be NULL or col[m] < 0: none) and
+   * zfix[m] = v[m, fix].  A log-softmax over N = thousands of columns then needs the fp32 logits neither written nor
+   * read back: eamd_rnnt_node_stats_part combines the partials (transducer loss: lse, log p(blank), log p(label) per
+   * lattice node; reference: transducer/loss.py:74-76 hands the materialised logits to warp-transducer). */
+  struct { float* part; const int32_t* col; float* zcol; float* zfix; int32_t fix; int32_t reserved; } stats;
 } eamd_gemm_t;
 
 int eamd_gemm(const eamd_gemm_t* p, void* stream);
@@ -536,6 +544,11 @@ int eamd_rnnt_node_stats(const float* logits_rows, const int32_t* labels, float*
                          int B, int T, int U, int V, int blank, void* stream);
 int eamd_rnnt_alpha_beta(float* workspace, const int32_t* tlens, const int32_t* ulens, float* loss, int B, int T, int U,
                          void* stream);
+/* eamd_rnnt_node_stats for logits that were never stored: part / zlab / zblank are what eamd_gemm's row-statistics
+ * epilogue (epilogue 7, eamd_gemm_t.stats with col[m] = the node's next label or -1, fix = blank) left for the nrows nodes
+ * node0 .. node0 + nrows - 1; tiles_n = ceil(V / tile) of that launch. */
+int eamd_rnnt_node_stats_part(const float* part, const float* zlab, const float* zblank, float* workspace, int64_t node0,
+                              int64_t nrows, int tiles_n, int B, int T, int U, void* stream);
 int eamd_rnnt_node_grad(const float* logits_rows, float* grad_rows, void* grad_rows_bf16, const int32_t* labels,
                         const int32_t* tlens, const int32_t* ulens, const float* workspace, int64_t node0, int64_t nrows,
                         int B, int T, int U, int V, int blank, const float* gscale_dev, float scale, void* stream);

@@ -1177,3 +1177,38 @@ def test_add_cast_colsum2(ops, shape):
     assert off == 0 or bool((out[:, :off] == 0).all())
     report("add_colsum2_f32 suma", sa, 1 + a.double().sum(0), 1e-5)
     report("add_colsum2_f32 sumb", sb, -2 + b.double().sum(0), 1e-5)
+
+
+@pytest.mark.parametrize("prec,tile,M,N,K", [("fp32", 64, 150, 333, 64), ("fp32", 128, 300, 5000, 320), ("bf16", 64, 700, 5000, 320),
+                                             ("bf16", 128, 2500, 5000, 320), ("bf16", 64, 4200, 1000, 256)])
+def test_gemm_row_statistics_epilogue(ops, prec, tile, M, N, K):
+    """epilogue 7 (eamd_gemm_t.stats): per-row, per-column-tile (max, sum exp) of v = A W^T + bias and two gathered columns,
+    without v being stored; combined they give the row log-sum-exp.  Against torch on the same operands (float64)."""
+    import espnet_amd
+    espnet_amd.set_precision(prec)
+    try:
+        dt = ops.act_dtype()
+        g = torch.Generator().manual_seed(M + N)
+        a = (torch.randn(M, K, generator=g) * 0.7).to(dt).to(DEV)
+        w = (torch.randn(N, K, generator=g) * 0.3).to(dt).to(DEV)
+        bias = torch.randn(N, generator=g).to(DEV)
+        col = torch.randint(-1, N, (M,), generator=g).to(torch.int32).to(DEV)
+        fix = 0
+        tn = (N + tile - 1) // tile
+        part = torch.full((M * tn * 2,), float("nan"), device=DEV)
+        zcol = torch.full((M,), float("nan"), device=DEV)
+        zfix = torch.full((M,), float("nan"), device=DEV)
+        ops.gemm(a, w, None, M, N, K, K, K, N, bias=bias, epilogue=ops.EPI_ROW_STATS, tile=tile, stats=(part, col, zcol, zfix, fix))
+        v = a.double() @ w.double().t() + bias.double()
+        pm = part.view(M, tn, 2).double()
+        mx = pm[:, :, 0].max(1).values
+        lse = mx + torch.log((pm[:, :, 1] * torch.exp(pm[:, :, 0] - mx[:, None])).sum(1))
+        report("row-stats lse %s tile %d" % (prec, tile), lse, torch.logsumexp(v, 1), 2e-6)
+        report("row-stats fixed column", zfix, v[:, fix], 1e-5)
+        has = col >= 0
+        report("row-stats gathered column", zcol[has], v[has, col[has].long()], 1e-5)
+        # every tile's maximum is the true maximum of its columns
+        vt = torch.nn.functional.pad(v, (0, tn * tile - N), value=float("-inf")).view(M, tn, tile).max(2).values
+        report("row-stats tile maxima", pm[:, :, 0], vt, 1e-5)
+    finally:
+        espnet_amd.set_precision("fp32")

@@ -392,6 +392,37 @@ def test_transducer_fused_joint_loss_golden(name, chunk_rows):
         JointNetwork.loss = orig
 
 
+@pytest.mark.parametrize("prec", ["bf16", "fp32"])
+def test_rnnt_loss_statistics_from_gemm_epilogue_match_stored_logits(prec):
+    """JointRNNTLossFn with the node statistics taken from the logits GEMM's row-statistics epilogue (no logits written in
+    the forward) against the same function storing the logits chunk: loss and every gradient"""
+    import espnet_amd
+    from espnet_amd import ops
+    from espnet_amd import rnn_functional as R_
+    espnet_amd.set_precision(prec)
+    try:
+        g = torch.Generator().manual_seed(3)
+        B, T, U, J, V = 3, 40, 9, 64, 777
+        e0, d0 = torch.randn(B, T, J, generator=g).to(DEV), torch.randn(B, U, J, generator=g).to(DEV)
+        w0, b0 = (torch.randn(V, J, generator=g) * 0.2).to(DEV), torch.randn(V, generator=g).to(DEV)
+        labels = torch.randint(1, V, (B, U - 1), generator=g).to(torch.int32).to(DEV)
+        tl, ul = [40, 33, 17], [8, 5, 8]
+        tlens, ulens = torch.tensor(tl, dtype=torch.int32, device=DEV), torch.tensor(ul, dtype=torch.int32, device=DEV)
+        res = {}
+        for fused in (True, False):
+            ops.RNNT_FUSED_STATS = fused
+            e, d, w, b = (t.clone().requires_grad_(True) for t in (e0, d0, w0, b0))
+            loss = R_.JointRNNTLossFn.apply(e, d, w, b, labels, tlens, ulens, 0, ops.ACT_TANH, tl, 150)
+            loss.backward()
+            res[fused] = (loss.detach().clone(), e.grad.clone(), d.grad.clone(), w.grad.clone(), b.grad.clone())
+        tol = 2e-5 if prec == "fp32" else 2e-3
+        for name, a_, b_ in zip(("loss", "d e", "d d", "d w_out", "d b_out"), res[True], res[False]):
+            report("rnnt fused statistics %s %s" % (prec, name), a_, b_, tol)
+    finally:
+        ops.RNNT_FUSED_STATS = True
+        espnet_amd.set_precision("fp32")
+
+
 @pytest.mark.parametrize("prec", ["fp32", "bf16"])
 def test_fused_joint_loss_config5_shape_vs_materialised(prec):
     """the width of BASELINE config 5 (J = 320, V = 5000, U = 101) on a short ragged batch: JointRNNTLossFn against the
