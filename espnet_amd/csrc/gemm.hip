@@ -381,10 +381,13 @@ extern "C" int eamd_gemm(const eamd_gemm_t* pp, void* stream_) {
   eamd_gemm_t p = *pp;
   hipStream_t stream = (hipStream_t)stream_;
   const bool stats = p.epilogue == 7;          // row statistics instead of a result (eamd_gemm_t.stats)
+  const bool rowgrad = p.epilogue == 8;        // softmax-gradient rows from per-row coefficients
   if (!p.A || !p.B || (!p.C && !p.Cb && !stats)) return EAMD_EINVAL;
-  if (stats && (!p.stats.part || !p.stats.zfix || (p.stats.col && !p.stats.zcol) || p.stats.fix < 0 || p.stats.fix >= p.N ||
-                (p.tile != 64 && p.tile != 128) || p.splitk > 1 || p.batch1 * p.batch2 != 1 || p.cmap.enabled ||
-                p.gather.enabled || p.Hb || p.drop_p != 0.f || p.R || p.colsum))
+  if (stats && (!p.stats.part || !p.stats.zfix || (p.stats.col && !p.stats.zcol))) return EAMD_EINVAL;
+  if (rowgrad && !p.stats.rowc) return EAMD_EINVAL;
+  if ((stats || rowgrad) && (p.stats.fix < 0 || p.stats.fix >= p.N || (p.tile != 64 && p.tile != 128) || p.splitk > 1 ||
+                             p.batch1 * p.batch2 != 1 || p.cmap.enabled || p.gather.enabled || p.Hb || p.drop_p != 0.f ||
+                             p.R || p.colsum || p.beta != 0.f))
     return EAMD_EINVAL;
   if (p.in_dtype != 0 && p.in_dtype != 1) return EAMD_EINVAL;
   if (p.in_dtype == 1 && p.precision != 1) return EAMD_EINVAL;
@@ -393,7 +396,7 @@ extern "C" int eamd_gemm(const eamd_gemm_t* pp, void* stream_) {
   if (p.batch1 <= 0 || p.batch2 <= 0) return EAMD_EINVAL;
   if (p.splitk < 1) p.splitk = 1;
   if (p.splitk > 1 && p.epilogue != 0) return EAMD_EINVAL;
-  if (p.epilogue < 0 || p.epilogue > 7) return EAMD_EINVAL;
+  if (p.epilogue < 0 || p.epilogue > 8) return EAMD_EINVAL;
   if (p.epilogue >= 3 && p.epilogue <= 5 && !p.aux) return EAMD_EINVAL;
   if (p.epilogue == 6 && (!p.Hb || p.drop_p <= 0.f)) return EAMD_EINVAL;      // only with the dual-output dropout epilogue
   if (p.precision != 0 && p.precision != 1) return EAMD_EINVAL;
@@ -456,7 +459,7 @@ extern "C" int eamd_gemm(const eamd_gemm_t* pp, void* stream_) {
     if (rc != EAMD_EUNSUPPORTED) return rc;
     if (p.drop_p != 0.f || p.a_drop_p != 0.f || p.b_drop_p != 0.f || p.Hb) return EAMD_EUNSUPPORTED;   // generic kernel: no dropout
   }
-  if (stats) return EAMD_EUNSUPPORTED;       // the generic kernel has no row-statistics epilogue
+  if (stats || rowgrad) return EAMD_EUNSUPPORTED;       // the generic kernel has neither row epilogue
   if (tile == 128) {
     return p.precision ? launch<128, 128, 1>(p, stream) : launch<128, 128, 0>(p, stream);
   }

@@ -201,6 +201,44 @@ __device__ __forceinline__ void store_c_tile(const eamd_gemm_t& p, f32x4 (&acc)[
     }
     return;
   }
+  if (p.epilogue == 8) {
+    // softmax-gradient rows (see eamd_gemm_t.stats): the recomputed logits leave as their gradient
+    const float sc = p.stats.scale * (p.stats.gscale ? p.stats.gscale[0] : 1.f);
+    for (int rr = t / V4_PER_ROW; rr < BM; rr += ROWS_PER_PASS) {
+      const int m = m0 + rr;
+      if (m >= p.M || n >= p.N) continue;
+      const float4 a4 = *reinterpret_cast<const float4*>(&cl[rr * LDC + c4 * 4]);
+      const float* rc = p.stats.rowc + (long)m * 3;
+      const float tot = rc[0], gb = rc[1], gl = rc[2];
+      const int lc = p.stats.col ? p.stats.col[m] : -1;
+      float gq[4] = {a4.x + bv[0], a4.y + bv[1], a4.z + bv[2], a4.w + bv[3]};
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        float gv = tot > -INFINITY ? expf(gq[e] + tot) : 0.f;
+        if (n + e == p.stats.fix) gv -= gb;
+        if (n + e == lc) gv -= gl;
+        gq[e] = tot > -INFINITY ? sc * gv : 0.f;
+      }
+      const long ci = coff + (long)m * p.ldc + n;
+      if (cvec && n + 3 < p.N) {
+        if (p.C) *reinterpret_cast<float4*>(p.C + ci) = make_float4(gq[0], gq[1], gq[2], gq[3]);
+        if (Cb) {
+          uint2 o;
+          o.x = eamd_f2bf(gq[0]) | ((unsigned)eamd_f2bf(gq[1]) << 16);
+          o.y = eamd_f2bf(gq[2]) | ((unsigned)eamd_f2bf(gq[3]) << 16);
+          *reinterpret_cast<uint2*>(Cb + ci) = o;
+        }
+      } else {
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+          if (n + e < p.N) {
+            if (p.C) p.C[ci + e] = gq[e];
+            if (Cb) Cb[ci + e] = eamd_f2bf(gq[e]);
+          }
+      }
+    }
+    return;
+  }
   // per-pass arithmetic + stores on values already in registers
   auto emit = [&](long ci, int nn, bool full, float (&v)[4], const float (&ax)[4], const float (&rv)[4],
                   const float (&cold)[4]) __attribute__((always_inline)) {

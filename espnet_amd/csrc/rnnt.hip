@@ -163,6 +163,34 @@ __global__ __launch_bounds__(256) void rnnt_stats_combine_kernel(const float* __
   lpb[row] = zblank[r] - l;
   lpl[row] = (u < U - 1) ? zlab[r] - l : -INFINITY;
 }
+// the per-node part of rnnt_grad_kernel: (tot, gb, gl) and the node's next label, for the gradient epilogue of the GEMM
+__global__ __launch_bounds__(256) void rnnt_row_coef_kernel(const int* __restrict__ labels, const float* __restrict__ lse,
+                                                            const float* __restrict__ lpb, const float* __restrict__ lpl,
+                                                            const float* __restrict__ alpha, const float* __restrict__ beta,
+                                                            const int* __restrict__ tlens, const int* __restrict__ ulens,
+                                                            float* __restrict__ rowc, int* __restrict__ col, int T, int U,
+                                                            long node0, long nrows) {
+  const long r = (long)blockIdx.x * 256 + threadIdx.x;
+  if (r >= nrows) return;
+  const long row = node0 + r;
+  const int u = (int)(row % U);
+  const int t = (int)((row / U) % T);
+  const long b = row / ((long)T * U);
+  const int Tb = tlens[b], Ub = ulens[b] + 1;
+  const float logZ = beta[b * (long)T * U];
+  const float a = alpha[row];
+  const bool valid = t < Tb && u < Ub && a > -INFINITY && beta[row] > -INFINITY && isfinite(logZ);
+  float tot = -INFINITY, gb = 0.f, gl = 0.f;
+  int lab = -1;
+  if (valid) {
+    tot = a + beta[row] - logZ - lse[row];
+    if (t < Tb - 1) gb = expf(a + lpb[row] + beta[row + U] - logZ);
+    else gb = (u == Ub - 1) ? expf(a + lpb[row] - logZ) : 0.f;
+    if (u < Ub - 1) { lab = labels[b * (U - 1) + u]; gl = expf(a + lpl[row] + beta[row + 1] - logZ); }
+  }
+  rowc[r * 3] = tot; rowc[r * 3 + 1] = gb; rowc[r * 3 + 2] = gl;
+  col[r] = lab;
+}
 static void launch_lse_gather(const float* z, const int* labels, float* lse, float* lpb, float* lpl, int T, int U, int V,
                               int blank, long node0, long nrows, hipStream_t s) {
   if (V % 4 == 0 && V <= RNNT_LSE_MAXP * 256 && (reinterpret_cast<uintptr_t>(z) & 15) == 0)
@@ -416,6 +444,19 @@ int eamd_rnnt_node_stats_part(const float* part, const float* zlab, const float*
   float* lse = workspace;
   hipLaunchKernelGGL(rnnt_stats_combine_kernel, dim3((unsigned)((nrows + 255) / 256)), dim3(256), 0, (hipStream_t)stream, part,
                      zlab, zblank, lse, lse + n, lse + 2 * n, tiles_n, U, (long)node0, (long)nrows);
+  EAMD_LAUNCH_CHECK();
+  return EAMD_OK;
+}
+
+int eamd_rnnt_row_coef(const int32_t* labels, const int32_t* tlens, const int32_t* ulens, const float* workspace, float* rowc,
+                       int32_t* col, int64_t node0, int64_t nrows, int B, int T, int U, void* stream) {
+  if (!labels || !tlens || !ulens || !workspace || !rowc || !col || B <= 0 || T <= 0 || U <= 0 || node0 < 0 || nrows <= 0)
+    return EAMD_EINVAL;
+  const long n = (long)B * T * U;
+  if (node0 + nrows > n) return EAMD_EINVAL;
+  const float* lse = workspace;
+  hipLaunchKernelGGL(rnnt_row_coef_kernel, dim3((unsigned)((nrows + 255) / 256)), dim3(256), 0, (hipStream_t)stream, labels, lse,
+                     lse + n, lse + 2 * n, lse + 3 * n, lse + 4 * n, tlens, ulens, rowc, col, T, U, (long)node0, (long)nrows);
   EAMD_LAUNCH_CHECK();
   return EAMD_OK;
 }

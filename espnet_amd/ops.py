@@ -13,7 +13,7 @@ from . import _lib
 from ._lib import GatherT, GemmT, RowMapT, check, ptr, stream_ptr
 
 ACT_NONE, ACT_RELU, ACT_SWISH = 0, 1, 2
-EPI_NONE, EPI_RELU, EPI_SWISH, EPI_MUL_RELU_MASK, EPI_MUL_DSWISH, EPI_MUL_AUX, EPI_DACT_FACTOR, EPI_ROW_STATS = 0, 1, 2, 3, 4, 5, 6, 7
+EPI_NONE, EPI_RELU, EPI_SWISH, EPI_MUL_RELU_MASK, EPI_MUL_DSWISH, EPI_MUL_AUX, EPI_DACT_FACTOR, EPI_ROW_STATS, EPI_ROW_GRAD = 0, 1, 2, 3, 4, 5, 6, 7, 8
 
 _PRECISIONS = {"fp32": 0, "bf16": 1}
 _state = {"precision": 0}
@@ -123,8 +123,9 @@ def gemm(A, B, Cm, M, N, K, lda, ldb, ldc, *, transA=0, transB=0, bias=None, aux
     bf = A.dtype == torch.bfloat16
     if A.dtype != B.dtype or A.dtype not in (torch.float32, torch.bfloat16) or not (A.is_cuda and B.is_cuda):
         raise _lib.EamdError("gemm needs float32 or bfloat16 GPU operands of one dtype")
-    if stats is not None:      # row statistics instead of a result (EPI_ROW_STATS): (part, col, zcol, zfix, fix), Cm = None
-        assert Cm is None and Cb is None and epilogue == EPI_ROW_STATS and tile in (64, 128) and splitk == 1
+    if stats is not None:      # EPI_ROW_STATS: (part, col, zcol, zfix, fix), Cm = None;  EPI_ROW_GRAD: (rowc, col, fix, gscale, scale)
+        assert epilogue in (EPI_ROW_STATS, EPI_ROW_GRAD) and tile in (64, 128) and splitk == 1
+        assert (Cm is None and Cb is None) if epilogue == EPI_ROW_STATS else Cm is not None
     c32 = Cm if (Cm is not None and Cm.dtype == torch.float32) else None
     c16 = Cb if Cb is not None else (Cm if (Cm is not None and Cm.dtype == torch.bfloat16) else None)
     if c16 is not None and (c16.dtype != torch.bfloat16 or not bf):
@@ -176,7 +177,12 @@ def gemm(A, B, Cm, M, N, K, lda, ldb, ldc, *, transA=0, transB=0, bias=None, aux
     p.in_dtype = 1 if bf else 0
     p.precision = 1 if bf else (_state["precision"] if precision is None else precision)
     p.tile = tile
-    if stats is not None:
+    if stats is not None and epilogue == EPI_ROW_GRAD:
+        rowc, col, fix, gscale, scale = stats
+        if rowc.dtype != torch.float32 or rowc.numel() < 3 * M or col.dtype != torch.int32 or col.numel() < M or not (0 <= fix < N):
+            raise _lib.EamdError("gemm: row-gradient coefficients too small or of the wrong dtype")
+        p.stats.rowc, p.stats.col, p.stats.fix, p.stats.gscale, p.stats.scale = ptr(rowc), ptr(col), int(fix), ptr(gscale), float(scale)
+    elif stats is not None:
         part, col, zcol, zfix, fix = stats
         tn = (N + tile - 1) // tile
         if part.dtype != torch.float32 or part.numel() < M * tn * 2 or zfix.numel() < M or not (0 <= fix < N) or \
@@ -1319,6 +1325,30 @@ def rnnt_node_stats_fused(H2, W, b_out, col, ws, node0, B, T, U, blank):
     check(_lib.lib().eamd_rnnt_node_stats_part(ptr(part), ptr(zcol), ptr(zfix), ptr(ws), C.c_int64(node0), C.c_int64(nrows), tn,
                                                B, T, U, stream_ptr()), "eamd_rnnt_node_stats_part")
     return True
+
+
+def rnnt_node_grad_fused(H2, W, b_out, labels, tlens, ulens, ws, node0, B, T, U, blank, gscale, scale, out_dtype):
+    """d loss / d logits of the lattice rows node0.. -> [nrows, V] in out_dtype, written by the recomputing logits GEMM itself
+    (epilogue 8 with eamd_rnnt_row_coef's per-node coefficients): no fp32 logits chunk, no separate gradient pass.
+    Returns None if the library declines."""
+    if not RNNT_FUSED_STATS:
+        return None
+    nrows, J = H2.shape
+    V = W.shape[0]
+    dev = H2.device
+    rowc = torch.empty(nrows * 3, device=dev, dtype=torch.float32)
+    col = torch.empty(nrows, device=dev, dtype=torch.int32)
+    check(_lib.lib().eamd_rnnt_row_coef(ptr(labels), ptr(tlens), ptr(ulens), ptr(ws), ptr(rowc), ptr(col), C.c_int64(node0),
+                                        C.c_int64(nrows), B, T, U, stream_ptr()), "eamd_rnnt_row_coef")
+    dZ = torch.empty(nrows, V, device=dev, dtype=out_dtype)
+    try:
+        gemm(H2, W, dZ, nrows, V, J, J, J, V, bias=b_out, epilogue=EPI_ROW_GRAD, tile=128 if nrows >= 2048 else 64,
+             stats=(rowc, col, blank, gscale, scale))
+    except _lib.EamdError as e:
+        if ("code %d" % _lib.EAMD_EUNSUPPORTED) in str(e):
+            return None
+        raise
+    return dZ
 
 
 def rnnt_alpha_beta(ws, tlens, ulens, B, T, U):

@@ -572,8 +572,12 @@ class JointRNNTLossFn(torch.autograd.Function):
             eb, db_ = e[b:b + 1, t0:t0 + nt], d[b:b + 1]
             H = ops.joint_fwd(eb, db_, act, out_dtype=adt)
             H2 = H.view(nt * U, J)
-            Z = ops.linear_fwd(H2, ops.wshadow(w_out), b_out)
-            dZ = ops.rnnt_node_grad(Z, labels, tlens, ulens, ws, (b * T + t0) * U, B, T, U, blank, gs, 1.0 / B, out_dtype=adt)
+            # the recomputed logits leave the GEMM as their gradient (epilogue 8); declined shapes: logits, then a gradient pass
+            dZ = ops.rnnt_node_grad_fused(H2, ops.wshadow(w_out), b_out, labels, tlens, ulens, ws, (b * T + t0) * U, B, T, U,
+                                          blank, gs, 1.0 / B, adt)
+            if dZ is None:
+                Z = ops.linear_fwd(H2, ops.wshadow(w_out), b_out)
+                dZ = ops.rnnt_node_grad(Z, labels, tlens, ulens, ws, (b * T + t0) * U, B, T, U, blank, gs, 1.0 / B, out_dtype=adt)
             ops.linear_bwd_w(dZ, H2, sink.buf(0), db=sink.buf(1))
             dH = ops.linear_bwd_x(dZ, ops.wshadow(w_out))
             de_c, dd_c = ops.joint_bwd(dH.view(1, nt, U, J), eb.contiguous(), db_, act)

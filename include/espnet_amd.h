@@ -111,8 +111,16 @@ typedef struct {
    * and the values of two columns per row: zcol[m] = v[m, col[m]] (col may be NULL or col[m] < 0: none) and
    * zfix[m] = v[m, fix].  A log-softmax over N = thousands of columns then needs the fp32 logits neither written nor
    * read back: eamd_rnnt_node_stats_part combines the partials (transducer loss: lse, log p(blank), log p(label) per
-   * lattice node; reference: transducer/loss.py:74-76 hands the materialised logits to warp-transducer). */
-  struct { float* part; const int32_t* col; float* zcol; float* zfix; int32_t fix; int32_t reserved; } stats;
+   * lattice node; reference: transducer/loss.py:74-76 hands the materialised logits to warp-transducer).
+   * epilogue 8 (softmax-gradient rows; same restrictions, C and / or Cb required): with the per-row coefficients
+   * rowc[m] = (tot, gb, gl) the stored result is
+   *   sc * (exp(v[m,n] + tot) - [n == fix] * gb - [n == col[m]] * gl),   sc = scale * (gscale ? gscale[0] : 1),
+   * and 0 for rows with tot = -inf: d(-log P) / d logits of a transducer lattice node (tot = log occupancy - lse, gb / gl the
+   * blank / label transition posteriors; eamd_rnnt_row_coef fills rowc) written straight from the recomputed logits. */
+  struct {
+    float* part; const int32_t* col; float* zcol; float* zfix; int32_t fix; int32_t reserved;
+    const float* rowc; const float* gscale; float scale; int32_t reserved2;
+  } stats;
 } eamd_gemm_t;
 
 int eamd_gemm(const eamd_gemm_t* p, void* stream);
@@ -549,6 +557,11 @@ int eamd_rnnt_alpha_beta(float* workspace, const int32_t* tlens, const int32_t* 
  * node0 .. node0 + nrows - 1; tiles_n = ceil(V / tile) of that launch. */
 int eamd_rnnt_node_stats_part(const float* part, const float* zlab, const float* zblank, float* workspace, int64_t node0,
                               int64_t nrows, int tiles_n, int B, int T, int U, void* stream);
+/* per-node coefficients (tot, gb, gl) of the lattice rows node0 .. node0 + nrows - 1 for eamd_gemm's epilogue 8, from the
+ * workspace eamd_rnnt_alpha_beta completed: rowc [nrows][3] (tot = -inf marks a node outside the lattice or unreachable) and
+ * col [nrows] = the node's next label or -1. */
+int eamd_rnnt_row_coef(const int32_t* labels, const int32_t* tlens, const int32_t* ulens, const float* workspace, float* rowc,
+                       int32_t* col, int64_t node0, int64_t nrows, int B, int T, int U, void* stream);
 int eamd_rnnt_node_grad(const float* logits_rows, float* grad_rows, void* grad_rows_bf16, const int32_t* labels,
                         const int32_t* tlens, const int32_t* ulens, const float* workspace, int64_t node0, int64_t nrows,
                         int B, int T, int U, int V, int blank, const float* gscale_dev, float scale, void* stream);
