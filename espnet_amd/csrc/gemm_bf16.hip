@@ -26,7 +26,7 @@ namespace {
 // steady-state loop carries no transcendental code and no branches around it.
 // One workgroup's share of a problem: `bid` of `nblk` workgroups (tile x split-K slice), batch index `zb`.
 // gemm_bf16_kernel runs it on a launch of its own; gemm_bf16_group_kernel looks the problem up in a device table.
-template <int BM, int BN, bool TA, bool TB, bool FAST, bool GAT, bool ACT>
+template <int BM, int BN, bool TA, bool TB, bool FAST, bool GAT, bool ACT, bool ROWEPI = false>
 __device__ __forceinline__ void gemm_bf16_body(const eamd_gemm_t& p, const int bid, const int nblk, const int zb) {
   constexpr int WM = BM / 2, WN = BN / 2;
   constexpr int MT = WM / 16, NTL = WN / 16;
@@ -459,12 +459,12 @@ __device__ __forceinline__ void gemm_bf16_body(const eamd_gemm_t& p, const int b
   }
 
   static_assert(sizeof(float) * BM * (BN + 4) <= sizeof(S), "C tile must fit in the operand buffers");
-  store_c_tile<BM, BN, true>(p, acc, reinterpret_cast<float*>(smem_raw), m0, n0, coff);   // operand buffers are free now
+  store_c_tile<BM, BN, true, ROWEPI>(p, acc, reinterpret_cast<float*>(smem_raw), m0, n0, coff);   // operand buffers are free now
 }
 
-template <int BM, int BN, bool TA, bool TB, bool FAST, bool GAT, bool ACT>
+template <int BM, int BN, bool TA, bool TB, bool FAST, bool GAT, bool ACT, bool ROWEPI = false>
 __global__ __launch_bounds__(NT_, 2) void gemm_bf16_kernel(const eamd_gemm_t p) {
-  gemm_bf16_body<BM, BN, TA, TB, FAST, GAT, ACT>(p, blockIdx.x, gridDim.x, blockIdx.z);
+  gemm_bf16_body<BM, BN, TA, TB, FAST, GAT, ACT, ROWEPI>(p, blockIdx.x, gridDim.x, blockIdx.z);
 }
 
 // Grouped launch: workgroups first[i] .. first[i + 1] - 1 work on problem i of a device-resident descriptor table
@@ -485,6 +485,21 @@ template <int BM, int BN, bool TA, bool TB, bool FAST, bool GAT, bool ACT>
 int launch_b2(const eamd_gemm_t& p, hipStream_t stream) {
   dim3 grid(((p.M + BM - 1) / BM) * ((p.N + BN - 1) / BN) * p.splitk, 1, p.batch1 * p.batch2);
   size_t smem = sizeof(SmemB<BM, BN, TA, TB>);
+  if (p.epilogue >= 7) {      // row epilogues (eamd_gemm_t.stats): instantiated for plain x W^T products only
+    if constexpr (!TA && !TB && FAST && !GAT && !ACT) {
+      if (smem > 64 * 1024) {
+        static const hipError_t attr_err_r = hipFuncSetAttribute(
+            reinterpret_cast<const void*>(&gemm_bf16_kernel<BM, BN, TA, TB, FAST, GAT, ACT, true>),
+            hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(SmemB<BM, BN, TA, TB>));
+        if (attr_err_r != hipSuccess) return (int)attr_err_r;
+      }
+      hipLaunchKernelGGL((gemm_bf16_kernel<BM, BN, TA, TB, FAST, GAT, ACT, true>), grid, dim3(NT_), smem, stream, p);
+      EAMD_LAUNCH_CHECK();
+      return EAMD_OK;
+    } else {
+      return EAMD_EUNSUPPORTED;
+    }
+  }
   if (smem > 64 * 1024) {
     static const hipError_t attr_err = hipFuncSetAttribute(
         reinterpret_cast<const void*>(&gemm_bf16_kernel<BM, BN, TA, TB, FAST, GAT, ACT>),
@@ -549,7 +564,7 @@ int eamd_gemm_bf16_dispatch(const eamd_gemm_t& p, int tile, hipStream_t stream) 
     const long ntiles = (long)((p.M + 63) / 64) * ((p.N + 63) / 64);
     if (persist_min > 0 && ntiles >= persist_min && ntiles < (1L << 30) && p.K % 256 == 0 && p.splitk == 1 &&
         p.batch1 * p.batch2 == 1 && !p.colsum && p.a_act == EAMD_ACT_NONE && p.b_act == EAMD_ACT_NONE && !p.cmap.enabled &&
-        !p.transB && !p.aux) {   // measured: the k-strided-B (NN) launches do not gain, aux epilogues want the prefetch
+        !p.transB && !p.aux && p.epilogue < 7) {   // measured: the k-strided-B (NN) launches do not gain, aux epilogues want the prefetch
       return eamd_gemm_bf16_persist(p, (int)ntiles, stream);
     }
   }

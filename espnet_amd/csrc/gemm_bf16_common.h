@@ -134,7 +134,7 @@ __device__ __forceinline__ float rowgroup_sum(float v) {
 // PREFETCH: request the aux / residual operands of four row passes together before consuming them (costs up to
 // 32 VGPRs while the epilogue runs: free in the general kernel whose ring registers are dead by then, not in the
 // persistent kernel whose ring keeps running).
-template <int BM, int BN, bool PREFETCH>
+template <int BM, int BN, bool PREFETCH, bool ROWEPI = false>
 __device__ __forceinline__ void store_c_tile(const eamd_gemm_t& p, f32x4 (&acc)[BM / 32][BN / 32], float* cl, int m0,
                                              int n0, long coff) {
   constexpr int WM = BM / 2, WN = BN / 2;
@@ -172,7 +172,9 @@ __device__ __forceinline__ void store_c_tile(const eamd_gemm_t& p, f32x4 (&acc)[
 #pragma unroll
     for (int e = 0; e < 4; ++e) if (n + e < p.N) bv[e] = p.bias[n + e];
   }
-  if (p.epilogue == 7) {
+  // (ROWEPI: the two row epilogues are compiled into their own kernel instantiations only - inlined everywhere they cost
+  // the ordinary epilogues 1 % of the config-2 step)
+  if (ROWEPI && p.epilogue == 7) {
     // row statistics instead of the result (see eamd_gemm_t.stats): the V4_PER_ROW lanes of a row reduce their four
     // columns each to the tile's (max, sum exp) for that row; the two gathered columns leave from whichever lane holds them
     static_assert(V4_PER_ROW == 16 || V4_PER_ROW == 32, "a staged row is one or two DPP rows of lanes");
@@ -201,7 +203,7 @@ __device__ __forceinline__ void store_c_tile(const eamd_gemm_t& p, f32x4 (&acc)[
     }
     return;
   }
-  if (p.epilogue == 8) {
+  if (ROWEPI && p.epilogue == 8) {
     // softmax-gradient rows (see eamd_gemm_t.stats): the recomputed logits leave as their gradient
     const float sc = p.stats.scale * (p.stats.gscale ? p.stats.gscale[0] : 1.f);
     for (int rr = t / V4_PER_ROW; rr < BM; rr += ROWS_PER_PASS) {

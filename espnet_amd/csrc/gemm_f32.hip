@@ -54,7 +54,7 @@ __device__ __forceinline__ float4 mask4(float4 v, int nv) {
 
 // One workgroup's share of a problem: `bid` of `nblk` workgroups (tile x split-K slice), batch index `zb`.
 // gemm_f32_kernel runs it on a launch of its own; gemm_f32_group_kernel looks the problem up in a device table.
-template <int BM, int BN, bool TA, bool TB, bool GAT, bool ACT>
+template <int BM, int BN, bool TA, bool TB, bool GAT, bool ACT, bool ROWEPI = false>
 __device__ __forceinline__ void gemm_f32_body(const eamd_gemm_t& p, const int bid, const int nblk, const int zb) {
   constexpr int WM = BM / 2, WN = BN / 2;
   constexpr int MT = WM / 16, NTL = WN / 16;
@@ -495,12 +495,12 @@ __device__ __forceinline__ void gemm_f32_body(const eamd_gemm_t& p, const int bi
     }
     return;
   }
-  store_c_tile<BM, BN, true>(p, acc, sm.ab, m0, n0, coff);      // operand buffers are free now (last phase ended in a barrier)
+  store_c_tile<BM, BN, true, ROWEPI>(p, acc, sm.ab, m0, n0, coff);      // operand buffers are free now (last phase ended in a barrier)
 }
 
-template <int BM, int BN, bool TA, bool TB, bool GAT, bool ACT>
+template <int BM, int BN, bool TA, bool TB, bool GAT, bool ACT, bool ROWEPI = false>
 __global__ __launch_bounds__(NT_, 2) void gemm_f32_kernel(const eamd_gemm_t p) {
-  gemm_f32_body<BM, BN, TA, TB, GAT, ACT>(p, blockIdx.x, gridDim.x, blockIdx.z);
+  gemm_f32_body<BM, BN, TA, TB, GAT, ACT, ROWEPI>(p, blockIdx.x, gridDim.x, blockIdx.z);
 }
 
 // Grouped launch: workgroups first[i] .. first[i + 1] - 1 work on problem i of a device-resident descriptor table
@@ -521,6 +521,21 @@ template <int BM, int BN, bool TA, bool TB, bool GAT, bool ACT>
 int launch_f2(const eamd_gemm_t& p, hipStream_t stream) {
   dim3 grid(((p.M + BM - 1) / BM) * ((p.N + BN - 1) / BN) * p.splitk, 1, p.batch1 * p.batch2);
   constexpr size_t smem = sizeof(SmemF<BM, BN, TA, TB>);
+  if (p.epilogue >= 7) {      // row epilogues (eamd_gemm_t.stats): instantiated for plain x W^T products only
+    if constexpr (!TA && !TB && !GAT && !ACT) {
+      if (smem > 64 * 1024) {
+        static const hipError_t attr_err_r = hipFuncSetAttribute(
+            reinterpret_cast<const void*>(&gemm_f32_kernel<BM, BN, TA, TB, GAT, ACT, true>),
+            hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+        if (attr_err_r != hipSuccess) return (int)attr_err_r;
+      }
+      hipLaunchKernelGGL((gemm_f32_kernel<BM, BN, TA, TB, GAT, ACT, true>), grid, dim3(NT_), smem, stream, p);
+      EAMD_LAUNCH_CHECK();
+      return EAMD_OK;
+    } else {
+      return EAMD_EUNSUPPORTED;
+    }
+  }
   if (smem > 64 * 1024) {
     static const hipError_t attr_err = hipFuncSetAttribute(
         reinterpret_cast<const void*>(&gemm_f32_kernel<BM, BN, TA, TB, GAT, ACT>),
