@@ -263,6 +263,7 @@ def _in_grad_arena(t):
 
 def wgrad_group_begin():
     _wgroup["on"] = GROUP_WGRAD
+    _wgroup["items"], _wgroup["stack"] = [], {}      # nothing queued by a backward pass that ended in an exception survives
 
 
 def _wgroup_accepts(p):
