@@ -210,7 +210,20 @@ def gemm(A, B, Cm, M, N, K, lda, ldb, ldc, *, transA=0, transB=0, bias=None, aux
             setattr(p, which + "_drop_salt", int(d[1]))
             p.drop_step = ptr(rng_state(A.device))
     if group and _wgroup["on"] and _in_grad_arena(Cm) and _wgroup_accepts(p):
+        # Two queued problems that accumulate into the same dW may share one launch only if BOTH add with atomics:
+        # splitk == 1 with beta == 1 is a plain read-modify-write of the tile, and workgroups of one launch are not
+        # ordered (a weight used twice per backward pass with 65..511 reduction rows: per-step decoder cells, shared
+        # parameters).  The earlier problems leave first (stream order keeps the sums exact); so does the queue when
+        # the operands it keeps alive exceed GROUP_WGRAD_MAX_BYTES (streamed losses queue one weight gradient per chunk).
+        lo = Cm.data_ptr() + 4 * c_off
+        hi = lo + 4 * _span(M, ldc, N)
+        nbytes = A.numel() * A.element_size() + B.numel() * B.element_size()
+        clash = any(lo < qhi and qlo < hi and (splitk == 1 or qsk == 1) for qlo, qhi, qsk in _wgroup["ranges"])
+        if clash or _wgroup["bytes"] + nbytes > GROUP_WGRAD_MAX_BYTES:
+            wgrad_group_flush()
         _wgroup["items"].append((p, (A, B, Cm, colsum)))
+        _wgroup["ranges"].append((lo, hi, splitk))
+        _wgroup["bytes"] += nbytes
         return
     if _gemm_record is not None:
         _gemm_record.append((p, (A, B, Cm, bias, aux, R, colsum, Cb, Hb, stats),
@@ -235,7 +248,10 @@ GROUP_WGRAD_SK_DIV = int(os.environ.get("EAMD_GROUP_SK_DIV", "2"))
 # GROUP_WGRAD_T128_WGS workgroups (tiles x K-splits) each
 GROUP_WGRAD_TILE128_MIN = int(os.environ.get("EAMD_GROUP_T128_MIN", "100"))
 GROUP_WGRAD_T128_WGS = int(os.environ.get("EAMD_GROUP_T128_WGS", "96"))
-_wgroup = {"on": False, "items": [], "stack": {}, "pinned": [], "reserve": [], "arenas": {}}
+# operand bytes the queue may keep alive before it is flushed early (the operands of every queued problem stay
+# allocated until the grouped launch has been issued)
+GROUP_WGRAD_MAX_BYTES = int(os.environ.get("EAMD_GROUP_MAX_BYTES", str(4 << 30)))
+_wgroup = {"on": False, "items": [], "ranges": [], "bytes": 0, "stack": {}, "pinned": [], "reserve": [], "arenas": {}}
 
 
 def register_grad_arena(t):
@@ -264,6 +280,7 @@ def _in_grad_arena(t):
 def wgrad_group_begin():
     _wgroup["on"] = GROUP_WGRAD
     _wgroup["items"], _wgroup["stack"] = [], {}      # nothing queued by a backward pass that ended in an exception survives
+    _wgroup["ranges"], _wgroup["bytes"] = [], 0
 
 
 def _wgroup_accepts(p):
@@ -307,7 +324,7 @@ def wgrad_group_flush():
     items = _wgroup["items"]
     if not items:
         return
-    _wgroup["items"] = []
+    _wgroup["items"], _wgroup["ranges"], _wgroup["bytes"] = [], [], 0
     for tile in (64, 128):
         part = [it for it in items if (128 if it[0].tile == 128 else 64) == tile]
         if part:
@@ -453,10 +470,12 @@ def wgrad_join():
         _wgrad["used"] = False
 
 
-def linear_bwd_w(dy, x, dW, *, alpha=1.0, b_act=ACT_NONE, db=None, a_drop=None, b_drop=None):
+def linear_bwd_w(dy, x, dW, *, alpha=1.0, b_act=ACT_NONE, db=None, a_drop=None, b_drop=None, group=True):
+    """group=False: never queued for the grouped launch (per-chunk gradients of a streamed loss: queueing would keep
+    every chunk's operands alive until the flush)"""
     st = _wgrad["stream"]
     if st is None:
-        return _linear_bwd_w(dy, x, dW, alpha=alpha, b_act=b_act, db=db, a_drop=a_drop, b_drop=b_drop)
+        return _linear_bwd_w(dy, x, dW, alpha=alpha, b_act=b_act, db=db, a_drop=a_drop, b_drop=b_drop, group=group)
     cur = torch.cuda.current_stream()
     st.wait_stream(cur)                 # operands were produced on the main stream
     with torch.cuda.stream(st):
@@ -466,14 +485,15 @@ def linear_bwd_w(dy, x, dW, *, alpha=1.0, b_act=ACT_NONE, db=None, a_drop=None, 
     _wgrad["used"] = True
 
 
-def _linear_bwd_w(dy, x, dW, *, alpha=1.0, b_act=ACT_NONE, db=None, a_drop=None, b_drop=None):
+def _linear_bwd_w(dy, x, dW, *, alpha=1.0, b_act=ACT_NONE, db=None, a_drop=None, b_drop=None, group=True):
     """dW[N,K] += alpha * drop_a(dy)[M,N]^T @ drop_b(b_act(x))[M,K]   (split-K, f32 atomics)
     db[N] += alpha * column sums of drop_a(dy) (bias gradient, fused into the same launch);
     a_drop / b_drop = (p, salt): fp32 mode only, the operand is dropped while it is staged (eamd_gemm_t.a_drop_p)"""
     M, N = dy.shape
     K = x.shape[1]
     assert x.shape[0] == M and dW.numel() == N * K and dW.dtype == torch.float32
-    if (_wgroup["on"] and _wgrad["stream"] is None and M <= STACK_WGRAD_MAX_ROWS and alpha == 1.0 and b_act == ACT_NONE
+    grouping = group and _wgroup["on"] and _wgrad["stream"] is None
+    if (grouping and M <= STACK_WGRAD_MAX_ROWS and alpha == 1.0 and b_act == ACT_NONE
             and a_drop is None and b_drop is None and dy.is_contiguous() and x.is_contiguous() and _in_grad_arena(dW)):
         # one decoder step's weight gradient (M = batch rows) reads and writes the whole dW for a reduction of M: the
         # steps of a backward pass are stacked along the reduction instead and leave as ONE product at the flush
@@ -487,8 +507,7 @@ def _linear_bwd_w(dy, x, dW, *, alpha=1.0, b_act=ACT_NONE, db=None, a_drop=None,
     sk = auto_splitk(N, K, M)
     tile = 0
     t64 = ((N + 63) // 64) * ((K + 63) // 64)
-    if (_wgroup["on"] and _wgrad["stream"] is None and t64 <= GROUP_WGRAD_MAX_TILES
-            and _in_grad_arena(dW)):
+    if grouping and t64 <= GROUP_WGRAD_MAX_TILES and _in_grad_arena(dW):
         if t64 >= GROUP_WGRAD_TILE128_MIN and N >= 128 and K >= 128 and dy.dtype == torch.float32 and _state["precision"] == 0:
             # big outputs (the FFN weights) go to the 128x128 grouped launch: a quarter of the operand re-reads
             tile = 128
@@ -497,7 +516,7 @@ def _linear_bwd_w(dy, x, dW, *, alpha=1.0, b_act=ACT_NONE, db=None, a_drop=None,
             tile = 64
             sk = max(1, sk // GROUP_WGRAD_SK_DIV)
     gemm(dy, x, dW, N, K, M, N, K, K, transA=1, transB=1, alpha=alpha, b_act=b_act, splitk=sk, tile=tile,
-         beta=1.0 if sk == 1 else 0.0, colsum=db, a_drop=a_drop, b_drop=b_drop, group=_wgrad["stream"] is None)
+         beta=1.0 if sk == 1 else 0.0, colsum=db, a_drop=a_drop, b_drop=b_drop, group=grouping)
 
 
 def colsum(x, out, scale=1.0, rows=None, D=None, ld=None):

@@ -578,7 +578,7 @@ class JointRNNTLossFn(torch.autograd.Function):
             if dZ is None:
                 Z = ops.linear_fwd(H2, ops.wshadow(w_out), b_out)
                 dZ = ops.rnnt_node_grad(Z, labels, tlens, ulens, ws, (b * T + t0) * U, B, T, U, blank, gs, 1.0 / B, out_dtype=adt)
-            ops.linear_bwd_w(dZ, H2, sink.buf(0), db=sink.buf(1))
+            ops.linear_bwd_w(dZ, H2, sink.buf(0), db=sink.buf(1), group=False)   # per-chunk: queueing would keep every chunk alive
             dH = ops.linear_bwd_x(dZ, ops.wshadow(w_out))
             de_c, dd_c = ops.joint_bwd(dH.view(1, nt, U, J), eb.contiguous(), db_, act)
             de[b, t0:t0 + nt].copy_(de_c[0])

@@ -537,7 +537,10 @@ class EpochRunner:
         self.pre_step = pre_step or (lambda: ops.rng_advance(flat.data.device))     # new dropout masks per micro-step
         self.cap = max(1, int(bucket_mb * 1024 * 1024 // 4))
         self.dev = flat.data.device
-        self.total_count = 0          # reporter.get_total_count(): optimizer-step attempts so far (gradient-noise decay)
+        # reporter.get_total_count() (espnet2/train/reporter.py:154-165): MICRO-steps registered so far by the "train"
+        # sub-reporter, the current one included - incremented before forward, carried across epochs (the caller may
+        # restore it from a checkpoint); drives the gradient-noise decay (trainer.py:420-427)
+        self.total_count = 0
         self.history = []             # averaged statistics of every finished micro-step (device tensors, read lazily)
 
     # ---- defaults for the model shells of this package ----
@@ -642,6 +645,7 @@ class EpochRunner:
             iiter += 1
             w = self._weight_of(batch)
             if train:
+                self.total_count += 1
                 self.pre_step()
                 loss, stats, _w = self.forward(batch)
                 ops.wgrad_group_begin()
@@ -663,7 +667,6 @@ class EpochRunner:
                     ops.add_gradient_noise(self.flat.grad, 1.0 / ((self.total_count // 100) + 1) ** 0.55)
                 self.opt.step()                          # clip, non-finite skip, Adam, scheduler: all on the device
                 self.flat.zero_grad()
-                self.total_count += 1
         if iiter > 0:                                    # statistics of the last micro-step: one more (blocking) exchange
             tickets.append(self._send(0.0, 0.0, pending))
         if dev.type == "cuda":

@@ -224,3 +224,32 @@ def test_epoch_runner_single_process_validation():
     assert all(abs(float(h["loss"]) - w) < 1e-6 for h, w in zip(hist, want))
     avg = run.averaged()
     assert abs(avg["loss"] - sum(w * n for w, n in zip(want, (3, 2, 4))) / 9.0) < 1e-6
+
+
+def test_epoch_runner_gradient_noise_iteration_count(monkeypatch):
+    """add_gradient_noise is driven by reporter.get_total_count() (espnet2/train/trainer.py:420-427,
+    reporter.py:154-165): the cumulative MICRO-step count, the current one included, carried over epochs - with
+    accum_grad 2 and `duration` 100 the interval advances every 50 optimizer steps, first at micro-step 100"""
+    from espnet_amd import train, ops
+    torch.manual_seed(0)
+    model = torch.nn.Linear(7, 5)
+    flat = train.FlatParams(model)
+    sigmas = []
+    monkeypatch.setattr(ops, "add_gradient_noise", lambda g, sigma, salt=0: sigmas.append(sigma))
+    monkeypatch.setattr(ops, "wgrad_join", lambda: None)
+
+    def forward(batch):
+        x, y = batch
+        return ((model(x) - y) ** 2).mean(), {}, float(x.shape[0])
+
+    run = train.EpochRunner(model, flat, _StubOpt(flat), accum_grad=2, grad_noise=True, forward=forward,
+                            pre_step=lambda: None)
+    g = torch.Generator().manual_seed(5)
+    batches = [(torch.randn(2, 7, generator=g), torch.randn(2, 5, generator=g)) for _ in range(66)]
+    for _epoch in range(2):
+        run.train_one_epoch(batches)
+    counts = list(range(2, 133, 2))            # the reference's get_total_count() at each of the 66 optimizer steps
+    want = [1.0 / ((c // 100) + 1) ** 0.55 for c in counts]
+    assert run.total_count == 132 and len(sigmas) == 66
+    assert all(abs(a - b) < 1e-12 for a, b in zip(sigmas, want))
+    assert sigmas[48] == 1.0 and sigmas[49] < 1.0          # micro-step 100 = optimizer step 50 is the first in interval 2

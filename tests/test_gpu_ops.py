@@ -785,6 +785,47 @@ def test_grouped_weight_gradient_launch_vs_float64(ops, prec):
         espnet_amd.set_precision("fp32")
 
 
+@pytest.mark.gpu
+@pytest.mark.parametrize("prec", ["fp32", "bf16"])
+def test_grouped_weight_gradients_same_destination(ops, prec):
+    """several queued weight gradients that accumulate into the SAME dW - a weight used more than once
+    per backward pass with 65..511 reduction rows (split-K 1 = plain read-modify-write tiles) and mixes of plain and
+    atomic problems - must not share one grouped launch; the result equals the float64 sum of all contributions"""
+    import espnet_amd
+    espnet_amd.set_precision(prec)
+    try:
+        g = torch.Generator().manual_seed(11)
+        adt = ops.act_dtype()
+        n, k = 320, 256
+        arena = torch.randn(n * k + n + 64 * 64, generator=g).to(DEV)
+        before = arena.clone()
+        ops.register_grad_arena(arena)
+        dW, db = arena[:n * k].view(n, k), arena[n * k:n * k + n]
+        other = arena[n * k + n:].view(64, 64)
+        ops.wgrad_group_begin()
+        terms, oterms = [], []
+        for m in (128, 128, 96, 2000, 128, 300, 128):      # 2000 rows: split-K > 1 (atomics) between the plain ones
+            dy = (0.1 * torch.randn(m, n, generator=g)).to(torch.bfloat16).to(adt).to(DEV)
+            x = torch.randn(m, k, generator=g).to(torch.bfloat16).to(adt).to(DEV)
+            ops.linear_bwd_w(dy, x, dW, db=db)
+            terms.append((dy, x))
+            dy2 = (0.1 * torch.randn(m, 64, generator=g)).to(torch.bfloat16).to(adt).to(DEV)     # a second weight in between
+            x2 = torch.randn(m, 64, generator=g).to(torch.bfloat16).to(adt).to(DEV)
+            ops.linear_bwd_w(dy2, x2, other)
+            oterms.append((dy2, x2))
+        ops.wgrad_group_end()
+        torch.cuda.synchronize()
+        want = before[:n * k].view(n, k).double().cpu() + sum(a.double().cpu().t() @ b.double().cpu() for a, b in terms)
+        report("dW shared by 7 queued problems (%s)" % prec, dW, want, 2e-5)
+        wb = before[n * k:n * k + n].double().cpu() + sum(a.double().cpu().sum(0) for a, _ in terms)
+        report("db shared by 7 queued problems (%s)" % prec, db, wb, 2e-5)
+        wo = before[n * k + n:].view(64, 64).double().cpu() + sum(a.double().cpu().t() @ b.double().cpu() for a, b in oterms)
+        report("second dW (%s)" % prec, other, wo, 2e-5)
+    finally:
+        ops.wgrad_group_end()
+        espnet_amd.set_precision("fp32")
+
+
 @pytest.mark.parametrize("shape", [(32, 249, 256, 31), (3, 70, 96, 15), (2, 33, 300, 7), (1, 5, 32, 3)])
 def test_dwconv_glu_fused_vs_float64(ops, shape):
     """eamd_dwconv_glu_fwd / _bwd_x / _bwd_w (GLU formed on load, its derivative applied in the input-gradient store)
