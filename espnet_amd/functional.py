@@ -220,6 +220,19 @@ class FFNBlockFn(torch.autograd.Function):
         assert eps is not None or p_out <= 0.0
         fused = ops.fast()      # bf16-operand GEMMs carry the dropout masks in their epilogues
         h, zf = None, False
+        if (eps is not None and ops.f32_epilogue_drop() and not ops.f32_operand_drop() and xn.dtype == torch.float32
+                and ops.ffn_fused_ok(xn, w1, w2, act)):
+            # fp32 mode, d = 256: BOTH products in one launch (csrc/ffn_f32.hip) - 32 rows per workgroup, the hidden units
+            # never make a round trip for the second product; kept for backward: h and the factor f (no grad: neither)
+            need = torch.is_grad_enabled() and any(ctx.needs_input_grad[:7])
+            out, z, h = ops.ffn_fwd(xn, w1, b1, w2, b2, act=act, alpha=scale, R=x2, drop=(p_in, s_in, p_out, s_out), save=need)
+            ctx.save_for_backward(x2, mean, rstd, xn, z, h)
+            ctx.pr = GradSink.use((ln_w, ln_b, w1, b1, w2, b2))
+            ctx.cfg = (scale, act, shp, drop)
+            ctx.in_opd, ctx.zf, ctx.one_launch = False, True, True
+            ctx.prev = _prev_drop(x)
+            return _tag_out(out.view(shp), p_out, s_out)
+        ctx.one_launch = False
         if p_in > 0.0 and (fused or (ops.f32_epilogue_drop() and not ops.f32_operand_drop())):
             # z and h = dropout(act(z)) from one launch (second output of the epilogue), in the operand dtype
             # ... and what is kept for backward is not z but the ready factor f = mask / (1 - p) * act'(z): the input-gradient
@@ -267,6 +280,11 @@ class FFNBlockFn(torch.autograd.Function):
         else:                                         # dW2 += s * drop(do)^T drop(act(z))
             ops.linear_bwd_w(dob, z, sink.buf(4), alpha=scale, b_act=act, db=sink.buf(5), a_drop=g_drop,
                              b_drop=(p_in, s_in) if ctx.in_opd else None)
+        if ctx.one_launch and g_drop is None and dob.dtype == torch.float32:
+            dz, dxn = ops.ffn_bwd(dob, w1, w2, z, alpha=scale)          # dz = s (dob W2) (.) f and dxn = dz W1: one launch
+            ops.linear_bwd_w(dz, xn, sink.buf(2), db=sink.buf(3))
+            dx = _ln_bwd_out(dxn, x2, ln_w, mean, rstd, do, sink.buf(0), sink.buf(1), ctx.prev, shp)
+            return (dx,) + sink.results() + (None, None, None, None)
         if ctx.zf:       # z holds mask / (1 - p) * act'(z) already
             dz = ops.linear_bwd_x(dob, ops.wshadow(w2), epilogue=EPI_MUL_AUX, aux=z, alpha=scale, out_dtype=adt, a_drop=g_drop)
         elif inner and (ops.fast() or ops.f32_epilogue_drop()):

@@ -444,6 +444,70 @@ def linear_bwd_x(dy, W, out=None, *, beta=0.0, epilogue=EPI_NONE, aux=None, alph
     return out
 
 
+# ---- fused position-wise feed-forward (csrc/ffn_f32.hip) ------------------------------------------
+FUSED_FFN = os.environ.get("EAMD_FUSED_FFN", "1") != "0"
+FUSED_FFN_MIN_ROWS = int(os.environ.get("EAMD_FUSED_FFN_MIN_ROWS", "4096"))     # 32 rows per workgroup: fewer rows leave CUs idle
+
+
+def ffn_fused_ok(x, w1, w2, act):
+    """True if eamd_ffn_fwd / _bwd take this problem (fp32 operands, D = 256, F a multiple of 128, enough rows to fill
+    the chip); otherwise the block runs as two eamd_gemm products"""
+    return (FUSED_FFN and x.dtype == torch.float32 and w1.dtype == torch.float32 and _state["precision"] == 0
+            and x.shape[1] == 256 and w1.shape[1] == 256 and w1.shape[0] % 128 == 0 and w1.shape[0] >= 256
+            and tuple(w2.shape) == (256, w1.shape[0]) and act in (ACT_RELU, ACT_SWISH) and x.shape[0] >= FUSED_FFN_MIN_ROWS)
+
+
+def _ffn_desc(x, w1, b1, w2, b2, R, out, f, h, act, alpha, drop):
+    p = _lib.FfnT()
+    p.x, p.w1, p.b1, p.w2, p.b2, p.R = ptr(x), ptr(w1), ptr(b1), ptr(w2), ptr(b2), ptr(R)
+    p.out, p.f, p.h = ptr(out), ptr(f), ptr(h)
+    p.M, p.D, p.F, p.act = x.shape[0], x.shape[1], w1.shape[0], act
+    p.alpha = alpha
+    p_in, s_in, p_out, s_out = drop
+    p.p_in, p.salt_in, p.p_out, p.salt_out = float(p_in), int(s_in), float(p_out), int(s_out)
+    if p_in > 0.0 or p_out > 0.0:
+        p.drop_step = ptr(rng_state(x.device))
+    return p
+
+
+def _ffn_call(name, p, keep):
+    fn = getattr(_lib.lib(), name)
+    if _gemm_record is not None:
+        _gemm_record.append((None, keep, lambda sp, p=p: check(fn(C.byref(p), sp), name)))
+    check(fn(C.byref(p), stream_ptr()), name)
+
+
+def ffn_fwd(x, w1, b1, w2, b2, *, act, alpha=1.0, R=None, drop=(0.0, 0, 0.0, 0), save=True):
+    """out = R + alpha * drop_out(drop_in(act(x W1^T + b1)) W2^T + b2) in ONE launch; with save also the two tensors
+    backward needs: h = drop_in(act(z)) and f = mask / (1 - p) * act'(z).  -> (out, f, h)"""
+    M, D = x.shape
+    F = w1.shape[0]
+    for t_ in (x, w1, w2) + tuple(v for v in (b1, b2, R) if v is not None):
+        if t_.dtype != torch.float32 or not t_.is_contiguous():
+            raise _lib.EamdError("ffn_fwd: contiguous float32 tensors")
+    out = torch.empty(M, D, device=x.device, dtype=torch.float32)
+    f = torch.empty(M, F, device=x.device, dtype=torch.float32) if save else None
+    h = torch.empty(M, F, device=x.device, dtype=torch.float32) if save else None
+    p = _ffn_desc(x, w1, b1, w2, b2, R, out, f, h, act, alpha, drop)
+    _ffn_call("eamd_ffn_fwd", p, (x, w1, b1, w2, b2, R, out, f, h))
+    return out, f, h
+
+
+def ffn_bwd(dy, w1, w2, f, *, alpha=1.0):
+    """dz = alpha * (dy W2) (.) f and dx = dz W1 in ONE launch -> (dz [M, F], dx [M, D])"""
+    M, D = dy.shape
+    F = w1.shape[0]
+    for t_ in (dy, w1, w2, f):
+        if t_.dtype != torch.float32 or not t_.is_contiguous():
+            raise _lib.EamdError("ffn_bwd: contiguous float32 tensors")
+    assert f.shape == (M, F)
+    dz = torch.empty(M, F, device=dy.device, dtype=torch.float32)
+    dx = torch.empty(M, D, device=dy.device, dtype=torch.float32)
+    p = _ffn_desc(dy, w1, None, w2, None, None, dx, f, dz, ACT_NONE, alpha, (0.0, 0, 0.0, 0))
+    _ffn_call("eamd_ffn_bwd", p, (dy, w1, w2, f, dz, dx))
+    return dz, dx
+
+
 # ---- weight-gradient side stream ---------------------------------------------------------------
 # dW = dY^T X is needed only by the optimizer (and the gradient all-reduce), never by the rest of
 # backward.  When enabled, every weight-gradient GEMM is issued on a second HIP stream so that it

@@ -139,6 +139,29 @@ int eamd_gemm_group_plan(const eamd_gemm_t* descs, int n, int32_t* first);
 int eamd_gemm_group_launch(const eamd_gemm_t* descs_dev, const int32_t* first_dev, int n, int total, int in_dtype, int tile,
                            void* stream);
 
+/* Fused position-wise feed-forward block.  reference: transformer/positionwise_feed_forward.py:12-32 (w_2(dropout(act(w_1(x))))),
+ * wired as conformer/encoder_layer.py:96-103,139-146 / transformer/encoder_layer.py (x + ff_scale * dropout(ff(norm(x)))).
+ * One workgroup takes 32 rows through BOTH products; the [M, F] hidden units are written once for backward and never
+ * read back by the second product.
+ *   eamd_ffn_fwd:  out[M,D] = R + alpha * drop_out( drop_in(act(x W1^T + b1)) W2^T + b2 )
+ *                  h[M,F] <- drop_in(act(z)),  f[M,F] <- mask_in / (1 - p_in) * act'(z)   (either may be NULL: inference)
+ *   eamd_ffn_bwd:  h[M,F] <- dz = alpha * (x W2) (.) f   (x = gradient of the block output [M,D], f as left by forward),
+ *                  out[M,D] <- dz W1
+ * Dropout masks are eamd_dropout's (element index of the contiguous [M,F] / [M,D] tensor, salts salt_in / salt_out,
+ * drop_step = the device step counter of eamd_rng_advance).  w1 [F,D], w2 [D,F] row-major (nn.Linear layout).
+ * dtype 0 = fp32 operands on v_mfma_f32_16x16x4_f32.  Returns EAMD_EUNSUPPORTED for shapes the kernel is not built for
+ * (D != 256, F not a multiple of 128, unaligned operands): the caller then runs the two eamd_gemm products. */
+typedef struct {
+  const float* x; const float* w1; const float* b1; const float* w2; const float* b2; const float* R;
+  float* out; float* f; float* h;
+  int32_t M, D, F, act;
+  float alpha;
+  float p_in; uint64_t salt_in; float p_out; uint64_t salt_out; const void* drop_step;
+  int32_t dtype; int32_t reserved;
+} eamd_ffn_t;
+int eamd_ffn_fwd(const eamd_ffn_t* p, void* stream);
+int eamd_ffn_bwd(const eamd_ffn_t* p, void* stream);
+
 /* ------------------------------------------------------------------------------------------
  * Row kernels (HBM-bound).
  * ------------------------------------------------------------------------------------------ */

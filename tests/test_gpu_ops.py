@@ -1253,3 +1253,60 @@ def test_gemm_row_statistics_epilogue(ops, prec, tile, M, N, K):
         report("row-stats tile maxima", pm[:, :, 0], vt, 1e-5)
     finally:
         espnet_amd.set_precision("fp32")
+
+
+# ---------------------------------------------------------------------------------------------
+# fused position-wise feed-forward (eamd_ffn_fwd / eamd_ffn_bwd)
+# ---------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("M,F,act,p_in,p_out", [(7968, 2048, 2, 0.1, 0.1), (4100, 1024, 1, 0.0, 0.0), (4097, 256, 2, 0.1, 0.0),
+                                                (33, 384, 2, 0.0, 0.2)])
+def test_ffn_fused_vs_float64(ops, M, F, act, p_in, p_out):
+    """positionwise_feed_forward.py:12-32 + the block wiring of conformer/encoder_layer.py:96-103 as ONE launch, against
+    float64: out = R + alpha * drop(drop(act(x W1^T + b1)) W2^T + b2), the two tensors kept for backward (h and the
+    factor f = mask / (1 - p) * act'(z)), and the backward launch dz = alpha (dy W2) (.) f, dx = dz W1.  The dropout
+    masks must be eamd_dropout's own (same salts, same step): they are drawn here by dropping a tensor of ones."""
+    import espnet_amd
+    espnet_amd.set_precision("fp32")
+    g = torch.Generator().manual_seed(M + F)
+    D = 256
+    x = torch.randn(M, D, generator=g)
+    w1 = torch.randn(F, D, generator=g) * 0.06
+    b1 = torch.randn(F, generator=g) * 0.1
+    w2 = torch.randn(D, F, generator=g) * 0.03
+    b2 = torch.randn(D, generator=g) * 0.1
+    R = torch.randn(M, D, generator=g)
+    dy = torch.randn(M, D, generator=g)
+    alpha = 0.5
+    ops.manual_seed(5)
+    s_in, s_out = 1234, 987
+    dev = [t.to(DEV) for t in (x, w1, b1, w2, b2, R, dy)]
+    xd, w1d, b1d, w2d, b2d, Rd, dyd = dev
+    out, f, h = ops.ffn_fwd(xd, w1d, b1d, w2d, b2d, act=act, alpha=alpha, R=Rd, drop=(p_in, s_in, p_out, s_out))
+    dz, dx = ops.ffn_bwd(dyd, w1d, w2d, f, alpha=alpha)
+    out_nosave, f0, h0 = ops.ffn_fwd(xd, w1d, b1d, w2d, b2d, act=act, alpha=alpha, R=Rd, drop=(p_in, s_in, p_out, s_out), save=False)
+    assert f0 is None and h0 is None and torch.equal(out_nosave, out)
+    m_in = ops.dropout(torch.ones(M, F, device=DEV), p_in, s_in).double().cpu() if p_in > 0 else torch.ones(M, F, dtype=torch.float64)
+    m_out = ops.dropout(torch.ones(M, D, device=DEV), p_out, s_out).double().cpu() if p_out > 0 else torch.ones(M, D, dtype=torch.float64)
+    if p_in > 0:
+        assert 0.85 < float((m_in > 0).double().mean()) < 0.95
+    z = x.double() @ w1.double().t() + b1.double()
+    if act == 2:
+        sg = torch.sigmoid(z)
+        a, d = z * sg, sg * (1 + z * (1 - sg))
+    else:
+        a, d = z.clamp_min(0), (z > 0).double()
+    h_ref, f_ref = a * m_in, d * m_in
+    out_ref = R.double() + alpha * ((h_ref @ w2.double().t() + b2.double()) * m_out)
+    tag = "M=%d F=%d act=%d p=(%g,%g)" % (M, F, act, p_in, p_out)
+    if act == 1:       # ReLU: pre-activations within fp32 rounding of zero may take either side
+        sure = (z.abs() > 1e-4)
+        assert torch.equal((h.double().cpu() != 0) & sure, (h_ref != 0) & sure)
+        h_cmp, f_cmp = torch.where(sure, h.double().cpu(), h_ref), torch.where(sure, f.double().cpu(), f_ref)
+    else:
+        h_cmp, f_cmp = h, f
+    report("ffn fused h  " + tag, h_cmp, h_ref, 2e-6)
+    report("ffn fused f  " + tag, f_cmp, f_ref, 2e-6)
+    report("ffn fused out " + tag, out, out_ref, 2e-6)
+    dz_ref = alpha * (dy.double() @ w2.double()) * f.double().cpu()
+    report("ffn fused dz " + tag, dz, dz_ref, 2e-6)
+    report("ffn fused dx " + tag, dx, dz_ref @ w1.double(), 2e-6)
