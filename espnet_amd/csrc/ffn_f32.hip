@@ -26,12 +26,25 @@
 #include "common.h"
 #include "../../include/espnet_amd.h"
 
+#ifdef FFN_STAMP
+// diagnostic build only: s_memtime stamps of one up and one down wave of workgroup 100 during body 4
+__device__ unsigned long long ffn_stamps[2][2][8][8];
+#define STAMP(k)                                                                                         \
+  do {                                                                                                   \
+    if (blockIdx.x == 100 && c == 4 && (wave == 0 || wave == 4) && lane == 0)                            \
+      ffn_stamps[BWD][ROLE][s][k] = __builtin_amdgcn_s_memtime();                                        \
+  } while (0)
+#else
+#define STAMP(k) do { } while (0)
+#endif
+
 namespace {
 
 constexpr int FBM = 32;          // rows per workgroup
 constexpr int FD = 256;          // model width (template constant of this kernel)
 constexpr int FHC = 128;         // hidden units per chunk
 constexpr int FNT = 512;
+constexpr int FLAG_LAG = 12;      // steps the down waves run behind the up waves (8 = one chunk, + 2 epilogue steps, + 2)
 constexpr int XS_LD = 264;       // [32][256 + 8]: ds_read_b128 conflict-free (row stride = 2 mod 16 chunks)
 constexpr int HS_LD = 136;       // [32][128 + 8]
 constexpr int W1F_LD = 40;       // forward: [128 hidden][32 k + 8]
@@ -55,7 +68,7 @@ __global__ __launch_bounds__(FNT, 2) void ffn_f32_kernel(const eamd_ffn_t p) {
   float* const hs = w2s + 2 * W2S_SZ;
 
   const int t = threadIdx.x;
-  const int lane = t & 63, wave = t >> 6;
+  const int lane = t & 63, wave = __builtin_amdgcn_readfirstlane(t >> 6);     // scalar: role branches are s_cbranch, not exec masks
   const bool up = wave < 4;            // wave-uniform role
   const int wq = wave & 3;
   const int fr = lane & 15, fq = lane >> 4;
@@ -77,10 +90,10 @@ __global__ __launch_bounds__(FNT, 2) void ffn_f32_kernel(const eamd_ffn_t p) {
 
   // ---- weight-tile staging ----
   // up tile g = (chunk c = g / 8, step s = g % 8); down pair P = (chunk cd = P / 4, pair sp = P % 4) serves down steps 2P, 2P+1
-  f32x4 r1[2][2], r2[2][4];      // native vectors: a float4 struct copied global -> array -> LDS becomes two memcpys that keep the array in scratch
+  f32x4 r1[2][2], r2[2][2];      // native vectors: a float4 struct copied global -> array -> LDS becomes two memcpys that keep the array in scratch
   // per-thread byte offsets inside a tile (the tile's origin is wave-uniform: scalar base + 32-bit vector offset)
   const unsigned w1_toff = BWD ? (unsigned)(((t >> 5) * F + (t & 31) * 4) * 4) : (unsigned)(((t >> 3) * FD + (t & 7) * 4) * 4);
-  const unsigned w2_toff = BWD ? (unsigned)(((t >> 6) * FD + (t & 63) * 4) * 4) : (unsigned)(((t >> 3) * F + (t & 7) * 4) * 4);
+  const unsigned w2_toff = BWD ? (unsigned)(((t >> 6) * FD + (t & 63) * 4) * 4) : (unsigned)(((t >> 2) * F + (t & 3) * 4) * 4);
   auto load_w1 = [&](auto set_c, int g) __attribute__((always_inline)) {
     constexpr int SET = decltype(set_c)::value;
     const int c = min(g >> 3, nch - 1), s = g & 7;
@@ -89,7 +102,8 @@ __global__ __launch_bounds__(FNT, 2) void ffn_f32_kernel(const eamd_ffn_t p) {
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
       const char* bi = base + (BWD ? (long)i * 16 * F * 4 : (long)i * 64 * FD * 4);
-      r1[SET][i] = *reinterpret_cast<const f32x4*>(bi + w1_toff);
+      if (p.reserved & 1) r1[SET][i] = *reinterpret_cast<const f32x4*>(reinterpret_cast<const char*>(Wa) + ((g & 7) * 2 + i) * 8192 + t * 16);   // timing experiment
+      else r1[SET][i] = *reinterpret_cast<const f32x4*>(bi + w1_toff);
     }
   };
   auto store_w1 = [&](auto set_c, int buf) __attribute__((always_inline)) {
@@ -102,45 +116,36 @@ __global__ __launch_bounds__(FNT, 2) void ffn_f32_kernel(const eamd_ffn_t p) {
       else *reinterpret_cast<f32x4*>(&dst[(idx >> 5) * W1B_LD + (idx & 31) * 4]) = r1[SET][i];
     }
   };
-  auto load_w2 = [&](auto set_c, int P) __attribute__((always_inline)) {
+  // down tile gd = (chunk cd = gd / 8, step sd = gd % 8): the 16 hidden units that down step contracts
+  auto load_w2 = [&](auto set_c, int gd) __attribute__((always_inline)) {
     constexpr int SET = decltype(set_c)::value;
-    const int Pc = min(P, 4 * nch - 1);
-    const int cd = Pc >> 2, sp = Pc & 3;
-    // forward: W2[row][cd*128 + sp*32 + kc*4], row = idx >> 3 (i adds 64 rows);  backward: W1[cd*128 + sp*32 + row][cc*4], row = idx >> 6 (i adds 8)
-    const char* base = reinterpret_cast<const char*>(BWD ? Wb + (long)(cd * FHC + sp * 32) * FD : Wb + cd * FHC + sp * 32);
+    const int gc = min(max(gd, 0), 8 * nch - 1);
+    const int cd = gc >> 3, sd = gc & 7;
+    // forward: W2[row][cd*128 + sd*16 + kc*4], row = idx >> 2 (i adds 128 rows);  backward: W1[cd*128 + sd*16 + row][cc*4], row = idx >> 6 (i adds 8)
+    const char* base = reinterpret_cast<const char*>(BWD ? Wb + (long)(cd * FHC + sd * 16) * FD : Wb + cd * FHC + sd * 16);
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      const char* bi = base + (BWD ? (long)i * 8 * FD * 4 : (long)i * 64 * F * 4);
-      r2[SET][i] = *reinterpret_cast<const f32x4*>(bi + w2_toff);
+    for (int i = 0; i < 2; ++i) {
+      const char* bi = base + (BWD ? (long)i * 8 * FD * 4 : (long)i * 128 * F * 4);
+      if (p.reserved & 1) r2[SET][i] = *reinterpret_cast<const f32x4*>(reinterpret_cast<const char*>(Wb) + ((gc & 7) * 2 + i) * 8192 + t * 16);  // timing experiment
+      else r2[SET][i] = *reinterpret_cast<const f32x4*>(bi + w2_toff);
     }
   };
-  // half = 0 / 1: the 16 reduction elements of the pair tile that the next down step contracts
-  auto store_w2 = [&](auto set_c, int half, int buf) __attribute__((always_inline)) {
+  auto store_w2 = [&](auto set_c, int buf) __attribute__((always_inline)) {
     constexpr int SET = decltype(set_c)::value;
     float* dst = w2s + buf * W2S_SZ;
-    if constexpr (!BWD) {
-      if (((t >> 2) & 1) == half) {      // this thread's chunks (kc = t & 7) belong to half kc >> 2
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-          const int idx = t + FNT * i;
-          *reinterpret_cast<f32x4*>(&dst[(idx >> 3) * W2F_LD + (idx & 3) * 4]) = r2[SET][i];
-        }
-      }
-    } else {                             // rows 0-15 of the pair tile are chunks i = 0, 1; rows 16-31 chunks 2, 3
-#pragma unroll
-      for (int i = 0; i < 2; ++i) {
-        const int idx = t + FNT * i;     // row within the half = idx >> 6 (0..15)
-        const f32x4 v = half ? r2[SET][i + 2] : r2[SET][i];
-        *reinterpret_cast<f32x4*>(&dst[(idx >> 6) * W2B_LD + (idx & 63) * 4]) = v;
-      }
+    for (int i = 0; i < 2; ++i) {
+      const int idx = t + FNT * i;
+      if constexpr (!BWD) *reinterpret_cast<f32x4*>(&dst[(idx >> 2) * W2F_LD + (idx & 3) * 4]) = r2[SET][i];
+      else *reinterpret_cast<f32x4*>(&dst[(idx >> 6) * W2B_LD + (idx & 63) * 4]) = r2[SET][i];
     }
   };
 
-  f32x4 zacc[2][2], yacc[2][4];
+  f32x4 zacc[2][2], zold[2][2], yacc[2][4];
 #pragma unroll
   for (int i = 0; i < 2; ++i) {
 #pragma unroll
-    for (int j = 0; j < 2; ++j) zacc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    for (int j = 0; j < 2; ++j) { zacc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f}; zold[i][j] = zacc[i][j]; }
 #pragma unroll
     for (int j = 0; j < 4; ++j) yacc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
   }
@@ -149,209 +154,242 @@ __global__ __launch_bounds__(FNT, 2) void ffn_f32_kernel(const eamd_ffn_t p) {
   const unsigned thr_in = eamd_drop_thr16(p.p_in);
   const float inv_in = p.p_in > 0.f ? eamd_drop_inv(thr_in) : 1.f;
   const unsigned seed_in = (!BWD && p.p_in > 0.f) ? eamd_drop_seed((const unsigned long long*)p.drop_step, p.salt_in) : 0u;
-  float fpre[2][2][4];     // backward: the factor f at this lane's accumulator positions (requested at the chunk's first step)
-
-  // ---- one step ----
-  auto up_mfma = [&](int s, int buf) __attribute__((always_inline)) {
-    const float* wb = w1s + buf * W1S_SZ;
-    float4 xa[2][2];
-#pragma unroll
-    for (int i = 0; i < 2; ++i)
-#pragma unroll
-      for (int q = 0; q < 2; ++q)
-        xa[i][q] = *reinterpret_cast<const float4*>(&xs[(i * 16 + fr) * XS_LD + s * 32 + q * 16 + fq * 4]);
-    if constexpr (!BWD) {
-      float4 wv[2][2];
-#pragma unroll
-      for (int j = 0; j < 2; ++j)
-#pragma unroll
-        for (int q = 0; q < 2; ++q)
-          wv[j][q] = *reinterpret_cast<const float4*>(&wb[(wq * 32 + j * 16 + fr) * W1F_LD + q * 16 + fq * 4]);
-#pragma unroll
-      for (int q = 0; q < 2; ++q)
-#pragma unroll
-        for (int e = 0; e < 4; ++e)
-#pragma unroll
-          for (int i = 0; i < 2; ++i)
-#pragma unroll
-            for (int j = 0; j < 2; ++j)
-              zacc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(xa[i][q][e], wv[j][q][e], zacc[i][j], 0, 0, 0);
-    } else {
-#pragma unroll
-      for (int q = 0; q < 2; ++q) {
-        float wv[2][4];
-#pragma unroll
-        for (int j = 0; j < 2; ++j)
-#pragma unroll
-          for (int e = 0; e < 4; ++e) wv[j][e] = wb[(q * 16 + fq * 4 + e) * W1B_LD + wq * 32 + j * 16 + fr];
-#pragma unroll
-        for (int e = 0; e < 4; ++e)
-#pragma unroll
-          for (int i = 0; i < 2; ++i)
-#pragma unroll
-            for (int j = 0; j < 2; ++j)
-              zacc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(xa[i][q][e], wv[j][e], zacc[i][j], 0, 0, 0);
-      }
-    }
-  };
-  auto down_mfma = [&](int s, int buf, int hb) __attribute__((always_inline)) {
-    const float* wb = w2s + buf * W2S_SZ;
-    const float* hp = hs + hb * HS_SZ;
-    float4 ha[2];
-#pragma unroll
-    for (int i = 0; i < 2; ++i) ha[i] = *reinterpret_cast<const float4*>(&hp[(i * 16 + fr) * HS_LD + s * 16 + fq * 4]);
-    if constexpr (!BWD) {
-      float4 wv[4];
-#pragma unroll
-      for (int j = 0; j < 4; ++j) wv[j] = *reinterpret_cast<const float4*>(&wb[(wq * 64 + j * 16 + fr) * W2F_LD + fq * 4]);
-#pragma unroll
-      for (int e = 0; e < 4; ++e)
-#pragma unroll
-        for (int i = 0; i < 2; ++i)
-#pragma unroll
-          for (int j = 0; j < 4; ++j)
-            yacc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(ha[i][e], wv[j][e], yacc[i][j], 0, 0, 0);
-    } else {
-      float wv[4][4];
-#pragma unroll
-      for (int j = 0; j < 4; ++j)
-#pragma unroll
-        for (int e = 0; e < 4; ++e) wv[j][e] = wb[(fq * 4 + e) * W2B_LD + wq * 64 + j * 16 + fr];
-#pragma unroll
-      for (int e = 0; e < 4; ++e)
-#pragma unroll
-        for (int i = 0; i < 2; ++i)
-#pragma unroll
-          for (int j = 0; j < 4; ++j)
-            yacc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(ha[i][e], wv[j][e], yacc[i][j], 0, 0, 0);
-    }
-  };
-  // the up waves' chunk epilogue: accumulators -> hidden units (LDS for the down waves, global memory for backward).
-  // Straight-line code: the activation is a template constant, the row guard is taken only by the ragged last workgroup.
+  float bpre[2] = {0.f, 0.f};   // forward: b1 at this lane's two columns of the chunk in flight (requested mid-chunk: a load consumed
+                                // at once would wait for every tile request in front of it in the vmcnt queue)
+  float fpre[2][2][4];     // backward: the factor f at this lane's accumulator positions (requested mid-chunk)
   const bool full_rows = m0 + FBM <= p.M;
   const unsigned e_toff = (unsigned)(((fq * 4) * F + wq * 32 + fr) * 4);      // this lane's first accumulator element
-  auto up_epilogue = [&](int c) __attribute__((always_inline)) {
-    float* hp = hs + (c & 1) * HS_SZ;
-    float hv[2][2][4], fv[2][2][4];
-#pragma unroll
-    for (int j = 0; j < 2; ++j) {
-      const int lc = wq * 32 + j * 16 + fr;        // column inside the chunk
-      float bj = 0.f;
-      if constexpr (!BWD) bj = p.b1 ? p.b1[c * FHC + lc] : 0.f;
+
+  // ---- fragments: a step's 32 MFMAs per wave are two halves of 16; each half has its own fragment registers, so the
+  // reads of one half fly under the MFMAs of the other and the first half of step g + 1 is read right behind the barrier
+  // that ends step g, in front of the second half of step g.
+  //   up wave:   half q = reduction elements q*16 .. q*16+15 of the step's 32 (A: 2 row tiles, B: 2 column tiles)
+  //   down wave: half hh = output column tiles 2 hh, 2 hh + 1 (A: the step's 16 hidden units, read for both halves)
+  float fA[2][2][4], fB[2][2][4];
+  auto read_half = [&](auto role_c, auto s_c, auto half_c, int hbuf) __attribute__((always_inline)) {
+    constexpr int s = decltype(s_c)::value, hh = decltype(half_c)::value;
+    constexpr int buf = s & 1;
+    if constexpr (decltype(role_c)::value == 0) {
+      const float* wb = w1s + buf * W1S_SZ;
 #pragma unroll
       for (int i = 0; i < 2; ++i) {
+        const float4 v = *reinterpret_cast<const float4*>(&xs[(i * 16 + fr) * XS_LD + s * 32 + hh * 16 + fq * 4]);
+        fA[hh][i][0] = v.x; fA[hh][i][1] = v.y; fA[hh][i][2] = v.z; fA[hh][i][3] = v.w;
+      }
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          if constexpr (!BWD) {
-            float a, d;
-            eamd_act_dact(zacc[i][j][r] + bj, ACT, a, d);
-            hv[i][j][r] = a; fv[i][j][r] = d;
-          } else {
-            hv[i][j][r] = (zacc[i][j][r] * fpre[i][j][r]) * p.alpha;
-          }
+      for (int j = 0; j < 2; ++j) {
+        if constexpr (!BWD) {
+          const float4 v = *reinterpret_cast<const float4*>(&wb[(wq * 32 + j * 16 + fr) * W1F_LD + hh * 16 + fq * 4]);
+          fB[hh][j][0] = v.x; fB[hh][j][1] = v.y; fB[hh][j][2] = v.z; fB[hh][j][3] = v.w;
+        } else {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) fB[hh][j][e] = wb[(hh * 16 + fq * 4 + e) * W1B_LD + wq * 32 + j * 16 + fr];
+        }
+      }
+    } else {
+      constexpr int sd = (s + 8 - (FLAG_LAG & 7)) & 7;          // down step inside its chunk
+      const float* wb = w2s + buf * W2S_SZ;
+      const float* hp = hs + hbuf * HS_SZ;       // hbuf = parity of the chunk this down step contracts
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        const float4 v = *reinterpret_cast<const float4*>(&hp[(i * 16 + fr) * HS_LD + sd * 16 + fq * 4]);
+        fA[hh][i][0] = v.x; fA[hh][i][1] = v.y; fA[hh][i][2] = v.z; fA[hh][i][3] = v.w;
+      }
+#pragma unroll
+      for (int jj = 0; jj < 2; ++jj) {
+        if constexpr (!BWD) {
+          const float4 v = *reinterpret_cast<const float4*>(&wb[(wq * 64 + (2 * hh + jj) * 16 + fr) * W2F_LD + fq * 4]);
+          fB[hh][jj][0] = v.x; fB[hh][jj][1] = v.y; fB[hh][jj][2] = v.z; fB[hh][jj][3] = v.w;
+        } else {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) fB[hh][jj][e] = wb[(fq * 4 + e) * W2B_LD + wq * 64 + (2 * hh + jj) * 16 + fr];
         }
       }
     }
-    if constexpr (!BWD) {
-      if (p.p_in > 0.f) {       // wave-uniform
+  };
+  auto mfma_half = [&](auto role_c, auto half_c, auto upon_c, auto downon_c) __attribute__((always_inline)) {
+    constexpr int hh = decltype(half_c)::value;
+    constexpr bool up_on = decltype(upon_c)::value, down_on = decltype(downon_c)::value;
+    if constexpr (decltype(role_c)::value == 0) {
+      if constexpr (up_on) {
 #pragma unroll
-        for (int j = 0; j < 2; ++j)
+        for (int e = 0; e < 4; ++e)
 #pragma unroll
           for (int i = 0; i < 2; ++i)
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-              const unsigned gi = (unsigned)(m0 + i * 16 + fq * 4 + r) * (unsigned)F + (unsigned)(c * FHC + wq * 32 + j * 16 + fr);
-              const bool keep = eamd_drop_keep(seed_in, (unsigned long long)gi, thr_in);
-              hv[i][j][r] = keep ? hv[i][j][r] * inv_in : 0.f;
-              fv[i][j][r] = keep ? fv[i][j][r] * inv_in : 0.f;
-            }
+            for (int j = 0; j < 2; ++j)
+              zacc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(fA[hh][i][e], fB[hh][j][e], zacc[i][j], 0, 0, 0);
+      }
+    } else {
+      if constexpr (down_on) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+#pragma unroll
+          for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int jj = 0; jj < 2; ++jj)
+              yacc[i][2 * hh + jj] = __builtin_amdgcn_mfma_f32_16x16x4f32(fA[hh][i][e], fB[hh][jj][e], yacc[i][2 * hh + jj], 0, 0, 0);
       }
     }
+  };
+
+  // One quarter (row tile i, column tile j) of the up waves' chunk epilogue: 4 accumulator elements per lane -> hidden
+  // units (LDS for the down waves, global memory for backward).  The four quarters of chunk c run in the four half steps
+  // of steps 8 (c + 1) and 8 (c + 1) + 1, beside the MFMAs of the next chunk (zold = the finished accumulators).
+  auto epi_quarter = [&](auto i_c, auto j_c, int c) __attribute__((always_inline)) {
+    constexpr int i = decltype(i_c)::value, j = decltype(j_c)::value;
+    float* hp = hs + (c & 1) * HS_SZ;
+    const int lc = wq * 32 + j * 16 + fr;        // column inside the chunk
+    float hv[4], fv[4];
+    if constexpr (!BWD) {
+      const float bj = bpre[j];
 #pragma unroll
-    for (int j = 0; j < 2; ++j)
+      for (int r = 0; r < 4; ++r) eamd_act_dact(zold[i][j][r] + bj, ACT, hv[r], fv[r]);
+      if (p.p_in > 0.f) {       // wave-uniform
 #pragma unroll
-      for (int i = 0; i < 2; ++i)
+        for (int r = 0; r < 4; ++r) {
+          const unsigned gi = (unsigned)(m0 + i * 16 + fq * 4 + r) * (unsigned)F + (unsigned)(c * FHC + lc);
+          const bool keep = eamd_drop_keep(seed_in, (unsigned long long)gi, thr_in);
+          hv[r] = keep ? hv[r] * inv_in : 0.f;
+          fv[r] = keep ? fv[r] * inv_in : 0.f;
+        }
+      }
+    } else {
 #pragma unroll
-        for (int r = 0; r < 4; ++r) hp[(i * 16 + fq * 4 + r) * HS_LD + wq * 32 + j * 16 + fr] = hv[i][j][r];
-    // global copies for backward: element (i, j, r) sits (i*16 + r) rows and j*16 columns from the lane's first one
-    auto put = [&](float* dstp, const float (&val)[2][2][4]) __attribute__((always_inline)) {
+      for (int r = 0; r < 4; ++r) hv[r] = (zold[i][j][r] * fpre[i][j][r]) * p.alpha;
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) hp[(i * 16 + fq * 4 + r) * HS_LD + lc] = hv[r];
+    // global copies for backward: element r sits (i*16 + r) rows and j*16 columns from the lane's first one
+    auto put = [&](float* dstp, const float (&val)[4]) __attribute__((always_inline)) {
       char* base = reinterpret_cast<char*>(dstp + (long)m0 * F + c * FHC);
       if (full_rows) {
 #pragma unroll
-        for (int j = 0; j < 2; ++j)
-#pragma unroll
-          for (int i = 0; i < 2; ++i)
-#pragma unroll
-            for (int r = 0; r < 4; ++r)
-              *reinterpret_cast<float*>(base + ((long)(i * 16 + r) * F + j * 16) * 4 + e_toff) = val[i][j][r];
+        for (int r = 0; r < 4; ++r) *reinterpret_cast<float*>(base + ((long)(i * 16 + r) * F + j * 16) * 4 + e_toff) = val[r];
       } else {
 #pragma unroll
-        for (int j = 0; j < 2; ++j)
-#pragma unroll
-          for (int i = 0; i < 2; ++i)
-#pragma unroll
-            for (int r = 0; r < 4; ++r)
-              if (m0 + i * 16 + fq * 4 + r < p.M)
-                *reinterpret_cast<float*>(base + ((long)(i * 16 + r) * F + j * 16) * 4 + e_toff) = val[i][j][r];
+        for (int r = 0; r < 4; ++r)
+          if (m0 + i * 16 + fq * 4 + r < p.M)
+            *reinterpret_cast<float*>(base + ((long)(i * 16 + r) * F + j * 16) * 4 + e_toff) = val[r];
       }
     };
     if (p.h) put(p.h, hv);
     if constexpr (!BWD) { if (p.f) put(p.f, fv); }
-#pragma unroll
-    for (int i = 0; i < 2; ++i)
-#pragma unroll
-      for (int j = 0; j < 2; ++j) zacc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
   };
   auto load_f = [&](int c) __attribute__((always_inline)) {
     const char* base = reinterpret_cast<const char*>(p.f + (long)m0 * F + c * FHC);
+    if (full_rows) {          // scalar base + this lane's 32-bit offset
 #pragma unroll
-    for (int j = 0; j < 2; ++j)
+      for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+          for (int r = 0; r < 4; ++r)
+            fpre[i][j][r] = *reinterpret_cast<const float*>(base + ((long)(i * 16 + r) * F + j * 16) * 4 + e_toff);
+    } else {
+#pragma unroll
+      for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            // rows past M: any valid address (their products only reach rows that are never stored)
+            const long ro = (long)(min(m0 + i * 16 + fq * 4 + r, p.M - 1) - m0 - fq * 4) * F;
+            fpre[i][j][r] = *reinterpret_cast<const float*>(base + (ro + j * 16) * 4 + e_toff);
+          }
+    }
+  };
+
+  // Step g = 8 c + s of "body" c.  Up waves: chunk c is being formed (UP: c < nch); the epilogue of chunk c - 1 runs in
+  // steps s = 0, 1 (DA).  Down waves run LAG = 12 steps behind: steps s >= 4 contract chunk c - 1 (DA: 1 <= c <= nch),
+  // steps s < 4 chunk c - 2 (DB: 2 <= c <= nch + 1).  The flags are compile-time: a runtime condition around the MFMAs
+  // makes the compiler copy the accumulators at every join (and wait for the matrix pipe to drain first).
+  // ROLE 0 = up wave, 1 = down wave: each role runs its OWN copy of the step sequence (the role split sits outside the
+  // loops - inside a step it makes the compiler merge the two arms and copy accumulators at every join); both copies
+  // stage the weight tiles and meet at the same barriers.
+  auto step = [&](auto role_c, auto s_c, auto up_c, auto da_c, auto db_c, int c) __attribute__((always_inline)) {
+    constexpr int ROLE = decltype(role_c)::value;
+    constexpr int s = decltype(s_c)::value;
+    constexpr bool UP = decltype(up_c)::value, DA = decltype(da_c)::value, DB = decltype(db_c)::value;
+    constexpr bool DOWN = s >= FLAG_LAG - 8 ? DA : DB;              // this step's down product
+    constexpr bool DOWN2 = (s + 2 < FLAG_LAG - 8) ? DB : DA;         // the down step two ahead (s = 6, 7: next body's DB = this DA)
+    constexpr bool DOWN1 = (s + 1 < FLAG_LAG - 8) ? DB : DA;         // the down step one ahead
+    const int g = 8 * c + s;
+    constexpr int buf = s & 1;
+    // requests: up tile g + 2 (same register set as tile g, stored a step ago); the down tile of step g + 2
+    STAMP(0);
+    if constexpr (UP) load_w1(std::integral_constant<int, s & 1>{}, g + 2);
+    if constexpr (DOWN2) load_w2(std::integral_constant<int, s & 1>{}, g + 2 - FLAG_LAG);
+    if constexpr (BWD && UP && s == 3 && ROLE == 0) load_f(c);
+    if constexpr (!BWD && UP && s == 3 && ROLE == 0) {
+      if (p.b1) { bpre[0] = p.b1[c * FHC + wq * 32 + fr]; bpre[1] = p.b1[c * FHC + wq * 32 + 16 + fr]; }
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    // down step g contracts chunk c - 1 (s >= LAG - 8) or c - 2; the step after s = 7 is the next body's first
+    read_half(role_c, s_c, std::integral_constant<int, 1>{}, (s >= FLAG_LAG - 8 ? c + 1 : c) & 1);
+    mfma_half(role_c, std::integral_constant<int, 0>{}, std::integral_constant<bool, UP>{}, std::integral_constant<bool, DOWN>{});
+    STAMP(1);
+    if constexpr (ROLE == 0 && DA && s < 2) epi_quarter(std::integral_constant<int, 0>{}, std::integral_constant<int, s>{}, c - 1);
+    STAMP(2);
+    __builtin_amdgcn_sched_barrier(0);
+    // the tiles of step g + 1 (their buffers were last read in step g - 1, or right behind the barrier that ended it)
+    if constexpr (UP) { if (s < 7 || g + 1 < 8 * nch) store_w1(std::integral_constant<int, (s + 1) & 1>{}, buf ^ 1); }
+    if constexpr (DOWN1) store_w2(std::integral_constant<int, (s + 1) & 1>{}, buf ^ 1);
+    STAMP(3);
+    __builtin_amdgcn_sched_barrier(0);
+    // Stagger: the two waves of a SIMD (one up, one down) must not sit in their LDS-store / barrier window together, or the
+    // matrix pipe idles through it.  The second half's fragments are in registers before the barrier, so the DOWN wave
+    // issues its second half in FRONT of the barrier (under the up wave's stores and barrier wait) and the UP wave BEHIND
+    // it (under the down wave's fragment reads and tile requests).
+    if constexpr (ROLE == 1) {
+      mfma_half(role_c, std::integral_constant<int, 1>{}, std::integral_constant<bool, UP>{}, std::integral_constant<bool, DOWN>{});
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    STAMP(4);
+    __syncthreads();
+    STAMP(5);
+    read_half(role_c, std::integral_constant<int, (s + 1) & 7>{}, std::integral_constant<int, 0>{}, (s == 7 || s + 1 >= FLAG_LAG - 8 ? c + 1 : c) & 1);
+    if constexpr (ROLE == 0) {
+      // MFMAs are pure register operations: ordered behind the barrier (and the cold reads just issued) by passing their
+      // fragments through an empty volatile asm
+#pragma unroll
+      for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { asm volatile("" : "+v"(fA[1][a][e])); asm volatile("" : "+v"(fB[1][a][e])); }
+      __builtin_amdgcn_sched_barrier(0);
+      mfma_half(role_c, std::integral_constant<int, 1>{}, std::integral_constant<bool, UP>{}, std::integral_constant<bool, DOWN>{});
+    }
+    STAMP(6);
+    if constexpr (ROLE == 0 && DA && s < 2) epi_quarter(std::integral_constant<int, 1>{}, std::integral_constant<int, s>{}, c - 1);
+    STAMP(7);
+    if constexpr (ROLE == 0 && UP && s == 7) {
 #pragma unroll
       for (int i = 0; i < 2; ++i)
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          // rows past M: any valid address (their products only reach rows that are never stored)
-          const long ro = full_rows ? (long)(i * 16 + r) * F : (long)(min(m0 + i * 16 + fq * 4 + r, p.M - 1) - m0 - fq * 4) * F;
-          fpre[i][j][r] = *reinterpret_cast<const float*>(base + (ro + j * 16) * 4 + e_toff);
-        }
-  };
-
-  // step g = 8 c + s.  UP: chunk c < nch is being formed; DOWN: chunk c - 1 is being contracted.
-  auto step = [&](auto s_c, auto up_c, auto down_c, int c) __attribute__((always_inline)) {
-    constexpr int s = decltype(s_c)::value;
-    constexpr bool UP = decltype(up_c)::value, DOWN = decltype(down_c)::value;
-    const int g = 8 * c + s;
-    constexpr int buf = s & 1;
-    // requests: up tile g + 2 (same register set as tile g, stored a step ago), down pair for steps g + 2, g + 3
-    if constexpr (UP) load_w1(std::integral_constant<int, s & 1>{}, g + 2);
-    if constexpr ((DOWN || s >= 6) && (s % 2 == 0)) load_w2(std::integral_constant<int, ((s + 2) / 2) & 1>{}, (g + 2 - 8) >> 1);
-    if constexpr (BWD && UP && s == 0) { if (up) load_f(c); }
-    __builtin_amdgcn_sched_barrier(0);
-    if (up) {
-      if constexpr (UP) up_mfma(s, buf);
-    } else {
-      if constexpr (DOWN) down_mfma(s, buf, (c - 1) & 1);
+        for (int j = 0; j < 2; ++j) { zold[i][j] = zacc[i][j]; zacc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f}; }
     }
-    __builtin_amdgcn_sched_barrier(0);
-    // the tiles of step g + 1 (their buffers were last read in step g - 1)
-    if constexpr (UP) { if (g + 1 < 8 * nch) store_w1(std::integral_constant<int, (s + 1) & 1>{}, buf ^ 1); }
-    if constexpr (DOWN || s == 7) {
-      // down step gd = g + 1 - 8, pair gd / 2 (register set (gd / 2) & 1), half gd & 1
-      constexpr int gdl = (s + 1) & 7;          // gd mod 8 (chunks are 8 steps: the pair parity repeats per chunk)
-      if (g + 1 - 8 < 8 * nch) store_w2(std::integral_constant<int, (gdl / 2) & 1>{}, gdl & 1, buf ^ 1);
-    }
-    if constexpr (UP && s == 7) { if (up) up_epilogue(c); }
-    __syncthreads();
   };
-  auto chunk = [&](auto up_c, auto down_c, int c) __attribute__((always_inline)) {
-    step(std::integral_constant<int, 0>{}, up_c, down_c, c);
-    step(std::integral_constant<int, 1>{}, up_c, down_c, c);
-    step(std::integral_constant<int, 2>{}, up_c, down_c, c);
-    step(std::integral_constant<int, 3>{}, up_c, down_c, c);
-    step(std::integral_constant<int, 4>{}, up_c, down_c, c);
-    step(std::integral_constant<int, 5>{}, up_c, down_c, c);
-    step(std::integral_constant<int, 6>{}, up_c, down_c, c);
-    step(std::integral_constant<int, 7>{}, up_c, down_c, c);
+  auto body = [&](auto role_c, auto up_c, auto da_c, auto db_c, int c) __attribute__((always_inline)) {
+    step(role_c, std::integral_constant<int, 0>{}, up_c, da_c, db_c, c);
+    step(role_c, std::integral_constant<int, 1>{}, up_c, da_c, db_c, c);
+    step(role_c, std::integral_constant<int, 2>{}, up_c, da_c, db_c, c);
+    step(role_c, std::integral_constant<int, 3>{}, up_c, da_c, db_c, c);
+    if constexpr (decltype(up_c)::value || decltype(da_c)::value) {      // the last body ends with the down waves' step s = 3
+      step(role_c, std::integral_constant<int, 4>{}, up_c, da_c, db_c, c);
+      step(role_c, std::integral_constant<int, 5>{}, up_c, da_c, db_c, c);
+      step(role_c, std::integral_constant<int, 6>{}, up_c, da_c, db_c, c);
+      step(role_c, std::integral_constant<int, 7>{}, up_c, da_c, db_c, c);
+    }
+  };
+  using T_ = std::true_type;
+  using F_ = std::false_type;
+  auto program = [&](auto role_c) __attribute__((always_inline)) {
+    read_half(role_c, std::integral_constant<int, 0>{}, std::integral_constant<int, 0>{}, 0);
+    body(role_c, T_{}, F_{}, F_{}, 0);
+    body(role_c, T_{}, T_{}, F_{}, 1);
+    for (int c = 2; c < nch; ++c) body(role_c, T_{}, T_{}, T_{}, c);
+    body(role_c, F_{}, T_{}, T_{}, nch);
+    body(role_c, F_{}, F_{}, T_{}, nch + 1);
   };
 
   // prologue: up tiles 0 (-> LDS) and 1 (in flight)
@@ -359,15 +397,11 @@ __global__ __launch_bounds__(FNT, 2) void ffn_f32_kernel(const eamd_ffn_t p) {
   load_w1(std::integral_constant<int, 1>{}, 1);
   store_w1(std::integral_constant<int, 0>{}, 0);
   __syncthreads();
-
-  using T_ = std::true_type;
-  using F_ = std::false_type;
-  chunk(T_{}, F_{}, 0);
-  for (int c = 1; c < nch; ++c) chunk(T_{}, T_{}, c);
-  chunk(F_{}, T_{}, nch);
-
-  // ---- output rows: accumulators of the down waves -> LDS (over the input rows) -> 16-byte row stores ----
-  if (!up) {
+  if (up) {
+    program(std::integral_constant<int, 0>{});
+  } else {
+    program(std::integral_constant<int, 1>{});
+    // output rows: accumulators -> LDS, over the input rows (the up waves read those for the last time 12 steps ago)
 #pragma unroll
     for (int i = 0; i < 2; ++i)
 #pragma unroll
@@ -376,6 +410,8 @@ __global__ __launch_bounds__(FNT, 2) void ffn_f32_kernel(const eamd_ffn_t p) {
         for (int r = 0; r < 4; ++r) xs[(i * 16 + fq * 4 + r) * XS_LD + wq * 64 + j * 16 + fr] = yacc[i][j][r];
   }
   __syncthreads();
+
+  // ---- output rows: LDS -> 16-byte row stores (all 512 threads) ----
   const unsigned thr_out = eamd_drop_thr16(p.p_out);
   const float inv_out = eamd_drop_inv(thr_out);
   const unsigned seed_out = (!BWD && p.p_out > 0.f) ? eamd_drop_seed((const unsigned long long*)p.drop_step, p.salt_out) : 0u;
@@ -439,6 +475,12 @@ int check_ffn(const eamd_ffn_t* p, bool bwd) {
 }
 
 }  // namespace
+
+#ifdef FFN_STAMP
+extern "C" int eamd_ffn_debug_stamps(unsigned long long* host) {
+  return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(ffn_stamps), sizeof(ffn_stamps));
+}
+#endif
 
 extern "C" int eamd_ffn_fwd(const eamd_ffn_t* p, void* stream) {
   const int rc = check_ffn(p, false);

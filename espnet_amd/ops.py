@@ -467,6 +467,7 @@ def _ffn_desc(x, w1, b1, w2, b2, R, out, f, h, act, alpha, drop):
     p.p_in, p.salt_in, p.p_out, p.salt_out = float(p_in), int(s_in), float(p_out), int(s_out)
     if p_in > 0.0 or p_out > 0.0:
         p.drop_step = ptr(rng_state(x.device))
+    p.reserved = int(os.environ.get("EAMD_FFN_DEBUG", "0"))
     return p
 
 
