@@ -442,6 +442,336 @@ __global__ __launch_bounds__(FNT, 2) void ffn_f32_kernel(const eamd_ffn_t p) {
   }
 }
 
+// ------------------------------------------------------------------------------------------------------------------
+// Version 3: weights straight from global memory into MFMA operand registers.
+// No weight element is shared between waves of a workgroup (an up wave owns 32 hidden columns of the chunk, a down wave
+// 64 output columns), so staging the tiles through LDS only bought a layout change - and cost four ds_write_b128 per
+// thread and step, the fragment reads, and ONE BARRIER PER STEP that made the two waves of every SIMD wait for each
+// other 140 times per launch.  Here a lane fetches its own operand fragments (16 bytes along k for the k-contiguous
+// forward weights; along n for the k-strided backward weights, the output columns of a tile being interleaved to
+// match) three steps ahead into a ring of four register sets; LDS holds only the 32 input rows and the hidden-unit
+// chunks, and the roles meet at ONE barrier per chunk (256 MFMAs per wave): the up waves' epilogue arithmetic no longer
+// holds the down waves back.
+//   period P (8 steps): up waves form chunk P and run the epilogue of chunk P - 1 in steps 0-3 (one quarter each);
+//   down waves contract chunk P - 2; barrier at the end of every period.
+constexpr int D_SMEM_FLOATS = XS_SZ + 4 * HS_SZ;      // input rows + 2 hidden-unit chunks + (forward) 2 factor chunks
+
+template <bool BWD, int ACT>
+__global__ __launch_bounds__(FNT, 2) void ffn_f32_direct_kernel(const eamd_ffn_t p) {
+  extern __shared__ __attribute__((aligned(16))) float sm[];
+  float* const xs = sm;
+  float* const hs = xs + XS_SZ;
+  float* const fs = hs + 2 * HS_SZ;     // forward: the factor chunks, staged like h for the down waves' 16-byte global stores
+  const int t = threadIdx.x;
+  const int lane = t & 63, wave = __builtin_amdgcn_readfirstlane(t >> 6);
+  const bool up = wave < 4;
+  const int wq = wave & 3;
+  const int fr = lane & 15, fq = lane >> 4;
+  const int m0 = blockIdx.x * FBM;
+  const int F = p.F;
+  const int nch = F / FHC;
+  const int nsteps = 8 * nch;
+  const bool full_rows = m0 + FBM <= p.M;
+  using T_ = std::true_type;
+  using F_ = std::false_type;
+
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int idx = t + FNT * i, row = idx >> 6, c4 = idx & 63;
+    *reinterpret_cast<f32x4*>(&xs[row * XS_LD + c4 * 4]) =
+        *reinterpret_cast<const f32x4*>(p.x + (long)min(m0 + row, p.M - 1) * FD + c4 * 4);
+  }
+  __syncthreads();
+
+  if (up) {
+    // =============================== up waves ===============================
+    const float* __restrict__ W = BWD ? p.w2 : p.w1;
+    // column of accumulator tile j inside the chunk: forward j*16 + fr; backward (float2 fragments along n) 2*fr + j
+    const int lc0 = BWD ? wq * 32 + 2 * fr : wq * 32 + fr;
+    constexpr int LCJ = BWD ? 1 : 16;
+    const unsigned boff = BWD ? (unsigned)(((fq * 4) * F + wq * 32 + 2 * fr) * 4) : (unsigned)(((wq * 32 + fr) * FD + fq * 4) * 4);
+    f32x4 bs[4][4];            // forward: [set][q*2 + j] = 4 k-elements;  backward: [set][q*2 + e/2] = (e even: j0 j1, e odd: j0 j1)
+    f32x4 zacc[2][2], zold[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int j = 0; j < 2; ++j) { zacc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f}; zold[i][j] = zacc[i][j]; }
+    const unsigned thr_in = eamd_drop_thr16(p.p_in);
+    const float inv_in = p.p_in > 0.f ? eamd_drop_inv(thr_in) : 1.f;
+    const unsigned seed_in = (!BWD && p.p_in > 0.f) ? eamd_drop_seed((const unsigned long long*)p.drop_step, p.salt_in) : 0u;
+    float bpre[2] = {0.f, 0.f};
+    float fpre[2][2][4];
+    const unsigned e_toff = (unsigned)(((fq * 4) * F + lc0) * 4);
+
+    auto load_b = [&](auto set_c, int g) __attribute__((always_inline)) {
+      constexpr int SET = decltype(set_c)::value;
+      const int gc = min(g, nsteps - 1);
+      const int c = gc >> 3, s = gc & 7;
+      if constexpr (!BWD) {
+        const char* base = reinterpret_cast<const char*>(W + (long)(c * FHC) * FD + s * 32);
+#pragma unroll
+        for (int q = 0; q < 2; ++q)
+#pragma unroll
+          for (int j = 0; j < 2; ++j)
+            bs[SET][q * 2 + j] = *reinterpret_cast<const f32x4*>(base + ((long)(j * 16) * FD + q * 16) * 4 + boff);
+      } else {
+        const char* base = reinterpret_cast<const char*>(W + (long)(s * 32) * F + c * FHC);
+#pragma unroll
+        for (int q = 0; q < 2; ++q)
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            const float2 v = *reinterpret_cast<const float2*>(base + ((long)(q * 16 + e) * F) * 4 + boff);
+            bs[SET][q * 2 + (e >> 1)][(e & 1) * 2] = v.x;
+            bs[SET][q * 2 + (e >> 1)][(e & 1) * 2 + 1] = v.y;
+          }
+      }
+    };
+    float fA[2][2][4];
+    auto read_a = [&](auto s_c, auto half_c) __attribute__((always_inline)) {
+      constexpr int s = decltype(s_c)::value, hh = decltype(half_c)::value;
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        const float4 v = *reinterpret_cast<const float4*>(&xs[(i * 16 + fr) * XS_LD + s * 32 + hh * 16 + fq * 4]);
+        fA[hh][i][0] = v.x; fA[hh][i][1] = v.y; fA[hh][i][2] = v.z; fA[hh][i][3] = v.w;
+      }
+    };
+    auto mfma_half = [&](auto set_c, auto half_c) __attribute__((always_inline)) {
+      constexpr int SET = decltype(set_c)::value, q = decltype(half_c)::value;
+#pragma unroll
+      for (int e = 0; e < 4; ++e)
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+          for (int j = 0; j < 2; ++j) {
+            const float b = BWD ? bs[SET][q * 2 + (e >> 1)][(e & 1) * 2 + j] : bs[SET][q * 2 + j][e];
+            zacc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(fA[q][i][e], b, zacc[i][j], 0, 0, 0);
+          }
+    };
+    // epilogue of rows i*16 + fq*4 + r (r = 0..3) x column tile j of chunk c
+    auto epi_quarter = [&](auto i_c, auto j_c, int c) __attribute__((always_inline)) {
+      constexpr int i = decltype(i_c)::value, j = decltype(j_c)::value;
+      float* hp = hs + (c & 1) * HS_SZ;
+      const int lc = lc0 + j * LCJ;
+      float hv[4], fv[4];
+      if constexpr (!BWD) {
+        const float bj = bpre[j];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) eamd_act_dact(zold[i][j][r] + bj, ACT, hv[r], fv[r]);
+        if (p.p_in > 0.f) {
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const unsigned gi = (unsigned)(m0 + i * 16 + fq * 4 + r) * (unsigned)F + (unsigned)(c * FHC + lc);
+            const bool keep = eamd_drop_keep(seed_in, (unsigned long long)gi, thr_in);
+            hv[r] = keep ? hv[r] * inv_in : 0.f;
+            fv[r] = keep ? fv[r] * inv_in : 0.f;
+          }
+        }
+      } else {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) hv[r] = (zold[i][j][r] * fpre[i][j][r]) * p.alpha;
+      }
+#pragma unroll
+      for (int r = 0; r < 4; ++r) hp[(i * 16 + fq * 4 + r) * HS_LD + lc] = hv[r];
+      // the copies for backward (h, f) leave from LDS: the down waves store them as whole 16-byte row pieces next period
+      if constexpr (!BWD) {
+        float* fp = fs + (c & 1) * HS_SZ;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) fp[(i * 16 + fq * 4 + r) * HS_LD + lc] = fv[r];
+      }
+    };
+    auto load_f = [&](int c) __attribute__((always_inline)) {
+      const char* base = reinterpret_cast<const char*>(p.f + (long)m0 * F + c * FHC);
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const long ro = full_rows ? (long)(i * 16 + r) * F : (long)(min(m0 + i * 16 + fq * 4 + r, p.M - 1) - m0 - fq * 4) * F;
+          const float2 v = *reinterpret_cast<const float2*>(base + ro * 4 + e_toff);       // columns 2 fr, 2 fr + 1 = tiles 0, 1
+          fpre[i][0][r] = v.x; fpre[i][1][r] = v.y;
+        }
+    };
+    auto step = [&](auto s_c, auto up_c, auto epi_c, int P) __attribute__((always_inline)) {
+      constexpr int s = decltype(s_c)::value;
+      constexpr bool UP = decltype(up_c)::value, EPI = decltype(epi_c)::value;
+      if constexpr (UP) {
+        load_b(std::integral_constant<int, (s + 3) & 3>{}, 8 * P + s + 3);
+        if constexpr (s == 4) {      // behind the last epilogue quarter of the previous chunk (step 3), which still reads them
+          if constexpr (BWD) load_f(P);
+          else if (p.b1) { bpre[0] = p.b1[P * FHC + lc0]; bpre[1] = p.b1[P * FHC + lc0 + 16]; }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        read_a(s_c, std::integral_constant<int, 1>{});
+        mfma_half(std::integral_constant<int, s & 3>{}, std::integral_constant<int, 0>{});
+      }
+      if constexpr (EPI && s < 4) epi_quarter(std::integral_constant<int, s & 1>{}, std::integral_constant<int, (s / 2)>{}, P - 1);
+      if constexpr (UP) {
+        __builtin_amdgcn_sched_barrier(0);
+        read_a(std::integral_constant<int, (s + 1) & 7>{}, std::integral_constant<int, 0>{});
+        mfma_half(std::integral_constant<int, s & 3>{}, std::integral_constant<int, 1>{});
+        if constexpr (s == 7) {
+#pragma unroll
+          for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j) { zold[i][j] = zacc[i][j]; zacc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f}; }
+        }
+      }
+      if constexpr (s == 7) __syncthreads();
+    };
+    auto period = [&](auto up_c, auto epi_c, int P) __attribute__((always_inline)) {
+      step(std::integral_constant<int, 0>{}, up_c, epi_c, P);
+      step(std::integral_constant<int, 1>{}, up_c, epi_c, P);
+      step(std::integral_constant<int, 2>{}, up_c, epi_c, P);
+      step(std::integral_constant<int, 3>{}, up_c, epi_c, P);
+      step(std::integral_constant<int, 4>{}, up_c, epi_c, P);
+      step(std::integral_constant<int, 5>{}, up_c, epi_c, P);
+      step(std::integral_constant<int, 6>{}, up_c, epi_c, P);
+      step(std::integral_constant<int, 7>{}, up_c, epi_c, P);
+    };
+    load_b(std::integral_constant<int, 0>{}, 0);
+    load_b(std::integral_constant<int, 1>{}, 1);
+    load_b(std::integral_constant<int, 2>{}, 2);
+    read_a(std::integral_constant<int, 0>{}, std::integral_constant<int, 0>{});
+    period(T_{}, F_{}, 0);
+    for (int P = 1; P < nch; ++P) period(T_{}, T_{}, P);
+    period(F_{}, T_{}, nch);
+    period(F_{}, F_{}, nch + 1);
+  } else {
+    // =============================== down waves ===============================
+    const float* __restrict__ W = BWD ? p.w1 : p.w2;
+    const unsigned boff = BWD ? (unsigned)(((fq * 4) * FD + wq * 64 + 4 * fr) * 4) : (unsigned)(((wq * 64 + fr) * F + fq * 4) * 4);
+    f32x4 bs[4][4];            // forward: [set][j] = 4 k-elements of column tile j;  backward: [set][e] = column tiles 0..3 at k = fq*4 + e
+    f32x4 yacc[2][4];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) yacc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    auto load_b = [&](auto set_c, int gd) __attribute__((always_inline)) {
+      constexpr int SET = decltype(set_c)::value;
+      const int gc = min(max(gd, 0), nsteps - 1);
+      const int cd = gc >> 3, sd = gc & 7;
+      if constexpr (!BWD) {
+        const char* base = reinterpret_cast<const char*>(W + cd * FHC + sd * 16);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) bs[SET][j] = *reinterpret_cast<const f32x4*>(base + ((long)(j * 16) * F) * 4 + boff);
+      } else {
+        const char* base = reinterpret_cast<const char*>(W + (long)(cd * FHC + sd * 16) * FD);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) bs[SET][e] = *reinterpret_cast<const f32x4*>(base + ((long)e * FD) * 4 + boff);
+      }
+    };
+    float fA[2][2][4];         // [step parity][row tile][4 k-elements]
+    auto read_a = [&](auto par_c, int sd, int hbuf) __attribute__((always_inline)) {
+      constexpr int PAR = decltype(par_c)::value;
+      const float* hp = hs + hbuf * HS_SZ;
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        const float4 v = *reinterpret_cast<const float4*>(&hp[(i * 16 + fr) * HS_LD + sd * 16 + fq * 4]);
+        fA[PAR][i][0] = v.x; fA[PAR][i][1] = v.y; fA[PAR][i][2] = v.z; fA[PAR][i][3] = v.w;
+      }
+    };
+    auto mfma_step = [&](auto set_c, auto par_c) __attribute__((always_inline)) {
+      constexpr int SET = decltype(set_c)::value, PAR = decltype(par_c)::value;
+#pragma unroll
+      for (int e = 0; e < 4; ++e)
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            const float b = BWD ? bs[SET][e][j] : bs[SET][j][e];
+            yacc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(fA[PAR][i][e], b, yacc[i][j], 0, 0, 0);
+          }
+    };
+    // period P contracts chunk P - 2 (D: 2 <= P <= nch + 1); DN = the next period is a down period too (prefetch target)
+    auto step = [&](auto s_c, auto d_c, auto dn_c, int P) __attribute__((always_inline)) {
+      constexpr int s = decltype(s_c)::value;
+      constexpr bool D = decltype(d_c)::value, DN = decltype(dn_c)::value;
+      const int gd = 8 * (P - 2) + s;
+      if constexpr (s + 3 < 8 ? D : DN) load_b(std::integral_constant<int, (s + 3) & 3>{}, gd + 3);
+      if constexpr (D && (s == 1 || s == 3)) {
+        // global copies of chunk P - 2 for backward (forward: h at s = 1, f at s = 3; backward: dz at s = 1): 32 rows x 512 bytes
+        // from the LDS image, four 16-byte pieces per lane
+        float* dstp = (s == 1) ? p.h : (BWD ? nullptr : p.f);
+        if (dstp) {
+          const float* src = (s == 1 ? hs : fs) + (P & 1) * HS_SZ;
+          const int dt = t - 256;
+#pragma unroll
+          for (int k = 0; k < 4; ++k) {
+            const int idx = dt + 256 * k, lr = idx >> 5, c4 = idx & 31;
+            if (full_rows || m0 + lr < p.M)
+              *reinterpret_cast<float4*>(dstp + (long)(m0 + lr) * F + (P - 2) * FHC + c4 * 4) =
+                  *reinterpret_cast<const float4*>(&src[lr * HS_LD + c4 * 4]);
+          }
+        }
+      }
+      if constexpr (D) {
+        __builtin_amdgcn_sched_barrier(0);
+        if constexpr (s < 7) read_a(std::integral_constant<int, (s + 1) & 1>{}, s + 1, P & 1);
+        mfma_step(std::integral_constant<int, s & 3>{}, std::integral_constant<int, s & 1>{});
+      }
+      if constexpr (s == 7) {
+        __syncthreads();
+        if constexpr (DN) read_a(std::integral_constant<int, 0>{}, 0, (P + 1) & 1);      // chunk P - 1 is complete behind this barrier
+      }
+    };
+    auto period = [&](auto d_c, auto dn_c, int P) __attribute__((always_inline)) {
+      step(std::integral_constant<int, 0>{}, d_c, dn_c, P);
+      step(std::integral_constant<int, 1>{}, d_c, dn_c, P);
+      step(std::integral_constant<int, 2>{}, d_c, dn_c, P);
+      step(std::integral_constant<int, 3>{}, d_c, dn_c, P);
+      step(std::integral_constant<int, 4>{}, d_c, dn_c, P);
+      step(std::integral_constant<int, 5>{}, d_c, dn_c, P);
+      step(std::integral_constant<int, 6>{}, d_c, dn_c, P);
+      step(std::integral_constant<int, 7>{}, d_c, dn_c, P);
+    };
+    period(F_{}, F_{}, 0);
+    period(F_{}, T_{}, 1);
+    for (int P = 2; P <= nch; ++P) period(T_{}, T_{}, P);
+    period(T_{}, F_{}, nch + 1);
+    // output rows: accumulators -> LDS over the input rows (the up waves read those for the last time two periods ago)
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        if constexpr (BWD) {
+          *reinterpret_cast<float4*>(&xs[(i * 16 + fq * 4 + r) * XS_LD + wq * 64 + 4 * fr]) =
+              make_float4(yacc[i][0][r], yacc[i][1][r], yacc[i][2][r], yacc[i][3][r]);
+        } else {
+#pragma unroll
+          for (int j = 0; j < 4; ++j) xs[(i * 16 + fq * 4 + r) * XS_LD + wq * 64 + j * 16 + fr] = yacc[i][j][r];
+        }
+      }
+  }
+  __syncthreads();
+  const unsigned thr_out = eamd_drop_thr16(p.p_out);
+  const float inv_out = eamd_drop_inv(thr_out);
+  const unsigned seed_out = (!BWD && p.p_out > 0.f) ? eamd_drop_seed((const unsigned long long*)p.drop_step, p.salt_out) : 0u;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int idx = t + FNT * i, lr = idx >> 6, c4 = idx & 63;
+    const int row = m0 + lr;
+    if (row >= p.M) continue;
+    const float4 a4 = *reinterpret_cast<const float4*>(&xs[lr * XS_LD + c4 * 4]);
+    float v[4] = {a4.x, a4.y, a4.z, a4.w};
+    const long gi = (long)row * FD + c4 * 4;
+    if constexpr (!BWD) {
+      if (p.b2) {
+        const float4 b4 = *reinterpret_cast<const float4*>(p.b2 + c4 * 4);
+        v[0] += b4.x; v[1] += b4.y; v[2] += b4.z; v[3] += b4.w;
+      }
+      if (p.p_out > 0.f) {
+        bool keep[4];
+        eamd_drop_keep4(seed_out, (unsigned long long)gi, thr_out, keep);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] = keep[e] ? v[e] * inv_out : 0.f;
+      }
+      float4 r4 = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (p.R) r4 = *reinterpret_cast<const float4*>(p.R + gi);
+      v[0] = v[0] * p.alpha + r4.x; v[1] = v[1] * p.alpha + r4.y; v[2] = v[2] * p.alpha + r4.z; v[3] = v[3] * p.alpha + r4.w;
+    }
+    *reinterpret_cast<float4*>(p.out + gi) = make_float4(v[0], v[1], v[2], v[3]);
+  }
+}
+
 bool al16(const void* q) { return (reinterpret_cast<uintptr_t>(q) & 15) == 0; }
 
 template <bool BWD, int ACT>
@@ -451,6 +781,15 @@ int launch_ffn(const eamd_ffn_t& p, hipStream_t stream) {
                                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
   if (attr_err != hipSuccess) return (int)attr_err;
   const int nblk = (p.M + FBM - 1) / FBM;
+  if (!(p.reserved & 32)) {      // default: the register-direct version (bit 5 of `reserved` selects the LDS-staged one)
+    constexpr size_t smem_d = (size_t)D_SMEM_FLOATS * sizeof(float);
+    static const hipError_t attr_err_d = hipFuncSetAttribute(reinterpret_cast<const void*>(&ffn_f32_direct_kernel<BWD, ACT>),
+                                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem_d);
+    if (attr_err_d != hipSuccess) return (int)attr_err_d;
+    hipLaunchKernelGGL((ffn_f32_direct_kernel<BWD, ACT>), dim3(nblk), dim3(FNT), smem_d, stream, p);
+    EAMD_LAUNCH_CHECK();
+    return EAMD_OK;
+  }
   hipLaunchKernelGGL((ffn_f32_kernel<BWD, ACT>), dim3(nblk), dim3(FNT), smem, stream, p);
   EAMD_LAUNCH_CHECK();
   return EAMD_OK;

@@ -224,7 +224,7 @@ class FFNBlockFn(torch.autograd.Function):
                 and ops.ffn_fused_ok(xn, w1, w2, act)):
             # fp32 mode, d = 256: BOTH products in one launch (csrc/ffn_f32.hip) - 32 rows per workgroup, the hidden units
             # never make a round trip for the second product; kept for backward: h and the factor f (no grad: neither)
-            need = torch.is_grad_enabled() and any(ctx.needs_input_grad[:7])
+            need = any(ctx.needs_input_grad[:7])          # (grad mode is off inside forward: needs_input_grad tells no-grad calls apart)
             out, z, h = ops.ffn_fwd(xn, w1, b1, w2, b2, act=act, alpha=scale, R=x2, drop=(p_in, s_in, p_out, s_out), save=need)
             ctx.save_for_backward(x2, mean, rstd, xn, z, h)
             ctx.pr = GradSink.use((ln_w, ln_b, w1, b1, w2, b2))

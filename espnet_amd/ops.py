@@ -250,7 +250,7 @@ GROUP_WGRAD_TILE128_MIN = int(os.environ.get("EAMD_GROUP_T128_MIN", "100"))
 GROUP_WGRAD_T128_WGS = int(os.environ.get("EAMD_GROUP_T128_WGS", "96"))
 # operand bytes the queue may keep alive before it is flushed early (the operands of every queued problem stay
 # allocated until the grouped launch has been issued)
-GROUP_WGRAD_MAX_BYTES = int(os.environ.get("EAMD_GROUP_MAX_BYTES", str(4 << 30)))
+GROUP_WGRAD_MAX_BYTES = int(os.environ.get("EAMD_GROUP_MAX_BYTES", str(16 << 30)))     # config 2 queues 4.6 GB per backward pass
 _wgroup = {"on": False, "items": [], "ranges": [], "bytes": 0, "stack": {}, "pinned": [], "reserve": [], "arenas": {}}
 
 
