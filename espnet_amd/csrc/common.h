@@ -20,7 +20,10 @@ typedef __attribute__((ext_vector_type(8))) short bf16x8;
 typedef __attribute__((ext_vector_type(4))) short bf16x4;
 
 // activation ids shared by host and device
-enum { EAMD_ACT_NONE = 0, EAMD_ACT_RELU = 1, EAMD_ACT_SWISH = 2, EAMD_ACT_TANH = 3 };
+// (reference: nets_utils.py:485-498 get_activation - hardtanh, tanh, relu, selu, swish)
+enum { EAMD_ACT_NONE = 0, EAMD_ACT_RELU = 1, EAMD_ACT_SWISH = 2, EAMD_ACT_TANH = 3, EAMD_ACT_HARDTANH = 4, EAMD_ACT_SELU = 5 };
+#define EAMD_SELU_ALPHA 1.6732632423543772848170429916717f
+#define EAMD_SELU_SCALE 1.0507009873554804934193349852946f
 
 // v_exp_f32 + v_rcp_f32 (1 ulp each); an IEEE division here costs ten more VALU instructions per element, which the
 // GEMM epilogues (Swish / its derivative on every FFN hidden unit) cannot hide
@@ -35,6 +38,8 @@ __device__ __forceinline__ float eamd_act(float x, int act) {
   if (act == EAMD_ACT_RELU) return x > 0.f ? x : 0.f;
   if (act == EAMD_ACT_SWISH) return eamd_swish(x);
   if (act == EAMD_ACT_TANH) return tanhf(x);
+  if (act == EAMD_ACT_HARDTANH) return fminf(fmaxf(x, -1.f), 1.f);
+  if (act == EAMD_ACT_SELU) return EAMD_SELU_SCALE * (x > 0.f ? x : EAMD_SELU_ALPHA * expm1f(x));
   return x;
 }
 // activation and its derivative from ONE sigmoid / tanh (the FFN forward's factor epilogue needs both per element)
@@ -49,6 +54,13 @@ __device__ __forceinline__ void eamd_act_dact(float x, int act, float& a, float&
   } else if (act == EAMD_ACT_TANH) {
     a = tanhf(x);
     d = 1.f - a * a;
+  } else if (act == EAMD_ACT_HARDTANH) {
+    a = fminf(fmaxf(x, -1.f), 1.f);
+    d = (x > -1.f && x < 1.f) ? 1.f : 0.f;
+  } else if (act == EAMD_ACT_SELU) {
+    const float ex = EAMD_SELU_ALPHA * expm1f(x);
+    a = EAMD_SELU_SCALE * (x > 0.f ? x : ex);
+    d = EAMD_SELU_SCALE * (x > 0.f ? 1.f : ex + EAMD_SELU_ALPHA);
   } else {
     a = x;
     d = 1.f;
@@ -59,6 +71,8 @@ __device__ __forceinline__ float eamd_dact(float x, int act) {
   if (act == EAMD_ACT_RELU) return x > 0.f ? 1.f : 0.f;
   if (act == EAMD_ACT_SWISH) return eamd_dswish(x);
   if (act == EAMD_ACT_TANH) { float t = tanhf(x); return 1.f - t * t; }
+  if (act == EAMD_ACT_HARDTANH) return (x > -1.f && x < 1.f) ? 1.f : 0.f;
+  if (act == EAMD_ACT_SELU) return EAMD_SELU_SCALE * (x > 0.f ? 1.f : EAMD_SELU_ALPHA * __expf(x));
   return 1.f;
 }
 

@@ -482,6 +482,7 @@ __global__ __launch_bounds__(256) void bn_bwd_partial_kernel(const float* __rest
       float d = dp[e];   // rows past M hold dy = 0 => contribute nothing
       if (act == EAMD_ACT_SWISH) d *= eamd_dswish(z);
       else if (act == EAMD_ACT_RELU) d = z > 0.f ? d : 0.f;
+      else if (act != EAMD_ACT_NONE) d *= eamd_dact(z, act);
       a1[e] += d; a2[e] += d * xh;
     }
   }
@@ -549,6 +550,7 @@ __global__ void bn_bwd_apply_kernel(const float* __restrict__ dy, const float* _
     float d = dy[i];
     if (act == EAMD_ACT_SWISH) d *= eamd_dswish(z);
     else if (act == EAMD_ACT_RELU) d = z > 0.f ? d : 0.f;
+    else if (act != EAMD_ACT_NONE) d *= eamd_dact(z, act);
     if (training) dx[i] = g * rs * (d - sums[c] * invM - xh * sums[C + c] * invM);
     else dx[i] = g * rs * d;
   }

@@ -233,6 +233,28 @@ class FFNBlockFn(torch.autograd.Function):
             ctx.prev = _prev_drop(x)
             return _tag_out(out.view(shp), p_out, s_out)
         ctx.one_launch = False
+        if act not in (ACT_RELU, ACT_SWISH):
+            # hardtanh / tanh / selu (nets_utils.py:485-498): with inner dropout the dual-output epilogue below is generic
+            # over eamd_act ids; without it the activation is its own pass (eamd_act_fwd / _bwd) - no staging-side variant
+            if not (p_in > 0.0 and (fused or ops.f32_epilogue_drop())):
+                z = ops.linear_fwd(xn, ops.wshadow(w1), b1)
+                h = ops.act_fwd_any(z, act)
+                if p_in > 0.0:
+                    h = ops.dropout(h, p_in, s_in)
+                hop = ops.to_act(h)
+                if p_out > 0.0 and (fused or ops.f32_epilogue_drop()):
+                    out = ops.linear_fwd(hop, ops.wshadow(w2), b2, R=x2 if eps is not None else None, alpha=scale, drop=(p_out, s_out))
+                elif p_out > 0.0:
+                    out = ops.axpby(x2, ops.dropout(ops.linear_fwd(hop, ops.wshadow(w2), b2), p_out, s_out), 1.0, scale)
+                else:
+                    out = ops.linear_fwd(hop, ops.wshadow(w2), b2, R=x2 if eps is not None else None, alpha=scale)
+                ctx.save_for_backward(x2, mean, rstd, xn, z, hop)
+                ctx.pr = GradSink.use((ln_w, ln_b, w1, b1, w2, b2))
+                ctx.cfg = (scale, act, shp, drop)
+                ctx.in_opd, ctx.zf, ctx.generic_act = False, False, True
+                ctx.prev = _prev_drop(x)
+                return _tag_out(out.view(shp), p_out, s_out)
+        ctx.generic_act = False
         if p_in > 0.0 and (fused or (ops.f32_epilogue_drop() and not ops.f32_operand_drop())):
             # z and h = dropout(act(z)) from one launch (second output of the epilogue), in the operand dtype
             # ... and what is kept for backward is not z but the ready factor f = mask / (1 - p) * act'(z): the input-gradient
@@ -280,6 +302,15 @@ class FFNBlockFn(torch.autograd.Function):
         else:                                         # dW2 += s * drop(do)^T drop(act(z))
             ops.linear_bwd_w(dob, z, sink.buf(4), alpha=scale, b_act=act, db=sink.buf(5), a_drop=g_drop,
                              b_drop=(p_in, s_in) if ctx.in_opd else None)
+        if getattr(ctx, "generic_act", False):
+            dh = ops.linear_bwd_x(dob, ops.wshadow(w2), alpha=scale, a_drop=g_drop)
+            if p_in > 0.0:
+                dh = ops.dropout(dh, p_in, s_in)
+            dz = ops.to_act(ops.act_bwd_any(dh, z, act))
+            ops.linear_bwd_w(dz, xn, sink.buf(2), db=sink.buf(3))
+            dxn = ops.linear_bwd_x(dz, ops.wshadow(w1))
+            dx = _ln_bwd_out(dxn, x2, ln_w, mean, rstd, do, sink.buf(0), sink.buf(1), ctx.prev, shp)
+            return (dx,) + sink.results() + (None, None, None, None)
         if ctx.one_launch and g_drop is None and dob.dtype == torch.float32:
             dz, dxn = ops.ffn_bwd(dob, w1, w2, z, alpha=scale)          # dz = s (dob W2) (.) f and dxn = dz W1: one launch
             ops.linear_bwd_w(dz, xn, sink.buf(2), db=sink.buf(3))

@@ -27,7 +27,15 @@ def _act_id(activation_type):
         return ops.ACT_SWISH
     if activation_type == "relu" or isinstance(activation_type, torch.nn.ReLU):
         return ops.ACT_RELU
-    raise NotImplementedError(f"activation {activation_type!r} has no HIP kernel (relu, swish supported)")
+    if activation_type == "tanh" or isinstance(activation_type, torch.nn.Tanh):
+        return ops.ACT_TANH
+    if activation_type == "hardtanh" or isinstance(activation_type, torch.nn.Hardtanh):
+        if isinstance(activation_type, torch.nn.Hardtanh) and (activation_type.min_val, activation_type.max_val) != (-1.0, 1.0):
+            raise NotImplementedError("Hardtanh: only the default range [-1, 1] (get_activation's) has a HIP kernel")
+        return ops.ACT_HARDTANH
+    if activation_type == "selu" or isinstance(activation_type, torch.nn.SELU):
+        return ops.ACT_SELU
+    raise NotImplementedError(f"activation {activation_type!r} has no HIP kernel (hardtanh, tanh, relu, selu, swish)")
 
 
 def _p(module, p):
@@ -47,9 +55,9 @@ class Swish(torch.nn.Module):
 
 def get_activation(act):
     """reference: nets_utils.py:485-498"""
-    table = {"relu": torch.nn.ReLU, "swish": Swish}
-    if act not in table:
-        raise NotImplementedError(f"activation {act!r}: only relu and swish have HIP kernels")
+    # the returned module is what the reference hands to PositionwiseFeedForward / ConvolutionModule; those shells map it
+    # to an eamd_act id (_act_id) for their fused blocks, so torch's own kernels never run on the path
+    table = {"hardtanh": torch.nn.Hardtanh, "tanh": torch.nn.Tanh, "relu": torch.nn.ReLU, "selu": torch.nn.SELU, "swish": Swish}
     return table[act]()
 
 
@@ -223,14 +231,28 @@ class Conv2dSubsampling(torch.nn.Module):
         self.out = torch.nn.Sequential(
             torch.nn.Linear(odim * (((idim - 1) // 2 - 1) // 2), odim),
             pos_enc if pos_enc is not None else PositionalEncoding(odim, dropout_rate))
-        if odim % 64 != 0:
-            raise NotImplementedError("Conv2dSubsampling HIP path needs odim % 64 == 0 (implicit-GEMM tiles)")
+
+    def _params(self):
+        """(c1_w, c1_b, lin_w, lin_b, [w, b of every C -> C stage]).  The implicit-GEMM convolutions gather whole 64-channel
+        pieces, so an odim that is not a multiple of 64 (subsampling.py:14-59 takes any) runs with its channel axis
+        zero-padded to the next one: zero filters give ReLU(0) = 0 channels that meet zero weights downstream, and autograd
+        slices the padded gradients back into the parameters."""
+        c1_w, c1_b, lin_w, lin_b = self.conv[0].weight, self.conv[0].bias, self.out[0].weight, self.out[0].bias
+        stages = [t for i in range(2, len(self.conv), 2) for t in (self.conv[i].weight, self.conv[i].bias)]
+        C = c1_w.shape[0]
+        pad = (-C) % 64
+        if pad:
+            pd = torch.nn.functional.pad
+            c1_w, c1_b = pd(c1_w, (0, 0, 0, 0, 0, 0, 0, pad)), pd(c1_b, (0, pad))
+            stages = [pd(t, (0, 0, 0, 0, 0, pad, 0, pad)) if t.dim() == 4 else pd(t, (0, pad)) for t in stages]
+            D, CW = lin_w.shape
+            lin_w = pd(lin_w.view(D, C, CW // C), (0, 0, 0, pad)).reshape(D, (C + pad) * (CW // C))      # columns are (c, f)
+        return c1_w, c1_b, lin_w, lin_b, stages
 
     def forward(self, x, x_mask):
         pos = self.out[1]
-        stages = [t for i in range(2, len(self.conv), 2) for t in (self.conv[i].weight, self.conv[i].bias)]
-        y = F_.Conv2dSubsamplingFn.apply(x, pos.xscale, self.conv[0].weight, self.conv[0].bias, self.out[0].weight,
-                                         self.out[0].bias, *stages)
+        c1_w, c1_b, lin_w, lin_b, stages = self._params()
+        y = F_.Conv2dSubsamplingFn.apply(x, pos.xscale, c1_w, c1_b, lin_w, lin_b, *stages)
         if isinstance(pos, RelPositionalEncoding):
             pe = pos.pos_emb(y.size(1), y.device).unsqueeze(0)
             y = (F_.dropout(y, pos.dropout_rate, pos.salt, pos.training),
@@ -258,8 +280,6 @@ class Conv2dSubsampling8(Conv2dSubsampling):
         self.out = torch.nn.Sequential(
             torch.nn.Linear(odim * ((((idim - 1) // 2 - 1) // 2 - 1) // 2), odim),
             pos_enc if pos_enc is not None else PositionalEncoding(odim, dropout_rate))
-        if odim % 64 != 0:
-            raise NotImplementedError("Conv2dSubsampling HIP path needs odim % 64 == 0 (implicit-GEMM tiles)")
 
     def forward(self, x, x_mask):
         y, m = super().forward(x, None if x_mask is None else x_mask)
@@ -278,8 +298,6 @@ class Conv2dSubsampling6(Conv2dSubsampling):
         self.out = torch.nn.Sequential(
             torch.nn.Linear(odim * (((idim - 1) // 2 - 2) // 3), odim),
             pos_enc if pos_enc is not None else PositionalEncoding(odim, dropout_rate))
-        if odim % 64 != 0:
-            raise NotImplementedError("Conv2dSubsampling HIP path needs odim % 64 == 0 (implicit-GEMM tiles)")
 
     def forward(self, x, x_mask):
         y, _ = super().forward(x, None)

@@ -467,7 +467,6 @@ def _ffn_desc(x, w1, b1, w2, b2, R, out, f, h, act, alpha, drop):
     p.p_in, p.salt_in, p.p_out, p.salt_out = float(p_in), int(s_in), float(p_out), int(s_out)
     if p_in > 0.0 or p_out > 0.0:
         p.drop_step = ptr(rng_state(x.device))
-    p.reserved = int(os.environ.get("EAMD_FFN_DEBUG", "0"))
     return p
 
 
@@ -1237,7 +1236,7 @@ def make_rowmap(Ho, Wo, Hc, Wc, sh, oh, sw, ow):
 
 
 # ---- recurrent layers / RNN-Transducer (rows a20, a21) -------------------------------------------
-ACT_TANH = 3
+ACT_TANH, ACT_HARDTANH, ACT_SELU = 3, 4, 5      # eamd_act ids beyond relu / swish (nets_utils.py:485-498)
 
 
 def act_fwd_any(x, act):
