@@ -43,6 +43,7 @@ struct AttnF32Args {
   float scale;
   // attention dropout (attention.py:91): Pd = dropout(P) feeds the context; mask index = element index in P
   float* Pd; float drop_p; const unsigned long long* drop_step; unsigned long long drop_salt;
+  const int* tshift;     // device scalar: length the legacy rel_shift works on (NULL: T2) - see eamd_attn_fwd
 };
 
 __device__ __forceinline__ float xmax16_32(float v) {
@@ -155,7 +156,16 @@ __global__ __launch_bounds__(256, NKT > 16 ? 1 : 2) void attn_f32_fwd_kernel(con
   const int qi = min(r0 + fr, T1 - 1);             // this lane's query (clamped lanes are never stored)
 
   float* X = reinterpret_cast<float*>(smem_raw);
+  // Ts: the length the legacy rel_shift is taken over.  A batch padded beyond its own longest utterance (shape-bucketed
+  // graphs) passes that utterance's length here: the shift then maps bd exactly as the reference's T' x T' matrix does;
+  // keys from Ts on are masked by the caller's mask, and the score matrix is cleared first so that the rows / columns the
+  // shift no longer reaches hold zeros instead of stale LDS.
+  const int Ts = (REL && a.tshift) ? min(max(a.tshift[0], 1), T2) : T2;
   if (REL) {
+    if (Ts < T2) {
+      for (int e = t; e < 64 * XLD; e += 256) X[e] = 0.f;
+      __syncthreads();
+    }
     // ---- bd, stored at its rel-shifted place: bd[i][m] -> (i, m - (T-1-i)) if m >= T-1-i, else (i - 1, m + i + 1).
     // The map is one-to-one; the only elements of a row it never reaches are (i, i + 1) - zeroed here - and, for the
     // last query of the workgroup, the part fed by bd row r0w + 64 (the dot products below) ----
@@ -173,19 +183,19 @@ __global__ __launch_bounds__(256, NKT > 16 ? 1 : 2) void attn_f32_fwd_kernel(con
       for (int qt = 0; qt < 4; ++qt) {
         const f32x4 c = dot_tile(pf, qf[qt], (f32x4){0.f, 0.f, 0.f, 0.f});   // c[r] = bd[query 16 qt + fr][m = 16 mt + 4 fq + r]
         const int ql = qt * 16 + fr, i = r0w + ql;
-        const int lim = T2 - 1 - i;
+        const int lim = Ts - 1 - i;
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
           const int m = mt * 16 + 4 * fq + r;
           const int row = m >= lim ? ql : ql - 1, j = m >= lim ? m - lim : m + i + 1;
-          if (m < T2 && ql < nq && row >= 0) X[row * XLD + j] = c[r];
+          if (m < Ts && i < Ts && ql < nq && row >= 0) X[row * XLD + j] = c[r];
         }
       }
     }
     const int i64 = r0w + 64;                        // first query of the next workgroup: its low positions feed query r0w + 63
-    if (live && i64 < T1) {
+    if (live && i64 < Ts) {
       const float4* qr = reinterpret_cast<const float4*>(a.qv + ((long)b * T1 + i64) * a.ldqv + h * ATT_DK);
-      for (int m = t; m <= T2 - 2 - i64; m += 256) {
+      for (int m = t; m <= Ts - 2 - i64; m += 256) {
         const float4* pr = reinterpret_cast<const float4*>(a.pos + (long)m * a.ldpos + h * ATT_DK);
         float s = 0.f;
 #pragma unroll
@@ -311,6 +321,7 @@ struct AttnF32BwdArgs {
   int B, H, T1, T2, nqb;
   float scale;
   float drop_p; const unsigned long long* drop_step; unsigned long long drop_salt;   // the forward's attention dropout
+  const int* tshift;
 };
 
 template <int NKT>
@@ -325,6 +336,7 @@ __global__ __launch_bounds__(256, NKT > 16 ? 1 : 2) void attn_f32_bwd_q_kernel(c
   const int zz = live ? z : 0;
   const int h = zz / a.B, b = zz % a.B;
   const int T1 = a.T1, T2 = a.T2;
+  const int Ts = (a.dbd && a.tshift) ? min(max(a.tshift[0], 1), T2) : T2;      // rel_shift length (see the forward kernel)
   const int r0w = min((jb % a.nqb) * 64, T1 - 1);
   const int nq = T1 - r0w;
   const int r0 = r0w + wave * 16;
@@ -383,9 +395,10 @@ __global__ __launch_bounds__(256, NKT > 16 ? 1 : 2) void attn_f32_bwd_q_kernel(c
         const float g = j < T2 ? pr[r] * (S[kt][r] - s) * a.scale : 0.f;
         S[kt][r] = g;
         if (a.dbd && qok) {
-          // inverse rel_shift for T1 == T2 = T: padded index T + i T + j lands in row i (j <= i) or row i + 1
-          if (j < T2) {
-            const int R = j <= i ? i : i + 1, c = j <= i ? T2 + j - i : j - i - 1;
+          // inverse rel_shift for T1 == T2 = T (Ts when the shift is shorter than the padded matrix: everything outside the
+          // Ts x Ts square is zero): padded index T + i T + j lands in row i (j <= i) or row i + 1
+          if (j < Ts && i < Ts) {
+            const int R = j <= i ? i : i + 1, c = j <= i ? Ts + j - i : j - i - 1;
             if (c != 0) a.dbd[zo + (long)R * a.ldp + (c - 1)] = g;
           } else if (j < (int)a.ldp) {
             a.dbd[zo + (long)i * a.ldp + j] = 0.f;    // pad columns of this row
@@ -395,7 +408,7 @@ __global__ __launch_bounds__(256, NKT > 16 ? 1 : 2) void attn_f32_bwd_q_kernel(c
       if (qok && j0 < (int)a.ldp) *reinterpret_cast<float4*>(srow + j0) = make_float4(S[kt][0], S[kt][1], S[kt][2], S[kt][3]);
     }
     if (a.dbd && r0 == 0)                            // the head of row 0 the scatter never reaches
-      for (int f = 1 + lane; f < T1; f += 64) a.dbd[zo + (f - 1)] = 0.f;
+      for (int f = 1 + lane; f < Ts; f += 64) a.dbd[zo + (f - 1)] = 0.f;
   } else {
 #pragma unroll
     for (int kt = 0; kt < NKT; ++kt) S[kt] = (f32x4){0.f, 0.f, 0.f, 0.f};
@@ -451,7 +464,7 @@ extern "C" int eamd_attn_fwd_f32(const float* qu, int64_t ldq, const float* qv, 
                                  const float* v, int64_t ldv, const float* pos, int64_t ldpos, const unsigned char* mask,
                                  int64_t mask_bstride, int64_t mask_qstride, float* P, int64_t ldp, float* ctx,
                                  int64_t ldc, int B, int H, int T1, int T2, int dk, float scale, float* Pd, float drop_p,
-                                 const uint64_t* drop_step, uint64_t drop_salt, void* stream) {
+                                 const uint64_t* drop_step, uint64_t drop_salt, const int32_t* shift_len, void* stream) {
   if (!qu || !k || !v || !P || !ctx || B <= 0 || H <= 0 || T1 <= 0 || T2 <= 0) return EAMD_EINVAL;
   if (drop_p < 0.f || drop_p >= 1.f || (drop_p > 0.f && (!Pd || !drop_step || !al16(Pd)))) return EAMD_EINVAL;
   if ((pos == nullptr) != (qv == nullptr)) return EAMD_EINVAL;
@@ -467,6 +480,7 @@ extern "C" int eamd_attn_fwd_f32(const float* qu, int64_t ldq, const float* qv, 
   a.mb = mask_bstride; a.mi = mask_qstride;
   a.B = B; a.H = H; a.T1 = T1; a.T2 = T2; a.nqb = (T1 + 63) / 64; a.scale = scale;
   a.Pd = Pd; a.drop_p = drop_p; a.drop_step = (const unsigned long long*)drop_step; a.drop_salt = drop_salt;
+  a.tshift = shift_len;
   const int nkt = T2 <= 128 ? 8 : T2 <= 256 ? 16 : 32;               // key tiles of 16 the instantiation covers
   const size_t smem = (size_t)nkt * 16 * PLD * sizeof(float);        // V panel (the score matrix X is smaller)
   hipStream_t s = (hipStream_t)stream;
@@ -477,7 +491,7 @@ extern "C" int eamd_attn_fwd_f32(const float* qu, int64_t ldq, const float* qv, 
 extern "C" int eamd_attn_bwd_q_f32(const float* dctx, int64_t ldd, const float* k, int64_t ldk, const float* v, int64_t ldv,
                                    const float* P, int64_t ldp, float* dS, float* dbd, float* dq, int64_t ldo, int B, int H,
                                    int T1, int T2, int dk, float scale, float drop_p, const uint64_t* drop_step,
-                                   uint64_t drop_salt, void* stream) {
+                                   uint64_t drop_salt, const int32_t* shift_len, void* stream) {
   if (!dctx || !k || !v || !P || !dS || !dq || B <= 0 || H <= 0 || T1 <= 0 || T2 <= 0) return EAMD_EINVAL;
   if (drop_p < 0.f || drop_p >= 1.f || (drop_p > 0.f && !drop_step)) return EAMD_EINVAL;
   if (dk != ATT_DK || T2 > ATT_MAXK || (dbd && T1 != T2)) return EAMD_EUNSUPPORTED;
@@ -489,6 +503,7 @@ extern "C" int eamd_attn_bwd_q_f32(const float* dctx, int64_t ldd, const float* 
   a.ldd = ldd; a.ldk = ldk; a.ldv = ldv; a.ldp = ldp; a.ldo = ldo;
   a.B = B; a.H = H; a.T1 = T1; a.T2 = T2; a.nqb = (T1 + 63) / 64; a.scale = scale;
   a.drop_p = drop_p; a.drop_step = (const unsigned long long*)drop_step; a.drop_salt = drop_salt;
+  a.tshift = shift_len;
   return T2 <= 128 ? launch_bwd<8>(a, (hipStream_t)stream) : T2 <= 256 ? launch_bwd<16>(a, (hipStream_t)stream)
                                                                          : launch_bwd<32>(a, (hipStream_t)stream);
 }

@@ -31,6 +31,7 @@ struct AttnArgs {
   float scale;
   // attention dropout (attention.py:91): Pd = dropout(P) feeds the context; mask index = element index in P
   bf16_t* Pd; float drop_p; const unsigned long long* drop_step; unsigned long long drop_salt;
+  const int* tshift;     // device scalar: length the legacy rel_shift works on (NULL: T2) - see eamd_attn_fwd
 };
 
 __device__ __forceinline__ float xor_max16_32(float v) {
@@ -113,7 +114,16 @@ __global__ __launch_bounds__(256, NKT > 16 ? 1 : 2) void attn_fwd_kernel(const A
   const int qi = min(r0 + fr, T1 - 1);             // this lane's query (clamped lanes are never stored)
 
   float* X = reinterpret_cast<float*>(smem_raw);
+  // Ts: the length the legacy rel_shift is taken over.  A batch padded beyond its own longest utterance (shape-bucketed
+  // graphs) passes that utterance's length here: the shift then maps bd exactly as the reference's T' x T' matrix does;
+  // keys from Ts on are masked by the caller's mask, and the score matrix is cleared first so that the rows / columns the
+  // shift no longer reaches hold zeros instead of stale LDS.
+  const int Ts = (REL && a.tshift) ? min(max(a.tshift[0], 1), T2) : T2;
   if (REL) {
+    if (Ts < T2) {
+      for (int e = t; e < 64 * XLD; e += 256) X[e] = 0.f;
+      __syncthreads();
+    }
     // ---- bd, stored at its rel-shifted place: bd[i][m] -> (i, m - (T-1-i)) if m >= T-1-i, else (i - 1, m + i + 1) ----
     uint4 qf[4][2];
     const bf16_t* qs = a.qv + ((long)b * T1 + r0w) * a.ldqv + h * ATT_DK;
@@ -135,19 +145,19 @@ __global__ __launch_bounds__(256, NKT > 16 ? 1 : 2) void attn_fwd_kernel(const A
         c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, p0), __builtin_bit_cast(bf16x8, qf[qt][0]), c, 0, 0, 0);
         c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, p1), __builtin_bit_cast(bf16x8, qf[qt][1]), c, 0, 0, 0);
         const int ql = qt * 16 + fr, i = r0w + ql;       // c[r] = bd[query i][m = 16 mt + 4 fq + r]
-        const int lim = T2 - 1 - i;
+        const int lim = Ts - 1 - i;
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
           const int m = mt * 16 + 4 * fq + r;
           const int row = m >= lim ? ql : ql - 1, j = m >= lim ? m - lim : m + i + 1;
-          if (m < T2 && ql < nq && row >= 0) X[row * XLD + j] = c[r];
+          if (m < Ts && i < Ts && ql < nq && row >= 0) X[row * XLD + j] = c[r];
         }
       }
     }
     const int i64 = r0w + 64;                        // first query of the next workgroup: its low positions feed query r0w + 63
-    if (live && i64 < T1) {
+    if (live && i64 < Ts) {
       const uint4* qr = reinterpret_cast<const uint4*>(a.qv + ((long)b * T1 + i64) * a.ldqv + h * ATT_DK);
-      for (int m = t; m <= T2 - 2 - i64; m += 256) {
+      for (int m = t; m <= Ts - 2 - i64; m += 256) {
         const uint4* pr = reinterpret_cast<const uint4*>(a.pos + (long)m * a.ldpos + h * ATT_DK);
         float s = 0.f;
 #pragma unroll
@@ -301,6 +311,7 @@ struct AttnBwdArgs {
   int B, H, T1, T2, nqb, dq_bf16;
   float scale;
   float drop_p; const unsigned long long* drop_step; unsigned long long drop_salt;   // the forward's attention dropout
+  const int* tshift;
 };
 
 template <int NKT>
@@ -315,6 +326,7 @@ __global__ __launch_bounds__(256, NKT > 16 ? 1 : 2) void attn_bwd_q_kernel(const
   const int h = zz / a.B, b = zz % a.B;
   constexpr int XLD = NKT * 16 + 4;
   const int T1 = a.T1, T2 = a.T2;
+  const int Ts = (a.dbd && a.tshift) ? min(max(a.tshift[0], 1), T2) : T2;      // rel_shift length (see the forward kernel)
   const int r0w = min((jb % a.nqb) * 64, T1 - 1);
   const int nq = T1 - r0w;
   const int r0 = r0w + wave * 16;
@@ -382,9 +394,10 @@ __global__ __launch_bounds__(256, NKT > 16 ? 1 : 2) void attn_bwd_q_kernel(const
         const int j = j0 + r;
         g16[r] = eamd_f2bf(j < T2 ? unpack(kt, r) * (S[kt][r] - s) * a.scale : 0.f);
         if (a.dbd && qok) {
-          // inverse rel_shift for T1 == T2 = T: padded index T + i T + j lands in row i (j <= i) or row i + 1
-          if (j < T2) {
-            const int R = j <= i ? i : i + 1, c = j <= i ? T2 + j - i : j - i - 1;
+          // inverse rel_shift for T1 == T2 = T (Ts when the shift is shorter than the padded matrix: everything outside the
+          // Ts x Ts square is zero): padded index T + i T + j lands in row i (j <= i) or row i + 1
+          if (j < Ts && i < Ts) {
+            const int R = j <= i ? i : i + 1, c = j <= i ? Ts + j - i : j - i - 1;
             if (c != 0) a.dbd[zo + (long)R * a.ldp + (c - 1)] = g16[r];
           } else if (j < (int)a.ldp) {
             a.dbd[zo + (long)i * a.ldp + j] = 0;      // pad columns of this row
@@ -396,7 +409,7 @@ __global__ __launch_bounds__(256, NKT > 16 ? 1 : 2) void attn_bwd_q_kernel(const
       if (qok && j0 < (int)a.ldp) *reinterpret_cast<uint2*>(srow + j0) = Gk[kt];
     }
     if (a.dbd && r0 == 0)                            // the head of row 0 the scatter never reaches
-      for (int f = 1 + lane; f < T1; f += 64) a.dbd[zo + (f - 1)] = 0;
+      for (int f = 1 + lane; f < Ts; f += 64) a.dbd[zo + (f - 1)] = 0;
   }
   // K panel [16 NKT keys][64 channels]: loads in flight across the barrier, staged over X once every wave has its rows
   uint4 kreg[NKT / 2];
@@ -585,7 +598,7 @@ extern "C" int eamd_attn_fwd(const void* qu, int64_t ldq, const void* qv, int64_
                              const void* v, int64_t ldv, const void* pos, int64_t ldpos, const unsigned char* mask,
                              int64_t mask_bstride, int64_t mask_qstride, void* P_bf16, int64_t ldp, void* ctx_bf16,
                              int64_t ldc, int B, int H, int T1, int T2, int dk, float scale, void* Pd_bf16, float drop_p,
-                             const uint64_t* drop_step, uint64_t drop_salt, void* stream) {
+                             const uint64_t* drop_step, uint64_t drop_salt, const int32_t* shift_len, void* stream) {
   if (!qu || !k || !v || !P_bf16 || !ctx_bf16 || B <= 0 || H <= 0 || T1 <= 0 || T2 <= 0) return EAMD_EINVAL;
   if (drop_p < 0.f || drop_p >= 1.f || (drop_p > 0.f && (!Pd_bf16 || !drop_step || !al16(Pd_bf16)))) return EAMD_EINVAL;
   if ((pos == nullptr) != (qv == nullptr)) return EAMD_EINVAL;
@@ -603,6 +616,7 @@ extern "C" int eamd_attn_fwd(const void* qu, int64_t ldq, const void* qv, int64_
   a.mb = mask_bstride; a.mi = mask_qstride;
   a.B = B; a.H = H; a.T1 = T1; a.T2 = T2; a.nqb = (T1 + 63) / 64; a.scale = scale;
   a.Pd = (bf16_t*)Pd_bf16; a.drop_p = drop_p; a.drop_step = (const unsigned long long*)drop_step; a.drop_salt = drop_salt;
+  a.tshift = shift_len;
   const int nkt = T2 <= 128 ? 8 : T2 <= 256 ? 16 : 32;               // key tiles of 16 the instantiation covers
   const size_t smem = (size_t)64 * (nkt * 16 + 4) * sizeof(float);   // score matrix X (the V panel staged over it is smaller)
   hipStream_t s = (hipStream_t)stream;
@@ -615,7 +629,7 @@ extern "C" int eamd_attn_fwd(const void* qu, int64_t ldq, const void* qv, int64_
 extern "C" int eamd_attn_bwd_q(const void* dctx, int64_t ldd, const void* k, int64_t ldk, const void* v, int64_t ldv,
                                const void* P_bf16, int64_t ldp, void* dS_bf16, void* dbd_bf16, void* dq, int64_t ldo,
                                int dq_is_bf16, int B, int H, int T1, int T2, int dk, float scale, float drop_p,
-                               const uint64_t* drop_step, uint64_t drop_salt, void* stream) {
+                               const uint64_t* drop_step, uint64_t drop_salt, const int32_t* shift_len, void* stream) {
   if (!dctx || !k || !v || !P_bf16 || !dS_bf16 || !dq || B <= 0 || H <= 0 || T1 <= 0 || T2 <= 0) return EAMD_EINVAL;
   if (drop_p < 0.f || drop_p >= 1.f || (drop_p > 0.f && !drop_step)) return EAMD_EINVAL;
   if (dk != ATT_DK || T2 > ATT_MAXK || (dbd_bf16 && T1 != T2)) return EAMD_EUNSUPPORTED;
@@ -630,6 +644,7 @@ extern "C" int eamd_attn_bwd_q(const void* dctx, int64_t ldd, const void* k, int
   a.ldd = ldd; a.ldk = ldk; a.ldv = ldv; a.ldp = ldp; a.ldo = ldo;
   a.B = B; a.H = H; a.T1 = T1; a.T2 = T2; a.nqb = (T1 + 63) / 64; a.dq_bf16 = dq_is_bf16; a.scale = scale;
   a.drop_p = drop_p; a.drop_step = (const unsigned long long*)drop_step; a.drop_salt = drop_salt;
+  a.tshift = shift_len;
   return T2 <= 128 ? launch_attn_bwd<8>(a, (hipStream_t)stream) : T2 <= 256 ? launch_attn_bwd<16>(a, (hipStream_t)stream)
                                                                              : launch_attn_bwd<32>(a, (hipStream_t)stream);
 }

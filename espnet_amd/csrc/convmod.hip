@@ -331,8 +331,10 @@ __device__ __forceinline__ void chan_merge(float& n, float& mean, float& m2, flo
   n = nt;
 }
 
+// (T, bound): optional row bound - rows whose time index (row % T) is not below bound[0] take no part in the statistics (a
+// batch padded beyond its own longest utterance by a shape-bucketed graph: conformer/convolution.py:56-79 never sees those frames)
 __global__ __launch_bounds__(256) void bn_partial_kernel(const float* __restrict__ x, float* __restrict__ part,
-                                                         long M, int C) {
+                                                         long M, int C, int T, const int* __restrict__ bound) {
   __shared__ float4 sh_mean[256], sh_m2[256];
   __shared__ float sh_n[256];
   const BnGeom g = bn_geom(C);
@@ -343,10 +345,13 @@ __global__ __launch_bounds__(256) void bn_partial_kernel(const float* __restrict
   float4 v[BN_R];
   float n = 0.f;
   float4 sum = make_float4(0.f, 0.f, 0.f, 0.f);
+  const int tb = bound ? bound[0] : T;
+  unsigned okm = 0u;
 #pragma unroll
   for (int i = 0; i < BN_R; ++i) {
     const long r = r0 + (long)i * g.rs;
-    const bool ok = live && r < M;
+    const bool ok = live && r < M && (!bound || (int)(r % T) < tb);
+    okm |= ok ? (1u << i) : 0u;
     v[i] = ok ? reinterpret_cast<const float4*>(x + r * C)[q] : make_float4(0.f, 0.f, 0.f, 0.f);
     n += ok ? 1.f : 0.f;
     sum.x += v[i].x; sum.y += v[i].y; sum.z += v[i].z; sum.w += v[i].w;
@@ -356,7 +361,7 @@ __global__ __launch_bounds__(256) void bn_partial_kernel(const float* __restrict
   float4 m2 = make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
   for (int i = 0; i < BN_R; ++i) {
-    const bool ok = live && (r0 + (long)i * g.rs) < M;
+    const bool ok = (okm >> i) & 1u;
     if (ok) {
       float a = v[i].x - mean.x, b = v[i].y - mean.y, c = v[i].z - mean.z, d = v[i].w - mean.w;
       m2.x += a * a; m2.y += b * b; m2.z += c * c; m2.w += d * d;
@@ -449,8 +454,10 @@ __global__ __launch_bounds__(256) void bn_bwd_partial_kernel(const float* __rest
                                                              const float* __restrict__ rstd,
                                                              const float* __restrict__ gamma,
                                                              const float* __restrict__ beta, float* __restrict__ part,
-                                                             long M, int C, int act) {
+                                                             long M, int C, int act, int T,
+                                                             const int* __restrict__ bound) {
   __shared__ float4 sh1[256], sh2[256];
+  const int tb = bound ? bound[0] : T;
   const BnGeom g = bn_geom(C);
   const int t = threadIdx.x;
   const int q = t % g.cq, sub = t / g.cq;
@@ -465,7 +472,7 @@ __global__ __launch_bounds__(256) void bn_bwd_partial_kernel(const float* __rest
 #pragma unroll
   for (int i = 0; i < BN_R; ++i) {
     const long r = r0 + (long)i * g.rs;
-    const bool ok = live && r < M;
+    const bool ok = live && r < M && (!bound || (int)(r % T) < tb);     // rows past the bound: dy = 0
     xv[i] = ok ? reinterpret_cast<const float4*>(x + r * C)[q] : make_float4(0.f, 0.f, 0.f, 0.f);
     dv[i] = ok ? reinterpret_cast<const float4*>(dy + r * C)[q] : make_float4(0.f, 0.f, 0.f, 0.f);
   }
@@ -538,12 +545,14 @@ __global__ void bn_bwd_apply_kernel(const float* __restrict__ dy, const float* _
                                     const float* __restrict__ mean, const float* __restrict__ rstd,
                                     const float* __restrict__ gamma, const float* __restrict__ beta,
                                     const float* __restrict__ sums, float* __restrict__ dx, long M, int C, int act,
-                                    int training) {
+                                    int training, int T, const int* __restrict__ bound) {
   const long n = M * C;
   const long stride = (long)gridDim.x * blockDim.x;
-  const float invM = 1.f / (float)M;
+  const int tb = bound ? bound[0] : T;
+  const float invM = bound ? 1.f / ((float)(M / T) * (float)tb) : 1.f / (float)M;      // rows that took part in the statistics
   for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
     int c = i % C;
+    if (bound && (int)((i / C) % T) >= tb) { dx[i] = 0.f; continue; }
     float rs = rstd[c], g = gamma[c];
     float xh = (x[i] - mean[c]) * rs;
     float z = xh * g + beta[c];
@@ -870,19 +879,31 @@ int eamd_bn_nslab(int64_t M, int C) {
   return (int)((M + g.slab_rows - 1) / g.slab_rows);
 }
 
-int eamd_bn_stats(const float* x, float* workspace, float* mean, float* rstd, float* running_mean,
-                  float* running_var, int64_t* num_batches_tracked, int64_t M, int C, float eps, float momentum, void* stream) {
+static int bn_stats_impl(const float* x, float* workspace, float* mean, float* rstd, float* running_mean,
+                         float* running_var, int64_t* num_batches_tracked, int64_t M, int C, float eps, float momentum, int T,
+                         const int32_t* bound, void* stream) {
   if (!x || !workspace || !mean || !rstd || M <= 0 || C <= 0) return EAMD_EINVAL;
+  if (bound && (T <= 0 || M % T != 0)) return EAMD_EINVAL;
   if (!bn_shape_ok(C)) return EAMD_EUNSUPPORTED;   // channel counts 4..1024, multiples of 4
   if ((uintptr_t)x & 15) return EAMD_EINVAL;
   hipStream_t s = (hipStream_t)stream;
   const int nslab = eamd_bn_nslab(M, C);
-  hipLaunchKernelGGL(bn_partial_kernel, dim3(nslab), dim3(256), 0, s, x, workspace, (long)M, C);
+  hipLaunchKernelGGL(bn_partial_kernel, dim3(nslab), dim3(256), 0, s, x, workspace, (long)M, C, T, (const int*)bound);
   EAMD_LAUNCH_CHECK();
   hipLaunchKernelGGL(bn_finalize_kernel, dim3((C + BN_CPB - 1) / BN_CPB), dim3(1024), 0, s, workspace, nslab, C, eps, momentum, mean, rstd,
                      running_mean, running_var, (long long*)num_batches_tracked);
   EAMD_LAUNCH_CHECK();
   return EAMD_OK;
+}
+int eamd_bn_stats(const float* x, float* workspace, float* mean, float* rstd, float* running_mean,
+                  float* running_var, int64_t* num_batches_tracked, int64_t M, int C, float eps, float momentum, void* stream) {
+  return bn_stats_impl(x, workspace, mean, rstd, running_mean, running_var, num_batches_tracked, M, C, eps, momentum, 1, nullptr, stream);
+}
+int eamd_bn_stats_bounded(const float* x, float* workspace, float* mean, float* rstd, float* running_mean,
+                          float* running_var, int64_t* num_batches_tracked, int64_t M, int C, float eps, float momentum, int T,
+                          const int32_t* bound, void* stream) {
+  if (!bound) return EAMD_EINVAL;
+  return bn_stats_impl(x, workspace, mean, rstd, running_mean, running_var, num_batches_tracked, M, C, eps, momentum, T, bound, stream);
 }
 
 /* second stage of eamd_bn_stats alone, for partial statistics a producer kernel left behind (eamd_dwconv_glu_fwd's bn_part:
@@ -906,11 +927,12 @@ int eamd_bn_apply(const float* x, const float* mean, const float* rstd, const fl
 }
 
 /* workspace: (2*nslab + 2)*C floats */
-int eamd_bn_bwd(const float* dy, const float* x, const float* mean, const float* rstd, const float* gamma,
-                const float* beta, float* workspace, float* dx, float* dgamma, float* dbeta, int64_t M, int C,
-                int act, int training, void* stream) {
+static int bn_bwd_impl(const float* dy, const float* x, const float* mean, const float* rstd, const float* gamma,
+                       const float* beta, float* workspace, float* dx, float* dgamma, float* dbeta, int64_t M, int C,
+                       int act, int training, int T, const int32_t* bound, void* stream) {
   if (!dy || !x || !mean || !rstd || !gamma || !beta || !workspace || !dx || !dgamma || !dbeta || M <= 0 || C <= 0)
     return EAMD_EINVAL;
+  if (bound && (T <= 0 || M % T != 0)) return EAMD_EINVAL;
   if (!bn_shape_ok(C)) return EAMD_EUNSUPPORTED;
   if (((uintptr_t)x | (uintptr_t)dy | (uintptr_t)mean | (uintptr_t)rstd | (uintptr_t)gamma | (uintptr_t)beta) & 15)
     return EAMD_EINVAL;
@@ -918,14 +940,25 @@ int eamd_bn_bwd(const float* dy, const float* x, const float* mean, const float*
   const int nslab = eamd_bn_nslab(M, C);
   float* sums = workspace + (long)nslab * 2 * C;
   hipLaunchKernelGGL(bn_bwd_partial_kernel, dim3(nslab), dim3(256), 0, s, dy, x, mean, rstd, gamma, beta,
-                     workspace, (long)M, C, act);
+                     workspace, (long)M, C, act, T, (const int*)bound);
   EAMD_LAUNCH_CHECK();
   hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((C + BN_CPB - 1) / BN_CPB), dim3(1024), 0, s, workspace, nslab, C, sums, dgamma, dbeta);
   EAMD_LAUNCH_CHECK();
   hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(grid_for(M * C)), dim3(256), 0, s, dy, x, mean, rstd, gamma, beta,
-                     sums, dx, (long)M, C, act, training);
+                     sums, dx, (long)M, C, act, training, T, (const int*)bound);
   EAMD_LAUNCH_CHECK();
   return EAMD_OK;
+}
+int eamd_bn_bwd(const float* dy, const float* x, const float* mean, const float* rstd, const float* gamma,
+                const float* beta, float* workspace, float* dx, float* dgamma, float* dbeta, int64_t M, int C,
+                int act, int training, void* stream) {
+  return bn_bwd_impl(dy, x, mean, rstd, gamma, beta, workspace, dx, dgamma, dbeta, M, C, act, training, 1, nullptr, stream);
+}
+int eamd_bn_bwd_bounded(const float* dy, const float* x, const float* mean, const float* rstd, const float* gamma,
+                        const float* beta, float* workspace, float* dx, float* dgamma, float* dbeta, int64_t M, int C,
+                        int act, int training, int T, const int32_t* bound, void* stream) {
+  if (!bound) return EAMD_EINVAL;
+  return bn_bwd_impl(dy, x, mean, rstd, gamma, beta, workspace, dx, dgamma, dbeta, M, C, act, training, T, bound, stream);
 }
 
 static int conv_c1_fwd(const float* x, const float* w, const float* bias, void* y, int B, int T, int F, int C,

@@ -469,6 +469,29 @@ int eamd_act_bwd(const float* dy, const float* x, float* dx, int64_t n, int act,
   return EAMD_OK;
 }
 
+// rows whose time index (row % T) is not below bound[0] <- 0, in place (fp32, or bf16 with 2-byte elements)
+__global__ __launch_bounds__(256) void mask_time_f32_kernel(float* __restrict__ x, long rows, int C, int T, const int* __restrict__ bound) {
+  const int tb = bound[0];
+  const long n = rows * C, stride = (long)gridDim.x * blockDim.x;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride)
+    if ((int)((i / C) % T) >= tb) x[i] = 0.f;
+}
+__global__ __launch_bounds__(256) void mask_time_b16_kernel(unsigned short* __restrict__ x, long rows, int C, int T, const int* __restrict__ bound) {
+  const int tb = bound[0];
+  const long n = rows * C, stride = (long)gridDim.x * blockDim.x;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride)
+    if ((int)((i / C) % T) >= tb) x[i] = 0;
+}
+int eamd_mask_time(void* x, int64_t rows, int C, int T, const int32_t* bound, int is_bf16, void* stream) {
+  if (!x || !bound || rows <= 0 || C <= 0 || T <= 0) return EAMD_EINVAL;
+  if (is_bf16) hipLaunchKernelGGL(mask_time_b16_kernel, dim3(grid_for(rows * C)), dim3(256), 0, (hipStream_t)stream,
+                                  (unsigned short*)x, (long)rows, C, T, (const int*)bound);
+  else hipLaunchKernelGGL(mask_time_f32_kernel, dim3(grid_for(rows * C)), dim3(256), 0, (hipStream_t)stream, (float*)x,
+                          (long)rows, C, T, (const int*)bound);
+  EAMD_LAUNCH_CHECK();
+  return EAMD_OK;
+}
+
 int eamd_mask_rows(const float* x, const uint8_t* keep, float* y, int64_t rows, int D, void* stream) {
   if (!x || !keep || !y || rows <= 0 || D <= 0) return EAMD_EINVAL;
   hipLaunchKernelGGL(mask_rows_kernel, dim3(grid_for(rows * D)), dim3(256), 0, (hipStream_t)stream, x, keep, y,

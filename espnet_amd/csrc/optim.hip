@@ -32,7 +32,7 @@ __global__ __launch_bounds__(1024) void sumsq_final_kernel(const float* __restri
 }
 
 // state (device, 8 floats): [0]=step (float count), [1]=lr, [2]=bias_corr1, [3]=bias_corr2,
-//                           [4]=last grad norm, [5]=skipped-steps counter, [6]=clip coef
+//                           [4]=last grad norm, [5]=skipped-steps counter, [6]=clip coef, [7]=Adadelta eps (host-set)
 // Noam / WarmupLR schedule evaluated on device so the whole training step stays capturable.
 //   mode 0: lr = base           (constant)
 //   mode 1: lr = factor * d^-0.5 * min(step^-0.5, step*warmup^-1.5)         (NoamOpt)
@@ -101,6 +101,52 @@ __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, const 
     v[i] = beta2 * v[i] + (1.f - beta2) * gg * gg;
     float denom = sqrtf(v[i]) * inv_sqrt_bc2 + eps;
     p[i] -= step_size * m[i] / denom;
+    if (p16) p16[i] = eamd_f2bf(p[i]);
+  }
+}
+
+// torch.optim.Adadelta semantics (the optimizer of the RNN recipes: espnet/asr/pytorch_backend/asr.py:505-508,
+// rho 0.95, eps from --eps, decayed by the trainer: asr.py:798-830 multiplies param_group["eps"] by --eps-decay when the
+// validation criterion stops improving).  eps lives in state[7] so that a captured step follows its decay; the
+// gradient is pre-scaled by the clip coefficient state[6]; a non-finite gradient norm skips the step (asr.py:228-240).
+__global__ __launch_bounds__(256) void adadelta_kernel(float* __restrict__ p, const float* __restrict__ g,
+                                                       float* __restrict__ sq, float* __restrict__ acc,
+                                                       unsigned short* __restrict__ p16, long n,
+                                                       const float* __restrict__ st, float rho, float weight_decay) {
+  if (!isfinite(st[4])) return;
+  const float lr = st[1], coef = st[6], eps = st[7];
+  const long stride = (long)gridDim.x * blockDim.x;
+  const long n4 = n / 4;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += stride) {
+    float4 pv = reinterpret_cast<float4*>(p)[i];
+    const float4 gv = reinterpret_cast<const float4*>(g)[i];
+    float4 sv = reinterpret_cast<float4*>(sq)[i];
+    float4 av = reinterpret_cast<float4*>(acc)[i];
+    float* pp = &pv.x; const float* gp = &gv.x; float* sp = &sv.x; float* ap = &av.x;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const float gg = gp[k] * coef + weight_decay * pp[k];
+      sp[k] = sp[k] * rho + (1.f - rho) * gg * gg;
+      const float delta = sqrtf(ap[k] + eps) / sqrtf(sp[k] + eps) * gg;
+      ap[k] = ap[k] * rho + (1.f - rho) * delta * delta;
+      pp[k] -= lr * delta;
+    }
+    reinterpret_cast<float4*>(p)[i] = pv;
+    reinterpret_cast<float4*>(sq)[i] = sv;
+    reinterpret_cast<float4*>(acc)[i] = av;
+    if (p16) {
+      uint2 h;
+      h.x = eamd_f2bf(pv.x) | ((unsigned)eamd_f2bf(pv.y) << 16);
+      h.y = eamd_f2bf(pv.z) | ((unsigned)eamd_f2bf(pv.w) << 16);
+      reinterpret_cast<uint2*>(p16)[i] = h;
+    }
+  }
+  for (long i = n4 * 4 + (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+    const float gg = g[i] * coef + weight_decay * p[i];
+    sq[i] = sq[i] * rho + (1.f - rho) * gg * gg;
+    const float delta = sqrtf(acc[i] + eps) / sqrtf(sq[i] + eps) * gg;
+    acc[i] = acc[i] * rho + (1.f - rho) * delta * delta;
+    p[i] -= lr * delta;
     if (p16) p16[i] = eamd_f2bf(p[i]);
   }
 }
@@ -175,4 +221,15 @@ int eamd_adam_step(float* p, const float* g, float* m, float* v, void* p_bf16, i
   return EAMD_OK;
 }
 
+int eamd_adadelta_step(float* p, const float* g, float* square_avg, float* acc_delta, void* p_bf16, int64_t n,
+                       const float* state, float rho, float weight_decay, void* stream) {
+  if (!p || !g || !square_avg || !acc_delta || !state || n <= 0 || !(rho >= 0.f && rho <= 1.f)) return EAMD_EINVAL;
+  if (((uintptr_t)p | (uintptr_t)g | (uintptr_t)square_avg | (uintptr_t)acc_delta) & 15) return EAMD_EINVAL;
+  long want = (n / 4 + 255) / 256;
+  int nblk = (int)(want < 1 ? 1 : (want > 2048 ? 2048 : want));
+  hipLaunchKernelGGL(adadelta_kernel, dim3(nblk), dim3(256), 0, (hipStream_t)stream, p, g, square_avg, acc_delta,
+                     (unsigned short*)p_bf16, (long)n, state, rho, weight_decay);
+  EAMD_LAUNCH_CHECK();
+  return EAMD_OK;
+}
 }  // extern "C"

@@ -445,7 +445,7 @@ FUSE_ATTN = True   # tests flip this to compare against the GEMM / softmax / GEM
 ATTN_TAP = None    # a list while E2E.calculate_all_attentions runs: every attention block appends its probabilities
 
 
-def attn_fwd_fused(qu, qv, k, v, p, mask, B, T1, T2, H, dk, drop=None):
+def attn_fwd_fused(qu, qv, k, v, p, mask, B, T1, T2, H, dk, drop=None, shift_len=None):
     """(P, Pd, ctx) from eamd_attn_fwd, or None when the library declines the operands; drop = (p, salt): attention
     dropout inside the kernel (Pd = dropout(P) is what the context is built from; Pd is P without dropout)"""
     qu, k, v = _mv(qu), _mv(k), _mv(v)
@@ -454,7 +454,7 @@ def attn_fwd_fused(qu, qv, k, v, p, mask, B, T1, T2, H, dk, drop=None):
         qvm, pm = _mv(qv), _mv(p)
         qv3, p3 = (qvm.t, qvm.off, qvm.ld), (pm.t, pm.off, pm.ld)
     return ops.attn_fwd((qu.t, qu.off, qu.ld), qv3, (k.t, k.off, k.ld), (v.t, v.off, v.ld), p3, mask, B, T1, T2, H, dk,
-                        _ldp(T2), 1.0 / math.sqrt(dk), drop=drop)
+                        _ldp(T2), 1.0 / math.sqrt(dk), drop=drop, shift_len=shift_len)
 
 
 def attn_context_fwd(P, v, B, T1, T2, H, dk):
@@ -467,7 +467,7 @@ def attn_context_fwd(P, v, B, T1, T2, H, dk):
     return ctxv
 
 
-def attn_core_bwd(dctx, P, qu, qv, k, v, p, B, T1, T2, H, dk, Pd=None, attn_drop=(0.0, 0), dqkv=None, dkv_out=None,
+def attn_core_bwd(dctx, P, qu, qv, k, v, p, B, T1, T2, H, dk, Pd=None, attn_drop=(0.0, 0), dqkv=None, dkv_out=None, shift_len=None,
                   dp_out=None):
     """returns dqu (fp32), dqv (fp32 or None), dk, dv (GEMM-operand dtype), dp (fp32 or None)
     Pd = dropped-out probabilities actually used for the context (None when attention dropout is off).
@@ -507,8 +507,10 @@ def attn_core_bwd(dctx, P, qu, qv, k, v, p, B, T1, T2, H, dk, Pd=None, attn_drop
         dqu = None if dq_in_qkv else torch.empty(B * T1, D, device=dev, dtype=torch.float32)
         dq_view = (dqkv, 0, ldo) if dq_in_qkv else (dqu, 0, D)
         if not ops.attn_bwd_q((dctx, 0, D), (k.t, k.off, k.ld), (v.t, v.off, v.ld), P, dS, dbd, dq_view, B, T1, T2, H, dk,
-                              ldp, 1.0 / math.sqrt(dk), drop=attn_drop if Pd is not None else None):
+                              ldp, 1.0 / math.sqrt(dk), drop=attn_drop if Pd is not None else None, shift_len=shift_len):
             dS = None
+    if dS is None and shift_len is not None:
+        raise ops._lib.EamdError("relative-position attention backward on a shape-bucketed batch needs the fused kernel")
     if dS is None:
         dP = torch.empty(H * B * T1 * ldp, device=dev, dtype=torch.float32)
         ops.gemm(dctx, v.t, dP, T1, T2, dk, D, v.ld, ldp, batch=(B, H), sA=(T1 * D, dk), sB=(T2 * v.ld, dk), sC=sP,
@@ -760,12 +762,19 @@ class MHABlockFn(torch.autograd.Function):
         else:
             p, qu, qv = None, q, None
         fwd = None
+        tb = ops.time_bound() if (rel and T1 == T2) else None      # padded batch: rel_shift over the batch's own length
+        ctx.shift_len = tb
         if FUSE_ATTN and ops.attn_fwd_supported(T1, T2, dk, rel):
             # scores, softmax, attention dropout and context in one launch
-            fwd = attn_fwd_fused(qu, qv, k, v, p, mask, B, T1, T2, H, dk, drop=(p_att, s_att) if p_att > 0.0 else None)
+            fwd = attn_fwd_fused(qu, qv, k, v, p, mask, B, T1, T2, H, dk, drop=(p_att, s_att) if p_att > 0.0 else None,
+                                 shift_len=tb)
         if fwd is not None:
             P, Pd, cx = fwd
         else:
+            if tb is not None:
+                # a padded batch needs the rel_shift over its own length; only the fused kernels take it (shift_len)
+                raise ops._lib.EamdError("relative-position attention on a shape-bucketed batch needs the fused attention kernels "
+                                         "(d_k = 64, T' <= 512); this shape runs the GEMM + softmax path")
             P = attn_scores_fwd(qu, qv, k, p, mask, B, T1, T2, H, dk)
             Pd = ops.dropout(P, p_att, s_att) if p_att > 0.0 else P
             cx = attn_context_fwd(Pd, v, B, T1, T2, H, dk)
@@ -822,7 +831,8 @@ class MHABlockFn(torch.autograd.Function):
             dqkv = torch.empty(B * T1, 3 * D, device=do.device, dtype=adt)
             quv = qu if rel else _MV(qkv, 0, 3 * D)
             dqu, dqv, _, _, dp = attn_core_bwd(dctx, P, quv, qv, _MV(qkv, D, 3 * D), _MV(qkv, 2 * D, 3 * D), p, B, T1,
-                                               T2, H, dk, Pd=Pd, attn_drop=(p_att, s_att), dqkv=dqkv, dp_out=dp_out)
+                                               T2, H, dk, Pd=Pd, attn_drop=(p_att, s_att), dqkv=dqkv, dp_out=dp_out,
+                                               shift_len=ctx.shift_len)
             if rel:
                 wpos = params[10]
                 # dq = dqu + dqv (operand dtype, into the fused buffer) + both bias gradients in one pass
@@ -839,7 +849,8 @@ class MHABlockFn(torch.autograd.Function):
             k, v = pre_kv[1].block(pre_kv[2], 0), pre_kv[1].block(pre_kv[2], D)
             dkv_out = pre_kv[1].grad_block(pre_kv[2])
         dqu, dqv, dkk, dv, dp = attn_core_bwd(dctx, P, qu, qv, k, v, p, B, T1, T2, H, dk,
-                                              Pd=Pd, attn_drop=(p_att, s_att), dkv_out=dkv_out, dp_out=dp_out)
+                                              Pd=Pd, attn_drop=(p_att, s_att), dkv_out=dkv_out, dp_out=dp_out,
+                                              shift_len=ctx.shift_len)
         if rel:
             wpos = params[10]
             dq = ops.add_cast_colsum2(dqu, dqv, sink.buf(11).view(-1), sink.buf(12).view(-1))
@@ -890,6 +901,12 @@ class ConvModuleBlockFn(torch.autograd.Function):
         xn, mean, rstd = _ln_fwd_in(x2, ln_w, ln_b, eps, adt)
         assert eps is not None or p_out <= 0.0
         a = ops.linear_fwd(xn, ops.wshadow(w1).view(2 * Cc, D), b1)     # pointwise conv 1  [M, 2C] fp32
+        # a batch padded beyond its own longest utterance (ops.set_time_bound): frames from the bound on are zeroed in front of
+        # the depthwise convolution (GLU(0, 0) = 0: the zero padding the reference has there) and left out of the BatchNorm
+        tb = ops.time_bound()
+        bound = (T, tb) if tb is not None else None
+        if bound is not None:
+            ops.mask_time(a, T, tb)
         # GLU + depthwise conv over time in one launch (GLU(a) formed while the conv loads its rows, never written)
         # (in training mode the same launch leaves the BatchNorm partial statistics of its output tiles behind).
         # The BatchNorm's num_batches_tracked buffer rides on running_mean (ConvolutionModule sets it): += 1 in the
@@ -898,15 +915,15 @@ class ConvModuleBlockFn(torch.autograd.Function):
         nbt = getattr(running_mean, "_eamd_nbt", None)
         if FUSE_GLU_DWCONV:
             d = ops.dwconv_glu_fwd(a, wd.view(Cc, K), bd_, B, T, Cc, K,
-                                   bn=(bn_eps, bn_momentum, running_mean, running_var, nbt) if training else None)
-            if d is not None and training:
+                                   bn=(bn_eps, bn_momentum, running_mean, running_var, nbt) if (training and bound is None) else None)
+            if d is not None and training and bound is None:
                 d, bmean, brstd = d
         if d is None:
             gl = ops.glu_fwd(a, Cc)                                      # [M, C]
             d = ops.dwconv_fwd(gl, wd.view(Cc, K), bd_, B, T, Cc, K)
         if training:
             if bmean is None:
-                bmean, brstd = ops.bn_stats(d, M, Cc, bn_eps, bn_momentum, running_mean, running_var, nbt)
+                bmean, brstd = ops.bn_stats(d, M, Cc, bn_eps, bn_momentum, running_mean, running_var, nbt, bound=bound)
         else:
             bmean = running_mean
             brstd = ops.axpby(running_var, None, 1.0, 0.0)
@@ -922,6 +939,7 @@ class ConvModuleBlockFn(torch.autograd.Function):
         ctx.save_for_backward(x2, mean, rstd, xn, a, gl, d, bmean, brstd, e)
         ctx.pr = GradSink.use(params)
         ctx.cfg = (B, T, D, Cc, K, act, training, drop)
+        ctx.bound = bound
         ctx.prev = _prev_drop(x)
         return _tag_out(out.view(B, T, D), p_out, s_out)
 
@@ -937,14 +955,19 @@ class ConvModuleBlockFn(torch.autograd.Function):
         dob, g_drop = _grad_operand(dout, do, p_out, s_out)
         ops.linear_bwd_w(dob, e, sink.buf(8).view(Cc, Cc), db=sink.buf(9), a_drop=g_drop)
         de = ops.linear_bwd_x(dob, ops.wshadow(w2).view(Cc, Cc), a_drop=g_drop)
-        dd = ops.bn_bwd(de, d, bmean, brstd, g, be, sink.buf(6), sink.buf(7), M, Cc, act, training)
+        # (time bound: the bounded BatchNorm backward takes dy = 0 and writes dx = 0 from the bound on)
+        dd = ops.bn_bwd(de, d, bmean, brstd, g, be, sink.buf(6), sink.buf(7), M, Cc, act, training, bound=ctx.bound)
         if gl is None:       # GLU fused into the depthwise kernels: its derivative in the input-gradient store, GLU(a) on load
             da = ops.dwconv_glu_bwd_x(dd, wd.view(Cc, K), a, B, T, Cc, K, adt)
+            if ctx.bound is not None:
+                ops.mask_time(da, T, ctx.bound[1])      # the forward zeroed these rows of a
             ops.dwconv_glu_bwd_w(dd, a, sink.buf(4).view(Cc, K), sink.buf(5), B, T, Cc, K)
         else:
             dgl = ops.dwconv_bwd_x(dd, wd.view(Cc, K), B, T, Cc, K)
             ops.dwconv_bwd_w(dd, gl, sink.buf(4).view(Cc, K), sink.buf(5), B, T, Cc, K)
             da = ops.glu_bwd(dgl, a, Cc, adt)
+            if ctx.bound is not None:
+                ops.mask_time(da, T, ctx.bound[1])
         ops.linear_bwd_w(da, xn, sink.buf(2).view(2 * Cc, D), db=sink.buf(3))
         dxn = ops.linear_bwd_x(da, ops.wshadow(w1).view(2 * Cc, D))
         dx = _ln_bwd_out(dxn, x2, ln_w, mean, rstd, do, sink.buf(0), sink.buf(1), ctx.prev, (B, T, D))
@@ -1207,10 +1230,11 @@ class CTCLossFn(torch.autograd.Function):
     reference: ctc.py:53-66,67-123 (loss_fn + forward), espnet2/asr/ctc.py:44-108."""
 
     @staticmethod
-    def forward(ctx, acts, ys_pad, hlens, blank, ignore_id):
-        B = acts.shape[0]
+    def forward(ctx, acts, ys_pad, hlens, blank, ignore_id, time_major=False):
+        """time_major: acts is (T, B, V) as warp-ctc takes it; read in place (strides), no transposed copy"""
+        B = acts.shape[1] if time_major else acts.shape[0]
         nll, grad = ops.ctc_loss(acts.contiguous(), ys_pad, hlens, blank, ignore_id, 1.0 / B,
-                                 want_grad=acts.requires_grad)
+                                 want_grad=acts.requires_grad, time_major=time_major)
         ctx.save_for_backward(grad)
         ctx.nll = nll
         return ops.reduce_sum(nll, 1.0 / B)
@@ -1218,7 +1242,7 @@ class CTCLossFn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, g):
         (grad,) = ctx.saved_tensors
-        return ops.scale_dev(grad, g.contiguous(), 1.0, out=grad), None, None, None, None
+        return ops.scale_dev(grad, g.contiguous(), 1.0, out=grad), None, None, None, None, None
 
 
 class LabelSmoothingLossFn(torch.autograd.Function):

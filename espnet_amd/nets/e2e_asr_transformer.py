@@ -15,7 +15,7 @@ from .. import functional as F_
 from .. import ops
 from .asr_interface import ASRInterface
 from .modules import (CTC, Decoder, LabelSmoothingLoss, TransformerEncoder, make_non_pad_mask,
-                      embed_output_lengths, grad_cut, subsampled_lengths, subsequent_mask, th_accuracy)
+                      embed_output_lengths, grad_cut, subsampled_lengths, subsampled_stride, subsequent_mask, th_accuracy)
 
 CTC_LOSS_THRESHOLD = 10000  # reference: e2e_asr.py:43
 
@@ -166,9 +166,14 @@ class E2E(ASRInterface, torch.nn.Module):
         il = [int(v) for v in (ilens.tolist() if isinstance(ilens, torch.Tensor) else ilens)]
         tmax = max(il)
         dev = next(self.parameters()).device
+        hl_true = tbound = None
         if pad_to is not None:
             Tb, Lb = pad_to
             assert Tb >= tmax
+            # what the reference computes on this batch cropped to its own longest utterance: the valid encoder frames of
+            # every utterance and the length T' of the encoder's time axis (= those of the longest utterance)
+            hl_true = embed_output_lengths(self.encoder.embed, il, tmax)
+            tbound = embed_output_lengths(self.encoder.embed, [tmax], tmax)[0]
             xp = xs_pad.new_zeros(xs_pad.shape[0], Tb, xs_pad.shape[2])
             xp[:, :tmax] = xs_pad[:, :tmax]
             yp = ys_pad.new_full((ys_pad.shape[0], Lb), self.ignore_id)
@@ -179,8 +184,17 @@ class E2E(ASRInterface, torch.nn.Module):
         # stream here, so the next batch is prepared while the previous step still runs
         xs_pad = ops.h2d_async(xs_pad[:, :tmax], dev).contiguous()
         ys_pad = ops.h2d_async(ys_pad, dev).contiguous()
-        src_mask = ops.h2d_async(make_non_pad_mask(il, tmax).unsqueeze(-2).to(torch.uint8), dev)     # (B,1,T)
+        if hl_true is None:
+            mask_len = il
+        else:
+            # the input layer subsamples the mask by plain slicing (encoder frame t' <- input frame t' * stride): a padded batch
+            # gets the input mask whose slices are exactly the reference's encoder mask (t' < hl_true[b])
+            stride = max(1, subsampled_stride(self.encoder.embed))
+            mask_len = [(h - 1) * stride + 1 if h > 0 else 0 for h in hl_true]
+        src_mask = ops.h2d_async(make_non_pad_mask(mask_len, tmax).unsqueeze(-2).to(torch.uint8), dev)     # (B,1,T)
         batch = dict(xs_pad=xs_pad, ys_pad=ys_pad, src_mask=src_mask, B=xs_pad.size(0))
+        if tbound is not None:
+            batch["tbound"] = ops.h2d_async(torch.tensor([tbound], dtype=torch.int32), dev)
         if self.decoder is not None:
             ys_in_pad, ys_out_pad, _ = ops.add_sos_eos(ys_pad, self.sos, self.eos, self.ignore_id)
             U = ys_in_pad.size(1)
@@ -189,13 +203,20 @@ class E2E(ASRInterface, torch.nn.Module):
             batch.update(ys_in_pad=ys_in_pad, ys_out_pad=ys_out_pad, ys_mask=ops.h2d_async(ys_mask, dev),
                          n_valid=(ys_out_pad != self.ignore_id).sum())
         if self.mtlalpha > 0.0:
-            batch["hs_len"] = ops.h2d_async(torch.tensor(embed_output_lengths(self.encoder.embed, il, tmax), dtype=torch.int32), dev)
+            hl = hl_true if hl_true is not None else embed_output_lengths(self.encoder.embed, il, tmax)
+            batch["hs_len"] = ops.h2d_async(torch.tensor(hl, dtype=torch.int32), dev)
         return batch
 
     def forward_core(self, batch):
         """Kernel-only part of forward (reference: e2e_asr_transformer.py:175-232)."""
         xs_pad = batch["xs_pad"]
-        hs_pad, hs_mask = self.encoder(xs_pad, batch["src_mask"])
+        # a batch padded by a shape bucket carries the length of its own encoder time axis: rel_shift, the depthwise
+        # convolution's zero padding and the BatchNorm statistics follow it (ops.set_time_bound); None otherwise
+        ops.set_time_bound(batch.get("tbound"))
+        try:
+            hs_pad, hs_mask = self.encoder(xs_pad, batch["src_mask"])
+        finally:
+            ops.set_time_bound(None)       # the blocks keep the bound they read for their backward
         hs_pad = grad_cut(hs_pad)        # no-op unless a phased backward is being set up (modules.GradCuts)
         self.hs_pad = hs_pad
         if hs_mask is not None and not hs_mask.is_contiguous():

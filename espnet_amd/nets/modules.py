@@ -125,6 +125,17 @@ def subsampled_lengths(ilens, tmax=None, stages=2):
     return out
 
 
+def subsampled_stride(embed):
+    """input frames per encoder frame of an input layer (product of the mask-slicing steps)"""
+    if isinstance(embed, Conv2dSubsampling8):
+        return 8
+    if isinstance(embed, Conv2dSubsampling6):
+        return 6
+    if isinstance(embed, Conv2dSubsampling):
+        return 4
+    return 1
+
+
 def embed_output_lengths(embed, ilens, tmax=None):
     """valid frames behind an encoder input layer: the conv2d family subsamples the mask, linear / embed keep it"""
     if isinstance(embed, Conv2dSubsampling8):

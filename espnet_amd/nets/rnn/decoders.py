@@ -2,6 +2,8 @@
 (Decoder.__init__/zero_state/rnn_forward/forward, lstm, single encoder, no scheduled sampling)."""
 import math
 
+import random
+
 import numpy as np
 import torch
 
@@ -55,9 +57,8 @@ class Decoder(torch.nn.Module):
         super().__init__()
         if dtype not in ("lstm", "gru"):
             raise NotImplementedError("dtype %r: lstm and gru decoders have HIP kernels" % dtype)
-        if num_encs != 1 or replace_sos or labeldist is not None or sampling_probability > 0.0:
-            raise NotImplementedError("multi-encoder / replace_sos / label-dist smoothing / scheduled sampling "
-                                      "are outside the hot-path scope")
+        if num_encs != 1 or replace_sos or labeldist is not None:
+            raise NotImplementedError("multi-encoder / replace_sos / label-dist smoothing are outside the hot-path scope")
         self.dtype, self.dunits, self.dlayers, self.context_residual = dtype, dunits, dlayers, context_residual
         self.embed = torch.nn.Embedding(odim, dunits)
         cell = LSTMCell if dtype == "lstm" else GRUCell
@@ -117,7 +118,17 @@ class Decoder(torch.nn.Module):
                          self.training)
         for i in range(olength):
             att_c, att_w = att(hs_pad, hlens, self._drop(0, z_list[0], i + olength), att_w)
-            ey = torch.cat((eys[:, i, :], att_c), dim=1)
+            if i > 0 and random.random() < self.sampling_probability:
+                # scheduled sampling (decoders.py:249-254): the previous step's own argmax token is embedded instead of the
+                # reference label - one host-side coin per step as in the reference; the argmax and the embedding lookup
+                # stay on the device (no host read-back)
+                z_out = F_.LinearFn.apply(z_all[-1], self.output.weight, self.output.bias)
+                tok = ops.argmax_rows(z_out.detach().contiguous()).view(batch, 1).long()
+                z_emb = F_.dropout(R_.PlainEmbedFn.apply(tok, self.embed.weight, -1), self.dropout, self.salt_emb + 977 * (i + 1),
+                                   self.training)
+                ey = torch.cat((z_emb[:, 0, :], att_c), dim=1)
+            else:
+                ey = torch.cat((eys[:, i, :], att_c), dim=1)
             z_list, c_list = self.rnn_forward(ey, z_list, c_list, z_list, c_list, step=i)
             top = self._drop(self.dlayers - 1, z_list[-1], i + 2 * olength)
             z_all.append(torch.cat((top, att_c), dim=-1) if self.context_residual else top)

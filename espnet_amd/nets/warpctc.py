@@ -42,5 +42,6 @@ class CTCLoss(torch.nn.Module):
             off += n
         ys_pad = torch.from_numpy(ys).to(acts.device)
         hl = torch.from_numpy(al).to(acts.device)
-        loss = F_.CTCLossFn.apply(acts.transpose(0, 1).contiguous(), ys_pad, hl, self.blank, -1)     # sum_b nll_b / B
+        # (T, B, V) is handed over as it is: eamd_ctc_loss takes (stride_t, stride_b) - no 159 MB transposed copy at config 2
+        loss = F_.CTCLossFn.apply(acts, ys_pad, hl, self.blank, -1, True)     # sum_b nll_b / B
         return (loss if self.size_average else loss * float(B)).reshape(1)

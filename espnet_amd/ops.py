@@ -107,6 +107,36 @@ def _span(rows, ld, cols):
     return (rows - 1) * ld + cols if rows > 0 else 0
 
 
+# ---- time bound of a padded batch ---------------------------------------------------------------------------------
+# A shape-bucketed graph (train.BucketedGraphStep) pads a batch's frame axis beyond its own longest utterance.  The
+# reference never sees those frames, and three places of the Conformer encoder depend on the batch's own length: the
+# legacy rel_shift (attention.py:160-171, taken over T' x T'), the depthwise convolution's zero padding and the BatchNorm
+# statistics (convolution.py:56-79, over B x T' frames).  While a bound is set (device int32 scalar = the batch's own
+# subsampled length, read by the kernels at run time, i.e. per graph replay) those three follow it.  The blocks read the
+# bound in their FORWARD and keep it for their backward; the model clears it at the end of its forward pass.
+_time_bound = {"t": None}
+
+
+def set_time_bound(t):
+    """t: int32 device tensor with one element, or None"""
+    if t is not None and not (t.is_cuda and t.dtype == torch.int32 and t.numel() == 1):
+        raise _lib.EamdError("time bound: one int32 element on the device")
+    _time_bound["t"] = t
+
+
+def time_bound():
+    return _time_bound["t"]
+
+
+def mask_time(x, T, bound):
+    """rows (b, t) of the [B*T, C] tensor x with t >= bound[0] <- 0, in place"""
+    rows = x.numel() // x.shape[-1]
+    assert x.is_contiguous() and rows % T == 0 and x.dtype in (torch.float32, torch.bfloat16)
+    check(_lib.lib().eamd_mask_time(ptr(x), C.c_int64(rows), x.shape[-1], T, ptr(bound), int(x.dtype == torch.bfloat16),
+                                    stream_ptr()), "eamd_mask_time")
+    return x
+
+
 # bench.py: list collecting every MFMA-contraction launch of one step as (descriptor or None, operand references,
 # replay(stream_ptr)) - eamd_gemm descriptors and the fused attention kernels (descriptor None)
 _gemm_record = None
@@ -680,7 +710,7 @@ def attn_fwd_supported(T1, T2, dk, rel):
     return (fast() or F32_FUSED_ATTN) and dk == 64 and T2 <= 512 and (not rel or T1 == T2)
 
 
-def attn_fwd(qu, qv, k, v, pos, mask, B, T1, T2, H, dk, ldp, scale, drop=None):
+def attn_fwd(qu, qv, k, v, pos, mask, B, T1, T2, H, dk, ldp, scale, drop=None, shift_len=None):
     """qu / qv / k / v: (tensor, element offset, row stride) views of [rows, *] matrices, heads side by side, all bf16
     (eamd_attn_fwd) or all fp32 (eamd_attn_fwd_f32); pos: such a view of the [T2, H*dk] projected positions, or None.
     Returns (P [H*B*T1*ldp], Pd, ctx [B*T1, H*dk]) in that dtype, or None if the library declines the operands
@@ -710,6 +740,8 @@ def attn_fwd(qu, qv, k, v, pos, mask, B, T1, T2, H, dk, ldp, scale, drop=None):
             ptr(k[0], k[1]), i64(k[2]), ptr(v[0], v[1]), i64(v[2]), ptr(pos[0], pos[1]) if pos is not None else None,
             i64(pos[2] if pos is not None else 0),
             ptr(mask), i64(mb), i64(mi), ptr(P), i64(ldp), ptr(cx), i64(D), B, H, T1, T2, dk, C.c_float(scale)) + dargs
+    # relative positions on a padded batch: the rel_shift is taken over the batch's own length (shift_len: int32 device scalar)
+    args = args + (ptr(shift_len) if (pos is not None and T1 == T2) else None,)
     name = "eamd_attn_fwd" if dt == torch.bfloat16 else "eamd_attn_fwd_f32"
     fn = getattr(_lib.lib(), name)
     rc = fn(*args, stream_ptr())
@@ -721,7 +753,7 @@ def attn_fwd(qu, qv, k, v, pos, mask, B, T1, T2, H, dk, ldp, scale, drop=None):
     return P, Pd, cx
 
 
-def attn_bwd_q(dctx, k, v, P, dS, dbd, dq, B, T1, T2, H, dk, ldp, scale, drop=None):
+def attn_bwd_q(dctx, k, v, P, dS, dbd, dq, B, T1, T2, H, dk, ldp, scale, drop=None, shift_len=None):
     """dctx / k / v / dq: (tensor, element offset, row stride) views; P, dS (and dbd or None): [H*B*T1*ldp], bf16
     (eamd_attn_bwd_q; dq fp32 or bf16) or everything fp32 (eamd_attn_bwd_q_f32).
     dS, dbd and dq are written.  Returns False if the library declines the operands (EAMD_EUNSUPPORTED)."""
@@ -740,6 +772,7 @@ def attn_bwd_q(dctx, k, v, P, dS, dbd, dq, B, T1, T2, H, dk, ldp, scale, drop=No
             assert t_.dtype == torch.float32
         args = (ptr(dctx[0], dctx[1]), i64(dctx[2]), ptr(k[0], k[1]), i64(k[2]), ptr(v[0], v[1]), i64(v[2]), ptr(P), i64(ldp),
                 ptr(dS), ptr(dbd), ptr(dq[0], dq[1]), i64(dq[2]), B, H, T1, T2, dk, C.c_float(scale)) + dargs
+    args = args + (ptr(shift_len) if (dbd is not None and T1 == T2) else None,)
     fn = getattr(_lib.lib(), name)
     rc = fn(*args, stream_ptr())
     if rc == _lib.EAMD_EUNSUPPORTED:
@@ -1070,12 +1103,18 @@ def dwconv_glu_bwd_w(dy, a, dw, db, B, T, Cc, K):
           "eamd_dwconv_glu_bwd_w")
 
 
-def bn_stats(x, M, Cc, eps, momentum, running_mean, running_var, num_batches_tracked=None):
+def bn_stats(x, M, Cc, eps, momentum, running_mean, running_var, num_batches_tracked=None, bound=None):
+    """bound = (T, int32 device scalar): rows (b, t) with t >= bound[0] are left out (eamd_bn_stats_bounded)"""
     nslab = _lib.lib().eamd_bn_nslab(C.c_int64(M), Cc)
     ws = torch.empty(3 * Cc * nslab, device=x.device, dtype=torch.float32)
     mean = torch.empty(Cc, device=x.device, dtype=torch.float32)
     rstd = torch.empty(Cc, device=x.device, dtype=torch.float32)
     assert num_batches_tracked is None or (num_batches_tracked.dtype == torch.int64 and num_batches_tracked.is_cuda)
+    if bound is not None:
+        check(_lib.lib().eamd_bn_stats_bounded(ptr(x), ptr(ws), ptr(mean), ptr(rstd), ptr(running_mean), ptr(running_var),
+                                               ptr(num_batches_tracked), C.c_int64(M), Cc, C.c_float(eps), C.c_float(momentum),
+                                               int(bound[0]), ptr(bound[1]), stream_ptr()), "eamd_bn_stats_bounded")
+        return mean, rstd
     check(_lib.lib().eamd_bn_stats(ptr(x), ptr(ws), ptr(mean), ptr(rstd), ptr(running_mean), ptr(running_var),
                                    ptr(num_batches_tracked), C.c_int64(M), Cc, C.c_float(eps), C.c_float(momentum), stream_ptr()),
           "eamd_bn_stats")
@@ -1089,10 +1128,15 @@ def bn_apply(x, mean, rstd, gamma, beta, M, Cc, act, out_dtype=torch.float32):
     return y
 
 
-def bn_bwd(dy, x, mean, rstd, gamma, beta, dgamma, dbeta, M, Cc, act, training):
+def bn_bwd(dy, x, mean, rstd, gamma, beta, dgamma, dbeta, M, Cc, act, training, bound=None):
     nslab = _lib.lib().eamd_bn_nslab(C.c_int64(M), Cc)
     ws = torch.empty((2 * nslab + 2) * Cc, device=x.device, dtype=torch.float32)
     dx = torch.empty_like(x)
+    if bound is not None:
+        check(_lib.lib().eamd_bn_bwd_bounded(ptr(dy), ptr(x), ptr(mean), ptr(rstd), ptr(gamma), ptr(beta), ptr(ws), ptr(dx),
+                                             ptr(dgamma), ptr(dbeta), C.c_int64(M), Cc, act, int(training), int(bound[0]),
+                                             ptr(bound[1]), stream_ptr()), "eamd_bn_bwd_bounded")
+        return dx
     check(_lib.lib().eamd_bn_bwd(ptr(dy), ptr(x), ptr(mean), ptr(rstd), ptr(gamma), ptr(beta), ptr(ws), ptr(dx),
                                  ptr(dgamma), ptr(dbeta), C.c_int64(M), Cc, act, int(training), stream_ptr()),
           "eamd_bn_bwd")
@@ -1161,9 +1205,15 @@ def ctc_collapse(ids, hlens, blank):
 
 
 # ---- CTC -----------------------------------------------------------------------------------------
-def ctc_loss(acts_btv, ys_pad, ilens, blank=0, ignore_id=-1, grad_scale=1.0, want_grad=True):
-    """acts [B,T,V] raw activations; ys_pad [B,L] int64; ilens [B] int32 -> nll [B], grad [B,T,V]"""
-    B, T, V = acts_btv.shape
+def ctc_loss(acts_btv, ys_pad, ilens, blank=0, ignore_id=-1, grad_scale=1.0, want_grad=True, time_major=False):
+    """acts [B,T,V] raw activations (time_major: [T,B,V], warp-ctc's layout - read in place through the entry point's
+    (stride_t, stride_b), the gradient comes back in the same layout); ys_pad [B,L] int64; ilens [B] int32 -> nll [B], grad"""
+    if time_major:
+        T, B, V = acts_btv.shape
+        st, sb = B * V, V
+    else:
+        B, T, V = acts_btv.shape
+        st, sb = V, T * V
     L = ys_pad.shape[1]
     assert acts_btv.is_contiguous() and ys_pad.is_contiguous() and ys_pad.dtype == torch.int64
     assert ilens.dtype == torch.int32 and ilens.numel() == B and ys_pad.shape[0] == B
@@ -1171,8 +1221,8 @@ def ctc_loss(acts_btv, ys_pad, ilens, blank=0, ignore_id=-1, grad_scale=1.0, wan
     ws = torch.empty(ws_bytes, device=acts_btv.device, dtype=torch.uint8)
     nll = torch.empty(B, device=acts_btv.device, dtype=torch.float32)
     grad = torch.empty_like(acts_btv) if want_grad else None
-    check(_lib.lib().eamd_ctc_loss(ptr(acts_btv), C.c_int64(V), C.c_int64(T * V), ptr(ys_pad), ptr(ilens), ptr(nll),
-                                   ptr(grad), C.c_int64(V), C.c_int64(T * V), ptr(ws), B, T, V, L, blank, ignore_id,
+    check(_lib.lib().eamd_ctc_loss(ptr(acts_btv), C.c_int64(st), C.c_int64(sb), ptr(ys_pad), ptr(ilens), ptr(nll),
+                                   ptr(grad), C.c_int64(st), C.c_int64(sb), ptr(ws), B, T, V, L, blank, ignore_id,
                                    C.c_float(grad_scale), stream_ptr()), "eamd_ctc_loss")
     return nll, grad
 
@@ -1210,6 +1260,11 @@ def adam_step(p, g, m, v, state, beta1, beta2, eps, weight_decay, p16=None):
     check(_lib.lib().eamd_adam_step(ptr(p), ptr(g), ptr(m), ptr(v), ptr(p16), C.c_int64(n), ptr(state), C.c_float(beta1),
                                     C.c_float(beta2), C.c_float(eps), C.c_float(weight_decay), stream_ptr()),
           "eamd_adam_step")
+
+
+def adadelta_step(p, g, sq, acc, state, rho, weight_decay, p16=None):
+    check(_lib.lib().eamd_adadelta_step(ptr(p), ptr(g), ptr(sq), ptr(acc), ptr(p16), C.c_int64(p.numel()), ptr(state),
+                                        C.c_float(rho), C.c_float(weight_decay), stream_ptr()), "eamd_adadelta_step")
 
 
 def add_gradient_noise(g, sigma, salt=0x6e6f697365):

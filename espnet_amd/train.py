@@ -161,6 +161,50 @@ class NoamAdam:
         self.state.copy_(sd["state"])
 
 
+class Adadelta:
+    """torch.optim.Adadelta(rho=0.95, eps=args.eps, weight_decay=args.weight_decay) on the flat arenas - the optimizer of the
+    RNN recipes (espnet/asr/pytorch_backend/asr.py:505-508; egs/librispeech/asr1/conf/tuning/train_rnn.yaml: opt adadelta)
+    - with the espnet1 trainer's gradient clipping / non-finite guard (asr.py:228-240) and its eps decay
+    (asr.py:798-830 -> `eps_decay(factor)`).  Same interface as NoamAdam (step / stats / state_dict)."""
+
+    def __init__(self, flat, lr=1.0, rho=0.95, eps=1e-8, weight_decay=0.0, max_grad_norm=5.0):
+        self.flat = flat
+        self.lr, self.rho, self.weight_decay, self.max_grad_norm = lr, rho, weight_decay, max_grad_norm
+        dev = flat.data.device
+        self.square_avg = torch.zeros_like(flat.data)
+        self.acc_delta = torch.zeros_like(flat.data)
+        self.state = torch.zeros(8, device=dev, dtype=torch.float32)
+        self.state[7] = eps
+        self.gnorm = torch.zeros(1, device=dev, dtype=torch.float32)
+        self.ws = torch.empty(1024, device=dev, dtype=torch.float32)
+
+    @property
+    def eps(self):
+        return float(self.state[7])
+
+    def eps_decay(self, factor):
+        """asr.py:798-830 (adadelta_eps_decay): p["eps"] *= eps_decay; a device-side update, seen by captured steps"""
+        self.state[7:8].mul_(factor)
+
+    def step(self):
+        ops.grad_norm(self.flat.grad, self.ws, self.gnorm)
+        ops.sched_step(self.state, self.gnorm, 0, self.lr, 1.0, 1.0, 1.0, 0.0, 0.0, self.max_grad_norm)
+        ops.adadelta_step(self.flat.data, self.flat.grad, self.square_avg, self.acc_delta, self.state, self.rho,
+                          self.weight_decay, p16=self.flat.shadow)
+
+    def stats(self):
+        s = self.state.tolist()
+        return dict(step=int(s[0]), lr=s[1], grad_norm=s[4], skipped=int(s[5]), clip_coef=s[6], eps=s[7])
+
+    def state_dict(self):
+        return dict(square_avg=self.square_avg, acc_delta=self.acc_delta, state=self.state)
+
+    def load_state_dict(self, sd):
+        self.square_avg.copy_(sd["square_avg"])
+        self.acc_delta.copy_(sd["acc_delta"])
+        self.state.copy_(sd["state"])
+
+
 class GradReducer:
     """Bucketed, backward-overlapped gradient all-reduce on the flat arena (torch.distributed; the
     'nccl' backend is RCCL over xGMI on ROCm, 'gloo' for CPU rehearsal of the control flow)."""
@@ -437,10 +481,14 @@ class BucketedGraphStep:
     needs, and it is a real training step, so the trajectory does not depend on the cache); the second sight captures
     and replays; later ones copy the new batch into the graph's static inputs and replay.
 
-    Padding semantics: frames are padded with zeros and masked exactly as a longer utterance in the same batch would
-    mask them, labels with ignore_id; the result equals the eager step on the same padded batch (tested).  It is not
-    bit-equal to the step on the cropped batch: the reference's own results depend on a batch's longest utterance the
-    same way (subsampled mask lengths, and BatchNorm statistics that include padded frames, conformer/convolution.py)."""
+    Padding semantics: frames are padded with zeros, labels with ignore_id, and the step computes WHAT THE REFERENCE COMPUTES ON
+    THE BATCH CROPPED TO ITS OWN LONGEST UTTERANCE: `model.prepare(pad_to=)` hands the kernels the length T' of the batch's own
+    encoder time axis as a device scalar (`tbound`, refreshed per replay), the encoder mask is the reference's, and the three
+    places of the Conformer that depend on T' follow the bound - the legacy rel_shift (eamd_attn_*'s shift_len), the depthwise
+    convolution's zero padding (eamd_mask_time in front of it) and the BatchNorm statistics (eamd_bn_*_bounded).  Tested against
+    the oracle on the exact-shape batch (tests/test_gpu_model.py::test_bucketed_graph_step_conformer_is_reference_exact:
+    loss 8e-8, running statistics 1e-7, gradients 1e-3) in all three modes.  Needs the fused attention kernels for
+    relative positions (d_k = 64, T' <= 512); other shapes raise."""
 
     def __init__(self, model, flat, opt, t_edge=64, l_edge=8, max_graphs=8):
         from collections import OrderedDict

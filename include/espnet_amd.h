@@ -224,11 +224,15 @@ int eamd_softmax_bwd(const float* P, const void* P_bf16, float* dP, float* dbd, 
  * Attention dropout (attention.py:91; drop_p > 0): ctx = dropout(P) v with the mask eamd_dropout draws for
  * (drop_step, drop_salt) on the elements of P; P stays undropped (the softmax backward needs it) and the dropped
  * probabilities are written to Pd_bf16 (same shape: the operand of dv = Pd^T dctx). */
+/* shift_len (all four entry points; device int32 scalar or NULL = T2): the length the legacy rel_shift
+ * (transformer/attention.py:160-171) is taken over.  A batch that a shape-bucketed graph padded beyond its own longest
+ * utterance T'max passes T'max: bd is then shifted as the reference's T'max x T'max matrix (the keys from T'max on must be
+ * masked by `mask`), so the padded launch reproduces the exact-shape result; read at run time, i.e. per graph replay. */
 int eamd_attn_fwd(const void* qu, int64_t ldq, const void* qv, int64_t ldqv, const void* k, int64_t ldk, const void* v,
                   int64_t ldv, const void* pos, int64_t ldpos, const unsigned char* mask, int64_t mask_bstride,
                   int64_t mask_qstride, void* P_bf16, int64_t ldp, void* ctx_bf16, int64_t ldc, int B, int H, int T1,
                   int T2, int dk, float scale, void* Pd_bf16, float drop_p, const uint64_t* drop_step, uint64_t drop_salt,
-                  void* stream);
+                  const int32_t* shift_len, void* stream);
 
 /* Query side of the attention backward in one launch (same operand layouts and limits as eamd_attn_fwd):
  * dP = dctx v^T, dS = scale * P (dP - rowsum(P dP)) -> dS_bf16 [H][B][T1][ldp] (pad columns zeroed), its inverse
@@ -239,7 +243,7 @@ int eamd_attn_fwd(const void* qu, int64_t ldq, const void* qv, int64_t ldqv, con
 int eamd_attn_bwd_q(const void* dctx, int64_t ldd, const void* k, int64_t ldk, const void* v, int64_t ldv,
                     const void* P_bf16, int64_t ldp, void* dS_bf16, void* dbd_bf16, void* dq, int64_t ldo, int dq_is_bf16,
                     int B, int H, int T1, int T2, int dk, float scale, float drop_p, const uint64_t* drop_step,
-                    uint64_t drop_salt, void* stream);   /* drop_*: the forward's attention dropout (dP <- mask * dP / (1 - p)) */
+                    uint64_t drop_salt, const int32_t* shift_len, void* stream);   /* drop_*: the forward's attention dropout (dP <- mask * dP / (1 - p)) */
 
 /* fp32 twins of eamd_attn_fwd / eamd_attn_bwd_q (the reference's precision; v_mfma_f32_16x16x4_f32): same operand
  * layouts, limits (d_k = 64, T2 <= 512, T1 == T2 with relative positions) and results, every tensor fp32: P, dS, dbd
@@ -249,11 +253,11 @@ int eamd_attn_fwd_f32(const float* qu, int64_t ldq, const float* qv, int64_t ldq
                       const float* v, int64_t ldv, const float* pos, int64_t ldpos, const unsigned char* mask,
                       int64_t mask_bstride, int64_t mask_qstride, float* P, int64_t ldp, float* ctx, int64_t ldc, int B,
                       int H, int T1, int T2, int dk, float scale, float* Pd, float drop_p, const uint64_t* drop_step,
-                      uint64_t drop_salt, void* stream);
+                      uint64_t drop_salt, const int32_t* shift_len, void* stream);
 int eamd_attn_bwd_q_f32(const float* dctx, int64_t ldd, const float* k, int64_t ldk, const float* v, int64_t ldv,
                         const float* P, int64_t ldp, float* dS, float* dbd, float* dq, int64_t ldo, int B, int H, int T1,
                         int T2, int dk, float scale, float drop_p, const uint64_t* drop_step, uint64_t drop_salt,
-                        void* stream);
+                        const int32_t* shift_len, void* stream);
 
 /* Key side of the attention backward in one launch (fp32 tensors, d_k = 64; any T1 / T2): dv = Pd^T dctx, dk = dS^T qu and,
  * with relative positions (dbd, qv, dpos all set; T1 == T2), dpos += dbd^T qv summed over the batch (dpos is ACCUMULATED
@@ -372,6 +376,18 @@ int eamd_bn_finalize(const float* part, int nslab, float* mean, float* rstd, flo
                      int64_t* num_batches_tracked, int C, float eps, float momentum, void* stream);
 int eamd_bn_apply(const float* x, const float* mean, const float* rstd, const float* gamma, const float* beta,
                   void* y, int64_t M, int C, int act, int y_bf16, void* stream);
+/* Time-bounded variants for batches that a shape-bucketed graph padded beyond their own longest utterance (rows are
+ * (b, t) with t = row % T; bound = device int32 scalar, read at run time): rows with t >= bound[0] take no part in the
+ * statistics / sums, count as B * bound rows, and receive dx = 0 - what conformer/convolution.py:56-79 computes on the
+ * batch cropped to its own length.  eamd_mask_time zeroes those rows of an [rows, C] tensor in place (the depthwise
+ * convolution then sees the zero padding the reference has there). */
+int eamd_bn_stats_bounded(const float* x, float* workspace, float* mean, float* rstd, float* running_mean,
+                          float* running_var, int64_t* num_batches_tracked, int64_t M, int C, float eps, float momentum, int T,
+                          const int32_t* bound, void* stream);
+int eamd_bn_bwd_bounded(const float* dy, const float* x, const float* mean, const float* rstd, const float* gamma,
+                        const float* beta, float* workspace, float* dx, float* dgamma, float* dbeta, int64_t M, int C,
+                        int act, int training, int T, const int32_t* bound, void* stream);
+int eamd_mask_time(void* x, int64_t rows, int C, int T, const int32_t* bound, int is_bf16, void* stream);
 /* workspace (2*nslab+2)*C floats; dgamma/dbeta ACCUMULATED. */
 int eamd_bn_bwd(const float* dy, const float* x, const float* mean, const float* rstd, const float* gamma,
                 const float* beta, float* workspace, float* dx, float* dgamma, float* dbeta, int64_t M, int C,
@@ -600,6 +616,11 @@ int eamd_sched_step(float* state, const float* gnorm, int mode, float base_lr, f
 /* p_bf16 (optional): bf16 shadow of the updated parameters, written by the same pass */
 int eamd_adam_step(float* p, const float* g, float* m, float* v, void* p_bf16, int64_t n, const float* state,
                    float beta1, float beta2, float eps, float weight_decay, void* stream);
+/* torch.optim.Adadelta step on flat arenas (the RNN recipes' optimizer: espnet/asr/pytorch_backend/asr.py:505-508).
+ * lr = state[1], clip coefficient = state[6] (eamd_sched_step), eps = state[7] (written by the host; the trainer's
+ * eps decay, asr.py:798-830, rescales it in place); skipped when the gradient norm state[4] is not finite. */
+int eamd_adadelta_step(float* p, const float* g, float* square_avg, float* acc_delta, void* p_bf16, int64_t n,
+                       const float* state, float rho, float weight_decay, void* stream);
 /* g[i] += sigma * N(0,1) over the flat gradient arena (espnet2/torch_utils/add_gradient_noise.py:4-31; the caller
  * computes sigma = eta / (iteration // duration + 1)^scale_factor).  Counter-based draws keyed by the device step
  * counter and `salt`: no generator state, graph-replayable. */

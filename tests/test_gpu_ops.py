@@ -529,6 +529,40 @@ def test_optimizer(ops):
     assert torch.equal(p, before) and float(state[0]) == 5.0 and float(state[5]) == 1.0
 
 
+def test_adadelta_and_warmuplr_golden(ops):
+    """eamd_adadelta_step (+ the trainer's clipping and eps decay) against the trajectory torch.optim.Adadelta produced
+    inside the reference's own loop pieces (asr.py:505-508, asr_utils.py:517-528), and eamd_sched_step mode 2 against
+    the learning rates espnet2's WarmupLR (schedulers/warmup_lr.py:10-53) handed to 14 optimizer steps"""
+    from conftest import load_golden
+    from espnet_amd import train
+    g = load_golden("adadelta.npz")
+    p0, grads, traj = torch.from_numpy(g["p0"]), torch.from_numpy(g["grads"]), torch.from_numpy(g["traj"])
+    lin = torch.nn.Linear(p0.numel(), 1, bias=False).to(DEV)
+    with torch.no_grad():
+        lin.weight.copy_(p0.view(1, -1))
+    flat = train.FlatParams(lin)
+    opt = train.Adadelta(flat, lr=1.0, rho=0.95, eps=1e-8, weight_decay=0.0, max_grad_norm=5.0)
+    for step in range(grads.shape[0]):
+        flat.grad.zero_()
+        lin.weight._eamd_grad.copy_(grads[step].view(1, -1))
+        opt.step()
+        report("adadelta step %d" % step, lin.weight.detach().view(-1), traj[step], 2e-6)
+        if step == 2:
+            opt.eps_decay(0.01)
+    assert abs(opt.eps - float(g["eps_after"])) < 1e-12 * 1e-8 + 1e-16
+    assert opt.stats()["step"] == grads.shape[0]
+    # non-finite gradient: skipped
+    before = lin.weight.detach().clone()
+    lin.weight._eamd_grad.fill_(float("inf"))
+    opt.step()
+    assert torch.equal(lin.weight.detach(), before) and opt.stats()["skipped"] == 1
+    w = load_golden("warmup_lr.npz")
+    state, gn = torch.zeros(8, device=DEV), torch.ones(1, device=DEV)
+    for k, want in enumerate(w["lrs"].tolist()):
+        ops.sched_step(state, gn, 2, float(w["base_lr"]), 1.0, 1.0, float(w["warmup"]), 0.9, 0.98, 0.0)
+        assert abs(float(state[1]) - want) <= 2e-7 * want, (k, float(state[1]), want)
+
+
 # ---------------------------------------------------------------------------------------------
 # bf16-operand fast GEMM (gemm_bf16.hip): inputs are rounded to bf16 on the host first, so the only
 # difference to the float64 reference is fp32 accumulation order -> tight tolerance, which pins the

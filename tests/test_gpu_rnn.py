@@ -249,6 +249,27 @@ def test_e2e_rnn_golden():
     check_grads(m, grads, tol=5e-4)
 
 
+def test_e2e_rnn_scheduled_sampling_golden():
+    """scheduled sampling (rnn/decoders.py:249-254, sampling_probability 0.5): with the Python `random` stream seeded as
+    the fixture's run the decoder embeds its own argmax token at the same steps - loss, accuracy and every gradient equal
+    the reference's"""
+    import random
+    from espnet_amd.nets.e2e_asr import E2E
+    p, sd, grads = split_golden(load_golden("e2e_rnn_ss.npz"))
+    m = load_sd(E2E(12, 7, _rnn_args(sampling_probability=0.5)), sd)
+    m.train()
+    random.seed(7)
+    loss = m(p["xs"].to(DEV), p["ilens"], p["ys"].to(DEV))
+    for name, got, want in (("loss", loss, p["loss"]), ("loss_att", m.loss_att, p["loss_att"]),
+                            ("loss_ctc", m.loss_ctc, p["loss_ctc"])):
+        rel = abs(float(got) - float(want)) / abs(float(want))
+        print("[parity] e2e_rnn_ss %s hip %.6f ref %.6f rel %.2e" % (name, float(got), float(want), rel))
+        assert rel < 1e-5
+    assert abs(float(m.acc) - float(p["acc"])) < 1e-6
+    loss.backward()
+    check_grads(m, grads, tol=5e-4)
+
+
 def test_e2e_rnn_golden_stacked_step_weight_gradients():
     """the same fixture with the gradients in a flat arena and backward inside wgrad_group_begin / end: the weight
     gradients of the per-step products (decoder LSTM cells, attention projections: M = batch rows) are stacked along

@@ -480,3 +480,57 @@ def test_e2e_conformer_dk64(oracle):
     close(out["hs_pad"], torch.from_numpy(g["hs_pad"]), rtol=2e-4, atol=2e-5)
     out["loss"].backward()
     assert _check_seeded_grads(SW, sd, g, 2e-4) < 2e-4
+
+
+# ---- round-3 fixtures (oracle/gen_golden_r3.py): the remaining get_activation entries, any-width subsampling, scheduled
+# sampling, the WarmupLR / Adadelta traces ---------------------------------------------------------------------------
+@pytest.mark.parametrize("name", ["hardtanh", "tanh", "selu"])
+def test_ffn_other_activations(oracle, name):
+    p, sd, grads = split_golden(load_golden("ffn_%s.npz" % name))
+    sd = req(sd)
+    x = p["x"].clone().requires_grad_(True)
+    y = oracle.ffn(sd, "", x, oracle.activation(name))
+    close(y, p["y"])
+    y.backward(p["gy"])
+    close(x.grad, p["gx"])
+    check_param_grads(sd, grads)
+
+
+def test_conv_module_selu(oracle):
+    p, sd, grads = split_golden(load_golden("conv_module_selu.npz"))
+    sd = req(sd)
+    x = p["x"].clone().requires_grad_(True)
+    y = oracle.conv_module(sd, "", x, oracle.activation("selu"), True)
+    close(y, p["y"], rtol=1e-4, atol=1e-5)
+    y.backward(p["gy"])
+    close(x.grad, p["gx"], rtol=1e-4, atol=1e-5)
+    check_param_grads(sd, grads, rtol=1e-4, atol=1e-5)
+
+
+@pytest.mark.parametrize("name", ["subsampling_odim40.npz", "subsampling6_odim48.npz"])
+def test_subsampling_any_width(oracle, name):
+    p, sd, grads = split_golden(load_golden(name))
+    sd = req(sd)
+    y, _, m = oracle.conv2d_subsampling(sd, "", p["x"], p["mask"], False)
+    close(y, p["y"], rtol=1e-4, atol=1e-5)
+    assert torch.equal(m, p["ymask"])
+    y.backward(p["gy"])
+    check_param_grads(sd, grads, rtol=1e-4, atol=1e-4)
+
+
+def test_e2e_rnn_scheduled_sampling(oracle):
+    """rnn/decoders.py:249-254: the decoder feeds back its own argmax token when random.random() < sampling_probability"""
+    import random
+    p, sd, grads = split_golden(load_golden("e2e_rnn_ss.npz"))
+    sd = req(sd)
+    hs, hlens = oracle.rnn_encoder(sd, "enc.", p["xs"], p["ilens"].tolist(), 2, [1, 1, 1])
+    loss_ctc = oracle.ctc_loss(oracle.linear(sd, "ctc.ctc_lo.", hs), torch.tensor(hlens), p["ys"])
+    random.seed(7)
+    loss_att, acc, _ = oracle.rnn_att_decoder(sd, "dec.", hs, hlens, p["ys"], 6, 6, 2, "att.0.", sampling_probability=0.5)
+    close(loss_att.detach(), p["loss_att"], rtol=1e-4, atol=1e-5)
+    assert abs(acc - float(p["acc"])) < 1e-6
+    loss = 0.5 * loss_ctc + 0.5 * loss_att
+    close(loss.detach(), p["loss"], rtol=1e-4, atol=1e-5)
+    loss.backward()
+    _grad_check(sd, grads)
+    assert sum(c < 0.5 for c in p["coins"].tolist()[:6]) >= 1       # the fixture does exercise the sampling branch
