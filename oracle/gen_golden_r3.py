@@ -7,6 +7,7 @@
   conv_module_selu.npz           ConvolutionModule(64, 7, SELU): activation behind BatchNorm, forward + backward
   subsampling_odim40.npz         Conv2dSubsampling(20, 40): an output width that is not a multiple of 64
   subsampling6_odim48.npz        Conv2dSubsampling6(30, 48)
+  e2e_rnn_vggblstm.npz           RNN E2E with etype vggblstm (stacked BLSTM without projections: BASELINE config 4's encoder)
   e2e_rnn_ss.npz                 RNN E2E (as e2e_rnn.npz) with sampling_probability 0.5 (rnn/decoders.py:249-254); the
                                  Python `random` stream is seeded with 7 right before the forward pass
   warmup_lr.npz                  espnet2 WarmupLR (schedulers/warmup_lr.py:10-53): the lr of 14 optimizer steps, warmup 5
@@ -121,6 +122,17 @@ def main():
     coins = [random.random() for _ in range(6)]      # the draws the decoder made (steps 1..6), for the record
     save(out("e2e_rnn_ss.npz"), xs=xs, ilens=ilens, ys=ys, loss=float(loss), loss_att=float(m.loss_att),
          loss_ctc=float(m.loss_ctc), acc=float(m.acc), coins=np.asarray(coins), **sd0, **grads_np(m))
+
+    # ---- a20 with BASELINE config 4's encoder type: VGG + stacked (non-projected) BLSTM (rnn/encoders.py:103-162) ----
+    torch.manual_seed(34)
+    m = RnnE2E(12, 7, rnn_args(etype="vggblstm", elayers=2, eunits=12, eprojs=10))
+    m.train()
+    sd0 = sd_np(m, "sd/")
+    hs, hlens, _ = m.enc(xs, ilens)
+    loss = m(xs, ilens, ys)
+    loss.backward()
+    save(out("e2e_rnn_vggblstm.npz"), xs=xs, ilens=ilens, ys=ys, hs_pad=hs.detach(), hlens=np.asarray(hlens, dtype=np.int64),
+         loss=float(loss), loss_att=float(m.loss_att), loss_ctc=float(m.loss_ctc), acc=float(m.acc), **sd0, **grads_np(m))
 
     # ---- a18: WarmupLR ----
     from espnet2.schedulers.warmup_lr import WarmupLR

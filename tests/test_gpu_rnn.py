@@ -9,7 +9,7 @@ import torch
 
 from conftest import load_golden, split_golden
 from test_gpu_model import check_grads, load_sd
-from test_gpu_ops import report
+from test_gpu_ops import rel_err, report
 
 pytestmark = pytest.mark.gpu
 DEV = "cuda"
@@ -270,6 +270,150 @@ def test_e2e_rnn_scheduled_sampling_golden():
     check_grads(m, grads, tol=5e-4)
 
 
+def test_e2e_rnn_vggblstm_golden():
+    """BASELINE config 4's encoder type (etype vggblstm: VGG + stacked non-projected BLSTM + tanh(l_last),
+    rnn/encoders.py:103-162) against the reference's own run: encoder states, losses, accuracy, every gradient"""
+    from espnet_amd.nets.e2e_asr import E2E
+    p, sd, grads = split_golden(load_golden("e2e_rnn_vggblstm.npz"))
+    m = load_sd(E2E(12, 7, _rnn_args(etype="vggblstm", elayers=2, eunits=12, eprojs=10)), sd)
+    m.train()
+    loss = m(p["xs"].to(DEV), p["ilens"], p["ys"].to(DEV))
+    assert m.hlens == p["hlens"].tolist()
+    report("e2e_rnn_vggblstm hs_pad", m.hs_pad, p["hs_pad"], 1e-4)
+    for name, got, want in (("loss", loss, p["loss"]), ("loss_att", m.loss_att, p["loss_att"]), ("loss_ctc", m.loss_ctc, p["loss_ctc"])):
+        rel = abs(float(got) - float(want)) / abs(float(want))
+        print("[parity] e2e_rnn_vggblstm %s hip %.6f ref %.6f rel %.2e" % (name, float(got), float(want), rel))
+        assert rel < 1e-5
+    assert abs(float(m.acc) - float(p["acc"])) < 1e-6
+    loss.backward()
+    check_grads(m, grads, tol=5e-4)
+
+
+def _config4_args(eunits, adim, dunits, aconv_chans=10, aconv_filts=100, elayers=3):
+    return _rnn_args(elayers=elayers, subsample="1_1_1_1", etype="vggblstm", eunits=eunits, eprojs=eunits, dtype="lstm", dlayers=1,
+                     dunits=dunits, atype="location", aheads=4, awin=5, aconv_chans=aconv_chans, aconv_filts=aconv_filts,
+                     mtlalpha=0.5, adim=adim, char_list=None)
+
+
+@pytest.mark.parametrize("prec", ["fp32", "bf16"])
+def test_config4_midsize_vs_oracle(prec):
+    """BASELINE config 4's architecture (VGG-BLSTM x3, location-aware attention with the recipe's
+    10 x 100 location filters, 1-layer LSTM decoder, CTC) at a width the one-launch LSTM step kernels and the fused attention
+    kernels take (eunits = adim = dunits = 320), B = 4, T = 400, L = 12, V = 500 - one training step against the CPU oracle
+    (e2e_asr.py:205-338 restated): encoder states, both losses, accuracy, the gradient of every parameter tensor"""
+    import espnet_amd
+    from espnet_amd import ops, train
+    from espnet_amd.nets.e2e_asr import E2E
+    from oracle import asr_oracle as oracle
+    espnet_amd.set_precision(prec)
+    try:
+        torch.manual_seed(4)
+        V = 500
+        m = E2E(80, V, _config4_args(320, 320, 320))
+        g = torch.Generator().manual_seed(44)
+        B, T, L = 4, 400, 12
+        ilens = [400, 371, 333, 260]
+        xs = torch.randn(B, T, 80, generator=g)
+        for i, n in enumerate(ilens):
+            xs[i, n:] = 0.0
+        ys = torch.randint(1, V - 1, (B, L), generator=g)
+        ys[1, 9:] = -1
+        ys[3, 7:] = -1
+        sd = {k: v.detach().clone() for k, v in m.state_dict().items()}
+        sdr = {k: (v.clone().requires_grad_(True) if v.is_floating_point() else v.clone()) for k, v in sd.items()}
+        hs, hlens = oracle.rnn_encoder(sdr, "enc.", xs, ilens, 3, [1, 1, 1, 1], proj=False)
+        loss_ctc = oracle.ctc_loss(oracle.linear(sdr, "ctc.ctc_lo.", hs), torch.tensor(hlens), ys)
+        loss_att, acc, _ = oracle.rnn_att_decoder(sdr, "dec.", hs, hlens, ys, V - 1, V - 1, 1, "att.0.")
+        want = 0.5 * loss_ctc + 0.5 * loss_att
+        want.backward()
+        m = m.to(DEV).train()
+        flat = train.FlatParams(m)
+        flat.expose_grads()
+        flat.zero_grad()
+        assert ops.lstm_step_ok(B, 320)
+        loss = m(xs.to(DEV), ilens, ys.to(DEV))
+        ops.wgrad_group_begin()
+        try:
+            loss.backward()
+        finally:
+            ops.wgrad_group_end()
+        assert m.hlens == hlens
+        ltol, gtol, htol = (1e-5, 2e-3, 1e-4) if prec == "fp32" else (2e-3, 6e-2, 2e-2)
+        report("config 4 mid-size [%s] hs_pad" % prec, m.hs_pad, hs.detach(), htol)
+        for name, got, ref in (("loss", loss, want), ("loss_att", m.loss_att, loss_att), ("loss_ctc", m.loss_ctc, loss_ctc)):
+            rel = abs(float(got) - float(ref)) / abs(float(ref))
+            print("[parity] config 4 mid-size [%s] %s hip %.6f oracle %.6f rel %.2e" % (prec, name, float(got), float(ref), rel))
+            assert rel < ltol
+        assert abs(float(m.acc) - acc) < (1e-6 if prec == "fp32" else 0.05)
+        worst = ("", 0.0)
+        gmax = max(float(v.grad.abs().max()) for v in sdr.values() if getattr(v, "grad", None) is not None)
+        for name, prm in m.named_parameters():
+            if sdr[name].grad is None:
+                continue
+            if float(sdr[name].grad.abs().max()) < 1e-6 * gmax:
+                # mathematically zero (gvec.bias: the attention softmax is invariant to a shift of all energies): rounding
+                # noise on both sides, compared by size
+                assert float(prm.grad.abs().max()) < 1e-4 * gmax, name
+                continue
+            e = rel_err(prm.grad, sdr[name].grad)
+            worst = max(worst, (name, e), key=lambda kv: kv[1])
+            assert e < gtol, (name, e)
+        print("[parity] config 4 mid-size [%s]: worst parameter-gradient rel err %.2e (%s)" % (prec, worst[1], worst[0]))
+    finally:
+        espnet_amd.set_precision("fp32")
+
+
+def test_config4_fullsize_properties():
+    """BASELINE config 4 at FULL size (VGG-BLSTM 3 x 1024, location attention 10 x 100, LSTM decoder 1024, B = 32, T = 1000,
+    L = 100, V = 5000): properties the size does not change - a finite loss, the captured step's replay equals the eager step,
+    two replays are bit-equal (no atomics race in loss or encoder states), every gradient finite"""
+    import math
+    import espnet_amd
+    from espnet_amd import ops, train
+    from espnet_amd.nets.e2e_asr import E2E
+    espnet_amd.set_precision("fp32")
+    torch.manual_seed(0)
+    V = 5000
+    m = E2E(80, V, _config4_args(1024, 1024, 1024)).to(DEV).train()
+    flat = train.FlatParams(m)
+    g = torch.Generator().manual_seed(0)
+    B, T, L = 32, 1000, 100
+    xs = torch.randn(B, T, 80, generator=g).to(DEV)
+    ilens = [T - 7 * i for i in range(B)]
+    ys = torch.randint(1, V - 1, (B, L), generator=g)
+
+    def step():
+        flat.zero_grad()
+        loss = m(xs, ilens, ys)
+        ops.wgrad_group_begin()
+        try:
+            loss.backward()
+        finally:
+            ops.wgrad_group_end()
+        return loss
+
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        eager = float(step())
+        step()
+        torch.cuda.synchronize()
+    torch.cuda.current_stream().wait_stream(side)
+    gr = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(gr):
+        loss = step()
+    gr.replay()
+    torch.cuda.synchronize()
+    l1, hs1 = float(loss), m.hs_pad.clone()
+    gr.replay()
+    torch.cuda.synchronize()
+    l2 = float(loss)
+    print("[parity] config 4 full size: loss eager %.6f, replay %.6f / %.6f" % (eager, l1, l2))
+    assert math.isfinite(eager) and abs(l1 - eager) <= 1e-5 * abs(eager)
+    assert l1 == l2 and torch.equal(hs1, m.hs_pad)
+    assert bool(torch.isfinite(flat.grad).all())
+
+
 def test_e2e_rnn_golden_stacked_step_weight_gradients():
     """the same fixture with the gradients in a flat arena and backward inside wgrad_group_begin / end: the weight
     gradients of the per-step products (decoder LSTM cells, attention projections: M = batch rows) are stacked along
@@ -480,6 +624,51 @@ def test_fused_joint_loss_config5_shape_vs_materialised(prec):
         report("fused joint+loss [%s] d h_dec" % prec, res[0][2], res[1][2], tol)
         for (n_, _q), ga, gb in zip(jn.named_parameters(), res[0][3], res[1][3]):
             report("fused joint+loss [%s] d %s" % (prec, n_), ga, gb, tol)
+    finally:
+        espnet_amd.set_precision("fp32")
+
+
+@pytest.mark.parametrize("prec", ["fp32", "bf16"])
+def test_fused_joint_loss_config5_width_vs_oracle(prec):
+    """the streamed joint network + transducer loss at BASELINE config 5's real width (J = 320, V = 5000,
+    U = 101), GEMM row epilogues 7 / 8 on (the logits are never stored), against the ORACLE in float64: joint network
+    lin_out(tanh(lin_enc(h_enc) + lin_dec(h_dec))) (transducer/joint_network.py) -> oracle.rnnt_loss (Graves 2012 recursion,
+    brute-force-checked on small lattices; the loss VALUE stays 'parity unpinned by the package') -> autograd.
+    Loss 1e-5 (fp32) / 1e-3 (bf16 operands), all five gradients."""
+    import espnet_amd
+    from espnet_amd.nets.transducer.joint_network import JointNetwork
+    from oracle import asr_oracle as oracle
+    espnet_amd.set_precision(prec)
+    try:
+        torch.manual_seed(5)
+        B, T, U, De, Dd, J, V = 2, 41, 101, 256, 320, 320, 5000
+        jn = JointNetwork(V, De, Dd, J, "tanh")
+        g = torch.Generator().manual_seed(56)
+        he, hd = 0.5 * torch.randn(B, T, De, generator=g), 0.5 * torch.randn(B, U, Dd, generator=g)
+        y = torch.randint(1, V, (B, U - 1), generator=g).int()
+        tl_host, ul_host = [41, 29], [100, 63]
+        # ---- oracle, float64 ----
+        sd = {k: v.detach().double().clone().requires_grad_(True) for k, v in jn.state_dict().items()}
+        a64, b64 = he.double().clone().requires_grad_(True), hd.double().clone().requires_grad_(True)
+        pre = oracle.linear(sd, "lin_enc.", a64).unsqueeze(2) + torch.nn.functional.linear(b64, sd["lin_dec.weight"]).unsqueeze(1)
+        z = oracle.linear(sd, "lin_out.", torch.tanh(pre))                                   # (B, T, U, V) float64: 0.33 GB
+        want = oracle.rnnt_loss(z, y.long(), torch.tensor(tl_host), torch.tensor(ul_host), blank=0)
+        want.backward()
+        del z, pre
+        # ---- HIP: streamed, row epilogues ----
+        jn = jn.to(DEV)
+        a, b = he.to(DEV).requires_grad_(True), hd.to(DEV).requires_grad_(True)
+        tl, ul = torch.tensor(tl_host, dtype=torch.int32).to(DEV), torch.tensor(ul_host, dtype=torch.int32).to(DEV)
+        loss = jn.loss(a, b, y.to(DEV), tl, ul, tl_host, 0, chunk_rows=1500)
+        loss.backward()
+        rel = abs(float(loss) - float(want)) / abs(float(want))
+        print("[parity] fused joint+loss [%s] J=320 V=5000 vs float64 oracle: %.6f vs %.6f (rel %.2e)" % (prec, float(loss), float(want), rel))
+        assert rel < (1e-5 if prec == "fp32" else 1e-3)
+        tol = 2e-4 if prec == "fp32" else 3e-2
+        report("fused joint+loss vs oracle [%s] d h_enc" % prec, a.grad, a64.grad, tol)
+        report("fused joint+loss vs oracle [%s] d h_dec" % prec, b.grad, b64.grad, tol)
+        for n_, q in jn.named_parameters():
+            report("fused joint+loss vs oracle [%s] d %s" % (prec, n_), q.grad, sd[n_].grad, tol)
     finally:
         espnet_amd.set_precision("fp32")
 

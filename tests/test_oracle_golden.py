@@ -534,3 +534,19 @@ def test_e2e_rnn_scheduled_sampling(oracle):
     loss.backward()
     _grad_check(sd, grads)
     assert sum(c < 0.5 for c in p["coins"].tolist()[:6]) >= 1       # the fixture does exercise the sampling branch
+
+
+def test_e2e_rnn_vggblstm(oracle):
+    """BASELINE config 4's encoder type: VGG + stacked non-projected BLSTM + tanh(l_last) (rnn/encoders.py:103-162)"""
+    p, sd, grads = split_golden(load_golden("e2e_rnn_vggblstm.npz"))
+    sd = req(sd)
+    hs, hlens = oracle.rnn_encoder(sd, "enc.", p["xs"], p["ilens"].tolist(), 2, [1, 1, 1], proj=False)
+    assert hlens == p["hlens"].tolist()
+    close(hs, p["hs_pad"], rtol=1e-4, atol=1e-5)
+    loss_ctc = oracle.ctc_loss(oracle.linear(sd, "ctc.ctc_lo.", hs), torch.tensor(hlens), p["ys"])
+    loss_att, acc, _ = oracle.rnn_att_decoder(sd, "dec.", hs, hlens, p["ys"], 6, 6, 2, "att.0.")
+    loss = 0.5 * loss_ctc + 0.5 * loss_att
+    close(loss.detach(), p["loss"], rtol=1e-4, atol=1e-5)
+    assert abs(acc - float(p["acc"])) < 1e-6
+    loss.backward()
+    _grad_check(sd, grads)
