@@ -405,6 +405,9 @@ def main():
                          "all-reduces")
     ap.add_argument("--ragged", action="store_true",
                     help="N=1: add a `ragged` object: variable-length batch stream, eager vs shape-bucketed hipGraph cache")
+    ap.add_argument("--no-decode", action="store_true", help="skip the `decode` object (greedy CTC / beam searches, ~30 s)")
+    ap.add_argument("--no-extra-configs", action="store_true",
+                    help="skip the `configs` object (BASELINE configs 4 and 5 at full size, both precisions, ~40 s)")
     ap.add_argument("--rehearse-dp", action="store_true",
                     help="N=1 only: run the N>1 'graph' code path on a one-rank RCCL group")
     a = ap.parse_args()
@@ -431,6 +434,17 @@ def main():
     ragged = None
     if rank == 0 and world == 1 and a.ragged:
         ragged = ragged_leg(a, a.precision, dev)
+
+    extra = None
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    if rank == 0 and world == 1 and not a.no_extra_configs:
+        from tools import bench_rnn
+        extra = bench_rnn.extra_configs()
+
+    decode = None
+    if rank == 0 and world == 1 and not a.no_decode:
+        from tools import bench_decode
+        decode = bench_decode.decode_leg(dev, c2_args)
 
     cpu = orc = None
     if rank == 0 and world == 1 and not a.no_cpu_baseline:
@@ -480,6 +494,10 @@ def main():
         }
         if ragged is not None:
             out["ragged"] = ragged
+        if extra is not None:
+            out["configs"] = extra
+        if decode is not None:
+            out["decode"] = decode
         print(json.dumps(out))
     if torch.distributed.is_initialized():
         torch.distributed.barrier()

@@ -1332,19 +1332,31 @@ def lstm_step_ok(B, H):
 LSTM_FUSED_STEP = True      # tests flip this to compare against the GEMM + cell-kernel steps
 
 
+# bench.py: list collecting the recurrent launches of one step as (tag, operand references, replay(stream_ptr), bytes)
+_rnn_record = None
+
+
 def lstm_step_fwd(gx_t, w_hh, b_hh, h_prev, c_prev, live_t, h, c, y, acts):
     B, H4 = gx_t.shape
     H = H4 // 4
-    check(_lib.lib().eamd_lstm_step_fwd(ptr(gx_t), ptr(w_hh), ptr(b_hh), ptr(h_prev), ptr(c_prev), ptr(live_t), ptr(h), ptr(c),
-                                        ptr(y), ptr(acts), B, H, stream_ptr()), "eamd_lstm_step_fwd")
+    args = (ptr(gx_t), ptr(w_hh), ptr(b_hh), ptr(h_prev), ptr(c_prev), ptr(live_t), ptr(h), ptr(c), ptr(y), ptr(acts), B, H)
+    fn = _lib.lib().eamd_lstm_step_fwd
+    if _rnn_record is not None:
+        _rnn_record.append(("lstm_step_fwd", (gx_t, w_hh, b_hh, h_prev, c_prev, live_t, h, c, y, acts),
+                            lambda sp, args=args: check(fn(*args, sp), "eamd_lstm_step_fwd"), 4 * (H4 * H + 3 * B * H4)))
+    check(fn(*args, stream_ptr()), "eamd_lstm_step_fwd")
 
 
 def lstm_step_bwd(dy_t, dgates_next, w_t, dh_pass_in, dc, acts, c_prev, c, live_t, dgates, dc_prev, dh_pass):
     B, H4 = acts.shape
     H = H4 // 4
-    check(_lib.lib().eamd_lstm_step_bwd(ptr(dy_t), ptr(dgates_next), ptr(w_t), ptr(dh_pass_in), ptr(dc), ptr(acts), ptr(c_prev),
-                                        ptr(c), ptr(live_t), ptr(dgates), ptr(dc_prev), ptr(dh_pass), B, H, stream_ptr()),
-          "eamd_lstm_step_bwd")
+    args = (ptr(dy_t), ptr(dgates_next), ptr(w_t), ptr(dh_pass_in), ptr(dc), ptr(acts), ptr(c_prev), ptr(c), ptr(live_t),
+            ptr(dgates), ptr(dc_prev), ptr(dh_pass), B, H)
+    fn = _lib.lib().eamd_lstm_step_bwd
+    if _rnn_record is not None:
+        _rnn_record.append(("lstm_step_bwd", (dy_t, dgates_next, w_t, dh_pass_in, dc, acts, c_prev, c, live_t, dgates, dc_prev, dh_pass),
+                            lambda sp, args=args: check(fn(*args, sp), "eamd_lstm_step_bwd"), 4 * (H4 * H + 4 * B * H4)))
+    check(fn(*args, stream_ptr()), "eamd_lstm_step_bwd")
 
 
 def maxpool2x2_fwd(x):
