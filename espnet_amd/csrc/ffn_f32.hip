@@ -42,6 +42,9 @@ __device__ unsigned long long ffn_stamps[2][2][8][8];
 #define STAMP3(role, P, s, k) do { } while (0)
 #endif
 
+bool eamd_ffn_bf16_ok(const eamd_ffn_t* p);                      // ffn_bf16.hip
+int eamd_ffn_bf16_launch(const eamd_ffn_t* p, int bwd, void* stream);
+
 namespace {
 
 constexpr int FBM = 32;          // rows per workgroup
@@ -406,7 +409,14 @@ int launch_ffn(const eamd_ffn_t& p, hipStream_t stream) {
 int check_ffn(const eamd_ffn_t* p, bool bwd) {
   if (!p || !p->x || !p->w1 || !p->w2 || !p->out) return EAMD_EINVAL;
   if (p->M <= 0 || p->D <= 0 || p->F <= 0) return EAMD_EINVAL;
-  if (p->dtype != 0) return EAMD_EUNSUPPORTED;                       // fp32 operands (the bf16 twin: not built)
+  if (p->dtype != 0 && p->dtype != 1) return EAMD_EINVAL;
+  if (p->dtype == 1) {                                               // bf16 operands: ffn_bf16.hip
+    if (!eamd_ffn_bf16_ok(p)) return EAMD_EUNSUPPORTED;
+    if (bwd) return p->f ? EAMD_OK : EAMD_EINVAL;
+    if (p->p_in < 0.f || p->p_in >= 1.f || p->p_out < 0.f || p->p_out >= 1.f) return EAMD_EINVAL;
+    if ((p->p_in > 0.f || p->p_out > 0.f) && !p->drop_step) return EAMD_EINVAL;
+    return (p->act == EAMD_ACT_RELU || p->act == EAMD_ACT_SWISH) ? EAMD_OK : EAMD_EUNSUPPORTED;
+  }
   if (p->D != FD || p->F % FHC != 0 || p->F < 2 * FHC) return EAMD_EUNSUPPORTED;
   if ((long)p->M * p->F >= (1L << 31)) return EAMD_EUNSUPPORTED;     // 32-bit dropout pair index space
   if (!al16(p->x) || !al16(p->w1) || !al16(p->w2) || !al16(p->out) || (p->R && !al16(p->R)) || (p->b2 && !al16(p->b2)))
@@ -432,6 +442,7 @@ extern "C" int eamd_ffn_debug_stamps(unsigned long long* host) {
 extern "C" int eamd_ffn_fwd(const eamd_ffn_t* p, void* stream) {
   const int rc = check_ffn(p, false);
   if (rc != EAMD_OK) return rc;
+  if (p->dtype == 1) return eamd_ffn_bf16_launch(p, 0, stream);
   return p->act == EAMD_ACT_SWISH ? launch_ffn<false, EAMD_ACT_SWISH>(*p, (hipStream_t)stream)
                                   : launch_ffn<false, EAMD_ACT_RELU>(*p, (hipStream_t)stream);
 }
@@ -439,5 +450,6 @@ extern "C" int eamd_ffn_fwd(const eamd_ffn_t* p, void* stream) {
 extern "C" int eamd_ffn_bwd(const eamd_ffn_t* p, void* stream) {
   const int rc = check_ffn(p, true);
   if (rc != EAMD_OK) return rc;
+  if (p->dtype == 1) return eamd_ffn_bf16_launch(p, 1, stream);
   return launch_ffn<true, EAMD_ACT_NONE>(*p, (hipStream_t)stream);
 }

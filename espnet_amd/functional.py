@@ -220,12 +220,15 @@ class FFNBlockFn(torch.autograd.Function):
         assert eps is not None or p_out <= 0.0
         fused = ops.fast()      # bf16-operand GEMMs carry the dropout masks in their epilogues
         h, zf = None, False
-        if (eps is not None and ops.f32_epilogue_drop() and not ops.f32_operand_drop() and xn.dtype == torch.float32
-                and ops.ffn_fused_ok(xn, w1, w2, act)):
+        if (eps is not None and (ops.fast() or (ops.f32_epilogue_drop() and not ops.f32_operand_drop()))
+                and ops.ffn_fused_ok(xn, ops.wshadow(w1), ops.wshadow(w2), act)):
             # fp32 mode, d = 256: BOTH products in one launch (csrc/ffn_f32.hip) - 32 rows per workgroup, the hidden units
             # never make a round trip for the second product; kept for backward: h and the factor f (no grad: neither)
             need = any(ctx.needs_input_grad[:7])          # (grad mode is off inside forward: needs_input_grad tells no-grad calls apart)
-            out, z, h = ops.ffn_fwd(xn, w1, b1, w2, b2, act=act, alpha=scale, R=x2, drop=(p_in, s_in, p_out, s_out), save=need)
+            packs = ops.ffn_pack(w1, w2) if ops.fast() else None       # bf16 mode: the four packed weight images of this layer
+            out, z, h = ops.ffn_fwd(xn, ops.wshadow(w1), b1, ops.wshadow(w2), b2, act=act, alpha=scale, R=x2,
+                                    drop=(p_in, s_in, p_out, s_out), save=need, packed=packs[:2] if packs else None)
+            ctx.packs = packs[2:] if packs else None
             ctx.save_for_backward(x2, mean, rstd, xn, z, h)
             ctx.pr = GradSink.use((ln_w, ln_b, w1, b1, w2, b2))
             ctx.cfg = (scale, act, shp, drop)
@@ -311,8 +314,12 @@ class FFNBlockFn(torch.autograd.Function):
             dxn = ops.linear_bwd_x(dz, ops.wshadow(w1))
             dx = _ln_bwd_out(dxn, x2, ln_w, mean, rstd, do, sink.buf(0), sink.buf(1), ctx.prev, shp)
             return (dx,) + sink.results() + (None, None, None, None)
-        if ctx.one_launch and g_drop is None and dob.dtype == torch.float32:
-            dz, dxn = ops.ffn_bwd(dob, w1, w2, z, alpha=scale)          # dz = s (dob W2) (.) f and dxn = dz W1: one launch
+        if ctx.one_launch and g_drop is None and dob.dtype == z.dtype:
+            # dz = s (dob W2) (.) f and dxn = dz W1: one launch (bf16 operands: on the transposed weight copies)
+            if dob.dtype == torch.bfloat16:
+                dz, dxn = ops.ffn_bwd(dob, w1, w2, z, alpha=scale, packed=ctx.packs)
+            else:
+                dz, dxn = ops.ffn_bwd(dob, w1, w2, z, alpha=scale)
             ops.linear_bwd_w(dz, xn, sink.buf(2), db=sink.buf(3))
             dx = _ln_bwd_out(dxn, x2, ln_w, mean, rstd, do, sink.buf(0), sink.buf(1), ctx.prev, shp)
             return (dx,) + sink.results() + (None, None, None, None)

@@ -480,19 +480,23 @@ FUSED_FFN_MIN_ROWS = int(os.environ.get("EAMD_FUSED_FFN_MIN_ROWS", "4096"))     
 
 
 def ffn_fused_ok(x, w1, w2, act):
-    """True if eamd_ffn_fwd / _bwd take this problem (fp32 operands, D = 256, F a multiple of 128, enough rows to fill
-    the chip); otherwise the block runs as two eamd_gemm products"""
-    return (FUSED_FFN and x.dtype == torch.float32 and w1.dtype == torch.float32 and _state["precision"] == 0
-            and x.shape[1] == 256 and w1.shape[1] == 256 and w1.shape[0] % 128 == 0 and w1.shape[0] >= 256
+    """True if eamd_ffn_fwd / _bwd take this problem (operands all fp32 in fp32 mode or all bf16 in bf16 mode, D = 256, F a
+    multiple of 128 / 256, enough rows to fill the chip); otherwise the block runs as two eamd_gemm products"""
+    bf = x.dtype == torch.bfloat16
+    if not FUSED_FFN or x.dtype != w1.dtype or w1.dtype != w2.dtype or (bf and _state["precision"] != 1) or \
+            (not bf and (x.dtype != torch.float32 or _state["precision"] != 0)):
+        return False
+    return (x.shape[1] == 256 and w1.shape[1] == 256 and w1.shape[0] % (256 if bf else 128) == 0 and w1.shape[0] >= 256
             and tuple(w2.shape) == (256, w1.shape[0]) and act in (ACT_RELU, ACT_SWISH) and x.shape[0] >= FUSED_FFN_MIN_ROWS)
 
 
-def _ffn_desc(x, w1, b1, w2, b2, R, out, f, h, act, alpha, drop):
+def _ffn_desc(x, w1, b1, w2, b2, R, out, f, h, act, alpha, drop, F=None):
     p = _lib.FfnT()
     p.x, p.w1, p.b1, p.w2, p.b2, p.R = ptr(x), ptr(w1), ptr(b1), ptr(w2), ptr(b2), ptr(R)
     p.out, p.f, p.h = ptr(out), ptr(f), ptr(h)
-    p.M, p.D, p.F, p.act = x.shape[0], x.shape[1], w1.shape[0], act
+    p.M, p.D, p.F, p.act = x.shape[0], x.shape[1], (F if F is not None else w1.shape[0]), act
     p.alpha = alpha
+    p.dtype = 1 if x.dtype == torch.bfloat16 else 0
     p_in, s_in, p_out, s_out = drop
     p.p_in, p.salt_in, p.p_out, p.salt_out = float(p_in), int(s_in), float(p_out), int(s_out)
     if p_in > 0.0 or p_out > 0.0:
@@ -507,34 +511,68 @@ def _ffn_call(name, p, keep):
     check(fn(C.byref(p), stream_ptr()), name)
 
 
-def ffn_fwd(x, w1, b1, w2, b2, *, act, alpha=1.0, R=None, drop=(0.0, 0, 0.0, 0), save=True):
+def ffn_fwd(x, w1, b1, w2, b2, *, act, alpha=1.0, R=None, drop=(0.0, 0, 0.0, 0), save=True, packed=None):
     """out = R + alpha * drop_out(drop_in(act(x W1^T + b1)) W2^T + b2) in ONE launch; with save also the two tensors
-    backward needs: h = drop_in(act(z)) and f = mask / (1 - p) * act'(z).  -> (out, f, h)"""
+    backward needs: h = drop_in(act(z)) and f = mask / (1 - p) * act'(z).  -> (out fp32, f, h); x / w1 / w2 all fp32 or all
+    bf16 (f, h in that dtype)"""
     M, D = x.shape
     F = w1.shape[0]
-    for t_ in (x, w1, w2) + tuple(v for v in (b1, b2, R) if v is not None):
+    dt = x.dtype
+    for t_ in (x, w1, w2):
+        if t_.dtype != dt or dt not in (torch.float32, torch.bfloat16) or not t_.is_contiguous():
+            raise _lib.EamdError("ffn_fwd: contiguous float32 or bfloat16 operands of one dtype")
+    for t_ in tuple(v for v in (b1, b2, R) if v is not None):
         if t_.dtype != torch.float32 or not t_.is_contiguous():
-            raise _lib.EamdError("ffn_fwd: contiguous float32 tensors")
+            raise _lib.EamdError("ffn_fwd: biases / residual are contiguous float32 tensors")
     out = torch.empty(M, D, device=x.device, dtype=torch.float32)
-    f = torch.empty(M, F, device=x.device, dtype=torch.float32) if save else None
-    h = torch.empty(M, F, device=x.device, dtype=torch.float32) if save else None
+    f = torch.empty(M, F, device=x.device, dtype=dt) if save else None
+    h = torch.empty(M, F, device=x.device, dtype=dt) if save else None
+    if dt == torch.bfloat16:      # the kernel reads the packed images (ffn_pack)
+        if packed is None:
+            packed = ffn_pack(w1, w2)[:2]
+        p = _ffn_desc(x, packed[0], b1, packed[1], b2, R, out, f, h, act, alpha, drop, F=F)
+        _ffn_call("eamd_ffn_fwd", p, (x, packed, b1, b2, R, out, f, h))
+        return out, f, h
     p = _ffn_desc(x, w1, b1, w2, b2, R, out, f, h, act, alpha, drop)
     _ffn_call("eamd_ffn_fwd", p, (x, w1, b1, w2, b2, R, out, f, h))
     return out, f, h
 
 
-def ffn_bwd(dy, w1, w2, f, *, alpha=1.0):
-    """dz = alpha * (dy W2) (.) f and dx = dz W1 in ONE launch -> (dz [M, F], dx [M, D])"""
+def ffn_pack(w1, w2):
+    """the four packed bf16 weight images of one FFN (eamd_ffn_pack_bf16) -> (fwd_first, fwd_second, bwd_first, bwd_second),
+    each F * D elements.  Cached buffers on w1; the PACKING is redone at every call: the optimizer kernel rewrites the bf16
+    shadow arena in place (no tensor version to watch), and under hipGraph capture it has to be part of the replayed step."""
+    F, D = w1.shape
+    s1, s2 = (wshadow(w1), wshadow(w2)) if w1.dtype != torch.bfloat16 else (w1, w2)
+    buf = getattr(w1, "_eamd_ffn_pack", None)
+    if buf is None or buf.numel() != 4 * F * D or buf.device != s1.device:
+        buf = torch.empty(4, F * D, device=s1.device, dtype=torch.bfloat16)
+        w1._eamd_ffn_pack = buf
+    check(_lib.lib().eamd_ffn_pack_bf16(ptr(s1), ptr(s2), ptr(buf[0]), ptr(buf[1]), ptr(buf[2]), ptr(buf[3]), D, F, stream_ptr()),
+          "eamd_ffn_pack_bf16")
+    return buf[0], buf[1], buf[2], buf[3]
+
+
+def ffn_bwd(dy, w1, w2, f, *, alpha=1.0, packed=None):
+    """dz = alpha * (dy W2) (.) f and dx = dz W1 in ONE launch -> (dz [M, F], dx [M, D] fp32).  bf16 operands: packed =
+    (bwd_first, bwd_second) of ffn_pack are what the kernel reads"""
     M, D = dy.shape
     F = w1.shape[0]
-    for t_ in (dy, w1, w2, f):
-        if t_.dtype != torch.float32 or not t_.is_contiguous():
-            raise _lib.EamdError("ffn_bwd: contiguous float32 tensors")
-    assert f.shape == (M, F)
-    dz = torch.empty(M, F, device=dy.device, dtype=torch.float32)
+    dt = dy.dtype
+    assert f.shape == (M, F) and f.dtype == dt and f.is_contiguous() and dy.is_contiguous()
+    dz = torch.empty(M, F, device=dy.device, dtype=dt)
     dx = torch.empty(M, D, device=dy.device, dtype=torch.float32)
-    p = _ffn_desc(dy, w1, None, w2, None, None, dx, f, dz, ACT_NONE, alpha, (0.0, 0, 0.0, 0))
-    _ffn_call("eamd_ffn_bwd", p, (dy, w1, w2, f, dz, dx))
+    if dt == torch.bfloat16:
+        assert packed is not None and packed[0].numel() == F * D and packed[1].numel() == F * D
+        p = _ffn_desc(dy, packed[0], None, packed[1], None, None, dx, f, dz, ACT_NONE, alpha, (0.0, 0, 0.0, 0), F=F)
+        keep = (dy, packed, f, dz, dx)
+    else:
+        for t_ in (dy, w1, w2, f):
+            if t_.dtype != torch.float32 or not t_.is_contiguous():
+                raise _lib.EamdError("ffn_bwd: contiguous float32 tensors")
+        p = _ffn_desc(dy, w1, None, w2, None, None, dx, f, dz, ACT_NONE, alpha, (0.0, 0, 0.0, 0))
+        keep = (dy, w1, w2, f, dz, dx)
+    _ffn_call("eamd_ffn_bwd", p, keep)
     return dz, dx
 
 

@@ -486,7 +486,7 @@ class BucketedGraphStep:
     encoder time axis as a device scalar (`tbound`, refreshed per replay), the encoder mask is the reference's, and the three
     places of the Conformer that depend on T' follow the bound - the legacy rel_shift (eamd_attn_*'s shift_len), the depthwise
     convolution's zero padding (eamd_mask_time in front of it) and the BatchNorm statistics (eamd_bn_*_bounded).  Tested against
-    the oracle on the exact-shape batch (tests/test_gpu_model.py::test_bucketed_graph_step_conformer_is_reference_exact:
+    the CPU restatement of the reference on the exact-shape batch (tests/test_gpu_model.py::test_bucketed_graph_step_conformer_is_reference_exact:
     loss 8e-8, running statistics 1e-7, gradients 1e-3) in all three modes.  Needs the fused attention kernels for
     relative positions (d_k = 64, T' <= 512); other shapes raise."""
 

@@ -149,8 +149,14 @@ int eamd_gemm_group_launch(const eamd_gemm_t* descs_dev, const int32_t* first_de
  *                  out[M,D] <- dz W1
  * Dropout masks are eamd_dropout's (element index of the contiguous [M,F] / [M,D] tensor, salts salt_in / salt_out,
  * drop_step = the device step counter of eamd_rng_advance).  w1 [F,D], w2 [D,F] row-major (nn.Linear layout).
- * dtype 0 = fp32 operands on v_mfma_f32_16x16x4_f32.  Returns EAMD_EUNSUPPORTED for shapes the kernel is not built for
- * (D != 256, F not a multiple of 128, unaligned operands): the caller then runs the two eamd_gemm products. */
+ * dtype 0 = fp32 operands on v_mfma_f32_16x16x4_f32.
+ * dtype 1 = bf16 operands on v_mfma_f32_16x16x32_bf16: x, f, h address bf16 (b1, b2, R, out stay fp32); F a multiple of
+ *   256; w1 / w2 address the PACKED weight images of eamd_ffn_pack_bf16 (MFMA fragment order: every wave-instruction of the
+ *   kernel reads 1 KB of consecutive bytes): fwd_first / fwd_second for eamd_ffn_fwd, bwd_first / bwd_second for eamd_ffn_bwd.
+ *   eamd_ffn_pack_bf16 makes the four images (F * D * 2 bytes each) of one layer from its nn.Linear-layout bf16 weights
+ *   (w1 [F, D], w2 [D, F]) in one launch; re-run it whenever the weights change (every optimizer step).
+ * Returns EAMD_EUNSUPPORTED for shapes the kernels are not built for (D != 256, F not a multiple of 128 / 256, unaligned
+ * operands): the caller then runs the two eamd_gemm products. */
 typedef struct {
   const float* x; const float* w1; const float* b1; const float* w2; const float* b2; const float* R;
   float* out; float* f; float* h;
@@ -161,6 +167,8 @@ typedef struct {
 } eamd_ffn_t;
 int eamd_ffn_fwd(const eamd_ffn_t* p, void* stream);
 int eamd_ffn_bwd(const eamd_ffn_t* p, void* stream);
+int eamd_ffn_pack_bf16(const void* w1, const void* w2, void* fwd_first, void* fwd_second, void* bwd_first, void* bwd_second,
+                       int D, int F, void* stream);
 
 /* ------------------------------------------------------------------------------------------
  * Row kernels (HBM-bound).

@@ -1344,3 +1344,54 @@ def test_ffn_fused_vs_float64(ops, M, F, act, p_in, p_out):
     dz_ref = alpha * (dy.double() @ w2.double()) * f.double().cpu()
     report("ffn fused dz " + tag, dz, dz_ref, 2e-6)
     report("ffn fused dx " + tag, dx, dz_ref @ w1.double(), 2e-6)
+
+
+@pytest.mark.parametrize("M,F,act,p_in,p_out", [(7968, 2048, 2, 0.1, 0.1), (4100, 1024, 1, 0.0, 0.0), (33, 256, 2, 0.1, 0.2)])
+def test_ffn_fused_bf16_vs_float64(ops, M, F, act, p_in, p_out):
+    """the bf16-operand twin (eamd_ffn_fwd / _bwd with dtype 1, csrc/ffn_bf16.hip) against float64 on the SAME bf16-rounded
+    operands: h and f (stored bf16: rounding 2^-9), out (fp32 accumulation of bf16 products, h rounded to bf16 in between),
+    and the backward launch on the transposed weight copies - dz (bf16), dx (fp32)"""
+    import espnet_amd
+    espnet_amd.set_precision("bf16")
+    try:
+        g = torch.Generator().manual_seed(M + F + 1)
+        D = 256
+        rb = lambda t_: t_.to(torch.bfloat16).float()  # noqa: E731
+        x, w1, w2 = rb(torch.randn(M, D, generator=g)), rb(torch.randn(F, D, generator=g) * 0.06), rb(torch.randn(D, F, generator=g) * 0.03)
+        b1, b2 = torch.randn(F, generator=g) * 0.1, torch.randn(D, generator=g) * 0.1
+        R, dy = torch.randn(M, D, generator=g), rb(torch.randn(M, D, generator=g))
+        alpha = 0.5
+        ops.manual_seed(6)
+        s_in, s_out = 4321, 789
+        bf = lambda t_: t_.to(DEV).to(torch.bfloat16)  # noqa: E731
+        xd, w1d, w2d, dyd = bf(x), bf(w1), bf(w2), bf(dy)
+        out, f, h = ops.ffn_fwd(xd, w1d, b1.to(DEV), w2d, b2.to(DEV), act=act, alpha=alpha, R=R.to(DEV), drop=(p_in, s_in, p_out, s_out))
+        assert f.dtype == torch.bfloat16 and h.dtype == torch.bfloat16 and out.dtype == torch.float32
+        packs = ops.ffn_pack(w1d, w2d)
+        dz, dx = ops.ffn_bwd(dyd, w1d, w2d, f, alpha=alpha, packed=packs[2:])
+        m_in = ops.dropout(torch.ones(M, F, device=DEV), p_in, s_in).double().cpu() if p_in > 0 else torch.ones(M, F, dtype=torch.float64)
+        m_out = ops.dropout(torch.ones(M, D, device=DEV), p_out, s_out).double().cpu() if p_out > 0 else torch.ones(M, D, dtype=torch.float64)
+        z = x.double() @ w1.double().t() + b1.double()
+        if act == 2:
+            sg = torch.sigmoid(z)
+            a, d = z * sg, sg * (1 + z * (1 - sg))
+        else:
+            a, d = z.clamp_min(0), (z > 0).double()
+        h_ref, f_ref = a * m_in, d * m_in
+        tag = "bf16 M=%d F=%d act=%d p=(%g,%g)" % (M, F, act, p_in, p_out)
+        if act == 1:
+            sure = z.abs() > 1e-3
+            h_cmp, f_cmp = torch.where(sure, h.double().cpu(), h_ref), torch.where(sure, f.double().cpu(), f_ref)
+        else:
+            h_cmp, f_cmp = h, f
+        report("ffn fused h  " + tag, h_cmp, h_ref, 4e-3)
+        report("ffn fused f  " + tag, f_cmp, f_ref, 4e-3)
+        hq = h.double().cpu()                     # the second product reads the stored (rounded) h
+        out_ref = R.double() + alpha * ((hq @ w2.double().t() + b2.double()) * m_out)
+        report("ffn fused out " + tag, out, out_ref, 2e-5)
+        fq_ = f.double().cpu()
+        dz_ref = alpha * (dy.double() @ w2.double()) * fq_
+        report("ffn fused dz " + tag, dz, dz_ref, 4e-3)
+        report("ffn fused dx " + tag, dx, dz.double().cpu() @ w1.double(), 2e-5)
+    finally:
+        espnet_amd.set_precision("fp32")
