@@ -99,13 +99,12 @@ __global__ __launch_bounds__(FNT, 2) void ffn_f32_direct_kernel(const eamd_ffn_t
 
   if (up) {
     // =============================== up waves ===============================
-    const float* __restrict__ W = BWD ? p.w2 : p.w1;
+    const float* __restrict__ W = p.w1;          // packed image of the first product (forward: W1; backward: W2 read along its rows)
     // column of accumulator tile j inside the chunk: forward j*16 + fr; backward (float2 fragments along n) 2*fr + j
     // both directions interleave the two column tiles (tile j holds columns 2 fr + j): a lane's (j = 0, 1) elements of one
     // row are neighbours - one dropout hash (an element PAIR), one 8-byte LDS store
     const int lc0 = wq * 32 + 2 * fr;
     constexpr int LCJ = 1;
-    const unsigned boff = BWD ? (unsigned)(((fq * 4) * F + wq * 32 + 2 * fr) * 4) : (unsigned)(((wq * 32 + 2 * fr) * FD + fq * 4) * 4);
     f32x4 bs[4][4];            // forward: [set][q*2 + j] = 4 k-elements;  backward: [set][q*2 + e/2] = (e even: j0 j1, e odd: j0 j1)
     f32x4 zacc[2][2], zold[2][2];
 #pragma unroll
@@ -119,28 +118,13 @@ __global__ __launch_bounds__(FNT, 2) void ffn_f32_direct_kernel(const eamd_ffn_t
     float fpre[2][2][4];
     const unsigned e_toff = (unsigned)(((fq * 4) * F + lc0) * 4);
 
+    // operand fragments from the PACKED image of this product (eamd_ffn_pack_f32: fragment order, a wave-instruction reads
+    // 1 KB of consecutive bytes; from the nn.Linear layout it touched 16 rows x 64 bytes): image[step g][wave][v][lane]
     auto load_b = [&](auto set_c, int g) __attribute__((always_inline)) {
       constexpr int SET = decltype(set_c)::value;
-      const int gc = min(g, nsteps - 1);
-      const int c = gc >> 3, s = gc & 7;
-      if constexpr (!BWD) {
-        const char* base = reinterpret_cast<const char*>(W + (long)(c * FHC) * FD + s * 32);
+      const char* base = reinterpret_cast<const char*>(W) + ((long)min(g, nsteps - 1) * 4 + wq) * 4096 + lane * 16;
 #pragma unroll
-        for (int q = 0; q < 2; ++q)
-#pragma unroll
-          for (int j = 0; j < 2; ++j)
-            bs[SET][q * 2 + j] = *reinterpret_cast<const f32x4*>(base + ((long)j * FD + q * 16) * 4 + boff);
-      } else {
-        const char* base = reinterpret_cast<const char*>(W + (long)(s * 32) * F + c * FHC);
-#pragma unroll
-        for (int q = 0; q < 2; ++q)
-#pragma unroll
-          for (int e = 0; e < 4; ++e) {
-            const float2 v = *reinterpret_cast<const float2*>(base + ((long)(q * 16 + e) * F) * 4 + boff);
-            bs[SET][q * 2 + (e >> 1)][(e & 1) * 2] = v.x;
-            bs[SET][q * 2 + (e >> 1)][(e & 1) * 2 + 1] = v.y;
-          }
-      }
+      for (int v = 0; v < 4; ++v) bs[SET][v] = *reinterpret_cast<const f32x4*>(base + v * 1024);
     };
     float fA[2][2][4];
     auto read_a = [&](auto s_c, auto half_c) __attribute__((always_inline)) {
@@ -254,8 +238,7 @@ __global__ __launch_bounds__(FNT, 2) void ffn_f32_direct_kernel(const eamd_ffn_t
     period(F_{}, F_{}, nch + 1);
   } else {
     // =============================== down waves ===============================
-    const float* __restrict__ W = BWD ? p.w1 : p.w2;
-    const unsigned boff = BWD ? (unsigned)(((fq * 4) * FD + wq * 64 + 4 * fr) * 4) : (unsigned)(((wq * 64 + fr) * F + fq * 4) * 4);
+    const float* __restrict__ W = p.w2;          // packed image of the second product
     f32x4 bs[4][4];            // forward: [set][j] = 4 k-elements of column tile j;  backward: [set][e] = column tiles 0..3 at k = fq*4 + e
     f32x4 yacc[2][4];
 #pragma unroll
@@ -264,17 +247,9 @@ __global__ __launch_bounds__(FNT, 2) void ffn_f32_direct_kernel(const eamd_ffn_t
       for (int j = 0; j < 4; ++j) yacc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
     auto load_b = [&](auto set_c, int gd) __attribute__((always_inline)) {
       constexpr int SET = decltype(set_c)::value;
-      const int gc = min(max(gd, 0), nsteps - 1);
-      const int cd = gc >> 3, sd = gc & 7;
-      if constexpr (!BWD) {
-        const char* base = reinterpret_cast<const char*>(W + cd * FHC + sd * 16);
+      const char* base = reinterpret_cast<const char*>(W) + ((long)min(max(gd, 0), nsteps - 1) * 4 + wq) * 4096 + lane * 16;
 #pragma unroll
-        for (int j = 0; j < 4; ++j) bs[SET][j] = *reinterpret_cast<const f32x4*>(base + ((long)(j * 16) * F) * 4 + boff);
-      } else {
-        const char* base = reinterpret_cast<const char*>(W + (long)(cd * FHC + sd * 16) * FD);
-#pragma unroll
-        for (int e = 0; e < 4; ++e) bs[SET][e] = *reinterpret_cast<const f32x4*>(base + ((long)e * FD) * 4 + boff);
-      }
+      for (int v = 0; v < 4; ++v) bs[SET][v] = *reinterpret_cast<const f32x4*>(base + v * 1024);
     };
     float fA[2][2][4];         // [step parity][row tile][4 k-elements]
     auto read_a = [&](auto par_c, int sd, int hbuf) __attribute__((always_inline)) {
@@ -392,6 +367,40 @@ __global__ __launch_bounds__(FNT, 2) void ffn_f32_direct_kernel(const eamd_ffn_t
   }
 }
 
+// The four packed weight images of one FFN, fragment order image[step g = chunk*8 + s][wave wq][v][lane] (float4 each):
+//   which 0 forward first  : v = q*2 + j  <- W1[c*128 + wq*32 + 2 fr + j][s*32 + q*16 + fq*4 + (0..3)]
+//   which 1 forward second : v = j        <- W2[wq*64 + j*16 + fr][c*128 + s*16 + fq*4 + (0..3)]
+//   which 2 backward first : v = q*2 + e/2, component (e%2)*2 + j  <- W2[s*32 + q*16 + fq*4 + e][c*128 + wq*32 + 2 fr + j]
+//   which 3 backward second: v = e        <- W1[c*128 + s*16 + fq*4 + e][wq*64 + 4 fr + (0..3)]
+__global__ __launch_bounds__(256) void ffn_pack_f32_kernel(const float* __restrict__ w1, const float* __restrict__ w2,
+                                                           float* __restrict__ p0, float* __restrict__ p1,
+                                                           float* __restrict__ p2, float* __restrict__ p3, int F) {
+  const int which = blockIdx.y;
+  const long piece = (long)blockIdx.x * 256 + threadIdx.x;           // ((g*4 + wq)*4 + v)*64 + lane
+  const long npiece = (long)(F / FHC) * 8 * 4 * 4 * 64;
+  if (piece >= npiece) return;
+  const int lane = piece & 63, v = (piece >> 6) & 3, wq = (piece >> 8) & 3;
+  const int g = (int)(piece >> 10), c = g >> 3, s = g & 7;
+  const int fr = lane & 15, fq = lane >> 4;
+  float4 o;
+  if (which == 0) {
+    const int q = v >> 1, j = v & 1;
+    o = *reinterpret_cast<const float4*>(w1 + (long)(c * FHC + wq * 32 + 2 * fr + j) * FD + s * 32 + q * 16 + fq * 4);
+    *reinterpret_cast<float4*>(p0 + piece * 4) = o;
+  } else if (which == 1) {
+    o = *reinterpret_cast<const float4*>(w2 + (long)(wq * 64 + v * 16 + fr) * F + c * FHC + s * 16 + fq * 4);
+    *reinterpret_cast<float4*>(p1 + piece * 4) = o;
+  } else if (which == 2) {
+    const int q = v >> 1, e0 = (v & 1) * 2;
+    const float* r0 = w2 + (long)(s * 32 + q * 16 + fq * 4 + e0) * F + c * FHC + wq * 32 + 2 * fr;
+    const float2 a = *reinterpret_cast<const float2*>(r0), b = *reinterpret_cast<const float2*>(r0 + F);
+    *reinterpret_cast<float4*>(p2 + piece * 4) = make_float4(a.x, a.y, b.x, b.y);
+  } else {
+    o = *reinterpret_cast<const float4*>(w1 + (long)(c * FHC + s * 16 + fq * 4 + v) * FD + wq * 64 + 4 * fr);
+    *reinterpret_cast<float4*>(p3 + piece * 4) = o;
+  }
+}
+
 bool al16(const void* q) { return (reinterpret_cast<uintptr_t>(q) & 15) == 0; }
 
 template <bool BWD, int ACT>
@@ -438,6 +447,20 @@ extern "C" int eamd_ffn_debug_stamps(unsigned long long* host) {
   return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(ffn_stamps), sizeof(ffn_stamps));
 }
 #endif
+
+extern "C" int eamd_ffn_pack_f32(const float* w1, const float* w2, float* fwd_first, float* fwd_second, float* bwd_first,
+                                 float* bwd_second, int D, int F, void* stream) {
+  if (!w1 || !w2 || !fwd_first || !fwd_second || !bwd_first || !bwd_second || F <= 0) return EAMD_EINVAL;
+  if (D != FD || F % FHC != 0 || F < 2 * FHC) return EAMD_EUNSUPPORTED;
+  for (const void* q : {(const void*)w1, (const void*)w2, (const void*)fwd_first, (const void*)fwd_second, (const void*)bwd_first,
+                        (const void*)bwd_second})
+    if (!al16(q)) return EAMD_EUNSUPPORTED;
+  const long npiece = (long)(F / FHC) * 8 * 4 * 4 * 64;
+  hipLaunchKernelGGL(ffn_pack_f32_kernel, dim3((unsigned)((npiece + 255) / 256), 4), dim3(256), 0, (hipStream_t)stream, w1, w2,
+                     fwd_first, fwd_second, bwd_first, bwd_second, F);
+  EAMD_LAUNCH_CHECK();
+  return EAMD_OK;
+}
 
 extern "C" int eamd_ffn_fwd(const eamd_ffn_t* p, void* stream) {
   const int rc = check_ffn(p, false);

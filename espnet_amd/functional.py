@@ -225,10 +225,10 @@ class FFNBlockFn(torch.autograd.Function):
             # fp32 mode, d = 256: BOTH products in one launch (csrc/ffn_f32.hip) - 32 rows per workgroup, the hidden units
             # never make a round trip for the second product; kept for backward: h and the factor f (no grad: neither)
             need = any(ctx.needs_input_grad[:7])          # (grad mode is off inside forward: needs_input_grad tells no-grad calls apart)
-            packs = ops.ffn_pack(w1, w2) if ops.fast() else None       # bf16 mode: the four packed weight images of this layer
+            packs = ops.ffn_pack(w1, w2)       # the four packed weight images of this layer (forward pair, backward pair)
             out, z, h = ops.ffn_fwd(xn, ops.wshadow(w1), b1, ops.wshadow(w2), b2, act=act, alpha=scale, R=x2,
-                                    drop=(p_in, s_in, p_out, s_out), save=need, packed=packs[:2] if packs else None)
-            ctx.packs = packs[2:] if packs else None
+                                    drop=(p_in, s_in, p_out, s_out), save=need, packed=packs[:2])
+            ctx.packs = packs[2:]
             ctx.save_for_backward(x2, mean, rstd, xn, z, h)
             ctx.pr = GradSink.use((ln_w, ln_b, w1, b1, w2, b2))
             ctx.cfg = (scale, act, shp, drop)
@@ -316,10 +316,7 @@ class FFNBlockFn(torch.autograd.Function):
             return (dx,) + sink.results() + (None, None, None, None)
         if ctx.one_launch and g_drop is None and dob.dtype == z.dtype:
             # dz = s (dob W2) (.) f and dxn = dz W1: one launch (bf16 operands: on the transposed weight copies)
-            if dob.dtype == torch.bfloat16:
-                dz, dxn = ops.ffn_bwd(dob, w1, w2, z, alpha=scale, packed=ctx.packs)
-            else:
-                dz, dxn = ops.ffn_bwd(dob, w1, w2, z, alpha=scale)
+            dz, dxn = ops.ffn_bwd(dob, w1, w2, z, alpha=scale, packed=ctx.packs)
             ops.linear_bwd_w(dz, xn, sink.buf(2), db=sink.buf(3))
             dx = _ln_bwd_out(dxn, x2, ln_w, mean, rstd, do, sink.buf(0), sink.buf(1), ctx.prev, shp)
             return (dx,) + sink.results() + (None, None, None, None)

@@ -527,52 +527,45 @@ def ffn_fwd(x, w1, b1, w2, b2, *, act, alpha=1.0, R=None, drop=(0.0, 0, 0.0, 0),
     out = torch.empty(M, D, device=x.device, dtype=torch.float32)
     f = torch.empty(M, F, device=x.device, dtype=dt) if save else None
     h = torch.empty(M, F, device=x.device, dtype=dt) if save else None
-    if dt == torch.bfloat16:      # the kernel reads the packed images (ffn_pack)
-        if packed is None:
-            packed = ffn_pack(w1, w2)[:2]
-        p = _ffn_desc(x, packed[0], b1, packed[1], b2, R, out, f, h, act, alpha, drop, F=F)
-        _ffn_call("eamd_ffn_fwd", p, (x, packed, b1, b2, R, out, f, h))
-        return out, f, h
-    p = _ffn_desc(x, w1, b1, w2, b2, R, out, f, h, act, alpha, drop)
-    _ffn_call("eamd_ffn_fwd", p, (x, w1, b1, w2, b2, R, out, f, h))
+    if packed is None:            # the kernels read the packed images (ffn_pack)
+        packed = ffn_pack(w1, w2)[:2]
+    p = _ffn_desc(x, packed[0], b1, packed[1], b2, R, out, f, h, act, alpha, drop, F=F)
+    _ffn_call("eamd_ffn_fwd", p, (x, packed, b1, b2, R, out, f, h))
     return out, f, h
 
 
 def ffn_pack(w1, w2):
-    """the four packed bf16 weight images of one FFN (eamd_ffn_pack_bf16) -> (fwd_first, fwd_second, bwd_first, bwd_second),
-    each F * D elements.  Cached buffers on w1; the PACKING is redone at every call: the optimizer kernel rewrites the bf16
-    shadow arena in place (no tensor version to watch), and under hipGraph capture it has to be part of the replayed step."""
+    """the four packed weight images of one FFN (eamd_ffn_pack_f32 / _bf16) -> (fwd_first, fwd_second, bwd_first, bwd_second),
+    each F * D elements in the operand dtype of the current mode.  Cached buffers on w1; the PACKING is redone at every call:
+    the optimizer kernel rewrites the weights (and the bf16 shadow arena) in place - no tensor version to watch - and under
+    hipGraph capture it has to be part of the replayed step."""
     F, D = w1.shape
+    bf = fast() or w1.dtype == torch.bfloat16
     s1, s2 = (wshadow(w1), wshadow(w2)) if w1.dtype != torch.bfloat16 else (w1, w2)
+    dt = torch.bfloat16 if bf else torch.float32
     buf = getattr(w1, "_eamd_ffn_pack", None)
-    if buf is None or buf.numel() != 4 * F * D or buf.device != s1.device:
-        buf = torch.empty(4, F * D, device=s1.device, dtype=torch.bfloat16)
+    if buf is None or buf.numel() != 4 * F * D or buf.device != s1.device or buf.dtype != dt:
+        buf = torch.empty(4, F * D, device=s1.device, dtype=dt)
         w1._eamd_ffn_pack = buf
-    check(_lib.lib().eamd_ffn_pack_bf16(ptr(s1), ptr(s2), ptr(buf[0]), ptr(buf[1]), ptr(buf[2]), ptr(buf[3]), D, F, stream_ptr()),
-          "eamd_ffn_pack_bf16")
+    name = "eamd_ffn_pack_bf16" if bf else "eamd_ffn_pack_f32"
+    check(getattr(_lib.lib(), name)(ptr(s1), ptr(s2), ptr(buf[0]), ptr(buf[1]), ptr(buf[2]), ptr(buf[3]), D, F, stream_ptr()), name)
     return buf[0], buf[1], buf[2], buf[3]
 
 
 def ffn_bwd(dy, w1, w2, f, *, alpha=1.0, packed=None):
-    """dz = alpha * (dy W2) (.) f and dx = dz W1 in ONE launch -> (dz [M, F], dx [M, D] fp32).  bf16 operands: packed =
-    (bwd_first, bwd_second) of ffn_pack are what the kernel reads"""
+    """dz = alpha * (dy W2) (.) f and dx = dz W1 in ONE launch -> (dz [M, F], dx [M, D] fp32); packed = (bwd_first,
+    bwd_second) of ffn_pack(w1, w2) (made here when not given)"""
     M, D = dy.shape
     F = w1.shape[0]
     dt = dy.dtype
     assert f.shape == (M, F) and f.dtype == dt and f.is_contiguous() and dy.is_contiguous()
     dz = torch.empty(M, F, device=dy.device, dtype=dt)
     dx = torch.empty(M, D, device=dy.device, dtype=torch.float32)
-    if dt == torch.bfloat16:
-        assert packed is not None and packed[0].numel() == F * D and packed[1].numel() == F * D
-        p = _ffn_desc(dy, packed[0], None, packed[1], None, None, dx, f, dz, ACT_NONE, alpha, (0.0, 0, 0.0, 0), F=F)
-        keep = (dy, packed, f, dz, dx)
-    else:
-        for t_ in (dy, w1, w2, f):
-            if t_.dtype != torch.float32 or not t_.is_contiguous():
-                raise _lib.EamdError("ffn_bwd: contiguous float32 tensors")
-        p = _ffn_desc(dy, w1, None, w2, None, None, dx, f, dz, ACT_NONE, alpha, (0.0, 0, 0.0, 0))
-        keep = (dy, w1, w2, f, dz, dx)
-    _ffn_call("eamd_ffn_bwd", p, keep)
+    if packed is None:
+        packed = ffn_pack(w1, w2)[2:]
+    assert packed[0].numel() == F * D and packed[1].numel() == F * D and packed[0].dtype == dt
+    p = _ffn_desc(dy, packed[0], None, packed[1], None, None, dx, f, dz, ACT_NONE, alpha, (0.0, 0, 0.0, 0), F=F)
+    _ffn_call("eamd_ffn_bwd", p, (dy, packed, f, dz, dx))
     return dz, dx
 
 

@@ -149,12 +149,15 @@ int eamd_gemm_group_launch(const eamd_gemm_t* descs_dev, const int32_t* first_de
  *                  out[M,D] <- dz W1
  * Dropout masks are eamd_dropout's (element index of the contiguous [M,F] / [M,D] tensor, salts salt_in / salt_out,
  * drop_step = the device step counter of eamd_rng_advance).  w1 [F,D], w2 [D,F] row-major (nn.Linear layout).
- * dtype 0 = fp32 operands on v_mfma_f32_16x16x4_f32.
- * dtype 1 = bf16 operands on v_mfma_f32_16x16x32_bf16: x, f, h address bf16 (b1, b2, R, out stay fp32); F a multiple of
- *   256; w1 / w2 address the PACKED weight images of eamd_ffn_pack_bf16 (MFMA fragment order: every wave-instruction of the
- *   kernel reads 1 KB of consecutive bytes): fwd_first / fwd_second for eamd_ffn_fwd, bwd_first / bwd_second for eamd_ffn_bwd.
- *   eamd_ffn_pack_bf16 makes the four images (F * D * 2 bytes each) of one layer from its nn.Linear-layout bf16 weights
- *   (w1 [F, D], w2 [D, F]) in one launch; re-run it whenever the weights change (every optimizer step).
+ * In BOTH dtypes w1 / w2 address the PACKED weight images of eamd_ffn_pack_f32 / eamd_ffn_pack_bf16 (MFMA fragment order:
+ * every wave-instruction of the kernels reads 1 KB of consecutive bytes - fetched from the nn.Linear layout a fragment load
+ * touches 16 rows x 64 bytes and the kernels sit at the vector memory path's line rate): fwd_first / fwd_second for
+ * eamd_ffn_fwd, bwd_first / bwd_second for eamd_ffn_bwd.  The pack entry points make the four images (F * D elements each)
+ * of one layer from its nn.Linear-layout weights (w1 [F, D], w2 [D, F]) in one launch; re-run whenever the weights change
+ * (every optimizer step).
+ * dtype 0 = fp32 operands on v_mfma_f32_16x16x4_f32 (F a multiple of 128).
+ * dtype 1 = bf16 operands on v_mfma_f32_16x16x32_bf16: x, f, h and the images address bf16 (b1, b2, R, out stay fp32); F a
+ *   multiple of 256.
  * Returns EAMD_EUNSUPPORTED for shapes the kernels are not built for (D != 256, F not a multiple of 128 / 256, unaligned
  * operands): the caller then runs the two eamd_gemm products. */
 typedef struct {
@@ -167,6 +170,8 @@ typedef struct {
 } eamd_ffn_t;
 int eamd_ffn_fwd(const eamd_ffn_t* p, void* stream);
 int eamd_ffn_bwd(const eamd_ffn_t* p, void* stream);
+int eamd_ffn_pack_f32(const float* w1, const float* w2, float* fwd_first, float* fwd_second, float* bwd_first, float* bwd_second,
+                      int D, int F, void* stream);
 int eamd_ffn_pack_bf16(const void* w1, const void* w2, void* fwd_first, void* fwd_second, void* bwd_first, void* bwd_second,
                        int D, int F, void* stream);
 

@@ -26,7 +26,7 @@ def main():
     drop = (0.1, 11, 0.1, 12)
     gf = 4.0 * M * D * F / 1e6
     out, f, h = ops.ffn_fwd(x, w1, b1, w2, b2, act=ops.ACT_SWISH, alpha=0.5, R=R, drop=drop)
-    packs = ops.ffn_pack(w1, w2) if prec == "bf16" else None
+    packs = ops.ffn_pack(w1, w2)
 
     def pair_fwd():
         hh = torch.empty(M, F, device=dev, dtype=dt)
@@ -37,11 +37,10 @@ def main():
         dz = ops.linear_bwd_x(dy, w2, epilogue=ops.EPI_MUL_AUX, aux=f, alpha=0.5, out_dtype=dt)
         return ops.linear_bwd_x(dz, w1)
 
-    kw = dict(packed=packs[2:]) if prec == "bf16" else {}
-    kf = dict(packed=packs[:2]) if prec == "bf16" else {}
+    kw, kf = dict(packed=packs[2:]), dict(packed=packs[:2])
     rows = [("fused fwd (save)", lambda: ops.ffn_fwd(x, w1, b1, w2, b2, act=ops.ACT_SWISH, alpha=0.5, R=R, drop=drop, **kf)),
             ("fused fwd (no save)", lambda: ops.ffn_fwd(x, w1, b1, w2, b2, act=ops.ACT_SWISH, alpha=0.5, R=R, drop=drop, save=False, **kf)),
-            ("pack (4 images)", (lambda: ops.ffn_pack(w1, w2)) if prec == "bf16" else (lambda: None)),
+            ("pack (4 images)", lambda: ops.ffn_pack(w1, w2)),
             ("pair  fwd", pair_fwd),
             ("fused bwd", lambda: ops.ffn_bwd(dy, w1, w2, f, alpha=0.5, **kw)),
             ("pair  bwd", pair_bwd)]
