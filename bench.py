@@ -247,6 +247,41 @@ def run_precision(a, prec, rank, world, dev):
     loss_val = float(model.loss.detach())
     st = opt.stats()
 
+    # ---- data-parallel runs explain themselves: collectives alone, the step with and without them, and the N = 1
+    #      step (one graph, no phases) measured in this very process on rank 0 ----
+    comm = None
+    if dp_step is not None:
+        comm = dp_step.comm_profile(steps=8)
+        if world > 1:
+            worst = torch.tensor([comm["step_ms"], comm["compute_only_ms"], comm["allreduce_ms_total"]], device=dev, dtype=torch.float64)
+            torch.distributed.all_reduce(worst, op=torch.distributed.ReduceOp.MAX)
+            comm["max_over_ranks"] = dict(step_ms=round(float(worst[0]), 3), compute_only_ms=round(float(worst[1]), 3),
+                                          allreduce_ms_total=round(float(worst[2]), 3))
+        if rank == 0:
+            g1 = torch.cuda.CUDAGraph()
+            s1 = torch.cuda.Stream()
+            s1.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(s1):
+                step()
+            torch.cuda.current_stream().wait_stream(s1)
+            torch.cuda.synchronize()
+            with torch.cuda.graph(g1):
+                step()
+            for _ in range(2):
+                g1.replay()
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            for _ in range(8):
+                g1.replay()
+            torch.cuda.synchronize()
+            comm["n1_ms"] = round((time.perf_counter() - t1) / 8 * 1e3, 3)
+            comm["note"] = ("allreduce_ms: each phase's arena range reduced alone (stream events); exposed_comm_ms = step_ms - "
+                            "compute_only_ms (same graphs, no collective); n1_ms = the single-graph step bench.py times at --gpus 1, "
+                            "run on rank 0 while the other ranks idle")
+            del g1
+        if world > 1:
+            torch.distributed.barrier()
+
     # ---- roofline of the dominant kernel family (MFMA contractions), measured live with stream events ----
     # Every MFMA-contraction launch of one training step (eamd_gemm descriptors, the fused attention kernels) is
     # recorded (operands kept alive), then the whole family is replayed back to back as ONE hipGraph on a stream and
@@ -304,8 +339,8 @@ def run_precision(a, prec, rank, world, dev):
             traffic_src = os.path.basename(traffic_src)
         except Exception:  # noqa: BLE001
             traffic = None
-        kern = ("gemm_f32_kernel<*> (+ gemm_kernel<*> for unaligned operands) + attn_f32_{fwd,bwd_q,bwd_kv}_kernel: every MFMA contraction, v_mfma_f32_16x16x4_f32"
-                if prec == "fp32" else "gemm_bf16_*_kernel<*> + attn_{fwd,bwd_q,bwd_kv}_kernel: every MFMA contraction, v_mfma_f32_16x16x32_bf16")
+        kern = ("gemm_f32_kernel<*> (+ gemm_kernel<*> for unaligned operands) + ffn_f32_direct_kernel<*> (fused position-wise FFN) + attn_f32_{fwd,bwd_q,bwd_kv}_kernel: every MFMA contraction, v_mfma_f32_16x16x4_f32"
+                if prec == "fp32" else "gemm_bf16_*_kernel<*> + ffn_bf16_kernel<*> (fused position-wise FFN) + attn_{fwd,bwd_q,bwd_kv}_kernel: every MFMA contraction, v_mfma_f32_16x16x32_bf16")
         roof = dict(bound="mfma", achieved=round(ach, 2), peak=PEAK_TFLOPS[prec], unit="TFLOP/s",
                     frac=round(ach / PEAK_TFLOPS[prec], 4), traffic=traffic,
                     traffic_note=("HBM bytes per launch, rocprofv3 PMC (FETCH_SIZE doubled + WRITE_SIZE), profiles/%s" % traffic_src) if traffic else "no PMC pass committed for this build",
@@ -321,6 +356,8 @@ def run_precision(a, prec, rank, world, dev):
                launch=(("hipGraph fwd+bwd in %d phases, RCCL all-reduce of each phase's arena range under the next | hipGraph optimizer"
                         % len(dp_step.ranges)) if dp_step is not None else "hipGraph" if use_graph else "eager"),
                roofline=roof)
+    if comm is not None:
+        res["comm"] = comm
     if reducer is not None:
         train.attach_reducer(None)
     del model, flat, opt, run
@@ -474,6 +511,8 @@ def main():
             sec = dict(dtype=DTYPE[other][0], dtype_detail=DTYPE[other][1], ms_per_step=second["ms_per_step"],
                        value=second["value"], unit="frames/s", utt_per_s=second["utt_per_s"], loss=second["loss"],
                        roofline=second["roofline"])
+            if second.get("comm") is not None:
+                sec["comm"] = second["comm"]
             if step0_head is not None and step0_other is not None:
                 sec["loss_rel_vs_%s_step0" % a.precision] = float(
                     "%.3e" % (abs(step0_other["loss"] - step0_head["loss"]) / abs(step0_head["loss"])))
@@ -492,6 +531,9 @@ def main():
             "roofline": head["roofline"], "roofline_hbm": hbm, "cpu_baseline": cpu, "parity": parity,
             other: sec,
         }
+        if head.get("comm") is not None:
+            out["comm"] = head["comm"]
+            out["rccl_ranks"] = head["comm"]["rccl_ranks"]
         if ragged is not None:
             out["ragged"] = ragged
         if extra is not None:

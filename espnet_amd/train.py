@@ -471,6 +471,58 @@ class GraphedDataParallelStep:
         self.graph_b.replay()
         return self.loss
 
+    def comm_profile(self, steps=8):
+        """Where a data-parallel step's time goes, measured on this rank (every rank must call it: it issues collectives):
+          allreduce_ms[k]   the all-reduce of phase k's arena range ALONE (nothing else on the device), stream events
+                            around issue + wait, mean of `steps`;
+          step_ms           the step as __call__ runs it;
+          compute_only_ms   the same graphs with no collective issued (what one rank would need without peers);
+          exposed_comm_ms   step_ms - compute_only_ms: the communication the backward phases do not hide.
+        Parameters move on (the optimizer graph runs); call it after the timed region."""
+        import time
+        dist = self.dist
+        on = dist.is_initialized()
+
+        def sync():
+            if on:
+                dist.barrier(group=self.group)
+            torch.cuda.synchronize()
+
+        def timed(fn):
+            for _ in range(2):
+                fn()
+            sync()
+            t0 = time.perf_counter()
+            for _ in range(steps):
+                fn()
+            torch.cuda.synchronize()
+            return (time.perf_counter() - t0) / steps * 1e3
+
+        def compute_only():
+            for g in self.graphs:
+                g.replay()
+            self.graph_b.replay()
+
+        ar = []
+        for k in range(len(self.ranges)):
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            self._wait(self._reduce(k))
+            sync()
+            e0.record()
+            for _ in range(steps):
+                self._wait(self._reduce(k))
+            e1.record()
+            torch.cuda.synchronize()
+            ar.append(e0.elapsed_time(e1) / steps if on else 0.0)
+        self.flat.zero_grad()      # the repeated SUMs above grew the arena world^steps-fold
+        step_ms = timed(self.__call__)
+        comp_ms = timed(compute_only)
+        return dict(rccl_ranks=(dist.get_world_size(self.group) if on else 1),
+                    phase_mbytes=[round((hi - lo) * 4 / 1e6, 1) for lo, hi in self.ranges],
+                    allreduce_ms=[round(v, 3) for v in ar], allreduce_ms_total=round(sum(ar), 3),
+                    step_ms=round(step_ms, 3), compute_only_ms=round(comp_ms, 3),
+                    exposed_comm_ms=round(step_ms - comp_ms, 3))
+
 
 class BucketedGraphStep:
     """hipGraph replay for batches whose shapes vary (real recipes batch by `batch_bins`: B, T and L all move).
