@@ -390,7 +390,8 @@ def _wgroup_launch(items, tile):
     args = (ptr(tab), ptr(tab, nb_desc), n, total, in_dtype, tile)
     check(L.eamd_gemm_group_launch(*args, stream_ptr()), "eamd_gemm_group_launch")
     if _gemm_record is not None:
-        _gemm_record.append((None, (tab, [it[1] for it in items]),
+        _gemm_record.append((dict(kind="group%d" % tile, flop=sum(2.0 * it[0].M * it[0].N * it[0].K * it[0].batch1 * it[0].batch2 for it in items)),
+                             (tab, [it[1] for it in items]),
                              lambda sp, args=args: check(L.eamd_gemm_group_launch(*args, sp), "eamd_gemm_group_launch")))
 
 
@@ -507,7 +508,7 @@ def _ffn_desc(x, w1, b1, w2, b2, R, out, f, h, act, alpha, drop, F=None):
 def _ffn_call(name, p, keep):
     fn = getattr(_lib.lib(), name)
     if _gemm_record is not None:
-        _gemm_record.append((None, keep, lambda sp, p=p: check(fn(C.byref(p), sp), name)))
+        _gemm_record.append((dict(kind=name, flop=4.0 * p.M * p.D * p.F), keep, lambda sp, p=p: check(fn(C.byref(p), sp), name)))
     check(fn(C.byref(p), stream_ptr()), name)
 
 
@@ -780,7 +781,7 @@ def attn_fwd(qu, qv, k, v, pos, mask, B, T1, T2, H, dk, ldp, scale, drop=None, s
         return None
     check(rc, name)
     if _gemm_record is not None:
-        _gemm_record.append((None, (qu, qv, k, v, pos, mask, P, Pd, cx), lambda sp, args=args: check(fn(*args, sp), name)))
+        _gemm_record.append((dict(kind=name, flop=0.0), (qu, qv, k, v, pos, mask, P, Pd, cx), lambda sp, args=args: check(fn(*args, sp), name)))
     return P, Pd, cx
 
 
@@ -810,7 +811,7 @@ def attn_bwd_q(dctx, k, v, P, dS, dbd, dq, B, T1, T2, H, dk, ldp, scale, drop=No
         return False
     check(rc, name)
     if _gemm_record is not None:
-        _gemm_record.append((None, (dctx, k, v, P, dS, dbd, dq), lambda sp, args=args: check(fn(*args, sp), name)))
+        _gemm_record.append((dict(kind=name, flop=0.0), (dctx, k, v, P, dS, dbd, dq), lambda sp, args=args: check(fn(*args, sp), name)))
     return True
 
 
@@ -845,7 +846,7 @@ def attn_bwd_kv(Pd, dS, dbd, dctx, qu, qv, dv, dk_, dpos, B, T1, T2, H, dk, ldp)
         return False
     check(rc, name)
     if _gemm_record is not None:
-        _gemm_record.append((None, (Pd, dS, dbd, dctx, qu, qv, dv, dk_, dpos),
+        _gemm_record.append((dict(kind=name, flop=0.0), (Pd, dS, dbd, dctx, qu, qv, dv, dk_, dpos),
                              lambda sp, args=args: check(fn(*args, sp), name)))
     return True
 

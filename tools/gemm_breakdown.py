@@ -67,9 +67,12 @@ def main():
     ops._gemm_record = None
     lib = L_.lib()
     groups = collections.OrderedDict()
+    tagged = {}
     for p, keep, replay in rec:
-        if p is None:      # fused attention launch
-            groups.setdefault(("attention",) + (0,) * 16, []).append(replay)
+        if isinstance(p, dict):      # grouped / fused FFN / fused attention launch
+            k_ = (p["kind"],) + (0,) * 16
+            groups.setdefault(k_, []).append(replay)
+            tagged[k_] = tagged.get(k_, 0.0) + p["flop"]
             continue
         key = (p.M, p.N, p.K, p.transA, p.transB, p.batch1 * p.batch2, p.splitk, p.epilogue, int(p.gather.enabled),
                int(bool(p.C)), int(bool(p.Cb)), int(bool(p.Hb)), int(bool(p.R)), int(bool(p.aux)), int(bool(p.colsum)),
@@ -101,13 +104,13 @@ def main():
             g.replay()
         torch.cuda.synchronize()
         us = (time.perf_counter() - t0) / 5 / reps / len(ps) * 1e6
-        fl = 0.0 if key[0] == "attention" else 2.0 * key[0] * key[1] * key[2] * key[5]
+        fl = tagged[key] / len(ps) if key in tagged else 2.0 * key[0] * key[1] * key[2] * key[5]
         rows.append((us * len(ps), len(ps), us, fl / us / 1e6, key))
     # algorithmic HBM bytes of the descriptor launches: every operand and result once (A, B, C, residual, aux, second output)
     esz = 2 if sys.argv[1:2] != ["fp32"] else 4
     alg = 0
     for p, keep, replay in rec:
-        if p is None:
+        if isinstance(p, dict):
             continue
         nb = p.batch1 * p.batch2
         alg += nb * (p.M * p.K + p.N * p.K) * esz + nb * p.M * p.N * (4 if p.C else 0)

@@ -7,7 +7,7 @@ root=$(pwd)
 mkdir -p gpurun_out
 cd /tmp && export TMPDIR=/tmp
 timeout -k 10 500 rocprofv3 --kernel-trace --stats --output-format csv -d "$root/gpurun_out/prof_$tag" -- \
-  python3 "$root/bench.py" --steps 20 --warmup 3 --no-cpu-baseline "$@" > "$root/gpurun_out/prof_$tag.log" 2>&1 || exit 1
+  python3 "$root/bench.py" --steps 20 --warmup 3 --no-cpu-baseline --no-extra-configs --no-decode "$@" > "$root/gpurun_out/prof_$tag.log" 2>&1 || exit 1
 cd "$root"
 f=$(find gpurun_out/prof_$tag -name "*kernel_stats.csv" | head -1)
 echo "stats: $f"
