@@ -65,6 +65,17 @@ class FfnT(C.Structure):
                 ("salt_out", C.c_uint64), ("drop_step", C.c_void_p), ("dtype", C.c_int32), ("reserved", C.c_int32)]
 
 
+class LstmSeqFwdT(C.Structure):
+    _fields_ = [("gx", C.c_void_p), ("w_hh", C.c_void_p), ("b_hh", C.c_void_p), ("live", C.c_void_p),
+                ("h_out", C.c_void_p), ("c_out", C.c_void_p), ("y", C.c_void_p), ("acts", C.c_void_p),
+                ("reverse", C.c_int32), ("reserved", C.c_int32)]
+
+
+class LstmSeqBwdT(C.Structure):
+    _fields_ = [("dy", C.c_void_p), ("w_t", C.c_void_p), ("acts", C.c_void_p), ("c_out", C.c_void_p),
+                ("live", C.c_void_p), ("dgates", C.c_void_p), ("reverse", C.c_int32), ("reserved", C.c_int32)]
+
+
 _lib = None
 
 # every symbol include/espnet_amd.h declares (tests check they are all exported)
@@ -78,7 +89,7 @@ SYMBOLS = [
     "eamd_conv2_weight_prep", "eamd_conv2_weight_grad", "eamd_add_sos_eos", "eamd_ctc_collapse",
     "eamd_ctc_workspace_bytes", "eamd_ctc_loss", "eamd_ctc_prefix_score", "eamd_grad_norm", "eamd_sched_step", "eamd_adam_step", "eamd_adadelta_step", "eamd_add_gradient_noise",
     "eamd_specaug", "eamd_global_mvn", "eamd_utterance_mvn", "eamd_reflect_pad", "eamd_logmel", "eamd_unfold1d", "eamd_fold1d", "eamd_attloc_convmax_fwd", "eamd_attloc_convmax_bwd", "eamd_layernorm_bwd_drop",
-    "eamd_lstm_cell_fwd", "eamd_lstm_cell_bwd", "eamd_lstm_step_fwd", "eamd_lstm_step_bwd", "eamd_gru_cell_fwd", "eamd_gru_cell_bwd", "eamd_maxpool2x2_fwd", "eamd_maxpool2x2_bwd", "eamd_mask_rows",
+    "eamd_lstm_cell_fwd", "eamd_lstm_cell_bwd", "eamd_lstm_step_fwd", "eamd_lstm_step_bwd", "eamd_lstm_seq_sync_bytes", "eamd_lstm_seq_fwd", "eamd_lstm_seq_bwd", "eamd_lstm_seq_status", "eamd_gru_cell_fwd", "eamd_gru_cell_bwd", "eamd_maxpool2x2_fwd", "eamd_maxpool2x2_bwd", "eamd_mask_rows",
     "eamd_joint_fwd", "eamd_joint_bwd", "eamd_rnnt_workspace", "eamd_rnnt_loss", "eamd_rnnt_grad", "eamd_rnnt_node_stats", "eamd_rnnt_node_stats_part", "eamd_rnnt_row_coef", "eamd_rnnt_alpha_beta", "eamd_rnnt_node_grad",
     "eamd_conv3x3_c1_fwd", "eamd_conv3x3_c1_bwd_w_workspace", "eamd_conv3x3_c1_bwd_w", "eamd_attloc_fwd", "eamd_attloc_bwd_energy", "eamd_attloc_bwd_workspace", "eamd_attloc_bwd_energy_conv", "eamd_attloc_bwd_conv",
     "eamd_att_dot_energy_fwd", "eamd_att_dot_energy_bwd", "eamd_att_ctx_fwd", "eamd_att_ctx_bwd",
@@ -99,6 +110,7 @@ def lib():
         _lib.eamd_rnnt_workspace.restype = C.c_int64
         _lib.eamd_attloc_bwd_workspace.restype = C.c_int64
         _lib.eamd_conv1_bwd_w_workspace.restype = C.c_int64
+        _lib.eamd_lstm_seq_sync_bytes.restype = C.c_int64
         _lib.eamd_conv3x3_c1_bwd_w_workspace.restype = C.c_int64
         for s in SYMBOLS:
             getattr(_lib, s)  # AttributeError here = header/library mismatch

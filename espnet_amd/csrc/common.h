@@ -15,6 +15,25 @@
     if (e__ != hipSuccess) return (int)e__;      \
   } while (0)
 
+// Zero n bytes (n % 4 == 0, p 4-byte aligned) with a KERNEL.  Not hipMemsetAsync: captured into a hipGraph by torch
+// (ROCm 7.2) the memset node filled the block with 16-byte garbage from the second replay on (tools/lstm_seq_graph_min.py).
+template <typename W>
+static __global__ __launch_bounds__(256) void eamd_zero_kernel(W* p, long n) {
+  W z;
+  __builtin_memset(&z, 0, sizeof(W));
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) p[i] = z;
+}
+static inline int eamd_zero_async(void* p, size_t bytes, hipStream_t s) {
+  if (bytes == 0) return EAMD_OK;
+  if ((bytes & 3) || ((uintptr_t)p & 3)) return EAMD_EINVAL;
+  const bool wide = !(bytes & 15) && !((uintptr_t)p & 15);
+  const long n = (long)(bytes / (wide ? 16 : 4));
+  const int blocks = (int)((n + 255) / 256 < 2048 ? (n + 255) / 256 : 2048);
+  if (wide) hipLaunchKernelGGL(eamd_zero_kernel<uint4>, dim3(blocks), dim3(256), 0, s, (uint4*)p, n);
+  else hipLaunchKernelGGL(eamd_zero_kernel<unsigned>, dim3(blocks), dim3(256), 0, s, (unsigned*)p, n);
+  return hipGetLastError() == hipSuccess ? EAMD_OK : EAMD_EINVAL;
+}
+
 typedef __attribute__((ext_vector_type(4))) float f32x4;
 typedef __attribute__((ext_vector_type(8))) short bf16x8;
 typedef __attribute__((ext_vector_type(4))) short bf16x4;

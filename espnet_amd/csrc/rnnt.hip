@@ -356,7 +356,7 @@ int eamd_joint_bwd(const float* dh, const float* enc, const float* dec, float* d
   // few (b, u) rows (one utterance's chunk): the frames are cut into slices so that ~512 workgroups share the pass
   int slices = 1;
   while ((long)B * U * slices < 512 && T / (slices * 2) >= 16) slices *= 2;
-  if (slices > 1 && hipMemsetAsync(d_dec, 0, (size_t)B * U * J * sizeof(float), s) != hipSuccess) return EAMD_EINVAL;
+  if (slices > 1 && eamd_zero_async(d_dec, (size_t)B * U * J * sizeof(float), s) != EAMD_OK) return EAMD_EINVAL;
   hipLaunchKernelGGL(joint_bwd_dec_kernel, dim3(B * U, slices), dim3(256), 0, s, dh, enc, dec, d_dec, B, T, U, J, act);
   EAMD_LAUNCH_CHECK();
   return EAMD_OK;

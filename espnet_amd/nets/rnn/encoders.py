@@ -62,6 +62,16 @@ def _directions(seq_fn, x_tm, live, bidir, param):
     def one(sfx, rev):
         gx = F_.LinearFn.apply(x_tm, param("weight_ih", sfx), param("bias_ih", sfx))
         return seq_fn.apply(gx, param("weight_hh", sfx), param("bias_hh", sfx), live, rev)
+    sfxs = [("", False), ("_reverse", True)] if bidir else [("", False)]
+    T, B = x_tm.shape[0], x_tm.shape[1]
+    H = param("weight_hh", "").shape[1]
+    if seq_fn is R_.LSTMSeqFn and x_tm.is_cuda and ops.lstm_seq_ok(len(sfxs), B, H):
+        # all time steps of the layer - both directions side by side - in one persistent launch (csrc/lstm_seq.hip)
+        flat = []
+        for sfx, rev in sfxs:
+            gx = F_.LinearFn.apply(x_tm, param("weight_ih", sfx), param("bias_ih", sfx))
+            flat += [gx, param("weight_hh", sfx), param("bias_hh", sfx), rev]
+        return list(R_.LSTMSeqGroupFn.apply(live, len(sfxs), *flat))
     if not bidir:
         return [one("", False)]
     if not (ops.TWO_STREAM_BIRNN and x_tm.is_cuda):

@@ -1391,6 +1391,62 @@ def lstm_step_bwd(dy_t, dgates_next, w_t, dh_pass_in, dc, acts, c_prev, c, live_
     check(fn(*args, stream_ptr()), "eamd_lstm_step_bwd")
 
 
+LSTM_PERSISTENT = True      # whole-sequence persistent LSTM launches (csrc/lstm_seq.hip); tests flip it
+_lstm_seq_last_ws = None    # sync words of the most recent persistent launch (lstm_seq_status)
+
+
+def lstm_seq_ok(njobs, B, H):
+    """shapes eamd_lstm_seq_fwd / _bwd take for `njobs` recurrences side by side (one workgroup per CU for the whole
+    launch; the entry points themselves answer EAMD_EUNSUPPORTED for anything else)"""
+    if not (LSTM_PERSISTENT and LSTM_FUSED_STEP and H % 64 == 0 and B <= 64 and H <= 1024):
+        return False
+    cus = torch.cuda.get_device_properties(torch.cuda.current_device()).multi_processor_count
+    return njobs * (H // 8) <= cus and njobs * (H // 16) * ((B + 15) // 16) <= cus
+
+
+def _lstm_seq_ws(dev):
+    global _lstm_seq_last_ws
+    n = int(_lib.lib().eamd_lstm_seq_sync_bytes())
+    _lstm_seq_last_ws = torch.empty(n, dtype=torch.uint8, device=dev)
+    return _lstm_seq_last_ws
+
+
+def lstm_seq_fwd(jobs, T, B, H):
+    """jobs: list of (gx [T,B,4H], w_hh, b_hh, live [T,B] | None, h_out, c_out, y, acts, reverse) - ONE persistent launch"""
+    arr = (_lib.LstmSeqFwdT * len(jobs))()
+    for q, (gx, w, b, live, h, c, y, acts, rev) in zip(arr, jobs):
+        q.gx, q.w_hh, q.b_hh, q.live = ptr(gx), ptr(w), ptr(b), ptr(live)
+        q.h_out, q.c_out, q.y, q.acts, q.reverse = ptr(h), ptr(c), ptr(y), ptr(acts), int(bool(rev))
+    ws = _lstm_seq_ws(jobs[0][0].device)
+    fn = _lib.lib().eamd_lstm_seq_fwd
+    args = (arr, len(jobs), T, B, H, ptr(ws))
+    if _rnn_record is not None:
+        _rnn_record.append(("lstm_seq_fwd", (jobs, ws, arr), lambda sp, args=args: check(fn(*args, sp), "eamd_lstm_seq_fwd"),
+                            4 * len(jobs) * (4 * H * H + T * B * 9 * H)))
+    check(fn(*args, stream_ptr()), "eamd_lstm_seq_fwd")
+
+
+def lstm_seq_bwd(jobs, T, B, H):
+    """jobs: list of (dy [T,B,H], w_t [H,4H], acts, c_out, live | None, dgates (out), reverse = the FORWARD direction)"""
+    arr = (_lib.LstmSeqBwdT * len(jobs))()
+    for q, (dy, w_t, acts, c, live, dg, rev) in zip(arr, jobs):
+        q.dy, q.w_t, q.acts, q.c_out, q.live, q.dgates, q.reverse = ptr(dy), ptr(w_t), ptr(acts), ptr(c), ptr(live), ptr(dg), int(bool(rev))
+    ws = _lstm_seq_ws(jobs[0][2].device)
+    fn = _lib.lib().eamd_lstm_seq_bwd
+    args = (arr, len(jobs), T, B, H, ptr(ws))
+    if _rnn_record is not None:
+        _rnn_record.append(("lstm_seq_bwd", (jobs, ws, arr), lambda sp, args=args: check(fn(*args, sp), "eamd_lstm_seq_bwd"),
+                            4 * len(jobs) * (4 * H * H + T * B * 11 * H)))
+    check(fn(*args, stream_ptr()), "eamd_lstm_seq_bwd")
+
+
+def lstm_seq_status():
+    """status word of the most recent persistent LSTM launch (synchronises): 0 = every hand-off wait completed"""
+    if _lstm_seq_last_ws is None:
+        return 0
+    return int(_lib.lib().eamd_lstm_seq_status(ptr(_lstm_seq_last_ws), stream_ptr()))
+
+
 def maxpool2x2_fwd(x):
     B, H, W, Cc = x.shape
     y = torch.empty(B, (H + 1) // 2, (W + 1) // 2, Cc, device=x.device, dtype=torch.float32)

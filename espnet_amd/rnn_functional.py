@@ -145,6 +145,62 @@ class LSTMSeqFn(torch.autograd.Function):
         return (dgates,) + sink.results() + (None, None)
 
 
+class LSTMSeqGroupFn(torch.autograd.Function):
+    """One or two independent LSTM recurrences over the same (T, B) - the directions of a BLSTM layer - as ONE
+    persistent launch forward and ONE backward (csrc/lstm_seq.hip).  apply(live, n, gx_0, w_hh_0, b_hh_0, rev_0, ...)
+    -> (y_0, ...).  reference: rnn/encoders.py:36-39,110-117 (torch.nn.LSTM(bidirectional=True) on packed sequences)."""
+
+    @staticmethod
+    def forward(ctx, live, n, *flat):
+        jobs = [flat[4 * i: 4 * i + 4] for i in range(n)]
+        T, B, H4 = jobs[0][0].shape
+        H = H4 // 4
+        dev = jobs[0][0].device
+        saved, outs, launch = [], [], []
+        for gx, w_hh, b_hh, rev in jobs:
+            gx = gx.contiguous()
+            h_out = torch.empty(T, B, H, device=dev, dtype=torch.float32)
+            c_out = torch.empty(T, B, H, device=dev, dtype=torch.float32)
+            acts = torch.empty(T, B, H4, device=dev, dtype=torch.float32)
+            y = torch.empty(T, B, H, device=dev, dtype=torch.float32)
+            launch.append((gx, w_hh, b_hh, live, h_out, c_out, y, acts, rev))
+            saved += [h_out, c_out, acts]
+            outs.append(y)
+        ops.lstm_seq_fwd(launch, T, B, H)
+        ctx.save_for_backward(*saved, *([live] if live is not None else []))
+        ctx.prs = [GradSink.use((w_hh, b_hh)) for _gx, w_hh, b_hh, _r in jobs]
+        ctx.cfg = (n, [bool(j[3]) for j in jobs], live is not None)
+        return tuple(outs)
+
+    @staticmethod
+    def backward(ctx, *dys):
+        n, revs, has_live = ctx.cfg
+        saved = ctx.saved_tensors
+        live = saved[3 * n] if has_live else None
+        T, B, H4 = saved[2].shape
+        H = H4 // 4
+        dev = saved[2].device
+        launch, dgs = [], []
+        for i in range(n):
+            h_out, c_out, acts = saved[3 * i: 3 * i + 3]
+            w_hh, _b = ctx.prs[i]
+            dy = dys[i].contiguous() if dys[i] is not None else torch.zeros(T, B, H, device=dev, dtype=torch.float32)
+            dgates = torch.empty(T, B, H4, device=dev, dtype=torch.float32)
+            launch.append((dy, w_hh.detach().t().contiguous(), acts, c_out, live, dgates, revs[i]))
+            dgs.append(dgates)
+        ops.lstm_seq_bwd(launch, T, B, H)
+        res = [None, None]
+        for i in range(n):
+            h_out = saved[3 * i]
+            sink = GradSink(ctx.prs[i])
+            if T > 1:
+                dg, hp = (dgs[i][:-1], h_out[1:]) if revs[i] else (dgs[i][1:], h_out[:-1])
+                ops.linear_bwd_w(dg.reshape(-1, H4), hp.reshape(-1, H), sink.buf(0))
+            ops.colsum(dgs[i].view(-1, H4), sink.buf(1))
+            res += [dgs[i]] + list(sink.results()) + [None]
+        return tuple(res)
+
+
 class LSTMCellFn(torch.autograd.Function):
     """one LSTMCell step whose input depends on the previous step (attention decoder, decoders.py:120-134):
     gates = gx (= x W_ih^T + b_ih, a LinearFn product) + h W_hh^T + b_hh."""

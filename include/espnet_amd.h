@@ -492,6 +492,43 @@ int eamd_lstm_step_fwd(const float* gx, const float* w_hh, const float* b_hh, co
 int eamd_lstm_step_bwd(const float* dy, const float* dgates_next, const float* w_t, const float* dh_pass_in, const float* dc,
                        const float* acts, const float* c_prev, const float* c, const uint8_t* live, float* dgates,
                        float* dc_prev, float* dh_pass, int B, int H, void* stream);
+/* A whole LSTM sequence - all T time steps of one or two independent recurrences (the two directions of a BLSTM
+ * layer) - in ONE persistent launch: recurrent weights and cell state stay in registers, h_t (forward) / dgates_t
+ * (backward) are handed from workgroup to workgroup through write-through stores + one flag per workgroup, both
+ * directions run side by side (csrc/lstm_seq.hip).  Layouts as the step entry points: gx / acts / dgates [T, B, 4H],
+ * h_out / c_out / y / dy [T, B, H], live [T, B] (0 = padding frame of a packed sequence) or NULL, initial states 0;
+ * `reverse` runs the recurrence from t = T-1 down (the backward of a job walks against its forward direction).
+ * sync_ws: eamd_lstm_seq_sync_bytes() bytes of device memory at the start of an allocation, zeroed by the call (a small
+ * kernel ahead of the persistent one); eamd_lstm_seq_status() copies its status word to the host: 0 = every wait completed.
+ * EAMD_EUNSUPPORTED when the shape does not fit (H % 64, B <= 64, one workgroup per CU for all jobs): run the jobs one
+ * per call, or the per-step entry points.
+ * reference: rnn/encoders.py:36-39,110-117 (torch.nn.LSTM, bidirectional, packed sequences). */
+typedef struct {
+  const float* gx;
+  const float* w_hh;     /* [4H, H] */
+  const float* b_hh;     /* [4H] or NULL */
+  const uint8_t* live;
+  float* h_out;
+  float* c_out;
+  float* y;              /* h with padding frames zeroed, or NULL */
+  float* acts;           /* the four gate activations per (t, b, unit), for backward */
+  int32_t reverse;
+  int32_t reserved;
+} eamd_lstm_seq_fwd_t;
+typedef struct {
+  const float* dy;       /* gradient wrt y, or NULL */
+  const float* w_t;      /* W_hh^T [H, 4H] */
+  const float* acts;
+  const float* c_out;
+  const uint8_t* live;
+  float* dgates;         /* out: gate pre-activation gradients */
+  int32_t reverse;       /* the job's FORWARD direction */
+  int32_t reserved;
+} eamd_lstm_seq_bwd_t;
+int64_t eamd_lstm_seq_sync_bytes(void);
+int eamd_lstm_seq_fwd(const eamd_lstm_seq_fwd_t* jobs, int njobs, int T, int B, int H, void* sync_ws, void* stream);
+int eamd_lstm_seq_bwd(const eamd_lstm_seq_bwd_t* jobs, int njobs, int T, int B, int H, void* sync_ws, void* stream);
+int eamd_lstm_seq_status(const void* sync_ws, void* stream);
 /* One GRU step (torch.nn.GRU / GRUCell, gate order r,z,n; rnn/encoders.py:31-33,110-119, rnn/decoders.py:96,105,
  * transducer/rnn_decoder.py:50) on gx = x W_ih^T + b_ih and gh = h W_hh^T + b_hh (both [B,3H], eamd_gemm products).
  * acts [B,4H] = r, z, n, gh_n.  Backward: dgx, dgh [B,3H] and dh_direct [B,H] (the part of the gradient that reaches

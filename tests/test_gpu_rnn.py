@@ -871,3 +871,76 @@ def test_lstm_fused_step_kernels(shape):
         yb = R.LSTMSeqFn.apply(gx, w_hh, b_hh, None, True)
         yf = R.LSTMSeqFn.apply(gx.flip(0).contiguous(), w_hh, b_hh, None, False)
         report("lstm fused step reverse %s" % (shape,), yb, yf.flip(0), 1e-6)
+
+
+@pytest.mark.parametrize("shape", [(32, 1024, 12, True, 2), (32, 1024, 6, False, 1), (16, 320, 7, True, 2), (5, 64, 11, True, 2),
+                                   (48, 128, 5, True, 1), (64, 256, 9, True, 2), (20, 512, 40, True, 2)])
+def test_lstm_persistent_sequence_kernels(shape):
+    """eamd_lstm_seq_fwd / _bwd (csrc/lstm_seq.hip: all time steps of one or two recurrences in ONE persistent launch,
+    recurrent weights in registers, h_t / dgates_t handed between workgroups through write-through stores + flags)
+    against torch.nn.LSTM(bidirectional) in float64 on packed sequences, and against the per-step kernels; every
+    hand-off wait completed (status word 0), and a second launch reproduces the first bit for bit (nothing stale is
+    ever read)."""
+    from espnet_amd import ops
+    from espnet_amd import rnn_functional as R
+    B, H, T, masked, ndir = shape
+    g = torch.Generator().manual_seed(B + H + T)
+    ref = torch.nn.LSTM(H, H, 1, bidirectional=(ndir == 2)).double()
+    x = torch.randn(T, B, H, generator=g).double()
+    lens = sorted([max(1, T - (i * T) // (2 * B)) for i in range(B)], reverse=True) if masked else [T] * B
+    live = (torch.arange(T)[:, None] < torch.tensor(lens)[None, :]).to(torch.uint8).to(DEV).contiguous() if masked else None
+    gy = torch.randn(T, B, ndir * H, generator=g)
+    for t in range(T):
+        for b in range(B):
+            if t >= lens[b]:
+                gy[t, b] = 0.0
+    xr = x.clone().requires_grad_(True)
+    packed = torch.nn.utils.rnn.pack_padded_sequence(xr, torch.tensor(lens), enforce_sorted=True)
+    yr, _ = torch.nn.utils.rnn.pad_packed_sequence(ref(packed)[0], total_length=T)
+    yr.backward(gy.double())
+    sfx = ["", "_reverse"][:ndir]
+    w = {s: (getattr(ref, "weight_hh_l0" + s).detach().float().to(DEV), getattr(ref, "bias_hh_l0" + s).detach().float().to(DEV))
+         for s in sfx}
+    gx_ref = {s: (x @ getattr(ref, "weight_ih_l0" + s).detach().t() + getattr(ref, "bias_ih_l0" + s).detach()).float().to(DEV)
+              for s in sfx}
+    assert ops.lstm_seq_ok(ndir, B, H)
+
+    def run(persistent):
+        ops.LSTM_PERSISTENT = persistent
+        try:
+            leaves = []
+            if persistent:
+                flat = []
+                for i, s in enumerate(sfx):
+                    gx, wh, bh = gx_ref[s].clone().requires_grad_(True), w[s][0].clone().requires_grad_(True), w[s][1].clone().requires_grad_(True)
+                    leaves.append((gx, wh, bh))
+                    flat += [gx, wh, bh, i == 1]
+                ys = R.LSTMSeqGroupFn.apply(live, ndir, *flat)
+                st_f = ops.lstm_seq_status()
+                torch.autograd.backward(list(ys), [gy[..., i * H:(i + 1) * H].contiguous().to(DEV) for i in range(ndir)])
+                st_b = ops.lstm_seq_status()
+                assert st_f == 0 and st_b == 0, (st_f, st_b)
+            else:
+                ys = []
+                for i, s in enumerate(sfx):
+                    gx, wh, bh = gx_ref[s].clone().requires_grad_(True), w[s][0].clone().requires_grad_(True), w[s][1].clone().requires_grad_(True)
+                    leaves.append((gx, wh, bh))
+                    ys.append(R.LSTMSeqFn.apply(gx, wh, bh, live, i == 1))
+                torch.autograd.backward(ys, [gy[..., i * H:(i + 1) * H].contiguous().to(DEV) for i in range(ndir)])
+            return [y.detach() for y in ys], leaves
+        finally:
+            ops.LSTM_PERSISTENT = True
+
+    ys_p, lv_p = run(True)
+    ys_p2, lv_p2 = run(True)
+    ys_s, lv_s = run(False)
+    for i, s in enumerate(sfx):
+        tag = "%s dir %d" % (shape, i)
+        report("lstm persistent y " + tag, ys_p[i], yr.detach()[..., i * H:(i + 1) * H], 2e-6)
+        report("lstm persistent dW_hh " + tag, lv_p[i][1].grad, getattr(ref, "weight_hh_l0" + s).grad, 2e-5)
+        report("lstm persistent db_hh " + tag, lv_p[i][2].grad, getattr(ref, "bias_hh_l0" + s).grad, 2e-5)
+        report("lstm persistent dgates vs step kernels " + tag, lv_p[i][0].grad, lv_s[i][0].grad, 2e-5)
+        assert torch.equal(ys_p[i], ys_p2[i]) and torch.equal(lv_p[i][0].grad, lv_p2[i][0].grad), "persistent launch not reproducible " + tag
+        report("lstm persistent y vs step kernels " + tag, ys_p[i], ys_s[i], 1e-6)
+    dx = sum(lv_p[i][0].grad.double().cpu() @ getattr(ref, "weight_ih_l0" + s).detach() for i, s in enumerate(sfx))
+    report("lstm persistent dx %s" % (shape,), dx, xr.grad, 2e-5)

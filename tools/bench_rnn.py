@@ -103,7 +103,7 @@ def run(name, model, xs, ilens, ys, steps=3, graph=True, dominant=None, quiet=Fa
                                           "(MI355X_MICROARCH.md); the launches are latency-bound (DESIGN.md section 4)"))
         elif isinstance(dominant, tuple) and dominant[0] == "gemm":
             Vv = dominant[1]
-            sel = [r for r in grec if r[0] is not None and Vv in (r[0].M, r[0].N, r[0].K)]
+            sel = [r for r in grec if r[0] is not None and not isinstance(r[0], dict) and Vv in (r[0].M, r[0].N, r[0].K)]
             if sel:
                 ms = _replay_ms([r[2] for r in sel])
                 fl = sum(_gemm_flops(r[0]) for r in sel)
