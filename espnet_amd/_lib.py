@@ -100,6 +100,8 @@ def lib():
     """Load the HIP shared library (once).  Raises if it has not been built."""
     global _lib
     if _lib is None:
+        if os.environ.get("EAMD_LIB"):          # diagnostic builds of tools/ (timing probes): never set in production
+            globals()["LIB_PATH"] = os.environ["EAMD_LIB"]
         if not os.path.exists(LIB_PATH):
             raise EamdError(
                 f"{LIB_PATH} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "

@@ -69,12 +69,25 @@ __device__ __forceinline__ bool wait_flags(unsigned* ws, int first, int n, unsig
   }
 }
 
+// timing probes of the diagnostic build (-DLSTM_SEQ_PROBE, EAMD_LSTM_PROBE bits; results are wrong by design):
+// 1 = no MFMAs, 2 = no loads of the handed-over rows, 4 = no waiting for the flags, 8 = no cell arithmetic / stores
+#ifdef LSTM_SEQ_PROBE
+#define PROBE(bit) ((a.probe & (bit)) != 0)
+#else
+#define PROBE(bit) false
+#endif
+
+// handed-over rows: plain 16-byte loads behind the polling wave's agent-scope acquire (acq mode 1, the default: the 32
+// workgroups of an XCD then share the rows through its L2 - 11.5 / 12.3 us per step forward / backward at config 4), or
+// sc1 loads with no acquire (mode 0: every workgroup pulls its own copy over the fabric, 12.4 / 16.8 us)
+#define LD_X4(p) (a.acq == 1 ? *reinterpret_cast<const f32x4*>(p) : ld_sc1_x4(p))
+
 struct FwdJob {
   const float* gx; const float* w_hh; const float* b_hh; const unsigned char* live;
   float* h_out; float* c_out; float* y; float* acts;
   int reverse;
 };
-struct FwdArgs { FwdJob job[2]; int T, B, H, nwg; unsigned* ws; int acq; };
+struct FwdArgs { FwdJob job[2]; int T, B, H, nwg; unsigned* ws; int acq, probe; };
 
 // Forward.  Workgroup = (job, slice of U = 4 * NT hidden units): B-operand tile nt row n = gate (n / 4) of unit
 // u0 + 4 nt + n % 4.  NW waves split the reduction over the H recurrent inputs, KQ quad-steps of 16 each.
@@ -135,7 +148,7 @@ __global__ __launch_bounds__(1024) void lstm_seq_fwd_kernel(const FwdArgs a) {
       for (int nt = 0; nt < NT; ++nt) acc[i][nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
     if (s > 0) {
       if (wave == 0) {
-        const bool ok = wait_flags(a.ws, jb * a.nwg, a.nwg, (unsigned)s, lane, 0x100u + jb);
+        const bool ok = PROBE(4) ? true : wait_flags(a.ws, jb * a.nwg, a.nwg, (unsigned)s, lane, 0x100u + jb);
         if (lane == 0) go = ok ? 1 : 0;
         if (a.acq == 1) {
           __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
@@ -149,7 +162,7 @@ __global__ __launch_bounds__(1024) void lstm_seq_fwd_kernel(const FwdArgs a) {
 #pragma unroll
       for (int q = 0; q < KQ; ++q)
 #pragma unroll
-        for (int i = 0; i < MT; ++i) av[i][q] = ld_sc1_x4(hp + aoff[i] + q * 16);
+        for (int i = 0; i < MT; ++i) av[i][q] = PROBE(2) ? (f32x4){0.f, 0.f, 0.f, 0.f} : LD_X4(hp + aoff[i] + q * 16);
 #pragma unroll
       for (int q = 0; q < KQ; ++q)
 #pragma unroll
@@ -159,7 +172,7 @@ __global__ __launch_bounds__(1024) void lstm_seq_fwd_kernel(const FwdArgs a) {
             const float ae = av[i][q][e];
 #pragma unroll
             for (int nt = 0; nt < NT; ++nt)
-              acc[i][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(ae, bv[nt][q][e], acc[i][nt], 0, 0, 0);
+              if (!PROBE(1)) acc[i][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(ae, bv[nt][q][e], acc[i][nt], 0, 0, 0);
           }
     }
 #pragma unroll
@@ -169,7 +182,7 @@ __global__ __launch_bounds__(1024) void lstm_seq_fwd_kernel(const FwdArgs a) {
 #pragma unroll
         for (int r = 0; r < 4; ++r) part[wave][i * 16 + fq * 4 + r][nt * 16 + fr] = acc[i][nt][r];
     __syncthreads();
-    if (cell) {
+    if (cell && !PROBE(8)) {
       float g4[4];
 #pragma unroll
       for (int g = 0; g < 4; ++g) {
@@ -202,7 +215,7 @@ struct BwdJob {
   float* dgates;
   int reverse;
 };
-struct BwdArgs { BwdJob job[2]; int T, B, H, nut, nmt; unsigned* ws; int acq; };
+struct BwdArgs { BwdJob job[2]; int T, B, H, nut, nmt; unsigned* ws; int acq, probe; };
 
 // Backward.  Workgroup = (job, 16 hidden units, 16 batch rows):
 //   dh[b, u] = pass[b, u] + sum_r dgates_next[b, r] W_hh[r, u]   (r over the 4H gate rows, split over NW waves x KQ quad-steps),
@@ -256,7 +269,7 @@ __global__ __launch_bounds__(1024) void lstm_seq_bwd_kernel(const BwdArgs a) {
     f32x4 acc = (f32x4){0.f, 0.f, 0.f, 0.f};
     if (s > 0) {
       if (wave == 0) {
-        const bool ok = wait_flags(a.ws, jb * per_job + mt * a.nut, a.nut, (unsigned)s, lane, 0x200u + jb);
+        const bool ok = PROBE(4) ? true : wait_flags(a.ws, jb * per_job + mt * a.nut, a.nut, (unsigned)s, lane, 0x200u + jb);
         if (lane == 0) go = ok ? 1 : 0;
         if (a.acq == 1) {
           __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
@@ -268,24 +281,24 @@ __global__ __launch_bounds__(1024) void lstm_seq_bwd_kernel(const BwdArgs a) {
       const float* dg = J.dgates + (long)tn * B * K;
       f32x4 av[2][CH];
 #pragma unroll
-      for (int q = 0; q < CH; ++q) av[0][q] = ld_sc1_x4(dg + aoff + q * 16);
+      for (int q = 0; q < CH; ++q) av[0][q] = PROBE(2) ? (f32x4){0.f, 0.f, 0.f, 0.f} : LD_X4(dg + aoff + q * 16);
 #pragma unroll
       for (int c = 0; c < KQ / CH; ++c) {
         if (c + 1 < KQ / CH)
 #pragma unroll
           for (int q = 0; q < CH; ++q)
-            av[(c + 1) & 1][q] = ld_sc1_x4(dg + aoff + ((c + 1) * CH + q) * 16);
+            av[(c + 1) & 1][q] = PROBE(2) ? (f32x4){0.f, 0.f, 0.f, 0.f} : LD_X4(dg + aoff + ((c + 1) * CH + q) * 16);
 #pragma unroll
         for (int q = 0; q < CH; ++q)
 #pragma unroll
           for (int e = 0; e < 4; ++e)
-            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av[c & 1][q][e], bv[c * CH + q][e], acc, 0, 0, 0);
+            if (!PROBE(1)) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av[c & 1][q][e], bv[c * CH + q][e], acc, 0, 0, 0);
       }
     }
 #pragma unroll
     for (int r = 0; r < 4; ++r) part[wave][fq * 4 + r][fr] = acc[r];
     __syncthreads();
-    if (cell) {
+    if (cell && !PROBE(8)) {
       float dhr = pass_reg;
       if (s > 0)
         for (int w = 0; w < NW; ++w) dhr += part[w][t >> 4][t & 15];
@@ -330,9 +343,18 @@ int acq_mode() {
   static int m = -1;
   if (m < 0) {
     const char* e = getenv("EAMD_LSTM_SEQ_ACQ");
-    m = e ? atoi(e) : 0;
+    m = e ? atoi(e) : 1;
   }
   return m;
+}
+
+int probe_bits() {
+#ifdef LSTM_SEQ_PROBE
+  const char* e = getenv("EAMD_LSTM_PROBE");
+  return e ? atoi(e) : 0;
+#else
+  return 0;
+#endif
 }
 
 constexpr int64_t SYNC_BYTES = 4096;     // status word + 256 bytes of padding + up to 960 flags
@@ -372,7 +394,7 @@ int eamd_lstm_seq_fwd(const eamd_lstm_seq_fwd_t* jobs, int njobs, int T, int B, 
     const eamd_lstm_seq_fwd_t& q = jobs[j < njobs ? j : 0];
     a.job[j] = FwdJob{q.gx, q.w_hh, q.b_hh, q.live, q.h_out, q.c_out, q.y, q.acts, q.reverse};
   }
-  a.T = T; a.B = B; a.H = H; a.nwg = nwg; a.ws = (unsigned*)sync_ws; a.acq = acq_mode();
+  a.T = T; a.B = B; a.H = H; a.nwg = nwg; a.ws = (unsigned*)sync_ws; a.acq = acq_mode(); a.probe = probe_bits();
   const dim3 grid(njobs * nwg), block(64 * nw);
   const size_t lds = (size_t)nw * mt * 16 * (nt * 16 + 1) * sizeof(float);
 #define EAMD_LQF(MT_, NT_, KQ_)                                                                                          \
@@ -421,7 +443,7 @@ int eamd_lstm_seq_bwd(const eamd_lstm_seq_bwd_t* jobs, int njobs, int T, int B, 
     const eamd_lstm_seq_bwd_t& q = jobs[j < njobs ? j : 0];
     a.job[j] = BwdJob{q.dy, q.w_t, q.acts, q.c_out, q.live, q.dgates, q.reverse};
   }
-  a.T = T; a.B = B; a.H = H; a.nut = nut; a.nmt = nmt; a.ws = (unsigned*)sync_ws; a.acq = acq_mode();
+  a.T = T; a.B = B; a.H = H; a.nut = nut; a.nmt = nmt; a.ws = (unsigned*)sync_ws; a.acq = acq_mode(); a.probe = probe_bits();
   const dim3 grid(njobs * nut * nmt), block(64 * nw);
   const size_t lds = (size_t)nw * 16 * 17 * sizeof(float);
 #define EAMD_LQB(KQ_) hipLaunchKernelGGL(lstm_seq_bwd_kernel<KQ_>, grid, block, lds, s, a)

@@ -10,6 +10,7 @@ import numpy as np
 import torch
 
 from .. import functional as F_
+from .. import ops
 from .asr_interface import ASRInterface
 from .modules import CTC
 from .rnn.attentions import att_for
@@ -99,6 +100,11 @@ class E2E(ASRInterface, torch.nn.Module):
 
     def forward(self, xs_pad, ilens, ys_pad):
         """xs_pad (B,Tmax,idim), ilens (B), ys_pad (B,Lmax) -> loss (e2e_asr.py:205-338)"""
+        if xs_pad.is_cuda:
+            if self.training and torch.is_grad_enabled():
+                ops.zero_arena_begin(xs_pad.device)      # the decoder loop's zero-filled buffers: one fill per step
+            else:
+                ops.zero_arena_off()
         hs_pad, hlens, _ = self.enc(xs_pad, ilens)
         self.hs_pad, self.hlens = hs_pad, hlens
         self.loss_ctc = None if self.mtlalpha == 0 else self.ctc(hs_pad, hlens, ys_pad)

@@ -427,17 +427,68 @@ def linear_fwd(x, W, b, out=None, *, act=EPI_NONE, R=None, alpha=1.0, a_act=ACT_
     M, K = x.shape
     N = W.shape[0]
     assert W.shape[1] == K and x.is_contiguous() and W.is_contiguous()
-    if out is None:
-        out = torch.empty(M, N, device=x.device, dtype=out_dtype)
     sk = 1
-    if out.dtype == torch.float32 and act == EPI_NONE and R is None and drop is None and Hb is None and a_drop is None \
-            and alpha == 1.0:
+    if (out_dtype if out is None else out.dtype) == torch.float32 and act == EPI_NONE and R is None and drop is None \
+            and Hb is None and a_drop is None and alpha == 1.0:
         sk = _skinny_splitk(M, N, K)
-    if sk > 1:
+    if out is None:
+        out = zeros(M, N, device=x.device) if sk > 1 else torch.empty(M, N, device=x.device, dtype=out_dtype)
+    elif sk > 1:
         out.zero_()
     gemm(x, W, out, M, N, K, K, K, N, bias=b, epilogue=act, R=R, ldr=N, alpha=alpha, a_act=a_act, drop=drop, Hb=Hb,
          h_act=h_act, a_drop=a_drop, splitk=sk)
     return out
+
+
+# ---- zero arena --------------------------------------------------------------------------------------------------
+# A decoder loop asks for hundreds of small zero-filled buffers per training step (split-K results that accumulate
+# through atomics, gradient accumulators of the attention steps): 716 fill launches of 4 us at BASELINE config 4.
+# Between zero_arena_begin() (the model's forward in training mode) and the next one, zeros() hands out fresh
+# slices of ONE buffer that a single fill zeroed at begin; its size is the previous step's demand (the first step,
+# and anything beyond the buffer, falls back to torch.zeros).  Slices are never handed out twice.
+class _ZeroArena:
+    buf = None
+    off = 0
+    need = 0        # bytes asked for since the last begin
+    cap = 0         # bytes the next arena gets
+    active = False
+
+
+_zarena = _ZeroArena()
+ZERO_ARENA = os.environ.get("EAMD_ZERO_ARENA", "1") != "0"
+
+
+def zero_arena_begin(device):
+    """a FRESH buffer per step (one allocation + one fill): slices a still-living autograd graph of an earlier forward
+    holds keep their storage alive, so a second forward before that backward cannot clobber them"""
+    a = _zarena
+    a.cap = max(a.cap, (int(a.need * 1.25) + 4095) // 4096 * 4096)
+    a.off, a.need = 0, 0
+    a.active = ZERO_ARENA and a.cap > 0
+    a.buf = torch.zeros(a.cap // 4, device=device, dtype=torch.float32) if a.active else None
+
+
+def zero_arena_off():
+    """inference paths: zeros() is torch.zeros again"""
+    _zarena.active = False
+    _zarena.buf = None
+
+
+def zeros(*shape, device):
+    """fp32 zeros: a slice of the step's zero arena when one is active, else torch.zeros"""
+    if len(shape) == 1 and isinstance(shape[0], (tuple, list, torch.Size)):
+        shape = tuple(shape[0])
+    n = 1
+    for d in shape:
+        n *= int(d)
+    a = _zarena
+    nb = (n * 4 + 255) // 256 * 256
+    a.need += nb
+    if a.active and n > 0 and a.off + nb <= a.buf.numel() * 4 and a.buf.device == torch.device(device):
+        t = a.buf[a.off // 4: a.off // 4 + n].view(shape)
+        a.off += nb
+        return t
+    return torch.zeros(shape, device=device, dtype=torch.float32)
 
 
 def _skinny_splitk(M, N, K):
@@ -461,15 +512,13 @@ def linear_bwd_x(dy, W, out=None, *, beta=0.0, epilogue=EPI_NONE, aux=None, alph
     K = W.shape[1]
     assert W.shape[0] == N and dy.is_contiguous()
     fresh = out is None
-    if out is None:
-        assert beta == 0.0
-        out = torch.empty(M, K, device=dy.device, dtype=out_dtype)
     sk = 1
-    if fresh and out.dtype == torch.float32 and epilogue == EPI_NONE and aux is None and drop is None and a_drop is None \
+    if fresh and out_dtype == torch.float32 and epilogue == EPI_NONE and aux is None and drop is None and a_drop is None \
             and alpha == 1.0:
         sk = _skinny_splitk(M, K, N)
-    if sk > 1:
-        out.zero_()
+    if out is None:
+        assert beta == 0.0
+        out = zeros(M, K, device=dy.device) if sk > 1 else torch.empty(M, K, device=dy.device, dtype=out_dtype)
     gemm(dy, W, out, M, K, N, N, K, K, transB=1, beta=beta, epilogue=epilogue, aux=aux, ldaux=K, alpha=alpha,
          drop=drop, a_drop=a_drop, splitk=sk)
     return out
@@ -1637,7 +1686,7 @@ def attloc_bwd_energy(dctx, dw_ext, w, enc_h, th, gvec, scaling, dgvec, dgb):
     de = torch.empty(B, T, device=dev, dtype=torch.float32)
     d_enc_h = torch.empty(B, T, E, device=dev, dtype=torch.float32)
     df = torch.empty(B, T, A, device=dev, dtype=torch.float32)
-    d_dec = torch.zeros(B, A, device=dev, dtype=torch.float32)
+    d_dec = zeros(B, A, device=dev)
     check(_lib.lib().eamd_attloc_bwd_energy(ptr(dctx), ptr(dw_ext), ptr(w), ptr(enc_h), ptr(th), ptr(gvec),
                                             C.c_float(scaling), ptr(de), ptr(d_enc_h), ptr(df), ptr(dgvec), ptr(dgb),
                                             ptr(d_dec), B, T, A, E, stream_ptr()), "eamd_attloc_bwd_energy")
@@ -1668,7 +1717,7 @@ def attloc_bwd_energy_conv(dctx, dw_ext, w, enc_h, th, gvec, scaling, conv, w_at
         d_enc_h = torch.empty(B, T, E, device=dev, dtype=torch.float32)
         df = torch.empty(B, T, A, device=dev, dtype=torch.float32)
     dconv = torch.empty(B, T, Cc, device=dev, dtype=torch.float32)
-    d_dec = torch.zeros(B, A, device=dev, dtype=torch.float32)
+    d_dec = zeros(B, A, device=dev)
     rc = lib.eamd_attloc_bwd_energy_conv(ptr(dctx), ptr(dw_ext), ptr(w), ptr(enc_h), ptr(th), ptr(gvec), C.c_float(scaling),
                                          ptr(conv), ptr(w_att), ptr(de), ptr(d_enc_h), ptr(df), ptr(dconv), ptr(dgvec),
                                          ptr(dgb), ptr(d_dec), ptr(dw_att), ptr(ws), int(accumulate), B, T, A, Cc, E,
@@ -1705,7 +1754,7 @@ def attloc_convmax_fwd(att_prev, conv_w):
 def attloc_convmax_bwd(dpool, pooled, idx, att_prev, conv_w, dconv_w):
     B, T = att_prev.shape
     Cc, K = conv_w.shape[0], conv_w.shape[-1]
-    d_prev = torch.zeros(B, T, device=att_prev.device, dtype=torch.float32)
+    d_prev = zeros(B, T, device=att_prev.device)
     check(_lib.lib().eamd_attloc_convmax_bwd(ptr(dpool), ptr(pooled), ptr(idx), ptr(att_prev), ptr(conv_w), ptr(d_prev),
                                              ptr(dconv_w), B, T, Cc, K, stream_ptr()), "eamd_attloc_convmax_bwd")
     return d_prev
@@ -1742,8 +1791,8 @@ def att_dot_bwd(dctx, dw_ext, w, k, q, v, scaling):
     de = torch.empty(B, T, device=dev, dtype=torch.float32)
     d_v = torch.empty(B, T, E, device=dev, dtype=torch.float32)
     dk = torch.empty(B, T, A, device=dev, dtype=torch.float32)
-    dq = torch.zeros(B, A, device=dev, dtype=torch.float32)
-    dsum = torch.zeros(1, device=dev, dtype=torch.float32)
+    dq = zeros(B, A, device=dev)
+    dsum = zeros(1, device=dev)
     L = _lib.lib()
     check(L.eamd_att_ctx_bwd(ptr(dctx), ptr(dw_ext), ptr(w), ptr(v), C.c_float(scaling), ptr(de), ptr(d_v), ptr(dsum),
                              B, T, E, stream_ptr()), "eamd_att_ctx_bwd")

@@ -64,9 +64,12 @@ def _rec_gemm(a, w, out, M, N, K, lda, ldb, ldc, *, transB=0, bias=None, R=None,
     sk = 1
     while tiles * sk < 512 and K // (sk * 2) >= 128:
         sk *= 2
-    if sk > 1:
+    if out is None:        # a fresh [M, N] result: zeros come from the step's zero arena (no fill launch)
+        out = ops.zeros(M, N, device=a.device) if sk > 1 else torch.empty(M, N, device=a.device, dtype=torch.float32)
+    elif sk > 1:
         out.zero_()
     ops.gemm(a, w, out, M, N, K, lda, ldb, ldc, transB=transB, bias=bias, R=R, ldr=ldr, splitk=sk)
+    return out
 
 
 class LSTMSeqFn(torch.autograd.Function):
@@ -236,8 +239,7 @@ class LSTMCellFn(torch.autograd.Function):
         dc_prev = torch.empty(B, H, device=dev, dtype=torch.float32)
         ops.lstm_cell_bwd(None, dh.contiguous() if dh is not None else None, dc.contiguous() if dc is not None else None,
                           acts, c_prev, c, None, dgates, dc_prev, None)
-        dh_prev = torch.empty(B, H, device=dev, dtype=torch.float32)
-        _rec_gemm(dgates, w_hh, dh_prev, B, H, H4, H4, H, H, transB=1)
+        dh_prev = _rec_gemm(dgates, w_hh, None, B, H, H4, H4, H, H, transB=1)
         has_b = len(ctx.pr) > 1
         ops.linear_bwd_w(dgates, h_prev, sink.buf(0), db=sink.buf(1) if has_b else None)
         return (dgates, dh_prev, dc_prev) + sink.results() + (() if has_b else (None,))

@@ -135,6 +135,4 @@ def test_unsupported_variants_fail_loudly():
         initial_att("no_such_attention", 8, 8, 2, 4, 3, 2, 1)
     with pytest.raises(ValueError):
         Encoder("brnnp", 10, 1, 4, 4, np.ones(2, dtype=np.int64), 0.0)
-    from espnet_amd.nets.rnn.decoders import Decoder
-    with pytest.raises(NotImplementedError):
-        Decoder(4, 5, "lstm", 1, 4, 4, 4, None, sampling_probability=0.5)
+    # scheduled sampling (sampling_probability > 0) is implemented since round 3: tests/test_gpu_rnn.py covers it
