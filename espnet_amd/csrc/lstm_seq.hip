@@ -29,8 +29,7 @@ namespace {
 __device__ __forceinline__ float sigm_(float x) { return 1.0f / (1.0f + expf(-x)); }
 
 // 16 bytes of handed-off data as two 8-byte agent-scope relaxed loads (global_load_dwordx2 sc1: served by L2, never by
-// this CU's L1).  Not __builtin_amdgcn_raw_buffer_load_b128(..., sc1): hipcc 7.2 narrows that load to the first dword
-// when its elements are extracted one by one (every MFMA got element 0).
+// this CU's L1).
 __device__ __forceinline__ f32x4 ld_sc1_x4(const float* p) {
   const unsigned long long* q = reinterpret_cast<const unsigned long long*>(p);
   const unsigned long long a = __hip_atomic_load(q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -77,6 +76,21 @@ __device__ __forceinline__ bool wait_flags(unsigned* ws, int first, int n, unsig
 #define PROBE(bit) false
 #endif
 
+// 16 bytes of hand-off payload as two write-through (sc1) 8-byte stores
+__device__ __forceinline__ void st_sc1_x4(float* p, f32x4 v) {
+  unsigned long long* q = reinterpret_cast<unsigned long long*>(p);
+  // (scalar copies first: hipcc 7.2 folds __builtin_bit_cast(unsigned, v[i]) of an ext_vector ELEMENT to element 0)
+  const float v0 = v[0], v1 = v[1], v2 = v[2], v3 = v[3];
+  const unsigned long long a = (unsigned long long)__float_as_uint(v0) | ((unsigned long long)__float_as_uint(v1) << 32);
+  const unsigned long long b = (unsigned long long)__float_as_uint(v2) | ((unsigned long long)__float_as_uint(v3) << 32);
+  __hip_atomic_store(q, a, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  __hip_atomic_store(q + 1, b, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+// the values of lanes l .. l + 3 (l % 4 == 0 uses the result): four adjacent hidden units of one row leave as one 16-byte store
+__device__ __forceinline__ f32x4 quad_gather(float x) {
+  return (f32x4){x, __shfl_down(x, 1), __shfl_down(x, 2), __shfl_down(x, 3)};
+}
+
 // handed-over rows: plain 16-byte loads behind the polling wave's agent-scope acquire (acq mode 1, the default: the 32
 // workgroups of an XCD then share the rows through its L2 - 11.5 / 12.3 us per step forward / backward at config 4), or
 // sc1 loads with no acquire (mode 0: every workgroup pulls its own copy over the fabric, 12.4 / 16.8 us)
@@ -87,10 +101,11 @@ struct FwdJob {
   float* h_out; float* c_out; float* y; float* acts;
   int reverse;
 };
-struct FwdArgs { FwdJob job[2]; int T, B, H, nwg; unsigned* ws; int acq, probe; };
+struct FwdArgs { FwdJob job[2]; int T, B, H, nut, nmt; unsigned* ws; int acq, probe; };
 
-// Forward.  Workgroup = (job, slice of U = 4 * NT hidden units): B-operand tile nt row n = gate (n / 4) of unit
-// u0 + 4 nt + n % 4.  NW waves split the reduction over the H recurrent inputs, KQ quad-steps of 16 each.
+// Forward.  Workgroup = (job, 16 * MT batch rows, U = 4 * NT hidden units): B-operand tile nt row n = gate (n / 4) of
+// unit u0 + 4 nt + n % 4.  NW waves split the reduction over the H recurrent inputs, KQ quad-steps of 16 each.  It
+// waits only for the workgroups of its own batch-row tile (the rows of h it multiplies).
 template <int MT, int NT, int KQ>
 __global__ __launch_bounds__(1024) void lstm_seq_fwd_kernel(const FwdArgs a) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -99,11 +114,13 @@ __global__ __launch_bounds__(1024) void lstm_seq_fwd_kernel(const FwdArgs a) {
   __shared__ int go;
   const int t = threadIdx.x, lane = t & 63, wave = __builtin_amdgcn_readfirstlane(t >> 6), fr = lane & 15, fq = lane >> 4;
   const int NW = blockDim.x >> 6;
-  const int jb = blockIdx.x / a.nwg, wg = blockIdx.x % a.nwg;
+  const int per_job = a.nut * a.nmt;
+  const int jb = blockIdx.x / per_job, rem = blockIdx.x % per_job;
+  const int mt = rem / a.nut, wg = rem % a.nut;       // the workgroups of one batch-row tile are neighbours in the flag array
   const FwdJob J = a.job[jb];
   const int B = a.B, H = a.H, T = a.T;
   constexpr int U = 4 * NT;
-  const int u0 = wg * U;
+  const int u0 = wg * U, b0 = mt * 16 * MT;
   const int kbeg = wave * (KQ * 16);
   // recurrent weights: registers for the whole sequence
   f32x4 bv[NT][KQ];
@@ -113,9 +130,9 @@ __global__ __launch_bounds__(1024) void lstm_seq_fwd_kernel(const FwdArgs a) {
 #pragma unroll
     for (int q = 0; q < KQ; ++q) bv[nt][q] = *reinterpret_cast<const f32x4*>(wrow + kbeg + q * 16 + fq * 4);
   }
-  // the cell of (b, unit j) belongs to thread b * U + j for all steps
-  const bool cell = t < B * U;
-  const int cb = t / U, cj = t % U, cu = u0 + cj;
+  // the cell of (row r, unit j) of the tile belongs to thread r * U + j for all steps
+  const int cr = t / U, cb = b0 + cr, cj = t % U, cu = u0 + cj;
+  const bool cell = t < 16 * MT * U && cb < B;
   float bias4[4] = {0.f, 0.f, 0.f, 0.f};
   if (cell && J.b_hh)
 #pragma unroll
@@ -127,7 +144,7 @@ __global__ __launch_bounds__(1024) void lstm_seq_fwd_kernel(const FwdArgs a) {
   }
   int aoff[MT];
 #pragma unroll
-  for (int i = 0; i < MT; ++i) aoff[i] = min(i * 16 + fr, B - 1) * H + kbeg + fq * 4;
+  for (int i = 0; i < MT; ++i) aoff[i] = min(b0 + i * 16 + fr, B - 1) * H + kbeg + fq * 4;
 
   for (int s = 0; s < T; ++s) {
     const int tt = J.reverse ? T - 1 - s : s;
@@ -148,7 +165,7 @@ __global__ __launch_bounds__(1024) void lstm_seq_fwd_kernel(const FwdArgs a) {
       for (int nt = 0; nt < NT; ++nt) acc[i][nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
     if (s > 0) {
       if (wave == 0) {
-        const bool ok = PROBE(4) ? true : wait_flags(a.ws, jb * a.nwg, a.nwg, (unsigned)s, lane, 0x100u + jb);
+        const bool ok = PROBE(4) ? true : wait_flags(a.ws, jb * per_job + mt * a.nut, a.nut, (unsigned)s, lane, 0x100u + jb);
         if (lane == 0) go = ok ? 1 : 0;
         if (a.acq == 1) {
           __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
@@ -188,7 +205,7 @@ __global__ __launch_bounds__(1024) void lstm_seq_fwd_kernel(const FwdArgs a) {
       for (int g = 0; g < 4; ++g) {
         const int n = (cj >> 2) * 16 + g * 4 + (cj & 3);
         float sacc = 0.f;
-        for (int w = 0; w < NW; ++w) sacc += part[w][cb][n];
+        for (int w = 0; w < NW; ++w) sacc += part[w][cr][n];
         g4[g] = sacc + gxv[g] + bias4[g];
       }
       const float ig = sigm_(g4[0]), fg = sigm_(g4[1]), gg = tanhf(g4[2]), og = sigm_(g4[3]);
@@ -198,11 +215,18 @@ __global__ __launch_bounds__(1024) void lstm_seq_fwd_kernel(const FwdArgs a) {
       if (!lv) { cn = c_reg; hn = h_reg; yo = 0.f; }
       c_reg = cn; h_reg = hn;
       const long idx = ((long)tt * B + cb) * H + cu;
-      __hip_atomic_store(J.h_out + idx, hn, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);      // sc1: the payload of the hand-off
-      J.c_out[idx] = cn;
-      if (J.y) J.y[idx] = yo;
-      float* ab = J.acts + ((long)tt * B + cb) * 4 * H + cu;
-      ab[0] = ig; ab[H] = fg; ab[2 * H] = gg; ab[3 * H] = og;
+      const f32x4 hv = quad_gather(hn), cv = quad_gather(cn), yv = quad_gather(yo);
+      const f32x4 iv = quad_gather(ig), fv = quad_gather(fg), gv = quad_gather(gg), ov = quad_gather(og);
+      if ((cj & 3) == 0) {
+        st_sc1_x4(J.h_out + idx, hv);                       // sc1: the payload of the hand-off
+        *reinterpret_cast<f32x4*>(J.c_out + idx) = cv;
+        if (J.y) *reinterpret_cast<f32x4*>(J.y + idx) = yv;
+        float* ab = J.acts + ((long)tt * B + cb) * 4 * H + cu;
+        *reinterpret_cast<f32x4*>(ab) = iv;
+        *reinterpret_cast<f32x4*>(ab + H) = fv;
+        *reinterpret_cast<f32x4*>(ab + 2 * H) = gv;
+        *reinterpret_cast<f32x4*>(ab + 3 * H) = ov;
+      }
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // every storing wave drains before the barrier
     __syncthreads();                                         // also: part[] free for the next step
@@ -320,7 +344,10 @@ __global__ __launch_bounds__(1024) void lstm_seq_bwd_kernel(const BwdArgs a) {
         pass_reg = 0.f;
       }
 #pragma unroll
-      for (int g = 0; g < 4; ++g) __hip_atomic_store(db + g * H, d4[g], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // sc1
+      for (int g = 0; g < 4; ++g) {
+        const f32x4 dv = quad_gather(d4[g]);
+        if ((t & 3) == 0) st_sc1_x4(db + g * H, dv);        // sc1: the payload of the hand-off
+      }
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
@@ -380,13 +407,19 @@ int eamd_lstm_seq_fwd(const eamd_lstm_seq_fwd_t* jobs, int njobs, int T, int B, 
   if (!kq) return EAMD_EUNSUPPORTED;
   const int nw = H / (16 * kq);
   const int cus = device_cus();
-  int nt = 0;
-  for (int c : {1, 2})
-    if (njobs * (H / (4 * c)) <= cus && H % (4 * c) == 0) { nt = c; break; }
-  if (!nt || B * 4 * nt > 64 * nw) return EAMD_EUNSUPPORTED;
-  const int mt = B <= 16 ? 1 : B <= 32 ? 2 : 4;
-  const int nwg = H / (4 * nt);
-  if (njobs * nwg > 960) return EAMD_EUNSUPPORTED;
+  // (rows, units) per workgroup: as many workgroups as there are CUs (the MFMA work spreads), then as few rows as
+  // possible (a workgroup reads its rows of h every step: 64 KB for 16 rows at H = 1024), then as many units
+  int mt = 0, nt = 0, best = 0;
+  for (int m : {1, 2, 4})
+    for (int n : {4, 2, 1}) {
+      if (H % (4 * n) != 0 || 16 * m * 4 * n > 64 * nw) continue;
+      if (m > 1 && 16 * (m / 2) >= B) continue;                     // tiles of rows that do not exist
+      const int wgs = njobs * (H / (4 * n)) * ((B + 16 * m - 1) / (16 * m));
+      if (wgs > cus || wgs > 960 || H / (4 * n) > 256) continue;
+      if (wgs > best) { best = wgs; mt = m; nt = n; }
+    }
+  if (!best) return EAMD_EUNSUPPORTED;
+  const int nut = H / (4 * nt), nmt = (B + 16 * mt - 1) / (16 * mt);
   hipStream_t s = (hipStream_t)stream;
   if (eamd_zero_async(sync_ws, SYNC_BYTES, s) != EAMD_OK) return EAMD_EINVAL;
   FwdArgs a;
@@ -394,8 +427,8 @@ int eamd_lstm_seq_fwd(const eamd_lstm_seq_fwd_t* jobs, int njobs, int T, int B, 
     const eamd_lstm_seq_fwd_t& q = jobs[j < njobs ? j : 0];
     a.job[j] = FwdJob{q.gx, q.w_hh, q.b_hh, q.live, q.h_out, q.c_out, q.y, q.acts, q.reverse};
   }
-  a.T = T; a.B = B; a.H = H; a.nwg = nwg; a.ws = (unsigned*)sync_ws; a.acq = acq_mode(); a.probe = probe_bits();
-  const dim3 grid(njobs * nwg), block(64 * nw);
+  a.T = T; a.B = B; a.H = H; a.nut = nut; a.nmt = nmt; a.ws = (unsigned*)sync_ws; a.acq = acq_mode(); a.probe = probe_bits();
+  const dim3 grid(njobs * nut * nmt), block(64 * nw);
   const size_t lds = (size_t)nw * mt * 16 * (nt * 16 + 1) * sizeof(float);
 #define EAMD_LQF(MT_, NT_, KQ_)                                                                                          \
   do {                                                                                                                   \
@@ -409,7 +442,7 @@ int eamd_lstm_seq_fwd(const eamd_lstm_seq_fwd_t* jobs, int njobs, int T, int B, 
   } while (0)
 #define EAMD_LQF_N(MT_)                                                                                                  \
   do {                                                                                                                   \
-    if (nt == 1) EAMD_LQF_K(MT_, 1); else EAMD_LQF_K(MT_, 2);                                                            \
+    if (nt == 1) EAMD_LQF_K(MT_, 1); else if (nt == 2) EAMD_LQF_K(MT_, 2); else EAMD_LQF_K(MT_, 4);                      \
   } while (0)
   if (mt == 1) EAMD_LQF_N(1); else if (mt == 2) EAMD_LQF_N(2); else EAMD_LQF_N(4);
 #undef EAMD_LQF_N
