@@ -1471,7 +1471,7 @@ def lstm_seq_fwd(jobs, T, B, H):
     args = (arr, len(jobs), T, B, H, ptr(ws))
     if _rnn_record is not None:
         _rnn_record.append(("lstm_seq_fwd", (jobs, ws, arr), lambda sp, args=args: check(fn(*args, sp), "eamd_lstm_seq_fwd"),
-                            4 * len(jobs) * (4 * H * H + T * B * 9 * H)))
+                            4 * len(jobs) * (4 * H * H + T * B * 9 * H), 2.0 * len(jobs) * (T - 1) * B * 4 * H * H))
     check(fn(*args, stream_ptr()), "eamd_lstm_seq_fwd")
 
 
@@ -1485,7 +1485,7 @@ def lstm_seq_bwd(jobs, T, B, H):
     args = (arr, len(jobs), T, B, H, ptr(ws))
     if _rnn_record is not None:
         _rnn_record.append(("lstm_seq_bwd", (jobs, ws, arr), lambda sp, args=args: check(fn(*args, sp), "eamd_lstm_seq_bwd"),
-                            4 * len(jobs) * (4 * H * H + T * B * 11 * H)))
+                            4 * len(jobs) * (4 * H * H + T * B * 11 * H), 2.0 * len(jobs) * (T - 1) * B * 4 * H * H))
     check(fn(*args, stream_ptr()), "eamd_lstm_seq_bwd")
 
 

@@ -91,16 +91,32 @@ def run(name, model, xs, ilens, ys, steps=3, graph=True, dominant=None, quiet=Fa
         finally:
             ops._gemm_record = ops._rnn_record = None
         if dominant == "lstm" and rrec:
-            ms = _replay_ms([r[2] for r in rrec])
-            nbytes = float(sum(r[3] for r in rrec))
-            ach = nbytes / (ms * 1e-3) / 1e9
-            dom = dict(kernel="lstm_step_fwd_kernel / lstm_step_bwd_kernel: one launch per LSTM time step, recurrent weights + "
-                              "states from L2 / Infinity Cache (no HBM traffic: 16 MB per layer-direction stays resident)",
-                       launches_per_step=len(rrec), ms_per_step=round(ms, 3), us_per_launch=round(ms * 1e3 / len(rrec), 2),
-                       roofline=dict(bound="l2", achieved=round(ach, 1), peak=34500.0, unit="GB/s", frac=round(ach / 34500.0, 4),
-                                     bytes_per_launch=int(nbytes / len(rrec)),
-                                     note="bytes = W_hh + gate / state rows of the launch; peak = aggregate L2 bandwidth "
-                                          "(MI355X_MICROARCH.md); the launches are latency-bound (DESIGN.md section 4)"))
+            seq = [r for r in rrec if r[0].startswith("lstm_seq")]
+            if seq:      # the persistent whole-sequence launches (csrc/lstm_seq.hip): fp32 MFMA recurrences, one grid hand-off per time step
+                ms = _replay_ms([r[2] for r in seq])
+                flop = float(sum(r[4] for r in seq))
+                ach = flop / (ms * 1e-3) / 1e12
+                nsteps = sum(r[1][0][0][0].shape[0] if r[0] == "lstm_seq_fwd" else r[1][0][0][2].shape[0] for r in seq)
+                dom = dict(kernel="lstm_seq_fwd_kernel / lstm_seq_bwd_kernel: all time steps of both directions of a BLSTM layer in one "
+                                  "persistent launch (recurrent weights in registers, h_t / dgates_t handed between workgroups per step)",
+                           launches_per_step=len(seq), ms_per_step=round(ms, 3), time_steps=int(nsteps),
+                           us_per_time_step=round(ms * 1e3 / nsteps, 2),
+                           roofline=dict(bound="mfma", achieved=round(ach, 2), peak=157.3, unit="TFLOP/s", frac=round(ach / 157.3, 4),
+                                         flop_per_step=flop,
+                                         note="fp32 MFMA (v_mfma_f32_16x16x4_f32) in both precision modes; the rest of a time step "
+                                              "is the grid-wide hand-off of h_t / dgates_t (DESIGN.md section 4)"),
+                           other_recurrent_launches=len(rrec) - len(seq))
+            else:
+                ms = _replay_ms([r[2] for r in rrec])
+                nbytes = float(sum(r[3] for r in rrec))
+                ach = nbytes / (ms * 1e-3) / 1e9
+                dom = dict(kernel="lstm_step_fwd_kernel / lstm_step_bwd_kernel: one launch per LSTM time step, recurrent weights + "
+                                  "states from L2 / Infinity Cache (no HBM traffic: 16 MB per layer-direction stays resident)",
+                           launches_per_step=len(rrec), ms_per_step=round(ms, 3), us_per_launch=round(ms * 1e3 / len(rrec), 2),
+                           roofline=dict(bound="l2", achieved=round(ach, 1), peak=34500.0, unit="GB/s", frac=round(ach / 34500.0, 4),
+                                         bytes_per_launch=int(nbytes / len(rrec)),
+                                         note="bytes = W_hh + gate / state rows of the launch; peak = aggregate L2 bandwidth "
+                                              "(MI355X_MICROARCH.md); the launches are latency-bound (DESIGN.md section 4)"))
         elif isinstance(dominant, tuple) and dominant[0] == "gemm":
             Vv = dominant[1]
             sel = [r for r in grec if r[0] is not None and not isinstance(r[0], dict) and Vv in (r[0].M, r[0].N, r[0].K)]
