@@ -433,6 +433,366 @@ __global__ __launch_bounds__(256, NKT > 16 ? 1 : 2) void attn_f32_bwd_q_kernel(c
   }
 }
 
+// =====================================================================================================================
+// Rows of more than 512 keys (up to ATT_LONG_MAXK).  The kernels above keep a query block's whole score row in registers
+// (S[NKT]) and a V / K panel of all keys in LDS; that stops at 512 keys.  The long-row forms keep the structure - the
+// score matrix X[query][key] of a query block lives in LDS for the whole kernel, so the legacy rel_shift stays the same
+// one-to-one scatter of the bd tiles - but a workgroup takes 16 queries (X = 16 x (T2 + 4) floats: 131 KB at 2048 keys)
+// and ALL FOUR phases are split over the keys: wave w owns key tiles w, w + 4, w + 8, ... in the score products, in the
+// softmax (row maxima / sums meet through 128 floats of LDS) and in the product with V (K), whose 16-key tiles each wave
+// stages in a private 4 KB LDS buffer; the four partial context (dq) tiles are summed through LDS at the end.  The
+// softmax walks X three times (max, exp + sum, normalise) instead of holding the row in registers.
+// Per workgroup K, V and the positions are read once (768 KB at 1024 keys) for 16 queries: four times the L2 traffic of
+// the 64-query kernels per query, which is what the LDS budget allows.
+constexpr int ATT_LONG_MAXK = 2048;
+constexpr int LQ = 16;                                      // queries per workgroup
+
+// element access for the two storage types of the long-row kernels: float (fp32 mode) and bf16 bits (bf16-operand mode:
+// same kernels, operands widened on load, fp32 MFMA; P / dS / dbd / ctx rounded to bf16 on store)
+typedef unsigned short bfbits;
+__device__ __forceinline__ float bf2f_(unsigned short b) { return __uint_as_float((unsigned)b << 16); }
+__device__ __forceinline__ float4 ld4(const float* p) { return *reinterpret_cast<const float4*>(p); }
+__device__ __forceinline__ float4 ld4(const bfbits* p) {
+  const uint2 u = *reinterpret_cast<const uint2*>(p);
+  return make_float4(bf2f_(u.x & 0xffffu), bf2f_(u.x >> 16), bf2f_(u.y & 0xffffu), bf2f_(u.y >> 16));
+}
+__device__ __forceinline__ void st4(float* p, float4 v) { *reinterpret_cast<float4*>(p) = v; }
+__device__ __forceinline__ void st4(bfbits* p, float4 v) {
+  uint2 u;
+  u.x = (unsigned)eamd_f2bf(v.x) | ((unsigned)eamd_f2bf(v.y) << 16);
+  u.y = (unsigned)eamd_f2bf(v.z) | ((unsigned)eamd_f2bf(v.w) << 16);
+  *reinterpret_cast<uint2*>(p) = u;
+}
+__device__ __forceinline__ void st1(float* p, float v) { *p = v; }
+__device__ __forceinline__ void st1(bfbits* p, float v) { *p = eamd_f2bf(v); }
+__device__ __forceinline__ float rnd(const float*, float v) { return v; }                      // value as the storage type keeps it
+__device__ __forceinline__ float rnd(const bfbits*, float v) { return bf2f_(eamd_f2bf(v)); }
+template <typename T>
+__device__ __forceinline__ void load_frag_t(const T* row, int fq, float4 (&f)[4]) {
+#pragma unroll
+  for (int j = 0; j < 4; ++j) f[j] = ld4(row + 16 * j + 4 * fq);
+}
+
+// stage one 16-key tile (rows key0 .. key0 + 15 of `src`, clamped to T2 - 1) into this wave's [16][PLD] LDS buffer
+template <typename T>
+__device__ __forceinline__ void tile_load(const T* src, long ld, int key0, int T2, int lane, float4 (&r)[4]) {
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    const int c = lane + 64 * q, row = c >> 4, c4 = c & 15;
+    r[q] = ld4(src + (long)min(key0 + row, T2 - 1) * ld + c4 * 4);
+    if (key0 + row >= T2) r[q] = make_float4(0.f, 0.f, 0.f, 0.f);
+  }
+}
+__device__ __forceinline__ void tile_store(const float4 (&r)[4], float* dst, int lane) {
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    const int c = lane + 64 * q, row = c >> 4, c4 = c & 15;
+    *reinterpret_cast<float4*>(&dst[row * PLD + c4 * 4]) = r[q];
+  }
+}
+// C^T[channel][query] += tile^T[channel][key] G^T[key][query] for one 16-key tile, G in the accumulator layout
+__device__ __forceinline__ void tile_product(const float* tile, const f32x4& G, int fr, int fq, f32x4 (&C)[4]) {
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    const float* row = &tile[(4 * fq + r) * PLD + fr];
+#pragma unroll
+    for (int dt = 0; dt < 4; ++dt) C[dt] = __builtin_amdgcn_mfma_f32_16x16x4f32(row[dt * 16], G[r], C[dt], 0, 0, 0);
+  }
+}
+// sum of the four waves' C^T tiles -> out[query][64 channels] (16-byte stores); `scr` = 4 x [64][17] floats
+template <typename T>
+__device__ __forceinline__ void reduce_store_ct(const f32x4 (&C)[4], float* scr, int wave, int fr, int fq, int t, T* out,
+                                                long ld, int nq) {
+#pragma unroll
+  for (int dt = 0; dt < 4; ++dt)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) scr[(wave * 64 + dt * 16 + fq * 4 + r) * 17 + fr] = C[dt][r];
+  __syncthreads();
+  const int q = t >> 4, c4 = (t & 15) * 4;
+  if (q < nq) {
+    float o[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      float v = 0.f;
+#pragma unroll
+      for (int w = 0; w < 4; ++w) v += scr[(w * 64 + c4 + e) * 17 + q];
+      o[e] = v;
+    }
+    st4(out + (long)q * ld + c4, make_float4(o[0], o[1], o[2], o[3]));
+  }
+}
+
+template <typename T, bool REL>
+__global__ __launch_bounds__(256) void attn_fwd_long_kernel(const AttnF32Args a, const int nkt) {
+  const T* const a_qu = reinterpret_cast<const T*>(a.qu); const T* const a_qv = reinterpret_cast<const T*>(a.qv);
+  const T* const a_k = reinterpret_cast<const T*>(a.k); const T* const a_v = reinterpret_cast<const T*>(a.v);
+  const T* const a_pos = reinterpret_cast<const T*>(a.pos);
+  T* const a_P = reinterpret_cast<T*>(a.P); T* const a_Pd = reinterpret_cast<T*>(a.Pd); T* const a_ctx = reinterpret_cast<T*>(a.ctx);
+  extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+  const int XLD = nkt * 16 + 4;
+  const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+  const int fr = lane & 15, fq = lane >> 4;
+  const int xcd = blockIdx.x & 7, jb = blockIdx.x >> 3;
+  const int z = (jb / a.nqb) * 8 + xcd;
+  const bool live = z < a.B * a.H;
+  const int zz = live ? z : 0;
+  const int h = zz / a.B, b = zz % a.B;
+  const int T1 = a.T1, T2 = a.T2;
+  const int r0w = min((jb % a.nqb) * LQ, T1 - 1);
+  const int nq = min(LQ, T1 - r0w);
+  const int qi = min(r0w + fr, T1 - 1);
+  const bool qok = live && fr < nq;
+  float* X = reinterpret_cast<float*>(smem_raw);
+  float* Tw = X + LQ * XLD + wave * 16 * PLD;           // this wave's tile buffer
+  float* red = X + LQ * XLD + 4 * 16 * PLD;             // [2][4][LQ]
+  const int Ts = (REL && a.tshift) ? min(max(a.tshift[0], 1), T2) : T2;
+  if (REL) {
+    if (Ts < T2) {
+      for (int e = t; e < LQ * XLD; e += 256) X[e] = 0.f;
+      __syncthreads();
+    }
+    float4 qf[4];
+    load_frag_t(a_qv + ((long)b * T1 + r0w + min(fr, nq - 1)) * a.ldqv + h * ATT_DK, fq, qf);
+    if (t < LQ && r0w + t + 1 < T2) X[t * XLD + r0w + t + 1] = 0.f;
+    for (int mt = wave; mt < nkt; mt += 4) {
+      float4 pf[4];
+      load_frag_t(a_pos + (long)min(mt * 16 + fr, T2 - 1) * a.ldpos + h * ATT_DK, fq, pf);
+      const f32x4 c = dot_tile(pf, qf, (f32x4){0.f, 0.f, 0.f, 0.f});     // c[r] = bd[query fr][m = 16 mt + 4 fq + r]
+      const int i = r0w + fr, lim = Ts - 1 - i;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int m = mt * 16 + 4 * fq + r;
+        const int row = m >= lim ? fr : fr - 1, j = m >= lim ? m - lim : m + i + 1;
+        if (m < Ts && i < Ts && fr < nq && row >= 0) X[row * XLD + j] = c[r];
+      }
+    }
+    const int i16 = r0w + LQ;                         // first query of the next workgroup: its low positions feed query r0w + 15
+    if (live && i16 < Ts) {
+      const T* qr = a_qv + ((long)b * T1 + i16) * a.ldqv + h * ATT_DK;
+      for (int m = t; m <= Ts - 2 - i16; m += 256) {
+        const T* pr = a_pos + (long)m * a.ldpos + h * ATT_DK;
+        float s = 0.f;
+#pragma unroll
+        for (int j = 0; j < 16; ++j) {
+          const float4 x = ld4(qr + 4 * j), y = ld4(pr + 4 * j);
+          s += x.x * y.x + x.y * y.y + x.z * y.z + x.w * y.w;
+        }
+        X[(LQ - 1) * XLD + m + i16 + 1] = s;
+      }
+    }
+    __syncthreads();
+  }
+  // ---- ac on top, then scale + mask, in place; row maxima ----
+  const unsigned char* mr = a.mask ? a.mask + (long)b * a.mb + (long)qi * a.mi : nullptr;
+  float mx = -INFINITY;
+  {
+    float4 qf[4];
+    load_frag_t(a_qu + ((long)b * T1 + r0w + min(fr, nq - 1)) * a.ldq + h * ATT_DK, fq, qf);
+    const T* keys = a_k + (long)b * T2 * a.ldk + h * ATT_DK;
+    for (int kt = wave; kt < nkt; kt += 4) {
+      float4 kf[4];
+      load_frag_t(keys + (long)min(kt * 16 + fr, T2 - 1) * a.ldk, fq, kf);
+      float4* xp = reinterpret_cast<float4*>(&X[fr * XLD + kt * 16 + 4 * fq]);
+      f32x4 c = (f32x4){0.f, 0.f, 0.f, 0.f};
+      if (REL) { const float4 o = *xp; c = (f32x4){o.x, o.y, o.z, o.w}; }
+      c = dot_tile(kf, qf, c);                        // c[r]: key 16 kt + 4 fq + r, query fr
+      const int j0 = kt * 16 + fq * 4;
+      unsigned mk = 0x01010101u;
+      if (mr) mk = mr[min(j0, T2 - 1)] | (mr[min(j0 + 1, T2 - 1)] << 8) | (mr[min(j0 + 2, T2 - 1)] << 16) | (mr[min(j0 + 3, T2 - 1)] << 24);
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        float x = c[r] * a.scale;
+        if (j0 + r >= T2 || ((mk >> (8 * r)) & 0xffu) == 0u) x = -INFINITY;
+        c[r] = x;
+        mx = fmaxf(mx, x);
+      }
+      *xp = make_float4(c[0], c[1], c[2], c[3]);
+    }
+  }
+  mx = xmax16_32(mx);
+  if (fq == 0) red[wave * LQ + fr] = mx;
+  __syncthreads();
+  mx = fmaxf(fmaxf(red[fr], red[LQ + fr]), fmaxf(red[2 * LQ + fr], red[3 * LQ + fr]));
+  const bool dead = mx == -INFINITY;                  // every key masked: zeros (softmax of min, then masked_fill(0))
+  float sum = 0.f;
+  for (int kt = wave; kt < nkt; kt += 4) {
+    float4* xp = reinterpret_cast<float4*>(&X[fr * XLD + kt * 16 + 4 * fq]);
+    float4 v = *xp;
+    v.x = dead ? 0.f : __expf(v.x - mx); v.y = dead ? 0.f : __expf(v.y - mx);
+    v.z = dead ? 0.f : __expf(v.z - mx); v.w = dead ? 0.f : __expf(v.w - mx);
+    sum += (v.x + v.y) + (v.z + v.w);
+    *xp = v;
+  }
+  sum = xsum16_32(sum);
+  if (fq == 0) red[4 * LQ + wave * LQ + fr] = sum;
+  __syncthreads();
+  sum = (red[4 * LQ + fr] + red[5 * LQ + fr]) + (red[6 * LQ + fr] + red[7 * LQ + fr]);
+  const float inv = dead ? 0.f : 1.f / sum;
+  // ---- probabilities out, context^T = V^T Pd^T over this wave's key tiles ----
+  const long pro = ((long)zz * T1 + qi) * a.ldp;
+  const bool drop = a.drop_p > 0.f;
+  const unsigned seed = drop ? eamd_drop_seed(a.drop_step, a.drop_salt) : 0u, thr = eamd_drop_thr16(a.drop_p);
+  const float dinv = eamd_drop_inv(thr);
+  const T* vs = a_v + (long)b * T2 * a.ldv + h * ATT_DK;
+  f32x4 C[4];
+#pragma unroll
+  for (int dt = 0; dt < 4; ++dt) C[dt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  float4 vreg[4];
+  if (wave < nkt) tile_load(vs, a.ldv, wave * 16, live ? T2 : 1, lane, vreg);
+  for (int kt = wave; kt < nkt; kt += 4) {
+    tile_store(vreg, Tw, lane);
+    if (kt + 4 < nkt) tile_load(vs, a.ldv, (kt + 4) * 16, live ? T2 : 1, lane, vreg);
+    const float4 e = *reinterpret_cast<const float4*>(&X[fr * XLD + kt * 16 + 4 * fq]);
+    f32x4 Pv = (f32x4){e.x * inv, e.y * inv, e.z * inv, e.w * inv};
+    const int j0 = kt * 16 + fq * 4;
+    if (qok && j0 < a.ldp) st4(a_P + pro + j0, make_float4(Pv[0], Pv[1], Pv[2], Pv[3]));
+    if (drop) {
+      bool kp[4];
+      eamd_drop_keep4(seed, (unsigned long long)(pro + min(j0, (int)a.ldp - 4)), thr, kp);
+#pragma unroll
+      for (int r = 0; r < 4; ++r) Pv[r] = kp[r] ? Pv[r] * dinv : 0.f;
+      if (qok && j0 < a.ldp) st4(a_Pd + pro + j0, make_float4(Pv[0], Pv[1], Pv[2], Pv[3]));
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) Pv[r] = rnd(a_P, Pv[r]);      // the context is built from the probabilities backward will read
+    tile_product(Tw, Pv, fr, fq, C);
+  }
+  __syncthreads();                                    // X is dead: its head becomes the reduction scratch
+  reduce_store_ct(C, X, wave, fr, fq, t, a_ctx + ((long)b * T1 + r0w) * a.ldc + h * ATT_DK, a.ldc, live ? nq : 0);
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void attn_bwd_q_long_kernel(const AttnF32BwdArgs a, const int nkt, const int dq_bf16) {
+  const T* const a_dctx = reinterpret_cast<const T*>(a.dctx); const T* const a_k = reinterpret_cast<const T*>(a.k);
+  const T* const a_v = reinterpret_cast<const T*>(a.v); const T* const a_P = reinterpret_cast<const T*>(a.P);
+  T* const a_dS = reinterpret_cast<T*>(a.dS); T* const a_dbd = reinterpret_cast<T*>(a.dbd);
+  extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+  const int XLD = nkt * 16 + 4;
+  const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+  const int fr = lane & 15, fq = lane >> 4;
+  const int xcd = blockIdx.x & 7, jb = blockIdx.x >> 3;
+  const int z = (jb / a.nqb) * 8 + xcd;
+  const bool live = z < a.B * a.H;
+  const int zz = live ? z : 0;
+  const int h = zz / a.B, b = zz % a.B;
+  const int T1 = a.T1, T2 = a.T2;
+  const int Ts = (a.dbd && a.tshift) ? min(max(a.tshift[0], 1), T2) : T2;
+  const int r0w = min((jb % a.nqb) * LQ, T1 - 1);
+  const int nq = min(LQ, T1 - r0w);
+  const int qi = min(r0w + fr, T1 - 1);
+  const bool qok = live && fr < nq;
+  float* X = reinterpret_cast<float*>(smem_raw);
+  float* Tw = X + LQ * XLD + wave * 16 * PLD;
+  float* red = X + LQ * XLD + 4 * 16 * PLD;
+  const long zo = (long)zz * T1 * a.ldp;
+  const long pro = zo + (long)qi * a.ldp;
+  const bool drop = a.drop_p > 0.f;
+  const unsigned seed = drop ? eamd_drop_seed(a.drop_step, a.drop_salt) : 0u, thr = eamd_drop_thr16(a.drop_p);
+  const float dinv = eamd_drop_inv(thr);
+  // ---- dP tiles (gradient of the dropped probabilities -> of P), row sums of P dP ----
+  float s = 0.f;
+  {
+    float4 df[4];
+    load_frag_t(a_dctx + ((long)b * T1 + r0w + min(fr, nq - 1)) * a.ldd + h * ATT_DK, fq, df);
+    const T* vs = a_v + (long)b * T2 * a.ldv + h * ATT_DK;
+    for (int kt = wave; kt < nkt; kt += 4) {
+      float4 vf[4];
+      load_frag_t(vs + (long)min(kt * 16 + fr, T2 - 1) * a.ldv, fq, vf);
+      f32x4 c = dot_tile(vf, df, (f32x4){0.f, 0.f, 0.f, 0.f});      // c[r]: key 16 kt + 4 fq + r, query fr
+      const int j0 = kt * 16 + fq * 4;
+      float4 pr = ld4(a_P + pro + min(j0, (int)a.ldp - 4));
+      if (j0 >= (int)a.ldp) pr = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (drop) {
+        bool kp[4];
+        eamd_drop_keep4(seed, (unsigned long long)(pro + min(j0, (int)a.ldp - 4)), thr, kp);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) c[r] = kp[r] ? c[r] * dinv : 0.f;
+      }
+      const float p4[4] = {pr.x, pr.y, pr.z, pr.w};
+#pragma unroll
+      for (int r = 0; r < 4; ++r) if (j0 + r < T2) s += p4[r] * c[r];
+      *reinterpret_cast<float4*>(&X[fr * XLD + kt * 16 + 4 * fq]) = make_float4(c[0], c[1], c[2], c[3]);
+    }
+  }
+  s = xsum16_32(s);
+  if (fq == 0) red[wave * LQ + fr] = s;
+  __syncthreads();
+  s = (red[fr] + red[LQ + fr]) + (red[2 * LQ + fr] + red[3 * LQ + fr]);
+  // ---- dS (+ the inverse rel_shift scatter dbd), dq^T = K^T dS^T over this wave's key tiles ----
+  const T* ks = a_k + (long)b * T2 * a.ldk + h * ATT_DK;
+  const int i = r0w + fr;
+  f32x4 C[4];
+#pragma unroll
+  for (int dt = 0; dt < 4; ++dt) C[dt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  float4 kreg[4];
+  if (wave < nkt) tile_load(ks, a.ldk, wave * 16, live ? T2 : 1, lane, kreg);
+  for (int kt = wave; kt < nkt; kt += 4) {
+    tile_store(kreg, Tw, lane);
+    if (kt + 4 < nkt) tile_load(ks, a.ldk, (kt + 4) * 16, live ? T2 : 1, lane, kreg);
+    const int j0 = kt * 16 + fq * 4;
+    float4 pr = ld4(a_P + pro + min(j0, (int)a.ldp - 4));
+    if (j0 >= (int)a.ldp) pr = make_float4(0.f, 0.f, 0.f, 0.f);
+    const float4 dp = *reinterpret_cast<const float4*>(&X[fr * XLD + kt * 16 + 4 * fq]);
+    const float p4[4] = {pr.x, pr.y, pr.z, pr.w}, d4[4] = {dp.x, dp.y, dp.z, dp.w};
+    f32x4 G;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int j = j0 + r;
+      const float g = j < T2 ? p4[r] * (d4[r] - s) * a.scale : 0.f;
+      G[r] = g;
+      if (a.dbd && qok) {
+        if (j < Ts && i < Ts) {
+          const int R = j <= i ? i : i + 1, c = j <= i ? Ts + j - i : j - i - 1;
+          if (c != 0) st1(a_dbd + zo + (long)R * a.ldp + (c - 1), g);
+        } else if (j < (int)a.ldp) {
+          st1(a_dbd + zo + (long)i * a.ldp + j, 0.f);
+        }
+      }
+    }
+    if (qok && j0 < (int)a.ldp) st4(a_dS + pro + j0, make_float4(G[0], G[1], G[2], G[3]));
+#pragma unroll
+    for (int r = 0; r < 4; ++r) G[r] = rnd(a_dS, G[r]);       // dq from the dS the key-side kernels will read
+    tile_product(Tw, G, fr, fq, C);
+  }
+  if (a.dbd && live && r0w == 0)                      // the head of row 0 the scatter never reaches
+    for (int f = 1 + t; f < Ts; f += 256) st1(a_dbd + zo + (f - 1), 0.f);
+  __syncthreads();
+  if (dq_bf16)
+    reduce_store_ct(C, X, wave, fr, fq, t, reinterpret_cast<bfbits*>(a.dq) + ((long)b * T1 + r0w) * a.ldo + h * ATT_DK, a.ldo, live ? nq : 0);
+  else
+    reduce_store_ct(C, X, wave, fr, fq, t, a.dq + ((long)b * T1 + r0w) * a.ldo + h * ATT_DK, a.ldo, live ? nq : 0);
+}
+
+template <typename T, bool REL>
+int launch_fwd_long(AttnF32Args a, hipStream_t stream) {
+  const int nkt = (a.T2 + 15) / 16;
+  const size_t smem = ((size_t)LQ * (nkt * 16 + 4) + 4 * 16 * PLD + 8 * LQ) * sizeof(float);
+  if (smem > 160 * 1024) return EAMD_EUNSUPPORTED;
+  static const hipError_t attr_err = hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_fwd_long_kernel<T, REL>),
+                                                         hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+  if (attr_err != hipSuccess) return (int)attr_err;
+  a.nqb = (a.T1 + LQ - 1) / LQ;
+  const int nz = (a.B * a.H + 7) / 8 * 8;
+  hipLaunchKernelGGL((attn_fwd_long_kernel<T, REL>), dim3((unsigned)(a.nqb * nz)), dim3(256), smem, stream, a, nkt);
+  EAMD_LAUNCH_CHECK();
+  return EAMD_OK;
+}
+
+template <typename T>
+int launch_bwd_long(AttnF32BwdArgs a, int dq_bf16, hipStream_t stream) {
+  const int nkt = (a.T2 + 15) / 16;
+  const size_t smem = ((size_t)LQ * (nkt * 16 + 4) + 4 * 16 * PLD + 8 * LQ) * sizeof(float);
+  if (smem > 160 * 1024) return EAMD_EUNSUPPORTED;
+  static const hipError_t attr_err = hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_bwd_q_long_kernel<T>),
+                                                         hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+  if (attr_err != hipSuccess) return (int)attr_err;
+  a.nqb = (a.T1 + LQ - 1) / LQ;
+  const int nz = (a.B * a.H + 7) / 8 * 8;
+  hipLaunchKernelGGL((attn_bwd_q_long_kernel<T>), dim3((unsigned)(a.nqb * nz)), dim3(256), smem, stream, a, nkt, dq_bf16);
+  EAMD_LAUNCH_CHECK();
+  return EAMD_OK;
+}
+
 template <bool REL, int NKT>
 int launch_fwd(const AttnF32Args& a, size_t smem, hipStream_t stream) {
   static const hipError_t attr_err = hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_f32_fwd_kernel<REL, NKT>),
@@ -460,6 +820,38 @@ bool al16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
 
 }  // namespace
 
+// bf16-operand mode, rows of 513 .. ATT_LONG_MAXK keys: called by eamd_attn_fwd / eamd_attn_bwd_q (attn_fused.hip), which
+// have validated the operands; pointers are bf16 tensors, leading dimensions in elements
+int eamd_attn_long_fwd_bf16(const void* qu, int64_t ldq, const void* qv, int64_t ldqv, const void* k, int64_t ldk, const void* v,
+                            int64_t ldv, const void* pos, int64_t ldpos, const unsigned char* mask, int64_t mb, int64_t mi,
+                            void* P, int64_t ldp, void* ctx, int64_t ldc, int B, int H, int T1, int T2, float scale, void* Pd,
+                            float drop_p, const uint64_t* drop_step, uint64_t drop_salt, const int32_t* shift_len, void* stream) {
+  if (T2 > ATT_LONG_MAXK || ldq % 4 || ldk % 4 || ldv % 4 || ldc % 4 || ldp % 4) return EAMD_EUNSUPPORTED;
+  AttnF32Args a;
+  a.qu = (const float*)qu; a.qv = (const float*)qv; a.k = (const float*)k; a.v = (const float*)v; a.pos = (const float*)pos;
+  a.mask = mask; a.P = (float*)P; a.ctx = (float*)ctx;
+  a.ldq = ldq; a.ldqv = ldqv; a.ldk = ldk; a.ldv = ldv; a.ldpos = ldpos; a.ldc = ldc; a.ldp = ldp; a.mb = mb; a.mi = mi;
+  a.B = B; a.H = H; a.T1 = T1; a.T2 = T2; a.nqb = 0; a.scale = scale;
+  a.Pd = (float*)Pd; a.drop_p = drop_p; a.drop_step = (const unsigned long long*)drop_step; a.drop_salt = drop_salt;
+  a.tshift = shift_len;
+  return pos ? launch_fwd_long<bfbits, true>(a, (hipStream_t)stream) : launch_fwd_long<bfbits, false>(a, (hipStream_t)stream);
+}
+
+int eamd_attn_long_bwd_q_bf16(const void* dctx, int64_t ldd, const void* k, int64_t ldk, const void* v, int64_t ldv, const void* P,
+                              int64_t ldp, void* dS, void* dbd, void* dq, int64_t ldo, int dq_is_bf16, int B, int H, int T1, int T2,
+                              float scale, float drop_p, const uint64_t* drop_step, uint64_t drop_salt, const int32_t* shift_len,
+                              void* stream) {
+  if (T2 > ATT_LONG_MAXK || ldd % 4 || ldk % 4 || ldv % 4 || ldp % 4 || ldo % 4) return EAMD_EUNSUPPORTED;
+  AttnF32BwdArgs a;
+  a.dctx = (const float*)dctx; a.k = (const float*)k; a.v = (const float*)v; a.P = (const float*)P;
+  a.dS = (float*)dS; a.dbd = (float*)dbd; a.dq = (float*)dq;
+  a.ldd = ldd; a.ldk = ldk; a.ldv = ldv; a.ldp = ldp; a.ldo = ldo;
+  a.B = B; a.H = H; a.T1 = T1; a.T2 = T2; a.nqb = 0; a.scale = scale;
+  a.drop_p = drop_p; a.drop_step = (const unsigned long long*)drop_step; a.drop_salt = drop_salt;
+  a.tshift = shift_len;
+  return launch_bwd_long<bfbits>(a, dq_is_bf16, (hipStream_t)stream);
+}
+
 extern "C" int eamd_attn_fwd_f32(const float* qu, int64_t ldq, const float* qv, int64_t ldqv, const float* k, int64_t ldk,
                                  const float* v, int64_t ldv, const float* pos, int64_t ldpos, const unsigned char* mask,
                                  int64_t mask_bstride, int64_t mask_qstride, float* P, int64_t ldp, float* ctx,
@@ -468,7 +860,7 @@ extern "C" int eamd_attn_fwd_f32(const float* qu, int64_t ldq, const float* qv, 
   if (!qu || !k || !v || !P || !ctx || B <= 0 || H <= 0 || T1 <= 0 || T2 <= 0) return EAMD_EINVAL;
   if (drop_p < 0.f || drop_p >= 1.f || (drop_p > 0.f && (!Pd || !drop_step || !al16(Pd)))) return EAMD_EINVAL;
   if ((pos == nullptr) != (qv == nullptr)) return EAMD_EINVAL;
-  if (dk != ATT_DK || T2 > ATT_MAXK || (pos && T1 != T2)) return EAMD_EUNSUPPORTED;
+  if (dk != ATT_DK || T2 > ATT_LONG_MAXK || (pos && T1 != T2)) return EAMD_EUNSUPPORTED;
   if (ldq % 4 || ldk % 4 || ldv % 4 || ldc % 4 || ldp % 4 || ldp < T2 || (pos && (ldqv % 4 || ldpos % 4)))
     return EAMD_EUNSUPPORTED;
   if (!al16(qu) || !al16(k) || !al16(v) || !al16(P) || !al16(ctx) || (pos && (!al16(qv) || !al16(pos))))
@@ -481,6 +873,7 @@ extern "C" int eamd_attn_fwd_f32(const float* qu, int64_t ldq, const float* qv, 
   a.B = B; a.H = H; a.T1 = T1; a.T2 = T2; a.nqb = (T1 + 63) / 64; a.scale = scale;
   a.Pd = Pd; a.drop_p = drop_p; a.drop_step = (const unsigned long long*)drop_step; a.drop_salt = drop_salt;
   a.tshift = shift_len;
+  if (T2 > ATT_MAXK) return pos ? launch_fwd_long<float, true>(a, (hipStream_t)stream) : launch_fwd_long<float, false>(a, (hipStream_t)stream);
   const int nkt = T2 <= 128 ? 8 : T2 <= 256 ? 16 : 32;               // key tiles of 16 the instantiation covers
   const size_t smem = (size_t)nkt * 16 * PLD * sizeof(float);        // V panel (the score matrix X is smaller)
   hipStream_t s = (hipStream_t)stream;
@@ -494,7 +887,7 @@ extern "C" int eamd_attn_bwd_q_f32(const float* dctx, int64_t ldd, const float* 
                                    uint64_t drop_salt, const int32_t* shift_len, void* stream) {
   if (!dctx || !k || !v || !P || !dS || !dq || B <= 0 || H <= 0 || T1 <= 0 || T2 <= 0) return EAMD_EINVAL;
   if (drop_p < 0.f || drop_p >= 1.f || (drop_p > 0.f && !drop_step)) return EAMD_EINVAL;
-  if (dk != ATT_DK || T2 > ATT_MAXK || (dbd && T1 != T2)) return EAMD_EUNSUPPORTED;
+  if (dk != ATT_DK || T2 > ATT_LONG_MAXK || (dbd && T1 != T2)) return EAMD_EUNSUPPORTED;
   if (ldd % 4 || ldk % 4 || ldv % 4 || ldp % 4 || ldp < T2 || ldo % 4) return EAMD_EUNSUPPORTED;
   if (!al16(dctx) || !al16(k) || !al16(v) || !al16(P) || !al16(dS) || !al16(dq)) return EAMD_EUNSUPPORTED;
   if ((long)B * H * ((T1 + 63) / 64) >= (1L << 28)) return EAMD_EUNSUPPORTED;
@@ -504,6 +897,7 @@ extern "C" int eamd_attn_bwd_q_f32(const float* dctx, int64_t ldd, const float* 
   a.B = B; a.H = H; a.T1 = T1; a.T2 = T2; a.nqb = (T1 + 63) / 64; a.scale = scale;
   a.drop_p = drop_p; a.drop_step = (const unsigned long long*)drop_step; a.drop_salt = drop_salt;
   a.tshift = shift_len;
+  if (T2 > ATT_MAXK) return launch_bwd_long<float>(a, 0, (hipStream_t)stream);
   return T2 <= 128 ? launch_bwd<8>(a, (hipStream_t)stream) : T2 <= 256 ? launch_bwd<16>(a, (hipStream_t)stream)
                                                                          : launch_bwd<32>(a, (hipStream_t)stream);
 }

@@ -594,6 +594,15 @@ bool al16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
 
 }  // namespace
 
+int eamd_attn_long_fwd_bf16(const void* qu, int64_t ldq, const void* qv, int64_t ldqv, const void* k, int64_t ldk, const void* v,
+                            int64_t ldv, const void* pos, int64_t ldpos, const unsigned char* mask, int64_t mb, int64_t mi,
+                            void* P, int64_t ldp, void* ctx, int64_t ldc, int B, int H, int T1, int T2, float scale, void* Pd,
+                            float drop_p, const uint64_t* drop_step, uint64_t drop_salt, const int32_t* shift_len, void* stream);   // attn_f32.hip
+int eamd_attn_long_bwd_q_bf16(const void* dctx, int64_t ldd, const void* k, int64_t ldk, const void* v, int64_t ldv, const void* P,
+                              int64_t ldp, void* dS, void* dbd, void* dq, int64_t ldo, int dq_is_bf16, int B, int H, int T1, int T2,
+                              float scale, float drop_p, const uint64_t* drop_step, uint64_t drop_salt, const int32_t* shift_len,
+                              void* stream);
+
 extern "C" int eamd_attn_fwd(const void* qu, int64_t ldq, const void* qv, int64_t ldqv, const void* k, int64_t ldk,
                              const void* v, int64_t ldv, const void* pos, int64_t ldpos, const unsigned char* mask,
                              int64_t mask_bstride, int64_t mask_qstride, void* P_bf16, int64_t ldp, void* ctx_bf16,
@@ -602,13 +611,16 @@ extern "C" int eamd_attn_fwd(const void* qu, int64_t ldq, const void* qv, int64_
   if (!qu || !k || !v || !P_bf16 || !ctx_bf16 || B <= 0 || H <= 0 || T1 <= 0 || T2 <= 0) return EAMD_EINVAL;
   if (drop_p < 0.f || drop_p >= 1.f || (drop_p > 0.f && (!Pd_bf16 || !drop_step || !al16(Pd_bf16)))) return EAMD_EINVAL;
   if ((pos == nullptr) != (qv == nullptr)) return EAMD_EINVAL;
-  if (dk != ATT_DK || T2 > ATT_MAXK || (pos && T1 != T2)) return EAMD_EUNSUPPORTED;
+  if (dk != ATT_DK || (pos && T1 != T2)) return EAMD_EUNSUPPORTED;
   if (ldq % 8 || ldk % 8 || ldv % 8 || ldc % 4 || ldp % 8 || ldp < T2 || (pos && (ldqv % 8 || ldpos % 8)))
     return EAMD_EUNSUPPORTED;
   if (!al16(qu) || !al16(k) || !al16(v) || !al16(P_bf16) || (reinterpret_cast<uintptr_t>(ctx_bf16) & 7) ||
       (pos && (!al16(qv) || !al16(pos))))
     return EAMD_EUNSUPPORTED;
-  if ((long)B * H * ((T1 + 63) / 64) >= (1L << 28)) return EAMD_EUNSUPPORTED;
+  if ((long)B * H * ((T1 + 15) / 16) >= (1L << 28)) return EAMD_EUNSUPPORTED;
+  if (T2 > ATT_MAXK)            // rows of 513 .. 2048 keys: the key-split long-row kernels (attn_f32.hip), operands widened on load
+    return eamd_attn_long_fwd_bf16(qu, ldq, qv, ldqv, k, ldk, v, ldv, pos, ldpos, mask, mask_bstride, mask_qstride, P_bf16, ldp,
+                                   ctx_bf16, ldc, B, H, T1, T2, scale, Pd_bf16, drop_p, drop_step, drop_salt, shift_len, stream);
   AttnArgs a;
   a.qu = (const bf16_t*)qu; a.qv = (const bf16_t*)qv; a.k = (const bf16_t*)k; a.v = (const bf16_t*)v;
   a.pos = (const bf16_t*)pos; a.mask = mask; a.P = (bf16_t*)P_bf16; a.ctx = (bf16_t*)ctx_bf16;
@@ -632,12 +644,15 @@ extern "C" int eamd_attn_bwd_q(const void* dctx, int64_t ldd, const void* k, int
                                const uint64_t* drop_step, uint64_t drop_salt, const int32_t* shift_len, void* stream) {
   if (!dctx || !k || !v || !P_bf16 || !dS_bf16 || !dq || B <= 0 || H <= 0 || T1 <= 0 || T2 <= 0) return EAMD_EINVAL;
   if (drop_p < 0.f || drop_p >= 1.f || (drop_p > 0.f && !drop_step)) return EAMD_EINVAL;
-  if (dk != ATT_DK || T2 > ATT_MAXK || (dbd_bf16 && T1 != T2)) return EAMD_EUNSUPPORTED;
+  if (dk != ATT_DK || (dbd_bf16 && T1 != T2)) return EAMD_EUNSUPPORTED;
   if (ldd % 8 || ldk % 8 || ldv % 8 || ldp % 8 || ldp < T2 || ldo % 4) return EAMD_EUNSUPPORTED;
   if (!al16(dctx) || !al16(k) || !al16(v) || !al16(P_bf16) || !al16(dS_bf16) ||
       (reinterpret_cast<uintptr_t>(dq) & (dq_is_bf16 ? 7 : 15)))
     return EAMD_EUNSUPPORTED;
-  if ((long)B * H * ((T1 + 63) / 64) >= (1L << 28)) return EAMD_EUNSUPPORTED;
+  if ((long)B * H * ((T1 + 15) / 16) >= (1L << 28)) return EAMD_EUNSUPPORTED;
+  if (T2 > ATT_MAXK)
+    return eamd_attn_long_bwd_q_bf16(dctx, ldd, k, ldk, v, ldv, P_bf16, ldp, dS_bf16, dbd_bf16, dq, ldo, dq_is_bf16, B, H, T1, T2,
+                                     scale, drop_p, drop_step, drop_salt, shift_len, stream);
   AttnBwdArgs a;
   a.dctx = (const bf16_t*)dctx; a.k = (const bf16_t*)k; a.v = (const bf16_t*)v; a.P = (const bf16_t*)P_bf16;
   a.dS = (bf16_t*)dS_bf16; a.dbd = (bf16_t*)dbd_bf16; a.dq = dq;

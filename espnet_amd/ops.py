@@ -788,7 +788,9 @@ F32_FUSED_ATTN = True   # fp32 mode: eamd_attn_fwd_f32 / eamd_attn_bwd_q_f32 (te
 
 def attn_fwd_supported(T1, T2, dk, rel):
     """shapes the fused attention forward (eamd_attn_fwd) covers; alignment is checked by the library"""
-    return (fast() or F32_FUSED_ATTN) and dk == 64 and T2 <= 512 and (not rel or T1 == T2)
+    if dk != 64 or (rel and T1 != T2):
+        return False
+    return (fast() or F32_FUSED_ATTN) and T2 <= 2048          # rows of 513 .. 2048 keys: the key-split long-row kernels (attn_f32.hip)
 
 
 def attn_fwd(qu, qv, k, v, pos, mask, B, T1, T2, H, dk, ldp, scale, drop=None, shift_len=None):

@@ -226,7 +226,8 @@ int eamd_softmax_fwd(const float* ac, const float* bd, const unsigned char* mask
 int eamd_softmax_bwd(const float* P, const void* P_bf16, float* dP, float* dbd, void* dS_bf16, void* dbd_bf16,
                      int nblocks, int T1, int T2, int64_t ld, float scale, void* stream);
 
-/* Fused attention forward (bf16 activations, d_k = 64, T2 <= 512; rows of more than 256 keys run at one workgroup per CU): P = softmax(mask(scale * (qu k^T + rel_shift(qv pos^T))))
+/* Fused attention forward (bf16 activations, d_k = 64, T2 <= 2048; rows of more than 256 keys run at one workgroup per CU,
+ * rows of 513 .. 2048 keys on the 16-query long-row kernels of attn_f32.hip with the operands widened on load): P = softmax(mask(scale * (qu k^T + rel_shift(qv pos^T))))
  * and ctx = P v in one launch; the fp32 scores stay on chip.  reference: transformer/attention.py:63-114 (forward_attention,
  * MultiHeadedAttention.forward), :141-206 (RelPositionMultiHeadedAttention).  All operands are bf16 with heads side by side:
  * element (b, t, h, d) of qu at qu[(b*T1 + t)*ldq + h*64 + d] (k, v: T2 rows per batch; pos: (m, h, d) at pos[m*ldpos + h*64 + d],
@@ -259,7 +260,7 @@ int eamd_attn_bwd_q(const void* dctx, int64_t ldd, const void* k, int64_t ldk, c
                     uint64_t drop_salt, const int32_t* shift_len, void* stream);   /* drop_*: the forward's attention dropout (dP <- mask * dP / (1 - p)) */
 
 /* fp32 twins of eamd_attn_fwd / eamd_attn_bwd_q (the reference's precision; v_mfma_f32_16x16x4_f32): same operand
- * layouts, limits (d_k = 64, T2 <= 512, T1 == T2 with relative positions) and results, every tensor fp32: P, dS, dbd
+ * layouts, limits (d_k = 64, T2 <= 2048 - 513 .. 2048 keys on the long-row kernels -, T1 == T2 with relative positions) and results, every tensor fp32: P, dS, dbd
  * [H][B][T1][ldp] (ldp % 4 == 0, pad columns zeroed), ctx / dq (b, t, h, d).  Row strides are multiples of 4 floats and
  * base pointers 16-byte aligned, else EAMD_EUNSUPPORTED (callers then run the GEMM / eamd_softmax_* path). */
 int eamd_attn_fwd_f32(const float* qu, int64_t ldq, const float* qv, int64_t ldqv, const float* k, int64_t ldk,

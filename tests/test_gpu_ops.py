@@ -1229,6 +1229,80 @@ def test_attention_fused_vs_oracle(ops, oracle, case, prec):
         espnet_amd.set_precision("fp32")
 
 
+@pytest.mark.parametrize("case", [
+    dict(B=2, T1=999, T2=999, rel=True, mask="len"), dict(B=1, T1=1500, T2=1500, rel=True, mask=None),
+    dict(B=2, T1=101, T2=999, rel=False, mask="len"), dict(B=2, T1=600, T2=600, rel=True, mask="dead"),
+    dict(B=1, T1=530, T2=530, rel=False, mask="causal"), dict(B=1, T1=2048, T2=2048, rel=True, mask="len")])
+@pytest.mark.parametrize("prec", ["fp32", "bf16"])
+def test_attention_fused_long_rows_vs_oracle(ops, oracle, case, prec):
+    """Rows of 513 .. 2048 keys stay on the fused path in both precision modes (attn_fwd_long_kernel / attn_bwd_q_long_kernel:
+    16 queries per workgroup, every phase split over the keys; bf16 operands are widened on load): probabilities, context
+    and every gradient against the oracle in float64, the legacy rel_shift at T1 = T2 = 999 / 1500 / 2048, cross-attention
+    101 x 999, a causal mask and a fully masked utterance.  Tolerances as test_attention_fused_vs_oracle.
+    reference: transformer/attention.py:63-92, 141-206."""
+    import espnet_amd
+    from espnet_amd import functional as F_
+    espnet_amd.set_precision(prec)
+    try:
+        _long_attention_case(ops, oracle, case, prec, F_)
+    finally:
+        espnet_amd.set_precision("fp32")
+
+
+def _long_attention_case(ops, oracle, case, prec, F_):
+    tol_f, tol_g = (4e-3, 8e-3) if prec == "bf16" else (2e-6, 1e-5)
+    B, T1, T2, rel, mk = case["B"], case["T1"], case["T2"], case["rel"], case["mask"]
+    H, dk = 4, 64
+    D = H * dk
+    g = torch.Generator().manual_seed(T1 * 11 + T2)
+    bf = lambda *s: (0.5 * torch.randn(*s, generator=g)).to(torch.bfloat16).to(ops.act_dtype()).to(DEV)
+    qu, k, v = bf(B * T1, D), bf(B * T2, D), bf(B * T2, D)
+    qv = bf(B * T1, D) if rel else None
+    p = bf(T2, D) if rel else None
+    mask = None
+    if mk == "len":
+        lens = torch.linspace(T2, max(1, T2 // 2), B).long()
+        mask = (torch.arange(T2)[None, :] < lens[:, None]).to(torch.uint8).view(B, 1, T2).contiguous().to(DEV)
+    elif mk == "causal":
+        mask = torch.tril(torch.ones(T1, T2)).to(torch.uint8).expand(B, T1, T2).contiguous().to(DEV)
+    elif mk == "dead":
+        mask = torch.ones(B, 1, T2, dtype=torch.uint8)
+        mask[1] = 0
+        mask[0, 0, T2 // 2:] = 0
+        mask = mask.to(DEV)
+    assert ops.attn_fwd_supported(T1, T2, dk, rel)
+    fused = F_.attn_fwd_fused(qu, qv, k, v, p, mask, B, T1, T2, H, dk)
+    assert fused is not None, "eamd_attn_fwd_f32 declined a long row"
+    P1, _Pd, c1 = fused
+    dctx = bf(B * T1, D)
+    took, orig = [], ops.attn_bwd_q
+
+    def spy(*a_, **k_):
+        took.append(orig(*a_, **k_))
+        return took[-1]
+    ops.attn_bwd_q = spy
+    try:
+        dqu, dqv, dkk, dvv, dpos = F_.attn_core_bwd(dctx, P1, qu, qv, k, v, p, B, T1, T2, H, dk)
+    finally:
+        ops.attn_bwd_q = orig
+    assert took == [True], "the query-side backward left the fused path"
+    attn, ctx, gq, gqv, gk, gv, gp = _oracle_attention(oracle, qu, qv, k, v, p, mask, dctx, B, T1, T2, H, dk)
+    ldp = F_._ldp(T2)
+    Pv = P1.view(H, B, T1, ldp).float().permute(1, 0, 2, 3)
+    report("long attn P vs oracle %s" % case, Pv[..., :T2], attn, tol_f)
+    assert bool((Pv[..., T2:] == 0).all())
+    report("long attn ctx vs oracle %s" % case, c1.float(), ctx, tol_f)
+    if mk == "dead":
+        assert bool((Pv[1] == 0).all()) and bool((c1.view(B, T1, D)[1] == 0).all())
+    r2 = lambda t, T: t.reshape(B * T, D)
+    report("long attn dq(u) vs oracle %s" % case, dqu.float(), r2(gq, T1), tol_g)
+    report("long attn dk vs oracle %s" % case, dkk.float(), r2(gk, T2), tol_g)
+    report("long attn dv vs oracle %s" % case, dvv.float(), r2(gv, T2), tol_g)
+    if rel:
+        report("long attn dq(v) vs oracle %s" % case, dqv.float(), r2(gqv, T1), tol_g)
+        report("long attn dpos vs oracle %s" % case, dpos.float().view(T2, D), gp.reshape(T2, D), tol_g)
+
+
 @pytest.mark.parametrize("shape", [(7968, 256, 768), (333, 64, 64), (70, 320, 320), (5, 512, 1024)])
 def test_add_cast_colsum2(ops, shape):
     """one pass: out = bf16(a + b) into a column block, both column sums accumulated"""
