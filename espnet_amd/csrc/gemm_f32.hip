@@ -54,7 +54,7 @@ __device__ __forceinline__ float4 mask4(float4 v, int nv) {
 
 // One workgroup's share of a problem: `bid` of `nblk` workgroups (tile x split-K slice), batch index `zb`.
 // gemm_f32_kernel runs it on a launch of its own; gemm_f32_group_kernel looks the problem up in a device table.
-template <int BM, int BN, bool TA, bool TB, bool GAT, bool ACT, bool ROWEPI = false>
+template <int BM, int BN, bool TA, bool TB, bool GAT, bool ACT, bool ROWEPI = false, bool NOPAD = false>
 __device__ __forceinline__ void gemm_f32_body(const eamd_gemm_t& p, const int bid, const int nblk, const int zb) {
   constexpr int WM = BM / 2, WN = BN / 2;
   constexpr int MT = WM / 16, NTL = WN / 16;
@@ -131,9 +131,24 @@ __device__ __forceinline__ void gemm_f32_body(const eamd_gemm_t& p, const int bi
     else b_off[i] = (long)b_r[i] * p.ldb + min(n0 + b_c[i] * 4, (p.N - 1) & ~3);
   }
   RowStateB a_rs[NCA];
+  // a convolution without padding (Conv2dSubsampling's second 3x3 / stride-2 layer: every tap of every output pixel lies
+  // inside the source) needs no per-tile range check: offset = row base + a tap offset that is uniform over the workgroup
+  constexpr bool g_nopad = NOPAD;         // checked on the host (gather_nopad): no tap of any output pixel leaves the source
   if constexpr (GAT && !TA) {
 #pragma unroll
     for (int i = 0; i < NCA; ++i) a_rs[i] = decompose_b(p.gather, m0 + a_r[i], p.M);
+  }
+  // transposed gather (weight gradient: the reduction runs over the output pixels): lanes 0 .. FBK-1 of the workgroup keep
+  // the (b, i, j) of the next reduction row they publish and step it by FBK rows per K-tile instead of dividing again
+  int pr_row = 0, pr_j = 0, pr_i = 0, pr_b = 0;
+  if constexpr (GAT && TA) {
+    if (t < FBK) {
+      pr_row = kt_begin * FBK + t;
+      pr_j = pr_row % p.gather.Wo;
+      const int tt = pr_row / p.gather.Wo;
+      pr_i = tt % p.gather.Ho;
+      pr_b = tt / p.gather.Ho;
+    }
   }
   // register ring: DEPTH-1 tiles of loads in flight across the MFMA phases.  A 128x128 phase is 4096 MFMA cycles
   // per wave (longer than an HBM round trip): one tile ahead is enough; 64x64 phases are 1024 cycles: two ahead.
@@ -146,11 +161,16 @@ __device__ __forceinline__ void gemm_f32_body(const eamd_gemm_t& p, const int bi
   const bool do_colsum = TA && p.colsum != nullptr && !GAT && tile_n == 0;
   float cs[4] = {0.f, 0.f, 0.f, 0.f};
 
-  auto fill_poff = [&](int kt, int slot) __attribute__((always_inline)) {
+  auto fill_poff = [&](int kt, int slot) __attribute__((always_inline)) {      // called for kt_begin, kt_begin + 1, ... in order
     if (t < FBK) {
       const int tap = m0 / p.gather.C;
-      RowStateB s = decompose_b(p.gather, kt * FBK + t, p.K);
+      RowStateB s;
+      s.ok = pr_row < p.K;
+      s.base = pr_b * p.gather.Hin * p.gather.Win; s.ih = pr_i * p.gather.sh; s.jw = pr_j * p.gather.sw;
       sm.poff[slot][t] = (int)gather_off_b(p.gather, s, tap);
+      pr_row += FBK; pr_j += FBK;
+      while (pr_j >= p.gather.Wo) { pr_j -= p.gather.Wo; ++pr_i; }
+      while (pr_i >= p.gather.Ho) { pr_i -= p.gather.Ho; ++pr_b; }
     }
   };
 
@@ -169,9 +189,12 @@ __device__ __forceinline__ void gemm_f32_body(const eamd_gemm_t& p, const int bi
         }
       } else {
         const int tap = k0 / p.gather.C, c0 = k0 % p.gather.C;
+        const int tappix = p.gather.dh[tap] * p.gather.Win + p.gather.dw[tap];                                // uniform
 #pragma unroll
         for (int i = 0; i < NCA; ++i) {
-          const long off = gather_off_b(p.gather, a_rs[i], tap);
+          long off;
+          if (g_nopad) off = a_rs[i].ok ? (long)(a_rs[i].base + a_rs[i].ih * p.gather.Win + a_rs[i].jw + tappix) * p.gather.C : -1L;
+          else off = gather_off_b(p.gather, a_rs[i], tap);
           ra[SET][i] = *reinterpret_cast<const float4*>(A + (off >= 0 ? off + c0 + a_c[i] * 4 : 0L));
         }
       }
@@ -215,7 +238,7 @@ __device__ __forceinline__ void gemm_f32_body(const eamd_gemm_t& p, const int bi
 #pragma unroll
       for (int i = 0; i < NCA; ++i) {
         bool ok;
-        if constexpr (!TA) ok = gather_off_b(p.gather, a_rs[i], k0 / p.gather.C) >= 0;
+        if constexpr (!TA) ok = g_nopad ? a_rs[i].ok != 0 : gather_off_b(p.gather, a_rs[i], k0 / p.gather.C) >= 0;
         else ok = sm.poff[kt % 8][a_r[i]] >= 0;
         ra[SET][i] = mask4(ra[SET][i], ok ? 4 : 0);
       }
@@ -498,9 +521,9 @@ __device__ __forceinline__ void gemm_f32_body(const eamd_gemm_t& p, const int bi
   store_c_tile<BM, BN, true, ROWEPI>(p, acc, sm.ab, m0, n0, coff);      // operand buffers are free now (last phase ended in a barrier)
 }
 
-template <int BM, int BN, bool TA, bool TB, bool GAT, bool ACT, bool ROWEPI = false>
+template <int BM, int BN, bool TA, bool TB, bool GAT, bool ACT, bool ROWEPI = false, bool NOPAD = false>
 __global__ __launch_bounds__(NT_, 2) void gemm_f32_kernel(const eamd_gemm_t p) {
-  gemm_f32_body<BM, BN, TA, TB, GAT, ACT, ROWEPI>(p, blockIdx.x, gridDim.x, blockIdx.z);
+  gemm_f32_body<BM, BN, TA, TB, GAT, ACT, ROWEPI, NOPAD>(p, blockIdx.x, gridDim.x, blockIdx.z);
 }
 
 // Grouped launch: workgroups first[i] .. first[i + 1] - 1 work on problem i of a device-resident descriptor table
@@ -517,7 +540,7 @@ __global__ __launch_bounds__(NT_, 2) void gemm_f32_group_kernel(const eamd_gemm_
   gemm_f32_body<BM, BN, TA, TB, false, false>(p, (int)blockIdx.x - first[lo], -(first[lo + 1] - first[lo]), 0);
 }
 
-template <int BM, int BN, bool TA, bool TB, bool GAT, bool ACT>
+template <int BM, int BN, bool TA, bool TB, bool GAT, bool ACT, bool NOPAD = false>
 int launch_f2(const eamd_gemm_t& p, hipStream_t stream) {
   dim3 grid(((p.M + BM - 1) / BM) * ((p.N + BN - 1) / BN) * p.splitk, 1, p.batch1 * p.batch2);
   constexpr size_t smem = sizeof(SmemF<BM, BN, TA, TB>);
@@ -538,17 +561,27 @@ int launch_f2(const eamd_gemm_t& p, hipStream_t stream) {
   }
   if (smem > 64 * 1024) {
     static const hipError_t attr_err = hipFuncSetAttribute(
-        reinterpret_cast<const void*>(&gemm_f32_kernel<BM, BN, TA, TB, GAT, ACT>),
+        reinterpret_cast<const void*>(&gemm_f32_kernel<BM, BN, TA, TB, GAT, ACT, false, NOPAD>),
         hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
     if (attr_err != hipSuccess) return (int)attr_err;
   }
-  hipLaunchKernelGGL((gemm_f32_kernel<BM, BN, TA, TB, GAT, ACT>), grid, dim3(NT_), smem, stream, p);
+  hipLaunchKernelGGL((gemm_f32_kernel<BM, BN, TA, TB, GAT, ACT, false, NOPAD>), grid, dim3(NT_), smem, stream, p);
   EAMD_LAUNCH_CHECK();
   return EAMD_OK;
 }
 
+// implicit-conv gather whose taps never leave the source (no padding): the kernel skips the per-tile range checks
+inline bool gather_nopad(const eamd_gather_t& g) {
+  for (int tp = 0; tp < g.ntap; ++tp)
+    if (g.dh[tp] < 0 || (g.Ho - 1) * g.sh + g.dh[tp] >= g.Hin || g.dw[tp] < 0 || (g.Wo - 1) * g.sw + g.dw[tp] >= g.Win) return false;
+  return true;
+}
+
 template <int BM, int BN, bool TA, bool TB, bool GAT>
 int launch_f(const eamd_gemm_t& p, hipStream_t stream) {
+  if constexpr (GAT && !TA) {
+    if (gather_nopad(p.gather) && p.epilogue < 7) return launch_f2<BM, BN, TA, TB, GAT, false, true>(p, stream);
+  }
   if constexpr (GAT) return launch_f2<BM, BN, TA, TB, GAT, false>(p, stream);
   else if (p.a_act != EAMD_ACT_NONE || p.b_act != EAMD_ACT_NONE || p.a_drop_p > 0.f || p.b_drop_p > 0.f)
     return launch_f2<BM, BN, TA, TB, GAT, true>(p, stream);

@@ -6,6 +6,7 @@ the flat gradient arena (``param._eamd_grad`` installed by espnet_amd.train.Flat
 present, otherwise they are returned to autograd like any other Function would.
 """
 import math
+import os
 
 import torch
 
@@ -1010,11 +1011,14 @@ def _conv3s2_bwd(dy, y_in, wd, dw_buf, db_buf, B, Hi, Wi, Ho, Wo, Cc, adt):
     # weight gradient: dwf[(tap, ci), co] = sum_pos col[pos, (tap, ci)] * dy[pos, co]
     dwf = torch.zeros(9 * Cc, Cc, device=dev, dtype=torch.float32)
     g = ops.make_gather(Cc, _TAPS_FWD, Ho, Wo, Hi, Wi, 2, 2)
-    tile = 64
+    # bf16 operands: 64x64 tiles, 1024 workgroups.  fp32-MFMA kernel (measured at config 2, tools/gemm_breakdown.py fp32): the
+    # 128x128 tile at just under two rounds of two workgroups per CU - 36 tiles x split-K 28 = 1008 workgroups - takes
+    # 1.58 ms; 64x64 tiles x split-K 16 = 2304 workgroups 1.70 ms; 128x128 at 1.5 or 3 rounds 1.63-1.73 ms
+    f32_big = (not ops.fast()) and Cc % 128 == 0
+    tile = int(os.environ.get("EAMD_CONV_DW_TILE", "128" if f32_big else "64"))
     ntile = (9 * Cc // tile) * ((Cc + tile - 1) // tile)
-    # workgroups wanted: 1024 with bf16 operands; the fp32-MFMA kernel (lower occupancy, 16x the MFMA time per tile) is
-    # best from about 2300 (split-K 16 at config 2: 1.94 -> 1.7 ms)
-    sk = max(2, min(64, ((1024 if ops.fast() else 2304) + ntile - 1) // ntile, max(1, M // 256)))
+    want = int(os.environ.get("EAMD_CONV_DW_WGS", "0")) or (1024 if ops.fast() else 1008 if f32_big else 2304)
+    sk = max(2, min(64, (want + ntile - 1) // ntile, max(1, M // 256)))
     ops.gemm(y_in, dy, dwf, 9 * Cc, Cc, M, 9 * Cc, Cc, Cc, transA=1, transB=1, gather=g, splitk=sk, tile=tile)
     ops.conv2_weight_grad(dwf, dw_buf, Cc, Cc)
     # input gradient, one implicit GEMM per stride-parity class
