@@ -148,6 +148,12 @@ class TransformerDecoder(AbsDecoder, BatchScorerInterface):
     def batch_score(self, ys, states, xs):
         return self._dec[0].batch_score(ys, states, xs)
 
+    def score_tree(self, ys, tree, xs):
+        return self._dec[0].score_tree(ys, tree, xs)
+
+    def final_tree(self, tree):
+        return 0.0
+
 
 class CTC(torch.nn.Module):
     """reference: espnet2/asr/ctc.py:6-111 (forward takes ys_lens; builtin and warpctc compute the same

@@ -73,6 +73,15 @@ class TransformerLM(AbsLM):
         logits = F_.LinearFn.apply(h[:, -1].contiguous(), self.decoder.weight, self.decoder.bias)
         return ops.log_softmax_rows(logits.contiguous()).squeeze(0), cache
 
+    def score_tree(self, ys, tree, xs):
+        """batch_score on a batched cache (list per layer of [n, L-1, D], or None)"""
+        h, _, new = self.encoder.forward_one_step(self._emb(ys), self._target_mask(ys), cache=tree)
+        logits = F_.LinearFn.apply(h[:, -1].contiguous(), self.decoder.weight, self.decoder.bias)
+        return ops.log_softmax_rows(logits.contiguous()), new
+
+    def final_tree(self, tree):
+        return 0.0
+
     def batch_score(self, ys, states, xs):
         n_batch, n_layers = len(ys), len(self.encoder.encoders)
         batch_state = None if states[0] is None else \
@@ -143,6 +152,19 @@ class SequentialRNNLM(AbsLM):
     def score(self, y, state, x):
         y, new_state = self(y[-1].view(1, 1), state)
         return ops.log_softmax_rows(y.view(1, -1).contiguous()).view(-1), new_state
+
+    def score_tree(self, ys, tree, xs):
+        """batch_score on a batched state with the hypothesis axis FIRST: (h, c) each (n, nlayers, nhid), or h alone, or None"""
+        lstm = self.rnn_type == "LSTM"
+        hidden = None
+        if tree is not None:
+            hidden = tuple(t.transpose(0, 1).contiguous() for t in tree) if lstm else tree.transpose(0, 1).contiguous()
+        y, hidden = self(ys[:, -1:], hidden)
+        logp = ops.log_softmax_rows(y.squeeze(1).contiguous())
+        return logp, (tuple(t.transpose(0, 1) for t in hidden) if lstm else hidden.transpose(0, 1))
+
+    def final_tree(self, tree):
+        return 0.0
 
     def batch_score(self, ys, states, xs):
         """reference: seq_rnn_lm.py:126-174; state of one hypothesis = (h, c) each (nlayers, nhid)"""

@@ -191,8 +191,164 @@ class BeamSearch(torch.nn.Module):
                 remained.append(hyp)
         return remained
 
+    # ---- the same search with the hypotheses on the device ----------------------------------------------
+    # `beam_size` slots hold prefixes [n, maxlen + 2], accumulated scores, per-scorer scores and every scorer's state as a
+    # BATCHED tree (score_tree / CTC (s [n], r [n, T, 2])); a step selects with index_select / gather on device indices, dead
+    # slots (ended or never filled) carry -inf and can never be selected again, and what the host needs of a step - scores,
+    # tokens, the prefixes of the slots that ended - is logged in device tensors and fetched ONCE every `sync_every` steps
+    # (one device -> host copy), where the reference's end detection is replayed step by step and the search is cut at the
+    # step it would have stopped at.  Steps run beyond that point are discarded; results are those of the host loop.
+    device_loop = True
+    sync_every = 8
+
+    def _device_loop_ok(self, x):
+        return (self.device_loop and x.is_cuda and all(hasattr(d, "score_tree") for d in self.full_scorers.values())
+                and all(isinstance(d, CTCPrefixScorer) for d in self.part_scorers.values()) and len(self.part_scorers) <= 1)
+
+    @staticmethod
+    def _tree_index(tree, idx):
+        if tree is None:
+            return None
+        if torch.is_tensor(tree):
+            return tree.index_select(0, idx)
+        if isinstance(tree, dict):
+            return {k: BeamSearch._tree_index(v, idx) for k, v in tree.items()}
+        if isinstance(tree, (list, tuple)):
+            return type(tree)(BeamSearch._tree_index(v, idx) for v in tree)
+        raise TypeError(type(tree))
+
+    def _forward_device(self, x, maxlenratio, minlenratio):
+        from .. import ops
+        T, V, n, dev = x.shape[0], self.n_vocab, self.beam_size, x.device
+        maxlen = T if maxlenratio == 0 else max(1, int(maxlenratio * T))
+        NEG = -float("inf")
+        names = list(self.full_scorers.keys())
+        pname = next(iter(self.part_scorers), None)
+        ctc = self.part_scorers[pname] if pname is not None else None
+        allk = names + ([pname] if pname is not None else [])
+        yseq = torch.full((n, maxlen + 2), self.eos, dtype=torch.int64, device=dev)
+        yseq[:, 0] = self.sos
+        hyp = torch.full((n,), NEG, device=dev, dtype=torch.float32)
+        hyp[0] = 0.0
+        sc = {k: torch.zeros(n, device=dev, dtype=torch.float32) for k in allk}
+        trees = {k: None for k in names}
+        for k, d in self.full_scorers.items():       # scorers that prepare per-utterance tensors (none of the tree scorers keeps one)
+            if hasattr(d, "batch_init_state"):
+                d.batch_init_state(x)
+        if ctc is not None:
+            s0, r0 = ctc.init_state(x)
+            c_s = torch.zeros(n, device=dev, dtype=torch.float32)
+            c_r = r0.unsqueeze(0).expand(n, *r0.shape).contiguous()
+        xs = x.unsqueeze(0).expand(n, *x.shape)
+        ended, pending, stop_at = [], [], None
+        arange_v = torch.arange(V, device=dev).unsqueeze(0).expand(n, V) if (ctc is not None and not self.do_pre_beam) else None
+
+        def flush():
+            """fetch the logged steps, replay the reference's bookkeeping; returns True when the search is over"""
+            nonlocal pending
+            if not pending:
+                return False
+            host = torch.stack([p for p in pending]).cpu()          # [steps, n, 3 + len(allk) + maxlen + 2]
+            pending = []
+            for row in host:
+                i = int(row[0, 0])
+                alive = 0
+                for slot in row.tolist():
+                    top_s, tok = slot[1], int(slot[2])
+                    if not math.isfinite(top_s):
+                        continue
+                    L = i + 2
+                    seq = [int(v) for v in slot[3 + len(allk): 3 + len(allk) + L]]
+                    if i == maxlen - 1:
+                        seq.append(self.eos)
+                    if seq[-1] == self.eos:
+                        scores = {k: slot[3 + j] for j, k in enumerate(allk)}
+                        if self.apply_final_score:
+                            for k, d in chain(self.full_scorers.items(), self.part_scorers.items()):
+                                f = float(d.final_score(None)) if not hasattr(d, "final_tree") else float(d.final_tree(None))
+                                scores[k] += f
+                                top_s += self.weights[k] * f
+                        ended.append(Hypothesis(yseq=torch.tensor(seq, dtype=torch.int64), score=top_s, scores=scores, states={}))
+                    else:
+                        alive += 1
+                if maxlenratio == 0.0 and end_detect([h.asdict() for h in ended], i):
+                    return True
+                if alive == 0:
+                    return True
+            return False
+
+        with torch.no_grad():
+            for i in range(maxlen):
+                L = i + 1
+                ys = yseq[:, :L]
+                weighted = torch.zeros(n, V, device=dev, dtype=torch.float32)
+                logps, newtrees = {}, {}
+                for k, d in self.full_scorers.items():
+                    logps[k], newtrees[k] = d.score_tree(ys, trees[k], xs)
+                    weighted += self.weights[k] * logps[k]
+                part_ids = None
+                if self.do_pre_beam:
+                    pre = weighted if self.pre_beam_score_key == "full" else logps[self.pre_beam_score_key]
+                    part_ids = torch.topk(pre, self.pre_beam_size, dim=-1)[1]
+                if ctc is not None:
+                    last = ys[:, -1].to(torch.int32).contiguous()
+                    olen = torch.full((n,), L - 1, dtype=torch.int32, device=dev)
+                    if self.partial_mode == "full":
+                        ids = part_ids if part_ids is not None else torch.arange(V, device=dev).unsqueeze(0).expand(n, V)
+                        psi, r_new = ops.ctc_prefix_score(ctc.logp, c_r, ids.to(torch.int32).contiguous(), last, olen, ctc.blank, ctc.eos)
+                        full = torch.full((n, V), -10000000000.0, device=dev, dtype=torch.float32)
+                        full.scatter_(1, ids.long(), psi)
+                        full[:, ctc.eos] = torch.logsumexp(c_r[:, -1, :], dim=-1)
+                        full[:, ctc.blank] = -10000000000.0
+                        idmap = torch.full((n, V), -1, dtype=torch.int64, device=dev)
+                        idmap.scatter_(1, ids.long(), torch.arange(ids.shape[1], device=dev).expand(n, -1))
+                        c_local = full - c_s[:, None]
+                        weighted += self.weights[pname] * c_local
+                    else:
+                        ids = part_ids if part_ids is not None else arange_v
+                        psi, r_new = ops.ctc_prefix_score(ctc.logp, c_r, ids.to(torch.int32).contiguous(), last, olen, ctc.blank, ctc.eos)
+                        c_local = psi - c_s[:, None]
+                        if part_ids is not None:
+                            kept = torch.full_like(weighted, NEG)
+                            kept.scatter_(1, ids, torch.gather(weighted, 1, ids) + self.weights[pname] * c_local)
+                            weighted = kept
+                        else:
+                            weighted += self.weights[pname] * c_local
+                weighted += hyp[:, None]
+                top_s, top_i = weighted.view(-1).topk(n)
+                hyp_i, tok_i = top_i // V, top_i % V
+                for k in names:
+                    sc[k] = sc[k][hyp_i] + logps[k][hyp_i, tok_i]
+                    trees[k] = self._tree_index(newtrees[k], hyp_i)
+                if ctc is not None:
+                    if self.partial_mode == "full":
+                        sc[pname] = sc[pname][hyp_i] + c_local[hyp_i, tok_i]
+                        j = idmap[hyp_i, tok_i].clamp_min(0)
+                        c_s, c_r = full[hyp_i, tok_i], r_new[hyp_i, j]
+                    else:
+                        pos = (ids[hyp_i] == tok_i[:, None]).float().argmax(-1) if part_ids is not None else tok_i
+                        sc[pname] = sc[pname][hyp_i] + c_local[hyp_i, pos]
+                        c_s, c_r = psi[hyp_i, pos], r_new[hyp_i, pos]
+                yseq = yseq.index_select(0, hyp_i)
+                yseq[:, L] = tok_i
+                finite = torch.isfinite(top_s)
+                done = finite & (tok_i == self.eos) if i < maxlen - 1 else finite
+                rec = torch.cat([torch.full((n, 1), float(i), device=dev), top_s[:, None], tok_i[:, None].float()]
+                                + [sc[k][:, None] for k in allk] + [yseq.float()], dim=1)
+                pending.append(rec)
+                hyp = torch.where(done | ~finite, torch.full_like(top_s, NEG), top_s)
+                if len(pending) >= self.sync_every or i == maxlen - 1:
+                    if flush():
+                        break
+        nbest = sorted(ended, key=lambda h: float(h.score), reverse=True)
+        if len(nbest) == 0:
+            return [] if minlenratio < 0.1 else self.forward(x, maxlenratio, max(0.0, minlenratio - 0.1))
+        return nbest
+
     def forward(self, x, maxlenratio=0.0, minlenratio=0.0):
         """x: (T, D) encoder output.  Returns the ended hypotheses, best first."""
+        if self._device_loop_ok(x):
+            return self._forward_device(x, maxlenratio, minlenratio)
         T = x.shape[0]
         maxlen = T if maxlenratio == 0 else max(1, int(maxlenratio * T))
         with torch.no_grad():

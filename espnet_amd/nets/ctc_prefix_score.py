@@ -118,3 +118,9 @@ class LengthBonus(BatchScorerInterface):
 
     def batch_score(self, ys, states, xs):
         return torch.ones(len(ys), self.n, device=xs.device, dtype=xs.dtype), None
+
+    def score_tree(self, ys, tree, xs):
+        return torch.ones(len(ys), self.n, device=xs.device, dtype=xs.dtype), None
+
+    def final_tree(self, tree):
+        return 0.0

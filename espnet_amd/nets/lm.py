@@ -119,6 +119,14 @@ class DefaultRNNLM(torch.nn.Module, BatchScorerInterface):
     def final_score(self, state):
         return self.model.final(state)
 
+    def score_tree(self, ys, tree, xs):
+        """batch_score on the merged state itself ({key: [layer tensors (n, n_units)]} or None)"""
+        tree, logp = self.model.predict(tree, ys[:, -1].contiguous())
+        return logp, tree
+
+    def final_tree(self, tree):
+        return self.model.final(tree)
+
     def batch_score(self, ys, states, xs):
         """reference: default.py:139-169; state of one hypothesis = {key: [layer tensors (n_units,)]}"""
         n_batch, n_layers = len(ys), self.model.predictor.n_layers

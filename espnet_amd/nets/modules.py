@@ -915,6 +915,15 @@ class Decoder(torch.nn.Module, BatchScorerInterface):
         logp, state = self.forward_one_step(ys.unsqueeze(0), ys_mask, x.unsqueeze(0), cache=state)
         return logp.squeeze(0), state
 
+    def score_tree(self, ys, tree, xs):
+        """batch_score on a BATCHED state (list per layer of [n, L-1, D], or None): no per-hypothesis stacking / slicing;
+        the search reorders it with index_select (BeamSearch device loop)"""
+        ys_mask = subsequent_mask(ys.size(-1), device=xs.device).unsqueeze(0)
+        return self.forward_one_step(ys, ys_mask, xs, cache=tree)
+
+    def final_tree(self, tree):
+        return 0.0
+
     def batch_score(self, ys, states, xs):
         n_batch = len(ys)
         n_layers = len(self.decoders)

@@ -941,6 +941,7 @@ def test_decode_fusion_golden(tag, batch, lm, cw, lw):
     cls = BatchBeamSearch if batch else BeamSearch
     bs = cls(scorers, dict(decoder=1.0 - cw, ctc=cw, lm=lw, length_bonus=0.1), 4, 30, model.sos, model.eos,
              pre_beam_score_key=None if cw == 1.0 else "full")
+    assert bs._device_loop_ok(enc[0])       # hypotheses, scores and scorer states stay on the device (one copy per 8 steps)
     got = bs(enc[0])[:3]
     want, scores = _nbest_from(p, tag)
     print(f"[parity] {tag}: hip {[round(float(h.score), 4) for h in got]} ref {[round(s, 4) for s in scores]}")
@@ -948,6 +949,14 @@ def test_decode_fusion_golden(tag, batch, lm, cw, lw):
     for h, s in zip(got, scores):
         assert abs(float(h.score) - s) <= 1e-4 * max(1.0, abs(s))
         assert abs(sum(bs.weights[k] * float(v) for k, v in h.scores.items()) - float(h.score)) < 1e-3
+    # the host-side loop (the reference's bookkeeping, hypothesis by hypothesis) finds the same n-best
+    bs.device_loop = False
+    host = bs(enc[0])[:3]
+    assert [h.yseq.tolist() for h in host] == want
+    for a, b in zip(got, host):
+        assert abs(float(a.score) - float(b.score)) <= 1e-5 * max(1.0, abs(float(b.score)))
+        for k in b.scores:
+            assert abs(float(a.scores[k]) - float(b.scores[k])) <= 1e-4 * max(1.0, abs(float(b.scores[k]))), k
 
 
 def test_speech2text():

@@ -93,12 +93,14 @@ def decode_leg(dev, c2_args, n_beam_utts=2, beam=10, ctc_weight=0.3, maxlenratio
         enc0 = hs[0, : hl[0]].contiguous()
         bs(enc0, maxlenratio=0.02)               # warm-up (lazy buffers, first-launch costs)
         torch.cuda.synchronize()
-        # launches of ONE beam step in steady state: step 3 of a fresh search
-        with torch.no_grad():
-            running = bs.init_hyp(enc0)
-            for i in range(3):
-                running = bs.post_process(i, 10 ** 6, 1.0, bs.search(running, enc0), [])
-            counts = _count_step(lambda: bs.search(running, enc0))
+        # launches and copies of a whole short search (16 beam steps), per beam step: the hypotheses, scores and scorer
+        # states stay on the device; the host fetches the step log once every `sync_every` steps
+        nstep = 16
+        ratio = (nstep + 0.5) / enc0.shape[0]
+        counts = _count_step(lambda: bs(enc0, maxlenratio=ratio))
+        counts = {k: (round(v / nstep, 2) if isinstance(v, (int, float)) else v) for k, v in counts.items()}
+        counts["device_loop"] = bool(bs._device_loop_ok(enc0))
+        counts["sync_every"] = bs.sync_every
         steps = tot = 0
         t0 = time.perf_counter()
         for b in range(n_beam_utts):
@@ -111,7 +113,8 @@ def decode_leg(dev, c2_args, n_beam_utts=2, beam=10, ctc_weight=0.3, maxlenratio
         out[tag] = dict(beam=beam, ctc_weight=ctc_weight, maxlenratio=maxlenratio, utterances_timed=n_beam_utts,
                         utt_per_s=round(n_beam_utts / tot, 2), rtf=float("%.3e" % (tot / a_s)), beam_steps=steps,
                         ms_per_beam_step=round(tot / steps * 1e3, 3), per_beam_step=counts,
-                        note="encoder outputs precomputed (the greedy leg times the encoder); hypotheses on the host")
+                        note="encoder outputs precomputed (the greedy leg times the encoder); hypotheses, scores and scorer "
+                             "states on the device, one device->host copy of the step log per sync_every steps")
 
     # ---- CPU oracle beside it: greedy CTC of a bounded sample, ids compared ----
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
