@@ -135,6 +135,22 @@ class E2E(ASRInterface, torch.nn.Module):
             hs, _, _ = self.enc(h, [x.shape[0]])
         return hs.squeeze(0)
 
+    def recognize_batch(self, xs, recog_args, char_list=None, rnnlm=None, ctc_scoring_num=None):
+        """xs list of ndarrays (T_b, D) -> per utterance an n-best list (e2e_asr.py:394-445 -> Decoder.recognize_beam_batch)"""
+        self.eval()
+        p = next(self.parameters())
+        ilens = [int(x.shape[0]) for x in xs]
+        feats = [torch.as_tensor(x, device=p.device, dtype=p.dtype) for x in xs]
+        xs_pad = torch.nn.utils.rnn.pad_sequence(feats, batch_first=True)
+        with torch.no_grad():
+            hs_pad, hlens, _ = self.enc(xs_pad, ilens)
+            if recog_args.ctc_weight > 0.0:
+                lpz, normalize = self.ctc.log_softmax(hs_pad), False
+            else:
+                lpz, normalize = None, True
+            return self.dec.recognize_beam_batch(hs_pad, hlens, lpz, recog_args, char_list, rnnlm, normalize_score=normalize,
+                                                 ctc_scoring_num=ctc_scoring_num)
+
     def recognize(self, x, recog_args, char_list=None, rnnlm=None):
         """x ndarray (T, D) -> n-best list of {"score", "yseq"} (e2e_asr.py:372-392)"""
         hs = self.encode(x).unsqueeze(0)

@@ -257,6 +257,175 @@ def _recognize_beam(self, h, lpz, recog_args, char_list=None, rnnlm=None, strm_i
 Decoder.recognize_beam = _recognize_beam
 
 
+def _recognize_beam_batch(self, h, hlens, lpz, recog_args, char_list=None, rnnlm=None, normalize_score=True, strm_idx=0,
+                          ctc_scoring_num=None):
+    """Vectorised beam search over a BATCH of utterances (reference: rnn/decoders.py:632-974, single encoder, no CTC window):
+    h (B, Tmax, eprojs), hlens (B,), lpz (B, Tmax, odim) CTC log-posteriors or None -> per utterance an n-best list of
+    {"yseq", "score", "vscore"}.
+
+    All B x beam hypotheses advance together: ONE embedding / attention / decoder-cell / output step per position over the
+    (B * beam) rows, a top-`beam` per utterance over its beam x odim candidates (<eos> is scored aside: a hypothesis ends
+    when its <eos> score beats the worst survivor), CTC prefix scores in the reference's full-matrix form (CTCPrefixScoreTH:
+    log-zero outside the scored labels, <eos> from the last frame, blank excluded; one eamd_ctc_prefix_score launch per
+    utterance and step on the utterance's own frames - padding frames change nothing in that recursion).  Prefixes, scores and
+    every state stay on the device; the host reads one small tensor per step for the ended-hypothesis bookkeeping and the
+    per-utterance end detection (e2e_asr_common.end_detect), as the reference does.
+    ctc_scoring_num: labels per hypothesis that receive a CTC score; None = the reference's rule for device tensors (0: the whole
+    vocabulary); its CPU rule is int(1.5 * beam) (what the fixtures were recorded with)."""
+    from ..beam_search import BeamSearch, end_detect
+    from ..ctc_prefix_score import CTCPrefixScorer
+    dev = h.device
+    hlens = [int(v) for v in hlens]
+    B, beam, V = len(hlens), int(recog_args.beam_size), self.odim
+    penalty = float(recog_args.penalty)
+    ctc_weight = float(getattr(recog_args, "ctc_weight", 0.0)) if lpz is not None else 0.0
+    att_weight = 1.0 - ctc_weight
+    lm_weight = float(getattr(recog_args, "lm_weight", 0.0))
+    if int(getattr(recog_args, "ctc_window_margin", 0)) > 0:
+        raise NotImplementedError("ctc_window_margin > 0 (attention-windowed CTC scoring) is outside the hot-path scope")
+    att = self.att[min(strm_idx, len(self.att) - 1)]
+    n = B * beam
+    tmask = torch.arange(h.size(1), device=dev)[None, :] < torch.tensor(hlens, device=dev)[:, None]
+    h = h * tmask.unsqueeze(-1)                                                       # mask_by_length(h, hlens, 0.0)
+    max_hlen = max(hlens)
+    maxlen = max_hlen if recog_args.maxlenratio == 0 else max(1, int(recog_args.maxlenratio * max_hlen))
+    minlen = int(recog_args.minlenratio * max_hlen)
+    exp_h = h.unsqueeze(1).expand(B, beam, h.size(1), h.size(2)).reshape(n, h.size(1), h.size(2)).contiguous()
+    exp_hlens = [hlens[b] for b in range(B) for _ in range(beam)]
+    z_prev = [exp_h.new_zeros(n, self.dunits) for _ in range(self.dlayers)]
+    c_prev = [exp_h.new_zeros(n, self.dunits) for _ in range(self.dlayers)]
+    a_prev = None
+    att.reset()
+    yseq = torch.full((n, maxlen + 2), self.eos, dtype=torch.long, device=dev)
+    yseq[:, 0] = self.sos
+    vscores = torch.zeros(B, beam, device=dev)
+    base = (torch.arange(B, device=dev) * beam).view(B, 1)
+    scorers, c_s, c_r = None, None, None
+    if lpz is not None:
+        if ctc_scoring_num is None:
+            ctc_scoring_num = 0
+        snum = min(int(ctc_scoring_num) if att_weight > 0.0 else 0, V)
+        scorers = []
+        for b in range(B):
+            sc = CTCPrefixScorer(None, self.eos)
+            sc.logp = lpz[b, : hlens[b]].detach().contiguous()
+            scorers.append(sc)
+        c_s = [torch.zeros(beam, device=dev) for _ in range(B)]
+        c_r = []
+        for b in range(B):
+            r0 = torch.full((hlens[b], 2), self.logzero, device=dev)
+            r0[:, 1] = torch.cumsum(scorers[b].logp[:, 0], 0)
+            c_r.append(r0.unsqueeze(0).expand(beam, hlens[b], 2).contiguous())
+    lm_state = None
+    stop = [False] * B
+    ended = [[] for _ in range(B)]
+    with torch.no_grad():
+        for i in range(maxlen):
+            L = i + 1
+            vy = yseq[:, i].contiguous()
+            ey = R_.PlainEmbedFn.apply(vy, self.embed.weight, -1)
+            att_c, att_w = att(exp_h, exp_hlens, z_prev[0], a_prev)
+            ey = torch.cat((ey, att_c), dim=1)
+            z_list, c_list = self.rnn_forward(ey, [None] * self.dlayers, [None] * self.dlayers, z_prev, c_prev)
+            top = torch.cat((z_list[-1], att_c), dim=-1) if self.context_residual else z_list[-1]
+            logits = F_.LinearFn.apply(top, self.output.weight, self.output.bias)
+            local = att_weight * ops.log_softmax_rows(logits.contiguous())
+            if rnnlm is not None:
+                lm_state, lm_scores = rnnlm.buff_predict(lm_state, vy, n)
+                local = local + lm_weight * lm_scores
+            c_full, c_rnew, c_idmap = None, None, None
+            if scorers is not None:
+                local[:, 0] = self.logzero                                      # blank is never chosen
+                part_ids = torch.topk(local, snum, dim=-1)[1] if snum > 0 else None
+                c_full, c_rnew, c_idmap = [], [], []
+                ys = yseq[:, :L]
+                for b in range(B):
+                    rows = slice(b * beam, (b + 1) * beam)
+                    ids = part_ids[rows] if part_ids is not None else torch.arange(V, device=dev).unsqueeze(0).expand(beam, V)
+                    last = ys[rows, -1].to(torch.int32).contiguous()
+                    olen = torch.full((beam,), L - 1, dtype=torch.int32, device=dev)
+                    psi, r_new = ops.ctc_prefix_score(scorers[b].logp, c_r[b], ids.to(torch.int32).contiguous(), last, olen, 0,
+                                                      self.eos)
+                    full = torch.full((beam, V), self.logzero, device=dev)
+                    full.scatter_(1, ids.long(), psi)
+                    full[:, self.eos] = torch.logsumexp(c_r[b][:, -1, :], dim=-1)
+                    full[:, 0] = self.logzero
+                    idmap = torch.full((beam, V), -1, dtype=torch.long, device=dev)
+                    idmap.scatter_(1, ids.long(), torch.arange(ids.shape[1], device=dev).expand(beam, -1))
+                    local[rows] += ctc_weight * (full - c_s[b][:, None])
+                    c_full.append(full)
+                    c_rnew.append(r_new)
+                    c_idmap.append(idmap)
+            local = local.view(B, beam, V)
+            if i == 0:
+                local[:, 1:, :] = self.logzero                                  # all slots hold the same <sos> prefix
+            eos_vscores = local[:, :, self.eos] + vscores
+            cand = vscores.unsqueeze(-1).expand(B, beam, V).clone()
+            cand[:, :, self.eos] = self.logzero
+            cand = (cand + local).view(B, beam * V)
+            best_scores, best_ids = torch.topk(cand, beam, dim=1)
+            tok = best_ids % V
+            src = (best_ids // V + base).view(-1)                                # row of the (B * beam) batch each survivor extends
+            y_prev = yseq
+            yseq = yseq.index_select(0, src)
+            yseq[:, L] = tok.view(-1)
+            vscores = best_scores
+            a_prev = att_w.index_select(0, src) if torch.is_tensor(att_w) else None
+            if not torch.is_tensor(att_w):
+                raise NotImplementedError("recognize_beam_batch: attention types whose state is not one weight tensor")
+            z_prev = [z.index_select(0, src) for z in z_list]
+            c_prev = [c.index_select(0, src) for c in c_list] if self.dtype == "lstm" else c_prev
+            # ---- ended hypotheses and end detection: one device -> host copy per step ----
+            if i >= minlen:
+                host = torch.cat([eos_vscores, best_scores], dim=1).cpu()         # [B, 2 * beam]
+                pen = (i + 1) * penalty
+                yp_host = yn_host = None
+                for b in range(B):
+                    if stop[b]:
+                        continue
+                    thr = float(host[b, 2 * beam - 1])
+                    for j in range(beam):
+                        k = b * beam + j
+                        val, seq = None, None
+                        if float(host[b, j]) > thr:
+                            if L <= hlens[b]:
+                                if yp_host is None:
+                                    yp_host = y_prev[:, :L].cpu()
+                                val, seq = float(host[b, j]) + pen, yp_host[k].tolist()
+                        elif i == maxlen - 1:
+                            if yn_host is None:
+                                yn_host = yseq[:, : L + 1].cpu()
+                            val, seq = float(host[b, beam + j]) + pen, yn_host[k].tolist()
+                        if val:                                                  # the reference's truthiness test on the score
+                            seq = seq + [self.eos]
+                            if rnnlm is not None:
+                                val += lm_weight * float(rnnlm.final(lm_state, index=k))
+                            ended[b].append({"yseq": seq, "vscore": val, "score": val})
+            stop = [stop[b] or end_detect(ended[b], i) for b in range(B)]
+            if all(stop):
+                break
+            if rnnlm is not None:
+                lm_state = BeamSearch._tree_index(lm_state, src)
+            if scorers is not None:
+                for b in range(B):
+                    hb = best_ids[b] // V
+                    tb = tok[b]
+                    j = c_idmap[b][hb, tb].clamp_min(0)
+                    c_s[b] = c_full[b][hb, tb]
+                    c_r[b] = c_rnew[b][hb, j]
+    out = []
+    for b in range(B):
+        hyps = ended[b] if ended[b] else [{"yseq": [self.sos, self.eos], "score": -float("inf"), "vscore": -float("inf")}]
+        if normalize_score:
+            for x in hyps:
+                x["score"] = x["score"] / len(x["yseq"])
+        out.append(sorted(hyps, key=lambda x: x["score"], reverse=True)[: min(len(hyps), int(recog_args.nbest))])
+    return out
+
+
+Decoder.recognize_beam_batch = _recognize_beam_batch
+
+
 def decoder_for(args, odim, sos, eos, att, labeldist):
     """reference: rnn/decoders.py:1199-1218"""
     return Decoder(args.eprojs, odim, args.dtype, args.dlayers, args.dunits, sos, eos, att, args.verbose,

@@ -13,6 +13,9 @@
   warmup_lr.npz                  espnet2 WarmupLR (schedulers/warmup_lr.py:10-53): the lr of 14 optimizer steps, warmup 5
   adadelta.npz                   torch.optim.Adadelta as asr.py:505-508 builds it (rho 0.95, eps 1e-8) with clip_grad_norm_(5)
                                  and one _adadelta_eps_decay(0.01) (asr_utils.py:517-528) after the third step
+  e2e_rnn_batchbeam.npz          E2E.recognize_batch -> Decoder.recognize_beam_batch (e2e_asr.py:394-445, rnn/decoders.py:632-974)
+                                 on the three utterances of e2e_rnn.npz (the model of seed 31): attention only, joint CTC (the CPU
+                                 rule: CTC scores for the int(1.5 * beam) best labels of a hypothesis), CTC + RNNLM, nbest 2
 
 Usage: python oracle/gen_golden_r3.py [--ref /root/reference] [--out tests/golden]
 """
@@ -133,6 +136,30 @@ def main():
     loss.backward()
     save(out("e2e_rnn_vggblstm.npz"), xs=xs, ilens=ilens, ys=ys, hs_pad=hs.detach(), hlens=np.asarray(hlens, dtype=np.int64),
          loss=float(loss), loss_att=float(m.loss_att), loss_ctc=float(m.loss_ctc), acc=float(m.acc), **sd0, **grads_np(m))
+
+    # ---- a19 / a20: vectorised batch beam search of the RNN decoder ----
+    from espnet.nets.pytorch_backend.lm.default import ClassifierWithState, RNNLM
+    torch.manual_seed(31)
+    m = RnnE2E(12, 7, rnn_args())
+    m.eval()
+    sd0 = sd_np(m, "sd/")
+    torch.manual_seed(131)
+    lm = ClassifierWithState(RNNLM(7, 1, 8, None, "lstm", 0.0)).eval()
+    res = dict(sd_np(lm, "rlm/"))
+    feats = [xs[b, : int(ilens[b])].numpy() for b in range(3)]
+    with torch.no_grad():
+        for tag, kw, use_lm in (("b3", dict(beam_size=3, ctc_weight=0.0, penalty=0.0), False),
+                                ("b3ctc", dict(beam_size=3, ctc_weight=0.5, penalty=0.1), False),
+                                ("b2lm", dict(beam_size=2, ctc_weight=0.3, penalty=0.0, lm_weight=0.4), True),
+                                ("b4len", dict(beam_size=4, ctc_weight=0.3, penalty=0.2, maxlenratio=0.4, minlenratio=0.1), False)):
+            ra = argparse.Namespace(**dict(dict(nbest=2, maxlenratio=0.0, minlenratio=0.0, lm_weight=0.0, ctc_window_margin=0), **kw))
+            nb = m.recognize_batch(feats, ra, rnn_args().char_list, lm if use_lm else None)
+            res["bb_%s_n" % tag] = np.asarray([len(u) for u in nb], dtype=np.int64)
+            res["bb_%s_scores" % tag] = np.asarray([float(np.asarray(h["score"]).reshape(-1)[0]) for u in nb for h in u], dtype=np.float64)
+            res["bb_%s_lens" % tag] = np.asarray([len(h["yseq"]) for u in nb for h in u], dtype=np.int64)
+            res["bb_%s_yseq" % tag] = np.asarray(sum([[int(t) for t in h["yseq"]] for u in nb for h in u], []), dtype=np.int64)
+            print(tag, [[(h["yseq"], round(float(np.asarray(h["score"]).reshape(-1)[0]), 4)) for h in u] for u in nb])
+    save(out("e2e_rnn_batchbeam.npz"), xs=xs, ilens=ilens, **sd0, **res)
 
     # ---- a18: WarmupLR ----
     from espnet2.schedulers.warmup_lr import WarmupLR

@@ -757,6 +757,48 @@ def test_rnn_decoding_golden(name, idim, kw):
                                                                                scores[0]))
 
 
+def test_rnn_batch_beam_search_golden():
+    """a19 / a20: E2E.recognize_batch -> Decoder.recognize_beam_batch (rnn/decoders.py:632-974), the vectorised search over a
+    batch of utterances x beam: attention only, joint CTC (CTCPrefixScoreTH arithmetic with the reference's CPU pre-selection
+    of int(1.5 * beam) labels, which is what recorded the fixture), CTC + RNNLM fusion, a length-capped search with a minimum
+    length - the reference's n-best per utterance: token sequences exactly, scores to 1e-4."""
+    from espnet_amd.nets.e2e_asr import E2E
+    from espnet_amd.nets.lm import ClassifierWithState, RNNLM
+    p, sd, _ = split_golden(load_golden("e2e_rnn_batchbeam.npz"))
+    m = load_sd(E2E(12, 7, _rnn_args()), sd).eval()
+    lm = ClassifierWithState(RNNLM(7, 1, 8, None, "lstm", 0.0))
+    lm.load_state_dict({k[4:]: v for k, v in p.items() if k.startswith("rlm/")})
+    lm.to(DEV).eval()
+    ilens = p["ilens"].tolist()
+    feats = [p["xs"][b, : ilens[b]].numpy() for b in range(3)]
+    for tag, rkw, use_lm in (("b3", dict(beam_size=3, ctc_weight=0.0, penalty=0.0), False),
+                             ("b3ctc", dict(beam_size=3, ctc_weight=0.5, penalty=0.1), False),
+                             ("b2lm", dict(beam_size=2, ctc_weight=0.3, penalty=0.0, lm_weight=0.4), True),
+                             ("b4len", dict(beam_size=4, ctc_weight=0.3, penalty=0.2, maxlenratio=0.4, minlenratio=0.1), False)):
+        ra = argparse.Namespace(**dict(dict(nbest=2, maxlenratio=0.0, minlenratio=0.0, lm_weight=0.0, ctc_window_margin=0), **rkw))
+        nb = m.recognize_batch(feats, ra, _rnn_args().char_list, lm if use_lm else None,
+                               ctc_scoring_num=int(ra.beam_size * 1.5))
+        counts, lens = p["bb_%s_n" % tag].tolist(), p["bb_%s_lens" % tag].tolist()
+        flat, scores = p["bb_%s_yseq" % tag].tolist(), p["bb_%s_scores" % tag].tolist()
+        assert [len(u) for u in nb] == counts, (tag, [len(u) for u in nb], counts)
+        o = q = 0
+        for u in nb:
+            for hyp in u:
+                n, sc = lens[q], scores[q]
+                assert hyp["yseq"] == flat[o:o + n], (tag, q, hyp["yseq"], flat[o:o + n])
+                assert abs(float(hyp["score"]) - sc) <= 1e-4 * max(1.0, abs(sc)), (tag, q, float(hyp["score"]), sc)
+                o += n
+                q += 1
+        print("[parity] recognize_beam_batch %s: %d hypotheses of 3 utterances identical, best %s (ref %s)"
+              % (tag, q, [round(float(u[0]["score"]), 4) for u in nb], [round(scores[i], 4) for i in (0, counts[0], counts[0] + counts[1])]))
+    # the reference's rule for device tensors (CTC scores for the whole vocabulary) runs too and agrees on the best hypothesis
+    ra = argparse.Namespace(nbest=1, maxlenratio=0.0, minlenratio=0.0, lm_weight=0.0, ctc_window_margin=0, beam_size=3,
+                            ctc_weight=0.5, penalty=0.1)
+    full = m.recognize_batch(feats, ra, _rnn_args().char_list, None)
+    pre = m.recognize_batch(feats, ra, _rnn_args().char_list, None, ctc_scoring_num=4)
+    assert [u[0]["yseq"] for u in full] == [u[0]["yseq"] for u in pre]
+
+
 @pytest.mark.parametrize("tag,cls,kw", [
     ("rnnp", "RNNEncoder", dict(num_layers=3, hidden_size=12, output_size=10, subsample=(2, 1))),
     ("gru", "RNNEncoder", dict(rnn_type="gru", bidirectional=False, use_projection=False, num_layers=2, hidden_size=12,
