@@ -17,7 +17,9 @@
 //     one lane of each storing workgroup signals for all its stores after every storing wave's vmcnt(0) wait);
 //   * both directions of a layer run side by side on disjoint workgroups of the same launch (grid <= number of CUs, one
 //     workgroup per CU, so every workgroup is resident and every spin is bounded by a wall-clock limit that sets a
-//     status word and lets the whole grid drain).
+//     status word, writes NaN into the step's outputs and lets the whole grid drain).  Residency is the caller's side of
+//     the contract: two such launches running CONCURRENTLY on one device (two streams, or two processes sharing a GPU)
+//     can each hold half the CUs while waiting for workgroups that cannot start - they then time out, they do not hang.
 // The reduction over the recurrent inputs is split over the waves of a workgroup exactly as in the per-step kernels
 // (results agree with theirs to the last bit or two: only the compiler's fma contraction of the cell update differs).
 #include <stdlib.h>
@@ -69,7 +71,8 @@ __device__ __forceinline__ bool wait_flags(unsigned* ws, int first, int n, unsig
 }
 
 // timing probes of the diagnostic build (-DLSTM_SEQ_PROBE, EAMD_LSTM_PROBE bits; results are wrong by design):
-// 1 = no MFMAs, 2 = no loads of the handed-over rows, 4 = no waiting for the flags, 8 = no cell arithmetic / stores
+// 1 = no MFMAs, 2 = no loads of the handed-over rows, 4 = no waiting for the flags, 8 = no cell arithmetic / stores,
+// 16 = workgroup 0 never publishes its flag (exercises the give-up path: status word, NaN outputs, drain)
 #ifdef LSTM_SEQ_PROBE
 #define PROBE(bit) ((a.probe & (bit)) != 0)
 #else
@@ -173,7 +176,14 @@ __global__ __launch_bounds__(1024) void lstm_seq_fwd_kernel(const FwdArgs a) {
         }
       }
       __syncthreads();
-      if (!go) break;                               // workgroup-uniform: a wait gave up somewhere, drain
+      if (!go) {                                    // workgroup-uniform: a wait gave up somewhere - poison the outputs (the loss
+        if (cell) {                                 // turns NaN, the optimizer's non-finite guard skips the step) and drain
+          const long idx = ((long)tt * B + cb) * H + cu;
+          J.h_out[idx] = __builtin_nanf("");
+          if (J.y) J.y[idx] = __builtin_nanf("");
+        }
+        break;
+      }
       const float* hp = J.h_out + (long)tp * B * H;
       f32x4 av[MT][KQ];
 #pragma unroll
@@ -230,7 +240,8 @@ __global__ __launch_bounds__(1024) void lstm_seq_fwd_kernel(const FwdArgs a) {
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // every storing wave drains before the barrier
     __syncthreads();                                         // also: part[] free for the next step
-    if (t == 0) __hip_atomic_store(a.ws + SYNC_FLAG0 + blockIdx.x, (unsigned)(s + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (t == 0 && !(PROBE(16) && blockIdx.x == 0))
+      __hip_atomic_store(a.ws + SYNC_FLAG0 + blockIdx.x, (unsigned)(s + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   }
 }
 
@@ -301,7 +312,10 @@ __global__ __launch_bounds__(1024) void lstm_seq_bwd_kernel(const BwdArgs a) {
         }
       }
       __syncthreads();
-      if (!go) break;
+      if (!go) {                                    // as in the forward: NaN into this step's gradients, then drain
+        if (cell) J.dgates[((long)tt * B + cb) * K + cu] = __builtin_nanf("");
+        break;
+      }
       const float* dg = J.dgates + (long)tn * B * K;
       f32x4 av[2][CH];
 #pragma unroll
@@ -351,7 +365,8 @@ __global__ __launch_bounds__(1024) void lstm_seq_bwd_kernel(const BwdArgs a) {
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
-    if (t == 0) __hip_atomic_store(a.ws + SYNC_FLAG0 + blockIdx.x, (unsigned)(s + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (t == 0 && !(PROBE(16) && blockIdx.x == 0))
+      __hip_atomic_store(a.ws + SYNC_FLAG0 + blockIdx.x, (unsigned)(s + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   }
 }
 

@@ -500,7 +500,9 @@ int eamd_lstm_step_bwd(const float* dy, const float* dgates_next, const float* w
  * h_out / c_out / y / dy [T, B, H], live [T, B] (0 = padding frame of a packed sequence) or NULL, initial states 0;
  * `reverse` runs the recurrence from t = T-1 down (the backward of a job walks against its forward direction).
  * sync_ws: eamd_lstm_seq_sync_bytes() bytes of device memory at the start of an allocation, zeroed by the call (a small
- * kernel ahead of the persistent one); eamd_lstm_seq_status() copies its status word to the host: 0 = every wait completed.
+ * kernel ahead of the persistent one); eamd_lstm_seq_status() copies its status word to the host: 0 = every wait completed
+ * (a wait that gives up after 3 s also writes NaN into that step's outputs, so a training step cannot pass silently; do not run two
+ * such launches concurrently on one device - each needs one workgroup per CU resident).
  * EAMD_EUNSUPPORTED when the shape does not fit (H % 64, B <= 64, one workgroup per CU for all jobs): run the jobs one
  * per call, or the per-step entry points.
  * reference: rnn/encoders.py:36-39,110-117 (torch.nn.LSTM, bidirectional, packed sequences). */
