@@ -328,7 +328,58 @@ __global__ void ctc_prefix_kernel(const float* __restrict__ logp, const float* _
   if (c == blank) lpsi = kLogZero;
   psi[(long)h * ncand + j] = lpsi;
 }
+// The same recursion for the hypotheses of SEVERAL utterances in one launch: hypothesis h belongs to utterance h / per_utt,
+// whose posteriors are logp[u] ([Tmax, V], lens[u] valid frames); r_prev / r_new rows are padded to Tmax (rows from lens[u] on
+// are never read).
+__global__ void ctc_prefix_batch_kernel(const float* __restrict__ logp_all, const int* __restrict__ lens, int per_utt,
+                                        const float* __restrict__ r_prev, const int* __restrict__ cand,
+                                        const int* __restrict__ last, const int* __restrict__ olen, float* __restrict__ psi,
+                                        float* __restrict__ r_new, int Tmax, int V, int ncand, int blank, int eos) {
+  const int j = blockIdx.x * blockDim.x + threadIdx.x;
+  const int h = blockIdx.y;
+  if (j >= ncand) return;
+  const int u = h / per_utt;
+  const int T = lens[u];
+  const float* logp = logp_all + (long)u * Tmax * V;
+  const int c = cand[(long)h * ncand + j];
+  const float* rp = r_prev + (long)h * Tmax * 2;
+  float* rn = r_new + ((long)h * ncand + j) * Tmax * 2;
+  const int ol = olen[h];
+  const bool same = ol > 0 && last[h] == c;
+  const int start = max(ol, 1);
+  for (int t = 0; t < min(start - 1, T); ++t) { rn[2 * t] = kLogZero; rn[2 * t + 1] = kLogZero; }
+  float rn_n, rn_b;
+  if (ol == 0) { rn_n = logp[c]; rn_b = kLogZero; }
+  else { rn_n = kLogZero; rn_b = kLogZero; }
+  if (start - 1 < T) { rn[2 * (start - 1)] = rn_n; rn[2 * (start - 1) + 1] = rn_b; }
+  float lpsi = rn_n;
+  for (int t = start; t < T; ++t) {
+    const float pn = rp[2 * (t - 1)], pb = rp[2 * (t - 1) + 1];
+    const float phi = same ? pb : lae(pn, pb);
+    const float x = logp[(long)t * V + c];
+    const float nn = lae(rn_n, phi) + x;
+    const float nb = lae(rn_n, rn_b) + logp[(long)t * V + blank];
+    lpsi = lae(lpsi, phi + x);
+    rn_n = nn; rn_b = nb;
+    rn[2 * t] = nn; rn[2 * t + 1] = nb;
+  }
+  if (c == eos) lpsi = lae(rp[2 * (T - 1)], rp[2 * (T - 1) + 1]);
+  if (c == blank) lpsi = kLogZero;
+  psi[(long)h * ncand + j] = lpsi;
+}
 }  // namespace
+
+extern "C" int eamd_ctc_prefix_score_batch(const float* logp, const int32_t* lens, int nutt, int per_utt, const float* r_prev,
+                                           const int32_t* cand, const int32_t* last, const int32_t* olen, float* psi,
+                                           float* r_new, int ncand, int Tmax, int V, int blank, int eos, void* stream) {
+  if (!logp || !lens || !r_prev || !cand || !last || !olen || !psi || !r_new || nutt <= 0 || per_utt <= 0 || ncand <= 0 ||
+      Tmax <= 0 || V <= 0)
+    return EAMD_EINVAL;
+  hipLaunchKernelGGL(ctc_prefix_batch_kernel, dim3((ncand + 63) / 64, nutt * per_utt), dim3(64), 0, (hipStream_t)stream, logp,
+                     lens, per_utt, r_prev, cand, last, olen, psi, r_new, Tmax, V, ncand, blank, eos);
+  EAMD_LAUNCH_CHECK();
+  return EAMD_OK;
+}
 
 extern "C" int eamd_ctc_prefix_score(const float* logp, const float* r_prev, const int32_t* cand, const int32_t* last,
                                      const int32_t* olen, float* psi, float* r_new, int nhyp, int ncand, int T, int V,

@@ -148,8 +148,8 @@ class TransformerDecoder(AbsDecoder, BatchScorerInterface):
     def batch_score(self, ys, states, xs):
         return self._dec[0].batch_score(ys, states, xs)
 
-    def score_tree(self, ys, tree, xs):
-        return self._dec[0].score_tree(ys, tree, xs)
+    def score_tree(self, ys, tree, xs, memory_mask=None):
+        return self._dec[0].score_tree(ys, tree, xs, memory_mask=memory_mask)
 
     def final_tree(self, tree):
         return 0.0

@@ -345,6 +345,170 @@ class BeamSearch(torch.nn.Module):
             return [] if minlenratio < 0.1 else self.forward(x, maxlenratio, max(0.0, minlenratio - 0.1))
         return nbest
 
+    def forward_batch(self, xs, maxlenratio=0.0, minlenratio=0.0):
+        """Several utterances in ONE search: xs = list of (T_b, D) encoder outputs -> list of n-best lists (what forward() returns for
+        each utterance alone).  B x beam slots share every launch of a beam step - one batch_score per scorer over all slots with the
+        padded frames of shorter utterances masked in the source attention, one CTC prefix-score launch for all utterances
+        (eamd_ctc_prefix_score_batch), one top-`beam` per utterance - and the host reads the step log once per `sync_every` steps,
+        replaying ended-hypothesis bookkeeping and end detection per utterance.  An utterance that has finished keeps its slots (dead)
+        until the last one finishes.  Falls back to one forward() per utterance when the scorers cannot keep batched states."""
+        from .. import ops
+        B = len(xs)
+        if B == 0:
+            return []
+        if B == 1 or not self._device_loop_ok(xs[0]) or minlenratio != 0.0:
+            return [self.forward(x, maxlenratio, minlenratio) for x in xs]
+        V, beam, dev = self.n_vocab, self.beam_size, xs[0].device
+        n = B * beam
+        Ts = [int(x.shape[0]) for x in xs]
+        Tmax = max(Ts)
+        maxlens = [T if maxlenratio == 0 else max(1, int(maxlenratio * T)) for T in Ts]
+        maxlen = max(maxlens)
+        NEG = -float("inf")
+        names = list(self.full_scorers.keys())
+        pname = next(iter(self.part_scorers), None)
+        ctc = self.part_scorers[pname] if pname is not None else None
+        allk = names + ([pname] if pname is not None else [])
+        xpad = torch.nn.utils.rnn.pad_sequence(list(xs), batch_first=True)                   # [B, Tmax, D]
+        lens_d = torch.tensor(Ts, dtype=torch.int32, device=dev)
+        xall = xpad.unsqueeze(1).expand(B, beam, Tmax, xpad.shape[-1]).reshape(n, Tmax, xpad.shape[-1])
+        mem_mask = (torch.arange(Tmax, device=dev)[None, :] < lens_d[:, None]).unsqueeze(1)    # [B, 1, Tmax]
+        mem_mask = mem_mask.unsqueeze(1).expand(B, beam, 1, Tmax).reshape(n, 1, Tmax)
+        uniform = all(T == Tmax for T in Ts)
+        import inspect
+        masked = {k for k, d in self.full_scorers.items() if "memory_mask" in inspect.signature(d.score_tree).parameters}
+        yseq = torch.full((n, maxlen + 2), self.eos, dtype=torch.int64, device=dev)
+        yseq[:, 0] = self.sos
+        hyp = torch.full((B, beam), NEG, device=dev, dtype=torch.float32)
+        hyp[:, 0] = 0.0
+        hyp = hyp.view(-1)
+        sc = {k: torch.zeros(n, device=dev, dtype=torch.float32) for k in allk}
+        trees = {k: None for k in names}
+        base = (torch.arange(B, device=dev) * beam).view(B, 1)
+        if ctc is not None:
+            with torch.no_grad():
+                logp = ctc.ctc.log_softmax(xpad).contiguous()                                 # [B, Tmax, V]
+            c_s = torch.zeros(n, device=dev, dtype=torch.float32)
+            r0 = torch.full((B, Tmax, 2), -10000000000.0, device=dev, dtype=torch.float32)
+            r0[:, :, 1] = torch.cumsum(logp[:, :, ctc.blank], 1)
+            c_r = r0.unsqueeze(1).expand(B, beam, Tmax, 2).reshape(n, Tmax, 2).contiguous()
+            last_idx = (lens_d.long() - 1).view(B, 1).expand(B, beam).reshape(n)                # last valid frame of each slot's utterance
+        maxlen_d = torch.tensor(maxlens, device=dev).view(B, 1)
+        ended = [[] for _ in range(B)]
+        stopped = [False] * B
+        pending = []
+
+        def flush():
+            nonlocal pending
+            if not pending:
+                return all(stopped)
+            host = torch.stack(pending).cpu()                   # [steps, n, 3 + len(allk) + maxlen + 2]
+            pending = []
+            for row in host:
+                i = int(row[0, 0])
+                slots = row.tolist()
+                for b in range(B):
+                    if stopped[b]:
+                        continue
+                    alive = 0
+                    for slot in slots[b * beam: (b + 1) * beam]:
+                        top_s = slot[1]
+                        if not math.isfinite(top_s):
+                            continue
+                        L = i + 2
+                        seq = [int(v) for v in slot[3 + len(allk): 3 + len(allk) + L]]
+                        if i == maxlens[b] - 1:
+                            seq.append(self.eos)
+                        if seq[-1] == self.eos:
+                            scores = {k: slot[3 + j] for j, k in enumerate(allk)}
+                            if self.apply_final_score:
+                                for k, d in chain(self.full_scorers.items(), self.part_scorers.items()):
+                                    f = float(d.final_tree(None)) if hasattr(d, "final_tree") else float(d.final_score(None))
+                                    scores[k] += f
+                                    top_s += self.weights[k] * f
+                            ended[b].append(Hypothesis(yseq=torch.tensor(seq, dtype=torch.int64), score=top_s, scores=scores, states={}))
+                        else:
+                            alive += 1
+                    if (maxlenratio == 0.0 and end_detect([h.asdict() for h in ended[b]], i)) or alive == 0 or i == maxlens[b] - 1:
+                        stopped[b] = True
+                if all(stopped):
+                    return True
+            return False
+
+        with torch.no_grad():
+            for i in range(maxlen):
+                L = i + 1
+                ys = yseq[:, :L]
+                weighted = torch.zeros(n, V, device=dev, dtype=torch.float32)
+                logps, newtrees = {}, {}
+                for k, d in self.full_scorers.items():
+                    if not uniform and k in masked:
+                        logps[k], newtrees[k] = d.score_tree(ys, trees[k], xall, memory_mask=mem_mask)
+                    else:
+                        logps[k], newtrees[k] = d.score_tree(ys, trees[k], xall)
+                    weighted += self.weights[k] * logps[k]
+                part_ids = None
+                if self.do_pre_beam:
+                    pre = weighted if self.pre_beam_score_key == "full" else logps[self.pre_beam_score_key]
+                    part_ids = torch.topk(pre, self.pre_beam_size, dim=-1)[1]
+                if ctc is not None:
+                    last = ys[:, -1].to(torch.int32).contiguous()
+                    olen = torch.full((n,), L - 1, dtype=torch.int32, device=dev)
+                    ids = part_ids if part_ids is not None else torch.arange(V, device=dev).unsqueeze(0).expand(n, V)
+                    psi, r_new = ops.ctc_prefix_score_batch(logp, lens_d, beam, c_r, ids.to(torch.int32).contiguous(), last, olen,
+                                                            ctc.blank, ctc.eos)
+                    if self.partial_mode == "full":
+                        full = torch.full((n, V), -10000000000.0, device=dev, dtype=torch.float32)
+                        full.scatter_(1, ids.long(), psi)
+                        full[:, ctc.eos] = torch.logsumexp(c_r[torch.arange(n, device=dev), last_idx], dim=-1)
+                        full[:, ctc.blank] = -10000000000.0
+                        idmap = torch.full((n, V), -1, dtype=torch.int64, device=dev)
+                        idmap.scatter_(1, ids.long(), torch.arange(ids.shape[1], device=dev).expand(n, -1))
+                        c_local = full - c_s[:, None]
+                        weighted += self.weights[pname] * c_local
+                    else:
+                        c_local = psi - c_s[:, None]
+                        if part_ids is not None:
+                            kept = torch.full_like(weighted, NEG)
+                            kept.scatter_(1, ids, torch.gather(weighted, 1, ids) + self.weights[pname] * c_local)
+                            weighted = kept
+                        else:
+                            weighted += self.weights[pname] * c_local
+                weighted += hyp[:, None]
+                top_s, top_i = weighted.view(B, beam * V).topk(beam, dim=1)
+                hyp_i = (top_i // V + base).view(-1)
+                tok_i = (top_i % V).view(-1)
+                top_s = top_s.reshape(-1)
+                for k in names:
+                    sc[k] = sc[k][hyp_i] + logps[k][hyp_i, tok_i]
+                    trees[k] = self._tree_index(newtrees[k], hyp_i)
+                if ctc is not None:
+                    if self.partial_mode == "full":
+                        sc[pname] = sc[pname][hyp_i] + c_local[hyp_i, tok_i]
+                        j = idmap[hyp_i, tok_i].clamp_min(0)
+                        c_s, c_r = full[hyp_i, tok_i], r_new[hyp_i, j]
+                    else:
+                        pos = (ids[hyp_i] == tok_i[:, None]).float().argmax(-1) if part_ids is not None else tok_i
+                        sc[pname] = sc[pname][hyp_i] + c_local[hyp_i, pos]
+                        c_s, c_r = psi[hyp_i, pos], r_new[hyp_i, pos]
+                yseq = yseq.index_select(0, hyp_i)
+                yseq[:, L] = tok_i
+                finite = torch.isfinite(top_s)
+                at_cap = (maxlen_d <= i + 1).expand(B, beam).reshape(-1)             # the utterance's own length cap: everything ends
+                done = finite & ((tok_i == self.eos) | at_cap)
+                rec = torch.cat([torch.full((n, 1), float(i), device=dev), top_s[:, None], tok_i[:, None].float()]
+                                + [sc[k][:, None] for k in allk] + [yseq.float()], dim=1)
+                pending.append(rec)
+                hyp = torch.where(done | ~finite, torch.full_like(top_s, NEG), top_s)
+                if len(pending) >= self.sync_every or i == maxlen - 1:
+                    if flush():
+                        break
+        out = []
+        for b in range(B):
+            nbest = sorted(ended[b], key=lambda h: float(h.score), reverse=True)
+            out.append(nbest)
+        return out
+
     def forward(self, x, maxlenratio=0.0, minlenratio=0.0):
         """x: (T, D) encoder output.  Returns the ended hypotheses, best first."""
         if self._device_loop_ok(x):

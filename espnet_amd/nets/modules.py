@@ -880,14 +880,14 @@ class Decoder(torch.nn.Module, BatchScorerInterface):
             x = F_.LinearFn.apply(x, self.output_layer.weight, self.output_layer.bias)
         return x, tgt_mask
 
-    def forward_one_step(self, tgt, tgt_mask, memory, cache=None):
-        """reference: decoder.py:283-321"""
+    def forward_one_step(self, tgt, tgt_mask, memory, cache=None, memory_mask=None):
+        """reference: decoder.py:283-321 (memory_mask [n, 1, T]: padded frames of a batch of utterances - batched beam search)"""
         x = self._embed(tgt)
         if cache is None:
             cache = [None] * len(self.decoders)
         new_cache = []
         for c, decoder in zip(cache, self.decoders):
-            x, tgt_mask, memory, memory_mask = decoder(x, tgt_mask, memory, None, cache=c)
+            x, tgt_mask, memory, memory_mask = decoder(x, tgt_mask, memory, memory_mask, cache=c)
             new_cache.append(x)
         y = x[:, -1]
         if self.normalize_before:
@@ -915,11 +915,11 @@ class Decoder(torch.nn.Module, BatchScorerInterface):
         logp, state = self.forward_one_step(ys.unsqueeze(0), ys_mask, x.unsqueeze(0), cache=state)
         return logp.squeeze(0), state
 
-    def score_tree(self, ys, tree, xs):
+    def score_tree(self, ys, tree, xs, memory_mask=None):
         """batch_score on a BATCHED state (list per layer of [n, L-1, D], or None): no per-hypothesis stacking / slicing;
         the search reorders it with index_select (BeamSearch device loop)"""
         ys_mask = subsequent_mask(ys.size(-1), device=xs.device).unsqueeze(0)
-        return self.forward_one_step(ys, ys_mask, xs, cache=tree)
+        return self.forward_one_step(ys, ys_mask, xs, cache=tree, memory_mask=memory_mask)
 
     def final_tree(self, tree):
         return 0.0

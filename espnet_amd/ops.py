@@ -1316,12 +1316,27 @@ def ctc_prefix_score(logp, r_prev, cand, last, olen, blank, eos):
     T, V = logp.shape
     nhyp, ncand = cand.shape
     assert r_prev.shape == (nhyp, T, 2) and cand.dtype == torch.int32 and logp.is_contiguous()
-    assert int(cand.max()) < V and int(cand.min()) >= 0
+    # (candidates come from top-k / arange over the V scores: in range by construction; checking would cost a host sync per beam step)
     psi = torch.empty(nhyp, ncand, device=logp.device, dtype=torch.float32)
     r_new = torch.empty(nhyp, ncand, T, 2, device=logp.device, dtype=torch.float32)
     check(_lib.lib().eamd_ctc_prefix_score(ptr(logp), ptr(r_prev.contiguous()), ptr(cand.contiguous()), ptr(last),
                                            ptr(olen), ptr(psi), ptr(r_new), nhyp, ncand, T, V, blank, eos,
                                            stream_ptr()), "eamd_ctc_prefix_score")
+    return psi, r_new
+
+
+def ctc_prefix_score_batch(logp, lens, per_utt, r_prev, cand, last, olen, blank, eos):
+    """the hypotheses of several utterances at once: logp [U,Tmax,V], lens [U] int32 (device), r_prev [U*per_utt,Tmax,2],
+    cand [U*per_utt,ncand] int32 -> psi [U*per_utt,ncand], r_new [U*per_utt,ncand,Tmax,2] (rows beyond an utterance's length: 0)"""
+    U, Tmax, V = logp.shape
+    nhyp, ncand = cand.shape
+    assert nhyp == U * per_utt and r_prev.shape == (nhyp, Tmax, 2) and cand.dtype == torch.int32 and logp.is_contiguous()
+    assert lens.dtype == torch.int32 and lens.numel() == U
+    psi = torch.empty(nhyp, ncand, device=logp.device, dtype=torch.float32)
+    r_new = torch.zeros(nhyp, ncand, Tmax, 2, device=logp.device, dtype=torch.float32)
+    check(_lib.lib().eamd_ctc_prefix_score_batch(ptr(logp), ptr(lens), U, per_utt, ptr(r_prev.contiguous()), ptr(cand.contiguous()),
+                                                 ptr(last), ptr(olen), ptr(psi), ptr(r_new), ncand, Tmax, V, blank, eos,
+                                                 stream_ptr()), "eamd_ctc_prefix_score_batch")
     return psi, r_new
 
 

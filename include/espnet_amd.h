@@ -434,6 +434,13 @@ int eamd_ctc_prefix_score(const float* logp, const float* r_prev, const int32_t*
                           const int32_t* olen, float* psi, float* r_new, int nhyp, int ncand, int T, int V,
                           int blank, int eos, void* stream);
 
+/* The same for the hypotheses of `nutt` utterances in one launch (batched beam search): hypothesis h belongs to utterance
+ * h / per_utt; logp [nutt, Tmax, V] with lens[u] valid frames; r_prev [nutt*per_utt, Tmax, 2], r_new [.., ncand, Tmax, 2]
+ * (rows from lens[u] on are neither read nor written).  reference: ctc_prefix_score.py:12-221 (CTCPrefixScoreTH). */
+int eamd_ctc_prefix_score_batch(const float* logp, const int32_t* lens, int nutt, int per_utt, const float* r_prev,
+                                const int32_t* cand, const int32_t* last, const int32_t* olen, float* psi, float* r_new,
+                                int ncand, int Tmax, int V, int blank, int eos, void* stream);
+
 /* ---- feature-side layers ----------------------------------------------
  * SpecAugment on a [B,T,F] batch (x != y).  reference: espnet2/asr/specaug/specaug.py:19-84,
  * espnet2/layers/time_warp.py:15-94 (bicubic F.interpolate along time, align_corners=False, of the segments left and

@@ -959,6 +959,39 @@ def test_decode_fusion_golden(tag, batch, lm, cw, lw):
             assert abs(float(a.scores[k]) - float(b.scores[k])) <= 1e-4 * max(1.0, abs(float(b.scores[k]))), k
 
 
+@pytest.mark.parametrize("batch,lm,cw,lw", [(False, None, 0.3, 0.0), (True, None, 0.3, 0.0), (True, "tlm", 0.3, 0.6),
+                                            (False, "rlm", 0.3, 0.6), (True, "dlm", 0.5, 0.4), (True, None, 0.0, 0.0)])
+def test_beam_search_batch_of_utterances(batch, lm, cw, lw):
+    """BeamSearch.forward_batch: several utterances of different lengths in ONE device-resident search (B x beam slots, the
+    shorter utterances' padded frames masked in the source attention, one CTC prefix-score launch for all) gives each
+    utterance the n-best its own search gives it: token sequences equal, scores to 1e-4."""
+    from espnet_amd.nets.batch_beam_search import BatchBeamSearch
+    from espnet_amd.nets.beam_search import BeamSearch
+    from espnet_amd.nets.ctc_prefix_score import CTCPrefixScorer, LengthBonus
+    p, model, lms = _fusion_models()
+    with torch.no_grad():
+        enc, _ = model.encode(p["speech"].unsqueeze(0).to(DEV), torch.tensor([p["speech"].shape[0]]))
+    x = enc[0]
+    T = x.shape[0]
+    utts = [x, x[: max(4, (2 * T) // 3)].contiguous(), (x[: max(3, T // 2)] * 1.5).contiguous(), x.flip(0).contiguous()]
+    scorers = dict(decoder=model.decoder, ctc=CTCPrefixScorer(model.ctc, model.eos) if cw > 0 else None, length_bonus=LengthBonus(30),
+                   lm=lms[lm] if lm else None)
+    cls = BatchBeamSearch if batch else BeamSearch
+    bs = cls(scorers, dict(decoder=1.0 - cw, ctc=cw, lm=lw, length_bonus=0.1), 4, 30, model.sos, model.eos,
+             pre_beam_score_key=None if cw in (0.0, 1.0) else "full")
+    assert bs._device_loop_ok(x)
+    for ratio in (0.0, 0.5):
+        alone = [bs(u, maxlenratio=ratio) for u in utts]
+        together = bs.forward_batch(utts, maxlenratio=ratio)
+        assert len(together) == len(utts)
+        for b, (a, t) in enumerate(zip(alone, together)):
+            assert [h.yseq.tolist() for h in t[:3]] == [h.yseq.tolist() for h in a[:3]], (ratio, b)
+            for ha, ht in zip(a[:3], t[:3]):
+                assert abs(float(ha.score) - float(ht.score)) <= 1e-4 * max(1.0, abs(float(ha.score))), (ratio, b)
+        print("[parity] forward_batch %s lm=%s ratio %.1f: %d utterances, best scores %s"
+              % (cls.__name__, lm, ratio, len(utts), [round(float(t[0].score), 4) for t in together]))
+
+
 def test_speech2text():
     """espnet2 inference surface: Speech2Text(model, lm) -> [(text, token, token_int, hyp)], BatchBeamSearch selected
     as in asr_inference.py:108-118; same n-best as the reference's search with these weights."""

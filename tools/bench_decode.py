@@ -110,9 +110,21 @@ def decode_leg(dev, c2_args, n_beam_utts=2, beam=10, ctc_weight=0.3, maxlenratio
         torch.cuda.synchronize()
         tot = time.perf_counter() - t0
         a_s = sum(ilens[:n_beam_utts]) * 0.01
+        # all 32 utterances in ONE search (forward_batch: 32 x beam slots share every launch of a beam step)
+        encs = [hs[b, : hl[b]].contiguous() for b in range(B)]
+        bs.forward_batch(encs[:4], maxlenratio=0.02)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        nb = bs.forward_batch(encs, maxlenratio=maxlenratio)
+        torch.cuda.synchronize()
+        tb = time.perf_counter() - t0
+        bsteps = max(1, int(maxlenratio * max(hl)))
+        batched = dict(utterances=B, utt_per_s=round(B / tb, 2), rtf=float("%.3e" % (tb / audio_s)), beam_steps=bsteps,
+                       ms_per_beam_step=round(tb / bsteps * 1e3, 3), hypotheses_found=[len(u) for u in nb][:4],
+                       note="BeamSearch.forward_batch: one device-resident search over all utterances")
         out[tag] = dict(beam=beam, ctc_weight=ctc_weight, maxlenratio=maxlenratio, utterances_timed=n_beam_utts,
                         utt_per_s=round(n_beam_utts / tot, 2), rtf=float("%.3e" % (tot / a_s)), beam_steps=steps,
-                        ms_per_beam_step=round(tot / steps * 1e3, 3), per_beam_step=counts,
+                        ms_per_beam_step=round(tot / steps * 1e3, 3), per_beam_step=counts, batched=batched,
                         note="encoder outputs precomputed (the greedy leg times the encoder); hypotheses, scores and scorer "
                              "states on the device, one device->host copy of the step log per sync_every steps")
 
