@@ -61,6 +61,48 @@ def test_struct_layout_matches_header():
     assert ctypes.sizeof(GemmT) % 8 == 0 and ctypes.sizeof(GemmT) >= 48 + 20 + 40 + 8 + 48 + 8 + 24 + 108 + 36
 
 
+def test_round3_struct_layouts_and_null_arguments():
+    """eamd_ffn_t / eamd_lstm_seq_*_t as ctypes sees them = as the header lays them out; the new entry points reject NULL
+    arguments before touching a device"""
+    from espnet_amd import _lib
+    assert ctypes.sizeof(_lib.FfnT) == 136                 # 9 pointers, 4 int32, 2 float, u64, float (+pad), u64, pointer, 2 int32
+    assert ctypes.sizeof(_lib.LstmSeqFwdT) == 8 * 8 + 8    # 8 pointers, 2 int32
+    assert ctypes.sizeof(_lib.LstmSeqBwdT) == 6 * 8 + 8    # 6 pointers, 2 int32
+    lib = _lib.lib()
+    assert lib.eamd_lstm_seq_sync_bytes() == 4096
+    assert lib.eamd_lstm_seq_fwd(None, 1, 4, 2, 64, None, None) < 0
+    assert lib.eamd_lstm_seq_bwd(None, 2, 4, 2, 64, None, None) < 0
+    assert lib.eamd_ffn_fwd(None, None) < 0 and lib.eamd_ffn_bwd(None, None) < 0
+    assert lib.eamd_ctc_prefix_score_batch(None, None, 1, 1, None, None, None, None, None, None, 1, 1, 1, 0, 1, None) < 0
+
+
+def test_zero_arena_host_logic():
+    """ops.zeros: torch.zeros until a step has been measured; then distinct 256-byte aligned slices of one fresh buffer per
+    begin (slices of an earlier step keep their own storage), torch.zeros again beyond the buffer and after zero_arena_off"""
+    import torch
+    from espnet_amd import ops
+    a = ops._zarena
+    a.cap, a.need, a.buf, a.active = 0, 0, None, False
+    ops.zero_arena_begin("cpu")
+    assert not a.active
+    x, y = ops.zeros(3, 5, device="cpu"), ops.zeros((7,), device="cpu")
+    assert x.shape == (3, 5) and y.shape == (7,) and a.need == 512
+    ops.zero_arena_begin("cpu")
+    assert a.active and a.cap >= 512
+    p, q = ops.zeros(3, 5, device="cpu"), ops.zeros((7,), device="cpu")
+    assert p.data_ptr() == a.buf.data_ptr() and q.data_ptr() - p.data_ptr() == 256
+    p += 1.0
+    big = ops.zeros(1 << 20, device="cpu")                  # beyond the buffer: an ordinary allocation
+    assert big.data_ptr() < a.buf.data_ptr() or big.data_ptr() >= a.buf.data_ptr() + a.cap
+    ops.zero_arena_begin("cpu")
+    r = ops.zeros(3, 5, device="cpu")
+    assert float(r.sum()) == 0.0 and float(p.sum()) == 15.0 and r.data_ptr() != p.data_ptr()   # the old slice lives on
+    ops.zero_arena_off()
+    z = ops.zeros(4, device="cpu")
+    assert a.buf is None and float(z.sum()) == 0.0
+    a.cap, a.need = 0, 0
+
+
 def test_product_path_has_no_cpu_fallback():
     import torch
     from espnet_amd import ops, _lib
