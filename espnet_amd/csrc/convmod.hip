@@ -627,9 +627,11 @@ __global__ __launch_bounds__(256) void conv1_fwd_kernel(const float* __restrict_
         }
         if (w0 + u < W) {
           const long oi = o + (long)(w0 + u) * C;
-          if (NC == 2) y32[oi >> 1] = (unsigned)eamd_f2bf(acc[0]) | ((unsigned)eamd_f2bf(acc[NC - 1]) << 16);
+          // the 320 / 640 MB result is written once and read by a later kernel: streaming (nt) stores keep it from
+          // evicting the working set in L2 (fp32: 184 -> 140 us = 0.44 -> 0.58 of the HBM rate)
+          if (NC == 2) __builtin_nontemporal_store((unsigned)eamd_f2bf(acc[0]) | ((unsigned)eamd_f2bf(acc[NC - 1]) << 16), &y32[oi >> 1]);
           else if (bf16) y16[oi] = eamd_f2bf(acc[0]);
-          else y[oi] = acc[0];
+          else __builtin_nontemporal_store(acc[0], &y[oi]);
         }
       }
     }
