@@ -44,6 +44,9 @@ __device__ unsigned long long ffn_stamps[2][2][8][8];
 
 bool eamd_ffn_bf16_ok(const eamd_ffn_t* p);                      // ffn_bf16.hip
 int eamd_ffn_bf16_launch(const eamd_ffn_t* p, int bwd, void* stream);
+bool eamd_ffn_f32_sym(int F);                                    // ffn_f32_sym.hip: the symmetric fp32 form (F % 256 == 0)
+int eamd_ffn_f32_sym_launch(const eamd_ffn_t* p, int bwd, void* stream);
+int eamd_ffn_f32_sym_pack(const float* w1, const float* w2, float* p0, float* p1, float* p2, float* p3, int F, void* stream);
 
 namespace {
 
@@ -455,6 +458,7 @@ extern "C" int eamd_ffn_pack_f32(const float* w1, const float* w2, float* fwd_fi
   for (const void* q : {(const void*)w1, (const void*)w2, (const void*)fwd_first, (const void*)fwd_second, (const void*)bwd_first,
                         (const void*)bwd_second})
     if (!al16(q)) return EAMD_EUNSUPPORTED;
+  if (eamd_ffn_f32_sym(F)) return eamd_ffn_f32_sym_pack(w1, w2, fwd_first, fwd_second, bwd_first, bwd_second, F, stream);
   const long npiece = (long)(F / FHC) * 8 * 4 * 4 * 64;
   hipLaunchKernelGGL(ffn_pack_f32_kernel, dim3((unsigned)((npiece + 255) / 256), 4), dim3(256), 0, (hipStream_t)stream, w1, w2,
                      fwd_first, fwd_second, bwd_first, bwd_second, F);
@@ -466,6 +470,7 @@ extern "C" int eamd_ffn_fwd(const eamd_ffn_t* p, void* stream) {
   const int rc = check_ffn(p, false);
   if (rc != EAMD_OK) return rc;
   if (p->dtype == 1) return eamd_ffn_bf16_launch(p, 0, stream);
+  if (eamd_ffn_f32_sym(p->F)) return eamd_ffn_f32_sym_launch(p, 0, stream);
   return p->act == EAMD_ACT_SWISH ? launch_ffn<false, EAMD_ACT_SWISH>(*p, (hipStream_t)stream)
                                   : launch_ffn<false, EAMD_ACT_RELU>(*p, (hipStream_t)stream);
 }
@@ -474,5 +479,6 @@ extern "C" int eamd_ffn_bwd(const eamd_ffn_t* p, void* stream) {
   const int rc = check_ffn(p, true);
   if (rc != EAMD_OK) return rc;
   if (p->dtype == 1) return eamd_ffn_bf16_launch(p, 1, stream);
+  if (eamd_ffn_f32_sym(p->F)) return eamd_ffn_f32_sym_launch(p, 1, stream);
   return launch_ffn<true, EAMD_ACT_NONE>(*p, (hipStream_t)stream);
 }
