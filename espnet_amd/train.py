@@ -518,6 +518,7 @@ class GraphedDataParallelStep:
         step_ms = timed(self.__call__)
         comp_ms = timed(compute_only)
         return dict(rccl_ranks=(dist.get_world_size(self.group) if on else 1),
+                    backend=(dist.get_backend(self.group) if on else "none"),      # "nccl" = RCCL over xGMI; "gloo" = a CPU rehearsal
                     phase_mbytes=[round((hi - lo) * 4 / 1e6, 1) for lo, hi in self.ranges],
                     allreduce_ms=[round(v, 3) for v in ar], allreduce_ms_total=round(sum(ar), 3),
                     step_ms=round(step_ms, 3), compute_only_ms=round(comp_ms, 3),
