@@ -294,7 +294,7 @@ def test_config2_fullsize_vs_oracle(oracle):
     kernels and shapes bench.py times - against the CPU oracle on the same weights and batch:
       * fp32 mode: total / CTC / attention loss rel <= 1e-5 (bar 1e-3), accuracy equal, min gradient cosine >= 0.9999,
         greedy-CTC argmax bit-exact on every frame whose oracle top-2 logit gap exceeds fp32 accumulation noise
-        (1e-4 of the logit scale), collapsed ids bit-exact for every utterance without such a near-tie frame;
+        (2e-5 of the logit scale; on the others only the oracle's runner-up is admissible), collapsed ids bit-exact for every utterance without such a near-tie frame;
       * bf16 mode (the fused attention / persistent GEMM dispatch): the three losses rel <= 1e-3, min gradient
         cosine >= 0.999."""
     import espnet_amd
@@ -337,12 +337,15 @@ def test_config2_fullsize_vs_oracle(oracle):
     gap = (top2.values[..., 0] - top2.values[..., 1]) / lg.abs().amax(dim=-1).clamp_min(1e-20)
     near_tie, frames, mism = 0, 0, 0
     for b in range(B):
-        clear = gap[b, : hl[b]] > 1e-4
+        clear = gap[b, : hl[b]] > 2e-5           # fp32 summation-order noise of a 256-term dot product is ~1e-6 of the logit scale
         frames += int(hl[b])
         near_tie += int((~clear).sum())
         same = am[b, : hl[b]] == top2.indices[b, : hl[b], 0]
         mism += int((~same).sum())
         assert bool(same[clear].all()), "greedy CTC argmax differs on a frame without a near-tie (utt %d)" % b
+        # on a near-tie frame the only admissible difference is the oracle's runner-up
+        swapped = am[b, : hl[b]] == top2.indices[b, : hl[b], 1]
+        assert bool((same | swapped).all()), "greedy CTC argmax outside the oracle's top two (utt %d)" % b
         if bool(clear.all()):
             assert ids[b, : int(n[b])].tolist() == oracle.greedy_ctc(lg[b, : hl[b]]), b
     print(f"[parity] config2 full size: greedy argmax equal on {frames - mism}/{frames} frames ({near_tie} near-tie frames)")
