@@ -32,9 +32,14 @@ constexpr int FBK = 32;
 
 template <int BM, int BN, bool TA, bool TB>
 struct SmemF {
-  static constexpr int LDA = TA ? BM + 4 : FBK + 4;     // floats per image row
+  // k-strided images [k][cols + pad], read with ds_read_b32 by lanes (col fr, k-group fq): the four fq groups are EQ k-rows
+  // apart (EQ = 4 for the 64x64 tile, 2 for 128x128), and the two groups of a 32-lane half must land 16 banks apart:
+  // EQ * (cols + pad) = 16 (mod 32) -> pad 4 at 64 columns, pad 8 at 128 (with pad 4 the 128-column image shifted by 8 banks:
+  // SQ_LDS_BANK_CONFLICT was a third of SQ_LDS_IDX_ACTIVE in the grouped weight-gradient launch)
+  static constexpr int KPAD_A = BM >= 128 ? 8 : 4, KPAD_B = BN >= 128 ? 8 : 4;
+  static constexpr int LDA = TA ? BM + KPAD_A : FBK + 4;     // floats per image row
   static constexpr int RA = TA ? FBK : BM;
-  static constexpr int LDB = TB ? BN + 4 : FBK + 4;
+  static constexpr int LDB = TB ? BN + KPAD_B : FBK + 4;
   static constexpr int RB = TB ? FBK : BN;
   static constexpr int OPS = 2 * (RA * LDA + RB * LDB);
   static constexpr int CT = BM * (BN + 4);
