@@ -564,7 +564,8 @@ def attn_core_bwd(dctx, P, qu, qv, k, v, p, B, T1, T2, H, dk, Pd=None, attn_drop
         # dp[j, h, :] = sum_{b,i} dbd[h, b, i, j] * qv[b, i, h, :]   (reduction over B*T1 rows, split-K)
         ops.gemm(dbd, qv, dpt, T2, dk, B * T1, ldp, D, ldd, transA=1, transB=1, batch=(1, H),
                  sA=(0, B * T1 * ldp), sB=(0, dk), sC=(0, dk), c_off=dp_off,
-                 splitk=max(2, ops.auto_splitk(T2, dk, B * T1) // H + 1))
+                 splitk=int(os.environ.get("EAMD_DPOS_SK", "0")) or max(2, ops.auto_splitk(T2, dk, B * T1) // 2))
+        # (measured at config 2, 4 tiles x 4 heads: split-K 9 -> 26.7 us, 16 -> 20.7 us, 24 -> 22.4, 32 -> 23.9)
     return dqu, dqv, dkk, dv, dp
 
 
