@@ -311,7 +311,7 @@ __global__ __launch_bounds__(WNWV * 64) void dwconv_bwd_w_kernel(const float* __
 // registers with all loads in flight, forms (n, mean, M2) there (exact two-pass, no re-read), and the
 // row-subgroups of the block are merged with Chan's update through LDS.  The finalize block merges the
 // slab partials the same way (fixed order => bitwise reproducible).
-constexpr int BN_R = 16;
+constexpr int BN_R = 4;
 struct BnGeom { int cq, rs, slab_rows; };
 __host__ __device__ inline BnGeom bn_geom(int C) {
   BnGeom g;
