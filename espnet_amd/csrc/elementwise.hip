@@ -625,7 +625,7 @@ int eamd_add_cast_colsum2(const float* a, const float* b, void* out_bf16, int64_
                             int64_t rows, int D, void* stream) {
   if (!a || !b || !out_bf16 || !suma || !sumb || rows <= 0 || D <= 0 || ld_out < D) return EAMD_EINVAL;
   if (D % 2 || D > 512 || ld_out % 2 || (((uintptr_t)a | (uintptr_t)b) & 7) || ((uintptr_t)out_bf16 & 3)) return EAMD_EUNSUPPORTED;
-  const int rpb = 64;
+  static const int rpb = [] { const char* e = getenv("EAMD_ACC_RPB"); return e ? atoi(e) : 64; }();
   hipLaunchKernelGGL(add_cast_colsum2_kernel<false>, dim3((unsigned)((rows + rpb - 1) / rpb)), dim3(256), 0, (hipStream_t)stream, a, b,
                      (unsigned int*)out_bf16, (long)ld_out, suma, sumb, (long)rows, D, rpb);
   EAMD_LAUNCH_CHECK();
@@ -636,7 +636,7 @@ int eamd_add_colsum2_f32(const float* a, const float* b, float* out, int64_t ld_
                          int D, void* stream) {
   if (!a || !b || !out || !suma || !sumb || rows <= 0 || D <= 0 || ld_out < D) return EAMD_EINVAL;
   if (D % 2 || D > 512 || ld_out % 2 || (((uintptr_t)a | (uintptr_t)b | (uintptr_t)out) & 7)) return EAMD_EUNSUPPORTED;
-  const int rpb = 64;
+  static const int rpb = [] { const char* e = getenv("EAMD_ACC_RPB"); return e ? atoi(e) : 64; }();
   hipLaunchKernelGGL(add_cast_colsum2_kernel<true>, dim3((unsigned)((rows + rpb - 1) / rpb)), dim3(256), 0, (hipStream_t)stream, a, b,
                      (unsigned int*)out, (long)ld_out, suma, sumb, (long)rows, D, rpb);
   EAMD_LAUNCH_CHECK();
