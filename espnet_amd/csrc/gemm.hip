@@ -376,10 +376,8 @@ int launch(const eamd_gemm_t& p, hipStream_t stream) {
 int eamd_gemm_bf16_dispatch(const eamd_gemm_t& p, int tile, hipStream_t stream);  // gemm_bf16.hip
 int eamd_gemm_f32_dispatch(const eamd_gemm_t& p, int tile, hipStream_t stream);   // gemm_f32.hip
 
-extern "C" int eamd_gemm(const eamd_gemm_t* pp, void* stream_) {
-  if (!pp) return EAMD_EINVAL;
-  eamd_gemm_t p = *pp;
-  hipStream_t stream = (hipStream_t)stream_;
+// argument validation and tile choice shared by eamd_gemm and eamd_gemm_multi (normalises p.splitk)
+static int gemm_check(eamd_gemm_t& p, int& tile_out) {
   const bool stats = p.epilogue == 7;          // row statistics instead of a result (eamd_gemm_t.stats)
   const bool rowgrad = p.epilogue == 8;        // softmax-gradient rows from per-row coefficients
   if (!p.A || !p.B || (!p.C && !p.Cb && !stats)) return EAMD_EINVAL;
@@ -441,6 +439,18 @@ extern "C" int eamd_gemm(const eamd_gemm_t* pp, void* stream_) {
   if (p.in_dtype != 1 && ((p.Hb && !(p.h_dtype == 1 && p.precision == 0)) || (p.drop_p != 0.f && p.precision != 0)))
     return EAMD_EUNSUPPORTED;
   if ((p.a_drop_p != 0.f || p.b_drop_p != 0.f) && (p.in_dtype != 0 || p.precision != 0)) return EAMD_EUNSUPPORTED;
+  tile_out = tile;
+  return EAMD_OK;
+}
+
+extern "C" int eamd_gemm(const eamd_gemm_t* pp, void* stream_) {
+  if (!pp) return EAMD_EINVAL;
+  eamd_gemm_t p = *pp;
+  hipStream_t stream = (hipStream_t)stream_;
+  int tile = 0;
+  const int chk = gemm_check(p, tile);
+  if (chk != EAMD_OK) return chk;
+  const bool stats = p.epilogue == 7, rowgrad = p.epilogue == 8;
   if (p.in_dtype == 1) return eamd_gemm_bf16_dispatch(p, tile, stream);
 
   // fp32 operands asked to go through the bf16 matrix cores (precision 1, bf16 mode's leftovers: activations a producer
@@ -464,6 +474,32 @@ extern "C" int eamd_gemm(const eamd_gemm_t* pp, void* stream_) {
     return p.precision ? launch<128, 128, 1>(p, stream) : launch<128, 128, 0>(p, stream);
   }
   return p.precision ? launch<64, 64, 1>(p, stream) : launch<64, 64, 0>(p, stream);
+}
+
+int eamd_gemm_f32_multi(const eamd_gemm_t* ps, const int* tiles, int n, hipStream_t stream);   // gemm_f32.hip
+
+extern "C" int eamd_gemm_multi(const eamd_gemm_t* descs, int n, void* stream) {
+  if (!descs || n < 1) return EAMD_EINVAL;
+  if (n >= 2 && n <= EAMD_GEMM_MULTI_MAX) {
+    eamd_gemm_t ps[EAMD_GEMM_MULTI_MAX];
+    int tiles[EAMD_GEMM_MULTI_MAX];
+    bool f32 = true;
+    for (int i = 0; i < n; ++i) {
+      ps[i] = descs[i];
+      const int chk = gemm_check(ps[i], tiles[i]);
+      if (chk != EAMD_OK) return chk;              // nothing has been launched yet
+      f32 = f32 && ps[i].in_dtype == 0 && ps[i].precision == 0;
+    }
+    if (f32) {
+      const int rc = eamd_gemm_f32_multi(ps, tiles, n, (hipStream_t)stream);
+      if (rc != EAMD_EUNSUPPORTED) return rc;
+    }
+  }
+  for (int i = 0; i < n; ++i) {
+    const int rc = eamd_gemm(&descs[i], stream);
+    if (rc != EAMD_OK) return rc;
+  }
+  return EAMD_OK;
 }
 
 int eamd_gemm_f32_group_count(const eamd_gemm_t& p);                                            // gemm_f32.hip

@@ -136,6 +136,29 @@ __device__ __forceinline__ void gemm_f32_body(const eamd_gemm_t& p, const int bi
     else b_off[i] = (long)b_r[i] * p.ldb + min(n0 + b_c[i] * 4, (p.N - 1) & ~3);
   }
   RowStateB a_rs[NCA];
+  // gathered A rows: everything the K loop needs of the descriptor is taken into scalar registers HERE.  A scalar load inside
+  // the loop (p.gather.dh[tap] once per tile, and - when the descriptor sits behind a run-time index, as in the
+  // eamd_gemm_multi kernel - every p.* the compiler may not speculate) is followed by s_waitcnt lgkmcnt(0), which also
+  // drains the wave's LDS reads: the tap offsets travel as 4-bit fields of two 64-bit scalars (host: -8 <= dh, dw <= 7).
+  unsigned long long dh_pack = 0ull, dw_pack = 0ull;
+  int gC = 1, gHin = 0, gWin = 0;
+  if constexpr (GAT && !TA) {
+#pragma unroll
+    for (int tp = 0; tp < 9; ++tp) {
+      dh_pack |= (unsigned long long)((unsigned)(p.gather.dh[tp] + 8) & 15u) << (4 * tp);
+      dw_pack |= (unsigned long long)((unsigned)(p.gather.dw[tp] + 8) & 15u) << (4 * tp);
+    }
+    gC = p.gather.C; gHin = p.gather.Hin; gWin = p.gather.Win;
+  }
+  const int pK = p.K;
+  const long ldaL = p.lda, ldbL = p.ldb;
+  auto tap_dh = [&](int tap) __attribute__((always_inline)) { return (int)((dh_pack >> (4 * tap)) & 15ull) - 8; };
+  auto tap_dw = [&](int tap) __attribute__((always_inline)) { return (int)((dw_pack >> (4 * tap)) & 15ull) - 8; };
+  auto goff = [&](const RowStateB& rs, int dh, int dw) __attribute__((always_inline)) -> long {   // gather_off_b on the local copies
+    const int hh = rs.ih + dh, ww = rs.jw + dw;
+    const bool ok = rs.ok && hh >= 0 && hh < gHin && ww >= 0 && ww < gWin;
+    return ok ? ((long)(rs.base + hh * gWin + ww)) * gC : -1L;
+  };
   // a convolution without padding (Conv2dSubsampling's second 3x3 / stride-2 layer: every tap of every output pixel lies
   // inside the source) needs no per-tile range check: offset = row base + a tap offset that is uniform over the workgroup
   constexpr bool g_nopad = NOPAD;         // checked on the host (gather_nopad): no tap of any output pixel leaves the source
@@ -189,17 +212,18 @@ __device__ __forceinline__ void gemm_f32_body(const eamd_gemm_t& p, const int bi
       if constexpr (!GAT) {
 #pragma unroll
         for (int i = 0; i < NCA; ++i) {
-          const int kk = (GUARD && k0 + a_c[i] * 4 >= p.K) ? -a_c[i] * 4 : k0;
+          const int kk = (GUARD && k0 + a_c[i] * 4 >= pK) ? -a_c[i] * 4 : k0;
           ra[SET][i] = *reinterpret_cast<const float4*>(A + a_off[i] + kk);
         }
       } else {
-        const int tap = k0 / p.gather.C, c0 = k0 % p.gather.C;
-        const int tappix = p.gather.dh[tap] * p.gather.Win + p.gather.dw[tap];                                // uniform
+        const int tap = k0 / gC, c0 = k0 - tap * gC;
+        const int dh = tap_dh(tap), dw = tap_dw(tap);                                                     // uniform
+        const int tappix = dh * gWin + dw;
 #pragma unroll
         for (int i = 0; i < NCA; ++i) {
           long off;
-          if (g_nopad) off = a_rs[i].ok ? (long)(a_rs[i].base + a_rs[i].ih * p.gather.Win + a_rs[i].jw + tappix) * p.gather.C : -1L;
-          else off = gather_off_b(p.gather, a_rs[i], tap);
+          if (g_nopad) off = a_rs[i].ok ? (long)(a_rs[i].base + a_rs[i].ih * gWin + a_rs[i].jw + tappix) * gC : -1L;
+          else off = goff(a_rs[i], dh, dw);
           ra[SET][i] = *reinterpret_cast<const float4*>(A + (off >= 0 ? off + c0 + a_c[i] * 4 : 0L));
         }
       }
@@ -207,8 +231,8 @@ __device__ __forceinline__ void gemm_f32_body(const eamd_gemm_t& p, const int bi
       if constexpr (!GAT) {
 #pragma unroll
         for (int i = 0; i < NCA; ++i) {
-          const int kk = (GUARD && k0 + a_r[i] >= p.K) ? -a_r[i] : k0;
-          ra[SET][i] = *reinterpret_cast<const float4*>(A + a_off[i] + (long)kk * p.lda);
+          const int kk = (GUARD && k0 + a_r[i] >= pK) ? -a_r[i] : k0;
+          ra[SET][i] = *reinterpret_cast<const float4*>(A + a_off[i] + (long)kk * ldaL);
         }
       } else {
         const int c = (m0 % p.gather.C) + a_c[0] * 4;
@@ -223,14 +247,14 @@ __device__ __forceinline__ void gemm_f32_body(const eamd_gemm_t& p, const int bi
     if constexpr (!TB) {
 #pragma unroll
       for (int i = 0; i < NCB; ++i) {
-        const int kk = (GUARD && k0 + b_c[i] * 4 >= p.K) ? -b_c[i] * 4 : k0;
+        const int kk = (GUARD && k0 + b_c[i] * 4 >= pK) ? -b_c[i] * 4 : k0;
         rb[SET][i] = *reinterpret_cast<const float4*>(B + b_off[i] + kk);
       }
     } else {
 #pragma unroll
       for (int i = 0; i < NCB; ++i) {
-        const int kk = (GUARD && k0 + b_r[i] >= p.K) ? -b_r[i] : k0;
-        rb[SET][i] = *reinterpret_cast<const float4*>(B + b_off[i] + (long)kk * p.ldb);
+        const int kk = (GUARD && k0 + b_r[i] >= pK) ? -b_r[i] : k0;
+        rb[SET][i] = *reinterpret_cast<const float4*>(B + b_off[i] + (long)kk * ldbL);
       }
     }
   };
@@ -240,24 +264,26 @@ __device__ __forceinline__ void gemm_f32_body(const eamd_gemm_t& p, const int bi
     constexpr bool GUARD = decltype(guard_c)::value;
     const int k0 = kt * FBK;
     if constexpr (GAT) {   // gathered rows are either fully valid or fully zero (padding taps / row tail)
+      int sdh = 0, sdw = 0;
+      if constexpr (!TA && !g_nopad) { const int tap = k0 / gC; sdh = tap_dh(tap); sdw = tap_dw(tap); }
 #pragma unroll
       for (int i = 0; i < NCA; ++i) {
         bool ok;
-        if constexpr (!TA) ok = g_nopad ? a_rs[i].ok != 0 : gather_off_b(p.gather, a_rs[i], k0 / p.gather.C) >= 0;
+        if constexpr (!TA) ok = g_nopad ? a_rs[i].ok != 0 : goff(a_rs[i], sdh, sdw) >= 0;
         else ok = sm.poff[kt % 8][a_r[i]] >= 0;
         ra[SET][i] = mask4(ra[SET][i], ok ? 4 : 0);
       }
     }
     if constexpr (GUARD) {
-      if (k0 + FBK > p.K) {      // ragged last K-tile: zero the out-of-range reduction elements
+      if (k0 + FBK > pK) {      // ragged last K-tile: zero the out-of-range reduction elements
         if constexpr (!GAT) {
 #pragma unroll
           for (int i = 0; i < NCA; ++i)
-            ra[SET][i] = mask4(ra[SET][i], TA ? ((k0 + a_r[i]) < p.K ? 4 : 0) : p.K - (k0 + a_c[i] * 4));
+            ra[SET][i] = mask4(ra[SET][i], TA ? ((k0 + a_r[i]) < pK ? 4 : 0) : pK - (k0 + a_c[i] * 4));
         }
 #pragma unroll
         for (int i = 0; i < NCB; ++i)
-          rb[SET][i] = mask4(rb[SET][i], TB ? ((k0 + b_r[i]) < p.K ? 4 : 0) : p.K - (k0 + b_c[i] * 4));
+          rb[SET][i] = mask4(rb[SET][i], TB ? ((k0 + b_r[i]) < pK ? 4 : 0) : pK - (k0 + b_c[i] * 4));
       }
     }
     float* la = sm.a(buf);
@@ -545,6 +571,35 @@ __global__ __launch_bounds__(NT_, 2) void gemm_f32_group_kernel(const eamd_gemm_
   gemm_f32_body<BM, BN, TA, TB, false, false>(p, (int)blockIdx.x - first[lo], -(first[lo + 1] - first[lo]), 0);
 }
 
+// Several independent implicit-convolution products in ONE launch (eamd_gemm_multi): the stride-parity classes of a strided
+// convolution's input gradient are four x W^T products of 4, 2, 2 and 1 taps over the same rows; launched one after another
+// each ends in a partly filled last tile round (2366 tiles = 4.6 rounds of 512) and a launch gap.  The problems follow each
+// other inside one grid (groups of 8 workgroups, one per XCD, so that id & 7 stays the XCD inside a problem): config 2,
+// 2003 -> 1890 us.  Dealing the groups to the problems in turn instead (EAMD_GEMM_MULTI_ORDER=0: tiles of all reduction
+// lengths resident together, stores of one under the main loop of another) was much SLOWER, 3130 us: the four weight
+// images (2.4 MB) and four result streams then compete for each XCD's 4 MB of L2.
+struct MultiF {
+  eamd_gemm_t p[EAMD_GEMM_MULTI_MAX];
+  int nt[EAMD_GEMM_MULTI_MAX];
+  int n, order;
+};
+
+template <int BM, int BN, bool TA, bool TB, bool GAT, bool NOPAD>
+__global__ __launch_bounds__(NT_, 2) void gemm_f32_multi_kernel(const MultiF m) {
+  const int g = (int)blockIdx.x >> 3;
+  int cls, bid;
+  if (m.order == 0) {
+    cls = g % m.n;
+    bid = (g / m.n) * 8 + ((int)blockIdx.x & 7);
+  } else {
+    const int per = (int)gridDim.x / (8 * m.n);
+    cls = g / per;
+    bid = (g - cls * per) * 8 + ((int)blockIdx.x & 7);
+  }
+  if (bid >= m.nt[cls]) return;            // this problem has fewer tiles than the largest one of the launch
+  gemm_f32_body<BM, BN, TA, TB, GAT, false, false, NOPAD>(m.p[cls], bid, m.nt[cls], 0);
+}
+
 template <int BM, int BN, bool TA, bool TB, bool GAT, bool ACT, bool NOPAD = false>
 int launch_f2(const eamd_gemm_t& p, hipStream_t stream) {
   dim3 grid(((p.M + BM - 1) / BM) * ((p.N + BN - 1) / BN) * p.splitk, 1, p.batch1 * p.batch2);
@@ -579,6 +634,13 @@ int launch_f2(const eamd_gemm_t& p, hipStream_t stream) {
 inline bool gather_nopad(const eamd_gather_t& g) {
   for (int tp = 0; tp < g.ntap; ++tp)
     if (g.dh[tp] < 0 || (g.Ho - 1) * g.sh + g.dh[tp] >= g.Hin || g.dw[tp] < 0 || (g.Wo - 1) * g.sw + g.dw[tp] >= g.Win) return false;
+  return true;
+}
+
+// gathered A rows (not the transposed gather): the kernel keeps the tap offsets as 4-bit fields
+inline bool gather_taps_small(const eamd_gather_t& g) {
+  for (int tp = 0; tp < g.ntap; ++tp)
+    if (g.dh[tp] < -8 || g.dh[tp] > 7 || g.dw[tp] < -8 || g.dw[tp] > 7) return false;
   return true;
 }
 
@@ -626,6 +688,7 @@ int eamd_gemm_f32_dispatch(const eamd_gemm_t& p, int tile, hipStream_t stream) {
     const eamd_gather_t& g = p.gather;
     if (g.C % FBK != 0 || !p.transB || !aligned16f(p.A) || !b_ok) return EAMD_EUNSUPPORTED;
     if (p.a_act != EAMD_ACT_NONE || p.b_act != EAMD_ACT_NONE) return EAMD_EUNSUPPORTED;
+    if (!p.transA && !gather_taps_small(g)) return EAMD_EUNSUPPORTED;       // tap offsets travel as 4-bit fields
     if (p.transA && g.C % tile != 0) return EAMD_EUNSUPPORTED;
     if (tile == 128)
       return p.transA ? launch_f<128, 128, true, true, true>(p, stream) : launch_f<128, 128, false, true, true>(p, stream);
@@ -633,6 +696,51 @@ int eamd_gemm_f32_dispatch(const eamd_gemm_t& p, int tile, hipStream_t stream) {
   }
   if (!a_ok || !b_ok) return EAMD_EUNSUPPORTED;
   return tile == 128 ? dispatch_layout_f<128>(p, stream) : dispatch_layout_f<64>(p, stream);
+}
+
+// ---- several implicit-convolution products in one launch (eamd_gemm_multi, fp32 operands) ----
+// ps[i] have passed eamd_gemm's argument validation; tiles[i] is the tile eamd_gemm would pick.  EAMD_EUNSUPPORTED: the caller
+// launches them one by one.
+template <bool NOPAD>
+static int multi_launch_t(const MultiF& m, int grid, hipStream_t stream) {
+  constexpr size_t smem = sizeof(SmemF<128, 128, false, true>);
+  static const hipError_t attr_err = hipFuncSetAttribute(
+      reinterpret_cast<const void*>(&gemm_f32_multi_kernel<128, 128, false, true, true, NOPAD>),
+      hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+  if (attr_err != hipSuccess) return (int)attr_err;
+  hipLaunchKernelGGL((gemm_f32_multi_kernel<128, 128, false, true, true, NOPAD>), dim3((unsigned)grid), dim3(NT_), smem, stream, m);
+  EAMD_LAUNCH_CHECK();
+  return EAMD_OK;
+}
+
+int eamd_gemm_f32_multi(const eamd_gemm_t* ps, const int* tiles, int n, hipStream_t stream) {
+  static const int on = [] { const char* e = getenv("EAMD_GEMM_MULTI"); return e ? atoi(e) : 1; }();
+  if (!on || n < 2 || n > EAMD_GEMM_MULTI_MAX) return EAMD_EUNSUPPORTED;
+  MultiF m;
+  bool nopad = true;
+  int maxnt = 0;
+  for (int i = 0; i < n; ++i) {
+    const eamd_gemm_t& p = ps[i];
+    if (tiles[i] != 128 || p.in_dtype != 0 || p.precision != 0) return EAMD_EUNSUPPORTED;
+    if (!p.gather.enabled || p.transA || !p.transB || p.splitk != 1 || p.batch1 * p.batch2 != 1) return EAMD_EUNSUPPORTED;
+    if (!p.C || p.Cb || p.Hb || p.aux_dtype || p.epilogue > 5 || p.colsum) return EAMD_EUNSUPPORTED;
+    if (p.a_act != EAMD_ACT_NONE || p.b_act != EAMD_ACT_NONE || p.drop_p != 0.f || p.a_drop_p != 0.f || p.b_drop_p != 0.f)
+      return EAMD_EUNSUPPORTED;
+    const bool b_ok = aligned16f(p.B) && p.ldb % 4 == 0 && p.ldb >= (p.N + 3) / 4 * 4;
+    if (p.gather.C % FBK != 0 || !aligned16f(p.A) || !b_ok || !gather_taps_small(p.gather)) return EAMD_EUNSUPPORTED;
+    const long nt = (long)((p.M + 127) / 128) * ((p.N + 127) / 128);
+    if (nt > (1L << 24)) return EAMD_EUNSUPPORTED;
+    nopad = nopad && gather_nopad(p.gather);
+    m.p[i] = p;
+    m.nt[i] = (int)nt;
+    maxnt = nt > maxnt ? (int)nt : maxnt;
+  }
+  for (int i = n; i < EAMD_GEMM_MULTI_MAX; ++i) { m.p[i] = ps[0]; m.nt[i] = 0; }
+  m.n = n;
+  static const int order = [] { const char* e = getenv("EAMD_GEMM_MULTI_ORDER"); return e ? atoi(e) : 1; }();
+  m.order = order;
+  const int grid = (maxnt + 7) / 8 * 8 * n;
+  return nopad ? multi_launch_t<true>(m, grid, stream) : multi_launch_t<false>(m, grid, stream);
 }
 
 // ---- grouped weight-gradient launch (fp32 operands) ----

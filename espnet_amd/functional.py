@@ -1022,9 +1022,10 @@ def _conv3s2_bwd(dy, y_in, wd, dw_buf, db_buf, B, Hi, Wi, Ho, Wo, Cc, adt):
     sk = max(2, min(64, (want + ntile - 1) // ntile, max(1, M // 256)))
     ops.gemm(y_in, dy, dwf, 9 * Cc, Cc, M, 9 * Cc, Cc, Cc, transA=1, transB=1, gather=g, splitk=sk, tile=tile)
     ops.conv2_weight_grad(dwf, dw_buf, Cc, Cc)
-    # input gradient, one implicit GEMM per stride-parity class
+    # input gradient, one implicit GEMM per stride-parity class; the classes write disjoint rows of dy_in and leave together
+    # (ops.gemm_multi: one launch in fp32 mode)
     dy_in = torch.empty(y_in.shape, device=dev, dtype=adt)
-    q0 = 0
+    q0, classes = 0, []
     for (ph, pw), taps in _CLASSES:
         Hc, Wc = (Hi - ph + 1) // 2, (Wi - pw + 1) // 2
         if Hc > 0 and Wc > 0:
@@ -1032,8 +1033,9 @@ def _conv3s2_bwd(dy, y_in, wd, dw_buf, db_buf, B, Hi, Wi, Ho, Wo, Cc, adt):
             cm = ops.make_rowmap(Hc, Wc, Hi, Wi, 2, ph, 2, pw)
             nt = len(taps)
             ops.gemm(dy, wd, dy_in, B * Hc * Wc, Cc, nt * Cc, nt * Cc, Cc, Cc, transB=1, b_off=q0 * Cc * Cc,
-                     gather=gt, cmap=cm, epilogue=EPI_MUL_RELU_MASK, aux=y_in, ldaux=Cc)
+                     gather=gt, cmap=cm, epilogue=EPI_MUL_RELU_MASK, aux=y_in, ldaux=Cc, defer=classes)
         q0 += len(taps)
+    ops.gemm_multi(classes)
     return dy_in
 
 
@@ -1087,7 +1089,7 @@ def _conv_ks_bwd(dy, y_in, wd, dw_buf, db_buf, B, Hi, Wi, Ho, Wo, Cc, adt, k, st
             classes.append(((ph, pw), ct))
             order += [kh * k + kw for kh, kw in ct]
     wd_cls = wd.index_select(0, torch.tensor(order, device=dev)).contiguous()          # class-ordered taps (data movement)
-    q0 = 0
+    q0, jobs = 0, []
     for (ph, pw), ct in classes:
         Hc, Wc = (Hi - ph + st - 1) // st, (Wi - pw + st - 1) // st
         if Hc > 0 and Wc > 0 and ct:
@@ -1095,8 +1097,9 @@ def _conv_ks_bwd(dy, y_in, wd, dw_buf, db_buf, B, Hi, Wi, Ho, Wo, Cc, adt, k, st
             cm = ops.make_rowmap(Hc, Wc, Hi, Wi, st, ph, st, pw)
             nt = len(ct)
             ops.gemm(dy, wd_cls, dy_in, B * Hc * Wc, Cc, nt * Cc, nt * Cc, Cc, Cc, transB=1, b_off=q0 * Cc * Cc,
-                     gather=gt, cmap=cm, epilogue=EPI_MUL_RELU_MASK, aux=y_in, ldaux=Cc)
+                     gather=gt, cmap=cm, epilogue=EPI_MUL_RELU_MASK, aux=y_in, ldaux=Cc, defer=jobs)
         q0 += len(ct)
+    ops.gemm_multi(jobs)
     return dy_in
 
 

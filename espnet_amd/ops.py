@@ -145,9 +145,11 @@ _gemm_record = None
 def gemm(A, B, Cm, M, N, K, lda, ldb, ldc, *, transA=0, transB=0, bias=None, aux=None, ldaux=0, R=None,
          ldr=0, batch=(1, 1), sA=(0, 0), sB=(0, 0), sC=(0, 0), alpha=1.0, beta=0.0, a_act=0, b_act=0,
          epilogue=0, splitk=1, tile=0, gather=None, cmap=None, a_off=0, b_off=0, c_off=0, precision=None,
-         colsum=None, Cb=None, drop=None, Hb=None, h_act=0, a_drop=None, b_drop=None, group=False, stats=None):
+         colsum=None, Cb=None, drop=None, Hb=None, h_act=0, a_drop=None, b_drop=None, group=False, stats=None, defer=None):
     """A, B: both float32 or both bfloat16 (bf16 operands select the fast MFMA kernel).
     Cm: float32 result, or bfloat16 result (then no fp32 copy is written); Cb: extra bf16 copy.
+    defer=list: the checked descriptor is appended to the list instead of being launched; gemm_multi(list) then issues
+    all of them together (eamd_gemm_multi: independent products, e.g. the parity classes of a strided convolution's dX).
     group=True (weight gradients): while wgrad_group_begin() is in effect the launch is queued and leaves with all other
     queued ones as ONE grouped launch at wgrad_join() (eamd_gemm_group_*), if the library accepts it for that."""
     bf = A.dtype == torch.bfloat16
@@ -255,10 +257,31 @@ def gemm(A, B, Cm, M, N, K, lda, ldb, ldc, *, transA=0, transB=0, bias=None, aux
         _wgroup["ranges"].append((lo, hi, splitk))
         _wgroup["bytes"] += nbytes
         return
+    if defer is not None:
+        defer.append((p, (A, B, Cm, bias, aux, R, colsum, Cb, Hb, stats)))
+        return
     if _gemm_record is not None:
         _gemm_record.append((p, (A, B, Cm, bias, aux, R, colsum, Cb, Hb, stats),
                              lambda sp, p=p: check(_lib.lib().eamd_gemm(C.byref(p), sp), "eamd_gemm")))
     check(_lib.lib().eamd_gemm(C.byref(p), stream_ptr()), "eamd_gemm")
+
+
+GEMM_MULTI_MAX = 4
+
+
+def gemm_multi(items):
+    """issue the products collected with gemm(..., defer=items) together: up to GEMM_MULTI_MAX per eamd_gemm_multi call (one
+    launch where the library has a kernel for the combination, otherwise one launch each, in order)"""
+    L = _lib.lib()
+    for i0 in range(0, len(items), GEMM_MULTI_MAX):
+        part = items[i0:i0 + GEMM_MULTI_MAX]
+        arr = (GemmT * len(part))(*[it[0] for it in part])
+        n = len(part)
+        if _gemm_record is not None:
+            _gemm_record.append((dict(kind="multi%d" % n, flop=sum(2.0 * it[0].M * it[0].N * it[0].K for it in part)),
+                                 (arr, [it[1] for it in part]),
+                                 lambda sp, arr=arr, n=n: check(L.eamd_gemm_multi(arr, n, sp), "eamd_gemm_multi")))
+        check(L.eamd_gemm_multi(arr, n, stream_ptr()), "eamd_gemm_multi")
 
 
 # ---- grouped weight-gradient launches ------------------------------------------------------------

@@ -125,6 +125,16 @@ typedef struct {
 
 int eamd_gemm(const eamd_gemm_t* p, void* stream);
 
+/* Up to EAMD_GEMM_MULTI_MAX INDEPENDENT products (no result of one is an operand or overlaps a result of another) issued
+ * together: the stride-parity classes of a strided convolution's input gradient (reference: the autograd of
+ * transformer/subsampling.py:28-35's second Conv2d) are implicit products of 1 - 4 taps over the same rows, and one launch
+ * whose workgroups are dealt to the problems in turn keeps tiles of all reduction lengths resident together.  Every
+ * descriptor is validated as eamd_gemm validates it BEFORE anything is launched.  One launch when all are fp32-operand,
+ * precision 0, gathered x W^T products on the 128 x 128 tile (splitk 1, batch 1, epilogue <= 5, no dropout, no second
+ * output); any other combination runs as n eamd_gemm calls in order.  Results are those of the separate calls, bit for bit. */
+#define EAMD_GEMM_MULTI_MAX 4
+int eamd_gemm_multi(const eamd_gemm_t* descs, int n, void* stream);
+
 /* Grouped launch of independent weight-gradient GEMMs (the dW_i += alpha dY_i^T X_i of one backward pass - reference:
  * the autograd of every nn.Linear on the path, e.g. transformer/attention.py:30-33 - each too small to fill the chip on
  * its own): ONE kernel whose workgroups look their problem up in a device-resident table.

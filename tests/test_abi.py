@@ -74,6 +74,10 @@ def test_round3_struct_layouts_and_null_arguments():
     assert lib.eamd_lstm_seq_bwd(None, 2, 4, 2, 64, None, None) < 0
     assert lib.eamd_ffn_fwd(None, None) < 0 and lib.eamd_ffn_bwd(None, None) < 0
     assert lib.eamd_ctc_prefix_score_batch(None, None, 1, 1, None, None, None, None, None, None, 1, 1, 1, 0, 1, None) < 0
+    # eamd_gemm_multi validates every descriptor before it launches anything: NULL table, n < 1, and a descriptor without operands
+    assert lib.eamd_gemm_multi(None, 2, None) < 0
+    arr = (_lib.GemmT * 2)()
+    assert lib.eamd_gemm_multi(arr, 0, None) < 0 and lib.eamd_gemm_multi(arr, 2, None) < 0
 
 
 def test_zero_arena_host_logic():

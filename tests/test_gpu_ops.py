@@ -1469,3 +1469,41 @@ def test_ffn_fused_bf16_vs_float64(ops, M, F, act, p_in, p_out):
         report("ffn fused dx " + tag, dx, dz.double().cpu() @ w1.double(), 2e-5)
     finally:
         espnet_amd.set_precision("fp32")
+
+
+@pytest.mark.parametrize("shape", [(8, 199, 39, 256), (2, 29, 19, 64), (3, 257, 39, 128)])
+@pytest.mark.parametrize("prec", ["fp32", "bf16"])
+def test_conv2_input_gradient_classes_in_one_launch(ops, shape, prec):
+    """eamd_gemm_multi: the four stride-parity products of Conv2dSubsampling's second convolution issued together are, bit for
+    bit, the four eamd_gemm launches (first shape: the one-launch fp32 kernel; the others and bf16 operands: the library's own
+    one-by-one route), and equal conv2d's input gradient in float64.  reference: transformer/subsampling.py:28-35"""
+    import espnet_amd
+    from espnet_amd import functional as Fn
+    B, Hi, Wi, Cc = shape
+    espnet_amd.set_precision(prec)
+    try:
+        adt = torch.bfloat16 if prec == "bf16" else torch.float32
+        g = torch.Generator().manual_seed(5)
+        Ho, Wo = (Hi - 3) // 2 + 1, (Wi - 3) // 2 + 1
+        w = (torch.randn(Cc, Cc, 3, 3, generator=g) / (3.0 * Cc ** 0.5)).to(DEV)
+        y_in = torch.relu(torch.randn(B * Hi * Wi, Cc, generator=g)).to(DEV).to(adt)
+        dy = torch.randn(B * Ho * Wo, Cc, generator=g).to(DEV).to(adt)
+        _wf, wd = ops.conv2_weight_prep(w, adt)
+
+        def run(per_call):
+            keep, ops.GEMM_MULTI_MAX = ops.GEMM_MULTI_MAX, per_call
+            try:
+                dw, db = torch.zeros(Cc, Cc, 3, 3, device=DEV), torch.zeros(Cc, device=DEV)
+                return Fn._conv3s2_bwd(dy, y_in, wd, dw, db, B, Hi, Wi, Ho, Wo, Cc, adt), dw
+            finally:
+                ops.GEMM_MULTI_MAX = keep
+        (d4, dw4), (d1, dw1) = run(4), run(1)
+        (d3, _dw3) = run(3)                                  # 3 + 1: a launch of three problems, then a single one
+        torch.cuda.synchronize()
+        assert torch.equal(d4, d1) and torch.equal(d3, d1)
+        ref = torch.nn.grad.conv2d_input((B, Cc, Hi, Wi), w.double().cpu(),
+                                         dy.double().cpu().view(B, Ho, Wo, Cc).permute(0, 3, 1, 2), stride=2)
+        ref = ref.permute(0, 2, 3, 1).reshape(B * Hi * Wi, Cc) * (y_in.double().cpu() > 0)
+        report("conv2 dX classes %s %s" % (shape, prec), d4, ref, 2e-5 if prec == "fp32" else 1e-2)
+    finally:
+        espnet_amd.set_precision("fp32")
