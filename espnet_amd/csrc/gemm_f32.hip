@@ -142,7 +142,7 @@ __device__ __forceinline__ void gemm_f32_body(const eamd_gemm_t& p, const int bi
   // drains the wave's LDS reads: the tap offsets travel as 4-bit fields of two 64-bit scalars (host: -8 <= dh, dw <= 7).
   unsigned long long dh_pack = 0ull, dw_pack = 0ull;
   int gC = 1, gHin = 0, gWin = 0;
-  if constexpr (GAT && !TA) {
+  if constexpr (GAT) {
 #pragma unroll
     for (int tp = 0; tp < 9; ++tp) {
       dh_pack |= (unsigned long long)((unsigned)(p.gather.dh[tp] + 8) & 15u) << (4 * tp);
@@ -189,16 +189,18 @@ __device__ __forceinline__ void gemm_f32_body(const eamd_gemm_t& p, const int bi
   const bool do_colsum = TA && p.colsum != nullptr && !GAT && tile_n == 0;
   float cs[4] = {0.f, 0.f, 0.f, 0.f};
 
+  const int gWo = GAT ? p.gather.Wo : 1, gHo = GAT ? p.gather.Ho : 1, gsh = GAT ? p.gather.sh : 0, gsw = GAT ? p.gather.sw : 0;
+  const int ta_tap = (GAT && TA) ? m0 / gC : 0;                      // transposed gather: one tap per M-tile
+  const int ta_dh = tap_dh(ta_tap), ta_dw = tap_dw(ta_tap);
   auto fill_poff = [&](int kt, int slot) __attribute__((always_inline)) {      // called for kt_begin, kt_begin + 1, ... in order
     if (t < FBK) {
-      const int tap = m0 / p.gather.C;
       RowStateB s;
-      s.ok = pr_row < p.K;
-      s.base = pr_b * p.gather.Hin * p.gather.Win; s.ih = pr_i * p.gather.sh; s.jw = pr_j * p.gather.sw;
-      sm.poff[slot][t] = (int)gather_off_b(p.gather, s, tap);
+      s.ok = pr_row < pK;
+      s.base = pr_b * gHin * gWin; s.ih = pr_i * gsh; s.jw = pr_j * gsw;
+      sm.poff[slot][t] = (int)goff(s, ta_dh, ta_dw);
       pr_row += FBK; pr_j += FBK;
-      while (pr_j >= p.gather.Wo) { pr_j -= p.gather.Wo; ++pr_i; }
-      while (pr_i >= p.gather.Ho) { pr_i -= p.gather.Ho; ++pr_b; }
+      while (pr_j >= gWo) { pr_j -= gWo; ++pr_i; }
+      while (pr_i >= gHo) { pr_i -= gHo; ++pr_b; }
     }
   };
 
@@ -235,7 +237,7 @@ __device__ __forceinline__ void gemm_f32_body(const eamd_gemm_t& p, const int bi
           ra[SET][i] = *reinterpret_cast<const float4*>(A + a_off[i] + (long)kk * ldaL);
         }
       } else {
-        const int c = (m0 % p.gather.C) + a_c[0] * 4;
+        const int c = (m0 % gC) + a_c[0] * 4;
         const int slot = kt % 8;
 #pragma unroll
         for (int i = 0; i < NCA; ++i) {
@@ -597,7 +599,8 @@ __global__ __launch_bounds__(NT_, 2) void gemm_f32_multi_kernel(const MultiF m) 
     bid = (g - cls * per) * 8 + ((int)blockIdx.x & 7);
   }
   if (bid >= m.nt[cls]) return;            // this problem has fewer tiles than the largest one of the launch
-  gemm_f32_body<BM, BN, TA, TB, GAT, false, false, NOPAD>(m.p[cls], bid, m.nt[cls], 0);
+  const eamd_gemm_t p = m.p[cls];          // wave-uniform copy: scalar loads up front, none inside the tile
+  gemm_f32_body<BM, BN, TA, TB, GAT, false, false, NOPAD>(p, bid, m.nt[cls], 0);
 }
 
 template <int BM, int BN, bool TA, bool TB, bool GAT, bool ACT, bool NOPAD = false>
@@ -637,7 +640,7 @@ inline bool gather_nopad(const eamd_gather_t& g) {
   return true;
 }
 
-// gathered A rows (not the transposed gather): the kernel keeps the tap offsets as 4-bit fields
+// the gathered kernels keep the tap offsets as 4-bit fields of two scalars
 inline bool gather_taps_small(const eamd_gather_t& g) {
   for (int tp = 0; tp < g.ntap; ++tp)
     if (g.dh[tp] < -8 || g.dh[tp] > 7 || g.dw[tp] < -8 || g.dw[tp] > 7) return false;
@@ -688,7 +691,7 @@ int eamd_gemm_f32_dispatch(const eamd_gemm_t& p, int tile, hipStream_t stream) {
     const eamd_gather_t& g = p.gather;
     if (g.C % FBK != 0 || !p.transB || !aligned16f(p.A) || !b_ok) return EAMD_EUNSUPPORTED;
     if (p.a_act != EAMD_ACT_NONE || p.b_act != EAMD_ACT_NONE) return EAMD_EUNSUPPORTED;
-    if (!p.transA && !gather_taps_small(g)) return EAMD_EUNSUPPORTED;       // tap offsets travel as 4-bit fields
+    if (!gather_taps_small(g)) return EAMD_EUNSUPPORTED;       // tap offsets travel as 4-bit fields
     if (p.transA && g.C % tile != 0) return EAMD_EUNSUPPORTED;
     if (tile == 128)
       return p.transA ? launch_f<128, 128, true, true, true>(p, stream) : launch_f<128, 128, false, true, true>(p, stream);
