@@ -22,6 +22,7 @@
 #include <type_traits>
 #include "common.h"
 #include "../../include/espnet_amd.h"
+#include "ffn_ln.h"
 
 namespace {
 
@@ -57,11 +58,20 @@ __global__ __launch_bounds__(BNT, 2) void ffn_bf16_kernel(const eamd_ffn_t p) {
 
   // ---- the 32 input rows: LDS image, A fragments (lane = row fr of row tile i, k-group fq: 8 consecutive k) read per k-step
   // (held in registers they cost 64 VGPRs - the room the one-chunk-ahead prefetch of BOTH weight sets needs) ----
+  if (!BWD && p.ln_x) {        // LayerNorm in front: normalise the fp32 rows on their way into the bf16 LDS image (ffn_ln.h)
+    ffn_ln_stage(p, m0, t, [&](int row, int col, float4 y) __attribute__((always_inline)) {
+      uint2 hh;
+      hh.x = eamd_f2bf(y.x) | ((unsigned)eamd_f2bf(y.y) << 16);
+      hh.y = eamd_f2bf(y.z) | ((unsigned)eamd_f2bf(y.w) << 16);
+      *reinterpret_cast<uint2*>(&xs[row * XLDB + col]) = hh;
+    });
+  } else {
 #pragma unroll
-  for (int k = 0; k < 2; ++k) {
-    const int idx = t + BNT * k, row = idx >> 5, c8 = idx & 31;          // 32 rows x 32 pieces of 8 elements
-    *reinterpret_cast<uint4*>(&xs[row * XLDB + c8 * 8]) =
-        *reinterpret_cast<const uint4*>(X + (long)min(m0 + row, p.M - 1) * BD + c8 * 8);
+    for (int k = 0; k < 2; ++k) {
+      const int idx = t + BNT * k, row = idx >> 5, c8 = idx & 31;          // 32 rows x 32 pieces of 8 elements
+      *reinterpret_cast<uint4*>(&xs[row * XLDB + c8 * 8]) =
+          *reinterpret_cast<const uint4*>(X + (long)min(m0 + row, p.M - 1) * BD + c8 * 8);
+    }
   }
   // ---- weight fragments, from the PACKED images eamd_ffn_pack_bf16 makes (fragment order: one wave-instruction reads 1 KB of
   // consecutive bytes = 8 whole cache lines; fetched from the nn.Linear layout a fragment load touches 16 rows x 64 bytes -

@@ -29,6 +29,7 @@
 #include <type_traits>
 #include "common.h"
 #include "../../include/espnet_amd.h"
+#include "ffn_ln.h"
 
 #ifdef FFN_STAMP
 // diagnostic build only: s_memtime stamps of one up and one down wave of workgroup 100 during body 4
@@ -92,11 +93,17 @@ __global__ __launch_bounds__(FNT, 2) void ffn_f32_direct_kernel(const eamd_ffn_t
   using T_ = std::true_type;
   using F_ = std::false_type;
 
+  if (!BWD && p.ln_x) {        // LayerNorm in front: normalise the rows on their way into LDS (ffn_ln.h)
+    ffn_ln_stage(p, m0, t, [&](int row, int col, float4 y) __attribute__((always_inline)) {
+      *reinterpret_cast<f32x4*>(&xs[row * XS_LD + col]) = (f32x4){y.x, y.y, y.z, y.w};
+    });
+  } else {
 #pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    const int idx = t + FNT * i, row = idx >> 6, c4 = idx & 63;
-    *reinterpret_cast<f32x4*>(&xs[row * XS_LD + c4 * 4]) =
-        *reinterpret_cast<const f32x4*>(p.x + (long)min(m0 + row, p.M - 1) * FD + c4 * 4);
+    for (int i = 0; i < 4; ++i) {
+      const int idx = t + FNT * i, row = idx >> 6, c4 = idx & 63;
+      *reinterpret_cast<f32x4*>(&xs[row * XS_LD + c4 * 4]) =
+          *reinterpret_cast<const f32x4*>(p.x + (long)min(m0 + row, p.M - 1) * FD + c4 * 4);
+    }
   }
   __syncthreads();
 
@@ -422,6 +429,10 @@ int check_ffn(const eamd_ffn_t* p, bool bwd) {
   if (!p || !p->x || !p->w1 || !p->w2 || !p->out) return EAMD_EINVAL;
   if (p->M <= 0 || p->D <= 0 || p->F <= 0) return EAMD_EINVAL;
   if (p->dtype != 0 && p->dtype != 1) return EAMD_EINVAL;
+  if (p->ln_x) {      // LayerNorm in front (forward only): x is written, not read
+    if (bwd || !p->ln_w || !p->ln_b || !p->ln_mean || !p->ln_rstd) return EAMD_EINVAL;
+    if (!al16(p->ln_x) || !al16(p->ln_w) || !al16(p->ln_b)) return EAMD_EUNSUPPORTED;
+  }
   if (p->dtype == 1) {                                               // bf16 operands: ffn_bf16.hip
     if (!eamd_ffn_bf16_ok(p)) return EAMD_EUNSUPPORTED;
     if (bwd) return p->f ? EAMD_OK : EAMD_EINVAL;

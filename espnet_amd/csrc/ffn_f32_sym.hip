@@ -17,6 +17,7 @@
 #include <type_traits>
 #include "common.h"
 #include "../../include/espnet_amd.h"
+#include "ffn_ln.h"
 
 namespace {
 
@@ -37,11 +38,17 @@ __global__ __launch_bounds__(SNT, 2) void ffn_f32_sym_kernel(const eamd_ffn_t p)
   const int m0 = blockIdx.x * SBM;
   const int F = p.F, nch = F / SHC;
   const bool full_rows = m0 + SBM <= p.M;
+  if (!BWD && p.ln_x) {        // LayerNorm in front: normalise the rows on their way into LDS (ffn_ln.h)
+    ffn_ln_stage(p, m0, t, [&](int row, int col, float4 y) __attribute__((always_inline)) {
+      *reinterpret_cast<f32x4*>(&xs[row * SX_LD + col]) = (f32x4){y.x, y.y, y.z, y.w};
+    });
+  } else {
 #pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    const int idx = t + SNT * i, row = idx >> 6, c4 = idx & 63;
-    *reinterpret_cast<f32x4*>(&xs[row * SX_LD + c4 * 4]) =
-        *reinterpret_cast<const f32x4*>(p.x + (long)min(m0 + row, p.M - 1) * SD + c4 * 4);
+    for (int i = 0; i < 4; ++i) {
+      const int idx = t + SNT * i, row = idx >> 6, c4 = idx & 63;
+      *reinterpret_cast<f32x4*>(&xs[row * SX_LD + c4 * 4]) =
+          *reinterpret_cast<const f32x4*>(p.x + (long)min(m0 + row, p.M - 1) * SD + c4 * 4);
+    }
   }
   // packed images (ffn_pack_f32_sym_kernel): image[c][w][g][j][lane] = four k-elements of column tile j for the 16-k group g
   const char* const Wa = reinterpret_cast<const char*>(p.w1) + (long)w * 16 * GROUP_BYTES + lane * 16;

@@ -217,18 +217,28 @@ class FFNBlockFn(torch.autograd.Function):
         adt = ops.act_dtype()
         p_in, s_in, p_out, s_out = drop
         x2 = x.reshape(-1, D).contiguous()
-        xn, mean, rstd = _ln_fwd_in(x2, ln_w, ln_b, eps, adt)                   # GEMM operand (bf16 in fast mode)
         assert eps is not None or p_out <= 0.0
         fused = ops.fast()      # bf16-operand GEMMs carry the dropout masks in their epilogues
         h, zf = None, False
-        if (eps is not None and (ops.fast() or (ops.f32_epilogue_drop() and not ops.f32_operand_drop()))
-                and ops.ffn_fused_ok(xn, ops.wshadow(w1), ops.wshadow(w2), act)):
+        one = eps is not None and (ops.fast() or (ops.f32_epilogue_drop() and not ops.f32_operand_drop()))
+        ln_in = None
+        if one and ops.FFN_LN_FUSED and x2.dtype == torch.float32 and D == 256:
+            # the one-launch kernel below normalises its rows itself (eamd_ffn_t.ln_x): no LayerNorm launch, and the
+            # normalised rows are written once (for the weight gradient) instead of written and read back
+            xn = torch.empty(x2.shape, device=x2.device, dtype=adt)
+            if ops.ffn_fused_ok(xn, ops.wshadow(w1), ops.wshadow(w2), act):
+                mean = torch.empty(x2.shape[0], device=x2.device, dtype=torch.float32)
+                rstd = torch.empty(x2.shape[0], device=x2.device, dtype=torch.float32)
+                ln_in = (x2, ln_w, ln_b, eps, mean, rstd)
+        if ln_in is None:
+            xn, mean, rstd = _ln_fwd_in(x2, ln_w, ln_b, eps, adt)               # GEMM operand (bf16 in fast mode)
+        if one and (ln_in is not None or ops.ffn_fused_ok(xn, ops.wshadow(w1), ops.wshadow(w2), act)):
             # fp32 mode, d = 256: BOTH products in one launch (csrc/ffn_f32.hip) - 32 rows per workgroup, the hidden units
             # never make a round trip for the second product; kept for backward: h and the factor f (no grad: neither)
             need = any(ctx.needs_input_grad[:7])          # (grad mode is off inside forward: needs_input_grad tells no-grad calls apart)
             packs = ops.ffn_pack(w1, w2)       # the four packed weight images of this layer (forward pair, backward pair)
             out, z, h = ops.ffn_fwd(xn, ops.wshadow(w1), b1, ops.wshadow(w2), b2, act=act, alpha=scale, R=x2,
-                                    drop=(p_in, s_in, p_out, s_out), save=need, packed=packs[:2])
+                                    drop=(p_in, s_in, p_out, s_out), save=need, packed=packs[:2], ln=ln_in)
             ctx.packs = packs[2:]
             ctx.save_for_backward(x2, mean, rstd, xn, z, h)
             ctx.pr = GradSink.use((ln_w, ln_b, w1, b1, w2, b2))

@@ -584,10 +584,16 @@ def _ffn_call(name, p, keep):
     check(fn(C.byref(p), stream_ptr()), name)
 
 
-def ffn_fwd(x, w1, b1, w2, b2, *, act, alpha=1.0, R=None, drop=(0.0, 0, 0.0, 0), save=True, packed=None):
+FFN_LN_FUSED = os.environ.get("EAMD_FFN_LN", "1") != "0"      # the LayerNorm in front of a fused FFN runs inside its kernel
+
+
+def ffn_fwd(x, w1, b1, w2, b2, *, act, alpha=1.0, R=None, drop=(0.0, 0, 0.0, 0), save=True, packed=None, ln=None):
     """out = R + alpha * drop_out(drop_in(act(x W1^T + b1)) W2^T + b2) in ONE launch; with save also the two tensors
     backward needs: h = drop_in(act(z)) and f = mask / (1 - p) * act'(z).  -> (out fp32, f, h); x / w1 / w2 all fp32 or all
-    bf16 (f, h in that dtype)"""
+    bf16 (f, h in that dtype).
+    ln = (x_raw fp32 [M, D], gamma, beta, eps, mean [M], rstd [M]): the block input is LayerNorm(x_raw), formed by the kernel
+    while it stages its rows; `x` is then an uninitialised [M, D] buffer of the operand dtype that RECEIVES the normalised
+    rows, and mean / rstd receive the row statistics (what eamd_layernorm_fwd would have left for backward)."""
     M, D = x.shape
     F = w1.shape[0]
     dt = x.dtype
@@ -603,7 +609,15 @@ def ffn_fwd(x, w1, b1, w2, b2, *, act, alpha=1.0, R=None, drop=(0.0, 0, 0.0, 0),
     if packed is None:            # the kernels read the packed images (ffn_pack)
         packed = ffn_pack(w1, w2)[:2]
     p = _ffn_desc(x, packed[0], b1, packed[1], b2, R, out, f, h, act, alpha, drop, F=F)
-    _ffn_call("eamd_ffn_fwd", p, (x, packed, b1, b2, R, out, f, h))
+    if ln is not None:
+        xr, g, b, eps, mean, rstd = ln
+        for t_ in (xr, g, b, mean, rstd):
+            if t_.dtype != torch.float32 or not t_.is_contiguous():
+                raise _lib.EamdError("ffn_fwd: LayerNorm operands are contiguous float32 tensors")
+        if tuple(xr.shape) != (M, D) or g.numel() != D or b.numel() != D or mean.numel() < M or rstd.numel() < M:
+            raise _lib.EamdError("ffn_fwd: LayerNorm operand shapes")
+        p.ln_x, p.ln_w, p.ln_b, p.ln_mean, p.ln_rstd, p.ln_eps = ptr(xr), ptr(g), ptr(b), ptr(mean), ptr(rstd), float(eps)
+    _ffn_call("eamd_ffn_fwd", p, (x, packed, b1, b2, R, out, f, h, ln))
     return out, f, h
 
 

@@ -177,6 +177,13 @@ typedef struct {
   float alpha;
   float p_in; uint64_t salt_in; float p_out; uint64_t salt_out; const void* drop_step;
   int32_t dtype; int32_t reserved;
+  /* Optional LayerNorm in front, eamd_ffn_fwd only (the norm_ff / norm_ff_macaron of conformer/encoder_layer.py:96-103,139-146
+   * and transformer/decoder_layer.py: x + s * dropout(ff(norm(x)))).  ln_x != NULL: the block input is ln_x [M, D] fp32 and
+   * the workgroup normalises its 32 rows while it stages them (nn.LayerNorm arithmetic: biased variance, rsqrt(var + eps));
+   * `x` is then an OUTPUT - the normalised rows in the operand dtype, which backward's weight gradient reads - together with
+   * ln_mean / ln_rstd [M].  ln_w, ln_b [D] fp32.  ln_x == NULL: the other ln_* fields are ignored. */
+  const float* ln_x; const float* ln_w; const float* ln_b; float* ln_mean; float* ln_rstd;
+  float ln_eps; int32_t reserved2;
 } eamd_ffn_t;
 int eamd_ffn_fwd(const eamd_ffn_t* p, void* stream);
 int eamd_ffn_bwd(const eamd_ffn_t* p, void* stream);

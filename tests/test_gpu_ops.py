@@ -1507,3 +1507,43 @@ def test_conv2_input_gradient_classes_in_one_launch(ops, shape, prec):
         report("conv2 dX classes %s %s" % (shape, prec), d4, ref, 2e-5 if prec == "fp32" else 1e-2)
     finally:
         espnet_amd.set_precision("fp32")
+
+
+@pytest.mark.parametrize("prec", ["fp32", "bf16"])
+@pytest.mark.parametrize("M,F,act", [(7968, 2048, 2), (1000, 512, 1), (3232, 2048, 1)])
+def test_ffn_layernorm_in_front(ops, prec, M, F, act):
+    """eamd_ffn_t.ln_x: the feed-forward kernel normalises its own input rows.  Against eamd_layernorm_fwd followed by the
+    kernel without it: row statistics and normalised rows (which backward reads) to rounding, block output likewise; and the
+    normalised rows against float64.  reference: conformer/encoder_layer.py:96-103 (x + s * dropout(ff(norm_ff(x))))"""
+    import espnet_amd
+    espnet_amd.set_precision(prec)
+    try:
+        g = torch.Generator().manual_seed(11)
+        D = 256
+        adt = torch.bfloat16 if prec == "bf16" else torch.float32
+        x = (torch.randn(M, D, generator=g) * 3.0 + 0.5).to(DEV)
+        gam, bet = (1.0 + 0.1 * torch.randn(D, generator=g)).to(DEV), (0.1 * torch.randn(D, generator=g)).to(DEV)
+        w1 = (torch.randn(F, D, generator=g) / 16.0).to(DEV).to(adt)
+        w2 = (torch.randn(D, F, generator=g) / (F ** 0.5)).to(DEV).to(adt)
+        b1, b2 = (0.1 * torch.randn(F, generator=g)).to(DEV), (0.1 * torch.randn(D, generator=g)).to(DEV)
+        eps = 1e-12
+        drop = (0.1, 77, 0.1, 78)
+        y_ref, mean_ref, rstd_ref = ops.layernorm_fwd(x, gam, bet, eps, adt)
+        out_ref, f_ref, h_ref = ops.ffn_fwd(y_ref, w1, b1, w2, b2, act=act, alpha=0.5, R=x, drop=drop)
+        xn = torch.full((M, D), float("nan"), device=DEV).to(adt)
+        mean, rstd = torch.full((M,), float("nan"), device=DEV), torch.full((M,), float("nan"), device=DEV)
+        out, f, h = ops.ffn_fwd(xn, w1, b1, w2, b2, act=act, alpha=0.5, R=x, drop=drop, ln=(x, gam, bet, eps, mean, rstd))
+        torch.cuda.synchronize()
+        tag = "%s M=%d F=%d act=%d" % (prec, M, F, act)
+        report("ffn+ln mean " + tag, mean, mean_ref, 1e-6)
+        report("ffn+ln rstd " + tag, rstd, rstd_ref, 1e-6)
+        xd = x.double().cpu()
+        y64 = (xd - xd.mean(1, keepdim=True)) / torch.sqrt(xd.var(1, unbiased=False, keepdim=True) + eps) * gam.double().cpu() + bet.double().cpu()
+        report("ffn+ln rows vs float64 " + tag, xn, y64, 1e-6 if prec == "fp32" else 4e-3)
+        report("ffn+ln rows " + tag, xn, y_ref, 1e-6 if prec == "fp32" else 1e-3)
+        report("ffn+ln out  " + tag, out, out_ref, 1e-5 if prec == "fp32" else 2e-3)
+        assert torch.isfinite(out).all() and torch.isfinite(xn.float()).all()
+        if prec == "fp32":            # same masks, same arithmetic on rows that differ in the last bit
+            report("ffn+ln h    " + tag, h, h_ref, 1e-5)
+    finally:
+        espnet_amd.set_precision("fp32")
