@@ -277,7 +277,10 @@ def gemm_multi(items):
         part = items[i0:i0 + GEMM_MULTI_MAX]
         arr = (GemmT * len(part))(*[it[0] for it in part])
         n = len(part)
-        if _gemm_record is not None:
+        if _gemm_record is not None and any(it[0].in_dtype != 0 or it[0].precision != 0 for it in part):
+            for p_, keep in part:          # no one-launch kernel for these operands: n launches, recorded as such
+                _gemm_record.append((p_, keep, lambda sp, p_=p_: check(L.eamd_gemm(C.byref(p_), sp), "eamd_gemm")))
+        elif _gemm_record is not None:
             _gemm_record.append((dict(kind="multi%d" % n, flop=sum(2.0 * it[0].M * it[0].N * it[0].K for it in part)),
                                  (arr, [it[1] for it in part]),
                                  lambda sp, arr=arr, n=n: check(L.eamd_gemm_multi(arr, n, sp), "eamd_gemm_multi")))
