@@ -120,6 +120,8 @@ __device__ __forceinline__ void gemm_bf16_body(const eamd_gemm_t& p, const int b
 #pragma unroll
     for (int i = 0; i < NCA; ++i) a_rs[i] = decompose_b(p.gather, m0 + a_r[i], p.M);
   }
+  GatherRegs gr = {0ull, 0ull, 1, 0, 0};          // tap offsets in scalar registers (gemm_bf16_common.h)
+  if constexpr (gat) gr = gather_regs(p.gather);
   // register ring of DEPTH tile sets: DEPTH-1 tiles of loads stay in flight across the MFMA phases
   // (skinny N=256 GEMMs have ~2 workgroups per CU, so bytes in flight per workgroup hide HBM latency)
   constexpr int DEPTH = BM >= 128 ? 3 : 4;
@@ -132,9 +134,9 @@ __device__ __forceinline__ void gemm_bf16_body(const eamd_gemm_t& p, const int b
 
   auto fill_poff = [&](int kt, int slot) __attribute__((always_inline)) {
     if (t < BK) {
-      const int tap = m0 / p.gather.C;
+      const int tap = m0 / gr.C;
       RowStateB s = decompose_b(p.gather, kt * BK + t, p.K);
-      sm.poff[slot][t] = (int)gather_off_b(p.gather, s, tap);
+      sm.poff[slot][t] = (int)gather_off_r(gr, s, tap);
     }
   };
 
@@ -159,10 +161,10 @@ __device__ __forceinline__ void gemm_bf16_body(const eamd_gemm_t& p, const int b
           }
         }
       } else {
-        const int tap = k0 / p.gather.C, c0 = k0 % p.gather.C;
+        const int tap = k0 / gr.C, c0 = k0 - tap * gr.C;
 #pragma unroll
         for (int i = 0; i < NCA; ++i) {
-          const long off = gather_off_b(p.gather, a_rs[i], tap);
+          const long off = gather_off_r(gr, a_rs[i], tap);
           ra[SET][i] = load8_fast(A, off + c0 + a_c[i] * 8, off >= 0 ? 8 : 0);
         }
       }
@@ -221,7 +223,7 @@ __device__ __forceinline__ void gemm_bf16_body(const eamd_gemm_t& p, const int b
   auto nv_a = [&](int i, int kt) __attribute__((always_inline)) -> int {
     const int k0 = kt * BK;
     if constexpr (gat) {
-      if constexpr (!TA) return gather_off_b(p.gather, a_rs[i], k0 / p.gather.C) >= 0 ? 8 : 0;
+      if constexpr (!TA) return gather_off_r(gr, a_rs[i], k0 / gr.C) >= 0 ? 8 : 0;
       else return sm.poff[kt % 8][a_r[i]] >= 0 ? 8 : 0;
     } else if constexpr (!TA) {
       return min(8, p.K - (k0 + a_c[i] * 8));       // K edge only (M edge: clamped rows, never stored)
@@ -546,6 +548,7 @@ int eamd_gemm_bf16_dispatch(const eamd_gemm_t& p, int tile, hipStream_t stream) 
     const eamd_gather_t& g = p.gather;
     if (g.C % BK != 0 || !p.transB || !aligned16(p.A) || !b_ok) return EAMD_EINVAL;
     if (p.a_act != EAMD_ACT_NONE || p.b_act != EAMD_ACT_NONE) return EAMD_EINVAL;
+    if (!gather_taps_fit(g)) return EAMD_EUNSUPPORTED;          // tap offsets travel as 4-bit fields
     if (p.transA && g.C % tile != 0) return EAMD_EINVAL;
     if (tile == 128)
       return p.transA ? launch_b<128, 128, true, true, true, true>(p, stream)

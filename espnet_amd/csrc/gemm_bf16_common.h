@@ -59,6 +59,32 @@ __device__ __forceinline__ long gather_off_b(const eamd_gather_t& g, const RowSt
   return ok ? ((long)(s.base + hh * g.Win + ww)) * g.C : -1L;
 }
 
+// The tap offsets of a gather descriptor as 4-bit fields of two 64-bit scalars (host check: -8 <= dh, dw <= 7, gather_taps_fit):
+// indexing eamd_gather_t.dh[tap] with a run-time tap makes the compiler keep the whole kernel argument in memory and fetch
+// fields with s_load inside the K loop - and the s_waitcnt lgkmcnt(0) behind each of them also drains the wave's LDS reads.
+struct GatherRegs { unsigned long long dh, dw; int C, Hin, Win; };
+__device__ __forceinline__ GatherRegs gather_regs(const eamd_gather_t& g) {
+  GatherRegs r;
+  r.dh = 0ull; r.dw = 0ull;
+#pragma unroll
+  for (int tp = 0; tp < 9; ++tp) {
+    r.dh |= (unsigned long long)((unsigned)(g.dh[tp] + 8) & 15u) << (4 * tp);
+    r.dw |= (unsigned long long)((unsigned)(g.dw[tp] + 8) & 15u) << (4 * tp);
+  }
+  r.C = g.C; r.Hin = g.Hin; r.Win = g.Win;
+  return r;
+}
+__device__ __forceinline__ long gather_off_r(const GatherRegs& g, const RowStateB& s, int tap) {
+  const int hh = s.ih + (int)((g.dh >> (4 * tap)) & 15ull) - 8, ww = s.jw + (int)((g.dw >> (4 * tap)) & 15ull) - 8;
+  const bool ok = s.ok && hh >= 0 && hh < g.Hin && ww >= 0 && ww < g.Win;
+  return ok ? ((long)(s.base + hh * g.Win + ww)) * g.C : -1L;
+}
+inline bool gather_taps_fit(const eamd_gather_t& g) {
+  for (int tp = 0; tp < g.ntap; ++tp)
+    if (g.dh[tp] < -8 || g.dh[tp] > 7 || g.dw[tp] < -8 || g.dw[tp] > 7) return false;
+  return true;
+}
+
 __device__ __forceinline__ float bf2f(bf16_t h) { return __uint_as_float(((unsigned)h) << 16); }
 
 // 8 consecutive bf16 starting at p[idx]; `nvalid` of them are in range (0..8); vec = 16-byte path usable
