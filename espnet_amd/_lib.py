@@ -62,7 +62,7 @@ class FfnT(C.Structure):
                 ("R", C.c_void_p), ("out", C.c_void_p), ("f", C.c_void_p), ("h", C.c_void_p),
                 ("M", C.c_int32), ("D", C.c_int32), ("F", C.c_int32), ("act", C.c_int32),
                 ("alpha", C.c_float), ("p_in", C.c_float), ("salt_in", C.c_uint64), ("p_out", C.c_float),
-                ("salt_out", C.c_uint64), ("drop_step", C.c_void_p), ("dtype", C.c_int32), ("reserved", C.c_int32),
+                ("salt_out", C.c_uint64), ("drop_step", C.c_void_p), ("dtype", C.c_int32), ("hsplit", C.c_int32),
                 ("ln_x", C.c_void_p), ("ln_w", C.c_void_p), ("ln_b", C.c_void_p), ("ln_mean", C.c_void_p),
                 ("ln_rstd", C.c_void_p), ("ln_eps", C.c_float), ("reserved2", C.c_int32)]
 

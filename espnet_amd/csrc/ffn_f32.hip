@@ -87,7 +87,10 @@ __global__ __launch_bounds__(FNT, 2) void ffn_f32_direct_kernel(const eamd_ffn_t
   const int fr = lane & 15, fq = lane >> 4;
   const int m0 = blockIdx.x * FBM;
   const int F = p.F;
-  const int nch = F / FHC;
+  // hidden split (eamd_ffn_t.hsplit = gridDim.y > 1, few rows): this workgroup takes hidden units hid0 .. hid0 + nch * 128 - 1 of
+  // its 32 rows and ADDS its share of the second product to `out` (zeroed by the caller; slice 0 also brings bias / residual)
+  const int nch = F / FHC / (int)gridDim.y;
+  const int hid0 = (int)blockIdx.y * nch * FHC;
   const int nsteps = 8 * nch;
   const bool full_rows = m0 + FBM <= p.M;
   using T_ = std::true_type;
@@ -109,7 +112,7 @@ __global__ __launch_bounds__(FNT, 2) void ffn_f32_direct_kernel(const eamd_ffn_t
 
   if (up) {
     // =============================== up waves ===============================
-    const float* __restrict__ W = p.w1;          // packed image of the first product (forward: W1; backward: W2 read along its rows)
+    const float* __restrict__ W = p.w1 + (long)hid0 * FD;      // packed image of the first product (forward: W1; backward: W2 read along its rows), chunk-major
     // column of accumulator tile j inside the chunk: forward j*16 + fr; backward (float2 fragments along n) 2*fr + j
     // both directions interleave the two column tiles (tile j holds columns 2 fr + j): a lane's (j = 0, 1) elements of one
     // row are neighbours - one dropout hash (an element PAIR), one 8-byte LDS store
@@ -171,7 +174,7 @@ __global__ __launch_bounds__(FNT, 2) void ffn_f32_direct_kernel(const eamd_ffn_t
 #pragma unroll
           for (int j = 0; j < 2; ++j) eamd_act_dact(zold[i][j][r] + bpre[j], ACT, hv[j], fv[j]);
           if (p.p_in > 0.f) {
-            const unsigned gi = (unsigned)(m0 + i * 16 + fq * 4 + r) * (unsigned)F + (unsigned)(c * FHC + lc0);      // even
+            const unsigned gi = (unsigned)(m0 + i * 16 + fq * 4 + r) * (unsigned)F + (unsigned)(hid0 + c * FHC + lc0);      // even
             const unsigned hsh = eamd_drop_pair(seed_in, (unsigned long long)(gi >> 1));
             const bool k0 = (hsh & 0xffffu) >= thr_in, k1 = (hsh >> 16) >= thr_in;
             hv[0] = k0 ? hv[0] * inv_in : 0.f; fv[0] = k0 ? fv[0] * inv_in : 0.f;
@@ -186,7 +189,7 @@ __global__ __launch_bounds__(FNT, 2) void ffn_f32_direct_kernel(const eamd_ffn_t
       }
     };
     auto load_f = [&](int c) __attribute__((always_inline)) {
-      const char* base = reinterpret_cast<const char*>(p.f + (long)m0 * F + c * FHC);
+      const char* base = reinterpret_cast<const char*>(p.f + (long)m0 * F + hid0 + c * FHC);
 #pragma unroll
       for (int i = 0; i < 2; ++i)
 #pragma unroll
@@ -204,7 +207,7 @@ __global__ __launch_bounds__(FNT, 2) void ffn_f32_direct_kernel(const eamd_ffn_t
         load_b(std::integral_constant<int, (s + 3) & 3>{}, 8 * P + s + 3);
         if constexpr (s == 4) {      // behind the last epilogue quarter of the previous chunk (step 3), which still reads them
           if constexpr (BWD) load_f(P);
-          else if (p.b1) { bpre[0] = p.b1[P * FHC + lc0]; bpre[1] = p.b1[P * FHC + lc0 + 1]; }
+          else if (p.b1) { bpre[0] = p.b1[hid0 + P * FHC + lc0]; bpre[1] = p.b1[hid0 + P * FHC + lc0 + 1]; }
         }
         __builtin_amdgcn_sched_barrier(0);
         read_a(s_c, std::integral_constant<int, 1>{});
@@ -248,7 +251,7 @@ __global__ __launch_bounds__(FNT, 2) void ffn_f32_direct_kernel(const eamd_ffn_t
     period(F_{}, F_{}, nch + 1);
   } else {
     // =============================== down waves ===============================
-    const float* __restrict__ W = p.w2;          // packed image of the second product
+    const float* __restrict__ W = p.w2 + (long)hid0 * FD;      // packed image of the second product, chunk-major
     f32x4 bs[4][4];            // forward: [set][j] = 4 k-elements of column tile j;  backward: [set][e] = column tiles 0..3 at k = fq*4 + e
     f32x4 yacc[2][4];
 #pragma unroll
@@ -301,7 +304,7 @@ __global__ __launch_bounds__(FNT, 2) void ffn_f32_direct_kernel(const eamd_ffn_t
           for (int k = 0; k < 4; ++k) {
             const int idx = dt + 256 * k, lr = idx >> 5, c4 = idx & 31;
             if (full_rows || m0 + lr < p.M)
-              *reinterpret_cast<float4*>(dstp + (long)(m0 + lr) * F + (P - 2) * FHC + c4 * 4) =
+              *reinterpret_cast<float4*>(dstp + (long)(m0 + lr) * F + hid0 + (P - 2) * FHC + c4 * 4) =
                   *reinterpret_cast<const float4*>(&src[lr * HS_LD + c4 * 4]);
           }
         }
@@ -358,8 +361,9 @@ __global__ __launch_bounds__(FNT, 2) void ffn_f32_direct_kernel(const eamd_ffn_t
     const float4 a4 = *reinterpret_cast<const float4*>(&xs[lr * XS_LD + c4 * 4]);
     float v[4] = {a4.x, a4.y, a4.z, a4.w};
     const long gi = (long)row * FD + c4 * 4;
+    const bool first = blockIdx.y == 0;         // hidden split: bias and residual come with slice 0
     if constexpr (!BWD) {
-      if (p.b2) {
+      if (p.b2 && first) {
         const float4 b4 = *reinterpret_cast<const float4*>(p.b2 + c4 * 4);
         v[0] += b4.x; v[1] += b4.y; v[2] += b4.z; v[3] += b4.w;
       }
@@ -370,10 +374,15 @@ __global__ __launch_bounds__(FNT, 2) void ffn_f32_direct_kernel(const eamd_ffn_t
         for (int e = 0; e < 4; ++e) v[e] = keep[e] ? v[e] * inv_out : 0.f;
       }
       float4 r4 = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (p.R) r4 = *reinterpret_cast<const float4*>(p.R + gi);
+      if (p.R && first) r4 = *reinterpret_cast<const float4*>(p.R + gi);
       v[0] = v[0] * p.alpha + r4.x; v[1] = v[1] * p.alpha + r4.y; v[2] = v[2] * p.alpha + r4.z; v[3] = v[3] * p.alpha + r4.w;
     }
-    *reinterpret_cast<float4*>(p.out + gi) = make_float4(v[0], v[1], v[2], v[3]);
+    if (gridDim.y > 1) {       // two addends onto zeros: the sum does not depend on their order
+#pragma unroll
+      for (int e = 0; e < 4; ++e) atomicAdd(p.out + gi + e, v[e]);
+    } else {
+      *reinterpret_cast<float4*>(p.out + gi) = make_float4(v[0], v[1], v[2], v[3]);
+    }
   }
 }
 
@@ -420,7 +429,7 @@ int launch_ffn(const eamd_ffn_t& p, hipStream_t stream) {
                                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
   if (attr_err != hipSuccess) return (int)attr_err;
   const int nblk = (p.M + FBM - 1) / FBM;
-  hipLaunchKernelGGL((ffn_f32_direct_kernel<BWD, ACT>), dim3(nblk), dim3(FNT), smem, stream, p);
+  hipLaunchKernelGGL((ffn_f32_direct_kernel<BWD, ACT>), dim3(nblk, p.hsplit > 1 ? p.hsplit : 1), dim3(FNT), smem, stream, p);
   EAMD_LAUNCH_CHECK();
   return EAMD_OK;
 }
@@ -433,14 +442,16 @@ int check_ffn(const eamd_ffn_t* p, bool bwd) {
     if (bwd || !p->ln_w || !p->ln_b || !p->ln_mean || !p->ln_rstd) return EAMD_EINVAL;
     if (!al16(p->ln_x) || !al16(p->ln_w) || !al16(p->ln_b)) return EAMD_EUNSUPPORTED;
   }
+  if (p->hsplit < 0) return EAMD_EINVAL;
   if (p->dtype == 1) {                                               // bf16 operands: ffn_bf16.hip
-    if (!eamd_ffn_bf16_ok(p)) return EAMD_EUNSUPPORTED;
+    if (!eamd_ffn_bf16_ok(p) || p->hsplit > 1) return EAMD_EUNSUPPORTED;
     if (bwd) return p->f ? EAMD_OK : EAMD_EINVAL;
     if (p->p_in < 0.f || p->p_in >= 1.f || p->p_out < 0.f || p->p_out >= 1.f) return EAMD_EINVAL;
     if ((p->p_in > 0.f || p->p_out > 0.f) && !p->drop_step) return EAMD_EINVAL;
     return (p->act == EAMD_ACT_RELU || p->act == EAMD_ACT_SWISH) ? EAMD_OK : EAMD_EUNSUPPORTED;
   }
   if (p->D != FD || p->F % FHC != 0 || p->F < 2 * FHC) return EAMD_EUNSUPPORTED;
+  if (p->hsplit > 1 && (p->hsplit != 2 || (p->F / FHC) % 2 != 0 || p->F < 4 * FHC)) return EAMD_EUNSUPPORTED;
   if ((long)p->M * p->F >= (1L << 31)) return EAMD_EUNSUPPORTED;     // 32-bit dropout pair index space
   if (!al16(p->x) || !al16(p->w1) || !al16(p->w2) || !al16(p->out) || (p->R && !al16(p->R)) || (p->b2 && !al16(p->b2)))
     return EAMD_EUNSUPPORTED;
@@ -481,7 +492,7 @@ extern "C" int eamd_ffn_fwd(const eamd_ffn_t* p, void* stream) {
   const int rc = check_ffn(p, false);
   if (rc != EAMD_OK) return rc;
   if (p->dtype == 1) return eamd_ffn_bf16_launch(p, 0, stream);
-  if (eamd_ffn_f32_sym(p->F)) return eamd_ffn_f32_sym_launch(p, 0, stream);
+  if (p->hsplit <= 1 && eamd_ffn_f32_sym(p->F)) return eamd_ffn_f32_sym_launch(p, 0, stream);
   return p->act == EAMD_ACT_SWISH ? launch_ffn<false, EAMD_ACT_SWISH>(*p, (hipStream_t)stream)
                                   : launch_ffn<false, EAMD_ACT_RELU>(*p, (hipStream_t)stream);
 }
@@ -490,6 +501,6 @@ extern "C" int eamd_ffn_bwd(const eamd_ffn_t* p, void* stream) {
   const int rc = check_ffn(p, true);
   if (rc != EAMD_OK) return rc;
   if (p->dtype == 1) return eamd_ffn_bf16_launch(p, 1, stream);
-  if (eamd_ffn_f32_sym(p->F)) return eamd_ffn_f32_sym_launch(p, 1, stream);
+  if (p->hsplit <= 1 && eamd_ffn_f32_sym(p->F)) return eamd_ffn_f32_sym_launch(p, 1, stream);
   return launch_ffn<true, EAMD_ACT_NONE>(*p, (hipStream_t)stream);
 }

@@ -563,7 +563,20 @@ def ffn_fused_ok(x, w1, w2, act):
             (not bf and (x.dtype != torch.float32 or _state["precision"] != 0)):
         return False
     return (x.shape[1] == 256 and w1.shape[1] == 256 and w1.shape[0] % (256 if bf else 128) == 0 and w1.shape[0] >= 256
-            and tuple(w2.shape) == (256, w1.shape[0]) and act in (ACT_RELU, ACT_SWISH) and x.shape[0] >= FUSED_FFN_MIN_ROWS)
+            and tuple(w2.shape) == (256, w1.shape[0]) and act in (ACT_RELU, ACT_SWISH)
+            and (x.shape[0] >= FUSED_FFN_MIN_ROWS or ffn_hsplit(x.shape[0], w1.shape[0], bf) > 1))
+
+
+# fp32 operands, few rows (the decoder's 3232 target positions = 101 row blocks on 256 CUs): two workgroups per row block, each over
+# half of the hidden units, adding their halves of the second product into a zeroed result (eamd_ffn_t.hsplit).  Measured at
+# config 2's decoder: one workgroup per block 147 us whatever the grid, the GEMM pair 104 us, split in two 77 us.
+FUSED_FFN_HSPLIT_MIN_ROWS = int(os.environ.get("EAMD_FUSED_FFN_HSPLIT_MIN_ROWS", "1536"))
+
+
+def ffn_hsplit(M, F, bf):
+    if bf or M >= FUSED_FFN_MIN_ROWS or M < FUSED_FFN_HSPLIT_MIN_ROWS or F % 256 != 0 or F < 512:
+        return 1
+    return 2
 
 
 def _ffn_desc(x, w1, b1, w2, b2, R, out, f, h, act, alpha, drop, F=None):
@@ -606,12 +619,14 @@ def ffn_fwd(x, w1, b1, w2, b2, *, act, alpha=1.0, R=None, drop=(0.0, 0, 0.0, 0),
     for t_ in tuple(v for v in (b1, b2, R) if v is not None):
         if t_.dtype != torch.float32 or not t_.is_contiguous():
             raise _lib.EamdError("ffn_fwd: biases / residual are contiguous float32 tensors")
-    out = torch.empty(M, D, device=x.device, dtype=torch.float32)
+    hs = ffn_hsplit(M, F, dt == torch.bfloat16)
+    out = zeros(M, D, device=x.device) if hs > 1 else torch.empty(M, D, device=x.device, dtype=torch.float32)
     f = torch.empty(M, F, device=x.device, dtype=dt) if save else None
     h = torch.empty(M, F, device=x.device, dtype=dt) if save else None
     if packed is None:            # the kernels read the packed images (ffn_pack)
         packed = ffn_pack(w1, w2)[:2]
     p = _ffn_desc(x, packed[0], b1, packed[1], b2, R, out, f, h, act, alpha, drop, F=F)
+    p.hsplit = hs
     if ln is not None:
         xr, g, b, eps, mean, rstd = ln
         for t_ in (xr, g, b, mean, rstd):
@@ -650,11 +665,13 @@ def ffn_bwd(dy, w1, w2, f, *, alpha=1.0, packed=None):
     dt = dy.dtype
     assert f.shape == (M, F) and f.dtype == dt and f.is_contiguous() and dy.is_contiguous()
     dz = torch.empty(M, F, device=dy.device, dtype=dt)
-    dx = torch.empty(M, D, device=dy.device, dtype=torch.float32)
+    hs = ffn_hsplit(M, F, dt == torch.bfloat16)
+    dx = zeros(M, D, device=dy.device) if hs > 1 else torch.empty(M, D, device=dy.device, dtype=torch.float32)
     if packed is None:
         packed = ffn_pack(w1, w2)[2:]
     assert packed[0].numel() == F * D and packed[1].numel() == F * D and packed[0].dtype == dt
     p = _ffn_desc(dy, packed[0], None, packed[1], None, None, dx, f, dz, ACT_NONE, alpha, (0.0, 0, 0.0, 0), F=F)
+    p.hsplit = hs
     _ffn_call("eamd_ffn_bwd", p, (dy, packed, f, dz, dx))
     return dz, dx
 

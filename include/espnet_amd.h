@@ -176,7 +176,12 @@ typedef struct {
   int32_t M, D, F, act;
   float alpha;
   float p_in; uint64_t salt_in; float p_out; uint64_t salt_out; const void* drop_step;
-  int32_t dtype; int32_t reserved;
+  int32_t dtype;
+  /* hsplit = 2 (fp32 operands, F a multiple of 256; 0 / 1 = off): for few rows (M / 32 workgroups fill half the chip or less,
+   * e.g. the decoder's 3232 target positions) every 32-row block is served by TWO workgroups, each over half of the hidden
+   * units; both ADD their share of the second product to `out`, which the caller has ZEROED (two addends onto zeros: the
+   * result does not depend on their order).  h / f / dz are written per half as before. */
+  int32_t hsplit;
   /* Optional LayerNorm in front, eamd_ffn_fwd only (the norm_ff / norm_ff_macaron of conformer/encoder_layer.py:96-103,139-146
    * and transformer/decoder_layer.py: x + s * dropout(ff(norm(x)))).  ln_x != NULL: the block input is ln_x [M, D] fp32 and
    * the workgroup normalises its 32 rows while it stages them (nn.LayerNorm arithmetic: biased variance, rsqrt(var + eps));

@@ -1367,7 +1367,8 @@ def test_gemm_row_statistics_epilogue(ops, prec, tile, M, N, K):
 # fused position-wise feed-forward (eamd_ffn_fwd / eamd_ffn_bwd)
 # ---------------------------------------------------------------------------------------------
 @pytest.mark.parametrize("M,F,act,p_in,p_out", [(7968, 2048, 2, 0.1, 0.1), (4100, 1024, 1, 0.0, 0.0), (4097, 256, 2, 0.1, 0.0),
-                                                (33, 384, 2, 0.0, 0.2)])
+                                                (33, 384, 2, 0.0, 0.2),
+                                                (3232, 2048, 1, 0.1, 0.1), (1601, 512, 2, 0.1, 0.0)])      # hidden split in two
 def test_ffn_fused_vs_float64(ops, M, F, act, p_in, p_out):
     """positionwise_feed_forward.py:12-32 + the block wiring of conformer/encoder_layer.py:96-103 as ONE launch, against
     float64: out = R + alpha * drop(drop(act(x W1^T + b1)) W2^T + b2), the two tensors kept for backward (h and the

@@ -13,7 +13,7 @@ def main():
     prec = sys.argv[1] if len(sys.argv) > 1 else "fp32"
     espnet_amd.set_precision(prec)
     dt = ops.act_dtype()
-    M, D, F = 7968, 256, 2048
+    M, D, F = int(os.environ.get("FFN_PROBE_M", "7968")), 256, 2048
     dev = "cuda"
     x = torch.randn(M, D, device=dev).to(dt)
     w1 = (torch.randn(F, D, device=dev) * 0.05).to(dt)
