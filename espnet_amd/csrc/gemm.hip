@@ -417,6 +417,10 @@ static int gemm_check(eamd_gemm_t& p, int& tile_out) {
       // stores and barriers per MFMA), below that the 64x64 tile's 4x as many workgroups do
       // (the generic kernel, which still serves fp32 operands with bf16 MFMA, keeps its old threshold)
       tile = (t128 >= (p.precision == 0 ? 240 : 512) && p.M >= 128 && p.N >= 128) ? 128 : 64;
+      // ... except between one and one and a half tiles per CU: the second half-filled round of 128x128 tiles costs more than
+      // the 64x64 tile's loop (QKV projection 7968 x 768 x 256 = 378 tiles: 46.5 us, 41.5 us with 64x64; 252 and 416 tiles
+      // (7968 x 512, 3232 x 2048) are as good or better with 128x128)
+      if (p.precision == 0 && tile == 128 && t128 > 256 && t128 < 400 && p.splitk == 1) tile = 64;
     }
   }
   if (tile != 64 && tile != 128) return EAMD_EINVAL;

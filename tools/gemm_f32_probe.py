@@ -17,6 +17,8 @@ SHAPES = [  # name, M, N, K, transA, transB, splitks
     ("dW1     TN", 2048, 256, M, 1, 1, (1, 2, 4, 8)), ("dW2     TN", 256, 2048, M, 1, 1, (1, 2, 4, 8)),
     ("dWproj  TN", 256, 256, M, 1, 1, (4, 8, 16, 32)), ("pw1     NT", M, 512, 256, 0, 0, (1,)),
     ("dec ffn NT", 3232, 2048, 256, 0, 0, (1,)), ("dec prj NT", 3232, 256, 256, 0, 0, (1,)),
+    ("qkv     NT", M, 768, 256, 0, 0, (1,)), ("dqkv    NN", M, 256, 768, 0, 1, (1, 2)), ("dpw1    NN", M, 256, 512, 0, 1, (1, 2)),
+    ("dec out NT", 3232, 5000, 256, 0, 0, (1,)), ("dec dout NN", 3232, 256, 5000, 0, 1, (1, 2, 4)),
     ("ctc_lo  NT", M, 5000, 256, 0, 0, (1,)), ("embed   NT", M, 256, 4864, 0, 0, (1, 2, 4)),
 ]
 
