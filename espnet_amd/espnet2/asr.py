@@ -148,6 +148,11 @@ class TransformerDecoder(AbsDecoder, BatchScorerInterface):
     def batch_score(self, ys, states, xs):
         return self._dec[0].batch_score(ys, states, xs)
 
+    shared_memory_ok = True      # see nets.modules.Decoder: the searches hand over the memory of G utterances, not of G * beam rows
+
+    def batch_init_state(self, x):
+        return self._dec[0].batch_init_state(x)
+
     def score_tree(self, ys, tree, xs, memory_mask=None):
         return self._dec[0].score_tree(ys, tree, xs, memory_mask=memory_mask)
 

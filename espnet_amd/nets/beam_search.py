@@ -240,6 +240,7 @@ class BeamSearch(torch.nn.Module):
             c_s = torch.zeros(n, device=dev, dtype=torch.float32)
             c_r = r0.unsqueeze(0).expand(n, *r0.shape).contiguous()
         xs = x.unsqueeze(0).expand(n, *x.shape)
+        x1 = x.unsqueeze(0)            # for scorers with shared_memory_ok: ONE memory for the n hypotheses
         ended, pending, stop_at = [], [], None
         arange_v = torch.arange(V, device=dev).unsqueeze(0).expand(n, V) if (ctc is not None and not self.do_pre_beam) else None
 
@@ -284,7 +285,7 @@ class BeamSearch(torch.nn.Module):
                 weighted = torch.zeros(n, V, device=dev, dtype=torch.float32)
                 logps, newtrees = {}, {}
                 for k, d in self.full_scorers.items():
-                    logps[k], newtrees[k] = d.score_tree(ys, trees[k], xs)
+                    logps[k], newtrees[k] = d.score_tree(ys, trees[k], x1 if getattr(d, "shared_memory_ok", False) else xs)
                     weighted += self.weights[k] * logps[k]
                 part_ids = None
                 if self.do_pre_beam:
@@ -372,8 +373,11 @@ class BeamSearch(torch.nn.Module):
         xpad = torch.nn.utils.rnn.pad_sequence(list(xs), batch_first=True)                   # [B, Tmax, D]
         lens_d = torch.tensor(Ts, dtype=torch.int32, device=dev)
         xall = xpad.unsqueeze(1).expand(B, beam, Tmax, xpad.shape[-1]).reshape(n, Tmax, xpad.shape[-1])
-        mem_mask = (torch.arange(Tmax, device=dev)[None, :] < lens_d[:, None]).unsqueeze(1)    # [B, 1, Tmax]
-        mem_mask = mem_mask.unsqueeze(1).expand(B, beam, 1, Tmax).reshape(n, 1, Tmax)
+        mem_mask1 = (torch.arange(Tmax, device=dev)[None, :] < lens_d[:, None]).unsqueeze(1)   # [B, 1, Tmax]
+        mem_mask = mem_mask1.unsqueeze(1).expand(B, beam, 1, Tmax).reshape(n, 1, Tmax)
+        for d in self.full_scorers.values():         # a new search (scorers that keep per-search tensors drop them)
+            if hasattr(d, "batch_init_state"):
+                d.batch_init_state(xpad)
         uniform = all(T == Tmax for T in Ts)
         import inspect
         masked = {k for k, d in self.full_scorers.items() if "memory_mask" in inspect.signature(d.score_tree).parameters}
@@ -442,10 +446,12 @@ class BeamSearch(torch.nn.Module):
                 weighted = torch.zeros(n, V, device=dev, dtype=torch.float32)
                 logps, newtrees = {}, {}
                 for k, d in self.full_scorers.items():
+                    # scorers that take it get the memory of the B utterances, not of the B * beam slots (shared_memory_ok)
+                    mem, mm = (xpad, mem_mask1) if getattr(d, "shared_memory_ok", False) else (xall, mem_mask)
                     if not uniform and k in masked:
-                        logps[k], newtrees[k] = d.score_tree(ys, trees[k], xall, memory_mask=mem_mask)
+                        logps[k], newtrees[k] = d.score_tree(ys, trees[k], mem, memory_mask=mm)
                     else:
-                        logps[k], newtrees[k] = d.score_tree(ys, trees[k], xall)
+                        logps[k], newtrees[k] = d.score_tree(ys, trees[k], mem)
                     weighted += self.weights[k] * logps[k]
                 part_ids = None
                 if self.do_pre_beam:

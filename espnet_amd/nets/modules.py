@@ -815,8 +815,18 @@ class DecoderLayer(torch.nn.Module):
             assert cache.shape == (tgt.shape[0], tgt.shape[1] - 1, self.size)
             q_mask = None if tgt_mask is None else tgt_mask[:, -1:, :]
             x = mha_block(self.norm1, self.self_attn, tgt, None, None, q_mask, last_query_only=True, p_out=p)
-        x = mha_block(self.norm2, self.src_attn, x, memory, None, memory_mask, p_out=p,
-                      pre=self._pre if cache is None else None)
+        if memory.shape[0] != x.shape[0]:
+            # beam search: memory [G, T, D] of G utterances for n = G * g hypotheses with ONE query position each (row r
+            # belongs to utterance r // g).  The g hypotheses of an utterance are g query positions over ITS memory: keys and
+            # values are read once per utterance instead of once per hypothesis (and come from Decoder's per-search memo)
+            G, n = memory.shape[0], x.shape[0]
+            assert x.shape[1] == 1 and n % G == 0
+            xg = mha_block(self.norm2, self.src_attn, x.reshape(G, n // G, self.size), memory, None, memory_mask, p_out=p,
+                           pre=self._pre)
+            x = xg.reshape(n, 1, self.size)
+        else:
+            x = mha_block(self.norm2, self.src_attn, x, memory, None, memory_mask, p_out=p,
+                          pre=self._pre if cache is None else None)
         x = ffn_block(self.norm3, self.feed_forward, x, 1.0, p)
         if cache is not None:
             x = torch.cat([cache, x], dim=1)
@@ -886,9 +896,19 @@ class Decoder(torch.nn.Module, BatchScorerInterface):
         if cache is None:
             cache = [None] * len(self.decoders)
         new_cache = []
-        for c, decoder in zip(cache, self.decoders):
-            x, tgt_mask, memory, memory_mask = decoder(x, tgt_mask, memory, memory_mask, cache=c)
-            new_cache.append(x)
+        grouped = memory.shape[0] != x.shape[0]       # memory of G utterances for G * g hypotheses (DecoderLayer.forward)
+        if grouped:
+            sp = self._memory_kv(memory)
+            for i, decoder in enumerate(self.decoders):
+                decoder._pre = ("kv", sp, i, None)
+        try:
+            for c, decoder in zip(cache, self.decoders):
+                x, tgt_mask, memory, memory_mask = decoder(x, tgt_mask, memory, memory_mask, cache=c)
+                new_cache.append(x)
+        finally:
+            if grouped:
+                for decoder in self.decoders:
+                    decoder._pre = None
         y = x[:, -1]
         if self.normalize_before:
             y = self.after_norm(y.contiguous())
@@ -902,7 +922,29 @@ class Decoder(torch.nn.Module, BatchScorerInterface):
         return None
 
     def batch_init_state(self, x):
+        self._kv_memo = None          # a new search: the memory (and possibly the weights) changed
         return None
+
+    # The device-resident beam searches hand score_tree the memory of G utterances ([G, T, D], not repeated per hypothesis)
+    shared_memory_ok = True
+    _kv_memo = None
+
+    def _memory_kv(self, memory):
+        """keys and values of EVERY layer's source attention for the memory of a search, as one projection (the reference
+        recomputes linear_k / linear_v of the same memory in every layer at every step: decoder_layer.py:103-115) ->
+        F_.SharedProj whose column block i holds layer i's [k | v]; kept until batch_init_state() announces the next search"""
+        key = (memory.data_ptr(), tuple(memory.shape), memory.dtype, ops.act_dtype())
+        if self._kv_memo is not None and self._kv_memo[0] == key:
+            return self._kv_memo[1]
+        atts = [m.src_attn for m in self.decoders]
+        D = memory.shape[-1]
+        with torch.no_grad():
+            W = torch.cat([ops.wshadow(w).detach() for a in atts for w in (a.linear_k.weight, a.linear_v.weight)], 0)
+            b = torch.cat([v.detach() for a in atts for v in (a.linear_k.bias, a.linear_v.bias)], 0)
+            out = ops.linear_fwd(ops.to_act_shared(memory).reshape(-1, D), W, b, out_dtype=ops.act_dtype())
+        sp = F_.SharedProj(out, len(atts), False, ops.act_dtype())
+        self._kv_memo = (key, sp)
+        return sp
 
     def select_state(self, state, i, new_id=None):
         return None if state is None else state[i]
