@@ -1752,3 +1752,46 @@ def test_graphed_data_parallel_step_two_ranks():
         assert nph == 3 and steps == 4, (nph, steps)
         report("graphed DP step, 2 ranks (rank %d) vs single process" % rank, torch.from_numpy(data), want, 2e-5)
     assert np.array_equal(got[0][2], got[1][2])
+
+
+@pytest.mark.parametrize("prec", ["fp32", "bf16"])
+def test_decoder_step_memory_shared_by_the_hypotheses(prec):
+    """Decoder.score_tree with the memory of the G utterances ([G, T, D]: the hypotheses of an utterance are query positions
+    over its memory, keys / values of all layers from one projection per search) against the same call with the memory repeated
+    per hypothesis as the reference does (decoder.py:283-321, decoder_layer.py:103-115): same log-probabilities and caches
+    over four steps, one utterance and two utterances of different length (padded frames masked)."""
+    import espnet_amd
+    from espnet_amd.nets.modules import Decoder
+    espnet_amd.set_precision(prec)
+    try:
+        torch.manual_seed(3)
+        V, D, beam = 50, 256, 5
+        dec = Decoder(V, attention_dim=D, attention_heads=4, linear_units=512, num_blocks=2, dropout_rate=0.0,
+                      positional_dropout_rate=0.0, self_attention_dropout_rate=0.0, src_attention_dropout_rate=0.0).to("cuda").eval()
+        g = torch.Generator().manual_seed(4)
+        tol = 2e-5 if prec == "fp32" else 3e-2
+        for Ts in ([37], [41, 29]):
+            G = len(Ts)
+            n = G * beam
+            mem = torch.randn(G, max(Ts), D, generator=g).to("cuda")
+            lens = torch.tensor(Ts, device="cuda")
+            mask1 = (torch.arange(max(Ts), device="cuda")[None, :] < lens[:, None]).unsqueeze(1)          # [G, 1, T]
+            mem_rep = mem.unsqueeze(1).expand(G, beam, *mem.shape[1:]).reshape(n, *mem.shape[1:])
+            mask_rep = mask1.unsqueeze(1).expand(G, beam, 1, max(Ts)).reshape(n, 1, max(Ts))
+            ys = torch.randint(1, V - 1, (n, 5), generator=g).to("cuda")
+            dec.batch_init_state(mem)
+            tree_a = tree_b = None
+            with torch.no_grad():
+                for L in range(1, 5):
+                    la, tree_a = dec.score_tree(ys[:, :L], tree_a, mem, memory_mask=mask1 if G > 1 else None)
+                    lb, tree_b = dec.score_tree(ys[:, :L], tree_b, mem_rep, memory_mask=mask_rep if G > 1 else None)
+                    assert la.shape == (n, V) and torch.isfinite(la).all()
+                    report("decoder step %d, %d utterance(s), %s" % (L, G, prec), la, lb, tol)
+                    for ta, tb in zip(tree_a, tree_b):
+                        assert ta.shape == tb.shape == (n, L, D)
+                        assert rel_err(ta, tb) <= tol
+            assert dec._kv_memo is not None
+            dec.batch_init_state(mem)
+            assert dec._kv_memo is None
+    finally:
+        espnet_amd.set_precision("fp32")
