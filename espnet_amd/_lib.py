@@ -147,6 +147,8 @@ def ptr(t, offset=0):
         return None
     if not t.is_cuda:
         raise EamdError("espnet_amd kernels need GPU tensors (no CPU fallback in the product path)")
+    if offset == 0:
+        return C.c_void_p(t.data_ptr())
     return C.c_void_p(t.data_ptr() + offset * t.element_size())
 
 
