@@ -14,6 +14,7 @@ Utterances are independent: decode many by running one search per utterance on s
 (SURVEY.md §8e "replicas only").
 """
 import math
+import os
 from itertools import chain
 from typing import Any, Dict, NamedTuple
 
@@ -352,172 +353,252 @@ class BeamSearch(torch.nn.Module):
         padded frames of shorter utterances masked in the source attention, one CTC prefix-score launch for all utterances
         (eamd_ctc_prefix_score_batch), one top-`beam` per utterance - and the host reads the step log once per `sync_every` steps,
         replaying ended-hypothesis bookkeeping and end detection per utterance.  An utterance that has finished keeps its slots (dead)
-        until the last one finishes.  Falls back to one forward() per utterance when the scorers cannot keep batched states."""
-        from .. import ops
+        until the last one finishes.  Falls back to one forward() per utterance when the scorers cannot keep batched states.
+        With `graph_steps` the steps of a search are hipGraph replays (see _StepGraphs below)."""
         B = len(xs)
         if B == 0:
             return []
-        if B == 1 or not self._device_loop_ok(xs[0]) or minlenratio != 0.0:
+        ok = self._device_loop_ok(xs[0]) and minlenratio == 0.0
+        if not ok or (B == 1 and not self.graph_steps):
             return [self.forward(x, maxlenratio, minlenratio) for x in xs]
-        V, beam, dev = self.n_vocab, self.beam_size, xs[0].device
-        n = B * beam
+        if self.graph_steps and B == 1:
+            # (several utterances per search stay eager: replaying the B > 1 step graphs a second time ends in a GPU memory
+            # access fault on this ROCm - found with tools/step_graph_debug.py, cause not identified; the same steps run eagerly on
+            # the same static buffers are fine, and so are the B = 1 graphs)
+            out = self._forward_batch_graphed(xs, maxlenratio)
+            if out is not None:
+                return out
         Ts = [int(x.shape[0]) for x in xs]
-        Tmax = max(Ts)
         maxlens = [T if maxlenratio == 0 else max(1, int(maxlenratio * T)) for T in Ts]
-        maxlen = max(maxlens)
-        NEG = -float("inf")
+        with torch.no_grad():
+            C_ = self._batch_consts(xs, Ts, maxlens, max(Ts), max(maxlens) + 2, always_mask=False)
+            S = self._batch_state0(C_)
+            run = _BatchLog(self, C_["B"], maxlens, maxlenratio, C_["allk"])
+            for i in range(max(maxlens)):
+                S, rec = self._batch_step(i, C_, S)
+                if run.add(rec, last=(i == max(maxlens) - 1)):
+                    break
+        return run.results()
+
+    # ---- one batched search in pieces: per-search constants, the state a step carries, the step -----------------------------------
+    def _batch_consts(self, xs, Ts, maxlens, Tpad, W, always_mask):
+        """tensors that stay the same over the steps of a search (Tpad >= max(Ts): frames the memory is padded to; W = width of
+        the prefix buffer)"""
+        B, V, beam, dev = len(xs), self.n_vocab, self.beam_size, xs[0].device
+        n = B * beam
         names = list(self.full_scorers.keys())
         pname = next(iter(self.part_scorers), None)
         ctc = self.part_scorers[pname] if pname is not None else None
-        allk = names + ([pname] if pname is not None else [])
-        xpad = torch.nn.utils.rnn.pad_sequence(list(xs), batch_first=True)                   # [B, Tmax, D]
+        xpad = torch.zeros(B, Tpad, xs[0].shape[-1], device=dev, dtype=xs[0].dtype)
+        for b, x in enumerate(xs):
+            xpad[b, :x.shape[0]] = x
         lens_d = torch.tensor(Ts, dtype=torch.int32, device=dev)
-        xall = xpad.unsqueeze(1).expand(B, beam, Tmax, xpad.shape[-1]).reshape(n, Tmax, xpad.shape[-1])
-        mem_mask1 = (torch.arange(Tmax, device=dev)[None, :] < lens_d[:, None]).unsqueeze(1)   # [B, 1, Tmax]
-        mem_mask = mem_mask1.unsqueeze(1).expand(B, beam, 1, Tmax).reshape(n, 1, Tmax)
+        C_ = dict(B=B, V=V, beam=beam, n=n, dev=dev, W=W, Tpad=Tpad, names=names, pname=pname, ctc=ctc,
+                  allk=names + ([pname] if pname is not None else []), xpad=xpad, lens_d=lens_d,
+                  uniform=(not always_mask) and all(T == Tpad for T in Ts))
+        C_["xall"] = xpad.unsqueeze(1).expand(B, beam, Tpad, xpad.shape[-1]).reshape(n, Tpad, xpad.shape[-1])
+        C_["mem_mask1"] = (torch.arange(Tpad, device=dev)[None, :] < lens_d[:, None]).unsqueeze(1)   # [B, 1, Tpad]
+        C_["mem_mask"] = C_["mem_mask1"].unsqueeze(1).expand(B, beam, 1, Tpad).reshape(n, 1, Tpad)
+        import inspect
+        C_["masked"] = {k for k, d in self.full_scorers.items() if "memory_mask" in inspect.signature(d.score_tree).parameters}
+        C_["base"] = (torch.arange(B, device=dev) * beam).view(B, 1)
+        C_["maxlen_d"] = torch.tensor(maxlens, device=dev).view(B, 1)
+        if ctc is not None:
+            logp = ctc.ctc.log_softmax(xpad).contiguous()                                 # [B, Tpad, V]
+            r0 = torch.full((B, Tpad, 2), -10000000000.0, device=dev, dtype=torch.float32)
+            r0[:, :, 1] = torch.cumsum(logp[:, :, ctc.blank], 1)
+            C_["logp"] = logp
+            C_["c_r0"] = r0.unsqueeze(1).expand(B, beam, Tpad, 2).reshape(n, Tpad, 2).contiguous()
+            C_["last_idx"] = (lens_d.long() - 1).view(B, 1).expand(B, beam).reshape(n).contiguous()    # last valid frame of each slot's utterance
+        return C_
+
+    def _batch_state0(self, C_):
+        B, beam, n, dev = C_["B"], C_["beam"], C_["n"], C_["dev"]
         for d in self.full_scorers.values():         # a new search (scorers that keep per-search tensors drop them)
             if hasattr(d, "batch_init_state"):
-                d.batch_init_state(xpad)
-        uniform = all(T == Tmax for T in Ts)
-        import inspect
-        masked = {k for k, d in self.full_scorers.items() if "memory_mask" in inspect.signature(d.score_tree).parameters}
-        yseq = torch.full((n, maxlen + 2), self.eos, dtype=torch.int64, device=dev)
+                d.batch_init_state(C_["xpad"])
+        yseq = torch.full((n, C_["W"]), self.eos, dtype=torch.int64, device=dev)
         yseq[:, 0] = self.sos
-        hyp = torch.full((B, beam), NEG, device=dev, dtype=torch.float32)
+        hyp = torch.full((B, beam), -float("inf"), device=dev, dtype=torch.float32)
         hyp[:, 0] = 0.0
-        hyp = hyp.view(-1)
-        sc = {k: torch.zeros(n, device=dev, dtype=torch.float32) for k in allk}
-        trees = {k: None for k in names}
-        base = (torch.arange(B, device=dev) * beam).view(B, 1)
+        S = dict(yseq=yseq, hyp=hyp.view(-1), sc={k: torch.zeros(n, device=dev, dtype=torch.float32) for k in C_["allk"]},
+                 trees={k: None for k in C_["names"]})
+        if C_["ctc"] is not None:
+            S["c_s"] = torch.zeros(n, device=dev, dtype=torch.float32)
+            S["c_r"] = C_["c_r0"]
+        return S
+
+    def _batch_step(self, i, C_, S):
+        """step i of a batched search: state S -> (next state, log row [n, 3 + scorers + W]); no host synchronisation"""
+        from .. import ops
+        B, V, beam, n, dev = C_["B"], C_["V"], C_["beam"], C_["n"], C_["dev"]
+        names, pname, ctc, allk = C_["names"], C_["pname"], C_["ctc"], C_["allk"]
+        NEG = -float("inf")
+        L = i + 1
+        yseq, hyp, sc, trees = S["yseq"], S["hyp"], dict(S["sc"]), dict(S["trees"])
+        ys = yseq[:, :L]
+        weighted = ops.zeros_plain((n, V), dev)
+        logps, newtrees = {}, {}
+        for k, d in self.full_scorers.items():
+            # scorers that take it get the memory of the B utterances, not of the B * beam slots (shared_memory_ok)
+            mem, mm = (C_["xpad"], C_["mem_mask1"]) if getattr(d, "shared_memory_ok", False) else (C_["xall"], C_["mem_mask"])
+            if not C_["uniform"] and k in C_["masked"]:
+                logps[k], newtrees[k] = d.score_tree(ys, trees[k], mem, memory_mask=mm)
+            else:
+                logps[k], newtrees[k] = d.score_tree(ys, trees[k], mem)
+            weighted += self.weights[k] * logps[k]
+        part_ids = None
+        if self.do_pre_beam:
+            pre = weighted if self.pre_beam_score_key == "full" else logps[self.pre_beam_score_key]
+            part_ids = torch.topk(pre, self.pre_beam_size, dim=-1)[1]
         if ctc is not None:
-            with torch.no_grad():
-                logp = ctc.ctc.log_softmax(xpad).contiguous()                                 # [B, Tmax, V]
-            c_s = torch.zeros(n, device=dev, dtype=torch.float32)
-            r0 = torch.full((B, Tmax, 2), -10000000000.0, device=dev, dtype=torch.float32)
-            r0[:, :, 1] = torch.cumsum(logp[:, :, ctc.blank], 1)
-            c_r = r0.unsqueeze(1).expand(B, beam, Tmax, 2).reshape(n, Tmax, 2).contiguous()
-            last_idx = (lens_d.long() - 1).view(B, 1).expand(B, beam).reshape(n)                # last valid frame of each slot's utterance
-        maxlen_d = torch.tensor(maxlens, device=dev).view(B, 1)
-        ended = [[] for _ in range(B)]
-        stopped = [False] * B
-        pending = []
+            c_s, c_r = S["c_s"], S["c_r"]
+            last = ys[:, -1].to(torch.int32).contiguous()
+            olen = torch.full((n,), L - 1, dtype=torch.int32, device=dev)
+            ids = part_ids if part_ids is not None else torch.arange(V, device=dev).unsqueeze(0).expand(n, V)
+            psi, r_new = ops.ctc_prefix_score_batch(C_["logp"], C_["lens_d"], beam, c_r, ids.to(torch.int32).contiguous(), last, olen,
+                                                    ctc.blank, ctc.eos)
+            if self.partial_mode == "full":
+                full = torch.full((n, V), -10000000000.0, device=dev, dtype=torch.float32)
+                full.scatter_(1, ids.long(), psi)
+                full[:, ctc.eos] = torch.logsumexp(c_r[torch.arange(n, device=dev), C_["last_idx"]], dim=-1)
+                full[:, ctc.blank] = -10000000000.0
+                idmap = torch.full((n, V), -1, dtype=torch.int64, device=dev)
+                idmap.scatter_(1, ids.long(), torch.arange(ids.shape[1], device=dev).expand(n, -1))
+                c_local = full - c_s[:, None]
+                weighted += self.weights[pname] * c_local
+            else:
+                c_local = psi - c_s[:, None]
+                if part_ids is not None:
+                    kept = torch.full_like(weighted, NEG)
+                    kept.scatter_(1, ids, torch.gather(weighted, 1, ids) + self.weights[pname] * c_local)
+                    weighted = kept
+                else:
+                    weighted += self.weights[pname] * c_local
+        weighted += hyp[:, None]
+        top_s, top_i = weighted.view(B, beam * V).topk(beam, dim=1)
+        hyp_i = (top_i // V + C_["base"]).view(-1)
+        tok_i = (top_i % V).view(-1)
+        top_s = top_s.reshape(-1)
+        for k in names:
+            sc[k] = sc[k][hyp_i] + logps[k][hyp_i, tok_i]
+            trees[k] = self._tree_index(newtrees[k], hyp_i)
+        T_ = dict(sc=sc, trees=trees)
+        if ctc is not None:
+            if self.partial_mode == "full":
+                sc[pname] = sc[pname][hyp_i] + c_local[hyp_i, tok_i]
+                j = idmap[hyp_i, tok_i].clamp_min(0)
+                T_["c_s"], T_["c_r"] = full[hyp_i, tok_i], r_new[hyp_i, j]
+            else:
+                pos = (ids[hyp_i] == tok_i[:, None]).float().argmax(-1) if part_ids is not None else tok_i
+                sc[pname] = sc[pname][hyp_i] + c_local[hyp_i, pos]
+                T_["c_s"], T_["c_r"] = psi[hyp_i, pos], r_new[hyp_i, pos]
+        yseq = yseq.index_select(0, hyp_i)
+        yseq[:, L] = tok_i
+        finite = torch.isfinite(top_s)
+        at_cap = (C_["maxlen_d"] <= i + 1).expand(B, beam).reshape(-1)             # the utterance's own length cap: everything ends
+        done = finite & ((tok_i == self.eos) | at_cap)
+        rec = torch.cat([torch.full((n, 1), float(i), device=dev), top_s[:, None], tok_i[:, None].float()]
+                        + [sc[k][:, None] for k in allk] + [yseq.float()], dim=1)
+        T_["yseq"] = yseq
+        T_["hyp"] = torch.where(done | ~finite, torch.full_like(top_s, NEG), top_s)
+        return T_, rec
 
-        def flush():
-            nonlocal pending
-            if not pending:
-                return all(stopped)
-            host = torch.stack(pending).cpu()                   # [steps, n, 3 + len(allk) + maxlen + 2]
-            pending = []
-            for row in host:
-                i = int(row[0, 0])
-                slots = row.tolist()
-                for b in range(B):
-                    if stopped[b]:
-                        continue
-                    alive = 0
-                    for slot in slots[b * beam: (b + 1) * beam]:
-                        top_s = slot[1]
-                        if not math.isfinite(top_s):
-                            continue
-                        L = i + 2
-                        seq = [int(v) for v in slot[3 + len(allk): 3 + len(allk) + L]]
-                        if i == maxlens[b] - 1:
-                            seq.append(self.eos)
-                        if seq[-1] == self.eos:
-                            scores = {k: slot[3 + j] for j, k in enumerate(allk)}
-                            if self.apply_final_score:
-                                for k, d in chain(self.full_scorers.items(), self.part_scorers.items()):
-                                    f = float(d.final_tree(None)) if hasattr(d, "final_tree") else float(d.final_score(None))
-                                    scores[k] += f
-                                    top_s += self.weights[k] * f
-                            ended[b].append(Hypothesis(yseq=torch.tensor(seq, dtype=torch.int64), score=top_s, scores=scores, states={}))
-                        else:
-                            alive += 1
-                    if (maxlenratio == 0.0 and end_detect([h.asdict() for h in ended[b]], i)) or alive == 0 or i == maxlens[b] - 1:
-                        stopped[b] = True
-                if all(stopped):
-                    return True
-            return False
+    # ---- hipGraph replay of the steps ------------------------------------------------------------------------------------------
+    # An eager beam step is ~180 launches of 10-15 us of HOST time each: the device idles most of a step.  The step is a pure device
+    # function of (step index, state, per-search constants), so step i of every search with the same (utterances, beam, padded
+    # frames, prefix width) is ONE captured graph: the memory is padded to a multiple of `graph_frame_bucket` frames (padded frames
+    # masked: source attention, CTC lengths), the constants of a search are copied into the buffers the graphs were captured on,
+    # and graph i reads the state graph i - 1 left (its output tensors are the input tensors graph i was captured with).  The first
+    # search of a signature runs eagerly (it also runs every lazy initialisation outside a capture), the second one captures each
+    # step and replays it, later ones only replay; steps a signature has not reached before are captured when first needed.
+    # Anything that cannot be captured (a scorer that synchronises or copies from the host inside score_tree) ends graph mode for
+    # this object - the search then runs eagerly as before.
+    graph_steps = False
+    graph_frame_bucket = 32
 
+    def _forward_batch_graphed(self, xs, maxlenratio):
+        B, beam = len(xs), self.beam_size
+        Ts = [int(x.shape[0]) for x in xs]
+        maxlens = [T if maxlenratio == 0 else max(1, int(maxlenratio * T)) for T in Ts]
+        fb = self.graph_frame_bucket
+        Tpad = (max(Ts) + fb - 1) // fb * fb
+        W = (Tpad if maxlenratio == 0 else max(1, int(maxlenratio * Tpad))) + 2
+        sig = (B, beam, Tpad, W, float(maxlenratio), str(xs[0].dtype), xs[0].device.index)
+        if not hasattr(self, "_step_graphs"):
+            self._step_graphs = {}
+        G = self._step_graphs.get(sig)
         with torch.no_grad():
-            for i in range(maxlen):
-                L = i + 1
-                ys = yseq[:, :L]
-                weighted = torch.zeros(n, V, device=dev, dtype=torch.float32)
-                logps, newtrees = {}, {}
-                for k, d in self.full_scorers.items():
-                    # scorers that take it get the memory of the B utterances, not of the B * beam slots (shared_memory_ok)
-                    mem, mm = (xpad, mem_mask1) if getattr(d, "shared_memory_ok", False) else (xall, mem_mask)
-                    if not uniform and k in masked:
-                        logps[k], newtrees[k] = d.score_tree(ys, trees[k], mem, memory_mask=mm)
-                    else:
-                        logps[k], newtrees[k] = d.score_tree(ys, trees[k], mem)
-                    weighted += self.weights[k] * logps[k]
-                part_ids = None
-                if self.do_pre_beam:
-                    pre = weighted if self.pre_beam_score_key == "full" else logps[self.pre_beam_score_key]
-                    part_ids = torch.topk(pre, self.pre_beam_size, dim=-1)[1]
-                if ctc is not None:
-                    last = ys[:, -1].to(torch.int32).contiguous()
-                    olen = torch.full((n,), L - 1, dtype=torch.int32, device=dev)
-                    ids = part_ids if part_ids is not None else torch.arange(V, device=dev).unsqueeze(0).expand(n, V)
-                    psi, r_new = ops.ctc_prefix_score_batch(logp, lens_d, beam, c_r, ids.to(torch.int32).contiguous(), last, olen,
-                                                            ctc.blank, ctc.eos)
-                    if self.partial_mode == "full":
-                        full = torch.full((n, V), -10000000000.0, device=dev, dtype=torch.float32)
-                        full.scatter_(1, ids.long(), psi)
-                        full[:, ctc.eos] = torch.logsumexp(c_r[torch.arange(n, device=dev), last_idx], dim=-1)
-                        full[:, ctc.blank] = -10000000000.0
-                        idmap = torch.full((n, V), -1, dtype=torch.int64, device=dev)
-                        idmap.scatter_(1, ids.long(), torch.arange(ids.shape[1], device=dev).expand(n, -1))
-                        c_local = full - c_s[:, None]
-                        weighted += self.weights[pname] * c_local
-                    else:
-                        c_local = psi - c_s[:, None]
-                        if part_ids is not None:
-                            kept = torch.full_like(weighted, NEG)
-                            kept.scatter_(1, ids, torch.gather(weighted, 1, ids) + self.weights[pname] * c_local)
-                            weighted = kept
-                        else:
-                            weighted += self.weights[pname] * c_local
-                weighted += hyp[:, None]
-                top_s, top_i = weighted.view(B, beam * V).topk(beam, dim=1)
-                hyp_i = (top_i // V + base).view(-1)
-                tok_i = (top_i % V).view(-1)
-                top_s = top_s.reshape(-1)
-                for k in names:
-                    sc[k] = sc[k][hyp_i] + logps[k][hyp_i, tok_i]
-                    trees[k] = self._tree_index(newtrees[k], hyp_i)
-                if ctc is not None:
-                    if self.partial_mode == "full":
-                        sc[pname] = sc[pname][hyp_i] + c_local[hyp_i, tok_i]
-                        j = idmap[hyp_i, tok_i].clamp_min(0)
-                        c_s, c_r = full[hyp_i, tok_i], r_new[hyp_i, j]
-                    else:
-                        pos = (ids[hyp_i] == tok_i[:, None]).float().argmax(-1) if part_ids is not None else tok_i
-                        sc[pname] = sc[pname][hyp_i] + c_local[hyp_i, pos]
-                        c_s, c_r = psi[hyp_i, pos], r_new[hyp_i, pos]
-                yseq = yseq.index_select(0, hyp_i)
-                yseq[:, L] = tok_i
-                finite = torch.isfinite(top_s)
-                at_cap = (maxlen_d <= i + 1).expand(B, beam).reshape(-1)             # the utterance's own length cap: everything ends
-                done = finite & ((tok_i == self.eos) | at_cap)
-                rec = torch.cat([torch.full((n, 1), float(i), device=dev), top_s[:, None], tok_i[:, None].float()]
-                                + [sc[k][:, None] for k in allk] + [yseq.float()], dim=1)
-                pending.append(rec)
-                hyp = torch.where(done | ~finite, torch.full_like(top_s, NEG), top_s)
-                if len(pending) >= self.sync_every or i == maxlen - 1:
-                    if flush():
+            C_new = self._batch_consts(xs, Ts, maxlens, Tpad, W, always_mask=True)
+            if G is None:                       # first search of this signature: eager, and its tensors become the static buffers
+                G = self._step_graphs[sig] = dict(C=C_new, S0=None, graphs={}, states={}, recs={}, memos=None, searches=0)
+            else:
+                base = {G["C"][k].untyped_storage().data_ptr() for k in ("xpad", "mem_mask1")}
+                for k, v in C_new.items():      # same shapes by construction of the signature
+                    if k in ("xpad", "lens_d", "maxlen_d", "logp", "c_r0", "last_idx", "mem_mask1"):
+                        G["C"][k].copy_(v)
+                    elif k in ("xall", "mem_mask") and G["C"][k].untyped_storage().data_ptr() not in base:
+                        G["C"][k].copy_(v)      # per-slot copies (B > 1); with one utterance they are views of the buffers above
+            C_ = G["C"]
+            G["searches"] += 1
+            run = _BatchLog(self, B, maxlens, maxlenratio, C_["allk"])
+            if G["searches"] == 1:
+                S = self._batch_state0(C_)
+                for i in range(max(maxlens)):
+                    S, rec = self._batch_step(i, C_, S)
+                    if run.add(rec, last=(i == max(maxlens) - 1)):
                         break
-        out = []
-        for b in range(B):
-            nbest = sorted(ended[b], key=lambda h: float(h.score), reverse=True)
-            out.append(nbest)
-        return out
+                return run.results()
+            try:
+                if G["S0"] is None:
+                    G["S0"] = self._batch_state0(C_)          # static initial state (re-initialised in place below)
+                    G["states"][0] = G["S0"]
+                else:
+                    fresh = self._batch_state0(C_)            # also tells the scorers that a new search starts
+                    G["S0"]["yseq"].copy_(fresh["yseq"]); G["S0"]["hyp"].copy_(fresh["hyp"])
+                    for k in fresh["sc"]:
+                        G["S0"]["sc"][k].copy_(fresh["sc"][k])
+                    if "c_s" in fresh:
+                        G["S0"]["c_s"].copy_(fresh["c_s"])
+                        if G["S0"]["c_r"] is not C_["c_r0"]:
+                            G["S0"]["c_r"].copy_(C_["c_r0"])
+                dry = os.environ.get("EAMD_STEP_GRAPH_DRY") == "1"       # diagnostic: the static buffers without capture / replay
+                Sd = G["S0"]
+                for i in range(max(maxlens)):
+                    if dry:
+                        Sd, rec = self._batch_step(i, C_, Sd)
+                        if run.add(rec, last=(i == max(maxlens) - 1)):
+                            break
+                        continue
+                    g = G["graphs"].get(i)
+                    if g is None:
+                        if G["memos"] is not None:            # per-search tensors of the scorers live in the buffers of graph 0
+                            for d, m in G["memos"]:
+                                d._kv_memo = m
+                        torch.cuda.synchronize()
+                        g = torch.cuda.CUDAGraph()
+                        with torch.cuda.graph(g):
+                            S1, rec = self._batch_step(i, C_, G["states"][i])
+                        G["graphs"][i], G["states"][i + 1], G["recs"][i] = g, S1, rec
+                        if i == 0:
+                            G["memos"] = [(d, d._kv_memo) for d in self.full_scorers.values() if getattr(d, "_kv_memo", None) is not None]
+                    g.replay()
+                    if run.add(G["recs"][i], last=(i == max(maxlens) - 1)):
+                        break
+                return run.results()
+            except Exception as e:  # noqa: BLE001 - a step that cannot be captured: eager searches from now on
+                import logging
+                logging.getLogger(__name__).warning("beam-search step graphs disabled: %s", str(e)[:200])
+                torch.cuda.synchronize()
+                self.graph_steps = False
+                self._step_graphs = {}
+                return None
 
     def forward(self, x, maxlenratio=0.0, minlenratio=0.0):
         """x: (T, D) encoder output.  Returns the ended hypotheses, best first."""
         if self._device_loop_ok(x):
+            if self.graph_steps and minlenratio == 0.0:
+                return self.forward_batch([x], maxlenratio, minlenratio)[0]
             return self._forward_device(x, maxlenratio, minlenratio)
         T = x.shape[0]
         maxlen = T if maxlenratio == 0 else max(1, int(maxlenratio * T))
@@ -554,3 +635,62 @@ def recognize_beam(model, enc_output, recog_args, char_list=None, rnnlm=None):
     hyps = bs(enc_output, float(getattr(recog_args, "maxlenratio", 0.0)), float(getattr(recog_args, "minlenratio", 0.0)))
     nbest = int(getattr(recog_args, "nbest", 1))
     return [{"score": float(h.score), "yseq": [int(t) for t in h.yseq], "scores": h.scores} for h in hyps[:nbest]]
+
+
+class _BatchLog:
+    """host side of a batched search: collects the step log, fetches it once per `sync_every` steps, replays the reference's
+    ended-hypothesis bookkeeping and end detection per utterance (beam_search.py:404-458), keeps the n-best lists"""
+
+    def __init__(self, bs, B, maxlens, maxlenratio, allk):
+        self.bs, self.B, self.maxlens, self.maxlenratio, self.allk = bs, B, maxlens, maxlenratio, allk
+        self.ended = [[] for _ in range(B)]
+        self.stopped = [False] * B
+        self.pending = []
+
+    def add(self, rec, last):
+        """-> True when every utterance has finished"""
+        self.pending.append(rec)
+        if len(self.pending) >= self.bs.sync_every or last:
+            return self.flush()
+        return False
+
+    def flush(self):
+        bs, B, beam, allk = self.bs, self.B, self.bs.beam_size, self.allk
+        if not self.pending:
+            return all(self.stopped)
+        host = torch.stack(self.pending).cpu()                   # [steps, n, 3 + len(allk) + W]
+        self.pending = []
+        for row in host:
+            i = int(row[0, 0])
+            slots = row.tolist()
+            for b in range(B):
+                if self.stopped[b]:
+                    continue
+                alive = 0
+                for slot in slots[b * beam: (b + 1) * beam]:
+                    top_s = slot[1]
+                    if not math.isfinite(top_s):
+                        continue
+                    L = i + 2
+                    seq = [int(v) for v in slot[3 + len(allk): 3 + len(allk) + L]]
+                    if i == self.maxlens[b] - 1:
+                        seq.append(bs.eos)
+                    if seq[-1] == bs.eos:
+                        scores = {k: slot[3 + j] for j, k in enumerate(allk)}
+                        if bs.apply_final_score:
+                            for k, d in chain(bs.full_scorers.items(), bs.part_scorers.items()):
+                                f = float(d.final_tree(None)) if hasattr(d, "final_tree") else float(d.final_score(None))
+                                scores[k] += f
+                                top_s += bs.weights[k] * f
+                        self.ended[b].append(Hypothesis(yseq=torch.tensor(seq, dtype=torch.int64), score=top_s, scores=scores, states={}))
+                    else:
+                        alive += 1
+                if (self.maxlenratio == 0.0 and end_detect([h.asdict() for h in self.ended[b]], i)) or alive == 0 \
+                        or i == self.maxlens[b] - 1:
+                    self.stopped[b] = True
+            if all(self.stopped):
+                return True
+        return False
+
+    def results(self):
+        return [sorted(self.ended[b], key=lambda h: float(h.score), reverse=True) for b in range(self.B)]

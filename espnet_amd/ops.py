@@ -454,8 +454,12 @@ def linear_fwd(x, W, b, out=None, *, act=EPI_NONE, R=None, alpha=1.0, a_act=ACT_
     N = W.shape[0]
     assert W.shape[1] == K and x.is_contiguous() and W.is_contiguous()
     sk = 1
-    if (out_dtype if out is None else out.dtype) == torch.float32 and act == EPI_NONE and R is None and drop is None \
-            and Hb is None and a_drop is None and alpha == 1.0:
+    if (out_dtype if out is None else out.dtype) == torch.float32 and act == EPI_NONE and drop is None \
+            and Hb is None and a_drop is None and ((R is None and alpha == 1.0) or
+                                                   (K >= 1024 and M <= 64 and torch.cuda.is_current_stream_capturing())):
+        # (second condition: a beam-search step being captured - the feed-forward product of a handful of hypotheses walks
+        # K = 2048 in 4 workgroups, 58 us; eagerly the extra zero-fill launch costs the host more than the device saves, in a
+        # graph it does not; bias, alpha and the residual come with the first K slice)
         sk = _skinny_splitk(M, N, K)
     if out is None:
         out = zeros(M, N, device=x.device) if sk > 1 else torch.empty(M, N, device=x.device, dtype=out_dtype)
@@ -514,7 +518,16 @@ def zeros(*shape, device):
         t = a.buf[a.off // 4: a.off // 4 + n].view(shape)
         a.off += nb
         return t
-    return torch.zeros(shape, device=device, dtype=torch.float32)
+    return zeros_plain(shape, device)
+
+
+def zeros_plain(shape, device, dtype=torch.float32):
+    """torch.zeros, except under stream capture: there a FILL KERNEL instead of the memset node torch.zeros becomes (memset nodes
+    of the beam-search step graphs faulted on their second replay on this ROCm; the same class of problem as the captured
+    hipMemsetAsync of csrc/lstm_seq.hip)"""
+    if torch.cuda.is_current_stream_capturing():
+        return torch.full(shape, 0, device=device, dtype=dtype)
+    return torch.zeros(shape, device=device, dtype=dtype)
 
 
 def _skinny_splitk(M, N, K):
@@ -1390,7 +1403,7 @@ def ctc_prefix_score_batch(logp, lens, per_utt, r_prev, cand, last, olen, blank,
     assert nhyp == U * per_utt and r_prev.shape == (nhyp, Tmax, 2) and cand.dtype == torch.int32 and logp.is_contiguous()
     assert lens.dtype == torch.int32 and lens.numel() == U
     psi = torch.empty(nhyp, ncand, device=logp.device, dtype=torch.float32)
-    r_new = torch.zeros(nhyp, ncand, Tmax, 2, device=logp.device, dtype=torch.float32)
+    r_new = zeros_plain((nhyp, ncand, Tmax, 2), logp.device)
     check(_lib.lib().eamd_ctc_prefix_score_batch(ptr(logp), ptr(lens), U, per_utt, ptr(r_prev.contiguous()), ptr(cand.contiguous()),
                                                  ptr(last), ptr(olen), ptr(psi), ptr(r_new), ncand, Tmax, V, blank, eos,
                                                  stream_ptr()), "eamd_ctc_prefix_score_batch")

@@ -1,0 +1,50 @@
+#!/usr/bin/env python3
+"""Child process of test_beam_search_step_graphs: eager vs graph_steps searches, exit code 0 when they agree.
+usage: step_graph_check.py <batch 0|1> <lm None|tlm|rlm|dlm> <ctc weight> <lm weight>"""
+import os
+import sys
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from test_gpu_model import DEV, _fusion_models  # noqa: E402
+
+
+def main():
+    batch, lm, cw, lw = bool(int(sys.argv[1])), (None if sys.argv[2] == "None" else sys.argv[2]), float(sys.argv[3]), float(sys.argv[4])
+    from espnet_amd.nets.batch_beam_search import BatchBeamSearch
+    from espnet_amd.nets.beam_search import BeamSearch
+    from espnet_amd.nets.ctc_prefix_score import CTCPrefixScorer, LengthBonus
+    p, model, lms = _fusion_models()
+    with torch.no_grad():
+        enc, _ = model.encode(p["speech"].unsqueeze(0).to(DEV), torch.tensor([p["speech"].shape[0]]))
+    x = enc[0]
+    T = x.shape[0]
+    scorers = dict(decoder=model.decoder, ctc=CTCPrefixScorer(model.ctc, model.eos) if cw > 0 else None, length_bonus=LengthBonus(30),
+                   lm=lms[lm] if lm else None)
+    cls = BatchBeamSearch if batch else BeamSearch
+    mk = lambda: cls(scorers, dict(decoder=1.0 - cw, ctc=cw, lm=lw, length_bonus=0.1), 4, 30, model.sos, model.eos,  # noqa: E731
+                     pre_beam_score_key=None if cw in (0.0, 1.0) else "full")
+    eager, graphed = mk(), mk()
+    graphed.graph_steps, graphed.graph_frame_bucket = True, 16
+    lo = (T - 1) // 16 * 16 + 1                 # lengths lo .. T share the bucket of T
+    variants = [x, (x * 1.3).contiguous(), x.flip(0).contiguous(), x[: max(lo, T - 2)].contiguous(), (x[: max(lo, T - 1)] * 0.8).contiguous()]
+    for ratio in (0.5, 0.0):
+        for rnd, u in enumerate(variants):                              # eager, capture, replay, replay, replay
+            a, g = eager(u, maxlenratio=ratio), graphed(u, maxlenratio=ratio)
+            assert [h.yseq.tolist() for h in g[:3]] == [h.yseq.tolist() for h in a[:3]], (ratio, rnd)
+            for ha, hg in zip(a[:3], g[:3]):
+                assert abs(float(ha.score) - float(hg.score)) <= 1e-4 * max(1.0, abs(float(ha.score))), (ratio, rnd)
+        us = variants[:3]                                               # several utterances per search: eager steps in both objects
+        a, g = eager.forward_batch(us, maxlenratio=ratio), graphed.forward_batch(us, maxlenratio=ratio)
+        for b in range(len(us)):
+            assert [h.yseq.tolist() for h in g[b][:3]] == [h.yseq.tolist() for h in a[b][:3]], (ratio, b)
+    assert graphed.graph_steps, "a step could not be captured: the searches above ran eagerly"
+    n_graphs = sum(len(G["graphs"]) for G in graphed._step_graphs.values())
+    assert n_graphs > 0
+    print("[parity] step graphs %s lm=%s: %d signatures, %d captured steps" % (cls.__name__, lm, len(graphed._step_graphs), n_graphs))
+
+
+if __name__ == "__main__":
+    main()

@@ -47,6 +47,21 @@ def _count_step(fn):
         return dict(error=str(e)[:120])
 
 
+def _graph_leg(tag, n_utts, beam, ctc_weight, maxlenratio):
+    """single-utterance searches with the steps as hipGraph replays (BeamSearch.graph_steps), in a CHILD process: replaying the
+    step graphs of multi-utterance searches has ended in a GPU fault on this ROCm, and no fault may take the bench with it"""
+    import json
+    import subprocess
+    try:
+        r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "bench_decode_graph.py"), str(n_utts), str(beam), str(ctc_weight),
+                            str(maxlenratio)], capture_output=True, text=True, timeout=300)
+        if r.returncode != 0:
+            return dict(error="child exited with %d: %s" % (r.returncode, r.stderr[-200:]))
+        return json.loads(r.stdout.strip().splitlines()[-1])
+    except Exception as e:  # noqa: BLE001
+        return dict(error=str(e)[:200])
+
+
 def decode_leg(dev, c2_args, n_beam_utts=2, beam=10, ctc_weight=0.3, maxlenratio=0.2, cpu_sample=4, threads=None):
     import espnet_amd
     from espnet_amd.nets.batch_beam_search import BatchBeamSearch
@@ -122,7 +137,8 @@ def decode_leg(dev, c2_args, n_beam_utts=2, beam=10, ctc_weight=0.3, maxlenratio
         batched = dict(utterances=B, utt_per_s=round(B / tb, 2), rtf=float("%.3e" % (tb / audio_s)), beam_steps=bsteps,
                        ms_per_beam_step=round(tb / bsteps * 1e3, 3), hypotheses_found=[len(u) for u in nb][:4],
                        note="BeamSearch.forward_batch: one device-resident search over all utterances")
-        out[tag] = dict(beam=beam, ctc_weight=ctc_weight, maxlenratio=maxlenratio, utterances_timed=n_beam_utts,
+        graph = _graph_leg(tag, n_beam_utts, beam, ctc_weight, maxlenratio) if tag == "beam_search" else None
+        out[tag] = dict(beam=beam, ctc_weight=ctc_weight, maxlenratio=maxlenratio, utterances_timed=n_beam_utts, graph_steps=graph,
                         utt_per_s=round(n_beam_utts / tot, 2), rtf=float("%.3e" % (tot / a_s)), beam_steps=steps,
                         ms_per_beam_step=round(tot / steps * 1e3, 3), per_beam_step=counts, batched=batched,
                         note="encoder outputs precomputed (the greedy leg times the encoder); hypotheses, scores and scorer "
