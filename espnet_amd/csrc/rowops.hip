@@ -731,6 +731,77 @@ __global__ __launch_bounds__(256) void log_softmax_rows_kernel(const float* __re
 
 }  // namespace
 
+// k largest of every row, sorted: value descending, equal values by ascending index (a total order: the selection is the same
+// whatever the grid or the replay).  One workgroup per row, k rounds of "largest element below the previous winner": a thread
+// scans its strided share, the 256 candidates meet through wave shuffles and LDS.  NaN counts as -inf.
+// For the beam search's selections (beam_search.py:143-176: top-k over V and over beam x V per utterance, k <= 1.5 beam):
+// n = 5000 .. 50000, k = 10 .. 15 - 15 rounds over 20 register-resident elements per thread at V = 5000.
+// torch.topk's multi-block path for these sizes (6 launches + a sort) is also what faults under hipGraph replay on this ROCm.
+namespace {
+__device__ __forceinline__ bool topk_before(float va, long ia, float vb, long ib) {      // (va, ia) ranks before (vb, ib)
+  return va > vb || (va == vb && ia < ib);
+}
+__global__ __launch_bounds__(256) void topk_rows_kernel(const float* __restrict__ x, long ld, int n, int k,
+                                                        float* __restrict__ vals, int64_t* __restrict__ idx) {
+  __shared__ float sv[4];
+  __shared__ long si[4];
+  __shared__ float wv;
+  __shared__ long wi;
+  const float* xr = x + (long)blockIdx.x * ld;
+  const int t = threadIdx.x, lane = t & 63, w = t >> 6;
+  constexpr int RMAX = 24;                       // register-resident elements per thread (n <= 6144); longer rows re-read memory
+  float reg[RMAX];
+  const bool inreg = n <= RMAX * 256;
+  if (inreg) {
+#pragma unroll
+    for (int q = 0; q < RMAX; ++q) {
+      const int i = t + 256 * q;
+      float v = i < n ? xr[i] : -INFINITY;
+      reg[q] = (v != v) ? -INFINITY : v;
+    }
+  }
+  float pv = INFINITY;                           // previous winner: everything ranks after (+inf, -1)
+  long pi = -1;
+  for (int r = 0; r < k; ++r) {
+    float bv = -INFINITY;
+    long bi = 0x7fffffffffffffffL;                // sentinel: ranks after every real element, even among -inf
+    if (inreg) {
+#pragma unroll
+      for (int q = 0; q < RMAX; ++q) {
+        const long i = t + 256 * q;
+        if (i < n && topk_before(pv, pi, reg[q], i) && topk_before(reg[q], i, bv, bi)) { bv = reg[q]; bi = i; }
+      }
+    } else {
+      for (long i = t; i < n; i += 256) {
+        float v = xr[i];
+        v = (v != v) ? -INFINITY : v;
+        if (topk_before(pv, pi, v, i) && topk_before(v, i, bv, bi)) { bv = v; bi = i; }
+      }
+    }
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) {
+      const float ov = __shfl_xor(bv, m);
+      const long oi = __shfl_xor(bi, m);
+      if (topk_before(ov, oi, bv, bi)) { bv = ov; bi = oi; }
+    }
+    if (lane == 0) { sv[w] = bv; si[w] = bi; }
+    __syncthreads();
+    if (t == 0) {
+      float fv = sv[0];
+      long fi = si[0];
+#pragma unroll
+      for (int q = 1; q < 4; ++q)
+        if (topk_before(sv[q], si[q], fv, fi)) { fv = sv[q]; fi = si[q]; }
+      wv = fv; wi = fi;
+      vals[(long)blockIdx.x * k + r] = fv;
+      idx[(long)blockIdx.x * k + r] = fi;
+    }
+    __syncthreads();
+    pv = wv; pi = wi;
+  }
+}
+}  // namespace
+
 extern "C" {
 
 int eamd_layernorm_fwd(const float* x, const float* gamma, const float* beta, float* y, void* y_bf16, float* mean,
@@ -930,6 +1001,14 @@ int eamd_argmax_rows(const float* x, int64_t ld, int32_t* out, int rows, int V, 
 int eamd_reduce_sum(const float* in, int64_t n, float* out, float scale, void* stream) {
   if (!in || !out || n < 0) return EAMD_EINVAL;
   hipLaunchKernelGGL(reduce_sum_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, in, (long)n, out, scale);
+  EAMD_LAUNCH_CHECK();
+  return EAMD_OK;
+}
+
+int eamd_topk_rows(const float* x, int64_t ld, int rows, int n, int k, float* vals, int64_t* idx, void* stream) {
+  if (!x || !vals || !idx || rows <= 0 || n <= 0 || k <= 0 || k > n || ld < n) return EAMD_EINVAL;
+  if (k > 64) return EAMD_EUNSUPPORTED;
+  hipLaunchKernelGGL(topk_rows_kernel, dim3(rows), dim3(256), 0, (hipStream_t)stream, x, ld, n, k, vals, idx);
   EAMD_LAUNCH_CHECK();
   return EAMD_OK;
 }

@@ -291,7 +291,7 @@ class BeamSearch(torch.nn.Module):
                 part_ids = None
                 if self.do_pre_beam:
                     pre = weighted if self.pre_beam_score_key == "full" else logps[self.pre_beam_score_key]
-                    part_ids = torch.topk(pre, self.pre_beam_size, dim=-1)[1]
+                    part_ids = ops.topk_rows(pre.contiguous(), self.pre_beam_size)[1]
                 if ctc is not None:
                     last = ys[:, -1].to(torch.int32).contiguous()
                     olen = torch.full((n,), L - 1, dtype=torch.int32, device=dev)
@@ -317,7 +317,9 @@ class BeamSearch(torch.nn.Module):
                         else:
                             weighted += self.weights[pname] * c_local
                 weighted += hyp[:, None]
-                top_s, top_i = weighted.view(-1).topk(n)
+                s1, i1 = ops.topk_rows(weighted, n)                      # per slot, then among the n x n (see _batch_step)
+                top_s, i2 = (v.view(-1) for v in ops.topk_rows(s1.view(1, n * n), n))
+                top_i = (i2 // n) * V + i1.view(-1)[i2]
                 hyp_i, tok_i = top_i // V, top_i % V
                 for k in names:
                     sc[k] = sc[k][hyp_i] + logps[k][hyp_i, tok_i]
@@ -361,10 +363,7 @@ class BeamSearch(torch.nn.Module):
         ok = self._device_loop_ok(xs[0]) and minlenratio == 0.0
         if not ok or (B == 1 and not self.graph_steps):
             return [self.forward(x, maxlenratio, minlenratio) for x in xs]
-        if self.graph_steps and B == 1:
-            # (several utterances per search stay eager: replaying the B > 1 step graphs a second time ends in a GPU memory
-            # access fault on this ROCm - found with tools/step_graph_debug.py, cause not identified; the same steps run eagerly on
-            # the same static buffers are fine, and so are the B = 1 graphs)
+        if self.graph_steps:
             out = self._forward_batch_graphed(xs, maxlenratio)
             if out is not None:
                 return out
@@ -437,7 +436,7 @@ class BeamSearch(torch.nn.Module):
         L = i + 1
         yseq, hyp, sc, trees = S["yseq"], S["hyp"], dict(S["sc"]), dict(S["trees"])
         ys = yseq[:, :L]
-        weighted = ops.zeros_plain((n, V), dev)
+        weighted = torch.zeros(n, V, device=dev, dtype=torch.float32)
         logps, newtrees = {}, {}
         for k, d in self.full_scorers.items():
             # scorers that take it get the memory of the B utterances, not of the B * beam slots (shared_memory_ok)
@@ -450,7 +449,7 @@ class BeamSearch(torch.nn.Module):
         part_ids = None
         if self.do_pre_beam:
             pre = weighted if self.pre_beam_score_key == "full" else logps[self.pre_beam_score_key]
-            part_ids = torch.topk(pre, self.pre_beam_size, dim=-1)[1]
+            part_ids = ops.topk_rows(pre.contiguous(), self.pre_beam_size)[1]
         if ctc is not None:
             c_s, c_r = S["c_s"], S["c_r"]
             last = ys[:, -1].to(torch.int32).contiguous()
@@ -476,7 +475,14 @@ class BeamSearch(torch.nn.Module):
                 else:
                     weighted += self.weights[pname] * c_local
         weighted += hyp[:, None]
-        top_s, top_i = weighted.view(B, beam * V).topk(beam, dim=1)
+        # one launch of eamd_topk_rows (value descending, ties by ascending index).  torch.topk takes its multi-block path for
+        # these sizes: six launches and a sort - and, over SEVERAL slices, a GPU memory access fault on the second replay of a
+        # captured step on this ROCm (tools/step_graph_debug.py)
+        # ... in two stages: the best `beam` of an utterance's beam x V continuations lie among the best `beam` of each of its
+        # slots (rows of V elements stay in registers; ONE workgroup walking beam x V ten times took 300 us)
+        s1, i1 = ops.topk_rows(weighted, beam)                                              # [n, beam] per slot
+        top_s, i2 = ops.topk_rows(s1.view(B, beam * beam), beam)                            # [B, beam] among beam x beam
+        top_i = (i2 // beam) * V + i1.view(B, beam * beam).gather(1, i2)
         hyp_i = (top_i // V + C_["base"]).view(-1)
         tok_i = (top_i % V).view(-1)
         top_s = top_s.reshape(-1)

@@ -518,16 +518,7 @@ def zeros(*shape, device):
         t = a.buf[a.off // 4: a.off // 4 + n].view(shape)
         a.off += nb
         return t
-    return zeros_plain(shape, device)
-
-
-def zeros_plain(shape, device, dtype=torch.float32):
-    """torch.zeros, except under stream capture: there a FILL KERNEL instead of the memset node torch.zeros becomes (memset nodes
-    of the beam-search step graphs faulted on their second replay on this ROCm; the same class of problem as the captured
-    hipMemsetAsync of csrc/lstm_seq.hip)"""
-    if torch.cuda.is_current_stream_capturing():
-        return torch.full(shape, 0, device=device, dtype=dtype)
-    return torch.zeros(shape, device=device, dtype=dtype)
+    return torch.zeros(shape, device=device, dtype=torch.float32)
 
 
 def _skinny_splitk(M, N, K):
@@ -1026,6 +1017,18 @@ def reduce_sum(x, scale=1.0):
     return out
 
 
+def topk_rows(x, k):
+    """(values [rows, k], indices [rows, k] int64) of the k largest of each row of a contiguous fp32 [rows, n] tensor, sorted
+    (value descending, ties by ascending index): one launch, graph-replay safe (torch.topk's multi-block path is neither)"""
+    rows, n = x.shape
+    if x.dtype != torch.float32 or not x.is_contiguous() or k > 64:
+        raise _lib.EamdError("topk_rows: contiguous float32 [rows, n], k <= 64")
+    vals = torch.empty(rows, k, device=x.device, dtype=torch.float32)
+    idx = torch.empty(rows, k, device=x.device, dtype=torch.int64)
+    check(_lib.lib().eamd_topk_rows(ptr(x), C.c_int64(n), rows, n, k, ptr(vals), ptr(idx), stream_ptr()), "eamd_topk_rows")
+    return vals, idx
+
+
 def log_softmax_rows(x):
     rows, V = x.shape
     y = torch.empty_like(x)
@@ -1403,7 +1406,7 @@ def ctc_prefix_score_batch(logp, lens, per_utt, r_prev, cand, last, olen, blank,
     assert nhyp == U * per_utt and r_prev.shape == (nhyp, Tmax, 2) and cand.dtype == torch.int32 and logp.is_contiguous()
     assert lens.dtype == torch.int32 and lens.numel() == U
     psi = torch.empty(nhyp, ncand, device=logp.device, dtype=torch.float32)
-    r_new = zeros_plain((nhyp, ncand, Tmax, 2), logp.device)
+    r_new = torch.zeros(nhyp, ncand, Tmax, 2, device=logp.device, dtype=torch.float32)
     check(_lib.lib().eamd_ctc_prefix_score_batch(ptr(logp), ptr(lens), U, per_utt, ptr(r_prev.contiguous()), ptr(cand.contiguous()),
                                                  ptr(last), ptr(olen), ptr(psi), ptr(r_new), ncand, Tmax, V, blank, eos,
                                                  stream_ptr()), "eamd_ctc_prefix_score_batch")

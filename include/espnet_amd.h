@@ -323,6 +323,10 @@ int eamd_argmax_rows(const float* x, int64_t ld, int32_t* out, int rows, int V, 
 int eamd_reduce_sum(const float* in, int64_t n, float* out, float scale, void* stream);
 /* reference: decoder.py:318, ctc.py:134-142. */
 int eamd_log_softmax_rows(const float* x, float* y, int rows, int V, void* stream);
+/* The k (<= 64) largest of each row of x [rows, n] (row stride ld), sorted by value descending, equal values by ascending index;
+ * NaN counts as -inf.  vals / idx [rows, k].  reference: the torch.topk selections of a beam step (beam_search.py:143-176,
+ * batch_beam_search.py:86-110: pre-beam over V, best `beam` of beam x V). */
+int eamd_topk_rows(const float* x, int64_t ld, int rows, int n, int k, float* vals, int64_t* idx, void* stream);
 
 /* ------------------------------------------------------------------------------------------
  * Element-wise helpers.

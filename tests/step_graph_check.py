@@ -36,10 +36,13 @@ def main():
             assert [h.yseq.tolist() for h in g[:3]] == [h.yseq.tolist() for h in a[:3]], (ratio, rnd)
             for ha, hg in zip(a[:3], g[:3]):
                 assert abs(float(ha.score) - float(hg.score)) <= 1e-4 * max(1.0, abs(float(ha.score))), (ratio, rnd)
-        us = variants[:3]                                               # several utterances per search: eager steps in both objects
-        a, g = eager.forward_batch(us, maxlenratio=ratio), graphed.forward_batch(us, maxlenratio=ratio)
-        for b in range(len(us)):
-            assert [h.yseq.tolist() for h in g[b][:3]] == [h.yseq.tolist() for h in a[b][:3]], (ratio, b)
+        sets = [variants[:3], variants[2:5], [variants[4], variants[0], variants[3]], variants[1:4]]
+        for rnd, us in enumerate(sets):                                 # three utterances per search: eager, capture, replay, replay
+            a, g = eager.forward_batch(us, maxlenratio=ratio), graphed.forward_batch(us, maxlenratio=ratio)
+            for b in range(len(us)):
+                assert [h.yseq.tolist() for h in g[b][:3]] == [h.yseq.tolist() for h in a[b][:3]], (ratio, rnd, b)
+                for ha, hg in zip(a[b][:3], g[b][:3]):
+                    assert abs(float(ha.score) - float(hg.score)) <= 1e-4 * max(1.0, abs(float(ha.score))), (ratio, rnd, b)
     assert graphed.graph_steps, "a step could not be captured: the searches above ran eagerly"
     n_graphs = sum(len(G["graphs"]) for G in graphed._step_graphs.values())
     assert n_graphs > 0

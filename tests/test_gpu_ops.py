@@ -1548,3 +1548,36 @@ def test_ffn_layernorm_in_front(ops, prec, M, F, act):
             report("ffn+ln h    " + tag, h, h_ref, 1e-5)
     finally:
         espnet_amd.set_precision("fp32")
+
+
+@pytest.mark.parametrize("rows,n,k", [(10, 5000, 15), (1, 50000, 10), (320, 5000, 10), (32, 50000, 10), (3, 7, 7), (5, 6144, 64), (4, 6145, 3)])
+def test_topk_rows(ops, rows, n, k):
+    """eamd_topk_rows against torch.topk (the selections of a beam step: beam_search.py:143-176): values equal element for
+    element; indices equal where the values are distinct; ties (planted duplicates, -inf runs of dead beam slots, NaN = -inf) in
+    ascending index order; two launches bit-equal."""
+    g = torch.Generator().manual_seed(rows * 131 + n)
+    x = torch.randn(rows, n, generator=g)
+    if n >= 100:
+        x[:, 17] = x[:, 3]                               # a duplicate value
+        x[0, : n // 2] = -float("inf")                   # dead slots
+        x[-1, 5] = float("nan")
+    if rows > 2:
+        x[1] = -float("inf")                             # a row of dead slots only: the first k indices
+    xd = x.to(DEV)
+    v, i = ops.topk_rows(xd, k)
+    v2, i2 = ops.topk_rows(xd, k)
+    torch.cuda.synchronize()
+    assert torch.equal(v, v2) and torch.equal(i, i2) and i.dtype == torch.int64 and v.shape == (rows, k)
+    xr = torch.where(torch.isnan(x), torch.full_like(x, -float("inf")), x)
+    rv, _ = torch.topk(xr, k, dim=1)
+    assert torch.equal(v.cpu(), rv)
+    gathered = torch.gather(xr, 1, i.cpu())
+    assert torch.equal(gathered, rv)                     # the indices address those values
+    ic = i.cpu()
+    for r in range(rows):                                # a permutation-free selection, ties by ascending index
+        assert len(set(ic[r].tolist())) == k
+        for a in range(k - 1):
+            if rv[r, a] == rv[r, a + 1]:
+                assert ic[r, a] < ic[r, a + 1]
+    if rows > 2:
+        assert ic[1].tolist() == list(range(k))

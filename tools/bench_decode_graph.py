@@ -50,14 +50,38 @@ def main():
     torch.cuda.synchronize()
     te = time.perf_counter() - t0
     steps = sum(max(1, int(ratio * hl[b])) for b in range(n_timed))
-    print(json.dumps(dict(active=bool(gs.graph_steps), frame_bucket=gs.graph_frame_bucket, utterances_timed=n_timed,
+    # 32 utterances in one search (forward_batch): the bench's utterance lengths, three searches in rotated orders
+    NB = 32
+    il2 = [int(v) for v in torch.linspace(T, 0.6 * T, NB).round().tolist()]
+    xs2 = torch.randn(NB, T, 80, generator=torch.Generator().manual_seed(2)).to(dev)
+    with torch.no_grad():
+        hs2, _ = model.encoder(xs2, make_non_pad_mask(il2).unsqueeze(-2).to(dev))
+    hl2 = [int(v) for v in embed_output_lengths(model.encoder.embed, il2, T)]
+    e2 = [hs2[b, : hl2[b]].contiguous() for b in range(NB)]
+    rot = lambda k: e2[k:] + e2[:k]  # noqa: E731
+    gs.forward_batch(rot(1), maxlenratio=ratio)
+    gs.forward_batch(rot(2), maxlenratio=ratio)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    nbg = gs.forward_batch(e2, maxlenratio=ratio)
+    torch.cuda.synchronize()
+    tgb = time.perf_counter() - t0
+    t0 = time.perf_counter()
+    nbe = eager.forward_batch(e2, maxlenratio=ratio)
+    torch.cuda.synchronize()
+    teb = time.perf_counter() - t0
+    bsteps = max(1, int(ratio * max(hl2)))
+    batched = dict(utterances=NB, utt_per_s=round(NB / tgb, 2), ms_per_beam_step=round(tgb / bsteps * 1e3, 3),
+                   eager_same_process=dict(utt_per_s=round(NB / teb, 2), ms_per_beam_step=round(teb / bsteps * 1e3, 3)),
+                   same_best_as_eager=sum(int(a[0].yseq.tolist() == b_[0].yseq.tolist()) for a, b_ in zip(nbg, nbe)))
+    print(json.dumps(dict(batched=batched, active=bool(gs.graph_steps), frame_bucket=gs.graph_frame_bucket, utterances_timed=n_timed,
                           utt_per_s=round(n_timed / tg, 2), ms_per_beam_step=round(tg / steps * 1e3, 3),
                           eager_same_process=dict(utt_per_s=round(n_timed / te, 2), ms_per_beam_step=round(te / steps * 1e3, 3)),
                           same_best_as_eager=[g[0].yseq.tolist() == r[0].yseq.tolist() for g, r in zip(got, ref)],
                           best_score_diff=[abs(float(g[0].score) - float(r[0].score)) for g, r in zip(got, ref)],
                           captured_steps=sum(len(G["graphs"]) for G in gs._step_graphs.values()),
                           note="single-utterance searches, steps replayed as hipGraphs after one eager and one capturing search "
-                               "of the (beam, padded frames) signature; multi-utterance searches stay eager")))
+                               "of the (utterances, beam, padded frames) signature")))
 
 
 if __name__ == "__main__":
