@@ -522,6 +522,7 @@ class BeamSearch(torch.nn.Module):
     # this object - the search then runs eagerly as before.
     graph_steps = False
     graph_frame_bucket = 32
+    graph_max_signatures = 8          # least recently used signatures (their graphs and static buffers) are dropped beyond this
 
     def _forward_batch_graphed(self, xs, maxlenratio):
         B, beam = len(xs), self.beam_size
@@ -533,7 +534,11 @@ class BeamSearch(torch.nn.Module):
         sig = (B, beam, Tpad, W, float(maxlenratio), str(xs[0].dtype), xs[0].device.index)
         if not hasattr(self, "_step_graphs"):
             self._step_graphs = {}
-        G = self._step_graphs.get(sig)
+        G = self._step_graphs.pop(sig, None)
+        if G is not None:
+            self._step_graphs[sig] = G                         # most recently used last
+        while len(self._step_graphs) >= self.graph_max_signatures and (G is None or len(self._step_graphs) > self.graph_max_signatures):
+            self._step_graphs.pop(next(iter(self._step_graphs)))
         with torch.no_grad():
             C_new = self._batch_consts(xs, Ts, maxlens, Tpad, W, always_mask=True)
             if G is None:                       # first search of this signature: eager, and its tensors become the static buffers
