@@ -731,6 +731,56 @@ __global__ __launch_bounds__(256) void log_softmax_rows_kernel(const float* __re
 
 }  // namespace
 
+// y[M, N] = alpha * act(a_act(x)[M, K] W[N, K]^T + bias) + R for a HANDFUL of rows (M <= 16: the hypotheses of one utterance in a
+// beam step - query / output projections, both feed-forward products, the output layer; decoder_layer.py:77-134).  As a tile
+// GEMM these are 1 x N/64 workgroups walking K alone (10.8 us at K = 256, 58 us at K = 2048); here a WAVE owns one output
+// column: lanes split K in 16-byte pieces (a weight row is read once, coalesced; the M input rows come from L1), the M dot
+// products meet in a wave reduction, lane m finishes row m.  Exact fp32 arithmetic, summation order (lane-strided partial sums,
+// then the wave tree) differs from the MFMA kernels'.
+namespace {
+__global__ __launch_bounds__(256) void linear_rows_f32_kernel(const float* __restrict__ x, const float* __restrict__ W,
+                                                              const float* __restrict__ bias, const float* __restrict__ R,
+                                                              float* __restrict__ y, int M, int N, int K, int a_act, int act,
+                                                              float alpha) {
+  const int lane = threadIdx.x & 63;
+  const int n = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (n >= N) return;
+  float acc[16];
+#pragma unroll
+  for (int m = 0; m < 16; ++m) acc[m] = 0.f;
+  const float* wr = W + (long)n * K;
+  for (int k = lane * 4; k < K; k += 256) {
+    const float4 w4 = *reinterpret_cast<const float4*>(wr + k);
+#pragma unroll
+    for (int m = 0; m < 16; ++m) {
+      if (m < M) {
+        float4 x4 = *reinterpret_cast<const float4*>(x + (long)m * K + k);
+        if (a_act != EAMD_ACT_NONE) {
+          x4.x = eamd_act(x4.x, a_act); x4.y = eamd_act(x4.y, a_act); x4.z = eamd_act(x4.z, a_act); x4.w = eamd_act(x4.w, a_act);
+        }
+        acc[m] = fmaf(x4.x, w4.x, fmaf(x4.y, w4.y, fmaf(x4.z, w4.z, fmaf(x4.w, w4.w, acc[m]))));
+      }
+    }
+  }
+  float mine = 0.f;
+#pragma unroll
+  for (int m = 0; m < 16; ++m) {
+    if (m < M) {
+      const float r = wave_sum(acc[m]);
+      if (lane == m) mine = r;
+    }
+  }
+  if (lane < M) {
+    float v = mine + (bias ? bias[n] : 0.f);
+    if (act == 1) v = fmaxf(v, 0.f);
+    else if (act == 2) v = eamd_swish(v);
+    v *= alpha;
+    if (R) v += R[(long)lane * N + n];
+    y[(long)lane * N + n] = v;
+  }
+}
+}  // namespace
+
 // k largest of every row, sorted: value descending, equal values by ascending index (a total order: the selection is the same
 // whatever the grid or the replay).  One workgroup per row, k rounds of "largest element below the previous winner": a thread
 // scans its strided share, the 256 candidates meet through wave shuffles and LDS.  NaN counts as -inf.
@@ -1001,6 +1051,17 @@ int eamd_argmax_rows(const float* x, int64_t ld, int32_t* out, int rows, int V, 
 int eamd_reduce_sum(const float* in, int64_t n, float* out, float scale, void* stream) {
   if (!in || !out || n < 0) return EAMD_EINVAL;
   hipLaunchKernelGGL(reduce_sum_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, in, (long)n, out, scale);
+  EAMD_LAUNCH_CHECK();
+  return EAMD_OK;
+}
+
+int eamd_linear_rows_f32(const float* x, const float* W, const float* bias, const float* R, float* y, int M, int N, int K,
+                         int a_act, int act, float alpha, void* stream) {
+  if (!x || !W || !y || M <= 0 || N <= 0 || K <= 0 || a_act < 0 || act < 0) return EAMD_EINVAL;
+  if (M > 16 || K % 4 != 0 || a_act > EAMD_ACT_SWISH || act > 2) return EAMD_EUNSUPPORTED;
+  if (((uintptr_t)x | (uintptr_t)W) & 15) return EAMD_EUNSUPPORTED;
+  hipLaunchKernelGGL(linear_rows_f32_kernel, dim3((N + 3) / 4), dim3(256), 0, (hipStream_t)stream, x, W, bias, R, y, M, N, K,
+                     a_act, act, alpha);
   EAMD_LAUNCH_CHECK();
   return EAMD_OK;
 }

@@ -445,6 +445,9 @@ def auto_splitk(m_out, n_out, k_red):
 
 
 # ---- nn.Linear pieces -------------------------------------------------------------------------
+LINEAR_ROWS = os.environ.get("EAMD_LINEAR_ROWS", "1") != "0"      # eamd_linear_rows_f32 for <= 16 rows without autograd
+
+
 def linear_fwd(x, W, b, out=None, *, act=EPI_NONE, R=None, alpha=1.0, a_act=ACT_NONE, out_dtype=torch.float32,
                drop=None, Hb=None, h_act=ACT_NONE, a_drop=None):
     """out[M,N] = alpha * drop(act(a_act(x)[M,K] @ W[N,K]^T + b)) + R      (x, W: both fp32 or both bf16)
@@ -453,6 +456,17 @@ def linear_fwd(x, W, b, out=None, *, act=EPI_NONE, R=None, alpha=1.0, a_act=ACT_
     M, K = x.shape
     N = W.shape[0]
     assert W.shape[1] == K and x.is_contiguous() and W.is_contiguous()
+    if (LINEAR_ROWS and M <= 16 and out is None and out_dtype == torch.float32 and x.dtype == torch.float32 and W.dtype == torch.float32
+            and act in (EPI_NONE, EPI_RELU, EPI_SWISH) and a_act in (ACT_NONE, ACT_RELU, ACT_SWISH) and drop is None and Hb is None
+            and a_drop is None and K % 4 == 0 and _state["precision"] == 0 and not torch.is_grad_enabled()
+            and (R is None or (R.is_contiguous() and tuple(R.shape) == (M, N)))):
+        # inference on a handful of rows (one utterance's hypotheses in a beam step): one wave per output column
+        y = torch.empty(M, N, device=x.device, dtype=torch.float32)
+        rc = _lib.lib().eamd_linear_rows_f32(ptr(x), ptr(W), ptr(b), ptr(R), ptr(y), M, N, K, a_act, act, C.c_float(alpha), stream_ptr())
+        if rc == 0:
+            return y
+        if rc != _lib.EAMD_EUNSUPPORTED:
+            check(rc, "eamd_linear_rows_f32")
     sk = 1
     if (out_dtype if out is None else out.dtype) == torch.float32 and act == EPI_NONE and drop is None \
             and Hb is None and a_drop is None and ((R is None and alpha == 1.0) or

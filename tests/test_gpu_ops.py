@@ -1581,3 +1581,28 @@ def test_topk_rows(ops, rows, n, k):
                 assert ic[r, a] < ic[r, a + 1]
     if rows > 2:
         assert ic[1].tolist() == list(range(k))
+
+
+@pytest.mark.parametrize("M,N,K,a_act,act,res", [(10, 256, 256, 0, 0, True), (10, 2048, 256, 0, 1, False), (10, 256, 2048, 1, 0, True),
+                                                 (16, 5000, 256, 0, 0, False), (1, 30, 64, 2, 2, True), (7, 257, 1028, 0, 0, True)])
+def test_linear_rows_f32(ops, M, N, K, a_act, act, res):
+    """eamd_linear_rows_f32 (nn.Linear on <= 16 rows, one wave per output column; taken by ops.linear_fwd without autograd) against
+    float64: y = alpha * act(a_act(x) W^T + b) + R.  reference: the per-step products of decoder_layer.py:77-134."""
+    import espnet_amd
+    espnet_amd.set_precision("fp32")
+    g = torch.Generator().manual_seed(M * 7 + N)
+    x = torch.randn(M, K, generator=g)
+    W = torch.randn(N, K, generator=g) / K ** 0.5
+    b = torch.randn(N, generator=g) * 0.1
+    R = torch.randn(M, N, generator=g) if res else None
+    f = {0: lambda v: v, 1: lambda v: v.clamp_min(0), 2: lambda v: v * torch.sigmoid(v)}
+    ref = 0.5 * f[act](f[a_act](x.double()) @ W.double().t() + b.double()) + (R.double() if res else 0.0)
+    with torch.no_grad():
+        y = ops.linear_fwd(x.to(DEV), W.to(DEV), b.to(DEV), act=act, a_act=a_act, alpha=0.5, R=R.to(DEV) if res else None)
+        keep, ops.LINEAR_ROWS = ops.LINEAR_ROWS, False
+        try:
+            y_tiles = ops.linear_fwd(x.to(DEV), W.to(DEV), b.to(DEV), act=act, a_act=a_act, alpha=0.5, R=R.to(DEV) if res else None)
+        finally:
+            ops.LINEAR_ROWS = keep
+    report("linear_rows %dx%dx%d a_act=%d act=%d" % (M, N, K, a_act, act), y, ref, 2e-6)
+    report("linear_rows vs the tile kernel", y, y_tiles, 2e-6)
