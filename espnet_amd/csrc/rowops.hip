@@ -749,16 +749,31 @@ __global__ __launch_bounds__(256) void linear_rows_f32_kernel(const float* __res
 #pragma unroll
   for (int m = 0; m < 16; ++m) acc[m] = 0.f;
   const float* wr = W + (long)n * K;
-  for (int k = lane * 4; k < K; k += 256) {
-    const float4 w4 = *reinterpret_cast<const float4*>(wr + k);
+  // four 16-byte pieces of the weight row per trip, requested together (K = 2048: two trips instead of eight dependent ones)
+  for (int k0 = lane * 4; k0 < K; k0 += 1024) {
+    float4 w4[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int k = k0 + 256 * q;
+      w4[q] = k < K ? *reinterpret_cast<const float4*>(wr + k) : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
 #pragma unroll
     for (int m = 0; m < 16; ++m) {
       if (m < M) {
-        float4 x4 = *reinterpret_cast<const float4*>(x + (long)m * K + k);
-        if (a_act != EAMD_ACT_NONE) {
-          x4.x = eamd_act(x4.x, a_act); x4.y = eamd_act(x4.y, a_act); x4.z = eamd_act(x4.z, a_act); x4.w = eamd_act(x4.w, a_act);
+        float4 x4[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const int k = k0 + 256 * q;
+          x4[q] = k < K ? *reinterpret_cast<const float4*>(x + (long)m * K + k) : make_float4(0.f, 0.f, 0.f, 0.f);
         }
-        acc[m] = fmaf(x4.x, w4.x, fmaf(x4.y, w4.y, fmaf(x4.z, w4.z, fmaf(x4.w, w4.w, acc[m]))));
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          float4 v = x4[q];
+          if (a_act != EAMD_ACT_NONE) {
+            v.x = eamd_act(v.x, a_act); v.y = eamd_act(v.y, a_act); v.z = eamd_act(v.z, a_act); v.w = eamd_act(v.w, a_act);
+          }
+          acc[m] = fmaf(v.x, w4[q].x, fmaf(v.y, w4[q].y, fmaf(v.z, w4[q].z, fmaf(v.w, w4[q].w, acc[m]))));
+        }
       }
     }
   }
