@@ -43,7 +43,8 @@ class CharTokenizer:
 
 class Speech2Text:
     def __init__(self, asr_model, lm=None, token_list=None, tokenizer=None, device="cuda", maxlenratio=0.0,
-                 minlenratio=0.0, batch_size=1, beam_size=20, ctc_weight=0.5, lm_weight=1.0, penalty=0.0, nbest=1):
+                 minlenratio=0.0, batch_size=1, beam_size=20, ctc_weight=0.5, lm_weight=1.0, penalty=0.0, nbest=1,
+                 graph_steps=False):
         asr_model.to(device).eval()
         token_list = token_list if token_list is not None else getattr(asr_model, "token_list", None)
         vocab = len(token_list) if token_list is not None else asr_model.vocab_size
@@ -58,6 +59,8 @@ class Speech2Text:
         if batch_size == 1 and all(isinstance(v, BatchScorerInterface) for v in beam_search.full_scorers.values()):
             beam_search.__class__ = BatchBeamSearch          # asr_inference.py:108-118
         beam_search.to(device).eval()
+        # graph_steps (not in the reference): the steps of a search replayed as hipGraphs, see nets.beam_search.BeamSearch.graph_steps
+        beam_search.graph_steps = bool(graph_steps)
         self.asr_model, self.beam_search = asr_model, beam_search
         self.converter = TokenIDConverter(token_list) if token_list is not None else None
         self.tokenizer = tokenizer
