@@ -445,7 +445,10 @@ def auto_splitk(m_out, n_out, k_red):
 
 
 # ---- nn.Linear pieces -------------------------------------------------------------------------
-LINEAR_ROWS = os.environ.get("EAMD_LINEAR_ROWS", "1") != "0"      # eamd_linear_rows_f32 for <= 16 rows without autograd
+LINEAR_ROWS = os.environ.get("EAMD_LINEAR_ROWS", "1") != "0"      # eamd_linear_rows_f32 for few rows without autograd
+# rows up to which it is used.  Beyond 16 the library runs blocks of 16 rows x four columns per wave: measured at the batched beam
+# search's M = 320 that form is SLOWER than the 64 x 64 tiles it was meant to replace (step 2.47 -> 2.77 ms), so it stays off
+LINEAR_ROWS_MAX = int(os.environ.get("EAMD_LINEAR_ROWS_MAX", "16"))
 
 
 def linear_fwd(x, W, b, out=None, *, act=EPI_NONE, R=None, alpha=1.0, a_act=ACT_NONE, out_dtype=torch.float32,
@@ -456,7 +459,7 @@ def linear_fwd(x, W, b, out=None, *, act=EPI_NONE, R=None, alpha=1.0, a_act=ACT_
     M, K = x.shape
     N = W.shape[0]
     assert W.shape[1] == K and x.is_contiguous() and W.is_contiguous()
-    if (LINEAR_ROWS and M <= 16 and out is None and out_dtype == torch.float32 and x.dtype == torch.float32 and W.dtype == torch.float32
+    if (LINEAR_ROWS and M <= LINEAR_ROWS_MAX and out is None and out_dtype == torch.float32 and x.dtype == torch.float32 and W.dtype == torch.float32
             and act in (EPI_NONE, EPI_RELU, EPI_SWISH) and a_act in (ACT_NONE, ACT_RELU, ACT_SWISH) and drop is None and Hb is None
             and a_drop is None and K % 4 == 0 and _state["precision"] == 0 and not torch.is_grad_enabled()
             and (R is None or (R.is_contiguous() and tuple(R.shape) == (M, N)))):

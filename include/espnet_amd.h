@@ -323,7 +323,7 @@ int eamd_argmax_rows(const float* x, int64_t ld, int32_t* out, int rows, int V, 
 int eamd_reduce_sum(const float* in, int64_t n, float* out, float scale, void* stream);
 /* reference: decoder.py:318, ctc.py:134-142. */
 int eamd_log_softmax_rows(const float* x, float* y, int rows, int V, void* stream);
-/* nn.Linear on a handful of rows (M <= 16, K a multiple of 4, fp32): y[M,N] = alpha * act(a_act(x) W^T + bias) + R with W [N,K]
+/* nn.Linear on a handful of rows (M <= 16; up to 1024 rows in blocks of 16 with four columns per wave; K a multiple of 4, fp32): y[M,N] = alpha * act(a_act(x) W^T + bias) + R with W [N,K]
  * row-major (nn.Linear layout), act 0 none / 1 relu / 2 swish on the result, a_act an eamd_act id applied to x while it is read.
  * One wave per output column instead of 64-wide tiles walking K alone.  reference: the per-step products of a decoding
  * hypothesis set, transformer/decoder_layer.py:77-134, decoder.py:283-321.  EAMD_EUNSUPPORTED: the caller uses eamd_gemm. */

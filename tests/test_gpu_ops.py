@@ -1584,7 +1584,9 @@ def test_topk_rows(ops, rows, n, k):
 
 
 @pytest.mark.parametrize("M,N,K,a_act,act,res", [(10, 256, 256, 0, 0, True), (10, 2048, 256, 0, 1, False), (10, 256, 2048, 1, 0, True),
-                                                 (16, 5000, 256, 0, 0, False), (1, 30, 64, 2, 2, True), (7, 257, 1028, 0, 0, True)])
+                                                 (16, 5000, 256, 0, 0, False), (1, 30, 64, 2, 2, True), (7, 257, 1028, 0, 0, True),
+                                                 (320, 256, 256, 0, 0, True), (320, 256, 2048, 1, 0, True), (41, 2049, 256, 0, 1, False),
+                                                 (17, 30, 64, 2, 2, True)])
 def test_linear_rows_f32(ops, M, N, K, a_act, act, res):
     """eamd_linear_rows_f32 (nn.Linear on <= 16 rows, one wave per output column; taken by ops.linear_fwd without autograd) against
     float64: y = alpha * act(a_act(x) W^T + b) + R.  reference: the per-step products of decoder_layer.py:77-134."""
@@ -1598,7 +1600,11 @@ def test_linear_rows_f32(ops, M, N, K, a_act, act, res):
     f = {0: lambda v: v, 1: lambda v: v.clamp_min(0), 2: lambda v: v * torch.sigmoid(v)}
     ref = 0.5 * f[act](f[a_act](x.double()) @ W.double().t() + b.double()) + (R.double() if res else 0.0)
     with torch.no_grad():
-        y = ops.linear_fwd(x.to(DEV), W.to(DEV), b.to(DEV), act=act, a_act=a_act, alpha=0.5, R=R.to(DEV) if res else None)
+        keep_max, ops.LINEAR_ROWS_MAX = ops.LINEAR_ROWS_MAX, 1024          # also the row-block form (M > 16: off by default)
+        try:
+            y = ops.linear_fwd(x.to(DEV), W.to(DEV), b.to(DEV), act=act, a_act=a_act, alpha=0.5, R=R.to(DEV) if res else None)
+        finally:
+            ops.LINEAR_ROWS_MAX = keep_max
         keep, ops.LINEAR_ROWS = ops.LINEAR_ROWS, False
         try:
             y_tiles = ops.linear_fwd(x.to(DEV), W.to(DEV), b.to(DEV), act=act, a_act=a_act, alpha=0.5, R=R.to(DEV) if res else None)
