@@ -471,13 +471,14 @@ def linear_fwd(x, W, b, out=None, *, act=EPI_NONE, R=None, alpha=1.0, a_act=ACT_
         if rc != _lib.EAMD_EUNSUPPORTED:
             check(rc, "eamd_linear_rows_f32")
     sk = 1
-    if (out_dtype if out is None else out.dtype) == torch.float32 and act == EPI_NONE and drop is None \
-            and Hb is None and a_drop is None and ((R is None and alpha == 1.0) or
-                                                   (K >= 1024 and M <= 64 and torch.cuda.is_current_stream_capturing())):
-        # (second condition: a beam-search step being captured - the feed-forward product of a handful of hypotheses walks
-        # K = 2048 in 4 workgroups, 58 us; eagerly the extra zero-fill launch costs the host more than the device saves, in a
-        # graph it does not; bias, alpha and the residual come with the first K slice)
-        sk = _skinny_splitk(M, N, K)
+    if (out_dtype if out is None else out.dtype) == torch.float32 and act == EPI_NONE and drop is None and Hb is None and a_drop is None:
+        if R is None and alpha == 1.0:
+            sk = _skinny_splitk(M, N, K)
+        elif K >= 1024 and M <= 512 and x.is_cuda and torch.cuda.is_current_stream_capturing():
+            # a beam-search step being captured: the second feed-forward product of a few (hundred) hypotheses walks K = 2048 in
+            # 4 .. 20 workgroups, 58 us; eagerly the extra zero-fill launch costs the host more than the device saves, in a graph it
+            # does not.  Bias, alpha and the residual come with the first K slice.
+            sk = _skinny_splitk(M, N, K, max_rows=512)
     if out is None:
         out = zeros(M, N, device=x.device) if sk > 1 else torch.empty(M, N, device=x.device, dtype=out_dtype)
     elif sk > 1:
@@ -538,12 +539,12 @@ def zeros(*shape, device):
     return torch.zeros(shape, device=device, dtype=torch.float32)
 
 
-def _skinny_splitk(M, N, K):
+def _skinny_splitk(M, N, K, max_rows=64):
     """a product with a handful of rows (one decoder step: M = batch, or batch x beam) is one row of 64-wide tiles - 16 to
     64 workgroups, each walking the whole reduction alone while the weight matrix streams through a fraction of the
     chip: split the reduction until ~256 workgroups share it (f32 atomics into the zeroed result; config 4's decoder
     steps: 20 -> 9 us for the 32 x 2048 x 4096 input gradient)"""
-    if M > 64 or N * K < 512 * 512:       # small weights: nothing to stream, keep the single-pass summation order
+    if M > max_rows or N * K < 512 * 512:       # small weights: nothing to stream, keep the single-pass summation order
         return 1
     tiles = (M + 63) // 64 * ((N + 63) // 64)
     sk = 1
