@@ -46,6 +46,15 @@ def main():
     assert graphed.graph_steps, "a step could not be captured: the searches above ran eagerly"
     n_graphs = sum(len(G["graphs"]) for G in graphed._step_graphs.values())
     assert n_graphs > 0
+    # least-recently-used eviction: with room for ONE signature, alternating two signatures never replays a stale graph
+    small = mk()
+    small.graph_steps, small.graph_frame_bucket, small.graph_max_signatures = True, 16, 1
+    for rnd in range(4):
+        for us in ([variants[0]], variants[:2]):
+            a, g = eager.forward_batch(us, maxlenratio=0.5) if len(us) > 1 else [eager(us[0], maxlenratio=0.5)], \
+                small.forward_batch(us, maxlenratio=0.5)
+            assert [h.yseq.tolist() for h in g[0][:2]] == [h.yseq.tolist() for h in a[0][:2]], ("lru", rnd, len(us))
+            assert len(small._step_graphs) <= 1
     print("[parity] step graphs %s lm=%s: %d signatures, %d captured steps" % (cls.__name__, lm, len(graphed._step_graphs), n_graphs))
 
 
