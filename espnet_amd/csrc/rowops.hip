@@ -796,6 +796,62 @@ __global__ __launch_bounds__(256) void linear_rows_f32_kernel(const float* __res
 }
 }  // namespace
 
+// Bookkeeping of a beam step after the selection, one thread per surviving slot (reference: beam_search.py:177-203 post_process /
+// batch_beam_search.py:249-284 on the host; here the state stays on the device): which hypothesis and token a winner is, the
+// per-scorer scores carried along, the prefix copied and extended, the length cap / <eos> test, the next step's running score
+// (-inf for ended or empty slots) and the row of the step log the host reads every few steps.  ~30 element-wise torch launches.
+namespace {
+struct BeamFinishArgs {
+  const float* logp[4];
+  const float* top_s; const int64_t* top_i; const int64_t* maxlen; const float* sc_in; const float* c_local; const int64_t* ids;
+  const int64_t* yseq_in;
+  float* sc_out; int64_t* yseq_out; float* hyp_out; int64_t* hyp_i; int64_t* tok_i; int64_t* pos; float* rec;
+  int64_t ldc;
+  int n, beam, V, W, L, step, eos, ns, nf, full_mode, ncand;
+};
+__global__ __launch_bounds__(64) void beam_finish_kernel(const BeamFinishArgs a) {
+  const int s = blockIdx.x * 64 + threadIdx.x;
+  if (s >= a.n) return;
+  const int u = s / a.beam;
+  const long ti = a.top_i[s];
+  const long h = (long)u * a.beam + ti / a.V;
+  const long tok = ti % a.V;
+  const float ts = a.top_s[s];
+  a.hyp_i[s] = h; a.tok_i[s] = tok;
+  const int RW = 3 + a.ns + a.W;
+  float* rec = a.rec + (long)s * RW;
+  rec[0] = (float)a.step; rec[1] = ts; rec[2] = (float)tok;
+  for (int j = 0; j < a.nf; ++j) {
+    const float v = a.sc_in[(long)j * a.n + h] + a.logp[j][h * a.V + tok];
+    a.sc_out[(long)j * a.n + s] = v;
+    rec[3 + j] = v;
+  }
+  long p = tok;                                          // position of the token among the hypothesis's candidates
+  if (a.ids) {
+    p = 0;                                               // (argmax of an all-false row, as the tensor code had it)
+    for (int q = 0; q < a.ncand; ++q)
+      if (a.ids[h * a.ncand + q] == tok) { p = q; break; }
+  }
+  a.pos[s] = p;
+  if (a.ns > a.nf) {
+    const float v = a.sc_in[(long)a.nf * a.n + h] + a.c_local[h * a.ldc + (a.full_mode ? tok : p)];
+    a.sc_out[(long)a.nf * a.n + s] = v;
+    rec[3 + a.nf] = v;
+  }
+  const int64_t* yi = a.yseq_in + h * a.W;
+  int64_t* yo = a.yseq_out + (long)s * a.W;
+  for (int w = 0; w < a.W; ++w) {
+    const int64_t t = w == a.L ? tok : yi[w];
+    yo[w] = t;
+    rec[3 + a.ns + w] = (float)t;
+  }
+  const bool finite = isfinite(ts);
+  const bool at_cap = a.maxlen[u] <= a.step + 1;
+  const bool done = finite && (tok == a.eos || at_cap);
+  a.hyp_out[s] = (done || !finite) ? -INFINITY : ts;
+}
+}  // namespace
+
 // The same product for a few hundred rows (a batched beam search steps B x beam hypotheses: M = 320): blocks of 16 rows, a wave
 // owns FOUR output columns of its block (the 16 input pieces a lane reads serve four weight rows), grid (N / 16, M / 16).  As
 // 64-wide tiles these launches are 5 x 4 workgroups walking K alone: 15.6 us at K = 256, 60 us at K = 2048.
@@ -1122,6 +1178,27 @@ int eamd_argmax_rows(const float* x, int64_t ld, int32_t* out, int rows, int V, 
 int eamd_reduce_sum(const float* in, int64_t n, float* out, float scale, void* stream) {
   if (!in || !out || n < 0) return EAMD_EINVAL;
   hipLaunchKernelGGL(reduce_sum_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, in, (long)n, out, scale);
+  EAMD_LAUNCH_CHECK();
+  return EAMD_OK;
+}
+
+int eamd_beam_finish(const float* top_s, const int64_t* top_i, int n, int beam, int V, int W, int L, int step, int eos,
+                     const int64_t* maxlen, int ns, int nf, const float* sc_in, const float* const* logps, const float* c_local,
+                     int64_t ldc, int full_mode, const int64_t* ids, int ncand, const int64_t* yseq_in, float* sc_out,
+                     int64_t* yseq_out, float* hyp_out, int64_t* hyp_i, int64_t* tok_i, int64_t* pos, float* rec, void* stream) {
+  if (!top_s || !top_i || !maxlen || !sc_in || !yseq_in || !sc_out || !yseq_out || !hyp_out || !hyp_i || !tok_i || !pos || !rec)
+    return EAMD_EINVAL;
+  if (n <= 0 || beam <= 0 || n % beam != 0 || V <= 0 || W <= 1 || L < 1 || L >= W || ns < 0 || nf < 0 || nf > 4 || ns < nf || ns > nf + 1)
+    return EAMD_EINVAL;
+  if ((nf > 0 && !logps) || (ns > nf && !c_local) || (ids && ncand <= 0)) return EAMD_EINVAL;
+  BeamFinishArgs a;
+  for (int j = 0; j < 4; ++j) a.logp[j] = j < nf ? logps[j] : nullptr;
+  for (int j = 0; j < nf; ++j) if (!a.logp[j]) return EAMD_EINVAL;
+  a.top_s = top_s; a.top_i = top_i; a.n = n; a.beam = beam; a.V = V; a.W = W; a.L = L; a.step = step; a.eos = eos; a.maxlen = maxlen;
+  a.ns = ns; a.nf = nf; a.sc_in = sc_in; a.c_local = c_local; a.ldc = ldc; a.full_mode = full_mode; a.ids = ids; a.ncand = ncand;
+  a.yseq_in = yseq_in; a.sc_out = sc_out; a.yseq_out = yseq_out; a.hyp_out = hyp_out; a.hyp_i = hyp_i; a.tok_i = tok_i; a.pos = pos;
+  a.rec = rec;
+  hipLaunchKernelGGL(beam_finish_kernel, dim3((n + 63) / 64), dim3(64), 0, (hipStream_t)stream, a);
   EAMD_LAUNCH_CHECK();
   return EAMD_OK;
 }

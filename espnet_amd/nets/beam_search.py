@@ -204,7 +204,8 @@ class BeamSearch(torch.nn.Module):
 
     def _device_loop_ok(self, x):
         return (self.device_loop and x.is_cuda and all(hasattr(d, "score_tree") for d in self.full_scorers.values())
-                and all(isinstance(d, CTCPrefixScorer) for d in self.part_scorers.values()) and len(self.part_scorers) <= 1)
+                and all(isinstance(d, CTCPrefixScorer) for d in self.part_scorers.values()) and len(self.part_scorers) <= 1
+                and len(self.full_scorers) <= 4)          # eamd_beam_finish carries up to four full scorers
 
     @staticmethod
     def _tree_index(tree, idx):
@@ -361,7 +362,7 @@ class BeamSearch(torch.nn.Module):
         if B == 0:
             return []
         ok = self._device_loop_ok(xs[0]) and minlenratio == 0.0
-        if not ok or (B == 1 and not self.graph_steps):
+        if not ok:
             return [self.forward(x, maxlenratio, minlenratio) for x in xs]
         if self.graph_steps:
             out = self._forward_batch_graphed(xs, maxlenratio)
@@ -420,7 +421,7 @@ class BeamSearch(torch.nn.Module):
         yseq[:, 0] = self.sos
         hyp = torch.full((B, beam), -float("inf"), device=dev, dtype=torch.float32)
         hyp[:, 0] = 0.0
-        S = dict(yseq=yseq, hyp=hyp.view(-1), sc={k: torch.zeros(n, device=dev, dtype=torch.float32) for k in C_["allk"]},
+        S = dict(yseq=yseq, hyp=hyp.view(-1), sc=torch.zeros(len(C_["allk"]), n, device=dev, dtype=torch.float32),     # rows as allk
                  trees={k: None for k in C_["names"]})
         if C_["ctc"] is not None:
             S["c_s"] = torch.zeros(n, device=dev, dtype=torch.float32)
@@ -434,7 +435,7 @@ class BeamSearch(torch.nn.Module):
         names, pname, ctc, allk = C_["names"], C_["pname"], C_["ctc"], C_["allk"]
         NEG = -float("inf")
         L = i + 1
-        yseq, hyp, sc, trees = S["yseq"], S["hyp"], dict(S["sc"]), dict(S["trees"])
+        yseq, hyp, trees = S["yseq"], S["hyp"], dict(S["trees"])
         ys = yseq[:, :L]
         weighted = torch.zeros(n, V, device=dev, dtype=torch.float32)
         logps, newtrees = {}, {}
@@ -462,8 +463,6 @@ class BeamSearch(torch.nn.Module):
                 full.scatter_(1, ids.long(), psi)
                 full[:, ctc.eos] = torch.logsumexp(c_r[torch.arange(n, device=dev), C_["last_idx"]], dim=-1)
                 full[:, ctc.blank] = -10000000000.0
-                idmap = torch.full((n, V), -1, dtype=torch.int64, device=dev)
-                idmap.scatter_(1, ids.long(), torch.arange(ids.shape[1], device=dev).expand(n, -1))
                 c_local = full - c_s[:, None]
                 weighted += self.weights[pname] * c_local
             else:
@@ -483,31 +482,20 @@ class BeamSearch(torch.nn.Module):
         s1, i1 = ops.topk_rows(weighted, beam)                                              # [n, beam] per slot
         top_s, i2 = ops.topk_rows(s1.view(B, beam * beam), beam)                            # [B, beam] among beam x beam
         top_i = (i2 // beam) * V + i1.view(B, beam * beam).gather(1, i2)
-        hyp_i = (top_i // V + C_["base"]).view(-1)
-        tok_i = (top_i % V).view(-1)
-        top_s = top_s.reshape(-1)
-        for k in names:
-            sc[k] = sc[k][hyp_i] + logps[k][hyp_i, tok_i]
-            trees[k] = self._tree_index(newtrees[k], hyp_i)
-        T_ = dict(sc=sc, trees=trees)
+        # which hypothesis / token each winner is, the scores carried along, prefixes, end tests and the log row: one launch
+        c_loc = ids_pos = None
         if ctc is not None:
-            if self.partial_mode == "full":
-                sc[pname] = sc[pname][hyp_i] + c_local[hyp_i, tok_i]
-                j = idmap[hyp_i, tok_i].clamp_min(0)
-                T_["c_s"], T_["c_r"] = full[hyp_i, tok_i], r_new[hyp_i, j]
-            else:
-                pos = (ids[hyp_i] == tok_i[:, None]).float().argmax(-1) if part_ids is not None else tok_i
-                sc[pname] = sc[pname][hyp_i] + c_local[hyp_i, pos]
-                T_["c_s"], T_["c_r"] = psi[hyp_i, pos], r_new[hyp_i, pos]
-        yseq = yseq.index_select(0, hyp_i)
-        yseq[:, L] = tok_i
-        finite = torch.isfinite(top_s)
-        at_cap = (C_["maxlen_d"] <= i + 1).expand(B, beam).reshape(-1)             # the utterance's own length cap: everything ends
-        done = finite & ((tok_i == self.eos) | at_cap)
-        rec = torch.cat([torch.full((n, 1), float(i), device=dev), top_s[:, None], tok_i[:, None].float()]
-                        + [sc[k][:, None] for k in allk] + [yseq.float()], dim=1)
-        T_["yseq"] = yseq
-        T_["hyp"] = torch.where(done | ~finite, torch.full_like(top_s, NEG), top_s)
+            c_loc = c_local.contiguous()
+            ids_pos = part_ids if part_ids is not None else None          # no pre-beam: the candidates are 0 .. V-1 in order
+        sc_new, yseq, hyp_new, hyp_i, tok_i, pos, rec = ops.beam_finish(
+            top_s.reshape(-1).contiguous(), top_i.reshape(-1).contiguous(), beam, V, L, i, self.eos, C_["maxlen_d"].view(-1),
+            S["sc"], [logps[k].contiguous() for k in names], c_loc, self.partial_mode == "full", ids_pos, yseq)
+        for k in names:
+            trees[k] = self._tree_index(newtrees[k], hyp_i)
+        T_ = dict(sc=sc_new, trees=trees, yseq=yseq, hyp=hyp_new)
+        if ctc is not None:
+            T_["c_s"] = full[hyp_i, tok_i] if self.partial_mode == "full" else psi[hyp_i, pos]
+            T_["c_r"] = r_new[hyp_i, pos]
         return T_, rec
 
     # ---- hipGraph replay of the steps ------------------------------------------------------------------------------------------
@@ -567,8 +555,7 @@ class BeamSearch(torch.nn.Module):
                 else:
                     fresh = self._batch_state0(C_)            # also tells the scorers that a new search starts
                     G["S0"]["yseq"].copy_(fresh["yseq"]); G["S0"]["hyp"].copy_(fresh["hyp"])
-                    for k in fresh["sc"]:
-                        G["S0"]["sc"][k].copy_(fresh["sc"][k])
+                    G["S0"]["sc"].copy_(fresh["sc"])
                     if "c_s" in fresh:
                         G["S0"]["c_s"].copy_(fresh["c_s"])
                         if G["S0"]["c_r"] is not C_["c_r0"]:
@@ -608,7 +595,7 @@ class BeamSearch(torch.nn.Module):
     def forward(self, x, maxlenratio=0.0, minlenratio=0.0):
         """x: (T, D) encoder output.  Returns the ended hypotheses, best first."""
         if self._device_loop_ok(x):
-            if self.graph_steps and minlenratio == 0.0:
+            if minlenratio == 0.0:       # one utterance = a batch of one: the same step code (selection / bookkeeping kernels, graphs)
                 return self.forward_batch([x], maxlenratio, minlenratio)[0]
             return self._forward_device(x, maxlenratio, minlenratio)
         T = x.shape[0]

@@ -1047,6 +1047,34 @@ def topk_rows(x, k):
     return vals, idx
 
 
+def beam_finish(top_s, top_i, beam, V, L, step, eos, maxlen, sc_in, logps, c_local, full_mode, ids, yseq_in):
+    """the bookkeeping of a beam step after the selection in one launch (eamd_beam_finish) ->
+    (sc_out [ns, n], yseq_out, hyp_out, hyp_i, tok_i, pos, rec)"""
+    n = top_s.numel()
+    ns, W = sc_in.shape[0], yseq_in.shape[1]
+    nf = len(logps)
+    dev = top_s.device
+    for t_ in (top_s, sc_in, c_local) + tuple(logps):
+        if t_ is not None and (t_.dtype != torch.float32 or not t_.is_contiguous()):
+            raise _lib.EamdError("beam_finish: contiguous float32 score tensors")
+    for t_ in (top_i, maxlen, ids, yseq_in):
+        if t_ is not None and (t_.dtype != torch.int64 or not t_.is_contiguous()):
+            raise _lib.EamdError("beam_finish: contiguous int64 index tensors")
+    assert top_i.numel() == n and sc_in.shape[1] == n and yseq_in.shape[0] == n and all(lp.shape == (n, V) for lp in logps)
+    assert ns in (nf, nf + 1) and (ns == nf or (c_local is not None and c_local.shape[0] == n))
+    sc_out = torch.empty(ns, n, device=dev, dtype=torch.float32)
+    yseq_out = torch.empty(n, W, device=dev, dtype=torch.int64)
+    hyp_out = torch.empty(n, device=dev, dtype=torch.float32)
+    hyp_i, tok_i, pos = (torch.empty(n, device=dev, dtype=torch.int64) for _ in range(3))
+    rec = torch.empty(n, 3 + ns + W, device=dev, dtype=torch.float32)
+    arr = (C.c_void_p * 4)(*[lp.data_ptr() for lp in logps] + [None] * (4 - nf))
+    check(_lib.lib().eamd_beam_finish(ptr(top_s), ptr(top_i), n, beam, V, W, L, step, eos, ptr(maxlen), ns, nf, ptr(sc_in), arr,
+                                      ptr(c_local), C.c_int64(c_local.shape[1] if c_local is not None else 0), int(bool(full_mode)),
+                                      ptr(ids), ids.shape[1] if ids is not None else 0, ptr(yseq_in), ptr(sc_out), ptr(yseq_out),
+                                      ptr(hyp_out), ptr(hyp_i), ptr(tok_i), ptr(pos), ptr(rec), stream_ptr()), "eamd_beam_finish")
+    return sc_out, yseq_out, hyp_out, hyp_i, tok_i, pos, rec
+
+
 def log_softmax_rows(x):
     rows, V = x.shape
     y = torch.empty_like(x)

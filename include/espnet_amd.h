@@ -323,6 +323,20 @@ int eamd_argmax_rows(const float* x, int64_t ld, int32_t* out, int rows, int V, 
 int eamd_reduce_sum(const float* in, int64_t n, float* out, float scale, void* stream);
 /* reference: decoder.py:318, ctc.py:134-142. */
 int eamd_log_softmax_rows(const float* x, float* y, int rows, int V, void* stream);
+/* Bookkeeping of a device-resident beam step after the selection (reference: beam_search.py:177-203, batch_beam_search.py:249-284,
+ * there on host objects).  For each of the n = utterances x beam surviving slots s with winner index top_i[s] (= slot * V + token
+ * inside its utterance) and score top_s[s]:
+ *   hyp_i[s] = the hypothesis it extends, tok_i[s] = the token, pos[s] = the token's position among that hypothesis's candidates
+ *              ids [n, ncand] (ids NULL: the token itself);
+ *   sc_out [ns, n]: per-scorer scores carried along - rows j < nf from logps[j] [n, V] (HOST array of nf <= 4 device pointers),
+ *              row nf (if ns == nf + 1) from c_local [n, ldc] at column token (full_mode) or pos;
+ *   yseq_out [n, W] = yseq_in[hyp_i] with position L set to the token;
+ *   hyp_out[s] = top_s[s], or -inf when the slot is empty (non-finite score) or ended (token == eos, or maxlen[utterance] <= step + 1);
+ *   rec [n, 3 + ns + W] = (step, top_s, token, sc_out[:, s], yseq_out[s, :]) as floats: the step log the host reads. */
+int eamd_beam_finish(const float* top_s, const int64_t* top_i, int n, int beam, int V, int W, int L, int step, int eos,
+                     const int64_t* maxlen, int ns, int nf, const float* sc_in, const float* const* logps, const float* c_local,
+                     int64_t ldc, int full_mode, const int64_t* ids, int ncand, const int64_t* yseq_in, float* sc_out,
+                     int64_t* yseq_out, float* hyp_out, int64_t* hyp_i, int64_t* tok_i, int64_t* pos, float* rec, void* stream);
 /* nn.Linear on a handful of rows (M <= 16; up to 1024 rows in blocks of 16 with four columns per wave; K a multiple of 4, fp32): y[M,N] = alpha * act(a_act(x) W^T + bias) + R with W [N,K]
  * row-major (nn.Linear layout), act 0 none / 1 relu / 2 swish on the result, a_act an eamd_act id applied to x while it is read.
  * One wave per output column instead of 64-wide tiles walking K alone.  reference: the per-step products of a decoding
