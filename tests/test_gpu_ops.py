@@ -1612,3 +1612,53 @@ def test_linear_rows_f32(ops, M, N, K, a_act, act, res):
             ops.LINEAR_ROWS = keep
     report("linear_rows %dx%dx%d a_act=%d act=%d" % (M, N, K, a_act, act), y, ref, 2e-6)
     report("linear_rows vs the tile kernel", y, y_tiles, 2e-6)
+
+
+@pytest.mark.parametrize("B,beam,V,nf,ctc,full_mode,pre", [(1, 10, 5000, 1, True, True, True), (3, 4, 30, 3, True, False, True),
+                                                           (2, 5, 50, 2, True, False, False), (4, 3, 40, 1, False, False, False),
+                                                           (2, 4, 30, 2, True, True, False)])
+def test_beam_finish(ops, B, beam, V, nf, ctc, full_mode, pre):
+    """eamd_beam_finish against the tensor expressions it replaced (beam_search.py:177-203 / batch_beam_search.py:249-284 on
+    device tensors): hypothesis / token of each winner, carried scores, prefixes, running scores with ended / empty slots at
+    -inf, position among the candidates, and the log row."""
+    g = torch.Generator().manual_seed(B * 100 + V)
+    n, W, L, step, eos = B * beam, 9, 3, 2, V - 1
+    ncand = 7 if pre else V
+    top_i = torch.stack([torch.randperm(beam * V, generator=g)[:beam] for _ in range(B)])           # distinct winners per utterance
+    top_i[0, 0] = (top_i[0, 0] // V) * V + eos                                                      # one winner ends with <eos>
+    top_s = torch.randn(B, beam, generator=g)
+    top_s[-1, -1] = -float("inf")                                                                   # an empty slot
+    maxlen = torch.tensor([step + 1] + [step + 5] * (B - 1))                                        # utterance 0 is at its length cap
+    ns = nf + int(ctc)
+    sc_in = torch.randn(ns, n, generator=g)
+    logps = [torch.randn(n, V, generator=g) for _ in range(nf)]
+    ids = torch.stack([torch.randperm(V, generator=g)[:ncand] for _ in range(n)]) if pre else None
+    c_local = torch.randn(n, V if (full_mode or not pre) else ncand, generator=g) if ctc else None
+    yseq_in = torch.randint(0, V, (n, W), generator=g)
+    dv = lambda t: None if t is None else t.to(DEV)                                                 # noqa: E731
+    out = ops.beam_finish(dv(top_s.reshape(-1)), dv(top_i.reshape(-1)), beam, V, L, step, eos, dv(maxlen), dv(sc_in),
+                          [dv(lp) for lp in logps], dv(c_local), full_mode, dv(ids), dv(yseq_in))
+    sc_out, yseq_out, hyp_out, hyp_i, tok_i, pos, rec = [t.cpu() for t in out]
+    base = (torch.arange(B) * beam).view(B, 1)
+    r_hyp = (top_i // V + base).view(-1)
+    r_tok = (top_i % V).view(-1)
+    assert torch.equal(hyp_i, r_hyp) and torch.equal(tok_i, r_tok)
+    r_pos = (ids[r_hyp] == r_tok[:, None]).float().argmax(-1) if pre else r_tok
+    assert torch.equal(pos, r_pos)
+    for j in range(nf):
+        assert torch.equal(sc_out[j], sc_in[j][r_hyp] + logps[j][r_hyp, r_tok])
+    if ctc:
+        col = r_tok if (full_mode or not pre) else r_pos
+        assert torch.equal(sc_out[nf], sc_in[nf][r_hyp] + c_local[r_hyp, col])
+    r_y = yseq_in.index_select(0, r_hyp).clone()
+    r_y[:, L] = r_tok
+    assert torch.equal(yseq_out, r_y)
+    ts = top_s.reshape(-1)
+    finite = torch.isfinite(ts)
+    at_cap = (maxlen.view(B, 1) <= step + 1).expand(B, beam).reshape(-1)
+    done = finite & ((r_tok == eos) | at_cap)
+    r_hypo = torch.where(done | ~finite, torch.full_like(ts, -float("inf")), ts)
+    assert torch.equal(hyp_out, r_hypo) and bool(done[0]) and float(hyp_out[-1]) == -float("inf")
+    r_rec = torch.cat([torch.full((n, 1), float(step)), ts[:, None], r_tok[:, None].float()] + [sc_out[j][:, None] for j in range(ns)]
+                      + [r_y.float()], dim=1)
+    assert torch.equal(rec, r_rec)
