@@ -960,7 +960,10 @@ class Decoder(torch.nn.Module, BatchScorerInterface):
     def score_tree(self, ys, tree, xs, memory_mask=None):
         """batch_score on a BATCHED state (list per layer of [n, L-1, D], or None): no per-hypothesis stacking / slicing;
         the search reorders it with index_select (BeamSearch device loop)"""
-        ys_mask = subsequent_mask(ys.size(-1), device=xs.device).unsqueeze(0)
+        # all hypotheses of a search have the same length and only the NEWEST position queries (cached decoding): its row of the
+        # causal mask is all ones, i.e. no mask at all - the reference builds subsequent_mask(L) and slices that row every step
+        # (decoder.py:342-343, decoder_layer.py:88-101); here that was a tril, a fill and six mask conversions per step
+        ys_mask = None if (tree is not None or ys.size(-1) == 1) else subsequent_mask(ys.size(-1), device=xs.device).unsqueeze(0)
         return self.forward_one_step(ys, ys_mask, xs, cache=tree, memory_mask=memory_mask)
 
     def final_tree(self, tree):
