@@ -852,58 +852,61 @@ __global__ __launch_bounds__(64) void beam_finish_kernel(const BeamFinishArgs a)
 }
 }  // namespace
 
-// The same product for a few hundred rows (a batched beam search steps B x beam hypotheses: M = 320): blocks of 16 rows, a wave
-// owns FOUR output columns of its block (the 16 input pieces a lane reads serve four weight rows), grid (N / 16, M / 16).  As
-// 64-wide tiles these launches are 5 x 4 workgroups walking K alone: 15.6 us at K = 256, 60 us at K = 2048.
+// The same product for a few hundred rows (a batched beam search steps B x beam hypotheses: M = 320).  As 64-wide tiles these
+// launches are 5 x 4 workgroups walking K alone (15.6 us at K = 256, 60 us at K = 2048).  Here every WAVE owns one 16 x 16 output
+// tile and feeds v_mfma_f32_16x16x4_f32 straight from global memory: a lane's 16 bytes of an input row and of a weight row are
+// four k-steps of both operands (k-group g of step e holds k = 4 g + e: every k once, both operands alike); no LDS, no barrier,
+// (M / 16) x (N / 16) independent waves.  Exact fp32 products; the summation order over k differs from the tile kernels'.
 namespace {
-__global__ __launch_bounds__(256) void linear_rowblocks_f32_kernel(const float* __restrict__ x, const float* __restrict__ W,
-                                                                   const float* __restrict__ bias, const float* __restrict__ R,
-                                                                   float* __restrict__ y, int M, int N, int K, int a_act, int act,
-                                                                   float alpha) {
-  constexpr int NC = 4;
-  const int lane = threadIdx.x & 63;
-  const int n0 = (blockIdx.x * 4 + (threadIdx.x >> 6)) * NC;
+__global__ __launch_bounds__(256) void linear_mfma16_f32_kernel(const float* __restrict__ x, const float* __restrict__ W,
+                                                                const float* __restrict__ bias, const float* __restrict__ R,
+                                                                float* __restrict__ y, int M, int N, int K, int a_act, int act,
+                                                                float alpha) {
+  const int lane = threadIdx.x & 63, fr = lane & 15, fq = lane >> 4;
+  const int n0 = (blockIdx.x * 4 + (threadIdx.x >> 6)) * 16;
   const int m0 = blockIdx.y * 16;
   if (n0 >= N) return;
-  float acc[16][NC];
+  const float* xr = x + (long)min(m0 + fr, M - 1) * K + fq * 4;          // clamped rows / columns are never stored
+  const float* wr = W + (long)min(n0 + fr, N - 1) * K + fq * 4;
+  f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+  constexpr int U = 8;                                                    // 16-k chunks requested together
+  for (int k0 = 0; k0 < K; k0 += 16 * U) {
+    float4 xa[U], wb[U];
 #pragma unroll
-  for (int m = 0; m < 16; ++m)
+    for (int u = 0; u < U; ++u) {
+      const int k = min(k0 + 16 * u, K - 16);                             // (K % 16 == 0: checked on the host)
+      xa[u] = *reinterpret_cast<const float4*>(xr + k);
+      wb[u] = *reinterpret_cast<const float4*>(wr + k);
+    }
 #pragma unroll
-    for (int c = 0; c < NC; ++c) acc[m][c] = 0.f;
-  const float* xr[16];
-#pragma unroll
-  for (int m = 0; m < 16; ++m) xr[m] = x + (long)min(m0 + m, M - 1) * K;            // clamped rows are never stored
-  for (int k = lane * 4; k < K; k += 256) {
-    float4 w4[NC];
-#pragma unroll
-    for (int c = 0; c < NC; ++c) w4[c] = *reinterpret_cast<const float4*>(W + (long)min(n0 + c, N - 1) * K + k);
-#pragma unroll
-    for (int m = 0; m < 16; ++m) {
-      float4 v = *reinterpret_cast<const float4*>(xr[m] + k);
-      if (a_act != EAMD_ACT_NONE) {
-        v.x = eamd_act(v.x, a_act); v.y = eamd_act(v.y, a_act); v.z = eamd_act(v.z, a_act); v.w = eamd_act(v.w, a_act);
+    for (int u = 0; u < U; ++u) {
+      if (k0 + 16 * u < K) {
+        float4 v = xa[u];
+        if (a_act != EAMD_ACT_NONE) {
+          v.x = eamd_act(v.x, a_act); v.y = eamd_act(v.y, a_act); v.z = eamd_act(v.z, a_act); v.w = eamd_act(v.w, a_act);
+        }
+        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(v.x, wb[u].x, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(v.y, wb[u].y, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(v.z, wb[u].z, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(v.w, wb[u].w, acc, 0, 0, 0);
       }
-#pragma unroll
-      for (int c = 0; c < NC; ++c)
-        acc[m][c] = fmaf(v.x, w4[c].x, fmaf(v.y, w4[c].y, fmaf(v.z, w4[c].z, fmaf(v.w, w4[c].w, acc[m][c]))));
     }
   }
-  float mine = 0.f;
+  const int n = n0 + fr;
+  if (n < N) {
+    const float b = bias ? bias[n] : 0.f;
 #pragma unroll
-  for (int m = 0; m < 16; ++m)
-#pragma unroll
-    for (int c = 0; c < NC; ++c) {
-      const float r = wave_sum(acc[m][c]);
-      if (lane == m * NC + c) mine = r;
+    for (int r = 0; r < 4; ++r) {
+      const int m = m0 + fq * 4 + r;
+      if (m < M) {
+        float v = acc[r] + b;
+        if (act == 1) v = fmaxf(v, 0.f);
+        else if (act == 2) v = eamd_swish(v);
+        v *= alpha;
+        if (R) v += R[(long)m * N + n];
+        y[(long)m * N + n] = v;
+      }
     }
-  const int m = m0 + lane / NC, n = n0 + lane % NC;
-  if (m < M && n < N) {
-    float v = mine + (bias ? bias[n] : 0.f);
-    if (act == 1) v = fmaxf(v, 0.f);
-    else if (act == 2) v = eamd_swish(v);
-    v *= alpha;
-    if (R) v += R[(long)m * N + n];
-    y[(long)m * N + n] = v;
   }
 }
 }  // namespace
@@ -1209,7 +1212,8 @@ int eamd_linear_rows_f32(const float* x, const float* W, const float* bias, cons
   if (M > 1024 || K % 4 != 0 || a_act > EAMD_ACT_SWISH || act > 2) return EAMD_EUNSUPPORTED;
   if (((uintptr_t)x | (uintptr_t)W) & 15) return EAMD_EUNSUPPORTED;
   if (M > 16) {
-    hipLaunchKernelGGL(linear_rowblocks_f32_kernel, dim3((N + 15) / 16, (M + 15) / 16), dim3(256), 0, (hipStream_t)stream, x, W, bias,
+    if (K % 16 != 0) return EAMD_EUNSUPPORTED;
+    hipLaunchKernelGGL(linear_mfma16_f32_kernel, dim3((N + 63) / 64, (M + 15) / 16), dim3(256), 0, (hipStream_t)stream, x, W, bias,
                        R, y, M, N, K, a_act, act, alpha);
     EAMD_LAUNCH_CHECK();
     return EAMD_OK;

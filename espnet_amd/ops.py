@@ -446,8 +446,9 @@ def auto_splitk(m_out, n_out, k_red):
 
 # ---- nn.Linear pieces -------------------------------------------------------------------------
 LINEAR_ROWS = os.environ.get("EAMD_LINEAR_ROWS", "1") != "0"      # eamd_linear_rows_f32 for few rows without autograd
-# rows up to which it is used.  Beyond 16 the library runs blocks of 16 rows x four columns per wave: measured at the batched beam
-# search's M = 320 that form is SLOWER than the 64 x 64 tiles it was meant to replace (step 2.47 -> 2.77 ms), so it stays off
+# rows up to which it is used.  Beyond 16 rows the library has a one-wave-per-16x16-tile MFMA form (direct global loads, no LDS);
+# at the batched beam search's M = 320 it changes nothing measurable (graph step 2.14 vs 2.16 ms: the replayed step is bound by
+# its number of kernel nodes, not by these launches), so the tiles stay
 LINEAR_ROWS_MAX = int(os.environ.get("EAMD_LINEAR_ROWS_MAX", "16"))
 
 
