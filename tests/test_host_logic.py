@@ -136,3 +136,49 @@ def test_unsupported_variants_fail_loudly():
     with pytest.raises(ValueError):
         Encoder("brnnp", 10, 1, 4, 4, np.ones(2, dtype=np.int64), 0.0)
     # scheduled sampling (sampling_probability > 0) is implemented since round 3: tests/test_gpu_rnn.py covers it
+
+
+def test_beam_step_log_replay_on_the_host():
+    """_BatchLog: the host side of a device-resident beam search - rows of the step log [step, score, token, per-scorer
+    scores, prefix] are fetched every sync_every steps and the reference's bookkeeping is replayed from them
+    (beam_search.py:404-458): a slot whose token is <eos> (or that reaches its utterance's length cap) becomes an ended
+    hypothesis with its prefix and scores, empty slots (-inf) are skipped, an utterance stops when nothing is alive or
+    end_detect says so, and the search is over when every utterance has stopped."""
+    from espnet_amd.nets.beam_search import _BatchLog
+
+    class Scorer:
+        def final_score(self, state):
+            return 0.25
+
+    class BS:
+        beam_size, eos, sync_every, apply_final_score = 2, 9, 2, True
+        full_scorers, part_scorers, weights = {"dec": Scorer()}, {}, {"dec": 0.5}
+
+    allk, W = ["dec"], 6
+    ninf = -float("inf")
+
+    def row(step, slots):                      # slots: (score, token, scorer score, prefix list)
+        r = torch.zeros(len(slots), 3 + len(allk) + W)
+        for s, (sc, tok, ds, pre) in enumerate(slots):
+            r[s, 0], r[s, 1], r[s, 2], r[s, 3] = step, sc, tok, ds
+            r[s, 4: 4 + len(pre)] = torch.tensor(pre, dtype=torch.float32)
+        return r
+
+    log = _BatchLog(BS(), 2, [3, 4], 0.5, allk)                     # two utterances, length caps 3 and 4
+    # step 0: utterance 0 slot 0 ends with <eos>; utterance 1: one live slot, one empty
+    assert not log.add(row(0, [(-1.0, 9, -0.5, [9, 9]), (-2.0, 3, -1.0, [9, 3]), (-1.5, 4, -0.7, [9, 4]), (ninf, 0, 0.0, [9, 0])]), last=False)
+    assert log.pending and not log.ended[0]                          # nothing fetched before sync_every rows are in
+    # step 1: utterance 0 alive; utterance 1 ends its only live slot
+    assert not log.add(row(1, [(-2.5, 5, -1.2, [9, 3, 5]), (ninf, 0, 0.0, [9, 0, 0]), (-2.0, 9, -0.9, [9, 4, 9]), (ninf, 0, 0.0, [9, 0, 0])]),
+                       last=False)
+    assert not log.pending
+    assert [h.yseq.tolist() for h in log.ended[0]] == [[9, 9]] and [h.yseq.tolist() for h in log.ended[1]] == [[9, 4, 9]]
+    e0 = log.ended[0][0]
+    assert abs(float(e0.score) - (-1.0 + 0.5 * 0.25)) < 1e-6 and abs(e0.scores["dec"] - (-0.5 + 0.25)) < 1e-6      # final scores added
+    assert log.stopped == [False, True]                              # utterance 1 has nothing alive any more
+    # step 2 = the length cap of utterance 0 (maxlen 3): its live slot ends with <eos> appended
+    assert log.add(row(2, [(-3.0, 6, -1.5, [9, 3, 5, 6]), (ninf, 0, 0.0, [9, 0, 0, 0]), (ninf, 0, 0.0, [9, 0, 0, 0]), (ninf, 0, 0.0, [9, 0, 0, 0])]),
+                   last=True)
+    assert [h.yseq.tolist() for h in log.ended[0]] == [[9, 9], [9, 3, 5, 6, 9]] and log.stopped == [True, True]
+    res = log.results()
+    assert [h.yseq.tolist() for h in res[0]] == [[9, 9], [9, 3, 5, 6, 9]] and len(res[1]) == 1                    # best first
