@@ -741,7 +741,7 @@ namespace {
 __global__ __launch_bounds__(256) void linear_rows_f32_kernel(const float* __restrict__ x, const float* __restrict__ W,
                                                               const float* __restrict__ bias, const float* __restrict__ R,
                                                               float* __restrict__ y, int M, int N, int K, int a_act, int act,
-                                                              float alpha) {
+                                                              float alpha, long ldx, long ldr) {
   const int lane = threadIdx.x & 63;
   const int n = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (n >= N) return;
@@ -764,7 +764,7 @@ __global__ __launch_bounds__(256) void linear_rows_f32_kernel(const float* __res
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
           const int k = k0 + 256 * q;
-          x4[q] = k < K ? *reinterpret_cast<const float4*>(x + (long)m * K + k) : make_float4(0.f, 0.f, 0.f, 0.f);
+          x4[q] = k < K ? *reinterpret_cast<const float4*>(x + (long)m * ldx + k) : make_float4(0.f, 0.f, 0.f, 0.f);
         }
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
@@ -790,7 +790,7 @@ __global__ __launch_bounds__(256) void linear_rows_f32_kernel(const float* __res
     if (act == 1) v = fmaxf(v, 0.f);
     else if (act == 2) v = eamd_swish(v);
     v *= alpha;
-    if (R) v += R[(long)lane * N + n];
+    if (R) v += R[(long)lane * ldr + n];
     y[(long)lane * N + n] = v;
   }
 }
@@ -861,12 +861,12 @@ namespace {
 __global__ __launch_bounds__(256) void linear_mfma16_f32_kernel(const float* __restrict__ x, const float* __restrict__ W,
                                                                 const float* __restrict__ bias, const float* __restrict__ R,
                                                                 float* __restrict__ y, int M, int N, int K, int a_act, int act,
-                                                                float alpha) {
+                                                                float alpha, long ldx, long ldr) {
   const int lane = threadIdx.x & 63, fr = lane & 15, fq = lane >> 4;
   const int n0 = (blockIdx.x * 4 + (threadIdx.x >> 6)) * 16;
   const int m0 = blockIdx.y * 16;
   if (n0 >= N) return;
-  const float* xr = x + (long)min(m0 + fr, M - 1) * K + fq * 4;          // clamped rows / columns are never stored
+  const float* xr = x + (long)min(m0 + fr, M - 1) * ldx + fq * 4;        // clamped rows / columns are never stored
   const float* wr = W + (long)min(n0 + fr, N - 1) * K + fq * 4;
   f32x4 acc = {0.f, 0.f, 0.f, 0.f};
   constexpr int U = 8;                                                    // 16-k chunks requested together
@@ -903,7 +903,7 @@ __global__ __launch_bounds__(256) void linear_mfma16_f32_kernel(const float* __r
         if (act == 1) v = fmaxf(v, 0.f);
         else if (act == 2) v = eamd_swish(v);
         v *= alpha;
-        if (R) v += R[(long)m * N + n];
+        if (R) v += R[(long)m * ldr + n];
         y[(long)m * N + n] = v;
       }
     }
@@ -1207,19 +1207,22 @@ int eamd_beam_finish(const float* top_s, const int64_t* top_i, int n, int beam, 
 }
 
 int eamd_linear_rows_f32(const float* x, const float* W, const float* bias, const float* R, float* y, int M, int N, int K,
-                         int a_act, int act, float alpha, void* stream) {
-  if (!x || !W || !y || M <= 0 || N <= 0 || K <= 0 || a_act < 0 || act < 0) return EAMD_EINVAL;
-  if (M > 1024 || K % 4 != 0 || a_act > EAMD_ACT_SWISH || act > 2) return EAMD_EUNSUPPORTED;
+                         int a_act, int act, float alpha, int64_t ldx, int64_t ldr, void* stream) {
+  if (!x || !W || !y || M <= 0 || N <= 0 || K <= 0 || a_act < 0 || act < 0 || ldx < 0 || ldr < 0) return EAMD_EINVAL;
+  if (ldx == 0) ldx = K;
+  if (ldr == 0) ldr = N;
+  if (ldx < K || ldr < N) return EAMD_EINVAL;
+  if (M > 1024 || K % 4 != 0 || ldx % 4 != 0 || a_act > EAMD_ACT_SWISH || act > 2) return EAMD_EUNSUPPORTED;
   if (((uintptr_t)x | (uintptr_t)W) & 15) return EAMD_EUNSUPPORTED;
   if (M > 16) {
     if (K % 16 != 0) return EAMD_EUNSUPPORTED;
     hipLaunchKernelGGL(linear_mfma16_f32_kernel, dim3((N + 63) / 64, (M + 15) / 16), dim3(256), 0, (hipStream_t)stream, x, W, bias,
-                       R, y, M, N, K, a_act, act, alpha);
+                       R, y, M, N, K, a_act, act, alpha, (long)ldx, (long)ldr);
     EAMD_LAUNCH_CHECK();
     return EAMD_OK;
   }
   hipLaunchKernelGGL(linear_rows_f32_kernel, dim3((N + 3) / 4), dim3(256), 0, (hipStream_t)stream, x, W, bias, R, y, M, N, K,
-                     a_act, act, alpha);
+                     a_act, act, alpha, (long)ldx, (long)ldr);
   EAMD_LAUNCH_CHECK();
   return EAMD_OK;
 }

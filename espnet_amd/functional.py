@@ -743,8 +743,10 @@ class MHABlockFn(torch.autograd.Function):
         else:
             kv_in, T2 = ops.to_act_shared(memory).reshape(-1, D), memory.shape[1]
         if last_query_only:   # cached decoding: only the newest position queries (decoder_layer.py:88-101)
-            xq = xn.view(B, T1f, D)[:, -1, :].contiguous()
-            res = x2.view(B, T1f, D)[:, -1, :].contiguous()
+            xq = xn.view(B, T1f, D)[:, -1, :]            # row-strided views: ops.linear_fwd copies only if its kernel needs dense rows
+            res = x2.view(B, T1f, D)[:, -1, :]
+            if torch.is_grad_enabled():
+                xq, res = xq.contiguous(), res.contiguous()
             T1 = 1
         else:
             xq, res, T1 = xn, (x2 if eps is not None else None), T1f

@@ -459,18 +459,22 @@ def linear_fwd(x, W, b, out=None, *, act=EPI_NONE, R=None, alpha=1.0, a_act=ACT_
     alone and Hb <- dropout(h_act(value)) is written as a second bf16 output."""
     M, K = x.shape
     N = W.shape[0]
-    assert W.shape[1] == K and x.is_contiguous() and W.is_contiguous()
+    assert W.shape[1] == K and W.is_contiguous() and x.stride(1) == 1 and (R is None or R.stride(-1) == 1)
     if (LINEAR_ROWS and M <= LINEAR_ROWS_MAX and out is None and out_dtype == torch.float32 and x.dtype == torch.float32 and W.dtype == torch.float32
             and act in (EPI_NONE, EPI_RELU, EPI_SWISH) and a_act in (ACT_NONE, ACT_RELU, ACT_SWISH) and drop is None and Hb is None
             and a_drop is None and K % 4 == 0 and _state["precision"] == 0 and not torch.is_grad_enabled()
-            and (R is None or (R.is_contiguous() and tuple(R.shape) == (M, N)))):
-        # inference on a handful of rows (one utterance's hypotheses in a beam step): one wave per output column
+            and (R is None or tuple(R.shape) == (M, N))):
+        # inference on a handful of rows (one utterance's hypotheses in a beam step): one wave per output column; x and R may be
+        # row-strided views (the newest position of every prefix)
         y = torch.empty(M, N, device=x.device, dtype=torch.float32)
-        rc = _lib.lib().eamd_linear_rows_f32(ptr(x), ptr(W), ptr(b), ptr(R), ptr(y), M, N, K, a_act, act, C.c_float(alpha), stream_ptr())
+        rc = _lib.lib().eamd_linear_rows_f32(ptr(x), ptr(W), ptr(b), ptr(R), ptr(y), M, N, K, a_act, act, C.c_float(alpha),
+                                             C.c_int64(x.stride(0)), C.c_int64(R.stride(0) if R is not None else 0), stream_ptr())
         if rc == 0:
             return y
         if rc != _lib.EAMD_EUNSUPPORTED:
             check(rc, "eamd_linear_rows_f32")
+    x = x.contiguous()
+    R = R.contiguous() if R is not None else None
     sk = 1
     if (out_dtype if out is None else out.dtype) == torch.float32 and act == EPI_NONE and drop is None and Hb is None and a_drop is None:
         if R is None and alpha == 1.0:

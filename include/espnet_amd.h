@@ -340,9 +340,10 @@ int eamd_beam_finish(const float* top_s, const int64_t* top_i, int n, int beam, 
 /* nn.Linear on a handful of rows (M <= 16; up to 1024 rows in blocks of 16 with four columns per wave; K a multiple of 4, fp32): y[M,N] = alpha * act(a_act(x) W^T + bias) + R with W [N,K]
  * row-major (nn.Linear layout), act 0 none / 1 relu / 2 swish on the result, a_act an eamd_act id applied to x while it is read.
  * One wave per output column instead of 64-wide tiles walking K alone.  reference: the per-step products of a decoding
- * hypothesis set, transformer/decoder_layer.py:77-134, decoder.py:283-321.  EAMD_EUNSUPPORTED: the caller uses eamd_gemm. */
+ * hypothesis set, transformer/decoder_layer.py:77-134, decoder.py:283-321.  ldx / ldr: row strides of x and R in elements (0 =
+ * dense; the newest position of every hypothesis's prefix is a strided set of rows).  EAMD_EUNSUPPORTED: the caller uses eamd_gemm. */
 int eamd_linear_rows_f32(const float* x, const float* W, const float* bias, const float* R, float* y, int M, int N, int K,
-                         int a_act, int act, float alpha, void* stream);
+                         int a_act, int act, float alpha, int64_t ldx, int64_t ldr, void* stream);
 /* The k (<= 64) largest of each row of x [rows, n] (row stride ld), sorted by value descending, equal values by ascending index;
  * NaN counts as -inf.  vals / idx [rows, k].  reference: the torch.topk selections of a beam step (beam_search.py:143-176,
  * batch_beam_search.py:86-110: pre-beam over V, best `beam` of beam x V). */
