@@ -69,7 +69,7 @@ class LayerNorm(torch.nn.LayerNorm):
         assert dim == -1, "only last-dim LayerNorm is on the ASR path"
 
     def forward(self, x):
-        return F_.LayerNormFn.apply(x, self.weight, self.bias, self.eps)
+        return F_.run(F_.LayerNormFn, x, self.weight, self.bias, self.eps)
 
 
 # ---- masks / padding helpers (integer work, host side like the reference) ----------------------
@@ -403,7 +403,7 @@ def mha_block(norm, attn, x, memory, pos_emb, mask, last_query_only=False, p_out
     pre = (kind, SharedProj, block, token): this layer's share of a projection the whole stack ran as one GEMM."""
     drop = (_p(attn, attn.dropout_rate), attn.salt_attn, p_out if attn.training else 0.0, attn.salt_out)
     n_tap = len(F_.ATTN_TAP) if F_.ATTN_TAP is not None else 0
-    out = F_.MHABlockFn.apply(x.contiguous(), memory, pos_emb, _mask_u8(mask, x.device), attn.h, norm.eps,
+    out = F_.run(F_.MHABlockFn, x.contiguous(), memory, pos_emb, _mask_u8(mask, x.device), attn.h, norm.eps,
                               last_query_only, drop, pre[:3] if pre is not None else None,
                               pre[3] if pre is not None else None, norm.weight, norm.bias, *attn.block_params())
     if F_.ATTN_TAP is not None and len(F_.ATTN_TAP) > n_tap:
@@ -472,7 +472,7 @@ def ffn_block(norm, ff, x, scale, p_out=0.0):
     if not isinstance(ff, PositionwiseFeedForward):
         return F_.Conv1dFFNBlockFn.apply(x.contiguous(), norm.weight, norm.bias, ff.w_1.weight, ff.w_1.bias,
                                          ff.w_2.weight, ff.w_2.bias, scale, norm.eps, drop)
-    return F_.FFNBlockFn.apply(x.contiguous(), norm.weight, norm.bias, ff.w_1.weight, ff.w_1.bias, ff.w_2.weight,
+    return F_.run(F_.FFNBlockFn, x.contiguous(), norm.weight, norm.bias, ff.w_1.weight, ff.w_1.bias, ff.w_2.weight,
                                ff.w_2.bias, scale, ff.act_id, norm.eps, drop)
 
 
@@ -871,7 +871,7 @@ class Decoder(torch.nn.Module, BatchScorerInterface):
     def _embed(self, tgt, pos_offset=0):
         pos = self.embed[1]
         pos.extend_pe(tgt.size(1) + pos_offset, self.embed[0].weight.device)
-        y = F_.EmbedPEFn.apply(tgt, self.embed[0].weight, pos.pe, pos.xscale, pos_offset)
+        y = F_.run(F_.EmbedPEFn, tgt, self.embed[0].weight, pos.pe, pos.xscale, pos_offset)
         return F_.dropout(y, pos.dropout_rate, pos.salt, pos.training)
 
     def forward(self, tgt, tgt_mask, memory, memory_mask):
@@ -913,7 +913,7 @@ class Decoder(torch.nn.Module, BatchScorerInterface):
         if self.normalize_before:
             y = self.after_norm(y.contiguous())
         if self.output_layer is not None:
-            y = F_.LinearFn.apply(y, self.output_layer.weight, self.output_layer.bias)
+            y = F_.run(F_.LinearFn, y, self.output_layer.weight, self.output_layer.bias)
             y = ops.log_softmax_rows(y.contiguous())
         return y, new_cache
 
