@@ -295,7 +295,7 @@ constexpr float kLogZero = -10000000000.0f;
 // series (1 + e would round the term away).  Absolute error of one call <= 1.2e-7 on values of magnitude 1 .. 100.
 __device__ __forceinline__ float lae(float a, float b) {
   const float m = fmaxf(a, b);
-  const float e = __expf(-fabsf(a - b));
+  const float e = a == b ? 1.f : __expf(-fabsf(a - b));     // equal operands incl. (-inf, -inf): log 2 on top of m, not NaN
   const float l = e < 2.44140625e-4f ? e * (1.f - 0.5f * e) : __logf(1.f + e);
   return m + l;
 }
@@ -307,9 +307,11 @@ __global__ void ctc_prefix_kernel(const float* __restrict__ logp, const float* _
   const int h = blockIdx.y;
   if (j >= ncand) return;
   const int c = cand[(long)h * ncand + j];
+  // a candidate outside the vocabulary is never dereferenced: its score is NaN (a selection treats NaN as -inf), its state untouched
+  if (c < 0 || c >= V) { psi[(long)h * ncand + j] = __builtin_nanf(""); return; }
   const float* rp = r_prev + (long)h * T * 2;
   float* rn = r_new + ((long)h * ncand + j) * T * 2;
-  const int ol = olen[h];
+  const int ol = min(max(olen[h], 0), T);
   const bool same = ol > 0 && last[h] == c;
   const int start = max(ol, 1);
   // rows before start-1 are never read by later steps; keep them at log-zero like the reference's r
@@ -361,12 +363,13 @@ __global__ void ctc_prefix_batch_kernel(const float* __restrict__ logp_all, cons
   const int h = blockIdx.y;
   if (j >= ncand) return;
   const int u = h / per_utt;
-  const int T = lens[u];
+  const int T = min(max(lens[u], 1), Tmax);                 // a length outside 1 .. Tmax never becomes an address
   const float* logp = logp_all + (long)u * Tmax * V;
   const int c = cand[(long)h * ncand + j];
+  if (c < 0 || c >= V) { psi[(long)h * ncand + j] = __builtin_nanf(""); return; }
   const float* rp = r_prev + (long)h * Tmax * 2;
   float* rn = r_new + ((long)h * ncand + j) * Tmax * 2;
-  const int ol = olen[h];
+  const int ol = min(max(olen[h], 0), T);
   const bool same = ol > 0 && last[h] == c;
   const int start = max(ol, 1);
   for (int t = 0; t < min(start - 1, T); ++t) { rn[2 * t] = kLogZero; rn[2 * t + 1] = kLogZero; }

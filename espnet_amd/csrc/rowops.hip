@@ -813,10 +813,12 @@ __global__ __launch_bounds__(64) void beam_finish_kernel(const BeamFinishArgs a)
   const int s = blockIdx.x * 64 + threadIdx.x;
   if (s >= a.n) return;
   const int u = s / a.beam;
-  const long ti = a.top_i[s];
+  long ti = a.top_i[s];
+  float ts = a.top_s[s];
+  // a selection index outside the utterance's beam x V continuations is never turned into an address: the slot dies (-inf)
+  if (ti < 0 || ti >= (long)a.beam * a.V) { ti = 0; ts = -INFINITY; }
   const long h = (long)u * a.beam + ti / a.V;
   const long tok = ti % a.V;
-  const float ts = a.top_s[s];
   a.hyp_i[s] = h; a.tok_i[s] = tok;
   const int RW = 3 + a.ns + a.W;
   float* rec = a.rec + (long)s * RW;

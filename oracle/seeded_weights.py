@@ -81,3 +81,37 @@ def grad_check(name, grad, fixture):
     el = float((l @ G - pl).norm() / (gn + 1e-30))
     en = abs(float(G.norm()) - gn) / (gn + 1e-30)
     return "probe", max(er, el, en)
+
+
+# ---- round 4: the decode fixture at BASELINE config 2's width (oracle/gen_golden_r4.py and the tests share this) ----
+DECODE_R4 = dict(
+    idim=80, odim=5000, salt=4, seed=4, lens=(1000, 640, 300), beam=10,
+    # random weights give near-uniform posteriors (nothing ever ends, no CTC blank): the two output layers are sharpened and
+    # <eos> / blank get a bias so that hypotheses end at different lengths and end detection fires, as on a trained model
+    out_scale=4.0, eos_bias=7.0, blank_bias=12.0,
+    ns=dict(adim=256, aheads=4, elayers=2, eunits=2048, dlayers=2, dunits=2048, mtlalpha=0.3, lsm_weight=0.1,
+            dropout_rate=0.0, transformer_attn_dropout_rate=0.0, transformer_length_normalized_loss=False,
+            transformer_init="pytorch", transformer_input_layer="conv2d", ctc_type="builtin", report_cer=False,
+            report_wer=False, char_list=None, sym_space="<space>", sym_blank="<blank>",
+            transformer_encoder_pos_enc_layer_type="rel_pos", transformer_encoder_selfattn_layer_type="rel_selfattn",
+            transformer_encoder_activation_type="swish", macaron_style=True, use_cnn_module=True, cnn_module_kernel=31))
+
+
+def decode_r4_model(E2E, spec=DECODE_R4):
+    """E2E = the Conformer E2E class of either side (reference or espnet_amd): same state_dict names -> same weights"""
+    import argparse
+    model = fill_parameters(E2E(spec["idim"], spec["odim"], argparse.Namespace(**spec["ns"])), salt=spec["salt"])
+    with torch.no_grad():
+        model.decoder.output_layer.weight *= spec["out_scale"]
+        model.ctc.ctc_lo.weight *= spec["out_scale"]
+        model.decoder.output_layer.bias[spec["odim"] - 1] += spec["eos_bias"]
+        model.ctc.ctc_lo.bias[0] += spec["blank_bias"]
+    return model.eval()
+
+
+def decode_r4_inputs(spec=DECODE_R4):
+    g = torch.Generator().manual_seed(spec["seed"])
+    return [torch.randn(T, spec["idim"], generator=g) for T in spec["lens"]]
+
+
+DECODE_R4_CASES = [(cw, ratio, 0.0 if ratio == 0.0 else 0.1) for cw in (0.0, 0.3, 1.0) for ratio in (0.0, 0.2)]

@@ -11,7 +11,39 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from test_gpu_model import DEV, _fusion_models  # noqa: E402
 
 
+def c2width():
+    """the reference-recorded searches at config 2's width through graph_steps: eager, capture, replay of every search"""
+    from test_gpu_model import c2width_compare, c2width_setup
+    from espnet_amd.nets.batch_beam_search import BatchBeamSearch
+    from espnet_amd.nets.beam_search import BeamSearch
+    from espnet_amd.nets.ctc_prefix_score import LengthBonus
+    SW, model, g, encs = c2width_setup()
+    spec = SW.DECODE_R4
+    n_graphs = 0
+    for cw, ratio, pen in ((0.3, 0.2, 0.1), (0.3, 0.0, 0.0), (1.0, 0.2, 0.1)):
+        for cls, nm in ((BeamSearch, "beam"), (BatchBeamSearch, "bbeam")):
+            scorers = model.scorers()
+            scorers["length_bonus"] = LengthBonus(spec["odim"])
+            bs = cls(scorers, dict(decoder=1.0 - cw, ctc=cw, length_bonus=pen), spec["beam"], spec["odim"], model.sos, model.eos,
+                     pre_beam_score_key=None if cw == 1.0 else "full")
+            bs.graph_steps = True
+            tags = ["u%d_%s_w%02d_r%02d" % (u, nm, int(cw * 10), int(ratio * 10)) for u in range(len(encs))]
+            for rnd in range(3):                                  # eager, capture + replay, replay
+                for u, enc in enumerate(encs):
+                    c2width_compare("graph_steps[%d] %s" % (rnd, cls.__name__), bs(enc, maxlenratio=ratio), g, tags[u])
+                together = bs.forward_batch(encs, maxlenratio=ratio)
+                for u in range(len(encs)):
+                    c2width_compare("graph_steps[%d] %s.forward_batch" % (rnd, cls.__name__), together[u], g, tags[u])
+            assert bs.graph_steps, "a step could not be captured: the searches above ran eagerly"
+            n_graphs += sum(len(G["graphs"]) for G in bs._step_graphs.values())
+            bs._step_graphs = {}
+    assert n_graphs > 0
+    print("[parity] step graphs c2width: %d captured steps" % n_graphs)
+
+
 def main():
+    if sys.argv[1] == "c2width":
+        return c2width()
     batch, lm, cw, lw = bool(int(sys.argv[1])), (None if sys.argv[2] == "None" else sys.argv[2]), float(sys.argv[3]), float(sys.argv[4])
     from espnet_amd.nets.batch_beam_search import BatchBeamSearch
     from espnet_amd.nets.beam_search import BeamSearch

@@ -1662,3 +1662,91 @@ def test_beam_finish(ops, B, beam, V, nf, ctc, full_mode, pre):
     r_rec = torch.cat([torch.full((n, 1), float(step)), ts[:, None], r_tok[:, None].float()] + [sc_out[j][:, None] for j in range(ns)]
                       + [r_y.float()], dim=1)
     assert torch.equal(rec, r_rec)
+
+
+def test_ctc_prefix_score_vs_float64(ops):
+    """eamd_ctc_prefix_score and eamd_ctc_prefix_score_batch at the benchmarked size (T' = 249, |V| = 5000, 10 hypotheses x 15
+    candidates, three utterances of 249 / 159 / 74 frames) against the float64 restatement of CTCPrefixScore.__call__
+    (ctc_prefix_score.py:255-310; oracle.ctc_prefix_step) over five chained search steps - every step's input state is the
+    float64 state of the chosen candidate, so rounding does not compound across steps and the bound is that of ONE 249-frame
+    recursion: candidates include <eos>, blank and the prefix's last token (the r^b-only branch), frames whose posterior is
+    -inf for a candidate AND for blank (np.logaddexp(-inf, -inf) = -inf), prefixes longer than a short utterance is not needed.
+    Bound: |err| <= 1e-5 + 2e-6 |ref| (fp32 ulp at |r| ~ 300 is 3e-5; the float32 numpy arithmetic of the reference itself
+    is measured beside it)."""
+    import sys, os
+    from conftest import ROOT
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import asr_oracle as O
+    V, per, P, blank, eos = 5000, 10, 15, 0, 4999
+    lens = [249, 159, 74]
+    U, Tmax = len(lens), max(lens)
+    g = torch.Generator().manual_seed(249)
+    logits = 2.5 * torch.randn(U, Tmax, V, generator=g)
+    logits[:, :, blank] += 9.0
+    logp = torch.log_softmax(logits, -1)
+    ninf_tok = 1234
+    logp[0, 40:43, ninf_tok] = -float("inf")
+    logp[0, 41, blank] = -float("inf")                    # frame 41 of utterance 0: candidate 1234 and blank both impossible
+    logp[1, 100, 77] = -float("inf")
+    logp_d = logp.to(DEV).contiguous()
+    lens_d = torch.tensor(lens, dtype=torch.int32, device=DEV)
+    # float64 chain
+    r_prev = np.stack([np.repeat(O.ctc_prefix_init(logp[u, :lens[u]].double().numpy(), blank, np.float64)[None], per, 0)
+                       if lens[u] == Tmax else
+                       np.concatenate([np.repeat(O.ctc_prefix_init(logp[u, :lens[u]].double().numpy(), blank, np.float64)[None], per, 0),
+                                       np.zeros((per, Tmax - lens[u], 2))], 1) for u in range(U)])          # [U, per, Tmax, 2]
+    last = np.full((U, per), eos, dtype=np.int64)
+    worst = dict(psi=0.0, r=0.0, psi32=0.0, r32=0.0)
+    for step in range(5):
+        cand = torch.randint(1, V - 1, (U, per, P), generator=g).numpy()
+        cand[:, :, 0], cand[:, :, 1] = eos, blank
+        if step > 0:
+            cand[:, :, 2] = last                                                  # the repeated-label branch
+        cand[0, :, 3] = ninf_tok
+        cand[1, :, 3] = 77
+        psi64, r64, psi32, r32 = [], [], [], []
+        for u in range(U):
+            T = lens[u]
+            lp = logp[u, :T].double().numpy()
+            p, r = O.ctc_prefix_step(lp, last[u], step, cand[u], r_prev[u][:, :T], blank, eos, np.float64)
+            psi64.append(p); r64.append(r)
+            with np.errstate(all="ignore"):
+                p3, r3 = O.ctc_prefix_step(lp.astype(np.float32), last[u], step, cand[u], r_prev[u][:, :T].astype(np.float32), blank, eos, np.float32)
+            psi32.append(p3); r32.append(r3)
+        cand_d = torch.from_numpy(cand.reshape(U * per, P)).to(torch.int32).to(DEV)
+        last_d = torch.from_numpy(last.reshape(-1)).to(torch.int32).to(DEV)
+        olen_d = torch.full((U * per,), step, dtype=torch.int32, device=DEV)
+        rp_d = torch.from_numpy(r_prev.reshape(U * per, Tmax, 2)).float().to(DEV)
+        psi_b, r_b = ops.ctc_prefix_score_batch(logp_d, lens_d, per, rp_d, cand_d, last_d, olen_d, blank, eos)
+        psi_1, r_1 = ops.ctc_prefix_score(logp_d[0], rp_d[:per].contiguous(), cand_d[:per].contiguous(), last_d[:per].contiguous(),
+                                          olen_d[:per].contiguous(), blank, eos)
+        torch.cuda.synchronize()
+        assert torch.equal(psi_1, psi_b[:per]) and torch.equal(r_1, r_b[:per])    # one utterance == its rows of the batched launch
+
+        def chk(name, got, ref, key):
+            got, ref = np.asarray(got, dtype=np.float64), np.asarray(ref, dtype=np.float64)
+            assert not np.isnan(got).any(), name
+            inf = np.isinf(ref)
+            assert np.array_equal(np.isinf(got), inf) and np.array_equal(got[inf], ref[inf]), name + ": -inf pattern"
+            e = np.abs(got[~inf] - ref[~inf]) / (1e-5 + 2e-6 * np.abs(ref[~inf]))
+            worst[key] = max(worst[key], float(e.max()) if e.size else 0.0)
+        for u in range(U):
+            T = lens[u]
+            sl = slice(u * per, (u + 1) * per)
+            # rows the reference leaves uninitialised (before start - 1) are never read by a later step: excluded
+            t0 = max(step, 1) - 1
+            chk("psi u%d step%d" % (u, step), psi_b[sl].cpu().numpy(), psi64[u], "psi")
+            chk("r u%d step%d" % (u, step), r_b[sl, :, t0:T].cpu().numpy(), r64[u][:, :, t0:], "r")
+            chk("psi32", psi32[u], psi64[u], "psi32")
+            chk("r32", r32[u][:, :, t0:], r64[u][:, :, t0:], "r32")
+            assert float(r_b[sl, :, T:].abs().max()) == 0.0 if T < Tmax else True   # rows beyond the utterance stay zero
+        # next step: each hypothesis takes one of its candidates (not blank / <eos>), state = the float64 one
+        pick = torch.randint(2, P, (U, per), generator=g).numpy()
+        for u in range(U):
+            T = lens[u]
+            for h in range(per):
+                r_prev[u, h, :T] = r64[u][h, pick[u, h]]
+                last[u, h] = cand[u, h, pick[u, h]]
+    print("[parity] ctc_prefix_score vs float64, worst err / (1e-5 + 2e-6 |ref|): HIP psi %.3f r %.3f | reference float32 "
+          "arithmetic (numpy) psi %.3f r %.3f" % (worst["psi"], worst["r"], worst["psi32"], worst["r32"]))
+    assert worst["psi"] <= 1.0 and worst["r"] <= 1.0

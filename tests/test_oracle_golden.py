@@ -550,3 +550,77 @@ def test_e2e_rnn_vggblstm(oracle):
     assert abs(acc - float(p["acc"])) < 1e-6
     loss.backward()
     _grad_check(sd, grads)
+
+
+# ---- round 4: the oracle's decoding functions (cached decoder step, CTC prefix scores, beam search) ------------------------------
+def _nbest(g, tag):
+    lens, flat = np.asarray(g[tag + "_lens"]).tolist(), np.asarray(g[tag + "_yseq"]).tolist()
+    seqs, o = [], 0
+    for n in lens:
+        seqs.append(flat[o:o + n])
+        o += n
+    return seqs, np.asarray(g[tag + "_scores"]).tolist()
+
+
+@pytest.mark.parametrize("name,cfg", [
+    ("e2e_conformer.npz", dict(conformer=True, rel_pos=True, activation="swish")),
+    ("e2e_transformer.npz", dict(conformer=False, rel_pos=False)),
+])
+def test_oracle_beam_search_small(oracle, name, cfg):
+    """oracle.beam_search (BeamSearch semantics) against the reference's recorded 3-best: ctc_weight 0 / 0.3 / 1, beam 4, |V| = 50"""
+    p, sd, _ = split_golden(load_golden(name))
+    cfg = dict(cfg, aheads=4, mtlalpha=0.3, lsm_weight=0.1, odim=50)
+    with torch.no_grad():
+        if cfg["conformer"]:     # the fixture decoded after one training forward: BatchNorm running statistics moved
+            bn = {}
+            oracle.e2e_forward(sd, p["xs"], p["ilens"].tolist(), p["ys"], cfg, training=True, bn_state=bn)
+            sd = dict(sd, **bn)
+        hs, _ = oracle.encoder(sd, "encoder.", p["xs"][1:2, :77], None, cfg, training=False)
+        for cw in (0.0, 0.3, 1.0):
+            tag = "beam_w%02d" % int(cw * 10)
+            nb = oracle.beam_search(sd, hs[0], cfg, dict(decoder=1 - cw, ctc=cw, length_bonus=0.2), 4, 0.0)[:3]
+            seqs, scores = _nbest(p, tag)
+            assert [h["yseq"] for h in nb] == seqs, tag
+            for h, s in zip(nb, scores):
+                assert abs(h["score"] - s) <= 1e-4 * max(1.0, abs(s)), (tag, h["score"], s)
+
+
+def test_oracle_decode_c2width(oracle):
+    """the decoding oracle at BASELINE config 2's width (decode_c2width.npz: d 256, |V| 5000, beam 10): encoder output and CTC
+    posteriors of the 300-frame utterance, then hybrid searches in both semantics - "ids" = the reference's BeamSearch, "full" =
+    its BatchBeamSearch (they differ on the 1000-frame utterance, where <eos> wins from outside the pre-beam) - ids exact,
+    total and per-scorer scores 1e-4."""
+    import os, sys
+    from conftest import ROOT
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import seeded_weights as SW
+    from espnet_amd.nets.e2e_asr_conformer import E2E
+    g = load_golden("decode_c2width.npz")
+    model = SW.decode_r4_model(E2E)
+    sd = {k: v.detach().clone() for k, v in model.state_dict().items()}
+    cfg = dict(conformer=True, rel_pos=True, activation="swish", aheads=4, odim=SW.DECODE_R4["odim"])
+    xs = SW.decode_r4_inputs()
+    torch.set_num_threads(8)
+    with torch.no_grad():
+        for u, cases in ((2, [(0.3, 0.2, 0.1), (0.3, 0.0, 0.0), (0.0, 0.0, 0.0)]), (0, [(0.3, 0.0, 0.0)])):
+            hs, _ = oracle.encoder(sd, "encoder.", xs[u].unsqueeze(0), None, cfg, training=False)
+            close(hs[0, ::8], torch.from_numpy(g["u%d_enc" % u]), rtol=2e-4, atol=2e-5)
+            logp = torch.log_softmax(oracle.linear(sd, "ctc.ctc_lo.", hs[0]), -1)
+            close(logp[::8, ::50], torch.from_numpy(g["u%d_logp" % u]), rtol=2e-4, atol=2e-4)
+            assert logp.argmax(-1).tolist() == g["u%d_ctc_argmax" % u].tolist()
+            for cw, ratio, pen in cases:
+                for mode, nm in (("ids", "beam"), ("full", "bbeam")):
+                    tag = "u%d_%s_w%02d_r%02d" % (u, nm, int(cw * 10), int(ratio * 10))
+                    nb = oracle.beam_search(sd, hs[0], cfg, dict(decoder=1 - cw, ctc=cw, length_bonus=pen), SW.DECODE_R4["beam"],
+                                            ratio, mode=mode)
+                    seqs, scores = _nbest(g, tag)
+                    assert len(nb) == int(g[tag + "_nended"]), (tag, len(nb))
+                    assert [h["yseq"] for h in nb[:len(seqs)]] == seqs, tag
+                    for k, (h, s) in enumerate(zip(nb, scores)):
+                        assert abs(h["score"] - s) <= 1e-4 * max(1.0, abs(s)), (tag, h["score"], s)
+                        for kk in h["scores"]:
+                            ref = float(g[tag + "_sc_" + kk][k])
+                            assert abs(h["scores"][kk] - ref) <= 1e-4 * max(1.0, abs(ref)), (tag, kk)
+    seq_a, _ = _nbest(g, "u0_beam_w03_r00")
+    seq_b, _ = _nbest(g, "u0_bbeam_w03_r00")
+    assert seq_a != seq_b            # the fixture does separate the two semantics
