@@ -219,9 +219,11 @@ def run_precision(a, prec, rank, world, dev):
     if dp_step is not None:
         run = dp_step
     elif use_graph:
-        graph = torch.cuda.CUDAGraph()
+        from espnet_amd import graphs
+        graph = graphs.new_graph()
         with torch.cuda.graph(graph):
             step()
+        graph_nodes = graphs.audit(graph, "training step graph")      # node kinds; raises on memset nodes (espnet_amd/graphs.py)
         run = graph.replay
     else:
         run = step
@@ -356,6 +358,8 @@ def run_precision(a, prec, rank, world, dev):
                launch=(("hipGraph fwd+bwd in %d phases, RCCL all-reduce of each phase's arena range under the next | hipGraph optimizer"
                         % len(dp_step.ranges)) if dp_step is not None else "hipGraph" if use_graph else "eager"),
                roofline=roof)
+    if use_graph and dp_step is None:
+        res["graph_nodes"] = graph_nodes
     if comm is not None:
         res["comm"] = comm
     if reducer is not None:
@@ -527,7 +531,7 @@ def main():
                        "global_batch": B * world, "frames": T, "parallelism": "dp%d" % world,
                        "dropout": a.dropout, "optimizer": "adam+noam, clip 5.0", "launch": head["launch"],
                        "wgrad_side_stream": a.wgrad_stream, "optimizer_steps_done": head["optimizer_steps_done"],
-                       "grad_norm": head["grad_norm"]},
+                       "grad_norm": head["grad_norm"], "graph_nodes": head.get("graph_nodes")},
             "roofline": head["roofline"], "roofline_hbm": hbm, "cpu_baseline": cpu, "parity": parity,
             other: sec,
         }

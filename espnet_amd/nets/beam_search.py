@@ -475,8 +475,8 @@ class BeamSearch(torch.nn.Module):
                     weighted += self.weights[pname] * c_local
         weighted += hyp[:, None]
         # one launch of eamd_topk_rows (value descending, ties by ascending index).  torch.topk takes its multi-block path for
-        # these sizes: six launches and a sort - and, over SEVERAL slices, a GPU memory access fault on the second replay of a
-        # captured step on this ROCm (tools/step_graph_debug.py)
+        # these sizes: six launches and a sort - and zeroes its counters with memset nodes, which a captured graph replays
+        # wrongly on this ROCm from the second launch on (espnet_amd/graphs.py; the round-3 step-graph fault)
         # ... in two stages: the best `beam` of an utterance's beam x V continuations lie among the best `beam` of each of its
         # slots (rows of V elements stay in registers; ONE workgroup walking beam x V ten times took 300 us)
         s1, i1 = ops.topk_rows(weighted, beam)                                              # [n, beam] per slot
@@ -513,6 +513,7 @@ class BeamSearch(torch.nn.Module):
     graph_max_signatures = 8          # least recently used signatures (their graphs and static buffers) are dropped beyond this
 
     def _forward_batch_graphed(self, xs, maxlenratio):
+        from .. import graphs
         B, beam = len(xs), self.beam_size
         Ts = [int(x.shape[0]) for x in xs]
         maxlens = [T if maxlenratio == 0 else max(1, int(maxlenratio * T)) for T in Ts]
@@ -574,9 +575,10 @@ class BeamSearch(torch.nn.Module):
                             for d, m in G["memos"]:
                                 d._kv_memo = m
                         torch.cuda.synchronize()
-                        g = torch.cuda.CUDAGraph()
+                        g = graphs.new_graph()
                         with torch.cuda.graph(g):
                             S1, rec = self._batch_step(i, C_, G["states"][i])
+                        graphs.audit(g, "beam step graph")      # a memset node (e.g. torch.topk's scratch) would replay wrongly
                         G["graphs"][i], G["states"][i + 1], G["recs"][i] = g, S1, rec
                         if i == 0:
                             G["memos"] = [(d, d._kv_memo) for d in self.full_scorers.values() if getattr(d, "_kv_memo", None) is not None]

@@ -18,7 +18,7 @@ import os
 import torch
 
 from . import functional as F_
-from . import ops
+from . import graphs, ops
 
 
 class FlatParams:
@@ -363,16 +363,18 @@ class GraphedDataParallelStep:
         # thread_local: the communicator's watchdog thread may query its events while we capture
         self.graphs = []
         for k in range(len(self.ranges)):
-            g = torch.cuda.CUDAGraph()
+            g = graphs.new_graph()
             with torch.cuda.graph(g, capture_error_mode="thread_local"):
                 out = self._phase(k)
+            graphs.audit(g, "training phase graph %d" % k)      # no memset nodes (they replay wrongly on this ROCm)
             if k == 0:
                 self.loss = out
             self.graphs.append(g)
         self.graph_a = self.graphs[0]
-        self.graph_b = torch.cuda.CUDAGraph()
+        self.graph_b = graphs.new_graph()
         with torch.cuda.graph(self.graph_b, capture_error_mode="thread_local"):
             opt.step()
+        graphs.audit(self.graph_b, "optimizer graph")
 
     def _plan_phases(self):
         """cut points + the arena range each backward phase completes; leaves the single-phase plan in place when the
@@ -580,11 +582,12 @@ class BucketedGraphStep:
             return train_step(self.model, self.flat, self.opt, batch)
         # second sight: capture the step on this batch's tensors (they become the graph's static inputs), then replay
         torch.cuda.synchronize()
-        g = torch.cuda.CUDAGraph()
+        g = graphs.new_graph()
         if self.pool is None:
             self.pool = torch.cuda.graph_pool_handle()
         with torch.cuda.graph(g, pool=self.pool):
             loss = train_step(self.model, self.flat, self.opt, batch)
+        graphs.audit(g, "bucketed step graph")
         g.replay()
         self.captures += 1
         self.cache[key] = dict(graph=g, static=batch, loss=loss)

@@ -102,6 +102,7 @@ def decode_leg(dev, c2_args, n_beam_utts=2, beam=10, ctc_weight=0.3, maxlenratio
         hs, _ = model.encoder(xd, make_non_pad_mask(ilens).unsqueeze(-2).to(dev))
     hl = [int(v) for v in __import__("espnet_amd.nets.modules", fromlist=["x"]).embed_output_lengths(model.encoder.embed, ilens, T)]
     weights = dict(decoder=1.0 - ctc_weight, ctc=ctc_weight, length_bonus=0.0)
+    dev_best = {}
     for tag, cls in (("beam_search", BeamSearch), ("batch_beam_search", BatchBeamSearch)):
         scorers = dict(decoder=model.decoder, ctc=CTCPrefixScorer(model.ctc, model.eos), length_bonus=LengthBonus(V))
         bs = cls(scorers, weights, beam, V, model.sos, model.eos, pre_beam_score_key="full")
@@ -120,7 +121,9 @@ def decode_leg(dev, c2_args, n_beam_utts=2, beam=10, ctc_weight=0.3, maxlenratio
         t0 = time.perf_counter()
         for b in range(n_beam_utts):
             enc = hs[b, : hl[b]].contiguous()
-            bs(enc, maxlenratio=maxlenratio)
+            nb_dev = bs(enc, maxlenratio=maxlenratio)
+            if b == 0:
+                dev_best[tag] = (nb_dev[0].yseq.tolist(), float(nb_dev[0].score))
             steps += max(1, int(maxlenratio * hl[b]))
         torch.cuda.synchronize()
         tot = time.perf_counter() - t0
@@ -171,6 +174,20 @@ def decode_leg(dev, c2_args, n_beam_utts=2, beam=10, ctc_weight=0.3, maxlenratio
     out["cpu_baseline_decode"] = dict(kind="port", what="oracle greedy CTC (encoder + argmax + collapse), %d utterances" % k,
                                       cores=torch.get_num_threads(), utt_per_s=round(k / dt_c, 3), rtf=float("%.3e" % (dt_c / a_s)),
                                       ids_bit_exact=[s for s in same], note="None = an utterance with a near-tie frame (top-2 gap < 1e-4)")
+    # ... and the CPU oracle's beam search (oracle.beam_search: the reference's BeamSearch algorithm, all running hypotheses
+    # scored together, pinned to the reference's recorded searches by tests/test_oracle_golden.py) on utterance 0, same weights / cap
+    t0 = time.perf_counter()
+    with torch.no_grad():
+        nb_c = oracle.beam_search(sd_cpu, hs_c[0, : hl[0]], cfg, weights, beam, maxlenratio, mode="ids")
+    dt_b = time.perf_counter() - t0
+    nsteps = max(1, int(maxlenratio * hl[0]))
+    ref_y, ref_s = dev_best.get("beam_search", (None, float("nan")))
+    out["cpu_baseline_decode"]["beam_search"] = dict(
+        kind="port", what="oracle.beam_search (BeamSearch semantics, CTCPrefixScore numpy recursion), utterance 0 (T' = %d), beam %d, "
+        "ctc_weight %.1f, maxlenratio %.1f, encoder output precomputed" % (hl[0], beam, ctc_weight, maxlenratio),
+        cores=torch.get_num_threads(), utterances=1, utt_per_s=round(1.0 / dt_b, 3), rtf=float("%.3e" % (dt_b / (ilens[0] * 0.01))),
+        beam_steps=nsteps, ms_per_beam_step=round(dt_b / nsteps * 1e3, 2), best_ids_equal_device=(nb_c[0]["yseq"] == ref_y),
+        best_score_diff_vs_device=float("%.3e" % abs(nb_c[0]["score"] - ref_s)))
     del model
     torch.cuda.empty_cache()
     return out

@@ -1,8 +1,8 @@
 #!/usr/bin/env python3
 """What kinds of nodes do captured hipGraphs hold, and does a MEMSET node replay correctly?  (VERDICT r3 item 2 / ADVICE r3.)
 
-Part 1 - node census: captures single torch ops and our own steps with CUDAGraph.enable_debug_mode(), dumps the graph with
-hipGraphDebugDotPrint (CUDAGraph.debug_dump) and counts node kinds per op.
+Part 1 - node census: captures single torch ops and our own steps into CUDAGraph(keep_graph=True) objects and walks the nodes
+with hipGraphGetNodes / hipGraphNodeGetType (espnet_amd.graphs.node_census; CUDAGraph.debug_dump writes an empty file on ROCm).
 Part 2 - a minimal memset-node probe: graph = [hipMemsetAsync(buf, 0, n)] -> [copy buf to out]; buf is refilled with 7.0 OUTSIDE
 the graph before every replay; prints how many bytes of `out` are non-zero after each replay (0 = the memset node did its job).
 Only buffers this script owns are read or written.  Output: gpurun_out/graph_census.txt (+ the raw dot of torch.topk).
@@ -27,6 +27,9 @@ def say(*a):
     print(*a, file=log, flush=True)
 
 
+from espnet_amd import graphs  # noqa: E402
+
+
 def capture(fn, keep_dot=None):
     side = torch.cuda.Stream()
     side.wait_stream(torch.cuda.current_stream())
@@ -34,25 +37,15 @@ def capture(fn, keep_dot=None):
         fn()
     torch.cuda.current_stream().wait_stream(side)
     torch.cuda.synchronize()
-    g = torch.cuda.CUDAGraph()
-    g.enable_debug_mode()
+    g = graphs.new_graph()
     with torch.cuda.graph(g):
         out = fn()
-    path = keep_dot or tempfile.mktemp(suffix=".dot")
-    g.debug_dump(path)
-    text = open(path).read() if os.path.exists(path) else ""
-    return g, out, text
+    return g, out, graphs.node_census(g)
 
 
-def kinds(text):
-    """node kinds in a hipGraphDebugDotPrint dump: counted by the label keywords the runtime writes"""
-    c = {}
-    for key in ("MEMSET", "MEMCPY", "KERNEL", "EMPTY", "HOST", "EVENT", "GRAPH"):
-        n = len(re.findall(key, text))
-        if n:
-            c[key] = n
-    c["nodes"] = len(re.findall(r"^\s*\"?[\w]+\"?\s*\[", text, flags=re.M))
-    return c
+def kinds(census):
+    k, memsets = census
+    return dict(k, memset_params=[(m["element_size"], m["width"], m["height"], m["value"]) for m in memsets]) if memsets else k
 
 
 def main():
@@ -82,11 +75,6 @@ def main():
         keep = os.path.join(OUT, "graph_topk320.dot") if name.startswith("torch.topk [320") else None
         _, _, text = capture(fn, keep)
         say("%-48s %s" % (name, kinds(text)))
-        if keep:
-            say("   (raw dot: gpurun_out/graph_topk320.dot, %d bytes)" % len(text))
-            for ln in text.splitlines():
-                if "MEMSET" in ln.upper():
-                    say("   ", ln.strip()[:400])
 
     say("== part 2: memset node probe (hipMemsetAsync captured, buffer refilled with 7.0 before every replay)")
     hip = ctypes.CDLL("libamdhip64.so")
@@ -95,13 +83,16 @@ def main():
     hip.hipMemsetD32Async.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_size_t, ctypes.c_void_p]
     hip.hipMemsetD32Async.restype = ctypes.c_int
     for nbytes in (16, 1024, 4096, 1 << 20):
-        for form in ("memset8", "memset32"):
+        for form in ("memset8", "memset32", "fill_kern"):
             b = torch.empty(nbytes // 4, device=dev)
             o = torch.empty_like(b)
 
             def work():
                 st = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
-                if form == "memset8":
+                if form == "fill_kern":            # control: the same block zeroed by a kernel node
+                    b.fill_(0.0)                   # torch's fill kernel
+                    rc = 0
+                elif form == "memset8":
                     rc = hip.hipMemsetAsync(ctypes.c_void_p(b.data_ptr()), 0, nbytes, st)
                 else:
                     rc = hip.hipMemsetD32Async(ctypes.c_void_p(b.data_ptr()), 0, nbytes // 4, st)
@@ -116,7 +107,9 @@ def main():
                 g.replay()
                 torch.cuda.synchronize()
                 res.append(int((o.view(torch.int32) != 0).sum()) * 4)
-            say("%-9s %8d bytes: nodes %s ; non-zero bytes of the copy after replay 0..3: %s" % (form, nbytes, kinds(text), res))
+            words = " ".join("%08x" % (v & 0xffffffff) for v in o.view(torch.int32)[:8].tolist())
+            say("%-9s %8d bytes: nodes %s ; non-zero bytes of the copy after replay 0..3: %s ; first words after replay 3: %s"
+                % (form, nbytes, kinds(text), res, words))
 
     if len(sys.argv) > 1 and sys.argv[1] == "steps":
         say("== part 3: our captured steps")
@@ -135,9 +128,6 @@ def main():
             S2 = dict(S)
             _, _, text = capture(lambda: bs._batch_step(2, C_, S2), os.path.join(OUT, "graph_beam_step.dot"))
         say("%-48s %s" % ("beam step (3 utterances x beam 10, V 5000)", kinds(text)))
-        for ln in text.splitlines():
-            if "MEMSET" in ln.upper() or "MEMCPY" in ln.upper():
-                say("   ", ln.strip()[:300])
     say("done")
 
 
