@@ -91,7 +91,7 @@ SYMBOLS = [
     "eamd_conv2_weight_prep", "eamd_conv2_weight_grad", "eamd_add_sos_eos", "eamd_ctc_collapse",
     "eamd_ctc_workspace_bytes", "eamd_ctc_loss", "eamd_ctc_prefix_score", "eamd_ctc_prefix_score_batch", "eamd_grad_norm", "eamd_sched_step", "eamd_adam_step", "eamd_adadelta_step", "eamd_add_gradient_noise",
     "eamd_specaug", "eamd_global_mvn", "eamd_utterance_mvn", "eamd_reflect_pad", "eamd_logmel", "eamd_unfold1d", "eamd_fold1d", "eamd_attloc_convmax_fwd", "eamd_attloc_convmax_bwd", "eamd_layernorm_bwd_drop",
-    "eamd_lstm_cell_fwd", "eamd_lstm_cell_bwd", "eamd_lstm_step_fwd", "eamd_lstm_step_bwd", "eamd_lstm_seq_sync_bytes", "eamd_lstm_seq_fwd", "eamd_lstm_seq_bwd", "eamd_lstm_seq_status", "eamd_gru_cell_fwd", "eamd_gru_cell_bwd", "eamd_maxpool2x2_fwd", "eamd_maxpool2x2_bwd", "eamd_mask_rows",
+    "eamd_lstm_cell_fwd", "eamd_lstm_cell_bwd", "eamd_lstm_step_fwd", "eamd_lstm_step_bwd", "eamd_lstm_seq_sync_bytes", "eamd_lstm_seq_fwd", "eamd_lstm_seq_bwd", "eamd_lstm_seq_status", "eamd_lstm_seq_status_merge", "eamd_gru_cell_fwd", "eamd_gru_cell_bwd", "eamd_maxpool2x2_fwd", "eamd_maxpool2x2_bwd", "eamd_mask_rows",
     "eamd_joint_fwd", "eamd_joint_bwd", "eamd_rnnt_workspace", "eamd_rnnt_loss", "eamd_rnnt_grad", "eamd_rnnt_node_stats", "eamd_rnnt_node_stats_part", "eamd_rnnt_row_coef", "eamd_rnnt_alpha_beta", "eamd_rnnt_node_grad",
     "eamd_conv3x3_c1_fwd", "eamd_conv3x3_c1_bwd_w_workspace", "eamd_conv3x3_c1_bwd_w", "eamd_attloc_fwd", "eamd_attloc_bwd_energy", "eamd_attloc_bwd_workspace", "eamd_attloc_bwd_energy_conv", "eamd_attloc_bwd_conv",
     "eamd_att_dot_energy_fwd", "eamd_att_dot_energy_bwd", "eamd_att_ctx_fwd", "eamd_att_ctx_bwd",

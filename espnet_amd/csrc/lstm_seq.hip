@@ -176,12 +176,13 @@ __global__ __launch_bounds__(1024) void lstm_seq_fwd_kernel(const FwdArgs a) {
         }
       }
       __syncthreads();
-      if (!go) {                                    // workgroup-uniform: a wait gave up somewhere - poison the outputs (the loss
-        if (cell) {                                 // turns NaN, the optimizer's non-finite guard skips the step) and drain
-          const long idx = ((long)tt * B + cb) * H + cu;
-          J.h_out[idx] = __builtin_nanf("");
-          if (J.y) J.y[idx] = __builtin_nanf("");
-        }
+      if (!go) {                                    // workgroup-uniform: a wait gave up somewhere - poison this and every later
+        if (cell)                                   // frame of the outputs (the loss turns NaN whichever frames reach it, the
+          for (int s2 = s; s2 < T; ++s2) {          // optimizer's non-finite guard skips the step) and drain
+            const long idx = ((long)(J.reverse ? T - 1 - s2 : s2) * B + cb) * H + cu;
+            J.h_out[idx] = __builtin_nanf("");
+            if (J.y) J.y[idx] = __builtin_nanf("");
+          }
         break;
       }
       const float* hp = J.h_out + (long)tp * B * H;
@@ -312,8 +313,9 @@ __global__ __launch_bounds__(1024) void lstm_seq_bwd_kernel(const BwdArgs a) {
         }
       }
       __syncthreads();
-      if (!go) {                                    // as in the forward: NaN into this step's gradients, then drain
-        if (cell) J.dgates[((long)tt * B + cb) * K + cu] = __builtin_nanf("");
+      if (!go) {                                    // as in the forward: NaN into this and every later step's gradients, then drain
+        if (cell)
+          for (int s2 = s; s2 < T; ++s2) J.dgates[((long)(J.reverse ? s2 : T - 1 - s2) * B + cb) * K + cu] = __builtin_nanf("");
         break;
       }
       const float* dg = J.dgates + (long)tn * B * K;
@@ -503,6 +505,24 @@ int eamd_lstm_seq_bwd(const eamd_lstm_seq_bwd_t* jobs, int njobs, int T, int B, 
     default: EAMD_LQB(16); break;
   }
 #undef EAMD_LQB
+  EAMD_LAUNCH_CHECK();
+  return EAMD_OK;
+}
+
+namespace {
+__global__ void lstm_seq_status_merge_kernel(const unsigned* __restrict__ ws, unsigned* __restrict__ sticky) {
+  const unsigned v = ws[SYNC_TMO_WORD];
+  if (v != 0 && sticky[0] == 0) sticky[0] = v;      // the first give-up since the caller cleared the word
+}
+}  // namespace
+
+/* folds the status word of the launch that used sync_ws into a caller-owned int32 device word (kept non-zero until the caller
+ * clears it): call it behind every eamd_lstm_seq_fwd / _bwd on the same stream and read the word where the host synchronises
+ * anyway (once per epoch / step log) - a launch that gave up must not only show as a skipped optimizer step */
+int eamd_lstm_seq_status_merge(const void* sync_ws, void* sticky, void* stream) {
+  if (!sync_ws || !sticky) return EAMD_EINVAL;
+  hipLaunchKernelGGL(lstm_seq_status_merge_kernel, dim3(1), dim3(1), 0, (hipStream_t)stream, (const unsigned*)sync_ws,
+                     (unsigned*)sticky);
   EAMD_LAUNCH_CHECK();
   return EAMD_OK;
 }

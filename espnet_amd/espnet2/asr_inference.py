@@ -10,6 +10,8 @@ full scorer is a BatchScorerInterface, `__call__(speech) -> [(text, token, token
 import numpy as np
 import torch
 
+from .. import ops
+
 from ..nets.batch_beam_search import BatchBeamSearch
 from ..nets.beam_search import BeamSearch, Hypothesis
 from ..nets.ctc_prefix_score import CTCPrefixScorer, LengthBonus
@@ -67,6 +69,7 @@ class Speech2Text:
         self.maxlenratio, self.minlenratio, self.device, self.nbest = maxlenratio, minlenratio, device, nbest
 
     @torch.no_grad()
+    @ops.inference_call
     def __call__(self, speech):
         """speech: (Nsamples,) waveform or (T, F) features, as the model's frontend expects"""
         if isinstance(speech, np.ndarray):

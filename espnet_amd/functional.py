@@ -132,7 +132,8 @@ def run(fn, *args):
     call, and a beam step of the decoder is ~45 such calls on a launch-bound path"""
     if torch.is_grad_enabled():
         return fn.apply(*args)
-    return fn.forward(_NoGradCtx(), *args)
+    with ops.inference():
+        return fn.forward(_NoGradCtx(), *args)
 
 
 class DropoutFn(torch.autograd.Function):
@@ -814,7 +815,8 @@ class MHABlockFn(torch.autograd.Function):
             if tb is not None:
                 # a padded batch needs the rel_shift over its own length; only the fused kernels take it (shift_len)
                 raise ops._lib.EamdError("relative-position attention on a shape-bucketed batch needs the fused attention kernels "
-                                         "(d_k = 64, T' <= 2048); this shape runs the GEMM + softmax path")
+                                         "(d_k = 64, T' <= 2048: ops.attn_fwd_supported; train.BucketedGraphStep checks this per bucket up front); "
+                                         "this shape runs the GEMM + softmax path")
             P = attn_scores_fwd(qu, qv, k, p, mask, B, T1, T2, H, dk)
             Pd = ops.dropout(P, p_att, s_att) if p_att > 0.0 else P
             cx = attn_context_fwd(Pd, v, B, T1, T2, H, dk)

@@ -36,10 +36,22 @@ def _runtime():
         h.hipGraphNodeGetType.argtypes = [C.c_void_p, C.POINTER(C.c_int)]
         h.hipGraphMemsetNodeGetParams.argtypes = [C.c_void_p, C.POINTER(_MemsetParams)]
         h.hipGraphChildGraphNodeGetGraph.argtypes = [C.c_void_p, C.POINTER(C.c_void_p)]
+        h.hipStreamGetCaptureInfo.argtypes = [C.c_void_p, C.POINTER(C.c_int), C.POINTER(C.c_ulonglong)]
+        h.hipStreamGetCaptureInfo.restype = C.c_int
         for f in (h.hipGraphGetNodes, h.hipGraphNodeGetType, h.hipGraphMemsetNodeGetParams, h.hipGraphChildGraphNodeGetGraph):
             f.restype = C.c_int
         _hip = h
     return _hip
+
+
+def capture_id(stream=None):
+    """unique id of the capture the stream is in, 0 when it is not capturing (hipStreamGetCaptureInfo)"""
+    h = _runtime()
+    st = C.c_void_p((stream or torch.cuda.current_stream()).cuda_stream)
+    status, cid = C.c_int(0), C.c_ulonglong(0)
+    if h.hipStreamGetCaptureInfo(st, C.byref(status), C.byref(cid)) != 0:
+        return -1
+    return int(cid.value) if status.value == 1 else 0          # hipStreamCaptureStatusActive = 1
 
 
 def new_graph():
@@ -91,5 +103,5 @@ def audit(g, what="captured graph"):
     if memsets:
         desc = ", ".join("%d x %d B at 0x%x" % (m["height"] * max(m["width"], 1), m["element_size"], m["dst"]) for m in memsets[:4])
         raise _lib.EamdError("%s holds %d memset node(s) (%s): they replay wrongly on this ROCm - zero the buffer with a kernel "
-                             "(ops.zero_ / eamd_zero_async) or keep the op out of the capture" % (what, len(memsets), desc))
+                             "(tensor.zero_() is one) or keep the op out of the capture" % (what, len(memsets), desc))
     return kinds

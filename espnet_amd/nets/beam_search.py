@@ -20,6 +20,7 @@ from typing import Any, Dict, NamedTuple
 
 import torch
 
+from ..ops import inference_call as _inference_call
 from .ctc_prefix_score import CTCPrefixScorer, LengthBonus
 from .scorer_interface import PartialScorerInterface, ScorerInterface
 
@@ -350,6 +351,7 @@ class BeamSearch(torch.nn.Module):
             return [] if minlenratio < 0.1 else self.forward(x, maxlenratio, max(0.0, minlenratio - 0.1))
         return nbest
 
+    @_inference_call
     def forward_batch(self, xs, maxlenratio=0.0, minlenratio=0.0):
         """Several utterances in ONE search: xs = list of (T_b, D) encoder outputs -> list of n-best lists (what forward() returns for
         each utterance alone).  B x beam slots share every launch of a beam step - one batch_score per scorer over all slots with the
@@ -361,6 +363,8 @@ class BeamSearch(torch.nn.Module):
         B = len(xs)
         if B == 0:
             return []
+        from .. import ops
+        ops.zero_arena_off()                    # a search never takes slices of a training step's zero arena
         ok = self._device_loop_ok(xs[0]) and minlenratio == 0.0
         if not ok:
             return [self.forward(x, maxlenratio, minlenratio) for x in xs]
@@ -594,8 +598,11 @@ class BeamSearch(torch.nn.Module):
                 self._step_graphs = {}
                 return None
 
+    @_inference_call
     def forward(self, x, maxlenratio=0.0, minlenratio=0.0):
         """x: (T, D) encoder output.  Returns the ended hypotheses, best first."""
+        from .. import ops
+        ops.zero_arena_off()
         if self._device_loop_ok(x):
             if minlenratio == 0.0:       # one utterance = a batch of one: the same step code (selection / bookkeeping kernels, graphs)
                 return self.forward_batch([x], maxlenratio, minlenratio)[0]

@@ -101,6 +101,7 @@ class BeamSearchTransducer:
         self.frame_chunk = frame_chunk
         self.batched = hasattr(decoder, "step")
 
+    @ops.inference_call
     def __call__(self, h):
         """h: encoder states of one utterance (T, D_enc) -> 1-best Hypothesis (greedy) or the sorted n-best list"""
         if hasattr(self.decoder, "att"):          # rnnt-att: forget the previous utterance's encoder projections

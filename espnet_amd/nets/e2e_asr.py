@@ -129,15 +129,18 @@ class E2E(ASRInterface, torch.nn.Module):
     def encode(self, x):
         """x ndarray (T, D) -> encoder states (T', eprojs) (e2e_asr.py:344-369)"""
         self.eval()
+        ops.zero_arena_off()                    # recognition: no slices of a training step's zero arena
         p = next(self.parameters())
         h = torch.as_tensor(x, device=p.device, dtype=p.dtype).unsqueeze(0)
         with torch.no_grad():
             hs, _, _ = self.enc(h, [x.shape[0]])
         return hs.squeeze(0)
 
+    @ops.inference_call
     def recognize_batch(self, xs, recog_args, char_list=None, rnnlm=None, ctc_scoring_num=None):
         """xs list of ndarrays (T_b, D) -> per utterance an n-best list (e2e_asr.py:394-445 -> Decoder.recognize_beam_batch)"""
         self.eval()
+        ops.zero_arena_off()
         p = next(self.parameters())
         ilens = [int(x.shape[0]) for x in xs]
         feats = [torch.as_tensor(x, device=p.device, dtype=p.dtype) for x in xs]
@@ -151,6 +154,7 @@ class E2E(ASRInterface, torch.nn.Module):
             return self.dec.recognize_beam_batch(hs_pad, hlens, lpz, recog_args, char_list, rnnlm, normalize_score=normalize,
                                                  ctc_scoring_num=ctc_scoring_num)
 
+    @ops.inference_call
     def recognize(self, x, recog_args, char_list=None, rnnlm=None):
         """x ndarray (T, D) -> n-best list of {"score", "yseq"} (e2e_asr.py:372-392)"""
         hs = self.encode(x).unsqueeze(0)

@@ -187,6 +187,7 @@ class E2E(ASRInterface, torch.nn.Module):
             hs, _, _ = self.enc(h, ilens)
         return hs.squeeze(0)
 
+    @ops.inference_call
     def recognize(self, x, beam_search):
         """x ndarray (T, D), beam_search: espnet_amd.nets.beam_search_transducer.BeamSearchTransducer
         -> n-best list of dicts (e2e_asr_transducer.py:604-625)"""

@@ -273,6 +273,7 @@ class E2E(ASRInterface, torch.nn.Module):
             enc_output, _ = self.encoder(x, None)
         return enc_output.squeeze(0)
 
+    @ops.inference_call
     def recognize(self, x, recog_args, char_list=None, rnnlm=None, use_jit=False):
         """reference: e2e_asr_transformer.py:259-477 (greedy CTC when ctc_weight == 1, else joint
         CTC/attention beam search through the scorer interface)."""

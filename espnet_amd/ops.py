@@ -446,6 +446,32 @@ def auto_splitk(m_out, n_out, k_red):
 
 # ---- nn.Linear pieces -------------------------------------------------------------------------
 LINEAR_ROWS = os.environ.get("EAMD_LINEAR_ROWS", "1") != "0"      # eamd_linear_rows_f32 for few rows without autograd
+_infer = 0      # > 0 inside an explicit inference region (ops.inference / @ops.inference_call: searches, F_.run's direct forward)
+
+
+class inference:
+    """marks an inference region: products of a handful of rows take eamd_linear_rows_f32 there.  NOT keyed on
+    torch.is_grad_enabled(): grad mode is also off inside every autograd.Function.forward of a TRAINING step, where the few-row
+    products (a small batch through the RNN decoder) must keep the summation order of the GEMMs used for their gradients."""
+
+    def __enter__(self):
+        global _infer
+        _infer += 1
+
+    def __exit__(self, *exc):
+        global _infer
+        _infer -= 1
+        return False
+
+
+def inference_call(fn):
+    import functools
+
+    @functools.wraps(fn)
+    def wrapped(*a, **k):
+        with inference():
+            return fn(*a, **k)
+    return wrapped
 # rows up to which it is used.  Beyond 16 rows the library has a one-wave-per-16x16-tile MFMA form (direct global loads, no LDS);
 # at the batched beam search's M = 320 it changes nothing measurable (graph step 2.14 vs 2.16 ms: the replayed step is bound by
 # its number of kernel nodes, not by these launches), so the tiles stay
@@ -462,8 +488,9 @@ def linear_fwd(x, W, b, out=None, *, act=EPI_NONE, R=None, alpha=1.0, a_act=ACT_
     assert W.shape[1] == K and W.is_contiguous() and x.stride(1) == 1 and (R is None or R.stride(-1) == 1)
     if (LINEAR_ROWS and M <= LINEAR_ROWS_MAX and out is None and out_dtype == torch.float32 and x.dtype == torch.float32 and W.dtype == torch.float32
             and act in (EPI_NONE, EPI_RELU, EPI_SWISH) and a_act in (ACT_NONE, ACT_RELU, ACT_SWISH) and drop is None and Hb is None
-            and a_drop is None and K % 4 == 0 and _state["precision"] == 0 and not torch.is_grad_enabled()
-            and (R is None or tuple(R.shape) == (M, N))):
+            and a_drop is None and K % 4 == 0 and _state["precision"] == 0 and _infer > 0 and not torch.is_grad_enabled()
+            and (R is None or (tuple(R.shape) == (M, N) and (M == 1 or R.stride(0) >= N))) and (M == 1 or x.stride(0) >= K)):
+        # (an expanded, stride-0 operand with M > 1 would read as `dense` on the C side: those go to the GEMM below via .contiguous())
         # inference on a handful of rows (one utterance's hypotheses in a beam step): one wave per output column; x and R may be
         # row-strided views (the newest position of every prefix)
         y = torch.empty(M, N, device=x.device, dtype=torch.float32)
@@ -502,29 +529,48 @@ def linear_fwd(x, W, b, out=None, *, act=EPI_NONE, R=None, alpha=1.0, a_act=ACT_
 class _ZeroArena:
     buf = None
     off = 0
-    need = 0        # bytes asked for since the last begin
+    need = 0        # bytes asked for since the last begin, counted only between a begin and the next begin / off
     cap = 0         # bytes the next arena gets
     active = False
+    tracking = False
+    capture = 0     # id of the stream capture zero_arena_begin ran in (0 = eager)
 
 
 _zarena = _ZeroArena()
 ZERO_ARENA = os.environ.get("EAMD_ZERO_ARENA", "1") != "0"
+ZERO_ARENA_MAX = int(os.environ.get("EAMD_ZERO_ARENA_MAX_MB", "1024")) << 20     # larger demands go to torch.zeros
+
+
+def _capture_id():
+    """0 when the current stream is not capturing, else a number that tells captures apart (the buffer an arena hands out
+    was zeroed by a fill INSIDE one capture, or eagerly: a slice may only be used where that fill runs too)"""
+    if not torch.cuda.is_available() or not torch.cuda.is_current_stream_capturing():
+        return 0
+    try:
+        from . import graphs
+        return graphs.capture_id()
+    except Exception:  # noqa: BLE001 - no id available: "some capture"
+        return -1
 
 
 def zero_arena_begin(device):
     """a FRESH buffer per step (one allocation + one fill): slices a still-living autograd graph of an earlier forward
-    holds keep their storage alive, so a second forward before that backward cannot clobber them"""
+    holds keep their storage alive, so a second forward before that backward cannot clobber them.  Its size follows the
+    demand of the step that just ended (up AND down), capped at ZERO_ARENA_MAX."""
     a = _zarena
-    a.cap = max(a.cap, (int(a.need * 1.25) + 4095) // 4096 * 4096)
-    a.off, a.need = 0, 0
+    if a.tracking:
+        a.cap = min(ZERO_ARENA_MAX, (int(a.need * 1.25) + 4095) // 4096 * 4096)
+    a.off, a.need, a.tracking = 0, 0, True
     a.active = ZERO_ARENA and a.cap > 0
+    a.capture = _capture_id() if (a.active and torch.device(device).type == "cuda") else 0
     a.buf = torch.zeros(a.cap // 4, device=device, dtype=torch.float32) if a.active else None
 
 
 def zero_arena_off():
-    """inference paths: zeros() is torch.zeros again"""
-    _zarena.active = False
-    _zarena.buf = None
+    """inference paths and everything else outside a training forward / backward: zeros() is torch.zeros again and its
+    demand is not counted towards the next training step's arena"""
+    a = _zarena
+    a.active, a.tracking, a.buf, a.off, a.need, a.capture = False, False, None, 0, 0, 0
 
 
 def zeros(*shape, device):
@@ -536,8 +582,10 @@ def zeros(*shape, device):
         n *= int(d)
     a = _zarena
     nb = (n * 4 + 255) // 256 * 256
-    a.need += nb
-    if a.active and n > 0 and a.off + nb <= a.buf.numel() * 4 and a.buf.device == torch.device(device):
+    if a.tracking:
+        a.need += nb
+    if a.active and n > 0 and a.off + nb <= a.buf.numel() * 4 and a.buf.device == torch.device(device) \
+            and (not a.buf.is_cuda or _capture_id() == a.capture):      # never a slice zeroed outside the capture that uses it
         t = a.buf[a.off // 4: a.off // 4 + n].view(shape)
         a.off += nb
         return t
@@ -1585,10 +1633,22 @@ LSTM_PERSISTENT = True      # whole-sequence persistent LSTM launches (csrc/lstm
 _lstm_seq_last_ws = None    # sync words of the most recent persistent launch (lstm_seq_status)
 
 
+_comm_overlap = False      # a gradient all-reduce may run beside backward (train.GradReducer / GraphedDataParallelStep, world > 1)
+_lstm_seq_sticky = {}       # device index -> int32 word: first give-up code of any persistent launch since it was last cleared
+
+
+def set_comm_overlap(active):
+    """the data-parallel drivers announce collectives that overlap backward: their kernels hold CUs, and a persistent LSTM launch
+    needs one workgroup on EVERY CU at once (it would sit in its flag waits until the collective drains) - lstm_seq_ok then
+    declines and the per-step kernels run"""
+    global _comm_overlap
+    _comm_overlap = bool(active)
+
+
 def lstm_seq_ok(njobs, B, H):
     """shapes eamd_lstm_seq_fwd / _bwd take for `njobs` recurrences side by side (one workgroup per CU for the whole
     launch; the entry points themselves answer EAMD_EUNSUPPORTED for anything else)"""
-    if not (LSTM_PERSISTENT and LSTM_FUSED_STEP and H % 64 == 0 and B <= 64 and H <= 1024):
+    if not (LSTM_PERSISTENT and LSTM_FUSED_STEP and H % 64 == 0 and B <= 64 and H <= 1024) or _comm_overlap:
         return False
     cus = torch.cuda.get_device_properties(torch.cuda.current_device()).multi_processor_count
     return njobs * (H // 8) <= cus and njobs * (H // 16) * ((B + 15) // 16) <= cus
@@ -1614,6 +1674,7 @@ def lstm_seq_fwd(jobs, T, B, H):
         _rnn_record.append(("lstm_seq_fwd", (jobs, ws, arr), lambda sp, args=args: check(fn(*args, sp), "eamd_lstm_seq_fwd"),
                             4 * len(jobs) * (4 * H * H + T * B * 9 * H), 2.0 * len(jobs) * (T - 1) * B * 4 * H * H))
     check(fn(*args, stream_ptr()), "eamd_lstm_seq_fwd")
+    _lstm_seq_merge(ws)
 
 
 def lstm_seq_bwd(jobs, T, B, H):
@@ -1628,6 +1689,30 @@ def lstm_seq_bwd(jobs, T, B, H):
         _rnn_record.append(("lstm_seq_bwd", (jobs, ws, arr), lambda sp, args=args: check(fn(*args, sp), "eamd_lstm_seq_bwd"),
                             4 * len(jobs) * (4 * H * H + T * B * 11 * H), 2.0 * len(jobs) * (T - 1) * B * 4 * H * H))
     check(fn(*args, stream_ptr()), "eamd_lstm_seq_bwd")
+    _lstm_seq_merge(ws)
+
+
+def _lstm_seq_merge(ws):
+    """fold the launch's status word into the device's sticky word (one tiny launch, no synchronisation)"""
+    dev = ws.device
+    st = _lstm_seq_sticky.get(dev.index)
+    if st is None:
+        if torch.cuda.is_current_stream_capturing():
+            return                   # first persistent launch inside a capture: no persistent word yet (eager warm-ups come first)
+        st = _lstm_seq_sticky[dev.index] = torch.zeros(1, dtype=torch.int32, device=dev)
+    check(_lib.lib().eamd_lstm_seq_status_merge(ptr(ws), ptr(st), stream_ptr()), "eamd_lstm_seq_status_merge")
+
+
+def lstm_seq_sticky_status(clear=True):
+    """first give-up code of ANY persistent LSTM launch on the current device since the last clear (synchronises: call it
+    where the host waits anyway - train.EpochRunner does once per epoch); 0 = all hand-off waits completed"""
+    st = _lstm_seq_sticky.get(torch.cuda.current_device()) if torch.cuda.is_available() else None
+    if st is None:
+        return 0
+    v = int(st.item())
+    if v and clear:
+        st.zero_()
+    return v
 
 
 def lstm_seq_status():

@@ -291,6 +291,7 @@ class GradReducer:
 
 
 def attach_reducer(reducer):
+    ops.set_comm_overlap(reducer is not None and getattr(reducer, "world", 2) > 1)    # collectives beside backward: see ops.lstm_seq_ok
     F_.GradSink.on_done = reducer.notify if reducer is not None else None
     F_.GradSink.on_use = reducer.use if reducer is not None else None
     ops.defer_ln_reduce = reducer is None     # overlapped buckets need every block's gradients final when it reports
@@ -333,6 +334,7 @@ class GraphedDataParallelStep:
     def __init__(self, model, flat, opt, batch, world=1, group=None, bucket_mb=128.0, warmup=2, phases=True):
         import torch.distributed as dist
         self.dist, self.group, self.world = dist, group, world
+        ops.set_comm_overlap(world > 1)          # each phase's all-reduce runs under the next phase's kernels
         self.model, self.flat, self.opt, self.batch = model, flat, opt, batch
         self.cap = max(1, int(bucket_mb * 1024 * 1024 // 4))
         # Phased backward (phases=True, models with an `encoder.encoders` layer stack): gradient cuts behind the
@@ -542,8 +544,9 @@ class BucketedGraphStep:
     places of the Conformer that depend on T' follow the bound - the legacy rel_shift (eamd_attn_*'s shift_len), the depthwise
     convolution's zero padding (eamd_mask_time in front of it) and the BatchNorm statistics (eamd_bn_*_bounded).  Tested against
     the CPU restatement of the reference on the exact-shape batch (tests/test_gpu_model.py::test_bucketed_graph_step_conformer_is_reference_exact:
-    loss 8e-8, running statistics 1e-7, gradients 1e-3) in all three modes.  Needs the fused attention kernels for
-    relative positions (d_k = 64, T' <= 512); other shapes raise."""
+    loss 8e-8, running statistics 1e-7, gradients 1e-3) in all three modes.  With relative positions the padded step needs the
+    fused attention kernels (d_k = 64, T' of the bucket <= 2048, ops.attn_fwd_supported): this is checked per bucket BEFORE
+    anything runs, and a bucket they decline takes the eager step on the batch's exact shape instead (one warning)."""
 
     def __init__(self, model, flat, opt, t_edge=64, l_edge=8, max_graphs=8):
         from collections import OrderedDict
@@ -551,6 +554,7 @@ class BucketedGraphStep:
         self.t_edge, self.l_edge, self.max_graphs = int(t_edge), int(l_edge), int(max_graphs)
         self.cache = OrderedDict()          # bucket -> dict(graph, static, loss)
         self.seen = {}                      # bucket -> number of eager runs so far
+        self._ok = {}                       # bucket -> the padded step is supported (padded_step_ok)
         self.pool = None
         self.hits = self.misses = self.captures = self.evictions = 0
 
@@ -564,8 +568,30 @@ class BucketedGraphStep:
         up = lambda v, e: (v + e - 1) // e * e  # noqa: E731
         return (int(xs_pad.shape[0]), up(T, self.t_edge), up(max(L, 1), self.l_edge))
 
+    def padded_step_ok(self, key):
+        """can the step run on the batch padded to bucket `key`?  (relative-position attention on a padded time axis needs
+        the rel_shift over the batch's own length, which only the fused attention kernels take)"""
+        ok = self._ok.get(key)
+        if ok is None:
+            from .nets.modules import RelPositionMultiHeadedAttention, embed_output_lengths
+            rel = [m for m in self.model.modules() if isinstance(m, RelPositionMultiHeadedAttention)]
+            ok = True
+            if rel:
+                tp = max(embed_output_lengths(self.model.encoder.embed, [key[1]], key[1]))
+                ok = all(ops.attn_fwd_supported(tp, tp, m.d_k, True) for m in rel)
+            self._ok[key] = ok
+            if not ok:
+                import logging
+                logging.getLogger(__name__).warning(
+                    "BucketedGraphStep: bucket %s runs eagerly on exact shapes (relative-position attention on a padded batch "
+                    "needs the fused attention kernels: d_k = 64, T' <= 2048)", key)
+        return ok
+
     def __call__(self, xs_pad, ilens, ys_pad, olens=None):
         key = self.bucket(xs_pad, ilens, ys_pad, olens)
+        if not self.padded_step_ok(key):
+            self.misses += 1
+            return train_step(self.model, self.flat, self.opt, self.model.prepare(xs_pad, ilens, ys_pad))
         batch = self.model.prepare(xs_pad, ilens, ys_pad, pad_to=key[1:])
         entry = self.cache.get(key)
         if entry is not None:
@@ -777,10 +803,26 @@ class EpochRunner:
             torch.cuda.current_stream(dev).wait_stream(self._side)
         self.history = [{k: t[0][3 + i] / t[0][2].clamp_min(1e-30) for i, k in enumerate(keys)} | {"weight": t[0][2]}
                         for t in tickets]
+        self._check_persistent_launches()
         if not train:
             return None
         nsteps = iiter // self.accum_grad
         return nsteps == 0 or (self.opt.stats()["skipped"] - skipped0) >= nsteps
+
+    def _check_persistent_launches(self):
+        """once per epoch, where the host waits anyway: did a persistent LSTM launch give up on a hand-off (its outputs are NaN,
+        the optimizer skipped those steps)?  Say so, and run the per-step kernels from here on - a skipped step must not be
+        the only trace (csrc/lstm_seq.hip: residency of one workgroup per CU is the caller's side of the contract)."""
+        if self.dev.type != "cuda":
+            return
+        code = ops.lstm_seq_sticky_status(clear=True)
+        self.lstm_seq_failures = getattr(self, "lstm_seq_failures", 0) + (1 if code else 0)
+        if code:
+            import logging
+            logging.getLogger(__name__).error(
+                "a persistent LSTM launch gave up waiting for a hand-off (code 0x%x): its steps were skipped as non-finite; "
+                "switching to the per-step LSTM kernels (another kernel was holding compute units?)", code)
+            ops.LSTM_PERSISTENT = False
 
     def train_one_epoch(self, iterator):
         """-> all_steps_are_invalid (trainer.py:495)"""

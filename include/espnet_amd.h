@@ -586,6 +586,10 @@ int64_t eamd_lstm_seq_sync_bytes(void);
 int eamd_lstm_seq_fwd(const eamd_lstm_seq_fwd_t* jobs, int njobs, int T, int B, int H, void* sync_ws, void* stream);
 int eamd_lstm_seq_bwd(const eamd_lstm_seq_bwd_t* jobs, int njobs, int T, int B, int H, void* sync_ws, void* stream);
 int eamd_lstm_seq_status(const void* sync_ws, void* stream);
+/* sticky[0] (int32, device, caller-owned, cleared by the caller) takes the status word of the launch that used sync_ws unless it
+ * already holds an earlier failure: one tiny launch behind each persistent launch, no synchronisation.  Replaces reading
+ * eamd_lstm_seq_status per launch in a training loop (trainer.py:439-455 only sees a non-finite gradient norm). */
+int eamd_lstm_seq_status_merge(const void* sync_ws, void* sticky, void* stream);
 /* One GRU step (torch.nn.GRU / GRUCell, gate order r,z,n; rnn/encoders.py:31-33,110-119, rnn/decoders.py:96,105,
  * transducer/rnn_decoder.py:50) on gx = x W_ih^T + b_ih and gh = h W_hh^T + b_hh (both [B,3H], eamd_gemm products).
  * acts [B,4H] = r, z, n, gh_n.  Backward: dgx, dgh [B,3H] and dh_direct [B,H] (the part of the gradient that reaches

@@ -86,7 +86,10 @@ def test_zero_arena_host_logic():
     import torch
     from espnet_amd import ops
     a = ops._zarena
-    a.cap, a.need, a.buf, a.active = 0, 0, None, False
+    ops.zero_arena_off()
+    a.cap = 0
+    ops.zeros(1 << 16, device="cpu")                        # demand outside a training step (an eval forward, a search): not counted
+    assert a.need == 0
     ops.zero_arena_begin("cpu")
     assert not a.active
     x, y = ops.zeros(3, 5, device="cpu"), ops.zeros((7,), device="cpu")
@@ -103,8 +106,17 @@ def test_zero_arena_host_logic():
     assert float(r.sum()) == 0.0 and float(p.sum()) == 15.0 and r.data_ptr() != p.data_ptr()   # the old slice lives on
     ops.zero_arena_off()
     z = ops.zeros(4, device="cpu")
-    assert a.buf is None and float(z.sum()) == 0.0
-    a.cap, a.need = 0, 0
+    assert a.buf is None and float(z.sum()) == 0.0 and a.need == 0
+    # the arena follows the last step's demand down as well as up
+    ops.zero_arena_begin("cpu")
+    ops.zeros(1 << 18, device="cpu")
+    ops.zero_arena_begin("cpu")
+    assert a.cap >= (1 << 20)
+    ops.zeros(16, device="cpu")
+    ops.zero_arena_begin("cpu")
+    assert a.cap == 4096
+    ops.zero_arena_off()
+    a.cap = 0
 
 
 def test_product_path_has_no_cpu_fallback():
