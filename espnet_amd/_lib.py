@@ -67,6 +67,23 @@ class FfnT(C.Structure):
                 ("ln_rstd", C.c_void_p), ("ln_eps", C.c_float), ("reserved2", C.c_int32)]
 
 
+class RowProjT(C.Structure):
+    _fields_ = [("a", C.c_void_p), ("lda", C.c_int64), ("w", C.c_void_p), ("bias", C.c_void_p), ("R", C.c_void_p),
+                ("ldr", C.c_int64), ("out", C.c_void_p), ("ldo", C.c_int64),
+                ("M", C.c_int32), ("K", C.c_int32), ("N", C.c_int32), ("a_act", C.c_int32),
+                ("alpha", C.c_float), ("p_out", C.c_float), ("salt_out", C.c_uint64), ("drop_step", C.c_void_p),
+                ("ln_x", C.c_void_p), ("ln_w", C.c_void_p), ("ln_b", C.c_void_p), ("ln_mean", C.c_void_p),
+                ("ln_rstd", C.c_void_p), ("ln_eps", C.c_float), ("lnb_drop_p", C.c_float),
+                ("a_scale", C.c_void_p), ("a_shift", C.c_void_p), ("a_out", C.c_void_p),
+                ("lnb_x", C.c_void_p), ("lnb_gamma", C.c_void_p), ("lnb_mean", C.c_void_p), ("lnb_rstd", C.c_void_p),
+                ("lnb_dres", C.c_void_p), ("lnb_ws", C.c_void_p), ("lnb_drop_out", C.c_void_p), ("lnb_drop_salt", C.c_uint64)]
+
+
+class RowProjPackT(C.Structure):
+    _fields_ = [("w", C.c_void_p), ("image", C.c_void_p), ("K", C.c_int32), ("N", C.c_int32), ("ldw", C.c_int32),
+                ("trans", C.c_int32)]
+
+
 class LstmSeqFwdT(C.Structure):
     _fields_ = [("gx", C.c_void_p), ("w_hh", C.c_void_p), ("b_hh", C.c_void_p), ("live", C.c_void_p),
                 ("h_out", C.c_void_p), ("c_out", C.c_void_p), ("y", C.c_void_p), ("acts", C.c_void_p),
@@ -82,7 +99,7 @@ _lib = None
 
 # every symbol include/espnet_amd.h declares (tests check they are all exported)
 SYMBOLS = [
-    "eamd_abi_version", "eamd_gemm", "eamd_gemm_multi", "eamd_gemm_group_plan", "eamd_gemm_group_launch", "eamd_ffn_fwd", "eamd_ffn_bwd", "eamd_ffn_pack_f32", "eamd_ffn_pack_bf16", "eamd_layernorm_fwd", "eamd_layernorm_bwd_workspace", "eamd_layernorm_bwd_drop_f32", "eamd_layernorm_bwd", "eamd_layernorm_bwd_reduce", "eamd_attn_fwd", "eamd_attn_bwd_q", "eamd_attn_fwd_f32", "eamd_attn_bwd_q_f32", "eamd_attn_bwd_kv_f32", "eamd_attn_bwd_kv", "eamd_softmax_fwd",
+    "eamd_abi_version", "eamd_gemm", "eamd_gemm_multi", "eamd_gemm_group_plan", "eamd_gemm_group_launch", "eamd_ffn_fwd", "eamd_ffn_bwd", "eamd_ffn_pack_f32", "eamd_ffn_pack_bf16", "eamd_rowproj", "eamd_rowproj_pack_f32", "eamd_rowproj_lnb_workspace", "eamd_layernorm_fwd", "eamd_layernorm_bwd_workspace", "eamd_layernorm_bwd_drop_f32", "eamd_layernorm_bwd", "eamd_layernorm_bwd_reduce", "eamd_attn_fwd", "eamd_attn_bwd_q", "eamd_attn_fwd_f32", "eamd_attn_bwd_q_f32", "eamd_attn_bwd_kv_f32", "eamd_attn_bwd_kv", "eamd_softmax_fwd",
     "eamd_softmax_bwd", "eamd_lsm_loss", "eamd_argmax_rows", "eamd_reduce_sum", "eamd_log_softmax_rows", "eamd_topk_rows", "eamd_linear_rows_f32", "eamd_beam_finish",
     "eamd_axpby", "eamd_cast_bf16", "eamd_scale_dev", "eamd_act_fwd", "eamd_act_bwd", "eamd_glu_fwd", "eamd_glu_bwd",
     "eamd_add_bias2", "eamd_add_cast_bf16", "eamd_add_block_f32", "eamd_add_cast_colsum2", "eamd_add_colsum2_f32", "eamd_colsum", "eamd_embed_pe", "eamd_embed_bwd", "eamd_posenc", "eamd_posenc_scaled", "eamd_posenc_scaled_bwd", "eamd_permute4",

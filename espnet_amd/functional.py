@@ -106,6 +106,20 @@ def _ln_bwd_out(dxn, x2, ln_w, mean, rstd, do, gbuf, bbuf, prev, shp):
     return ops.layernorm_bwd(dxn, x2, ln_w, mean, rstd, do, gbuf, bbuf).view(shp)
 
 
+def _rp_ln_bwd(dy, img, x2, ln_w, mean, rstd, do, gbuf, bbuf, prev, shp):
+    """dx = LayerNorm'(dy W) + do by ONE eamd_rowproj launch (the input-gradient product with the LayerNorm backward as its
+    epilogue); the gamma / beta partials join the pass's batched second stage; with `prev` also the dropped copy of dx"""
+    M, D = x2.shape
+    ws = ops.rowproj_lnb_ws(M, x2.device)
+    dcopy = torch.empty(M, D, device=x2.device, dtype=torch.float32) if prev is not None else None
+    dx = ops.rowproj(dy, img, D, lnb=(x2, ln_w, mean, rstd, do, ws, dcopy, prev))
+    ops.ln_partials_reduce(ws, gbuf, bbuf, (M + 31) // 32, D)
+    out = dx.view(shp)
+    if prev is not None:
+        out._eamd_dropped = (dcopy, prev)
+    return out
+
+
 def _act_epi(act):
     return {ACT_RELU: EPI_MUL_RELU_MASK, ACT_SWISH: EPI_MUL_DSWISH}[act]
 
@@ -759,7 +773,20 @@ class MHABlockFn(torch.autograd.Function):
         dk = D // H
         adt = ops.act_dtype()
         x2 = x.reshape(-1, D).contiguous()
-        xn, mean, rstd = _ln_fwd_in(x2, ln_w, ln_b, eps, adt)
+        fused = memory is None and not last_query_only and _qkv_adjacent(wq, wk, wv, bq, bk, bv)
+        # row-block projections (csrc/rowproj_f32.hip; fp32 mode, D = 256, enough rows): LayerNorm + q/k/v as ONE launch, the
+        # output projection with its dropout + residual as one, and in backward dctx = dy Wo and dxn = dqkv W3 + LayerNorm backward
+        rp = None
+        if fused and eps is not None and D == 256 and x2.dtype == torch.float32 and adt == torch.float32 \
+                and ops.rowproj_ok(x2.shape[0], D, 3 * D) and (p_out <= 0.0 or ops.f32_epilogue_drop()):
+            w3 = _span3(ops.wshadow(wq), (3 * D, D))
+            rp = ops.rowproj_images(wq, [(w3, False), (w3, True), (wo.detach(), False), (wo.detach(), True)])
+        if rp is not None:
+            xn = torch.empty_like(x2)
+            mean = torch.empty(x2.shape[0], device=x2.device, dtype=torch.float32)
+            rstd = torch.empty_like(mean)
+        else:
+            xn, mean, rstd = _ln_fwd_in(x2, ln_w, ln_b, eps, adt)
         assert eps is not None or (p_out <= 0.0 and not last_query_only)
         if memory is None:
             kv_in, T2 = xn, T1f
@@ -773,8 +800,10 @@ class MHABlockFn(torch.autograd.Function):
             T1 = 1
         else:
             xq, res, T1 = xn, (x2 if eps is not None else None), T1f
-        fused = memory is None and not last_query_only and _qkv_adjacent(wq, wk, wv, bq, bk, bv)
-        if fused:
+        if rp is not None:
+            qkv = ops.rowproj(xn, rp[0], 3 * D, bias=_span3(bq, (3 * D,)), ln=(x2, ln_w, ln_b, eps, mean, rstd))
+            q, k, v = _MV(qkv, 0, 3 * D), _MV(qkv, D, 3 * D), _MV(qkv, 2 * D, 3 * D)
+        elif fused:
             # q, k, v weights sit back to back in the arenas (FlatParams): one [M, D] x [3D, D]^T projection
             w3, b3 = _span3(ops.wshadow(wq), (3 * D, D)), _span3(bq, (3 * D,))
             qkv = ops.linear_fwd(xq, w3, b3, out_dtype=adt)
@@ -822,13 +851,16 @@ class MHABlockFn(torch.autograd.Function):
             cx = attn_context_fwd(Pd, v, B, T1, T2, H, dk)
         if ATTN_TAP is not None:      # calculate_all_attentions: the probabilities in the reference's (B, H, T1, T2) layout
             ATTN_TAP.append(Pd.view(H, B, T1, _ldp(T2))[..., :T2].permute(1, 0, 2, 3).float())
-        if p_out > 0.0 and (ops.fast() or ops.f32_epilogue_drop()):
+        if rp is not None:
+            out = ops.rowproj(cx, rp[2], D, bias=bo, R=res, drop=(p_out, s_out) if p_out > 0.0 else None)
+        elif p_out > 0.0 and (ops.fast() or ops.f32_epilogue_drop()):
             out = ops.linear_fwd(cx, ops.wshadow(wo), bo, R=res, drop=(p_out, s_out))
         elif p_out > 0.0:
             br = ops.linear_fwd(cx, ops.wshadow(wo), bo)
             out = ops.axpby(res, ops.dropout(br, p_out, s_out), 1.0, 1.0)
         else:
             out = ops.linear_fwd(cx, ops.wshadow(wo), bo, R=res)
+        ctx.rp = rp
         # tensors that live in a SharedProj stay out of save_for_backward (they are no outputs of this Function)
         p_sv = None if pre_pos is not None else p
         if fused:   # k, v (and q without relative positions) are column blocks of qkv
@@ -866,8 +898,12 @@ class MHABlockFn(torch.autograd.Function):
             p, dp_out = pre[1].block(pre[2]), pre[1].grad_block(pre[2])
         do = dout.reshape(-1, D).contiguous()
         dob, g_drop = _grad_operand(dout, do, p_out, s_out)
+        rp = ctx.rp if g_drop is None else None
         ops.linear_bwd_w(dob, cx, sink.buf(8), db=sink.buf(9), a_drop=g_drop)
-        dctx = ops.linear_bwd_x(dob, ops.wshadow(wo), out_dtype=adt, a_drop=g_drop)
+        if rp is not None:
+            dctx = ops.rowproj(dob, rp[3], D)
+        else:
+            dctx = ops.linear_bwd_x(dob, ops.wshadow(wo), out_dtype=adt, a_drop=g_drop)
         if ctx.fused:
             qkv = k
             dqkv = torch.empty(B * T1, 3 * D, device=do.device, dtype=adt)
@@ -883,8 +919,11 @@ class MHABlockFn(torch.autograd.Function):
                 if dp_out is None:
                     ops.linear_bwd_w(ops.to_act(dp), pos2, sink.buf(10))
             ops.linear_bwd_w(dqkv, xn, _span3(sink.buf(2), (3 * D, D)), db=_span3(sink.buf(3), (3 * D,)))
-            dxn = ops.linear_bwd_x(dqkv, _span3(ops.wshadow(wq), (3 * D, D)))
-            dx = _ln_bwd_out(dxn, x2, ln_w, mean, rstd, do, sink.buf(0), sink.buf(1), ctx.prev, (B, T1, D))
+            if rp is not None:      # dxn = dqkv W3 and the LayerNorm backward (+ residual gradient, + the dropped copy) in one launch
+                dx = _rp_ln_bwd(dqkv, rp[1], x2, ln_w, mean, rstd, do, sink.buf(0), sink.buf(1), ctx.prev, (B, T1, D))
+            else:
+                dxn = ops.linear_bwd_x(dqkv, _span3(ops.wshadow(wq), (3 * D, D)))
+                dx = _ln_bwd_out(dxn, x2, ln_w, mean, rstd, do, sink.buf(0), sink.buf(1), ctx.prev, (B, T1, D))
             return (dx, None, None, None, None, None, None, None, None, None) + sink.results()
         dkv_out = None
         if pre_kv is not None:
@@ -940,9 +979,22 @@ class ConvModuleBlockFn(torch.autograd.Function):
         M = B * T
         adt = ops.act_dtype()
         x2 = x.reshape(M, D).contiguous()
-        xn, mean, rstd = _ln_fwd_in(x2, ln_w, ln_b, eps, adt)
+        rp = None
+        if eps is not None and D == 256 and Cc == 256 and x2.dtype == torch.float32 and adt == torch.float32 \
+                and ops.rowproj_ok(M, D, 2 * Cc) and (p_out <= 0.0 or ops.f32_epilogue_drop()):
+            # row-block projections (csrc/rowproj_f32.hip): LayerNorm + pointwise conv 1 in one launch, pointwise conv 2 with
+            # dropout + residual in one, and in backward de = dy W2 and dxn = da W1 + LayerNorm backward
+            w1v, w2v = w1.detach().view(2 * Cc, D), w2.detach().view(Cc, Cc)
+            rp = ops.rowproj_images(w1, [(w1v, False), (w1v, True), (w2v, False), (w2v, True)])
+        if rp is not None:
+            xn = torch.empty_like(x2)
+            mean = torch.empty(M, device=x2.device, dtype=torch.float32)
+            rstd = torch.empty_like(mean)
+            a = ops.rowproj(xn, rp[0], 2 * Cc, bias=b1, ln=(x2, ln_w, ln_b, eps, mean, rstd))
+        else:
+            xn, mean, rstd = _ln_fwd_in(x2, ln_w, ln_b, eps, adt)
+            a = ops.linear_fwd(xn, ops.wshadow(w1).view(2 * Cc, D), b1)     # pointwise conv 1  [M, 2C] fp32
         assert eps is not None or p_out <= 0.0
-        a = ops.linear_fwd(xn, ops.wshadow(w1).view(2 * Cc, D), b1)     # pointwise conv 1  [M, 2C] fp32
         # a batch padded beyond its own longest utterance (ops.set_time_bound): frames from the bound on are zeroed in front of
         # the depthwise convolution (GLU(0, 0) = 0: the zero padding the reference has there) and left out of the BatchNorm
         tb = ops.time_bound()
@@ -971,7 +1023,10 @@ class ConvModuleBlockFn(torch.autograd.Function):
             brstd = ops.axpby(running_var, None, 1.0, 0.0)
             brstd = torch.rsqrt_(brstd.add_(bn_eps))  # tiny [C] host-issued op on eval path only
         e = ops.bn_apply(d, bmean, brstd, g, be, M, Cc, act, adt)
-        if p_out > 0.0 and (ops.fast() or ops.f32_epilogue_drop()):
+        ctx.rp = rp
+        if rp is not None:
+            out = ops.rowproj(e, rp[2], Cc, bias=b2, R=x2, drop=(p_out, s_out) if p_out > 0.0 else None)
+        elif p_out > 0.0 and (ops.fast() or ops.f32_epilogue_drop()):
             out = ops.linear_fwd(e, ops.wshadow(w2).view(Cc, Cc), b2, R=x2, drop=(p_out, s_out))
         elif p_out > 0.0:
             br = ops.linear_fwd(e, ops.wshadow(w2).view(Cc, Cc), b2)
@@ -995,8 +1050,12 @@ class ConvModuleBlockFn(torch.autograd.Function):
         sink = GradSink(ctx.pr)
         do = dout.reshape(M, D).contiguous()
         dob, g_drop = _grad_operand(dout, do, p_out, s_out)
+        rp = ctx.rp if g_drop is None else None
         ops.linear_bwd_w(dob, e, sink.buf(8).view(Cc, Cc), db=sink.buf(9), a_drop=g_drop)
-        de = ops.linear_bwd_x(dob, ops.wshadow(w2).view(Cc, Cc), a_drop=g_drop)
+        if rp is not None:
+            de = ops.rowproj(dob, rp[3], Cc)
+        else:
+            de = ops.linear_bwd_x(dob, ops.wshadow(w2).view(Cc, Cc), a_drop=g_drop)
         # (time bound: the bounded BatchNorm backward takes dy = 0 and writes dx = 0 from the bound on)
         dd = ops.bn_bwd(de, d, bmean, brstd, g, be, sink.buf(6), sink.buf(7), M, Cc, act, training, bound=ctx.bound)
         if gl is None:       # GLU fused into the depthwise kernels: its derivative in the input-gradient store, GLU(a) on load
@@ -1011,8 +1070,11 @@ class ConvModuleBlockFn(torch.autograd.Function):
             if ctx.bound is not None:
                 ops.mask_time(da, T, ctx.bound[1])
         ops.linear_bwd_w(da, xn, sink.buf(2).view(2 * Cc, D), db=sink.buf(3))
-        dxn = ops.linear_bwd_x(da, ops.wshadow(w1).view(2 * Cc, D))
-        dx = _ln_bwd_out(dxn, x2, ln_w, mean, rstd, do, sink.buf(0), sink.buf(1), ctx.prev, (B, T, D))
+        if rp is not None and da.dtype == torch.float32:
+            dx = _rp_ln_bwd(da, rp[1], x2, ln_w, mean, rstd, do, sink.buf(0), sink.buf(1), ctx.prev, (B, T, D))
+        else:
+            dxn = ops.linear_bwd_x(da, ops.wshadow(w1).view(2 * Cc, D))
+            dx = _ln_bwd_out(dxn, x2, ln_w, mean, rstd, do, sink.buf(0), sink.buf(1), ctx.prev, (B, T, D))
         return (dx, None, None, None, None, None, None, None, None) + sink.results()
 
 

@@ -686,9 +686,12 @@ class ConformerEncoder(torch.nn.Module):
         xs, masks = self.embed(xs, masks)
         # relative positions: linear_pos of all layers on the one positional embedding as one [T, D*layers] GEMM
         shared = isinstance(xs, tuple) and shared_stack_proj("pos", list(self.encoders), lambda m: m.self_attn, xs[1])
+        x0 = xs[0] if isinstance(xs, tuple) else xs
+        self._rowproj_prepack(x0.shape[0] * x0.shape[1], x0.shape[2])
         try:
             xs, masks = self.encoders(xs, masks)
         finally:
+            ops.rowproj_prepack_end()
             if shared:
                 for m in self.encoders:
                     m._pre = None
@@ -697,6 +700,30 @@ class ConformerEncoder(torch.nn.Module):
         if self.normalize_before:
             xs = self.after_norm(xs)
         return xs, masks
+
+
+def _conformer_rowproj_prepack(self, M, D):
+    """the packed weight images of ALL layers' row-block projections (q/k/v, attention output, both pointwise convolutions;
+    csrc/rowproj_f32.hip) in two launches at the start of the pass instead of two per layer; the blocks pick them up through
+    ops.rowproj_images"""
+    if not ops.rowproj_ok(M, D, D) or D != 256:
+        return
+    groups = []
+    for m in self.encoders:
+        att, cv = m.self_attn, m.conv_module
+        if F_._qkv_adjacent(att.linear_q.weight, att.linear_k.weight, att.linear_v.weight, att.linear_q.bias, att.linear_k.bias,
+                            att.linear_v.bias):
+            w3 = F_._span3(ops.wshadow(att.linear_q.weight), (3 * D, D))
+            wo = att.linear_out.weight.detach()
+            groups.append((att.linear_q.weight, [(w3, False), (w3, True), (wo, False), (wo, True)]))
+        if cv is not None and cv.pointwise_conv2.weight.shape[0] == D:
+            w1 = cv.pointwise_conv1.weight.detach().view(2 * D, D)
+            w2 = cv.pointwise_conv2.weight.detach().view(D, D)
+            groups.append((cv.pointwise_conv1.weight, [(w1, False), (w1, True), (w2, False), (w2, True)]))
+    ops.rowproj_prepack(groups)
+
+
+ConformerEncoder._rowproj_prepack = _conformer_rowproj_prepack
 
 
 class _LinearInput(torch.nn.Sequential):

@@ -751,6 +751,113 @@ def ffn_bwd(dy, w1, w2, f, *, alpha=1.0, packed=None):
     return dz, dx
 
 
+# ---- row-block projections (csrc/rowproj_f32.hip) ---------------------------------------------------
+ROWPROJ = os.environ.get("EAMD_ROWPROJ", "1") != "0"
+ROWPROJ_MIN_ROWS = int(os.environ.get("EAMD_ROWPROJ_MIN_ROWS", "4096"))       # 32 rows per workgroup: fewer rows leave CUs idle
+
+
+def rowproj_ok(M, K, N):
+    """shapes eamd_rowproj takes in the current mode (fp32 operands; K, N multiples of 256, K <= 768; enough rows to fill the chip)"""
+    return (ROWPROJ and _state["precision"] == 0 and M >= ROWPROJ_MIN_ROWS and K % 256 == 0 and N % 256 == 0 and 256 <= K <= 768
+            and N <= 1024)
+
+
+_rp = {"epoch": 0, "active": False}
+_rp_bufs = {}
+
+
+def rowproj_prepack(groups):
+    """groups: list of (holder tensor, [(W, trans), ...]): the images of MANY blocks in one or two launches (an encoder packs all
+    its layers' projection weights at the start of its forward); rowproj_images() then hands them out until rowproj_prepack_end()"""
+    _rp["epoch"] += 1
+    flat = [job for _, jobs in groups for job in jobs]
+    if not flat:
+        return
+    imgs = rowproj_pack(flat)
+    i = 0
+    for holder, jobs in groups:
+        holder._eamd_rp = (_rp["epoch"], [id(w) for w, _ in jobs], imgs[i:i + len(jobs)])
+        i += len(jobs)
+    _rp["active"] = True
+
+
+def rowproj_prepack_end():
+    _rp["active"] = False
+
+
+def rowproj_images(holder, jobs):
+    """packed images of `jobs` = [(W, trans), ...] (the projection weights of one block, cached on `holder`): those of the
+    running forward's prepack if there was one, else packed here (one launch)"""
+    c = getattr(holder, "_eamd_rp", None)
+    if _rp["active"] and c is not None and c[0] == _rp["epoch"] and len(c[2]) == len(jobs):
+        return c[2]
+    return rowproj_pack(jobs)
+
+
+def rowproj_pack(jobs):
+    """jobs: list of (W 2-D contiguous fp32 tensor (or view with a row stride), trans) -> list of packed images (K * N floats each),
+    ALL made by one launch.  trans = False: W is [N, K] (y = x W^T); trans = True: W is [K, N] (dx = dy W).  The image buffers are
+    cached on the weight tensor; the packing itself is redone at every call (the optimizer rewrites the weights in place, and
+    under hipGraph capture it has to be part of the replayed step)."""
+    arr = (_lib.RowProjPackT * len(jobs))()
+    imgs = []
+    for q, (W, trans) in zip(arr, jobs):
+        assert W.dim() == 2 and W.dtype == torch.float32 and W.stride(1) == 1
+        K, N = (W.shape[0], W.shape[1]) if trans else (W.shape[1], W.shape[0])
+        # image buffers are cached per (weight storage address, shape, orientation): the weights live in persistent arenas
+        key = (W.data_ptr(), K, N, int(bool(trans)), W.device.index)
+        img = _rp_bufs.get(key)
+        if img is None:
+            if len(_rp_bufs) > 4096:
+                _rp_bufs.clear()
+            img = _rp_bufs[key] = torch.empty(K * N, device=W.device, dtype=torch.float32)
+        q.w, q.image, q.K, q.N, q.ldw, q.trans = ptr(W), ptr(img), K, N, W.stride(0), int(bool(trans))
+        imgs.append(img)
+    check(_lib.lib().eamd_rowproj_pack_f32(arr, len(jobs), stream_ptr()), "eamd_rowproj_pack_f32")
+    return imgs
+
+
+def rowproj(a, img, N, *, bias=None, R=None, alpha=1.0, drop=None, ln=None, affine=None, lnb=None, out=None):
+    """out[M, N] = R + alpha * dropout(A' B + bias), 32 rows per workgroup through the whole product (eamd_rowproj).
+    a [M, K] fp32 (row stride allowed); img = rowproj_pack image of B [K, N].
+    ln = (x_raw [M, 256], gamma, beta, eps, mean [M], rstd [M]): A' = LayerNorm(x_raw), `a` RECEIVES the normalised rows.
+    affine = (scale [256], shift [256], act, a_out or None): A' = act(a * scale + shift), also written to a_out.
+    lnb = (x_block_input [M, 256], gamma, mean, rstd, dres or None, ws, drop_out or None, (p, salt) or None): N = 256, the
+    LayerNorm backward runs on the result rows: out = dx (+ dres), ws = per-workgroup partials of d gamma / d beta."""
+    M, K = a.shape
+    dev = a.device
+    if out is None:
+        out = torch.empty(M, N, device=dev, dtype=torch.float32)
+    p = _lib.RowProjT()
+    p.a, p.lda, p.w, p.bias = ptr(a), a.stride(0), ptr(img), ptr(bias)
+    p.R, p.ldr = ptr(R), (R.stride(0) if R is not None else 0)
+    p.out, p.ldo = ptr(out), out.stride(0)
+    p.M, p.K, p.N, p.alpha = M, K, N, float(alpha)
+    if drop is not None and drop[0] > 0.0:
+        p.p_out, p.salt_out, p.drop_step = float(drop[0]), int(drop[1]), ptr(rng_state(dev))
+    if ln is not None:
+        xr, g, b, eps, mean, rstd = ln
+        p.ln_x, p.ln_w, p.ln_b, p.ln_mean, p.ln_rstd, p.ln_eps = ptr(xr), ptr(g), ptr(b), ptr(mean), ptr(rstd), float(eps)
+    if affine is not None:
+        sc, sh, act, a_out = affine
+        p.a_scale, p.a_shift, p.a_act, p.a_out = ptr(sc), ptr(sh), int(act), ptr(a_out)
+    if lnb is not None:
+        xb, g, mean, rstd, dres, ws, d_out, d_ps = lnb
+        p.lnb_x, p.lnb_gamma, p.lnb_mean, p.lnb_rstd, p.lnb_dres, p.lnb_ws = ptr(xb), ptr(g), ptr(mean), ptr(rstd), ptr(dres), ptr(ws)
+        if d_out is not None:
+            p.lnb_drop_out, p.lnb_drop_p, p.lnb_drop_salt, p.drop_step = ptr(d_out), float(d_ps[0]), int(d_ps[1]), ptr(rng_state(dev))
+    fn = _lib.lib().eamd_rowproj
+    keep = (a, img, bias, R, out, ln, affine, lnb)
+    if _gemm_record is not None:
+        _gemm_record.append((dict(kind="rowproj", flop=2.0 * M * K * N), keep, lambda sp, p=p: check(fn(C.byref(p), sp), "eamd_rowproj")))
+    check(fn(C.byref(p), stream_ptr()), "eamd_rowproj")
+    return out
+
+
+def rowproj_lnb_ws(M, device):
+    return torch.empty(int(_lib.lib().eamd_rowproj_lnb_workspace(M)), device=device, dtype=torch.float32)
+
+
 # ---- weight-gradient side stream ---------------------------------------------------------------
 # dW = dY^T X is needed only by the optimizer (and the gradient all-reduce), never by the rest of
 # backward.  When enabled, every weight-gradient GEMM is issued on a second HIP stream so that it
@@ -872,6 +979,16 @@ def flush_ln_reduce():
         tab[i].ws, tab[i].dgamma, tab[i].dbeta, tab[i].nblk, tab[i].D = ws.data_ptr(), dg.data_ptr(), db.data_ptr(), nblk, D
     with torch.cuda.device(jobs[0][0].device):
         check(_lib.lib().eamd_layernorm_bwd_reduce(tab, len(jobs), stream_ptr()), "eamd_layernorm_bwd_reduce")
+
+
+def ln_partials_reduce(ws, dgamma, dbeta, nblk, D):
+    """per-block partial sums ws [nblk][2][D] of a LayerNorm backward (left by eamd_rowproj's epilogue) -> dgamma / dbeta: queued
+    behind the running backward pass like every other LayerNorm's second stage, or reduced right away outside one"""
+    if _defer_ln(ws, dgamma, dbeta, nblk, D):
+        return
+    tab = (_LnReduceJob * 1)()
+    tab[0].ws, tab[0].dgamma, tab[0].dbeta, tab[0].nblk, tab[0].D = ws.data_ptr(), dgamma.data_ptr(), dbeta.data_ptr(), nblk, D
+    check(_lib.lib().eamd_layernorm_bwd_reduce(tab, 1, stream_ptr()), "eamd_layernorm_bwd_reduce")
 
 
 def _defer_ln(ws, dgamma, dbeta, nblk, D):

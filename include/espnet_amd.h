@@ -192,6 +192,48 @@ typedef struct {
 } eamd_ffn_t;
 int eamd_ffn_fwd(const eamd_ffn_t* p, void* stream);
 int eamd_ffn_bwd(const eamd_ffn_t* p, void* stream);
+
+/* Row-block projection: out[M, N] = R + alpha * drop( A'[M, K] B[K, N] + bias ) with 32 rows per workgroup taken through the whole
+ * product (csrc/rowproj_f32.hip; fp32 operands, exact fp32 products; K a multiple of 256 up to 768, N a multiple of 256).
+ * Replaces, for the K = 256 / N = 256 products of a Conformer / Transformer block, the nn.Linear / pointwise Conv1d calls of
+ * transformer/attention.py:40-61,90-92 (linear_q/k/v as one [3D, D] product, linear_out) and conformer/convolution.py:63,76
+ * (pointwise_conv1, pointwise_conv2) TOGETHER WITH what surrounds them in conformer/encoder_layer.py:106-138:
+ *   the LayerNorm in front          ln_x != NULL (K = 256): A' = LayerNorm(ln_x) formed while the rows are staged; `a` is then an
+ *                                   OUTPUT (the normalised rows [M, 256], which backward's weight gradient reads), with ln_mean /
+ *                                   ln_rstd [M] (transformer/layer_norm.py:12-38);
+ *   BatchNorm apply + activation    a_scale != NULL (K = 256): A' = act(a * a_scale[k] + a_shift[k]) (convolution.py:73-75: the
+ *                                   caller folds mean / rstd / gamma / beta into scale and shift); a_out [M, 256] (optional)
+ *                                   receives A';
+ *   dropout + residual behind       p_out / salt_out / drop_step (eamd_dropout's mask of the contiguous [M, N] result), alpha, R;
+ *   the LayerNorm BACKWARD behind an input gradient   lnb_x != NULL (N = 256; the product is dxn = dy W): `out` receives
+ *                                   dx = LayerNorm'(dxn) + lnb_dres, lnb_drop_out (optional, fp32 [M, 256]) its dropped copy
+ *                                   (mask of salt lnb_drop_salt, probability lnb_drop_p: the incoming-gradient dropout of the
+ *                                   PREVIOUS block), and lnb_ws [ceil(M / 32)][2][256] the per-workgroup partial sums of d gamma /
+ *                                   d beta (second stage: eamd_layernorm_bwd_reduce with nblk = ceil(M / 32)).
+ * `w` addresses the PACKED image of B made by eamd_rowproj_pack_f32 (MFMA fragment order; re-packed whenever the weights change):
+ *   trans = 0: B[k][n] = W[n * ldw + k]  (y = x W^T, W [N, K] as nn.Linear stores it)
+ *   trans = 1: B[k][n] = W[k * ldw + n]  (dx = dy W, W [K rows, N columns])
+ * Any number of images is packed by one launch (a table of jobs travels in the kernel arguments, 48 per launch).
+ * EAMD_EUNSUPPORTED for other shapes / unaligned operands: the caller runs eamd_gemm (+ eamd_layernorm_*). */
+typedef struct {
+  const float* a; int64_t lda;
+  const float* w; const float* bias;
+  const float* R; int64_t ldr;
+  float* out; int64_t ldo;
+  int32_t M, K, N, a_act;
+  float alpha; float p_out; uint64_t salt_out; const void* drop_step;
+  const float* ln_x; const float* ln_w; const float* ln_b; float* ln_mean; float* ln_rstd; float ln_eps; float lnb_drop_p;
+  const float* a_scale; const float* a_shift; float* a_out;
+  const float* lnb_x; const float* lnb_gamma; const float* lnb_mean; const float* lnb_rstd; const float* lnb_dres;
+  float* lnb_ws; float* lnb_drop_out; uint64_t lnb_drop_salt;
+} eamd_rowproj_t;
+typedef struct {
+  const float* w; float* image;      /* image: K * N floats */
+  int32_t K, N, ldw, trans;
+} eamd_rowproj_pack_t;
+int eamd_rowproj(const eamd_rowproj_t* p, void* stream);
+int eamd_rowproj_pack_f32(const eamd_rowproj_pack_t* jobs, int njobs, void* stream);
+int64_t eamd_rowproj_lnb_workspace(int M);     /* floats of lnb_ws */
 int eamd_ffn_pack_f32(const float* w1, const float* w2, float* fwd_first, float* fwd_second, float* bwd_first, float* bwd_second,
                       int D, int F, void* stream);
 int eamd_ffn_pack_bf16(const void* w1, const void* w2, void* fwd_first, void* fwd_second, void* bwd_first, void* bwd_second,

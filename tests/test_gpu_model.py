@@ -488,6 +488,36 @@ def test_mha_dk64_golden(prec):
     _check_seeded(att, g, tol["g"], prefix="self_")
 
 
+@pytest.fixture
+def rowproj_any_rows():
+    """the row-block projection kernels (csrc/rowproj_f32.hip) for any number of rows: the fixtures have a few hundred, the
+    dispatch rule asks for >= 4096 (32 rows per workgroup on 256 CUs)"""
+    from espnet_amd import ops
+    old, ops.ROWPROJ_MIN_ROWS = ops.ROWPROJ_MIN_ROWS, 1
+    yield
+    ops.ROWPROJ_MIN_ROWS = old
+
+
+def test_e2e_conformer_dk64_golden_rowproj(rowproj_any_rows):
+    """the same reference fixture with the bench's fp32 dispatch of the attention / convolution-module projections: eamd_rowproj
+    (LayerNorm + q/k/v, output projection + residual, LayerNorm + pointwise conv 1, pointwise conv 2 + residual, and in backward
+    the input gradients with the LayerNorm backward as their epilogue), images packed once per encoder pass"""
+    from espnet_amd import ops
+    calls = []
+    orig = ops.rowproj
+
+    def spy(*a, **k):
+        calls.append((a[0].shape[1], a[2], "ln" if k.get("ln") else "lnb" if k.get("lnb") else "plain"))
+        return orig(*a, **k)
+    ops.rowproj = spy
+    try:
+        test_e2e_conformer_dk64_golden("fp32")
+    finally:
+        ops.rowproj = orig
+    kinds = {c for c in calls}
+    assert {(256, 768, "ln"), (256, 512, "ln"), (256, 256, "plain"), (768, 256, "lnb"), (512, 256, "lnb")} <= kinds, kinds
+
+
 @pytest.mark.parametrize("prec", ["fp32", "bf16"])
 def test_e2e_conformer_dk64_golden(prec):
     """espnet1 Conformer E2E at adim 256 / aheads 4 against the reference: loss, CTC loss, accuracy, encoder output,

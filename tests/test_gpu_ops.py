@@ -1750,3 +1750,87 @@ def test_ctc_prefix_score_vs_float64(ops):
     print("[parity] ctc_prefix_score vs float64, worst err / (1e-5 + 2e-6 |ref|): HIP psi %.3f r %.3f | reference float32 "
           "arithmetic (numpy) psi %.3f r %.3f" % (worst["psi"], worst["r"], worst["psi32"], worst["r32"]))
     assert worst["psi"] <= 1.0 and worst["r"] <= 1.0
+
+
+@pytest.mark.parametrize("M", [7968, 100, 32])
+def test_rowproj_vs_float64(ops, M):
+    """eamd_rowproj (32 rows per workgroup through the whole product, packed weight images) against float64:
+    y = x W^T + b for (K, N) = (256, 768 / 512 / 256) and dx = dy W for K = 768 / 512 / 256 -> 256, row-strided operands, bias,
+    alpha, residual; output dropout = eamd_dropout's mask on the plain product; LayerNorm in front (rows, mean, rstd as
+    eamd_layernorm_fwd); BatchNorm-style affine + Swish on the staged rows; the LayerNorm BACKWARD behind an input gradient
+    (dx, residual gradient, dropped copy, d gamma / d beta partials) against eamd_layernorm_bwd on the GEMM's result."""
+    g = torch.Generator().manual_seed(M)
+    rnd = lambda *s: torch.randn(*s, generator=g)  # noqa: E731
+    for K, N in ((256, 768), (256, 512), (256, 256), (768, 256), (512, 256)):
+        for trans in (False, True):
+            W = rnd(K, N) / K ** 0.5 if trans else rnd(N, K) / K ** 0.5
+            x, b, R = rnd(M, K), rnd(N), rnd(M, N)
+            Wd, xd, bd, Rd = W.to(DEV), x.to(DEV), b.to(DEV), R.to(DEV)
+            img, = ops.rowproj_pack([(Wd, trans)])
+            Bm = W.double() if trans else W.double().t()
+            y = ops.rowproj(xd, img, N, bias=bd, R=Rd, alpha=0.5)
+            report(f"rowproj M={M} K={K} N={N} trans={int(trans)}", y, R.double() + 0.5 * (x.double() @ Bm + b.double()), 2e-6)
+            # row-strided input / output (column blocks of wider buffers, as the q / k / v blocks of a fused projection are)
+            wide_in = torch.zeros(M, K + 64, device=DEV)
+            wide_in[:, 32:32 + K] = xd
+            wide_out = torch.full((M, N + 128), 7.0, device=DEV)
+            ops.rowproj(wide_in[:, 32:32 + K], img, N, out=wide_out[:, 64:64 + N])
+            report("rowproj strided", wide_out[:, 64:64 + N], x.double() @ Bm, 2e-6)
+            assert float(wide_out[:, :64].min()) == 7.0 and float(wide_out[:, 64 + N:].max()) == 7.0
+    # dropout + residual epilogue: the mask eamd_dropout draws for the contiguous [M, N] product
+    K, N = 256, 256
+    W, x, b, R = rnd(N, K) / 16, rnd(M, K), rnd(N), rnd(M, N)
+    Wd, xd, bd, Rd = W.to(DEV), x.to(DEV), b.to(DEV), R.to(DEV)
+    img, = ops.rowproj_pack([(Wd, False)])
+    ops.manual_seed(77)
+    plain = ops.rowproj(xd, img, N, bias=bd)
+    want = Rd + ops.dropout(plain, 0.1, 4242)
+    got = ops.rowproj(xd, img, N, bias=bd, R=Rd, drop=(0.1, 4242))
+    torch.cuda.synchronize()
+    assert torch.equal((got - Rd == 0), (want - Rd == 0)) or float(((got - Rd == 0) != (want - Rd == 0)).float().mean()) < 1e-6
+    report("rowproj dropout + residual", got, want, 1e-6)
+    # LayerNorm in front
+    gam, bet = (1.0 + 0.1 * rnd(K)).to(DEV), (0.1 * rnd(K)).to(DEV)
+    xn_ref, mean_ref, rstd_ref = ops.layernorm_fwd(xd, gam, bet, 1e-12, torch.float32)
+    xn = torch.empty(M, K, device=DEV)
+    mean, rstd = torch.empty(M, device=DEV), torch.empty(M, device=DEV)
+    y = ops.rowproj(xn, img, N, bias=bd, ln=(xd, gam, bet, 1e-12, mean, rstd))
+    report("rowproj LN rows", xn, xn_ref, 1e-6)
+    report("rowproj LN mean", mean, mean_ref[:M], 1e-6)
+    report("rowproj LN rstd", rstd, rstd_ref[:M], 1e-6)
+    ln64 = torch.nn.functional.layer_norm(x.double(), (K,), gam.cpu().double(), bet.cpu().double(), 1e-12)
+    report("rowproj LN + product", y, ln64 @ W.double().t() + b.double(), 2e-6)
+    # affine + Swish on the staged rows (BatchNorm apply in front of pointwise_conv2)
+    sc, sh = (1.0 + 0.2 * rnd(K)).to(DEV), (0.3 * rnd(K)).to(DEV)
+    e_out = torch.empty(M, K, device=DEV)
+    y = ops.rowproj(xd, img, N, bias=bd, affine=(sc, sh, ops.ACT_SWISH, e_out))
+    z = x.double() * sc.cpu().double() + sh.cpu().double()
+    e64 = z * torch.sigmoid(z)
+    report("rowproj affine rows", e_out, e64, 2e-6)
+    report("rowproj affine + product", y, e64 @ W.double().t() + b.double(), 3e-6)
+    # LayerNorm backward behind the input gradient dxn = dy W (K = 768 -> 256)
+    Kb = 768
+    W3, dy = rnd(Kb, 256) / Kb ** 0.5, rnd(M, Kb)
+    x_in, dres = rnd(M, 256), rnd(M, 256)
+    W3d, dyd, xind, dresd = W3.to(DEV), dy.to(DEV), x_in.to(DEV), dres.to(DEV)
+    imgb, = ops.rowproj_pack([(W3d, True)])
+    _, mean_i, rstd_i = ops.layernorm_fwd(xind, gam, bet, 1e-12, torch.float32)
+    dxn = ops.rowproj(dyd, imgb, 256)
+    dg_ref, db_ref = torch.zeros(256, device=DEV), torch.zeros(256, device=DEV)
+    ops.manual_seed(78)
+    dx_ref, dxd_ref = ops.layernorm_bwd(dxn, xind, gam, mean_i, rstd_i, dresd, dg_ref, db_ref, drop=(0.1, 999))
+    ws = ops.rowproj_lnb_ws(M, DEV)
+    ddrop = torch.empty(M, 256, device=DEV)
+    dx = ops.rowproj(dyd, imgb, 256, lnb=(xind, gam, mean_i, rstd_i, dresd, ws, ddrop, (0.1, 999)))
+    torch.cuda.synchronize()
+    report("rowproj LN-bwd dx", dx, dx_ref, 2e-6)
+    report("rowproj LN-bwd dropped copy", ddrop, dxd_ref.float(), 2e-6)
+    part = ws.view(-1, 2, 256).sum(0)
+    report("rowproj LN-bwd d gamma", part[0], dg_ref, 2e-5)
+    report("rowproj LN-bwd d beta", part[1], db_ref, 2e-5)
+    # float64 check of the whole chain on a few rows
+    xi = x_in[:8].double().requires_grad_(True)
+    gam64 = gam.cpu().double()
+    yl = torch.nn.functional.layer_norm(xi, (256,), gam64, bet.cpu().double(), 1e-12)
+    (yl * (dy[:8].double() @ W3.double())).sum().backward()
+    report("rowproj LN-bwd vs float64", dx[:8], xi.grad + dres[:8].double(), 5e-6)
