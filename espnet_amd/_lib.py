@@ -64,7 +64,10 @@ class FfnT(C.Structure):
                 ("alpha", C.c_float), ("p_in", C.c_float), ("salt_in", C.c_uint64), ("p_out", C.c_float),
                 ("salt_out", C.c_uint64), ("drop_step", C.c_void_p), ("dtype", C.c_int32), ("hsplit", C.c_int32),
                 ("ln_x", C.c_void_p), ("ln_w", C.c_void_p), ("ln_b", C.c_void_p), ("ln_mean", C.c_void_p),
-                ("ln_rstd", C.c_void_p), ("ln_eps", C.c_float), ("reserved2", C.c_int32)]
+                ("ln_rstd", C.c_void_p), ("ln_eps", C.c_float), ("reserved2", C.c_int32),
+                ("lnb_x", C.c_void_p), ("lnb_gamma", C.c_void_p), ("lnb_mean", C.c_void_p), ("lnb_rstd", C.c_void_p),
+                ("lnb_dres", C.c_void_p), ("lnb_ws", C.c_void_p), ("lnb_drop_out", C.c_void_p), ("lnb_drop_salt", C.c_uint64),
+                ("lnb_drop_p", C.c_float), ("reserved3", C.c_int32)]
 
 
 class RowProjT(C.Structure):

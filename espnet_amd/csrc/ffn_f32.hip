@@ -30,6 +30,7 @@
 #include "common.h"
 #include "../../include/espnet_amd.h"
 #include "ffn_ln.h"
+#include "ln_bwd_rows.h"
 
 #ifdef FFN_STAMP
 // diagnostic build only: s_memtime stamps of one up and one down wave of workgroup 100 during body 4
@@ -350,6 +351,14 @@ __global__ __launch_bounds__(FNT, 2) void ffn_f32_direct_kernel(const eamd_ffn_t
       }
   }
   __syncthreads();
+  if constexpr (BWD) {
+    if (p.lnb_x) {       // LayerNorm backward over the finished dx rows (ln_bwd_rows.h); scratch = the hidden-unit chunk buffers
+      const EamdLnbArgs la{p.lnb_x, p.lnb_gamma, p.lnb_mean, p.lnb_rstd, p.lnb_dres, p.lnb_ws, p.lnb_drop_out, p.lnb_drop_p,
+                           (unsigned long long)p.lnb_drop_salt, p.drop_step, p.out, (long)FD, p.M};
+      eamd_ln_bwd_rows32<XS_LD>(la, xs, hs, hs + FBM * FD, m0, t, (int)blockIdx.x);
+      return;
+    }
+  }
   const unsigned thr_out = eamd_drop_thr16(p.p_out);
   const float inv_out = eamd_drop_inv(thr_out);
   const unsigned seed_out = (!BWD && p.p_out > 0.f) ? eamd_drop_seed((const unsigned long long*)p.drop_step, p.salt_out) : 0u;
@@ -444,7 +453,7 @@ int check_ffn(const eamd_ffn_t* p, bool bwd) {
   }
   if (p->hsplit < 0) return EAMD_EINVAL;
   if (p->dtype == 1) {                                               // bf16 operands: ffn_bf16.hip
-    if (!eamd_ffn_bf16_ok(p) || p->hsplit > 1) return EAMD_EUNSUPPORTED;
+    if (!eamd_ffn_bf16_ok(p) || p->hsplit > 1 || p->lnb_x) return EAMD_EUNSUPPORTED;
     if (bwd) return p->f ? EAMD_OK : EAMD_EINVAL;
     if (p->p_in < 0.f || p->p_in >= 1.f || p->p_out < 0.f || p->p_out >= 1.f) return EAMD_EINVAL;
     if ((p->p_in > 0.f || p->p_out > 0.f) && !p->drop_step) return EAMD_EINVAL;
@@ -455,6 +464,12 @@ int check_ffn(const eamd_ffn_t* p, bool bwd) {
   if ((long)p->M * p->F >= (1L << 31)) return EAMD_EUNSUPPORTED;     // 32-bit dropout pair index space
   if (!al16(p->x) || !al16(p->w1) || !al16(p->w2) || !al16(p->out) || (p->R && !al16(p->R)) || (p->b2 && !al16(p->b2)))
     return EAMD_EUNSUPPORTED;
+  if (p->lnb_x) {
+    if (!bwd || p->hsplit > 1 || !p->lnb_gamma || !p->lnb_mean || !p->lnb_rstd || !p->lnb_ws) return EAMD_EINVAL;
+    if (p->lnb_drop_out && (!p->drop_step || p->lnb_drop_p < 0.f || p->lnb_drop_p >= 1.f)) return EAMD_EINVAL;
+    if (!al16(p->lnb_x) || !al16(p->lnb_gamma) || (p->lnb_dres && !al16(p->lnb_dres)) || (p->lnb_drop_out && !al16(p->lnb_drop_out)))
+      return EAMD_EUNSUPPORTED;
+  }
   if (bwd) {
     if (!p->f) return EAMD_EINVAL;
   } else {
@@ -501,6 +516,6 @@ extern "C" int eamd_ffn_bwd(const eamd_ffn_t* p, void* stream) {
   const int rc = check_ffn(p, true);
   if (rc != EAMD_OK) return rc;
   if (p->dtype == 1) return eamd_ffn_bf16_launch(p, 1, stream);
-  if (p->hsplit <= 1 && eamd_ffn_f32_sym(p->F)) return eamd_ffn_f32_sym_launch(p, 1, stream);
+  if (p->hsplit <= 1 && eamd_ffn_f32_sym(p->F) && !p->lnb_x) return eamd_ffn_f32_sym_launch(p, 1, stream);
   return launch_ffn<true, EAMD_ACT_NONE>(*p, (hipStream_t)stream);
 }

@@ -23,6 +23,7 @@
 #include <type_traits>
 #include "common.h"
 #include "../../include/espnet_amd.h"
+#include "ln_bwd_rows.h"
 
 namespace {
 
@@ -242,66 +243,9 @@ __global__ __launch_bounds__(RNT, 2) void rowproj_f32_kernel(const eamd_rowproj_
       for (int r = 0; r < 4; ++r)
         *reinterpret_cast<float2*>(&tl[(i * 16 + fq * 4 + r) * TL_LD + wave * 32 + 2 * fr]) = make_float2(acc[i][0][r], acc[i][1][r]);
     __syncthreads();
-    const int row = t >> 4, l = t & 15;
-    const bool live = m0 + row < p.M;
-    const long gr = (long)min(m0 + row, p.M - 1);
-    const float mu = p.lnb_mean[gr], rs = p.lnb_rstd[gr];
-    float4 dq[4], h4[4], g4[4], rv[4];
-    float s1 = 0.f, s2 = 0.f;
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      const int col = (l + 16 * j) * 4;
-      dq[j] = *reinterpret_cast<const float4*>(&tl[row * TL_LD + col]);
-      if (p.bias) {                                   // (a bias of the product itself; unused by the gradients)
-        const float4 bb = *reinterpret_cast<const float4*>(p.bias + col);
-        dq[j].x += bb.x; dq[j].y += bb.y; dq[j].z += bb.z; dq[j].w += bb.w;
-      }
-      const float4 xv = *reinterpret_cast<const float4*>(p.lnb_x + gr * D + col);
-      g4[j] = *reinterpret_cast<const float4*>(p.lnb_gamma + col);
-      rv[j] = p.lnb_dres ? *reinterpret_cast<const float4*>(p.lnb_dres + gr * D + col) : make_float4(0.f, 0.f, 0.f, 0.f);
-      h4[j] = make_float4((xv.x - mu) * rs, (xv.y - mu) * rs, (xv.z - mu) * rs, (xv.w - mu) * rs);
-      const float a = dq[j].x * g4[j].x, b = dq[j].y * g4[j].y, c2 = dq[j].z * g4[j].z, d = dq[j].w * g4[j].w;
-      s1 += (a + b) + (c2 + d);
-      s2 += (a * h4[j].x + b * h4[j].y) + (c2 * h4[j].z + d * h4[j].w);
-    }
-#pragma unroll
-    for (int m = 1; m < 16; m <<= 1) { s1 += __shfl_xor(s1, m); s2 += __shfl_xor(s2, m); }
-    s1 /= D; s2 /= D;
-    const unsigned thr_d = eamd_drop_thr16(p.lnb_drop_p);
-    const float inv_d = eamd_drop_inv(thr_d);
-    const unsigned seed_d = p.lnb_drop_out ? eamd_drop_seed((const unsigned long long*)p.drop_step, p.lnb_drop_salt) : 0u;
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      const int col = (l + 16 * j) * 4;
-      float4 o;
-      o.x = rs * (dq[j].x * g4[j].x - s1 - h4[j].x * s2) + rv[j].x;
-      o.y = rs * (dq[j].y * g4[j].y - s1 - h4[j].y * s2) + rv[j].y;
-      o.z = rs * (dq[j].z * g4[j].z - s1 - h4[j].z * s2) + rv[j].z;
-      o.w = rs * (dq[j].w * g4[j].w - s1 - h4[j].w * s2) + rv[j].w;
-      if (live) {
-        *reinterpret_cast<float4*>(p.out + gr * p.ldo + col) = o;
-        if (p.lnb_drop_out) {
-          bool keep[4];
-          eamd_drop_keep4(seed_d, (unsigned long long)(gr * D + col), thr_d, keep);
-          *reinterpret_cast<float4*>(p.lnb_drop_out + gr * D + col) =
-              make_float4(keep[0] ? o.x * inv_d : 0.f, keep[1] ? o.y * inv_d : 0.f, keep[2] ? o.z * inv_d : 0.f,
-                          keep[3] ? o.w * inv_d : 0.f);
-        }
-      }
-      const float z = live ? 1.f : 0.f;
-      *reinterpret_cast<float4*>(&gs[row * D + col]) =
-          make_float4(z * dq[j].x * h4[j].x, z * dq[j].y * h4[j].y, z * dq[j].z * h4[j].z, z * dq[j].w * h4[j].w);
-      *reinterpret_cast<float4*>(&bsum[row * D + col]) = make_float4(z * dq[j].x, z * dq[j].y, z * dq[j].z, z * dq[j].w);
-    }
-    __syncthreads();
-    {   // thread t sums one column of d gamma (t < 256) or d beta over the 32 rows: the workgroup's partial for the batched
-        // second stage (eamd_layernorm_bwd_reduce; ws[workgroup][2 D])
-      const float* src = (t < D ? gs : bsum) + (t & (D - 1));
-      float s = 0.f;
-#pragma unroll 8
-      for (int r = 0; r < RBM; ++r) s += src[r * D];
-      p.lnb_ws[(long)blockIdx.x * 2 * D + t] = s;
-    }
+    const EamdLnbArgs la{p.lnb_x, p.lnb_gamma, p.lnb_mean, p.lnb_rstd, p.lnb_dres, p.lnb_ws, p.lnb_drop_out, p.lnb_drop_p,
+                         (unsigned long long)p.lnb_drop_salt, p.drop_step, p.out, (long)p.ldo, p.M};
+    eamd_ln_bwd_rows32<TL_LD>(la, tl, gs, bsum, m0, t, (int)blockIdx.x);
   }
 }
 

@@ -364,6 +364,20 @@ class FFNBlockFn(torch.autograd.Function):
             return (dx,) + sink.results() + (None, None, None, None)
         if ctx.one_launch and g_drop is None and dob.dtype == z.dtype:
             # dz = s (dob W2) (.) f and dxn = dz W1: one launch (bf16 operands: on the transposed weight copies)
+            M, D = x2.shape
+            if mean is not None and D == 256 and ops.ROWPROJ and ops.ffn_bwd_lnb_ok(M, w1.shape[0], dob.dtype):
+                # ... and the LayerNorm backward of the block as the launch's epilogue (csrc/ln_bwd_rows.h)
+                ws = ops.rowproj_lnb_ws(M, x2.device)
+                prev = ctx.prev
+                dcopy = torch.empty(M, D, device=x2.device, dtype=torch.float32) if prev is not None else None
+                dz, dx = ops.ffn_bwd(dob, w1, w2, z, alpha=scale, packed=ctx.packs,
+                                     lnb=(x2, ln_w, mean, rstd, do, ws, dcopy, prev))
+                ops.ln_partials_reduce(ws, sink.buf(0), sink.buf(1), (M + 31) // 32, D)
+                ops.linear_bwd_w(dz, xn, sink.buf(2), db=sink.buf(3))
+                dx = dx.view(shp)
+                if prev is not None:
+                    dx._eamd_dropped = (dcopy, prev)
+                return (dx,) + sink.results() + (None, None, None, None)
             dz, dxn = ops.ffn_bwd(dob, w1, w2, z, alpha=scale, packed=ctx.packs)
             ops.linear_bwd_w(dz, xn, sink.buf(2), db=sink.buf(3))
             dx = _ln_bwd_out(dxn, x2, ln_w, mean, rstd, do, sink.buf(0), sink.buf(1), ctx.prev, shp)

@@ -732,9 +732,16 @@ def ffn_pack(w1, w2):
     return buf[0], buf[1], buf[2], buf[3]
 
 
-def ffn_bwd(dy, w1, w2, f, *, alpha=1.0, packed=None):
+def ffn_bwd_lnb_ok(M, F, dt):
+    """eamd_ffn_bwd can run the LayerNorm backward as its epilogue (fp32 operands, one workgroup per row block)"""
+    return dt == torch.float32 and ffn_hsplit(M, F, False) == 1 and os.environ.get("EAMD_FFN_F32_FORM", "") != "sym"
+
+
+def ffn_bwd(dy, w1, w2, f, *, alpha=1.0, packed=None, lnb=None):
     """dz = alpha * (dy W2) (.) f and dx = dz W1 in ONE launch -> (dz [M, F], dx [M, D] fp32); packed = (bwd_first,
-    bwd_second) of ffn_pack(w1, w2) (made here when not given)"""
+    bwd_second) of ffn_pack(w1, w2) (made here when not given).
+    lnb = (x_block_input, gamma, mean, rstd, dres or None, ws, drop_out or None, (p, salt) or None): the LayerNorm backward runs
+    on the dx rows inside the launch (as ops.rowproj's lnb): dx = LayerNorm'(dz W1) + dres."""
     M, D = dy.shape
     F = w1.shape[0]
     dt = dy.dtype
@@ -747,7 +754,12 @@ def ffn_bwd(dy, w1, w2, f, *, alpha=1.0, packed=None):
     assert packed[0].numel() == F * D and packed[1].numel() == F * D and packed[0].dtype == dt
     p = _ffn_desc(dy, packed[0], None, packed[1], None, None, dx, f, dz, ACT_NONE, alpha, (0.0, 0, 0.0, 0), F=F)
     p.hsplit = hs
-    _ffn_call("eamd_ffn_bwd", p, (dy, packed, f, dz, dx))
+    if lnb is not None:
+        xb, g, mean, rstd, dres, ws, d_out, d_ps = lnb
+        p.lnb_x, p.lnb_gamma, p.lnb_mean, p.lnb_rstd, p.lnb_dres, p.lnb_ws = ptr(xb), ptr(g), ptr(mean), ptr(rstd), ptr(dres), ptr(ws)
+        if d_out is not None:
+            p.lnb_drop_out, p.lnb_drop_p, p.lnb_drop_salt, p.drop_step = ptr(d_out), float(d_ps[0]), int(d_ps[1]), ptr(rng_state(dy.device))
+    _ffn_call("eamd_ffn_bwd", p, (dy, packed, f, dz, dx, lnb))
     return dz, dx
 
 

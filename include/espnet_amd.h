@@ -189,6 +189,13 @@ typedef struct {
    * ln_mean / ln_rstd [M].  ln_w, ln_b [D] fp32.  ln_x == NULL: the other ln_* fields are ignored. */
   const float* ln_x; const float* ln_w; const float* ln_b; float* ln_mean; float* ln_rstd;
   float ln_eps; int32_t reserved2;
+  /* Optional LayerNorm BACKWARD behind eamd_ffn_bwd (fp32 operands, no hsplit): lnb_x != NULL (the block input [M, D] of the
+   * forward's LayerNorm, with lnb_gamma [D], lnb_mean / lnb_rstd [M]): `out` receives dx = LayerNorm'(dz W1) + lnb_dres instead
+   * of dz W1, lnb_drop_out (optional, fp32 [M, D]) its dropped copy (probability lnb_drop_p, salt lnb_drop_salt, drop_step),
+   * lnb_ws [ceil(M / 32)][2][D] the per-workgroup partial sums of d gamma / d beta (eamd_layernorm_bwd_reduce, nblk = ceil(M / 32));
+   * same arithmetic as eamd_rowproj's lnb_* fields. */
+  const float* lnb_x; const float* lnb_gamma; const float* lnb_mean; const float* lnb_rstd; const float* lnb_dres;
+  float* lnb_ws; float* lnb_drop_out; uint64_t lnb_drop_salt; float lnb_drop_p; int32_t reserved3;
 } eamd_ffn_t;
 int eamd_ffn_fwd(const eamd_ffn_t* p, void* stream);
 int eamd_ffn_bwd(const eamd_ffn_t* p, void* stream);

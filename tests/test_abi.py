@@ -65,7 +65,10 @@ def test_round3_struct_layouts_and_null_arguments():
     """eamd_ffn_t / eamd_lstm_seq_*_t as ctypes sees them = as the header lays them out; the new entry points reject NULL
     arguments before touching a device"""
     from espnet_amd import _lib
-    assert ctypes.sizeof(_lib.FfnT) == 136 + 48            # 9 pointers, 4 int32, 2 float, u64, float (+pad), u64, pointer, 2 int32; LayerNorm in front: 5 pointers, float, int32
+    # 9 pointers, 4 int32, 2 float, u64, float (+pad), u64, pointer, 2 int32; LayerNorm in front: 5 pointers, float, int32;
+    # round 4, LayerNorm backward behind eamd_ffn_bwd: 7 pointers, u64, float, int32
+    assert ctypes.sizeof(_lib.FfnT) == 136 + 48 + 72
+    assert ctypes.sizeof(_lib.RowProjT) == 240 and ctypes.sizeof(_lib.RowProjPackT) == 32       # include/espnet_amd.h: eamd_rowproj_t, eamd_rowproj_pack_t
     assert ctypes.sizeof(_lib.LstmSeqFwdT) == 8 * 8 + 8    # 8 pointers, 2 int32
     assert ctypes.sizeof(_lib.LstmSeqBwdT) == 6 * 8 + 8    # 6 pointers, 2 int32
     lib = _lib.lib()

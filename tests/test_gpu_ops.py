@@ -1834,3 +1834,35 @@ def test_rowproj_vs_float64(ops, M):
     yl = torch.nn.functional.layer_norm(xi, (256,), gam64, bet.cpu().double(), 1e-12)
     (yl * (dy[:8].double() @ W3.double())).sum().backward()
     report("rowproj LN-bwd vs float64", dx[:8], xi.grad + dres[:8].double(), 5e-6)
+
+
+def test_ffn_bwd_layernorm_backward_epilogue(ops):
+    """eamd_ffn_bwd with the block's LayerNorm backward as its epilogue (eamd_ffn_t.lnb_*): dz unchanged, dx / dropped copy /
+    d gamma / d beta as eamd_layernorm_bwd gives them on the plain launch's dx; ragged last row block."""
+    g = torch.Generator().manual_seed(5)
+    rnd = lambda *s: torch.randn(*s, generator=g).to(DEV)  # noqa: E731
+    F = 512
+    for M in (4128, 100):
+        w1, w2 = rnd(F, 256) / 16, rnd(256, F) / F ** 0.5
+        dy, f, x_in, dres = rnd(M, 256), rnd(M, F), rnd(M, 256), rnd(M, 256)
+        gam, bet = 1.0 + 0.1 * rnd(256), 0.1 * rnd(256)
+        _, mean, rstd = ops.layernorm_fwd(x_in, gam, bet, 1e-12, torch.float32)
+        old = ops.FUSED_FFN_MIN_ROWS, ops.FUSED_FFN_HSPLIT_MIN_ROWS
+        ops.FUSED_FFN_MIN_ROWS, ops.FUSED_FFN_HSPLIT_MIN_ROWS = 1, 1 << 30
+        try:
+            dz0, dxn = ops.ffn_bwd(dy, w1, w2, f, alpha=0.5)
+            dg_ref, db_ref = torch.zeros(256, device=DEV), torch.zeros(256, device=DEV)
+            ops.manual_seed(9)
+            dx_ref, dxd_ref = ops.layernorm_bwd(dxn, x_in, gam, mean, rstd, dres, dg_ref, db_ref, drop=(0.1, 31))
+            ws = ops.rowproj_lnb_ws(M, DEV)
+            dcopy = torch.empty(M, 256, device=DEV)
+            dz1, dx = ops.ffn_bwd(dy, w1, w2, f, alpha=0.5, lnb=(x_in, gam, mean, rstd, dres, ws, dcopy, (0.1, 31)))
+        finally:
+            ops.FUSED_FFN_MIN_ROWS, ops.FUSED_FFN_HSPLIT_MIN_ROWS = old
+        torch.cuda.synchronize()
+        assert torch.equal(dz0, dz1)
+        report("ffn_bwd + LN-bwd dx (M=%d)" % M, dx, dx_ref, 2e-6)
+        report("ffn_bwd + LN-bwd dropped copy", dcopy, dxd_ref.float(), 2e-6)
+        part = ws.view(-1, 2, 256).sum(0)
+        report("ffn_bwd + LN-bwd d gamma", part[0], dg_ref, 2e-5)
+        report("ffn_bwd + LN-bwd d beta", part[1], db_ref, 2e-5)
