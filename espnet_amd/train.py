@@ -318,6 +318,108 @@ def train_step(model, flat, opt, batch, reducer=None, loss_scale=1.0):
     return loss
 
 
+class E2EPhases:
+    """Forward + backward of the hybrid CTC/attention model in PHASES separated by gradient cuts (nets/modules.GradCuts: the
+    activation behind the encoder and those in front of two encoder layers are replaced by detached leaves; `loss.backward()`
+    stops at the last cut, `upstream.backward(leaf.grad)` resumes).  The gradient arena keeps registration order, so each
+    phase completes ONE contiguous range of it - which a data-parallel driver all-reduces while the next phase runs.
+        phase 0      advance the dropout counter, forward, backward of decoder / CTC        -> ranges[0]
+        phase 1 ..   the encoder layers from the top down, the input layer last           -> ranges[1 ..]
+    Models without an `encoder.encoders` stack (or with interleaved arena ranges) get the single-phase plan.
+    Neither zeroes the gradients nor runs the optimizer: gradient accumulation belongs to the caller.
+    reference: what DistributedDataParallel's bucketed backward hooks do in espnet2/train/trainer.py:381-412."""
+
+    def __init__(self, model, flat, phases=True):
+        self.model, self.flat = model, flat
+        self.ranges = [(0, flat.numel)]
+        self.stack, self.cut_layers, self.cuts = None, (), []
+        if phases:
+            self._plan()
+
+    def _plan(self):
+        from .nets.modules import MultiSequential
+        enc = getattr(self.model, "encoder", None)
+        stack = getattr(enc, "encoders", None)
+        if not isinstance(stack, MultiSequential) or len(stack) < 2 or not hasattr(self.model, "forward_core"):
+            return
+        # cuts low in the stack keep the exposed last range small (input layer + the lowest sixth of the layers:
+        # 16 % of the bytes at config 2) while every other range has a whole phase of backward to hide under
+        n = len(stack)
+        cuts = sorted({max(1, n // 6), max(1, (7 * n) // 12)})
+        nph = len(cuts) + 2
+        phase_of = {}
+        for name, p in self.model.named_parameters():
+            if not name.startswith("encoder."):
+                ph = 0                                              # decoder, CTC, anything behind the encoder
+            elif getattr(p, "_eamd_stack_group", None) == "pos":
+                ph = nph - 1        # linear_pos of every layer lives (and is finished) with the lowest layers: F_.SharedProjFn
+            elif name.startswith("encoder.encoders."):
+                ph = 1 + sum(1 for c in cuts if int(name.split(".")[2]) < c)
+            elif name.startswith("encoder.after_norm."):
+                ph = 1
+            else:
+                ph = nph - 1                                        # input layer
+            phase_of[id(p)] = ph
+        spans = {}
+        for p, o in zip(self.flat.params, self.flat.offsets):
+            ph = phase_of.get(id(p))
+            if ph is None:
+                return
+            lo, hi = spans.get(ph, (o, o))
+            spans[ph] = (min(lo, o), max(hi, o + p.numel()))
+        if sorted(spans) != list(range(nph)):
+            return
+        order = sorted(spans.values())
+        if any(a[1] > b[0] for a, b in zip(order, order[1:])):      # interleaved in the arena: keep one phase
+            return
+        bounds = [0] + [sp[0] for sp in order[1:]] + [self.flat.numel]
+        self.ranges = [(bounds[order.index(spans[ph])], bounds[order.index(spans[ph]) + 1]) for ph in range(nph)]
+        self.stack, self.cut_layers = stack, tuple(cuts)
+
+    def phase(self, k, batch, scale):
+        """scale: python float or 0-dim device tensor (a captured phase 0 reads the tensor at replay time).
+        phase 0 -> (loss, {"loss_att", "loss_ctc", "acc"} device tensors the model left); later phases -> None"""
+        from .nets.modules import GradCuts
+        if k == 0:
+            ops.rng_advance(self.flat.data.device)
+            if self.stack is not None:
+                self.stack.cut_before = self.cut_layers
+                GradCuts.active = []
+            try:
+                loss = self.model.forward_core(batch) if isinstance(batch, dict) else self.model(*batch)
+                self.cuts = GradCuts.active or []
+            finally:
+                GradCuts.active = None
+                if self.stack is not None:
+                    self.stack.cut_before = ()
+            if self.stack is not None and len(self.cuts) != len(self.ranges) - 1:
+                raise RuntimeError("phased backward expects %d gradient cuts, found %d" % (len(self.ranges) - 1, len(self.cuts)))
+            if torch.is_tensor(scale):
+                grad = scale.to(loss.dtype).reshape(loss.shape)
+            else:
+                grad = torch.full((), float(scale), device=loss.device, dtype=loss.dtype) if scale != 1.0 else None
+            ops.wgrad_group_begin()      # one grouped launch of the small weight-gradient GEMMs per phase
+            try:
+                loss.backward(grad)
+            finally:
+                ops.wgrad_group_end()
+            ops.wgrad_join()
+            m = self.model
+            stats = {k_: getattr(m, a) for k_, a in (("loss_att", "_loss_att_t"), ("loss_ctc", "_loss_ctc_t"), ("acc", "_acc_t"))
+                     if getattr(m, a, None) is not None}
+            return loss, stats
+        upstream, leaf = self.cuts[len(self.cuts) - k]       # phase 1 resumes behind the encoder, the next ones lower in the stack
+        ops.wgrad_group_begin()
+        try:
+            upstream.backward(leaf.grad)
+        finally:
+            ops.wgrad_group_end()
+        ops.wgrad_join()
+        if k == len(self.ranges) - 1:
+            self.cuts = []
+        return None
+
+
 class GraphedDataParallelStep:
     """hipGraph replay of a data-parallel training step without capturing any collective:
       graph A = zero the gradient arena, advance the dropout counter, forward, backward (loss pre-scaled by
@@ -379,80 +481,19 @@ class GraphedDataParallelStep:
         graphs.audit(self.graph_b, "optimizer graph")
 
     def _plan_phases(self):
-        """cut points + the arena range each backward phase completes; leaves the single-phase plan in place when the
-        model has no layer stack to cut or the ranges would not be contiguous"""
-        from .nets.modules import MultiSequential
-        enc = getattr(self.model, "encoder", None)
-        stack = getattr(enc, "encoders", None)
-        if not isinstance(stack, MultiSequential) or len(stack) < 2 or not hasattr(self.model, "forward_core"):
-            return
-        # cuts low in the stack keep the exposed last range small (input layer + the lowest sixth of the layers:
-        # 16 % of the bytes at config 2) while every other range has a whole phase of backward to hide under
-        n = len(stack)
-        cuts = sorted({max(1, n // 6), max(1, (7 * n) // 12)})
-        nph = len(cuts) + 2
-        phase_of = {}
-        for name, p in self.model.named_parameters():
-            if not name.startswith("encoder."):
-                ph = 0                                              # decoder, CTC, anything behind the encoder
-            elif getattr(p, "_eamd_stack_group", None) == "pos":
-                ph = nph - 1        # linear_pos of every layer lives (and is finished) with the lowest layers: F_.SharedProjFn
-            elif name.startswith("encoder.encoders."):
-                ph = 1 + sum(1 for c in cuts if int(name.split(".")[2]) < c)
-            elif name.startswith("encoder.after_norm."):
-                ph = 1
-            else:
-                ph = nph - 1                                        # input layer
-            phase_of[id(p)] = ph
-        spans = {}
-        for p, o in zip(self.flat.params, self.flat.offsets):
-            ph = phase_of.get(id(p))
-            if ph is None:
-                return
-            lo, hi = spans.get(ph, (o, o))
-            spans[ph] = (min(lo, o), max(hi, o + p.numel()))
-        if sorted(spans) != list(range(nph)):
-            return
-        order = sorted(spans.values())
-        if any(a[1] > b[0] for a, b in zip(order, order[1:])):      # interleaved in the arena: keep one phase
-            return
-        bounds = [0] + [sp[0] for sp in order[1:]] + [self.flat.numel]
-        self.ranges = [(bounds[order.index(spans[ph])], bounds[order.index(spans[ph]) + 1]) for ph in range(nph)]
-        self._stack, self._cut_layers = stack, tuple(cuts)
+        plan = E2EPhases(self.model, self.flat)
+        if plan.stack is not None:
+            self.ranges, self._stack, self._cut_layers = plan.ranges, plan.stack, plan.cut_layers
+        self._plan = plan
 
     def _phase(self, k):
-        from .nets.modules import GradCuts
+        plan = getattr(self, "_plan", None)
+        if plan is None:
+            plan = self._plan = E2EPhases(self.model, self.flat, phases=False)
         if k == 0:
             self.flat.zero_grad()
-            ops.rng_advance(self.flat.data.device)
-            if self._stack is not None:
-                self._stack.cut_before = self._cut_layers
-                GradCuts.active = []
-            try:
-                loss = self.model.forward_core(self.batch)
-                self.cuts = GradCuts.active or []
-            finally:
-                GradCuts.active = None
-                if self._stack is not None:
-                    self._stack.cut_before = ()
-            if self._stack is not None and len(self.cuts) != len(self.ranges) - 1:
-                raise RuntimeError("phased backward expects %d gradient cuts, found %d" % (len(self.ranges) - 1, len(self.cuts)))
-            scale = 1.0 / self.world
-            ops.wgrad_group_begin()      # one grouped launch of the small weight-gradient GEMMs per phase
-            try:
-                loss.backward(torch.full((), scale, device=loss.device, dtype=loss.dtype) if scale != 1.0 else None)
-            finally:
-                ops.wgrad_group_end()
-            ops.wgrad_join()
-            return loss
-        upstream, leaf = self.cuts[len(self.cuts) - k]       # phase 1 resumes behind the encoder, the next ones lower in the stack
-        ops.wgrad_group_begin()
-        try:
-            upstream.backward(leaf.grad)
-        finally:
-            ops.wgrad_group_end()
-        ops.wgrad_join()
-        return None
+        out = plan.phase(k, self.batch, 1.0 / self.world)
+        return out[0] if k == 0 else None
 
     def _reduce(self, k):
         if not self.dist.is_initialized():
@@ -628,6 +669,175 @@ class BucketedGraphStep:
                     evictions=self.evictions, graphs=len(self.cache))
 
 
+class E2EProgram:
+    """what ComposedStep needs to know about the hybrid CTC/attention models of this package: shape buckets, padded
+    batches (model.prepare(pad_to=)), the phased forward / backward (E2EPhases).  raw batch = (xs_pad, ilens, ys_pad[, olens])."""
+
+    def __init__(self, model, flat, t_edge=64, l_edge=8, phases=True):
+        self.model, self.flat = model, flat
+        self.t_edge, self.l_edge = int(t_edge), int(l_edge)
+        self.plan = E2EPhases(model, flat, phases=phases)
+        self.ranges = self.plan.ranges
+        self._ok = {}
+
+    def bucket(self, raw):
+        xs_pad, ilens, ys_pad = raw[:3]
+        olens = raw[3] if len(raw) > 3 else None
+        il = [int(v) for v in (ilens.tolist() if torch.is_tensor(ilens) else ilens)]
+        if olens is not None:      # label lengths known on the host (a data loader has them): no device round trip
+            L = max(int(v) for v in (olens.tolist() if torch.is_tensor(olens) else olens))
+        else:
+            L = int((ys_pad != self.model.ignore_id).sum(1).max())
+        up = lambda v, e: (v + e - 1) // e * e  # noqa: E731
+        return (int(xs_pad.shape[0]), up(max(il), self.t_edge), up(max(L, 1), self.l_edge))
+
+    def supported(self, key):
+        """the step on the batch PADDED to its bucket computes what the reference computes on the exact shapes only where the
+        kernels take the batch's own time bound (BucketedGraphStep.padded_step_ok)"""
+        ok = self._ok.get(key)
+        if ok is None:
+            from .nets.modules import RelPositionMultiHeadedAttention, embed_output_lengths
+            rel = [m for m in self.model.modules() if isinstance(m, RelPositionMultiHeadedAttention)]
+            ok = True
+            if rel:
+                tp = max(embed_output_lengths(self.model.encoder.embed, [key[1]], key[1]))
+                ok = all(ops.attn_fwd_supported(tp, tp, m.d_k, True) for m in rel)
+            self._ok[key] = ok
+        return ok
+
+    def prepare(self, raw, key):
+        xs_pad, ilens, ys_pad = raw[:3]
+        return self.model.prepare(xs_pad, ilens, ys_pad, pad_to=key[1:]) if key is not None else self.model.prepare(xs_pad, ilens, ys_pad)
+
+    def phase(self, k, batch, scale):
+        return self.plan.phase(k, batch, scale)
+
+
+class ComposedStep:
+    """ONE training micro-step driver that is at once shape-bucketed, hipGraph-replayed, phased for data parallelism and
+    accumulation-aware (what BucketedGraphStep, GraphedDataParallelStep and EpochRunner's eager step each did alone):
+
+      * a batch goes to its shape bucket (program.bucket); first sight of a bucket runs the phases eagerly, the second sight
+        captures one hipGraph per PHASE on the padded batch, later ones copy the batch into the static inputs and replay;
+      * the backward scale w_r / (sum_r w_r * accum_grad) of espnet2's weighted data-parallel loss is a device scalar the captured
+        phase 0 reads at replay time (trainer.py:385-397);
+      * with reduce=True (the last micro-step of an accumulation window) the arena range each phase completed is all-reduced
+        (SUM) asynchronously right behind the phase - collective sizes depend on the MODEL only, so ranks may sit in different
+        buckets (or one eager, one replaying) in the same step - and runs under the next phase; wait() joins them;
+      * gradients accumulate in the flat arena across micro-steps; zeroing and the optimizer belong to the caller
+        (EpochRunner, or step() below for the plain one-batch-per-step loop).
+
+    `program` supplies the model-specific parts (E2EProgram for the models of this package; any object with ranges / bucket /
+    supported / prepare / phase, e.g. a toy model in the CPU tests).  Without CUDA (or graphs=False) every step is the eager
+    phased step.  reference: espnet2/train/trainer.py:325-495 under DistributedDataParallel, abs_task.py:1436-1445."""
+
+    def __init__(self, program, flat, opt, group=None, max_graphs=8, bucket_mb=128.0, use_graphs=None):
+        import torch.distributed as dist
+        from collections import OrderedDict
+        self.program, self.flat, self.opt = program, flat, opt
+        self.dist, self.group = dist, group
+        self.distributed = dist.is_available() and dist.is_initialized()
+        self.world = dist.get_world_size(group) if self.distributed else 1
+        self.cap = max(1, int(bucket_mb * 1024 * 1024 // 4))
+        self.use_graphs = flat.data.is_cuda if use_graphs is None else bool(use_graphs)
+        self.cache, self.seen, self.pool = OrderedDict(), {}, None
+        self.max_graphs = int(max_graphs)
+        self.scale = torch.ones((), device=flat.data.device, dtype=torch.float32)      # static input of every captured phase 0
+        self.works = []
+        self.hits = self.misses = self.captures = self.evictions = self.eager_exact = 0
+        ops.set_comm_overlap(self.world > 1)
+
+    # ---- collectives -----------------------------------------------------------------------------------------------------
+    def _reduce(self, k):
+        if not self.distributed or self.world == 1:
+            return
+        lo, hi = self.program.ranges[k]
+        g = self.flat.grad
+        self.works += [self.dist.all_reduce(g[s:min(hi, s + self.cap)], op=self.dist.ReduceOp.SUM, group=self.group, async_op=True)
+                       for s in range(lo, hi, self.cap)]
+
+    def wait(self):
+        """join the range all-reduces issued by the last micro_step(reduce=True) (RCCL: a stream-level wait, no host block)"""
+        works, self.works = self.works, []
+        for w in works:
+            w.wait()
+
+    # ---- one micro-step --------------------------------------------------------------------------------------------------
+    def micro_step(self, raw, scale=1.0, reduce=False):
+        """forward + backward of one batch, gradients ADDED to the arena; -> (loss, stats) device tensors (of a replayed bucket:
+        the graph's static outputs, valid until that bucket replays again)"""
+        prog = self.program
+        nph = len(prog.ranges)
+        key = prog.bucket(raw)
+        padded = prog.supported(key)
+        self.scale.fill_(float(scale))
+        entry = self.cache.get(key) if (self.use_graphs and padded) else None
+        if entry is not None:
+            self.cache.move_to_end(key)
+            batch = prog.prepare(raw, key)
+            for name, v in batch.items():
+                if torch.is_tensor(v):
+                    entry["static"][name].copy_(v, non_blocking=True)
+            for k, g in enumerate(entry["graphs"]):
+                g.replay()
+                if reduce:
+                    self._reduce(k)
+            self.hits += 1
+            return entry["out"]
+        self.misses += 1
+        if not padded:
+            self.eager_exact += 1
+        batch = prog.prepare(raw, key if padded else None)
+        if not (self.use_graphs and padded) or self.seen.get(key, 0) == 0:
+            # first sight of a bucket (doubles as the capture's warm-up; a real training step), CPU, or a bucket the padded
+            # step does not cover: the eager phased step
+            self.seen[key] = 1
+            out = None
+            for k in range(nph):
+                r = prog.phase(k, batch, self.scale)
+                out = r if k == 0 else out
+                if reduce:
+                    self._reduce(k)
+            return out
+        # second sight: capture the phases on this batch's tensors (they become the graphs' static inputs), then replay
+        torch.cuda.synchronize()
+        if self.pool is None:
+            self.pool = torch.cuda.graph_pool_handle()
+        gs, out = [], None
+        for k in range(nph):
+            g = graphs.new_graph()
+            with torch.cuda.graph(g, pool=self.pool, capture_error_mode="thread_local"):
+                r = prog.phase(k, batch, self.scale)
+            graphs.audit(g, "composed step, phase %d" % k)
+            out = r if k == 0 else out
+            gs.append(g)
+        for k, g in enumerate(gs):
+            g.replay()
+            if reduce:
+                self._reduce(k)
+        self.captures += 1
+        self.cache[key] = dict(graphs=gs, static=batch, out=out)
+        if len(self.cache) > self.max_graphs:
+            self.cache.popitem(last=False)
+            self.evictions += 1
+        return out
+
+    def step(self, raw):
+        """the plain loop (one batch per optimizer step, loss averaged over the ranks as DistributedDataParallel does):
+        zero, micro-step with the all-reduces under the backward phases, optimizer"""
+        self.flat.zero_grad()
+        out = self.micro_step(raw, 1.0 / self.world, reduce=True)
+        self.wait()
+        self.opt.step()
+        return out[0]
+
+    def stats(self):
+        n = self.hits + self.misses
+        return dict(steps=n, hits=self.hits, hit_rate=(self.hits / n if n else 0.0), captures=self.captures,
+                    evictions=self.evictions, graphs=len(self.cache), eager_exact_shape=self.eager_exact,
+                    phases=len(self.program.ranges), ranks=self.world)
+
+
 class EpochRunner:
     """espnet2 Trainer.train_one_epoch / validate_one_epoch semantics for one process per GPU
     (reference: espnet2/train/trainer.py:325-495,497-539; recursive_average, torch_utils/recursive_op.py:14-53).
@@ -654,13 +864,16 @@ class EpochRunner:
     NSTAT = 8
 
     def __init__(self, model, flat, opt, accum_grad=1, grad_noise=False, group=None, forward=None, backward=None,
-                 reduce_grads=None, pre_step=None, bucket_mb=128.0):
+                 reduce_grads=None, pre_step=None, bucket_mb=128.0, composed=None):
         import torch.distributed as dist
         self.dist, self.group = dist, group
         self.distributed = dist.is_available() and dist.is_initialized()
         self.world = dist.get_world_size(group) if self.distributed else 1
         self.model, self.flat, self.opt = model, flat, opt
         self.accum_grad, self.grad_noise = int(accum_grad), bool(grad_noise)
+        # composed = a ComposedStep: training micro-steps run through it (shape buckets, hipGraph replay, phased backward with the
+        # gradient all-reduce of each arena range under the next phase) instead of forward() / backward() / reduce_grads()
+        self.composed = composed
         self.forward = forward or self._forward_default
         self.backward = backward or (lambda loss, scale: loss.backward(scale))
         self.reduce_grads = reduce_grads or self._reduce_default
@@ -679,7 +892,7 @@ class EpochRunner:
         if isinstance(batch, dict) and "speech" in batch:          # espnet2 ESPnetASRModel
             loss, stats, weight = m(**batch)
             return loss.reshape(()), {k: v.reshape(()) for k, v in stats.items() if v is not None and k != "loss"}, float(weight)
-        loss = m.forward_core(batch) if isinstance(batch, dict) else m(*batch)
+        loss = m.forward_core(batch) if isinstance(batch, dict) else m(*batch[:3])      # (xs_pad, ilens, ys_pad[, olens])
         stats = {}
         if getattr(m, "_loss_att_t", None) is not None:
             stats["loss_att"] = m._loss_att_t
@@ -691,6 +904,8 @@ class EpochRunner:
         return loss, stats, float(B)
 
     def _reduce_default(self):
+        """the step WITHOUT a ComposedStep: the whole arena after backward (stream-ordered, exposed: nothing overlaps it).  The
+        overlapped form is `composed=` (phased backward, each arena range reduced under the next phase)."""
         if not self.distributed or self.world == 1:
             return
         g = self.flat.grad
@@ -774,7 +989,10 @@ class EpochRunner:
                 tickets.append(ticket)
             iiter += 1
             w = self._weight_of(batch)
-            if train:
+            if train and self.composed is not None:
+                self.total_count += 1
+                loss, stats = self.composed.micro_step(batch, w / (wsum * self.accum_grad), reduce=(iiter % self.accum_grad == 0))
+            elif train:
                 self.total_count += 1
                 self.pre_step()
                 loss, stats, _w = self.forward(batch)
@@ -791,7 +1009,10 @@ class EpochRunner:
             parts += [(stats[k].detach().float() * w if k in stats else torch.zeros((), device=dev)) for k in keys[1:]]
             pending = torch.stack(parts + [torch.zeros((), device=dev)])
             if train and iiter % self.accum_grad == 0:
-                self.reduce_grads()
+                if self.composed is not None:
+                    self.composed.wait()             # the range all-reduces were issued under the backward phases
+                else:
+                    self.reduce_grads()
                 if self.grad_noise:
                     # add_gradient_noise.py:4-31 with the reference's call-site constants (trainer.py:420-427)
                     ops.add_gradient_noise(self.flat.grad, 1.0 / ((self.total_count // 100) + 1) ** 0.55)

@@ -253,3 +253,127 @@ def test_epoch_runner_gradient_noise_iteration_count(monkeypatch):
     assert run.total_count == 132 and len(sigmas) == 66
     assert all(abs(a - b) < 1e-12 for a, b in zip(sigmas, want))
     assert sigmas[48] == 1.0 and sigmas[49] < 1.0          # micro-step 100 = optimizer step 50 is the first in interval 2
+
+
+# ---- ComposedStep: shape buckets x phased backward with per-range all-reduce x accumulation, inside EpochRunner -----------------
+class _ToyProgram:
+    """a three-layer model whose backward runs in TWO phases (a gradient cut in front of the last layer): phase 0 = forward +
+    backward of the last layer (arena range of layer 2), phase 1 = the two lower layers; batches are padded to a multiple of
+    four rows with a row mask, so ranks sit in different buckets in the same step"""
+
+    def __init__(self, model, flat):
+        self.model, self.flat = model, flat
+        n01 = sum(p.numel() for p in list(model[0].parameters()) + list(model[2].parameters()))
+        self.ranges = [(n01, flat.numel), (0, n01)]
+        self.calls = []
+
+    def bucket(self, raw):
+        return ((raw[0].shape[0] + 3) // 4 * 4,)
+
+    def supported(self, key):
+        return True
+
+    def prepare(self, raw, key):
+        x, y = raw
+        n = key[0] if key is not None else x.shape[0]
+        xp, yp, m = torch.zeros(n, 7), torch.zeros(n, 5), torch.zeros(n)
+        xp[:x.shape[0]], yp[:x.shape[0]], m[:x.shape[0]] = x, y, 1.0
+        return dict(x=xp, y=yp, m=m)
+
+    def phase(self, k, batch, scale):
+        lo, last = self.model[:3], self.model[3]
+        if k == 0:
+            h = lo(batch["x"])
+            self.leaf = h.detach().requires_grad_(True)
+            self.h = h
+            out = last(self.leaf)
+            loss = ((((out - batch["y"]) ** 2).mean(1)) * batch["m"]).sum() / batch["m"].sum()
+            grads = torch.autograd.grad(loss * scale, [self.leaf] + list(last.parameters()))
+            self.dleaf = grads[0]
+            for p, gr in zip(last.parameters(), grads[1:]):
+                p._eamd_grad.add_(gr)
+            self.calls.append(0)
+            return loss.detach(), {"loss_att": loss.detach() * 2}
+        grads = torch.autograd.grad(self.h, list(lo.parameters()), self.dleaf)
+        for p, gr in zip(lo.parameters(), grads):
+            p._eamd_grad.add_(gr)
+        self.calls.append(1)
+        return None
+
+
+def _ragged_batches(rank):
+    g = torch.Generator().manual_seed(200 + rank)
+    sizes = [3, 6, 2, 9, 5] if rank == 0 else [7, 1, 4, 10]           # rank 1 runs out first: both stop after 4 micro-steps
+    return [(torch.randn(n, 7, generator=g), torch.randn(n, 5, generator=g)) for n in sizes]
+
+
+def _toy_model():
+    torch.manual_seed(0)
+    return torch.nn.Sequential(torch.nn.Linear(7, 16), torch.nn.Tanh(), torch.nn.Linear(16, 16), torch.nn.Linear(16, 5))
+
+
+def _composed_worker(rank, world, port, accum, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
+                      LOCAL_RANK=str(rank))
+    from espnet_amd import train
+    train.init_distributed()
+    model = _toy_model()
+    flat = train.FlatParams(model)
+    opt = _StubOpt(flat)
+    prog = _ToyProgram(model, flat)
+    comp = train.ComposedStep(prog, flat, opt, bucket_mb=0.0001)          # several collectives per range
+    reduced = []
+    orig = comp._reduce
+    comp._reduce = lambda k: (reduced.append(k), orig(k))[1]
+    run = train.EpochRunner(model, flat, opt, accum_grad=accum, composed=comp, pre_step=lambda: None)
+    invalid = run.train_one_epoch(_ragged_batches(rank))
+    hist = [{k: float(v) for k, v in h.items()} for h in run.history]
+    q.put((rank, invalid, [s.tolist() for s in opt.seen], hist, flat.data.tolist(), reduced, comp.stats()))
+    torch.distributed.barrier()
+    torch.distributed.destroy_process_group()
+
+
+@pytest.mark.parametrize("accum", [1, 2])
+def test_composed_step_two_ranks(accum):
+    """EpochRunner(composed=ComposedStep) on two gloo ranks: a ragged stream (the ranks' batches fall into DIFFERENT shape buckets
+    in the same step), unequal batch counts (stop flag), accum_grad 1 / 2, the backward in two phases with each phase's arena
+    range all-reduced right behind it and only on the last micro-step of a window -> the same optimizer inputs and final
+    parameters as the single-process run of the reference's weighted loss over the union of the ranks' batches"""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_composed_worker, args=(r, 2, port, accum, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    got = sorted(q.get(timeout=120) for _ in range(2))
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    (_, inv0, seen0, hist0, data0, red0, st0), (_, inv1, seen1, hist1, data1, red1, st1) = got
+    assert inv0 is False and inv1 is False
+    assert len(seen0) == len(seen1) == 4 // accum and len(hist0) == len(hist1) == 4
+    assert seen0 == seen1 and data0 == data1                             # replicas stay identical
+    assert red0 == red1 == [0, 1] * (4 // accum)                         # ranges reduced phase by phase, once per window
+    assert st0["phases"] == 2 and st0["ranks"] == 2 and st0["steps"] == 4
+    from espnet_amd import train
+    model = _toy_model()
+    flat = train.FlatParams(model)
+    b0, b1 = _ragged_batches(0), _ragged_batches(1)
+    want_grads = []
+    for k in range(4):
+        parts = [b0[k], b1[k]]
+        wsum = float(sum(x.shape[0] for x, _ in parts))
+        losses = [((model(x) - y) ** 2).mean() for x, y in parts]
+        total = sum(l * x.shape[0] for l, (x, _) in zip(losses, parts)) / wsum / accum
+        grads = torch.autograd.grad(total, list(model.parameters()))
+        for p, gr in zip(model.parameters(), grads):
+            p._eamd_grad.add_(gr)
+        assert abs(hist0[k]["loss"] - float(sum(float(l) * x.shape[0] for l, (x, _) in zip(losses, parts)) / wsum)) < 1e-5
+        assert hist0[k]["weight"] == wsum
+        if (k + 1) % accum == 0:
+            want_grads.append(flat.grad.clone())
+            flat.data.add_(flat.grad, alpha=-0.1)
+            flat.zero_grad()
+    for got_g, want_g in zip(seen0, want_grads):
+        torch.testing.assert_close(torch.tensor(got_g), want_g, rtol=1e-5, atol=1e-6)
+    torch.testing.assert_close(torch.tensor(data0), flat.data, rtol=1e-5, atol=1e-6)
