@@ -390,29 +390,39 @@ def ragged_leg(a, prec, dev):
         stream.append((xs.to(dev), ilens, torch.randint(1, V - 1, (B, L), generator=g).to(dev)))
     frames = sum(sum(il) for _x, il, _y in stream)
     out = {}
-    for mode in ("eager", "bucketed"):
+    # "composed" = train.ComposedStep: the bucketed step with the backward in the data-parallel phases (one hipGraph per phase and
+    # bucket, each phase's arena range all-reduced under the next phase) - with --rehearse-dp through a one-rank RCCL group, so
+    # that the collectives really run; without a process group the phases replay back to back
+    for mode in ("eager", "bucketed", "composed"):
         torch.manual_seed(0)
         model = E2E(80, V, c2_args(a.dropout)).to(dev).train()
         model.sync_report = False
         flat = train.FlatParams(model)
         opt = train.NoamAdam(flat, mode="noam", factor=1.0, model_size=256, warmup=25000, max_grad_norm=5.0)
         step = train.BucketedGraphStep(model, flat, opt, t_edge=64, l_edge=8, max_graphs=8) if mode == "bucketed" else None
+        comp = (train.ComposedStep(train.E2EProgram(model, flat, t_edge=64, l_edge=8), flat, opt, max_graphs=8,
+                                   rehearse=a.rehearse_dp and torch.distributed.is_initialized()) if mode == "composed" else None)
         for ep in range(3):
             torch.cuda.synchronize()
             t0 = time.perf_counter()
             for xs, ilens, ys in stream:
                 if step is not None:
                     step(xs, ilens, ys, olens=[L] * B)       # label lengths from the host, as a data loader has them
+                elif comp is not None:
+                    comp.step((xs, ilens, ys, [L] * B))
                 else:
                     train.train_step(model, flat, opt, model.prepare(xs, ilens, ys))
             torch.cuda.synchronize()
             dt = time.perf_counter() - t0
         out[mode] = dict(ms_per_step=round(dt / len(stream) * 1e3, 3), valid_frames_per_s=round(frames / dt, 1))
-        if step is not None:
-            st = step.stats()
+        st = step.stats() if step is not None else comp.stats() if comp is not None else None
+        if st is not None:
             out[mode].update(hit_rate_last_pass=1.0 if st["evictions"] == 0 else None, buckets=st["graphs"],
                              captures=st["captures"], evictions=st["evictions"], hit_rate_overall=round(st["hit_rate"], 3))
-        del model, flat, opt, step
+        if comp is not None:
+            out[mode].update(phases=st["phases"], collectives=("one-rank RCCL group: each phase's arena range all-reduced under the next phase"
+                                                               if (a.rehearse_dp and torch.distributed.is_initialized()) else "none (no process group)"))
+        del model, flat, opt, step, comp
         torch.cuda.empty_cache()
     out["what"] = "28 batches, B=%d, T ~ U(600,1000) per batch, lengths linspace(T, 0.6T), L=100; third pass timed" % B
     return out

@@ -429,6 +429,38 @@ __global__ __launch_bounds__(256) void ffn_pack_f32_kernel(const float* __restri
   }
 }
 
+// the same packing for MANY layers in one launch (a table of jobs in the kernel arguments; blockIdx.z = job): a 12-layer macaron
+// Conformer packs 24 feed-forward blocks per step - 24 launches of 5.7 us with their gaps, or one launch of all of them
+constexpr int FFN_PACK_JOBS = 32;
+struct FfnPackJob { const float* w1; const float* w2; float* p0; float* p1; float* p2; float* p3; int F; int pad; };
+struct FfnPackTable { FfnPackJob j[FFN_PACK_JOBS]; };
+__global__ __launch_bounds__(256) void ffn_pack_f32_multi_kernel(const FfnPackTable tab) {
+  const FfnPackJob jb = tab.j[blockIdx.z];
+  const int which = blockIdx.y, F = jb.F;
+  const long npiece = (long)(F / FHC) * 8 * 4 * 4 * 64;
+  for (long piece = (long)blockIdx.x * 256 + threadIdx.x; piece < npiece; piece += (long)gridDim.x * 256) {
+    const int lane = piece & 63, v = (piece >> 6) & 3, wq = (piece >> 8) & 3;
+    const int g = (int)(piece >> 10), c = g >> 3, s = g & 7;
+    const int fr = lane & 15, fq = lane >> 4;
+    if (which == 0) {
+      const int q = v >> 1, j = v & 1;
+      *reinterpret_cast<float4*>(jb.p0 + piece * 4) =
+          *reinterpret_cast<const float4*>(jb.w1 + (long)(c * FHC + wq * 32 + 2 * fr + j) * FD + s * 32 + q * 16 + fq * 4);
+    } else if (which == 1) {
+      *reinterpret_cast<float4*>(jb.p1 + piece * 4) =
+          *reinterpret_cast<const float4*>(jb.w2 + (long)(wq * 64 + v * 16 + fr) * F + c * FHC + s * 16 + fq * 4);
+    } else if (which == 2) {
+      const int q = v >> 1, e0 = (v & 1) * 2;
+      const float* r0 = jb.w2 + (long)(s * 32 + q * 16 + fq * 4 + e0) * F + c * FHC + wq * 32 + 2 * fr;
+      const float2 a = *reinterpret_cast<const float2*>(r0), b = *reinterpret_cast<const float2*>(r0 + F);
+      *reinterpret_cast<float4*>(jb.p2 + piece * 4) = make_float4(a.x, a.y, b.x, b.y);
+    } else {
+      *reinterpret_cast<float4*>(jb.p3 + piece * 4) =
+          *reinterpret_cast<const float4*>(jb.w1 + (long)(c * FHC + s * 16 + fq * 4 + v) * FD + wq * 64 + 4 * fr);
+    }
+  }
+}
+
 bool al16(const void* q) { return (reinterpret_cast<uintptr_t>(q) & 15) == 0; }
 
 template <bool BWD, int ACT>
@@ -500,6 +532,33 @@ extern "C" int eamd_ffn_pack_f32(const float* w1, const float* w2, float* fwd_fi
   hipLaunchKernelGGL(ffn_pack_f32_kernel, dim3((unsigned)((npiece + 255) / 256), 4), dim3(256), 0, (hipStream_t)stream, w1, w2,
                      fwd_first, fwd_second, bwd_first, bwd_second, F);
   EAMD_LAUNCH_CHECK();
+  return EAMD_OK;
+}
+
+extern "C" int eamd_ffn_pack_f32_multi(const eamd_ffn_pack_t* jobs, int njobs, void* stream) {
+  if (!jobs || njobs <= 0) return EAMD_EINVAL;
+  for (int i = 0; i < njobs; ++i) {
+    const eamd_ffn_pack_t& q = jobs[i];
+    if (!q.w1 || !q.w2 || !q.fwd_first || !q.fwd_second || !q.bwd_first || !q.bwd_second || q.F <= 0) return EAMD_EINVAL;
+    if (q.D != FD || q.F % FHC != 0 || q.F < 2 * FHC || eamd_ffn_f32_sym(q.F)) return EAMD_EUNSUPPORTED;
+    for (const void* a : {(const void*)q.w1, (const void*)q.w2, (const void*)q.fwd_first, (const void*)q.fwd_second,
+                          (const void*)q.bwd_first, (const void*)q.bwd_second})
+      if (!al16(a)) return EAMD_EUNSUPPORTED;
+  }
+  for (int i0 = 0; i0 < njobs; i0 += FFN_PACK_JOBS) {
+    const int n = njobs - i0 < FFN_PACK_JOBS ? njobs - i0 : FFN_PACK_JOBS;
+    FfnPackTable tab;
+    int fmax = 0;
+    for (int i = 0; i < n; ++i) {
+      const eamd_ffn_pack_t& q = jobs[i0 + i];
+      tab.j[i] = FfnPackJob{q.w1, q.w2, q.fwd_first, q.fwd_second, q.bwd_first, q.bwd_second, q.F, 0};
+      fmax = q.F > fmax ? q.F : fmax;
+    }
+    const long npiece = (long)(fmax / FHC) * 8 * 4 * 4 * 64;
+    const unsigned bx = (unsigned)((npiece + 255) / 256 < 128 ? (npiece + 255) / 256 : 128);
+    hipLaunchKernelGGL(ffn_pack_f32_multi_kernel, dim3(bx, 4, n), dim3(256), 0, (hipStream_t)stream, tab);
+    EAMD_LAUNCH_CHECK();
+  }
   return EAMD_OK;
 }
 

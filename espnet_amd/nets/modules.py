@@ -708,6 +708,8 @@ def _conformer_rowproj_prepack(self, M, D):
     ops.rowproj_images"""
     if not ops.rowproj_ok(M, D, D) or D != 256:
         return
+    ffns = [f for m in self.encoders for f in (m.feed_forward_macaron, m.feed_forward)
+            if isinstance(f, PositionwiseFeedForward) and ops.FUSED_FFN and M >= ops.FUSED_FFN_MIN_ROWS]
     groups = []
     for m in self.encoders:
         att, cv = m.self_attn, m.conv_module
@@ -721,6 +723,7 @@ def _conformer_rowproj_prepack(self, M, D):
             w2 = cv.pointwise_conv2.weight.detach().view(D, D)
             groups.append((cv.pointwise_conv1.weight, [(w1, False), (w1, True), (w2, False), (w2, True)]))
     ops.rowproj_prepack(groups)
+    ops.ffn_prepack([(f.w_1.weight, f.w_2.weight) for f in ffns])        # ... and the fused feed-forward blocks' images in one more
 
 
 ConformerEncoder._rowproj_prepack = _conformer_rowproj_prepack

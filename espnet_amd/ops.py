@@ -727,9 +727,35 @@ def ffn_pack(w1, w2):
     if buf is None or buf.numel() != 4 * F * D or buf.device != s1.device or buf.dtype != dt:
         buf = torch.empty(4, F * D, device=s1.device, dtype=dt)
         w1._eamd_ffn_pack = buf
+    elif _rp["active"] and getattr(w1, "_eamd_ffn_pack_epoch", -1) == _rp["epoch"]:
+        return buf[0], buf[1], buf[2], buf[3]         # packed by this pass's ffn_prepack (one launch for all blocks)
     name = "eamd_ffn_pack_bf16" if bf else "eamd_ffn_pack_f32"
     check(getattr(_lib.lib(), name)(ptr(s1), ptr(s2), ptr(buf[0]), ptr(buf[1]), ptr(buf[2]), ptr(buf[3]), D, F, stream_ptr()), name)
     return buf[0], buf[1], buf[2], buf[3]
+
+
+def ffn_prepack(pairs):
+    """pairs: list of (w1 [F, 256], w2 [256, F]) fp32 parameters: the packed images of ALL these feed-forward blocks in one
+    launch (eamd_ffn_pack_f32_multi); ffn_pack() hands them out until rowproj_prepack_end().  fp32 mode only (no-op otherwise)."""
+    if fast() or not pairs or os.environ.get("EAMD_FFN_F32_FORM", "") == "sym" or not _rp["active"]:
+        return
+    arr = (_lib.FfnPackT * len(pairs))()
+    n = 0
+    for w1, w2 in pairs:
+        F, D = w1.shape
+        if D != 256 or F % 128 != 0 or F < 256 or w1.dtype != torch.float32:
+            continue
+        buf = getattr(w1, "_eamd_ffn_pack", None)
+        if buf is None or buf.numel() != 4 * F * D or buf.device != w1.device or buf.dtype != torch.float32:
+            buf = torch.empty(4, F * D, device=w1.device, dtype=torch.float32)
+            w1._eamd_ffn_pack = buf
+        q = arr[n]
+        q.w1, q.w2, q.fwd_first, q.fwd_second, q.bwd_first, q.bwd_second = ptr(w1), ptr(w2), ptr(buf[0]), ptr(buf[1]), ptr(buf[2]), ptr(buf[3])
+        q.D, q.F = D, F
+        w1._eamd_ffn_pack_epoch = _rp["epoch"]
+        n += 1
+    if n:
+        check(_lib.lib().eamd_ffn_pack_f32_multi(arr, n, stream_ptr()), "eamd_ffn_pack_f32_multi")
 
 
 def ffn_bwd_lnb_ok(M, F, dt):
@@ -782,6 +808,7 @@ def rowproj_prepack(groups):
     """groups: list of (holder tensor, [(W, trans), ...]): the images of MANY blocks in one or two launches (an encoder packs all
     its layers' projection weights at the start of its forward); rowproj_images() then hands them out until rowproj_prepack_end()"""
     _rp["epoch"] += 1
+    _rp["active"] = True
     flat = [job for _, jobs in groups for job in jobs]
     if not flat:
         return

@@ -731,7 +731,7 @@ class ComposedStep:
     supported / prepare / phase, e.g. a toy model in the CPU tests).  Without CUDA (or graphs=False) every step is the eager
     phased step.  reference: espnet2/train/trainer.py:325-495 under DistributedDataParallel, abs_task.py:1436-1445."""
 
-    def __init__(self, program, flat, opt, group=None, max_graphs=8, bucket_mb=128.0, use_graphs=None):
+    def __init__(self, program, flat, opt, group=None, max_graphs=8, bucket_mb=128.0, use_graphs=None, rehearse=False):
         import torch.distributed as dist
         from collections import OrderedDict
         self.program, self.flat, self.opt = program, flat, opt
@@ -745,11 +745,12 @@ class ComposedStep:
         self.scale = torch.ones((), device=flat.data.device, dtype=torch.float32)      # static input of every captured phase 0
         self.works = []
         self.hits = self.misses = self.captures = self.evictions = self.eager_exact = 0
+        self.rehearse = bool(rehearse)        # issue the collectives on a ONE-rank group too (bench.py --rehearse-dp)
         ops.set_comm_overlap(self.world > 1)
 
     # ---- collectives -----------------------------------------------------------------------------------------------------
     def _reduce(self, k):
-        if not self.distributed or self.world == 1:
+        if not self.distributed or (self.world == 1 and not self.rehearse):
             return
         lo, hi = self.program.ranges[k]
         g = self.flat.grad

@@ -199,6 +199,14 @@ typedef struct {
 } eamd_ffn_t;
 int eamd_ffn_fwd(const eamd_ffn_t* p, void* stream);
 int eamd_ffn_bwd(const eamd_ffn_t* p, void* stream);
+/* eamd_ffn_pack_f32 for MANY feed-forward blocks in one launch (fp32 operands, D = 256): a 12-layer macaron Conformer re-packs
+ * 24 blocks every optimizer step.  Each job names one block's nn.Linear-layout weights and its four image buffers. */
+typedef struct {
+  const float* w1; const float* w2;
+  float* fwd_first; float* fwd_second; float* bwd_first; float* bwd_second;
+  int32_t D, F;
+} eamd_ffn_pack_t;
+int eamd_ffn_pack_f32_multi(const eamd_ffn_pack_t* jobs, int njobs, void* stream);
 
 /* Row-block projection: out[M, N] = R + alpha * drop( A'[M, K] B[K, N] + bias ) with 32 rows per workgroup taken through the whole
  * product (csrc/rowproj_f32.hip; fp32 operands, exact fp32 products; K a multiple of 256 up to 768, N a multiple of 256).
