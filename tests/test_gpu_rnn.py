@@ -986,3 +986,69 @@ def test_lstm_persistent_sequence_kernels(shape):
         report("lstm persistent y vs step kernels " + tag, ys_p[i], ys_s[i], 1e-6)
     dx = sum(lv_p[i][0].grad.double().cpu() @ getattr(ref, "weight_ih_l0" + s).detach() for i, s in enumerate(sfx))
     report("lstm persistent dx %s" % (shape,), dx, xr.grad, 2e-5)
+
+
+def test_config5_fullsize_properties():
+    """BASELINE config 5 at FULL size (RNN-Transducer: 12-block Conformer encoder d 256, 1-layer LSTM predictor 512, joint 320,
+    B = 16, T = 1500 -> T' = 374, U = 101, V = 5000; 12.1 GB of joint logits if they were materialised): properties the size does
+    not change - a finite loss, the captured step's replay equals the eager step, two replays bit-equal in the loss and the
+    encoder states, every gradient finite - and the streamed joint / loss keeps the peak memory of the step below 32 GB
+    (the reference materialises the (B, T', U, V) logits: transducer/rnn_decoder.py:160-165)."""
+    import argparse
+    import math
+    import espnet_amd
+    from espnet_amd import graphs, ops, train
+    from espnet_amd.nets.e2e_asr_transducer import E2E
+    espnet_amd.set_precision("fp32")
+    arch = [dict(type="conformer", d_hidden=256, d_ff=2048, heads=4, macaron_style=True, use_conv_mod=True, conv_mod_kernel=31)]
+    ns = argparse.Namespace(etype="transformer", enc_block_arch=arch, enc_block_repeat=12, transformer_enc_input_layer="conv2d",
+                            transformer_enc_self_attn_type="rel_self_attn", transformer_enc_positional_encoding_type="rel_pos",
+                            transformer_enc_pw_activation_type="swish", transformer_enc_conv_mod_activation_type="swish",
+                            dtype="lstm", dlayers=1, dunits=512, dec_embed_dim=512, joint_dim=320, joint_activation_type="tanh",
+                            dropout_rate_decoder=0.0, dropout_rate_embed_decoder=0.0, rnnt_mode="rnnt", trans_type="warp-transducer",
+                            sym_space="<space>", sym_blank="<blank>", transformer_init="pytorch")
+    torch.manual_seed(0)
+    V, B, T, L = 5000, 16, 1500, 100
+    m = E2E(80, V, ns).to(DEV).train()
+    flat = train.FlatParams(m)
+    g = torch.Generator().manual_seed(0)
+    xs = torch.randn(B, T, 80, generator=g).to(DEV)
+    ilens = [T - 11 * i for i in range(B)]
+    ys = torch.randint(1, V - 1, (B, L), generator=g)        # labels are parsed on the host (as in the reference): no device sync
+    torch.cuda.reset_peak_memory_stats()
+
+    def step():
+        flat.zero_grad()
+        loss = m(xs, ilens, ys)
+        ops.wgrad_group_begin()
+        try:
+            loss.backward()
+        finally:
+            ops.wgrad_group_end()
+        return loss
+
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        eager = float(step())
+        step()
+        torch.cuda.synchronize()
+    torch.cuda.current_stream().wait_stream(side)
+    gr = graphs.new_graph()
+    with torch.cuda.graph(gr):
+        loss = step()
+    kinds = graphs.audit(gr, "config 5 step graph")
+    gr.replay()
+    torch.cuda.synchronize()
+    l1, g1 = float(loss), flat.grad.clone()
+    gr.replay()
+    torch.cuda.synchronize()
+    l2 = float(loss)
+    peak = torch.cuda.max_memory_allocated() / 2 ** 30
+    print("[parity] config 5 full size: loss eager %.6f, replay %.6f / %.6f; peak memory %.1f GB; graph nodes %s" % (eager, l1, l2, peak, kinds))
+    assert math.isfinite(eager) and abs(l1 - eager) <= 1e-5 * abs(eager)
+    assert l1 == l2
+    assert bool(torch.isfinite(flat.grad).all())
+    rel = float((flat.grad.double() - g1.double()).norm() / g1.double().norm())
+    assert rel < 1e-5, rel            # (split-K / column-sum atomics reorder fp32 sums between replays: not bit-equal, equal to rounding)
+    assert peak < 32.0, peak
