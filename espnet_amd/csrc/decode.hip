@@ -1,0 +1,208 @@
+// Cached decoding of the Transformer decoder for a beam search, a few launches per layer instead of fourteen.
+// reference: transformer/decoder.py:283-321 (forward_one_step), decoder_layer.py:81-134 (the cached step: only the newest position
+// queries; the reference keeps every layer's OUTPUTS and re-projects keys / values of the whole prefix at every step).
+//
+// Here a layer keeps the KEYS and VALUES of the prefix instead (the same numbers: LayerNorm and the projections are row-wise),
+// time-major in [Lcap, n, D] buffers that are only ever appended to, and a beam step's re-ordering of the hypotheses never moves
+// them: slot_at[i][t] names the slot whose row at position t belongs to the history of the hypothesis now in slot i (a table of
+// n x Lcap int32 per search, shared by all layers, re-ordered with the hypotheses).
+//   eamd_linear_rows_ln_f32   y = alpha * act(LayerNorm(x) W^T + b) + R for M <= 16 rows: the pre-norm of a sub-block inside the
+//                             product that follows it (norm1 + q/k/v, norm2 + q of the source attention, norm3 + w_1, after_norm
+//                             + the output layer)
+//   eamd_decode_self_attn     appends this step's k / v rows and attends the newest position over the prefix (one wave per
+//                             (hypothesis, head), d_k = 64)
+//   eamd_beam_slots           the slot table behind a beam step's selection
+#include <stdlib.h>
+#include "common.h"
+#include "../../include/espnet_amd.h"
+
+namespace {
+
+// one wave per output column (rowops.hip: linear_rows_f32_kernel); K <= 1024 so that a lane holds its 16-byte pieces of every
+// input row in registers: the row statistics (mean, then the centred sum of squares: layernorm_fwd's arithmetic) come from the
+// same registers the dot products use.  Every wave normalises the M rows itself (M x K FMAs against N/4 workgroups: nothing).
+__global__ __launch_bounds__(256) void linear_rows_ln_f32_kernel(const float* __restrict__ x, const float* __restrict__ gam,
+                                                                 const float* __restrict__ bet, float eps,
+                                                                 const float* __restrict__ W, const float* __restrict__ bias,
+                                                                 const float* __restrict__ R, float* __restrict__ y, int M, int N,
+                                                                 int K, int act, float alpha, long ldx, long ldr, long ldy) {
+  const int lane = threadIdx.x & 63;
+  const int n = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (n >= N) return;
+  const float* wr = W + (long)n * K;
+  float4 w4[4], g4[4], b4[4];
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    const int k = lane * 4 + 256 * q;
+    const bool in = k < K;
+    w4[q] = in ? *reinterpret_cast<const float4*>(wr + k) : make_float4(0.f, 0.f, 0.f, 0.f);
+    g4[q] = in ? *reinterpret_cast<const float4*>(gam + k) : make_float4(0.f, 0.f, 0.f, 0.f);
+    b4[q] = in ? *reinterpret_cast<const float4*>(bet + k) : make_float4(0.f, 0.f, 0.f, 0.f);
+  }
+  float mine = 0.f;
+#pragma unroll
+  for (int m = 0; m < 16; ++m) {
+    if (m < M) {
+      float4 x4[4];
+      float s = 0.f;
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const int k = lane * 4 + 256 * q;
+        x4[q] = k < K ? *reinterpret_cast<const float4*>(x + (long)m * ldx + k) : make_float4(0.f, 0.f, 0.f, 0.f);
+        s += (x4[q].x + x4[q].y) + (x4[q].z + x4[q].w);
+      }
+      const float mean = wave_sum(s) / K;
+      float c = 0.f;
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const int k = lane * 4 + 256 * q;
+        if (k < K) {
+          const float a0 = x4[q].x - mean, a1 = x4[q].y - mean, a2 = x4[q].z - mean, a3 = x4[q].w - mean;
+          c += (a0 * a0 + a1 * a1) + (a2 * a2 + a3 * a3);
+        }
+      }
+      const float rstd = rsqrtf(wave_sum(c) / K + eps);
+      float acc = 0.f;
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const float v0 = (x4[q].x - mean) * rstd * g4[q].x + b4[q].x, v1 = (x4[q].y - mean) * rstd * g4[q].y + b4[q].y;
+        const float v2 = (x4[q].z - mean) * rstd * g4[q].z + b4[q].z, v3 = (x4[q].w - mean) * rstd * g4[q].w + b4[q].w;
+        acc = fmaf(v0, w4[q].x, fmaf(v1, w4[q].y, fmaf(v2, w4[q].z, fmaf(v3, w4[q].w, acc))));      // (padding lanes: w = 0)
+      }
+      const float r = wave_sum(acc);
+      if (lane == m) mine = r;
+    }
+  }
+  if (lane < M) {
+    float v = mine + (bias ? bias[n] : 0.f);
+    if (act == 1) v = fmaxf(v, 0.f);
+    else if (act == 2) v = eamd_swish(v);
+    v *= alpha;
+    if (R) v += R[(long)lane * ldr + n];
+    y[(long)lane * ldy + n] = v;
+  }
+}
+
+// one wave per (hypothesis slot, head); lane = channel of the head (d_k = 64).
+//   qkv   [n, ldq]: q | k | v of the newest position (columns 0, D, 2 D)
+//   Kc,Vc [Lcap, n, D]: rows [pos][slot] are written here, rows t < pos are read through slot_at[slot][t]
+//   ctx   [n, D]
+__global__ __launch_bounds__(64) void decode_self_attn_kernel(const float* __restrict__ qkv, long ldq, float* __restrict__ Kc,
+                                                              float* __restrict__ Vc, const int* __restrict__ slot_at, int Lcap,
+                                                              int pos, int n, int D, float* __restrict__ ctx, float scale) {
+  extern __shared__ float sc[];                 // [pos + 1] scores, then probabilities; ints of the slots behind them
+  int* sl = reinterpret_cast<int*>(sc + Lcap);
+  const int h = blockIdx.x, row = blockIdx.y, lane = threadIdx.x;
+  const float* qr = qkv + (long)row * ldq + h * 64;
+  const float kq = qr[D + lane], vq = qr[2 * D + lane];
+  Kc[((long)pos * n + row) * D + h * 64 + lane] = kq;
+  Vc[((long)pos * n + row) * D + h * 64 + lane] = vq;
+  float4 q4[16];
+#pragma unroll
+  for (int i = 0; i < 16; ++i) q4[i] = *reinterpret_cast<const float4*>(qr + 4 * i);      // the whole query in every lane
+  // scores of the prefix: lane = position inside a trip of 64 (each position's key is 256 contiguous bytes)
+  float mx = -INFINITY;
+  for (int t0 = 0; t0 < pos; t0 += 64) {
+    const int t = t0 + lane;
+    if (t < pos) {
+      int s = slot_at[(long)row * Lcap + t];
+      s = min(max(s, 0), n - 1);                                     // a slot outside the beam is never turned into an address
+      const float4* kp = reinterpret_cast<const float4*>(Kc + ((long)t * n + s) * D + h * 64);
+      float a = 0.f;
+#pragma unroll
+      for (int i = 0; i < 16; ++i) {
+        const float4 kv = kp[i];
+        a = fmaf(q4[i].x, kv.x, fmaf(q4[i].y, kv.y, fmaf(q4[i].z, kv.z, fmaf(q4[i].w, kv.w, a))));
+      }
+      a *= scale;
+      sc[t] = a;
+      sl[t] = s;
+      mx = fmaxf(mx, a);
+    }
+  }
+  const float snew = wave_sum(qr[lane] * kq) * scale;                  // the newest position attends to itself from registers
+  mx = fmaxf(wave_max(mx), snew);
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+  float den = 0.f;
+  for (int t0 = 0; t0 < pos; t0 += 64) {
+    const int t = t0 + lane;
+    if (t < pos) {
+      const float e = __expf(sc[t] - mx);
+      sc[t] = e;
+      den += e;
+    }
+  }
+  const float enew = __expf(snew - mx);
+  den = wave_sum(den) + enew;
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+  // context: lane = channel; four positions' value rows in flight
+  float acc = enew * vq;
+  int t = 0;
+  for (; t + 4 <= pos; t += 4) {
+    float p[4], v[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      p[u] = sc[t + u];
+      v[u] = Vc[((long)(t + u) * n + sl[t + u]) * D + h * 64 + lane];
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) acc = fmaf(p[u], v[u], acc);
+  }
+  for (; t < pos; ++t) acc = fmaf(sc[t], Vc[((long)t * n + sl[t]) * D + h * 64 + lane], acc);
+  ctx[(long)row * D + h * 64 + lane] = acc / den;
+}
+
+// slot_out[i][t] = slot_in[hyp[i]][t] for t < pos, slot_out[i][pos] = hyp[i]: the history of the hypothesis selected into slot i
+__global__ __launch_bounds__(256) void beam_slots_kernel(const int* __restrict__ slot_in, int* __restrict__ slot_out,
+                                                         const long long* __restrict__ hyp, int n, int Lcap, int pos) {
+  const int i = blockIdx.x;
+  long long p = hyp[i];
+  p = p < 0 ? 0 : (p >= n ? n - 1 : p);
+  for (int t = threadIdx.x; t <= pos && t < Lcap; t += blockDim.x)
+    slot_out[(long)i * Lcap + t] = t < pos ? slot_in[p * Lcap + t] : (int)p;
+}
+
+}  // namespace
+
+extern "C" {
+
+int eamd_linear_rows_ln_f32(const float* x, const float* gamma, const float* beta, float eps, const float* W, const float* bias,
+                            const float* R, float* y, int M, int N, int K, int act, float alpha, int64_t ldx, int64_t ldr,
+                            int64_t ldy, void* stream) {
+  if (!x || !gamma || !beta || !W || !y || M <= 0 || N <= 0 || K <= 0 || act < 0 || ldx < 0 || ldr < 0 || ldy < 0) return EAMD_EINVAL;
+  if (ldx == 0) ldx = K;
+  if (ldr == 0) ldr = N;
+  if (ldy == 0) ldy = N;
+  if (ldx < K || ldr < N || ldy < N) return EAMD_EINVAL;
+  if (M > 16 || K > 1024 || K % 4 != 0 || ldx % 4 != 0 || act > 2) return EAMD_EUNSUPPORTED;
+  if (((uintptr_t)x | (uintptr_t)W | (uintptr_t)gamma | (uintptr_t)beta) & 15) return EAMD_EUNSUPPORTED;
+  hipLaunchKernelGGL(linear_rows_ln_f32_kernel, dim3((N + 3) / 4), dim3(256), 0, (hipStream_t)stream, x, gamma, beta, eps, W, bias, R,
+                     y, M, N, K, act, alpha, (long)ldx, (long)ldr, (long)ldy);
+  EAMD_LAUNCH_CHECK();
+  return EAMD_OK;
+}
+
+int eamd_decode_self_attn(const float* qkv, int64_t ldq, float* kcache, float* vcache, const int32_t* slot_at, int Lcap, int pos,
+                          int n, int H, int D, float* ctx, void* stream) {
+  if (!qkv || !kcache || !vcache || !slot_at || !ctx || n <= 0 || H <= 0 || D <= 0 || Lcap <= 0 || pos < 0) return EAMD_EINVAL;
+  if (pos >= Lcap || ldq < 3L * D) return EAMD_EINVAL;
+  if (D != H * 64 || Lcap > 4096 || ldq % 4 != 0 || (((uintptr_t)qkv | (uintptr_t)kcache | (uintptr_t)vcache) & 15)) return EAMD_EUNSUPPORTED;
+  hipLaunchKernelGGL(decode_self_attn_kernel, dim3(H, n), dim3(64), (size_t)Lcap * 8, (hipStream_t)stream, qkv, (long)ldq, kcache,
+                     vcache, slot_at, Lcap, pos, n, D, ctx, 0.125f);
+  EAMD_LAUNCH_CHECK();
+  return EAMD_OK;
+}
+
+int eamd_beam_slots(const int32_t* slot_in, int32_t* slot_out, const int64_t* hyp, int n, int Lcap, int pos, void* stream) {
+  if (!slot_in || !slot_out || !hyp || n <= 0 || Lcap <= 0 || pos < 0 || pos >= Lcap) return EAMD_EINVAL;
+  hipLaunchKernelGGL(beam_slots_kernel, dim3(n), dim3(256), 0, (hipStream_t)stream, slot_in, slot_out, (const long long*)hyp, n, Lcap,
+                     pos);
+  EAMD_LAUNCH_CHECK();
+  return EAMD_OK;
+}
+
+}  // extern "C"

@@ -208,6 +208,11 @@ class BeamSearch(torch.nn.Module):
                 and all(isinstance(d, CTCPrefixScorer) for d in self.part_scorers.values()) and len(self.part_scorers) <= 1
                 and len(self.full_scorers) <= 4)          # eamd_beam_finish carries up to four full scorers
 
+    def _reorder(self, d, tree, idx):
+        """a full scorer's batched state behind a selection: the scorer's own re-ordering where it has one (the Transformer decoder
+        keeps key / value caches that are never moved, only a slot table is), else index_select on every tensor of the tree"""
+        return d.reorder_tree(tree, idx) if hasattr(d, "reorder_tree") else self._tree_index(tree, idx)
+
     @staticmethod
     def _tree_index(tree, idx):
         if tree is None:
@@ -325,7 +330,7 @@ class BeamSearch(torch.nn.Module):
                 hyp_i, tok_i = top_i // V, top_i % V
                 for k in names:
                     sc[k] = sc[k][hyp_i] + logps[k][hyp_i, tok_i]
-                    trees[k] = self._tree_index(newtrees[k], hyp_i)
+                    trees[k] = self._reorder(self.full_scorers[k], newtrees[k], hyp_i)
                 if ctc is not None:
                     if self.partial_mode == "full":
                         sc[pname] = sc[pname][hyp_i] + c_local[hyp_i, tok_i]
@@ -495,7 +500,7 @@ class BeamSearch(torch.nn.Module):
             top_s.reshape(-1).contiguous(), top_i.reshape(-1).contiguous(), beam, V, L, i, self.eos, C_["maxlen_d"].view(-1),
             S["sc"], [logps[k].contiguous() for k in names], c_loc, self.partial_mode == "full", ids_pos, yseq)
         for k in names:
-            trees[k] = self._tree_index(newtrees[k], hyp_i)
+            trees[k] = self._reorder(self.full_scorers[k], newtrees[k], hyp_i)
         T_ = dict(sc=sc_new, trees=trees, yseq=yseq, hyp=hyp_new)
         if ctc is not None:
             T_["c_s"] = full[hyp_i, tok_i] if self.partial_mode == "full" else psi[hyp_i, pos]

@@ -987,9 +987,103 @@ class Decoder(torch.nn.Module, BatchScorerInterface):
         logp, state = self.forward_one_step(ys.unsqueeze(0), ys_mask, x.unsqueeze(0), cache=state)
         return logp.squeeze(0), state
 
+    # ---- cached decoding on key / value caches (csrc/decode.hip) ----------------------------------------------------------
+    # The reference's cached step (decoder_layer.py:81-134) keeps every layer's OUTPUTS and, at every step, normalises and projects
+    # keys / values of the WHOLE prefix again: 14 launches per layer here, their work growing with the prefix.  score_tree keeps
+    # each layer's keys and values instead (same numbers: LayerNorm and the projections are row-wise) in time-major [Lcap, n, D]
+    # buffers that a beam step never re-orders (a slot table is), folds every pre-norm into the product behind it, and runs a
+    # layer as: norm1 + q/k/v | append + self-attention | out + residual | norm2 + q | source attention | out + residual |
+    # norm3 + w_1 + ReLU | w_2 + residual = 8 launches.  fp32 mode, d_k = 64, memory shared by the hypotheses of an utterance.
+    DECODE_KV = True
+
+    def _kv_ok(self, ys, tree, xs):
+        n, D = ys.shape[0], self.embed[0].weight.shape[1]
+        att = self.decoders[0].self_attn
+        return (self.DECODE_KV and not self.training and not torch.is_grad_enabled() and ops._infer > 0 and xs.is_cuda
+                and ops.get_precision() == "fp32" and att.d_k == 64 and self.normalize_before and self.output_layer is not None
+                and xs.shape[0] != n and n % xs.shape[0] == 0 and (isinstance(tree, dict) or (tree is None and ys.shape[1] == 1))
+                and isinstance(self.decoders[0].feed_forward, PositionwiseFeedForward)
+                and self.decoders[0].feed_forward.act_id in (ops.ACT_RELU, ops.ACT_SWISH))
+
+    def _kv_weights(self):
+        """per layer: the q/k/v weights of the self-attention back to back ([3D, D], [3D]); rebuilt when a weight changes"""
+        ver = sum(int(m.self_attn.linear_q.weight._version) + int(m.self_attn.linear_k.weight._version) for m in self.decoders)
+        memo = getattr(self, "_kv_w3", None)
+        if memo is None or memo[0] != (ver, self.decoders[0].self_attn.linear_q.weight.data_ptr()):
+            with torch.no_grad():
+                w = [(torch.cat([a.linear_q.weight, a.linear_k.weight, a.linear_v.weight], 0).contiguous(),
+                      torch.cat([a.linear_q.bias, a.linear_k.bias, a.linear_v.bias], 0).contiguous())
+                     for a in (m.self_attn for m in self.decoders)]
+            memo = self._kv_w3 = ((ver, self.decoders[0].self_attn.linear_q.weight.data_ptr()), w)
+        return memo[1]
+
+    @staticmethod
+    def _ln_rows(x, norm, W, b, act=ops.EPI_NONE):
+        """act(LayerNorm(x) W^T + b): one launch for <= 16 rows, LayerNorm + product otherwise"""
+        y = ops.linear_rows_ln(x, norm.weight, norm.bias, norm.eps, W, b, act=act)
+        if y is None:
+            y = ops.linear_fwd(ops.layernorm_fwd(x, norm.weight, norm.bias, norm.eps)[0], W, b, act=act)
+        return y
+
+    def _score_tree_kv(self, ys, tree, xs, memory_mask):
+        n, L = ys.shape
+        pos = L - 1
+        D = self.embed[0].weight.shape[1]
+        G = xs.shape[0]
+        H = self.decoders[0].self_attn.h
+        if tree is None:
+            Lcap = max(int(ys.stride(0)), 8) if (ys.dim() == 2 and ys.stride(1) == 1 and ys.stride(0) >= L) else 64
+            tree = dict(K=[torch.empty(Lcap, n, D, device=xs.device) for _ in self.decoders],
+                        V=[torch.empty(Lcap, n, D, device=xs.device) for _ in self.decoders],
+                        slot=torch.zeros(n, Lcap, dtype=torch.int32, device=xs.device), Lcap=Lcap)
+        elif pos >= tree["Lcap"]:          # a prefix longer than the caches were made for: double them
+            Lcap = 2 * tree["Lcap"]
+            grow = lambda t: torch.cat([t, torch.empty_like(t)], 0)  # noqa: E731
+            tree = dict(K=[grow(t) for t in tree["K"]], V=[grow(t) for t in tree["V"]],
+                        slot=torch.cat([tree["slot"], torch.zeros_like(tree["slot"])], 1).contiguous(), Lcap=Lcap)
+        w3 = self._kv_weights()
+        sp = self._memory_kv(xs)
+        T = xs.shape[1]
+        mask = _mask_u8(memory_mask, xs.device)
+        x = self._embed(ys[:, -1:], pos_offset=pos).reshape(n, D)
+        for i, m in enumerate(self.decoders):
+            qkv = self._ln_rows(x, m.norm1, w3[i][0], w3[i][1])
+            ctx = ops.decode_self_attn(qkv, tree["K"][i], tree["V"][i], tree["slot"], pos, H)
+            x = ops.linear_fwd(ctx, m.self_attn.linear_out.weight, m.self_attn.linear_out.bias, R=x)
+            a = m.src_attn
+            q2 = self._ln_rows(x, m.norm2, a.linear_q.weight, a.linear_q.bias)
+            k2, v2 = sp.block(i, 0), sp.block(i, D)
+            fwd = F_.attn_fwd_fused(q2, None, k2, v2, None, mask, G, n // G, T, H, a.d_k) \
+                if (F_.FUSE_ATTN and ops.attn_fwd_supported(n // G, T, a.d_k, False)) else None
+            if fwd is not None:
+                cx = fwd[2]
+            else:
+                P = F_.attn_scores_fwd(q2, None, k2, None, mask, G, n // G, T, H, a.d_k)
+                cx = F_.attn_context_fwd(P, v2, G, n // G, T, H, a.d_k)
+            x = ops.linear_fwd(cx, a.linear_out.weight, a.linear_out.bias, R=x)
+            ff = m.feed_forward
+            h = self._ln_rows(x, m.norm3, ff.w_1.weight, ff.w_1.bias, act=ff.act_id)      # (ACT_RELU / ACT_SWISH = EPI_RELU / EPI_SWISH)
+            x = ops.linear_fwd(h, ff.w_2.weight, ff.w_2.bias, R=x)
+        y = self._ln_rows(x, self.after_norm, self.output_layer.weight, self.output_layer.bias)
+        new = dict(tree)
+        new["pos"] = pos
+        return ops.log_softmax_rows(y.contiguous()), new
+
+    @staticmethod
+    def reorder_tree(tree, hyp_i):
+        """the batched state behind a beam step's selection (BeamSearch._reorder): the layer-output caches of the reference-shaped
+        step are gathered; the key / value caches stay where they are, only the slot table follows the hypotheses"""
+        if not isinstance(tree, dict):
+            return None if tree is None else [t.index_select(0, hyp_i) for t in tree]
+        new = dict(tree)
+        new["slot"] = ops.beam_slots(tree["slot"], hyp_i, tree["pos"])
+        return new
+
     def score_tree(self, ys, tree, xs, memory_mask=None):
         """batch_score on a BATCHED state (list per layer of [n, L-1, D], or None): no per-hypothesis stacking / slicing;
         the search reorders it with index_select (BeamSearch device loop)"""
+        if self._kv_ok(ys, tree, xs):
+            return self._score_tree_kv(ys, tree, xs, memory_mask)
         # all hypotheses of a search have the same length and only the NEWEST position queries (cached decoding): its row of the
         # causal mask is all ones, i.e. no mask at all - the reference builds subsequent_mask(L) and slices that row every step
         # (decoder.py:342-343, decoder_layer.py:88-101); here that was a tril, a fill and six mask conversions per step

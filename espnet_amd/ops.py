@@ -1244,6 +1244,43 @@ def reduce_sum(x, scale=1.0):
     return out
 
 
+def linear_rows_ln(x, gamma, beta, eps, W, b, *, act=EPI_NONE, R=None, alpha=1.0, out=None):
+    """y = alpha * act(LayerNorm(x) W^T + b) + R for at most 16 rows in ONE launch (eamd_linear_rows_ln_f32), or None when the
+    library declines (more rows, K > 1024, unaligned): the caller then normalises and multiplies in two launches"""
+    M, K = x.shape
+    N = W.shape[0]
+    if M > 16 or K > 1024 or x.dtype != torch.float32 or W.dtype != torch.float32 or x.stride(1) != 1 or act not in (EPI_NONE, EPI_RELU, EPI_SWISH):
+        return None
+    y = out if out is not None else torch.empty(M, N, device=x.device, dtype=torch.float32)
+    rc = _lib.lib().eamd_linear_rows_ln_f32(ptr(x), ptr(gamma), ptr(beta), C.c_float(eps), ptr(W), ptr(b), ptr(R), ptr(y), M, N, K,
+                                            int(act), C.c_float(alpha), C.c_int64(x.stride(0) if M > 1 else K),
+                                            C.c_int64(R.stride(0) if (R is not None and M > 1) else 0), C.c_int64(y.stride(0)), stream_ptr())
+    if rc == _lib.EAMD_EUNSUPPORTED:
+        return None
+    check(rc, "eamd_linear_rows_ln_f32")
+    return y
+
+
+def decode_self_attn(qkv, Kc, Vc, slot_at, pos, H):
+    """the newest position of n hypotheses attends over its prefix; keys / values of this step (columns D.., 2D.. of qkv) are
+    appended to the time-major caches Kc / Vc [Lcap, n, D] at row `pos`; slot_at [n, Lcap] int32 (eamd_decode_self_attn) -> ctx [n, D]"""
+    n = qkv.shape[0]
+    Lcap, n2, D = Kc.shape
+    assert n2 == n and Vc.shape == Kc.shape and slot_at.shape == (n, Lcap) and slot_at.dtype == torch.int32 and qkv.stride(1) == 1
+    ctx = torch.empty(n, D, device=qkv.device, dtype=torch.float32)
+    check(_lib.lib().eamd_decode_self_attn(ptr(qkv), C.c_int64(qkv.stride(0)), ptr(Kc), ptr(Vc), ptr(slot_at), Lcap, int(pos), n, H, D,
+                                           ptr(ctx), stream_ptr()), "eamd_decode_self_attn")
+    return ctx
+
+
+def beam_slots(slot_in, hyp, pos):
+    """the slot table behind a beam step's selection: row i = row hyp[i] of slot_in with column `pos` set to hyp[i]"""
+    n, Lcap = slot_in.shape
+    out = torch.empty_like(slot_in)
+    check(_lib.lib().eamd_beam_slots(ptr(slot_in), ptr(out), ptr(hyp), n, Lcap, int(pos), stream_ptr()), "eamd_beam_slots")
+    return out
+
+
 def topk_rows(x, k):
     """(values [rows, k], indices [rows, k] int64) of the k largest of each row of a contiguous fp32 [rows, n] tensor, sorted
     (value descending, ties by ascending index): one launch, graph-replay safe (torch.topk's multi-block path is neither)"""

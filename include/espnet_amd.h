@@ -401,6 +401,22 @@ int eamd_beam_finish(const float* top_s, const int64_t* top_i, int n, int beam, 
  * dense; the newest position of every hypothesis's prefix is a strided set of rows).  EAMD_EUNSUPPORTED: the caller uses eamd_gemm. */
 int eamd_linear_rows_f32(const float* x, const float* W, const float* bias, const float* R, float* y, int M, int N, int K,
                          int a_act, int act, float alpha, int64_t ldx, int64_t ldr, void* stream);
+/* Cached decoding of the Transformer decoder, csrc/decode.hip (reference: transformer/decoder.py:283-321, decoder_layer.py:81-134).
+ * eamd_linear_rows_ln_f32: y[M, N] (row stride ldy) = alpha * act(LayerNorm(x; gamma, beta, eps) W^T + bias) + R for M <= 16 rows,
+ *   K <= 1024: the pre-norm of a decoder sub-block inside the product behind it (layer_norm.py:12-38 in front of attention.py:40-61 /
+ *   positionwise_feed_forward.py:28 / decoder.py:312-317); row strides 0 = dense.
+ * eamd_decode_self_attn: self-attention of the NEWEST position of n hypotheses over their prefixes, keys / values cached per layer in
+ *   time-major [Lcap, n, D] buffers: row (pos, slot) is written from qkv [n, ldq] = (q | k | v) of this step, rows t < pos are read
+ *   at slot_at[slot][t] ([n, Lcap] int32: the slot that held this hypothesis's ancestor at position t - a beam step re-orders that
+ *   table, never the caches).  d_k = 64 (D = 64 H); ctx [n, D]; no mask (a prefix has no padding).  The reference re-projects keys and
+ *   values of the whole prefix at every step from cached layer outputs (decoder_layer.py:88-107): same numbers.
+ * eamd_beam_slots: slot_out[i][t] = slot_in[hyp[i]][t] (t < pos), slot_out[i][pos] = hyp[i] - the table behind a selection. */
+int eamd_linear_rows_ln_f32(const float* x, const float* gamma, const float* beta, float eps, const float* W, const float* bias,
+                            const float* R, float* y, int M, int N, int K, int act, float alpha, int64_t ldx, int64_t ldr,
+                            int64_t ldy, void* stream);
+int eamd_decode_self_attn(const float* qkv, int64_t ldq, float* kcache, float* vcache, const int32_t* slot_at, int Lcap, int pos,
+                          int n, int H, int D, float* ctx, void* stream);
+int eamd_beam_slots(const int32_t* slot_in, int32_t* slot_out, const int64_t* hyp, int n, int Lcap, int pos, void* stream);
 /* The k (<= 64) largest of each row of x [rows, n] (row stride ld), sorted by value descending, equal values by ascending index;
  * NaN counts as -inf.  vals / idx [rows, k].  reference: the torch.topk selections of a beam step (beam_search.py:143-176,
  * batch_beam_search.py:86-110: pre-beam over V, best `beam` of beam x V). */

@@ -1866,3 +1866,44 @@ def test_ffn_bwd_layernorm_backward_epilogue(ops):
         part = ws.view(-1, 2, 256).sum(0)
         report("ffn_bwd + LN-bwd d gamma", part[0], dg_ref, 2e-5)
         report("ffn_bwd + LN-bwd d beta", part[1], db_ref, 2e-5)
+
+
+def test_decode_kernels_vs_float64(ops):
+    """csrc/decode.hip: eamd_linear_rows_ln_f32 against float64 LayerNorm + Linear (+ ReLU, residual, strided rows); the cached
+    self-attention (eamd_decode_self_attn + eamd_beam_slots) over six beam steps with random re-ordering of the hypotheses
+    against softmax attention in float64 over each hypothesis's TRUE history (keys / values gathered along its ancestry)."""
+    g = torch.Generator().manual_seed(11)
+    rnd = lambda *s: torch.randn(*s, generator=g)  # noqa: E731
+    for M, K, N in ((10, 256, 768), (1, 256, 256), (16, 256, 5000), (7, 512, 130)):
+        x, W, b, R = rnd(M, K) * 2 + 0.5, rnd(N, K) / K ** 0.5, rnd(N), rnd(M, N)
+        gam, bet = 1 + 0.1 * rnd(K), 0.1 * rnd(K)
+        ln = torch.nn.functional.layer_norm(x.double(), (K,), gam.double(), bet.double(), 1e-12)
+        y = ops.linear_rows_ln(x.to(DEV), gam.to(DEV), bet.to(DEV), 1e-12, W.to(DEV), b.to(DEV), act=ops.EPI_RELU, R=R.to(DEV), alpha=0.5)
+        assert y is not None
+        report(f"linear_rows_ln {M}x{K}x{N}", y, 0.5 * torch.relu(ln @ W.double().t() + b.double()) + R.double(), 2e-6)
+        wide = torch.zeros(M, 3, K)
+        wide[:, 2] = x
+        y2 = ops.linear_rows_ln(wide.to(DEV)[:, 2], gam.to(DEV), bet.to(DEV), 1e-12, W.to(DEV), None)
+        report("linear_rows_ln strided rows", y2, ln @ W.double().t(), 2e-6)
+    assert ops.linear_rows_ln(rnd(17, 256).to(DEV), rnd(256).to(DEV), rnd(256).to(DEV), 1e-12, rnd(8, 256).to(DEV), None) is None
+    n, H, D, Lcap = 10, 4, 256, 24
+    Kc, Vc = torch.full((Lcap, n, D), float("nan"), device=DEV), torch.full((Lcap, n, D), float("nan"), device=DEV)
+    slot = torch.zeros(n, Lcap, dtype=torch.int32, device=DEV)
+    hist_k = [[] for _ in range(n)]          # per current slot: list of (k, v) rows of its true history
+    for pos in range(6):
+        qkv = rnd(n, 3 * D)
+        ctx = ops.decode_self_attn(qkv.to(DEV), Kc, Vc, slot, pos, H)
+        for i in range(n):
+            hist_k[i] = hist_k[i] + [(qkv[i, D:2 * D].double(), qkv[i, 2 * D:].double())]
+        want = torch.zeros(n, D, dtype=torch.float64)
+        for i in range(n):
+            Kh = torch.stack([kv[0] for kv in hist_k[i]]).view(-1, H, 64)
+            Vh = torch.stack([kv[1] for kv in hist_k[i]]).view(-1, H, 64)
+            q = qkv[i, :D].double().view(H, 64)
+            p = torch.softmax(torch.einsum("hd,thd->ht", q, Kh) / 8.0, -1)
+            want[i] = torch.einsum("ht,thd->hd", p, Vh).reshape(D)
+        report(f"decode_self_attn step {pos}", ctx, want, 2e-6)
+        hyp = torch.randint(0, n, (n,), generator=g)            # the selection: slot i continues the hypothesis of slot hyp[i]
+        slot = ops.beam_slots(slot, hyp.to(DEV), pos)
+        hist_k = [list(hist_k[int(h)]) for h in hyp]
+        assert slot[:, pos].cpu().tolist() == hyp.tolist()
