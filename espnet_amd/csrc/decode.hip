@@ -206,3 +206,120 @@ int eamd_beam_slots(const int32_t* slot_in, int32_t* slot_out, const int64_t* hy
 }
 
 }  // extern "C"
+
+// ---- the selection of a beam step on the pre-beam candidates (reference: beam_search.py:296-334, :199-226) -------------------------
+// BeamSearch drops every token outside the pre-beam (weighted_scores[:] = -inf; weighted_scores[ids] = tmp), so the `beam` best
+// continuations of an utterance are among its beam x P candidates: one workgroup per utterance forms their scores in the
+// reference's order of operations - (sum_k w_k logp_k)[token] + w_ctc (psi - s_prev), + the hypothesis's running score - and picks
+// the best `beam` (value descending, ties by ascending slot * V + token: torch.topk's order on the flattened [beam, V] scores).
+// Replaces, per step: a fill of [n, V] with -inf, a gather, a scatter, the running-score add and two top-k passes.
+namespace {
+__global__ __launch_bounds__(256) void weighted_sum_kernel(const float* __restrict__ l0, const float* __restrict__ l1,
+                                                           const float* __restrict__ l2, const float* __restrict__ l3, float w0,
+                                                           float w1, float w2, float w3, float* __restrict__ out, long n4) {
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n4; i += (long)gridDim.x * 256) {
+    float4 a = reinterpret_cast<const float4*>(l0)[i];
+    float4 v = make_float4(0.f + w0 * a.x, 0.f + w0 * a.y, 0.f + w0 * a.z, 0.f + w0 * a.w);
+    if (l1) { a = reinterpret_cast<const float4*>(l1)[i]; v.x += w1 * a.x; v.y += w1 * a.y; v.z += w1 * a.z; v.w += w1 * a.w; }
+    if (l2) { a = reinterpret_cast<const float4*>(l2)[i]; v.x += w2 * a.x; v.y += w2 * a.y; v.z += w2 * a.z; v.w += w2 * a.w; }
+    if (l3) { a = reinterpret_cast<const float4*>(l3)[i]; v.x += w3 * a.x; v.y += w3 * a.y; v.z += w3 * a.z; v.w += w3 * a.w; }
+    reinterpret_cast<float4*>(out)[i] = v;
+  }
+}
+
+__device__ __forceinline__ bool sel_before(float va, long ia, float vb, long ib) { return va > vb || (va == vb && ia < ib); }
+
+__global__ __launch_bounds__(256) void beam_select_kernel(const float* __restrict__ pre, const long long* __restrict__ ids,
+                                                          const float* __restrict__ psi, const float* __restrict__ c_s,
+                                                          const float* __restrict__ hyp, float w_ctc, int beam, int P, int V,
+                                                          float* __restrict__ c_local, float* __restrict__ top_s,
+                                                          long long* __restrict__ top_i) {
+  __shared__ float sv[4];
+  __shared__ long si[4];
+  __shared__ float wv;
+  __shared__ long wi;
+  const int u = blockIdx.x, t = threadIdx.x, lane = t & 63, w = t >> 6;
+  const int C = beam * P;
+  constexpr int RMAX = 4;                         // beam * P <= 1024 candidates (host check)
+  float val[RMAX];
+  long key[RMAX];
+#pragma unroll
+  for (int q = 0; q < RMAX; ++q) {
+    const int c = t + 256 * q;
+    val[q] = -INFINITY;
+    key[q] = 0x7ffffffffffffffeL;
+    if (c < C) {
+      const int slot = c / P, j = c - slot * P;
+      const long h = (long)u * beam + slot;
+      long long tok = ids[h * P + j];
+      tok = tok < 0 ? 0 : (tok >= V ? V - 1 : tok);                 // (a token outside the vocabulary never becomes an address)
+      const float cl = psi[h * P + j] - c_s[h];
+      c_local[h * P + j] = cl;
+      float v = pre[h * V + tok] + w_ctc * cl;
+      v = v + hyp[h];
+      val[q] = (v != v) ? -INFINITY : v;
+      key[q] = (long)slot * V + tok;
+    }
+  }
+  float pv = INFINITY;
+  long pi = -1;
+  for (int r = 0; r < beam; ++r) {
+    float bv = -INFINITY;
+    long bi = 0x7fffffffffffffffL;
+#pragma unroll
+    for (int q = 0; q < RMAX; ++q)
+      if (t + 256 * q < C && sel_before(pv, pi, val[q], key[q]) && sel_before(val[q], key[q], bv, bi)) { bv = val[q]; bi = key[q]; }
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) {
+      const float ov = __shfl_xor(bv, m);
+      const long oi = __shfl_xor(bi, m);
+      if (sel_before(ov, oi, bv, bi)) { bv = ov; bi = oi; }
+    }
+    if (lane == 0) { sv[w] = bv; si[w] = bi; }
+    __syncthreads();
+    if (t == 0) {
+      float fv = sv[0];
+      long fi = si[0];
+#pragma unroll
+      for (int q = 1; q < 4; ++q)
+        if (sel_before(sv[q], si[q], fv, fi)) { fv = sv[q]; fi = si[q]; }
+      if (fi == 0x7fffffffffffffffL) { fv = -INFINITY; fi = 0; }     // fewer candidates than `beam`: a dead slot
+      wv = fv; wi = fi;
+      top_s[(long)u * beam + r] = fv;
+      top_i[(long)u * beam + r] = fi;
+    }
+    __syncthreads();
+    pv = wv; pi = wi;
+    if (pi == 0 && pv == -INFINITY) pi = -1;       // (after a dead slot every further rank is dead too)
+  }
+}
+}  // namespace
+
+extern "C" {
+
+int eamd_weighted_sum(const float* const* logps, const float* weights, int nf, int64_t numel, float* out, void* stream) {
+  if (!logps || !weights || !out || nf < 1 || nf > 4 || numel <= 0) return EAMD_EINVAL;
+  for (int i = 0; i < nf; ++i)
+    if (!logps[i] || ((uintptr_t)logps[i] & 15)) return logps[i] ? EAMD_EUNSUPPORTED : EAMD_EINVAL;
+  if (numel % 4 != 0 || ((uintptr_t)out & 15)) return EAMD_EUNSUPPORTED;
+  const long n4 = numel / 4;
+  const int blocks = (int)((n4 + 255) / 256 < 2048 ? (n4 + 255) / 256 : 2048);
+  hipLaunchKernelGGL(weighted_sum_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, logps[0], nf > 1 ? logps[1] : nullptr,
+                     nf > 2 ? logps[2] : nullptr, nf > 3 ? logps[3] : nullptr, weights[0], nf > 1 ? weights[1] : 0.f,
+                     nf > 2 ? weights[2] : 0.f, nf > 3 ? weights[3] : 0.f, out, n4);
+  EAMD_LAUNCH_CHECK();
+  return EAMD_OK;
+}
+
+int eamd_beam_select(const float* pre, const int64_t* ids, const float* psi, const float* c_s, const float* hyp, float w_ctc,
+                     int nutt, int beam, int P, int V, float* c_local, float* top_s, int64_t* top_i, void* stream) {
+  if (!pre || !ids || !psi || !c_s || !hyp || !c_local || !top_s || !top_i || nutt <= 0 || beam <= 0 || P <= 0 || V <= 0)
+    return EAMD_EINVAL;
+  if ((long)beam * P > 1024) return EAMD_EUNSUPPORTED;
+  hipLaunchKernelGGL(beam_select_kernel, dim3(nutt), dim3(256), 0, (hipStream_t)stream, pre, (const long long*)ids, psi, c_s, hyp,
+                     w_ctc, beam, P, V, c_local, top_s, (long long*)top_i);
+  EAMD_LAUNCH_CHECK();
+  return EAMD_OK;
+}
+
+}  // extern "C"

@@ -202,6 +202,7 @@ class BeamSearch(torch.nn.Module):
     # step it would have stopped at.  Steps run beyond that point are discarded; results are those of the host loop.
     device_loop = True
     sync_every = 8
+    candidate_select = True       # the selection of a step on the pre-beam candidates (eamd_beam_select); tests flip it
 
     def _device_loop_ok(self, x):
         return (self.device_loop and x.is_cuda and all(hasattr(d, "score_tree") for d in self.full_scorers.values())
@@ -446,7 +447,6 @@ class BeamSearch(torch.nn.Module):
         L = i + 1
         yseq, hyp, trees = S["yseq"], S["hyp"], dict(S["trees"])
         ys = yseq[:, :L]
-        weighted = torch.zeros(n, V, device=dev, dtype=torch.float32)
         logps, newtrees = {}, {}
         for k, d in self.full_scorers.items():
             # scorers that take it get the memory of the B utterances, not of the B * beam slots (shared_memory_ok)
@@ -455,6 +455,27 @@ class BeamSearch(torch.nn.Module):
                 logps[k], newtrees[k] = d.score_tree(ys, trees[k], mem, memory_mask=mm)
             else:
                 logps[k], newtrees[k] = d.score_tree(ys, trees[k], mem)
+        P = self.pre_beam_size
+        if (ctc is not None and self.do_pre_beam and self.partial_mode == "ids" and self.pre_beam_score_key == "full" and 1 <= len(names) <= 4
+                and V % 4 == 0 and beam * P <= 1024 and self.candidate_select
+                and all(logps[k].dtype == torch.float32 and logps[k].is_contiguous() for k in names)):
+            # BeamSearch with a pre-beam: the step's selection on the beam x P candidates (csrc/decode.hip: eamd_weighted_sum,
+            # eamd_beam_select) - same scores in the same order of operations as the tensor expressions below, 12 launches fewer
+            pre = ops.weighted_sum([logps[k] for k in names], [self.weights[k] for k in names])
+            part_ids = ops.topk_rows(pre, P)[1]
+            last = ys[:, -1].to(torch.int32).contiguous()
+            olen = torch.full((n,), L - 1, dtype=torch.int32, device=dev)
+            psi, r_new = ops.ctc_prefix_score_batch(C_["logp"], C_["lens_d"], beam, S["c_r"], part_ids.to(torch.int32), last, olen,
+                                                    ctc.blank, ctc.eos)
+            top_s, top_i, c_loc = ops.beam_select(pre, part_ids, psi, S["c_s"], hyp, self.weights[pname], B, beam)
+            sc_new, yseq, hyp_new, hyp_i, tok_i, pos, rec = ops.beam_finish(
+                top_s.reshape(-1), top_i.reshape(-1), beam, V, L, i, self.eos, C_["maxlen_d"].view(-1),
+                S["sc"], [logps[k] for k in names], c_loc, False, part_ids, yseq)
+            for k in names:
+                trees[k] = self._reorder(self.full_scorers[k], newtrees[k], hyp_i)
+            return dict(sc=sc_new, trees=trees, yseq=yseq, hyp=hyp_new, c_s=psi[hyp_i, pos], c_r=r_new[hyp_i, pos]), rec
+        weighted = torch.zeros(n, V, device=dev, dtype=torch.float32)
+        for k in names:
             weighted += self.weights[k] * logps[k]
         part_ids = None
         if self.do_pre_beam:

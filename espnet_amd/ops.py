@@ -1281,6 +1281,29 @@ def beam_slots(slot_in, hyp, pos):
     return out
 
 
+def weighted_sum(logps, weights):
+    """sum_k w_k logp_k over up to four contiguous fp32 [n, V] matrices, in torch's order ((0 + w_0 l_0) + w_1 l_1 ...): one launch"""
+    out = torch.empty_like(logps[0])
+    arr = (C.c_void_p * 4)(*[lp.data_ptr() for lp in logps] + [None] * (4 - len(logps)))
+    wts = (C.c_float * 4)(*[float(w) for w in weights] + [0.0] * (4 - len(weights)))
+    check(_lib.lib().eamd_weighted_sum(arr, wts, len(logps), C.c_int64(out.numel()), ptr(out), stream_ptr()), "eamd_weighted_sum")
+    return out
+
+
+def beam_select(pre, ids, psi, c_s, hyp, w_ctc, nutt, beam):
+    """the `beam` best continuations of each utterance among its beam x P pre-beam candidates (eamd_beam_select) ->
+    (top_s [nutt, beam], top_i [nutt, beam] = local slot * V + token, c_local [n, P] = psi - c_s)"""
+    n, V = pre.shape
+    P = ids.shape[1]
+    assert n == nutt * beam and ids.dtype == torch.int64 and ids.is_contiguous() and psi.shape == (n, P) and pre.is_contiguous()
+    top_s = torch.empty(nutt, beam, device=pre.device, dtype=torch.float32)
+    top_i = torch.empty(nutt, beam, device=pre.device, dtype=torch.int64)
+    c_local = torch.empty(n, P, device=pre.device, dtype=torch.float32)
+    check(_lib.lib().eamd_beam_select(ptr(pre), ptr(ids), ptr(psi), ptr(c_s), ptr(hyp), C.c_float(w_ctc), nutt, beam, P, V, ptr(c_local),
+                                      ptr(top_s), ptr(top_i), stream_ptr()), "eamd_beam_select")
+    return top_s, top_i, c_local
+
+
 def topk_rows(x, k):
     """(values [rows, k], indices [rows, k] int64) of the k largest of each row of a contiguous fp32 [rows, n] tensor, sorted
     (value descending, ties by ascending index): one launch, graph-replay safe (torch.topk's multi-block path is neither)"""

@@ -417,6 +417,17 @@ int eamd_linear_rows_ln_f32(const float* x, const float* gamma, const float* bet
 int eamd_decode_self_attn(const float* qkv, int64_t ldq, float* kcache, float* vcache, const int32_t* slot_at, int Lcap, int pos,
                           int n, int H, int D, float* ctx, void* stream);
 int eamd_beam_slots(const int32_t* slot_in, int32_t* slot_out, const int64_t* hyp, int n, int Lcap, int pos, void* stream);
+/* The selection of a beam step on the pre-beam candidates (reference: beam_search.py:296-334 with :199-226: tokens outside the pre-beam
+ * are dropped, so an utterance's `beam` best continuations are among its beam x P candidates).
+ * eamd_weighted_sum: out[i] = ((0 + w_0 logp_0[i]) + w_1 logp_1[i]) + ... over nf <= 4 full scorers ([n, V] each; numel = n V, a
+ *   multiple of 4): the sum the pre-beam top-k is taken on (beam_search.py:298-309), in the reference's order of operations.
+ * eamd_beam_select: per utterance (nutt of them, `beam` slots each), candidate (slot, j) scores
+ *   (pre[slot][ids[slot][j]] + w_ctc (psi[slot][j] - c_s[slot])) + hyp[slot]; the best `beam` leave as top_s / top_i [nutt, beam]
+ *   (top_i = local slot * V + token; value descending, ties by ascending top_i = torch.topk on the flattened scores; NaN ranks as
+ *   -inf), c_local [n, P] = psi - c_s (the partial scorer's score of each candidate, for eamd_beam_finish).  beam * P <= 1024. */
+int eamd_weighted_sum(const float* const* logps, const float* weights, int nf, int64_t numel, float* out, void* stream);
+int eamd_beam_select(const float* pre, const int64_t* ids, const float* psi, const float* c_s, const float* hyp, float w_ctc,
+                     int nutt, int beam, int P, int V, float* c_local, float* top_s, int64_t* top_i, void* stream);
 /* The k (<= 64) largest of each row of x [rows, n] (row stride ld), sorted by value descending, equal values by ascending index;
  * NaN counts as -inf.  vals / idx [rows, k].  reference: the torch.topk selections of a beam step (beam_search.py:143-176,
  * batch_beam_search.py:86-110: pre-beam over V, best `beam` of beam x V). */

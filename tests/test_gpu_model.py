@@ -2077,3 +2077,24 @@ def test_composed_step_two_ranks_conformer_vs_oracle():
             assert e < 1e-3, (k, n, e)
     print(f"[parity] composed step, 2 ranks x 5 ragged micro-steps (eager / capture / replay, different buckets per rank): "
           f"worst parameter-gradient rel err vs the oracle on exact shapes {worst:.2e}")
+
+
+def test_beam_candidate_selection_matches_tensor_expressions():
+    """BeamSearch with a pre-beam: a step's selection on the beam x P candidates (eamd_weighted_sum + eamd_beam_select) gives the
+    same n-best - token ids AND scores bit for bit - as the tensor expressions it replaces (fill -inf / gather / scatter / add /
+    two-stage top-k over V), single utterances and three utterances per search, at config 2's width"""
+    from espnet_amd.nets.beam_search import BeamSearch
+    from espnet_amd.nets.ctc_prefix_score import LengthBonus
+    SW, model, g, encs = c2width_setup()
+    spec = SW.DECODE_R4
+    res = {}
+    for sel in (True, False):
+        scorers = model.scorers()
+        scorers["length_bonus"] = LengthBonus(spec["odim"])
+        bs = BeamSearch(scorers, dict(decoder=0.7, ctc=0.3, length_bonus=0.1), spec["beam"], spec["odim"], model.sos, model.eos,
+                        pre_beam_score_key="full")
+        bs.candidate_select = sel
+        one = [bs(e, maxlenratio=0.2) for e in encs]
+        many = bs.forward_batch(encs, maxlenratio=0.0)
+        res[sel] = [[(h.yseq.tolist(), float(h.score), {k: float(v) for k, v in h.scores.items()}) for h in nb[:10]] for nb in one + many]
+    assert res[True] == res[False]
