@@ -218,11 +218,21 @@ __global__ __launch_bounds__(256) void weighted_sum_kernel(const float* __restri
                                                            const float* __restrict__ l2, const float* __restrict__ l3, float w0,
                                                            float w1, float w2, float w3, float* __restrict__ out, long n4) {
   for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n4; i += (long)gridDim.x * 256) {
+    // (separately rounded products and sums, as the tensor expressions `weighted += w * logp` round them: the empty asm keeps
+    // hipcc from fusing a * b + c)
     float4 a = reinterpret_cast<const float4*>(l0)[i];
-    float4 v = make_float4(0.f + w0 * a.x, 0.f + w0 * a.y, 0.f + w0 * a.z, 0.f + w0 * a.w);
-    if (l1) { a = reinterpret_cast<const float4*>(l1)[i]; v.x += w1 * a.x; v.y += w1 * a.y; v.z += w1 * a.z; v.w += w1 * a.w; }
-    if (l2) { a = reinterpret_cast<const float4*>(l2)[i]; v.x += w2 * a.x; v.y += w2 * a.y; v.z += w2 * a.z; v.w += w2 * a.w; }
-    if (l3) { a = reinterpret_cast<const float4*>(l3)[i]; v.x += w3 * a.x; v.y += w3 * a.y; v.z += w3 * a.z; v.w += w3 * a.w; }
+    float4 v = make_float4(w0 * a.x, w0 * a.y, w0 * a.z, w0 * a.w);
+#define EAMD_WS_ADD(L, W)                                                                                              \
+    if (L) {                                                                                                           \
+      a = reinterpret_cast<const float4*>(L)[i];                                                                       \
+      float p0 = W * a.x, p1 = W * a.y, p2 = W * a.z, p3 = W * a.w;                                                     \
+      asm volatile("" : "+v"(p0), "+v"(p1), "+v"(p2), "+v"(p3));                                                      \
+      v.x += p0; v.y += p1; v.z += p2; v.w += p3;                                                                      \
+    }
+    EAMD_WS_ADD(l1, w1)
+    EAMD_WS_ADD(l2, w2)
+    EAMD_WS_ADD(l3, w3)
+#undef EAMD_WS_ADD
     reinterpret_cast<float4*>(out)[i] = v;
   }
 }
@@ -253,9 +263,11 @@ __global__ __launch_bounds__(256) void beam_select_kernel(const float* __restric
       const long h = (long)u * beam + slot;
       long long tok = ids[h * P + j];
       tok = tok < 0 ? 0 : (tok >= V ? V - 1 : tok);                 // (a token outside the vocabulary never becomes an address)
-      const float cl = psi[h * P + j] - c_s[h];
+      const float cl = __fsub_rn(psi[h * P + j], c_s[h]);
       c_local[h * P + j] = cl;
-      float v = pre[h * V + tok] + w_ctc * cl;
+      float prod = w_ctc * cl;
+      asm volatile("" : "+v"(prod));                    // keeps the product separately rounded, as the tensor expressions round
+      float v = pre[h * V + tok] + prod;               // it (hipcc fuses a * b + c whatever the contraction pragma says)
       v = v + hyp[h];
       val[q] = (v != v) ? -INFINITY : v;
       key[q] = (long)slot * V + tok;
@@ -323,3 +335,84 @@ int eamd_beam_select(const float* pre, const int64_t* ids, const float* psi, con
 }
 
 }  // extern "C"
+
+// ---- source attention of a beam step: g hypotheses of an utterance over ITS memory (decoder_layer.py:109-121) -------------------
+// One wave per (hypothesis, head), lane = key inside a trip of 64 for the scores (a key row of one head is 256 contiguous bytes),
+// lane = channel for the context.  Keys / values are column blocks of the decoder stack's ONE projection of the memory
+// (F_.SharedProj: row stride ldkv).  The training kernel (attn_f32_fwd_kernel: 64 queries x all keys per workgroup, four
+// workgroups for one utterance) took 19 us per layer here; this one is bound by the latency of ~250 keys.
+namespace {
+__global__ __launch_bounds__(64) void decode_src_attn_kernel(const float* __restrict__ q, long ldq, const float* __restrict__ Km,
+                                                             const float* __restrict__ Vm, long ldkv, const unsigned char* __restrict__ mask,
+                                                             int g, int T, int D, float* __restrict__ ctx, float scale) {
+  extern __shared__ float sc[];                 // [T] scores, then probabilities
+  const int h = blockIdx.x, row = blockIdx.y, lane = threadIdx.x;
+  const int u = row / g;                        // utterance of this hypothesis
+  const float* qr = q + (long)row * ldq + h * 64;
+  const float* kb = Km + (long)u * T * ldkv + h * 64;
+  const float* vb = Vm + (long)u * T * ldkv + h * 64;
+  const unsigned char* mk = mask ? mask + (long)u * T : nullptr;
+  float4 q4[16];
+#pragma unroll
+  for (int i = 0; i < 16; ++i) q4[i] = *reinterpret_cast<const float4*>(qr + 4 * i);
+  float mx = -INFINITY;
+  for (int t0 = 0; t0 < T; t0 += 64) {
+    const int t = t0 + lane;
+    if (t < T) {
+      const float4* kp = reinterpret_cast<const float4*>(kb + (long)t * ldkv);
+      float a = 0.f;
+#pragma unroll
+      for (int i = 0; i < 16; ++i) {
+        const float4 kv = kp[i];
+        a = fmaf(q4[i].x, kv.x, fmaf(q4[i].y, kv.y, fmaf(q4[i].z, kv.z, fmaf(q4[i].w, kv.w, a))));
+      }
+      a = (mk && !mk[t]) ? -INFINITY : a * scale;          // a masked frame: finfo.min -> softmax -> 0 (attention.py:80-88)
+      sc[t] = a;
+      mx = fmaxf(mx, a);
+    }
+  }
+  mx = wave_max(mx);
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+  float den = 0.f;
+  for (int t0 = 0; t0 < T; t0 += 64) {
+    const int t = t0 + lane;
+    if (t < T) {
+      const float e = (mx == -INFINITY) ? 0.f : __expf(sc[t] - mx);
+      sc[t] = e;
+      den += e;
+    }
+  }
+  den = wave_sum(den);
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+  float acc = 0.f;
+  int t = 0;
+  for (; t + 4 <= T; t += 4) {
+    float p[4], v[4];
+#pragma unroll
+    for (int w = 0; w < 4; ++w) {
+      p[w] = sc[t + w];
+      v[w] = vb[(long)(t + w) * ldkv + lane];
+    }
+#pragma unroll
+    for (int w = 0; w < 4; ++w) acc = fmaf(p[w], v[w], acc);
+  }
+  for (; t < T; ++t) acc = fmaf(sc[t], vb[(long)t * ldkv + lane], acc);
+  ctx[(long)row * D + h * 64 + lane] = den > 0.f ? acc / den : 0.f;        // every frame masked: zeros (attention.py:84-88)
+}
+}  // namespace
+
+extern "C" int eamd_decode_src_attn(const float* q, int64_t ldq, const float* kmem, const float* vmem, int64_t ldkv,
+                                    const uint8_t* mask, int nutt, int g, int T, int H, int D, float* ctx, void* stream) {
+  if (!q || !kmem || !vmem || !ctx || nutt <= 0 || g <= 0 || T <= 0 || H <= 0 || D <= 0) return EAMD_EINVAL;
+  if (ldq < D || ldkv < D) return EAMD_EINVAL;
+  if (D != H * 64 || T > 8192 || ldq % 4 != 0 || ldkv % 4 != 0 || (((uintptr_t)q | (uintptr_t)kmem | (uintptr_t)vmem) & 15))
+    return EAMD_EUNSUPPORTED;
+  hipLaunchKernelGGL(decode_src_attn_kernel, dim3(H, nutt * g), dim3(64), (size_t)T * 4, (hipStream_t)stream, q, (long)ldq, kmem, vmem,
+                     (long)ldkv, mask, g, T, D, ctx, 0.125f);
+  EAMD_LAUNCH_CHECK();
+  return EAMD_OK;
+}

@@ -1053,9 +1053,14 @@ class Decoder(torch.nn.Module, BatchScorerInterface):
             a = m.src_attn
             q2 = self._ln_rows(x, m.norm2, a.linear_q.weight, a.linear_q.bias)
             k2, v2 = sp.block(i, 0), sp.block(i, D)
-            fwd = F_.attn_fwd_fused(q2, None, k2, v2, None, mask, G, n // G, T, H, a.d_k) \
-                if (F_.FUSE_ATTN and ops.attn_fwd_supported(n // G, T, a.d_k, False)) else None
-            if fwd is not None:
+            cx = ops.decode_src_attn(q2, k2.t, k2.off, v2.off, k2.ld, mask, G, n // G, T, H) \
+                if (k2.t.dtype == torch.float32 and (mask is None or mask.shape[1] == 1)) else None
+            fwd = None
+            if cx is None and F_.FUSE_ATTN and ops.attn_fwd_supported(n // G, T, a.d_k, False):
+                fwd = F_.attn_fwd_fused(q2, None, k2, v2, None, mask, G, n // G, T, H, a.d_k)
+            if cx is not None:
+                pass
+            elif fwd is not None:
                 cx = fwd[2]
             else:
                 P = F_.attn_scores_fwd(q2, None, k2, None, mask, G, n // G, T, H, a.d_k)

@@ -1273,6 +1273,20 @@ def decode_self_attn(qkv, Kc, Vc, slot_at, pos, H):
     return ctx
 
 
+def decode_src_attn(q, kv, k_off, v_off, ldkv, mask, G, g, T, H):
+    """one query position per hypothesis over the memory of its utterance (eamd_decode_src_attn): q [G * g, D]; kv = the tensor
+    that holds keys / values of this layer at element offsets k_off / v_off, row stride ldkv ([G * T] rows); mask [G, 1, T] uint8
+    or None -> ctx [G * g, D], or None when the library declines"""
+    n, D = q.shape
+    ctx = torch.empty(n, D, device=q.device, dtype=torch.float32)
+    rc = _lib.lib().eamd_decode_src_attn(ptr(q), C.c_int64(q.stride(0)), ptr(kv, k_off), ptr(kv, v_off), C.c_int64(ldkv), ptr(mask),
+                                         G, g, T, H, D, ptr(ctx), stream_ptr())
+    if rc == _lib.EAMD_EUNSUPPORTED:
+        return None
+    check(rc, "eamd_decode_src_attn")
+    return ctx
+
+
 def beam_slots(slot_in, hyp, pos):
     """the slot table behind a beam step's selection: row i = row hyp[i] of slot_in with column `pos` set to hyp[i]"""
     n, Lcap = slot_in.shape

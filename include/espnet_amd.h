@@ -417,6 +417,13 @@ int eamd_linear_rows_ln_f32(const float* x, const float* gamma, const float* bet
 int eamd_decode_self_attn(const float* qkv, int64_t ldq, float* kcache, float* vcache, const int32_t* slot_at, int Lcap, int pos,
                           int n, int H, int D, float* ctx, void* stream);
 int eamd_beam_slots(const int32_t* slot_in, int32_t* slot_out, const int64_t* hyp, int n, int Lcap, int pos, void* stream);
+/* Source attention of a beam step (decoder_layer.py:109-121 on one query position per hypothesis): hypothesis r of nutt * g belongs to
+ * utterance r / g and attends over that utterance's T memory frames; kmem / vmem address the keys / values of ONE layer inside the
+ * decoder stack's shared projection of the memory ([nutt, T, ldkv] row stride ldkv); mask [nutt, T] uint8 (0 = padded frame, may be
+ * NULL); q [nutt * g, ldq]; ctx [nutt * g, D]; d_k = 64.  Masked frames get probability 0, an all-masked row gives zeros
+ * (attention.py:80-88). */
+int eamd_decode_src_attn(const float* q, int64_t ldq, const float* kmem, const float* vmem, int64_t ldkv, const uint8_t* mask, int nutt,
+                         int g, int T, int H, int D, float* ctx, void* stream);
 /* The selection of a beam step on the pre-beam candidates (reference: beam_search.py:296-334 with :199-226: tokens outside the pre-beam
  * are dropped, so an utterance's `beam` best continuations are among its beam x P candidates).
  * eamd_weighted_sum: out[i] = ((0 + w_0 logp_0[i]) + w_1 logp_1[i]) + ... over nf <= 4 full scorers ([n, V] each; numel = n V, a

@@ -1907,3 +1907,32 @@ def test_decode_kernels_vs_float64(ops):
         slot = ops.beam_slots(slot, hyp.to(DEV), pos)
         hist_k = [list(hist_k[int(h)]) for h in hyp]
         assert slot[:, pos].cpu().tolist() == hyp.tolist()
+
+
+def test_decode_src_attn_vs_float64(ops):
+    """eamd_decode_src_attn: one query position per hypothesis over the memory of its utterance (keys / values as column blocks of
+    a wider projection buffer, padded frames masked, one fully masked utterance) against float64 softmax attention"""
+    g = torch.Generator().manual_seed(21)
+    G, gb, T, H, D, L = 3, 5, 77, 4, 256, 2
+    kv = torch.randn(G * T, 2 * D * L, generator=g)             # [rows, layers x (k | v)]
+    q = torch.randn(G * gb, D, generator=g)
+    lens = [77, 40, 0]
+    mask = (torch.arange(T)[None, :] < torch.tensor(lens)[:, None]).to(torch.uint8).unsqueeze(1).contiguous()
+    for layer in range(L):
+        k_off, v_off = layer * 2 * D, layer * 2 * D + D
+        ctx = ops.decode_src_attn(q.to(DEV), kv.to(DEV), k_off, v_off, 2 * D * L, mask.to(DEV), G, gb, T, H)
+        want = torch.zeros(G * gb, D, dtype=torch.float64)
+        for r in range(G * gb):
+            u = r // gb
+            if lens[u] == 0:
+                continue
+            K = kv[u * T: u * T + lens[u], k_off:k_off + D].double().view(-1, H, 64)
+            Vv = kv[u * T: u * T + lens[u], v_off:v_off + D].double().view(-1, H, 64)
+            p = torch.softmax(torch.einsum("hd,thd->ht", q[r].double().view(H, 64), K) / 8.0, -1)
+            want[r] = torch.einsum("ht,thd->hd", p, Vv).reshape(D)
+        report("decode_src_attn layer %d" % layer, ctx, want, 2e-6)
+        assert float(ctx[2 * gb:].abs().max()) == 0.0
+    ctx = ops.decode_src_attn(q.to(DEV), kv.to(DEV), 0, D, 2 * D * L, None, G, gb, T, H)
+    K = kv[:T, :D].double().view(-1, H, 64)
+    p = torch.softmax(torch.einsum("hd,thd->ht", q[0].double().view(H, 64), K) / 8.0, -1)
+    report("decode_src_attn no mask", ctx[0], torch.einsum("ht,thd->hd", p, kv[:T, D:2 * D].double().view(-1, H, 64)).reshape(D), 2e-6)
