@@ -18,62 +18,81 @@
 
 namespace {
 
-// one wave per output column (rowops.hip: linear_rows_f32_kernel); K <= 1024 so that a lane holds its 16-byte pieces of every
-// input row in registers: the row statistics (mean, then the centred sum of squares: layernorm_fwd's arithmetic) come from the
-// same registers the dot products use.  Every wave normalises the M rows itself (M x K FMAs against N/4 workgroups: nothing).
+// one wave per output column (rowops.hip: linear_rows_f32_kernel), four columns per workgroup; K <= 1024: the M rows fit LDS whole.
 __global__ __launch_bounds__(256) void linear_rows_ln_f32_kernel(const float* __restrict__ x, const float* __restrict__ gam,
                                                                  const float* __restrict__ bet, float eps,
                                                                  const float* __restrict__ W, const float* __restrict__ bias,
                                                                  const float* __restrict__ R, float* __restrict__ y, int M, int N,
                                                                  int K, int act, float alpha, long ldx, long ldr, long ldy) {
-  const int lane = threadIdx.x & 63;
-  const int n = blockIdx.x * 4 + (threadIdx.x >> 6);
-  if (n >= N) return;
+  // the M rows are staged once per workgroup in LDS (all loads of the pass in flight together), wave w normalises rows w, w + 4, ...
+  // in place (mean, then the centred sum of squares: layernorm_fwd's arithmetic), then every wave multiplies them with its column
+  extern __shared__ __attribute__((aligned(16))) float xs_ln[];        // [M][K]
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const int n = min(blockIdx.x * 4 + w, N - 1);
+  const bool store = blockIdx.x * 4 + w < N;
   const float* wr = W + (long)n * K;
-  float4 w4[4], g4[4], b4[4];
+  float4 w4[4];
 #pragma unroll
   for (int q = 0; q < 4; ++q) {
     const int k = lane * 4 + 256 * q;
-    const bool in = k < K;
-    w4[q] = in ? *reinterpret_cast<const float4*>(wr + k) : make_float4(0.f, 0.f, 0.f, 0.f);
-    g4[q] = in ? *reinterpret_cast<const float4*>(gam + k) : make_float4(0.f, 0.f, 0.f, 0.f);
-    b4[q] = in ? *reinterpret_cast<const float4*>(bet + k) : make_float4(0.f, 0.f, 0.f, 0.f);
+    w4[q] = k < K ? *reinterpret_cast<const float4*>(wr + k) : make_float4(0.f, 0.f, 0.f, 0.f);
   }
+  const int c4 = K >> 2;
+  for (int idx = threadIdx.x; idx < M * c4; idx += 256) {
+    const int m = idx / c4, c = idx - m * c4;
+    *reinterpret_cast<float4*>(&xs_ln[m * K + c * 4]) = *reinterpret_cast<const float4*>(x + (long)m * ldx + c * 4);
+  }
+  __syncthreads();
+  for (int m = w; m < M; m += 4) {
+    float4 x4[4];
+    float s = 0.f;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int k = lane * 4 + 256 * q;
+      x4[q] = k < K ? *reinterpret_cast<const float4*>(&xs_ln[m * K + k]) : make_float4(0.f, 0.f, 0.f, 0.f);
+      s += (x4[q].x + x4[q].y) + (x4[q].z + x4[q].w);
+    }
+    const float mean = wave_sum(s) / K;
+    float c = 0.f;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int k = lane * 4 + 256 * q;
+      if (k < K) {
+        const float a0 = x4[q].x - mean, a1 = x4[q].y - mean, a2 = x4[q].z - mean, a3 = x4[q].w - mean;
+        c += (a0 * a0 + a1 * a1) + (a2 * a2 + a3 * a3);
+      }
+    }
+    const float rstd = rsqrtf(wave_sum(c) / K + eps);
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int k = lane * 4 + 256 * q;
+      if (k < K) {
+        const float4 g = *reinterpret_cast<const float4*>(gam + k), b = *reinterpret_cast<const float4*>(bet + k);
+        *reinterpret_cast<float4*>(&xs_ln[m * K + k]) =
+            make_float4((x4[q].x - mean) * rstd * g.x + b.x, (x4[q].y - mean) * rstd * g.y + b.y,
+                        (x4[q].z - mean) * rstd * g.z + b.z, (x4[q].w - mean) * rstd * g.w + b.w);
+      }
+    }
+  }
+  __syncthreads();
   float mine = 0.f;
 #pragma unroll
   for (int m = 0; m < 16; ++m) {
     if (m < M) {
-      float4 x4[4];
-      float s = 0.f;
-#pragma unroll
-      for (int q = 0; q < 4; ++q) {
-        const int k = lane * 4 + 256 * q;
-        x4[q] = k < K ? *reinterpret_cast<const float4*>(x + (long)m * ldx + k) : make_float4(0.f, 0.f, 0.f, 0.f);
-        s += (x4[q].x + x4[q].y) + (x4[q].z + x4[q].w);
-      }
-      const float mean = wave_sum(s) / K;
-      float c = 0.f;
+      float acc = 0.f;
 #pragma unroll
       for (int q = 0; q < 4; ++q) {
         const int k = lane * 4 + 256 * q;
         if (k < K) {
-          const float a0 = x4[q].x - mean, a1 = x4[q].y - mean, a2 = x4[q].z - mean, a3 = x4[q].w - mean;
-          c += (a0 * a0 + a1 * a1) + (a2 * a2 + a3 * a3);
+          const float4 v = *reinterpret_cast<const float4*>(&xs_ln[m * K + k]);
+          acc = fmaf(v.x, w4[q].x, fmaf(v.y, w4[q].y, fmaf(v.z, w4[q].z, fmaf(v.w, w4[q].w, acc))));
         }
-      }
-      const float rstd = rsqrtf(wave_sum(c) / K + eps);
-      float acc = 0.f;
-#pragma unroll
-      for (int q = 0; q < 4; ++q) {
-        const float v0 = (x4[q].x - mean) * rstd * g4[q].x + b4[q].x, v1 = (x4[q].y - mean) * rstd * g4[q].y + b4[q].y;
-        const float v2 = (x4[q].z - mean) * rstd * g4[q].z + b4[q].z, v3 = (x4[q].w - mean) * rstd * g4[q].w + b4[q].w;
-        acc = fmaf(v0, w4[q].x, fmaf(v1, w4[q].y, fmaf(v2, w4[q].z, fmaf(v3, w4[q].w, acc))));      // (padding lanes: w = 0)
       }
       const float r = wave_sum(acc);
       if (lane == m) mine = r;
     }
   }
-  if (lane < M) {
+  if (lane < M && store) {
     float v = mine + (bias ? bias[n] : 0.f);
     if (act == 1) v = fmaxf(v, 0.f);
     else if (act == 2) v = eamd_swish(v);
@@ -180,7 +199,8 @@ int eamd_linear_rows_ln_f32(const float* x, const float* gamma, const float* bet
   if (ldx < K || ldr < N || ldy < N) return EAMD_EINVAL;
   if (M > 16 || K > 1024 || K % 4 != 0 || ldx % 4 != 0 || act > 2) return EAMD_EUNSUPPORTED;
   if (((uintptr_t)x | (uintptr_t)W | (uintptr_t)gamma | (uintptr_t)beta) & 15) return EAMD_EUNSUPPORTED;
-  hipLaunchKernelGGL(linear_rows_ln_f32_kernel, dim3((N + 3) / 4), dim3(256), 0, (hipStream_t)stream, x, gamma, beta, eps, W, bias, R,
+  hipLaunchKernelGGL(linear_rows_ln_f32_kernel, dim3((N + 3) / 4), dim3(256), (size_t)M * K * sizeof(float), (hipStream_t)stream, x,
+                     gamma, beta, eps, W, bias, R,
                      y, M, N, K, act, alpha, (long)ldx, (long)ldr, (long)ldy);
   EAMD_LAUNCH_CHECK();
   return EAMD_OK;
@@ -342,11 +362,15 @@ int eamd_beam_select(const float* pre, const int64_t* ids, const float* psi, con
 // (F_.SharedProj: row stride ldkv).  The training kernel (attn_f32_fwd_kernel: 64 queries x all keys per workgroup, four
 // workgroups for one utterance) took 19 us per layer here; this one is bound by the latency of ~250 keys.
 namespace {
-__global__ __launch_bounds__(64) void decode_src_attn_kernel(const float* __restrict__ q, long ldq, const float* __restrict__ Km,
-                                                             const float* __restrict__ Vm, long ldkv, const unsigned char* __restrict__ mask,
-                                                             int g, int T, int D, float* __restrict__ ctx, float scale) {
-  extern __shared__ float sc[];                 // [T] scores, then probabilities
-  const int h = blockIdx.x, row = blockIdx.y, lane = threadIdx.x;
+__global__ __launch_bounds__(256) void decode_src_attn_kernel(const float* __restrict__ q, long ldq, const float* __restrict__ Km,
+                                                              const float* __restrict__ Vm, long ldkv, const unsigned char* __restrict__ mask,
+                                                              int g, int T, int D, float* __restrict__ ctx, float scale) {
+  // four waves per (hypothesis, head): thread = key for the scores (a trip covers 256 keys), wave w walks keys w, w + 4, ... with
+  // eight value rows in flight for the context (one wave walking 249 keys four at a time took 25 us: 62 dependent round trips)
+  extern __shared__ float sc[];                 // [T] scores, then probabilities; [4][64] partial contexts; 8 reduction slots
+  float* part = sc + T;
+  float* red = part + 256;
+  const int h = blockIdx.x, row = blockIdx.y, t_ = threadIdx.x, lane = t_ & 63, w = t_ >> 6;
   const int u = row / g;                        // utterance of this hypothesis
   const float* qr = q + (long)row * ldq + h * 64;
   const float* kb = Km + (long)u * T * ldkv + h * 64;
@@ -356,52 +380,51 @@ __global__ __launch_bounds__(64) void decode_src_attn_kernel(const float* __rest
 #pragma unroll
   for (int i = 0; i < 16; ++i) q4[i] = *reinterpret_cast<const float4*>(qr + 4 * i);
   float mx = -INFINITY;
-  for (int t0 = 0; t0 < T; t0 += 64) {
-    const int t = t0 + lane;
-    if (t < T) {
-      const float4* kp = reinterpret_cast<const float4*>(kb + (long)t * ldkv);
-      float a = 0.f;
+  for (int t = t_; t < T; t += 256) {
+    const float4* kp = reinterpret_cast<const float4*>(kb + (long)t * ldkv);
+    float a = 0.f;
 #pragma unroll
-      for (int i = 0; i < 16; ++i) {
-        const float4 kv = kp[i];
-        a = fmaf(q4[i].x, kv.x, fmaf(q4[i].y, kv.y, fmaf(q4[i].z, kv.z, fmaf(q4[i].w, kv.w, a))));
-      }
-      a = (mk && !mk[t]) ? -INFINITY : a * scale;          // a masked frame: finfo.min -> softmax -> 0 (attention.py:80-88)
-      sc[t] = a;
-      mx = fmaxf(mx, a);
+    for (int i = 0; i < 16; ++i) {
+      const float4 kv = kp[i];
+      a = fmaf(q4[i].x, kv.x, fmaf(q4[i].y, kv.y, fmaf(q4[i].z, kv.z, fmaf(q4[i].w, kv.w, a))));
     }
+    a = (mk && !mk[t]) ? -INFINITY : a * scale;          // a masked frame: finfo.min -> softmax -> 0 (attention.py:80-88)
+    sc[t] = a;
+    mx = fmaxf(mx, a);
   }
   mx = wave_max(mx);
-  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-  __builtin_amdgcn_wave_barrier();
-  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+  if (lane == 0) red[w] = mx;
+  __syncthreads();
+  mx = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
   float den = 0.f;
-  for (int t0 = 0; t0 < T; t0 += 64) {
-    const int t = t0 + lane;
-    if (t < T) {
-      const float e = (mx == -INFINITY) ? 0.f : __expf(sc[t] - mx);
-      sc[t] = e;
-      den += e;
-    }
+  for (int t = t_; t < T; t += 256) {
+    const float e = (mx == -INFINITY) ? 0.f : __expf(sc[t] - mx);
+    sc[t] = e;
+    den += e;
   }
   den = wave_sum(den);
-  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-  __builtin_amdgcn_wave_barrier();
-  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+  if (lane == 0) red[4 + w] = den;
+  __syncthreads();
+  den = (red[4] + red[5]) + (red[6] + red[7]);
   float acc = 0.f;
-  int t = 0;
-  for (; t + 4 <= T; t += 4) {
-    float p[4], v[4];
+  int t = w;
+  for (; t + 28 < T; t += 32) {
+    float p[8], v[8];
 #pragma unroll
-    for (int w = 0; w < 4; ++w) {
-      p[w] = sc[t + w];
-      v[w] = vb[(long)(t + w) * ldkv + lane];
+    for (int k = 0; k < 8; ++k) {
+      p[k] = sc[t + 4 * k];
+      v[k] = vb[(long)(t + 4 * k) * ldkv + lane];
     }
 #pragma unroll
-    for (int w = 0; w < 4; ++w) acc = fmaf(p[w], v[w], acc);
+    for (int k = 0; k < 8; ++k) acc = fmaf(p[k], v[k], acc);
   }
-  for (; t < T; ++t) acc = fmaf(sc[t], vb[(long)t * ldkv + lane], acc);
-  ctx[(long)row * D + h * 64 + lane] = den > 0.f ? acc / den : 0.f;        // every frame masked: zeros (attention.py:84-88)
+  for (; t < T; t += 4) acc = fmaf(sc[t], vb[(long)t * ldkv + lane], acc);
+  part[w * 64 + lane] = acc;
+  __syncthreads();
+  if (w == 0) {
+    const float s = (part[lane] + part[64 + lane]) + (part[128 + lane] + part[192 + lane]);
+    ctx[(long)row * D + h * 64 + lane] = den > 0.f ? s / den : 0.f;        // every frame masked: zeros (attention.py:84-88)
+  }
 }
 }  // namespace
 
@@ -411,7 +434,7 @@ extern "C" int eamd_decode_src_attn(const float* q, int64_t ldq, const float* km
   if (ldq < D || ldkv < D) return EAMD_EINVAL;
   if (D != H * 64 || T > 8192 || ldq % 4 != 0 || ldkv % 4 != 0 || (((uintptr_t)q | (uintptr_t)kmem | (uintptr_t)vmem) & 15))
     return EAMD_EUNSUPPORTED;
-  hipLaunchKernelGGL(decode_src_attn_kernel, dim3(H, nutt * g), dim3(64), (size_t)T * 4, (hipStream_t)stream, q, (long)ldq, kmem, vmem,
+  hipLaunchKernelGGL(decode_src_attn_kernel, dim3(H, nutt * g), dim3(256), (size_t)(T + 256 + 8) * 4, (hipStream_t)stream, q, (long)ldq, kmem, vmem,
                      (long)ldkv, mask, g, T, D, ctx, 0.125f);
   EAMD_LAUNCH_CHECK();
   return EAMD_OK;

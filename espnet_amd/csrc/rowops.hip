@@ -738,41 +738,50 @@ __global__ __launch_bounds__(256) void log_softmax_rows_kernel(const float* __re
 // products meet in a wave reduction, lane m finishes row m.  Exact fp32 arithmetic, summation order (lane-strided partial sums,
 // then the wave tree) differs from the MFMA kernels'.
 namespace {
+// (round 4) the M input rows are staged ONCE per workgroup in LDS, every load of the staging pass in flight together: with each
+// wave fetching row after row from global memory the launch was ten dependent round trips long (12 us for 10 x 256 x 256).
+constexpr int ROWS_KC = 1024;          // reduction chunk staged at a time: 16 rows x 1024 floats = 64 KB of LDS
 __global__ __launch_bounds__(256) void linear_rows_f32_kernel(const float* __restrict__ x, const float* __restrict__ W,
                                                               const float* __restrict__ bias, const float* __restrict__ R,
                                                               float* __restrict__ y, int M, int N, int K, int a_act, int act,
                                                               float alpha, long ldx, long ldr) {
+  extern __shared__ __attribute__((aligned(16))) float xs_rows[];      // [M][kc]
   const int lane = threadIdx.x & 63;
-  const int n = blockIdx.x * 4 + (threadIdx.x >> 6);
-  if (n >= N) return;
+  const int n = min(blockIdx.x * 4 + (int)(threadIdx.x >> 6), N - 1);  // (surplus waves of the last workgroup redo column N - 1)
+  const bool store = blockIdx.x * 4 + (int)(threadIdx.x >> 6) < N;
   float acc[16];
 #pragma unroll
   for (int m = 0; m < 16; ++m) acc[m] = 0.f;
   const float* wr = W + (long)n * K;
-  // four 16-byte pieces of the weight row per trip, requested together (K = 2048: two trips instead of eight dependent ones)
-  for (int k0 = lane * 4; k0 < K; k0 += 1024) {
+  for (int kb = 0; kb < K; kb += ROWS_KC) {
+    const int kc = min(ROWS_KC, K - kb);
     float4 w4[4];
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
-      const int k = k0 + 256 * q;
-      w4[q] = k < K ? *reinterpret_cast<const float4*>(wr + k) : make_float4(0.f, 0.f, 0.f, 0.f);
+      const int k = lane * 4 + 256 * q;
+      w4[q] = k < kc ? *reinterpret_cast<const float4*>(wr + kb + k) : make_float4(0.f, 0.f, 0.f, 0.f);
     }
+    if (kb > 0) __syncthreads();
+    const int c4 = kc >> 2;
+    for (int idx = threadIdx.x; idx < M * c4; idx += 256) {
+      const int m = idx / c4, c = idx - m * c4;
+      float4 v = *reinterpret_cast<const float4*>(x + (long)m * ldx + kb + c * 4);
+      if (a_act != EAMD_ACT_NONE) {
+        v.x = eamd_act(v.x, a_act); v.y = eamd_act(v.y, a_act); v.z = eamd_act(v.z, a_act); v.w = eamd_act(v.w, a_act);
+      }
+      *reinterpret_cast<float4*>(&xs_rows[m * kc + c * 4]) = v;
+    }
+    __syncthreads();
 #pragma unroll
     for (int m = 0; m < 16; ++m) {
       if (m < M) {
-        float4 x4[4];
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
-          const int k = k0 + 256 * q;
-          x4[q] = k < K ? *reinterpret_cast<const float4*>(x + (long)m * ldx + k) : make_float4(0.f, 0.f, 0.f, 0.f);
-        }
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-          float4 v = x4[q];
-          if (a_act != EAMD_ACT_NONE) {
-            v.x = eamd_act(v.x, a_act); v.y = eamd_act(v.y, a_act); v.z = eamd_act(v.z, a_act); v.w = eamd_act(v.w, a_act);
+          const int k = lane * 4 + 256 * q;
+          if (k < kc) {
+            const float4 v = *reinterpret_cast<const float4*>(&xs_rows[m * kc + k]);
+            acc[m] = fmaf(v.x, w4[q].x, fmaf(v.y, w4[q].y, fmaf(v.z, w4[q].z, fmaf(v.w, w4[q].w, acc[m]))));
           }
-          acc[m] = fmaf(v.x, w4[q].x, fmaf(v.y, w4[q].y, fmaf(v.z, w4[q].z, fmaf(v.w, w4[q].w, acc[m]))));
         }
       }
     }
@@ -785,7 +794,7 @@ __global__ __launch_bounds__(256) void linear_rows_f32_kernel(const float* __res
       if (lane == m) mine = r;
     }
   }
-  if (lane < M) {
+  if (lane < M && store) {
     float v = mine + (bias ? bias[n] : 0.f);
     if (act == 1) v = fmaxf(v, 0.f);
     else if (act == 2) v = eamd_swish(v);
@@ -1216,15 +1225,16 @@ int eamd_linear_rows_f32(const float* x, const float* W, const float* bias, cons
   if (ldx < K || ldr < N) return EAMD_EINVAL;
   if (M > 1024 || K % 4 != 0 || ldx % 4 != 0 || a_act > EAMD_ACT_SWISH || act > 2) return EAMD_EUNSUPPORTED;
   if (((uintptr_t)x | (uintptr_t)W) & 15) return EAMD_EUNSUPPORTED;
-  if (M > 16) {
+  static const int rows_mfma = getenv("EAMD_ROWS_MFMA") ? atoi(getenv("EAMD_ROWS_MFMA")) : 0;      // A/B knob: the 16 x 16 tiles for M <= 16 too
+  if (M > 16 || (rows_mfma && K % 16 == 0)) {
     if (K % 16 != 0) return EAMD_EUNSUPPORTED;
     hipLaunchKernelGGL(linear_mfma16_f32_kernel, dim3((N + 63) / 64, (M + 15) / 16), dim3(256), 0, (hipStream_t)stream, x, W, bias,
                        R, y, M, N, K, a_act, act, alpha, (long)ldx, (long)ldr);
     EAMD_LAUNCH_CHECK();
     return EAMD_OK;
   }
-  hipLaunchKernelGGL(linear_rows_f32_kernel, dim3((N + 3) / 4), dim3(256), 0, (hipStream_t)stream, x, W, bias, R, y, M, N, K,
-                     a_act, act, alpha, (long)ldx, (long)ldr);
+  hipLaunchKernelGGL(linear_rows_f32_kernel, dim3((N + 3) / 4), dim3(256), (size_t)M * (K < ROWS_KC ? K : ROWS_KC) * sizeof(float),
+                     (hipStream_t)stream, x, W, bias, R, y, M, N, K, a_act, act, alpha, (long)ldx, (long)ldr);
   EAMD_LAUNCH_CHECK();
   return EAMD_OK;
 }
