@@ -1053,8 +1053,10 @@ class Decoder(torch.nn.Module, BatchScorerInterface):
             a = m.src_attn
             q2 = self._ln_rows(x, m.norm2, a.linear_q.weight, a.linear_q.bias)
             k2, v2 = sp.block(i, 0), sp.block(i, D)
+            # a handful of hypotheses: one wave group per (hypothesis, head); many (32 utterances x beam 10) re-read an utterance's
+            # keys / values once per hypothesis that way (431 -> 360 utt/s) - those keep the 64-queries-per-workgroup kernel
             cx = ops.decode_src_attn(q2, k2.t, k2.off, v2.off, k2.ld, mask, G, n // G, T, H) \
-                if (k2.t.dtype == torch.float32 and (mask is None or mask.shape[1] == 1)) else None
+                if (n <= 32 and k2.t.dtype == torch.float32 and (mask is None or mask.shape[1] == 1)) else None
             fwd = None
             if cx is None and F_.FUSE_ATTN and ops.attn_fwd_supported(n // G, T, a.d_k, False):
                 fwd = F_.attn_fwd_fused(q2, None, k2, v2, None, mask, G, n // G, T, H, a.d_k)
