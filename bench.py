@@ -341,7 +341,7 @@ def run_precision(a, prec, rank, world, dev):
             traffic_src = os.path.basename(traffic_src)
         except Exception:  # noqa: BLE001
             traffic = None
-        kern = ("gemm_f32_kernel<*> (+ gemm_kernel<*> for unaligned operands) + ffn_f32_direct_kernel<*> (fused position-wise FFN) + attn_f32_{fwd,bwd_q,bwd_kv}_kernel: every MFMA contraction, v_mfma_f32_16x16x4_f32"
+        kern = ("gemm_f32_kernel<*> (+ gemm_kernel<*> for unaligned operands) + ffn_f32_direct_kernel<*> (fused position-wise FFN) + rowproj_f32_kernel<*> (row-block projections, LayerNorm forward / backward inside) + attn_f32_{fwd,bwd_q,bwd_kv}_kernel: every MFMA contraction, v_mfma_f32_16x16x4_f32"
                 if prec == "fp32" else "gemm_bf16_*_kernel<*> + ffn_bf16_kernel<*> (fused position-wise FFN) + attn_{fwd,bwd_q,bwd_kv}_kernel: every MFMA contraction, v_mfma_f32_16x16x32_bf16")
         roof = dict(bound="mfma", achieved=round(ach, 2), peak=PEAK_TFLOPS[prec], unit="TFLOP/s",
                     frac=round(ach / PEAK_TFLOPS[prec], 4), traffic=traffic,
