@@ -1,3 +1,5 @@
+"""eamd_weighted_sum / eamd_beam_select against the tensor expressions they replace, bit for bit (the probe that showed hipcc fusing
+a * b + c inside the kernel: DESIGN.md section 4, round 4).  usage: python tools/beam_select_probe.py"""
 import sys, torch
 sys.path.insert(0, "/root/repo")
 from espnet_amd import ops
