@@ -37,7 +37,8 @@ for d in sorted(glob.glob(os.path.join(src, "pmc_*"))):
     for (k, c), (n, s) in agg.items():
         t = tot.setdefault(c, dict(gemm=[0, 0.0], all=[0, 0.0]))
         t["all"][0] += n; t["all"][1] += s
-        if "gemm" in k or "attn_" in k or ("ffn_" in k and "pack" not in k):      # the MFMA-contraction family: GEMM kernels, fused FFN, fused attention
+        # the MFMA-contraction family: GEMM kernels, fused FFN, row-block projections, fused attention (not the decode kernels)
+        if ("gemm" in k or "attn_" in k or ("ffn_" in k and "pack" not in k) or "rowproj_f32_kernel" in k) and "decode_" not in k:
             t["gemm"][0] += n; t["gemm"][1] += s
 if "FETCH_SIZE" in tot and "WRITE_SIZE" in tot:
     steps = tot["FETCH_SIZE"]["gemm"][0] / lps
