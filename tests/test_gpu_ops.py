@@ -1936,3 +1936,34 @@ def test_decode_src_attn_vs_float64(ops):
     K = kv[:T, :D].double().view(-1, H, 64)
     p = torch.softmax(torch.einsum("hd,thd->ht", q[0].double().view(H, 64), K) / 8.0, -1)
     report("decode_src_attn no mask", ctx[0], torch.einsum("ht,thd->hd", p, kv[:T, D:2 * D].double().view(-1, H, 64)).reshape(D), 2e-6)
+
+
+def test_graph_audit_rejects_memset_nodes():
+    """espnet_amd.graphs.audit: a captured graph that holds a MEMSET node is refused (on this ROCm such a node replays wrongly from
+    the second launch on: profiles/r04_graph_census.txt, DESIGN.md section 2 "Round 4").  torch.topk's multi-block path ([320, 5000])
+    zeroes its counters with memsets - the op whose step graphs faulted in round 3; its single-block path and our own selection
+    kernel capture kernels only.  Nothing captured here is ever replayed."""
+    from espnet_amd import _lib, graphs, ops as o
+    x320 = torch.randn(320, 5000, device=DEV)
+    x10 = torch.randn(10, 5000, device=DEV)
+
+    def capture(fn):
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            fn()
+        torch.cuda.current_stream().wait_stream(side)
+        torch.cuda.synchronize()
+        g = graphs.new_graph()
+        with torch.cuda.graph(g):
+            fn()
+        return g
+
+    kinds, memsets = graphs.node_census(capture(lambda: torch.topk(x320, 10, dim=-1)))
+    print("[parity] torch.topk [320, 5000] captured as", kinds, memsets)
+    assert kinds.get("memset", 0) >= 1 and len(memsets) == kinds["memset"]
+    with pytest.raises(_lib.EamdError):
+        graphs.audit(capture(lambda: torch.topk(x320, 10, dim=-1)), "a graph with torch.topk's multi-block path")
+    assert "memset" not in graphs.audit(capture(lambda: torch.topk(x10, 15, dim=-1)))
+    assert graphs.audit(capture(lambda: o.topk_rows(x320, 10))) == {"kernel": 1}
+    assert graphs.capture_id() == 0
