@@ -108,13 +108,13 @@ _lib = None
 # every symbol include/espnet_amd.h declares (tests check they are all exported)
 SYMBOLS = [
     "eamd_abi_version", "eamd_gemm", "eamd_gemm_multi", "eamd_gemm_group_plan", "eamd_gemm_group_launch", "eamd_ffn_fwd", "eamd_ffn_bwd", "eamd_ffn_pack_f32", "eamd_ffn_pack_bf16", "eamd_ffn_pack_f32_multi", "eamd_rowproj", "eamd_rowproj_pack_f32", "eamd_rowproj_lnb_workspace", "eamd_layernorm_fwd", "eamd_layernorm_bwd_workspace", "eamd_layernorm_bwd_drop_f32", "eamd_layernorm_bwd", "eamd_layernorm_bwd_reduce", "eamd_attn_fwd", "eamd_attn_bwd_q", "eamd_attn_fwd_f32", "eamd_attn_bwd_q_f32", "eamd_attn_bwd_kv_f32", "eamd_attn_bwd_kv", "eamd_softmax_fwd",
-    "eamd_softmax_bwd", "eamd_lsm_loss", "eamd_argmax_rows", "eamd_reduce_sum", "eamd_log_softmax_rows", "eamd_topk_rows", "eamd_linear_rows_f32", "eamd_linear_rows_ln_f32", "eamd_decode_self_attn", "eamd_beam_slots", "eamd_decode_src_attn", "eamd_weighted_sum", "eamd_beam_select", "eamd_beam_finish",
+    "eamd_softmax_bwd", "eamd_lsm_loss", "eamd_argmax_rows", "eamd_reduce_sum", "eamd_log_softmax_rows", "eamd_topk_rows", "eamd_topk_rows_i32", "eamd_beam_step", "eamd_embed_pe_ld", "eamd_linear_rows_f32", "eamd_linear_rows_ln_f32", "eamd_decode_self_attn", "eamd_beam_slots", "eamd_decode_src_attn", "eamd_weighted_sum", "eamd_beam_select", "eamd_beam_finish",
     "eamd_axpby", "eamd_cast_bf16", "eamd_scale_dev", "eamd_act_fwd", "eamd_act_bwd", "eamd_glu_fwd", "eamd_glu_bwd",
     "eamd_add_bias2", "eamd_add_cast_bf16", "eamd_add_block_f32", "eamd_add_cast_colsum2", "eamd_add_colsum2_f32", "eamd_colsum", "eamd_embed_pe", "eamd_embed_bwd", "eamd_posenc", "eamd_posenc_scaled", "eamd_posenc_scaled_bwd", "eamd_permute4",
     "eamd_dropout", "eamd_rng_advance", "eamd_dwconv_fwd", "eamd_dwconv_glu_fwd", "eamd_dwconv_glu_bwd_x", "eamd_dwconv_glu_bwd_w", "eamd_dwconv_bwd_x", "eamd_dwconv_bwd_w", "eamd_bn_nslab",
     "eamd_bn_stats", "eamd_bn_finalize", "eamd_bn_apply", "eamd_bn_bwd", "eamd_bn_stats_bounded", "eamd_bn_bwd_bounded", "eamd_mask_time", "eamd_conv1_fwd", "eamd_conv1_bwd_w_workspace", "eamd_conv1_bwd_w",
     "eamd_conv2_weight_prep", "eamd_conv2_weight_grad", "eamd_add_sos_eos", "eamd_ctc_collapse",
-    "eamd_ctc_workspace_bytes", "eamd_ctc_loss", "eamd_ctc_prefix_score", "eamd_ctc_prefix_score_batch", "eamd_grad_norm", "eamd_sched_step", "eamd_adam_step", "eamd_adadelta_step", "eamd_add_gradient_noise",
+    "eamd_ctc_workspace_bytes", "eamd_ctc_loss", "eamd_ctc_prefix_score", "eamd_ctc_prefix_score_batch", "eamd_ctc_prefix_psi", "eamd_ctc_prefix_state", "eamd_grad_norm", "eamd_sched_step", "eamd_adam_step", "eamd_adadelta_step", "eamd_add_gradient_noise",
     "eamd_specaug", "eamd_global_mvn", "eamd_utterance_mvn", "eamd_reflect_pad", "eamd_logmel", "eamd_unfold1d", "eamd_fold1d", "eamd_attloc_convmax_fwd", "eamd_attloc_convmax_bwd", "eamd_layernorm_bwd_drop",
     "eamd_lstm_cell_fwd", "eamd_lstm_cell_bwd", "eamd_lstm_step_fwd", "eamd_lstm_step_bwd", "eamd_lstm_seq_sync_bytes", "eamd_lstm_seq_fwd", "eamd_lstm_seq_bwd", "eamd_lstm_seq_status", "eamd_lstm_seq_status_merge", "eamd_gru_cell_fwd", "eamd_gru_cell_bwd", "eamd_maxpool2x2_fwd", "eamd_maxpool2x2_bwd", "eamd_mask_rows",
     "eamd_joint_fwd", "eamd_joint_bwd", "eamd_rnnt_workspace", "eamd_rnnt_loss", "eamd_rnnt_grad", "eamd_rnnt_node_stats", "eamd_rnnt_node_stats_part", "eamd_rnnt_row_coef", "eamd_rnnt_alpha_beta", "eamd_rnnt_node_grad",

@@ -466,6 +466,225 @@ __global__ void ctc_prefix_batch_kernel(const float* __restrict__ logp_all, cons
 }
 }  // namespace
 
+// ---- the same scores without the serial chain on a beam step's critical path ------------------------------------------------
+// log psi of a candidate is logsumexp over t of (phi(t-1) + x(t)) (ctc_prefix_score.py:290-296: log_psi never reads r[t]): a
+// PARALLEL reduction over the frames.  Only the forward variables r^n / r^b of the NEXT step need the frame-by-frame recursion,
+// and only for the `beam` continuations that survive the selection - so a step scores its candidates with ctc_prefix_psi_kernel
+// (one wave per (hypothesis, candidate), lanes over frames) and the survivors' states are made by ctc_prefix_state_kernel at the
+// START of the next step, on a second stream beside the decoder stack (160 us of serial recursion off the critical path).
+namespace {
+__global__ __launch_bounds__(64) void ctc_prefix_psi_kernel(const float* __restrict__ logp_all, const int* __restrict__ lens, int per_utt,
+                                                            const float* __restrict__ r_prev, const int* __restrict__ cand,
+                                                            const int* __restrict__ last, int ol, float* __restrict__ psi, int Tmax,
+                                                            int V, int ncand, int blank, int eos) {
+  const int j = blockIdx.x, h = blockIdx.y, lane = threadIdx.x;
+  const int u = h / per_utt;
+  const int T = min(max(lens[u], 1), Tmax);
+  const float* logp = logp_all + (long)u * Tmax * V;
+  const int c = cand[(long)h * ncand + j];
+  if (c < 0 || c >= V) { if (lane == 0) psi[(long)h * ncand + j] = __builtin_nanf(""); return; }
+  const float* rp = r_prev + (long)h * Tmax * 2;
+  ol = min(max(ol, 0), T);
+  const bool same = ol > 0 && last[h] == c;
+  const int start = max(ol, 1);
+  // terms phi(t-1) + x(t), t = start .. T-1, and the initial r[start-1, 0]; two passes: maximum, then the sum of exponentials
+  float term[8];                                   // Tmax <= 512 frames per wave (host check)
+  float mx = (ol == 0 && lane == 0) ? logp[c] : kLogZero;
+  const float init = mx;
+#pragma unroll
+  for (int q = 0; q < 8; ++q) {
+    const int t = start + lane + 64 * q;
+    term[q] = -INFINITY;
+    if (t < T) {
+      const float pn = rp[2 * (t - 1)], pb = rp[2 * (t - 1) + 1];
+      const float m = fmaxf(pn, pb);
+      const float phi = same ? pb : (m == -INFINITY ? -INFINITY : m + log1pf(expf(-fabsf(pn - pb))));
+      term[q] = phi + logp[(long)t * V + c];
+      mx = fmaxf(mx, term[q]);
+    }
+  }
+  mx = wave_max(mx);
+  float se = lane == 0 ? expf(init - mx) : 0.f;
+#pragma unroll
+  for (int q = 0; q < 8; ++q) se += (term[q] == -INFINITY) ? 0.f : expf(term[q] - mx);
+  se = wave_sum(se);
+  if (lane == 0) {
+    float lpsi = mx == -INFINITY ? -INFINITY : mx + logf(se);
+    if (c == eos) lpsi = lae(rp[2 * (T - 1)], rp[2 * (T - 1) + 1]);
+    if (c == blank) lpsi = kLogZero;
+    psi[(long)h * ncand + j] = lpsi;
+  }
+}
+
+// forward variables of the surviving continuations: slot s continues the hypothesis of slot parent[s] with token tok[s]; the
+// recursion of ctc_prefix_batch_kernel for that one (hypothesis, candidate) pair, written straight into r_out[s] ([n, Tmax, 2]).
+// dead[s] != 0 (an ended or empty slot): the row is filled with log-zero.
+__global__ __launch_bounds__(64) void ctc_prefix_state_kernel(const float* __restrict__ logp_all, const int* __restrict__ lens, int per_utt,
+                                                              const float* __restrict__ r_prev, const long long* __restrict__ parent,
+                                                              const long long* __restrict__ tok, const int* __restrict__ last, int ol,
+                                                              const float* __restrict__ alive, float* __restrict__ r_out, int n, int Tmax,
+                                                              int V, int blank) {
+  const int s = blockIdx.x * 64 + threadIdx.x;
+  if (s >= n) return;
+  const int u = s / per_utt;
+  const int T = min(max(lens[u], 1), Tmax);
+  const float* logp = logp_all + (long)u * Tmax * V;
+  float* rn = r_out + (long)s * Tmax * 2;
+  long long hh = parent[s];
+  hh = hh < 0 ? 0 : (hh >= n ? n - 1 : hh);
+  const int c = (int)tok[s];
+  if (c < 0 || c >= V || !(alive[s] > -INFINITY)) {                      // nothing continues in this slot
+    for (int t = 0; t < T; ++t) *reinterpret_cast<float2*>(rn + 2 * t) = make_float2(kLogZero, kLogZero);
+    return;
+  }
+  const float* rp = r_prev + hh * Tmax * 2;
+  ol = min(max(ol, 0), T);
+  const bool same = ol > 0 && last[hh] == c;
+  const int start = max(ol, 1);
+  for (int t = 0; t < min(start - 1, T); ++t) *reinterpret_cast<float2*>(rn + 2 * t) = make_float2(kLogZero, kLogZero);
+  float rn_n, rn_b;
+  if (ol == 0) { rn_n = logp[c]; rn_b = kLogZero; }
+  else { rn_n = kLogZero; rn_b = kLogZero; }
+  if (start - 1 < T) *reinterpret_cast<float2*>(rn + 2 * (start - 1)) = make_float2(rn_n, rn_b);
+  constexpr int PF = 8;
+  for (int t0 = start; t0 < T; t0 += PF) {
+    float xv[PF], bv[PF], phi[PF];
+#pragma unroll
+    for (int q = 0; q < PF; ++q) {
+      const int t = min(t0 + q, T - 1);
+      xv[q] = logp[(long)t * V + c];
+      bv[q] = logp[(long)t * V + blank];
+      const float pn = rp[2 * (t - 1)], pb = rp[2 * (t - 1) + 1];
+      phi[q] = same ? pb : lae(pn, pb);
+    }
+#pragma unroll
+    for (int q = 0; q < PF; ++q) {
+      const int t = t0 + q;
+      if (t < T) {
+        const float nn = lae(rn_n, phi[q]) + xv[q];
+        const float nb = lae(rn_n, rn_b) + bv[q];
+        rn_n = nn; rn_b = nb;
+        *reinterpret_cast<float2*>(rn + 2 * t) = make_float2(nn, nb);
+      }
+    }
+  }
+}
+
+// The same forward variables as a PARALLEL scan (Tmax <= 512): r^n does not read r^b -
+//   r^n(t) = logaddexp(x(t) + r^n(t-1), x(t) + phi(t-1)),   then   r^b(t) = logaddexp(b(t) + r^b(t-1), b(t) + r^n(t-1))
+// are two scalar recurrences s(t) = logaddexp(a(t) + s(t-1), c(t)); maps (a, c) compose as (a2 + a1, logaddexp(a2 + c1, c2)).
+// One wave per slot, a lane owns eight consecutive frames: inclusive maps inside the lane, a six-step scan of the lanes' totals,
+// then every frame applies its map to the state entering the lane - ~16 dependent logaddexp per recurrence instead of one per
+// frame (130 us -> a few us at T = 249).  Same quantities; the order of the additions differs from the frame-by-frame recursion
+// (both are within 1e-5 + 2e-6 |ref| of float64: test_ctc_prefix_score_vs_float64).
+struct ScanMap { float a, c; };
+__device__ __forceinline__ ScanMap scan_after(ScanMap later, ScanMap earlier) {     // later o earlier
+  return ScanMap{later.a + earlier.a, lae(later.a + earlier.c, later.c)};
+}
+__device__ __forceinline__ ScanMap wave_scan_exclusive(ScanMap tot, int lane) {
+  ScanMap inc = tot;
+#pragma unroll
+  for (int d = 1; d < 64; d <<= 1) {
+    ScanMap o{__shfl_up(inc.a, d, 64), __shfl_up(inc.c, d, 64)};
+    if (lane >= d) inc = scan_after(inc, o);
+  }
+  ScanMap ex{__shfl_up(inc.a, 1, 64), __shfl_up(inc.c, 1, 64)};
+  if (lane == 0) ex = ScanMap{0.f, -INFINITY};
+  return ex;
+}
+__global__ __launch_bounds__(64) void ctc_prefix_state_scan_kernel(const float* __restrict__ logp_all, const int* __restrict__ lens,
+                                                                   int per_utt, const float* __restrict__ r_prev,
+                                                                   const long long* __restrict__ parent, const long long* __restrict__ tok,
+                                                                   const int* __restrict__ last, int ol, const float* __restrict__ alive,
+                                                                   float* __restrict__ r_out, int n, int Tmax, int V, int blank) {
+  const int s = blockIdx.x, lane = threadIdx.x;
+  const int u = s / per_utt;
+  const int T = min(max(lens[u], 1), Tmax);
+  const float* logp = logp_all + (long)u * Tmax * V;
+  float* rn = r_out + (long)s * Tmax * 2;
+  long long hh = parent[s];
+  hh = hh < 0 ? 0 : (hh >= n ? n - 1 : hh);
+  const int c = (int)tok[s];
+  if (c < 0 || c >= V || !(alive[s] > -INFINITY)) {                      // nothing continues in this slot
+    for (int t = lane; t < T; t += 64) *reinterpret_cast<float2*>(rn + 2 * t) = make_float2(kLogZero, kLogZero);
+    return;
+  }
+  const float* rp = r_prev + hh * Tmax * 2;
+  ol = min(max(ol, 0), T);
+  const bool same = ol > 0 && last[hh] == c;
+  const int start = max(ol, 1);
+  for (int t = lane; t < min(start - 1, T); t += 64) *reinterpret_cast<float2*>(rn + 2 * t) = make_float2(kLogZero, kLogZero);
+  const float n0 = ol == 0 ? logp[c] : kLogZero, b0 = kLogZero;
+  if (lane == 0 && start - 1 < T) *reinterpret_cast<float2*>(rn + 2 * (start - 1)) = make_float2(n0, b0);
+  constexpr int Q = 8;
+  float xv[Q], bv[Q], phi[Q];
+#pragma unroll
+  for (int q = 0; q < Q; ++q) {
+    const int t = start + Q * lane + q;
+    xv[q] = 0.f; bv[q] = 0.f; phi[q] = -INFINITY;                        // past the last frame: the identity map
+    if (t < T) {
+      xv[q] = logp[(long)t * V + c];
+      bv[q] = logp[(long)t * V + blank];
+      const float2 p = *reinterpret_cast<const float2*>(rp + 2 * (t - 1));
+      phi[q] = same ? p.y : lae(p.x, p.y);
+    }
+  }
+  // r^n
+  ScanMap mp[Q];
+  mp[0] = ScanMap{xv[0], xv[0] + phi[0]};
+#pragma unroll
+  for (int q = 1; q < Q; ++q) mp[q] = scan_after(ScanMap{xv[q], xv[q] + phi[q]}, mp[q - 1]);
+  ScanMap ex = wave_scan_exclusive(mp[Q - 1], lane);
+  const float n_in = lae(ex.a + n0, ex.c);
+  float nn[Q];
+#pragma unroll
+  for (int q = 0; q < Q; ++q) nn[q] = lae(mp[q].a + n_in, mp[q].c);
+  // r^b
+  mp[0] = ScanMap{bv[0], start + Q * lane < T ? bv[0] + n_in : -INFINITY};
+#pragma unroll
+  for (int q = 1; q < Q; ++q) mp[q] = scan_after(ScanMap{bv[q], start + Q * lane + q < T ? bv[q] + nn[q - 1] : -INFINITY}, mp[q - 1]);
+  ex = wave_scan_exclusive(mp[Q - 1], lane);
+  const float b_in = lae(ex.a + b0, ex.c);
+#pragma unroll
+  for (int q = 0; q < Q; ++q) {
+    const int t = start + Q * lane + q;
+    if (t < T) *reinterpret_cast<float2*>(rn + 2 * t) = make_float2(nn[q], lae(mp[q].a + b_in, mp[q].c));
+  }
+}
+}  // namespace
+
+extern "C" int eamd_ctc_prefix_psi(const float* logp, const int32_t* lens, int nutt, int per_utt, const float* r_prev,
+                                   const int32_t* cand, const int32_t* last, int olen, float* psi, int ncand, int Tmax, int V, int blank,
+                                   int eos, void* stream) {
+  if (!logp || !lens || !r_prev || !cand || !last || !psi || nutt <= 0 || per_utt <= 0 || ncand <= 0 || Tmax <= 0 || V <= 0 || olen < 0)
+    return EAMD_EINVAL;
+  if (Tmax > 512) return EAMD_EUNSUPPORTED;             // eight frames per lane are held in registers
+  hipLaunchKernelGGL(ctc_prefix_psi_kernel, dim3(ncand, nutt * per_utt), dim3(64), 0, (hipStream_t)stream, logp, lens, per_utt, r_prev,
+                     cand, last, olen, psi, Tmax, V, ncand, blank, eos);
+  EAMD_LAUNCH_CHECK();
+  return EAMD_OK;
+}
+
+extern "C" int eamd_ctc_prefix_state(const float* logp, const int32_t* lens, int nutt, int per_utt, const float* r_prev,
+                                     const int64_t* parent, const int64_t* tok, const int32_t* last, int olen, const float* alive,
+                                     float* r_out, int Tmax, int V, int blank, void* stream) {
+  if (!logp || !lens || !r_prev || !parent || !tok || !last || !alive || !r_out || nutt <= 0 || per_utt <= 0 || Tmax <= 0 || V <= 0 ||
+      olen < 0)
+    return EAMD_EINVAL;
+  const int n = nutt * per_utt;
+  static const int state_scan = getenv("EAMD_CTC_STATE_SCAN") ? atoi(getenv("EAMD_CTC_STATE_SCAN")) : 1;     // A/B knob: 0 = frame by frame
+  if (state_scan && Tmax <= 512) {
+    hipLaunchKernelGGL(ctc_prefix_state_scan_kernel, dim3(n), dim3(64), 0, (hipStream_t)stream, logp, lens, per_utt, r_prev,
+                       (const long long*)parent, (const long long*)tok, last, olen, alive, r_out, n, Tmax, V, blank);
+    EAMD_LAUNCH_CHECK();
+    return EAMD_OK;
+  }
+  hipLaunchKernelGGL(ctc_prefix_state_kernel, dim3((n + 63) / 64), dim3(64), 0, (hipStream_t)stream, logp, lens, per_utt, r_prev,
+                     (const long long*)parent, (const long long*)tok, last, olen, alive, r_out, n, Tmax, V, blank);
+  EAMD_LAUNCH_CHECK();
+  return EAMD_OK;
+}
+
 extern "C" int eamd_ctc_prefix_score_batch(const float* logp, const int32_t* lens, int nutt, int per_utt, const float* r_prev,
                                            const int32_t* cand, const int32_t* last, const int32_t* olen, float* psi,
                                            float* r_new, int ncand, int Tmax, int V, int blank, int eos, void* stream) {

@@ -325,9 +325,152 @@ __global__ __launch_bounds__(256) void beam_select_kernel(const float* __restric
     if (pi == 0 && pv == -INFINITY) pi = -1;       // (after a dead slot every further rank is dead too)
   }
 }
+
+// The selection above and the bookkeeping behind it (rowops.hip: beam_finish_kernel) in ONE launch per step, one workgroup per
+// utterance: the `beam` winners stay in LDS; thread s then does slot s's scalars (which hypothesis / token, the scores carried
+// along, the CTC prefix score of the new prefix = psi at the token's candidate position, the end tests, the next running score)
+// and all threads copy the prefixes.  Same arithmetic as the two kernels; three launches (select, finish, the psi gather) and
+// the int32 cast of the newest tokens become one.
+struct BeamStepArgs {
+  const float* logp[4];
+  const float* pre; const long long* ids; const float* psi; const float* c_s; const float* hyp; const long long* maxlen;
+  const float* sc_in; const long long* yseq_in;
+  float* c_local; float* sc_out; long long* yseq_out; float* hyp_out; long long* hyp_i; long long* tok_i; int* tok32; float* cs_out;
+  float* rec;
+  float w_ctc;
+  int n, beam, P, V, W, L, step, eos, ns, nf;
+};
+__global__ __launch_bounds__(256) void beam_step_kernel(const BeamStepArgs a) {
+  __shared__ float sv[4];
+  __shared__ long si[4];
+  __shared__ float wv;
+  __shared__ long wi;
+  __shared__ float win_s[64];
+  __shared__ long win_i[64];
+  __shared__ long slot_h[64];
+  __shared__ long slot_tok[64];
+  const int u = blockIdx.x, t = threadIdx.x, lane = t & 63, w = t >> 6;
+  const int beam = a.beam, P = a.P, V = a.V;
+  const int C = beam * P;
+  constexpr int RMAX = 4;                         // beam * P <= 1024 candidates (host check)
+  float val[RMAX];
+  long key[RMAX];
+#pragma unroll
+  for (int q = 0; q < RMAX; ++q) {
+    const int c = t + 256 * q;
+    val[q] = -INFINITY;
+    key[q] = 0x7ffffffffffffffeL;
+    if (c < C) {
+      const int slot = c / P, j = c - slot * P;
+      const long h = (long)u * beam + slot;
+      long long tok = a.ids[h * P + j];
+      tok = tok < 0 ? 0 : (tok >= V ? V - 1 : tok);
+      const float cl = __fsub_rn(a.psi[h * P + j], a.c_s[h]);
+      a.c_local[h * P + j] = cl;
+      float prod = a.w_ctc * cl;
+      asm volatile("" : "+v"(prod));
+      float v = a.pre[h * V + tok] + prod;
+      v = v + a.hyp[h];
+      val[q] = (v != v) ? -INFINITY : v;
+      key[q] = (long)slot * V + tok;
+    }
+  }
+  float pv = INFINITY;
+  long pi = -1;
+  for (int r = 0; r < beam; ++r) {
+    float bv = -INFINITY;
+    long bi = 0x7fffffffffffffffL;
+#pragma unroll
+    for (int q = 0; q < RMAX; ++q)
+      if (t + 256 * q < C && sel_before(pv, pi, val[q], key[q]) && sel_before(val[q], key[q], bv, bi)) { bv = val[q]; bi = key[q]; }
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) {
+      const float ov = __shfl_xor(bv, m);
+      const long oi = __shfl_xor(bi, m);
+      if (sel_before(ov, oi, bv, bi)) { bv = ov; bi = oi; }
+    }
+    if (lane == 0) { sv[w] = bv; si[w] = bi; }
+    __syncthreads();
+    if (t == 0) {
+      float fv = sv[0];
+      long fi = si[0];
+#pragma unroll
+      for (int q = 1; q < 4; ++q)
+        if (sel_before(sv[q], si[q], fv, fi)) { fv = sv[q]; fi = si[q]; }
+      if (fi == 0x7fffffffffffffffL) { fv = -INFINITY; fi = 0; }
+      wv = fv; wi = fi;
+      win_s[r] = fv; win_i[r] = fi;
+    }
+    __syncthreads();
+    pv = wv; pi = wi;
+    if (pi == 0 && pv == -INFINITY) pi = -1;
+  }
+  // ---- the bookkeeping of this utterance's slots (c_local of the block above is visible: the barriers of the rounds) ----
+  const int RW = 3 + a.ns + a.W;
+  if (t < beam) {
+    const long s = (long)u * beam + t;
+    long ti = win_i[t];
+    float ts = win_s[t];
+    if (ti < 0 || ti >= (long)beam * V) { ti = 0; ts = -INFINITY; }
+    const long h = (long)u * beam + ti / V;
+    const long tok = ti % V;
+    a.hyp_i[s] = h; a.tok_i[s] = tok; a.tok32[s] = (int)tok;
+    slot_h[t] = h; slot_tok[t] = tok;
+    float* rec = a.rec + s * RW;
+    rec[0] = (float)a.step; rec[1] = ts; rec[2] = (float)tok;
+    for (int j = 0; j < a.nf; ++j) {
+      const float v = a.sc_in[(long)j * a.n + h] + a.logp[j][h * V + tok];
+      a.sc_out[(long)j * a.n + s] = v;
+      rec[3 + j] = v;
+    }
+    long p = 0;                                            // position of the token among the hypothesis's candidates
+    for (int q = 0; q < P; ++q)
+      if (a.ids[h * P + q] == tok) { p = q; break; }
+    if (a.ns > a.nf) {
+      const float v = a.sc_in[(long)a.nf * a.n + h] + a.c_local[h * P + p];
+      a.sc_out[(long)a.nf * a.n + s] = v;
+      rec[3 + a.nf] = v;
+    }
+    a.cs_out[s] = a.psi[h * P + p];
+    const bool finite = isfinite(ts);
+    const bool at_cap = a.maxlen[u] <= a.step + 1;
+    const bool done = finite && (tok == a.eos || at_cap);
+    a.hyp_out[s] = (done || !finite) ? -INFINITY : ts;
+  }
+  __syncthreads();
+  for (int idx = t; idx < beam * a.W; idx += 256) {
+    const int sl = idx / a.W, wq = idx - sl * a.W;
+    const long s = (long)u * beam + sl;
+    const long long tk = wq == a.L ? slot_tok[sl] : a.yseq_in[slot_h[sl] * a.W + wq];
+    a.yseq_out[s * a.W + wq] = tk;
+    a.rec[s * RW + 3 + a.ns + wq] = (float)tk;
+  }
+}
 }  // namespace
 
 extern "C" {
+
+int eamd_beam_step(const float* pre, const int64_t* ids, const float* psi, const float* c_s, const float* hyp, float w_ctc, int nutt,
+                   int beam, int P, int V, int W, int L, int step, int eos, const int64_t* maxlen, int ns, int nf, const float* sc_in,
+                   const float* const* logps, const int64_t* yseq_in, float* c_local, float* sc_out, int64_t* yseq_out, float* hyp_out,
+                   int64_t* hyp_i, int64_t* tok_i, int32_t* tok32, float* cs_out, float* rec, void* stream) {
+  if (!pre || !ids || !psi || !c_s || !hyp || !maxlen || !sc_in || !yseq_in || !c_local || !sc_out || !yseq_out || !hyp_out || !hyp_i ||
+      !tok_i || !tok32 || !cs_out || !rec)
+    return EAMD_EINVAL;
+  if (nutt <= 0 || beam <= 0 || P <= 0 || V <= 0 || W <= 0 || L < 0 || L >= W || ns < 1 || nf < 0 || nf > 4 || ns != nf + 1) return EAMD_EINVAL;
+  if ((nf > 0 && !logps) || (long)nutt * beam > 0x7fffffffL) return EAMD_EINVAL;
+  if ((long)beam * P > 1024 || beam > 64) return EAMD_EUNSUPPORTED;
+  BeamStepArgs a;
+  for (int j = 0; j < 4; ++j) a.logp[j] = j < nf ? logps[j] : nullptr;
+  for (int j = 0; j < nf; ++j) if (!a.logp[j]) return EAMD_EINVAL;
+  a.pre = pre; a.ids = (const long long*)ids; a.psi = psi; a.c_s = c_s; a.hyp = hyp; a.maxlen = (const long long*)maxlen; a.sc_in = sc_in;
+  a.yseq_in = (const long long*)yseq_in; a.c_local = c_local; a.sc_out = sc_out; a.yseq_out = (long long*)yseq_out; a.hyp_out = hyp_out;
+  a.hyp_i = (long long*)hyp_i; a.tok_i = (long long*)tok_i; a.tok32 = tok32; a.cs_out = cs_out; a.rec = rec; a.w_ctc = w_ctc;
+  a.n = nutt * beam; a.beam = beam; a.P = P; a.V = V; a.W = W; a.L = L; a.step = step; a.eos = eos; a.ns = ns; a.nf = nf;
+  hipLaunchKernelGGL(beam_step_kernel, dim3(nutt), dim3(256), 0, (hipStream_t)stream, a);
+  EAMD_LAUNCH_CHECK();
+  return EAMD_OK;
+}
 
 int eamd_weighted_sum(const float* const* logps, const float* weights, int nf, int64_t numel, float* out, void* stream) {
   if (!logps || !weights || !out || nf < 1 || nf > 4 || numel <= 0) return EAMD_EINVAL;

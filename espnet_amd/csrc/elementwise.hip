@@ -239,14 +239,14 @@ __global__ __launch_bounds__(256) void colsum_bf16x2_kernel(const unsigned int* 
 
 // Embedding lookup * scale + absolute positional encoding.
 // reference: decoder.py:251 (embed = Embedding + PositionalEncoding), embedding.py:80-91.
-__global__ void embed_pe_kernel(const long long* __restrict__ tok, const float* __restrict__ table,
+__global__ void embed_pe_kernel(const long long* __restrict__ tok, long ldt, const float* __restrict__ table,
                                 const float* __restrict__ pe, float* __restrict__ out, long rows, int U, int D,
                                 float scale, int pos_offset) {
   const long n = rows * D;
   const long stride = (long)gridDim.x * blockDim.x;
   for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
     long r = i / D; int d = i % D;
-    long id = tok[r];
+    long id = tok[r * ldt];
     int pos = (int)(r % U) + pos_offset;
     out[i] = table[id * D + d] * scale + (pe ? pe[(long)pos * D + d] : 0.f);
   }
@@ -685,9 +685,14 @@ int eamd_colsum(const void* x, int64_t ld, float* out, int64_t rows, int D, floa
 
 int eamd_embed_pe(const int64_t* tok, const float* table, const float* pe, float* out, int64_t rows, int U,
                   int D, float scale, int pos_offset, void* stream) {
-  if (!tok || !table || !out || rows <= 0 || U <= 0 || D <= 0) return EAMD_EINVAL;
+  return eamd_embed_pe_ld(tok, 1, table, pe, out, rows, U, D, scale, pos_offset, stream);
+}
+
+int eamd_embed_pe_ld(const int64_t* tok, int64_t ldt, const float* table, const float* pe, float* out, int64_t rows, int U,
+                     int D, float scale, int pos_offset, void* stream) {
+  if (!tok || !table || !out || rows <= 0 || U <= 0 || D <= 0 || ldt < 1) return EAMD_EINVAL;
   hipLaunchKernelGGL(embed_pe_kernel, dim3(grid_for(rows * D)), dim3(256), 0, (hipStream_t)stream,
-                     (const long long*)tok, table, pe, out, (long)rows, U, D, scale, pos_offset);
+                     (const long long*)tok, (long)ldt, table, pe, out, (long)rows, U, D, scale, pos_offset);
   EAMD_LAUNCH_CHECK();
   return EAMD_OK;
 }

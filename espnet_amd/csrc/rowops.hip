@@ -803,6 +803,89 @@ __global__ __launch_bounds__(256) void linear_rows_f32_kernel(const float* __res
     y[(long)lane * N + n] = v;
   }
 }
+
+// K >= 1024 (the feed-forward down-product, K = 2048: 16 us as above - two staged chunks of the rows, every wave walking all of K):
+// a WORKGROUP owns CB output columns and its four waves split K; a lane's pieces of the weight rows and of the input rows go
+// straight to registers, all requested together (no staging pass, no barrier in front of the products), the waves' partial sums
+// meet in LDS and are added in a fixed order.  Same exact fp32 products; the summation order differs from the kernel above.
+template <int QN, int CB>
+__global__ __launch_bounds__(256) void linear_rows_wide_f32_kernel(const float* __restrict__ x, const float* __restrict__ W,
+                                                                   const float* __restrict__ bias, const float* __restrict__ R,
+                                                                   float* __restrict__ y, int M, int N, int K, int a_act, int act,
+                                                                   float alpha, long ldx, long ldr) {
+  __shared__ float part[4][CB * 16];
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const int c0 = blockIdx.x * CB;
+  const int k0 = w * QN * 256 + lane * 4;                  // this lane's pieces: k0 + 256 q, q < QN   (4 * QN * 256 >= K)
+  float4 w4[CB][QN];
+#pragma unroll
+  for (int c = 0; c < CB; ++c) {
+    const float* wr = W + (long)min(c0 + c, N - 1) * K;
+#pragma unroll
+    for (int q = 0; q < QN; ++q) {
+      const int k = k0 + 256 * q;
+      w4[c][q] = k < K ? *reinterpret_cast<const float4*>(wr + k) : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+  }
+  float acc[CB][16];
+#pragma unroll
+  for (int c = 0; c < CB; ++c)
+#pragma unroll
+    for (int m = 0; m < 16; ++m) acc[c][m] = 0.f;
+#pragma unroll
+  for (int mb = 0; mb < 16; mb += 8) {
+    if (mb < M) {
+      float4 x4[8][QN];
+#pragma unroll
+      for (int m = 0; m < 8; ++m) {
+        const float* xr = x + (long)min(mb + m, M - 1) * ldx;
+#pragma unroll
+        for (int q = 0; q < QN; ++q) {
+          const int k = k0 + 256 * q;
+          x4[m][q] = k < K ? *reinterpret_cast<const float4*>(xr + k) : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+      }
+#pragma unroll
+      for (int m = 0; m < 8; ++m) {
+#pragma unroll
+        for (int q = 0; q < QN; ++q) {
+          float4 v = x4[m][q];
+          if (a_act != EAMD_ACT_NONE) {
+            v.x = eamd_act(v.x, a_act); v.y = eamd_act(v.y, a_act); v.z = eamd_act(v.z, a_act); v.w = eamd_act(v.w, a_act);
+          }
+#pragma unroll
+          for (int c = 0; c < CB; ++c)
+            acc[c][mb + m] = fmaf(v.x, w4[c][q].x, fmaf(v.y, w4[c][q].y, fmaf(v.z, w4[c][q].z, fmaf(v.w, w4[c][q].w, acc[c][mb + m]))));
+        }
+      }
+    }
+  }
+  float mine = 0.f;
+#pragma unroll
+  for (int c = 0; c < CB; ++c) {
+#pragma unroll
+    for (int m = 0; m < 16; ++m) {
+      if (m < M) {
+        const float r = wave_sum(acc[c][m]);
+        if (lane == c * 16 + m) mine = r;
+      }
+    }
+  }
+  if (lane < CB * 16) part[w][lane] = mine;
+  __syncthreads();
+  const int t = threadIdx.x;
+  if (t < CB * 16) {
+    const int c = t >> 4, m = t & 15, n = c0 + c;
+    if (m < M && n < N) {
+      float v = ((part[0][t] + part[1][t]) + (part[2][t] + part[3][t])) + (bias ? bias[n] : 0.f);
+      if (act == 1) v = fmaxf(v, 0.f);
+      else if (act == 2) v = eamd_swish(v);
+      v *= alpha;
+      if (R) v += R[(long)m * ldr + n];
+      y[(long)m * N + n] = v;
+    }
+  }
+}
 }  // namespace
 
 // Bookkeeping of a beam step after the selection, one thread per surviving slot (reference: beam_search.py:177-203 post_process /
@@ -923,72 +1006,120 @@ __global__ __launch_bounds__(256) void linear_mfma16_f32_kernel(const float* __r
 }  // namespace
 
 // k largest of every row, sorted: value descending, equal values by ascending index (a total order: the selection is the same
-// whatever the grid or the replay).  One workgroup per row, k rounds of "largest element below the previous winner": a thread
-// scans its strided share, the 256 candidates meet through wave shuffles and LDS.  NaN counts as -inf.
+// whatever the grid or the replay).  NaN counts as -inf, -0 as +0.  One workgroup per row; an element is the 64-bit key
+// (order-preserving bits of the value, ~index): "ranks before" is one unsigned compare.
 // For the beam search's selections (beam_search.py:143-176: top-k over V and over beam x V per utterance, k <= 1.5 beam):
-// n = 5000 .. 50000, k = 10 .. 15 - 15 rounds over 20 register-resident elements per thread at V = 5000.
+// n = 5000 .. 50000, k = 10 .. 15.  Rows of up to 6144 elements stay in registers (24 per thread) and are cut down first: every
+// element of the answer is >= the k-th largest of the 256 per-thread maxima (those k maxima alone are k elements that large), so
+// the elements above that threshold - a few dozen in general - are gathered in LDS and ranked by counting (35 us as k rounds of
+// "largest element below the previous winner" over the whole row, which remains the path for longer rows and for rows with more
+// than TOPK_CAP elements at the threshold).
 // torch.topk's multi-block path for these sizes (6 launches + a sort) is also what faults under hipGraph replay on this ROCm.
 namespace {
-__device__ __forceinline__ bool topk_before(float va, long ia, float vb, long ib) {      // (va, ia) ranks before (vb, ib)
-  return va > vb || (va == vb && ia < ib);
+constexpr int TOPK_CAP = 1024;
+__device__ __forceinline__ unsigned topk_bits(float v) {
+  v = (v != v) ? -INFINITY : v;
+  if (v == 0.f) v = 0.f;
+  const unsigned b = __float_as_uint(v);
+  return (b & 0x80000000u) ? ~b : (b | 0x80000000u);
 }
+__device__ __forceinline__ float topk_value(unsigned b) { return __uint_as_float((b & 0x80000000u) ? (b ^ 0x80000000u) : ~b); }
+__device__ __forceinline__ unsigned long long topk_key(unsigned bits, unsigned i) { return ((unsigned long long)bits << 32) | (0xFFFFFFFFu - i); }
+
 __global__ __launch_bounds__(256) void topk_rows_kernel(const float* __restrict__ x, long ld, int n, int k,
-                                                        float* __restrict__ vals, int64_t* __restrict__ idx) {
-  __shared__ float sv[4];
-  __shared__ long si[4];
-  __shared__ float wv;
-  __shared__ long wi;
+                                                        float* __restrict__ vals, int64_t* __restrict__ idx, int32_t* __restrict__ idx32) {
+  __shared__ __attribute__((aligned(16))) unsigned tmax[256];
+  __shared__ unsigned long long cand[TOPK_CAP];
+  __shared__ unsigned long long sk[4];
+  __shared__ unsigned long long wk;
+  __shared__ unsigned tau;
+  __shared__ int cnt;
   const float* xr = x + (long)blockIdx.x * ld;
   const int t = threadIdx.x, lane = t & 63, w = t >> 6;
   constexpr int RMAX = 24;                       // register-resident elements per thread (n <= 6144); longer rows re-read memory
-  float reg[RMAX];
+  unsigned reg[RMAX];                            // order-preserving bits; 0 (below every real element) past the end of the row
   const bool inreg = n <= RMAX * 256;
   if (inreg) {
+    unsigned tm = 0;
 #pragma unroll
     for (int q = 0; q < RMAX; ++q) {
       const int i = t + 256 * q;
-      float v = i < n ? xr[i] : -INFINITY;
-      reg[q] = (v != v) ? -INFINITY : v;
+      reg[q] = i < n ? topk_bits(xr[i]) : 0u;
+      tm = max(tm, reg[q]);
     }
+    tmax[t] = tm;
+    if (t == 0) { tau = 0xFFFFFFFFu; cnt = 0; }
+    __syncthreads();
+    int above = 0;                               // thread maxima strictly above mine
+#pragma unroll 8
+    for (int j = 0; j < 256; j += 4) {
+      const uint4 v = *reinterpret_cast<const uint4*>(&tmax[j]);
+      above += (v.x > tm) + (v.y > tm) + (v.z > tm) + (v.w > tm);
+    }
+    if (above < k && tm != 0u) atomicMin(&tau, tm);
+    __syncthreads();
+    const unsigned th = tau;
+#pragma unroll
+    for (int q = 0; q < RMAX; ++q) {
+      if (reg[q] >= th && reg[q] != 0u) {
+        const int p = atomicAdd(&cnt, 1);
+        if (p < TOPK_CAP) cand[p] = topk_key(reg[q], (unsigned)(t + 256 * q));
+      }
+    }
+    __syncthreads();
+    const int c = cnt;
+    if (c <= TOPK_CAP) {
+      for (int j = t; j < c; j += 256) {
+        const unsigned long long my = cand[j];
+        int r = 0;
+        for (int q = 0; q < c; ++q) r += cand[q] > my;
+        if (r < k) {
+          const long o = (long)blockIdx.x * k + r;
+          const unsigned i = 0xFFFFFFFFu - (unsigned)my;
+          vals[o] = topk_value((unsigned)(my >> 32));
+          idx[o] = (int64_t)i;
+          if (idx32) idx32[o] = (int32_t)i;
+        }
+      }
+      return;
+    }
+    __syncthreads();
   }
-  float pv = INFINITY;                           // previous winner: everything ranks after (+inf, -1)
-  long pi = -1;
+  unsigned long long prev = 0xFFFFFFFFFFFFFFFFull;      // previous winner: every element ranks after it
   for (int r = 0; r < k; ++r) {
-    float bv = -INFINITY;
-    long bi = 0x7fffffffffffffffL;                // sentinel: ranks after every real element, even among -inf
+    unsigned long long best = 0;
     if (inreg) {
 #pragma unroll
       for (int q = 0; q < RMAX; ++q) {
-        const long i = t + 256 * q;
-        if (i < n && topk_before(pv, pi, reg[q], i) && topk_before(reg[q], i, bv, bi)) { bv = reg[q]; bi = i; }
+        const unsigned long long key = topk_key(reg[q], (unsigned)(t + 256 * q));
+        if (reg[q] != 0u && key < prev && key > best) best = key;
       }
     } else {
       for (long i = t; i < n; i += 256) {
-        float v = xr[i];
-        v = (v != v) ? -INFINITY : v;
-        if (topk_before(pv, pi, v, i) && topk_before(v, i, bv, bi)) { bv = v; bi = i; }
+        const unsigned long long key = topk_key(topk_bits(xr[i]), (unsigned)i);
+        if (key < prev && key > best) best = key;
       }
     }
 #pragma unroll
     for (int m = 32; m >= 1; m >>= 1) {
-      const float ov = __shfl_xor(bv, m);
-      const long oi = __shfl_xor(bi, m);
-      if (topk_before(ov, oi, bv, bi)) { bv = ov; bi = oi; }
+      const unsigned long long o = __shfl_xor(best, m);
+      best = o > best ? o : best;
     }
-    if (lane == 0) { sv[w] = bv; si[w] = bi; }
+    if (lane == 0) sk[w] = best;
     __syncthreads();
     if (t == 0) {
-      float fv = sv[0];
-      long fi = si[0];
+      unsigned long long f = sk[0];
 #pragma unroll
-      for (int q = 1; q < 4; ++q)
-        if (topk_before(sv[q], si[q], fv, fi)) { fv = sv[q]; fi = si[q]; }
-      wv = fv; wi = fi;
-      vals[(long)blockIdx.x * k + r] = fv;
-      idx[(long)blockIdx.x * k + r] = fi;
+      for (int q = 1; q < 4; ++q) f = sk[q] > f ? sk[q] : f;
+      wk = f;
+      const long o = (long)blockIdx.x * k + r;
+      const unsigned i = 0xFFFFFFFFu - (unsigned)f;
+      vals[o] = topk_value((unsigned)(f >> 32));
+      idx[o] = (int64_t)i;
+      if (idx32) idx32[o] = (int32_t)i;
     }
     __syncthreads();
-    pv = wv; pi = wi;
+    prev = wk;
   }
 }
 }  // namespace
@@ -1233,6 +1364,19 @@ int eamd_linear_rows_f32(const float* x, const float* W, const float* bias, cons
     EAMD_LAUNCH_CHECK();
     return EAMD_OK;
   }
+  static const int rows_wide = getenv("EAMD_ROWS_WIDE") ? atoi(getenv("EAMD_ROWS_WIDE")) : 1;      // A/B knob: 0 = the staged kernel for every K
+  if (rows_wide && K >= 1024 && K <= 4096) {               // the waves of a workgroup split K
+    constexpr int CB = 2;
+    const dim3 grid((N + CB - 1) / CB);
+#define EAMD_ROWS_WIDE_(QN) hipLaunchKernelGGL((linear_rows_wide_f32_kernel<QN, CB>), grid, dim3(256), 0, (hipStream_t)stream, x, W, bias, R, y, M, \
+                                               N, K, a_act, act, alpha, (long)ldx, (long)ldr)
+    if (K <= 1024) EAMD_ROWS_WIDE_(1);
+    else if (K <= 2048) EAMD_ROWS_WIDE_(2);
+    else EAMD_ROWS_WIDE_(4);
+#undef EAMD_ROWS_WIDE_
+    EAMD_LAUNCH_CHECK();
+    return EAMD_OK;
+  }
   hipLaunchKernelGGL(linear_rows_f32_kernel, dim3((N + 3) / 4), dim3(256), (size_t)M * (K < ROWS_KC ? K : ROWS_KC) * sizeof(float),
                      (hipStream_t)stream, x, W, bias, R, y, M, N, K, a_act, act, alpha, (long)ldx, (long)ldr);
   EAMD_LAUNCH_CHECK();
@@ -1240,9 +1384,13 @@ int eamd_linear_rows_f32(const float* x, const float* W, const float* bias, cons
 }
 
 int eamd_topk_rows(const float* x, int64_t ld, int rows, int n, int k, float* vals, int64_t* idx, void* stream) {
+  return eamd_topk_rows_i32(x, ld, rows, n, k, vals, idx, nullptr, stream);
+}
+
+int eamd_topk_rows_i32(const float* x, int64_t ld, int rows, int n, int k, float* vals, int64_t* idx, int32_t* idx32, void* stream) {
   if (!x || !vals || !idx || rows <= 0 || n <= 0 || k <= 0 || k > n || ld < n) return EAMD_EINVAL;
   if (k > 64) return EAMD_EUNSUPPORTED;
-  hipLaunchKernelGGL(topk_rows_kernel, dim3(rows), dim3(256), 0, (hipStream_t)stream, x, ld, n, k, vals, idx);
+  hipLaunchKernelGGL(topk_rows_kernel, dim3(rows), dim3(256), 0, (hipStream_t)stream, x, ld, n, k, vals, idx, idx32);
   EAMD_LAUNCH_CHECK();
   return EAMD_OK;
 }

@@ -1293,6 +1293,8 @@ class EmbedPEFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, tokens, table, pe, scale, pos_offset):
         B, U = tokens.shape
+        if U == 1 and not torch.is_grad_enabled():       # a beam step's newest tokens: read in place (one column of the prefix buffer)
+            return ops.embed_pe(tokens, table, pe, U, scale, pos_offset).view(B, U, table.shape[1])
         tok = tokens.contiguous()
         out = ops.embed_pe(tok, table, pe, U, scale, pos_offset)
         ctx.save_for_backward(tok)

@@ -203,6 +203,18 @@ class BeamSearch(torch.nn.Module):
     device_loop = True
     sync_every = 8
     candidate_select = True       # the selection of a step on the pre-beam candidates (eamd_beam_select); tests flip it
+    step_kernel = True            # selection + bookkeeping of a pre-beam step in one launch (eamd_beam_step); tests flip it
+    ctc_psi_parallel = True       # candidates scored by eamd_ctc_prefix_psi, survivors' states by eamd_ctc_prefix_state; tests flip it
+    ctc_side_stream = "capture"   # ... the latter on a second stream beside the next step's decoder stack: True, False, or only where
+                                  # it pays: more than 512 frames (the frame-by-frame recursion, 130 us at 249 frames; up to 512 the
+                                  # states are a parallel scan of a few us) in a captured step graph (the fork and the join cost
+                                  # ~25 us of queue switches per replay; an eager step is bound by the host's launches)
+
+    def _ctc_stream(self, dev):
+        st = getattr(self, "_ctc_side", None)
+        if st is None or st.device != dev:
+            st = self._ctc_side = torch.cuda.Stream(device=dev)
+        return st
 
     def _device_loop_ok(self, x):
         return (self.device_loop and x.is_cuda and all(hasattr(d, "score_tree") for d in self.full_scorers.values())
@@ -407,7 +419,9 @@ class BeamSearch(torch.nn.Module):
                   allk=names + ([pname] if pname is not None else []), xpad=xpad, lens_d=lens_d,
                   uniform=(not always_mask) and all(T == Tpad for T in Ts))
         C_["xall"] = xpad.unsqueeze(1).expand(B, beam, Tpad, xpad.shape[-1]).reshape(n, Tpad, xpad.shape[-1])
-        C_["mem_mask1"] = (torch.arange(Tpad, device=dev)[None, :] < lens_d[:, None]).unsqueeze(1)   # [B, 1, Tpad]
+        # [B, 1, Tpad], already in the kernels' uint8 (a bool mask was converted by every step's score_tree)
+        C_["mem_mask1"] = (torch.arange(Tpad, device=dev)[None, :] < lens_d[:, None]).unsqueeze(1).to(torch.uint8)
+        C_["sos32"] = torch.full((n,), self.sos, dtype=torch.int32, device=dev)
         C_["mem_mask"] = C_["mem_mask1"].unsqueeze(1).expand(B, beam, 1, Tpad).reshape(n, 1, Tpad)
         import inspect
         C_["masked"] = {k for k, d in self.full_scorers.items() if "memory_mask" in inspect.signature(d.score_tree).parameters}
@@ -447,6 +461,21 @@ class BeamSearch(torch.nn.Module):
         L = i + 1
         yseq, hyp, trees = S["yseq"], S["hyp"], dict(S["trees"])
         ys = yseq[:, :L]
+        # CTC forward variables of the running hypotheses: ready (first step / the full-recursion path), or still to be made from the
+        # previous step's selection - then on a second stream BESIDE the decoder stack below (eamd_ctc_prefix_state: ~160 us of
+        # frame-by-frame recursion that nothing in this step needs before the candidates are scored)
+        c_r_now, side = S.get("c_r"), None
+        if ctc is not None and c_r_now is None:
+            pend = S["c_pend"]
+            c_r_now = torch.empty(n, C_["Tpad"], 2, device=dev, dtype=torch.float32)
+            if self.ctc_side_stream is True or (self.ctc_side_stream == "capture" and torch.cuda.is_current_stream_capturing()
+                                                and C_["Tpad"] > 512):
+                side = self._ctc_stream(dev)
+                side.wait_stream(torch.cuda.current_stream(dev))
+                with torch.cuda.stream(side):
+                    ops.ctc_prefix_state(C_["logp"], C_["lens_d"], beam, *pend, ctc.blank, out=c_r_now)
+            else:
+                ops.ctc_prefix_state(C_["logp"], C_["lens_d"], beam, *pend, ctc.blank, out=c_r_now)
         logps, newtrees = {}, {}
         for k, d in self.full_scorers.items():
             # scorers that take it get the memory of the B utterances, not of the B * beam slots (shared_memory_ok)
@@ -462,18 +491,38 @@ class BeamSearch(torch.nn.Module):
             # BeamSearch with a pre-beam: the step's selection on the beam x P candidates (csrc/decode.hip: eamd_weighted_sum,
             # eamd_beam_select) - same scores in the same order of operations as the tensor expressions below, 12 launches fewer
             pre = ops.weighted_sum([logps[k] for k in names], [self.weights[k] for k in names])
-            part_ids = ops.topk_rows(pre, P)[1]
-            last = ys[:, -1].to(torch.int32).contiguous()
-            olen = torch.full((n,), L - 1, dtype=torch.int32, device=dev)
-            psi, r_new = ops.ctc_prefix_score_batch(C_["logp"], C_["lens_d"], beam, S["c_r"], part_ids.to(torch.int32), last, olen,
-                                                    ctc.blank, ctc.eos)
-            top_s, top_i, c_loc = ops.beam_select(pre, part_ids, psi, S["c_s"], hyp, self.weights[pname], B, beam)
-            sc_new, yseq, hyp_new, hyp_i, tok_i, pos, rec = ops.beam_finish(
-                top_s.reshape(-1), top_i.reshape(-1), beam, V, L, i, self.eos, C_["maxlen_d"].view(-1),
-                S["sc"], [logps[k] for k in names], c_loc, False, part_ids, yseq)
+            _, part_ids, cand32 = ops.topk_rows(pre, P, idx32=True)
+            # the newest token of every prefix as int32: the previous step's selection wrote it (eamd_beam_step), <sos> at step 0
+            last = S["last32"] if "last32" in S else (C_["sos32"] if i == 0 else ys[:, -1].to(torch.int32).contiguous())
+            if side is not None:
+                torch.cuda.current_stream(dev).wait_stream(side)
+                side = None
+            psi = ops.ctc_prefix_psi(C_["logp"], C_["lens_d"], beam, c_r_now, cand32, last, L - 1, ctc.blank, ctc.eos) \
+                if self.ctc_psi_parallel else None
+            r_new = None
+            if psi is None:       # more than 512 frames: the full recursion for every candidate
+                olen = torch.full((n,), L - 1, dtype=torch.int32, device=dev)
+                psi, r_new = ops.ctc_prefix_score_batch(C_["logp"], C_["lens_d"], beam, c_r_now, cand32, last, olen, ctc.blank, ctc.eos)
+            if self.step_kernel and beam <= 64 and r_new is None:
+                sc_new, yseq, hyp_new, hyp_i, tok_i, tok32, cs_new, rec = ops.beam_step(
+                    pre, part_ids, psi, S["c_s"], hyp, self.weights[pname], B, beam, L, i, self.eos, C_["maxlen_d"].view(-1),
+                    S["sc"], [logps[k] for k in names], yseq)
+            else:
+                top_s, top_i, c_loc = ops.beam_select(pre, part_ids, psi, S["c_s"], hyp, self.weights[pname], B, beam)
+                sc_new, yseq, hyp_new, hyp_i, tok_i, pos, rec = ops.beam_finish(
+                    top_s.reshape(-1), top_i.reshape(-1), beam, V, L, i, self.eos, C_["maxlen_d"].view(-1),
+                    S["sc"], [logps[k] for k in names], c_loc, False, part_ids, yseq)
+                cs_new, tok32 = psi[hyp_i, pos], tok_i.to(torch.int32)
             for k in names:
                 trees[k] = self._reorder(self.full_scorers[k], newtrees[k], hyp_i)
-            return dict(sc=sc_new, trees=trees, yseq=yseq, hyp=hyp_new, c_s=psi[hyp_i, pos], c_r=r_new[hyp_i, pos]), rec
+            T_ = dict(sc=sc_new, trees=trees, yseq=yseq, hyp=hyp_new, c_s=cs_new, last32=tok32)
+            if r_new is not None:
+                T_["c_r"] = r_new[hyp_i, pos]
+            else:     # the survivors' forward variables are made at the start of the next step (see the top of this function)
+                T_["c_pend"] = (c_r_now, hyp_i, tok_i, last, L - 1, hyp_new)
+            return T_, rec
+        if side is not None:
+            torch.cuda.current_stream(dev).wait_stream(side)
         weighted = torch.zeros(n, V, device=dev, dtype=torch.float32)
         for k in names:
             weighted += self.weights[k] * logps[k]
@@ -482,7 +531,7 @@ class BeamSearch(torch.nn.Module):
             pre = weighted if self.pre_beam_score_key == "full" else logps[self.pre_beam_score_key]
             part_ids = ops.topk_rows(pre.contiguous(), self.pre_beam_size)[1]
         if ctc is not None:
-            c_s, c_r = S["c_s"], S["c_r"]
+            c_s, c_r = S["c_s"], c_r_now
             last = ys[:, -1].to(torch.int32).contiguous()
             olen = torch.full((n,), L - 1, dtype=torch.int32, device=dev)
             ids = part_ids if part_ids is not None else torch.arange(V, device=dev).unsqueeze(0).expand(n, V)

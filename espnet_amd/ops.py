@@ -1318,16 +1318,48 @@ def beam_select(pre, ids, psi, c_s, hyp, w_ctc, nutt, beam):
     return top_s, top_i, c_local
 
 
-def topk_rows(x, k):
+def topk_rows(x, k, idx32=False):
     """(values [rows, k], indices [rows, k] int64) of the k largest of each row of a contiguous fp32 [rows, n] tensor, sorted
-    (value descending, ties by ascending index): one launch, graph-replay safe (torch.topk's multi-block path is neither)"""
+    (value descending, ties by ascending index): one launch, graph-replay safe (torch.topk's multi-block path is neither).
+    idx32: a third result, the indices as int32 (the same launch)"""
     rows, n = x.shape
     if x.dtype != torch.float32 or not x.is_contiguous() or k > 64:
         raise _lib.EamdError("topk_rows: contiguous float32 [rows, n], k <= 64")
     vals = torch.empty(rows, k, device=x.device, dtype=torch.float32)
     idx = torch.empty(rows, k, device=x.device, dtype=torch.int64)
-    check(_lib.lib().eamd_topk_rows(ptr(x), C.c_int64(n), rows, n, k, ptr(vals), ptr(idx), stream_ptr()), "eamd_topk_rows")
-    return vals, idx
+    i32 = torch.empty(rows, k, device=x.device, dtype=torch.int32) if idx32 else None
+    check(_lib.lib().eamd_topk_rows_i32(ptr(x), C.c_int64(n), rows, n, k, ptr(vals), ptr(idx), ptr(i32), stream_ptr()), "eamd_topk_rows")
+    return (vals, idx, i32) if idx32 else (vals, idx)
+
+
+def beam_step(pre, ids, psi, c_s, hyp, w_ctc, nutt, beam, L, step, eos, maxlen, sc_in, logps, yseq_in):
+    """selection and bookkeeping of a BeamSearch step with a pre-beam in one launch (eamd_beam_step = eamd_beam_select +
+    eamd_beam_finish) -> (sc_out [ns, n], yseq_out, hyp_out, hyp_i, tok_i, tok32, cs_out, rec)"""
+    n, V = pre.shape
+    P = ids.shape[1]
+    ns, W = sc_in.shape[0], yseq_in.shape[1]
+    nf = len(logps)
+    dev = pre.device
+    for t_ in (pre, psi, c_s, hyp, sc_in) + tuple(logps):
+        if t_.dtype != torch.float32 or not t_.is_contiguous():
+            raise _lib.EamdError("beam_step: contiguous float32 score tensors")
+    for t_ in (ids, maxlen, yseq_in):
+        if t_.dtype != torch.int64 or not t_.is_contiguous():
+            raise _lib.EamdError("beam_step: contiguous int64 index tensors")
+    assert n == nutt * beam and psi.shape == (n, P) and c_s.numel() == n and hyp.numel() == n and sc_in.shape[1] == n
+    assert yseq_in.shape[0] == n and all(lp.shape == (n, V) for lp in logps) and ns == nf + 1 and maxlen.numel() == nutt
+    c_local = torch.empty(n, P, device=dev, dtype=torch.float32)
+    sc_out = torch.empty(ns, n, device=dev, dtype=torch.float32)
+    yseq_out = torch.empty(n, W, device=dev, dtype=torch.int64)
+    hyp_out, cs_out = (torch.empty(n, device=dev, dtype=torch.float32) for _ in range(2))
+    hyp_i, tok_i = (torch.empty(n, device=dev, dtype=torch.int64) for _ in range(2))
+    tok32 = torch.empty(n, device=dev, dtype=torch.int32)
+    rec = torch.empty(n, 3 + ns + W, device=dev, dtype=torch.float32)
+    arr = (C.c_void_p * 4)(*[lp.data_ptr() for lp in logps] + [None] * (4 - nf))
+    check(_lib.lib().eamd_beam_step(ptr(pre), ptr(ids), ptr(psi), ptr(c_s), ptr(hyp), C.c_float(w_ctc), nutt, beam, P, V, W, L, step, eos,
+                                    ptr(maxlen), ns, nf, ptr(sc_in), arr, ptr(yseq_in), ptr(c_local), ptr(sc_out), ptr(yseq_out),
+                                    ptr(hyp_out), ptr(hyp_i), ptr(tok_i), ptr(tok32), ptr(cs_out), ptr(rec), stream_ptr()), "eamd_beam_step")
+    return sc_out, yseq_out, hyp_out, hyp_i, tok_i, tok32, cs_out, rec
 
 
 def beam_finish(top_s, top_i, beam, V, L, step, eos, maxlen, sc_in, logps, c_local, full_mode, ids, yseq_in):
@@ -1452,14 +1484,19 @@ def add_cast_colsum2(a, b, suma, sumb, out=None, out_off=0, ld_out=None):
 
 
 def embed_pe(tok, table, pe, U, scale, pos_offset=0):
-    """out[r] = table[tok[r]] * scale + pe[r % U + pos_offset]   (pe None: plain embedding lookup)"""
+    """out[r] = table[tok[r]] * scale + pe[r % U + pos_offset]   (pe None: plain embedding lookup).  tok contiguous, or one
+    column of a wider buffer ([n, 1] with a row stride: the newest tokens of a beam step's prefixes)"""
     rows = tok.numel()
     D = table.shape[1]
-    assert tok.dtype == torch.int64 and tok.is_contiguous()
+    assert tok.dtype == torch.int64
+    ldt = 1
+    if not tok.is_contiguous():
+        assert tok.dim() == 2 and tok.shape[1] == 1 and tok.stride(0) >= 1
+        ldt = tok.stride(0)
     assert pe is None or (pe.shape[0] >= U + pos_offset and pe.shape[1] == D)
     out = torch.empty(rows, D, device=table.device, dtype=torch.float32)
-    check(_lib.lib().eamd_embed_pe(ptr(tok), ptr(table), ptr(pe), ptr(out), C.c_int64(rows), U, D,
-                                   C.c_float(scale), pos_offset, stream_ptr()), "eamd_embed_pe")
+    check(_lib.lib().eamd_embed_pe_ld(ptr(tok), C.c_int64(ldt), ptr(table), ptr(pe), ptr(out), C.c_int64(rows), U, D,
+                                      C.c_float(scale), pos_offset, stream_ptr()), "eamd_embed_pe")
     return out
 
 
@@ -1740,6 +1777,33 @@ def ctc_prefix_score_batch(logp, lens, per_utt, r_prev, cand, last, olen, blank,
                                                  ptr(last), ptr(olen), ptr(psi), ptr(r_new), ncand, Tmax, V, blank, eos,
                                                  stream_ptr()), "eamd_ctc_prefix_score_batch")
     return psi, r_new
+
+
+def ctc_prefix_psi(logp, lens, per_utt, r_prev, cand, last, olen, blank, eos):
+    """log psi of the candidates as a parallel reduction over the frames (eamd_ctc_prefix_psi): logp [U, Tmax, V], r_prev
+    [U * per_utt, Tmax, 2], cand [n, P] int32, last [n] int32, olen int -> psi [n, P]; None when the library declines (Tmax > 512)"""
+    U, Tmax, V = logp.shape
+    nhyp, ncand = cand.shape
+    assert nhyp == U * per_utt and r_prev.shape == (nhyp, Tmax, 2) and cand.dtype == torch.int32 and logp.is_contiguous()
+    psi = torch.empty(nhyp, ncand, device=logp.device, dtype=torch.float32)
+    rc = _lib.lib().eamd_ctc_prefix_psi(ptr(logp), ptr(lens), U, per_utt, ptr(r_prev.contiguous()), ptr(cand.contiguous()), ptr(last),
+                                        int(olen), ptr(psi), ncand, Tmax, V, blank, eos, stream_ptr())
+    if rc == _lib.EAMD_EUNSUPPORTED:
+        return None
+    check(rc, "eamd_ctc_prefix_psi")
+    return psi
+
+
+def ctc_prefix_state(logp, lens, per_utt, r_prev, parent, tok, last, olen, alive, blank, out=None):
+    """forward variables of the continuations that survived a selection (eamd_ctc_prefix_state): slot s continues hypothesis
+    parent[s] (whose state is r_prev[parent[s]], last token last[parent[s]], prefix length olen + 1) with token tok[s];
+    alive [n] = the slots' running scores (-inf: ended / empty) -> r [n, Tmax, 2]"""
+    U, Tmax, V = logp.shape
+    n = parent.numel()
+    r = out if out is not None else torch.empty(n, Tmax, 2, device=logp.device, dtype=torch.float32)
+    check(_lib.lib().eamd_ctc_prefix_state(ptr(logp), ptr(lens), U, per_utt, ptr(r_prev), ptr(parent), ptr(tok), ptr(last), int(olen),
+                                           ptr(alive), ptr(r), Tmax, V, blank, stream_ptr()), "eamd_ctc_prefix_state")
+    return r
 
 
 # ---- optimizer -------------------------------------------------------------------------------------

@@ -439,6 +439,17 @@ int eamd_beam_select(const float* pre, const int64_t* ids, const float* psi, con
  * NaN counts as -inf.  vals / idx [rows, k].  reference: the torch.topk selections of a beam step (beam_search.py:143-176,
  * batch_beam_search.py:86-110: pre-beam over V, best `beam` of beam x V). */
 int eamd_topk_rows(const float* x, int64_t ld, int rows, int n, int k, float* vals, int64_t* idx, void* stream);
+/* ... the indices also as int32 (idx32 [rows, k], may be NULL): the candidate list eamd_ctc_prefix_psi takes. */
+int eamd_topk_rows_i32(const float* x, int64_t ld, int rows, int n, int k, float* vals, int64_t* idx, int32_t* idx32, void* stream);
+/* eamd_beam_select + eamd_beam_finish of a BeamSearch step with a pre-beam in one launch (one workgroup per utterance; same
+ * arithmetic): the arguments of both - ids [n, P] the candidates, ns == nf + 1 (the partial scorer's row is last), W the width of the
+ * prefix buffers, L the position the new token takes - plus tok32 [n] = tok_i as int32 (the next step's `last`) and
+ * cs_out [n] = psi at the chosen candidate of the extended hypothesis (the partial scorer's running prefix score).  beam <= 64,
+ * beam * P <= 1024.  reference: beam_search.py:143-226,296-334. */
+int eamd_beam_step(const float* pre, const int64_t* ids, const float* psi, const float* c_s, const float* hyp, float w_ctc, int nutt,
+                   int beam, int P, int V, int W, int L, int step, int eos, const int64_t* maxlen, int ns, int nf, const float* sc_in,
+                   const float* const* logps, const int64_t* yseq_in, float* c_local, float* sc_out, int64_t* yseq_out, float* hyp_out,
+                   int64_t* hyp_i, int64_t* tok_i, int32_t* tok32, float* cs_out, float* rec, void* stream);
 
 /* ------------------------------------------------------------------------------------------
  * Element-wise helpers.
@@ -478,6 +489,9 @@ int eamd_colsum(const void* x, int64_t ld, float* out, int64_t rows, int D, floa
  * pad_idx >= 0 in the backward = nn.Embedding(padding_idx): that row gets no gradient (-1: none). */
 int eamd_embed_pe(const int64_t* tok, const float* table, const float* pe, float* out, int64_t rows, int U,
                   int D, float scale, int pos_offset, void* stream);
+/* ... token r read at tok[r * ldt] (the newest column of a [n, W] prefix buffer: a beam step's input). */
+int eamd_embed_pe_ld(const int64_t* tok, int64_t ldt, const float* table, const float* pe, float* out, int64_t rows, int U,
+                     int D, float scale, int pos_offset, void* stream);
 int eamd_embed_bwd(const int64_t* tok, const float* dout, float* dtable, int64_t rows, int D, float scale,
                    int64_t pad_idx, void* stream);
 int eamd_posenc(const float* x, const float* pe, float* out, int64_t rows, int T, int D, float scale,
@@ -578,6 +592,18 @@ int eamd_ctc_prefix_score(const float* logp, const float* r_prev, const int32_t*
 int eamd_ctc_prefix_score_batch(const float* logp, const int32_t* lens, int nutt, int per_utt, const float* r_prev,
                                 const int32_t* cand, const int32_t* last, const int32_t* olen, float* psi, float* r_new,
                                 int ncand, int Tmax, int V, int blank, int eos, void* stream);
+/* The same scores with the serial recursion OFF a beam step's critical path (csrc/ctc.hip): log psi of a candidate is a logsumexp over
+ * the frames of phi(t-1) + x(t) (ctc_prefix_score.py:290-296 never reads r[t] for it) - eamd_ctc_prefix_psi forms it as a parallel
+ * reduction (one wave per (hypothesis, candidate); Tmax <= 512) - and only the continuations that SURVIVE the selection need their
+ * forward variables: eamd_ctc_prefix_state runs the recursion of :291-295 for slot s = (hypothesis parent[s], token tok[s]) into
+ * r_out [n, Tmax, 2] (slots with alive[s] = -inf get log-zero rows); the caller issues it at the start of the next step on a second
+ * stream beside the decoder stack.  olen = prefix length - 1 of the scored hypotheses (one value: all hypotheses of a step have the
+ * same length); last [n] = their last tokens.  Same values as eamd_ctc_prefix_score_batch up to the order of the log-sum-exp. */
+int eamd_ctc_prefix_psi(const float* logp, const int32_t* lens, int nutt, int per_utt, const float* r_prev, const int32_t* cand,
+                        const int32_t* last, int olen, float* psi, int ncand, int Tmax, int V, int blank, int eos, void* stream);
+int eamd_ctc_prefix_state(const float* logp, const int32_t* lens, int nutt, int per_utt, const float* r_prev, const int64_t* parent,
+                          const int64_t* tok, const int32_t* last, int olen, const float* alive, float* r_out, int Tmax, int V, int blank,
+                          void* stream);
 
 /* ---- feature-side layers ----------------------------------------------
  * SpecAugment on a [B,T,F] batch (x != y).  reference: espnet2/asr/specaug/specaug.py:19-84,

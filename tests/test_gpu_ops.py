@@ -1550,7 +1550,8 @@ def test_ffn_layernorm_in_front(ops, prec, M, F, act):
         espnet_amd.set_precision("fp32")
 
 
-@pytest.mark.parametrize("rows,n,k", [(10, 5000, 15), (1, 50000, 10), (320, 5000, 10), (32, 50000, 10), (3, 7, 7), (5, 6144, 64), (4, 6145, 3)])
+@pytest.mark.parametrize("rows,n,k", [(10, 5000, 15), (1, 50000, 10), (320, 5000, 10), (32, 50000, 10), (3, 7, 7), (5, 6144, 64), (4, 6145, 3),
+                                      (6, 100, 10), (3, 300, 64), (2, 1, 1)])
 def test_topk_rows(ops, rows, n, k):
     """eamd_topk_rows against torch.topk (the selections of a beam step: beam_search.py:143-176): values equal element for
     element; indices equal where the values are distinct; ties (planted duplicates, -inf runs of dead beam slots, NaN = -inf) in
@@ -1565,9 +1566,10 @@ def test_topk_rows(ops, rows, n, k):
         x[1] = -float("inf")                             # a row of dead slots only: the first k indices
     xd = x.to(DEV)
     v, i = ops.topk_rows(xd, k)
-    v2, i2 = ops.topk_rows(xd, k)
+    v2, i2, j2 = ops.topk_rows(xd, k, idx32=True)
     torch.cuda.synchronize()
     assert torch.equal(v, v2) and torch.equal(i, i2) and i.dtype == torch.int64 and v.shape == (rows, k)
+    assert j2.dtype == torch.int32 and torch.equal(j2.long(), i2)
     xr = torch.where(torch.isnan(x), torch.full_like(x, -float("inf")), x)
     rv, _ = torch.topk(xr, k, dim=1)
     assert torch.equal(v.cpu(), rv)
@@ -1586,7 +1588,8 @@ def test_topk_rows(ops, rows, n, k):
 @pytest.mark.parametrize("M,N,K,a_act,act,res", [(10, 256, 256, 0, 0, True), (10, 2048, 256, 0, 1, False), (10, 256, 2048, 1, 0, True),
                                                  (16, 5000, 256, 0, 0, False), (1, 30, 64, 2, 2, True), (7, 257, 1028, 0, 0, True),
                                                  (320, 256, 256, 0, 0, True), (320, 256, 2048, 1, 0, True), (41, 2049, 256, 0, 1, False),
-                                                 (17, 30, 64, 2, 2, True)])
+                                                 (17, 30, 64, 2, 2, True), (16, 255, 4096, 0, 2, True), (9, 64, 1024, 2, 0, False),
+                                                 (12, 130, 3000, 0, 1, True)])
 def test_linear_rows_f32(ops, M, N, K, a_act, act, res):
     """eamd_linear_rows_f32 (nn.Linear on <= 16 rows, one wave per output column; taken by ops.linear_fwd without autograd) against
     float64: y = alpha * act(a_act(x) W^T + b) + R.  reference: the per-step products of decoder_layer.py:77-134."""
@@ -1696,7 +1699,7 @@ def test_ctc_prefix_score_vs_float64(ops):
                        np.concatenate([np.repeat(O.ctc_prefix_init(logp[u, :lens[u]].double().numpy(), blank, np.float64)[None], per, 0),
                                        np.zeros((per, Tmax - lens[u], 2))], 1) for u in range(U)])          # [U, per, Tmax, 2]
     last = np.full((U, per), eos, dtype=np.int64)
-    worst = dict(psi=0.0, r=0.0, psi32=0.0, r32=0.0)
+    worst = dict(psi=0.0, r=0.0, psi32=0.0, r32=0.0, rs=0.0)
     for step in range(5):
         cand = torch.randint(1, V - 1, (U, per, P), generator=g).numpy()
         cand[:, :, 0], cand[:, :, 1] = eos, blank
@@ -1742,14 +1745,33 @@ def test_ctc_prefix_score_vs_float64(ops):
             assert float(r_b[sl, :, T:].abs().max()) == 0.0 if T < Tmax else True   # rows beyond the utterance stay zero
         # next step: each hypothesis takes one of its candidates (not blank / <eos>), state = the float64 one
         pick = torch.randint(2, P, (U, per), generator=g).numpy()
+        # the split form of a beam step: candidates scored by the parallel reduction (eamd_ctc_prefix_psi: same bound against
+        # float64), the survivors' forward variables by eamd_ctc_prefix_state: bit-equal to the full recursion's rows
+        psi_p = ops.ctc_prefix_psi(logp_d, lens_d, per, rp_d, cand_d, last_d, step, blank, eos)
+        for u in range(U):
+            chk("psi (parallel) u%d step%d" % (u, step), psi_p[u * per:(u + 1) * per].cpu().numpy(), psi64[u], "psi")
+        tok_d = torch.from_numpy(np.take_along_axis(cand.reshape(U * per, P), pick.reshape(U * per, 1), 1)[:, 0].copy()).to(DEV)
+        alive = torch.zeros(U * per, device=DEV)
+        alive[3] = -float("inf")
+        r_s = ops.ctc_prefix_state(logp_d, lens_d, per, rp_d, torch.arange(U * per, device=DEV), tok_d, last_d, step, alive, blank)
+        torch.cuda.synchronize()
+        t0 = max(step, 1) - 1
+        for u in range(U):
+            for hh in range(per):
+                s_ = u * per + hh
+                if s_ == 3:
+                    assert float(r_s[s_, :lens[u]].max()) == -10000000000.0
+                else:      # (a parallel scan over the frames: same bound against float64 as the frame-by-frame recursion)
+                    chk("r (state) u%d step%d" % (u, step), r_s[s_, t0:lens[u]].cpu().numpy(), r64[u][hh, int(pick[u, hh]), t0:], "rs")
+                    assert float(r_s[s_, :t0].max()) <= -9.9e9 if t0 > 0 else True
         for u in range(U):
             T = lens[u]
             for h in range(per):
                 r_prev[u, h, :T] = r64[u][h, pick[u, h]]
                 last[u, h] = cand[u, h, pick[u, h]]
     print("[parity] ctc_prefix_score vs float64, worst err / (1e-5 + 2e-6 |ref|): HIP psi %.3f r %.3f | reference float32 "
-          "arithmetic (numpy) psi %.3f r %.3f" % (worst["psi"], worst["r"], worst["psi32"], worst["r32"]))
-    assert worst["psi"] <= 1.0 and worst["r"] <= 1.0
+          "arithmetic (numpy) psi %.3f r %.3f | survivors' states by the scan %.3f" % (worst["psi"], worst["r"], worst["psi32"], worst["r32"], worst["rs"]))
+    assert worst["psi"] <= 1.0 and worst["r"] <= 1.0 and worst["rs"] <= 1.0
 
 
 @pytest.mark.parametrize("M", [7968, 100, 32])
