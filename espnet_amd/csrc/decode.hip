@@ -19,6 +19,8 @@
 namespace {
 
 // one wave per output column (rowops.hip: linear_rows_f32_kernel), four columns per workgroup; K <= 1024: the M rows fit LDS whole.
+// (tried: no staging - every wave reads its pieces of all rows to registers and repeats the LayerNorm there: 10.5 - 11.9 us
+// against 7.3 - 7.8 for this form, the output layer 19.9 against 10.0; the repeated statistics cost more than the staging pass)
 __global__ __launch_bounds__(256) void linear_rows_ln_f32_kernel(const float* __restrict__ x, const float* __restrict__ gam,
                                                                  const float* __restrict__ bet, float eps,
                                                                  const float* __restrict__ W, const float* __restrict__ bias,
@@ -99,6 +101,82 @@ __global__ __launch_bounds__(256) void linear_rows_ln_f32_kernel(const float* __
     v *= alpha;
     if (R) v += R[(long)lane * ldr + n];
     y[(long)lane * ldy + n] = v;
+  }
+}
+
+// The same for a few hundred rows (a batched beam search steps utterances x beam hypotheses: M = 320) with K <= 256: every WAVE owns
+// a 16 x 16 output tile (rowops.hip: linear_mfma16_f32_kernel - operands straight from global memory into
+// v_mfma_f32_16x16x4_f32); its 16 input rows are whole in the registers of the wave (lane = row x k-group of four), so their
+// LayerNorm is two four-lane sums per row in front of the products - 19 LayerNorm launches per step go.
+typedef float lnm_f32x4 __attribute__((ext_vector_type(4)));
+__global__ __launch_bounds__(256) void linear_mfma16_ln_f32_kernel(const float* __restrict__ x, const float* __restrict__ gam,
+                                                                   const float* __restrict__ bet, float eps,
+                                                                   const float* __restrict__ W, const float* __restrict__ bias,
+                                                                   const float* __restrict__ R, float* __restrict__ y, int M, int N,
+                                                                   int K, int act, float alpha, long ldx, long ldr, long ldy) {
+  __shared__ __attribute__((aligned(16))) float gs[256], bs[256];        // gamma / beta once per workgroup (read from global inside
+  const int lane = threadIdx.x & 63, fr = lane & 15, fq = lane >> 4;      // the product loop each pair waited a memory round trip)
+  const int n0 = (blockIdx.x * 4 + (threadIdx.x >> 6)) * 16;
+  const int m0 = blockIdx.y * 16;
+  if (threadIdx.x * 4 < K) {
+    *reinterpret_cast<float4*>(&gs[threadIdx.x * 4]) = *reinterpret_cast<const float4*>(gam + threadIdx.x * 4);
+    *reinterpret_cast<float4*>(&bs[threadIdx.x * 4]) = *reinterpret_cast<const float4*>(bet + threadIdx.x * 4);
+  }
+  const float* xr = x + (long)min(m0 + fr, M - 1) * ldx + fq * 4;        // clamped rows / columns are never stored
+  const float* wr = W + (long)min(n0 + fr, N - 1) * K + fq * 4;
+  constexpr int U = 16;                                                   // K <= 256: 16-k chunks, all requested together
+  float4 xa[U], wb[U];
+#pragma unroll
+  for (int u = 0; u < U; ++u) {
+    const bool in = 16 * u < K;                                           // (K % 16 == 0: checked on the host)
+    xa[u] = in ? *reinterpret_cast<const float4*>(xr + 16 * u) : make_float4(0.f, 0.f, 0.f, 0.f);
+    wb[u] = in ? *reinterpret_cast<const float4*>(wr + 16 * u) : make_float4(0.f, 0.f, 0.f, 0.f);
+  }
+  float s = 0.f;
+#pragma unroll
+  for (int u = 0; u < U; ++u) s += (xa[u].x + xa[u].y) + (xa[u].z + xa[u].w);
+  s += __shfl_xor(s, 16, 64);
+  s += __shfl_xor(s, 32, 64);
+  const float mean = s / K;
+  float c = 0.f;
+#pragma unroll
+  for (int u = 0; u < U; ++u) {
+    if (16 * u < K) {
+      const float a0 = xa[u].x - mean, a1 = xa[u].y - mean, a2 = xa[u].z - mean, a3 = xa[u].w - mean;
+      c += (a0 * a0 + a1 * a1) + (a2 * a2 + a3 * a3);
+    }
+  }
+  c += __shfl_xor(c, 16, 64);
+  c += __shfl_xor(c, 32, 64);
+  const float rstd = rsqrtf(c / K + eps);
+  __syncthreads();
+  if (n0 >= N) return;
+  lnm_f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int u = 0; u < U; ++u) {
+    if (16 * u < K) {
+      const float4 g = *reinterpret_cast<const float4*>(&gs[fq * 4 + 16 * u]), b = *reinterpret_cast<const float4*>(&bs[fq * 4 + 16 * u]);
+      acc = __builtin_amdgcn_mfma_f32_16x16x4f32((xa[u].x - mean) * rstd * g.x + b.x, wb[u].x, acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_16x16x4f32((xa[u].y - mean) * rstd * g.y + b.y, wb[u].y, acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_16x16x4f32((xa[u].z - mean) * rstd * g.z + b.z, wb[u].z, acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_16x16x4f32((xa[u].w - mean) * rstd * g.w + b.w, wb[u].w, acc, 0, 0, 0);
+    }
+  }
+  const int n = n0 + fr;
+  if (n < N) {
+    const float bv = bias ? bias[n] : 0.f;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int m = m0 + fq * 4 + r;
+      if (m < M) {
+        float v = acc[r] + bv;
+        if (act == 1) v = fmaxf(v, 0.f);
+        else if (act == 2) v = eamd_swish(v);
+        v *= alpha;
+        if (R) v += R[(long)m * ldr + n];
+        y[(long)m * ldy + n] = v;
+      }
+    }
   }
 }
 
@@ -197,8 +275,15 @@ int eamd_linear_rows_ln_f32(const float* x, const float* gamma, const float* bet
   if (ldr == 0) ldr = N;
   if (ldy == 0) ldy = N;
   if (ldx < K || ldr < N || ldy < N) return EAMD_EINVAL;
-  if (M > 16 || K > 1024 || K % 4 != 0 || ldx % 4 != 0 || act > 2) return EAMD_EUNSUPPORTED;
+  if (K > 1024 || K % 4 != 0 || ldx % 4 != 0 || act > 2) return EAMD_EUNSUPPORTED;
   if (((uintptr_t)x | (uintptr_t)W | (uintptr_t)gamma | (uintptr_t)beta) & 15) return EAMD_EUNSUPPORTED;
+  if (M > 16) {                                            // blocks of 16 rows on the matrix cores (the input rows of a wave are whole in its registers)
+    if (M > 1024 || K > 256 || K % 16 != 0) return EAMD_EUNSUPPORTED;
+    hipLaunchKernelGGL(linear_mfma16_ln_f32_kernel, dim3((N + 63) / 64, (M + 15) / 16), dim3(256), 0, (hipStream_t)stream, x, gamma, beta,
+                       eps, W, bias, R, y, M, N, K, act, alpha, (long)ldx, (long)ldr, (long)ldy);
+    EAMD_LAUNCH_CHECK();
+    return EAMD_OK;
+  }
   hipLaunchKernelGGL(linear_rows_ln_f32_kernel, dim3((N + 3) / 4), dim3(256), (size_t)M * K * sizeof(float), (hipStream_t)stream, x,
                      gamma, beta, eps, W, bias, R,
                      y, M, N, K, act, alpha, (long)ldx, (long)ldr, (long)ldy);
@@ -340,26 +425,30 @@ struct BeamStepArgs {
   float w_ctc;
   int n, beam, P, V, W, L, step, eos, ns, nf;
 };
+__device__ __forceinline__ unsigned sel_bits(float v) {      // order-preserving bits (NaN was made -inf; -0 ranks as +0)
+  if (v == 0.f) v = 0.f;
+  const unsigned b = __float_as_uint(v);
+  return (b & 0x80000000u) ? ~b : (b | 0x80000000u);
+}
 __global__ __launch_bounds__(256) void beam_step_kernel(const BeamStepArgs a) {
-  __shared__ float sv[4];
-  __shared__ long si[4];
-  __shared__ float wv;
-  __shared__ long wi;
+  // the winners by counting: a candidate's rank is the number of candidates that come before it (value descending, then
+  // slot * V + token ascending - one unsigned compare on (value bits, ~index)); ranks below `beam` are the selection
+  __shared__ __attribute__((aligned(16))) unsigned long long ckey[1024];
   __shared__ float win_s[64];
   __shared__ long win_i[64];
   __shared__ long slot_h[64];
   __shared__ long slot_tok[64];
-  const int u = blockIdx.x, t = threadIdx.x, lane = t & 63, w = t >> 6;
+  const int u = blockIdx.x, t = threadIdx.x;
   const int beam = a.beam, P = a.P, V = a.V;
   const int C = beam * P;
   constexpr int RMAX = 4;                         // beam * P <= 1024 candidates (host check)
   float val[RMAX];
-  long key[RMAX];
+  unsigned long long key[RMAX];
 #pragma unroll
   for (int q = 0; q < RMAX; ++q) {
     const int c = t + 256 * q;
     val[q] = -INFINITY;
-    key[q] = 0x7ffffffffffffffeL;
+    key[q] = 0;
     if (c < C) {
       const int slot = c / P, j = c - slot * P;
       const long h = (long)u * beam + slot;
@@ -372,39 +461,25 @@ __global__ __launch_bounds__(256) void beam_step_kernel(const BeamStepArgs a) {
       float v = a.pre[h * V + tok] + prod;
       v = v + a.hyp[h];
       val[q] = (v != v) ? -INFINITY : v;
-      key[q] = (long)slot * V + tok;
+      key[q] = ((unsigned long long)sel_bits(val[q]) << 32) | (0xFFFFFFFFu - (unsigned)(slot * V + (int)tok));
+      ckey[c] = key[q];
     }
   }
-  float pv = INFINITY;
-  long pi = -1;
-  for (int r = 0; r < beam; ++r) {
-    float bv = -INFINITY;
-    long bi = 0x7fffffffffffffffL;
+  if (t < beam) { win_s[t] = -INFINITY; win_i[t] = 0; }            // fewer candidates than `beam`: dead slots
+  if (t == 0 && (C & 1)) ckey[C] = 0;                              // (the pair-wise walk below reads one past an odd count)
+  __syncthreads();
 #pragma unroll
-    for (int q = 0; q < RMAX; ++q)
-      if (t + 256 * q < C && sel_before(pv, pi, val[q], key[q]) && sel_before(val[q], key[q], bv, bi)) { bv = val[q]; bi = key[q]; }
-#pragma unroll
-    for (int m = 32; m >= 1; m >>= 1) {
-      const float ov = __shfl_xor(bv, m);
-      const long oi = __shfl_xor(bi, m);
-      if (sel_before(ov, oi, bv, bi)) { bv = ov; bi = oi; }
+  for (int q = 0; q < RMAX; ++q) {
+    if (t + 256 * q < C) {
+      int r = 0;
+      for (int j = 0; j < C; j += 2) {
+        const ulonglong2 o = *reinterpret_cast<const ulonglong2*>(&ckey[j]);
+        r += (o.x > key[q]) + (o.y > key[q]);
+      }
+      if (r < beam) { win_s[r] = val[q]; win_i[r] = (long)(0xFFFFFFFFu - (unsigned)key[q]); }
     }
-    if (lane == 0) { sv[w] = bv; si[w] = bi; }
-    __syncthreads();
-    if (t == 0) {
-      float fv = sv[0];
-      long fi = si[0];
-#pragma unroll
-      for (int q = 1; q < 4; ++q)
-        if (sel_before(sv[q], si[q], fv, fi)) { fv = sv[q]; fi = si[q]; }
-      if (fi == 0x7fffffffffffffffL) { fv = -INFINITY; fi = 0; }
-      wv = fv; wi = fi;
-      win_s[r] = fv; win_i[r] = fi;
-    }
-    __syncthreads();
-    pv = wv; pi = wi;
-    if (pi == 0 && pv == -INFINITY) pi = -1;
   }
+  __syncthreads();
   // ---- the bookkeeping of this utterance's slots (c_local of the block above is visible: the barriers of the rounds) ----
   const int RW = 3 + a.ns + a.W;
   if (t < beam) {
@@ -459,7 +534,7 @@ int eamd_beam_step(const float* pre, const int64_t* ids, const float* psi, const
     return EAMD_EINVAL;
   if (nutt <= 0 || beam <= 0 || P <= 0 || V <= 0 || W <= 0 || L < 0 || L >= W || ns < 1 || nf < 0 || nf > 4 || ns != nf + 1) return EAMD_EINVAL;
   if ((nf > 0 && !logps) || (long)nutt * beam > 0x7fffffffL) return EAMD_EINVAL;
-  if ((long)beam * P > 1024 || beam > 64) return EAMD_EUNSUPPORTED;
+  if ((long)beam * P > 1023 || beam > 64 || (long)beam * V > 0x7fffffffL) return EAMD_EUNSUPPORTED;
   BeamStepArgs a;
   for (int j = 0; j < 4; ++j) a.logp[j] = j < nf ? logps[j] : nullptr;
   for (int j = 0; j < nf; ++j) if (!a.logp[j]) return EAMD_EINVAL;
@@ -550,18 +625,14 @@ __global__ __launch_bounds__(256) void decode_src_attn_kernel(const float* __res
   __syncthreads();
   den = (red[4] + red[5]) + (red[6] + red[7]);
   float acc = 0.f;
-  int t = w;
-  for (; t + 28 < T; t += 32) {
-    float p[8], v[8];
+  for (int t0 = w; t0 < T; t0 += 256) {          // the value rows of 64 keys per wave requested together (see the grouped kernel)
+    float v[64];
+    const int tw = __builtin_amdgcn_readfirstlane(t0);
 #pragma unroll
-    for (int k = 0; k < 8; ++k) {
-      p[k] = sc[t + 4 * k];
-      v[k] = vb[(long)(t + 4 * k) * ldkv + lane];
-    }
+    for (int k = 0; k < 64; ++k) v[k] = (vb + (long)min(tw + 4 * k, T - 1) * ldkv)[lane];        // (unconditional, clamped: see below)
 #pragma unroll
-    for (int k = 0; k < 8; ++k) acc = fmaf(p[k], v[k], acc);
+    for (int k = 0; k < 64; ++k) acc = fmaf(tw + 4 * k < T ? sc[tw + 4 * k] : 0.f, v[k], acc);
   }
-  for (; t < T; t += 4) acc = fmaf(sc[t], vb[(long)t * ldkv + lane], acc);
   part[w * 64 + lane] = acc;
   __syncthreads();
   if (w == 0) {
@@ -570,6 +641,110 @@ __global__ __launch_bounds__(256) void decode_src_attn_kernel(const float* __res
   }
 }
 }  // namespace
+
+// Many utterances per search (32 x beam 10 hypotheses): one workgroup per (utterance, head) serves ALL g hypotheses of the utterance -
+// a key row and a value row are read once and meet the g queries / probability rows from LDS (the kernel above re-reads the
+// utterance's keys and values once per hypothesis: 431 -> 360 utt/s when it was tried at this size; the training kernel,
+// 64 queries per workgroup, took 23.5 us per layer here).  Same score and context arithmetic; the softmax sums run per wave.
+namespace {
+constexpr int SRC_GQ = 16;                       // hypotheses per utterance served by one workgroup
+__global__ __launch_bounds__(256) void decode_src_attn_group_kernel(const float* __restrict__ q, long ldq, const float* __restrict__ Km,
+                                                                    const float* __restrict__ Vm, long ldkv,
+                                                                    const unsigned char* __restrict__ mask, int g, int T, int Tp, int D,
+                                                                    float* __restrict__ ctx, float scale) {
+  extern __shared__ __attribute__((aligned(16))) float gsm[];
+  float* qs = gsm;                               // [SRC_GQ][64]
+  float* sc = qs + SRC_GQ * 64;                  // [g][Tp] scores, then unnormalised probabilities
+  float* part = sc + (long)SRC_GQ * Tp;          // [4][SRC_GQ][64]
+  float* den = part + 4 * SRC_GQ * 64;           // [SRC_GQ]
+  const int h = blockIdx.x, u = blockIdx.y, t_ = threadIdx.x, lane = t_ & 63, w = t_ >> 6;
+  const float* kb = Km + (long)u * T * ldkv + h * 64;
+  const float* vb = Vm + (long)u * T * ldkv + h * 64;
+  const unsigned char* mk = mask ? mask + (long)u * T : nullptr;
+  if (t_ < g * 16) {
+    const int r = t_ >> 4, c = t_ & 15;
+    *reinterpret_cast<float4*>(&qs[r * 64 + 4 * c]) = *reinterpret_cast<const float4*>(q + ((long)u * g + r) * ldq + h * 64 + 4 * c);
+  }
+  __syncthreads();
+  for (int t = t_; t < T; t += 256) {
+    const float4* kp = reinterpret_cast<const float4*>(kb + (long)t * ldkv);
+    float4 kv[16];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) kv[i] = kp[i];
+    const bool dead = mk && !mk[t];
+    for (int r = 0; r < g; ++r) {
+      float a = 0.f;
+#pragma unroll
+      for (int i = 0; i < 16; ++i) {
+        const float4 q4 = *reinterpret_cast<const float4*>(&qs[r * 64 + 4 * i]);
+        a = fmaf(q4.x, kv[i].x, fmaf(q4.y, kv[i].y, fmaf(q4.z, kv[i].z, fmaf(q4.w, kv[i].w, a))));
+      }
+      sc[(long)r * Tp + t] = dead ? -INFINITY : a * scale;
+    }
+  }
+  __syncthreads();
+  for (int r = w; r < g; r += 4) {               // a wave per probability row
+    float* sr = sc + (long)r * Tp;
+    float mx = -INFINITY;
+    for (int t = lane; t < T; t += 64) mx = fmaxf(mx, sr[t]);
+    mx = wave_max(mx);
+    float d = 0.f;
+    for (int t = lane; t < T; t += 64) {
+      const float e = mx == -INFINITY ? 0.f : __expf(sr[t] - mx);
+      sr[t] = e;
+      d += e;
+    }
+    d = wave_sum(d);
+    if (lane == 0) den[r] = d;
+  }
+  __syncthreads();
+  float acc[SRC_GQ];
+#pragma unroll
+  for (int r = 0; r < SRC_GQ; ++r) acc[r] = 0.f;
+  // a wave walks keys w, w + 4, ...: the value rows of 256 keys (64 per wave) are requested together (eight at a time, each
+  // batch waiting out a memory round trip, was most of this kernel's time)
+  for (int t0 = w; t0 < T; t0 += 256) {
+    // (unconditional loads of clamped rows: a load inside a branch is waited for at the end of its branch - 64 round trips)
+    float v[64];
+    const int tw = __builtin_amdgcn_readfirstlane(t0);
+#pragma unroll
+    for (int k = 0; k < 64; ++k) v[k] = (vb + (long)min(tw + 4 * k, T - 1) * ldkv)[lane];
+#pragma unroll
+    for (int k = 0; k < 64; ++k) v[k] = tw + 4 * k < T ? v[k] : 0.f;
+#pragma unroll
+    for (int r = 0; r < SRC_GQ; ++r) {
+      if (r < g) {
+#pragma unroll
+        for (int k = 0; k < 64; ++k) acc[r] = fmaf(sc[(long)r * Tp + min(tw + 4 * k, T - 1)], v[k], acc[r]);      // (past T: v = 0)
+      }
+    }
+  }
+#pragma unroll
+  for (int r = 0; r < SRC_GQ; ++r)
+    if (r < g) part[(w * SRC_GQ + r) * 64 + lane] = acc[r];
+  __syncthreads();
+  for (int idx = t_; idx < g * 64; idx += 256) {
+    const int r = idx >> 6, d = idx & 63;
+    const float s = (part[(0 * SRC_GQ + r) * 64 + d] + part[(1 * SRC_GQ + r) * 64 + d]) +
+                    (part[(2 * SRC_GQ + r) * 64 + d] + part[(3 * SRC_GQ + r) * 64 + d]);
+    ctx[((long)u * g + r) * D + h * 64 + d] = den[r] > 0.f ? s / den[r] : 0.f;        // every frame masked: zeros (attention.py:84-88)
+  }
+}
+}  // namespace
+
+extern "C" int eamd_decode_src_attn_group(const float* q, int64_t ldq, const float* kmem, const float* vmem, int64_t ldkv,
+                                          const uint8_t* mask, int nutt, int g, int T, int H, int D, float* ctx, void* stream) {
+  if (!q || !kmem || !vmem || !ctx || nutt <= 0 || g <= 0 || T <= 0 || H <= 0 || D <= 0) return EAMD_EINVAL;
+  if (ldq < D || ldkv < D) return EAMD_EINVAL;
+  if (D != H * 64 || T > 1024 || g > SRC_GQ || ldq % 4 != 0 || ldkv % 4 != 0 || (((uintptr_t)q | (uintptr_t)kmem | (uintptr_t)vmem) & 15))
+    return EAMD_EUNSUPPORTED;
+  const int Tp = (T + 3) & ~3;
+  const size_t lds = ((size_t)SRC_GQ * 64 + (size_t)SRC_GQ * Tp + 4 * SRC_GQ * 64 + SRC_GQ) * 4;
+  hipLaunchKernelGGL(decode_src_attn_group_kernel, dim3(H, nutt), dim3(256), lds, (hipStream_t)stream, q, (long)ldq, kmem, vmem, (long)ldkv,
+                     mask, g, T, Tp, D, ctx, 0.125f);
+  EAMD_LAUNCH_CHECK();
+  return EAMD_OK;
+}
 
 extern "C" int eamd_decode_src_attn(const float* q, int64_t ldq, const float* kmem, const float* vmem, int64_t ldkv,
                                     const uint8_t* mask, int nutt, int g, int T, int H, int D, float* ctx, void* stream) {

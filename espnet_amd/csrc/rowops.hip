@@ -716,9 +716,34 @@ __global__ __launch_bounds__(1024) void reduce_sum_kernel(const float* __restric
 // ctc.py:134-142 (CTC.log_softmax).
 __global__ __launch_bounds__(256) void log_softmax_rows_kernel(const float* __restrict__ x,
                                                                float* __restrict__ y, int V) {
+  // rows of up to 6144 elements are read ONCE and stay in registers over the three passes (maximum, sum of exponentials, write);
+  // a thread's elements and the order of its sums are those of the re-reading loops: the same bits
   __shared__ float red[16];
   const float* xr = x + (long)blockIdx.x * V;
   float* yr = y + (long)blockIdx.x * V;
+  constexpr int RMAX = 24;
+  const int t = threadIdx.x;
+  if (V <= RMAX * 256) {
+    float reg[RMAX];
+    float mx = -INFINITY;
+#pragma unroll
+    for (int q = 0; q < RMAX; ++q) {
+      const int v = t + 256 * q;
+      reg[q] = v < V ? xr[v] : -INFINITY;
+      mx = fmaxf(mx, reg[q]);
+    }
+    mx = block_max(mx, red);
+    float se = 0.f;
+#pragma unroll
+    for (int q = 0; q < RMAX; ++q)
+      if (t + 256 * q < V) se += __expf(reg[q] - mx);
+    se = block_sum(se, red);
+    const float lse = mx + __logf(se);
+#pragma unroll
+    for (int q = 0; q < RMAX; ++q)
+      if (t + 256 * q < V) yr[t + 256 * q] = reg[q] - lse;
+    return;
+  }
   float mx = -INFINITY;
   for (int v = threadIdx.x; v < V; v += blockDim.x) mx = fmaxf(mx, xr[v]);
   mx = block_max(mx, red);
@@ -832,33 +857,43 @@ __global__ __launch_bounds__(256) void linear_rows_wide_f32_kernel(const float* 
   for (int c = 0; c < CB; ++c)
 #pragma unroll
     for (int m = 0; m < 16; ++m) acc[c][m] = 0.f;
+  // rows in two halves of eight; both halves' loads are requested before the first product (QN <= 2: 32 float4 in flight)
+  constexpr bool BOTH = QN <= 2;
+  float4 xa[8][QN], xb[BOTH ? 8 : 1][QN];
+  auto load8 = [&](float4 (*dst)[QN], int mb) {
 #pragma unroll
-  for (int mb = 0; mb < 16; mb += 8) {
-    if (mb < M) {
-      float4 x4[8][QN];
+    for (int m = 0; m < 8; ++m) {
+      const float* xr = x + (long)min(mb + m, M - 1) * ldx;
 #pragma unroll
-      for (int m = 0; m < 8; ++m) {
-        const float* xr = x + (long)min(mb + m, M - 1) * ldx;
-#pragma unroll
-        for (int q = 0; q < QN; ++q) {
-          const int k = k0 + 256 * q;
-          x4[m][q] = k < K ? *reinterpret_cast<const float4*>(xr + k) : make_float4(0.f, 0.f, 0.f, 0.f);
-        }
-      }
-#pragma unroll
-      for (int m = 0; m < 8; ++m) {
-#pragma unroll
-        for (int q = 0; q < QN; ++q) {
-          float4 v = x4[m][q];
-          if (a_act != EAMD_ACT_NONE) {
-            v.x = eamd_act(v.x, a_act); v.y = eamd_act(v.y, a_act); v.z = eamd_act(v.z, a_act); v.w = eamd_act(v.w, a_act);
-          }
-#pragma unroll
-          for (int c = 0; c < CB; ++c)
-            acc[c][mb + m] = fmaf(v.x, w4[c][q].x, fmaf(v.y, w4[c][q].y, fmaf(v.z, w4[c][q].z, fmaf(v.w, w4[c][q].w, acc[c][mb + m]))));
-        }
+      for (int q = 0; q < QN; ++q) {
+        const int k = k0 + 256 * q;
+        dst[m][q] = k < K ? *reinterpret_cast<const float4*>(xr + k) : make_float4(0.f, 0.f, 0.f, 0.f);
       }
     }
+  };
+  auto fma8 = [&](float4 (*src)[QN], int mb) {
+#pragma unroll
+    for (int m = 0; m < 8; ++m) {
+#pragma unroll
+      for (int q = 0; q < QN; ++q) {
+        float4 v = src[m][q];
+        if (a_act != EAMD_ACT_NONE) {
+          v.x = eamd_act(v.x, a_act); v.y = eamd_act(v.y, a_act); v.z = eamd_act(v.z, a_act); v.w = eamd_act(v.w, a_act);
+        }
+#pragma unroll
+        for (int c = 0; c < CB; ++c)
+          acc[c][mb + m] = fmaf(v.x, w4[c][q].x, fmaf(v.y, w4[c][q].y, fmaf(v.z, w4[c][q].z, fmaf(v.w, w4[c][q].w, acc[c][mb + m]))));
+      }
+    }
+  };
+  load8(xa, 0);
+  if constexpr (BOTH) {
+    if (M > 8) load8(xb, 8);
+    fma8(xa, 0);
+    if (M > 8) fma8(xb, 8);
+  } else {
+    fma8(xa, 0);
+    if (M > 8) { load8(xa, 8); fma8(xa, 8); }
   }
   float mine = 0.f;
 #pragma unroll
@@ -1026,25 +1061,49 @@ __device__ __forceinline__ unsigned topk_bits(float v) {
 __device__ __forceinline__ float topk_value(unsigned b) { return __uint_as_float((b & 0x80000000u) ? (b ^ 0x80000000u) : ~b); }
 __device__ __forceinline__ unsigned long long topk_key(unsigned bits, unsigned i) { return ((unsigned long long)bits << 32) | (0xFFFFFFFFu - i); }
 
+// FUSED: the row is the weighted sum of up to four rows (the scorers' log-probabilities of a beam step, weighted_sum_kernel's
+// arithmetic: separately rounded products and sums), formed while it is read and written out as `pre` for the selection.
+struct TopkSum { const float* l[4]; float w[4]; float* pre; };
+template <bool FUSED>
 __global__ __launch_bounds__(256) void topk_rows_kernel(const float* __restrict__ x, long ld, int n, int k,
-                                                        float* __restrict__ vals, int64_t* __restrict__ idx, int32_t* __restrict__ idx32) {
+                                                        float* __restrict__ vals, int64_t* __restrict__ idx, int32_t* __restrict__ idx32,
+                                                        const TopkSum ws) {
+  auto element = [&](long i) -> float {
+    if constexpr (!FUSED) return x[(long)blockIdx.x * ld + i];
+    const long e = (long)blockIdx.x * n + i;
+    float v = ws.w[0] * ws.l[0][e];
+#pragma unroll
+    for (int j = 1; j < 4; ++j) {
+      if (ws.l[j]) {
+        float p = ws.w[j] * ws.l[j][e];
+        asm volatile("" : "+v"(p));                    // (keeps hipcc from fusing a * b + c: weighted_sum_kernel)
+        v += p;
+      }
+    }
+    ws.pre[e] = v;
+    return v;
+  };
   __shared__ __attribute__((aligned(16))) unsigned tmax[256];
   __shared__ unsigned long long cand[TOPK_CAP];
   __shared__ unsigned long long sk[4];
   __shared__ unsigned long long wk;
   __shared__ unsigned tau;
   __shared__ int cnt;
-  const float* xr = x + (long)blockIdx.x * ld;
   const int t = threadIdx.x, lane = t & 63, w = t >> 6;
   constexpr int RMAX = 24;                       // register-resident elements per thread (n <= 6144); longer rows re-read memory
   unsigned reg[RMAX];                            // order-preserving bits; 0 (below every real element) past the end of the row
   const bool inreg = n <= RMAX * 256;
+  const float* xr = FUSED ? ws.pre + (long)blockIdx.x * n : x + (long)blockIdx.x * ld;      // what the re-reading rounds walk
+  if (FUSED && !inreg) {                         // a long row: formed once, then read back like any other
+    for (long i = t; i < n; i += 256) element(i);
+    __syncthreads();
+  }
   if (inreg) {
     unsigned tm = 0;
 #pragma unroll
     for (int q = 0; q < RMAX; ++q) {
       const int i = t + 256 * q;
-      reg[q] = i < n ? topk_bits(xr[i]) : 0u;
+      reg[q] = i < n ? topk_bits(element(i)) : 0u;
       tm = max(tm, reg[q]);
     }
     tmax[t] = tm;
@@ -1387,10 +1446,24 @@ int eamd_topk_rows(const float* x, int64_t ld, int rows, int n, int k, float* va
   return eamd_topk_rows_i32(x, ld, rows, n, k, vals, idx, nullptr, stream);
 }
 
+int eamd_weighted_topk_rows(const float* const* logps, const float* weights, int nf, int rows, int n, int k, float* pre, float* vals,
+                            int64_t* idx, int32_t* idx32, void* stream) {
+  if (!logps || !weights || !pre || !vals || !idx || nf < 1 || nf > 4 || rows <= 0 || n <= 0 || k <= 0 || k > n) return EAMD_EINVAL;
+  if (k > 64) return EAMD_EUNSUPPORTED;
+  TopkSum ws;
+  for (int j = 0; j < 4; ++j) { ws.l[j] = j < nf ? logps[j] : nullptr; ws.w[j] = j < nf ? weights[j] : 0.f; }
+  for (int j = 0; j < nf; ++j) if (!ws.l[j]) return EAMD_EINVAL;
+  ws.pre = pre;
+  hipLaunchKernelGGL(topk_rows_kernel<true>, dim3(rows), dim3(256), 0, (hipStream_t)stream, (const float*)nullptr, (long)n, n, k, vals, idx,
+                     idx32, ws);
+  EAMD_LAUNCH_CHECK();
+  return EAMD_OK;
+}
+
 int eamd_topk_rows_i32(const float* x, int64_t ld, int rows, int n, int k, float* vals, int64_t* idx, int32_t* idx32, void* stream) {
   if (!x || !vals || !idx || rows <= 0 || n <= 0 || k <= 0 || k > n || ld < n) return EAMD_EINVAL;
   if (k > 64) return EAMD_EUNSUPPORTED;
-  hipLaunchKernelGGL(topk_rows_kernel, dim3(rows), dim3(256), 0, (hipStream_t)stream, x, ld, n, k, vals, idx, idx32);
+  hipLaunchKernelGGL(topk_rows_kernel<false>, dim3(rows), dim3(256), 0, (hipStream_t)stream, x, ld, n, k, vals, idx, idx32, TopkSum{});
   EAMD_LAUNCH_CHECK();
   return EAMD_OK;
 }

@@ -51,6 +51,19 @@ def end_detect(ended_hyps, i, M=3, D_end=math.log(1 * math.exp(-10))):
     return count == M
 
 
+def _end_detect_sl(ended, i, M=3, D_end=math.log(1 * math.exp(-10))):
+    """end_detect on (score, length) pairs (the same test without building a dict per hypothesis per step)"""
+    if not ended:
+        return False
+    best = max(s for s, _ in ended)
+    count = 0
+    for m in range(M):
+        same = [s for s, n in ended if n == i - m]
+        if same and max(same) - best < D_end:
+            count += 1
+    return count == M
+
+
 class BeamSearch(torch.nn.Module):
     # how partial scorers report: "ids" = scores of the pre-beam ids only, everything else is dropped
     # (beam_search.py:226-262); "full" = (n, V) matrices (batch_beam_search.py:221-231)
@@ -490,8 +503,11 @@ class BeamSearch(torch.nn.Module):
                 and all(logps[k].dtype == torch.float32 and logps[k].is_contiguous() for k in names)):
             # BeamSearch with a pre-beam: the step's selection on the beam x P candidates (csrc/decode.hip: eamd_weighted_sum,
             # eamd_beam_select) - same scores in the same order of operations as the tensor expressions below, 12 launches fewer
-            pre = ops.weighted_sum([logps[k] for k in names], [self.weights[k] for k in names])
-            _, part_ids, cand32 = ops.topk_rows(pre, P, idx32=True)
+            if self.step_kernel and P <= 64:      # the weighted sum is formed inside the pre-beam's top-k launch
+                pre, part_ids, cand32 = ops.weighted_topk_rows([logps[k] for k in names], [self.weights[k] for k in names], P)
+            else:
+                pre = ops.weighted_sum([logps[k] for k in names], [self.weights[k] for k in names])
+                _, part_ids, cand32 = ops.topk_rows(pre, P, idx32=True)
             # the newest token of every prefix as int32: the previous step's selection wrote it (eamd_beam_step), <sos> at step 0
             last = S["last32"] if "last32" in S else (C_["sos32"] if i == 0 else ys[:, -1].to(torch.int32).contiguous())
             if side is not None:
@@ -503,7 +519,7 @@ class BeamSearch(torch.nn.Module):
             if psi is None:       # more than 512 frames: the full recursion for every candidate
                 olen = torch.full((n,), L - 1, dtype=torch.int32, device=dev)
                 psi, r_new = ops.ctc_prefix_score_batch(C_["logp"], C_["lens_d"], beam, c_r_now, cand32, last, olen, ctc.blank, ctc.eos)
-            if self.step_kernel and beam <= 64 and r_new is None:
+            if self.step_kernel and beam <= 64 and beam * P <= 1023 and beam * V < 2 ** 31 and r_new is None:
                 sc_new, yseq, hyp_new, hyp_i, tok_i, tok32, cs_new, rec = ops.beam_step(
                     pre, part_ids, psi, S["c_s"], hyp, self.weights[pname], B, beam, L, i, self.eos, C_["maxlen_d"].view(-1),
                     S["sc"], [logps[k] for k in names], yseq)
@@ -726,6 +742,7 @@ class _BatchLog:
     def __init__(self, bs, B, maxlens, maxlenratio, allk):
         self.bs, self.B, self.maxlens, self.maxlenratio, self.allk = bs, B, maxlens, maxlenratio, allk
         self.ended = [[] for _ in range(B)]
+        self.ended_sl = [[] for _ in range(B)]            # (score, length) of the ended hypotheses: what end detection reads
         self.stopped = [False] * B
         self.pending = []
 
@@ -737,38 +754,45 @@ class _BatchLog:
         return False
 
     def flush(self):
+        """the fetched log rows, vectorised over slots: only the slots that END in a step are walked in Python (with the whole
+        [n, 3 + scorers + W] row turned into Python floats, a fetch of 8 steps x 320 slots took 2 - 20 ms of host time in
+        which the device idled)"""
+        import numpy as np
         bs, B, beam, allk = self.bs, self.B, self.bs.beam_size, self.allk
         if not self.pending:
             return all(self.stopped)
-        host = torch.stack(self.pending).cpu()                   # [steps, n, 3 + len(allk) + W]
+        host = torch.stack(self.pending).cpu().numpy()           # [steps, n, 3 + len(allk) + W]
         self.pending = []
+        na = len(allk)
+        maxl = np.asarray(self.maxlens)
         for row in host:
             i = int(row[0, 0])
-            slots = row.tolist()
+            L = i + 2
+            ts = row[:, 1].reshape(B, beam)
+            tok = row[:, 2].reshape(B, beam)
+            fin = np.isfinite(ts)
+            at_cap = (maxl - 1 == i)[:, None]
+            live = ~np.asarray(self.stopped)[:, None]
+            ends = fin & ((tok == bs.eos) | at_cap) & live
+            alive = (fin & ~ends).sum(1)
+            for b, j in zip(*np.nonzero(ends)):
+                slot = row[b * beam + j]
+                top_s = float(slot[1])
+                seq = slot[3 + na: 3 + na + L].astype(np.int64).tolist()
+                if i == self.maxlens[b] - 1:
+                    seq.append(bs.eos)
+                scores = {k: float(slot[3 + q]) for q, k in enumerate(allk)}
+                if bs.apply_final_score:
+                    for k, d in chain(bs.full_scorers.items(), bs.part_scorers.items()):
+                        f = float(d.final_tree(None)) if hasattr(d, "final_tree") else float(d.final_score(None))
+                        scores[k] += f
+                        top_s += bs.weights[k] * f
+                self.ended[b].append(Hypothesis(yseq=torch.tensor(seq, dtype=torch.int64), score=top_s, scores=scores, states={}))
+                self.ended_sl[b].append((top_s, len(seq)))
             for b in range(B):
                 if self.stopped[b]:
                     continue
-                alive = 0
-                for slot in slots[b * beam: (b + 1) * beam]:
-                    top_s = slot[1]
-                    if not math.isfinite(top_s):
-                        continue
-                    L = i + 2
-                    seq = [int(v) for v in slot[3 + len(allk): 3 + len(allk) + L]]
-                    if i == self.maxlens[b] - 1:
-                        seq.append(bs.eos)
-                    if seq[-1] == bs.eos:
-                        scores = {k: slot[3 + j] for j, k in enumerate(allk)}
-                        if bs.apply_final_score:
-                            for k, d in chain(bs.full_scorers.items(), bs.part_scorers.items()):
-                                f = float(d.final_tree(None)) if hasattr(d, "final_tree") else float(d.final_score(None))
-                                scores[k] += f
-                                top_s += bs.weights[k] * f
-                        self.ended[b].append(Hypothesis(yseq=torch.tensor(seq, dtype=torch.int64), score=top_s, scores=scores, states={}))
-                    else:
-                        alive += 1
-                if (self.maxlenratio == 0.0 and end_detect([h.asdict() for h in self.ended[b]], i)) or alive == 0 \
-                        or i == self.maxlens[b] - 1:
+                if (self.maxlenratio == 0.0 and _end_detect_sl(self.ended_sl[b], i)) or alive[b] == 0 or i == self.maxlens[b] - 1:
                     self.stopped[b] = True
             if all(self.stopped):
                 return True

@@ -1055,8 +1055,9 @@ class Decoder(torch.nn.Module, BatchScorerInterface):
             k2, v2 = sp.block(i, 0), sp.block(i, D)
             # a handful of hypotheses: one wave group per (hypothesis, head); many (32 utterances x beam 10) re-read an utterance's
             # keys / values once per hypothesis that way (431 -> 360 utt/s) - those keep the 64-queries-per-workgroup kernel
-            cx = ops.decode_src_attn(q2, k2.t, k2.off, v2.off, k2.ld, mask, G, n // G, T, H) \
-                if (n <= 32 and k2.t.dtype == torch.float32 and (mask is None or mask.shape[1] == 1)) else None
+            # (... 32 utterances: one workgroup per (utterance, head) for all its hypotheses, keys / values read once)
+            cx = ops.decode_src_attn(q2, k2.t, k2.off, v2.off, k2.ld, mask, G, n // G, T, H, group=n > 32) \
+                if (k2.t.dtype == torch.float32 and (mask is None or mask.shape[1] == 1)) else None
             fwd = None
             if cx is None and F_.FUSE_ATTN and ops.attn_fwd_supported(n // G, T, a.d_k, False):
                 fwd = F_.attn_fwd_fused(q2, None, k2, v2, None, mask, G, n // G, T, H, a.d_k)

@@ -472,10 +472,13 @@ def inference_call(fn):
         with inference():
             return fn(*a, **k)
     return wrapped
-# rows up to which it is used.  Beyond 16 rows the library has a one-wave-per-16x16-tile MFMA form (direct global loads, no LDS);
-# at the batched beam search's M = 320 it changes nothing measurable (graph step 2.14 vs 2.16 ms: the replayed step is bound by
-# its number of kernel nodes, not by these launches), so the tiles stay
+# rows up to which it is used.  Beyond 16 rows the library has a one-wave-per-16x16-tile MFMA form (direct global loads, no LDS).
+# Measured in the replayed step of a batched beam search (M = 320 rows, tools/trace_decode_graph.sh, round 4): 7.0 us against
+# 13.1 us of the 64 x 64 tiles for N = 256 / 768 at K = 256 (those are 20 / 60 workgroups walking K alone), the same for N = 2048,
+# SLOWER for K = 2048 (33 against 26 us with split-K: every wave re-reads its 32 rows of both operands) and for the output
+# layer (N = 5000: 29.7 against 17.8 us) - so it takes the narrow products only
 LINEAR_ROWS_MAX = int(os.environ.get("EAMD_LINEAR_ROWS_MAX", "16"))
+LINEAR_ROWS_BLOCK_MAX = int(os.environ.get("EAMD_LINEAR_ROWS_BLOCK_MAX", "1024"))      # ... up to this many rows, K <= 512, N <= 1024
 
 
 def linear_fwd(x, W, b, out=None, *, act=EPI_NONE, R=None, alpha=1.0, a_act=ACT_NONE, out_dtype=torch.float32,
@@ -486,7 +489,7 @@ def linear_fwd(x, W, b, out=None, *, act=EPI_NONE, R=None, alpha=1.0, a_act=ACT_
     M, K = x.shape
     N = W.shape[0]
     assert W.shape[1] == K and W.is_contiguous() and x.stride(1) == 1 and (R is None or R.stride(-1) == 1)
-    if (LINEAR_ROWS and M <= LINEAR_ROWS_MAX and out is None and out_dtype == torch.float32 and x.dtype == torch.float32 and W.dtype == torch.float32
+    if (LINEAR_ROWS and (M <= LINEAR_ROWS_MAX or (M <= LINEAR_ROWS_BLOCK_MAX and K <= 512 and N <= 1024 and K % 16 == 0)) and out is None and out_dtype == torch.float32 and x.dtype == torch.float32 and W.dtype == torch.float32
             and act in (EPI_NONE, EPI_RELU, EPI_SWISH) and a_act in (ACT_NONE, ACT_RELU, ACT_SWISH) and drop is None and Hb is None
             and a_drop is None and K % 4 == 0 and _state["precision"] == 0 and _infer > 0 and not torch.is_grad_enabled()
             and (R is None or (tuple(R.shape) == (M, N) and (M == 1 or R.stride(0) >= N))) and (M == 1 or x.stride(0) >= K)):
@@ -1245,11 +1248,14 @@ def reduce_sum(x, scale=1.0):
 
 
 def linear_rows_ln(x, gamma, beta, eps, W, b, *, act=EPI_NONE, R=None, alpha=1.0, out=None):
-    """y = alpha * act(LayerNorm(x) W^T + b) + R for at most 16 rows in ONE launch (eamd_linear_rows_ln_f32), or None when the
-    library declines (more rows, K > 1024, unaligned): the caller then normalises and multiplies in two launches"""
+    """y = alpha * act(LayerNorm(x) W^T + b) + R in ONE launch (eamd_linear_rows_ln_f32: at most 16 rows, or up to 1024 rows at
+    K <= 256 in 16-row blocks on the matrix cores), or None when the library declines (more rows, wider K, unaligned): the caller
+    then normalises and multiplies in two launches"""
     M, K = x.shape
     N = W.shape[0]
-    if M > 16 or K > 1024 or x.dtype != torch.float32 or W.dtype != torch.float32 or x.stride(1) != 1 or act not in (EPI_NONE, EPI_RELU, EPI_SWISH):
+    # (16-row blocks: every 16 x 16 tile's wave repeats the LayerNorm of its rows - measured at M = 320: 10.6 us against
+    # LayerNorm + product = 4.7 + 7.8 us at N = 256 / 768, but 18.8 against 18.4 at N = 2048 and 40 against 22.5 at N = 5000)
+    if (M > 16 and (K > 256 or M > LINEAR_ROWS_BLOCK_MAX or N > 1024)) or K > 1024 or x.dtype != torch.float32 or W.dtype != torch.float32 or x.stride(1) != 1 or act not in (EPI_NONE, EPI_RELU, EPI_SWISH):
         return None
     y = out if out is not None else torch.empty(M, N, device=x.device, dtype=torch.float32)
     rc = _lib.lib().eamd_linear_rows_ln_f32(ptr(x), ptr(gamma), ptr(beta), C.c_float(eps), ptr(W), ptr(b), ptr(R), ptr(y), M, N, K,
@@ -1273,13 +1279,15 @@ def decode_self_attn(qkv, Kc, Vc, slot_at, pos, H):
     return ctx
 
 
-def decode_src_attn(q, kv, k_off, v_off, ldkv, mask, G, g, T, H):
+def decode_src_attn(q, kv, k_off, v_off, ldkv, mask, G, g, T, H, group=False):
     """one query position per hypothesis over the memory of its utterance (eamd_decode_src_attn): q [G * g, D]; kv = the tensor
     that holds keys / values of this layer at element offsets k_off / v_off, row stride ldkv ([G * T] rows); mask [G, 1, T] uint8
-    or None -> ctx [G * g, D], or None when the library declines"""
+    or None -> ctx [G * g, D], or None when the library declines.  group: one workgroup per (utterance, head) for all g
+    hypotheses (eamd_decode_src_attn_group; g <= 16, T <= 1024) instead of one per (hypothesis, head)"""
     n, D = q.shape
     ctx = torch.empty(n, D, device=q.device, dtype=torch.float32)
-    rc = _lib.lib().eamd_decode_src_attn(ptr(q), C.c_int64(q.stride(0)), ptr(kv, k_off), ptr(kv, v_off), C.c_int64(ldkv), ptr(mask),
+    fn = _lib.lib().eamd_decode_src_attn_group if group else _lib.lib().eamd_decode_src_attn
+    rc = fn(ptr(q), C.c_int64(q.stride(0)), ptr(kv, k_off), ptr(kv, v_off), C.c_int64(ldkv), ptr(mask),
                                          G, g, T, H, D, ptr(ctx), stream_ptr())
     if rc == _lib.EAMD_EUNSUPPORTED:
         return None
@@ -1302,6 +1310,23 @@ def weighted_sum(logps, weights):
     wts = (C.c_float * 4)(*[float(w) for w in weights] + [0.0] * (4 - len(weights)))
     check(_lib.lib().eamd_weighted_sum(arr, wts, len(logps), C.c_int64(out.numel()), ptr(out), stream_ptr()), "eamd_weighted_sum")
     return out
+
+
+def weighted_topk_rows(logps, weights, k):
+    """weighted_sum + topk_rows(idx32=True) in one launch (eamd_weighted_topk_rows) -> (pre [n, V], idx int64 [n, k], idx32)"""
+    n, V = logps[0].shape
+    for lp in logps:
+        if lp.dtype != torch.float32 or not lp.is_contiguous() or lp.shape != (n, V):
+            raise _lib.EamdError("weighted_topk_rows: contiguous float32 [n, V] matrices")
+    pre = torch.empty_like(logps[0])
+    vals = torch.empty(n, k, device=pre.device, dtype=torch.float32)
+    idx = torch.empty(n, k, device=pre.device, dtype=torch.int64)
+    i32 = torch.empty(n, k, device=pre.device, dtype=torch.int32)
+    arr = (C.c_void_p * 4)(*[lp.data_ptr() for lp in logps] + [None] * (4 - len(logps)))
+    wts = (C.c_float * 4)(*[float(w) for w in weights] + [0.0] * (4 - len(weights)))
+    check(_lib.lib().eamd_weighted_topk_rows(arr, wts, len(logps), n, V, k, ptr(pre), ptr(vals), ptr(idx), ptr(i32), stream_ptr()),
+          "eamd_weighted_topk_rows")
+    return pre, idx, i32
 
 
 def beam_select(pre, ids, psi, c_s, hyp, w_ctc, nutt, beam):

@@ -403,7 +403,7 @@ int eamd_linear_rows_f32(const float* x, const float* W, const float* bias, cons
                          int a_act, int act, float alpha, int64_t ldx, int64_t ldr, void* stream);
 /* Cached decoding of the Transformer decoder, csrc/decode.hip (reference: transformer/decoder.py:283-321, decoder_layer.py:81-134).
  * eamd_linear_rows_ln_f32: y[M, N] (row stride ldy) = alpha * act(LayerNorm(x; gamma, beta, eps) W^T + bias) + R for M <= 16 rows,
- *   K <= 1024: the pre-norm of a decoder sub-block inside the product behind it (layer_norm.py:12-38 in front of attention.py:40-61 /
+ *   K <= 1024 (or 16 < M <= 1024 rows at K <= 256, K % 16 == 0: 16-row blocks on the matrix cores): the pre-norm of a decoder sub-block inside the product behind it (layer_norm.py:12-38 in front of attention.py:40-61 /
  *   positionwise_feed_forward.py:28 / decoder.py:312-317); row strides 0 = dense.
  * eamd_decode_self_attn: self-attention of the NEWEST position of n hypotheses over their prefixes, keys / values cached per layer in
  *   time-major [Lcap, n, D] buffers: row (pos, slot) is written from qkv [n, ldq] = (q | k | v) of this step, rows t < pos are read
@@ -424,6 +424,10 @@ int eamd_beam_slots(const int32_t* slot_in, int32_t* slot_out, const int64_t* hy
  * (attention.py:80-88). */
 int eamd_decode_src_attn(const float* q, int64_t ldq, const float* kmem, const float* vmem, int64_t ldkv, const uint8_t* mask, int nutt,
                          int g, int T, int H, int D, float* ctx, void* stream);
+/* ... one workgroup per (utterance, head) for all g <= 16 hypotheses of the utterance (many utterances per search: the keys and
+ * values of an utterance are read once per head, not once per hypothesis); T <= 1024. */
+int eamd_decode_src_attn_group(const float* q, int64_t ldq, const float* kmem, const float* vmem, int64_t ldkv, const uint8_t* mask, int nutt,
+                         int g, int T, int H, int D, float* ctx, void* stream);
 /* The selection of a beam step on the pre-beam candidates (reference: beam_search.py:296-334 with :199-226: tokens outside the pre-beam
  * are dropped, so an utterance's `beam` best continuations are among its beam x P candidates).
  * eamd_weighted_sum: out[i] = ((0 + w_0 logp_0[i]) + w_1 logp_1[i]) + ... over nf <= 4 full scorers ([n, V] each; numel = n V, a
@@ -441,11 +445,15 @@ int eamd_beam_select(const float* pre, const int64_t* ids, const float* psi, con
 int eamd_topk_rows(const float* x, int64_t ld, int rows, int n, int k, float* vals, int64_t* idx, void* stream);
 /* ... the indices also as int32 (idx32 [rows, k], may be NULL): the candidate list eamd_ctc_prefix_psi takes. */
 int eamd_topk_rows_i32(const float* x, int64_t ld, int rows, int n, int k, float* vals, int64_t* idx, int32_t* idx32, void* stream);
+/* eamd_weighted_sum + eamd_topk_rows_i32 in one launch: pre [rows, n] = sum_j weights[j] * logps[j] (written out; HOST arrays of
+ * nf <= 4 device pointers / floats, the same separately rounded arithmetic), and the k largest of each of its rows. */
+int eamd_weighted_topk_rows(const float* const* logps, const float* weights, int nf, int rows, int n, int k, float* pre, float* vals,
+                            int64_t* idx, int32_t* idx32, void* stream);
 /* eamd_beam_select + eamd_beam_finish of a BeamSearch step with a pre-beam in one launch (one workgroup per utterance; same
  * arithmetic): the arguments of both - ids [n, P] the candidates, ns == nf + 1 (the partial scorer's row is last), W the width of the
  * prefix buffers, L the position the new token takes - plus tok32 [n] = tok_i as int32 (the next step's `last`) and
  * cs_out [n] = psi at the chosen candidate of the extended hypothesis (the partial scorer's running prefix score).  beam <= 64,
- * beam * P <= 1024.  reference: beam_search.py:143-226,296-334. */
+ * beam * P <= 1023, beam * V < 2^31.  reference: beam_search.py:143-226,296-334. */
 int eamd_beam_step(const float* pre, const int64_t* ids, const float* psi, const float* c_s, const float* hyp, float w_ctc, int nutt,
                    int beam, int P, int V, int W, int L, int step, int eos, const int64_t* maxlen, int ns, int nf, const float* sc_in,
                    const float* const* logps, const int64_t* yseq_in, float* c_local, float* sc_out, int64_t* yseq_out, float* hyp_out,

@@ -1570,6 +1570,14 @@ def test_topk_rows(ops, rows, n, k):
     torch.cuda.synchronize()
     assert torch.equal(v, v2) and torch.equal(i, i2) and i.dtype == torch.int64 and v.shape == (rows, k)
     assert j2.dtype == torch.int32 and torch.equal(j2.long(), i2)
+    if n % 4 == 0:       # the same selection with the row formed inside the launch (eamd_weighted_topk_rows): bit-equal to sum, then top-k
+        parts = [torch.randn(rows, n, generator=g).to(DEV) for _ in range(3)]
+        wts = [0.7, 0.1, -0.35]
+        pre_ref = ops.weighted_sum(parts, wts)
+        vr, ir = ops.topk_rows(pre_ref, k)
+        pre, i3, j3 = ops.weighted_topk_rows(parts, wts, k)
+        torch.cuda.synchronize()
+        assert torch.equal(pre, pre_ref) and torch.equal(i3, ir) and torch.equal(j3.long(), ir)
     xr = torch.where(torch.isnan(x), torch.full_like(x, -float("inf")), x)
     rv, _ = torch.topk(xr, k, dim=1)
     assert torch.equal(v.cpu(), rv)
@@ -1603,7 +1611,7 @@ def test_linear_rows_f32(ops, M, N, K, a_act, act, res):
     f = {0: lambda v: v, 1: lambda v: v.clamp_min(0), 2: lambda v: v * torch.sigmoid(v)}
     ref = 0.5 * f[act](f[a_act](x.double()) @ W.double().t() + b.double()) + (R.double() if res else 0.0)
     with torch.no_grad():
-        keep_max, ops.LINEAR_ROWS_MAX = ops.LINEAR_ROWS_MAX, 1024          # also the row-block form (M > 16: off by default)
+        keep_max, ops.LINEAR_ROWS_MAX = ops.LINEAR_ROWS_MAX, 1024          # also the row-block form for every shape (M > 16: by default only K <= 512, N <= 1024)
         try:
             y = ops.linear_fwd(x.to(DEV), W.to(DEV), b.to(DEV), act=act, a_act=a_act, alpha=0.5, R=R.to(DEV) if res else None)
         finally:
@@ -1907,7 +1915,13 @@ def test_decode_kernels_vs_float64(ops):
         wide[:, 2] = x
         y2 = ops.linear_rows_ln(wide.to(DEV)[:, 2], gam.to(DEV), bet.to(DEV), 1e-12, W.to(DEV), None)
         report("linear_rows_ln strided rows", y2, ln @ W.double().t(), 2e-6)
-    assert ops.linear_rows_ln(rnd(17, 256).to(DEV), rnd(256).to(DEV), rnd(256).to(DEV), 1e-12, rnd(8, 256).to(DEV), None) is None
+    assert ops.linear_rows_ln(rnd(17, 512).to(DEV), rnd(512).to(DEV), rnd(512).to(DEV), 1e-12, rnd(8, 512).to(DEV), None) is None
+    # 16-row blocks on the matrix cores (a batched search's utterances x beam rows), K <= 256
+    for (M, K, N) in ((320, 256, 768), (33, 256, 1024), (17, 64, 30), (1000, 256, 256)):
+        x, gam, bet, W, b, R = rnd(M, K), 1.0 + 0.1 * rnd(K), 0.1 * rnd(K), rnd(N, K) / K ** 0.5, 0.1 * rnd(N), rnd(M, N)
+        y = ops.linear_rows_ln(x.to(DEV), gam.to(DEV), bet.to(DEV), 1e-12, W.to(DEV), b.to(DEV), act=ops.EPI_RELU, R=R.to(DEV), alpha=0.5)
+        ln = torch.nn.functional.layer_norm(x.double(), (K,), gam.double(), bet.double(), 1e-12)
+        report(f"linear_rows_ln (16-row blocks) {M}x{K}x{N}", y, 0.5 * torch.relu(ln @ W.double().t() + b.double()) + R.double(), 2e-6)
     n, H, D, Lcap = 10, 4, 256, 24
     Kc, Vc = torch.full((Lcap, n, D), float("nan"), device=DEV), torch.full((Lcap, n, D), float("nan"), device=DEV)
     slot = torch.zeros(n, Lcap, dtype=torch.int32, device=DEV)
@@ -1954,10 +1968,24 @@ def test_decode_src_attn_vs_float64(ops):
             want[r] = torch.einsum("ht,thd->hd", p, Vv).reshape(D)
         report("decode_src_attn layer %d" % layer, ctx, want, 2e-6)
         assert float(ctx[2 * gb:].abs().max()) == 0.0
+        # ... one workgroup per (utterance, head) for all hypotheses of the utterance
+        ctx_g = ops.decode_src_attn(q.to(DEV), kv.to(DEV), k_off, v_off, 2 * D * L, mask.to(DEV), G, gb, T, H, group=True)
+        report("decode_src_attn (grouped) layer %d" % layer, ctx_g, want, 2e-6)
+        assert float(ctx_g[2 * gb:].abs().max()) == 0.0
     ctx = ops.decode_src_attn(q.to(DEV), kv.to(DEV), 0, D, 2 * D * L, None, G, gb, T, H)
     K = kv[:T, :D].double().view(-1, H, 64)
     p = torch.softmax(torch.einsum("hd,thd->ht", q[0].double().view(H, 64), K) / 8.0, -1)
     report("decode_src_attn no mask", ctx[0], torch.einsum("ht,thd->hd", p, kv[:T, D:2 * D].double().view(-1, H, 64)).reshape(D), 2e-6)
+    # the benchmarked shape of a batched search: 32 utterances x 10 hypotheses, 249 frames
+    G, gb, T = 32, 10, 249
+    kv = torch.randn(G * T, 2 * D, generator=g)
+    q = torch.randn(G * gb, D, generator=g)
+    ctx_g = ops.decode_src_attn(q.to(DEV), kv.to(DEV), 0, D, 2 * D, None, G, gb, T, H, group=True)
+    K = kv[:, :D].double().view(G, T, H, 64)
+    Vv = kv[:, D:].double().view(G, T, H, 64)
+    p = torch.softmax(torch.einsum("gbhd,gthd->gbht", q.double().view(G, gb, H, 64), K) / 8.0, -1)
+    report("decode_src_attn (grouped) 32 x 10 x 249", ctx_g, torch.einsum("gbht,gthd->gbhd", p, Vv).reshape(G * gb, D), 2e-6)
+    assert ops.decode_src_attn(q.to(DEV), kv.to(DEV), 0, D, 2 * D, None, 16, 20, T, H, group=True) is None       # more than 16 per utterance
 
 
 def test_graph_audit_rejects_memset_nodes():

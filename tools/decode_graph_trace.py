@@ -19,8 +19,9 @@ bs = BeamSearch(dict(decoder=model.decoder, ctc=CTCPrefixScorer(model.ctc, model
 bs.graph_steps = True
 nstep = int(os.environ.get("EAMD_TRACE_STEPS", "24"))
 ratio = (nstep + 0.5) / enc.shape[0]
+nutt = int(os.environ.get("EAMD_TRACE_BATCH", "1"))          # > 1: that many utterances per search (forward_batch)
 for it in range(4):          # eager, capture, replay, replay
     torch.cuda.synchronize(); t0 = time.perf_counter()
-    nb = bs(enc, maxlenratio=ratio)
+    nb = bs(enc, maxlenratio=ratio) if nutt == 1 else bs.forward_batch([enc] * nutt, maxlenratio=ratio)[0]
     torch.cuda.synchronize(); t1 = time.perf_counter()
-    print("search %d: %.3f ms per step (%d steps), best len %d" % (it, (t1 - t0) * 1e3 / nstep, nstep, len(nb[0].yseq)), flush=True)
+    print("search %d: %.3f ms per step (%d steps, %d utterances), best len %d" % (it, (t1 - t0) * 1e3 / nstep, nstep, nutt, len(nb[0].yseq)), flush=True)
