@@ -453,6 +453,7 @@ __global__ __launch_bounds__(256) void beam_step_kernel(const BeamStepArgs a) {
       const int slot = c / P, j = c - slot * P;
       const long h = (long)u * beam + slot;
       long long tok = a.ids[h * P + j];
+      const bool none = tok < 0;                                       // no candidate in this column: ranks last, selects nothing
       tok = tok < 0 ? 0 : (tok >= V ? V - 1 : tok);
       const float cl = __fsub_rn(a.psi[h * P + j], a.c_s[h]);
       a.c_local[h * P + j] = cl;
@@ -460,8 +461,9 @@ __global__ __launch_bounds__(256) void beam_step_kernel(const BeamStepArgs a) {
       asm volatile("" : "+v"(prod));
       float v = a.pre[h * V + tok] + prod;
       v = v + a.hyp[h];
-      val[q] = (v != v) ? -INFINITY : v;
-      key[q] = ((unsigned long long)sel_bits(val[q]) << 32) | (0xFFFFFFFFu - (unsigned)(slot * V + (int)tok));
+      val[q] = (v != v || none) ? -INFINITY : v;
+      // (its index lies beyond the utterance's beam x V continuations: distinct from every real key, a dead slot if it ever wins)
+      key[q] = ((unsigned long long)sel_bits(val[q]) << 32) | (0xFFFFFFFFu - (unsigned)(none ? beam * V + c : slot * V + (int)tok));
       ckey[c] = key[q];
     }
   }
@@ -534,7 +536,7 @@ int eamd_beam_step(const float* pre, const int64_t* ids, const float* psi, const
     return EAMD_EINVAL;
   if (nutt <= 0 || beam <= 0 || P <= 0 || V <= 0 || W <= 0 || L < 0 || L >= W || ns < 1 || nf < 0 || nf > 4 || ns != nf + 1) return EAMD_EINVAL;
   if ((nf > 0 && !logps) || (long)nutt * beam > 0x7fffffffL) return EAMD_EINVAL;
-  if ((long)beam * P > 1023 || beam > 64 || (long)beam * V > 0x7fffffffL) return EAMD_EUNSUPPORTED;
+  if ((long)beam * P > 1023 || beam > 64 || (long)beam * V + 1024 > 0x7fffffffL) return EAMD_EUNSUPPORTED;
   BeamStepArgs a;
   for (int j = 0; j < 4; ++j) a.logp[j] = j < nf ? logps[j] : nullptr;
   for (int j = 0; j < nf; ++j) if (!a.logp[j]) return EAMD_EINVAL;

@@ -1063,7 +1063,9 @@ __device__ __forceinline__ unsigned long long topk_key(unsigned bits, unsigned i
 
 // FUSED: the row is the weighted sum of up to four rows (the scorers' log-probabilities of a beam step, weighted_sum_kernel's
 // arithmetic: separately rounded products and sums), formed while it is read and written out as `pre` for the selection.
-struct TopkSum { const float* l[4]; float w[4]; float* pre; };
+// extra >= 0: one more output column per row (row stride k + 1) = that token, or -1 when it is already among the k (the <eos> a
+// "full"-mode partial scorer always scores besides the pre-beam: batch_beam_search.py:221-231 with scorers/ctc.py:82-96).
+struct TopkSum { const float* l[4]; float w[4]; float* pre; int extra; };
 template <bool FUSED>
 __global__ __launch_bounds__(256) void topk_rows_kernel(const float* __restrict__ x, long ld, int n, int k,
                                                         float* __restrict__ vals, int64_t* __restrict__ idx, int32_t* __restrict__ idx32,
@@ -1090,6 +1092,12 @@ __global__ __launch_bounds__(256) void topk_rows_kernel(const float* __restrict_
   __shared__ unsigned tau;
   __shared__ int cnt;
   const int t = threadIdx.x, lane = t & 63, w = t >> 6;
+  const int ko = k + (ws.extra >= 0 ? 1 : 0);    // output row stride
+  if (t == 0 && ws.extra >= 0) {
+    idx[(long)blockIdx.x * ko + k] = ws.extra;
+    if (idx32) idx32[(long)blockIdx.x * ko + k] = ws.extra;
+    vals[(long)blockIdx.x * ko + k] = 0.f;
+  }
   constexpr int RMAX = 24;                       // register-resident elements per thread (n <= 6144); longer rows re-read memory
   unsigned reg[RMAX];                            // order-preserving bits; 0 (below every real element) past the end of the row
   const bool inreg = n <= RMAX * 256;
@@ -1133,11 +1141,15 @@ __global__ __launch_bounds__(256) void topk_rows_kernel(const float* __restrict_
         int r = 0;
         for (int q = 0; q < c; ++q) r += cand[q] > my;
         if (r < k) {
-          const long o = (long)blockIdx.x * k + r;
+          const long o = (long)blockIdx.x * ko + r;
           const unsigned i = 0xFFFFFFFFu - (unsigned)my;
           vals[o] = topk_value((unsigned)(my >> 32));
           idx[o] = (int64_t)i;
           if (idx32) idx32[o] = (int32_t)i;
+          if ((int)i == ws.extra) {              // (after the barriers above: ordered behind thread 0's store)
+            idx[(long)blockIdx.x * ko + k] = -1;
+            if (idx32) idx32[(long)blockIdx.x * ko + k] = -1;
+          }
         }
       }
       return;
@@ -1171,11 +1183,15 @@ __global__ __launch_bounds__(256) void topk_rows_kernel(const float* __restrict_
 #pragma unroll
       for (int q = 1; q < 4; ++q) f = sk[q] > f ? sk[q] : f;
       wk = f;
-      const long o = (long)blockIdx.x * k + r;
+      const long o = (long)blockIdx.x * ko + r;
       const unsigned i = 0xFFFFFFFFu - (unsigned)f;
       vals[o] = topk_value((unsigned)(f >> 32));
       idx[o] = (int64_t)i;
       if (idx32) idx32[o] = (int32_t)i;
+      if ((int)i == ws.extra) {
+        idx[(long)blockIdx.x * ko + k] = -1;
+        if (idx32) idx32[(long)blockIdx.x * ko + k] = -1;
+      }
     }
     __syncthreads();
     prev = wk;
@@ -1446,11 +1462,12 @@ int eamd_topk_rows(const float* x, int64_t ld, int rows, int n, int k, float* va
   return eamd_topk_rows_i32(x, ld, rows, n, k, vals, idx, nullptr, stream);
 }
 
-int eamd_weighted_topk_rows(const float* const* logps, const float* weights, int nf, int rows, int n, int k, float* pre, float* vals,
-                            int64_t* idx, int32_t* idx32, void* stream) {
-  if (!logps || !weights || !pre || !vals || !idx || nf < 1 || nf > 4 || rows <= 0 || n <= 0 || k <= 0 || k > n) return EAMD_EINVAL;
+int eamd_weighted_topk_rows(const float* const* logps, const float* weights, int nf, int rows, int n, int k, int extra, float* pre,
+                            float* vals, int64_t* idx, int32_t* idx32, void* stream) {
+  if (!logps || !weights || !pre || !vals || !idx || nf < 1 || nf > 4 || rows <= 0 || n <= 0 || k <= 0 || k > n || extra >= n) return EAMD_EINVAL;
   if (k > 64) return EAMD_EUNSUPPORTED;
   TopkSum ws;
+  ws.extra = extra < 0 ? -1 : extra;
   for (int j = 0; j < 4; ++j) { ws.l[j] = j < nf ? logps[j] : nullptr; ws.w[j] = j < nf ? weights[j] : 0.f; }
   for (int j = 0; j < nf; ++j) if (!ws.l[j]) return EAMD_EINVAL;
   ws.pre = pre;
@@ -1463,7 +1480,7 @@ int eamd_weighted_topk_rows(const float* const* logps, const float* weights, int
 int eamd_topk_rows_i32(const float* x, int64_t ld, int rows, int n, int k, float* vals, int64_t* idx, int32_t* idx32, void* stream) {
   if (!x || !vals || !idx || rows <= 0 || n <= 0 || k <= 0 || k > n || ld < n) return EAMD_EINVAL;
   if (k > 64) return EAMD_EUNSUPPORTED;
-  hipLaunchKernelGGL(topk_rows_kernel<false>, dim3(rows), dim3(256), 0, (hipStream_t)stream, x, ld, n, k, vals, idx, idx32, TopkSum{});
+  hipLaunchKernelGGL(topk_rows_kernel<false>, dim3(rows), dim3(256), 0, (hipStream_t)stream, x, ld, n, k, vals, idx, idx32, TopkSum{{nullptr, nullptr, nullptr, nullptr}, {0.f, 0.f, 0.f, 0.f}, nullptr, -1});
   EAMD_LAUNCH_CHECK();
   return EAMD_OK;
 }

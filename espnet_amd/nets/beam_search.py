@@ -51,6 +51,10 @@ def end_detect(ended_hyps, i, M=3, D_end=math.log(1 * math.exp(-10))):
     return count == M
 
 
+class _OutsideCandidates(Exception):
+    """raised by the host side of a "full"-mode search whose candidate selection kernel picked a log-zero continuation"""
+
+
 def _end_detect_sl(ended, i, M=3, D_end=math.log(1 * math.exp(-10))):
     """end_detect on (score, length) pairs (the same test without building a dict per hypothesis per step)"""
     if not ended:
@@ -399,6 +403,18 @@ class BeamSearch(torch.nn.Module):
         ok = self._device_loop_ok(xs[0]) and minlenratio == 0.0
         if not ok:
             return [self.forward(x, maxlenratio, minlenratio) for x in xs]
+        try:
+            return self._forward_batch(xs, maxlenratio)
+        except _OutsideCandidates:
+            # "full" mode only: a token OUTSIDE the pre-beam candidates could have won (fewer live candidates than the beam) -
+            # the search runs again on the tensor expressions over all V tokens
+            keep, self.candidate_select = self.candidate_select, False
+            try:
+                return self._forward_batch(xs, maxlenratio)
+            finally:
+                self.candidate_select = keep
+
+    def _forward_batch(self, xs, maxlenratio):
         if self.graph_steps:
             out = self._forward_batch_graphed(xs, maxlenratio)
             if out is not None:
@@ -498,12 +514,22 @@ class BeamSearch(torch.nn.Module):
             else:
                 logps[k], newtrees[k] = d.score_tree(ys, trees[k], mem)
         P = self.pre_beam_size
-        if (ctc is not None and self.do_pre_beam and self.partial_mode == "ids" and self.pre_beam_score_key == "full" and 1 <= len(names) <= 4
-                and V % 4 == 0 and beam * P <= 1024 and self.candidate_select
+        full_fast = (self.partial_mode == "full" and self.step_kernel and P <= 63 and P + 1 >= beam and beam * (P + 1) <= 1023
+                     and beam <= 64 and beam * V < 2 ** 31 - 1024
+                     and self.ctc_psi_parallel and C_["Tpad"] <= 512)
+        if (ctc is not None and self.do_pre_beam and (self.partial_mode == "ids" or full_fast) and self.pre_beam_score_key == "full"
+                and 1 <= len(names) <= 4 and V % 4 == 0 and beam * P <= 1024 and self.candidate_select
                 and all(logps[k].dtype == torch.float32 and logps[k].is_contiguous() for k in names)):
             # BeamSearch with a pre-beam: the step's selection on the beam x P candidates (csrc/decode.hip: eamd_weighted_sum,
             # eamd_beam_select) - same scores in the same order of operations as the tensor expressions below, 12 launches fewer
-            if self.step_kernel and P <= 64:      # the weighted sum is formed inside the pre-beam's top-k launch
+            # BatchBeamSearch ("full": the partial scorer reports a whole [n, V] row - log-zero outside the pre-beam, <eos> always
+            # scored; nothing is masked): the same selection on P + 1 candidates, the pre-beam and <eos>.  Every other token's
+            # score is ~ -3e9 (weight x log-zero): it can only win where an utterance has fewer live candidates than `beam` -
+            # the host sees that in the step log (a winner below -1e9) and repeats the search on the tensor expressions.
+            if full_fast:
+                pre, part_ids, cand32 = ops.weighted_topk_rows([logps[k] for k in names], [self.weights[k] for k in names], P,
+                                                               extra=ctc.eos)
+            elif self.step_kernel and P <= 64:      # the weighted sum is formed inside the pre-beam's top-k launch
                 pre, part_ids, cand32 = ops.weighted_topk_rows([logps[k] for k in names], [self.weights[k] for k in names], P)
             else:
                 pre = ops.weighted_sum([logps[k] for k in names], [self.weights[k] for k in names])
@@ -771,6 +797,8 @@ class _BatchLog:
             ts = row[:, 1].reshape(B, beam)
             tok = row[:, 2].reshape(B, beam)
             fin = np.isfinite(ts)
+            if bs.partial_mode == "full" and bs.candidate_select and (fin & (ts < -1e9) & ~np.asarray(self.stopped)[:, None]).any():
+                raise _OutsideCandidates()
             at_cap = (maxl - 1 == i)[:, None]
             live = ~np.asarray(self.stopped)[:, None]
             ends = fin & ((tok == bs.eos) | at_cap) & live

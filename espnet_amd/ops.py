@@ -1312,19 +1312,21 @@ def weighted_sum(logps, weights):
     return out
 
 
-def weighted_topk_rows(logps, weights, k):
-    """weighted_sum + topk_rows(idx32=True) in one launch (eamd_weighted_topk_rows) -> (pre [n, V], idx int64 [n, k], idx32)"""
+def weighted_topk_rows(logps, weights, k, extra=-1):
+    """weighted_sum + topk_rows(idx32=True) in one launch (eamd_weighted_topk_rows) -> (pre [n, V], idx int64 [n, k], idx32).
+    extra >= 0: a column k with that token (-1 where it is already among the k) is appended to idx / idx32"""
     n, V = logps[0].shape
+    ko = k + (1 if extra >= 0 else 0)
     for lp in logps:
         if lp.dtype != torch.float32 or not lp.is_contiguous() or lp.shape != (n, V):
             raise _lib.EamdError("weighted_topk_rows: contiguous float32 [n, V] matrices")
     pre = torch.empty_like(logps[0])
-    vals = torch.empty(n, k, device=pre.device, dtype=torch.float32)
-    idx = torch.empty(n, k, device=pre.device, dtype=torch.int64)
-    i32 = torch.empty(n, k, device=pre.device, dtype=torch.int32)
+    vals = torch.empty(n, ko, device=pre.device, dtype=torch.float32)
+    idx = torch.empty(n, ko, device=pre.device, dtype=torch.int64)
+    i32 = torch.empty(n, ko, device=pre.device, dtype=torch.int32)
     arr = (C.c_void_p * 4)(*[lp.data_ptr() for lp in logps] + [None] * (4 - len(logps)))
     wts = (C.c_float * 4)(*[float(w) for w in weights] + [0.0] * (4 - len(weights)))
-    check(_lib.lib().eamd_weighted_topk_rows(arr, wts, len(logps), n, V, k, ptr(pre), ptr(vals), ptr(idx), ptr(i32), stream_ptr()),
+    check(_lib.lib().eamd_weighted_topk_rows(arr, wts, len(logps), n, V, k, int(extra), ptr(pre), ptr(vals), ptr(idx), ptr(i32), stream_ptr()),
           "eamd_weighted_topk_rows")
     return pre, idx, i32
 

@@ -446,13 +446,16 @@ int eamd_topk_rows(const float* x, int64_t ld, int rows, int n, int k, float* va
 /* ... the indices also as int32 (idx32 [rows, k], may be NULL): the candidate list eamd_ctc_prefix_psi takes. */
 int eamd_topk_rows_i32(const float* x, int64_t ld, int rows, int n, int k, float* vals, int64_t* idx, int32_t* idx32, void* stream);
 /* eamd_weighted_sum + eamd_topk_rows_i32 in one launch: pre [rows, n] = sum_j weights[j] * logps[j] (written out; HOST arrays of
- * nf <= 4 device pointers / floats, the same separately rounded arithmetic), and the k largest of each of its rows. */
-int eamd_weighted_topk_rows(const float* const* logps, const float* weights, int nf, int rows, int n, int k, float* pre, float* vals,
-                            int64_t* idx, int32_t* idx32, void* stream);
+ * nf <= 4 device pointers / floats, the same separately rounded arithmetic), and the k largest of each of its rows.
+ * extra >= 0: vals / idx / idx32 are [rows, k + 1], the last column = the token `extra`, or -1 where it is already among the k
+ * (the <eos> a "full"-mode partial scorer scores besides the pre-beam: batch_beam_search.py:221-231, scorers/ctc.py:82-96). */
+int eamd_weighted_topk_rows(const float* const* logps, const float* weights, int nf, int rows, int n, int k, int extra, float* pre,
+                            float* vals, int64_t* idx, int32_t* idx32, void* stream);
 /* eamd_beam_select + eamd_beam_finish of a BeamSearch step with a pre-beam in one launch (one workgroup per utterance; same
  * arithmetic): the arguments of both - ids [n, P] the candidates, ns == nf + 1 (the partial scorer's row is last), W the width of the
  * prefix buffers, L the position the new token takes - plus tok32 [n] = tok_i as int32 (the next step's `last`) and
- * cs_out [n] = psi at the chosen candidate of the extended hypothesis (the partial scorer's running prefix score).  beam <= 64,
+ * cs_out [n] = psi at the chosen candidate of the extended hypothesis (the partial scorer's running prefix score).  A candidate
+ * id < 0 is no candidate (it is never selected).  beam <= 64,
  * beam * P <= 1023, beam * V < 2^31.  reference: beam_search.py:143-226,296-334. */
 int eamd_beam_step(const float* pre, const int64_t* ids, const float* psi, const float* c_s, const float* hyp, float w_ctc, int nutt,
                    int beam, int P, int V, int W, int L, int step, int eos, const int64_t* maxlen, int ns, int nf, const float* sc_in,

@@ -2126,3 +2126,28 @@ def test_beam_ctc_split_matches_full_recursion():
     for a, b in zip(res["full"], res["split"]):
         assert [x[0] for x in a] == [x[0] for x in b]
         assert all(abs(x[1] - y[1]) <= 1e-5 * max(1.0, abs(x[1])) for x, y in zip(a, b))
+
+
+def test_batch_beam_candidate_selection_matches_tensor_expressions():
+    """BatchBeamSearch ("full" mode: the CTC scorer reports whole [n, V] rows, log-zero outside the pre-beam, <eos> always scored):
+    the selection on the P + 1 candidates (pre-beam and <eos>: eamd_weighted_topk_rows with the extra column, eamd_ctc_prefix_psi,
+    eamd_beam_step) against the tensor expressions over all V tokens - same token ids, scores within 1e-5 relative (the candidates'
+    CTC scores come from the parallel reduction there and from the frame-by-frame recursion here)"""
+    from espnet_amd.nets.batch_beam_search import BatchBeamSearch
+    from espnet_amd.nets.ctc_prefix_score import LengthBonus
+    SW, model, g, encs = c2width_setup()
+    spec = SW.DECODE_R4
+    res = {}
+    for sel in (True, False):
+        scorers = model.scorers()
+        scorers["length_bonus"] = LengthBonus(spec["odim"])
+        bs = BatchBeamSearch(scorers, dict(decoder=0.7, ctc=0.3, length_bonus=0.1), spec["beam"], spec["odim"], model.sos, model.eos,
+                             pre_beam_score_key="full")
+        bs.candidate_select = sel
+        one = [bs(e, maxlenratio=0.2) for e in encs]
+        many = bs.forward_batch(encs, maxlenratio=0.0)
+        res[sel] = [[(h.yseq.tolist(), float(h.score), {k: float(v) for k, v in h.scores.items()}) for h in nb[:10]] for nb in one + many]
+    for a, b in zip(res[True], res[False]):
+        assert [x[0] for x in a] == [x[0] for x in b]
+        assert all(abs(x[1] - y[1]) <= 1e-5 * max(1.0, abs(x[1])) for x, y in zip(a, b))
+        assert all(abs(x[2][k] - y[2][k]) <= 1e-5 * max(1.0, abs(x[2][k])) for x, y in zip(a, b) for k in x[2])

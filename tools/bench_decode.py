@@ -54,7 +54,7 @@ def _graph_leg(tag, n_utts, beam, ctc_weight, maxlenratio):
     import subprocess
     try:
         r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "bench_decode_graph.py"), str(n_utts), str(beam), str(ctc_weight),
-                            str(maxlenratio)], capture_output=True, text=True, timeout=300)
+                            str(maxlenratio), tag], capture_output=True, text=True, timeout=300)
         if r.returncode != 0:
             return dict(error="child exited with %d: %s" % (r.returncode, r.stderr[-200:]))
         return json.loads(r.stdout.strip().splitlines()[-1])
@@ -140,7 +140,7 @@ def decode_leg(dev, c2_args, n_beam_utts=2, beam=10, ctc_weight=0.3, maxlenratio
         batched = dict(utterances=B, utt_per_s=round(B / tb, 2), rtf=float("%.3e" % (tb / audio_s)), beam_steps=bsteps,
                        ms_per_beam_step=round(tb / bsteps * 1e3, 3), hypotheses_found=[len(u) for u in nb][:4],
                        note="BeamSearch.forward_batch: one device-resident search over all utterances")
-        graph = _graph_leg(tag, n_beam_utts, beam, ctc_weight, maxlenratio) if tag == "beam_search" else None
+        graph = _graph_leg(tag, n_beam_utts, beam, ctc_weight, maxlenratio)
         out[tag] = dict(beam=beam, ctc_weight=ctc_weight, maxlenratio=maxlenratio, utterances_timed=n_beam_utts, graph_steps=graph,
                         utt_per_s=round(n_beam_utts / tot, 2), rtf=float("%.3e" % (tot / a_s)), beam_steps=steps,
                         ms_per_beam_step=round(tot / steps * 1e3, 3), per_beam_step=counts, batched=batched,

@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Child of tools/bench_decode.py: BeamSearch with graph_steps on utterances of one frame bucket (config-2 model, random-init
 weights) - one eager search, one capturing search, then the timed replays; prints one JSON line.
-usage: bench_decode_graph.py <utterances timed> <beam> <ctc weight> <maxlenratio>"""
+usage: bench_decode_graph.py <utterances timed> <beam> <ctc weight> <maxlenratio> [beam_search | batch_beam_search]"""
 import json
 import os
 import sys
@@ -15,9 +15,13 @@ sys.path.insert(0, ROOT)
 
 def main():
     n_timed, beam, cw, ratio = int(sys.argv[1]), int(sys.argv[2]), float(sys.argv[3]), float(sys.argv[4])
+    which = sys.argv[5] if len(sys.argv) > 5 else "beam_search"
     import bench
     import espnet_amd
-    from espnet_amd.nets.beam_search import BeamSearch
+    if which == "batch_beam_search":
+        from espnet_amd.nets.batch_beam_search import BatchBeamSearch as BeamSearch
+    else:
+        from espnet_amd.nets.beam_search import BeamSearch
     from espnet_amd.nets.ctc_prefix_score import CTCPrefixScorer
     from espnet_amd.nets.e2e_asr_conformer import E2E
     from espnet_amd.nets.modules import embed_output_lengths, make_non_pad_mask
