@@ -1,0 +1,79 @@
+#!/usr/bin/env python3
+"""Round-4 fixture (b), by RUNNING THE REFERENCE (kan-bayashi/espnet v0.9.5, PyTorch CPU) in the build container:
+
+  e2e_conformer_d512.npz  espnet1 Conformer E2E at the width of the reference's large recipes (egs/librispeech/asr1 conformer:
+                          adim 512, aheads 8 - d_k = 64 -, eunits = dunits = 2048), 2 encoder layers, 1 decoder layer,
+                          idim 80, |V| = 50, three utterances of 300 / 251 / 180 frames: loss, loss_ctc, acc, hs_pad, pred_pad,
+                          greedy CTC ids, every parameter gradient (whole where small, else as two random projections:
+                          oracle/seeded_weights.py grad_record).
+
+Weights are NOT stored: both sides fill them from oracle/seeded_weights.py (name-keyed generator, salt 512).
+Usage: python oracle/gen_golden_r4b.py [--ref /root/reference] [--out tests/golden]
+"""
+import argparse
+import os
+import sys
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, HERE)
+from gen_golden import install_stubs, save  # noqa: E402
+import seeded_weights as SW  # noqa: E402
+
+D512 = dict(idim=80, odim=50, salt=512, seed=512, lens=(300, 251, 180),
+            ns=dict(adim=512, aheads=8, elayers=2, eunits=2048, dlayers=1, dunits=2048, mtlalpha=0.3, lsm_weight=0.1, dropout_rate=0.0,
+                    transformer_attn_dropout_rate=0.0, transformer_length_normalized_loss=False, transformer_init="pytorch",
+                    transformer_input_layer="conv2d", ctc_type="builtin", report_cer=False, report_wer=False, char_list=None,
+                    sym_space="<space>", sym_blank="<blank>", transformer_encoder_pos_enc_layer_type="rel_pos",
+                    transformer_encoder_selfattn_layer_type="rel_selfattn", transformer_encoder_activation_type="swish",
+                    macaron_style=True, use_cnn_module=True, cnn_module_kernel=31))
+
+
+def d512_inputs():
+    g = torch.Generator().manual_seed(D512["seed"])
+    xs = torch.randn(3, 300, D512["idim"], generator=g)
+    ilens = torch.tensor(D512["lens"])
+    ys = torch.randint(1, D512["odim"] - 1, (3, 12), generator=g)
+    ys[1, 9:] = -1
+    ys[2, 5:] = -1
+    return xs, ilens, ys
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--ref", default="/root/reference")
+    ap.add_argument("--out", default=os.path.join(HERE, "..", "tests", "golden"))
+    a = ap.parse_args()
+    install_stubs()
+    sys.path.insert(0, a.ref)
+    torch.set_num_threads(8)
+    from espnet.nets.pytorch_backend.e2e_asr_conformer import E2E
+    torch.manual_seed(D512["seed"])
+    model = SW.fill_parameters(E2E(D512["idim"], D512["odim"], argparse.Namespace(**D512["ns"])), salt=D512["salt"])
+    model.train()
+    xs, ilens, ys = d512_inputs()
+    loss = model(xs, ilens, ys)
+    loss.backward()
+    rec = dict(loss=float(loss), acc=float(model.acc), hs_pad=model.hs_pad.detach().clone(), pred_pad=model.pred_pad.detach().clone(),
+               loss_ctc=float(model.ctc.loss))
+    for name, p in model.named_parameters():
+        if p.grad is not None:
+            rec.update(SW.grad_record(name, p.grad))
+    model.eval()
+    with torch.no_grad():
+        from itertools import groupby
+        greedy, glens = [], []
+        for b in range(3):
+            lz = model.ctc.argmax(model.encoder(xs[b:b + 1, :int(ilens[b])], None)[0])
+            ids = [v for v in (k[0] for k in groupby(lz[0].tolist())) if v != 0]
+            greedy += ids
+            glens.append(len(ids))
+    save(os.path.join(a.out, "e2e_conformer_d512.npz"), xs=xs, ilens=ilens, ys=ys, greedy=np.asarray(greedy, dtype=np.int64),
+         greedy_lens=np.asarray(glens, dtype=np.int64), **rec)
+    print("loss %.6f ctc %.6f acc %.4f greedy lens %s" % (float(loss), float(model.ctc.loss), float(model.acc), glens))
+
+
+if __name__ == "__main__":
+    main()

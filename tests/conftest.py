@@ -55,6 +55,21 @@ def seeded_weights():
     return SW
 
 
+def e2e_d512_model(dropout=0.0):
+    """our espnet1 Conformer E2E at the width of the reference's large recipes (adim 512, aheads 8, eunits = dunits = 2048) with
+    the name-keyed weights oracle/gen_golden_r4b.py gave the reference model of e2e_conformer_d512.npz; -> (model on CPU, oracle cfg)"""
+    import argparse
+    from espnet_amd.nets.e2e_asr_conformer import E2E
+    ns = argparse.Namespace(
+        adim=512, aheads=8, elayers=2, eunits=2048, dlayers=1, dunits=2048, mtlalpha=0.3, lsm_weight=0.1, dropout_rate=dropout,
+        transformer_length_normalized_loss=False, transformer_encoder_pos_enc_layer_type="rel_pos",
+        transformer_encoder_selfattn_layer_type="rel_selfattn", macaron_style=True, use_cnn_module=True,
+        cnn_module_kernel=31)
+    model = seeded_weights().fill_parameters(E2E(80, 50, ns), salt=512)
+    cfg = dict(conformer=True, rel_pos=True, activation="swish", aheads=8, mtlalpha=0.3, lsm_weight=0.1, odim=50)
+    return model, cfg
+
+
 def e2e_dk64_model(dropout=0.0):
     """our espnet1 Conformer E2E at adim 256 / aheads 4 (d_k = 64: the width at which bf16 mode dispatches the fused
     attention kernels) with the name-keyed weights oracle/gen_golden_r2.py gave the reference model of

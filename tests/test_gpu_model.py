@@ -560,6 +560,47 @@ def test_e2e_conformer_dk64_golden(prec):
             off += n
 
 
+@pytest.mark.parametrize("prec", ["fp32", "bf16"])
+def test_e2e_conformer_d512_golden(prec):
+    """espnet1 Conformer E2E at the width of the reference's large recipes (egs/librispeech/asr1 conformer: adim 512, aheads 8,
+    eunits = dunits = 2048; tests/golden/e2e_conformer_d512.npz from oracle/gen_golden_r4b.py) against the reference: loss, CTC
+    loss, accuracy, encoder output, every parameter gradient, greedy ids."""
+    import espnet_amd
+    from espnet_amd import train
+    from conftest import e2e_d512_model
+    g = load_golden("e2e_conformer_d512.npz")
+    model, _cfg = e2e_d512_model()
+    model = model.to(DEV).train()
+    flat = train.FlatParams(model)
+    flat.expose_grads()
+    espnet_amd.set_precision(prec)
+    try:
+        xs, ilens, ys = torch.from_numpy(g["xs"]).to(DEV), torch.from_numpy(g["ilens"]), torch.from_numpy(g["ys"]).to(DEV)
+        loss = model(xs, ilens, ys)
+        loss.backward()
+        ref = float(g["loss"])
+        rel = abs(float(loss) - ref) / abs(ref)
+        relc = abs(float(model.ctc.loss) - float(g["loss_ctc"])) / abs(float(g["loss_ctc"]))
+        print(f"[parity] e2e_conformer_d512[{prec}] loss hip={float(loss):.6f} ref={ref:.6f} rel={rel:.2e}; ctc rel={relc:.2e}; "
+              f"acc hip={model.acc} ref={float(g['acc'])}")
+        assert rel < (1e-5 if prec == "fp32" else 1e-3) and relc < (1e-5 if prec == "fp32" else 1e-3)
+        report("e2e_conformer_d512[%s] hs_pad" % prec, model.hs_pad, torch.from_numpy(g["hs_pad"]), 1e-4 if prec == "fp32" else 2e-2)
+        if prec == "fp32":
+            assert abs(model.acc - float(g["acc"])) < 1e-6
+        _check_seeded(model, g, 1e-3 if prec == "fp32" else 5e-2,
+                      loose=() if prec == "fp32" else (("decoders.0.feed_forward.w_1", 0.2), ("decoders.0.norm3", 0.1)))
+        if prec == "fp32":      # greedy CTC ids, bit-exact, every utterance at its own length
+            model.eval()
+            ra = argparse.Namespace(ctc_weight=1.0, beam_size=1)
+            off = 0
+            for b, n in enumerate(g["greedy_lens"].tolist()):
+                hyp = model.recognize(g["xs"][b, : int(g["ilens"][b])], ra)
+                assert hyp[0]["yseq"][1:] == g["greedy"][off:off + n].tolist(), b
+                off += n
+    finally:
+        espnet_amd.set_precision("fp32")
+
+
 def test_edge_fixtures_on_hip():
     """the standalone-module fixtures of rows a6 / a8 / a9 / a4 on the HIP path (they used to be consumed by the CPU
     oracle tests only): mha.npz (source attention, causal self-attention with a fully masked QUERY row), rel_mha.npz,

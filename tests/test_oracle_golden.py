@@ -482,6 +482,28 @@ def test_e2e_conformer_dk64(oracle):
     assert _check_seeded_grads(SW, sd, g, 2e-4) < 2e-4
 
 
+def test_e2e_conformer_d512(oracle):
+    """the oracle end to end at the width of the reference's large recipes (adim 512, aheads 8, eunits = dunits = 2048;
+    oracle/gen_golden_r4b.py) against the reference's loss, encoder output and gradients"""
+    import os, sys
+    from conftest import ROOT
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import seeded_weights as SW
+    from conftest import e2e_d512_model
+    g = load_golden("e2e_conformer_d512.npz")
+    model, cfg = e2e_d512_model()
+    sd = {k: (v.clone().requires_grad_(True) if v.is_floating_point() and "running" not in k else v.clone())
+          for k, v in model.state_dict().items()}
+    xs, ilens, ys = torch.from_numpy(g["xs"]), g["ilens"].tolist(), torch.from_numpy(g["ys"])
+    out = oracle.e2e_forward(sd, xs, ilens, ys, cfg, training=True)
+    assert abs(float(out["loss"]) - float(g["loss"])) <= 2e-5 * abs(float(g["loss"]))
+    assert abs(float(out["loss_ctc"]) - float(g["loss_ctc"])) <= 2e-5 * abs(float(g["loss_ctc"]))
+    assert abs(float(out["acc"]) - float(g["acc"])) < 1e-6
+    close(out["hs_pad"], torch.from_numpy(g["hs_pad"]), rtol=2e-4, atol=2e-5)
+    out["loss"].backward()
+    assert _check_seeded_grads(SW, sd, g, 2e-4) < 2e-4
+
+
 # ---- round-3 fixtures (oracle/gen_golden_r3.py): the remaining get_activation entries, any-width subsampling, scheduled
 # sampling, the WarmupLR / Adadelta traces ---------------------------------------------------------------------------
 @pytest.mark.parametrize("name", ["hardtanh", "tanh", "selu"])
