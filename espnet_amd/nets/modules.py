@@ -519,12 +519,13 @@ class ConformerEncoderLayer(torch.nn.Module):
     def __init__(self, size, self_attn, feed_forward, feed_forward_macaron, conv_module, dropout_rate,
                  normalize_before=True, concat_after=False):
         super().__init__()
-        if not normalize_before or concat_after:
-            raise NotImplementedError("only pre-norm without concat_after is on the HIP path")
         self.self_attn = self_attn
         self.feed_forward = feed_forward
         self.feed_forward_macaron = feed_forward_macaron
         self.conv_module = conv_module
+        if concat_after:
+            self.concat_linear = torch.nn.Linear(size + size, size)
+        self.salts = [ops.new_salt() for _ in range(4)]       # dropout sites of the composed (post-norm / concat) form
         self.norm_ff = LayerNorm(size)
         self.norm_mha = LayerNorm(size)
         if feed_forward_macaron is not None:
@@ -549,6 +550,9 @@ class ConformerEncoderLayer(torch.nn.Module):
             x, pos_emb = x_input
         else:
             x, pos_emb = x_input, None
+        if not self.normalize_before or self.concat_after:
+            x = self._forward_composed(x, pos_emb, mask)
+            return ((x, pos_emb), mask) if pos_emb is not None else (x, mask)
         if self.feed_forward_macaron is not None:
             x = ffn_block(self.norm_ff_macaron, self.feed_forward_macaron, x, self.ff_scale, p)
         x = mha_block(self.norm_mha, self.self_attn, x, None, pos_emb, mask, p_out=p, pre=self._pre)
@@ -562,13 +566,33 @@ class ConformerEncoderLayer(torch.nn.Module):
         return x, mask
 
 
+    def _forward_composed(self, x, pos_emb, mask):
+        """encoder_layer.py:99-157 with normalize_before=False (LayerNorm behind each residual sum) and / or concat_after
+        (x + concat_linear([x, att(x)])): composed from the modules' own forwards - the fused blocks are the pre-norm form"""
+        nb, tr, p = self.normalize_before, self.training, self.dropout_rate
+        drop = lambda y, i: F_.dropout(y, p, self.salts[i], tr)  # noqa: E731
+        if self.feed_forward_macaron is not None:
+            x = x + self.ff_scale * drop(self.feed_forward_macaron(self.norm_ff_macaron(x) if nb else x), 0)
+            x = x if nb else self.norm_ff_macaron(x)
+        xn = self.norm_mha(x) if nb else x
+        att = self.self_attn(xn, xn, xn, pos_emb, mask) if pos_emb is not None else self.self_attn(xn, xn, xn, mask)
+        x = x + (self.concat_linear(torch.cat([xn, att], -1)) if self.concat_after else drop(att, 1))
+        x = x if nb else self.norm_mha(x)
+        if self.conv_module is not None:
+            x = x + drop(self.conv_module(self.norm_conv(x) if nb else x), 2)
+            x = x if nb else self.norm_conv(x)
+        x = x + self.ff_scale * drop(self.feed_forward(self.norm_ff(x) if nb else x), 3)
+        x = x if nb else self.norm_ff(x)
+        if self.conv_module is not None:
+            x = self.norm_final(x)
+        return x
+
+
 class TransformerEncoderLayer(torch.nn.Module):
-    """reference: transformer/encoder_layer.py (pre-norm, no concat)"""
+    """reference: transformer/encoder_layer.py:16-101"""
 
     def __init__(self, size, self_attn, feed_forward, dropout_rate, normalize_before=True, concat_after=False):
         super().__init__()
-        if not normalize_before or concat_after:
-            raise NotImplementedError("only pre-norm without concat_after is on the HIP path")
         self.self_attn = self_attn
         self.feed_forward = feed_forward
         self.norm1 = LayerNorm(size)
@@ -577,9 +601,29 @@ class TransformerEncoderLayer(torch.nn.Module):
         self.size = size
         self.normalize_before = normalize_before
         self.concat_after = concat_after
+        if concat_after:
+            self.concat_linear = torch.nn.Linear(size + size, size)
+        self.salts = [ops.new_salt() for _ in range(2)]
+
+    def _forward_composed(self, x, mask, cache):
+        """encoder_layer.py:53-101 with normalize_before=False and / or concat_after, from the modules' own forwards"""
+        nb, tr, p = self.normalize_before, self.training, self.dropout_rate
+        res = x
+        xn = self.norm1(x) if nb else x
+        xq = xn
+        if cache is not None:       # only the newest position queries (:70-77)
+            xq, res, mask = xn[:, -1:, :], res[:, -1:, :], (None if mask is None else mask[:, -1:, :])
+        att = self.self_attn(xq, xn, xn, mask)
+        x = res + (self.concat_linear(torch.cat([xq, att], -1)) if self.concat_after else F_.dropout(att, p, self.salts[0], tr))
+        x = x if nb else self.norm1(x)
+        x = x + F_.dropout(self.feed_forward(self.norm2(x) if nb else x), p, self.salts[1], tr)
+        x = x if nb else self.norm2(x)
+        return torch.cat([cache, x], dim=1) if cache is not None else x
 
     def forward(self, x, mask, cache=None):
         p = self.dropout_rate
+        if not self.normalize_before or self.concat_after:
+            return self._forward_composed(x, mask, cache), mask
         if cache is None:
             x = mha_block(self.norm1, self.self_attn, x, None, None, mask, p_out=p)
         else:   # incremental scoring: only the newest position queries (encoder_layer.py:70-77)
@@ -822,9 +866,11 @@ class DecoderLayer(torch.nn.Module):
     def __init__(self, size, self_attn, src_attn, feed_forward, dropout_rate, normalize_before=True,
                  concat_after=False):
         super().__init__()
-        if not normalize_before or concat_after:
-            raise NotImplementedError("only pre-norm without concat_after is on the HIP path")
         self.size = size
+        if concat_after:
+            self.concat_linear1 = torch.nn.Linear(size + size, size)
+            self.concat_linear2 = torch.nn.Linear(size + size, size)
+        self.salts = [ops.new_salt() for _ in range(3)]
         self.self_attn = self_attn
         self.src_attn = src_attn
         self.feed_forward = feed_forward
@@ -837,8 +883,36 @@ class DecoderLayer(torch.nn.Module):
 
     _pre = None      # set by Decoder.forward for the duration of one pass (shared k / v projection of the stack)
 
+    def _forward_composed(self, tgt, tgt_mask, memory, memory_mask, cache):
+        """decoder_layer.py:60-134 with normalize_before=False and / or concat_after, from the modules' own forwards"""
+        nb, tr, p = self.normalize_before, self.training, self.dropout_rate
+        drop = lambda y, i: F_.dropout(y, p, self.salts[i], tr)  # noqa: E731
+        res = tgt
+        xn = self.norm1(tgt) if nb else tgt
+        xq, q_mask = xn, tgt_mask
+        if cache is not None:       # only the newest position queries (:81-93)
+            xq, res, q_mask = xn[:, -1:, :], res[:, -1:, :], (None if tgt_mask is None else tgt_mask[:, -1:, :])
+        att = self.self_attn(xq, xn, xn, q_mask)
+        x = res + (self.concat_linear1(torch.cat([xq, att], -1)) if self.concat_after else drop(att, 0))
+        x = x if nb else self.norm1(x)
+        xn = self.norm2(x) if nb else x
+        if memory.shape[0] != x.shape[0]:       # beam search on the memory of G utterances: one copy per hypothesis
+            g = x.shape[0] // memory.shape[0]
+            memory_x = memory.repeat_interleave(g, 0)
+            mmask_x = None if memory_mask is None else memory_mask.repeat_interleave(g, 0)
+        else:
+            memory_x, mmask_x = memory, memory_mask
+        att = self.src_attn(xn, memory_x, memory_x, mmask_x)
+        x = x + (self.concat_linear2(torch.cat([xn, att], -1)) if self.concat_after else drop(att, 1))
+        x = x if nb else self.norm2(x)
+        x = x + drop(self.feed_forward(self.norm3(x) if nb else x), 2)
+        x = x if nb else self.norm3(x)
+        return torch.cat([cache, x], dim=1) if cache is not None else x
+
     def forward(self, tgt, tgt_mask, memory, memory_mask, cache=None):
         p = self.dropout_rate
+        if not self.normalize_before or self.concat_after:
+            return self._forward_composed(tgt, tgt_mask, memory, memory_mask, cache), tgt_mask, memory, memory_mask
         if cache is None:
             x = mha_block(self.norm1, self.self_attn, tgt, None, None, tgt_mask, p_out=p)
         else:
@@ -1000,7 +1074,8 @@ class Decoder(torch.nn.Module, BatchScorerInterface):
         n, D = ys.shape[0], self.embed[0].weight.shape[1]
         att = self.decoders[0].self_attn
         return (self.DECODE_KV and not self.training and not torch.is_grad_enabled() and ops._infer > 0 and xs.is_cuda
-                and ops.get_precision() == "fp32" and att.d_k == 64 and self.normalize_before and self.output_layer is not None
+                and ops.get_precision() == "fp32" and att.d_k == 64 and self.normalize_before and not self.decoders[0].concat_after
+                and self.output_layer is not None
                 and xs.shape[0] != n and n % xs.shape[0] == 0 and (isinstance(tree, dict) or (tree is None and ys.shape[1] == 1))
                 and isinstance(self.decoders[0].feed_forward, PositionwiseFeedForward)
                 and self.decoders[0].feed_forward.act_id in (ops.ACT_RELU, ops.ACT_SWISH))

@@ -1,6 +1,11 @@
 #!/usr/bin/env python3
 """Round-4 fixture (b), by RUNNING THE REFERENCE (kan-bayashi/espnet v0.9.5, PyTorch CPU) in the build container:
 
+  postnorm_layers.npz     the layers with normalize_before=False and / or concat_after=True (conformer/encoder_layer.py:99-157,
+                          transformer/encoder_layer.py:53-101, transformer/decoder_layer.py:60-134; size 64, 4 heads, units 96,
+                          macaron + convolution module kernel 7): four variants (post-norm, post-norm + concat, pre-norm + concat)
+                          of each of the three layers - outputs, input gradients, every parameter gradient; the decoder layer
+                          also through its cached form (the newest position only)
   e2e_conformer_d512.npz  espnet1 Conformer E2E at the width of the reference's large recipes (egs/librispeech/asr1 conformer:
                           adim 512, aheads 8 - d_k = 64 -, eunits = dunits = 2048), 2 encoder layers, 1 decoder layer,
                           idim 80, |V| = 50, three utterances of 300 / 251 / 180 frames: loss, loss_ctc, acc, hs_pad, pred_pad,
@@ -41,6 +46,64 @@ def d512_inputs():
     return xs, ilens, ys
 
 
+POSTNORM_VARIANTS = (("post", False, False), ("postcat", False, True), ("precat", True, True))
+
+
+def postnorm_layers(out_path):
+    from espnet.nets.pytorch_backend.conformer.convolution import ConvolutionModule
+    from espnet.nets.pytorch_backend.conformer.encoder_layer import EncoderLayer as ConfLayer
+    from espnet.nets.pytorch_backend.conformer.swish import Swish
+    from espnet.nets.pytorch_backend.transformer.attention import MultiHeadedAttention, RelPositionMultiHeadedAttention
+    from espnet.nets.pytorch_backend.transformer.decoder_layer import DecoderLayer
+    from espnet.nets.pytorch_backend.transformer.embedding import RelPositionalEncoding
+    from espnet.nets.pytorch_backend.transformer.encoder_layer import EncoderLayer as TrfLayer
+    from espnet.nets.pytorch_backend.transformer.mask import subsequent_mask
+    from espnet.nets.pytorch_backend.transformer.positionwise_feed_forward import PositionwiseFeedForward
+    D, H, U = 64, 4, 96
+    g = torch.Generator().manual_seed(99)
+    B, T, L = 3, 37, 11
+    x = torch.randn(B, T, D, generator=g)
+    _, pos = RelPositionalEncoding(D, 0.0)(x)
+    mask = torch.ones(B, 1, T, dtype=torch.bool)
+    mask[1, 0, 30:] = False
+    tgt = torch.randn(B, L, D, generator=g)
+    tmask = subsequent_mask(L).unsqueeze(0).expand(B, L, L).clone()
+    gy, gyt = torch.randn(B, T, D, generator=g), torch.randn(B, L, D, generator=g)
+    rec = dict(x=x, pos=pos, mask=mask, tgt=tgt, tmask=tmask, gy=gy, gyt=gyt)
+
+    def grads(tag, module):
+        for name, p in module.named_parameters():
+            if p.grad is not None:
+                rec["%s/grad/%s" % (tag, name)] = p.grad.detach().clone()
+
+    for tag, nb, cat in POSTNORM_VARIANTS:
+        conf = ConfLayer(D, RelPositionMultiHeadedAttention(H, D, 0.0), PositionwiseFeedForward(D, U, 0.0, Swish()),
+                         PositionwiseFeedForward(D, U, 0.0, Swish()), ConvolutionModule(D, 7, Swish()), 0.0, nb, cat)
+        conf = SW.fill_parameters(conf, salt=990).train()
+        xi = x.clone().requires_grad_(True)
+        (y, _), _ = conf((xi, pos), mask)
+        y.backward(gy)
+        rec["conf_%s/y" % tag], rec["conf_%s/gx" % tag] = y.detach().clone(), xi.grad.clone()
+        grads("conf_" + tag, conf)
+        trf = SW.fill_parameters(TrfLayer(D, MultiHeadedAttention(H, D, 0.0), PositionwiseFeedForward(D, U, 0.0), 0.0, nb, cat), salt=991).train()
+        xi = x.clone().requires_grad_(True)
+        y, _ = trf(xi, mask)
+        y.backward(gy)
+        rec["trf_%s/y" % tag], rec["trf_%s/gx" % tag] = y.detach().clone(), xi.grad.clone()
+        grads("trf_" + tag, trf)
+        dec = SW.fill_parameters(DecoderLayer(D, MultiHeadedAttention(H, D, 0.0), MultiHeadedAttention(H, D, 0.0),
+                                              PositionwiseFeedForward(D, U, 0.0), 0.0, nb, cat), salt=992).train()
+        ti, mi = tgt.clone().requires_grad_(True), x.clone().requires_grad_(True)
+        y, *_ = dec(ti, tmask, mi, mask)
+        y.backward(gyt)
+        rec["dec_%s/y" % tag], rec["dec_%s/gtgt" % tag], rec["dec_%s/gmem" % tag] = y.detach().clone(), ti.grad.clone(), mi.grad.clone()
+        grads("dec_" + tag, dec)
+        with torch.no_grad():        # the cached form: prefix outputs of positions < L - 1 given, the newest position computed
+            yc, *_ = dec.eval()(tgt, tmask, x, mask, cache=y.detach()[:, :-1])
+        rec["dec_%s/y_cached" % tag] = yc.clone()
+    save(out_path, **rec)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--ref", default="/root/reference")
@@ -50,6 +113,7 @@ def main():
     sys.path.insert(0, a.ref)
     torch.set_num_threads(8)
     from espnet.nets.pytorch_backend.e2e_asr_conformer import E2E
+    postnorm_layers(os.path.join(a.out, "postnorm_layers.npz"))
     torch.manual_seed(D512["seed"])
     model = SW.fill_parameters(E2E(D512["idim"], D512["odim"], argparse.Namespace(**D512["ns"])), salt=D512["salt"])
     model.train()

@@ -55,6 +55,29 @@ def seeded_weights():
     return SW
 
 
+POSTNORM_VARIANTS = (("post", False, False), ("postcat", False, True), ("precat", True, True))
+
+
+def postnorm_layer(kind, normalize_before, concat_after):
+    """our conformer / transformer encoder layer or decoder layer (size 64, 4 heads, 96 units) with the name-keyed weights
+    oracle/gen_golden_r4b.py gave the reference layers of postnorm_layers.npz"""
+    from espnet_amd.nets import modules as M
+    D, H, U = 64, 4, 96
+    SW = seeded_weights()
+    if kind == "conf":
+        m = M.ConformerEncoderLayer(D, M.RelPositionMultiHeadedAttention(H, D, 0.0), M.PositionwiseFeedForward(D, U, 0.0, "swish"),
+                                    M.PositionwiseFeedForward(D, U, 0.0, "swish"), M.ConvolutionModule(D, 7, "swish"), 0.0,
+                                    normalize_before, concat_after)
+        return SW.fill_parameters(m, salt=990)
+    if kind == "trf":
+        m = M.TransformerEncoderLayer(D, M.MultiHeadedAttention(H, D, 0.0), M.PositionwiseFeedForward(D, U, 0.0), 0.0,
+                                      normalize_before, concat_after)
+        return SW.fill_parameters(m, salt=991)
+    m = M.DecoderLayer(D, M.MultiHeadedAttention(H, D, 0.0), M.MultiHeadedAttention(H, D, 0.0), M.PositionwiseFeedForward(D, U, 0.0), 0.0,
+                       normalize_before, concat_after)
+    return SW.fill_parameters(m, salt=992)
+
+
 def e2e_d512_model(dropout=0.0):
     """our espnet1 Conformer E2E at the width of the reference's large recipes (adim 512, aheads 8, eunits = dunits = 2048) with
     the name-keyed weights oracle/gen_golden_r4b.py gave the reference model of e2e_conformer_d512.npz; -> (model on CPU, oracle cfg)"""

@@ -601,6 +601,45 @@ def test_e2e_conformer_d512_golden(prec):
         espnet_amd.set_precision("fp32")
 
 
+def test_postnorm_layers_on_hip():
+    """normalize_before=False and / or concat_after=True: the conformer / transformer encoder layers and the decoder layer (the
+    composed form - LayerNorm behind each residual sum, x + concat_linear([x, att(x)]) - built from the HIP modules' own forwards)
+    against the reference's outputs, input gradients and parameter gradients; the decoder layer also in its cached form"""
+    from conftest import POSTNORM_VARIANTS, postnorm_layer
+    g = {k: torch.from_numpy(np.asarray(v)).to(DEV) for k, v in load_golden("postnorm_layers.npz").items()}
+    for tag, nb, cat in POSTNORM_VARIANTS:
+        for kind in ("conf", "trf", "dec"):
+            m = postnorm_layer(kind, nb, cat).to(DEV).train()
+            pre = "%s_%s/" % (kind, tag)
+            if kind == "dec":
+                tgt, mem = g["tgt"].clone().requires_grad_(True), g["x"].clone().requires_grad_(True)
+                y, *_ = m(tgt, g["tmask"], mem, g["mask"])
+                report(pre + "y", y, g[pre + "y"], 2e-5)
+                y.backward(g["gyt"])
+                report(pre + "d tgt", tgt.grad, g[pre + "gtgt"], 1e-4)
+                report(pre + "d memory", mem.grad, g[pre + "gmem"], 1e-4)
+                with torch.no_grad():
+                    yc, *_ = m.eval()(g["tgt"], g["tmask"], g["x"], g["mask"], cache=g[pre + "y"][:, :-1].contiguous())
+                report(pre + "cached y", yc, g[pre + "y_cached"], 2e-5)
+                m.train()
+            else:
+                x = g["x"].clone().requires_grad_(True)
+                if kind == "conf":
+                    (y, _), _ = m((x, g["pos"]), g["mask"])
+                else:
+                    y, _ = m(x, g["mask"])
+                report(pre + "y", y, g[pre + "y"], 2e-5)
+                y.backward(g["gy"])
+                report(pre + "dx", x.grad, g[pre + "gx"], 1e-4)
+            top = max(float(g[pre + "grad/" + k].norm()) for k, _ in m.named_parameters())
+            for k, q in m.named_parameters():
+                ref = g[pre + "grad/" + k]
+                if float(ref.norm()) < 1e-4 * top:       # mathematically zero in the reference (a bias in front of BatchNorm, the
+                    assert float(q.grad.norm()) < 1e-3 * top, k     # key bias of a softmax): its recorded value is rounding noise
+                else:
+                    report(pre + k, q.grad, ref, 2e-4)
+
+
 def test_edge_fixtures_on_hip():
     """the standalone-module fixtures of rows a6 / a8 / a9 / a4 on the HIP path (they used to be consumed by the CPU
     oracle tests only): mha.npz (source attention, causal self-attention with a fully masked QUERY row), rel_mha.npz,

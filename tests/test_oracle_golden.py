@@ -482,6 +482,33 @@ def test_e2e_conformer_dk64(oracle):
     assert _check_seeded_grads(SW, sd, g, 2e-4) < 2e-4
 
 
+def test_postnorm_layers(oracle):
+    """normalize_before=False and / or concat_after=True (conformer/encoder_layer.py:99-157, transformer/encoder_layer.py:53-101,
+    decoder_layer.py:60-134): the oracle's layers against the reference's outputs and gradients (postnorm_layers.npz)"""
+    from conftest import POSTNORM_VARIANTS, postnorm_layer
+    g = {k: torch.from_numpy(np.asarray(v)) for k, v in load_golden("postnorm_layers.npz").items()}
+    for tag, nb, cat in POSTNORM_VARIANTS:
+        cfg = dict(aheads=4, activation="swish", normalize_before=nb, concat_after=cat)
+        for kind in ("conf", "trf", "dec"):
+            sd = req({k: v.detach() for k, v in postnorm_layer(kind, nb, cat).state_dict().items()})
+            pre = "%s_%s/" % (kind, tag)
+            if kind == "dec":
+                tgt, mem = g["tgt"].clone().requires_grad_(True), g["x"].clone().requires_grad_(True)
+                y = oracle.decoder_layer(sd, "", tgt, g["tmask"], mem, g["mask"], 4, nb, cat)
+                close(y, g[pre + "y"])
+                y.backward(g["gyt"])
+                close(tgt.grad, g[pre + "gtgt"])
+                close(mem.grad, g[pre + "gmem"])
+            else:
+                x = g["x"].clone().requires_grad_(True)
+                y = (oracle.conformer_layer(sd, "", x, g["pos"], g["mask"], cfg, True) if kind == "conf"
+                     else oracle.transformer_enc_layer(sd, "", x, g["mask"], cfg))
+                close(y, g[pre + "y"])
+                y.backward(g["gy"])
+                close(x.grad, g[pre + "gx"])
+            check_param_grads(sd, {k[len(pre) + 5:]: v for k, v in g.items() if k.startswith(pre + "grad/")})
+
+
 def test_e2e_conformer_d512(oracle):
     """the oracle end to end at the width of the reference's large recipes (adim 512, aheads 8, eunits = dunits = 2048;
     oracle/gen_golden_r4b.py) against the reference's loss, encoder output and gradients"""
