@@ -797,7 +797,7 @@ class _BatchLog:
             ts = row[:, 1].reshape(B, beam)
             tok = row[:, 2].reshape(B, beam)
             fin = np.isfinite(ts)
-            if bs.partial_mode == "full" and bs.candidate_select and (fin & (ts < -1e9) & ~np.asarray(self.stopped)[:, None]).any():
+            if getattr(bs, "partial_mode", "ids") == "full" and getattr(bs, "candidate_select", False) and (fin & (ts < -1e9) & ~np.asarray(self.stopped)[:, None]).any():
                 raise _OutsideCandidates()
             at_cap = (maxl - 1 == i)[:, None]
             live = ~np.asarray(self.stopped)[:, None]

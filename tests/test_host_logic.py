@@ -176,6 +176,16 @@ def test_beam_step_log_replay_on_the_host():
     e0 = log.ended[0][0]
     assert abs(float(e0.score) - (-1.0 + 0.5 * 0.25)) < 1e-6 and abs(e0.scores["dec"] - (-0.5 + 0.25)) < 1e-6      # final scores added
     assert log.stopped == [False, True]                              # utterance 1 has nothing alive any more
+    # "full" mode with the candidate-selection kernels: a winner at log-zero level tells the host that a token outside the
+    # candidates could have won - the search is to be repeated on the tensor expressions (beam_search._OutsideCandidates)
+    from espnet_amd.nets.beam_search import _OutsideCandidates
+
+    class BSFull(BS):
+        partial_mode, candidate_select = "full", True
+    log2 = _BatchLog(BSFull(), 2, [3, 4], 0.5, allk)
+    log2.add(row(0, [(-1.0, 3, -0.5, [9, 3]), (-3.1e9, 4, -1.0, [9, 4]), (-1.5, 4, -0.7, [9, 4]), (ninf, 0, 0.0, [9, 0])]), last=False)
+    with pytest.raises(_OutsideCandidates):
+        log2.add(row(1, [(-2.5, 5, -1.2, [9, 3, 5]), (ninf, 0, 0.0, [9, 0, 0]), (-2.0, 9, -0.9, [9, 4, 9]), (ninf, 0, 0.0, [9, 0, 0])]), last=False)
     # step 2 = the length cap of utterance 0 (maxlen 3): its live slot ends with <eos> appended
     assert log.add(row(2, [(-3.0, 6, -1.5, [9, 3, 5, 6]), (ninf, 0, 0.0, [9, 0, 0, 0]), (ninf, 0, 0.0, [9, 0, 0, 0]), (ninf, 0, 0.0, [9, 0, 0, 0])]),
                    last=True)
