@@ -434,18 +434,19 @@ __global__ __launch_bounds__(256, NKT > 16 ? 1 : 2) void attn_f32_bwd_q_kernel(c
 }
 
 // =====================================================================================================================
-// Rows of more than 512 keys (up to ATT_LONG_MAXK).  The kernels above keep a query block's whole score row in registers
+// Rows of more than 512 keys (up to ATT_LONG_MAXK = 4096).  The kernels above keep a query block's whole score row in registers
 // (S[NKT]) and a V / K panel of all keys in LDS; that stops at 512 keys.  The long-row forms keep the structure - the
 // score matrix X[query][key] of a query block lives in LDS for the whole kernel, so the legacy rel_shift stays the same
-// one-to-one scatter of the bd tiles - but a workgroup takes 16 queries (X = 16 x (T2 + 4) floats: 131 KB at 2048 keys)
+// one-to-one scatter of the bd tiles - but a workgroup takes 16 queries (X = 16 x (T2 + 4) floats: 131 KB at 2048 keys; 8 queries
+// beyond that, up to 4096 keys: the 16 x 16 tiles then carry query LQ - 1 eight more times - same values stored to the same
+// addresses by lanes of one instruction - which halves the useful MFMA work but keeps such rows off the GEMM + softmax path)
 // and ALL FOUR phases are split over the keys: wave w owns key tiles w, w + 4, w + 8, ... in the score products, in the
 // softmax (row maxima / sums meet through 128 floats of LDS) and in the product with V (K), whose 16-key tiles each wave
 // stages in a private 4 KB LDS buffer; the four partial context (dq) tiles are summed through LDS at the end.  The
 // softmax walks X three times (max, exp + sum, normalise) instead of holding the row in registers.
 // Per workgroup K, V and the positions are read once (768 KB at 1024 keys) for 16 queries: four times the L2 traffic of
 // the 64-query kernels per query, which is what the LDS budget allows.
-constexpr int ATT_LONG_MAXK = 2048;
-constexpr int LQ = 16;                                      // queries per workgroup
+constexpr int ATT_LONG_MAXK = 4096;                         // (LQ, the queries per workgroup, is a template parameter: 16, or 8 beyond 2048 keys)
 
 // element access for the two storage types of the long-row kernels: float (fp32 mode) and bf16 bits (bf16-operand mode:
 // same kernels, operands widened on load, fp32 MFMA; P / dS / dbd / ctx rounded to bf16 on store)
@@ -522,7 +523,7 @@ __device__ __forceinline__ void reduce_store_ct(const f32x4 (&C)[4], float* scr,
   }
 }
 
-template <typename T, bool REL>
+template <typename T, bool REL, int LQ>
 __global__ __launch_bounds__(256) void attn_fwd_long_kernel(const AttnF32Args a, const int nkt) {
   const T* const a_qu = reinterpret_cast<const T*>(a.qu); const T* const a_qv = reinterpret_cast<const T*>(a.qv);
   const T* const a_k = reinterpret_cast<const T*>(a.k); const T* const a_v = reinterpret_cast<const T*>(a.v);
@@ -532,6 +533,7 @@ __global__ __launch_bounds__(256) void attn_fwd_long_kernel(const AttnF32Args a,
   const int XLD = nkt * 16 + 4;
   const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
   const int fr = lane & 15, fq = lane >> 4;
+  const int frx = min(fr, LQ - 1);                      // LQ = 8: lanes of the tile's upper half repeat query LQ - 1 (same values, same addresses)
   const int xcd = blockIdx.x & 7, jb = blockIdx.x >> 3;
   const int z = (jb / a.nqb) * 8 + xcd;
   const bool live = z < a.B * a.H;
@@ -540,7 +542,7 @@ __global__ __launch_bounds__(256) void attn_fwd_long_kernel(const AttnF32Args a,
   const int T1 = a.T1, T2 = a.T2;
   const int r0w = min((jb % a.nqb) * LQ, T1 - 1);
   const int nq = min(LQ, T1 - r0w);
-  const int qi = min(r0w + fr, T1 - 1);
+  const int qi = min(r0w + frx, T1 - 1);
   const bool qok = live && fr < nq;
   float* X = reinterpret_cast<float*>(smem_raw);
   float* Tw = X + LQ * XLD + wave * 16 * PLD;           // this wave's tile buffer
@@ -566,7 +568,7 @@ __global__ __launch_bounds__(256) void attn_fwd_long_kernel(const AttnF32Args a,
         if (m < Ts && i < Ts && fr < nq && row >= 0) X[row * XLD + j] = c[r];
       }
     }
-    const int i16 = r0w + LQ;                         // first query of the next workgroup: its low positions feed query r0w + 15
+    const int i16 = r0w + LQ;                         // first query of the next workgroup: its low positions feed query r0w + LQ - 1
     if (live && i16 < Ts) {
       const T* qr = a_qv + ((long)b * T1 + i16) * a.ldqv + h * ATT_DK;
       for (int m = t; m <= Ts - 2 - i16; m += 256) {
@@ -592,7 +594,7 @@ __global__ __launch_bounds__(256) void attn_fwd_long_kernel(const AttnF32Args a,
     for (int kt = wave; kt < nkt; kt += 4) {
       float4 kf[4];
       load_frag_t(keys + (long)min(kt * 16 + fr, T2 - 1) * a.ldk, fq, kf);
-      float4* xp = reinterpret_cast<float4*>(&X[fr * XLD + kt * 16 + 4 * fq]);
+      float4* xp = reinterpret_cast<float4*>(&X[frx * XLD + kt * 16 + 4 * fq]);
       f32x4 c = (f32x4){0.f, 0.f, 0.f, 0.f};
       if (REL) { const float4 o = *xp; c = (f32x4){o.x, o.y, o.z, o.w}; }
       c = dot_tile(kf, qf, c);                        // c[r]: key 16 kt + 4 fq + r, query fr
@@ -610,13 +612,13 @@ __global__ __launch_bounds__(256) void attn_fwd_long_kernel(const AttnF32Args a,
     }
   }
   mx = xmax16_32(mx);
-  if (fq == 0) red[wave * LQ + fr] = mx;
+  if (fq == 0) red[wave * LQ + frx] = mx;
   __syncthreads();
-  mx = fmaxf(fmaxf(red[fr], red[LQ + fr]), fmaxf(red[2 * LQ + fr], red[3 * LQ + fr]));
+  mx = fmaxf(fmaxf(red[frx], red[LQ + frx]), fmaxf(red[2 * LQ + frx], red[3 * LQ + frx]));
   const bool dead = mx == -INFINITY;                  // every key masked: zeros (softmax of min, then masked_fill(0))
   float sum = 0.f;
   for (int kt = wave; kt < nkt; kt += 4) {
-    float4* xp = reinterpret_cast<float4*>(&X[fr * XLD + kt * 16 + 4 * fq]);
+    float4* xp = reinterpret_cast<float4*>(&X[frx * XLD + kt * 16 + 4 * fq]);
     float4 v = *xp;
     v.x = dead ? 0.f : __expf(v.x - mx); v.y = dead ? 0.f : __expf(v.y - mx);
     v.z = dead ? 0.f : __expf(v.z - mx); v.w = dead ? 0.f : __expf(v.w - mx);
@@ -624,9 +626,9 @@ __global__ __launch_bounds__(256) void attn_fwd_long_kernel(const AttnF32Args a,
     *xp = v;
   }
   sum = xsum16_32(sum);
-  if (fq == 0) red[4 * LQ + wave * LQ + fr] = sum;
+  if (fq == 0) red[4 * LQ + wave * LQ + frx] = sum;
   __syncthreads();
-  sum = (red[4 * LQ + fr] + red[5 * LQ + fr]) + (red[6 * LQ + fr] + red[7 * LQ + fr]);
+  sum = (red[4 * LQ + frx] + red[5 * LQ + frx]) + (red[6 * LQ + frx] + red[7 * LQ + frx]);
   const float inv = dead ? 0.f : 1.f / sum;
   // ---- probabilities out, context^T = V^T Pd^T over this wave's key tiles ----
   const long pro = ((long)zz * T1 + qi) * a.ldp;
@@ -642,7 +644,7 @@ __global__ __launch_bounds__(256) void attn_fwd_long_kernel(const AttnF32Args a,
   for (int kt = wave; kt < nkt; kt += 4) {
     tile_store(vreg, Tw, lane);
     if (kt + 4 < nkt) tile_load(vs, a.ldv, (kt + 4) * 16, live ? T2 : 1, lane, vreg);
-    const float4 e = *reinterpret_cast<const float4*>(&X[fr * XLD + kt * 16 + 4 * fq]);
+    const float4 e = *reinterpret_cast<const float4*>(&X[frx * XLD + kt * 16 + 4 * fq]);
     f32x4 Pv = (f32x4){e.x * inv, e.y * inv, e.z * inv, e.w * inv};
     const int j0 = kt * 16 + fq * 4;
     if (qok && j0 < a.ldp) st4(a_P + pro + j0, make_float4(Pv[0], Pv[1], Pv[2], Pv[3]));
@@ -661,7 +663,7 @@ __global__ __launch_bounds__(256) void attn_fwd_long_kernel(const AttnF32Args a,
   reduce_store_ct(C, X, wave, fr, fq, t, a_ctx + ((long)b * T1 + r0w) * a.ldc + h * ATT_DK, a.ldc, live ? nq : 0);
 }
 
-template <typename T>
+template <typename T, int LQ>
 __global__ __launch_bounds__(256) void attn_bwd_q_long_kernel(const AttnF32BwdArgs a, const int nkt, const int dq_bf16) {
   const T* const a_dctx = reinterpret_cast<const T*>(a.dctx); const T* const a_k = reinterpret_cast<const T*>(a.k);
   const T* const a_v = reinterpret_cast<const T*>(a.v); const T* const a_P = reinterpret_cast<const T*>(a.P);
@@ -670,6 +672,7 @@ __global__ __launch_bounds__(256) void attn_bwd_q_long_kernel(const AttnF32BwdAr
   const int XLD = nkt * 16 + 4;
   const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
   const int fr = lane & 15, fq = lane >> 4;
+  const int frx = min(fr, LQ - 1);                      // LQ = 8: lanes of the tile's upper half repeat query LQ - 1 (same values, same addresses)
   const int xcd = blockIdx.x & 7, jb = blockIdx.x >> 3;
   const int z = (jb / a.nqb) * 8 + xcd;
   const bool live = z < a.B * a.H;
@@ -679,7 +682,7 @@ __global__ __launch_bounds__(256) void attn_bwd_q_long_kernel(const AttnF32BwdAr
   const int Ts = (a.dbd && a.tshift) ? min(max(a.tshift[0], 1), T2) : T2;
   const int r0w = min((jb % a.nqb) * LQ, T1 - 1);
   const int nq = min(LQ, T1 - r0w);
-  const int qi = min(r0w + fr, T1 - 1);
+  const int qi = min(r0w + frx, T1 - 1);
   const bool qok = live && fr < nq;
   float* X = reinterpret_cast<float*>(smem_raw);
   float* Tw = X + LQ * XLD + wave * 16 * PLD;
@@ -711,13 +714,13 @@ __global__ __launch_bounds__(256) void attn_bwd_q_long_kernel(const AttnF32BwdAr
       const float p4[4] = {pr.x, pr.y, pr.z, pr.w};
 #pragma unroll
       for (int r = 0; r < 4; ++r) if (j0 + r < T2) s += p4[r] * c[r];
-      *reinterpret_cast<float4*>(&X[fr * XLD + kt * 16 + 4 * fq]) = make_float4(c[0], c[1], c[2], c[3]);
+      *reinterpret_cast<float4*>(&X[frx * XLD + kt * 16 + 4 * fq]) = make_float4(c[0], c[1], c[2], c[3]);
     }
   }
   s = xsum16_32(s);
-  if (fq == 0) red[wave * LQ + fr] = s;
+  if (fq == 0) red[wave * LQ + frx] = s;
   __syncthreads();
-  s = (red[fr] + red[LQ + fr]) + (red[2 * LQ + fr] + red[3 * LQ + fr]);
+  s = (red[frx] + red[LQ + frx]) + (red[2 * LQ + frx] + red[3 * LQ + frx]);
   // ---- dS (+ the inverse rel_shift scatter dbd), dq^T = K^T dS^T over this wave's key tiles ----
   const T* ks = a_k + (long)b * T2 * a.ldk + h * ATT_DK;
   const int i = r0w + fr;
@@ -732,7 +735,7 @@ __global__ __launch_bounds__(256) void attn_bwd_q_long_kernel(const AttnF32BwdAr
     const int j0 = kt * 16 + fq * 4;
     float4 pr = ld4(a_P + pro + min(j0, (int)a.ldp - 4));
     if (j0 >= (int)a.ldp) pr = make_float4(0.f, 0.f, 0.f, 0.f);
-    const float4 dp = *reinterpret_cast<const float4*>(&X[fr * XLD + kt * 16 + 4 * fq]);
+    const float4 dp = *reinterpret_cast<const float4*>(&X[frx * XLD + kt * 16 + 4 * fq]);
     const float p4[4] = {pr.x, pr.y, pr.z, pr.w}, d4[4] = {dp.x, dp.y, dp.z, dp.w};
     f32x4 G;
 #pragma unroll
@@ -763,34 +766,45 @@ __global__ __launch_bounds__(256) void attn_bwd_q_long_kernel(const AttnF32BwdAr
     reduce_store_ct(C, X, wave, fr, fq, t, a.dq + ((long)b * T1 + r0w) * a.ldo + h * ATT_DK, a.ldo, live ? nq : 0);
 }
 
-template <typename T, bool REL>
-int launch_fwd_long(AttnF32Args a, hipStream_t stream) {
+template <typename T, bool REL, int LQ>
+int launch_fwd_long_q(AttnF32Args a, hipStream_t stream) {
   const int nkt = (a.T2 + 15) / 16;
   const size_t smem = ((size_t)LQ * (nkt * 16 + 4) + 4 * 16 * PLD + 8 * LQ) * sizeof(float);
   if (smem > 160 * 1024) return EAMD_EUNSUPPORTED;
-  static const hipError_t attr_err = hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_fwd_long_kernel<T, REL>),
+  static const hipError_t attr_err = hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_fwd_long_kernel<T, REL, LQ>),
                                                          hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
   if (attr_err != hipSuccess) return (int)attr_err;
   a.nqb = (a.T1 + LQ - 1) / LQ;
   const int nz = (a.B * a.H + 7) / 8 * 8;
-  hipLaunchKernelGGL((attn_fwd_long_kernel<T, REL>), dim3((unsigned)(a.nqb * nz)), dim3(256), smem, stream, a, nkt);
+  if ((long)a.nqb * nz >= (1L << 31)) return EAMD_EUNSUPPORTED;
+  hipLaunchKernelGGL((attn_fwd_long_kernel<T, REL, LQ>), dim3((unsigned)(a.nqb * nz)), dim3(256), smem, stream, a, nkt);
   EAMD_LAUNCH_CHECK();
   return EAMD_OK;
 }
+// 16 queries per workgroup while their score rows fit the LDS (2048 keys), 8 beyond (4096 keys: the MFMA tiles run half empty)
+template <typename T, bool REL>
+int launch_fwd_long(AttnF32Args a, hipStream_t stream) {
+  return a.T2 <= 2048 ? launch_fwd_long_q<T, REL, 16>(a, stream) : launch_fwd_long_q<T, REL, 8>(a, stream);
+}
 
-template <typename T>
-int launch_bwd_long(AttnF32BwdArgs a, int dq_bf16, hipStream_t stream) {
+template <typename T, int LQ>
+int launch_bwd_long_q(AttnF32BwdArgs a, int dq_bf16, hipStream_t stream) {
   const int nkt = (a.T2 + 15) / 16;
   const size_t smem = ((size_t)LQ * (nkt * 16 + 4) + 4 * 16 * PLD + 8 * LQ) * sizeof(float);
   if (smem > 160 * 1024) return EAMD_EUNSUPPORTED;
-  static const hipError_t attr_err = hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_bwd_q_long_kernel<T>),
+  static const hipError_t attr_err = hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_bwd_q_long_kernel<T, LQ>),
                                                          hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
   if (attr_err != hipSuccess) return (int)attr_err;
   a.nqb = (a.T1 + LQ - 1) / LQ;
   const int nz = (a.B * a.H + 7) / 8 * 8;
-  hipLaunchKernelGGL((attn_bwd_q_long_kernel<T>), dim3((unsigned)(a.nqb * nz)), dim3(256), smem, stream, a, nkt, dq_bf16);
+  if ((long)a.nqb * nz >= (1L << 31)) return EAMD_EUNSUPPORTED;
+  hipLaunchKernelGGL((attn_bwd_q_long_kernel<T, LQ>), dim3((unsigned)(a.nqb * nz)), dim3(256), smem, stream, a, nkt, dq_bf16);
   EAMD_LAUNCH_CHECK();
   return EAMD_OK;
+}
+template <typename T>
+int launch_bwd_long(AttnF32BwdArgs a, int dq_bf16, hipStream_t stream) {
+  return a.T2 <= 2048 ? launch_bwd_long_q<T, 16>(a, dq_bf16, stream) : launch_bwd_long_q<T, 8>(a, dq_bf16, stream);
 }
 
 template <bool REL, int NKT>

@@ -858,7 +858,7 @@ class MHABlockFn(torch.autograd.Function):
             if tb is not None:
                 # a padded batch needs the rel_shift over its own length; only the fused kernels take it (shift_len)
                 raise ops._lib.EamdError("relative-position attention on a shape-bucketed batch needs the fused attention kernels "
-                                         "(d_k = 64, T' <= 2048: ops.attn_fwd_supported; train.BucketedGraphStep checks this per bucket up front); "
+                                         "(d_k = 64, T' <= 4096: ops.attn_fwd_supported; train.BucketedGraphStep checks this per bucket up front); "
                                          "this shape runs the GEMM + softmax path")
             P = attn_scores_fwd(qu, qv, k, p, mask, B, T1, T2, H, dk)
             Pd = ops.dropout(P, p_att, s_att) if p_att > 0.0 else P

@@ -1081,7 +1081,8 @@ def attn_fwd_supported(T1, T2, dk, rel):
     """shapes the fused attention forward (eamd_attn_fwd) covers; alignment is checked by the library"""
     if dk != 64 or (rel and T1 != T2):
         return False
-    return (fast() or F32_FUSED_ATTN) and T2 <= 2048          # rows of 513 .. 2048 keys: the key-split long-row kernels (attn_f32.hip)
+    # rows of 513 .. 4096 keys: the key-split long-row kernels (attn_f32.hip; 16 queries per workgroup up to 2048 keys, 8 beyond)
+    return (fast() or F32_FUSED_ATTN) and T2 <= 4096
 
 
 def attn_fwd(qu, qv, k, v, pos, mask, B, T1, T2, H, dk, ldp, scale, drop=None, shift_len=None):
