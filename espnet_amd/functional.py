@@ -508,6 +508,9 @@ def attn_scores_fwd(qu, qv, k, p, mask, B, T1, T2, H, dk):
 
 
 FUSE_ATTN = True   # tests flip this to compare against the GEMM / softmax / GEMM path
+# attention blocks whose probabilities (P + dropped copy) exceed this many MB do not keep them for backward but run the fused
+# forward again there (MHABlockFn): memory kept per block O(T') instead of O(T'^2).  < 0: never; 0: always.
+ATTN_RECOMPUTE_MB = float(os.environ.get("EAMD_ATTN_RECOMPUTE_MB", "256"))
 ATTN_TAP = None    # a list while E2E.calculate_all_attentions runs: every attention block appends its probabilities
 
 
@@ -875,17 +878,27 @@ class MHABlockFn(torch.autograd.Function):
         else:
             out = ops.linear_fwd(cx, ops.wshadow(wo), bo, R=res)
         ctx.rp = rp
+        # O(T') memory kept for backward: beyond ATTN_RECOMPUTE_MB of probabilities (P and its dropped copy: B x H x T1 x T2 each) they
+        # are NOT kept - backward runs the fused forward kernel again (same operands, same dropout counter: the same bits) into
+        # transient buffers.  One more attention-forward launch per block in backward (2 - 3 % of a step at T' = 249, where it is
+        # off by default; at T' = 1000 P and Pd are 0.98 GB of the 2.57 GB a block keeps)
+        ctx.recompute = None
+        if fwd is not None and ATTN_RECOMPUTE_MB >= 0:
+            held = P.numel() * P.element_size() * (2 if p_att > 0.0 else 1)
+            if held >= ATTN_RECOMPUTE_MB * 2 ** 20:
+                ctx.recompute = mask
+                P = Pd = None
         # tensors that live in a SharedProj stay out of save_for_backward (they are no outputs of this Function)
         p_sv = None if pre_pos is not None else p
         if fused:   # k, v (and q without relative positions) are column blocks of qkv
             ctx.save_for_backward(x2, mean, rstd, xn, None, qu if rel else None, qv, qkv, None, p_sv, P, cx, pos2,
-                                  Pd if p_att > 0.0 else None)
+                                  Pd if (p_att > 0.0 and P is not None) else None)
         elif pre_kv is not None:
             ctx.save_for_backward(x2, mean, rstd, xn, None, qu, qv, None, None, p_sv, P, cx, pos2,
-                                  Pd if p_att > 0.0 else None)
+                                  Pd if (p_att > 0.0 and P is not None) else None)
         else:
             ctx.save_for_backward(x2, mean, rstd, xn, kv_in if memory is not None else None, qu, qv, k, v, p_sv, P, cx,
-                                  pos2, Pd if p_att > 0.0 else None)
+                                  pos2, Pd if (p_att > 0.0 and P is not None) else None)
         ctx.pre = pre
         if pre is not None:      # the shared projection owns these parameters' gradients
             skip = (4, 5, 6, 7) if pre_kv is not None else (10,)
@@ -918,10 +931,19 @@ class MHABlockFn(torch.autograd.Function):
             dctx = ops.rowproj(dob, rp[3], D)
         else:
             dctx = ops.linear_bwd_x(dob, ops.wshadow(wo), out_dtype=adt, a_drop=g_drop)
+        def again(qu_, qv_, k_, v_):
+            """the probabilities this block did not keep: the fused forward once more (MHABlockFn.forward, ATTN_RECOMPUTE_MB)"""
+            f = attn_fwd_fused(qu_, qv_, k_, v_, p, ctx.recompute, B, T1, T2, H, dk, drop=(p_att, s_att) if p_att > 0.0 else None,
+                               shift_len=ctx.shift_len)
+            if f is None:
+                raise ops._lib.EamdError("attention recompute: the fused forward declined operands it took in forward")
+            return f[0], (f[1] if p_att > 0.0 else None)
         if ctx.fused:
             qkv = k
             dqkv = torch.empty(B * T1, 3 * D, device=do.device, dtype=adt)
             quv = qu if rel else _MV(qkv, 0, 3 * D)
+            if P is None:
+                P, Pd = again(quv, qv, _MV(qkv, D, 3 * D), _MV(qkv, 2 * D, 3 * D))
             dqu, dqv, _, _, dp = attn_core_bwd(dctx, P, quv, qv, _MV(qkv, D, 3 * D), _MV(qkv, 2 * D, 3 * D), p, B, T1,
                                                T2, H, dk, Pd=Pd, attn_drop=(p_att, s_att), dqkv=dqkv, dp_out=dp_out,
                                                shift_len=ctx.shift_len)
@@ -943,6 +965,8 @@ class MHABlockFn(torch.autograd.Function):
         if pre_kv is not None:
             k, v = pre_kv[1].block(pre_kv[2], 0), pre_kv[1].block(pre_kv[2], D)
             dkv_out = pre_kv[1].grad_block(pre_kv[2])
+        if P is None:
+            P, Pd = again(qu, qv, k, v)
         dqu, dqv, dkk, dv, dp = attn_core_bwd(dctx, P, qu, qv, k, v, p, B, T1, T2, H, dk,
                                               Pd=Pd, attn_drop=(p_att, s_att), dkv_out=dkv_out, dp_out=dp_out,
                                               shift_len=ctx.shift_len)

@@ -640,6 +640,57 @@ def test_postnorm_layers_on_hip():
                     report(pre + k, q.grad, ref, 2e-4)
 
 
+@pytest.mark.parametrize("prec", ["fp32", "bf16"])
+def test_attention_recompute_matches_stored(prec):
+    """F_.ATTN_RECOMPUTE_MB: attention blocks that do not keep their probabilities for backward (the fused forward runs again there,
+    same operands, same dropout counter) give the same loss (bit-equal) and gradients (1e-5: split-K atomics) as the blocks that keep them - Conformer E2E at
+    adim 256 / aheads 4 with dropout 0.1 (self-attention with relative positions, decoder self- and source attention, attention
+    dropout masks) - and keep less memory after forward."""
+    import espnet_amd
+    from espnet_amd import functional as F_, ops, train
+    from conftest import e2e_dk64_model
+    g = load_golden("e2e_conformer_dk64.npz")
+    xs, ilens, ys = torch.from_numpy(g["xs"]).to(DEV), torch.from_numpy(g["ilens"]), torch.from_numpy(g["ys"]).to(DEV)
+    espnet_amd.set_precision(prec)
+    keep = F_.ATTN_RECOMPUTE_MB
+    res = {}
+    try:
+        salt0 = ops._rng["salt"]
+        for mode, mb in (("stored", -1.0), ("recompute", 0.0)):
+            F_.ATTN_RECOMPUTE_MB = mb
+            ops._rng["salt"] = salt0          # both models get the same dropout sites (salts are handed out at construction)
+            model, _ = e2e_dk64_model(dropout=0.1)
+            for m in model.modules():
+                if hasattr(m, "dropout_rate") and type(m).__name__.endswith("MultiHeadedAttention"):
+                    m.dropout_rate = 0.1
+            model = model.to(DEV).train()
+            flat = train.FlatParams(model)
+            flat.expose_grads()
+            ops.manual_seed(77)
+            torch.cuda.synchronize()
+            base = torch.cuda.memory_allocated()
+            loss = model(xs, ilens, ys)
+            held = torch.cuda.memory_allocated() - base
+            loss.backward()
+            res[mode] = (float(loss), held, {k: q.grad.detach().clone() for k, q in model.named_parameters()})
+            del model, flat, loss
+    finally:
+        F_.ATTN_RECOMPUTE_MB = keep
+        espnet_amd.set_precision("fp32")
+    assert res["stored"][0] == res["recompute"][0]
+    worst = 0.0
+    top = max(float(gr.double().norm()) for gr in res["stored"][2].values())
+    for k, gr in res["stored"][2].items():       # (weight gradients meet in split-K atomics: equal up to their summation order;
+        # gradients that are mathematically zero - a bias in front of BatchNorm - are rounding noise: measured against the largest)
+        d = float((gr.double() - res["recompute"][2][k].double()).norm()) / max(float(gr.double().norm()), 1e-3 * top)
+        worst = max(worst, d)
+        assert d <= 1e-5, (k, d)
+    print("[parity] attention recompute[%s]: worst relative gradient difference %.2e" % (prec, worst))
+    print("[parity] attention recompute[%s]: kept after forward %.1f MB stored / %.1f MB recomputed" %
+          (prec, res["stored"][1] / 2 ** 20, res["recompute"][1] / 2 ** 20))
+    assert res["recompute"][1] < res["stored"][1]
+
+
 def test_edge_fixtures_on_hip():
     """the standalone-module fixtures of rows a6 / a8 / a9 / a4 on the HIP path (they used to be consumed by the CPU
     oracle tests only): mha.npz (source attention, causal self-attention with a fully masked QUERY row), rel_mha.npz,
