@@ -4,7 +4,7 @@ set -u
 tag=${1:-w512}; prec=${2:-fp32}
 root=$(pwd)
 cd /tmp && export TMPDIR=/tmp
-timeout -k 10 500 rocprofv3 --kernel-trace --stats --output-format csv -d "$root/gpurun_out/pw_$tag" -- python3 "$root/tools/bench_width.py" --precision $prec --steps 20 > "$root/gpurun_out/pw_$tag.log" 2>&1 || { tail -n 5 "$root/gpurun_out/pw_$tag.log"; exit 1; }
+timeout -k 10 500 rocprofv3 --kernel-trace --stats --output-format csv -d "$root/gpurun_out/pw_$tag" -- python3 "$root/tools/bench_width.py" --precision $prec --steps 20 ${EAMD_WIDTH_ARGS:-} > "$root/gpurun_out/pw_$tag.log" 2>&1 || { tail -n 5 "$root/gpurun_out/pw_$tag.log"; exit 1; }
 cd "$root"
 grep "ms per step" gpurun_out/pw_$tag.log
 f=$(find gpurun_out/pw_$tag -name "*kernel_stats.csv" | head -1)
