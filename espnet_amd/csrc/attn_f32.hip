@@ -525,7 +525,8 @@ __device__ __forceinline__ void reduce_store_ct(const f32x4 (&C)[4], float* scr,
 
 template <typename T, bool REL, int LQ>
 __global__ __launch_bounds__(256) void attn_fwd_long_kernel(const AttnF32Args a, const int nkt) {
-  const T* const a_qu = reinterpret_cast<const T*>(a.qu); const T* const a_qv = reinterpret_cast<const T*>(a.qv);
+  constexpr int QT = LQ >= 16 ? LQ / 16 : 1;           // 16-query tiles of the workgroup: every key / value / position fragment a wave
+  const T* const a_qu = reinterpret_cast<const T*>(a.qu); const T* const a_qv = reinterpret_cast<const T*>(a.qv);      // loads serves all of them
   const T* const a_k = reinterpret_cast<const T*>(a.k); const T* const a_v = reinterpret_cast<const T*>(a.v);
   const T* const a_pos = reinterpret_cast<const T*>(a.pos);
   T* const a_P = reinterpret_cast<T*>(a.P); T* const a_Pd = reinterpret_cast<T*>(a.Pd); T* const a_ctx = reinterpret_cast<T*>(a.ctx);
@@ -533,7 +534,6 @@ __global__ __launch_bounds__(256) void attn_fwd_long_kernel(const AttnF32Args a,
   const int XLD = nkt * 16 + 4;
   const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
   const int fr = lane & 15, fq = lane >> 4;
-  const int frx = min(fr, LQ - 1);                      // LQ = 8: lanes of the tile's upper half repeat query LQ - 1 (same values, same addresses)
   const int xcd = blockIdx.x & 7, jb = blockIdx.x >> 3;
   const int z = (jb / a.nqb) * 8 + xcd;
   const bool live = z < a.B * a.H;
@@ -542,8 +542,17 @@ __global__ __launch_bounds__(256) void attn_fwd_long_kernel(const AttnF32Args a,
   const int T1 = a.T1, T2 = a.T2;
   const int r0w = min((jb % a.nqb) * LQ, T1 - 1);
   const int nq = min(LQ, T1 - r0w);
-  const int qi = min(r0w + frx, T1 - 1);
-  const bool qok = live && fr < nq;
+  // per query tile: the row of X / red this lane works on (LQ = 8: lanes of the tile's upper half repeat query LQ - 1 - same values,
+  // same addresses, one instruction), the query row it loads (clamped), the query whose mask / probability row it serves
+  int rowx[QT], qrow[QT], qi[QT];
+  bool qok[QT];
+#pragma unroll
+  for (int qt = 0; qt < QT; ++qt) {
+    rowx[qt] = min(fr + 16 * qt, LQ - 1);
+    qrow[qt] = r0w + min(fr + 16 * qt, nq - 1);
+    qi[qt] = min(r0w + rowx[qt], T1 - 1);
+    qok[qt] = live && fr + 16 * qt < nq;
+  }
   float* X = reinterpret_cast<float*>(smem_raw);
   float* Tw = X + LQ * XLD + wave * 16 * PLD;           // this wave's tile buffer
   float* red = X + LQ * XLD + 4 * 16 * PLD;             // [2][4][LQ]
@@ -553,19 +562,24 @@ __global__ __launch_bounds__(256) void attn_fwd_long_kernel(const AttnF32Args a,
       for (int e = t; e < LQ * XLD; e += 256) X[e] = 0.f;
       __syncthreads();
     }
-    float4 qf[4];
-    load_frag_t(a_qv + ((long)b * T1 + r0w + min(fr, nq - 1)) * a.ldqv + h * ATT_DK, fq, qf);
+    float4 qf[QT][4];
+#pragma unroll
+    for (int qt = 0; qt < QT; ++qt) load_frag_t(a_qv + ((long)b * T1 + qrow[qt]) * a.ldqv + h * ATT_DK, fq, qf[qt]);
     if (t < LQ && r0w + t + 1 < T2) X[t * XLD + r0w + t + 1] = 0.f;
     for (int mt = wave; mt < nkt; mt += 4) {
       float4 pf[4];
       load_frag_t(a_pos + (long)min(mt * 16 + fr, T2 - 1) * a.ldpos + h * ATT_DK, fq, pf);
-      const f32x4 c = dot_tile(pf, qf, (f32x4){0.f, 0.f, 0.f, 0.f});     // c[r] = bd[query fr][m = 16 mt + 4 fq + r]
-      const int i = r0w + fr, lim = Ts - 1 - i;
 #pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const int m = mt * 16 + 4 * fq + r;
-        const int row = m >= lim ? fr : fr - 1, j = m >= lim ? m - lim : m + i + 1;
-        if (m < Ts && i < Ts && fr < nq && row >= 0) X[row * XLD + j] = c[r];
+      for (int qt = 0; qt < QT; ++qt) {
+        const f32x4 c = dot_tile(pf, qf[qt], (f32x4){0.f, 0.f, 0.f, 0.f});     // c[r] = bd[query 16 qt + fr][m = 16 mt + 4 fq + r]
+        const int lr = fr + 16 * qt;                     // the query inside the block
+        const int i = r0w + lr, lim = Ts - 1 - i;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int m = mt * 16 + 4 * fq + r;
+          const int row = m >= lim ? lr : lr - 1, j = m >= lim ? m - lim : m + i + 1;
+          if (m < Ts && i < Ts && lr < nq && row >= 0) X[row * XLD + j] = c[r];
+        }
       }
     }
     const int i16 = r0w + LQ;                         // first query of the next workgroup: its low positions feed query r0w + LQ - 1
@@ -585,86 +599,127 @@ __global__ __launch_bounds__(256) void attn_fwd_long_kernel(const AttnF32Args a,
     __syncthreads();
   }
   // ---- ac on top, then scale + mask, in place; row maxima ----
-  const unsigned char* mr = a.mask ? a.mask + (long)b * a.mb + (long)qi * a.mi : nullptr;
-  float mx = -INFINITY;
+  float mx[QT];
   {
-    float4 qf[4];
-    load_frag_t(a_qu + ((long)b * T1 + r0w + min(fr, nq - 1)) * a.ldq + h * ATT_DK, fq, qf);
+    const unsigned char* mr[QT];
+    float4 qf[QT][4];
+#pragma unroll
+    for (int qt = 0; qt < QT; ++qt) {
+      mr[qt] = a.mask ? a.mask + (long)b * a.mb + (long)qi[qt] * a.mi : nullptr;
+      mx[qt] = -INFINITY;
+      load_frag_t(a_qu + ((long)b * T1 + qrow[qt]) * a.ldq + h * ATT_DK, fq, qf[qt]);
+    }
     const T* keys = a_k + (long)b * T2 * a.ldk + h * ATT_DK;
     for (int kt = wave; kt < nkt; kt += 4) {
       float4 kf[4];
       load_frag_t(keys + (long)min(kt * 16 + fr, T2 - 1) * a.ldk, fq, kf);
-      float4* xp = reinterpret_cast<float4*>(&X[frx * XLD + kt * 16 + 4 * fq]);
-      f32x4 c = (f32x4){0.f, 0.f, 0.f, 0.f};
-      if (REL) { const float4 o = *xp; c = (f32x4){o.x, o.y, o.z, o.w}; }
-      c = dot_tile(kf, qf, c);                        // c[r]: key 16 kt + 4 fq + r, query fr
       const int j0 = kt * 16 + fq * 4;
-      unsigned mk = 0x01010101u;
-      if (mr) mk = mr[min(j0, T2 - 1)] | (mr[min(j0 + 1, T2 - 1)] << 8) | (mr[min(j0 + 2, T2 - 1)] << 16) | (mr[min(j0 + 3, T2 - 1)] << 24);
 #pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        float x = c[r] * a.scale;
-        if (j0 + r >= T2 || ((mk >> (8 * r)) & 0xffu) == 0u) x = -INFINITY;
-        c[r] = x;
-        mx = fmaxf(mx, x);
+      for (int qt = 0; qt < QT; ++qt) {
+        float4* xp = reinterpret_cast<float4*>(&X[rowx[qt] * XLD + kt * 16 + 4 * fq]);
+        f32x4 c = (f32x4){0.f, 0.f, 0.f, 0.f};
+        if (REL) { const float4 o = *xp; c = (f32x4){o.x, o.y, o.z, o.w}; }
+        c = dot_tile(kf, qf[qt], c);                    // c[r]: key 16 kt + 4 fq + r, query 16 qt + fr
+        unsigned mk = 0x01010101u;
+        if (mr[qt]) mk = mr[qt][min(j0, T2 - 1)] | (mr[qt][min(j0 + 1, T2 - 1)] << 8) | (mr[qt][min(j0 + 2, T2 - 1)] << 16) |
+                         (mr[qt][min(j0 + 3, T2 - 1)] << 24);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          float x = c[r] * a.scale;
+          if (j0 + r >= T2 || ((mk >> (8 * r)) & 0xffu) == 0u) x = -INFINITY;
+          c[r] = x;
+          mx[qt] = fmaxf(mx[qt], x);
+        }
+        *xp = make_float4(c[0], c[1], c[2], c[3]);
       }
-      *xp = make_float4(c[0], c[1], c[2], c[3]);
     }
   }
-  mx = xmax16_32(mx);
-  if (fq == 0) red[wave * LQ + frx] = mx;
-  __syncthreads();
-  mx = fmaxf(fmaxf(red[frx], red[LQ + frx]), fmaxf(red[2 * LQ + frx], red[3 * LQ + frx]));
-  const bool dead = mx == -INFINITY;                  // every key masked: zeros (softmax of min, then masked_fill(0))
-  float sum = 0.f;
-  for (int kt = wave; kt < nkt; kt += 4) {
-    float4* xp = reinterpret_cast<float4*>(&X[frx * XLD + kt * 16 + 4 * fq]);
-    float4 v = *xp;
-    v.x = dead ? 0.f : __expf(v.x - mx); v.y = dead ? 0.f : __expf(v.y - mx);
-    v.z = dead ? 0.f : __expf(v.z - mx); v.w = dead ? 0.f : __expf(v.w - mx);
-    sum += (v.x + v.y) + (v.z + v.w);
-    *xp = v;
+#pragma unroll
+  for (int qt = 0; qt < QT; ++qt) {
+    mx[qt] = xmax16_32(mx[qt]);
+    if (fq == 0) red[wave * LQ + rowx[qt]] = mx[qt];
   }
-  sum = xsum16_32(sum);
-  if (fq == 0) red[4 * LQ + wave * LQ + frx] = sum;
   __syncthreads();
-  sum = (red[4 * LQ + frx] + red[5 * LQ + frx]) + (red[6 * LQ + frx] + red[7 * LQ + frx]);
-  const float inv = dead ? 0.f : 1.f / sum;
+  bool dead[QT];
+  float sum[QT];
+#pragma unroll
+  for (int qt = 0; qt < QT; ++qt) {
+    const int rx = rowx[qt];
+    mx[qt] = fmaxf(fmaxf(red[rx], red[LQ + rx]), fmaxf(red[2 * LQ + rx], red[3 * LQ + rx]));
+    dead[qt] = mx[qt] == -INFINITY;                    // every key masked: zeros (softmax of min, then masked_fill(0))
+    sum[qt] = 0.f;
+  }
+  for (int kt = wave; kt < nkt; kt += 4) {
+#pragma unroll
+    for (int qt = 0; qt < QT; ++qt) {
+      float4* xp = reinterpret_cast<float4*>(&X[rowx[qt] * XLD + kt * 16 + 4 * fq]);
+      float4 v = *xp;
+      v.x = dead[qt] ? 0.f : __expf(v.x - mx[qt]); v.y = dead[qt] ? 0.f : __expf(v.y - mx[qt]);
+      v.z = dead[qt] ? 0.f : __expf(v.z - mx[qt]); v.w = dead[qt] ? 0.f : __expf(v.w - mx[qt]);
+      sum[qt] += (v.x + v.y) + (v.z + v.w);
+      *xp = v;
+    }
+  }
+#pragma unroll
+  for (int qt = 0; qt < QT; ++qt) {
+    sum[qt] = xsum16_32(sum[qt]);
+    if (fq == 0) red[4 * LQ + wave * LQ + rowx[qt]] = sum[qt];
+  }
+  __syncthreads();
+  float inv[QT];
+  long pro[QT];
+#pragma unroll
+  for (int qt = 0; qt < QT; ++qt) {
+    const int rx = rowx[qt];
+    const float sm = (red[4 * LQ + rx] + red[5 * LQ + rx]) + (red[6 * LQ + rx] + red[7 * LQ + rx]);
+    inv[qt] = dead[qt] ? 0.f : 1.f / sm;
+    pro[qt] = ((long)zz * T1 + qi[qt]) * a.ldp;
+  }
   // ---- probabilities out, context^T = V^T Pd^T over this wave's key tiles ----
-  const long pro = ((long)zz * T1 + qi) * a.ldp;
   const bool drop = a.drop_p > 0.f;
   const unsigned seed = drop ? eamd_drop_seed(a.drop_step, a.drop_salt) : 0u, thr = eamd_drop_thr16(a.drop_p);
   const float dinv = eamd_drop_inv(thr);
   const T* vs = a_v + (long)b * T2 * a.ldv + h * ATT_DK;
-  f32x4 C[4];
+  f32x4 C[QT][4];
 #pragma unroll
-  for (int dt = 0; dt < 4; ++dt) C[dt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  for (int qt = 0; qt < QT; ++qt)
+#pragma unroll
+    for (int dt = 0; dt < 4; ++dt) C[qt][dt] = (f32x4){0.f, 0.f, 0.f, 0.f};
   float4 vreg[4];
   if (wave < nkt) tile_load(vs, a.ldv, wave * 16, live ? T2 : 1, lane, vreg);
   for (int kt = wave; kt < nkt; kt += 4) {
     tile_store(vreg, Tw, lane);
     if (kt + 4 < nkt) tile_load(vs, a.ldv, (kt + 4) * 16, live ? T2 : 1, lane, vreg);
-    const float4 e = *reinterpret_cast<const float4*>(&X[frx * XLD + kt * 16 + 4 * fq]);
-    f32x4 Pv = (f32x4){e.x * inv, e.y * inv, e.z * inv, e.w * inv};
     const int j0 = kt * 16 + fq * 4;
-    if (qok && j0 < a.ldp) st4(a_P + pro + j0, make_float4(Pv[0], Pv[1], Pv[2], Pv[3]));
-    if (drop) {
-      bool kp[4];
-      eamd_drop_keep4(seed, (unsigned long long)(pro + min(j0, (int)a.ldp - 4)), thr, kp);
 #pragma unroll
-      for (int r = 0; r < 4; ++r) Pv[r] = kp[r] ? Pv[r] * dinv : 0.f;
-      if (qok && j0 < a.ldp) st4(a_Pd + pro + j0, make_float4(Pv[0], Pv[1], Pv[2], Pv[3]));
+    for (int qt = 0; qt < QT; ++qt) {
+      const float4 e = *reinterpret_cast<const float4*>(&X[rowx[qt] * XLD + kt * 16 + 4 * fq]);
+      f32x4 Pv = (f32x4){e.x * inv[qt], e.y * inv[qt], e.z * inv[qt], e.w * inv[qt]};
+      if (qok[qt] && j0 < a.ldp) st4(a_P + pro[qt] + j0, make_float4(Pv[0], Pv[1], Pv[2], Pv[3]));
+      if (drop) {
+        bool kp[4];
+        eamd_drop_keep4(seed, (unsigned long long)(pro[qt] + min(j0, (int)a.ldp - 4)), thr, kp);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) Pv[r] = kp[r] ? Pv[r] * dinv : 0.f;
+        if (qok[qt] && j0 < a.ldp) st4(a_Pd + pro[qt] + j0, make_float4(Pv[0], Pv[1], Pv[2], Pv[3]));
+      }
+#pragma unroll
+      for (int r = 0; r < 4; ++r) Pv[r] = rnd(a_P, Pv[r]);      // the context is built from the probabilities backward will read
+      tile_product(Tw, Pv, fr, fq, C[qt]);
     }
-#pragma unroll
-    for (int r = 0; r < 4; ++r) Pv[r] = rnd(a_P, Pv[r]);      // the context is built from the probabilities backward will read
-    tile_product(Tw, Pv, fr, fq, C);
   }
   __syncthreads();                                    // X is dead: its head becomes the reduction scratch
-  reduce_store_ct(C, X, wave, fr, fq, t, a_ctx + ((long)b * T1 + r0w) * a.ldc + h * ATT_DK, a.ldc, live ? nq : 0);
+#pragma unroll
+  for (int qt = 0; qt < QT; ++qt) {
+    if (qt > 0) __syncthreads();
+    reduce_store_ct(C[qt], X, wave, fr, fq, t, a_ctx + ((long)b * T1 + r0w + 16 * qt) * a.ldc + h * ATT_DK, a.ldc,
+                    live ? max(0, min(16, nq - 16 * qt)) : 0);
+  }
 }
 
 template <typename T, int LQ>
 __global__ __launch_bounds__(256) void attn_bwd_q_long_kernel(const AttnF32BwdArgs a, const int nkt, const int dq_bf16) {
+  constexpr int QT = LQ >= 16 ? LQ / 16 : 1;
   const T* const a_dctx = reinterpret_cast<const T*>(a.dctx); const T* const a_k = reinterpret_cast<const T*>(a.k);
   const T* const a_v = reinterpret_cast<const T*>(a.v); const T* const a_P = reinterpret_cast<const T*>(a.P);
   T* const a_dS = reinterpret_cast<T*>(a.dS); T* const a_dbd = reinterpret_cast<T*>(a.dbd);
@@ -672,7 +727,6 @@ __global__ __launch_bounds__(256) void attn_bwd_q_long_kernel(const AttnF32BwdAr
   const int XLD = nkt * 16 + 4;
   const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
   const int fr = lane & 15, fq = lane >> 4;
-  const int frx = min(fr, LQ - 1);                      // LQ = 8: lanes of the tile's upper half repeat query LQ - 1 (same values, same addresses)
   const int xcd = blockIdx.x & 7, jb = blockIdx.x >> 3;
   const int z = (jb / a.nqb) * 8 + xcd;
   const bool live = z < a.B * a.H;
@@ -682,88 +736,120 @@ __global__ __launch_bounds__(256) void attn_bwd_q_long_kernel(const AttnF32BwdAr
   const int Ts = (a.dbd && a.tshift) ? min(max(a.tshift[0], 1), T2) : T2;
   const int r0w = min((jb % a.nqb) * LQ, T1 - 1);
   const int nq = min(LQ, T1 - r0w);
-  const int qi = min(r0w + frx, T1 - 1);
-  const bool qok = live && fr < nq;
+  const long zo = (long)zz * T1 * a.ldp;
+  int rowx[QT], qrow[QT];
+  long pro[QT];
+  bool qok[QT];
+#pragma unroll
+  for (int qt = 0; qt < QT; ++qt) {
+    rowx[qt] = min(fr + 16 * qt, LQ - 1);
+    qrow[qt] = r0w + min(fr + 16 * qt, nq - 1);
+    pro[qt] = zo + (long)min(r0w + rowx[qt], T1 - 1) * a.ldp;
+    qok[qt] = live && fr + 16 * qt < nq;
+  }
   float* X = reinterpret_cast<float*>(smem_raw);
   float* Tw = X + LQ * XLD + wave * 16 * PLD;
   float* red = X + LQ * XLD + 4 * 16 * PLD;
-  const long zo = (long)zz * T1 * a.ldp;
-  const long pro = zo + (long)qi * a.ldp;
   const bool drop = a.drop_p > 0.f;
   const unsigned seed = drop ? eamd_drop_seed(a.drop_step, a.drop_salt) : 0u, thr = eamd_drop_thr16(a.drop_p);
   const float dinv = eamd_drop_inv(thr);
   // ---- dP tiles (gradient of the dropped probabilities -> of P), row sums of P dP ----
-  float s = 0.f;
+  float s[QT];
   {
-    float4 df[4];
-    load_frag_t(a_dctx + ((long)b * T1 + r0w + min(fr, nq - 1)) * a.ldd + h * ATT_DK, fq, df);
+    float4 df[QT][4];
+#pragma unroll
+    for (int qt = 0; qt < QT; ++qt) {
+      s[qt] = 0.f;
+      load_frag_t(a_dctx + ((long)b * T1 + qrow[qt]) * a.ldd + h * ATT_DK, fq, df[qt]);
+    }
     const T* vs = a_v + (long)b * T2 * a.ldv + h * ATT_DK;
     for (int kt = wave; kt < nkt; kt += 4) {
       float4 vf[4];
       load_frag_t(vs + (long)min(kt * 16 + fr, T2 - 1) * a.ldv, fq, vf);
-      f32x4 c = dot_tile(vf, df, (f32x4){0.f, 0.f, 0.f, 0.f});      // c[r]: key 16 kt + 4 fq + r, query fr
       const int j0 = kt * 16 + fq * 4;
-      float4 pr = ld4(a_P + pro + min(j0, (int)a.ldp - 4));
-      if (j0 >= (int)a.ldp) pr = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (drop) {
-        bool kp[4];
-        eamd_drop_keep4(seed, (unsigned long long)(pro + min(j0, (int)a.ldp - 4)), thr, kp);
 #pragma unroll
-        for (int r = 0; r < 4; ++r) c[r] = kp[r] ? c[r] * dinv : 0.f;
+      for (int qt = 0; qt < QT; ++qt) {
+        f32x4 c = dot_tile(vf, df[qt], (f32x4){0.f, 0.f, 0.f, 0.f});      // c[r]: key 16 kt + 4 fq + r, query 16 qt + fr
+        float4 pr = ld4(a_P + pro[qt] + min(j0, (int)a.ldp - 4));
+        if (j0 >= (int)a.ldp) pr = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (drop) {
+          bool kp[4];
+          eamd_drop_keep4(seed, (unsigned long long)(pro[qt] + min(j0, (int)a.ldp - 4)), thr, kp);
+#pragma unroll
+          for (int r = 0; r < 4; ++r) c[r] = kp[r] ? c[r] * dinv : 0.f;
+        }
+        const float p4[4] = {pr.x, pr.y, pr.z, pr.w};
+#pragma unroll
+        for (int r = 0; r < 4; ++r) if (j0 + r < T2) s[qt] += p4[r] * c[r];
+        *reinterpret_cast<float4*>(&X[rowx[qt] * XLD + kt * 16 + 4 * fq]) = make_float4(c[0], c[1], c[2], c[3]);
       }
-      const float p4[4] = {pr.x, pr.y, pr.z, pr.w};
-#pragma unroll
-      for (int r = 0; r < 4; ++r) if (j0 + r < T2) s += p4[r] * c[r];
-      *reinterpret_cast<float4*>(&X[frx * XLD + kt * 16 + 4 * fq]) = make_float4(c[0], c[1], c[2], c[3]);
     }
   }
-  s = xsum16_32(s);
-  if (fq == 0) red[wave * LQ + frx] = s;
+#pragma unroll
+  for (int qt = 0; qt < QT; ++qt) {
+    s[qt] = xsum16_32(s[qt]);
+    if (fq == 0) red[wave * LQ + rowx[qt]] = s[qt];
+  }
   __syncthreads();
-  s = (red[frx] + red[LQ + frx]) + (red[2 * LQ + frx] + red[3 * LQ + frx]);
+#pragma unroll
+  for (int qt = 0; qt < QT; ++qt) {
+    const int rx = rowx[qt];
+    s[qt] = (red[rx] + red[LQ + rx]) + (red[2 * LQ + rx] + red[3 * LQ + rx]);
+  }
   // ---- dS (+ the inverse rel_shift scatter dbd), dq^T = K^T dS^T over this wave's key tiles ----
   const T* ks = a_k + (long)b * T2 * a.ldk + h * ATT_DK;
-  const int i = r0w + fr;
-  f32x4 C[4];
+  f32x4 C[QT][4];
 #pragma unroll
-  for (int dt = 0; dt < 4; ++dt) C[dt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  for (int qt = 0; qt < QT; ++qt)
+#pragma unroll
+    for (int dt = 0; dt < 4; ++dt) C[qt][dt] = (f32x4){0.f, 0.f, 0.f, 0.f};
   float4 kreg[4];
   if (wave < nkt) tile_load(ks, a.ldk, wave * 16, live ? T2 : 1, lane, kreg);
   for (int kt = wave; kt < nkt; kt += 4) {
     tile_store(kreg, Tw, lane);
     if (kt + 4 < nkt) tile_load(ks, a.ldk, (kt + 4) * 16, live ? T2 : 1, lane, kreg);
     const int j0 = kt * 16 + fq * 4;
-    float4 pr = ld4(a_P + pro + min(j0, (int)a.ldp - 4));
-    if (j0 >= (int)a.ldp) pr = make_float4(0.f, 0.f, 0.f, 0.f);
-    const float4 dp = *reinterpret_cast<const float4*>(&X[frx * XLD + kt * 16 + 4 * fq]);
-    const float p4[4] = {pr.x, pr.y, pr.z, pr.w}, d4[4] = {dp.x, dp.y, dp.z, dp.w};
-    f32x4 G;
 #pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      const int j = j0 + r;
-      const float g = j < T2 ? p4[r] * (d4[r] - s) * a.scale : 0.f;
-      G[r] = g;
-      if (a.dbd && qok) {
-        if (j < Ts && i < Ts) {
-          const int R = j <= i ? i : i + 1, c = j <= i ? Ts + j - i : j - i - 1;
-          if (c != 0) st1(a_dbd + zo + (long)R * a.ldp + (c - 1), g);
-        } else if (j < (int)a.ldp) {
-          st1(a_dbd + zo + (long)i * a.ldp + j, 0.f);
+    for (int qt = 0; qt < QT; ++qt) {
+      const int i = r0w + fr + 16 * qt;
+      float4 pr = ld4(a_P + pro[qt] + min(j0, (int)a.ldp - 4));
+      if (j0 >= (int)a.ldp) pr = make_float4(0.f, 0.f, 0.f, 0.f);
+      const float4 dp = *reinterpret_cast<const float4*>(&X[rowx[qt] * XLD + kt * 16 + 4 * fq]);
+      const float p4[4] = {pr.x, pr.y, pr.z, pr.w}, d4[4] = {dp.x, dp.y, dp.z, dp.w};
+      f32x4 G;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int j = j0 + r;
+        const float g = j < T2 ? p4[r] * (d4[r] - s[qt]) * a.scale : 0.f;
+        G[r] = g;
+        if (a.dbd && qok[qt]) {
+          if (j < Ts && i < Ts) {
+            const int R = j <= i ? i : i + 1, c = j <= i ? Ts + j - i : j - i - 1;
+            if (c != 0) st1(a_dbd + zo + (long)R * a.ldp + (c - 1), g);
+          } else if (j < (int)a.ldp) {
+            st1(a_dbd + zo + (long)i * a.ldp + j, 0.f);
+          }
         }
       }
-    }
-    if (qok && j0 < (int)a.ldp) st4(a_dS + pro + j0, make_float4(G[0], G[1], G[2], G[3]));
+      if (qok[qt] && j0 < (int)a.ldp) st4(a_dS + pro[qt] + j0, make_float4(G[0], G[1], G[2], G[3]));
 #pragma unroll
-    for (int r = 0; r < 4; ++r) G[r] = rnd(a_dS, G[r]);       // dq from the dS the key-side kernels will read
-    tile_product(Tw, G, fr, fq, C);
+      for (int r = 0; r < 4; ++r) G[r] = rnd(a_dS, G[r]);       // dq from the dS the key-side kernels will read
+      tile_product(Tw, G, fr, fq, C[qt]);
+    }
   }
   if (a.dbd && live && r0w == 0)                      // the head of row 0 the scatter never reaches
     for (int f = 1 + t; f < Ts; f += 256) st1(a_dbd + zo + (f - 1), 0.f);
   __syncthreads();
-  if (dq_bf16)
-    reduce_store_ct(C, X, wave, fr, fq, t, reinterpret_cast<bfbits*>(a.dq) + ((long)b * T1 + r0w) * a.ldo + h * ATT_DK, a.ldo, live ? nq : 0);
-  else
-    reduce_store_ct(C, X, wave, fr, fq, t, a.dq + ((long)b * T1 + r0w) * a.ldo + h * ATT_DK, a.ldo, live ? nq : 0);
+#pragma unroll
+  for (int qt = 0; qt < QT; ++qt) {
+    if (qt > 0) __syncthreads();
+    const int nqt = live ? max(0, min(16, nq - 16 * qt)) : 0;
+    const long orow = ((long)b * T1 + r0w + 16 * qt) * a.ldo + h * ATT_DK;
+    if (dq_bf16)
+      reduce_store_ct(C[qt], X, wave, fr, fq, t, reinterpret_cast<bfbits*>(a.dq) + orow, a.ldo, nqt);
+    else
+      reduce_store_ct(C[qt], X, wave, fr, fq, t, a.dq + orow, a.ldo, nqt);
+  }
 }
 
 template <typename T, bool REL, int LQ>
@@ -781,10 +867,25 @@ int launch_fwd_long_q(AttnF32Args a, hipStream_t stream) {
   EAMD_LAUNCH_CHECK();
   return EAMD_OK;
 }
-// 16 queries per workgroup while their score rows fit the LDS (2048 keys), 8 beyond (4096 keys: the MFMA tiles run half empty)
+// queries per workgroup.  These kernels are bound by latency, not by their L2 traffic: measured (tools/attn_long_lq_probe.py, B = 16,
+// forward / query-side backward TFLOP/s) 16 queries give 45 - 49 / 32 - 39 while TWO workgroups share a CU (LDS <= 80 KB: up to ~976
+// keys) and 30 - 32 / 20 - 23 beyond that, where one workgroup = four waves per CU is left; 32 queries (two 16-query tiles per
+// wave: every key / value / position fragment fetched serves both) give 41 - 46 / 26 - 30 wherever they fit (1100 keys) - worse than
+// two resident workgroups, better than one.  So: 16 up to 976 keys, 32 from there to 1100, 16 to 2048, 8 beyond (4096 keys: the
+// MFMA tiles run half empty).
+inline int long_lq(int T1, int T2) {
+  static const int force = getenv("EAMD_ATTN_LONG_LQ") ? atoi(getenv("EAMD_ATTN_LONG_LQ")) : 0;      // A/B knob
+  const int nkt = (T2 + 15) / 16;
+  auto fits = [&](int lq) { return ((size_t)lq * (nkt * 16 + 4) + 4 * 16 * PLD + 8 * lq) * sizeof(float) <= 160 * 1024; };
+  if (force == 32 || force == 16 || force == 8) { if (fits(force)) return force; }
+  if (T1 > 16 && T2 > 976 && T2 <= 1100 && fits(32)) return 32;
+  return fits(16) ? 16 : 8;
+}
 template <typename T, bool REL>
 int launch_fwd_long(AttnF32Args a, hipStream_t stream) {
-  return a.T2 <= 2048 ? launch_fwd_long_q<T, REL, 16>(a, stream) : launch_fwd_long_q<T, REL, 8>(a, stream);
+  const int lq = long_lq(a.T1, a.T2);
+  return lq == 32 ? launch_fwd_long_q<T, REL, 32>(a, stream) : lq == 16 ? launch_fwd_long_q<T, REL, 16>(a, stream)
+                                                                          : launch_fwd_long_q<T, REL, 8>(a, stream);
 }
 
 template <typename T, int LQ>
@@ -804,7 +905,9 @@ int launch_bwd_long_q(AttnF32BwdArgs a, int dq_bf16, hipStream_t stream) {
 }
 template <typename T>
 int launch_bwd_long(AttnF32BwdArgs a, int dq_bf16, hipStream_t stream) {
-  return a.T2 <= 2048 ? launch_bwd_long_q<T, 16>(a, dq_bf16, stream) : launch_bwd_long_q<T, 8>(a, dq_bf16, stream);
+  const int lq = long_lq(a.T1, a.T2);
+  return lq == 32 ? launch_bwd_long_q<T, 32>(a, dq_bf16, stream) : lq == 16 ? launch_bwd_long_q<T, 16>(a, dq_bf16, stream)
+                                                                              : launch_bwd_long_q<T, 8>(a, dq_bf16, stream);
 }
 
 template <bool REL, int NKT>

@@ -1234,11 +1234,14 @@ def test_attention_fused_vs_oracle(ops, oracle, case, prec):
     dict(B=2, T1=101, T2=999, rel=False, mask="len"), dict(B=2, T1=600, T2=600, rel=True, mask="dead"),
     dict(B=1, T1=530, T2=530, rel=False, mask="causal"), dict(B=1, T1=2048, T2=2048, rel=True, mask="len"),
     dict(B=1, T1=2500, T2=2500, rel=True, mask="len"), dict(B=2, T1=101, T2=4096, rel=False, mask="len"),
-    dict(B=1, T1=2100, T2=2100, rel=False, mask="causal"), dict(B=1, T1=4096, T2=4096, rel=True, mask=None)])
+    dict(B=1, T1=2100, T2=2100, rel=False, mask="causal"), dict(B=1, T1=4096, T2=4096, rel=True, mask=None),
+    dict(B=2, T1=1030, T2=1030, rel=True, mask="len"), dict(B=1, T1=1001, T2=1001, rel=False, mask="causal"),
+    dict(B=2, T1=77, T2=1090, rel=False, mask="dead")])
 @pytest.mark.parametrize("prec", ["fp32", "bf16"])
 def test_attention_fused_long_rows_vs_oracle(ops, oracle, case, prec):
     """Rows of 513 .. 4096 keys stay on the fused path in both precision modes (attn_fwd_long_kernel / attn_bwd_q_long_kernel:
-    16 queries per workgroup up to 2048 keys, 8 beyond; every phase split over the keys; bf16 operands are widened on load):
+    16 queries per workgroup up to 2048 keys - 32 between 977 and 1100 keys, two query tiles per wave -, 8 beyond; every phase split
+    over the keys; bf16 operands are widened on load):
     probabilities, context and every gradient against the oracle in float64, the legacy rel_shift at T1 = T2 = 999 / 1500 / 2048 /
     2500 / 4096, cross-attention 101 x 999 and 101 x 4096, causal masks and a fully masked utterance.  Tolerances as test_attention_fused_vs_oracle.
     reference: transformer/attention.py:63-92, 141-206."""
