@@ -473,6 +473,7 @@ __global__ void ctc_prefix_batch_kernel(const float* __restrict__ logp_all, cons
 // (one wave per (hypothesis, candidate), lanes over frames) and the survivors' states are made by ctc_prefix_state_kernel at the
 // START of the next step, on a second stream beside the decoder stack (160 us of serial recursion off the critical path).
 namespace {
+template <int NT>      // frames per lane: 64 NT >= Tmax
 __global__ __launch_bounds__(64) void ctc_prefix_psi_kernel(const float* __restrict__ logp_all, const int* __restrict__ lens, int per_utt,
                                                             const float* __restrict__ r_prev, const int* __restrict__ cand,
                                                             const int* __restrict__ last, int ol, float* __restrict__ psi, int Tmax,
@@ -488,11 +489,11 @@ __global__ __launch_bounds__(64) void ctc_prefix_psi_kernel(const float* __restr
   const bool same = ol > 0 && last[h] == c;
   const int start = max(ol, 1);
   // terms phi(t-1) + x(t), t = start .. T-1, and the initial r[start-1, 0]; two passes: maximum, then the sum of exponentials
-  float term[8];                                   // Tmax <= 512 frames per wave (host check)
+  float term[NT];                                  // Tmax <= 64 NT frames per wave (host check)
   float mx = (ol == 0 && lane == 0) ? logp[c] : kLogZero;
   const float init = mx;
 #pragma unroll
-  for (int q = 0; q < 8; ++q) {
+  for (int q = 0; q < NT; ++q) {
     const int t = start + lane + 64 * q;
     term[q] = -INFINITY;
     if (t < T) {
@@ -506,7 +507,7 @@ __global__ __launch_bounds__(64) void ctc_prefix_psi_kernel(const float* __restr
   mx = wave_max(mx);
   float se = lane == 0 ? expf(init - mx) : 0.f;
 #pragma unroll
-  for (int q = 0; q < 8; ++q) se += (term[q] == -INFINITY) ? 0.f : expf(term[q] - mx);
+  for (int q = 0; q < NT; ++q) se += (term[q] == -INFINITY) ? 0.f : expf(term[q] - mx);
   se = wave_sum(se);
   if (lane == 0) {
     float lpsi = mx == -INFINITY ? -INFINITY : mx + logf(se);
@@ -570,10 +571,10 @@ __global__ __launch_bounds__(64) void ctc_prefix_state_kernel(const float* __res
   }
 }
 
-// The same forward variables as a PARALLEL scan (Tmax <= 512): r^n does not read r^b -
+// The same forward variables as a PARALLEL scan (Tmax <= 2048: 8 / 16 / 32 frames per lane): r^n does not read r^b -
 //   r^n(t) = logaddexp(x(t) + r^n(t-1), x(t) + phi(t-1)),   then   r^b(t) = logaddexp(b(t) + r^b(t-1), b(t) + r^n(t-1))
 // are two scalar recurrences s(t) = logaddexp(a(t) + s(t-1), c(t)); maps (a, c) compose as (a2 + a1, logaddexp(a2 + c1, c2)).
-// One wave per slot, a lane owns eight consecutive frames: inclusive maps inside the lane, a six-step scan of the lanes' totals,
+// One wave per slot, a lane owns Q consecutive frames: inclusive maps inside the lane, a six-step scan of the lanes' totals,
 // then every frame applies its map to the state entering the lane - ~16 dependent logaddexp per recurrence instead of one per
 // frame (130 us -> a few us at T = 249).  Same quantities; the order of the additions differs from the frame-by-frame recursion
 // (both are within 1e-5 + 2e-6 |ref| of float64: test_ctc_prefix_score_vs_float64).
@@ -592,6 +593,7 @@ __device__ __forceinline__ ScanMap wave_scan_exclusive(ScanMap tot, int lane) {
   if (lane == 0) ex = ScanMap{0.f, -INFINITY};
   return ex;
 }
+template <int Q>       // consecutive frames per lane: 64 Q >= Tmax
 __global__ __launch_bounds__(64) void ctc_prefix_state_scan_kernel(const float* __restrict__ logp_all, const int* __restrict__ lens,
                                                                    int per_utt, const float* __restrict__ r_prev,
                                                                    const long long* __restrict__ parent, const long long* __restrict__ tok,
@@ -616,7 +618,6 @@ __global__ __launch_bounds__(64) void ctc_prefix_state_scan_kernel(const float* 
   for (int t = lane; t < min(start - 1, T); t += 64) *reinterpret_cast<float2*>(rn + 2 * t) = make_float2(kLogZero, kLogZero);
   const float n0 = ol == 0 ? logp[c] : kLogZero, b0 = kLogZero;
   if (lane == 0 && start - 1 < T) *reinterpret_cast<float2*>(rn + 2 * (start - 1)) = make_float2(n0, b0);
-  constexpr int Q = 8;
   float xv[Q], bv[Q], phi[Q];
 #pragma unroll
   for (int q = 0; q < Q; ++q) {
@@ -658,9 +659,13 @@ extern "C" int eamd_ctc_prefix_psi(const float* logp, const int32_t* lens, int n
                                    int eos, void* stream) {
   if (!logp || !lens || !r_prev || !cand || !last || !psi || nutt <= 0 || per_utt <= 0 || ncand <= 0 || Tmax <= 0 || V <= 0 || olen < 0)
     return EAMD_EINVAL;
-  if (Tmax > 512) return EAMD_EUNSUPPORTED;             // eight frames per lane are held in registers
-  hipLaunchKernelGGL(ctc_prefix_psi_kernel, dim3(ncand, nutt * per_utt), dim3(64), 0, (hipStream_t)stream, logp, lens, per_utt, r_prev,
-                     cand, last, olen, psi, Tmax, V, ncand, blank, eos);
+  if (Tmax > 2048) return EAMD_EUNSUPPORTED;            // 8 / 16 / 32 frames per lane are held in registers
+#define EAMD_PSI_(NT) hipLaunchKernelGGL(ctc_prefix_psi_kernel<NT>, dim3(ncand, nutt * per_utt), dim3(64), 0, (hipStream_t)stream, logp, lens, \
+                                         per_utt, r_prev, cand, last, olen, psi, Tmax, V, ncand, blank, eos)
+  if (Tmax <= 512) EAMD_PSI_(8);
+  else if (Tmax <= 1024) EAMD_PSI_(16);
+  else EAMD_PSI_(32);
+#undef EAMD_PSI_
   EAMD_LAUNCH_CHECK();
   return EAMD_OK;
 }
@@ -673,9 +678,13 @@ extern "C" int eamd_ctc_prefix_state(const float* logp, const int32_t* lens, int
     return EAMD_EINVAL;
   const int n = nutt * per_utt;
   static const int state_scan = getenv("EAMD_CTC_STATE_SCAN") ? atoi(getenv("EAMD_CTC_STATE_SCAN")) : 1;     // A/B knob: 0 = frame by frame
-  if (state_scan && Tmax <= 512) {
-    hipLaunchKernelGGL(ctc_prefix_state_scan_kernel, dim3(n), dim3(64), 0, (hipStream_t)stream, logp, lens, per_utt, r_prev,
-                       (const long long*)parent, (const long long*)tok, last, olen, alive, r_out, n, Tmax, V, blank);
+  if (state_scan && Tmax <= 2048) {
+#define EAMD_SCAN_(Q) hipLaunchKernelGGL(ctc_prefix_state_scan_kernel<Q>, dim3(n), dim3(64), 0, (hipStream_t)stream, logp, lens, per_utt, r_prev, \
+                                         (const long long*)parent, (const long long*)tok, last, olen, alive, r_out, n, Tmax, V, blank)
+    if (Tmax <= 512) EAMD_SCAN_(8);
+    else if (Tmax <= 1024) EAMD_SCAN_(16);
+    else EAMD_SCAN_(32);
+#undef EAMD_SCAN_
     EAMD_LAUNCH_CHECK();
     return EAMD_OK;
   }

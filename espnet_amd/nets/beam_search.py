@@ -223,7 +223,7 @@ class BeamSearch(torch.nn.Module):
     step_kernel = True            # selection + bookkeeping of a pre-beam step in one launch (eamd_beam_step); tests flip it
     ctc_psi_parallel = True       # candidates scored by eamd_ctc_prefix_psi, survivors' states by eamd_ctc_prefix_state; tests flip it
     ctc_side_stream = "capture"   # ... the latter on a second stream beside the next step's decoder stack: True, False, or only where
-                                  # it pays: more than 512 frames (the frame-by-frame recursion, 130 us at 249 frames; up to 512 the
+                                  # it pays: more than 2048 frames (the frame-by-frame recursion, 130 us at 249 frames; up to 2048 the
                                   # states are a parallel scan of a few us) in a captured step graph (the fork and the join cost
                                   # ~25 us of queue switches per replay; an eager step is bound by the host's launches)
 
@@ -498,7 +498,7 @@ class BeamSearch(torch.nn.Module):
             pend = S["c_pend"]
             c_r_now = torch.empty(n, C_["Tpad"], 2, device=dev, dtype=torch.float32)
             if self.ctc_side_stream is True or (self.ctc_side_stream == "capture" and torch.cuda.is_current_stream_capturing()
-                                                and C_["Tpad"] > 512):
+                                                and C_["Tpad"] > 2048):
                 side = self._ctc_stream(dev)
                 side.wait_stream(torch.cuda.current_stream(dev))
                 with torch.cuda.stream(side):
@@ -516,7 +516,7 @@ class BeamSearch(torch.nn.Module):
         P = self.pre_beam_size
         full_fast = (self.partial_mode == "full" and self.step_kernel and P <= 63 and P + 1 >= beam and beam * (P + 1) <= 1023
                      and beam <= 64 and beam * V < 2 ** 31 - 1024
-                     and self.ctc_psi_parallel and C_["Tpad"] <= 512)
+                     and self.ctc_psi_parallel and C_["Tpad"] <= 2048)
         if (ctc is not None and self.do_pre_beam and (self.partial_mode == "ids" or full_fast) and self.pre_beam_score_key == "full"
                 and 1 <= len(names) <= 4 and V % 4 == 0 and beam * P <= 1024 and self.candidate_select
                 and all(logps[k].dtype == torch.float32 and logps[k].is_contiguous() for k in names)):
@@ -542,7 +542,7 @@ class BeamSearch(torch.nn.Module):
             psi = ops.ctc_prefix_psi(C_["logp"], C_["lens_d"], beam, c_r_now, cand32, last, L - 1, ctc.blank, ctc.eos) \
                 if self.ctc_psi_parallel else None
             r_new = None
-            if psi is None:       # more than 512 frames: the full recursion for every candidate
+            if psi is None:       # more than 2048 frames: the full recursion for every candidate
                 olen = torch.full((n,), L - 1, dtype=torch.int32, device=dev)
                 psi, r_new = ops.ctc_prefix_score_batch(C_["logp"], C_["lens_d"], beam, c_r_now, cand32, last, olen, ctc.blank, ctc.eos)
             if self.step_kernel and beam <= 64 and beam * P <= 1023 and beam * V < 2 ** 31 and r_new is None:

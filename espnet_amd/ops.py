@@ -1809,7 +1809,7 @@ def ctc_prefix_score_batch(logp, lens, per_utt, r_prev, cand, last, olen, blank,
 
 def ctc_prefix_psi(logp, lens, per_utt, r_prev, cand, last, olen, blank, eos):
     """log psi of the candidates as a parallel reduction over the frames (eamd_ctc_prefix_psi): logp [U, Tmax, V], r_prev
-    [U * per_utt, Tmax, 2], cand [n, P] int32, last [n] int32, olen int -> psi [n, P]; None when the library declines (Tmax > 512)"""
+    [U * per_utt, Tmax, 2], cand [n, P] int32, last [n] int32, olen int -> psi [n, P]; None when the library declines (Tmax > 2048)"""
     U, Tmax, V = logp.shape
     nhyp, ncand = cand.shape
     assert nhyp == U * per_utt and r_prev.shape == (nhyp, Tmax, 2) and cand.dtype == torch.int32 and logp.is_contiguous()

@@ -605,7 +605,7 @@ int eamd_ctc_prefix_score_batch(const float* logp, const int32_t* lens, int nutt
                                 int ncand, int Tmax, int V, int blank, int eos, void* stream);
 /* The same scores with the serial recursion OFF a beam step's critical path (csrc/ctc.hip): log psi of a candidate is a logsumexp over
  * the frames of phi(t-1) + x(t) (ctc_prefix_score.py:290-296 never reads r[t] for it) - eamd_ctc_prefix_psi forms it as a parallel
- * reduction (one wave per (hypothesis, candidate); Tmax <= 512) - and only the continuations that SURVIVE the selection need their
+ * reduction (one wave per (hypothesis, candidate); Tmax <= 2048) - and only the continuations that SURVIVE the selection need their
  * forward variables: eamd_ctc_prefix_state runs the recursion of :291-295 for slot s = (hypothesis parent[s], token tok[s]) into
  * r_out [n, Tmax, 2] (slots with alive[s] = -inf get log-zero rows); the caller issues it at the start of the next step on a second
  * stream beside the decoder stack.  olen = prefix length - 1 of the scored hypotheses (one value: all hypotheses of a step have the

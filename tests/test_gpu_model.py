@@ -2241,6 +2241,8 @@ def test_beam_ctc_split_matches_full_recursion():
     from espnet_amd.nets.ctc_prefix_score import LengthBonus
     SW, model, g, encs = c2width_setup()
     spec = SW.DECODE_R4
+    # ... and an utterance of 657 frames (the three memories back to back: 16 frames per lane in the reduction and in the scan)
+    encs = list(encs) + [torch.cat([encs[0], encs[1], encs[0]], 0).contiguous()]
     res = {}
     for mode in ("full", "split", "split_inline"):
         scorers = model.scorers()
