@@ -1040,6 +1040,71 @@ __global__ __launch_bounds__(256) void linear_mfma16_f32_kernel(const float* __r
 }
 }  // namespace
 
+// ... and for a LONG reduction (the feed-forward down-product of a batched beam step: 320 x 256 x K = 2048): one 16 x 16 output tile
+// per WORKGROUP, its four waves split K (each walks K / 4 straight from global memory as above), the four partial tiles meet in LDS
+// and are added in a fixed order.  As one wave per tile that product took 33 us (every wave alone on a 2048-long chain), as
+// split-K 64 x 64 tiles with atomics 21 us + a 5 us zero fill.
+namespace {
+__global__ __launch_bounds__(256) void linear_mfma16_ksplit_f32_kernel(const float* __restrict__ x, const float* __restrict__ W,
+                                                                       const float* __restrict__ bias, const float* __restrict__ R,
+                                                                       float* __restrict__ y, int M, int N, int K, int a_act, int act,
+                                                                       float alpha, long ldx, long ldr) {
+  __shared__ float part[3][64][4];
+  const int lane = threadIdx.x & 63, fr = lane & 15, fq = lane >> 4, w = threadIdx.x >> 6;
+  const int n0 = blockIdx.x * 16, m0 = blockIdx.y * 16;
+  const int kq = ((K / 4 + 15) / 16) * 16;                                 // a wave's share of K (a multiple of 16)
+  const int kb = w * kq, ke = min(K, kb + kq);
+  const float* xr = x + (long)min(m0 + fr, M - 1) * ldx + fq * 4;          // clamped rows / columns are never stored
+  const float* wr = W + (long)min(n0 + fr, N - 1) * K + fq * 4;
+  f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+  constexpr int U = 8;                                                      // 16-k chunks requested together
+  for (int k0 = kb; k0 < ke; k0 += 16 * U) {
+    float4 xa[U], wb[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int k = min(k0 + 16 * u, K - 16);                               // (K % 16 == 0: checked on the host)
+      xa[u] = *reinterpret_cast<const float4*>(xr + k);
+      wb[u] = *reinterpret_cast<const float4*>(wr + k);
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      if (k0 + 16 * u < ke) {
+        float4 v = xa[u];
+        if (a_act != EAMD_ACT_NONE) {
+          v.x = eamd_act(v.x, a_act); v.y = eamd_act(v.y, a_act); v.z = eamd_act(v.z, a_act); v.w = eamd_act(v.w, a_act);
+        }
+        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(v.x, wb[u].x, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(v.y, wb[u].y, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(v.z, wb[u].z, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(v.w, wb[u].w, acc, 0, 0, 0);
+      }
+    }
+  }
+  if (w > 0) {
+#pragma unroll
+    for (int r = 0; r < 4; ++r) part[w - 1][lane][r] = acc[r];
+  }
+  __syncthreads();
+  if (w != 0) return;
+  const int n = n0 + fr;
+  if (n < N) {
+    const float b = bias ? bias[n] : 0.f;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int m = m0 + fq * 4 + r;
+      if (m < M) {
+        float v = ((acc[r] + part[0][lane][r]) + (part[1][lane][r] + part[2][lane][r])) + b;
+        if (act == 1) v = fmaxf(v, 0.f);
+        else if (act == 2) v = eamd_swish(v);
+        v *= alpha;
+        if (R) v += R[(long)m * ldr + n];
+        y[(long)m * N + n] = v;
+      }
+    }
+  }
+}
+}  // namespace
+
 // k largest of every row, sorted: value descending, equal values by ascending index (a total order: the selection is the same
 // whatever the grid or the replay).  NaN counts as -inf, -0 as +0.  One workgroup per row; an element is the 64-bit key
 // (order-preserving bits of the value, ~index): "ranks before" is one unsigned compare.
@@ -1434,6 +1499,12 @@ int eamd_linear_rows_f32(const float* x, const float* W, const float* bias, cons
   static const int rows_mfma = getenv("EAMD_ROWS_MFMA") ? atoi(getenv("EAMD_ROWS_MFMA")) : 0;      // A/B knob: the 16 x 16 tiles for M <= 16 too
   if (M > 16 || (rows_mfma && K % 16 == 0)) {
     if (K % 16 != 0) return EAMD_EUNSUPPORTED;
+    if (K >= 1024 && M > 16) {                               // a long reduction: the waves of a workgroup split K
+      hipLaunchKernelGGL(linear_mfma16_ksplit_f32_kernel, dim3((N + 15) / 16, (M + 15) / 16), dim3(256), 0, (hipStream_t)stream, x, W,
+                         bias, R, y, M, N, K, a_act, act, alpha, (long)ldx, (long)ldr);
+      EAMD_LAUNCH_CHECK();
+      return EAMD_OK;
+    }
     hipLaunchKernelGGL(linear_mfma16_f32_kernel, dim3((N + 63) / 64, (M + 15) / 16), dim3(256), 0, (hipStream_t)stream, x, W, bias,
                        R, y, M, N, K, a_act, act, alpha, (long)ldx, (long)ldr);
     EAMD_LAUNCH_CHECK();

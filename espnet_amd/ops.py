@@ -479,6 +479,8 @@ def inference_call(fn):
 # layer (N = 5000: 29.7 against 17.8 us) - so it takes the narrow products only
 LINEAR_ROWS_MAX = int(os.environ.get("EAMD_LINEAR_ROWS_MAX", "16"))
 LINEAR_ROWS_BLOCK_MAX = int(os.environ.get("EAMD_LINEAR_ROWS_BLOCK_MAX", "1024"))      # ... up to this many rows, K <= 512, N <= 1024
+# ... and the long reductions (K >= 1024: the waves of a workgroup split K, one 16 x 16 tile per workgroup) - A/B knob
+LINEAR_ROWS_KSPLIT = os.environ.get("EAMD_LINEAR_ROWS_KSPLIT", "1") != "0"
 
 
 def linear_fwd(x, W, b, out=None, *, act=EPI_NONE, R=None, alpha=1.0, a_act=ACT_NONE, out_dtype=torch.float32,
@@ -489,7 +491,8 @@ def linear_fwd(x, W, b, out=None, *, act=EPI_NONE, R=None, alpha=1.0, a_act=ACT_
     M, K = x.shape
     N = W.shape[0]
     assert W.shape[1] == K and W.is_contiguous() and x.stride(1) == 1 and (R is None or R.stride(-1) == 1)
-    if (LINEAR_ROWS and (M <= LINEAR_ROWS_MAX or (M <= LINEAR_ROWS_BLOCK_MAX and K <= 512 and N <= 1024 and K % 16 == 0)) and out is None and out_dtype == torch.float32 and x.dtype == torch.float32 and W.dtype == torch.float32
+    if (LINEAR_ROWS and (M <= LINEAR_ROWS_MAX or (M <= LINEAR_ROWS_BLOCK_MAX and (K <= 512 or (K >= 1024 and LINEAR_ROWS_KSPLIT)) and N <= 1024
+                                                  and K % 16 == 0)) and out is None and out_dtype == torch.float32 and x.dtype == torch.float32 and W.dtype == torch.float32
             and act in (EPI_NONE, EPI_RELU, EPI_SWISH) and a_act in (ACT_NONE, ACT_RELU, ACT_SWISH) and drop is None and Hb is None
             and a_drop is None and K % 4 == 0 and _state["precision"] == 0 and _infer > 0 and not torch.is_grad_enabled()
             and (R is None or (tuple(R.shape) == (M, N) and (M == 1 or R.stride(0) >= N))) and (M == 1 or x.stride(0) >= K)):

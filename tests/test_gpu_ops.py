@@ -1602,7 +1602,7 @@ def test_topk_rows(ops, rows, n, k):
                                                  (16, 5000, 256, 0, 0, False), (1, 30, 64, 2, 2, True), (7, 257, 1028, 0, 0, True),
                                                  (320, 256, 256, 0, 0, True), (320, 256, 2048, 1, 0, True), (41, 2049, 256, 0, 1, False),
                                                  (17, 30, 64, 2, 2, True), (16, 255, 4096, 0, 2, True), (9, 64, 1024, 2, 0, False),
-                                                 (12, 130, 3000, 0, 1, True)])
+                                                 (12, 130, 3000, 0, 1, True), (33, 48, 1040, 0, 2, True), (1000, 256, 4096, 2, 0, False)])
 def test_linear_rows_f32(ops, M, N, K, a_act, act, res):
     """eamd_linear_rows_f32 (nn.Linear on <= 16 rows, one wave per output column; taken by ops.linear_fwd without autograd) against
     float64: y = alpha * act(a_act(x) W^T + b) + R.  reference: the per-step products of decoder_layer.py:77-134."""
