@@ -500,8 +500,8 @@ __device__ __forceinline__ void tile_product(const float* tile, const f32x4& G, 
     for (int dt = 0; dt < 4; ++dt) C[dt] = __builtin_amdgcn_mfma_f32_16x16x4f32(row[dt * 16], G[r], C[dt], 0, 0, 0);
   }
 }
-// sum of the four waves' C^T tiles -> out[query][64 channels] (16-byte stores); `scr` = 4 x [64][17] floats
-template <typename T>
+// sum of the NW waves' C^T tiles -> out[query][64 channels] (16-byte stores); `scr` = NW x [64][17] floats
+template <int NW, typename T>
 __device__ __forceinline__ void reduce_store_ct(const f32x4 (&C)[4], float* scr, int wave, int fr, int fq, int t, T* out,
                                                 long ld, int nq) {
 #pragma unroll
@@ -516,16 +516,17 @@ __device__ __forceinline__ void reduce_store_ct(const f32x4 (&C)[4], float* scr,
     for (int e = 0; e < 4; ++e) {
       float v = 0.f;
 #pragma unroll
-      for (int w = 0; w < 4; ++w) v += scr[(w * 64 + c4 + e) * 17 + q];
+      for (int w = 0; w < NW; ++w) v += scr[(w * 64 + c4 + e) * 17 + q];
       o[e] = v;
     }
     st4(out + (long)q * ld + c4, make_float4(o[0], o[1], o[2], o[3]));
   }
 }
 
-template <typename T, bool REL, int LQ>
-__global__ __launch_bounds__(256) void attn_fwd_long_kernel(const AttnF32Args a, const int nkt) {
-  constexpr int QT = LQ >= 16 ? LQ / 16 : 1;           // 16-query tiles of the workgroup: every key / value / position fragment a wave
+template <typename T, bool REL, int LQ, int NW>
+__global__ __launch_bounds__(64 * NW) void attn_fwd_long_kernel(const AttnF32Args a, const int nkt) {
+  constexpr int QT = LQ >= 16 ? LQ / 16 : 1;
+  constexpr int NT = 64 * NW;                          // NW waves split the key tiles (4, or 8 where only one workgroup fits a CU)           // 16-query tiles of the workgroup: every key / value / position fragment a wave
   const T* const a_qu = reinterpret_cast<const T*>(a.qu); const T* const a_qv = reinterpret_cast<const T*>(a.qv);      // loads serves all of them
   const T* const a_k = reinterpret_cast<const T*>(a.k); const T* const a_v = reinterpret_cast<const T*>(a.v);
   const T* const a_pos = reinterpret_cast<const T*>(a.pos);
@@ -555,18 +556,18 @@ __global__ __launch_bounds__(256) void attn_fwd_long_kernel(const AttnF32Args a,
   }
   float* X = reinterpret_cast<float*>(smem_raw);
   float* Tw = X + LQ * XLD + wave * 16 * PLD;           // this wave's tile buffer
-  float* red = X + LQ * XLD + 4 * 16 * PLD;             // [2][4][LQ]
+  float* red = X + LQ * XLD + NW * 16 * PLD;            // [2][NW][LQ]
   const int Ts = (REL && a.tshift) ? min(max(a.tshift[0], 1), T2) : T2;
   if (REL) {
     if (Ts < T2) {
-      for (int e = t; e < LQ * XLD; e += 256) X[e] = 0.f;
+      for (int e = t; e < LQ * XLD; e += NT) X[e] = 0.f;
       __syncthreads();
     }
     float4 qf[QT][4];
 #pragma unroll
     for (int qt = 0; qt < QT; ++qt) load_frag_t(a_qv + ((long)b * T1 + qrow[qt]) * a.ldqv + h * ATT_DK, fq, qf[qt]);
     if (t < LQ && r0w + t + 1 < T2) X[t * XLD + r0w + t + 1] = 0.f;
-    for (int mt = wave; mt < nkt; mt += 4) {
+    for (int mt = wave; mt < nkt; mt += NW) {
       float4 pf[4];
       load_frag_t(a_pos + (long)min(mt * 16 + fr, T2 - 1) * a.ldpos + h * ATT_DK, fq, pf);
 #pragma unroll
@@ -585,7 +586,7 @@ __global__ __launch_bounds__(256) void attn_fwd_long_kernel(const AttnF32Args a,
     const int i16 = r0w + LQ;                         // first query of the next workgroup: its low positions feed query r0w + LQ - 1
     if (live && i16 < Ts) {
       const T* qr = a_qv + ((long)b * T1 + i16) * a.ldqv + h * ATT_DK;
-      for (int m = t; m <= Ts - 2 - i16; m += 256) {
+      for (int m = t; m <= Ts - 2 - i16; m += NT) {
         const T* pr = a_pos + (long)m * a.ldpos + h * ATT_DK;
         float s = 0.f;
 #pragma unroll
@@ -610,7 +611,7 @@ __global__ __launch_bounds__(256) void attn_fwd_long_kernel(const AttnF32Args a,
       load_frag_t(a_qu + ((long)b * T1 + qrow[qt]) * a.ldq + h * ATT_DK, fq, qf[qt]);
     }
     const T* keys = a_k + (long)b * T2 * a.ldk + h * ATT_DK;
-    for (int kt = wave; kt < nkt; kt += 4) {
+    for (int kt = wave; kt < nkt; kt += NW) {
       float4 kf[4];
       load_frag_t(keys + (long)min(kt * 16 + fr, T2 - 1) * a.ldk, fq, kf);
       const int j0 = kt * 16 + fq * 4;
@@ -645,11 +646,14 @@ __global__ __launch_bounds__(256) void attn_fwd_long_kernel(const AttnF32Args a,
 #pragma unroll
   for (int qt = 0; qt < QT; ++qt) {
     const int rx = rowx[qt];
-    mx[qt] = fmaxf(fmaxf(red[rx], red[LQ + rx]), fmaxf(red[2 * LQ + rx], red[3 * LQ + rx]));
+    float m_ = red[rx];
+#pragma unroll
+    for (int w_ = 1; w_ < NW; ++w_) m_ = fmaxf(m_, red[w_ * LQ + rx]);
+    mx[qt] = m_;
     dead[qt] = mx[qt] == -INFINITY;                    // every key masked: zeros (softmax of min, then masked_fill(0))
     sum[qt] = 0.f;
   }
-  for (int kt = wave; kt < nkt; kt += 4) {
+  for (int kt = wave; kt < nkt; kt += NW) {
 #pragma unroll
     for (int qt = 0; qt < QT; ++qt) {
       float4* xp = reinterpret_cast<float4*>(&X[rowx[qt] * XLD + kt * 16 + 4 * fq]);
@@ -663,7 +667,7 @@ __global__ __launch_bounds__(256) void attn_fwd_long_kernel(const AttnF32Args a,
 #pragma unroll
   for (int qt = 0; qt < QT; ++qt) {
     sum[qt] = xsum16_32(sum[qt]);
-    if (fq == 0) red[4 * LQ + wave * LQ + rowx[qt]] = sum[qt];
+    if (fq == 0) red[NW * LQ + wave * LQ + rowx[qt]] = sum[qt];
   }
   __syncthreads();
   float inv[QT];
@@ -671,7 +675,9 @@ __global__ __launch_bounds__(256) void attn_fwd_long_kernel(const AttnF32Args a,
 #pragma unroll
   for (int qt = 0; qt < QT; ++qt) {
     const int rx = rowx[qt];
-    const float sm = (red[4 * LQ + rx] + red[5 * LQ + rx]) + (red[6 * LQ + rx] + red[7 * LQ + rx]);
+    float sm = 0.f;
+#pragma unroll
+    for (int w_ = 0; w_ < NW; w_ += 2) sm += red[(NW + w_) * LQ + rx] + red[(NW + w_ + 1) * LQ + rx];      // (NW = 4: the pairs' sum as before)
     inv[qt] = dead[qt] ? 0.f : 1.f / sm;
     pro[qt] = ((long)zz * T1 + qi[qt]) * a.ldp;
   }
@@ -687,9 +693,9 @@ __global__ __launch_bounds__(256) void attn_fwd_long_kernel(const AttnF32Args a,
     for (int dt = 0; dt < 4; ++dt) C[qt][dt] = (f32x4){0.f, 0.f, 0.f, 0.f};
   float4 vreg[4];
   if (wave < nkt) tile_load(vs, a.ldv, wave * 16, live ? T2 : 1, lane, vreg);
-  for (int kt = wave; kt < nkt; kt += 4) {
+  for (int kt = wave; kt < nkt; kt += NW) {
     tile_store(vreg, Tw, lane);
-    if (kt + 4 < nkt) tile_load(vs, a.ldv, (kt + 4) * 16, live ? T2 : 1, lane, vreg);
+    if (kt + NW < nkt) tile_load(vs, a.ldv, (kt + NW) * 16, live ? T2 : 1, lane, vreg);
     const int j0 = kt * 16 + fq * 4;
 #pragma unroll
     for (int qt = 0; qt < QT; ++qt) {
@@ -712,14 +718,15 @@ __global__ __launch_bounds__(256) void attn_fwd_long_kernel(const AttnF32Args a,
 #pragma unroll
   for (int qt = 0; qt < QT; ++qt) {
     if (qt > 0) __syncthreads();
-    reduce_store_ct(C[qt], X, wave, fr, fq, t, a_ctx + ((long)b * T1 + r0w + 16 * qt) * a.ldc + h * ATT_DK, a.ldc,
+    reduce_store_ct<NW>(C[qt], X, wave, fr, fq, t, a_ctx + ((long)b * T1 + r0w + 16 * qt) * a.ldc + h * ATT_DK, a.ldc,
                     live ? max(0, min(16, nq - 16 * qt)) : 0);
   }
 }
 
-template <typename T, int LQ>
-__global__ __launch_bounds__(256) void attn_bwd_q_long_kernel(const AttnF32BwdArgs a, const int nkt, const int dq_bf16) {
+template <typename T, int LQ, int NW>
+__global__ __launch_bounds__(64 * NW) void attn_bwd_q_long_kernel(const AttnF32BwdArgs a, const int nkt, const int dq_bf16) {
   constexpr int QT = LQ >= 16 ? LQ / 16 : 1;
+  constexpr int NT = 64 * NW;                          // NW waves split the key tiles (4, or 8 where only one workgroup fits a CU)
   const T* const a_dctx = reinterpret_cast<const T*>(a.dctx); const T* const a_k = reinterpret_cast<const T*>(a.k);
   const T* const a_v = reinterpret_cast<const T*>(a.v); const T* const a_P = reinterpret_cast<const T*>(a.P);
   T* const a_dS = reinterpret_cast<T*>(a.dS); T* const a_dbd = reinterpret_cast<T*>(a.dbd);
@@ -749,7 +756,7 @@ __global__ __launch_bounds__(256) void attn_bwd_q_long_kernel(const AttnF32BwdAr
   }
   float* X = reinterpret_cast<float*>(smem_raw);
   float* Tw = X + LQ * XLD + wave * 16 * PLD;
-  float* red = X + LQ * XLD + 4 * 16 * PLD;
+  float* red = X + LQ * XLD + NW * 16 * PLD;
   const bool drop = a.drop_p > 0.f;
   const unsigned seed = drop ? eamd_drop_seed(a.drop_step, a.drop_salt) : 0u, thr = eamd_drop_thr16(a.drop_p);
   const float dinv = eamd_drop_inv(thr);
@@ -763,7 +770,7 @@ __global__ __launch_bounds__(256) void attn_bwd_q_long_kernel(const AttnF32BwdAr
       load_frag_t(a_dctx + ((long)b * T1 + qrow[qt]) * a.ldd + h * ATT_DK, fq, df[qt]);
     }
     const T* vs = a_v + (long)b * T2 * a.ldv + h * ATT_DK;
-    for (int kt = wave; kt < nkt; kt += 4) {
+    for (int kt = wave; kt < nkt; kt += NW) {
       float4 vf[4];
       load_frag_t(vs + (long)min(kt * 16 + fr, T2 - 1) * a.ldv, fq, vf);
       const int j0 = kt * 16 + fq * 4;
@@ -794,7 +801,10 @@ __global__ __launch_bounds__(256) void attn_bwd_q_long_kernel(const AttnF32BwdAr
 #pragma unroll
   for (int qt = 0; qt < QT; ++qt) {
     const int rx = rowx[qt];
-    s[qt] = (red[rx] + red[LQ + rx]) + (red[2 * LQ + rx] + red[3 * LQ + rx]);
+    float s_ = 0.f;
+#pragma unroll
+    for (int w_ = 0; w_ < NW; w_ += 2) s_ += red[w_ * LQ + rx] + red[(w_ + 1) * LQ + rx];
+    s[qt] = s_;
   }
   // ---- dS (+ the inverse rel_shift scatter dbd), dq^T = K^T dS^T over this wave's key tiles ----
   const T* ks = a_k + (long)b * T2 * a.ldk + h * ATT_DK;
@@ -805,9 +815,9 @@ __global__ __launch_bounds__(256) void attn_bwd_q_long_kernel(const AttnF32BwdAr
     for (int dt = 0; dt < 4; ++dt) C[qt][dt] = (f32x4){0.f, 0.f, 0.f, 0.f};
   float4 kreg[4];
   if (wave < nkt) tile_load(ks, a.ldk, wave * 16, live ? T2 : 1, lane, kreg);
-  for (int kt = wave; kt < nkt; kt += 4) {
+  for (int kt = wave; kt < nkt; kt += NW) {
     tile_store(kreg, Tw, lane);
-    if (kt + 4 < nkt) tile_load(ks, a.ldk, (kt + 4) * 16, live ? T2 : 1, lane, kreg);
+    if (kt + NW < nkt) tile_load(ks, a.ldk, (kt + NW) * 16, live ? T2 : 1, lane, kreg);
     const int j0 = kt * 16 + fq * 4;
 #pragma unroll
     for (int qt = 0; qt < QT; ++qt) {
@@ -838,7 +848,7 @@ __global__ __launch_bounds__(256) void attn_bwd_q_long_kernel(const AttnF32BwdAr
     }
   }
   if (a.dbd && live && r0w == 0)                      // the head of row 0 the scatter never reaches
-    for (int f = 1 + t; f < Ts; f += 256) st1(a_dbd + zo + (f - 1), 0.f);
+    for (int f = 1 + t; f < Ts; f += NT) st1(a_dbd + zo + (f - 1), 0.f);
   __syncthreads();
 #pragma unroll
   for (int qt = 0; qt < QT; ++qt) {
@@ -846,68 +856,80 @@ __global__ __launch_bounds__(256) void attn_bwd_q_long_kernel(const AttnF32BwdAr
     const int nqt = live ? max(0, min(16, nq - 16 * qt)) : 0;
     const long orow = ((long)b * T1 + r0w + 16 * qt) * a.ldo + h * ATT_DK;
     if (dq_bf16)
-      reduce_store_ct(C[qt], X, wave, fr, fq, t, reinterpret_cast<bfbits*>(a.dq) + orow, a.ldo, nqt);
+      reduce_store_ct<NW>(C[qt], X, wave, fr, fq, t, reinterpret_cast<bfbits*>(a.dq) + orow, a.ldo, nqt);
     else
-      reduce_store_ct(C[qt], X, wave, fr, fq, t, a.dq + orow, a.ldo, nqt);
+      reduce_store_ct<NW>(C[qt], X, wave, fr, fq, t, a.dq + orow, a.ldo, nqt);
   }
 }
 
-template <typename T, bool REL, int LQ>
+template <typename T, bool REL, int LQ, int NW>
 int launch_fwd_long_q(AttnF32Args a, hipStream_t stream) {
   const int nkt = (a.T2 + 15) / 16;
-  const size_t smem = ((size_t)LQ * (nkt * 16 + 4) + 4 * 16 * PLD + 8 * LQ) * sizeof(float);
-  if (smem > 160 * 1024) return EAMD_EUNSUPPORTED;
-  static const hipError_t attr_err = hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_fwd_long_kernel<T, REL, LQ>),
+  const size_t smem = ((size_t)LQ * (nkt * 16 + 4) + NW * 16 * PLD + 2 * NW * LQ) * sizeof(float);
+  if (smem > 160 * 1024 || smem < (size_t)NW * 64 * 17 * sizeof(float)) return EAMD_EUNSUPPORTED;
+  static const hipError_t attr_err = hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_fwd_long_kernel<T, REL, LQ, NW>),
                                                          hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
   if (attr_err != hipSuccess) return (int)attr_err;
   a.nqb = (a.T1 + LQ - 1) / LQ;
   const int nz = (a.B * a.H + 7) / 8 * 8;
   if ((long)a.nqb * nz >= (1L << 31)) return EAMD_EUNSUPPORTED;
-  hipLaunchKernelGGL((attn_fwd_long_kernel<T, REL, LQ>), dim3((unsigned)(a.nqb * nz)), dim3(256), smem, stream, a, nkt);
+  hipLaunchKernelGGL((attn_fwd_long_kernel<T, REL, LQ, NW>), dim3((unsigned)(a.nqb * nz)), dim3(64 * NW), smem, stream, a, nkt);
   EAMD_LAUNCH_CHECK();
   return EAMD_OK;
 }
-// queries per workgroup.  These kernels are bound by latency, not by their L2 traffic: measured (tools/attn_long_lq_probe.py, B = 16,
-// forward / query-side backward TFLOP/s) 16 queries give 45 - 49 / 32 - 39 while TWO workgroups share a CU (LDS <= 80 KB: up to ~976
-// keys) and 30 - 32 / 20 - 23 beyond that, where one workgroup = four waves per CU is left; 32 queries (two 16-query tiles per
-// wave: every key / value / position fragment fetched serves both) give 41 - 46 / 26 - 30 wherever they fit (1100 keys) - worse than
-// two resident workgroups, better than one.  So: 16 up to 976 keys, 32 from there to 1100, 16 to 2048, 8 beyond (4096 keys: the
-// MFMA tiles run half empty).
-inline int long_lq(int T1, int T2) {
-  static const int force = getenv("EAMD_ATTN_LONG_LQ") ? atoi(getenv("EAMD_ATTN_LONG_LQ")) : 0;      // A/B knob
+// queries and waves per workgroup.  These kernels are bound by latency, not by their L2 traffic: measured (tools/attn_long_lq_probe.py,
+// B = 16, forward / query-side backward TFLOP/s) 16 queries x 4 waves give 45 - 49 / 32 - 39 while TWO workgroups share a CU (LDS <= 80 KB:
+// up to ~976 keys) and 30 - 32 / 20 - 23 beyond that, where one workgroup = four waves per CU is left; 32 queries (two 16-query tiles per
+// wave: every key / value / position fragment fetched serves both) give 41 - 46 / 26 - 30 wherever they fit (1100 keys) - worse than two
+// resident workgroups, better than one.  Beyond 976 keys the one workgroup a CU holds therefore runs EIGHT waves (the key tiles
+// split eight ways: 45 - 48 / 36 up to 1900 keys), six where the tile buffers of eight no longer fit (2048 keys); 8 queries beyond
+// 2048 keys (to 4096: the MFMA tiles run half empty).
+struct LongGeom { int lq, nw; };
+inline LongGeom long_geom(int T1, int T2) {
+  static const int force_lq = getenv("EAMD_ATTN_LONG_LQ") ? atoi(getenv("EAMD_ATTN_LONG_LQ")) : 0;      // A/B knobs
+  static const int force_nw = getenv("EAMD_ATTN_LONG_NW") ? atoi(getenv("EAMD_ATTN_LONG_NW")) : 0;
   const int nkt = (T2 + 15) / 16;
-  auto fits = [&](int lq) { return ((size_t)lq * (nkt * 16 + 4) + 4 * 16 * PLD + 8 * lq) * sizeof(float) <= 160 * 1024; };
-  if (force == 32 || force == 16 || force == 8) { if (fits(force)) return force; }
-  if (T1 > 16 && T2 > 976 && T2 <= 1100 && fits(32)) return 32;
-  return fits(16) ? 16 : 8;
+  auto bytes = [&](int lq, int nw) { return ((size_t)lq * (nkt * 16 + 4) + nw * 16 * PLD + 2 * nw * lq) * sizeof(float); };
+  LongGeom g{16, 4};
+  if (bytes(16, 4) > 160 * 1024) g = LongGeom{8, 4};
+  if (bytes(g.lq, 4) > 80 * 1024) g.nw = bytes(g.lq, 8) <= 160 * 1024 ? 8 : bytes(g.lq, 6) <= 160 * 1024 ? 6 : 4;   // one workgroup per CU: more waves
+  if ((force_lq == 32 || force_lq == 16 || force_lq == 8) && bytes(force_lq, 4) <= 160 * 1024) g = LongGeom{force_lq, 4};
+  if ((force_nw == 4 || force_nw == 6 || force_nw == 8) && g.lq != 32 && bytes(g.lq, force_nw) <= 160 * 1024) g.nw = force_nw;
+  (void)T1;
+  return g;
 }
 template <typename T, bool REL>
 int launch_fwd_long(AttnF32Args a, hipStream_t stream) {
-  const int lq = long_lq(a.T1, a.T2);
-  return lq == 32 ? launch_fwd_long_q<T, REL, 32>(a, stream) : lq == 16 ? launch_fwd_long_q<T, REL, 16>(a, stream)
-                                                                          : launch_fwd_long_q<T, REL, 8>(a, stream);
+  const LongGeom g = long_geom(a.T1, a.T2);
+  if (g.lq == 32) return launch_fwd_long_q<T, REL, 32, 4>(a, stream);
+  if (g.lq == 16) return g.nw == 8 ? launch_fwd_long_q<T, REL, 16, 8>(a, stream) : g.nw == 6 ? launch_fwd_long_q<T, REL, 16, 6>(a, stream)
+                                                                                               : launch_fwd_long_q<T, REL, 16, 4>(a, stream);
+  return g.nw == 8 ? launch_fwd_long_q<T, REL, 8, 8>(a, stream) : g.nw == 6 ? launch_fwd_long_q<T, REL, 8, 6>(a, stream)
+                                                                              : launch_fwd_long_q<T, REL, 8, 4>(a, stream);
 }
 
-template <typename T, int LQ>
+template <typename T, int LQ, int NW>
 int launch_bwd_long_q(AttnF32BwdArgs a, int dq_bf16, hipStream_t stream) {
   const int nkt = (a.T2 + 15) / 16;
-  const size_t smem = ((size_t)LQ * (nkt * 16 + 4) + 4 * 16 * PLD + 8 * LQ) * sizeof(float);
-  if (smem > 160 * 1024) return EAMD_EUNSUPPORTED;
-  static const hipError_t attr_err = hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_bwd_q_long_kernel<T, LQ>),
+  const size_t smem = ((size_t)LQ * (nkt * 16 + 4) + NW * 16 * PLD + 2 * NW * LQ) * sizeof(float);
+  if (smem > 160 * 1024 || smem < (size_t)NW * 64 * 17 * sizeof(float)) return EAMD_EUNSUPPORTED;
+  static const hipError_t attr_err = hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_bwd_q_long_kernel<T, LQ, NW>),
                                                          hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
   if (attr_err != hipSuccess) return (int)attr_err;
   a.nqb = (a.T1 + LQ - 1) / LQ;
   const int nz = (a.B * a.H + 7) / 8 * 8;
   if ((long)a.nqb * nz >= (1L << 31)) return EAMD_EUNSUPPORTED;
-  hipLaunchKernelGGL((attn_bwd_q_long_kernel<T, LQ>), dim3((unsigned)(a.nqb * nz)), dim3(256), smem, stream, a, nkt, dq_bf16);
+  hipLaunchKernelGGL((attn_bwd_q_long_kernel<T, LQ, NW>), dim3((unsigned)(a.nqb * nz)), dim3(64 * NW), smem, stream, a, nkt, dq_bf16);
   EAMD_LAUNCH_CHECK();
   return EAMD_OK;
 }
 template <typename T>
 int launch_bwd_long(AttnF32BwdArgs a, int dq_bf16, hipStream_t stream) {
-  const int lq = long_lq(a.T1, a.T2);
-  return lq == 32 ? launch_bwd_long_q<T, 32>(a, dq_bf16, stream) : lq == 16 ? launch_bwd_long_q<T, 16>(a, dq_bf16, stream)
-                                                                              : launch_bwd_long_q<T, 8>(a, dq_bf16, stream);
+  const LongGeom g = long_geom(a.T1, a.T2);
+  if (g.lq == 32) return launch_bwd_long_q<T, 32, 4>(a, dq_bf16, stream);
+  // (six waves: measured SLOWER than four in this kernel at 2048 keys - 1058 against 760 us - while the forward gains, 639 against 820)
+  if (g.lq == 16) return g.nw == 8 ? launch_bwd_long_q<T, 16, 8>(a, dq_bf16, stream) : launch_bwd_long_q<T, 16, 4>(a, dq_bf16, stream);
+  return g.nw == 8 ? launch_bwd_long_q<T, 8, 8>(a, dq_bf16, stream) : launch_bwd_long_q<T, 8, 4>(a, dq_bf16, stream);
 }
 
 template <bool REL, int NKT>
