@@ -567,9 +567,12 @@ __global__ __launch_bounds__(64 * NW) void attn_fwd_long_kernel(const AttnF32Arg
 #pragma unroll
     for (int qt = 0; qt < QT; ++qt) load_frag_t(a_qv + ((long)b * T1 + qrow[qt]) * a.ldqv + h * ATT_DK, fq, qf[qt]);
     if (t < LQ && r0w + t + 1 < T2) X[t * XLD + r0w + t + 1] = 0.f;
+    // (the next tile's fragment is requested before this tile's products: with one or two workgroups of 4 - 8 waves per CU nothing
+    // else hides the round trip of these row-strided loads)
+    float4 pf[4], pfn[4];
+    if (wave < nkt) load_frag_t(a_pos + (long)min(wave * 16 + fr, T2 - 1) * a.ldpos + h * ATT_DK, fq, pf);
     for (int mt = wave; mt < nkt; mt += NW) {
-      float4 pf[4];
-      load_frag_t(a_pos + (long)min(mt * 16 + fr, T2 - 1) * a.ldpos + h * ATT_DK, fq, pf);
+      if (mt + NW < nkt) load_frag_t(a_pos + (long)min((mt + NW) * 16 + fr, T2 - 1) * a.ldpos + h * ATT_DK, fq, pfn);
 #pragma unroll
       for (int qt = 0; qt < QT; ++qt) {
         const f32x4 c = dot_tile(pf, qf[qt], (f32x4){0.f, 0.f, 0.f, 0.f});     // c[r] = bd[query 16 qt + fr][m = 16 mt + 4 fq + r]
@@ -582,6 +585,8 @@ __global__ __launch_bounds__(64 * NW) void attn_fwd_long_kernel(const AttnF32Arg
           if (m < Ts && i < Ts && lr < nq && row >= 0) X[row * XLD + j] = c[r];
         }
       }
+#pragma unroll
+      for (int j = 0; j < 4; ++j) pf[j] = pfn[j];
     }
     const int i16 = r0w + LQ;                         // first query of the next workgroup: its low positions feed query r0w + LQ - 1
     if (live && i16 < Ts) {
@@ -611,9 +616,10 @@ __global__ __launch_bounds__(64 * NW) void attn_fwd_long_kernel(const AttnF32Arg
       load_frag_t(a_qu + ((long)b * T1 + qrow[qt]) * a.ldq + h * ATT_DK, fq, qf[qt]);
     }
     const T* keys = a_k + (long)b * T2 * a.ldk + h * ATT_DK;
+    float4 kf[4], kfn[4];
+    if (wave < nkt) load_frag_t(keys + (long)min(wave * 16 + fr, T2 - 1) * a.ldk, fq, kf);
     for (int kt = wave; kt < nkt; kt += NW) {
-      float4 kf[4];
-      load_frag_t(keys + (long)min(kt * 16 + fr, T2 - 1) * a.ldk, fq, kf);
+      if (kt + NW < nkt) load_frag_t(keys + (long)min((kt + NW) * 16 + fr, T2 - 1) * a.ldk, fq, kfn);
       const int j0 = kt * 16 + fq * 4;
 #pragma unroll
       for (int qt = 0; qt < QT; ++qt) {
@@ -633,6 +639,8 @@ __global__ __launch_bounds__(64 * NW) void attn_fwd_long_kernel(const AttnF32Arg
         }
         *xp = make_float4(c[0], c[1], c[2], c[3]);
       }
+#pragma unroll
+      for (int j = 0; j < 4; ++j) kf[j] = kfn[j];
     }
   }
 #pragma unroll
@@ -770,9 +778,10 @@ __global__ __launch_bounds__(64 * NW) void attn_bwd_q_long_kernel(const AttnF32B
       load_frag_t(a_dctx + ((long)b * T1 + qrow[qt]) * a.ldd + h * ATT_DK, fq, df[qt]);
     }
     const T* vs = a_v + (long)b * T2 * a.ldv + h * ATT_DK;
+    float4 vf[4], vfn[4];
+    if (wave < nkt) load_frag_t(vs + (long)min(wave * 16 + fr, T2 - 1) * a.ldv, fq, vf);
     for (int kt = wave; kt < nkt; kt += NW) {
-      float4 vf[4];
-      load_frag_t(vs + (long)min(kt * 16 + fr, T2 - 1) * a.ldv, fq, vf);
+      if (kt + NW < nkt) load_frag_t(vs + (long)min((kt + NW) * 16 + fr, T2 - 1) * a.ldv, fq, vfn);
       const int j0 = kt * 16 + fq * 4;
 #pragma unroll
       for (int qt = 0; qt < QT; ++qt) {
@@ -790,6 +799,8 @@ __global__ __launch_bounds__(64 * NW) void attn_bwd_q_long_kernel(const AttnF32B
         for (int r = 0; r < 4; ++r) if (j0 + r < T2) s[qt] += p4[r] * c[r];
         *reinterpret_cast<float4*>(&X[rowx[qt] * XLD + kt * 16 + 4 * fq]) = make_float4(c[0], c[1], c[2], c[3]);
       }
+#pragma unroll
+      for (int j = 0; j < 4; ++j) vf[j] = vfn[j];
     }
   }
 #pragma unroll
