@@ -477,7 +477,8 @@ template <int NT>      // frames per lane: 64 NT >= Tmax
 __global__ __launch_bounds__(64) void ctc_prefix_psi_kernel(const float* __restrict__ logp_all, const int* __restrict__ lens, int per_utt,
                                                             const float* __restrict__ r_prev, const int* __restrict__ cand,
                                                             const int* __restrict__ last, int ol, float* __restrict__ psi, int Tmax,
-                                                            int V, int ncand, int blank, int eos) {
+                                                            int V, int ncand, int blank, int eos, const int* __restrict__ ol_dev) {
+  if (ol_dev) ol = ol_dev[0] + ol;                       // the prefix length from the device step index (+ host offset)
   const int j = blockIdx.x, h = blockIdx.y, lane = threadIdx.x;
   const int u = h / per_utt;
   const int T = min(max(lens[u], 1), Tmax);
@@ -524,7 +525,8 @@ __global__ __launch_bounds__(64) void ctc_prefix_state_kernel(const float* __res
                                                               const float* __restrict__ r_prev, const long long* __restrict__ parent,
                                                               const long long* __restrict__ tok, const int* __restrict__ last, int ol,
                                                               const float* __restrict__ alive, float* __restrict__ r_out, int n, int Tmax,
-                                                              int V, int blank) {
+                                                              int V, int blank, const int* __restrict__ ol_dev) {
+  if (ol_dev) ol = ol_dev[0] + ol;
   const int s = blockIdx.x * 64 + threadIdx.x;
   if (s >= n) return;
   const int u = s / per_utt;
@@ -598,7 +600,9 @@ __global__ __launch_bounds__(64) void ctc_prefix_state_scan_kernel(const float* 
                                                                    int per_utt, const float* __restrict__ r_prev,
                                                                    const long long* __restrict__ parent, const long long* __restrict__ tok,
                                                                    const int* __restrict__ last, int ol, const float* __restrict__ alive,
-                                                                   float* __restrict__ r_out, int n, int Tmax, int V, int blank) {
+                                                                   float* __restrict__ r_out, int n, int Tmax, int V, int blank,
+                                                                   const int* __restrict__ ol_dev) {
+  if (ol_dev) ol = ol_dev[0] + ol;
   const int s = blockIdx.x, lane = threadIdx.x;
   const int u = s / per_utt;
   const int T = min(max(lens[u], 1), Tmax);
@@ -657,11 +661,19 @@ __global__ __launch_bounds__(64) void ctc_prefix_state_scan_kernel(const float* 
 extern "C" int eamd_ctc_prefix_psi(const float* logp, const int32_t* lens, int nutt, int per_utt, const float* r_prev,
                                    const int32_t* cand, const int32_t* last, int olen, float* psi, int ncand, int Tmax, int V, int blank,
                                    int eos, void* stream) {
-  if (!logp || !lens || !r_prev || !cand || !last || !psi || nutt <= 0 || per_utt <= 0 || ncand <= 0 || Tmax <= 0 || V <= 0 || olen < 0)
+  return eamd_ctc_prefix_psi_dyn(logp, lens, nutt, per_utt, r_prev, cand, last, olen, nullptr, psi, ncand, Tmax, V, blank, eos, stream);
+}
+
+extern "C" int eamd_ctc_prefix_psi_dyn(const float* logp, const int32_t* lens, int nutt, int per_utt, const float* r_prev,
+                                       const int32_t* cand, const int32_t* last, int olen, const int32_t* olen_dev, float* psi, int ncand,
+                                       int Tmax, int V, int blank, int eos, void* stream) {
+  if (!logp || !lens || !r_prev || !cand || !last || !psi || nutt <= 0 || per_utt <= 0 || ncand <= 0 || Tmax <= 0 || V <= 0 ||
+      (!olen_dev && olen < 0))
     return EAMD_EINVAL;
+  const int* ol_dev = olen_dev;
   if (Tmax > 2048) return EAMD_EUNSUPPORTED;            // 8 / 16 / 32 frames per lane are held in registers
 #define EAMD_PSI_(NT) hipLaunchKernelGGL(ctc_prefix_psi_kernel<NT>, dim3(ncand, nutt * per_utt), dim3(64), 0, (hipStream_t)stream, logp, lens, \
-                                         per_utt, r_prev, cand, last, olen, psi, Tmax, V, ncand, blank, eos)
+                                         per_utt, r_prev, cand, last, olen, psi, Tmax, V, ncand, blank, eos, ol_dev)
   if (Tmax <= 512) EAMD_PSI_(8);
   else if (Tmax <= 1024) EAMD_PSI_(16);
   else EAMD_PSI_(32);
@@ -673,14 +685,21 @@ extern "C" int eamd_ctc_prefix_psi(const float* logp, const int32_t* lens, int n
 extern "C" int eamd_ctc_prefix_state(const float* logp, const int32_t* lens, int nutt, int per_utt, const float* r_prev,
                                      const int64_t* parent, const int64_t* tok, const int32_t* last, int olen, const float* alive,
                                      float* r_out, int Tmax, int V, int blank, void* stream) {
+  return eamd_ctc_prefix_state_dyn(logp, lens, nutt, per_utt, r_prev, parent, tok, last, olen, nullptr, alive, r_out, Tmax, V, blank, stream);
+}
+
+extern "C" int eamd_ctc_prefix_state_dyn(const float* logp, const int32_t* lens, int nutt, int per_utt, const float* r_prev,
+                                         const int64_t* parent, const int64_t* tok, const int32_t* last, int olen, const int32_t* olen_dev,
+                                         const float* alive, float* r_out, int Tmax, int V, int blank, void* stream) {
   if (!logp || !lens || !r_prev || !parent || !tok || !last || !alive || !r_out || nutt <= 0 || per_utt <= 0 || Tmax <= 0 || V <= 0 ||
-      olen < 0)
+      (!olen_dev && olen < 0))
     return EAMD_EINVAL;
+  const int* ol_dev = olen_dev;
   const int n = nutt * per_utt;
   static const int state_scan = getenv("EAMD_CTC_STATE_SCAN") ? atoi(getenv("EAMD_CTC_STATE_SCAN")) : 1;     // A/B knob: 0 = frame by frame
   if (state_scan && Tmax <= 2048) {
 #define EAMD_SCAN_(Q) hipLaunchKernelGGL(ctc_prefix_state_scan_kernel<Q>, dim3(n), dim3(64), 0, (hipStream_t)stream, logp, lens, per_utt, r_prev, \
-                                         (const long long*)parent, (const long long*)tok, last, olen, alive, r_out, n, Tmax, V, blank)
+                                         (const long long*)parent, (const long long*)tok, last, olen, alive, r_out, n, Tmax, V, blank, ol_dev)
     if (Tmax <= 512) EAMD_SCAN_(8);
     else if (Tmax <= 1024) EAMD_SCAN_(16);
     else EAMD_SCAN_(32);
@@ -689,7 +708,7 @@ extern "C" int eamd_ctc_prefix_state(const float* logp, const int32_t* lens, int
     return EAMD_OK;
   }
   hipLaunchKernelGGL(ctc_prefix_state_kernel, dim3((n + 63) / 64), dim3(64), 0, (hipStream_t)stream, logp, lens, per_utt, r_prev,
-                     (const long long*)parent, (const long long*)tok, last, olen, alive, r_out, n, Tmax, V, blank);
+                     (const long long*)parent, (const long long*)tok, last, olen, alive, r_out, n, Tmax, V, blank, ol_dev);
   EAMD_LAUNCH_CHECK();
   return EAMD_OK;
 }

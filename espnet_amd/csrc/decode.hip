@@ -186,8 +186,10 @@ __global__ __launch_bounds__(256) void linear_mfma16_ln_f32_kernel(const float* 
 //   ctx   [n, D]
 __global__ __launch_bounds__(64) void decode_self_attn_kernel(const float* __restrict__ qkv, long ldq, float* __restrict__ Kc,
                                                               float* __restrict__ Vc, const int* __restrict__ slot_at, int Lcap,
-                                                              int pos, int n, int D, float* __restrict__ ctx, float scale) {
+                                                              int pos, int n, int D, float* __restrict__ ctx, float scale,
+                                                              const int* __restrict__ pos_dev) {
   extern __shared__ float sc[];                 // [pos + 1] scores, then probabilities; ints of the slots behind them
+  if (pos_dev) pos = min(max(pos_dev[0] + pos, 0), Lcap - 1);      // the step index lives on the device (one graph for every step)
   int* sl = reinterpret_cast<int*>(sc + Lcap);
   const int h = blockIdx.x, row = blockIdx.y, lane = threadIdx.x;
   const float* qr = qkv + (long)row * ldq + h * 64;
@@ -255,7 +257,9 @@ __global__ __launch_bounds__(64) void decode_self_attn_kernel(const float* __res
 
 // slot_out[i][t] = slot_in[hyp[i]][t] for t < pos, slot_out[i][pos] = hyp[i]: the history of the hypothesis selected into slot i
 __global__ __launch_bounds__(256) void beam_slots_kernel(const int* __restrict__ slot_in, int* __restrict__ slot_out,
-                                                         const long long* __restrict__ hyp, int n, int Lcap, int pos) {
+                                                         const long long* __restrict__ hyp, int n, int Lcap, int pos,
+                                                         const int* __restrict__ pos_dev) {
+  if (pos_dev) pos = min(max(pos_dev[0] + pos, 0), Lcap - 1);
   const int i = blockIdx.x;
   long long p = hyp[i];
   p = p < 0 ? 0 : (p >= n ? n - 1 : p);
@@ -293,19 +297,29 @@ int eamd_linear_rows_ln_f32(const float* x, const float* gamma, const float* bet
 
 int eamd_decode_self_attn(const float* qkv, int64_t ldq, float* kcache, float* vcache, const int32_t* slot_at, int Lcap, int pos,
                           int n, int H, int D, float* ctx, void* stream) {
-  if (!qkv || !kcache || !vcache || !slot_at || !ctx || n <= 0 || H <= 0 || D <= 0 || Lcap <= 0 || pos < 0) return EAMD_EINVAL;
-  if (pos >= Lcap || ldq < 3L * D) return EAMD_EINVAL;
+  return eamd_decode_self_attn_dyn(qkv, ldq, kcache, vcache, slot_at, Lcap, pos, nullptr, n, H, D, ctx, stream);
+}
+
+int eamd_decode_self_attn_dyn(const float* qkv, int64_t ldq, float* kcache, float* vcache, const int32_t* slot_at, int Lcap, int pos,
+                              const int32_t* pos_dev, int n, int H, int D, float* ctx, void* stream) {
+  if (!qkv || !kcache || !vcache || !slot_at || !ctx || n <= 0 || H <= 0 || D <= 0 || Lcap <= 0 || (!pos_dev && pos < 0)) return EAMD_EINVAL;
+  if ((!pos_dev && pos >= Lcap) || ldq < 3L * D) return EAMD_EINVAL;
   if (D != H * 64 || Lcap > 4096 || ldq % 4 != 0 || (((uintptr_t)qkv | (uintptr_t)kcache | (uintptr_t)vcache) & 15)) return EAMD_EUNSUPPORTED;
   hipLaunchKernelGGL(decode_self_attn_kernel, dim3(H, n), dim3(64), (size_t)Lcap * 8, (hipStream_t)stream, qkv, (long)ldq, kcache,
-                     vcache, slot_at, Lcap, pos, n, D, ctx, 0.125f);
+                     vcache, slot_at, Lcap, pos, n, D, ctx, 0.125f, pos_dev);
   EAMD_LAUNCH_CHECK();
   return EAMD_OK;
 }
 
 int eamd_beam_slots(const int32_t* slot_in, int32_t* slot_out, const int64_t* hyp, int n, int Lcap, int pos, void* stream) {
-  if (!slot_in || !slot_out || !hyp || n <= 0 || Lcap <= 0 || pos < 0 || pos >= Lcap) return EAMD_EINVAL;
+  return eamd_beam_slots_dyn(slot_in, slot_out, hyp, n, Lcap, pos, nullptr, stream);
+}
+
+int eamd_beam_slots_dyn(const int32_t* slot_in, int32_t* slot_out, const int64_t* hyp, int n, int Lcap, int pos, const int32_t* pos_dev,
+                        void* stream) {
+  if (!slot_in || !slot_out || !hyp || n <= 0 || Lcap <= 0 || (!pos_dev && (pos < 0 || pos >= Lcap))) return EAMD_EINVAL;
   hipLaunchKernelGGL(beam_slots_kernel, dim3(n), dim3(256), 0, (hipStream_t)stream, slot_in, slot_out, (const long long*)hyp, n, Lcap,
-                     pos);
+                     pos, pos_dev);
   EAMD_LAUNCH_CHECK();
   return EAMD_OK;
 }
@@ -424,13 +438,22 @@ struct BeamStepArgs {
   float* rec;
   float w_ctc;
   int n, beam, P, V, W, L, step, eos, ns, nf;
+  // one graph for every step: the step index read from the device (L = step + 1), the log row written into a ring of `ring` rows
+  // ([ring][n][3 + ns + W]: slot step % ring), step + 1 left in step_out for the next replay
+  const int* step_dev; int* step_out; int ring;
 };
 __device__ __forceinline__ unsigned sel_bits(float v) {      // order-preserving bits (NaN was made -inf; -0 ranks as +0)
   if (v == 0.f) v = 0.f;
   const unsigned b = __float_as_uint(v);
   return (b & 0x80000000u) ? ~b : (b | 0x80000000u);
 }
-__global__ __launch_bounds__(256) void beam_step_kernel(const BeamStepArgs a) {
+__global__ __launch_bounds__(256) void beam_step_kernel(BeamStepArgs a) {
+  if (a.step_dev) {
+    a.step = min(max(a.step_dev[0], 0), a.W - 2);
+    a.L = a.step + 1;
+    if (a.ring > 0) a.rec += (long)(a.step % a.ring) * a.n * (3 + a.ns + a.W);
+    if (blockIdx.x == 0 && threadIdx.x == 0 && a.step_out) a.step_out[0] = a.step + 1;
+  }
   // the winners by counting: a candidate's rank is the number of candidates that come before it (value descending, then
   // slot * V + token ascending - one unsigned compare on (value bits, ~index)); ranks below `beam` are the selection
   __shared__ __attribute__((aligned(16))) unsigned long long ckey[1024];
@@ -531,10 +554,20 @@ int eamd_beam_step(const float* pre, const int64_t* ids, const float* psi, const
                    int beam, int P, int V, int W, int L, int step, int eos, const int64_t* maxlen, int ns, int nf, const float* sc_in,
                    const float* const* logps, const int64_t* yseq_in, float* c_local, float* sc_out, int64_t* yseq_out, float* hyp_out,
                    int64_t* hyp_i, int64_t* tok_i, int32_t* tok32, float* cs_out, float* rec, void* stream) {
+  return eamd_beam_step_dyn(pre, ids, psi, c_s, hyp, w_ctc, nutt, beam, P, V, W, L, step, eos, maxlen, ns, nf, sc_in, logps, yseq_in, c_local,
+                            sc_out, yseq_out, hyp_out, hyp_i, tok_i, tok32, cs_out, rec, nullptr, nullptr, 0, stream);
+}
+
+int eamd_beam_step_dyn(const float* pre, const int64_t* ids, const float* psi, const float* c_s, const float* hyp, float w_ctc, int nutt,
+                       int beam, int P, int V, int W, int L, int step, int eos, const int64_t* maxlen, int ns, int nf, const float* sc_in,
+                       const float* const* logps, const int64_t* yseq_in, float* c_local, float* sc_out, int64_t* yseq_out, float* hyp_out,
+                       int64_t* hyp_i, int64_t* tok_i, int32_t* tok32, float* cs_out, float* rec, const int32_t* step_dev, int32_t* step_out,
+                       int ring, void* stream) {
   if (!pre || !ids || !psi || !c_s || !hyp || !maxlen || !sc_in || !yseq_in || !c_local || !sc_out || !yseq_out || !hyp_out || !hyp_i ||
       !tok_i || !tok32 || !cs_out || !rec)
     return EAMD_EINVAL;
-  if (nutt <= 0 || beam <= 0 || P <= 0 || V <= 0 || W <= 0 || L < 0 || L >= W || ns < 1 || nf < 0 || nf > 4 || ns != nf + 1) return EAMD_EINVAL;
+  if (step_dev) { L = 0; step = 0; }
+  if (nutt <= 0 || beam <= 0 || P <= 0 || V <= 0 || W < 2 || L < 0 || L >= W || ns < 1 || nf < 0 || nf > 4 || ns != nf + 1 || ring < 0) return EAMD_EINVAL;
   if ((nf > 0 && !logps) || (long)nutt * beam > 0x7fffffffL) return EAMD_EINVAL;
   if ((long)beam * P > 1023 || beam > 64 || (long)beam * V + 1024 > 0x7fffffffL) return EAMD_EUNSUPPORTED;
   BeamStepArgs a;
@@ -544,6 +577,7 @@ int eamd_beam_step(const float* pre, const int64_t* ids, const float* psi, const
   a.yseq_in = (const long long*)yseq_in; a.c_local = c_local; a.sc_out = sc_out; a.yseq_out = (long long*)yseq_out; a.hyp_out = hyp_out;
   a.hyp_i = (long long*)hyp_i; a.tok_i = (long long*)tok_i; a.tok32 = tok32; a.cs_out = cs_out; a.rec = rec; a.w_ctc = w_ctc;
   a.n = nutt * beam; a.beam = beam; a.P = P; a.V = V; a.W = W; a.L = L; a.step = step; a.eos = eos; a.ns = ns; a.nf = nf;
+  a.step_dev = step_dev; a.step_out = step_out; a.ring = ring;
   hipLaunchKernelGGL(beam_step_kernel, dim3(nutt), dim3(256), 0, (hipStream_t)stream, a);
   EAMD_LAUNCH_CHECK();
   return EAMD_OK;
@@ -733,6 +767,41 @@ __global__ __launch_bounds__(256) void decode_src_attn_group_kernel(const float*
   }
 }
 }  // namespace
+
+// Up to 16 small device-to-device copies in ONE launch (the state a replayed beam step hands to the next replay of the same graph:
+// prefixes, scores, slot table, CTC state - a memcpy node each would cost ~4 us apiece).  Sizes in bytes, multiples of 4.
+namespace {
+struct CopyJobs { const unsigned* src[16]; unsigned* dst[16]; unsigned words[16]; int n; };
+__global__ __launch_bounds__(256) void copy_jobs_kernel(const CopyJobs j) {
+  const int job = blockIdx.y;
+  if (job >= j.n) return;
+  const unsigned* s = j.src[job];
+  unsigned* d = j.dst[job];
+  for (unsigned i = blockIdx.x * 256 + threadIdx.x; i < j.words[job]; i += gridDim.x * 256) d[i] = s[i];
+}
+}  // namespace
+
+extern "C" int eamd_copy_jobs(const void* const* src, void* const* dst, const int64_t* nbytes, int njobs, void* stream) {
+  if (!src || !dst || !nbytes || njobs <= 0 || njobs > 16) return EAMD_EINVAL;
+  CopyJobs j;
+  unsigned most = 0;
+  for (int i = 0; i < 16; ++i) {
+    j.src[i] = i < njobs ? (const unsigned*)src[i] : nullptr;
+    j.dst[i] = i < njobs ? (unsigned*)dst[i] : nullptr;
+    j.words[i] = 0;
+    if (i < njobs) {
+      if (!src[i] || !dst[i] || nbytes[i] < 0 || nbytes[i] % 4 != 0 || nbytes[i] > (1LL << 33)) return EAMD_EINVAL;
+      if (((uintptr_t)src[i] | (uintptr_t)dst[i]) & 3) return EAMD_EUNSUPPORTED;
+      j.words[i] = (unsigned)(nbytes[i] / 4);
+      most = j.words[i] > most ? j.words[i] : most;
+    }
+  }
+  j.n = njobs;
+  const unsigned bx = most == 0 ? 1 : ((most + 255) / 256 < 64 ? (most + 255) / 256 : 64);
+  hipLaunchKernelGGL(copy_jobs_kernel, dim3(bx, njobs), dim3(256), 0, (hipStream_t)stream, j);
+  EAMD_LAUNCH_CHECK();
+  return EAMD_OK;
+}
 
 extern "C" int eamd_decode_src_attn_group(const float* q, int64_t ldq, const float* kmem, const float* vmem, int64_t ldkv,
                                           const uint8_t* mask, int nutt, int g, int T, int H, int D, float* ctx, void* stream) {

@@ -241,7 +241,8 @@ __global__ __launch_bounds__(256) void colsum_bf16x2_kernel(const unsigned int* 
 // reference: decoder.py:251 (embed = Embedding + PositionalEncoding), embedding.py:80-91.
 __global__ void embed_pe_kernel(const long long* __restrict__ tok, long ldt, const float* __restrict__ table,
                                 const float* __restrict__ pe, float* __restrict__ out, long rows, int U, int D,
-                                float scale, int pos_offset) {
+                                float scale, int pos_offset, const int* __restrict__ pos_dev) {
+  if (pos_dev) pos_offset += pos_dev[0];                 // (the step index of a replayed beam step lives on the device)
   const long n = rows * D;
   const long stride = (long)gridDim.x * blockDim.x;
   for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
@@ -690,9 +691,14 @@ int eamd_embed_pe(const int64_t* tok, const float* table, const float* pe, float
 
 int eamd_embed_pe_ld(const int64_t* tok, int64_t ldt, const float* table, const float* pe, float* out, int64_t rows, int U,
                      int D, float scale, int pos_offset, void* stream) {
+  return eamd_embed_pe_dyn(tok, ldt, table, pe, out, rows, U, D, scale, pos_offset, nullptr, stream);
+}
+
+int eamd_embed_pe_dyn(const int64_t* tok, int64_t ldt, const float* table, const float* pe, float* out, int64_t rows, int U,
+                      int D, float scale, int pos_offset, const int32_t* pos_dev, void* stream) {
   if (!tok || !table || !out || rows <= 0 || U <= 0 || D <= 0 || ldt < 1) return EAMD_EINVAL;
   hipLaunchKernelGGL(embed_pe_kernel, dim3(grid_for(rows * D)), dim3(256), 0, (hipStream_t)stream,
-                     (const long long*)tok, (long)ldt, table, pe, out, (long)rows, U, D, scale, pos_offset);
+                     (const long long*)tok, (long)ldt, table, pe, out, (long)rows, U, D, scale, pos_offset, pos_dev);
   EAMD_LAUNCH_CHECK();
   return EAMD_OK;
 }

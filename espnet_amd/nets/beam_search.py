@@ -51,6 +51,10 @@ def end_detect(ended_hyps, i, M=3, D_end=math.log(1 * math.exp(-10))):
     return count == M
 
 
+class _NoDynStep(Exception):
+    """a beam step that cannot read its step index from the device (BeamSearch._batch_step(dyn=...)): one graph per step stays"""
+
+
 class _OutsideCandidates(Exception):
     """raised by the host side of a "full"-mode search whose candidate selection kernel picked a log-zero continuation"""
 
@@ -481,15 +485,28 @@ class BeamSearch(torch.nn.Module):
             S["c_r"] = C_["c_r0"]
         return S
 
-    def _batch_step(self, i, C_, S):
-        """step i of a batched search: state S -> (next state, log row [n, 3 + scorers + W]); no host synchronisation"""
+    def _batch_step(self, i, C_, S, dyn=None):
+        """step i of a batched search: state S -> (next state, log row [n, 3 + scorers + W]); no host synchronisation.
+        dyn = dict(step=int32 device scalar, step_out=..., ring=[R, n, 3 + scorers + W]): the step index is READ FROM THE DEVICE by
+        the kernels (i is ignored), the log row goes into slot step % R of the ring - a capture of this call serves every step >= 1
+        (_forward_batch_graphed, graph_one).  Only the candidate-selection path with scorers that take tree["dyn"] runs that way:
+        anything else raises _NoDynStep and the caller keeps one graph per step."""
         from .. import ops
         B, V, beam, n, dev = C_["B"], C_["V"], C_["beam"], C_["n"], C_["dev"]
         names, pname, ctc, allk = C_["names"], C_["pname"], C_["ctc"], C_["allk"]
         NEG = -float("inf")
         L = i + 1
         yseq, hyp, trees = S["yseq"], S["hyp"], dict(S["trees"])
-        ys = yseq[:, :L]
+        ys = yseq[:, :L] if dyn is None else yseq
+        sdev = dyn["step"] if dyn is not None else None
+        if dyn is not None:
+            if ctc is None or "c_r" not in S or "last32" not in S or "tok" not in S:
+                raise _NoDynStep("state")
+            for k in names:        # the scorers read the newest tokens and the position from device memory
+                if isinstance(trees[k], dict):
+                    trees[k] = dict(trees[k], dyn=(sdev, S["tok"]))
+                elif not getattr(self.full_scorers[k], "stateless_tree", False):
+                    raise _NoDynStep("scorer " + k)
         # CTC forward variables of the running hypotheses: ready (first step / the full-recursion path), or still to be made from the
         # previous step's selection - then on a second stream BESIDE the decoder stack below (eamd_ctc_prefix_state: ~160 us of
         # frame-by-frame recursion that nothing in this step needs before the candidates are scored)
@@ -539,8 +556,10 @@ class BeamSearch(torch.nn.Module):
             if side is not None:
                 torch.cuda.current_stream(dev).wait_stream(side)
                 side = None
-            psi = ops.ctc_prefix_psi(C_["logp"], C_["lens_d"], beam, c_r_now, cand32, last, L - 1, ctc.blank, ctc.eos) \
-                if self.ctc_psi_parallel else None
+            psi = ops.ctc_prefix_psi(C_["logp"], C_["lens_d"], beam, c_r_now, cand32, last, L - 1 if dyn is None else 0, ctc.blank, ctc.eos,
+                                     olen_dev=sdev) if self.ctc_psi_parallel else None
+            if dyn is not None and psi is None:
+                raise _NoDynStep("CTC candidates")
             r_new = None
             if psi is None:       # more than 2048 frames: the full recursion for every candidate
                 olen = torch.full((n,), L - 1, dtype=torch.int32, device=dev)
@@ -548,7 +567,10 @@ class BeamSearch(torch.nn.Module):
             if self.step_kernel and beam <= 64 and beam * P <= 1023 and beam * V < 2 ** 31 and r_new is None:
                 sc_new, yseq, hyp_new, hyp_i, tok_i, tok32, cs_new, rec = ops.beam_step(
                     pre, part_ids, psi, S["c_s"], hyp, self.weights[pname], B, beam, L, i, self.eos, C_["maxlen_d"].view(-1),
-                    S["sc"], [logps[k] for k in names], yseq)
+                    S["sc"], [logps[k] for k in names], yseq,
+                    dyn=(sdev, dyn["step_out"], dyn["ring"]) if dyn is not None else None)
+            elif dyn is not None:
+                raise _NoDynStep("selection kernel")
             else:
                 top_s, top_i, c_loc = ops.beam_select(pre, part_ids, psi, S["c_s"], hyp, self.weights[pname], B, beam)
                 sc_new, yseq, hyp_new, hyp_i, tok_i, pos, rec = ops.beam_finish(
@@ -557,12 +579,18 @@ class BeamSearch(torch.nn.Module):
                 cs_new, tok32 = psi[hyp_i, pos], tok_i.to(torch.int32)
             for k in names:
                 trees[k] = self._reorder(self.full_scorers[k], newtrees[k], hyp_i)
-            T_ = dict(sc=sc_new, trees=trees, yseq=yseq, hyp=hyp_new, c_s=cs_new, last32=tok32)
+            T_ = dict(sc=sc_new, trees=trees, yseq=yseq, hyp=hyp_new, c_s=cs_new, last32=tok32, tok=tok_i)
             if r_new is not None:
                 T_["c_r"] = r_new[hyp_i, pos]
-            else:     # the survivors' forward variables are made at the start of the next step (see the top of this function)
+            elif dyn is not None or self.ctc_side_stream is False or (self.ctc_side_stream == "capture" and C_["Tpad"] <= 2048):
+                # the survivors' forward variables right away (a parallel scan of a few us up to 2048 frames)
+                T_["c_r"] = ops.ctc_prefix_state(C_["logp"], C_["lens_d"], beam, c_r_now, hyp_i, tok_i, last, L - 1 if dyn is None else 0,
+                                                 hyp_new, ctc.blank, olen_dev=sdev)
+            else:     # ... or at the start of the next step, on a second stream beside its decoder stack (see the top of this function)
                 T_["c_pend"] = (c_r_now, hyp_i, tok_i, last, L - 1, hyp_new)
             return T_, rec
+        if dyn is not None:
+            raise _NoDynStep("tensor-expression path")
         if side is not None:
             torch.cuda.current_stream(dev).wait_stream(side)
         weighted = torch.zeros(n, V, device=dev, dtype=torch.float32)
@@ -630,11 +658,12 @@ class BeamSearch(torch.nn.Module):
     # Anything that cannot be captured (a scorer that synchronises or copies from the host inside score_tree) ends graph mode for
     # this object - the search then runs eagerly as before.
     graph_steps = os.environ.get("EAMD_BEAM_GRAPH_STEPS", "0") == "1"      # opt-in (attribute or environment): 33 -> 46 utt/s at config 2
+    graph_one = True                  # steps >= 1 of a search replay ONE graph that reads the step index from the device (else one per step)
     graph_frame_bucket = 32
     graph_max_signatures = 8          # least recently used signatures (their graphs and static buffers) are dropped beyond this
 
     def _forward_batch_graphed(self, xs, maxlenratio):
-        from .. import graphs
+        from .. import graphs, ops
         B, beam = len(xs), self.beam_size
         Ts = [int(x.shape[0]) for x in xs]
         maxlens = [T if maxlenratio == 0 else max(1, int(maxlenratio * T)) for T in Ts]
@@ -690,6 +719,18 @@ class BeamSearch(torch.nn.Module):
                         if run.add(rec, last=(i == max(maxlens) - 1)):
                             break
                         continue
+                    if i >= 1 and self.graph_one and G.get("dyn") is not False:
+                        # every step >= 1: ONE graph (the step index lives on the device); its state is loaded from step 0's outputs
+                        if G.get("dyn") is None:
+                            G["dyn"] = self._dyn_capture(C_, G)
+                        D = G["dyn"]
+                        if D:
+                            if i == 1:
+                                ops.copy_jobs(D["load"])
+                            D["graph"].replay()
+                            if run.add(D["ring"][i % D["ring"].shape[0]], last=(i == max(maxlens) - 1)):
+                                break
+                            continue
                     g = G["graphs"].get(i)
                     if g is None:
                         if G["memos"] is not None:            # per-search tensors of the scorers live in the buffers of graph 0
@@ -714,6 +755,44 @@ class BeamSearch(torch.nn.Module):
                 self.graph_steps = False
                 self._step_graphs = {}
                 return None
+
+    def _dyn_capture(self, C_, G):
+        """the one graph of steps >= 1 (graph_one): static state buffers, a capture of _batch_step(dyn=...) followed by ONE launch that
+        copies the step's outputs back over the state (eamd_copy_jobs), and the load list that fills the state from step 0's outputs.
+        -> dict, or False when a step cannot read its index from the device (then: one graph per step, as before)"""
+        from .. import graphs, ops
+        S1 = G["states"].get(1)
+        need = ("yseq", "hyp", "sc", "c_s", "last32", "tok", "c_r")
+        if S1 is None or any(k not in S1 for k in need) or self.sync_every < 1:
+            return False
+        dev, n = C_["dev"], C_["n"]
+        S = {k: torch.empty_like(S1[k].contiguous()) for k in need}
+        S["trees"] = {k: (dict(t, slot=torch.empty_like(t["slot"])) if isinstance(t, dict) else t) for k, t in S1["trees"].items()}
+        if any(isinstance(t, dict) and "slot" not in t for t in S1["trees"].values()):
+            return False
+        step = torch.zeros(1, dtype=torch.int32, device=dev)
+        step_out = torch.zeros(1, dtype=torch.int32, device=dev)
+        one = torch.ones(1, dtype=torch.int32, device=dev)
+        ring = torch.zeros(self.sync_every, n, 3 + len(C_["allk"]) + C_["W"], device=dev, dtype=torch.float32)
+        slots = [k for k, t in S["trees"].items() if isinstance(t, dict)]
+        load = [(S[k], S1[k].contiguous()) for k in need] + [(S["trees"][k]["slot"], S1["trees"][k]["slot"]) for k in slots] + [(step, one)]
+        if len(load) > 16 or any(not S1[k].is_contiguous() for k in need):
+            return False
+        ops.copy_jobs(load)
+        torch.cuda.synchronize()
+        g = graphs.new_graph()
+        try:
+            with torch.cuda.graph(g):
+                T_, _rec = self._batch_step(1, C_, S, dyn=dict(step=step, step_out=step_out, ring=ring))
+                ops.copy_jobs([(S[k], T_[k]) for k in need] + [(S["trees"][k]["slot"], T_["trees"][k]["slot"]) for k in slots]
+                              + [(step, step_out)])
+        except _NoDynStep as e:
+            import logging
+            logging.getLogger(__name__).info("beam search: one graph per step (%s)", e)
+            torch.cuda.synchronize()
+            return False
+        graphs.audit(g, "beam step graph (all steps)")
+        return dict(graph=g, S=S, ring=ring, load=load, step=step, keep=(step_out, one))
 
     @_inference_call
     def forward(self, x, maxlenratio=0.0, minlenratio=0.0):

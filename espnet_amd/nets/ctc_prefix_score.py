@@ -98,6 +98,8 @@ class CTCPrefixScorer(BatchPartialScorerInterface):
 class LengthBonus(BatchScorerInterface):
     """reference: espnet/nets/scorers/length_bonus.py:11-61 (+1 per emitted token)"""
 
+    stateless_tree = True          # score_tree needs neither the step index nor a state (BeamSearch's one-graph steps)
+
     def __init__(self, n_vocab):
         self.n = n_vocab
 

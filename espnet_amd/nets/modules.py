@@ -1106,11 +1106,19 @@ class Decoder(torch.nn.Module, BatchScorerInterface):
         D = self.embed[0].weight.shape[1]
         G = xs.shape[0]
         H = self.decoders[0].self_attn.h
+        # tree["dyn"] = (step on the device, newest tokens [n]): ONE captured graph serves every step - the position is read from
+        # device memory by the kernels (pos below becomes the offset 0), the caches were made for the whole prefix buffer
+        dyn = tree.get("dyn") if isinstance(tree, dict) else None
+        pos_dev = None
+        if dyn is not None:
+            pos_dev, newest = dyn
+            pos = 0
         if tree is None:
             Lcap = max(int(ys.stride(0)), 8) if (ys.dim() == 2 and ys.stride(1) == 1 and ys.stride(0) >= L) else 64
             tree = dict(K=[torch.empty(Lcap, n, D, device=xs.device) for _ in self.decoders],
                         V=[torch.empty(Lcap, n, D, device=xs.device) for _ in self.decoders],
                         slot=torch.zeros(n, Lcap, dtype=torch.int32, device=xs.device), Lcap=Lcap)
+            self.embed[1].extend_pe(Lcap + 1, xs.device)
         elif pos >= tree["Lcap"]:          # a prefix longer than the caches were made for: double them
             Lcap = 2 * tree["Lcap"]
             grow = lambda t: torch.cat([t, torch.empty_like(t)], 0)  # noqa: E731
@@ -1120,10 +1128,14 @@ class Decoder(torch.nn.Module, BatchScorerInterface):
         sp = self._memory_kv(xs)
         T = xs.shape[1]
         mask = _mask_u8(memory_mask, xs.device)
-        x = self._embed(ys[:, -1:], pos_offset=pos).reshape(n, D)
+        if dyn is not None:
+            pe = self.embed[1]
+            x = ops.embed_pe(newest, self.embed[0].weight, pe.pe, 1, pe.xscale, 0, pos_dev=pos_dev)
+        else:
+            x = self._embed(ys[:, -1:], pos_offset=pos).reshape(n, D)
         for i, m in enumerate(self.decoders):
             qkv = self._ln_rows(x, m.norm1, w3[i][0], w3[i][1])
-            ctx = ops.decode_self_attn(qkv, tree["K"][i], tree["V"][i], tree["slot"], pos, H)
+            ctx = ops.decode_self_attn(qkv, tree["K"][i], tree["V"][i], tree["slot"], pos, H, pos_dev=pos_dev)
             x = ops.linear_fwd(ctx, m.self_attn.linear_out.weight, m.self_attn.linear_out.bias, R=x)
             a = m.src_attn
             q2 = self._ln_rows(x, m.norm2, a.linear_q.weight, a.linear_q.bias)
@@ -1150,6 +1162,8 @@ class Decoder(torch.nn.Module, BatchScorerInterface):
         y = self._ln_rows(x, self.after_norm, self.output_layer.weight, self.output_layer.bias)
         new = dict(tree)
         new["pos"] = pos
+        new["pos_dev"] = pos_dev
+        new.pop("dyn", None)
         return ops.log_softmax_rows(y.contiguous()), new
 
     @staticmethod
@@ -1159,7 +1173,7 @@ class Decoder(torch.nn.Module, BatchScorerInterface):
         if not isinstance(tree, dict):
             return None if tree is None else [t.index_select(0, hyp_i) for t in tree]
         new = dict(tree)
-        new["slot"] = ops.beam_slots(tree["slot"], hyp_i, tree["pos"])
+        new["slot"] = ops.beam_slots(tree["slot"], hyp_i, tree["pos"], pos_dev=tree.get("pos_dev"))
         return new
 
     def score_tree(self, ys, tree, xs, memory_mask=None):

@@ -1271,15 +1271,15 @@ def linear_rows_ln(x, gamma, beta, eps, W, b, *, act=EPI_NONE, R=None, alpha=1.0
     return y
 
 
-def decode_self_attn(qkv, Kc, Vc, slot_at, pos, H):
+def decode_self_attn(qkv, Kc, Vc, slot_at, pos, H, pos_dev=None):
     """the newest position of n hypotheses attends over its prefix; keys / values of this step (columns D.., 2D.. of qkv) are
     appended to the time-major caches Kc / Vc [Lcap, n, D] at row `pos`; slot_at [n, Lcap] int32 (eamd_decode_self_attn) -> ctx [n, D]"""
     n = qkv.shape[0]
     Lcap, n2, D = Kc.shape
     assert n2 == n and Vc.shape == Kc.shape and slot_at.shape == (n, Lcap) and slot_at.dtype == torch.int32 and qkv.stride(1) == 1
     ctx = torch.empty(n, D, device=qkv.device, dtype=torch.float32)
-    check(_lib.lib().eamd_decode_self_attn(ptr(qkv), C.c_int64(qkv.stride(0)), ptr(Kc), ptr(Vc), ptr(slot_at), Lcap, int(pos), n, H, D,
-                                           ptr(ctx), stream_ptr()), "eamd_decode_self_attn")
+    check(_lib.lib().eamd_decode_self_attn_dyn(ptr(qkv), C.c_int64(qkv.stride(0)), ptr(Kc), ptr(Vc), ptr(slot_at), Lcap, int(pos),
+                                               ptr(pos_dev), n, H, D, ptr(ctx), stream_ptr()), "eamd_decode_self_attn")
     return ctx
 
 
@@ -1299,12 +1299,25 @@ def decode_src_attn(q, kv, k_off, v_off, ldkv, mask, G, g, T, H, group=False):
     return ctx
 
 
-def beam_slots(slot_in, hyp, pos):
-    """the slot table behind a beam step's selection: row i = row hyp[i] of slot_in with column `pos` set to hyp[i]"""
+def beam_slots(slot_in, hyp, pos, pos_dev=None):
+    """the slot table behind a beam step's selection: row i = row hyp[i] of slot_in with column `pos` set to hyp[i]
+    (pos_dev: int32 device scalar added to pos)"""
     n, Lcap = slot_in.shape
     out = torch.empty_like(slot_in)
-    check(_lib.lib().eamd_beam_slots(ptr(slot_in), ptr(out), ptr(hyp), n, Lcap, int(pos), stream_ptr()), "eamd_beam_slots")
+    check(_lib.lib().eamd_beam_slots_dyn(ptr(slot_in), ptr(out), ptr(hyp), n, Lcap, int(pos), ptr(pos_dev), stream_ptr()), "eamd_beam_slots")
     return out
+
+
+def copy_jobs(pairs):
+    """up to 16 small device-to-device copies (dst <- src, contiguous tensors of equal byte size) in one launch (eamd_copy_jobs)"""
+    assert 0 < len(pairs) <= 16
+    for d, s_ in pairs:
+        assert d.is_contiguous() and s_.is_contiguous() and d.numel() * d.element_size() == s_.numel() * s_.element_size(), (d.shape, s_.shape)
+    n = len(pairs)
+    src = (C.c_void_p * n)(*[s_.data_ptr() for _, s_ in pairs])
+    dst = (C.c_void_p * n)(*[d.data_ptr() for d, _ in pairs])
+    nb = (C.c_int64 * n)(*[d.numel() * d.element_size() for d, _ in pairs])
+    check(_lib.lib().eamd_copy_jobs(src, dst, nb, n, stream_ptr()), "eamd_copy_jobs")
 
 
 def weighted_sum(logps, weights):
@@ -1363,7 +1376,7 @@ def topk_rows(x, k, idx32=False):
     return (vals, idx, i32) if idx32 else (vals, idx)
 
 
-def beam_step(pre, ids, psi, c_s, hyp, w_ctc, nutt, beam, L, step, eos, maxlen, sc_in, logps, yseq_in):
+def beam_step(pre, ids, psi, c_s, hyp, w_ctc, nutt, beam, L, step, eos, maxlen, sc_in, logps, yseq_in, dyn=None):
     """selection and bookkeeping of a BeamSearch step with a pre-beam in one launch (eamd_beam_step = eamd_beam_select +
     eamd_beam_finish) -> (sc_out [ns, n], yseq_out, hyp_out, hyp_i, tok_i, tok32, cs_out, rec)"""
     n, V = pre.shape
@@ -1385,11 +1398,21 @@ def beam_step(pre, ids, psi, c_s, hyp, w_ctc, nutt, beam, L, step, eos, maxlen, 
     hyp_out, cs_out = (torch.empty(n, device=dev, dtype=torch.float32) for _ in range(2))
     hyp_i, tok_i = (torch.empty(n, device=dev, dtype=torch.int64) for _ in range(2))
     tok32 = torch.empty(n, device=dev, dtype=torch.int32)
-    rec = torch.empty(n, 3 + ns + W, device=dev, dtype=torch.float32)
+    # dyn = (step_dev, step_out, ring): the step index read from the device, step + 1 written to step_out, the log row into slot
+    # step % R of the ring [R, n, 3 + ns + W] (one graph for every step)
+    step_dev = step_out = None
+    ring = 0
+    if dyn is not None:
+        step_dev, step_out, rec = dyn
+        ring = rec.shape[0]
+        assert rec.shape[1:] == (n, 3 + ns + W) and rec.is_contiguous() and step_dev.dtype == torch.int32 and step_out.dtype == torch.int32
+    else:
+        rec = torch.empty(n, 3 + ns + W, device=dev, dtype=torch.float32)
     arr = (C.c_void_p * 4)(*[lp.data_ptr() for lp in logps] + [None] * (4 - nf))
-    check(_lib.lib().eamd_beam_step(ptr(pre), ptr(ids), ptr(psi), ptr(c_s), ptr(hyp), C.c_float(w_ctc), nutt, beam, P, V, W, L, step, eos,
-                                    ptr(maxlen), ns, nf, ptr(sc_in), arr, ptr(yseq_in), ptr(c_local), ptr(sc_out), ptr(yseq_out),
-                                    ptr(hyp_out), ptr(hyp_i), ptr(tok_i), ptr(tok32), ptr(cs_out), ptr(rec), stream_ptr()), "eamd_beam_step")
+    check(_lib.lib().eamd_beam_step_dyn(ptr(pre), ptr(ids), ptr(psi), ptr(c_s), ptr(hyp), C.c_float(w_ctc), nutt, beam, P, V, W, L, step, eos,
+                                        ptr(maxlen), ns, nf, ptr(sc_in), arr, ptr(yseq_in), ptr(c_local), ptr(sc_out), ptr(yseq_out),
+                                        ptr(hyp_out), ptr(hyp_i), ptr(tok_i), ptr(tok32), ptr(cs_out), ptr(rec), ptr(step_dev),
+                                        ptr(step_out), ring, stream_ptr()), "eamd_beam_step")
     return sc_out, yseq_out, hyp_out, hyp_i, tok_i, tok32, cs_out, rec
 
 
@@ -1514,7 +1537,7 @@ def add_cast_colsum2(a, b, suma, sumb, out=None, out_off=0, ld_out=None):
     return out
 
 
-def embed_pe(tok, table, pe, U, scale, pos_offset=0):
+def embed_pe(tok, table, pe, U, scale, pos_offset=0, pos_dev=None):
     """out[r] = table[tok[r]] * scale + pe[r % U + pos_offset]   (pe None: plain embedding lookup).  tok contiguous, or one
     column of a wider buffer ([n, 1] with a row stride: the newest tokens of a beam step's prefixes)"""
     rows = tok.numel()
@@ -1526,8 +1549,9 @@ def embed_pe(tok, table, pe, U, scale, pos_offset=0):
         ldt = tok.stride(0)
     assert pe is None or (pe.shape[0] >= U + pos_offset and pe.shape[1] == D)
     out = torch.empty(rows, D, device=table.device, dtype=torch.float32)
-    check(_lib.lib().eamd_embed_pe_ld(ptr(tok), C.c_int64(ldt), ptr(table), ptr(pe), ptr(out), C.c_int64(rows), U, D,
-                                      C.c_float(scale), pos_offset, stream_ptr()), "eamd_embed_pe")
+    # pos_dev: int32 device scalar added to pos_offset (the step index of a replayed beam step)
+    check(_lib.lib().eamd_embed_pe_dyn(ptr(tok), C.c_int64(ldt), ptr(table), ptr(pe), ptr(out), C.c_int64(rows), U, D,
+                                       C.c_float(scale), pos_offset, ptr(pos_dev), stream_ptr()), "eamd_embed_pe")
     return out
 
 
@@ -1810,30 +1834,31 @@ def ctc_prefix_score_batch(logp, lens, per_utt, r_prev, cand, last, olen, blank,
     return psi, r_new
 
 
-def ctc_prefix_psi(logp, lens, per_utt, r_prev, cand, last, olen, blank, eos):
+def ctc_prefix_psi(logp, lens, per_utt, r_prev, cand, last, olen, blank, eos, olen_dev=None):
     """log psi of the candidates as a parallel reduction over the frames (eamd_ctc_prefix_psi): logp [U, Tmax, V], r_prev
     [U * per_utt, Tmax, 2], cand [n, P] int32, last [n] int32, olen int -> psi [n, P]; None when the library declines (Tmax > 2048)"""
     U, Tmax, V = logp.shape
     nhyp, ncand = cand.shape
     assert nhyp == U * per_utt and r_prev.shape == (nhyp, Tmax, 2) and cand.dtype == torch.int32 and logp.is_contiguous()
     psi = torch.empty(nhyp, ncand, device=logp.device, dtype=torch.float32)
-    rc = _lib.lib().eamd_ctc_prefix_psi(ptr(logp), ptr(lens), U, per_utt, ptr(r_prev.contiguous()), ptr(cand.contiguous()), ptr(last),
-                                        int(olen), ptr(psi), ncand, Tmax, V, blank, eos, stream_ptr())
+    # olen_dev: int32 device scalar added to olen (the step index of a replayed beam step)
+    rc = _lib.lib().eamd_ctc_prefix_psi_dyn(ptr(logp), ptr(lens), U, per_utt, ptr(r_prev.contiguous()), ptr(cand.contiguous()), ptr(last),
+                                            int(olen), ptr(olen_dev), ptr(psi), ncand, Tmax, V, blank, eos, stream_ptr())
     if rc == _lib.EAMD_EUNSUPPORTED:
         return None
     check(rc, "eamd_ctc_prefix_psi")
     return psi
 
 
-def ctc_prefix_state(logp, lens, per_utt, r_prev, parent, tok, last, olen, alive, blank, out=None):
+def ctc_prefix_state(logp, lens, per_utt, r_prev, parent, tok, last, olen, alive, blank, out=None, olen_dev=None):
     """forward variables of the continuations that survived a selection (eamd_ctc_prefix_state): slot s continues hypothesis
     parent[s] (whose state is r_prev[parent[s]], last token last[parent[s]], prefix length olen + 1) with token tok[s];
     alive [n] = the slots' running scores (-inf: ended / empty) -> r [n, Tmax, 2]"""
     U, Tmax, V = logp.shape
     n = parent.numel()
     r = out if out is not None else torch.empty(n, Tmax, 2, device=logp.device, dtype=torch.float32)
-    check(_lib.lib().eamd_ctc_prefix_state(ptr(logp), ptr(lens), U, per_utt, ptr(r_prev), ptr(parent), ptr(tok), ptr(last), int(olen),
-                                           ptr(alive), ptr(r), Tmax, V, blank, stream_ptr()), "eamd_ctc_prefix_state")
+    check(_lib.lib().eamd_ctc_prefix_state_dyn(ptr(logp), ptr(lens), U, per_utt, ptr(r_prev), ptr(parent), ptr(tok), ptr(last), int(olen),
+                                               ptr(olen_dev), ptr(alive), ptr(r), Tmax, V, blank, stream_ptr()), "eamd_ctc_prefix_state")
     return r
 
 

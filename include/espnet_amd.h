@@ -445,6 +445,29 @@ int eamd_beam_select(const float* pre, const int64_t* ids, const float* psi, con
 int eamd_topk_rows(const float* x, int64_t ld, int rows, int n, int k, float* vals, int64_t* idx, void* stream);
 /* ... the indices also as int32 (idx32 [rows, k], may be NULL): the candidate list eamd_ctc_prefix_psi takes. */
 int eamd_topk_rows_i32(const float* x, int64_t ld, int rows, int n, int k, float* vals, int64_t* idx, int32_t* idx32, void* stream);
+/* One hipGraph for EVERY beam step (reference: the step index `i` of beam_search.py:349-364's loop, here a device integer): the
+ * variants below read the step-dependent integer from device memory - value = *dev + the host argument, which becomes an offset -
+ * so a captured step does not bake it in.  eamd_beam_step_dyn reads step (L = step + 1) from step_dev, writes the log row into
+ * slot step % ring of a [ring][n][3 + ns + W] ring (ring 0: as before) and leaves step + 1 in step_out.  eamd_copy_jobs: up to 16
+ * small device-to-device copies (sizes in bytes, multiples of 4) in one launch - the state a step hands to the next replay. */
+int eamd_decode_self_attn_dyn(const float* qkv, int64_t ldq, float* kcache, float* vcache, const int32_t* slot_at, int Lcap, int pos,
+                              const int32_t* pos_dev, int n, int H, int D, float* ctx, void* stream);
+int eamd_beam_slots_dyn(const int32_t* slot_in, int32_t* slot_out, const int64_t* hyp, int n, int Lcap, int pos, const int32_t* pos_dev,
+                        void* stream);
+int eamd_beam_step_dyn(const float* pre, const int64_t* ids, const float* psi, const float* c_s, const float* hyp, float w_ctc, int nutt,
+                       int beam, int P, int V, int W, int L, int step, int eos, const int64_t* maxlen, int ns, int nf, const float* sc_in,
+                       const float* const* logps, const int64_t* yseq_in, float* c_local, float* sc_out, int64_t* yseq_out, float* hyp_out,
+                       int64_t* hyp_i, int64_t* tok_i, int32_t* tok32, float* cs_out, float* rec, const int32_t* step_dev, int32_t* step_out,
+                       int ring, void* stream);
+int eamd_ctc_prefix_psi_dyn(const float* logp, const int32_t* lens, int nutt, int per_utt, const float* r_prev, const int32_t* cand,
+                            const int32_t* last, int olen, const int32_t* olen_dev, float* psi, int ncand, int Tmax, int V, int blank,
+                            int eos, void* stream);
+int eamd_ctc_prefix_state_dyn(const float* logp, const int32_t* lens, int nutt, int per_utt, const float* r_prev, const int64_t* parent,
+                              const int64_t* tok, const int32_t* last, int olen, const int32_t* olen_dev, const float* alive, float* r_out,
+                              int Tmax, int V, int blank, void* stream);
+int eamd_embed_pe_dyn(const int64_t* tok, int64_t ldt, const float* table, const float* pe, float* out, int64_t rows, int U, int D,
+                      float scale, int pos_offset, const int32_t* pos_dev, void* stream);
+int eamd_copy_jobs(const void* const* src, void* const* dst, const int64_t* nbytes, int njobs, void* stream);
 /* eamd_weighted_sum + eamd_topk_rows_i32 in one launch: pre [rows, n] = sum_j weights[j] * logps[j] (written out; HOST arrays of
  * nf <= 4 device pointers / floats, the same separately rounded arithmetic), and the k largest of each of its rows.
  * extra >= 0: vals / idx / idx32 are [rows, k + 1], the last column = the token `extra`, or -1 where it is already among the k

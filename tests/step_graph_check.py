@@ -35,7 +35,15 @@ def c2width():
                 for u in range(len(encs)):
                     c2width_compare("graph_steps[%d] %s.forward_batch" % (rnd, cls.__name__), together[u], g, tags[u])
             assert bs.graph_steps, "a step could not be captured: the searches above ran eagerly"
-            n_graphs += sum(len(G["graphs"]) for G in bs._step_graphs.values())
+            n_graphs += sum(len(G["graphs"]) + (1 if G.get("dyn") else 0) for G in bs._step_graphs.values())
+            # with the candidate-selection kernels (pre-beam, CTC weight 0.3) every step >= 1 replays ONE graph that reads the step index
+            # from the device; the tensor-expression path (CTC only, no pre-beam) keeps one graph per step
+            one = [bool(G.get("dyn")) for G in bs._step_graphs.values() if G["searches"] >= 2 and len(G["graphs"]) > 0]
+            if cw == 0.3 and ratio > 0:
+                assert one and all(one), one
+                assert all(len(G["graphs"]) == 1 for G in bs._step_graphs.values() if G.get("dyn"))
+            elif cw == 1.0:
+                assert not any(one), one
             bs._step_graphs = {}
     assert n_graphs > 0
     print("[parity] step graphs c2width: %d captured steps" % n_graphs)
