@@ -141,11 +141,24 @@ def decode_leg(dev, c2_args, n_beam_utts=2, beam=10, ctc_weight=0.3, maxlenratio
                        ms_per_beam_step=round(tb / bsteps * 1e3, 3), hypotheses_found=[len(u) for u in nb][:4],
                        note="BeamSearch.forward_batch: one device-resident search over all utterances")
         graph = _graph_leg(tag, n_beam_utts, beam, ctc_weight, maxlenratio)
+        eager = dict(utt_per_s=round(n_beam_utts / tot, 2), rtf=float("%.3e" % (tot / a_s)), beam_steps=steps,
+                     ms_per_beam_step=round(tot / steps * 1e3, 3))
         out[tag] = dict(beam=beam, ctc_weight=ctc_weight, maxlenratio=maxlenratio, utterances_timed=n_beam_utts, graph_steps=graph,
-                        utt_per_s=round(n_beam_utts / tot, 2), rtf=float("%.3e" % (tot / a_s)), beam_steps=steps,
-                        ms_per_beam_step=round(tot / steps * 1e3, 3), per_beam_step=counts, batched=batched,
+                        per_beam_step=counts, batched=batched, eager=eager,
                         note="encoder outputs precomputed (the greedy leg times the encoder); hypotheses, scores and scorer "
                              "states on the device, one device->host copy of the step log per sync_every steps")
+        # the figures of the search as a corpus would be decoded - steps replayed as hipGraphs (graph_steps: two warm searches per
+        # (utterances, beam, padded frames) signature, then replays; measured in the child process above) - where that leg ran;
+        # the eager search (one utterance after another, every launch issued by the host) beside it under `eager`
+        if isinstance(graph, dict) and graph.get("active") and "utt_per_s" in graph:
+            out[tag].update(mode="graph_steps", utt_per_s=graph["utt_per_s"], ms_per_beam_step=graph["ms_per_beam_step"],
+                            beam_steps=steps)
+            if isinstance(graph.get("batched"), dict) and "utt_per_s" in graph["batched"]:
+                out[tag]["batched"] = dict(batched, mode="graph_steps", utt_per_s=graph["batched"]["utt_per_s"],
+                                           ms_per_beam_step=graph["batched"]["ms_per_beam_step"],
+                                           eager=dict(utt_per_s=batched["utt_per_s"], ms_per_beam_step=batched["ms_per_beam_step"]))
+        else:
+            out[tag].update(mode="eager", **eager)
 
     # ---- CPU oracle beside it: greedy CTC of a bounded sample, ids compared ----
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
