@@ -441,6 +441,9 @@ struct BeamStepArgs {
   // one graph for every step: the step index read from the device (L = step + 1), the log row written into a ring of `ring` rows
   // ([ring][n][3 + ns + W]: slot step % ring), step + 1 left in step_out for the next replay
   const int* step_dev; int* step_out; int ring;
+  // the cached decoder's slot table behind the selection (beam_slots_kernel's work, for the one scorer that keeps such a table):
+  // slot_out[s][t] = slot_in[hypothesis of s][t] for t < step, the hypothesis's slot itself at t = step
+  const int* slot_in; int* slot_out; int Lcap;
 };
 __device__ __forceinline__ unsigned sel_bits(float v) {      // order-preserving bits (NaN was made -inf; -0 ranks as +0)
   if (v == 0.f) v = 0.f;
@@ -544,6 +547,15 @@ __global__ __launch_bounds__(256) void beam_step_kernel(const BeamStepArgs a) {
     a.yseq_out[s * a.W + wq] = tk;
     rec_[s * RW + 3 + a.ns + wq] = (float)tk;
   }
+  if (a.slot_in) {
+    const int pos = min(step_, a.Lcap - 1);
+    for (int idx = t; idx < beam * (pos + 1); idx += 256) {
+      const int sl = idx / (pos + 1), tt = idx - sl * (pos + 1);
+      const long s = (long)u * beam + sl;
+      const long h = min(max(slot_h[sl], 0L), (long)a.n - 1);
+      a.slot_out[s * a.Lcap + tt] = tt < pos ? a.slot_in[h * a.Lcap + tt] : (int)h;
+    }
+  }
 }
 }  // namespace
 
@@ -554,14 +566,14 @@ int eamd_beam_step(const float* pre, const int64_t* ids, const float* psi, const
                    const float* const* logps, const int64_t* yseq_in, float* c_local, float* sc_out, int64_t* yseq_out, float* hyp_out,
                    int64_t* hyp_i, int64_t* tok_i, int32_t* tok32, float* cs_out, float* rec, void* stream) {
   return eamd_beam_step_dyn(pre, ids, psi, c_s, hyp, w_ctc, nutt, beam, P, V, W, L, step, eos, maxlen, ns, nf, sc_in, logps, yseq_in, c_local,
-                            sc_out, yseq_out, hyp_out, hyp_i, tok_i, tok32, cs_out, rec, nullptr, nullptr, 0, stream);
+                            sc_out, yseq_out, hyp_out, hyp_i, tok_i, tok32, cs_out, rec, nullptr, nullptr, 0, nullptr, nullptr, 0, stream);
 }
 
 int eamd_beam_step_dyn(const float* pre, const int64_t* ids, const float* psi, const float* c_s, const float* hyp, float w_ctc, int nutt,
                        int beam, int P, int V, int W, int L, int step, int eos, const int64_t* maxlen, int ns, int nf, const float* sc_in,
                        const float* const* logps, const int64_t* yseq_in, float* c_local, float* sc_out, int64_t* yseq_out, float* hyp_out,
                        int64_t* hyp_i, int64_t* tok_i, int32_t* tok32, float* cs_out, float* rec, const int32_t* step_dev, int32_t* step_out,
-                       int ring, void* stream) {
+                       int ring, const int32_t* slot_in, int32_t* slot_out, int Lcap, void* stream) {
   if (!pre || !ids || !psi || !c_s || !hyp || !maxlen || !sc_in || !yseq_in || !c_local || !sc_out || !yseq_out || !hyp_out || !hyp_i ||
       !tok_i || !tok32 || !cs_out || !rec)
     return EAMD_EINVAL;
@@ -577,6 +589,8 @@ int eamd_beam_step_dyn(const float* pre, const int64_t* ids, const float* psi, c
   a.hyp_i = (long long*)hyp_i; a.tok_i = (long long*)tok_i; a.tok32 = tok32; a.cs_out = cs_out; a.rec = rec; a.w_ctc = w_ctc;
   a.n = nutt * beam; a.beam = beam; a.P = P; a.V = V; a.W = W; a.L = L; a.step = step; a.eos = eos; a.ns = ns; a.nf = nf;
   a.step_dev = step_dev; a.step_out = step_out; a.ring = ring;
+  if ((slot_in != nullptr) != (slot_out != nullptr) || (slot_in && Lcap <= 0)) return EAMD_EINVAL;
+  a.slot_in = slot_in; a.slot_out = slot_out; a.Lcap = Lcap;
   hipLaunchKernelGGL(beam_step_kernel, dim3(nutt), dim3(256), 0, (hipStream_t)stream, a);
   EAMD_LAUNCH_CHECK();
   return EAMD_OK;

@@ -564,11 +564,18 @@ class BeamSearch(torch.nn.Module):
             if psi is None:       # more than 2048 frames: the full recursion for every candidate
                 olen = torch.full((n,), L - 1, dtype=torch.int32, device=dev)
                 psi, r_new = ops.ctc_prefix_score_batch(C_["logp"], C_["lens_d"], beam, c_r_now, cand32, last, olen, ctc.blank, ctc.eos)
+            slot_done = None
             if self.step_kernel and beam <= 64 and beam * P <= 1023 and beam * V < 2 ** 31 and r_new is None:
-                sc_new, yseq, hyp_new, hyp_i, tok_i, tok32, cs_new, rec = ops.beam_step(
+                # one scorer with a slot table (the cached decoder): its re-ordering rides in the same launch
+                tabled = [k for k in names if isinstance(newtrees[k], dict) and "slot" in newtrees[k] and "pos" in newtrees[k]]
+                slot_in = newtrees[tabled[0]]["slot"] if len(tabled) == 1 else None
+                res = ops.beam_step(
                     pre, part_ids, psi, S["c_s"], hyp, self.weights[pname], B, beam, L, i, self.eos, C_["maxlen_d"].view(-1),
                     S["sc"], [logps[k] for k in names], yseq,
-                    dyn=(sdev, dyn["step_out"], dyn["ring"]) if dyn is not None else None)
+                    dyn=(sdev, dyn["step_out"], dyn["ring"]) if dyn is not None else None, slot_in=slot_in)
+                sc_new, yseq, hyp_new, hyp_i, tok_i, tok32, cs_new, rec = res[:8]
+                if slot_in is not None:
+                    slot_done = (tabled[0], res[8])
             elif dyn is not None:
                 raise _NoDynStep("selection kernel")
             else:
@@ -578,7 +585,10 @@ class BeamSearch(torch.nn.Module):
                     S["sc"], [logps[k] for k in names], c_loc, False, part_ids, yseq)
                 cs_new, tok32 = psi[hyp_i, pos], tok_i.to(torch.int32)
             for k in names:
-                trees[k] = self._reorder(self.full_scorers[k], newtrees[k], hyp_i)
+                if slot_done is not None and k == slot_done[0]:
+                    trees[k] = dict(newtrees[k], slot=slot_done[1])
+                else:
+                    trees[k] = self._reorder(self.full_scorers[k], newtrees[k], hyp_i)
             T_ = dict(sc=sc_new, trees=trees, yseq=yseq, hyp=hyp_new, c_s=cs_new, last32=tok32, tok=tok_i)
             if r_new is not None:
                 T_["c_r"] = r_new[hyp_i, pos]

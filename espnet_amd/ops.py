@@ -1376,7 +1376,7 @@ def topk_rows(x, k, idx32=False):
     return (vals, idx, i32) if idx32 else (vals, idx)
 
 
-def beam_step(pre, ids, psi, c_s, hyp, w_ctc, nutt, beam, L, step, eos, maxlen, sc_in, logps, yseq_in, dyn=None):
+def beam_step(pre, ids, psi, c_s, hyp, w_ctc, nutt, beam, L, step, eos, maxlen, sc_in, logps, yseq_in, dyn=None, slot_in=None):
     """selection and bookkeeping of a BeamSearch step with a pre-beam in one launch (eamd_beam_step = eamd_beam_select +
     eamd_beam_finish) -> (sc_out [ns, n], yseq_out, hyp_out, hyp_i, tok_i, tok32, cs_out, rec)"""
     n, V = pre.shape
@@ -1408,11 +1408,17 @@ def beam_step(pre, ids, psi, c_s, hyp, w_ctc, nutt, beam, L, step, eos, maxlen, 
         assert rec.shape[1:] == (n, 3 + ns + W) and rec.is_contiguous() and step_dev.dtype == torch.int32 and step_out.dtype == torch.int32
     else:
         rec = torch.empty(n, 3 + ns + W, device=dev, dtype=torch.float32)
+    slot_out, Lcap = None, 0
+    if slot_in is not None:
+        assert slot_in.dtype == torch.int32 and slot_in.is_contiguous() and slot_in.shape[0] == n
+        slot_out, Lcap = torch.empty_like(slot_in), slot_in.shape[1]
     arr = (C.c_void_p * 4)(*[lp.data_ptr() for lp in logps] + [None] * (4 - nf))
     check(_lib.lib().eamd_beam_step_dyn(ptr(pre), ptr(ids), ptr(psi), ptr(c_s), ptr(hyp), C.c_float(w_ctc), nutt, beam, P, V, W, L, step, eos,
                                         ptr(maxlen), ns, nf, ptr(sc_in), arr, ptr(yseq_in), ptr(c_local), ptr(sc_out), ptr(yseq_out),
                                         ptr(hyp_out), ptr(hyp_i), ptr(tok_i), ptr(tok32), ptr(cs_out), ptr(rec), ptr(step_dev),
-                                        ptr(step_out), ring, stream_ptr()), "eamd_beam_step")
+                                        ptr(step_out), ring, ptr(slot_in), ptr(slot_out), Lcap, stream_ptr()), "eamd_beam_step")
+    if slot_in is not None:       # (a ninth result: the cached decoder's slot table behind the selection)
+        return sc_out, yseq_out, hyp_out, hyp_i, tok_i, tok32, cs_out, rec, slot_out
     return sc_out, yseq_out, hyp_out, hyp_i, tok_i, tok32, cs_out, rec
 
 

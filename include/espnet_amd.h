@@ -448,7 +448,8 @@ int eamd_topk_rows_i32(const float* x, int64_t ld, int rows, int n, int k, float
 /* One hipGraph for EVERY beam step (reference: the step index `i` of beam_search.py:349-364's loop, here a device integer): the
  * variants below read the step-dependent integer from device memory - value = *dev + the host argument, which becomes an offset -
  * so a captured step does not bake it in.  eamd_beam_step_dyn reads step (L = step + 1) from step_dev, writes the log row into
- * slot step % ring of a [ring][n][3 + ns + W] ring (ring 0: as before) and leaves step + 1 in step_out.  eamd_copy_jobs: up to 16
+ * slot step % ring of a [ring][n][3 + ns + W] ring (ring 0: as before) and leaves step + 1 in step_out; with slot_in / slot_out
+ * ([n, Lcap] int32) it also does eamd_beam_slots' re-ordering of the cached decoder's slot table (position = step).  eamd_copy_jobs: up to 16
  * small device-to-device copies (sizes in bytes, multiples of 4) in one launch - the state a step hands to the next replay. */
 int eamd_decode_self_attn_dyn(const float* qkv, int64_t ldq, float* kcache, float* vcache, const int32_t* slot_at, int Lcap, int pos,
                               const int32_t* pos_dev, int n, int H, int D, float* ctx, void* stream);
@@ -458,7 +459,7 @@ int eamd_beam_step_dyn(const float* pre, const int64_t* ids, const float* psi, c
                        int beam, int P, int V, int W, int L, int step, int eos, const int64_t* maxlen, int ns, int nf, const float* sc_in,
                        const float* const* logps, const int64_t* yseq_in, float* c_local, float* sc_out, int64_t* yseq_out, float* hyp_out,
                        int64_t* hyp_i, int64_t* tok_i, int32_t* tok32, float* cs_out, float* rec, const int32_t* step_dev, int32_t* step_out,
-                       int ring, void* stream);
+                       int ring, const int32_t* slot_in, int32_t* slot_out, int Lcap, void* stream);
 int eamd_ctc_prefix_psi_dyn(const float* logp, const int32_t* lens, int nutt, int per_utt, const float* r_prev, const int32_t* cand,
                             const int32_t* last, int olen, const int32_t* olen_dev, float* psi, int ncand, int Tmax, int V, int blank,
                             int eos, void* stream);
