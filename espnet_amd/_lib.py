@@ -108,7 +108,7 @@ _lib = None
 # every symbol include/espnet_amd.h declares (tests check they are all exported)
 SYMBOLS = [
     "eamd_abi_version", "eamd_gemm", "eamd_gemm_multi", "eamd_gemm_group_plan", "eamd_gemm_group_launch", "eamd_ffn_fwd", "eamd_ffn_bwd", "eamd_ffn_pack_f32", "eamd_ffn_pack_bf16", "eamd_ffn_pack_f32_multi", "eamd_rowproj", "eamd_rowproj_pack_f32", "eamd_rowproj_lnb_workspace", "eamd_layernorm_fwd", "eamd_layernorm_bwd_workspace", "eamd_layernorm_bwd_drop_f32", "eamd_layernorm_bwd", "eamd_layernorm_bwd_reduce", "eamd_attn_fwd", "eamd_attn_bwd_q", "eamd_attn_fwd_f32", "eamd_attn_bwd_q_f32", "eamd_attn_bwd_kv_f32", "eamd_attn_bwd_kv", "eamd_softmax_fwd",
-    "eamd_softmax_bwd", "eamd_lsm_loss", "eamd_argmax_rows", "eamd_reduce_sum", "eamd_log_softmax_rows", "eamd_topk_rows", "eamd_topk_rows_i32", "eamd_weighted_topk_rows", "eamd_beam_step", "eamd_beam_step_dyn", "eamd_decode_self_attn_dyn", "eamd_beam_slots_dyn", "eamd_ctc_prefix_psi_dyn", "eamd_ctc_prefix_state_dyn", "eamd_embed_pe_dyn", "eamd_copy_jobs", "eamd_embed_pe_ld", "eamd_linear_rows_f32", "eamd_linear_rows_ln_f32", "eamd_decode_self_attn", "eamd_beam_slots", "eamd_decode_src_attn", "eamd_decode_src_attn_group", "eamd_weighted_sum", "eamd_beam_select", "eamd_beam_finish",
+    "eamd_softmax_bwd", "eamd_lsm_loss", "eamd_argmax_rows", "eamd_reduce_sum", "eamd_log_softmax_rows", "eamd_topk_rows", "eamd_topk_rows_i32", "eamd_weighted_topk_rows", "eamd_beam_step", "eamd_beam_step_dyn", "eamd_decode_self_attn_dyn", "eamd_beam_slots_dyn", "eamd_ctc_prefix_psi_dyn", "eamd_ctc_prefix_state_dyn", "eamd_embed_pe_dyn", "eamd_copy_jobs", "eamd_embed_pe_ld", "eamd_linear_rows_f32", "eamd_linear_rows_ln_f32", "eamd_decode_self_attn", "eamd_beam_slots", "eamd_decode_src_attn", "eamd_decode_src_attn_group", "eamd_decode_src_attn_split", "eamd_decode_src_attn_split_workspace", "eamd_weighted_sum", "eamd_beam_select", "eamd_beam_finish",
     "eamd_axpby", "eamd_cast_bf16", "eamd_scale_dev", "eamd_act_fwd", "eamd_act_bwd", "eamd_glu_fwd", "eamd_glu_bwd",
     "eamd_add_bias2", "eamd_add_cast_bf16", "eamd_add_block_f32", "eamd_add_cast_colsum2", "eamd_add_colsum2_f32", "eamd_colsum", "eamd_embed_pe", "eamd_embed_bwd", "eamd_posenc", "eamd_posenc_scaled", "eamd_posenc_scaled_bwd", "eamd_permute4",
     "eamd_dropout", "eamd_rng_advance", "eamd_dwconv_fwd", "eamd_dwconv_glu_fwd", "eamd_dwconv_glu_bwd_x", "eamd_dwconv_glu_bwd_w", "eamd_dwconv_bwd_x", "eamd_dwconv_bwd_w", "eamd_bn_nslab",

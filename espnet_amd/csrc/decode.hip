@@ -697,19 +697,32 @@ __global__ __launch_bounds__(256) void decode_src_attn_kernel(const float* __res
 // 64 queries per workgroup, took 23.5 us per layer here).  Same score and context arithmetic; the softmax sums run per wave.
 namespace {
 constexpr int SRC_GQ = 16;                       // hypotheses per utterance served by one workgroup
+// gridDim.z > 1: the keys of an utterance are split over gridDim.z workgroups (128 workgroups of ~250 keys each left the chip to
+// latency: 23 us); a split leaves its row maxima, sums and UNNORMALISED partial contexts in `part` ([nutt][H][splits][g][66]:
+// 64 channels, max, sum) and decode_src_attn_merge_kernel combines them in a fixed order.
 __global__ __launch_bounds__(256) void decode_src_attn_group_kernel(const float* __restrict__ q, long ldq, const float* __restrict__ Km,
                                                                     const float* __restrict__ Vm, long ldkv,
-                                                                    const unsigned char* __restrict__ mask, int g, int T, int Tp, int D,
-                                                                    float* __restrict__ ctx, float scale) {
+                                                                    const unsigned char* __restrict__ mask, int g, int Tall, int Tp, int D,
+                                                                    float* __restrict__ ctx, float scale, float* __restrict__ pws) {
   extern __shared__ __attribute__((aligned(16))) float gsm[];
   float* qs = gsm;                               // [SRC_GQ][64]
   float* sc = qs + SRC_GQ * 64;                  // [g][Tp] scores, then unnormalised probabilities
   float* part = sc + (long)SRC_GQ * Tp;          // [4][SRC_GQ][64]
-  float* den = part + 4 * SRC_GQ * 64;           // [SRC_GQ]
+  float* den = part + 4 * SRC_GQ * 64;           // [2][SRC_GQ]: sums, maxima
   const int h = blockIdx.x, u = blockIdx.y, t_ = threadIdx.x, lane = t_ & 63, w = t_ >> 6;
-  const float* kb = Km + (long)u * T * ldkv + h * 64;
-  const float* vb = Vm + (long)u * T * ldkv + h * 64;
-  const unsigned char* mk = mask ? mask + (long)u * T : nullptr;
+  const int ns = gridDim.z, sp = blockIdx.z;
+  const int per = ((Tall + ns - 1) / ns + 3) & ~3;       // keys per split
+  const int k0 = min(sp * per, Tall), T = min(per, Tall - k0);      // this workgroup's keys: k0 .. k0 + T - 1 (T may be 0)
+  const float* kb = Km + ((long)u * Tall + k0) * ldkv + h * 64;
+  const float* vb = Vm + ((long)u * Tall + k0) * ldkv + h * 64;
+  const unsigned char* mk = mask ? mask + (long)u * Tall + k0 : nullptr;
+  if (T <= 0) {                                          // a split past the last key (only with several splits): nothing to add
+    for (int idx = t_; idx < g * 66; idx += 256) {
+      const int r = idx / 66, d = idx - r * 66;
+      pws[((((long)u * gridDim.x + h) * ns + sp) * g + r) * 66 + d] = d == 64 ? -INFINITY : 0.f;
+    }
+    return;
+  }
   if (t_ < g * 16) {
     const int r = t_ >> 4, c = t_ & 15;
     *reinterpret_cast<float4*>(&qs[r * 64 + 4 * c]) = *reinterpret_cast<const float4*>(q + ((long)u * g + r) * ldq + h * 64 + 4 * c);
@@ -744,27 +757,34 @@ __global__ __launch_bounds__(256) void decode_src_attn_group_kernel(const float*
       d += e;
     }
     d = wave_sum(d);
-    if (lane == 0) den[r] = d;
+    if (lane == 0) { den[r] = d; den[SRC_GQ + r] = mx; }
+    if (lane < Tp - T) sr[T + lane] = 0.f;               // (the 16-byte reads below run to the next multiple of 4)
   }
   __syncthreads();
   float acc[SRC_GQ];
 #pragma unroll
   for (int r = 0; r < SRC_GQ; ++r) acc[r] = 0.f;
-  // a wave walks keys w, w + 4, ...: the value rows of 256 keys (64 per wave) are requested together (eight at a time, each
-  // batch waiting out a memory round trip, was most of this kernel's time)
-  for (int t0 = w; t0 < T; t0 += 256) {
-    // (unconditional loads of clamped rows: a load inside a branch is waited for at the end of its branch - 64 round trips)
-    float v[64];
-    const int tw = __builtin_amdgcn_readfirstlane(t0);
+  // a wave takes a contiguous quarter of the keys, four at a time: four value rows (lane = channel) against the four
+  // probabilities of every query in ONE 16-byte LDS read (probabilities read one by one - 640 LDS instructions per wave whatever
+  // the number of keys - were what this kernel spent its time on: 23 us)
+  {
+    const int Q = ((T + 3) / 4 + 3) & ~3;                // keys per wave (a multiple of 4)
+    const int kb0 = w * Q, ke0 = min(kb0 + Q, (T + 3) & ~3);
+    for (int kk = kb0; kk < ke0; kk += 16) {             // sixteen value rows in flight per round trip
+      float v[16];
 #pragma unroll
-    for (int k = 0; k < 64; ++k) v[k] = (vb + (long)min(tw + 4 * k, T - 1) * ldkv)[lane];
+      for (int e = 0; e < 16; ++e) v[e] = (vb + (long)min(kk + e, T - 1) * ldkv)[lane];       // (rows past T meet probability 0)
 #pragma unroll
-    for (int k = 0; k < 64; ++k) v[k] = tw + 4 * k < T ? v[k] : 0.f;
+      for (int c = 0; c < 4; ++c) {
+        if (kk + 4 * c < ke0) {
 #pragma unroll
-    for (int r = 0; r < SRC_GQ; ++r) {
-      if (r < g) {
-#pragma unroll
-        for (int k = 0; k < 64; ++k) acc[r] = fmaf(sc[(long)r * Tp + min(tw + 4 * k, T - 1)], v[k], acc[r]);      // (past T: v = 0)
+          for (int r = 0; r < SRC_GQ; ++r) {
+            if (r < g) {
+              const float4 p4 = *reinterpret_cast<const float4*>(&sc[(long)r * Tp + kk + 4 * c]);
+              acc[r] = fmaf(p4.x, v[4 * c], fmaf(p4.y, v[4 * c + 1], fmaf(p4.z, v[4 * c + 2], fmaf(p4.w, v[4 * c + 3], acc[r]))));
+            }
+          }
+        }
       }
     }
   }
@@ -776,8 +796,31 @@ __global__ __launch_bounds__(256) void decode_src_attn_group_kernel(const float*
     const int r = idx >> 6, d = idx & 63;
     const float s = (part[(0 * SRC_GQ + r) * 64 + d] + part[(1 * SRC_GQ + r) * 64 + d]) +
                     (part[(2 * SRC_GQ + r) * 64 + d] + part[(3 * SRC_GQ + r) * 64 + d]);
-    ctx[((long)u * g + r) * D + h * 64 + d] = den[r] > 0.f ? s / den[r] : 0.f;        // every frame masked: zeros (attention.py:84-88)
+    if (ns == 1) {
+      ctx[((long)u * g + r) * D + h * 64 + d] = den[r] > 0.f ? s / den[r] : 0.f;      // every frame masked: zeros (attention.py:84-88)
+    } else {
+      float* pr = pws + ((((long)u * gridDim.x + h) * ns + sp) * g + r) * 66;
+      pr[d] = s;
+      if (d == 0) { pr[64] = den[SRC_GQ + r]; pr[65] = den[r]; }
+    }
   }
+}
+// ctx[u, r, h] = sum_s e^(m_s - M) partial_s / sum_s e^(m_s - M) sum_s over the splits, in split order
+__global__ __launch_bounds__(64) void decode_src_attn_merge_kernel(const float* __restrict__ part, int ns, int g, int H, int D,
+                                                                   float* __restrict__ ctx) {
+  const int h = blockIdx.x, r = blockIdx.y % g, u = blockIdx.y / g, d = threadIdx.x;
+  const float* pr = part + ((((long)u * H + h) * ns) * g + r) * 66;
+  float M = -INFINITY;
+  for (int s = 0; s < ns; ++s) M = fmaxf(M, pr[(long)s * g * 66 + 64]);
+  float num = 0.f, den = 0.f;
+  for (int s = 0; s < ns; ++s) {
+    const float* ps = pr + (long)s * g * 66;
+    const float m = ps[64];
+    const float wgt = (m == -INFINITY) ? 0.f : __expf(m - M);
+    num = fmaf(wgt, ps[d], num);
+    den = fmaf(wgt, ps[65], den);
+  }
+  ctx[((long)u * g + r) * D + h * 64 + d] = den > 0.f ? num / den : 0.f;
 }
 }  // namespace
 
@@ -823,9 +866,32 @@ extern "C" int eamd_decode_src_attn_group(const float* q, int64_t ldq, const flo
   if (D != H * 64 || T > 1024 || g > SRC_GQ || ldq % 4 != 0 || ldkv % 4 != 0 || (((uintptr_t)q | (uintptr_t)kmem | (uintptr_t)vmem) & 15))
     return EAMD_EUNSUPPORTED;
   const int Tp = (T + 3) & ~3;
-  const size_t lds = ((size_t)SRC_GQ * 64 + (size_t)SRC_GQ * Tp + 4 * SRC_GQ * 64 + SRC_GQ) * 4;
-  hipLaunchKernelGGL(decode_src_attn_group_kernel, dim3(H, nutt), dim3(256), lds, (hipStream_t)stream, q, (long)ldq, kmem, vmem, (long)ldkv,
-                     mask, g, T, Tp, D, ctx, 0.125f);
+  const size_t lds = ((size_t)SRC_GQ * 64 + (size_t)SRC_GQ * Tp + 4 * SRC_GQ * 64 + 2 * SRC_GQ) * 4;
+  hipLaunchKernelGGL(decode_src_attn_group_kernel, dim3(H, nutt, 1), dim3(256), lds, (hipStream_t)stream, q, (long)ldq, kmem, vmem, (long)ldkv,
+                     mask, g, T, Tp, D, ctx, 0.125f, (float*)nullptr);
+  EAMD_LAUNCH_CHECK();
+  return EAMD_OK;
+}
+
+extern "C" int64_t eamd_decode_src_attn_split_workspace(int nutt, int g, int H, int splits) {
+  return (int64_t)nutt * H * splits * g * 66;            // floats
+}
+
+extern "C" int eamd_decode_src_attn_split(const float* q, int64_t ldq, const float* kmem, const float* vmem, int64_t ldkv,
+                                          const uint8_t* mask, int nutt, int g, int T, int H, int D, int splits, float* ws, float* ctx,
+                                          void* stream) {
+  if (!q || !kmem || !vmem || !ctx || !ws || nutt <= 0 || g <= 0 || T <= 0 || H <= 0 || D <= 0 || splits < 2 || splits > 16) return EAMD_EINVAL;
+  if (ldq < D || ldkv < D) return EAMD_EINVAL;
+  if (D != H * 64 || T > 4096 || g > SRC_GQ || ldq % 4 != 0 || ldkv % 4 != 0 || (((uintptr_t)q | (uintptr_t)kmem | (uintptr_t)vmem) & 15))
+    return EAMD_EUNSUPPORTED;
+  const int per = ((T + splits - 1) / splits + 3) & ~3;
+  const int Tp = per;
+  const size_t lds = ((size_t)SRC_GQ * 64 + (size_t)SRC_GQ * Tp + 4 * SRC_GQ * 64 + 2 * SRC_GQ) * 4;
+  if (lds > 64 * 1024) return EAMD_EUNSUPPORTED;
+  hipLaunchKernelGGL(decode_src_attn_group_kernel, dim3(H, nutt, splits), dim3(256), lds, (hipStream_t)stream, q, (long)ldq, kmem, vmem,
+                     (long)ldkv, mask, g, T, Tp, D, ctx, 0.125f, ws);
+  EAMD_LAUNCH_CHECK();
+  hipLaunchKernelGGL(decode_src_attn_merge_kernel, dim3(H, nutt * g), dim3(64), 0, (hipStream_t)stream, ws, splits, g, H, D, ctx);
   EAMD_LAUNCH_CHECK();
   return EAMD_OK;
 }

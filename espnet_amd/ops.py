@@ -1283,6 +1283,9 @@ def decode_self_attn(qkv, Kc, Vc, slot_at, pos, H, pos_dev=None):
     return ctx
 
 
+SRC_ATTN_SPLITS = int(os.environ.get("EAMD_SRC_ATTN_SPLITS", "4"))      # key splits of the grouped source attention (1: none)
+
+
 def decode_src_attn(q, kv, k_off, v_off, ldkv, mask, G, g, T, H, group=False):
     """one query position per hypothesis over the memory of its utterance (eamd_decode_src_attn): q [G * g, D]; kv = the tensor
     that holds keys / values of this layer at element offsets k_off / v_off, row stride ldkv ([G * T] rows); mask [G, 1, T] uint8
@@ -1290,6 +1293,16 @@ def decode_src_attn(q, kv, k_off, v_off, ldkv, mask, G, g, T, H, group=False):
     hypotheses (eamd_decode_src_attn_group; g <= 16, T <= 1024) instead of one per (hypothesis, head)"""
     n, D = q.shape
     ctx = torch.empty(n, D, device=q.device, dtype=torch.float32)
+    splits = SRC_ATTN_SPLITS if (group and T >= 128 and G * H * SRC_ATTN_SPLITS <= 4096) else 1
+    if group and splits > 1:       # the keys of an utterance over several workgroups + a merge launch (eamd_decode_src_attn_split)
+        L = _lib.lib()
+        L.eamd_decode_src_attn_split_workspace.restype = C.c_int64
+        ws = torch.empty(int(L.eamd_decode_src_attn_split_workspace(G, g, H, splits)), device=q.device, dtype=torch.float32)
+        rc = L.eamd_decode_src_attn_split(ptr(q), C.c_int64(q.stride(0)), ptr(kv, k_off), ptr(kv, v_off), C.c_int64(ldkv), ptr(mask),
+                                          G, g, T, H, D, splits, ptr(ws), ptr(ctx), stream_ptr())
+        if rc != _lib.EAMD_EUNSUPPORTED:
+            check(rc, "eamd_decode_src_attn_split")
+            return ctx
     fn = _lib.lib().eamd_decode_src_attn_group if group else _lib.lib().eamd_decode_src_attn
     rc = fn(ptr(q), C.c_int64(q.stride(0)), ptr(kv, k_off), ptr(kv, v_off), C.c_int64(ldkv), ptr(mask),
                                          G, g, T, H, D, ptr(ctx), stream_ptr())

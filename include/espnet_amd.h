@@ -428,6 +428,11 @@ int eamd_decode_src_attn(const float* q, int64_t ldq, const float* kmem, const f
  * values of an utterance are read once per head, not once per hypothesis); T <= 1024. */
 int eamd_decode_src_attn_group(const float* q, int64_t ldq, const float* kmem, const float* vmem, int64_t ldkv, const uint8_t* mask, int nutt,
                          int g, int T, int H, int D, float* ctx, void* stream);
+/* ... with the keys of every utterance split over `splits` (2 .. 16) workgroups and a merge launch behind them (row maxima, sums and
+ * unnormalised partial contexts meet in ws: eamd_decode_src_attn_split_workspace floats); T <= 4096. */
+int64_t eamd_decode_src_attn_split_workspace(int nutt, int g, int H, int splits);
+int eamd_decode_src_attn_split(const float* q, int64_t ldq, const float* kmem, const float* vmem, int64_t ldkv, const uint8_t* mask,
+                               int nutt, int g, int T, int H, int D, int splits, float* ws, float* ctx, void* stream);
 /* The selection of a beam step on the pre-beam candidates (reference: beam_search.py:296-334 with :199-226: tokens outside the pre-beam
  * are dropped, so an utterance's `beam` best continuations are among its beam x P candidates).
  * eamd_weighted_sum: out[i] = ((0 + w_0 logp_0[i]) + w_1 logp_1[i]) + ... over nf <= 4 full scorers ([n, V] each; numel = n V, a
