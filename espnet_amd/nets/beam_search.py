@@ -670,7 +670,7 @@ class BeamSearch(torch.nn.Module):
     graph_steps = os.environ.get("EAMD_BEAM_GRAPH_STEPS", "0") == "1"      # opt-in (attribute or environment): 33 -> 46 utt/s at config 2
     graph_one = True                  # steps >= 1 of a search replay ONE graph that reads the step index from the device (else one per step)
     graph_frame_bucket = 32
-    graph_max_signatures = 8          # least recently used signatures (their graphs and static buffers) are dropped beyond this
+    graph_max_signatures = 16         # least recently used signatures (their two graphs and static buffers) are dropped beyond this
 
     def _forward_batch_graphed(self, xs, maxlenratio):
         from .. import graphs, ops
