@@ -363,8 +363,29 @@ def _wgroup_staging(nbytes):
     return torch.empty(nbytes, dtype=torch.uint8, pin_memory=True)
 
 
+# EAMD_WGRAD_GROUP_SIDE=1: the grouped launches leave on a SECOND stream (the backward pass's input-gradient chain goes on beside
+# them; their operands are kept alive until wgrad_join) - with EAMD_GROUP_MAX_BYTES set so that a backward pass flushes several
+# times.  An experiment knob: see DESIGN.md for what it measured.
+WGROUP_SIDE = os.environ.get("EAMD_WGRAD_GROUP_SIDE", "0") == "1"
+
+
 def wgrad_group_flush():
     """launch everything queued so far: one grouped launch per tile size (a single queued GEMM goes out on its own)"""
+    if WGROUP_SIDE and (_wgroup["items"] or _wgroup["stack"]):
+        cur = torch.cuda.current_stream()
+        side = _wgroup.get("side")
+        if side is None or side.device != cur.device:
+            side = _wgroup["side"] = torch.cuda.Stream(device=cur.device)
+        _wgroup.setdefault("held", []).append(([it[1] for it in _wgroup["items"]], list(_wgroup["stack"].values())))
+        side.wait_stream(cur)
+        with torch.cuda.stream(side):
+            _wgroup_flush_now()
+        _wgroup["side_used"] = True
+        return
+    _wgroup_flush_now()
+
+
+def _wgroup_flush_now():
     stack, _wgroup["stack"] = _wgroup["stack"], {}
     for dW, db, dys, xs in stack.values():          # stacked small-M weight gradients: one product per weight
         if len(dys) == 1:
@@ -923,6 +944,10 @@ def wgrad_group_end():
 def wgrad_join():
     """launch the queued weight-gradient GEMMs and make the current stream wait for all weight-gradient work issued so far"""
     wgrad_group_flush()
+    if _wgroup.get("side_used"):
+        torch.cuda.current_stream().wait_stream(_wgroup["side"])
+        _wgroup["side_used"] = False
+        _wgroup["held"] = []
     st = _wgrad["stream"]
     if st is not None and _wgrad["used"]:
         torch.cuda.current_stream().wait_stream(st)
