@@ -880,36 +880,48 @@ class _BatchLog:
         self.pending = []
         na = len(allk)
         maxl = np.asarray(self.maxlens)
-        for row in host:
-            i = int(row[0, 0])
+        # everything that does not depend on which utterances have stopped, for all fetched steps at once (a numpy call costs a
+        # microsecond or two: per step and per quantity they were most of a fetch)
+        S_ = host.shape[0]
+        steps = host[:, 0, 0].astype(np.int64)
+        ts_all = host[:, :, 1].reshape(S_, B, beam)
+        tok_all = host[:, :, 2].reshape(S_, B, beam)
+        fin_all = np.isfinite(ts_all)
+        cap_all = (maxl[None, :] - 1 == steps[:, None])                        # [steps, B]
+        ends_all = fin_all & ((tok_all == bs.eos) | cap_all[:, :, None])
+        alive_all = (fin_all & ~ends_all).sum(2)                               # [steps, B]
+        es, eb, ej = np.nonzero(ends_all)
+        guard = getattr(bs, "partial_mode", "ids") == "full" and getattr(bs, "candidate_select", False)
+        low_all = (fin_all & (ts_all < -1e9)).any(2) if guard else None        # [steps, B]
+        k = 0
+        for si in range(S_):
+            i = int(steps[si])
             L = i + 2
-            ts = row[:, 1].reshape(B, beam)
-            tok = row[:, 2].reshape(B, beam)
-            fin = np.isfinite(ts)
-            if getattr(bs, "partial_mode", "ids") == "full" and getattr(bs, "candidate_select", False) and (fin & (ts < -1e9) & ~np.asarray(self.stopped)[:, None]).any():
+            row = host[si]
+            if guard and any(low_all[si, b] and not self.stopped[b] for b in range(B)):
                 raise _OutsideCandidates()
-            at_cap = (maxl - 1 == i)[:, None]
-            live = ~np.asarray(self.stopped)[:, None]
-            ends = fin & ((tok == bs.eos) | at_cap) & live
-            alive = (fin & ~ends).sum(1)
-            for b, j in zip(*np.nonzero(ends)):
+            while k < len(es) and es[k] == si:
+                b, j = int(eb[k]), int(ej[k])
+                k += 1
+                if self.stopped[b]:
+                    continue
                 slot = row[b * beam + j]
                 top_s = float(slot[1])
                 seq = slot[3 + na: 3 + na + L].astype(np.int64).tolist()
                 if i == self.maxlens[b] - 1:
                     seq.append(bs.eos)
-                scores = {k: float(slot[3 + q]) for q, k in enumerate(allk)}
+                scores = {kk: float(slot[3 + q]) for q, kk in enumerate(allk)}
                 if bs.apply_final_score:
-                    for k, d in chain(bs.full_scorers.items(), bs.part_scorers.items()):
+                    for kk, d in chain(bs.full_scorers.items(), bs.part_scorers.items()):
                         f = float(d.final_tree(None)) if hasattr(d, "final_tree") else float(d.final_score(None))
-                        scores[k] += f
-                        top_s += bs.weights[k] * f
+                        scores[kk] += f
+                        top_s += bs.weights[kk] * f
                 self.ended[b].append(Hypothesis(yseq=torch.tensor(seq, dtype=torch.int64), score=top_s, scores=scores, states={}))
                 self.ended_sl[b].append((top_s, len(seq)))
             for b in range(B):
                 if self.stopped[b]:
                     continue
-                if (self.maxlenratio == 0.0 and _end_detect_sl(self.ended_sl[b], i)) or alive[b] == 0 or i == self.maxlens[b] - 1:
+                if (self.maxlenratio == 0.0 and _end_detect_sl(self.ended_sl[b], i)) or alive_all[si, b] == 0 or i == self.maxlens[b] - 1:
                     self.stopped[b] = True
             if all(self.stopped):
                 return True
