@@ -2284,3 +2284,28 @@ def test_batch_beam_candidate_selection_matches_tensor_expressions():
         assert [x[0] for x in a] == [x[0] for x in b]
         assert all(abs(x[1] - y[1]) <= 1e-5 * max(1.0, abs(x[1])) for x, y in zip(a, b))
         assert all(abs(x[2][k] - y[2][k]) <= 1e-5 * max(1.0, abs(x[2][k])) for x, y in zip(a, b) for k in x[2])
+
+
+def test_decode_c2width_long_memory_golden():
+    """a 657-frame memory (the encoder outputs of utterances 0, 1, 0 back to back; tests/golden/decode_c2width_long.npz from
+    oracle/gen_golden_r4c.py): the reference's BeamSearch and BatchBeamSearch n-best (ctc_weight 0.3, maxlenratio 0.2, length bonus
+    0.1) against ours - eager and with step graphs; beyond 512 frames the CTC candidate reduction and the survivors' scan run with
+    16 frames per lane.  Token ids exact, scores 1e-4 (c2width_compare)."""
+    from espnet_amd.nets.batch_beam_search import BatchBeamSearch
+    from espnet_amd.nets.beam_search import BeamSearch
+    from espnet_amd.nets.ctc_prefix_score import LengthBonus
+    SW, model, _g, encs = c2width_setup()
+    g = load_golden("decode_c2width_long.npz")
+    spec = SW.DECODE_R4
+    enc = torch.cat([encs[0], encs[1], encs[0]], 0).contiguous()
+    report("long memory (every 16th frame)", enc[::16], torch.from_numpy(g["enc_sample"]), 2e-5)
+    for cls, nm in ((BeamSearch, "beam"), (BatchBeamSearch, "bbeam")):
+        scorers = model.scorers()
+        scorers["length_bonus"] = LengthBonus(spec["odim"])
+        bs = cls(scorers, dict(decoder=0.7, ctc=0.3, length_bonus=0.1), spec["beam"], spec["odim"], model.sos, model.eos,
+                 pre_beam_score_key="full")
+        c2width_compare("long memory %s" % cls.__name__, bs(enc, maxlenratio=0.2), g, "long_" + nm)
+        bs.graph_steps = True
+        for rnd in range(3):        # eager on the static buffers, capture + replay, replay
+            c2width_compare("long memory %s graph_steps[%d]" % (cls.__name__, rnd), bs(enc, maxlenratio=0.2), g, "long_" + nm)
+        assert bs.graph_steps

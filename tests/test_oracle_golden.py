@@ -673,3 +673,28 @@ def test_oracle_decode_c2width(oracle):
     seq_a, _ = _nbest(g, "u0_beam_w03_r00")
     seq_b, _ = _nbest(g, "u0_bbeam_w03_r00")
     assert seq_a != seq_b            # the fixture does separate the two semantics
+
+
+def test_oracle_decode_c2width_long(oracle):
+    """... on a 657-frame memory (decode_c2width_long.npz, oracle/gen_golden_r4c.py: encoder outputs of utterances 0, 1, 0 back to
+    back): oracle.beam_search in "ids" mode against the reference's BeamSearch - ids exact, scores 1e-4"""
+    import os, sys
+    from conftest import ROOT
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import seeded_weights as SW
+    from espnet_amd.nets.e2e_asr_conformer import E2E
+    g = load_golden("decode_c2width_long.npz")
+    model = SW.decode_r4_model(E2E)
+    sd = {k: v.detach().clone() for k, v in model.state_dict().items()}
+    cfg = dict(conformer=True, rel_pos=True, activation="swish", aheads=4, odim=SW.DECODE_R4["odim"])
+    xs = SW.decode_r4_inputs()
+    torch.set_num_threads(8)
+    with torch.no_grad():
+        hs = [oracle.encoder(sd, "encoder.", xs[u].unsqueeze(0), None, cfg, training=False)[0][0] for u in (0, 1)]
+        enc = torch.cat([hs[0], hs[1], hs[0]], 0)
+        close(enc[::16], torch.from_numpy(g["enc_sample"]), rtol=2e-4, atol=2e-5)
+        nb = oracle.beam_search(sd, enc, cfg, dict(decoder=0.7, ctc=0.3, length_bonus=0.1), SW.DECODE_R4["beam"], 0.2, mode="ids")
+    seqs, scores = _nbest(g, "long_beam")
+    assert [h["yseq"] for h in nb[:len(seqs)]] == seqs
+    for h, s_ in zip(nb, scores):
+        assert abs(h["score"] - s_) <= 1e-4 * max(1.0, abs(s_)), (h["score"], s_)
