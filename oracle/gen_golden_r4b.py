@@ -6,6 +6,9 @@
                           macaron + convolution module kernel 7): four variants (post-norm, post-norm + concat, pre-norm + concat)
                           of each of the three layers - outputs, input gradients, every parameter gradient; the decoder layer
                           also through its cached form (the newest position only)
+  e2e_conformer_long.npz  the model of e2e_conformer_dk64.npz (adim 256 / aheads 4, seeded weights salt 5) on LONG inputs: two
+                          utterances of 2200 / 1777 frames (T' = 549 / 443: attention rows beyond 512 keys, the legacy rel_shift on
+                          a padded batch), 30 / 22 labels - loss, loss_ctc, acc, hs_pad, every parameter gradient
   e2e_conformer_d512.npz  espnet1 Conformer E2E at the width of the reference's large recipes (egs/librispeech/asr1 conformer:
                           adim 512, aheads 8 - d_k = 64 -, eunits = dunits = 2048), 2 encoder layers, 1 decoder layer,
                           idim 80, |V| = 50, three utterances of 300 / 251 / 180 frames: loss, loss_ctc, acc, hs_pad, pred_pad,
@@ -104,6 +107,33 @@ def postnorm_layers(out_path):
     save(out_path, **rec)
 
 
+def long_inputs(out_path, E2E):
+    ns = argparse.Namespace(
+        adim=256, aheads=4, elayers=2, eunits=64, dlayers=1, dunits=64, mtlalpha=0.3, lsm_weight=0.1, dropout_rate=0.0,
+        transformer_attn_dropout_rate=0.0, transformer_length_normalized_loss=False, transformer_init="pytorch",
+        transformer_input_layer="conv2d", ctc_type="builtin", report_cer=False, report_wer=False, char_list=None,
+        sym_space="<space>", sym_blank="<blank>", transformer_encoder_pos_enc_layer_type="rel_pos",
+        transformer_encoder_selfattn_layer_type="rel_selfattn", transformer_encoder_activation_type="swish",
+        macaron_style=True, use_cnn_module=True, cnn_module_kernel=31)
+    torch.manual_seed(5)
+    model = SW.fill_parameters(E2E(20, 50, ns), salt=5)
+    model.train()
+    g = torch.Generator().manual_seed(2200)
+    xs = torch.randn(2, 2200, 20, generator=g)
+    ilens = torch.tensor([2200, 1777])
+    ys = torch.randint(1, 49, (2, 30), generator=g)
+    ys[1, 22:] = -1
+    loss = model(xs, ilens, ys)
+    loss.backward()
+    rec = dict(loss=float(loss), acc=float(model.acc), hs_pad=model.hs_pad.detach()[:, ::4].clone(), loss_ctc=float(model.ctc.loss))
+    for name, p in model.named_parameters():
+        if p.grad is not None:
+            rec.update(SW.grad_record(name, p.grad))
+    # inputs are regenerated by the test from the same generator (2 x 2200 x 20 floats are not stored)
+    save(out_path, ilens=ilens, ys=ys, **rec)
+    print("long: loss %.6f ctc %.6f acc %.4f" % (float(loss), float(model.ctc.loss), float(model.acc)))
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--ref", default="/root/reference")
@@ -114,6 +144,7 @@ def main():
     torch.set_num_threads(8)
     from espnet.nets.pytorch_backend.e2e_asr_conformer import E2E
     postnorm_layers(os.path.join(a.out, "postnorm_layers.npz"))
+    long_inputs(os.path.join(a.out, "e2e_conformer_long.npz"), E2E)
     torch.manual_seed(D512["seed"])
     model = SW.fill_parameters(E2E(D512["idim"], D512["odim"], argparse.Namespace(**D512["ns"])), salt=D512["salt"])
     model.train()

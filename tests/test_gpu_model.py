@@ -2309,3 +2309,48 @@ def test_decode_c2width_long_memory_golden():
         for rnd in range(3):        # eager on the static buffers, capture + replay, replay
             c2width_compare("long memory %s graph_steps[%d]" % (cls.__name__, rnd), bs(enc, maxlenratio=0.2), g, "long_" + nm)
         assert bs.graph_steps
+
+
+@pytest.mark.parametrize("recompute", [False, True])
+def test_e2e_conformer_long_inputs_golden(recompute):
+    """the adim 256 / aheads 4 Conformer E2E on LONG inputs against the reference (tests/golden/e2e_conformer_long.npz,
+    oracle/gen_golden_r4b.py): two utterances of 2200 / 1777 frames - attention rows of 549 keys (attn_fwd_long_kernel /
+    attn_bwd_q_long_kernel), the legacy rel_shift on a padded batch - loss, CTC loss, accuracy, encoder output (every 4th frame),
+    every parameter gradient; once keeping the attention probabilities for backward, once recomputing them there
+    (F_.ATTN_RECOMPUTE_MB = 0)."""
+    import espnet_amd
+    from espnet_amd import functional as F_, ops, train
+    from conftest import e2e_dk64_model
+    g = load_golden("e2e_conformer_long.npz")
+    model, _cfg = e2e_dk64_model()
+    model = model.to(DEV).train()
+    flat = train.FlatParams(model)
+    flat.expose_grads()
+    espnet_amd.set_precision("fp32")
+    gen = torch.Generator().manual_seed(2200)
+    xs = torch.randn(2, 2200, 20, generator=gen).to(DEV)
+    ilens, ys = torch.from_numpy(g["ilens"]), torch.from_numpy(g["ys"]).to(DEV)
+    took, orig = [], ops.attn_fwd
+    keep = F_.ATTN_RECOMPUTE_MB
+    F_.ATTN_RECOMPUTE_MB = 0.0 if recompute else -1.0
+
+    def spy(*a_, **k_):
+        took.append((a_[7], a_[8]))            # (T1, T2) of every fused attention forward
+        return orig(*a_, **k_)
+    ops.attn_fwd = spy
+    try:
+        loss = model(xs, ilens, ys)
+        n_fwd = len(took)
+        loss.backward()
+    finally:
+        ops.attn_fwd = orig
+        F_.ATTN_RECOMPUTE_MB = keep
+    assert (549, 549) in took, took                      # the long-row kernels ran
+    assert (len(took) > n_fwd) == recompute              # ... and ran again in backward only when asked to
+    ref = float(g["loss"])
+    rel = abs(float(loss) - ref) / abs(ref)
+    relc = abs(float(model.ctc.loss) - float(g["loss_ctc"])) / abs(float(g["loss_ctc"]))
+    print(f"[parity] e2e_conformer_long[recompute={recompute}] loss hip={float(loss):.6f} ref={ref:.6f} rel={rel:.2e}; ctc rel={relc:.2e}")
+    assert rel < 1e-5 and relc < 1e-5 and abs(model.acc - float(g["acc"])) < 1e-6
+    report("e2e_conformer_long hs_pad", model.hs_pad[:, ::4], torch.from_numpy(g["hs_pad"]), 1e-4)
+    _check_seeded(model, g, 1e-3)
